@@ -1,0 +1,275 @@
+"""Float64 numpy restatement of the robot callbacks on the hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Each function cites the reference file:line it follows (paths relative to the
+reference checkout).  States are flat float64 arrays ``X = [x, y, theta, v]``
+and inputs ``U = [a, omega]`` (DynamicUnicycle2D) or ``U = [a, beta]``
+(KinematicBicycle2D family); obstacles are 7-wide rows
+``[x, y, r, vx, vy, -, flag]`` (circle, flag 0) or
+``[ox, oy, a, b, e, theta, 1]`` (superellipsoid).
+"""
+import math
+
+import numpy as np
+
+MODEL_DU = 0          # DynamicUnicycle2D            (rel-deg 2 HOCBF)
+MODEL_KB = 1          # KinematicBicycle2D           (rel-deg 2 HOCBF)
+MODEL_KB_C3BF = 2     # KinematicBicycle2D_C3BF      (rel-deg 1 collision cone)
+MODEL_KB_DPCBF = 3    # KinematicBicycle2D_DPCBF     (rel-deg 1 dynamic parabola)
+
+MODEL_NAMES = {
+    "DynamicUnicycle2D": MODEL_DU,
+    "KinematicBicycle2D": MODEL_KB,
+    "KinematicBicycle2D_C3BF": MODEL_KB_C3BF,
+    "KinematicBicycle2D_DPCBF": MODEL_KB_DPCBF,
+}
+
+REL_DEG2 = (MODEL_DU, MODEL_KB)
+
+
+def angle_normalize(x):
+    """robots/dynamic_unicycle2D.py:13-16: Python ``%`` wrap into [-pi, pi)."""
+    return ((x + math.pi) % (2.0 * math.pi)) - math.pi
+
+
+def default_spec(model):
+    """Defaults the reference's robot classes ``setdefault`` into robot_spec.
+
+    DU: robots/dynamic_unicycle2D.py:36-40 ; KB: robots/kinematic_bicycle2D.py:42-53 ;
+    radius default robots/robot.py:49.
+    """
+    if model == MODEL_DU:
+        return dict(a_max=0.5, w_max=0.5, v_max=1.0, radius=0.25)
+    rear, wb = 0.2, 0.4
+    delta_max = np.deg2rad(32)
+    return dict(a_max=5.0, v_max=3.5, v_min=0.2, radius=0.3, rear_ax_dist=rear,
+                wheel_base=wb, delta_max=delta_max,
+                beta_max=float(np.arctan((rear / wb) * np.tan(delta_max))))
+
+
+# --------------------------------------------------------------------------
+# dynamics
+# --------------------------------------------------------------------------
+def f(model, X, spec=None):
+    """Drift. DU robots/dynamic_unicycle2D.py:42-54 ; KB robots/kinematic_bicycle2D.py:75-91."""
+    th, v = X[2], X[3]
+    return np.array([v * math.cos(th), v * math.sin(th), 0.0, 0.0])
+
+
+def g(model, X, spec=None):
+    """Input matrix. DU :64-73 (constant) ; KB robots/kinematic_bicycle2D.py:93-111 (state dependent)."""
+    if model == MODEL_DU:
+        return np.array([[0.0, 0.0], [0.0, 0.0], [0.0, 1.0], [1.0, 0.0]])
+    th, v = X[2], X[3]
+    L_r = spec["rear_ax_dist"]
+    return np.array([[0.0, -v * math.sin(th)],
+                     [0.0, v * math.cos(th)],
+                     [0.0, v / L_r],
+                     [1.0, 0.0]])
+
+
+def df_dx(model, X):
+    """Jacobian of f. DU :56-62 ; KB :67-73 (identical expressions)."""
+    th, v = X[2], X[3]
+    c, s = math.cos(th), math.sin(th)
+    J = np.zeros((4, 4))
+    J[0, 2], J[0, 3] = -v * s, c
+    J[1, 2], J[1, 3] = v * c, s
+    return J
+
+
+def step(model, X, U, dt, spec=None):
+    """Euler step + heading wrap. DU :75-78 ; KB :113-123 (also clips v to [v_min, v_max])."""
+    Xn = np.asarray(X, dtype=np.float64) + (f(model, X, spec) + g(model, X, spec) @ np.asarray(U, dtype=np.float64)) * dt
+    Xn[2] = angle_normalize(Xn[2])
+    if model != MODEL_DU:
+        Xn[3] = min(max(Xn[3], spec["v_min"]), spec["v_max"])
+    return Xn
+
+
+def nominal_input(model, X, goal, spec, d_min=0.05):
+    """Go-to-goal reference input.
+
+    DU robots/dynamic_unicycle2D.py:80-104 (gains k_omega=2, k_a=1, k_v=1,
+    overridable through ``nominal_k_*`` keys; output NOT clipped).
+    KB robots/kinematic_bicycle2D.py:125-147; its own defaults (.5, 1.5, .5) are
+    never used on the control_step path because BaseRobot.nominal_input
+    (robots/robot.py:401-408) forwards k_omega=2, k_a=1, k_v=1 positionally.
+    """
+    dxg, dyg = goal[0] - X[0], goal[1] - X[1]
+    dist_raw = math.sqrt((X[0] - goal[0]) ** 2 + (X[1] - goal[1]) ** 2)
+    theta_d = math.atan2(dyg, dxg)
+    err = angle_normalize(theta_d - X[2])
+    if model == MODEL_DU:
+        k_omega = spec.get("nominal_k_omega", 2.0)
+        k_a = spec.get("nominal_k_a", 1.0)
+        k_v = spec.get("nominal_k_v", 1.0)
+        distance = max(dist_raw - d_min, 0.0)
+        omega = k_omega * err
+        if abs(err) > math.radians(90):
+            v = 0.0
+        else:
+            v = min(k_v * distance * math.cos(err), spec["v_max"])
+        return np.array([k_a * (v - X[3]), omega])
+    k_theta, k_a, k_v = 2.0, 1.0, 1.0
+    distance = max(dist_raw - d_min, 0.05)
+    delta = min(max(k_theta * err, -spec["delta_max"]), spec["delta_max"])
+    beta = math.atan((spec["rear_ax_dist"] / spec["wheel_base"]) * math.tan(delta))
+    v_cmd = k_v * distance * max(0.0, math.cos(err))
+    v = min(max(v_cmd, spec["v_min"]), spec["v_max"])
+    return np.array([k_a * (v - X[3]), beta])
+
+
+def stop(model, X, spec):
+    """DU :106-111 (brake with k_a) ; KB :149-150 (zeros)."""
+    if model == MODEL_DU:
+        return np.array([spec.get("nominal_k_a", 1.0) * (0.0 - X[3]), 0.0])
+    return np.array([0.0, 0.0])
+
+
+def has_stopped(model, X, tol=0.05):
+    """DU :113-114 ; KB :152-153."""
+    return abs(X[3]) < tol
+
+
+def rotate_to(model, X, theta_des, k=2.0):
+    """DU :116-119 ; KB :155-158."""
+    return np.array([0.0, k * angle_normalize(theta_des - X[2])])
+
+
+# --------------------------------------------------------------------------
+# continuous-time barriers
+# --------------------------------------------------------------------------
+def _hocbf_circle(X, obs, R, beta):
+    """h, h_dot, d(h_dot)/dx for the distance barrier (rel-deg 2).
+
+    DU robots/dynamic_unicycle2D.py:136-146 ; KB robots/kinematic_bicycle2D.py:160-173.
+    """
+    th, v = X[2], X[3]
+    c, s = math.cos(th), math.sin(th)
+    ex, ey = X[0] - obs[0], X[1] - obs[1]
+    d_min = obs[2] + R
+    h = math.sqrt(ex * ex + ey * ey) ** 2 - beta * d_min ** 2
+    f0, f1 = v * c, v * s
+    h_dot = 2.0 * (ex * f0 + ey * f1)
+    dhd = np.array([2.0 * f0, 2.0 * f1,
+                    2.0 * (ex * (-v * s) + ey * (v * c)),
+                    2.0 * (ex * c + ey * s)])
+    return h, h_dot, dhd
+
+
+def _hocbf_superellipsoid(X, obs, R):
+    """DU robots/dynamic_unicycle2D.py:148-183 (signed ``**`` as in numpy)."""
+    th, v = X[2], X[3]
+    c, s = math.cos(th), math.sin(th)
+    ox, oy, a, b, e, tho = (np.float64(obs[i]) for i in range(6))
+    ct, st = np.cos(tho), np.sin(tho)
+    px = ct * (X[0] - ox) + st * (X[1] - oy)
+    py = -st * (X[0] - ox) + ct * (X[1] - oy)
+    Aa, Bb = a + R, b + R
+    with np.errstate(all="ignore"):
+        h = (px / Aa) ** e + (py / Bb) ** e - 1.0
+        gx = e * px ** (e - 1) / Aa ** e          # d/dpx of (px/Aa)^e
+        gy = e * py ** (e - 1) / Bb ** e
+        dh_x = gx * ct - gy * st
+        dh_y = gx * st + gy * ct
+        h_dot = dh_x * v * c + dh_y * v * s
+        ca = e * (e - 1) / Aa ** e * px ** (e - 2)
+        cb = e * (e - 1) / Bb ** e * py ** (e - 2)
+        hxx = ca * ct * ct + cb * st * st
+        hxy = (ca - cb) * ct * st
+        hyy = ca * st * st + cb * ct * ct
+        dhd = np.array([hxx * v * c + hxy * v * s,
+                        hxy * v * c + hyy * v * s,
+                        dh_x * (-v * s) + dh_y * (v * c),
+                        dh_x * c + dh_y * s], dtype=np.float64)
+    return float(h), float(h_dot), dhd
+
+
+def _c3bf(X, obs, R, beta=1.0):
+    """dynamic_env/kinematic_bicycle2D_c3bf.py:15-75 (collision-cone CBF, rel-deg 1)."""
+    th, v = X[2], X[3]
+    c, s = math.cos(th), math.sin(th)
+    ovx, ovy = obs[3], obs[4]
+    ego = (obs[2] + R) * beta
+    px, py = obs[0] - X[0], obs[1] - X[1]
+    vx, vy = ovx - v * c, ovy - v * s
+    pm = math.sqrt(px * px + py * py)
+    vm = math.sqrt(vx * vx + vy * vy)
+    eps = 1e-6
+    sq = math.sqrt(max(pm ** 2 - ego ** 2, eps))
+    cos_phi = sq / (pm + eps)
+    h = (px * vx + py * vy) + pm * vm * cos_phi
+    with np.errstate(all="ignore"):
+        k = np.float64(sq + eps) / np.float64(vm)
+        dh = np.array([-vx - vm * px / (sq + eps),
+                       -vy - vm * py / (sq + eps),
+                       v * s * px - v * c * py + k * (v * (ovx * s - ovy * c)),
+                       -c * px - s * py + k * (v - (ovx * c + ovy * s))], dtype=np.float64)
+    return h, dh
+
+
+def _dpcbf(X, obs, R, s_margin=1.05, k_lambda=0.1, k_mu=0.5):
+    """dynamic_env/kinematic_bicycle2D_dpcbf.py:16-84 (dynamic parabolic CBF, rel-deg 1).
+
+    Note the reference's gradient uses the bare gains k_lambda / k_mu (no
+    sqrt(s^2-1)/ego_dim factor) while h uses the scaled ones; restated as is.
+    """
+    th, v = X[2], X[3]
+    c, s = math.cos(th), math.sin(th)
+    ovx, ovy = obs[3], obs[4]
+    ego = (obs[2] + R) * s_margin
+    px, py = obs[0] - X[0], obs[1] - X[1]
+    vx, vy = ovx - v * c, ovy - v * s
+    pm = math.sqrt(px * px + py * py)
+    vm = math.sqrt(vx * vx + vy * vy)
+    rot = math.atan2(py, px)
+    cr, sr = math.cos(rot), math.sin(rot)
+    vnx = cr * vx + sr * vy
+    vny = -sr * vx + cr * vy
+    eps = 1e-6
+    d_safe = max(pm ** 2 - ego ** 2, eps)
+    sd = math.sqrt(d_safe)
+    with np.errstate(all="ignore"):
+        vm_ = np.float64(vm)
+        pm2 = np.float64(pm) ** 2
+        lam = k_lambda * sd / vm_ * math.sqrt(s_margin ** 2 - 1) / ego
+        mu = k_mu * sd * math.sqrt(s_margin ** 2 - 1) / ego
+        h = vnx + lam * vny ** 2 + mu
+        dh = np.array([
+            py * vny / pm2 - k_lambda * px * vny ** 2 / vm_ / sd
+            - 2 * k_lambda * sd / vm_ * vny * py / pm2 * vnx - k_mu * px / sd,
+            -px * vny / pm2 - k_lambda * py * vny ** 2 / vm_ / sd
+            + 2 * k_lambda * sd / vm_ * vny * px / pm2 * vnx - k_mu * py / sd,
+            -v * math.sin(rot - th)
+            - k_lambda * sd * v * (ovx * s - ovy * c) * vny ** 2 / vm_ ** 3
+            - 2 * k_lambda * sd * vny * v * math.cos(rot - th) / vm_,
+            -math.cos(rot - th)
+            - k_lambda * sd / vm_ ** 3 * (v - ovx * c - ovy * s) * vny ** 2
+            - 2 * k_lambda * sd * vny * math.sin(rot - th) / vm_], dtype=np.float64)
+    return float(h), dh
+
+
+def agent_barrier(model, X, obs, R):
+    """Dispatch mirroring robots/robot.py:435-436 -> <model>.agent_barrier.
+
+    Returns ``(h, h_dot, dh_dot_dx)`` for rel-deg-2 models and ``(h, dh_dx)``
+    for rel-deg-1 models.  An obstacle flag other than 0/1 for the DU model
+    raises ValueError (the reference returns integer zeros and the caller's
+    ``@`` fails, dynamic_unicycle2D.py:133-136).
+    """
+    if model == MODEL_DU:
+        flag = obs[-1]
+        if flag == 0:
+            return _hocbf_circle(X, obs, R, 1.01)
+        if flag == 1:
+            return _hocbf_superellipsoid(X, obs, R)
+        raise ValueError("DynamicUnicycle2D: obstacle flag must be 0 or 1")
+    if model == MODEL_KB:
+        return _hocbf_circle(X, obs, R, 1.1)
+    if model == MODEL_KB_C3BF:
+        return _c3bf(X, obs, R)
+    if model == MODEL_KB_DPCBF:
+        return _dpcbf(X, obs, R)
+    raise ValueError("unknown model id %r" % (model,))

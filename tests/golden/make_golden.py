@@ -1,0 +1,334 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the reference itself.
+
+Run ONLY in the build container (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is produced by the *reference's own code* (imported through
+tests/golden/_ref_import.py): dynamics f/g/step, nominal_input/stop/rotate_to,
+agent_barrier outputs, the CBF rows A1/b1 written by
+CBFQP.solve_control_problem (position_control/cbf_qp.py:108-187, executed
+verbatim), get_nearest_unpassed_obs, and closed-loop control_step
+trajectories of LocalTrackingController / LocalTrackingControllerDyn.
+
+What is NOT produced by the reference: the QP minimiser u*.  cvxpy/GUROBI are
+not installable here, so ``Problem.solve`` is replaced by the oracle's exact
+active-set enumerator (oracle/qp.py).  u* is pinned by uniqueness of the
+minimiser of a strictly convex QP, not by a reference solver run; the fixture
+field names say so (``u_star_oracle``).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import _ref_import  # noqa: E402
+
+_ref_import.install()
+
+from oracle import qp as oqp  # noqa: E402
+
+from safe_control.utils.headless_plot import NullAxes  # noqa: E402
+from safe_control.robots.robot import BaseRobot  # noqa: E402
+from safe_control.position_control.cbf_qp import CBFQP  # noqa: E402
+from safe_control.tracking import LocalTrackingController  # noqa: E402
+from safe_control.utils import env as ref_env  # noqa: E402
+
+DT = 0.05
+
+
+class OracleProblem:
+    """Stands where cvxpy.Problem would: solves with the oracle enumerator."""
+
+    def __init__(self, ctrl, lo, hi):
+        self.ctrl, self.lo, self.hi = ctrl, lo, hi
+        self.status = "optimal"
+
+    def solve(self, **_):
+        c = self.ctrl
+        Gb, cb = oqp.box_rows(self.lo, self.hi)
+        u, st = oqp.solve_qp2(np.vstack([c.A1.value, Gb]),
+                              np.concatenate([c.b1.value.reshape(-1), cb]),
+                              np.asarray(c.u_ref.value, dtype=float).reshape(-1))
+        self.status = "optimal" if st == 0 else "infeasible"
+        c.u.value = None if u is None else u.reshape(2, 1)
+
+
+def bounds_for(spec):
+    if spec["model"] == "DynamicUnicycle2D":
+        hi = np.array([spec["a_max"], spec["w_max"]])
+    else:
+        hi = np.array([spec["a_max"], spec["beta_max"]])
+    return -hi, hi
+
+
+def make_robot(model_name, extra=None):
+    spec = {"model": model_name}
+    if model_name == "DynamicUnicycle2D":
+        spec.update(a_max=1.0, w_max=0.5, radius=0.25)
+    else:
+        spec.update(a_max=5.0, radius=0.3)
+    if extra:
+        spec.update(extra)
+    robot = BaseRobot(np.zeros((4, 1)), spec, DT, NullAxes())
+    return robot, spec
+
+
+def draw_state(rng, model_name):
+    x, y = rng.uniform(0, 14, 2)
+    th = rng.uniform(-np.pi, np.pi)
+    v = rng.uniform(0, 1) if model_name == "DynamicUnicycle2D" else rng.uniform(0.2, 3.5)
+    return np.array([x, y, th, v])
+
+
+def draw_circles(rng, X, K, R, moving=False, rho_max=4.0, overlap=False):
+    obs = np.zeros((K, 7))
+    for k in range(K):
+        r = rng.uniform(0.2, 1.0)
+        lo = 0.7 * (r + R) if overlap else r + R + 0.05
+        rho = rng.uniform(lo, rho_max)
+        phi = rng.uniform(-np.pi, np.pi)
+        obs[k, 0:3] = [X[0] + rho * np.cos(phi), X[1] + rho * np.sin(phi), r]
+        if moving:
+            obs[k, 3:5] = rng.uniform(-0.5, 0.5, 2)
+    return obs
+
+
+def draw_superellipsoids(rng, X, K, R):
+    obs = np.zeros((K, 7))
+    for k in range(K):
+        a, b = rng.uniform(0.3, 1.2, 2)
+        e = float(rng.choice([4, 6, 10]))
+        tho = rng.uniform(-np.pi, np.pi)
+        rho = rng.uniform(max(a, b) + R + 0.3, 4.5)
+        phi = rng.uniform(-np.pi, np.pi)
+        obs[k] = [X[0] + rho * np.cos(phi), X[1] + rho * np.sin(phi), a, b, e, tho, 1.0]
+    return obs
+
+
+# ---------------------------------------------------------------------------
+def gen_callbacks(rng):
+    out = {}
+    for name in ["DynamicUnicycle2D", "KinematicBicycle2D", "KinematicBicycle2D_C3BF",
+                 "KinematicBicycle2D_DPCBF"]:
+        robot, spec = make_robot(name)
+        N = 96
+        rec = {k: [] for k in ["X", "U", "goal", "theta_des", "obs", "f", "g", "step",
+                               "nominal", "stop", "rotate", "h", "g1", "g2"]}
+        for i in range(N):
+            X = draw_state(rng, name)
+            robot.X = X.reshape(-1, 1).copy()
+            U = rng.uniform(-1, 1, 2) * np.array([spec["a_max"], 0.5])
+            goal = rng.uniform(0, 14, 2)
+            th_des = rng.uniform(-np.pi, np.pi)
+            if name == "DynamicUnicycle2D" and i % 3 == 2:
+                obs = draw_superellipsoids(rng, X, 1, spec["radius"])[0]
+            else:
+                obs = draw_circles(rng, X, 1, spec["radius"], moving=("_" in name))[0]
+            rec["X"].append(X); rec["U"].append(U); rec["goal"].append(goal)
+            rec["theta_des"].append(th_des); rec["obs"].append(obs)
+            rec["f"].append(robot.f().reshape(-1))
+            rec["g"].append(np.asarray(robot.g(), dtype=float))
+            rec["nominal"].append(robot.nominal_input(goal).reshape(-1))
+            rec["stop"].append(np.asarray(robot.stop(), dtype=float).reshape(-1))
+            rec["rotate"].append(robot.rotate_to(th_des).reshape(-1))
+            bar = robot.agent_barrier(obs)
+            rec["h"].append(float(np.asarray(bar[0]).reshape(-1)[0]))
+            if len(bar) == 3:
+                rec["g1"].append(float(np.asarray(bar[1]).reshape(-1)[0]))
+                rec["g2"].append(np.asarray(bar[2], dtype=float).reshape(-1))
+            else:
+                rec["g1"].append(np.nan)
+                rec["g2"].append(np.asarray(bar[1], dtype=float).reshape(-1))
+            Xn = robot.step(U.reshape(-1, 1)).reshape(-1).copy()
+            rec["step"].append(Xn)
+        for k, v in rec.items():
+            out[f"{name}/{k}"] = np.array(v, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "callbacks.npz"), **out)
+    print("callbacks.npz", len(out), "arrays")
+
+
+# ---------------------------------------------------------------------------
+def run_cbfqp_case(ctrl, robot, X, u_ref, obs_list):
+    robot.X = X.reshape(-1, 1).copy()
+    control_ref = {"state_machine": "track", "u_ref": u_ref.reshape(2, 1), "goal": None}
+    u = ctrl.solve_control_problem(robot.X, control_ref, obs_list)
+    return (ctrl.A1.value.copy(), ctrl.b1.value.reshape(-1).copy(),
+            None if u is None else np.asarray(u, dtype=float).reshape(-1), ctrl.status)
+
+
+def gen_cbfqp(rng):
+    out = {}
+    KMAX = 12
+    groups = [
+        # name, model, num_obs, n_cases, obstacle kind, spec extras
+        ("du_circle", "DynamicUnicycle2D", 8, 160, "circle", None),
+        ("du_circle_hard", "DynamicUnicycle2D", 8, 48, "circle", {"cbf_mode": "hard"}),
+        ("du_superellipsoid", "DynamicUnicycle2D", 8, 96, "super", None),
+        ("du_mixed_trunc", "DynamicUnicycle2D", 5, 64, "mixed", None),      # K > num_obs and K < num_obs
+        ("du_overlap", "DynamicUnicycle2D", 8, 96, "overlap", None),        # many infeasible
+        ("kb_circle", "KinematicBicycle2D", 8, 64, "circle", None),
+        ("c3bf", "KinematicBicycle2D_C3BF", 10, 96, "moving", None),
+        ("c3bf_k16", "KinematicBicycle2D_C3BF", 16, 48, "moving16", None),
+        ("dpcbf", "KinematicBicycle2D_DPCBF", 10, 96, "moving", None),
+    ]
+    for gname, model, num_obs, n, kind, extra in groups:
+        robot, spec = make_robot(model, extra)
+        ctrl = CBFQP(robot, spec, num_obs=num_obs)
+        lo, hi = bounds_for(spec)
+        ctrl.cbf_controller = OracleProblem(ctrl, lo, hi)
+        rec = {k: [] for k in ["X", "u_ref", "obs", "k", "A", "b", "u_star_oracle", "status_oracle"]}
+        kmax = 16 if kind == "moving16" else KMAX
+        for i in range(n):
+            X = draw_state(rng, model)
+            R = spec["radius"]
+            if kind == "circle":
+                K = 8; obs = draw_circles(rng, X, K, R)
+            elif kind == "super":
+                K = int(rng.integers(1, 9)); obs = draw_superellipsoids(rng, X, K, R)
+            elif kind == "mixed":
+                K = int(rng.integers(1, 10))
+                obs = np.vstack([draw_circles(rng, X, K, R)[: (K + 1) // 2],
+                                 draw_superellipsoids(rng, X, K, R)[: K // 2]]) if K > 1 else draw_circles(rng, X, 1, R)
+                K = obs.shape[0]
+            elif kind == "overlap":
+                K = 8; obs = draw_circles(rng, X, K, R, rho_max=2.0, overlap=True)
+            elif kind == "moving":
+                K = int(rng.integers(1, 11)); obs = draw_circles(rng, X, K, R, moving=True, rho_max=6.0)
+                obs[:, 5:7] = rng.uniform(-5, 5, (K, 2))      # y_min/y_max slots are ignored by C3BF/DPCBF
+            elif kind == "moving16":
+                K = 16; obs = draw_circles(rng, X, K, R, moving=True, rho_max=8.0)
+            goal = rng.uniform(0, 14, 2)
+            robot.X = X.reshape(-1, 1).copy()
+            u_ref = robot.nominal_input(goal).reshape(-1)
+            if i % 7 == 3:
+                u_ref = u_ref * 4.0                               # push u_ref outside the box
+            A, b, u, status = run_cbfqp_case(ctrl, robot, X, u_ref, list(obs))
+            obs_p = np.full((kmax, 7), np.nan); obs_p[:K] = obs
+            rec["X"].append(X); rec["u_ref"].append(u_ref); rec["obs"].append(obs_p); rec["k"].append(K)
+            rec["A"].append(A); rec["b"].append(b)
+            rec["u_star_oracle"].append(np.full(2, np.nan) if u is None else u)
+            rec["status_oracle"].append(0 if status == "optimal" else 1)
+        for k, v in rec.items():
+            out[f"{gname}/{k}"] = np.array(v)
+        out[f"{gname}/meta"] = np.array([num_obs, spec["radius"], lo[0], lo[1], hi[0], hi[1],
+                                         spec.get("rear_ax_dist", 0.0)], dtype=np.float64)
+        n_inf = int(np.sum(rec["status_oracle"]))
+        print(f"{gname}: {n} cases, {n_inf} infeasible")
+    # obs_list None: returns u_ref unclipped, status optimal (cbf_qp.py:113-118)
+    robot, spec = make_robot("DynamicUnicycle2D")
+    ctrl = CBFQP(robot, spec, num_obs=8)
+    u_ref = np.array([3.0, -2.0])
+    robot.X = np.array([1.0, 2.0, 0.3, 0.5]).reshape(-1, 1)
+    u = ctrl.solve_control_problem(robot.X, {"u_ref": u_ref.reshape(2, 1)}, None)
+    out["none/u_ref"] = u_ref
+    out["none/u"] = np.asarray(u, dtype=float).reshape(-1)
+    out["none/status_optimal"] = np.array([ctrl.status == "optimal"])
+    np.savez_compressed(os.path.join(HERE, "cbfqp_cases.npz"), **out)
+
+
+# ---------------------------------------------------------------------------
+def gen_nearest(rng):
+    out = {}
+    for name in ["DynamicUnicycle2D", "KinematicBicycle2D_C3BF"]:
+        spec = {"model": name, "radius": 0.25}
+        if name == "DynamicUnicycle2D":
+            spec.update(a_max=1.0, w_max=0.5)
+        ctl = LocalTrackingController(np.array([1.0, 1.0, 0.0, 0.5]), spec,
+                                      controller_type={"pos": "cbf_qp"}, dt=DT, env=ref_env.Env())
+        Xs, tables, counts, sel, nsel = [], [], [], [], []
+        for i in range(64):
+            M = int(rng.integers(1, 25))
+            table = np.zeros((24, 7)); table[:] = np.nan
+            obs = np.zeros((M, 7))
+            obs[:, 0:2] = rng.uniform(0, 14, (M, 2)); obs[:, 2] = rng.uniform(0.2, 1.0, M)
+            table[:M] = obs
+            X = draw_state(rng, name)
+            ctl.robot.X = X.reshape(-1, 1).copy(); ctl.robot.yaw = X[2]
+            ctl.obs = obs.copy()
+            got = ctl.get_nearest_unpassed_obs([], obs_num=10)
+            s = np.full((10, 7), np.nan); s[: len(got)] = got
+            Xs.append(X); tables.append(table); counts.append(M); sel.append(s); nsel.append(len(got))
+        out[f"{name}/X"] = np.array(Xs); out[f"{name}/table"] = np.array(tables)
+        out[f"{name}/m"] = np.array(counts); out[f"{name}/sel"] = np.array(sel); out[f"{name}/nsel"] = np.array(nsel)
+    np.savez_compressed(os.path.join(HERE, "nearest_obs.npz"), **out)
+    print("nearest_obs.npz")
+
+
+# ---------------------------------------------------------------------------
+def gen_closed_loop():
+    """BASELINE config 1: examples/test_tracking.py --model du --algo cbf_qp (no sensor, headless)."""
+    out = {}
+    known = np.array([[2.2, 5.0, 0.2], [3.0, 5.0, 0.2], [4.0, 9.0, 0.3], [1.5, 10.0, 0.5], [9.0, 11.0, 1.0],
+                      [7.0, 7.0, 3.0], [4.0, 3.5, 1.5], [10.0, 7.3, 0.4], [6.0, 13.0, 0.7], [5.0, 10.0, 0.6],
+                      [11.0, 5.0, 0.8], [13.5, 11.0, 0.6], [2.0, 7.0, 0.7], [2.0, 8.0, 0.5]])
+    known = np.hstack((known, np.zeros((known.shape[0], 4))))
+    wps = np.array([[2, 2, np.pi / 2], [2, 12, 0], [12, 12, 0], [12, 2, 0]], dtype=np.float64)
+    for tag, table in [("du14", known), ("du3", known[:3])]:
+        spec = {"model": "DynamicUnicycle2D", "w_max": 0.5, "a_max": 1.0, "radius": 0.25}
+        ctl = LocalTrackingController(np.append(wps[0], 1.0), spec, controller_type={"pos": "cbf_qp"},
+                                      dt=DT, env=ref_env.Env())
+        lo, hi = bounds_for(spec)
+        ctl.pos_controller.cbf_controller = OracleProblem(ctl.pos_controller, lo, hi)
+        ctl.obs = table.copy()
+        ctl.set_waypoints(wps)
+        Xs, Us, rets, sms = [ctl.robot.X.reshape(-1).copy()], [], [], []
+        for _ in range(2000):
+            ret = ctl.control_step()
+            rets.append(ret); sms.append(["idle", "track", "stop", "rotate"].index(ctl.state_machine))
+            if ret == -2:
+                break
+            Xs.append(ctl.robot.X.reshape(-1).copy()); Us.append(ctl.get_control_input().reshape(-1).copy())
+            if ret == -1:
+                break
+        out[f"{tag}/obs"] = table; out[f"{tag}/waypoints"] = wps
+        out[f"{tag}/X"] = np.array(Xs); out[f"{tag}/U"] = np.array(Us)
+        out[f"{tag}/ret"] = np.array(rets); out[f"{tag}/sm"] = np.array(sms)
+        print(tag, "steps", len(rets), "last ret", rets[-1])
+
+    # moving obstacles: dynamic_env/main.py LocalTrackingControllerDyn with C3BF
+    from safe_control.dynamic_env.main import LocalTrackingControllerDyn
+    rng = np.random.default_rng(7)
+    obs = np.zeros((8, 7))
+    obs[:, 0] = rng.uniform(6, 20, 8); obs[:, 1] = rng.uniform(1, 9, 8); obs[:, 2] = 0.4
+    obs[:, 3] = -0.5; obs[:, 4] = rng.choice([-0.5, 0.5], 8); obs[:, 5] = 0.0; obs[:, 6] = 10.0
+    wps = np.array([[1, 5, 0], [22, 5, 0]], dtype=np.float64)
+    for tag, model in [("c3bf_dyn", "KinematicBicycle2D_C3BF"), ("dpcbf_dyn", "KinematicBicycle2D_DPCBF")]:
+        spec = {"model": model, "a_max": 5.0, "radius": 0.3}
+        ctl = LocalTrackingControllerDyn(np.append(wps[0], 1.0), spec, controller_type={"pos": "cbf_qp"},
+                                         dt=DT, env=ref_env.Env())
+        lo, hi = bounds_for(spec)
+        ctl.pos_controller.cbf_controller = OracleProblem(ctl.pos_controller, lo, hi)
+        ctl.obs = obs.copy()
+        # cone / parabola drawing (dynamic_env/robot.py) is rendering only: skip it
+        ctl.robot.draw_collision_cone = lambda *a, **k: None
+        ctl.robot.draw_collision_parabola = lambda *a, **k: None
+        ctl.set_waypoints(wps)
+        Xs, Us, rets = [ctl.robot.X.reshape(-1).copy()], [], []
+        for _ in range(600):
+            ret = ctl.control_step()
+            rets.append(ret)
+            if ret == -2:
+                break
+            Xs.append(ctl.robot.X.reshape(-1).copy()); Us.append(ctl.get_control_input().reshape(-1).copy())
+            if ret == -1:
+                break
+        out[f"{tag}/obs0"] = obs; out[f"{tag}/waypoints"] = wps
+        out[f"{tag}/X"] = np.array(Xs); out[f"{tag}/U"] = np.array(Us); out[f"{tag}/ret"] = np.array(rets)
+        out[f"{tag}/obs_final"] = ctl.obs.copy()
+        print(tag, "steps", len(rets), "last ret", rets[-1])
+    np.savez_compressed(os.path.join(HERE, "closed_loop.npz"), **out)
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(20240611)
+    gen_callbacks(rng)
+    gen_cbfqp(rng)
+    gen_nearest(rng)
+    gen_closed_loop()
