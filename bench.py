@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched CBF-QP hot path on MI355X (BASELINE.json metric:
+"QP solves/sec (batched agents)").
+
+    python bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path over one batch: one fused kernel launch
+that assembles the CBF rows of every agent and solves every QP.  The default
+workload is BASELINE.json configs[1]: 4096 DynamicUnicycle2D agents x 8
+circular obstacles each (seeded synthetic inputs, resident in HBM before the
+timed region).  With N > 1 (launched by torch.distributed.run, one rank per
+GPU) every rank owns its own 4096-agent shard -- weak scaling, no data-path
+collective -- and the job time is the MAX over ranks.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      HBM roofline of the fused kernel on this workload (algorithmic bytes / launch time)
+  cpu_baseline  the oracle's C restatement timed on this box's host cores (N = 1 only)
+  sweep         the same kernel at larger batches, where the HBM roofline is the binding limit
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_IN_CBFQP = lambda K, es: (4 + 2 + 7 * K) * es            # X + u_ref + obs rows   # noqa: E731
+BYTES_OUT_CBFQP = lambda K, es: (2 + K) * es + 4               # u + h + status(int32)   # noqa: E731
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--agents", type=int, default=4096, help="agents per GPU (BASELINE configs[1]: 4096)")
+    ap.add_argument("--obstacles", type=int, default=8)
+    ap.add_argument("--compute", choices=["f32", "f64"], default="f64", help="arithmetic type inside the kernel")
+    ap.add_argument("--io", choices=["f32", "f64"], default="f32", help="storage type of states/obstacles/outputs")
+    ap.add_argument("--eager", action="store_true", help="launch each step from Python instead of one hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(X, u_ref, obs, seconds):
+    """Oracle (C restatement, kind "port") on the host cores: bounded sample of the same workload."""
+    import numpy as np
+    from oracle import c_oracle, cbf_qp as ocbf, robots as R
+    spec = R.default_spec(R.MODEL_DU)
+    spec.update(a_max=1.0, w_max=0.5, radius=0.25)
+    cp = ocbf.default_cbf_param(R.MODEL_DU)
+    threads = os.cpu_count() or 1
+    out = {}
+    for label, nt, budget in (("all_cores", threads, seconds * 0.7), ("one_core", 1, seconds * 0.3)):
+        c_oracle.cbfqp_batch(R.MODEL_DU, X, u_ref, obs, spec, cp, n_threads=nt)      # warm
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            c_oracle.cbfqp_batch(R.MODEL_DU, X, u_ref, obs, spec, cp, n_threads=nt)
+            n += 1
+        dt = time.perf_counter() - t0
+        out[label] = (n * X.shape[0] / dt, nt, n)
+    v, nt, n = out["all_cores"]
+    return {"value": v, "unit": "solves/s", "cores": nt, "kind": "port",
+            "sample": f"{n} passes over the same {X.shape[0]}-agent x {obs.shape[1]}-obstacle batch, "
+                      f"oracle/c/cbfqp_oracle.c (float64, exact active-set enumeration), OpenMP {nt} threads",
+            "one_core_value": out["one_core"][0]}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import safe_control_amd as sca
+    from safe_control_amd import sharding, workloads as W
+
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if ws > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    if a.gpus != ws and rank == 0 and ws > 1:
+        print(f"note: --gpus {a.gpus} but WORLD_SIZE {ws}; using WORLD_SIZE", file=sys.stderr)
+
+    B, K = a.agents, a.obstacles
+    spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}
+    ctl = sca.BatchedCBFQP(dict(spec), dt=0.05, io_dtype=a.io, compute_dtype=a.compute)
+    td = ctl.torch_dtype
+    es = 4 if a.io == "f32" else 8
+    Xn, goal, un, on = W.du_cbfqp_batch(B, K, seed=rank)           # each rank: its own shard
+    X = torch.tensor(Xn, dtype=td, device=dev)
+    ur = torch.tensor(un, dtype=td, device=dev)
+    ob = torch.tensor(on, dtype=td, device=dev)
+    out = (torch.empty((B, 2), dtype=td, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
+           torch.empty((B, K), dtype=td, device=dev))
+
+    def step():
+        ctl.solve(X, ur, ob, out=out)
+
+    for _ in range(max(a.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+
+    graph = None
+    if not a.eager:
+        # the launch-bound inner loop as ONE hipGraph: K kernel nodes on the capture stream
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            step()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(a.steps):
+                    step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        graph.replay()                                              # untimed: first replay uploads the graph
+        torch.cuda.synchronize()
+
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    if ws > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()                                                     # same stream the kernels run on
+    if graph is not None:
+        graph.replay()
+    else:
+        for _ in range(a.steps):
+            step()
+    e1.record()
+    torch.cuda.synchronize()
+    if ws > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = sharding.max_over_ranks(t1 - t0, device=dev)
+    kernel_ms = e0.elapsed_time(e1) / a.steps                       # avg launch duration over the timed region
+
+    st = out[1]
+    n_opt = int((st == 0).sum().item())
+    if rank == 0:
+        total = B * ws * a.steps
+        alg_bytes = (BYTES_IN_CBFQP(K, es) + BYTES_OUT_CBFQP(K, es)) * B
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": "QP solves/sec (batched agents)", "value": total / elapsed, "unit": "solves/s",
+            "n_gpus": ws, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.compute, "data": "synthetic",
+            "config": {"workload": f"{B}-agent batch DynamicUnicycle2D CBF-QP, {K} obstacles each (BASELINE configs[1])"
+                                   if (B, K) == (4096, 8) else f"{B}-agent batch DynamicUnicycle2D CBF-QP, {K} obstacles each",
+                       "agents_per_gpu": B, "obstacles": K, "storage": a.io, "arithmetic": a.compute,
+                       "launch": "eager" if a.eager else "hipGraph", "sharding": f"agents x{ws}, no collective",
+                       "optimal_fraction": n_opt / B},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "cbfqp_kernel", "kernel_us": 1e3 * kernel_ms,
+                         "algorithmic_bytes_per_solve": BYTES_IN_CBFQP(K, es) + BYTES_OUT_CBFQP(K, es)},
+        }
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                res["roofline"]["traffic"] = json.load(open(pmc)).get(f"cbfqp_B{B}_K{K}_{a.io}")
+            except Exception:
+                pass
+        if ws == 1 and not a.no_sweep:
+            res["sweep"] = sweep(ctl, dev, td, es, K)
+        if ws == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(X.double().cpu().numpy(), ur.double().cpu().numpy(),
+                                               ob.double().cpu().numpy(), a.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if ws > 1:
+        dist.destroy_process_group()
+
+
+def sweep(ctl, dev, td, es, K):
+    """Same kernel at batch sizes where HBM is the binding limit (inputs drawn on-device)."""
+    import math
+    import torch
+    res = []
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    for B in (65536, 1 << 20, 1 << 24):
+        X = torch.rand((B, 4), generator=g, device=dev, dtype=torch.float32)
+        X[:, 0:2] *= 14.0
+        X[:, 2] = (X[:, 2] * 2 - 1) * math.pi
+        goal = torch.rand((B, 2), generator=g, device=dev) * 14.0
+        r = torch.rand((B, K), generator=g, device=dev) * 0.8 + 0.2
+        rho = torch.rand((B, K), generator=g, device=dev) * (4.0 - (r + 0.3)) + (r + 0.3)
+        phi = (torch.rand((B, K), generator=g, device=dev) * 2 - 1) * math.pi
+        obs = torch.zeros((B, K, 7), device=dev)
+        obs[:, :, 0] = X[:, None, 0] + rho * torch.cos(phi)
+        obs[:, :, 1] = X[:, None, 1] + rho * torch.sin(phi)
+        obs[:, :, 2] = r
+        err = torch.remainder(torch.atan2(goal[:, 1] - X[:, 1], goal[:, 0] - X[:, 0]) - X[:, 2] + math.pi, 2 * math.pi) - math.pi
+        d = (torch.hypot(X[:, 0] - goal[:, 0], X[:, 1] - goal[:, 1]) - 0.05).clamp_min(0)
+        v = torch.where(err.abs() > math.pi / 2, torch.zeros_like(d), (d * torch.cos(err)).clamp_max(1.0))
+        ur = torch.stack([v - X[:, 3], 2.0 * err], dim=1)
+        X, ur, obs = X.to(td).contiguous(), ur.to(td).contiguous(), obs.to(td).contiguous()
+        out = (torch.empty((B, 2), dtype=td, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
+               torch.empty((B, K), dtype=td, device=dev))
+        for _ in range(3):
+            ctl.solve(X, ur, obs, out=out)
+        torch.cuda.synchronize()
+        n = 20 if B <= (1 << 20) else 10
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            ctl.solve(X, ur, obs, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        nbytes = (BYTES_IN_CBFQP(K, es) + BYTES_OUT_CBFQP(K, es)) * B
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        res.append({"agents": B, "kernel_us": 1e3 * ms, "solves_per_s": B / (ms * 1e-3),
+                    "achieved_GBs": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS})
+        del X, ur, obs, out
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+/*
+ * safe_control_amd.h -- C-ABI of the MI355X batched CBF-QP / MPC-CBF solve engine.
+ *
+ * The reference (tkkim-robot/safe_control) has no FFI: its hot path sits
+ * behind a duck-typed Python plugin protocol (tracking.py:140-154 picks
+ * `pos_controller`; tracking.py:611-616 calls
+ * `pos_controller.solve_control_problem(robot.X, control_ref, obs)`).  This
+ * header is therefore the *new* boundary a maintainer binds with ctypes (see
+ * INTEGRATION.md); every entry point cites the reference interface it
+ * replaces.  Plain pointers and sizes only; no exceptions cross the ABI; all
+ * functions return an `sc_error` (0 = ok).
+ *
+ * Memory: all `*_batch` entry points take DEVICE pointers (HBM resident, as
+ * handed out by hipMalloc / torch) and enqueue on `stream` (a hipStream_t, may
+ * be NULL = default stream) without synchronising.  The `*_host` twins take
+ * HOST pointers, stage through device buffers and synchronise before
+ * returning (single-agent drop-in use).  Caller owns every buffer.
+ * Thread safety: calls on distinct streams are independent; the library
+ * keeps no mutable global state besides a thread-local last-error string.
+ *
+ * Array layouts are exactly the reference's numpy layouts, row-major:
+ *   X      [B, 4]     state  [x, y, theta, v]          (robot.X, robots/robot.py:38)
+ *   u_ref  [B, 2]     nominal input                    (control_ref['u_ref'], tracking.py:607-609)
+ *   obs    [B, K, 7]  obstacle rows [x,y,r,vx,vy,-,flag] or [ox,oy,a,b,e,theta,1]
+ *                     (nearest_multi_obs, tracking.py:584); [K, 7] when obs_shared != 0
+ *   n_obs  [B] int32  optional per-agent count of valid rows (<= K); NULL = all K.
+ *                     Rows >= n_obs[i] are "0*u + 0 >= 0" like the reference's
+ *                     zero-initialised A1/b1 rows (position_control/cbf_qp.py:110-111).
+ */
+#ifndef SAFE_CONTROL_AMD_H
+#define SAFE_CONTROL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_VERSION_MAJOR 0
+#define SC_VERSION_MINOR 1
+
+/* ---- return codes ------------------------------------------------------ */
+typedef enum sc_error {
+    SC_OK = 0,
+    SC_ERR_INVALID_ARGUMENT = 1,   /* NULL pointer, bad K/B/dtype/model id            */
+    SC_ERR_UNSUPPORTED = 2,        /* K (or horizon) above the compiled maximum       */
+    SC_ERR_HIP = 3,                /* a HIP runtime call failed (see sc_last_error)   */
+    SC_ERR_NO_DEVICE = 4           /* no gfx950 device visible                        */
+} sc_error;
+
+/* ---- per-problem solve status (int32 in status_out) --------------------
+ * Mapped by the Python shim to the strings tracking.py:628 compares with
+ * 'optimal' ('optimal' / 'infeasible' / 'optimal_inaccurate').             */
+#define SC_STATUS_OPTIMAL      0
+#define SC_STATUS_INFEASIBLE   1
+#define SC_STATUS_INACCURATE   2   /* MPC-CBF only: iteration limit reached            */
+#define SC_STATUS_BAD_OBSTACLE 3   /* obstacle flag not 0/1 for a model that needs it
+                                      (the reference raises inside agent_barrier,
+                                      robots/dynamic_unicycle2D.py:133-136)            */
+
+/* ---- robot models: robots/robot.py:65-175 dispatch ---------------------- */
+#define SC_MODEL_DYNAMIC_UNICYCLE2D        0  /* robots/dynamic_unicycle2D.py                    */
+#define SC_MODEL_KINEMATIC_BICYCLE2D       1  /* robots/kinematic_bicycle2D.py                   */
+#define SC_MODEL_KINEMATIC_BICYCLE2D_C3BF  2  /* dynamic_env/kinematic_bicycle2D_c3bf.py         */
+#define SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF 3  /* dynamic_env/kinematic_bicycle2D_dpcbf.py        */
+
+#define SC_DTYPE_F32 0
+#define SC_DTYPE_F64 1
+
+#define SC_CBF_MODE_CBF  0   /* robot_spec['cbf_mode'] == 'cbf'  (cbf_qp.py:120)  */
+#define SC_CBF_MODE_HARD 1   /* robot_spec['cbf_mode'] == 'hard' (cbf_qp.py:158-161,170-177) */
+
+#define SC_CBFQP_MAX_OBS 32  /* largest K the CBF-QP kernels are instantiated for */
+
+/* Parameters of one CBFQP controller instance: what CBFQP.__init__ /
+ * setup_control_problem read from robot_spec and cbf_param
+ * (position_control/cbf_qp.py:5-45, 47-106).                               */
+typedef struct sc_cbfqp_params {
+    int32_t model_id;        /* SC_MODEL_*                                            */
+    int32_t io_dtype;        /* SC_DTYPE_*: element type of X,u_ref,obs,u_out,h_out   */
+    int32_t compute_dtype;   /* SC_DTYPE_*: arithmetic type inside the kernel         */
+    int32_t cbf_mode;        /* SC_CBF_MODE_*                                         */
+    int32_t obs_shared;      /* 0: obs is [B,K,7]; 1: one [K,7] table for all agents  */
+    int32_t reserved0;
+    double  robot_radius;    /* robot.robot_radius (robots/robot.py:49-50)            */
+    double  dt;              /* robot.dt, used by 'hard' mode only                    */
+    double  alpha1;          /* cbf_param['alpha1'] (rel-deg 2) or ['alpha'] (rel-deg 1) */
+    double  alpha2;          /* cbf_param['alpha2'] (rel-deg 2), unused otherwise     */
+    double  u_min[2];        /* input box, cbf_qp.py:62-65 / :70-73                   */
+    double  u_max[2];
+    double  rear_ax_dist;    /* robot_spec['rear_ax_dist'] (KinematicBicycle2D family) */
+} sc_cbfqp_params;
+
+/* ---- library ------------------------------------------------------------ */
+int         sc_version(void);                 /* major*1000 + minor                        */
+const char* sc_last_error(void);              /* thread-local message of the last failure   */
+int         sc_device_count(int* count_out);  /* number of visible HIP devices              */
+
+/* ---- CBF-QP -------------------------------------------------------------
+ * Replaces, for a whole batch of agents in one launch:
+ *   CBFQP.solve_control_problem(robot_state, control_ref, obs_list)
+ *     position_control/cbf_qp.py:108-199  (row assembly :120-183, solve :190, status :195)
+ *   robot.f()/g()/agent_barrier(obs)   robots/robot.py:389-436 -> robots/<model>.py
+ *   cvxpy -> GUROBI solve of  min ||u-u_ref||^2  s.t. A1 u + b1 >= 0, box
+ *
+ * u_out [B,2]: minimiser (NaN where status != OPTIMAL; the reference returns None).
+ * status_out [B] int32: SC_STATUS_*.
+ * h_out [B,K] or NULL: barrier value h(x) per obstacle row (0 for rows >= n_obs[i]).
+ * Element type of X/u_ref/obs/u_out/h_out is params->io_dtype.
+ */
+int sc_cbfqp_solve_batch(const sc_cbfqp_params* params, int64_t B, int32_t K,
+                         const void* X, const void* u_ref, const void* obs,
+                         const int32_t* n_obs,
+                         void* u_out, int32_t* status_out, void* h_out,
+                         void* stream);
+
+/* Same computation, HOST pointers; copies in/out and synchronises. */
+int sc_cbfqp_solve_batch_host(const sc_cbfqp_params* params, int64_t B, int32_t K,
+                              const void* X, const void* u_ref, const void* obs,
+                              const int32_t* n_obs,
+                              void* u_out, int32_t* status_out, void* h_out,
+                              int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAFE_CONTROL_AMD_H */

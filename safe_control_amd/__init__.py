@@ -1,0 +1,13 @@
+"""MI355X-native batched CBF-QP / MPC-CBF solve engine (drop-in for the
+position_control.cbf_qp / mpc_cbf plugins of tkkim-robot/safe_control).
+
+The compute path is hand-written HIP for gfx950 behind a C-ABI
+(include/safe_control_amd.h, safe_control_amd/csrc).  This Python package is
+the host-side mirror of the reference's plugin interface; it has no CPU
+fallback and raises if the HIP library is missing.
+"""
+from ._lib import HipLibraryError, load as load_library  # noqa: F401
+from .position_control.cbf_qp import CBFQP, BatchedCBFQP  # noqa: F401
+from .robots.spec import RobotHandle, complete_robot_spec  # noqa: F401
+
+__version__ = "0.1.0"

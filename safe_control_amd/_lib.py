@@ -1,0 +1,82 @@
+"""ctypes binding of the HIP library (include/safe_control_amd.h).
+
+There is NO CPU fallback: if ``lib/libsafe_control_hip.so`` is missing or a
+symbol is absent, importing a solver raises.  Build with
+``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C safe_control_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsafe_control_hip.so")
+
+SC_OK = 0
+STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_INACCURATE, STATUS_BAD_OBSTACLE = 0, 1, 2, 3
+STATUS_STRINGS = {0: "optimal", 1: "infeasible", 2: "optimal_inaccurate", 3: "bad_obstacle"}
+DTYPE_F32, DTYPE_F64 = 0, 1
+CBF_MODE = {"cbf": 0, "hard": 1}
+CBFQP_MAX_OBS = 32
+
+MODEL_IDS = {
+    "DynamicUnicycle2D": 0,
+    "KinematicBicycle2D": 1,
+    "KinematicBicycle2D_C3BF": 2,
+    "KinematicBicycle2D_DPCBF": 3,
+}
+
+
+class CbfQpParams(C.Structure):
+    """Mirror of ``sc_cbfqp_params``."""
+    _fields_ = [
+        ("model_id", C.c_int32), ("io_dtype", C.c_int32), ("compute_dtype", C.c_int32),
+        ("cbf_mode", C.c_int32), ("obs_shared", C.c_int32), ("reserved0", C.c_int32),
+        ("robot_radius", C.c_double), ("dt", C.c_double),
+        ("alpha1", C.c_double), ("alpha2", C.c_double),
+        ("u_min", C.c_double * 2), ("u_max", C.c_double * 2),
+        ("rear_ax_dist", C.c_double),
+    ]
+
+
+# every symbol include/safe_control_amd.h declares, with its ctypes signature
+SYMBOLS = {
+    "sc_version": (C.c_int, []),
+    "sc_last_error": (C.c_char_p, []),
+    "sc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "sc_cbfqp_solve_batch": (C.c_int, [C.POINTER(CbfQpParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sc_cbfqp_solve_batch_host": (C.c_int, [C.POINTER(CbfQpParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library or raise HipLibraryError (never falls back to a CPU path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C safe_control_amd/csrc` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != SC_OK:
+        msg = load().sc_last_error()
+        raise HipLibraryError(f"{what} failed (sc_error {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,117 @@
+// C-ABI entry points (include/safe_control_amd.h).  No exceptions cross this file.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/safe_control_amd.h"
+
+namespace sc {
+hipError_t cbfqp_launch(const sc_cbfqp_params& p, long long B, int K, const void* X, const void* u_ref,
+                        const void* obs, const int* n_obs, void* u_out, int* status, void* h_out,
+                        hipStream_t stream);
+
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char* msg) {
+    std::snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+static int fail_hip(hipError_t e, const char* where) {
+    std::snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return e == hipErrorNoDevice ? SC_ERR_NO_DEVICE : SC_ERR_HIP;
+}
+
+static int check_cbfqp(const sc_cbfqp_params* p, int64_t B, int32_t K, const void* X, const void* u_ref,
+                       const void* obs, const void* u_out, const void* status_out) {
+    if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (B < 0) return fail(SC_ERR_INVALID_ARGUMENT, "B < 0");
+    if (K < 1) return fail(SC_ERR_INVALID_ARGUMENT, "K < 1 (pass obs_list=None handling to the caller: u = u_ref)");
+    if (K > SC_CBFQP_MAX_OBS) return fail(SC_ERR_UNSUPPORTED, "K exceeds SC_CBFQP_MAX_OBS");
+    if (p->model_id < 0 || p->model_id > SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF)
+        return fail(SC_ERR_INVALID_ARGUMENT, "unknown model_id");
+    if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
+        return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
+    if (p->compute_dtype != SC_DTYPE_F32 && p->compute_dtype != SC_DTYPE_F64)
+        return fail(SC_ERR_INVALID_ARGUMENT, "compute_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
+    if (p->io_dtype == SC_DTYPE_F64 && p->compute_dtype == SC_DTYPE_F32)
+        return fail(SC_ERR_UNSUPPORTED, "f64 storage with f32 arithmetic is not built");
+    if (p->cbf_mode != SC_CBF_MODE_CBF && p->cbf_mode != SC_CBF_MODE_HARD)
+        return fail(SC_ERR_INVALID_ARGUMENT, "cbf_mode must be 0 (cbf) or 1 (hard)");
+    if (!(p->dt > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "dt must be > 0");
+    if (p->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && !(p->rear_ax_dist > 0))
+        return fail(SC_ERR_INVALID_ARGUMENT, "rear_ax_dist must be > 0 for the KinematicBicycle2D family");
+    if (B > 0 && (!X || !u_ref || !obs || !u_out || !status_out))
+        return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    return SC_OK;
+}
+}  // namespace sc
+
+extern "C" {
+
+int sc_version(void) { return SC_VERSION_MAJOR * 1000 + SC_VERSION_MINOR; }
+
+const char* sc_last_error(void) { return sc::g_err; }
+
+int sc_device_count(int* count_out) {
+    if (!count_out) return sc::fail(SC_ERR_INVALID_ARGUMENT, "count_out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count_out = 0; return sc::fail_hip(e, "hipGetDeviceCount"); }
+    *count_out = n;
+    return SC_OK;
+}
+
+int sc_cbfqp_solve_batch(const sc_cbfqp_params* params, int64_t B, int32_t K, const void* X, const void* u_ref,
+                         const void* obs, const int32_t* n_obs, void* u_out, int32_t* status_out, void* h_out,
+                         void* stream) {
+    int rc = sc::check_cbfqp(params, B, K, X, u_ref, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::cbfqp_launch(*params, (long long)B, (int)K, X, u_ref, obs, n_obs, u_out, status_out, h_out,
+                                    (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "cbfqp kernel launch");
+    return SC_OK;
+}
+
+int sc_cbfqp_solve_batch_host(const sc_cbfqp_params* params, int64_t B, int32_t K, const void* X,
+                              const void* u_ref, const void* obs, const int32_t* n_obs, void* u_out,
+                              int32_t* status_out, void* h_out, int device) {
+    int rc = sc::check_cbfqp(params, B, K, X, u_ref, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipSetDevice");
+    const size_t es = params->io_dtype == SC_DTYPE_F64 ? 8 : 4;
+    const size_t nX = (size_t)B * 4 * es, nU = (size_t)B * 2 * es;
+    const size_t nO = (params->obs_shared ? (size_t)K * 7 : (size_t)B * K * 7) * es;
+    const size_t nH = (size_t)B * K * es, nS = (size_t)B * 4, nN = n_obs ? (size_t)B * 4 : 0;
+    // one allocation, 256-byte aligned sections
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t oX = 0, oU = oX + up(nX), oO = oU + up(nU), oN = oO + up(nO), oUo = oN + up(nN),
+                 oS = oUo + up(nU), oH = oS + up(nS), total = oH + up(nH);
+    unsigned char* d = nullptr;
+    e = hipMalloc((void**)&d, total);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipMalloc");
+    hipStream_t s = nullptr;
+    rc = SC_OK;
+    do {
+        if ((e = hipMemcpyAsync(d + oX, X, nX, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oU, u_ref, nU, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if (n_obs && (e = hipMemcpyAsync(d + oN, n_obs, nN, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        e = sc::cbfqp_launch(*params, (long long)B, (int)K, d + oX, d + oU, d + oO,
+                             n_obs ? (const int*)(d + oN) : nullptr, d + oUo, (int*)(d + oS),
+                             h_out ? d + oH : nullptr, s);
+        if (e != hipSuccess) break;
+        if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (h_out && (e = hipMemcpyAsync(h_out, d + oH, nH, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        e = hipStreamSynchronize(s);
+    } while (0);
+    if (e != hipSuccess) rc = sc::fail_hip(e, "sc_cbfqp_solve_batch_host");
+    hipFree(d);
+    return rc;
+}
+
+}  // extern "C"

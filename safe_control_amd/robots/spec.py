@@ -1,0 +1,55 @@
+"""Host-side robot description consumed by the batched controllers.
+
+The reference keeps per-model numpy callbacks in robots/<model>.py and a
+dispatcher robots/robot.py:BaseRobot; on the batched path those callbacks run
+inside the HIP kernels (csrc/sc_models.hpp), selected by model id.  What stays
+on the host is the ``robot_spec`` dict and the three attributes the position
+controllers read from the robot object: ``X``, ``dt``, ``robot_radius``.
+A reference ``BaseRobot`` can be passed to CBFQP/MPCCBF directly; RobotHandle
+is the minimal stand-in when the reference package is not importable.
+"""
+import math
+
+import numpy as np
+
+from .._lib import MODEL_IDS
+
+
+def complete_robot_spec(robot_spec):
+    """Apply the defaults the reference's robot classes ``setdefault`` into robot_spec.
+
+    DynamicUnicycle2D: robots/dynamic_unicycle2D.py:34-40 ; KinematicBicycle2D
+    family: robots/kinematic_bicycle2D.py:42-53 ; radius: robots/robot.py:49.
+    Mutates and returns the dict, like the reference does.
+    """
+    model = robot_spec.setdefault("model", "DynamicUnicycle2D")
+    if model not in MODEL_IDS:
+        raise ValueError(f"model {model!r} is not supported by the batched engine (supported: {sorted(MODEL_IDS)})")
+    if model == "DynamicUnicycle2D":
+        robot_spec.setdefault("a_max", 0.5)
+        robot_spec.setdefault("w_max", 0.5)
+        robot_spec.setdefault("v_max", 1.0)
+        robot_spec.setdefault("radius", 0.25)
+    else:
+        robot_spec.setdefault("wheel_base", 0.4)
+        robot_spec.setdefault("body_width", 0.3)
+        robot_spec.setdefault("radius", 0.3)
+        robot_spec.setdefault("front_ax_dist", 0.2)
+        robot_spec.setdefault("rear_ax_dist", 0.2)
+        robot_spec.setdefault("v_max", 3.5)
+        robot_spec.setdefault("a_max", 5.0)
+        robot_spec.setdefault("delta_max", math.radians(32))
+        robot_spec.setdefault("beta_max", math.atan((robot_spec["rear_ax_dist"] / robot_spec["wheel_base"])
+                                                    * math.tan(robot_spec["delta_max"])))
+        robot_spec.setdefault("v_min", 0.2)
+    return robot_spec
+
+
+class RobotHandle:
+    """Minimal robot object: what CBFQP / MPCCBF read from ``robot`` (robots/robot.py:38-50)."""
+
+    def __init__(self, X0, robot_spec, dt=0.05):
+        self.robot_spec = complete_robot_spec(robot_spec)
+        self.X = np.asarray(X0, dtype=np.float64).reshape(-1, 1)
+        self.dt = float(dt)
+        self.robot_radius = float(self.robot_spec["radius"])

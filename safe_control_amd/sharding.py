@@ -1,0 +1,117 @@
+"""Agent-range sharding across the GPUs of one node (one process per GPU).
+
+Every agent's QP / NLP depends only on its own state, goal, previous input
+and obstacle rows (the reference's multi-robot example steps robots fully
+independently, examples/test_multi_robot.py:77-80), so the batch shards by
+contiguous agent ranges with NO collective on the solve path.  Collectives
+(RCCL on GPUs, gloo in the CPU tests) appear only at the edges: scattering
+inputs / gathering results when the host asks, the timing reduction of
+bench.py, the broadcast of a shared obstacle table and -- an extension with
+no reference counterpart -- the all-gather of agent states used when agents
+are each other's obstacles.
+"""
+import torch
+import torch.distributed as dist
+
+
+def agent_range(n_agents, world_size, rank):
+    """Contiguous range [lo, hi) owned by ``rank``; sizes differ by at most one."""
+    base, rem = divmod(int(n_agents), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(n_agents, world_size):
+    return [agent_range(n_agents, world_size, r)[1] - agent_range(n_agents, world_size, r)[0]
+            for r in range(world_size)]
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def scatter_agents(full, n_agents, src=0):
+    """Rank ``src`` holds ``full`` [n_agents, ...]; every rank gets its contiguous shard."""
+    ws, rank = world()
+    if ws == 1:
+        return full
+    sizes = shard_sizes(n_agents, ws)
+    meta = [None]
+    if rank == src:
+        meta = [(tuple(full.shape[1:]), full.dtype, full.device.type)]
+    dist.broadcast_object_list(meta, src=src)
+    tail, dtype, _ = meta[0]
+    dev = full.device if rank == src else (torch.device("cuda", torch.cuda.current_device())
+                                          if dist.get_backend() == "nccl" else torch.device("cpu"))
+    out = torch.empty((sizes[rank],) + tail, dtype=dtype, device=dev)
+    if rank == src:
+        chunks = list(torch.split(full.contiguous(), sizes, dim=0))
+        # dist.scatter needs equal sizes: send point-to-point instead
+        for r, ch in enumerate(chunks):
+            if r == src:
+                out.copy_(ch)
+            else:
+                dist.send(ch.contiguous(), dst=r)
+    else:
+        dist.recv(out, src=src)
+    return out
+
+
+def gather_agents(local, n_agents, dst=0):
+    """Inverse of scatter_agents: rank ``dst`` returns the [n_agents, ...] tensor, others None."""
+    ws, rank = world()
+    if ws == 1:
+        return local
+    sizes = shard_sizes(n_agents, ws)
+    if rank == dst:
+        parts = []
+        for r in range(ws):
+            if r == dst:
+                parts.append(local)
+            else:
+                buf = torch.empty((sizes[r],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+                dist.recv(buf, src=r)
+                parts.append(buf)
+        return torch.cat(parts, dim=0)
+    dist.send(local.contiguous(), dst=dst)
+    return None
+
+
+def broadcast_obstacle_table(table, src=0):
+    """Shared [K,7] obstacle table: one broadcast per step (K*7 values, latency-bound)."""
+    ws, _ = world()
+    if ws > 1:
+        dist.broadcast(table, src=src)
+    return table
+
+
+def all_gather_states(X_local, n_agents):
+    """Neighbour-state exchange (extension): every rank gets all agents' states [n_agents, nx].
+
+    One all-gather per control step; over xGMI this is latency-bound
+    (65 536 agents x 16 B = 1 MiB in total).  Shards may differ by one agent,
+    so the padded all_gather_into_tensor form is used and the padding dropped.
+    """
+    ws, rank = world()
+    if ws == 1:
+        return X_local
+    sizes = shard_sizes(n_agents, ws)
+    m = max(sizes)
+    pad = torch.zeros((m,) + tuple(X_local.shape[1:]), dtype=X_local.dtype, device=X_local.device)
+    pad[: X_local.shape[0]] = X_local
+    out = torch.empty((ws * m,) + tuple(X_local.shape[1:]), dtype=X_local.dtype, device=X_local.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * m: r * m + sizes[r]] for r in range(ws)], dim=0)
+
+
+def max_over_ranks(seconds, device=None):
+    """bench.py timing contract: the job time is the MAX over ranks."""
+    ws, _ = world()
+    if ws == 1:
+        return float(seconds)
+    t = torch.tensor([float(seconds)], dtype=torch.float64,
+                     device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,91 @@
+"""Seeded synthetic workloads for BASELINE.json's configurations.
+
+Vectorised numpy generation of agent states, goals, nominal inputs and
+obstacle tables.  This prepares *inputs* for tests and bench.py; it is not on
+the solve path.
+"""
+import math
+
+import numpy as np
+
+
+def wrap_angle(x):
+    """Python-% wrap into [-pi, pi) (robots/dynamic_unicycle2D.py:13-16)."""
+    return np.mod(x + np.pi, 2.0 * np.pi) - np.pi
+
+
+def nominal_input_du(X, goal, v_max=1.0, k_omega=2.0, k_a=1.0, k_v=1.0, d_min=0.05):
+    """Vectorised DynamicUnicycle2D.nominal_input (robots/dynamic_unicycle2D.py:80-104)."""
+    d = np.maximum(np.hypot(X[:, 0] - goal[:, 0], X[:, 1] - goal[:, 1]) - d_min, 0.0)
+    err = wrap_angle(np.arctan2(goal[:, 1] - X[:, 1], goal[:, 0] - X[:, 0]) - X[:, 2])
+    v = np.where(np.abs(err) > math.radians(90), 0.0, np.minimum(k_v * d * np.cos(err), v_max))
+    return np.stack([k_a * (v - X[:, 3]), k_omega * err], axis=1)
+
+
+def nominal_input_kb(X, goal, spec, k_theta=2.0, k_a=1.0, k_v=1.0, d_min=0.05):
+    """Vectorised KinematicBicycle2D.nominal_input with the gains BaseRobot forwards
+    (robots/kinematic_bicycle2D.py:125-147 via robots/robot.py:401-408)."""
+    d = np.maximum(np.hypot(X[:, 0] - goal[:, 0], X[:, 1] - goal[:, 1]) - d_min, 0.05)
+    err = wrap_angle(np.arctan2(goal[:, 1] - X[:, 1], goal[:, 0] - X[:, 0]) - X[:, 2])
+    delta = np.clip(k_theta * err, -spec["delta_max"], spec["delta_max"])
+    beta = np.arctan((spec["rear_ax_dist"] / spec["wheel_base"]) * np.tan(delta))
+    v = np.clip(k_v * d * np.maximum(0.0, np.cos(err)), spec["v_min"], spec["v_max"])
+    return np.stack([k_a * (v - X[:, 3]), beta], axis=1)
+
+
+def du_cbfqp_batch(B=4096, K=8, seed=0, radius=0.25, v_max=1.0):
+    """BASELINE config 2: B DynamicUnicycle2D agents, K circular obstacles each.
+
+    x,y ~ U(0,14); theta ~ U(-pi,pi); v ~ U(0,1); goal ~ U(0,14)^2; u_ref from the
+    nominal controller; obstacle k of agent i: r ~ U(.2,1), centre at polar offset
+    rho ~ U(r+R+.05, 4), phi ~ U(-pi,pi) from the agent; columns 3..6 zero (circle).
+    Returns float64 arrays X[B,4], goal[B,2], u_ref[B,2], obs[B,K,7].
+    """
+    rng = np.random.default_rng(seed)
+    X = np.empty((B, 4))
+    X[:, 0:2] = rng.uniform(0.0, 14.0, (B, 2))
+    X[:, 2] = rng.uniform(-np.pi, np.pi, B)
+    X[:, 3] = rng.uniform(0.0, 1.0, B)
+    goal = rng.uniform(0.0, 14.0, (B, 2))
+    r = rng.uniform(0.2, 1.0, (B, K))
+    rho = rng.uniform(0.0, 1.0, (B, K)) * (4.0 - (r + radius + 0.05)) + (r + radius + 0.05)
+    phi = rng.uniform(-np.pi, np.pi, (B, K))
+    obs = np.zeros((B, K, 7))
+    obs[:, :, 0] = X[:, None, 0] + rho * np.cos(phi)
+    obs[:, :, 1] = X[:, None, 1] + rho * np.sin(phi)
+    obs[:, :, 2] = r
+    u_ref = nominal_input_du(X, goal, v_max=v_max)
+    return X, goal, u_ref, obs
+
+
+def kb_c3bf_batch(B=16384, K=16, seed=0, spec=None, shared_table=False):
+    """BASELINE config 4: KinematicBicycle2D (C3BF/DPCBF) agents with K moving circles.
+
+    v ~ U(.2,3.5); obstacles r=.5, vx,vy ~ U(-.5,.5), placed at polar offset
+    rho ~ U(r+R+.3, 8) from the agent (or uniformly in the 14x14 field when one
+    table is shared by all agents).
+    """
+    from .robots.spec import complete_robot_spec
+    spec = complete_robot_spec(dict(spec or {"model": "KinematicBicycle2D_C3BF"}))
+    rng = np.random.default_rng(seed)
+    X = np.empty((B, 4))
+    X[:, 0:2] = rng.uniform(0.0, 14.0, (B, 2))
+    X[:, 2] = rng.uniform(-np.pi, np.pi, B)
+    X[:, 3] = rng.uniform(0.2, 3.5, B)
+    goal = rng.uniform(0.0, 14.0, (B, 2))
+    R = spec["radius"]
+    if shared_table:
+        obs = np.zeros((K, 7))
+        obs[:, 0:2] = rng.uniform(0.0, 14.0, (K, 2))
+        obs[:, 2] = 0.5
+        obs[:, 3:5] = rng.uniform(-0.5, 0.5, (K, 2))
+    else:
+        rho = rng.uniform(0.5 + R + 0.3, 8.0, (B, K))
+        phi = rng.uniform(-np.pi, np.pi, (B, K))
+        obs = np.zeros((B, K, 7))
+        obs[:, :, 0] = X[:, None, 0] + rho * np.cos(phi)
+        obs[:, :, 1] = X[:, None, 1] + rho * np.sin(phi)
+        obs[:, :, 2] = 0.5
+        obs[:, :, 3:5] = rng.uniform(-0.5, 0.5, (B, K, 2))
+    u_ref = nominal_input_kb(X, goal, spec)
+    return X, goal, u_ref, obs

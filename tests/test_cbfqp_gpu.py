@@ -1,0 +1,307 @@
+"""GPU parity tests for the fused CBF-QP kernels (run on the MI355X box: pytest -m gpu).
+
+Everything goes through the C-ABI (ctypes -> libsafe_control_hip.so); the
+oracle (oracle/) is only the checker.
+
+Stated tolerances (DESIGN.md "Parity"):
+  * f64 arithmetic (f64 or f32 storage): |u - u_oracle| <= 1e-7 * max(1, |u|_inf) on f64
+    storage, one f32 ulp (2e-6 relative) on f32 storage; h likewise; status equal except for
+    problems whose feasibility margin is below 1e-6 (set aside and counted).
+  * f32 arithmetic: |u - u_oracle| <= 1e-4 * max(1, bound) per SURVEY 8c on >= 99.5 % of the
+    optimal cases, h within 1e-5 * max(1, |h|); status equal except margin < 1e-4.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import c_oracle, cbf_qp as ocbf, qp as oqp, robots as R  # noqa: E402
+import safe_control_amd as sca  # noqa: E402
+from safe_control_amd import workloads as W  # noqa: E402
+
+DEV = "cuda:0"
+
+MODEL_NAME = {R.MODEL_DU: "DynamicUnicycle2D", R.MODEL_KB: "KinematicBicycle2D",
+              R.MODEL_KB_C3BF: "KinematicBicycle2D_C3BF", R.MODEL_KB_DPCBF: "KinematicBicycle2D_DPCBF"}
+
+
+def du_spec():
+    return {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}
+
+
+def kb_spec(name):
+    return {"model": name, "a_max": 5.0, "radius": 0.3}
+
+
+def oracle_spec(model, spec):
+    s = R.default_spec(model)
+    s.update({k: v for k, v in spec.items() if k != "model"})
+    return s
+
+
+def margins(model, X, obs, spec, cbf_param, n_obs=None, cbf_mode="cbf"):
+    """Feasibility margin of every problem (oracle rows + Chebyshev LP)."""
+    out = np.empty(X.shape[0])
+    lo, hi = ocbf.input_bounds(model, spec)
+    Gb, cb = oqp.box_rows(lo, hi)
+    K = obs.shape[-2]
+    for i in range(X.shape[0]):
+        o = obs if obs.ndim == 2 else obs[i]
+        k = K if n_obs is None else int(n_obs[i])
+        A, b, _ = ocbf.assemble_rows(model, X[i], list(o[:k]), spec, cbf_param, K, 0.05, cbf_mode)
+        out[i] = oqp.feasibility_margin(np.vstack([A, Gb]), np.concatenate([b, cb]))
+    return out
+
+
+def run_gpu(spec, X, u_ref, obs, io="f32", comp="f64", n_obs=None):
+    ctl = sca.BatchedCBFQP(dict(spec), dt=0.05, io_dtype=io, compute_dtype=comp)
+    td = ctl.torch_dtype
+    tX = torch.tensor(X, dtype=td, device=DEV)
+    tu = torch.tensor(u_ref, dtype=td, device=DEV)
+    to = torch.tensor(obs, dtype=td, device=DEV)
+    tn = None if n_obs is None else torch.tensor(n_obs, dtype=torch.int32, device=DEV)
+    u, st, h = ctl.solve(tX, tu, to, tn)
+    torch.cuda.synchronize()
+    # what the kernel actually saw (storage-rounded inputs), for the oracle
+    seen = (tX.double().cpu().numpy(), tu.double().cpu().numpy(), to.double().cpu().numpy())
+    return u.double().cpu().numpy(), st.cpu().numpy(), h.double().cpu().numpy(), seen
+
+
+def compare(model, spec, X, u_ref, obs, io, comp, n_obs=None, cbf_mode="cbf", frac_ok=1.0):
+    ug, sg, hg, (Xs, us, os_) = run_gpu(spec, X, u_ref, obs, io, comp, n_obs)
+    ospec = oracle_spec(model, spec)
+    cp = ocbf.default_cbf_param(model)
+    uo, so, ho = c_oracle.cbfqp_batch(model, Xs, us, os_, ospec, cp, 0.05, cbf_mode, n_obs)
+    mtol = 1e-6 if comp == "f64" else 1e-4
+    diff = np.nonzero(sg != so)[0]
+    if len(diff):
+        mg = margins(model, Xs[diff], os_ if os_.ndim == 2 else os_[diff], ospec, cp,
+                     None if n_obs is None else np.asarray(n_obs)[diff], cbf_mode)
+        assert np.all(np.abs(mg) < mtol), f"status mismatch away from the margin: {diff[:8]}, margins {mg[:8]}"
+    assert len(diff) <= max(2, 0.01 * len(sg))
+    ok = (sg == 0) & (so == 0)
+    assert np.all(np.isnan(ug[sg != 0]))
+    bound = max(1.0, float(np.max(np.abs(ocbf.input_bounds(model, ospec)[1]))))
+    err = np.max(np.abs(ug[ok] - uo[ok]), axis=1)
+    if comp == "f64":
+        tol_u = (1e-7 if io == "f64" else 2e-6) * bound
+        tol_h = (1e-9 if io == "f64" else 2e-6)
+    else:
+        tol_u, tol_h = 1e-4 * bound, 1e-5
+    good = err <= tol_u
+    assert good.mean() >= frac_ok, f"u*: {100 * good.mean():.3f}% within {tol_u}, worst {err.max()}"
+    herr = np.abs(hg - ho) / np.maximum(1.0, np.abs(ho))
+    assert np.all(herr <= tol_h), f"h: worst {herr.max()}"
+    return dict(n=len(sg), infeasible=int((so != 0).sum()), excluded=len(diff), worst_u=float(err.max()))
+
+
+# ------------------------------------------------------------------ config 2
+@pytest.mark.parametrize("io,comp,frac", [("f64", "f64", 1.0), ("f32", "f64", 1.0), ("f32", "f32", 0.995)])
+def test_config2_du_4096x8(io, comp, frac):
+    """BASELINE config 2: 4096 DynamicUnicycle2D agents, 8 circles each, seed 0."""
+    X, goal, u_ref, obs = W.du_cbfqp_batch(4096, 8, seed=0)
+    r = compare(R.MODEL_DU, du_spec(), X, u_ref, obs, io, comp, frac_ok=frac)
+    assert r["infeasible"] > 0          # the seeded batch contains infeasible agents: they must be reported
+
+
+@pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 127, 1000])
+def test_ragged_batch_sizes(B):
+    X, goal, u_ref, obs = W.du_cbfqp_batch(B, 8, seed=B)
+    compare(R.MODEL_DU, du_spec(), X, u_ref, obs, "f32", "f64")
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 5, 7, 9, 10, 12, 13, 16, 17, 24, 25, 32])
+def test_every_row_count(K):
+    """K hits every kernel instantiation, both the K == KMAX wide-read path and the generic one."""
+    X, goal, u_ref, obs = W.du_cbfqp_batch(333, K, seed=100 + K)
+    compare(R.MODEL_DU, du_spec(), X, u_ref, obs, "f32", "f64")
+    compare(R.MODEL_DU, du_spec(), X, u_ref, obs, "f64", "f64")
+
+
+def test_ragged_obstacle_counts():
+    """n_obs[i] < K: unused rows are the reference's zero rows (cbf_qp.py:110-111)."""
+    X, goal, u_ref, obs = W.du_cbfqp_batch(500, 10, seed=5)
+    rng = np.random.default_rng(5)
+    n_obs = rng.integers(0, 11, 500).astype(np.int32)
+    obs2 = obs.copy()
+    for i in range(500):
+        obs2[i, n_obs[i]:] = 1e30        # garbage beyond n_obs must be ignored
+    compare(R.MODEL_DU, du_spec(), X, u_ref, obs2, "f32", "f64", n_obs=n_obs)
+    ug, sg, hg, _ = run_gpu(du_spec(), X, u_ref, obs2, "f32", "f64", n_obs)
+    for i in range(500):
+        assert np.all(hg[i, n_obs[i]:] == 0)
+
+
+def test_shared_obstacle_table():
+    X, goal, u_ref, _ = W.du_cbfqp_batch(777, 8, seed=9)
+    rng = np.random.default_rng(9)
+    table = np.zeros((6, 7))
+    table[:, 0:2] = rng.uniform(0, 14, (6, 2)); table[:, 2] = rng.uniform(0.2, 0.6, 6)
+    compare(R.MODEL_DU, du_spec(), X, u_ref, table, "f32", "f64")
+
+
+def test_superellipsoid_and_mixed_obstacles():
+    rng = np.random.default_rng(11)
+    B, K = 600, 6
+    X, goal, u_ref, obs = W.du_cbfqp_batch(B, K, seed=11)
+    for i in range(B):
+        for k in range(K):
+            if rng.random() < 0.5:
+                a, b = rng.uniform(0.3, 1.2, 2)
+                rho = rng.uniform(max(a, b) + 0.55, 4.5); phi = rng.uniform(-np.pi, np.pi)
+                obs[i, k] = [X[i, 0] + rho * np.cos(phi), X[i, 1] + rho * np.sin(phi), a, b,
+                             float(rng.choice([4, 6, 10])), rng.uniform(-np.pi, np.pi), 1.0]
+    # superellipsoid barrier values reach 1e4..1e8: compare u with f64 arithmetic only
+    compare(R.MODEL_DU, du_spec(), X, u_ref, obs, "f64", "f64")
+
+
+def test_hard_mode():
+    X, goal, u_ref, obs = W.du_cbfqp_batch(400, 8, seed=21)
+    spec = du_spec(); spec["cbf_mode"] = "hard"
+    compare(R.MODEL_DU, spec, X, u_ref, obs, "f64", "f64", cbf_mode="hard")
+
+
+@pytest.mark.parametrize("model", [R.MODEL_KB, R.MODEL_KB_C3BF, R.MODEL_KB_DPCBF])
+@pytest.mark.parametrize("K", [10, 16])
+def test_kinematic_bicycle_family(model, K):
+    """Config-4 family: moving circles, state-dependent g, rel-deg-1 C3BF / DPCBF rows."""
+    spec = kb_spec(MODEL_NAME[model])
+    X, goal, u_ref, obs = W.kb_c3bf_batch(1024, K, seed=31, spec=spec)
+    compare(model, spec, X, u_ref, obs, "f64", "f64")
+    compare(model, spec, X, u_ref, obs, "f32", "f64")
+
+
+def test_bad_obstacle_flag_and_nan_inputs():
+    X, goal, u_ref, obs = W.du_cbfqp_batch(130, 8, seed=3)
+    obs[5, 2, 6] = 2.0                     # invalid flag
+    X[7, 0] = np.nan                       # NaN state -> non-finite rows -> not optimal
+    u_ref[9, 1] = np.inf
+    ug, sg, hg, _ = run_gpu(du_spec(), X, u_ref, obs, "f32", "f64")
+    assert sg[5] == 3 and np.all(np.isnan(ug[5]))
+    assert sg[7] == 1 and sg[9] == 1
+    other = np.ones(130, bool); other[[5, 7, 9]] = False
+    uo, so, ho = c_oracle.cbfqp_batch(R.MODEL_DU, X[other].astype(np.float32).astype(np.float64),
+                                      u_ref[other].astype(np.float32).astype(np.float64),
+                                      obs[other].astype(np.float32).astype(np.float64),
+                                      oracle_spec(R.MODEL_DU, du_spec()), ocbf.default_cbf_param(R.MODEL_DU))
+    assert np.array_equal(sg[other], so)
+
+
+# ------------------------------------------------------------------ golden fixtures
+def test_golden_cases_through_dropin_class(golden_dir):
+    """tests/golden/cbfqp_cases.npz through the reference-shaped CBFQP class (host-pointer C-ABI)."""
+    g = np.load(os.path.join(golden_dir, "cbfqp_cases.npz"))
+    groups = {"du_circle": ("DynamicUnicycle2D", None), "du_circle_hard": ("DynamicUnicycle2D", "hard"),
+              "du_superellipsoid": ("DynamicUnicycle2D", None), "du_mixed_trunc": ("DynamicUnicycle2D", None),
+              "du_overlap": ("DynamicUnicycle2D", None), "kb_circle": ("KinematicBicycle2D", None),
+              "c3bf": ("KinematicBicycle2D_C3BF", None), "c3bf_k16": ("KinematicBicycle2D_C3BF", None),
+              "dpcbf": ("KinematicBicycle2D_DPCBF", None)}
+    for gname, (model, mode) in groups.items():
+        num_obs = int(g[f"{gname}/meta"][0])
+        spec = du_spec() if model == "DynamicUnicycle2D" else kb_spec(model)
+        if mode:
+            spec["cbf_mode"] = mode
+        robot = sca.RobotHandle(np.zeros(4), spec, dt=0.05)
+        ctl = sca.CBFQP(robot, spec, num_obs=num_obs)
+        Xs, us, obs, ks = g[f"{gname}/X"], g[f"{gname}/u_ref"], g[f"{gname}/obs"], g[f"{gname}/k"]
+        ustar, st = g[f"{gname}/u_star_oracle"], g[f"{gname}/status_oracle"]
+        for i in range(len(Xs)):
+            robot.X = Xs[i].reshape(-1, 1)
+            u = ctl.solve_control_problem(robot.X, {"u_ref": us[i].reshape(2, 1)}, list(obs[i][: int(ks[i])]))
+            if st[i] == 0:
+                assert ctl.status == "optimal", (gname, i)
+                np.testing.assert_allclose(u.reshape(-1), ustar[i], rtol=1e-7, atol=1e-7)
+                assert u.shape == (2, 1)
+            else:
+                assert ctl.status != "optimal" and u is None, (gname, i)
+    # obs_list None -> u_ref unclipped
+    robot = sca.RobotHandle(np.zeros(4), du_spec())
+    ctl = sca.CBFQP(robot, du_spec(), num_obs=8)
+    u = ctl.solve_control_problem(robot.X, {"u_ref": g["none/u_ref"].reshape(2, 1)}, None)
+    np.testing.assert_array_equal(u.reshape(-1), g["none/u"])
+    assert ctl.status == "optimal"
+
+
+# ------------------------------------------------------------------ full-size properties
+def _rows_du_circle(X, obs, R_, a1=1.5, a2=1.5):
+    """fp64 torch restatement of the DU circle rows, only to verify constraint satisfaction at scale."""
+    x, y, th, v = X[:, 0:1], X[:, 1:2], X[:, 2:3], X[:, 3:4]
+    c, s = torch.cos(th), torch.sin(th)
+    ex, ey = x - obs[:, :, 0], y - obs[:, :, 1]
+    d = obs[:, :, 2] + R_
+    h = ex * ex + ey * ey - 1.01 * d * d
+    hdot = 2 * (ex * v * c + ey * v * s)
+    n0 = 2 * (ex * c + ey * s)
+    n1 = 2 * v * (-ex * s + ey * c)
+    b = 2 * v * v * (c * c + s * s) + (a1 + a2) * hdot + a1 * a2 * h
+    return n0, n1, b
+
+
+@pytest.mark.parametrize("comp", ["f64", "f32"])
+def test_full_size_properties(comp):
+    """B = 2^20 agents x 8 obstacles: feasibility of every reported optimum, idempotence,
+    obstacle-order invariance, batch-position independence."""
+    B, K = 1 << 20, 8
+    X, goal, u_ref, obs = W.du_cbfqp_batch(B, K, seed=1)
+    ctl = sca.BatchedCBFQP(du_spec(), io_dtype="f32", compute_dtype=comp)
+    tX = torch.tensor(X, dtype=torch.float32, device=DEV)
+    tu = torch.tensor(u_ref, dtype=torch.float32, device=DEV)
+    to = torch.tensor(obs, dtype=torch.float32, device=DEV)
+    u, st, h = ctl.solve(tX, tu, to)
+    ok = st == 0
+    assert 0.90 < ok.double().mean().item() < 1.0
+    # (1) every optimum satisfies box and CBF rows
+    n0, n1, b = _rows_du_circle(tX.double(), to.double(), 0.25)
+    ud = u.double()
+    slack = n0 * ud[:, 0:1] + n1 * ud[:, 1:2] + b
+    scale = 1 + n0.abs() * ud[:, 0:1].abs() + n1.abs() * ud[:, 1:2].abs() + b.abs()
+    tol = 5e-6 if comp == "f64" else 2e-4
+    assert (slack[ok] >= -tol * scale[ok]).all()
+    assert (ud[ok, 0].abs() <= 1.0 + 1e-6).all() and (ud[ok, 1].abs() <= 0.5 + 1e-6).all()
+    # h output equals the barrier value
+    hd = (tX[:, 0:1].double() - to[:, :, 0].double()) ** 2 + (tX[:, 1:2].double() - to[:, :, 1].double()) ** 2 \
+        - 1.01 * (to[:, :, 2].double() + 0.25) ** 2
+    assert ((h.double() - hd).abs() <= 2e-6 * (1 + hd.abs())).all()
+    # (2) projection is idempotent: u_ref := u* gives u* back
+    u2, st2, _ = ctl.solve(tX, torch.where(ok[:, None], u, tu), to)
+    assert (st2[ok] == 0).all()
+    assert ((u2[ok] - u[ok]).abs().max().item()) <= (1e-6 if comp == "f64" else 5e-4)
+    # (3) the answer does not depend on the obstacle order (the kernel walks rows incrementally)
+    perm = torch.randperm(K, device=DEV)
+    u3, st3, _ = ctl.solve(tX, tu, to[:, perm].contiguous())
+    same = (st3 == st)
+    assert same.double().mean().item() > 0.9999
+    both = ok & (st3 == 0)
+    d3 = (u3[both] - u[both]).abs().max(dim=1).values
+    assert (d3 <= (1e-6 if comp == "f64" else 1e-3)).double().mean().item() >= (1.0 if comp == "f64" else 0.999)
+    # (4) an agent's result does not depend on where it sits in the batch
+    u4, st4, _ = ctl.solve(tX[12345:12345 + 4099].contiguous(), tu[12345:12345 + 4099].contiguous(),
+                           to[12345:12345 + 4099].contiguous())
+    assert torch.equal(st4, st[12345:12345 + 4099])
+    assert torch.equal(torch.nan_to_num(u4, nan=7.0), torch.nan_to_num(u[12345:12345 + 4099], nan=7.0))
+    # oracle on a strided sample of the big batch
+    idx = np.arange(0, B, 509)
+    uo, so, ho = c_oracle.cbfqp_batch(R.MODEL_DU, tX[idx].double().cpu().numpy(), tu[idx].double().cpu().numpy(),
+                                      to[idx].double().cpu().numpy(), oracle_spec(R.MODEL_DU, du_spec()),
+                                      ocbf.default_cbf_param(R.MODEL_DU))
+    sg = st[idx].cpu().numpy(); ug = u[idx].double().cpu().numpy()
+    agree = sg == so
+    assert agree.mean() > 0.998
+    okk = agree & (so == 0)
+    e = np.abs(ug[okk] - uo[okk]).max(axis=1)
+    assert np.mean(e <= (2e-6 if comp == "f64" else 1e-4)) >= (1.0 if comp == "f64" else 0.995)
+
+
+def test_argument_errors():
+    ctl = sca.BatchedCBFQP(du_spec())
+    tX = torch.zeros((4, 4), device=DEV); tu = torch.zeros((4, 2), device=DEV)
+    with pytest.raises(sca.HipLibraryError):
+        ctl.solve(tX, tu, torch.zeros((4, 40, 7), device=DEV))     # K above SC_CBFQP_MAX_OBS
+    with pytest.raises(ValueError):
+        ctl.solve(tX.cpu(), tu, torch.zeros((4, 8, 7), device=DEV))
+    with pytest.raises(ValueError):
+        sca.BatchedCBFQP({"model": "Quad3D"})

@@ -1,0 +1,79 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/safe_control_amd.h declares.
+
+No compute calls (there is no GPU here); argument validation happens before any HIP call,
+so error paths can be exercised.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from safe_control_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "safe_control_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert header_functions() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in header_functions():
+        assert hasattr(lib, name), name
+    assert lib.sc_version() == 1
+
+
+def test_params_struct_layout_matches_header():
+    # 6 x int32 + 9 x double, no padding surprises
+    assert C.sizeof(_lib.CbfQpParams) == 6 * 4 + 9 * 8
+    assert _lib.CbfQpParams.robot_radius.offset == 24
+    assert _lib.CbfQpParams.rear_ax_dist.offset == 24 + 8 * 8
+
+
+def test_argument_validation_without_gpu():
+    lib = _lib.load()
+    p = _lib.CbfQpParams()
+    p.model_id, p.io_dtype, p.compute_dtype, p.dt = 0, 0, 1, 0.05
+    one = np.zeros(64)
+    ptr = one.ctypes.data
+    assert lib.sc_cbfqp_solve_batch(None, 1, 8, ptr, ptr, ptr, None, ptr, ptr, None, None) == 1
+    assert lib.sc_cbfqp_solve_batch(C.byref(p), 1, 0, ptr, ptr, ptr, None, ptr, ptr, None, None) == 1
+    assert lib.sc_cbfqp_solve_batch(C.byref(p), 1, 33, ptr, ptr, ptr, None, ptr, ptr, None, None) == 2
+    assert b"SC_CBFQP_MAX_OBS" in lib.sc_last_error()
+    assert lib.sc_cbfqp_solve_batch(C.byref(p), 1, 8, None, ptr, ptr, None, ptr, ptr, None, None) == 1
+    p.model_id = 9
+    assert lib.sc_cbfqp_solve_batch(C.byref(p), 1, 8, ptr, ptr, ptr, None, ptr, ptr, None, None) == 1
+    p.model_id, p.io_dtype, p.compute_dtype = 0, 1, 0
+    assert lib.sc_cbfqp_solve_batch(C.byref(p), 1, 8, ptr, ptr, ptr, None, ptr, ptr, None, None) == 2
+    p.model_id, p.io_dtype, p.compute_dtype = 2, 0, 1          # KB family needs rear_ax_dist
+    assert lib.sc_cbfqp_solve_batch(C.byref(p), 1, 8, ptr, ptr, ptr, None, ptr, ptr, None, None) == 1
+    # B == 0 is a no-op
+    p.model_id = 0
+    assert lib.sc_cbfqp_solve_batch(C.byref(p), 0, 8, None, None, None, None, None, None, None, None) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not reference the oracle (no CPU fallback)."""
+    pkg = os.path.join(ROOT, "safe_control_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "liboracle" not in txt, f

@@ -1,0 +1,71 @@
+"""CPU tests: the C restatement (oracle/c) against the numpy oracle and the golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, cbf_qp, robots as R
+from safe_control_amd import workloads as W
+
+
+def spec_for(model):
+    s = R.default_spec(model)
+    if model == R.MODEL_DU:
+        s.update(a_max=1.0, w_max=0.5, radius=0.25)
+    else:
+        s.update(a_max=5.0, radius=0.3)
+    return s
+
+
+GROUPS = {"du_circle": (R.MODEL_DU, "cbf"), "du_circle_hard": (R.MODEL_DU, "hard"),
+          "du_superellipsoid": (R.MODEL_DU, "cbf"), "du_mixed_trunc": (R.MODEL_DU, "cbf"),
+          "du_overlap": (R.MODEL_DU, "cbf"), "kb_circle": (R.MODEL_KB, "cbf"), "c3bf": (R.MODEL_KB_C3BF, "cbf"),
+          "c3bf_k16": (R.MODEL_KB_C3BF, "cbf"), "dpcbf": (R.MODEL_KB_DPCBF, "cbf")}
+
+
+@pytest.mark.parametrize("gname", list(GROUPS))
+def test_c_oracle_on_golden_cases(golden_dir, gname):
+    g = np.load(os.path.join(golden_dir, "cbfqp_cases.npz"))
+    model, mode = GROUPS[gname]
+    num_obs = int(g[f"{gname}/meta"][0])
+    X, ur, obs, ks = g[f"{gname}/X"], g[f"{gname}/u_ref"], g[f"{gname}/obs"], g[f"{gname}/k"]
+    n = len(X)
+    o = np.zeros((n, num_obs, 7))
+    kk = np.minimum(ks, num_obs).astype(np.int32)
+    for i in range(n):
+        o[i, : kk[i]] = obs[i, : kk[i]]
+    u, st, h = c_oracle.cbfqp_batch(model, X, ur, o, spec_for(model), cbf_qp.default_cbf_param(model), 0.05, mode, kk)
+    assert np.array_equal(st, g[f"{gname}/status_oracle"])
+    ok = st == 0
+    np.testing.assert_allclose(u[ok], g[f"{gname}/u_star_oracle"][ok], rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize("model,K", [(R.MODEL_DU, 8), (R.MODEL_KB, 5), (R.MODEL_KB_C3BF, 16), (R.MODEL_KB_DPCBF, 10)])
+def test_c_oracle_equals_numpy_oracle(model, K):
+    spec = spec_for(model)
+    if model == R.MODEL_DU:
+        X, goal, ur, obs = W.du_cbfqp_batch(300, K, seed=4)
+    else:
+        X, goal, ur, obs = W.kb_c3bf_batch(300, K, seed=4)
+    cp = cbf_qp.default_cbf_param(model)
+    u1, s1, h1 = cbf_qp.solve_batch(model, X, ur, obs, spec, cp)
+    u2, s2, h2 = c_oracle.cbfqp_batch(model, X, ur, obs, spec, cp, n_threads=2)
+    assert np.array_equal(s1, s2)
+    ok = s1 == 0
+    np.testing.assert_allclose(u1[ok], u2[ok], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(h1, h2, rtol=1e-10, atol=1e-10)
+
+
+def test_workload_nominal_inputs_match_oracle():
+    X, goal, ur, obs = W.du_cbfqp_batch(200, 8, seed=0)
+    spec = spec_for(R.MODEL_DU)
+    for i in range(200):
+        np.testing.assert_allclose(R.nominal_input(R.MODEL_DU, X[i], goal[i], spec), ur[i], rtol=1e-12, atol=1e-12)
+    X, goal, ur, obs = W.kb_c3bf_batch(200, 4, seed=0)
+    spec = spec_for(R.MODEL_KB_C3BF)
+    for i in range(200):
+        np.testing.assert_allclose(R.nominal_input(R.MODEL_KB_C3BF, X[i], goal[i], spec), ur[i], rtol=1e-12, atol=1e-12)
+    # every generated obstacle starts outside the inflated radius (h > 0)
+    X, goal, ur, obs = W.du_cbfqp_batch(1000, 8, seed=0)
+    d = np.hypot(obs[:, :, 0] - X[:, None, 0], obs[:, :, 1] - X[:, None, 1])
+    assert np.all(d ** 2 - 1.01 * (obs[:, :, 2] + 0.25) ** 2 > 0)
