@@ -54,9 +54,13 @@ def cpu_baseline(X, u_ref, obs, seconds):
     spec = R.default_spec(R.MODEL_DU)
     spec.update(a_max=1.0, w_max=0.5, radius=0.25)
     cp = ocbf.default_cbf_param(R.MODEL_DU)
-    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, 64, X.shape[0] // 64))           # >= 64 agents per thread
     out = {}
-    for label, nt, budget in (("all_cores", threads, seconds * 0.7), ("one_core", 1, seconds * 0.3)):
+    for label, nt, budget in (("all_cores", threads, seconds * 0.6), ("one_core", 1, seconds * 0.4)):
         c_oracle.cbfqp_batch(R.MODEL_DU, X, u_ref, obs, spec, cp, n_threads=nt)      # warm
         n, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < budget:
@@ -64,11 +68,13 @@ def cpu_baseline(X, u_ref, obs, seconds):
             n += 1
         dt = time.perf_counter() - t0
         out[label] = (n * X.shape[0] / dt, nt, n)
-    v, nt, n = out["all_cores"]
+    best = "all_cores" if out["all_cores"][0] >= out["one_core"][0] else "one_core"
+    v, nt, n = out[best]
     return {"value": v, "unit": "solves/s", "cores": nt, "kind": "port",
             "sample": f"{n} passes over the same {X.shape[0]}-agent x {obs.shape[1]}-obstacle batch, "
                       f"oracle/c/cbfqp_oracle.c (float64, exact active-set enumeration), OpenMP {nt} threads",
-            "one_core_value": out["one_core"][0]}
+            "one_core_value": out["one_core"][0], "all_cores_value": out["all_cores"][0],
+            "all_cores_threads": out["all_cores"][1]}
 
 
 def main():

@@ -39,8 +39,125 @@ __device__ __forceinline__ void wave_dma16(const unsigned char* __restrict__ src
     }
 }
 
-// KMAX > 0: rows in registers, loops unrolled to KMAX (K <= KMAX <= 8).
-// KMAX == 0: rows in LDS, run-time loops (any K up to SC_CBFQP_MAX_OBS).
+// ======================================================================================
+// K <= 8: register kernel.  No LDS at all: each lane pulls its own agent's K x 7 obstacle
+// values straight into VGPRs with 16-byte loads (the block is contiguous and 16-byte aligned
+// in the reference's [B,K,7] layout; every byte of every cache line is consumed by the lanes
+// that touch it, the 8 partial touches of a line merge in the vector L1), builds the rows in
+// registers with the row loop unrolled, and runs the unrolled walk.  With no LDS footprint the
+// occupancy is set by VGPRs only, which is what hides the HBM latency of a pure streaming pass.
+template <typename TIO> struct vec4io;
+template <> struct vec4io<float> { using type = float4; static constexpr int N = 4; };
+template <> struct vec4io<double> { using type = double2; static constexpr int N = 2; };
+
+template <typename TIO, typename TC, int KMAX, int MODEL>
+__global__ __launch_bounds__(256) void cbfqp_reg_kernel(const sc_cbfqp_params p, const long long B, const int K,
+                                                        const TIO* __restrict__ X, const TIO* __restrict__ u_ref,
+                                                        const TIO* __restrict__ obs, const int* __restrict__ n_obs,
+                                                        TIO* __restrict__ u_out, int* __restrict__ status_out,
+                                                        TIO* __restrict__ h_out) {
+    const long long agent = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = agent < B;
+    const long long ag_i = active ? agent : 0;           // inactive lanes compute on agent 0, store nothing
+    using V2 = typename vec2<TIO>::type;
+    using V4 = typename vec4io<TIO>::type;
+    constexpr int VN = vec4io<TIO>::N;
+
+    // ---- loads: obstacles first (longest latency), then state ---------------------------
+    TIO flat[KMAX * 7];
+    const TIO* src = obs + (p.obs_shared ? 0 : (size_t)ag_i * K * 7);
+    if (K == KMAX && ((KMAX * 7) % VN == 0) && ((reinterpret_cast<uintptr_t>(obs) & 15u) == 0) &&
+        ((KMAX * 7 * sizeof(TIO)) % 16 == 0)) {
+        const V4* s4 = reinterpret_cast<const V4*>(src);
+#pragma unroll
+        for (int e = 0; e < KMAX * 7 / VN; ++e) {
+            const V4 q = s4[e];
+            if constexpr (VN == 4) {
+                flat[e * 4 + 0] = q.x; flat[e * 4 + 1] = q.y; flat[e * 4 + 2] = q.z; flat[e * 4 + 3] = q.w;
+            } else {
+                flat[e * 2 + 0] = q.x; flat[e * 2 + 1] = q.y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < KMAX; ++r) {
+#pragma unroll
+            for (int f = 0; f < 7; ++f) flat[r * 7 + f] = (r < K) ? src[r * 7 + f] : TIO(0);
+        }
+    }
+    const V2* Xv = reinterpret_cast<const V2*>(X) + ag_i * 2;
+    const V2 xa = Xv[0], xb = Xv[1];
+    const V2 ur = reinterpret_cast<const V2*>(u_ref)[ag_i];
+    int nk = K;
+    if (n_obs) {
+        nk = n_obs[ag_i];
+        nk = nk < 0 ? 0 : (nk > K ? K : nk);
+    }
+    const TC ur0 = TC(ur.x), ur1 = TC(ur.y);
+    const CbfConsts<TC> k = make_consts<TC>(p);
+    const Agent<TC> ag = make_agent<TC>(TC(xa.x), TC(xa.y), TC(xb.x), TC(xb.y));
+
+    // ---- rows: agent_barrier + cbf_qp.py:155-183, unrolled, in registers ------------------
+    TC n0[KMAX], n1[KMAX], c[KMAX];
+    TIO hv[KMAX];
+    bool bad_obs = false;
+    TC poison = TC(0);
+#pragma unroll
+    for (int r = 0; r < KMAX; ++r) {
+        TC o[7];
+#pragma unroll
+        for (int f = 0; f < 7; ++f) o[f] = TC(flat[r * 7 + f]);
+        TC h, a0, a1, cc;
+        const bool ok = cbf_row<TC, MODEL, true>(ag, o, k, a0, a1, cc, h);
+        const bool used = r < nk;                   // nk <= K <= KMAX
+        bad_obs |= used && !ok;
+        a0 = used ? a0 : TC(0); a1 = used ? a1 : TC(0); cc = used ? cc : TC(0);
+        normalise_row(a0, a1, cc, poison);
+        n0[r] = a0; n1[r] = a1; c[r] = cc;
+        hv[r] = used ? TIO(h) : TIO(0);
+    }
+
+    // ---- solve + outputs --------------------------------------------------------------------
+    TC u0, u1;
+    int st = qp2_solve<TC, KMAX>(n0, n1, c, K, ur0, ur1, poison, k, u0, u1);
+    if (bad_obs) st = SC_STATUS_BAD_OBSTACLE;
+    if (st != SC_STATUS_OPTIMAL) { u0 = num<TC>::nan(); u1 = num<TC>::nan(); }
+    if (active) {
+        V2 uo; uo.x = TIO(u0); uo.y = TIO(u1);
+        reinterpret_cast<V2*>(u_out)[agent] = uo;
+        status_out[agent] = st;
+        if (h_out) {
+            TIO* hp = h_out + agent * K;
+            if (K == KMAX && (KMAX % VN == 0) && ((reinterpret_cast<uintptr_t>(h_out) & 15u) == 0)) {
+                V4* h4 = reinterpret_cast<V4*>(hp);
+#pragma unroll
+                for (int e = 0; e < KMAX / VN; ++e) {
+                    V4 q;
+                    if constexpr (VN == 4) { q.x = hv[e * 4]; q.y = hv[e * 4 + 1]; q.z = hv[e * 4 + 2]; q.w = hv[e * 4 + 3]; }
+                    else { q.x = hv[e * 2]; q.y = hv[e * 2 + 1]; }
+                    h4[e] = q;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < KMAX; ++r) if (r < K) hp[r] = hv[r];
+            }
+        }
+    }
+}
+
+// ======================================================================================
+// K > 8: LDS kernel.
+// The kernel has three phases per 64-agent wave:
+//   1. stage   obstacle rows HBM -> LDS (16-byte LDS-DMA), state / u_ref -> registers
+//   2. assemble one CBF row per obstacle (rolled loop, one copy of the row builder) -> LDS
+//              rows[(obstacle*3 + comp)*64 + lane]  (lane-contiguous: bank-conflict free)
+//   3. solve   KMAX > 0: rows are pulled into registers and the walk is fully unrolled (K <= KMAX <= 8)
+//              KMAX == 0: rows stay in LDS, run-time loops (any K up to SC_CBFQP_MAX_OBS)
+//
+// Phase 2 reads the staged obstacle rows with a per-lane rotation: lane l handles obstacle
+// (r + l / P) mod K at step r, P = 32 / gcd(K, 32).  Lanes whose staged rows start on the same
+// LDS bank (stride K*7 dwords) then read different rows, which removes the 8- (K = 8) to 16-way
+// (K = 16) bank conflict of the straightforward order; the QP does not care about row order.
 template <typename TIO, typename TC, int KMAX, int MODEL>
 __global__ __launch_bounds__(64) void cbfqp_kernel(const sc_cbfqp_params p, const long long B, const int K,
                                                    const TIO* __restrict__ X, const TIO* __restrict__ u_ref,
@@ -57,7 +174,7 @@ __global__ __launch_bounds__(64) void cbfqp_kernel(const sc_cbfqp_params p, cons
     const bool active = lane < nag;
     const int row_elems = K * 7;
 
-    // ---- obstacles: HBM -> LDS ------------------------------------------------
+    // ---- 1. obstacles: HBM -> LDS ------------------------------------------------
     if (p.obs_shared) {
         for (int e = lane; e < row_elems; e += 64) lobs[e] = obs[e];
     } else {
@@ -71,7 +188,7 @@ __global__ __launch_bounds__(64) void cbfqp_kernel(const sc_cbfqp_params p, cons
         }
     }
 
-    // ---- state / reference (coalesced, overlaps the DMA) -----------------------
+    // state / reference (coalesced, overlaps the DMA)
     using V2 = typename vec2<TIO>::type;
     TC x = 0, y = 0, th = 0, v = 0, ur0 = 0, ur1 = 0;
     int nk = K;
@@ -92,93 +209,81 @@ __global__ __launch_bounds__(64) void cbfqp_kernel(const sc_cbfqp_params p, cons
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // LDS-DMA landed (it is tracked by vmcnt)
     __syncthreads();
 
+    // ---- 2. row assembly: agent_barrier + cbf_qp.py:155-183 ------------------------
+    const size_t stage_bytes = ((p.obs_shared ? (size_t)row_elems : (size_t)64 * row_elems) * sizeof(TIO) + 15) & ~(size_t)15;
+    TC* rows = reinterpret_cast<TC*>(smem + stage_bytes);          // [K][3][64]
+    TIO* hl = reinterpret_cast<TIO*>(rows + (size_t)K * 3 * 64);   // [K][64], natural obstacle order
     const TIO* mine = lobs + (p.obs_shared ? 0 : lane * row_elems);
+    int period = 32;                                               // P = 32 / gcd(K, 32)
+    while (((K * (32 / period)) & 31) != 0 && period > 1) period >>= 1;
+    // (period ends as the smallest power of two with K*32/period = 0 mod 32, i.e. 32/gcd(K,32))
+    const int rot = p.obs_shared ? 0 : (lane / period) % K;
     bool bad_obs = false;
+    TC poison = TC(0);                                             // NaN once any row entry is non-finite
+#pragma nounroll
+    for (int r = 0; r < K; ++r) {
+        int ro = r + rot;
+        ro = ro >= K ? ro - K : ro;
+        TC o[7];
+#pragma unroll
+        for (int f = 0; f < 7; ++f) o[f] = TC(mine[ro * 7 + f]);
+        TC h, a0, a1, cc;
+        const bool ok = cbf_row<TC, MODEL>(ag, o, k, a0, a1, cc, h);
+        const bool used = ro < nk;
+        bad_obs |= used && !ok;
+        a0 = used ? a0 : TC(0); a1 = used ? a1 : TC(0); cc = used ? cc : TC(0);
+        normalise_row(a0, a1, cc, poison);
+        // stored at the obstacle's own index: the walk order (hence the rounding) is the same for every lane
+        rows[(ro * 3 + 0) * 64 + lane] = a0;
+        rows[(ro * 3 + 1) * 64 + lane] = a1;
+        rows[(ro * 3 + 2) * 64 + lane] = cc;
+        if constexpr (KMAX > 0) {
+            hl[ro * 64 + lane] = used ? TIO(h) : TIO(0);
+        } else {
+            // large K: no LDS left for an h stage (f64, K = 32 uses all 160 KiB) -- store directly
+            if (active && h_out) h_out[agent * K + ro] = used ? TIO(h) : TIO(0);
+        }
+    }
+
+    // ---- 3. solve ---------------------------------------------------------------------
     TC u0, u1;
     int st;
-
     if constexpr (KMAX > 0) {
-        // ---- row assembly (agent_barrier + cbf_qp.py:155-183), rows in registers ----
         TC n0[KMAX], n1[KMAX], c[KMAX];
-        TIO hv[KMAX];
-        if (K == KMAX) {
-            // compile-time stride: the compiler turns these into wide ds_reads
-            TIO flat[KMAX * 7];
 #pragma unroll
-            for (int e = 0; e < KMAX * 7; ++e) flat[e] = mine[e];
-#pragma unroll
-            for (int r = 0; r < KMAX; ++r) {
-                TC o[7];
-#pragma unroll
-                for (int f = 0; f < 7; ++f) o[f] = TC(flat[r * 7 + f]);
-                TC h;
-                const bool ok = cbf_row<TC, MODEL>(ag, o, k, n0[r], n1[r], c[r], h);
-                const bool used = r < nk;
-                bad_obs |= used && !ok;
-                n0[r] = used ? n0[r] : TC(0);
-                n1[r] = used ? n1[r] : TC(0);
-                c[r] = used ? c[r] : TC(0);
-                hv[r] = used ? TIO(h) : TIO(0);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < KMAX; ++r) {
-                n0[r] = n1[r] = c[r] = TC(0);
-                hv[r] = TIO(0);
-                if (r < K) {
-                    TC o[7];
-#pragma unroll
-                    for (int f = 0; f < 7; ++f) o[f] = TC(mine[r * 7 + f]);
-                    TC h, a0, a1, cc;
-                    const bool ok = cbf_row<TC, MODEL>(ag, o, k, a0, a1, cc, h);
-                    const bool used = r < nk;
-                    bad_obs |= used && !ok;
-                    n0[r] = used ? a0 : TC(0);
-                    n1[r] = used ? a1 : TC(0);
-                    c[r] = used ? cc : TC(0);
-                    hv[r] = used ? TIO(h) : TIO(0);
-                }
-            }
+        for (int j = 0; j < KMAX; ++j) {
+            const bool in = j < K;
+            n0[j] = in ? rows[(j * 3 + 0) * 64 + lane] : TC(0);
+            n1[j] = in ? rows[(j * 3 + 1) * 64 + lane] : TC(0);
+            c[j] = in ? rows[(j * 3 + 2) * 64 + lane] : TC(0);
         }
-        st = qp2_solve<TC, KMAX>(n0, n1, c, K, ur0, ur1, k, u0, u1);
-        if (active && h_out) {
-            TIO* hp = h_out + agent * K;
-            if (K == KMAX) {
-#pragma unroll
-                for (int r = 0; r < KMAX; ++r) hp[r] = hv[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < KMAX; ++r) if (r < K) hp[r] = hv[r];
-            }
-        }
+        st = qp2_solve<TC, KMAX>(n0, n1, c, K, ur0, ur1, poison, k, u0, u1);
     } else {
-        // ---- rows in LDS: [K][3][64] of TC behind the obstacle stage -----------------
-        const size_t stage_bytes = ((p.obs_shared ? (size_t)row_elems : (size_t)64 * row_elems) * sizeof(TIO) + 15) & ~(size_t)15;
-        TC* rows = reinterpret_cast<TC*>(smem + stage_bytes);
-        TIO* hp = h_out ? h_out + agent * K : nullptr;
-#pragma nounroll
-        for (int r = 0; r < K; ++r) {
-            TC o[7];
-#pragma unroll
-            for (int f = 0; f < 7; ++f) o[f] = TC(mine[r * 7 + f]);
-            TC h, a0, a1, cc;
-            const bool ok = cbf_row<TC, MODEL>(ag, o, k, a0, a1, cc, h);
-            const bool used = r < nk;
-            bad_obs |= used && !ok;
-            rows[(r * 3 + 0) * 64 + lane] = used ? a0 : TC(0);
-            rows[(r * 3 + 1) * 64 + lane] = used ? a1 : TC(0);
-            rows[(r * 3 + 2) * 64 + lane] = used ? cc : TC(0);
-            if (active && hp) hp[r] = used ? TIO(h) : TIO(0);
-        }
-        st = qp2_solve_lds<TC>(rows, lane, K, ur0, ur1, k, u0, u1);
+        st = qp2_solve_lds<TC>(rows, lane, K, ur0, ur1, poison, k, u0, u1);
     }
 
     if (bad_obs) st = SC_STATUS_BAD_OBSTACLE;
     if (st != SC_STATUS_OPTIMAL) { u0 = num<TC>::nan(); u1 = num<TC>::nan(); }
+
+    // ---- outputs ----------------------------------------------------------------------
     if (active) {
         V2 uo; uo.x = TIO(u0); uo.y = TIO(u1);
         reinterpret_cast<V2*>(u_out)[agent] = uo;
         status_out[agent] = st;
+        if constexpr (KMAX > 0) {
+            if (h_out) {
+                TIO* hp = h_out + agent * K;
+                if (K == KMAX) {                 // static indices: vector stores
+                    TIO hv[KMAX];
+#pragma unroll
+                    for (int r = 0; r < KMAX; ++r) hv[r] = hl[r * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < KMAX; ++r) hp[r] = hv[r];
+                } else {
+                    for (int r = 0; r < K; ++r) hp[r] = hl[r * 64 + lane];
+                }
+            }
+        }
     }
 }
 
@@ -187,9 +292,16 @@ template <typename TIO, typename TC, int KMAX, int MODEL>
 static hipError_t launch_one(const sc_cbfqp_params& p, long long B, int K, const void* X, const void* u_ref,
                              const void* obs, const int* n_obs, void* u_out, int* status, void* h_out,
                              hipStream_t stream) {
+    if constexpr (KMAX > 0) {
+        const unsigned threads = 256;
+        const unsigned nblk = (unsigned)((B + threads - 1) / threads);
+        hipLaunchKernelGGL((cbfqp_reg_kernel<TIO, TC, KMAX, MODEL>), dim3(nblk), dim3(threads), 0, stream, p, B, K,
+                           (const TIO*)X, (const TIO*)u_ref, (const TIO*)obs, n_obs, (TIO*)u_out, status, (TIO*)h_out);
+        return hipGetLastError();
+    } else {
     const unsigned blocks = (unsigned)((B + 63) / 64);
     size_t lds = (p.obs_shared ? (size_t)K * 7 : (size_t)64 * K * 7) * sizeof(TIO);
-    if (KMAX == 0) lds = ((lds + 15) & ~(size_t)15) + (size_t)K * 3 * 64 * sizeof(TC);
+    lds = ((lds + 15) & ~(size_t)15) + (size_t)K * 3 * 64 * sizeof(TC) + (KMAX > 0 ? (size_t)K * 64 * sizeof(TIO) : 0);
     auto kern = cbfqp_kernel<TIO, TC, KMAX, MODEL>;
     if (lds > 64 * 1024) {
         static bool raised = false;        // dynamic LDS above 64 KiB needs the attribute once
@@ -203,6 +315,7 @@ static hipError_t launch_one(const sc_cbfqp_params& p, long long B, int K, const
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, p, B, K,
                        (const TIO*)X, (const TIO*)u_ref, (const TIO*)obs, n_obs, (TIO*)u_out, status, (TIO*)h_out);
     return hipGetLastError();
+    }
 }
 
 template <typename TIO, typename TC, int MODEL>

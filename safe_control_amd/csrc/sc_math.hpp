@@ -10,13 +10,13 @@ template <typename T> struct num;
 template <> struct num<float> {
     static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
     static __device__ __forceinline__ float nan() { return __builtin_nanf(""); }
-    static __device__ __forceinline__ float eps_par() { return 1e-6f; }    // |sin| below which two rows count as parallel
+    static __device__ __forceinline__ float eps_par() { return 1e-5f; }    // |sin| below which two rows count as parallel
     static __device__ __forceinline__ float tol_feas() { return 1e-5f; }   // relative infeasibility tolerance
 };
 template <> struct num<double> {
     static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
     static __device__ __forceinline__ double nan() { return __builtin_nan(""); }
-    static __device__ __forceinline__ double eps_par() { return 1e-13; }
+    static __device__ __forceinline__ double eps_par() { return 1e-12; }
     static __device__ __forceinline__ double tol_feas() { return 1e-9; }
 };
 

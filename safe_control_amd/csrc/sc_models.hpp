@@ -112,6 +112,25 @@ __device__ __forceinline__ void hocbf_superellipsoid(const Agent<T>& a, const T*
     dhd[3] = dhx * a.c + dhy * a.s;
 }
 
+// Out-of-line copy for kernels that unroll the row loop: superellipsoids are the rare,
+// code-heavy case (sincos + pow chains + divisions); one shared body instead of K inlined
+// copies keeps the unrolled kernels inside the instruction cache.  Everything by value.
+template <typename T>
+struct SuperOut { T h, hdot, d0, d1, d2, d3; };
+
+template <typename T>
+__device__ __attribute__((noinline)) SuperOut<T> hocbf_superellipsoid_outlined(
+        T ax, T ay, T ac, T as, T af0, T af1, T o0, T o1, T o2, T o3, T o4, T o5, T R) {
+    Agent<T> a;
+    a.x = ax; a.y = ay; a.th = T(0); a.v = T(0); a.c = ac; a.s = as; a.f0 = af0; a.f1 = af1;
+    const T o[7] = {o0, o1, o2, o3, o4, o5, T(1)};
+    SuperOut<T> r;
+    T dhd[4];
+    hocbf_superellipsoid(a, o, R, r.h, r.hdot, dhd);
+    r.d0 = dhd[0]; r.d1 = dhd[1]; r.d2 = dhd[2]; r.d3 = dhd[3];
+    return r;
+}
+
 // ---- rel-deg-1 barriers with moving obstacles ------------------------------
 // dynamic_env/kinematic_bicycle2D_c3bf.py:15-75
 template <typename T>
@@ -169,7 +188,7 @@ __device__ __forceinline__ void dpcbf(const Agent<T>& a, const T* o, T R, T& h, 
 
 // One CBF row for obstacle `o` (7 values, compute type).  Returns false when
 // the obstacle flag is invalid for the model (DU needs flag 0 or 1).
-template <typename T, int MODEL>
+template <typename T, int MODEL, bool OUTLINE_RARE = false>
 __device__ __forceinline__ bool cbf_row(const Agent<T>& a, const T* o, const CbfConsts<T>& k,
                                         T& n0, T& n1, T& c, T& h) {
     if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D || MODEL == SC_MODEL_KINEMATIC_BICYCLE2D) {
@@ -179,7 +198,13 @@ __device__ __forceinline__ bool cbf_row(const Agent<T>& a, const T* o, const Cbf
             if (flag == T(0)) {
                 hocbf_circle(a, o, k.R, T(1.01), h, hdot, dhd);
             } else if (flag == T(1)) {
-                hocbf_superellipsoid(a, o, k.R, h, hdot, dhd);
+                if constexpr (OUTLINE_RARE) {
+                    const SuperOut<T> r = hocbf_superellipsoid_outlined<T>(a.x, a.y, a.c, a.s, a.f0, a.f1, o[0], o[1],
+                                                                           o[2], o[3], o[4], o[5], k.R);
+                    h = r.h; hdot = r.hdot; dhd[0] = r.d0; dhd[1] = r.d1; dhd[2] = r.d2; dhd[3] = r.d3;
+                } else {
+                    hocbf_superellipsoid(a, o, k.R, h, hdot, dhd);
+                }
             } else {
                 n0 = n1 = c = h = T(0);
                 return false;

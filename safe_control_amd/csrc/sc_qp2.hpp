@@ -7,155 +7,207 @@
 // the constraints incrementally (Seidel-style): the running optimum u of
 // {box, rows 0..i-1} is kept; if row i is violated at u, the optimum of
 // {box, rows 0..i} lies on the line of row i, where the problem is the
-// projection of u_ref onto that line clipped to the interval the earlier
-// constraints leave.  Interval ends are kept as fractions (num, den > 0) and
-// compared by cross-multiplication, so a solve costs at most one division per
-// violated row.  Rows are held in registers; everything is predicated, the
-// only branch is a wave-uniform skip when no lane violates row i.
+// projection of u_ref onto that line clipped to the interval [lo, hi] the box
+// and the earlier rows leave on it.
+//
+// Rows arrive NORMALISED (unit normal, see normalise_row): then for line i with
+// unit direction d = (-n1, n0) and foot point p (projection of u_ref), an
+// earlier row j restricts the line parameter t through
+//       a t + r >= 0,   a = n_j . d  (sine of the angle between the rows),  r = n_j . p + c_j
+// i.e. t >= -r/a for a >= 0 and t <= -r/a for a < 0.  IEEE arithmetic covers
+// the degenerate cases without branches: a == 0 (parallel or all-zero row)
+// gives t = -r * inf = -inf (no restriction) when the line satisfies row j and
+// +inf (empty interval => infeasible) when it does not.
+// If rounding leaves lo > hi by a hair the midpoint is taken and the walk goes
+// on.  Feasibility is decided ONCE, at the end, in slack space: the returned
+// point must satisfy every (normalised) row to tol_feas -- what a QP solver's
+// feasibility tolerance means -- so a problem is reported infeasible exactly
+// when even the best point found violates a row by more than the tolerance.
+// Everything is predicated; the only branch is a wave-uniform skip when no
+// lane violates row i.
 #pragma once
 #include "sc_models.hpp"
 
 namespace sc {
 
-template <typename T>
-struct Interval {      // t in [lo_n/lo_d, hi_n/hi_d], dens >= 0 (0 = unbounded)
-    T lo_n, lo_d, hi_n, hi_d;
-    bool par_bad;      // a parallel earlier constraint excludes the whole line
-};
+__device__ __forceinline__ float rcp_(float a) { return __builtin_amdgcn_rcpf(a); }     // v_rcp_f32, 1 ulp
+__device__ __forceinline__ double rcp_(double a) { return 1.0 / a; }                   // IEEE (accuracy mode)
+__device__ __forceinline__ float rsqrt_(float a) { return __builtin_amdgcn_rsqf(a); }
+__device__ __forceinline__ double rsqrt_(double a) { return 1.0 / sqrt(a); }
 
-// clip the line  u(t) = p + t d  against  a t + r >= 0   where  a = g.d, r = g.p + gc
+// Scale a row to a unit normal.  All-zero rows (the reference's unused rows,
+// cbf_qp.py:110-111) stay (0, 0, c).  `poison` accumulates 0 * (row entries): it turns
+// NaN as soon as any entry is non-finite, which the solve reports as infeasible.
 template <typename T>
-__device__ __forceinline__ void clip(Interval<T>& I, T a, T r, T par2, T tol_r) {
-    const bool is_par = a * a <= par2;            // |sin angle| <= eps_par
-    const bool up = a > T(0);
-    // candidate bound t* = -r / a  as a fraction with positive denominator
-    const T cn = up ? -r : r;
-    const T cd = up ? a : -a;
-    const bool take_lo = !is_par && up && (cn * I.lo_d > I.lo_n * cd);
-    const bool take_hi = !is_par && !up && (cn * I.hi_d < I.hi_n * cd);
-    I.lo_n = take_lo ? cn : I.lo_n;
-    I.lo_d = take_lo ? cd : I.lo_d;
-    I.hi_n = take_hi ? cn : I.hi_n;
-    I.hi_d = take_hi ? cd : I.hi_d;
-    I.par_bad |= is_par && (r < -tol_r);
+__device__ __forceinline__ void normalise_row(T& n0, T& n1, T& c, T& poison) {
+    const T nn = n0 * n0 + n1 * n1;
+    poison += T(0) * (nn + c);
+    const T inv = nn > T(0) ? rsqrt_(nn) : T(1);
+    n0 *= inv; n1 *= inv; c *= inv;
 }
 
-// Returns SC_STATUS_OPTIMAL / SC_STATUS_INFEASIBLE; u0,u1 valid when optimal.
+template <typename T>
+struct LineQP {        // state of one incremental step
+    T p0, p1, d0, d1, lo, hi;
+};
+
+// interval the box leaves on the line p + t d
+template <typename T>
+__device__ __forceinline__ void clip_box(LineQP<T>& L, const CbfConsts<T>& k) {
+    const T inf = num<T>::inf();
+    const T tol = num<T>::tol_feas();
+    // axis 0
+    {
+        const T r = rcp_(L.d0);
+        const T t1 = (k.lo0 - L.p0) * r, t2 = (k.hi0 - L.p0) * r;
+        const bool flat = L.d0 == T(0);
+        const bool inside = (L.p0 >= k.lo0 - tol) && (L.p0 <= k.hi0 + tol);
+        const T lo = flat ? (inside ? -inf : inf) : fmin_(t1, t2);
+        const T hi = flat ? inf : fmax_(t1, t2);
+        L.lo = lo; L.hi = hi;
+    }
+    {
+        const T r = rcp_(L.d1);
+        const T t1 = (k.lo1 - L.p1) * r, t2 = (k.hi1 - L.p1) * r;
+        const bool flat = L.d1 == T(0);
+        const bool inside = (L.p1 >= k.lo1 - tol) && (L.p1 <= k.hi1 + tol);
+        const T lo = flat ? (inside ? -inf : inf) : fmin_(t1, t2);
+        const T hi = flat ? inf : fmax_(t1, t2);
+        L.lo = fmax_(L.lo, lo); L.hi = fmin_(L.hi, hi);
+    }
+}
+
+// restriction an earlier (normalised) row (g0, g1, gc) puts on the line:  a t + r >= 0.
+// q = r/|a|:  a >= 0 -> t >= -q ;  a < 0 -> t <= q.   Rows closer than eps_par to parallel
+// (|a| = |sin angle|; duplicates of row i, all-zero rows) restrict nothing when the line
+// satisfies them and empty the interval when it violates them beyond tolerance.
+template <typename T>
+__device__ __forceinline__ void clip_row(LineQP<T>& L, T g0, T g1, T gc) {
+    const T inf = num<T>::inf();
+    const T a = g0 * L.d0 + g1 * L.d1;
+    const T r = g0 * L.p0 + (g1 * L.p1 + gc);
+    const bool par = fabs_(a) <= num<T>::eps_par();
+    const bool par_viol = r < -num<T>::tol_feas() * fmax_(T(1), fabs_(gc));
+    T q = r * rcp_(fabs_(a));
+    q = par ? (par_viol ? -inf : inf) : q;
+    const bool up = par || (a >= T(0));
+    L.lo = fmax_(L.lo, up ? -q : -inf);
+    L.hi = fmin_(L.hi, up ? inf : q);
+}
+
+template <typename T>
+struct QpState {
+    T u0, u1, ur0, ur1;
+};
+
+template <typename T>
+__device__ __forceinline__ void qp_begin(QpState<T>& S, T ur0, T ur1, const CbfConsts<T>& k) {
+    S.ur0 = ur0; S.ur1 = ur1;
+    S.u0 = fmin_(fmax_(ur0, k.lo0), k.hi0);          // optimum of the box alone
+    S.u1 = fmin_(fmax_(ur1, k.lo1), k.hi1);
+}
+
+// first half of step i: is row i violated at the running optimum?  (sets up the line if so)
+template <typename T>
+__device__ __forceinline__ bool qp_row_violated(QpState<T>& S, T a0, T a1, T ci, LineQP<T>& L,
+                                                const CbfConsts<T>& k) {
+    const T s = a0 * S.u0 + (a1 * S.u1 + ci);
+    // an all-zero row is "0 >= -c": nothing to project on (the final slack check reports c < 0)
+    const bool zero_row = (a0 == T(0)) && (a1 == T(0));
+    const bool viol = !zero_row && (s < T(0));
+    const T sr = a0 * S.ur0 + (a1 * S.ur1 + ci);
+    L.p0 = S.ur0 - sr * a0;                           // projection of u_ref on the line
+    L.p1 = S.ur1 - sr * a1;
+    L.d0 = -a1; L.d1 = a0;
+    return viol;
+}
+
+// second half of step i, after the clips
+template <typename T>
+__device__ __forceinline__ void qp_row_commit(QpState<T>& S, const LineQP<T>& L, bool viol) {
+    T t = fmin_(fmax_(T(0), L.lo), L.hi);            // closest point of [lo, hi] to the foot point (t = 0)
+    t = (L.lo > L.hi) ? T(0.5) * (L.lo + L.hi) : t;  // empty (rounding, or truly infeasible): split the difference
+    const T v0 = L.p0 + t * L.d0, v1 = L.p1 + t * L.d1;
+    S.u0 = viol ? v0 : S.u0;
+    S.u1 = viol ? v1 : S.u1;
+}
+
+// slack of one normalised row at the final point, folded into the running minimum
+template <typename T>
+__device__ __forceinline__ T qp_row_margin(T worst, T a0, T a1, T ci, T u0, T u1, T& poison) {
+    const T s = a0 * u0 + (a1 * u1 + ci);
+    const T m = s + num<T>::tol_feas() * fmax_(T(1), fabs_(ci));     // >= 0 when satisfied to tolerance
+    poison += T(0) * s;                  // a NaN / inf slack (poisoned walk) must count as violated: min() drops NaN
+    return fmin_(worst, m);
+}
+
+template <typename T>
+__device__ __forceinline__ int qp_status(const QpState<T>& S, T worst, T poison, const CbfConsts<T>& k) {
+    const bool finite = (poison == poison) && finite_(S.ur0 + S.ur1);
+    const bool box_ok = (k.lo0 <= k.hi0) && (k.lo1 <= k.hi1);
+    return (!(worst >= T(0)) || !finite || !box_ok) ? SC_STATUS_INFEASIBLE : SC_STATUS_OPTIMAL;
+}
+
+// the box is a hard actuator limit: clamp (removes the last-ulp overshoot of p + t d) before the check
+template <typename T>
+__device__ __forceinline__ void qp_finish_box(QpState<T>& S, const CbfConsts<T>& k) {
+    S.u0 = fmin_(fmax_(S.u0, k.lo0), k.hi0);
+    S.u1 = fmin_(fmax_(S.u1, k.lo1), k.hi1);
+}
+
+// ---- rows in registers, loops unrolled (K <= KMAX) -----------------------------------
 template <typename T, int KMAX>
 __device__ __forceinline__ int qp2_solve(const T (&n0)[KMAX], const T (&n1)[KMAX], const T (&c)[KMAX],
-                                         int K, T ur0, T ur1, const CbfConsts<T>& k, T& u0, T& u1) {
-    const T tol = num<T>::tol_feas();
-    const T epar = num<T>::eps_par();
-    const T epar2 = epar * epar;
-    bool infeas = (k.lo0 > k.hi0) || (k.lo1 > k.hi1);
-    bool finite = finite_(ur0 + ur1);
-    u0 = fmin_(fmax_(ur0, k.lo0), k.hi0);        // optimum of the box alone
-    u1 = fmin_(fmax_(ur1, k.lo1), k.hi1);
-
+                                         int K, T ur0, T ur1, T poison, const CbfConsts<T>& k, T& u0, T& u1) {
+    QpState<T> S;
+    qp_begin(S, ur0, ur1, k);
 #pragma unroll
     for (int i = 0; i < KMAX; ++i) {
         if (i >= K) break;                         // K is wave-uniform
-        const T a0 = n0[i], a1 = n1[i], ci = c[i];
-        const T nn = a0 * a0 + a1 * a1;
-        finite = finite && finite_(nn + ci);
-        const bool zero_row = !(nn > T(0));
-        infeas |= zero_row && (ci < -tol * fmax_(T(1), fabs_(ci)));
-        const T s = a0 * u0 + a1 * u1 + ci;
-        const bool viol = !zero_row && (s < T(0));
+        LineQP<T> L;
+        const bool viol = qp_row_violated(S, n0[i], n1[i], c[i], L, k);
         if (__builtin_amdgcn_ballot_w64(viol) == 0) continue;
-
-        const T inv = T(1) / nn;
-        const T sr = (a0 * ur0 + a1 * ur1 + ci) * inv;
-        const T p0 = ur0 - sr * a0, p1 = ur1 - sr * a1;   // projection of u_ref on the line
-        const T d0 = -a1, d1 = a0;                        // line direction, |d|^2 = nn
-        Interval<T> I{T(-1), T(0), T(1), T(0), false};
-        const T par_box = epar2 * nn;
-        const T tol_box = tol * fmax_(T(1), fmax_(fmax_(fabs_(k.lo0), fabs_(k.hi0)), fmax_(fabs_(k.lo1), fabs_(k.hi1))));
-        clip(I, d0, p0 - k.lo0, par_box, tol_box);
-        clip(I, -d0, k.hi0 - p0, par_box, tol_box);
-        clip(I, d1, p1 - k.lo1, par_box, tol_box);
-        clip(I, -d1, k.hi1 - p1, par_box, tol_box);
+        clip_box(L, k);
 #pragma unroll
-        for (int j = 0; j < i; ++j) {
-            const T g0 = n0[j], g1 = n1[j], gc = c[j];
-            const T gg = g0 * g0 + g1 * g1;
-            const T a = g0 * d0 + g1 * d1;
-            const T r = g0 * p0 + g1 * p1 + gc;
-            // zero rows (gg == 0) give a = 0, r = gc: handled as "parallel"; their
-            // own feasibility was already accounted for above.
-            clip(I, a, r, epar2 * gg * nn, tol * fmax_(T(1), fabs_(gc)));
-        }
-        // empty interval?  lo > hi (+ relative slack)
-        const T gap = I.lo_n * I.hi_d - I.hi_n * I.lo_d;
-        const T gsc = I.lo_d * I.hi_d + fabs_(I.lo_n) * I.hi_d + fabs_(I.hi_n) * I.lo_d;
-        const bool empty = gap > tol * gsc;
-        T t = T(0);
-        if (I.lo_n > T(0)) t = I.lo_n / I.lo_d;           // lo_d > 0 whenever lo_n > 0
-        else if (I.hi_n < T(0)) t = I.hi_n / I.hi_d;
-        const T v0 = p0 + t * d0, v1 = p1 + t * d1;
-        u0 = viol ? v0 : u0;
-        u1 = viol ? v1 : u1;
-        infeas |= viol && (empty || I.par_bad);
+        for (int j = 0; j < i; ++j) clip_row(L, n0[j], n1[j], c[j]);
+        qp_row_commit(S, L, viol);
     }
-    return (infeas || !finite) ? SC_STATUS_INFEASIBLE : SC_STATUS_OPTIMAL;
+    qp_finish_box(S, k);
+    T worst = num<T>::inf();
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i)
+        if (i < K) worst = qp_row_margin(worst, n0[i], n1[i], c[i], S.u0, S.u1, poison);
+    u0 = S.u0; u1 = S.u1;
+    return qp_status(S, worst, poison, k);
 }
 
-// Same walk with the rows held in LDS instead of registers (K > 8: 3*K values
-// per lane no longer fit the register file in f64).  Row (r, comp) of lane l
-// lives at rows[(r*3 + comp)*64 + l]: lane-contiguous, bank-conflict free.
+// ---- rows in LDS, run-time loops (any K) ------------------------------------------------
+// Row (r, comp) of lane l lives at rows[(r*3 + comp)*64 + l]: lane-contiguous, conflict free.
 template <typename T>
-__device__ __forceinline__ int qp2_solve_lds(const T* rows, int lane, int K, T ur0, T ur1,
+__device__ __forceinline__ int qp2_solve_lds(const T* rows, int lane, int K, T ur0, T ur1, T poison,
                                              const CbfConsts<T>& k, T& u0, T& u1) {
-    const T tol = num<T>::tol_feas();
-    const T epar = num<T>::eps_par();
-    const T epar2 = epar * epar;
-    bool infeas = (k.lo0 > k.hi0) || (k.lo1 > k.hi1);
-    bool finite = finite_(ur0 + ur1);
-    u0 = fmin_(fmax_(ur0, k.lo0), k.hi0);
-    u1 = fmin_(fmax_(ur1, k.lo1), k.hi1);
-    const T tol_box = tol * fmax_(T(1), fmax_(fmax_(fabs_(k.lo0), fabs_(k.hi0)), fmax_(fabs_(k.lo1), fabs_(k.hi1))));
+    QpState<T> S;
+    qp_begin(S, ur0, ur1, k);
     const T* mine = rows + lane;
 #pragma nounroll
     for (int i = 0; i < K; ++i) {
-        const T a0 = mine[(i * 3 + 0) * 64], a1 = mine[(i * 3 + 1) * 64], ci = mine[(i * 3 + 2) * 64];
-        const T nn = a0 * a0 + a1 * a1;
-        finite = finite && finite_(nn + ci);
-        const bool zero_row = !(nn > T(0));
-        infeas |= zero_row && (ci < -tol * fmax_(T(1), fabs_(ci)));
-        const T s = a0 * u0 + a1 * u1 + ci;
-        const bool viol = !zero_row && (s < T(0));
+        LineQP<T> L;
+        const bool viol = qp_row_violated(S, mine[(i * 3 + 0) * 64], mine[(i * 3 + 1) * 64],
+                                          mine[(i * 3 + 2) * 64], L, k);
         if (__builtin_amdgcn_ballot_w64(viol) == 0) continue;
-
-        const T inv = T(1) / nn;
-        const T sr = (a0 * ur0 + a1 * ur1 + ci) * inv;
-        const T p0 = ur0 - sr * a0, p1 = ur1 - sr * a1;
-        const T d0 = -a1, d1 = a0;
-        Interval<T> I{T(-1), T(0), T(1), T(0), false};
-        const T par_box = epar2 * nn;
-        clip(I, d0, p0 - k.lo0, par_box, tol_box);
-        clip(I, -d0, k.hi0 - p0, par_box, tol_box);
-        clip(I, d1, p1 - k.lo1, par_box, tol_box);
-        clip(I, -d1, k.hi1 - p1, par_box, tol_box);
+        clip_box(L, k);
 #pragma nounroll
-        for (int j = 0; j < i; ++j) {
-            const T g0 = mine[(j * 3 + 0) * 64], g1 = mine[(j * 3 + 1) * 64], gc = mine[(j * 3 + 2) * 64];
-            const T gg = g0 * g0 + g1 * g1;
-            const T a = g0 * d0 + g1 * d1;
-            const T r = g0 * p0 + g1 * p1 + gc;
-            clip(I, a, r, epar2 * gg * nn, tol * fmax_(T(1), fabs_(gc)));
-        }
-        const T gap = I.lo_n * I.hi_d - I.hi_n * I.lo_d;
-        const T gsc = I.lo_d * I.hi_d + fabs_(I.lo_n) * I.hi_d + fabs_(I.hi_n) * I.lo_d;
-        const bool empty = gap > tol * gsc;
-        T t = T(0);
-        if (I.lo_n > T(0)) t = I.lo_n / I.lo_d;
-        else if (I.hi_n < T(0)) t = I.hi_n / I.hi_d;
-        const T v0 = p0 + t * d0, v1 = p1 + t * d1;
-        u0 = viol ? v0 : u0;
-        u1 = viol ? v1 : u1;
-        infeas |= viol && (empty || I.par_bad);
+        for (int j = 0; j < i; ++j)
+            clip_row(L, mine[(j * 3 + 0) * 64], mine[(j * 3 + 1) * 64], mine[(j * 3 + 2) * 64]);
+        qp_row_commit(S, L, viol);
     }
-    return (infeas || !finite) ? SC_STATUS_INFEASIBLE : SC_STATUS_OPTIMAL;
+    qp_finish_box(S, k);
+    T worst = num<T>::inf();
+#pragma nounroll
+    for (int i = 0; i < K; ++i)
+        worst = qp_row_margin(worst, mine[(i * 3 + 0) * 64], mine[(i * 3 + 1) * 64], mine[(i * 3 + 2) * 64], S.u0, S.u1, poison);
+    u0 = S.u0; u1 = S.u1;
+    return qp_status(S, worst, poison, k);
 }
 
 }  // namespace sc
