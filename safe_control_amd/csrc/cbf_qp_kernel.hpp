@@ -293,7 +293,8 @@ static hipError_t launch_one(const sc_cbfqp_params& p, long long B, int K, const
                              const void* obs, const int* n_obs, void* u_out, int* status, void* h_out,
                              hipStream_t stream) {
     if constexpr (KMAX > 0) {
-        const unsigned threads = 256;
+        // small batches are latency-bound: one wave per workgroup spreads them over more CUs
+        const unsigned threads = B <= 32768 ? 64 : 256;
         const unsigned nblk = (unsigned)((B + threads - 1) / threads);
         hipLaunchKernelGGL((cbfqp_reg_kernel<TIO, TC, KMAX, MODEL>), dim3(nblk), dim3(threads), 0, stream, p, B, K,
                            (const TIO*)X, (const TIO*)u_ref, (const TIO*)obs, n_obs, (TIO*)u_out, status, (TIO*)h_out);
