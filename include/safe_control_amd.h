@@ -121,6 +121,50 @@ int sc_cbfqp_solve_batch_host(const sc_cbfqp_params* params, int64_t B, int32_t 
                               void* u_out, int32_t* status_out, void* h_out,
                               int device);
 
+/* ---- MPC-CBF ------------------------------------------------------------
+ * Parameters of one MPCCBF controller instance: what MPCCBF.__init__ reads
+ * from robot_spec (position_control/mpc_cbf.py:7-100).                     */
+#define SC_MPCCBF_MAX_HORIZON 32
+
+typedef struct sc_mpccbf_params {
+    int32_t model_id;        /* SC_MODEL_DYNAMIC_UNICYCLE2D (others: SC_ERR_UNSUPPORTED)          */
+    int32_t io_dtype;        /* SC_DTYPE_*: element type of X,u_prev,goal,obs,u_out,z_out          */
+    int32_t horizon;         /* robot_spec['mpc_horizon'], default 10 (mpc_cbf.py:15)              */
+    int32_t max_iter;        /* interior-point iteration limit (-> SC_STATUS_INACCURATE)           */
+    int32_t obs_shared;      /* 0: obs is [B,K,7]; 1: one [K,7] table for all agents               */
+    int32_t reserved0;
+    double  dt;              /* robot.dt                                                           */
+    double  Q[4];            /* diagonal state weights, DU: 50,50,.01,30 (mpc_cbf.py:25-27)        */
+    double  R[2];            /* input-rate weights of mpc.set_rterm, DU: .5,.5 (mpc_cbf.py:180)    */
+    double  alpha1, alpha2;  /* DT-CBF gains, DU: .15,.15 (mpc_cbf.py:56-59)                       */
+    double  v_max;           /* |x[3]| <= v_max on every stage (mpc_cbf.py:193-195)                */
+    double  u_max[2];        /* |a| <= a_max, |omega| <= w_max (mpc_cbf.py:196-199)                */
+    double  robot_radius;
+    double  beta;            /* barrier inflation, 1.01 (dynamic_unicycle2D.py:188)                */
+    double  tol;             /* KKT tolerance on the gradient-scaled problem (1e-6)                */
+    double  mu_init;         /* initial barrier parameter (0.1, IPOPT's default)                   */
+    double  mu_min;          /* smallest barrier parameter (1e-9)                                  */
+} sc_mpccbf_params;
+
+/* Replaces, for a whole batch of agents in one launch:
+ *   MPCCBF.solve_control_problem(robot_state, control_ref, nearest_obs)   mpc_cbf.py:366-402
+ *     mpc.x0 = x; mpc.set_initial_guess(); update_tvp(goal, obs); mpc.make_step(x)  (IPOPT)
+ * X [B,4], u_prev [B,2] (last applied input = do-mpc's u0, zeros on the first call),
+ * goal [B,2], obs [B,K,7] already padded with [1000,1000,0,...] rows like update_tvp
+ * (mpc_cbf.py:338-364).  u_out [B,2] first move of the horizon; status_out [B] SC_STATUS_*;
+ * iters_out [B] or NULL; z_out [B, 2*horizon] or NULL (whole input sequence).
+ * One NLP per wavefront; arithmetic is always f64.
+ */
+int sc_mpccbf_solve_batch(const sc_mpccbf_params* params, int64_t B, int32_t K,
+                          const void* X, const void* u_prev, const void* goal, const void* obs,
+                          void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out,
+                          void* stream);
+
+int sc_mpccbf_solve_batch_host(const sc_mpccbf_params* params, int64_t B, int32_t K,
+                               const void* X, const void* u_prev, const void* goal, const void* obs,
+                               void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out,
+                               int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,340 @@
+"""Float64 restatement of the MPC-CBF NLP (position_control/mpc_cbf.py) and a reference solver.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).   **Parity unpinned**: the
+reference solves this NLP with do-mpc -> casadi -> IPOPT (mpc_cbf.py:163,384),
+none of which can be installed here, the NLP is non-convex, and no reference
+test pins its result.  What is restated from the reference is the *problem*:
+
+  model       x+ = x + (f(x) + g(x) u) dt, no angle wrap           mpc_cbf.py:135-141
+  cost        sum_{k<N} (x_k-goal)'Q(x_k-goal) + terminal same      mpc_cbf.py:144,176-178,267
+              + sum_k sum_i R_i (u_k,i - u_{k-1,i})^2  (do-mpc rterm) mpc_cbf.py:180
+  weights     DU: Q = diag(50,50,.01,30), R = (.5,.5), N = 10       mpc_cbf.py:15,25-27
+  CBF         dd_h + (a1+a2) d_h + a1 a2 h >= 0 at stages 0..N-1     mpc_cbf.py:304,316-321
+              with x1 = step(x_k,u_k), x2 = step(x1,u_k)             robots/dynamic_unicycle2D.py:188-238
+              DT gains a1 = a2 = 0.15                                mpc_cbf.py:56-59
+  obstacles   padded to num_obs rows with [1000,1000,0,...]          mpc_cbf.py:338-364
+  bounds      |v_k| <= v_max (all k), |a| <= a_max, |w| <= w_max     mpc_cbf.py:193-199
+  protocol    constant initial guess x0 / u_prev every call          mpc_cbf.py:366-384 (set_initial_guess)
+
+The barrier h depends on the position only, so the heading wrap inside
+``step`` (fmod) cannot change it; with x1 = x_{k+1} and x2's position equal to
+the next predicted position, every CBF row is a function of three consecutive
+predicted positions p_k, p_{k+1}, p_{k+2}.
+
+Solver (the algorithm the HIP kernel implements, here in numpy float64): the
+NLP is condensed by single shooting onto z = (u_0..u_{N-1}) and solved by a
+primal-dual interior-point method with slacks on every inequality, a
+Gauss-Newton Hessian (always positive definite thanks to the input-rate
+penalty), fraction-to-the-boundary steps and an l1-merit backtracking line
+search, started from the same constant guess the reference uses.
+"""
+import math
+
+import numpy as np
+
+STATUS_OPTIMAL = 0
+STATUS_INFEASIBLE = 1
+STATUS_INACCURATE = 2
+
+DEFAULTS = dict(N=10, dt=0.05, Q=(50.0, 50.0, 0.01, 30.0), R=(0.5, 0.5), alpha1=0.15, alpha2=0.15,
+                v_max=1.0, a_max=1.0, w_max=0.5, radius=0.25, beta=1.01,
+                tol=1e-6, max_iter=100, mu_init=0.1, mu_min=1e-9)
+
+DUMMY_OBS = np.array([1000.0, 1000.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+
+
+def pad_obstacles(obs, num_obs):
+    """update_tvp, mpc_cbf.py:338-364: 3-wide rows get zero tails, missing rows are far-away dummies."""
+    out = np.tile(DUMMY_OBS, (num_obs, 1))
+    if obs is None or len(obs) == 0:
+        return out
+    rows = []
+    for ob in obs:
+        ob = np.asarray(ob, dtype=np.float64)
+        if ob.shape[0] == 3:
+            ob = np.concatenate([ob, np.zeros(4)])
+        elif ob.shape[0] != 7:
+            raise ValueError(f"Invalid obstacle format: {ob}")
+        rows.append(ob)
+    rows = np.array(rows)[:num_obs]
+    out[: len(rows)] = rows
+    return out
+
+
+def rollout(x0, z, P):
+    """Predicted states x_0..x_N plus one extra position p_{N+1} (second step of the last DT-CBF row)."""
+    N, dt = P["N"], P["dt"]
+    X = np.zeros((N + 1, 4))
+    X[0] = x0
+    for k in range(N):
+        x, y, th, v = X[k]
+        a, w = z[2 * k], z[2 * k + 1]
+        X[k + 1] = [x + dt * v * math.cos(th), y + dt * v * math.sin(th), th + dt * w, v + dt * a]
+    xe = X[N]
+    p_extra = np.array([xe[0] + dt * xe[3] * math.cos(xe[2]), xe[1] + dt * xe[3] * math.sin(xe[2])])
+    return X, p_extra
+
+
+def position_jacobians(X, P):
+    """dP[k] = d p_k / d z for k = 0..N+1, shape (N+2, 2, 2N).
+
+    d p_k / d a_j = dt^2 sum_{i=j+1}^{k-1} (cos th_i, sin th_i),
+    d p_k / d w_j = dt^2 sum_{i=j+1}^{k-1} v_i (-sin th_i, cos th_i).
+    """
+    N, dt = P["N"], P["dt"]
+    n = 2 * N
+    C = np.stack([np.cos(X[:, 2]), np.sin(X[:, 2])], axis=1)              # (N+1,2)
+    D = np.stack([-X[:, 3] * np.sin(X[:, 2]), X[:, 3] * np.cos(X[:, 2])], axis=1)
+    PC = np.vstack([np.zeros((1, 2)), np.cumsum(C, axis=0)])                # PC[k] = sum_{i<k} C_i, k = 0..N+1
+    PD = np.vstack([np.zeros((1, 2)), np.cumsum(D, axis=0)])
+    dP = np.zeros((N + 2, 2, n))
+    for k in range(N + 2):
+        for j in range(N):
+            if j + 1 <= k - 1:
+                dP[k, :, 2 * j] = dt * dt * (PC[k] - PC[j + 1])
+                dP[k, :, 2 * j + 1] = dt * dt * (PD[k] - PD[j + 1])
+    return dP
+
+
+def barrier(p, obs, P):
+    """h, dh/dp (2,), d2h/dp2 (2,2) at position p.
+
+    Circle robots/dynamic_unicycle2D.py:194-202, superellipsoid :204-220 (fabs, clamps a,b >= 1e-3, e >= 2).
+    """
+    R, beta = P["radius"], P["beta"]
+    if obs[6] < 0.5:
+        d = R + obs[2]
+        e = p - obs[0:2]
+        return e @ e - beta * d * d, 2.0 * e, 2.0 * np.eye(2)
+    a = max(abs(obs[2]), 1e-3) + R
+    b = max(abs(obs[3]), 1e-3) + R
+    ex = max(abs(obs[4]), 2.0)
+    ct, st = math.cos(obs[5]), math.sin(obs[5])
+    dx, dy = p[0] - obs[0], p[1] - obs[1]
+    px, py = ct * dx + st * dy, -st * dx + ct * dy
+    ax, ay = abs(px) / a, abs(py) / b
+    h = ax ** ex + ay ** ex - 1.0
+    gpx = ex * ax ** (ex - 1) / a * np.sign(px)
+    gpy = ex * ay ** (ex - 1) / b * np.sign(py)
+    hxx = ex * (ex - 1) * ax ** (ex - 2) / (a * a)
+    hyy = ex * (ex - 1) * ay ** (ex - 2) / (b * b)
+    Rm = np.array([[ct, st], [-st, ct]])                                    # p' = Rm (p - o)
+    return h, Rm.T @ np.array([gpx, gpy]), Rm.T @ np.diag([hxx, hyy]) @ Rm
+
+
+def cbf_weights(P):
+    """c = w2 h(p_{k+2}) + w1 h(p_{k+1}) + w0 h(p_k)  ==  dd_h + (a1+a2) d_h + a1 a2 h  (mpc_cbf.py:316-321)."""
+    g1 = P["alpha1"] + P["alpha2"]
+    g2 = P["alpha1"] * P["alpha2"]
+    return 1.0 - g1 + g2, g1 - 2.0, 1.0
+
+
+def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
+    """Problem functions at z.
+
+    level 0: f, g.   level 1: + grad f, J.   level 2: + W = Hessian of f - lam' g  (exact).
+    Inequalities g >= 0 are ordered [CBF (k major, obstacle minor) | v_max - v_k, v_max + v_k (k=1..N) |
+    u_max - z | u_max + z].
+    """
+    N, dt = P["N"], P["dt"]
+    n = 2 * N
+    Q, Rw = np.asarray(P["Q"], dtype=np.float64), np.asarray(P["R"], dtype=np.float64)
+    K = obs.shape[0]
+    w0, w1, w2 = cbf_weights(P)
+    X, p_extra = rollout(x0, z, P)
+    pos = np.vstack([X[:, 0:2], p_extra[None, :]])                          # p_0..p_{N+1}
+    gpos = np.asarray(goal, dtype=np.float64)[0:2]
+    out = {}
+    # ---- values -------------------------------------------------------------------------
+    f = 0.0
+    for k in range(1, N + 1):
+        e = pos[k] - gpos
+        f += Q[0] * e[0] ** 2 + Q[1] * e[1] ** 2 + Q[2] * X[k, 2] ** 2 + Q[3] * X[k, 3] ** 2
+    up = np.concatenate([np.asarray(u_prev, dtype=np.float64), z])
+    du = up[2:] - up[:-2]
+    Rd = np.tile(Rw, N)
+    f += float(np.sum(Rd * du * du))
+    hk = np.zeros((N + 2, K)); dh = np.zeros((N + 2, K, 2)); Hh = np.zeros((N + 2, K, 2, 2))
+    for k in range(N + 2):
+        for j in range(K):
+            hk[k, j], dh[k, j], Hh[k, j] = barrier(pos[k], obs[j], P)
+    m = N * K + 2 * N + 2 * n
+    g = np.zeros(m)
+    for k in range(N):
+        g[k * K:(k + 1) * K] = w2 * hk[k + 2] + w1 * hk[k + 1] + w0 * hk[k]
+    o = N * K
+    for k in range(1, N + 1):
+        g[o + 2 * (k - 1)] = P["v_max"] - X[k, 3]
+        g[o + 2 * (k - 1) + 1] = P["v_max"] + X[k, 3]
+    o += 2 * N
+    ub = np.tile([P["a_max"], P["w_max"]], N)
+    g[o:o + n] = ub - z
+    g[o + n:o + 2 * n] = ub + z
+    out.update(f=float(f), g=g, X=X)
+    if level == 0:
+        return out
+    # ---- first derivatives ------------------------------------------------------------------
+    dP = position_jacobians(X, P)                                           # (N+2, 2, n)
+    dTh = np.zeros((N + 1, n)); dV = np.zeros((N + 1, n))                   # d theta_k / dz, d v_k / dz
+    for k in range(N + 1):
+        for j in range(k):
+            dTh[k, 2 * j + 1] = dt
+            dV[k, 2 * j] = dt
+    grad = np.zeros(n)
+    for k in range(1, N + 1):
+        grad += dP[k].T @ (2.0 * Q[0:2] * (pos[k] - gpos)) + 2.0 * Q[2] * X[k, 2] * dTh[k] + 2.0 * Q[3] * X[k, 3] * dV[k]
+    Dm = np.eye(n) - np.eye(n, k=-2)
+    grad += 2.0 * Dm.T @ (Rd * du)
+    J = np.zeros((m, n))
+    for k in range(N):
+        for j in range(K):
+            J[k * K + j] = w2 * dh[k + 2, j] @ dP[k + 2] + w1 * dh[k + 1, j] @ dP[k + 1] + w0 * dh[k, j] @ dP[k]
+    o = N * K
+    for k in range(1, N + 1):
+        J[o + 2 * (k - 1)] = -dV[k]
+        J[o + 2 * (k - 1) + 1] = dV[k]
+    o += 2 * N
+    J[o:o + n] = -np.eye(n)
+    J[o + n:o + 2 * n] = np.eye(n)
+    out.update(grad=grad, J=J)
+    if level == 1:
+        return out
+    # ---- exact Hessian of the Lagrangian ------------------------------------------------------
+    # L = sum_k phi_k(p_k) + (terms quadratic in z),  phi_k(p) = Qp-weighted |p - goal|^2 - sum_j mu_kj h_j(p)
+    # mu_kj = w2 lam_{k-2,j} + w1 lam_{k-1,j} + w0 lam_{k,j}   (CBF multipliers touching position k)
+    lam = np.zeros(m) if lam is None else lam
+    lc = lam[: N * K].reshape(N, K)
+    mu = np.zeros((N + 2, K))
+    for k in range(N + 2):
+        if k - 2 >= 0: mu[k] += w2 * lc[k - 2]
+        if 1 <= k <= N: mu[k] += w1 * lc[k - 1]
+        if k <= N - 1: mu[k] += w0 * lc[k]
+    W = 2.0 * Dm.T @ (Rd[:, None] * Dm)
+    q = np.zeros((N + 2, 2))                                                # d L / d p_k
+    for k in range(N + 2):
+        Om = -np.einsum("j,jab->ab", mu[k], Hh[k])
+        qk = -mu[k] @ dh[k]
+        if 1 <= k <= N:
+            Om = Om + np.diag(2.0 * Q[0:2])
+            qk = qk + 2.0 * Q[0:2] * (pos[k] - gpos)
+            W += 2.0 * Q[2] * np.outer(dTh[k], dTh[k]) + 2.0 * Q[3] * np.outer(dV[k], dV[k])
+        q[k] = qk
+        W += dP[k].T @ Om @ dP[k]
+    # second derivatives of the positions: p_k = p_0 + dt sum_{i<k} v_i (cos th_i, sin th_i), th_i and v_i linear in z
+    #   sum_k q_k . d2 p_k = dt sum_i [ A_i (dV_i dTh_i' + dTh_i dV_i') - B_i dTh_i dTh_i' ],
+    #   qbar_i = sum_{k>i} q_k,  A_i = qbar_i . (-sin, cos)_i,  B_i = v_i qbar_i . (cos, sin)_i
+    for i in range(N + 1):
+        qbar = q[i + 1:].sum(axis=0)
+        th, v = X[i, 2], X[i, 3]
+        Ai = qbar @ np.array([-math.sin(th), math.cos(th)])
+        Bi = v * (qbar @ np.array([math.cos(th), math.sin(th)]))
+        W += dt * (Ai * (np.outer(dV[i], dTh[i]) + np.outer(dTh[i], dV[i])) - Bi * np.outer(dTh[i], dTh[i]))
+    out.update(W=W)
+    return out
+
+
+def problem_functions(x0, z, u_prev, goal, obs, P, want_jac=True):
+    """Back-compat helper used by the scipy cross-checks: (f, g, X) or (f, grad, W0, g, J, X)."""
+    if not want_jac:
+        r = evaluate(x0, z, u_prev, goal, obs, P, level=0)
+        return r["f"], r["g"], r["X"]
+    r = evaluate(x0, z, u_prev, goal, obs, P, level=2)
+    return r["f"], r["grad"], r["W"], r["g"], r["J"], r["X"]
+
+
+def solve(x0, u_prev, goal, obs, params=None, return_info=False):
+    """One MPC-CBF solve.  Returns u_0 (2,), status, iterations [, info dict].
+
+    Primal-dual interior point on  min f(z) s.t. g(z) - s = 0, s >= 0  with the exact Hessian of the
+    Lagrangian, inertia correction (W + delta I until the condensed matrix is positive definite),
+    fraction-to-the-boundary 0.995, l1 merit backtracking, monotone barrier decrease
+    mu <- max(mu_min, min(0.2 mu, mu^1.5)) once the barrier problem is solved to 10 mu.
+    The objective is scaled by min(1, 100 / |grad f(z0)|_inf) like IPOPT's gradient-based scaling.
+    """
+    P = dict(DEFAULTS)
+    if params:
+        P.update(params)
+    N = P["N"]
+    x0 = np.asarray(x0, dtype=np.float64)
+    obs = np.asarray(obs, dtype=np.float64)
+    ub = np.tile([P["a_max"], P["w_max"]], N)
+    z = np.clip(np.tile(np.asarray(u_prev, dtype=np.float64), N), -0.99 * ub, 0.99 * ub)   # set_initial_guess
+    ev = evaluate(x0, z, u_prev, goal, obs, P, None, level=1)
+    sf = min(1.0, 100.0 / max(1e-12, float(np.max(np.abs(ev["grad"])))))   # objective scaling
+    g = ev["g"]
+    m = g.shape[0]
+    mu = P["mu_init"]
+    s = np.maximum(g, 1e-2)
+    lam = mu / s
+    status, it = STATUS_INACCURATE, 0
+    tau, nu, delta_last = 0.995, 10.0, 0.0
+    err = np.inf
+    n_eval = 1
+    for it in range(1, P["max_iter"] + 1):
+        ev = evaluate(x0, z, u_prev, goal, obs, P, lam / sf, level=2)      # multipliers of the unscaled problem
+        f, grad, W, g, J = sf * ev["f"], sf * ev["grad"], sf * ev["W"], ev["g"], ev["J"]
+        r_d = grad - J.T @ lam
+        r_p = g - s
+        e_opt = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam)))
+        e_mu = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam - mu)))
+        err = e_opt
+        if e_opt <= P["tol"]:
+            status = STATUS_OPTIMAL
+            break
+        if np.max(lam) > 1e10:                                              # multipliers diverge: locally infeasible
+            status = STATUS_INFEASIBLE
+            break
+        while e_mu <= 10.0 * mu and mu > P["mu_min"]:
+            mu = max(P["mu_min"], min(0.2 * mu, mu ** 1.5))
+            e_mu = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam - mu)))
+        sig = lam / s
+        Mb = W + J.T @ (sig[:, None] * J)
+        rhs = -grad - J.T @ (sig * r_p) + J.T @ (mu / s)
+        delta = 0.0
+        L = None
+        for _try in range(40):                                              # inertia correction
+            try:
+                L = np.linalg.cholesky(Mb + delta * np.eye(2 * N))
+                break
+            except np.linalg.LinAlgError:
+                delta = max(1e-4, delta_last / 3.0) if delta == 0.0 else delta * 8.0
+        if L is None:
+            break
+        if delta > 0:
+            delta_last = delta
+        dz = np.linalg.solve(L.T, np.linalg.solve(L, rhs))
+        ds = J @ dz + r_p
+        dlam = -sig * ds - (lam - mu / s)
+        neg = ds < 0
+        ap = min(1.0, float(np.min(-tau * s[neg] / ds[neg]))) if np.any(neg) else 1.0
+        neg = dlam < 0
+        ad = min(1.0, float(np.min(-tau * lam[neg] / dlam[neg]))) if np.any(neg) else 1.0
+        nu = max(nu, 1.1 * float(np.max(np.abs(lam))))
+        phi0 = f - mu * np.sum(np.log(s)) + nu * np.sum(np.abs(r_p))
+        dphi = grad @ dz - mu * np.sum(ds / s) - nu * np.sum(np.abs(r_p))
+        alpha, accepted = ap, False
+        for _ in range(30):
+            zt, st = z + alpha * dz, s + alpha * ds
+            e0 = evaluate(x0, zt, u_prev, goal, obs, P, level=0)
+            n_eval += 1
+            phit = sf * e0["f"] - mu * np.sum(np.log(st)) + nu * np.sum(np.abs(e0["g"] - st))
+            if phit <= phi0 + 1e-4 * alpha * dphi:
+                accepted = True
+                break
+            alpha *= 0.5
+        if not accepted:
+            break
+        z, s = z + alpha * dz, s + alpha * ds
+        lam = lam + ad * dlam
+        lam = np.minimum(np.maximum(lam, mu / (1e10 * s)), 1e10 * mu / s)   # IPOPT eq. (16) safeguard
+    ev = evaluate(x0, z, u_prev, goal, obs, P, level=0)
+    if status != STATUS_OPTIMAL:
+        if np.min(ev["g"]) < -1e-6:
+            status = STATUS_INFEASIBLE
+        elif status != STATUS_INFEASIBLE:
+            status = STATUS_INACCURATE
+    u0 = z[0:2].copy()
+    if return_info:
+        return u0, status, it, dict(z=z, X=ev["X"], f=ev["f"], g=ev["g"], lam=lam / sf, s=s, err=err, mu=mu,
+                                    n_eval=n_eval, scale=sf)
+    return u0, status, it

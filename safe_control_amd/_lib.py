@@ -38,6 +38,21 @@ class CbfQpParams(C.Structure):
     ]
 
 
+MPCCBF_MAX_HORIZON = 32
+
+
+class MpcCbfParams(C.Structure):
+    """Mirror of ``sc_mpccbf_params``."""
+    _fields_ = [
+        ("model_id", C.c_int32), ("io_dtype", C.c_int32), ("horizon", C.c_int32), ("max_iter", C.c_int32),
+        ("obs_shared", C.c_int32), ("reserved0", C.c_int32),
+        ("dt", C.c_double), ("Q", C.c_double * 4), ("R", C.c_double * 2),
+        ("alpha1", C.c_double), ("alpha2", C.c_double), ("v_max", C.c_double), ("u_max", C.c_double * 2),
+        ("robot_radius", C.c_double), ("beta", C.c_double), ("tol", C.c_double),
+        ("mu_init", C.c_double), ("mu_min", C.c_double),
+    ]
+
+
 # every symbol include/safe_control_amd.h declares, with its ctypes signature
 SYMBOLS = {
     "sc_version": (C.c_int, []),
@@ -47,6 +62,12 @@ SYMBOLS = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sc_cbfqp_solve_batch_host": (C.c_int, [C.POINTER(CbfQpParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "sc_mpccbf_solve_batch": (C.c_int, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "sc_mpccbf_solve_batch_host": (C.c_int, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_int]),
 }
 
 _lib = None

@@ -11,6 +11,11 @@ hipError_t cbfqp_launch(const sc_cbfqp_params& p, long long B, int K, const void
                         const void* obs, const int* n_obs, void* u_out, int* status, void* h_out,
                         hipStream_t stream);
 
+hipError_t mpccbf_launch(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
+                         const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
+                         hipStream_t stream);
+size_t mpccbf_lds_bytes(int N, int K);
+
 static thread_local char g_err[256] = "";
 
 static int fail(int code, const char* msg) {
@@ -43,6 +48,28 @@ static int check_cbfqp(const sc_cbfqp_params* p, int64_t B, int32_t K, const voi
         return fail(SC_ERR_INVALID_ARGUMENT, "rear_ax_dist must be > 0 for the KinematicBicycle2D family");
     if (B > 0 && (!X || !u_ref || !obs || !u_out || !status_out))
         return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    return SC_OK;
+}
+static int check_mpccbf(const sc_mpccbf_params* p, int64_t B, int32_t K, const void* X, const void* u_prev,
+                        const void* goal, const void* obs, const void* u_out, const void* status_out) {
+    if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (B < 0) return fail(SC_ERR_INVALID_ARGUMENT, "B < 0");
+    if (K < 1) return fail(SC_ERR_INVALID_ARGUMENT, "K < 1 (pad with [1000,1000,0,...] rows like update_tvp)");
+    if (p->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D)
+        return fail(SC_ERR_UNSUPPORTED, "MPC-CBF is built for DynamicUnicycle2D only");
+    if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
+        return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
+    if (p->horizon < 1 || p->horizon > SC_MPCCBF_MAX_HORIZON)
+        return fail(SC_ERR_UNSUPPORTED, "horizon outside [1, SC_MPCCBF_MAX_HORIZON]");
+    if (mpccbf_lds_bytes(p->horizon, K) > 160 * 1024)
+        return fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
+    if (!(p->dt > 0) || !(p->tol > 0) || p->max_iter < 1 || !(p->mu_init > 0) || !(p->mu_min > 0))
+        return fail(SC_ERR_INVALID_ARGUMENT, "dt, tol, mu_init, mu_min must be > 0 and max_iter >= 1");
+    if (!(p->u_max[0] > 0) || !(p->u_max[1] > 0) || !(p->v_max > 0))
+        return fail(SC_ERR_INVALID_ARGUMENT, "u_max and v_max must be > 0");
+    if (B > 0 && (!X || !u_prev || !goal || !obs || !u_out || !status_out))
+        return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
     return SC_OK;
 }
 }  // namespace sc
@@ -110,7 +137,59 @@ int sc_cbfqp_solve_batch_host(const sc_cbfqp_params* params, int64_t B, int32_t 
         e = hipStreamSynchronize(s);
     } while (0);
     if (e != hipSuccess) rc = sc::fail_hip(e, "sc_cbfqp_solve_batch_host");
-    hipFree(d);
+    (void)hipFree(d);
+    return rc;
+}
+
+int sc_mpccbf_solve_batch(const sc_mpccbf_params* params, int64_t B, int32_t K, const void* X, const void* u_prev,
+                          const void* goal, const void* obs, void* u_out, int32_t* status_out, int32_t* iters_out,
+                          void* z_out, void* stream) {
+    int rc = sc::check_mpccbf(params, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::mpccbf_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out,
+                                     z_out, (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "mpccbf kernel launch");
+    return SC_OK;
+}
+
+int sc_mpccbf_solve_batch_host(const sc_mpccbf_params* params, int64_t B, int32_t K, const void* X,
+                               const void* u_prev, const void* goal, const void* obs, void* u_out,
+                               int32_t* status_out, int32_t* iters_out, void* z_out, int device) {
+    int rc = sc::check_mpccbf(params, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipSetDevice");
+    const size_t es = params->io_dtype == SC_DTYPE_F64 ? 8 : 4;
+    const size_t n = 2 * (size_t)params->horizon;
+    const size_t nX = (size_t)B * 4 * es, nU = (size_t)B * 2 * es, nG = nU;
+    const size_t nO = (params->obs_shared ? (size_t)K * 7 : (size_t)B * K * 7) * es;
+    const size_t nS = (size_t)B * 4, nZ = (size_t)B * n * es;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t oX = 0, oU = oX + up(nX), oG = oU + up(nU), oO = oG + up(nG), oUo = oO + up(nO), oS = oUo + up(nU),
+                 oI = oS + up(nS), oZ = oI + up(nS), total = oZ + up(nZ);
+    unsigned char* d = nullptr;
+    e = hipMalloc((void**)&d, total);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipMalloc");
+    hipStream_t s = nullptr;
+    do {
+        if ((e = hipMemcpyAsync(d + oX, X, nX, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oU, u_prev, nU, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oG, goal, nG, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        e = sc::mpccbf_launch(*params, (long long)B, (int)K, d + oX, d + oU, d + oG, d + oO, d + oUo, (int*)(d + oS),
+                              (int*)(d + oI), z_out ? d + oZ : nullptr, s);
+        if (e != hipSuccess) break;
+        if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (iters_out && (e = hipMemcpyAsync(iters_out, d + oI, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (z_out && (e = hipMemcpyAsync(z_out, d + oZ, nZ, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        e = hipStreamSynchronize(s);
+    } while (0);
+    rc = SC_OK;
+    if (e != hipSuccess) rc = sc::fail_hip(e, "sc_mpccbf_solve_batch_host");
+    (void)hipFree(d);
     return rc;
 }
 

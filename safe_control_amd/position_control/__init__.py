@@ -1,1 +1,2 @@
 from .cbf_qp import CBFQP, BatchedCBFQP  # noqa: F401
+from .mpc_cbf import MPCCBF, BatchedMPCCBF  # noqa: F401

@@ -1,0 +1,196 @@
+"""MPC-CBF position controllers backed by the gfx950 HIP kernel (csrc/mpc_cbf.hip).
+
+``MPCCBF`` keeps the plugin surface of the reference class of the same name
+(position_control/mpc_cbf.py:6-402): ``__init__(robot, robot_spec,
+show_mpc_traj=False, num_obs=5)``, ``setup_control_problem()``,
+``update_tvp(goal, obs)``, ``solve_control_problem(robot_state, control_ref,
+nearest_obs)``, attributes ``status``, ``cbf_param``, ``horizon``, ``Q``, ``R``,
+``goal``, ``obs``.  ``BatchedMPCCBF`` solves B agents' NLPs in one launch, one
+NLP per wavefront.
+
+The reference's NLP is solved by IPOPT (do-mpc); here the same NLP is solved by
+the kernel's own interior-point method from the same constant initial guess.
+No CPU fallback: the HIP library must be present.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from ..robots.spec import complete_robot_spec
+
+DUMMY_OBS = np.array([1000.0, 1000.0, 0.0, 0.0, 0.0, 0.0, 0.0])      # mpc_cbf.py:343,360
+
+
+def default_mpc_weights(model):
+    """Q, R of MPCCBF.__init__ (position_control/mpc_cbf.py:19-43)."""
+    if model == "DynamicUnicycle2D":
+        return np.diag([50.0, 50.0, 0.01, 30.0]), np.array([0.5, 0.5])
+    raise NotImplementedError(f"MPC-CBF on the batched engine supports DynamicUnicycle2D, not {model}")
+
+
+def default_mpc_cbf_param(model):
+    """DT-CBF gains, position_control/mpc_cbf.py:49-88."""
+    if model == "DynamicUnicycle2D":
+        return {"alpha1": 0.15, "alpha2": 0.15}
+    raise NotImplementedError(model)
+
+
+def apply_mpc_overrides(cbf_param, robot_spec):
+    """position_control/mpc_cbf.py:90-95."""
+    for key, src in (("alpha", "mpc_cbf_alpha"), ("alpha1", "mpc_cbf_alpha1"), ("alpha2", "mpc_cbf_alpha2")):
+        if src in robot_spec:
+            cbf_param[key] = float(robot_spec[src])
+    return cbf_param
+
+
+def pad_obstacles(obs, num_obs):
+    """update_tvp (mpc_cbf.py:338-364): 3-wide rows get zero tails, anything but 3/7 wide raises,
+    missing rows become far-away dummies, extra rows are dropped."""
+    out = np.tile(DUMMY_OBS, (num_obs, 1))
+    if obs is None or len(obs) == 0:
+        return out
+    rows = []
+    for ob in obs:
+        ob = np.asarray(ob, dtype=np.float64).reshape(-1)
+        if ob.shape[0] == 3:
+            ob = np.concatenate([ob, [0.0, 0.0, 0.0, 0.0]])
+        elif ob.shape[0] != 7:
+            raise ValueError(f"Invalid obstacle format: {ob}")
+        rows.append(ob)
+    rows = np.array(rows)[:num_obs]
+    out[: len(rows)] = rows
+    return out
+
+
+def make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_shared=False,
+                tol=1e-6, max_iter=100, mu_init=0.1, mu_min=1e-9):
+    p = _lib.MpcCbfParams()
+    p.model_id = _lib.MODEL_IDS[robot_spec["model"]]
+    p.io_dtype = io_dtype
+    p.horizon = int(horizon)
+    p.max_iter = int(max_iter)
+    p.obs_shared = 1 if obs_shared else 0
+    p.dt = float(dt)
+    qd = np.diag(np.asarray(Q, dtype=np.float64)) if np.ndim(Q) == 2 else np.asarray(Q, dtype=np.float64)
+    for i in range(4):
+        p.Q[i] = float(qd[i])
+    p.R[0], p.R[1] = float(R[0]), float(R[1])
+    p.alpha1, p.alpha2 = float(cbf_param["alpha1"]), float(cbf_param["alpha2"])
+    p.v_max = float(robot_spec["v_max"])
+    p.u_max[0], p.u_max[1] = float(robot_spec["a_max"]), float(robot_spec["w_max"])
+    p.robot_radius = float(radius)
+    p.beta = 1.01                                           # agent_barrier_dt default, dynamic_unicycle2D.py:188
+    p.tol, p.mu_init, p.mu_min = float(tol), float(mu_init), float(mu_min)
+    return p
+
+
+class MPCCBF:
+    """Drop-in for position_control.mpc_cbf.MPCCBF (single agent per call)."""
+
+    def __init__(self, robot, robot_spec, show_mpc_traj=False, num_obs=5, device=0):
+        self.robot = robot
+        self.robot_spec = complete_robot_spec(robot_spec)
+        self.status = "optimal"                             # the reference hard-wires this (mpc_cbf.py:10)
+        self.show_mpc_traj = show_mpc_traj
+        self.num_obs = int(num_obs)
+        self.device = device
+        self.horizon = int(self.robot_spec.get("mpc_horizon", 10))       # mpc_cbf.py:15
+        self.dt = robot.dt
+        model = self.robot_spec["model"]
+        self.Q, self.R = default_mpc_weights(model)
+        self.n_controls, self.n_states = 2, 4
+        self.goal = np.array([0, 0])
+        self.cbf_param = apply_mpc_overrides(default_mpc_cbf_param(model), self.robot_spec)
+        self.obs = None
+        self.setup_control_problem()
+
+    def setup_control_problem(self):
+        """The reference compiles a do-mpc/casadi NLP here (mpc_cbf.py:102-106)."""
+        if not 1 <= self.horizon <= _lib.MPCCBF_MAX_HORIZON:
+            raise ValueError(f"mpc_horizon must be in [1, {_lib.MPCCBF_MAX_HORIZON}]")
+        self._lib = _lib.load()
+        self.u_prev = np.zeros(2, dtype=np.float64)         # do-mpc's u0: last applied input, zeros at start
+        self.z = np.zeros(2 * self.horizon, dtype=np.float64)
+        self.iterations = 0
+        self.solver_status = "optimal"
+
+    def update_tvp(self, goal, obs):
+        self.goal = np.array(goal)
+        self.obs = pad_obstacles(obs, self.num_obs)
+
+    def solve_control_problem(self, robot_state, control_ref, nearest_obs):
+        goal = control_ref["goal"]
+        self.update_tvp(goal, nearest_obs)
+        if control_ref["state_machine"] != "track":         # mpc_cbf.py:379-381: pass the reference through
+            return control_ref["u_ref"]
+        X = np.ascontiguousarray(np.asarray(robot_state, dtype=np.float64).reshape(-1)[:4])
+        g = np.ascontiguousarray(np.asarray(self.goal, dtype=np.float64).reshape(-1)[:2])
+        obs = np.ascontiguousarray(self.obs, dtype=np.float64)
+        p = make_params(self.robot_spec, self.cbf_param, self.Q, self.R, self.horizon, self.dt,
+                        self.robot.robot_radius, _lib.DTYPE_F64)
+        u = np.zeros(2); st = np.zeros(1, dtype=np.int32); it = np.zeros(1, dtype=np.int32)
+        rc = self._lib.sc_mpccbf_solve_batch_host(
+            C.byref(p), 1, self.num_obs, X.ctypes.data, self.u_prev.ctypes.data, g.ctypes.data, obs.ctypes.data,
+            u.ctypes.data, st.ctypes.data, it.ctypes.data, self.z.ctypes.data, int(self.device))
+        _lib.check(rc, "sc_mpccbf_solve_batch_host")
+        self.iterations = int(it[0])
+        # the reference never reports MPC failures to control_step (status stays 'optimal', mpc_cbf.py:10,400);
+        # the real outcome is kept in solver_status
+        self.solver_status = _lib.STATUS_STRINGS[int(st[0])]
+        self.u_prev = u.copy()
+        return u.reshape(-1, 1).copy()
+
+
+class BatchedMPCCBF:
+    """MPC-CBF for B agents per launch on device tensors.
+
+    ``solve(X[B,4], u_prev[B,2], goal[B,2], obs[B,K,7] | obs[K,7])`` ->
+    ``u[B,2]``, ``status[B] int32``, ``iters[B] int32`` (and ``z[B,2N]`` if asked).
+    """
+
+    def __init__(self, robot_spec, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None,
+                 tol=1e-6, max_iter=100):
+        self.robot_spec = complete_robot_spec(robot_spec)
+        model = self.robot_spec["model"]
+        self.dt = float(dt)
+        self.io_dtype = {"f32": _lib.DTYPE_F32, "f64": _lib.DTYPE_F64}[io_dtype]
+        self.horizon = int(horizon if horizon is not None else self.robot_spec.get("mpc_horizon", 10))
+        self.Q, self.R = default_mpc_weights(model)
+        self.cbf_param = cbf_param or apply_mpc_overrides(default_mpc_cbf_param(model), self.robot_spec)
+        self.tol, self.max_iter = tol, max_iter
+        self._lib = _lib.load()
+
+    @property
+    def torch_dtype(self):
+        import torch
+        return torch.float32 if self.io_dtype == _lib.DTYPE_F32 else torch.float64
+
+    def solve(self, X, u_prev, goal, obs, want_z=False, out=None):
+        import torch
+        dt_ = self.torch_dtype
+        for name, t in (("X", X), ("u_prev", u_prev), ("goal", goal), ("obs", obs)):
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == dt_):
+                raise ValueError(f"{name} must be a contiguous CUDA tensor of dtype {dt_}")
+        B = X.shape[0]
+        shared = obs.dim() == 2
+        K = obs.shape[-2]
+        if X.shape != (B, 4) or u_prev.shape != (B, 2) or goal.shape != (B, 2) or obs.shape[-1] != 7 \
+                or (not shared and obs.shape[0] != B):
+            raise ValueError("expected X[B,4], u_prev[B,2], goal[B,2], obs[B,K,7] or obs[K,7]")
+        if out is None:
+            u = torch.empty((B, 2), dtype=dt_, device=X.device)
+            status = torch.empty((B,), dtype=torch.int32, device=X.device)
+            iters = torch.empty((B,), dtype=torch.int32, device=X.device)
+            z = torch.empty((B, 2 * self.horizon), dtype=dt_, device=X.device) if want_z else None
+        else:
+            u, status, iters, z = out
+        p = make_params(self.robot_spec, self.cbf_param, self.Q, self.R, self.horizon, self.dt,
+                        self.robot_spec["radius"], self.io_dtype, obs_shared=shared, tol=self.tol,
+                        max_iter=self.max_iter)
+        stream = torch.cuda.current_stream(X.device).cuda_stream
+        rc = self._lib.sc_mpccbf_solve_batch(
+            C.byref(p), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(),
+            u.data_ptr(), status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        _lib.check(rc, "sc_mpccbf_solve_batch")
+        return (u, status, iters, z) if want_z else (u, status, iters)
