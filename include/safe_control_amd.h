@@ -142,6 +142,7 @@ typedef struct sc_mpccbf_params {
     double  robot_radius;
     double  beta;            /* barrier inflation, 1.01 (dynamic_unicycle2D.py:188)                */
     double  tol;             /* KKT tolerance on the gradient-scaled problem (1e-6)                */
+    double  acceptable_tol;  /* accepted when the iteration stalls at the precision limit (1e-5)   */
     double  mu_init;         /* initial barrier parameter (0.1, IPOPT's default)                   */
     double  mu_min;          /* smallest barrier parameter (1e-9)                                  */
 } sc_mpccbf_params;

