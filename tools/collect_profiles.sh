@@ -1,0 +1,34 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun) from the repo root:  bash tools/collect_profiles.sh r01
+# Writes rocprofv3 summaries under gpurun_out/profiles_<round>/ ; tools/parse_profiles.py turns them
+# into the committed files under profiles/.
+set -u
+ROUND=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profiles_$ROUND
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-sweep --no-mpc"
+# 1. kernel trace + stats of the bench command (timed region = 200 launches of the B=4096 workload)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- $BENCH > $OUT/bench_under_rocprof.json 2>/dev/null
+# 2. HBM traffic counters, separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o bench_fetch -- $BENCH > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o bench_write -- $BENCH > /dev/null 2>&1
+# 3. same counters on large batches (calibration of the counter against known algorithmic bytes, and the
+#    regime where HBM is the binding limit): 2^20 and 2^23 agents, f32 storage, f32 and f64 arithmetic
+for CFG in "1048576 8 f32 f32" "1048576 8 f32 f64" "8388608 8 f32 f32" "4096 8 f32 f64"; do
+  TAG=$(echo $CFG | tr ' ' '_')
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o big_$TAG -- python3 $R/tools/prof_cbfqp.py $CFG 6 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o bigf_$TAG -- python3 $R/tools/prof_cbfqp.py $CFG 6 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o bigw_$TAG -- python3 $R/tools/prof_cbfqp.py $CFG 6 > /dev/null 2>&1
+done
+# 4. SQ counters of the dominant kernel at 2^20 agents (f32/f32 and f32/f64)
+for CFG in "1048576 8 f32 f32" "1048576 8 f32 f64"; do
+  TAG=$(echo $CFG | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT -o sqa_$TAG -- python3 $R/tools/prof_cbfqp.py $CFG 4 > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT -o sqb_$TAG -- python3 $R/tools/prof_cbfqp.py $CFG 4 > /dev/null 2>&1
+done
+# 5. MPC-CBF kernel
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o mpc -- python3 $R/bench.py --workload mpc_cbf --steps 5 --warmup 1 > $OUT/mpc_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o mpc_sq -- python3 $R/bench.py --workload mpc_cbf --steps 2 --warmup 1 > /dev/null 2>&1
+ls $OUT | head -80
