@@ -18,6 +18,12 @@
 
 namespace sc {
 
+// batches up to this many agents use the cooperative (8 lanes per agent) kernel: below it the
+// lane-per-QP kernel cannot fill the chip (65536 agents = 1024 waves = one per SIMD)
+#ifndef SC_COOP_MAX_AGENTS
+#define SC_COOP_MAX_AGENTS 32768
+#endif
+
 using as1_void = const __attribute__((address_space(1))) void;
 using as3_void = __attribute__((address_space(3))) void;
 
@@ -142,6 +148,108 @@ __global__ __launch_bounds__(256) void cbfqp_reg_kernel(const sc_cbfqp_params p,
                 for (int r = 0; r < KMAX; ++r) if (r < K) hp[r] = hv[r];
             }
         }
+    }
+}
+
+// ======================================================================================
+// K <= 8, small batches: cooperative kernel, 8 lanes per agent (one obstacle row per lane).
+//
+// At BASELINE's 4096-agent batch the lane-per-QP kernel runs 64 waves on a chip with 1024 SIMDs and
+// its time is one wave's instruction stream (~1700 VALU).  Here an agent is spread over 8 lanes:
+// each lane builds ONE row, the incremental walk broadcasts row i inside the 8-lane group, every
+// lane clips the line against its own row in parallel, and the interval ends are combined with
+// three xor-shuffle steps.  512 waves instead of 64, each ~4x shorter; with only 8 agents per wave
+// the wave-uniform "nobody violates row i" skip fires most of the time.  Arithmetic per row is the
+// same code as the lane-per-QP kernel (min/max reductions are exact), so both give the same answer.
+template <typename T>
+__device__ __forceinline__ T group_max8(T v) {
+    v = fmax_(v, __shfl_xor(v, 1)); v = fmax_(v, __shfl_xor(v, 2)); v = fmax_(v, __shfl_xor(v, 4));
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T group_min8(T v) {
+    v = fmin_(v, __shfl_xor(v, 1)); v = fmin_(v, __shfl_xor(v, 2)); v = fmin_(v, __shfl_xor(v, 4));
+    return v;
+}
+
+template <typename TIO, typename TC, int MODEL>
+__global__ __launch_bounds__(64) void cbfqp_coop_kernel(const sc_cbfqp_params p, const long long B, const int K,
+                                                        const TIO* __restrict__ X, const TIO* __restrict__ u_ref,
+                                                        const TIO* __restrict__ obs, const int* __restrict__ n_obs,
+                                                        TIO* __restrict__ u_out, int* __restrict__ status_out,
+                                                        TIO* __restrict__ h_out) {
+    const int lane = threadIdx.x;
+    const int sub = lane & 7;                              // obstacle row handled by this lane
+    const long long agent = (long long)blockIdx.x * 8 + (lane >> 3);
+    const bool active = agent < B;
+    const long long ag_i = active ? agent : 0;
+    using V2 = typename vec2<TIO>::type;
+
+    TIO orow[7];
+    const bool has_row = sub < K;
+    const TIO* src = obs + (p.obs_shared ? 0 : (size_t)ag_i * K * 7) + (has_row ? sub * 7 : 0);
+#pragma unroll
+    for (int f = 0; f < 7; ++f) orow[f] = src[f];
+    const V2* Xv = reinterpret_cast<const V2*>(X) + ag_i * 2;
+    const V2 xa = Xv[0], xb = Xv[1];
+    const V2 ur = reinterpret_cast<const V2*>(u_ref)[ag_i];
+    int nk = K;
+    if (n_obs) {
+        nk = n_obs[ag_i];
+        nk = nk < 0 ? 0 : (nk > K ? K : nk);
+    }
+    const TC ur0 = TC(ur.x), ur1 = TC(ur.y);
+    const CbfConsts<TC> k = make_consts<TC>(p);
+    const Agent<TC> ag = make_agent<TC>(TC(xa.x), TC(xa.y), TC(xb.x), TC(xb.y));
+
+    // ---- this lane's row -------------------------------------------------------------------
+    TC o[7];
+#pragma unroll
+    for (int f = 0; f < 7; ++f) o[f] = TC(orow[f]);
+    TC h, a0, a1, cc;
+    const bool ok = cbf_row<TC, MODEL, false>(ag, o, k, a0, a1, cc, h);
+    const bool used = sub < nk;
+    const bool bad_mine = used && !ok;
+    a0 = used ? a0 : TC(0); a1 = used ? a1 : TC(0); cc = used ? cc : TC(0);
+    TC poison = TC(0);
+    normalise_row(a0, a1, cc, poison);
+
+    // ---- cooperative walk ----------------------------------------------------------------------
+    QpState<TC> S;
+    qp_begin(S, ur0, ur1, k);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i >= K) break;
+        const TC bi0 = __shfl(a0, i, 8), bi1 = __shfl(a1, i, 8), bic = __shfl(cc, i, 8);   // row i of my agent
+        LineQP<TC> L;
+        const bool viol = qp_row_violated(S, bi0, bi1, bic, L, k);
+        if (__builtin_amdgcn_ballot_w64(viol) == 0) continue;
+        clip_box(L, k);
+        if (sub < i) clip_row(L, a0, a1, cc);             // rows j < i, one per lane, in parallel
+        L.lo = group_max8(L.lo);
+        L.hi = group_min8(L.hi);
+        qp_row_commit(S, L, viol);
+    }
+    qp_finish_box(S, k);
+    TC worst = qp_row_margin(num<TC>::inf(), a0, a1, cc, S.u0, S.u1, poison);
+    worst = group_min8(worst);
+    // NaN anywhere in the group must poison the status: min() drops NaN, so combine the flags explicitly
+    const bool nan_mine = !(poison == poison);
+    const unsigned long long nan_mask = __builtin_amdgcn_ballot_w64(nan_mine);
+    const unsigned long long bad_mask = __builtin_amdgcn_ballot_w64(bad_mine);
+    const unsigned long long grp = 0xFFull << (lane & ~7);
+    if (nan_mask & grp) poison = num<TC>::nan();
+    int st = qp_status(S, worst, poison, k);
+    if (bad_mask & grp) st = SC_STATUS_BAD_OBSTACLE;
+    TC u0 = S.u0, u1 = S.u1;
+    if (st != SC_STATUS_OPTIMAL) { u0 = num<TC>::nan(); u1 = num<TC>::nan(); }
+    if (active) {
+        if (sub == 0) {
+            V2 uo; uo.x = TIO(u0); uo.y = TIO(u1);
+            reinterpret_cast<V2*>(u_out)[agent] = uo;
+            status_out[agent] = st;
+        }
+        if (h_out && has_row) h_out[agent * K + sub] = used ? TIO(h) : TIO(0);
     }
 }
 
@@ -293,8 +401,14 @@ static hipError_t launch_one(const sc_cbfqp_params& p, long long B, int K, const
                              const void* obs, const int* n_obs, void* u_out, int* status, void* h_out,
                              hipStream_t stream) {
     if constexpr (KMAX > 0) {
-        // small batches are latency-bound: one wave per workgroup spreads them over more CUs
-        const unsigned threads = B <= 32768 ? 64 : 256;
+        if (B <= SC_COOP_MAX_AGENTS) {
+            // latency-bound regime: 8 lanes per agent, 8 agents per wave
+            const unsigned nblk = (unsigned)((B + 7) / 8);
+            hipLaunchKernelGGL((cbfqp_coop_kernel<TIO, TC, MODEL>), dim3(nblk), dim3(64), 0, stream, p, B, K,
+                               (const TIO*)X, (const TIO*)u_ref, (const TIO*)obs, n_obs, (TIO*)u_out, status, (TIO*)h_out);
+            return hipGetLastError();
+        }
+        const unsigned threads = 256;
         const unsigned nblk = (unsigned)((B + threads - 1) / threads);
         hipLaunchKernelGGL((cbfqp_reg_kernel<TIO, TC, KMAX, MODEL>), dim3(nblk), dim3(threads), 0, stream, p, B, K,
                            (const TIO*)X, (const TIO*)u_ref, (const TIO*)obs, n_obs, (TIO*)u_out, status, (TIO*)h_out);

@@ -175,15 +175,48 @@ def test_kinematic_bicycle_family(model, K):
     compare(model, spec, X, u_ref, obs, "f32", "f64")
 
 
+@pytest.mark.parametrize("model,K", [(R.MODEL_DU, 8), (R.MODEL_DU, 5), (R.MODEL_DU, 3), (R.MODEL_KB, 8),
+                                     (R.MODEL_KB_C3BF, 8), (R.MODEL_KB_DPCBF, 6)])
+@pytest.mark.parametrize("io,comp", [("f32", "f64"), ("f64", "f64"), ("f32", "f32")])
+def test_lane_per_qp_kernel_above_coop_threshold(model, K, io, comp):
+    """Batches above 32768 agents run the lane-per-QP register kernel: same oracle, same tolerances."""
+    B = 36864 + 37
+    if model == R.MODEL_DU:
+        spec = du_spec()
+        X, goal, u_ref, obs = W.du_cbfqp_batch(B, K, seed=77 + K)
+        if K == 5:                                   # mix in superellipsoids and ragged counts
+            rng = np.random.default_rng(5)
+            idx = rng.choice(B, 3000, replace=False)
+            for i in idx:
+                a, b = rng.uniform(0.3, 1.2, 2)
+                rho, phi = rng.uniform(max(a, b) + 0.55, 4.5), rng.uniform(-np.pi, np.pi)
+                obs[i, 1] = [X[i, 0] + rho * np.cos(phi), X[i, 1] + rho * np.sin(phi), a, b,
+                             float(rng.choice([4, 6])), rng.uniform(-np.pi, np.pi), 1.0]
+    else:
+        spec = kb_spec(MODEL_NAME[model])
+        X, goal, u_ref, obs = W.kb_c3bf_batch(B, K, seed=78 + K, spec=spec)
+    n_obs = None
+    if K == 3:
+        n_obs = np.random.default_rng(3).integers(0, 4, B).astype(np.int32)
+    if comp == "f32" and model == R.MODEL_DU and K == 5:
+        pytest.skip("superellipsoid rows reach 1e4..1e8: f64 arithmetic only (SURVEY 7)")
+    compare(model, spec, X, u_ref, obs, io, comp, n_obs=n_obs, frac_ok=1.0 if comp == "f64" else 0.99)
+
+
 def test_bad_obstacle_flag_and_nan_inputs():
-    X, goal, u_ref, obs = W.du_cbfqp_batch(130, 8, seed=3)
+    _bad_flag_case(130)
+    _bad_flag_case(33000)                  # same through the lane-per-QP kernel
+
+
+def _bad_flag_case(B):
+    X, goal, u_ref, obs = W.du_cbfqp_batch(B, 8, seed=3)
     obs[5, 2, 6] = 2.0                     # invalid flag
     X[7, 0] = np.nan                       # NaN state -> non-finite rows -> not optimal
     u_ref[9, 1] = np.inf
     ug, sg, hg, _ = run_gpu(du_spec(), X, u_ref, obs, "f32", "f64")
     assert sg[5] == 3 and np.all(np.isnan(ug[5]))
     assert sg[7] == 1 and sg[9] == 1
-    other = np.ones(130, bool); other[[5, 7, 9]] = False
+    other = np.ones(B, bool); other[[5, 7, 9]] = False
     uo, so, ho = c_oracle.cbfqp_batch(R.MODEL_DU, X[other].astype(np.float32).astype(np.float64),
                                       u_ref[other].astype(np.float32).astype(np.float64),
                                       obs[other].astype(np.float32).astype(np.float64),
@@ -278,11 +311,18 @@ def test_full_size_properties(comp):
     both = ok & (st3 == 0)
     d3 = (u3[both] - u[both]).abs().max(dim=1).values
     assert (d3 <= (1e-6 if comp == "f64" else 1e-3)).double().mean().item() >= (1.0 if comp == "f64" else 0.999)
-    # (4) an agent's result does not depend on where it sits in the batch
-    u4, st4, _ = ctl.solve(tX[12345:12345 + 4099].contiguous(), tu[12345:12345 + 4099].contiguous(),
-                           to[12345:12345 + 4099].contiguous())
-    assert torch.equal(st4, st[12345:12345 + 4099])
-    assert torch.equal(torch.nan_to_num(u4, nan=7.0), torch.nan_to_num(u[12345:12345 + 4099], nan=7.0))
+    # (4) an agent's result does not depend on where it sits in the batch (same kernel: bitwise)
+    lo, n4 = 12345, 40003
+    u4, st4, _ = ctl.solve(tX[lo:lo + n4].contiguous(), tu[lo:lo + n4].contiguous(), to[lo:lo + n4].contiguous())
+    assert torch.equal(st4, st[lo:lo + n4])
+    assert torch.equal(torch.nan_to_num(u4, nan=7.0), torch.nan_to_num(u[lo:lo + n4], nan=7.0))
+    # ... nor on which kernel serves the batch size: <= 32768 agents go to the 8-lanes-per-agent kernel
+    u5, st5, h5 = ctl.solve(tX[lo:lo + 4099].contiguous(), tu[lo:lo + 4099].contiguous(), to[lo:lo + 4099].contiguous())
+    assert (st5 == st[lo:lo + 4099]).double().mean().item() >= (1.0 if comp == "f64" else 0.999)
+    b5 = (st5 == 0) & (st[lo:lo + 4099] == 0)
+    d5 = (u5[b5] - u[lo:lo + 4099][b5]).abs().max(dim=1).values
+    assert (d5 <= (1e-6 if comp == "f64" else 1e-4)).double().mean().item() >= (1.0 if comp == "f64" else 0.999)
+    assert torch.equal(h5, h[lo:lo + 4099])
     # oracle on a strided sample of the big batch
     idx = np.arange(0, B, 509)
     uo, so, ho = c_oracle.cbfqp_batch(R.MODEL_DU, tX[idx].double().cpu().numpy(), tu[idx].double().cpu().numpy(),
