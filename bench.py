@@ -130,17 +130,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)          # (several ranks share a GPU only in the 1-GPU flow test below)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    # RCCL over xGMI (backend "nccl" on ROCm).  SC_BENCH_BACKEND=gloo exists only to exercise the
+    # N > 1 control flow on a 1-GPU box (tests/test_bench_flow_gpu.py); it is never the measured setup.
+    backend = os.environ.get("SC_BENCH_BACKEND", "nccl")
     if ws > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     if a.gpus != ws and rank == 0 and ws > 1:
         print(f"note: --gpus {a.gpus} but WORLD_SIZE {ws}; using WORLD_SIZE", file=sys.stderr)
 
     B, K = a.agents, a.obstacles
     if a.workload == "mpc_cbf":
         r = mpc_leg(dev, B, K, a.horizon, a.steps, a.warmup, seed=rank)
-        elapsed = sharding.max_over_ranks(B * a.steps / r["value"], device=dev)
+        elapsed = sharding.max_over_ranks(B * a.steps / r["value"], device=dev if backend == "nccl" else None)
         if rank == 0:
             print(json.dumps({"metric": "QP solves/sec (batched agents)", "value": B * ws * a.steps / elapsed,
                               "unit": "solves/s", "n_gpus": ws, "steps": a.steps, "warmup": a.warmup,
@@ -207,7 +215,7 @@ def main():
     if ws > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    elapsed = sharding.max_over_ranks(t1 - t0, device=dev)
+    elapsed = sharding.max_over_ranks(t1 - t0, device=dev if backend == "nccl" else None)
     kernel_ms = e0.elapsed_time(e1) / a.steps                       # avg launch duration over the timed region
 
     st = out[1]
@@ -228,7 +236,8 @@ def main():
                        "optimal_fraction": n_opt / B},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "cbfqp_kernel", "kernel_us": 1e3 * kernel_ms,
+                         "kernel": ("cbfqp_coop_kernel" if B <= 32768 else "cbfqp_reg_kernel") if K <= 8 else "cbfqp_coop_kernel",
+                         "kernel_us": 1e3 * kernel_ms,
                          "algorithmic_bytes_per_solve": BYTES_IN_CBFQP(K, es) + BYTES_OUT_CBFQP(K, es)},
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")

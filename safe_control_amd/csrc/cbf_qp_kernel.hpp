@@ -14,6 +14,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "sc_qp2.hpp"
 
 namespace sc {
@@ -23,6 +25,17 @@ namespace sc {
 #ifndef SC_COOP_MAX_AGENTS
 #define SC_COOP_MAX_AGENTS 32768
 #endif
+
+// test / profiling hook: SC_FORCE_LDS_KERNEL=1 routes K > 8 to the LDS-staged kernel instead of the
+// row-per-lane kernel
+static inline long long sc_coop_max_agents() {             // SC_COOP_MAX_AGENTS=<n> overrides the compiled default
+    static const long long v = [] { const char* e = getenv("SC_COOP_MAX_AGENTS"); return e ? atoll(e) : (long long)SC_COOP_MAX_AGENTS; }();
+    return v;
+}
+static inline bool sc_force_lds_kernel() {
+    static const bool v = [] { const char* e = getenv("SC_FORCE_LDS_KERNEL"); return e && e[0] == '1'; }();
+    return v;
+}
 
 using as1_void = const __attribute__((address_space(1))) void;
 using as3_void = __attribute__((address_space(3))) void;
@@ -161,26 +174,30 @@ __global__ __launch_bounds__(256) void cbfqp_reg_kernel(const sc_cbfqp_params p,
 // three xor-shuffle steps.  512 waves instead of 64, each ~4x shorter; with only 8 agents per wave
 // the wave-uniform "nobody violates row i" skip fires most of the time.  Arithmetic per row is the
 // same code as the lane-per-QP kernel (min/max reductions are exact), so both give the same answer.
-template <typename T>
-__device__ __forceinline__ T group_max8(T v) {
-    v = fmax_(v, __shfl_xor(v, 1)); v = fmax_(v, __shfl_xor(v, 2)); v = fmax_(v, __shfl_xor(v, 4));
+template <typename T, int G>
+__device__ __forceinline__ T group_max(T v) {
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) v = fmax_(v, __shfl_xor(v, o));
     return v;
 }
-template <typename T>
-__device__ __forceinline__ T group_min8(T v) {
-    v = fmin_(v, __shfl_xor(v, 1)); v = fmin_(v, __shfl_xor(v, 2)); v = fmin_(v, __shfl_xor(v, 4));
+template <typename T, int G>
+__device__ __forceinline__ T group_min(T v) {
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) v = fmin_(v, __shfl_xor(v, o));
     return v;
 }
 
-template <typename TIO, typename TC, int MODEL>
+// G lanes per agent (G = 8, 16 or 32 >= K), 64 / G agents per wave.
+template <typename TIO, typename TC, int G, int MODEL>
 __global__ __launch_bounds__(64) void cbfqp_coop_kernel(const sc_cbfqp_params p, const long long B, const int K,
                                                         const TIO* __restrict__ X, const TIO* __restrict__ u_ref,
                                                         const TIO* __restrict__ obs, const int* __restrict__ n_obs,
                                                         TIO* __restrict__ u_out, int* __restrict__ status_out,
                                                         TIO* __restrict__ h_out) {
+    constexpr int APW = 64 / G;                            // agents per wave
     const int lane = threadIdx.x;
-    const int sub = lane & 7;                              // obstacle row handled by this lane
-    const long long agent = (long long)blockIdx.x * 8 + (lane >> 3);
+    const int sub = lane & (G - 1);                        // obstacle row handled by this lane
+    const long long agent = (long long)blockIdx.x * APW + lane / G;
     const bool active = agent < B;
     const long long ag_i = active ? agent : 0;
     using V2 = typename vec2<TIO>::type;
@@ -217,27 +234,27 @@ __global__ __launch_bounds__(64) void cbfqp_coop_kernel(const sc_cbfqp_params p,
     // ---- cooperative walk ----------------------------------------------------------------------
     QpState<TC> S;
     qp_begin(S, ur0, ur1, k);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+#pragma unroll 8
+    for (int i = 0; i < G; ++i) {
         if (i >= K) break;
-        const TC bi0 = __shfl(a0, i, 8), bi1 = __shfl(a1, i, 8), bic = __shfl(cc, i, 8);   // row i of my agent
+        const TC bi0 = __shfl(a0, i, G), bi1 = __shfl(a1, i, G), bic = __shfl(cc, i, G);   // row i of my agent
         LineQP<TC> L;
         const bool viol = qp_row_violated(S, bi0, bi1, bic, L, k);
         if (__builtin_amdgcn_ballot_w64(viol) == 0) continue;
         clip_box(L, k);
         if (sub < i) clip_row(L, a0, a1, cc);             // rows j < i, one per lane, in parallel
-        L.lo = group_max8(L.lo);
-        L.hi = group_min8(L.hi);
+        L.lo = group_max<TC, G>(L.lo);
+        L.hi = group_min<TC, G>(L.hi);
         qp_row_commit(S, L, viol);
     }
     qp_finish_box(S, k);
     TC worst = qp_row_margin(num<TC>::inf(), a0, a1, cc, S.u0, S.u1, poison);
-    worst = group_min8(worst);
+    worst = group_min<TC, G>(worst);
     // NaN anywhere in the group must poison the status: min() drops NaN, so combine the flags explicitly
     const bool nan_mine = !(poison == poison);
     const unsigned long long nan_mask = __builtin_amdgcn_ballot_w64(nan_mine);
     const unsigned long long bad_mask = __builtin_amdgcn_ballot_w64(bad_mine);
-    const unsigned long long grp = 0xFFull << (lane & ~7);
+    const unsigned long long grp = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane & ~(G - 1));
     if (nan_mask & grp) poison = num<TC>::nan();
     int st = qp_status(S, worst, poison, k);
     if (bad_mask & grp) st = SC_STATUS_BAD_OBSTACLE;
@@ -251,6 +268,17 @@ __global__ __launch_bounds__(64) void cbfqp_coop_kernel(const sc_cbfqp_params p,
         }
         if (h_out && has_row) h_out[agent * K + sub] = used ? TIO(h) : TIO(0);
     }
+}
+
+template <typename TIO, typename TC, int G, int MODEL>
+static hipError_t launch_coop(const sc_cbfqp_params& p, long long B, int K, const void* X, const void* u_ref,
+                              const void* obs, const int* n_obs, void* u_out, int* status, void* h_out,
+                              hipStream_t stream) {
+    constexpr int APW = 64 / G;
+    const unsigned nblk = (unsigned)((B + APW - 1) / APW);
+    hipLaunchKernelGGL((cbfqp_coop_kernel<TIO, TC, G, MODEL>), dim3(nblk), dim3(64), 0, stream, p, B, K,
+                       (const TIO*)X, (const TIO*)u_ref, (const TIO*)obs, n_obs, (TIO*)u_out, status, (TIO*)h_out);
+    return hipGetLastError();
 }
 
 // ======================================================================================
@@ -401,19 +429,18 @@ static hipError_t launch_one(const sc_cbfqp_params& p, long long B, int K, const
                              const void* obs, const int* n_obs, void* u_out, int* status, void* h_out,
                              hipStream_t stream) {
     if constexpr (KMAX > 0) {
-        if (B <= SC_COOP_MAX_AGENTS) {
-            // latency-bound regime: 8 lanes per agent, 8 agents per wave
-            const unsigned nblk = (unsigned)((B + 7) / 8);
-            hipLaunchKernelGGL((cbfqp_coop_kernel<TIO, TC, MODEL>), dim3(nblk), dim3(64), 0, stream, p, B, K,
-                               (const TIO*)X, (const TIO*)u_ref, (const TIO*)obs, n_obs, (TIO*)u_out, status, (TIO*)h_out);
-            return hipGetLastError();
-        }
+        if (B <= sc_coop_max_agents())                    // latency-bound regime: 8 lanes per agent
+            return launch_coop<TIO, TC, 8, MODEL>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
         const unsigned threads = 256;
         const unsigned nblk = (unsigned)((B + threads - 1) / threads);
         hipLaunchKernelGGL((cbfqp_reg_kernel<TIO, TC, KMAX, MODEL>), dim3(nblk), dim3(threads), 0, stream, p, B, K,
                            (const TIO*)X, (const TIO*)u_ref, (const TIO*)obs, n_obs, (TIO*)u_out, status, (TIO*)h_out);
         return hipGetLastError();
     } else {
+    if (!sc_force_lds_kernel()) {                          // K > 8: one row per lane, 16 or 32 lanes per agent
+        if (K <= 16) return launch_coop<TIO, TC, 16, MODEL>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
+        return launch_coop<TIO, TC, 32, MODEL>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
+    }
     const unsigned blocks = (unsigned)((B + 63) / 64);
     size_t lds = (p.obs_shared ? (size_t)K * 7 : (size_t)64 * K * 7) * sizeof(TIO);
     lds = ((lds + 15) & ~(size_t)15) + (size_t)K * 3 * 64 * sizeof(TC) + (KMAX > 0 ? (size_t)K * 64 * sizeof(TIO) : 0);

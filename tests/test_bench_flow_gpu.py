@@ -1,0 +1,47 @@
+"""GPU-box tests of bench.py's control flow: the default N = 1 line carries every contract field, and the
+N = 2 path (one process per rank, barrier, max-over-ranks) runs end to end.  The box has ONE GPU, so the
+two ranks share it and rendezvous over gloo (SC_BENCH_BACKEND=gloo); RCCL itself is exercised only by the
+driver's multi-GPU runs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def last_json(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert lines, out
+    return json.loads(lines[-1])
+
+
+def test_single_gpu_line_has_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2",
+                        "--cpu-seconds", "1", "--no-sweep"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["unit"] == "solves/s" and d["vs_baseline"] is None
+    assert d["value"] > 1e5                          # BASELINE target: >= 100k CBF-QP solves/s on one MI355X
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    assert d["mpc_cbf"]["value"] > 5e3               # BASELINE target: >= 5k MPC-CBF (N = 10) solves/s
+
+
+def test_two_rank_flow_on_one_gpu():
+    env = dict(os.environ, SC_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "20", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["agents_per_gpu"] == 4096
+    assert abs(d["value"] - 2 * 4096 * 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-6

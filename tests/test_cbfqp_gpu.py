@@ -259,6 +259,42 @@ def test_golden_cases_through_dropin_class(golden_dir):
     assert ctl.status == "optimal"
 
 
+# ------------------------------------------------------------------ closed loop through the plugin surface
+@pytest.mark.parametrize("tag,model_name,steps", [("du14", "DynamicUnicycle2D", 700), ("du3", "DynamicUnicycle2D", 400),
+                                                  ("c3bf_dyn", "KinematicBicycle2D_C3BF", 160),
+                                                  ("dpcbf_dyn", "KinematicBicycle2D_DPCBF", 198)])
+def test_closed_loop_control_step_with_dropin_controller(golden_dir, tag, model_name, steps):
+    """BASELINE config 1 (examples/test_tracking.py --model du --algo cbf_qp) and the dynamic_env runs:
+    the control_step data flow (oracle/tracking.py, pinned to the reference's trajectories) with the HIP-backed
+    CBFQP class behind the boundary must reproduce the reference's closed-loop X and U."""
+    from oracle import tracking
+    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    model = {v: k for k, v in MODEL_NAME.items()}[model_name]
+    spec = du_spec() if model == R.MODEL_DU else kb_spec(model_name)
+    wps = g[f"{tag}/waypoints"]
+    robot = sca.RobotHandle(np.append(wps[0], 1.0), dict(spec), dt=0.05)
+    ctl = sca.CBFQP(robot, dict(spec), num_obs=10)
+
+    def solve_fn(X, control_ref, obs):
+        robot.X = np.asarray(X, dtype=np.float64).reshape(-1, 1)
+        u = ctl.solve_control_problem(robot.X, {"u_ref": np.asarray(control_ref["u_ref"]).reshape(2, 1)}, obs)
+        return (None if u is None else u.reshape(-1)), (0 if ctl.status == "optimal" else 1)
+
+    dyn = tag.endswith("_dyn")
+    obs0 = g[f"{tag}/obs0"] if dyn else g[f"{tag}/obs"]
+    t = tracking.TrackingOracle(model, np.append(wps[0], 1.0), {k: v for k, v in spec.items() if k != "model"}, dt=0.05,
+                                obs=obs0, num_constraints=10, dyn_obs=dyn, solve_fn=solve_fn)
+    t.set_waypoints(wps)
+    Xg, Ug, retg = g[f"{tag}/X"], g[f"{tag}/U"], g[f"{tag}/ret"]
+    for k in range(min(steps, len(retg))):
+        ret = t.control_step()
+        assert ret == retg[k], (k, ret, retg[k])
+        if ret != 0:
+            break
+        np.testing.assert_allclose(t.u_pos, Ug[k], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(t.X, Xg[k + 1], rtol=1e-6, atol=1e-6)
+
+
 # ------------------------------------------------------------------ full-size properties
 def _rows_du_circle(X, obs, R_, a1=1.5, a2=1.5):
     """fp64 torch restatement of the DU circle rows, only to verify constraint satisfaction at scale."""
