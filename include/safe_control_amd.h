@@ -166,6 +166,52 @@ int sc_mpccbf_solve_batch_host(const sc_mpccbf_params* params, int64_t B, int32_
                                void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out,
                                int device);
 
+/* ---- closed-loop control_step, fused -----------------------
+ * Runs `n_steps` iterations of LocalTrackingController.control_step (tracking.py:559-668; moving
+ * obstacles: dynamic_env/main.py:126-236) for B agents in ONE launch, with the CBF-QP solve behind
+ * the boundary: goal / state machine (tracking.py:497-535, :569-577), nearest-unpassed obstacle
+ * selection (:345-403), nominal input choice (:589-604; robots/<model>.py nominal_input / stop /
+ * rotate_to), CBFQP.solve_control_problem, collision checks (:445-495, :627-646), robot.step (:637)
+ * and the return code (:666-668).  Agent state stays in registers between steps.
+ */
+#define SC_SM_IDLE   0
+#define SC_SM_TRACK  1
+#define SC_SM_STOP   2
+#define SC_SM_ROTATE 3
+
+#define SC_TRACKING_MAX_CONSTRAINTS 16   /* num_constraints (reference default 10, tracking.py:134-138) */
+
+typedef struct sc_tracking_params {
+    sc_cbfqp_params qp;          /* the position controller (io_dtype applies to every float array) */
+    int32_t n_steps;             /* control steps in this launch                                    */
+    int32_t max_waypoints;       /* W: row count of `waypoints` per agent                           */
+    int32_t waypoints_shared;    /* 1: waypoints is [W,2] and n_wp is [1]; 0: [B,W,2] and [B]       */
+    int32_t enable_rotation;     /* LocalTrackingController(enable_rotation=...)                    */
+    int32_t dyn_obs;             /* 1: obstacle table moves obs[:,0:2] += obs[:,3:5]*dt after the
+                                    selection of each step (dynamic_env/main.py:54-58,147)          */
+    int32_t num_constraints;     /* K: rows of the CBF-QP (tracking.py:138)                         */
+    double  reached_threshold;   /* 0.3  (tracking.py:49)                                           */
+    double  rotation_threshold;  /* 0.1  (tracking.py:46)                                           */
+    double  v_max, v_min;        /* robot_spec: nominal-input saturation; KB step clips v to both   */
+    double  k_omega, k_a, k_v;   /* nominal_input gains as forwarded by BaseRobot (2, 1, 1)         */
+    double  delta_max;           /* KB family                                                       */
+    double  wheel_base;          /* KB family                                                       */
+} sc_tracking_params;
+
+/* X [B,4] in/out; waypoints [B,W,2] (or [W,2]); n_wp [B] (or [1]); wp_index [B] in/out;
+ * state_machine [B] in/out (SC_SM_*); goal [B,3] in/out = (gx, gy, valid);
+ * obs_table [M,7] in/out (shared by all agents; moved when dyn_obs); u_last [B,2] out;
+ * ret [B] in/out: 0 running, -1 all waypoints reached, -2 infeasible or collision (sticky: an agent
+ * whose ret != 0 is frozen); ret_step [B] out: step index (0-based, within this launch) at which ret
+ * turned non-zero, or -1; traj_X [n_steps,B,4], traj_U [n_steps,B,2] optional (NULL to skip):
+ * state AFTER each step and the input applied (rows of frozen agents repeat their last state).
+ */
+int sc_tracking_rollout_batch(const sc_tracking_params* params, int64_t B, int32_t M,
+                              void* X, const void* waypoints, const int32_t* n_wp,
+                              int32_t* wp_index, int32_t* state_machine, void* goal,
+                              void* obs_table, void* u_last, int32_t* ret, int32_t* ret_step,
+                              void* traj_X, void* traj_U, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

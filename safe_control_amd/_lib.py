@@ -53,6 +53,24 @@ class MpcCbfParams(C.Structure):
     ]
 
 
+SM_IDLE, SM_TRACK, SM_STOP, SM_ROTATE = 0, 1, 2, 3
+SM_NAMES = {0: "idle", 1: "track", 2: "stop", 3: "rotate"}
+TRACKING_MAX_CONSTRAINTS = 16
+
+
+class TrackingParams(C.Structure):
+    """Mirror of ``sc_tracking_params``."""
+    _fields_ = [
+        ("qp", CbfQpParams),
+        ("n_steps", C.c_int32), ("max_waypoints", C.c_int32), ("waypoints_shared", C.c_int32),
+        ("enable_rotation", C.c_int32), ("dyn_obs", C.c_int32), ("num_constraints", C.c_int32),
+        ("reached_threshold", C.c_double), ("rotation_threshold", C.c_double),
+        ("v_max", C.c_double), ("v_min", C.c_double),
+        ("k_omega", C.c_double), ("k_a", C.c_double), ("k_v", C.c_double),
+        ("delta_max", C.c_double), ("wheel_base", C.c_double),
+    ]
+
+
 # every symbol include/safe_control_amd.h declares, with its ctypes signature
 SYMBOLS = {
     "sc_version": (C.c_int, []),
@@ -65,6 +83,7 @@ SYMBOLS = {
     "sc_mpccbf_solve_batch": (C.c_int, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "sc_tracking_rollout_batch": (C.c_int, [C.POINTER(TrackingParams), C.c_int64, C.c_int32] + [C.c_void_p] * 13),
     "sc_mpccbf_solve_batch_host": (C.c_int, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int]),

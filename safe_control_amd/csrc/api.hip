@@ -15,6 +15,9 @@ hipError_t mpccbf_launch(const sc_mpccbf_params& p, long long B, int K, const vo
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                          hipStream_t stream);
 size_t mpccbf_lds_bytes(int N, int K);
+hipError_t tracking_launch(const sc_tracking_params& p, long long B, int M, void* X, const void* wps, const int* n_wp,
+                           int* wp_index, int* sm, void* goal, void* table, void* u_last, int* ret, int* ret_step,
+                           void* tX, void* tU, hipStream_t stream);
 
 static thread_local char g_err[256] = "";
 
@@ -191,6 +194,33 @@ int sc_mpccbf_solve_batch_host(const sc_mpccbf_params* params, int64_t B, int32_
     if (e != hipSuccess) rc = sc::fail_hip(e, "sc_mpccbf_solve_batch_host");
     (void)hipFree(d);
     return rc;
+}
+
+int sc_tracking_rollout_batch(const sc_tracking_params* params, int64_t B, int32_t M, void* X, const void* waypoints,
+                              const int32_t* n_wp, int32_t* wp_index, int32_t* state_machine, void* goal,
+                              void* obs_table, void* u_last, int32_t* ret, int32_t* ret_step, void* traj_X,
+                              void* traj_U, void* stream) {
+    if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    const sc_cbfqp_params* q = &params->qp;
+    if (B < 0 || M < 0) return sc::fail(SC_ERR_INVALID_ARGUMENT, "B < 0 or M < 0");
+    if (q->model_id < 0 || q->model_id > SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF)
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "unknown model_id");
+    if (q->io_dtype != SC_DTYPE_F32 && q->io_dtype != SC_DTYPE_F64)
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
+    if (params->num_constraints < 1 || params->num_constraints > SC_TRACKING_MAX_CONSTRAINTS)
+        return sc::fail(SC_ERR_UNSUPPORTED, "num_constraints outside [1, SC_TRACKING_MAX_CONSTRAINTS]");
+    if (params->n_steps < 0 || params->max_waypoints < 1) return sc::fail(SC_ERR_INVALID_ARGUMENT, "n_steps < 0 or max_waypoints < 1");
+    if (!(q->dt > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "dt must be > 0");
+    if (q->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && (!(q->rear_ax_dist > 0) || !(params->wheel_base > 0)))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "rear_ax_dist and wheel_base must be > 0 for the KinematicBicycle2D family");
+    if ((size_t)M * 7 * 8 > 160 * 1024) return sc::fail(SC_ERR_UNSUPPORTED, "obstacle table does not fit the LDS");
+    if (B > 0 && (!X || !waypoints || !n_wp || !wp_index || !state_machine || !goal || !u_last || !ret || !ret_step || (M > 0 && !obs_table)))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    if (B == 0 || params->n_steps == 0) return SC_OK;
+    hipError_t e = sc::tracking_launch(*params, (long long)B, (int)M, X, waypoints, n_wp, wp_index, state_machine, goal,
+                                       obs_table, u_last, ret, ret_step, traj_X, traj_U, (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "tracking kernel launch");
+    return SC_OK;
 }
 
 }  // extern "C"

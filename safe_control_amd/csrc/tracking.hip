@@ -1,0 +1,318 @@
+// Fused closed-loop control_step for B agents: one launch = n_steps iterations of
+//   LocalTrackingController.control_step        tracking.py:559-668
+//   LocalTrackingControllerDyn.control_step     dynamic_env/main.py:126-236 (moving obstacles)
+// with the CBF-QP row builders / solver of the solve kernels behind the boundary.  One agent per
+// lane; the agent's state (X, waypoint index, state machine, goal) lives in registers for the
+// whole rollout; the shared obstacle table lives in LDS (and moves there when dyn_obs).
+#include <hip/hip_runtime.h>
+
+#include "sc_qp2.hpp"
+
+namespace sc {
+
+template <typename TIO> struct tvec2;
+template <> struct tvec2<float> { using type = float2; };
+template <> struct tvec2<double> { using type = double2; };
+
+template <typename T>
+struct TrackConsts {
+    T reached, rot_thr, v_max, v_min, k_omega, k_a, k_v, delta_max, wheel_base, Lr, dt;
+    int enable_rotation, dyn_obs, K;
+};
+
+// nominal_input: DU robots/dynamic_unicycle2D.py:80-104 ; KB robots/kinematic_bicycle2D.py:125-147
+// (gains as BaseRobot forwards them, robots/robot.py:401-408)
+template <typename T, int MODEL>
+__device__ __forceinline__ void nominal_input(const T x, const T y, const T th, const T v, const T gx, const T gy,
+                                              const TrackConsts<T>& t, T& u0, T& u1) {
+    const T pi = T(3.14159265358979323846);
+    const T dx = x - gx, dy = y - gy;
+    const T dist = sqrt_(dx * dx + dy * dy);
+    const T err = angle_normalize(atan2_(gy - y, gx - x) - th);
+    T sn, cs;
+    sincos_(err, &sn, &cs);
+    if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) {
+        const T d = fmax_(dist - T(0.05), T(0));
+        const T vd = (fabs_(err) > pi / T(2)) ? T(0) : fmin_(t.k_v * d * cs, t.v_max);
+        u0 = t.k_a * (vd - v);
+        u1 = t.k_omega * err;
+    } else {
+        const T d = fmax_(dist - T(0.05), T(0.05));
+        const T delta = fmin_(fmax_(t.k_omega * err, -t.delta_max), t.delta_max);
+        u1 = atan(double((t.Lr / t.wheel_base) * tan(double(delta))));
+        const T vcmd = t.k_v * d * fmax_(T(0), cs);
+        const T vd = fmin_(fmax_(vcmd, t.v_min), t.v_max);
+        u0 = t.k_a * (vd - v);
+    }
+}
+
+// tracking.py:445-495 known-obstacle collision test (circle / superellipsoid, geometry rule :428-443)
+template <typename T>
+__device__ __forceinline__ bool collides(const T x, const T y, const T* table, int M, T R) {
+    bool hit = false;
+    for (int m = 0; m < M; ++m) {
+        const T* o = table + 7 * m;
+        const bool superell = (fabs_(o[6] - T(1)) <= T(1e-8) + T(1e-5)) && (o[4] >= T(2));     // np.isclose(flag, 1)
+        if (!superell) {
+            const T dx = x - o[0], dy = y - o[1];
+            hit |= sqrt_(dx * dx + dy * dy) < o[2] + R;
+        } else {
+            T st, ct;
+            sincos_(o[5], &st, &ct);
+            const T px = ct * (x - o[0]) + st * (y - o[1]);
+            const T py = -st * (x - o[0]) + ct * (y - o[1]);
+            const T h = pow_(px / (o[2] + R), o[4]) + pow_(py / (o[3] + R), o[4]) - T(1);
+            hit |= h <= T(0);
+        }
+    }
+    return hit;
+}
+
+template <typename TIO, typename TC, int KMAX, int MODEL>
+__global__ __launch_bounds__(64) void tracking_rollout_kernel(
+        const sc_tracking_params p, const long long B, const int M,
+        TIO* __restrict__ X, const TIO* __restrict__ waypoints, const int* __restrict__ n_wp,
+        int* __restrict__ wp_index, int* __restrict__ state_machine, TIO* __restrict__ goal,
+        TIO* __restrict__ obs_table, TIO* __restrict__ u_last, int* __restrict__ ret_out, int* __restrict__ ret_step,
+        TIO* __restrict__ traj_X, TIO* __restrict__ traj_U) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    TC* table = reinterpret_cast<TC*>(smem_raw);                     // [M][7]
+    const int lane = threadIdx.x;
+    const long long agent = (long long)blockIdx.x * 64 + lane;
+    const bool active = agent < B;
+    const long long ag = active ? agent : 0;
+
+    for (int e = lane; e < M * 7; e += 64) table[e] = TC(obs_table[e]);
+    __syncthreads();
+
+    const CbfConsts<TC> k = make_consts<TC>(p.qp);
+    TrackConsts<TC> t;
+    t.reached = TC(p.reached_threshold); t.rot_thr = TC(p.rotation_threshold);
+    t.v_max = TC(p.v_max); t.v_min = TC(p.v_min);
+    t.k_omega = TC(p.k_omega); t.k_a = TC(p.k_a); t.k_v = TC(p.k_v);
+    t.delta_max = TC(p.delta_max); t.wheel_base = TC(p.wheel_base); t.Lr = TC(p.qp.rear_ax_dist); t.dt = TC(p.qp.dt);
+    t.enable_rotation = p.enable_rotation; t.dyn_obs = p.dyn_obs; t.K = p.num_constraints;
+    const TC pi = TC(3.14159265358979323846);
+    const TC half_unpassed = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? TC(1.2) * pi / TC(2) : pi;   // tracking.py:352-357
+
+    // ---- agent state -> registers ------------------------------------------------------------
+    TC x = TC(X[ag * 4 + 0]), y = TC(X[ag * 4 + 1]), th = TC(X[ag * 4 + 2]), v = TC(X[ag * 4 + 3]);
+    int wp = wp_index[ag], sm = state_machine[ag];
+    TC gx = TC(goal[ag * 3 + 0]), gy = TC(goal[ag * 3 + 1]);
+    bool gvalid = goal[ag * 3 + 2] != TIO(0);
+    int ret = active ? ret_out[ag] : -2;
+    int rstep = -1;
+    const int W = p.max_waypoints;
+    const TIO* wps = waypoints + (p.waypoints_shared ? 0 : (size_t)ag * W * 2);
+    const int nw = n_wp[p.waypoints_shared ? 0 : ag];
+    TC ul0 = TC(0), ul1 = TC(0);
+
+    auto wp_x = [&](int i) { return TC(wps[2 * i]); };
+    auto wp_y = [&](int i) { return TC(wps[2 * i + 1]); };
+
+    // tracking.py:497-535
+    auto update_goal = [&]() {
+        if (sm == SC_SM_ROTATE) {
+            const int i = wp < nw ? wp : nw - 1;
+            const TC rx = wp_x(i), ry = wp_y(i);
+            const TC goal_angle = atan2_(ry - y, rx - x);
+            if (!t.enable_rotation) sm = SC_SM_TRACK;
+            if (fabs_(th - goal_angle) > t.rot_thr) { gx = rx; gy = ry; gvalid = true; return; }
+            sm = SC_SM_TRACK;
+        }
+        if (wp >= nw) { gvalid = false; return; }
+        {
+            const TC dx = x - wp_x(wp), dy = y - wp_y(wp);
+            if (sqrt_(dx * dx + dy * dy) < t.reached) {
+                wp += 1;
+                if (wp >= nw) { sm = SC_SM_IDLE; gvalid = false; return; }
+            }
+        }
+        gx = wp_x(wp); gy = wp_y(wp); gvalid = true;
+    };
+
+    for (int step = 0; step < p.n_steps; ++step) {
+        const bool run = (ret == 0);
+        if (run) {
+            // ---- state machine / goal (tracking.py:569-577) ----------------------------------
+            if (sm == SC_SM_STOP) {
+                if (fabs_(v) < TC(0.05)) {
+                    sm = t.enable_rotation ? SC_SM_ROTATE : SC_SM_TRACK;
+                    update_goal();
+                }
+            } else {
+                update_goal();
+            }
+        }
+        // ---- nearest unpassed obstacles (tracking.py:345-403): K smallest centre distances ------
+        TC sd[KMAX];
+        int si[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) { sd[j] = num<TC>::inf(); si[j] = -1; }
+        int n_unpassed = 0;
+        for (int m = 0; m < M; ++m) {
+            const TC ang = atan2_(table[7 * m + 1] - y, table[7 * m] - x);
+            n_unpassed += (fabs_(angle_normalize(ang - th)) <= half_unpassed) ? 1 : 0;
+        }
+        const bool use_all = n_unpassed == 0;
+        for (int m = 0; m < M; ++m) {
+            const TC ox = table[7 * m], oy = table[7 * m + 1];
+            const TC ang = atan2_(oy - y, ox - x);
+            const bool pass = use_all || (fabs_(angle_normalize(ang - th)) <= half_unpassed);
+            const TC dx = ox - x, dy = oy - y;
+            TC cd = pass ? sqrt_(dx * dx + dy * dy) : num<TC>::inf();
+            int ci = pass ? m : -1;
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {
+                const bool sw = cd < sd[j];
+                const TC td = sd[j]; const int ti = si[j];
+                sd[j] = sw ? cd : td; si[j] = sw ? ci : ti;
+                cd = sw ? td : cd; ci = sw ? ti : ci;
+            }
+        }
+        // ---- rows in registers (selection order = distance order, as the reference passes them) ---
+        const Agent<TC> agn = make_agent<TC>(x, y, th, v);
+        TC n0[KMAX], n1[KMAX], c[KMAX];
+        bool bad_obs = false;
+        TC poison = TC(0);
+        int nk = 0;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            const bool used = (j < t.K) && (si[j] >= 0);
+            nk += used ? 1 : 0;
+            const TC* orow = table + 7 * (si[j] >= 0 ? si[j] : 0);
+            TC o[7];
+#pragma unroll
+            for (int f = 0; f < 7; ++f) o[f] = orow[f];
+            TC h, a0, a1, cc;
+            const bool ok = cbf_row<TC, MODEL, true>(agn, o, k, a0, a1, cc, h);
+            bad_obs |= used && !ok;
+            a0 = used ? a0 : TC(0); a1 = used ? a1 : TC(0); cc = used ? cc : TC(0);
+            normalise_row(a0, a1, cc, poison);
+            n0[j] = a0; n1[j] = a1; c[j] = cc;
+        }
+        // moving obstacles advance AFTER the selection (dynamic_env/main.py:147-150): the solve sees the old table
+        __syncthreads();
+        if (t.dyn_obs) {
+            for (int m = lane; m < M; m += 64) {
+                table[7 * m] += table[7 * m + 3] * t.dt;
+                table[7 * m + 1] += table[7 * m + 4] * t.dt;
+            }
+        }
+        __syncthreads();
+        // ---- nominal input (tracking.py:589-604) ------------------------------------------------
+        TC ur0, ur1;
+        if (sm == SC_SM_ROTATE) {
+            const TC ga = atan2_(gy - y, gx - x);
+            ur0 = TC(0); ur1 = TC(2) * angle_normalize(ga - th);           // rotate_to, k = 2
+        } else if (!gvalid) {
+            ur0 = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? t.k_a * (TC(0) - v) : TC(0);   // stop()
+            ur1 = TC(0);
+        } else {
+            nominal_input<TC, MODEL>(x, y, th, v, gx, gy, t, ur0, ur1);
+        }
+        // ---- solve (cbf_qp.py:108-199) -----------------------------------------------------------
+        TC u0, u1;
+        int st;
+        if (M == 0) { u0 = ur0; u1 = ur1; st = SC_STATUS_OPTIMAL; }         // obs_list None: u_ref unclipped
+        else {
+            st = qp2_solve<TC, KMAX>(n0, n1, c, t.K, ur0, ur1, poison, k, u0, u1);
+            if (bad_obs) st = SC_STATUS_BAD_OBSTACLE;
+        }
+        // ---- collision / status / step (tracking.py:627-646) ---------------------------------------
+        // pre-step: infeasible or already colliding -> -2, the robot does not move
+        const bool pre_fail = (st != SC_STATUS_OPTIMAL) || collides<TC>(x, y, table, M, k.R);
+        TC nx, ny, nth, nv;
+        if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) {
+            nx = x + (agn.f0) * t.dt; ny = y + (agn.f1) * t.dt;
+            nth = th + (TC(0) + u1) * t.dt; nv = v + (TC(0) + u0) * t.dt;
+        } else {
+            nx = x + (agn.f0 + (-agn.f1) * u1) * t.dt;
+            ny = y + (agn.f1 + agn.f0 * u1) * t.dt;
+            nth = th + (TC(0) + (v / t.Lr) * u1) * t.dt;
+            nv = v + (TC(0) + u0) * t.dt;
+            nv = fmin_(fmax_(nv, t.v_min), t.v_max);                        // np.clip in KinematicBicycle2D.step
+        }
+        nth = angle_normalize(nth);
+        int code;
+        if (pre_fail) code = -2;
+        else if (collides<TC>(nx, ny, table, M, k.R)) code = -2;             // post-step: the robot HAS moved
+        else code = (!gvalid && sm != SC_SM_STOP) ? -1 : 0;                  // tracking.py:666-667
+        if (run) {
+            if (!pre_fail) { x = nx; y = ny; th = nth; v = nv; ul0 = u0; ul1 = u1; }
+            if (code != 0) { ret = code; rstep = step; }
+        }
+        if (active && traj_X) {
+            TIO* tx = traj_X + ((size_t)step * B + agent) * 4;
+            tx[0] = TIO(x); tx[1] = TIO(y); tx[2] = TIO(th); tx[3] = TIO(v);
+        }
+        if (active && traj_U) {
+            TIO* tu = traj_U + ((size_t)step * B + agent) * 2;
+            tu[0] = TIO(ul0); tu[1] = TIO(ul1);
+        }
+    }
+
+    if (active) {
+        X[agent * 4 + 0] = TIO(x); X[agent * 4 + 1] = TIO(y); X[agent * 4 + 2] = TIO(th); X[agent * 4 + 3] = TIO(v);
+        wp_index[agent] = wp; state_machine[agent] = sm;
+        goal[agent * 3 + 0] = TIO(gx); goal[agent * 3 + 1] = TIO(gy); goal[agent * 3 + 2] = gvalid ? TIO(1) : TIO(0);
+        u_last[agent * 2 + 0] = TIO(ul0); u_last[agent * 2 + 1] = TIO(ul1);
+        ret_out[agent] = ret; ret_step[agent] = rstep;
+    }
+    if (blockIdx.x == 0 && t.dyn_obs) {
+        __syncthreads();
+        for (int e = lane; e < M * 7; e += 64) obs_table[e] = TIO(table[e]);
+    }
+}
+
+template <typename TIO, typename TC, int KMAX, int MODEL>
+static hipError_t launch_track(const sc_tracking_params& p, long long B, int M, void* X, const void* wps, const int* n_wp,
+                               int* wp_index, int* sm, void* goal, void* table, void* u_last, int* ret, int* ret_step,
+                               void* tX, void* tU, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((B + 63) / 64);
+    const size_t lds = (size_t)(M > 0 ? M : 1) * 7 * sizeof(TC);
+    auto kern = tracking_rollout_kernel<TIO, TC, KMAX, MODEL>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, p, B, M, (TIO*)X, (const TIO*)wps, n_wp, wp_index, sm,
+                       (TIO*)goal, (TIO*)table, (TIO*)u_last, ret, ret_step, (TIO*)tX, (TIO*)tU);
+    return hipGetLastError();
+}
+
+template <typename TIO, typename TC, int MODEL>
+static hipError_t launch_track_k(const sc_tracking_params& p, long long B, int M, void* X, const void* wps, const int* n_wp,
+                                 int* wp_index, int* sm, void* goal, void* table, void* u_last, int* ret, int* ret_step,
+                                 void* tX, void* tU, hipStream_t stream) {
+    if (p.num_constraints <= 8)
+        return launch_track<TIO, TC, 8, MODEL>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+    return launch_track<TIO, TC, 16, MODEL>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+}
+
+template <typename TIO, typename TC>
+static hipError_t launch_track_m(const sc_tracking_params& p, long long B, int M, void* X, const void* wps, const int* n_wp,
+                                 int* wp_index, int* sm, void* goal, void* table, void* u_last, int* ret, int* ret_step,
+                                 void* tX, void* tU, hipStream_t stream) {
+    switch (p.qp.model_id) {
+        case SC_MODEL_DYNAMIC_UNICYCLE2D:
+            return launch_track_k<TIO, TC, SC_MODEL_DYNAMIC_UNICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+        case SC_MODEL_KINEMATIC_BICYCLE2D:
+            return launch_track_k<TIO, TC, SC_MODEL_KINEMATIC_BICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+        case SC_MODEL_KINEMATIC_BICYCLE2D_C3BF:
+            return launch_track_k<TIO, TC, SC_MODEL_KINEMATIC_BICYCLE2D_C3BF>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+        default:
+            return launch_track_k<TIO, TC, SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+    }
+}
+
+hipError_t tracking_launch(const sc_tracking_params& p, long long B, int M, void* X, const void* wps, const int* n_wp,
+                           int* wp_index, int* sm, void* goal, void* table, void* u_last, int* ret, int* ret_step,
+                           void* tX, void* tU, hipStream_t stream) {
+    // closed loops amplify rounding: arithmetic is always f64 here; storage follows io_dtype
+    if (p.qp.io_dtype == SC_DTYPE_F32)
+        return launch_track_m<float, double>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+    return launch_track_m<double, double>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+}
+
+}  // namespace sc

@@ -1,0 +1,200 @@
+"""Batched closed-loop tracking controller backed by the fused rollout kernel (csrc/tracking.hip).
+
+``BatchedTrackingController`` is the many-agent counterpart of the reference's
+``LocalTrackingController`` (tracking.py:36-756) for the part of ``control_step`` that surrounds the
+solve: goal / state machine, nearest-unpassed obstacle selection, nominal input, CBF-QP, collision
+checks, robot step and return code all run on the GPU, ``n`` control steps per launch, with every
+agent's state resident in registers between steps.  Rendering, sensing footprints, unknown-obstacle
+detection and attitude controllers are out of scope.
+
+Host side (this file) only prepares waypoints the way ``set_waypoints`` / ``filter_waypoints`` do
+(tracking.py:197-249) and owns the device tensors.  No CPU fallback.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from .position_control.cbf_qp import apply_cbf_overrides, default_cbf_param, make_params
+from .robots.spec import complete_robot_spec
+
+
+def _wrap(a):
+    return ((a + math.pi) % (2.0 * math.pi)) - math.pi
+
+
+class BatchedTrackingController:
+    """B agents, one shared obstacle table ``obs [M,7]`` (known obstacles, tracking.py:113), one
+    waypoint list per agent (or one shared list).
+
+    ``control_step(n=1)`` advances every running agent ``n`` steps and returns the per-agent return
+    codes (0 running, -1 all waypoints reached, -2 infeasible QP or collision; sticky), like
+    ``LocalTrackingController.control_step`` does for one robot.
+    """
+
+    def __init__(self, X0, robot_spec, controller_type=None, dt=0.05, enable_rotation=True, obs=None,
+                 dyn_obs=False, io_dtype="f64", device="cuda:0"):
+        import torch
+        self.torch = torch
+        controller_type = controller_type or {"pos": "cbf_qp"}
+        if controller_type.get("pos", "cbf_qp") != "cbf_qp":
+            raise ValueError("the fused rollout implements the 'cbf_qp' position controller")
+        self.robot_spec = complete_robot_spec(robot_spec)
+        self.robot_spec.setdefault("exploration", False)
+        self.model = self.robot_spec["model"]
+        self.dt = float(dt)
+        self.enable_rotation = bool(enable_rotation)
+        self.dyn_obs = bool(dyn_obs)
+        self.device = torch.device(device)
+        self.io_dtype = {"f32": _lib.DTYPE_F32, "f64": _lib.DTYPE_F64}[io_dtype]
+        self.tdtype = torch.float32 if io_dtype == "f32" else torch.float64
+        self.num_constraints = int(self.robot_spec.get("num_constraints", 10))          # tracking.py:134-138
+        self.reached_threshold = float(self.robot_spec.get("reached_threshold", 0.3))    # tracking.py:49-54
+        self.rotation_threshold = 0.1                                                    # tracking.py:46
+        self.fov_angle = math.radians(float(self.robot_spec.get("fov_angle", 70.0)))      # robots/robot.py:53-54
+        self.cbf_param = apply_cbf_overrides(default_cbf_param(self.model), self.robot_spec)
+        self._lib = _lib.load()
+
+        X0 = np.asarray(X0, dtype=np.float64)
+        if X0.ndim == 1:
+            X0 = X0[None, :]
+        if X0.shape[1] == 3:                                   # tracking.py:66-68: initial speed 0
+            X0 = np.hstack([X0, np.zeros((X0.shape[0], 1))])
+        self.B = X0.shape[0]
+        t = lambda a, dt_=None: torch.tensor(a, dtype=dt_ or self.tdtype, device=self.device)
+        self.X = t(X0)
+        self.state_machine = torch.zeros(self.B, dtype=torch.int32, device=self.device)      # 'idle'
+        self.current_goal_index = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self.goal = torch.zeros((self.B, 3), dtype=self.tdtype, device=self.device)          # gx, gy, valid
+        self.ret = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self.ret_step = torch.full((self.B,), -1, dtype=torch.int32, device=self.device)
+        self.u_pos = torch.zeros((self.B, 2), dtype=self.tdtype, device=self.device)
+        self.set_obstacles(obs)
+        self.waypoints = None
+        self.n_wp = None
+        self.steps_done = 0
+
+    # -- obstacles -----------------------------------------------------------------------------
+    def set_obstacles(self, obs):
+        torch = self.torch
+        if obs is None or len(obs) == 0:
+            self.obs = torch.zeros((0, 7), dtype=self.tdtype, device=self.device)
+            return
+        obs = np.asarray(obs, dtype=np.float64)
+        if obs.shape[1] < 7:                                   # examples/test_tracking.py:147-148
+            obs = np.hstack([obs, np.zeros((obs.shape[0], 7 - obs.shape[1]))])
+        self.obs = torch.tensor(obs[:, :7], dtype=self.tdtype, device=self.device).contiguous()
+
+    # -- waypoints: set_waypoints / filter_waypoints / first update_goal (tracking.py:197-249, 497-535) --
+    def set_waypoints(self, waypoints):
+        torch = self.torch
+        X = self.X.double().cpu().numpy()
+        # one list of [x, y(, theta)] rows shared by every agent, or one such list per agent
+        shared = (isinstance(waypoints, np.ndarray) and waypoints.ndim == 2) or \
+            (isinstance(waypoints, (list, tuple)) and len(waypoints) > 0 and np.ndim(waypoints[0]) == 1)
+        lists = [np.asarray(waypoints, dtype=np.float64)] * self.B if shared else \
+            [np.asarray(w, dtype=np.float64) for w in waypoints]
+        filt = []
+        for i in range(self.B):
+            wp = lists[i]
+            if len(wp) >= 2:                                   # filter_waypoints
+                aug = np.vstack((X[i, :2], wp[:, :2]))
+                dist = np.linalg.norm(np.diff(aug, axis=0), axis=1)
+                mask = np.concatenate(([False], dist >= self.reached_threshold))
+                wp = aug[mask]
+            filt.append(np.asarray(wp, dtype=np.float64)[:, :2].reshape(-1, 2))
+        W = max(1, max(len(w) for w in filt))
+        wps = np.zeros((self.B, W, 2))
+        n_wp = np.zeros(self.B, dtype=np.int32)
+        idx = np.zeros(self.B, dtype=np.int32)
+        sm = np.zeros(self.B, dtype=np.int32)
+        goal = np.zeros((self.B, 3))
+        for i in range(self.B):
+            w = filt[i]
+            n_wp[i] = len(w)
+            wps[i, : len(w)] = w
+            # update_goal with state machine 'idle' (tracking.py:517-535)
+            g = None
+            if len(w) > 0:
+                if np.linalg.norm(X[i, :2] - w[0]) < self.reached_threshold:
+                    idx[i] = 1
+                if idx[i] < len(w):
+                    g = w[idx[i]]
+            if g is not None:                                   # tracking.py:214-226
+                ang = math.atan2(g[1] - X[i, 1], g[0] - X[i, 0])
+                in_fov = abs(_wrap(ang - X[i, 2])) <= self.fov_angle / 2
+                if not in_fov:
+                    if self.robot_spec["exploration"]:
+                        sm[i] = _lib.SM_ROTATE
+                        goal[i] = [g[0], g[1], 1.0]
+                    else:
+                        sm[i] = _lib.SM_STOP
+                else:
+                    sm[i] = _lib.SM_TRACK
+                    goal[i] = [g[0], g[1], 1.0]
+        self.waypoints = torch.tensor(wps, dtype=self.tdtype, device=self.device).contiguous()
+        self.n_wp = torch.tensor(n_wp, dtype=torch.int32, device=self.device)
+        self.current_goal_index = torch.tensor(idx, dtype=torch.int32, device=self.device)
+        self.state_machine = torch.tensor(sm, dtype=torch.int32, device=self.device)
+        self.goal = torch.tensor(goal, dtype=self.tdtype, device=self.device).contiguous()
+        self.ret.zero_()
+        self.ret_step.fill_(-1)
+
+    # -- params --------------------------------------------------------------------------------
+    def _params(self, n_steps):
+        rs = self.robot_spec
+        p = _lib.TrackingParams()
+        p.qp = make_params(rs, self.cbf_param, self.dt, rs["radius"], self.io_dtype, _lib.DTYPE_F64)
+        p.n_steps = int(n_steps)
+        p.max_waypoints = int(self.waypoints.shape[1])
+        p.waypoints_shared = 0
+        p.enable_rotation = 1 if self.enable_rotation else 0
+        p.dyn_obs = 1 if self.dyn_obs else 0
+        p.num_constraints = self.num_constraints
+        p.reached_threshold = self.reached_threshold
+        p.rotation_threshold = self.rotation_threshold
+        p.v_max = float(rs["v_max"])
+        p.v_min = float(rs.get("v_min", 0.0))
+        if self.model == "DynamicUnicycle2D":                   # robots/dynamic_unicycle2D.py:84-86
+            p.k_omega = float(rs.get("nominal_k_omega", 2.0))
+            p.k_a = float(rs.get("nominal_k_a", 1.0))
+            p.k_v = float(rs.get("nominal_k_v", 1.0))
+        else:                                                   # forwarded positionally by BaseRobot (robot.py:401-408)
+            p.k_omega, p.k_a, p.k_v = 2.0, 1.0, 1.0
+        p.delta_max = float(rs.get("delta_max", 0.0))
+        p.wheel_base = float(rs.get("wheel_base", 0.0))
+        return p
+
+    # -- stepping -------------------------------------------------------------------------------
+    def control_step(self, n=1, record=False):
+        """Advance ``n`` control steps in one launch.  Returns ``ret`` [B] (and ``(traj_X [n,B,4],
+        traj_U [n,B,2])`` when ``record``)."""
+        torch = self.torch
+        if self.waypoints is None:
+            raise RuntimeError("call set_waypoints first")
+        p = self._params(n)
+        tX = torch.empty((n, self.B, 4), dtype=self.tdtype, device=self.device) if record else None
+        tU = torch.empty((n, self.B, 2), dtype=self.tdtype, device=self.device) if record else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._lib.sc_tracking_rollout_batch(
+            C.byref(p), self.B, int(self.obs.shape[0]), self.X.data_ptr(), self.waypoints.data_ptr(),
+            self.n_wp.data_ptr(), self.current_goal_index.data_ptr(), self.state_machine.data_ptr(),
+            self.goal.data_ptr(), self.obs.data_ptr() if self.obs.shape[0] else None, self.u_pos.data_ptr(),
+            self.ret.data_ptr(), self.ret_step.data_ptr(),
+            tX.data_ptr() if record else None, tU.data_ptr() if record else None, stream)
+        _lib.check(rc, "sc_tracking_rollout_batch")
+        self.steps_done += n
+        return (self.ret, tX, tU) if record else self.ret
+
+    def run_all_steps(self, tf=30, chunk=200):
+        """tracking.py:711-752 for every agent: run int(tf/dt) steps (agents stop at their first -1 / -2)."""
+        total = int(tf / self.dt)
+        done = 0
+        while done < total:
+            n = min(chunk, total - done)
+            self.control_step(n)
+            done += n
+            if bool((self.ret != 0).all().item()):
+                break
+        return self.ret

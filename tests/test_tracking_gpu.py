@@ -1,0 +1,111 @@
+"""GPU tests of the fused closed-loop rollout (csrc/tracking.hip) against oracle/tracking.py, which is
+itself pinned to the reference's closed-loop trajectories (tests/test_oracle_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import robots as R, tracking  # noqa: E402
+import safe_control_amd as sca  # noqa: E402
+
+DEV = "cuda:0"
+SM = {"idle": 0, "track": 1, "stop": 2, "rotate": 3}
+
+
+def oracle_rollout(model, X0, spec, obs, wps, T, dyn=False, num_constraints=10):
+    t = tracking.TrackingOracle(model, X0, spec, dt=0.05, obs=obs, num_constraints=num_constraints, dyn_obs=dyn)
+    t.set_waypoints(wps)
+    Xs, rets = [], []
+    for k in range(T):
+        ret = t.control_step()
+        Xs.append(t.X.copy()); rets.append(ret)
+        if ret != 0:
+            break
+    return np.array(Xs), rets, t
+
+
+def test_reference_config1_scene_single_agent(golden_dir):
+    """examples/test_tracking.py --model du --algo cbf_qp: the reference's own trajectory, 700 steps in 4 launches."""
+    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    wps = g["du14/waypoints"]
+    spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}
+    ctl = sca.BatchedTrackingController(np.append(wps[0], 1.0)[None, :], spec, obs=g["du14/obs"], io_dtype="f64")
+    ctl.set_waypoints(wps)
+    Xg, Ug, retg = g["du14/X"], g["du14/U"], g["du14/ret"]
+    done = 0
+    for n in (1, 199, 250, 250):
+        ret, tX, tU = ctl.control_step(n, record=True)
+        tX = tX.cpu().numpy()[:, 0]; tU = tU.cpu().numpy()[:, 0]
+        np.testing.assert_allclose(tX, Xg[done + 1: done + n + 1], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(tU, Ug[done: done + n], rtol=1e-6, atol=1e-6)
+        done += n
+    assert int(ret[0].item()) == 0 and np.all(retg[:700] == 0)
+
+
+@pytest.mark.parametrize("model_name,tag", [("KinematicBicycle2D_C3BF", "c3bf_dyn"), ("KinematicBicycle2D_DPCBF", "dpcbf_dyn")])
+def test_reference_moving_obstacle_runs(golden_dir, model_name, tag):
+    """dynamic_env/main.py scenario: obstacles move after the selection of each step; run ends with -1."""
+    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    wps = g[f"{tag}/waypoints"]
+    spec = {"model": model_name, "a_max": 5.0, "radius": 0.3}
+    ctl = sca.BatchedTrackingController(np.append(wps[0], 1.0)[None, :], spec, obs=g[f"{tag}/obs0"], dyn_obs=True)
+    ctl.set_waypoints(wps)
+    Xg, retg = g[f"{tag}/X"], g[f"{tag}/ret"]
+    T = len(retg)
+    ret, tX, tU = ctl.control_step(T + 5, record=True)
+    tX = tX.cpu().numpy()[:, 0]
+    np.testing.assert_allclose(tX[:T], Xg[1: T + 1], rtol=1e-6, atol=1e-6)
+    assert int(ret[0].item()) == -1 and int(ctl.ret_step[0].item()) == T - 1
+    np.testing.assert_allclose(tX[T:], np.repeat(Xg[T][None], 5, 0), atol=1e-9)     # frozen after finishing
+    np.testing.assert_allclose(ctl.obs.cpu().numpy(), g[f"{tag}/obs_final"] + 5 * 0.05 * np.pad(g[f"{tag}/obs0"][:, 3:5], ((0, 0), (0, 5)))[:, [0, 1, 2, 3, 4, 5, 6]] * 0
+                               + np.hstack([5 * 0.05 * g[f"{tag}/obs0"][:, 3:5], np.zeros((8, 5))]), atol=1e-9)
+
+
+def test_many_agents_static_scene_against_oracle(golden_dir):
+    """48 agents scattered over the config-1 scene, each with its own start pose and waypoint list."""
+    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    obs = g["du14/obs"]
+    rng = np.random.default_rng(42)
+    B, T = 48, 260
+    spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}
+    X0, wlists = [], []
+    while len(X0) < B:
+        p = rng.uniform(0.5, 13.5, 2)
+        if np.min(np.hypot(obs[:, 0] - p[0], obs[:, 1] - p[1]) - obs[:, 2]) < 0.6:
+            continue
+        X0.append([p[0], p[1], rng.uniform(-np.pi, np.pi), rng.uniform(0, 1)])
+        wlists.append(rng.uniform(1, 13, (int(rng.integers(1, 4)), 2)))
+    X0 = np.array(X0)
+    ctl = sca.BatchedTrackingController(X0, dict(spec), obs=obs, io_dtype="f64")
+    ctl.set_waypoints(wlists)
+    ret, tX, tU = ctl.control_step(T, record=True)
+    tX = tX.cpu().numpy(); ret = ret.cpu().numpy(); rstep = ctl.ret_step.cpu().numpy()
+    ospec = {k: v for k, v in spec.items() if k != "model"}
+    n_finished = n_failed = 0
+    for i in range(B):
+        Xo, rets, t = oracle_rollout(R.MODEL_DU, X0[i], ospec, obs, wlists[i], T)
+        n = len(rets)
+        np.testing.assert_allclose(tX[:n, i], Xo, rtol=1e-6, atol=1e-6, err_msg=f"agent {i}")
+        if rets[-1] != 0:
+            assert ret[i] == rets[-1] and rstep[i] == n - 1, (i, ret[i], rets[-1], rstep[i], n)
+            n_finished += rets[-1] == -1; n_failed += rets[-1] == -2
+        else:
+            assert ret[i] == 0
+        assert int(ctl.state_machine[i].item()) == SM[t.state_machine]
+        assert int(ctl.current_goal_index[i].item()) == t.current_goal_index
+    assert n_finished > 0            # the scenario exercises the finished (-1) path; failures (-2) may or may not occur
+
+
+def test_no_obstacles_passes_u_ref_through():
+    """obs_list None -> u = u_ref, unclipped (cbf_qp.py:113-118): the agent just follows the nominal controller."""
+    spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}
+    X0 = np.array([[1.0, 1.0, 0.2, 0.0]])
+    wps = np.array([[6.0, 2.0], [6.0, 6.0]])
+    ctl = sca.BatchedTrackingController(X0, dict(spec), obs=None)
+    ctl.set_waypoints(wps)
+    ret, tX, tU = ctl.control_step(100, record=True)
+    Xo, rets, t = oracle_rollout(R.MODEL_DU, X0[0], {k: v for k, v in spec.items() if k != "model"}, None, wps, 100)
+    np.testing.assert_allclose(tX.cpu().numpy()[: len(rets), 0], Xo, rtol=1e-7, atol=1e-7)
