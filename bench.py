@@ -117,6 +117,46 @@ def mpc_leg(dev, B, K, N, steps, warmup, seed=0):
             "achieved_GBs": nbytes / (ms * 1e-3) / 1e9, "algorithmic_bytes_per_solve": nbytes // B}
 
 
+def closed_loop_leg(dev, B=4096, T=200, seed=0):
+    """BASELINE config 2, closed-loop variant: B DynamicUnicycle2D agents track waypoints through the 14-circle
+    scene of examples/test_tracking.py for T control steps (selection + nominal input + CBF-QP + step + collision
+    check per step) in ONE launch of the fused rollout kernel."""
+    import numpy as np
+    import torch
+    import safe_control_amd as sca
+    obs = np.array([[2.2, 5.0, 0.2], [3.0, 5.0, 0.2], [4.0, 9.0, 0.3], [1.5, 10.0, 0.5], [9.0, 11.0, 1.0], [7.0, 7.0, 3.0],
+                    [4.0, 3.5, 1.5], [10.0, 7.3, 0.4], [6.0, 13.0, 0.7], [5.0, 10.0, 0.6], [11.0, 5.0, 0.8],
+                    [13.5, 11.0, 0.6], [2.0, 7.0, 0.7], [2.0, 8.0, 0.5]])
+    rng = np.random.default_rng(seed)
+    X0 = np.zeros((0, 4))
+    while len(X0) < B:                                                    # collision-free start poses
+        p = rng.uniform(0.5, 13.5, (2 * B, 2))
+        ok = np.min(np.hypot(obs[None, :, 0] - p[:, None, 0], obs[None, :, 1] - p[:, None, 1]) - obs[None, :, 2], axis=1) > 0.6
+        p = p[ok]
+        X0 = np.vstack([X0, np.hstack([p, rng.uniform(-np.pi, np.pi, (len(p), 1)), rng.uniform(0, 1, (len(p), 1))])])
+    X0 = X0[:B]
+    wps = [rng.uniform(1, 13, (3, 2)) for _ in range(B)]
+    spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}
+    ctl = sca.BatchedTrackingController(X0, dict(spec), obs=obs, io_dtype="f32", device=str(dev))
+    ctl.set_waypoints(wps)
+    ctl.control_step(1)                                                   # warm-up launch
+    torch.cuda.synchronize()
+    ctl = sca.BatchedTrackingController(X0, dict(spec), obs=obs, io_dtype="f32", device=str(dev))
+    ctl.set_waypoints(wps)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ret = ctl.control_step(T)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    ret = ret.cpu().numpy(); rs = ctl.ret_step.cpu().numpy()
+    steps_run = np.where(ret == 0, T, rs + 1).sum()
+    return {"workload": f"{B} DynamicUnicycle2D agents x {T} closed-loop control steps, 14 shared obstacles, num_constraints 10, one launch",
+            "kernel_ms": ms, "agent_steps_per_s": float(steps_run) / (ms * 1e-3), "agent_steps": int(steps_run),
+            "finished": int((ret == -1).sum()), "failed": int((ret == -2).sum()), "running": int((ret == 0).sum()),
+            "dtype": "f64", "storage": "f32"}
+
+
 def main():
     a = parse()
     import numpy as np
@@ -250,6 +290,7 @@ def main():
             res["sweep"] = sweep(ctl, dev, td, es, K)
         if ws == 1 and not a.no_mpc:
             res["mpc_cbf"] = mpc_leg(dev, 4096, 8, 10, steps=3, warmup=1)
+            res["closed_loop"] = closed_loop_leg(dev)
         if ws == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(X.double().cpu().numpy(), ur.double().cpu().numpy(),
                                                ob.double().cpu().numpy(), a.cpu_seconds)

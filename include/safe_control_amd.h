@@ -166,6 +166,32 @@ int sc_mpccbf_solve_batch_host(const sc_mpccbf_params* params, int64_t B, int32_
                                void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out,
                                int device);
 
+/* ---- optimal-decay CBF-QP --------------------------------------
+ * OptimalDecayCBFQP (position_control/optimal_decay_cbf_qp.py:13-158): decision variables u (2) and the
+ * decay multipliers omega1, omega2 with penalties p_sb (omega - omega_ref)^2 (:72-76); ONE obstacle row
+ *   rel-deg 2 (DU, KB):  A u + b + (alpha1+alpha2) omega1 h_dot + alpha1 alpha2 h omega2 >= 0   (:83-90)
+ *   rel-deg 1 (C3BF/DPCBF): A u + b + alpha h omega1 >= 0, no omega2 term                        (:99-104)
+ * plus the input box.  `qp.alpha1/alpha2` carry the optimal-decay gains (0.5, :19-20).  The reference
+ * copy is stale (it is handed a (k,7) array): here the obstacle is one 7-wide row per
+ * agent (the nearest), has_obs[i] == 0 reproduces the `nearest_obs is None` branch (:133-137).
+ */
+typedef struct sc_odcbfqp_params {
+    sc_cbfqp_params qp;      /* model, dtypes, radius, alpha1/alpha2 (or alpha), input box, rear_ax_dist */
+    double omega_ref[2];     /* cbf_param['omega1'], ['omega2'] = 1.0                                 */
+    double p_sb[2];          /* cbf_param['p_sb1'], ['p_sb2'] = 1e4                                   */
+} sc_odcbfqp_params;
+
+/* X [B,4], u_ref [B,2], obs [B,7], has_obs [B] int32 or NULL (all present);
+ * u_out [B,2] (NaN if not optimal), omega_out [B,2] (omega2 = omega_ref[1] for rel-deg-1 models),
+ * status_out [B], h_out [B] or NULL. */
+int sc_odcbfqp_solve_batch(const sc_odcbfqp_params* params, int64_t B,
+                           const void* X, const void* u_ref, const void* obs, const int32_t* has_obs,
+                           void* u_out, void* omega_out, int32_t* status_out, void* h_out, void* stream);
+
+int sc_odcbfqp_solve_batch_host(const sc_odcbfqp_params* params, int64_t B,
+                                const void* X, const void* u_ref, const void* obs, const int32_t* has_obs,
+                                void* u_out, void* omega_out, int32_t* status_out, void* h_out, int device);
+
 /* ---- closed-loop control_step, fused -----------------------
  * Runs `n_steps` iterations of LocalTrackingController.control_step (tracking.py:559-668; moving
  * obstacles: dynamic_env/main.py:126-236) for B agents in ONE launch, with the CBF-QP solve behind

@@ -53,6 +53,11 @@ class MpcCbfParams(C.Structure):
     ]
 
 
+class OdCbfQpParams(C.Structure):
+    """Mirror of ``sc_odcbfqp_params``."""
+    _fields_ = [("qp", CbfQpParams), ("omega_ref", C.c_double * 2), ("p_sb", C.c_double * 2)]
+
+
 SM_IDLE, SM_TRACK, SM_STOP, SM_ROTATE = 0, 1, 2, 3
 SM_NAMES = {0: "idle", 1: "track", 2: "stop", 3: "rotate"}
 TRACKING_MAX_CONSTRAINTS = 16
@@ -83,6 +88,8 @@ SYMBOLS = {
     "sc_mpccbf_solve_batch": (C.c_int, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "sc_odcbfqp_solve_batch": (C.c_int, [C.POINTER(OdCbfQpParams), C.c_int64] + [C.c_void_p] * 9),
+    "sc_odcbfqp_solve_batch_host": (C.c_int, [C.POINTER(OdCbfQpParams), C.c_int64] + [C.c_void_p] * 8 + [C.c_int]),
     "sc_tracking_rollout_batch": (C.c_int, [C.POINTER(TrackingParams), C.c_int64, C.c_int32] + [C.c_void_p] * 13),
     "sc_mpccbf_solve_batch_host": (C.c_int, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

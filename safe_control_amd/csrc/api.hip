@@ -15,6 +15,8 @@ hipError_t mpccbf_launch(const sc_mpccbf_params& p, long long B, int K, const vo
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                          hipStream_t stream);
 size_t mpccbf_lds_bytes(int N, int K);
+hipError_t odcbfqp_launch(const sc_odcbfqp_params& p, long long B, const void* X, const void* u_ref, const void* obs,
+                          const int* has_obs, void* u_out, void* w_out, int* status, void* h_out, hipStream_t stream);
 hipError_t tracking_launch(const sc_tracking_params& p, long long B, int M, void* X, const void* wps, const int* n_wp,
                            int* wp_index, int* sm, void* goal, void* table, void* u_last, int* ret, int* ret_step,
                            void* tX, void* tU, hipStream_t stream);
@@ -221,6 +223,65 @@ int sc_tracking_rollout_batch(const sc_tracking_params* params, int64_t B, int32
                                        obs_table, u_last, ret, ret_step, traj_X, traj_U, (hipStream_t)stream);
     if (e != hipSuccess) return sc::fail_hip(e, "tracking kernel launch");
     return SC_OK;
+}
+
+static int check_od(const sc_odcbfqp_params* p, int64_t B, const void* X, const void* u_ref, const void* obs,
+                    const void* u_out, const void* w_out, const void* st) {
+    if (!p) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    int rc = sc::check_cbfqp(&p->qp, B, 1, X, u_ref, obs, u_out, st);
+    if (rc != SC_OK) return rc;
+    if (!(p->p_sb[0] > 0) || !(p->p_sb[1] > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "p_sb must be > 0");
+    if (B > 0 && !w_out) return sc::fail(SC_ERR_INVALID_ARGUMENT, "omega_out is NULL");
+    return SC_OK;
+}
+
+int sc_odcbfqp_solve_batch(const sc_odcbfqp_params* params, int64_t B, const void* X, const void* u_ref, const void* obs,
+                           const int32_t* has_obs, void* u_out, void* omega_out, int32_t* status_out, void* h_out,
+                           void* stream) {
+    int rc = check_od(params, B, X, u_ref, obs, u_out, omega_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::odcbfqp_launch(*params, (long long)B, X, u_ref, obs, has_obs, u_out, omega_out, status_out, h_out,
+                                      (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "odcbfqp kernel launch");
+    return SC_OK;
+}
+
+int sc_odcbfqp_solve_batch_host(const sc_odcbfqp_params* params, int64_t B, const void* X, const void* u_ref,
+                                const void* obs, const int32_t* has_obs, void* u_out, void* omega_out,
+                                int32_t* status_out, void* h_out, int device) {
+    int rc = check_od(params, B, X, u_ref, obs, u_out, omega_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipSetDevice");
+    const size_t es = params->qp.io_dtype == SC_DTYPE_F64 ? 8 : 4;
+    const size_t nX = (size_t)B * 4 * es, nU = (size_t)B * 2 * es, nO = (size_t)B * 7 * es, nS = (size_t)B * 4, nH = (size_t)B * es;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t oX = 0, oU = oX + up(nX), oO = oU + up(nU), oN = oO + up(nO), oUo = oN + up(nS), oW = oUo + up(nU),
+                 oS = oW + up(nU), oH = oS + up(nS), total = oH + up(nH);
+    unsigned char* d = nullptr;
+    e = hipMalloc((void**)&d, total);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipMalloc");
+    hipStream_t s = nullptr;
+    do {
+        if ((e = hipMemcpyAsync(d + oX, X, nX, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oU, u_ref, nU, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if (has_obs && (e = hipMemcpyAsync(d + oN, has_obs, nS, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        e = sc::odcbfqp_launch(*params, (long long)B, d + oX, d + oU, d + oO, has_obs ? (const int*)(d + oN) : nullptr,
+                               d + oUo, d + oW, (int*)(d + oS), h_out ? d + oH : nullptr, s);
+        if (e != hipSuccess) break;
+        if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(omega_out, d + oW, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (h_out && (e = hipMemcpyAsync(h_out, d + oH, nH, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        e = hipStreamSynchronize(s);
+    } while (0);
+    rc = SC_OK;
+    if (e != hipSuccess) rc = sc::fail_hip(e, "sc_odcbfqp_solve_batch_host");
+    (void)hipFree(d);
+    return rc;
 }
 
 }  // extern "C"

@@ -1,2 +1,3 @@
 from .cbf_qp import CBFQP, BatchedCBFQP  # noqa: F401
 from .mpc_cbf import MPCCBF, BatchedMPCCBF  # noqa: F401
+from .optimal_decay_cbf_qp import OptimalDecayCBFQP, BatchedOptimalDecayCBFQP  # noqa: F401
