@@ -63,6 +63,9 @@ typedef enum sc_error {
 #define SC_MODEL_KINEMATIC_BICYCLE2D       1  /* robots/kinematic_bicycle2D.py                   */
 #define SC_MODEL_KINEMATIC_BICYCLE2D_C3BF  2  /* dynamic_env/kinematic_bicycle2D_c3bf.py         */
 #define SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF 3  /* dynamic_env/kinematic_bicycle2D_dpcbf.py        */
+#define SC_MODEL_SINGLE_INTEGRATOR2D       4  /* robots/single_integrator2D.py: X = [x, y, -, -], U = [vx, vy]   */
+#define SC_MODEL_DOUBLE_INTEGRATOR2D       5  /* robots/double_integrator2D.py: X = [x, y, vx, vy], U = [ax, ay] */
+#define SC_MODEL_COUNT                     6
 
 #define SC_DTYPE_F32 0
 #define SC_DTYPE_F64 1

@@ -24,7 +24,7 @@
 
 #define KMAX 64
 
-enum { DU = 0, KB = 1, C3BF = 2, DPCBF = 3 };
+enum { DU = 0, KB = 1, C3BF = 2, DPCBF = 3, SI = 4, DI = 5 };
 
 typedef struct {
     int model, cbf_mode;
@@ -94,8 +94,41 @@ static void dpcbf(const double* X, const double* o, double R, double* h, double*
             - 2 * kl * sd * vny * sin(rot - th) / vm;
 }
 
+/* superellipsoid pieces shared by the integrator models (robots/single_integrator2D.py:131-147,
+   robots/double_integrator2D.py:187-218) */
+static void super_terms(const double* X, const double* o, double R, double* h, double* dhx, double* dhy, double* hxx,
+                        double* hxy, double* hyy) {
+    double a = o[2] + R, b = o[3] + R, e = o[4], ct = cos(o[5]), st = sin(o[5]);
+    double px = ct * (X[0] - o[0]) + st * (X[1] - o[1]);
+    double py = -st * (X[0] - o[0]) + ct * (X[1] - o[1]);
+    *h = pow(px / a, e) + pow(py / b, e) - 1.0;
+    double gx = e * pow(px, e - 1) / pow(a, e), gy = e * pow(py, e - 1) / pow(b, e);
+    *dhx = gx * ct - gy * st; *dhy = gx * st + gy * ct;
+    double ca = e * (e - 1) / pow(a, e) * pow(px, e - 2), cb = e * (e - 1) / pow(b, e) * pow(py, e - 2);
+    *hxx = ca * ct * ct + cb * st * st; *hxy = (ca - cb) * ct * st; *hyy = ca * st * st + cb * ct * ct;
+}
+
 /* one row; returns 0 on bad obstacle flag */
 static int cbf_row(const par_t* p, const double* X, const double* o, double* n, double* c, double* h) {
+    if (p->model == SI || p->model == DI) {
+        double hx, dhx, dhy, hxx = 0, hxy = 0, hyy = 0;
+        if (o[6] == 0.0) {
+            double ex = X[0] - o[0], ey = X[1] - o[1], dmin = o[2] + p->R, nrm = sqrt(ex * ex + ey * ey);
+            hx = nrm * nrm - 1.01 * dmin * dmin; dhx = 2.0 * ex; dhy = 2.0 * ey; hxx = 2.0; hyy = 2.0;
+        } else if (o[6] == 1.0) super_terms(X, o, p->R, &hx, &dhx, &dhy, &hxx, &hxy, &hyy);
+        else return 0;
+        *h = hx;
+        n[0] = dhx; n[1] = dhy;
+        if (p->model == SI) {
+            *c = p->cbf_mode ? (hx / p->dt) : (p->a1 * hx);
+        } else {
+            double vx = X[2], vy = X[3], hdot = dhx * vx + dhy * vy;
+            double Lf = (hxx * vx + hxy * vy) * vx + (hxy * vx + hyy * vy) * vy;
+            *c = p->cbf_mode ? (hx / (p->dt * p->dt) + 2.0 * hdot / p->dt + Lf)
+                             : (Lf + (p->a1 + p->a2) * hdot + (p->a1 * p->a2) * hx);
+        }
+        return 1;
+    }
     double th = X[2], v = X[3], cs = cos(th), sn = sin(th), f0 = v * cs, f1 = v * sn;
     double g[4][2] = {{0, 0}, {0, 0}, {0, 1}, {1, 0}};
     if (p->model != DU) {

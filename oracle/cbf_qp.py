@@ -12,6 +12,8 @@ def default_cbf_param(model):
     """CBF gains per model, position_control/cbf_qp.py:12-35."""
     if model in R.REL_DEG2:
         return {"alpha1": 1.5, "alpha2": 1.5}
+    if model == R.MODEL_SI:
+        return {"alpha": 1.0}
     return {"alpha": 1.5}
 
 
@@ -19,6 +21,10 @@ def input_bounds(model, spec):
     """Input box, position_control/cbf_qp.py:62-65 (DU) and :70-73 (KB family)."""
     if model == R.MODEL_DU:
         hi = np.array([spec["a_max"], spec["w_max"]], dtype=np.float64)
+    elif model == R.MODEL_SI:                              # cbf_qp.py:54-57
+        hi = np.array([spec["v_max"], spec["v_max"]], dtype=np.float64)
+    elif model == R.MODEL_DI:                              # cbf_qp.py:66-69
+        hi = np.array([spec["a_max"], spec["a_max"]], dtype=np.float64)
     else:
         hi = np.array([spec["a_max"], spec["beta_max"]], dtype=np.float64)
     return -hi, hi

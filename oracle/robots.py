@@ -18,14 +18,19 @@ MODEL_KB = 1          # KinematicBicycle2D           (rel-deg 2 HOCBF)
 MODEL_KB_C3BF = 2     # KinematicBicycle2D_C3BF      (rel-deg 1 collision cone)
 MODEL_KB_DPCBF = 3    # KinematicBicycle2D_DPCBF     (rel-deg 1 dynamic parabola)
 
+MODEL_SI = 4          # SingleIntegrator2D           (rel-deg 1 distance barrier), X = [x, y, -, -], U = [vx, vy]
+MODEL_DI = 5          # DoubleIntegrator2D           (rel-deg 2 HOCBF),            X = [x, y, vx, vy], U = [ax, ay]
+
 MODEL_NAMES = {
     "DynamicUnicycle2D": MODEL_DU,
     "KinematicBicycle2D": MODEL_KB,
     "KinematicBicycle2D_C3BF": MODEL_KB_C3BF,
     "KinematicBicycle2D_DPCBF": MODEL_KB_DPCBF,
+    "SingleIntegrator2D": MODEL_SI,
+    "DoubleIntegrator2D": MODEL_DI,
 }
 
-REL_DEG2 = (MODEL_DU, MODEL_KB)
+REL_DEG2 = (MODEL_DU, MODEL_KB, MODEL_DI)
 
 
 def angle_normalize(x):
@@ -41,6 +46,10 @@ def default_spec(model):
     """
     if model == MODEL_DU:
         return dict(a_max=0.5, w_max=0.5, v_max=1.0, radius=0.25)
+    if model == MODEL_SI:                                  # robots/single_integrator2D.py:40-43
+        return dict(v_max=1.0, w_max=0.5, radius=0.25)
+    if model == MODEL_DI:                                  # robots/double_integrator2D.py:38-44
+        return dict(a_max=1.0, v_max=1.0, w_max=0.5, radius=0.25)
     rear, wb = 0.2, 0.4
     delta_max = np.deg2rad(32)
     return dict(a_max=5.0, v_max=3.5, v_min=0.2, radius=0.3, rear_ax_dist=rear,
@@ -52,7 +61,12 @@ def default_spec(model):
 # dynamics
 # --------------------------------------------------------------------------
 def f(model, X, spec=None):
-    """Drift. DU robots/dynamic_unicycle2D.py:42-54 ; KB robots/kinematic_bicycle2D.py:75-91."""
+    """Drift. DU robots/dynamic_unicycle2D.py:42-54 ; KB robots/kinematic_bicycle2D.py:75-91 ;
+    SI robots/single_integrator2D.py:45-55 (zero) ; DI robots/double_integrator2D.py:46-59 ([vx, vy, 0, 0])."""
+    if model == MODEL_SI:
+        return np.zeros(4)
+    if model == MODEL_DI:
+        return np.array([X[2], X[3], 0.0, 0.0])
     th, v = X[2], X[3]
     return np.array([v * math.cos(th), v * math.sin(th), 0.0, 0.0])
 
@@ -61,6 +75,10 @@ def g(model, X, spec=None):
     """Input matrix. DU :64-73 (constant) ; KB robots/kinematic_bicycle2D.py:93-111 (state dependent)."""
     if model == MODEL_DU:
         return np.array([[0.0, 0.0], [0.0, 0.0], [0.0, 1.0], [1.0, 0.0]])
+    if model == MODEL_SI:                                  # single_integrator2D.py:57-65 (identity on x, y)
+        return np.array([[1.0, 0.0], [0.0, 1.0], [0.0, 0.0], [0.0, 0.0]])
+    if model == MODEL_DI:                                  # double_integrator2D.py:69-79
+        return np.array([[0.0, 0.0], [0.0, 0.0], [1.0, 0.0], [0.0, 1.0]])
     th, v = X[2], X[3]
     L_r = spec["rear_ax_dist"]
     return np.array([[0.0, -v * math.sin(th)],
@@ -82,6 +100,14 @@ def df_dx(model, X):
 def step(model, X, U, dt, spec=None):
     """Euler step + heading wrap. DU :75-78 ; KB :113-123 (also clips v to [v_min, v_max])."""
     Xn = np.asarray(X, dtype=np.float64) + (f(model, X, spec) + g(model, X, spec) @ np.asarray(U, dtype=np.float64)) * dt
+    if model == MODEL_SI:                                  # single_integrator2D.py:67-69
+        return Xn
+    if model == MODEL_DI:                                  # double_integrator2D.py:81-108: speed saturation
+        vm = math.sqrt(Xn[2] ** 2 + Xn[3] ** 2)
+        if spec.get("v_max") is not None and vm > spec["v_max"]:
+            Xn[2] *= spec["v_max"] / vm
+            Xn[3] *= spec["v_max"] / vm
+        return Xn
     Xn[2] = angle_normalize(Xn[2])
     if model != MODEL_DU:
         Xn[3] = min(max(Xn[3], spec["v_min"]), spec["v_max"])
@@ -97,6 +123,24 @@ def nominal_input(model, X, goal, spec, d_min=0.05):
     never used on the control_step path because BaseRobot.nominal_input
     (robots/robot.py:401-408) forwards k_omega=2, k_a=1, k_v=1 positionally.
     """
+    if model in (MODEL_SI, MODEL_DI):
+        # SI robots/single_integrator2D.py:75-93 ; DI robots/double_integrator2D.py:114-141
+        # (BaseRobot forwards d_min, k_v(, k_a) = .05, 1(, 1): robots/robot.py:402-403,408-409)
+        k_v = spec.get("nominal_k_v", 1.0) if model == MODEL_DI else 1.0
+        k_a = spec.get("nominal_k_a", 1.0)
+        pe = np.array([goal[0] - X[0], goal[1] - X[1]])
+        pe = np.sign(pe) * np.maximum(np.abs(pe) - d_min, 0.0)
+        v_des = k_v * pe
+        vm = np.linalg.norm(v_des)
+        if vm > spec["v_max"]:
+            v_des = v_des * spec["v_max"] / vm
+        if model == MODEL_SI:
+            return v_des
+        a = k_a * (v_des - np.array([X[2], X[3]]))
+        am = np.linalg.norm(a)
+        if am > spec["a_max"]:
+            a = a * spec["a_max"] / am
+        return a
     dxg, dyg = goal[0] - X[0], goal[1] - X[1]
     dist_raw = math.sqrt((X[0] - goal[0]) ** 2 + (X[1] - goal[1]) ** 2)
     theta_d = math.atan2(dyg, dxg)
@@ -122,7 +166,12 @@ def nominal_input(model, X, goal, spec, d_min=0.05):
 
 
 def stop(model, X, spec):
-    """DU :106-111 (brake with k_a) ; KB :149-150 (zeros)."""
+    """DU :106-111 (brake with k_a) ; KB :149-150 (zeros) ; SI :103-106 (zeros) ; DI :151-157 (brake both axes)."""
+    if model == MODEL_SI:
+        return np.array([0.0, 0.0])
+    if model == MODEL_DI:
+        k_a = spec.get("nominal_k_a", 1.0)
+        return np.array([k_a * (0.0 - X[2]), k_a * (0.0 - X[3])])
     if model == MODEL_DU:
         return np.array([spec.get("nominal_k_a", 1.0) * (0.0 - X[3]), 0.0])
     return np.array([0.0, 0.0])
@@ -185,6 +234,49 @@ def _hocbf_superellipsoid(X, obs, R):
                         dh_x * (-v * s) + dh_y * (v * c),
                         dh_x * c + dh_y * s], dtype=np.float64)
     return float(h), float(h_dot), dhd
+
+
+def _superellipsoid_terms(X, obs, R):
+    """h, dh/dp (2,), d2h/dp2 entries of the superellipsoid barrier (shared by SI / DI / DU formulas)."""
+    ox, oy, a, b, e, tho = (np.float64(obs[i]) for i in range(6))
+    ct, st = np.cos(tho), np.sin(tho)
+    px = ct * (X[0] - ox) + st * (X[1] - oy)
+    py = -st * (X[0] - ox) + ct * (X[1] - oy)
+    Aa, Bb = a + R, b + R
+    with np.errstate(all="ignore"):
+        h = (px / Aa) ** e + (py / Bb) ** e - 1.0
+        gx = e * px ** (e - 1) / Aa ** e
+        gy = e * py ** (e - 1) / Bb ** e
+        ca = e * (e - 1) / Aa ** e * px ** (e - 2)
+        cb = e * (e - 1) / Bb ** e * py ** (e - 2)
+    return (float(h), np.array([gx * ct - gy * st, gx * st + gy * ct]),
+            ca * ct * ct + cb * st * st, (ca - cb) * ct * st, ca * st * st + cb * ct * ct)
+
+
+def _si_barrier(X, obs, R, beta=1.01):
+    """robots/single_integrator2D.py:119-149 (rel-deg 1): h and dh/dx over the 2 position states (padded to 4)."""
+    if obs[-1] == 0:
+        ex, ey = X[0] - obs[0], X[1] - obs[1]
+        d_min = obs[2] + R
+        return math.sqrt(ex * ex + ey * ey) ** 2 - beta * d_min ** 2, np.array([2.0 * ex, 2.0 * ey, 0.0, 0.0])
+    if obs[-1] == 1:
+        h, dh, _, _, _ = _superellipsoid_terms(X, obs, R)
+        return h, np.array([dh[0], dh[1], 0.0, 0.0])
+    raise ValueError("SingleIntegrator2D: obstacle flag must be 0 or 1")
+
+
+def _di_barrier(X, obs, R, beta=1.01):
+    """robots/double_integrator2D.py:167-220 (rel-deg 2): h, h_dot, d(h_dot)/dx."""
+    vx, vy = X[2], X[3]
+    if obs[-1] == 0:
+        ex, ey = X[0] - obs[0], X[1] - obs[1]
+        d_min = obs[2] + R
+        h = math.sqrt(ex * ex + ey * ey) ** 2 - beta * d_min ** 2
+        return h, 2.0 * (ex * vx + ey * vy), np.array([2.0 * vx, 2.0 * vy, 2.0 * ex, 2.0 * ey])
+    if obs[-1] == 1:
+        h, dh, hxx, hxy, hyy = _superellipsoid_terms(X, obs, R)
+        return h, float(dh[0] * vx + dh[1] * vy), np.array([hxx * vx + hxy * vy, hxy * vx + hyy * vy, dh[0], dh[1]])
+    raise ValueError("DoubleIntegrator2D: obstacle flag must be 0 or 1")
 
 
 def _c3bf(X, obs, R, beta=1.0):
@@ -266,6 +358,10 @@ def agent_barrier(model, X, obs, R):
         if flag == 1:
             return _hocbf_superellipsoid(X, obs, R)
         raise ValueError("DynamicUnicycle2D: obstacle flag must be 0 or 1")
+    if model == MODEL_SI:
+        return _si_barrier(X, obs, R)
+    if model == MODEL_DI:
+        return _di_barrier(X, obs, R)
     if model == MODEL_KB:
         return _hocbf_circle(X, obs, R, 1.1)
     if model == MODEL_KB_C3BF:

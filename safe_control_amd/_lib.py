@@ -23,6 +23,8 @@ MODEL_IDS = {
     "KinematicBicycle2D": 1,
     "KinematicBicycle2D_C3BF": 2,
     "KinematicBicycle2D_DPCBF": 3,
+    "SingleIntegrator2D": 4,
+    "DoubleIntegrator2D": 5,
 }
 
 

@@ -38,7 +38,7 @@ static int check_cbfqp(const sc_cbfqp_params* p, int64_t B, int32_t K, const voi
     if (B < 0) return fail(SC_ERR_INVALID_ARGUMENT, "B < 0");
     if (K < 1) return fail(SC_ERR_INVALID_ARGUMENT, "K < 1 (pass obs_list=None handling to the caller: u = u_ref)");
     if (K > SC_CBFQP_MAX_OBS) return fail(SC_ERR_UNSUPPORTED, "K exceeds SC_CBFQP_MAX_OBS");
-    if (p->model_id < 0 || p->model_id > SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF)
+    if (p->model_id < 0 || p->model_id >= SC_MODEL_COUNT)
         return fail(SC_ERR_INVALID_ARGUMENT, "unknown model_id");
     if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
         return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
@@ -49,7 +49,8 @@ static int check_cbfqp(const sc_cbfqp_params* p, int64_t B, int32_t K, const voi
     if (p->cbf_mode != SC_CBF_MODE_CBF && p->cbf_mode != SC_CBF_MODE_HARD)
         return fail(SC_ERR_INVALID_ARGUMENT, "cbf_mode must be 0 (cbf) or 1 (hard)");
     if (!(p->dt > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "dt must be > 0");
-    if (p->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && !(p->rear_ax_dist > 0))
+    if (p->model_id >= SC_MODEL_KINEMATIC_BICYCLE2D && p->model_id <= SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF &&
+        !(p->rear_ax_dist > 0))
         return fail(SC_ERR_INVALID_ARGUMENT, "rear_ax_dist must be > 0 for the KinematicBicycle2D family");
     if (B > 0 && (!X || !u_ref || !obs || !u_out || !status_out))
         return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
@@ -206,7 +207,7 @@ int sc_tracking_rollout_batch(const sc_tracking_params* params, int64_t B, int32
     const sc_cbfqp_params* q = &params->qp;
     if (B < 0 || M < 0) return sc::fail(SC_ERR_INVALID_ARGUMENT, "B < 0 or M < 0");
     if (q->model_id < 0 || q->model_id > SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF)
-        return sc::fail(SC_ERR_INVALID_ARGUMENT, "unknown model_id");
+        return sc::fail(SC_ERR_UNSUPPORTED, "the fused rollout is built for the unicycle / bicycle models");
     if (q->io_dtype != SC_DTYPE_F32 && q->io_dtype != SC_DTYPE_F64)
         return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
     if (params->num_constraints < 1 || params->num_constraints > SC_TRACKING_MAX_CONSTRAINTS)
@@ -230,6 +231,8 @@ static int check_od(const sc_odcbfqp_params* p, int64_t B, const void* X, const 
     if (!p) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
     int rc = sc::check_cbfqp(&p->qp, B, 1, X, u_ref, obs, u_out, st);
     if (rc != SC_OK) return rc;
+    if (p->qp.model_id > SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF)
+        return sc::fail(SC_ERR_UNSUPPORTED, "optimal-decay CBF-QP is built for the unicycle / bicycle models");
     if (!(p->p_sb[0] > 0) || !(p->p_sb[1] > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "p_sb must be > 0");
     if (B > 0 && !w_out) return sc::fail(SC_ERR_INVALID_ARGUMENT, "omega_out is NULL");
     return SC_OK;

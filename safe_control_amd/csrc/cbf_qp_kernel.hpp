@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void cbfqp_reg_kernel(const sc_cbfqp_params p,
     }
     const TC ur0 = TC(ur.x), ur1 = TC(ur.y);
     const CbfConsts<TC> k = make_consts<TC>(p);
-    const Agent<TC> ag = make_agent<TC>(TC(xa.x), TC(xa.y), TC(xb.x), TC(xb.y));
+    const Agent<TC> ag = make_agent_m<TC, MODEL>(TC(xa.x), TC(xa.y), TC(xb.x), TC(xb.y));
 
     // ---- rows: agent_barrier + cbf_qp.py:155-183, unrolled, in registers ------------------
     TC n0[KMAX], n1[KMAX], c[KMAX];
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64) void cbfqp_coop_kernel(const sc_cbfqp_params p,
     }
     const TC ur0 = TC(ur.x), ur1 = TC(ur.y);
     const CbfConsts<TC> k = make_consts<TC>(p);
-    const Agent<TC> ag = make_agent<TC>(TC(xa.x), TC(xa.y), TC(xb.x), TC(xb.y));
+    const Agent<TC> ag = make_agent_m<TC, MODEL>(TC(xa.x), TC(xa.y), TC(xb.x), TC(xb.y));
 
     // ---- this lane's row -------------------------------------------------------------------
     TC o[7];
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64) void cbfqp_kernel(const sc_cbfqp_params p, cons
         }
     }
     const CbfConsts<TC> k = make_consts<TC>(p);
-    const Agent<TC> ag = make_agent<TC>(x, y, th, v);
+    const Agent<TC> ag = make_agent_m<TC, MODEL>(x, y, th, v);
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // LDS-DMA landed (it is tracked by vmcnt)
     __syncthreads();
@@ -482,6 +482,10 @@ static hipError_t launch_model(const sc_cbfqp_params& p, long long B, int K, con
             return launch_k<TIO, TC, SC_MODEL_KINEMATIC_BICYCLE2D>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
         case SC_MODEL_KINEMATIC_BICYCLE2D_C3BF:
             return launch_k<TIO, TC, SC_MODEL_KINEMATIC_BICYCLE2D_C3BF>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
+        case SC_MODEL_SINGLE_INTEGRATOR2D:
+            return launch_k<TIO, TC, SC_MODEL_SINGLE_INTEGRATOR2D>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
+        case SC_MODEL_DOUBLE_INTEGRATOR2D:
+            return launch_k<TIO, TC, SC_MODEL_DOUBLE_INTEGRATOR2D>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
         default:
             return launch_k<TIO, TC, SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
     }

@@ -55,6 +55,21 @@ __device__ __forceinline__ Agent<T> make_agent(T x, T y, T th, T v) {
     return a;
 }
 
+// Integrator models keep (vx, vy) where the unicycle keeps (theta, v): f(x)[0:2] = (vx, vy) for the double
+// integrator (robots/double_integrator2D.py:46-59), zero for the single integrator (single_integrator2D.py:45-55).
+template <typename T, int MODEL>
+__device__ __forceinline__ Agent<T> make_agent_m(T x0, T x1, T x2, T x3) {
+    if constexpr (MODEL == SC_MODEL_SINGLE_INTEGRATOR2D || MODEL == SC_MODEL_DOUBLE_INTEGRATOR2D) {
+        Agent<T> a;
+        a.x = x0; a.y = x1; a.th = T(0); a.v = T(0); a.c = T(1); a.s = T(0);
+        a.f0 = (MODEL == SC_MODEL_DOUBLE_INTEGRATOR2D) ? x2 : T(0);
+        a.f1 = (MODEL == SC_MODEL_DOUBLE_INTEGRATOR2D) ? x3 : T(0);
+        return a;
+    } else {
+        return make_agent<T>(x0, x1, x2, x3);
+    }
+}
+
 // ---- rel-deg-2 distance barrier -------------------------------------------
 // DU robots/dynamic_unicycle2D.py:136-146 (beta 1.01), KB robots/kinematic_bicycle2D.py:160-173 (beta 1.1)
 template <typename T>
@@ -191,7 +206,39 @@ __device__ __forceinline__ void dpcbf(const Agent<T>& a, const T* o, T R, T& h, 
 template <typename T, int MODEL, bool OUTLINE_RARE = false>
 __device__ __forceinline__ bool cbf_row(const Agent<T>& a, const T* o, const CbfConsts<T>& k,
                                         T& n0, T& n1, T& c, T& h) {
-    if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D || MODEL == SC_MODEL_KINEMATIC_BICYCLE2D) {
+    if constexpr (MODEL == SC_MODEL_SINGLE_INTEGRATOR2D || MODEL == SC_MODEL_DOUBLE_INTEGRATOR2D) {
+        // SI robots/single_integrator2D.py:119-149 (rel-deg 1), DI robots/double_integrator2D.py:167-220 (rel-deg 2);
+        // g is the identity on the actuated pair, so A = dh/dp for both.
+        const T flag = o[6];
+        T dhx, dhy, hxx = T(2), hxy = T(0), hyy = T(2);
+        if (flag == T(0)) {
+            const T ex = a.x - o[0], ey = a.y - o[1];
+            const T dmin = o[2] + k.R;
+            h = (ex * ex + ey * ey) - T(1.01) * dmin * dmin;
+            dhx = T(2) * ex; dhy = T(2) * ey;
+        } else if (flag == T(1)) {
+            // reuse the unicycle superellipsoid with heading 0 and speed 1: dhd[3] = dh/dx, and the Hessian
+            // entries come back through dhd[0..1] evaluated for the two unit velocities
+            Agent<T> ux = a; ux.c = T(1); ux.s = T(0); ux.f0 = T(1); ux.f1 = T(0);
+            Agent<T> uy = a; uy.c = T(0); uy.s = T(1); uy.f0 = T(0); uy.f1 = T(1);
+            T hd, d[4];
+            hocbf_superellipsoid(ux, o, k.R, h, hd, d);
+            dhx = d[3]; hxx = d[0]; hxy = d[1];
+            hocbf_superellipsoid(uy, o, k.R, h, hd, d);
+            dhy = d[3]; hyy = d[1];
+        } else {
+            n0 = n1 = c = h = T(0);
+            return false;
+        }
+        n0 = dhx; n1 = dhy;
+        if constexpr (MODEL == SC_MODEL_SINGLE_INTEGRATOR2D) {
+            c = k.hard ? (h * k.inv_dt) : (k.a1 * h);                     // f = 0: b = alpha h  (cbf_qp.py:158-165)
+        } else {
+            const T hdot = dhx * a.f0 + dhy * a.f1;
+            const T Lf = (hxx * a.f0 + hxy * a.f1) * a.f0 + (hxy * a.f0 + hyy * a.f1) * a.f1;
+            c = k.hard ? (h * k.inv_dt2 + T(2) * hdot * k.inv_dt + Lf) : (Lf + k.g1 * hdot + k.g2 * h);
+        }
+    } else if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D || MODEL == SC_MODEL_KINEMATIC_BICYCLE2D) {
         T hdot, dhd[4];
         if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) {
             const T flag = o[6];

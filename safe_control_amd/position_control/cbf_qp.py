@@ -19,13 +19,15 @@ import numpy as np
 from .. import _lib
 from ..robots.spec import complete_robot_spec
 
-REL_DEG2_MODELS = ("DynamicUnicycle2D", "KinematicBicycle2D")
+REL_DEG2_MODELS = ("DynamicUnicycle2D", "KinematicBicycle2D", "DoubleIntegrator2D")
 
 
 def default_cbf_param(model):
     """position_control/cbf_qp.py:12-35 (models the batched engine supports)."""
     if model in REL_DEG2_MODELS:
         return {"alpha1": 1.5, "alpha2": 1.5}
+    if model == "SingleIntegrator2D":
+        return {"alpha": 1.0}
     return {"alpha": 1.5}
 
 
@@ -41,6 +43,10 @@ def input_bounds(robot_spec):
     """Input box of setup_control_problem: DU cbf_qp.py:62-65, KB family :70-73."""
     if robot_spec["model"] == "DynamicUnicycle2D":
         hi = (float(robot_spec["a_max"]), float(robot_spec["w_max"]))
+    elif robot_spec["model"] == "SingleIntegrator2D":          # cbf_qp.py:54-57
+        hi = (float(robot_spec["v_max"]), float(robot_spec["v_max"]))
+    elif robot_spec["model"] == "DoubleIntegrator2D":          # cbf_qp.py:66-69
+        hi = (float(robot_spec["a_max"]), float(robot_spec["a_max"]))
     else:
         hi = (float(robot_spec["a_max"]), float(robot_spec["beta_max"]))
     return (-hi[0], -hi[1]), hi
@@ -118,7 +124,9 @@ class CBFQP:
         if k:
             obs[:k] = np.asarray(rows)
         n_obs = np.array([k], dtype=np.int32)
-        X = np.ascontiguousarray(np.asarray(robot_state, dtype=np.float64).reshape(-1)[:4])
+        xs = np.asarray(robot_state, dtype=np.float64).reshape(-1)[:4]
+        X = np.zeros(4, dtype=np.float64)                 # SingleIntegrator2D has 2 states: padded to the [B,4] layout
+        X[: xs.shape[0]] = xs
         p = make_params(self.robot_spec, self.cbf_param, self.robot.dt, self.robot.robot_radius,
                         _lib.DTYPE_F64, _lib.DTYPE_F64)
         h = np.zeros(K, dtype=np.float64)

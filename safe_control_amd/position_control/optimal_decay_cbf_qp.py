@@ -26,7 +26,7 @@ class NotCompatibleError(Exception):
 
 def default_od_param(model):
     """optimal_decay_cbf_qp.py:17-50."""
-    if model in REL_DEG2_MODELS:
+    if model in ("DynamicUnicycle2D", "KinematicBicycle2D"):
         return dict(alpha1=0.5, alpha2=0.5, omega1=1.0, p_sb1=10 ** 4, omega2=1.0, p_sb2=10 ** 4)
     if model in ("KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"):
         return dict(alpha=0.5, omega1=1.0, p_sb1=10 ** 4)

@@ -18,14 +18,26 @@ from .._lib import MODEL_IDS
 def complete_robot_spec(robot_spec):
     """Apply the defaults the reference's robot classes ``setdefault`` into robot_spec.
 
-    DynamicUnicycle2D: robots/dynamic_unicycle2D.py:34-40 ; KinematicBicycle2D
+    SingleIntegrator2D / DoubleIntegrator2D: see below ; DynamicUnicycle2D:
+    robots/dynamic_unicycle2D.py:34-40 ; KinematicBicycle2D
     family: robots/kinematic_bicycle2D.py:42-53 ; radius: robots/robot.py:49.
     Mutates and returns the dict, like the reference does.
     """
     model = robot_spec.setdefault("model", "DynamicUnicycle2D")
     if model not in MODEL_IDS:
         raise ValueError(f"model {model!r} is not supported by the batched engine (supported: {sorted(MODEL_IDS)})")
-    if model == "DynamicUnicycle2D":
+    if model == "SingleIntegrator2D":               # robots/single_integrator2D.py:40-43
+        robot_spec.setdefault("v_max", 1.0)
+        robot_spec.setdefault("w_max", 0.5)
+        robot_spec.setdefault("radius", 0.25)
+    elif model == "DoubleIntegrator2D":             # robots/double_integrator2D.py:38-44
+        robot_spec.setdefault("a_max", 1.0)
+        robot_spec.setdefault("v_max", 1.0)
+        robot_spec.setdefault("ax_max", robot_spec["a_max"])
+        robot_spec.setdefault("ay_max", robot_spec["a_max"])
+        robot_spec.setdefault("w_max", 0.5)
+        robot_spec.setdefault("radius", 0.25)
+    elif model == "DynamicUnicycle2D":
         robot_spec.setdefault("a_max", 0.5)
         robot_spec.setdefault("w_max", 0.5)
         robot_spec.setdefault("v_max", 1.0)

@@ -326,9 +326,69 @@ def gen_closed_loop():
     np.savez_compressed(os.path.join(HERE, "closed_loop.npz"), **out)
 
 
+# ---------------------------------------------------------------------------
+def gen_integrators():
+    """SingleIntegrator2D / DoubleIntegrator2D callbacks and CBF-QP rows, own seed and file so
+    the earlier fixtures stay byte-identical."""
+    rng = np.random.default_rng(77)
+    out = {}
+    for name, nx in [("SingleIntegrator2D", 2), ("DoubleIntegrator2D", 4)]:
+        spec = {"model": name, "radius": 0.25}
+        if name == "SingleIntegrator2D":
+            spec.update(v_max=1.0)
+            X0 = np.zeros((3, 1))
+        else:
+            spec.update(v_max=1.0, a_max=1.5)
+            X0 = np.zeros((5, 1))
+        robot = BaseRobot(X0, spec, DT, NullAxes())
+        ctrl = CBFQP(robot, spec, num_obs=6)
+        hi = np.array([spec["v_max"]] * 2) if name == "SingleIntegrator2D" else np.array([spec["a_max"]] * 2)
+        ctrl.cbf_controller = OracleProblem(ctrl, -hi, hi)
+        rec = {k: [] for k in ["X", "goal", "U", "u_ref", "obs", "k", "f", "g", "step", "nominal", "stop", "A", "b",
+                               "u_star_oracle", "status_oracle"]}
+        for i in range(120):
+            x, y = rng.uniform(0, 14, 2)
+            X = np.array([x, y]) if nx == 2 else np.array([x, y, *rng.uniform(-0.8, 0.8, 2)])
+            goal = rng.uniform(0, 14, 2)
+            U = rng.uniform(-1, 1, 2)
+            K = int(rng.integers(1, 7))
+            Xp = np.array([X[0], X[1], 0.0, 0.0])
+            if i % 3 == 2:
+                obs = draw_superellipsoids(rng, Xp, K, spec["radius"])
+            else:
+                obs = draw_circles(rng, Xp, K, spec["radius"], overlap=(i % 5 == 0), rho_max=3.0)
+            robot.X = X.reshape(-1, 1).copy()
+            rec["f"].append(np.asarray(robot.f(), dtype=float).reshape(-1))
+            rec["g"].append(np.asarray(robot.g(), dtype=float))
+            u_ref = robot.nominal_input(goal).reshape(-1)
+            if i % 7 == 3:
+                u_ref = u_ref * 4.0
+            rec["nominal"].append(robot.nominal_input(goal).reshape(-1))
+            rec["stop"].append(np.asarray(robot.stop(), dtype=float).reshape(-1))
+            A, b, u, status = run_cbfqp_case(ctrl, robot, X, u_ref, list(obs))
+            robot.X = X.reshape(-1, 1).copy()
+            Xn = robot.robot.step(robot.X.copy(), U.reshape(-1, 1)).reshape(-1).copy()
+            obs_p = np.full((6, 7), np.nan); obs_p[:K] = obs
+            Xpad = np.zeros(4); Xpad[:nx] = X
+            Xnpad = np.zeros(4); Xnpad[:nx] = Xn
+            rec["X"].append(Xpad); rec["goal"].append(goal); rec["U"].append(U); rec["u_ref"].append(u_ref)
+            rec["obs"].append(obs_p); rec["k"].append(K); rec["step"].append(Xnpad)
+            rec["A"].append(A); rec["b"].append(b)
+            rec["u_star_oracle"].append(np.full(2, np.nan) if u is None else u)
+            rec["status_oracle"].append(0 if status == "optimal" else 1)
+        for k, v in rec.items():
+            out[f"{name}/{k}"] = np.array(v)
+        print(name, "cases", len(rec["k"]), "infeasible", int(np.sum(rec["status_oracle"])))
+    np.savez_compressed(os.path.join(HERE, "integrators.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "integrators":
+        gen_integrators()
+        sys.exit(0)
     rng = np.random.default_rng(20240611)
     gen_callbacks(rng)
     gen_cbfqp(rng)
     gen_nearest(rng)
     gen_closed_loop()
+    gen_integrators()

@@ -26,7 +26,8 @@ from safe_control_amd import workloads as W  # noqa: E402
 DEV = "cuda:0"
 
 MODEL_NAME = {R.MODEL_DU: "DynamicUnicycle2D", R.MODEL_KB: "KinematicBicycle2D",
-              R.MODEL_KB_C3BF: "KinematicBicycle2D_C3BF", R.MODEL_KB_DPCBF: "KinematicBicycle2D_DPCBF"}
+              R.MODEL_KB_C3BF: "KinematicBicycle2D_C3BF", R.MODEL_KB_DPCBF: "KinematicBicycle2D_DPCBF",
+              R.MODEL_SI: "SingleIntegrator2D", R.MODEL_DI: "DoubleIntegrator2D"}
 
 
 def du_spec():
@@ -257,6 +258,40 @@ def test_golden_cases_through_dropin_class(golden_dir):
     u = ctl.solve_control_problem(robot.X, {"u_ref": g["none/u_ref"].reshape(2, 1)}, None)
     np.testing.assert_array_equal(u.reshape(-1), g["none/u"])
     assert ctl.status == "optimal"
+
+
+# ------------------------------------------------------------------ integrator models
+@pytest.mark.parametrize("name,model", [("SingleIntegrator2D", R.MODEL_SI), ("DoubleIntegrator2D", R.MODEL_DI)])
+def test_integrator_models(golden_dir, name, model):
+    """Reference-generated cases through the drop-in class, then a 40k-agent batch (both kernels) vs the C oracle."""
+    g = np.load(os.path.join(golden_dir, "integrators.npz"))
+    G = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(name + "/")}
+    spec = {"model": name, "radius": 0.25, "v_max": 1.0}
+    if model == R.MODEL_DI:
+        spec["a_max"] = 1.5
+    robot = sca.RobotHandle(np.zeros(4), dict(spec), dt=0.05)
+    ctl = sca.CBFQP(robot, dict(spec), num_obs=6)
+    nx = 2 if model == R.MODEL_SI else 4
+    for i in range(len(G["X"])):
+        robot.X = G["X"][i][:nx].reshape(-1, 1)
+        u = ctl.solve_control_problem(robot.X, {"u_ref": G["u_ref"][i].reshape(2, 1)}, list(G["obs"][i][: int(G["k"][i])]))
+        if G["status_oracle"][i] == 0:
+            assert ctl.status == "optimal"
+            np.testing.assert_allclose(u.reshape(-1), G["u_star_oracle"][i], rtol=1e-7, atol=1e-7)
+        else:
+            assert u is None and ctl.status != "optimal"
+    # batches: superellipsoids mixed in, speeds in the (theta, v) slots for the double integrator
+    for B in (3000, 40000):
+        X, goal, u_ref, obs = W.du_cbfqp_batch(B, 6, seed=B)
+        rng = np.random.default_rng(B)
+        X[:, 2:4] = rng.uniform(-0.8, 0.8, (B, 2)) if model == R.MODEL_DI else 0.0
+        u_ref = rng.uniform(-2, 2, (B, 2))
+        for i in rng.choice(B, B // 10, replace=False):
+            a, b = rng.uniform(0.3, 1.2, 2)
+            rho, phi = rng.uniform(max(a, b) + 0.55, 4.5), rng.uniform(-np.pi, np.pi)
+            obs[i, 2] = [X[i, 0] + rho * np.cos(phi), X[i, 1] + rho * np.sin(phi), a, b, float(rng.choice([4, 6])),
+                         rng.uniform(-np.pi, np.pi), 1.0]
+        compare(model, spec, X, u_ref, obs, "f64", "f64")
 
 
 # ------------------------------------------------------------------ closed loop through the plugin surface

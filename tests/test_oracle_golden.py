@@ -215,3 +215,28 @@ def test_closed_loop_moving_obstacles(golden_dir, tag, model):
         np.testing.assert_allclose(t.u_pos, Ug[k], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(t.X, Xg[k + 1], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(t.obs, g[f"{tag}/obs_final"], rtol=1e-12, atol=1e-12)
+
+
+# ------------------------------------------------------------------ integrator models
+@pytest.mark.parametrize("name,model", [("SingleIntegrator2D", R.MODEL_SI), ("DoubleIntegrator2D", R.MODEL_DI)])
+def test_integrator_models_against_reference(golden_dir, name, model):
+    """tests/golden/integrators.npz: f, g, step, nominal_input, stop, CBF rows (reference code verbatim), u*."""
+    g = np.load(os.path.join(golden_dir, "integrators.npz"))
+    G = {k.split("/", 1)[1]: g[k] for k in g.files if k.startswith(name + "/")}
+    spec = R.default_spec(model)
+    if model == R.MODEL_DI:
+        spec.update(a_max=1.5)
+    nx = 2 if model == R.MODEL_SI else 4
+    for i in range(len(G["X"])):
+        X, K = G["X"][i], int(G["k"][i])
+        np.testing.assert_allclose(R.f(model, X, spec)[:nx], G["f"][i], atol=1e-12)
+        np.testing.assert_allclose(R.g(model, X, spec)[:nx], G["g"][i], atol=1e-12)
+        np.testing.assert_allclose(R.nominal_input(model, X, G["goal"][i], spec), G["nominal"][i], atol=1e-12)
+        np.testing.assert_allclose(R.stop(model, X, spec), G["stop"][i], atol=1e-12)
+        np.testing.assert_allclose(R.step(model, X, G["U"][i], 0.05, spec), G["step"][i], atol=1e-12)
+        r = cbf_qp.solve(model, X, G["u_ref"][i], list(G["obs"][i][:K]), spec, num_obs=6)
+        np.testing.assert_allclose(r["A"], G["A"][i], rtol=1e-9, atol=1e-8)
+        assert np.all(np.abs(r["b"] - G["b"][i]) <= 1e-9 * (1 + np.abs(G["b"][i])))
+        assert r["status"] == int(G["status_oracle"][i])
+        if r["status"] == 0:
+            np.testing.assert_allclose(r["u"], G["u_star_oracle"][i], rtol=1e-8, atol=1e-8)
