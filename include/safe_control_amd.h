@@ -195,6 +195,19 @@ int sc_odcbfqp_solve_batch_host(const sc_odcbfqp_params* params, int64_t B,
                                 const void* X, const void* u_ref, const void* obs, const int32_t* has_obs,
                                 void* u_out, void* omega_out, int32_t* status_out, void* h_out, int device);
 
+/* ---- neighbour agents as moving obstacles (extension) -----------------
+ * The reference's robots never see each other (examples/test_multi_robot.py:77-80); BASELINE
+ * config 4 asks for it.  After the per-step all-gather of agent states (RCCL over xGMI when the
+ * batch is sharded), every local agent takes its K nearest OTHER agents as circular moving
+ * obstacles [x, y, r, vx, vy, 0, 0] with r = neighbour_radius, (vx, vy) = v (cos theta, sin theta),
+ * ordered by centre distance like tracking.py:393-403.  Rows beyond the number of other agents are
+ * far-away dummies [1e3, 1e3, 0, ...] (mpc_cbf.py:343).  X_all [B_all,4]; the local agents are
+ * X_all[first_local : first_local + B_local]; obs_out [B_local, K, 7], K <= 32.
+ */
+int sc_neighbor_obstacles_batch(int32_t io_dtype, int64_t B_all, int64_t first_local, int64_t B_local,
+                                int32_t K, double neighbour_radius, const void* X_all, void* obs_out,
+                                void* stream);
+
 /* ---- closed-loop control_step, fused -----------------------
  * Runs `n_steps` iterations of LocalTrackingController.control_step (tracking.py:559-668; moving
  * obstacles: dynamic_env/main.py:126-236) for B agents in ONE launch, with the CBF-QP solve behind

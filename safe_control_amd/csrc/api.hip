@@ -15,6 +15,8 @@ hipError_t mpccbf_launch(const sc_mpccbf_params& p, long long B, int K, const vo
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                          hipStream_t stream);
 size_t mpccbf_lds_bytes(int N, int K);
+hipError_t neighbors_launch(int io_dtype, long long B_all, long long first, long long B_local, int K, double r, const void* X,
+                            void* out, hipStream_t stream);
 hipError_t odcbfqp_launch(const sc_odcbfqp_params& p, long long B, const void* X, const void* u_ref, const void* obs,
                           const int* has_obs, void* u_out, void* w_out, int* status, void* h_out, hipStream_t stream);
 hipError_t tracking_launch(const sc_tracking_params& p, long long B, int M, void* X, const void* wps, const int* n_wp,
@@ -285,6 +287,22 @@ int sc_odcbfqp_solve_batch_host(const sc_odcbfqp_params* params, int64_t B, cons
     if (e != hipSuccess) rc = sc::fail_hip(e, "sc_odcbfqp_solve_batch_host");
     (void)hipFree(d);
     return rc;
+}
+
+int sc_neighbor_obstacles_batch(int32_t io_dtype, int64_t B_all, int64_t first_local, int64_t B_local, int32_t K,
+                                double neighbour_radius, const void* X_all, void* obs_out, void* stream) {
+    if (io_dtype != SC_DTYPE_F32 && io_dtype != SC_DTYPE_F64)
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
+    if (B_all < 0 || B_local < 0 || first_local < 0 || first_local + B_local > B_all)
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "local range outside [0, B_all)");
+    if (K < 1 || K > SC_CBFQP_MAX_OBS) return sc::fail(SC_ERR_UNSUPPORTED, "K outside [1, SC_CBFQP_MAX_OBS]");
+    if (B_all > 0x7fffffffLL) return sc::fail(SC_ERR_UNSUPPORTED, "more than 2^31 agents");
+    if (B_local == 0) return SC_OK;
+    if (!X_all || !obs_out) return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    hipError_t e = sc::neighbors_launch(io_dtype, (long long)B_all, (long long)first_local, (long long)B_local, (int)K,
+                                        neighbour_radius, X_all, obs_out, (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "neighbour kernel launch");
+    return SC_OK;
 }
 
 }  // extern "C"

@@ -115,3 +115,26 @@ def max_over_ranks(seconds, device=None):
                      device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def neighbor_obstacles(X_local, n_agents, K, neighbour_radius):
+    """Agents-as-obstacles step (extension, BASELINE config 4): all-gather every agent's state
+    (one RCCL all-gather per control step when sharded; a no-op on one rank), then let the HIP kernel
+    pick each local agent's K nearest other agents as moving circular obstacles.
+
+    Returns ``obs [B_local, K, 7]`` ready for ``BatchedCBFQP.solve`` (C3BF / DPCBF use the velocity columns).
+    """
+    import ctypes as C
+
+    from . import _lib
+    ws, rank = world()
+    X_all = all_gather_states(X_local, n_agents).contiguous()
+    lo, hi = agent_range(n_agents, ws, rank)
+    assert hi - lo == X_local.shape[0], "X_local must be this rank's agent_range shard"
+    obs = torch.empty((hi - lo, K, 7), dtype=X_local.dtype, device=X_local.device)
+    io = _lib.DTYPE_F32 if X_local.dtype == torch.float32 else _lib.DTYPE_F64
+    stream = torch.cuda.current_stream(X_local.device).cuda_stream
+    rc = _lib.load().sc_neighbor_obstacles_batch(io, n_agents, lo, hi - lo, K, float(neighbour_radius),
+                                                 X_all.data_ptr(), obs.data_ptr(), stream)
+    _lib.check(rc, "sc_neighbor_obstacles_batch")
+    return obs
