@@ -44,6 +44,71 @@ __device__ __forceinline__ double wmax(double v) {
     return v;
 }
 
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// ---- f64 MFMA tiles (v_mfma_f64_16x16x4_f64) for the two dense contractions of an iteration ------------
+// Operand layout (MI355X guide, "f64 MFMA"): lane l feeds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
+// result register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15].
+//
+// tile (ti, tj) of  M += A' diag(sig) A  for a row-major A [rows][n] in LDS (the CBF Jacobian): the K-dimension
+// of the contraction is the constraint index.
+__device__ __forceinline__ d4_t mfma_tile_AtSA(const double* A, const double* sig, int rows, int n, int ti, int tj, int lane) {
+    const int q = lane >> 4, cA = 16 * ti + (lane & 15), cB = 16 * tj + (lane & 15);
+    const bool okA = cA < n, okB = cB < n;
+    const int ca = okA ? cA : 0, cb = okB ? cB : 0;
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < rows; k0 += 4) {
+        const int row = k0 + q;
+        const bool okr = row < rows;
+        const int rr = okr ? row : 0;
+        double a = A[(size_t)rr * n + ca] * sig[rr];
+        double b = A[(size_t)rr * n + cb];
+        a = (okA && okr) ? a : 0.0;
+        b = (okB && okr) ? b : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// tile (ti, tj) of  sum_k dP_k' Om_k dP_k  (dP row-major [2 (N+2)][n], Om_k symmetric 2x2 as xx, xy, yy)
+__device__ __forceinline__ d4_t mfma_tile_PtOP(const double* dP, const double* Om, int rows, int n, int ti, int tj, int lane) {
+    const int q = lane >> 4, cA = 16 * ti + (lane & 15), cB = 16 * tj + (lane & 15);
+    const bool okA = cA < n, okB = cB < n;
+    const int ca = okA ? cA : 0, cb = okB ? cB : 0;
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < rows; k0 += 4) {
+        const int row = k0 + q;                          // row = 2 k + d
+        const bool okr = row < rows;
+        const int rr = okr ? row : 0, k = rr >> 1, d = rr & 1;
+        double a = dP[(size_t)rr * n + ca];
+        const double o0 = d ? Om[3 * k + 1] : Om[3 * k], o1 = d ? Om[3 * k + 2] : Om[3 * k + 1];
+        double b = o0 * dP[(size_t)(2 * k) * n + cb] + o1 * dP[(size_t)(2 * k + 1) * n + cb];
+        a = (okA && okr) ? a : 0.0;
+        b = (okB && okr) ? b : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// add the lower-triangular tiles of a symmetric product into M (mirroring the off-diagonal tiles)
+template <typename TileFn>
+__device__ __forceinline__ void mfma_accumulate_sym(double* M, int n, int lane, TileFn tile) {
+    const int nt = (n + 15) >> 4;
+    for (int ti = 0; ti < nt; ++ti) {
+        for (int tj = 0; tj <= ti; ++tj) {
+            const d4_t acc = tile(ti, tj);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
+                if (row < n && col < n) {
+                    M[(size_t)row * n + col] += acc[r];
+                    if (ti != tj) M[(size_t)col * n + row] += acc[r];
+                }
+            }
+        }
+    }
+}
+
 struct MpcMem {                 // LDS carve-up (doubles)
     double *z, *zt, *dz, *grad, *rhs, *zb;        // n
     double *TH, *V, *C, *S;                       // N+1
@@ -283,12 +348,7 @@ __device__ inline void eval_derivs(const MpcMem& W, const MpcConst& c, int lane,
     for (int e = lane; e < n * n; e += 64) {
         const int r = e / n, cc = e - r * n;
         const int jr = r >> 1, jc = cc >> 1, jm = jr > jc ? jr : jc;
-        double acc = 0.0;
-        for (int k = 0; k <= N + 1; ++k) {
-            const double a0 = W.dP[(size_t)(2 * k) * n + r], a1 = W.dP[(size_t)(2 * k + 1) * n + r];
-            const double b0 = W.dP[(size_t)(2 * k) * n + cc], b1 = W.dP[(size_t)(2 * k + 1) * n + cc];
-            acc += a0 * (W.Om[3 * k] * b0 + W.Om[3 * k + 1] * b1) + a1 * (W.Om[3 * k + 1] * b0 + W.Om[3 * k + 2] * b1);
-        }
+        double acc = 0.0;                                 // the sum_k dP_k' Om_k dP_k part is added by MFMA below
         const bool ra = !(r & 1), ca = !(cc & 1);
         if (ra && ca) acc += 2.0 * c.Qv * dt2 * (double)(N - jm);            // sum_k dV_k dV_k'
         else if (!ra && !ca) acc += 2.0 * c.Qth * dt2 * (double)(N - jm) - dt3 * W.SB[jm + 1];
@@ -299,6 +359,8 @@ __device__ inline void eval_derivs(const MpcMem& W, const MpcConst& c, int lane,
         else if (r == cc + 2 || cc == r + 2) acc -= 2.0 * Rc;
         W.M[e] = acc;
     }
+    SC_SYNC();
+    mfma_accumulate_sym(W.M, n, lane, [&](int ti, int tj) { return mfma_tile_PtOP(W.dP, W.Om, 2 * (N + 2), n, ti, tj, lane); });
     SC_SYNC();
 }
 
@@ -371,8 +433,10 @@ __device__ inline double j_times(const MpcMem& W, const MpcConst& c, const doubl
     return r < n ? -v[r] : v[r - n];
 }
 
-template <typename TIO>
-__global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, const long long B, const int K,
+// NT, KT > 0: horizon and obstacle count are compile-time constants (index arithmetic folds to shifts and
+// multiplies); NT == 0: run-time sizes.
+template <typename TIO, int NT, int KT>
+__global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, const long long B, const int K_rt,
                                                     const TIO* __restrict__ X, const TIO* __restrict__ u_prev,
                                                     const TIO* __restrict__ goal, const TIO* __restrict__ obs,
                                                     TIO* __restrict__ u_out, int* __restrict__ status_out,
@@ -382,7 +446,8 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
     const long long prob = blockIdx.x;
     if (prob >= B) return;
     MpcConst c;
-    c.N = p.horizon; c.K = K; c.n = 2 * c.N; c.mc = c.N * K; c.m = c.mc + 2 * c.N + 2 * c.n;
+    const int K = KT > 0 ? KT : K_rt;
+    c.N = NT > 0 ? NT : p.horizon; c.K = K; c.n = 2 * c.N; c.mc = c.N * K; c.m = c.mc + 2 * c.N + 2 * c.n;
     c.dt = p.dt; c.Qx = p.Q[0]; c.Qy = p.Q[1]; c.Qth = p.Q[2]; c.Qv = p.Q[3]; c.R0 = p.R[0]; c.R1 = p.R[1];
     const double g1 = p.alpha1 + p.alpha2, g2 = p.alpha1 * p.alpha2;
     c.w0 = 1.0 - g1 + g2; c.w1 = g1 - 2.0; c.w2 = 1.0;
@@ -464,8 +529,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         for (int col = lane; col < n; col += 64) W.rhs[col] = -sf * W.grad[col] + jt_times(W, c, W.w, col);
         for (int e = lane; e < n * n; e += 64) {
             const int r = e / n, cc = e - r * n;
-            double acc = sf * W.M[e];
-            for (int row = 0; row < c.mc; ++row) acc += W.J[(size_t)row * n + r] * W.st[row] * W.J[(size_t)row * n + cc];
+            double acc = sf * W.M[e];                                   // + J_cbf' Sigma J_cbf by MFMA below
             if (!(r & 1) && !(cc & 1)) {                                  // speed rows: dt^2 sum_{k > max(jr,jc)} (sig+ + sig-)
                 const int jm = (r > cc ? r : cc) >> 1;
                 double sv = 0.0;
@@ -475,6 +539,8 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             if (r == cc) acc += W.st[c.mc + 2 * N + r] + W.st[c.mc + 2 * N + n + r];
             W.M[e] = acc;                                                 // M now holds the condensed matrix
         }
+        SC_SYNC();
+        mfma_accumulate_sym(W.M, n, lane, [&](int ti, int tj) { return mfma_tile_AtSA(W.J, W.st, c.mc, n, ti, tj, lane); });
         SC_SYNC();
         // inertia correction: M + delta I until the Cholesky succeeds
         double delta = 0.0;
@@ -565,29 +631,37 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
 
 size_t mpccbf_lds_bytes(int N, int K) { return mpc_lds_doubles(N, K) * sizeof(double); }
 
+template <typename TIO, int NT, int KT>
+static hipError_t mpc_launch_one(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
+                                 const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
+                                 hipStream_t stream) {
+    const size_t lds = mpc_lds_doubles(p.horizon, K) * sizeof(double);
+    auto kern = mpccbf_kernel<TIO, NT, KT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, B, K, (const TIO*)X, (const TIO*)u_prev,
+                       (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status, iters, (TIO*)z_out);
+    return hipGetLastError();
+}
+
+template <typename TIO>
+static hipError_t mpc_launch_t(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
+                               const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
+                               hipStream_t stream) {
+    if (p.horizon == 10 && K == 8)            // BASELINE config 3
+        return mpc_launch_one<TIO, 10, 8>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+    return mpc_launch_one<TIO, 0, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+}
+
 hipError_t mpccbf_launch(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                          hipStream_t stream) {
-    const size_t lds = mpc_lds_doubles(p.horizon, K) * sizeof(double);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (p.io_dtype == SC_DTYPE_F32) {
-        auto kern = mpccbf_kernel<float>;
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, B, K, (const float*)X, (const float*)u_prev,
-                           (const float*)goal, (const float*)obs, (float*)u_out, status, iters, (float*)z_out);
-    } else {
-        auto kern = mpccbf_kernel<double>;
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-        }
-        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, B, K, (const double*)X, (const double*)u_prev,
-                           (const double*)goal, (const double*)obs, (double*)u_out, status, iters, (double*)z_out);
-    }
-    return hipGetLastError();
+    if (mpc_lds_doubles(p.horizon, K) * sizeof(double) > 160 * 1024) return hipErrorInvalidValue;
+    if (p.io_dtype == SC_DTYPE_F32)
+        return mpc_launch_t<float>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+    return mpc_launch_t<double>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
 }
 
 }  // namespace sc
