@@ -19,7 +19,7 @@
  * keeps no mutable global state besides a thread-local last-error string.
  *
  * Array layouts are exactly the reference's numpy layouts, row-major:
- *   X      [B, 4]     state  [x, y, theta, v]          (robot.X, robots/robot.py:38)
+ *   X      [B, 4]     state  [x, y, theta, v]          (robot.X, robots/robot.py:38; [B, 6] for Quad2D)
  *   u_ref  [B, 2]     nominal input                    (control_ref['u_ref'], tracking.py:607-609)
  *   obs    [B, K, 7]  obstacle rows [x,y,r,vx,vy,-,flag] or [ox,oy,a,b,e,theta,1]
  *                     (nearest_multi_obs, tracking.py:584); [K, 7] when obs_shared != 0
@@ -65,7 +65,8 @@ typedef enum sc_error {
 #define SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF 3  /* dynamic_env/kinematic_bicycle2D_dpcbf.py        */
 #define SC_MODEL_SINGLE_INTEGRATOR2D       4  /* robots/single_integrator2D.py: X = [x, y, -, -], U = [vx, vy]   */
 #define SC_MODEL_DOUBLE_INTEGRATOR2D       5  /* robots/double_integrator2D.py: X = [x, y, vx, vy], U = [ax, ay] */
-#define SC_MODEL_COUNT                     6
+#define SC_MODEL_QUAD2D                    6  /* robots/quad2D.py: X = [x, z, theta, vx, vz, theta_dot] (state_dim 6), U = [F_right, F_left] */
+#define SC_MODEL_COUNT                     7
 
 #define SC_DTYPE_F32 0
 #define SC_DTYPE_F64 1
@@ -84,7 +85,7 @@ typedef struct sc_cbfqp_params {
     int32_t compute_dtype;   /* SC_DTYPE_*: arithmetic type inside the kernel         */
     int32_t cbf_mode;        /* SC_CBF_MODE_*                                         */
     int32_t obs_shared;      /* 0: obs is [B,K,7]; 1: one [K,7] table for all agents  */
-    int32_t reserved0;
+    int32_t state_dim;       /* row length of X: 0 or 4 for the 4-state models, 6 for Quad2D */
     double  robot_radius;    /* robot.robot_radius (robots/robot.py:49-50)            */
     double  dt;              /* robot.dt, used by 'hard' mode only                    */
     double  alpha1;          /* cbf_param['alpha1'] (rel-deg 2) or ['alpha'] (rel-deg 1) */
@@ -92,6 +93,7 @@ typedef struct sc_cbfqp_params {
     double  u_min[2];        /* input box, cbf_qp.py:62-65 / :70-73                   */
     double  u_max[2];
     double  rear_ax_dist;    /* robot_spec['rear_ax_dist'] (KinematicBicycle2D family) */
+    double  mass;            /* robot_spec['mass'] (Quad2D, robots/quad2D.py:41)      */
 } sc_cbfqp_params;
 
 /* ---- library ------------------------------------------------------------ */

@@ -24,11 +24,11 @@
 
 #define KMAX 64
 
-enum { DU = 0, KB = 1, C3BF = 2, DPCBF = 3, SI = 4, DI = 5 };
+enum { DU = 0, KB = 1, C3BF = 2, DPCBF = 3, SI = 4, DI = 5, QUAD2D = 6 };
 
 typedef struct {
     int model, cbf_mode;
-    double R, dt, a1, a2, lo[2], hi[2], Lr;
+    double R, dt, a1, a2, lo[2], hi[2], Lr, mass;
 } par_t;
 
 static void hocbf_circle(const double* X, const double* o, double R, double beta, double* h, double* hdot,
@@ -110,6 +110,18 @@ static void super_terms(const double* X, const double* o, double R, double* h, d
 
 /* one row; returns 0 on bad obstacle flag */
 static int cbf_row(const par_t* p, const double* X, const double* o, double* n, double* c, double* h) {
+    if (p->model == QUAD2D) { /* robots/quad2D.py:46-81,166-177: X = [x, z, th, vx, vz, thdot] */
+        double ex = X[0] - o[0], ez = X[1] - o[1], dmin = o[2] + p->R, nrm = sqrt(ex * ex + ez * ez);
+        double vx = X[3], vz = X[4], sn = sin(X[2]), cs = cos(X[2]);
+        *h = nrm * nrm - 1.01 * dmin * dmin;
+        double hdot = 2.0 * (ex * vx + ez * vz);
+        double a = 2.0 * ex * (-sn / p->mass) + 2.0 * ez * (cs / p->mass);
+        n[0] = a; n[1] = a;
+        double Lf = 2.0 * vx * vx + 2.0 * vz * vz + 2.0 * ez * (-9.81);
+        *c = p->cbf_mode ? (*h / (p->dt * p->dt) + 2.0 * hdot / p->dt + Lf)
+                         : (Lf + (p->a1 + p->a2) * hdot + (p->a1 * p->a2) * (*h));
+        return 1;
+    }
     if (p->model == SI || p->model == DI) {
         double hx, dhx, dhy, hxx = 0, hxy = 0, hyy = 0;
         if (o[6] == 0.0) {
@@ -199,9 +211,10 @@ static int solve_qp2(int m, const double (*G)[2], const double* c, const double*
 int oracle_cbfqp_batch(int model, long B, int K, const double* X, const double* u_ref, const double* obs,
                        int obs_shared, const int* n_obs, double radius, double dt, double alpha1, double alpha2,
                        const double* u_min, const double* u_max, double rear_ax_dist, int cbf_mode,
-                       double* u_out, int* status, double* h_out, int n_threads) {
+                       double* u_out, int* status, double* h_out, int n_threads, int nx, double mass) {
     if (K < 1 || K > KMAX) return 1;
-    par_t p = {model, cbf_mode, radius, dt, alpha1, alpha2, {u_min[0], u_min[1]}, {u_max[0], u_max[1]}, rear_ax_dist};
+    if (nx < 4) nx = 4;
+    par_t p = {model, cbf_mode, radius, dt, alpha1, alpha2, {u_min[0], u_min[1]}, {u_max[0], u_max[1]}, rear_ax_dist, mass};
 #ifdef _OPENMP
     if (n_threads > 0) omp_set_num_threads(n_threads);
 #pragma omp parallel for schedule(static)
@@ -214,7 +227,7 @@ int oracle_cbfqp_batch(int model, long B, int K, const double* X, const double* 
         for (int r = 0; r < K; ++r) {
             G[r][0] = G[r][1] = c[r] = 0.0;
             h = 0.0;
-            if (r < nk && !cbf_row(&p, X + 4 * i, o + 7 * r, G[r], &c[r], &h)) bad = 1;
+            if (r < nk && !cbf_row(&p, X + (size_t)nx * i, o + 7 * r, G[r], &c[r], &h)) bad = 1;
             if (h_out) h_out[(size_t)i * K + r] = (r < nk) ? h : 0.0;
         }
         G[K][0] = 1; G[K][1] = 0; c[K] = -p.lo[0];

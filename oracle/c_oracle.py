@@ -48,7 +48,8 @@ def cbfqp_batch(model, X, u_ref, obs, spec, cbf_param, dt=0.05, cbf_mode="cbf", 
         obs.ctypes.data_as(C.c_void_p), C.c_int(shared), nptr, C.c_double(spec["radius"]), C.c_double(dt),
         C.c_double(a1), C.c_double(a2), lo.ctypes.data_as(C.c_void_p), hi.ctypes.data_as(C.c_void_p),
         C.c_double(spec.get("rear_ax_dist", 0.0)), C.c_int(1 if cbf_mode == "hard" else 0),
-        u.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p), C.c_int(n_threads))
+        u.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p), C.c_int(n_threads),
+        C.c_int(X.shape[1]), C.c_double(spec.get("mass", 1.0)))
     if rc != 0:
         raise ValueError("oracle_cbfqp_batch: bad arguments")
     return u, st, h

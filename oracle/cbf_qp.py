@@ -25,6 +25,9 @@ def input_bounds(model, spec):
         hi = np.array([spec["v_max"], spec["v_max"]], dtype=np.float64)
     elif model == R.MODEL_DI:                              # cbf_qp.py:66-69
         hi = np.array([spec["a_max"], spec["a_max"]], dtype=np.float64)
+    elif model == R.MODEL_QUAD2D:                          # cbf_qp.py:74-79: f_min <= u <= f_max (not symmetric)
+        return (np.array([spec["f_min"], spec["f_min"]], dtype=np.float64),
+                np.array([spec["f_max"], spec["f_max"]], dtype=np.float64))
     else:
         hi = np.array([spec["a_max"], spec["beta_max"]], dtype=np.float64)
     return -hi, hi

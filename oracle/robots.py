@@ -21,6 +21,9 @@ MODEL_KB_DPCBF = 3    # KinematicBicycle2D_DPCBF     (rel-deg 1 dynamic parabola
 MODEL_SI = 4          # SingleIntegrator2D           (rel-deg 1 distance barrier), X = [x, y, -, -], U = [vx, vy]
 MODEL_DI = 5          # DoubleIntegrator2D           (rel-deg 2 HOCBF),            X = [x, y, vx, vy], U = [ax, ay]
 
+MODEL_QUAD2D = 6      # Quad2D (rel-deg 2 HOCBF), X = [x, z, theta, vx, vz, theta_dot], U = [F_right, F_left]
+GRAVITY = 9.81        # robots/quad2D.py:47
+
 MODEL_NAMES = {
     "DynamicUnicycle2D": MODEL_DU,
     "KinematicBicycle2D": MODEL_KB,
@@ -28,9 +31,10 @@ MODEL_NAMES = {
     "KinematicBicycle2D_DPCBF": MODEL_KB_DPCBF,
     "SingleIntegrator2D": MODEL_SI,
     "DoubleIntegrator2D": MODEL_DI,
+    "Quad2D": MODEL_QUAD2D,
 }
 
-REL_DEG2 = (MODEL_DU, MODEL_KB, MODEL_DI)
+REL_DEG2 = (MODEL_DU, MODEL_KB, MODEL_DI, MODEL_QUAD2D)
 
 
 def angle_normalize(x):
@@ -50,6 +54,8 @@ def default_spec(model):
         return dict(v_max=1.0, w_max=0.5, radius=0.25)
     if model == MODEL_DI:                                  # robots/double_integrator2D.py:38-44
         return dict(a_max=1.0, v_max=1.0, w_max=0.5, radius=0.25)
+    if model == MODEL_QUAD2D:                              # robots/quad2D.py:41-44
+        return dict(mass=1.0, inertia=0.01, f_min=1.0, f_max=10.0, radius=0.25)
     rear, wb = 0.2, 0.4
     delta_max = np.deg2rad(32)
     return dict(a_max=5.0, v_max=3.5, v_min=0.2, radius=0.3, rear_ax_dist=rear,
@@ -67,6 +73,8 @@ def f(model, X, spec=None):
         return np.zeros(4)
     if model == MODEL_DI:
         return np.array([X[2], X[3], 0.0, 0.0])
+    if model == MODEL_QUAD2D:                              # robots/quad2D.py:46-58
+        return np.array([X[3], X[4], X[5], 0.0, -GRAVITY, 0.0])
     th, v = X[2], X[3]
     return np.array([v * math.cos(th), v * math.sin(th), 0.0, 0.0])
 
@@ -79,6 +87,10 @@ def g(model, X, spec=None):
         return np.array([[1.0, 0.0], [0.0, 1.0], [0.0, 0.0], [0.0, 0.0]])
     if model == MODEL_DI:                                  # double_integrator2D.py:69-79
         return np.array([[0.0, 0.0], [0.0, 0.0], [1.0, 0.0], [0.0, 1.0]])
+    if model == MODEL_QUAD2D:                              # robots/quad2D.py:68-81
+        m, I, r = spec["mass"], spec["inertia"], spec["radius"]
+        sn, cs = math.sin(X[2]), math.cos(X[2])
+        return np.array([[0, 0, 0, -sn / m, cs / m, r / I], [0, 0, 0, -sn / m, cs / m, -r / I]], dtype=np.float64).T
     th, v = X[2], X[3]
     L_r = spec["rear_ax_dist"]
     return np.array([[0.0, -v * math.sin(th)],
@@ -101,6 +113,9 @@ def step(model, X, U, dt, spec=None):
     """Euler step + heading wrap. DU :75-78 ; KB :113-123 (also clips v to [v_min, v_max])."""
     Xn = np.asarray(X, dtype=np.float64) + (f(model, X, spec) + g(model, X, spec) @ np.asarray(U, dtype=np.float64)) * dt
     if model == MODEL_SI:                                  # single_integrator2D.py:67-69
+        return Xn
+    if model == MODEL_QUAD2D:                              # robots/quad2D.py:83-86
+        Xn[2] = angle_normalize(Xn[2])
         return Xn
     if model == MODEL_DI:                                  # double_integrator2D.py:81-108: speed saturation
         vm = math.sqrt(Xn[2] ** 2 + Xn[3] ** 2)
@@ -358,6 +373,11 @@ def agent_barrier(model, X, obs, R):
         if flag == 1:
             return _hocbf_superellipsoid(X, obs, R)
         raise ValueError("DynamicUnicycle2D: obstacle flag must be 0 or 1")
+    if model == MODEL_QUAD2D:                              # robots/quad2D.py:166-177 (circle only, no flag test)
+        ex, ez = X[0] - obs[0], X[1] - obs[1]
+        d_min = obs[2] + R
+        h = math.sqrt(ex * ex + ez * ez) ** 2 - 1.01 * d_min ** 2
+        return h, 2.0 * (ex * X[3] + ez * X[4]), np.array([2.0 * X[3], 2.0 * X[4], 0.0, 2.0 * ex, 2.0 * ez, 0.0])
     if model == MODEL_SI:
         return _si_barrier(X, obs, R)
     if model == MODEL_DI:

@@ -25,18 +25,21 @@ MODEL_IDS = {
     "KinematicBicycle2D_DPCBF": 3,
     "SingleIntegrator2D": 4,
     "DoubleIntegrator2D": 5,
+    "Quad2D": 6,
 }
+
+STATE_DIM = {"Quad2D": 6}          # everything else: 4
 
 
 class CbfQpParams(C.Structure):
     """Mirror of ``sc_cbfqp_params``."""
     _fields_ = [
         ("model_id", C.c_int32), ("io_dtype", C.c_int32), ("compute_dtype", C.c_int32),
-        ("cbf_mode", C.c_int32), ("obs_shared", C.c_int32), ("reserved0", C.c_int32),
+        ("cbf_mode", C.c_int32), ("obs_shared", C.c_int32), ("state_dim", C.c_int32),
         ("robot_radius", C.c_double), ("dt", C.c_double),
         ("alpha1", C.c_double), ("alpha2", C.c_double),
         ("u_min", C.c_double * 2), ("u_max", C.c_double * 2),
-        ("rear_ax_dist", C.c_double),
+        ("rear_ax_dist", C.c_double), ("mass", C.c_double),
     ]
 
 

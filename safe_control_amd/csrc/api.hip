@@ -54,6 +54,10 @@ static int check_cbfqp(const sc_cbfqp_params* p, int64_t B, int32_t K, const voi
     if (p->model_id >= SC_MODEL_KINEMATIC_BICYCLE2D && p->model_id <= SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF &&
         !(p->rear_ax_dist > 0))
         return fail(SC_ERR_INVALID_ARGUMENT, "rear_ax_dist must be > 0 for the KinematicBicycle2D family");
+    const int want_dim = p->model_id == SC_MODEL_QUAD2D ? 6 : 4;
+    if (!((p->state_dim == 0 && want_dim == 4) || p->state_dim == want_dim))
+        return fail(SC_ERR_INVALID_ARGUMENT, "state_dim must be 4 (or 0) for the 4-state models and 6 for Quad2D");
+    if (p->model_id == SC_MODEL_QUAD2D && !(p->mass > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "mass must be > 0 for Quad2D");
     if (B > 0 && (!X || !u_ref || !obs || !u_out || !status_out))
         return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
     return SC_OK;
@@ -118,7 +122,7 @@ int sc_cbfqp_solve_batch_host(const sc_cbfqp_params* params, int64_t B, int32_t 
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return sc::fail_hip(e, "hipSetDevice");
     const size_t es = params->io_dtype == SC_DTYPE_F64 ? 8 : 4;
-    const size_t nX = (size_t)B * 4 * es, nU = (size_t)B * 2 * es;
+    const size_t nX = (size_t)B * (params->model_id == SC_MODEL_QUAD2D ? 6 : 4) * es, nU = (size_t)B * 2 * es;
     const size_t nO = (params->obs_shared ? (size_t)K * 7 : (size_t)B * K * 7) * es;
     const size_t nH = (size_t)B * K * es, nS = (size_t)B * 4, nN = n_obs ? (size_t)B * 4 : 0;
     // one allocation, 256-byte aligned sections

@@ -40,6 +40,18 @@ static inline bool sc_force_lds_kernel() {
 using as1_void = const __attribute__((address_space(1))) void;
 using as3_void = __attribute__((address_space(3))) void;
 
+// State row -> (x0..x4) in the compute type.  4-state models: two 8/16-byte loads; Quad2D: six values per row.
+template <typename TIO, typename TC, int MODEL>
+__device__ __forceinline__ Agent<TC> load_agent(const TIO* __restrict__ X, long long agent) {
+    if constexpr (MODEL == SC_MODEL_QUAD2D) {
+        const TIO* r = X + agent * 6;
+        return make_agent_m<TC, MODEL>(TC(r[0]), TC(r[1]), TC(r[2]), TC(r[3]), TC(r[4]));
+    } else {
+        const TIO* r = X + agent * 4;
+        return make_agent_m<TC, MODEL>(TC(r[0]), TC(r[1]), TC(r[2]), TC(r[3]));
+    }
+}
+
 template <typename TIO> struct vec2;
 template <> struct vec2<float> { using type = float2; };
 template <> struct vec2<double> { using type = double2; };
@@ -104,8 +116,6 @@ __global__ __launch_bounds__(256) void cbfqp_reg_kernel(const sc_cbfqp_params p,
             for (int f = 0; f < 7; ++f) flat[r * 7 + f] = (r < K) ? src[r * 7 + f] : TIO(0);
         }
     }
-    const V2* Xv = reinterpret_cast<const V2*>(X) + ag_i * 2;
-    const V2 xa = Xv[0], xb = Xv[1];
     const V2 ur = reinterpret_cast<const V2*>(u_ref)[ag_i];
     int nk = K;
     if (n_obs) {
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(256) void cbfqp_reg_kernel(const sc_cbfqp_params p,
     }
     const TC ur0 = TC(ur.x), ur1 = TC(ur.y);
     const CbfConsts<TC> k = make_consts<TC>(p);
-    const Agent<TC> ag = make_agent_m<TC, MODEL>(TC(xa.x), TC(xa.y), TC(xb.x), TC(xb.y));
+    const Agent<TC> ag = load_agent<TIO, TC, MODEL>(X, ag_i);
 
     // ---- rows: agent_barrier + cbf_qp.py:155-183, unrolled, in registers ------------------
     TC n0[KMAX], n1[KMAX], c[KMAX];
@@ -207,8 +217,6 @@ __global__ __launch_bounds__(64) void cbfqp_coop_kernel(const sc_cbfqp_params p,
     const TIO* src = obs + (p.obs_shared ? 0 : (size_t)ag_i * K * 7) + (has_row ? sub * 7 : 0);
 #pragma unroll
     for (int f = 0; f < 7; ++f) orow[f] = src[f];
-    const V2* Xv = reinterpret_cast<const V2*>(X) + ag_i * 2;
-    const V2 xa = Xv[0], xb = Xv[1];
     const V2 ur = reinterpret_cast<const V2*>(u_ref)[ag_i];
     int nk = K;
     if (n_obs) {
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(64) void cbfqp_coop_kernel(const sc_cbfqp_params p,
     }
     const TC ur0 = TC(ur.x), ur1 = TC(ur.y);
     const CbfConsts<TC> k = make_consts<TC>(p);
-    const Agent<TC> ag = make_agent_m<TC, MODEL>(TC(xa.x), TC(xa.y), TC(xb.x), TC(xb.y));
+    const Agent<TC> ag = load_agent<TIO, TC, MODEL>(X, ag_i);
 
     // ---- this lane's row -------------------------------------------------------------------
     TC o[7];
@@ -326,13 +334,10 @@ __global__ __launch_bounds__(64) void cbfqp_kernel(const sc_cbfqp_params p, cons
 
     // state / reference (coalesced, overlaps the DMA)
     using V2 = typename vec2<TIO>::type;
-    TC x = 0, y = 0, th = 0, v = 0, ur0 = 0, ur1 = 0;
+    TC ur0 = 0, ur1 = 0;
     int nk = K;
     if (active) {
-        const V2* Xv = reinterpret_cast<const V2*>(X) + agent * 2;
-        const V2 xa = Xv[0], xb = Xv[1];
         const V2 ur = reinterpret_cast<const V2*>(u_ref)[agent];
-        x = TC(xa.x); y = TC(xa.y); th = TC(xb.x); v = TC(xb.y);
         ur0 = TC(ur.x); ur1 = TC(ur.y);
         if (n_obs) {
             nk = n_obs[agent];
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(64) void cbfqp_kernel(const sc_cbfqp_params p, cons
         }
     }
     const CbfConsts<TC> k = make_consts<TC>(p);
-    const Agent<TC> ag = make_agent_m<TC, MODEL>(x, y, th, v);
+    const Agent<TC> ag = load_agent<TIO, TC, MODEL>(X, active ? agent : 0);
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // LDS-DMA landed (it is tracked by vmcnt)
     __syncthreads();
@@ -486,6 +491,8 @@ static hipError_t launch_model(const sc_cbfqp_params& p, long long B, int K, con
             return launch_k<TIO, TC, SC_MODEL_SINGLE_INTEGRATOR2D>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
         case SC_MODEL_DOUBLE_INTEGRATOR2D:
             return launch_k<TIO, TC, SC_MODEL_DOUBLE_INTEGRATOR2D>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
+        case SC_MODEL_QUAD2D:
+            return launch_k<TIO, TC, SC_MODEL_QUAD2D>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
         default:
             return launch_k<TIO, TC, SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
     }

@@ -18,6 +18,7 @@ struct CbfConsts {
     T inv_dt, inv_dt2;
     T lo0, hi0, lo1, hi1;
     T inv_Lr;      // 1 / rear_ax_dist (KB family)
+    T inv_mass;    // 1 / mass (Quad2D)
     int hard;
 };
 
@@ -34,6 +35,7 @@ __device__ __forceinline__ CbfConsts<T> make_consts(const sc_cbfqp_params& p) {
     k.lo0 = T(p.u_min[0]); k.hi0 = T(p.u_max[0]);
     k.lo1 = T(p.u_min[1]); k.hi1 = T(p.u_max[1]);
     k.inv_Lr = T(p.rear_ax_dist > 0 ? 1.0 / p.rear_ax_dist : 0.0);
+    k.inv_mass = T(p.mass > 0 ? 1.0 / p.mass : 1.0);
     k.hard = p.cbf_mode == SC_CBF_MODE_HARD;
     return k;
 }
@@ -58,8 +60,15 @@ __device__ __forceinline__ Agent<T> make_agent(T x, T y, T th, T v) {
 // Integrator models keep (vx, vy) where the unicycle keeps (theta, v): f(x)[0:2] = (vx, vy) for the double
 // integrator (robots/double_integrator2D.py:46-59), zero for the single integrator (single_integrator2D.py:45-55).
 template <typename T, int MODEL>
-__device__ __forceinline__ Agent<T> make_agent_m(T x0, T x1, T x2, T x3) {
-    if constexpr (MODEL == SC_MODEL_SINGLE_INTEGRATOR2D || MODEL == SC_MODEL_DOUBLE_INTEGRATOR2D) {
+__device__ __forceinline__ Agent<T> make_agent_m(T x0, T x1, T x2, T x3, T x4 = T(0)) {
+    if constexpr (MODEL == SC_MODEL_QUAD2D) {
+        // robots/quad2D.py:46-58: f(x)[0:2] = (vx, vz); the heading only enters through g
+        Agent<T> a;
+        a.x = x0; a.y = x1; a.th = x2; a.v = T(0);
+        sincos_(x2, &a.s, &a.c);
+        a.f0 = x3; a.f1 = x4;
+        return a;
+    } else if constexpr (MODEL == SC_MODEL_SINGLE_INTEGRATOR2D || MODEL == SC_MODEL_DOUBLE_INTEGRATOR2D) {
         Agent<T> a;
         a.x = x0; a.y = x1; a.th = T(0); a.v = T(0); a.c = T(1); a.s = T(0);
         a.f0 = (MODEL == SC_MODEL_DOUBLE_INTEGRATOR2D) ? x2 : T(0);
@@ -206,7 +215,18 @@ __device__ __forceinline__ void dpcbf(const Agent<T>& a, const T* o, T R, T& h, 
 template <typename T, int MODEL, bool OUTLINE_RARE = false>
 __device__ __forceinline__ bool cbf_row(const Agent<T>& a, const T* o, const CbfConsts<T>& k,
                                         T& n0, T& n1, T& c, T& h) {
-    if constexpr (MODEL == SC_MODEL_SINGLE_INTEGRATOR2D || MODEL == SC_MODEL_DOUBLE_INTEGRATOR2D) {
+    if constexpr (MODEL == SC_MODEL_QUAD2D) {
+        // robots/quad2D.py:166-177 (circle, no flag test) with g of :68-81: both thrusts enter identically,
+        // A = dh_dot_dx g = [a, a],  a = (2 ex (-sin th) + 2 ez cos th) / m;  L_f = 2 |v|^2 - 2 g ez
+        const T ex = a.x - o[0], ez = a.y - o[1];
+        const T dmin = o[2] + k.R;
+        h = (ex * ex + ez * ez) - T(1.01) * dmin * dmin;
+        const T hdot = T(2) * (ex * a.f0 + ez * a.f1);
+        n0 = (T(2) * ex * (-a.s) + T(2) * ez * a.c) * k.inv_mass;
+        n1 = n0;
+        const T Lf = T(2) * a.f0 * a.f0 + T(2) * a.f1 * a.f1 + T(2) * ez * T(-9.81);
+        c = k.hard ? (h * k.inv_dt2 + T(2) * hdot * k.inv_dt + Lf) : (Lf + k.g1 * hdot + k.g2 * h);
+    } else if constexpr (MODEL == SC_MODEL_SINGLE_INTEGRATOR2D || MODEL == SC_MODEL_DOUBLE_INTEGRATOR2D) {
         // SI robots/single_integrator2D.py:119-149 (rel-deg 1), DI robots/double_integrator2D.py:167-220 (rel-deg 2);
         // g is the identity on the actuated pair, so A = dh/dp for both.
         const T flag = o[6];

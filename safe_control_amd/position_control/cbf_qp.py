@@ -19,7 +19,7 @@ import numpy as np
 from .. import _lib
 from ..robots.spec import complete_robot_spec
 
-REL_DEG2_MODELS = ("DynamicUnicycle2D", "KinematicBicycle2D", "DoubleIntegrator2D")
+REL_DEG2_MODELS = ("DynamicUnicycle2D", "KinematicBicycle2D", "DoubleIntegrator2D", "Quad2D")
 
 
 def default_cbf_param(model):
@@ -47,6 +47,8 @@ def input_bounds(robot_spec):
         hi = (float(robot_spec["v_max"]), float(robot_spec["v_max"]))
     elif robot_spec["model"] == "DoubleIntegrator2D":          # cbf_qp.py:66-69
         hi = (float(robot_spec["a_max"]), float(robot_spec["a_max"]))
+    elif robot_spec["model"] == "Quad2D":                      # cbf_qp.py:74-79: f_min <= u <= f_max
+        return ((float(robot_spec["f_min"]),) * 2, (float(robot_spec["f_max"]),) * 2)
     else:
         hi = (float(robot_spec["a_max"]), float(robot_spec["beta_max"]))
     return (-hi[0], -hi[1]), hi
@@ -73,6 +75,8 @@ def make_params(robot_spec, cbf_param, dt, radius, io_dtype, compute_dtype, obs_
     p.u_min[0], p.u_min[1] = lo
     p.u_max[0], p.u_max[1] = hi
     p.rear_ax_dist = float(robot_spec.get("rear_ax_dist", 0.0))
+    p.state_dim = _lib.STATE_DIM.get(model, 4)
+    p.mass = float(robot_spec.get("mass", 1.0))
     return p
 
 
@@ -124,8 +128,9 @@ class CBFQP:
         if k:
             obs[:k] = np.asarray(rows)
         n_obs = np.array([k], dtype=np.int32)
-        xs = np.asarray(robot_state, dtype=np.float64).reshape(-1)[:4]
-        X = np.zeros(4, dtype=np.float64)                 # SingleIntegrator2D has 2 states: padded to the [B,4] layout
+        nx = _lib.STATE_DIM.get(self.robot_spec["model"], 4)
+        xs = np.asarray(robot_state, dtype=np.float64).reshape(-1)[:nx]
+        X = np.zeros(nx, dtype=np.float64)                # SingleIntegrator2D has 2 states: padded to the [B,4] layout
         X[: xs.shape[0]] = xs
         p = make_params(self.robot_spec, self.cbf_param, self.robot.dt, self.robot.robot_radius,
                         _lib.DTYPE_F64, _lib.DTYPE_F64)
@@ -176,8 +181,9 @@ class BatchedCBFQP:
         B = X.shape[0]
         shared = obs.dim() == 2
         K = obs.shape[-2]
-        if X.shape != (B, 4) or u_ref.shape != (B, 2) or obs.shape[-1] != 7 or (not shared and obs.shape[0] != B):
-            raise ValueError("expected X[B,4], u_ref[B,2], obs[B,K,7] or obs[K,7]")
+        nx = _lib.STATE_DIM.get(self.robot_spec["model"], 4)
+        if X.shape != (B, nx) or u_ref.shape != (B, 2) or obs.shape[-1] != 7 or (not shared and obs.shape[0] != B):
+            raise ValueError(f"expected X[B,{nx}], u_ref[B,2], obs[B,K,7] or obs[K,7]")
         if n_obs is not None and not (n_obs.is_cuda and n_obs.dtype == torch.int32 and n_obs.shape == (B,)
                                       and n_obs.is_contiguous()):
             raise ValueError("n_obs must be a contiguous CUDA int32 tensor of shape [B]")

@@ -382,7 +382,47 @@ def gen_integrators():
     np.savez_compressed(os.path.join(HERE, "integrators.npz"), **out)
 
 
+def gen_quad2d():
+    """Quad2D (6 states, thrust inputs with an asymmetric box): f, g, step, agent_barrier, CBF rows."""
+    rng = np.random.default_rng(99)
+    out = {}
+    spec = {"model": "Quad2D", "f_min": 3.0, "f_max": 10.0, "radius": 0.25}      # examples/test_tracking.py:112-118
+    robot = BaseRobot(np.zeros((6, 1)), spec, DT, NullAxes())
+    ctrl = CBFQP(robot, spec, num_obs=6)
+    ctrl.cbf_controller = OracleProblem(ctrl, np.array([spec["f_min"]] * 2), np.array([spec["f_max"]] * 2))
+    rec = {k: [] for k in ["X", "U", "u_ref", "obs", "k", "f", "g", "step", "h", "hdot", "dhd", "A", "b",
+                           "u_star_oracle", "status_oracle"]}
+    for i in range(140):
+        X = np.array([*rng.uniform(0, 14, 2), rng.uniform(-0.6, 0.6), *rng.uniform(-1.5, 1.5, 2), rng.uniform(-1, 1)])
+        U = rng.uniform(3.0, 10.0, 2)
+        K = int(rng.integers(1, 7))
+        obs = draw_circles(rng, np.array([X[0], X[1], 0, 0]), K, spec["radius"], overlap=(i % 6 == 0), rho_max=3.5)
+        u_ref = rng.uniform(2.0, 11.0, 2)                                       # some outside [f_min, f_max]
+        robot.X = X.reshape(-1, 1).copy()
+        rec["f"].append(np.asarray(robot.f(), dtype=float).reshape(-1))
+        rec["g"].append(np.asarray(robot.g(), dtype=float))
+        bar = robot.agent_barrier(obs[0])
+        rec["h"].append(float(np.asarray(bar[0]).reshape(-1)[0])); rec["hdot"].append(float(np.asarray(bar[1]).reshape(-1)[0]))
+        rec["dhd"].append(np.asarray(bar[2], dtype=float).reshape(-1))
+        A, b, u, status = run_cbfqp_case(ctrl, robot, X, u_ref, list(obs))
+        robot.X = X.reshape(-1, 1).copy()
+        Xn = robot.robot.step(robot.X.copy(), U.reshape(-1, 1)).reshape(-1).copy()
+        obs_p = np.full((6, 7), np.nan); obs_p[:K] = obs
+        rec["X"].append(X); rec["U"].append(U); rec["u_ref"].append(u_ref); rec["obs"].append(obs_p); rec["k"].append(K)
+        rec["step"].append(Xn); rec["A"].append(A); rec["b"].append(b)
+        rec["u_star_oracle"].append(np.full(2, np.nan) if u is None else u)
+        rec["status_oracle"].append(0 if status == "optimal" else 1)
+    for k, v in rec.items():
+        out[f"Quad2D/{k}"] = np.array(v)
+    out["Quad2D/meta"] = np.array([spec["f_min"], spec["f_max"], spec["radius"], robot.robot_spec["mass"], robot.robot_spec["inertia"]])
+    print("Quad2D cases", len(rec["k"]), "infeasible", int(np.sum(rec["status_oracle"])))
+    np.savez_compressed(os.path.join(HERE, "quad2d.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "quad2d":
+        gen_quad2d()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "integrators":
         gen_integrators()
         sys.exit(0)
@@ -392,3 +432,4 @@ if __name__ == "__main__":
     gen_nearest(rng)
     gen_closed_loop()
     gen_integrators()
+    gen_quad2d()

@@ -225,6 +225,31 @@ def _bad_flag_case(B):
     assert np.array_equal(sg[other], so)
 
 
+def test_degenerate_geometry():
+    """Duplicate obstacles (parallel duplicate rows), an agent standing still (v = 0: second column of every row
+    vanishes), obstacle rows collinear with the agent, an agent exactly on an obstacle centre, huge coordinates."""
+    rng = np.random.default_rng(99)
+    for B in (512, 33000):                                  # cooperative kernel and lane-per-QP kernel
+        X, goal, u_ref, obs = W.du_cbfqp_batch(B, 8, seed=B + 1)
+        obs[0::7, 3] = obs[0::7, 1]                          # exact duplicates
+        obs[1::7, 5] = obs[1::7, 4]; obs[1::7, 6] = obs[1::7, 4]
+        X[2::7, 3] = 0.0                                     # standing still
+        th = X[3::7, 2]
+        for k in range(4):                                   # collinear obstacles straight ahead
+            obs[3::7, k, 0] = X[3::7, 0] + (1.5 + k) * np.cos(th)
+            obs[3::7, k, 1] = X[3::7, 1] + (1.5 + k) * np.sin(th)
+            obs[3::7, k, 2] = 0.3
+        obs[4::7, 2, 0:2] = X[4::7, 0:2]                     # agent on the obstacle centre (h < 0)
+        X[5::7, 0:2] += 1e6; obs[5::7, :, 0:2] += 1e6        # far from the origin
+        u_ref = np.where(rng.random((B, 1)) < 0.3, u_ref * 5.0, u_ref)
+        for io, comp in (("f64", "f64"), ("f32", "f64")):
+            if io == "f32":
+                keep = np.ones(B, bool); keep[5::7] = False   # 1e6 + O(1) is not representable in f32 storage
+                compare(R.MODEL_DU, du_spec(), X[keep], u_ref[keep], obs[keep], io, comp)
+            else:
+                compare(R.MODEL_DU, du_spec(), X, u_ref, obs, io, comp)
+
+
 # ------------------------------------------------------------------ golden fixtures
 def test_golden_cases_through_dropin_class(golden_dir):
     """tests/golden/cbfqp_cases.npz through the reference-shaped CBFQP class (host-pointer C-ABI)."""
@@ -292,6 +317,46 @@ def test_integrator_models(golden_dir, name, model):
             obs[i, 2] = [X[i, 0] + rho * np.cos(phi), X[i, 1] + rho * np.sin(phi), a, b, float(rng.choice([4, 6])),
                          rng.uniform(-np.pi, np.pi), 1.0]
         compare(model, spec, X, u_ref, obs, "f64", "f64")
+
+
+def test_quad2d_model(golden_dir):
+    """Quad2D (6 states, thrust box [f_min, f_max], both inputs enter identically => all rows parallel):
+    reference-generated cases through the drop-in class, then 3000 / 40000-agent batches vs the C oracle."""
+    g = np.load(os.path.join(golden_dir, "quad2d.npz"))
+    G = {k.split("/", 1)[1]: g[k] for k in g.files}
+    spec = {"model": "Quad2D", "f_min": 3.0, "f_max": 10.0, "radius": 0.25}
+    robot = sca.RobotHandle(np.zeros(6), dict(spec), dt=0.05)
+    ctl = sca.CBFQP(robot, dict(spec), num_obs=6)
+    for i in range(len(G["X"])):
+        robot.X = G["X"][i].reshape(-1, 1)
+        u = ctl.solve_control_problem(robot.X, {"u_ref": G["u_ref"][i].reshape(2, 1)}, list(G["obs"][i][: int(G["k"][i])]))
+        if G["status_oracle"][i] == 0:
+            assert ctl.status == "optimal", i
+            np.testing.assert_allclose(u.reshape(-1), G["u_star_oracle"][i], rtol=1e-7, atol=1e-7)
+        else:
+            assert u is None and ctl.status != "optimal", i
+    ospec = R.default_spec(R.MODEL_QUAD2D); ospec.update(f_min=3.0, f_max=10.0)
+    cp = ocbf.default_cbf_param(R.MODEL_QUAD2D)
+    for B in (3000, 40000):
+        rng = np.random.default_rng(B)
+        Xd, goal, _, obs = W.du_cbfqp_batch(B, 6, seed=B + 5)
+        X = np.column_stack([Xd[:, 0], Xd[:, 1], rng.uniform(-0.6, 0.6, B), rng.uniform(-1.5, 1.5, B),
+                             rng.uniform(-1.5, 1.5, B), rng.uniform(-1, 1, B)])
+        u_ref = rng.uniform(2.0, 11.0, (B, 2))
+        for io in ("f64", "f32"):
+            bc = sca.BatchedCBFQP(dict(spec), io_dtype=io, compute_dtype="f64")
+            td = bc.torch_dtype
+            tX, tu, to = (torch.tensor(a, dtype=td, device=DEV) for a in (X, u_ref, obs))
+            u, st, h = bc.solve(tX, tu, to)
+            uo, so, ho = c_oracle.cbfqp_batch(R.MODEL_QUAD2D, tX.double().cpu().numpy(), tu.double().cpu().numpy(),
+                                              to.double().cpu().numpy(), ospec, cp, n_threads=4)
+            sg = st.cpu().numpy()
+            assert (sg == so).mean() >= 0.999
+            ok = (sg == 0) & (so == 0)
+            assert 0.3 < ok.mean() < 1.0
+            err = np.abs(u.double().cpu().numpy()[ok] - uo[ok]).max()
+            assert err <= (1e-6 if io == "f64" else 5e-5), err
+            assert np.abs(h.double().cpu().numpy() - ho).max() <= (1e-9 if io == "f64" else 1e-4)
 
 
 # ------------------------------------------------------------------ closed loop through the plugin surface

@@ -33,10 +33,11 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_params_struct_layout_matches_header():
-    # 6 x int32 + 9 x double, no padding surprises
-    assert C.sizeof(_lib.CbfQpParams) == 6 * 4 + 9 * 8
+    # 6 x int32 + 10 x double, no padding surprises
+    assert C.sizeof(_lib.CbfQpParams) == 6 * 4 + 10 * 8
     assert _lib.CbfQpParams.robot_radius.offset == 24
     assert _lib.CbfQpParams.rear_ax_dist.offset == 24 + 8 * 8
+    assert _lib.CbfQpParams.mass.offset == 24 + 9 * 8
 
 
 def test_argument_validation_without_gpu():

@@ -240,3 +240,26 @@ def test_integrator_models_against_reference(golden_dir, name, model):
         assert r["status"] == int(G["status_oracle"][i])
         if r["status"] == 0:
             np.testing.assert_allclose(r["u"], G["u_star_oracle"][i], rtol=1e-8, atol=1e-8)
+
+
+def test_quad2d_against_reference(golden_dir):
+    """tests/golden/quad2d.npz: f, g, step, agent_barrier, CBF rows (reference code verbatim), u*."""
+    g = np.load(os.path.join(golden_dir, "quad2d.npz"))
+    G = {k.split("/", 1)[1]: g[k] for k in g.files}
+    m = R.MODEL_QUAD2D
+    spec = R.default_spec(m)
+    spec.update(f_min=3.0, f_max=10.0)
+    for i in range(len(G["X"])):
+        X, K = G["X"][i], int(G["k"][i])
+        np.testing.assert_allclose(R.f(m, X, spec), G["f"][i], atol=1e-12)
+        np.testing.assert_allclose(R.g(m, X, spec), G["g"][i], atol=1e-12)
+        np.testing.assert_allclose(R.step(m, X, G["U"][i], 0.05, spec), G["step"][i], atol=1e-12)
+        h, hd, dhd = R.agent_barrier(m, X, G["obs"][i][0], spec["radius"])
+        np.testing.assert_allclose([h, hd], [G["h"][i], G["hdot"][i]], rtol=1e-10)
+        np.testing.assert_allclose(dhd, G["dhd"][i], rtol=1e-10, atol=1e-12)
+        r = cbf_qp.solve(m, X, G["u_ref"][i], list(G["obs"][i][:K]), spec, num_obs=6)
+        np.testing.assert_allclose(r["A"], G["A"][i], rtol=1e-9, atol=1e-8)
+        assert np.all(np.abs(r["b"] - G["b"][i]) <= 1e-9 * (1 + np.abs(G["b"][i])))
+        assert r["status"] == int(G["status_oracle"][i])
+        if r["status"] == 0:
+            np.testing.assert_allclose(r["u"], G["u_star_oracle"][i], rtol=1e-8, atol=1e-8)
