@@ -28,6 +28,14 @@ namespace sc {
 
 #define SC_SYNC() __syncthreads()
 
+// -DSC_MPC_PROF: developer build that returns per-phase shader-clock totals in z_out instead of the solution
+// (tools/exp_mpc_phases.py); never defined in the shipped library.
+#ifdef SC_MPC_PROF
+#define SC_PH(i) do { const long long t_ = clock64(); ph[i] += (double)(t_ - tph); tph = t_; } while (0)
+#else
+#define SC_PH(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ double wsum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -122,14 +130,14 @@ struct MpcMem {                 // LDS carve-up (doubles)
     double *g, *sl, *lam, *ds, *dlam, *w, *st;    // m
     double *J;                                    // mc*n   (CBF rows only)
     double *dP;                                   // (N+2)*2*n
-    double *M, *L;                                // n*n
+    double *M, *L;                                // n*n, n*(n+1)
 };
 
 __host__ __device__ inline size_t mpc_lds_doubles(int N, int K) {
     const size_t n = 2 * (size_t)N, mc = (size_t)N * K, m = mc + 2 * N + 2 * n;
     return 6 * n + 4 * (N + 1) + 4 * 2 * (N + 2) + 3 * (N + 2) + (size_t)K * 7 + 2 * (size_t)(N + 2) * K +
            (size_t)(N + 2) * K * 2 + (size_t)(N + 2) * K * 3 + (size_t)(N + 2) * 3 + 7 * m + mc * n +
-           (size_t)(N + 2) * 2 * n + 2 * n * n;
+           (size_t)(N + 2) * 2 * n + 2 * n * n + n;
 }
 
 __device__ inline MpcMem carve(double* b, int N, int K) {
@@ -148,7 +156,7 @@ __device__ inline MpcMem carve(double* b, int N, int K) {
     M.g = take(m); M.sl = take(m); M.lam = take(m); M.ds = take(m); M.dlam = take(m); M.w = take(m); M.st = take(m);
     M.J = take((size_t)mc * n);
     M.dP = take((size_t)(N + 2) * 2 * n);
-    M.M = take((size_t)n * n); M.L = take((size_t)n * n);
+    M.M = take((size_t)n * n); M.L = take((size_t)n * (n + 1));
     return M;
 }
 
@@ -403,6 +411,68 @@ __device__ inline void chol_solve(const double* L, double* b, int n, int lane) {
     }
 }
 
+// ---- register-resident Cholesky for a compile-time order (n = 2 NT <= 64) -------------------------------------
+// Lane i < n keeps row i of the matrix in VGPRs; a pivot row element is broadcast with v_readlane (the source lane
+// is a compile-time constant in the fully unrolled loops), so a column step costs no LDS round trip and no barrier:
+// ~1.3 k instructions for n = 20 against 60 barrier-separated LDS passes in cholesky()/chol_solve().
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// In: a[k] = A[lane][k] (lower triangle used).  Out: a[k] = L[lane][k] for k <= lane, piv_out = L[lane][lane].
+// Same operation order as cholesky(): right-looking, l_ij = a_ij / sqrt(d_j).  Returns false on a pivot <= 0.
+template <int n>
+__device__ __forceinline__ bool chol_reg(double (&a)[n], int lane, double& diag) {
+    diag = 1.0;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+        const double d = bcast_lane(a[j], j);
+        if (!(d > 0.0)) return false;                  // uniform
+        const double piv = sqrt(d);
+        a[j] = (lane == j) ? piv : a[j] / piv;
+        diag = (lane == j) ? piv : diag;
+#pragma unroll
+        for (int k = j + 1; k < n; ++k) {
+            const double lkj = bcast_lane(a[j], k);
+            a[k] -= a[j] * lkj;                        // meaningful for lanes >= k; the upper triangle is never read
+        }
+    }
+    return true;
+}
+
+// Solve L L' x = b with L row-held in a[] (from chol_reg), b = this lane's right-hand-side entry.  Lt is an LDS
+// scratch of n (n + 1) doubles used once to transpose L (row stride n + 1 keeps the 64 banks conflict-free).
+template <int n>
+__device__ __forceinline__ double chol_solve_reg(double (&a)[n], double diag, double b, double* Lt, int lane) {
+    const double dinv = 1.0 / diag;
+    constexpr int ld = n + 1;
+#pragma unroll
+    for (int k = 0; k < n; ++k) {
+        if (lane < n && k < lane) Lt[lane * ld + k] = a[k];
+        a[k] = (lane > k && lane < n) ? a[k] : 0.0;    // strictly lower part only: the updates below need no select
+    }
+    // forward  L y = b
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+        const double yj = bcast_lane(b * dinv, j);
+        b -= a[j] * yj;
+    }
+    b *= dinv;                                          // y_i
+    SC_SYNC();
+    double c[n];                                        // c[k] = L[k][lane] for k > lane (column of L)
+#pragma unroll
+    for (int k = 0; k < n; ++k) c[k] = (k > lane && lane < n) ? Lt[k * ld + lane] : 0.0;
+    // backward  L' x = y
+#pragma unroll
+    for (int j = n - 1; j >= 0; --j) {
+        const double xj = bcast_lane(b * dinv, j);
+        b -= c[j] * xj;
+    }
+    return b * dinv;
+}
+
 // (J' w)[col] over all rows: CBF rows dense, speed rows -/+ dt for stages k > j, box rows -/+ identity
 __device__ inline double jt_times(const MpcMem& W, const MpcConst& c, const double* w, int col) {
     const int N = c.N, n = c.n, j = col >> 1;
@@ -485,12 +555,18 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
     SC_SYNC();
 
     int status = SC_STATUS_INACCURATE, it = 0;
+#ifdef SC_MPC_PROF
+    double ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tph = clock64();
+#endif
     const double tau = 0.995;
     double nu = 10.0, delta_last = 0.0, e_best = 1e300;
     for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
     for (it = 1; it <= p.max_iter; ++it) {
         if (it > 1) f = eval_values(W.z, W, c, lane, true);
+        SC_PH(0);
         eval_derivs(W, c, lane, 1.0 / sf);
+        SC_PH(1);
         // residuals
         double e_d = 0.0, e_p = 0.0, e_c0 = 0.0, lmax = 0.0;
         for (int col = lane; col < n; col += 64) {
@@ -519,6 +595,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             if (e_mu <= 10.0 * mu && mu > p.mu_min) mu = fmax(p.mu_min, fmin(0.2 * mu, pow(mu, 1.5)));
             else break;
         }
+        SC_PH(2);
         // condensed system  (sf W + J' Sigma J) dz = -sf grad + J' (mu/s - Sigma r_p)
         for (int i = lane; i < m; i += 64) {
             const double s = W.sl[i], sig = W.lam[i] / s;
@@ -542,20 +619,40 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         SC_SYNC();
         mfma_accumulate_sym(W.M, n, lane, [&](int ti, int tj) { return mfma_tile_AtSA(W.J, W.st, c.mc, n, ti, tj, lane); });
         SC_SYNC();
+        SC_PH(3);
         // inertia correction: M + delta I until the Cholesky succeeds
         double delta = 0.0;
         bool ok = false;
-        for (int t = 0; t < 40 && !ok; ++t) {
-            for (int e = lane; e < n * n; e += 64) W.L[e] = W.M[e] + ((e / n == e % n) ? delta : 0.0);
+        if constexpr (NT > 0) {
+            constexpr int nn = 2 * NT;
+            double a[nn], diag;
+            for (int t = 0; t < 40 && !ok; ++t) {
+#pragma unroll
+                for (int k = 0; k < nn; ++k) a[k] = (lane < nn) ? W.M[lane * nn + k] + (lane == k ? delta : 0.0) : 0.0;
+                ok = chol_reg<nn>(a, lane, diag);
+                if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
+            }
+            if (!ok) break;
+            if (delta > 0.0) delta_last = delta;
+            SC_PH(4);
+            const double x = chol_solve_reg<nn>(a, diag, lane < nn ? W.rhs[lane] : 0.0, W.L, lane);
+            if (lane < nn) W.dz[lane] = x;
             SC_SYNC();
-            ok = cholesky(W.L, n, lane);
-            if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
+        } else {
+            for (int t = 0; t < 40 && !ok; ++t) {
+                for (int e = lane; e < n * n; e += 64) W.L[e] = W.M[e] + ((e / n == e % n) ? delta : 0.0);
+                SC_SYNC();
+                ok = cholesky(W.L, n, lane);
+                if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
+            }
+            if (!ok) break;
+            if (delta > 0.0) delta_last = delta;
+            SC_PH(4);
+            for (int i = lane; i < n; i += 64) W.dz[i] = W.rhs[i];
+            SC_SYNC();
+            chol_solve(W.L, W.dz, n, lane);
         }
-        if (!ok) break;
-        if (delta > 0.0) delta_last = delta;
-        for (int i = lane; i < n; i += 64) W.dz[i] = W.rhs[i];
-        SC_SYNC();
-        chol_solve(W.L, W.dz, n, lane);
+        SC_PH(5);
         // ds, dlam, step lengths
         double ap = 1.0, ad = 1.0, sum_ds_s = 0.0, sum_rp = 0.0, sum_log = 0.0;
         for (int i = lane; i < m; i += 64) {
@@ -574,6 +671,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         gdz = wsum(gdz);
         const double phi0 = sf * f - mu * sum_log + nu * sum_rp;
         const double dphi = gdz - mu * sum_ds_s - nu * sum_rp;
+        SC_PH(6);
         // l1-merit backtracking
         double alpha = ap;
         bool accepted = false;
@@ -593,6 +691,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0)) { accepted = true; break; }
             alpha *= 0.5;
         }
+        SC_PH(7);
         if (!accepted) break;
         for (int i = lane; i < n; i += 64) W.z[i] = W.z[i] + alpha * W.dz[i];
         for (int i = lane; i < m; i += 64) {
@@ -602,6 +701,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             W.sl[i] = s; W.lam[i] = lam;
         }
         SC_SYNC();
+        SC_PH(8);
     }
     if (it > p.max_iter) it = p.max_iter;
     if (status != SC_STATUS_OPTIMAL && e_best <= p.acceptable_tol) {
@@ -626,7 +726,11 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         status_out[prob] = status;
         if (iters_out) iters_out[prob] = it;
     }
+#ifdef SC_MPC_PROF
+    if (z_out && lane < 12) z_out[prob * n + lane] = (TIO)ph[lane];
+#else
     if (z_out) for (int i = lane; i < n; i += 64) z_out[prob * n + i] = (TIO)W.z[i];
+#endif
 }
 
 size_t mpccbf_lds_bytes(int N, int K) { return mpc_lds_doubles(N, K) * sizeof(double); }
