@@ -54,108 +54,59 @@ __device__ __forceinline__ double wmax(double v) {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-// ---- f64 MFMA tiles (v_mfma_f64_16x16x4_f64) for the two dense contractions of an iteration ------------
-// Operand layout (MI355X guide, "f64 MFMA"): lane l feeds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
-// result register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15].
-//
-// tile (ti, tj) of  M += A' diag(sig) A  for a row-major A [rows][n] in LDS (the CBF Jacobian): the K-dimension
-// of the contraction is the constraint index.
-__device__ __forceinline__ d4_t mfma_tile_AtSA(const double* A, const double* sig, int rows, int n, int ti, int tj, int lane) {
-    const int q = lane >> 4, cA = 16 * ti + (lane & 15), cB = 16 * tj + (lane & 15);
-    const bool okA = cA < n, okB = cB < n;
-    const int ca = okA ? cA : 0, cb = okB ? cB : 0;
-    d4_t acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < rows; k0 += 4) {
-        const int row = k0 + q;
-        const bool okr = row < rows;
-        const int rr = okr ? row : 0;
-        double a = A[(size_t)rr * n + ca] * sig[rr];
-        double b = A[(size_t)rr * n + cb];
-        a = (okA && okr) ? a : 0.0;
-        b = (okB && okr) ? b : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    return acc;
-}
-
-// tile (ti, tj) of  sum_k dP_k' Om_k dP_k  (dP row-major [2 (N+2)][n], Om_k symmetric 2x2 as xx, xy, yy)
-__device__ __forceinline__ d4_t mfma_tile_PtOP(const double* dP, const double* Om, int rows, int n, int ti, int tj, int lane) {
-    const int q = lane >> 4, cA = 16 * ti + (lane & 15), cB = 16 * tj + (lane & 15);
-    const bool okA = cA < n, okB = cB < n;
-    const int ca = okA ? cA : 0, cb = okB ? cB : 0;
-    d4_t acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < rows; k0 += 4) {
-        const int row = k0 + q;                          // row = 2 k + d
-        const bool okr = row < rows;
-        const int rr = okr ? row : 0, k = rr >> 1, d = rr & 1;
-        double a = dP[(size_t)rr * n + ca];
-        const double o0 = d ? Om[3 * k + 1] : Om[3 * k], o1 = d ? Om[3 * k + 2] : Om[3 * k + 1];
-        double b = o0 * dP[(size_t)(2 * k) * n + cb] + o1 * dP[(size_t)(2 * k + 1) * n + cb];
-        a = (okA && okr) ? a : 0.0;
-        b = (okB && okr) ? b : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-    }
-    return acc;
-}
-
-// add the lower-triangular tiles of a symmetric product into M (mirroring the off-diagonal tiles)
-template <typename TileFn>
-__device__ __forceinline__ void mfma_accumulate_sym(double* M, int n, int lane, TileFn tile) {
-    const int nt = (n + 15) >> 4;
-    for (int ti = 0; ti < nt; ++ti) {
-        for (int tj = 0; tj <= ti; ++tj) {
-            const d4_t acc = tile(ti, tj);
+// inclusive suffix sum over lanes: out[l] = sum_{l' >= l} v[l'] (v must be 0 in lanes outside the range of interest)
+__device__ __forceinline__ double suffix_sum(double v, int lane) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
-                if (row < n && col < n) {
-                    M[(size_t)row * n + col] += acc[r];
-                    if (ti != tj) M[(size_t)col * n + row] += acc[r];
-                }
-            }
-        }
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_down(v, o);
+        if (lane + o < 64) v += t;
     }
+    return v;
 }
 
-struct MpcMem {                 // LDS carve-up (doubles)
-    double *z, *zt, *dz, *grad, *rhs, *zb;        // n
+struct MpcMem {                 // LDS carve-up (doubles); NP = N + 2 predicted positions, n = 2 N, m rows
+    double *z, *zt, *dz, *rhs, *zb;               // n
+    double *cv;                                   // 3 n : column pass results (r_d | J'(1/s) | J'(sig r_p + lam))
     double *TH, *V, *C, *S;                       // N+1
-    double *pos, *PC, *PD, *q;                    // 2*(N+2)
-    double *SA, *SB, *SV;                         // N+2 suffix sums
+    double *pos, *PC, *PD, *dp;                   // 2 NP
+    double *Y;                                    // 3 * 2 NP : position-space vectors  q | A'(1/s) | A'(sig r_p + lam)
+    double *dV;                                   // N+1
+    double *SA, *SB, *SS;                         // NP suffix sums
     double *obs;                                  // K*7
-    double *hk, *mu;                              // (N+2)*K
-    double *dh;                                   // (N+2)*K*2
-    double *Hh;                                   // (N+2)*K*3
-    double *Om;                                   // (N+2)*3
-    double *g, *sl, *lam, *ds, *dlam, *w, *st;    // m
-    double *J;                                    // mc*n   (CBF rows only)
-    double *dP;                                   // (N+2)*2*n
-    double *M, *L;                                // n*n, n*(n+1)
+    double *hk;                                   // NP*K
+    double *dh;                                   // NP*K*2
+    double *Hh;                                   // NP*K*3
+    double *g, *sl, *lam, *st;                    // m
+    double *ds, *dlam;                            // m   (aliases: is = ds, vb = dlam, dead before ds/dlam are written)
+    double *Phi;                                  // 2 NP * 10 : block-pentadiagonal position-space matrix, band rows
+    double *dP, *T;                               // 2 NP * n : G = d p / d z  and  T = Phi G
+    double *M, *L;                                // n*n condensed matrix; n*(n+1) transposition scratch / LDS Cholesky
 };
 
 __host__ __device__ inline size_t mpc_lds_doubles(int N, int K) {
-    const size_t n = 2 * (size_t)N, mc = (size_t)N * K, m = mc + 2 * N + 2 * n;
-    return 6 * n + 4 * (N + 1) + 4 * 2 * (N + 2) + 3 * (N + 2) + (size_t)K * 7 + 2 * (size_t)(N + 2) * K +
-           (size_t)(N + 2) * K * 2 + (size_t)(N + 2) * K * 3 + (size_t)(N + 2) * 3 + 7 * m + mc * n +
-           (size_t)(N + 2) * 2 * n + 2 * n * n + n;
+    const size_t n = 2 * (size_t)N, NP = (size_t)N + 2, m = (size_t)N * K + 2 * N + 2 * n;
+    return 5 * n + 3 * n + 4 * (N + 1) + 4 * 2 * NP + 3 * 2 * NP + (N + 1) + 3 * NP + (size_t)K * 7 + NP * K * 6 +
+           6 * m + 2 * NP * 10 + 2 * (2 * NP * n) + n * n + n * (n + 1);
 }
 
 __device__ inline MpcMem carve(double* b, int N, int K) {
-    const int n = 2 * N, mc = N * K, m = mc + 2 * N + 2 * n;
+    const int n = 2 * N, NP = N + 2, m = N * K + 2 * N + 2 * n;
     MpcMem M;
     auto take = [&](size_t c) { double* r = b; b += c; return r; };
-    M.z = take(n); M.zt = take(n); M.dz = take(n); M.grad = take(n); M.rhs = take(n); M.zb = take(n);
+    M.z = take(n); M.zt = take(n); M.dz = take(n); M.rhs = take(n); M.zb = take(n);
+    M.cv = take(3 * n);
     M.TH = take(N + 1); M.V = take(N + 1); M.C = take(N + 1); M.S = take(N + 1);
-    M.pos = take(2 * (N + 2)); M.PC = take(2 * (N + 2)); M.PD = take(2 * (N + 2)); M.q = take(2 * (N + 2));
-    M.SA = take(N + 2); M.SB = take(N + 2); M.SV = take(N + 2);
+    M.pos = take(2 * NP); M.PC = take(2 * NP); M.PD = take(2 * NP); M.dp = take(2 * NP);
+    M.Y = take(6 * NP);
+    M.dV = take(N + 1);
+    M.SA = take(NP); M.SB = take(NP); M.SS = take(NP);
     M.obs = take((size_t)K * 7);
-    M.hk = take((size_t)(N + 2) * K); M.mu = take((size_t)(N + 2) * K);
-    M.dh = take((size_t)(N + 2) * K * 2);
-    M.Hh = take((size_t)(N + 2) * K * 3);
-    M.Om = take((size_t)(N + 2) * 3);
-    M.g = take(m); M.sl = take(m); M.lam = take(m); M.ds = take(m); M.dlam = take(m); M.w = take(m); M.st = take(m);
-    M.J = take((size_t)mc * n);
-    M.dP = take((size_t)(N + 2) * 2 * n);
+    M.hk = take((size_t)NP * K);
+    M.dh = take((size_t)NP * K * 2);
+    M.Hh = take((size_t)NP * K * 3);
+    M.g = take(m); M.sl = take(m); M.lam = take(m); M.st = take(m); M.ds = take(m); M.dlam = take(m);
+    M.Phi = take((size_t)2 * NP * 10);
+    M.dP = take((size_t)2 * NP * n); M.T = take((size_t)2 * NP * n);
     M.M = take((size_t)n * n); M.L = take((size_t)n * (n + 1));
     return M;
 }
@@ -220,6 +171,21 @@ __device__ inline double eval_values(const double* z, const MpcMem& W, const Mpc
         W.pos[2 * lane] = px; W.pos[2 * lane + 1] = py;
     }
     SC_SYNC();
+    if (derivs) {
+        // G = d p / d z:  dP[2k+d][col] = dt^2 (P[k][d] - P[j+1][d]) for stages j <= k - 2, P = PC (accel) | PD (omega)
+        const double dt2 = c.dt * c.dt;
+        for (int e = lane; e < (N + 2) * n; e += 64) {
+            const int k = e / n, col = e - k * n, j = col >> 1;
+            double v0 = 0.0, v1 = 0.0;
+            if (j + 1 <= k - 1) {
+                const double* P = (col & 1) ? W.PD : W.PC;
+                v0 = dt2 * (P[2 * k] - P[2 * (j + 1)]);
+                v1 = dt2 * (P[2 * k + 1] - P[2 * (j + 1) + 1]);
+            }
+            W.dP[(size_t)(2 * k) * n + col] = v0;
+            W.dP[(size_t)(2 * k + 1) * n + col] = v1;
+        }
+    }
     for (int e = lane; e < (N + 2) * K; e += 64) {
         const int k = e / K, j = e - k * K;
         double h, d0, d1, hxx, hxy, hyy;
@@ -263,113 +229,202 @@ __device__ inline double eval_values(const double* z, const MpcMem& W, const Mpc
     return wsum(part);
 }
 
-// ---- first and second derivatives at W.z (oracle: evaluate level 1, 2) ---------------------------
-// lam_scale = 1/sf converts the scaled problem's multipliers to those of the unscaled one.
-__device__ inline void eval_derivs(const MpcMem& W, const MpcConst& c, int lane, double lam_scale) {
-    const int N = c.N, K = c.K, n = c.n;
-    const double dt = c.dt, dt2 = dt * dt;
-    // dP[k][d][col] = d p_k / d z_col
-    for (int e = lane; e < (N + 2) * n; e += 64) {
-        const int k = e / n, col = e - k * n, j = col >> 1;
-        double v0 = 0.0, v1 = 0.0;
-        if (j + 1 <= k - 1) {
-            const double* P = (col & 1) ? W.PD : W.PC;
-            v0 = dt2 * (P[2 * k] - P[2 * (j + 1)]);
-            v1 = dt2 * (P[2 * k + 1] - P[2 * (j + 1) + 1]);
-        }
-        W.dP[(size_t)(2 * k) * n + col] = v0;
-        W.dP[(size_t)(2 * k + 1) * n + col] = v1;
+// ---- assembly in position space ------------------------------------------------------------------------------
+// With G = d(p_0..p_{N+1})/dz (2 NP x n) and A = d g_cbf / d p (row (kappa, jo) has the three 1x2 blocks
+// w_t dh[kappa + t, jo], t = 0..2), the CBF Jacobian is J = A G and is never formed:
+//   J' v            = G' (A' v)                                  (A' v is a 2 NP vector, one 2-vector per position)
+//   sf W + J' S J   = G' (sf Om + A' S A) G + structured terms   (Phi = sf Om + A' S A is block pentadiagonal)
+//   J dz            = A (G dz)
+// which replaces the N K x 2 N Jacobian build and every loop over its rows by work on 2 NP = 24 position rows.
+
+// rows: sigma = lam / s, 1/s, sigma r_p + lam; returns the lane-partial residual norms
+__device__ __forceinline__ void row_pass(const MpcMem& W, const MpcConst& c, int lane, double& e_p, double& e_c0, double& lmax) {
+    double* is = W.ds;
+    double* vb = W.dlam;
+    e_p = 0.0; e_c0 = 0.0; lmax = 0.0;
+    for (int i = lane; i < c.m; i += 64) {
+        const double s = W.sl[i], l = W.lam[i], rp = W.g[i] - s;
+        const double inv = 1.0 / s, sig = l * inv;
+        W.st[i] = sig; is[i] = inv; vb[i] = sig * rp + l;
+        e_p = fmax(e_p, fabs(rp));
+        e_c0 = fmax(e_c0, fabs(s * l));
+        lmax = fmax(lmax, l);
     }
-    // multipliers touching position k:  mu_kj = w2 lam_{k-2,j} + w1 lam_{k-1,j} + w0 lam_{k,j}
-    for (int e = lane; e < (N + 2) * K; e += 64) {
-        const int k = e / K, j = e - k * K;
-        double mu = 0.0;
-        if (k - 2 >= 0) mu += c.w2 * (W.lam[(k - 2) * K + j] * lam_scale);
-        if (k >= 1 && k <= N) mu += c.w1 * (W.lam[(k - 1) * K + j] * lam_scale);
-        if (k <= N - 1) mu += c.w0 * (W.lam[k * K + j] * lam_scale);
-        W.mu[e] = mu;
-    }
-    SC_SYNC();
-    // Om_k = d2 L / d p_k^2 (2x2 sym), q_k = d L / d p_k
-    if (lane <= N + 1) {
-        const int k = lane;
-        double oxx = 0, oxy = 0, oyy = 0, q0 = 0, q1 = 0;
-        for (int j = 0; j < K; ++j) {
-            const int e = k * K + j;
-            const double mu = W.mu[e];
-            oxx -= mu * W.Hh[3 * e]; oxy -= mu * W.Hh[3 * e + 1]; oyy -= mu * W.Hh[3 * e + 2];
-            q0 -= mu * W.dh[2 * e]; q1 -= mu * W.dh[2 * e + 1];
+    e_p = wmax(e_p); e_c0 = wmax(e_c0); lmax = wmax(lmax);
+}
+
+// positions: lane k < NP builds  q_k = d L / d p_k,  Om_k,  the position-space vectors A'(1/s), A'(sig r_p + lam),
+// row block k of Phi, and the suffix sums the structured Hessian terms need.  Multipliers are those of the scaled
+// problem (objective times sf), so everything here is already scaled.
+template <int KT>
+__device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, int lane, double sf) {
+    const int N = c.N, K = c.K, NP = N + 2, k = lane;
+    const double* is = W.ds;
+    const double* vb = W.dlam;
+    double q0 = 0.0, q1 = 0.0;
+    if (k < NP) {
+        double oxx = 0, oxy = 0, oyy = 0, ya0 = 0, ya1 = 0, yb0 = 0, yb1 = 0;
+        double f0xx = 0, f0xy = 0, f0yy = 0, f1[4] = {0, 0, 0, 0}, f2[4] = {0, 0, 0, 0};
+        const bool t0 = k <= N - 1, t1 = k >= 1 && k <= N, t2 = k >= 2;       // row kappa = k - t exists
+        const int r0 = (t0 ? k : 0) * K, r1 = (t1 ? k - 1 : 0) * K, r2 = (t2 ? k - 2 : 0) * K;
+        const double w0 = t0 ? c.w0 : 0.0, w1 = t1 ? c.w1 : 0.0, w2 = t2 ? c.w2 : 0.0;
+        const int k1 = k + 1 < NP ? k + 1 : k, k2 = k + 2 < NP ? k + 2 : k;
+        constexpr int UNR = KT > 0 ? KT : 4;
+#pragma unroll UNR
+        for (int jo = 0; jo < K; ++jo) {
+            const double l0 = W.lam[r0 + jo], l1 = W.lam[r1 + jo], l2 = W.lam[r2 + jo];
+            const double i0 = is[r0 + jo], i1 = is[r1 + jo], i2 = is[r2 + jo];
+            const double b0 = vb[r0 + jo], b1 = vb[r1 + jo], b2 = vb[r2 + jo];
+            const double s0 = W.st[r0 + jo], s1 = W.st[r1 + jo];
+            const double s2 = W.st[r2 + jo];
+            const double ml = w0 * l0 + w1 * l1 + w2 * l2, ma = w0 * i0 + w1 * i1 + w2 * i2, mb = w0 * b0 + w1 * b1 + w2 * b2;
+            const double c0 = w0 * w0 * s0 + w1 * w1 * s1 + w2 * w2 * s2;
+            const double c1 = w1 * c.w2 * s1 + w0 * c.w1 * s0;      // rows kappa = k-1 (t = 1, 2) and kappa = k (t = 0, 1)
+            const double c2 = w0 * c.w2 * s0;                        // row kappa = k (t = 0, 2)
+            const int e = k * K + jo, e1 = k1 * K + jo, e2 = k2 * K + jo;
+            const double d0 = W.dh[2 * e], d1 = W.dh[2 * e + 1];
+            const double a0 = W.dh[2 * e1], a1 = W.dh[2 * e1 + 1], g0 = W.dh[2 * e2], g1 = W.dh[2 * e2 + 1];
+            oxx -= ml * W.Hh[3 * e]; oxy -= ml * W.Hh[3 * e + 1]; oyy -= ml * W.Hh[3 * e + 2];
+            q0 -= ml * d0; q1 -= ml * d1;
+            ya0 += ma * d0; ya1 += ma * d1; yb0 += mb * d0; yb1 += mb * d1;
+            f0xx += c0 * d0 * d0; f0xy += c0 * d0 * d1; f0yy += c0 * d1 * d1;
+            f1[0] += c1 * d0 * a0; f1[1] += c1 * d0 * a1; f1[2] += c1 * d1 * a0; f1[3] += c1 * d1 * a1;
+            f2[0] += c2 * d0 * g0; f2[1] += c2 * d0 * g1; f2[2] += c2 * d1 * g0; f2[3] += c2 * d1 * g1;
         }
         if (k >= 1 && k <= N) {
-            oxx += 2.0 * c.Qx; oyy += 2.0 * c.Qy;
-            q0 += 2.0 * c.Qx * (W.pos[2 * k] - c.gx);
-            q1 += 2.0 * c.Qy * (W.pos[2 * k + 1] - c.gy);
+            oxx += sf * 2.0 * c.Qx; oyy += sf * 2.0 * c.Qy;
+            q0 += sf * 2.0 * c.Qx * (W.pos[2 * k] - c.gx);
+            q1 += sf * 2.0 * c.Qy * (W.pos[2 * k + 1] - c.gy);
         }
-        W.Om[3 * k] = oxx; W.Om[3 * k + 1] = oxy; W.Om[3 * k + 2] = oyy;
-        W.q[2 * k] = q0; W.q[2 * k + 1] = q1;
+        W.Y[2 * k] = q0; W.Y[2 * k + 1] = q1;
+        W.Y[2 * NP + 2 * k] = ya0; W.Y[2 * NP + 2 * k + 1] = ya1;
+        W.Y[4 * NP + 2 * k] = yb0; W.Y[4 * NP + 2 * k + 1] = yb1;
+        // Phi band rows: Phi[(2k+d) * 10 + (delta + 2) * 2 + d'] = Phi[(k, d), (k + delta, d')]
+        double* R0 = W.Phi + (size_t)(2 * k) * 10;
+        double* R1 = R0 + 10;
+        R0[4] = f0xx + oxx; R0[5] = f0xy + oxy; R1[4] = f0xy + oxy; R1[5] = f0yy + oyy;
+        if (k + 1 < NP) {
+            R0[6] = f1[0]; R0[7] = f1[1]; R1[6] = f1[2]; R1[7] = f1[3];
+            double* Q0 = W.Phi + (size_t)(2 * (k + 1)) * 10;      // transposed block at (k+1, k): delta = -1
+            Q0[2] = f1[0]; Q0[3] = f1[2]; Q0[12] = f1[1]; Q0[13] = f1[3];
+        }
+        if (k + 2 < NP) {
+            R0[8] = f2[0]; R0[9] = f2[1]; R1[8] = f2[2]; R1[9] = f2[3];
+            double* Q0 = W.Phi + (size_t)(2 * (k + 2)) * 10;      // delta = -2
+            Q0[0] = f2[0]; Q0[1] = f2[2]; Q0[10] = f2[1]; Q0[11] = f2[3];
+        }
     }
-    // CBF Jacobian rows
-    for (int e = lane; e < c.mc * n; e += 64) {
-        const int row = e / n, col = e - row * n, k = row / K, j = row - k * K;
+    // suffix sums (wave scans): qbar_i = sum_{k > i} q_k;  A_i = qbar_i . (-s_i, c_i),  B_i = v_i qbar_i . (c_i, s_i);
+    // SA[t] = sum_{i >= t} A_i, SB likewise (t = 0..N+1, zero at N+1);  SS[t] = sum_{k >= t} (sig+_k + sig-_k), k = 1..N
+    const double qs0 = suffix_sum(q0, lane) - q0, qs1 = suffix_sum(q1, lane) - q1;
+    double Ai = 0.0, Bi = 0.0, sk = 0.0;
+    if (k <= N) {
+        const double ci = W.C[k], si = W.S[k];
+        Ai = qs0 * (-si) + qs1 * ci;
+        Bi = W.V[k] * (qs0 * ci + qs1 * si);
+        if (k >= 1) sk = W.st[c.mc + 2 * (k - 1)] + W.st[c.mc + 2 * (k - 1) + 1];
+    }
+    const double sa = suffix_sum(Ai, lane), sb = suffix_sum(Bi, lane), ss = suffix_sum(sk, lane);
+    if (k < NP) { W.SA[k] = sa; W.SB[k] = sb; W.SS[k] = ss; }
+}
+
+// columns: cv[v][col] for the three row vectors  v = 0: r_d = sf grad f - J' lam;  1: J'(1/s);  2: J'(sig r_p + lam)
+__device__ __forceinline__ double col_pass(const MpcMem& W, const MpcConst& c, int lane, double sf) {
+    const int N = c.N, n = c.n, NP = N + 2;
+    double e_d = 0.0;
+    for (int idx = lane; idx < 3 * n; idx += 64) {
+        const int v = idx / n, col = idx - v * n, j = col >> 1;
+        const double* y = W.Y + (size_t)v * 2 * NP;
+        const double* vec = v == 0 ? W.lam : (v == 1 ? W.ds : W.dlam);
         double acc = 0.0;
-        const double wt[3] = {c.w0, c.w1, c.w2};
+        for (int row = 2 * (j + 2); row < 2 * NP; ++row) acc += W.dP[(size_t)row * n + col] * y[row];
+        double sb = vec[c.mc + 2 * N + n + col] - vec[c.mc + 2 * N + col];
+        if (!(col & 1)) {
+            double sp = 0.0;
+            for (int k = j + 1; k <= N; ++k) sp += vec[c.mc + 2 * (k - 1) + 1] - vec[c.mc + 2 * (k - 1)];
+            sb += c.dt * sp;
+        }
+        if (v == 0) {
+            double sx = 0.0;                                     // sum_{k > j} theta_k | v_k
+            const double* Xs = (col & 1) ? W.TH : W.V;
+            for (int k = j + 1; k <= N; ++k) sx += Xs[k];
+            const double Rc = (col & 1) ? c.R1 : c.R0, Qs = (col & 1) ? c.Qth : c.Qv;
+            const double prev = col >= 2 ? W.z[col - 2] : ((col & 1) ? c.up1 : c.up0);
+            double gr = 2.0 * Qs * c.dt * sx + 2.0 * Rc * (W.z[col] - prev);
+            if (col + 2 < n) gr -= 2.0 * Rc * (W.z[col + 2] - W.z[col]);
+            acc += sf * gr - sb;
+            e_d = fmax(e_d, fabs(acc));
+        } else {
+            acc += sb;
+        }
+        W.cv[idx] = acc;
+    }
+    return wmax(e_d);
+}
+
+// T = Phi G  (2 NP x n), Phi block pentadiagonal
+__device__ __forceinline__ void phi_times_G(const MpcMem& W, const MpcConst& c, int lane) {
+    const int n = c.n, NP = c.N + 2;
+    for (int e = lane; e < 2 * NP * n; e += 64) {
+        const int row = e / n, col = e - row * n, k = row >> 1;
+        const double* ph = W.Phi + (size_t)row * 10;
+        double acc = 0.0;
 #pragma unroll
-        for (int t = 2; t >= 0; --t) {
-            const int kk = k + t, hh = kk * K + j;
-            acc += wt[t] * (W.dh[2 * hh] * W.dP[(size_t)(2 * kk) * n + col] + W.dh[2 * hh + 1] * W.dP[(size_t)(2 * kk + 1) * n + col]);
+        for (int dl = -2; dl <= 2; ++dl) {
+            const int kk = k + dl;
+            if (kk >= 0 && kk < NP)
+                acc += ph[(dl + 2) * 2] * W.dP[(size_t)(2 * kk) * n + col] + ph[(dl + 2) * 2 + 1] * W.dP[(size_t)(2 * kk + 1) * n + col];
         }
-        W.J[e] = acc;
+        W.T[e] = acc;
     }
-    SC_SYNC();
-    // suffix sums over stages i = 0..N:  A_i = qbar_i . (-s_i, c_i),  B_i = v_i qbar_i . (c_i, s_i),  qbar_i = sum_{k>i} q_k
-    if (lane <= N) {
-        const int i = lane;
-        double qb0 = 0, qb1 = 0;
-        for (int k = i + 1; k <= N + 1; ++k) { qb0 += W.q[2 * k]; qb1 += W.q[2 * k + 1]; }
-        W.SA[i] = qb0 * (-W.S[i]) + qb1 * W.C[i];
-        W.SB[i] = W.V[i] * (qb0 * W.C[i] + qb1 * W.S[i]);
-    }
-    SC_SYNC();
-    if (lane == 0) {                                  // in-place suffix sums  SA[t] = sum_{i>=t} A_i
-        double a = 0, b = 0;
-        for (int i = N; i >= 0; --i) { a += W.SA[i]; b += W.SB[i]; W.SA[i] = a; W.SB[i] = b; }
-        W.SA[N + 1] = 0; W.SB[N + 1] = 0;
-    }
-    // gradient of f
-    for (int col = lane; col < n; col += 64) {
-        const int j = col >> 1;
-        double acc = 0.0;
-        for (int k = 1; k <= N; ++k) {
-            acc += W.dP[(size_t)(2 * k) * n + col] * (2.0 * c.Qx * (W.pos[2 * k] - c.gx)) +
-                   W.dP[(size_t)(2 * k + 1) * n + col] * (2.0 * c.Qy * (W.pos[2 * k + 1] - c.gy));
-            if (k > j) acc += (col & 1) ? 2.0 * c.Qth * W.TH[k] * dt : 2.0 * c.Qv * W.V[k] * dt;
+}
+
+// ---- f64 MFMA (v_mfma_f64_16x16x4_f64): condensed matrix  M = G' T + structured terms ---------------------------
+// Operand layout (MI355X guide, "f64 MFMA"): lane l feeds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
+// result register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15].  The contraction index is the position row.
+__device__ __forceinline__ double condensed_base(const MpcMem& W, const MpcConst& c, double sf, int r, int cc) {
+    const int N = c.N, n = c.n;
+    const int jr = r >> 1, jc = cc >> 1, jm = jr > jc ? jr : jc;
+    const double dt2 = c.dt * c.dt, dt3 = dt2 * c.dt;
+    const bool ra = !(r & 1), ca = !(cc & 1);
+    double acc;
+    if (ra && ca) acc = sf * 2.0 * c.Qv * dt2 * (double)(N - jm) + dt2 * W.SS[jm + 1];     // d v_k: objective + speed rows
+    else if (!ra && !ca) acc = sf * 2.0 * c.Qth * dt2 * (double)(N - jm) - dt3 * W.SB[jm + 1];
+    else acc = dt3 * W.SA[jm + 1];
+    const double Rc = (r & 1) ? c.R1 : c.R0;                                               // input-rate penalty 2 D' R D
+    if (r == cc) acc += sf * 2.0 * Rc * ((r + 2 < n) ? 2.0 : 1.0) + W.st[c.mc + 2 * N + r] + W.st[c.mc + 2 * N + n + r];
+    else if (r == cc + 2 || cc == r + 2) acc -= sf * 2.0 * Rc;
+    return acc;
+}
+
+__device__ __forceinline__ void condense_mfma(const MpcMem& W, const MpcConst& c, int lane, double sf) {
+    const int n = c.n, rows = 2 * (c.N + 2), nt = (n + 15) >> 4, q = lane >> 4, l15 = lane & 15;
+    for (int ti = 0; ti < nt; ++ti) {
+        for (int tj = 0; tj <= ti; ++tj) {
+            const int cA = 16 * ti + l15, cB = 16 * tj + l15;
+            const bool okA = cA < n, okB = cB < n;
+            const int ca = okA ? cA : 0, cb = okB ? cB : 0;
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            for (int k0 = 0; k0 < rows; k0 += 4) {
+                const int row = k0 + q;
+                const bool okr = row < rows;
+                const int rr = okr ? row : 0;
+                double a = W.dP[(size_t)rr * n + ca], b = W.T[(size_t)rr * n + cb];
+                a = (okA && okr) ? a : 0.0;
+                b = (okB && okr) ? b : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + q + 4 * r, col = 16 * tj + l15;
+                if (row < n && col < n) {
+                    const double v = acc[r] + condensed_base(W, c, sf, row, col);
+                    W.M[(size_t)row * n + col] = v;
+                    if (ti != tj) W.M[(size_t)col * n + row] = v;
+                }
+            }
         }
-        const double Rc = (col & 1) ? c.R1 : c.R0;
-        const double prev = col >= 2 ? W.z[col - 2] : ((col & 1) ? c.up1 : c.up0);
-        acc += 2.0 * Rc * (W.z[col] - prev);
-        if (col + 2 < n) acc -= 2.0 * Rc * (W.z[col + 2] - W.z[col]);
-        W.grad[col] = acc;
     }
-    SC_SYNC();
-    // exact Hessian of the Lagrangian  W.M (full n x n)
-    const double dt3 = dt2 * dt;
-    for (int e = lane; e < n * n; e += 64) {
-        const int r = e / n, cc = e - r * n;
-        const int jr = r >> 1, jc = cc >> 1, jm = jr > jc ? jr : jc;
-        double acc = 0.0;                                 // the sum_k dP_k' Om_k dP_k part is added by MFMA below
-        const bool ra = !(r & 1), ca = !(cc & 1);
-        if (ra && ca) acc += 2.0 * c.Qv * dt2 * (double)(N - jm);            // sum_k dV_k dV_k'
-        else if (!ra && !ca) acc += 2.0 * c.Qth * dt2 * (double)(N - jm) - dt3 * W.SB[jm + 1];
-        else acc += dt3 * W.SA[jm + 1];
-        // input-rate penalty 2 D' R D
-        const double Rc = (r & 1) ? c.R1 : c.R0;
-        if (r == cc) acc += 2.0 * Rc * ((r + 2 < n) ? 2.0 : 1.0);
-        else if (r == cc + 2 || cc == r + 2) acc -= 2.0 * Rc;
-        W.M[e] = acc;
-    }
-    SC_SYNC();
-    mfma_accumulate_sym(W.M, n, lane, [&](int ti, int tj) { return mfma_tile_PtOP(W.dP, W.Om, 2 * (N + 2), n, ti, tj, lane); });
-    SC_SYNC();
 }
 
 // Cholesky of (W.L = lower of A) in place; returns false on a non-positive pivot.
@@ -473,36 +528,6 @@ __device__ __forceinline__ double chol_solve_reg(double (&a)[n], double diag, do
     return b * dinv;
 }
 
-// (J' w)[col] over all rows: CBF rows dense, speed rows -/+ dt for stages k > j, box rows -/+ identity
-__device__ inline double jt_times(const MpcMem& W, const MpcConst& c, const double* w, int col) {
-    const int N = c.N, n = c.n, j = col >> 1;
-    double acc = 0.0;
-    for (int r = 0; r < c.mc; ++r) acc += W.J[(size_t)r * n + col] * w[r];
-    if (!(col & 1)) {
-        for (int k = j + 1; k <= N; ++k) acc += c.dt * (w[c.mc + 2 * (k - 1) + 1] - w[c.mc + 2 * (k - 1)]);
-    }
-    acc += w[c.mc + 2 * N + n + col] - w[c.mc + 2 * N + col];
-    return acc;
-}
-
-// (J v)[row]
-__device__ inline double j_times(const MpcMem& W, const MpcConst& c, const double* v, int row) {
-    const int N = c.N, n = c.n;
-    if (row < c.mc) {
-        double acc = 0.0;
-        for (int col = 0; col < n; ++col) acc += W.J[(size_t)row * n + col] * v[col];
-        return acc;
-    }
-    if (row < c.mc + 2 * N) {
-        const int r = row - c.mc, k = (r >> 1) + 1;
-        double acc = 0.0;
-        for (int j = 0; j < k; ++j) acc += c.dt * v[2 * j];
-        return (r & 1) ? acc : -acc;
-    }
-    const int r = row - c.mc - 2 * N;
-    return r < n ? -v[r] : v[r - n];
-}
-
 // NT, KT > 0: horizon and obstacle count are compile-time constants (index arithmetic folds to shifts and
 // multiplies); NT == 0: run-time sizes.
 template <typename TIO, int NT, int KT>
@@ -539,19 +564,19 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
     SC_SYNC();
 
     double f = eval_values(W.z, W, c, lane, true);
-    for (int i = lane; i < m; i += 64) W.lam[i] = 0.0;
+    // objective scaling from |grad f|_inf at the start: with lam = 0 the column pass returns r_d = grad f
+    for (int i = lane; i < m; i += 64) { W.sl[i] = fmax(W.g[i], 1e-2); W.lam[i] = 0.0; }
     SC_SYNC();
-    eval_derivs(W, c, lane, 1.0);
-    double gmax = 0.0;
-    for (int i = lane; i < n; i += 64) gmax = fmax(gmax, fabs(W.grad[i]));
-    gmax = wmax(gmax);
+    double e_p, e_c0, lmax;
+    row_pass(W, c, lane, e_p, e_c0, lmax);
+    SC_SYNC();
+    stage_pass<KT>(W, c, lane, 1.0);
+    SC_SYNC();
+    const double gmax = col_pass(W, c, lane, 1.0);
     const double sf = fmin(1.0, 100.0 / fmax(1e-12, gmax));             // objective scaling
     double mu = p.mu_init;
-    for (int i = lane; i < m; i += 64) {
-        const double s = fmax(W.g[i], 1e-2);
-        W.sl[i] = s;
-        W.lam[i] = mu / s;
-    }
+    SC_SYNC();
+    for (int i = lane; i < m; i += 64) W.lam[i] = mu / W.sl[i];
     SC_SYNC();
 
     int status = SC_STATUS_INACCURATE, it = 0;
@@ -565,20 +590,14 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
     for (it = 1; it <= p.max_iter; ++it) {
         if (it > 1) f = eval_values(W.z, W, c, lane, true);
         SC_PH(0);
-        eval_derivs(W, c, lane, 1.0 / sf);
+        row_pass(W, c, lane, e_p, e_c0, lmax);
+        SC_SYNC();
         SC_PH(1);
-        // residuals
-        double e_d = 0.0, e_p = 0.0, e_c0 = 0.0, lmax = 0.0;
-        for (int col = lane; col < n; col += 64) {
-            const double rd = sf * W.grad[col] - jt_times(W, c, W.lam, col);
-            e_d = fmax(e_d, fabs(rd));
-        }
-        for (int i = lane; i < m; i += 64) {
-            e_p = fmax(e_p, fabs(W.g[i] - W.sl[i]));
-            e_c0 = fmax(e_c0, fabs(W.sl[i] * W.lam[i]));
-            lmax = fmax(lmax, W.lam[i]);
-        }
-        e_d = wmax(e_d); e_p = wmax(e_p); e_c0 = wmax(e_c0); lmax = wmax(lmax);
+        stage_pass<KT>(W, c, lane, sf);
+        SC_SYNC();
+        SC_PH(2);
+        const double e_d = col_pass(W, c, lane, sf);
+        SC_PH(3);
         const double e_opt = fmax(e_d, fmax(e_p, e_c0));
         if (e_opt < e_best) {                                            // remember the best iterate
             e_best = e_opt;
@@ -595,31 +614,15 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             if (e_mu <= 10.0 * mu && mu > p.mu_min) mu = fmax(p.mu_min, fmin(0.2 * mu, pow(mu, 1.5)));
             else break;
         }
-        SC_PH(2);
-        // condensed system  (sf W + J' Sigma J) dz = -sf grad + J' (mu/s - Sigma r_p)
-        for (int i = lane; i < m; i += 64) {
-            const double s = W.sl[i], sig = W.lam[i] / s;
-            W.st[i] = sig;                                               // Sigma
-            W.w[i] = mu / s - sig * (W.g[i] - s);
-        }
+        SC_PH(4);
+        phi_times_G(W, c, lane);
         SC_SYNC();
-        for (int col = lane; col < n; col += 64) W.rhs[col] = -sf * W.grad[col] + jt_times(W, c, W.w, col);
-        for (int e = lane; e < n * n; e += 64) {
-            const int r = e / n, cc = e - r * n;
-            double acc = sf * W.M[e];                                   // + J_cbf' Sigma J_cbf by MFMA below
-            if (!(r & 1) && !(cc & 1)) {                                  // speed rows: dt^2 sum_{k > max(jr,jc)} (sig+ + sig-)
-                const int jm = (r > cc ? r : cc) >> 1;
-                double sv = 0.0;
-                for (int k = jm + 1; k <= N; ++k) sv += W.st[c.mc + 2 * (k - 1)] + W.st[c.mc + 2 * (k - 1) + 1];
-                acc += c.dt * c.dt * sv;
-            }
-            if (r == cc) acc += W.st[c.mc + 2 * N + r] + W.st[c.mc + 2 * N + n + r];
-            W.M[e] = acc;                                                 // M now holds the condensed matrix
-        }
+        SC_PH(5);
+        // condensed system  (sf W + J' Sigma J) dz = -r_d + J' (mu/s - Sigma r_p - lam)
+        for (int col = lane; col < n; col += 64) W.rhs[col] = -W.cv[col] + (mu * W.cv[n + col] - W.cv[2 * n + col]);
+        condense_mfma(W, c, lane, sf);
         SC_SYNC();
-        mfma_accumulate_sym(W.M, n, lane, [&](int ti, int tj) { return mfma_tile_AtSA(W.J, W.st, c.mc, n, ti, tj, lane); });
-        SC_SYNC();
-        SC_PH(3);
+        SC_PH(6);
         // inertia correction: M + delta I until the Cholesky succeeds
         double delta = 0.0;
         bool ok = false;
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             }
             if (!ok) break;
             if (delta > 0.0) delta_last = delta;
-            SC_PH(4);
+            SC_PH(7);
             const double x = chol_solve_reg<nn>(a, diag, lane < nn ? W.rhs[lane] : 0.0, W.L, lane);
             if (lane < nn) W.dz[lane] = x;
             SC_SYNC();
@@ -647,31 +650,60 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             }
             if (!ok) break;
             if (delta > 0.0) delta_last = delta;
-            SC_PH(4);
+            SC_PH(7);
             for (int i = lane; i < n; i += 64) W.dz[i] = W.rhs[i];
             SC_SYNC();
             chol_solve(W.L, W.dz, n, lane);
         }
-        SC_PH(5);
-        // ds, dlam, step lengths
+        SC_PH(8);
+        // position and speed displacements  dp = G dz,  dV_k = dt sum_{j < k} dz_{2j}
+        for (int row = lane; row < 2 * (N + 2); row += 64) {
+            double acc = 0.0;
+            const int cend = 2 * ((row >> 1) - 1);                        // p_k depends on stages j <= k - 2
+            for (int col = 0; col < cend; ++col) acc += W.dP[(size_t)row * n + col] * W.dz[col];
+            W.dp[row] = acc;
+        }
+        for (int k = lane; k <= N; k += 64) {
+            double acc = 0.0;
+            for (int j = 0; j < k; ++j) acc += W.dz[2 * j];
+            W.dV[k] = c.dt * acc;
+        }
+        double gdz = 0.0;
+        for (int i = lane; i < n; i += 64) gdz += W.cv[i] * W.dz[i];      // r_d . dz
+        SC_SYNC();
+        SC_PH(9);
+        // ds = J dz + r_p, dlam, step lengths
         double ap = 1.0, ad = 1.0, sum_ds_s = 0.0, sum_rp = 0.0, sum_log = 0.0;
         for (int i = lane; i < m; i += 64) {
             const double s = W.sl[i], lam = W.lam[i], rp = W.g[i] - s;
-            const double ds = j_times(W, c, W.dz, i) + rp;
+            double jd;
+            if (i < c.mc) {
+                const int k = i / K, jo = i - k * K;
+                const int e0 = k * K + jo, e1 = e0 + K, e2 = e1 + K;
+                jd = c.w0 * (W.dh[2 * e0] * W.dp[2 * k] + W.dh[2 * e0 + 1] * W.dp[2 * k + 1]) +
+                     c.w1 * (W.dh[2 * e1] * W.dp[2 * k + 2] + W.dh[2 * e1 + 1] * W.dp[2 * k + 3]) +
+                     c.w2 * (W.dh[2 * e2] * W.dp[2 * k + 4] + W.dh[2 * e2 + 1] * W.dp[2 * k + 5]);
+            } else if (i < c.mc + 2 * N) {
+                const int r = i - c.mc, k = (r >> 1) + 1;
+                jd = (r & 1) ? W.dV[k] : -W.dV[k];
+            } else {
+                const int r = i - c.mc - 2 * N;
+                jd = r < n ? -W.dz[r] : W.dz[r - n];
+            }
+            const double ds = jd + rp;
             const double dl = -W.st[i] * ds - (lam - mu / s);
-            W.ds[i] = ds; W.dlam[i] = dl;
+            gdz += lam * jd;                                              // sf grad f . dz = r_d . dz + lam . (J dz)
             if (ds < 0.0) ap = fmin(ap, -tau * s / ds);
             if (dl < 0.0) ad = fmin(ad, -tau * lam / dl);
             sum_ds_s += ds / s; sum_rp += fabs(rp); sum_log += log(s);
+            W.ds[i] = ds; W.dlam[i] = dl;
         }
         ap = wmin(ap); ad = wmin(ad); sum_ds_s = wsum(sum_ds_s); sum_rp = wsum(sum_rp); sum_log = wsum(sum_log);
-        nu = fmax(nu, 1.1 * lmax);
-        double gdz = 0.0;
-        for (int i = lane; i < n; i += 64) gdz += sf * W.grad[i] * W.dz[i];
         gdz = wsum(gdz);
+        nu = fmax(nu, 1.1 * lmax);
         const double phi0 = sf * f - mu * sum_log + nu * sum_rp;
         const double dphi = gdz - mu * sum_ds_s - nu * sum_rp;
-        SC_PH(6);
+        SC_PH(10);
         // l1-merit backtracking
         double alpha = ap;
         bool accepted = false;
@@ -691,7 +723,6 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0)) { accepted = true; break; }
             alpha *= 0.5;
         }
-        SC_PH(7);
         if (!accepted) break;
         for (int i = lane; i < n; i += 64) W.z[i] = W.z[i] + alpha * W.dz[i];
         for (int i = lane; i < m; i += 64) {
@@ -701,7 +732,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             W.sl[i] = s; W.lam[i] = lam;
         }
         SC_SYNC();
-        SC_PH(8);
+        SC_PH(11);
     }
     if (it > p.max_iter) it = p.max_iter;
     if (status != SC_STATUS_OPTIMAL && e_best <= p.acceptable_tol) {
