@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "sc_math.hpp"
+#include "sc_qp2.hpp"
 #include "../../include/safe_control_amd.h"
 
 namespace sc {
@@ -30,39 +31,64 @@ namespace sc {
 
 // -DSC_MPC_PROF: developer build that returns per-phase shader-clock totals in z_out instead of the solution
 // (tools/exp_mpc_phases.py); never defined in the shipped library.
+struct Prof {
 #ifdef SC_MPC_PROF
-#define SC_PH(i) do { const long long t_ = clock64(); ph[i] += (double)(t_ - tph); tph = t_; } while (0)
+    double ph[20];
+    long long t;
+    __device__ __forceinline__ void start() { for (int i = 0; i < 20; ++i) ph[i] = 0.0; t = clock64(); }
+    __device__ __forceinline__ void mark(int i) { const long long t_ = clock64(); ph[i] += (double)(t_ - t); t = t_; }
 #else
-#define SC_PH(i) do { } while (0)
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
 #endif
+};
+#define SC_PH(i) pf.mark(i)
 
-__device__ __forceinline__ double wsum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+// ---- wave reductions on DPP ---------------------------------------------------------------------------------------
+// A __shfl_xor butterfly is six dependent ds_bpermute round trips (~100 cycles each for a lone wave).  Here four DPP
+// moves (xor 1, xor 2, half-row mirror, row mirror: VALU latency) leave every lane with its 16-lane row total, and
+// the four row totals are combined from v_readlane.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wmin(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-    return v;
+__device__ __forceinline__ double lane_value(double v, int src) {        // src: compile-time constant lane
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wmax(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+template <typename Op>
+__device__ __forceinline__ double wreduce(double v, Op op) {
+    v = op(v, dpp_move<0xB1>(v));        // quad_perm [1,0,3,2]
+    v = op(v, dpp_move<0x4E>(v));        // quad_perm [2,3,0,1]
+    v = op(v, dpp_move<0x141>(v));       // row_half_mirror
+    v = op(v, dpp_move<0x140>(v));       // row_mirror
+    return op(op(lane_value(v, 0), lane_value(v, 16)), op(lane_value(v, 32), lane_value(v, 48)));
 }
+__device__ __forceinline__ double wsum(double v) { return wreduce(v, [](double a, double b) { return a + b; }); }
+__device__ __forceinline__ double wmin(double v) { return wreduce(v, [](double a, double b) { return fmin(a, b); }); }
+__device__ __forceinline__ double wmax(double v) { return wreduce(v, [](double a, double b) { return fmax(a, b); }); }
+__device__ __forceinline__ double wprod(double v) { return wreduce(v, [](double a, double b) { return a * b; }); }
+__device__ __forceinline__ int wsumi(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+           __builtin_amdgcn_readlane(v, 48);
+}
+// sum of log(x_i) over the wave as log(prod mantissas) + ln2 * sum exponents: one log per wave instead of one per
+// row.  A lane multiplies at most a few mantissas in [0.5, 1), the wave product stays above 2^-(64 * rows per lane).
+struct LogSum {
+    double pm = 1.0;
+    int pe = 0;
+    __device__ __forceinline__ void add(double x) { pm *= __builtin_amdgcn_frexp_mant(x); pe += __builtin_amdgcn_frexp_exp(x); }
+    __device__ __forceinline__ double total() const { return log(wprod(pm)) + 0.6931471805599453 * (double)wsumi(pe); }
+};
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
-
-// inclusive suffix sum over lanes: out[l] = sum_{l' >= l} v[l'] (v must be 0 in lanes outside the range of interest)
-__device__ __forceinline__ double suffix_sum(double v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double t = __shfl_down(v, o);
-        if (lane + o < 64) v += t;
-    }
-    return v;
-}
 
 struct MpcMem {                 // LDS carve-up (doubles); NP = N + 2 predicted positions, n = 2 N, m rows
     double *z, *zt, *dz, *rhs, *zb;               // n
@@ -77,7 +103,7 @@ struct MpcMem {                 // LDS carve-up (doubles); NP = N + 2 predicted 
     double *dh;                                   // NP*K*2
     double *Hh;                                   // NP*K*3
     double *g, *sl, *lam, *st;                    // m
-    double *ds, *dlam;                            // m   (aliases: is = ds, vb = dlam, dead before ds/dlam are written)
+    double *ds, *dlam, *is;                       // m   (vb aliases dlam: dead before dlam is written)
     double *Phi;                                  // 2 NP * 10 : block-pentadiagonal position-space matrix, band rows
     double *dP, *T;                               // 2 NP * n : G = d p / d z  and  T = Phi G
     double *M, *L;                                // n*n condensed matrix; n*(n+1) transposition scratch / LDS Cholesky
@@ -86,7 +112,7 @@ struct MpcMem {                 // LDS carve-up (doubles); NP = N + 2 predicted 
 __host__ __device__ inline size_t mpc_lds_doubles(int N, int K) {
     const size_t n = 2 * (size_t)N, NP = (size_t)N + 2, m = (size_t)N * K + 2 * N + 2 * n;
     return 5 * n + 3 * n + 4 * (N + 1) + 4 * 2 * NP + 3 * 2 * NP + (N + 1) + 3 * NP + (size_t)K * 7 + NP * K * 6 +
-           6 * m + 2 * NP * 10 + 2 * (2 * NP * n) + n * n + n * (n + 1);
+           7 * m + 2 * NP * 10 + 2 * (2 * NP * n) + n * n + n * (n + 1);
 }
 
 __device__ inline MpcMem carve(double* b, int N, int K) {
@@ -104,7 +130,7 @@ __device__ inline MpcMem carve(double* b, int N, int K) {
     M.hk = take((size_t)NP * K);
     M.dh = take((size_t)NP * K * 2);
     M.Hh = take((size_t)NP * K * 3);
-    M.g = take(m); M.sl = take(m); M.lam = take(m); M.st = take(m); M.ds = take(m); M.dlam = take(m);
+    M.g = take(m); M.sl = take(m); M.lam = take(m); M.st = take(m); M.ds = take(m); M.dlam = take(m); M.is = take(m);
     M.Phi = take((size_t)2 * NP * 10);
     M.dP = take((size_t)2 * NP * n); M.T = take((size_t)2 * NP * n);
     M.M = take((size_t)n * n); M.L = take((size_t)n * (n + 1));
@@ -147,46 +173,91 @@ __device__ inline void barrier_at(double px_, double py_, const double* o, const
     hyy = st * st * cxx + ct * ct * cyy;
 }
 
+// ---- scans over the first lanes of the wave -----------------------------------------------------------------------
+// ROW16 = true: all NP = N + 2 stages sit in lanes 0..15, one DPP row, and a scan step is a row_shr / row_shl move
+// (VALU latency, zero fill at the row edge) instead of a ds_bpermute round trip.
+// inclusive prefix sum  out[l] = sum_{l' <= l} v[l']
+template <bool ROW16>
+__device__ __forceinline__ double prefix_sum(double v, int lane) {
+    if constexpr (ROW16) {
+        v += dpp_move<0x111>(v); v += dpp_move<0x112>(v); v += dpp_move<0x114>(v); v += dpp_move<0x118>(v);   // row_shr:1,2,4,8
+    } else {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double t = __shfl_up(v, o);
+            if (lane >= o) v += t;
+        }
+    }
+    return v;
+}
+// inclusive suffix sum  out[l] = sum_{l' >= l} v[l']   (v must be 0 in lanes outside the range of interest)
+template <bool ROW16>
+__device__ __forceinline__ double suffix_sum(double v, int lane) {
+    if constexpr (ROW16) {
+        v += dpp_move<0x101>(v); v += dpp_move<0x102>(v); v += dpp_move<0x104>(v); v += dpp_move<0x108>(v);   // row_shl:1,2,4,8
+    } else {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double t = __shfl_down(v, o);
+            if (lane + o < 64) v += t;
+        }
+    }
+    return v;
+}
+
 // ---- rollout + barrier values + g + f at a trial z (oracle: evaluate level 0) --------------------
-__device__ inline double eval_values(const double* z, const MpcMem& W, const MpcConst& c, int lane, bool derivs) {
-    const int N = c.N, K = c.K, n = c.n;
-    if (lane <= N) {
-        double th = c.th0, v = c.v0;
-        for (int j = 0; j < lane; ++j) { th += c.dt * z[2 * j + 1]; v += c.dt * z[2 * j]; }
-        W.TH[lane] = th; W.V[lane] = v;
-        double sn, cs;
-        sincos(th, &sn, &cs);
-        W.C[lane] = cs; W.S[lane] = sn;
-    }
-    SC_SYNC();
-    if (lane <= N + 1) {
-        double pcx = 0, pcy = 0, pdx = 0, pdy = 0, px = c.x0, py = c.y0;
-        for (int i = 0; i < lane; ++i) {
-            const double ci = W.C[i], si = W.S[i], vi = W.V[i];
-            pcx += ci; pcy += si; pdx += -vi * si; pdy += vi * ci;
-            px += c.dt * vi * ci; py += c.dt * vi * si;
-        }
-        W.PC[2 * lane] = pcx; W.PC[2 * lane + 1] = pcy;
-        W.PD[2 * lane] = pdx; W.PD[2 * lane + 1] = pdy;
+// Lane k holds stage k: heading / speed are exclusive prefix sums of the inputs, positions and the position
+// sensitivities PC_k = sum_{i<k} (cos, sin), PD_k = sum_{i<k} v_i (-sin, cos) prefix sums of the stage terms.
+template <bool ROW16>
+__device__ inline double eval_values(const double* z, const MpcMem& W, const MpcConst& c, int lane, bool derivs, Prof& pf, int slot) {
+    const int N = c.N, K = c.K, n = c.n, NP = N + 2;
+    double ak = 0.0, wk = 0.0;
+    if (lane < N) { ak = z[2 * lane]; wk = z[2 * lane + 1]; }
+    const double th = c.th0 + c.dt * (prefix_sum<ROW16>(wk, lane) - wk);
+    const double v = c.v0 + c.dt * (prefix_sum<ROW16>(ak, lane) - ak);
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    const bool stg = lane <= N;
+    const double tc = stg ? cs : 0.0, ts = stg ? sn : 0.0, tdx = stg ? -v * sn : 0.0, tdy = stg ? v * cs : 0.0;
+    const double pcx = prefix_sum<ROW16>(tc, lane) - tc, pcy = prefix_sum<ROW16>(ts, lane) - ts;
+    const double pdx = prefix_sum<ROW16>(tdx, lane) - tdx, pdy = prefix_sum<ROW16>(tdy, lane) - tdy;
+    const double px = c.x0 + c.dt * pdy, py = c.y0 - c.dt * pdx;
+    if (stg) { W.TH[lane] = th; W.V[lane] = v; W.C[lane] = cs; W.S[lane] = sn; }
+    if (lane < NP) {
         W.pos[2 * lane] = px; W.pos[2 * lane + 1] = py;
+        if (derivs) { W.PC[2 * lane] = pcx; W.PC[2 * lane + 1] = pcy; W.PD[2 * lane] = pdx; W.PD[2 * lane + 1] = pdy; }
+    }
+    // f
+    double part = 0.0;
+    if (lane >= 1 && lane <= N) {
+        const double ex = px - c.gx, ey = py - c.gy;
+        part = c.Qx * ex * ex + c.Qy * ey * ey + c.Qth * th * th + c.Qv * v * v;
+    }
+    for (int i = lane; i < n; i += 64) {
+        const double prev = i >= 2 ? z[i - 2] : ((i & 1) ? c.up1 : c.up0);
+        const double du = z[i] - prev;
+        part += ((i & 1) ? c.R1 : c.R0) * du * du;
     }
     SC_SYNC();
+    SC_PH(slot);
     if (derivs) {
-        // G = d p / d z:  dP[2k+d][col] = dt^2 (P[k][d] - P[j+1][d]) for stages j <= k - 2, P = PC (accel) | PD (omega)
+        // G = d p / d z:  dP[2k+d][col] = dt^2 (P[k][d] - P[j+1][d]) for stages j <= k - 2, P = PC (accel) | PD (omega);
+        // the structural zeros (k < j + 2) are written once at kernel start
         const double dt2 = c.dt * c.dt;
-        for (int e = lane; e < (N + 2) * n; e += 64) {
-            const int k = e / n, col = e - k * n, j = col >> 1;
-            double v0 = 0.0, v1 = 0.0;
-            if (j + 1 <= k - 1) {
-                const double* P = (col & 1) ? W.PD : W.PC;
-                v0 = dt2 * (P[2 * k] - P[2 * (j + 1)]);
-                v1 = dt2 * (P[2 * k + 1] - P[2 * (j + 1) + 1]);
+        for (int e = lane; e < 3 * n; e += 64) {
+            const int gq = e / n, col = e - gq * n, j = col >> 1;
+            const double* P = (col & 1) ? W.PD : W.PC;
+            const double b0 = P[2 * (j + 1)], b1 = P[2 * (j + 1) + 1];
+            for (int k = gq; k < NP; k += 3) {
+                if (k >= j + 2) {
+                    W.dP[(size_t)(2 * k) * n + col] = dt2 * (P[2 * k] - b0);
+                    W.dP[(size_t)(2 * k + 1) * n + col] = dt2 * (P[2 * k + 1] - b1);
+                }
             }
-            W.dP[(size_t)(2 * k) * n + col] = v0;
-            W.dP[(size_t)(2 * k + 1) * n + col] = v1;
         }
     }
-    for (int e = lane; e < (N + 2) * K; e += 64) {
+    SC_PH(slot + 1);
+    for (int e = lane; e < NP * K; e += 64) {
         const int k = e / K, j = e - k * K;
         double h, d0, d1, hxx, hxy, hyy;
         barrier_at(W.pos[2 * k], W.pos[2 * k + 1], W.obs + 7 * j, c, derivs, h, d0, d1, hxx, hxy, hyy);
@@ -197,6 +268,7 @@ __device__ inline double eval_values(const double* z, const MpcMem& W, const Mpc
         }
     }
     SC_SYNC();
+    SC_PH(slot + 2);
     // g >= 0 : [CBF (k major) | v_max -/+ v_k (k = 1..N) | u_max - z | u_max + z]
     for (int i = lane; i < c.m; i += 64) {
         double gi;
@@ -214,19 +286,10 @@ __device__ inline double eval_values(const double* z, const MpcMem& W, const Mpc
         }
         W.g[i] = gi;
     }
-    // f
-    double part = 0.0;
-    if (lane >= 1 && lane <= N) {
-        const double ex = W.pos[2 * lane] - c.gx, ey = W.pos[2 * lane + 1] - c.gy;
-        part = c.Qx * ex * ex + c.Qy * ey * ey + c.Qth * W.TH[lane] * W.TH[lane] + c.Qv * W.V[lane] * W.V[lane];
-    }
-    for (int i = lane; i < n; i += 64) {
-        const double prev = i >= 2 ? z[i - 2] : ((i & 1) ? c.up1 : c.up0);
-        const double du = z[i] - prev;
-        part += ((i & 1) ? c.R1 : c.R0) * du * du;
-    }
     SC_SYNC();
-    return wsum(part);
+    const double fsum = wsum(part);
+    SC_PH(slot + 3);
+    return fsum;
 }
 
 // ---- assembly in position space ------------------------------------------------------------------------------
@@ -239,12 +302,12 @@ __device__ inline double eval_values(const double* z, const MpcMem& W, const Mpc
 
 // rows: sigma = lam / s, 1/s, sigma r_p + lam; returns the lane-partial residual norms
 __device__ __forceinline__ void row_pass(const MpcMem& W, const MpcConst& c, int lane, double& e_p, double& e_c0, double& lmax) {
-    double* is = W.ds;
+    double* is = W.is;
     double* vb = W.dlam;
     e_p = 0.0; e_c0 = 0.0; lmax = 0.0;
     for (int i = lane; i < c.m; i += 64) {
         const double s = W.sl[i], l = W.lam[i], rp = W.g[i] - s;
-        const double inv = 1.0 / s, sig = l * inv;
+        const double inv = rcp_(s), sig = l * inv;
         W.st[i] = sig; is[i] = inv; vb[i] = sig * rp + l;
         e_p = fmax(e_p, fabs(rp));
         e_c0 = fmax(e_c0, fabs(s * l));
@@ -256,10 +319,10 @@ __device__ __forceinline__ void row_pass(const MpcMem& W, const MpcConst& c, int
 // positions: lane k < NP builds  q_k = d L / d p_k,  Om_k,  the position-space vectors A'(1/s), A'(sig r_p + lam),
 // row block k of Phi, and the suffix sums the structured Hessian terms need.  Multipliers are those of the scaled
 // problem (objective times sf), so everything here is already scaled.
-template <int KT>
+template <int KT, bool ROW16>
 __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, int lane, double sf) {
     const int N = c.N, K = c.K, NP = N + 2, k = lane;
-    const double* is = W.ds;
+    const double* is = W.is;
     const double* vb = W.dlam;
     double q0 = 0.0, q1 = 0.0;
     if (k < NP) {
@@ -316,7 +379,7 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
     }
     // suffix sums (wave scans): qbar_i = sum_{k > i} q_k;  A_i = qbar_i . (-s_i, c_i),  B_i = v_i qbar_i . (c_i, s_i);
     // SA[t] = sum_{i >= t} A_i, SB likewise (t = 0..N+1, zero at N+1);  SS[t] = sum_{k >= t} (sig+_k + sig-_k), k = 1..N
-    const double qs0 = suffix_sum(q0, lane) - q0, qs1 = suffix_sum(q1, lane) - q1;
+    const double qs0 = suffix_sum<ROW16>(q0, lane) - q0, qs1 = suffix_sum<ROW16>(q1, lane) - q1;
     double Ai = 0.0, Bi = 0.0, sk = 0.0;
     if (k <= N) {
         const double ci = W.C[k], si = W.S[k];
@@ -324,30 +387,34 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
         Bi = W.V[k] * (qs0 * ci + qs1 * si);
         if (k >= 1) sk = W.st[c.mc + 2 * (k - 1)] + W.st[c.mc + 2 * (k - 1) + 1];
     }
-    const double sa = suffix_sum(Ai, lane), sb = suffix_sum(Bi, lane), ss = suffix_sum(sk, lane);
+    const double sa = suffix_sum<ROW16>(Ai, lane), sb = suffix_sum<ROW16>(Bi, lane), ss = suffix_sum<ROW16>(sk, lane);
     if (k < NP) { W.SA[k] = sa; W.SB[k] = sb; W.SS[k] = ss; }
 }
 
-// columns: cv[v][col] for the three row vectors  v = 0: r_d = sf grad f - J' lam;  1: J'(1/s);  2: J'(sig r_p + lam)
+// columns: cv[v][col] for the three row vectors  v = 0: r_d = sf grad f - J' lam;  1: J'(1/s);  2: J'(sig r_p + lam).
+// Every inner loop has a trip count that does not depend on the lane (structural zeros of G, masks on the stage
+// sums), so with compile-time N the loads of a lane are issued back to back instead of one round trip per term.
 __device__ __forceinline__ double col_pass(const MpcMem& W, const MpcConst& c, int lane, double sf) {
     const int N = c.N, n = c.n, NP = N + 2;
     double e_d = 0.0;
     for (int idx = lane; idx < 3 * n; idx += 64) {
         const int v = idx / n, col = idx - v * n, j = col >> 1;
         const double* y = W.Y + (size_t)v * 2 * NP;
-        const double* vec = v == 0 ? W.lam : (v == 1 ? W.ds : W.dlam);
+        const double* vec = v == 0 ? W.lam : (v == 1 ? W.is : W.dlam);
         double acc = 0.0;
-        for (int row = 2 * (j + 2); row < 2 * NP; ++row) acc += W.dP[(size_t)row * n + col] * y[row];
-        double sb = vec[c.mc + 2 * N + n + col] - vec[c.mc + 2 * N + col];
-        if (!(col & 1)) {
-            double sp = 0.0;
-            for (int k = j + 1; k <= N; ++k) sp += vec[c.mc + 2 * (k - 1) + 1] - vec[c.mc + 2 * (k - 1)];
-            sb += c.dt * sp;
+#pragma unroll
+        for (int row = 4; row < 2 * NP; ++row) acc += W.dP[(size_t)row * n + col] * y[row];       // rows 0..3 of G are zero
+        double sp = 0.0, sx = 0.0;
+        const double* Xs = (col & 1) ? W.TH : W.V;
+#pragma unroll
+        for (int k = 1; k <= N; ++k) {
+            const double dv = vec[c.mc + 2 * (k - 1) + 1] - vec[c.mc + 2 * (k - 1)], xk = Xs[k];
+            sp += k > j ? dv : 0.0;                               // speed rows of stages k > j
+            sx += k > j ? xk : 0.0;                               // sum_{k > j} theta_k | v_k
         }
+        double sb = vec[c.mc + 2 * N + n + col] - vec[c.mc + 2 * N + col];
+        if (!(col & 1)) sb += c.dt * sp;
         if (v == 0) {
-            double sx = 0.0;                                     // sum_{k > j} theta_k | v_k
-            const double* Xs = (col & 1) ? W.TH : W.V;
-            for (int k = j + 1; k <= N; ++k) sx += Xs[k];
             const double Rc = (col & 1) ? c.R1 : c.R0, Qs = (col & 1) ? c.Qth : c.Qv;
             const double prev = col >= 2 ? W.z[col - 2] : ((col & 1) ? c.up1 : c.up0);
             double gr = 2.0 * Qs * c.dt * sx + 2.0 * Rc * (W.z[col] - prev);
@@ -362,56 +429,81 @@ __device__ __forceinline__ double col_pass(const MpcMem& W, const MpcConst& c, i
     return wmax(e_d);
 }
 
-// T = Phi G  (2 NP x n), Phi block pentadiagonal
+// ---- f64 MFMA (v_mfma_f64_16x16x4_f64) -----------------------------------------------------------------------------
+// Operand layout (MI355X guide, "f64 MFMA"): lane l feeds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
+// result register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15].
+// p_0 and p_1 do not depend on z, so rows 0..3 of G vanish: both products run on the n = 2 N rows 4.. of G, T and
+// Phi (G', T', Phi').  k-steps outside a tile's structural non-zeros are skipped:
+//   G'[kk][col] = 0 for kk < 2 (col >> 1)   (block lower triangular),   Phi'[i][kk] = 0 for |kk/2 - i/2| > 2.
+
+// T' = Phi' G'   (9 MFMAs for N = 10)
 __device__ __forceinline__ void phi_times_G(const MpcMem& W, const MpcConst& c, int lane) {
-    const int n = c.n, NP = c.N + 2;
-    for (int e = lane; e < 2 * NP * n; e += 64) {
-        const int row = e / n, col = e - row * n, k = row >> 1;
-        const double* ph = W.Phi + (size_t)row * 10;
-        double acc = 0.0;
+    const int n = c.n, nt = (n + 15) >> 4, q = lane >> 4, l15 = lane & 15;
+    for (int ti = 0; ti < nt; ++ti) {
+        const int i = 16 * ti + l15, R = i + 4, kR = R >> 1;
+        const bool okA = i < n;
+        const double* band = W.Phi + (size_t)(okA ? R : 4) * 10;
+        for (int tj = 0; tj < nt; ++tj) {
+            const int cB = 16 * tj + l15;
+            const bool okB = cB < n;
+            const int cb = okB ? cB : 0;
+            int lo = 16 * ti - 4;
+            lo = lo > 16 * tj ? lo : 16 * tj;
+            lo = lo > 0 ? lo : 0;
+            const int hi = (16 * ti + 20) < n ? (16 * ti + 20) : n;
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int dl = -2; dl <= 2; ++dl) {
-            const int kk = k + dl;
-            if (kk >= 0 && kk < NP)
-                acc += ph[(dl + 2) * 2] * W.dP[(size_t)(2 * kk) * n + col] + ph[(dl + 2) * 2 + 1] * W.dP[(size_t)(2 * kk + 1) * n + col];
+            for (int k0 = lo; k0 < hi; k0 += 4) {
+                const int kk = k0 + q, Cc = kk + 4, dl = (Cc >> 1) - kR;
+                const bool okk = kk < n, inband = dl >= -2 && dl <= 2;
+                double a = band[(inband ? dl + 2 : 2) * 2 + (Cc & 1)];
+                double b = W.dP[(size_t)(okk ? Cc : 4) * n + cb];
+                a = (okA && okk && inband) ? a : 0.0;
+                b = (okB && okk) ? b : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + q + 4 * r, col = 16 * tj + l15;
+                if (row < n && col < n) W.T[(size_t)(row + 4) * n + col] = acc[r];
+            }
         }
-        W.T[e] = acc;
     }
 }
 
-// ---- f64 MFMA (v_mfma_f64_16x16x4_f64): condensed matrix  M = G' T + structured terms ---------------------------
-// Operand layout (MI355X guide, "f64 MFMA"): lane l feeds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15];
-// result register r of lane l is D[row = (l >> 4) + 4 r][col = l & 15].  The contraction index is the position row.
+// structured part of the condensed matrix at (r, cc)
 __device__ __forceinline__ double condensed_base(const MpcMem& W, const MpcConst& c, double sf, int r, int cc) {
     const int N = c.N, n = c.n;
     const int jr = r >> 1, jc = cc >> 1, jm = jr > jc ? jr : jc;
     const double dt2 = c.dt * c.dt, dt3 = dt2 * c.dt;
     const bool ra = !(r & 1), ca = !(cc & 1);
-    double acc;
-    if (ra && ca) acc = sf * 2.0 * c.Qv * dt2 * (double)(N - jm) + dt2 * W.SS[jm + 1];     // d v_k: objective + speed rows
-    else if (!ra && !ca) acc = sf * 2.0 * c.Qth * dt2 * (double)(N - jm) - dt3 * W.SB[jm + 1];
-    else acc = dt3 * W.SA[jm + 1];
+    const double ss = W.SS[jm + 1], sb = W.SB[jm + 1], sa = W.SA[jm + 1];
+    const double vaa = sf * 2.0 * c.Qv * dt2 * (double)(N - jm) + dt2 * ss;             // d v_k: objective + speed rows
+    const double vww = sf * 2.0 * c.Qth * dt2 * (double)(N - jm) - dt3 * sb;
+    double acc = (ra && ca) ? vaa : ((!ra && !ca) ? vww : dt3 * sa);
     const double Rc = (r & 1) ? c.R1 : c.R0;                                               // input-rate penalty 2 D' R D
-    if (r == cc) acc += sf * 2.0 * Rc * ((r + 2 < n) ? 2.0 : 1.0) + W.st[c.mc + 2 * N + r] + W.st[c.mc + 2 * N + n + r];
-    else if (r == cc + 2 || cc == r + 2) acc -= sf * 2.0 * Rc;
+    const double dg = sf * 2.0 * Rc * ((r + 2 < n) ? 2.0 : 1.0) + W.st[c.mc + 2 * N + r] + W.st[c.mc + 2 * N + n + r];
+    acc += (r == cc) ? dg : ((r == cc + 2 || cc == r + 2) ? -sf * 2.0 * Rc : 0.0);
     return acc;
 }
 
+// M = G'' T' + structured terms   (7 MFMAs for N = 10; lower tiles, mirrored)
 __device__ __forceinline__ void condense_mfma(const MpcMem& W, const MpcConst& c, int lane, double sf) {
-    const int n = c.n, rows = 2 * (c.N + 2), nt = (n + 15) >> 4, q = lane >> 4, l15 = lane & 15;
+    const int n = c.n, nt = (n + 15) >> 4, q = lane >> 4, l15 = lane & 15;
     for (int ti = 0; ti < nt; ++ti) {
         for (int tj = 0; tj <= ti; ++tj) {
             const int cA = 16 * ti + l15, cB = 16 * tj + l15;
             const bool okA = cA < n, okB = cB < n;
             const int ca = okA ? cA : 0, cb = okB ? cB : 0;
             d4_t acc = {0.0, 0.0, 0.0, 0.0};
-            for (int k0 = 0; k0 < rows; k0 += 4) {
-                const int row = k0 + q;
-                const bool okr = row < rows;
-                const int rr = okr ? row : 0;
+#pragma unroll
+            for (int k0 = 16 * ti; k0 < n; k0 += 4) {
+                const int kk = k0 + q;
+                const bool okk = kk < n;
+                const int rr = (okk ? kk : 0) + 4;
                 double a = W.dP[(size_t)rr * n + ca], b = W.T[(size_t)rr * n + cb];
-                a = (okA && okr) ? a : 0.0;
-                b = (okB && okr) ? b : 0.0;
+                a = (okA && okk) ? a : 0.0;
+                b = (okB && okk) ? b : 0.0;
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
             }
 #pragma unroll
@@ -476,18 +568,19 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-// In: a[k] = A[lane][k] (lower triangle used).  Out: a[k] = L[lane][k] for k <= lane, piv_out = L[lane][lane].
-// Same operation order as cholesky(): right-looking, l_ij = a_ij / sqrt(d_j).  Returns false on a pivot <= 0.
+// In: a[k] = A[lane][k] (lower triangle used).  Out: a[k] = L[lane][k] for k <= lane, dinv = 1 / L[lane][lane].
+// Right-looking; the pivot's reciprocal square root (v_rsq_f64 + two Newton steps) replaces sqrt and the division.
+// Returns false on a pivot <= 0.
 template <int n>
-__device__ __forceinline__ bool chol_reg(double (&a)[n], int lane, double& diag) {
-    diag = 1.0;
+__device__ __forceinline__ bool chol_reg(double (&a)[n], int lane, double& dinv) {
+    dinv = 1.0;
 #pragma unroll
     for (int j = 0; j < n; ++j) {
         const double d = bcast_lane(a[j], j);
         if (!(d > 0.0)) return false;                  // uniform
-        const double piv = sqrt(d);
-        a[j] = (lane == j) ? piv : a[j] / piv;
-        diag = (lane == j) ? piv : diag;
+        const double r = rsqrt_(d);
+        a[j] = (lane == j) ? d * r : a[j] * r;
+        dinv = (lane == j) ? r : dinv;
 #pragma unroll
         for (int k = j + 1; k < n; ++k) {
             const double lkj = bcast_lane(a[j], k);
@@ -500,8 +593,7 @@ __device__ __forceinline__ bool chol_reg(double (&a)[n], int lane, double& diag)
 // Solve L L' x = b with L row-held in a[] (from chol_reg), b = this lane's right-hand-side entry.  Lt is an LDS
 // scratch of n (n + 1) doubles used once to transpose L (row stride n + 1 keeps the 64 banks conflict-free).
 template <int n>
-__device__ __forceinline__ double chol_solve_reg(double (&a)[n], double diag, double b, double* Lt, int lane) {
-    const double dinv = 1.0 / diag;
+__device__ __forceinline__ double chol_solve_reg(double (&a)[n], double dinv, double b, double* Lt, int lane) {
     constexpr int ld = n + 1;
 #pragma unroll
     for (int k = 0; k < n; ++k) {
@@ -552,6 +644,8 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
     c.gx = (double)goal[prob * 2 + 0]; c.gy = (double)goal[prob * 2 + 1];
     const int N = c.N, n = c.n, m = c.m;
     const MpcMem W = carve(sm, N, K);
+    constexpr bool ROW16 = NT > 0 && NT + 2 <= 16;
+    for (int e = lane; e < 2 * (N + 2) * n; e += 64) W.dP[e] = 0.0;      // structural zeros of G stay
 
     const TIO* osrc = obs + (p.obs_shared ? 0 : (size_t)prob * K * 7);
     for (int e = lane; e < K * 7; e += 64) W.obs[e] = (double)osrc[e];
@@ -563,37 +657,36 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
     }
     SC_SYNC();
 
-    double f = eval_values(W.z, W, c, lane, true);
+    Prof pf;
+    pf.start();
+    double f = eval_values<ROW16>(W.z, W, c, lane, true, pf, 12);
     // objective scaling from |grad f|_inf at the start: with lam = 0 the column pass returns r_d = grad f
     for (int i = lane; i < m; i += 64) { W.sl[i] = fmax(W.g[i], 1e-2); W.lam[i] = 0.0; }
     SC_SYNC();
     double e_p, e_c0, lmax;
     row_pass(W, c, lane, e_p, e_c0, lmax);
     SC_SYNC();
-    stage_pass<KT>(W, c, lane, 1.0);
+    stage_pass<KT, ROW16>(W, c, lane, 1.0);
     SC_SYNC();
     const double gmax = col_pass(W, c, lane, 1.0);
     const double sf = fmin(1.0, 100.0 / fmax(1e-12, gmax));             // objective scaling
     double mu = p.mu_init;
     SC_SYNC();
-    for (int i = lane; i < m; i += 64) W.lam[i] = mu / W.sl[i];
+    for (int i = lane; i < m; i += 64) W.lam[i] = mu * W.is[i];
     SC_SYNC();
 
     int status = SC_STATUS_INACCURATE, it = 0;
-#ifdef SC_MPC_PROF
-    double ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long tph = clock64();
-#endif
+    pf.start();
     const double tau = 0.995;
     double nu = 10.0, delta_last = 0.0, e_best = 1e300;
     for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
     for (it = 1; it <= p.max_iter; ++it) {
-        if (it > 1) f = eval_values(W.z, W, c, lane, true);
+        if (it > 1) f = eval_values<ROW16>(W.z, W, c, lane, true, pf, 12);
         SC_PH(0);
         row_pass(W, c, lane, e_p, e_c0, lmax);
         SC_SYNC();
         SC_PH(1);
-        stage_pass<KT>(W, c, lane, sf);
+        stage_pass<KT, ROW16>(W, c, lane, sf);
         SC_SYNC();
         SC_PH(2);
         const double e_d = col_pass(W, c, lane, sf);
@@ -611,7 +704,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             for (int i = lane; i < m; i += 64) e_c = fmax(e_c, fabs(W.sl[i] * W.lam[i] - mu));
             e_c = wmax(e_c);
             const double e_mu = fmax(e_d, fmax(e_p, e_c));
-            if (e_mu <= 10.0 * mu && mu > p.mu_min) mu = fmax(p.mu_min, fmin(0.2 * mu, pow(mu, 1.5)));
+            if (e_mu <= 10.0 * mu && mu > p.mu_min) mu = fmax(p.mu_min, fmin(0.2 * mu, mu * sqrt(mu)));
             else break;
         }
         SC_PH(4);
@@ -658,14 +751,15 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         SC_PH(8);
         // position and speed displacements  dp = G dz,  dV_k = dt sum_{j < k} dz_{2j}
         for (int row = lane; row < 2 * (N + 2); row += 64) {
-            double acc = 0.0;
-            const int cend = 2 * ((row >> 1) - 1);                        // p_k depends on stages j <= k - 2
-            for (int col = 0; col < cend; ++col) acc += W.dP[(size_t)row * n + col] * W.dz[col];
+            double acc = 0.0;                                             // p_k depends on stages j <= k - 2 (zeros stored)
+#pragma unroll
+            for (int col = 0; col < n; ++col) acc += W.dP[(size_t)row * n + col] * W.dz[col];
             W.dp[row] = acc;
         }
         for (int k = lane; k <= N; k += 64) {
             double acc = 0.0;
-            for (int j = 0; j < k; ++j) acc += W.dz[2 * j];
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc += j < k ? W.dz[2 * j] : 0.0;
             W.dV[k] = c.dt * acc;
         }
         double gdz = 0.0;
@@ -673,9 +767,10 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         SC_SYNC();
         SC_PH(9);
         // ds = J dz + r_p, dlam, step lengths
-        double ap = 1.0, ad = 1.0, sum_ds_s = 0.0, sum_rp = 0.0, sum_log = 0.0;
+        double rs_min = 0.0, rl_min = 0.0, sum_ds_s = 0.0, sum_rp = 0.0;
+        LogSum ls0;
         for (int i = lane; i < m; i += 64) {
-            const double s = W.sl[i], lam = W.lam[i], rp = W.g[i] - s;
+            const double s = W.sl[i], lam = W.lam[i], rp = W.g[i] - s, isv = W.is[i];
             double jd;
             if (i < c.mc) {
                 const int k = i / K, jo = i - k * K;
@@ -691,14 +786,16 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
                 jd = r < n ? -W.dz[r] : W.dz[r - n];
             }
             const double ds = jd + rp;
-            const double dl = -W.st[i] * ds - (lam - mu / s);
+            const double dl = -W.st[i] * ds - (lam - mu * isv);
             gdz += lam * jd;                                              // sf grad f . dz = r_d . dz + lam . (J dz)
-            if (ds < 0.0) ap = fmin(ap, -tau * s / ds);
-            if (dl < 0.0) ad = fmin(ad, -tau * lam / dl);
-            sum_ds_s += ds / s; sum_rp += fabs(rp); sum_log += log(s);
+            const double rs = ds * isv, rl = dl * rcp_(lam);              // fraction to the boundary: most negative ratios
+            rs_min = fmin(rs_min, rs); rl_min = fmin(rl_min, rl);
+            sum_ds_s += rs; sum_rp += fabs(rp); ls0.add(s);
             W.ds[i] = ds; W.dlam[i] = dl;
         }
-        ap = wmin(ap); ad = wmin(ad); sum_ds_s = wsum(sum_ds_s); sum_rp = wsum(sum_rp); sum_log = wsum(sum_log);
+        rs_min = wmin(rs_min); rl_min = wmin(rl_min); sum_ds_s = wsum(sum_ds_s); sum_rp = wsum(sum_rp);
+        const double sum_log = ls0.total();
+        const double ap = rs_min < 0.0 ? fmin(1.0, -tau / rs_min) : 1.0, ad = rl_min < 0.0 ? fmin(1.0, -tau / rl_min) : 1.0;
         gdz = wsum(gdz);
         nu = fmax(nu, 1.1 * lmax);
         const double phi0 = sf * f - mu * sum_log + nu * sum_rp;
@@ -710,13 +807,15 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         for (int ls = 0; ls < 12; ++ls) {                              // at most 12 halvings, then give up (best iterate)
             for (int i = lane; i < n; i += 64) W.zt[i] = W.z[i] + alpha * W.dz[i];
             SC_SYNC();
-            const double ft = eval_values(W.zt, W, c, lane, false);
-            double slog = 0.0, srp = 0.0;
+            const double ft = eval_values<ROW16>(W.zt, W, c, lane, false, pf, 16);
+            double srp = 0.0;
+            LogSum lst;
             for (int i = lane; i < m; i += 64) {
                 const double st = W.sl[i] + alpha * W.ds[i];
-                slog += log(st); srp += fabs(W.g[i] - st);
+                lst.add(st); srp += fabs(W.g[i] - st);
             }
-            slog = wsum(slog); srp = wsum(srp);
+            const double slog = lst.total();
+            srp = wsum(srp);
             const double phit = sf * ft - mu * slog + nu * srp;
             // Armijo, with an allowance for round-off in the merit function near convergence
             // (f is a sum of a few hundred terms of size |phi|: its noise is ~1e-13 |phi|)
@@ -728,7 +827,8 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         for (int i = lane; i < m; i += 64) {
             const double s = W.sl[i] + alpha * W.ds[i];
             double lam = W.lam[i] + ad * W.dlam[i];
-            lam = fmin(fmax(lam, mu / (1e10 * s)), 1e10 * mu / s);       // IPOPT eq. (16) safeguard
+            const double mus = mu * rcp_(s);
+            lam = fmin(fmax(lam, 1e-10 * mus), 1e10 * mus);               // IPOPT eq. (16) safeguard
             W.sl[i] = s; W.lam[i] = lam;
         }
         SC_SYNC();
@@ -743,7 +843,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         status = SC_STATUS_OPTIMAL;
     }
     SC_SYNC();
-    eval_values(W.z, W, c, lane, false);
+    eval_values<ROW16>(W.z, W, c, lane, false, pf, 16);
     if (status != SC_STATUS_OPTIMAL) {
         double gmin = 1e300;
         for (int i = lane; i < m; i += 64) gmin = fmin(gmin, W.g[i]);
@@ -758,7 +858,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         if (iters_out) iters_out[prob] = it;
     }
 #ifdef SC_MPC_PROF
-    if (z_out && lane < 12) z_out[prob * n + lane] = (TIO)ph[lane];
+    if (z_out && lane < 20 && lane < n) z_out[prob * n + lane] = (TIO)pf.ph[lane];
 #else
     if (z_out) for (int i = lane; i < n; i += 64) z_out[prob * n + i] = (TIO)W.z[i];
 #endif

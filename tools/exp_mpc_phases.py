@@ -6,8 +6,10 @@ sys.path.insert(0, ".")
 import safe_control_amd as sca
 from safe_control_amd import workloads as W
 
-NAMES = ["eval_values(+G)", "row pass", "stage pass", "col pass", "mu update", "T = Phi G", "rhs+condense MFMA",
-         "cholesky", "chol_solve", "dp, dV", "step rows", "line search+update"]
+NAMES = ["(eval_values tail)", "row pass", "stage pass", "col pass", "mu update", "T = Phi G", "rhs+condense MFMA",
+         "cholesky", "chol_solve", "dp, dV", "step rows", "line search+update (excl. eval)",
+         "eval(derivs): rollout", "eval(derivs): G", "eval(derivs): barrier", "eval(derivs): g, f",
+         "eval(LS): rollout", "eval(LS): -", "eval(LS): barrier", "eval(LS): g, f"]
 dev = torch.device("cuda:0")
 spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}
 ctl = sca.BatchedMPCCBF(dict(spec), io_dtype="f32", horizon=10)
@@ -18,7 +20,7 @@ X, g, ob = t(Xn), t(goal), t(on)
 up = torch.zeros((B, 2), dtype=torch.float32, device=dev)
 u, st, it, z = ctl.solve(X, up, g, ob, want_z=True)
 torch.cuda.synchronize()
-ph = z.cpu().numpy()[:, :12].astype(np.float64)
+ph = z.cpu().numpy()[:, :20].astype(np.float64)
 itn = it.cpu().numpy().astype(np.float64)
 tot = ph.sum(1)
 print(f"B={B} mean iters {itn.mean():.2f}; cycles/iter {tot.sum()/itn.sum():.0f}")
