@@ -79,6 +79,25 @@ __device__ __forceinline__ int wsumi(int v) {
     return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
            __builtin_amdgcn_readlane(v, 48);
 }
+// v[l] + v[l ^ 16] + v[l ^ 32] + v[l ^ 48]: the same lane of the four 16-lane rows, on the gfx950 row swaps
+// (v_permlane16_swap exchanges odd rows of one register with even rows of the other, v_permlane32_swap the wave
+// halves; called with two copies of v the two results are "mine" and "the partner row's" in every lane)
+__device__ __forceinline__ double sum_rows4(double v) {
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    return v;
+}
+
 // sum of log(x_i) over the wave as log(prod mantissas) + ln2 * sum exponents: one log per wave instead of one per
 // row.  A lane multiplies at most a few mantissas in [0.5, 1), the wave product stays above 2^-(64 * rows per lane).
 struct LogSum {
@@ -246,7 +265,7 @@ __device__ inline double eval_values(const double* z, const MpcMem& W, const Mpc
         const double dt2 = c.dt * c.dt;
         for (int e = lane; e < 3 * n; e += 64) {
             const int gq = e / n, col = e - gq * n, j = col >> 1;
-            const double* P = (col & 1) ? W.PD : W.PC;
+            const double* P = W.PC + ((col & 1) ? (W.PD - W.PC) : 0);
             const double b0 = P[2 * (j + 1)], b1 = P[2 * (j + 1) + 1];
             for (int k = gq; k < NP; k += 3) {
                 if (k >= j + 2) {
@@ -321,44 +340,60 @@ __device__ __forceinline__ void row_pass(const MpcMem& W, const MpcConst& c, int
 // problem (objective times sf), so everything here is already scaled.
 template <int KT, bool ROW16>
 __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, int lane, double sf) {
-    const int N = c.N, K = c.K, NP = N + 2, k = lane;
+    // ROW16: the obstacle loop of stage k is split over lanes k, k + 16, k + 32, k + 48 (jo = part, part + 4, ..) and
+    // the partial sums are added across the four rows; every row then holds the totals, row 0 stores them.
+    const int N = c.N, K = c.K, NP = N + 2;
+    const int part = ROW16 ? (lane >> 4) : 0, k = ROW16 ? (lane & 15) : lane;
+    constexpr int PSTEP = ROW16 ? 4 : 1;
     const double* is = W.is;
     const double* vb = W.dlam;
     double q0 = 0.0, q1 = 0.0;
+    double oxx = 0, oxy = 0, oyy = 0, ya0 = 0, ya1 = 0, yb0 = 0, yb1 = 0;
+    double f0xx = 0, f0xy = 0, f0yy = 0, f1[4] = {0, 0, 0, 0}, f2[4] = {0, 0, 0, 0};
     if (k < NP) {
-        double oxx = 0, oxy = 0, oyy = 0, ya0 = 0, ya1 = 0, yb0 = 0, yb1 = 0;
-        double f0xx = 0, f0xy = 0, f0yy = 0, f1[4] = {0, 0, 0, 0}, f2[4] = {0, 0, 0, 0};
         const bool t0 = k <= N - 1, t1 = k >= 1 && k <= N, t2 = k >= 2;       // row kappa = k - t exists
         const int r0 = (t0 ? k : 0) * K, r1 = (t1 ? k - 1 : 0) * K, r2 = (t2 ? k - 2 : 0) * K;
         const double w0 = t0 ? c.w0 : 0.0, w1 = t1 ? c.w1 : 0.0, w2 = t2 ? c.w2 : 0.0;
         const int k1 = k + 1 < NP ? k + 1 : k, k2 = k + 2 < NP ? k + 2 : k;
-        constexpr int UNR = KT > 0 ? KT : 4;
+        constexpr int UNR = KT > 0 ? (KT + PSTEP - 1) / PSTEP : 4;
 #pragma unroll UNR
-        for (int jo = 0; jo < K; ++jo) {
+        for (int jo = part; jo < K; jo += PSTEP) {
             const double l0 = W.lam[r0 + jo], l1 = W.lam[r1 + jo], l2 = W.lam[r2 + jo];
             const double i0 = is[r0 + jo], i1 = is[r1 + jo], i2 = is[r2 + jo];
             const double b0 = vb[r0 + jo], b1 = vb[r1 + jo], b2 = vb[r2 + jo];
             const double s0 = W.st[r0 + jo], s1 = W.st[r1 + jo];
             const double s2 = W.st[r2 + jo];
+            const int e = k * K + jo, e1 = k1 * K + jo, e2 = k2 * K + jo;
+            const double d0 = W.dh[2 * e], d1 = W.dh[2 * e + 1];
+            const double a0 = W.dh[2 * e1], a1 = W.dh[2 * e1 + 1], g0 = W.dh[2 * e2], g1 = W.dh[2 * e2 + 1];
+            const double hxx = W.Hh[3 * e], hxy = W.Hh[3 * e + 1], hyy = W.Hh[3 * e + 2];
             const double ml = w0 * l0 + w1 * l1 + w2 * l2, ma = w0 * i0 + w1 * i1 + w2 * i2, mb = w0 * b0 + w1 * b1 + w2 * b2;
             const double c0 = w0 * w0 * s0 + w1 * w1 * s1 + w2 * w2 * s2;
             const double c1 = w1 * c.w2 * s1 + w0 * c.w1 * s0;      // rows kappa = k-1 (t = 1, 2) and kappa = k (t = 0, 1)
             const double c2 = w0 * c.w2 * s0;                        // row kappa = k (t = 0, 2)
-            const int e = k * K + jo, e1 = k1 * K + jo, e2 = k2 * K + jo;
-            const double d0 = W.dh[2 * e], d1 = W.dh[2 * e + 1];
-            const double a0 = W.dh[2 * e1], a1 = W.dh[2 * e1 + 1], g0 = W.dh[2 * e2], g1 = W.dh[2 * e2 + 1];
-            oxx -= ml * W.Hh[3 * e]; oxy -= ml * W.Hh[3 * e + 1]; oyy -= ml * W.Hh[3 * e + 2];
+            oxx -= ml * hxx; oxy -= ml * hxy; oyy -= ml * hyy;
             q0 -= ml * d0; q1 -= ml * d1;
             ya0 += ma * d0; ya1 += ma * d1; yb0 += mb * d0; yb1 += mb * d1;
             f0xx += c0 * d0 * d0; f0xy += c0 * d0 * d1; f0yy += c0 * d1 * d1;
             f1[0] += c1 * d0 * a0; f1[1] += c1 * d0 * a1; f1[2] += c1 * d1 * a0; f1[3] += c1 * d1 * a1;
             f2[0] += c2 * d0 * g0; f2[1] += c2 * d0 * g1; f2[2] += c2 * d1 * g0; f2[3] += c2 * d1 * g1;
         }
+    }
+    if constexpr (ROW16) {
+        auto rows4 = [](double& v) { v = sum_rows4(v); };
+        rows4(oxx); rows4(oxy); rows4(oyy); rows4(q0); rows4(q1); rows4(ya0); rows4(ya1); rows4(yb0); rows4(yb1);
+        rows4(f0xx); rows4(f0xy); rows4(f0yy);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { rows4(f1[t]); rows4(f2[t]); }
+    }
+    if (k < NP) {
         if (k >= 1 && k <= N) {
             oxx += sf * 2.0 * c.Qx; oyy += sf * 2.0 * c.Qy;
             q0 += sf * 2.0 * c.Qx * (W.pos[2 * k] - c.gx);
             q1 += sf * 2.0 * c.Qy * (W.pos[2 * k + 1] - c.gy);
         }
+    }
+    if (k < NP && part == 0) {
         W.Y[2 * k] = q0; W.Y[2 * k + 1] = q1;
         W.Y[2 * NP + 2 * k] = ya0; W.Y[2 * NP + 2 * k + 1] = ya1;
         W.Y[4 * NP + 2 * k] = yb0; W.Y[4 * NP + 2 * k + 1] = yb1;
@@ -379,6 +414,7 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
     }
     // suffix sums (wave scans): qbar_i = sum_{k > i} q_k;  A_i = qbar_i . (-s_i, c_i),  B_i = v_i qbar_i . (c_i, s_i);
     // SA[t] = sum_{i >= t} A_i, SB likewise (t = 0..N+1, zero at N+1);  SS[t] = sum_{k >= t} (sig+_k + sig-_k), k = 1..N
+    if (k >= NP) { q0 = 0.0; q1 = 0.0; }
     const double qs0 = suffix_sum<ROW16>(q0, lane) - q0, qs1 = suffix_sum<ROW16>(q1, lane) - q1;
     double Ai = 0.0, Bi = 0.0, sk = 0.0;
     if (k <= N) {
@@ -388,7 +424,7 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
         if (k >= 1) sk = W.st[c.mc + 2 * (k - 1)] + W.st[c.mc + 2 * (k - 1) + 1];
     }
     const double sa = suffix_sum<ROW16>(Ai, lane), sb = suffix_sum<ROW16>(Bi, lane), ss = suffix_sum<ROW16>(sk, lane);
-    if (k < NP) { W.SA[k] = sa; W.SB[k] = sb; W.SS[k] = ss; }
+    if (k < NP && part == 0) { W.SA[k] = sa; W.SB[k] = sb; W.SS[k] = ss; }
 }
 
 // columns: cv[v][col] for the three row vectors  v = 0: r_d = sf grad f - J' lam;  1: J'(1/s);  2: J'(sig r_p + lam).
@@ -400,12 +436,13 @@ __device__ __forceinline__ double col_pass(const MpcMem& W, const MpcConst& c, i
     for (int idx = lane; idx < 3 * n; idx += 64) {
         const int v = idx / n, col = idx - v * n, j = col >> 1;
         const double* y = W.Y + (size_t)v * 2 * NP;
-        const double* vec = v == 0 ? W.lam : (v == 1 ? W.is : W.dlam);
+        // (an offset select: a select between the pointers themselves makes the compiler spill MpcMem to scratch)
+        const double* vec = W.lam + (v == 0 ? 0 : (v == 1 ? (W.is - W.lam) : (W.dlam - W.lam)));
         double acc = 0.0;
 #pragma unroll
         for (int row = 4; row < 2 * NP; ++row) acc += W.dP[(size_t)row * n + col] * y[row];       // rows 0..3 of G are zero
         double sp = 0.0, sx = 0.0;
-        const double* Xs = (col & 1) ? W.TH : W.V;
+        const double* Xs = W.V + ((col & 1) ? (W.TH - W.V) : 0);
 #pragma unroll
         for (int k = 1; k <= N; ++k) {
             const double dv = vec[c.mc + 2 * (k - 1) + 1] - vec[c.mc + 2 * (k - 1)], xk = Xs[k];
@@ -436,7 +473,23 @@ __device__ __forceinline__ double col_pass(const MpcMem& W, const MpcConst& c, i
 // Phi (G', T', Phi').  k-steps outside a tile's structural non-zeros are skipped:
 //   G'[kk][col] = 0 for kk < 2 (col >> 1)   (block lower triangular),   Phi'[i][kk] = 0 for |kk/2 - i/2| > 2.
 
+// k-steps lo, lo + 4, .. < hi of one tile: operands of S steps are loaded first (one LDS round trip), then S MFMAs
+template <int S, typename LoadA, typename LoadB>
+__device__ __forceinline__ d4_t mfma_ksteps(int lo, int hi, LoadA load_a, LoadB load_b) {
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int kb = lo; kb < hi; kb += 4 * S) {
+        double a[S], b[S];
+#pragma unroll
+        for (int t = 0; t < S; ++t) { a[t] = load_a(kb + 4 * t); b[t] = load_b(kb + 4 * t); }
+#pragma unroll
+        for (int t = 0; t < S; ++t)
+            if (kb + 4 * t < hi) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[t], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
 // T' = Phi' G'   (9 MFMAs for N = 10)
+template <int S>
 __device__ __forceinline__ void phi_times_G(const MpcMem& W, const MpcConst& c, int lane) {
     const int n = c.n, nt = (n + 15) >> 4, q = lane >> 4, l15 = lane & 15;
     for (int ti = 0; ti < nt; ++ti) {
@@ -451,17 +504,19 @@ __device__ __forceinline__ void phi_times_G(const MpcMem& W, const MpcConst& c, 
             lo = lo > 16 * tj ? lo : 16 * tj;
             lo = lo > 0 ? lo : 0;
             const int hi = (16 * ti + 20) < n ? (16 * ti + 20) : n;
-            d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k0 = lo; k0 < hi; k0 += 4) {
-                const int kk = k0 + q, Cc = kk + 4, dl = (Cc >> 1) - kR;
-                const bool okk = kk < n, inband = dl >= -2 && dl <= 2;
-                double a = band[(inband ? dl + 2 : 2) * 2 + (Cc & 1)];
-                double b = W.dP[(size_t)(okk ? Cc : 4) * n + cb];
-                a = (okA && okk && inband) ? a : 0.0;
-                b = (okB && okk) ? b : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-            }
+            const d4_t acc = mfma_ksteps<S>(lo, hi,
+                [&](int k0) {
+                    const int kk = k0 + q, Cc = kk + 4, dl = (Cc >> 1) - kR;
+                    const bool inband = dl >= -2 && dl <= 2, ok = okA && kk < hi && inband;
+                    const double a = band[(inband ? dl + 2 : 2) * 2 + (Cc & 1)];
+                    return ok ? a : 0.0;
+                },
+                [&](int k0) {
+                    const int kk = k0 + q;
+                    const bool ok = okB && kk < hi;
+                    const double b = W.dP[(size_t)(ok ? kk + 4 : 4) * n + cb];
+                    return ok ? b : 0.0;
+                });
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + q + 4 * r, col = 16 * tj + l15;
@@ -488,6 +543,7 @@ __device__ __forceinline__ double condensed_base(const MpcMem& W, const MpcConst
 }
 
 // M = G'' T' + structured terms   (7 MFMAs for N = 10; lower tiles, mirrored)
+template <int S>
 __device__ __forceinline__ void condense_mfma(const MpcMem& W, const MpcConst& c, int lane, double sf) {
     const int n = c.n, nt = (n + 15) >> 4, q = lane >> 4, l15 = lane & 15;
     for (int ti = 0; ti < nt; ++ti) {
@@ -495,22 +551,30 @@ __device__ __forceinline__ void condense_mfma(const MpcMem& W, const MpcConst& c
             const int cA = 16 * ti + l15, cB = 16 * tj + l15;
             const bool okA = cA < n, okB = cB < n;
             const int ca = okA ? cA : 0, cb = okB ? cB : 0;
-            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            double base[4];
 #pragma unroll
-            for (int k0 = 16 * ti; k0 < n; k0 += 4) {
-                const int kk = k0 + q;
-                const bool okk = kk < n;
-                const int rr = (okk ? kk : 0) + 4;
-                double a = W.dP[(size_t)rr * n + ca], b = W.T[(size_t)rr * n + cb];
-                a = (okA && okk) ? a : 0.0;
-                b = (okB && okk) ? b : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + q + 4 * r, col = 16 * tj + l15;
+                base[r] = (row < n && col < n) ? condensed_base(W, c, sf, row, col) : 0.0;
             }
+            const d4_t acc = mfma_ksteps<S>(16 * ti, n,
+                [&](int k0) {
+                    const int kk = k0 + q;
+                    const bool ok = okA && kk < n;
+                    const double a = W.dP[(size_t)((ok ? kk : 0) + 4) * n + ca];
+                    return ok ? a : 0.0;
+                },
+                [&](int k0) {
+                    const int kk = k0 + q;
+                    const bool ok = okB && kk < n;
+                    const double b = W.T[(size_t)((ok ? kk : 0) + 4) * n + cb];
+                    return ok ? b : 0.0;
+                });
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + q + 4 * r, col = 16 * tj + l15;
                 if (row < n && col < n) {
-                    const double v = acc[r] + condensed_base(W, c, sf, row, col);
+                    const double v = acc[r] + base[r];
                     W.M[(size_t)row * n + col] = v;
                     if (ti != tj) W.M[(size_t)col * n + row] = v;
                 }
@@ -574,10 +638,11 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
 template <int n>
 __device__ __forceinline__ bool chol_reg(double (&a)[n], int lane, double& dinv) {
     dinv = 1.0;
-#pragma unroll
+    bool ok = true;                                    // no early exit: one basic block, so the scheduler overlaps the
+#pragma unroll                                         // pivot chain of column j + 1 with the trailing update of column j
     for (int j = 0; j < n; ++j) {
         const double d = bcast_lane(a[j], j);
-        if (!(d > 0.0)) return false;                  // uniform
+        ok = ok && (d > 0.0);                          // a pivot <= 0 poisons the rest with NaN; the caller retries
         const double r = rsqrt_(d);
         a[j] = (lane == j) ? d * r : a[j] * r;
         dinv = (lane == j) ? r : dinv;
@@ -587,7 +652,7 @@ __device__ __forceinline__ bool chol_reg(double (&a)[n], int lane, double& dinv)
             a[k] -= a[j] * lkj;                        // meaningful for lanes >= k; the upper triangle is never read
         }
     }
-    return true;
+    return ok;
 }
 
 // Solve L L' x = b with L row-held in a[] (from chol_reg), b = this lane's right-hand-side entry.  Lt is an LDS
@@ -595,29 +660,37 @@ __device__ __forceinline__ bool chol_reg(double (&a)[n], int lane, double& dinv)
 template <int n>
 __device__ __forceinline__ double chol_solve_reg(double (&a)[n], double dinv, double b, double* Lt, int lane) {
     constexpr int ld = n + 1;
+    const bool act = lane < n;
+    // whole rows go to the scratch, the upper-triangle garbage is never selected (one exec region, no per-entry branch)
+    if (act) {
 #pragma unroll
-    for (int k = 0; k < n; ++k) {
-        if (lane < n && k < lane) Lt[lane * ld + k] = a[k];
-        a[k] = (lane > k && lane < n) ? a[k] : 0.0;    // strictly lower part only: the updates below need no select
+        for (int k = 0; k < n; ++k) Lt[lane * ld + k] = a[k];
     }
-    // forward  L y = b
+    // rows scaled to a unit diagonal: the forward step is  y_j = b_j;  b_i -= (L_ij / L_ii) y_j
+#pragma unroll
+    for (int k = 0; k < n; ++k) a[k] = (lane > k && act) ? a[k] * dinv : 0.0;   // strictly lower part: no select below
+    b *= dinv;
 #pragma unroll
     for (int j = 0; j < n; ++j) {
-        const double yj = bcast_lane(b * dinv, j);
+        const double yj = bcast_lane(b, j);
         b -= a[j] * yj;
     }
-    b *= dinv;                                          // y_i
     SC_SYNC();
-    double c[n];                                        // c[k] = L[k][lane] for k > lane (column of L)
+    double c[n];                                        // c[k] = L[k][lane] / L[lane][lane] for k > lane (column of L)
+    const int lc = act ? lane : 0;
 #pragma unroll
-    for (int k = 0; k < n; ++k) c[k] = (k > lane && lane < n) ? Lt[k * ld + lane] : 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double v = Lt[k * ld + lc];
+        c[k] = (k > lane && act) ? v * dinv : 0.0;
+    }
     // backward  L' x = y
+    b *= dinv;
 #pragma unroll
     for (int j = n - 1; j >= 0; --j) {
-        const double xj = bcast_lane(b * dinv, j);
+        const double xj = bcast_lane(b, j);
         b -= c[j] * xj;
     }
-    return b * dinv;
+    return b;
 }
 
 // NT, KT > 0: horizon and obstacle count are compile-time constants (index arithmetic folds to shifts and
@@ -645,6 +718,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
     const int N = c.N, n = c.n, m = c.m;
     const MpcMem W = carve(sm, N, K);
     constexpr bool ROW16 = NT > 0 && NT + 2 <= 16;
+    constexpr int MS = NT > 0 ? (2 * NT + 3) / 4 : 4;                  // MFMA k-steps batched per LDS round trip
     for (int e = lane; e < 2 * (N + 2) * n; e += 64) W.dP[e] = 0.0;      // structural zeros of G stay
 
     const TIO* osrc = obs + (p.obs_shared ? 0 : (size_t)prob * K * 7);
@@ -708,12 +782,12 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             else break;
         }
         SC_PH(4);
-        phi_times_G(W, c, lane);
+        phi_times_G<MS>(W, c, lane);
         SC_SYNC();
         SC_PH(5);
         // condensed system  (sf W + J' Sigma J) dz = -r_d + J' (mu/s - Sigma r_p - lam)
         for (int col = lane; col < n; col += 64) W.rhs[col] = -W.cv[col] + (mu * W.cv[n + col] - W.cv[2 * n + col]);
-        condense_mfma(W, c, lane, sf);
+        condense_mfma<MS>(W, c, lane, sf);
         SC_SYNC();
         SC_PH(6);
         // inertia correction: M + delta I until the Cholesky succeeds
@@ -724,14 +798,14 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             double a[nn], diag;
             for (int t = 0; t < 40 && !ok; ++t) {
 #pragma unroll
-                for (int k = 0; k < nn; ++k) a[k] = (lane < nn) ? W.M[lane * nn + k] + (lane == k ? delta : 0.0) : 0.0;
+                for (int k = 0; k < nn; ++k) a[k] = W.M[(lane < nn ? lane : 0) * nn + k] + (lane == k ? delta : 0.0);   // lanes >= n: unused copies of row 0
                 ok = chol_reg<nn>(a, lane, diag);
                 if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
             }
             if (!ok) break;
             if (delta > 0.0) delta_last = delta;
             SC_PH(7);
-            const double x = chol_solve_reg<nn>(a, diag, lane < nn ? W.rhs[lane] : 0.0, W.L, lane);
+            const double x = chol_solve_reg<nn>(a, diag, W.rhs[lane < nn ? lane : 0], W.L, lane);
             if (lane < nn) W.dz[lane] = x;
             SC_SYNC();
         } else {
@@ -759,7 +833,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
         for (int k = lane; k <= N; k += 64) {
             double acc = 0.0;
 #pragma unroll
-            for (int j = 0; j < N; ++j) acc += j < k ? W.dz[2 * j] : 0.0;
+            for (int j = 0; j < N; ++j) { const double dzj = W.dz[2 * j]; acc += j < k ? dzj : 0.0; }
             W.dV[k] = c.dt * acc;
         }
         double gdz = 0.0;
