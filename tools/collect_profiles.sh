@@ -28,6 +28,8 @@ for CFG in "1048576 8 f32 f32" "1048576 8 f32 f64"; do
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT -o sqa_$TAG -- python3 $R/tools/prof_cbfqp.py $CFG 4 > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT -o sqb_$TAG -- python3 $R/tools/prof_cbfqp.py $CFG 4 > /dev/null 2>&1
 done
+# 4b. the full default bench line (sweep, closed-loop rollout and MPC legs) under the kernel trace
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench_full -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_full_under_rocprof.json 2>/dev/null
 # 5. MPC-CBF kernel
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o mpc -- python3 $R/bench.py --workload mpc_cbf --steps 5 --warmup 1 > $OUT/mpc_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o mpc_sq -- python3 $R/bench.py --workload mpc_cbf --steps 2 --warmup 1 > /dev/null 2>&1
