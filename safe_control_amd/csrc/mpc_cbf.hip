@@ -31,6 +31,11 @@ namespace sc {
 
 // -DSC_MPC_PROF: developer build that returns per-phase shader-clock totals in z_out instead of the solution
 // (tools/exp_mpc_phases.py); never defined in the shipped library.
+// An opaque copy of the lane id at the top of every phase: nothing derived from it can be hoisted out of the
+// interior-point loop or shared between phases, which is what kept ~330 VGPRs live.  With it the kernel fits 256
+// VGPRs without spills, i.e. two waves per SIMD.
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
 struct Prof {
 #ifdef SC_MPC_PROF
     double ph[20];
@@ -110,49 +115,51 @@ struct LogSum {
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 struct MpcMem {                 // LDS carve-up (doubles); NP = N + 2 predicted positions, n = 2 N, m rows
-    double *z, *zt, *dz, *rhs, *zb;               // n
+    double *z, *zt, *dz, *zb;                     // n        (the right-hand side is solved in place in dz)
     double *cv;                                   // 3 n : column pass results (r_d | J'(1/s) | J'(sig r_p + lam))
     double *TH, *V, *C, *S;                       // N+1
     double *pos, *PC, *PD, *dp;                   // 2 NP
-    double *Y;                                    // 3 * 2 NP : position-space vectors  q | A'(1/s) | A'(sig r_p + lam)
     double *dV;                                   // N+1
     double *SA, *SB, *SS;                         // NP suffix sums
     double *obs;                                  // K*7
-    double *hk;                                   // NP*K
     double *dh;                                   // NP*K*2
-    double *Hh;                                   // NP*K*3
     double *g, *sl, *lam, *st;                    // m
-    double *ds, *dlam, *is;                       // m   (vb aliases dlam: dead before dlam is written)
-    double *Phi;                                  // 2 NP * 10 : block-pentadiagonal position-space matrix, band rows
-    double *dP, *T;                               // 2 NP * n : G = d p / d z  and  T = Phi G
-    double *M, *L;                                // n*n condensed matrix; n*(n+1) transposition scratch / LDS Cholesky
+    double *ds, *dlam;                            // m   (aliases: is = ds, vb = dlam, dead before ds / dlam are written)
+    double *dP;                                   // 2 NP * n : G = d p / d z
+    // region A, max(n n, NP (26 + K)):  [Phi 2 NP * 10 | Y 3 * 2 NP | hk NP K]  then  M n*n
+    //   Phi, Y die with the T and column passes, hk with the g rows; M lives from the condensation to the Cholesky
+    double *Phi, *Y, *hk, *M;
+    // region B, 2 NP * n:  T = Phi G (until the condensation)  then  L (transposition scratch / LDS Cholesky)
+    double *T, *L;
+    double *rhs, *is;                             // aliases of dz, ds
 };
 
 __host__ __device__ inline size_t mpc_lds_doubles(int N, int K) {
     const size_t n = 2 * (size_t)N, NP = (size_t)N + 2, m = (size_t)N * K + 2 * N + 2 * n;
-    return 5 * n + 3 * n + 4 * (N + 1) + 4 * 2 * NP + 3 * 2 * NP + (N + 1) + 3 * NP + (size_t)K * 7 + NP * K * 6 +
-           7 * m + 2 * NP * 10 + 2 * (2 * NP * n) + n * n + n * (n + 1);
+    const size_t regA = n * n > NP * (26 + K) ? n * n : NP * (26 + K);
+    return 4 * n + 3 * n + 4 * (N + 1) + 4 * 2 * NP + (N + 1) + 3 * NP + (size_t)K * 7 + NP * K * 2 + 6 * m +
+           2 * NP * n + regA + 2 * NP * n;
 }
 
 __device__ inline MpcMem carve(double* b, int N, int K) {
     const int n = 2 * N, NP = N + 2, m = N * K + 2 * N + 2 * n;
     MpcMem M;
     auto take = [&](size_t c) { double* r = b; b += c; return r; };
-    M.z = take(n); M.zt = take(n); M.dz = take(n); M.rhs = take(n); M.zb = take(n);
+    M.z = take(n); M.zt = take(n); M.dz = take(n); M.zb = take(n);
     M.cv = take(3 * n);
     M.TH = take(N + 1); M.V = take(N + 1); M.C = take(N + 1); M.S = take(N + 1);
     M.pos = take(2 * NP); M.PC = take(2 * NP); M.PD = take(2 * NP); M.dp = take(2 * NP);
-    M.Y = take(6 * NP);
     M.dV = take(N + 1);
     M.SA = take(NP); M.SB = take(NP); M.SS = take(NP);
     M.obs = take((size_t)K * 7);
-    M.hk = take((size_t)NP * K);
     M.dh = take((size_t)NP * K * 2);
-    M.Hh = take((size_t)NP * K * 3);
-    M.g = take(m); M.sl = take(m); M.lam = take(m); M.st = take(m); M.ds = take(m); M.dlam = take(m); M.is = take(m);
-    M.Phi = take((size_t)2 * NP * 10);
-    M.dP = take((size_t)2 * NP * n); M.T = take((size_t)2 * NP * n);
-    M.M = take((size_t)n * n); M.L = take((size_t)n * (n + 1));
+    M.g = take(m); M.sl = take(m); M.lam = take(m); M.st = take(m); M.ds = take(m); M.dlam = take(m);
+    M.dP = take((size_t)2 * NP * n);
+    const size_t regA = (size_t)n * n > (size_t)NP * (26 + K) ? (size_t)n * n : (size_t)NP * (26 + K);
+    double* A = take(regA);
+    M.Phi = A; M.Y = A + (size_t)2 * NP * 10; M.hk = M.Y + 6 * NP; M.M = A;
+    M.T = take((size_t)2 * NP * n); M.L = M.T;
+    M.rhs = M.dz; M.is = M.ds;
     return M;
 }
 
@@ -229,6 +236,7 @@ __device__ __forceinline__ double suffix_sum(double v, int lane) {
 // sensitivities PC_k = sum_{i<k} (cos, sin), PD_k = sum_{i<k} v_i (-sin, cos) prefix sums of the stage terms.
 template <bool ROW16>
 __device__ inline double eval_values(const double* z, const MpcMem& W, const MpcConst& c, int lane, bool derivs, Prof& pf, int slot) {
+    lane = opaque(lane);
     const int N = c.N, K = c.K, n = c.n, NP = N + 2;
     double ak = 0.0, wk = 0.0;
     if (lane < N) { ak = z[2 * lane]; wk = z[2 * lane + 1]; }
@@ -283,7 +291,6 @@ __device__ inline double eval_values(const double* z, const MpcMem& W, const Mpc
         W.hk[e] = h;
         if (derivs) {
             W.dh[2 * e] = d0; W.dh[2 * e + 1] = d1;
-            W.Hh[3 * e] = hxx; W.Hh[3 * e + 1] = hxy; W.Hh[3 * e + 2] = hyy;
         }
     }
     SC_SYNC();
@@ -321,6 +328,7 @@ __device__ inline double eval_values(const double* z, const MpcMem& W, const Mpc
 
 // rows: sigma = lam / s, 1/s, sigma r_p + lam; returns the lane-partial residual norms
 __device__ __forceinline__ void row_pass(const MpcMem& W, const MpcConst& c, int lane, double& e_p, double& e_c0, double& lmax) {
+    lane = opaque(lane);
     double* is = W.is;
     double* vb = W.dlam;
     e_p = 0.0; e_c0 = 0.0; lmax = 0.0;
@@ -340,6 +348,7 @@ __device__ __forceinline__ void row_pass(const MpcMem& W, const MpcConst& c, int
 // problem (objective times sf), so everything here is already scaled.
 template <int KT, bool ROW16>
 __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, int lane, double sf) {
+    lane = opaque(lane);
     // ROW16: the obstacle loop of stage k is split over lanes k, k + 16, k + 32, k + 48 (jo = part, part + 4, ..) and
     // the partial sums are added across the four rows; every row then holds the totals, row 0 stores them.
     const int N = c.N, K = c.K, NP = N + 2;
@@ -355,6 +364,7 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
         const int r0 = (t0 ? k : 0) * K, r1 = (t1 ? k - 1 : 0) * K, r2 = (t2 ? k - 2 : 0) * K;
         const double w0 = t0 ? c.w0 : 0.0, w1 = t1 ? c.w1 : 0.0, w2 = t2 ? c.w2 : 0.0;
         const int k1 = k + 1 < NP ? k + 1 : k, k2 = k + 2 < NP ? k + 2 : k;
+        const double pk0 = W.pos[2 * k], pk1 = W.pos[2 * k + 1];
         constexpr int UNR = KT > 0 ? (KT + PSTEP - 1) / PSTEP : 4;
 #pragma unroll UNR
         for (int jo = part; jo < K; jo += PSTEP) {
@@ -366,7 +376,11 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
             const int e = k * K + jo, e1 = k1 * K + jo, e2 = k2 * K + jo;
             const double d0 = W.dh[2 * e], d1 = W.dh[2 * e + 1];
             const double a0 = W.dh[2 * e1], a1 = W.dh[2 * e1 + 1], g0 = W.dh[2 * e2], g1 = W.dh[2 * e2 + 1];
-            const double hxx = W.Hh[3 * e], hxy = W.Hh[3 * e + 1], hyy = W.Hh[3 * e + 2];
+            double hxx = 2.0, hxy = 0.0, hyy = 2.0;                  // d2h/dp2 of a circle; superellipsoids recompute theirs
+            if (W.obs[7 * jo + 6] >= 0.5) {
+                double h_, g0_, g1_;
+                barrier_at(pk0, pk1, W.obs + 7 * jo, c, true, h_, g0_, g1_, hxx, hxy, hyy);
+            }
             const double ml = w0 * l0 + w1 * l1 + w2 * l2, ma = w0 * i0 + w1 * i1 + w2 * i2, mb = w0 * b0 + w1 * b1 + w2 * b2;
             const double c0 = w0 * w0 * s0 + w1 * w1 * s1 + w2 * w2 * s2;
             const double c1 = w1 * c.w2 * s1 + w0 * c.w1 * s0;      // rows kappa = k-1 (t = 1, 2) and kappa = k (t = 0, 1)
@@ -431,6 +445,7 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
 // Every inner loop has a trip count that does not depend on the lane (structural zeros of G, masks on the stage
 // sums), so with compile-time N the loads of a lane are issued back to back instead of one round trip per term.
 __device__ __forceinline__ double col_pass(const MpcMem& W, const MpcConst& c, int lane, double sf) {
+    lane = opaque(lane);
     const int N = c.N, n = c.n, NP = N + 2;
     double e_d = 0.0;
     for (int idx = lane; idx < 3 * n; idx += 64) {
@@ -491,6 +506,7 @@ __device__ __forceinline__ d4_t mfma_ksteps(int lo, int hi, LoadA load_a, LoadB 
 // T' = Phi' G'   (9 MFMAs for N = 10)
 template <int S>
 __device__ __forceinline__ void phi_times_G(const MpcMem& W, const MpcConst& c, int lane) {
+    lane = opaque(lane);
     const int n = c.n, nt = (n + 15) >> 4, q = lane >> 4, l15 = lane & 15;
     for (int ti = 0; ti < nt; ++ti) {
         const int i = 16 * ti + l15, R = i + 4, kR = R >> 1;
@@ -545,6 +561,7 @@ __device__ __forceinline__ double condensed_base(const MpcMem& W, const MpcConst
 // M = G'' T' + structured terms   (7 MFMAs for N = 10; lower tiles, mirrored)
 template <int S>
 __device__ __forceinline__ void condense_mfma(const MpcMem& W, const MpcConst& c, int lane, double sf) {
+    lane = opaque(lane);
     const int n = c.n, nt = (n + 15) >> 4, q = lane >> 4, l15 = lane & 15;
     for (int ti = 0; ti < nt; ++ti) {
         for (int tj = 0; tj <= ti; ++tj) {
@@ -696,7 +713,7 @@ __device__ __forceinline__ double chol_solve_reg(double (&a)[n], double dinv, do
 // NT, KT > 0: horizon and obstacle count are compile-time constants (index arithmetic folds to shifts and
 // multiplies); NT == 0: run-time sizes.
 template <typename TIO, int NT, int KT>
-__global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, const long long B, const int K_rt,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mpccbf_kernel(const sc_mpccbf_params p, const long long B, const int K_rt,
                                                     const TIO* __restrict__ X, const TIO* __restrict__ u_prev,
                                                     const TIO* __restrict__ goal, const TIO* __restrict__ obs,
                                                     TIO* __restrict__ u_out, int* __restrict__ status_out,
@@ -818,9 +835,7 @@ __global__ __launch_bounds__(64) void mpccbf_kernel(const sc_mpccbf_params p, co
             if (!ok) break;
             if (delta > 0.0) delta_last = delta;
             SC_PH(7);
-            for (int i = lane; i < n; i += 64) W.dz[i] = W.rhs[i];
-            SC_SYNC();
-            chol_solve(W.L, W.dz, n, lane);
+            chol_solve(W.L, W.dz, n, lane);                  // rhs is dz: solved in place
         }
         SC_PH(8);
         // position and speed displacements  dp = G dz,  dV_k = dt sum_{j < k} dz_{2j}
