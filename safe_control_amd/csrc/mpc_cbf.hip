@@ -116,29 +116,32 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 
 struct MpcMem {                 // LDS carve-up (doubles); NP = N + 2 predicted positions, n = 2 N, m rows
     double *z, *zt, *dz, *zb;                     // n        (the right-hand side is solved in place in dz)
-    double *cv;                                   // 3 n : column pass results (r_d | J'(1/s) | J'(sig r_p + lam))
+    // cv: 3 n column-pass results (r_d | J'(1/s) | J'(sig r_p + lam)); the last two die with the right-hand side and
+    // their space then holds dp (2 NP) and dV (N + 1)
+    double *cv, *dp, *dV;
     double *TH, *V, *C, *S;                       // N+1
-    double *pos, *PC, *PD, *dp;                   // 2 NP
-    double *dV;                                   // N+1
+    double *pos;                                  // 2 NP
     double *SA, *SB, *SS;                         // NP suffix sums
     double *obs;                                  // K*7
     double *dh;                                   // NP*K*2
-    double *g, *sl, *lam, *st;                    // m
+    double *g, *sl, *lam;                         // m
     double *ds, *dlam;                            // m   (aliases: is = ds, vb = dlam, dead before ds / dlam are written)
     double *dP;                                   // 2 NP * n : G = d p / d z
     // region A, max(n n, NP (26 + K)):  [Phi 2 NP * 10 | Y 3 * 2 NP | hk NP K]  then  M n*n
     //   Phi, Y die with the T and column passes, hk with the g rows; M lives from the condensation to the Cholesky
     double *Phi, *Y, *hk, *M;
-    // region B, 2 NP * n:  T = Phi G (until the condensation)  then  L (transposition scratch / LDS Cholesky)
-    double *T, *L;
+    // region B, 2 NP * n:  PC, PD (2 NP each, inside eval_values only), T = Phi G (until the condensation), then
+    //   L (transposition scratch / LDS Cholesky)
+    double *PC, *PD, *T, *L;
     double *rhs, *is;                             // aliases of dz, ds
 };
 
 __host__ __device__ inline size_t mpc_lds_doubles(int N, int K) {
     const size_t n = 2 * (size_t)N, NP = (size_t)N + 2, m = (size_t)N * K + 2 * N + 2 * n;
     const size_t regA = n * n > NP * (26 + K) ? n * n : NP * (26 + K);
-    return 4 * n + 3 * n + 4 * (N + 1) + 4 * 2 * NP + (N + 1) + 3 * NP + (size_t)K * 7 + NP * K * 2 + 6 * m +
-           2 * NP * n + regA + 2 * NP * n;
+    const size_t cvt = 2 * n > 3 * (size_t)N + 5 ? 2 * n : 3 * (size_t)N + 5;
+    return 4 * n + n + cvt + 4 * (N + 1) + 2 * NP + 3 * NP + (size_t)K * 7 + NP * K * 2 + 5 * m + 2 * NP * n + regA +
+           2 * NP * n;
 }
 
 __device__ inline MpcMem carve(double* b, int N, int K) {
@@ -146,19 +149,19 @@ __device__ inline MpcMem carve(double* b, int N, int K) {
     MpcMem M;
     auto take = [&](size_t c) { double* r = b; b += c; return r; };
     M.z = take(n); M.zt = take(n); M.dz = take(n); M.zb = take(n);
-    M.cv = take(3 * n);
+    const size_t cvt = 2 * n > 3 * N + 5 ? 2 * n : 3 * N + 5;
+    M.cv = take(n + cvt); M.dp = M.cv + n; M.dV = M.dp + 2 * NP;
     M.TH = take(N + 1); M.V = take(N + 1); M.C = take(N + 1); M.S = take(N + 1);
-    M.pos = take(2 * NP); M.PC = take(2 * NP); M.PD = take(2 * NP); M.dp = take(2 * NP);
-    M.dV = take(N + 1);
+    M.pos = take(2 * NP);
     M.SA = take(NP); M.SB = take(NP); M.SS = take(NP);
     M.obs = take((size_t)K * 7);
     M.dh = take((size_t)NP * K * 2);
-    M.g = take(m); M.sl = take(m); M.lam = take(m); M.st = take(m); M.ds = take(m); M.dlam = take(m);
+    M.g = take(m); M.sl = take(m); M.lam = take(m); M.ds = take(m); M.dlam = take(m);
     M.dP = take((size_t)2 * NP * n);
     const size_t regA = (size_t)n * n > (size_t)NP * (26 + K) ? (size_t)n * n : (size_t)NP * (26 + K);
     double* A = take(regA);
     M.Phi = A; M.Y = A + (size_t)2 * NP * 10; M.hk = M.Y + 6 * NP; M.M = A;
-    M.T = take((size_t)2 * NP * n); M.L = M.T;
+    M.T = take((size_t)2 * NP * n); M.L = M.T; M.PC = M.T; M.PD = M.T + 2 * NP;
     M.rhs = M.dz; M.is = M.ds;
     return M;
 }
@@ -335,7 +338,7 @@ __device__ __forceinline__ void row_pass(const MpcMem& W, const MpcConst& c, int
     for (int i = lane; i < c.m; i += 64) {
         const double s = W.sl[i], l = W.lam[i], rp = W.g[i] - s;
         const double inv = rcp_(s), sig = l * inv;
-        W.st[i] = sig; is[i] = inv; vb[i] = sig * rp + l;
+        is[i] = inv; vb[i] = sig * rp + l;
         e_p = fmax(e_p, fabs(rp));
         e_c0 = fmax(e_c0, fabs(s * l));
         lmax = fmax(lmax, l);
@@ -371,8 +374,7 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
             const double l0 = W.lam[r0 + jo], l1 = W.lam[r1 + jo], l2 = W.lam[r2 + jo];
             const double i0 = is[r0 + jo], i1 = is[r1 + jo], i2 = is[r2 + jo];
             const double b0 = vb[r0 + jo], b1 = vb[r1 + jo], b2 = vb[r2 + jo];
-            const double s0 = W.st[r0 + jo], s1 = W.st[r1 + jo];
-            const double s2 = W.st[r2 + jo];
+            const double s0 = l0 * i0, s1 = l1 * i1, s2 = l2 * i2;       // Sigma = lam / s
             const int e = k * K + jo, e1 = k1 * K + jo, e2 = k2 * K + jo;
             const double d0 = W.dh[2 * e], d1 = W.dh[2 * e + 1];
             const double a0 = W.dh[2 * e1], a1 = W.dh[2 * e1 + 1], g0 = W.dh[2 * e2], g1 = W.dh[2 * e2 + 1];
@@ -435,7 +437,10 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
         const double ci = W.C[k], si = W.S[k];
         Ai = qs0 * (-si) + qs1 * ci;
         Bi = W.V[k] * (qs0 * ci + qs1 * si);
-        if (k >= 1) sk = W.st[c.mc + 2 * (k - 1)] + W.st[c.mc + 2 * (k - 1) + 1];
+        if (k >= 1) {
+            const int r = c.mc + 2 * (k - 1);
+            sk = W.lam[r] * is[r] + W.lam[r + 1] * is[r + 1];
+        }
     }
     const double sa = suffix_sum<ROW16>(Ai, lane), sb = suffix_sum<ROW16>(Bi, lane), ss = suffix_sum<ROW16>(sk, lane);
     if (k < NP && part == 0) { W.SA[k] = sa; W.SB[k] = sb; W.SS[k] = ss; }
@@ -553,7 +558,8 @@ __device__ __forceinline__ double condensed_base(const MpcMem& W, const MpcConst
     const double vww = sf * 2.0 * c.Qth * dt2 * (double)(N - jm) - dt3 * sb;
     double acc = (ra && ca) ? vaa : ((!ra && !ca) ? vww : dt3 * sa);
     const double Rc = (r & 1) ? c.R1 : c.R0;                                               // input-rate penalty 2 D' R D
-    const double dg = sf * 2.0 * Rc * ((r + 2 < n) ? 2.0 : 1.0) + W.st[c.mc + 2 * N + r] + W.st[c.mc + 2 * N + n + r];
+    const int bx = c.mc + 2 * N + r;
+    const double dg = sf * 2.0 * Rc * ((r + 2 < n) ? 2.0 : 1.0) + W.lam[bx] * W.is[bx] + W.lam[bx + n] * W.is[bx + n];
     acc += (r == cc) ? dg : ((r == cc + 2 || cc == r + 2) ? -sf * 2.0 * Rc : 0.0);
     return acc;
 }
@@ -875,7 +881,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 jd = r < n ? -W.dz[r] : W.dz[r - n];
             }
             const double ds = jd + rp;
-            const double dl = -W.st[i] * ds - (lam - mu * isv);
+            const double dl = -(lam * isv) * ds - (lam - mu * isv);
             gdz += lam * jd;                                              // sf grad f . dz = r_d . dz + lam . (J dz)
             const double rs = ds * isv, rl = dl * rcp_(lam);              // fraction to the boundary: most negative ratios
             rs_min = fmin(rs_min, rs); rl_min = fmin(rl_min, rl);
