@@ -368,8 +368,8 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
         const double w0 = t0 ? c.w0 : 0.0, w1 = t1 ? c.w1 : 0.0, w2 = t2 ? c.w2 : 0.0;
         const int k1 = k + 1 < NP ? k + 1 : k, k2 = k + 2 < NP ? k + 2 : k;
         const double pk0 = W.pos[2 * k], pk1 = W.pos[2 * k + 1];
-        constexpr int UNR = KT > 0 ? (KT + PSTEP - 1) / PSTEP : 4;
-#pragma unroll UNR
+        // not unrolled: both iterations' 24 loads in flight at once cost 16 VGPR spills under the 256-register cap
+#pragma unroll 1
         for (int jo = part; jo < K; jo += PSTEP) {
             const double l0 = W.lam[r0 + jo], l1 = W.lam[r1 + jo], l2 = W.lam[r2 + jo];
             const double i0 = is[r0 + jo], i1 = is[r1 + jo], i2 = is[r2 + jo];

@@ -3,6 +3,10 @@ import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 import safe_control_amd as sca
+from safe_control_amd import _lib as _L
+import os
+if os.environ.get('SC_EXP_LIB'):            # experiment only: time a variant build of the library
+    _L.LIB_PATH = os.environ['SC_EXP_LIB']
 from safe_control_amd import workloads as W
 
 dev = torch.device("cuda:0")
