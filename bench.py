@@ -81,7 +81,21 @@ def cpu_baseline(X, u_ref, obs, seconds):
             "all_cores_threads": out["all_cores"][1]}
 
 
-def mpc_leg(dev, B, K, N, steps, warmup, seed=0):
+def mpc_cpu_baseline(Xn, goal, on, N, seconds):
+    """oracle/mpc_cbf.py (numpy float64, the same interior-point method) on one host core: bounded sample of the
+    same batch, starting from its first problem."""
+    import numpy as np
+    from oracle import mpc_cbf as O
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds and n < Xn.shape[0]:
+        O.solve(Xn[n], np.zeros(2), goal[n], on[n], params={"N": N})
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} problems of the same batch, oracle/mpc_cbf.py (numpy float64 interior point), 1 thread"}
+
+
+def mpc_leg(dev, B, K, N, steps, warmup, seed=0, cpu_seconds=0.0):
     """BASELINE configs[2]: B DynamicUnicycle2D agents, MPC-CBF horizon N, K obstacles, u_prev = 0."""
     import torch
     import safe_control_amd as sca
@@ -108,7 +122,8 @@ def mpc_leg(dev, B, K, N, steps, warmup, seed=0):
     ms = e0.elapsed_time(e1) / steps
     st, it = out[1], out[2]
     nbytes = ((4 + 2 + 2 + 7 * K) * 4 + 2 * 4 + 4 + 4) * B
-    return {"workload": f"{B}-agent batch DynamicUnicycle2D MPC-CBF, horizon N={N}, {K} obstacles (BASELINE configs[2])",
+    extra = {"cpu_baseline": mpc_cpu_baseline(Xn, goal, on, N, cpu_seconds)} if cpu_seconds > 0 else {}
+    return {**extra, "workload": f"{B}-agent batch DynamicUnicycle2D MPC-CBF, horizon N={N}, {K} obstacles (BASELINE configs[2])",
             "value": B * steps / wall, "unit": "solves/s", "steps": steps, "kernel_ms": ms,
             "dtype": "f64", "storage": "f32",
             "optimal_fraction": float((st == 0).double().mean().item()),
@@ -187,7 +202,8 @@ def main():
 
     B, K = a.agents, a.obstacles
     if a.workload == "mpc_cbf":
-        r = mpc_leg(dev, B, K, a.horizon, a.steps, a.warmup, seed=rank)
+        r = mpc_leg(dev, B, K, a.horizon, a.steps, a.warmup, seed=rank,
+                    cpu_seconds=(6.0 if (ws == 1 and not a.no_cpu_baseline) else 0.0))
         elapsed = sharding.max_over_ranks(B * a.steps / r["value"], device=dev if backend == "nccl" else None)
         if rank == 0:
             print(json.dumps({"metric": "QP solves/sec (batched agents)", "value": B * ws * a.steps / elapsed,
@@ -200,7 +216,7 @@ def main():
                                            "unit": "GB/s", "frac": r["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
                                            "kernel": "mpccbf_kernel", "kernel_us": 1e3 * r["kernel_ms"],
                                            "note": "ALU/LDS-bound interior-point iterations; HBM fraction reported for completeness"},
-                              "mpc": r}), flush=True)
+                              "cpu_baseline": r.get("cpu_baseline"), "mpc": r}), flush=True)
         if ws > 1:
             dist.destroy_process_group()
         return
@@ -289,7 +305,8 @@ def main():
         if ws == 1 and not a.no_sweep:
             res["sweep"] = sweep(ctl, dev, td, es, K)
         if ws == 1 and not a.no_mpc:
-            res["mpc_cbf"] = mpc_leg(dev, 4096, 8, 10, steps=3, warmup=1)
+            res["mpc_cbf"] = mpc_leg(dev, 4096, 8, 10, steps=3, warmup=1,
+                                     cpu_seconds=0.0 if a.no_cpu_baseline else 6.0)
             res["closed_loop"] = closed_loop_leg(dev)
         if ws == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(X.double().cpu().numpy(), ur.double().cpu().numpy(),
