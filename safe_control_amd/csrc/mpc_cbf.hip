@@ -719,12 +719,11 @@ __device__ __forceinline__ double chol_solve_reg(double (&a)[n], double dinv, do
 // NT, KT > 0: horizon and obstacle count are compile-time constants (index arithmetic folds to shifts and
 // multiplies); NT == 0: run-time sizes.
 template <typename TIO, int NT, int KT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void mpccbf_kernel(const sc_mpccbf_params p, const long long B, const int K_rt,
-                                                    const TIO* __restrict__ X, const TIO* __restrict__ u_prev,
-                                                    const TIO* __restrict__ goal, const TIO* __restrict__ obs,
-                                                    TIO* __restrict__ u_out, int* __restrict__ status_out,
-                                                    int* __restrict__ iters_out, TIO* __restrict__ z_out) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+__device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& p, const long long B, const int K_rt,
+                                            const TIO* __restrict__ X, const TIO* __restrict__ u_prev,
+                                            const TIO* __restrict__ goal, const TIO* __restrict__ obs,
+                                            TIO* __restrict__ u_out, int* __restrict__ status_out,
+                                            int* __restrict__ iters_out, TIO* __restrict__ z_out) {
     const int lane = threadIdx.x;
     const long long prob = blockIdx.x;
     if (prob >= B) return;
@@ -959,6 +958,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
 }
 
+// Compile-time horizon: capped at 256 VGPRs (two waves per SIMD; fits without spills).  Run-time sizes: no cap --
+// the run-time index arithmetic needs more registers and would spill heavily under it.
+template <typename TIO, int NT, int KT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void mpccbf_kernel(const sc_mpccbf_params p, const long long B, const int K_rt, const TIO* __restrict__ X,
+                   const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
+                   TIO* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    mpccbf_body<TIO, NT, KT>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
+}
+template <typename TIO>
+__global__ __launch_bounds__(64)
+void mpccbf_kernel_rt(const sc_mpccbf_params p, const long long B, const int K_rt, const TIO* __restrict__ X,
+                      const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
+                      TIO* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    mpccbf_body<TIO, 0, 0>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
+}
+
 size_t mpccbf_lds_bytes(int N, int K) { return mpc_lds_doubles(N, K) * sizeof(double); }
 
 template <typename TIO, int NT, int KT>
@@ -966,14 +984,17 @@ static hipError_t mpc_launch_one(const sc_mpccbf_params& p, long long B, int K, 
                                  const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                                  hipStream_t stream) {
     const size_t lds = mpc_lds_doubles(p.horizon, K) * sizeof(double);
-    auto kern = mpccbf_kernel<TIO, NT, KT>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, B, K, (const TIO*)X, (const TIO*)u_prev,
-                       (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status, iters, (TIO*)z_out);
-    return hipGetLastError();
+    auto launch = [&](auto kern) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, B, K, (const TIO*)X, (const TIO*)u_prev,
+                           (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status, iters, (TIO*)z_out);
+        return hipGetLastError();
+    };
+    if constexpr (NT > 0) return launch(mpccbf_kernel<TIO, NT, KT>);
+    else return launch(mpccbf_kernel_rt<TIO>);
 }
 
 template <typename TIO>
@@ -982,6 +1003,8 @@ static hipError_t mpc_launch_t(const sc_mpccbf_params& p, long long B, int K, co
                                hipStream_t stream) {
     if (p.horizon == 10 && K == 8)            // BASELINE config 3
         return mpc_launch_one<TIO, 10, 8>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+    if (p.horizon == 10)                      // the reference's default horizon (mpc_cbf.py:15) with any obstacle count
+        return mpc_launch_one<TIO, 10, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
     return mpc_launch_one<TIO, 0, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
 }
 
