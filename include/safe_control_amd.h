@@ -171,6 +171,33 @@ int sc_mpccbf_solve_batch_host(const sc_mpccbf_params* params, int64_t B, int32_
                                void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out,
                                int device);
 
+/* ---- optimal-decay MPC-CBF ---------------------------------------
+ * OptimalDecayMPCCBF (position_control/optimal_decay_mpc_cbf.py:15-330) for DynamicUnicycle2D: the MPC-CBF NLP with
+ * two decay variables per stage (omega1_k, omega2_k, model inputs at :123-124) that scale the DT-CBF gains,
+ *   dd_h + (alpha1 omega1 + alpha2 omega2) d_h + alpha1 alpha2 omega1 omega2 h >= 0                  (:291-297)
+ * and are pulled to their references by p_sb (omega - omega_ref)^2 (:181-184); the input term is R u^2 (:178-179,
+ * an expression r-term, not the delta-u penalty of MPCCBF).  `mpc.alpha1/alpha2` carry the optimal-decay gains
+ * (0.01 for DU, :59-60); `mpc.R` the weights of u^2.  The reference copy is stale (5-wide obstacle rows, 5 fixed
+ * slots): here obstacles are the K 7-wide rows of sc_mpccbf_solve_batch.  No runnable reference exists; parity is
+ * against oracle/od_mpc_cbf.py.
+ * Outputs as sc_mpccbf_solve_batch plus rho_out [B, 2*horizon] or NULL: (omega1_k, omega2_k) for every stage.
+ */
+typedef struct sc_odmpccbf_params {
+    sc_mpccbf_params mpc;
+    double omega_ref[2];     /* cbf_param['omega1'], ['omega2'] = 1 (:88,90)   */
+    double p_sb[2];          /* cbf_param['p_sb1'], ['p_sb2'] = 10 (:89,91)    */
+} sc_odmpccbf_params;
+
+int sc_odmpccbf_solve_batch(const sc_odmpccbf_params* params, int64_t B, int32_t K,
+                            const void* X, const void* u_prev, const void* goal, const void* obs,
+                            void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out,
+                            void* stream);
+
+int sc_odmpccbf_solve_batch_host(const sc_odmpccbf_params* params, int64_t B, int32_t K,
+                                 const void* X, const void* u_prev, const void* goal, const void* obs,
+                                 void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out,
+                                 int device);
+
 /* ---- optimal-decay CBF-QP --------------------------------------
  * OptimalDecayCBFQP (position_control/optimal_decay_cbf_qp.py:13-158): decision variables u (2) and the
  * decay multipliers omega1, omega2 with penalties p_sb (omega - omega_ref)^2 (:72-76); ONE obstacle row

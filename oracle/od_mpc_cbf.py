@@ -163,13 +163,22 @@ def evaluate(x0, zz, goal, obs, P, lam=None, level=2):
     return out
 
 
-def shift_block(D):
-    """Make a symmetric 2x2 block positive definite: D + max(0, eps - lambda_min) I, eps = 1e-8 max(1, |trace|)."""
+def block_eig(D):
+    """Eigen form of a symmetric 2x2 block, shifted to positive definite: (vs, vw, ls, lw) with
+    D + sh I = ls vs vs' + lw vw vw', sh = max(0, eps - lambda_min), eps = 1e-8 max(1, |trace|).
+    The decay blocks have one huge (sum sig a a') and one small (penalty) eigenvalue; applying D^-1 through
+    this form keeps the huge direction accurate, which an explicit inverse does not."""
     a, b, c = D[0, 0], D[0, 1], D[1, 1]
-    lmin = 0.5 * (a + c) - math.sqrt(0.25 * (a - c) ** 2 + b * b)
-    eps = 1e-8 * max(1.0, abs(a) + abs(c))
-    sh = max(0.0, eps - lmin)
-    return D + sh * np.eye(2), sh
+    tr, df = a + c, a - c
+    rad = math.sqrt(df * df + 4.0 * b * b)
+    ls = 0.5 * (tr + rad)
+    lw = (a * c - b * b) / ls
+    vx, vy = (df + rad, 2.0 * b) if df >= 0.0 else (2.0 * b, rad - df)
+    vn = math.hypot(vx, vy)
+    vs = np.array([vx / vn, vy / vn]) if vn > 0 else np.array([1.0, 0.0])
+    vw = np.array([-vs[1], vs[0]])
+    sh = max(0.0, 1e-8 * max(1.0, abs(a) + abs(c)) - lw)
+    return vs, vw, ls + sh, lw + sh
 
 
 def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra="schur"):
@@ -194,6 +203,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
     tau, nu, delta_last = 0.995, 10.0, 0.0
     err = np.inf
     e_best, zz_best = np.inf, zz.copy()
+    trace = []
     for it in range(1, P["max_iter"] + 1):
         ev = evaluate(x0, zz, goal, obs, P, lam / sf, level=2)
         f, grad, W, g, J = sf * ev["f"], sf * ev["grad"], sf * ev["W"], ev["g"], ev["J"]
@@ -202,6 +212,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
         e_opt = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam)))
         e_mu = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam - mu)))
         err = e_opt
+        trace.append((float(np.max(np.abs(r_d))), float(np.max(np.abs(r_p))), float(np.max(np.abs(s * lam))), mu))
         if e_opt < e_best:
             e_best, zz_best = e_opt, zz.copy()
         if e_opt <= P["tol"]:
@@ -217,9 +228,18 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
         Mb = W + J.T @ (sig[:, None] * J)
         rhs = -r_d + J.T @ (mu / s - sig * r_p - lam)
         Muu, Mur, Mrr = Mb[:n, :n], Mb[:n, n:], Mb[n:, n:].copy()
-        for k in range(N):                                                  # decay blocks: shift to positive definite
-            blk, _ = shift_block(Mrr[2 * k:2 * k + 2, 2 * k:2 * k + 2])
-            Mrr[2 * k:2 * k + 2, 2 * k:2 * k + 2] = blk
+        eig = []
+        for k in range(N):                                                  # decay blocks: eigen form, shifted to PD
+            vs, vw, ls, lw = block_eig(Mrr[2 * k:2 * k + 2, 2 * k:2 * k + 2])
+            eig.append((vs, vw, ls, lw))
+            Mrr[2 * k:2 * k + 2, 2 * k:2 * k + 2] = ls * np.outer(vs, vs) + lw * np.outer(vw, vw)
+
+        def apply_dinv(y):                                                  # D^-1 y, block by block in eigen form
+            out = np.zeros_like(y)
+            for k, (vs, vw, ls, lw) in enumerate(eig):
+                yk = y[2 * k:2 * k + 2]
+                out[2 * k:2 * k + 2] = vs * ((vs @ yk) / ls) + vw * ((vw @ yk) / lw)
+            return out
         delta, dzz = 0.0, None
         for _try in range(40):
             try:
@@ -228,11 +248,13 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
                     Lf = np.linalg.cholesky(full)
                     dzz = np.linalg.solve(Lf.T, np.linalg.solve(Lf, rhs))
                 else:
-                    Dinv = np.linalg.inv(Mrr)                               # block diagonal
-                    S = Muu - Mur @ Dinv @ Mur.T + delta * np.eye(n)
+                    S = Muu + delta * np.eye(n)
+                    for k, (vs, vw, ls, lw) in enumerate(eig):
+                        cs, cw = Mur[:, 2 * k:2 * k + 2] @ vs, Mur[:, 2 * k:2 * k + 2] @ vw
+                        S = S - np.outer(cs, cs) / ls - np.outer(cw, cw) / lw
                     L = np.linalg.cholesky(S)
-                    du = np.linalg.solve(L.T, np.linalg.solve(L, rhs[:n] - Mur @ (Dinv @ rhs[n:])))
-                    dr = Dinv @ (rhs[n:] - Mur.T @ du)
+                    du = np.linalg.solve(L.T, np.linalg.solve(L, rhs[:n] - Mur @ apply_dinv(rhs[n:])))
+                    dr = apply_dinv(rhs[n:] - Mur.T @ du)
                     dzz = np.concatenate([du, dr])
                 break
             except np.linalg.LinAlgError:
@@ -274,5 +296,5 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
             status = STATUS_INACCURATE
     u0, rho0 = zz[0:2].copy(), zz[n:n + 2].copy()
     if return_info:
-        return u0, rho0, status, it, dict(zz=zz, X=ev["X"], f=ev["f"], g=ev["g"], lam=lam / sf, s=s, err=err, mu=mu, scale=sf)
+        return u0, rho0, status, it, dict(zz=zz, X=ev["X"], f=ev["f"], g=ev["g"], lam=lam / sf, s=s, err=err, mu=mu, scale=sf, trace=trace)
     return u0, rho0, status, it

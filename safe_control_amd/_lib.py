@@ -63,6 +63,11 @@ class OdCbfQpParams(C.Structure):
     _fields_ = [("qp", CbfQpParams), ("omega_ref", C.c_double * 2), ("p_sb", C.c_double * 2)]
 
 
+class OdMpcCbfParams(C.Structure):
+    """Mirror of ``sc_odmpccbf_params``."""
+    _fields_ = [("mpc", MpcCbfParams), ("omega_ref", C.c_double * 2), ("p_sb", C.c_double * 2)]
+
+
 SM_IDLE, SM_TRACK, SM_STOP, SM_ROTATE = 0, 1, 2, 3
 SM_NAMES = {0: "idle", 1: "track", 2: "stop", 3: "rotate"}
 TRACKING_MAX_CONSTRAINTS = 16
@@ -93,6 +98,8 @@ SYMBOLS = {
     "sc_mpccbf_solve_batch": (C.c_int, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "sc_odmpccbf_solve_batch": (C.c_int, [C.POINTER(OdMpcCbfParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
+    "sc_odmpccbf_solve_batch_host": (C.c_int, [C.POINTER(OdMpcCbfParams), C.c_int64, C.c_int32] + [C.c_void_p] * 9 + [C.c_int]),
     "sc_odcbfqp_solve_batch": (C.c_int, [C.POINTER(OdCbfQpParams), C.c_int64] + [C.c_void_p] * 9),
     "sc_odcbfqp_solve_batch_host": (C.c_int, [C.POINTER(OdCbfQpParams), C.c_int64] + [C.c_void_p] * 8 + [C.c_int]),
     "sc_neighbor_obstacles_batch": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double,

@@ -15,6 +15,10 @@ hipError_t mpccbf_launch(const sc_mpccbf_params& p, long long B, int K, const vo
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                          hipStream_t stream);
 size_t mpccbf_lds_bytes(int N, int K);
+size_t odmpccbf_lds_bytes(int N, int K);
+hipError_t odmpccbf_launch(const sc_odmpccbf_params& q, long long B, int K, const void* X, const void* u_prev,
+                           const void* goal, const void* obs, void* u_out, void* rho_out, int* status, int* iters,
+                           void* z_out, hipStream_t stream);
 hipError_t neighbors_launch(int io_dtype, long long B_all, long long first, long long B_local, int K, double r, const void* X,
                             void* out, hipStream_t stream);
 hipError_t odcbfqp_launch(const sc_odcbfqp_params& p, long long B, const void* X, const void* u_ref, const void* obs,
@@ -201,6 +205,71 @@ int sc_mpccbf_solve_batch_host(const sc_mpccbf_params* params, int64_t B, int32_
     } while (0);
     rc = SC_OK;
     if (e != hipSuccess) rc = sc::fail_hip(e, "sc_mpccbf_solve_batch_host");
+    (void)hipFree(d);
+    return rc;
+}
+
+static int check_odmpccbf(const sc_odmpccbf_params* q, int64_t B, int32_t K, const void* X, const void* u_prev,
+                          const void* goal, const void* obs, const void* u_out, const void* status_out) {
+    if (!q) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    int rc = sc::check_mpccbf(&q->mpc, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (sc::odmpccbf_lds_bytes(q->mpc.horizon, K) > 160 * 1024)
+        return sc::fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
+    if (!(q->p_sb[0] > 0) || !(q->p_sb[1] > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "p_sb must be > 0");
+    return SC_OK;
+}
+
+int sc_odmpccbf_solve_batch(const sc_odmpccbf_params* params, int64_t B, int32_t K, const void* X, const void* u_prev,
+                            const void* goal, const void* obs, void* u_out, void* rho_out, int32_t* status_out,
+                            int32_t* iters_out, void* z_out, void* stream) {
+    int rc = check_odmpccbf(params, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::odmpccbf_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, rho_out, status_out,
+                                       iters_out, z_out, (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "odmpccbf kernel launch");
+    return SC_OK;
+}
+
+int sc_odmpccbf_solve_batch_host(const sc_odmpccbf_params* params, int64_t B, int32_t K, const void* X,
+                                 const void* u_prev, const void* goal, const void* obs, void* u_out, void* rho_out,
+                                 int32_t* status_out, int32_t* iters_out, void* z_out, int device) {
+    int rc = check_odmpccbf(params, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipSetDevice");
+    const sc_mpccbf_params* mp = &params->mpc;
+    const size_t es = mp->io_dtype == SC_DTYPE_F64 ? 8 : 4;
+    const size_t n = 2 * (size_t)mp->horizon;
+    const size_t nX = (size_t)B * 4 * es, nU = (size_t)B * 2 * es, nG = nU;
+    const size_t nO = (mp->obs_shared ? (size_t)K * 7 : (size_t)B * K * 7) * es;
+    const size_t nS = (size_t)B * 4, nZ = (size_t)B * n * es;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t oX = 0, oU = oX + up(nX), oG = oU + up(nU), oO = oG + up(nG), oUo = oO + up(nO), oS = oUo + up(nU),
+                 oI = oS + up(nS), oZ = oI + up(nS), oR = oZ + up(nZ), total = oR + up(nZ);
+    unsigned char* d = nullptr;
+    e = hipMalloc((void**)&d, total);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipMalloc");
+    hipStream_t s = nullptr;
+    do {
+        if ((e = hipMemcpyAsync(d + oX, X, nX, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oU, u_prev, nU, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oG, goal, nG, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        e = sc::odmpccbf_launch(*params, (long long)B, (int)K, d + oX, d + oU, d + oG, d + oO, d + oUo,
+                                rho_out ? d + oR : nullptr, (int*)(d + oS), (int*)(d + oI), z_out ? d + oZ : nullptr, s);
+        if (e != hipSuccess) break;
+        if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (iters_out && (e = hipMemcpyAsync(iters_out, d + oI, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (z_out && (e = hipMemcpyAsync(z_out, d + oZ, nZ, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (rho_out && (e = hipMemcpyAsync(rho_out, d + oR, nZ, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        e = hipStreamSynchronize(s);
+    } while (0);
+    rc = SC_OK;
+    if (e != hipSuccess) rc = sc::fail_hip(e, "sc_odmpccbf_solve_batch_host");
     (void)hipFree(d);
     return rc;
 }

@@ -134,17 +134,28 @@ struct MpcMem {                 // LDS carve-up (doubles); NP = N + 2 predicted 
     //   L (transposition scratch / LDS Cholesky)
     double *PC, *PD, *T, *L;
     double *rhs, *is;                             // aliases of dz, ds
+    // optimal-decay variant only
+    double *rho, *rhot, *drho, *rhob;             // 2 N decay variables (current, trial, step, best iterate)
+    double *w0s, *w1s;                            // N stage weights of the rows
+    double *A1, *A2;                              // N K : d row / d rho_1, d rho_2
+    double *ods;                                  // 22 N : per stage C (12), eigen form of D^-1 (4), t0 t1 t2 (6)
+    double *XS;                                   // 39 N exchange scratch inside region B (E packed 21, c_v 18)
 };
 
-__host__ __device__ inline size_t mpc_lds_doubles(int N, int K) {
+__host__ __device__ inline size_t mpc_region_b(int N, bool od) {
+    const size_t n = 2 * (size_t)N, NP = (size_t)N + 2;
+    return (od && 39 * (size_t)N > 2 * NP * n) ? 39 * (size_t)N : 2 * NP * n;
+}
+__host__ __device__ inline size_t mpc_lds_doubles(int N, int K, bool od = false) {
     const size_t n = 2 * (size_t)N, NP = (size_t)N + 2, m = (size_t)N * K + 2 * N + 2 * n;
     const size_t regA = n * n > NP * (26 + K) ? n * n : NP * (26 + K);
     const size_t cvt = 2 * n > 3 * (size_t)N + 5 ? 2 * n : 3 * (size_t)N + 5;
+    const size_t odx = od ? 4 * n + 2 * (size_t)N + 2 * (size_t)N * K + 22 * (size_t)N : 0;
     return 4 * n + n + cvt + 4 * (N + 1) + 2 * NP + 3 * NP + (size_t)K * 7 + NP * K * 2 + 5 * m + 2 * NP * n + regA +
-           2 * NP * n;
+           mpc_region_b(N, od) + odx;
 }
 
-__device__ inline MpcMem carve(double* b, int N, int K) {
+__device__ inline MpcMem carve(double* b, int N, int K, bool od = false) {
     const int n = 2 * N, NP = N + 2, m = N * K + 2 * N + 2 * n;
     MpcMem M;
     auto take = [&](size_t c) { double* r = b; b += c; return r; };
@@ -161,8 +172,15 @@ __device__ inline MpcMem carve(double* b, int N, int K) {
     const size_t regA = (size_t)n * n > (size_t)NP * (26 + K) ? (size_t)n * n : (size_t)NP * (26 + K);
     double* A = take(regA);
     M.Phi = A; M.Y = A + (size_t)2 * NP * 10; M.hk = M.Y + 6 * NP; M.M = A;
-    M.T = take((size_t)2 * NP * n); M.L = M.T; M.PC = M.T; M.PD = M.T + 2 * NP;
+    M.T = take(mpc_region_b(N, od)); M.L = M.T; M.PC = M.T; M.PD = M.T + 2 * NP; M.XS = M.T;
     M.rhs = M.dz; M.is = M.ds;
+    M.rho = M.rhot = M.drho = M.rhob = M.w0s = M.w1s = M.A1 = M.A2 = M.ods = nullptr;
+    if (od) {
+        M.rho = take(n); M.rhot = take(n); M.drho = take(n); M.rhob = take(n);
+        M.w0s = take(N); M.w1s = take(N);
+        M.A1 = take((size_t)N * K); M.A2 = take((size_t)N * K);
+        M.ods = take((size_t)22 * N);
+    }
     return M;
 }
 
@@ -170,6 +188,7 @@ struct MpcConst {
     int N, K, n, mc, m;
     double dt, Qx, Qy, Qth, Qv, R0, R1, w0, w1, w2, vmax, amax, wmaxu, Rrob, beta;
     double x0, y0, th0, v0, up0, up1, gx, gy;
+    double al1, al2, ps1, ps2, rf1, rf2;          // optimal decay: CBF gains, decay penalties and references
 };
 
 // ---- barrier h, dh/dp, d2h/dp2 at a position (oracle/mpc_cbf.py: barrier) ---------------------
@@ -237,8 +256,9 @@ __device__ __forceinline__ double suffix_sum(double v, int lane) {
 // ---- rollout + barrier values + g + f at a trial z (oracle: evaluate level 0) --------------------
 // Lane k holds stage k: heading / speed are exclusive prefix sums of the inputs, positions and the position
 // sensitivities PC_k = sum_{i<k} (cos, sin), PD_k = sum_{i<k} v_i (-sin, cos) prefix sums of the stage terms.
-template <bool ROW16>
-__device__ inline double eval_values(const double* z, const MpcMem& W, const MpcConst& c, int lane, bool derivs, Prof& pf, int slot) {
+template <bool ROW16, bool OD>
+__device__ inline double eval_values(const double* z, const double* rho, const MpcMem& W, const MpcConst& c, int lane, bool derivs,
+                                     Prof& pf, int slot) {
     lane = opaque(lane);
     const int N = c.N, K = c.K, n = c.n, NP = N + 2;
     double ak = 0.0, wk = 0.0;
@@ -265,8 +285,17 @@ __device__ inline double eval_values(const double* z, const MpcMem& W, const Mpc
     }
     for (int i = lane; i < n; i += 64) {
         const double prev = i >= 2 ? z[i - 2] : ((i & 1) ? c.up1 : c.up0);
-        const double du = z[i] - prev;
+        const double du = OD ? z[i] : z[i] - prev;                    // OD: R u^2 (optimal_decay_mpc_cbf.py:178-179)
         part += ((i & 1) ? c.R1 : c.R0) * du * du;
+    }
+    if constexpr (OD) {
+        // stage weights of the rows  w1_k = s_k - 2,  w0_k = 1 - s_k + q_k  and the decay penalty
+        if (lane < N) {
+            const double r1 = rho[2 * lane], r2 = rho[2 * lane + 1];
+            const double sk = c.al1 * r1 + c.al2 * r2, qk = c.al1 * c.al2 * r1 * r2;
+            W.w0s[lane] = 1.0 - sk + qk; W.w1s[lane] = sk - 2.0;
+            part += c.ps1 * (r1 - c.rf1) * (r1 - c.rf1) + c.ps2 * (r2 - c.rf2) * (r2 - c.rf2);
+        }
     }
     SC_SYNC();
     SC_PH(slot);
@@ -303,7 +332,17 @@ __device__ inline double eval_values(const double* z, const MpcMem& W, const Mpc
         double gi;
         if (i < c.mc) {
             const int k = i / K, j = i - k * K;
-            gi = c.w2 * W.hk[(k + 2) * K + j] + c.w1 * W.hk[(k + 1) * K + j] + c.w0 * W.hk[k * K + j];
+            const double h2 = W.hk[(k + 2) * K + j], h1 = W.hk[(k + 1) * K + j], h0 = W.hk[k * K + j];
+            if constexpr (OD) {
+                gi = h2 + W.w1s[k] * h1 + W.w0s[k] * h0;
+                if (derivs) {                                       // d row / d rho_i = a_i (h1 - h0) + a1 a2 rho_other h0
+                    const double aa = c.al1 * c.al2 * h0;
+                    W.A1[i] = c.al1 * (h1 - h0) + aa * rho[2 * k + 1];
+                    W.A2[i] = c.al2 * (h1 - h0) + aa * rho[2 * k];
+                }
+            } else {
+                gi = c.w2 * h2 + c.w1 * h1 + c.w0 * h0;
+            }
         } else if (i < c.mc + 2 * N) {
             const int r = i - c.mc, k = (r >> 1) + 1;
             gi = (r & 1) ? (c.vmax + W.V[k]) : (c.vmax - W.V[k]);
@@ -349,8 +388,8 @@ __device__ __forceinline__ void row_pass(const MpcMem& W, const MpcConst& c, int
 // positions: lane k < NP builds  q_k = d L / d p_k,  Om_k,  the position-space vectors A'(1/s), A'(sig r_p + lam),
 // row block k of Phi, and the suffix sums the structured Hessian terms need.  Multipliers are those of the scaled
 // problem (objective times sf), so everything here is already scaled.
-template <int KT, bool ROW16>
-__device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, int lane, double sf) {
+template <int KT, bool ROW16, bool OD>
+__device__ __forceinline__ double stage_pass(const MpcMem& W, const MpcConst& c, int lane, double sf) {
     lane = opaque(lane);
     // ROW16: the obstacle loop of stage k is split over lanes k, k + 16, k + 32, k + 48 (jo = part, part + 4, ..) and
     // the partial sums are added across the four rows; every row then holds the totals, row 0 stores them.
@@ -362,10 +401,22 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
     double q0 = 0.0, q1 = 0.0;
     double oxx = 0, oxy = 0, oyy = 0, ya0 = 0, ya1 = 0, yb0 = 0, yb1 = 0;
     double f0xx = 0, f0xy = 0, f0yy = 0, f1[4] = {0, 0, 0, 0}, f2[4] = {0, 0, 0, 0};
+    // optimal decay, stage kappa = k: D = sum sig a a' (+ Hessian), lh = sum lam h0, t_v = sum a v, C (6 x 2)
+    double S11 = 0, S12 = 0, S22 = 0, lh = 0, T0[2] = {0, 0}, T1[2] = {0, 0}, T2[2] = {0, 0};
+    double Cm[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                 // Cm[(2 t + d) * 2 + i]
     if (k < NP) {
         const bool t0 = k <= N - 1, t1 = k >= 1 && k <= N, t2 = k >= 2;       // row kappa = k - t exists
         const int r0 = (t0 ? k : 0) * K, r1 = (t1 ? k - 1 : 0) * K, r2 = (t2 ? k - 2 : 0) * K;
-        const double w0 = t0 ? c.w0 : 0.0, w1 = t1 ? c.w1 : 0.0, w2 = t2 ? c.w2 : 0.0;
+        // weights of the three rows that touch position k (OD: they depend on the row's stage)
+        const double w0 = t0 ? (OD ? W.w0s[t0 ? k : 0] : c.w0) : 0.0, w1 = t1 ? (OD ? W.w1s[t1 ? k - 1 : 0] : c.w1) : 0.0,
+                     w2 = t2 ? c.w2 : 0.0;
+        const double w1k = OD ? W.w1s[t0 ? k : 0] : c.w1;                 // t = 1 weight of row kappa = k
+        double cr1 = 0.0, cr2 = 0.0;                                      // d2 row / d rho_i d p_kappa = cr_i dh0
+        if constexpr (OD) {
+            const int kk = t0 ? k : 0;
+            cr1 = -c.al1 + c.al1 * c.al2 * W.rho[2 * kk + 1];
+            cr2 = -c.al2 + c.al1 * c.al2 * W.rho[2 * kk];
+        }
         const int k1 = k + 1 < NP ? k + 1 : k, k2 = k + 2 < NP ? k + 2 : k;
         const double pk0 = W.pos[2 * k], pk1 = W.pos[2 * k + 1];
         // not unrolled: both iterations' 24 loads in flight at once cost 16 VGPR spills under the 256-register cap
@@ -385,7 +436,7 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
             }
             const double ml = w0 * l0 + w1 * l1 + w2 * l2, ma = w0 * i0 + w1 * i1 + w2 * i2, mb = w0 * b0 + w1 * b1 + w2 * b2;
             const double c0 = w0 * w0 * s0 + w1 * w1 * s1 + w2 * w2 * s2;
-            const double c1 = w1 * c.w2 * s1 + w0 * c.w1 * s0;      // rows kappa = k-1 (t = 1, 2) and kappa = k (t = 0, 1)
+            const double c1 = w1 * c.w2 * s1 + w0 * w1k * s0;       // rows kappa = k-1 (t = 1, 2) and kappa = k (t = 0, 1)
             const double c2 = w0 * c.w2 * s0;                        // row kappa = k (t = 0, 2)
             oxx -= ml * hxx; oxy -= ml * hxy; oyy -= ml * hyy;
             q0 -= ml * d0; q1 -= ml * d1;
@@ -393,6 +444,22 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
             f0xx += c0 * d0 * d0; f0xy += c0 * d0 * d1; f0yy += c0 * d1 * d1;
             f1[0] += c1 * d0 * a0; f1[1] += c1 * d0 * a1; f1[2] += c1 * d1 * a0; f1[3] += c1 * d1 * a1;
             f2[0] += c2 * d0 * g0; f2[1] += c2 * d0 * g1; f2[2] += c2 * d1 * g0; f2[3] += c2 * d1 * g1;
+            if constexpr (OD) {
+                const double tz = t0 ? 1.0 : 0.0;
+                const double aa1 = tz * W.A1[r0 + jo], aa2 = tz * W.A2[r0 + jo];
+                const double l0z = tz * l0, s0z = tz * s0;
+                S11 += s0z * aa1 * aa1; S12 += s0z * aa1 * aa2; S22 += s0z * aa2 * aa2;
+                lh += l0z * W.hk[e];
+                T0[0] -= l0z * aa1; T0[1] -= l0z * aa2;
+                T1[0] += i0 * aa1; T1[1] += i0 * aa2;
+                T2[0] += b0 * aa1; T2[1] += b0 * aa2;
+                const double e01 = s0z * w0 * aa1 - l0z * cr1, e02 = s0z * w0 * aa2 - l0z * cr2;
+                const double e11 = s0z * w1k * aa1 - l0z * c.al1, e12 = s0z * w1k * aa2 - l0z * c.al2;
+                const double e21 = s0z * aa1, e22 = s0z * aa2;
+                Cm[0] += d0 * e01; Cm[1] += d0 * e02; Cm[2] += d1 * e01; Cm[3] += d1 * e02;
+                Cm[4] += a0 * e11; Cm[5] += a0 * e12; Cm[6] += a1 * e11; Cm[7] += a1 * e12;
+                Cm[8] += g0 * e21; Cm[9] += g0 * e22; Cm[10] += g1 * e21; Cm[11] += g1 * e22;
+            }
         }
     }
     if constexpr (ROW16) {
@@ -401,6 +468,83 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
         rows4(f0xx); rows4(f0xy); rows4(f0yy);
 #pragma unroll
         for (int t = 0; t < 4; ++t) { rows4(f1[t]); rows4(f2[t]); }
+        if constexpr (OD) {
+            rows4(S11); rows4(S12); rows4(S22); rows4(lh);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { rows4(T0[t]); rows4(T1[t]); rows4(T2[t]); }
+#pragma unroll
+            for (int t = 0; t < 12; ++t) rows4(Cm[t]);
+        }
+    }
+    double e_rho = 0.0;
+    if constexpr (OD) {
+        // eliminate the decay variables of stage kappa = k:  E = C D^-1 C',  c_v = C D^-1 t_v  go to the exchange scratch,
+        // C, D^-1 and t_v stay in W.ods for the back-substitution after the solve
+        if (k < N && part == 0) {
+            const double r1 = W.rho[2 * k], r2 = W.rho[2 * k + 1];
+            T0[0] += sf * 2.0 * c.ps1 * (r1 - c.rf1); T0[1] += sf * 2.0 * c.ps2 * (r2 - c.rf2);
+            e_rho = fmax(fabs(T0[0]), fabs(T0[1]));
+            double d11 = sf * 2.0 * c.ps1 + S11, d22 = sf * 2.0 * c.ps2 + S22;
+            const double d12 = S12 - c.al1 * c.al2 * lh;
+            // D^-1 is applied through the eigen-decomposition  D = ls vs vs' + lw vw vw'.  With a1 ~ a2 the two
+            // columns of C and the rows of D are nearly parallel: D has one huge (sum sig a a') and one small (the
+            // penalty) eigenvalue, and an explicit inverse loses the huge direction against the small one
+            // (relative error ~1e-3 in C D^-1 C' at sig ~ 1e6, which stalls the last iterations).
+            const double tr = d11 + d22, df = d11 - d22, rad = sqrt(df * df + 4.0 * d12 * d12);
+            double ls = 0.5 * (tr + rad), lw = (d11 * d22 - d12 * d12) / ls;
+            double vx = df >= 0.0 ? df + rad : 2.0 * d12, vy = df >= 0.0 ? 2.0 * d12 : rad - df;
+            const double vn = vx * vx + vy * vy;
+            if (vn > 0.0) { const double rn = rsqrt_(vn); vx *= rn; vy *= rn; } else { vx = 1.0; vy = 0.0; }
+            // shift to positive definite: + max(0, eps - lambda_min) I, eps = 1e-8 max(1, |d11| + |d22|)
+            const double sh = fmax(0.0, 1e-8 * fmax(1.0, fabs(d11) + fabs(d22)) - lw);
+            ls += sh; lw += sh;
+            const double ils = 1.0 / ls, ilw = 1.0 / lw;
+            double cs[6], cw[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                cs[r] = Cm[2 * r] * vx + Cm[2 * r + 1] * vy;
+                cw[r] = -Cm[2 * r] * vy + Cm[2 * r + 1] * vx;
+            }
+            double* xs = W.XS + (size_t)39 * k;
+            int o = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int q2 = r; q2 < 6; ++q2) xs[o++] = cs[r] * cs[q2] * ils + cw[r] * cw[q2] * ilw;
+            const double p0s = (vx * T0[0] + vy * T0[1]) * ils, p0w = (-vy * T0[0] + vx * T0[1]) * ilw;
+            const double p1s = (vx * T1[0] + vy * T1[1]) * ils, p1w = (-vy * T1[0] + vx * T1[1]) * ilw;
+            const double p2s = (vx * T2[0] + vy * T2[1]) * ils, p2w = (-vy * T2[0] + vx * T2[1]) * ilw;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                xs[21 + r] = cs[r] * p0s + cw[r] * p0w;
+                xs[27 + r] = cs[r] * p1s + cw[r] * p1w;
+                xs[33 + r] = cs[r] * p2s + cw[r] * p2w;
+            }
+            double* od = W.ods + (size_t)22 * k;
+#pragma unroll
+            for (int t = 0; t < 12; ++t) od[t] = Cm[t];
+            od[12] = vx; od[13] = vy; od[14] = ils; od[21] = ilw;
+            od[15] = T0[0]; od[16] = T0[1]; od[17] = T1[0]; od[18] = T1[1]; od[19] = T2[0]; od[20] = T2[1];
+        }
+        SC_SYNC();
+        if (k < NP) {
+            // gather: Phi -= sum_kappa E_kappa,  Y1 -= c_1,  Y2 -= c_2 + c_0   (rows of stages kappa = k - t, t = 0..2)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int kap = k - t;
+                if (kap < 0 || kap > N - 1) continue;
+                const double* xs = W.XS + (size_t)39 * kap;
+                auto E = [&](int r, int q2) { return xs[r * 6 - (r * (r - 1)) / 2 + (q2 - r)]; };
+                f0xx -= E(2 * t, 2 * t); f0xy -= E(2 * t, 2 * t + 1); f0yy -= E(2 * t + 1, 2 * t + 1);
+                if (t <= 1) {
+                    f1[0] -= E(2 * t, 2 * t + 2); f1[1] -= E(2 * t, 2 * t + 3);
+                    f1[2] -= E(2 * t + 1, 2 * t + 2); f1[3] -= E(2 * t + 1, 2 * t + 3);
+                }
+                if (t == 0) { f2[0] -= E(0, 4); f2[1] -= E(0, 5); f2[2] -= E(1, 4); f2[3] -= E(1, 5); }
+                ya0 -= xs[27 + 2 * t]; ya1 -= xs[27 + 2 * t + 1];
+                yb0 -= xs[33 + 2 * t] + xs[21 + 2 * t]; yb1 -= xs[33 + 2 * t + 1] + xs[21 + 2 * t + 1];
+            }
+        }
     }
     if (k < NP) {
         if (k >= 1 && k <= N) {
@@ -444,11 +588,13 @@ __device__ __forceinline__ void stage_pass(const MpcMem& W, const MpcConst& c, i
     }
     const double sa = suffix_sum<ROW16>(Ai, lane), sb = suffix_sum<ROW16>(Bi, lane), ss = suffix_sum<ROW16>(sk, lane);
     if (k < NP && part == 0) { W.SA[k] = sa; W.SB[k] = sb; W.SS[k] = ss; }
+    return OD ? wmax(e_rho) : 0.0;                                    // |r_d| of the decay variables
 }
 
 // columns: cv[v][col] for the three row vectors  v = 0: r_d = sf grad f - J' lam;  1: J'(1/s);  2: J'(sig r_p + lam).
 // Every inner loop has a trip count that does not depend on the lane (structural zeros of G, masks on the stage
 // sums), so with compile-time N the loads of a lane are issued back to back instead of one round trip per term.
+template <bool OD>
 __device__ __forceinline__ double col_pass(const MpcMem& W, const MpcConst& c, int lane, double sf) {
     lane = opaque(lane);
     const int N = c.N, n = c.n, NP = N + 2;
@@ -474,8 +620,8 @@ __device__ __forceinline__ double col_pass(const MpcMem& W, const MpcConst& c, i
         if (v == 0) {
             const double Rc = (col & 1) ? c.R1 : c.R0, Qs = (col & 1) ? c.Qth : c.Qv;
             const double prev = col >= 2 ? W.z[col - 2] : ((col & 1) ? c.up1 : c.up0);
-            double gr = 2.0 * Qs * c.dt * sx + 2.0 * Rc * (W.z[col] - prev);
-            if (col + 2 < n) gr -= 2.0 * Rc * (W.z[col + 2] - W.z[col]);
+            double gr = 2.0 * Qs * c.dt * sx + 2.0 * Rc * (OD ? W.z[col] : W.z[col] - prev);
+            if (!OD && col + 2 < n) gr -= 2.0 * Rc * (W.z[col + 2] - W.z[col]);
             acc += sf * gr - sb;
             e_d = fmax(e_d, fabs(acc));
         } else {
@@ -548,6 +694,7 @@ __device__ __forceinline__ void phi_times_G(const MpcMem& W, const MpcConst& c, 
 }
 
 // structured part of the condensed matrix at (r, cc)
+template <bool OD>
 __device__ __forceinline__ double condensed_base(const MpcMem& W, const MpcConst& c, double sf, int r, int cc) {
     const int N = c.N, n = c.n;
     const int jr = r >> 1, jc = cc >> 1, jm = jr > jc ? jr : jc;
@@ -559,13 +706,13 @@ __device__ __forceinline__ double condensed_base(const MpcMem& W, const MpcConst
     double acc = (ra && ca) ? vaa : ((!ra && !ca) ? vww : dt3 * sa);
     const double Rc = (r & 1) ? c.R1 : c.R0;                                               // input-rate penalty 2 D' R D
     const int bx = c.mc + 2 * N + r;
-    const double dg = sf * 2.0 * Rc * ((r + 2 < n) ? 2.0 : 1.0) + W.lam[bx] * W.is[bx] + W.lam[bx + n] * W.is[bx + n];
-    acc += (r == cc) ? dg : ((r == cc + 2 || cc == r + 2) ? -sf * 2.0 * Rc : 0.0);
+    const double dg = sf * 2.0 * Rc * ((!OD && r + 2 < n) ? 2.0 : 1.0) + W.lam[bx] * W.is[bx] + W.lam[bx + n] * W.is[bx + n];
+    acc += (r == cc) ? dg : ((!OD && (r == cc + 2 || cc == r + 2)) ? -sf * 2.0 * Rc : 0.0);
     return acc;
 }
 
 // M = G'' T' + structured terms   (7 MFMAs for N = 10; lower tiles, mirrored)
-template <int S>
+template <int S, bool OD>
 __device__ __forceinline__ void condense_mfma(const MpcMem& W, const MpcConst& c, int lane, double sf) {
     lane = opaque(lane);
     const int n = c.n, nt = (n + 15) >> 4, q = lane >> 4, l15 = lane & 15;
@@ -578,7 +725,7 @@ __device__ __forceinline__ void condense_mfma(const MpcMem& W, const MpcConst& c
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + q + 4 * r, col = 16 * tj + l15;
-                base[r] = (row < n && col < n) ? condensed_base(W, c, sf, row, col) : 0.0;
+                base[r] = (row < n && col < n) ? condensed_base<OD>(W, c, sf, row, col) : 0.0;
             }
             const d4_t acc = mfma_ksteps<S>(16 * ti, n,
                 [&](int k0) {
@@ -718,12 +865,15 @@ __device__ __forceinline__ double chol_solve_reg(double (&a)[n], double dinv, do
 
 // NT, KT > 0: horizon and obstacle count are compile-time constants (index arithmetic folds to shifts and
 // multiplies); NT == 0: run-time sizes.
-template <typename TIO, int NT, int KT>
+struct OdExtra { double omega_ref[2], p_sb[2]; };
+
+template <typename TIO, int NT, int KT, bool OD = false>
 __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& p, const long long B, const int K_rt,
                                             const TIO* __restrict__ X, const TIO* __restrict__ u_prev,
                                             const TIO* __restrict__ goal, const TIO* __restrict__ obs,
                                             TIO* __restrict__ u_out, int* __restrict__ status_out,
-                                            int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+                                            int* __restrict__ iters_out, TIO* __restrict__ z_out,
+                                            const OdExtra od = OdExtra{{1.0, 1.0}, {0.0, 0.0}}, TIO* __restrict__ rho_out = nullptr) {
     const int lane = threadIdx.x;
     const long long prob = blockIdx.x;
     if (prob >= B) return;
@@ -737,8 +887,9 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     c.x0 = (double)X[prob * 4 + 0]; c.y0 = (double)X[prob * 4 + 1]; c.th0 = (double)X[prob * 4 + 2]; c.v0 = (double)X[prob * 4 + 3];
     c.up0 = (double)u_prev[prob * 2 + 0]; c.up1 = (double)u_prev[prob * 2 + 1];
     c.gx = (double)goal[prob * 2 + 0]; c.gy = (double)goal[prob * 2 + 1];
+    c.al1 = p.alpha1; c.al2 = p.alpha2; c.ps1 = od.p_sb[0]; c.ps2 = od.p_sb[1]; c.rf1 = od.omega_ref[0]; c.rf2 = od.omega_ref[1];
     const int N = c.N, n = c.n, m = c.m;
-    const MpcMem W = carve(sm, N, K);
+    const MpcMem W = carve(sm, N, K, OD);
     constexpr bool ROW16 = NT > 0 && NT + 2 <= 16;
     constexpr int MS = NT > 0 ? (2 * NT + 3) / 4 : 4;                  // MFMA k-steps batched per LDS round trip
     for (int e = lane; e < 2 * (N + 2) * n; e += 64) W.dP[e] = 0.0;      // structural zeros of G stay
@@ -750,21 +901,22 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         const double ub = (i & 1) ? c.wmaxu : c.amax;
         const double u = (i & 1) ? c.up1 : c.up0;
         W.z[i] = fmin(fmax(u, -0.99 * ub), 0.99 * ub);
+        if constexpr (OD) W.rho[i] = (i & 1) ? c.rf2 : c.rf1;            // decay variables start at their references
     }
     SC_SYNC();
 
     Prof pf;
     pf.start();
-    double f = eval_values<ROW16>(W.z, W, c, lane, true, pf, 12);
+    double f = eval_values<ROW16, OD>(W.z, W.rho, W, c, lane, true, pf, 12);
     // objective scaling from |grad f|_inf at the start: with lam = 0 the column pass returns r_d = grad f
     for (int i = lane; i < m; i += 64) { W.sl[i] = fmax(W.g[i], 1e-2); W.lam[i] = 0.0; }
     SC_SYNC();
     double e_p, e_c0, lmax;
     row_pass(W, c, lane, e_p, e_c0, lmax);
     SC_SYNC();
-    stage_pass<KT, ROW16>(W, c, lane, 1.0);
+    stage_pass<KT, ROW16, OD>(W, c, lane, 1.0);
     SC_SYNC();
-    const double gmax = col_pass(W, c, lane, 1.0);
+    const double gmax = col_pass<OD>(W, c, lane, 1.0);
     const double sf = fmin(1.0, 100.0 / fmax(1e-12, gmax));             // objective scaling
     double mu = p.mu_init;
     SC_SYNC();
@@ -775,22 +927,22 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     pf.start();
     const double tau = 0.995;
     double nu = 10.0, delta_last = 0.0, e_best = 1e300;
-    for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
+    for (int i = lane; i < n; i += 64) { W.zb[i] = W.z[i]; if constexpr (OD) W.rhob[i] = W.rho[i]; }
     for (it = 1; it <= p.max_iter; ++it) {
-        if (it > 1) f = eval_values<ROW16>(W.z, W, c, lane, true, pf, 12);
+        if (it > 1) f = eval_values<ROW16, OD>(W.z, W.rho, W, c, lane, true, pf, 12);
         SC_PH(0);
         row_pass(W, c, lane, e_p, e_c0, lmax);
         SC_SYNC();
         SC_PH(1);
-        stage_pass<KT, ROW16>(W, c, lane, sf);
+        const double e_rho = stage_pass<KT, ROW16, OD>(W, c, lane, sf);
         SC_SYNC();
         SC_PH(2);
-        const double e_d = col_pass(W, c, lane, sf);
+        const double e_d = fmax(e_rho, col_pass<OD>(W, c, lane, sf));
         SC_PH(3);
         const double e_opt = fmax(e_d, fmax(e_p, e_c0));
         if (e_opt < e_best) {                                            // remember the best iterate
             e_best = e_opt;
-            for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
+            for (int i = lane; i < n; i += 64) { W.zb[i] = W.z[i]; if constexpr (OD) W.rhob[i] = W.rho[i]; }
         }
         if (e_opt <= p.tol) { status = SC_STATUS_OPTIMAL; break; }
         if (lmax > 1e10) { status = SC_STATUS_INFEASIBLE; break; }
@@ -809,7 +961,7 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         SC_PH(5);
         // condensed system  (sf W + J' Sigma J) dz = -r_d + J' (mu/s - Sigma r_p - lam)
         for (int col = lane; col < n; col += 64) W.rhs[col] = -W.cv[col] + (mu * W.cv[n + col] - W.cv[2 * n + col]);
-        condense_mfma<MS>(W, c, lane, sf);
+        condense_mfma<MS, OD>(W, c, lane, sf);
         SC_SYNC();
         SC_PH(6);
         // inertia correction: M + delta I until the Cholesky succeeds
@@ -859,6 +1011,24 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         double gdz = 0.0;
         for (int i = lane; i < n; i += 64) gdz += W.cv[i] * W.dz[i];      // r_d . dz
         SC_SYNC();
+        if constexpr (OD) {
+            // back-substitution of the decay variables:  d rho_k = D_k^-1 (rhs_k - C_k' dp_{k..k+2}),  rhs = -t0 + mu t1 - t2
+            for (int k = lane; k < N; k += 64) {
+                const double* od_ = W.ods + (size_t)22 * k;
+                double v0 = -od_[15] + mu * od_[17] - od_[19], v1 = -od_[16] + mu * od_[18] - od_[20];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    const double dpr = W.dp[2 * k + r];
+                    v0 -= od_[2 * r] * dpr; v1 -= od_[2 * r + 1] * dpr;
+                }
+                const double vx = od_[12], vy = od_[13];
+                const double ps_ = (vx * v0 + vy * v1) * od_[14], pw_ = (-vy * v0 + vx * v1) * od_[21];
+                const double dr1 = vx * ps_ - vy * pw_, dr2 = vy * ps_ + vx * pw_;
+                W.drho[2 * k] = dr1; W.drho[2 * k + 1] = dr2;
+                gdz += od_[15] * dr1 + od_[16] * dr2;                     // r_d of the decay variables . d rho
+            }
+            SC_SYNC();
+        }
         SC_PH(9);
         // ds = J dz + r_p, dlam, step lengths
         double rs_min = 0.0, rl_min = 0.0, sum_ds_s = 0.0, sum_rp = 0.0;
@@ -869,9 +1039,11 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
             if (i < c.mc) {
                 const int k = i / K, jo = i - k * K;
                 const int e0 = k * K + jo, e1 = e0 + K, e2 = e1 + K;
-                jd = c.w0 * (W.dh[2 * e0] * W.dp[2 * k] + W.dh[2 * e0 + 1] * W.dp[2 * k + 1]) +
-                     c.w1 * (W.dh[2 * e1] * W.dp[2 * k + 2] + W.dh[2 * e1 + 1] * W.dp[2 * k + 3]) +
+                const double w0r = OD ? W.w0s[k] : c.w0, w1r = OD ? W.w1s[k] : c.w1;
+                jd = w0r * (W.dh[2 * e0] * W.dp[2 * k] + W.dh[2 * e0 + 1] * W.dp[2 * k + 1]) +
+                     w1r * (W.dh[2 * e1] * W.dp[2 * k + 2] + W.dh[2 * e1 + 1] * W.dp[2 * k + 3]) +
                      c.w2 * (W.dh[2 * e2] * W.dp[2 * k + 4] + W.dh[2 * e2 + 1] * W.dp[2 * k + 5]);
+                if constexpr (OD) jd += W.A1[i] * W.drho[2 * k] + W.A2[i] * W.drho[2 * k + 1];
             } else if (i < c.mc + 2 * N) {
                 const int r = i - c.mc, k = (r >> 1) + 1;
                 jd = (r & 1) ? W.dV[k] : -W.dV[k];
@@ -899,9 +1071,12 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         double alpha = ap;
         bool accepted = false;
         for (int ls = 0; ls < 12; ++ls) {                              // at most 12 halvings, then give up (best iterate)
-            for (int i = lane; i < n; i += 64) W.zt[i] = W.z[i] + alpha * W.dz[i];
+            for (int i = lane; i < n; i += 64) {
+                W.zt[i] = W.z[i] + alpha * W.dz[i];
+                if constexpr (OD) W.rhot[i] = W.rho[i] + alpha * W.drho[i];
+            }
             SC_SYNC();
-            const double ft = eval_values<ROW16>(W.zt, W, c, lane, false, pf, 16);
+            const double ft = eval_values<ROW16, OD>(W.zt, W.rhot, W, c, lane, false, pf, 16);
             double srp = 0.0;
             LogSum lst;
             for (int i = lane; i < m; i += 64) {
@@ -917,7 +1092,10 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
             alpha *= 0.5;
         }
         if (!accepted) break;
-        for (int i = lane; i < n; i += 64) W.z[i] = W.z[i] + alpha * W.dz[i];
+        for (int i = lane; i < n; i += 64) {
+            W.z[i] = W.z[i] + alpha * W.dz[i];
+            if constexpr (OD) W.rho[i] = W.rho[i] + alpha * W.drho[i];
+        }
         for (int i = lane; i < m; i += 64) {
             const double s = W.sl[i] + alpha * W.ds[i];
             double lam = W.lam[i] + ad * W.dlam[i];
@@ -933,11 +1111,11 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         // stalled at the precision limit (ill-conditioned condensed system at mu ~ 1e-9): the best iterate is
         // within the acceptable tolerance, like IPOPT's acceptable_tol exit
         SC_SYNC();
-        for (int i = lane; i < n; i += 64) W.z[i] = W.zb[i];
+        for (int i = lane; i < n; i += 64) { W.z[i] = W.zb[i]; if constexpr (OD) W.rho[i] = W.rhob[i]; }
         status = SC_STATUS_OPTIMAL;
     }
     SC_SYNC();
-    eval_values<ROW16>(W.z, W, c, lane, false, pf, 16);
+    eval_values<ROW16, OD>(W.z, W.rho, W, c, lane, false, pf, 16);
     if (status != SC_STATUS_OPTIMAL) {
         double gmin = 1e300;
         for (int i = lane; i < m; i += 64) gmin = fmin(gmin, W.g[i]);
@@ -956,6 +1134,9 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
 #else
     if (z_out) for (int i = lane; i < n; i += 64) z_out[prob * n + i] = (TIO)W.z[i];
 #endif
+    if constexpr (OD) {
+        if (rho_out) for (int i = lane; i < n; i += 64) rho_out[prob * n + i] = (TIO)W.rho[i];
+    }
 }
 
 // Compile-time horizon: capped at 256 VGPRs (two waves per SIMD; fits without spills).  Run-time sizes: no cap --
@@ -977,7 +1158,49 @@ void mpccbf_kernel_rt(const sc_mpccbf_params p, const long long B, const int K_r
     mpccbf_body<TIO, 0, 0>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
 }
 
+// optimal-decay variant (position_control/optimal_decay_mpc_cbf.py): NT = 10 or run-time horizon, K run-time, no register cap
+template <typename TIO, int NT>
+__global__ __launch_bounds__(64)
+void odmpccbf_kernel(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const TIO* __restrict__ X,
+                     const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
+                     TIO* __restrict__ u_out, TIO* __restrict__ rho_out, int* __restrict__ status_out,
+                     int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    mpccbf_body<TIO, NT, 0, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
+}
+
 size_t mpccbf_lds_bytes(int N, int K) { return mpc_lds_doubles(N, K) * sizeof(double); }
+size_t odmpccbf_lds_bytes(int N, int K) { return mpc_lds_doubles(N, K, true) * sizeof(double); }
+
+template <typename TIO>
+static hipError_t odmpc_launch_t(const sc_odmpccbf_params& q, long long B, int K, const void* X, const void* u_prev,
+                                 const void* goal, const void* obs, void* u_out, void* rho_out, int* status, int* iters,
+                                 void* z_out, hipStream_t stream) {
+    const sc_mpccbf_params& p = q.mpc;
+    const size_t lds = mpc_lds_doubles(p.horizon, K, true) * sizeof(double);
+    OdExtra od;
+    od.omega_ref[0] = q.omega_ref[0]; od.omega_ref[1] = q.omega_ref[1]; od.p_sb[0] = q.p_sb[0]; od.p_sb[1] = q.p_sb[1];
+    auto launch = [&](auto kern) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, od, B, K, (const TIO*)X, (const TIO*)u_prev,
+                           (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, (TIO*)rho_out, status, iters, (TIO*)z_out);
+        return hipGetLastError();
+    };
+    if (p.horizon == 10) return launch(odmpccbf_kernel<TIO, 10>);
+    return launch(odmpccbf_kernel<TIO, 0>);
+}
+
+hipError_t odmpccbf_launch(const sc_odmpccbf_params& q, long long B, int K, const void* X, const void* u_prev,
+                           const void* goal, const void* obs, void* u_out, void* rho_out, int* status, int* iters,
+                           void* z_out, hipStream_t stream) {
+    if (mpc_lds_doubles(q.mpc.horizon, K, true) * sizeof(double) > 160 * 1024) return hipErrorInvalidValue;
+    if (q.mpc.io_dtype == SC_DTYPE_F32)
+        return odmpc_launch_t<float>(q, B, K, X, u_prev, goal, obs, u_out, rho_out, status, iters, z_out, stream);
+    return odmpc_launch_t<double>(q, B, K, X, u_prev, goal, obs, u_out, rho_out, status, iters, z_out, stream);
+}
 
 template <typename TIO, int NT, int KT>
 static hipError_t mpc_launch_one(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
