@@ -132,6 +132,33 @@ def mpc_leg(dev, B, K, N, steps, warmup, seed=0, cpu_seconds=0.0):
             "achieved_GBs": nbytes / (ms * 1e-3) / 1e9, "algorithmic_bytes_per_solve": nbytes // B}
 
 
+def od_mpc_leg(dev, B=4096, K=8, N=10, steps=2, seed=0):
+    """Optimal-decay MPC-CBF on the config-3 batch: two decay variables per stage."""
+    import torch
+    import safe_control_amd as sca
+    from safe_control_amd import workloads as W
+    spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}
+    ctl = sca.BatchedOptimalDecayMPCCBF(dict(spec), io_dtype="f32", horizon=N)
+    Xn, goal, un, on = W.du_cbfqp_batch(B, K, seed=seed)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    X, g, ob = t(Xn), t(goal), t(on)
+    up = torch.zeros((B, 2), dtype=torch.float32, device=dev)
+    u, rho, st, it = ctl.solve(X, up, g, ob)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        u, rho, st, it = ctl.solve(X, up, g, ob)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return {"workload": f"{B}-agent batch DynamicUnicycle2D optimal-decay MPC-CBF, horizon N={N}, {K} obstacles",
+            "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
+            "optimal_fraction": float((st == 0).double().mean().item()),
+            "mean_ipm_iterations": float(it.double().mean().item()),
+            "max_decay_deviation": float((rho - 1.0).abs().max().item())}
+
+
 def closed_loop_leg(dev, B=4096, T=200, seed=0):
     """BASELINE config 2, closed-loop variant: B DynamicUnicycle2D agents track waypoints through the 14-circle
     scene of examples/test_tracking.py for T control steps (selection + nominal input + CBF-QP + step + collision
@@ -307,6 +334,7 @@ def main():
         if ws == 1 and not a.no_mpc:
             res["mpc_cbf"] = mpc_leg(dev, 4096, 8, 10, steps=3, warmup=1,
                                      cpu_seconds=0.0 if a.no_cpu_baseline else 6.0)
+            res["od_mpc_cbf"] = od_mpc_leg(dev)
             res["closed_loop"] = closed_loop_leg(dev)
         if ws == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(X.double().cpu().numpy(), ur.double().cpu().numpy(),

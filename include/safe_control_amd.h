@@ -137,7 +137,8 @@ typedef struct sc_mpccbf_params {
     int32_t horizon;         /* robot_spec['mpc_horizon'], default 10 (mpc_cbf.py:15)              */
     int32_t max_iter;        /* interior-point iteration limit (-> SC_STATUS_INACCURATE)           */
     int32_t obs_shared;      /* 0: obs is [B,K,7]; 1: one [K,7] table for all agents               */
-    int32_t reserved0;
+    int32_t acceptable_iter; /* stop after this many consecutive iterations within acceptable_tol (IPOPT's
+                              * acceptable_iter, 15); 0 = 15                                       */
     double  dt;              /* robot.dt                                                           */
     double  Q[4];            /* diagonal state weights, DU: 50,50,.01,30 (mpc_cbf.py:25-27)        */
     double  R[2];            /* input-rate weights of mpc.set_rterm, DU: .5,.5 (mpc_cbf.py:180)    */

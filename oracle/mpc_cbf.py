@@ -38,7 +38,7 @@ STATUS_INACCURATE = 2
 
 DEFAULTS = dict(N=10, dt=0.05, Q=(50.0, 50.0, 0.01, 30.0), R=(0.5, 0.5), alpha1=0.15, alpha2=0.15,
                 v_max=1.0, a_max=1.0, w_max=0.5, radius=0.25, beta=1.01,
-                tol=1e-6, acceptable_tol=1e-5, max_iter=100, mu_init=0.1, mu_min=1e-9)
+                tol=1e-6, acceptable_tol=1e-5, acceptable_iter=15, max_iter=100, mu_init=0.1, mu_min=1e-9)
 
 DUMMY_OBS = np.array([1000.0, 1000.0, 0.0, 0.0, 0.0, 0.0, 0.0])
 
@@ -268,6 +268,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False):
     lam = mu / s
     status, it = STATUS_INACCURATE, 0
     tau, nu, delta_last = 0.995, 10.0, 0.0
+    n_acc = 0
     err = np.inf
     e_best, z_best = np.inf, z.copy()
     n_eval = 1
@@ -283,6 +284,9 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False):
             e_best, z_best = e_opt, z.copy()
         if e_opt <= P["tol"]:
             status = STATUS_OPTIMAL
+            break
+        n_acc = n_acc + 1 if e_opt <= P["acceptable_tol"] else 0          # IPOPT's acceptable_iter rule
+        if n_acc >= P["acceptable_iter"]:
             break
         if np.max(lam) > 1e10:                                              # multipliers diverge: locally infeasible
             status = STATUS_INFEASIBLE

@@ -201,6 +201,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
     lam = mu / s
     status, it = STATUS_INACCURATE, 0
     tau, nu, delta_last = 0.995, 10.0, 0.0
+    n_acc = 0
     err = np.inf
     e_best, zz_best = np.inf, zz.copy()
     trace = []
@@ -217,6 +218,9 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
             e_best, zz_best = e_opt, zz.copy()
         if e_opt <= P["tol"]:
             status = STATUS_OPTIMAL
+            break
+        n_acc = n_acc + 1 if e_opt <= P["acceptable_tol"] else 0          # IPOPT's acceptable_iter rule
+        if n_acc >= P["acceptable_iter"]:
             break
         if np.max(lam) > 1e10:
             status = STATUS_INFEASIBLE

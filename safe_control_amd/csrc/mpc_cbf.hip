@@ -927,6 +927,8 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     pf.start();
     const double tau = 0.995;
     double nu = 10.0, delta_last = 0.0, e_best = 1e300;
+    int n_acc = 0;
+    const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
     for (int i = lane; i < n; i += 64) { W.zb[i] = W.z[i]; if constexpr (OD) W.rhob[i] = W.rho[i]; }
     for (it = 1; it <= p.max_iter; ++it) {
         if (it > 1) f = eval_values<ROW16, OD>(W.z, W.rho, W, c, lane, true, pf, 12);
@@ -945,6 +947,10 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
             for (int i = lane; i < n; i += 64) { W.zb[i] = W.z[i]; if constexpr (OD) W.rhob[i] = W.rho[i]; }
         }
         if (e_opt <= p.tol) { status = SC_STATUS_OPTIMAL; break; }
+        // IPOPT's acceptable-point rule: acceptable_iter consecutive iterates within acceptable_tol end the solve (the
+        // best iterate is returned below)
+        n_acc = e_opt <= p.acceptable_tol ? n_acc + 1 : 0;
+        if (n_acc >= acc_iter) break;
         if (lmax > 1e10) { status = SC_STATUS_INFEASIBLE; break; }
         // barrier update
         for (;;) {

@@ -12,13 +12,15 @@ from safe_control_amd import workloads as W
 dev = torch.device("cuda:0")
 spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}
 NH = int(os.environ.get('SC_EXP_N', 10)); KO = int(os.environ.get('SC_EXP_K', 8))
-ctl = sca.BatchedMPCCBF(dict(spec), io_dtype="f32", horizon=NH)
+OD = os.environ.get('SC_EXP_OD') == '1'
+ctl = (sca.BatchedOptimalDecayMPCCBF if OD else sca.BatchedMPCCBF)(dict(spec), io_dtype="f32", horizon=NH)
 for B in [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384, 65536]:
     Xn, goal, un, on = W.du_cbfqp_batch(B, KO, seed=0)
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
     X, g, ob = t(Xn), t(goal), t(on)
     up = torch.zeros((B, 2), dtype=torch.float32, device=dev)
-    u, st, it = ctl.solve(X, up, g, ob)[:3]
+    r_ = ctl.solve(X, up, g, ob)
+    u, st, it = (r_[0], r_[2], r_[3]) if OD else r_[:3]
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
