@@ -6,7 +6,10 @@
 // whole rollout; the shared obstacle table lives in LDS (and moves there when dyn_obs).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "sc_qp2.hpp"
+#include "sc_group.hpp"
 
 namespace sc {
 
@@ -265,6 +268,293 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
     }
 }
 
+// ======================================================================================
+// Cooperative rollout: G lanes per agent (G = 8 or 16 >= num_constraints), one obstacle row per lane.
+//
+// With one agent per lane a 4096-agent rollout is 64 waves on 1024 SIMDs and a step is one wave's ~9 k
+// instructions (K rows built one after the other, sorted insertion over M obstacles, sequential walk).  Here the
+// G lanes of a group share one agent: the scalar parts (state machine, nominal input, Euler step) run redundantly
+// in every lane, the obstacle scan / selection / row build / QP walk / collision tests are split over the lanes:
+//   selection   lane sub scans obstacles sub, sub + G, ..; the rank of a candidate = number of candidates that
+//               come before it in (distance, index) order, counted against group broadcasts; rank r < G goes to
+//               lane r through a G-entry LDS slot -- the same order as the sorted insertion (ties: lower index)
+//   rows / QP   the cooperative walk of the CBF-QP kernel (sc_group.hpp)
+//   collisions  per-lane partial tests, group OR through the ballot
+// Same arithmetic per row and per obstacle as the lane-per-agent kernel, which stays as the fallback for
+// M > 4 G and as a cross-check (SC_TRACK_LANE_PER_AGENT=1).
+template <typename T, int G>
+__device__ __forceinline__ int group_sum_int(int v) {
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one round of the rank count: candidate (slot Q2, lane I) of every group against this lane's CM candidates
+template <typename TC, int G, int CM, int Q2, int I>
+__device__ __forceinline__ void rank_step(const TC (&cd)[CM], int (&rank)[CM], int sub) {
+    const TC od = group_bcast<TC, G, I>(cd[Q2], sub);
+    const int m2 = I + Q2 * G;
+#pragma unroll
+    for (int q = 0; q < CM; ++q) {
+        const int m = sub + q * G;
+        rank[q] += ((od < cd[q]) || (od == cd[q] && m2 < m)) ? 1 : 0;
+    }
+}
+template <typename TC, int G, int CM, int Q2, int... Is>
+__device__ __forceinline__ void rank_round(const TC (&cd)[CM], int (&rank)[CM], int sub, std::integer_sequence<int, Is...>) {
+    (rank_step<TC, G, CM, Q2, Is>(cd, rank, sub), ...);
+}
+
+template <typename T>
+__device__ __forceinline__ bool collides_one(const T x, const T y, const T* o, T R) {
+    const bool superell = (fabs_(o[6] - T(1)) <= T(1e-8) + T(1e-5)) && (o[4] >= T(2));     // np.isclose(flag, 1)
+    if (!superell) {
+        const T dx = x - o[0], dy = y - o[1];
+        return sqrt_(dx * dx + dy * dy) < o[2] + R;
+    }
+    T st, ct;
+    sincos_(o[5], &st, &ct);
+    const T px = ct * (x - o[0]) + st * (y - o[1]);
+    const T py = -st * (x - o[0]) + ct * (y - o[1]);
+    return pow_(px / (o[2] + R), o[4]) + pow_(py / (o[3] + R), o[4]) - T(1) <= T(0);
+}
+
+template <typename TIO, typename TC, int G, int MODEL>
+__global__ __launch_bounds__(64) void tracking_coop_kernel(
+        const sc_tracking_params p, const long long B, const int M,
+        TIO* __restrict__ X, const TIO* __restrict__ waypoints, const int* __restrict__ n_wp,
+        int* __restrict__ wp_index, int* __restrict__ state_machine, TIO* __restrict__ goal,
+        TIO* __restrict__ obs_table, TIO* __restrict__ u_last, int* __restrict__ ret_out, int* __restrict__ ret_step,
+        TIO* __restrict__ traj_X, TIO* __restrict__ traj_U) {
+    constexpr int APW = 64 / G;                                       // agents per wave
+    constexpr int CM = 4;                                             // obstacles per lane (M <= CM * G)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    TC* table = reinterpret_cast<TC*>(smem_raw);                     // [M][7]
+    int* sel = reinterpret_cast<int*>(table + (size_t)(M > 0 ? M : 1) * 7);   // [64]: selected obstacle of every lane
+    const int lane = threadIdx.x;
+    const int sub = lane & (G - 1);
+    const long long agent = (long long)blockIdx.x * APW + lane / G;
+    const bool active = agent < B;
+    const long long ag = active ? agent : 0;
+    const unsigned long long grp = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (lane & ~(G - 1));
+
+    for (int e = lane; e < M * 7; e += 64) table[e] = TC(obs_table[e]);
+    __syncthreads();
+
+    const CbfConsts<TC> k = make_consts<TC>(p.qp);
+    TrackConsts<TC> t;
+    t.reached = TC(p.reached_threshold); t.rot_thr = TC(p.rotation_threshold);
+    t.v_max = TC(p.v_max); t.v_min = TC(p.v_min);
+    t.k_omega = TC(p.k_omega); t.k_a = TC(p.k_a); t.k_v = TC(p.k_v);
+    t.delta_max = TC(p.delta_max); t.wheel_base = TC(p.wheel_base); t.Lr = TC(p.qp.rear_ax_dist); t.dt = TC(p.qp.dt);
+    t.enable_rotation = p.enable_rotation; t.dyn_obs = p.dyn_obs; t.K = p.num_constraints;
+    const TC pi = TC(3.14159265358979323846);
+    const TC half_unpassed = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? TC(1.2) * pi / TC(2) : pi;   // tracking.py:352-357
+
+    TC x = TC(X[ag * 4 + 0]), y = TC(X[ag * 4 + 1]), th = TC(X[ag * 4 + 2]), v = TC(X[ag * 4 + 3]);
+    int wp = wp_index[ag], sm = state_machine[ag];
+    TC gx = TC(goal[ag * 3 + 0]), gy = TC(goal[ag * 3 + 1]);
+    bool gvalid = goal[ag * 3 + 2] != TIO(0);
+    int ret = active ? ret_out[ag] : -2;
+    int rstep = -1;
+    const int W = p.max_waypoints;
+    const TIO* wps = waypoints + (p.waypoints_shared ? 0 : (size_t)ag * W * 2);
+    const int nw = n_wp[p.waypoints_shared ? 0 : ag];
+    TC ul0 = TC(0), ul1 = TC(0);
+
+    auto wp_x = [&](int i) { return TC(wps[2 * i]); };
+    auto wp_y = [&](int i) { return TC(wps[2 * i + 1]); };
+    auto update_goal = [&]() {                                       // tracking.py:497-535
+        if (sm == SC_SM_ROTATE) {
+            const int i = wp < nw ? wp : nw - 1;
+            const TC rx = wp_x(i), ry = wp_y(i);
+            const TC goal_angle = atan2_(ry - y, rx - x);
+            if (!t.enable_rotation) sm = SC_SM_TRACK;
+            if (fabs_(th - goal_angle) > t.rot_thr) { gx = rx; gy = ry; gvalid = true; return; }
+            sm = SC_SM_TRACK;
+        }
+        if (wp >= nw) { gvalid = false; return; }
+        {
+            const TC dx = x - wp_x(wp), dy = y - wp_y(wp);
+            if (sqrt_(dx * dx + dy * dy) < t.reached) {
+                wp += 1;
+                if (wp >= nw) { sm = SC_SM_IDLE; gvalid = false; return; }
+            }
+        }
+        gx = wp_x(wp); gy = wp_y(wp); gvalid = true;
+    };
+    auto group_any = [&](bool b) { return (__builtin_amdgcn_ballot_w64(b) & grp) != 0ull; };
+    auto collides_group = [&](TC px_, TC py_) {
+        bool hit = false;
+#pragma unroll
+        for (int q = 0; q < CM; ++q) {
+            const int m = sub + q * G;
+            if (m < M) hit |= collides_one<TC>(px_, py_, table + 7 * m, k.R);
+        }
+        return group_any(hit);
+    };
+
+    for (int step = 0; step < p.n_steps; ++step) {
+        const bool run = (ret == 0);
+        if (run) {
+            if (sm == SC_SM_STOP) {                                   // tracking.py:569-577
+                if (fabs_(v) < TC(0.05)) {
+                    sm = t.enable_rotation ? SC_SM_ROTATE : SC_SM_TRACK;
+                    update_goal();
+                }
+            } else {
+                update_goal();
+            }
+        }
+        // ---- nearest unpassed obstacles (tracking.py:345-403) ---------------------------------------
+        TC cd[CM];
+        int ci[CM];
+        bool inview[CM];
+        int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < CM; ++q) {
+            const int m = sub + q * G;
+            const bool valid = m < M;
+            const TC* o = table + 7 * (valid ? m : 0);
+            const TC ox = o[0], oy = o[1];
+            const TC ang = atan2_(oy - y, ox - x);
+            inview[q] = valid && (fabs_(angle_normalize(ang - th)) <= half_unpassed);
+            cnt += inview[q] ? 1 : 0;
+            const TC dx = ox - x, dy = oy - y;
+            cd[q] = sqrt_(dx * dx + dy * dy);
+            ci[q] = valid ? m : -1;
+        }
+        const bool use_all = group_sum_int<TC, G>(cnt) == 0;
+#pragma unroll
+        for (int q = 0; q < CM; ++q) {
+            const bool pass = (ci[q] >= 0) && (use_all || inview[q]);
+            cd[q] = pass ? cd[q] : num<TC>::inf();
+            ci[q] = pass ? ci[q] : -1;
+        }
+        int rank[CM] = {0, 0, 0, 0};
+        rank_round<TC, G, CM, 0>(cd, rank, sub, std::make_integer_sequence<int, G>{});
+        if (M > G) rank_round<TC, G, CM, 1>(cd, rank, sub, std::make_integer_sequence<int, G>{});
+        if (M > 2 * G) rank_round<TC, G, CM, 2>(cd, rank, sub, std::make_integer_sequence<int, G>{});
+        if (M > 3 * G) rank_round<TC, G, CM, 3>(cd, rank, sub, std::make_integer_sequence<int, G>{});
+        sel[lane] = -1;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CM; ++q)
+            if (sub + q * G < M && rank[q] < G) sel[(lane & ~(G - 1)) + rank[q]] = ci[q];
+        __syncthreads();
+        const int si = sel[lane];
+        // ---- this lane's row -------------------------------------------------------------------------
+        const Agent<TC> agn = make_agent<TC>(x, y, th, v);
+        const bool used = (sub < t.K) && (si >= 0);
+        TC a0, a1, cc;
+        TC poison = TC(0);
+        bool bad_mine;
+        {
+            const TC* orow = table + 7 * (si >= 0 ? si : 0);
+            TC o[7];
+#pragma unroll
+            for (int f = 0; f < 7; ++f) o[f] = orow[f];
+            TC h;
+            const bool ok = cbf_row<TC, MODEL, true>(agn, o, k, a0, a1, cc, h);
+            bad_mine = used && !ok;
+            a0 = used ? a0 : TC(0); a1 = used ? a1 : TC(0); cc = used ? cc : TC(0);
+            normalise_row(a0, a1, cc, poison);
+        }
+        // moving obstacles advance AFTER the selection (dynamic_env/main.py:147-150): the solve sees the old table
+        __syncthreads();
+        if (t.dyn_obs) {
+            for (int m = lane; m < M; m += 64) {
+                table[7 * m] += table[7 * m + 3] * t.dt;
+                table[7 * m + 1] += table[7 * m + 4] * t.dt;
+            }
+        }
+        __syncthreads();
+        // ---- nominal input (tracking.py:589-604) ------------------------------------------------
+        TC ur0, ur1;
+        if (sm == SC_SM_ROTATE) {
+            const TC ga = atan2_(gy - y, gx - x);
+            ur0 = TC(0); ur1 = TC(2) * angle_normalize(ga - th);           // rotate_to, k = 2
+        } else if (!gvalid) {
+            ur0 = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? t.k_a * (TC(0) - v) : TC(0);   // stop()
+            ur1 = TC(0);
+        } else {
+            nominal_input<TC, MODEL>(x, y, th, v, gx, gy, t, ur0, ur1);
+        }
+        // ---- cooperative solve (cbf_qp.py:108-199) ---------------------------------------------------
+        TC u0, u1;
+        int st;
+        if (M == 0) { u0 = ur0; u1 = ur1; st = SC_STATUS_OPTIMAL; }         // obs_list None: u_ref unclipped
+        else {
+            QpState<TC> S;
+            qp_begin(S, ur0, ur1, k);
+            coop_walk<TC, G>(S, t.K, sub, a0, a1, cc, k, std::make_integer_sequence<int, G>{});
+            qp_finish_box(S, k);
+            TC worst = qp_row_margin(num<TC>::inf(), a0, a1, cc, S.u0, S.u1, poison);
+            worst = group_min<TC, G>(worst);
+            if (group_any(!(poison == poison))) poison = num<TC>::nan();
+            st = qp_status(S, worst, poison, k);
+            if (group_any(bad_mine)) st = SC_STATUS_BAD_OBSTACLE;
+            u0 = S.u0; u1 = S.u1;
+        }
+        // ---- collision / status / step (tracking.py:627-646) ---------------------------------------
+        const bool pre_fail = (st != SC_STATUS_OPTIMAL) || collides_group(x, y);
+        TC nx, ny, nth, nv;
+        if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) {
+            nx = x + (agn.f0) * t.dt; ny = y + (agn.f1) * t.dt;
+            nth = th + (TC(0) + u1) * t.dt; nv = v + (TC(0) + u0) * t.dt;
+        } else {
+            nx = x + (agn.f0 + (-agn.f1) * u1) * t.dt;
+            ny = y + (agn.f1 + agn.f0 * u1) * t.dt;
+            nth = th + (TC(0) + (v / t.Lr) * u1) * t.dt;
+            nv = v + (TC(0) + u0) * t.dt;
+            nv = fmin_(fmax_(nv, t.v_min), t.v_max);                        // np.clip in KinematicBicycle2D.step
+        }
+        nth = angle_normalize(nth);
+        const bool post_hit = collides_group(nx, ny);
+        int code;
+        if (pre_fail) code = -2;
+        else if (post_hit) code = -2;                                       // post-step: the robot HAS moved
+        else code = (!gvalid && sm != SC_SM_STOP) ? -1 : 0;                  // tracking.py:666-667
+        if (run) {
+            if (!pre_fail) { x = nx; y = ny; th = nth; v = nv; ul0 = u0; ul1 = u1; }
+            if (code != 0) { ret = code; rstep = step; }
+        }
+        if (active && sub == 0 && traj_X) {
+            TIO* tx = traj_X + ((size_t)step * B + agent) * 4;
+            tx[0] = TIO(x); tx[1] = TIO(y); tx[2] = TIO(th); tx[3] = TIO(v);
+        }
+        if (active && sub == 0 && traj_U) {
+            TIO* tu = traj_U + ((size_t)step * B + agent) * 2;
+            tu[0] = TIO(ul0); tu[1] = TIO(ul1);
+        }
+    }
+
+    if (active && sub == 0) {
+        X[agent * 4 + 0] = TIO(x); X[agent * 4 + 1] = TIO(y); X[agent * 4 + 2] = TIO(th); X[agent * 4 + 3] = TIO(v);
+        wp_index[agent] = wp; state_machine[agent] = sm;
+        goal[agent * 3 + 0] = TIO(gx); goal[agent * 3 + 1] = TIO(gy); goal[agent * 3 + 2] = gvalid ? TIO(1) : TIO(0);
+        u_last[agent * 2 + 0] = TIO(ul0); u_last[agent * 2 + 1] = TIO(ul1);
+        ret_out[agent] = ret; ret_step[agent] = rstep;
+    }
+    if (blockIdx.x == 0 && t.dyn_obs) {
+        __syncthreads();
+        for (int e = lane; e < M * 7; e += 64) obs_table[e] = TIO(table[e]);
+    }
+}
+
+template <typename TIO, typename TC, int G, int MODEL>
+static hipError_t launch_track_coop(const sc_tracking_params& p, long long B, int M, void* X, const void* wps, const int* n_wp,
+                                    int* wp_index, int* sm, void* goal, void* table, void* u_last, int* ret, int* ret_step,
+                                    void* tX, void* tU, hipStream_t stream) {
+    constexpr int APW = 64 / G;
+    const unsigned blocks = (unsigned)((B + APW - 1) / APW);
+    const size_t lds = (size_t)(M > 0 ? M : 1) * 7 * sizeof(TC) + 64 * sizeof(int);
+    auto kern = tracking_coop_kernel<TIO, TC, G, MODEL>;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, p, B, M, (TIO*)X, (const TIO*)wps, n_wp, wp_index, sm,
+                       (TIO*)goal, (TIO*)table, (TIO*)u_last, ret, ret_step, (TIO*)tX, (TIO*)tU);
+    return hipGetLastError();
+}
+
 template <typename TIO, typename TC, int KMAX, int MODEL>
 static hipError_t launch_track(const sc_tracking_params& p, long long B, int M, void* X, const void* wps, const int* n_wp,
                                int* wp_index, int* sm, void* goal, void* table, void* u_last, int* ret, int* ret_step,
@@ -285,6 +575,14 @@ template <typename TIO, typename TC, int MODEL>
 static hipError_t launch_track_k(const sc_tracking_params& p, long long B, int M, void* X, const void* wps, const int* n_wp,
                                  int* wp_index, int* sm, void* goal, void* table, void* u_last, int* ret, int* ret_step,
                                  void* tX, void* tU, hipStream_t stream) {
+    const char* env_lpa = std::getenv("SC_TRACK_LANE_PER_AGENT");        // read per call: the tests flip it
+    const bool lane_per_agent = env_lpa && env_lpa[0] == '1';
+    if (!lane_per_agent) {
+        if (p.num_constraints <= 8 && M <= 32)
+            return launch_track_coop<TIO, TC, 8, MODEL>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+        if (M <= 64)
+            return launch_track_coop<TIO, TC, 16, MODEL>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+    }
     if (p.num_constraints <= 8)
         return launch_track<TIO, TC, 8, MODEL>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
     return launch_track<TIO, TC, 16, MODEL>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);

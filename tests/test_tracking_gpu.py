@@ -109,3 +109,36 @@ def test_no_obstacles_passes_u_ref_through():
     ret, tX, tU = ctl.control_step(100, record=True)
     Xo, rets, t = oracle_rollout(R.MODEL_DU, X0[0], {k: v for k, v in spec.items() if k != "model"}, None, wps, 100)
     np.testing.assert_allclose(tX.cpu().numpy()[: len(rets), 0], Xo, rtol=1e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize("num_constraints,n_obs", [(10, 14), (8, 14), (4, 40)])
+def test_cooperative_and_lane_per_agent_kernels_agree(golden_dir, num_constraints, n_obs):
+    """The cooperative rollout (G lanes per agent: ranked selection, one row per lane, cooperative walk) and the
+    lane-per-agent rollout (sorted insertion, sequential walk) are two implementations of the same step."""
+    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    rng = np.random.default_rng(7)
+    obs = g["du14/obs"]
+    if n_obs > len(obs):                                         # extra small circles, some at equal distances (ties)
+        extra = np.zeros((n_obs - len(obs), 7))
+        extra[:, 0:2] = rng.uniform(0.5, 13.5, (len(extra), 2))
+        extra[:, 2] = 0.15
+        extra[1] = extra[0]                                      # a duplicate: identical distance from every agent
+        obs = np.vstack([obs, extra])
+    B, T = 200, 150
+    spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25, "num_constraints": num_constraints}
+    X0 = np.column_stack([rng.uniform(0.5, 13.5, (B, 2)), rng.uniform(-np.pi, np.pi, B), rng.uniform(0, 1, B)])
+    wl = [rng.uniform(1, 13, (3, 2)) for _ in range(B)]
+    out = {}
+    for mode in ("0", "1"):
+        os.environ["SC_TRACK_LANE_PER_AGENT"] = mode
+        try:
+            ctl = sca.BatchedTrackingController(X0, dict(spec), obs=obs, io_dtype="f64")
+            ctl.set_waypoints(wl)
+            ret, tX, tU = ctl.control_step(T, record=True)
+            out[mode] = (ret.cpu().numpy(), tX.cpu().numpy(), tU.cpu().numpy(), ctl.ret_step.cpu().numpy())
+        finally:
+            os.environ.pop("SC_TRACK_LANE_PER_AGENT", None)
+    assert np.array_equal(out["0"][0], out["1"][0]) and np.array_equal(out["0"][3], out["1"][3])
+    np.testing.assert_allclose(out["0"][1], out["1"][1], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(out["0"][2], out["1"][2], rtol=0, atol=1e-9)
+    assert (out["0"][0] != 0).any() and (out["0"][0] == 0).any()
