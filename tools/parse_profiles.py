@@ -26,7 +26,7 @@ src = os.path.join(ROOT, "gpurun_out", f"profiles_{rnd}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-OURS = ("cbfqp", "mpccbf", "tracking_rollout", "neighbor_kernel", "odcbfqp")
+OURS = ("cbfqp", "mpccbf", "tracking_rollout", "tracking_coop", "neighbor_kernel", "odcbfqp")
 
 
 def counters(path):
