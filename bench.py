@@ -132,6 +132,35 @@ def mpc_leg(dev, B, K, N, steps, warmup, seed=0, cpu_seconds=0.0):
             "achieved_GBs": nbytes / (ms * 1e-3) / 1e9, "algorithmic_bytes_per_solve": nbytes // B}
 
 
+def closed_loop_mpc_leg(dev, B=4096, T=20):
+    """Closed loop with the reference's default position controller (examples/test_tracking.py:15, --algo mpc_cbf):
+    per step select -> one MPC-CBF launch for the batch -> apply, on the 14-circle scene."""
+    import numpy as np
+    import torch
+    import safe_control_amd as sca
+    obs = np.array([[2.2, 5.0, 0.2], [3.0, 5.0, 0.2], [4.0, 9.0, 0.3], [1.5, 10.0, 0.5], [9.0, 11.0, 1.0], [7.0, 7.0, 3.0],
+                    [4.0, 3.5, 1.5], [10.0, 7.3, 0.4], [6.0, 13.0, 0.7], [5.0, 10.0, 0.6], [11.0, 5.0, 0.8],
+                    [13.5, 11.0, 0.6], [2.0, 7.0, 0.7], [2.0, 8.0, 0.5]])
+    rng = np.random.default_rng(0)
+    P = rng.uniform(0.5, 13.5, (4 * B, 2))                                       # starts at least 0.6 m clear of every circle
+    clear = (np.hypot(P[:, None, 0] - obs[None, :, 0], P[:, None, 1] - obs[None, :, 1]) - obs[None, :, 2]).min(axis=1) > 0.85
+    P = P[clear][:B]
+    X0 = np.column_stack([P, rng.uniform(-np.pi, np.pi, B), rng.uniform(0, 1, B)])
+    spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25, "num_constraints": 8}
+    ctl = sca.BatchedTrackingController(X0, spec, controller_type={"pos": "mpc_cbf"}, obs=obs, io_dtype="f32", device=str(dev))
+    ctl.set_waypoints(np.array([[2.0, 2.0], [2.0, 12.0], [12.0, 12.0], [12.0, 2.0]]))
+    ctl.control_step(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctl.control_step(T)
+    torch.cuda.synchronize()
+    dt_ = time.perf_counter() - t0
+    return {"workload": f"{B} DynamicUnicycle2D agents x {T} closed-loop control steps, MPC-CBF (N=10, 8 nearest obstacles) "
+                        "as position controller, 14 shared obstacles",
+            "ms_per_control_step": 1e3 * dt_ / T, "agent_steps_per_s": B * T / dt_,
+            "running": int((ctl.ret == 0).sum().item()), "dtype": "f64", "storage": "f32"}
+
+
 def od_mpc_leg(dev, B=4096, K=8, N=10, steps=2, seed=0):
     """Optimal-decay MPC-CBF on the config-3 batch: two decay variables per stage."""
     import torch
@@ -336,6 +365,7 @@ def main():
                                      cpu_seconds=0.0 if a.no_cpu_baseline else 6.0)
             res["od_mpc_cbf"] = od_mpc_leg(dev)
             res["closed_loop"] = closed_loop_leg(dev)
+            res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
         if ws == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(X.double().cpu().numpy(), ur.double().cpu().numpy(),
                                                ob.double().cpu().numpy(), a.cpu_seconds)

@@ -284,6 +284,28 @@ int sc_tracking_rollout_batch(const sc_tracking_params* params, int64_t B, int32
                               void* obs_table, void* u_last, int32_t* ret, int32_t* ret_step,
                               void* traj_X, void* traj_U, void* stream);
 
+/* control_step split around the solve, for position controllers that are their own launch (MPC-CBF, optimal-decay
+ * MPC-CBF; the reference's default `--algo mpc_cbf`, examples/test_tracking.py:15):
+ *   sc_tracking_select_batch = tracking.py:569-609: state machine / goal update, nearest-unpassed selection
+ *     (num_constraints rows, missing rows padded [1000,1000,0,..] like MPCCBF.update_tvp, mpc_cbf.py:338-364) and the
+ *     nominal input.  Outputs obs_out [B,K,7], goal_out [B,2] (the agent's own position when it has no goal),
+ *     u_ref_out [B,2], track_out [B] = 1 where control_ref['state_machine'] == 'track' (the controllers pass u_ref
+ *     through otherwise, mpc_cbf.py:379-381).  wp_index / state_machine / goal are updated in place.
+ *   sc_tracking_apply_batch = tracking.py:627-668: collision checks, robot.step(u), return codes.  u [B,2] is the
+ *     input to apply; u_status [B] (SC_STATUS_*) or NULL when the controller never reports failure (MPCCBF.status is
+ *     hard-wired to 'optimal', mpc_cbf.py:10).  DynamicUnicycle2D and the KinematicBicycle2D family; static tables.
+ */
+int sc_tracking_select_batch(const sc_tracking_params* params, int64_t B, int32_t M,
+                             const void* X, const void* waypoints, const int32_t* n_wp,
+                             int32_t* wp_index, int32_t* state_machine, void* goal,
+                             const void* obs_table, const int32_t* ret,
+                             void* obs_out, void* goal_out, void* u_ref_out, int32_t* track_out, void* stream);
+
+int sc_tracking_apply_batch(const sc_tracking_params* params, int64_t B, int32_t M, int32_t step_index,
+                            void* X, const int32_t* state_machine, const void* goal, const void* obs_table,
+                            const void* u, const int32_t* u_status, void* u_last,
+                            int32_t* ret, int32_t* ret_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,6 +105,8 @@ SYMBOLS = {
     "sc_neighbor_obstacles_batch": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double,
                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "sc_tracking_rollout_batch": (C.c_int, [C.POINTER(TrackingParams), C.c_int64, C.c_int32] + [C.c_void_p] * 13),
+    "sc_tracking_select_batch": (C.c_int, [C.POINTER(TrackingParams), C.c_int64, C.c_int32] + [C.c_void_p] * 13),
+    "sc_tracking_apply_batch": (C.c_int, [C.POINTER(TrackingParams), C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 10),
     "sc_mpccbf_solve_batch_host": (C.c_int, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_int]),

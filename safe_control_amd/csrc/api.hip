@@ -23,6 +23,12 @@ hipError_t neighbors_launch(int io_dtype, long long B_all, long long first, long
                             void* out, hipStream_t stream);
 hipError_t odcbfqp_launch(const sc_odcbfqp_params& p, long long B, const void* X, const void* u_ref, const void* obs,
                           const int* has_obs, void* u_out, void* w_out, int* status, void* h_out, hipStream_t stream);
+hipError_t tracking_select_launch(const sc_tracking_params& p, long long B, int M, const void* X, const void* wps,
+                                  const int* n_wp, int* wp_index, int* sm, void* goal, const void* table, const int* ret,
+                                  void* obs_out, void* goal_out, void* u_ref_out, int* track_out, hipStream_t stream);
+hipError_t tracking_apply_launch(const sc_tracking_params& p, long long B, int M, int step_index, void* X, const int* sm,
+                                 const void* goal, const void* table, const void* u, const int* u_status, void* u_last,
+                                 int* ret, int* ret_step, hipStream_t stream);
 hipError_t tracking_launch(const sc_tracking_params& p, long long B, int M, void* X, const void* wps, const int* n_wp,
                            int* wp_index, int* sm, void* goal, void* table, void* u_last, int* ret, int* ret_step,
                            void* tX, void* tU, hipStream_t stream);
@@ -298,6 +304,55 @@ int sc_tracking_rollout_batch(const sc_tracking_params* params, int64_t B, int32
     hipError_t e = sc::tracking_launch(*params, (long long)B, (int)M, X, waypoints, n_wp, wp_index, state_machine, goal,
                                        obs_table, u_last, ret, ret_step, traj_X, traj_U, (hipStream_t)stream);
     if (e != hipSuccess) return sc::fail_hip(e, "tracking kernel launch");
+    return SC_OK;
+}
+
+static int check_tracking_split(const sc_tracking_params* params, int64_t B, int32_t M) {
+    if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    const sc_cbfqp_params* q = &params->qp;
+    if (B < 0 || M < 0) return sc::fail(SC_ERR_INVALID_ARGUMENT, "B < 0 or M < 0");
+    if (q->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && q->model_id != SC_MODEL_KINEMATIC_BICYCLE2D)
+        return sc::fail(SC_ERR_UNSUPPORTED, "select / apply are built for DynamicUnicycle2D and KinematicBicycle2D");
+    if (q->io_dtype != SC_DTYPE_F32 && q->io_dtype != SC_DTYPE_F64)
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
+    if (params->num_constraints < 1 || params->num_constraints > SC_TRACKING_MAX_CONSTRAINTS)
+        return sc::fail(SC_ERR_UNSUPPORTED, "num_constraints outside [1, SC_TRACKING_MAX_CONSTRAINTS]");
+    if (params->dyn_obs) return sc::fail(SC_ERR_UNSUPPORTED, "select / apply take a static obstacle table");
+    if (!(q->dt > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "dt must be > 0");
+    if (q->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && (!(q->rear_ax_dist > 0) || !(params->wheel_base > 0)))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "rear_ax_dist and wheel_base must be > 0 for the KinematicBicycle2D family");
+    if ((size_t)M * 7 * 8 > 160 * 1024) return sc::fail(SC_ERR_UNSUPPORTED, "obstacle table does not fit the LDS");
+    return SC_OK;
+}
+
+int sc_tracking_select_batch(const sc_tracking_params* params, int64_t B, int32_t M, const void* X, const void* waypoints,
+                             const int32_t* n_wp, int32_t* wp_index, int32_t* state_machine, void* goal,
+                             const void* obs_table, const int32_t* ret, void* obs_out, void* goal_out, void* u_ref_out,
+                             int32_t* track_out, void* stream) {
+    int rc = check_tracking_split(params, B, M);
+    if (rc != SC_OK) return rc;
+    if (params->max_waypoints < 1) return sc::fail(SC_ERR_INVALID_ARGUMENT, "max_waypoints < 1");
+    if (B > 0 && (!X || !waypoints || !n_wp || !wp_index || !state_machine || !goal || !ret || !obs_out || !goal_out ||
+                  !u_ref_out || !track_out || (M > 0 && !obs_table)))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::tracking_select_launch(*params, (long long)B, (int)M, X, waypoints, n_wp, wp_index, state_machine, goal,
+                                              obs_table, ret, obs_out, goal_out, u_ref_out, track_out, (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "tracking select kernel launch");
+    return SC_OK;
+}
+
+int sc_tracking_apply_batch(const sc_tracking_params* params, int64_t B, int32_t M, int32_t step_index, void* X,
+                            const int32_t* state_machine, const void* goal, const void* obs_table, const void* u,
+                            const int32_t* u_status, void* u_last, int32_t* ret, int32_t* ret_step, void* stream) {
+    int rc = check_tracking_split(params, B, M);
+    if (rc != SC_OK) return rc;
+    if (B > 0 && (!X || !state_machine || !goal || !u || !u_last || !ret || !ret_step || (M > 0 && !obs_table)))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::tracking_apply_launch(*params, (long long)B, (int)M, (int)step_index, X, state_machine, goal, obs_table,
+                                             u, u_status, u_last, ret, ret_step, (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "tracking apply kernel launch");
     return SC_OK;
 }
 

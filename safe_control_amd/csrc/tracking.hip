@@ -269,6 +269,178 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
 }
 
 // ======================================================================================
+// control_step split around the solve, for position controllers that are their own launch (MPC-CBF, optimal-decay
+// MPC-CBF): `select` is everything before pos_controller.solve_control_problem (tracking.py:569-609), `apply`
+// everything after it (:627-668).  One agent per lane (the solve between them dominates).
+template <typename TIO, typename TC, int KMAX, int MODEL>
+__global__ __launch_bounds__(64) void tracking_select_kernel(
+        const sc_tracking_params p, const long long B, const int M,
+        const TIO* __restrict__ X, const TIO* __restrict__ waypoints, const int* __restrict__ n_wp,
+        int* __restrict__ wp_index, int* __restrict__ state_machine, TIO* __restrict__ goal,
+        const TIO* __restrict__ obs_table, const int* __restrict__ ret_in,
+        TIO* __restrict__ obs_out, TIO* __restrict__ goal_out, TIO* __restrict__ u_ref_out, int* __restrict__ track_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    TC* table = reinterpret_cast<TC*>(smem_raw);                     // [M][7]
+    const int lane = threadIdx.x;
+    const long long agent = (long long)blockIdx.x * 64 + lane;
+    const bool active = agent < B;
+    const long long ag = active ? agent : 0;
+    for (int e = lane; e < M * 7; e += 64) table[e] = TC(obs_table[e]);
+    __syncthreads();
+
+    TrackConsts<TC> t;
+    t.reached = TC(p.reached_threshold); t.rot_thr = TC(p.rotation_threshold);
+    t.v_max = TC(p.v_max); t.v_min = TC(p.v_min);
+    t.k_omega = TC(p.k_omega); t.k_a = TC(p.k_a); t.k_v = TC(p.k_v);
+    t.delta_max = TC(p.delta_max); t.wheel_base = TC(p.wheel_base); t.Lr = TC(p.qp.rear_ax_dist); t.dt = TC(p.qp.dt);
+    t.enable_rotation = p.enable_rotation; t.dyn_obs = 0; t.K = p.num_constraints;
+    const TC pi = TC(3.14159265358979323846);
+    const TC half_unpassed = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? TC(1.2) * pi / TC(2) : pi;
+
+    const TC x = TC(X[ag * 4 + 0]), y = TC(X[ag * 4 + 1]), th = TC(X[ag * 4 + 2]), v = TC(X[ag * 4 + 3]);
+    int wp = wp_index[ag], sm = state_machine[ag];
+    TC gx = TC(goal[ag * 3 + 0]), gy = TC(goal[ag * 3 + 1]);
+    bool gvalid = goal[ag * 3 + 2] != TIO(0);
+    const bool run = active && ret_in[ag] == 0;
+    const int W = p.max_waypoints;
+    const TIO* wps = waypoints + (p.waypoints_shared ? 0 : (size_t)ag * W * 2);
+    const int nw = n_wp[p.waypoints_shared ? 0 : ag];
+    auto wp_x = [&](int i) { return TC(wps[2 * i]); };
+    auto wp_y = [&](int i) { return TC(wps[2 * i + 1]); };
+    auto update_goal = [&]() {                                       // tracking.py:497-535
+        if (sm == SC_SM_ROTATE) {
+            const int i = wp < nw ? wp : nw - 1;
+            const TC rx = wp_x(i), ry = wp_y(i);
+            const TC goal_angle = atan2_(ry - y, rx - x);
+            if (!t.enable_rotation) sm = SC_SM_TRACK;
+            if (fabs_(th - goal_angle) > t.rot_thr) { gx = rx; gy = ry; gvalid = true; return; }
+            sm = SC_SM_TRACK;
+        }
+        if (wp >= nw) { gvalid = false; return; }
+        {
+            const TC dx = x - wp_x(wp), dy = y - wp_y(wp);
+            if (sqrt_(dx * dx + dy * dy) < t.reached) {
+                wp += 1;
+                if (wp >= nw) { sm = SC_SM_IDLE; gvalid = false; return; }
+            }
+        }
+        gx = wp_x(wp); gy = wp_y(wp); gvalid = true;
+    };
+    if (run) {
+        if (sm == SC_SM_STOP) {
+            if (fabs_(v) < TC(0.05)) {
+                sm = t.enable_rotation ? SC_SM_ROTATE : SC_SM_TRACK;
+                update_goal();
+            }
+        } else {
+            update_goal();
+        }
+    }
+    // nearest unpassed obstacles (tracking.py:345-403): K smallest centre distances
+    TC sd[KMAX];
+    int si[KMAX];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) { sd[j] = num<TC>::inf(); si[j] = -1; }
+    int n_unpassed = 0;
+    for (int m = 0; m < M; ++m) {
+        const TC ang = atan2_(table[7 * m + 1] - y, table[7 * m] - x);
+        n_unpassed += (fabs_(angle_normalize(ang - th)) <= half_unpassed) ? 1 : 0;
+    }
+    const bool use_all = n_unpassed == 0;
+    for (int m = 0; m < M; ++m) {
+        const TC ox = table[7 * m], oy = table[7 * m + 1];
+        const TC ang = atan2_(oy - y, ox - x);
+        const bool pass = use_all || (fabs_(angle_normalize(ang - th)) <= half_unpassed);
+        const TC dx = ox - x, dy = oy - y;
+        TC cd = pass ? sqrt_(dx * dx + dy * dy) : num<TC>::inf();
+        int ci = pass ? m : -1;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            const bool sw = cd < sd[j];
+            const TC td = sd[j]; const int ti = si[j];
+            sd[j] = sw ? cd : td; si[j] = sw ? ci : ti;
+            cd = sw ? td : cd; ci = sw ? ti : ci;
+        }
+    }
+    TC ur0, ur1;
+    if (sm == SC_SM_ROTATE) {
+        const TC ga = atan2_(gy - y, gx - x);
+        ur0 = TC(0); ur1 = TC(2) * angle_normalize(ga - th);
+    } else if (!gvalid) {
+        ur0 = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? t.k_a * (TC(0) - v) : TC(0);
+        ur1 = TC(0);
+    } else {
+        nominal_input<TC, MODEL>(x, y, th, v, gx, gy, t, ur0, ur1);
+    }
+    if (active) {
+        wp_index[agent] = wp; state_machine[agent] = sm;
+        goal[agent * 3 + 0] = TIO(gx); goal[agent * 3 + 1] = TIO(gy); goal[agent * 3 + 2] = gvalid ? TIO(1) : TIO(0);
+        // obstacle rows for the solve, padded like MPCCBF.update_tvp (mpc_cbf.py:338-364)
+        TIO* oo = obs_out + (size_t)agent * t.K * 7;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            if (j >= t.K) break;
+            const bool have = si[j] >= 0;
+            const TC* orow = table + 7 * (have ? si[j] : 0);
+#pragma unroll
+            for (int f = 0; f < 7; ++f) oo[j * 7 + f] = have ? TIO(orow[f]) : (f < 2 ? TIO(1000) : TIO(0));
+        }
+        goal_out[agent * 2 + 0] = TIO(gvalid ? gx : x); goal_out[agent * 2 + 1] = TIO(gvalid ? gy : y);
+        u_ref_out[agent * 2 + 0] = TIO(ur0); u_ref_out[agent * 2 + 1] = TIO(ur1);
+        track_out[agent] = (run && sm == SC_SM_TRACK && gvalid) ? 1 : 0;
+    }
+}
+
+template <typename TIO, typename TC, int MODEL>
+__global__ __launch_bounds__(64) void tracking_apply_kernel(
+        const sc_tracking_params p, const long long B, const int M, const int step_index,
+        TIO* __restrict__ X, const int* __restrict__ state_machine, const TIO* __restrict__ goal,
+        const TIO* __restrict__ obs_table, const TIO* __restrict__ u, const int* __restrict__ u_status,
+        TIO* __restrict__ u_last, int* __restrict__ ret_out, int* __restrict__ ret_step) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    TC* table = reinterpret_cast<TC*>(smem_raw);
+    const int lane = threadIdx.x;
+    const long long agent = (long long)blockIdx.x * 64 + lane;
+    const bool active = agent < B;
+    const long long ag = active ? agent : 0;
+    for (int e = lane; e < M * 7; e += 64) table[e] = TC(obs_table[e]);
+    __syncthreads();
+    const CbfConsts<TC> k = make_consts<TC>(p.qp);
+    const TC dt = TC(p.qp.dt), Lr = TC(p.qp.rear_ax_dist);
+    const TC x = TC(X[ag * 4 + 0]), y = TC(X[ag * 4 + 1]), th = TC(X[ag * 4 + 2]), v = TC(X[ag * 4 + 3]);
+    const int sm = state_machine[ag];
+    const bool gvalid = goal[ag * 3 + 2] != TIO(0);
+    const TC u0 = TC(u[ag * 2 + 0]), u1 = TC(u[ag * 2 + 1]);
+    const int st = u_status ? u_status[ag] : SC_STATUS_OPTIMAL;
+    const bool run = active && ret_out[ag] == 0;
+    const Agent<TC> agn = make_agent<TC>(x, y, th, v);
+    const bool pre_fail = (st != SC_STATUS_OPTIMAL) || collides<TC>(x, y, table, M, k.R);
+    TC nx, ny, nth, nv;
+    if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) {
+        nx = x + (agn.f0) * dt; ny = y + (agn.f1) * dt;
+        nth = th + (TC(0) + u1) * dt; nv = v + (TC(0) + u0) * dt;
+    } else {
+        nx = x + (agn.f0 + (-agn.f1) * u1) * dt;
+        ny = y + (agn.f1 + agn.f0 * u1) * dt;
+        nth = th + (TC(0) + (v / Lr) * u1) * dt;
+        nv = v + (TC(0) + u0) * dt;
+        nv = fmin_(fmax_(nv, TC(p.v_min)), TC(p.v_max));
+    }
+    nth = angle_normalize(nth);
+    int code;
+    if (pre_fail) code = -2;
+    else if (collides<TC>(nx, ny, table, M, k.R)) code = -2;
+    else code = (!gvalid && sm != SC_SM_STOP) ? -1 : 0;
+    if (run) {
+        if (!pre_fail) {
+            X[agent * 4 + 0] = TIO(nx); X[agent * 4 + 1] = TIO(ny); X[agent * 4 + 2] = TIO(nth); X[agent * 4 + 3] = TIO(nv);
+            u_last[agent * 2 + 0] = TIO(u0); u_last[agent * 2 + 1] = TIO(u1);
+        }
+        if (code != 0) { ret_out[agent] = code; ret_step[agent] = step_index; }
+    }
+}
+
+// ======================================================================================
 // Cooperative rollout: G lanes per agent (G = 8 or 16 >= num_constraints), one obstacle row per lane.
 //
 // With one agent per lane a 4096-agent rollout is 64 waves on 1024 SIMDs and a step is one wave's ~9 k
@@ -602,6 +774,69 @@ static hipError_t launch_track_m(const sc_tracking_params& p, long long B, int M
         default:
             return launch_track_k<TIO, TC, SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
     }
+}
+
+template <typename TIO, int MODEL>
+static hipError_t launch_select_m(const sc_tracking_params& p, long long B, int M, const void* X, const void* wps,
+                                  const int* n_wp, int* wp_index, int* sm, void* goal, const void* table, const int* ret,
+                                  void* obs_out, void* goal_out, void* u_ref_out, int* track_out, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((B + 63) / 64);
+    const size_t lds = (size_t)(M > 0 ? M : 1) * 7 * sizeof(double);
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, p, B, M, (const TIO*)X, (const TIO*)wps, n_wp, wp_index,
+                           sm, (TIO*)goal, (const TIO*)table, ret, (TIO*)obs_out, (TIO*)goal_out, (TIO*)u_ref_out, track_out);
+        return hipGetLastError();
+    };
+    if (p.num_constraints <= 8) return go(tracking_select_kernel<TIO, double, 8, MODEL>);
+    return go(tracking_select_kernel<TIO, double, 16, MODEL>);
+}
+
+template <typename TIO>
+static hipError_t launch_select_t(const sc_tracking_params& p, long long B, int M, const void* X, const void* wps,
+                                  const int* n_wp, int* wp_index, int* sm, void* goal, const void* table, const int* ret,
+                                  void* obs_out, void* goal_out, void* u_ref_out, int* track_out, hipStream_t stream) {
+    if (p.qp.model_id == SC_MODEL_DYNAMIC_UNICYCLE2D)
+        return launch_select_m<TIO, SC_MODEL_DYNAMIC_UNICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, ret, obs_out, goal_out, u_ref_out, track_out, stream);
+    return launch_select_m<TIO, SC_MODEL_KINEMATIC_BICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, ret, obs_out, goal_out, u_ref_out, track_out, stream);
+}
+
+hipError_t tracking_select_launch(const sc_tracking_params& p, long long B, int M, const void* X, const void* wps,
+                                  const int* n_wp, int* wp_index, int* sm, void* goal, const void* table, const int* ret,
+                                  void* obs_out, void* goal_out, void* u_ref_out, int* track_out, hipStream_t stream) {
+    if (p.qp.io_dtype == SC_DTYPE_F32)
+        return launch_select_t<float>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, ret, obs_out, goal_out, u_ref_out, track_out, stream);
+    return launch_select_t<double>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, ret, obs_out, goal_out, u_ref_out, track_out, stream);
+}
+
+template <typename TIO>
+static hipError_t launch_apply_t(const sc_tracking_params& p, long long B, int M, int step_index, void* X, const int* sm,
+                                 const void* goal, const void* table, const void* u, const int* u_status, void* u_last,
+                                 int* ret, int* ret_step, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((B + 63) / 64);
+    const size_t lds = (size_t)(M > 0 ? M : 1) * 7 * sizeof(double);
+    auto go = [&](auto kern) {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds, stream, p, B, M, step_index, (TIO*)X, sm, (const TIO*)goal,
+                           (const TIO*)table, (const TIO*)u, u_status, (TIO*)u_last, ret, ret_step);
+        return hipGetLastError();
+    };
+    if (p.qp.model_id == SC_MODEL_DYNAMIC_UNICYCLE2D) return go(tracking_apply_kernel<TIO, double, SC_MODEL_DYNAMIC_UNICYCLE2D>);
+    return go(tracking_apply_kernel<TIO, double, SC_MODEL_KINEMATIC_BICYCLE2D>);
+}
+
+hipError_t tracking_apply_launch(const sc_tracking_params& p, long long B, int M, int step_index, void* X, const int* sm,
+                                 const void* goal, const void* table, const void* u, const int* u_status, void* u_last,
+                                 int* ret, int* ret_step, hipStream_t stream) {
+    if (p.qp.io_dtype == SC_DTYPE_F32)
+        return launch_apply_t<float>(p, B, M, step_index, X, sm, goal, table, u, u_status, u_last, ret, ret_step, stream);
+    return launch_apply_t<double>(p, B, M, step_index, X, sm, goal, table, u, u_status, u_last, ret, ret_step, stream);
 }
 
 hipError_t tracking_launch(const sc_tracking_params& p, long long B, int M, void* X, const void* wps, const int* n_wp,

@@ -38,8 +38,10 @@ class BatchedTrackingController:
         import torch
         self.torch = torch
         controller_type = controller_type or {"pos": "cbf_qp"}
-        if controller_type.get("pos", "cbf_qp") != "cbf_qp":
-            raise ValueError("the fused rollout implements the 'cbf_qp' position controller")
+        self.pos_controller_type = controller_type.get("pos", "cbf_qp")           # tracking.py:140-154
+        if self.pos_controller_type not in ("cbf_qp", "mpc_cbf", "optimal_decay_mpc_cbf"):
+            raise ValueError("position controllers of the batched loop: 'cbf_qp' (fused rollout), 'mpc_cbf', "
+                             "'optimal_decay_mpc_cbf' (select / solve / apply per step)")
         self.robot_spec = complete_robot_spec(robot_spec)
         self.robot_spec.setdefault("exploration", False)
         self.model = self.robot_spec["model"]
@@ -74,6 +76,16 @@ class BatchedTrackingController:
         self.waypoints = None
         self.n_wp = None
         self.steps_done = 0
+        self.mpc = None
+        if self.pos_controller_type != "cbf_qp":
+            if self.dyn_obs:
+                raise ValueError("moving obstacle tables are stepped by the fused 'cbf_qp' rollout only")
+            from .position_control.mpc_cbf import BatchedMPCCBF
+            from .position_control.optimal_decay_mpc_cbf import BatchedOptimalDecayMPCCBF
+            cls = BatchedMPCCBF if self.pos_controller_type == "mpc_cbf" else BatchedOptimalDecayMPCCBF
+            self.mpc = cls(self.robot_spec, dt=self.dt, io_dtype=io_dtype)
+            self.u_prev = torch.zeros((self.B, 2), dtype=self.tdtype, device=self.device)   # do-mpc's u0 per agent
+            self.mpc_status = torch.zeros(self.B, dtype=torch.int32, device=self.device)
 
     # -- obstacles -----------------------------------------------------------------------------
     def set_obstacles(self, obs):
@@ -173,6 +185,8 @@ class BatchedTrackingController:
         torch = self.torch
         if self.waypoints is None:
             raise RuntimeError("call set_waypoints first")
+        if self.mpc is not None:
+            return self._control_step_split(n, record)
         p = self._params(n)
         tX = torch.empty((n, self.B, 4), dtype=self.tdtype, device=self.device) if record else None
         tU = torch.empty((n, self.B, 2), dtype=self.tdtype, device=self.device) if record else None
@@ -184,6 +198,43 @@ class BatchedTrackingController:
             self.ret.data_ptr(), self.ret_step.data_ptr(),
             tX.data_ptr() if record else None, tU.data_ptr() if record else None, stream)
         _lib.check(rc, "sc_tracking_rollout_batch")
+        self.steps_done += n
+        return (self.ret, tX, tU) if record else self.ret
+
+    def _control_step_split(self, n, record):
+        """control_step with an MPC position controller: per step  select (tracking.py:569-609) -> one MPC launch for
+        the whole batch -> apply (tracking.py:627-668).  Agents whose state machine is not 'track' get u_ref
+        (mpc_cbf.py:379-381) and keep their u_prev; MPC failures are not reported to the loop (mpc_cbf.py:10)."""
+        torch = self.torch
+        p = self._params(1)
+        M, K, B = int(self.obs.shape[0]), self.num_constraints, self.B
+        obs_sel = torch.empty((B, K, 7), dtype=self.tdtype, device=self.device)
+        goal2 = torch.empty((B, 2), dtype=self.tdtype, device=self.device)
+        u_ref = torch.empty((B, 2), dtype=self.tdtype, device=self.device)
+        track = torch.empty(B, dtype=torch.int32, device=self.device)
+        tX = torch.empty((n, B, 4), dtype=self.tdtype, device=self.device) if record else None
+        tU = torch.empty((n, B, 2), dtype=self.tdtype, device=self.device) if record else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        obs_ptr = self.obs.data_ptr() if M else None
+        for k in range(n):
+            rc = self._lib.sc_tracking_select_batch(
+                C.byref(p), B, M, self.X.data_ptr(), self.waypoints.data_ptr(), self.n_wp.data_ptr(),
+                self.current_goal_index.data_ptr(), self.state_machine.data_ptr(), self.goal.data_ptr(), obs_ptr,
+                self.ret.data_ptr(), obs_sel.data_ptr(), goal2.data_ptr(), u_ref.data_ptr(), track.data_ptr(), stream)
+            _lib.check(rc, "sc_tracking_select_batch")
+            out = self.mpc.solve(self.X, self.u_prev, goal2, obs_sel)
+            u_mpc, st = (out[0], out[2]) if self.pos_controller_type == "optimal_decay_mpc_cbf" else (out[0], out[1])
+            tr = (track != 0).unsqueeze(1)
+            u = torch.where(tr, u_mpc, u_ref).contiguous()
+            self.u_prev = torch.where(tr, u_mpc, self.u_prev).contiguous()
+            self.mpc_status = torch.where(track != 0, st, self.mpc_status)
+            rc = self._lib.sc_tracking_apply_batch(
+                C.byref(p), B, M, k, self.X.data_ptr(), self.state_machine.data_ptr(), self.goal.data_ptr(), obs_ptr,
+                u.data_ptr(), None, self.u_pos.data_ptr(), self.ret.data_ptr(), self.ret_step.data_ptr(), stream)
+            _lib.check(rc, "sc_tracking_apply_batch")
+            if record:
+                tX[k] = self.X
+                tU[k] = self.u_pos
         self.steps_done += n
         return (self.ret, tX, tU) if record else self.ret
 

@@ -142,3 +142,48 @@ def test_cooperative_and_lane_per_agent_kernels_agree(golden_dir, num_constraint
     np.testing.assert_allclose(out["0"][1], out["1"][1], rtol=0, atol=1e-9)
     np.testing.assert_allclose(out["0"][2], out["1"][2], rtol=0, atol=1e-9)
     assert (out["0"][0] != 0).any() and (out["0"][0] == 0).any()
+
+
+@pytest.mark.parametrize("pos", ["mpc_cbf", "optimal_decay_mpc_cbf"])
+def test_closed_loop_with_mpc_position_controller(golden_dir, pos):
+    """examples/test_tracking.py's default --algo mpc_cbf, batched: select -> one MPC launch -> apply per step, against
+    the oracle loop with the oracle MPC behind solve_fn (u_prev feedback, u_ref pass-through when not tracking)."""
+    from oracle import mpc_cbf as M, od_mpc_cbf as O
+    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    obs = g["du14/obs"]
+    K = 8
+    spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25, "num_constraints": K}
+    X0 = np.array([[2.0, 2.0, np.pi / 2, 1.0], [6.0, 1.0, 2.6, 0.3], [1.0, 6.0, -1.2, 0.0]])   # the last one starts in 'stop'
+    wl = [np.array([[2.0, 12.0], [12.0, 12.0]]), np.array([[1.0, 4.0]]), np.array([[1.0, 12.0]])]
+    T = 30
+    ctl = sca.BatchedTrackingController(X0, dict(spec), controller_type={"pos": pos}, obs=obs, io_dtype="f64")
+    ctl.set_waypoints(wl)
+    ret, tX, tU = ctl.control_step(T, record=True)
+    tX = tX.cpu().numpy(); tU = tU.cpu().numpy(); ret = ret.cpu().numpy()
+    ospec = {k: v for k, v in spec.items() if k not in ("model", "num_constraints")}
+    n_track = 0
+    for i in range(len(X0)):
+        state = {"up": np.zeros(2)}
+
+        def solve_fn(X, cref, nobs, state=state):
+            if cref["state_machine"] != "track":
+                return np.asarray(cref["u_ref"], dtype=np.float64).reshape(-1), 0
+            o = M.pad_obstacles(None if nobs is None else list(nobs), K)
+            if pos == "mpc_cbf":
+                u, st, it = M.solve(X, state["up"], cref["goal"], o)
+            else:
+                u, rho, st, it = O.solve(X, state["up"], cref["goal"], o)
+            state["up"] = u
+            state["n"] = state.get("n", 0) + 1
+            return u, 0                                           # MPCCBF.status stays 'optimal' (mpc_cbf.py:10)
+
+        t = tracking.TrackingOracle(R.MODEL_DU, X0[i], ospec, dt=0.05, obs=obs, num_constraints=K, solve_fn=solve_fn)
+        t.set_waypoints(wl[i])
+        for k in range(T):
+            r = t.control_step()
+            np.testing.assert_allclose(tX[k, i], t.X, rtol=0, atol=5e-6, err_msg=f"agent {i} step {k}")
+            if r != 0:
+                assert ret[i] == r
+                break
+        n_track += state.get("n", 0)
+    assert n_track >= T                                           # the MPC really ran in the loop
