@@ -1094,15 +1094,26 @@ void mpccbf_kernel_rt(const sc_mpccbf_params p, const long long B, const int K_r
     mpccbf_body<TIO, 0, 0>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
 }
 
-// optimal-decay variant (position_control/optimal_decay_mpc_cbf.py): NT = 10 or run-time horizon, K run-time, no register cap
+// optimal-decay variant (position_control/optimal_decay_mpc_cbf.py), K run-time.  Compile-time horizon: capped at 256
+// VGPRs (about 60 spilled registers, still 23 % faster at large batches: 6 problems per CU instead of 4); run-time
+// horizon: no cap.
 template <typename TIO, int NT>
-__global__ __launch_bounds__(64)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void odmpccbf_kernel(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const TIO* __restrict__ X,
                      const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
                      TIO* __restrict__ u_out, TIO* __restrict__ rho_out, int* __restrict__ status_out,
                      int* __restrict__ iters_out, TIO* __restrict__ z_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     mpccbf_body<TIO, NT, 0, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
+}
+template <typename TIO>
+__global__ __launch_bounds__(64)
+void odmpccbf_kernel_rt(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const TIO* __restrict__ X,
+                        const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
+                        TIO* __restrict__ u_out, TIO* __restrict__ rho_out, int* __restrict__ status_out,
+                        int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    mpccbf_body<TIO, 0, 0, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
 }
 
 size_t mpccbf_lds_bytes(int N, int K) { return mpc_lds_doubles(N, K) * sizeof(double); }
@@ -1126,7 +1137,7 @@ static hipError_t odmpc_launch_t(const sc_odmpccbf_params& q, long long B, int K
         return hipGetLastError();
     };
     if (p.horizon == 10) return launch(odmpccbf_kernel<TIO, 10>);
-    return launch(odmpccbf_kernel<TIO, 0>);
+    return launch(odmpccbf_kernel_rt<TIO>);
 }
 
 hipError_t odmpccbf_launch(const sc_odmpccbf_params& q, long long B, int K, const void* X, const void* u_prev,
