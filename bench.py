@@ -378,6 +378,11 @@ def sweep(ctl, dev, td, es, K):
     """Same kernel at batch sizes where HBM is the binding limit (inputs drawn on-device)."""
     import math
     import torch
+    import safe_control_amd as sca
+    from safe_control_amd import _lib
+    ctl32 = None
+    if ctl.compute_dtype != _lib.DTYPE_F32 and ctl.io_dtype == _lib.DTYPE_F32:
+        ctl32 = sca.BatchedCBFQP(dict(ctl.robot_spec), dt=ctl.dt, io_dtype="f32", compute_dtype="f32")
     res = []
     g = torch.Generator(device=dev)
     g.manual_seed(0)
@@ -400,21 +405,27 @@ def sweep(ctl, dev, td, es, K):
         X, ur, obs = X.to(td).contiguous(), ur.to(td).contiguous(), obs.to(td).contiguous()
         out = (torch.empty((B, 2), dtype=td, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
                torch.empty((B, K), dtype=td, device=dev))
-        for _ in range(3):
-            ctl.solve(X, ur, obs, out=out)
-        torch.cuda.synchronize()
-        n = 20 if B <= (1 << 20) else 10
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            ctl.solve(X, ur, obs, out=out)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / n
         nbytes = (BYTES_IN_CBFQP(K, es) + BYTES_OUT_CBFQP(K, es)) * B
-        gbs = nbytes / (ms * 1e-3) / 1e9
-        res.append({"agents": B, "kernel_us": 1e3 * ms, "solves_per_s": B / (ms * 1e-3),
-                    "achieved_GBs": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS})
+        row = {"agents": B}
+        # the arithmetic of the headline line first, then (same storage) f32 arithmetic where HBM is the tighter bound
+        for label, c in (("", ctl), ("_f32_arithmetic", ctl32)):
+            if c is None:
+                continue
+            for _ in range(3):
+                c.solve(X, ur, obs, out=out)
+            torch.cuda.synchronize()
+            n = 20 if B <= (1 << 20) else 10
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                c.solve(X, ur, obs, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            row.update({"kernel_us" + label: 1e3 * ms, "solves_per_s" + label: B / (ms * 1e-3),
+                        "achieved_GBs" + label: gbs, "frac_hbm_peak" + label: gbs / HBM_PEAK_GBS})
+        res.append(row)
         del X, ur, obs, out
     return res
 
