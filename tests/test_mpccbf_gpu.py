@@ -153,3 +153,28 @@ def test_dropin_class_closed_loop_matches_oracle():
     assert ctl.solve_control_problem(robot.X, {"state_machine": "stop", "u_ref": ur, "goal": goal}, obs) is ur
     with pytest.raises(ValueError):
         ctl.solve_control_problem(robot.X, {"state_machine": "track", "u_ref": ur, "goal": goal}, [[1.0, 2.0, 0.3, 0.0, 0.0]])
+
+
+def test_non_finite_inputs_terminate_and_are_not_reported_optimal():
+    """NaN / inf in the state, the goal or an obstacle row: every loop of the kernels is bounded (max_iter, 12 halvings,
+    40 inertia retries), the launch returns and the affected problems are not 'optimal'; the others are untouched."""
+    X, goal, ur, obs = W.du_cbfqp_batch(64, 8, seed=11)
+    bad = {3: "X", 10: "goal", 17: "obs", 30: "Xinf"}
+    X2, g2, o2 = X.copy(), goal.copy(), obs.copy()
+    X2[3, 2] = np.nan; g2[10, 0] = np.nan; o2[17, 4, 1] = np.nan; X2[30, 0] = np.inf
+    up = np.zeros((64, 2))
+    u, st, it, z, _ = run_gpu(X2, up, g2, o2, "f64")
+    u0, st0, it0, z0, _ = run_gpu(X, up, goal, obs, "f64")
+    for i in bad:
+        assert st[i] != 0, (i, st[i])
+    good = [i for i in range(64) if i not in bad]
+    assert np.array_equal(st[good], st0[good]) and np.array_equal(u[good], u0[good])
+    import safe_control_amd as sca
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=dev)
+    od = sca.BatchedOptimalDecayMPCCBF(dict(SPEC), io_dtype="f64")
+    uo, rho, sto, ito = od.solve(t(X2), t(up), t(g2), t(o2))
+    torch.cuda.synchronize()
+    sto = sto.cpu().numpy()
+    for i in bad:
+        assert sto[i] != 0, (i, sto[i])
