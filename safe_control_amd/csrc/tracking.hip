@@ -560,6 +560,7 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
         bool hit = false;
 #pragma unroll
         for (int q = 0; q < CM; ++q) {
+            if (q * G >= M) break;
             const int m = sub + q * G;
             if (m < M) hit |= collides_one<TC>(px_, py_, table + 7 * m, k.R);
         }
@@ -584,7 +585,10 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
         bool inview[CM];
         int cnt = 0;
 #pragma unroll
+        for (int q = 0; q < CM; ++q) { cd[q] = num<TC>::inf(); ci[q] = -1; inview[q] = false; }
+#pragma unroll
         for (int q = 0; q < CM; ++q) {
+            if (q * G >= M) break;                                    // uniform: only ceil(M / G) obstacles per lane exist
             const int m = sub + q * G;
             const bool valid = m < M;
             const TC* o = table + 7 * (valid ? m : 0);
