@@ -258,6 +258,8 @@ def main():
 
     B, K = a.agents, a.obstacles
     if a.workload == "mpc_cbf":
+        if ws > 1:
+            dist.barrier()
         r = mpc_leg(dev, B, K, a.horizon, a.steps, a.warmup, seed=rank,
                     cpu_seconds=(6.0 if (ws == 1 and not a.no_cpu_baseline) else 0.0))
         elapsed = sharding.max_over_ranks(B * a.steps / r["value"], device=dev if backend == "nccl" else None)
@@ -324,9 +326,9 @@ def main():
             step()
     e1.record()
     torch.cuda.synchronize()
+    t1 = time.perf_counter()                                        # this rank's K steps are complete
     if ws > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
+        dist.barrier()                                              # closing bracket; the job time is the MAX over ranks
     elapsed = sharding.max_over_ranks(t1 - t0, device=dev if backend == "nccl" else None)
     kernel_ms = e0.elapsed_time(e1) / a.steps                       # avg launch duration over the timed region
 
