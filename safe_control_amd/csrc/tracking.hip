@@ -178,11 +178,9 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
         TC n0[KMAX], n1[KMAX], c[KMAX];
         bool bad_obs = false;
         TC poison = TC(0);
-        int nk = 0;
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) {
             const bool used = (j < t.K) && (si[j] >= 0);
-            nk += used ? 1 : 0;
             const TC* orow = table + 7 * (si[j] >= 0 ? si[j] : 0);
             TC o[7];
 #pragma unroll
