@@ -30,6 +30,7 @@
 #ifndef SAFE_CONTROL_AMD_H
 #define SAFE_CONTROL_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -237,6 +238,16 @@ int sc_odcbfqp_solve_batch_host(const sc_odcbfqp_params* params, int64_t B,
 int sc_neighbor_obstacles_batch(int32_t io_dtype, int64_t B_all, int64_t first_local, int64_t B_local,
                                 int32_t K, double neighbour_radius, const void* X_all, void* obs_out,
                                 void* stream);
+
+/* Same result, bit for bit, with the candidate range cut into slices (one wave per 64 agents x slice, then a merge):
+ * the single-scan form above takes the same time whatever the shard size, this one shortens with the shard, which is
+ * what sharding the fleet over several GPUs needs.  `workspace` is device memory of at least
+ * sc_neighbor_workspace_bytes(io_dtype, B_all, B_local, K) bytes (0 on invalid arguments).
+ */
+size_t sc_neighbor_workspace_bytes(int32_t io_dtype, int64_t B_all, int64_t B_local, int32_t K);
+int sc_neighbor_obstacles_batch_ws(int32_t io_dtype, int64_t B_all, int64_t first_local, int64_t B_local,
+                                   int32_t K, double neighbour_radius, const void* X_all, void* obs_out,
+                                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- closed-loop control_step, fused -----------------------
  * Runs `n_steps` iterations of LocalTrackingController.control_step (tracking.py:559-668; moving

@@ -104,6 +104,9 @@ SYMBOLS = {
     "sc_odcbfqp_solve_batch_host": (C.c_int, [C.POINTER(OdCbfQpParams), C.c_int64] + [C.c_void_p] * 8 + [C.c_int]),
     "sc_neighbor_obstacles_batch": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double,
                                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sc_neighbor_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64, C.c_int64, C.c_int32]),
+    "sc_neighbor_obstacles_batch_ws": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sc_tracking_rollout_batch": (C.c_int, [C.POINTER(TrackingParams), C.c_int64, C.c_int32] + [C.c_void_p] * 13),
     "sc_tracking_select_batch": (C.c_int, [C.POINTER(TrackingParams), C.c_int64, C.c_int32] + [C.c_void_p] * 13),
     "sc_tracking_apply_batch": (C.c_int, [C.POINTER(TrackingParams), C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 10),

@@ -23,6 +23,9 @@ hipError_t neighbors_launch(int io_dtype, long long B_all, long long first, long
                             void* out, hipStream_t stream);
 hipError_t odcbfqp_launch(const sc_odcbfqp_params& p, long long B, const void* X, const void* u_ref, const void* obs,
                           const int* has_obs, void* u_out, void* w_out, int* status, void* h_out, hipStream_t stream);
+size_t neighbors_workspace_bytes(int io_dtype, long long B_all, long long B_local, int K);
+hipError_t neighbors_split_launch(int io_dtype, long long B_all, long long first, long long B_local, int K, double r,
+                                  const void* X, void* out, void* ws, hipStream_t stream);
 hipError_t tracking_select_launch(const sc_tracking_params& p, long long B, int M, const void* X, const void* wps,
                                   const int* n_wp, int* wp_index, int* sm, void* goal, const void* table, const int* ret,
                                   void* obs_out, void* goal_out, void* u_ref_out, int* track_out, hipStream_t stream);
@@ -430,6 +433,30 @@ int sc_neighbor_obstacles_batch(int32_t io_dtype, int64_t B_all, int64_t first_l
     hipError_t e = sc::neighbors_launch(io_dtype, (long long)B_all, (long long)first_local, (long long)B_local, (int)K,
                                         neighbour_radius, X_all, obs_out, (hipStream_t)stream);
     if (e != hipSuccess) return sc::fail_hip(e, "neighbour kernel launch");
+    return SC_OK;
+}
+
+size_t sc_neighbor_workspace_bytes(int32_t io_dtype, int64_t B_all, int64_t B_local, int32_t K) {
+    if ((io_dtype != SC_DTYPE_F32 && io_dtype != SC_DTYPE_F64) || B_all < 0 || B_local < 0 || K < 1 || K > SC_CBFQP_MAX_OBS) return 0;
+    return sc::neighbors_workspace_bytes(io_dtype, (long long)B_all, (long long)B_local, (int)K);
+}
+
+int sc_neighbor_obstacles_batch_ws(int32_t io_dtype, int64_t B_all, int64_t first_local, int64_t B_local, int32_t K,
+                                   double neighbour_radius, const void* X_all, void* obs_out, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    if (io_dtype != SC_DTYPE_F32 && io_dtype != SC_DTYPE_F64)
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
+    if (B_all < 0 || B_local < 0 || first_local < 0 || first_local + B_local > B_all)
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "local range outside [0, B_all)");
+    if (K < 1 || K > SC_CBFQP_MAX_OBS) return sc::fail(SC_ERR_UNSUPPORTED, "K outside [1, SC_CBFQP_MAX_OBS]");
+    if (B_all > 0x7fffffffLL) return sc::fail(SC_ERR_UNSUPPORTED, "more than 2^31 agents");
+    if (B_local == 0) return SC_OK;
+    if (!X_all || !obs_out || !workspace) return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    if (workspace_bytes < sc::neighbors_workspace_bytes(io_dtype, (long long)B_all, (long long)B_local, (int)K))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "workspace smaller than sc_neighbor_workspace_bytes()");
+    hipError_t e = sc::neighbors_split_launch(io_dtype, (long long)B_all, (long long)first_local, (long long)B_local, (int)K,
+                                              neighbour_radius, X_all, obs_out, workspace, (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "neighbour kernels launch");
     return SC_OK;
 }
 

@@ -165,9 +165,11 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
             const TC dx = ox - x, dy = oy - y;
             TC cd = pass ? sqrt_(dx * dx + dy * dy) : num<TC>::inf();
             int ci = pass ? m : -1;
+            bool moved = false;                    // stable: once the candidate is placed, everything after it shifts
 #pragma unroll
             for (int j = 0; j < KMAX; ++j) {
-                const bool sw = cd < sd[j];
+                const bool sw = moved || (cd < sd[j]);
+                moved = sw;
                 const TC td = sd[j]; const int ti = si[j];
                 sd[j] = sw ? cd : td; si[j] = sw ? ci : ti;
                 cd = sw ? td : cd; ci = sw ? ti : ci;
@@ -352,9 +354,11 @@ __global__ __launch_bounds__(64) void tracking_select_kernel(
         const TC dx = ox - x, dy = oy - y;
         TC cd = pass ? sqrt_(dx * dx + dy * dy) : num<TC>::inf();
         int ci = pass ? m : -1;
+        bool moved = false;                    // stable: once the candidate is placed, everything after it shifts
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) {
-            const bool sw = cd < sd[j];
+            const bool sw = moved || (cd < sd[j]);
+            moved = sw;
             const TC td = sd[j]; const int ti = si[j];
             sd[j] = sw ? cd : td; si[j] = sw ? ci : ti;
             cd = sw ? td : cd; ci = sw ? ti : ci;

@@ -134,7 +134,10 @@ def neighbor_obstacles(X_local, n_agents, K, neighbour_radius):
     obs = torch.empty((hi - lo, K, 7), dtype=X_local.dtype, device=X_local.device)
     io = _lib.DTYPE_F32 if X_local.dtype == torch.float32 else _lib.DTYPE_F64
     stream = torch.cuda.current_stream(X_local.device).cuda_stream
-    rc = _lib.load().sc_neighbor_obstacles_batch(io, n_agents, lo, hi - lo, K, float(neighbour_radius),
-                                                 X_all.data_ptr(), obs.data_ptr(), stream)
-    _lib.check(rc, "sc_neighbor_obstacles_batch")
+    lib = _lib.load()
+    nbytes = int(lib.sc_neighbor_workspace_bytes(io, n_agents, hi - lo, K))
+    ws_ = torch.empty((max(nbytes, 8),), dtype=torch.uint8, device=X_local.device)   # caching allocator: no hipMalloc per step
+    rc = lib.sc_neighbor_obstacles_batch_ws(io, n_agents, lo, hi - lo, K, float(neighbour_radius), X_all.data_ptr(),
+                                            obs.data_ptr(), ws_.data_ptr(), nbytes, stream)
+    _lib.check(rc, "sc_neighbor_obstacles_batch_ws")
     return obs

@@ -83,3 +83,32 @@ def test_agents_as_obstacles_pipeline_one_rank():
     assert np.array_equal(st.cpu().numpy(), so) or (st.cpu().numpy() == so).mean() > 0.999
     ok = (so == 0) & (st.cpu().numpy() == 0)
     assert np.abs(u.cpu().numpy()[ok] - uo[ok]).max() < 1e-6
+
+
+@pytest.mark.parametrize("B,lo,n_local,K,dtype", [(20000, 0, 20000, 16, torch.float32), (20000, 5000, 2500, 16, torch.float32),
+                                                   (3000, 100, 777, 8, torch.float64), (900, 0, 900, 32, torch.float64),
+                                                   (300, 0, 300, 16, torch.float32)])
+def test_candidate_split_search_equals_the_single_scan(B, lo, n_local, K, dtype):
+    """sc_neighbor_obstacles_batch_ws (slices + merge) against sc_neighbor_obstacles_batch (one scan): bit for bit, with
+    exact ties (agents on a grid) and duplicate positions."""
+    from safe_control_amd import _lib
+    rng = np.random.default_rng(B + K)
+    X = np.column_stack([rng.integers(0, 60, B).astype(np.float64), rng.integers(0, 60, B).astype(np.float64),
+                         rng.uniform(-np.pi, np.pi, B), rng.uniform(0.2, 3.5, B)])      # integer grid: many equal distances
+    tX = torch.tensor(X, dtype=dtype, device=DEV)
+    io = 0 if dtype == torch.float32 else 1
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    a = torch.empty((n_local, K, 7), dtype=dtype, device=DEV)
+    b = torch.empty((n_local, K, 7), dtype=dtype, device=DEV)
+    assert lib.sc_neighbor_obstacles_batch(io, B, lo, n_local, K, 0.3, tX.data_ptr(), a.data_ptr(), stream) == 0
+    nbytes = int(lib.sc_neighbor_workspace_bytes(io, B, n_local, K))
+    assert nbytes > 0
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=DEV)
+    assert lib.sc_neighbor_obstacles_batch_ws(io, B, lo, n_local, K, 0.3, tX.data_ptr(), b.data_ptr(), ws.data_ptr(), nbytes, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    if B <= 3000:                                                 # ties resolve by index, like a stable sort
+        want = brute_force(tX.double().cpu().numpy(), lo, lo + n_local, K, 0.3)
+        np.testing.assert_allclose(b.double().cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+    assert lib.sc_neighbor_obstacles_batch_ws(io, B, lo, n_local, K, 0.3, tX.data_ptr(), b.data_ptr(), ws.data_ptr(), nbytes - 1, stream) != 0
