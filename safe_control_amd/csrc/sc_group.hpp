@@ -75,4 +75,36 @@ __device__ __forceinline__ void coop_walk(QpState<TC>& S, int K, int sub, TC a0,
     (coop_step<TC, G, Is>(S, K, sub, a0, a1, cc, k), ...);
 }
 
+// The same walk, driven by the violated rows instead of by the row index.  Every lane tests its OWN row at the running
+// optimum; the first violated row of a group (lowest index above the last committed one) is broadcast and committed;
+// repeat until no group of the wave has a violated row left.  Rows that are satisfied when their turn comes change
+// nothing in the index-driven walk either, so both visit the same rows in the same order with the same arithmetic --
+// but a wave whose agents have no violated row (the common case) leaves after one test instead of K.
+template <typename TC, int G>
+__device__ __forceinline__ void coop_walk_violated(QpState<TC>& S, int K, int sub, int lane, TC a0, TC a1, TC cc,
+                                                   const CbfConsts<TC>& k) {
+    const int gbase = lane & ~(G - 1);
+    const unsigned long long grp = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gbase;
+    const bool testable = (sub < K) && !((a0 == TC(0)) && (a1 == TC(0)));     // all-zero rows are never projected on
+    int last = -1;
+    for (int it = 0; it < G; ++it) {                          // at most K commits per agent
+        const TC s = a0 * S.u0 + (a1 * S.u1 + cc);
+        const bool v = testable && (sub > last) && (s < TC(0));
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(v);
+        if (m == 0ull) break;                                 // wave-uniform
+        const unsigned long long mg = m & grp;
+        const bool has = mg != 0ull;
+        const int istar = has ? (__builtin_ctzll(mg) - gbase) : 0;
+        const TC bi0 = __shfl(a0, istar, G), bi1 = __shfl(a1, istar, G), bic = __shfl(cc, istar, G);
+        LineQP<TC> L;
+        const bool viol = qp_row_violated(S, bi0, bi1, bic, L, k) && has;
+        clip_box(L, k);
+        if (sub < istar) clip_row(L, a0, a1, cc);             // rows j < i*, one per lane, in parallel
+        L.lo = group_max<TC, G>(L.lo);
+        L.hi = group_min<TC, G>(L.hi);
+        qp_row_commit(S, L, viol);
+        last = has ? istar : K;
+    }
+}
+
 }  // namespace sc

@@ -665,7 +665,7 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
         else {
             QpState<TC> S;
             qp_begin(S, ur0, ur1, k);
-            coop_walk<TC, G>(S, t.K, sub, a0, a1, cc, k, std::make_integer_sequence<int, G>{});
+            coop_walk_violated<TC, G>(S, t.K, sub, lane, a0, a1, cc, k);
             qp_finish_box(S, k);
             TC worst = qp_row_margin(num<TC>::inf(), a0, a1, cc, S.u0, S.u1, poison);
             worst = group_min<TC, G>(worst);
