@@ -67,7 +67,8 @@ typedef enum sc_error {
 #define SC_MODEL_SINGLE_INTEGRATOR2D       4  /* robots/single_integrator2D.py: X = [x, y, -, -], U = [vx, vy]   */
 #define SC_MODEL_DOUBLE_INTEGRATOR2D       5  /* robots/double_integrator2D.py: X = [x, y, vx, vy], U = [ax, ay] */
 #define SC_MODEL_QUAD2D                    6  /* robots/quad2D.py: X = [x, z, theta, vx, vz, theta_dot] (state_dim 6), U = [F_right, F_left] */
-#define SC_MODEL_COUNT                     7
+#define SC_MODEL_UNICYCLE2D                 7  /* robots/unicycle2D.py: X = [x, y, theta, -], U = [v, omega] (rel-deg 1) */
+#define SC_MODEL_COUNT                     8
 
 #define SC_DTYPE_F32 0
 #define SC_DTYPE_F64 1

@@ -24,7 +24,7 @@
 
 #define KMAX 64
 
-enum { DU = 0, KB = 1, C3BF = 2, DPCBF = 3, SI = 4, DI = 5, QUAD2D = 6 };
+enum { DU = 0, KB = 1, C3BF = 2, DPCBF = 3, SI = 4, DI = 5, QUAD2D = 6, UNI = 7 };
 
 typedef struct {
     int model, cbf_mode;
@@ -120,6 +120,16 @@ static int cbf_row(const par_t* p, const double* X, const double* o, double* n, 
         double Lf = 2.0 * vx * vx + 2.0 * vz * vz + 2.0 * ez * (-9.81);
         *c = p->cbf_mode ? (*h / (p->dt * p->dt) + 2.0 * hdot / p->dt + Lf)
                          : (Lf + (p->a1 + p->a2) * hdot + (p->a1 * p->a2) * (*h));
+        return 1;
+    }
+    if (p->model == UNI) { /* robots/unicycle2D.py:52-62,100-128: rel-deg 1, sigma(s) = k2 tanh((k1 - s) / 2) */
+        double ex = X[0] - o[0], ey = X[1] - o[1], dmin = o[2] + p->R, nrm = sqrt(ex * ex + ey * ey);
+        double cs = cos(X[2]), sn = sin(X[2]), s = ex * cs + ey * sn, th = tanh(0.5 * (0.5 - s));
+        double dsig = -0.5 * 1.8 * (1.0 - th * th);
+        *h = nrm * nrm - 1.01 * dmin * dmin - 1.8 * th;
+        double dhx = 2.0 * ex - dsig * cs, dhy = 2.0 * ey - dsig * sn, dht = -dsig * (-sn * ex + cs * ey);
+        n[0] = dhx * cs + dhy * sn; n[1] = dht;                 /* dh_dx g, g = [[c, 0], [s, 0], [0, 1]] */
+        *c = p->cbf_mode ? (*h / p->dt) : (p->a1 * (*h));      /* f = 0 */
         return 1;
     }
     if (p->model == SI || p->model == DI) {

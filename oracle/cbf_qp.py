@@ -12,7 +12,7 @@ def default_cbf_param(model):
     """CBF gains per model, position_control/cbf_qp.py:12-35."""
     if model in R.REL_DEG2:
         return {"alpha1": 1.5, "alpha2": 1.5}
-    if model == R.MODEL_SI:
+    if model in (R.MODEL_SI, R.MODEL_UNI):                 # cbf_qp.py:12-15
         return {"alpha": 1.0}
     return {"alpha": 1.5}
 
@@ -23,6 +23,8 @@ def input_bounds(model, spec):
         hi = np.array([spec["a_max"], spec["w_max"]], dtype=np.float64)
     elif model == R.MODEL_SI:                              # cbf_qp.py:54-57
         hi = np.array([spec["v_max"], spec["v_max"]], dtype=np.float64)
+    elif model == R.MODEL_UNI:                             # cbf_qp.py:58-61
+        hi = np.array([spec["v_max"], spec["w_max"]], dtype=np.float64)
     elif model == R.MODEL_DI:                              # cbf_qp.py:66-69
         hi = np.array([spec["a_max"], spec["a_max"]], dtype=np.float64)
     elif model == R.MODEL_QUAD2D:                          # cbf_qp.py:74-79: f_min <= u <= f_max (not symmetric)

@@ -23,6 +23,8 @@ MODEL_DI = 5          # DoubleIntegrator2D           (rel-deg 2 HOCBF),         
 
 MODEL_QUAD2D = 6      # Quad2D (rel-deg 2 HOCBF), X = [x, z, theta, vx, vz, theta_dot], U = [F_right, F_left]
 GRAVITY = 9.81        # robots/quad2D.py:47
+MODEL_UNI = 7         # Unicycle2D (rel-deg 1, distance barrier minus sigma(s)), X = [x, y, theta, -], U = [v, omega]
+UNI_K1, UNI_K2 = 0.5, 1.8   # robots/unicycle2D.py:36-37
 
 MODEL_NAMES = {
     "DynamicUnicycle2D": MODEL_DU,
@@ -32,6 +34,7 @@ MODEL_NAMES = {
     "SingleIntegrator2D": MODEL_SI,
     "DoubleIntegrator2D": MODEL_DI,
     "Quad2D": MODEL_QUAD2D,
+    "Unicycle2D": MODEL_UNI,
 }
 
 REL_DEG2 = (MODEL_DU, MODEL_KB, MODEL_DI, MODEL_QUAD2D)
@@ -56,6 +59,8 @@ def default_spec(model):
         return dict(a_max=1.0, v_max=1.0, w_max=0.5, radius=0.25)
     if model == MODEL_QUAD2D:                              # robots/quad2D.py:41-44
         return dict(mass=1.0, inertia=0.01, f_min=1.0, f_max=10.0, radius=0.25)
+    if model == MODEL_UNI:                                 # robots/unicycle2D.py:39-40
+        return dict(v_max=1.0, w_max=0.5, radius=0.25)
     rear, wb = 0.2, 0.4
     delta_max = np.deg2rad(32)
     return dict(a_max=5.0, v_max=3.5, v_min=0.2, radius=0.3, rear_ax_dist=rear,
@@ -69,7 +74,7 @@ def default_spec(model):
 def f(model, X, spec=None):
     """Drift. DU robots/dynamic_unicycle2D.py:42-54 ; KB robots/kinematic_bicycle2D.py:75-91 ;
     SI robots/single_integrator2D.py:45-55 (zero) ; DI robots/double_integrator2D.py:46-59 ([vx, vy, 0, 0])."""
-    if model == MODEL_SI:
+    if model in (MODEL_SI, MODEL_UNI):                     # unicycle2D.py:42-50: zero drift
         return np.zeros(4)
     if model == MODEL_DI:
         return np.array([X[2], X[3], 0.0, 0.0])
@@ -85,6 +90,8 @@ def g(model, X, spec=None):
         return np.array([[0.0, 0.0], [0.0, 0.0], [0.0, 1.0], [1.0, 0.0]])
     if model == MODEL_SI:                                  # single_integrator2D.py:57-65 (identity on x, y)
         return np.array([[1.0, 0.0], [0.0, 1.0], [0.0, 0.0], [0.0, 0.0]])
+    if model == MODEL_UNI:                                 # unicycle2D.py:52-62 (3 states, padded to 4)
+        return np.array([[math.cos(X[2]), 0.0], [math.sin(X[2]), 0.0], [0.0, 1.0], [0.0, 0.0]])
     if model == MODEL_DI:                                  # double_integrator2D.py:69-79
         return np.array([[0.0, 0.0], [0.0, 0.0], [1.0, 0.0], [0.0, 1.0]])
     if model == MODEL_QUAD2D:                              # robots/quad2D.py:68-81
@@ -114,7 +121,7 @@ def step(model, X, U, dt, spec=None):
     Xn = np.asarray(X, dtype=np.float64) + (f(model, X, spec) + g(model, X, spec) @ np.asarray(U, dtype=np.float64)) * dt
     if model == MODEL_SI:                                  # single_integrator2D.py:67-69
         return Xn
-    if model == MODEL_QUAD2D:                              # robots/quad2D.py:83-86
+    if model in (MODEL_QUAD2D, MODEL_UNI):                 # robots/quad2D.py:83-86, unicycle2D.py:64-67
         Xn[2] = angle_normalize(Xn[2])
         return Xn
     if model == MODEL_DI:                                  # double_integrator2D.py:81-108: speed saturation
@@ -160,6 +167,10 @@ def nominal_input(model, X, goal, spec, d_min=0.05):
     dist_raw = math.sqrt((X[0] - goal[0]) ** 2 + (X[1] - goal[1]) ** 2)
     theta_d = math.atan2(dyg, dxg)
     err = angle_normalize(theta_d - X[2])
+    if model == MODEL_UNI:                                 # unicycle2D.py:69-85 with (d_min, k_omega, k_v) = (.05, 2, 1)
+        distance = max(dist_raw - d_min, 0.05)             # forwarded by robots/robot.py:404-405; output not clipped
+        v = 0.0 if abs(err) > math.radians(90) else 1.0 * distance * math.cos(err)
+        return np.array([v, 2.0 * err])
     if model == MODEL_DU:
         k_omega = spec.get("nominal_k_omega", 2.0)
         k_a = spec.get("nominal_k_a", 1.0)
@@ -182,7 +193,7 @@ def nominal_input(model, X, goal, spec, d_min=0.05):
 
 def stop(model, X, spec):
     """DU :106-111 (brake with k_a) ; KB :149-150 (zeros) ; SI :103-106 (zeros) ; DI :151-157 (brake both axes)."""
-    if model == MODEL_SI:
+    if model in (MODEL_SI, MODEL_UNI):                     # unicycle2D.py:87-88
         return np.array([0.0, 0.0])
     if model == MODEL_DI:
         k_a = spec.get("nominal_k_a", 1.0)
@@ -193,7 +204,9 @@ def stop(model, X, spec):
 
 
 def has_stopped(model, X, tol=0.05):
-    """DU :113-114 ; KB :152-153."""
+    """DU :113-114 ; KB :152-153 ; Unicycle2D unicycle2D.py:90-92 (always)."""
+    if model == MODEL_UNI:
+        return True
     return abs(X[3]) < tol
 
 
@@ -266,6 +279,23 @@ def _superellipsoid_terms(X, obs, R):
         cb = e * (e - 1) / Bb ** e * py ** (e - 2)
     return (float(h), np.array([gx * ct - gy * st, gx * st + gy * ct]),
             ca * ct * ct + cb * st * st, (ca - cb) * ct * st, ca * st * st + cb * ct * ct)
+
+
+def _uni_barrier(X, obs, R, beta=1.01):
+    """robots/unicycle2D.py:107-128 (rel-deg 1): h = |p - o|^2 - beta d_min^2 - sigma(s), s = (p - o) . heading,
+    sigma(s) = k2 (e^(k1-s) - 1) / (e^(k1-s) + 1); the obstacle flag is not looked at.  sigma is evaluated as
+    k2 tanh((k1 - s) / 2), the same function without the overflow of e^(k1-s) for obstacles far behind the robot
+    (the reference returns NaN there); the reference indexes the obstacle as a column (obs[2][0]), which the 1-D rows
+    cbf_qp.py hands over do not support -- the goldens call it with a column."""
+    ex, ey = X[0] - obs[0], X[1] - obs[1]
+    c, sn = math.cos(X[2]), math.sin(X[2])
+    d_min = obs[2] + R
+    s = ex * c + ey * sn
+    th = math.tanh(0.5 * (UNI_K1 - s))
+    sig = UNI_K2 * th
+    dsig = -0.5 * UNI_K2 * (1.0 - th * th)
+    h = math.sqrt(ex * ex + ey * ey) ** 2 - beta * d_min ** 2 - sig
+    return h, np.array([2.0 * ex - dsig * c, 2.0 * ey - dsig * sn, -dsig * (-sn * ex + c * ey), 0.0])
 
 
 def _si_barrier(X, obs, R, beta=1.01):
@@ -380,6 +410,8 @@ def agent_barrier(model, X, obs, R):
         return h, 2.0 * (ex * X[3] + ez * X[4]), np.array([2.0 * X[3], 2.0 * X[4], 0.0, 2.0 * ex, 2.0 * ez, 0.0])
     if model == MODEL_SI:
         return _si_barrier(X, obs, R)
+    if model == MODEL_UNI:
+        return _uni_barrier(X, obs, R)
     if model == MODEL_DI:
         return _di_barrier(X, obs, R)
     if model == MODEL_KB:

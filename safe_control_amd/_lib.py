@@ -26,6 +26,7 @@ MODEL_IDS = {
     "SingleIntegrator2D": 4,
     "DoubleIntegrator2D": 5,
     "Quad2D": 6,
+    "Unicycle2D": 7,
 }
 
 STATE_DIM = {"Quad2D": 6}          # everything else: 4

@@ -471,6 +471,8 @@ static hipError_t launch_model(const sc_cbfqp_params& p, long long B, int K, con
             return launch_k<TIO, TC, SC_MODEL_DOUBLE_INTEGRATOR2D>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
         case SC_MODEL_QUAD2D:
             return launch_k<TIO, TC, SC_MODEL_QUAD2D>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
+        case SC_MODEL_UNICYCLE2D:
+            return launch_k<TIO, TC, SC_MODEL_UNICYCLE2D>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
         default:
             return launch_k<TIO, TC, SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
     }

@@ -215,7 +215,21 @@ __device__ __forceinline__ void dpcbf(const Agent<T>& a, const T* o, T R, T& h, 
 template <typename T, int MODEL, bool OUTLINE_RARE = false>
 __device__ __forceinline__ bool cbf_row(const Agent<T>& a, const T* o, const CbfConsts<T>& k,
                                         T& n0, T& n1, T& c, T& h) {
-    if constexpr (MODEL == SC_MODEL_QUAD2D) {
+    if constexpr (MODEL == SC_MODEL_UNICYCLE2D) {
+        // robots/unicycle2D.py:100-128 (rel-deg 1): h = |p - o|^2 - beta d_min^2 - sigma(s), s = (p - o) . heading,
+        // sigma(s) = k2 (e^(k1-s) - 1) / (e^(k1-s) + 1) = k2 tanh((k1 - s) / 2)  (k1 = .5, k2 = 1.8; the tanh form has
+        // no overflow for obstacles far behind the robot, where the reference returns NaN); the flag is not looked at.
+        // g = [[c, 0], [s, 0], [0, 1]], f = 0  =>  A = (dh/dp . heading, dh/dtheta),  b = alpha h  (cbf_qp.py:155-165).
+        const T ex = a.x - o[0], ey = a.y - o[1];
+        const T dmin = o[2] + k.R;
+        const T s = ex * a.c + ey * a.s;
+        const T th = T(tanh(double(T(0.5) * (T(0.5) - s))));
+        const T dsig = T(-0.9) * (T(1) - th * th);
+        h = (ex * ex + ey * ey) - T(1.01) * dmin * dmin - T(1.8) * th;
+        n0 = T(2) * s - dsig;                                      // (2 e - dsig heading) . heading
+        n1 = -dsig * (-a.s * ex + a.c * ey);
+        c = k.hard ? (h * k.inv_dt) : (k.a1 * h);
+    } else if constexpr (MODEL == SC_MODEL_QUAD2D) {
         // robots/quad2D.py:166-177 (circle, no flag test) with g of :68-81: both thrusts enter identically,
         // A = dh_dot_dx g = [a, a],  a = (2 ex (-sin th) + 2 ez cos th) / m;  L_f = 2 |v|^2 - 2 g ez
         const T ex = a.x - o[0], ez = a.y - o[1];

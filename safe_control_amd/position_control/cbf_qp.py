@@ -26,7 +26,7 @@ def default_cbf_param(model):
     """position_control/cbf_qp.py:12-35 (models the batched engine supports)."""
     if model in REL_DEG2_MODELS:
         return {"alpha1": 1.5, "alpha2": 1.5}
-    if model == "SingleIntegrator2D":
+    if model in ("SingleIntegrator2D", "Unicycle2D"):
         return {"alpha": 1.0}
     return {"alpha": 1.5}
 
@@ -45,6 +45,8 @@ def input_bounds(robot_spec):
         hi = (float(robot_spec["a_max"]), float(robot_spec["w_max"]))
     elif robot_spec["model"] == "SingleIntegrator2D":          # cbf_qp.py:54-57
         hi = (float(robot_spec["v_max"]), float(robot_spec["v_max"]))
+    elif robot_spec["model"] == "Unicycle2D":                  # cbf_qp.py:58-61
+        hi = (float(robot_spec["v_max"]), float(robot_spec["w_max"]))
     elif robot_spec["model"] == "DoubleIntegrator2D":          # cbf_qp.py:66-69
         hi = (float(robot_spec["a_max"]), float(robot_spec["a_max"]))
     elif robot_spec["model"] == "Quad2D":                      # cbf_qp.py:74-79: f_min <= u <= f_max

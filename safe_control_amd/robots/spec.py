@@ -37,6 +37,10 @@ def complete_robot_spec(robot_spec):
         robot_spec.setdefault("ay_max", robot_spec["a_max"])
         robot_spec.setdefault("w_max", 0.5)
         robot_spec.setdefault("radius", 0.25)
+    elif model == "Unicycle2D":                     # robots/unicycle2D.py:39-40
+        robot_spec.setdefault("v_max", 1.0)
+        robot_spec.setdefault("w_max", 0.5)
+        robot_spec.setdefault("radius", 0.25)
     elif model == "Quad2D":                         # robots/quad2D.py:41-44
         robot_spec.setdefault("mass", 1.0)
         robot_spec.setdefault("inertia", 0.01)

@@ -419,7 +419,62 @@ def gen_quad2d():
     np.savez_compressed(os.path.join(HERE, "quad2d.npz"), **out)
 
 
+def gen_unicycle2d():
+    """Unicycle2D (3 states, inputs v, omega; rel-deg-1 barrier with the sigma(s) term): f, g, step, nominal_input,
+    stop, rotate_to and agent_barrier from the reference.  CBFQP.solve_control_problem cannot run for this model as
+    checked in (agent_barrier indexes the obstacle as a column, obs[2][0], cbf_qp.py hands over 1-D rows), so the
+    barrier is called with a column and the rows are assembled HERE the way cbf_qp.py:155-165 does for rel-deg-1
+    models (A = dh_dx g, b = dh_dx f + alpha h, alpha = 1.0 from cbf_qp.py:14-15)."""
+    from oracle import qp as oqp
+    rng = np.random.default_rng(4242)
+    spec = {"model": "Unicycle2D", "v_max": 1.0, "w_max": 0.5, "radius": 0.25}
+    robot = BaseRobot(np.zeros((3, 1)), spec, DT, NullAxes())
+    rec = {k: [] for k in ["X", "goal", "U", "u_ref", "obs", "k", "f", "g", "step", "nominal", "stop", "rotate", "h", "dh",
+                           "A", "b", "u_star_oracle", "status_oracle"]}
+    alpha = 1.0
+    hi = np.array([spec["v_max"], spec["w_max"]])
+    for i in range(140):
+        X = np.array([*rng.uniform(0, 14, 2), rng.uniform(-np.pi, np.pi)])
+        goal = rng.uniform(0, 14, 2)
+        U = np.array([rng.uniform(-1, 1), rng.uniform(-0.5, 0.5)])
+        K = int(rng.integers(1, 7))
+        obs = draw_circles(rng, np.array([X[0], X[1], X[2], 0.0]), K, spec["radius"], overlap=(i % 6 == 0), rho_max=3.0)
+        robot.X = X.reshape(-1, 1).copy()
+        fx = np.asarray(robot.f(), dtype=float).reshape(-1)
+        gx = np.asarray(robot.g(), dtype=float)
+        u_ref = robot.nominal_input(goal).reshape(-1)
+        if i % 7 == 3:
+            u_ref = u_ref * 3.0
+        A = np.zeros((6, 2)); b = np.zeros(6); hs = np.full(6, np.nan); dhs = np.full((6, 3), np.nan)
+        for r in range(K):
+            h, dh = robot.robot.agent_barrier(robot.X, obs[r].reshape(-1, 1), spec["radius"])
+            h = float(np.asarray(h).reshape(-1)[0]); dh = np.asarray(dh, dtype=float).reshape(-1)
+            A[r] = dh @ gx
+            b[r] = dh @ fx + alpha * h
+            hs[r] = h; dhs[r] = dh
+        Gb = np.vstack([A, np.eye(2), -np.eye(2)]); cb = np.concatenate([b, hi, hi])
+        u, status = oqp.solve_qp2(Gb, cb, u_ref)
+        Xn = robot.robot.step(robot.X.copy(), U.reshape(-1, 1)).reshape(-1).copy()
+        robot.X = X.reshape(-1, 1).copy()
+        obs_p = np.full((6, 7), np.nan); obs_p[:K] = obs
+        pad = lambda v: np.concatenate([v, [0.0]])
+        rec["X"].append(pad(X)); rec["goal"].append(goal); rec["U"].append(U); rec["u_ref"].append(u_ref)
+        rec["obs"].append(obs_p); rec["k"].append(K); rec["f"].append(pad(fx)); rec["g"].append(np.vstack([gx, np.zeros((1, 2))]))
+        rec["step"].append(pad(Xn)); rec["nominal"].append(robot.nominal_input(goal).reshape(-1))
+        rec["stop"].append(np.asarray(robot.stop(), dtype=float).reshape(-1))
+        rec["rotate"].append(np.asarray(robot.rotate_to(0.7), dtype=float).reshape(-1))
+        rec["h"].append(hs); rec["dh"].append(dhs); rec["A"].append(A); rec["b"].append(b)
+        rec["u_star_oracle"].append(np.full(2, np.nan) if u is None else u)
+        rec["status_oracle"].append(int(status))
+    out = {f"Unicycle2D/{k}": np.array(v) for k, v in rec.items()}
+    print("Unicycle2D cases", len(rec["k"]), "infeasible", int(np.sum(rec["status_oracle"])))
+    np.savez_compressed(os.path.join(HERE, "unicycle2d.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "unicycle2d":
+        gen_unicycle2d()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "quad2d":
         gen_quad2d()
         sys.exit(0)
@@ -433,3 +488,4 @@ if __name__ == "__main__":
     gen_closed_loop()
     gen_integrators()
     gen_quad2d()
+    gen_unicycle2d()

@@ -319,6 +319,34 @@ def test_integrator_models(golden_dir, name, model):
         compare(model, spec, X, u_ref, obs, "f64", "f64")
 
 
+def test_unicycle2d_model(golden_dir):
+    """Unicycle2D (3 states, inputs v / omega, rel-deg-1 barrier with the sigma(s) term): reference-generated cases
+    through the drop-in class, then 3000 / 40000-agent batches (both kernels, far padding rows included) vs the C oracle."""
+    g = np.load(os.path.join(golden_dir, "unicycle2d.npz"))
+    G = {k.split("/", 1)[1]: g[k] for k in g.files}
+    spec = {"model": "Unicycle2D", "radius": 0.25, "v_max": 1.0, "w_max": 0.5}
+    robot = sca.RobotHandle(np.zeros(4), dict(spec), dt=0.05)
+    ctl = sca.CBFQP(robot, dict(spec), num_obs=6)
+    assert ctl.cbf_param == {"alpha": 1.0}
+    for i in range(len(G["X"])):
+        robot.X = G["X"][i][:3].reshape(-1, 1)
+        u = ctl.solve_control_problem(robot.X, {"u_ref": G["u_ref"][i].reshape(2, 1)}, list(G["obs"][i][: int(G["k"][i])]))
+        if G["status_oracle"][i] == 0:
+            assert ctl.status == "optimal"
+            np.testing.assert_allclose(u.reshape(-1), G["u_star_oracle"][i], rtol=1e-7, atol=1e-7)
+            np.testing.assert_allclose(ctl.h, G["h"][i][: int(G["k"][i])], rtol=1e-9, atol=1e-9)
+        else:
+            assert u is None and ctl.status != "optimal"
+    for B in (3000, 40000):
+        X, goal, u_ref, obs = W.du_cbfqp_batch(B, 6, seed=B + 1)
+        rng = np.random.default_rng(B)
+        X[:, 3] = 0.0
+        u_ref = np.column_stack([rng.uniform(-1.5, 1.5, B), rng.uniform(-1, 1, B)])
+        obs[rng.choice(B, B // 8, replace=False), 5] = [1000.0, 1000.0, 0, 0, 0, 0, 0]      # update_tvp-style padding rows
+        compare(R.MODEL_UNI, spec, X, u_ref, obs, "f64", "f64")
+        compare(R.MODEL_UNI, spec, X, u_ref, obs, "f32", "f64")
+
+
 def test_quad2d_model(golden_dir):
     """Quad2D (6 states, thrust box [f_min, f_max], both inputs enter identically => all rows parallel):
     reference-generated cases through the drop-in class, then 3000 / 40000-agent batches vs the C oracle."""

@@ -69,3 +69,18 @@ def test_workload_nominal_inputs_match_oracle():
     X, goal, ur, obs = W.du_cbfqp_batch(1000, 8, seed=0)
     d = np.hypot(obs[:, :, 0] - X[:, None, 0], obs[:, :, 1] - X[:, None, 1])
     assert np.all(d ** 2 - 1.01 * (obs[:, :, 2] + 0.25) ** 2 > 0)
+
+
+def test_c_oracle_unicycle2d_on_reference_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "unicycle2d.npz"))
+    G = {k.split("/", 1)[1]: g[k] for k in g.files}
+    m = R.MODEL_UNI
+    n = len(G["X"])
+    kk = G["k"].astype(np.int32)
+    o = np.zeros((n, 6, 7))
+    for i in range(n):
+        o[i, : kk[i]] = G["obs"][i][: kk[i]]
+    u, st, h = c_oracle.cbfqp_batch(m, G["X"], G["u_ref"], o, R.default_spec(m), cbf_qp.default_cbf_param(m), 0.05, "cbf", kk)
+    assert np.array_equal(st, G["status_oracle"])
+    ok = st == 0
+    np.testing.assert_allclose(u[ok], G["u_star_oracle"][ok], rtol=1e-8, atol=1e-8)

@@ -263,3 +263,44 @@ def test_quad2d_against_reference(golden_dir):
         assert r["status"] == int(G["status_oracle"][i])
         if r["status"] == 0:
             np.testing.assert_allclose(r["u"], G["u_star_oracle"][i], rtol=1e-8, atol=1e-8)
+
+
+def test_unicycle2d_against_reference(golden_dir):
+    """tests/golden/unicycle2d.npz: f, g, step, nominal_input, stop, rotate_to and agent_barrier of the reference's
+    Unicycle2D (barrier called with a column obstacle, see make_golden.gen_unicycle2d); rows per cbf_qp.py:155-165."""
+    g = np.load(os.path.join(golden_dir, "unicycle2d.npz"))
+    G = {k.split("/", 1)[1]: g[k] for k in g.files}
+    m = R.MODEL_UNI
+    spec = R.default_spec(m)
+    for i in range(len(G["X"])):
+        X, K = G["X"][i], int(G["k"][i])
+        np.testing.assert_allclose(R.f(m, X, spec), G["f"][i], atol=1e-12)
+        np.testing.assert_allclose(R.g(m, X, spec), G["g"][i], atol=1e-12)
+        np.testing.assert_allclose(R.step(m, X, G["U"][i], 0.05, spec), G["step"][i], atol=1e-12)
+        np.testing.assert_allclose(R.nominal_input(m, X, G["goal"][i], spec), G["nominal"][i], atol=1e-12)
+        np.testing.assert_allclose(R.stop(m, X, spec), G["stop"][i], atol=1e-12)
+        np.testing.assert_allclose(R.rotate_to(m, X, 0.7), G["rotate"][i], atol=1e-12)
+        for r in range(K):
+            h, dh = R.agent_barrier(m, X, G["obs"][i][r], spec["radius"])
+            np.testing.assert_allclose(h, G["h"][i][r], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(dh[:3], G["dh"][i][r], rtol=1e-11, atol=1e-12)
+        r_ = cbf_qp.solve(m, X, G["u_ref"][i], list(G["obs"][i][:K]), spec, num_obs=6)
+        np.testing.assert_allclose(r_["A"], G["A"][i], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(r_["b"], G["b"][i], rtol=1e-10, atol=1e-10)
+        assert r_["status"] == int(G["status_oracle"][i])
+        if r_["status"] == 0:
+            np.testing.assert_allclose(r_["u"], G["u_star_oracle"][i], rtol=1e-9, atol=1e-9)
+
+
+def test_unicycle2d_sigma_has_no_overflow_far_behind_the_robot():
+    """The reference's sigma(s) = k2 (e^(k1-s) - 1) / (e^(k1-s) + 1) is NaN once e^(k1-s) overflows (an obstacle more
+    than ~709 m behind the heading, e.g. the [1000, 1000] padding rows); the restated tanh form is finite there and
+    equal elsewhere."""
+    m = R.MODEL_UNI
+    X = np.array([0.0, 0.0, 0.0, 0.0])
+    h, dh = R.agent_barrier(m, X, np.array([1000.0, 0.0, 0.5, 0, 0, 0, 0]), 0.25)
+    assert np.isfinite(h) and np.all(np.isfinite(dh))
+    for s_ in (-3.0, 0.0, 2.5):
+        k1, k2 = R.UNI_K1, R.UNI_K2
+        ref = k2 * (np.exp(k1 - s_) - 1) / (np.exp(k1 - s_) + 1)
+        assert abs(ref - k2 * np.tanh(0.5 * (k1 - s_))) < 1e-14
