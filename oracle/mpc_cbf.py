@@ -242,7 +242,7 @@ def problem_functions(x0, z, u_prev, goal, obs, P, want_jac=True):
     return r["f"], r["grad"], r["W"], r["g"], r["J"], r["X"]
 
 
-def solve(x0, u_prev, goal, obs, params=None, return_info=False):
+def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=None):
     """One MPC-CBF solve.  Returns u_0 (2,), status, iterations [, info dict].
 
     Primal-dual interior point on  min f(z) s.t. g(z) - s = 0, s >= 0  with the exact Hessian of the
@@ -255,6 +255,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False):
     if params:
         P.update(params)
     N = P["N"]
+    evaluate = evaluate_fn or globals()["evaluate"]       # other models plug their problem functions in here
     x0 = np.asarray(x0, dtype=np.float64)
     obs = np.asarray(obs, dtype=np.float64)
     ub = np.tile([P["a_max"], P["w_max"]], N)
