@@ -134,7 +134,10 @@ int sc_cbfqp_solve_batch_host(const sc_cbfqp_params* params, int64_t B, int32_t 
 #define SC_MPCCBF_MAX_HORIZON 32
 
 typedef struct sc_mpccbf_params {
-    int32_t model_id;        /* SC_MODEL_DYNAMIC_UNICYCLE2D (others: SC_ERR_UNSUPPORTED)          */
+    int32_t model_id;        /* SC_MODEL_DYNAMIC_UNICYCLE2D or SC_MODEL_UNICYCLE2D (others: SC_ERR_UNSUPPORTED).
+                              * Unicycle2D (robots/unicycle2D.py): inputs [v, omega], u_max = (v_max, w_max),
+                              * one-step CBF rows h(p_k+1) - (1 - alpha1) h(p_k) >= 0 (mpc_cbf.py:312-315,
+                              * unicycle2D.py:127-145), Q[3], alpha2, v_max and X[:,3] unused               */
     int32_t io_dtype;        /* SC_DTYPE_*: element type of X,u_prev,goal,obs,u_out,z_out          */
     int32_t horizon;         /* robot_spec['mpc_horizon'], default 10 (mpc_cbf.py:15)              */
     int32_t max_iter;        /* interior-point iteration limit (-> SC_STATUS_INACCURATE)           */

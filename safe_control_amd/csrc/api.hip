@@ -80,8 +80,8 @@ static int check_mpccbf(const sc_mpccbf_params* p, int64_t B, int32_t K, const v
     if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
     if (B < 0) return fail(SC_ERR_INVALID_ARGUMENT, "B < 0");
     if (K < 1) return fail(SC_ERR_INVALID_ARGUMENT, "K < 1 (pad with [1000,1000,0,...] rows like update_tvp)");
-    if (p->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D)
-        return fail(SC_ERR_UNSUPPORTED, "MPC-CBF is built for DynamicUnicycle2D only");
+    if (p->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && p->model_id != SC_MODEL_UNICYCLE2D)
+        return fail(SC_ERR_UNSUPPORTED, "MPC-CBF is built for DynamicUnicycle2D and Unicycle2D only");
     if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
         return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
     if (p->horizon < 1 || p->horizon > SC_MPCCBF_MAX_HORIZON)
@@ -223,6 +223,8 @@ static int check_odmpccbf(const sc_odmpccbf_params* q, int64_t B, int32_t K, con
     if (!q) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
     int rc = sc::check_mpccbf(&q->mpc, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
+    if (q->mpc.model_id != SC_MODEL_DYNAMIC_UNICYCLE2D)
+        return sc::fail(SC_ERR_UNSUPPORTED, "optimal-decay MPC-CBF is built for DynamicUnicycle2D only");
     if (sc::odmpccbf_lds_bytes(q->mpc.horizon, K) > 160 * 1024)
         return sc::fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
     if (!(q->p_sb[0] > 0) || !(q->p_sb[1] > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "p_sb must be > 0");

@@ -148,7 +148,7 @@ __host__ __device__ inline size_t mpc_region_b(int N, bool od) {
     return (od && 39 * (size_t)N > 2 * NP * n) ? 39 * (size_t)N : 2 * NP * n;
 }
 __host__ __device__ inline size_t mpc_lds_doubles(int N, int K, bool od = false) {
-    const size_t n = 2 * (size_t)N, NP = (size_t)N + 2, m = (size_t)N * K + 2 * N + 2 * n;
+    const size_t n = 2 * (size_t)N, NP = (size_t)N + 2, m = (size_t)N * K + 2 * N + 2 * n;   // (rows: sized for the larger, DU, layout)
     const size_t regA = n * n > NP * (26 + K) ? n * n : NP * (26 + K);
     const size_t cvt = 2 * n > 3 * (size_t)N + 5 ? 2 * n : 3 * (size_t)N + 5;
     const size_t odx = od ? 4 * n + 2 * (size_t)N + 2 * (size_t)N * K + 22 * (size_t)N : 0;
@@ -186,7 +186,7 @@ __device__ inline MpcMem carve(double* b, int N, int K, bool od = false) {
 }
 
 struct MpcConst {
-    int N, K, n, mc, m;
+    int N, K, n, mc, m, ns;                       // ns: speed-bound rows (2 N for DynamicUnicycle2D, 0 for Unicycle2D)
     double dt, Qx, Qy, Qth, Qv, R0, R1, w0, w1, w2, vmax, amax, wmaxu, Rrob, beta;
     double x0, y0, th0, v0, up0, up1, gx, gy;
     double al1, al2, ps1, ps2, rf1, rf2;          // optimal decay: CBF gains, decay penalties and references
@@ -257,7 +257,9 @@ __device__ __forceinline__ double suffix_sum(double v, int lane) {
 // ---- rollout + barrier values + g + f at a trial z (oracle: evaluate level 0) --------------------
 // Lane k holds stage k: heading / speed are exclusive prefix sums of the inputs, positions and the position
 // sensitivities PC_k = sum_{i<k} (cos, sin), PD_k = sum_{i<k} v_i (-sin, cos) prefix sums of the stage terms.
-template <bool ROW16, bool OD>
+// UNI = kinematic Unicycle2D (robots/unicycle2D.py): the first input IS the speed of its stage (no speed state), the
+// position of stage k+1 therefore depends on v_k directly (G has dt (cos, sin)_j in the v_j column for k >= j + 1).
+template <bool ROW16, bool OD, bool UNI = false>
 __device__ inline double eval_values(const double* z, const double* rho, const MpcMem& W, const MpcConst& c, int lane, bool derivs,
                                      Prof& pf, int slot) {
     lane = opaque(lane);
@@ -265,15 +267,15 @@ __device__ inline double eval_values(const double* z, const double* rho, const M
     double ak = 0.0, wk = 0.0;
     if (lane < N) { ak = z[2 * lane]; wk = z[2 * lane + 1]; }
     const double th = c.th0 + c.dt * (prefix_sum<ROW16>(wk, lane) - wk);
-    const double v = c.v0 + c.dt * (prefix_sum<ROW16>(ak, lane) - ak);
+    const double v = UNI ? ak : c.v0 + c.dt * (prefix_sum<ROW16>(ak, lane) - ak);
     double sn, cs;
     sincos(th, &sn, &cs);
-    const bool stg = lane <= N;
+    const bool stg = UNI ? lane < N : lane <= N;                      // stages whose (v, heading) move a later position
     const double tc = stg ? cs : 0.0, ts = stg ? sn : 0.0, tdx = stg ? -v * sn : 0.0, tdy = stg ? v * cs : 0.0;
     const double pcx = prefix_sum<ROW16>(tc, lane) - tc, pcy = prefix_sum<ROW16>(ts, lane) - ts;
     const double pdx = prefix_sum<ROW16>(tdx, lane) - tdx, pdy = prefix_sum<ROW16>(tdy, lane) - tdy;
     const double px = c.x0 + c.dt * pdy, py = c.y0 - c.dt * pdx;
-    if (stg) { W.TH[lane] = th; W.V[lane] = v; W.C[lane] = cs; W.S[lane] = sn; }
+    if (lane <= N) { W.TH[lane] = th; W.V[lane] = v; W.C[lane] = cs; W.S[lane] = sn; }
     if (lane < NP) {
         W.pos[2 * lane] = px; W.pos[2 * lane + 1] = py;
         if (derivs) { W.PC[2 * lane] = pcx; W.PC[2 * lane + 1] = pcy; W.PD[2 * lane] = pdx; W.PD[2 * lane + 1] = pdy; }
@@ -306,6 +308,13 @@ __device__ inline double eval_values(const double* z, const double* rho, const M
         const double dt2 = c.dt * c.dt;
         for (int e = lane; e < 3 * n; e += 64) {
             const int gq = e / n, col = e - gq * n, j = col >> 1;
+            if (UNI && !(col & 1)) {                                  // d p_k / d v_j = dt (cos, sin)(theta_j), k >= j + 1
+                const double g0 = c.dt * W.C[j], g1 = c.dt * W.S[j];
+                for (int k = gq; k < NP; k += 3) {
+                    if (k >= j + 1) { W.dP[(size_t)(2 * k) * n + col] = g0; W.dP[(size_t)(2 * k + 1) * n + col] = g1; }
+                }
+                continue;
+            }
             const double* P = W.PC + ((col & 1) ? (W.PD - W.PC) : 0);
             const double b0 = P[2 * (j + 1)], b1 = P[2 * (j + 1) + 1];
             for (int k = gq; k < NP; k += 3) {
@@ -344,11 +353,11 @@ __device__ inline double eval_values(const double* z, const double* rho, const M
             } else {
                 gi = c.w2 * h2 + c.w1 * h1 + c.w0 * h0;
             }
-        } else if (i < c.mc + 2 * N) {
+        } else if (i < c.mc + c.ns) {
             const int r = i - c.mc, k = (r >> 1) + 1;
             gi = (r & 1) ? (c.vmax + W.V[k]) : (c.vmax - W.V[k]);
         } else {
-            const int r = i - c.mc - 2 * N;
+            const int r = i - c.mc - c.ns;
             const int col = r < n ? r : r - n;
             const double ub = (col & 1) ? c.wmaxu : c.amax;
             gi = r < n ? (ub - z[col]) : (ub + z[col]);
@@ -389,7 +398,7 @@ __device__ __forceinline__ void row_pass(const MpcMem& W, const MpcConst& c, int
 // positions: lane k < NP builds  q_k = d L / d p_k,  Om_k,  the position-space vectors A'(1/s), A'(sig r_p + lam),
 // row block k of Phi, and the suffix sums the structured Hessian terms need.  Multipliers are those of the scaled
 // problem (objective times sf), so everything here is already scaled.
-template <int KT, bool ROW16, bool OD>
+template <int KT, bool ROW16, bool OD, bool UNI = false>
 __device__ __forceinline__ double stage_pass(const MpcMem& W, const MpcConst& c, int lane, double sf) {
     lane = opaque(lane);
     // ROW16: the obstacle loop of stage k is split over lanes k, k + 16, k + 32, k + 48 (jo = part, part + 4, ..) and
@@ -582,12 +591,13 @@ __device__ __forceinline__ double stage_pass(const MpcMem& W, const MpcConst& c,
         const double ci = W.C[k], si = W.S[k];
         Ai = qs0 * (-si) + qs1 * ci;
         Bi = W.V[k] * (qs0 * ci + qs1 * si);
-        if (k >= 1) {
+        if (!UNI && k >= 1) {
             const int r = c.mc + 2 * (k - 1);
             sk = W.lam[r] * is[r] + W.lam[r + 1] * is[r + 1];
         }
     }
-    const double sa = suffix_sum<ROW16>(Ai, lane), sb = suffix_sum<ROW16>(Bi, lane), ss = suffix_sum<ROW16>(sk, lane);
+    // UNI: v_j only moves stage j, so the (v_j, omega_i) curvature is A_j itself (i < j), not a suffix sum
+    const double sa = UNI ? Ai : suffix_sum<ROW16>(Ai, lane), sb = suffix_sum<ROW16>(Bi, lane), ss = suffix_sum<ROW16>(sk, lane);
     if (k < NP && part == 0) { W.SA[k] = sa; W.SB[k] = sb; W.SS[k] = ss; }
     return OD ? wmax(e_rho) : 0.0;                                    // |r_d| of the decay variables
 }
@@ -595,7 +605,7 @@ __device__ __forceinline__ double stage_pass(const MpcMem& W, const MpcConst& c,
 // columns: cv[v][col] for the three row vectors  v = 0: r_d = sf grad f - J' lam;  1: J'(1/s);  2: J'(sig r_p + lam).
 // Every inner loop has a trip count that does not depend on the lane (structural zeros of G, masks on the stage
 // sums), so with compile-time N the loads of a lane are issued back to back instead of one round trip per term.
-template <bool OD>
+template <bool OD, bool UNI = false>
 __device__ __forceinline__ double col_pass(const MpcMem& W, const MpcConst& c, int lane, double sf) {
     lane = opaque(lane);
     const int N = c.N, n = c.n, NP = N + 2;
@@ -607,17 +617,18 @@ __device__ __forceinline__ double col_pass(const MpcMem& W, const MpcConst& c, i
         const double* vec = W.lam + (v == 0 ? 0 : (v == 1 ? (W.is - W.lam) : (W.dlam - W.lam)));
         double acc = 0.0;
 #pragma unroll
-        for (int row = 4; row < 2 * NP; ++row) acc += W.dP[(size_t)row * n + col] * y[row];       // rows 0..3 of G are zero
+        for (int row = UNI ? 2 : 4; row < 2 * NP; ++row) acc += W.dP[(size_t)row * n + col] * y[row];   // leading rows of G are zero
         double sp = 0.0, sx = 0.0;
         const double* Xs = W.V + ((col & 1) ? (W.TH - W.V) : 0);
 #pragma unroll
         for (int k = 1; k <= N; ++k) {
-            const double dv = vec[c.mc + 2 * (k - 1) + 1] - vec[c.mc + 2 * (k - 1)], xk = Xs[k];
+            const double dv = UNI ? 0.0 : vec[c.mc + 2 * (k - 1) + 1] - vec[c.mc + 2 * (k - 1)], xk = Xs[k];
             sp += k > j ? dv : 0.0;                               // speed rows of stages k > j
             sx += k > j ? xk : 0.0;                               // sum_{k > j} theta_k | v_k
         }
-        double sb = vec[c.mc + 2 * N + n + col] - vec[c.mc + 2 * N + col];
-        if (!(col & 1)) sb += c.dt * sp;
+        if (UNI && !(col & 1)) sx = 0.0;                          // the speed is an input, not a state: no state cost on it
+        double sb = vec[c.mc + c.ns + n + col] - vec[c.mc + c.ns + col];
+        if (!UNI && !(col & 1)) sb += c.dt * sp;
         if (v == 0) {
             const double Rc = (col & 1) ? c.R1 : c.R0, Qs = (col & 1) ? c.Qth : c.Qv;
             const double prev = col >= 2 ? W.z[col - 2] : ((col & 1) ? c.up1 : c.up0);
@@ -656,14 +667,15 @@ __device__ __forceinline__ d4_t mfma_ksteps(int lo, int hi, LoadA load_a, LoadB 
 }
 
 // T' = Phi' G'   (9 MFMAs for N = 10)
-template <int S>
+// R0: first row of G that can be non-zero (4 for DynamicUnicycle2D: p_0, p_1 fixed; 2 for Unicycle2D: p_0 fixed)
+template <int S, int R0 = 4>
 __device__ __forceinline__ void phi_times_G(const MpcMem& W, const MpcConst& c, int lane) {
     lane = opaque(lane);
     const int n = c.n, nt = (n + 15) >> 4, q = lane >> 4, l15 = lane & 15;
     for (int ti = 0; ti < nt; ++ti) {
-        const int i = 16 * ti + l15, R = i + 4, kR = R >> 1;
+        const int i = 16 * ti + l15, R = i + R0, kR = R >> 1;
         const bool okA = i < n;
-        const double* band = W.Phi + (size_t)(okA ? R : 4) * 10;
+        const double* band = W.Phi + (size_t)(okA ? R : R0) * 10;
         for (int tj = 0; tj < nt; ++tj) {
             const int cB = 16 * tj + l15;
             const bool okB = cB < n;
@@ -674,7 +686,7 @@ __device__ __forceinline__ void phi_times_G(const MpcMem& W, const MpcConst& c, 
             const int hi = (16 * ti + 20) < n ? (16 * ti + 20) : n;
             const d4_t acc = mfma_ksteps<S>(lo, hi,
                 [&](int k0) {
-                    const int kk = k0 + q, Cc = kk + 4, dl = (Cc >> 1) - kR;
+                    const int kk = k0 + q, Cc = kk + R0, dl = (Cc >> 1) - kR;
                     const bool inband = dl >= -2 && dl <= 2, ok = okA && kk < hi && inband;
                     const double a = band[(inband ? dl + 2 : 2) * 2 + (Cc & 1)];
                     return ok ? a : 0.0;
@@ -682,20 +694,20 @@ __device__ __forceinline__ void phi_times_G(const MpcMem& W, const MpcConst& c, 
                 [&](int k0) {
                     const int kk = k0 + q;
                     const bool ok = okB && kk < hi;
-                    const double b = W.dP[(size_t)(ok ? kk + 4 : 4) * n + cb];
+                    const double b = W.dP[(size_t)(ok ? kk + R0 : R0) * n + cb];
                     return ok ? b : 0.0;
                 });
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + q + 4 * r, col = 16 * tj + l15;
-                if (row < n && col < n) W.T[(size_t)(row + 4) * n + col] = acc[r];
+                if (row < n && col < n) W.T[(size_t)(row + R0) * n + col] = acc[r];
             }
         }
     }
 }
 
 // structured part of the condensed matrix at (r, cc)
-template <bool OD>
+template <bool OD, bool UNI = false>
 __device__ __forceinline__ double condensed_base(const MpcMem& W, const MpcConst& c, double sf, int r, int cc) {
     const int N = c.N, n = c.n;
     const int jr = r >> 1, jc = cc >> 1, jm = jr > jc ? jr : jc;
@@ -705,15 +717,20 @@ __device__ __forceinline__ double condensed_base(const MpcMem& W, const MpcConst
     const double vaa = sf * 2.0 * c.Qv * dt2 * (double)(N - jm) + dt2 * ss;             // d v_k: objective + speed rows
     const double vww = sf * 2.0 * c.Qth * dt2 * (double)(N - jm) - dt3 * sb;
     double acc = (ra && ca) ? vaa : ((!ra && !ca) ? vww : dt3 * sa);
+    if constexpr (UNI) {
+        // (v_j, omega_i): dt^2 A_j for i < j (SA holds A itself);  (v, v): nothing;  (omega, omega): as above
+        const int jv = ra ? jr : jc, jw = ra ? jc : jr;
+        acc = (ra && ca) ? 0.0 : ((!ra && !ca) ? vww : ((jw < jv) ? dt2 * W.SA[jv] : 0.0));
+    }
     const double Rc = (r & 1) ? c.R1 : c.R0;                                               // input-rate penalty 2 D' R D
-    const int bx = c.mc + 2 * N + r;
+    const int bx = c.mc + c.ns + r;
     const double dg = sf * 2.0 * Rc * ((!OD && r + 2 < n) ? 2.0 : 1.0) + W.lam[bx] * W.is[bx] + W.lam[bx + n] * W.is[bx + n];
     acc += (r == cc) ? dg : ((!OD && (r == cc + 2 || cc == r + 2)) ? -sf * 2.0 * Rc : 0.0);
     return acc;
 }
 
 // M = G'' T' + structured terms   (7 MFMAs for N = 10; lower tiles, mirrored)
-template <int S, bool OD>
+template <int S, bool OD, bool UNI = false>
 __device__ __forceinline__ void condense_mfma(const MpcMem& W, const MpcConst& c, int lane, double sf) {
     lane = opaque(lane);
     const int n = c.n, nt = (n + 15) >> 4, q = lane >> 4, l15 = lane & 15;
@@ -726,19 +743,19 @@ __device__ __forceinline__ void condense_mfma(const MpcMem& W, const MpcConst& c
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + q + 4 * r, col = 16 * tj + l15;
-                base[r] = (row < n && col < n) ? condensed_base<OD>(W, c, sf, row, col) : 0.0;
+                base[r] = (row < n && col < n) ? condensed_base<OD, UNI>(W, c, sf, row, col) : 0.0;
             }
             const d4_t acc = mfma_ksteps<S>(16 * ti, n,
                 [&](int k0) {
                     const int kk = k0 + q;
                     const bool ok = okA && kk < n;
-                    const double a = W.dP[(size_t)((ok ? kk : 0) + 4) * n + ca];
+                    const double a = W.dP[(size_t)((ok ? kk : 0) + (UNI ? 2 : 4)) * n + ca];
                     return ok ? a : 0.0;
                 },
                 [&](int k0) {
                     const int kk = k0 + q;
                     const bool ok = okB && kk < n;
-                    const double b = W.T[(size_t)((ok ? kk : 0) + 4) * n + cb];
+                    const double b = W.T[(size_t)((ok ? kk : 0) + (UNI ? 2 : 4)) * n + cb];
                     return ok ? b : 0.0;
                 });
 #pragma unroll
@@ -797,7 +814,7 @@ __device__ inline void chol_solve(const double* L, double* b, int n, int lane) {
 // multiplies); NT == 0: run-time sizes.
 struct OdExtra { double omega_ref[2], p_sb[2]; };
 
-template <typename TIO, int NT, int KT, bool OD = false>
+template <typename TIO, int NT, int KT, bool OD = false, bool UNI = false>
 __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& p, const long long B, const int K_rt,
                                             const TIO* __restrict__ X, const TIO* __restrict__ u_prev,
                                             const TIO* __restrict__ goal, const TIO* __restrict__ obs,
@@ -809,12 +826,13 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     if (prob >= B) return;
     MpcConst c;
     const int K = KT > 0 ? KT : K_rt;
-    c.N = NT > 0 ? NT : p.horizon; c.K = K; c.n = 2 * c.N; c.mc = c.N * K; c.m = c.mc + 2 * c.N + 2 * c.n;
-    c.dt = p.dt; c.Qx = p.Q[0]; c.Qy = p.Q[1]; c.Qth = p.Q[2]; c.Qv = p.Q[3]; c.R0 = p.R[0]; c.R1 = p.R[1];
+    c.N = NT > 0 ? NT : p.horizon; c.K = K; c.n = 2 * c.N; c.mc = c.N * K; c.ns = UNI ? 0 : 2 * c.N; c.m = c.mc + c.ns + 2 * c.n;
+    c.dt = p.dt; c.Qx = p.Q[0]; c.Qy = p.Q[1]; c.Qth = p.Q[2]; c.Qv = UNI ? 0.0 : p.Q[3]; c.R0 = p.R[0]; c.R1 = p.R[1];
     const double g1 = p.alpha1 + p.alpha2, g2 = p.alpha1 * p.alpha2;
     c.w0 = 1.0 - g1 + g2; c.w1 = g1 - 2.0; c.w2 = 1.0;
+    if constexpr (UNI) { c.w0 = -(1.0 - p.alpha1); c.w1 = 1.0; c.w2 = 0.0; }   // relative degree 1: h(p_k+1) - (1 - alpha) h(p_k)
     c.vmax = p.v_max; c.amax = p.u_max[0]; c.wmaxu = p.u_max[1]; c.Rrob = p.robot_radius; c.beta = p.beta;
-    c.x0 = (double)X[prob * 4 + 0]; c.y0 = (double)X[prob * 4 + 1]; c.th0 = (double)X[prob * 4 + 2]; c.v0 = (double)X[prob * 4 + 3];
+    c.x0 = (double)X[prob * 4 + 0]; c.y0 = (double)X[prob * 4 + 1]; c.th0 = (double)X[prob * 4 + 2]; c.v0 = UNI ? 0.0 : (double)X[prob * 4 + 3];
     c.up0 = (double)u_prev[prob * 2 + 0]; c.up1 = (double)u_prev[prob * 2 + 1];
     c.gx = (double)goal[prob * 2 + 0]; c.gy = (double)goal[prob * 2 + 1];
     c.al1 = p.alpha1; c.al2 = p.alpha2; c.ps1 = od.p_sb[0]; c.ps2 = od.p_sb[1]; c.rf1 = od.omega_ref[0]; c.rf2 = od.omega_ref[1];
@@ -837,16 +855,16 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
 
     Prof pf;
     pf.start();
-    double f = eval_values<ROW16, OD>(W.z, W.rho, W, c, lane, true, pf, 12);
+    double f = eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, true, pf, 12);
     // objective scaling from |grad f|_inf at the start: with lam = 0 the column pass returns r_d = grad f
     for (int i = lane; i < m; i += 64) { W.sl[i] = fmax(W.g[i], 1e-2); W.lam[i] = 0.0; }
     SC_SYNC();
     double e_p, e_c0, lmax;
     row_pass(W, c, lane, e_p, e_c0, lmax);
     SC_SYNC();
-    stage_pass<KT, ROW16, OD>(W, c, lane, 1.0);
+    stage_pass<KT, ROW16, OD, UNI>(W, c, lane, 1.0);
     SC_SYNC();
-    const double gmax = col_pass<OD>(W, c, lane, 1.0);
+    const double gmax = col_pass<OD, UNI>(W, c, lane, 1.0);
     const double sf = fmin(1.0, 100.0 / fmax(1e-12, gmax));             // objective scaling
     double mu = p.mu_init;
     SC_SYNC();
@@ -861,15 +879,15 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
     for (int i = lane; i < n; i += 64) { W.zb[i] = W.z[i]; if constexpr (OD) W.rhob[i] = W.rho[i]; }
     for (it = 1; it <= p.max_iter; ++it) {
-        if (it > 1) f = eval_values<ROW16, OD>(W.z, W.rho, W, c, lane, true, pf, 12);
+        if (it > 1) f = eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, true, pf, 12);
         SC_PH(0);
         row_pass(W, c, lane, e_p, e_c0, lmax);
         SC_SYNC();
         SC_PH(1);
-        const double e_rho = stage_pass<KT, ROW16, OD>(W, c, lane, sf);
+        const double e_rho = stage_pass<KT, ROW16, OD, UNI>(W, c, lane, sf);
         SC_SYNC();
         SC_PH(2);
-        const double e_d = fmax(e_rho, col_pass<OD>(W, c, lane, sf));
+        const double e_d = fmax(e_rho, col_pass<OD, UNI>(W, c, lane, sf));
         SC_PH(3);
         const double e_opt = fmax(e_d, fmax(e_p, e_c0));
         if (e_opt < e_best) {                                            // remember the best iterate
@@ -892,12 +910,12 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
             else break;
         }
         SC_PH(4);
-        phi_times_G<MS>(W, c, lane);
+        phi_times_G<MS, UNI ? 2 : 4>(W, c, lane);
         SC_SYNC();
         SC_PH(5);
         // condensed system  (sf W + J' Sigma J) dz = -r_d + J' (mu/s - Sigma r_p - lam)
         for (int col = lane; col < n; col += 64) W.rhs[col] = -W.cv[col] + (mu * W.cv[n + col] - W.cv[2 * n + col]);
-        condense_mfma<MS, OD>(W, c, lane, sf);
+        condense_mfma<MS, OD, UNI>(W, c, lane, sf);
         SC_SYNC();
         SC_PH(6);
         // inertia correction: M + delta I until the Cholesky succeeds
@@ -980,11 +998,11 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
                      w1r * (W.dh[2 * e1] * W.dp[2 * k + 2] + W.dh[2 * e1 + 1] * W.dp[2 * k + 3]) +
                      c.w2 * (W.dh[2 * e2] * W.dp[2 * k + 4] + W.dh[2 * e2 + 1] * W.dp[2 * k + 5]);
                 if constexpr (OD) jd += W.A1[i] * W.drho[2 * k] + W.A2[i] * W.drho[2 * k + 1];
-            } else if (i < c.mc + 2 * N) {
+            } else if (i < c.mc + c.ns) {
                 const int r = i - c.mc, k = (r >> 1) + 1;
                 jd = (r & 1) ? W.dV[k] : -W.dV[k];
             } else {
-                const int r = i - c.mc - 2 * N;
+                const int r = i - c.mc - c.ns;
                 jd = r < n ? -W.dz[r] : W.dz[r - n];
             }
             const double ds = jd + rp;
@@ -1012,7 +1030,7 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
                 if constexpr (OD) W.rhot[i] = W.rho[i] + alpha * W.drho[i];
             }
             SC_SYNC();
-            const double ft = eval_values<ROW16, OD>(W.zt, W.rhot, W, c, lane, false, pf, 16);
+            const double ft = eval_values<ROW16, OD, UNI>(W.zt, W.rhot, W, c, lane, false, pf, 16);
             double srp = 0.0;
             LogSum lst;
             for (int i = lane; i < m; i += 64) {
@@ -1051,7 +1069,7 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         status = SC_STATUS_OPTIMAL;
     }
     SC_SYNC();
-    eval_values<ROW16, OD>(W.z, W.rho, W, c, lane, false, pf, 16);
+    eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, false, pf, 16);
     if (status != SC_STATUS_OPTIMAL) {
         double gmin = 1e300;
         for (int i = lane; i < m; i += 64) gmin = fmin(gmin, W.g[i]);
@@ -1092,6 +1110,24 @@ void mpccbf_kernel_rt(const sc_mpccbf_params p, const long long B, const int K_r
                       TIO* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, TIO* __restrict__ z_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     mpccbf_body<TIO, 0, 0>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
+}
+
+// kinematic Unicycle2D (robots/unicycle2D.py through position_control/mpc_cbf.py), K run-time
+template <typename TIO, int NT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void mpccbf_uni_kernel(const sc_mpccbf_params p, const long long B, const int K_rt, const TIO* __restrict__ X,
+                       const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
+                       TIO* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    mpccbf_body<TIO, NT, 0, false, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
+}
+template <typename TIO>
+__global__ __launch_bounds__(64)
+void mpccbf_uni_kernel_rt(const sc_mpccbf_params p, const long long B, const int K_rt, const TIO* __restrict__ X,
+                          const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
+                          TIO* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    mpccbf_body<TIO, 0, 0, false, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
 }
 
 // optimal-decay variant (position_control/optimal_decay_mpc_cbf.py), K run-time.  Compile-time horizon: capped at 256
@@ -1149,7 +1185,7 @@ hipError_t odmpccbf_launch(const sc_odmpccbf_params& q, long long B, int K, cons
     return odmpc_launch_t<double>(q, B, K, X, u_prev, goal, obs, u_out, rho_out, status, iters, z_out, stream);
 }
 
-template <typename TIO, int NT, int KT>
+template <typename TIO, int NT, int KT, bool UNI = false>
 static hipError_t mpc_launch_one(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
                                  const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                                  hipStream_t stream) {
@@ -1163,7 +1199,9 @@ static hipError_t mpc_launch_one(const sc_mpccbf_params& p, long long B, int K, 
                            (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status, iters, (TIO*)z_out);
         return hipGetLastError();
     };
-    if constexpr (NT > 0) return launch(mpccbf_kernel<TIO, NT, KT>);
+    if constexpr (UNI && NT > 0) return launch(mpccbf_uni_kernel<TIO, NT>);
+    else if constexpr (UNI) return launch(mpccbf_uni_kernel_rt<TIO>);
+    else if constexpr (NT > 0) return launch(mpccbf_kernel<TIO, NT, KT>);
     else return launch(mpccbf_kernel_rt<TIO>);
 }
 
@@ -1171,6 +1209,10 @@ template <typename TIO>
 static hipError_t mpc_launch_t(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
                                const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                                hipStream_t stream) {
+    if (p.model_id == SC_MODEL_UNICYCLE2D) {
+        if (p.horizon == 10) return mpc_launch_one<TIO, 10, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        return mpc_launch_one<TIO, 0, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+    }
     if (p.horizon == 10 && K == 8)            // BASELINE config 3
         return mpc_launch_one<TIO, 10, 8>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
     if (p.horizon == 10)                      // the reference's default horizon (mpc_cbf.py:15) with any obstacle count

@@ -26,13 +26,17 @@ def default_mpc_weights(model):
     """Q, R of MPCCBF.__init__ (position_control/mpc_cbf.py:19-43)."""
     if model == "DynamicUnicycle2D":
         return np.diag([50.0, 50.0, 0.01, 30.0]), np.array([0.5, 0.5])
-    raise NotImplementedError(f"MPC-CBF on the batched engine supports DynamicUnicycle2D, not {model}")
+    if model == "Unicycle2D":
+        return np.diag([50.0, 50.0, 0.01]), np.array([0.5, 0.5])
+    raise NotImplementedError(f"MPC-CBF on the batched engine supports DynamicUnicycle2D and Unicycle2D, not {model}")
 
 
 def default_mpc_cbf_param(model):
     """DT-CBF gains, position_control/mpc_cbf.py:49-88."""
     if model == "DynamicUnicycle2D":
         return {"alpha1": 0.15, "alpha2": 0.15}
+    if model == "Unicycle2D":
+        return {"alpha": 0.05}                              # mpc_cbf.py:52-53
     raise NotImplementedError(model)
 
 
@@ -74,11 +78,15 @@ def make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_
     p.dt = float(dt)
     qd = np.diag(np.asarray(Q, dtype=np.float64)) if np.ndim(Q) == 2 else np.asarray(Q, dtype=np.float64)
     for i in range(4):
-        p.Q[i] = float(qd[i])
+        p.Q[i] = float(qd[i]) if i < len(qd) else 0.0
     p.R[0], p.R[1] = float(R[0]), float(R[1])
-    p.alpha1, p.alpha2 = float(cbf_param["alpha1"]), float(cbf_param["alpha2"])
     p.v_max = float(robot_spec["v_max"])
-    p.u_max[0], p.u_max[1] = float(robot_spec["a_max"]), float(robot_spec["w_max"])
+    if robot_spec["model"] == "Unicycle2D":                 # inputs [v, omega] (mpc_cbf.py:188-192), one gain alpha
+        p.alpha1, p.alpha2 = float(cbf_param["alpha"]), 0.0
+        p.u_max[0], p.u_max[1] = float(robot_spec["v_max"]), float(robot_spec["w_max"])
+    else:
+        p.alpha1, p.alpha2 = float(cbf_param["alpha1"]), float(cbf_param["alpha2"])
+        p.u_max[0], p.u_max[1] = float(robot_spec["a_max"]), float(robot_spec["w_max"])
     p.robot_radius = float(radius)
     p.beta = 1.01                                           # agent_barrier_dt default, dynamic_unicycle2D.py:188
     p.tol, p.mu_init, p.mu_min = float(tol), float(mu_init), float(mu_min)
@@ -100,7 +108,7 @@ class MPCCBF:
         self.dt = robot.dt
         model = self.robot_spec["model"]
         self.Q, self.R = default_mpc_weights(model)
-        self.n_controls, self.n_states = 2, 4
+        self.n_controls, self.n_states = 2, (3 if model == "Unicycle2D" else 4)
         self.goal = np.array([0, 0])
         self.cbf_param = apply_mpc_overrides(default_mpc_cbf_param(model), self.robot_spec)
         self.obs = None
@@ -125,7 +133,9 @@ class MPCCBF:
         self.update_tvp(goal, nearest_obs)
         if control_ref["state_machine"] != "track":         # mpc_cbf.py:379-381: pass the reference through
             return control_ref["u_ref"]
-        X = np.ascontiguousarray(np.asarray(robot_state, dtype=np.float64).reshape(-1)[:4])
+        X = np.zeros(4)                                     # the C-ABI takes [B,4] rows; Unicycle2D leaves X[3] unused
+        xs = np.asarray(robot_state, dtype=np.float64).reshape(-1)[: self.n_states]
+        X[: xs.shape[0]] = xs
         g = np.ascontiguousarray(np.asarray(self.goal, dtype=np.float64).reshape(-1)[:2])
         obs = np.ascontiguousarray(self.obs, dtype=np.float64)
         p = make_params(self.robot_spec, self.cbf_param, self.Q, self.R, self.horizon, self.dt,
@@ -148,6 +158,7 @@ class BatchedMPCCBF:
 
     ``solve(X[B,4], u_prev[B,2], goal[B,2], obs[B,K,7] | obs[K,7])`` ->
     ``u[B,2]``, ``status[B] int32``, ``iters[B] int32`` (and ``z[B,2N]`` if asked).
+    Unicycle2D states are [x, y, theta] padded to 4 columns (the last is not read).
     """
 
     def __init__(self, robot_spec, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None,

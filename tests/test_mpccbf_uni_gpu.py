@@ -1,0 +1,87 @@
+"""GPU tests of the MPC-CBF kernel on the kinematic Unicycle2D model (pytest -m gpu), through the C-ABI.
+
+Same bar as tests/test_mpccbf_gpu.py: the kernel follows oracle/mpc_cbf_uni.py + oracle/mpc_cbf.solve iterate for
+iterate in f64 (same status, iteration counts within 2, |u0 - u0_oracle| <= 1e-6), and every point reported optimal
+is feasible to 1e-6 on the restated problem.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from oracle import mpc_cbf_uni as U  # noqa: E402
+import safe_control_amd as sca  # noqa: E402
+from safe_control_amd import workloads as W  # noqa: E402
+
+DEV = "cuda:0"
+SPEC = {"model": "Unicycle2D", "v_max": 1.0, "w_max": 0.5, "radius": 0.25}
+P = dict(U.DEFAULTS)
+
+
+def scene(B, K, seed):
+    X, goal, ur, obs = W.du_cbfqp_batch(B, K, seed=seed)
+    X[:, 3] = 0.0
+    return X, goal, obs
+
+
+def run_gpu(X, up, goal, obs, io="f64", horizon=10):
+    ctl = sca.BatchedMPCCBF(dict(SPEC), io_dtype=io, horizon=horizon)
+    td = ctl.torch_dtype
+    t = lambda a: torch.tensor(a, dtype=td, device=DEV)
+    tX, tu, tg, to = t(X), t(up), t(goal), t(obs)
+    u, st, it, z = ctl.solve(tX, tu, tg, to, want_z=True)
+    torch.cuda.synchronize()
+    seen = tuple(a.double().cpu().numpy() for a in (tX, tu, tg, to))
+    return u.double().cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), z.double().cpu().numpy(), seen
+
+
+@pytest.mark.parametrize("io", ["f64", "f32"])
+def test_batch_against_oracle(io):
+    B = 96
+    X, goal, obs = scene(B, 8, seed=0)
+    rng = np.random.default_rng(0)
+    up = rng.uniform(-1, 1, (B, 2)) * np.array([0.8, 0.4])
+    u, st, it, z, (Xs, us, gs, os_) = run_gpu(X, up, goal, obs, io)
+    same = 0
+    for i in range(B):
+        uo, so, ito, info = U.solve(Xs[i], us[i], gs[i], os_[i], return_info=True)
+        assert st[i] == so, (i, st[i], so)
+        if so == 0:
+            tol = 1e-6 if io == "f64" else 5e-6
+            assert np.abs(u[i] - uo).max() <= tol, (i, u[i], uo)
+            assert np.abs(z[i] - info["z"]).max() <= 20 * tol
+            assert abs(it[i] - ito) <= 2
+            ev = U.evaluate(Xs[i], z[i], us[i], gs[i], os_[i], P, level=0)
+            assert ev["g"].min() >= -1e-6
+        same += int(it[i] == ito)
+    assert same >= 0.9 * B
+    assert (st == 0).mean() > 0.8
+
+
+@pytest.mark.parametrize("N,K", [(5, 3), (10, 1), (16, 5), (20, 12)])
+def test_other_horizons_and_obstacle_counts(N, K):
+    B = 16
+    X, goal, obs = scene(B, K, seed=N * 10 + K)
+    up = np.zeros((B, 2))
+    u, st, it, z, _ = run_gpu(X, up, goal, obs, "f64", horizon=N)
+    for i in range(0, B, 2):
+        uo, so, ito = U.solve(X[i], up[i], goal[i], obs[i], params={"N": N})
+        assert st[i] == so
+        if so == 0:
+            assert np.abs(u[i] - uo).max() <= 1e-6
+
+
+def test_single_agent_plugin_and_unsupported_optimal_decay():
+    from safe_control_amd.robots.spec import RobotHandle
+    X, goal, obs = scene(4, 5, seed=2)
+    robot = RobotHandle(X[0][:3].reshape(-1, 1), dict(SPEC), 0.05)
+    ctl = sca.MPCCBF(robot, dict(SPEC), num_obs=5)
+    assert ctl.n_states == 3 and ctl.cbf_param == {"alpha": 0.05}
+    ref = {"goal": goal[0], "state_machine": "track", "u_ref": np.zeros((2, 1))}
+    u = ctl.solve_control_problem(X[0][:3].reshape(-1, 1), ref, obs[0])
+    uo, so, ito = U.solve(X[0], np.zeros(2), goal[0], obs[0])
+    assert ctl.solver_status == "optimal" and so == 0
+    assert np.abs(u.ravel() - uo).max() <= 1e-6
+    with pytest.raises(NotImplementedError):
+        sca.BatchedOptimalDecayMPCCBF(dict(SPEC))
