@@ -39,6 +39,12 @@ __device__ __forceinline__ void nominal_input(const T x, const T y, const T th, 
         const T vd = (fabs_(err) > pi / T(2)) ? T(0) : fmin_(t.k_v * d * cs, t.v_max);
         u0 = t.k_a * (vd - v);
         u1 = t.k_omega * err;
+    } else if constexpr (MODEL == SC_MODEL_UNICYCLE2D) {
+        // robots/unicycle2D.py:69-85 with the gains BaseRobot forwards (robots/robot.py:404-405): d_min .05,
+        // k_omega 2, k_v 1; the speed command is not clipped
+        const T d = fmax_(dist - T(0.05), T(0.05));
+        u0 = (fabs_(err) > pi / T(2)) ? T(0) : T(1) * d * cs;
+        u1 = T(2) * err;
     } else {
         const T d = fmax_(dist - T(0.05), T(0.05));
         const T delta = fmin_(fmax_(t.k_omega * err, -t.delta_max), t.delta_max);
@@ -47,6 +53,39 @@ __device__ __forceinline__ void nominal_input(const T x, const T y, const T th, 
         const T vd = fmin_(fmax_(vcmd, t.v_min), t.v_max);
         u0 = t.k_a * (vd - v);
     }
+}
+
+// stop(): DU brakes with k_a (dynamic_unicycle2D.py:106-111); KB and Unicycle2D return zeros (kinematic_bicycle2D.py:149-150,
+// unicycle2D.py:87-88)
+template <typename T, int MODEL>
+__device__ __forceinline__ T stop_input0(const T v, const T k_a) {
+    return (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? k_a * (T(0) - v) : T(0);
+}
+// has_stopped(): |v| < .05 (DU :113-114, KB :152-153); the kinematic unicycle always has (unicycle2D.py:90-92)
+template <typename T, int MODEL>
+__device__ __forceinline__ bool has_stopped(const T v) {
+    if constexpr (MODEL == SC_MODEL_UNICYCLE2D) return true;
+    else return fabs_(v) < T(0.05);
+}
+// step(): X + (f + g u) dt, heading wrapped (DU :75-78 ; KB :113-123, speed clipped ; Unicycle2D unicycle2D.py:64-67,
+// whose 4th state column is padding and stays as it is)
+template <typename T, int MODEL>
+__device__ __forceinline__ void robot_step(const Agent<T>& a, const T u0, const T u1, const T dt, const T Lr, const T v_min,
+                                           const T v_max, T& nx, T& ny, T& nth, T& nv) {
+    if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) {
+        nx = a.x + (a.f0) * dt; ny = a.y + (a.f1) * dt;
+        nth = a.th + (T(0) + u1) * dt; nv = a.v + (T(0) + u0) * dt;
+    } else if constexpr (MODEL == SC_MODEL_UNICYCLE2D) {
+        nx = a.x + (T(0) + a.c * u0) * dt; ny = a.y + (T(0) + a.s * u0) * dt;
+        nth = a.th + (T(0) + u1) * dt; nv = a.v;
+    } else {
+        nx = a.x + (a.f0 + (-a.f1) * u1) * dt;
+        ny = a.y + (a.f1 + a.f0 * u1) * dt;
+        nth = a.th + (T(0) + (a.v / Lr) * u1) * dt;
+        nv = a.v + (T(0) + u0) * dt;
+        nv = fmin_(fmax_(nv, v_min), v_max);                              // np.clip in KinematicBicycle2D.step
+    }
+    nth = angle_normalize(nth);
 }
 
 // tracking.py:445-495 known-obstacle collision test (circle / superellipsoid, geometry rule :428-443)
@@ -139,7 +178,7 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
         if (run) {
             // ---- state machine / goal (tracking.py:569-577) ----------------------------------
             if (sm == SC_SM_STOP) {
-                if (fabs_(v) < TC(0.05)) {
+                if (has_stopped<TC, MODEL>(v)) {
                     sm = t.enable_rotation ? SC_SM_ROTATE : SC_SM_TRACK;
                     update_goal();
                 }
@@ -209,7 +248,7 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
             const TC ga = atan2_(gy - y, gx - x);
             ur0 = TC(0); ur1 = TC(2) * angle_normalize(ga - th);           // rotate_to, k = 2
         } else if (!gvalid) {
-            ur0 = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? t.k_a * (TC(0) - v) : TC(0);   // stop()
+            ur0 = stop_input0<TC, MODEL>(v, t.k_a);                          // stop()
             ur1 = TC(0);
         } else {
             nominal_input<TC, MODEL>(x, y, th, v, gx, gy, t, ur0, ur1);
@@ -226,17 +265,7 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
         // pre-step: infeasible or already colliding -> -2, the robot does not move
         const bool pre_fail = (st != SC_STATUS_OPTIMAL) || collides<TC>(x, y, table, M, k.R);
         TC nx, ny, nth, nv;
-        if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) {
-            nx = x + (agn.f0) * t.dt; ny = y + (agn.f1) * t.dt;
-            nth = th + (TC(0) + u1) * t.dt; nv = v + (TC(0) + u0) * t.dt;
-        } else {
-            nx = x + (agn.f0 + (-agn.f1) * u1) * t.dt;
-            ny = y + (agn.f1 + agn.f0 * u1) * t.dt;
-            nth = th + (TC(0) + (v / t.Lr) * u1) * t.dt;
-            nv = v + (TC(0) + u0) * t.dt;
-            nv = fmin_(fmax_(nv, t.v_min), t.v_max);                        // np.clip in KinematicBicycle2D.step
-        }
-        nth = angle_normalize(nth);
+        robot_step<TC, MODEL>(agn, u0, u1, t.dt, t.Lr, t.v_min, t.v_max, nx, ny, nth, nv);
         int code;
         if (pre_fail) code = -2;
         else if (collides<TC>(nx, ny, table, M, k.R)) code = -2;             // post-step: the robot HAS moved
@@ -328,7 +357,7 @@ __global__ __launch_bounds__(64) void tracking_select_kernel(
     };
     if (run) {
         if (sm == SC_SM_STOP) {
-            if (fabs_(v) < TC(0.05)) {
+            if (has_stopped<TC, MODEL>(v)) {
                 sm = t.enable_rotation ? SC_SM_ROTATE : SC_SM_TRACK;
                 update_goal();
             }
@@ -369,7 +398,7 @@ __global__ __launch_bounds__(64) void tracking_select_kernel(
         const TC ga = atan2_(gy - y, gx - x);
         ur0 = TC(0); ur1 = TC(2) * angle_normalize(ga - th);
     } else if (!gvalid) {
-        ur0 = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? t.k_a * (TC(0) - v) : TC(0);
+        ur0 = stop_input0<TC, MODEL>(v, t.k_a);
         ur1 = TC(0);
     } else {
         nominal_input<TC, MODEL>(x, y, th, v, gx, gy, t, ur0, ur1);
@@ -418,17 +447,7 @@ __global__ __launch_bounds__(64) void tracking_apply_kernel(
     const Agent<TC> agn = make_agent<TC>(x, y, th, v);
     const bool pre_fail = (st != SC_STATUS_OPTIMAL) || collides<TC>(x, y, table, M, k.R);
     TC nx, ny, nth, nv;
-    if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) {
-        nx = x + (agn.f0) * dt; ny = y + (agn.f1) * dt;
-        nth = th + (TC(0) + u1) * dt; nv = v + (TC(0) + u0) * dt;
-    } else {
-        nx = x + (agn.f0 + (-agn.f1) * u1) * dt;
-        ny = y + (agn.f1 + agn.f0 * u1) * dt;
-        nth = th + (TC(0) + (v / Lr) * u1) * dt;
-        nv = v + (TC(0) + u0) * dt;
-        nv = fmin_(fmax_(nv, TC(p.v_min)), TC(p.v_max));
-    }
-    nth = angle_normalize(nth);
+    robot_step<TC, MODEL>(agn, u0, u1, dt, Lr, TC(p.v_min), TC(p.v_max), nx, ny, nth, nv);
     int code;
     if (pre_fail) code = -2;
     else if (collides<TC>(nx, ny, table, M, k.R)) code = -2;
@@ -573,7 +592,7 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
         const bool run = (ret == 0);
         if (run) {
             if (sm == SC_SM_STOP) {                                   // tracking.py:569-577
-                if (fabs_(v) < TC(0.05)) {
+                if (has_stopped<TC, MODEL>(v)) {
                     sm = t.enable_rotation ? SC_SM_ROTATE : SC_SM_TRACK;
                     update_goal();
                 }
@@ -653,7 +672,7 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
             const TC ga = atan2_(gy - y, gx - x);
             ur0 = TC(0); ur1 = TC(2) * angle_normalize(ga - th);           // rotate_to, k = 2
         } else if (!gvalid) {
-            ur0 = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? t.k_a * (TC(0) - v) : TC(0);   // stop()
+            ur0 = stop_input0<TC, MODEL>(v, t.k_a);                          // stop()
             ur1 = TC(0);
         } else {
             nominal_input<TC, MODEL>(x, y, th, v, gx, gy, t, ur0, ur1);
@@ -677,17 +696,7 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
         // ---- collision / status / step (tracking.py:627-646) ---------------------------------------
         const bool pre_fail = (st != SC_STATUS_OPTIMAL) || collides_group(x, y);
         TC nx, ny, nth, nv;
-        if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) {
-            nx = x + (agn.f0) * t.dt; ny = y + (agn.f1) * t.dt;
-            nth = th + (TC(0) + u1) * t.dt; nv = v + (TC(0) + u0) * t.dt;
-        } else {
-            nx = x + (agn.f0 + (-agn.f1) * u1) * t.dt;
-            ny = y + (agn.f1 + agn.f0 * u1) * t.dt;
-            nth = th + (TC(0) + (v / t.Lr) * u1) * t.dt;
-            nv = v + (TC(0) + u0) * t.dt;
-            nv = fmin_(fmax_(nv, t.v_min), t.v_max);                        // np.clip in KinematicBicycle2D.step
-        }
-        nth = angle_normalize(nth);
+        robot_step<TC, MODEL>(agn, u0, u1, t.dt, t.Lr, t.v_min, t.v_max, nx, ny, nth, nv);
         const bool post_hit = collides_group(nx, ny);
         int code;
         if (pre_fail) code = -2;
@@ -775,6 +784,8 @@ static hipError_t launch_track_m(const sc_tracking_params& p, long long B, int M
             return launch_track_k<TIO, TC, SC_MODEL_DYNAMIC_UNICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
         case SC_MODEL_KINEMATIC_BICYCLE2D:
             return launch_track_k<TIO, TC, SC_MODEL_KINEMATIC_BICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+        case SC_MODEL_UNICYCLE2D:
+            return launch_track_k<TIO, TC, SC_MODEL_UNICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
         case SC_MODEL_KINEMATIC_BICYCLE2D_C3BF:
             return launch_track_k<TIO, TC, SC_MODEL_KINEMATIC_BICYCLE2D_C3BF>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
         default:
@@ -807,6 +818,8 @@ static hipError_t launch_select_t(const sc_tracking_params& p, long long B, int 
                                   void* obs_out, void* goal_out, void* u_ref_out, int* track_out, hipStream_t stream) {
     if (p.qp.model_id == SC_MODEL_DYNAMIC_UNICYCLE2D)
         return launch_select_m<TIO, SC_MODEL_DYNAMIC_UNICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, ret, obs_out, goal_out, u_ref_out, track_out, stream);
+    if (p.qp.model_id == SC_MODEL_UNICYCLE2D)
+        return launch_select_m<TIO, SC_MODEL_UNICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, ret, obs_out, goal_out, u_ref_out, track_out, stream);
     return launch_select_m<TIO, SC_MODEL_KINEMATIC_BICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, ret, obs_out, goal_out, u_ref_out, track_out, stream);
 }
 
@@ -834,6 +847,7 @@ static hipError_t launch_apply_t(const sc_tracking_params& p, long long B, int M
         return hipGetLastError();
     };
     if (p.qp.model_id == SC_MODEL_DYNAMIC_UNICYCLE2D) return go(tracking_apply_kernel<TIO, double, SC_MODEL_DYNAMIC_UNICYCLE2D>);
+    if (p.qp.model_id == SC_MODEL_UNICYCLE2D) return go(tracking_apply_kernel<TIO, double, SC_MODEL_UNICYCLE2D>);
     return go(tracking_apply_kernel<TIO, double, SC_MODEL_KINEMATIC_BICYCLE2D>);
 }
 

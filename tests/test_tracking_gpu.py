@@ -187,3 +187,86 @@ def test_closed_loop_with_mpc_position_controller(golden_dir, pos):
                 break
         n_track += state.get("n", 0)
     assert n_track >= T                                           # the MPC really ran in the loop
+
+
+def test_unicycle2d_closed_loop_against_oracle(golden_dir):
+    """test_tracking.py --model un with the CBF-QP behind it: the reference's CBFQP cannot run this model as checked in
+    (tests/golden/make_golden.py gen_unicycle2d), so the loop is checked against oracle/tracking.py over the robot
+    functions that ARE pinned on the reference (tests/golden/unicycle2d.npz: step, nominal_input, stop, rotate_to,
+    barrier).  3-wide start poses; has_stopped() is always true for this model."""
+    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    obs = g["du14/obs"]
+    rng = np.random.default_rng(11)
+    B, T = 40, 300
+    spec = {"model": "Unicycle2D", "v_max": 1.0, "w_max": 0.5, "radius": 0.25}
+    X0, wlists = [], []
+    while len(X0) < B:
+        p = rng.uniform(0.5, 13.5, 2)
+        if np.min(np.hypot(obs[:, 0] - p[0], obs[:, 1] - p[1]) - obs[:, 2]) < 0.6:
+            continue
+        X0.append([p[0], p[1], rng.uniform(-np.pi, np.pi)])
+        wlists.append(rng.uniform(1, 13, (int(rng.integers(1, 4)), 2)))
+    X0 = np.array(X0)
+    ospec = {k: v for k, v in spec.items() if k != "model"}
+    for mode in ("0", "1"):                                       # cooperative and lane-per-agent kernels
+        os.environ["SC_TRACK_LANE_PER_AGENT"] = mode
+        try:
+            ctl = sca.BatchedTrackingController(X0, dict(spec), obs=obs, io_dtype="f64")
+            ctl.set_waypoints(wlists)
+            ret, tX, tU = ctl.control_step(T, record=True)
+        finally:
+            os.environ.pop("SC_TRACK_LANE_PER_AGENT", None)
+        tX = tX.cpu().numpy(); ret = ret.cpu().numpy(); rstep = ctl.ret_step.cpu().numpy()
+        n_done = 0
+        for i in range(B):
+            Xo, rets, t = oracle_rollout(R.MODEL_UNI, X0[i], ospec, obs, wlists[i], T)
+            n = len(rets)
+            np.testing.assert_allclose(tX[:n, i], Xo, rtol=1e-6, atol=1e-6, err_msg=f"agent {i}")
+            if rets[-1] != 0:
+                assert ret[i] == rets[-1] and rstep[i] == n - 1, (i, ret[i], rets[-1], rstep[i], n)
+                n_done += 1
+            else:
+                assert ret[i] == 0
+            assert int(ctl.state_machine[i].item()) == SM[t.state_machine]
+        assert n_done > 0
+
+
+def test_unicycle2d_closed_loop_with_mpc(golden_dir):
+    """test_tracking.py --model un (default --algo mpc_cbf), batched, against the oracle loop with the Unicycle2D MPC
+    oracle behind solve_fn."""
+    from oracle import mpc_cbf as M, mpc_cbf_uni as U
+    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    obs = g["du14/obs"]
+    K = 8
+    spec = {"model": "Unicycle2D", "v_max": 1.0, "w_max": 0.5, "radius": 0.25, "num_constraints": K}
+    X0 = np.array([[2.0, 2.0, np.pi / 2], [6.0, 1.0, 2.6], [1.0, 6.0, -1.2]])       # the last one starts in 'stop'
+    wl = [np.array([[2.0, 12.0], [12.0, 12.0]]), np.array([[1.0, 4.0]]), np.array([[1.0, 12.0]])]
+    T = 30
+    ctl = sca.BatchedTrackingController(X0, dict(spec), controller_type={"pos": "mpc_cbf"}, obs=obs, io_dtype="f64")
+    ctl.set_waypoints(wl)
+    ret, tX, tU = ctl.control_step(T, record=True)
+    tX = tX.cpu().numpy(); ret = ret.cpu().numpy()
+    ospec = {k: v for k, v in spec.items() if k not in ("model", "num_constraints")}
+    n_track = 0
+    for i in range(len(X0)):
+        state = {"up": np.zeros(2)}
+
+        def solve_fn(X, cref, nobs, state=state):
+            if cref["state_machine"] != "track":
+                return np.asarray(cref["u_ref"], dtype=np.float64).reshape(-1), 0
+            o = M.pad_obstacles(None if nobs is None else list(nobs), K)
+            u, st, it = U.solve(X, state["up"], cref["goal"], o)
+            state["up"] = u
+            state["n"] = state.get("n", 0) + 1
+            return u, 0
+
+        t = tracking.TrackingOracle(R.MODEL_UNI, X0[i], ospec, dt=0.05, obs=obs, num_constraints=K, solve_fn=solve_fn)
+        t.set_waypoints(wl[i])
+        for k in range(T):
+            r = t.control_step()
+            np.testing.assert_allclose(tX[k, i], t.X, rtol=0, atol=5e-6, err_msg=f"agent {i} step {k}")
+            if r != 0:
+                assert ret[i] == r
+                break
+        n_track += state.get("n", 0)
+    assert n_track >= T
