@@ -810,17 +810,43 @@ __device__ inline void chol_solve(const double* L, double* b, int n, int lane) {
     }
 }
 
+// Factor M + delta I and solve for the right-hand side, all in registers (mpc_chol.hpp); false on a pivot <= 0.
+// Arguments are offsets (doubles) into the workgroup's LDS block.  NOT inlined on purpose: unrolled for n = 40 the
+// factorisation and the two triangular solves are ~45 KB of code, and inlined they push the interior-point loop of the
+// N = 20 kernel past the +-128 KB reach of s_cbranch; the relaxed long branches need a free SGPR pair, which a kernel
+// with a few hundred spilled SGPRs does not have -- the result was a kernel whose iterates changed with unrelated
+// code motion.  Out of line the loop stays ~100 KB for every instantiation.
+template <int nn>
+__device__ __attribute__((noinline)) bool chol_factor_solve(int oM, int oRhs, int oLt, int oOut, double delta, int lane) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const double* M = lds + oM;
+    double a[nn], diag;
+    const int row = lane < nn ? lane : 0;                                  // lanes >= n: unused copies of row 0
+#pragma unroll
+    for (int k = 0; k < nn; ++k) a[k] = M[row * nn + k] + (lane == k ? delta : 0.0);
+    if (!chol_reg<nn>(a, lane, diag)) return false;
+    const double x = chol_solve_reg<nn>(a, diag, lds[oRhs + row], lds + oLt, lane);
+    if (lane < nn) lds[oOut + lane] = x;
+    SC_SYNC();
+    return true;
+}
+
 // NT, KT > 0: horizon and obstacle count are compile-time constants (index arithmetic folds to shifts and
 // multiplies); NT == 0: run-time sizes.
 struct OdExtra { double omega_ref[2], p_sb[2]; };
 
-template <typename TIO, int NT, int KT, bool OD = false, bool UNI = false>
+// The element type of the caller's arrays (p.io_dtype) only matters for the handful of loads at the start and stores at
+// the end, so it is a run-time switch: one body per (NT, KT, OD, UNI) instead of two.
+template <int NT, int KT, bool OD = false, bool UNI = false>
 __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& p, const long long B, const int K_rt,
-                                            const TIO* __restrict__ X, const TIO* __restrict__ u_prev,
-                                            const TIO* __restrict__ goal, const TIO* __restrict__ obs,
-                                            TIO* __restrict__ u_out, int* __restrict__ status_out,
-                                            int* __restrict__ iters_out, TIO* __restrict__ z_out,
-                                            const OdExtra od = OdExtra{{1.0, 1.0}, {0.0, 0.0}}, TIO* __restrict__ rho_out = nullptr) {
+                                            const void* __restrict__ X, const void* __restrict__ u_prev,
+                                            const void* __restrict__ goal, const void* __restrict__ obs,
+                                            void* __restrict__ u_out, int* __restrict__ status_out,
+                                            int* __restrict__ iters_out, void* __restrict__ z_out,
+                                            const OdExtra od = OdExtra{{1.0, 1.0}, {0.0, 0.0}}, void* __restrict__ rho_out = nullptr) {
+    const bool io32 = p.io_dtype == SC_DTYPE_F32;
+    auto ld = [io32](const void* a, size_t i) { return io32 ? (double)((const float*)a)[i] : ((const double*)a)[i]; };
+    auto st = [io32](void* a, size_t i, double v) { if (io32) ((float*)a)[i] = (float)v; else ((double*)a)[i] = v; };
     const int lane = threadIdx.x;
     const long long prob = blockIdx.x;
     if (prob >= B) return;
@@ -832,9 +858,9 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     c.w0 = 1.0 - g1 + g2; c.w1 = g1 - 2.0; c.w2 = 1.0;
     if constexpr (UNI) { c.w0 = -(1.0 - p.alpha1); c.w1 = 1.0; c.w2 = 0.0; }   // relative degree 1: h(p_k+1) - (1 - alpha) h(p_k)
     c.vmax = p.v_max; c.amax = p.u_max[0]; c.wmaxu = p.u_max[1]; c.Rrob = p.robot_radius; c.beta = p.beta;
-    c.x0 = (double)X[prob * 4 + 0]; c.y0 = (double)X[prob * 4 + 1]; c.th0 = (double)X[prob * 4 + 2]; c.v0 = UNI ? 0.0 : (double)X[prob * 4 + 3];
-    c.up0 = (double)u_prev[prob * 2 + 0]; c.up1 = (double)u_prev[prob * 2 + 1];
-    c.gx = (double)goal[prob * 2 + 0]; c.gy = (double)goal[prob * 2 + 1];
+    c.x0 = ld(X, prob * 4 + 0); c.y0 = ld(X, prob * 4 + 1); c.th0 = ld(X, prob * 4 + 2); c.v0 = UNI ? 0.0 : ld(X, prob * 4 + 3);
+    c.up0 = ld(u_prev, prob * 2 + 0); c.up1 = ld(u_prev, prob * 2 + 1);
+    c.gx = ld(goal, prob * 2 + 0); c.gy = ld(goal, prob * 2 + 1);
     c.al1 = p.alpha1; c.al2 = p.alpha2; c.ps1 = od.p_sb[0]; c.ps2 = od.p_sb[1]; c.rf1 = od.omega_ref[0]; c.rf2 = od.omega_ref[1];
     const int N = c.N, n = c.n, m = c.m;
     const MpcMem W = carve(sm, N, K, OD);
@@ -842,8 +868,8 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     constexpr int MS = NT > 0 ? (2 * NT + 3) / 4 : 4;                  // MFMA k-steps batched per LDS round trip
     for (int e = lane; e < 2 * (N + 2) * n; e += 64) W.dP[e] = 0.0;      // structural zeros of G stay
 
-    const TIO* osrc = obs + (p.obs_shared ? 0 : (size_t)prob * K * 7);
-    for (int e = lane; e < K * 7; e += 64) W.obs[e] = (double)osrc[e];
+    const size_t obase = p.obs_shared ? 0 : (size_t)prob * K * 7;
+    for (int e = lane; e < K * 7; e += 64) W.obs[e] = ld(obs, obase + e);
     // set_initial_guess (mpc_cbf.py:369): u_prev at every stage, pulled strictly inside the box
     for (int i = lane; i < n; i += 64) {
         const double ub = (i & 1) ? c.wmaxu : c.amax;
@@ -922,20 +948,15 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         double delta = 0.0;
         bool ok = false;
         if constexpr (NT > 0) {
-            constexpr int nn = 2 * NT;
-            double a[nn], diag;
+            constexpr int nn = NT > 0 ? 2 * NT : 2;
+            // out of line (see chol_factor_solve): keeps the interior-point loop short enough for plain branches
             for (int t = 0; t < 40 && !ok; ++t) {
-#pragma unroll
-                for (int k = 0; k < nn; ++k) a[k] = W.M[(lane < nn ? lane : 0) * nn + k] + (lane == k ? delta : 0.0);   // lanes >= n: unused copies of row 0
-                ok = chol_reg<nn>(a, lane, diag);
+                ok = chol_factor_solve<nn>((int)(W.M - sm), (int)(W.rhs - sm), (int)(W.L - sm), (int)(W.dz - sm), delta, lane);
                 if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
             }
             if (!ok) break;
             if (delta > 0.0) delta_last = delta;
             SC_PH(7);
-            const double x = chol_solve_reg<nn>(a, diag, W.rhs[lane < nn ? lane : 0], W.L, lane);
-            if (lane < nn) W.dz[lane] = x;
-            SC_SYNC();
         } else {
             for (int t = 0; t < 40 && !ok; ++t) {
                 for (int e = lane; e < n * n; e += 64) W.L[e] = W.M[e] + ((e / n == e % n) ? delta : 0.0);
@@ -1059,6 +1080,9 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         }
         SC_SYNC();
         SC_PH(11);
+#if defined(SC_EXP_TRACE) && !defined(SC_EXP_BOTH)
+        if (z_out && lane == 0 && it <= 20) { st(z_out, prob * n + (it - 1) * 2, e_opt); st(z_out, prob * n + (it - 1) * 2 + 1, delta > 0 ? delta : alpha); }
+#endif
     }
     if (it > p.max_iter) it = p.max_iter;
     if (status != SC_STATUS_OPTIMAL && e_best <= p.acceptable_tol) {
@@ -1078,84 +1102,81 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         else if (status != SC_STATUS_INFEASIBLE) status = SC_STATUS_INACCURATE;
     }
     if (lane == 0) {
-        u_out[prob * 2 + 0] = (TIO)W.z[0];
-        u_out[prob * 2 + 1] = (TIO)W.z[1];
+        st(u_out, prob * 2 + 0, W.z[0]);
+        st(u_out, prob * 2 + 1, W.z[1]);
         status_out[prob] = status;
         if (iters_out) iters_out[prob] = it;
     }
 #ifdef SC_MPC_PROF
-    if (z_out && lane < 20 && lane < n) z_out[prob * n + lane] = (TIO)pf.ph[lane];
+    if (z_out && lane < 20 && lane < n) st(z_out, prob * n + lane, pf.ph[lane]);
+#elif defined(SC_EXP_TRACE)
 #else
-    if (z_out) for (int i = lane; i < n; i += 64) z_out[prob * n + i] = (TIO)W.z[i];
+    if (z_out) for (int i = lane; i < n; i += 64) st(z_out, prob * n + i, W.z[i]);
 #endif
     if constexpr (OD) {
-        if (rho_out) for (int i = lane; i < n; i += 64) rho_out[prob * n + i] = (TIO)W.rho[i];
+        if (rho_out) for (int i = lane; i < n; i += 64) st(rho_out, prob * n + i, W.rho[i]);
     }
 }
 
 // Compile-time horizon: capped at 256 VGPRs (two waves per SIMD; fits without spills).  Run-time sizes: no cap --
 // the run-time index arithmetic needs more registers and would spill heavily under it.
-template <typename TIO, int NT, int KT>
+template <int NT, int KT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void mpccbf_kernel(const sc_mpccbf_params p, const long long B, const int K_rt, const TIO* __restrict__ X,
-                   const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
-                   TIO* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+void mpccbf_kernel(const sc_mpccbf_params p, const long long B, const int K_rt, const void* __restrict__ X,
+                   const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
+                   void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<TIO, NT, KT>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
+    mpccbf_body<NT, KT>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
 }
-template <typename TIO>
 __global__ __launch_bounds__(64)
-void mpccbf_kernel_rt(const sc_mpccbf_params p, const long long B, const int K_rt, const TIO* __restrict__ X,
-                      const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
-                      TIO* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+void mpccbf_kernel_rt(const sc_mpccbf_params p, const long long B, const int K_rt, const void* __restrict__ X,
+                      const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
+                      void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<TIO, 0, 0>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
+    mpccbf_body<0, 0>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
 }
 
 // kinematic Unicycle2D (robots/unicycle2D.py through position_control/mpc_cbf.py), K run-time
-template <typename TIO, int NT>
+template <int NT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void mpccbf_uni_kernel(const sc_mpccbf_params p, const long long B, const int K_rt, const TIO* __restrict__ X,
-                       const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
-                       TIO* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+void mpccbf_uni_kernel(const sc_mpccbf_params p, const long long B, const int K_rt, const void* __restrict__ X,
+                       const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
+                       void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<TIO, NT, 0, false, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
+    mpccbf_body<NT, 0, false, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
 }
-template <typename TIO>
 __global__ __launch_bounds__(64)
-void mpccbf_uni_kernel_rt(const sc_mpccbf_params p, const long long B, const int K_rt, const TIO* __restrict__ X,
-                          const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
-                          TIO* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+void mpccbf_uni_kernel_rt(const sc_mpccbf_params p, const long long B, const int K_rt, const void* __restrict__ X,
+                          const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
+                          void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<TIO, 0, 0, false, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
+    mpccbf_body<0, 0, false, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
 }
 
 // optimal-decay variant (position_control/optimal_decay_mpc_cbf.py), K run-time.  Compile-time horizon: capped at 256
 // VGPRs (about 60 spilled registers, still 23 % faster at large batches: 6 problems per CU instead of 4); run-time
 // horizon: no cap.
-template <typename TIO, int NT>
+template <int NT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void odmpccbf_kernel(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const TIO* __restrict__ X,
-                     const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
-                     TIO* __restrict__ u_out, TIO* __restrict__ rho_out, int* __restrict__ status_out,
-                     int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+void odmpccbf_kernel(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const void* __restrict__ X,
+                     const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
+                     void* __restrict__ u_out, void* __restrict__ rho_out, int* __restrict__ status_out,
+                     int* __restrict__ iters_out, void* __restrict__ z_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<TIO, NT, 0, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
+    mpccbf_body<NT, 0, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
 }
-template <typename TIO>
 __global__ __launch_bounds__(64)
-void odmpccbf_kernel_rt(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const TIO* __restrict__ X,
-                        const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
-                        TIO* __restrict__ u_out, TIO* __restrict__ rho_out, int* __restrict__ status_out,
-                        int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+void odmpccbf_kernel_rt(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const void* __restrict__ X,
+                        const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
+                        void* __restrict__ u_out, void* __restrict__ rho_out, int* __restrict__ status_out,
+                        int* __restrict__ iters_out, void* __restrict__ z_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<TIO, 0, 0, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
+    mpccbf_body<0, 0, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
 }
 
 size_t mpccbf_lds_bytes(int N, int K) { return mpc_lds_doubles(N, K) * sizeof(double); }
 size_t odmpccbf_lds_bytes(int N, int K) { return mpc_lds_doubles(N, K, true) * sizeof(double); }
 
-template <typename TIO>
 static hipError_t odmpc_launch_t(const sc_odmpccbf_params& q, long long B, int K, const void* X, const void* u_prev,
                                  const void* goal, const void* obs, void* u_out, void* rho_out, int* status, int* iters,
                                  void* z_out, hipStream_t stream) {
@@ -1168,24 +1189,22 @@ static hipError_t odmpc_launch_t(const sc_odmpccbf_params& q, long long B, int K
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, od, B, K, (const TIO*)X, (const TIO*)u_prev,
-                           (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, (TIO*)rho_out, status, iters, (TIO*)z_out);
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, od, B, K, X, u_prev,
+                           goal, obs, u_out, rho_out, status, iters, z_out);
         return hipGetLastError();
     };
-    if (p.horizon == 10) return launch(odmpccbf_kernel<TIO, 10>);
-    return launch(odmpccbf_kernel_rt<TIO>);
+    if (p.horizon == 10) return launch(odmpccbf_kernel<10>);
+    return launch(odmpccbf_kernel_rt);
 }
 
 hipError_t odmpccbf_launch(const sc_odmpccbf_params& q, long long B, int K, const void* X, const void* u_prev,
                            const void* goal, const void* obs, void* u_out, void* rho_out, int* status, int* iters,
                            void* z_out, hipStream_t stream) {
     if (mpc_lds_doubles(q.mpc.horizon, K, true) * sizeof(double) > 160 * 1024) return hipErrorInvalidValue;
-    if (q.mpc.io_dtype == SC_DTYPE_F32)
-        return odmpc_launch_t<float>(q, B, K, X, u_prev, goal, obs, u_out, rho_out, status, iters, z_out, stream);
-    return odmpc_launch_t<double>(q, B, K, X, u_prev, goal, obs, u_out, rho_out, status, iters, z_out, stream);
+    return odmpc_launch_t(q, B, K, X, u_prev, goal, obs, u_out, rho_out, status, iters, z_out, stream);
 }
 
-template <typename TIO, int NT, int KT, bool UNI = false>
+template <int NT, int KT, bool UNI = false>
 static hipError_t mpc_launch_one(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
                                  const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                                  hipStream_t stream) {
@@ -1195,38 +1214,37 @@ static hipError_t mpc_launch_one(const sc_mpccbf_params& p, long long B, int K, 
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, B, K, (const TIO*)X, (const TIO*)u_prev,
-                           (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status, iters, (TIO*)z_out);
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, B, K, X, u_prev,
+                           goal, obs, u_out, status, iters, z_out);
         return hipGetLastError();
     };
-    if constexpr (UNI && NT > 0) return launch(mpccbf_uni_kernel<TIO, NT>);
-    else if constexpr (UNI) return launch(mpccbf_uni_kernel_rt<TIO>);
-    else if constexpr (NT > 0) return launch(mpccbf_kernel<TIO, NT, KT>);
-    else return launch(mpccbf_kernel_rt<TIO>);
+    if constexpr (UNI && NT > 0) return launch(mpccbf_uni_kernel<NT>);
+    else if constexpr (UNI) return launch(mpccbf_uni_kernel_rt);
+    else if constexpr (NT > 0) return launch(mpccbf_kernel<NT, KT>);
+    else return launch(mpccbf_kernel_rt);
 }
 
-template <typename TIO>
 static hipError_t mpc_launch_t(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
                                const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                                hipStream_t stream) {
     if (p.model_id == SC_MODEL_UNICYCLE2D) {
-        if (p.horizon == 10) return mpc_launch_one<TIO, 10, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
-        return mpc_launch_one<TIO, 0, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        if (p.horizon == 10) return mpc_launch_one<10, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        return mpc_launch_one<0, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
     }
     if (p.horizon == 10 && K == 8)            // BASELINE config 3
-        return mpc_launch_one<TIO, 10, 8>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        return mpc_launch_one<10, 8>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
     if (p.horizon == 10)                      // the reference's default horizon (mpc_cbf.py:15) with any obstacle count
-        return mpc_launch_one<TIO, 10, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
-    return mpc_launch_one<TIO, 0, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        return mpc_launch_one<10, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+    if (p.horizon == 20)                      // BASELINE config 5's horizon
+        return mpc_launch_one<20, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+    return mpc_launch_one<0, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
 }
 
 hipError_t mpccbf_launch(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                          hipStream_t stream) {
     if (mpc_lds_doubles(p.horizon, K) * sizeof(double) > 160 * 1024) return hipErrorInvalidValue;
-    if (p.io_dtype == SC_DTYPE_F32)
-        return mpc_launch_t<float>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
-    return mpc_launch_t<double>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+    return mpc_launch_t(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
 }
 
 }  // namespace sc
