@@ -101,3 +101,66 @@ def feasibility_margin(G, c):
     if res.status != 0:
         return float("nan")
     return float(res.x[2])
+
+
+# ---------------------------------------------------------------------------
+# n-variable projection QP (Manipulator2D: n = 3, up to 150 CBF rows + 6 box rows, cbf_qp.py:94-104)
+# ---------------------------------------------------------------------------
+def _enumerate_qpn(G, c, u_ref, tol):
+    """Exact minimiser of ||u - u_ref||^2 s.t. G u + c >= 0 by enumerating every active set of size <= n.
+    For each set S the equality-constrained minimiser is u_ref - G_S^T (G_S G_S^T)^-1 (G_S u_ref + c_S); the feasible
+    candidate of smallest cost is the answer (strict convexity => unique).  Exponential in n: small row counts only."""
+    from itertools import combinations
+    m, n = G.shape
+    best, best_cost = None, np.inf
+    if _feasible(G, c, u_ref, tol):
+        return u_ref.copy()
+    for q in range(1, n + 1):
+        for S in combinations(range(m), q):
+            GS = G[list(S)]
+            gram = GS @ GS.T
+            if np.linalg.cond(gram) > 1e12:
+                continue
+            lam = np.linalg.solve(gram, GS @ u_ref + c[list(S)])
+            u = u_ref - GS.T @ lam
+            cost = float((u - u_ref) @ (u - u_ref))
+            if cost < best_cost and _feasible(G, c, u, tol):
+                best, best_cost = u, cost
+    return best
+
+
+def solve_qpn(G, c, u_ref, tol=FEAS_TOL, max_rounds=400):
+    """Exact n-variable projection QP with many rows: constraint generation around the enumerator.
+
+    Keep a working subset W of rows (initially none); solve the QP restricted to W exactly by enumeration; if its
+    minimiser satisfies every row of the full problem it is the full minimiser (the restricted problem is a
+    relaxation); otherwise add the most violated (normalised) row and repeat.  If a restricted problem is infeasible
+    so is the full one.  W only ever needs the rows that are active somewhere along the way, a handful for n = 3.
+    Deliberately a different algorithm from the HIP kernel (dual active set with rank-one steps)."""
+    G = np.asarray(G, dtype=np.float64)
+    c = np.asarray(c, dtype=np.float64).reshape(-1)
+    u_ref = np.asarray(u_ref, dtype=np.float64).reshape(-1)
+    m, n = G.shape
+    if not (np.all(np.isfinite(G)) and np.all(np.isfinite(c)) and np.all(np.isfinite(u_ref))):
+        return None, STATUS_INFEASIBLE
+    nrm = np.sqrt(np.einsum("ij,ij->i", G, G))
+    if np.any((nrm == 0) & (c < -tol * np.maximum(1.0, np.abs(c)))):
+        return None, STATUS_INFEASIBLE
+    W = []
+    u = u_ref.copy()
+    for _ in range(max_rounds):
+        r = G @ u + c
+        scale = np.maximum(1.0, np.abs(G) @ np.abs(u) + np.abs(c))
+        viol = r < -tol * scale
+        if not np.any(viol):
+            return u, STATUS_OPTIMAL
+        score = np.where(viol & (nrm > 0), r / np.where(nrm > 0, nrm, 1.0), np.inf)
+        score[W] = np.inf
+        p = int(np.argmin(score))
+        if not np.isfinite(score[p]):
+            return None, STATUS_INFEASIBLE          # only rows already in W are violated: W itself is infeasible
+        W.append(p)
+        u = _enumerate_qpn(G[W], c[W], u_ref, tol)
+        if u is None:
+            return None, STATUS_INFEASIBLE
+    raise RuntimeError("solve_qpn: constraint generation did not terminate")

@@ -471,7 +471,75 @@ def gen_unicycle2d():
     np.savez_compressed(os.path.join(HERE, "unicycle2d.npz"), **out)
 
 
+def gen_manipulator():
+    """Manipulator2D (3 joints, joint-velocity inputs, one CBF row per link circle per obstacle): f, g, step,
+    get_end_effector, get_jacobian, nominal_input, get_link_circles, agent_barrier from the reference's robot class, and
+    the rows A1/b1 written by CBFQP.solve_control_problem (cbf_qp.py:110-151, executed verbatim; 'cbf' and 'hard'
+    modes).  u* comes from the oracle's n-variable exact solver standing in for cvxpy/GUROBI."""
+    rng = np.random.default_rng(777)
+    out = {}
+    NR = 80                                               # num_obs of the controller = row cap (tracking.py:134-138 uses 150)
+    for mode in ("cbf", "hard"):
+        spec = {"model": "Manipulator2D", "w_max": 2.0, "Kp": 5.0, "radius": 0.25, "cbf_mode": mode}   # examples/test_tracking.py:124-131
+        robot = BaseRobot(np.zeros((3, 1)), spec, DT, NullAxes())
+        robot.robot.base_pos = np.array([5.0, 3.5])       # examples/test_tracking.py:163-165
+        ctrl = CBFQP(robot, spec, num_obs=NR)
+
+        class Problem3:
+            status = "optimal"
+
+            def solve(self, **_):
+                G = np.vstack([ctrl.A1.value, np.eye(3), -np.eye(3)])
+                c = np.concatenate([ctrl.b1.value.reshape(-1), np.full(6, spec["w_max"])])
+                u, st = oqp.solve_qpn(G, c, np.asarray(ctrl.u_ref.value, dtype=float).reshape(-1))
+                self.status = "optimal" if st == 0 else "infeasible"
+                ctrl.u.value = None if u is None else u.reshape(3, 1)
+
+        ctrl.cbf_controller = Problem3()
+        rec = {k: [] for k in ["X", "goal", "U", "u_ref", "obs", "k", "step", "ee", "jac", "nominal", "circles", "h0", "dh0",
+                               "A", "b", "u_star_oracle", "status_oracle"]}
+        n = 90 if mode == "cbf" else 30
+        for i in range(n):
+            X = rng.uniform(-np.pi, np.pi, 3)
+            goal = np.array([5.0, 3.5]) + rng.uniform(-3, 3, 2)
+            U = rng.uniform(-2, 2, 3)
+            K = int(rng.integers(1, 5))
+            obs = np.zeros((K, 7))
+            for r in range(K):                            # obstacles around the arm's workspace; some touch it
+                rho, phi = rng.uniform(0.6, 3.6), rng.uniform(-np.pi, np.pi)
+                obs[r, 0:3] = [5.0 + rho * np.cos(phi), 3.5 + rho * np.sin(phi), rng.uniform(0.15, 0.5)]
+            robot.X = X.reshape(-1, 1).copy()
+            u_ref = robot.nominal_input(goal).reshape(-1)
+            if i % 5 == 2:
+                u_ref = rng.uniform(-3, 3, 3)             # outside the box
+            circ = robot.robot.get_link_circles(robot.X, radius=spec["radius"])
+            hs, dhs = robot.agent_barrier(obs[0])
+            control_ref = {"state_machine": "track", "u_ref": u_ref.reshape(3, 1), "goal": None}
+            u = ctrl.solve_control_problem(robot.X, control_ref, list(obs))
+            robot.X = X.reshape(-1, 1).copy()
+            obs_p = np.full((4, 7), np.nan); obs_p[:K] = obs
+            rec["X"].append(X); rec["goal"].append(goal); rec["U"].append(U); rec["u_ref"].append(u_ref)
+            rec["obs"].append(obs_p); rec["k"].append(K)
+            rec["step"].append(robot.robot.step(robot.X.copy(), U.reshape(-1, 1)).reshape(-1).copy())
+            rec["ee"].append(np.asarray(robot.robot.get_end_effector(robot.X), dtype=float).reshape(-1))
+            rec["jac"].append(np.asarray(robot.robot.get_jacobian(robot.X), dtype=float))
+            rec["nominal"].append(robot.nominal_input(goal).reshape(-1))
+            rec["circles"].append(np.array([[c["x"], c["y"], c["link_idx"]] for c in circ]))
+            rec["h0"].append(np.array(hs, dtype=float)); rec["dh0"].append(np.array(dhs, dtype=float))
+            rec["A"].append(ctrl.A1.value.copy()); rec["b"].append(ctrl.b1.value.reshape(-1).copy())
+            rec["u_star_oracle"].append(np.full(3, np.nan) if u is None else np.asarray(u, dtype=float).reshape(-1))
+            rec["status_oracle"].append(0 if ctrl.status == "optimal" else 1)
+        for k, v in rec.items():
+            out[f"{mode}/{k}"] = np.array(v)
+        print("Manipulator2D", mode, "cases", n, "infeasible", int(np.sum(rec["status_oracle"])), "circles/obstacle", len(circ))
+    out["meta"] = np.array([2.0, 5.0, 0.25, 5.0, 3.5, NR, DT])          # w_max, Kp, radius, base_x, base_y, num_rows, dt
+    np.savez_compressed(os.path.join(HERE, "manipulator2d.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "manipulator2d":
+        gen_manipulator()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "unicycle2d":
         gen_unicycle2d()
         sys.exit(0)
@@ -489,3 +557,4 @@ if __name__ == "__main__":
     gen_integrators()
     gen_quad2d()
     gen_unicycle2d()
+    gen_manipulator()
