@@ -230,6 +230,45 @@ int sc_odcbfqp_solve_batch_host(const sc_odcbfqp_params* params, int64_t B,
                                 const void* X, const void* u_ref, const void* obs, const int32_t* has_obs,
                                 void* u_out, void* omega_out, int32_t* status_out, void* h_out, int device);
 
+/* ---- Manipulator2D CBF-QP -------------------------------------
+ * The Manipulator2D branches of CBFQP (position_control/cbf_qp.py:34-35 alpha = 1.0, :94-104 three inputs with
+ * |u_i| <= w_max, :130-151 row loop) over robots/manipulator2D.py: a planar 3-joint arm, state X = [theta1..3], input
+ * U = joint velocities, f = 0, g = I.  get_link_circles (:129-152) discretises link i into link_steps[i] + 1 circles
+ * (the reference evaluates int(np.ceil(link_len / (10/60))) in float64: 8, 8, 6 for its 80/70/50-pixel links -- the
+ * host passes the counts so the device never re-derives that rounding); agent_barrier (:185-224) returns one
+ * (h, dh/dq) per circle: h = |c - o|^2 - beta (R + r)^2, dh/dq = 2 (c - o)^T J_c with beta = 1.3.  Rows are written
+ * obstacle by obstacle, circle by circle, until `num_rows` (= CBFQP's num_obs; 150 by default, tracking.py:134-138)
+ * are used: A = dh/dq, b = alpha h ('cbf') or h / dt ('hard').
+ * X [B,3], u_ref [B,3], obs [B,K,7] (or [K,7]) circles [x, y, r, ...], n_obs [B] or NULL;
+ * u_out [B,3] (NaN where not optimal), status_out [B], h_out [B,num_rows] or NULL (0 for unused rows).
+ * One QP (3 variables, up to 250 + 6 rows) per wavefront, dual active set; arithmetic is f64.
+ */
+#define SC_MANIP_MAX_ROWS 250
+
+typedef struct sc_manip_cbfqp_params {
+    int32_t io_dtype;        /* SC_DTYPE_*: element type of X,u_ref,obs,u_out,h_out                     */
+    int32_t cbf_mode;        /* SC_CBF_MODE_*                                                           */
+    int32_t obs_shared;      /* 0: obs is [B,K,7]; 1: one [K,7] table for all agents                    */
+    int32_t num_rows;        /* CBFQP(num_obs=...): row cap, 1..SC_MANIP_MAX_ROWS                       */
+    int32_t link_steps[3];   /* circles per link minus one (manipulator2D.py:143), each >= 1            */
+    int32_t reserved;
+    double  robot_radius;    /* robot.robot_radius: radius of every link circle                         */
+    double  dt;              /* robot.dt ('hard' mode)                                                  */
+    double  alpha;           /* cbf_param['alpha'] = 1.0 (cbf_qp.py:34-35)                              */
+    double  w_max;           /* robot_spec['w_max'] = 2.0 (manipulator2D.py:21)                         */
+    double  beta;            /* barrier inflation, 1.3 (manipulator2D.py:185)                           */
+    double  link_lengths[3]; /* manipulator2D.py:18                                                     */
+    double  base_pos[2];     /* manipulator2D.py:24 (examples/test_tracking.py:163-165 moves it)        */
+} sc_manip_cbfqp_params;
+
+int sc_manip_cbfqp_solve_batch(const sc_manip_cbfqp_params* params, int64_t B, int32_t K,
+                               const void* X, const void* u_ref, const void* obs, const int32_t* n_obs,
+                               void* u_out, int32_t* status_out, void* h_out, void* stream);
+
+int sc_manip_cbfqp_solve_batch_host(const sc_manip_cbfqp_params* params, int64_t B, int32_t K,
+                                    const void* X, const void* u_ref, const void* obs, const int32_t* n_obs,
+                                    void* u_out, int32_t* status_out, void* h_out, int device);
+
 /* ---- neighbour agents as moving obstacles (extension) -----------------
  * The reference's robots never see each other (examples/test_multi_robot.py:77-80); BASELINE
  * config 4 asks for it.  After the per-step all-gather of agent states (RCCL over xGMI when the

@@ -88,7 +88,10 @@ def feasibility_margin(G, c):
     """
     from scipy.optimize import linprog
 
-    G = np.asarray(G, dtype=np.float64).reshape(-1, 2)
+    G = np.asarray(G, dtype=np.float64)
+    if G.ndim != 2:
+        G = G.reshape(-1, 2)
+    n = G.shape[1]                                          # 2 for the planar models, 3 for Manipulator2D
     c = np.asarray(c, dtype=np.float64).reshape(-1)
     nrm = np.sqrt(np.einsum("ij,ij->i", G, G))
     zero = nrm <= 0
@@ -97,10 +100,10 @@ def feasibility_margin(G, c):
     Gn, cn, nn = G[~zero], c[~zero], nrm[~zero]
     # maximise t  s.t.  G u + c >= t*||G_i||   <=>  -G u + ||G_i|| t <= c
     A_ub = np.hstack([-Gn, nn[:, None]])
-    res = linprog(c=[0, 0, -1.0], A_ub=A_ub, b_ub=cn, bounds=[(None, None)] * 3, method="highs")
+    res = linprog(c=[0.0] * n + [-1.0], A_ub=A_ub, b_ub=cn, bounds=[(None, None)] * (n + 1), method="highs")
     if res.status != 0:
         return float("nan")
-    return float(res.x[2])
+    return float(res.x[n])
 
 
 # ---------------------------------------------------------------------------

@@ -69,6 +69,19 @@ class OdMpcCbfParams(C.Structure):
     _fields_ = [("mpc", MpcCbfParams), ("omega_ref", C.c_double * 2), ("p_sb", C.c_double * 2)]
 
 
+MANIP_MAX_ROWS = 250
+
+
+class ManipCbfQpParams(C.Structure):
+    """Mirror of ``sc_manip_cbfqp_params``."""
+    _fields_ = [
+        ("io_dtype", C.c_int32), ("cbf_mode", C.c_int32), ("obs_shared", C.c_int32), ("num_rows", C.c_int32),
+        ("link_steps", C.c_int32 * 3), ("reserved", C.c_int32),
+        ("robot_radius", C.c_double), ("dt", C.c_double), ("alpha", C.c_double), ("w_max", C.c_double),
+        ("beta", C.c_double), ("link_lengths", C.c_double * 3), ("base_pos", C.c_double * 2),
+    ]
+
+
 SM_IDLE, SM_TRACK, SM_STOP, SM_ROTATE = 0, 1, 2, 3
 SM_NAMES = {0: "idle", 1: "track", 2: "stop", 3: "rotate"}
 TRACKING_MAX_CONSTRAINTS = 16
@@ -96,6 +109,8 @@ SYMBOLS = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sc_cbfqp_solve_batch_host": (C.c_int, [C.POINTER(CbfQpParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "sc_manip_cbfqp_solve_batch": (C.c_int, [C.POINTER(ManipCbfQpParams), C.c_int64, C.c_int32] + [C.c_void_p] * 8),
+    "sc_manip_cbfqp_solve_batch_host": (C.c_int, [C.POINTER(ManipCbfQpParams), C.c_int64, C.c_int32] + [C.c_void_p] * 7 + [C.c_int]),
     "sc_mpccbf_solve_batch": (C.c_int, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),

@@ -36,6 +36,9 @@ hipError_t tracking_launch(const sc_tracking_params& p, long long B, int M, void
                            int* wp_index, int* sm, void* goal, void* table, void* u_last, int* ret, int* ret_step,
                            void* tX, void* tU, hipStream_t stream);
 
+hipError_t manip_cbfqp_launch(const sc_manip_cbfqp_params& p, long long B, int K, const void* X, const void* u_ref,
+                              const void* obs, const int* n_obs, void* u_out, int* status, void* h_out, hipStream_t stream);
+
 static thread_local char g_err[256] = "";
 
 static int fail(int code, const char* msg) {
@@ -97,9 +100,81 @@ static int check_mpccbf(const sc_mpccbf_params* p, int64_t B, int32_t K, const v
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
     return SC_OK;
 }
+static int check_manip(const sc_manip_cbfqp_params* p, int64_t B, int32_t K, const void* X, const void* u_ref,
+                       const void* obs, const void* u_out, const void* status_out) {
+    if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (B < 0) return fail(SC_ERR_INVALID_ARGUMENT, "B < 0");
+    if (K < 1) return fail(SC_ERR_INVALID_ARGUMENT, "K < 1 (obs_list=None is the caller's branch: u = u_ref)");
+    if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
+        return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
+    if (p->cbf_mode != SC_CBF_MODE_CBF && p->cbf_mode != SC_CBF_MODE_HARD)
+        return fail(SC_ERR_INVALID_ARGUMENT, "cbf_mode must be 0 (cbf) or 1 (hard)");
+    if (p->num_rows < 1) return fail(SC_ERR_INVALID_ARGUMENT, "num_rows < 1");
+    if (p->num_rows > SC_MANIP_MAX_ROWS) return fail(SC_ERR_UNSUPPORTED, "num_rows exceeds SC_MANIP_MAX_ROWS");
+    for (int i = 0; i < 3; ++i) {
+        if (p->link_steps[i] < 1 || p->link_steps[i] > 64) return fail(SC_ERR_INVALID_ARGUMENT, "link_steps must be in [1, 64]");
+        if (!(p->link_lengths[i] > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "link_lengths must be > 0");
+    }
+    if (!(p->dt > 0) || !(p->w_max > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "dt and w_max must be > 0");
+    if (B > 0 && (!X || !u_ref || !obs || !u_out || !status_out))
+        return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
+    return SC_OK;
+}
 }  // namespace sc
 
 extern "C" {
+
+int sc_manip_cbfqp_solve_batch(const sc_manip_cbfqp_params* params, int64_t B, int32_t K, const void* X, const void* u_ref,
+                               const void* obs, const int32_t* n_obs, void* u_out, int32_t* status_out, void* h_out,
+                               void* stream) {
+    int rc = sc::check_manip(params, B, K, X, u_ref, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::manip_cbfqp_launch(*params, (long long)B, (int)K, X, u_ref, obs, n_obs, u_out, status_out, h_out,
+                                          (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "manipulator cbfqp kernel launch");
+    return SC_OK;
+}
+
+int sc_manip_cbfqp_solve_batch_host(const sc_manip_cbfqp_params* params, int64_t B, int32_t K, const void* X,
+                                    const void* u_ref, const void* obs, const int32_t* n_obs, void* u_out,
+                                    int32_t* status_out, void* h_out, int device) {
+    int rc = sc::check_manip(params, B, K, X, u_ref, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipSetDevice");
+    const size_t es = params->io_dtype == SC_DTYPE_F64 ? 8 : 4;
+    const size_t nX = (size_t)B * 3 * es, nU = nX;
+    const size_t nO = (params->obs_shared ? (size_t)K * 7 : (size_t)B * K * 7) * es;
+    const size_t nH = (size_t)B * params->num_rows * es, nS = (size_t)B * 4, nN = n_obs ? (size_t)B * 4 : 0;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t oX = 0, oU = oX + up(nX), oO = oU + up(nU), oN = oO + up(nO), oUo = oN + up(nN),
+                 oS = oUo + up(nU), oH = oS + up(nS), total = oH + up(nH);
+    unsigned char* d = nullptr;
+    e = hipMalloc((void**)&d, total);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipMalloc");
+    hipStream_t s = nullptr;
+    rc = SC_OK;
+    do {
+        if ((e = hipMemcpyAsync(d + oX, X, nX, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oU, u_ref, nU, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if (n_obs && (e = hipMemcpyAsync(d + oN, n_obs, nN, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        e = sc::manip_cbfqp_launch(*params, (long long)B, (int)K, d + oX, d + oU, d + oO,
+                                   n_obs ? (const int*)(d + oN) : nullptr, d + oUo, (int*)(d + oS),
+                                   h_out ? d + oH : nullptr, s);
+        if (e != hipSuccess) break;
+        if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (h_out && (e = hipMemcpyAsync(h_out, d + oH, nH, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        e = hipStreamSynchronize(s);
+    } while (0);
+    if (e != hipSuccess) rc = sc::fail_hip(e, "sc_manip_cbfqp_solve_batch_host");
+    (void)hipFree(d);
+    return rc;
+}
 
 int sc_version(void) { return SC_VERSION_MAJOR * 1000 + SC_VERSION_MINOR; }
 

@@ -1,0 +1,295 @@
+// Manipulator2D CBF-QP: three joint-velocity inputs, one CBF row per link circle per obstacle.
+//   CBFQP.setup_control_problem / solve_control_problem, Manipulator2D branches   position_control/cbf_qp.py:94-104, :130-151
+//   Manipulator2D.get_link_circles / get_points_jacobian / agent_barrier         robots/manipulator2D.py:129-224
+//
+// One agent per wavefront.  The reference discretises the three links into 25 circles and writes one row per circle and
+// obstacle until `num_obs` rows are used (150 by default, tracking.py:134-138), so a QP has 3 variables and up to
+// 250 + 6 rows: every lane builds and keeps `RPL` rows in registers (row r lives in lane r % 64, slot r / 64), and the
+// wave solves
+//        minimise ||u - u_ref||^2   s.t.  n_r . u + c_r >= 0  (CBF rows and the box |u_i| <= w_max as six more rows)
+// with the dual active-set method of Goldfarb and Idnani specialised to an identity Hessian: start at u_ref, pick the
+// most violated (normalised) row by a wave arg-min, move along the projection of its normal onto the null space of the
+// active normals until the row is satisfied or a multiplier of an active row reaches zero (that row is dropped), repeat.
+// The active set has at most three rows, so its QR (Gram-Schmidt) is recomputed from the stored normals each time --
+// wave-uniform arithmetic every lane does redundantly; the only cross-lane traffic per round is the arg-min (6 xor
+// steps) and the broadcast of the chosen row.  The objective is strictly convex, so the minimiser is unique and the
+// oracle's different algorithm (constraint generation around active-set enumeration, oracle/qp.py: solve_qpn) is a real
+// check.  Arithmetic is f64; the caller's arrays are f32 or f64.
+#include <hip/hip_runtime.h>
+
+#include "../../include/safe_control_amd.h"
+#include "sc_math.hpp"
+#include "sc_qp2.hpp"
+
+namespace sc {
+
+namespace {
+
+struct ArgMin { double v; int i; };
+
+__device__ __forceinline__ ArgMin wave_argmin(ArgMin a) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double ov = __shfl_xor(a.v, o);
+        const int oi = __shfl_xor(a.i, o);
+        const bool take = (ov < a.v) || (ov == a.v && oi < a.i);
+        a.v = take ? ov : a.v;
+        a.i = take ? oi : a.i;
+    }
+    return a;
+}
+
+// Orthonormal basis of the active normals and the triangular factor (N = Q R), q <= 3.
+struct ActiveSet {
+    int q;
+    int idx[3];
+    double n[3][3];      // active normals (unit length)
+    double lam[3];       // their multipliers (>= 0)
+};
+
+struct Qr { double Q[3][3]; double R[3][3]; };
+
+__device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+__device__ __forceinline__ void factor(const ActiveSet& A, Qr& F) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j < A.q) {
+            double v[3] = {A.n[j][0], A.n[j][1], A.n[j][2]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if (i < j) {
+                    const double r = dot3(F.Q[i], A.n[j]);
+                    F.R[i][j] = r;
+                    v[0] -= r * F.Q[i][0]; v[1] -= r * F.Q[i][1]; v[2] -= r * F.Q[i][2];
+                }
+            }
+            const double nv = sqrt(dot3(v, v));
+            const double inv = 1.0 / nv;
+            F.R[j][j] = nv;
+            F.Q[j][0] = v[0] * inv; F.Q[j][1] = v[1] * inv; F.Q[j][2] = v[2] * inv;
+        }
+    }
+}
+
+// z = (I - Q Q^T) np,  r = R^-1 Q^T np
+__device__ __forceinline__ void directions(const ActiveSet& A, const Qr& F, const double* np, double* z, double* r) {
+    double d[3] = {0, 0, 0};
+    z[0] = np[0]; z[1] = np[1]; z[2] = np[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i < A.q) {
+            d[i] = dot3(F.Q[i], np);
+            z[0] -= d[i] * F.Q[i][0]; z[1] -= d[i] * F.Q[i][1]; z[2] -= d[i] * F.Q[i][2];
+        }
+    }
+    r[0] = r[1] = r[2] = 0.0;
+#pragma unroll
+    for (int i = 2; i >= 0; --i) {
+        if (i < A.q) {
+            double s = d[i];
+#pragma unroll
+            for (int j = 2; j > i; --j)
+                if (j < A.q) s -= F.R[i][j] * r[j];
+            r[i] = s / F.R[i][i];
+        }
+    }
+}
+
+__device__ __forceinline__ void drop(ActiveSet& A, int l) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j >= l && j + 1 < A.q) {
+            A.idx[j] = A.idx[j + 1]; A.lam[j] = A.lam[j + 1];
+            A.n[j][0] = A.n[j + 1][0]; A.n[j][1] = A.n[j + 1][1]; A.n[j][2] = A.n[j + 1][2];
+        }
+    }
+    A.q -= 1;
+}
+
+template <int RPL>
+__global__ __launch_bounds__(256) void manip_cbfqp_kernel(const sc_manip_cbfqp_params p, const long long B, const int K,
+                                                          const void* __restrict__ X, const void* __restrict__ u_ref,
+                                                          const void* __restrict__ obs, const int* __restrict__ n_obs,
+                                                          void* __restrict__ u_out, int* __restrict__ status_out,
+                                                          void* __restrict__ h_out) {
+    const int lane = threadIdx.x & 63;
+    const long long agent = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (agent >= B) return;
+    const bool io32 = p.io_dtype == SC_DTYPE_F32;
+    auto ld = [io32](const void* a, size_t i) { return io32 ? (double)((const float*)a)[i] : ((const double*)a)[i]; };
+    auto st = [io32](void* a, size_t i, double v) { if (io32) ((float*)a)[i] = (float)v; else ((double*)a)[i] = v; };
+
+    // ---- kinematic chain (wave-uniform): joints P0..P2, link vectors d0..d2 (manipulator2D.py:129-152) ----------
+    const double q0 = ld(X, agent * 3 + 0), q1 = ld(X, agent * 3 + 1), q2 = ld(X, agent * 3 + 2);
+    double Px[3], Py[3], dx[3], dy[3];
+    {
+        double ang = 0.0, px = p.base_pos[0], py = p.base_pos[1];
+        const double qs[3] = {q0, q1, q2};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ang += qs[i];
+            double s, c;
+            sincos(ang, &s, &c);
+            Px[i] = px; Py[i] = py;
+            dx[i] = p.link_lengths[i] * c; dy[i] = p.link_lengths[i] * s;
+            px += dx[i]; py += dy[i];
+        }
+    }
+    const int c0 = p.link_steps[0] + 1, c1 = p.link_steps[1] + 1, c2 = p.link_steps[2] + 1;
+    const int C = c0 + c1 + c2;
+    const int kv = n_obs ? min(max(n_obs[agent], 0), K) : K;
+    const int Rr = min(p.num_rows, kv * C);                       // CBF rows in use (cbf_qp.py:126-128, :133)
+    const int m = Rr + 6;                                         // + the box
+    const size_t obase = p.obs_shared ? 0 : (size_t)agent * K * 7;
+    const double gain = p.cbf_mode == SC_CBF_MODE_HARD ? 1.0 / p.dt : p.alpha;    // cbf_qp.py:136-147
+
+    double n0[RPL], n1[RPL], n2[RPL], cc[RPL];
+    bool dead = false;                                            // a row 0.u + c >= 0 with c < 0, or non-finite data
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) {
+        const int r = lane + 64 * s;
+        n0[s] = n1[s] = n2[s] = 0.0;
+        cc[s] = num<double>::inf();                               // unused slot: never violated
+        if (r < Rr) {
+            const int o = r / C, ci = r - o * C;
+            int li, j, ns;
+            if (ci < c0) { li = 0; j = ci; ns = p.link_steps[0]; }
+            else if (ci < c0 + c1) { li = 1; j = ci - c0; ns = p.link_steps[1]; }
+            else { li = 2; j = ci - c0 - c1; ns = p.link_steps[2]; }
+            const double t = (double)j / (double)ns;
+            const double sx = li == 0 ? Px[0] : (li == 1 ? Px[1] : Px[2]), sy = li == 0 ? Py[0] : (li == 1 ? Py[1] : Py[2]);
+            const double lx = li == 0 ? dx[0] : (li == 1 ? dx[1] : dx[2]), ly = li == 0 ? dy[0] : (li == 1 ? dy[1] : dy[2]);
+            const double cx = sx + t * lx, cy = sy + t * ly;
+            const double ox = ld(obs, obase + (size_t)o * 7 + 0), oy = ld(obs, obase + (size_t)o * 7 + 1);
+            const double orad = ld(obs, obase + (size_t)o * 7 + 2);
+            const double ex = cx - ox, ey = cy - oy;
+            const double dmin = p.robot_radius + orad;
+            const double h = ex * ex + ey * ey - p.beta * (dmin * dmin);
+            // dh/dq_k = 2 (e . z x (c - P_k)) for k <= li (manipulator2D.py:154-182, :216)
+            double a[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double jx = -(cy - Py[k]), jy = cx - Px[k];
+                a[k] = k <= li ? 2.0 * (ex * jx + ey * jy) : 0.0;
+            }
+            const double b = gain * h;
+            if (h_out) st(h_out, (size_t)agent * p.num_rows + r, h);
+            const double nn = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
+            if (!(finite_(nn) && finite_(b))) dead = true;
+            if (nn > 0.0) {
+                const double inv = rsqrt_(nn);
+                n0[s] = a[0] * inv; n1[s] = a[1] * inv; n2[s] = a[2] * inv; cc[s] = b * inv;
+            } else if (b < -num<double>::tol_feas() * fmax(1.0, fabs(b))) {
+                dead = true;
+            }
+        } else if (r < m) {                                       // box rows: +-e_i . u + w_max >= 0
+            const int bi = r - Rr, ax = bi >> 1;
+            const double sg = (bi & 1) ? -1.0 : 1.0;
+            n0[s] = ax == 0 ? sg : 0.0; n1[s] = ax == 1 ? sg : 0.0; n2[s] = ax == 2 ? sg : 0.0;
+            cc[s] = p.w_max;
+        }
+        if (h_out && r >= Rr && r < p.num_rows) st(h_out, (size_t)agent * p.num_rows + r, 0.0);
+    }
+
+    double u[3] = {ld(u_ref, agent * 3 + 0), ld(u_ref, agent * 3 + 1), ld(u_ref, agent * 3 + 2)};
+    if (!(finite_(u[0]) && finite_(u[1]) && finite_(u[2]))) dead = true;
+    int status = __any(dead) ? SC_STATUS_INFEASIBLE : -1;
+
+    ActiveSet A;
+    A.q = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { A.idx[j] = -1; A.lam[j] = 0.0; A.n[j][0] = A.n[j][1] = A.n[j][2] = 0.0; }
+    const double tol = num<double>::tol_feas();
+    int budget = 8 * 64;                                          // far above what the method needs; guards the loop
+    while (status < 0) {
+        // most violated row (normalised slack); rows of the active set sit at ~0 and are never below -tol
+        ArgMin best{num<double>::inf(), 0x7fffffff};
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const double sl = n0[s] * u[0] + n1[s] * u[1] + n2[s] * u[2] + cc[s];
+            const double mrg = sl + tol * fmax(1.0, fabs(cc[s]));
+            if (mrg < best.v) { best.v = mrg; best.i = lane + 64 * s; }
+        }
+        best = wave_argmin(best);
+        if (!(best.v < 0.0)) { status = SC_STATUS_OPTIMAL; break; }
+        const int pr = best.i, owner = pr & 63, slot = pr >> 6;
+        double np_[3], cp;
+        {
+            double a0 = n0[0], a1 = n1[0], a2 = n2[0], ac = cc[0];
+#pragma unroll
+            for (int s = 1; s < RPL; ++s)
+                if (slot == s) { a0 = n0[s]; a1 = n1[s]; a2 = n2[s]; ac = cc[s]; }
+            np_[0] = __shfl(a0, owner); np_[1] = __shfl(a1, owner); np_[2] = __shfl(a2, owner); cp = __shfl(ac, owner);
+        }
+        double sp = dot3(np_, u) + cp;                            // < 0
+        double lam_p = 0.0;
+        // bring row pr to equality, dropping active rows whose multiplier would turn negative
+        while (true) {
+            if (--budget < 0) { status = SC_STATUS_INACCURATE; break; }
+            Qr F;
+            factor(A, F);
+            double z[3], r[3];
+            directions(A, F, np_, z, r);
+            const double zz = dot3(z, z);
+            const bool dep = zz <= 1e-12;                         // np in the span of the active normals
+            double t1 = num<double>::inf();
+            int l = -1;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < A.q && r[j] > 1e-14) {
+                    const double tj = A.lam[j] / r[j];
+                    if (tj < t1) { t1 = tj; l = j; }
+                }
+            const double t2 = dep ? num<double>::inf() : -sp / zz;
+            if (l < 0 && dep) { status = SC_STATUS_INFEASIBLE; break; }
+            const double t = fmin(t1, t2);
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < A.q) A.lam[j] = fmax(A.lam[j] - t * r[j], 0.0);
+            lam_p += t;
+            if (!dep) {
+                u[0] += t * z[0]; u[1] += t * z[1]; u[2] += t * z[2];
+                sp += t * zz;
+            }
+            if (t2 <= t1) {                                       // full step: the row becomes active
+                const int j = A.q;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (k == j) { A.idx[k] = pr; A.lam[k] = lam_p; A.n[k][0] = np_[0]; A.n[k][1] = np_[1]; A.n[k][2] = np_[2]; }
+                A.q += 1;
+                break;
+            }
+            drop(A, l);
+        }
+    }
+    if (lane == 0) {
+        const bool ok = status == SC_STATUS_OPTIMAL;
+        st(u_out, agent * 3 + 0, ok ? u[0] : num<double>::nan());
+        st(u_out, agent * 3 + 1, ok ? u[1] : num<double>::nan());
+        st(u_out, agent * 3 + 2, ok ? u[2] : num<double>::nan());
+        status_out[agent] = status;
+    }
+}
+
+}  // namespace
+
+hipError_t manip_cbfqp_launch(const sc_manip_cbfqp_params& p, long long B, int K, const void* X, const void* u_ref,
+                              const void* obs, const int* n_obs, void* u_out, int* status, void* h_out, hipStream_t stream) {
+    const int C = p.link_steps[0] + p.link_steps[1] + p.link_steps[2] + 3;
+    long long rows = (long long)K * C;
+    if (rows > p.num_rows) rows = p.num_rows;
+    const int m = (int)rows + 6;
+    const int rpl = (m + 63) / 64;
+    const dim3 block(256), grid((unsigned)((B + 3) / 4));
+    switch (rpl) {
+        case 1: hipLaunchKernelGGL(manip_cbfqp_kernel<1>, grid, block, 0, stream, p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out); break;
+        case 2: hipLaunchKernelGGL(manip_cbfqp_kernel<2>, grid, block, 0, stream, p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out); break;
+        case 3: hipLaunchKernelGGL(manip_cbfqp_kernel<3>, grid, block, 0, stream, p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out); break;
+        case 4: hipLaunchKernelGGL(manip_cbfqp_kernel<4>, grid, block, 0, stream, p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace sc

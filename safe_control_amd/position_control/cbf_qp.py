@@ -98,6 +98,14 @@ def _pad_obstacle(ob):
 class CBFQP:
     """Drop-in for position_control.cbf_qp.CBFQP (single agent per call)."""
 
+    def __new__(cls, robot, robot_spec, *args, **kwargs):
+        # the reference's CBFQP serves the 3-joint arm from the same class (cbf_qp.py:94-104, :130-151); here it is its
+        # own kernel and host class
+        if cls is CBFQP and robot_spec.get("model") == "Manipulator2D":
+            from .manipulator_cbf_qp import ManipulatorCBFQP
+            return ManipulatorCBFQP(robot, robot_spec, *args, **kwargs)
+        return super().__new__(cls)
+
     def __init__(self, robot, robot_spec, num_obs=1, device=0):
         self.robot = robot
         self.robot_spec = complete_robot_spec(robot_spec)

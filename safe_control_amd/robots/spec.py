@@ -24,6 +24,11 @@ def complete_robot_spec(robot_spec):
     Mutates and returns the dict, like the reference does.
     """
     model = robot_spec.setdefault("model", "DynamicUnicycle2D")
+    if model == "Manipulator2D":                    # robots/manipulator2D.py:21-22 ; radius robots/robot.py:49
+        robot_spec.setdefault("w_max", 2.0)
+        robot_spec.setdefault("Kp", 3.0)
+        robot_spec.setdefault("radius", 0.25)
+        return robot_spec
     if model not in MODEL_IDS:
         raise ValueError(f"model {model!r} is not supported by the batched engine (supported: {sorted(MODEL_IDS)})")
     if model == "SingleIntegrator2D":               # robots/single_integrator2D.py:40-43
