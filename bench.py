@@ -190,6 +190,37 @@ def od_mpc_leg(dev, B=4096, K=8, N=10, steps=2, seed=0):
             "max_decay_deviation": float((rho - 1.0).abs().max().item())}
 
 
+def manip_leg(dev, B=4096, K=3, steps=20, seed=0):
+    """Manipulator2D CBF-QP: B three-joint arms, K circular obstacles each in the arm's workspace
+    (25 link circles per obstacle -> 25 K rows, row cap 150 as in tracking.py:134-138), one QP per wavefront."""
+    import numpy as np
+    import torch
+    import safe_control_amd as sca
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-np.pi, np.pi, (B, 3))
+    ur = rng.uniform(-2.5, 2.5, (B, 3))
+    rho, phi = rng.uniform(0.8, 3.8, (B, K)), rng.uniform(-np.pi, np.pi, (B, K))
+    obs = np.zeros((B, K, 7))
+    obs[..., 0], obs[..., 1], obs[..., 2] = rho * np.cos(phi), rho * np.sin(phi), rng.uniform(0.15, 0.5, (B, K))
+    ctl = sca.BatchedManipulatorCBFQP({"model": "Manipulator2D", "w_max": 2.0, "radius": 0.25}, io_dtype="f32", num_rows=150)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    tX, tu, to = t(X), t(ur), t(obs)
+    u, st, h = ctl.solve(tX, tu, to)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        u, st, h = ctl.solve(tX, tu, to)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    rows = min(150, 25 * K)
+    return {"workload": f"{B} Manipulator2D arms, {K} obstacles each ({rows} CBF rows + 6 box rows, 3 inputs)",
+            "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
+            "optimal_fraction": float((st == 0).double().mean().item()),
+            "constrained_fraction": float(((u - tu).abs().amax(dim=1) > 1e-6).double().mean().item())}
+
+
 def closed_loop_leg(dev, B=4096, T=200, seed=0):
     """BASELINE config 2, closed-loop variant: B DynamicUnicycle2D agents track waypoints through the 14-circle
     scene of examples/test_tracking.py for T control steps (selection + nominal input + CBF-QP + step + collision
@@ -374,6 +405,7 @@ def main():
                                      cpu_seconds=0.0 if a.no_cpu_baseline else 6.0)
             res["od_mpc_cbf"] = od_mpc_leg(dev)
             res["closed_loop"] = closed_loop_leg(dev)
+            res["manipulator_cbf_qp"] = manip_leg(dev)
             res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
         if ws == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(X.double().cpu().numpy(), ur.double().cpu().numpy(),
