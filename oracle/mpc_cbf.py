@@ -258,8 +258,13 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     evaluate = evaluate_fn or globals()["evaluate"]       # other models plug their problem functions in here
     x0 = np.asarray(x0, dtype=np.float64)
     obs = np.asarray(obs, dtype=np.float64)
-    ub = np.tile([P["a_max"], P["w_max"]], N)
-    z = np.clip(np.tile(np.asarray(u_prev, dtype=np.float64), N), -0.99 * ub, 0.99 * ub)   # set_initial_guess
+    if "u_hi" in P:                                       # models with their own input box (oracle/mpc_lin.py)
+        lo_, hi_ = np.tile(np.asarray(P["u_lo"], dtype=np.float64), N), np.tile(np.asarray(P["u_hi"], dtype=np.float64), N)
+        z = np.clip(np.tile(np.asarray(u_prev, dtype=np.float64), N), lo_ + 0.005 * (hi_ - lo_), hi_ - 0.005 * (hi_ - lo_))
+    else:
+        ub = np.tile([P["a_max"], P["w_max"]], N)
+        z = np.clip(np.tile(np.asarray(u_prev, dtype=np.float64), N), -0.99 * ub, 0.99 * ub)   # set_initial_guess
+    nz = z.shape[0]
     ev = evaluate(x0, z, u_prev, goal, obs, P, None, level=1)
     sf = min(1.0, 100.0 / max(1e-12, float(np.max(np.abs(ev["grad"])))))   # objective scaling
     g = ev["g"]
@@ -302,7 +307,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
         L = None
         for _try in range(40):                                              # inertia correction
             try:
-                L = np.linalg.cholesky(Mb + delta * np.eye(2 * N))
+                L = np.linalg.cholesky(Mb + delta * np.eye(nz))
                 break
             except np.linalg.LinAlgError:
                 delta = max(1e-4, delta_last / 3.0) if delta == 0.0 else delta * 8.0
@@ -347,7 +352,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
             status = STATUS_INFEASIBLE
         elif status != STATUS_INFEASIBLE:
             status = STATUS_INACCURATE
-    u0 = z[0:2].copy()
+    u0 = z[0:P.get("nu", 2)].copy()
     if return_info:
         return u0, status, it, dict(z=z, X=ev["X"], f=ev["f"], g=ev["g"], lam=lam / sf, s=s, err=err, mu=mu,
                                     n_eval=n_eval, scale=sf)

@@ -536,7 +536,39 @@ def gen_manipulator():
     np.savez_compressed(os.path.join(HERE, "manipulator2d.npz"), **out)
 
 
+def gen_linear_models():
+    """Quad3D (linear 12-state model, MPC-CBF only): f, g and step from the reference's robot class -- what oracle/mpc_lin.py builds its Euler prediction (x + (f + g u) dt, mpc_cbf.py:135-141)
+    and the barrier's own one-step map (robot.step: Euler for SI, RK4 for Quad3D) from."""
+    rng = np.random.default_rng(31)
+    out = {}
+    for name, nx, nu in (("Quad3D", 12, 4),):                # SingleIntegrator2D's f / g / step are in integrators.npz
+        spec = {"model": name, "radius": 0.25}
+        robot = BaseRobot(np.zeros((nx, 1)), spec, DT, NullAxes())
+        rec = {k: [] for k in ["X", "U", "f", "g", "step"]}
+        for i in range(40):
+            X = rng.uniform(-1, 1, nx)
+            if name == "Quad3D":
+                X[0:3] = rng.uniform(0, 10, 3); X[3:6] = rng.uniform(-0.4, 0.4, 3)     # angles away from the wrap
+            else:
+                X = rng.uniform(0, 10, 2)
+            U = rng.uniform(-3, 3, nu)
+            robot.X = X.reshape(-1, 1).copy()
+            rec["X"].append(X); rec["U"].append(U)
+            rec["f"].append(np.asarray(robot.f(), dtype=float).reshape(-1))
+            rec["g"].append(np.asarray(robot.g(), dtype=float))
+            rec["step"].append(np.asarray(robot.robot.step(robot.X.copy(), U.reshape(-1, 1)), dtype=float).reshape(-1))
+        for k, v in rec.items():
+            out[f"{name}/{k}"] = np.array(v)
+        out[f"{name}/spec"] = np.array([float(robot.robot_spec.get(k, np.nan)) for k in
+                                        ("mass", "Ix", "Iy", "Iz", "L", "nu", "u_max", "u_min", "v_max", "radius")])
+        print(name, "cases", len(rec["X"]))
+    np.savez_compressed(os.path.join(HERE, "linear_models.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "linear_models":
+        gen_linear_models()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "manipulator2d":
         gen_manipulator()
         sys.exit(0)
@@ -558,3 +590,4 @@ if __name__ == "__main__":
     gen_quad2d()
     gen_unicycle2d()
     gen_manipulator()
+    gen_linear_models()
