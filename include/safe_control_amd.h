@@ -177,6 +177,46 @@ int sc_mpccbf_solve_batch_host(const sc_mpccbf_params* params, int64_t B, int32_
                                void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out,
                                int device);
 
+/* ---- MPC-CBF for the reference's linear models (SingleIntegrator2D, Quad3D) ---------------
+ * MPCCBF (position_control/mpc_cbf.py:7-402) over a robot whose f(x) = A x and g(x) = B are constant
+ * (robots/single_integrator2D.py:45-62; robots/quad3D.py:77-119, MPC only: its CBF-QP barrier raises, quad3D.py:269-273):
+ *   prediction  x+ = x + (f + g u) dt = Ae x + Be u                                   (mpc_cbf.py:135-141)
+ *   cost        sum_{k=1..N} (x_k - xg)' diag(Q) (x_k - xg), xg = [goal, 0, ..] (:144,176-178,267) + r-term R on delta u (:180)
+ *   CBF rows    h(step(x_k, u_k)) - (1 - alpha) h(x_k) >= 0 per stage and obstacle  (:312-315), step = the robot's own
+ *               one-step map  As x + Bs u  (Euler for SI; RK4 of the linear system for Quad3D, quad3D.py:121-158);
+ *               h = circle distance barrier (Quad3D: circles only, quad3D.py:283-291; SI also superellipsoids)
+ *   bounds      u_lo <= u <= u_hi                                                     (:183-187, :219-223)
+ * Every barrier point is affine in the inputs, so the condensed cost Hessian and the point Jacobian are constants of
+ * the controller: sc_mpclin_build_model computes them once on the HOST from (Ae, Be, As, Bs) (row-major nx x nx,
+ * nx x nu, nx x nx, nx x nu) into a blob of sc_mpclin_model_doubles doubles that the caller keeps in DEVICE memory
+ * for sc_mpclin_solve_batch (HOST memory for the _host twin).
+ * X [B,nx], u_prev [B,nu], goal [B,ng], obs [B,K,7] (or [K,7]) padded like update_tvp; u_out [B,nu], status_out [B],
+ * iters_out [B] or NULL, z_out [B, nu*horizon] or NULL.  One NLP per wavefront, f64 arithmetic.
+ */
+typedef struct sc_mpclin_params {
+    int32_t io_dtype;        /* SC_DTYPE_*: element type of X,u_prev,goal,obs,u_out,z_out                 */
+    int32_t nx, nu, ng;      /* states (<= 12), inputs (<= 4), goal entries (2: SI, 3: Quad3D, mpc_cbf.py:80-81) */
+    int32_t horizon;         /* robot_spec['mpc_horizon'], default 10; nu * horizon <= 64                  */
+    int32_t max_iter, obs_shared, acceptable_iter;   /* as sc_mpccbf_params                              */
+    int32_t circles_only;    /* 1: the model's barrier has no superellipsoid branch (Quad3D)               */
+    int32_t reserved;
+    double  alpha;           /* DT-CBF gain: SI 0.05 (mpc_cbf.py:48-50), Quad3D 0.15 (:77-78)              */
+    double  robot_radius, beta, tol, acceptable_tol, mu_init, mu_min;   /* as sc_mpccbf_params            */
+    double  Q[12];           /* diagonal state weights (mpc_cbf.py:19-20, :37-38)                          */
+    double  R[4];            /* input-rate weights (mpc_cbf.py:21, :39)                                    */
+    double  u_lo[4], u_hi[4];
+} sc_mpclin_params;
+
+size_t sc_mpclin_model_doubles(int32_t nx, int32_t nu, int32_t horizon);
+int sc_mpclin_build_model(const sc_mpclin_params* params, const double* Ae, const double* Be, const double* As,
+                          const double* Bs, double* model_out);
+int sc_mpclin_solve_batch(const sc_mpclin_params* params, const double* model, int64_t B, int32_t K,
+                          const void* X, const void* u_prev, const void* goal, const void* obs,
+                          void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
+int sc_mpclin_solve_batch_host(const sc_mpclin_params* params, const double* model, int64_t B, int32_t K,
+                               const void* X, const void* u_prev, const void* goal, const void* obs,
+                               void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, int device);
+
 /* ---- optimal-decay MPC-CBF ---------------------------------------
  * OptimalDecayMPCCBF (position_control/optimal_decay_mpc_cbf.py:15-330) for DynamicUnicycle2D: the MPC-CBF NLP with
  * two decay variables per stage (omega1_k, omega2_k, model inputs at :123-124) that scale the DT-CBF gains,

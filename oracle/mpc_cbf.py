@@ -326,14 +326,26 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
         phi0 = f - mu * np.sum(np.log(s)) + nu * np.sum(np.abs(r_p))
         dphi = grad @ dz - mu * np.sum(ds / s) - nu * np.sum(np.abs(r_p))
         alpha, accepted = ap, False
+        Hq = P.get("quadratic_cost")                                        # linear models: f is exactly quadratic in z
+        curv = sf * float(dz @ Hq @ dz) if Hq is not None else 0.0
+        # round-off of the constraint part of the merit: a far-away dummy obstacle row has h ~ 2e6, so |g - s| carries an
+        # absolute error of ~ulp(2e6) per such row, times nu (only the linear models ask for this allowance)
+        noise_rows = P.get("row_noise", 0.0) * nu * float(np.sum(np.abs(g)))
         for _ in range(12):                                                 # at most 12 halvings, then give up (best iterate)
             zt, st = z + alpha * dz, s + alpha * ds
             e0 = evaluate(x0, zt, u_prev, goal, obs, P, level=0)
             n_eval += 1
-            phit = sf * e0["f"] - mu * np.sum(np.log(st)) + nu * np.sum(np.abs(e0["g"] - st))
+            if Hq is not None:
+                # f(z + a dz) - f(z) = a grad.dz + a^2/2 dz'H dz without the cancellation of two sums of size |f|
+                # (a quadrotor far from its goal has f ~ 1e3 and a decrease of 1e-9 to resolve)
+                phit = phi0 + alpha * float(grad @ dz) + 0.5 * alpha * alpha * curv \
+                    - mu * float(np.sum(np.log(st) - np.log(s))) \
+                    + nu * float(np.sum(np.abs(e0["g"] - st)) - np.sum(np.abs(r_p)))
+            else:
+                phit = sf * e0["f"] - mu * np.sum(np.log(st)) + nu * np.sum(np.abs(e0["g"] - st))
             # Armijo, with an allowance for round-off in the merit function near convergence
             # (f is a sum of a few hundred terms of size |phi|: its noise is ~1e-13 |phi|)
-            if phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * abs(phi0):
+            if phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * abs(phi0) + noise_rows:
                 accepted = True
                 break
             alpha *= 0.5

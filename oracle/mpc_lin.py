@@ -97,6 +97,8 @@ def params(model, N=10, **over):
     P = dict(M.DEFAULTS, N=N, dt=model["dt"], nu=model["nu"], u_lo=model["u_lo"], u_hi=model["u_hi"], radius=model["radius"],
              alpha=model["alpha"], model=model)
     P.update(over)
+    P["quadratic_cost"] = condensed(model, P["N"])[0]       # exact merit differences in the line search
+    P.setdefault("row_noise", 1e-15)
     return P
 
 

@@ -69,6 +69,18 @@ class OdMpcCbfParams(C.Structure):
     _fields_ = [("mpc", MpcCbfParams), ("omega_ref", C.c_double * 2), ("p_sb", C.c_double * 2)]
 
 
+class MpcLinParams(C.Structure):
+    """Mirror of ``sc_mpclin_params``."""
+    _fields_ = [
+        ("io_dtype", C.c_int32), ("nx", C.c_int32), ("nu", C.c_int32), ("ng", C.c_int32), ("horizon", C.c_int32),
+        ("max_iter", C.c_int32), ("obs_shared", C.c_int32), ("acceptable_iter", C.c_int32), ("circles_only", C.c_int32),
+        ("reserved", C.c_int32),
+        ("alpha", C.c_double), ("robot_radius", C.c_double), ("beta", C.c_double), ("tol", C.c_double),
+        ("acceptable_tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double),
+        ("Q", C.c_double * 12), ("R", C.c_double * 4), ("u_lo", C.c_double * 4), ("u_hi", C.c_double * 4),
+    ]
+
+
 MANIP_MAX_ROWS = 250
 
 
@@ -109,6 +121,10 @@ SYMBOLS = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sc_cbfqp_solve_batch_host": (C.c_int, [C.POINTER(CbfQpParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "sc_mpclin_model_doubles": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "sc_mpclin_build_model": (C.c_int, [C.POINTER(MpcLinParams)] + [C.c_void_p] * 5),
+    "sc_mpclin_solve_batch": (C.c_int, [C.POINTER(MpcLinParams), C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 9),
+    "sc_mpclin_solve_batch_host": (C.c_int, [C.POINTER(MpcLinParams), C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 8 + [C.c_int]),
     "sc_manip_cbfqp_solve_batch": (C.c_int, [C.POINTER(ManipCbfQpParams), C.c_int64, C.c_int32] + [C.c_void_p] * 8),
     "sc_manip_cbfqp_solve_batch_host": (C.c_int, [C.POINTER(ManipCbfQpParams), C.c_int64, C.c_int32] + [C.c_void_p] * 7 + [C.c_int]),
     "sc_mpccbf_solve_batch": (C.c_int, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,

@@ -39,6 +39,14 @@ hipError_t tracking_launch(const sc_tracking_params& p, long long B, int M, void
 hipError_t manip_cbfqp_launch(const sc_manip_cbfqp_params& p, long long B, int K, const void* X, const void* u_ref,
                               const void* obs, const int* n_obs, void* u_out, int* status, void* h_out, hipStream_t stream);
 
+size_t mpclin_lds_bytes(int N, int K, int nx, int nu);
+size_t mpclin_model_doubles(int nx, int nu, int N);
+void mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const double* Be, const double* As, const double* Bs,
+                        double* out);
+hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long long B, int K, const void* X, const void* u_prev,
+                         const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
+                         hipStream_t stream);
+
 static thread_local char g_err[256] = "";
 
 static int fail(int code, const char* msg) {
@@ -100,6 +108,32 @@ static int check_mpccbf(const sc_mpccbf_params* p, int64_t B, int32_t K, const v
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
     return SC_OK;
 }
+static int check_mpclin_dims(const sc_mpclin_params* p) {
+    if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (p->nx < 2 || p->nx > 12 || p->nu < 1 || p->nu > 4 || p->ng < 2 || p->ng > p->nx)
+        return fail(SC_ERR_INVALID_ARGUMENT, "need 2 <= nx <= 12, 1 <= nu <= 4, 2 <= ng <= nx");
+    if (p->horizon < 1 || p->horizon * p->nu > 64) return fail(SC_ERR_UNSUPPORTED, "need 1 <= horizon and nu * horizon <= 64");
+    return SC_OK;
+}
+static int check_mpclin(const sc_mpclin_params* p, const double* model, int64_t B, int32_t K, const void* X, const void* u_prev,
+                        const void* goal, const void* obs, const void* u_out, const void* status_out) {
+    int rc = check_mpclin_dims(p);
+    if (rc != SC_OK) return rc;
+    if (B < 0) return fail(SC_ERR_INVALID_ARGUMENT, "B < 0");
+    if (K < 1) return fail(SC_ERR_INVALID_ARGUMENT, "K < 1 (pad with [1000,1000,0,...] rows like update_tvp)");
+    if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
+        return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
+    if (mpclin_lds_bytes(p->horizon, K, p->nx, p->nu) > 160 * 1024)
+        return fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
+    if (!(p->tol > 0) || !(p->acceptable_tol >= p->tol) || p->max_iter < 1 || !(p->mu_init > 0) || !(p->mu_min > 0))
+        return fail(SC_ERR_INVALID_ARGUMENT, "tol, mu_init, mu_min must be > 0 and max_iter >= 1");
+    for (int i = 0; i < p->nu; ++i)
+        if (!(p->u_hi[i] > p->u_lo[i])) return fail(SC_ERR_INVALID_ARGUMENT, "u_hi must be > u_lo");
+    if (B > 0 && (!model || !X || !u_prev || !goal || !obs || !u_out || !status_out))
+        return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
+    return SC_OK;
+}
 static int check_manip(const sc_manip_cbfqp_params* p, int64_t B, int32_t K, const void* X, const void* u_ref,
                        const void* obs, const void* u_out, const void* status_out) {
     if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
@@ -124,6 +158,74 @@ static int check_manip(const sc_manip_cbfqp_params* p, int64_t B, int32_t K, con
 }  // namespace sc
 
 extern "C" {
+
+size_t sc_mpclin_model_doubles(int32_t nx, int32_t nu, int32_t horizon) {
+    if (nx < 2 || nx > 12 || nu < 1 || nu > 4 || horizon < 1 || horizon * nu > 64) return 0;
+    return sc::mpclin_model_doubles(nx, nu, horizon);
+}
+
+int sc_mpclin_build_model(const sc_mpclin_params* params, const double* Ae, const double* Be, const double* As,
+                          const double* Bs, double* model_out) {
+    int rc = sc::check_mpclin_dims(params);
+    if (rc != SC_OK) return rc;
+    if (!Ae || !Be || !As || !Bs || !model_out) return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL matrix pointer");
+    sc::mpclin_build_model(*params, Ae, Be, As, Bs, model_out);
+    return SC_OK;
+}
+
+int sc_mpclin_solve_batch(const sc_mpclin_params* params, const double* model, int64_t B, int32_t K, const void* X,
+                          const void* u_prev, const void* goal, const void* obs, void* u_out, int32_t* status_out,
+                          int32_t* iters_out, void* z_out, void* stream) {
+    int rc = sc::check_mpclin(params, model, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::mpclin_launch(*params, model, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out,
+                                     z_out, (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "mpclin kernel launch");
+    return SC_OK;
+}
+
+int sc_mpclin_solve_batch_host(const sc_mpclin_params* params, const double* model, int64_t B, int32_t K, const void* X,
+                               const void* u_prev, const void* goal, const void* obs, void* u_out, int32_t* status_out,
+                               int32_t* iters_out, void* z_out, int device) {
+    int rc = sc::check_mpclin(params, model, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipSetDevice");
+    const size_t es = params->io_dtype == SC_DTYPE_F64 ? 8 : 4;
+    const size_t n = (size_t)params->nu * params->horizon;
+    const size_t nM = sc::mpclin_model_doubles(params->nx, params->nu, params->horizon) * 8;
+    const size_t nX = (size_t)B * params->nx * es, nU = (size_t)B * params->nu * es, nG = (size_t)B * params->ng * es;
+    const size_t nO = (params->obs_shared ? (size_t)K * 7 : (size_t)B * K * 7) * es;
+    const size_t nS = (size_t)B * 4, nZ = (size_t)B * n * es;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t oM = 0, oX = oM + up(nM), oU = oX + up(nX), oG = oU + up(nU), oO = oG + up(nG), oUo = oO + up(nO),
+                 oS = oUo + up(nU), oI = oS + up(nS), oZ = oI + up(nS), total = oZ + up(nZ);
+    unsigned char* d = nullptr;
+    e = hipMalloc((void**)&d, total);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipMalloc");
+    hipStream_t s = nullptr;
+    rc = SC_OK;
+    do {
+        if ((e = hipMemcpyAsync(d + oM, model, nM, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oX, X, nX, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oU, u_prev, nU, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oG, goal, nG, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        e = sc::mpclin_launch(*params, (const double*)(d + oM), (long long)B, (int)K, d + oX, d + oU, d + oG, d + oO, d + oUo,
+                              (int*)(d + oS), iters_out ? (int*)(d + oI) : nullptr, z_out ? d + oZ : nullptr, s);
+        if (e != hipSuccess) break;
+        if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (iters_out && (e = hipMemcpyAsync(iters_out, d + oI, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (z_out && (e = hipMemcpyAsync(z_out, d + oZ, nZ, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        e = hipStreamSynchronize(s);
+    } while (0);
+    if (e != hipSuccess) rc = sc::fail_hip(e, "sc_mpclin_solve_batch_host");
+    (void)hipFree(d);
+    return rc;
+}
 
 int sc_manip_cbfqp_solve_batch(const sc_manip_cbfqp_params* params, int64_t B, int32_t K, const void* X, const void* u_ref,
                                const void* obs, const int32_t* n_obs, void* u_out, int32_t* status_out, void* h_out,

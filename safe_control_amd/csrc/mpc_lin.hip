@@ -1,0 +1,610 @@
+// MPC-CBF for the reference's LINEAR robot models (SingleIntegrator2D, Quad3D), one NLP per wavefront.
+//   MPCCBF (position_control/mpc_cbf.py:7-402) over robots/single_integrator2D.py and robots/quad3D.py:
+//     prediction  x+ = x + (f(x) + g(x) u) dt = Ae x + Be u                                  mpc_cbf.py:135-141
+//     cost        sum_k (x_k - xg)' Q (x_k - xg) + r-term R on delta u                        mpc_cbf.py:144,176-180
+//     CBF         h(step(x_k, u_k)) - (1 - alpha) h(x_k) >= 0 per stage and obstacle          mpc_cbf.py:312-315
+//                 (step = the robot's own one-step map: Euler for SI, RK4 of the linear system for Quad3D, quad3D.py:121-158)
+//     bounds      box on the inputs                                                            mpc_cbf.py:183-187,219-223
+//   Oracle: oracle/mpc_lin.py (problem functions) + oracle/mpc_cbf.py: solve (the interior-point method followed here).
+//
+// With linear dynamics every barrier point is affine in z = (u_0..u_{N-1}):  a_k = pos(x_k),  b_k = pos(As x_k + Bs u_k),
+// points = const + G z with a CONSTANT G (4N x n) and the cost Hessian Hc (n x n) is constant too; both are built once
+// per controller on the host (sc_mpclin_build_model) and shared by every problem of the batch (read through L1/L2).
+// What is left per interior-point iteration is: a rollout (N sequential nx-wide matrix-vector steps), 2 N K barrier
+// evaluations, the 4x4 stage blocks Phi_k of J' Sigma J - sum lam grad^2 g over the point pair (a_k, b_k), T = Phi G,
+// M = sf Hc + G' T + box terms, one Cholesky of order n = N nu <= 64, and the line search (rollout + barriers only).
+// Single shooting, slacks on all N K + 2 n inequalities, exact Hessian of the Lagrangian, inertia correction,
+// fraction-to-boundary 0.995, l1-merit backtracking, monotone barrier decrease -- iterate for iterate the oracle's method.
+// Arithmetic is f64; the caller's arrays are f32 or f64.
+#include <hip/hip_runtime.h>
+
+#include "../../include/safe_control_amd.h"
+#include "sc_math.hpp"
+#include "mpc_chol.hpp"
+
+namespace sc {
+
+namespace {
+
+template <typename F>
+__device__ __forceinline__ double wred(double v, F f) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v = f(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double lsum(double v) { return wred(v, [](double a, double b) { return a + b; }); }
+__device__ __forceinline__ double lmin(double v) { return wred(v, [](double a, double b) { return fmin(a, b); }); }
+__device__ __forceinline__ double lmax_(double v) { return wred(v, [](double a, double b) { return fmax(a, b); }); }
+
+struct LinMem {
+    double *Ae, *Be, *As2, *Bs2, *xg, *up, *lx;          // model, goal state, previous input, adjoint (2 nx)
+    double *z, *zt, *zb, *dz, *gs, *rd, *rhs;            // n each
+    double *xs, *pts, *y, *pdz, *obs, *hk, *dh, *hh;     // (N+1) nx | 4N | 4N | 4N | 7K | 2N K | 4N K | 6N K
+    double *g, *s, *lam, *ds, *dlam, *vb;                // m each
+    double *cq;                                          // Q (12) | R (4) | u_lo (4) | u_hi (4)
+    double *Phi, *T, *M, *L, *G;                         // 16 N | 4N n | n n | n (n + 1) | 4N n
+};
+
+struct LinDims { int N, K, nx, nu, n, m, mc; };
+
+__host__ __device__ inline size_t mpclin_lds_doubles(int N, int K, int nx, int nu) {
+    const size_t n = (size_t)N * nu, m = (size_t)N * K + 2 * n;
+    return (size_t)nx * nx + (size_t)nx * nu + 2 * nx + 2 * nu + nx + nu + 2 * nx + 24 + 7 * n + (size_t)(N + 1) * nx + 12 * N +
+           7 * (size_t)K + 12 * (size_t)N * K + 6 * m + 16 * N + 8 * (size_t)N * n + n * n + n * (n + 1);
+}
+
+__device__ inline LinMem carve_lin(double* b, const LinDims& d) {
+    LinMem W;
+    auto take = [&](size_t c) { double* r = b; b += c; return r; };
+    const int N = d.N, K = d.K, nx = d.nx, nu = d.nu, n = d.n, m = d.m;
+    W.Ae = take(nx * nx); W.Be = take(nx * nu); W.As2 = take(2 * nx); W.Bs2 = take(2 * nu);
+    W.xg = take(nx); W.up = take(nu); W.lx = take(2 * nx); W.cq = take(24);
+    W.z = take(n); W.zt = take(n); W.zb = take(n); W.dz = take(n); W.gs = take(n); W.rd = take(n); W.rhs = take(n);
+    W.xs = take((N + 1) * nx); W.pts = take(4 * N); W.y = take(4 * N); W.pdz = take(4 * N);
+    W.obs = take(7 * K); W.hk = take(2 * N * K); W.dh = take(4 * N * K); W.hh = take(6 * N * K);
+    W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m); W.vb = take(m);
+    W.Phi = take(16 * N); W.T = take((size_t)4 * N * n); W.M = take((size_t)n * n); W.L = take((size_t)n * (n + 1));
+    W.G = take((size_t)4 * N * n);
+    return W;
+}
+
+struct LinConst {
+    double w0, Rrob, beta;
+    int circles_only;
+};
+
+// h, dh/dp, d2h/dp2 at a planar point: circle (every model) or superellipsoid (single_integrator2D.py:162-181: fabs,
+// a, b >= 1e-3, e >= 2); oracle/mpc_cbf.py: barrier
+__device__ inline void lin_barrier(double px_, double py_, const double* o, const LinConst& c, bool derivs, double& h,
+                                   double& d0, double& d1, double& hxx, double& hxy, double& hyy) {
+    if (c.circles_only || o[6] < 0.5) {
+        const double d = c.Rrob + o[2];
+        const double ex = px_ - o[0], ey = py_ - o[1];
+        h = (ex * ex + ey * ey) - c.beta * d * d;
+        d0 = 2.0 * ex; d1 = 2.0 * ey; hxx = 2.0; hxy = 0.0; hyy = 2.0;
+        return;
+    }
+    const double a = fmax(fabs(o[2]), 1e-3) + c.Rrob, b = fmax(fabs(o[3]), 1e-3) + c.Rrob;
+    const double e = fmax(fabs(o[4]), 2.0);
+    double st, ct;
+    sincos(o[5], &st, &ct);
+    const double dx = px_ - o[0], dy = py_ - o[1];
+    const double px = ct * dx + st * dy, py = -st * dx + ct * dy;
+    const double ax = fabs(px) / a, ay = fabs(py) / b;
+    h = pow(ax, e) + pow(ay, e) - 1.0;
+    if (!derivs) { d0 = d1 = hxx = hxy = hyy = 0.0; return; }
+    const double sx = px > 0 ? 1.0 : (px < 0 ? -1.0 : 0.0), sy = py > 0 ? 1.0 : (py < 0 ? -1.0 : 0.0);
+    const double gpx = e * pow(ax, e - 1) / a * sx, gpy = e * pow(ay, e - 1) / b * sy;
+    const double cxx = e * (e - 1) * pow(ax, e - 2) / (a * a), cyy = e * (e - 1) * pow(ay, e - 2) / (b * b);
+    d0 = ct * gpx - st * gpy;
+    d1 = st * gpx + ct * gpy;
+    hxx = ct * ct * cxx + st * st * cyy;
+    hxy = ct * st * cxx - st * ct * cyy;
+    hyy = st * st * cxx + ct * ct * cyy;
+}
+
+// rollout, barrier points, f, barrier values (and derivatives), g.  Points: a_k = index k, b_k = index N + k.
+__device__ __forceinline__ double lin_eval(const double* zv, const LinMem& W, const LinDims& d, const LinConst& c, int lane,
+                                        bool derivs) {
+    const int N = d.N, K = d.K, nx = d.nx, nu = d.nu, n = d.n;
+    for (int k = 0; k < N; ++k) {
+        if (lane < nx) {
+            double acc = 0.0;
+            for (int j = 0; j < nx; ++j) acc += W.Ae[lane * nx + j] * W.xs[k * nx + j];
+            for (int j = 0; j < nu; ++j) acc += W.Be[lane * nu + j] * zv[k * nu + j];
+            W.xs[(k + 1) * nx + lane] = acc;
+        }
+        SC_SYNC();
+    }
+    for (int e = lane; e < 2 * N; e += 64) {
+        const int k = e >> 1, dd = e & 1;
+        W.pts[e] = W.xs[k * nx + dd];
+        double acc = 0.0;
+        for (int j = 0; j < nx; ++j) acc += W.As2[dd * nx + j] * W.xs[k * nx + j];
+        for (int j = 0; j < nu; ++j) acc += W.Bs2[dd * nu + j] * zv[k * nu + j];
+        W.pts[2 * N + e] = acc;
+    }
+    double part = 0.0;
+    for (int e = lane; e < N * nx; e += 64) {
+        const int k = e / nx + 1, i = e - (k - 1) * nx;
+        const double dv = W.xs[k * nx + i] - W.xg[i];
+        part += W.cq[i] * dv * dv;
+    }
+    for (int i = lane; i < n; i += 64) {
+        const double prev = i >= nu ? zv[i - nu] : W.up[i];
+        const double du = zv[i] - prev;
+        part += W.cq[12 + i % nu] * du * du;
+    }
+    SC_SYNC();
+    for (int e = lane; e < 2 * N * K; e += 64) {
+        const int pt = e / K, j = e - pt * K;
+        double h, d0, d1, hxx, hxy, hyy;
+        lin_barrier(W.pts[2 * pt], W.pts[2 * pt + 1], W.obs + 7 * j, c, derivs, h, d0, d1, hxx, hxy, hyy);
+        W.hk[e] = h;
+        if (derivs) {
+            W.dh[2 * e] = d0; W.dh[2 * e + 1] = d1;
+            W.hh[3 * e] = hxx; W.hh[3 * e + 1] = hxy; W.hh[3 * e + 2] = hyy;
+        }
+    }
+    SC_SYNC();
+    for (int i = lane; i < d.m; i += 64) {
+        double gi;
+        if (i < d.mc) {
+            const int k = i / K, j = i - k * K;
+            gi = W.hk[(N + k) * K + j] + c.w0 * W.hk[k * K + j];
+        } else if (i < d.mc + n) {
+            const int col = i - d.mc;
+            gi = W.cq[20 + col % nu] - zv[col];
+        } else {
+            const int col = i - d.mc - n;
+            gi = zv[col] - W.cq[16 + col % nu];
+        }
+        W.g[i] = gi;
+    }
+    SC_SYNC();
+    return lsum(part);
+}
+
+// gradient of the (unscaled) cost by the adjoint recursion:  l_k = 2 Q (x_k - xg) + Ae' l_{k+1},  df/du_{k-1} = Be' l_k
+__device__ __forceinline__ void lin_grad(const LinMem& W, const LinDims& d, const LinConst& c, int lane, double sf) {
+    const int N = d.N, nx = d.nx, nu = d.nu, n = d.n;
+    for (int k = N; k >= 1; --k) {
+        double* cur = W.lx + (k & 1) * nx;
+        const double* nxt = W.lx + ((k + 1) & 1) * nx;
+        if (lane < nx) {
+            double acc = 2.0 * W.cq[lane] * (W.xs[k * nx + lane] - W.xg[lane]);
+            if (k < N)
+                for (int j = 0; j < nx; ++j) acc += W.Ae[j * nx + lane] * nxt[j];
+            cur[lane] = acc;
+        }
+        SC_SYNC();
+        if (lane < nu) {
+            double acc = 0.0;
+            for (int j = 0; j < nx; ++j) acc += W.Be[j * nu + lane] * cur[j];
+            W.gs[(k - 1) * nu + lane] = acc;
+        }
+        SC_SYNC();
+    }
+    for (int i = lane; i < n; i += 64) {
+        const double prev = i >= nu ? W.z[i - nu] : W.up[i];
+        double gr = W.gs[i] + 2.0 * W.cq[12 + i % nu] * (W.z[i] - prev);
+        if (i + nu < n) gr -= 2.0 * W.cq[12 + i % nu] * (W.z[i + nu] - W.z[i]);
+        W.gs[i] = sf * gr;
+    }
+    SC_SYNC();
+}
+
+// out = J' v for a row vector v (m):  G' (A' v) - v_hi + v_lo
+__device__ __forceinline__ void lin_jt(const double* v, double* out, const LinMem& W, const LinDims& d, const LinConst& c,
+                                    const double* G, int lane) {
+    const int N = d.N, K = d.K, n = d.n;
+    for (int e = lane; e < 4 * N; e += 64) {
+        const int pt = e >> 1, dd = e & 1, k = pt < N ? pt : pt - N;
+        double acc = 0.0;
+        for (int j = 0; j < K; ++j) acc += v[k * K + j] * W.dh[2 * (pt * K + j) + dd];
+        W.y[e] = pt < N ? c.w0 * acc : acc;
+    }
+    SC_SYNC();
+    for (int i = lane; i < n; i += 64) {
+        double acc = 0.0;
+        for (int r = 0; r < 4 * N; ++r) acc += G[(size_t)r * n + i] * W.y[r];
+        out[i] = acc - v[d.mc + i] + v[d.mc + n + i];
+    }
+    SC_SYNC();
+}
+
+// Cholesky in LDS (L = lower of A, row stride n), false on a pivot <= 0; then L L' x = b in place
+__device__ __forceinline__ bool lin_cholesky(double* A, int n, int lane) {
+    bool ok = true;
+    for (int j = 0; j < n; ++j) {
+        const double dd = A[j * n + j];
+        if (!(dd > 0.0)) ok = false;
+        const double piv = sqrt(dd);
+        SC_SYNC();
+        for (int i = j + lane; i < n; i += 64) A[i * n + j] = (i == j) ? piv : A[i * n + j] / piv;
+        SC_SYNC();
+        const int rem = n - j - 1;
+        for (int e = lane; e < rem * rem; e += 64) {
+            const int i = j + 1 + e / rem, k = j + 1 + e % rem;
+            if (k <= i) A[i * n + k] -= A[i * n + j] * A[k * n + j];
+        }
+        SC_SYNC();
+        if (!ok) break;
+    }
+    return ok;
+}
+__device__ __forceinline__ void lin_chol_solve(const double* L, double* b, int n, int lane) {
+    for (int j = 0; j < n; ++j) {
+        if (lane == 0) b[j] = b[j] / L[j * n + j];
+        SC_SYNC();
+        const double yj = b[j];
+        for (int i = j + 1 + lane; i < n; i += 64) b[i] -= L[i * n + j] * yj;
+        SC_SYNC();
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        if (lane == 0) b[j] = b[j] / L[j * n + j];
+        SC_SYNC();
+        const double xj = b[j];
+        for (int i = lane; i < j; i += 64) b[i] -= L[j * n + i] * xj;
+        SC_SYNC();
+    }
+}
+
+// register Cholesky for a compile-time order (mpc_chol.hpp); out of line like mpc_cbf.hip's (code size)
+template <int nn>
+__device__ __noinline__ bool lin_chol_reg(const double* M, const double* rhs, double* Lt, double* out, double delta, int lane) {
+    double a[nn], diag;
+    const int row = lane < nn ? lane : 0;
+#pragma unroll
+    for (int k = 0; k < nn; ++k) a[k] = M[row * nn + k] + (lane == k ? delta : 0.0);
+    if (!chol_reg<nn>(a, lane, diag)) return false;
+    const double x = chol_solve_reg<nn>(a, diag, rhs[row], Lt, lane);
+    if (lane < nn) out[lane] = x;
+    SC_SYNC();
+    return true;
+}
+
+template <int NN>
+__global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, const long long B,
+                                                    const int K, const void* __restrict__ X, const void* __restrict__ u_prev,
+                                                    const void* __restrict__ goal, const void* __restrict__ obs,
+                                                    void* __restrict__ u_out, int* __restrict__ status_out,
+                                                    int* __restrict__ iters_out, void* __restrict__ z_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane = threadIdx.x;
+    const long long prob = blockIdx.x;
+    if (prob >= B) return;
+    const bool io32 = p.io_dtype == SC_DTYPE_F32;
+    auto ld = [io32](const void* a, size_t i) { return io32 ? (double)((const float*)a)[i] : ((const double*)a)[i]; };
+    auto st = [io32](void* a, size_t i, double v) { if (io32) ((float*)a)[i] = (float)v; else ((double*)a)[i] = v; };
+
+    LinDims d;
+    d.N = p.horizon; d.K = K; d.nx = p.nx; d.nu = p.nu; d.n = NN > 0 ? NN : d.N * d.nu; d.mc = d.N * K; d.m = d.mc + 2 * d.n;
+    const int N = d.N, nx = d.nx, nu = d.nu, n = d.n, m = d.m;
+    const LinMem W = carve_lin(sm, d);
+    LinConst c;
+    c.w0 = -(1.0 - p.alpha); c.Rrob = p.robot_radius; c.beta = p.beta; c.circles_only = p.circles_only;
+    if (lane < 12) W.cq[lane] = p.Q[lane];
+    if (lane < 4) { W.cq[12 + lane] = p.R[lane]; W.cq[16 + lane] = p.u_lo[lane]; W.cq[20 + lane] = p.u_hi[lane]; }
+    // model blob: Ae [nx nx] | Be [nx nu] | As2 [2 nx] | Bs2 [2 nu] | Hc [n n] | G [4N n]
+    const int nmat = nx * nx + nx * nu + 2 * nx + 2 * nu;
+    for (int e = lane; e < nmat; e += 64) W.Ae[e] = model[e];            // the four small matrices are contiguous in LDS too
+    const double* __restrict__ Hc = model + nmat;
+    {
+        const double* __restrict__ Gg = Hc + (size_t)n * n;
+        for (int e = lane; e < 4 * N * n; e += 64) W.G[e] = Gg[e];
+    }
+    const double* G = W.G;
+    for (int i = lane; i < nx; i += 64) { W.xs[i] = ld(X, prob * nx + i); W.xg[i] = i < p.ng ? ld(goal, prob * p.ng + i) : 0.0; }
+    for (int i = lane; i < nu; i += 64) W.up[i] = ld(u_prev, prob * nu + i);
+    const size_t obase = p.obs_shared ? 0 : (size_t)prob * K * 7;
+    for (int e = lane; e < K * 7; e += 64) W.obs[e] = ld(obs, obase + e);
+    SC_SYNC();
+    // set_initial_guess (mpc_cbf.py:369): u_prev at every stage, pulled strictly inside the box
+    for (int i = lane; i < n; i += 64) {
+        const double lo = W.cq[16 + i % nu], hi = W.cq[20 + i % nu], pad = 0.005 * (hi - lo);
+        W.z[i] = fmin(fmax(W.up[i % nu], lo + pad), hi - pad);
+    }
+    SC_SYNC();
+
+    double f = lin_eval(W.z, W, d, c, lane, true);
+    lin_grad(W, d, c, lane, 1.0);
+    double gmax = 0.0;
+    for (int i = lane; i < n; i += 64) gmax = fmax(gmax, fabs(W.gs[i]));
+    gmax = lmax_(gmax);
+    const double sf = fmin(1.0, 100.0 / fmax(1e-12, gmax));             // objective scaling
+    double mu = p.mu_init;
+    for (int i = lane; i < m; i += 64) { const double s = fmax(W.g[i], 1e-2); W.s[i] = s; W.lam[i] = mu / s; }
+    for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
+    SC_SYNC();
+
+    int status = SC_STATUS_INACCURATE, it = 0;
+    const double tau = 0.995;
+    double nu_m = 10.0, delta_last = 0.0, e_best = 1e300;
+    int n_acc = 0;
+    const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
+    for (it = 1; it <= p.max_iter; ++it) {
+        if (it > 1) f = lin_eval(W.z, W, d, c, lane, true);
+        lin_grad(W, d, c, lane, sf);                                      // gs = sf grad f
+        lin_jt(W.lam, W.rd, W, d, c, G, lane);
+        double e_d = 0.0, e_p = 0.0, e_c0 = 0.0, lmx = 0.0;
+        for (int i = lane; i < n; i += 64) { const double r = W.gs[i] - W.rd[i]; W.rd[i] = r; e_d = fmax(e_d, fabs(r)); }
+        for (int i = lane; i < m; i += 64) {
+            const double s = W.s[i], l = W.lam[i];
+            e_p = fmax(e_p, fabs(W.g[i] - s)); e_c0 = fmax(e_c0, fabs(s * l)); lmx = fmax(lmx, l);
+        }
+        e_d = lmax_(e_d); e_p = lmax_(e_p); e_c0 = lmax_(e_c0); lmx = lmax_(lmx);
+        const double e_opt = fmax(e_d, fmax(e_p, e_c0));
+        if (e_opt < e_best) {
+            e_best = e_opt;
+            for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
+        }
+        if (e_opt <= p.tol) { status = SC_STATUS_OPTIMAL; break; }
+        n_acc = e_opt <= p.acceptable_tol ? n_acc + 1 : 0;
+        if (n_acc >= acc_iter) break;
+        if (lmx > 1e10) { status = SC_STATUS_INFEASIBLE; break; }
+        if (!(e_opt < 1e300)) break;                                      // non-finite data: give up
+        for (;;) {                                                        // barrier update
+            double e_c = 0.0;
+            for (int i = lane; i < m; i += 64) e_c = fmax(e_c, fabs(W.s[i] * W.lam[i] - mu));
+            e_c = lmax_(e_c);
+            const double e_mu = fmax(e_d, fmax(e_p, e_c));
+            if (e_mu <= 10.0 * mu && mu > p.mu_min) mu = fmax(p.mu_min, fmin(0.2 * mu, mu * sqrt(mu)));
+            else break;
+        }
+        // rhs = -sf grad f + J' (mu / s - sig r_p)
+        for (int i = lane; i < m; i += 64) {
+            const double s = W.s[i], l = W.lam[i];
+            W.vb[i] = mu / s - (l / s) * (W.g[i] - s);
+        }
+        SC_SYNC();
+        lin_jt(W.vb, W.rhs, W, d, c, G, lane);
+        for (int i = lane; i < n; i += 64) W.rhs[i] = -W.gs[i] + W.rhs[i];
+        // stage blocks Phi_k over (a_k, b_k):  sum_j sig_kj v v' (v = [w0 dh_a; dh_b])  -  sum_j lam_kj [w0 Hh_a, 0; 0, Hh_b]
+        for (int e = lane; e < 16 * N; e += 64) {
+            const int k = e >> 4, r = (e >> 2) & 3, cc = e & 3;
+            double acc = 0.0;
+            for (int j = 0; j < K; ++j) {
+                const int ea = k * K + j, eb = (N + k) * K + j, row = k * K + j;
+                const double l = W.lam[row], sig = l / W.s[row];
+                const double vr = r < 2 ? c.w0 * W.dh[2 * ea + r] : W.dh[2 * eb + r - 2];
+                const double vc = cc < 2 ? c.w0 * W.dh[2 * ea + cc] : W.dh[2 * eb + cc - 2];
+                acc += sig * vr * vc;
+                if (r < 2 && cc < 2) acc -= l * c.w0 * W.hh[3 * ea + r + cc];
+                if (r >= 2 && cc >= 2) acc -= l * W.hh[3 * eb + (r - 2) + (cc - 2)];
+            }
+            W.Phi[e] = acc;
+        }
+        SC_SYNC();
+        // T = Phi G (rows 4k..4k+3), then M = sf Hc + G' T + diag(sig_hi + sig_lo)
+        for (int e = lane; e < 4 * N * n; e += 64) {
+            const int row = e / n, col = e - row * n, k = row >> 2, r = row & 3;
+            double acc = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int gr = cc < 2 ? 2 * k + cc : 2 * N + 2 * k + cc - 2;
+                acc += W.Phi[16 * k + 4 * r + cc] * G[(size_t)gr * n + col];
+            }
+            W.T[e] = acc;
+        }
+        SC_SYNC();
+        for (int e = lane; e < n * n; e += 64) {
+            const int i = e / n, j = e - i * n;
+            if (j > i) continue;
+            double acc = sf * Hc[e];
+            for (int k = 0; k < N; ++k) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int gr = r < 2 ? 2 * k + r : 2 * N + 2 * k + r - 2;
+                    acc += G[(size_t)gr * n + i] * W.T[(size_t)(4 * k + r) * n + j];
+                }
+            }
+            if (i == j) acc += W.lam[d.mc + i] / W.s[d.mc + i] + W.lam[d.mc + n + i] / W.s[d.mc + n + i];
+            W.M[e] = acc;
+            W.M[j * n + i] = acc;
+        }
+        SC_SYNC();
+        // inertia correction: M + delta I until the Cholesky succeeds
+        double delta = 0.0;
+        bool ok = false;
+        for (int t = 0; t < 40 && !ok; ++t) {
+            if constexpr (NN > 0) {
+                ok = lin_chol_reg<NN>(W.M, W.rhs, W.L, W.dz, delta, lane);
+            } else {
+                for (int e = lane; e < n * n; e += 64) W.L[e] = W.M[e] + ((e / n == e % n) ? delta : 0.0);
+                SC_SYNC();
+                ok = lin_cholesky(W.L, n, lane);
+            }
+            if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
+        }
+        if (!ok) break;
+        if (delta > 0.0) delta_last = delta;
+        if constexpr (NN == 0) {
+            for (int i = lane; i < n; i += 64) W.dz[i] = W.rhs[i];
+            SC_SYNC();
+            lin_chol_solve(W.L, W.dz, n, lane);
+        }
+        // point displacements  G dz, then ds = J dz + r_p, dlam, step lengths
+        for (int r = lane; r < 4 * N; r += 64) {
+            double acc = 0.0;
+            for (int i = 0; i < n; ++i) acc += G[(size_t)r * n + i] * W.dz[i];
+            W.pdz[r] = acc;
+        }
+        // sf grad f . dz and the curvature sf dz' Hc dz: the cost is exactly quadratic in z, so the line search takes
+        // f(z + a dz) - f(z) = a grad.dz + a^2/2 dz' Hc dz instead of the difference of two sums of size |f|
+        double gdz = 0.0, curv = 0.0;
+        for (int i = lane; i < n; i += 64) {
+            gdz += W.gs[i] * W.dz[i];
+            double q = 0.0;
+            for (int j = 0; j < n; ++j) q += Hc[(size_t)j * n + i] * W.dz[j];
+            curv += q * W.dz[i];
+        }
+        curv = sf * lsum(curv);
+        SC_SYNC();
+        double rs_min = 0.0, rl_min = 0.0, sum_ds_s = 0.0, sum_rp = 0.0, sum_log = 0.0, sum_g = 0.0;
+        for (int i = lane; i < m; i += 64) {
+            const double s = W.s[i], l = W.lam[i], rp = W.g[i] - s;
+            double jd;
+            if (i < d.mc) {
+                const int k = i / K, j = i - k * K, ea = k * K + j, eb = (N + k) * K + j;
+                jd = c.w0 * (W.dh[2 * ea] * W.pdz[2 * k] + W.dh[2 * ea + 1] * W.pdz[2 * k + 1]) +
+                     (W.dh[2 * eb] * W.pdz[2 * N + 2 * k] + W.dh[2 * eb + 1] * W.pdz[2 * N + 2 * k + 1]);
+            } else if (i < d.mc + n) {
+                jd = -W.dz[i - d.mc];
+            } else {
+                jd = W.dz[i - d.mc - n];
+            }
+            const double dsi = jd + rp;
+            const double dl = -(l / s) * dsi - (l - mu / s);
+            const double rs = dsi / s, rl = dl / l;
+            rs_min = fmin(rs_min, rs); rl_min = fmin(rl_min, rl);
+            sum_ds_s += rs; sum_rp += fabs(rp); sum_log += log(s); sum_g += fabs(W.g[i]);
+            W.ds[i] = dsi; W.dlam[i] = dl;
+        }
+        rs_min = lmin(rs_min); rl_min = lmin(rl_min); sum_ds_s = lsum(sum_ds_s); sum_rp = lsum(sum_rp); sum_log = lsum(sum_log);
+        gdz = lsum(gdz); sum_g = lsum(sum_g);
+        const double ap = rs_min < 0.0 ? fmin(1.0, -tau / rs_min) : 1.0, ad = rl_min < 0.0 ? fmin(1.0, -tau / rl_min) : 1.0;
+        nu_m = fmax(nu_m, 1.1 * lmx);
+        const double phi0 = sf * f - mu * sum_log + nu_m * sum_rp;
+        const double dphi = gdz - mu * sum_ds_s - nu_m * sum_rp;
+        // round-off of the constraint part of the merit: a far-away dummy obstacle row has h ~ 2e6 (oracle: row_noise)
+        const double noise_rows = 1e-15 * nu_m * sum_g;
+        double alpha = ap;
+        bool accepted = false;
+        for (int ls = 0; ls < 12; ++ls) {
+            for (int i = lane; i < n; i += 64) W.zt[i] = W.z[i] + alpha * W.dz[i];
+            SC_SYNC();
+            lin_eval(W.zt, W, d, c, lane, false);
+            double srp = 0.0, slog = 0.0;
+            for (int i = lane; i < m; i += 64) {
+                const double s_t = W.s[i] + alpha * W.ds[i];
+                slog += log(s_t); srp += fabs(W.g[i] - s_t);
+            }
+            slog = lsum(slog); srp = lsum(srp);
+            const double phit = phi0 + alpha * gdz + 0.5 * alpha * alpha * curv - mu * (slog - sum_log) + nu_m * (srp - sum_rp);
+            if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0) + noise_rows) { accepted = true; break; }
+            alpha *= 0.5;
+        }
+        if (!accepted) break;
+        for (int i = lane; i < n; i += 64) W.z[i] = W.z[i] + alpha * W.dz[i];
+        for (int i = lane; i < m; i += 64) {
+            const double s = W.s[i] + alpha * W.ds[i];
+            double l = W.lam[i] + ad * W.dlam[i];
+            const double mus = mu / s;
+            l = fmin(fmax(l, 1e-10 * mus), 1e10 * mus);                   // IPOPT eq. (16) safeguard
+            W.s[i] = s; W.lam[i] = l;
+        }
+        SC_SYNC();
+    }
+    if (it > p.max_iter) it = p.max_iter;
+    if (status != SC_STATUS_OPTIMAL && e_best <= p.acceptable_tol) {
+        SC_SYNC();
+        for (int i = lane; i < n; i += 64) W.z[i] = W.zb[i];
+        status = SC_STATUS_OPTIMAL;
+    }
+    SC_SYNC();
+    lin_eval(W.z, W, d, c, lane, false);
+    if (status != SC_STATUS_OPTIMAL) {
+        double gmin = 1e300;
+        for (int i = lane; i < m; i += 64) gmin = fmin(gmin, W.g[i]);
+        gmin = lmin(gmin);
+        if (gmin < -1e-6) status = SC_STATUS_INFEASIBLE;
+        else if (status != SC_STATUS_INFEASIBLE) status = SC_STATUS_INACCURATE;
+    }
+    if (lane < nu) st(u_out, prob * nu + lane, W.z[lane]);
+    if (lane == 0) {
+        status_out[prob] = status;
+        if (iters_out) iters_out[prob] = it;
+    }
+    if (z_out) for (int i = lane; i < n; i += 64) st(z_out, prob * n + i, W.z[i]);
+}
+
+}  // namespace
+
+size_t mpclin_lds_bytes(int N, int K, int nx, int nu) { return mpclin_lds_doubles(N, K, nx, nu) * sizeof(double); }
+
+// Host: constant matrices of the condensed problem from (Ae, Be, As, Bs, Q, R, N); layout of the blob as the kernel reads it
+size_t mpclin_model_doubles(int nx, int nu, int N) {
+    const size_t n = (size_t)N * nu;
+    return (size_t)nx * nx + (size_t)nx * nu + 2 * nx + 2 * nu + n * n + 4 * (size_t)N * n;
+}
+
+void mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const double* Be, const double* As, const double* Bs,
+                        double* out) {
+    const int nx = p.nx, nu = p.nu, N = p.horizon, n = N * nu;
+    double* o = out;
+    for (int i = 0; i < nx * nx; ++i) *o++ = Ae[i];
+    for (int i = 0; i < nx * nu; ++i) *o++ = Be[i];
+    for (int i = 0; i < 2 * nx; ++i) *o++ = As[i];                        // rows 0..1 of As (the planar position)
+    for (int i = 0; i < 2 * nu; ++i) *o++ = Bs[i];
+    double* Hc = o;
+    double* G = Hc + (size_t)n * n;
+    // Phi_k = d x_k / d z (nx x n), Phi_0 = 0, Phi_{k+1} = Ae Phi_k + Be E_k
+    double* Phi = new double[(size_t)(N + 1) * nx * n]();
+    for (int k = 0; k < N; ++k) {
+        const double* Pk = Phi + (size_t)k * nx * n;
+        double* Pn = Phi + (size_t)(k + 1) * nx * n;
+        for (int i = 0; i < nx; ++i)
+            for (int col = 0; col < n; ++col) {
+                double acc = 0.0;
+                for (int j = 0; j < nx; ++j) acc += Ae[i * nx + j] * Pk[(size_t)j * n + col];
+                Pn[(size_t)i * n + col] = acc;
+            }
+        for (int i = 0; i < nx; ++i)
+            for (int cu = 0; cu < nu; ++cu) Pn[(size_t)i * n + k * nu + cu] += Be[i * nu + cu];
+    }
+    for (size_t e = 0; e < (size_t)n * n; ++e) Hc[e] = 0.0;
+    for (int k = 1; k <= N; ++k) {
+        const double* Pk = Phi + (size_t)k * nx * n;
+        for (int a = 0; a < n; ++a)
+            for (int b = 0; b < n; ++b) {
+                double acc = 0.0;
+                for (int i = 0; i < nx; ++i) acc += Pk[(size_t)i * n + a] * p.Q[i] * Pk[(size_t)i * n + b];
+                Hc[(size_t)a * n + b] += 2.0 * acc;
+            }
+    }
+    // r-term: sum_i R (z_i - z_{i - nu})^2  ->  2 D' R D
+    for (int i = 0; i < n; ++i) {
+        const double r = p.R[i % nu];
+        Hc[(size_t)i * n + i] += 2.0 * r;
+        if (i >= nu) {
+            Hc[(size_t)(i - nu) * n + (i - nu)] += 2.0 * r;
+            Hc[(size_t)i * n + (i - nu)] -= 2.0 * r;
+            Hc[(size_t)(i - nu) * n + i] -= 2.0 * r;
+        }
+    }
+    for (int k = 0; k < N; ++k) {
+        const double* Pk = Phi + (size_t)k * nx * n;
+        for (int dd = 0; dd < 2; ++dd)
+            for (int col = 0; col < n; ++col) {
+                G[(size_t)(2 * k + dd) * n + col] = Pk[(size_t)dd * n + col];
+                double acc = 0.0;
+                for (int j = 0; j < nx; ++j) acc += As[dd * nx + j] * Pk[(size_t)j * n + col];
+                if (col >= k * nu && col < (k + 1) * nu) acc += Bs[dd * nu + (col - k * nu)];
+                G[(size_t)(2 * N + 2 * k + dd) * n + col] = acc;
+            }
+    }
+    delete[] Phi;
+}
+
+hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long long B, int K, const void* X, const void* u_prev,
+                         const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
+                         hipStream_t stream) {
+    const size_t lds = mpclin_lds_bytes(p.horizon, K, p.nx, p.nu);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto launch = [&](auto kern) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, model, B, K, X, u_prev, goal, obs, u_out, status,
+                           iters, z_out);
+        return hipGetLastError();
+    };
+    const int n = p.horizon * p.nu;
+    if (n == 20) return launch(mpclin_kernel<20>);
+    if (n == 40) return launch(mpclin_kernel<40>);
+    return launch(mpclin_kernel<0>);
+}
+
+}  // namespace sc

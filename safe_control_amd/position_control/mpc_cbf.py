@@ -97,6 +97,13 @@ def make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_
 class MPCCBF:
     """Drop-in for position_control.mpc_cbf.MPCCBF (single agent per call)."""
 
+    def __new__(cls, robot, robot_spec, *args, **kwargs):
+        # the reference serves every model from this one class; the linear models run on their own kernel
+        if cls is MPCCBF and robot_spec.get("model") in ("SingleIntegrator2D", "Quad3D"):
+            from .mpc_cbf_linear import LinearMPCCBF
+            return LinearMPCCBF(robot, robot_spec, *args, **kwargs)
+        return super().__new__(cls)
+
     def __init__(self, robot, robot_spec, show_mpc_traj=False, num_obs=5, device=0):
         self.robot = robot
         self.robot_spec = complete_robot_spec(robot_spec)

@@ -29,6 +29,11 @@ def complete_robot_spec(robot_spec):
         robot_spec.setdefault("Kp", 3.0)
         robot_spec.setdefault("radius", 0.25)
         return robot_spec
+    if model == "Quad3D":                           # robots/quad3D.py:50-59 (MPC-CBF only)
+        for k, v in (("mass", 3.0), ("Ix", 0.5), ("Iy", 0.5), ("Iz", 0.5), ("L", 0.3), ("nu", 0.1), ("u_max", 10.0),
+                     ("u_min", -10.0), ("radius", 0.25)):
+            robot_spec.setdefault(k, v)
+        return robot_spec
     if model not in MODEL_IDS:
         raise ValueError(f"model {model!r} is not supported by the batched engine (supported: {sorted(MODEL_IDS)})")
     if model == "SingleIntegrator2D":               # robots/single_integrator2D.py:40-43

@@ -1,0 +1,135 @@
+"""GPU: MPC-CBF kernel for the linear models (csrc/mpc_lin.hip) through the C-ABI against the numpy oracle
+(oracle/mpc_lin.py problem functions + oracle/mpc_cbf.py solver).  The kernel follows the oracle's interior-point
+method iterate for iterate: same status, iteration counts within 2, |u0 - u0_oracle| <= 1e-6, |z - z_oracle| <= 2e-5."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import safe_control_amd as sca  # noqa: E402
+from oracle import mpc_cbf as M  # noqa: E402
+from oracle import mpc_lin as L  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def t(a, dtype=torch.float64):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV)
+
+
+def draw(mdl, rng, K):
+    nx = mdl["nx"]
+    x0 = np.zeros(nx); x0[:2] = rng.uniform(0, 8, 2)
+    goal = np.concatenate([rng.uniform(0, 8, 2), [rng.uniform(0.5, 2.0)]])[: mdl["ng"]]
+    obs = np.tile(M.DUMMY_OBS, (K, 1))
+    for j in range(max(1, K - 1)):                                 # the last row stays an update_tvp dummy when K > 1
+        rho, ph = rng.uniform(0.9, 3.0), rng.uniform(-np.pi, np.pi)
+        obs[j] = [x0[0] + rho * np.cos(ph), x0[1] + rho * np.sin(ph), rng.uniform(0.2, 0.6), 0, 0, 0, 0]
+    if nx == 12:
+        x0[2] = rng.uniform(0.5, 2.0); x0[6:8] = rng.uniform(-0.8, 0.8, 2); x0[3:5] = rng.uniform(-0.05, 0.05, 2)
+        v = x0[6:8]; d = v / max(np.linalg.norm(v), 1e-9)
+        rho = rng.uniform(1.1, 2.0)                                 # an obstacle ahead: a CBF row binds inside the horizon
+        obs[0, :3] = [x0[0] + rho * d[0], x0[1] + rho * d[1], 0.4]
+        goal[:2] = x0[:2] + 4.0 * d
+    return x0, goal, obs
+
+
+def batch(name, B, K, seed):
+    mdl = L.si_model() if name == "SingleIntegrator2D" else L.quad3d_model()
+    rng = np.random.default_rng(seed)
+    X = np.zeros((B, mdl["nx"])); G = np.zeros((B, mdl["ng"])); O = np.zeros((B, K, 7))
+    for i in range(B):
+        X[i], G[i], O[i] = draw(mdl, rng, K)
+    return mdl, X, G, O
+
+
+@pytest.mark.parametrize("name,N,K", [("SingleIntegrator2D", 10, 8), ("Quad3D", 10, 8), ("SingleIntegrator2D", 5, 3),
+                                      ("Quad3D", 6, 2), ("Quad3D", 16, 4)])
+def test_batch_matches_oracle(name, N, K):
+    B = 24
+    mdl, X, G, O = batch(name, B, K, seed=N * 10 + K)
+    up = np.random.default_rng(1).uniform(-0.2, 0.2, (B, mdl["nu"]))
+    ctl = sca.BatchedLinearMPCCBF({"model": name}, io_dtype="f64", horizon=N)
+    u, st, it, z = ctl.solve(t(X), t(up), t(G), t(O), want_z=True)
+    torch.cuda.synchronize()
+    u, st, it, z = u.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), z.cpu().numpy()
+    n_opt = n_act = n_loose = 0
+    for i in range(B):
+        uo, so, ito, info = L.solve(mdl, X[i], up[i], G[i], O[i], N=N, return_info=True)
+        assert st[i] == so, f"status differs at problem {i}"
+        if so == 0 and info["err"] > 1e-6:
+            # the oracle left through the acceptable-point rule (stalled at the f64 limit of this badly scaled model, KKT
+            # error between tol and acceptable_tol): both solvers are within acceptable_tol of the same point, the
+            # iteration at which they give up depends on rounding
+            assert np.abs(u[i] - uo).max() <= 1e-4 * max(1.0, np.abs(uo).max())
+            n_loose += 1
+            continue
+        assert abs(int(it[i]) - ito) <= 2, f"iterations differ at problem {i}: {it[i]} vs {ito}"
+        if so == 0:
+            assert np.abs(u[i] - uo).max() <= 1e-6
+            assert np.abs(z[i] - info["z"]).max() <= 2e-5
+            n_opt += 1
+            n_act += int(np.min(info["g"][: N * K]) < 1e-4)
+    assert n_opt >= B // 3 and n_act >= (1 if N >= 10 else 0) and n_loose <= B // 4
+
+
+def test_superellipsoid_obstacles_single_integrator():
+    B, K, N = 16, 3, 10
+    mdl, X, G, O = batch("SingleIntegrator2D", B, K, seed=5)
+    rng = np.random.default_rng(6)
+    for i in range(B):
+        rho, ph = rng.uniform(1.8, 3.0), rng.uniform(-np.pi, np.pi)
+        O[i, 1] = [X[i, 0] + rho * np.cos(ph), X[i, 1] + rho * np.sin(ph), *rng.uniform(0.4, 1.0, 2), float(rng.choice([2, 4, 6])),
+                   rng.uniform(-3, 3), 1.0]
+    up = np.zeros((B, 2))
+    ctl = sca.BatchedLinearMPCCBF({"model": "SingleIntegrator2D"}, io_dtype="f64", horizon=N)
+    u, st, it = ctl.solve(t(X), t(up), t(G), t(O))
+    u, st = u.cpu().numpy(), st.cpu().numpy()
+    for i in range(B):
+        uo, so, ito, info = L.solve(mdl, X[i], up[i], G[i], O[i], N=N, return_info=True)
+        assert st[i] == so
+        if so == 0:
+            assert np.abs(u[i] - uo).max() <= (1e-6 if info["err"] <= 1e-6 else 1e-4)
+
+
+def test_f32_arrays_and_shared_table():
+    B, K, N = 32, 4, 10
+    mdl, X, G, O = batch("Quad3D", B, K, seed=9)
+    shared = O[0].copy(); shared[:, :2] += 50.0                     # far away for everybody but present
+    X32, G32, S32 = X.astype(np.float32), G.astype(np.float32), shared.astype(np.float32)
+    up = np.zeros((B, 4), dtype=np.float32)
+    ctl = sca.BatchedLinearMPCCBF({"model": "Quad3D"}, io_dtype="f32", horizon=N)
+    u, st, it = ctl.solve(t(X32, torch.float32), t(up, torch.float32), t(G32, torch.float32), t(S32, torch.float32))
+    u, st = u.double().cpu().numpy(), st.cpu().numpy()
+    for i in range(0, B, 4):
+        uo, so, _, info = L.solve(mdl, X32[i].astype(np.float64), up[i].astype(np.float64), G32[i].astype(np.float64),
+                                  S32.astype(np.float64), N=N, return_info=True)
+        assert st[i] == so
+        if so == 0:
+            assert np.abs(u[i] - uo).max() <= (2e-6 if info["err"] <= 1e-6 else 1e-4) * max(1.0, np.abs(uo).max())
+
+
+def test_drop_in_class_and_bad_arguments():
+    for name in ("SingleIntegrator2D", "Quad3D"):
+        mdl = L.si_model() if name == "SingleIntegrator2D" else L.quad3d_model()
+        rng = np.random.default_rng(2)
+        x0, goal, obs = draw(mdl, rng, 3)
+        robot = sca.RobotHandle(x0, {"model": name})
+        ctl = sca.MPCCBF(robot, robot.robot_spec, num_obs=5)
+        assert type(ctl).__name__ == "LinearMPCCBF" and ctl.horizon == 10 and ctl.status == "optimal"
+        ref = {"state_machine": "track", "u_ref": np.zeros((mdl["nu"], 1)), "goal": goal}
+        u = ctl.solve_control_problem(robot.X, ref, obs[:2, :3])              # 3-wide rows, padded to num_obs like update_tvp
+        uo, so, _, info = L.solve(mdl, x0, np.zeros(mdl["nu"]), goal, M.pad_obstacles(obs[:2, :3], 5), return_info=True)
+        assert ctl.solver_status == ("optimal" if so == 0 else ctl.solver_status)
+        if so == 0:
+            assert u.shape == (mdl["nu"], 1) and np.abs(u.reshape(-1) - uo).max() <= (1e-6 if info["err"] <= 1e-6 else 1e-4)
+        ref["state_machine"] = "stop"
+        assert ctl.solve_control_problem(robot.X, ref, None) is ref["u_ref"]  # mpc_cbf.py:379-381
+    ctl = sca.BatchedLinearMPCCBF({"model": "Quad3D"}, horizon=10)
+    with pytest.raises(ValueError):
+        ctl.solve(t(np.zeros((2, 4))), t(np.zeros((2, 4))), t(np.zeros((2, 3))), t(np.zeros((2, 1, 7))))
+    with pytest.raises(ValueError):
+        sca.BatchedLinearMPCCBF({"model": "Quad3D"}, horizon=17)              # nu * horizon > 64
+    with pytest.raises(NotImplementedError):
+        sca.BatchedLinearMPCCBF({"model": "DynamicUnicycle2D"})

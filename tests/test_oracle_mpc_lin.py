@@ -104,3 +104,27 @@ def test_solver_reaches_a_local_optimum_slsqp_cannot_improve(name):
                      method="SLSQP", options={"ftol": 1e-13, "maxiter": 100})
         assert r.fun >= info["f"] * (1 - 1e-6) - 1e-6
     assert n_act >= 1
+
+
+def test_library_host_side_condensed_matrices_match_oracle():
+    """sc_mpclin_build_model (host code of the HIP library, no GPU call) against oracle.mpc_lin.condensed."""
+    import safe_control_amd as sca
+    from safe_control_amd import _lib
+    from safe_control_amd.position_control import mpc_cbf_linear as ML
+    from safe_control_amd.robots.linear_models import linear_model
+    lib = _lib.load()
+    for name, om in (("SingleIntegrator2D", L.si_model()), ("Quad3D", L.quad3d_model())):
+        spec = sca.complete_robot_spec({"model": name})
+        mdl = linear_model(spec, DT)
+        for key in ("Ae", "Be", "As", "Bs"):
+            np.testing.assert_allclose(mdl[key], om[key], rtol=0, atol=1e-15)
+        for N in (10, 6):
+            p = ML.make_params(mdl, mdl["cbf_param"], N, 0.25, _lib.DTYPE_F64)
+            blob = ML.build_model_blob(lib, p, mdl)
+            Hc, G, _ = L.condensed(om, N)
+            nx, nu = mdl["nx"], mdl["nu"]
+            n = N * nu
+            off = nx * nx + nx * nu + 2 * nx + 2 * nu
+            np.testing.assert_allclose(blob[off:off + n * n].reshape(n, n), Hc, rtol=1e-13, atol=1e-12)
+            np.testing.assert_allclose(blob[off + n * n:].reshape(4 * N, n), G, rtol=0, atol=1e-15)
+    assert lib.sc_mpclin_model_doubles(12, 4, 17) == 0            # nu * horizon > 64
