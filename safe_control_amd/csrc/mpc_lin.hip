@@ -110,7 +110,9 @@ __device__ __forceinline__ double lin_eval(const double* zv, const LinMem& W, co
     for (int k = 0; k < N; ++k) {
         if (lane < nx) {
             double acc = 0.0;
+#pragma unroll
             for (int j = 0; j < nx; ++j) acc += W.Ae[lane * nx + j] * W.xs[k * nx + j];
+#pragma unroll
             for (int j = 0; j < nu; ++j) acc += W.Be[lane * nu + j] * zv[k * nu + j];
             W.xs[(k + 1) * nx + lane] = acc;
         }
@@ -120,7 +122,9 @@ __device__ __forceinline__ double lin_eval(const double* zv, const LinMem& W, co
         const int k = e >> 1, dd = e & 1;
         W.pts[e] = W.xs[k * nx + dd];
         double acc = 0.0;
+#pragma unroll
         for (int j = 0; j < nx; ++j) acc += W.As2[dd * nx + j] * W.xs[k * nx + j];
+#pragma unroll
         for (int j = 0; j < nu; ++j) acc += W.Bs2[dd * nu + j] * zv[k * nu + j];
         W.pts[2 * N + e] = acc;
     }
@@ -174,12 +178,14 @@ __device__ __forceinline__ void lin_grad(const LinMem& W, const LinDims& d, cons
         if (lane < nx) {
             double acc = 2.0 * W.cq[lane] * (W.xs[k * nx + lane] - W.xg[lane]);
             if (k < N)
+#pragma unroll
                 for (int j = 0; j < nx; ++j) acc += W.Ae[j * nx + lane] * nxt[j];
             cur[lane] = acc;
         }
         SC_SYNC();
         if (lane < nu) {
             double acc = 0.0;
+#pragma unroll
             for (int j = 0; j < nx; ++j) acc += W.Be[j * nu + lane] * cur[j];
             W.gs[(k - 1) * nu + lane] = acc;
         }
@@ -201,12 +207,14 @@ __device__ __forceinline__ void lin_jt(const double* v, double* out, const LinMe
     for (int e = lane; e < 4 * N; e += 64) {
         const int pt = e >> 1, dd = e & 1, k = pt < N ? pt : pt - N;
         double acc = 0.0;
+#pragma unroll
         for (int j = 0; j < K; ++j) acc += v[k * K + j] * W.dh[2 * (pt * K + j) + dd];
         W.y[e] = pt < N ? c.w0 * acc : acc;
     }
     SC_SYNC();
     for (int i = lane; i < n; i += 64) {
         double acc = 0.0;
+#pragma unroll
         for (int r = 0; r < 4 * N; ++r) acc += G[(size_t)r * n + i] * W.y[r];
         out[i] = acc - v[d.mc + i] + v[d.mc + n + i];
     }
@@ -264,9 +272,17 @@ __device__ __noinline__ bool lin_chol_reg(const double* M, const double* rhs, do
     return true;
 }
 
-template <int NN>
+#ifdef SC_LIN_PROF
+#define LP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += (double)(t_ - tlast); tlast = t_; } while (0)
+#else
+#define LP(i) do { } while (0)
+#endif
+
+// NX, NU, NT, KT > 0: states, inputs, horizon, obstacle rows are compile-time constants (inner loops unroll and their LDS
+// loads are issued back to back; with run-time bounds every multiply-add waits a full LDS round trip); 0: run-time sizes.
+template <int NX, int NU, int NT, int KT>
 __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, const long long B,
-                                                    const int K, const void* __restrict__ X, const void* __restrict__ u_prev,
+                                                    const int K_rt, const void* __restrict__ X, const void* __restrict__ u_prev,
                                                     const void* __restrict__ goal, const void* __restrict__ obs,
                                                     void* __restrict__ u_out, int* __restrict__ status_out,
                                                     int* __restrict__ iters_out, void* __restrict__ z_out) {
@@ -278,8 +294,11 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
     auto ld = [io32](const void* a, size_t i) { return io32 ? (double)((const float*)a)[i] : ((const double*)a)[i]; };
     auto st = [io32](void* a, size_t i, double v) { if (io32) ((float*)a)[i] = (float)v; else ((double*)a)[i] = v; };
 
+    constexpr int NN = NX > 0 ? NT * NU : 0;                      // order of the condensed system when known at compile time
     LinDims d;
-    d.N = p.horizon; d.K = K; d.nx = p.nx; d.nu = p.nu; d.n = NN > 0 ? NN : d.N * d.nu; d.mc = d.N * K; d.m = d.mc + 2 * d.n;
+    d.N = NX > 0 ? NT : p.horizon; d.K = KT > 0 ? KT : K_rt; d.nx = NX > 0 ? NX : p.nx; d.nu = NX > 0 ? NU : p.nu;
+    d.n = d.N * d.nu; d.mc = d.N * d.K; d.m = d.mc + 2 * d.n;
+    const int K = d.K;
     const int N = d.N, nx = d.nx, nu = d.nu, n = d.n, m = d.m;
     const LinMem W = carve_lin(sm, d);
     LinConst c;
@@ -323,10 +342,18 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
     double nu_m = 10.0, delta_last = 0.0, e_best = 1e300;
     int n_acc = 0;
     const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
+#ifdef SC_LIN_PROF
+    double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
+#endif
     for (it = 1; it <= p.max_iter; ++it) {
+        LP(11);
         if (it > 1) f = lin_eval(W.z, W, d, c, lane, true);
+        LP(0);
         lin_grad(W, d, c, lane, sf);                                      // gs = sf grad f
+        LP(1);
         lin_jt(W.lam, W.rd, W, d, c, G, lane);
+        LP(2);
         double e_d = 0.0, e_p = 0.0, e_c0 = 0.0, lmx = 0.0;
         for (int i = lane; i < n; i += 64) { const double r = W.gs[i] - W.rd[i]; W.rd[i] = r; e_d = fmax(e_d, fabs(r)); }
         for (int i = lane; i < m; i += 64) {
@@ -352,6 +379,7 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
             if (e_mu <= 10.0 * mu && mu > p.mu_min) mu = fmax(p.mu_min, fmin(0.2 * mu, mu * sqrt(mu)));
             else break;
         }
+        LP(3);
         // rhs = -sf grad f + J' (mu / s - sig r_p)
         for (int i = lane; i < m; i += 64) {
             const double s = W.s[i], l = W.lam[i];
@@ -360,10 +388,12 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         SC_SYNC();
         lin_jt(W.vb, W.rhs, W, d, c, G, lane);
         for (int i = lane; i < n; i += 64) W.rhs[i] = -W.gs[i] + W.rhs[i];
+        LP(4);
         // stage blocks Phi_k over (a_k, b_k):  sum_j sig_kj v v' (v = [w0 dh_a; dh_b])  -  sum_j lam_kj [w0 Hh_a, 0; 0, Hh_b]
         for (int e = lane; e < 16 * N; e += 64) {
             const int k = e >> 4, r = (e >> 2) & 3, cc = e & 3;
             double acc = 0.0;
+#pragma unroll
             for (int j = 0; j < K; ++j) {
                 const int ea = k * K + j, eb = (N + k) * K + j, row = k * K + j;
                 const double l = W.lam[row], sig = l / W.s[row];
@@ -376,6 +406,7 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
             W.Phi[e] = acc;
         }
         SC_SYNC();
+        LP(5);
         // T = Phi G (rows 4k..4k+3), then M = sf Hc + G' T + diag(sig_hi + sig_lo)
         for (int e = lane; e < 4 * N * n; e += 64) {
             const int row = e / n, col = e - row * n, k = row >> 2, r = row & 3;
@@ -388,11 +419,16 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
             W.T[e] = acc;
         }
         SC_SYNC();
-        for (int e = lane; e < n * n; e += 64) {
-            const int i = e / n, j = e - i * n;
-            if (j > i) continue;
-            double acc = sf * Hc[e];
+        for (int e = lane; e < n * (n + 1) / 2; e += 64) {               // lower triangle, mirrored
+            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while ((i + 1) * (i + 2) / 2 <= e) ++i;
+            while (i * (i + 1) / 2 > e) --i;
+            const int j = e - i * (i + 1) / 2;
+            double acc = sf * Hc[(size_t)i * n + j];
+            const int kb = i / nu;                                        // b_k depends on u_0..u_k, a_k on u_0..u_{k-1}: G[.][i] = 0 before
+#pragma unroll
             for (int k = 0; k < N; ++k) {
+                if (k < kb) continue;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int gr = r < 2 ? 2 * k + r : 2 * N + 2 * k + r - 2;
@@ -400,10 +436,11 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
                 }
             }
             if (i == j) acc += W.lam[d.mc + i] / W.s[d.mc + i] + W.lam[d.mc + n + i] / W.s[d.mc + n + i];
-            W.M[e] = acc;
-            W.M[j * n + i] = acc;
+            W.M[(size_t)i * n + j] = acc;
+            W.M[(size_t)j * n + i] = acc;
         }
         SC_SYNC();
+        LP(6);
         // inertia correction: M + delta I until the Cholesky succeeds
         double delta = 0.0;
         bool ok = false;
@@ -424,9 +461,11 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
             SC_SYNC();
             lin_chol_solve(W.L, W.dz, n, lane);
         }
+        LP(7);
         // point displacements  G dz, then ds = J dz + r_p, dlam, step lengths
         for (int r = lane; r < 4 * N; r += 64) {
             double acc = 0.0;
+#pragma unroll
             for (int i = 0; i < n; ++i) acc += G[(size_t)r * n + i] * W.dz[i];
             W.pdz[r] = acc;
         }
@@ -436,6 +475,7 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         for (int i = lane; i < n; i += 64) {
             gdz += W.gs[i] * W.dz[i];
             double q = 0.0;
+#pragma unroll
             for (int j = 0; j < n; ++j) q += Hc[(size_t)j * n + i] * W.dz[j];
             curv += q * W.dz[i];
         }
@@ -469,6 +509,7 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         const double dphi = gdz - mu * sum_ds_s - nu_m * sum_rp;
         // round-off of the constraint part of the merit: a far-away dummy obstacle row has h ~ 2e6 (oracle: row_noise)
         const double noise_rows = 1e-15 * nu_m * sum_g;
+        LP(8);
         double alpha = ap;
         bool accepted = false;
         for (int ls = 0; ls < 12; ++ls) {
@@ -485,6 +526,7 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
             if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0) + noise_rows) { accepted = true; break; }
             alpha *= 0.5;
         }
+        LP(9);
         if (!accepted) break;
         for (int i = lane; i < n; i += 64) W.z[i] = W.z[i] + alpha * W.dz[i];
         for (int i = lane; i < m; i += 64) {
@@ -516,7 +558,11 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         status_out[prob] = status;
         if (iters_out) iters_out[prob] = it;
     }
+#ifdef SC_LIN_PROF
+    if (z_out && lane == 0) for (int i = 0; i < 12; ++i) st(z_out, prob * n + i, prof[i]);
+#else
     if (z_out) for (int i = lane; i < n; i += 64) st(z_out, prob * n + i, W.z[i]);
+#endif
 }
 
 }  // namespace
@@ -601,10 +647,11 @@ hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long lo
                            iters, z_out);
         return hipGetLastError();
     };
-    const int n = p.horizon * p.nu;
-    if (n == 20) return launch(mpclin_kernel<20>);
-    if (n == 40) return launch(mpclin_kernel<40>);
-    return launch(mpclin_kernel<0>);
+    if (p.horizon == 10 && p.nx == 12 && p.nu == 4)               // Quad3D at the reference's default horizon
+        return K == 8 ? launch(mpclin_kernel<12, 4, 10, 8>) : launch(mpclin_kernel<12, 4, 10, 0>);
+    if (p.horizon == 10 && p.nx == 2 && p.nu == 2)                // SingleIntegrator2D
+        return K == 8 ? launch(mpclin_kernel<2, 2, 10, 8>) : launch(mpclin_kernel<2, 2, 10, 0>);
+    return launch(mpclin_kernel<0, 0, 0, 0>);
 }
 
 }  // namespace sc
