@@ -221,6 +221,33 @@ def manip_leg(dev, B=4096, K=3, steps=20, seed=0):
             "constrained_fraction": float(((u - tu).abs().amax(dim=1) > 1e-6).double().mean().item())}
 
 
+def linear_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
+    """MPC-CBF on the reference's linear models (BASELINE config 5 names Quad3D): B agents, horizon N,
+    K obstacles, one NLP per wavefront (csrc/mpc_lin.hip)."""
+    import torch
+    import safe_control_amd as sca
+    from safe_control_amd import workloads as W
+    ctl = sca.BatchedLinearMPCCBF({"model": model}, io_dtype="f32", horizon=N)
+    Xn, gn, on = W.linear_mpc_batch(model, B, K, seed=seed)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    X, g, ob = t(Xn), t(gn), t(on)
+    up = torch.zeros((B, Xn.shape[1] == 12 and 4 or 2), dtype=torch.float32, device=dev)
+    u, st, it = ctl.solve(X, up, g, ob)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        u, st, it = ctl.solve(X, up, g, ob)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return {"workload": f"{B}-agent batch {model} MPC-CBF, horizon N={N}, {K} obstacles ({N * up.shape[1]} variables)",
+            "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
+            "optimal_fraction": float((st == 0).double().mean().item()),
+            "infeasible_fraction": float((st == 1).double().mean().item()),
+            "mean_ipm_iterations": float(it.double().mean().item())}
+
+
 def closed_loop_leg(dev, B=4096, T=200, seed=0):
     """BASELINE config 2, closed-loop variant: B DynamicUnicycle2D agents track waypoints through the 14-circle
     scene of examples/test_tracking.py for T control steps (selection + nominal input + CBF-QP + step + collision
@@ -406,6 +433,8 @@ def main():
             res["od_mpc_cbf"] = od_mpc_leg(dev)
             res["closed_loop"] = closed_loop_leg(dev)
             res["manipulator_cbf_qp"] = manip_leg(dev)
+            res["quad3d_mpc_cbf"] = linear_mpc_leg(dev, "Quad3D")
+            res["single_integrator_mpc_cbf"] = linear_mpc_leg(dev, "SingleIntegrator2D")
             res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
         if ws == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(X.double().cpu().numpy(), ur.double().cpu().numpy(),

@@ -89,3 +89,28 @@ def kb_c3bf_batch(B=16384, K=16, seed=0, spec=None, shared_table=False):
         obs[:, :, 3:5] = rng.uniform(-0.5, 0.5, (B, K, 2))
     u_ref = nominal_input_kb(X, goal, spec)
     return X, goal, u_ref, obs
+
+
+def linear_mpc_batch(model="Quad3D", B=4096, K=8, seed=0, radius=0.25):
+    """Batch for the linear-model MPC-CBF kernel (BASELINE config 5 names Quad3D): positions ~ U(0,14)^2, goals
+    ~ U(0,14)^2 (Quad3D: altitude 1..2, goal altitude 1..2, planar speed up to 0.8 m/s, small attitude), K circular
+    obstacles per agent as in du_cbfqp_batch.  Returns float64 X[B,nx], goal[B,ng], obs[B,K,7]."""
+    rng = np.random.default_rng(seed)
+    nx, ng = (12, 3) if model == "Quad3D" else (2, 2)
+    X = np.zeros((B, nx))
+    X[:, 0:2] = rng.uniform(0.0, 14.0, (B, 2))
+    goal = np.zeros((B, ng))
+    goal[:, 0:2] = rng.uniform(0.0, 14.0, (B, 2))
+    if model == "Quad3D":
+        X[:, 2] = rng.uniform(1.0, 2.0, B)
+        X[:, 3:5] = rng.uniform(-0.05, 0.05, (B, 2))
+        X[:, 6:8] = rng.uniform(-0.8, 0.8, (B, 2)) / np.sqrt(2.0)
+        goal[:, 2] = rng.uniform(1.0, 2.0, B)
+    r = rng.uniform(0.2, 1.0, (B, K))
+    rho = rng.uniform(0.0, 1.0, (B, K)) * (4.0 - (r + radius + 0.05)) + (r + radius + 0.05)
+    phi = rng.uniform(-np.pi, np.pi, (B, K))
+    obs = np.zeros((B, K, 7))
+    obs[:, :, 0] = X[:, None, 0] + rho * np.cos(phi)
+    obs[:, :, 1] = X[:, None, 1] + rho * np.sin(phi)
+    obs[:, :, 2] = r
+    return X, goal, obs
