@@ -56,6 +56,13 @@ def input_bounds(robot_spec):
     return (-hi[0], -hi[1]), hi
 
 
+def _check_cbfqp_model(robot_spec):
+    """Quad3D / VTOL2D have no CBF-QP in the reference either (quad3D.py:269-273 raises); Manipulator2D has its own class."""
+    if robot_spec["model"] not in _lib.MODEL_IDS:
+        raise ValueError(f"CBF-QP on the batched engine does not support model {robot_spec['model']!r} "
+                         f"(supported: {sorted(_lib.MODEL_IDS)} and Manipulator2D through ManipulatorCBFQP)")
+
+
 def make_params(robot_spec, cbf_param, dt, radius, io_dtype, compute_dtype, obs_shared=False):
     model = robot_spec["model"]
     p = _lib.CbfQpParams()
@@ -109,6 +116,7 @@ class CBFQP:
     def __init__(self, robot, robot_spec, num_obs=1, device=0):
         self.robot = robot
         self.robot_spec = complete_robot_spec(robot_spec)
+        _check_cbfqp_model(self.robot_spec)
         self.num_obs = int(num_obs)
         self.device = device
         self.cbf_param = apply_cbf_overrides(default_cbf_param(self.robot_spec["model"]), self.robot_spec)
@@ -171,6 +179,7 @@ class BatchedCBFQP:
 
     def __init__(self, robot_spec, dt=0.05, io_dtype="f32", compute_dtype="f64", cbf_param=None):
         self.robot_spec = complete_robot_spec(robot_spec)
+        _check_cbfqp_model(self.robot_spec)
         self.dt = float(dt)
         self.io_dtype = {"f32": _lib.DTYPE_F32, "f64": _lib.DTYPE_F64}[io_dtype]
         self.compute_dtype = {"f32": _lib.DTYPE_F32, "f64": _lib.DTYPE_F64}[compute_dtype]

@@ -45,6 +45,8 @@ class BatchedTrackingController:
         self.robot_spec = complete_robot_spec(robot_spec)
         self.robot_spec.setdefault("exploration", False)
         self.model = self.robot_spec["model"]
+        if self.model not in _lib.MODEL_IDS:
+            raise ValueError(f"the batched closed loop does not support model {self.model!r}")
         self.dt = float(dt)
         self.enable_rotation = bool(enable_rotation)
         self.dyn_obs = bool(dyn_obs)
