@@ -33,4 +33,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench_full -- py
 # 5. MPC-CBF kernel
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o mpc -- python3 $R/bench.py --workload mpc_cbf --steps 5 --warmup 1 > $OUT/mpc_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o mpc_sq -- python3 $R/bench.py --workload mpc_cbf --steps 2 --warmup 1 > /dev/null 2>&1
+# 6. linear-model MPC-CBF kernel (Quad3D, n = 40): instruction mix and LDS conflicts
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o mpclin -- python3 $R/tools/prof_mpclin.py Quad3D 4096 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o mpclin_sq -- python3 $R/tools/prof_mpclin.py Quad3D 4096 2 > /dev/null 2>&1
 ls $OUT | head -80

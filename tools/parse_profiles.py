@@ -26,7 +26,7 @@ src = os.path.join(ROOT, "gpurun_out", f"profiles_{rnd}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-OURS = ("cbfqp", "mpccbf", "tracking_rollout", "tracking_coop", "neighbor_kernel", "odcbfqp")
+OURS = ("cbfqp", "mpccbf", "tracking_rollout", "tracking_coop", "neighbor_kernel", "odcbfqp", "mpclin")   # manip_cbfqp matches "cbfqp"
 
 
 def counters(path):
@@ -36,7 +36,7 @@ def counters(path):
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
         if any(o in k for o in OURS):
-            acc[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            acc[k.replace("(anonymous namespace)::", "").split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 
 
@@ -57,7 +57,7 @@ with open(os.path.join(dst, f"{rnd}_kernel_stats.csv"), "w", newline="") as f:
         for r in stats(tag):
             r = dict(r)
             r["run"] = os.path.basename(tag).replace("_kernel_stats.csv", "")
-            r["Name"] = r["Name"].split("(")[0]
+            r["Name"] = r["Name"].replace("(anonymous namespace)::", "").split("(")[0]
             if w is None:
                 w = csv.DictWriter(f, fieldnames=["run"] + [k for k in r if k != "run"])
                 w.writeheader()
