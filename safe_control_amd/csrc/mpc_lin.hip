@@ -43,17 +43,24 @@ struct LinMem {
     double *g, *s, *lam, *ds, *dlam, *vb;                // m each
     double *cq;                                          // Q (12) | R (4) | u_lo (4) | u_hi (4)
     double *Phi, *T, *M, *L, *G;                         // 16 N | 4N n | n n | n (n + 1) | 4N n
+    double *Hc, *clin;                                   // lean kernels: n n copy of the cost Hessian, n constant part of grad f
 };
 
 struct LinDims { int N, K, nx, nu, n, m, mc; };
 
-__host__ __device__ inline size_t mpclin_lds_doubles(int N, int K, int nx, int nu) {
+// lean = the compile-time instantiations: the Cholesky runs in registers, so its only LDS need is the n (n + 1) transpose
+// scratch, which reuses the dead T | M region; the space goes to a copy of Hc (M assembly, line-search curvature and the
+// gradient Hc z + c read it every iteration; 75 KB for Quad3D at N = 10, K = 8).  Reading G from global
+// memory as well (49 KB, three problems per CU instead of two) was measured: 8 % faster at 65536 problems, 15 % slower
+// at 4096 (the L1/L2 latency sits on every iteration's critical path) -- G stays in LDS.
+__host__ __device__ inline size_t mpclin_lds_doubles(int N, int K, int nx, int nu, bool lean = false) {
     const size_t n = (size_t)N * nu, m = (size_t)N * K + 2 * n;
     return (size_t)nx * nx + (size_t)nx * nu + 2 * nx + 2 * nu + nx + nu + 2 * nx + 24 + 7 * n + (size_t)(N + 1) * nx + 12 * N +
-           7 * (size_t)K + 12 * (size_t)N * K + 6 * m + 16 * N + 8 * (size_t)N * n + n * n + n * (n + 1);
+           7 * (size_t)K + 12 * (size_t)N * K + 6 * m + 16 * N + 4 * (size_t)N * n + n * n +
+           4 * (size_t)N * n + (lean ? n * n + n : n * (n + 1));
 }
 
-__device__ inline LinMem carve_lin(double* b, const LinDims& d) {
+__device__ inline LinMem carve_lin(double* b, const LinDims& d, bool lean) {
     LinMem W;
     auto take = [&](size_t c) { double* r = b; b += c; return r; };
     const int N = d.N, K = d.K, nx = d.nx, nu = d.nu, n = d.n, m = d.m;
@@ -63,8 +70,11 @@ __device__ inline LinMem carve_lin(double* b, const LinDims& d) {
     W.xs = take((N + 1) * nx); W.pts = take(4 * N); W.y = take(4 * N); W.pdz = take(4 * N);
     W.obs = take(7 * K); W.hk = take(2 * N * K); W.dh = take(4 * N * K); W.hh = take(6 * N * K);
     W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m); W.vb = take(m);
-    W.Phi = take(16 * N); W.T = take((size_t)4 * N * n); W.M = take((size_t)n * n); W.L = take((size_t)n * (n + 1));
+    W.Phi = take(16 * N); W.T = take((size_t)4 * N * n); W.M = take((size_t)n * n);
     W.G = take((size_t)4 * N * n);
+    W.Hc = W.clin = nullptr;
+    if (lean) { W.L = W.T; W.Hc = take((size_t)n * n); W.clin = take(n); }                   // the transpose scratch lives in the dead T | M region (4N n + n n >= n (n + 1))
+    else W.L = take((size_t)n * (n + 1));
     return W;
 }
 
@@ -272,6 +282,54 @@ __device__ __noinline__ bool lin_chol_reg(const double* M, const double* rhs, do
     return true;
 }
 
+// M = sf Hc + G' T + diag(box) with v_mfma_f64_16x16x4_f64 (compile-time horizon).  Operand layout (MI355X guide, "f64
+// MFMA"): lane l feeds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; result register r of lane l is
+// D[row = (l >> 4) + 4 r][col = l & 15].  The contraction runs over the 4N point rows; k-step `st` is stage st (its a_k and
+// b_k rows), so A[i][.] = G[row(st, q)][i] and B[.][j] = T[4 st + q][j].  Only the lower tiles are computed (T = Phi G with
+// a symmetric Phi), and a row tile skips the stages whose points cannot depend on any of its columns (b_k depends on
+// u_0..u_k): 28 MFMAs instead of 90 for n = 40.  `box` holds sig_hi + sig_lo per column.
+typedef double lin_d4 __attribute__((ext_vector_type(4)));
+template <int NT, int NU>
+__device__ __forceinline__ void lin_condense_mfma(const LinMem& W, double sf, const double* Hc, const double* G, const double* box,
+                                                  int lane) {
+    constexpr int n = NT * NU, nt = (n + 15) / 16;
+    const int q = lane >> 4, l15 = lane & 15;
+#pragma unroll
+    for (int ti = 0; ti < nt; ++ti) {
+        const int ia = 16 * ti + l15;
+        const bool okA = ia < n;
+        const int iac = okA ? ia : 0;
+        const int k_lo = (16 * ti) / NU;
+#pragma unroll
+        for (int tj = 0; tj <= ti; ++tj) {
+            const int jb = 16 * tj + l15;
+            const bool okB = jb < n;
+            const int jbc = okB ? jb : 0;
+            double a[NT], b[NT];
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int gr = q < 2 ? 2 * k + q : 2 * NT + 2 * k + q - 2;
+                const double av = G[(size_t)gr * n + iac], bv = W.T[(size_t)(4 * k + q) * n + jbc];
+                a[k] = okA ? av : 0.0;
+                b[k] = okB ? bv : 0.0;
+            }
+            lin_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < NT; ++k)
+                if (k >= k_lo) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k], b[k], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ti + q + 4 * r, col = 16 * tj + l15;
+                if (row < n && col < n) {
+                    const double v = acc[r] + sf * Hc[(size_t)row * n + col] + (row == col ? box[row] : 0.0);
+                    W.M[(size_t)row * n + col] = v;
+                    if (ti != tj) W.M[(size_t)col * n + row] = v;
+                }
+            }
+        }
+    }
+}
+
 #ifdef SC_LIN_PROF
 #define LP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += (double)(t_ - tlast); tlast = t_; } while (0)
 #else
@@ -300,7 +358,8 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
     d.n = d.N * d.nu; d.mc = d.N * d.K; d.m = d.mc + 2 * d.n;
     const int K = d.K;
     const int N = d.N, nx = d.nx, nu = d.nu, n = d.n, m = d.m;
-    const LinMem W = carve_lin(sm, d);
+    constexpr bool LEAN = NX > 0;
+    const LinMem W = carve_lin(sm, d, LEAN);
     LinConst c;
     c.w0 = -(1.0 - p.alpha); c.Rrob = p.robot_radius; c.beta = p.beta; c.circles_only = p.circles_only;
     if (lane < 12) W.cq[lane] = p.Q[lane];
@@ -308,11 +367,13 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
     // model blob: Ae [nx nx] | Be [nx nu] | As2 [2 nx] | Bs2 [2 nu] | Hc [n n] | G [4N n]
     const int nmat = nx * nx + nx * nu + 2 * nx + 2 * nu;
     for (int e = lane; e < nmat; e += 64) W.Ae[e] = model[e];            // the four small matrices are contiguous in LDS too
-    const double* __restrict__ Hc = model + nmat;
-    {
-        const double* __restrict__ Gg = Hc + (size_t)n * n;
-        for (int e = lane; e < 4 * N * n; e += 64) W.G[e] = Gg[e];
+    const double* __restrict__ Hcg = model + nmat;
+    const double* __restrict__ Gg = Hcg + (size_t)n * n;
+    if constexpr (LEAN) {
+        for (int e = lane; e < n * n; e += 64) W.Hc[e] = Hcg[e];
     }
+    const double* Hc = LEAN ? W.Hc : Hcg;
+    for (int e = lane; e < 4 * N * n; e += 64) W.G[e] = Gg[e];
     const double* G = W.G;
     for (int i = lane; i < nx; i += 64) { W.xs[i] = ld(X, prob * nx + i); W.xg[i] = i < p.ng ? ld(goal, prob * p.ng + i) : 0.0; }
     for (int i = lane; i < nu; i += 64) W.up[i] = ld(u_prev, prob * nu + i);
@@ -328,6 +389,16 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
 
     double f = lin_eval(W.z, W, d, c, lane, true);
     lin_grad(W, d, c, lane, 1.0);
+    if constexpr (LEAN) {
+        // the cost is quadratic: grad f = Hc z + c with c fixed for the solve (one adjoint pass, here)
+        for (int i = lane; i < n; i += 64) {
+            double q = 0.0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) q += Hc[(size_t)j * n + i] * W.z[j];
+            W.clin[i] = W.gs[i] - q;
+        }
+        SC_SYNC();
+    }
     double gmax = 0.0;
     for (int i = lane; i < n; i += 64) gmax = fmax(gmax, fabs(W.gs[i]));
     gmax = lmax_(gmax);
@@ -350,7 +421,17 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         LP(11);
         if (it > 1) f = lin_eval(W.z, W, d, c, lane, true);
         LP(0);
-        lin_grad(W, d, c, lane, sf);                                      // gs = sf grad f
+        if constexpr (LEAN) {                                             // gs = sf grad f = sf (Hc z + c)
+            for (int i = lane; i < n; i += 64) {
+                double q = W.clin[i];
+#pragma unroll
+                for (int j = 0; j < n; ++j) q += Hc[(size_t)j * n + i] * W.z[j];
+                W.gs[i] = sf * q;
+            }
+            SC_SYNC();
+        } else {
+            lin_grad(W, d, c, lane, sf);
+        }
         LP(1);
         lin_jt(W.lam, W.rd, W, d, c, G, lane);
         LP(2);
@@ -383,7 +464,9 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         // rhs = -sf grad f + J' (mu / s - sig r_p)
         for (int i = lane; i < m; i += 64) {
             const double s = W.s[i], l = W.lam[i];
-            W.vb[i] = mu / s - (l / s) * (W.g[i] - s);
+            const double sig = l / s;
+            W.vb[i] = mu / s - sig * (W.g[i] - s);
+            W.ds[i] = sig;                                                // read by the Phi blocks below; ds proper is written after the solve
         }
         SC_SYNC();
         lin_jt(W.vb, W.rhs, W, d, c, G, lane);
@@ -396,7 +479,7 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const int ea = k * K + j, eb = (N + k) * K + j, row = k * K + j;
-                const double l = W.lam[row], sig = l / W.s[row];
+                const double l = W.lam[row], sig = W.ds[row];
                 const double vr = r < 2 ? c.w0 * W.dh[2 * ea + r] : W.dh[2 * eb + r - 2];
                 const double vc = cc < 2 ? c.w0 * W.dh[2 * ea + cc] : W.dh[2 * eb + cc - 2];
                 acc += sig * vr * vc;
@@ -419,25 +502,32 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
             W.T[e] = acc;
         }
         SC_SYNC();
-        for (int e = lane; e < n * (n + 1) / 2; e += 64) {               // lower triangle, mirrored
-            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-            while ((i + 1) * (i + 2) / 2 <= e) ++i;
-            while (i * (i + 1) / 2 > e) --i;
-            const int j = e - i * (i + 1) / 2;
-            double acc = sf * Hc[(size_t)i * n + j];
-            const int kb = i / nu;                                        // b_k depends on u_0..u_k, a_k on u_0..u_{k-1}: G[.][i] = 0 before
-#pragma unroll
-            for (int k = 0; k < N; ++k) {
-                if (k < kb) continue;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int gr = r < 2 ? 2 * k + r : 2 * N + 2 * k + r - 2;
-                    acc += G[(size_t)gr * n + i] * W.T[(size_t)(4 * k + r) * n + j];
+        if constexpr (LEAN) {
+            for (int i = lane; i < n; i += 64)                               // r_d is consumed: its space holds the box terms
+                W.rd[i] = W.lam[d.mc + i] / W.s[d.mc + i] + W.lam[d.mc + n + i] / W.s[d.mc + n + i];
+            SC_SYNC();
+            lin_condense_mfma<NT, NU>(W, sf, Hc, G, W.rd, lane);
+        } else {
+            for (int e = lane; e < n * (n + 1) / 2; e += 64) {               // lower triangle, mirrored
+                int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                while ((i + 1) * (i + 2) / 2 <= e) ++i;
+                while (i * (i + 1) / 2 > e) --i;
+                const int j = e - i * (i + 1) / 2;
+                double acc = sf * Hc[(size_t)i * n + j];
+                // every stage, branch-free: G[.][i] is zero for the stages that cannot reach column i (b_k depends on
+                // u_0..u_k, a_k on u_0..u_{k-1}); skipping them per lane would serialise the LDS loads behind branches
+    #pragma unroll
+                for (int k = 0; k < N; ++k) {
+    #pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int gr = r < 2 ? 2 * k + r : 2 * N + 2 * k + r - 2;
+                        acc += G[(size_t)gr * n + i] * W.T[(size_t)(4 * k + r) * n + j];
+                    }
                 }
+                if (i == j) acc += W.lam[d.mc + i] / W.s[d.mc + i] + W.lam[d.mc + n + i] / W.s[d.mc + n + i];
+                W.M[(size_t)i * n + j] = acc;
+                W.M[(size_t)j * n + i] = acc;
             }
-            if (i == j) acc += W.lam[d.mc + i] / W.s[d.mc + i] + W.lam[d.mc + n + i] / W.s[d.mc + n + i];
-            W.M[(size_t)i * n + j] = acc;
-            W.M[(size_t)j * n + i] = acc;
         }
         SC_SYNC();
         LP(6);
@@ -567,7 +657,8 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
 
 }  // namespace
 
-size_t mpclin_lds_bytes(int N, int K, int nx, int nu) { return mpclin_lds_doubles(N, K, nx, nu) * sizeof(double); }
+static bool mpclin_is_lean(int N, int nx, int nu) { return N == 10 && ((nx == 12 && nu == 4) || (nx == 2 && nu == 2)); }
+size_t mpclin_lds_bytes(int N, int K, int nx, int nu) { return mpclin_lds_doubles(N, K, nx, nu, mpclin_is_lean(N, nx, nu)) * sizeof(double); }
 
 // Host: constant matrices of the condensed problem from (Ae, Be, As, Bs, Q, R, N); layout of the blob as the kernel reads it
 size_t mpclin_model_doubles(int nx, int nu, int N) {
