@@ -196,7 +196,7 @@ int sc_mpccbf_solve_batch_host(const sc_mpccbf_params* params, int64_t B, int32_
 typedef struct sc_mpclin_params {
     int32_t io_dtype;        /* SC_DTYPE_*: element type of X,u_prev,goal,obs,u_out,z_out                 */
     int32_t nx, nu, ng;      /* states (<= 12), inputs (<= 4), goal entries (2: SI, 3: Quad3D, mpc_cbf.py:80-81) */
-    int32_t horizon;         /* robot_spec['mpc_horizon'], default 10; nu * horizon <= 64                  */
+    int32_t horizon;         /* robot_spec['mpc_horizon'], default 10; nu * horizon <= 128 and the LDS fit (Quad3D: N <= 20) */
     int32_t max_iter, obs_shared, acceptable_iter;   /* as sc_mpccbf_params                              */
     int32_t circles_only;    /* 1: the model's barrier has no superellipsoid branch (Quad3D)               */
     int32_t reserved;

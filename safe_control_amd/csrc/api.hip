@@ -112,7 +112,7 @@ static int check_mpclin_dims(const sc_mpclin_params* p) {
     if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
     if (p->nx < 2 || p->nx > 12 || p->nu < 1 || p->nu > 4 || p->ng < 2 || p->ng > p->nx)
         return fail(SC_ERR_INVALID_ARGUMENT, "need 2 <= nx <= 12, 1 <= nu <= 4, 2 <= ng <= nx");
-    if (p->horizon < 1 || p->horizon * p->nu > 64) return fail(SC_ERR_UNSUPPORTED, "need 1 <= horizon and nu * horizon <= 64");
+    if (p->horizon < 1 || p->horizon * p->nu > 128) return fail(SC_ERR_UNSUPPORTED, "need 1 <= horizon and nu * horizon <= 128");
     return SC_OK;
 }
 static int check_mpclin(const sc_mpclin_params* p, const double* model, int64_t B, int32_t K, const void* X, const void* u_prev,
@@ -160,7 +160,7 @@ static int check_manip(const sc_manip_cbfqp_params* p, int64_t B, int32_t K, con
 extern "C" {
 
 size_t sc_mpclin_model_doubles(int32_t nx, int32_t nu, int32_t horizon) {
-    if (nx < 2 || nx > 12 || nu < 1 || nu > 4 || horizon < 1 || horizon * nu > 64) return 0;
+    if (nx < 2 || nx > 12 || nu < 1 || nu > 4 || horizon < 1 || horizon * nu > 128) return 0;
     return sc::mpclin_model_doubles(nx, nu, horizon);
 }
 

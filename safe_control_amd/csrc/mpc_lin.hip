@@ -53,14 +53,19 @@ struct LinDims { int N, K, nx, nu, n, m, mc; };
 // gradient Hc z + c read it every iteration; 75 KB for Quad3D at N = 10, K = 8).  Reading G from global
 // memory as well (49 KB, three problems per CU instead of two) was measured: 8 % faster at 65536 problems, 15 % slower
 // at 4096 (the L1/L2 latency sits on every iteration's critical path) -- G stays in LDS.
-__host__ __device__ inline size_t mpclin_lds_doubles(int N, int K, int nx, int nu, bool lean = false) {
+// big (mode 2) = run-time sizes whose standard layout exceeds the 160 KB of a CU (Quad3D at N = 20: n = 80): G is read from
+// global memory and the LDS Cholesky factor takes the dead T region (4N n >= n n whenever nu <= 4).
+enum { LIN_STD = 0, LIN_LEAN = 1, LIN_BIG = 2 };
+__host__ __device__ inline size_t mpclin_lds_doubles(int N, int K, int nx, int nu, int mode = LIN_STD) {
+    const bool lean = mode == LIN_LEAN;
     const size_t n = (size_t)N * nu, m = (size_t)N * K + 2 * n;
     return (size_t)nx * nx + (size_t)nx * nu + 2 * nx + 2 * nu + nx + nu + 2 * nx + 24 + 7 * n + (size_t)(N + 1) * nx + 12 * N +
            7 * (size_t)K + 12 * (size_t)N * K + 6 * m + 16 * N + 4 * (size_t)N * n + n * n +
-           4 * (size_t)N * n + (lean ? n * n + n : n * (n + 1));
+           (mode == LIN_BIG ? 0 : 4 * (size_t)N * n + (lean ? n * n + n : n * (n + 1)));
 }
 
-__device__ inline LinMem carve_lin(double* b, const LinDims& d, bool lean) {
+__device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode) {
+    const bool lean = mode == LIN_LEAN;
     LinMem W;
     auto take = [&](size_t c) { double* r = b; b += c; return r; };
     const int N = d.N, K = d.K, nx = d.nx, nu = d.nu, n = d.n, m = d.m;
@@ -71,8 +76,9 @@ __device__ inline LinMem carve_lin(double* b, const LinDims& d, bool lean) {
     W.obs = take(7 * K); W.hk = take(2 * N * K); W.dh = take(4 * N * K); W.hh = take(6 * N * K);
     W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m); W.vb = take(m);
     W.Phi = take(16 * N); W.T = take((size_t)4 * N * n); W.M = take((size_t)n * n);
-    W.G = take((size_t)4 * N * n);
     W.Hc = W.clin = nullptr;
+    if (mode == LIN_BIG) { W.G = nullptr; W.L = W.T; return W; }
+    W.G = take((size_t)4 * N * n);
     if (lean) { W.L = W.T; W.Hc = take((size_t)n * n); W.clin = take(n); }                   // the transpose scratch lives in the dead T | M region (4N n + n n >= n (n + 1))
     else W.L = take((size_t)n * (n + 1));
     return W;
@@ -224,30 +230,57 @@ __device__ __forceinline__ void lin_jt(const double* v, double* out, const LinMe
     SC_SYNC();
     for (int i = lane; i < n; i += 64) {
         double acc = 0.0;
-#pragma unroll
+#pragma unroll 8
         for (int r = 0; r < 4 * N; ++r) acc += G[(size_t)r * n + i] * W.y[r];
         out[i] = acc - v[d.mc + i] + v[d.mc + n + i];
     }
     SC_SYNC();
 }
 
-// Cholesky in LDS (L = lower of A, row stride n), false on a pivot <= 0; then L L' x = b in place
+// Cholesky in LDS for run-time orders (L = lower of A, row stride n), false on a pivot <= 0.  Right-looking with panels of
+// 4 columns: the panel is factored column by column (updates confined to the panel), the trailing matrix then takes ONE
+// rank-4 update per 16 x 16 tile as a v_mfma_f64_16x16x4_f64 (A = panel rows of the tile's rows, B' = panel rows of its
+// columns): n^3 / 3 multiply-adds leave the LDS read-modify-write loop (n = 80: 533 k -> 60 k cycles).
+typedef double lin_c4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool lin_cholesky(double* A, int n, int lane) {
     bool ok = true;
-    for (int j = 0; j < n; ++j) {
-        const double dd = A[j * n + j];
-        if (!(dd > 0.0)) ok = false;
-        const double piv = sqrt(dd);
-        SC_SYNC();
-        for (int i = j + lane; i < n; i += 64) A[i * n + j] = (i == j) ? piv : A[i * n + j] / piv;
-        SC_SYNC();
-        const int rem = n - j - 1;
-        for (int e = lane; e < rem * rem; e += 64) {
-            const int i = j + 1 + e / rem, k = j + 1 + e % rem;
-            if (k <= i) A[i * n + k] -= A[i * n + j] * A[k * n + j];
+    const int q = lane >> 4, l15 = lane & 15;
+    for (int j0 = 0; j0 < n; j0 += 4) {
+        const int pw = n - j0 < 4 ? n - j0 : 4;
+        for (int jj = 0; jj < pw; ++jj) {
+            const int j = j0 + jj;
+            const double dd = A[j * n + j];
+            if (!(dd > 0.0)) ok = false;
+            const double inv = 1.0 / sqrt(dd);
+            SC_SYNC();
+            for (int i = j + lane; i < n; i += 64) A[i * n + j] = (i == j) ? dd * inv : A[i * n + j] * inv;
+            SC_SYNC();
+            // the remaining panel columns c = j+1 .. j0+pw-1, rows i >= c
+            for (int e = lane; e < (n - j - 1) * (pw - jj - 1); e += 64) {
+                const int c = j + 1 + e / (n - j - 1), i = j + 1 + e % (n - j - 1);
+                if (i >= c) A[i * n + c] -= A[i * n + j] * A[c * n + j];
+            }
+            SC_SYNC();
+            if (!ok) return false;                                         // uniform: every lane read the same pivot
+        }
+        const int t0 = j0 + pw;                                            // trailing matrix starts here
+        if (t0 >= n) break;
+        const int ntile = (n - t0 + 15) >> 4;
+        for (int ti = 0; ti < ntile; ++ti) {
+            for (int tj = 0; tj <= ti; ++tj) {
+                const int ra = t0 + 16 * ti + l15, rb = t0 + 16 * tj + l15;
+                const double a = (ra < n && q < pw) ? A[ra * n + j0 + q] : 0.0;
+                const double b = (rb < n && q < pw) ? A[rb * n + j0 + q] : 0.0;
+                lin_c4 acc = {0.0, 0.0, 0.0, 0.0};
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = t0 + 16 * ti + q + 4 * r, col = t0 + 16 * tj + l15;
+                    if (row < n && col <= row) A[row * n + col] -= acc[r];
+                }
+            }
         }
         SC_SYNC();
-        if (!ok) break;
     }
     return ok;
 }
@@ -289,34 +322,38 @@ __device__ __noinline__ bool lin_chol_reg(const double* M, const double* rhs, do
 // a symmetric Phi), and a row tile skips the stages whose points cannot depend on any of its columns (b_k depends on
 // u_0..u_k): 28 MFMAs instead of 90 for n = 40.  `box` holds sig_hi + sig_lo per column.
 typedef double lin_d4 __attribute__((ext_vector_type(4)));
+// NT, NU > 0: compile-time horizon and input count (all operands of a tile are loaded first, then its MFMAs issue back to
+// back); NT == 0: run-time sizes, operands in chunks of 4 stages.
 template <int NT, int NU>
-__device__ __forceinline__ void lin_condense_mfma(const LinMem& W, double sf, const double* Hc, const double* G, const double* box,
-                                                  int lane) {
-    constexpr int n = NT * NU, nt = (n + 15) / 16;
+__device__ __forceinline__ void lin_condense_mfma(const LinMem& W, const int N_rt, const int nu_rt, double sf, const double* Hc,
+                                                  const double* G, const double* box, int lane) {
+    const int N = NT > 0 ? NT : N_rt, nu = NT > 0 ? NU : nu_rt, n = N * nu, nt = (n + 15) / 16;
+    constexpr int S = NT > 0 ? NT : 4;
     const int q = lane >> 4, l15 = lane & 15;
-#pragma unroll
     for (int ti = 0; ti < nt; ++ti) {
         const int ia = 16 * ti + l15;
         const bool okA = ia < n;
         const int iac = okA ? ia : 0;
-        const int k_lo = (16 * ti) / NU;
-#pragma unroll
+        const int k_lo = (16 * ti) / nu;
         for (int tj = 0; tj <= ti; ++tj) {
             const int jb = 16 * tj + l15;
             const bool okB = jb < n;
             const int jbc = okB ? jb : 0;
-            double a[NT], b[NT];
-#pragma unroll
-            for (int k = 0; k < NT; ++k) {
-                const int gr = q < 2 ? 2 * k + q : 2 * NT + 2 * k + q - 2;
-                const double av = G[(size_t)gr * n + iac], bv = W.T[(size_t)(4 * k + q) * n + jbc];
-                a[k] = okA ? av : 0.0;
-                b[k] = okB ? bv : 0.0;
-            }
             lin_d4 acc = {0.0, 0.0, 0.0, 0.0};
+            for (int k0 = NT > 0 ? 0 : k_lo; k0 < N; k0 += S) {
+                double a[S], b[S];
 #pragma unroll
-            for (int k = 0; k < NT; ++k)
-                if (k >= k_lo) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k], b[k], acc, 0, 0, 0);
+                for (int t = 0; t < S; ++t) {
+                    const int k = k0 + t < N ? k0 + t : N - 1;
+                    const int gr = q < 2 ? 2 * k + q : 2 * N + 2 * k + q - 2;
+                    const double av = G[(size_t)gr * n + iac], bv = W.T[(size_t)(4 * k + q) * n + jbc];
+                    a[t] = okA ? av : 0.0;
+                    b[t] = okB ? bv : 0.0;
+                }
+#pragma unroll
+                for (int t = 0; t < S; ++t)
+                    if (k0 + t >= k_lo && k0 + t < N) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[t], acc, 0, 0, 0);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * ti + q + 4 * r, col = 16 * tj + l15;
@@ -336,9 +373,10 @@ __device__ __forceinline__ void lin_condense_mfma(const LinMem& W, double sf, co
 #define LP(i) do { } while (0)
 #endif
 
-// NX, NU, NT, KT > 0: states, inputs, horizon, obstacle rows are compile-time constants (inner loops unroll and their LDS
-// loads are issued back to back; with run-time bounds every multiply-add waits a full LDS round trip); 0: run-time sizes.
-template <int NX, int NU, int NT, int KT>
+// NX, NU > 0: states and inputs are compile-time constants (the short matrix-vector loops unroll and their LDS loads are
+// issued back to back; with run-time bounds every multiply-add waits a full LDS round trip); NT > 0 (needs NX > 0): the
+// horizon too -- register Cholesky, lean LDS layout; KT > 0: obstacle rows.  0: run-time size.
+template <int NX, int NU, int NT, int KT, bool BIG = false>
 __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, const long long B,
                                                     const int K_rt, const void* __restrict__ X, const void* __restrict__ u_prev,
                                                     const void* __restrict__ goal, const void* __restrict__ obs,
@@ -352,14 +390,14 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
     auto ld = [io32](const void* a, size_t i) { return io32 ? (double)((const float*)a)[i] : ((const double*)a)[i]; };
     auto st = [io32](void* a, size_t i, double v) { if (io32) ((float*)a)[i] = (float)v; else ((double*)a)[i] = v; };
 
-    constexpr int NN = NX > 0 ? NT * NU : 0;                      // order of the condensed system when known at compile time
+    constexpr int NN = NT > 0 ? NT * NU : 0;                      // order of the condensed system when known at compile time
     LinDims d;
-    d.N = NX > 0 ? NT : p.horizon; d.K = KT > 0 ? KT : K_rt; d.nx = NX > 0 ? NX : p.nx; d.nu = NX > 0 ? NU : p.nu;
+    d.N = NT > 0 ? NT : p.horizon; d.K = KT > 0 ? KT : K_rt; d.nx = NX > 0 ? NX : p.nx; d.nu = NX > 0 ? NU : p.nu;
     d.n = d.N * d.nu; d.mc = d.N * d.K; d.m = d.mc + 2 * d.n;
     const int K = d.K;
     const int N = d.N, nx = d.nx, nu = d.nu, n = d.n, m = d.m;
-    constexpr bool LEAN = NX > 0;
-    const LinMem W = carve_lin(sm, d, LEAN);
+    constexpr bool LEAN = NT > 0;
+    const LinMem W = carve_lin(sm, d, LEAN ? LIN_LEAN : (BIG ? LIN_BIG : LIN_STD));
     LinConst c;
     c.w0 = -(1.0 - p.alpha); c.Rrob = p.robot_radius; c.beta = p.beta; c.circles_only = p.circles_only;
     if (lane < 12) W.cq[lane] = p.Q[lane];
@@ -373,8 +411,10 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         for (int e = lane; e < n * n; e += 64) W.Hc[e] = Hcg[e];
     }
     const double* Hc = LEAN ? W.Hc : Hcg;
-    for (int e = lane; e < 4 * N * n; e += 64) W.G[e] = Gg[e];
-    const double* G = W.G;
+    if constexpr (!BIG) {
+        for (int e = lane; e < 4 * N * n; e += 64) W.G[e] = Gg[e];
+    }
+    const double* G = BIG ? Gg : W.G;
     for (int i = lane; i < nx; i += 64) { W.xs[i] = ld(X, prob * nx + i); W.xg[i] = i < p.ng ? ld(goal, prob * p.ng + i) : 0.0; }
     for (int i = lane; i < nu; i += 64) W.up[i] = ld(u_prev, prob * nu + i);
     const size_t obase = p.obs_shared ? 0 : (size_t)prob * K * 7;
@@ -502,33 +542,10 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
             W.T[e] = acc;
         }
         SC_SYNC();
-        if constexpr (LEAN) {
-            for (int i = lane; i < n; i += 64)                               // r_d is consumed: its space holds the box terms
-                W.rd[i] = W.lam[d.mc + i] / W.s[d.mc + i] + W.lam[d.mc + n + i] / W.s[d.mc + n + i];
-            SC_SYNC();
-            lin_condense_mfma<NT, NU>(W, sf, Hc, G, W.rd, lane);
-        } else {
-            for (int e = lane; e < n * (n + 1) / 2; e += 64) {               // lower triangle, mirrored
-                int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-                while ((i + 1) * (i + 2) / 2 <= e) ++i;
-                while (i * (i + 1) / 2 > e) --i;
-                const int j = e - i * (i + 1) / 2;
-                double acc = sf * Hc[(size_t)i * n + j];
-                // every stage, branch-free: G[.][i] is zero for the stages that cannot reach column i (b_k depends on
-                // u_0..u_k, a_k on u_0..u_{k-1}); skipping them per lane would serialise the LDS loads behind branches
-    #pragma unroll
-                for (int k = 0; k < N; ++k) {
-    #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int gr = r < 2 ? 2 * k + r : 2 * N + 2 * k + r - 2;
-                        acc += G[(size_t)gr * n + i] * W.T[(size_t)(4 * k + r) * n + j];
-                    }
-                }
-                if (i == j) acc += W.lam[d.mc + i] / W.s[d.mc + i] + W.lam[d.mc + n + i] / W.s[d.mc + n + i];
-                W.M[(size_t)i * n + j] = acc;
-                W.M[(size_t)j * n + i] = acc;
-            }
-        }
+        for (int i = lane; i < n; i += 64)                                   // r_d is consumed: its space holds the box terms
+            W.rd[i] = W.lam[d.mc + i] / W.s[d.mc + i] + W.lam[d.mc + n + i] / W.s[d.mc + n + i];
+        SC_SYNC();
+        lin_condense_mfma<NT, NU>(W, N, nu, sf, Hc, G, W.rd, lane);
         SC_SYNC();
         LP(6);
         // inertia correction: M + delta I until the Cholesky succeeds
@@ -555,7 +572,7 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         // point displacements  G dz, then ds = J dz + r_p, dlam, step lengths
         for (int r = lane; r < 4 * N; r += 64) {
             double acc = 0.0;
-#pragma unroll
+#pragma unroll 8
             for (int i = 0; i < n; ++i) acc += G[(size_t)r * n + i] * W.dz[i];
             W.pdz[r] = acc;
         }
@@ -565,7 +582,7 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         for (int i = lane; i < n; i += 64) {
             gdz += W.gs[i] * W.dz[i];
             double q = 0.0;
-#pragma unroll
+#pragma unroll 8
             for (int j = 0; j < n; ++j) q += Hc[(size_t)j * n + i] * W.dz[j];
             curv += q * W.dz[i];
         }
@@ -657,8 +674,18 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
 
 }  // namespace
 
-static bool mpclin_is_lean(int N, int nx, int nu) { return N == 10 && ((nx == 12 && nu == 4) || (nx == 2 && nu == 2)); }
-size_t mpclin_lds_bytes(int N, int K, int nx, int nu) { return mpclin_lds_doubles(N, K, nx, nu, mpclin_is_lean(N, nx, nu)) * sizeof(double); }
+// the compile-time instantiations: both models at the reference's default horizon 10 (mpc_cbf.py:15), and the other
+// horizons whose order n = N nu still fits the register Cholesky (n <= 64): SingleIntegrator2D N = 20, Quad3D N = 16
+static bool mpclin_is_lean(int N, int nx, int nu) {
+    if (nx == 12 && nu == 4) return N == 10 || N == 16;
+    if (nx == 2 && nu == 2) return N == 10 || N == 20;
+    return false;
+}
+static int mpclin_mode(int N, int K, int nx, int nu) {
+    if (mpclin_is_lean(N, nx, nu) && mpclin_lds_doubles(N, K, nx, nu, LIN_LEAN) * sizeof(double) <= 160 * 1024) return LIN_LEAN;
+    return mpclin_lds_doubles(N, K, nx, nu, LIN_STD) * sizeof(double) > 160 * 1024 ? LIN_BIG : LIN_STD;
+}
+size_t mpclin_lds_bytes(int N, int K, int nx, int nu) { return mpclin_lds_doubles(N, K, nx, nu, mpclin_mode(N, K, nx, nu)) * sizeof(double); }
 
 // Host: constant matrices of the condensed problem from (Ae, Be, As, Bs, Q, R, N); layout of the blob as the kernel reads it
 size_t mpclin_model_doubles(int nx, int nu, int N) {
@@ -738,11 +765,19 @@ hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long lo
                            iters, z_out);
         return hipGetLastError();
     };
-    if (p.horizon == 10 && p.nx == 12 && p.nu == 4)               // Quad3D at the reference's default horizon
-        return K == 8 ? launch(mpclin_kernel<12, 4, 10, 8>) : launch(mpclin_kernel<12, 4, 10, 0>);
-    if (p.horizon == 10 && p.nx == 2 && p.nu == 2)                // SingleIntegrator2D
-        return K == 8 ? launch(mpclin_kernel<2, 2, 10, 8>) : launch(mpclin_kernel<2, 2, 10, 0>);
-    return launch(mpclin_kernel<0, 0, 0, 0>);
+    const int mode = mpclin_mode(p.horizon, K, p.nx, p.nu);
+    if (mode == LIN_LEAN) {
+        if (p.horizon == 10 && p.nx == 12)                            // Quad3D at the reference's default horizon
+            return K == 8 ? launch(mpclin_kernel<12, 4, 10, 8>) : launch(mpclin_kernel<12, 4, 10, 0>);
+        if (p.horizon == 10 && p.nx == 2)                             // SingleIntegrator2D
+            return K == 8 ? launch(mpclin_kernel<2, 2, 10, 8>) : launch(mpclin_kernel<2, 2, 10, 0>);
+        if (p.horizon == 20 && p.nx == 2) return launch(mpclin_kernel<2, 2, 20, 0>);
+        if (p.horizon == 16 && p.nx == 12) return launch(mpclin_kernel<12, 4, 16, 0>);
+    }
+    const bool big = mode == LIN_BIG;
+    if (p.nx == 12 && p.nu == 4) return big ? launch(mpclin_kernel<12, 4, 0, 0, true>) : launch(mpclin_kernel<12, 4, 0, 0>);
+    if (p.nx == 2 && p.nu == 2) return big ? launch(mpclin_kernel<2, 2, 0, 0, true>) : launch(mpclin_kernel<2, 2, 0, 0>);
+    return big ? launch(mpclin_kernel<0, 0, 0, 0, true>) : launch(mpclin_kernel<0, 0, 0, 0>);
 }
 
 }  // namespace sc

@@ -39,7 +39,7 @@ def build_model_blob(lib, p, mdl):
     """Constant matrices of the condensed problem (host, float64): sc_mpclin_build_model."""
     nd = lib.sc_mpclin_model_doubles(p.nx, p.nu, p.horizon)
     if nd == 0:
-        raise ValueError("unsupported dimensions: need nx <= 12, nu <= 4, nu * horizon <= 64")
+        raise ValueError("unsupported dimensions: need nx <= 12, nu <= 4, nu * horizon <= 128")
     blob = np.zeros(nd, dtype=np.float64)
     mats = [np.ascontiguousarray(mdl[k], dtype=np.float64) for k in ("Ae", "Be", "As", "Bs")]
     rc = lib.sc_mpclin_build_model(C.byref(p), *[m.ctypes.data for m in mats], blob.ctypes.data)

@@ -45,7 +45,7 @@ def batch(name, B, K, seed):
 
 
 @pytest.mark.parametrize("name,N,K", [("SingleIntegrator2D", 10, 8), ("Quad3D", 10, 8), ("SingleIntegrator2D", 5, 3),
-                                      ("Quad3D", 6, 2), ("Quad3D", 16, 4)])
+                                      ("Quad3D", 6, 2), ("Quad3D", 16, 4), ("Quad3D", 20, 8), ("SingleIntegrator2D", 20, 4)])
 def test_batch_matches_oracle(name, N, K):
     B = 24
     mdl, X, G, O = batch(name, B, K, seed=N * 10 + K)
@@ -130,6 +130,6 @@ def test_drop_in_class_and_bad_arguments():
     with pytest.raises(ValueError):
         ctl.solve(t(np.zeros((2, 4))), t(np.zeros((2, 4))), t(np.zeros((2, 3))), t(np.zeros((2, 1, 7))))
     with pytest.raises(ValueError):
-        sca.BatchedLinearMPCCBF({"model": "Quad3D"}, horizon=17)              # nu * horizon > 64
+        sca.BatchedLinearMPCCBF({"model": "Quad3D"}, horizon=33)              # nu * horizon > 128
     with pytest.raises(NotImplementedError):
         sca.BatchedLinearMPCCBF({"model": "DynamicUnicycle2D"})

@@ -127,4 +127,4 @@ def test_library_host_side_condensed_matrices_match_oracle():
             off = nx * nx + nx * nu + 2 * nx + 2 * nu
             np.testing.assert_allclose(blob[off:off + n * n].reshape(n, n), Hc, rtol=1e-13, atol=1e-12)
             np.testing.assert_allclose(blob[off + n * n:].reshape(4 * N, n), G, rtol=0, atol=1e-15)
-    assert lib.sc_mpclin_model_doubles(12, 4, 17) == 0            # nu * horizon > 64
+    assert lib.sc_mpclin_model_doubles(12, 4, 33) == 0            # nu * horizon > 128
