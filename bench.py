@@ -44,10 +44,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--workload", choices=["cbf_qp", "mpc_cbf", "kb_c3bf"], default="cbf_qp",
+    ap.add_argument("--workload", choices=["cbf_qp", "mpc_cbf", "kb_c3bf", "hetero_fleet"], default="cbf_qp",
                     help="cbf_qp = BASELINE configs[1] (default, the headline metric); mpc_cbf = configs[2]; "
                          "kb_c3bf = configs[3]: 16384 KinematicBicycle2D C3BF agents in total (strong scaling), each "
-                         "taking its 16 nearest other agents as moving obstacles after an all-gather of the states")
+                         "taking its 16 nearest other agents as moving obstacles after an all-gather of the states; "
+                         "hetero_fleet = configs[4] as far as the reference defines it: a 65536-agent fleet, half Unicycle2D "
+                         "and half Quad3D, MPC-CBF with horizon 20 and 8 obstacles each, sharded over the ranks (strong "
+                         "scaling), the two model kernels on two HIP streams")
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--no-mpc", action="store_true", help="skip the short MPC-CBF leg of the default run")
     return ap.parse_args()
@@ -338,6 +341,11 @@ def main():
         if ws > 1:
             dist.destroy_process_group()
         return
+    if a.workload == "hetero_fleet":
+        hetero_fleet_workload(a, dev, ws, rank, backend)
+        if ws > 1:
+            dist.destroy_process_group()
+        return
     if a.workload == "kb_c3bf":
         kb_c3bf_workload(a, dev, ws, rank, backend)
         if ws > 1:
@@ -442,6 +450,75 @@ def main():
         print(json.dumps(res), flush=True)
     if ws > 1:
         dist.destroy_process_group()
+
+
+def hetero_fleet_workload(a, dev, ws, rank, backend):
+    """BASELINE configs[4] (extension): a heterogeneous fleet of 65536 agents (or --agents per GPU x ranks when given),
+    half kinematic Unicycle2D and half Quad3D, every agent solving an MPC-CBF with horizon 20 and 8 circular obstacles.
+    The reference's OptimalDecayMPCCBF accepts neither model (optimal_decay_mpc_cbf.py:19-20) and neither model's barrier
+    has a superellipsoid branch (unicycle2D.py:127-145, quad3D.py:283-291), so this is the plain MPCCBF of both models on
+    circles.  Agents are independent: contiguous shards per rank, no collective; the two model kernels run on two HIP
+    streams of the same GPU."""
+    import torch
+    import torch.distributed as dist
+    import safe_control_amd as sca
+    from safe_control_amd import sharding, workloads as W
+    n_total = 65536 if a.agents == 4096 else a.agents * ws
+    N, K = 20, 8
+    lo, hi = sharding.agent_range(n_total // 2, ws, rank)             # the same range of each half
+    Bl = hi - lo
+    uni = sca.BatchedMPCCBF({"model": "Unicycle2D", "v_max": 1.0, "w_max": 0.5, "radius": 0.25}, io_dtype="f32", horizon=N)
+    quad = sca.BatchedLinearMPCCBF({"model": "Quad3D"}, io_dtype="f32", horizon=N)
+    Xu, gu, _, ou = W.du_cbfqp_batch(n_total // 2, K, seed=0)
+    Xq, gq, oq = W.linear_mpc_batch("Quad3D", n_total // 2, K, seed=1)
+    t = lambda arr: torch.tensor(arr[lo:hi], dtype=torch.float32, device=dev)
+    tXu, tgu, tou = t(Xu), t(gu), t(ou)
+    tXq, tgq, toq = t(Xq), t(gq), t(oq)
+    upu = torch.zeros((Bl, 2), dtype=torch.float32, device=dev)
+    upq = torch.zeros((Bl, 4), dtype=torch.float32, device=dev)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    res = {}
+
+    def step():
+        with torch.cuda.stream(s1):
+            res["u"] = uni.solve(tXu, upu, tgu, tou)
+        with torch.cuda.stream(s2):
+            res["q"] = quad.solve(tXq, upq, tgq, toq)
+
+    torch.cuda.synchronize()
+    steps, warm = min(a.steps, 5), min(max(a.warmup, 1), 2)           # a step is 2 x Bl NLPs: seconds, not microseconds
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    if ws > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if ws > 1:
+        dist.barrier()
+    elapsed = sharding.max_over_ranks(t1 - t0, device=dev if backend == "nccl" else None)
+    if rank == 0:
+        su, sq = res["u"][1], res["q"][1]
+        nbytes = ((16 + 8 + 8 + 7 * K * 4 + 8 + 4 + 4) + (48 + 16 + 12 + 7 * K * 4 + 16 + 4 + 4)) * (n_total // 2)
+        print(json.dumps({"metric": "QP solves/sec (batched agents)", "value": n_total * steps / elapsed, "unit": "solves/s",
+                          "n_gpus": ws, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * elapsed / steps,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": f"{n_total}-agent heterogeneous fleet (Unicycle2D + Quad3D), MPC-CBF N=20, "
+                                                 "8 circular obstacles (BASELINE configs[4] as far as the reference defines it)",
+                                     "agents_total": n_total, "horizon": N, "obstacles": K, "storage": "f32",
+                                     "sharding": f"agents x{ws}, no collective; two model kernels on two streams",
+                                     "unicycle_optimal_fraction": float((su == 0).double().mean().item()),
+                                     "quad3d_optimal_fraction": float((sq == 0).double().mean().item()),
+                                     "unicycle_mean_iterations": float(res["u"][2].double().mean().item()),
+                                     "quad3d_mean_iterations": float(res["q"][2].double().mean().item())},
+                          "roofline": {"bound": "hbm", "achieved": nbytes * steps / elapsed / 1e9, "peak": HBM_PEAK_GBS * ws,
+                                       "unit": "GB/s", "frac": nbytes * steps / elapsed / 1e9 / (HBM_PEAK_GBS * ws), "traffic": None,
+                                       "kernel": "mpccbf_uni_kernel_rt + mpclin_kernel<12,4,0,0,big>",
+                                       "note": "interior-point solves: VALU / latency bound, HBM bytes are negligible"},
+                          "cpu_baseline": None}), flush=True)
 
 
 def kb_c3bf_workload(a, dev, ws, rank, backend):

@@ -45,3 +45,18 @@ def test_two_rank_flow_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     assert d["config"]["agents_per_gpu"] == 4096
     assert abs(d["value"] - 2 * 4096 * 20 / (d["ms_per_step"] * 20 / 1e3)) / d["value"] < 1e-6
+
+
+def test_two_rank_heterogeneous_fleet_flow():
+    """--workload hetero_fleet (BASELINE configs[4] as far as the reference defines it) on two ranks sharing the GPU:
+    512 agents per rank = 1024 in total, half Unicycle2D and half Quad3D, MPC-CBF N = 20."""
+    env = dict(os.environ, SC_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29519", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--workload", "hetero_fleet", "--agents", "512", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["agents_total"] == 1024
+    assert d["config"]["unicycle_optimal_fraction"] > 0.8 and d["config"]["quad3d_optimal_fraction"] > 0.5
+    assert d["value"] > 5e3
