@@ -339,6 +339,9 @@ int sc_neighbor_obstacles_batch_ws(int32_t io_dtype, int64_t B_all, int64_t firs
  * selection (:345-403), nominal input choice (:589-604; robots/<model>.py nominal_input / stop /
  * rotate_to), CBFQP.solve_control_problem, collision checks (:445-495, :627-646), robot.step (:637)
  * and the return code (:666-668).  Agent state stays in registers between steps.
+ * Models: DynamicUnicycle2D, Unicycle2D, the KinematicBicycle2D family, and SingleIntegrator2D / DoubleIntegrator2D with
+ * enable_rotation = 0 (their rotate state runs the attitude controllers, which are outside this library; without them the
+ * heading of an integrator never changes and only decides the first state-machine state, which the caller sets).
  */
 #define SC_SM_IDLE   0
 #define SC_SM_TRACK  1

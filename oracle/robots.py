@@ -205,8 +205,10 @@ def stop(model, X, spec):
 
 def has_stopped(model, X, tol=0.05):
     """DU :113-114 ; KB :152-153 ; Unicycle2D unicycle2D.py:90-92 (always)."""
-    if model == MODEL_UNI:
+    if model in (MODEL_UNI, MODEL_SI):                     # single_integrator2D.py:105-107: always
         return True
+    if model == MODEL_DI:                                  # double_integrator2D.py:158-159: |(vx, vy)| < tol
+        return math.hypot(X[2], X[3]) < tol
     return abs(X[3]) < tol
 
 

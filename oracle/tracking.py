@@ -62,8 +62,14 @@ class TrackingOracle:
     """Single-agent closed loop with the oracle solver behind the boundary."""
 
     def __init__(self, model, X0, spec, dt=0.05, obs=None, num_constraints=10,
-                 enable_rotation=True, dyn_obs=False, solve_fn=None, cbf_param=None):
+                 enable_rotation=True, dyn_obs=False, solve_fn=None, cbf_param=None, yaw0=None):
         self.model = model
+        # the integrators keep their heading outside the state (robots/robot.py:66-72: X0 = [x, y, (vx, vy,) yaw]); without
+        # an attitude controller it stays at its initial value
+        self.integrator = model in (R.MODEL_SI, R.MODEL_DI)
+        if self.integrator and enable_rotation:
+            raise ValueError("the integrators' rotate state needs the attitude controllers (out of scope)")
+        self.yaw = float(yaw0) if yaw0 is not None else 0.0
         self.spec = dict(R.default_spec(model))
         self.spec.update(spec)
         self.spec.setdefault("exploration", False)
@@ -101,7 +107,8 @@ class TrackingOracle:
         self.goal = self.update_goal()
         if self.goal is not None:                        # tracking.py:214-226
             ang = math.atan2(self.goal[1] - self.X[1], self.goal[0] - self.X[0])
-            in_fov = abs(R.angle_normalize(ang - self.X[2])) <= self.fov_angle / 2   # robot.py:854-872
+            yaw = self.yaw if self.integrator else self.X[2]
+            in_fov = abs(R.angle_normalize(ang - yaw)) <= self.fov_angle / 2   # robot.py:854-872
             if not in_fov:
                 if self.spec["exploration"]:
                     self.state_machine = "rotate"
@@ -143,7 +150,7 @@ class TrackingOracle:
             self.goal = self.update_goal()
 
         self.nearest_multi_obs = get_nearest_unpassed_obs(
-            m, self.obs, self.X[:2], self.X[2], self.num_constraints)
+            m, self.obs, self.X[:2], self.yaw if self.integrator else self.X[2], self.num_constraints)
         if self.dyn_obs and len(self.obs) and self.obs.shape[1] >= 5:   # main.py:54-58 (after selection)
             self.obs[:, 0] += self.obs[:, 3] * self.dt
             self.obs[:, 1] += self.obs[:, 4] * self.dt

@@ -19,7 +19,7 @@ template <> struct tvec2<double> { using type = double2; };
 
 template <typename T>
 struct TrackConsts {
-    T reached, rot_thr, v_max, v_min, k_omega, k_a, k_v, delta_max, wheel_base, Lr, dt;
+    T reached, rot_thr, v_max, v_min, k_omega, k_a, k_v, delta_max, wheel_base, Lr, dt, a_max;
     int enable_rotation, dyn_obs, K;
 };
 
@@ -28,6 +28,22 @@ struct TrackConsts {
 template <typename T, int MODEL>
 __device__ __forceinline__ void nominal_input(const T x, const T y, const T th, const T v, const T gx, const T gy,
                                               const TrackConsts<T>& t, T& u0, T& u1) {
+    if constexpr (MODEL == SC_MODEL_SINGLE_INTEGRATOR2D || MODEL == SC_MODEL_DOUBLE_INTEGRATOR2D) {
+        // single_integrator2D.py:72-90 / double_integrator2D.py:113-140 (th, v carry vx, vy for the double integrator):
+        // dead-banded position error -> desired velocity, saturated in norm; DI: acceleration towards it, saturated in norm
+        const T ex = gx - x, ey = gy - y;
+        T vx = t.k_v * copysign(fmax_(fabs_(ex) - T(0.05), T(0)), ex), vy = t.k_v * copysign(fmax_(fabs_(ey) - T(0.05), T(0)), ey);
+        const T vm = sqrt_(vx * vx + vy * vy);
+        if (vm > t.v_max) { vx = vx * t.v_max / vm; vy = vy * t.v_max / vm; }
+        if constexpr (MODEL == SC_MODEL_SINGLE_INTEGRATOR2D) { u0 = vx; u1 = vy; }
+        else {
+            T ax = t.k_a * (vx - th), ay = t.k_a * (vy - v);
+            const T am = sqrt_(ax * ax + ay * ay);
+            if (am > t.a_max) { ax = ax * t.a_max / am; ay = ay * t.a_max / am; }
+            u0 = ax; u1 = ay;
+        }
+        return;
+    }
     const T pi = T(3.14159265358979323846);
     const T dx = x - gx, dy = y - gy;
     const T dist = sqrt_(dx * dx + dy * dy);
@@ -57,14 +73,18 @@ __device__ __forceinline__ void nominal_input(const T x, const T y, const T th, 
 
 // stop(): DU brakes with k_a (dynamic_unicycle2D.py:106-111); KB and Unicycle2D return zeros (kinematic_bicycle2D.py:149-150,
 // unicycle2D.py:87-88)
+// SingleIntegrator2D: zeros (single_integrator2D.py:100-103); DoubleIntegrator2D brakes both components
+// (double_integrator2D.py:149-156; th, v carry vx, vy)
 template <typename T, int MODEL>
-__device__ __forceinline__ T stop_input0(const T v, const T k_a) {
-    return (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? k_a * (T(0) - v) : T(0);
+__device__ __forceinline__ void stop_input(const T th, const T v, const T k_a, T& u0, T& u1) {
+    if constexpr (MODEL == SC_MODEL_DOUBLE_INTEGRATOR2D) { u0 = k_a * (T(0) - th); u1 = k_a * (T(0) - v); }
+    else { u0 = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? k_a * (T(0) - v) : T(0); u1 = T(0); }
 }
 // has_stopped(): |v| < .05 (DU :113-114, KB :152-153); the kinematic unicycle always has (unicycle2D.py:90-92)
 template <typename T, int MODEL>
-__device__ __forceinline__ bool has_stopped(const T v) {
-    if constexpr (MODEL == SC_MODEL_UNICYCLE2D) return true;
+__device__ __forceinline__ bool has_stopped(const T th, const T v) {
+    if constexpr (MODEL == SC_MODEL_UNICYCLE2D || MODEL == SC_MODEL_SINGLE_INTEGRATOR2D) return true;
+    else if constexpr (MODEL == SC_MODEL_DOUBLE_INTEGRATOR2D) return sqrt_(th * th + v * v) < T(0.05);   // |(vx, vy)|
     else return fabs_(v) < T(0.05);
 }
 // step(): X + (f + g u) dt, heading wrapped (DU :75-78 ; KB :113-123, speed clipped ; Unicycle2D unicycle2D.py:64-67,
@@ -72,7 +92,16 @@ __device__ __forceinline__ bool has_stopped(const T v) {
 template <typename T, int MODEL>
 __device__ __forceinline__ void robot_step(const Agent<T>& a, const T u0, const T u1, const T dt, const T Lr, const T v_min,
                                            const T v_max, T& nx, T& ny, T& nth, T& nv) {
-    if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) {
+    if constexpr (MODEL == SC_MODEL_SINGLE_INTEGRATOR2D) {               // single_integrator2D.py:64-66; columns 2, 3 are padding
+        nx = a.x + (T(0) + u0) * dt; ny = a.y + (T(0) + u1) * dt; nth = a.th; nv = a.v;
+        return;
+    } else if constexpr (MODEL == SC_MODEL_DOUBLE_INTEGRATOR2D) {        // double_integrator2D.py:79-107: speed rescaled to v_max
+        nx = a.x + (a.f0 + T(0)) * dt; ny = a.y + (a.f1 + T(0)) * dt;
+        nth = a.f0 + (T(0) + u0) * dt; nv = a.f1 + (T(0) + u1) * dt;
+        const T vm = sqrt_(nth * nth + nv * nv);
+        if (vm > v_max) { const T sc = v_max / vm; nth *= sc; nv *= sc; }
+        return;
+    } else if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) {
         nx = a.x + (a.f0) * dt; ny = a.y + (a.f1) * dt;
         nth = a.th + (T(0) + u1) * dt; nv = a.v + (T(0) + u0) * dt;
     } else if constexpr (MODEL == SC_MODEL_UNICYCLE2D) {
@@ -132,7 +161,7 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
     t.reached = TC(p.reached_threshold); t.rot_thr = TC(p.rotation_threshold);
     t.v_max = TC(p.v_max); t.v_min = TC(p.v_min);
     t.k_omega = TC(p.k_omega); t.k_a = TC(p.k_a); t.k_v = TC(p.k_v);
-    t.delta_max = TC(p.delta_max); t.wheel_base = TC(p.wheel_base); t.Lr = TC(p.qp.rear_ax_dist); t.dt = TC(p.qp.dt);
+    t.delta_max = TC(p.delta_max); t.wheel_base = TC(p.wheel_base); t.Lr = TC(p.qp.rear_ax_dist); t.dt = TC(p.qp.dt); t.a_max = TC(p.qp.u_max[0]);
     t.enable_rotation = p.enable_rotation; t.dyn_obs = p.dyn_obs; t.K = p.num_constraints;
     const TC pi = TC(3.14159265358979323846);
     const TC half_unpassed = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? TC(1.2) * pi / TC(2) : pi;   // tracking.py:352-357
@@ -178,7 +207,7 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
         if (run) {
             // ---- state machine / goal (tracking.py:569-577) ----------------------------------
             if (sm == SC_SM_STOP) {
-                if (has_stopped<TC, MODEL>(v)) {
+                if (has_stopped<TC, MODEL>(th, v)) {
                     sm = t.enable_rotation ? SC_SM_ROTATE : SC_SM_TRACK;
                     update_goal();
                 }
@@ -215,7 +244,7 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
             }
         }
         // ---- rows in registers (selection order = distance order, as the reference passes them) ---
-        const Agent<TC> agn = make_agent<TC>(x, y, th, v);
+        const Agent<TC> agn = make_agent_m<TC, MODEL>(x, y, th, v);
         TC n0[KMAX], n1[KMAX], c[KMAX];
         bool bad_obs = false;
         TC poison = TC(0);
@@ -248,8 +277,7 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
             const TC ga = atan2_(gy - y, gx - x);
             ur0 = TC(0); ur1 = TC(2) * angle_normalize(ga - th);           // rotate_to, k = 2
         } else if (!gvalid) {
-            ur0 = stop_input0<TC, MODEL>(v, t.k_a);                          // stop()
-            ur1 = TC(0);
+            stop_input<TC, MODEL>(th, v, t.k_a, ur0, ur1);                  // stop()
         } else {
             nominal_input<TC, MODEL>(x, y, th, v, gx, gy, t, ur0, ur1);
         }
@@ -321,7 +349,7 @@ __global__ __launch_bounds__(64) void tracking_select_kernel(
     t.reached = TC(p.reached_threshold); t.rot_thr = TC(p.rotation_threshold);
     t.v_max = TC(p.v_max); t.v_min = TC(p.v_min);
     t.k_omega = TC(p.k_omega); t.k_a = TC(p.k_a); t.k_v = TC(p.k_v);
-    t.delta_max = TC(p.delta_max); t.wheel_base = TC(p.wheel_base); t.Lr = TC(p.qp.rear_ax_dist); t.dt = TC(p.qp.dt);
+    t.delta_max = TC(p.delta_max); t.wheel_base = TC(p.wheel_base); t.Lr = TC(p.qp.rear_ax_dist); t.dt = TC(p.qp.dt); t.a_max = TC(p.qp.u_max[0]);
     t.enable_rotation = p.enable_rotation; t.dyn_obs = 0; t.K = p.num_constraints;
     const TC pi = TC(3.14159265358979323846);
     const TC half_unpassed = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? TC(1.2) * pi / TC(2) : pi;
@@ -357,7 +385,7 @@ __global__ __launch_bounds__(64) void tracking_select_kernel(
     };
     if (run) {
         if (sm == SC_SM_STOP) {
-            if (has_stopped<TC, MODEL>(v)) {
+            if (has_stopped<TC, MODEL>(th, v)) {
                 sm = t.enable_rotation ? SC_SM_ROTATE : SC_SM_TRACK;
                 update_goal();
             }
@@ -398,8 +426,7 @@ __global__ __launch_bounds__(64) void tracking_select_kernel(
         const TC ga = atan2_(gy - y, gx - x);
         ur0 = TC(0); ur1 = TC(2) * angle_normalize(ga - th);
     } else if (!gvalid) {
-        ur0 = stop_input0<TC, MODEL>(v, t.k_a);
-        ur1 = TC(0);
+        stop_input<TC, MODEL>(th, v, t.k_a, ur0, ur1);
     } else {
         nominal_input<TC, MODEL>(x, y, th, v, gx, gy, t, ur0, ur1);
     }
@@ -444,7 +471,7 @@ __global__ __launch_bounds__(64) void tracking_apply_kernel(
     const TC u0 = TC(u[ag * 2 + 0]), u1 = TC(u[ag * 2 + 1]);
     const int st = u_status ? u_status[ag] : SC_STATUS_OPTIMAL;
     const bool run = active && ret_out[ag] == 0;
-    const Agent<TC> agn = make_agent<TC>(x, y, th, v);
+    const Agent<TC> agn = make_agent_m<TC, MODEL>(x, y, th, v);
     const bool pre_fail = (st != SC_STATUS_OPTIMAL) || collides<TC>(x, y, table, M, k.R);
     TC nx, ny, nth, nv;
     robot_step<TC, MODEL>(agn, u0, u1, dt, Lr, TC(p.v_min), TC(p.v_max), nx, ny, nth, nv);
@@ -539,7 +566,7 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
     t.reached = TC(p.reached_threshold); t.rot_thr = TC(p.rotation_threshold);
     t.v_max = TC(p.v_max); t.v_min = TC(p.v_min);
     t.k_omega = TC(p.k_omega); t.k_a = TC(p.k_a); t.k_v = TC(p.k_v);
-    t.delta_max = TC(p.delta_max); t.wheel_base = TC(p.wheel_base); t.Lr = TC(p.qp.rear_ax_dist); t.dt = TC(p.qp.dt);
+    t.delta_max = TC(p.delta_max); t.wheel_base = TC(p.wheel_base); t.Lr = TC(p.qp.rear_ax_dist); t.dt = TC(p.qp.dt); t.a_max = TC(p.qp.u_max[0]);
     t.enable_rotation = p.enable_rotation; t.dyn_obs = p.dyn_obs; t.K = p.num_constraints;
     const TC pi = TC(3.14159265358979323846);
     const TC half_unpassed = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) ? TC(1.2) * pi / TC(2) : pi;   // tracking.py:352-357
@@ -592,7 +619,7 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
         const bool run = (ret == 0);
         if (run) {
             if (sm == SC_SM_STOP) {                                   // tracking.py:569-577
-                if (has_stopped<TC, MODEL>(v)) {
+                if (has_stopped<TC, MODEL>(th, v)) {
                     sm = t.enable_rotation ? SC_SM_ROTATE : SC_SM_TRACK;
                     update_goal();
                 }
@@ -641,7 +668,7 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
         __syncthreads();
         const int si = sel[lane];
         // ---- this lane's row -------------------------------------------------------------------------
-        const Agent<TC> agn = make_agent<TC>(x, y, th, v);
+        const Agent<TC> agn = make_agent_m<TC, MODEL>(x, y, th, v);
         const bool used = (sub < t.K) && (si >= 0);
         TC a0, a1, cc;
         TC poison = TC(0);
@@ -672,8 +699,7 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
             const TC ga = atan2_(gy - y, gx - x);
             ur0 = TC(0); ur1 = TC(2) * angle_normalize(ga - th);           // rotate_to, k = 2
         } else if (!gvalid) {
-            ur0 = stop_input0<TC, MODEL>(v, t.k_a);                          // stop()
-            ur1 = TC(0);
+            stop_input<TC, MODEL>(th, v, t.k_a, ur0, ur1);                  // stop()
         } else {
             nominal_input<TC, MODEL>(x, y, th, v, gx, gy, t, ur0, ur1);
         }
@@ -788,6 +814,10 @@ static hipError_t launch_track_m(const sc_tracking_params& p, long long B, int M
             return launch_track_k<TIO, TC, SC_MODEL_UNICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
         case SC_MODEL_KINEMATIC_BICYCLE2D_C3BF:
             return launch_track_k<TIO, TC, SC_MODEL_KINEMATIC_BICYCLE2D_C3BF>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+        case SC_MODEL_SINGLE_INTEGRATOR2D:
+            return launch_track_k<TIO, TC, SC_MODEL_SINGLE_INTEGRATOR2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+        case SC_MODEL_DOUBLE_INTEGRATOR2D:
+            return launch_track_k<TIO, TC, SC_MODEL_DOUBLE_INTEGRATOR2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
         default:
             return launch_track_k<TIO, TC, SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
     }

@@ -45,8 +45,13 @@ class BatchedTrackingController:
         self.robot_spec = complete_robot_spec(robot_spec)
         self.robot_spec.setdefault("exploration", False)
         self.model = self.robot_spec["model"]
-        if self.model not in _lib.MODEL_IDS:
+        if self.model not in _lib.MODEL_IDS or self.model == "Quad2D":
             raise ValueError(f"the batched closed loop does not support model {self.model!r}")
+        # the integrators keep their heading outside the state (robots/robot.py:66-72); their rotate state runs the
+        # attitude controllers, which are out of scope: enable_rotation must be off and the heading then never changes
+        self.integrator = self.model in ("SingleIntegrator2D", "DoubleIntegrator2D")
+        if self.integrator and (enable_rotation or controller_type.get("pos", "cbf_qp") != "cbf_qp"):
+            raise ValueError("SingleIntegrator2D / DoubleIntegrator2D run in the fused 'cbf_qp' loop with enable_rotation=False")
         self.dt = float(dt)
         self.enable_rotation = bool(enable_rotation)
         self.dyn_obs = bool(dyn_obs)
@@ -63,7 +68,12 @@ class BatchedTrackingController:
         X0 = np.asarray(X0, dtype=np.float64)
         if X0.ndim == 1:
             X0 = X0[None, :]
-        if X0.shape[1] == 3:                                   # tracking.py:66-68: initial speed 0
+        self.yaw = None
+        if self.integrator:                                    # robots/robot.py:66-72: X0 = [x, y, (vx, vy,) yaw]
+            nst = 2 if self.model == "SingleIntegrator2D" else 4
+            self.yaw = X0[:, nst].copy() if X0.shape[1] > nst else np.zeros(X0.shape[0])
+            X0 = np.hstack([X0[:, :nst], np.zeros((X0.shape[0], 4 - nst))])
+        elif X0.shape[1] == 3:                                 # tracking.py:66-68: initial speed 0
             X0 = np.hstack([X0, np.zeros((X0.shape[0], 1))])
         self.B = X0.shape[0]
         t = lambda a, dt_=None: torch.tensor(a, dtype=dt_ or self.tdtype, device=self.device)
@@ -137,7 +147,8 @@ class BatchedTrackingController:
                     g = w[idx[i]]
             if g is not None:                                   # tracking.py:214-226
                 ang = math.atan2(g[1] - X[i, 1], g[0] - X[i, 0])
-                in_fov = abs(_wrap(ang - X[i, 2])) <= self.fov_angle / 2
+                yaw = self.yaw[i] if self.integrator else X[i, 2]
+                in_fov = abs(_wrap(ang - yaw)) <= self.fov_angle / 2
                 if not in_fov:
                     if self.robot_spec["exploration"]:
                         sm[i] = _lib.SM_ROTATE
@@ -170,7 +181,11 @@ class BatchedTrackingController:
         p.rotation_threshold = self.rotation_threshold
         p.v_max = float(rs["v_max"])
         p.v_min = float(rs.get("v_min", 0.0))
-        if self.model == "DynamicUnicycle2D":                   # robots/dynamic_unicycle2D.py:84-86
+        if self.model == "DoubleIntegrator2D":                  # double_integrator2D.py:117-118, :151
+            p.k_omega = 2.0
+            p.k_a = float(rs.get("nominal_k_a", 1.0))
+            p.k_v = float(rs.get("nominal_k_v", 1.0))
+        elif self.model == "DynamicUnicycle2D":                 # robots/dynamic_unicycle2D.py:84-86
             p.k_omega = float(rs.get("nominal_k_omega", 2.0))
             p.k_a = float(rs.get("nominal_k_a", 1.0))
             p.k_v = float(rs.get("nominal_k_v", 1.0))

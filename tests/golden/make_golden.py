@@ -565,7 +565,46 @@ def gen_linear_models():
     np.savez_compressed(os.path.join(HERE, "linear_models.npz"), **out)
 
 
+def gen_closed_loop_integrators():
+    """examples/test_tracking.py scene with --model si / di --algo cbf_qp, enable_rotation=False (no attitude controller:
+    the yaw of the integrators stays at its initial value and only decides the first state machine state)."""
+    out = {}
+    known = np.array([[2.2, 5.0, 0.2], [3.0, 5.0, 0.2], [4.0, 9.0, 0.3], [1.5, 10.0, 0.5], [9.0, 11.0, 1.0],
+                      [7.0, 7.0, 3.0], [4.0, 3.5, 1.5], [10.0, 7.3, 0.4], [6.0, 13.0, 0.7], [5.0, 10.0, 0.6],
+                      [11.0, 5.0, 0.8], [13.5, 11.0, 0.6], [2.0, 7.0, 0.7], [2.0, 8.0, 0.5]])
+    known = np.hstack((known, np.zeros((known.shape[0], 4))))
+    wps = np.array([[2, 2, np.pi / 2], [2, 12, 0], [12, 12, 0], [12, 2, 0]], dtype=np.float64)
+    cases = [("si", "SingleIntegrator2D", {"v_max": 1.0}, wps[0].copy()),
+             ("di", "DoubleIntegrator2D", {"v_max": 1.0, "a_max": 1.0}, np.array([2.0, 2.0, 0.0, 0.0, np.pi / 2])),
+             ("di_back", "DoubleIntegrator2D", {"v_max": 1.0, "a_max": 1.0}, np.array([2.0, 2.0, 0.3, -0.4, -np.pi / 2]))]
+    for tag, model, extra, x0 in cases:
+        spec = dict(extra, model=model, radius=0.25)
+        ctl = LocalTrackingController(x0, spec, controller_type={"pos": "cbf_qp"}, dt=DT, env=ref_env.Env(),
+                                      enable_rotation=False)
+        hi = np.array([spec["v_max"]] * 2) if model == "SingleIntegrator2D" else np.array([spec["a_max"]] * 2)
+        ctl.pos_controller.cbf_controller = OracleProblem(ctl.pos_controller, -hi, hi)
+        ctl.obs = known.copy()
+        ctl.set_waypoints(wps)
+        Xs, Us, rets, sms = [ctl.robot.X.reshape(-1).copy()], [], [], [["idle", "track", "stop", "rotate"].index(ctl.state_machine)]
+        for _ in range(1200):
+            ret = ctl.control_step()
+            rets.append(ret); sms.append(["idle", "track", "stop", "rotate"].index(ctl.state_machine))
+            if ret == -2:
+                break
+            Xs.append(ctl.robot.X.reshape(-1).copy()); Us.append(ctl.get_control_input().reshape(-1).copy())
+            if ret == -1:
+                break
+        out[f"{tag}/obs"] = known; out[f"{tag}/waypoints"] = wps; out[f"{tag}/x0"] = x0
+        out[f"{tag}/X"] = np.array(Xs); out[f"{tag}/U"] = np.array(Us)
+        out[f"{tag}/ret"] = np.array(rets); out[f"{tag}/sm"] = np.array(sms)
+        print(tag, "steps", len(rets), "last ret", rets[-1], "first sm", sms[0])
+    np.savez_compressed(os.path.join(HERE, "closed_loop_integrators.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "closed_loop_integrators":
+        gen_closed_loop_integrators()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "linear_models":
         gen_linear_models()
         sys.exit(0)
@@ -591,3 +630,4 @@ if __name__ == "__main__":
     gen_unicycle2d()
     gen_manipulator()
     gen_linear_models()
+    gen_closed_loop_integrators()

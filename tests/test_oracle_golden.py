@@ -304,3 +304,24 @@ def test_unicycle2d_sigma_has_no_overflow_far_behind_the_robot():
         k1, k2 = R.UNI_K1, R.UNI_K2
         ref = k2 * (np.exp(k1 - s_) - 1) / (np.exp(k1 - s_) + 1)
         assert abs(ref - k2 * np.tanh(0.5 * (k1 - s_))) < 1e-14
+
+
+@pytest.mark.parametrize("tag,model", [("si", R.MODEL_SI), ("di", R.MODEL_DI), ("di_back", R.MODEL_DI)])
+def test_integrator_closed_loops_match_reference(golden_dir, tag, model):
+    """LocalTrackingController with SingleIntegrator2D / DoubleIntegrator2D, enable_rotation=False
+    (tests/golden/make_golden.py: gen_closed_loop_integrators): every state of the reference's run to the last waypoint."""
+    from oracle import tracking as T
+    g = np.load(os.path.join(golden_dir, "closed_loop_integrators.npz"))
+    x0 = g[f"{tag}/x0"]
+    if model == R.MODEL_SI:
+        X0, yaw, spec = np.array([x0[0], x0[1], 0.0, 0.0]), x0[2], dict(v_max=1.0, radius=0.25)
+    else:
+        X0, yaw, spec = x0[:4], x0[4], dict(v_max=1.0, a_max=1.0, radius=0.25)
+    o = T.TrackingOracle(model, X0, spec, obs=g[f"{tag}/obs"], num_constraints=10, enable_rotation=False, yaw0=yaw)
+    o.set_waypoints(g[f"{tag}/waypoints"])
+    assert ["idle", "track", "stop", "rotate"].index(o.state_machine) == g[f"{tag}/sm"][0]
+    Xr, rets = g[f"{tag}/X"], g[f"{tag}/ret"]
+    for i in range(len(rets)):
+        assert o.control_step() == rets[i]
+        np.testing.assert_allclose(o.X[: Xr.shape[1]], Xr[i + 1], rtol=0, atol=1e-9)
+    assert rets[-1] == -1

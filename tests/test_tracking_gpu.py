@@ -270,3 +270,67 @@ def test_unicycle2d_closed_loop_with_mpc(golden_dir):
                 break
         n_track += state.get("n", 0)
     assert n_track >= T
+
+
+@pytest.mark.parametrize("tag,model_name", [("si", "SingleIntegrator2D"), ("di", "DoubleIntegrator2D"), ("di_back", "DoubleIntegrator2D")])
+def test_integrators_reproduce_the_reference_closed_loop(golden_dir, tag, model_name):
+    """examples/test_tracking.py --model si / di --algo cbf_qp with enable_rotation=False: the reference's own trajectories
+    (tests/golden/closed_loop_integrators.npz) through the 14-circle scene to the last waypoint, in three launches; the
+    'di_back' start faces away from the first goal, so it begins in 'stop' and brakes first."""
+    g = np.load(os.path.join(golden_dir, "closed_loop_integrators.npz"))
+    spec = {"model": model_name, "v_max": 1.0, "radius": 0.25}
+    if model_name == "DoubleIntegrator2D":
+        spec["a_max"] = 1.0
+    ctl = sca.BatchedTrackingController(g[f"{tag}/x0"][None, :], spec, obs=g[f"{tag}/obs"], io_dtype="f64", enable_rotation=False)
+    ctl.set_waypoints(g[f"{tag}/waypoints"])
+    assert int(ctl.state_machine[0].item()) == int(g[f"{tag}/sm"][0])
+    Xg, Ug, retg = g[f"{tag}/X"], g[f"{tag}/U"], g[f"{tag}/ret"]
+    T, nx = len(retg), Xg.shape[1]
+    done = 0
+    for n in (1, 399, T - 400 + 5):
+        ret, tX, tU = ctl.control_step(n, record=True)
+        tX = tX.cpu().numpy()[:, 0]; tU = tU.cpu().numpy()[:, 0]
+        m = min(n, T - done)
+        np.testing.assert_allclose(tX[:m, :nx], Xg[done + 1: done + m + 1], rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(tU[:m], Ug[done: done + m], rtol=1e-7, atol=1e-7)
+        done += n
+    assert int(ret[0].item()) == -1 and int(retg[-1]) == -1 and ctl.steps_done == T + 5
+    with pytest.raises(ValueError):
+        sca.BatchedTrackingController(g[f"{tag}/x0"][None, :], dict(spec), obs=g[f"{tag}/obs"])    # enable_rotation defaults to True
+
+
+def test_integrator_fleet_against_oracle(golden_dir):
+    """32 DoubleIntegrator2D agents with their own start states / headings / waypoints against oracle/tracking.py."""
+    g = np.load(os.path.join(golden_dir, "closed_loop_integrators.npz"))
+    obs = g["di/obs"]
+    rng = np.random.default_rng(17)
+    B, T = 32, 220
+    spec = {"model": "DoubleIntegrator2D", "v_max": 1.0, "a_max": 1.0, "radius": 0.25}
+    X0, wl = [], []
+    while len(X0) < B:
+        p = rng.uniform(0.5, 13.5, 2)
+        if np.min(np.linalg.norm(obs[:, :2] - p, axis=1) - obs[:, 2]) < 0.6:
+            continue
+        X0.append([p[0], p[1], *rng.uniform(-0.5, 0.5, 2), rng.uniform(-np.pi, np.pi)])
+        wl.append(np.vstack([p, rng.uniform(1, 13, (2, 2))]))
+    X0 = np.array(X0)
+    ctl = sca.BatchedTrackingController(X0, dict(spec), obs=obs, io_dtype="f64", enable_rotation=False)
+    ctl.set_waypoints(wl)
+    ret, tX, tU = ctl.control_step(T, record=True)
+    tX = tX.cpu().numpy(); ret = ret.cpu().numpy()
+    n_fin = 0
+    for i in range(B):
+        t = tracking.TrackingOracle(R.MODEL_DI, X0[i, :4], spec, dt=0.05, obs=obs, num_constraints=10, enable_rotation=False,
+                                    yaw0=X0[i, 4])
+        t.set_waypoints(wl[i])
+        last = 0
+        for k in range(T):
+            last = t.control_step()
+            if last == -2:
+                break
+            np.testing.assert_allclose(tX[k, i], t.X, rtol=1e-7, atol=1e-7)
+            if last != 0:
+                break
+        assert ret[i] == last
+        n_fin += int(last != -2)
+    assert n_fin > B // 2                                  # most agents are still under way (or done), not failed
