@@ -28,7 +28,7 @@ GRAVITY_Q3D = 9.8                                           # quad3D.py:70
 
 
 def si_model(spec=None, dt=0.05):
-    spec = dict(v_max=1.0, radius=0.25, **(spec or {}))
+    spec = {**dict(v_max=1.0, radius=0.25), **(spec or {})}
     A = np.zeros((2, 2)); B = np.eye(2)
     Ae, Be = np.eye(2) + dt * A, dt * B
     return dict(name="SingleIntegrator2D", nx=2, nu=2, ng=2, Ae=Ae, Be=Be, As=Ae.copy(), Bs=Be.copy(),

@@ -497,15 +497,19 @@ static int check_tracking_split(const sc_tracking_params* params, int64_t B, int
     if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
     const sc_cbfqp_params* q = &params->qp;
     if (B < 0 || M < 0) return sc::fail(SC_ERR_INVALID_ARGUMENT, "B < 0 or M < 0");
-    if (q->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && q->model_id != SC_MODEL_KINEMATIC_BICYCLE2D && q->model_id != SC_MODEL_UNICYCLE2D)
-        return sc::fail(SC_ERR_UNSUPPORTED, "select / apply are built for DynamicUnicycle2D, Unicycle2D and KinematicBicycle2D");
+    const bool integrator = q->model_id == SC_MODEL_SINGLE_INTEGRATOR2D || q->model_id == SC_MODEL_DOUBLE_INTEGRATOR2D;
+    if (q->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && q->model_id != SC_MODEL_KINEMATIC_BICYCLE2D && q->model_id != SC_MODEL_UNICYCLE2D &&
+        !integrator)
+        return sc::fail(SC_ERR_UNSUPPORTED, "select / apply are built for DynamicUnicycle2D, Unicycle2D, KinematicBicycle2D and the integrators");
+    if (integrator && params->enable_rotation)
+        return sc::fail(SC_ERR_UNSUPPORTED, "the integrators' rotate state needs an attitude controller: enable_rotation must be 0");
     if (q->io_dtype != SC_DTYPE_F32 && q->io_dtype != SC_DTYPE_F64)
         return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
     if (params->num_constraints < 1 || params->num_constraints > SC_TRACKING_MAX_CONSTRAINTS)
         return sc::fail(SC_ERR_UNSUPPORTED, "num_constraints outside [1, SC_TRACKING_MAX_CONSTRAINTS]");
     if (params->dyn_obs) return sc::fail(SC_ERR_UNSUPPORTED, "select / apply take a static obstacle table");
     if (!(q->dt > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "dt must be > 0");
-    if (q->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && q->model_id != SC_MODEL_UNICYCLE2D &&
+    if (q->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && q->model_id != SC_MODEL_UNICYCLE2D && !integrator &&
         (!(q->rear_ax_dist > 0) || !(params->wheel_base > 0)))
         return sc::fail(SC_ERR_INVALID_ARGUMENT, "rear_ax_dist and wheel_base must be > 0 for the KinematicBicycle2D family");
     if ((size_t)M * 7 * 8 > 160 * 1024) return sc::fail(SC_ERR_UNSUPPORTED, "obstacle table does not fit the LDS");

@@ -850,6 +850,10 @@ static hipError_t launch_select_t(const sc_tracking_params& p, long long B, int 
         return launch_select_m<TIO, SC_MODEL_DYNAMIC_UNICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, ret, obs_out, goal_out, u_ref_out, track_out, stream);
     if (p.qp.model_id == SC_MODEL_UNICYCLE2D)
         return launch_select_m<TIO, SC_MODEL_UNICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, ret, obs_out, goal_out, u_ref_out, track_out, stream);
+    if (p.qp.model_id == SC_MODEL_SINGLE_INTEGRATOR2D)
+        return launch_select_m<TIO, SC_MODEL_SINGLE_INTEGRATOR2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, ret, obs_out, goal_out, u_ref_out, track_out, stream);
+    if (p.qp.model_id == SC_MODEL_DOUBLE_INTEGRATOR2D)
+        return launch_select_m<TIO, SC_MODEL_DOUBLE_INTEGRATOR2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, ret, obs_out, goal_out, u_ref_out, track_out, stream);
     return launch_select_m<TIO, SC_MODEL_KINEMATIC_BICYCLE2D>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, ret, obs_out, goal_out, u_ref_out, track_out, stream);
 }
 
@@ -878,6 +882,8 @@ static hipError_t launch_apply_t(const sc_tracking_params& p, long long B, int M
     };
     if (p.qp.model_id == SC_MODEL_DYNAMIC_UNICYCLE2D) return go(tracking_apply_kernel<TIO, double, SC_MODEL_DYNAMIC_UNICYCLE2D>);
     if (p.qp.model_id == SC_MODEL_UNICYCLE2D) return go(tracking_apply_kernel<TIO, double, SC_MODEL_UNICYCLE2D>);
+    if (p.qp.model_id == SC_MODEL_SINGLE_INTEGRATOR2D) return go(tracking_apply_kernel<TIO, double, SC_MODEL_SINGLE_INTEGRATOR2D>);
+    if (p.qp.model_id == SC_MODEL_DOUBLE_INTEGRATOR2D) return go(tracking_apply_kernel<TIO, double, SC_MODEL_DOUBLE_INTEGRATOR2D>);
     return go(tracking_apply_kernel<TIO, double, SC_MODEL_KINEMATIC_BICYCLE2D>);
 }
 

@@ -50,8 +50,11 @@ class BatchedTrackingController:
         # the integrators keep their heading outside the state (robots/robot.py:66-72); their rotate state runs the
         # attitude controllers, which are out of scope: enable_rotation must be off and the heading then never changes
         self.integrator = self.model in ("SingleIntegrator2D", "DoubleIntegrator2D")
-        if self.integrator and (enable_rotation or controller_type.get("pos", "cbf_qp") != "cbf_qp"):
-            raise ValueError("SingleIntegrator2D / DoubleIntegrator2D run in the fused 'cbf_qp' loop with enable_rotation=False")
+        if self.integrator and enable_rotation:
+            raise ValueError("SingleIntegrator2D / DoubleIntegrator2D run with enable_rotation=False")
+        if self.integrator and self.pos_controller_type != "cbf_qp" and \
+                not (self.model == "SingleIntegrator2D" and self.pos_controller_type == "mpc_cbf"):
+            raise ValueError("integrators: 'cbf_qp' (both) or 'mpc_cbf' (SingleIntegrator2D, the linear-model kernel)")
         self.dt = float(dt)
         self.enable_rotation = bool(enable_rotation)
         self.dyn_obs = bool(dyn_obs)
@@ -94,7 +97,11 @@ class BatchedTrackingController:
                 raise ValueError("moving obstacle tables are stepped by the fused 'cbf_qp' rollout only")
             from .position_control.mpc_cbf import BatchedMPCCBF
             from .position_control.optimal_decay_mpc_cbf import BatchedOptimalDecayMPCCBF
-            cls = BatchedMPCCBF if self.pos_controller_type == "mpc_cbf" else BatchedOptimalDecayMPCCBF
+            if self.model == "SingleIntegrator2D":             # linear model: csrc/mpc_lin.hip
+                from .position_control.mpc_cbf_linear import BatchedLinearMPCCBF
+                cls = BatchedLinearMPCCBF
+            else:
+                cls = BatchedMPCCBF if self.pos_controller_type == "mpc_cbf" else BatchedOptimalDecayMPCCBF
             self.mpc = cls(self.robot_spec, dt=self.dt, io_dtype=io_dtype)
             self.u_prev = torch.zeros((self.B, 2), dtype=self.tdtype, device=self.device)   # do-mpc's u0 per agent
             self.mpc_status = torch.zeros(self.B, dtype=torch.int32, device=self.device)
@@ -239,7 +246,8 @@ class BatchedTrackingController:
                 self.current_goal_index.data_ptr(), self.state_machine.data_ptr(), self.goal.data_ptr(), obs_ptr,
                 self.ret.data_ptr(), obs_sel.data_ptr(), goal2.data_ptr(), u_ref.data_ptr(), track.data_ptr(), stream)
             _lib.check(rc, "sc_tracking_select_batch")
-            out = self.mpc.solve(self.X, self.u_prev, goal2, obs_sel)
+            Xm = self.X[:, :2].contiguous() if self.model == "SingleIntegrator2D" else self.X
+            out = self.mpc.solve(Xm, self.u_prev, goal2, obs_sel)
             u_mpc, st = (out[0], out[2]) if self.pos_controller_type == "optimal_decay_mpc_cbf" else (out[0], out[1])
             tr = (track != 0).unsqueeze(1)
             u = torch.where(tr, u_mpc, u_ref).contiguous()

@@ -334,3 +334,46 @@ def test_integrator_fleet_against_oracle(golden_dir):
         assert ret[i] == last
         n_fin += int(last != -2)
     assert n_fin > B // 2                                  # most agents are still under way (or done), not failed
+
+
+def test_single_integrator_closed_loop_with_mpc(golden_dir):
+    """examples/test_tracking.py --model si (default --algo mpc_cbf), batched: select -> linear-model MPC launch -> apply,
+    against the oracle loop with oracle/mpc_lin.py behind solve_fn."""
+    from oracle import mpc_cbf as M, mpc_lin as L
+    g = np.load(os.path.join(golden_dir, "closed_loop_integrators.npz"))
+    obs = g["si/obs"]
+    K = 6
+    spec = {"model": "SingleIntegrator2D", "v_max": 1.0, "radius": 0.25, "num_constraints": K}
+    X0 = np.array([[2.0, 2.0, np.pi / 2], [6.0, 1.0, 2.6], [1.0, 6.0, -1.2]])                   # the last one starts in 'stop'
+    wl = [np.array([[2.0, 12.0], [12.0, 12.0]]), np.array([[1.0, 4.0]]), np.array([[1.0, 12.0]])]
+    T = 40
+    ctl = sca.BatchedTrackingController(X0, dict(spec), controller_type={"pos": "mpc_cbf"}, obs=obs, io_dtype="f64",
+                                        enable_rotation=False)
+    ctl.set_waypoints(wl)
+    ret, tX, tU = ctl.control_step(T, record=True)
+    tX = tX.cpu().numpy(); ret = ret.cpu().numpy()
+    mdl = L.si_model({"v_max": 1.0, "radius": 0.25})
+    n_track = 0
+    for i in range(len(X0)):
+        state = {"up": np.zeros(2)}
+
+        def solve_fn(X, cref, nobs, state=state):
+            if cref["state_machine"] != "track":
+                return np.asarray(cref["u_ref"], dtype=np.float64).reshape(-1), 0
+            o = M.pad_obstacles(None if nobs is None else list(nobs), K)
+            u, st, it = L.solve(mdl, X[:2], state["up"], cref["goal"], o)
+            state["up"] = u
+            state["n"] = state.get("n", 0) + 1
+            return u, 0
+
+        t = tracking.TrackingOracle(R.MODEL_SI, [X0[i, 0], X0[i, 1], 0.0, 0.0], {"v_max": 1.0, "radius": 0.25}, dt=0.05, obs=obs,
+                                    num_constraints=K, solve_fn=solve_fn, enable_rotation=False, yaw0=X0[i, 2])
+        t.set_waypoints(wl[i])
+        for k in range(T):
+            r = t.control_step()
+            np.testing.assert_allclose(tX[k, i, :2], t.X[:2], rtol=0, atol=5e-6, err_msg=f"agent {i} step {k}")
+            if r != 0:
+                assert ret[i] == r
+                break
+        n_track += state.get("n", 0)
+    assert n_track >= T
