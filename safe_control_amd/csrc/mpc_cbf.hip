@@ -1194,6 +1194,7 @@ static hipError_t odmpc_launch_t(const sc_odmpccbf_params& q, long long B, int K
         return hipGetLastError();
     };
     if (p.horizon == 10) return launch(odmpccbf_kernel<10>);
+    if (p.horizon == 20) return launch(odmpccbf_kernel<20>);         // BASELINE config 5's horizon
     return launch(odmpccbf_kernel_rt);
 }
 
@@ -1229,6 +1230,7 @@ static hipError_t mpc_launch_t(const sc_mpccbf_params& p, long long B, int K, co
                                hipStream_t stream) {
     if (p.model_id == SC_MODEL_UNICYCLE2D) {
         if (p.horizon == 10) return mpc_launch_one<10, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        if (p.horizon == 20) return mpc_launch_one<20, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
         return mpc_launch_one<0, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
     }
     if (p.horizon == 10 && K == 8)            // BASELINE config 3
