@@ -217,6 +217,40 @@ int sc_mpclin_solve_batch_host(const sc_mpclin_params* params, const double* mod
                                const void* X, const void* u_prev, const void* goal, const void* obs,
                                void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, int device);
 
+/* ---- MPC-CBF for DoubleIntegrator2D and Quad2D -----------------------------------------------
+ * MPCCBF (position_control/mpc_cbf.py:7-402) for the planar models whose rel-deg-2 DT-CBF steps the state with the robot's
+ * own step(): x1 = step(x_k, u_k), x2 = step(x1, u_k) (double_integrator2D.py:222-272 with the speed rescaled to v_max
+ * :79-107; quad2D.py:179-206), so the barrier points are functions of (x_k, u_k) and not predicted positions.  Weights /
+ * gains / bounds of mpc_cbf.py: DI Q = diag(50,50,20,20), R = (.5,.5), alpha .2, |a| <= (ax_max, ay_max); Quad2D Q =
+ * diag(25,25,50,10,10,50), R = (.5,.5), alpha .15, f_min <= u <= f_max.  Interior point with a Gauss-Newton Hessian
+ * (oracle/mpc_gn.py).  KinematicBicycle2D has the same structure but needs the exact Hessian (not served: SC_ERR_UNSUPPORTED).
+ * X [B,nx] (nx = 4, or 6 for Quad2D), u_prev [B,2], goal [B,2], obs [B,K,7] (or [K,7]) padded like update_tvp;
+ * u_out [B,2], status_out [B], iters_out [B] or NULL, z_out [B, 2*horizon] or NULL.  One NLP per wavefront, f64 arithmetic.
+ */
+typedef struct sc_mpcgn_params {
+    int32_t model_id;        /* SC_MODEL_DOUBLE_INTEGRATOR2D or SC_MODEL_QUAD2D                                    */
+    int32_t io_dtype, horizon, max_iter, obs_shared, acceptable_iter;      /* as sc_mpccbf_params                  */
+    int32_t circles_only;    /* 1: no superellipsoid branch in the model's DT barrier (KB, Quad2D)                 */
+    int32_t reserved;
+    double  dt;
+    double  Q[6], R[2];      /* mpc_cbf.py:28-36                                                                   */
+    double  alpha1, alpha2;  /* mpc_cbf.py:60-76                                                                   */
+    double  u_lo[2], u_hi[2];
+    double  v_min, v_max;    /* DI: speed rescaling of step() (v_max); v_min reserved                              */
+    double  rear_ax_dist;    /* reserved (KinematicBicycle2D)                                                      */
+    double  mass, inertia;   /* Quad2D                                                                             */
+    double  robot_radius;    /* barrier radius (and the rotor arm of Quad2D, quad2D.py:72)                         */
+    double  beta;            /* barrier inflation: 1.01                                                            */
+    double  tol, acceptable_tol, mu_init, mu_min;
+} sc_mpcgn_params;
+
+int sc_mpcgn_solve_batch(const sc_mpcgn_params* params, int64_t B, int32_t K,
+                         const void* X, const void* u_prev, const void* goal, const void* obs,
+                         void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
+int sc_mpcgn_solve_batch_host(const sc_mpcgn_params* params, int64_t B, int32_t K,
+                              const void* X, const void* u_prev, const void* goal, const void* obs,
+                              void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, int device);
+
 /* ---- optimal-decay MPC-CBF ---------------------------------------
  * OptimalDecayMPCCBF (position_control/optimal_decay_mpc_cbf.py:15-330) for DynamicUnicycle2D: the MPC-CBF NLP with
  * two decay variables per stage (omega1_k, omega2_k, model inputs at :123-124) that scale the DT-CBF gains,

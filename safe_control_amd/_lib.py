@@ -81,6 +81,18 @@ class MpcLinParams(C.Structure):
     ]
 
 
+class MpcGnParams(C.Structure):
+    """Mirror of ``sc_mpcgn_params``."""
+    _fields_ = [
+        ("model_id", C.c_int32), ("io_dtype", C.c_int32), ("horizon", C.c_int32), ("max_iter", C.c_int32),
+        ("obs_shared", C.c_int32), ("acceptable_iter", C.c_int32), ("circles_only", C.c_int32), ("reserved", C.c_int32),
+        ("dt", C.c_double), ("Q", C.c_double * 6), ("R", C.c_double * 2), ("alpha1", C.c_double), ("alpha2", C.c_double),
+        ("u_lo", C.c_double * 2), ("u_hi", C.c_double * 2), ("v_min", C.c_double), ("v_max", C.c_double),
+        ("rear_ax_dist", C.c_double), ("mass", C.c_double), ("inertia", C.c_double), ("robot_radius", C.c_double),
+        ("beta", C.c_double), ("tol", C.c_double), ("acceptable_tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double),
+    ]
+
+
 MANIP_MAX_ROWS = 250
 
 
@@ -121,6 +133,8 @@ SYMBOLS = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sc_cbfqp_solve_batch_host": (C.c_int, [C.POINTER(CbfQpParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "sc_mpcgn_solve_batch": (C.c_int, [C.POINTER(MpcGnParams), C.c_int64, C.c_int32] + [C.c_void_p] * 9),
+    "sc_mpcgn_solve_batch_host": (C.c_int, [C.POINTER(MpcGnParams), C.c_int64, C.c_int32] + [C.c_void_p] * 8 + [C.c_int]),
     "sc_mpclin_model_doubles": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sc_mpclin_build_model": (C.c_int, [C.POINTER(MpcLinParams)] + [C.c_void_p] * 5),
     "sc_mpclin_solve_batch": (C.c_int, [C.POINTER(MpcLinParams), C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 9),

@@ -47,6 +47,10 @@ hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long lo
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                          hipStream_t stream);
 
+size_t mpcgn_lds_bytes(int model_id, int N, int K);
+hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
+                        const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream);
+
 static thread_local char g_err[256] = "";
 
 static int fail(int code, const char* msg) {
@@ -134,6 +138,27 @@ static int check_mpclin(const sc_mpclin_params* p, const double* model, int64_t 
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
     return SC_OK;
 }
+static int check_mpcgn(const sc_mpcgn_params* p, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,
+                       const void* obs, const void* u_out, const void* status_out) {
+    if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (p->model_id != SC_MODEL_DOUBLE_INTEGRATOR2D && p->model_id != SC_MODEL_QUAD2D)
+        return fail(SC_ERR_UNSUPPORTED, "this entry point serves DoubleIntegrator2D and Quad2D");
+    if (B < 0) return fail(SC_ERR_INVALID_ARGUMENT, "B < 0");
+    if (K < 1) return fail(SC_ERR_INVALID_ARGUMENT, "K < 1 (pad with [1000,1000,0,...] rows like update_tvp)");
+    if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
+        return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
+    if (p->horizon < 1 || p->horizon > 32) return fail(SC_ERR_UNSUPPORTED, "horizon outside [1, 32]");
+    if (mpcgn_lds_bytes(p->model_id, p->horizon, K) > 160 * 1024)
+        return fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
+    if (!(p->dt > 0) || !(p->tol > 0) || !(p->acceptable_tol >= p->tol) || p->max_iter < 1 || !(p->mu_init > 0) || !(p->mu_min > 0))
+        return fail(SC_ERR_INVALID_ARGUMENT, "dt, tol, mu_init, mu_min must be > 0 and max_iter >= 1");
+    if (!(p->u_hi[0] > p->u_lo[0]) || !(p->u_hi[1] > p->u_lo[1])) return fail(SC_ERR_INVALID_ARGUMENT, "u_hi must be > u_lo");
+    if (p->model_id == SC_MODEL_DOUBLE_INTEGRATOR2D && !(p->v_max > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "DoubleIntegrator2D needs v_max > 0");
+    if (p->model_id == SC_MODEL_QUAD2D && (!(p->mass > 0) || !(p->inertia > 0))) return fail(SC_ERR_INVALID_ARGUMENT, "Quad2D needs mass, inertia > 0");
+    if (B > 0 && (!X || !u_prev || !goal || !obs || !u_out || !status_out)) return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
+    return SC_OK;
+}
 static int check_manip(const sc_manip_cbfqp_params* p, int64_t B, int32_t K, const void* X, const void* u_ref,
                        const void* obs, const void* u_out, const void* status_out) {
     if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
@@ -158,6 +183,57 @@ static int check_manip(const sc_manip_cbfqp_params* p, int64_t B, int32_t K, con
 }  // namespace sc
 
 extern "C" {
+
+int sc_mpcgn_solve_batch(const sc_mpcgn_params* params, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,
+                         const void* obs, void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream) {
+    int rc = sc::check_mpcgn(params, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::mpcgn_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out,
+                                    (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "mpcgn kernel launch");
+    return SC_OK;
+}
+
+int sc_mpcgn_solve_batch_host(const sc_mpcgn_params* params, int64_t B, int32_t K, const void* X, const void* u_prev,
+                              const void* goal, const void* obs, void* u_out, int32_t* status_out, int32_t* iters_out,
+                              void* z_out, int device) {
+    int rc = sc::check_mpcgn(params, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipSetDevice");
+    const size_t es = params->io_dtype == SC_DTYPE_F64 ? 8 : 4;
+    const size_t nx = params->model_id == SC_MODEL_QUAD2D ? 6 : 4, n = 2 * (size_t)params->horizon;
+    const size_t nX = (size_t)B * nx * es, nU = (size_t)B * 2 * es, nG = nU;
+    const size_t nO = (params->obs_shared ? (size_t)K * 7 : (size_t)B * K * 7) * es;
+    const size_t nS = (size_t)B * 4, nZ = (size_t)B * n * es;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t oX = 0, oU = oX + up(nX), oG = oU + up(nU), oO = oG + up(nG), oUo = oO + up(nO), oS = oUo + up(nU),
+                 oI = oS + up(nS), oZ = oI + up(nS), total = oZ + up(nZ);
+    unsigned char* d = nullptr;
+    e = hipMalloc((void**)&d, total);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipMalloc");
+    hipStream_t s = nullptr;
+    rc = SC_OK;
+    do {
+        if ((e = hipMemcpyAsync(d + oX, X, nX, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oU, u_prev, nU, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oG, goal, nG, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        e = sc::mpcgn_launch(*params, (long long)B, (int)K, d + oX, d + oU, d + oG, d + oO, d + oUo, (int*)(d + oS),
+                             iters_out ? (int*)(d + oI) : nullptr, z_out ? d + oZ : nullptr, s);
+        if (e != hipSuccess) break;
+        if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (iters_out && (e = hipMemcpyAsync(iters_out, d + oI, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (z_out && (e = hipMemcpyAsync(z_out, d + oZ, nZ, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        e = hipStreamSynchronize(s);
+    } while (0);
+    if (e != hipSuccess) rc = sc::fail_hip(e, "sc_mpcgn_solve_batch_host");
+    (void)hipFree(d);
+    return rc;
+}
 
 size_t sc_mpclin_model_doubles(int32_t nx, int32_t nu, int32_t horizon) {
     if (nx < 2 || nx > 12 || nu < 1 || nu > 4 || horizon < 1 || horizon * nu > 128) return 0;

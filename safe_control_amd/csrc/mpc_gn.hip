@@ -1,0 +1,686 @@
+// MPC-CBF for the reference's planar models with a relative-degree-2 distance barrier and non-affine barrier points --
+// DoubleIntegrator2D and Quad2D -- one NLP per wavefront.  (KinematicBicycle2D has the same structure -- its row of the
+// table below is kept for reference -- but its fast heading dynamics need the second derivatives of the dynamics that
+// this Gauss-Newton method drops: the oracle converges on under half of the test draws, so it is not served)
+//   MPCCBF (position_control/mpc_cbf.py:7-402) over robots/double_integrator2D.py, robots/quad2D.py:
+//     prediction  x+ = x + (f(x) + g(x) u) dt                                               mpc_cbf.py:135-141
+//     cost        sum_k (x_k - xg)' Q (x_k - xg) + r-term R on delta u                       mpc_cbf.py:28-36,144,176-180
+//     CBF         dd_h + (a1 + a2) d_h + a1 a2 h >= 0 with x1 = step(x_k, u_k), x2 = step(x1, u_k)  mpc_cbf.py:316-321;
+//                 kinematic_bicycle2D.py:113-123,175-199 (speed clipped); double_integrator2D.py:79-107,222-272 (speed
+//                 rescaled); quad2D.py:81-84,179-206
+//     bounds      input boxes (KB adds |v_k| <= v_max: the state-bound rows are implemented, NB > 0)  mpc_cbf.py:193-216
+//   Oracle: oracle/mpc_gn.py (problem functions, Gauss-Newton Hessian) + oracle/mpc_cbf.py: solve.
+//
+// The robot's own step() applies u_k twice and clips, so the barrier points b_k = pos(S(x_k, u_k)), c_k = pos(S(S(x_k, u_k), u_k))
+// are functions of (x_k, u_k), not predicted positions.  Structure of one interior-point iteration:
+//   * rollout and sensitivities: lane c < n owns COLUMN c of Phi_k = d x_k / d z and carries it through the horizon in
+//     registers (Phi_{k+1} = A_k Phi_k + B_k E_k); the state, A_k, B_k and the Jacobians of S are wave-uniform and computed
+//     redundantly by every lane, so the pass has no cross-lane step at all; it leaves Phi (cost, speed rows) and
+//     G = d points / d z (6N x n) in LDS;
+//   * Gauss-Newton Hessian: sf (2 sum Phi_k' Q Phi_k + 2 D' R D) + G' Psi G + speed-row and box terms, Psi = the 6 x 6 stage
+//     blocks of J' Sigma J - sum lam grad^2 h over (a_k, b_k, c_k): exact second derivatives of the cost in the states and
+//     of h in the points, none of the dynamics (quasi-Newton; the oracle uses the same matrix);
+//   * register Cholesky, fraction-to-boundary, l1-merit backtracking exactly as kernels 3 and 7.
+// Arithmetic is f64; the caller's arrays are f32 or f64.
+#include <hip/hip_runtime.h>
+
+#include "../../include/safe_control_amd.h"
+#include "sc_math.hpp"
+#include "mpc_chol.hpp"
+
+namespace sc {
+
+namespace {
+
+template <typename F>
+__device__ __forceinline__ double gred(double v, F f) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v = f(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double gsum(double v) { return gred(v, [](double a, double b) { return a + b; }); }
+__device__ __forceinline__ double gmin(double v) { return gred(v, [](double a, double b) { return fmin(a, b); }); }
+__device__ __forceinline__ double gmax_(double v) { return gred(v, [](double a, double b) { return fmax(a, b); }); }
+
+struct GnPar {                      // model constants (wave-uniform)
+    double dt, Lr, v_min, v_max, mass, inertia, rad;
+};
+
+// ---- models: prediction F, the robot's own step S, their Jacobians (oracle/mpc_gn.py: kb_F, kb_S, di_F, di_S, q2_F) -------
+template <int MODEL> struct GnModel;
+
+template <> struct GnModel<SC_MODEL_DOUBLE_INTEGRATOR2D> {
+    static constexpr int NX = 4, NB = 0, BIDX = 0;
+    template <bool JAC, bool STEP>
+    static __device__ __forceinline__ void map(const double* x, const double* u, const GnPar& q, double* xn, double (*A)[4], double (*B)[2]) {
+        const double dt = q.dt;
+        xn[0] = x[0] + dt * x[2]; xn[1] = x[1] + dt * x[3];
+        double w0 = x[2] + dt * u[0], w1 = x[3] + dt * u[1];
+        if constexpr (JAC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) A[i][j] = i == j ? 1.0 : 0.0;
+                B[i][0] = 0.0; B[i][1] = 0.0;
+            }
+            A[0][2] = dt; A[1][3] = dt; B[2][0] = dt; B[3][1] = dt;
+        }
+        if constexpr (STEP) {                                               // speed rescaled to v_max
+            const double vm = sqrt(w0 * w0 + w1 * w1);
+            if (vm > q.v_max) {
+                if constexpr (JAC) {
+                    const double i1 = q.v_max / vm, i3 = q.v_max / (vm * vm * vm);
+                    const double j00 = i1 - w0 * w0 * i3, j01 = -w0 * w1 * i3, j11 = i1 - w1 * w1 * i3;
+                    // rows 2, 3 of [A | B] are [0 0 1 0 | dt 0], [0 0 0 1 | 0 dt] before the rescaling
+                    A[2][2] = j00; A[2][3] = j01; A[3][2] = j01; A[3][3] = j11;
+                    B[2][0] = j00 * dt; B[2][1] = j01 * dt; B[3][0] = j01 * dt; B[3][1] = j11 * dt;
+                }
+                const double sc_ = q.v_max / vm;
+                w0 *= sc_; w1 *= sc_;
+            }
+        }
+        xn[2] = w0; xn[3] = w1;
+    }
+};
+
+template <> struct GnModel<SC_MODEL_QUAD2D> {
+    static constexpr int NX = 6, NB = 0, BIDX = 0;
+    template <bool JAC, bool STEP>
+    static __device__ __forceinline__ void map(const double* x, const double* u, const GnPar& q, double* xn, double (*A)[6], double (*B)[2]) {
+        double s, c;
+        sincos(x[2], &s, &c);
+        const double dt = q.dt, T = u[0] + u[1], im = 1.0 / q.mass, ri = q.rad / q.inertia;
+        xn[0] = x[0] + dt * x[3]; xn[1] = x[1] + dt * x[4]; xn[2] = x[2] + dt * x[5];
+        xn[3] = x[3] + dt * (-s * im) * T;
+        xn[4] = x[4] + dt * (-9.81 + (c * im) * T);
+        xn[5] = x[5] + dt * ri * (u[0] - u[1]);
+        if constexpr (JAC) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) A[i][j] = i == j ? 1.0 : 0.0;
+                B[i][0] = 0.0; B[i][1] = 0.0;
+            }
+            A[0][3] = dt; A[1][4] = dt; A[2][5] = dt;
+            A[3][2] = dt * (-c * im) * T; A[4][2] = dt * (-s * im) * T;
+            B[3][0] = B[3][1] = dt * (-s * im); B[4][0] = B[4][1] = dt * (c * im); B[5][0] = dt * ri; B[5][1] = -dt * ri;
+        }
+    }
+};
+
+struct GnMem {
+    double *cq, *xg, *up;                                 // Q (6) | R (2) | u_lo (2) | u_hi (2) ; goal state ; previous input
+    double *z, *zt, *zb, *dz, *gs, *rd, *rhs;             // n each
+    double *xs, *Ph, *pts, *y, *pdz, *G, *T;              // (N+1) nx | (N+1) nx n | 6N | 6N | 6N | 6N n | 6N n
+    double *obs, *hk, *dh, *hh;                           // 7K | 3N K | 6N K | 9N K
+    double *g, *s, *lam, *ds, *dlam, *vb;                 // m each
+    double *Psi, *Hc, *M, *L;                             // 36 N | n n | n n | (L: scratch in T)
+};
+
+struct GnDims { int N, K, n, m, mc, ms; };
+
+__host__ __device__ inline size_t mpcgn_lds_doubles(int N, int K, int nx, int nb) {
+    const size_t n = 2 * (size_t)N, m = (size_t)N * K + 2 * (size_t)nb * N + 2 * n;
+    size_t tot = 12 + nx + 2 + 7 * n + (size_t)(N + 1) * nx + (size_t)(N + 1) * nx * n + 18 * (size_t)N + 12 * (size_t)N * n +
+                 7 * (size_t)K + 18 * (size_t)N * K + 6 * m + 36 * (size_t)N + 2 * n * n;
+    const size_t need_l = n * (n + 1), have = 6 * (size_t)N * n;             // transpose scratch of the register Cholesky lives in T
+    return tot + (need_l > have ? need_l - have : 0);
+}
+
+template <int NX>
+__device__ inline GnMem carve_gn(double* b, const GnDims& d) {
+    GnMem W;
+    auto take = [&](size_t c) { double* r = b; b += c; return r; };
+    const int N = d.N, K = d.K, n = d.n, m = d.m;
+    W.cq = take(12); W.xg = take(NX); W.up = take(2);
+    W.z = take(n); W.zt = take(n); W.zb = take(n); W.dz = take(n); W.gs = take(n); W.rd = take(n); W.rhs = take(n);
+    W.xs = take((N + 1) * NX); W.Ph = take((size_t)(N + 1) * NX * n);
+    W.pts = take(6 * N); W.y = take(6 * N); W.pdz = take(6 * N);
+    W.G = take((size_t)6 * N * n);
+    W.obs = take(7 * K); W.hk = take(3 * N * K); W.dh = take(6 * N * K); W.hh = take(9 * N * K);
+    W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m); W.vb = take(m);
+    W.Psi = take(36 * N); W.Hc = take((size_t)n * n); W.M = take((size_t)n * n);
+    W.T = take((size_t)6 * N * n); W.L = W.T;                     // T is dead once M is assembled
+    return W;
+}
+
+struct GnConst { double w0, w1, w2, Rrob, beta, blo, bhi; int circles_only; };
+
+__device__ inline void gn_barrier(double px_, double py_, const double* o, const GnConst& c, bool derivs, double& h, double& d0,
+                                  double& d1, double& hxx, double& hxy, double& hyy) {
+    if (c.circles_only || o[6] < 0.5) {
+        const double d = c.Rrob + o[2];
+        const double ex = px_ - o[0], ey = py_ - o[1];
+        h = (ex * ex + ey * ey) - c.beta * d * d;
+        d0 = 2.0 * ex; d1 = 2.0 * ey; hxx = 2.0; hxy = 0.0; hyy = 2.0;
+        return;
+    }
+    const double a = fmax(fabs(o[2]), 1e-3) + c.Rrob, b = fmax(fabs(o[3]), 1e-3) + c.Rrob;
+    const double e = fmax(fabs(o[4]), 2.0);
+    double st, ct;
+    sincos(o[5], &st, &ct);
+    const double dx = px_ - o[0], dy = py_ - o[1];
+    const double px = ct * dx + st * dy, py = -st * dx + ct * dy;
+    const double ax = fabs(px) / a, ay = fabs(py) / b;
+    h = pow(ax, e) + pow(ay, e) - 1.0;
+    if (!derivs) { d0 = d1 = hxx = hxy = hyy = 0.0; return; }
+    const double sx = px > 0 ? 1.0 : (px < 0 ? -1.0 : 0.0), sy = py > 0 ? 1.0 : (py < 0 ? -1.0 : 0.0);
+    const double gpx = e * pow(ax, e - 1) / a * sx, gpy = e * pow(ay, e - 1) / b * sy;
+    const double cxx = e * (e - 1) * pow(ax, e - 2) / (a * a), cyy = e * (e - 1) * pow(ay, e - 2) / (b * b);
+    d0 = ct * gpx - st * gpy;
+    d1 = st * gpx + ct * gpy;
+    hxx = ct * ct * cxx + st * st * cyy;
+    hxy = ct * st * cxx - st * ct * cyy;
+    hyy = st * st * cxx + ct * ct * cyy;
+}
+
+// rollout (+ sensitivities), f, barrier values (+ derivatives), g.  Point index: 3 k + p, p = 0 (a_k), 1 (b_k), 2 (c_k).
+template <int MODEL>
+__device__ __forceinline__ double gn_eval(const double* zv, const GnMem& W, const GnDims& d, const GnConst& c, const GnPar& q,
+                                          int lane, bool derivs) {
+    using Mdl = GnModel<MODEL>;
+    constexpr int NX = Mdl::NX;
+    const int N = d.N, K = d.K, n = d.n;
+    // every lane rolls the (wave-uniform) state out in registers; lane `lane` < n also carries column `lane` of Phi
+    double x[NX], col[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { x[i] = W.xs[i]; col[i] = 0.0; }
+    const int myk = lane >> 1, myc = lane & 1;                               // z index lane = input myc of stage myk
+    for (int k = 0; k < N; ++k) {
+        const double u[2] = {zv[2 * k], zv[2 * k + 1]};
+        double xn[NX], y1[NX], y2[NX];
+        if (derivs) {
+            double A[NX][NX], B[NX][2], S1x[NX][NX], S1u[NX][2], S2x[NX][NX], S2u[NX][2];
+            Mdl::template map<true, false>(x, u, q, xn, A, B);
+            Mdl::template map<true, true>(x, u, q, y1, S1x, S1u);
+            Mdl::template map<true, true>(y1, u, q, y2, S2x, S2u);
+            const bool mine = (lane < n) && (myk == k);
+            double nc[NX], Y1[NX], Y2[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = 0.0, b1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) { a += A[i][j] * col[j]; b1 += S1x[i][j] * col[j]; }
+                nc[i] = a + (mine ? B[i][myc] : 0.0);
+                Y1[i] = b1 + (mine ? S1u[i][myc] : 0.0);
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double b2 = 0.0;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) b2 += S2x[i][j] * Y1[j];
+                Y2[i] = b2 + (mine ? S2u[i][myc] : 0.0);
+            }
+            if (lane < n) {
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd) {
+                    W.G[(size_t)((3 * k + 0) * 2 + dd) * n + lane] = col[dd];
+                    W.G[(size_t)((3 * k + 1) * 2 + dd) * n + lane] = Y1[dd];
+                    W.G[(size_t)((3 * k + 2) * 2 + dd) * n + lane] = Y2[dd];
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { col[i] = nc[i]; W.Ph[(size_t)((k + 1) * NX + i) * n + lane] = nc[i]; }
+            }
+        } else {
+            double (*nul4)[NX] = nullptr;
+            double (*nul2)[2] = nullptr;
+            Mdl::template map<false, false>(x, u, q, xn, nul4, nul2);
+            Mdl::template map<false, true>(x, u, q, y1, nul4, nul2);
+            Mdl::template map<false, true>(y1, u, q, y2, nul4, nul2);
+        }
+        if (lane == 0) {
+            W.pts[6 * k + 0] = x[0]; W.pts[6 * k + 1] = x[1];
+            W.pts[6 * k + 2] = y1[0]; W.pts[6 * k + 3] = y1[1];
+            W.pts[6 * k + 4] = y2[0]; W.pts[6 * k + 5] = y2[1];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) W.xs[(k + 1) * NX + i] = xn[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    }
+    SC_SYNC();
+    double part = 0.0;
+    for (int e = lane; e < N * NX; e += 64) {
+        const int k = e / NX + 1, i = e - (k - 1) * NX;
+        const double dv = W.xs[k * NX + i] - W.xg[i];
+        part += W.cq[i] * dv * dv;
+    }
+    for (int i = lane; i < n; i += 64) {
+        const double prev = i >= 2 ? zv[i - 2] : W.up[i];
+        const double du = zv[i] - prev;
+        part += W.cq[6 + (i & 1)] * du * du;
+    }
+    for (int e = lane; e < 3 * N * K; e += 64) {
+        const int pt = e / K, j = e - pt * K;
+        double h, d0, d1, hxx, hxy, hyy;
+        gn_barrier(W.pts[2 * pt], W.pts[2 * pt + 1], W.obs + 7 * j, c, derivs, h, d0, d1, hxx, hxy, hyy);
+        W.hk[e] = h;
+        if (derivs) {
+            W.dh[2 * e] = d0; W.dh[2 * e + 1] = d1;
+            W.hh[3 * e] = hxx; W.hh[3 * e + 1] = hxy; W.hh[3 * e + 2] = hyy;
+        }
+    }
+    SC_SYNC();
+    for (int i = lane; i < d.m; i += 64) {
+        double gi;
+        if (i < d.mc) {
+            const int k = i / K, j = i - k * K;
+            gi = c.w0 * W.hk[(3 * k) * K + j] + c.w1 * W.hk[(3 * k + 1) * K + j] + c.w2 * W.hk[(3 * k + 2) * K + j];
+        } else if (i < d.mc + d.ms) {
+            const int r = i - d.mc, k = (r >> 1) + 1;
+            const double xv = W.xs[k * NX + Mdl::BIDX];
+            gi = (r & 1) ? xv - c.blo : c.bhi - xv;
+        } else if (i < d.mc + d.ms + n) {
+            const int col_ = i - d.mc - d.ms;
+            gi = W.cq[10 + (col_ & 1)] - zv[col_];
+        } else {
+            const int col_ = i - d.mc - d.ms - n;
+            gi = zv[col_] - W.cq[8 + (col_ & 1)];
+        }
+        W.g[i] = gi;
+    }
+    SC_SYNC();
+    return gsum(part);
+}
+
+// out = J' v:  G' (A' v) + Phi' (speed rows) - v_hi + v_lo
+template <int MODEL>
+__device__ __forceinline__ void gn_jt(const double* v, double* out, const GnMem& W, const GnDims& d, const GnConst& c, int lane) {
+    using Mdl = GnModel<MODEL>;
+    constexpr int NX = Mdl::NX;
+    const int N = d.N, K = d.K, n = d.n;
+    for (int e = lane; e < 6 * N; e += 64) {
+        const int pt = e >> 1, dd = e & 1, k = pt / 3, p = pt - 3 * k;
+        double acc = 0.0;
+        for (int j = 0; j < K; ++j) acc += v[k * K + j] * W.dh[2 * (pt * K + j) + dd];
+        W.y[e] = (p == 0 ? c.w0 : (p == 1 ? c.w1 : c.w2)) * acc;
+    }
+    SC_SYNC();
+    for (int i = lane; i < n; i += 64) {
+        double acc = 0.0;
+        for (int r = 0; r < 6 * N; ++r) acc += W.G[(size_t)r * n + i] * W.y[r];
+        if constexpr (Mdl::NB > 0) {
+            for (int k = 1; k <= N; ++k)                                       // rows hi - x: -Phi ; x - lo: +Phi
+                acc += (v[d.mc + 2 * (k - 1) + 1] - v[d.mc + 2 * (k - 1)]) * W.Ph[(size_t)(k * NX + Mdl::BIDX) * n + i];
+        }
+        out[i] = acc - v[d.mc + d.ms + i] + v[d.mc + d.ms + n + i];
+    }
+    SC_SYNC();
+}
+
+__device__ __forceinline__ bool gn_cholesky(double* A, int n, int lane) {       // LDS, run-time order (small n: column by column)
+    bool ok = true;
+    for (int j = 0; j < n; ++j) {
+        const double dd = A[j * n + j];
+        if (!(dd > 0.0)) ok = false;
+        const double piv = sqrt(dd);
+        SC_SYNC();
+        for (int i = j + lane; i < n; i += 64) A[i * n + j] = (i == j) ? piv : A[i * n + j] / piv;
+        SC_SYNC();
+        const int rem = n - j - 1;
+        for (int e = lane; e < rem * rem; e += 64) {
+            const int i = j + 1 + e / rem, k = j + 1 + e % rem;
+            if (k <= i) A[i * n + k] -= A[i * n + j] * A[k * n + j];
+        }
+        SC_SYNC();
+        if (!ok) break;
+    }
+    return ok;
+}
+__device__ __forceinline__ void gn_chol_solve(const double* L, double* b, int n, int lane) {
+    for (int j = 0; j < n; ++j) {
+        if (lane == 0) b[j] = b[j] / L[j * n + j];
+        SC_SYNC();
+        const double yj = b[j];
+        for (int i = j + 1 + lane; i < n; i += 64) b[i] -= L[i * n + j] * yj;
+        SC_SYNC();
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        if (lane == 0) b[j] = b[j] / L[j * n + j];
+        SC_SYNC();
+        const double xj = b[j];
+        for (int i = lane; i < j; i += 64) b[i] -= L[j * n + i] * xj;
+        SC_SYNC();
+    }
+}
+template <int nn>
+__device__ __noinline__ bool gn_chol_reg(const double* M, const double* rhs, double* Lt, double* out, double delta, int lane) {
+    double a[nn], diag;
+    const int row = lane < nn ? lane : 0;
+#pragma unroll
+    for (int k = 0; k < nn; ++k) a[k] = M[row * nn + k] + (lane == k ? delta : 0.0);
+    if (!chol_reg<nn>(a, lane, diag)) return false;
+    const double x = chol_solve_reg<nn>(a, diag, rhs[row], Lt, lane);
+    if (lane < nn) out[lane] = x;
+    SC_SYNC();
+    return true;
+}
+
+// NT > 0: compile-time horizon (register Cholesky of order 2 NT); 0: run-time horizon, LDS Cholesky.
+template <int MODEL, int NT>
+__global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, const long long B, const int K,
+                                                   const void* __restrict__ X, const void* __restrict__ u_prev,
+                                                   const void* __restrict__ goal, const void* __restrict__ obs,
+                                                   void* __restrict__ u_out, int* __restrict__ status_out,
+                                                   int* __restrict__ iters_out, void* __restrict__ z_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    using Mdl = GnModel<MODEL>;
+    constexpr int NX = Mdl::NX, NB = Mdl::NB;
+    const int lane = threadIdx.x;
+    const long long prob = blockIdx.x;
+    if (prob >= B) return;
+    const bool io32 = p.io_dtype == SC_DTYPE_F32;
+    auto ld = [io32](const void* a, size_t i) { return io32 ? (double)((const float*)a)[i] : ((const double*)a)[i]; };
+    auto st = [io32](void* a, size_t i, double v) { if (io32) ((float*)a)[i] = (float)v; else ((double*)a)[i] = v; };
+
+    GnDims d;
+    d.N = NT > 0 ? NT : p.horizon; d.K = K; d.n = 2 * d.N; d.mc = d.N * K; d.ms = 2 * NB * d.N; d.m = d.mc + d.ms + 2 * d.n;
+    const int N = d.N, n = d.n, m = d.m;
+    const GnMem W = carve_gn<NX>(sm, d);
+    GnConst c;
+    {
+        const double g1 = p.alpha1 + p.alpha2, g2 = p.alpha1 * p.alpha2;
+        c.w0 = 1.0 - g1 + g2; c.w1 = g1 - 2.0; c.w2 = 1.0;
+    }
+    c.Rrob = p.robot_radius; c.beta = p.beta; c.circles_only = p.circles_only; c.blo = -p.v_max; c.bhi = p.v_max;
+    GnPar q;
+    q.dt = p.dt; q.Lr = p.rear_ax_dist; q.v_min = p.v_min; q.v_max = p.v_max; q.mass = p.mass; q.inertia = p.inertia; q.rad = p.robot_radius;
+    if (lane < 6) W.cq[lane] = p.Q[lane];
+    if (lane < 2) { W.cq[6 + lane] = p.R[lane]; W.cq[8 + lane] = p.u_lo[lane]; W.cq[10 + lane] = p.u_hi[lane]; }
+    for (int i = lane; i < NX; i += 64) { W.xs[i] = ld(X, prob * NX + i); W.xg[i] = i < 2 ? ld(goal, prob * 2 + i) : 0.0; }
+    if (lane < 2) W.up[lane] = ld(u_prev, prob * 2 + lane);
+    const size_t obase = p.obs_shared ? 0 : (size_t)prob * K * 7;
+    for (int e = lane; e < K * 7; e += 64) W.obs[e] = ld(obs, obase + e);
+    for (int e = lane; e < NX * n; e += 64) W.Ph[e] = 0.0;                  // Phi_0 = 0
+    SC_SYNC();
+    for (int i = lane; i < n; i += 64) {                                   // set_initial_guess: u_prev, strictly inside the box
+        const double lo = W.cq[8 + (i & 1)], hi = W.cq[10 + (i & 1)], pad = 0.005 * (hi - lo);
+        W.z[i] = fmin(fmax(W.up[i & 1], lo + pad), hi - pad);
+    }
+    SC_SYNC();
+
+    // grad f = sum_k Phi_k' 2 Q (x_k - xg) + r-term; gs = sf grad f
+    auto grad_f = [&](double sf) {
+        for (int i = lane; i < n; i += 64) {
+            double acc = 0.0;
+            for (int k = 1; k <= N; ++k) {
+#pragma unroll
+                for (int s_ = 0; s_ < NX; ++s_)
+                    acc += W.Ph[(size_t)(k * NX + s_) * n + i] * (2.0 * W.cq[s_] * (W.xs[k * NX + s_] - W.xg[s_]));
+            }
+            const double prev = i >= 2 ? W.z[i - 2] : W.up[i];
+            acc += 2.0 * W.cq[6 + (i & 1)] * (W.z[i] - prev);
+            if (i + 2 < n) acc -= 2.0 * W.cq[6 + (i & 1)] * (W.z[i + 2] - W.z[i]);
+            W.gs[i] = sf * acc;
+        }
+        SC_SYNC();
+    };
+
+    double f = gn_eval<MODEL>(W.z, W, d, c, q, lane, true);
+    grad_f(1.0);
+    double gmx = 0.0;
+    for (int i = lane; i < n; i += 64) gmx = fmax(gmx, fabs(W.gs[i]));
+    gmx = gmax_(gmx);
+    const double sf = fmin(1.0, 100.0 / fmax(1e-12, gmx));
+    double mu = p.mu_init;
+    for (int i = lane; i < m; i += 64) { const double s = fmax(W.g[i], 1e-2); W.s[i] = s; W.lam[i] = mu / s; }
+    for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
+    SC_SYNC();
+
+    int status = SC_STATUS_INACCURATE, it = 0;
+    const double tau = 0.995;
+    double nu_m = 10.0, delta_last = 0.0, e_best = 1e300;
+    int n_acc = 0;
+    const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
+    for (it = 1; it <= p.max_iter; ++it) {
+        if (it > 1) f = gn_eval<MODEL>(W.z, W, d, c, q, lane, true);
+        grad_f(sf);
+        gn_jt<MODEL>(W.lam, W.rd, W, d, c, lane);
+        double e_d = 0.0, e_p = 0.0, e_c0 = 0.0, lmx = 0.0;
+        for (int i = lane; i < n; i += 64) { const double r = W.gs[i] - W.rd[i]; W.rd[i] = r; e_d = fmax(e_d, fabs(r)); }
+        for (int i = lane; i < m; i += 64) {
+            const double s = W.s[i], l = W.lam[i];
+            e_p = fmax(e_p, fabs(W.g[i] - s)); e_c0 = fmax(e_c0, fabs(s * l)); lmx = fmax(lmx, l);
+        }
+        e_d = gmax_(e_d); e_p = gmax_(e_p); e_c0 = gmax_(e_c0); lmx = gmax_(lmx);
+        const double e_opt = fmax(e_d, fmax(e_p, e_c0));
+        if (e_opt < e_best) {
+            e_best = e_opt;
+            for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
+        }
+        if (e_opt <= p.tol) { status = SC_STATUS_OPTIMAL; break; }
+        n_acc = e_opt <= p.acceptable_tol ? n_acc + 1 : 0;
+        if (n_acc >= acc_iter) break;
+        if (lmx > 1e10) { status = SC_STATUS_INFEASIBLE; break; }
+        if (!(e_opt < 1e300)) break;
+        for (;;) {
+            double e_c = 0.0;
+            for (int i = lane; i < m; i += 64) e_c = fmax(e_c, fabs(W.s[i] * W.lam[i] - mu));
+            e_c = gmax_(e_c);
+            const double e_mu = fmax(e_d, fmax(e_p, e_c));
+            if (e_mu <= 10.0 * mu && mu > p.mu_min) mu = fmax(p.mu_min, fmin(0.2 * mu, mu * sqrt(mu)));
+            else break;
+        }
+        for (int i = lane; i < m; i += 64) {
+            const double s = W.s[i], l = W.lam[i], sig = l / s;
+            W.vb[i] = mu / s - sig * (W.g[i] - s);
+            W.ds[i] = sig;                                                // sigma, read below; ds proper is written after the solve
+        }
+        SC_SYNC();
+        gn_jt<MODEL>(W.vb, W.rhs, W, d, c, lane);
+        for (int i = lane; i < n; i += 64) W.rhs[i] = -W.gs[i] + W.rhs[i];
+        // stage blocks Psi_k (6 x 6 over a_k, b_k, c_k): sum_j sig v v' (v = [w0 dh_a; w1 dh_b; w2 dh_c]) - sum_j lam w_p Hh_p
+        for (int e = lane; e < 36 * N; e += 64) {
+            const int k = e / 36, r = (e - 36 * k) / 6, cc = e - 36 * k - 6 * r, pr = r >> 1, pc = cc >> 1;
+            const double wr = pr == 0 ? c.w0 : (pr == 1 ? c.w1 : c.w2), wc = pc == 0 ? c.w0 : (pc == 1 ? c.w1 : c.w2);
+            double acc = 0.0;
+            for (int j = 0; j < K; ++j) {
+                const int row = k * K + j, er = (3 * k + pr) * K + j, ec = (3 * k + pc) * K + j;
+                const double l = W.lam[row], sig = W.ds[row];
+                acc += sig * (wr * W.dh[2 * er + (r & 1)]) * (wc * W.dh[2 * ec + (cc & 1)]);
+                if (pr == pc) acc -= l * wr * W.hh[3 * er + (r & 1) + (cc & 1)];
+            }
+            W.Psi[e] = acc;
+        }
+        // Gauss-Newton cost Hessian  Hc = 2 sum_k Phi_k' Q Phi_k + 2 D' R D  (lower triangle, mirrored)
+        for (int e = lane; e < n * (n + 1) / 2; e += 64) {
+            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while ((i + 1) * (i + 2) / 2 <= e) ++i;
+            while (i * (i + 1) / 2 > e) --i;
+            const int j = e - i * (i + 1) / 2;
+            double acc = 0.0;
+            for (int k = 1; k <= N; ++k) {
+#pragma unroll
+                for (int s_ = 0; s_ < NX; ++s_)
+                    acc += W.cq[s_] * W.Ph[(size_t)(k * NX + s_) * n + i] * W.Ph[(size_t)(k * NX + s_) * n + j];
+            }
+            acc *= 2.0;
+            const double ri = W.cq[6 + (i & 1)];
+            if (i == j) acc += 2.0 * ri + (i + 2 < n ? 2.0 * ri : 0.0);
+            if (i == j + 2) acc -= 2.0 * ri;
+            W.Hc[(size_t)i * n + j] = acc;
+            W.Hc[(size_t)j * n + i] = acc;
+        }
+        SC_SYNC();
+        for (int e = lane; e < 6 * N * n; e += 64) {                          // T = Psi G
+            const int row = e / n, col_ = e - row * n, k = row / 6, r = row - 6 * k;
+            double acc = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) acc += W.Psi[36 * k + 6 * r + cc] * W.G[(size_t)(6 * k + cc) * n + col_];
+            W.T[e] = acc;
+        }
+        SC_SYNC();
+        for (int e = lane; e < n * (n + 1) / 2; e += 64) {                    // M = sf Hc + G' T + speed rows + box
+            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while ((i + 1) * (i + 2) / 2 <= e) ++i;
+            while (i * (i + 1) / 2 > e) --i;
+            const int j = e - i * (i + 1) / 2;
+            double acc = sf * W.Hc[(size_t)i * n + j];
+            for (int r = 0; r < 6 * N; ++r) acc += W.G[(size_t)r * n + i] * W.T[(size_t)r * n + j];
+            if constexpr (NB > 0) {
+                for (int k = 1; k <= N; ++k) {
+                    const int r0 = d.mc + 2 * (k - 1);
+                    acc += (W.ds[r0] + W.ds[r0 + 1]) * W.Ph[(size_t)(k * NX + Mdl::BIDX) * n + i] * W.Ph[(size_t)(k * NX + Mdl::BIDX) * n + j];
+                }
+            }
+            if (i == j) acc += W.ds[d.mc + d.ms + i] + W.ds[d.mc + d.ms + n + i];
+            W.M[(size_t)i * n + j] = acc;
+            W.M[(size_t)j * n + i] = acc;
+        }
+        SC_SYNC();
+        double delta = 0.0;
+        bool ok = false;
+        for (int t = 0; t < 40 && !ok; ++t) {
+            if constexpr (NT > 0) {
+                ok = gn_chol_reg<2 * NT>(W.M, W.rhs, W.L, W.dz, delta, lane);
+            } else {
+                for (int e = lane; e < n * n; e += 64) W.L[e] = W.M[e] + ((e / n == e % n) ? delta : 0.0);
+                SC_SYNC();
+                ok = gn_cholesky(W.L, n, lane);
+            }
+            if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
+        }
+        if (!ok) break;
+        if (delta > 0.0) delta_last = delta;
+        if constexpr (NT == 0) {
+            for (int i = lane; i < n; i += 64) W.dz[i] = W.rhs[i];
+            SC_SYNC();
+            gn_chol_solve(W.L, W.dz, n, lane);
+        }
+        for (int r = lane; r < 6 * N; r += 64) {
+            double acc = 0.0;
+            for (int i = 0; i < n; ++i) acc += W.G[(size_t)r * n + i] * W.dz[i];
+            W.pdz[r] = acc;
+        }
+        double gdz = 0.0;
+        for (int i = lane; i < n; i += 64) gdz += W.gs[i] * W.dz[i];
+        SC_SYNC();
+        double rs_min = 0.0, rl_min = 0.0, sum_ds_s = 0.0, sum_rp = 0.0, sum_log = 0.0, sum_g = 0.0;
+        for (int i = lane; i < m; i += 64) {
+            const double s = W.s[i], l = W.lam[i], rp = W.g[i] - s, sig = W.ds[i];
+            sum_g += fabs(W.g[i]);
+            double jd;
+            if (i < d.mc) {
+                const int k = i / K, j = i - k * K;
+                jd = 0.0;
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp) {
+                    const int ep = (3 * k + pp) * K + j;
+                    const double wv = pp == 0 ? c.w0 : (pp == 1 ? c.w1 : c.w2);
+                    jd += wv * (W.dh[2 * ep] * W.pdz[6 * k + 2 * pp] + W.dh[2 * ep + 1] * W.pdz[6 * k + 2 * pp + 1]);
+                }
+            } else if (i < d.mc + d.ms) {
+                const int r = i - d.mc, k = (r >> 1) + 1;
+                double acc = 0.0;
+                for (int cc = 0; cc < n; ++cc) acc += W.Ph[(size_t)(k * NX + Mdl::BIDX) * n + cc] * W.dz[cc];
+                jd = (r & 1) ? acc : -acc;
+            } else if (i < d.mc + d.ms + n) {
+                jd = -W.dz[i - d.mc - d.ms];
+            } else {
+                jd = W.dz[i - d.mc - d.ms - n];
+            }
+            const double dsi = jd + rp;
+            const double dl = -sig * dsi - (l - mu / s);
+            const double rs = dsi / s, rl = dl / l;
+            rs_min = fmin(rs_min, rs); rl_min = fmin(rl_min, rl);
+            sum_ds_s += rs; sum_rp += fabs(rp); sum_log += log(s);
+            W.dlam[i] = dl;
+            W.vb[i] = dsi;                                                // ds (W.ds still holds sigma for other lanes' rows)
+        }
+        SC_SYNC();
+        for (int i = lane; i < m; i += 64) W.ds[i] = W.vb[i];
+        rs_min = gmin(rs_min); rl_min = gmin(rl_min); sum_ds_s = gsum(sum_ds_s); sum_rp = gsum(sum_rp); sum_log = gsum(sum_log);
+        gdz = gsum(gdz); sum_g = gsum(sum_g);
+        SC_SYNC();
+        const double ap = rs_min < 0.0 ? fmin(1.0, -tau / rs_min) : 1.0, ad = rl_min < 0.0 ? fmin(1.0, -tau / rl_min) : 1.0;
+        nu_m = fmax(nu_m, 1.1 * lmx);
+        const double phi0 = sf * f - mu * sum_log + nu_m * sum_rp;
+        const double dphi = gdz - mu * sum_ds_s - nu_m * sum_rp;
+        const double noise_rows = 1e-15 * nu_m * sum_g;                  // round-off of far dummy-obstacle rows (oracle: row_noise)
+        double alpha = ap;
+        bool accepted = false;
+        for (int ls = 0; ls < 12; ++ls) {
+            for (int i = lane; i < n; i += 64) W.zt[i] = W.z[i] + alpha * W.dz[i];
+            SC_SYNC();
+            const double ft = gn_eval<MODEL>(W.zt, W, d, c, q, lane, false);
+            double srp = 0.0, slog = 0.0;
+            for (int i = lane; i < m; i += 64) {
+                const double s_t = W.s[i] + alpha * W.ds[i];
+                slog += log(s_t); srp += fabs(W.g[i] - s_t);
+            }
+            slog = gsum(slog); srp = gsum(srp);
+            const double phit = sf * ft - mu * slog + nu_m * srp;
+            if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0) + noise_rows) { accepted = true; break; }
+            alpha *= 0.5;
+        }
+        if (!accepted) break;
+        for (int i = lane; i < n; i += 64) W.z[i] = W.z[i] + alpha * W.dz[i];
+        for (int i = lane; i < m; i += 64) {
+            const double s = W.s[i] + alpha * W.ds[i];
+            double l = W.lam[i] + ad * W.dlam[i];
+            const double mus = mu / s;
+            l = fmin(fmax(l, 1e-10 * mus), 1e10 * mus);
+            W.s[i] = s; W.lam[i] = l;
+        }
+        SC_SYNC();
+    }
+    if (it > p.max_iter) it = p.max_iter;
+    if (status != SC_STATUS_OPTIMAL && e_best <= p.acceptable_tol) {
+        SC_SYNC();
+        for (int i = lane; i < n; i += 64) W.z[i] = W.zb[i];
+        status = SC_STATUS_OPTIMAL;
+    }
+    SC_SYNC();
+    gn_eval<MODEL>(W.z, W, d, c, q, lane, false);
+    if (status != SC_STATUS_OPTIMAL) {
+        double g_min = 1e300;
+        for (int i = lane; i < m; i += 64) g_min = fmin(g_min, W.g[i]);
+        g_min = gmin(g_min);
+        if (g_min < -1e-6) status = SC_STATUS_INFEASIBLE;
+        else if (status != SC_STATUS_INFEASIBLE) status = SC_STATUS_INACCURATE;
+    }
+    if (lane < 2) st(u_out, prob * 2 + lane, W.z[lane]);
+    if (lane == 0) {
+        status_out[prob] = status;
+        if (iters_out) iters_out[prob] = it;
+    }
+    if (z_out) for (int i = lane; i < n; i += 64) st(z_out, prob * n + i, W.z[i]);
+}
+
+template <int MODEL>
+static hipError_t mpcgn_launch_m(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
+                                 const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream) {
+    const size_t lds = mpcgn_lds_doubles(p.horizon, K, GnModel<MODEL>::NX, GnModel<MODEL>::NB) * sizeof(double);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    auto launch = [&](auto kern) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out);
+        return hipGetLastError();
+    };
+    if (p.horizon == 10) return launch(mpcgn_kernel<MODEL, 10>);
+    return launch(mpcgn_kernel<MODEL, 0>);
+}
+
+}  // namespace
+
+size_t mpcgn_lds_bytes(int model_id, int N, int K) {
+    const int nx = model_id == SC_MODEL_QUAD2D ? 6 : 4;
+    return mpcgn_lds_doubles(N, K, nx, 0) * sizeof(double);
+}
+
+hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
+                        const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream) {
+    switch (p.model_id) {
+        case SC_MODEL_DOUBLE_INTEGRATOR2D:
+            return mpcgn_launch_m<SC_MODEL_DOUBLE_INTEGRATOR2D>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        case SC_MODEL_QUAD2D:
+            return mpcgn_launch_m<SC_MODEL_QUAD2D>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        default:
+            return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace sc

@@ -4,3 +4,4 @@ from .optimal_decay_mpc_cbf import OptimalDecayMPCCBF, BatchedOptimalDecayMPCCBF
 from .optimal_decay_cbf_qp import OptimalDecayCBFQP, BatchedOptimalDecayCBFQP  # noqa: F401
 from .manipulator_cbf_qp import ManipulatorCBFQP, BatchedManipulatorCBFQP  # noqa: F401
 from .mpc_cbf_linear import LinearMPCCBF, BatchedLinearMPCCBF  # noqa: F401
+from .mpc_cbf_gn import GnMPCCBF, BatchedGnMPCCBF  # noqa: F401

@@ -102,6 +102,9 @@ class MPCCBF:
         if cls is MPCCBF and robot_spec.get("model") in ("SingleIntegrator2D", "Quad3D"):
             from .mpc_cbf_linear import LinearMPCCBF
             return LinearMPCCBF(robot, robot_spec, *args, **kwargs)
+        if cls is MPCCBF and robot_spec.get("model") in ("DoubleIntegrator2D", "Quad2D"):
+            from .mpc_cbf_gn import GnMPCCBF
+            return GnMPCCBF(robot, robot_spec, *args, **kwargs)
         return super().__new__(cls)
 
     def __init__(self, robot, robot_spec, show_mpc_traj=False, num_obs=5, device=0):

@@ -1,0 +1,159 @@
+"""MPC-CBF for DoubleIntegrator2D and Quad2D on the gfx950 kernel csrc/mpc_gn.hip.
+
+``safe_control_amd.MPCCBF(robot, robot_spec, ...)`` returns a ``GnMPCCBF`` for these models (the reference serves every
+model from the one MPCCBF class, position_control/mpc_cbf.py:7-100); ``BatchedGnMPCCBF`` solves B agents per launch on
+device tensors.  No CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib
+from ..robots.spec import complete_robot_spec
+from .mpc_cbf import apply_mpc_overrides, pad_obstacles
+
+GN_MODELS = ("DoubleIntegrator2D", "Quad2D")
+
+
+def model_constants(robot_spec):
+    """Weights, gains and bounds of MPCCBF.__init__ / create_mpc for the model (mpc_cbf.py:28-36, :60-76, :193-216) and the
+    barrier inflation of its agent_barrier_dt (double_integrator2D.py:222, quad2D.py:179: 1.01)."""
+    m = robot_spec["model"]
+    if m == "DoubleIntegrator2D":
+        return dict(nx=4, Q=[50.0, 50.0, 20.0, 20.0], R=[0.5, 0.5], cbf_param={"alpha1": 0.2, "alpha2": 0.2}, beta=1.01,
+                    u_lo=[-robot_spec["ax_max"], -robot_spec["ay_max"]], u_hi=[robot_spec["ax_max"], robot_spec["ay_max"]],
+                    circles_only=False)
+    if m == "Quad2D":
+        return dict(nx=6, Q=[25.0, 25.0, 50.0, 10.0, 10.0, 50.0], R=[0.5, 0.5], cbf_param={"alpha1": 0.15, "alpha2": 0.15},
+                    beta=1.01, u_lo=[robot_spec["f_min"]] * 2, u_hi=[robot_spec["f_max"]] * 2, circles_only=True)
+    raise NotImplementedError(m)
+
+
+def make_params(robot_spec, mc, cbf_param, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=100,
+                mu_init=0.1, mu_min=1e-9, acceptable_tol=1e-5):
+    p = _lib.MpcGnParams()
+    p.model_id = _lib.MODEL_IDS[robot_spec["model"]]
+    p.io_dtype = io_dtype
+    p.horizon = int(horizon)
+    p.max_iter = int(max_iter)
+    p.obs_shared = 1 if obs_shared else 0
+    p.circles_only = 1 if mc["circles_only"] else 0
+    p.dt = float(dt)
+    for i, v in enumerate(mc["Q"]):
+        p.Q[i] = float(v)
+    for i in range(2):
+        p.R[i], p.u_lo[i], p.u_hi[i] = float(mc["R"][i]), float(mc["u_lo"][i]), float(mc["u_hi"][i])
+    p.alpha1, p.alpha2 = float(cbf_param["alpha1"]), float(cbf_param["alpha2"])
+    p.v_min = float(robot_spec.get("v_min", 0.0))
+    p.v_max = float(robot_spec.get("v_max", 0.0))
+    p.rear_ax_dist = float(robot_spec.get("rear_ax_dist", 0.0))
+    p.mass = float(robot_spec.get("mass", 0.0))
+    p.inertia = float(robot_spec.get("inertia", 0.0))
+    p.robot_radius = float(radius)
+    p.beta = float(mc["beta"])
+    p.tol, p.acceptable_tol, p.mu_init, p.mu_min = float(tol), float(acceptable_tol), float(mu_init), float(mu_min)
+    return p
+
+
+class GnMPCCBF:
+    """Drop-in for position_control.mpc_cbf.MPCCBF with a DoubleIntegrator2D or Quad2D robot."""
+
+    def __init__(self, robot, robot_spec, show_mpc_traj=False, num_obs=5, device=0):
+        self.robot = robot
+        self.robot_spec = complete_robot_spec(robot_spec)
+        self.status = "optimal"                               # mpc_cbf.py:10
+        self.show_mpc_traj = show_mpc_traj
+        self.num_obs = int(num_obs)
+        self.device = device
+        self.horizon = int(self.robot_spec.get("mpc_horizon", 10))
+        self.dt = robot.dt
+        self._mc = model_constants(self.robot_spec)
+        self.Q, self.R = np.diag(self._mc["Q"]), np.array(self._mc["R"])
+        self.n_states, self.n_controls = self._mc["nx"], 2
+        self.goal = np.array([0, 0])
+        self.cbf_param = apply_mpc_overrides(dict(self._mc["cbf_param"]), self.robot_spec)
+        self.obs = None
+        self.setup_control_problem()
+
+    def setup_control_problem(self):
+        if not 1 <= self.horizon <= 32:
+            raise ValueError("mpc_horizon must be in [1, 32]")
+        self._lib = _lib.load()
+        self.u_prev = np.zeros(2)
+        self.z = np.zeros(2 * self.horizon)
+        self.iterations = 0
+        self.solver_status = "optimal"
+
+    def update_tvp(self, goal, obs):
+        self.goal = np.array(goal)
+        self.obs = pad_obstacles(obs, self.num_obs)
+
+    def solve_control_problem(self, robot_state, control_ref, nearest_obs):
+        self.update_tvp(control_ref["goal"], nearest_obs)
+        if control_ref["state_machine"] != "track":           # mpc_cbf.py:379-381
+            return control_ref["u_ref"]
+        nx = self._mc["nx"]
+        X = np.zeros(nx)
+        xs = np.asarray(robot_state, dtype=np.float64).reshape(-1)[:nx]
+        X[: xs.shape[0]] = xs
+        g = np.ascontiguousarray(np.asarray(self.goal, dtype=np.float64).reshape(-1)[:2])
+        obs = np.ascontiguousarray(self.obs, dtype=np.float64)
+        p = make_params(self.robot_spec, self._mc, self.cbf_param, self.horizon, self.dt, self.robot.robot_radius, _lib.DTYPE_F64)
+        u = np.zeros(2); st = np.zeros(1, dtype=np.int32); it = np.zeros(1, dtype=np.int32)
+        rc = self._lib.sc_mpcgn_solve_batch_host(
+            C.byref(p), 1, self.num_obs, X.ctypes.data, self.u_prev.ctypes.data, g.ctypes.data, obs.ctypes.data,
+            u.ctypes.data, st.ctypes.data, it.ctypes.data, self.z.ctypes.data, int(self.device))
+        _lib.check(rc, "sc_mpcgn_solve_batch_host")
+        self.iterations = int(it[0])
+        self.solver_status = _lib.STATUS_STRINGS[int(st[0])]
+        self.u_prev = u.copy()
+        return u.reshape(-1, 1).copy()
+
+
+class BatchedGnMPCCBF:
+    """``solve(X[B,nx], u_prev[B,2], goal[B,2], obs[B,K,7] | obs[K,7])`` -> ``u[B,2]``, ``status[B]``, ``iters[B]`` (and
+    ``z[B,2N]`` if asked); nx = 4 (DoubleIntegrator2D) or 6 (Quad2D)."""
+
+    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=100):
+        self.robot_spec = complete_robot_spec(robot_spec)
+        if self.robot_spec["model"] not in GN_MODELS:
+            raise NotImplementedError(f"this controller serves {GN_MODELS}")
+        self.dt = float(dt)
+        self.io_dtype = {"f32": _lib.DTYPE_F32, "f64": _lib.DTYPE_F64}[io_dtype]
+        self.horizon = int(horizon if horizon is not None else self.robot_spec.get("mpc_horizon", 10))
+        self._mc = model_constants(self.robot_spec)
+        self.Q, self.R = np.diag(self._mc["Q"]), np.array(self._mc["R"])
+        self.cbf_param = cbf_param or apply_mpc_overrides(dict(self._mc["cbf_param"]), self.robot_spec)
+        self.tol, self.max_iter = tol, max_iter
+        self._lib = _lib.load()
+
+    @property
+    def torch_dtype(self):
+        import torch
+        return torch.float32 if self.io_dtype == _lib.DTYPE_F32 else torch.float64
+
+    def solve(self, X, u_prev, goal, obs, want_z=False):
+        import torch
+        dt_ = self.torch_dtype
+        for name, t in (("X", X), ("u_prev", u_prev), ("goal", goal), ("obs", obs)):
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == dt_):
+                raise ValueError(f"{name} must be a contiguous CUDA tensor of dtype {dt_}")
+        B = X.shape[0]
+        nx = self._mc["nx"]
+        shared = obs.dim() == 2
+        K = obs.shape[-2]
+        if X.shape != (B, nx) or u_prev.shape != (B, 2) or goal.shape != (B, 2) or obs.shape[-1] != 7 \
+                or (not shared and obs.shape[0] != B):
+            raise ValueError(f"expected X[B,{nx}], u_prev[B,2], goal[B,2], obs[B,K,7] or obs[K,7]")
+        u = torch.empty((B, 2), dtype=dt_, device=X.device)
+        status = torch.empty((B,), dtype=torch.int32, device=X.device)
+        iters = torch.empty((B,), dtype=torch.int32, device=X.device)
+        z = torch.empty((B, 2 * self.horizon), dtype=dt_, device=X.device) if want_z else None
+        p = make_params(self.robot_spec, self._mc, self.cbf_param, self.horizon, self.dt, self.robot_spec["radius"],
+                        self.io_dtype, obs_shared=shared, tol=self.tol, max_iter=self.max_iter)
+        stream = torch.cuda.current_stream(X.device).cuda_stream
+        rc = self._lib.sc_mpcgn_solve_batch(
+            C.byref(p), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(),
+            status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        _lib.check(rc, "sc_mpcgn_solve_batch")
+        return (u, status, iters, z) if want_z else (u, status, iters)
