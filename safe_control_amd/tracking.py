@@ -52,9 +52,8 @@ class BatchedTrackingController:
         self.integrator = self.model in ("SingleIntegrator2D", "DoubleIntegrator2D")
         if self.integrator and enable_rotation:
             raise ValueError("SingleIntegrator2D / DoubleIntegrator2D run with enable_rotation=False")
-        if self.integrator and self.pos_controller_type != "cbf_qp" and \
-                not (self.model == "SingleIntegrator2D" and self.pos_controller_type == "mpc_cbf"):
-            raise ValueError("integrators: 'cbf_qp' (both) or 'mpc_cbf' (SingleIntegrator2D, the linear-model kernel)")
+        if self.integrator and self.pos_controller_type not in ("cbf_qp", "mpc_cbf"):
+            raise ValueError("integrators: 'cbf_qp' or 'mpc_cbf' (SingleIntegrator2D: csrc/mpc_lin.hip, DoubleIntegrator2D: csrc/mpc_gn.hip)")
         self.dt = float(dt)
         self.enable_rotation = bool(enable_rotation)
         self.dyn_obs = bool(dyn_obs)
@@ -100,6 +99,9 @@ class BatchedTrackingController:
             if self.model == "SingleIntegrator2D":             # linear model: csrc/mpc_lin.hip
                 from .position_control.mpc_cbf_linear import BatchedLinearMPCCBF
                 cls = BatchedLinearMPCCBF
+            elif self.model == "DoubleIntegrator2D":           # barrier through the robot's own step(): csrc/mpc_gn.hip
+                from .position_control.mpc_cbf_gn import BatchedGnMPCCBF
+                cls = BatchedGnMPCCBF
             else:
                 cls = BatchedMPCCBF if self.pos_controller_type == "mpc_cbf" else BatchedOptimalDecayMPCCBF
             self.mpc = cls(self.robot_spec, dt=self.dt, io_dtype=io_dtype)

@@ -377,3 +377,46 @@ def test_single_integrator_closed_loop_with_mpc(golden_dir):
                 break
         n_track += state.get("n", 0)
     assert n_track >= T
+
+
+def test_double_integrator_closed_loop_with_mpc(golden_dir):
+    """--model di with the default --algo mpc_cbf, batched: select -> Gauss-Newton MPC launch (csrc/mpc_gn.hip) -> apply,
+    against the oracle loop with oracle/mpc_gn.py behind solve_fn."""
+    from oracle import mpc_cbf as M, mpc_gn as G
+    g = np.load(os.path.join(golden_dir, "closed_loop_integrators.npz"))
+    obs = g["di/obs"]
+    K = 6
+    spec = {"model": "DoubleIntegrator2D", "v_max": 1.0, "a_max": 1.0, "radius": 0.25, "num_constraints": K}
+    X0 = np.array([[2.0, 2.0, 0.0, 0.3, np.pi / 2], [6.0, 1.0, -0.2, 0.1, 2.6], [1.0, 6.0, 0.3, -0.3, -1.2]])   # the last starts in 'stop'
+    wl = [np.array([[2.0, 12.0], [12.0, 12.0]]), np.array([[1.0, 4.0]]), np.array([[1.0, 12.0]])]
+    T = 40
+    ctl = sca.BatchedTrackingController(X0, dict(spec), controller_type={"pos": "mpc_cbf"}, obs=obs, io_dtype="f64",
+                                        enable_rotation=False)
+    ctl.set_waypoints(wl)
+    ret, tX, tU = ctl.control_step(T, record=True)
+    tX = tX.cpu().numpy(); ret = ret.cpu().numpy()
+    mdl = G.di_model({"v_max": 1.0, "a_max": 1.0, "radius": 0.25})
+    n_track = 0
+    for i in range(len(X0)):
+        state = {"up": np.zeros(2)}
+
+        def solve_fn(X, cref, nobs, state=state):
+            if cref["state_machine"] != "track":
+                return np.asarray(cref["u_ref"], dtype=np.float64).reshape(-1), 0
+            o = M.pad_obstacles(None if nobs is None else list(nobs), K)
+            u, st, it = G.solve(mdl, X[:4], state["up"], cref["goal"], o)
+            state["up"] = u
+            state["n"] = state.get("n", 0) + 1
+            return u, 0
+
+        t = tracking.TrackingOracle(R.MODEL_DI, X0[i, :4], {"v_max": 1.0, "a_max": 1.0, "radius": 0.25}, dt=0.05, obs=obs,
+                                    num_constraints=K, solve_fn=solve_fn, enable_rotation=False, yaw0=X0[i, 4])
+        t.set_waypoints(wl[i])
+        for k in range(T):
+            r = t.control_step()
+            np.testing.assert_allclose(tX[k, i], t.X, rtol=0, atol=2e-5, err_msg=f"agent {i} step {k}")
+            if r != 0:
+                assert ret[i] == r
+                break
+        n_track += state.get("n", 0)
+    assert n_track >= T
