@@ -222,8 +222,9 @@ int sc_mpclin_solve_batch_host(const sc_mpclin_params* params, const double* mod
  * own step(): x1 = step(x_k, u_k), x2 = step(x1, u_k) (double_integrator2D.py:222-272 with the speed rescaled to v_max
  * :79-107; quad2D.py:179-206), so the barrier points are functions of (x_k, u_k) and not predicted positions.  Weights /
  * gains / bounds of mpc_cbf.py: DI Q = diag(50,50,20,20), R = (.5,.5), alpha .2, |a| <= (ax_max, ay_max); Quad2D Q =
- * diag(25,25,50,10,10,50), R = (.5,.5), alpha .15, f_min <= u <= f_max.  Interior point with a Gauss-Newton Hessian
- * (oracle/mpc_gn.py).  KinematicBicycle2D has the same structure but needs the exact Hessian (not served: SC_ERR_UNSUPPORTED).
+ * diag(25,25,50,10,10,50), R = (.5,.5), alpha .15, f_min <= u <= f_max.  Interior point as sc_mpccbf_solve_batch (exact
+ * Hessian for Quad2D, Gauss-Newton for the linear DoubleIntegrator2D; oracle/mpc_gn.py).  KinematicBicycle2D has the same
+ * structure but the solver does not converge reliably on it yet (not served: SC_ERR_UNSUPPORTED).
  * X [B,nx] (nx = 4, or 6 for Quad2D), u_prev [B,2], goal [B,2], obs [B,K,7] (or [K,7]) padded like update_tvp;
  * u_out [B,2], status_out [B], iters_out [B] or NULL, z_out [B, 2*horizon] or NULL.  One NLP per wavefront, f64 arithmetic.
  */

@@ -21,9 +21,11 @@ integrators.npz, quad2d.npz).
               Quad2D f_min <= u <= f_max                                                            mpc_cbf.py:193-216
 
 Because S applies u_k twice (and clips), the barrier points b_k = pos(S(x_k,u_k)), c_k = pos(S(S(x_k,u_k),u_k)) are NOT the
-predicted positions; they are functions of (x_k, u_k).  Hessian: Gauss-Newton -- exact second derivatives of the cost in
-the states and of h in the barrier points, no second derivatives of the dynamics (the solver is a quasi-Newton interior
-point method with this matrix; it is the algorithm the HIP kernel csrc/mpc_gn.hip follows iterate for iterate).
+predicted positions; they are functions of (x_k, u_k).  Hessian: the Gauss-Newton part (exact second derivatives of the cost
+in the states and of h in the barrier points) plus, per model flag `exact`, the second derivatives of the dynamics and of
+step o step weighted by the costates of the Lagrangian (Quad2D: on; DoubleIntegrator2D: off -- its dynamics are linear and
+the curvature of the speed rescaling changes nothing measurable).  The HIP kernel csrc/mpc_gn.hip follows this iterate for
+iterate.
 Rows: [CBF (stage major, obstacle minor) | state bounds hi - x, x - lo (stage major) | u_hi - z | z - u_lo].
 """
 import math
@@ -114,6 +116,48 @@ def q2_F(x, u, spec, dt, jac=False):
     return xn, A, B
 
 
+# ---- contracted second derivatives  sum_i c_i grad^2 F_i(x, u)  over the variables (x, u), (nx + 2) x (nx + 2) -----------
+def kb_H(x, u, spec, dt, c, step=False):
+    """KinematicBicycle2D, F and S alike: the clipped component (the speed) is linear in (x, u) either way."""
+    th, v, b = x[2], x[3], u[1]
+    s, co = math.sin(th), math.cos(th)
+    H = np.zeros((6, 6))
+    H[2, 2] = c[0] * dt * (-v * co + v * s * b) + c[1] * dt * (-v * s - v * co * b)
+    H[2, 3] = c[0] * dt * (-s - co * b) + c[1] * dt * (co - s * b)
+    H[2, 5] = c[0] * (-dt * v * co) + c[1] * (-dt * v * s)
+    H[3, 5] = c[0] * (-dt * s) + c[1] * (dt * co) + c[2] * dt / spec["rear_ax_dist"]
+    return H + np.triu(H, 1).T
+
+
+def di_H(x, u, spec, dt, c, step=False):
+    """DoubleIntegrator2D: F is linear; S rescales w = v + dt u to norm v_max when above it."""
+    H = np.zeros((6, 6))
+    if not step:
+        return H
+    w = np.array([x[2] + dt * u[0], x[3] + dt * u[1]])
+    vm = math.hypot(w[0], w[1])
+    if vm <= spec["v_max"]:
+        return H
+    Hw = np.zeros((2, 2))
+    for d in range(2):
+        for a in range(2):
+            for b in range(2):
+                Hw[a, b] += c[2 + d] * spec["v_max"] * (-((d == a) * w[b] + (d == b) * w[a] + (a == b) * w[d]) / vm ** 3
+                                                      + 3.0 * w[d] * w[a] * w[b] / vm ** 5)
+    Jw = np.zeros((2, 6)); Jw[0, 2] = 1.0; Jw[1, 3] = 1.0; Jw[0, 4] = dt; Jw[1, 5] = dt
+    return Jw.T @ Hw @ Jw
+
+
+def q2_H(x, u, spec, dt, c, step=False):
+    m = spec["mass"]
+    s, co = math.sin(x[2]), math.cos(x[2])
+    T = u[0] + u[1]
+    H = np.zeros((8, 8))
+    H[2, 2] = c[3] * (dt * s * T / m) + c[4] * (-dt * co * T / m)
+    H[2, 6] = H[2, 7] = c[3] * (-dt * co / m) + c[4] * (-dt * s / m)
+    return H + np.triu(H, 1).T
+
+
 def kb_model(spec=None, dt=0.05):
     """EXPERIMENTAL, not served by the HIP kernel: with the Gauss-Newton matrix this interior point converges on well
     under half of the test draws for the bicycle (fast heading dynamics, large tracking residuals: the dropped second
@@ -121,7 +165,7 @@ def kb_model(spec=None, dt=0.05):
     s = dict(wheel_base=0.4, radius=0.3, rear_ax_dist=0.2, v_max=3.5, a_max=5.0, v_min=0.2)
     s["beta_max"] = math.atan((0.2 / 0.4) * math.tan(math.radians(32)))
     s.update(spec or {})
-    return dict(name="KinematicBicycle2D", nx=4, nu=2, F=kb_F, S=kb_S, spec=s, dt=dt, Q=np.array([50.0, 50.0, 1.0, 1.0]),
+    return dict(name="KinematicBicycle2D", nx=4, nu=2, F=kb_F, S=kb_S, H=kb_H, spec=s, dt=dt, Q=np.array([50.0, 50.0, 1.0, 1.0]),
                 R=np.array([0.5, 5000.0]), alpha1=0.1, alpha2=0.1, beta=1.1, radius=s["radius"],
                 u_lo=np.array([-s["a_max"], -s["beta_max"]]), u_hi=np.array([s["a_max"], s["beta_max"]]),
                 xb=[(3, -s["v_max"], s["v_max"])], circles_only=True)
@@ -131,15 +175,16 @@ def di_model(spec=None, dt=0.05):
     s = dict(a_max=1.0, v_max=1.0, radius=0.25)
     s.update(spec or {})
     s.setdefault("ax_max", s["a_max"]); s.setdefault("ay_max", s["a_max"])
-    return dict(name="DoubleIntegrator2D", nx=4, nu=2, F=di_F, S=di_S, spec=s, dt=dt, Q=np.array([50.0, 50.0, 20.0, 20.0]),
+    return dict(name="DoubleIntegrator2D", nx=4, nu=2, F=di_F, S=di_S, H=di_H, spec=s, dt=dt, Q=np.array([50.0, 50.0, 20.0, 20.0]),
                 R=np.array([0.5, 0.5]), alpha1=0.2, alpha2=0.2, beta=1.01, radius=s["radius"],
-                u_lo=np.array([-s["ax_max"], -s["ay_max"]]), u_hi=np.array([s["ax_max"], s["ay_max"]]), xb=[], circles_only=False)
+                u_lo=np.array([-s["ax_max"], -s["ay_max"]]), u_hi=np.array([s["ax_max"], s["ay_max"]]), xb=[], circles_only=False,
+                exact=False)      # linear dynamics: Gauss-Newton is exact except for the curvature of the speed rescaling, which is left out
 
 
 def quad2d_model(spec=None, dt=0.05):
     s = dict(mass=1.0, inertia=0.01, f_min=1.0, f_max=10.0, radius=0.25)
     s.update(spec or {})
-    return dict(name="Quad2D", nx=6, nu=2, F=q2_F, S=q2_F, spec=s, dt=dt, Q=np.array([25.0, 25.0, 50.0, 10.0, 10.0, 50.0]),
+    return dict(name="Quad2D", nx=6, nu=2, F=q2_F, S=q2_F, H=q2_H, spec=s, dt=dt, Q=np.array([25.0, 25.0, 50.0, 10.0, 10.0, 50.0]),
                 R=np.array([0.5, 0.5]), alpha1=0.15, alpha2=0.15, beta=1.01, radius=s["radius"],
                 u_lo=np.full(2, s["f_min"]), u_hi=np.full(2, s["f_max"]), xb=[], circles_only=True)
 
@@ -173,6 +218,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     X = np.zeros((N + 1, nx)); X[0] = np.asarray(x0, dtype=np.float64)[:nx]
     Phi = np.zeros((N + 1, nx, n))
     pts = np.zeros((N, 3, 2)); G = np.zeros((N, 3, 2, n))
+    jac = [None] * N
     for k in range(N):
         E = np.zeros((nu, n)); E[:, k * nu:(k + 1) * nu] = np.eye(nu)
         if der:
@@ -183,6 +229,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
             Y1 = S1x @ Phi[k] + S1u @ E
             Y2 = S2x @ Y1 + S2u @ E
             G[k, 0] = Phi[k][0:2]; G[k, 1] = Y1[0:2]; G[k, 2] = Y2[0:2]
+            jac[k] = (A, S1x, S1u, S2x, y1)
         else:
             xn = mdl["F"](X[k], U[k], spec, dt)
             y1 = mdl["S"](X[k], U[k], spec, dt)
@@ -246,6 +293,35 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
         for p in range(3):
             Om = -wp[p] * np.einsum("j,jab->ab", lc[k], Hh[k, p])
             W += G[k, p].T @ Om @ G[k, p]
+    if P.get("exact_hessian", mdl.get("exact", True)):
+        # second derivatives of the dynamics and of step o step, weighted by the costates of the Lagrangian
+        #   p_N = mu_N,  p_k = mu_k + (d points_k / d x_k)' nu + A_k' p_{k+1};   mu_k = 2 Q (x_k - xg) + bound multipliers,
+        #   nu_p = -w_p sum_j lam_kj dh_j(point_p);   W += V_k' H_k V_k,  V_k = [Phi_k; E_k],
+        #   H_k = H_F(x_k,u_k; p_{k+1}) + H_S(x_k,u_k; P'nu_1) + D' H_S(y1,u_k; P'nu_2) D + H_S(x_k,u_k; S2x' P'nu_2)
+        ls = lam[N * K:N * K + 2 * nb * N].reshape(N, nb, 2) if nb else None
+        pk = np.zeros(nx)
+        for k in range(N, -1, -1):
+            mu_k = np.zeros(nx)
+            if k >= 1:
+                mu_k = 2.0 * Q * (X[k] - xg)
+                for bi, (idx, lo, hi) in enumerate(xb):
+                    mu_k[idx] += ls[k - 1, bi, 0] - ls[k - 1, bi, 1]
+            if k == N:
+                pk = mu_k
+                continue
+            A, S1x, S1u, S2x, y1 = jac[k]
+            nu_ = [-wp[p] * (lc[k] @ dh[k, p]) for p in range(3)]
+            c1 = np.zeros(nx); c1[0:2] = nu_[1]
+            c2 = np.zeros(nx); c2[0:2] = nu_[2]
+            D = np.zeros((nx + 2, nx + 2)); D[:nx, :nx] = S1x; D[:nx, nx:] = S1u; D[nx:, nx:] = np.eye(2)
+            Hk = mdl["H"](X[k], U[k], spec, dt, pk) + mdl["H"](X[k], U[k], spec, dt, c1, True) \
+                + D.T @ mdl["H"](y1, U[k], spec, dt, c2, True) @ D + mdl["H"](X[k], U[k], spec, dt, S2x[0:2].T @ nu_[2], True)
+            E = np.zeros((nu, n)); E[:, k * nu:(k + 1) * nu] = np.eye(nu)
+            V = np.vstack([Phi[k], E])
+            W += V.T @ Hk @ V
+            g_pts = np.zeros(nx); g_pts[0:2] = nu_[0]
+            g_pts += S1x[0:2].T @ nu_[1] + (S2x[0:2] @ S1x).T @ nu_[2]
+            pk = mu_k + g_pts + A.T @ pk
     out.update(W=W)
     return out
 
