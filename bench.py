@@ -251,6 +251,40 @@ def linear_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
             "mean_ipm_iterations": float(it.double().mean().item())}
 
 
+def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
+    """MPC-CBF for DoubleIntegrator2D / Quad2D (csrc/mpc_gn.hip): the barrier steps the state with the robot's
+    own step(), one NLP per wavefront."""
+    import numpy as np
+    import torch
+    import safe_control_amd as sca
+    from safe_control_amd import workloads as W
+    ctl = sca.BatchedGnMPCCBF({"model": model}, io_dtype="f32", horizon=N)
+    Xd, gn, _, on = W.du_cbfqp_batch(B, K, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    if model == "Quad2D":
+        Xn = np.zeros((B, 6)); Xn[:, 0:2] = Xd[:, 0:2]; Xn[:, 2] = rng.uniform(-0.2, 0.2, B); Xn[:, 3:5] = rng.uniform(-0.5, 0.5, (B, 2))
+        up0 = np.full((B, 2), 0.5 * (ctl.robot_spec["f_min"] + ctl.robot_spec["f_max"]))
+    else:
+        Xn = np.zeros((B, 4)); Xn[:, 0:2] = Xd[:, 0:2]; Xn[:, 2:4] = rng.uniform(-0.7, 0.7, (B, 2))
+        up0 = np.zeros((B, 2))
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    X, g, ob, up = t(Xn), t(gn), t(on), t(up0)
+    u, st, it = ctl.solve(X, up, g, ob)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        u, st, it = ctl.solve(X, up, g, ob)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return {"workload": f"{B}-agent batch {model} MPC-CBF, horizon N={N}, {K} obstacles",
+            "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
+            "optimal_fraction": float((st == 0).double().mean().item()),
+            "infeasible_fraction": float((st == 1).double().mean().item()),
+            "mean_ipm_iterations": float(it.double().mean().item())}
+
+
 def closed_loop_leg(dev, B=4096, T=200, seed=0):
     """BASELINE config 2, closed-loop variant: B DynamicUnicycle2D agents track waypoints through the 14-circle
     scene of examples/test_tracking.py for T control steps (selection + nominal input + CBF-QP + step + collision
@@ -443,6 +477,8 @@ def main():
             res["manipulator_cbf_qp"] = manip_leg(dev)
             res["quad3d_mpc_cbf"] = linear_mpc_leg(dev, "Quad3D")
             res["single_integrator_mpc_cbf"] = linear_mpc_leg(dev, "SingleIntegrator2D")
+            res["double_integrator_mpc_cbf"] = gn_mpc_leg(dev, "DoubleIntegrator2D")
+            res["quad2d_mpc_cbf"] = gn_mpc_leg(dev, "Quad2D")
             res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
         if ws == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(X.double().cpu().numpy(), ur.double().cpu().numpy(),

@@ -93,3 +93,39 @@ def test_solver_reaches_a_local_optimum_slsqp_cannot_improve(mk):
         assert r.fun >= info["f"] * (1 - 1e-6) - 1e-6
         n_ok += 1
     assert n_ok >= 3
+
+
+@pytest.mark.parametrize("mk", [G.kb_model, G.di_model, G.quad2d_model])
+def test_exact_hessian_against_finite_differences_of_the_lagrangian_gradient(mk):
+    """Costate-weighted second derivatives of the dynamics and of step o step (oracle/mpc_gn.py: evaluate, exact_hessian):
+    W = d/dz (grad f - J' lam) at fixed multipliers, for the served models and for the bicycle kept for later."""
+    mdl = mk()
+    rng = np.random.default_rng(0)
+    N = 5
+    P = G.params(mdl, N, exact_hessian=True)
+    nx = mdl["nx"]
+    x0 = np.zeros(nx); x0[:2] = [1.0, 1.0]
+    if mdl["name"] == "KinematicBicycle2D":
+        x0[2], x0[3] = 0.4, 1.5
+    elif mdl["name"] == "DoubleIntegrator2D":
+        x0[2:4] = [0.7, 0.75]                                                   # speed rescaling active
+    else:
+        x0[2] = 0.1; x0[3:5] = [0.5, 0.2]
+    goal = np.array([4.0, 3.0]); obs = np.array([[2.0, 1.8, 0.4, 0, 0, 0, 0], [3.0, 3.0, 0.5, 0, 0, 0, 0]])
+    lo, hi = mdl["u_lo"], mdl["u_hi"]
+    z = np.tile((lo + hi) / 2, N) + rng.normal(size=2 * N) * 0.1 * (hi - lo).mean()
+    up = (lo + hi) / 2
+    m = G.evaluate(x0, z, up, goal, obs, P, level=0)["g"].shape[0]
+    lam = rng.uniform(0, 1, m)
+    W = G.evaluate(x0, z, up, goal, obs, P, lam, 2)["W"]
+
+    def gl(zz):
+        e = G.evaluate(x0, zz, up, goal, obs, P, level=1)
+        return e["grad"] - e["J"].T @ lam
+    eps = 1e-6
+    Wfd = np.zeros_like(W)
+    for i in range(2 * N):
+        d = np.zeros(2 * N); d[i] = eps
+        Wfd[:, i] = (gl(z + d) - gl(z - d)) / (2 * eps)
+    assert np.abs(Wfd - W).max() <= 1e-7 * np.abs(Wfd).max()
+    assert np.abs(W - W.T).max() <= 1e-12 * np.abs(W).max()
