@@ -28,20 +28,15 @@
 #include "../../include/safe_control_amd.h"
 #include "sc_math.hpp"
 #include "mpc_chol.hpp"
+#include "mpc_ipm_common.hpp"
 
 namespace sc {
 
 namespace {
 
-template <typename F>
-__device__ __forceinline__ double gred(double v, F f) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v = f(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ double gsum(double v) { return gred(v, [](double a, double b) { return a + b; }); }
-__device__ __forceinline__ double gmin(double v) { return gred(v, [](double a, double b) { return fmin(a, b); }); }
-__device__ __forceinline__ double gmax_(double v) { return gred(v, [](double a, double b) { return fmax(a, b); }); }
+__device__ __forceinline__ double gsum(double v) { return ipm::wsum(v); }
+__device__ __forceinline__ double gmin(double v) { return ipm::wmin(v); }
+__device__ __forceinline__ double gmax_(double v) { return ipm::wmax(v); }
 
 struct GnPar {                      // model constants (wave-uniform)
     double dt, Lr, v_min, v_max, mass, inertia, rad;
@@ -196,34 +191,6 @@ __device__ inline GnMem carve_gn(double* b, const GnDims& d) {
 
 struct GnConst { double w0, w1, w2, Rrob, beta, blo, bhi; int circles_only; };
 
-__device__ inline void gn_barrier(double px_, double py_, const double* o, const GnConst& c, bool derivs, double& h, double& d0,
-                                  double& d1, double& hxx, double& hxy, double& hyy) {
-    if (c.circles_only || o[6] < 0.5) {
-        const double d = c.Rrob + o[2];
-        const double ex = px_ - o[0], ey = py_ - o[1];
-        h = (ex * ex + ey * ey) - c.beta * d * d;
-        d0 = 2.0 * ex; d1 = 2.0 * ey; hxx = 2.0; hxy = 0.0; hyy = 2.0;
-        return;
-    }
-    const double a = fmax(fabs(o[2]), 1e-3) + c.Rrob, b = fmax(fabs(o[3]), 1e-3) + c.Rrob;
-    const double e = fmax(fabs(o[4]), 2.0);
-    double st, ct;
-    sincos(o[5], &st, &ct);
-    const double dx = px_ - o[0], dy = py_ - o[1];
-    const double px = ct * dx + st * dy, py = -st * dx + ct * dy;
-    const double ax = fabs(px) / a, ay = fabs(py) / b;
-    h = pow(ax, e) + pow(ay, e) - 1.0;
-    if (!derivs) { d0 = d1 = hxx = hxy = hyy = 0.0; return; }
-    const double sx = px > 0 ? 1.0 : (px < 0 ? -1.0 : 0.0), sy = py > 0 ? 1.0 : (py < 0 ? -1.0 : 0.0);
-    const double gpx = e * pow(ax, e - 1) / a * sx, gpy = e * pow(ay, e - 1) / b * sy;
-    const double cxx = e * (e - 1) * pow(ax, e - 2) / (a * a), cyy = e * (e - 1) * pow(ay, e - 2) / (b * b);
-    d0 = ct * gpx - st * gpy;
-    d1 = st * gpx + ct * gpy;
-    hxx = ct * ct * cxx + st * st * cyy;
-    hxy = ct * st * cxx - st * ct * cyy;
-    hyy = st * st * cxx + ct * ct * cyy;
-}
-
 // rollout (+ sensitivities), f, barrier values (+ derivatives), g.  Point index: 3 k + p, p = 0 (a_k), 1 (b_k), 2 (c_k).
 template <int MODEL>
 __device__ __forceinline__ double gn_eval(const double* zv, const GnMem& W, const GnDims& d, const GnConst& c, const GnPar& q,
@@ -303,7 +270,7 @@ __device__ __forceinline__ double gn_eval(const double* zv, const GnMem& W, cons
     for (int e = lane; e < 3 * N * K; e += 64) {
         const int pt = e / K, j = e - pt * K;
         double h, d0, d1, hxx, hxy, hyy;
-        gn_barrier(W.pts[2 * pt], W.pts[2 * pt + 1], W.obs + 7 * j, c, derivs, h, d0, d1, hxx, hxy, hyy);
+        ipm::ipm_barrier(W.pts[2 * pt], W.pts[2 * pt + 1], W.obs + 7 * j, c.Rrob, c.beta, c.circles_only != 0, derivs, h, d0, d1, hxx, hxy, hyy);
         W.hk[e] = h;
         if (derivs) {
             W.dh[2 * e] = d0; W.dh[2 * e + 1] = d1;
@@ -356,54 +323,6 @@ __device__ __forceinline__ void gn_jt(const double* v, double* out, const GnMem&
         out[i] = acc - v[d.mc + d.ms + i] + v[d.mc + d.ms + n + i];
     }
     SC_SYNC();
-}
-
-__device__ __forceinline__ bool gn_cholesky(double* A, int n, int lane) {       // LDS, run-time order (small n: column by column)
-    bool ok = true;
-    for (int j = 0; j < n; ++j) {
-        const double dd = A[j * n + j];
-        if (!(dd > 0.0)) ok = false;
-        const double piv = sqrt(dd);
-        SC_SYNC();
-        for (int i = j + lane; i < n; i += 64) A[i * n + j] = (i == j) ? piv : A[i * n + j] / piv;
-        SC_SYNC();
-        const int rem = n - j - 1;
-        for (int e = lane; e < rem * rem; e += 64) {
-            const int i = j + 1 + e / rem, k = j + 1 + e % rem;
-            if (k <= i) A[i * n + k] -= A[i * n + j] * A[k * n + j];
-        }
-        SC_SYNC();
-        if (!ok) break;
-    }
-    return ok;
-}
-__device__ __forceinline__ void gn_chol_solve(const double* L, double* b, int n, int lane) {
-    for (int j = 0; j < n; ++j) {
-        if (lane == 0) b[j] = b[j] / L[j * n + j];
-        SC_SYNC();
-        const double yj = b[j];
-        for (int i = j + 1 + lane; i < n; i += 64) b[i] -= L[i * n + j] * yj;
-        SC_SYNC();
-    }
-    for (int j = n - 1; j >= 0; --j) {
-        if (lane == 0) b[j] = b[j] / L[j * n + j];
-        SC_SYNC();
-        const double xj = b[j];
-        for (int i = lane; i < j; i += 64) b[i] -= L[j * n + i] * xj;
-        SC_SYNC();
-    }
-}
-template <int nn>
-__device__ __noinline__ bool gn_chol_reg(const double* M, const double* rhs, double* Lt, double* out, double delta, int lane) {
-    double a[nn], diag;
-    const int row = lane < nn ? lane : 0;
-#pragma unroll
-    for (int k = 0; k < nn; ++k) a[k] = M[row * nn + k] + (lane == k ? delta : 0.0);
-    if (!chol_reg<nn>(a, lane, diag)) return false;
-    const double x = chol_solve_reg<nn>(a, diag, rhs[row], Lt, lane);
-    if (lane < nn) out[lane] = x;
-    SC_SYNC();
-    return true;
 }
 
 // NT > 0: compile-time horizon (register Cholesky of order 2 NT); 0: run-time horizon, LDS Cholesky.
@@ -700,11 +619,11 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         bool ok = false;
         for (int t = 0; t < 40 && !ok; ++t) {
             if constexpr (NT > 0) {
-                ok = gn_chol_reg<2 * NT>(W.M, W.rhs, W.L, W.dz, delta, lane);
+                ok = ipm::chol_reg_solve<2 * NT>(W.M, W.rhs, W.L, W.dz, delta, lane);
             } else {
                 for (int e = lane; e < n * n; e += 64) W.L[e] = W.M[e] + ((e / n == e % n) ? delta : 0.0);
                 SC_SYNC();
-                ok = gn_cholesky(W.L, n, lane);
+                ok = ipm::cholesky_lds(W.L, n, lane);
             }
             if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
         }
@@ -713,7 +632,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         if constexpr (NT == 0) {
             for (int i = lane; i < n; i += 64) W.dz[i] = W.rhs[i];
             SC_SYNC();
-            gn_chol_solve(W.L, W.dz, n, lane);
+            ipm::chol_solve_lds(W.L, W.dz, n, lane);
         }
         for (int r = lane; r < 6 * N; r += 64) {
             double acc = 0.0;
