@@ -20,7 +20,7 @@
 //   * Hessian of the Lagrangian, exact: sf (2 sum Phi_k' Q Phi_k + 2 D' R D) + G' Psi G + box terms (Psi = the 6 x 6 stage blocks
 //     of J' Sigma J - sum lam grad^2 h over (a_k, b_k, c_k)) + sum_k V_k' H_k V_k, V_k = [Phi_k; E_k], where H_k collects the
 //     second derivatives of the dynamics and of step o step weighted by the costates p_k of the Lagrangian (a backward
-//     pass, again wave-uniform in registers);
+//     pass, again wave-uniform in registers; per model in closed form -- Quad2D: two scalars per stage);
 //   * register Cholesky, fraction-to-boundary, l1-merit backtracking exactly as kernels 3 and 7.
 // Arithmetic is f64; the caller's arrays are f32 or f64.
 #include <hip/hip_runtime.h>
@@ -51,6 +51,7 @@ template <> struct GnModel<SC_MODEL_DOUBLE_INTEGRATOR2D> {
     // and including that curvature changes neither the convergence statistics nor the iteration counts on the test draws
     // while the backward pass costs 70 % more time per solve (measured) -- so it is left out (the oracle does the same).
     static constexpr bool EXACT = false;
+    static constexpr int TIDX = 0;
     template <bool JAC, bool STEP>
     static __device__ __forceinline__ void map(const double* x, const double* u, const GnPar& q, double* xn, double (*A)[4], double (*B)[2]) {
         const double dt = q.dt;
@@ -81,40 +82,11 @@ template <> struct GnModel<SC_MODEL_DOUBLE_INTEGRATOR2D> {
         }
         xn[2] = w0; xn[3] = w1;
     }
-    // H += sum_i c_i grad^2 (F or S)_i over (x, u): F is linear; S rescales w = v + dt u to norm v_max when above it
-    template <bool STEP>
-    static __device__ __forceinline__ void hess(const double* x, const double* u, const GnPar& q, const double* c, double (*H)[6]) {
-        if constexpr (STEP) {
-            const double dt = q.dt, w[2] = {x[2] + dt * u[0], x[3] + dt * u[1]};
-            const double vm2 = w[0] * w[0] + w[1] * w[1];
-            if (vm2 > q.v_max * q.v_max) {
-                const double vm = sqrt(vm2), i3 = q.v_max / (vm2 * vm), i5 = 3.0 * q.v_max / (vm2 * vm2 * vm);
-                double Hw[2][2];
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int dd = 0; dd < 2; ++dd)
-                            acc += c[2 + dd] * (-((dd == a ? w[b] : 0.0) + (dd == b ? w[a] : 0.0) + (a == b ? w[dd] : 0.0)) * i3 +
-                                                w[dd] * w[a] * w[b] * i5);
-                        Hw[a][b] = acc;
-                    }
-                const int wi[4] = {0, 1, 0, 1};                                // variables 2, 3, 4, 5 -> component of w, scale
-                const double sc[4] = {1.0, 1.0, dt, dt};
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) H[2 + a][2 + b] += sc[a] * sc[b] * Hw[wi[a]][wi[b]];
-            }
-        }
-    }
 };
 
 template <> struct GnModel<SC_MODEL_QUAD2D> {
     static constexpr int NX = 6, NB = 0, BIDX = 0;
-    // thrust direction: exact second derivatives take the solver from 97 % to 99-100 % optimal and from 21.5 to 13.8 iterations
+    // thrust direction: exact second derivatives take the solver from 97 % to 99 % optimal and from 21.5 to 13.8 iterations
     static constexpr bool EXACT = true;
     template <bool JAC, bool STEP>
     static __device__ __forceinline__ void map(const double* x, const double* u, const GnPar& q, double* xn, double (*A)[6], double (*B)[2]) {
@@ -137,16 +109,42 @@ template <> struct GnModel<SC_MODEL_QUAD2D> {
             B[3][0] = B[3][1] = dt * (-s * im); B[4][0] = B[4][1] = dt * (c * im); B[5][0] = dt * ri; B[5][1] = -dt * ri;
         }
     }
-    // only vx+ = vx - dt sin(theta) T / m and vz+ = vz + dt (cos(theta) T / m - g) are nonlinear: entries (theta, theta), (theta, u)
-    template <bool STEP>
-    static __device__ __forceinline__ void hess(const double* x, const double* u, const GnPar& q, const double* c, double (*H)[8]) {
-        double s, co;
-        sincos(x[2], &s, &co);
-        const double dt = q.dt, T = u[0] + u[1], im = 1.0 / q.mass;
-        const double htt = c[3] * (dt * s * T * im) + c[4] * (-dt * co * T * im);
-        const double htu = c[3] * (-dt * co * im) + c[4] * (-dt * s * im);
-        H[2][2] += htt;
-        H[2][6] += htu; H[6][2] += htu; H[2][7] += htu; H[7][2] += htu;
+    // Second-order terms in closed form.  Only vx+ = vx - dt sin(theta) T / m and vz+ = vz + dt (cos(theta) T / m - g) are
+    // nonlinear, in (theta, u): sum_i c_i grad^2 F_i = a e_t e_t' + b (e_t s' + s e_t'), a = c_3 dt sin T / m - c_4 dt cos T / m,
+    // b = -(c_3 cos + c_4 sin) dt / m.  For stage k the weights are c = p_{k+1} + S2x' P' nu_2 (the point b_k is linear in
+    // (x, u); c_k = pos(F(F(x, u), u)) reaches the nonlinear rows through x + dt v), the term D' H(y1; P' nu_2) D vanishes
+    // (P' nu_2 has no velocity component).  Costates: p_N = mu_N, p_k = mu_k + (d points_k / d x_k)' nu + A_k' p_{k+1}, with
+    // A_k = I + dt (e_0 e_3' + e_1 e_4' + e_2 e_5') + A32 e_3 e_2' + A42 e_4 e_2'.  Wave-uniform: every lane, in registers.
+    static constexpr int TIDX = 2;
+    static __device__ __forceinline__ void second_order(const double* xs, const double* z, const double* y, const double* cq,
+                                                        const double* xg, double* ab, int N, double sf, const GnPar& q, int lane) {
+        const double dt = q.dt, im = 1.0 / q.mass;
+        double p[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) p[i] = sf * 2.0 * cq[i] * (xs[N * 6 + i] - xg[i]);
+        for (int k = N - 1; k >= 0; --k) {
+            double s, co;
+            sincos(xs[k * 6 + 2], &s, &co);
+            const double T = z[2 * k] + z[2 * k + 1];
+            const double n0x = -y[6 * k], n0y = -y[6 * k + 1], n1x = -y[6 * k + 2], n1y = -y[6 * k + 3], n2x = -y[6 * k + 4], n2y = -y[6 * k + 5];
+            const double c3 = p[3] + dt * n2x, c4 = p[4] + dt * n2y;
+            if (lane == 0) {
+                ab[2 * k] = c3 * (dt * s * T * im) + c4 * (-dt * co * T * im);
+                ab[2 * k + 1] = c3 * (-dt * co * im) + c4 * (-dt * s * im);
+            }
+            if (k >= 1) {
+                const double A32 = dt * (-co * im) * T, A42 = dt * (-s * im) * T;
+                double np_[6];
+                np_[0] = p[0] + n0x + n1x + n2x;
+                np_[1] = p[1] + n0y + n1y + n2y;
+                np_[2] = p[2] + A32 * p[3] + A42 * p[4] + dt * (A32 * n2x + A42 * n2y);
+                np_[3] = p[3] + dt * p[0] + dt * n1x + 2.0 * dt * n2x;
+                np_[4] = p[4] + dt * p[1] + dt * n1y + 2.0 * dt * n2y;
+                np_[5] = p[5] + dt * p[2];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) p[i] = np_[i] + sf * 2.0 * cq[i] * (xs[k * 6 + i] - xg[i]);
+            }
+        }
     }
 };
 
@@ -157,7 +155,7 @@ struct GnMem {
     double *obs, *hk, *dh, *hh;                           // 7K | 3N K | 6N K | 9N K
     double *g, *s, *lam, *ds, *dlam, *vb;                 // m each
     double *Psi, *Hc, *M, *L;                             // 36 N | n n | n n | (L: scratch in T)
-    double *Hk, *HV;                                      // N (nx+2)^2 | N (nx+2) n: second-order terms of the dynamics
+    double *Hk;                                           // 2 N: second-order terms of the dynamics (a_k, b_k)
 };
 
 struct GnDims { int N, K, n, m, mc, ms; };
@@ -165,8 +163,7 @@ struct GnDims { int N, K, n, m, mc, ms; };
 __host__ __device__ inline size_t mpcgn_lds_doubles(int N, int K, int nx, int nb) {
     const size_t n = 2 * (size_t)N, m = (size_t)N * K + 2 * (size_t)nb * N + 2 * n;
     size_t tot = 12 + nx + 2 + 7 * n + (size_t)(N + 1) * nx + (size_t)(N + 1) * nx * n + 18 * (size_t)N + 12 * (size_t)N * n +
-                 7 * (size_t)K + 18 * (size_t)N * K + 6 * m + 36 * (size_t)N + 2 * n * n +
-                 (size_t)N * (nx + 2) * (nx + 2) + (size_t)N * (nx + 2) * n;
+                 7 * (size_t)K + 18 * (size_t)N * K + 6 * m + 36 * (size_t)N + 2 * n * n + 2 * (size_t)N;
     const size_t need_l = n * (n + 1), have = 6 * (size_t)N * n;             // transpose scratch of the register Cholesky lives in T
     return tot + (need_l > have ? need_l - have : 0);
 }
@@ -184,7 +181,7 @@ __device__ inline GnMem carve_gn(double* b, const GnDims& d) {
     W.obs = take(7 * K); W.hk = take(3 * N * K); W.dh = take(6 * N * K); W.hh = take(9 * N * K);
     W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m); W.vb = take(m);
     W.Psi = take(36 * N); W.Hc = take((size_t)n * n); W.M = take((size_t)n * n);
-    W.Hk = take((size_t)N * (NX + 2) * (NX + 2)); W.HV = take((size_t)N * (NX + 2) * n);
+    W.Hk = take(2 * (size_t)N);
     W.T = take((size_t)6 * N * n); W.L = W.T;                     // T is dead once M is assembled
     return W;
 }
@@ -325,6 +322,12 @@ __device__ __forceinline__ void gn_jt(const double* v, double* out, const GnMem&
     SC_SYNC();
 }
 
+#ifdef SC_GN_PROF
+#define GP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += (double)(t_ - tlast); tlast = t_; } while (0)
+#else
+#define GP(i) do { } while (0)
+#endif
+
 // NT > 0: compile-time horizon (register Cholesky of order 2 NT); 0: run-time horizon, LDS Cholesky.
 template <int MODEL, int NT>
 __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, const long long B, const int K,
@@ -401,108 +404,22 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
     double nu_m = 10.0, delta_last = 0.0, e_best = 1e300;
     int n_acc = 0;
     const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
+#ifdef SC_GN_PROF
+    double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
+#endif
     for (it = 1; it <= p.max_iter; ++it) {
+        GP(11);
         if (it > 1) f = gn_eval<MODEL>(W.z, W, d, c, q, lane, true);
+        GP(0);
         grad_f(sf);
         gn_jt<MODEL>(W.lam, W.rd, W, d, c, lane);
-        bool any_h = false;                                               // some stage has second-order terms
-        if constexpr (Mdl::EXACT)
+        GP(1);
         // ---- second derivatives of the dynamics and of step o step, weighted by the costates of the Lagrangian (oracle:
-        // evaluate, exact_hessian): backward pass over the stages, wave-uniform, every lane redundantly in registers.
-        // W.y still holds A' lam per point (= -nu).  Leaves the stage matrices H_k in LDS.
-        {
-            constexpr int NV = NX + 2;
-            static_assert(NV * NV <= 64, "one lane per entry of the stage matrix");
-            any_h = false;
-            double pk[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) pk[i] = sf * 2.0 * W.cq[i] * (W.xs[N * NX + i] - W.xg[i]);
-            for (int k = N - 1; k >= 0; --k) {
-                double x[NX], xn[NX], y1[NX], y2[NX];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) x[i] = W.xs[k * NX + i];
-                const double u[2] = {W.z[2 * k], W.z[2 * k + 1]};
-                double A[NX][NX], Bm[NX][2], S1x[NX][NX], S1u[NX][2], S2x[NX][NX], S2u[NX][2];
-                Mdl::template map<true, false>(x, u, q, xn, A, Bm);
-                Mdl::template map<true, true>(x, u, q, y1, S1x, S1u);
-                Mdl::template map<true, true>(y1, u, q, y2, S2x, S2u);
-                double nu_[3][2];
-#pragma unroll
-                for (int pp = 0; pp < 3; ++pp) { nu_[pp][0] = -W.y[6 * k + 2 * pp]; nu_[pp][1] = -W.y[6 * k + 2 * pp + 1]; }
-                double H[NV][NV], H2[NV][NV];
-#pragma unroll
-                for (int a = 0; a < NV; ++a)
-#pragma unroll
-                    for (int b = 0; b < NV; ++b) { H[a][b] = 0.0; H2[a][b] = 0.0; }
-                double c1[NX], c2[NX], c3[NX];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    c1[i] = i < 2 ? nu_[1][i] : 0.0;
-                    c2[i] = i < 2 ? nu_[2][i] : 0.0;
-                    c3[i] = S2x[0][i] * nu_[2][0] + S2x[1][i] * nu_[2][1];
-                }
-                Mdl::template hess<false>(x, u, q, pk, H);
-                Mdl::template hess<true>(x, u, q, c1, H);
-                Mdl::template hess<true>(x, u, q, c3, H);
-                Mdl::template hess<true>(y1, u, q, c2, H2);
-                // H_k = H + D' H2 D,  D = [[S1x, S1u], [0, I]].  The operands are wave-uniform; the two NV x NV products
-                // are spread over the lanes (one entry each) through a scratch in the not-yet-used Psi region instead of
-                // every lane redoing all of them.  Stages with H2 = 0 (an integrator below its speed limit) skip it.
-                double h2n = 0.0, hn = 0.0;
-#pragma unroll
-                for (int a = 0; a < NV; ++a)
-#pragma unroll
-                    for (int b = 0; b < NV; ++b) { h2n += fabs(H2[a][b]); hn += fabs(H[a][b]); }
-                double* sD = W.Psi;                                            // D | H2 | HD, NV*NV each
-                double* sH2 = sD + NV * NV;
-                double* sHD = sH2 + NV * NV;
-                double* Hdst = W.Hk + (size_t)k * NV * NV;
-                if (lane == 0) {
-#pragma unroll
-                    for (int a = 0; a < NV; ++a)
-#pragma unroll
-                        for (int b = 0; b < NV; ++b) {
-                            Hdst[a * NV + b] = H[a][b];
-                            if (h2n > 0.0) {
-                                sH2[a * NV + b] = H2[a][b];
-                                sD[a * NV + b] = a < NX ? (b < NX ? S1x[a][b] : S1u[a][b - NX]) : (a == b ? 1.0 : 0.0);
-                            }
-                        }
-                }
-                any_h = any_h || (hn + h2n > 0.0);
-                if (h2n > 0.0) {
-                    SC_SYNC();
-                    if (lane < NV * NV) {
-                        const int a = lane / NV, b = lane - a * NV;
-                        double acc = 0.0;
-#pragma unroll
-                        for (int t_ = 0; t_ < NV; ++t_) acc += sH2[a * NV + t_] * sD[t_ * NV + b];
-                        sHD[lane] = acc;
-                    }
-                    SC_SYNC();
-                    if (lane < NV * NV) {
-                        const int a = lane / NV, b = lane - a * NV;
-                        double acc = 0.0;
-#pragma unroll
-                        for (int t_ = 0; t_ < NV; ++t_) acc += sD[t_ * NV + a] * sHD[t_ * NV + b];
-                        Hdst[lane] += acc;
-                    }
-                    SC_SYNC();
-                }
-                if (k >= 1) {
-                    double np_[NX];
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) {
-                        double acc = sf * 2.0 * W.cq[i] * (x[i] - W.xg[i]) + (i < 2 ? nu_[0][i] : 0.0) + S1x[0][i] * nu_[1][0] + S1x[1][i] * nu_[1][1];
-#pragma unroll
-                        for (int t_ = 0; t_ < NX; ++t_) acc += c3[t_] * S1x[t_][i] + A[t_][i] * pk[t_];
-                        np_[i] = acc;
-                    }
-#pragma unroll
-                    for (int i = 0; i < NX; ++i) pk[i] = np_[i];
-                }
-            }
-        }
+        // evaluate, exact_hessian).  W.y still holds A' lam per point (= -nu).  Leaves two scalars per stage in W.Hk.
+        if constexpr (Mdl::EXACT) Mdl::second_order(W.xs, W.z, W.y, W.cq, W.xg, W.Hk, N, sf, q, lane);
+        SC_SYNC();
+        GP(2);
         double e_d = 0.0, e_p = 0.0, e_c0 = 0.0, lmx = 0.0;
         for (int i = lane; i < n; i += 64) { const double r = W.gs[i] - W.rd[i]; W.rd[i] = r; e_d = fmax(e_d, fabs(r)); }
         for (int i = lane; i < m; i += 64) {
@@ -536,6 +453,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         SC_SYNC();
         gn_jt<MODEL>(W.vb, W.rhs, W, d, c, lane);
         for (int i = lane; i < n; i += 64) W.rhs[i] = -W.gs[i] + W.rhs[i];
+        GP(3);
         // stage blocks Psi_k (6 x 6 over a_k, b_k, c_k): sum_j sig v v' (v = [w0 dh_a; w1 dh_b; w2 dh_c]) - sum_j lam w_p Hh_p
         for (int e = lane; e < 36 * N; e += 64) {
             const int k = e / 36, r = (e - 36 * k) / 6, cc = e - 36 * k - 6 * r, pr = r >> 1, pc = cc >> 1;
@@ -549,6 +467,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             }
             W.Psi[e] = acc;
         }
+        GP(4);
         // Gauss-Newton cost Hessian  Hc = 2 sum_k Phi_k' Q Phi_k + 2 D' R D  (lower triangle, mirrored)
         for (int e = lane; e < n * (n + 1) / 2; e += 64) {
             int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
@@ -569,24 +488,13 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             W.Hc[(size_t)j * n + i] = acc;
         }
         SC_SYNC();
+        GP(5);
         for (int e = lane; e < 6 * N * n; e += 64) {                          // T = Psi G
             const int row = e / n, col_ = e - row * n, k = row / 6, r = row - 6 * k;
             double acc = 0.0;
 #pragma unroll
             for (int cc = 0; cc < 6; ++cc) acc += W.Psi[36 * k + 6 * r + cc] * W.G[(size_t)(6 * k + cc) * n + col_];
             W.T[e] = acc;
-        }
-        SC_SYNC();
-        if (any_h) {
-            constexpr int NV = NX + 2;
-            for (int e = lane; e < N * NV * n; e += 64) {                       // HV_k = H_k V_k,  V_k = [Phi_k; E_k]
-                const int k = e / (NV * n), a = (e - k * NV * n) / n, i = e - k * NV * n - a * n;
-                double acc = 0.0;
-#pragma unroll
-                for (int b = 0; b < NX; ++b) acc += W.Hk[(size_t)k * NV * NV + a * NV + b] * W.Ph[(size_t)(k * NX + b) * n + i];
-                if ((i >> 1) == k) acc += W.Hk[(size_t)k * NV * NV + a * NV + NX + (i & 1)];
-                W.HV[e] = acc;
-            }
         }
         SC_SYNC();
         for (int e = lane; e < n * (n + 1) / 2; e += 64) {                    // M = sf Hc + G' T + V' H V + speed rows + box
@@ -602,12 +510,11 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
                     acc += (W.ds[r0] + W.ds[r0 + 1]) * W.Ph[(size_t)(k * NX + Mdl::BIDX) * n + i] * W.Ph[(size_t)(k * NX + Mdl::BIDX) * n + j];
                 }
             }
-            if (any_h) {
-                constexpr int NV = NX + 2;
+            if constexpr (Mdl::EXACT) {
+                // V_k' H_k V_k with H_k = a_k e_t e_t' + b_k (e_t s' + s e_t'): t = the model's angle state, s = the two inputs of stage k
                 for (int k = 0; k < N; ++k) {
-#pragma unroll
-                    for (int a = 0; a < NX; ++a) acc += W.Ph[(size_t)(k * NX + a) * n + i] * W.HV[(size_t)(k * NV + a) * n + j];
-                    if ((i >> 1) == k) acc += W.HV[(size_t)(k * NV + NX + (i & 1)) * n + j];
+                    const double ti = W.Ph[(size_t)(k * NX + Mdl::TIDX) * n + i], tj = W.Ph[(size_t)(k * NX + Mdl::TIDX) * n + j];
+                    acc += W.Hk[2 * k] * ti * tj + W.Hk[2 * k + 1] * (ti * ((j >> 1) == k ? 1.0 : 0.0) + ((i >> 1) == k ? 1.0 : 0.0) * tj);
                 }
             }
             if (i == j) acc += W.ds[d.mc + d.ms + i] + W.ds[d.mc + d.ms + n + i];
@@ -615,6 +522,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             W.M[(size_t)j * n + i] = acc;
         }
         SC_SYNC();
+        GP(6);
         double delta = 0.0;
         bool ok = false;
         for (int t = 0; t < 40 && !ok; ++t) {
@@ -634,6 +542,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             SC_SYNC();
             ipm::chol_solve_lds(W.L, W.dz, n, lane);
         }
+        GP(7);
         for (int r = lane; r < 6 * N; r += 64) {
             double acc = 0.0;
             for (int i = 0; i < n; ++i) acc += W.G[(size_t)r * n + i] * W.dz[i];
@@ -684,6 +593,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         const double phi0 = sf * f - mu * sum_log + nu_m * sum_rp;
         const double dphi = gdz - mu * sum_ds_s - nu_m * sum_rp;
         const double noise_rows = 1e-15 * nu_m * sum_g;                  // round-off of far dummy-obstacle rows (oracle: row_noise)
+        GP(8);
         double alpha = ap;
         bool accepted = false;
         for (int ls = 0; ls < 12; ++ls) {
@@ -700,6 +610,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0) + noise_rows) { accepted = true; break; }
             alpha *= 0.5;
         }
+        GP(9);
         if (!accepted) break;
         for (int i = lane; i < n; i += 64) W.z[i] = W.z[i] + alpha * W.dz[i];
         for (int i = lane; i < m; i += 64) {
@@ -731,7 +642,11 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         status_out[prob] = status;
         if (iters_out) iters_out[prob] = it;
     }
+#ifdef SC_GN_PROF
+    if (z_out && lane == 0) for (int i = 0; i < 12; ++i) st(z_out, prob * n + i, prof[i]);
+#else
     if (z_out) for (int i = lane; i < n; i += 64) st(z_out, prob * n + i, W.z[i]);
+#endif
 }
 
 template <int MODEL>
