@@ -62,6 +62,52 @@ def test_argument_validation_without_gpu():
     assert lib.sc_cbfqp_solve_batch(C.byref(p), 0, 8, None, None, None, None, None, None, None, None) == 0
 
 
+def test_argument_validation_of_the_newer_entry_points_without_gpu():
+    """Manipulator2D CBF-QP, linear-model MPC-CBF, step()-barrier MPC-CBF: everything is rejected before a launch."""
+    import safe_control_amd as sca
+    from safe_control_amd.position_control import manipulator_cbf_qp as MQ, mpc_cbf_gn as GN, mpc_cbf_linear as ML
+    from safe_control_amd.robots.linear_models import linear_model
+    lib = _lib.load()
+    buf = np.zeros(4096)
+    ptr = buf.ctypes.data
+    # Manipulator2D
+    spec = sca.complete_robot_spec({"model": "Manipulator2D"})
+    p = MQ.make_params(spec, 1.0, 0.05, 0.25, _lib.DTYPE_F64, 150, (0.0, 0.0))
+    assert lib.sc_manip_cbfqp_solve_batch(C.byref(p), 0, 3, None, None, None, None, None, None, None, None) == 0      # B == 0
+    assert lib.sc_manip_cbfqp_solve_batch(C.byref(p), 1, 0, ptr, ptr, ptr, None, ptr, ptr, None, None) == 1
+    assert lib.sc_manip_cbfqp_solve_batch(C.byref(p), 1, 3, None, ptr, ptr, None, ptr, ptr, None, None) == 1
+    p.num_rows = 251
+    assert lib.sc_manip_cbfqp_solve_batch(C.byref(p), 1, 3, ptr, ptr, ptr, None, ptr, ptr, None, None) == 2
+    assert b"SC_MANIP_MAX_ROWS" in lib.sc_last_error()
+    p.num_rows, p.link_steps[1] = 150, 0
+    assert lib.sc_manip_cbfqp_solve_batch(C.byref(p), 1, 3, ptr, ptr, ptr, None, ptr, ptr, None, None) == 1
+    # linear models
+    mdl = linear_model(sca.complete_robot_spec({"model": "Quad3D"}), 0.05)
+    q = ML.make_params(mdl, mdl["cbf_param"], 10, 0.25, _lib.DTYPE_F64)
+    blob = ML.build_model_blob(lib, q, mdl)
+    bp = blob.ctypes.data
+    assert lib.sc_mpclin_solve_batch(C.byref(q), bp, 0, 8, None, None, None, None, None, None, None, None, None) == 0
+    assert lib.sc_mpclin_solve_batch(C.byref(q), None, 1, 8, ptr, ptr, ptr, ptr, ptr, ptr, None, None, None) == 1     # no model blob
+    assert lib.sc_mpclin_solve_batch(C.byref(q), bp, 1, 0, ptr, ptr, ptr, ptr, ptr, ptr, None, None, None) == 1
+    assert lib.sc_mpclin_solve_batch(C.byref(q), bp, 1, 200, ptr, ptr, ptr, ptr, ptr, ptr, None, None, None) == 2     # LDS
+    q.u_hi[2] = q.u_lo[2]
+    assert lib.sc_mpclin_solve_batch(C.byref(q), bp, 1, 8, ptr, ptr, ptr, ptr, ptr, ptr, None, None, None) == 1
+    q.u_hi[2], q.nu = 10.0, 5
+    assert lib.sc_mpclin_build_model(C.byref(q), ptr, ptr, ptr, ptr, ptr) == 1
+    # step()-barrier models
+    gspec = sca.complete_robot_spec({"model": "Quad2D"})
+    mc = GN.model_constants(gspec)
+    g = GN.make_params(gspec, mc, mc["cbf_param"], 10, 0.05, 0.25, _lib.DTYPE_F64)
+    assert lib.sc_mpcgn_solve_batch(C.byref(g), 0, 8, None, None, None, None, None, None, None, None, None) == 0
+    assert lib.sc_mpcgn_solve_batch(C.byref(g), 1, 8, ptr, ptr, None, ptr, ptr, ptr, None, None, None) == 1
+    g.model_id = _lib.MODEL_IDS["KinematicBicycle2D"]
+    assert lib.sc_mpcgn_solve_batch(C.byref(g), 1, 8, ptr, ptr, ptr, ptr, ptr, ptr, None, None, None) == 2           # not served
+    g.model_id, g.horizon = _lib.MODEL_IDS["Quad2D"], 33
+    assert lib.sc_mpcgn_solve_batch(C.byref(g), 1, 8, ptr, ptr, ptr, ptr, ptr, ptr, None, None, None) == 2
+    g.horizon, g.mass = 10, 0.0
+    assert lib.sc_mpcgn_solve_batch(C.byref(g), 1, 8, ptr, ptr, ptr, ptr, ptr, ptr, None, None, None) == 1
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
