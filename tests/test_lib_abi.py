@@ -124,3 +124,22 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "liboracle" not in txt, f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/safe_control_amd.h is the boundary a C / cgo / JNI caller binds: it must compile as C99 on its own and its
+    structs must have the sizes the ctypes mirrors assume."""
+    import subprocess
+    import safe_control_amd  # noqa: F401
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "safe_control_amd.h"\nint main(void) {\n'
+                   '  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sc_cbfqp_params), sizeof(sc_mpccbf_params), sizeof(sc_tracking_params),\n'
+                   '         sizeof(sc_manip_cbfqp_params), sizeof(sc_mpclin_params), sizeof(sc_mpcgn_params), sizeof(sc_odmpccbf_params));\n'
+                   '  return 0;\n}\n')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    mirrors = [_lib.CbfQpParams, _lib.MpcCbfParams, _lib.TrackingParams, _lib.ManipCbfQpParams, _lib.MpcLinParams, _lib.MpcGnParams,
+               _lib.OdMpcCbfParams]
+    assert sizes == [C.sizeof(m) for m in mirrors]
