@@ -9,11 +9,28 @@
 namespace sc {
 namespace ipm {
 
+// Wave reductions on DPP: a __shfl_xor butterfly is six dependent ds_bpermute round trips per 32-bit half (~100 cycles
+// each for a lone wave) and an interior-point iteration does about twenty reductions.  Four DPP moves (xor 1, xor 2,
+// half-row mirror, row mirror: VALU latency) leave every lane with its 16-lane row total; the four row totals are
+// combined from v_readlane, so the result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mv(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_value(double v, int src) {          // src: compile-time constant lane
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
 template <typename F>
 __device__ __forceinline__ double wred(double v, F f) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) v = f(v, __shfl_xor(v, o));
-    return v;
+    v = f(v, dpp_mv<0xB1>(v));           // quad_perm [1,0,3,2]
+    v = f(v, dpp_mv<0x4E>(v));           // quad_perm [2,3,0,1]
+    v = f(v, dpp_mv<0x141>(v));          // row_half_mirror
+    v = f(v, dpp_mv<0x140>(v));          // row_mirror
+    return f(f(row_value(v, 0), row_value(v, 16)), f(row_value(v, 32), row_value(v, 48)));
 }
 __device__ __forceinline__ double wsum(double v) { return wred(v, [](double a, double b) { return a + b; }); }
 __device__ __forceinline__ double wmin(double v) { return wred(v, [](double a, double b) { return fmin(a, b); }); }
