@@ -11,8 +11,8 @@
 // most violated (normalised) row by a wave arg-min, move along the projection of its normal onto the null space of the
 // active normals until the row is satisfied or a multiplier of an active row reaches zero (that row is dropped), repeat.
 // The active set has at most three rows, so its QR (Gram-Schmidt) is recomputed from the stored normals each time --
-// wave-uniform arithmetic every lane does redundantly; the only cross-lane traffic per round is the arg-min (6 xor
-// steps) and the broadcast of the chosen row.  The objective is strictly convex, so the minimiser is unique and the
+// wave-uniform arithmetic every lane does redundantly; the only cross-lane traffic per round is the arg-min (a DPP
+// reduction, a ballot and a v_readlane) and the broadcast of the chosen row (v_readlane).  The objective is strictly convex, so the minimiser is unique and the
 // oracle's different algorithm (constraint generation around active-set enumeration, oracle/qp.py: solve_qpn) is a real
 // check.  Arithmetic is f64; the caller's arrays are f32 or f64.
 #include <hip/hip_runtime.h>
@@ -27,16 +27,31 @@ namespace {
 
 struct ArgMin { double v; int i; };
 
-__device__ __forceinline__ ArgMin wave_argmin(ArgMin a) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double ov = __shfl_xor(a.v, o);
-        const int oi = __shfl_xor(a.i, o);
-        const bool take = (ov < a.v) || (ov == a.v && oi < a.i);
-        a.v = take ? ov : a.v;
-        a.i = take ? oi : a.i;
-    }
-    return a;
+// Wave arg-min without a shuffle butterfly (18 dependent ds_bpermute round trips per call, and the solver calls it once
+// per active-set round): the minimum VALUE comes from a DPP reduction, the lanes holding it answer a ballot, the first of
+// them supplies the row index through v_readlane.  Ties (the joint circles of two links coincide, so identical rows are
+// common) go to the lowest lane instead of the lowest row index -- the rows are identical, the QP does not care.
+template <int CTRL>
+__device__ __forceinline__ double am_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double am_lane(double v, int src) {            // src wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ ArgMin wave_argmin(ArgMin a, int& owner) {
+    double v = a.v;
+    v = fmin(v, am_dpp<0xB1>(v)); v = fmin(v, am_dpp<0x4E>(v)); v = fmin(v, am_dpp<0x141>(v)); v = fmin(v, am_dpp<0x140>(v));
+    const double mn = fmin(fmin(am_lane(v, 0), am_lane(v, 16)), fmin(am_lane(v, 32), am_lane(v, 48)));
+    const unsigned long long hit = __builtin_amdgcn_ballot_w64(a.v == mn);
+    owner = hit ? (int)__builtin_ctzll(hit) : 0;                          // hit == 0 only for NaN slacks: the caller stops
+    ArgMin r;
+    r.v = mn;
+    r.i = __builtin_amdgcn_readlane(a.i, owner);
+    return r;
 }
 
 // Orthonormal basis of the active normals and the triangular factor (N = Q R), q <= 3.
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(256) void manip_cbfqp_kernel(const sc_manip_cbfqp_p
         for (int i = 0; i < 3; ++i) {
             ang += qs[i];
             double s, c;
-            sincos(ang, &s, &c);
+            sincos_(ang, &s, &c);
             Px[i] = px; Py[i] = py;
             dx[i] = p.link_lengths[i] * c; dy[i] = p.link_lengths[i] * s;
             px += dx[i]; py += dy[i];
@@ -211,16 +226,17 @@ __global__ __launch_bounds__(256) void manip_cbfqp_kernel(const sc_manip_cbfqp_p
             const double mrg = sl + tol * fmax(1.0, fabs(cc[s]));
             if (mrg < best.v) { best.v = mrg; best.i = lane + 64 * s; }
         }
-        best = wave_argmin(best);
+        int owner;
+        best = wave_argmin(best, owner);
         if (!(best.v < 0.0)) { status = SC_STATUS_OPTIMAL; break; }
-        const int pr = best.i, owner = pr & 63, slot = pr >> 6;
+        const int pr = best.i, slot = pr >> 6;
         double np_[3], cp;
         {
             double a0 = n0[0], a1 = n1[0], a2 = n2[0], ac = cc[0];
 #pragma unroll
             for (int s = 1; s < RPL; ++s)
                 if (slot == s) { a0 = n0[s]; a1 = n1[s]; a2 = n2[s]; ac = cc[s]; }
-            np_[0] = __shfl(a0, owner); np_[1] = __shfl(a1, owner); np_[2] = __shfl(a2, owner); cp = __shfl(ac, owner);
+            np_[0] = am_lane(a0, owner); np_[1] = am_lane(a1, owner); np_[2] = am_lane(a2, owner); cp = am_lane(ac, owner);
         }
         double sp = dot3(np_, u) + cp;                            // < 0
         double lam_p = 0.0;

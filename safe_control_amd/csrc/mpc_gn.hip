@@ -91,7 +91,7 @@ template <> struct GnModel<SC_MODEL_QUAD2D> {
     template <bool JAC, bool STEP>
     static __device__ __forceinline__ void map(const double* x, const double* u, const GnPar& q, double* xn, double (*A)[6], double (*B)[2]) {
         double s, c;
-        sincos(x[2], &s, &c);
+        sincos_(x[2], &s, &c);
         const double dt = q.dt, T = u[0] + u[1], im = 1.0 / q.mass, ri = q.rad / q.inertia;
         xn[0] = x[0] + dt * x[3]; xn[1] = x[1] + dt * x[4]; xn[2] = x[2] + dt * x[5];
         xn[3] = x[3] + dt * (-s * im) * T;
@@ -124,7 +124,7 @@ template <> struct GnModel<SC_MODEL_QUAD2D> {
         for (int i = 0; i < 6; ++i) p[i] = sf * 2.0 * cq[i] * (xs[N * 6 + i] - xg[i]);
         for (int k = N - 1; k >= 0; --k) {
             double s, co;
-            sincos(xs[k * 6 + 2], &s, &co);
+            sincos_(xs[k * 6 + 2], &s, &co);
             const double T = z[2 * k] + z[2 * k + 1];
             const double n0x = -y[6 * k], n0y = -y[6 * k + 1], n1x = -y[6 * k + 2], n1y = -y[6 * k + 3], n2x = -y[6 * k + 4], n2y = -y[6 * k + 5];
             const double c3 = p[3] + dt * n2x, c4 = p[4] + dt * n2y;
