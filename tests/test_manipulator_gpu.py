@@ -155,3 +155,13 @@ def test_base_circle_inside_obstacle_is_infeasible_and_bad_arguments():
         sca.BatchedManipulatorCBFQP(dict(SPEC), num_rows=251)
     with pytest.raises(ValueError):
         ctl.solve(t(np.zeros((1, 4))), t(np.zeros((1, 3))), t(obs))
+
+
+def test_non_finite_inputs_are_infeasible_not_hung():
+    ctl = sca.BatchedManipulatorCBFQP(dict(SPEC), io_dtype="f64", num_rows=150, base_pos=BASE)
+    X, ur, obs = random_batch(4, 2, seed=3)
+    X[1, 0] = np.nan; ur[2, 1] = np.inf; obs[3, 0, 2] = np.nan
+    u, st, h = ctl.solve(t(X), t(ur), t(obs))
+    torch.cuda.synchronize()
+    st = st.cpu().numpy()
+    assert np.all(st[1:] != 0) and bool(torch.isnan(u[1:]).all())

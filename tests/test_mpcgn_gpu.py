@@ -132,3 +132,18 @@ def test_drop_in_class_and_bad_arguments():
     ctl = sca.BatchedGnMPCCBF({"model": "Quad2D"})
     with pytest.raises(ValueError):
         ctl.solve(t(np.zeros((2, 4))), t(np.zeros((2, 2))), t(np.zeros((2, 2))), t(np.zeros((2, 1, 7))))
+
+
+def test_non_finite_inputs_terminate_and_are_not_reported_optimal():
+    for name in MODELS:
+        mdl = MODELS[name]()
+        rng = np.random.default_rng(1)
+        X = np.zeros((4, mdl["nx"])); Gl = np.zeros((4, 2)); O = np.zeros((4, 3, 7))
+        for i in range(4):
+            X[i], Gl[i], O[i] = draw(mdl, rng, 3)
+        X[1, 0] = np.nan; Gl[2, 1] = np.inf; O[3, 0, 2] = np.nan
+        ctl = sca.BatchedGnMPCCBF({"model": name}, io_dtype="f64", horizon=10)
+        u, st, it = ctl.solve(t(X), t(np.tile(u_start(mdl), (4, 1))), t(Gl), t(O))
+        torch.cuda.synchronize()
+        st = st.cpu().numpy()
+        assert np.all(st[1:] != 0) and np.all(it.cpu().numpy() <= 100)

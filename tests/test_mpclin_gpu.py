@@ -133,3 +133,14 @@ def test_drop_in_class_and_bad_arguments():
         sca.BatchedLinearMPCCBF({"model": "Quad3D"}, horizon=33)              # nu * horizon > 128
     with pytest.raises(NotImplementedError):
         sca.BatchedLinearMPCCBF({"model": "DynamicUnicycle2D"})
+
+
+def test_non_finite_inputs_terminate_and_are_not_reported_optimal():
+    for name in ("SingleIntegrator2D", "Quad3D"):
+        mdl, X, G, O = batch(name, 4, 3, seed=1)
+        X[1, 0] = np.nan; G[2, 1] = np.inf; O[3, 0, 2] = np.nan
+        ctl = sca.BatchedLinearMPCCBF({"model": name}, io_dtype="f64", horizon=10)
+        u, st, it = ctl.solve(t(X), t(np.zeros((4, mdl["nu"]))), t(G), t(O))
+        torch.cuda.synchronize()
+        st = st.cpu().numpy()
+        assert np.all(st[1:] != 0) and np.all(it.cpu().numpy() <= 100)
