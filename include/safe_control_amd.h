@@ -438,6 +438,28 @@ int sc_tracking_apply_batch(const sc_tracking_params* params, int64_t B, int32_t
                             const void* u, const int32_t* u_status, void* u_last,
                             int32_t* ret, int32_t* ret_step, void* stream);
 
+/* Closed loop for the arm (SURVEY 8f-1 for Manipulator2D): `n_steps` iterations of LocalTrackingController.control_step
+ * (tracking.py:559-668; goal_reached on the end effector :263-268; update_goal :497-535) with nominal_input / step of
+ * robots/manipulator2D.py:38-41,110-127 and the CBF-QP above, one arm per wavefront, joint angles in registers.
+ * obs_table [M,7]: the known obstacles ALREADY ORDERED by distance to the base (what get_nearest_unpassed_obs returns
+ * for this model: robot.get_position() is the fixed base, robots/robot.py:354-356); the first min(M, num_rows) go to the
+ * controller.  X [B,3] in/out; waypoints [B,W,2] (or [W,2]); n_wp, wp_index, state_machine, goal [B,3] = (gx, gy, valid),
+ * ret, ret_step as in sc_tracking_rollout_batch; u_last [B,3]; traj_X / traj_U [n_steps,B,3] or NULL.
+ */
+typedef struct sc_manip_tracking_params {
+    sc_manip_cbfqp_params qp;      /* num_rows = num_constraints (150 by default, tracking.py:134-138)          */
+    int32_t n_steps, max_waypoints, waypoints_shared, enable_rotation;
+    double  Kp;                    /* robot_spec['Kp'] (manipulator2D.py:22; examples use 5.0)                  */
+    double  reached_threshold;     /* robot_spec['reached_threshold'] (0.3; examples/test_tracking.py:130: 0.5) */
+    double  rotation_threshold;    /* 0.1 (tracking.py:46)                                                      */
+} sc_manip_tracking_params;
+
+int sc_manip_tracking_rollout_batch(const sc_manip_tracking_params* params, int64_t B, int32_t M,
+                                    void* X, const void* waypoints, const int32_t* n_wp,
+                                    int32_t* wp_index, int32_t* state_machine, void* goal,
+                                    const void* obs_table, void* u_last, int32_t* ret, int32_t* ret_step,
+                                    void* traj_X, void* traj_U, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -161,3 +161,90 @@ def solve(X, u_ref, obs_list, spec, alpha=1.0, num_rows=150, dt=0.05, cbf_mode="
     Gb = np.vstack([np.eye(3), -np.eye(3)])
     u, status = solve_qpn(np.vstack([A, Gb]), np.concatenate([b, np.full(6, w)]), u_ref)
     return dict(u=u, status=status, h=hv, A=A, b=b)
+
+
+class ArmTrackingOracle:
+    """LocalTrackingController with a Manipulator2D robot, single arm (tracking.py:197-249 set_waypoints / filter_waypoints,
+    :263-268 goal_reached on the end effector, :497-535 update_goal, :559-668 control_step).  The yaw of the robot object
+    stays 0 (robots/robot.py:139-148) and its "position" is the fixed base (:354-356), which is what the obstacle ranking,
+    the field-of-view test and the collision test see."""
+
+    def __init__(self, q0, spec, base=(0.0, 0.0), dt=0.05, obs=None, num_constraints=150, enable_rotation=True, alpha=1.0):
+        self.spec = dict(default_spec()); self.spec.update(spec)
+        self.base = np.asarray(base, dtype=np.float64)
+        self.dt = dt
+        self.X = np.asarray(q0, dtype=np.float64).reshape(-1).copy()
+        self.obs = np.zeros((0, 7)) if obs is None else np.array(obs, dtype=np.float64)
+        self.num_constraints = num_constraints
+        self.enable_rotation = enable_rotation
+        self.alpha = alpha
+        self.reached_threshold = self.spec.get("reached_threshold", 0.3)
+        self.rotation_threshold = 0.1
+        self.fov_angle = math.radians(float(self.spec.get("fov_angle", 70.0)))
+        self.state_machine = "idle"
+        self.current_goal_index = 0
+        self.goal = None
+        self.status = STATUS_OPTIMAL
+        self.u_pos = None
+
+    def set_waypoints(self, waypoints):
+        wp = np.array(waypoints, dtype=np.float64)
+        if len(wp) >= 2:                                    # filter_waypoints with the end effector as the robot position
+            aug = np.vstack((end_effector(self.X, self.base), wp[:, :2]))
+            dist = np.linalg.norm(np.diff(aug, axis=0), axis=1)
+            wp = aug[np.concatenate(([False], dist >= self.reached_threshold))]
+        self.waypoints = wp
+        self.current_goal_index = 0
+        self.goal = self.update_goal()
+        if self.goal is not None:
+            ang = math.atan2(self.goal[1] - self.base[1], self.goal[0] - self.base[0])
+            wrapped = ((ang - 0.0 + math.pi) % (2.0 * math.pi)) - math.pi
+            if abs(wrapped) <= self.fov_angle / 2:
+                self.state_machine = "track"
+            else:                                            # 'exploration' is False: stop first (tracking.py:221-224)
+                self.state_machine = "stop"
+                self.goal = None
+
+    def update_goal(self):
+        if self.state_machine == "rotate":
+            rg = self.waypoints[self.current_goal_index]
+            goal_angle = math.atan2(rg[1] - self.X[1], rg[0] - self.X[0])      # joint angles where positions are meant
+            self.state_machine = "track"                     # Manipulator2D skips 'rotate' (tracking.py:512-513)
+            if abs(0.0 - goal_angle) > self.rotation_threshold:
+                return rg[:2]
+        if self.current_goal_index >= len(self.waypoints):
+            return None
+        wp = self.waypoints[self.current_goal_index]
+        if np.linalg.norm(end_effector(self.X, self.base) - wp[:2]) < self.reached_threshold:
+            self.current_goal_index += 1
+            if self.current_goal_index >= len(self.waypoints):
+                self.state_machine = "idle"
+                return None
+        return np.array(self.waypoints[self.current_goal_index][0:2])
+
+    def ranked_obstacles(self):
+        if len(self.obs) == 0:
+            return None
+        d = np.linalg.norm(self.obs[:, :2] - self.base[None, :], axis=1)
+        return self.obs[np.argsort(d)[: self.num_constraints]]
+
+    def control_step(self):
+        if self.state_machine == "stop":                    # has_stopped() is always True for the arm
+            self.state_machine = "rotate" if self.enable_rotation else "track"
+            self.goal = self.update_goal()
+        else:
+            self.goal = self.update_goal()
+        near = self.ranked_obstacles()
+        u_ref = np.zeros(3) if self.goal is None else nominal_input(self.X, self.goal, self.spec, self.base)
+        r = solve(self.X, u_ref, None if near is None else list(near), self.spec, self.alpha, self.num_constraints, self.dt,
+                  "cbf", self.base)
+        self.status = r["status"]
+        collide = bool(len(self.obs)) and bool(np.any(np.linalg.norm(self.obs[:, :2] - self.base[None, :], axis=1)
+                                                      < self.obs[:, 2] + self.spec["radius"]))
+        if self.status != STATUS_OPTIMAL or collide:
+            return -2
+        self.X = step(self.X, r["u"], self.dt)
+        self.u_pos = r["u"]
+        if self.goal is None and self.state_machine != "stop":
+            return -1
+        return 0

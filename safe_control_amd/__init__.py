@@ -8,7 +8,7 @@ fallback and raises if the HIP library is missing.
 """
 from ._lib import HipLibraryError, load as load_library  # noqa: F401
 from .position_control.cbf_qp import CBFQP, BatchedCBFQP  # noqa: F401
-from .position_control.manipulator_cbf_qp import ManipulatorCBFQP, BatchedManipulatorCBFQP  # noqa: F401
+from .position_control.manipulator_cbf_qp import ManipulatorCBFQP, BatchedManipulatorCBFQP, BatchedManipulatorTracking  # noqa: F401
 from .position_control.mpc_cbf import MPCCBF, BatchedMPCCBF  # noqa: F401
 from .position_control.mpc_cbf_linear import LinearMPCCBF, BatchedLinearMPCCBF  # noqa: F401
 from .position_control.mpc_cbf_gn import GnMPCCBF, BatchedGnMPCCBF  # noqa: F401

@@ -106,6 +106,15 @@ class ManipCbfQpParams(C.Structure):
     ]
 
 
+class ManipTrackingParams(C.Structure):
+    """Mirror of ``sc_manip_tracking_params``."""
+    _fields_ = [
+        ("qp", ManipCbfQpParams),
+        ("n_steps", C.c_int32), ("max_waypoints", C.c_int32), ("waypoints_shared", C.c_int32), ("enable_rotation", C.c_int32),
+        ("Kp", C.c_double), ("reached_threshold", C.c_double), ("rotation_threshold", C.c_double),
+    ]
+
+
 SM_IDLE, SM_TRACK, SM_STOP, SM_ROTATE = 0, 1, 2, 3
 SM_NAMES = {0: "idle", 1: "track", 2: "stop", 3: "rotate"}
 TRACKING_MAX_CONSTRAINTS = 16
@@ -139,6 +148,7 @@ SYMBOLS = {
     "sc_mpclin_build_model": (C.c_int, [C.POINTER(MpcLinParams)] + [C.c_void_p] * 5),
     "sc_mpclin_solve_batch": (C.c_int, [C.POINTER(MpcLinParams), C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 9),
     "sc_mpclin_solve_batch_host": (C.c_int, [C.POINTER(MpcLinParams), C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 8 + [C.c_int]),
+    "sc_manip_tracking_rollout_batch": (C.c_int, [C.POINTER(ManipTrackingParams), C.c_int64, C.c_int32] + [C.c_void_p] * 13),
     "sc_manip_cbfqp_solve_batch": (C.c_int, [C.POINTER(ManipCbfQpParams), C.c_int64, C.c_int32] + [C.c_void_p] * 8),
     "sc_manip_cbfqp_solve_batch_host": (C.c_int, [C.POINTER(ManipCbfQpParams), C.c_int64, C.c_int32] + [C.c_void_p] * 7 + [C.c_int]),
     "sc_mpccbf_solve_batch": (C.c_int, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,

@@ -51,6 +51,10 @@ size_t mpcgn_lds_bytes(int model_id, int N, int K);
 hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
                         const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream);
 
+hipError_t manip_rollout_launch(const sc_manip_tracking_params& t, long long B, int M, void* X, const void* wps, const int* n_wp,
+                                int* wp_index, int* sm, void* goal, const void* table, void* u_last, int* ret, int* ret_step,
+                                void* tX, void* tU, hipStream_t stream);
+
 static thread_local char g_err[256] = "";
 
 static int fail(int code, const char* msg) {
@@ -301,6 +305,26 @@ int sc_mpclin_solve_batch_host(const sc_mpclin_params* params, const double* mod
     if (e != hipSuccess) rc = sc::fail_hip(e, "sc_mpclin_solve_batch_host");
     (void)hipFree(d);
     return rc;
+}
+
+int sc_manip_tracking_rollout_batch(const sc_manip_tracking_params* params, int64_t B, int32_t M, void* X, const void* waypoints,
+                                    const int32_t* n_wp, int32_t* wp_index, int32_t* state_machine, void* goal,
+                                    const void* obs_table, void* u_last, int32_t* ret, int32_t* ret_step, void* traj_X,
+                                    void* traj_U, void* stream) {
+    if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    static const double dummy = 0.0;
+    int rc = sc::check_manip(&params->qp, B, 1, &dummy, &dummy, &dummy, &dummy, &dummy);
+    if (rc != SC_OK) return rc;
+    if (M < 0) return sc::fail(SC_ERR_INVALID_ARGUMENT, "M < 0");
+    if (params->n_steps < 0 || params->max_waypoints < 1) return sc::fail(SC_ERR_INVALID_ARGUMENT, "n_steps < 0 or max_waypoints < 1");
+    if ((size_t)M * 7 * 8 > 64 * 1024) return sc::fail(SC_ERR_UNSUPPORTED, "obstacle table does not fit 64 KiB of LDS");
+    if (B > 0 && (!X || !waypoints || !n_wp || !wp_index || !state_machine || !goal || !u_last || !ret || !ret_step || (M > 0 && !obs_table)))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    if (B == 0 || params->n_steps == 0) return SC_OK;
+    hipError_t e = sc::manip_rollout_launch(*params, (long long)B, (int)M, X, waypoints, n_wp, wp_index, state_machine, goal,
+                                            obs_table, u_last, ret, ret_step, traj_X, traj_U, (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "manipulator rollout kernel launch");
+    return SC_OK;
 }
 
 int sc_manip_cbfqp_solve_batch(const sc_manip_cbfqp_params* params, int64_t B, int32_t K, const void* X, const void* u_ref,

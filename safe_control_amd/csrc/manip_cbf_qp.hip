@@ -122,21 +122,14 @@ __device__ __forceinline__ void drop(ActiveSet& A, int l) {
     A.q -= 1;
 }
 
-template <int RPL>
-__global__ __launch_bounds__(256) void manip_cbfqp_kernel(const sc_manip_cbfqp_params p, const long long B, const int K,
-                                                          const void* __restrict__ X, const void* __restrict__ u_ref,
-                                                          const void* __restrict__ obs, const int* __restrict__ n_obs,
-                                                          void* __restrict__ u_out, int* __restrict__ status_out,
-                                                          void* __restrict__ h_out) {
-    const int lane = threadIdx.x & 63;
-    const long long agent = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (agent >= B) return;
-    const bool io32 = p.io_dtype == SC_DTYPE_F32;
-    auto ld = [io32](const void* a, size_t i) { return io32 ? (double)((const float*)a)[i] : ((const double*)a)[i]; };
-    auto st = [io32](void* a, size_t i, double v) { if (io32) ((float*)a)[i] = (float)v; else ((double*)a)[i] = v; };
-
+// One Manipulator2D CBF-QP for the wave: rows from the joint angles (q0, q1, q2) and `kv` obstacles read through
+// getobs(o, f), minimiser of ||u - (ur0, ur1, ur2)||^2 in u[]; returns SC_STATUS_*.  puth(r, h) receives the barrier value
+// of row r (0 for unused rows).  Everything is wave-uniform except the rows, which live RPL per lane.
+template <int RPL, typename GetObs, typename PutH>
+__device__ __forceinline__ int manip_qp(const sc_manip_cbfqp_params& p, const double q0, const double q1, const double q2,
+                                        const double ur0, const double ur1, const double ur2, const int kv, const int lane,
+                                        GetObs getobs, PutH puth, double (&u)[3]) {
     // ---- kinematic chain (wave-uniform): joints P0..P2, link vectors d0..d2 (manipulator2D.py:129-152) ----------
-    const double q0 = ld(X, agent * 3 + 0), q1 = ld(X, agent * 3 + 1), q2 = ld(X, agent * 3 + 2);
     double Px[3], Py[3], dx[3], dy[3];
     {
         double ang = 0.0, px = p.base_pos[0], py = p.base_pos[1];
@@ -153,10 +146,8 @@ __global__ __launch_bounds__(256) void manip_cbfqp_kernel(const sc_manip_cbfqp_p
     }
     const int c0 = p.link_steps[0] + 1, c1 = p.link_steps[1] + 1, c2 = p.link_steps[2] + 1;
     const int C = c0 + c1 + c2;
-    const int kv = n_obs ? min(max(n_obs[agent], 0), K) : K;
     const int Rr = min(p.num_rows, kv * C);                       // CBF rows in use (cbf_qp.py:126-128, :133)
     const int m = Rr + 6;                                         // + the box
-    const size_t obase = p.obs_shared ? 0 : (size_t)agent * K * 7;
     const double gain = p.cbf_mode == SC_CBF_MODE_HARD ? 1.0 / p.dt : p.alpha;    // cbf_qp.py:136-147
 
     double n0[RPL], n1[RPL], n2[RPL], cc[RPL];
@@ -176,8 +167,8 @@ __global__ __launch_bounds__(256) void manip_cbfqp_kernel(const sc_manip_cbfqp_p
             const double sx = li == 0 ? Px[0] : (li == 1 ? Px[1] : Px[2]), sy = li == 0 ? Py[0] : (li == 1 ? Py[1] : Py[2]);
             const double lx = li == 0 ? dx[0] : (li == 1 ? dx[1] : dx[2]), ly = li == 0 ? dy[0] : (li == 1 ? dy[1] : dy[2]);
             const double cx = sx + t * lx, cy = sy + t * ly;
-            const double ox = ld(obs, obase + (size_t)o * 7 + 0), oy = ld(obs, obase + (size_t)o * 7 + 1);
-            const double orad = ld(obs, obase + (size_t)o * 7 + 2);
+            const double ox = getobs(o, 0), oy = getobs(o, 1);
+            const double orad = getobs(o, 2);
             const double ex = cx - ox, ey = cy - oy;
             const double dmin = p.robot_radius + orad;
             const double h = ex * ex + ey * ey - p.beta * (dmin * dmin);
@@ -189,7 +180,7 @@ __global__ __launch_bounds__(256) void manip_cbfqp_kernel(const sc_manip_cbfqp_p
                 a[k] = k <= li ? 2.0 * (ex * jx + ey * jy) : 0.0;
             }
             const double b = gain * h;
-            if (h_out) st(h_out, (size_t)agent * p.num_rows + r, h);
+            puth(r, h);
             const double nn = a[0] * a[0] + a[1] * a[1] + a[2] * a[2];
             if (!(finite_(nn) && finite_(b))) dead = true;
             if (nn > 0.0) {
@@ -204,10 +195,10 @@ __global__ __launch_bounds__(256) void manip_cbfqp_kernel(const sc_manip_cbfqp_p
             n0[s] = ax == 0 ? sg : 0.0; n1[s] = ax == 1 ? sg : 0.0; n2[s] = ax == 2 ? sg : 0.0;
             cc[s] = p.w_max;
         }
-        if (h_out && r >= Rr && r < p.num_rows) st(h_out, (size_t)agent * p.num_rows + r, 0.0);
+        if (r >= Rr && r < p.num_rows) puth(r, 0.0);
     }
 
-    double u[3] = {ld(u_ref, agent * 3 + 0), ld(u_ref, agent * 3 + 1), ld(u_ref, agent * 3 + 2)};
+    u[0] = ur0; u[1] = ur1; u[2] = ur2;
     if (!(finite_(u[0]) && finite_(u[1]) && finite_(u[2]))) dead = true;
     int status = __any(dead) ? SC_STATUS_INFEASIBLE : -1;
 
@@ -279,12 +270,149 @@ __global__ __launch_bounds__(256) void manip_cbfqp_kernel(const sc_manip_cbfqp_p
             drop(A, l);
         }
     }
+    return status;
+}
+
+template <int RPL>
+__global__ __launch_bounds__(256) void manip_cbfqp_kernel(const sc_manip_cbfqp_params p, const long long B, const int K,
+                                                          const void* __restrict__ X, const void* __restrict__ u_ref,
+                                                          const void* __restrict__ obs, const int* __restrict__ n_obs,
+                                                          void* __restrict__ u_out, int* __restrict__ status_out,
+                                                          void* __restrict__ h_out) {
+    const int lane = threadIdx.x & 63;
+    const long long agent = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (agent >= B) return;
+    const bool io32 = p.io_dtype == SC_DTYPE_F32;
+    auto ld = [io32](const void* a, size_t i) { return io32 ? (double)((const float*)a)[i] : ((const double*)a)[i]; };
+    auto st = [io32](void* a, size_t i, double v) { if (io32) ((float*)a)[i] = (float)v; else ((double*)a)[i] = v; };
+    const int kv = n_obs ? min(max(n_obs[agent], 0), K) : K;
+    const size_t obase = p.obs_shared ? 0 : (size_t)agent * K * 7;
+    double u[3];
+    const int status = manip_qp<RPL>(p, ld(X, agent * 3 + 0), ld(X, agent * 3 + 1), ld(X, agent * 3 + 2), ld(u_ref, agent * 3 + 0),
+                                     ld(u_ref, agent * 3 + 1), ld(u_ref, agent * 3 + 2), kv, lane,
+                                     [&](int o, int f) { return ld(obs, obase + (size_t)o * 7 + f); },
+                                     [&](int r, double h) { if (h_out) st(h_out, (size_t)agent * p.num_rows + r, h); }, u);
     if (lane == 0) {
         const bool ok = status == SC_STATUS_OPTIMAL;
         st(u_out, agent * 3 + 0, ok ? u[0] : num<double>::nan());
         st(u_out, agent * 3 + 1, ok ? u[1] : num<double>::nan());
         st(u_out, agent * 3 + 2, ok ? u[2] : num<double>::nan());
         status_out[agent] = status;
+    }
+}
+
+// ---- closed loop for the arm: LocalTrackingController.control_step with a Manipulator2D robot, n_steps per launch ---------
+//   tracking.py:497-535 (update_goal; goal_reached on the end effector :263-268), :559-668 (control_step),
+//   manipulator2D.py:42-127 (end effector, Jacobian, nominal_input), :38-41 (step).  One arm per wavefront, joint angles in
+//   registers across the steps; the obstacle table is shared, static and already ordered by distance to the base
+//   (get_nearest_unpassed_obs ranks by the distance to robot.get_position(), which is the fixed base, robots/robot.py:354-356;
+//   every obstacle passes the "unpassed" test because the model keeps the default angle of 2 pi, tracking.py:345-357).
+//   Quirks kept: the collision test also uses the base position (tracking.py:445-495), so it is constant over the run; in
+//   the step that leaves 'stop' the reference passes through update_goal's rotate branch, which compares the yaw (0) with
+//   atan2(wp_y - X[1], wp_x - X[0]) -- joint angles where positions are meant -- and, when they differ by more than the
+//   rotation threshold, returns the current waypoint without the reached test (tracking.py:505-516).
+template <int RPL>
+__global__ __launch_bounds__(64) void manip_rollout_kernel(const sc_manip_tracking_params t, const long long B, const int M,
+                                                           void* __restrict__ X, const void* __restrict__ waypoints,
+                                                           const int* __restrict__ n_wp, int* __restrict__ wp_index,
+                                                           int* __restrict__ state_machine, void* __restrict__ goal,
+                                                           const void* __restrict__ obs_table, void* __restrict__ u_last,
+                                                           int* __restrict__ ret_out, int* __restrict__ ret_step,
+                                                           void* __restrict__ traj_X, void* __restrict__ traj_U) {
+    extern __shared__ __attribute__((aligned(16))) double table[];        // [M][7]
+    const sc_manip_cbfqp_params& p = t.qp;
+    const int lane = threadIdx.x;
+    const long long agent = blockIdx.x;
+    if (agent >= B) return;
+    const bool io32 = p.io_dtype == SC_DTYPE_F32;
+    auto ld = [io32](const void* a, size_t i) { return io32 ? (double)((const float*)a)[i] : ((const double*)a)[i]; };
+    auto st = [io32](void* a, size_t i, double v) { if (io32) ((float*)a)[i] = (float)v; else ((double*)a)[i] = v; };
+    for (int e = lane; e < M * 7; e += 64) table[e] = ld(obs_table, e);
+    __syncthreads();
+    double q[3] = {ld(X, agent * 3 + 0), ld(X, agent * 3 + 1), ld(X, agent * 3 + 2)};
+    int wp = wp_index[agent], sm = state_machine[agent], ret = ret_out[agent], rstep = -1;
+    double gx = ld(goal, agent * 3 + 0), gy = ld(goal, agent * 3 + 1);
+    bool gvalid = ld(goal, agent * 3 + 2) != 0.0;
+    const int W = t.max_waypoints;
+    const size_t wbase = t.waypoints_shared ? 0 : (size_t)agent * W * 2;
+    const int nw = n_wp[t.waypoints_shared ? 0 : agent];
+    const int kv = M < p.num_rows ? M : p.num_rows;                       // obstacles handed to the controller (tracking.py:584)
+    bool hit = false;                                                     // the base never moves
+    for (int mo = 0; mo < M; ++mo) {
+        const double dx = p.base_pos[0] - table[7 * mo], dy = p.base_pos[1] - table[7 * mo + 1];
+        hit |= sqrt(dx * dx + dy * dy) < table[7 * mo + 2] + p.robot_radius;
+    }
+    double ul[3] = {0.0, 0.0, 0.0};
+
+    auto end_effector = [&](double& ex, double& ey, double (&sn)[3], double (&cs)[3]) {
+        double ang = 0.0;
+        ex = p.base_pos[0]; ey = p.base_pos[1];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            ang += q[i];
+            sincos_(ang, &sn[i], &cs[i]);
+            ex += p.link_lengths[i] * cs[i]; ey += p.link_lengths[i] * sn[i];
+        }
+    };
+    auto update_goal = [&](bool from_stop) {
+        if (from_stop && wp < nw) {                                       // rotate branch (see the header comment)
+            const double ga = atan2(ld(waypoints, wbase + 2 * wp + 1) - q[1], ld(waypoints, wbase + 2 * wp) - q[0]);
+            if (fabs(0.0 - ga) > t.rotation_threshold) { gx = ld(waypoints, wbase + 2 * wp); gy = ld(waypoints, wbase + 2 * wp + 1); gvalid = true; return; }
+        }
+        if (wp >= nw) { gvalid = false; return; }
+        double ex, ey, sn[3], cs[3];
+        end_effector(ex, ey, sn, cs);
+        const double dx = ex - ld(waypoints, wbase + 2 * wp), dy = ey - ld(waypoints, wbase + 2 * wp + 1);
+        if (sqrt(dx * dx + dy * dy) < t.reached_threshold) {
+            wp += 1;
+            if (wp >= nw) { sm = SC_SM_IDLE; gvalid = false; return; }
+        }
+        gx = ld(waypoints, wbase + 2 * wp); gy = ld(waypoints, wbase + 2 * wp + 1); gvalid = true;
+    };
+
+    for (int step = 0; step < t.n_steps; ++step) {
+        const bool run = ret == 0;
+        if (run) {
+            if (sm == SC_SM_STOP) { sm = SC_SM_TRACK; update_goal(t.enable_rotation != 0); }   // has_stopped() is always true
+            else update_goal(false);
+        }
+        // nominal input: Jacobian-transpose control, clipped (manipulator2D.py:110-127); no goal: stop() = zeros
+        double ur[3] = {0.0, 0.0, 0.0};
+        if (gvalid) {
+            double ex, ey, sn[3], cs[3];
+            end_effector(ex, ey, sn, cs);
+            const double vx = t.Kp * (gx - ex), vy = t.Kp * (gy - ey);
+            double jx = 0.0, jy = 0.0;
+#pragma unroll
+            for (int i = 2; i >= 0; --i) {
+                jx -= p.link_lengths[i] * sn[i]; jy += p.link_lengths[i] * cs[i];
+                ur[i] = fmin(fmax(jx * vx + jy * vy, -p.w_max), p.w_max);
+            }
+        }
+        double u[3] = {ur[0], ur[1], ur[2]};
+        int status = SC_STATUS_OPTIMAL;
+        if (M > 0) status = manip_qp<RPL>(p, q[0], q[1], q[2], ur[0], ur[1], ur[2], kv, lane,
+                                          [&](int o, int f) { return table[7 * o + f]; }, [](int, double) {}, u);
+        const bool pre_fail = status != SC_STATUS_OPTIMAL || hit;
+        const int code = pre_fail ? -2 : ((!gvalid && sm != SC_SM_STOP) ? -1 : 0);
+        if (run) {
+            if (!pre_fail) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { q[i] = q[i] + u[i] * p.dt; ul[i] = u[i]; }
+            }
+            if (code != 0) { ret = code; rstep = step; }
+        }
+        if (lane < 3) {
+            if (traj_X) st(traj_X, ((size_t)step * B + agent) * 3 + lane, lane == 0 ? q[0] : (lane == 1 ? q[1] : q[2]));
+            if (traj_U) st(traj_U, ((size_t)step * B + agent) * 3 + lane, lane == 0 ? ul[0] : (lane == 1 ? ul[1] : ul[2]));
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { st(X, agent * 3 + i, q[i]); st(u_last, agent * 3 + i, ul[i]); }
+        wp_index[agent] = wp; state_machine[agent] = sm;
+        st(goal, agent * 3 + 0, gx); st(goal, agent * 3 + 1, gy); st(goal, agent * 3 + 2, gvalid ? 1.0 : 0.0);
+        ret_out[agent] = ret; ret_step[agent] = rstep;
     }
 }
 
@@ -303,6 +431,26 @@ hipError_t manip_cbfqp_launch(const sc_manip_cbfqp_params& p, long long B, int K
         case 2: hipLaunchKernelGGL(manip_cbfqp_kernel<2>, grid, block, 0, stream, p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out); break;
         case 3: hipLaunchKernelGGL(manip_cbfqp_kernel<3>, grid, block, 0, stream, p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out); break;
         case 4: hipLaunchKernelGGL(manip_cbfqp_kernel<4>, grid, block, 0, stream, p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t manip_rollout_launch(const sc_manip_tracking_params& t, long long B, int M, void* X, const void* wps, const int* n_wp,
+                                int* wp_index, int* sm, void* goal, const void* table, void* u_last, int* ret, int* ret_step,
+                                void* tX, void* tU, hipStream_t stream) {
+    const sc_manip_cbfqp_params& p = t.qp;
+    const int C = p.link_steps[0] + p.link_steps[1] + p.link_steps[2] + 3;
+    long long rows = (long long)(M < p.num_rows ? M : p.num_rows) * C;
+    if (rows > p.num_rows) rows = p.num_rows;
+    const int rpl = ((int)rows + 6 + 63) / 64;
+    const size_t lds = (size_t)(M > 0 ? M : 1) * 7 * sizeof(double);
+    const dim3 block(64), grid((unsigned)B);
+    switch (rpl) {
+        case 1: hipLaunchKernelGGL(manip_rollout_kernel<1>, grid, block, lds, stream, t, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU); break;
+        case 2: hipLaunchKernelGGL(manip_rollout_kernel<2>, grid, block, lds, stream, t, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU); break;
+        case 3: hipLaunchKernelGGL(manip_rollout_kernel<3>, grid, block, lds, stream, t, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU); break;
+        case 4: hipLaunchKernelGGL(manip_rollout_kernel<4>, grid, block, lds, stream, t, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -166,3 +166,116 @@ class BatchedManipulatorCBFQP:
             h.data_ptr() if h is not None else None, stream)
         _lib.check(rc, "sc_manip_cbfqp_solve_batch")
         return u, status, h
+
+
+class BatchedManipulatorTracking:
+    """Closed loop for B arms that share one known-obstacle table: ``control_step(n)`` runs n iterations of
+    ``LocalTrackingController.control_step`` (tracking.py:559-668) with a Manipulator2D robot in ONE launch
+    (csrc/manip_cbf_qp.hip: manip_rollout_kernel).  ``q0 [B,3]`` joint angles, ``obs [M,3|7]``, one waypoint list per arm
+    or one shared list; return codes as the reference (0 running, -1 all waypoints reached, -2 infeasible / collision)."""
+
+    def __init__(self, q0, robot_spec, base_pos=(0.0, 0.0), dt=0.05, obs=None, enable_rotation=True, io_dtype="f64",
+                 device="cuda:0"):
+        import torch
+        self.torch = torch
+        self.robot_spec = complete_robot_spec(robot_spec)
+        self.dt = float(dt)
+        self.base_pos = np.asarray(base_pos, dtype=np.float64).reshape(-1)[:2]
+        self.enable_rotation = bool(enable_rotation)
+        self.device = torch.device(device)
+        self.io_dtype = {"f32": _lib.DTYPE_F32, "f64": _lib.DTYPE_F64}[io_dtype]
+        self.tdtype = torch.float32 if io_dtype == "f32" else torch.float64
+        self.num_constraints = int(self.robot_spec.get("num_constraints", DEFAULT_NUM_ROWS))       # tracking.py:134-138
+        if not 1 <= self.num_constraints <= _lib.MANIP_MAX_ROWS:
+            raise ValueError(f"num_constraints must be in [1, {_lib.MANIP_MAX_ROWS}]")
+        self.reached_threshold = float(self.robot_spec.get("reached_threshold", 0.3))
+        self.fov_angle = np.radians(float(self.robot_spec.get("fov_angle", 70.0)))
+        self.alpha = float(self.robot_spec.get("cbf_alpha", 1.0))
+        self._lib = _lib.load()
+        q0 = np.asarray(q0, dtype=np.float64)
+        if q0.ndim == 1:
+            q0 = q0[None, :]
+        self.B = q0.shape[0]
+        self.X = torch.tensor(q0[:, :3], dtype=self.tdtype, device=self.device).contiguous()
+        if obs is None or len(obs) == 0:
+            tab = np.zeros((0, 7))
+        else:
+            tab = np.asarray(obs, dtype=np.float64)
+            if tab.shape[1] < 7:
+                tab = np.hstack([tab, np.zeros((tab.shape[0], 7 - tab.shape[1]))])
+            # get_nearest_unpassed_obs ranks by the distance to robot.get_position() = the base (robots/robot.py:354-356)
+            tab = tab[np.argsort(np.linalg.norm(tab[:, :2] - self.base_pos[None, :], axis=1))][:, :7]
+        self.obs = torch.tensor(tab, dtype=self.tdtype, device=self.device).contiguous()
+        z = lambda *shape, dt_=torch.int32: torch.zeros(shape, dtype=dt_, device=self.device)
+        self.state_machine, self.current_goal_index, self.ret = z(self.B), z(self.B), z(self.B)
+        self.ret_step = torch.full((self.B,), -1, dtype=torch.int32, device=self.device)
+        self.goal = z(self.B, 3, dt_=self.tdtype)
+        self.u_pos = z(self.B, 3, dt_=self.tdtype)
+        self.waypoints = None
+        self.steps_done = 0
+
+    def _end_effector(self, q):
+        ang = np.cumsum(q)
+        return self.base_pos + np.array([np.sum(np.asarray(LINK_LENGTHS) * np.cos(ang)), np.sum(np.asarray(LINK_LENGTHS) * np.sin(ang))])
+
+    def set_waypoints(self, waypoints):
+        """set_waypoints / filter_waypoints / first update_goal (tracking.py:197-249, :497-535) per arm, on the host."""
+        torch = self.torch
+        Q = self.X.double().cpu().numpy()
+        shared = (isinstance(waypoints, np.ndarray) and waypoints.ndim == 2) or \
+            (isinstance(waypoints, (list, tuple)) and len(waypoints) > 0 and np.ndim(waypoints[0]) == 1)
+        lists = [np.asarray(waypoints, dtype=np.float64)] * self.B if shared else [np.asarray(w, dtype=np.float64) for w in waypoints]
+        filt = []
+        for i in range(self.B):
+            wp = lists[i]
+            if len(wp) >= 2:
+                aug = np.vstack((self._end_effector(Q[i]), wp[:, :2]))
+                dist = np.linalg.norm(np.diff(aug, axis=0), axis=1)
+                wp = aug[np.concatenate(([False], dist >= self.reached_threshold))]
+            filt.append(np.asarray(wp, dtype=np.float64)[:, :2].reshape(-1, 2))
+        W = max(1, max(len(w) for w in filt))
+        wps = np.zeros((self.B, W, 2)); n_wp = np.zeros(self.B, dtype=np.int32)
+        idx = np.zeros(self.B, dtype=np.int32); sm = np.zeros(self.B, dtype=np.int32); goal = np.zeros((self.B, 3))
+        for i in range(self.B):
+            w = filt[i]
+            n_wp[i] = len(w); wps[i, : len(w)] = w
+            g = None
+            if len(w) > 0:
+                if np.linalg.norm(self._end_effector(Q[i]) - w[0]) < self.reached_threshold:
+                    idx[i] = 1
+                if idx[i] < len(w):
+                    g = w[idx[i]]
+            if g is not None:                                   # is_in_fov from the base with yaw 0 (robots/robot.py:854-872)
+                ang = np.arctan2(g[1] - self.base_pos[1], g[0] - self.base_pos[0])
+                if abs(((ang + np.pi) % (2 * np.pi)) - np.pi) <= self.fov_angle / 2:
+                    sm[i] = _lib.SM_TRACK; goal[i] = [g[0], g[1], 1.0]
+                else:
+                    sm[i] = _lib.SM_STOP
+        self.waypoints = torch.tensor(wps, dtype=self.tdtype, device=self.device).contiguous()
+        self.n_wp = torch.tensor(n_wp, dtype=torch.int32, device=self.device)
+        self.current_goal_index = torch.tensor(idx, dtype=torch.int32, device=self.device)
+        self.state_machine = torch.tensor(sm, dtype=torch.int32, device=self.device)
+        self.goal = torch.tensor(goal, dtype=self.tdtype, device=self.device).contiguous()
+        self.ret.zero_(); self.ret_step.fill_(-1)
+
+    def control_step(self, n=1, record=False):
+        torch = self.torch
+        if self.waypoints is None:
+            raise RuntimeError("call set_waypoints first")
+        p = _lib.ManipTrackingParams()
+        p.qp = make_params(self.robot_spec, self.alpha, self.dt, self.robot_spec["radius"], self.io_dtype, self.num_constraints,
+                           self.base_pos, obs_shared=True)
+        p.n_steps, p.max_waypoints, p.waypoints_shared = int(n), int(self.waypoints.shape[1]), 0
+        p.enable_rotation = 1 if self.enable_rotation else 0
+        p.Kp, p.reached_threshold, p.rotation_threshold = float(self.robot_spec["Kp"]), self.reached_threshold, 0.1
+        tX = torch.empty((n, self.B, 3), dtype=self.tdtype, device=self.device) if record else None
+        tU = torch.empty((n, self.B, 3), dtype=self.tdtype, device=self.device) if record else None
+        M = int(self.obs.shape[0])
+        rc = self._lib.sc_manip_tracking_rollout_batch(
+            C.byref(p), self.B, M, self.X.data_ptr(), self.waypoints.data_ptr(), self.n_wp.data_ptr(),
+            self.current_goal_index.data_ptr(), self.state_machine.data_ptr(), self.goal.data_ptr(),
+            self.obs.data_ptr() if M else None, self.u_pos.data_ptr(), self.ret.data_ptr(), self.ret_step.data_ptr(),
+            tX.data_ptr() if record else None, tU.data_ptr() if record else None, torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(rc, "sc_manip_tracking_rollout_batch")
+        self.steps_done += n
+        return (self.ret, tX, tU) if record else self.ret

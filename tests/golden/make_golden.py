@@ -601,7 +601,60 @@ def gen_closed_loop_integrators():
     np.savez_compressed(os.path.join(HERE, "closed_loop_integrators.npz"), **out)
 
 
+def gen_closed_loop_manipulator():
+    """examples/test_tracking.py --model ma --algo cbf_qp (base moved to (5, 3.5), three known obstacles, two waypoints), plus
+    a scene with an obstacle in the arm's sweep and a first waypoint outside the field of view (starts in 'stop')."""
+    out = {}
+    base = np.array([5.0, 3.5])
+    scenes = {
+        "example": (np.array([[6.0, 4.5, 0.3], [4.0, 1.0, 0.3], [1.0, 4.0, 0.3]]), np.array([[6.5, 4.0, 0.0], [2.0, 4.5, 0.0]]), np.zeros(3)),
+        "sweep": (np.array([[6.4, 5.3, 0.25], [3.4, 5.6, 0.3], [7.6, 2.0, 0.3]]), np.array([[5.5, 6.0, 0.0], [3.0, 4.8, 0.0]]), np.array([0.2, 0.4, -0.3])),
+        "behind": (np.array([[6.0, 1.6, 0.3], [2.6, 2.2, 0.3]]), np.array([[3.2, 3.0, 0.0], [6.0, 5.2, 0.0]]), np.array([0.0, 0.3, 0.3])),
+    }
+    for tag, (known, wps, q0) in scenes.items():
+        known = np.hstack((known, np.zeros((known.shape[0], 4))))
+        spec = {"model": "Manipulator2D", "w_max": 2.0, "Kp": 5.0, "radius": 0.25, "reached_threshold": 0.5}
+        ctl = LocalTrackingController(q0.copy(), spec, controller_type={"pos": "cbf_qp"}, dt=DT, env=ref_env.Env())
+        ctl.robot.robot.base_pos = base.copy()                     # examples/test_tracking.py:163-165
+        pc = ctl.pos_controller
+
+        class Problem3:
+            status = "optimal"
+
+            def solve(self, **_):
+                G = np.vstack([pc.A1.value, np.eye(3), -np.eye(3)])
+                c = np.concatenate([pc.b1.value.reshape(-1), np.full(6, spec["w_max"])])
+                u, st = oqp.solve_qpn(G, c, np.asarray(pc.u_ref.value, dtype=float).reshape(-1))
+                self.status = "optimal" if st == 0 else "infeasible"
+                pc.u.value = None if u is None else u.reshape(3, 1)
+
+        pc.cbf_controller = Problem3()
+        ctl.obs = known.copy()
+        ctl.set_waypoints(wps)
+        names = ["idle", "track", "stop", "rotate"]
+        Xs, Us, rets, sms = [ctl.robot.X.reshape(-1).copy()], [], [], [names.index(ctl.state_machine)]
+        for _ in range(600):
+            ret = ctl.control_step()
+            rets.append(ret); sms.append(names.index(ctl.state_machine))
+            if ret == -2:
+                break
+            Xs.append(ctl.robot.X.reshape(-1).copy()); Us.append(ctl.get_control_input().reshape(-1).copy())
+            if ret == -1:
+                break
+        out[f"{tag}/obs"] = known; out[f"{tag}/waypoints"] = wps; out[f"{tag}/q0"] = q0
+        out[f"{tag}/filtered_waypoints"] = np.asarray(ctl.waypoints, dtype=float)
+        out[f"{tag}/X"] = np.array(Xs); out[f"{tag}/U"] = np.array(Us)
+        out[f"{tag}/ret"] = np.array(rets); out[f"{tag}/sm"] = np.array(sms)
+        print(tag, "steps", len(rets), "last ret", rets[-1], "first sm", names[sms[0]], "constrained steps",
+              int(np.sum(np.abs(np.array(Us) - np.clip(np.array(Us), -2, 2)).sum(axis=1) >= 0)))
+    out["base"] = base
+    np.savez_compressed(os.path.join(HERE, "closed_loop_manipulator.npz"), **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "closed_loop_manipulator":
+        gen_closed_loop_manipulator()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "closed_loop_integrators":
         gen_closed_loop_integrators()
         sys.exit(0)
@@ -631,3 +684,4 @@ if __name__ == "__main__":
     gen_manipulator()
     gen_linear_models()
     gen_closed_loop_integrators()
+    gen_closed_loop_manipulator()

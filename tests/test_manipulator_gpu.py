@@ -165,3 +165,63 @@ def test_non_finite_inputs_are_infeasible_not_hung():
     torch.cuda.synchronize()
     st = st.cpu().numpy()
     assert np.all(st[1:] != 0) and bool(torch.isnan(u[1:]).all())
+
+
+@pytest.mark.parametrize("tag", ["example", "sweep", "behind"])
+def test_closed_loop_reproduces_the_reference_run(tag):
+    """examples/test_tracking.py --model ma --algo cbf_qp and two harder scenes (an obstacle in the arm's sweep; a first
+    waypoint outside the field of view, so the run starts in 'stop'): the reference's own joint trajectories to the last
+    waypoint (tests/golden/closed_loop_manipulator.npz), fused on the device, in two launches."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "closed_loop_manipulator.npz"))
+    spec = {"model": "Manipulator2D", "w_max": 2.0, "Kp": 5.0, "radius": 0.25, "reached_threshold": 0.5}
+    ctl = sca.BatchedManipulatorTracking(g[f"{tag}/q0"][None, :], spec, base_pos=g["base"], obs=g[f"{tag}/obs"], io_dtype="f64")
+    ctl.set_waypoints(g[f"{tag}/waypoints"])
+    assert int(ctl.state_machine[0].item()) == int(g[f"{tag}/sm"][0])
+    Xg, Ug, retg = g[f"{tag}/X"], g[f"{tag}/U"], g[f"{tag}/ret"]
+    T = len(retg)
+    done = 0
+    for n in (1, T + 4):
+        ret, tX, tU = ctl.control_step(n, record=True)
+        tX = tX.cpu().numpy()[:, 0]; tU = tU.cpu().numpy()[:, 0]
+        m = min(n, T - done)
+        np.testing.assert_allclose(tX[:m], Xg[done + 1: done + m + 1], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(tU[:m], Ug[done: done + m], rtol=0, atol=1e-7)
+        done += n
+    assert int(ret[0].item()) == -1 and int(ctl.ret_step[0].item()) == T - 2      # second launch started at step 1
+    np.testing.assert_allclose(tX[-1], Xg[-1], atol=1e-7)                          # frozen after finishing
+
+
+def test_arm_fleet_against_the_oracle_loop():
+    """24 arms with their own start angles and waypoints around shared obstacles, some of which constrain the motion."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "closed_loop_manipulator.npz"))
+    base = g["base"]
+    obs = np.array([[6.6, 5.2, 0.3, 0, 0, 0, 0], [3.4, 5.4, 0.3, 0, 0, 0, 0], [7.4, 2.2, 0.3, 0, 0, 0, 0], [3.0, 1.8, 0.35, 0, 0, 0, 0]])
+    rng = np.random.default_rng(12)
+    B, T = 24, 120
+    spec = {"model": "Manipulator2D", "w_max": 2.0, "Kp": 5.0, "radius": 0.25, "reached_threshold": 0.4}
+    q0 = rng.uniform(-1.2, 1.2, (B, 3))
+    wl = []
+    for i in range(B):
+        ang = rng.uniform(-np.pi, np.pi, 2); rad = rng.uniform(1.6, 3.0, 2)
+        wl.append(np.stack([base[0] + rad * np.cos(ang), base[1] + rad * np.sin(ang)], axis=1))
+    ctl = sca.BatchedManipulatorTracking(q0, dict(spec), base_pos=base, obs=obs, io_dtype="f64")
+    ctl.set_waypoints(wl)
+    ret, tX, tU = ctl.control_step(T, record=True)
+    tX = tX.cpu().numpy(); tU = tU.cpu().numpy(); ret = ret.cpu().numpy()
+    n_active = 0
+    for i in range(B):
+        o = M.ArmTrackingOracle(q0[i], {k: v for k, v in spec.items() if k != "model"}, base=base, obs=obs)
+        o.set_waypoints(wl[i])
+        last = 0
+        for k in range(T):
+            goal_before = o.goal
+            last = o.control_step()
+            if last == -2:
+                break
+            np.testing.assert_allclose(tX[k, i], o.X, rtol=0, atol=1e-7, err_msg=f"arm {i} step {k}")
+            if o.goal is not None:
+                n_active += int(np.abs(o.u_pos - M.nominal_input(tX[k - 1, i] if k else q0[i], o.goal, o.spec, base)).max() > 1e-6)
+            if last != 0:
+                break
+        assert ret[i] == last
+    assert n_active > 20                                           # the CBF rows really changed the nominal input along the way

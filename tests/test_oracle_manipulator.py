@@ -95,3 +95,21 @@ def test_qpn_against_full_enumeration_and_slsqp():
 def test_no_obstacle_returns_u_ref_unclipped():
     r = M.solve(np.zeros(3), [5.0, -7.0, 1.0], None, SPEC)
     assert r["status"] == 0 and np.all(r["u"] == [5.0, -7.0, 1.0])
+
+
+@pytest.mark.parametrize("tag", ["example", "sweep", "behind"])
+def test_arm_closed_loop_matches_reference(tag):
+    """LocalTrackingController with Manipulator2D (tests/golden/make_golden.py: gen_closed_loop_manipulator): every joint
+    state, return code and state-machine state of the reference's run to the last waypoint."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "closed_loop_manipulator.npz"))
+    names = ["idle", "track", "stop", "rotate"]
+    o = M.ArmTrackingOracle(g[f"{tag}/q0"], dict(w_max=2.0, Kp=5.0, radius=0.25, reached_threshold=0.5), base=g["base"], obs=g[f"{tag}/obs"])
+    o.set_waypoints(g[f"{tag}/waypoints"])
+    np.testing.assert_allclose(o.waypoints, g[f"{tag}/filtered_waypoints"][:, :2], rtol=0, atol=1e-12)
+    assert names.index(o.state_machine) == g[f"{tag}/sm"][0]
+    Xr, rets = g[f"{tag}/X"], g[f"{tag}/ret"]
+    for i in range(len(rets)):
+        assert o.control_step() == rets[i]
+        assert names.index(o.state_machine) == g[f"{tag}/sm"][i + 1]
+        np.testing.assert_allclose(o.X, Xr[i + 1], rtol=0, atol=1e-10)
+    assert rets[-1] == -1
