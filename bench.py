@@ -285,6 +285,34 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
             "mean_ipm_iterations": float(it.double().mean().item())}
 
 
+def manip_closed_loop_leg(dev, B=4096, T=100, seed=0):
+    """Fused closed loop for B arms (csrc/manip_cbf_qp.hip: manip_rollout_kernel): T control steps in one launch, four shared
+    obstacles around the workspace, two waypoints per arm."""
+    import numpy as np
+    import torch
+    import safe_control_amd as sca
+    rng = np.random.default_rng(seed)
+    base = np.array([5.0, 3.5])
+    obs = np.array([[6.6, 5.2, 0.3], [3.4, 5.4, 0.3], [7.4, 2.2, 0.3], [3.0, 1.8, 0.35]])
+    q0 = rng.uniform(-1.2, 1.2, (B, 3))
+    ang, rad = rng.uniform(-np.pi, np.pi, (B, 2)), rng.uniform(1.6, 3.0, (B, 2))
+    wl = [np.stack([base[0] + rad[i] * np.cos(ang[i]), base[1] + rad[i] * np.sin(ang[i])], axis=1) for i in range(B)]
+    spec = {"model": "Manipulator2D", "w_max": 2.0, "Kp": 5.0, "radius": 0.25, "reached_threshold": 0.4}
+    ctl = sca.BatchedManipulatorTracking(q0, dict(spec), base_pos=base, obs=obs, io_dtype="f32", device=dev)
+    ctl.set_waypoints(wl)
+    ctl.control_step(1)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ret = ctl.control_step(T)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    return {"workload": f"{B} Manipulator2D arms x {T} closed-loop control steps, 4 shared obstacles (100 CBF rows + 6 box rows), one launch",
+            "kernel_ms": ms, "agent_steps_per_s": B * T / (ms * 1e-3), "finished": int((ret == -1).sum().item()),
+            "failed": int((ret == -2).sum().item()), "running": int((ret == 0).sum().item()), "dtype": "f64", "storage": "f32"}
+
+
 def closed_loop_leg(dev, B=4096, T=200, seed=0):
     """BASELINE config 2, closed-loop variant: B DynamicUnicycle2D agents track waypoints through the 14-circle
     scene of examples/test_tracking.py for T control steps (selection + nominal input + CBF-QP + step + collision
@@ -475,6 +503,7 @@ def main():
             res["od_mpc_cbf"] = od_mpc_leg(dev)
             res["closed_loop"] = closed_loop_leg(dev)
             res["manipulator_cbf_qp"] = manip_leg(dev)
+            res["manipulator_closed_loop"] = manip_closed_loop_leg(dev)
             res["quad3d_mpc_cbf"] = linear_mpc_leg(dev, "Quad3D")
             res["single_integrator_mpc_cbf"] = linear_mpc_leg(dev, "SingleIntegrator2D")
             res["double_integrator_mpc_cbf"] = gn_mpc_leg(dev, "DoubleIntegrator2D")
