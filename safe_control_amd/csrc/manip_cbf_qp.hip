@@ -62,7 +62,7 @@ struct ActiveSet {
     double lam[3];       // their multipliers (>= 0)
 };
 
-struct Qr { double Q[3][3]; double R[3][3]; };
+struct Qr { double Q[3][3]; double R[3][3]; double Rinv[3]; };   // Rinv[j] = 1 / R[j][j]
 
 __device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
@@ -79,9 +79,12 @@ __device__ __forceinline__ void factor(const ActiveSet& A, Qr& F) {
                     v[0] -= r * F.Q[i][0]; v[1] -= r * F.Q[i][1]; v[2] -= r * F.Q[i][2];
                 }
             }
-            const double nv = sqrt(dot3(v, v));
-            const double inv = 1.0 / nv;
-            F.R[j][j] = nv;
+            // the scalar chain of the active-set step is latency bound: v_rsq / v_rcp seeds + Newton (sc_qp2.hpp) instead of
+            // the IEEE sqrt and divisions (an ulp or two apart; the active normals are independent by construction, |v| > 1e-6)
+            const double vv = dot3(v, v);
+            const double inv = rsqrt_(vv);
+            F.R[j][j] = vv * inv;
+            F.Rinv[j] = inv;
             F.Q[j][0] = v[0] * inv; F.Q[j][1] = v[1] * inv; F.Q[j][2] = v[2] * inv;
         }
     }
@@ -106,7 +109,7 @@ __device__ __forceinline__ void directions(const ActiveSet& A, const Qr& F, cons
 #pragma unroll
             for (int j = 2; j > i; --j)
                 if (j < A.q) s -= F.R[i][j] * r[j];
-            r[i] = s / F.R[i][i];
+            r[i] = s * F.Rinv[i];
         }
     }
 }
@@ -245,10 +248,10 @@ __device__ __forceinline__ int manip_qp(const sc_manip_cbfqp_params& p, const do
 #pragma unroll
             for (int j = 0; j < 3; ++j)
                 if (j < A.q && r[j] > 1e-14) {
-                    const double tj = A.lam[j] / r[j];
+                    const double tj = A.lam[j] * rcp_(r[j]);
                     if (tj < t1) { t1 = tj; l = j; }
                 }
-            const double t2 = dep ? num<double>::inf() : -sp / zz;
+            const double t2 = dep ? num<double>::inf() : -sp * rcp_(zz);
             if (l < 0 && dep) { status = SC_STATUS_INFEASIBLE; break; }
             const double t = fmin(t1, t2);
 #pragma unroll
