@@ -446,8 +446,8 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             else break;
         }
         for (int i = lane; i < m; i += 64) {
-            const double s = W.s[i], l = W.lam[i], sig = l / s;
-            W.vb[i] = mu / s - sig * (W.g[i] - s);
+            const double s = W.s[i], l = W.lam[i], is = rcp_(s), sig = l * is;   // v_rcp seed + two Newton steps (sc_qp2.hpp)
+            W.vb[i] = mu * is - sig * (W.g[i] - s);
             W.ds[i] = sig;                                                // sigma, read below; ds proper is written after the solve
         }
         SC_SYNC();
@@ -576,8 +576,9 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
                 jd = W.dz[i - d.mc - d.ms - n];
             }
             const double dsi = jd + rp;
-            const double dl = -sig * dsi - (l - mu / s);
-            const double rs = dsi / s, rl = dl / l;
+            const double is = rcp_(s);
+            const double dl = -sig * dsi - (l - mu * is);
+            const double rs = dsi * is, rl = dl * rcp_(l);
             rs_min = fmin(rs_min, rs); rl_min = fmin(rl_min, rl);
             sum_ds_s += rs; sum_rp += fabs(rp); sum_log += log(s);
             W.dlam[i] = dl;
@@ -616,7 +617,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         for (int i = lane; i < m; i += 64) {
             const double s = W.s[i] + alpha * W.ds[i];
             double l = W.lam[i] + ad * W.dlam[i];
-            const double mus = mu / s;
+            const double mus = mu * rcp_(s);
             l = fmin(fmax(l, 1e-10 * mus), 1e10 * mus);
             W.s[i] = s; W.lam[i] = l;
         }

@@ -393,8 +393,8 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         // rhs = -sf grad f + J' (mu / s - sig r_p)
         for (int i = lane; i < m; i += 64) {
             const double s = W.s[i], l = W.lam[i];
-            const double sig = l / s;
-            W.vb[i] = mu / s - sig * (W.g[i] - s);
+            const double is = rcp_(s), sig = l * is;                      // v_rcp seed + two Newton steps (sc_qp2.hpp), as kernel 3
+            W.vb[i] = mu * is - sig * (W.g[i] - s);
             W.ds[i] = sig;                                                // read by the Phi blocks below; ds proper is written after the solve
         }
         SC_SYNC();
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         }
         SC_SYNC();
         for (int i = lane; i < n; i += 64)                                   // r_d is consumed: its space holds the box terms
-            W.rd[i] = W.lam[d.mc + i] / W.s[d.mc + i] + W.lam[d.mc + n + i] / W.s[d.mc + n + i];
+            W.rd[i] = W.ds[d.mc + i] + W.ds[d.mc + n + i];                    // sigma of the two box rows (stored above)
         SC_SYNC();
         lin_condense_mfma<NT, NU>(W, N, nu, sf, Hc, G, W.rd, lane);
         SC_SYNC();
@@ -491,8 +491,9 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
                 jd = W.dz[i - d.mc - n];
             }
             const double dsi = jd + rp;
-            const double dl = -(l / s) * dsi - (l - mu / s);
-            const double rs = dsi / s, rl = dl / l;
+            const double is = rcp_(s);
+            const double dl = -(l * is) * dsi - (l - mu * is);
+            const double rs = dsi * is, rl = dl * rcp_(l);
             rs_min = fmin(rs_min, rs); rl_min = fmin(rl_min, rl);
             sum_ds_s += rs; sum_rp += fabs(rp); sum_log += log(s); sum_g += fabs(W.g[i]);
             W.ds[i] = dsi; W.dlam[i] = dl;
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         for (int i = lane; i < m; i += 64) {
             const double s = W.s[i] + alpha * W.ds[i];
             double l = W.lam[i] + ad * W.dlam[i];
-            const double mus = mu / s;
+            const double mus = mu * rcp_(s);
             l = fmin(fmax(l, 1e-10 * mus), 1e10 * mus);                   // IPOPT eq. (16) safeguard
             W.s[i] = s; W.lam[i] = l;
         }
