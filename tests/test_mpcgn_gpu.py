@@ -147,3 +147,31 @@ def test_non_finite_inputs_terminate_and_are_not_reported_optimal():
         torch.cuda.synchronize()
         st = st.cpu().numpy()
         assert np.all(st[1:] != 0) and np.all(it.cpu().numpy() <= 100)
+
+
+@pytest.mark.parametrize("name", ["DoubleIntegrator2D", "Quad2D"])
+def test_full_batch_properties(name):
+    """4096 problems: deterministic launches, termination within the iteration limit, reported optima feasible (oracle's
+    constraint functions on a strided sample) and inside the input box."""
+    B, K, N = 4096, 8, 10
+    mdl = MODELS[name]()
+    rng = np.random.default_rng(21)
+    X = np.zeros((B, mdl["nx"])); Gl = np.zeros((B, 2)); O = np.zeros((B, K, 7))
+    for i in range(B):
+        X[i], Gl[i], O[i] = draw(mdl, rng, K)
+    up = np.tile(u_start(mdl), (B, 1))
+    ctl = sca.BatchedGnMPCCBF({"model": name}, io_dtype="f64", horizon=N)
+    args = (t(X), t(up), t(Gl), t(O))
+    u1, s1, i1, z1 = ctl.solve(*args, want_z=True)
+    u2, s2, i2, z2 = ctl.solve(*args, want_z=True)
+    torch.cuda.synchronize()
+    assert torch.equal(u1, u2) and torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(z1, z2)
+    st, it, z = s1.cpu().numpy(), i1.cpu().numpy(), z1.cpu().numpy()
+    assert it.max() <= 100 and set(np.unique(st)) <= {0, 1, 2} and (st == 0).mean() > 0.85
+    lo, hi = np.tile(mdl["u_lo"], N), np.tile(mdl["u_hi"], N)
+    ok = st == 0
+    assert np.all(z[ok] >= lo - 1e-9) and np.all(z[ok] <= hi + 1e-9)
+    P = G.params(mdl, N)
+    for i in np.flatnonzero(ok)[::97]:
+        g = G.evaluate(X[i], z[i], up[i], Gl[i], O[i], P, level=0)["g"]
+        assert g.min() >= -1e-6

@@ -144,3 +144,28 @@ def test_non_finite_inputs_terminate_and_are_not_reported_optimal():
         torch.cuda.synchronize()
         st = st.cpu().numpy()
         assert np.all(st[1:] != 0) and np.all(it.cpu().numpy() <= 100)
+
+
+@pytest.mark.parametrize("name", ["SingleIntegrator2D", "Quad3D"])
+def test_full_batch_properties(name):
+    """4096 problems (the batch size of BASELINE configs[2]): launches are deterministic, every problem terminates within the
+    iteration limit, reported optima are feasible (oracle's constraint functions on a strided sample) and inside the box."""
+    from safe_control_amd import workloads as W
+    B, K, N = 4096, 8, 10
+    mdl = L.si_model() if name == "SingleIntegrator2D" else L.quad3d_model()
+    Xn, gn, on = W.linear_mpc_batch(name, B, K, seed=2)
+    ctl = sca.BatchedLinearMPCCBF({"model": name}, io_dtype="f64", horizon=N)
+    args = (t(Xn), t(np.zeros((B, mdl["nu"]))), t(gn), t(on))
+    u1, s1, i1, z1 = ctl.solve(*args, want_z=True)
+    u2, s2, i2, z2 = ctl.solve(*args, want_z=True)
+    torch.cuda.synchronize()
+    assert torch.equal(u1, u2) and torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(z1, z2)
+    st, it, z = s1.cpu().numpy(), i1.cpu().numpy(), z1.cpu().numpy()
+    assert it.max() <= 100 and set(np.unique(st)) <= {0, 1, 2} and (st == 0).mean() > 0.8
+    lo, hi = np.tile(mdl["u_lo"], N), np.tile(mdl["u_hi"], N)
+    ok = st == 0
+    assert np.all(z[ok] >= lo - 1e-9) and np.all(z[ok] <= hi + 1e-9)
+    P = L.params(mdl, N)
+    for i in np.flatnonzero(ok)[::97]:
+        g = L.evaluate(Xn[i], z[i], np.zeros(mdl["nu"]), gn[i], on[i], P, level=0)["g"]
+        assert g.min() >= -1e-6
