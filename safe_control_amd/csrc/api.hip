@@ -47,7 +47,7 @@ hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long lo
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                          hipStream_t stream);
 
-size_t mpcgn_lds_bytes(int model_id, int N, int K);
+size_t mpcgn_lds_bytes(int model_id, int N, int K, int circles_only);
 hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
                         const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream);
 
@@ -152,7 +152,7 @@ static int check_mpcgn(const sc_mpcgn_params* p, int64_t B, int32_t K, const voi
     if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
         return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
     if (p->horizon < 1 || p->horizon > 32) return fail(SC_ERR_UNSUPPORTED, "horizon outside [1, 32]");
-    if (mpcgn_lds_bytes(p->model_id, p->horizon, K) > 160 * 1024)
+    if (mpcgn_lds_bytes(p->model_id, p->horizon, K, p->circles_only) > 160 * 1024)
         return fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
     if (!(p->dt > 0) || !(p->tol > 0) || !(p->acceptable_tol >= p->tol) || p->max_iter < 1 || !(p->mu_init > 0) || !(p->mu_min > 0))
         return fail(SC_ERR_INVALID_ARGUMENT, "dt, tol, mu_init, mu_min must be > 0 and max_iter >= 1");

@@ -154,17 +154,18 @@ struct GnMem {
     double *xs, *Ph, *pts, *y, *pdz, *G, *T;              // (N+1) nx | (N+1) nx n | 6N | 6N | 6N | 6N n | 6N n
     double *obs, *hk, *dh, *hh;                           // 7K | 3N K | 6N K | 9N K
     double *g, *s, *lam, *ds, *dlam, *vb;                 // m each
-    double *Psi, *Hc, *M, *L;                             // 36 N | n n | n n | (L: scratch in T)
+    double *Psi, *M, *L;                                  // 36 N | n n | (L: scratch in T)
     double *Hk;                                           // 2 N: second-order terms of the dynamics (a_k, b_k)
 };
 
-struct GnDims { int N, K, n, m, mc, ms; };
+struct GnDims { int N, K, n, m, mc, ms; bool circles; };
 
-__host__ __device__ inline size_t mpcgn_lds_doubles(int N, int K, int nx, int nb) {
+// circles: the barrier Hessian of a circle is 2 I, so its per-point table (9 N K) is not stored
+__host__ __device__ inline size_t mpcgn_lds_doubles(int N, int K, int nx, int nb, bool circles) {
     const size_t n = 2 * (size_t)N, m = (size_t)N * K + 2 * (size_t)nb * N + 2 * n;
     size_t tot = 12 + nx + 2 + 7 * n + (size_t)(N + 1) * nx + (size_t)(N + 1) * nx * n + 18 * (size_t)N + 12 * (size_t)N * n +
-                 7 * (size_t)K + 18 * (size_t)N * K + 6 * m + 36 * (size_t)N + 2 * n * n + 2 * (size_t)N;
-    const size_t need_l = n * (n + 1), have = 6 * (size_t)N * n;             // transpose scratch of the register Cholesky lives in T
+                 7 * (size_t)K + (circles ? 9 : 18) * (size_t)N * K + 5 * m + 36 * (size_t)N + n * n + 2 * (size_t)N;
+    const size_t need_l = n * (n + 1) + m, have = 6 * (size_t)N * n;         // Cholesky scratch L and the row vector vb live in T
     return tot + (need_l > have ? need_l - have : 0);
 }
 
@@ -178,11 +179,12 @@ __device__ inline GnMem carve_gn(double* b, const GnDims& d) {
     W.xs = take((N + 1) * NX); W.Ph = take((size_t)(N + 1) * NX * n);
     W.pts = take(6 * N); W.y = take(6 * N); W.pdz = take(6 * N);
     W.G = take((size_t)6 * N * n);
-    W.obs = take(7 * K); W.hk = take(3 * N * K); W.dh = take(6 * N * K); W.hh = take(9 * N * K);
-    W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m); W.vb = take(m);
-    W.Psi = take(36 * N); W.Hc = take((size_t)n * n); W.M = take((size_t)n * n);
+    W.obs = take(7 * K); W.hk = take(3 * N * K); W.dh = take(6 * N * K); W.hh = take(d.circles ? 0 : 9 * N * K);
+    W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m);
+    W.Psi = take(36 * N); W.M = take((size_t)n * n);
     W.Hk = take(2 * (size_t)N);
     W.T = take((size_t)6 * N * n); W.L = W.T;                     // T is dead once M is assembled
+    W.vb = W.T + (size_t)n * (n + 1);                              // written before T is built and again after the solve
     return W;
 }
 
@@ -271,7 +273,7 @@ __device__ __forceinline__ double gn_eval(const double* zv, const GnMem& W, cons
         W.hk[e] = h;
         if (derivs) {
             W.dh[2 * e] = d0; W.dh[2 * e + 1] = d1;
-            W.hh[3 * e] = hxx; W.hh[3 * e + 1] = hxy; W.hh[3 * e + 2] = hyy;
+            if (!d.circles) { W.hh[3 * e] = hxx; W.hh[3 * e + 1] = hxy; W.hh[3 * e + 2] = hyy; }
         }
     }
     SC_SYNC();
@@ -347,6 +349,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
 
     GnDims d;
     d.N = NT > 0 ? NT : p.horizon; d.K = K; d.n = 2 * d.N; d.mc = d.N * K; d.ms = 2 * NB * d.N; d.m = d.mc + d.ms + 2 * d.n;
+    d.circles = p.circles_only != 0;
     const int N = d.N, n = d.n, m = d.m;
     const GnMem W = carve_gn<NX>(sm, d);
     GnConst c;
@@ -463,30 +466,11 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
                 const int row = k * K + j, er = (3 * k + pr) * K + j, ec = (3 * k + pc) * K + j;
                 const double l = W.lam[row], sig = W.ds[row];
                 acc += sig * (wr * W.dh[2 * er + (r & 1)]) * (wc * W.dh[2 * ec + (cc & 1)]);
-                if (pr == pc) acc -= l * wr * W.hh[3 * er + (r & 1) + (cc & 1)];
+                if (pr == pc) acc -= l * wr * (d.circles ? ((r & 1) == (cc & 1) ? 2.0 : 0.0) : W.hh[3 * er + (r & 1) + (cc & 1)]);
             }
             W.Psi[e] = acc;
         }
         GP(4);
-        // Gauss-Newton cost Hessian  Hc = 2 sum_k Phi_k' Q Phi_k + 2 D' R D  (lower triangle, mirrored)
-        for (int e = lane; e < n * (n + 1) / 2; e += 64) {
-            int i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-            while ((i + 1) * (i + 2) / 2 <= e) ++i;
-            while (i * (i + 1) / 2 > e) --i;
-            const int j = e - i * (i + 1) / 2;
-            double acc = 0.0;
-            for (int k = 1; k <= N; ++k) {
-#pragma unroll
-                for (int s_ = 0; s_ < NX; ++s_)
-                    acc += W.cq[s_] * W.Ph[(size_t)(k * NX + s_) * n + i] * W.Ph[(size_t)(k * NX + s_) * n + j];
-            }
-            acc *= 2.0;
-            const double ri = W.cq[6 + (i & 1)];
-            if (i == j) acc += 2.0 * ri + (i + 2 < n ? 2.0 * ri : 0.0);
-            if (i == j + 2) acc -= 2.0 * ri;
-            W.Hc[(size_t)i * n + j] = acc;
-            W.Hc[(size_t)j * n + i] = acc;
-        }
         SC_SYNC();
         GP(5);
         for (int e = lane; e < 6 * N * n; e += 64) {                          // T = Psi G
@@ -502,7 +486,17 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             while ((i + 1) * (i + 2) / 2 <= e) ++i;
             while (i * (i + 1) / 2 > e) --i;
             const int j = e - i * (i + 1) / 2;
-            double acc = sf * W.Hc[(size_t)i * n + j];
+            double acc = 0.0;                                                 // Gauss-Newton cost Hessian 2 sum_k Phi_k' Q Phi_k + 2 D' R D
+            for (int k = 1; k <= N; ++k) {
+#pragma unroll
+                for (int s_ = 0; s_ < NX; ++s_)
+                    acc += W.cq[s_] * W.Ph[(size_t)(k * NX + s_) * n + i] * W.Ph[(size_t)(k * NX + s_) * n + j];
+            }
+            acc *= 2.0;
+            const double ri = W.cq[6 + (i & 1)];
+            if (i == j) acc += 2.0 * ri + (i + 2 < n ? 2.0 * ri : 0.0);
+            if (i == j + 2) acc -= 2.0 * ri;
+            acc *= sf;
             for (int r = 0; r < 6 * N; ++r) acc += W.G[(size_t)r * n + i] * W.T[(size_t)r * n + j];
             if constexpr (NB > 0) {
                 for (int k = 1; k <= N; ++k) {
@@ -653,7 +647,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
 template <int MODEL>
 static hipError_t mpcgn_launch_m(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
                                  const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream) {
-    const size_t lds = mpcgn_lds_doubles(p.horizon, K, GnModel<MODEL>::NX, GnModel<MODEL>::NB) * sizeof(double);
+    const size_t lds = mpcgn_lds_doubles(p.horizon, K, GnModel<MODEL>::NX, GnModel<MODEL>::NB, p.circles_only != 0) * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 64 * 1024) {
@@ -669,9 +663,9 @@ static hipError_t mpcgn_launch_m(const sc_mpcgn_params& p, long long B, int K, c
 
 }  // namespace
 
-size_t mpcgn_lds_bytes(int model_id, int N, int K) {
+size_t mpcgn_lds_bytes(int model_id, int N, int K, int circles_only) {
     const int nx = model_id == SC_MODEL_QUAD2D ? 6 : 4;
-    return mpcgn_lds_doubles(N, K, nx, 0) * sizeof(double);
+    return mpcgn_lds_doubles(N, K, nx, 0, circles_only != 0) * sizeof(double);
 }
 
 hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
