@@ -523,9 +523,10 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             if constexpr (NT > 0) {
                 ok = ipm::chol_reg_solve<2 * NT>(W.M, W.rhs, W.L, W.dz, delta, lane);
             } else {
-                for (int e = lane; e < n * n; e += 64) W.L[e] = W.M[e] + ((e / n == e % n) ? delta : 0.0);
+                for (int r = 0; r < n; ++r)                                 // lower triangle, row stride n | 1 (odd: no LDS bank conflicts)
+                    for (int cc = lane; cc <= r; cc += 64) W.L[r * (n | 1) + cc] = W.M[r * n + cc] + (cc == r ? delta : 0.0);
                 SC_SYNC();
-                ok = ipm::cholesky_lds(W.L, n, lane);
+                ok = ipm::cholesky_lds(W.L, n, n | 1, lane);
             }
             if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
         }
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         if constexpr (NT == 0) {
             for (int i = lane; i < n; i += 64) W.dz[i] = W.rhs[i];
             SC_SYNC();
-            ipm::chol_solve_lds(W.L, W.dz, n, lane);
+            ipm::chol_solve_lds(W.L, W.dz, n, n | 1, lane);
         }
         GP(7);
         for (int r = lane; r < 6 * N; r += 64) {

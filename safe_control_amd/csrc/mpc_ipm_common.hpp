@@ -68,68 +68,166 @@ __device__ inline void ipm_barrier(double px_, double py_, const double* o, doub
 }
 
 
-// Cholesky in LDS for run-time orders (L = lower of A, row stride n), false on a pivot <= 0.  Right-looking with panels of
-// 4 columns: the panel is factored column by column (updates confined to the panel), the trailing matrix then takes ONE
-// rank-4 update per 16 x 16 tile as a v_mfma_f64_16x16x4_f64 (A = panel rows of the tile's rows, B' = panel rows of its
-// columns): n^3 / 3 multiply-adds leave the LDS read-modify-write loop (n = 80: 533 k -> 60 k cycles).
+// Cholesky in LDS for run-time orders (L = lower of A, row stride ld), false on a pivot <= 0.  ld is ODD (callers pass
+// n + 1 for even n): a column walk A[i * ld + j] over the lanes then touches 32 distinct bank pairs, where the natural
+// stride n = 80 doubles maps every row onto two (a 32-way conflict on each column scale, panel update and MFMA operand read).
+// Right-looking with panels of 4 columns: the panel is factored column by column (updates confined to the panel), the
+// trailing matrix then takes ONE rank-4 update per 16 x 16 tile as a v_mfma_f64_16x16x4_f64 (A = panel rows of the tile's
+// rows, B' = panel rows of its columns).  The diagonal is left as 1 / L_jj: the solves multiply.
 typedef double ipm_c4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bool cholesky_lds(double* A, int n, int lane) {
-    bool ok = true;
-    const int q = lane >> 4, l15 = lane & 15;
-    for (int j0 = 0; j0 < n; j0 += 4) {
-        const int pw = n - j0 < 4 ? n - j0 : 4;
-        for (int jj = 0; jj < pw; ++jj) {
-            const int j = j0 + jj;
-            const double dd = A[j * n + j];
-            if (!(dd > 0.0)) ok = false;
-            const double inv = 1.0 / sqrt(dd);
-            SC_SYNC();
-            for (int i = j + lane; i < n; i += 64) A[i * n + j] = (i == j) ? dd * inv : A[i * n + j] * inv;
-            SC_SYNC();
-            // the remaining panel columns c = j+1 .. j0+pw-1, rows i >= c
-            for (int e = lane; e < (n - j - 1) * (pw - jj - 1); e += 64) {
-                const int c = j + 1 + e / (n - j - 1), i = j + 1 + e % (n - j - 1);
-                if (i >= c) A[i * n + c] -= A[i * n + j] * A[c * n + j];
-            }
-            SC_SYNC();
-            if (!ok) return false;                                         // uniform: every lane read the same pivot
-        }
-        const int t0 = j0 + pw;                                            // trailing matrix starts here
-        if (t0 >= n) break;
-        const int ntile = (n - t0 + 15) >> 4;
-        for (int ti = 0; ti < ntile; ++ti) {
-            for (int tj = 0; tj <= ti; ++tj) {
-                const int ra = t0 + 16 * ti + l15, rb = t0 + 16 * tj + l15;
-                const double a = (ra < n && q < pw) ? A[ra * n + j0 + q] : 0.0;
-                const double b = (rb < n && q < pw) ? A[rb * n + j0 + q] : 0.0;
-                ipm_c4 acc = {0.0, 0.0, 0.0, 0.0};
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+__device__ __forceinline__ double lane_value(double v, int src);
+// n <= 128.  A lone wave hides no latency and issues one instruction every few cycles, so what this routine costs is its
+// count of DEPENDENT LDS round trips and of instructions.  The panel is factored in registers (lane l holds the four panel
+// entries of rows l and 64 + l; pivots and multipliers travel by v_readlane: one load burst and one store burst per panel
+// instead of ~20 round trips and 12 barriers).  The trailing update walks the FIXED 16 x 16 tile grid: rows and columns
+// that are not part of the trailing matrix (already final) are switched off by zeroing their MFMA operand, so a tile
+// element needs no predicate (the strict upper triangle holds don't-care values); only the last tile row of an order that
+// is not a multiple of 16 takes the guarded variant (rows and columns >= n do not exist in the n x ld scratch).
+template <int U, bool GUARD>
+__device__ __forceinline__ void chol_tiles(double* A, int ld, int j0, int t0, int n, int pw, int ti, int tj0, double a, int q, int l15) {
+    double b[U];
+    ipm_c4 acc[U];
+    double* crow = A + (16 * ti + q) * ld + l15;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = t0 + 16 * ti + q + 4 * r, col = t0 + 16 * tj + l15;
-                    if (row < n && col <= row) A[row * n + col] -= acc[r];
+    for (int u = 0; u < U; ++u) {
+        const int rb = 16 * (tj0 + u) + l15;
+        const double bv = A[(GUARD && rb >= n ? 0 : rb) * ld + j0 + q];
+        b[u] = (rb >= t0 && rb < n && q < pw) ? bv : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool in = !GUARD || (16 * ti + q + 4 * r < n && rb < n);
+            acc[u][r] = in ? crow[4 * r * ld + 16 * (tj0 + u)] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[u], acc[u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool in = !GUARD || (16 * ti + q + 4 * r < n && 16 * (tj0 + u) + l15 < n);
+            if (in) crow[4 * r * ld + 16 * (tj0 + u)] = acc[u][r];
+        }
+    }
+}
+// One panel (columns j0 .. j0 + pw - 1) in the registers of ONE wave; false (wave-uniform) on a pivot <= 0.
+__device__ __forceinline__ bool chol_panel(double* A, int n, int ld, int j0, int pw, int lane) {
+    const int r0 = lane, r1 = 64 + lane;
+    const int c1 = r1 < n ? r1 : r0;                                       // in-range stand-in row for the loads of lanes without a second row
+    double p0[4], p1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        p0[c] = A[r0 * ld + j0 + (c < pw ? c : 0)];
+        p1[c] = A[c1 * ld + j0 + (c < pw ? c : 0)];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        if (jj < pw) {
+            const int j = j0 + jj;
+            const double dd = j < 64 ? lane_value(p0[jj], j) : lane_value(p1[jj], j - 64);
+            if (!(dd > 0.0)) return false;
+            const double inv = rsqrt_(dd);                                 // v_rsq_f64 + two Newton steps (sc_qp2.hpp), as mpc_chol.hpp
+            p0[jj] = r0 == j ? inv : p0[jj] * inv;                         // (rows above the diagonal carry don't-care values)
+            p1[jj] = r1 == j ? inv : p1[jj] * inv;
+#pragma unroll
+            for (int c = jj + 1; c < 4; ++c) {
+                if (c < pw) {
+                    const int rc = j0 + c;
+                    const double lc = rc < 64 ? lane_value(p0[jj], rc) : lane_value(p1[jj], rc - 64);
+                    p0[c] -= p0[jj] * lc;
+                    p1[c] -= p1[jj] * lc;
                 }
             }
         }
-        SC_SYNC();
     }
-    return ok;
+    if (r0 >= j0 && r0 < n) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < pw) A[r0 * ld + j0 + c] = p0[c];
+    }
+    if (r1 >= j0 && r1 < n) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (c < pw) A[r1 * ld + j0 + c] = p1[c];
+    }
+    return true;
 }
-__device__ __forceinline__ void chol_solve_lds(const double* L, double* b, int n, int lane) {
+// NW waves share the factorisation (tid = thread index among them): wave 0 factors the panel and posts its verdict in
+// `flag` (an LDS word), the tiles of the trailing update are dealt round-robin.  NW = 1: flag unused.
+template <int NW = 1>
+__device__ __forceinline__ bool cholesky_lds(double* A, int n, int ld, int tid, double* flag = nullptr) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const int q = lane >> 4, l15 = lane & 15;
+    for (int j0 = 0; j0 < n; j0 += 4) {
+        const int pw = n - j0 < 4 ? n - j0 : 4;
+        bool ok = true;
+        if (NW == 1 || wv == 0) ok = chol_panel(A, n, ld, j0, pw, lane);
+        if constexpr (NW > 1) {
+            if (tid == 0) *flag = ok ? 1.0 : 0.0;
+            SC_SYNC();
+            ok = *flag != 0.0;
+        } else {
+            SC_SYNC();
+        }
+        if (!ok) return false;
+        const int t0 = j0 + pw;                                            // trailing matrix starts here
+        if (t0 >= n) break;
+        const int tb = t0 >> 4, te = (n + 15) >> 4;
+        int item = 0;
+        for (int ti = tb; ti < te; ++ti) {
+            const int ra = 16 * ti + l15;
+            const double av = A[(ra < n ? ra : 0) * ld + j0 + q];
+            const double a = (ra >= t0 && ra < n && q < pw) ? -av : 0.0;
+            int tj = tb;
+            if (16 * ti + 16 <= n) {
+                if constexpr (NW == 1) {
+                    for (; tj + 3 <= ti; tj += 4) chol_tiles<4, false>(A, ld, j0, t0, n, pw, ti, tj, a, q, l15);
+                    if (tj + 1 <= ti) { chol_tiles<2, false>(A, ld, j0, t0, n, pw, ti, tj, a, q, l15); tj += 2; }
+                    if (tj <= ti) chol_tiles<1, false>(A, ld, j0, t0, n, pw, ti, tj, a, q, l15);
+                } else {
+                    for (; tj <= ti; ++tj)
+                        if ((item++ & (NW - 1)) == wv) chol_tiles<1, false>(A, ld, j0, t0, n, pw, ti, tj, a, q, l15);
+                }
+            } else {
+                for (; tj <= ti; ++tj)
+                    if (NW == 1 || (item++ & (NW - 1)) == wv) chol_tiles<1, true>(A, ld, j0, t0, n, pw, ti, tj, a, q, l15);
+            }
+        }
+        SC_SYNC();
+    }
+    return true;
+}
+__device__ __forceinline__ double lane_value(double v, int src) {           // src: wave-uniform lane
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// L L' x = b in place, n <= 128: lane l keeps entries l and 64 + l in registers, the pivot entry is broadcast with
+// v_readlane, so the 2 n elimination steps run without a barrier and the L reads (addresses independent of the data) pipeline.
+template <int NW = 1>
+__device__ __forceinline__ void chol_solve_lds(const double* L, double* b, int n, int ld, int tid) {
+    if (NW > 1 && tid >= 64) { SC_SYNC(); return; }                        // the other waves of the problem wait for wave 0
+    const int lane = tid;
+    const int i0 = lane, i1 = 64 + lane;
+    const int c0 = i0 < n ? i0 : 0, c1 = i1 < n ? i1 : c0;                // in-range rows for the unpredicated loads
+    double b0 = i0 < n ? b[i0] : 0.0, b1 = i1 < n ? b[i1] : 0.0;
+    const double* l0 = L + c0 * ld;
+    const double* l1 = L + c1 * ld;
+#pragma unroll 4
     for (int j = 0; j < n; ++j) {
-        if (lane == 0) b[j] = b[j] / L[j * n + j];
-        SC_SYNC();
-        const double yj = b[j];
-        for (int i = j + 1 + lane; i < n; i += 64) b[i] -= L[i * n + j] * yj;
-        SC_SYNC();
+        const double m0 = l0[j], m1 = l1[j];
+        const double yj = (j < 64 ? lane_value(b0, j) : lane_value(b1, j - 64)) * L[j * ld + j];
+        b0 = i0 == j ? yj : (i0 > j ? b0 - m0 * yj : b0);
+        b1 = i1 == j ? yj : (i1 > j ? b1 - m1 * yj : b1);
     }
+#pragma unroll 4
     for (int j = n - 1; j >= 0; --j) {
-        if (lane == 0) b[j] = b[j] / L[j * n + j];
-        SC_SYNC();
-        const double xj = b[j];
-        for (int i = lane; i < j; i += 64) b[i] -= L[j * n + i] * xj;
-        SC_SYNC();
+        const double m0 = L[j * ld + c0], m1 = L[j * ld + c1];
+        const double xj = (j < 64 ? lane_value(b0, j) : lane_value(b1, j - 64)) * L[j * ld + j];
+        b0 = i0 == j ? xj : (i0 < j ? b0 - m0 * xj : b0);
+        b1 = i1 == j ? xj : (i1 < j ? b1 - m1 * xj : b1);
     }
+    if (i0 < n) b[i0] = b0;
+    if (i1 < n) b[i1] = b1;
+    SC_SYNC();
 }
 
 // register Cholesky for a compile-time order (mpc_chol.hpp); out of line like mpc_cbf.hip's (code size)

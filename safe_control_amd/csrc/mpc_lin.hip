@@ -29,9 +29,31 @@ namespace {
 
 using ipm::cholesky_lds;
 using ipm::chol_solve_lds;
-__device__ __forceinline__ double lsum(double v) { return ipm::wsum(v); }
-__device__ __forceinline__ double lmin(double v) { return ipm::wmin(v); }
-__device__ __forceinline__ double lmax_(double v) { return ipm::wmax(v); }
+// Reductions over the TH threads that share a problem.  TH = 64: the wave reduction.  TH = 256 (the big layout, one problem
+// per CU: its four waves sit on the four SIMDs): wave totals meet in LDS; two alternating slots, so ONE barrier per
+// reduction (a slot is rewritten only after the barrier of the next reduction, which every reader of it has passed).
+struct Red { double* buf; int par; };
+template <int TH, typename F, typename WF>
+__device__ __forceinline__ double block_red(double v, Red& R, F f, WF wf) {
+    v = wf(v);
+    if constexpr (TH > 64) {
+        double* b = R.buf + 4 * R.par;
+        R.par ^= 1;
+        if ((threadIdx.x & 63) == 0) b[threadIdx.x >> 6] = v;
+        SC_SYNC();
+        v = f(f(b[0], b[1]), f(b[2], b[3]));
+    }
+    return v;
+}
+template <int TH> __device__ __forceinline__ double lsum(double v, Red& R) {
+    return block_red<TH>(v, R, [](double a, double b) { return a + b; }, [](double a) { return ipm::wsum(a); });
+}
+template <int TH> __device__ __forceinline__ double lmin(double v, Red& R) {
+    return block_red<TH>(v, R, [](double a, double b) { return fmin(a, b); }, [](double a) { return ipm::wmin(a); });
+}
+template <int TH> __device__ __forceinline__ double lmax_(double v, Red& R) {
+    return block_red<TH>(v, R, [](double a, double b) { return fmax(a, b); }, [](double a) { return ipm::wmax(a); });
+}
 
 struct LinMem {
     double *Ae, *Be, *As2, *Bs2, *xg, *up, *lx;          // model, goal state, previous input, adjoint (2 nx)
@@ -40,6 +62,7 @@ struct LinMem {
     double *g, *s, *lam, *ds, *dlam, *vb;                // m each
     double *cq;                                          // Q (12) | R (4) | u_lo (4) | u_hi (4)
     double *Phi, *T, *M, *L, *G;                         // 16 N | 4N n | n n | n (n + 1) | 4N n
+    double *red;                                         // 8 reduction slots + the Cholesky status word (multi-wave layout)
     double *Hc, *clin;                                   // lean kernels: n n copy of the cost Hessian, n constant part of grad f
 };
 
@@ -56,9 +79,10 @@ enum { LIN_STD = 0, LIN_LEAN = 1, LIN_BIG = 2 };
 __host__ __device__ inline size_t mpclin_lds_doubles(int N, int K, int nx, int nu, int mode = LIN_STD) {
     const bool lean = mode == LIN_LEAN;
     const size_t n = (size_t)N * nu, m = (size_t)N * K + 2 * n;
-    return (size_t)nx * nx + (size_t)nx * nu + 2 * nx + 2 * nu + nx + nu + 2 * nx + 24 + 7 * n + (size_t)(N + 1) * nx + 12 * N +
+    return (size_t)nx * nx + (size_t)nx * nu + 2 * nx + 2 * nu + nx + nu + 2 * nx + 24 + 10 + 7 * n + (size_t)(N + 1) * nx + 12 * N +
            7 * (size_t)K + 12 * (size_t)N * K + 6 * m + 16 * N + 4 * (size_t)N * n + n * n +
-           (mode == LIN_BIG ? 0 : 4 * (size_t)N * n + (lean ? n * n + n : n * (n + 1)));
+           (mode == LIN_BIG ? (n * (n + 1) > 4 * (size_t)N * n ? n * (n + 1) - 4 * (size_t)N * n : 0)
+                            : 4 * (size_t)N * n + (lean ? n * n + n : n * (n + 1)));
 }
 
 __device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode) {
@@ -67,12 +91,13 @@ __device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode) {
     auto take = [&](size_t c) { double* r = b; b += c; return r; };
     const int N = d.N, K = d.K, nx = d.nx, nu = d.nu, n = d.n, m = d.m;
     W.Ae = take(nx * nx); W.Be = take(nx * nu); W.As2 = take(2 * nx); W.Bs2 = take(2 * nu);
-    W.xg = take(nx); W.up = take(nu); W.lx = take(2 * nx); W.cq = take(24);
+    W.xg = take(nx); W.up = take(nu); W.lx = take(2 * nx); W.cq = take(24); W.red = take(10);
     W.z = take(n); W.zt = take(n); W.zb = take(n); W.dz = take(n); W.gs = take(n); W.rd = take(n); W.rhs = take(n);
     W.xs = take((N + 1) * nx); W.pts = take(4 * N); W.y = take(4 * N); W.pdz = take(4 * N);
     W.obs = take(7 * K); W.hk = take(2 * N * K); W.dh = take(4 * N * K); W.hh = take(6 * N * K);
     W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m); W.vb = take(m);
-    W.Phi = take(16 * N); W.T = take((size_t)4 * N * n); W.M = take((size_t)n * n);
+    const size_t tsz = (size_t)4 * N * n, lsz = (size_t)n * (n + 1);       // big: L (row stride n | 1) takes the dead T, widened to hold it
+    W.Phi = take(16 * N); W.T = take(mode == LIN_BIG && lsz > tsz ? lsz : tsz); W.M = take((size_t)n * n);
     W.Hc = W.clin = nullptr;
     if (mode == LIN_BIG) { W.G = nullptr; W.L = W.T; return W; }
     W.G = take((size_t)4 * N * n);
@@ -87,8 +112,9 @@ struct LinConst {
 };
 
 // rollout, barrier points, f, barrier values (and derivatives), g.  Points: a_k = index k, b_k = index N + k.
+template <int TH>
 __device__ __forceinline__ double lin_eval(const double* zv, const LinMem& W, const LinDims& d, const LinConst& c, int lane,
-                                        bool derivs) {
+                                        bool derivs, Red& R) {
     const int N = d.N, K = d.K, nx = d.nx, nu = d.nu, n = d.n;
     for (int k = 0; k < N; ++k) {
         if (lane < nx) {
@@ -101,7 +127,7 @@ __device__ __forceinline__ double lin_eval(const double* zv, const LinMem& W, co
         }
         SC_SYNC();
     }
-    for (int e = lane; e < 2 * N; e += 64) {
+    for (int e = lane; e < 2 * N; e += TH) {
         const int k = e >> 1, dd = e & 1;
         W.pts[e] = W.xs[k * nx + dd];
         double acc = 0.0;
@@ -112,18 +138,18 @@ __device__ __forceinline__ double lin_eval(const double* zv, const LinMem& W, co
         W.pts[2 * N + e] = acc;
     }
     double part = 0.0;
-    for (int e = lane; e < N * nx; e += 64) {
+    for (int e = lane; e < N * nx; e += TH) {
         const int k = e / nx + 1, i = e - (k - 1) * nx;
         const double dv = W.xs[k * nx + i] - W.xg[i];
         part += W.cq[i] * dv * dv;
     }
-    for (int i = lane; i < n; i += 64) {
+    for (int i = lane; i < n; i += TH) {
         const double prev = i >= nu ? zv[i - nu] : W.up[i];
         const double du = zv[i] - prev;
         part += W.cq[12 + i % nu] * du * du;
     }
     SC_SYNC();
-    for (int e = lane; e < 2 * N * K; e += 64) {
+    for (int e = lane; e < 2 * N * K; e += TH) {
         const int pt = e / K, j = e - pt * K;
         double h, d0, d1, hxx, hxy, hyy;
         ipm::ipm_barrier(W.pts[2 * pt], W.pts[2 * pt + 1], W.obs + 7 * j, c.Rrob, c.beta, c.circles_only != 0, derivs, h, d0, d1, hxx, hxy, hyy);
@@ -134,7 +160,7 @@ __device__ __forceinline__ double lin_eval(const double* zv, const LinMem& W, co
         }
     }
     SC_SYNC();
-    for (int i = lane; i < d.m; i += 64) {
+    for (int i = lane; i < d.m; i += TH) {
         double gi;
         if (i < d.mc) {
             const int k = i / K, j = i - k * K;
@@ -149,10 +175,11 @@ __device__ __forceinline__ double lin_eval(const double* zv, const LinMem& W, co
         W.g[i] = gi;
     }
     SC_SYNC();
-    return lsum(part);
+    return lsum<TH>(part, R);
 }
 
 // gradient of the (unscaled) cost by the adjoint recursion:  l_k = 2 Q (x_k - xg) + Ae' l_{k+1},  df/du_{k-1} = Be' l_k
+template <int TH>
 __device__ __forceinline__ void lin_grad(const LinMem& W, const LinDims& d, const LinConst& c, int lane, double sf) {
     const int N = d.N, nx = d.nx, nu = d.nu, n = d.n;
     for (int k = N; k >= 1; --k) {
@@ -174,7 +201,7 @@ __device__ __forceinline__ void lin_grad(const LinMem& W, const LinDims& d, cons
         }
         SC_SYNC();
     }
-    for (int i = lane; i < n; i += 64) {
+    for (int i = lane; i < n; i += TH) {
         const double prev = i >= nu ? W.z[i - nu] : W.up[i];
         double gr = W.gs[i] + 2.0 * W.cq[12 + i % nu] * (W.z[i] - prev);
         if (i + nu < n) gr -= 2.0 * W.cq[12 + i % nu] * (W.z[i + nu] - W.z[i]);
@@ -184,10 +211,11 @@ __device__ __forceinline__ void lin_grad(const LinMem& W, const LinDims& d, cons
 }
 
 // out = J' v for a row vector v (m):  G' (A' v) - v_hi + v_lo
+template <int TH>
 __device__ __forceinline__ void lin_jt(const double* v, double* out, const LinMem& W, const LinDims& d, const LinConst& c,
                                     const double* G, int lane) {
     const int N = d.N, K = d.K, n = d.n;
-    for (int e = lane; e < 4 * N; e += 64) {
+    for (int e = lane; e < 4 * N; e += TH) {
         const int pt = e >> 1, dd = e & 1, k = pt < N ? pt : pt - N;
         double acc = 0.0;
 #pragma unroll
@@ -195,7 +223,7 @@ __device__ __forceinline__ void lin_jt(const double* v, double* out, const LinMe
         W.y[e] = pt < N ? c.w0 * acc : acc;
     }
     SC_SYNC();
-    for (int i = lane; i < n; i += 64) {
+    for (int i = lane; i < n; i += TH) {
         double acc = 0.0;
 #pragma unroll 8
         for (int r = 0; r < 4 * N; ++r) acc += G[(size_t)r * n + i] * W.y[r];
@@ -213,9 +241,12 @@ __device__ __forceinline__ void lin_jt(const double* v, double* out, const LinMe
 typedef double lin_d4 __attribute__((ext_vector_type(4)));
 // NT, NU > 0: compile-time horizon and input count (all operands of a tile are loaded first, then its MFMAs issue back to
 // back); NT == 0: run-time sizes, operands in chunks of 4 stages.
-template <int NT, int NU>
+// NW > 1: the tiles are dealt round-robin to the NW waves of the problem (tid = thread index among them).
+template <int NT, int NU, int NW = 1>
 __device__ __forceinline__ void lin_condense_mfma(const LinMem& W, const int N_rt, const int nu_rt, double sf, const double* Hc,
-                                                  const double* G, const double* box, int lane) {
+                                                  const double* G, const double* box, int tid) {
+    const int lane = tid & 63, wv = tid >> 6;
+    int tile = 0;
     const int N = NT > 0 ? NT : N_rt, nu = NT > 0 ? NU : nu_rt, n = N * nu, nt = (n + 15) / 16;
     constexpr int S = NT > 0 ? NT : 4;
     const int q = lane >> 4, l15 = lane & 15;
@@ -225,6 +256,7 @@ __device__ __forceinline__ void lin_condense_mfma(const LinMem& W, const int N_r
         const int iac = okA ? ia : 0;
         const int k_lo = (16 * ti) / nu;
         for (int tj = 0; tj <= ti; ++tj) {
+            if (NW > 1 && (tile++ & (NW - 1)) != wv) continue;
             const int jb = 16 * tj + l15;
             const bool okB = jb < n;
             const int jbc = okB ? jb : 0;
@@ -266,13 +298,14 @@ __device__ __forceinline__ void lin_condense_mfma(const LinMem& W, const int N_r
 // issued back to back; with run-time bounds every multiply-add waits a full LDS round trip); NT > 0 (needs NX > 0): the
 // horizon too -- register Cholesky, lean LDS layout; KT > 0: obstacle rows.  0: run-time size.
 template <int NX, int NU, int NT, int KT, bool BIG = false>
-__global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, const long long B,
+__global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, const long long B,
                                                     const int K_rt, const void* __restrict__ X, const void* __restrict__ u_prev,
                                                     const void* __restrict__ goal, const void* __restrict__ obs,
                                                     void* __restrict__ u_out, int* __restrict__ status_out,
                                                     int* __restrict__ iters_out, void* __restrict__ z_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int lane = threadIdx.x;
+    constexpr int NW = BIG ? 4 : 1, TH = 64 * NW;                 // threads per problem: the big layout leaves one problem per CU, so it takes all four SIMDs
+    const int lane = threadIdx.x;                                 // index among the TH threads of the problem
     const long long prob = blockIdx.x;
     if (prob >= B) return;
     const bool io32 = p.io_dtype == SC_DTYPE_F32;
@@ -287,40 +320,42 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
     const int N = d.N, nx = d.nx, nu = d.nu, n = d.n, m = d.m;
     constexpr bool LEAN = NT > 0;
     const LinMem W = carve_lin(sm, d, LEAN ? LIN_LEAN : (BIG ? LIN_BIG : LIN_STD));
+    Red R;
+    R.buf = W.red; R.par = 0;
     LinConst c;
     c.w0 = -(1.0 - p.alpha); c.Rrob = p.robot_radius; c.beta = p.beta; c.circles_only = p.circles_only;
     if (lane < 12) W.cq[lane] = p.Q[lane];
     if (lane < 4) { W.cq[12 + lane] = p.R[lane]; W.cq[16 + lane] = p.u_lo[lane]; W.cq[20 + lane] = p.u_hi[lane]; }
     // model blob: Ae [nx nx] | Be [nx nu] | As2 [2 nx] | Bs2 [2 nu] | Hc [n n] | G [4N n]
     const int nmat = nx * nx + nx * nu + 2 * nx + 2 * nu;
-    for (int e = lane; e < nmat; e += 64) W.Ae[e] = model[e];            // the four small matrices are contiguous in LDS too
+    for (int e = lane; e < nmat; e += TH) W.Ae[e] = model[e];            // the four small matrices are contiguous in LDS too
     const double* __restrict__ Hcg = model + nmat;
     const double* __restrict__ Gg = Hcg + (size_t)n * n;
     if constexpr (LEAN) {
-        for (int e = lane; e < n * n; e += 64) W.Hc[e] = Hcg[e];
+        for (int e = lane; e < n * n; e += TH) W.Hc[e] = Hcg[e];
     }
     const double* Hc = LEAN ? W.Hc : Hcg;
     if constexpr (!BIG) {
-        for (int e = lane; e < 4 * N * n; e += 64) W.G[e] = Gg[e];
+        for (int e = lane; e < 4 * N * n; e += TH) W.G[e] = Gg[e];
     }
     const double* G = BIG ? Gg : W.G;
-    for (int i = lane; i < nx; i += 64) { W.xs[i] = ld(X, prob * nx + i); W.xg[i] = i < p.ng ? ld(goal, prob * p.ng + i) : 0.0; }
-    for (int i = lane; i < nu; i += 64) W.up[i] = ld(u_prev, prob * nu + i);
+    for (int i = lane; i < nx; i += TH) { W.xs[i] = ld(X, prob * nx + i); W.xg[i] = i < p.ng ? ld(goal, prob * p.ng + i) : 0.0; }
+    for (int i = lane; i < nu; i += TH) W.up[i] = ld(u_prev, prob * nu + i);
     const size_t obase = p.obs_shared ? 0 : (size_t)prob * K * 7;
-    for (int e = lane; e < K * 7; e += 64) W.obs[e] = ld(obs, obase + e);
+    for (int e = lane; e < K * 7; e += TH) W.obs[e] = ld(obs, obase + e);
     SC_SYNC();
     // set_initial_guess (mpc_cbf.py:369): u_prev at every stage, pulled strictly inside the box
-    for (int i = lane; i < n; i += 64) {
+    for (int i = lane; i < n; i += TH) {
         const double lo = W.cq[16 + i % nu], hi = W.cq[20 + i % nu], pad = 0.005 * (hi - lo);
         W.z[i] = fmin(fmax(W.up[i % nu], lo + pad), hi - pad);
     }
     SC_SYNC();
 
-    double f = lin_eval(W.z, W, d, c, lane, true);
-    lin_grad(W, d, c, lane, 1.0);
+    double f = lin_eval<TH>(W.z, W, d, c, lane, true, R);
+    lin_grad<TH>(W, d, c, lane, 1.0);
     if constexpr (LEAN) {
         // the cost is quadratic: grad f = Hc z + c with c fixed for the solve (one adjoint pass, here)
-        for (int i = lane; i < n; i += 64) {
+        for (int i = lane; i < n; i += TH) {
             double q = 0.0;
 #pragma unroll
             for (int j = 0; j < n; ++j) q += Hc[(size_t)j * n + i] * W.z[j];
@@ -329,12 +364,12 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         SC_SYNC();
     }
     double gmax = 0.0;
-    for (int i = lane; i < n; i += 64) gmax = fmax(gmax, fabs(W.gs[i]));
-    gmax = lmax_(gmax);
+    for (int i = lane; i < n; i += TH) gmax = fmax(gmax, fabs(W.gs[i]));
+    gmax = lmax_<TH>(gmax, R);
     const double sf = fmin(1.0, 100.0 / fmax(1e-12, gmax));             // objective scaling
     double mu = p.mu_init;
-    for (int i = lane; i < m; i += 64) { const double s = fmax(W.g[i], 1e-2); W.s[i] = s; W.lam[i] = mu / s; }
-    for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
+    for (int i = lane; i < m; i += TH) { const double s = fmax(W.g[i], 1e-2); W.s[i] = s; W.lam[i] = mu / s; }
+    for (int i = lane; i < n; i += TH) W.zb[i] = W.z[i];
     SC_SYNC();
 
     int status = SC_STATUS_INACCURATE, it = 0;
@@ -348,10 +383,10 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
 #endif
     for (it = 1; it <= p.max_iter; ++it) {
         LP(11);
-        if (it > 1) f = lin_eval(W.z, W, d, c, lane, true);
+        if (it > 1) f = lin_eval<TH>(W.z, W, d, c, lane, true, R);
         LP(0);
         if constexpr (LEAN) {                                             // gs = sf grad f = sf (Hc z + c)
-            for (int i = lane; i < n; i += 64) {
+            for (int i = lane; i < n; i += TH) {
                 double q = W.clin[i];
 #pragma unroll
                 for (int j = 0; j < n; ++j) q += Hc[(size_t)j * n + i] * W.z[j];
@@ -359,22 +394,22 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
             }
             SC_SYNC();
         } else {
-            lin_grad(W, d, c, lane, sf);
+            lin_grad<TH>(W, d, c, lane, sf);
         }
         LP(1);
-        lin_jt(W.lam, W.rd, W, d, c, G, lane);
+        lin_jt<TH>(W.lam, W.rd, W, d, c, G, lane);
         LP(2);
         double e_d = 0.0, e_p = 0.0, e_c0 = 0.0, lmx = 0.0;
-        for (int i = lane; i < n; i += 64) { const double r = W.gs[i] - W.rd[i]; W.rd[i] = r; e_d = fmax(e_d, fabs(r)); }
-        for (int i = lane; i < m; i += 64) {
+        for (int i = lane; i < n; i += TH) { const double r = W.gs[i] - W.rd[i]; W.rd[i] = r; e_d = fmax(e_d, fabs(r)); }
+        for (int i = lane; i < m; i += TH) {
             const double s = W.s[i], l = W.lam[i];
             e_p = fmax(e_p, fabs(W.g[i] - s)); e_c0 = fmax(e_c0, fabs(s * l)); lmx = fmax(lmx, l);
         }
-        e_d = lmax_(e_d); e_p = lmax_(e_p); e_c0 = lmax_(e_c0); lmx = lmax_(lmx);
+        e_d = lmax_<TH>(e_d, R); e_p = lmax_<TH>(e_p, R); e_c0 = lmax_<TH>(e_c0, R); lmx = lmax_<TH>(lmx, R);
         const double e_opt = fmax(e_d, fmax(e_p, e_c0));
         if (e_opt < e_best) {
             e_best = e_opt;
-            for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
+            for (int i = lane; i < n; i += TH) W.zb[i] = W.z[i];
         }
         if (e_opt <= p.tol) { status = SC_STATUS_OPTIMAL; break; }
         n_acc = e_opt <= p.acceptable_tol ? n_acc + 1 : 0;
@@ -383,26 +418,26 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         if (!(e_opt < 1e300)) break;                                      // non-finite data: give up
         for (;;) {                                                        // barrier update
             double e_c = 0.0;
-            for (int i = lane; i < m; i += 64) e_c = fmax(e_c, fabs(W.s[i] * W.lam[i] - mu));
-            e_c = lmax_(e_c);
+            for (int i = lane; i < m; i += TH) e_c = fmax(e_c, fabs(W.s[i] * W.lam[i] - mu));
+            e_c = lmax_<TH>(e_c, R);
             const double e_mu = fmax(e_d, fmax(e_p, e_c));
             if (e_mu <= 10.0 * mu && mu > p.mu_min) mu = fmax(p.mu_min, fmin(0.2 * mu, mu * sqrt(mu)));
             else break;
         }
         LP(3);
         // rhs = -sf grad f + J' (mu / s - sig r_p)
-        for (int i = lane; i < m; i += 64) {
+        for (int i = lane; i < m; i += TH) {
             const double s = W.s[i], l = W.lam[i];
             const double is = rcp_(s), sig = l * is;                      // v_rcp seed + two Newton steps (sc_qp2.hpp), as kernel 3
             W.vb[i] = mu * is - sig * (W.g[i] - s);
             W.ds[i] = sig;                                                // read by the Phi blocks below; ds proper is written after the solve
         }
         SC_SYNC();
-        lin_jt(W.vb, W.rhs, W, d, c, G, lane);
-        for (int i = lane; i < n; i += 64) W.rhs[i] = -W.gs[i] + W.rhs[i];
+        lin_jt<TH>(W.vb, W.rhs, W, d, c, G, lane);
+        for (int i = lane; i < n; i += TH) W.rhs[i] = -W.gs[i] + W.rhs[i];
         LP(4);
         // stage blocks Phi_k over (a_k, b_k):  sum_j sig_kj v v' (v = [w0 dh_a; dh_b])  -  sum_j lam_kj [w0 Hh_a, 0; 0, Hh_b]
-        for (int e = lane; e < 16 * N; e += 64) {
+        for (int e = lane; e < 16 * N; e += TH) {
             const int k = e >> 4, r = (e >> 2) & 3, cc = e & 3;
             double acc = 0.0;
 #pragma unroll
@@ -420,7 +455,7 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         SC_SYNC();
         LP(5);
         // T = Phi G (rows 4k..4k+3), then M = sf Hc + G' T + diag(sig_hi + sig_lo)
-        for (int e = lane; e < 4 * N * n; e += 64) {
+        for (int e = lane; e < 4 * N * n; e += TH) {
             const int row = e / n, col = e - row * n, k = row >> 2, r = row & 3;
             double acc = 0.0;
 #pragma unroll
@@ -431,10 +466,10 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
             W.T[e] = acc;
         }
         SC_SYNC();
-        for (int i = lane; i < n; i += 64)                                   // r_d is consumed: its space holds the box terms
+        for (int i = lane; i < n; i += TH)                                   // r_d is consumed: its space holds the box terms
             W.rd[i] = W.ds[d.mc + i] + W.ds[d.mc + n + i];                    // sigma of the two box rows (stored above)
         SC_SYNC();
-        lin_condense_mfma<NT, NU>(W, N, nu, sf, Hc, G, W.rd, lane);
+        lin_condense_mfma<NT, NU, NW>(W, N, nu, sf, Hc, G, W.rd, lane);
         SC_SYNC();
         LP(6);
         // inertia correction: M + delta I until the Cholesky succeeds
@@ -444,22 +479,23 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
             if constexpr (NN > 0) {
                 ok = ipm::chol_reg_solve<NN>(W.M, W.rhs, W.L, W.dz, delta, lane);
             } else {
-                for (int e = lane; e < n * n; e += 64) W.L[e] = W.M[e] + ((e / n == e % n) ? delta : 0.0);
+                for (int r = lane >> 6; r < n; r += NW)                      // lower triangle, row stride n | 1 (odd: no LDS bank conflicts)
+                    for (int cc = lane & 63; cc <= r; cc += 64) W.L[r * (n | 1) + cc] = W.M[r * n + cc] + (cc == r ? delta : 0.0);
                 SC_SYNC();
-                ok = cholesky_lds(W.L, n, lane);
+                ok = cholesky_lds<NW>(W.L, n, n | 1, lane, W.red + 8);
             }
             if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
         }
         if (!ok) break;
         if (delta > 0.0) delta_last = delta;
         if constexpr (NN == 0) {
-            for (int i = lane; i < n; i += 64) W.dz[i] = W.rhs[i];
+            for (int i = lane; i < n; i += TH) W.dz[i] = W.rhs[i];
             SC_SYNC();
-            chol_solve_lds(W.L, W.dz, n, lane);
+            chol_solve_lds<NW>(W.L, W.dz, n, n | 1, lane);
         }
         LP(7);
         // point displacements  G dz, then ds = J dz + r_p, dlam, step lengths
-        for (int r = lane; r < 4 * N; r += 64) {
+        for (int r = lane; r < 4 * N; r += TH) {
             double acc = 0.0;
 #pragma unroll 8
             for (int i = 0; i < n; ++i) acc += G[(size_t)r * n + i] * W.dz[i];
@@ -468,17 +504,17 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         // sf grad f . dz and the curvature sf dz' Hc dz: the cost is exactly quadratic in z, so the line search takes
         // f(z + a dz) - f(z) = a grad.dz + a^2/2 dz' Hc dz instead of the difference of two sums of size |f|
         double gdz = 0.0, curv = 0.0;
-        for (int i = lane; i < n; i += 64) {
+        for (int i = lane; i < n; i += TH) {
             gdz += W.gs[i] * W.dz[i];
             double q = 0.0;
 #pragma unroll 8
             for (int j = 0; j < n; ++j) q += Hc[(size_t)j * n + i] * W.dz[j];
             curv += q * W.dz[i];
         }
-        curv = sf * lsum(curv);
+        curv = sf * lsum<TH>(curv, R);
         SC_SYNC();
         double rs_min = 0.0, rl_min = 0.0, sum_ds_s = 0.0, sum_rp = 0.0, sum_log = 0.0, sum_g = 0.0;
-        for (int i = lane; i < m; i += 64) {
+        for (int i = lane; i < m; i += TH) {
             const double s = W.s[i], l = W.lam[i], rp = W.g[i] - s;
             double jd;
             if (i < d.mc) {
@@ -498,8 +534,8 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
             sum_ds_s += rs; sum_rp += fabs(rp); sum_log += log(s); sum_g += fabs(W.g[i]);
             W.ds[i] = dsi; W.dlam[i] = dl;
         }
-        rs_min = lmin(rs_min); rl_min = lmin(rl_min); sum_ds_s = lsum(sum_ds_s); sum_rp = lsum(sum_rp); sum_log = lsum(sum_log);
-        gdz = lsum(gdz); sum_g = lsum(sum_g);
+        rs_min = lmin<TH>(rs_min, R); rl_min = lmin<TH>(rl_min, R); sum_ds_s = lsum<TH>(sum_ds_s, R); sum_rp = lsum<TH>(sum_rp, R); sum_log = lsum<TH>(sum_log, R);
+        gdz = lsum<TH>(gdz, R); sum_g = lsum<TH>(sum_g, R);
         const double ap = rs_min < 0.0 ? fmin(1.0, -tau / rs_min) : 1.0, ad = rl_min < 0.0 ? fmin(1.0, -tau / rl_min) : 1.0;
         nu_m = fmax(nu_m, 1.1 * lmx);
         const double phi0 = sf * f - mu * sum_log + nu_m * sum_rp;
@@ -510,23 +546,23 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
         double alpha = ap;
         bool accepted = false;
         for (int ls = 0; ls < 12; ++ls) {
-            for (int i = lane; i < n; i += 64) W.zt[i] = W.z[i] + alpha * W.dz[i];
+            for (int i = lane; i < n; i += TH) W.zt[i] = W.z[i] + alpha * W.dz[i];
             SC_SYNC();
-            lin_eval(W.zt, W, d, c, lane, false);
+            lin_eval<TH>(W.zt, W, d, c, lane, false, R);
             double srp = 0.0, slog = 0.0;
-            for (int i = lane; i < m; i += 64) {
+            for (int i = lane; i < m; i += TH) {
                 const double s_t = W.s[i] + alpha * W.ds[i];
                 slog += log(s_t); srp += fabs(W.g[i] - s_t);
             }
-            slog = lsum(slog); srp = lsum(srp);
+            slog = lsum<TH>(slog, R); srp = lsum<TH>(srp, R);
             const double phit = phi0 + alpha * gdz + 0.5 * alpha * alpha * curv - mu * (slog - sum_log) + nu_m * (srp - sum_rp);
             if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0) + noise_rows) { accepted = true; break; }
             alpha *= 0.5;
         }
         LP(9);
         if (!accepted) break;
-        for (int i = lane; i < n; i += 64) W.z[i] = W.z[i] + alpha * W.dz[i];
-        for (int i = lane; i < m; i += 64) {
+        for (int i = lane; i < n; i += TH) W.z[i] = W.z[i] + alpha * W.dz[i];
+        for (int i = lane; i < m; i += TH) {
             const double s = W.s[i] + alpha * W.ds[i];
             double l = W.lam[i] + ad * W.dlam[i];
             const double mus = mu * rcp_(s);
@@ -538,15 +574,15 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
     if (it > p.max_iter) it = p.max_iter;
     if (status != SC_STATUS_OPTIMAL && e_best <= p.acceptable_tol) {
         SC_SYNC();
-        for (int i = lane; i < n; i += 64) W.z[i] = W.zb[i];
+        for (int i = lane; i < n; i += TH) W.z[i] = W.zb[i];
         status = SC_STATUS_OPTIMAL;
     }
     SC_SYNC();
-    lin_eval(W.z, W, d, c, lane, false);
+    lin_eval<TH>(W.z, W, d, c, lane, false, R);
     if (status != SC_STATUS_OPTIMAL) {
         double gmin = 1e300;
-        for (int i = lane; i < m; i += 64) gmin = fmin(gmin, W.g[i]);
-        gmin = lmin(gmin);
+        for (int i = lane; i < m; i += TH) gmin = fmin(gmin, W.g[i]);
+        gmin = lmin<TH>(gmin, R);
         if (gmin < -1e-6) status = SC_STATUS_INFEASIBLE;
         else if (status != SC_STATUS_INFEASIBLE) status = SC_STATUS_INACCURATE;
     }
@@ -558,7 +594,7 @@ __global__ __launch_bounds__(64) void mpclin_kernel(const sc_mpclin_params p, co
 #ifdef SC_LIN_PROF
     if (z_out && lane == 0) for (int i = 0; i < 12; ++i) st(z_out, prob * n + i, prof[i]);
 #else
-    if (z_out) for (int i = lane; i < n; i += 64) st(z_out, prob * n + i, W.z[i]);
+    if (z_out) for (int i = lane; i < n; i += TH) st(z_out, prob * n + i, W.z[i]);
 #endif
 }
 
@@ -646,16 +682,17 @@ hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long lo
                          hipStream_t stream) {
     const size_t lds = mpclin_lds_bytes(p.horizon, K, p.nx, p.nu);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const int mode = mpclin_mode(p.horizon, K, p.nx, p.nu);
+    const unsigned threads = mode == LIN_BIG ? 256 : 64;                  // big layout: four waves per problem
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, model, B, K, X, u_prev, goal, obs, u_out, status,
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(threads), lds, stream, p, model, B, K, X, u_prev, goal, obs, u_out, status,
                            iters, z_out);
         return hipGetLastError();
     };
-    const int mode = mpclin_mode(p.horizon, K, p.nx, p.nu);
     if (mode == LIN_LEAN) {
         if (p.horizon == 10 && p.nx == 12)                            // Quad3D at the reference's default horizon
             return K == 8 ? launch(mpclin_kernel<12, 4, 10, 8>) : launch(mpclin_kernel<12, 4, 10, 0>);

@@ -45,7 +45,8 @@ def batch(name, B, K, seed):
 
 
 @pytest.mark.parametrize("name,N,K", [("SingleIntegrator2D", 10, 8), ("Quad3D", 10, 8), ("SingleIntegrator2D", 5, 3),
-                                      ("Quad3D", 6, 2), ("Quad3D", 16, 4), ("Quad3D", 20, 8), ("SingleIntegrator2D", 20, 4)])
+                                      ("Quad3D", 6, 2), ("Quad3D", 16, 4), ("Quad3D", 20, 8), ("SingleIntegrator2D", 20, 4),
+                                      ("Quad3D", 18, 3), ("SingleIntegrator2D", 27, 2)])
 def test_batch_matches_oracle(name, N, K):
     B = 24
     mdl, X, G, O = batch(name, B, K, seed=N * 10 + K)

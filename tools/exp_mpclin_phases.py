@@ -7,7 +7,7 @@ from safe_control_amd import _lib as _L
 _L.LIB_PATH = os.environ["SC_EXP_LIB"]
 import safe_control_amd as sca
 import test_mpclin_gpu as T
-name = os.environ.get("SC_EXP_MODEL", "Quad3D"); N = 10; K = 8; B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+name = os.environ.get("SC_EXP_MODEL", "Quad3D"); N = int(os.environ.get("SC_EXP_N", "10")); K = 8; B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 mdl, X, G, O = T.batch(name, B, K, seed=3)
 ctl = sca.BatchedLinearMPCCBF({"model": name}, io_dtype="f64", horizon=N)
 u, st, it, z = ctl.solve(T.t(X), T.t(np.zeros((B, mdl["nu"]))), T.t(G), T.t(O), want_z=True)
