@@ -200,33 +200,67 @@ __device__ __forceinline__ double lane_value(double v, int src) {           // s
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
 }
-// L L' x = b in place, n <= 128: lane l keeps entries l and 64 + l in registers, the pivot entry is broadcast with
-// v_readlane, so the 2 n elimination steps run without a barrier and the L reads (addresses independent of the data) pipeline.
-template <int NW = 1>
-__device__ __forceinline__ void chol_solve_lds(const double* L, double* b, int n, int ld, int tid) {
-    if (NW > 1 && tid >= 64) { SC_SYNC(); return; }                        // the other waves of the problem wait for wave 0
-    const int lane = tid;
+// L L' x = b in place, n <= 128, on ONE wave: lane l keeps entries l and 64 + l of the right-hand side AND the two
+// reciprocal pivots of its rows in registers; the pivot entry and its reciprocal are broadcast with v_readlane, so the 2 n
+// elimination steps run without a barrier and with no LDS access on their dependency chain: the multipliers of 16 steps
+// (a block column of L going down, a block row going up) are loaded in one burst ahead of them.
+// TWO: n > 64.  LO: the 16 pivots of the block are first-row entries (c0 < 64).
+template <bool TWO, bool LO, bool FWD>
+__device__ __forceinline__ void chol_solve_block(const double* L, int n, int ld, int c0, int lane, int k0, int k1, double d0, double d1,
+                                                 double& b0, double& b1) {
     const int i0 = lane, i1 = 64 + lane;
-    const int c0 = i0 < n ? i0 : 0, c1 = i1 < n ? i1 : c0;                // in-range rows for the unpredicated loads
-    double b0 = i0 < n ? b[i0] : 0.0, b1 = i1 < n ? b[i1] : 0.0;
-    const double* l0 = L + c0 * ld;
-    const double* l1 = L + c1 * ld;
-#pragma unroll 4
-    for (int j = 0; j < n; ++j) {
-        const double m0 = l0[j], m1 = l1[j];
-        const double yj = (j < 64 ? lane_value(b0, j) : lane_value(b1, j - 64)) * L[j * ld + j];
-        b0 = i0 == j ? yj : (i0 > j ? b0 - m0 * yj : b0);
-        b1 = i1 == j ? yj : (i1 > j ? b1 - m1 * yj : b1);
+    double m0[16], m1[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int j = c0 + c < n ? c0 + c : n - 1;
+        if (FWD) {                                                         // column j of L, rows of this lane
+            if (LO) m0[c] = L[k0 * ld + j];
+            if (TWO) m1[c] = L[k1 * ld + j];
+        } else {                                                           // row j of L, columns of this lane
+            m0[c] = L[j * ld + k0];
+            if (TWO && !LO) m1[c] = L[j * ld + k1];
+        }
     }
-#pragma unroll 4
-    for (int j = n - 1; j >= 0; --j) {
-        const double m0 = L[j * ld + c0], m1 = L[j * ld + c1];
-        const double xj = (j < 64 ? lane_value(b0, j) : lane_value(b1, j - 64)) * L[j * ld + j];
-        b0 = i0 == j ? xj : (i0 < j ? b0 - m0 * xj : b0);
-        b1 = i1 == j ? xj : (i1 < j ? b1 - m1 * xj : b1);
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {
+        const int c = FWD ? cc : 15 - cc, j = c0 + c;
+        if (j < n) {                                                       // wave-uniform
+            const int jl = j & 63;
+            const double v = (LO ? lane_value(b0, jl) : lane_value(b1, jl)) * (LO ? lane_value(d0, jl) : lane_value(d1, jl));
+            if (FWD) {
+                if (LO) { b0 = i0 == j ? v : (i0 > j ? b0 - m0[c] * v : b0); if (TWO) b1 -= m1[c] * v; }
+                else b1 = i1 == j ? v : (i1 > j ? b1 - m1[c] * v : b1);
+            } else {
+                if (LO) b0 = i0 == j ? v : (i0 < j ? b0 - m0[c] * v : b0);
+                else { b1 = i1 == j ? v : (i1 < j ? b1 - m1[c] * v : b1); b0 -= m0[c] * v; }
+            }
+        }
+    }
+}
+template <bool TWO>
+__device__ __forceinline__ void chol_solve_wave(const double* L, double* b, int n, int ld, int lane) {
+    const int i0 = lane, i1 = 64 + lane;
+    const int k0 = i0 < n ? i0 : 0, k1 = i1 < n ? i1 : k0;                 // in-range rows for the unpredicated loads
+    double b0 = i0 < n ? b[i0] : 0.0, b1 = (TWO && i1 < n) ? b[i1] : 0.0;
+    const double d0 = L[k0 * ld + k0], d1 = TWO ? L[k1 * ld + k1] : 0.0;
+    const int nb = (n + 15) >> 4;
+    for (int kb = 0; kb < nb; ++kb) {
+        if (!TWO || kb < 4) chol_solve_block<TWO, true, true>(L, n, ld, 16 * kb, lane, k0, k1, d0, d1, b0, b1);
+        else chol_solve_block<TWO, false, true>(L, n, ld, 16 * kb, lane, k0, k1, d0, d1, b0, b1);
+    }
+    for (int kb = nb - 1; kb >= 0; --kb) {
+        if (!TWO || kb < 4) chol_solve_block<TWO, true, false>(L, n, ld, 16 * kb, lane, k0, k1, d0, d1, b0, b1);
+        else chol_solve_block<TWO, false, false>(L, n, ld, 16 * kb, lane, k0, k1, d0, d1, b0, b1);
     }
     if (i0 < n) b[i0] = b0;
-    if (i1 < n) b[i1] = b1;
+    if (TWO && i1 < n) b[i1] = b1;
+}
+template <int NW = 1>
+__device__ __forceinline__ void chol_solve_lds(const double* L, double* b, int n, int ld, int tid) {
+    if (NW == 1 || tid < 64) {                                             // the other waves of the problem wait for wave 0
+        if (n > 64) chol_solve_wave<true>(L, b, n, ld, tid);
+        else chol_solve_wave<false>(L, b, n, ld, tid);
+    }
     SC_SYNC();
 }
 

@@ -36,4 +36,10 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 # 6. linear-model MPC-CBF kernel (Quad3D, n = 40): instruction mix and LDS conflicts
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o mpclin -- python3 $R/tools/prof_mpclin.py Quad3D 4096 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o mpclin_sq -- python3 $R/tools/prof_mpclin.py Quad3D 4096 2 > /dev/null 2>&1
+# 7. the same kernel's big layout (Quad3D at N = 20, n = 80: four waves per problem): kernel trace, instruction mix, I-cache
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o mpclin_big -- python3 $R/tools/prof_mpclin.py Quad3D 4096 2 20 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o mpclin_big_sq -- python3 $R/tools/prof_mpclin.py Quad3D 1024 2 20 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES --output-format csv -d $OUT -o mpclin_big_ic -- python3 $R/tools/prof_mpclin.py Quad3D 1024 2 20 > /dev/null 2>&1
+# 8. heterogeneous fleet (BASELINE configs[4] as far as the reference defines it)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o hetero -- python3 $R/bench.py --workload hetero_fleet --steps 1 --warmup 1 > $OUT/hetero_under_rocprof.json 2>/dev/null
 ls $OUT | head -80
