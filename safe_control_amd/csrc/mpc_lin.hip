@@ -393,8 +393,8 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
                 W.gs[i] = sf * q;
             }
             SC_SYNC();
-        } else {
-            lin_grad<TH>(W, d, c, lane, sf);
+        } else if (it == 1) {
+            lin_grad<TH>(W, d, c, lane, sf);                                // later iterations: gs += alpha sf Hc dz at the update (the cost is quadratic)
         }
         LP(1);
         lin_jt<TH>(W.lam, W.rd, W, d, c, G, lane);
@@ -510,6 +510,7 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
 #pragma unroll 8
             for (int j = 0; j < n; ++j) q += Hc[(size_t)j * n + i] * W.dz[j];
             curv += q * W.dz[i];
+            if constexpr (!LEAN) W.rd[i] = q;                               // (Hc dz)_i: r_d's space is free until the next iteration
         }
         curv = sf * lsum<TH>(curv, R);
         SC_SYNC();
@@ -561,7 +562,10 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
         }
         LP(9);
         if (!accepted) break;
-        for (int i = lane; i < n; i += TH) W.z[i] = W.z[i] + alpha * W.dz[i];
+        for (int i = lane; i < n; i += TH) {
+            W.z[i] = W.z[i] + alpha * W.dz[i];
+            if constexpr (!LEAN) W.gs[i] += alpha * sf * W.rd[i];
+        }
         for (int i = lane; i < m; i += TH) {
             const double s = W.s[i] + alpha * W.ds[i];
             double l = W.lam[i] + ad * W.dlam[i];
