@@ -376,6 +376,7 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
     const double tau = 0.995;
     double nu_m = 10.0, delta_last = 0.0, e_best = 1e300;
     int n_acc = 0;
+    bool fresh = false;
     const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
 #ifdef SC_LIN_PROF
     double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
 #endif
     for (it = 1; it <= p.max_iter; ++it) {
         LP(11);
-        if (it > 1) f = lin_eval<TH>(W.z, W, d, c, lane, true, R);
+        if (it > 1 && !fresh) f = lin_eval<TH>(W.z, W, d, c, lane, true, R);   // fresh: the accepted trial point was evaluated with derivatives
         LP(0);
         if constexpr (LEAN) {                                             // gs = sf grad f = sf (Hc z + c)
             for (int i = lane; i < n; i += TH) {
@@ -546,10 +547,12 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
         LP(8);
         double alpha = ap;
         bool accepted = false;
+        fresh = false;
         for (int ls = 0; ls < 12; ++ls) {
             for (int i = lane; i < n; i += TH) W.zt[i] = W.z[i] + alpha * W.dz[i];
             SC_SYNC();
-            lin_eval<TH>(W.zt, W, d, c, lane, false, R);
+            const bool full = ls == 0 && c.circles_only != 0;                  // the full step is taken most of the time: evaluate it once, with the
+            const double f_t = lin_eval<TH>(W.zt, W, d, c, lane, full, R);     // derivatives (circles: they cost nothing next to the rollout)
             double srp = 0.0, slog = 0.0;
             for (int i = lane; i < m; i += TH) {
                 const double s_t = W.s[i] + alpha * W.ds[i];
@@ -557,7 +560,11 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
             }
             slog = lsum<TH>(slog, R); srp = lsum<TH>(srp, R);
             const double phit = phi0 + alpha * gdz + 0.5 * alpha * alpha * curv - mu * (slog - sum_log) + nu_m * (srp - sum_rp);
-            if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0) + noise_rows) { accepted = true; break; }
+            if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0) + noise_rows) {
+                accepted = true; fresh = full;
+                if (fresh) f = f_t;
+                break;
+            }
             alpha *= 0.5;
         }
         LP(9);
