@@ -24,6 +24,7 @@
 #include "sc_math.hpp"
 #include "sc_qp2.hpp"
 #include "mpc_chol.hpp"
+#include "mpc_ipm_common.hpp"
 #include "../../include/safe_control_amd.h"
 
 namespace sc {
@@ -771,45 +772,6 @@ __device__ __forceinline__ void condense_mfma(const MpcMem& W, const MpcConst& c
     }
 }
 
-// Cholesky of (W.L = lower of A) in place; returns false on a non-positive pivot.
-__device__ inline bool cholesky(double* A, int n, int lane) {
-    bool ok = true;
-    for (int j = 0; j < n; ++j) {
-        const double d = A[j * n + j];
-        if (!(d > 0.0)) ok = false;
-        const double piv = sqrt(d);
-        SC_SYNC();
-        for (int i = j + lane; i < n; i += 64) A[i * n + j] = (i == j) ? piv : A[i * n + j] / piv;
-        SC_SYNC();
-        const int rem = n - j - 1;
-        for (int e = lane; e < rem * rem; e += 64) {
-            const int i = j + 1 + e / rem, k = j + 1 + e % rem;
-            if (k <= i) A[i * n + k] -= A[i * n + j] * A[k * n + j];
-        }
-        SC_SYNC();
-        if (!ok) break;                       // uniform: every lane read the same pivot
-    }
-    return ok;
-}
-
-// solve L L' x = b in place (b in LDS), lanes cooperate column by column
-__device__ inline void chol_solve(const double* L, double* b, int n, int lane) {
-    for (int j = 0; j < n; ++j) {
-        if (lane == 0) b[j] = b[j] / L[j * n + j];
-        SC_SYNC();
-        const double yj = b[j];
-        for (int i = j + 1 + lane; i < n; i += 64) b[i] -= L[i * n + j] * yj;
-        SC_SYNC();
-    }
-    for (int j = n - 1; j >= 0; --j) {
-        if (lane == 0) b[j] = b[j] / L[j * n + j];
-        SC_SYNC();
-        const double xj = b[j];
-        for (int i = lane; i < j; i += 64) b[i] -= L[j * n + i] * xj;
-        SC_SYNC();
-    }
-}
-
 // Factor M + delta I and solve for the right-hand side, all in registers (mpc_chol.hpp); false on a pivot <= 0.
 // Arguments are offsets (doubles) into the workgroup's LDS block.  NOT inlined on purpose: unrolled for n = 40 the
 // factorisation and the two triangular solves are ~45 KB of code, and inlined they push the interior-point loop of the
@@ -959,15 +921,16 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
             SC_PH(7);
         } else {
             for (int t = 0; t < 40 && !ok; ++t) {
-                for (int e = lane; e < n * n; e += 64) W.L[e] = W.M[e] + ((e / n == e % n) ? delta : 0.0);
+                for (int r = 0; r < n; ++r)                  // lower triangle, odd row stride (mpc_ipm_common.hpp: no LDS bank conflicts)
+                    for (int cc = lane; cc <= r; cc += 64) W.L[r * (n | 1) + cc] = W.M[r * n + cc] + (cc == r ? delta : 0.0);
                 SC_SYNC();
-                ok = cholesky(W.L, n, lane);
+                ok = ipm::cholesky_lds(W.L, n, n | 1, lane);
                 if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
             }
             if (!ok) break;
             if (delta > 0.0) delta_last = delta;
             SC_PH(7);
-            chol_solve(W.L, W.dz, n, lane);                  // rhs is dz: solved in place
+            ipm::chol_solve_lds(W.L, W.dz, n, n | 1, lane);  // rhs is dz: solved in place
         }
         SC_PH(8);
         // position and speed displacements  dp = G dz,  dV_k = dt sum_{j < k} dz_{2j}
