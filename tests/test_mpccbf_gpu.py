@@ -79,7 +79,7 @@ def test_feasibility_and_local_optimality_independent_of_oracle_solver():
     assert checked == 10
 
 
-@pytest.mark.parametrize("N,K", [(5, 3), (10, 1), (20, 8), (12, 16)])
+@pytest.mark.parametrize("N,K", [(5, 3), (10, 1), (20, 8), (12, 16), (15, 8), (30, 4)])   # 30: order 60, partial last tile row of the LDS Cholesky
 def test_other_horizons_and_obstacle_counts(N, K):
     B = 24
     X, goal, ur, obs = W.du_cbfqp_batch(B, K, seed=N * 100 + K)
