@@ -73,8 +73,9 @@ struct LinDims { int N, K, nx, nu, n, m, mc; };
 // gradient Hc z + c read it every iteration; 75 KB for Quad3D at N = 10, K = 8).  Reading G from global
 // memory as well (49 KB, three problems per CU instead of two) was measured: 8 % faster at 65536 problems, 15 % slower
 // at 4096 (the L1/L2 latency sits on every iteration's critical path) -- G stays in LDS.
-// big (mode 2) = run-time sizes whose standard layout exceeds the 160 KB of a CU (Quad3D at N = 20: n = 80): G is read from
-// global memory and the LDS Cholesky factor takes the dead T region (4N n >= n n whenever nu <= 4).
+// big (mode 2) = run-time sizes whose standard layout exceeds 80 KB, i.e. leaves one problem per CU or does not fit at all
+// (Quad3D at N = 20: n = 80, 250 KB): G is read from global memory, the LDS Cholesky factor takes the dead T region (widened to
+// n (n + 1) where 4N n falls short), and the block is FOUR waves per problem (see mpclin_kernel).
 enum { LIN_STD = 0, LIN_LEAN = 1, LIN_BIG = 2 };
 __host__ __device__ inline size_t mpclin_lds_doubles(int N, int K, int nx, int nu, int mode = LIN_STD) {
     const bool lean = mode == LIN_LEAN;
@@ -620,7 +621,10 @@ static bool mpclin_is_lean(int N, int nx, int nu) {
 }
 static int mpclin_mode(int N, int K, int nx, int nu) {
     if (mpclin_is_lean(N, nx, nu) && mpclin_lds_doubles(N, K, nx, nu, LIN_LEAN) * sizeof(double) <= 160 * 1024) return LIN_LEAN;
-    return mpclin_lds_doubles(N, K, nx, nu, LIN_STD) * sizeof(double) > 160 * 1024 ? LIN_BIG : LIN_STD;
+    // the standard layout above 80 KB leaves one single-wave problem per CU (three SIMDs idle): the big layout with its four
+    // waves per problem is faster from there on (measured, 4096 Quad3D problems: N = 12 15.9 -> 11.9 ms, N = 14 25.0 -> 17.4 ms;
+    // SingleIntegrator2D N = 18 27.5 -> 20.4 ms; below, two or three single-wave problems per CU win: Quad3D N = 8 5.2 against 6.5 ms)
+    return mpclin_lds_doubles(N, K, nx, nu, LIN_STD) * sizeof(double) > 80 * 1024 ? LIN_BIG : LIN_STD;
 }
 size_t mpclin_lds_bytes(int N, int K, int nx, int nu) { return mpclin_lds_doubles(N, K, nx, nu, mpclin_mode(N, K, nx, nu)) * sizeof(double); }
 
