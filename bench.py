@@ -506,6 +506,7 @@ def main():
             res["manipulator_closed_loop"] = manip_closed_loop_leg(dev)
             res["quad3d_mpc_cbf"] = linear_mpc_leg(dev, "Quad3D")
             res["single_integrator_mpc_cbf"] = linear_mpc_leg(dev, "SingleIntegrator2D")
+            res["quad3d_mpc_cbf_n20"] = linear_mpc_leg(dev, "Quad3D", N=20, steps=2)   # BASELINE config 5's horizon: big layout, four waves per problem
             res["double_integrator_mpc_cbf"] = gn_mpc_leg(dev, "DoubleIntegrator2D")
             res["quad2d_mpc_cbf"] = gn_mpc_leg(dev, "Quad2D")
             res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
