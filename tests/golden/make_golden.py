@@ -651,12 +651,217 @@ def gen_closed_loop_manipulator():
     np.savez_compressed(os.path.join(HERE, "closed_loop_manipulator.npz"), **out)
 
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# MPC-CBF problem functions, executed from the reference's own source
+# ---------------------------------------------------------------------------------------------------------------
+MPC_MODELS = {
+    # name: (BaseRobot X0 rows, nx, nu, spec)  -- specs are the ones examples/test_tracking.py passes per model
+    "SingleIntegrator2D": (3, 2, 2, {"v_max": 1.0, "radius": 0.25}),
+    "Unicycle2D": (3, 3, 2, {"v_max": 1.0, "w_max": 0.5, "radius": 0.25}),
+    "DynamicUnicycle2D": (4, 4, 2, {"a_max": 1.0, "w_max": 0.5, "v_max": 1.0, "radius": 0.25}),
+    "DoubleIntegrator2D": (5, 4, 2, {"v_max": 1.0, "a_max": 1.0, "radius": 0.25}),
+    "KinematicBicycle2D": (4, 4, 2, {"a_max": 0.5, "radius": 0.5}),
+    "KinematicBicycle2D_C3BF": (4, 4, 2, {"a_max": 0.5, "radius": 0.5}),
+    "KinematicBicycle2D_DPCBF": (4, 4, 2, {"a_max": 0.5, "radius": 0.5}),
+    "Quad2D": (6, 6, 2, {"f_min": 3.0, "f_max": 10.0, "radius": 0.25}),
+    "Quad3D": (12, 12, 4, {"radius": 0.25}),
+    "VTOL2D": (6, 6, 4, {"radius": 0.6}),
+}
+
+
+def _draw_mpc_state(rng, name):
+    if name == "SingleIntegrator2D":
+        return rng.uniform(0, 14, 2)
+    if name == "Unicycle2D":
+        return np.array([*rng.uniform(0, 14, 2), rng.uniform(-4.0, 4.0)])           # heading past +-pi: no wrap in the model
+    if name == "DynamicUnicycle2D":
+        return np.array([*rng.uniform(0, 14, 2), rng.uniform(-4.0, 4.0), rng.uniform(-1.0, 1.0)])
+    if name == "DoubleIntegrator2D":
+        return np.array([*rng.uniform(0, 14, 2), *rng.uniform(-1.2, 1.2, 2)])        # some speeds above v_max (rescaled in step)
+    if name.startswith("KinematicBicycle2D"):
+        return np.array([*rng.uniform(0, 14, 2), rng.uniform(-4.0, 4.0), rng.uniform(-0.3, 4.0)])   # both sides of the v clip
+    if name == "Quad2D":
+        return np.array([*rng.uniform(0, 14, 2), rng.uniform(-0.6, 0.6), *rng.uniform(-1.5, 1.5, 2), rng.uniform(-1, 1)])
+    if name == "Quad3D":
+        X = rng.uniform(-1, 1, 12); X[0:3] = rng.uniform(0, 10, 3); X[3:6] = rng.uniform(-0.4, 0.4, 3)
+        return X
+    if name == "VTOL2D":
+        return np.array([rng.uniform(0, 60), rng.uniform(2, 14), rng.uniform(-0.3, 0.3), rng.uniform(3, 15),
+                         rng.uniform(-3, 3), rng.uniform(-0.5, 0.5)])
+    raise KeyError(name)
+
+
+def _draw_mpc_input(rng, name, spec):
+    if name == "SingleIntegrator2D":
+        return rng.uniform(-1.2, 1.2, 2)
+    if name == "Unicycle2D":
+        return np.array([rng.uniform(-1.2, 1.2), rng.uniform(-0.6, 0.6)])
+    if name == "DynamicUnicycle2D":
+        return np.array([rng.uniform(-1.2, 1.2), rng.uniform(-0.6, 0.6)])
+    if name == "DoubleIntegrator2D":
+        return rng.uniform(-1.2, 1.2, 2)
+    if name.startswith("KinematicBicycle2D"):
+        return np.array([rng.uniform(-6, 6), rng.uniform(-0.35, 0.35)])
+    if name == "Quad2D":
+        return rng.uniform(2.0, 11.0, 2)
+    if name == "Quad3D":
+        return rng.uniform(-3, 12, 4)
+    if name == "VTOL2D":
+        return np.array([*rng.uniform(0, 1, 3), rng.uniform(-0.5, 0.5)])
+    raise KeyError(name)
+
+
+def _draw_mpc_obstacles(rng, name, X, K, R, i):
+    """K rows of 7: circles near the robot, superellipsoids where the model's DT barrier has that branch, moving
+    circles for the C3BF / DPCBF barriers, and the [1000, 1000, 0, ...] dummy row update_tvp pads with."""
+    pos = np.array([X[0], X[1], 0.0, 0.0])
+    obs = draw_circles(rng, pos, K, R, moving=name in ("KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"),
+                       overlap=(i % 7 == 0))
+    obs = np.asarray(obs, dtype=float)
+    if name in ("SingleIntegrator2D", "DynamicUnicycle2D", "DoubleIntegrator2D") and i % 3 == 1:
+        se = np.asarray(draw_superellipsoids(rng, pos, K, R), dtype=float)
+        pick = rng.random(K) < 0.6
+        obs[pick] = se[pick]
+    if i % 5 == 2:
+        obs[-1] = [1000.0, 1000.0, 0, 0, 0, 0, 0]
+    return obs
+
+
+def gen_mpc_functions():
+    """Executes, under the numeric casadi / do_mpc recorder (tests/golden/_casadi_numeric.py), the reference's OWN
+    MPCCBF.__init__ (weights, horizon, gains, overrides: position_control/mpc_cbf.py:7-100), create_model (:108-160:
+    x_next, stage cost), create_mpc (:162-259: n_horizon, rterm, bounds), set_cbf_constraint / compute_cbf_constraint
+    (:295-325) with each robot's agent_barrier_dt, and update_tvp / tvp_fun (:261-293, :338-364) -- for every model the
+    class accepts.  Stored per model: the tables, and on seeded (x, u, goal, obs) draws the values x_next, cost,
+    (h_k, d_h[, dd_h]) per obstacle and the registered constraint expressions (-cbf <= 0)."""
+    import _casadi_numeric as CN
+    CN.install_casadi()
+    CN.install_do_mpc()
+    import importlib
+    for modname in [m for m in list(sys.modules) if m.startswith("safe_control.") and ("robots." in m or "dynamic_env." in m or m.endswith("mpc_cbf"))]:
+        del sys.modules[modname]                   # re-import the robot modules against the numeric casadi
+    robot_mod = importlib.import_module("safe_control.robots.robot")
+    importlib.reload(robot_mod)
+    mpc_mod = importlib.import_module("safe_control.position_control.mpc_cbf")
+    BaseRobotN, MPCCBFRef = robot_mod.BaseRobot, mpc_mod.MPCCBF
+    import casadi as ca
+
+    rng = np.random.default_rng(4242)
+    out = {}
+    K = 4
+    for name, (rows0, nx, nu, spec0) in MPC_MODELS.items():
+        spec = dict(spec0, model=name)
+        robot = BaseRobotN(np.zeros((rows0, 1)), spec, DT, NullAxes())
+        spec = robot.robot_spec
+        CN.POINT.clear()
+        ctrl = MPCCBFRef(robot, spec, num_obs=K)
+        # ---- tables
+        out[f"{name}/Q"] = np.asarray(ctrl.Q, dtype=float)
+        out[f"{name}/R"] = np.asarray(ctrl.R, dtype=float)
+        out[f"{name}/horizon"] = np.array(ctrl.horizon)
+        out[f"{name}/n_horizon_param"] = np.array(ctrl.mpc.params["n_horizon"])
+        out[f"{name}/t_step"] = np.array(ctrl.mpc.params["t_step"])
+        out[f"{name}/n_states"] = np.array(ctrl.n_states)
+        out[f"{name}/n_controls"] = np.array(ctrl.n_controls)
+        out[f"{name}/goal_init"] = np.asarray(ctrl.goal, dtype=float)
+        out[f"{name}/rterm_u"] = ctrl.mpc.rterm["u"]
+        for key, val in ctrl.cbf_param.items():
+            out[f"{name}/cbf_param/{key}"] = np.array(float(val))
+        lo_u = np.full(nu, -np.inf); hi_u = np.full(nu, np.inf); lo_x = np.full(nx, -np.inf); hi_x = np.full(nx, np.inf)
+        for key, val in ctrl.mpc.bounds.items():
+            side, vt = key[0], key[1]
+            tgt = {("lower", "_u"): lo_u, ("upper", "_u"): hi_u, ("lower", "_x"): lo_x, ("upper", "_x"): hi_x}[(side, vt)]
+            if len(key) == 4:
+                tgt[key[3]] = float(val)
+            else:
+                tgt[:] = np.asarray(val, dtype=float).reshape(-1)
+        out[f"{name}/u_lo"], out[f"{name}/u_hi"], out[f"{name}/x_lo"], out[f"{name}/x_hi"] = lo_u, hi_u, lo_x, hi_x
+        out[f"{name}/spec_keys"] = np.array(sorted(k for k, v in spec.items() if isinstance(v, (int, float)) and k != "model"))
+        out[f"{name}/spec_vals"] = np.array([float(spec[k]) for k in out[f"{name}/spec_keys"]])
+        out[f"{name}/robot_radius"] = np.array(float(robot.robot_radius))
+        # gain overrides (mpc_cbf.py:90-95)
+        ov = dict(spec, mpc_cbf_alpha=0.31, mpc_cbf_alpha1=0.27, mpc_cbf_alpha2=0.19, mpc_horizon=7)
+        c2 = MPCCBFRef(BaseRobotN(np.zeros((rows0, 1)), dict(ov), DT, NullAxes()), dict(ov), num_obs=2)
+        out[f"{name}/override/keys"] = np.array(sorted(c2.cbf_param))
+        out[f"{name}/override/vals"] = np.array([float(c2.cbf_param[k]) for k in sorted(c2.cbf_param)])
+        out[f"{name}/override/horizon"] = np.array(c2.horizon)
+        # ---- values on draws
+        rec = {k: [] for k in ["x", "u", "goal", "obs", "x_next", "cost", "cost_next", "f", "g", "hk", "dh", "ddh", "cons", "step"]}
+        n_cases = 48
+        for i in range(n_cases):
+            x = _draw_mpc_state(rng, name)
+            u = _draw_mpc_input(rng, name, spec)
+            goal = rng.uniform(0, 14, 3 if name == "Quad3D" else 2)
+            obs = _draw_mpc_obstacles(rng, name, x, K, float(robot.robot_radius), i)
+            goal_pad = np.concatenate([goal, np.zeros(nx - goal.shape[0])])
+            CN.POINT.clear()
+            CN.POINT.update(x=x.reshape(nx, 1), u=u.reshape(nu, 1), goal=goal_pad.reshape(nx, 1), obs=obs,
+                            alpha=np.array([[ctrl.cbf_param.get("alpha", 0.0)]]),
+                            alpha1=np.array([[ctrl.cbf_param.get("alpha1", 0.0)]]),
+                            alpha2=np.array([[ctrl.cbf_param.get("alpha2", 0.0)]]))
+            ctrl.setup_control_problem()                      # re-traces create_model / create_mpc at this point
+            rec["x"].append(x); rec["u"].append(u); rec["goal"].append(goal); rec["obs"].append(obs)
+            rec["x_next"].append(ctrl.model.rhs["x"].v.reshape(-1))
+            rec["cost"].append(float(ctrl.model.aux["cost"]))
+            rec["f"].append(np.array(CN._val(robot.f_casadi(ca.SX(x.reshape(nx, 1))))).reshape(-1))
+            rec["g"].append(np.array(CN._val(robot.g_casadi(ca.SX(x.reshape(nx, 1))))))
+            cons = []
+            for j in range(K):
+                expr, ub = ctrl.mpc.nl_cons[f"cbf_{j}"]
+                assert ub == 0
+                cons.append(float(expr))
+            rec["cons"].append(cons)
+            hk, dh, ddh = [], [], []
+            for j in range(K):
+                r = robot.agent_barrier_dt(ca.SX(x.reshape(nx, 1)), ca.SX(u.reshape(nu, 1)), ca.SX(obs[j].reshape(1, 7)))
+                hk.append(float(r[0])); dh.append(float(r[1])); ddh.append(float(r[2]) if len(r) > 2 else np.nan)
+            rec["hk"].append(hk); rec["dh"].append(dh); rec["ddh"].append(ddh)
+            CN.POINT["x"] = rec["x_next"][-1].reshape(nx, 1)      # the stage cost at the predicted state (what lterm / mterm see next)
+            ctrl.setup_control_problem()
+            rec["cost_next"].append(float(ctrl.model.aux["cost"]))
+            # the robot's numpy step() -- what the DT barrier composes, minus casadi's fmod/clip spelling
+            try:
+                rec["step"].append(np.asarray(robot.robot.step(x.reshape(nx, 1).copy(), u.reshape(nu, 1)), dtype=float).reshape(-1))
+            except Exception:
+                rec["step"].append(np.full(nx, np.nan))
+        for k, v in rec.items():
+            out[f"{name}/{k}"] = np.array(v, dtype=float)
+        # ---- update_tvp / tvp_fun (mpc_cbf.py:261-293, :338-364)
+        tv = {}
+        cases = {"none": None, "empty": [], "three_wide": [[1.0, 2.0, 0.3], [4.0, 5.0, 0.6]],
+                 "seven_wide": [[1.0, 2.0, 0.3, 0.1, -0.2, 0.0, 0.0], [3.0, 3.0, 0.5, 0.8, 4.0, 0.3, 1.0]],
+                 "too_many": [[float(j), float(j) + 1.0, 0.2 + 0.1 * j] for j in range(K + 2)]}
+        for cname, ob in cases.items():
+            goal = np.array([3.5, -1.25, 2.0])[: (3 if name == "Quad3D" else 2)]
+            ctrl.update_tvp(goal, None if ob is None else [np.array(o) for o in ob])
+            tpl = ctrl.mpc.tvp_fun(0.0)
+            tv[cname] = tpl
+            out[f"{name}/tvp/{cname}/obs_attr"] = np.asarray(ctrl.obs, dtype=float)
+            out[f"{name}/tvp/{cname}/obs"] = tpl.values["obs"]
+            out[f"{name}/tvp/{cname}/goal"] = tpl.values["goal"].reshape(-1)
+            for key in ("alpha", "alpha1", "alpha2"):
+                if key in tpl.values:
+                    out[f"{name}/tvp/{cname}/{key}"] = tpl.values[key]
+        raised = False
+        try:
+            ctrl.update_tvp(np.zeros(2), [np.array([1.0, 2.0, 0.3, 0.0, 0.0])])
+        except ValueError:
+            raised = True
+        out[f"{name}/tvp/five_wide_raises"] = np.array(raised)
+        print(name, "mpc cases", n_cases, "cons[0] =", rec["cons"][0])
+    np.savez_compressed(os.path.join(HERE, "mpc_functions.npz"), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "closed_loop_manipulator":
         gen_closed_loop_manipulator()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "closed_loop_integrators":
         gen_closed_loop_integrators()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mpc_functions":
+        gen_mpc_functions()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "linear_models":
         gen_linear_models()
@@ -685,3 +890,4 @@ if __name__ == "__main__":
     gen_linear_models()
     gen_closed_loop_integrators()
     gen_closed_loop_manipulator()
+    gen_mpc_functions()        # last: it swaps the inert casadi / do_mpc stand-ins for the numeric ones
