@@ -54,6 +54,28 @@ def test_config3_sample_against_oracle(io):
     assert (st == 0).mean() > 0.8 and (st == 1).sum() > 0
 
 
+def test_config3_full_batch_against_oracle():
+    """ALL 4096 problems of BASELINE config 3 (not a sample): the numpy oracle runs on the host cores in child processes
+    (tests/_oracle_pool.py); same status everywhere, |u0 - u0_oracle| <= 1e-6 and |z - z_oracle| <= 2e-5 on every optimal
+    problem, iteration counts within 2."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from _oracle_pool import mpc_cbf_solve_many
+    B = 4096
+    X, goal, ur, obs = W.du_cbfqp_batch(B, 8, seed=0)
+    up = np.zeros((B, 2))
+    u, st, it, z, (Xs, us, gs, os_) = run_gpu(X, up, goal, obs, "f64")
+    uo, so, ito, zo, fo = mpc_cbf_solve_many(Xs, us, gs, os_)
+    assert np.array_equal(st, so), np.flatnonzero(st != so)[:10]
+    ok = so == M.STATUS_OPTIMAL
+    assert ok.mean() > 0.85
+    assert np.abs(u[ok] - uo[ok]).max() <= 1e-6
+    assert np.abs(z[ok] - zo[ok]).max() <= 2e-5
+    assert np.abs(it[ok] - ito[ok]).max() <= 2
+    assert (it == ito).mean() >= 0.95
+
+
 def test_feasibility_and_local_optimality_independent_of_oracle_solver():
     from scipy.optimize import minimize
     B = 64

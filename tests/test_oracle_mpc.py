@@ -82,6 +82,39 @@ def test_oracle_solution_is_a_local_optimum_slsqp_agrees(i):
     assert np.abs(u0 - r.x[:2]).max() <= 1e-5
 
 
+def test_config3_optima_agree_with_an_independent_solver_on_200_problems():
+    """BASELINE config 3 draws (seed 0, first 230 agents => ~200 feasible): scipy SLSQP from the reference's constant
+    initial guess (z = 0), with every inequality (CBF rows, speed box, input box) in play, reaches the same cost (1e-7
+    relative) and the same first move (1e-5) as the oracle's interior point.  The NLP is non-convex: a different local
+    optimum is legitimate, so up to 1 % of the problems may differ -- each of those must still be a KKT point."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from _mpc_checks import kkt_residual, slsqp_from
+    from _oracle_pool import mpc_cbf_solve_many
+    B = 230
+    X, goal, ur, obs = W.du_cbfqp_batch(4096, 8, seed=0)
+    X, goal, obs = X[:B], goal[:B], obs[:B]
+    up = np.zeros((B, 2))
+    u, st, it, z, f = mpc_cbf_solve_many(X, up, goal, obs, workers=min(8, os.cpu_count() or 1))
+    opt = np.flatnonzero(st == M.STATUS_OPTIMAL)
+    assert len(opt) >= 200
+    differ, active = [], 0
+    for i in opt:
+        ev = lambda zz, lvl: M.evaluate(X[i], zz, up[i], goal[i], obs[i], P, level=lvl)
+        r = slsqp_from(ev, np.zeros(20))
+        g_s = ev(r.x, 0)["g"]
+        assert g_s.min() >= -1e-6                                           # SLSQP's own feasibility tolerance
+        active += int((ev(z[i], 0)["g"][:80] < 1e-6).any())
+        same = abs(r.fun - f[i]) <= 1e-7 * max(1.0, abs(f[i])) and np.abs(r.x[:2] - u[i]).max() <= 1e-5
+        if not same:
+            differ.append(i)
+            res, gmin, _ = kkt_residual(ev, z[i], active_tol=1e-4)
+            assert res <= 1e-3 and gmin >= -1e-7, (i, res, gmin)        # the oracle's point is a KKT point all the same
+    assert len(differ) <= 0.01 * len(opt), differ
+    assert active >= 25                                                     # the agreement includes problems with active CBF rows
+
+
 def test_infeasible_start_is_reported():
     """An agent already violating the DT-CBF row at k = 0 beyond the input authority: no feasible point."""
     x0, goal, obs = case(7)
