@@ -394,6 +394,9 @@ typedef struct sc_tracking_params {
     int32_t dyn_obs;             /* 1: obstacle table moves obs[:,0:2] += obs[:,3:5]*dt after the
                                     selection of each step (dynamic_env/main.py:54-58,147)          */
     int32_t num_constraints;     /* K: rows of the CBF-QP (tracking.py:138)                         */
+    int32_t step_offset;         /* control steps already run before this launch: ret_step stores
+                                    step_offset + the index inside the launch                       */
+    int32_t reserved0;           /* keep 0                                                          */
     double  reached_threshold;   /* 0.3  (tracking.py:49)                                           */
     double  rotation_threshold;  /* 0.1  (tracking.py:46)                                           */
     double  v_max, v_min;        /* robot_spec: nominal-input saturation; KB step clips v to both   */
@@ -404,10 +407,12 @@ typedef struct sc_tracking_params {
 
 /* X [B,4] in/out; waypoints [B,W,2] (or [W,2]); n_wp [B] (or [1]); wp_index [B] in/out;
  * state_machine [B] in/out (SC_SM_*); goal [B,3] in/out = (gx, gy, valid);
- * obs_table [M,7] in/out (shared by all agents; moved when dyn_obs); u_last [B,2] out;
+ * obs_table [M,7] in/out (shared by all agents; when dyn_obs every block of the launch reads the table
+ * as it was at launch and a stream-ordered follow-up kernel writes the table advanced by n_steps);
+ * u_last [B,2] in/out: the last input an agent applied (kept across launches for frozen agents);
  * ret [B] in/out: 0 running, -1 all waypoints reached, -2 infeasible or collision (sticky: an agent
- * whose ret != 0 is frozen); ret_step [B] out: step index (0-based, within this launch) at which ret
- * turned non-zero, or -1; traj_X [n_steps,B,4], traj_U [n_steps,B,2] optional (NULL to skip):
+ * whose ret != 0 is frozen); ret_step [B] in/out: step_offset + step index inside the launch at which
+ * ret turned non-zero (initialise to -1; untouched for agents that were already frozen); traj_X [n_steps,B,4], traj_U [n_steps,B,2] optional (NULL to skip):
  * state AFTER each step and the input applied (rows of frozen agents repeat their last state).
  */
 int sc_tracking_rollout_batch(const sc_tracking_params* params, int64_t B, int32_t M,
@@ -449,6 +454,7 @@ int sc_tracking_apply_batch(const sc_tracking_params* params, int64_t B, int32_t
 typedef struct sc_manip_tracking_params {
     sc_manip_cbfqp_params qp;      /* num_rows = num_constraints (150 by default, tracking.py:134-138)          */
     int32_t n_steps, max_waypoints, waypoints_shared, enable_rotation;
+    int32_t step_offset, reserved0; /* as in sc_tracking_params: ret_step = step_offset + index in the launch    */
     double  Kp;                    /* robot_spec['Kp'] (manipulator2D.py:22; examples use 5.0)                  */
     double  reached_threshold;     /* robot_spec['reached_threshold'] (0.3; examples/test_tracking.py:130: 0.5) */
     double  rotation_threshold;    /* 0.1 (tracking.py:46)                                                      */

@@ -111,6 +111,7 @@ class ManipTrackingParams(C.Structure):
     _fields_ = [
         ("qp", ManipCbfQpParams),
         ("n_steps", C.c_int32), ("max_waypoints", C.c_int32), ("waypoints_shared", C.c_int32), ("enable_rotation", C.c_int32),
+        ("step_offset", C.c_int32), ("reserved0", C.c_int32),
         ("Kp", C.c_double), ("reached_threshold", C.c_double), ("rotation_threshold", C.c_double),
     ]
 
@@ -126,6 +127,7 @@ class TrackingParams(C.Structure):
         ("qp", CbfQpParams),
         ("n_steps", C.c_int32), ("max_waypoints", C.c_int32), ("waypoints_shared", C.c_int32),
         ("enable_rotation", C.c_int32), ("dyn_obs", C.c_int32), ("num_constraints", C.c_int32),
+        ("step_offset", C.c_int32), ("reserved0", C.c_int32),
         ("reached_threshold", C.c_double), ("rotation_threshold", C.c_double),
         ("v_max", C.c_double), ("v_min", C.c_double),
         ("k_omega", C.c_double), ("k_a", C.c_double), ("k_v", C.c_double),

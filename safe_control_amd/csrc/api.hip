@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdint>
 #include <cstring>
 
 #include "../../include/safe_control_amd.h"
@@ -41,7 +42,7 @@ hipError_t manip_cbfqp_launch(const sc_manip_cbfqp_params& p, long long B, int K
 
 size_t mpclin_lds_bytes(int N, int K, int nx, int nu);
 size_t mpclin_model_doubles(int nx, int nu, int N);
-void mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const double* Be, const double* As, const double* Bs,
+bool mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const double* Be, const double* As, const double* Bs,
                         double* out);
 hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long long B, int K, const void* X, const void* u_prev,
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
@@ -56,6 +57,35 @@ hipError_t manip_rollout_launch(const sc_manip_tracking_params& t, long long B, 
                                 void* tX, void* tU, hipStream_t stream);
 
 static thread_local char g_err[256] = "";
+
+// The launch and hipFuncSetAttribute calls act on the CURRENT device of the calling thread.  A process that drives
+// several GPUs may call with tensors of a device that is not current: derive the device from the stream (or, for the
+// null stream, from the first data pointer), make it current for the call, restore it afterwards.  One-GPU processes
+// (the deployment this library is built for: one process per GPU) skip all of it.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    DeviceGuard(void* stream, const void* ptr) {
+        static const int n_dev = [] { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 1; } return n; }();
+        if (n_dev <= 1) return;
+        int cur = 0, want = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (stream) {
+            hipDevice_t d;
+            if (hipStreamGetDevice((hipStream_t)stream, &d) == hipSuccess) want = (int)d; else (void)hipGetLastError();
+        } else if (ptr) {
+            hipPointerAttribute_t a;
+            if (hipPointerGetAttributes(&a, ptr) == hipSuccess) want = a.device; else (void)hipGetLastError();
+        }
+        if (want >= 0 && want != cur) { prev = cur; switched = hipSetDevice(want) == hipSuccess; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// the kernels read X / u_ref / u_out with 8- and 16-byte vector accesses
+static bool misaligned(const void* p, size_t a) { return p && (reinterpret_cast<uintptr_t>(p) % a) != 0; }
 
 static int fail(int code, const char* msg) {
     std::snprintf(g_err, sizeof(g_err), "%s", msg);
@@ -92,6 +122,9 @@ static int check_cbfqp(const sc_cbfqp_params* p, int64_t B, int32_t K, const voi
     if (p->model_id == SC_MODEL_QUAD2D && !(p->mass > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "mass must be > 0 for Quad2D");
     if (B > 0 && (!X || !u_ref || !obs || !u_out || !status_out))
         return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    const size_t es = p->io_dtype == SC_DTYPE_F64 ? 8 : 4;
+    if (misaligned(X, 16) || misaligned(u_ref, 2 * es) || misaligned(u_out, 2 * es))
+        return fail(SC_ERR_INVALID_ARGUMENT, "X must be 16-byte aligned, u_ref / u_out aligned to two elements (vector loads)");
     return SC_OK;
 }
 static int check_mpccbf(const sc_mpccbf_params* p, int64_t B, int32_t K, const void* X, const void* u_prev,
@@ -120,7 +153,8 @@ static int check_mpclin_dims(const sc_mpclin_params* p) {
     if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
     if (p->nx < 2 || p->nx > 12 || p->nu < 1 || p->nu > 4 || p->ng < 2 || p->ng > p->nx)
         return fail(SC_ERR_INVALID_ARGUMENT, "need 2 <= nx <= 12, 1 <= nu <= 4, 2 <= ng <= nx");
-    if (p->horizon < 1 || p->horizon * p->nu > 128) return fail(SC_ERR_UNSUPPORTED, "need 1 <= horizon and nu * horizon <= 128");
+    if (p->horizon < 1 || p->horizon > 128 || p->horizon * p->nu > 128)           // horizon bounded first: the product cannot overflow
+        return fail(SC_ERR_UNSUPPORTED, "need 1 <= horizon and nu * horizon <= 128");
     return SC_OK;
 }
 static int check_mpclin(const sc_mpclin_params* p, const double* model, int64_t B, int32_t K, const void* X, const void* u_prev,
@@ -190,6 +224,7 @@ extern "C" {
 
 int sc_mpcgn_solve_batch(const sc_mpcgn_params* params, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,
                          const void* obs, void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
     int rc = sc::check_mpcgn(params, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
@@ -240,7 +275,7 @@ int sc_mpcgn_solve_batch_host(const sc_mpcgn_params* params, int64_t B, int32_t 
 }
 
 size_t sc_mpclin_model_doubles(int32_t nx, int32_t nu, int32_t horizon) {
-    if (nx < 2 || nx > 12 || nu < 1 || nu > 4 || horizon < 1 || horizon * nu > 128) return 0;
+    if (nx < 2 || nx > 12 || nu < 1 || nu > 4 || horizon < 1 || horizon > 128 || horizon * nu > 128) return 0;
     return sc::mpclin_model_doubles(nx, nu, horizon);
 }
 
@@ -249,13 +284,14 @@ int sc_mpclin_build_model(const sc_mpclin_params* params, const double* Ae, cons
     int rc = sc::check_mpclin_dims(params);
     if (rc != SC_OK) return rc;
     if (!Ae || !Be || !As || !Bs || !model_out) return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL matrix pointer");
-    sc::mpclin_build_model(*params, Ae, Be, As, Bs, model_out);
+    if (!sc::mpclin_build_model(*params, Ae, Be, As, Bs, model_out)) return sc::fail(SC_ERR_HIP, "out of host memory building the condensed model");
     return SC_OK;
 }
 
 int sc_mpclin_solve_batch(const sc_mpclin_params* params, const double* model, int64_t B, int32_t K, const void* X,
                           const void* u_prev, const void* goal, const void* obs, void* u_out, int32_t* status_out,
                           int32_t* iters_out, void* z_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
     int rc = sc::check_mpclin(params, model, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
@@ -311,6 +347,7 @@ int sc_manip_tracking_rollout_batch(const sc_manip_tracking_params* params, int6
                                     const int32_t* n_wp, int32_t* wp_index, int32_t* state_machine, void* goal,
                                     const void* obs_table, void* u_last, int32_t* ret, int32_t* ret_step, void* traj_X,
                                     void* traj_U, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
     if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
     static const double dummy = 0.0;
     int rc = sc::check_manip(&params->qp, B, 1, &dummy, &dummy, &dummy, &dummy, &dummy);
@@ -330,6 +367,7 @@ int sc_manip_tracking_rollout_batch(const sc_manip_tracking_params* params, int6
 int sc_manip_cbfqp_solve_batch(const sc_manip_cbfqp_params* params, int64_t B, int32_t K, const void* X, const void* u_ref,
                                const void* obs, const int32_t* n_obs, void* u_out, int32_t* status_out, void* h_out,
                                void* stream) {
+    sc::DeviceGuard on_device(stream, X);
     int rc = sc::check_manip(params, B, K, X, u_ref, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
@@ -394,6 +432,7 @@ int sc_device_count(int* count_out) {
 int sc_cbfqp_solve_batch(const sc_cbfqp_params* params, int64_t B, int32_t K, const void* X, const void* u_ref,
                          const void* obs, const int32_t* n_obs, void* u_out, int32_t* status_out, void* h_out,
                          void* stream) {
+    sc::DeviceGuard on_device(stream, X);
     int rc = sc::check_cbfqp(params, B, K, X, u_ref, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
@@ -446,6 +485,7 @@ int sc_cbfqp_solve_batch_host(const sc_cbfqp_params* params, int64_t B, int32_t 
 int sc_mpccbf_solve_batch(const sc_mpccbf_params* params, int64_t B, int32_t K, const void* X, const void* u_prev,
                           const void* goal, const void* obs, void* u_out, int32_t* status_out, int32_t* iters_out,
                           void* z_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
     int rc = sc::check_mpccbf(params, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
@@ -511,6 +551,7 @@ static int check_odmpccbf(const sc_odmpccbf_params* q, int64_t B, int32_t K, con
 int sc_odmpccbf_solve_batch(const sc_odmpccbf_params* params, int64_t B, int32_t K, const void* X, const void* u_prev,
                             const void* goal, const void* obs, void* u_out, void* rho_out, int32_t* status_out,
                             int32_t* iters_out, void* z_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
     int rc = check_odmpccbf(params, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
@@ -566,6 +607,7 @@ int sc_tracking_rollout_batch(const sc_tracking_params* params, int64_t B, int32
                               const int32_t* n_wp, int32_t* wp_index, int32_t* state_machine, void* goal,
                               void* obs_table, void* u_last, int32_t* ret, int32_t* ret_step, void* traj_X,
                               void* traj_U, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
     if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
     const sc_cbfqp_params* q = &params->qp;
     if (B < 0 || M < 0) return sc::fail(SC_ERR_INVALID_ARGUMENT, "B < 0 or M < 0");
@@ -620,6 +662,7 @@ int sc_tracking_select_batch(const sc_tracking_params* params, int64_t B, int32_
                              const int32_t* n_wp, int32_t* wp_index, int32_t* state_machine, void* goal,
                              const void* obs_table, const int32_t* ret, void* obs_out, void* goal_out, void* u_ref_out,
                              int32_t* track_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
     int rc = check_tracking_split(params, B, M);
     if (rc != SC_OK) return rc;
     if (params->max_waypoints < 1) return sc::fail(SC_ERR_INVALID_ARGUMENT, "max_waypoints < 1");
@@ -636,6 +679,7 @@ int sc_tracking_select_batch(const sc_tracking_params* params, int64_t B, int32_
 int sc_tracking_apply_batch(const sc_tracking_params* params, int64_t B, int32_t M, int32_t step_index, void* X,
                             const int32_t* state_machine, const void* goal, const void* obs_table, const void* u,
                             const int32_t* u_status, void* u_last, int32_t* ret, int32_t* ret_step, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
     int rc = check_tracking_split(params, B, M);
     if (rc != SC_OK) return rc;
     if (B > 0 && (!X || !state_machine || !goal || !u || !u_last || !ret || !ret_step || (M > 0 && !obs_table)))
@@ -662,6 +706,7 @@ static int check_od(const sc_odcbfqp_params* p, int64_t B, const void* X, const 
 int sc_odcbfqp_solve_batch(const sc_odcbfqp_params* params, int64_t B, const void* X, const void* u_ref, const void* obs,
                            const int32_t* has_obs, void* u_out, void* omega_out, int32_t* status_out, void* h_out,
                            void* stream) {
+    sc::DeviceGuard on_device(stream, X);
     int rc = check_od(params, B, X, u_ref, obs, u_out, omega_out, status_out);
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
@@ -710,6 +755,7 @@ int sc_odcbfqp_solve_batch_host(const sc_odcbfqp_params* params, int64_t B, cons
 
 int sc_neighbor_obstacles_batch(int32_t io_dtype, int64_t B_all, int64_t first_local, int64_t B_local, int32_t K,
                                 double neighbour_radius, const void* X_all, void* obs_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X_all);
     if (io_dtype != SC_DTYPE_F32 && io_dtype != SC_DTYPE_F64)
         return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
     if (B_all < 0 || B_local < 0 || first_local < 0 || first_local + B_local > B_all)
@@ -732,6 +778,7 @@ size_t sc_neighbor_workspace_bytes(int32_t io_dtype, int64_t B_all, int64_t B_lo
 int sc_neighbor_obstacles_batch_ws(int32_t io_dtype, int64_t B_all, int64_t first_local, int64_t B_local, int32_t K,
                                    double neighbour_radius, const void* X_all, void* obs_out, void* workspace,
                                    size_t workspace_bytes, void* stream) {
+    sc::DeviceGuard on_device(stream, X_all);
     if (io_dtype != SC_DTYPE_F32 && io_dtype != SC_DTYPE_F64)
         return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
     if (B_all < 0 || B_local < 0 || first_local < 0 || first_local + B_local > B_all)

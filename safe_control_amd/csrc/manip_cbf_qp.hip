@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64) void manip_rollout_kernel(const sc_manip_tracki
     for (int e = lane; e < M * 7; e += 64) table[e] = ld(obs_table, e);
     __syncthreads();
     double q[3] = {ld(X, agent * 3 + 0), ld(X, agent * 3 + 1), ld(X, agent * 3 + 2)};
-    int wp = wp_index[agent], sm = state_machine[agent], ret = ret_out[agent], rstep = -1;
+    int wp = wp_index[agent], sm = state_machine[agent], ret = ret_out[agent], rstep = ret_step[agent];
     double gx = ld(goal, agent * 3 + 0), gy = ld(goal, agent * 3 + 1);
     bool gvalid = ld(goal, agent * 3 + 2) != 0.0;
     const int W = t.max_waypoints;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64) void manip_rollout_kernel(const sc_manip_tracki
         const double dx = p.base_pos[0] - table[7 * mo], dy = p.base_pos[1] - table[7 * mo + 1];
         hit |= sqrt(dx * dx + dy * dy) < table[7 * mo + 2] + p.robot_radius;
     }
-    double ul[3] = {0.0, 0.0, 0.0};
+    double ul[3] = {ld(u_last, agent * 3 + 0), ld(u_last, agent * 3 + 1), ld(u_last, agent * 3 + 2)};   // the last input applied so far
 
     auto end_effector = [&](double& ex, double& ey, double (&sn)[3], double (&cs)[3]) {
         double ang = 0.0;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64) void manip_rollout_kernel(const sc_manip_tracki
 #pragma unroll
                 for (int i = 0; i < 3; ++i) { q[i] = q[i] + u[i] * p.dt; ul[i] = u[i]; }
             }
-            if (code != 0) { ret = code; rstep = step; }
+            if (code != 0) { ret = code; rstep = t.step_offset + step; }
         }
         if (lane < 3) {
             if (traj_X) st(traj_X, ((size_t)step * B + agent) * 3 + lane, lane == 0 ? q[0] : (lane == 1 ? q[1] : q[2]));

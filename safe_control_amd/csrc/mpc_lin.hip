@@ -18,6 +18,8 @@
 // Arithmetic is f64; the caller's arrays are f32 or f64.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../../include/safe_control_amd.h"
 #include "sc_math.hpp"
 #include "mpc_chol.hpp"
@@ -634,7 +636,7 @@ size_t mpclin_model_doubles(int nx, int nu, int N) {
     return (size_t)nx * nx + (size_t)nx * nu + 2 * nx + 2 * nu + n * n + 4 * (size_t)N * n;
 }
 
-void mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const double* Be, const double* As, const double* Bs,
+bool mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const double* Be, const double* As, const double* Bs,
                         double* out) {
     const int nx = p.nx, nu = p.nu, N = p.horizon, n = N * nu;
     double* o = out;
@@ -645,7 +647,8 @@ void mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const doubl
     double* Hc = o;
     double* G = Hc + (size_t)n * n;
     // Phi_k = d x_k / d z (nx x n), Phi_0 = 0, Phi_{k+1} = Ae Phi_k + Be E_k
-    double* Phi = new double[(size_t)(N + 1) * nx * n]();
+    double* Phi = static_cast<double*>(std::calloc((size_t)(N + 1) * nx * n, sizeof(double)));   // no exception may cross the C-ABI
+    if (!Phi) return false;
     for (int k = 0; k < N; ++k) {
         const double* Pk = Phi + (size_t)k * nx * n;
         double* Pn = Phi + (size_t)(k + 1) * nx * n;
@@ -689,7 +692,8 @@ void mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const doubl
                 G[(size_t)(2 * N + 2 * k + dd) * n + col] = acc;
             }
     }
-    delete[] Phi;
+    std::free(Phi);
+    return true;
 }
 
 hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long long B, int K, const void* X, const void* u_prev,

@@ -172,11 +172,11 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
     TC gx = TC(goal[ag * 3 + 0]), gy = TC(goal[ag * 3 + 1]);
     bool gvalid = goal[ag * 3 + 2] != TIO(0);
     int ret = active ? ret_out[ag] : -2;
-    int rstep = -1;
+    int rstep = active ? ret_step[ag] : -1;                          // kept for agents frozen in an earlier launch
     const int W = p.max_waypoints;
     const TIO* wps = waypoints + (p.waypoints_shared ? 0 : (size_t)ag * W * 2);
     const int nw = n_wp[p.waypoints_shared ? 0 : ag];
-    TC ul0 = TC(0), ul1 = TC(0);
+    TC ul0 = TC(u_last[ag * 2 + 0]), ul1 = TC(u_last[ag * 2 + 1]);     // the last input applied so far
 
     auto wp_x = [&](int i) { return TC(wps[2 * i]); };
     auto wp_y = [&](int i) { return TC(wps[2 * i + 1]); };
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
         else code = (!gvalid && sm != SC_SM_STOP) ? -1 : 0;                  // tracking.py:666-667
         if (run) {
             if (!pre_fail) { x = nx; y = ny; th = nth; v = nv; ul0 = u0; ul1 = u1; }
-            if (code != 0) { ret = code; rstep = step; }
+            if (code != 0) { ret = code; rstep = p.step_offset + step; }
         }
         if (active && traj_X) {
             TIO* tx = traj_X + ((size_t)step * B + agent) * 4;
@@ -318,10 +318,6 @@ __global__ __launch_bounds__(64) void tracking_rollout_kernel(
         goal[agent * 3 + 0] = TIO(gx); goal[agent * 3 + 1] = TIO(gy); goal[agent * 3 + 2] = gvalid ? TIO(1) : TIO(0);
         u_last[agent * 2 + 0] = TIO(ul0); u_last[agent * 2 + 1] = TIO(ul1);
         ret_out[agent] = ret; ret_step[agent] = rstep;
-    }
-    if (blockIdx.x == 0 && t.dyn_obs) {
-        __syncthreads();
-        for (int e = lane; e < M * 7; e += 64) obs_table[e] = TIO(table[e]);
     }
 }
 
@@ -576,11 +572,11 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
     TC gx = TC(goal[ag * 3 + 0]), gy = TC(goal[ag * 3 + 1]);
     bool gvalid = goal[ag * 3 + 2] != TIO(0);
     int ret = active ? ret_out[ag] : -2;
-    int rstep = -1;
+    int rstep = active ? ret_step[ag] : -1;                          // kept for agents frozen in an earlier launch
     const int W = p.max_waypoints;
     const TIO* wps = waypoints + (p.waypoints_shared ? 0 : (size_t)ag * W * 2);
     const int nw = n_wp[p.waypoints_shared ? 0 : ag];
-    TC ul0 = TC(0), ul1 = TC(0);
+    TC ul0 = TC(u_last[ag * 2 + 0]), ul1 = TC(u_last[ag * 2 + 1]);     // the last input applied so far
 
     auto wp_x = [&](int i) { return TC(wps[2 * i]); };
     auto wp_y = [&](int i) { return TC(wps[2 * i + 1]); };
@@ -730,7 +726,7 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
         else code = (!gvalid && sm != SC_SM_STOP) ? -1 : 0;                  // tracking.py:666-667
         if (run) {
             if (!pre_fail) { x = nx; y = ny; th = nth; v = nv; ul0 = u0; ul1 = u1; }
-            if (code != 0) { ret = code; rstep = step; }
+            if (code != 0) { ret = code; rstep = p.step_offset + step; }
         }
         if (active && sub == 0 && traj_X) {
             TIO* tx = traj_X + ((size_t)step * B + agent) * 4;
@@ -749,10 +745,20 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
         u_last[agent * 2 + 0] = TIO(ul0); u_last[agent * 2 + 1] = TIO(ul1);
         ret_out[agent] = ret; ret_step[agent] = rstep;
     }
-    if (blockIdx.x == 0 && t.dyn_obs) {
-        __syncthreads();
-        for (int e = lane; e < M * 7; e += 64) obs_table[e] = TIO(table[e]);
-    }
+}
+
+// Moving obstacles: every block of a rollout launch reads the table as it was at launch and advances its own LDS copy
+// (a grid larger than one resident wave of blocks starts late blocks after early ones have finished, so nobody may
+// write the table while the launch runs).  This stream-ordered follow-up leaves the table where n_steps of
+// `obs[:, 0:2] += obs[:, 3:5] * dt` (dynamic_env/main.py:54-58) put it -- the same f64 additions in the same order.
+template <typename TIO>
+__global__ void advance_obstacle_table_kernel(TIO* __restrict__ obs_table, const int M, const int n_steps, const double dt) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    double x = double(obs_table[7 * m]), y = double(obs_table[7 * m + 1]);
+    const double vx = double(obs_table[7 * m + 3]), vy = double(obs_table[7 * m + 4]);
+    for (int s = 0; s < n_steps; ++s) { x += vx * dt; y += vy * dt; }
+    obs_table[7 * m] = TIO(x); obs_table[7 * m + 1] = TIO(y);
 }
 
 template <typename TIO, typename TC, int G, int MODEL>
@@ -899,9 +905,14 @@ hipError_t tracking_launch(const sc_tracking_params& p, long long B, int M, void
                            int* wp_index, int* sm, void* goal, void* table, void* u_last, int* ret, int* ret_step,
                            void* tX, void* tU, hipStream_t stream) {
     // closed loops amplify rounding: arithmetic is always f64 here; storage follows io_dtype
-    if (p.qp.io_dtype == SC_DTYPE_F32)
-        return launch_track_m<float, double>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
-    return launch_track_m<double, double>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+    const bool f32 = p.qp.io_dtype == SC_DTYPE_F32;
+    hipError_t e = f32 ? launch_track_m<float, double>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream)
+                       : launch_track_m<double, double>(p, B, M, X, wps, n_wp, wp_index, sm, goal, table, u_last, ret, ret_step, tX, tU, stream);
+    if (e != hipSuccess || !p.dyn_obs || M == 0) return e;
+    const unsigned blocks = (unsigned)((M + 255) / 256);
+    if (f32) hipLaunchKernelGGL(advance_obstacle_table_kernel<float>, dim3(blocks), dim3(256), 0, stream, (float*)table, M, p.n_steps, p.qp.dt);
+    else hipLaunchKernelGGL(advance_obstacle_table_kernel<double>, dim3(blocks), dim3(256), 0, stream, (double*)table, M, p.n_steps, p.qp.dt);
+    return hipGetLastError();
 }
 
 }  // namespace sc

@@ -266,6 +266,7 @@ class BatchedManipulatorTracking:
         p.qp = make_params(self.robot_spec, self.alpha, self.dt, self.robot_spec["radius"], self.io_dtype, self.num_constraints,
                            self.base_pos, obs_shared=True)
         p.n_steps, p.max_waypoints, p.waypoints_shared = int(n), int(self.waypoints.shape[1]), 0
+        p.step_offset = int(self.steps_done)
         p.enable_rotation = 1 if self.enable_rotation else 0
         p.Kp, p.reached_threshold, p.rotation_threshold = float(self.robot_spec["Kp"]), self.reached_threshold, 0.1
         tX = torch.empty((n, self.B, 3), dtype=self.tdtype, device=self.device) if record else None

@@ -181,6 +181,7 @@ class BatchedTrackingController:
         p = _lib.TrackingParams()
         p.qp = make_params(rs, self.cbf_param, self.dt, rs["radius"], self.io_dtype, _lib.DTYPE_F64)
         p.n_steps = int(n_steps)
+        p.step_offset = int(self.steps_done)                     # ret_step is an absolute control-step index
         p.max_waypoints = int(self.waypoints.shape[1])
         p.waypoints_shared = 0
         p.enable_rotation = 1 if self.enable_rotation else 0
@@ -249,14 +250,17 @@ class BatchedTrackingController:
                 self.ret.data_ptr(), obs_sel.data_ptr(), goal2.data_ptr(), u_ref.data_ptr(), track.data_ptr(), stream)
             _lib.check(rc, "sc_tracking_select_batch")
             Xm = self.X[:, :2].contiguous() if self.model == "SingleIntegrator2D" else self.X
-            out = self.mpc.solve(Xm, self.u_prev, goal2, obs_sel)
+            # OptimalDecayMPCCBF has five fixed obstacle slots (optimal_decay_mpc_cbf.py:249-252,333-339: padded_obs[:5]):
+            # it sees the five nearest of the selected rows, MPCCBF all num_constraints of them
+            obs_in = obs_sel[:, :5].contiguous() if (self.pos_controller_type == "optimal_decay_mpc_cbf" and K > 5) else obs_sel
+            out = self.mpc.solve(Xm, self.u_prev, goal2, obs_in)
             u_mpc, st = (out[0], out[2]) if self.pos_controller_type == "optimal_decay_mpc_cbf" else (out[0], out[1])
             tr = (track != 0).unsqueeze(1)
             u = torch.where(tr, u_mpc, u_ref).contiguous()
             self.u_prev = torch.where(tr, u_mpc, self.u_prev).contiguous()
             self.mpc_status = torch.where(track != 0, st, self.mpc_status)
             rc = self._lib.sc_tracking_apply_batch(
-                C.byref(p), B, M, k, self.X.data_ptr(), self.state_machine.data_ptr(), self.goal.data_ptr(), obs_ptr,
+                C.byref(p), B, M, self.steps_done + k, self.X.data_ptr(), self.state_machine.data_ptr(), self.goal.data_ptr(), obs_ptr,
                 u.data_ptr(), None, self.u_pos.data_ptr(), self.ret.data_ptr(), self.ret_step.data_ptr(), stream)
             _lib.check(rc, "sc_tracking_apply_batch")
             if record:

@@ -64,6 +64,64 @@ def test_reference_moving_obstacle_runs(golden_dir, model_name, tag):
                                + np.hstack([5 * 0.05 * g[f"{tag}/obs0"][:, 3:5], np.zeros((8, 5))]), atol=1e-9)
 
 
+@pytest.mark.parametrize("lane_per_agent", ["0", "1"])
+def test_moving_obstacles_large_grid_every_block_sees_the_same_table(golden_dir, lane_per_agent, monkeypatch):
+    """131072 copies of the reference's moving-obstacle agent: a grid many times larger than what the chip keeps resident, so
+    late blocks start after early ones have finished.  Every copy must reproduce the reference trajectory bit for bit like
+    copy 0 (the table a block reads is the table at launch; the advance is a stream-ordered follow-up kernel), across
+    two launches, and the table must end where n_steps of obs += v dt put it."""
+    monkeypatch.setenv("SC_TRACK_LANE_PER_AGENT", lane_per_agent)
+    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    tag = "c3bf_dyn"
+    wps = g[f"{tag}/waypoints"]
+    spec = {"model": "KinematicBicycle2D_C3BF", "a_max": 5.0, "radius": 0.3}
+    B = 131072
+    X0 = np.repeat(np.append(wps[0], 1.0)[None, :], B, 0)
+    ctl = sca.BatchedTrackingController(X0, spec, obs=g[f"{tag}/obs0"], dyn_obs=True)
+    ctl.set_waypoints(np.repeat(wps[None], B, 0))
+    Xg = g[f"{tag}/X"]
+    T1, T2 = 40, 35
+    ctl.control_step(T1)
+    X1 = ctl.X.cpu().numpy()
+    assert np.array_equal(X1, np.repeat(X1[:1], B, 0))
+    np.testing.assert_allclose(X1[0], Xg[T1], rtol=1e-6, atol=1e-6)
+    ctl.control_step(T2)
+    X2 = ctl.X.cpu().numpy()
+    assert np.array_equal(X2, np.repeat(X2[:1], B, 0))
+    np.testing.assert_allclose(X2[0], Xg[T1 + T2], rtol=1e-6, atol=1e-6)
+    obs0 = g[f"{tag}/obs0"]
+    want = obs0.copy()
+    for _ in range(T1 + T2):
+        want[:, 0:2] += want[:, 3:5] * 0.05
+    np.testing.assert_allclose(ctl.obs.cpu().numpy(), want, rtol=0, atol=1e-12)
+
+
+def test_finish_step_and_last_input_survive_later_launches(golden_dir):
+    """run_all_steps works in chunks: an agent that finished (or failed) in an earlier launch keeps its absolute ret_step
+    and its last applied input; the fused rollout and the select / apply split agree on both."""
+    g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
+    obs = g["du14/obs"]
+    spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}
+    X0 = np.array([[2.0, 2.0, np.pi / 2, 1.0], [6.0, 1.0, 2.6, 0.3], [1.0, 6.0, -1.2, 0.0]])
+    wl = [np.array([[2.0, 3.2]]), np.array([[5.2, 1.4]]), np.array([[1.0, 12.0]])]     # two short routes, one long
+    one = sca.BatchedTrackingController(X0, dict(spec), obs=obs, io_dtype="f64")
+    one.set_waypoints(wl)
+    ret1, tX1, tU1 = one.control_step(120, record=True)
+    rs1 = one.ret_step.cpu().numpy().copy(); ul1 = one.u_pos.cpu().numpy().copy(); ret1 = ret1.cpu().numpy().copy()
+    assert (ret1[:2] == -1).all() and ret1[2] == 0 and (rs1[:2] >= 0).all() and (rs1[:2] < 100).all()
+    many = sca.BatchedTrackingController(X0, dict(spec), obs=obs, io_dtype="f64")
+    many.set_waypoints(wl)
+    for n in (7, 33, 50, 30):
+        many.control_step(n)
+    assert np.array_equal(many.ret.cpu().numpy(), ret1)
+    assert np.array_equal(many.ret_step.cpu().numpy(), rs1)
+    np.testing.assert_array_equal(many.u_pos.cpu().numpy(), ul1)
+    np.testing.assert_array_equal(many.X.cpu().numpy(), one.X.cpu().numpy())
+    tU1 = tU1.cpu().numpy()
+    for i in range(2):                                                           # the last input is the one applied at the finishing step
+        np.testing.assert_array_equal(ul1[i], tU1[rs1[i], i])
+
+
 def test_many_agents_static_scene_against_oracle(golden_dir):
     """48 agents scattered over the config-1 scene, each with its own start pose and waypoint list."""
     g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
@@ -168,7 +226,7 @@ def test_closed_loop_with_mpc_position_controller(golden_dir, pos):
         def solve_fn(X, cref, nobs, state=state):
             if cref["state_machine"] != "track":
                 return np.asarray(cref["u_ref"], dtype=np.float64).reshape(-1), 0
-            o = M.pad_obstacles(None if nobs is None else list(nobs), K)
+            o = M.pad_obstacles(None if nobs is None else list(nobs), K if pos == "mpc_cbf" else 5)   # OD: five slots
             if pos == "mpc_cbf":
                 u, st, it = M.solve(X, state["up"], cref["goal"], o)
             else:
