@@ -187,7 +187,7 @@ def test_closed_loop_reproduces_the_reference_run(tag):
         np.testing.assert_allclose(tX[:m], Xg[done + 1: done + m + 1], rtol=0, atol=1e-7)
         np.testing.assert_allclose(tU[:m], Ug[done: done + m], rtol=0, atol=1e-7)
         done += n
-    assert int(ret[0].item()) == -1 and int(ctl.ret_step[0].item()) == T - 2      # second launch started at step 1
+    assert int(ret[0].item()) == -1 and int(ctl.ret_step[0].item()) == T - 1      # absolute step index across the two launches
     np.testing.assert_allclose(tX[-1], Xg[-1], atol=1e-7)                          # frozen after finishing
 
 
