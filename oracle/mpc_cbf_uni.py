@@ -38,8 +38,10 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     n = 2 * N
     Q, Rw = np.asarray(P["Q"], dtype=np.float64), np.asarray(P["R"], dtype=np.float64)
     K = obs.shape[0]
-    al = P["alpha"]
-    w0, w1 = -(1.0 - al), 1.0
+    # per-stage gain: the optimal-decay extension (oracle/od_mpc_rd1.py) scales alpha by the stage's decay variable
+    al = np.broadcast_to(np.asarray(P.get("alpha_k", P["alpha"]), dtype=np.float64), (N,))
+    w0, w1 = -(1.0 - al), 1.0                                                # w0[k]: weight of h(p_k) in row k
+    u2 = P.get("rterm", "du") == "u2"                                        # optimal decay: R u^2, not do-mpc's delta-u penalty
     X = rollout(x0, z, P)
     pos = X[:, 0:2]
     gpos = np.asarray(goal, dtype=np.float64)[0:2]
@@ -49,7 +51,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
         e = pos[k] - gpos
         f += Q[0] * e[0] ** 2 + Q[1] * e[1] ** 2 + Q[2] * X[k, 2] ** 2
     up = np.concatenate([np.asarray(u_prev, dtype=np.float64), z])
-    du = up[2:] - up[:-2]
+    du = z.copy() if u2 else up[2:] - up[:-2]
     Rd = np.tile(Rw, N)
     f += float(np.sum(Rd * du * du))
     hk = np.zeros((N + 1, K)); dh = np.zeros((N + 1, K, 2)); Hh = np.zeros((N + 1, K, 2, 2))
@@ -59,7 +61,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     m = N * K + 2 * n
     g = np.zeros(m)
     for k in range(N):
-        g[k * K:(k + 1) * K] = w1 * hk[k + 1] + w0 * hk[k]
+        g[k * K:(k + 1) * K] = w1 * hk[k + 1] + w0[k] * hk[k]
     o = N * K
     ub = np.tile([P["a_max"], P["w_max"]], N)
     g[o:o + n] = ub - z
@@ -82,16 +84,18 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     grad = np.zeros(n)
     for k in range(1, N + 1):
         grad += dP[k].T @ (2.0 * Q[0:2] * (pos[k] - gpos)) + 2.0 * Q[2] * X[k, 2] * dTh[k]
-    Dm = np.eye(n) - np.eye(n, k=-2)
+    Dm = np.eye(n) if u2 else np.eye(n) - np.eye(n, k=-2)
     grad += 2.0 * Dm.T @ (Rd * du)
     J = np.zeros((m, n))
     for k in range(N):
         for j in range(K):
-            J[k * K + j] = w1 * dh[k + 1, j] @ dP[k + 1] + w0 * dh[k, j] @ dP[k]
+            J[k * K + j] = w1 * dh[k + 1, j] @ dP[k + 1] + w0[k] * dh[k, j] @ dP[k]
     o = N * K
     J[o:o + n] = -np.eye(n)
     J[o + n:o + 2 * n] = np.eye(n)
     out.update(grad=grad, J=J)
+    if P.get("want_internals"):                                              # h(a_kj) and its Jacobian in z, a_k = p_k
+        out.update(ha=hk[:N].copy(), Ja=np.einsum("kja,kan->kjn", dh[:N], dP[:N]))
     if level == 1:
         return out
     lam = np.zeros(m) if lam is None else lam
@@ -99,7 +103,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     mu = np.zeros((N + 1, K))
     for k in range(N + 1):
         if 1 <= k: mu[k] += w1 * lc[k - 1]
-        if k <= N - 1: mu[k] += w0 * lc[k]
+        if k <= N - 1: mu[k] += w0[k] * lc[k]
     W = 2.0 * Dm.T @ (Rd[:, None] * Dm)
     q = np.zeros((N + 1, 2))
     for k in range(N + 1):

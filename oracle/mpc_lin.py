@@ -68,7 +68,7 @@ def quad3d_model(spec=None, dt=0.05):
                 u_lo=np.full(4, s["u_min"]), u_hi=np.full(4, s["u_max"]), radius=s["radius"], dt=dt, circles_only=True)
 
 
-def condensed(model, N):
+def condensed(model, N, rterm="du"):
     """Constant matrices of the condensed problem: Hc = Hessian of the cost in z (n x n), G = d points / d z
     (4N x n, points ordered a_0..a_{N-1}, b_0..b_{N-1}, two rows each)."""
     nx, nu = model["nx"], model["nu"]
@@ -81,7 +81,7 @@ def condensed(model, N):
     Hc = np.zeros((n, n))
     for k in range(1, N + 1):
         Hc += 2.0 * Phi[k].T @ (model["Q"][:, None] * Phi[k])
-    Dm = np.eye(n) - np.eye(n, k=-nu)
+    Dm = np.eye(n) if rterm == "u2" else np.eye(n) - np.eye(n, k=-nu)      # optimal decay: R u^2 instead of the delta-u penalty
     Rd = np.tile(model["R"], N)
     Hc += 2.0 * Dm.T @ (Rd[:, None] * Dm)
     G = np.zeros((4 * N, n))
@@ -97,7 +97,7 @@ def params(model, N=10, **over):
     P = dict(M.DEFAULTS, N=N, dt=model["dt"], nu=model["nu"], u_lo=model["u_lo"], u_hi=model["u_hi"], radius=model["radius"],
              alpha=model["alpha"], model=model)
     P.update(over)
-    P["quadratic_cost"] = condensed(model, P["N"])[0]       # exact merit differences in the line search
+    P["quadratic_cost"] = condensed(model, P["N"], P.get("rterm", "du"))[0]   # exact merit differences in the line search
     P.setdefault("row_noise", 1e-15)
     return P
 
@@ -116,7 +116,9 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     n = N * nu
     K = obs.shape[0]
     Q, Rw = mdl["Q"], mdl["R"]
-    w0 = -(1.0 - P["alpha"])
+    # per-stage gain: the optimal-decay extension (oracle/od_mpc_rd1.py) scales alpha by the stage's decay variable
+    w0 = -(1.0 - np.broadcast_to(np.asarray(P.get("alpha_k", P["alpha"]), dtype=np.float64), (N,)))
+    u2 = P.get("rterm", "du") == "u2"
     xg = np.zeros(nx); xg[: mdl["ng"]] = np.asarray(goal, dtype=np.float64)[: mdl["ng"]]   # mpc_cbf.py:267
     X = np.zeros((N + 1, nx)); X[0] = np.asarray(x0, dtype=np.float64)[:nx]
     U = z.reshape(N, nu)
@@ -129,7 +131,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
         e = X[k] - xg
         f += float(Q @ (e * e))
     up = np.concatenate([np.asarray(u_prev, dtype=np.float64)[:nu], z])
-    du = up[nu:] - up[:-nu]
+    du = z.copy() if u2 else up[nu:] - up[:-nu]
     Rd = np.tile(Rw, N)
     f += float(np.sum(Rd * du * du))
     ha = np.zeros((N, K)); hb = np.zeros((N, K)); da = np.zeros((N, K, 2)); db = np.zeros((N, K, 2))
@@ -140,27 +142,29 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
             hb[k, j], db[k, j], Hb[k, j] = barrier(b[k], obs[j], P)
     m = N * K + 2 * n
     g = np.zeros(m)
-    g[: N * K] = (hb + w0 * ha).reshape(-1)
+    g[: N * K] = (hb + w0[:, None] * ha).reshape(-1)
     hi, lo = np.tile(mdl["u_hi"], N), np.tile(mdl["u_lo"], N)
     g[N * K:N * K + n] = hi - z
     g[N * K + n:] = z - lo
     out = dict(f=float(f), g=g, X=X)
     if level == 0:
         return out
-    Hc, G, Phi = condensed(mdl, N)
+    Hc, G, Phi = condensed(mdl, N, "u2" if u2 else "du")
     grad = np.zeros(n)
     for k in range(1, N + 1):
         grad += Phi[k].T @ (2.0 * Q * (X[k] - xg))
-    Dm = np.eye(n) - np.eye(n, k=-nu)
+    Dm = np.eye(n) if u2 else np.eye(n) - np.eye(n, k=-nu)
     grad += 2.0 * Dm.T @ (Rd * du)
     J = np.zeros((m, n))
     Ga, Gb = G[: 2 * N].reshape(N, 2, n), G[2 * N:].reshape(N, 2, n)
     for k in range(N):
         for j in range(K):
-            J[k * K + j] = db[k, j] @ Gb[k] + w0 * (da[k, j] @ Ga[k])
+            J[k * K + j] = db[k, j] @ Gb[k] + w0[k] * (da[k, j] @ Ga[k])
     J[N * K:N * K + n] = -np.eye(n)
     J[N * K + n:] = np.eye(n)
     out.update(grad=grad, J=J)
+    if P.get("want_internals"):                                              # h(a_kj) and its Jacobian in z
+        out.update(ha=ha.copy(), Ja=np.einsum("kja,kan->kjn", da, Ga))
     if level == 1:
         return out
     lam = np.zeros(m) if lam is None else lam
@@ -168,7 +172,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     W = Hc.copy()
     for k in range(N):
         Om_b = -np.einsum("j,jab->ab", lc[k], Hb[k])
-        Om_a = -w0 * np.einsum("j,jab->ab", lc[k], Ha[k])
+        Om_a = -w0[k] * np.einsum("j,jab->ab", lc[k], Ha[k])
         W += Gb[k].T @ Om_b @ Gb[k] + Ga[k].T @ Om_a @ Ga[k]
     out.update(W=W)
     return out
