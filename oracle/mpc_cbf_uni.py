@@ -66,7 +66,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     ub = np.tile([P["a_max"], P["w_max"]], N)
     g[o:o + n] = ub - z
     g[o + n:o + 2 * n] = ub + z
-    out.update(f=float(f), g=g, X=X)
+    out.update(f=float(f), g=g, X=X, pts=pos)
     if level == 0:
         return out
     # first derivatives: theta_k = th0 + dt sum_{i<k} w_i ; p_k = p0 + dt sum_{l<k} v_l (cos, sin)(theta_l)

@@ -262,7 +262,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     hi_, lo_ = np.tile(mdl["u_hi"], N), np.tile(mdl["u_lo"], N)
     g[o:o + n] = hi_ - z
     g[o + n:] = z - lo_
-    out = dict(f=float(f), g=g, X=X)
+    out = dict(f=float(f), g=g, X=X, pts=pts.reshape(-1, 2))
     if level == 0:
         return out
     grad = np.zeros(n)

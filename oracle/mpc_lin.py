@@ -146,7 +146,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     hi, lo = np.tile(mdl["u_hi"], N), np.tile(mdl["u_lo"], N)
     g[N * K:N * K + n] = hi - z
     g[N * K + n:] = z - lo
-    out = dict(f=float(f), g=g, X=X)
+    out = dict(f=float(f), g=g, X=X, pts=np.vstack([a, b]))
     if level == 0:
         return out
     Hc, G, Phi = condensed(mdl, N, "u2" if u2 else "du")

@@ -86,7 +86,7 @@ def evaluate(x0, zz, goal, obs, P, lam=None, level=2):
     ub = np.tile([P["a_max"], P["w_max"]], N)
     g[o:o + n] = ub - z
     g[o + n:o + 2 * n] = ub + z
-    out.update(f=float(f), g=g, X=X)
+    out.update(f=float(f), g=g, X=X, pts=pos)
     if level == 0:
         return out
     dP = M.position_jacobians(X, P)
@@ -194,6 +194,10 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
     z = np.clip(np.tile(np.asarray(u_prev, dtype=np.float64), N), -0.99 * ub, 0.99 * ub)   # set_initial_guess
     zz = np.concatenate([z, np.tile([P["omega1"], P["omega2"]], N)])
     ev = evaluate(x0, zz, goal, obs, P, None, level=1)
+    if np.any(obs[:, 6] >= 0.5):
+        obs = M.barrier_scales(ev["pts"], obs, P)                          # steep (superellipsoid) barriers: IPOPT-style scaling
+        if np.any(obs[:, 7] < 1.0):
+            ev = evaluate(x0, zz, goal, obs, P, None, level=1)
     sf = min(1.0, 100.0 / max(1e-12, float(np.max(np.abs(ev["grad"][:n])))))
     g = ev["g"]
     mu = P["mu_init"]
@@ -300,5 +304,5 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
             status = STATUS_INACCURATE
     u0, rho0 = zz[0:2].copy(), zz[n:n + 2].copy()
     if return_info:
-        return u0, rho0, status, it, dict(zz=zz, X=ev["X"], f=ev["f"], g=ev["g"], lam=lam / sf, s=s, err=err, mu=mu, scale=sf, trace=trace)
+        return u0, rho0, status, it, dict(zz=zz, X=ev["X"], f=ev["f"], g=ev["g"], lam=lam / sf, s=s, err=err, mu=mu, scale=sf, obs=obs, trace=trace)
     return u0, rho0, status, it

@@ -62,7 +62,7 @@ def evaluate(x0, zz, goal, obs, P, lam=None, level=2):
     Pk = dict(P, alpha_k=al * rho, want_internals=True)
     ev = _base(P)(x0, z, np.zeros(nu), goal, obs, Pk, lam, level)
     K = obs.shape[0]
-    out = dict(f=ev["f"] + float(ps * np.sum((rho - ref) ** 2)), g=ev["g"], X=ev["X"])
+    out = dict(f=ev["f"] + float(ps * np.sum((rho - ref) ** 2)), g=ev["g"], X=ev["X"], pts=ev["pts"])
     if level == 0:
         return out
     m = ev["g"].shape[0]
@@ -103,6 +103,11 @@ def solve(x0, u_prev, goal, obs, P, return_info=False, linear_algebra="schur"):
         z = np.clip(np.tile(np.asarray(u_prev, dtype=np.float64), N), -0.99 * ub, 0.99 * ub)   # set_initial_guess
     zz = np.concatenate([z, np.full(N, P["omega1"])])
     ev = evaluate(x0, zz, goal, obs, P, None, level=1)
+    circles_only = "model" in P and P["model"]["circles_only"]
+    if np.any(obs[:, 6] >= 0.5) and not circles_only:
+        obs = M.barrier_scales(ev["pts"], obs, P)                          # steep (superellipsoid) barriers: IPOPT-style scaling
+        if np.any(obs[:, 7] < 1.0):
+            ev = evaluate(x0, zz, goal, obs, P, None, level=1)
     sf = min(1.0, 100.0 / max(1e-12, float(np.max(np.abs(ev["grad"][:n])))))
     g = ev["g"]
     mu = P["mu_init"]
@@ -201,5 +206,5 @@ def solve(x0, u_prev, goal, obs, P, return_info=False, linear_algebra="schur"):
             status = STATUS_INACCURATE
     u0, rho0 = zz[0:nu].copy(), float(zz[n])
     if return_info:
-        return u0, rho0, status, it, dict(zz=zz, z=zz[:n].copy(), rho=zz[n:].copy(), X=ev["X"], f=ev["f"], g=ev["g"], lam=lam / sf, s=s, err=err, mu=mu, scale=sf)
+        return u0, rho0, status, it, dict(zz=zz, z=zz[:n].copy(), rho=zz[n:].copy(), X=ev["X"], f=ev["f"], g=ev["g"], lam=lam / sf, s=s, err=err, mu=mu, scale=sf, obs=obs)
     return u0, rho0, status, it

@@ -540,8 +540,11 @@ static int check_odmpccbf(const sc_odmpccbf_params* q, int64_t B, int32_t K, con
     if (!q) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
     int rc = sc::check_mpccbf(&q->mpc, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
-    if (q->mpc.model_id != SC_MODEL_DYNAMIC_UNICYCLE2D)
-        return sc::fail(SC_ERR_UNSUPPORTED, "optimal-decay MPC-CBF is built for DynamicUnicycle2D only");
+    // DynamicUnicycle2D: the reference's problem (optimal_decay_mpc_cbf.py).  Unicycle2D: BASELINE config 5's EXTENSION -- the
+    // reference class rejects that model (:19-20); rows d_h + alpha rho_k h_k, one live decay variable per stage
+    // (oracle/od_mpc_rd1.py).  The host classes only reach it with extension=True.
+    if (q->mpc.model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && q->mpc.model_id != SC_MODEL_UNICYCLE2D)
+        return sc::fail(SC_ERR_UNSUPPORTED, "optimal-decay MPC-CBF is built for DynamicUnicycle2D and (extension) Unicycle2D");
     if (sc::odmpccbf_lds_bytes(q->mpc.horizon, K) > 160 * 1024)
         return sc::fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
     if (!(q->p_sb[0] > 0) || !(q->p_sb[1] > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "p_sb must be > 0");

@@ -197,7 +197,7 @@ struct MpcConst {
 // circle robots/dynamic_unicycle2D.py:194-202; superellipsoid :204-220 (fabs, clamps a,b>=1e-3, e>=2)
 __device__ inline void barrier_at(double px_, double py_, const double* o, const MpcConst& c, bool derivs,
                                   double& h, double& d0, double& d1, double& hxx, double& hxy, double& hyy) {
-    if (o[6] < 0.5) {
+    if (o[6] == 0.0) {                      // LDS rows: 0 = circle, otherwise the row scale of a superellipsoid (mpc_ipm_common.hpp)
         const double d = c.Rrob + o[2];
         const double ex = px_ - o[0], ey = py_ - o[1];
         h = (ex * ex + ey * ey) - c.beta * d * d;
@@ -211,16 +211,17 @@ __device__ inline void barrier_at(double px_, double py_, const double* o, const
     const double dx = px_ - o[0], dy = py_ - o[1];
     const double px = ct * dx + st * dy, py = -st * dx + ct * dy;
     const double ax = fabs(px) / a, ay = fabs(py) / b;
-    h = pow(ax, e) + pow(ay, e) - 1.0;
+    const double sc = o[6];
+    h = sc * (pow(ax, e) + pow(ay, e) - 1.0);
     if (!derivs) { d0 = d1 = hxx = hxy = hyy = 0.0; return; }
     const double sx = px > 0 ? 1.0 : (px < 0 ? -1.0 : 0.0), sy = py > 0 ? 1.0 : (py < 0 ? -1.0 : 0.0);
     const double gpx = e * pow(ax, e - 1) / a * sx, gpy = e * pow(ay, e - 1) / b * sy;
     const double cxx = e * (e - 1) * pow(ax, e - 2) / (a * a), cyy = e * (e - 1) * pow(ay, e - 2) / (b * b);
-    d0 = ct * gpx - st * gpy;
-    d1 = st * gpx + ct * gpy;
-    hxx = ct * ct * cxx + st * st * cyy;
-    hxy = ct * st * cxx - st * ct * cyy;
-    hyy = st * st * cxx + ct * ct * cyy;
+    d0 = sc * (ct * gpx - st * gpy);
+    d1 = sc * (st * gpx + ct * gpy);
+    hxx = sc * (ct * ct * cxx + st * st * cyy);
+    hxy = sc * (ct * st * cxx - st * ct * cyy);
+    hyy = sc * (st * st * cxx + ct * ct * cyy);
 }
 
 // ---- scans over the first lanes of the wave -----------------------------------------------------------------------
@@ -296,8 +297,14 @@ __device__ inline double eval_values(const double* z, const double* rho, const M
         // stage weights of the rows  w1_k = s_k - 2,  w0_k = 1 - s_k + q_k  and the decay penalty
         if (lane < N) {
             const double r1 = rho[2 * lane], r2 = rho[2 * lane + 1];
-            const double sk = c.al1 * r1 + c.al2 * r2, qk = c.al1 * c.al2 * r1 * r2;
-            W.w0s[lane] = 1.0 - sk + qk; W.w1s[lane] = sk - 2.0;
+            if constexpr (UNI) {
+                // relative degree 1 (config-5 extension, oracle/od_mpc_rd1.py):  h(p_k+1) - (1 - alpha rho1_k) h(p_k);  the
+                // second decay variable of the layout is inert (it stays at its reference)
+                W.w0s[lane] = -(1.0 - c.al1 * r1); W.w1s[lane] = 1.0;
+            } else {
+                const double sk = c.al1 * r1 + c.al2 * r2, qk = c.al1 * c.al2 * r1 * r2;
+                W.w0s[lane] = 1.0 - sk + qk; W.w1s[lane] = sk - 2.0;
+            }
             part += c.ps1 * (r1 - c.rf1) * (r1 - c.rf1) + c.ps2 * (r2 - c.rf2) * (r2 - c.rf2);
         }
     }
@@ -345,11 +352,14 @@ __device__ inline double eval_values(const double* z, const double* rho, const M
             const int k = i / K, j = i - k * K;
             const double h2 = W.hk[(k + 2) * K + j], h1 = W.hk[(k + 1) * K + j], h0 = W.hk[k * K + j];
             if constexpr (OD) {
-                gi = h2 + W.w1s[k] * h1 + W.w0s[k] * h0;
+                gi = c.w2 * h2 + W.w1s[k] * h1 + W.w0s[k] * h0;      // w2 = 1 (rel-degree 2) or 0 (rel-degree 1)
                 if (derivs) {                                       // d row / d rho_i = a_i (h1 - h0) + a1 a2 rho_other h0
-                    const double aa = c.al1 * c.al2 * h0;
-                    W.A1[i] = c.al1 * (h1 - h0) + aa * rho[2 * k + 1];
-                    W.A2[i] = c.al2 * (h1 - h0) + aa * rho[2 * k];
+                    if constexpr (UNI) { W.A1[i] = c.al1 * h0; W.A2[i] = 0.0; }
+                    else {
+                        const double aa = c.al1 * c.al2 * h0;
+                        W.A1[i] = c.al1 * (h1 - h0) + aa * rho[2 * k + 1];
+                        W.A2[i] = c.al2 * (h1 - h0) + aa * rho[2 * k];
+                    }
                 }
             } else {
                 gi = c.w2 * h2 + c.w1 * h1 + c.w0 * h0;
@@ -425,8 +435,8 @@ __device__ __forceinline__ double stage_pass(const MpcMem& W, const MpcConst& c,
         double cr1 = 0.0, cr2 = 0.0;                                      // d2 row / d rho_i d p_kappa = cr_i dh0
         if constexpr (OD) {
             const int kk = t0 ? k : 0;
-            cr1 = -c.al1 + c.al1 * c.al2 * W.rho[2 * kk + 1];
-            cr2 = -c.al2 + c.al1 * c.al2 * W.rho[2 * kk];
+            cr1 = UNI ? c.al1 : -c.al1 + c.al1 * c.al2 * W.rho[2 * kk + 1];
+            cr2 = UNI ? 0.0 : -c.al2 + c.al1 * c.al2 * W.rho[2 * kk];
         }
         const int k1 = k + 1 < NP ? k + 1 : k, k2 = k + 2 < NP ? k + 2 : k;
         const double pk0 = W.pos[2 * k], pk1 = W.pos[2 * k + 1];
@@ -441,7 +451,7 @@ __device__ __forceinline__ double stage_pass(const MpcMem& W, const MpcConst& c,
             const double d0 = W.dh[2 * e], d1 = W.dh[2 * e + 1];
             const double a0 = W.dh[2 * e1], a1 = W.dh[2 * e1 + 1], g0 = W.dh[2 * e2], g1 = W.dh[2 * e2 + 1];
             double hxx = 2.0, hxy = 0.0, hyy = 2.0;                  // d2h/dp2 of a circle; superellipsoids recompute theirs
-            if (W.obs[7 * jo + 6] >= 0.5) {
+            if (W.obs[7 * jo + 6] != 0.0) {
                 double h_, g0_, g1_;
                 barrier_at(pk0, pk1, W.obs + 7 * jo, c, true, h_, g0_, g1_, hxx, hxy, hyy);
             }
@@ -465,8 +475,9 @@ __device__ __forceinline__ double stage_pass(const MpcMem& W, const MpcConst& c,
                 T1[0] += i0 * aa1; T1[1] += i0 * aa2;
                 T2[0] += b0 * aa1; T2[1] += b0 * aa2;
                 const double e01 = s0z * w0 * aa1 - l0z * cr1, e02 = s0z * w0 * aa2 - l0z * cr2;
-                const double e11 = s0z * w1k * aa1 - l0z * c.al1, e12 = s0z * w1k * aa2 - l0z * c.al2;
-                const double e21 = s0z * aa1, e22 = s0z * aa2;
+                // d2 row / d rho_i d p_(k+1) = d w1 / d rho_i dh1: a_i for the rel-degree-2 row, nothing for the rel-degree-1 one
+                const double e11 = s0z * w1k * aa1 - (UNI ? 0.0 : l0z * c.al1), e12 = s0z * w1k * aa2 - (UNI ? 0.0 : l0z * c.al2);
+                const double e21 = s0z * c.w2 * aa1, e22 = s0z * c.w2 * aa2;
                 Cm[0] += d0 * e01; Cm[1] += d0 * e02; Cm[2] += d1 * e01; Cm[3] += d1 * e02;
                 Cm[4] += a0 * e11; Cm[5] += a0 * e12; Cm[6] += a1 * e11; Cm[7] += a1 * e12;
                 Cm[8] += g0 * e21; Cm[9] += g0 * e22; Cm[10] += g1 * e21; Cm[11] += g1 * e22;
@@ -496,7 +507,7 @@ __device__ __forceinline__ double stage_pass(const MpcMem& W, const MpcConst& c,
             T0[0] += sf * 2.0 * c.ps1 * (r1 - c.rf1); T0[1] += sf * 2.0 * c.ps2 * (r2 - c.rf2);
             e_rho = fmax(fabs(T0[0]), fabs(T0[1]));
             double d11 = sf * 2.0 * c.ps1 + S11, d22 = sf * 2.0 * c.ps2 + S22;
-            const double d12 = S12 - c.al1 * c.al2 * lh;
+            const double d12 = UNI ? 0.0 : S12 - c.al1 * c.al2 * lh;
             // D^-1 is applied through the eigen-decomposition  D = ls vs vs' + lw vw vw'.  With a1 ~ a2 the two
             // columns of C and the rows of D are nearly parallel: D has one huge (sum sig a a') and one small (the
             // penalty) eigenvalue, and an explicit inverse loses the huge direction against the small one
@@ -509,7 +520,10 @@ __device__ __forceinline__ double stage_pass(const MpcMem& W, const MpcConst& c,
             // shift to positive definite: + max(0, eps - lambda_min) I, eps = 1e-8 max(1, |d11| + |d22|)
             const double sh = fmax(0.0, 1e-8 * fmax(1.0, fabs(d11) + fabs(d22)) - lw);
             ls += sh; lw += sh;
-            const double ils = 1.0 / ls, ilw = 1.0 / lw;
+            double ils = 1.0 / ls, ilw = 1.0 / lw;
+            if constexpr (UNI) {                                          // one live decay variable: the block is the scalar d11 > 0
+                vx = 1.0; vy = 0.0; ils = 1.0 / d11; ilw = 0.0;
+            }
             double cs[6], cw[6];
 #pragma unroll
             for (int r = 0; r < 6; ++r) {
@@ -832,6 +846,8 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
 
     const size_t obase = p.obs_shared ? 0 : (size_t)prob * K * 7;
     for (int e = lane; e < K * 7; e += 64) W.obs[e] = ld(obs, obase + e);
+    SC_SYNC();
+    ipm::normalise_obstacle_flags(W.obs, K, lane, 64);
     // set_initial_guess (mpc_cbf.py:369): u_prev at every stage, pulled strictly inside the box
     for (int i = lane; i < n; i += 64) {
         const double ub = (i & 1) ? c.wmaxu : c.amax;
@@ -844,6 +860,9 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     Prof pf;
     pf.start();
     double f = eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, true, pf, 12);
+    // steep (superellipsoid) barriers: IPOPT-style gradient-based row scaling from the initial guess, then a fresh evaluation
+    if (ipm::scale_steep_barriers(W.obs, K, W.dh, N + 2, lane, 64, [](double v) { return wmax(v); }, [] { SC_SYNC(); }))
+        f = eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, true, pf, 12);
     // objective scaling from |grad f|_inf at the start: with lam = 0 the column pass returns r_d = grad f
     for (int i = lane; i < m; i += 64) { W.sl[i] = fmax(W.g[i], 1e-2); W.lam[i] = 0.0; }
     SC_SYNC();
@@ -1081,10 +1100,13 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     }
 }
 
-// Compile-time horizon: capped at 256 VGPRs (two waves per SIMD; fits without spills).  Run-time sizes: no cap --
+// Compile-time horizon N <= 10: capped at 256 VGPRs (two waves per SIMD; fits without spills).  N = 20 keeps ~59 KiB of
+// LDS per problem, so at most two problems share a CU (half a wave per SIMD): there the cap bought nothing but 70-90
+// spilled VGPRs on the dependency chain, and the kernels take the whole register file instead.  Run-time sizes: no cap --
 // the run-time index arithmetic needs more registers and would spill heavily under it.
+#define SC_MPC_WAVES(NT) __attribute__((amdgpu_waves_per_eu((NT) <= 10 ? 2 : 1, (NT) <= 10 ? 2 : 1)))
 template <int NT, int KT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(64) SC_MPC_WAVES(NT)
 void mpccbf_kernel(const sc_mpccbf_params p, const long long B, const int K_rt, const void* __restrict__ X,
                    const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
                    void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out) {
@@ -1101,7 +1123,7 @@ void mpccbf_kernel_rt(const sc_mpccbf_params p, const long long B, const int K_r
 
 // kinematic Unicycle2D (robots/unicycle2D.py through position_control/mpc_cbf.py), K run-time
 template <int NT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(64) SC_MPC_WAVES(NT)
 void mpccbf_uni_kernel(const sc_mpccbf_params p, const long long B, const int K_rt, const void* __restrict__ X,
                        const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
                        void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out) {
@@ -1120,7 +1142,7 @@ void mpccbf_uni_kernel_rt(const sc_mpccbf_params p, const long long B, const int
 // VGPRs (about 60 spilled registers, still 23 % faster at large batches: 6 problems per CU instead of 4); run-time
 // horizon: no cap.
 template <int NT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(64) SC_MPC_WAVES(NT)
 void odmpccbf_kernel(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const void* __restrict__ X,
                      const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
                      void* __restrict__ u_out, void* __restrict__ rho_out, int* __restrict__ status_out,
@@ -1135,6 +1157,25 @@ void odmpccbf_kernel_rt(const sc_mpccbf_params p, const OdExtra od, const long l
                         int* __restrict__ iters_out, void* __restrict__ z_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     mpccbf_body<0, 0, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
+}
+
+// optimal decay on the kinematic Unicycle2D: BASELINE config 5's extension (oracle/od_mpc_rd1.py)
+template <int NT>
+__global__ __launch_bounds__(64) SC_MPC_WAVES(NT)
+void odmpccbf_uni_kernel(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const void* __restrict__ X,
+                         const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
+                         void* __restrict__ u_out, void* __restrict__ rho_out, int* __restrict__ status_out,
+                         int* __restrict__ iters_out, void* __restrict__ z_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    mpccbf_body<NT, 0, true, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
+}
+__global__ __launch_bounds__(64)
+void odmpccbf_uni_kernel_rt(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const void* __restrict__ X,
+                            const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
+                            void* __restrict__ u_out, void* __restrict__ rho_out, int* __restrict__ status_out,
+                            int* __restrict__ iters_out, void* __restrict__ z_out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    mpccbf_body<0, 0, true, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
 }
 
 size_t mpccbf_lds_bytes(int N, int K) { return mpc_lds_doubles(N, K) * sizeof(double); }
@@ -1156,6 +1197,11 @@ static hipError_t odmpc_launch_t(const sc_odmpccbf_params& q, long long B, int K
                            goal, obs, u_out, rho_out, status, iters, z_out);
         return hipGetLastError();
     };
+    if (p.model_id == SC_MODEL_UNICYCLE2D) {
+        if (p.horizon == 10) return launch(odmpccbf_uni_kernel<10>);
+        if (p.horizon == 20) return launch(odmpccbf_uni_kernel<20>);  // BASELINE config 5's horizon
+        return launch(odmpccbf_uni_kernel_rt);
+    }
     if (p.horizon == 10) return launch(odmpccbf_kernel<10>);
     if (p.horizon == 20) return launch(odmpccbf_kernel<20>);         // BASELINE config 5's horizon
     return launch(odmpccbf_kernel_rt);

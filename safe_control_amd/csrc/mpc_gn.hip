@@ -368,6 +368,8 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
     for (int e = lane; e < K * 7; e += 64) W.obs[e] = ld(obs, obase + e);
     for (int e = lane; e < NX * n; e += 64) W.Ph[e] = 0.0;                  // Phi_0 = 0
     SC_SYNC();
+    if (!c.circles_only) ipm::normalise_obstacle_flags(W.obs, K, lane, 64);
+    SC_SYNC();
     for (int i = lane; i < n; i += 64) {                                   // set_initial_guess: u_prev, strictly inside the box
         const double lo = W.cq[8 + (i & 1)], hi = W.cq[10 + (i & 1)], pad = 0.005 * (hi - lo);
         W.z[i] = fmin(fmax(W.up[i & 1], lo + pad), hi - pad);
@@ -392,6 +394,10 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
     };
 
     double f = gn_eval<MODEL>(W.z, W, d, c, q, lane, true);
+    // steep (superellipsoid) barriers: IPOPT-style gradient-based row scaling from the initial guess, then a fresh evaluation
+    if (!c.circles_only &&
+        ipm::scale_steep_barriers(W.obs, K, W.dh, 3 * N, lane, 64, [](double v) { return gmax_(v); }, [] { SC_SYNC(); }))
+        f = gn_eval<MODEL>(W.z, W, d, c, q, lane, true);
     grad_f(1.0);
     double gmx = 0.0;
     for (int i = lane; i < n; i += 64) gmx = fmax(gmx, fabs(W.gs[i]));

@@ -39,9 +39,11 @@ __device__ __forceinline__ double wmax(double v) { return wred(v, [](double a, d
 
 // h, dh/dp, d2h/dp2 at a planar point: circle (every model) or superellipsoid (single_integrator2D.py:162-181: fabs,
 // a, b >= 1e-3, e >= 2); oracle/mpc_cbf.py: barrier
+// LDS obstacle rows of the kernels that have the superellipsoid branch are normalised on load (normalise_obstacle_flags):
+// slot 6 is 0 for a circle and the ROW SCALE (> 0, 1 until scale_steep_barriers has run) for a superellipsoid.
 __device__ inline void ipm_barrier(double px_, double py_, const double* o, double Rrob, double beta, bool circles_only, bool derivs,
                                    double& h, double& d0, double& d1, double& hxx, double& hxy, double& hyy) {
-    if (circles_only || o[6] < 0.5) {
+    if (circles_only || o[6] == 0.0) {
         const double d = Rrob + o[2];
         const double ex = px_ - o[0], ey = py_ - o[1];
         h = (ex * ex + ey * ey) - beta * d * d;
@@ -55,16 +57,47 @@ __device__ inline void ipm_barrier(double px_, double py_, const double* o, doub
     const double dx = px_ - o[0], dy = py_ - o[1];
     const double px = ct * dx + st * dy, py = -st * dx + ct * dy;
     const double ax = fabs(px) / a, ay = fabs(py) / b;
-    h = pow(ax, e) + pow(ay, e) - 1.0;
+    const double sc = o[6];
+    h = sc * (pow(ax, e) + pow(ay, e) - 1.0);
     if (!derivs) { d0 = d1 = hxx = hxy = hyy = 0.0; return; }
     const double sx = px > 0 ? 1.0 : (px < 0 ? -1.0 : 0.0), sy = py > 0 ? 1.0 : (py < 0 ? -1.0 : 0.0);
     const double gpx = e * pow(ax, e - 1) / a * sx, gpy = e * pow(ay, e - 1) / b * sy;
     const double cxx = e * (e - 1) * pow(ax, e - 2) / (a * a), cyy = e * (e - 1) * pow(ay, e - 2) / (b * b);
-    d0 = ct * gpx - st * gpy;
-    d1 = st * gpx + ct * gpy;
-    hxx = ct * ct * cxx + st * st * cyy;
-    hxy = ct * st * cxx - st * ct * cyy;
-    hyy = st * st * cxx + ct * ct * cyy;
+    d0 = sc * (ct * gpx - st * gpy);
+    d1 = sc * (st * gpx + ct * gpy);
+    hxx = sc * (ct * ct * cxx + st * st * cyy);
+    hxy = sc * (ct * st * cxx - st * ct * cyy);
+    hyy = sc * (st * st * cxx + ct * ct * cyy);
+}
+
+__device__ inline void normalise_obstacle_flags(double* obs, int K, int tid, int nthreads) {
+    for (int j = tid; j < K; j += nthreads) obs[7 * j + 6] = obs[7 * j + 6] < 0.5 ? 0.0 : 1.0;
+}
+
+// Gradient-based scaling of the steep (superellipsoid) barriers -- oracle/mpc_cbf.py: barrier_scales, IPOPT's default NLP
+// scaling (nlp_scaling_max_gradient = 100) per obstacle:  h_j <- sc_j h_j,  sc_j = min(1, 100 / max_pts |grad h_j|_inf) over
+// the barrier points of the initial guess.  dh holds (d0, d1) of entry e = pt * K + j from the first evaluation (scale 1).
+// Returns true when some scale is below 1: the caller re-evaluates.  block_max: block-wide maximum (the same value in
+// every thread); sync: block barrier.
+template <typename MaxFn, typename SyncFn>
+__device__ inline bool scale_steep_barriers(double* obs, int K, const double* dh, int npts, int tid, int nthreads, MaxFn block_max,
+                                            SyncFn sync) {
+    bool any = false;
+    for (int j = 0; j < K; ++j) {
+        if (obs[7 * j + 6] == 0.0) continue;                              // block-uniform
+        double gm = 0.0;
+        for (int pt = tid; pt < npts; pt += nthreads) {
+            const int e = pt * K + j;
+            gm = fmax(gm, fmax(fabs(dh[2 * e]), fabs(dh[2 * e + 1])));
+        }
+        gm = block_max(gm);
+        const double sc = fmax(fmin(1.0, 100.0 / fmax(gm, 1e-300)), 1e-30);
+        any = any || sc < 1.0;
+        sync();
+        if (tid == 0) obs[7 * j + 6] = sc;
+    }
+    sync();
+    return any;
 }
 
 

@@ -347,6 +347,8 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
     const size_t obase = p.obs_shared ? 0 : (size_t)prob * K * 7;
     for (int e = lane; e < K * 7; e += TH) W.obs[e] = ld(obs, obase + e);
     SC_SYNC();
+    if (!c.circles_only) ipm::normalise_obstacle_flags(W.obs, K, lane, TH);
+    SC_SYNC();
     // set_initial_guess (mpc_cbf.py:369): u_prev at every stage, pulled strictly inside the box
     for (int i = lane; i < n; i += TH) {
         const double lo = W.cq[16 + i % nu], hi = W.cq[20 + i % nu], pad = 0.005 * (hi - lo);
@@ -355,6 +357,10 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
     SC_SYNC();
 
     double f = lin_eval<TH>(W.z, W, d, c, lane, true, R);
+    // steep (superellipsoid) barriers: IPOPT-style gradient-based row scaling from the initial guess, then a fresh evaluation
+    if (!c.circles_only &&
+        ipm::scale_steep_barriers(W.obs, K, W.dh, 2 * N, lane, TH, [&](double v) { return lmax_<TH>(v, R); }, [] { SC_SYNC(); }))
+        f = lin_eval<TH>(W.z, W, d, c, lane, true, R);
     lin_grad<TH>(W, d, c, lane, 1.0);
     if constexpr (LEAN) {
         // the cost is quadratic: grad f = Hc z + c with c fixed for the solve (one adjoint pass, here)

@@ -19,11 +19,17 @@ from ..robots.spec import complete_robot_spec
 from .mpc_cbf import default_mpc_weights, make_params, pad_obstacles
 
 
-def default_od_mpc_param(model):
-    """optimal_decay_mpc_cbf.py:54-91."""
+def default_od_mpc_param(model, extension=False):
+    """optimal_decay_mpc_cbf.py:54-91.  ``extension``: BASELINE config 5 asks for optimal decay on models the reference
+    class rejects (Unicycle2D, :19-20) or serves with the plain row (Quad3D, :284-287); the build-defined semantics are
+    the rel-degree-1 row of the reference's optimal-decay CBF-QP, d_h + alpha omega1 h_k (optimal_decay_cbf_qp.py:96-101),
+    with MPCCBF's gain for the model (mpc_cbf.py:52-53) -- see oracle/od_mpc_rd1.py."""
     if model == "DynamicUnicycle2D":
         return {"alpha1": 0.01, "alpha2": 0.01, "omega1": 1.0, "p_sb1": 10.0, "omega2": 1.0, "p_sb2": 10.0}
-    raise NotImplementedError(f"optimal-decay MPC-CBF on the batched engine supports DynamicUnicycle2D, not {model}")
+    if model == "Unicycle2D" and extension:
+        return {"alpha": 0.05, "omega1": 1.0, "p_sb1": 10.0, "omega2": 1.0, "p_sb2": 10.0}
+    raise NotImplementedError(f"optimal-decay MPC-CBF on the batched engine supports DynamicUnicycle2D "
+                              f"(and Unicycle2D with extension=True), not {model}")
 
 
 def make_od_mpc_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6,
@@ -98,17 +104,22 @@ class BatchedOptimalDecayMPCCBF:
     """Optimal-decay MPC-CBF for B agents per launch on device tensors.
 
     ``solve(X[B,4], u_prev[B,2], goal[B,2], obs[B,K,7] | obs[K,7])`` -> ``u[B,2]``, ``rho[B,2N]`` (omega1_k, omega2_k
-    per stage), ``status[B] int32``, ``iters[B] int32`` (and ``z[B,2N]`` if asked).
+    per stage), ``status[B] int32``, ``iters[B] int32`` (and ``z[B,2N]`` if asked).  ``extension=True`` also serves
+    Unicycle2D (states padded to 4 columns like everywhere in the batched engine; omega2_k is inert and stays at its
+    reference) -- BASELINE config 5, no reference counterpart.
     """
 
-    def __init__(self, robot_spec, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None, tol=1e-6, max_iter=100):
+    def __init__(self, robot_spec, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None, tol=1e-6, max_iter=100,
+                 extension=False):
         self.robot_spec = complete_robot_spec(robot_spec)
         model = self.robot_spec["model"]
         self.dt = float(dt)
         self.io_dtype = {"f32": _lib.DTYPE_F32, "f64": _lib.DTYPE_F64}[io_dtype]
         self.horizon = int(horizon if horizon is not None else self.robot_spec.get("mpc_horizon", 10))
         self.Q, self.R = default_mpc_weights(model)
-        self.cbf_param = cbf_param or default_od_mpc_param(model)
+        self.extension = bool(extension)
+        self.cbf_param = cbf_param or default_od_mpc_param(model, extension=self.extension)
+        self.nx = 3 if model == "Unicycle2D" else 4
         self.tol, self.max_iter = tol, max_iter
         self._lib = _lib.load()
 

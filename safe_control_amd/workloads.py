@@ -114,3 +114,23 @@ def linear_mpc_batch(model="Quad3D", B=4096, K=8, seed=0, radius=0.25):
     obs[:, :, 1] = X[:, None, 1] + rho * np.sin(phi)
     obs[:, :, 2] = r
     return X, goal, obs
+
+
+def superellipsoid_obstacles(pos, K=8, seed=0, radius=0.25, exponents=(4.0, 6.0), rho_max=4.0):
+    """BASELINE config 5's obstacles: K superellipsoid rows ``[ox, oy, a, b, e, theta, 1]`` per agent (the 7-wide layout of
+    robots/dynamic_unicycle2D.py:148-183 / :204-220), semi-axes U(0.2, 0.8), exponent drawn from ``exponents``, random
+    orientation, centred at a distance that keeps the inflated shape clear of the agent at the start (h > 0)."""
+    rng = np.random.default_rng(seed)
+    pos = np.asarray(pos, dtype=np.float64)
+    B = pos.shape[0]
+    a = rng.uniform(0.2, 0.8, (B, K)); b = rng.uniform(0.2, 0.8, (B, K))
+    e = rng.choice(np.asarray(exponents, dtype=np.float64), (B, K))
+    th = rng.uniform(-np.pi, np.pi, (B, K))
+    clear = np.hypot(a + radius, b + radius) + 0.05                       # the corner of the bounding box of the inflated shape
+    rho = clear + rng.uniform(0.0, 1.0, (B, K)) * np.maximum(rho_max - clear, 0.1)
+    phi = rng.uniform(-np.pi, np.pi, (B, K))
+    obs = np.zeros((B, K, 7))
+    obs[..., 0] = pos[:, None, 0] + rho * np.cos(phi)
+    obs[..., 1] = pos[:, None, 1] + rho * np.sin(phi)
+    obs[..., 2], obs[..., 3], obs[..., 4], obs[..., 5], obs[..., 6] = a, b, e, th, 1.0
+    return obs
