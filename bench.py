@@ -48,9 +48,11 @@ def parse():
                     help="cbf_qp = BASELINE configs[1] (default, the headline metric); mpc_cbf = configs[2]; "
                          "kb_c3bf = configs[3]: 16384 KinematicBicycle2D C3BF agents in total (strong scaling), each "
                          "taking its 16 nearest other agents as moving obstacles after an all-gather of the states; "
-                         "hetero_fleet = configs[4] as far as the reference defines it: a 65536-agent fleet, half Unicycle2D "
-                         "and half Quad3D, MPC-CBF with horizon 20 and 8 obstacles each, sharded over the ranks (strong "
-                         "scaling), the two model kernels on two HIP streams")
+                         "hetero_fleet = configs[4] (extension, SURVEY 8d): a 65536-agent fleet, half Unicycle2D and half "
+                         "Quad3D, optimal-decay MPC-CBF with horizon 20 and 8 superellipsoid obstacles each, sharded over "
+                         "the ranks (strong scaling), the two model kernels on two HIP streams")
+    ap.add_argument("--plain-fleet", action="store_true",
+                    help="hetero_fleet: plain MPCCBF of both models on circular obstacles (round 1's variant)")
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--no-mpc", action="store_true", help="skip the short MPC-CBF leg of the default run")
     return ap.parse_args()
@@ -519,12 +521,14 @@ def main():
 
 
 def hetero_fleet_workload(a, dev, ws, rank, backend):
-    """BASELINE configs[4] (extension): a heterogeneous fleet of 65536 agents (or --agents per GPU x ranks when given),
-    half kinematic Unicycle2D and half Quad3D, every agent solving an MPC-CBF with horizon 20 and 8 circular obstacles.
-    The reference's OptimalDecayMPCCBF accepts neither model (optimal_decay_mpc_cbf.py:19-20) and neither model's barrier
-    has a superellipsoid branch (unicycle2D.py:127-145, quad3D.py:283-291), so this is the plain MPCCBF of both models on
-    circles.  Agents are independent: contiguous shards per rank, no collective; the two model kernels run on two HIP
-    streams of the same GPU."""
+    """BASELINE configs[4], built as SURVEY 8d defines it -- a labelled EXTENSION (no runnable reference): a heterogeneous
+    fleet of 65536 agents (or --agents per GPU x ranks when given), half kinematic Unicycle2D and half Quad3D, every
+    agent solving an OPTIMAL-DECAY MPC-CBF with horizon 20 against 8 SUPERELLIPSOID obstacles (7-wide rows).  The
+    reference's OptimalDecayMPCCBF accepts neither model with decay variables (optimal_decay_mpc_cbf.py:19-20,284-287), so
+    the semantics are those of oracle/od_mpc_rd1.py: one decay variable per stage scaling the DT-CBF gain, penalty
+    p_sb1 (rho - omega1)^2, r-term R u^2; parity is against that oracle only.  --plain-fleet runs round 1's variant (plain
+    MPCCBF of both models on circles).  Agents are independent: contiguous shards per rank, no collective; the two model
+    kernels run on two HIP streams of the same GPU."""
     import torch
     import torch.distributed as dist
     import safe_control_amd as sca
@@ -533,10 +537,19 @@ def hetero_fleet_workload(a, dev, ws, rank, backend):
     N, K = 20, 8
     lo, hi = sharding.agent_range(n_total // 2, ws, rank)             # the same range of each half
     Bl = hi - lo
-    uni = sca.BatchedMPCCBF({"model": "Unicycle2D", "v_max": 1.0, "w_max": 0.5, "radius": 0.25}, io_dtype="f32", horizon=N)
-    quad = sca.BatchedLinearMPCCBF({"model": "Quad3D"}, io_dtype="f32", horizon=N)
+    uspec = {"model": "Unicycle2D", "v_max": 1.0, "w_max": 0.5, "radius": 0.25}
+    od = not a.plain_fleet
     Xu, gu, _, ou = W.du_cbfqp_batch(n_total // 2, K, seed=0)
     Xq, gq, oq = W.linear_mpc_batch("Quad3D", n_total // 2, K, seed=1)
+    if od:
+        uni = sca.BatchedOptimalDecayMPCCBF(uspec, io_dtype="f32", horizon=N, extension=True)
+        quad = sca.BatchedOptimalDecayLinearMPCCBF({"model": "Quad3D"}, io_dtype="f32", horizon=N)
+        Xu[:, 3] = 0.0
+        ou = W.superellipsoid_obstacles(Xu[:, :2], K, seed=1000)
+        oq = W.superellipsoid_obstacles(Xq[:, :2], K, seed=1001)
+    else:
+        uni = sca.BatchedMPCCBF(uspec, io_dtype="f32", horizon=N)
+        quad = sca.BatchedLinearMPCCBF({"model": "Quad3D"}, io_dtype="f32", horizon=N)
     t = lambda arr: torch.tensor(arr[lo:hi], dtype=torch.float32, device=dev)
     tXu, tgu, tou = t(Xu), t(gu), t(ou)
     tXq, tgq, toq = t(Xq), t(gq), t(oq)
@@ -567,22 +580,28 @@ def hetero_fleet_workload(a, dev, ws, rank, backend):
         dist.barrier()
     elapsed = sharding.max_over_ranks(t1 - t0, device=dev if backend == "nccl" else None)
     if rank == 0:
-        su, sq = res["u"][1], res["q"][1]
+        su, sq = (res["u"][2], res["q"][2]) if od else (res["u"][1], res["q"][1])
+        iu, iq = (res["u"][3], res["q"][3]) if od else (res["u"][2], res["q"][2])
         nbytes = ((16 + 8 + 8 + 7 * K * 4 + 8 + 4 + 4) + (48 + 16 + 12 + 7 * K * 4 + 16 + 4 + 4)) * (n_total // 2)
         print(json.dumps({"metric": "QP solves/sec (batched agents)", "value": n_total * steps / elapsed, "unit": "solves/s",
                           "n_gpus": ws, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * elapsed / steps,
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                          "config": {"workload": f"{n_total}-agent heterogeneous fleet (Unicycle2D + Quad3D), MPC-CBF N=20, "
-                                                 "8 circular obstacles (BASELINE configs[4] as far as the reference defines it)",
+                          "config": {"workload": (f"{n_total}-agent heterogeneous fleet (Unicycle2D + Quad3D), optimal-decay MPC-CBF "
+                                                  "N=20, 8 superellipsoid obstacles (BASELINE configs[4]; extension, oracle/od_mpc_rd1.py)")
+                                                 if od else
+                                                 (f"{n_total}-agent heterogeneous fleet (Unicycle2D + Quad3D), MPC-CBF N=20, "
+                                                  "8 circular obstacles (plain MPCCBF of both models)"),
+                                     "extension": bool(od),
                                      "agents_total": n_total, "horizon": N, "obstacles": K, "storage": "f32",
                                      "sharding": f"agents x{ws}, no collective; two model kernels on two streams",
                                      "unicycle_optimal_fraction": float((su == 0).double().mean().item()),
                                      "quad3d_optimal_fraction": float((sq == 0).double().mean().item()),
-                                     "unicycle_mean_iterations": float(res["u"][2].double().mean().item()),
-                                     "quad3d_mean_iterations": float(res["q"][2].double().mean().item())},
+                                     "unicycle_mean_iterations": float(iu.double().mean().item()),
+                                     "quad3d_mean_iterations": float(iq.double().mean().item())},
                           "roofline": {"bound": "hbm", "achieved": nbytes * steps / elapsed / 1e9, "peak": HBM_PEAK_GBS * ws,
                                        "unit": "GB/s", "frac": nbytes * steps / elapsed / 1e9 / (HBM_PEAK_GBS * ws), "traffic": None,
-                                       "kernel": "mpccbf_uni_kernel_rt + mpclin_kernel<12,4,0,0,big>",
+                                       "kernel": ("odmpccbf_kernel<20,UNI> + mpclin_kernel<12,4,0,0,big,od>" if od else
+                                                  "mpccbf_uni_kernel<20> + mpclin_kernel<12,4,0,0,big>"),
                                        "note": "interior-point solves: VALU / latency bound, HBM bytes are negligible"},
                           "cpu_baseline": None}), flush=True)
 

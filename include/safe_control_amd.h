@@ -199,12 +199,17 @@ typedef struct sc_mpclin_params {
     int32_t horizon;         /* robot_spec['mpc_horizon'], default 10; nu * horizon <= 128 and the LDS fit (Quad3D: N <= 20) */
     int32_t max_iter, obs_shared, acceptable_iter;   /* as sc_mpccbf_params                              */
     int32_t circles_only;    /* 1: the model's barrier has no superellipsoid branch (Quad3D)               */
-    int32_t reserved;
+    int32_t optimal_decay;   /* 0: MPCCBF.  1: EXTENSION (BASELINE config 5, no reference counterpart; Quad3D only): one
+                                decay variable rho_k per stage, rows h(step) - (1 - alpha rho_k) h(x_k) >= 0 -- the
+                                rel-degree-1 form of optimal_decay_cbf_qp.py:96-101,113-125 -- cost + od_p_sb (rho_k -
+                                od_omega_ref)^2, r-term R u^2 (optimal_decay_mpc_cbf.py:178-184); oracle/od_mpc_rd1.py.
+                                The model blob must be built with the same flag (its cost Hessian differs).   */
     double  alpha;           /* DT-CBF gain: SI 0.05 (mpc_cbf.py:48-50), Quad3D 0.15 (:77-78)              */
     double  robot_radius, beta, tol, acceptable_tol, mu_init, mu_min;   /* as sc_mpccbf_params            */
     double  Q[12];           /* diagonal state weights (mpc_cbf.py:19-20, :37-38)                          */
     double  R[4];            /* input-rate weights (mpc_cbf.py:21, :39)                                    */
     double  u_lo[4], u_hi[4];
+    double  od_omega_ref, od_p_sb;   /* optimal_decay = 1: reference 1.0 and penalty 10.0 (optimal_decay_mpc_cbf.py:88-89) */
 } sc_mpclin_params;
 
 size_t sc_mpclin_model_doubles(int32_t nx, int32_t nu, int32_t horizon);
@@ -216,6 +221,10 @@ int sc_mpclin_solve_batch(const sc_mpclin_params* params, const double* model, i
 int sc_mpclin_solve_batch_host(const sc_mpclin_params* params, const double* model, int64_t B, int32_t K,
                                const void* X, const void* u_prev, const void* goal, const void* obs,
                                void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, int device);
+/* optimal_decay = 1 (see sc_mpclin_params): as sc_mpclin_solve_batch plus rho_out [B, horizon] (or NULL), the decay variables. */
+int sc_odmpclin_solve_batch(const sc_mpclin_params* params, const double* model, int64_t B, int32_t K,
+                            const void* X, const void* u_prev, const void* goal, const void* obs,
+                            void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
 
 /* ---- MPC-CBF for DoubleIntegrator2D and Quad2D -----------------------------------------------
  * MPCCBF (position_control/mpc_cbf.py:7-402) for the planar models whose rel-deg-2 DT-CBF steps the state with the robot's

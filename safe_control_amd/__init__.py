@@ -10,7 +10,7 @@ from ._lib import HipLibraryError, load as load_library  # noqa: F401
 from .position_control.cbf_qp import CBFQP, BatchedCBFQP  # noqa: F401
 from .position_control.manipulator_cbf_qp import ManipulatorCBFQP, BatchedManipulatorCBFQP, BatchedManipulatorTracking  # noqa: F401
 from .position_control.mpc_cbf import MPCCBF, BatchedMPCCBF  # noqa: F401
-from .position_control.mpc_cbf_linear import LinearMPCCBF, BatchedLinearMPCCBF  # noqa: F401
+from .position_control.mpc_cbf_linear import LinearMPCCBF, BatchedLinearMPCCBF, BatchedOptimalDecayLinearMPCCBF  # noqa: F401
 from .position_control.mpc_cbf_gn import GnMPCCBF, BatchedGnMPCCBF  # noqa: F401
 from .position_control.optimal_decay_cbf_qp import OptimalDecayCBFQP, BatchedOptimalDecayCBFQP  # noqa: F401
 from .position_control.optimal_decay_mpc_cbf import OptimalDecayMPCCBF, BatchedOptimalDecayMPCCBF  # noqa: F401

@@ -74,10 +74,11 @@ class MpcLinParams(C.Structure):
     _fields_ = [
         ("io_dtype", C.c_int32), ("nx", C.c_int32), ("nu", C.c_int32), ("ng", C.c_int32), ("horizon", C.c_int32),
         ("max_iter", C.c_int32), ("obs_shared", C.c_int32), ("acceptable_iter", C.c_int32), ("circles_only", C.c_int32),
-        ("reserved", C.c_int32),
+        ("optimal_decay", C.c_int32),
         ("alpha", C.c_double), ("robot_radius", C.c_double), ("beta", C.c_double), ("tol", C.c_double),
         ("acceptable_tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double),
         ("Q", C.c_double * 12), ("R", C.c_double * 4), ("u_lo", C.c_double * 4), ("u_hi", C.c_double * 4),
+        ("od_omega_ref", C.c_double), ("od_p_sb", C.c_double),
     ]
 
 
@@ -149,6 +150,7 @@ SYMBOLS = {
     "sc_mpclin_model_doubles": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sc_mpclin_build_model": (C.c_int, [C.POINTER(MpcLinParams)] + [C.c_void_p] * 5),
     "sc_mpclin_solve_batch": (C.c_int, [C.POINTER(MpcLinParams), C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 9),
+    "sc_odmpclin_solve_batch": (C.c_int, [C.POINTER(MpcLinParams), C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_mpclin_solve_batch_host": (C.c_int, [C.POINTER(MpcLinParams), C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 8 + [C.c_int]),
     "sc_manip_tracking_rollout_batch": (C.c_int, [C.POINTER(ManipTrackingParams), C.c_int64, C.c_int32] + [C.c_void_p] * 13),
     "sc_manip_cbfqp_solve_batch": (C.c_int, [C.POINTER(ManipCbfQpParams), C.c_int64, C.c_int32] + [C.c_void_p] * 8),

@@ -40,12 +40,12 @@ hipError_t tracking_launch(const sc_tracking_params& p, long long B, int M, void
 hipError_t manip_cbfqp_launch(const sc_manip_cbfqp_params& p, long long B, int K, const void* X, const void* u_ref,
                               const void* obs, const int* n_obs, void* u_out, int* status, void* h_out, hipStream_t stream);
 
-size_t mpclin_lds_bytes(int N, int K, int nx, int nu);
+size_t mpclin_lds_bytes(int N, int K, int nx, int nu, bool od = false);
 size_t mpclin_model_doubles(int nx, int nu, int N);
 bool mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const double* Be, const double* As, const double* Bs,
                         double* out);
 hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long long B, int K, const void* X, const void* u_prev,
-                         const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
+                         const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out, void* rho_out,
                          hipStream_t stream);
 
 size_t mpcgn_lds_bytes(int model_id, int N, int K, int circles_only);
@@ -165,7 +165,11 @@ static int check_mpclin(const sc_mpclin_params* p, const double* model, int64_t 
     if (K < 1) return fail(SC_ERR_INVALID_ARGUMENT, "K < 1 (pad with [1000,1000,0,...] rows like update_tvp)");
     if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
         return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
-    if (mpclin_lds_bytes(p->horizon, K, p->nx, p->nu) > 160 * 1024)
+    if (p->optimal_decay != 0 && p->optimal_decay != 1) return fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay must be 0 or 1");
+    if (p->optimal_decay && !(p->nx == 12 && p->nu == 4))
+        return fail(SC_ERR_UNSUPPORTED, "the optimal-decay extension of this kernel is built for Quad3D (nx = 12, nu = 4)");
+    if (p->optimal_decay && !(p->od_p_sb > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "od_p_sb must be > 0");
+    if (mpclin_lds_bytes(p->horizon, K, p->nx, p->nu, p->optimal_decay != 0) > 160 * 1024)
         return fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
     if (!(p->tol > 0) || !(p->acceptable_tol >= p->tol) || p->max_iter < 1 || !(p->mu_init > 0) || !(p->mu_min > 0))
         return fail(SC_ERR_INVALID_ARGUMENT, "tol, mu_init, mu_min must be > 0 and max_iter >= 1");
@@ -295,9 +299,24 @@ int sc_mpclin_solve_batch(const sc_mpclin_params* params, const double* model, i
     int rc = sc::check_mpclin(params, model, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
+    if (params->optimal_decay) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay = 1: call sc_odmpclin_solve_batch");
     hipError_t e = sc::mpclin_launch(*params, model, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out,
-                                     z_out, (hipStream_t)stream);
+                                     z_out, nullptr, (hipStream_t)stream);
     if (e != hipSuccess) return sc::fail_hip(e, "mpclin kernel launch");
+    return SC_OK;
+}
+
+int sc_odmpclin_solve_batch(const sc_mpclin_params* params, const double* model, int64_t B, int32_t K, const void* X,
+                            const void* u_prev, const void* goal, const void* obs, void* u_out, void* rho_out,
+                            int32_t* status_out, int32_t* iters_out, void* z_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    int rc = sc::check_mpclin(params, model, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (!params->optimal_decay) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay = 0: call sc_mpclin_solve_batch");
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::mpclin_launch(*params, model, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out,
+                                     z_out, rho_out, (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "mpclin (optimal decay) kernel launch");
     return SC_OK;
 }
 
@@ -330,7 +349,7 @@ int sc_mpclin_solve_batch_host(const sc_mpclin_params* params, const double* mod
         if ((e = hipMemcpyAsync(d + oG, goal, nG, hipMemcpyHostToDevice, s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
         e = sc::mpclin_launch(*params, (const double*)(d + oM), (long long)B, (int)K, d + oX, d + oU, d + oG, d + oO, d + oUo,
-                              (int*)(d + oS), iters_out ? (int*)(d + oI) : nullptr, z_out ? d + oZ : nullptr, s);
+                              (int*)(d + oS), iters_out ? (int*)(d + oI) : nullptr, z_out ? d + oZ : nullptr, nullptr, s);
         if (e != hipSuccess) break;
         if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;

@@ -66,6 +66,9 @@ struct LinMem {
     double *Phi, *T, *M, *L, *G;                         // 16 N | 4N n | n n | n (n + 1) | 4N n
     double *red;                                         // 8 reduction slots + the Cholesky status word (multi-wave layout)
     double *Hc, *clin;                                   // lean kernels: n n copy of the cost Hessian, n constant part of grad f
+    // optimal decay (config-5 extension, oracle/od_mpc_rd1.py): one decay variable per stage
+    double *rho, *rhot, *drho, *rhob, *w0k;              // N each: current, trial, step, best iterate; stage weight -(1 - alpha rho_k)
+    double *Cv, *dinv, *rr, *rdr;                        // 4N | N | N | N: point-space coupling C_k, 1 / D_k, right-hand side, r_d of rho_k
 };
 
 struct LinDims { int N, K, nx, nu, n, m, mc; };
@@ -79,16 +82,16 @@ struct LinDims { int N, K, nx, nu, n, m, mc; };
 // (Quad3D at N = 20: n = 80, 250 KB): G is read from global memory, the LDS Cholesky factor takes the dead T region (widened to
 // n (n + 1) where 4N n falls short), and the block is FOUR waves per problem (see mpclin_kernel).
 enum { LIN_STD = 0, LIN_LEAN = 1, LIN_BIG = 2 };
-__host__ __device__ inline size_t mpclin_lds_doubles(int N, int K, int nx, int nu, int mode = LIN_STD) {
+__host__ __device__ inline size_t mpclin_lds_doubles(int N, int K, int nx, int nu, int mode = LIN_STD, bool od = false) {
     const bool lean = mode == LIN_LEAN;
     const size_t n = (size_t)N * nu, m = (size_t)N * K + 2 * n;
-    return (size_t)nx * nx + (size_t)nx * nu + 2 * nx + 2 * nu + nx + nu + 2 * nx + 24 + 10 + 7 * n + (size_t)(N + 1) * nx + 12 * N +
+    return (od ? 12 * (size_t)N : 0) + (size_t)nx * nx + (size_t)nx * nu + 2 * nx + 2 * nu + nx + nu + 2 * nx + 24 + 10 + 7 * n + (size_t)(N + 1) * nx + 12 * N +
            7 * (size_t)K + 12 * (size_t)N * K + 6 * m + 16 * N + 4 * (size_t)N * n + n * n +
            (mode == LIN_BIG ? (n * (n + 1) > 4 * (size_t)N * n ? n * (n + 1) - 4 * (size_t)N * n : 0)
                             : 4 * (size_t)N * n + (lean ? n * n + n : n * (n + 1)));
 }
 
-__device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode) {
+__device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode, bool od = false) {
     const bool lean = mode == LIN_LEAN;
     LinMem W;
     auto take = [&](size_t c) { double* r = b; b += c; return r; };
@@ -102,21 +105,29 @@ __device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode) {
     const size_t tsz = (size_t)4 * N * n, lsz = (size_t)n * (n + 1);       // big: L (row stride n | 1) takes the dead T, widened to hold it
     W.Phi = take(16 * N); W.T = take(mode == LIN_BIG && lsz > tsz ? lsz : tsz); W.M = take((size_t)n * n);
     W.Hc = W.clin = nullptr;
-    if (mode == LIN_BIG) { W.G = nullptr; W.L = W.T; return W; }
+    W.rho = W.rhot = W.drho = W.rhob = W.w0k = W.Cv = W.dinv = W.rr = W.rdr = nullptr;
+    auto take_od = [&]() {
+        if (!od) return;
+        W.rho = take(N); W.rhot = take(N); W.drho = take(N); W.rhob = take(N); W.w0k = take(N);
+        W.Cv = take(4 * N); W.dinv = take(N); W.rr = take(N); W.rdr = take(N);
+    };
+    if (mode == LIN_BIG) { W.G = nullptr; W.L = W.T; take_od(); return W; }
     W.G = take((size_t)4 * N * n);
     if (lean) { W.L = W.T; W.Hc = take((size_t)n * n); W.clin = take(n); }                   // the transpose scratch lives in the dead T | M region (4N n + n n >= n (n + 1))
     else W.L = take((size_t)n * (n + 1));
+    take_od();
     return W;
 }
 
 struct LinConst {
     double w0, Rrob, beta;
     int circles_only;
+    double alpha, ps, rf;                                // optimal decay: gain, penalty p_sb1, reference omega1
 };
 
 // rollout, barrier points, f, barrier values (and derivatives), g.  Points: a_k = index k, b_k = index N + k.
-template <int TH>
-__device__ __forceinline__ double lin_eval(const double* zv, const LinMem& W, const LinDims& d, const LinConst& c, int lane,
+template <int TH, bool OD = false>
+__device__ __forceinline__ double lin_eval(const double* zv, const double* rhov, const LinMem& W, const LinDims& d, const LinConst& c, int lane,
                                         bool derivs, Red& R) {
     const int N = d.N, K = d.K, nx = d.nx, nu = d.nu, n = d.n;
     for (int k = 0; k < N; ++k) {
@@ -148,8 +159,15 @@ __device__ __forceinline__ double lin_eval(const double* zv, const LinMem& W, co
     }
     for (int i = lane; i < n; i += TH) {
         const double prev = i >= nu ? zv[i - nu] : W.up[i];
-        const double du = zv[i] - prev;
+        const double du = OD ? zv[i] : zv[i] - prev;                      // optimal decay: R u^2 (optimal_decay_mpc_cbf.py:178-179)
         part += W.cq[12 + i % nu] * du * du;
+    }
+    if constexpr (OD) {
+        for (int k = lane; k < N; k += TH) {                              // row k:  h(b_k) - (1 - alpha rho_k) h(a_k)
+            const double r = rhov[k];
+            W.w0k[k] = -(1.0 - c.alpha * r);
+            part += c.ps * (r - c.rf) * (r - c.rf);
+        }
     }
     SC_SYNC();
     for (int e = lane; e < 2 * N * K; e += TH) {
@@ -167,7 +185,7 @@ __device__ __forceinline__ double lin_eval(const double* zv, const LinMem& W, co
         double gi;
         if (i < d.mc) {
             const int k = i / K, j = i - k * K;
-            gi = W.hk[(N + k) * K + j] + c.w0 * W.hk[k * K + j];
+            gi = W.hk[(N + k) * K + j] + (OD ? W.w0k[k] : c.w0) * W.hk[k * K + j];
         } else if (i < d.mc + n) {
             const int col = i - d.mc;
             gi = W.cq[20 + col % nu] - zv[col];
@@ -182,7 +200,7 @@ __device__ __forceinline__ double lin_eval(const double* zv, const LinMem& W, co
 }
 
 // gradient of the (unscaled) cost by the adjoint recursion:  l_k = 2 Q (x_k - xg) + Ae' l_{k+1},  df/du_{k-1} = Be' l_k
-template <int TH>
+template <int TH, bool OD = false>
 __device__ __forceinline__ void lin_grad(const LinMem& W, const LinDims& d, const LinConst& c, int lane, double sf) {
     const int N = d.N, nx = d.nx, nu = d.nu, n = d.n;
     for (int k = N; k >= 1; --k) {
@@ -206,24 +224,29 @@ __device__ __forceinline__ void lin_grad(const LinMem& W, const LinDims& d, cons
     }
     for (int i = lane; i < n; i += TH) {
         const double prev = i >= nu ? W.z[i - nu] : W.up[i];
-        double gr = W.gs[i] + 2.0 * W.cq[12 + i % nu] * (W.z[i] - prev);
-        if (i + nu < n) gr -= 2.0 * W.cq[12 + i % nu] * (W.z[i + nu] - W.z[i]);
+        double gr = W.gs[i] + 2.0 * W.cq[12 + i % nu] * (OD ? W.z[i] : W.z[i] - prev);
+        if (!OD && i + nu < n) gr -= 2.0 * W.cq[12 + i % nu] * (W.z[i + nu] - W.z[i]);
         W.gs[i] = sf * gr;
     }
     SC_SYNC();
 }
 
 // out = J' v for a row vector v (m):  G' (A' v) - v_hi + v_lo
-template <int TH>
+// ycorr (optimal decay): the point-space vector subtracted from A' v before the G' product (Schur correction of the rhs)
+template <int TH, bool OD = false>
 __device__ __forceinline__ void lin_jt(const double* v, double* out, const LinMem& W, const LinDims& d, const LinConst& c,
-                                    const double* G, int lane) {
+                                    const double* G, int lane, bool ycorr = false) {
     const int N = d.N, K = d.K, n = d.n;
     for (int e = lane; e < 4 * N; e += TH) {
         const int pt = e >> 1, dd = e & 1, k = pt < N ? pt : pt - N;
         double acc = 0.0;
 #pragma unroll
         for (int j = 0; j < K; ++j) acc += v[k * K + j] * W.dh[2 * (pt * K + j) + dd];
-        W.y[e] = pt < N ? c.w0 * acc : acc;
+        double yv = pt < N ? (OD ? W.w0k[k] : c.w0) * acc : acc;
+        if constexpr (OD) {
+            if (ycorr) yv -= W.Cv[4 * k + (pt < N ? dd : 2 + dd)] * (W.rr[k] * W.dinv[k]);
+        }
+        W.y[e] = yv;
     }
     SC_SYNC();
     for (int i = lane; i < n; i += TH) {
@@ -300,12 +323,19 @@ __device__ __forceinline__ void lin_condense_mfma(const LinMem& W, const int N_r
 // NX, NU > 0: states and inputs are compile-time constants (the short matrix-vector loops unroll and their LDS loads are
 // issued back to back; with run-time bounds every multiply-add waits a full LDS round trip); NT > 0 (needs NX > 0): the
 // horizon too -- register Cholesky, lean LDS layout; KT > 0: obstacle rows.  0: run-time size.
-template <int NX, int NU, int NT, int KT, bool BIG = false>
+// OD: optimal decay on a relative-degree-1 model (BASELINE config 5's extension, oracle/od_mpc_rd1.py): one decay variable
+// rho_k per stage scales the gain of that stage's rows, h(b_k) - (1 - alpha rho_k) h(a_k) >= 0, at the price p_sb (rho_k - 1)^2;
+// the input term is R u^2.  rho_k only meets the rows of stage k and enters them linearly, so its positive scalar block
+// D_k = 2 sf p_sb + sum_j sig_kj (alpha h(a_kj))^2 is eliminated in POINT space: Phi_k -= C_k C_k' / D_k on the 4 x 4 stage block,
+// the right-hand side loses G_k' C_k rr_k / D_k, and d rho_k = (rr_k - C_k' (G dz)_k) / D_k after the solve -- the condensed
+// n x n system, its MFMA assembly and the Cholesky are untouched.
+template <int NX, int NU, int NT, int KT, bool BIG = false, bool OD = false>
 __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, const long long B,
                                                     const int K_rt, const void* __restrict__ X, const void* __restrict__ u_prev,
                                                     const void* __restrict__ goal, const void* __restrict__ obs,
                                                     void* __restrict__ u_out, int* __restrict__ status_out,
-                                                    int* __restrict__ iters_out, void* __restrict__ z_out) {
+                                                    int* __restrict__ iters_out, void* __restrict__ z_out,
+                                                    void* __restrict__ rho_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int NW = BIG ? 4 : 1, TH = 64 * NW;                 // threads per problem: the big layout leaves one problem per CU, so it takes all four SIMDs
     const int lane = threadIdx.x;                                 // index among the TH threads of the problem
@@ -322,11 +352,12 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
     const int K = d.K;
     const int N = d.N, nx = d.nx, nu = d.nu, n = d.n, m = d.m;
     constexpr bool LEAN = NT > 0;
-    const LinMem W = carve_lin(sm, d, LEAN ? LIN_LEAN : (BIG ? LIN_BIG : LIN_STD));
+    const LinMem W = carve_lin(sm, d, LEAN ? LIN_LEAN : (BIG ? LIN_BIG : LIN_STD), OD);
     Red R;
     R.buf = W.red; R.par = 0;
     LinConst c;
     c.w0 = -(1.0 - p.alpha); c.Rrob = p.robot_radius; c.beta = p.beta; c.circles_only = p.circles_only;
+    c.alpha = p.alpha; c.ps = p.od_p_sb; c.rf = p.od_omega_ref;
     if (lane < 12) W.cq[lane] = p.Q[lane];
     if (lane < 4) { W.cq[12 + lane] = p.R[lane]; W.cq[16 + lane] = p.u_lo[lane]; W.cq[20 + lane] = p.u_hi[lane]; }
     // model blob: Ae [nx nx] | Be [nx nu] | As2 [2 nx] | Bs2 [2 nu] | Hc [n n] | G [4N n]
@@ -354,14 +385,15 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
         const double lo = W.cq[16 + i % nu], hi = W.cq[20 + i % nu], pad = 0.005 * (hi - lo);
         W.z[i] = fmin(fmax(W.up[i % nu], lo + pad), hi - pad);
     }
+    if constexpr (OD) for (int k = lane; k < N; k += TH) { W.rho[k] = c.rf; W.rhob[k] = c.rf; }   // decay variables start at their reference
     SC_SYNC();
 
-    double f = lin_eval<TH>(W.z, W, d, c, lane, true, R);
+    double f = lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, true, R);
     // steep (superellipsoid) barriers: IPOPT-style gradient-based row scaling from the initial guess, then a fresh evaluation
     if (!c.circles_only &&
         ipm::scale_steep_barriers(W.obs, K, W.dh, 2 * N, lane, TH, [&](double v) { return lmax_<TH>(v, R); }, [] { SC_SYNC(); }))
-        f = lin_eval<TH>(W.z, W, d, c, lane, true, R);
-    lin_grad<TH>(W, d, c, lane, 1.0);
+        f = lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, true, R);
+    lin_grad<TH, OD>(W, d, c, lane, 1.0);
     if constexpr (LEAN) {
         // the cost is quadratic: grad f = Hc z + c with c fixed for the solve (one adjoint pass, here)
         for (int i = lane; i < n; i += TH) {
@@ -393,7 +425,7 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
 #endif
     for (it = 1; it <= p.max_iter; ++it) {
         LP(11);
-        if (it > 1 && !fresh) f = lin_eval<TH>(W.z, W, d, c, lane, true, R);   // fresh: the accepted trial point was evaluated with derivatives
+        if (it > 1 && !fresh) f = lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, true, R);   // fresh: the accepted trial point was evaluated with derivatives
         LP(0);
         if constexpr (LEAN) {                                             // gs = sf grad f = sf (Hc z + c)
             for (int i = lane; i < n; i += TH) {
@@ -404,13 +436,22 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
             }
             SC_SYNC();
         } else if (it == 1) {
-            lin_grad<TH>(W, d, c, lane, sf);                                // later iterations: gs += alpha sf Hc dz at the update (the cost is quadratic)
+            lin_grad<TH, OD>(W, d, c, lane, sf);                            // later iterations: gs += alpha sf Hc dz at the update (the cost is quadratic)
         }
         LP(1);
-        lin_jt<TH>(W.lam, W.rd, W, d, c, G, lane);
+        lin_jt<TH, OD>(W.lam, W.rd, W, d, c, G, lane);
         LP(2);
         double e_d = 0.0, e_p = 0.0, e_c0 = 0.0, lmx = 0.0;
         for (int i = lane; i < n; i += TH) { const double r = W.gs[i] - W.rd[i]; W.rd[i] = r; e_d = fmax(e_d, fabs(r)); }
+        if constexpr (OD) {
+            for (int k = lane; k < N; k += TH) {                         // r_d of rho_k = sf 2 p_sb (rho_k - ref) - sum_j lam_kj alpha h(a_kj)
+                double acc = sf * 2.0 * c.ps * (W.rho[k] - c.rf);
+#pragma unroll
+                for (int j = 0; j < K; ++j) acc -= W.lam[k * K + j] * c.alpha * W.hk[k * K + j];
+                W.rdr[k] = acc;
+                e_d = fmax(e_d, fabs(acc));
+            }
+        }
         for (int i = lane; i < m; i += TH) {
             const double s = W.s[i], l = W.lam[i];
             e_p = fmax(e_p, fabs(W.g[i] - s)); e_c0 = fmax(e_c0, fabs(s * l)); lmx = fmax(lmx, l);
@@ -420,6 +461,7 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
         if (e_opt < e_best) {
             e_best = e_opt;
             for (int i = lane; i < n; i += TH) W.zb[i] = W.z[i];
+            if constexpr (OD) for (int k = lane; k < N; k += TH) W.rhob[k] = W.rho[k];
         }
         if (e_opt <= p.tol) { status = SC_STATUS_OPTIMAL; break; }
         n_acc = e_opt <= p.acceptable_tol ? n_acc + 1 : 0;
@@ -443,7 +485,26 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
             W.ds[i] = sig;                                                // read by the Phi blocks below; ds proper is written after the solve
         }
         SC_SYNC();
-        lin_jt<TH>(W.vb, W.rhs, W, d, c, G, lane);
+        if constexpr (OD) {
+            // decay blocks of the stages: C_k (over the point pair: [w0 dh_a; dh_b] sig A - lam alpha [dh_a; 0], A = alpha h(a)),
+            // 1 / D_k, and the right-hand side rr_k = -sf 2 p_sb (rho_k - ref) + sum_j vb_kj A_kj
+            for (int e = lane; e < 5 * N; e += TH) {
+                const int k = e / 5, r = e - 5 * k;
+                double acc = 0.0, acc2 = 0.0;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const int ea = k * K + j, eb = (N + k) * K + j;
+                    const double A = c.alpha * W.hk[ea], sig = W.ds[ea], l = W.lam[ea];
+                    if (r == 4) { acc += sig * A * A; acc2 += W.vb[ea] * A; }
+                    else if (r < 2) acc += (sig * A * W.w0k[k] - l * c.alpha) * W.dh[2 * ea + r];
+                    else acc += sig * A * W.dh[2 * eb + r - 2];
+                }
+                if (r == 4) { W.dinv[k] = 1.0 / (sf * 2.0 * c.ps + acc); W.rr[k] = -sf * 2.0 * c.ps * (W.rho[k] - c.rf) + acc2; }
+                else W.Cv[4 * k + r] = acc;
+            }
+            SC_SYNC();
+        }
+        lin_jt<TH, OD>(W.vb, W.rhs, W, d, c, G, lane, true);
         for (int i = lane; i < n; i += TH) W.rhs[i] = -W.gs[i] + W.rhs[i];
         LP(4);
         // stage blocks Phi_k over (a_k, b_k):  sum_j sig_kj v v' (v = [w0 dh_a; dh_b])  -  sum_j lam_kj [w0 Hh_a, 0; 0, Hh_b]
@@ -454,12 +515,14 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
             for (int j = 0; j < K; ++j) {
                 const int ea = k * K + j, eb = (N + k) * K + j, row = k * K + j;
                 const double l = W.lam[row], sig = W.ds[row];
-                const double vr = r < 2 ? c.w0 * W.dh[2 * ea + r] : W.dh[2 * eb + r - 2];
-                const double vc = cc < 2 ? c.w0 * W.dh[2 * ea + cc] : W.dh[2 * eb + cc - 2];
+                const double w0 = OD ? W.w0k[k] : c.w0;
+                const double vr = r < 2 ? w0 * W.dh[2 * ea + r] : W.dh[2 * eb + r - 2];
+                const double vc = cc < 2 ? w0 * W.dh[2 * ea + cc] : W.dh[2 * eb + cc - 2];
                 acc += sig * vr * vc;
-                if (r < 2 && cc < 2) acc -= l * c.w0 * W.hh[3 * ea + r + cc];
+                if (r < 2 && cc < 2) acc -= l * w0 * W.hh[3 * ea + r + cc];
                 if (r >= 2 && cc >= 2) acc -= l * W.hh[3 * eb + (r - 2) + (cc - 2)];
             }
+            if constexpr (OD) acc -= W.Cv[4 * k + r] * W.Cv[4 * k + cc] * W.dinv[k];   // Schur complement of the stage's decay variable
             W.Phi[e] = acc;
         }
         SC_SYNC();
@@ -522,6 +585,16 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
             curv += q * W.dz[i];
             if constexpr (!LEAN) W.rd[i] = q;                               // (Hc dz)_i: r_d's space is free until the next iteration
         }
+        if constexpr (OD) {
+            // d rho_k = (rr_k - C_k' (G dz)_k) / D_k; the decay part of grad f . d and of the (exactly quadratic) curvature
+            for (int k = lane; k < N; k += TH) {
+                const double dr = (W.rr[k] - (W.Cv[4 * k] * W.pdz[2 * k] + W.Cv[4 * k + 1] * W.pdz[2 * k + 1] +
+                                              W.Cv[4 * k + 2] * W.pdz[2 * N + 2 * k] + W.Cv[4 * k + 3] * W.pdz[2 * N + 2 * k + 1])) * W.dinv[k];
+                W.drho[k] = dr;
+                gdz += sf * 2.0 * c.ps * (W.rho[k] - c.rf) * dr;
+                curv += 2.0 * c.ps * dr * dr;
+            }
+        }
         curv = sf * lsum<TH>(curv, R);
         SC_SYNC();
         double rs_min = 0.0, rl_min = 0.0, sum_ds_s = 0.0, sum_rp = 0.0, sum_log = 0.0, sum_g = 0.0;
@@ -530,8 +603,9 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
             double jd;
             if (i < d.mc) {
                 const int k = i / K, j = i - k * K, ea = k * K + j, eb = (N + k) * K + j;
-                jd = c.w0 * (W.dh[2 * ea] * W.pdz[2 * k] + W.dh[2 * ea + 1] * W.pdz[2 * k + 1]) +
+                jd = (OD ? W.w0k[k] : c.w0) * (W.dh[2 * ea] * W.pdz[2 * k] + W.dh[2 * ea + 1] * W.pdz[2 * k + 1]) +
                      (W.dh[2 * eb] * W.pdz[2 * N + 2 * k] + W.dh[2 * eb + 1] * W.pdz[2 * N + 2 * k + 1]);
+                if constexpr (OD) jd += c.alpha * W.hk[ea] * W.drho[k];
             } else if (i < d.mc + n) {
                 jd = -W.dz[i - d.mc];
             } else {
@@ -559,9 +633,10 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
         fresh = false;
         for (int ls = 0; ls < 12; ++ls) {
             for (int i = lane; i < n; i += TH) W.zt[i] = W.z[i] + alpha * W.dz[i];
+            if constexpr (OD) for (int k = lane; k < N; k += TH) W.rhot[k] = W.rho[k] + alpha * W.drho[k];
             SC_SYNC();
             const bool full = ls == 0 && c.circles_only != 0;                  // the full step is taken most of the time: evaluate it once, with the
-            const double f_t = lin_eval<TH>(W.zt, W, d, c, lane, full, R);     // derivatives (circles: they cost nothing next to the rollout)
+            const double f_t = lin_eval<TH, OD>(W.zt, W.rhot, W, d, c, lane, full, R);     // derivatives (circles: they cost nothing next to the rollout)
             double srp = 0.0, slog = 0.0;
             for (int i = lane; i < m; i += TH) {
                 const double s_t = W.s[i] + alpha * W.ds[i];
@@ -582,6 +657,7 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
             W.z[i] = W.z[i] + alpha * W.dz[i];
             if constexpr (!LEAN) W.gs[i] += alpha * sf * W.rd[i];
         }
+        if constexpr (OD) for (int k = lane; k < N; k += TH) W.rho[k] = W.rho[k] + alpha * W.drho[k];
         for (int i = lane; i < m; i += TH) {
             const double s = W.s[i] + alpha * W.ds[i];
             double l = W.lam[i] + ad * W.dlam[i];
@@ -595,10 +671,11 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
     if (status != SC_STATUS_OPTIMAL && e_best <= p.acceptable_tol) {
         SC_SYNC();
         for (int i = lane; i < n; i += TH) W.z[i] = W.zb[i];
+        if constexpr (OD) for (int k = lane; k < N; k += TH) W.rho[k] = W.rhob[k];
         status = SC_STATUS_OPTIMAL;
     }
     SC_SYNC();
-    lin_eval<TH>(W.z, W, d, c, lane, false, R);
+    lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, false, R);
     if (status != SC_STATUS_OPTIMAL) {
         double gmin = 1e300;
         for (int i = lane; i < m; i += TH) gmin = fmin(gmin, W.g[i]);
@@ -616,6 +693,9 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
 #else
     if (z_out) for (int i = lane; i < n; i += TH) st(z_out, prob * n + i, W.z[i]);
 #endif
+    if constexpr (OD) {
+        if (rho_out) for (int k = lane; k < N; k += TH) st(rho_out, prob * N + k, W.rho[k]);
+    }
 }
 
 }  // namespace
@@ -627,14 +707,17 @@ static bool mpclin_is_lean(int N, int nx, int nu) {
     if (nx == 2 && nu == 2) return N == 10 || N == 20;
     return false;
 }
-static int mpclin_mode(int N, int K, int nx, int nu) {
-    if (mpclin_is_lean(N, nx, nu) && mpclin_lds_doubles(N, K, nx, nu, LIN_LEAN) * sizeof(double) <= 160 * 1024) return LIN_LEAN;
+static int mpclin_mode(int N, int K, int nx, int nu, bool od = false) {
+    if (od && !(nx == 12 && nu == 4 && N == 10)) {                     // optimal decay: Quad3D, lean at the default horizon only
+        return mpclin_lds_doubles(N, K, nx, nu, LIN_STD, true) * sizeof(double) > 80 * 1024 ? LIN_BIG : LIN_STD;
+    }
+    if (mpclin_is_lean(N, nx, nu) && mpclin_lds_doubles(N, K, nx, nu, LIN_LEAN, od) * sizeof(double) <= 160 * 1024) return LIN_LEAN;
     // the standard layout above 80 KB leaves one single-wave problem per CU (three SIMDs idle): the big layout with its four
     // waves per problem is faster from there on (measured, 4096 Quad3D problems: N = 12 15.9 -> 11.9 ms, N = 14 25.0 -> 17.4 ms;
     // SingleIntegrator2D N = 18 27.5 -> 20.4 ms; below, two or three single-wave problems per CU win: Quad3D N = 8 5.2 against 6.5 ms)
     return mpclin_lds_doubles(N, K, nx, nu, LIN_STD) * sizeof(double) > 80 * 1024 ? LIN_BIG : LIN_STD;
 }
-size_t mpclin_lds_bytes(int N, int K, int nx, int nu) { return mpclin_lds_doubles(N, K, nx, nu, mpclin_mode(N, K, nx, nu)) * sizeof(double); }
+size_t mpclin_lds_bytes(int N, int K, int nx, int nu, bool od) { return mpclin_lds_doubles(N, K, nx, nu, mpclin_mode(N, K, nx, nu, od), od) * sizeof(double); }
 
 // Host: constant matrices of the condensed problem from (Ae, Be, As, Bs, Q, R, N); layout of the blob as the kernel reads it
 size_t mpclin_model_doubles(int nx, int nu, int N) {
@@ -677,11 +760,11 @@ bool mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const doubl
                 Hc[(size_t)a * n + b] += 2.0 * acc;
             }
     }
-    // r-term: sum_i R (z_i - z_{i - nu})^2  ->  2 D' R D
+    // r-term: sum_i R (z_i - z_{i - nu})^2  ->  2 D' R D   (optimal decay: sum_i R z_i^2 -> 2 R)
     for (int i = 0; i < n; ++i) {
         const double r = p.R[i % nu];
         Hc[(size_t)i * n + i] += 2.0 * r;
-        if (i >= nu) {
+        if (i >= nu && !p.optimal_decay) {
             Hc[(size_t)(i - nu) * n + (i - nu)] += 2.0 * r;
             Hc[(size_t)i * n + (i - nu)] -= 2.0 * r;
             Hc[(size_t)(i - nu) * n + i] -= 2.0 * r;
@@ -703,11 +786,12 @@ bool mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const doubl
 }
 
 hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long long B, int K, const void* X, const void* u_prev,
-                         const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
+                         const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out, void* rho_out,
                          hipStream_t stream) {
-    const size_t lds = mpclin_lds_bytes(p.horizon, K, p.nx, p.nu);
+    const bool od = p.optimal_decay != 0;
+    const size_t lds = mpclin_lds_bytes(p.horizon, K, p.nx, p.nu, od);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    const int mode = mpclin_mode(p.horizon, K, p.nx, p.nu);
+    const int mode = mpclin_mode(p.horizon, K, p.nx, p.nu, od);
     const unsigned threads = mode == LIN_BIG ? 256 : 64;                  // big layout: four waves per problem
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 64 * 1024) {
@@ -715,9 +799,14 @@ hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long lo
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(threads), lds, stream, p, model, B, K, X, u_prev, goal, obs, u_out, status,
-                           iters, z_out);
+                           iters, z_out, rho_out);
         return hipGetLastError();
     };
+    if (od) {                                                           // the config-5 extension: Quad3D only
+        if (!(p.nx == 12 && p.nu == 4)) return hipErrorInvalidValue;
+        if (mode == LIN_LEAN) return launch(mpclin_kernel<12, 4, 10, 0, false, true>);
+        return mode == LIN_BIG ? launch(mpclin_kernel<12, 4, 0, 0, true, true>) : launch(mpclin_kernel<12, 4, 0, 0, false, true>);
+    }
     if (mode == LIN_LEAN) {
         if (p.horizon == 10 && p.nx == 12)                            // Quad3D at the reference's default horizon
             return K == 8 ? launch(mpclin_kernel<12, 4, 10, 8>) : launch(mpclin_kernel<12, 4, 10, 0>);

@@ -3,5 +3,5 @@ from .mpc_cbf import MPCCBF, BatchedMPCCBF  # noqa: F401
 from .optimal_decay_mpc_cbf import OptimalDecayMPCCBF, BatchedOptimalDecayMPCCBF  # noqa: F401
 from .optimal_decay_cbf_qp import OptimalDecayCBFQP, BatchedOptimalDecayCBFQP  # noqa: F401
 from .manipulator_cbf_qp import ManipulatorCBFQP, BatchedManipulatorCBFQP, BatchedManipulatorTracking  # noqa: F401
-from .mpc_cbf_linear import LinearMPCCBF, BatchedLinearMPCCBF  # noqa: F401
+from .mpc_cbf_linear import LinearMPCCBF, BatchedLinearMPCCBF, BatchedOptimalDecayLinearMPCCBF  # noqa: F401
 from .mpc_cbf_gn import GnMPCCBF, BatchedGnMPCCBF  # noqa: F401

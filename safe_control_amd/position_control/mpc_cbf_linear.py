@@ -161,3 +161,62 @@ class BatchedLinearMPCCBF:
             obs.data_ptr(), u.data_ptr(), status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
         _lib.check(rc, "sc_mpclin_solve_batch")
         return (u, status, iters, z) if want_z else (u, status, iters)
+
+
+class BatchedOptimalDecayLinearMPCCBF(BatchedLinearMPCCBF):
+    """EXTENSION (BASELINE config 5; no reference counterpart): optimal-decay MPC-CBF for Quad3D with circles AND
+    superellipsoid obstacles -- rows ``h(step(x_k,u_k)) - (1 - alpha rho_k) h(x_k) >= 0`` with one decay variable per stage
+    (the rel-degree-1 form of the reference's optimal-decay CBF-QP, optimal_decay_cbf_qp.py:96-101,113-125), cost
+    ``+ p_sb1 (rho_k - omega1)^2`` and the input term ``R u^2`` (optimal_decay_mpc_cbf.py:178-184); gains, weights and bounds are
+    MPCCBF's for the model.  oracle/od_mpc_rd1.py states the problem and the method.
+    ``solve(...)`` -> ``u[B,4]``, ``rho[B,N]``, ``status[B]``, ``iters[B]`` (and ``z[B,4N]`` if asked)."""
+
+    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=100,
+                 superellipsoids=True):
+        spec = complete_robot_spec(robot_spec)
+        if spec["model"] != "Quad3D":
+            raise NotImplementedError("the optimal-decay extension of the linear-model kernel serves Quad3D")
+        self.od = {"omega1": 1.0, "p_sb1": 10.0}              # optimal_decay_mpc_cbf.py:88-89
+        if cbf_param:
+            self.od.update({k: cbf_param[k] for k in ("omega1", "p_sb1") if k in cbf_param})
+        self._superellipsoids = bool(superellipsoids)
+        super().__init__(robot_spec, dt=dt, io_dtype=io_dtype, horizon=horizon, cbf_param=cbf_param, tol=tol, max_iter=max_iter)
+
+    def _params(self, **kw):
+        p = make_params(self._mdl, self.cbf_param, self.horizon, self.robot_spec["radius"], self.io_dtype, **kw)
+        p.optimal_decay = 1
+        p.od_omega_ref, p.od_p_sb = float(self.od["omega1"]), float(self.od["p_sb1"])
+        if self._superellipsoids:
+            p.circles_only = 0                               # the 7-wide obstacle rows of the other models (SURVEY 8d, config 5)
+        return p
+
+    def solve(self, X, u_prev, goal, obs, want_z=False):
+        import torch
+        dt_ = self.torch_dtype
+        for name, t in (("X", X), ("u_prev", u_prev), ("goal", goal), ("obs", obs)):
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == dt_):
+                raise ValueError(f"{name} must be a contiguous CUDA tensor of dtype {dt_}")
+        B = X.shape[0]
+        nx, nu, ng = self._mdl["nx"], self._mdl["nu"], self._mdl["ng"]
+        shared = obs.dim() == 2
+        K = obs.shape[-2]
+        if X.shape != (B, nx) or u_prev.shape != (B, nu) or goal.shape != (B, ng) or obs.shape[-1] != 7 \
+                or (not shared and obs.shape[0] != B):
+            raise ValueError(f"expected X[B,{nx}], u_prev[B,{nu}], goal[B,{ng}], obs[B,K,7] or obs[K,7]")
+        if "od" not in self._blob_dev:                       # the cost Hessian of the blob depends on the r-term: rebuild once
+            p0 = self._params()
+            self._blob_host = build_model_blob(self._lib, p0, self._mdl)
+            self._blob_dev = {"od": True}
+        u = torch.empty((B, nu), dtype=dt_, device=X.device)
+        rho = torch.empty((B, self.horizon), dtype=dt_, device=X.device)
+        status = torch.empty((B,), dtype=torch.int32, device=X.device)
+        iters = torch.empty((B,), dtype=torch.int32, device=X.device)
+        z = torch.empty((B, nu * self.horizon), dtype=dt_, device=X.device) if want_z else None
+        p = self._params(obs_shared=shared, tol=self.tol, max_iter=self.max_iter)
+        stream = torch.cuda.current_stream(X.device).cuda_stream
+        rc = self._lib.sc_odmpclin_solve_batch(
+            C.byref(p), self._blob(X.device).data_ptr(), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(),
+            obs.data_ptr(), u.data_ptr(), rho.data_ptr(), status.data_ptr(), iters.data_ptr(),
+            z.data_ptr() if z is not None else None, stream)
+        _lib.check(rc, "sc_odmpclin_solve_batch")
+        return (u, rho, status, iters, z) if want_z else (u, rho, status, iters)

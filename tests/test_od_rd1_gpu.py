@@ -70,3 +70,90 @@ def test_unicycle2d_f32_storage_and_batch_position_independence():
     sel = np.arange(100, 164)
     u2, rho2, st2, it2, z2, _ = run_uni(X[sel], goal[sel], obs[sel], 20, io="f32")
     assert np.array_equal(u[sel], u2) and np.array_equal(st[sel], st2) and np.array_equal(rho[sel], rho2)
+
+
+# ---- Quad3D (csrc/mpc_lin.hip, OD = true instantiations) ---------------------------------------------------------------
+
+def quad_scene(B, K, seed, superell=True):
+    """Quad3D draws of W.linear_mpc_batch with an obstacle on the way to the goal (so rows bind and the decay rates move)."""
+    X, goal, obs = W.linear_mpc_batch("Quad3D", B, K, seed=seed)
+    rng = np.random.default_rng(seed + 77)
+    if superell:
+        obs = W.superellipsoid_obstacles(X[:, :2], K, seed=seed + 1000, rho_max=3.0)
+        obs[::5, 0] = W.linear_mpc_batch("Quad3D", B, K, seed=seed)[2][::5, 0]      # every fifth agent keeps one circle
+    v = X[:, 6:8]
+    d = v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-9)
+    goal[:, :2] = X[:, :2] + 4.0 * d
+    rho = rng.uniform(1.4, 2.2, B)
+    obs[:, 1, 0:2] = X[:, :2] + rho[:, None] * d                                    # ahead of the vehicle, on its course
+    return X, goal, obs
+
+
+def run_quad(X, goal, obs, N, io="f64", superell=True):
+    import safe_control_amd as sca
+    td = torch.float64 if io == "f64" else torch.float32
+    ctl = sca.BatchedOptimalDecayLinearMPCCBF({"model": "Quad3D"}, io_dtype=io, horizon=N, superellipsoids=superell)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=td, device=DEV)
+    B = X.shape[0]
+    tX, tg, to = t(X), t(goal), t(obs)
+    u, rho, st, it, z = ctl.solve(tX, torch.zeros((B, 4), dtype=td, device=DEV), tg, to, want_z=True)
+    torch.cuda.synchronize()
+    seen = tuple(a.double().cpu().numpy() for a in (tX, tg, to))
+    return u.double().cpu().numpy(), rho.double().cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), z.double().cpu().numpy(), seen
+
+
+@pytest.mark.parametrize("N,K,superell", [(20, 8, True), (10, 8, True), (10, 5, False), (7, 3, True), (14, 4, True)])
+def test_quad3d_against_oracle(N, K, superell):
+    """N = 20: big layout (four waves), N = 10: lean layout (register Cholesky), N = 7: standard, N = 14: big."""
+    B = 64
+    X, goal, obs = quad_scene(B, K, seed=N * 10 + K, superell=superell)
+    u, rho, st, it, z, (Xs, gs, os_) = run_quad(X, goal, obs, N, superell=superell)
+    r = od_rd1_solve_many("od_quad3d", Xs, np.zeros((B, 4)), gs, os_, params={"N": N})
+    assert np.array_equal(st, r["st"]), np.flatnonzero(st != r["st"])
+    ok = r["st"] == O.STATUS_OPTIMAL
+    assert ok.sum() >= 0.7 * B
+    tight = ok & (np.abs(it - r["it"]) <= 2)                  # problems that left through the acceptable-point rule stop where rounding says
+    assert tight.sum() >= 0.85 * ok.sum()
+    assert np.abs(u[tight] - r["u"][tight]).max() <= 1e-6
+    assert np.abs(z[tight] - r["z"][tight]).max() <= 2e-5
+    assert np.abs(rho[tight] - r["rho"][tight]).max() <= 1e-4
+    loose = ok & ~tight
+    if loose.any():
+        assert np.abs(u[loose] - r["u"][loose]).max() <= 1e-4 * max(1.0, np.abs(r["u"][loose]).max())
+    from oracle import mpc_lin as L
+    P = O.lin_params(dict(L.quad3d_model(), circles_only=False), N=N)
+    for i in np.flatnonzero(ok)[:16]:
+        g = O.evaluate(Xs[i], np.concatenate([z[i], rho[i]]), gs[i], os_[i], P, level=0)["g"]
+        assert g.min() >= -1e-6
+    if N >= 10:
+        assert np.abs(rho[ok] - 1.0).max() > 1e-3                                   # the decay rates do move (short horizons never reach the obstacle)
+
+
+def test_quad3d_f32_storage_and_batch_position_independence():
+    X, goal, obs = quad_scene(256, 8, seed=5)
+    u, rho, st, it, z, _ = run_quad(X, goal, obs, 20, io="f32")
+    assert (st == 0).mean() > 0.7
+    sel = np.arange(100, 164)
+    u2, rho2, st2, it2, z2, _ = run_quad(X[sel], goal[sel], obs[sel], 20, io="f32")
+    assert np.array_equal(u[sel], u2) and np.array_equal(st[sel], st2) and np.array_equal(rho[sel], rho2)
+
+
+def test_quad3d_entry_point_guards():
+    import ctypes as C
+    import safe_control_amd as sca
+    from safe_control_amd import _lib
+    lib = _lib.load()
+    ctl = sca.BatchedOptimalDecayLinearMPCCBF({"model": "Quad3D"}, horizon=10)
+    p = ctl._params()
+    blob = torch.zeros(int(lib.sc_mpclin_model_doubles(12, 4, 10)), dtype=torch.float64, device=DEV)
+    X = torch.zeros((1, 12), dtype=torch.float64, device=DEV)
+    a = lambda t_: t_.data_ptr()
+    o = torch.zeros((1, 1, 7), dtype=torch.float64, device=DEV)
+    uo = torch.zeros((1, 4), dtype=torch.float64, device=DEV); so = torch.zeros(1, dtype=torch.int32, device=DEV)
+    g = torch.zeros((1, 3), dtype=torch.float64, device=DEV)
+    # the plain entry point refuses an optimal-decay parameter block and vice versa
+    assert lib.sc_mpclin_solve_batch(C.byref(p), a(blob), 1, 1, a(X), a(uo), a(g), a(o), a(uo), a(so), None, None, None) == 1
+    p.optimal_decay = 0
+    assert lib.sc_odmpclin_solve_batch(C.byref(p), a(blob), 1, 1, a(X), a(uo), a(g), a(o), a(uo), None, a(so), None, None, None) == 1
+    p.optimal_decay = 1; p.nx = 2; p.nu = 2
+    assert lib.sc_odmpclin_solve_batch(C.byref(p), a(blob), 1, 1, a(X), a(uo), a(g), a(o), a(uo), None, a(so), None, None, None) == 2
