@@ -475,6 +475,52 @@ int sc_manip_tracking_rollout_batch(const sc_manip_tracking_params* params, int6
                                     const void* obs_table, void* u_last, int32_t* ret, int32_t* ret_step,
                                     void* traj_X, void* traj_U, void* stream);
 
+/* ---- Backup-CBF QP --------------------------------------------------------------------------------
+ * BackupCBF.solve_control_problem (position_control/backup_cbf_qp.py:563-794) for B agents per launch on the scenario the
+ * reference ships for it (examples/evade/test_evade.py --algo backupcbf): DoubleIntegrator2D
+ * (robots/double_integrator2D.py:46-107), EvadeBackupController (position_control/backup_controller.py:420-572) and
+ * EvadeEnv with its constant-speed rectangular bullet (envs/evade_env.py:30-83,360-406).  Per agent: rollout of the backup
+ * controller over n_steps = int(backup_horizon / dt) states with robot.step, sensitivities by forward differences
+ * (:236-320), one row per backup step from the finite-difference gradient of _h_safety (:343-461, :620-665) plus the
+ * terminal row (_h_terminal :463-561, :668-676), the QP in scaled inputs (:678-716) solved EXACTLY (the reference calls
+ * OSQP, :717-726), and the fallback rules (:737-774).  DriftingCar / LaneChangeController (examples/drift_car) are not served.
+ * status_out: -1 no row survived |lhs| > 1e-6 (u = the reference input as given), 0 QP solved, 1 QP infeasible or
+ * non-finite rows (u = clipped reference input when min h > 0.01, else the backup input).
+ */
+typedef struct sc_backupcbf_params {
+    int32_t io_dtype;            /* SC_DTYPE_F32 / SC_DTYPE_F64: element type of X, u_nom, bullet_x, u_out, h_min_out    */
+    int32_t n_steps;             /* int(backup_horizon / dt) (backup_cbf_qp.py:55), 2 <= n_steps <= 128                  */
+    int32_t bullet_shared;       /* 1: bullet_x is [1] (one environment for every agent), 0: [B]                         */
+    int32_t reserved;            /* keep 0                                                                               */
+    double  dt, backup_horizon;  /* backup_horizon also dates the safety value inside _h_terminal (:537-541)             */
+    double  fd_eps;              /* 1e-5 (:282, :451, :551)                                                              */
+    double  robot_radius, a_max, v_max, safety_margin;   /* robot_spec (test_evade.py:75-88,298-299)                     */
+    double  alpha, alpha_terminal;                       /* 1.0, 2.0 (:93-94)                                            */
+    double  backup_kp, backup_kd;                        /* 2.0, 2.0 (backup_controller.py:449-450)                      */
+    double  hallway_length, half_width;                  /* EvadeEnv geometry (envs/evade_env.py:51-79)                  */
+    double  pocket_x_min, pocket_x_max, pocket_y_min, pocket_y_max;
+    double  goal_x_min, goal_x_max;
+    double  bullet_speed, bullet_length, bullet_width, bullet_start_x;
+} sc_backupcbf_params;
+
+/* X [B,4] = (x, y, vx, vy); u_nom [B,2] the nominal input (nominal_u_traj[0], :179-181) or NULL for the example's
+ * EvadeNominalController (test_evade.py:128-166); bullet_x [B] or [1]: EvadeEnv.bullet_x (the box the barrier sees is
+ * get_bullet_state()'s: centre + length / 6, length 4/3); u_out [B,2]; status_out [B] as above; using_backup_out [B]
+ * (BackupCBF.is_using_backup()), h_min_out [B] (_last_h_min), n_rows_out [B] and rows_out [B, n_steps, 3] (float64, the
+ * kept rows "(G S) us >= h" in the order the reference appends them, first n_rows_out[b] entries) may be NULL. */
+int sc_backupcbf_solve_batch(const sc_backupcbf_params* params, int64_t B, const void* X, const void* u_nom,
+                             const void* bullet_x, void* u_out, int32_t* status_out, int32_t* using_backup_out,
+                             void* h_min_out, int32_t* n_rows_out, double* rows_out, void* stream);
+
+/* The example's closed loop (test_evade.py:425-500), n_ctrl control steps in one launch: nominal controller -> Backup-CBF
+ * QP -> robot.step -> speed clamp -> step_bullet (respawn past the hallway) -> collision / goal checks.  X [B,4] and
+ * bullet_x ([B]; with bullet_shared the caller advances the shared bullet) in/out; ret [B] in/out: 0 running, 1 goal
+ * reached, -2 collision with the bullet (sticky: frozen afterwards); ret_step [B] in/out: step_offset + index inside the
+ * launch at which ret turned non-zero; u_out / status_out / using_backup_out / h_min_out: values of the last step. */
+int sc_backupcbf_rollout_batch(const sc_backupcbf_params* params, int64_t B, int32_t n_ctrl, int32_t step_offset,
+                               void* X, void* bullet_x, void* u_out, int32_t* status_out, int32_t* using_backup_out,
+                               void* h_min_out, int32_t* ret, int32_t* ret_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

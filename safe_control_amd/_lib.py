@@ -44,6 +44,20 @@ class CbfQpParams(C.Structure):
     ]
 
 
+class BackupCbfParams(C.Structure):
+    """Mirror of ``sc_backupcbf_params``."""
+    _fields_ = [
+        ("io_dtype", C.c_int32), ("n_steps", C.c_int32), ("bullet_shared", C.c_int32), ("reserved", C.c_int32),
+        ("dt", C.c_double), ("backup_horizon", C.c_double), ("fd_eps", C.c_double),
+        ("robot_radius", C.c_double), ("a_max", C.c_double), ("v_max", C.c_double), ("safety_margin", C.c_double),
+        ("alpha", C.c_double), ("alpha_terminal", C.c_double), ("backup_kp", C.c_double), ("backup_kd", C.c_double),
+        ("hallway_length", C.c_double), ("half_width", C.c_double),
+        ("pocket_x_min", C.c_double), ("pocket_x_max", C.c_double), ("pocket_y_min", C.c_double), ("pocket_y_max", C.c_double),
+        ("goal_x_min", C.c_double), ("goal_x_max", C.c_double),
+        ("bullet_speed", C.c_double), ("bullet_length", C.c_double), ("bullet_width", C.c_double), ("bullet_start_x", C.c_double),
+    ]
+
+
 MPCCBF_MAX_HORIZON = 32
 
 
@@ -167,6 +181,8 @@ SYMBOLS = {
     "sc_neighbor_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64, C.c_int64, C.c_int32]),
     "sc_neighbor_obstacles_batch_ws": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sc_backupcbf_solve_batch": (C.c_int, [C.POINTER(BackupCbfParams), C.c_int64] + [C.c_void_p] * 10),
+    "sc_backupcbf_rollout_batch": (C.c_int, [C.POINTER(BackupCbfParams), C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 9),
     "sc_tracking_rollout_batch": (C.c_int, [C.POINTER(TrackingParams), C.c_int64, C.c_int32] + [C.c_void_p] * 13),
     "sc_tracking_select_batch": (C.c_int, [C.POINTER(TrackingParams), C.c_int64, C.c_int32] + [C.c_void_p] * 13),
     "sc_tracking_apply_batch": (C.c_int, [C.POINTER(TrackingParams), C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 10),

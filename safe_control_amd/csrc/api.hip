@@ -40,6 +40,10 @@ hipError_t tracking_launch(const sc_tracking_params& p, long long B, int M, void
 hipError_t manip_cbfqp_launch(const sc_manip_cbfqp_params& p, long long B, int K, const void* X, const void* u_ref,
                               const void* obs, const int* n_obs, void* u_out, int* status, void* h_out, hipStream_t stream);
 
+hipError_t backupcbf_launch(const sc_backupcbf_params& p, long long B, int n_ctrl, int advance, void* X, const void* u_nom,
+                            void* bullet_x, void* u_out, int* status, int* using_backup, void* h_min, int* n_rows, double* rows_out,
+                            int* ret, int* ret_step, int step0, hipStream_t stream);
+
 size_t mpclin_lds_bytes(int N, int K, int nx, int nu, bool od = false);
 size_t mpclin_model_doubles(int nx, int nu, int N);
 bool mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const double* Be, const double* As, const double* Bs,
@@ -380,6 +384,51 @@ int sc_manip_tracking_rollout_batch(const sc_manip_tracking_params* params, int6
     hipError_t e = sc::manip_rollout_launch(*params, (long long)B, (int)M, X, waypoints, n_wp, wp_index, state_machine, goal,
                                             obs_table, u_last, ret, ret_step, traj_X, traj_U, (hipStream_t)stream);
     if (e != hipSuccess) return sc::fail_hip(e, "manipulator rollout kernel launch");
+    return SC_OK;
+}
+
+static int check_backupcbf(const sc_backupcbf_params* p, int64_t B, const void* X, const void* bullet_x, const void* u_out,
+                           const void* status_out) {
+    if (!p) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (B < 0) return sc::fail(SC_ERR_INVALID_ARGUMENT, "B < 0");
+    if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
+    if (p->n_steps < 2) return sc::fail(SC_ERR_INVALID_ARGUMENT, "n_steps < 2 (int(backup_horizon / dt))");
+    if (p->n_steps > 128) return sc::fail(SC_ERR_UNSUPPORTED, "n_steps > 128 backup states");
+    if (!(p->dt > 0) || !(p->fd_eps > 0) || !(p->a_max > 0) || !(p->v_max > 0) || !(p->backup_horizon > 0))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "dt, fd_eps, a_max, v_max, backup_horizon must be > 0");
+    if (!(p->pocket_x_min < p->pocket_x_max) || !(p->pocket_y_min < p->pocket_y_max) || !(p->half_width > 0) || !(p->hallway_length > 0))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "degenerate EvadeEnv geometry");
+    if (B > 0 && (!X || !bullet_x || !u_out || !status_out)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    return SC_OK;
+}
+
+int sc_backupcbf_solve_batch(const sc_backupcbf_params* params, int64_t B, const void* X, const void* u_nom,
+                             const void* bullet_x, void* u_out, int32_t* status_out, int32_t* using_backup_out,
+                             void* h_min_out, int32_t* n_rows_out, double* rows_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    int rc = check_backupcbf(params, B, X, bullet_x, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::backupcbf_launch(*params, (long long)B, 1, 0, const_cast<void*>(X), u_nom, const_cast<void*>(bullet_x), u_out,
+                                        status_out, using_backup_out, h_min_out, n_rows_out, rows_out, nullptr, nullptr, 0,
+                                        (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "backup-CBF kernel launch");
+    return SC_OK;
+}
+
+int sc_backupcbf_rollout_batch(const sc_backupcbf_params* params, int64_t B, int32_t n_ctrl, int32_t step_offset, void* X,
+                               void* bullet_x, void* u_out, int32_t* status_out, int32_t* using_backup_out, void* h_min_out,
+                               int32_t* ret, int32_t* ret_step, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    int rc = check_backupcbf(params, B, X, bullet_x, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (n_ctrl < 0) return sc::fail(SC_ERR_INVALID_ARGUMENT, "n_ctrl < 0");
+    if (B > 0 && (!ret || !ret_step)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    if (B == 0 || n_ctrl == 0) return SC_OK;
+    hipError_t e = sc::backupcbf_launch(*params, (long long)B, n_ctrl, 1, X, nullptr, bullet_x, u_out, status_out, using_backup_out,
+                                        h_min_out, nullptr, nullptr, ret, ret_step, step_offset, (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "backup-CBF rollout kernel launch");
     return SC_OK;
 }
 
