@@ -226,6 +226,34 @@ def manip_leg(dev, B=4096, K=3, steps=20, seed=0):
             "constrained_fraction": float(((u - tu).abs().amax(dim=1) > 1e-6).double().mean().item())}
 
 
+def backup_cbf_leg(dev, B=4096, steps=5, seed=0):
+    """Backup-CBF QP (SURVEY 8f-4) on the reference's evade scenario: B agents spread over the hallway, one shared bullet;
+    per agent a 120-state backup rollout with forward-difference sensitivities, 120 rows, exact QP (csrc/backup_cbf.hip)."""
+    import numpy as np
+    import torch
+    import safe_control_amd as sca
+    rng = np.random.default_rng(seed)
+    X = np.column_stack([rng.uniform(2, 58, B), rng.uniform(-1.4, 1.4, B), rng.uniform(-0.5, 1.5, B), rng.uniform(-0.5, 0.5, B)])
+    ctl = sca.BatchedBackupCBF(io_dtype="f32")
+    tX = torch.tensor(X, dtype=torch.float32, device=dev)
+    bx = torch.tensor(X[:, 0] - rng.uniform(-10, 25, B), dtype=torch.float32, device=dev)
+    u, st, using, hmin = ctl.solve(tX, None, bx)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        u, st, using, hmin = ctl.solve(tX, None, bx)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return {"workload": f"{B} DoubleIntegrator2D agents, Backup-CBF QP on the evade scenario (120 backup states, forward-difference "
+                        "sensitivities, <= 120 rows, 2 inputs)",
+            "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
+            "qp_solved_fraction": float((st == 0).double().mean().item()),
+            "qp_infeasible_fraction": float((st == 1).double().mean().item()),
+            "using_backup_fraction": float((using != 0).double().mean().item())}
+
+
 def linear_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
     """MPC-CBF on the reference's linear models (BASELINE config 5 names Quad3D): B agents, horizon N,
     K obstacles, one NLP per wavefront (csrc/mpc_lin.hip)."""
@@ -512,6 +540,7 @@ def main():
             res["double_integrator_mpc_cbf"] = gn_mpc_leg(dev, "DoubleIntegrator2D")
             res["quad2d_mpc_cbf"] = gn_mpc_leg(dev, "Quad2D")
             res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
+            res["backup_cbf_qp"] = backup_cbf_leg(dev)
         if ws == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(X.double().cpu().numpy(), ur.double().cpu().numpy(),
                                                ob.double().cpu().numpy(), a.cpu_seconds)
