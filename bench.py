@@ -79,13 +79,52 @@ def cpu_baseline(X, u_ref, obs, seconds):
             n += 1
         dt = time.perf_counter() - t0
         out[label] = (n * X.shape[0] / dt, nt, n)
+    # B0 of BASELINE.md section 4: the numpy oracle called agent by agent from Python -- the closest stand-in for the
+    # reference's per-call cost (its own stack, cvxpy + GUROBI per control step, is not installable here)
+    n_py, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < min(3.0, 0.25 * seconds) and n_py < X.shape[0]:
+        ocbf.solve(R.MODEL_DU, X[n_py], u_ref[n_py], obs[n_py], spec, cp, num_obs=obs.shape[1])
+        n_py += 1
+    py_rate = n_py / (time.perf_counter() - t0)
     best = "all_cores" if out["all_cores"][0] >= out["one_core"][0] else "one_core"
     v, nt, n = out[best]
     return {"value": v, "unit": "solves/s", "cores": nt, "kind": "port",
             "sample": f"{n} passes over the same {X.shape[0]}-agent x {obs.shape[1]}-obstacle batch, "
                       f"oracle/c/cbfqp_oracle.c (float64, exact active-set enumeration), OpenMP {nt} threads",
             "one_core_value": out["one_core"][0], "all_cores_value": out["all_cores"][0],
+            "python_per_agent_loop_value": py_rate, "python_per_agent_loop_sample": f"first {n_py} agents, oracle/cbf_qp.py (numpy float64), 1 thread",
             "all_cores_threads": out["all_cores"][1]}
+
+
+VALU_PEAK_GIPS = 519.0   # measured sustained f64 VALU issue rate of the chip, G wave-instructions/s (tools/micro/valu_peak.hip,
+                         # profiles/r02_valu_peak.txt: 0.507 G/s per SIMD at four waves per SIMD; 1024 SIMDs x 2.4 GHz / 4 = 614 on paper)
+
+
+def valu_roofline(run, kernel_substr, kernel_ms, note=None):
+    """VALU-issue roofline of an interior-point kernel: VALU wave-instructions per launch -- the SQ_INSTS_VALU counter of
+    the same launch configuration, collected with rocprofv3 --pmc and committed under profiles/ (the count is a property
+    of the batch: same seed, same iterates) -- over this run's measured launch time, against the measured issue peak."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_counters.json")
+        if not os.path.exists(path):
+            continue
+        try:
+            d = json.load(open(path)).get(run, {})
+        except Exception:
+            continue
+        for k, c in d.items():
+            if kernel_substr in k and "SQ_INSTS_VALU" in c:
+                insts = c["SQ_INSTS_VALU"]
+                ach = insts / (kernel_ms * 1e-3) / 1e9
+                out = {"bound": "valu_issue", "achieved": ach, "peak": VALU_PEAK_GIPS, "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GIPS,
+                       "traffic": None, "kernel": k.replace("void sc::", ""), "kernel_us": 1e3 * kernel_ms,
+                       "valu_instructions_per_launch": insts, "source": f"profiles/{rnd}_counters.json:{run}"}
+                if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_ACTIVE_INST_LDS"):
+                    out["lds_bank_conflict_fraction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_ACTIVE_INST_LDS"]
+                if note:
+                    out["note"] = note
+                return out
+    return None
 
 
 def mpc_cpu_baseline(Xn, goal, on, N, seconds):
@@ -130,6 +169,11 @@ def mpc_leg(dev, B, K, N, steps, warmup, seed=0, cpu_seconds=0.0):
     st, it = out[1], out[2]
     nbytes = ((4 + 2 + 2 + 7 * K) * 4 + 2 * 4 + 4 + 4) * B
     extra = {"cpu_baseline": mpc_cpu_baseline(Xn, goal, on, N, cpu_seconds)} if cpu_seconds > 0 else {}
+    if (B, K, N, seed) == (4096, 8, 10, 0):
+        rl = valu_roofline("mpc_sq", "mpccbf_kernel<10, 8>", ms, note="4096 problems = two rounds of 2048 resident waves; the launch ends with its "
+                           "slowest problem (max 67 interior-point iterations against a mean of 18)")
+        if rl:
+            extra["roofline"] = rl
     return {**extra, "workload": f"{B}-agent batch DynamicUnicycle2D MPC-CBF, horizon N={N}, {K} obstacles (BASELINE configs[2])",
             "value": B * steps / wall, "unit": "solves/s", "steps": steps, "kernel_ms": ms,
             "dtype": "f64", "storage": "f32",
@@ -425,10 +469,11 @@ def main():
                               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                               "config": {"workload": r["workload"], "agents_per_gpu": B, "obstacles": K,
                                          "horizon": a.horizon, "storage": "f32"},
-                              "roofline": {"bound": "hbm", "achieved": r["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                              "roofline": r.get("roofline") or {"bound": "hbm", "achieved": r["achieved_GBs"], "peak": HBM_PEAK_GBS,
                                            "unit": "GB/s", "frac": r["achieved_GBs"] / HBM_PEAK_GBS, "traffic": None,
                                            "kernel": "mpccbf_kernel", "kernel_us": 1e3 * r["kernel_ms"],
-                                           "note": "ALU/LDS-bound interior-point iterations; HBM fraction reported for completeness"},
+                                           "note": "ALU/LDS-bound interior-point iterations; no VALU counter profile committed for this "
+                                                   "configuration, HBM fraction reported for completeness"},
                               "cpu_baseline": r.get("cpu_baseline"), "mpc": r}), flush=True)
         if ws > 1:
             dist.destroy_process_group()
@@ -499,6 +544,9 @@ def main():
 
     st = out[1]
     n_opt = int((st == 0).sum().item())
+    # N > 1: the one collective of the design (RCCL all-gather of the agent states, BASELINE configs[3]) is measured in the
+    # same run, on every rank, so that a scaling sweep of the default command covers the exchange path as well
+    coll = kb_c3bf_workload(a, dev, ws, rank, backend, collect=True, steps_override=20) if ws > 1 else None
     if rank == 0:
         total = B * ws * a.steps
         alg_bytes = (BYTES_IN_CBFQP(K, es) + BYTES_OUT_CBFQP(K, es)) * B
@@ -525,6 +573,8 @@ def main():
                 res["roofline"]["traffic"] = json.load(open(pmc)).get(f"cbfqp_B{B}_K{K}_{a.io}")
             except Exception:
                 pass
+        if coll is not None:
+            res["collective_leg"] = coll
         if ws == 1 and not a.no_sweep:
             res["sweep"] = sweep(ctl, dev, td, es, K)
         if ws == 1 and not a.no_mpc:
@@ -635,7 +685,7 @@ def hetero_fleet_workload(a, dev, ws, rank, backend):
                           "cpu_baseline": None}), flush=True)
 
 
-def kb_c3bf_workload(a, dev, ws, rank, backend):
+def kb_c3bf_workload(a, dev, ws, rank, backend, collect=False, steps_override=None):
     """BASELINE configs[3]: 16384 KinematicBicycle2D C3BF agents in total, sharded over the ranks (strong scaling);
     a step = all-gather of the agent states (RCCL over xGMI; a no-op on one rank) -> K = 16 nearest other agents as
     moving circular obstacles (neighbour kernel) -> C3BF CBF-QP for the local shard."""
@@ -658,23 +708,32 @@ def kb_c3bf_workload(a, dev, ws, rank, backend):
     out = (torch.empty((Bl, 2), dtype=torch.float32, device=dev), torch.empty((Bl,), dtype=torch.int32, device=dev),
            torch.empty((Bl, K), dtype=torch.float32, device=dev))
 
-    def step():
-        obs = sharding.neighbor_obstacles(X, n_agents, K, 0.3)
-        ctl.solve(X, ur, obs, out=out)
+    ex = sharding.NeighborExchange(n_agents, K, 0.3, nx=4, dtype=torch.float32, device=dev)   # persistent buffers
 
+    def step():
+        ctl.solve(X, ur, ex.step(X), out=out)
+
+    steps = steps_override or a.steps
     for _ in range(max(a.warmup, 1)):
         step()
     if ws > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     if ws > 1:
         dist.barrier()
     elapsed = sharding.max_over_ranks(t1 - t0, device=dev if backend == "nccl" else None)
+    if collect:
+        nb = (16 + 8 + 7 * K * 4 + 8 + 4 + K * 4) * n_agents
+        return {"workload": "16384-agent KinematicBicycle2D C3BF, 16 nearest other agents as moving obstacles (BASELINE configs[3]): "
+                            "all-gather of the states (RCCL) -> neighbour kernel -> CBF-QP per step",
+                "value": n_agents * steps / elapsed, "unit": "solves/s", "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
+                "scaling": "strong", "agents_total": n_agents, "all_gather_bytes_per_step": n_agents * 16,
+                "equal_shards": bool(ex.equal), "achieved_GBs": nb * steps / elapsed / 1e9}
     if rank == 0:
         nbytes = (16 + 8 + 7 * K * 4 + 8 + 4 + K * 4) * n_agents
         print(json.dumps({"metric": "QP solves/sec (batched agents)", "value": n_agents * a.steps / elapsed, "unit": "solves/s",

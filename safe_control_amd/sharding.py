@@ -141,3 +141,62 @@ def neighbor_obstacles(X_local, n_agents, K, neighbour_radius):
                                             obs.data_ptr(), ws_.data_ptr(), nbytes, stream)
     _lib.check(rc, "sc_neighbor_obstacles_batch_ws")
     return obs
+
+
+def _all_gather_into(out, inp):
+    """all_gather_into_tensor; device tensors under the gloo backend (the 1-GPU control-flow test only) go through the host."""
+    if inp.is_cuda and dist.get_backend() == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu())
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+
+
+class NeighborExchange:
+    """Persistent buffers for the per-step neighbour-state exchange + selection (BASELINE config 4): the all-gather
+    destination, the obstacle rows and the selection workspace are allocated once; with equal shards the all-gather writes
+    straight into the final [n_agents, nx] layout (``all_gather_into_tensor``, no padding, no concatenation), with ragged
+    shards into a padded buffer whose valid rows are packed by one index_select on a precomputed index."""
+
+    def __init__(self, n_agents, K, neighbour_radius, nx=4, dtype=torch.float32, device="cuda"):
+        from . import _lib
+        self.ws, self.rank = world()
+        self.n_agents, self.K, self.radius = int(n_agents), int(K), float(neighbour_radius)
+        self.lo, self.hi = agent_range(n_agents, self.ws, self.rank)
+        self.sizes = shard_sizes(n_agents, self.ws)
+        self.equal = len(set(self.sizes)) == 1
+        m = max(self.sizes)
+        dev = torch.device(device)
+        self.X_all = torch.empty((n_agents, nx), dtype=dtype, device=dev)
+        if self.ws > 1 and not self.equal:
+            self.pad_in = torch.zeros((m, nx), dtype=dtype, device=dev)
+            self.pad_out = torch.empty((self.ws * m, nx), dtype=dtype, device=dev)
+            self.pack = torch.cat([torch.arange(r * m, r * m + self.sizes[r]) for r in range(self.ws)]).to(dev)
+        self.obs = torch.empty((self.hi - self.lo, K, 7), dtype=dtype, device=dev)
+        self.io = _lib.DTYPE_F32 if dtype == torch.float32 else _lib.DTYPE_F64
+        self._lib = _lib.load()
+        self.nbytes = int(self._lib.sc_neighbor_workspace_bytes(self.io, n_agents, self.hi - self.lo, K))
+        self.work = torch.empty((max(self.nbytes, 8),), dtype=torch.uint8, device=dev)
+
+    def gather(self, X_local):
+        """All agents' states on every rank (one RCCL all-gather; a copy on one rank)."""
+        if self.ws == 1:
+            self.X_all.copy_(X_local)
+        elif self.equal:
+            _all_gather_into(self.X_all, X_local.contiguous())
+        else:
+            self.pad_in[: X_local.shape[0]] = X_local
+            _all_gather_into(self.pad_out, self.pad_in)
+            torch.index_select(self.pad_out, 0, self.pack, out=self.X_all)
+        return self.X_all
+
+    def step(self, X_local):
+        """gather + K nearest other agents as moving obstacles for the local shard -> obs [B_local, K, 7]."""
+        from . import _lib
+        X_all = self.gather(X_local)
+        stream = torch.cuda.current_stream(X_local.device).cuda_stream
+        rc = self._lib.sc_neighbor_obstacles_batch_ws(self.io, self.n_agents, self.lo, self.hi - self.lo, self.K, self.radius,
+                                                      X_all.data_ptr(), self.obs.data_ptr(), self.work.data_ptr(), self.nbytes, stream)
+        _lib.check(rc, "sc_neighbor_obstacles_batch_ws")
+        return self.obs

@@ -45,6 +45,13 @@ def _worker(rank, world, port, n_agents, q):
         # neighbour-state exchange: everyone sees every agent's state, in agent order
         allx = sharding.all_gather_states(local, n_agents)
         assert torch.equal(allx, torch.arange(n_agents * 4, dtype=torch.float64).reshape(n_agents, 4))
+        # the persistent-buffer exchange used by bench.py's collective leg: same result, equal and ragged shards, repeated steps
+        ex = sharding.NeighborExchange(n_agents, 4, 0.3, nx=4, dtype=torch.float64, device="cpu")
+        assert ex.equal == (n_agents % world == 0)
+        for rep in range(2):
+            got = ex.gather(local + rep)
+            assert torch.equal(got, torch.arange(n_agents * 4, dtype=torch.float64).reshape(n_agents, 4) + rep)
+            assert got.data_ptr() == ex.X_all.data_ptr()                       # written in place, no new allocation
         # shared obstacle table
         table = torch.full((5, 7), float(rank))
         sharding.broadcast_obstacle_table(table, src=0)

@@ -26,7 +26,7 @@ src = os.path.join(ROOT, "gpurun_out", f"profiles_{rnd}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-OURS = ("cbfqp", "mpccbf", "tracking_rollout", "tracking_coop", "neighbor_kernel", "odcbfqp", "mpclin", "mpcgn")   # manip_cbfqp matches "cbfqp"
+OURS = ("cbfqp", "mpccbf", "tracking_rollout", "tracking_coop", "tracking_select", "tracking_apply", "neighbor_kernel", "odcbfqp", "mpclin", "mpcgn", "backupcbf")   # manip_cbfqp matches "cbfqp"
 
 
 def counters(path):
@@ -115,4 +115,7 @@ for tag, B, io, comp in (("bench", 4096, "f32", "f64"), ("big_4096", 4096, "f32"
     traffic[key + "_detail"] = {"FETCH_SIZE_KiB": f_, "WRITE_SIZE_KiB": w_, "algorithmic_bytes": (alg_read + alg_write) * B,
                                 "traffic_over_algorithmic": byt / ((alg_read + alg_write) * B)}
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+vp = os.path.join(src, "valu_peak.txt")
+if os.path.exists(vp):
+    open(os.path.join(dst, f"{rnd}_valu_peak.txt"), "w").write(open(vp).read())
 print(json.dumps(traffic, indent=1, sort_keys=True))
