@@ -521,6 +521,46 @@ int sc_backupcbf_rollout_batch(const sc_backupcbf_params* params, int64_t B, int
                                void* X, void* bullet_x, void* u_out, int32_t* status_out, int32_t* using_backup_out,
                                void* h_min_out, int32_t* ret, int32_t* ret_step, void* stream);
 
+/* ---- control_step around the solve for Quad2D / Quad3D (SURVEY 8f-1 over the 8f-3 models) ----------------------------------
+ * The split of sc_tracking_select_batch / sc_tracking_apply_batch for the two quadrotor models, whose states (6 / 12), inputs
+ * (2 / 4) and goals (2-D / 3-D) do not fit the 4-state kernels: LocalTrackingController.control_step (tracking.py:559-668) with
+ * update_goal (:497-535; Quad2D skips 'rotate', Quad3D waypoints are [x, y, z]), the K nearest obstacles
+ * (get_nearest_unpassed_obs :345-403, angle_unpassed = 2 pi for both), nominal_input / stop / has_stopped / rotate_to / step
+ * of robots/quad2D.py:83-164 and robots/quad3D.py:113-257.  Between the two calls the caller runs the position controller
+ * (sc_mpcgn_solve_batch for Quad2D, sc_mpclin_solve_batch for Quad3D) and passes u_ref through for agents with track_out == 0
+ * (mpc_cbf.py:379-381).
+ */
+#define SC_QUADTRACK_QUAD2D 0
+#define SC_QUADTRACK_QUAD3D 1
+
+typedef struct sc_quadtrack_params {
+    int32_t model;               /* SC_QUADTRACK_QUAD2D: X [B,6], u [B,2], goal_out [B,2];  _QUAD3D: X [B,12], u [B,4], goal_out [B,3] */
+    int32_t io_dtype;            /* SC_DTYPE_F32 / SC_DTYPE_F64: element type of every float array                          */
+    int32_t max_waypoints;       /* W: rows of `waypoints` per agent, [B,W,3] (or [W,3] when waypoints_shared)              */
+    int32_t waypoints_shared;
+    int32_t enable_rotation;     /* LocalTrackingController(enable_rotation=...)                                            */
+    int32_t num_constraints;     /* K <= SC_TRACKING_MAX_CONSTRAINTS obstacle rows handed to the controller                 */
+    int32_t reserved0, reserved1;
+    double  dt, reached_threshold, rotation_threshold, robot_radius;   /* 0.05, 0.3, 0.1 (tracking.py:46-54), robot_spec     */
+    double  mass;                /* Quad2D 1.0 (quad2D.py:41), Quad3D 3.0 (quad3D.py:50)                                    */
+    double  inertia, f_min, f_max;                                   /* Quad2D (quad2D.py:42-44)                            */
+    double  Ix, Iy, Iz, L, nu, u_min, u_max;                         /* Quad3D (quad3D.py:51-59)                            */
+} sc_quadtrack_params;
+
+/* X [B,nx]; waypoints, n_wp, wp_index, state_machine, ret as in sc_tracking_select_batch; goal [B,4] in/out = (gx, gy, gz,
+ * valid); obs_table [M,7]; obs_out [B,K,7] (missing rows padded [1000,1000,0,..]); goal_out [B,ng] (the own position when
+ * the agent has no goal); u_ref_out [B,nu]; track_out [B]. */
+int sc_quadtrack_select_batch(const sc_quadtrack_params* params, int64_t B, int32_t M,
+                              const void* X, const void* waypoints, const int32_t* n_wp,
+                              int32_t* wp_index, int32_t* state_machine, void* goal,
+                              const void* obs_table, const int32_t* ret,
+                              void* obs_out, void* goal_out, void* u_ref_out, int32_t* track_out, void* stream);
+
+/* X [B,nx] in/out; u [B,nu] the input to apply; u_last [B,nu]; ret / ret_step as in sc_tracking_apply_batch. */
+int sc_quadtrack_apply_batch(const sc_quadtrack_params* params, int64_t B, int32_t M, int32_t step_index,
+                             void* X, const int32_t* state_machine, const void* goal, const void* obs_table,
+                             const void* u, void* u_last, int32_t* ret, int32_t* ret_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

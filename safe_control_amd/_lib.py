@@ -44,6 +44,18 @@ class CbfQpParams(C.Structure):
     ]
 
 
+class QuadTrackParams(C.Structure):
+    """Mirror of ``sc_quadtrack_params``."""
+    _fields_ = [
+        ("model", C.c_int32), ("io_dtype", C.c_int32), ("max_waypoints", C.c_int32), ("waypoints_shared", C.c_int32),
+        ("enable_rotation", C.c_int32), ("num_constraints", C.c_int32), ("reserved0", C.c_int32), ("reserved1", C.c_int32),
+        ("dt", C.c_double), ("reached_threshold", C.c_double), ("rotation_threshold", C.c_double), ("robot_radius", C.c_double),
+        ("mass", C.c_double), ("inertia", C.c_double), ("f_min", C.c_double), ("f_max", C.c_double),
+        ("Ix", C.c_double), ("Iy", C.c_double), ("Iz", C.c_double), ("L", C.c_double), ("nu", C.c_double),
+        ("u_min", C.c_double), ("u_max", C.c_double),
+    ]
+
+
 class BackupCbfParams(C.Structure):
     """Mirror of ``sc_backupcbf_params``."""
     _fields_ = [
@@ -181,6 +193,8 @@ SYMBOLS = {
     "sc_neighbor_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64, C.c_int64, C.c_int32]),
     "sc_neighbor_obstacles_batch_ws": (C.c_int, [C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_double,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sc_quadtrack_select_batch": (C.c_int, [C.POINTER(QuadTrackParams), C.c_int64, C.c_int32] + [C.c_void_p] * 13),
+    "sc_quadtrack_apply_batch": (C.c_int, [C.POINTER(QuadTrackParams), C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 9),
     "sc_backupcbf_solve_batch": (C.c_int, [C.POINTER(BackupCbfParams), C.c_int64] + [C.c_void_p] * 10),
     "sc_backupcbf_rollout_batch": (C.c_int, [C.POINTER(BackupCbfParams), C.c_int64, C.c_int32, C.c_int32] + [C.c_void_p] * 9),
     "sc_tracking_rollout_batch": (C.c_int, [C.POINTER(TrackingParams), C.c_int64, C.c_int32] + [C.c_void_p] * 13),

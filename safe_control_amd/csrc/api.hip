@@ -40,6 +40,11 @@ hipError_t tracking_launch(const sc_tracking_params& p, long long B, int M, void
 hipError_t manip_cbfqp_launch(const sc_manip_cbfqp_params& p, long long B, int K, const void* X, const void* u_ref,
                               const void* obs, const int* n_obs, void* u_out, int* status, void* h_out, hipStream_t stream);
 
+hipError_t quadtrack_select_launch(const sc_quadtrack_params& p, long long B, int M, const void* X, const void* wps, const int* n_wp,
+                                   int* wp_index, int* sm, void* goal, const void* obs_table, const int* ret, void* obs_out,
+                                   void* goal_out, void* u_ref_out, int* track_out, hipStream_t stream);
+hipError_t quadtrack_apply_launch(const sc_quadtrack_params& p, long long B, int M, int step_index, void* X, const int* sm, const void* goal,
+                                  const void* obs_table, const void* u, void* u_last, int* ret, int* ret_step, hipStream_t stream);
 hipError_t backupcbf_launch(const sc_backupcbf_params& p, long long B, int n_ctrl, int advance, void* X, const void* u_nom,
                             void* bullet_x, void* u_out, int* status, int* using_backup, void* h_min, int* n_rows, double* rows_out,
                             int* ret, int* ret_step, int step0, hipStream_t stream);
@@ -384,6 +389,52 @@ int sc_manip_tracking_rollout_batch(const sc_manip_tracking_params* params, int6
     hipError_t e = sc::manip_rollout_launch(*params, (long long)B, (int)M, X, waypoints, n_wp, wp_index, state_machine, goal,
                                             obs_table, u_last, ret, ret_step, traj_X, traj_U, (hipStream_t)stream);
     if (e != hipSuccess) return sc::fail_hip(e, "manipulator rollout kernel launch");
+    return SC_OK;
+}
+
+static int check_quadtrack(const sc_quadtrack_params* p, int64_t B, int32_t M) {
+    if (!p) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (B < 0 || M < 0) return sc::fail(SC_ERR_INVALID_ARGUMENT, "B < 0 or M < 0");
+    if (p->model != SC_QUADTRACK_QUAD2D && p->model != SC_QUADTRACK_QUAD3D) return sc::fail(SC_ERR_INVALID_ARGUMENT, "model must be SC_QUADTRACK_QUAD2D or _QUAD3D");
+    if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64) return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
+    if (p->num_constraints < 1 || p->num_constraints > SC_TRACKING_MAX_CONSTRAINTS) return sc::fail(SC_ERR_UNSUPPORTED, "num_constraints outside 1..SC_TRACKING_MAX_CONSTRAINTS");
+    if (p->max_waypoints < 1) return sc::fail(SC_ERR_INVALID_ARGUMENT, "max_waypoints < 1");
+    if ((size_t)M * 7 * 8 > 64 * 1024) return sc::fail(SC_ERR_UNSUPPORTED, "obstacle table does not fit 64 KiB of LDS");
+    if (!(p->dt > 0) || !(p->mass > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "dt and mass must be > 0");
+    if (p->model == SC_QUADTRACK_QUAD2D && (!(p->inertia > 0) || !(p->robot_radius > 0))) return sc::fail(SC_ERR_INVALID_ARGUMENT, "Quad2D: inertia and radius must be > 0");
+    if (p->model == SC_QUADTRACK_QUAD3D && (!(p->Ix > 0) || !(p->Iy > 0) || !(p->Iz > 0) || !(p->L > 0) || !(p->nu > 0)))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "Quad3D: Ix, Iy, Iz, L, nu must be > 0");
+    return SC_OK;
+}
+
+int sc_quadtrack_select_batch(const sc_quadtrack_params* params, int64_t B, int32_t M, const void* X, const void* waypoints,
+                              const int32_t* n_wp, int32_t* wp_index, int32_t* state_machine, void* goal, const void* obs_table,
+                              const int32_t* ret, void* obs_out, void* goal_out, void* u_ref_out, int32_t* track_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    int rc = check_quadtrack(params, B, M);
+    if (rc != SC_OK) return rc;
+    if (B > 0 && (!X || !waypoints || !n_wp || !wp_index || !state_machine || !goal || !ret || !obs_out || !goal_out || !u_ref_out ||
+                  !track_out || (M > 0 && !obs_table)))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::quadtrack_select_launch(*params, (long long)B, (int)M, X, waypoints, n_wp, wp_index, state_machine, goal, obs_table,
+                                               ret, obs_out, goal_out, u_ref_out, track_out, (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "quadrotor select kernel launch");
+    return SC_OK;
+}
+
+int sc_quadtrack_apply_batch(const sc_quadtrack_params* params, int64_t B, int32_t M, int32_t step_index, void* X,
+                             const int32_t* state_machine, const void* goal, const void* obs_table, const void* u, void* u_last,
+                             int32_t* ret, int32_t* ret_step, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    int rc = check_quadtrack(params, B, M);
+    if (rc != SC_OK) return rc;
+    if (B > 0 && (!X || !state_machine || !goal || !u || !u_last || !ret || !ret_step || (M > 0 && !obs_table)))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::quadtrack_apply_launch(*params, (long long)B, (int)M, (int)step_index, X, state_machine, goal, obs_table, u, u_last,
+                                              ret, ret_step, (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "quadrotor apply kernel launch");
     return SC_OK;
 }
 

@@ -33,6 +33,11 @@ class BatchedTrackingController:
     ``LocalTrackingController.control_step`` does for one robot.
     """
 
+    def __new__(cls, X0, robot_spec, *args, **kwargs):
+        if cls is BatchedTrackingController and robot_spec.get("model") in ("Quad2D", "Quad3D"):
+            return super().__new__(BatchedQuadTrackingController)      # 6 / 12 states, 2 / 4 inputs: its own select / apply kernels
+        return super().__new__(cls)
+
     def __init__(self, X0, robot_spec, controller_type=None, dt=0.05, enable_rotation=True, obs=None,
                  dyn_obs=False, io_dtype="f64", device="cuda:0"):
         import torch
@@ -280,3 +285,188 @@ class BatchedTrackingController:
             if bool((self.ret != 0).all().item()):
                 break
         return self.ret
+
+
+class BatchedQuadTrackingController(BatchedTrackingController):
+    """The batched closed loop for Quad2D (examples/test_tracking.py --model quad) and Quad3D (--model quad3d) with the
+    reference's default position controller ``mpc_cbf``: per step  sc_quadtrack_select_batch -> one MPC-CBF launch for the
+    batch (csrc/mpc_gn.hip / csrc/mpc_lin.hip) -> sc_quadtrack_apply_batch.  ``X0`` rows follow tracking.py:80-93 (Quad2D:
+    [x, z(, .)] or six states; Quad3D: [x, y], [x, y, yaw], [x, y, z, yaw] or twelve states); waypoints are [x, y, z] rows for
+    Quad3D (the example's third column -- a heading for the planar models -- is the altitude goal there, tracking.py:501-502)."""
+
+    def __init__(self, X0, robot_spec, controller_type=None, dt=0.05, enable_rotation=True, obs=None, dyn_obs=False,
+                 io_dtype="f64", device="cuda:0"):
+        import torch
+        self.torch = torch
+        controller_type = controller_type or {"pos": "mpc_cbf"}
+        self.pos_controller_type = controller_type.get("pos", "mpc_cbf")
+        if self.pos_controller_type != "mpc_cbf":
+            raise ValueError("Quad2D / Quad3D closed loop: position controller 'mpc_cbf' (the reference's default)")
+        if dyn_obs:
+            raise ValueError("moving obstacle tables are stepped by the fused 'cbf_qp' rollout only")
+        self.model = robot_spec["model"]
+        self.q3 = self.model == "Quad3D"
+        self.robot_spec = complete_robot_spec(robot_spec)
+        self.robot_spec.setdefault("exploration", False)
+        self.integrator = False
+        self.dt, self.enable_rotation, self.dyn_obs = float(dt), bool(enable_rotation), False
+        self.device = torch.device(device)
+        self.io_dtype = {"f32": _lib.DTYPE_F32, "f64": _lib.DTYPE_F64}[io_dtype]
+        self.tdtype = torch.float32 if io_dtype == "f32" else torch.float64
+        self.num_constraints = int(self.robot_spec.get("num_constraints", 10))
+        self.reached_threshold = float(self.robot_spec.get("reached_threshold", 0.3))
+        self.rotation_threshold = 0.1
+        self.fov_angle = math.radians(float(self.robot_spec.get("fov_angle", 70.0)))
+        self._lib = _lib.load()
+        self.nx, self.nu, self.ng = (12, 4, 3) if self.q3 else (6, 2, 2)
+        X0 = np.asarray(X0, dtype=np.float64)
+        if X0.ndim == 1:
+            X0 = X0[None, :]
+        B = X0.shape[0]
+        X = np.zeros((B, self.nx))
+        if not self.q3:                                        # tracking.py:80-84
+            if X0.shape[1] in (2, 3):
+                X[:, :2] = X0[:, :2]
+            elif X0.shape[1] == 6:
+                X = X0.copy()
+            else:
+                raise ValueError("Invalid initial state dimension for Quad2D")
+        else:                                                  # tracking.py:85-93
+            if X0.shape[1] == 2:
+                X[:, :2] = X0
+            elif X0.shape[1] == 3:
+                X[:, 0], X[:, 1], X[:, 5] = X0[:, 0], X0[:, 1], X0[:, 2]
+            elif X0.shape[1] == 4:
+                X[:, 0], X[:, 1], X[:, 2], X[:, 5] = X0[:, 0], X0[:, 1], X0[:, 2], X0[:, 3]
+            elif X0.shape[1] == 12:
+                X = X0.copy()
+            else:
+                raise ValueError("Invalid initial state dimension for Quad3D")
+        self.B = B
+        t = lambda a, dt_=None: torch.tensor(a, dtype=dt_ or self.tdtype, device=self.device)
+        self.X = t(X)
+        self.state_machine = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self.current_goal_index = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self.goal = torch.zeros((B, 4), dtype=self.tdtype, device=self.device)            # gx, gy, gz, valid
+        self.ret = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self.ret_step = torch.full((B,), -1, dtype=torch.int32, device=self.device)
+        self.u_pos = torch.zeros((B, self.nu), dtype=self.tdtype, device=self.device)
+        self.set_obstacles(obs)
+        self.waypoints = self.n_wp = None
+        self.steps_done = 0
+        if self.q3:
+            from .position_control.mpc_cbf_linear import BatchedLinearMPCCBF as cls
+        else:
+            from .position_control.mpc_cbf_gn import BatchedGnMPCCBF as cls
+        self.mpc = cls(self.robot_spec, dt=self.dt, io_dtype=io_dtype)
+        self.u_prev = torch.zeros((B, self.nu), dtype=self.tdtype, device=self.device)
+        self.mpc_status = torch.zeros(B, dtype=torch.int32, device=self.device)
+
+    def set_waypoints(self, waypoints):
+        """set_waypoints / filter_waypoints / first update_goal (tracking.py:197-262, 497-535) on the host."""
+        torch = self.torch
+        X = self.X.double().cpu().numpy()
+        npos = 3 if self.q3 else 2
+        shared = (isinstance(waypoints, np.ndarray) and waypoints.ndim == 2) or \
+            (isinstance(waypoints, (list, tuple)) and len(waypoints) > 0 and np.ndim(waypoints[0]) == 1)
+        lists = [np.asarray(waypoints, dtype=np.float64)] * self.B if shared else [np.asarray(w, dtype=np.float64) for w in waypoints]
+        filt = []
+        for i in range(self.B):
+            wp = lists[i]
+            if wp.shape[1] < npos:
+                raise ValueError(f"{self.model} waypoints need {npos} columns")
+            if len(wp) >= 2:
+                aug = np.vstack((X[i, :npos], wp[:, :npos]))
+                dist = np.linalg.norm(np.diff(aug, axis=0), axis=1)
+                wp = aug[np.concatenate(([False], dist >= self.reached_threshold))]
+            w3 = np.zeros((len(wp), 3))
+            w3[:, :npos] = np.asarray(wp, dtype=np.float64)[:, :npos]
+            filt.append(w3)
+        W = max(1, max(len(w) for w in filt))
+        wps = np.zeros((self.B, W, 3)); n_wp = np.zeros(self.B, dtype=np.int32); idx = np.zeros(self.B, dtype=np.int32)
+        sm = np.zeros(self.B, dtype=np.int32); goal = np.zeros((self.B, 4))
+        for i in range(self.B):
+            w = filt[i]
+            n_wp[i] = len(w)
+            wps[i, : len(w)] = w
+            g = None
+            if len(w) > 0:
+                if np.linalg.norm(X[i, :2] - w[0, :2]) < self.reached_threshold:
+                    idx[i] = 1
+                if idx[i] < len(w):
+                    g = w[idx[i]]
+            if g is not None:
+                ang = math.atan2(g[1] - X[i, 1], g[0] - X[i, 0])
+                # is_in_fov (robots/robot.py:854-872): always True for Quad2D; yaw = X[5] for Quad3D (robot.py:451-452)
+                in_fov = (not self.q3) or abs(_wrap(ang - X[i, 5])) <= self.fov_angle / 2
+                if not in_fov:
+                    if self.robot_spec["exploration"]:
+                        sm[i] = _lib.SM_ROTATE
+                        goal[i] = [g[0], g[1], g[2], 1.0]
+                    else:
+                        sm[i] = _lib.SM_STOP
+                else:
+                    sm[i] = _lib.SM_TRACK
+                    goal[i] = [g[0], g[1], g[2], 1.0]
+        self.waypoints = torch.tensor(wps, dtype=self.tdtype, device=self.device).contiguous()
+        self.n_wp = torch.tensor(n_wp, dtype=torch.int32, device=self.device)
+        self.current_goal_index = torch.tensor(idx, dtype=torch.int32, device=self.device)
+        self.state_machine = torch.tensor(sm, dtype=torch.int32, device=self.device)
+        self.goal = torch.tensor(goal, dtype=self.tdtype, device=self.device).contiguous()
+        self.ret.zero_()
+        self.ret_step.fill_(-1)
+
+    def _params(self, n_steps=1):
+        rs = self.robot_spec
+        p = _lib.QuadTrackParams()
+        p.model = 1 if self.q3 else 0
+        p.io_dtype = self.io_dtype
+        p.max_waypoints = int(self.waypoints.shape[1])
+        p.waypoints_shared = 0
+        p.enable_rotation = 1 if self.enable_rotation else 0
+        p.num_constraints = self.num_constraints
+        p.dt, p.reached_threshold, p.rotation_threshold = self.dt, self.reached_threshold, self.rotation_threshold
+        p.robot_radius = float(rs["radius"])
+        p.mass = float(rs["mass"])
+        if self.q3:
+            p.Ix, p.Iy, p.Iz, p.L, p.nu = (float(rs[k]) for k in ("Ix", "Iy", "Iz", "L", "nu"))
+            p.u_min, p.u_max = float(rs["u_min"]), float(rs["u_max"])
+        else:
+            p.inertia, p.f_min, p.f_max = float(rs["inertia"]), float(rs["f_min"]), float(rs["f_max"])
+        return p
+
+    def control_step(self, n=1, record=False):
+        torch = self.torch
+        if self.waypoints is None:
+            raise RuntimeError("call set_waypoints first")
+        p = self._params()
+        M, K, B = int(self.obs.shape[0]), self.num_constraints, self.B
+        obs_sel = torch.empty((B, K, 7), dtype=self.tdtype, device=self.device)
+        goal_c = torch.empty((B, self.ng), dtype=self.tdtype, device=self.device)
+        u_ref = torch.empty((B, self.nu), dtype=self.tdtype, device=self.device)
+        track = torch.empty(B, dtype=torch.int32, device=self.device)
+        tX = torch.empty((n, B, self.nx), dtype=self.tdtype, device=self.device) if record else None
+        tU = torch.empty((n, B, self.nu), dtype=self.tdtype, device=self.device) if record else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        obs_ptr = self.obs.data_ptr() if M else None
+        for k in range(n):
+            rc = self._lib.sc_quadtrack_select_batch(
+                C.byref(p), B, M, self.X.data_ptr(), self.waypoints.data_ptr(), self.n_wp.data_ptr(), self.current_goal_index.data_ptr(),
+                self.state_machine.data_ptr(), self.goal.data_ptr(), obs_ptr, self.ret.data_ptr(), obs_sel.data_ptr(), goal_c.data_ptr(),
+                u_ref.data_ptr(), track.data_ptr(), stream)
+            _lib.check(rc, "sc_quadtrack_select_batch")
+            out = self.mpc.solve(self.X, self.u_prev, goal_c, obs_sel)
+            u_mpc, st = out[0], out[1]
+            tr = (track != 0).unsqueeze(1)
+            u = torch.where(tr, u_mpc, u_ref).contiguous()                       # mpc_cbf.py:379-381: u_ref passes through outside 'track'
+            self.u_prev = torch.where(tr, u_mpc, self.u_prev).contiguous()
+            self.mpc_status = torch.where(track != 0, st, self.mpc_status)
+            rc = self._lib.sc_quadtrack_apply_batch(
+                C.byref(p), B, M, self.steps_done + k, self.X.data_ptr(), self.state_machine.data_ptr(), self.goal.data_ptr(), obs_ptr,
+                u.data_ptr(), self.u_pos.data_ptr(), self.ret.data_ptr(), self.ret_step.data_ptr(), stream)
+            _lib.check(rc, "sc_quadtrack_apply_batch")
+            if record:
+                tX[k] = self.X
+                tU[k] = self.u_pos
+        self.steps_done += n
+        return (self.ret, tX, tU) if record else self.ret

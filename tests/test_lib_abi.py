@@ -137,10 +137,11 @@ def test_header_is_plain_c(tmp_path):
                    '  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sc_cbfqp_params), sizeof(sc_mpccbf_params), sizeof(sc_tracking_params),\n'
                    '         sizeof(sc_manip_cbfqp_params), sizeof(sc_mpclin_params), sizeof(sc_mpcgn_params), sizeof(sc_odmpccbf_params));\n'
                    '  printf("%zu %zu %zu\\n", sizeof(sc_manip_tracking_params), sizeof(sc_odcbfqp_params), sizeof(sc_backupcbf_params));\n'
+                   '  printf("%zu\\n", sizeof(sc_quadtrack_params));\n'
                    '  return 0;\n}\n')
     exe = tmp_path / "abi"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
     sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     mirrors = [_lib.CbfQpParams, _lib.MpcCbfParams, _lib.TrackingParams, _lib.ManipCbfQpParams, _lib.MpcLinParams, _lib.MpcGnParams,
-               _lib.OdMpcCbfParams, _lib.ManipTrackingParams, _lib.OdCbfQpParams, _lib.BackupCbfParams]
+               _lib.OdMpcCbfParams, _lib.ManipTrackingParams, _lib.OdCbfQpParams, _lib.BackupCbfParams, _lib.QuadTrackParams]
     assert sizes == [C.sizeof(m) for m in mirrors]
