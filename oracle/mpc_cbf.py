@@ -380,6 +380,9 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
                 accepted = True
                 break
             alpha *= 0.5
+        if P.get("trace") is not None:
+            P["trace"].append(dict(it=it, e_opt=e_opt, r_d=float(np.max(np.abs(r_d))), r_p=float(np.max(np.abs(r_p))), mu=mu, delta=delta,
+                                   alpha=alpha if accepted else 0.0, ap=ap, ad=ad, dz=float(np.max(np.abs(dz))), z=z.copy()))
         if not accepted:
             break
         z, s = z + alpha * dz, s + alpha * ds
