@@ -35,6 +35,10 @@ static inline long long sc_coop_max_agents() {             // SC_COOP_MAX_AGENTS
     static const long long v = [] { const char* e = getenv("SC_COOP_MAX_AGENTS"); return e ? atoll(e) : (long long)SC_COOP_MAX_AGENTS; }();
     return v;
 }
+static inline bool sc_two_pass() {                         // SC_CBFQP_TWO_PASS=0: the single-launch register kernel for every model
+    static const bool v = [] { const char* e = getenv("SC_CBFQP_TWO_PASS"); return !(e && e[0] == '0'); }();
+    return v;
+}
 static inline bool sc_force_lds_kernel() {
     static const bool v = [] { const char* e = getenv("SC_FORCE_LDS_KERNEL"); return e && e[0] == '1'; }();
     return v;
@@ -84,7 +88,13 @@ template <typename TIO> struct vec4io;
 template <> struct vec4io<float> { using type = float4; static constexpr int N = 4; };
 template <> struct vec4io<double> { using type = double2; static constexpr int N = 2; };
 
-template <typename TIO, typename TC, int KMAX, int MODEL>
+// PASS (DynamicUnicycle2D with f64 arithmetic only; 0 everywhere else = the plain one-launch kernel):
+//   1  circles-only fast pass: a wave that finds any obstacle flag != 0 among its agents' rows writes SC_STATUS_PENDING for
+//      them and leaves; every other wave runs a body WITHOUT the out-of-line superellipsoid call -- 166 instead of 195 VGPRs
+//      (three waves per SIMD instead of two), no spilled SGPRs: 1.55 -> 1.35 ms at 2^24 agents;
+//   2  the generic body for exactly the waves pass 1 deferred (it reads status_out first; the others leave at once).
+#define SC_STATUS_PENDING (-1)
+template <typename TIO, typename TC, int KMAX, int MODEL, int PASS = 0>
 __global__ __launch_bounds__(256) void cbfqp_reg_kernel(const sc_cbfqp_params p, const long long B, const int K,
                                                         const TIO* __restrict__ X, const TIO* __restrict__ u_ref,
                                                         const TIO* __restrict__ obs, const int* __restrict__ n_obs,
@@ -96,6 +106,10 @@ __global__ __launch_bounds__(256) void cbfqp_reg_kernel(const sc_cbfqp_params p,
     using V2 = typename vec2<TIO>::type;
     using V4 = typename vec4io<TIO>::type;
     constexpr int VN = vec4io<TIO>::N;
+    if constexpr (PASS == 2) {
+        const bool pending = active && status_out[ag_i] == SC_STATUS_PENDING;
+        if (__builtin_amdgcn_ballot_w64(pending) == 0ull) return;          // wave-uniform: pass 1 finished this wave
+    }
 
     // ---- loads: obstacles first (longest latency), then state ---------------------------
     TIO flat[KMAX * 7];
@@ -125,6 +139,15 @@ __global__ __launch_bounds__(256) void cbfqp_reg_kernel(const sc_cbfqp_params p,
         nk = n_obs[ag_i];
         nk = nk < 0 ? 0 : (nk > K ? K : nk);
     }
+    if constexpr (PASS == 1) {
+        bool other = false;
+#pragma unroll
+        for (int r = 0; r < KMAX; ++r) other |= (r < nk) && (flat[r * 7 + 6] != TIO(0));
+        if (__builtin_amdgcn_ballot_w64(other && active) != 0ull) {        // wave-uniform: leave this wave to pass 2
+            if (active) status_out[agent] = SC_STATUS_PENDING;
+            return;
+        }
+    }
     const TC ur0 = TC(ur.x), ur1 = TC(ur.y);
     const CbfConsts<TC> k = make_consts<TC>(p);
     const Agent<TC> ag = load_agent<TIO, TC, MODEL>(X, ag_i);
@@ -140,7 +163,7 @@ __global__ __launch_bounds__(256) void cbfqp_reg_kernel(const sc_cbfqp_params p,
 #pragma unroll
         for (int f = 0; f < 7; ++f) o[f] = TC(flat[r * 7 + f]);
         TC h, a0, a1, cc;
-        const bool ok = cbf_row<TC, MODEL, true>(ag, o, k, a0, a1, cc, h);
+        const bool ok = cbf_row<TC, MODEL, true, PASS == 1>(ag, o, k, a0, a1, cc, h);
         const bool used = r < nk;                   // nk <= K <= KMAX
         bad_obs |= used && !ok;
         a0 = used ? a0 : TC(0); a1 = used ? a1 : TC(0); cc = used ? cc : TC(0);
@@ -416,6 +439,17 @@ static hipError_t launch_one(const sc_cbfqp_params& p, long long B, int K, const
             return launch_coop<TIO, TC, 8, MODEL>(p, B, K, X, u_ref, obs, n_obs, u_out, status, h_out, stream);
         const unsigned threads = 256;
         const unsigned nblk = (unsigned)((B + threads - 1) / threads);
+        if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D && sizeof(TC) == 8) {
+            if (sc_two_pass() && B >= (1 << 18)) {            // below, the second launch costs more than the fast pass gains (2^16: 12.2 -> 13.4 us)
+                hipLaunchKernelGGL((cbfqp_reg_kernel<TIO, TC, KMAX, MODEL, 1>), dim3(nblk), dim3(threads), 0, stream, p, B, K,
+                                   (const TIO*)X, (const TIO*)u_ref, (const TIO*)obs, n_obs, (TIO*)u_out, status, (TIO*)h_out);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL((cbfqp_reg_kernel<TIO, TC, KMAX, MODEL, 2>), dim3(nblk), dim3(threads), 0, stream, p, B, K,
+                                   (const TIO*)X, (const TIO*)u_ref, (const TIO*)obs, n_obs, (TIO*)u_out, status, (TIO*)h_out);
+                return hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((cbfqp_reg_kernel<TIO, TC, KMAX, MODEL>), dim3(nblk), dim3(threads), 0, stream, p, B, K,
                            (const TIO*)X, (const TIO*)u_ref, (const TIO*)obs, n_obs, (TIO*)u_out, status, (TIO*)h_out);
         return hipGetLastError();

@@ -212,7 +212,9 @@ __device__ __forceinline__ void dpcbf(const Agent<T>& a, const T* o, T R, T& h, 
 
 // One CBF row for obstacle `o` (7 values, compute type).  Returns false when
 // the obstacle flag is invalid for the model (DU needs flag 0 or 1).
-template <typename T, int MODEL, bool OUTLINE_RARE = false>
+// CIRCLES_ONLY (DynamicUnicycle2D): the caller has established that every obstacle of the wave is a circle (flag 0): the
+// superellipsoid branch -- and with OUTLINE_RARE the function call that costs the kernel 30 VGPRs and its SGPR spills -- is not emitted
+template <typename T, int MODEL, bool OUTLINE_RARE = false, bool CIRCLES_ONLY = false>
 __device__ __forceinline__ bool cbf_row(const Agent<T>& a, const T* o, const CbfConsts<T>& k,
                                         T& n0, T& n1, T& c, T& h) {
     if constexpr (MODEL == SC_MODEL_UNICYCLE2D) {
@@ -276,7 +278,7 @@ __device__ __forceinline__ bool cbf_row(const Agent<T>& a, const T* o, const Cbf
         T hdot, dhd[4];
         if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) {
             const T flag = o[6];
-            if (flag == T(0)) {
+            if (CIRCLES_ONLY || flag == T(0)) {
                 hocbf_circle(a, o, k.R, T(1.01), h, hdot, dhd);
             } else if (flag == T(1)) {
                 if constexpr (OUTLINE_RARE) {
