@@ -108,6 +108,45 @@ def test_argument_validation_of_the_newer_entry_points_without_gpu():
     assert lib.sc_mpcgn_solve_batch(C.byref(g), 1, 8, ptr, ptr, ptr, ptr, ptr, ptr, None, None, None) == 1
 
 
+def test_argument_validation_of_the_round2_entry_points_without_gpu():
+    """Backup-CBF QP, quadrotor select / apply, optimal-decay linear-model MPC: rejected before a launch; host tables equal the oracle's."""
+    from oracle import backup_cbf as OB
+    from safe_control_amd.position_control import backup_cbf_qp as BK
+    lib = _lib.load()
+    buf = np.zeros(4096)
+    ptr = buf.ctypes.data
+    env = BK.default_evade_env()
+    oe = OB.default_env()
+    assert all(env[k] == oe[k] for k in BK.ENV_KEYS)                       # the host mirror of EvadeEnv == the pinned oracle's
+    p = BK.make_params(env, {"radius": 0.5, "a_max": 2.0, "v_max": 1.5, "safety_margin": 0.5}, 0.1, 12.0, _lib.DTYPE_F64)
+    assert p.n_steps == 120 and p.fd_eps == 1e-5 and (p.alpha, p.alpha_terminal) == (1.0, 2.0)
+    assert lib.sc_backupcbf_solve_batch(C.byref(p), 0, None, None, None, None, None, None, None, None, None, None) == 0     # B == 0
+    assert lib.sc_backupcbf_solve_batch(None, 1, ptr, None, ptr, ptr, ptr, None, None, None, None, None) == 1
+    assert lib.sc_backupcbf_solve_batch(C.byref(p), 1, None, None, ptr, ptr, ptr, None, None, None, None, None) == 1
+    p.n_steps = 129
+    assert lib.sc_backupcbf_solve_batch(C.byref(p), 1, ptr, None, ptr, ptr, ptr, None, None, None, None, None) == 2
+    p.n_steps, p.pocket_x_max = 120, p.pocket_x_min
+    assert lib.sc_backupcbf_solve_batch(C.byref(p), 1, ptr, None, ptr, ptr, ptr, None, None, None, None, None) == 1
+    p = BK.make_params(env, {}, 0.1, 12.0, _lib.DTYPE_F64)
+    assert lib.sc_backupcbf_rollout_batch(C.byref(p), 1, -1, 0, ptr, ptr, ptr, ptr, None, None, ptr, ptr, None) == 1
+    assert lib.sc_backupcbf_rollout_batch(C.byref(p), 1, 1, 0, ptr, ptr, ptr, ptr, None, None, None, ptr, None) == 1       # ret is NULL
+    # quadrotor select / apply
+    q = _lib.QuadTrackParams()
+    q.model, q.io_dtype, q.max_waypoints, q.num_constraints = 1, _lib.DTYPE_F64, 2, 10
+    q.dt, q.mass, q.Ix, q.Iy, q.Iz, q.L, q.nu = 0.05, 3.0, 0.5, 0.5, 0.5, 0.3, 0.1
+    iptr = np.zeros(64, dtype=np.int32).ctypes.data
+    assert lib.sc_quadtrack_select_batch(C.byref(q), 0, 0, *([None] * 13)) == 0
+    assert lib.sc_quadtrack_select_batch(C.byref(q), 1, 0, None, ptr, iptr, iptr, iptr, ptr, None, iptr, ptr, ptr, ptr, iptr, None) == 1
+    q.num_constraints = 17
+    assert lib.sc_quadtrack_select_batch(C.byref(q), 1, 0, ptr, ptr, iptr, iptr, iptr, ptr, None, iptr, ptr, ptr, ptr, iptr, None) == 2
+    q.num_constraints, q.model = 10, 2
+    assert lib.sc_quadtrack_apply_batch(C.byref(q), 1, 0, 0, ptr, iptr, ptr, None, ptr, ptr, iptr, iptr, None) == 1
+    q.model, q.L = 1, 0.0
+    assert lib.sc_quadtrack_apply_batch(C.byref(q), 1, 0, 0, ptr, iptr, ptr, None, ptr, ptr, iptr, iptr, None) == 1
+    q.model, q.inertia, q.robot_radius = 0, 0.01, 0.25
+    assert lib.sc_quadtrack_apply_batch(C.byref(q), 1, 1, 0, ptr, iptr, ptr, None, ptr, ptr, iptr, iptr, None) == 1       # M > 0 without a table
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
