@@ -720,12 +720,32 @@ def hetero_fleet_workload(a, dev, ws, rank, backend):
                                      "quad3d_optimal_fraction": float((sq == 0).double().mean().item()),
                                      "unicycle_mean_iterations": float(iu.double().mean().item()),
                                      "quad3d_mean_iterations": float(iq.double().mean().item())},
-                          "roofline": {"bound": "hbm", "achieved": nbytes * steps / elapsed / 1e9, "peak": HBM_PEAK_GBS * ws,
-                                       "unit": "GB/s", "frac": nbytes * steps / elapsed / 1e9 / (HBM_PEAK_GBS * ws), "traffic": None,
-                                       "kernel": ("odmpccbf_kernel<20,UNI> + mpclin_kernel<12,4,0,0,big,od>" if od else
-                                                  "mpccbf_uni_kernel<20> + mpclin_kernel<12,4,0,0,big>"),
-                                       "note": "interior-point solves: VALU / latency bound, HBM bytes are negligible"},
+                          "roofline": hetero_roofline(od, n_total, ws, steps, elapsed, nbytes),
                           "cpu_baseline": None}), flush=True)
+
+
+def hetero_roofline(od, n_total, ws, steps, elapsed, nbytes):
+    """VALU-issue roofline of the fleet step from the committed counter profile of the same 65536-agent launch pair (both
+    model kernels run side by side on two streams: their instruction counts add); falls back to the (meaningless) HBM
+    figure when the profile does not hold this configuration."""
+    if od and n_total == 65536:
+        for rnd in ("r02",):
+            path = os.path.join(ROOT, "profiles", f"{rnd}_counters.json")
+            try:
+                d = json.load(open(path)).get("hetero_sq", {})
+            except Exception:
+                d = {}
+            insts = [c["SQ_INSTS_VALU"] for k, c in d.items() if ("mpclin_kernel" in k or "odmpccbf_uni_kernel" in k) and "SQ_INSTS_VALU" in c]
+            if len(insts) == 2:
+                ach = sum(insts) * steps / elapsed / 1e9
+                return {"bound": "valu_issue", "achieved": ach, "peak": VALU_PEAK_GIPS * ws, "unit": "G wave-instr/s", "frac": ach / (VALU_PEAK_GIPS * ws),
+                        "traffic": None, "kernel": "odmpccbf_uni_kernel<20> + mpclin_kernel<12,4,0,0,big,od>", "valu_instructions_per_step": sum(insts),
+                        "source": f"profiles/{rnd}_counters.json:hetero_sq",
+                        "note": "latency-bound interior-point solves (one Quad3D problem per CU: 147 KB of LDS, four waves)"}
+    return {"bound": "hbm", "achieved": nbytes * steps / elapsed / 1e9, "peak": HBM_PEAK_GBS * ws, "unit": "GB/s",
+            "frac": nbytes * steps / elapsed / 1e9 / (HBM_PEAK_GBS * ws), "traffic": None,
+            "kernel": ("odmpccbf_uni_kernel<20> + mpclin_kernel<12,4,0,0,big,od>" if od else "mpccbf_uni_kernel<20> + mpclin_kernel<12,4,0,0,big>"),
+            "note": "interior-point solves: VALU / latency bound, HBM bytes are negligible (no VALU counter profile committed for this configuration)"}
 
 
 def kb_c3bf_workload(a, dev, ws, rank, backend, collect=False, steps_override=None):

@@ -43,6 +43,7 @@ rocprofv3 --kernel-trace --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES 
 # 8. heterogeneous fleet, BASELINE configs[4] as stated (optimal decay + superellipsoids, extension) and round 1's plain variant
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o hetero -- python3 $R/bench.py --workload hetero_fleet --steps 1 --warmup 1 > $OUT/hetero_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o hetero_plain -- python3 $R/bench.py --workload hetero_fleet --plain-fleet --steps 1 --warmup 1 > $OUT/hetero_plain_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o hetero_sq -- python3 $R/bench.py --workload hetero_fleet --steps 1 --warmup 1 > /dev/null 2>&1
 # 9. Backup-CBF QP kernel: instruction mix
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o backup_sq -- python3 $R/tools/prof_backup.py 4096 3 > /dev/null 2>&1
 # 10. sustained VALU issue peak of the part (the denominator of the valu_issue rooflines)
