@@ -190,7 +190,7 @@ def quad2d_model(spec=None, dt=0.05):
 
 
 def params(model, N=10, **over):
-    P = dict(M.DEFAULTS, N=N, dt=model["dt"], nu=2, u_lo=model["u_lo"], u_hi=model["u_hi"], radius=model["radius"],
+    P = dict(M.DEFAULTS, N=N, dt=model["dt"], nu=model.get("nu", 2), u_lo=model["u_lo"], u_hi=model["u_hi"], radius=model["radius"],
              alpha1=model["alpha1"], alpha2=model["alpha2"], beta=model["beta"], model=model)
     P.update(over)
     P.setdefault("row_noise", 1e-15)                       # Armijo allowance for the round-off of far dummy-obstacle rows (as mpc_lin)
@@ -207,7 +207,7 @@ def barrier(p, obs, P):
 
 def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     mdl = P["model"]
-    N, nx, nu, dt, spec = P["N"], mdl["nx"], 2, mdl["dt"], mdl["spec"]
+    N, nx, nu, dt, spec = P["N"], mdl["nx"], mdl.get("nu", 2), mdl["dt"], mdl["spec"]
     n = N * nu
     K = obs.shape[0]
     Q, Rw, xb = mdl["Q"], mdl["R"], mdl["xb"]
@@ -251,14 +251,22 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
                 hv[k, p, j], dh[k, p, j], Hh[k, p, j] = barrier(pts[k, p], obs[j], P)
     wp = (w0, w1, w2)
     nb = len(xb)
-    m = N * K + 2 * nb * N + 2 * n
+    one_sided = any(not (np.isfinite(lo) and np.isfinite(hi)) for (_, lo, hi) in xb)    # VTOL2D: descent-speed floor only
+    nbr = sum(int(np.isfinite(lo)) + int(np.isfinite(hi)) for (_, lo, hi) in xb) if one_sided else 2 * nb
+    m = N * K + nbr * N + 2 * n
     g = np.zeros(m)
     g[: N * K] = (w0 * hv[:, 0] + w1 * hv[:, 1] + w2 * hv[:, 2]).reshape(-1)
     o = N * K
     for k in range(1, N + 1):
         for (idx, lo, hi) in xb:
-            g[o] = hi - X[k, idx]; g[o + 1] = X[k, idx] - lo
-            o += 2
+            if not one_sided:
+                g[o] = hi - X[k, idx]; g[o + 1] = X[k, idx] - lo
+                o += 2
+                continue
+            if np.isfinite(hi):
+                g[o] = hi - X[k, idx]; o += 1
+            if np.isfinite(lo):
+                g[o] = X[k, idx] - lo; o += 1
     hi_, lo_ = np.tile(mdl["u_hi"], N), np.tile(mdl["u_lo"], N)
     g[o:o + n] = hi_ - z
     g[o + n:] = z - lo_
@@ -277,8 +285,14 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     o = N * K
     for k in range(1, N + 1):
         for (idx, lo, hi) in xb:
-            J[o] = -Phi[k][idx]; J[o + 1] = Phi[k][idx]
-            o += 2
+            if not one_sided:
+                J[o] = -Phi[k][idx]; J[o + 1] = Phi[k][idx]
+                o += 2
+                continue
+            if np.isfinite(hi):
+                J[o] = -Phi[k][idx]; o += 1
+            if np.isfinite(lo):
+                J[o] = Phi[k][idx]; o += 1
     J[o:o + n] = -np.eye(n)
     J[o + n:] = np.eye(n)
     out.update(grad=grad, J=J)
@@ -298,6 +312,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
         #   p_N = mu_N,  p_k = mu_k + (d points_k / d x_k)' nu + A_k' p_{k+1};   mu_k = 2 Q (x_k - xg) + bound multipliers,
         #   nu_p = -w_p sum_j lam_kj dh_j(point_p);   W += V_k' H_k V_k,  V_k = [Phi_k; E_k],
         #   H_k = H_F(x_k,u_k; p_{k+1}) + H_S(x_k,u_k; P'nu_1) + D' H_S(y1,u_k; P'nu_2) D + H_S(x_k,u_k; S2x' P'nu_2)
+        assert not one_sided, "exact Hessian: two-sided state bounds only"
         ls = lam[N * K:N * K + 2 * nb * N].reshape(N, nb, 2) if nb else None
         pk = np.zeros(nx)
         for k in range(N, -1, -1):
@@ -313,7 +328,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
             nu_ = [-wp[p] * (lc[k] @ dh[k, p]) for p in range(3)]
             c1 = np.zeros(nx); c1[0:2] = nu_[1]
             c2 = np.zeros(nx); c2[0:2] = nu_[2]
-            D = np.zeros((nx + 2, nx + 2)); D[:nx, :nx] = S1x; D[:nx, nx:] = S1u; D[nx:, nx:] = np.eye(2)
+            D = np.zeros((nx + nu, nx + nu)); D[:nx, :nx] = S1x; D[:nx, nx:] = S1u; D[nx:, nx:] = np.eye(nu)
             Hk = mdl["H"](X[k], U[k], spec, dt, pk) + mdl["H"](X[k], U[k], spec, dt, c1, True) \
                 + D.T @ mdl["H"](y1, U[k], spec, dt, c2, True) @ D + mdl["H"](X[k], U[k], spec, dt, S2x[0:2].T @ nu_[2], True)
             E = np.zeros((nu, n)); E[:, k * nu:(k + 1) * nu] = np.eye(nu)
