@@ -336,12 +336,9 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
         rhs = -grad - J.T @ (sig * r_p) + J.T @ (mu / s)
         delta = 0.0
         L = None
-        Dreg = np.eye(nz)
-        if P.get("inertia_scale") == "diag":                                # experiment: scale-invariant regularisation
-            Dreg = np.diag(np.maximum(np.abs(np.diag(Mb)), 1e-8))
         for _try in range(40):                                              # inertia correction
             try:
-                L = np.linalg.cholesky(Mb + delta * Dreg)
+                L = np.linalg.cholesky(Mb + delta * np.eye(nz))
                 break
             except np.linalg.LinAlgError:
                 delta = max(1e-4, delta_last / 3.0) if delta == 0.0 else delta * 8.0
