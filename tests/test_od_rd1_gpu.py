@@ -157,3 +157,56 @@ def test_quad3d_entry_point_guards():
     assert lib.sc_odmpclin_solve_batch(C.byref(p), a(blob), 1, 1, a(X), a(uo), a(g), a(o), a(uo), None, a(so), None, None, None) == 1
     p.optimal_decay = 1; p.nx = 2; p.nu = 2; p.ng = 2                       # SingleIntegrator2D: not served by the extension
     assert lib.sc_odmpclin_solve_batch(C.byref(p), a(blob), 1, 1, a(X), a(uo), a(g), a(o), a(uo), None, a(so), None, None, None) in (1, 2)
+
+
+# ---- BASELINE configs[4] at its full size (65536 agents on one GPU): size-independent properties -----------------------------
+
+def test_config5_full_size_properties():
+    """32768 Unicycle2D + 32768 Quad3D agents, optimal-decay MPC-CBF at N = 20 against 8 superellipsoids each (bench.py's
+    hetero_fleet batches): launches are deterministic, nearly every problem converges, every reported optimum satisfies its rows
+    and bounds (checked with the oracle's problem functions on a sample), and a sample of the batch re-solved as a small batch
+    gives the same answers (batch-position independence)."""
+    import safe_control_amd as sca
+    from oracle import mpc_lin as L
+    n_half, N, K = 32768, 20, 8
+    Xu, gu, _, _ = W.du_cbfqp_batch(n_half, K, seed=0)
+    Xu[:, 3] = 0.0
+    ou = W.superellipsoid_obstacles(Xu[:, :2], K, seed=1000)
+    Xq, gq, _ = W.linear_mpc_batch("Quad3D", n_half, K, seed=1)
+    oq = W.superellipsoid_obstacles(Xq[:, :2], K, seed=1001)
+    t32 = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=DEV)
+    uni = sca.BatchedOptimalDecayMPCCBF(dict(UNI_SPEC), io_dtype="f32", horizon=N, extension=True)
+    quad = sca.BatchedOptimalDecayLinearMPCCBF({"model": "Quad3D"}, io_dtype="f32", horizon=N)
+    tXu, tgu, tou, tXq, tgq, toq = t32(Xu), t32(gu), t32(ou), t32(Xq), t32(gq), t32(oq)
+    upu = torch.zeros((n_half, 2), dtype=torch.float32, device=DEV); upq = torch.zeros((n_half, 4), dtype=torch.float32, device=DEV)
+    ru = uni.solve(tXu, upu, tgu, tou, want_z=True)
+    rq = quad.solve(tXq, upq, tgq, toq, want_z=True)
+    ru2 = uni.solve(tXu, upu, tgu, tou, want_z=True)
+    rq2 = quad.solve(tXq, upq, tgq, toq, want_z=True)
+    torch.cuda.synchronize()
+    for a, b in zip(ru + rq, ru2 + rq2):                                 # deterministic: bit-identical outputs
+        assert torch.equal(a.nan_to_num(), b.nan_to_num())
+    (uu, rhou, stu, itu, zu), (uq, rhoq, stq, itq, zq) = ru, rq
+    assert (stu == 0).double().mean().item() > 0.97 and (stq == 0).double().mean().item() > 0.90
+    assert int(itu.max()) <= 100 and int(itq.max()) <= 100 and int(itu.min()) >= 1
+    # bounds on every problem
+    assert float(uu[:, 0].abs().max()) <= 1.0 + 1e-5 and float(uu[:, 1].abs().max()) <= 0.5 + 1e-5
+    assert float(uq.abs().max()) <= 10.0 + 1e-4
+    # rows of reported optima on a sample, with the oracle's problem functions on the f32-rounded inputs the kernel saw
+    Pu = O.uni_params(N=N)
+    Pq = O.lin_params(dict(L.quad3d_model(), circles_only=False), N=N)
+    rng = np.random.default_rng(0)
+    for i in rng.choice(n_half, 24, replace=False):
+        if int(stu[i]) == 0:
+            zz = np.concatenate([zu[i].double().cpu().numpy(), rhou[i].double().cpu().numpy()[0::2]])
+            g = O.evaluate(tXu[i, :3].double().cpu().numpy(), zz, tgu[i].double().cpu().numpy(), tou[i].double().cpu().numpy(), Pu, level=0)["g"]
+            assert g.min() >= -1e-4, (i, g.min())                         # f32 storage of z / rho: 1e-4, not 1e-6
+        if int(stq[i]) == 0:
+            zz = np.concatenate([zq[i].double().cpu().numpy(), rhoq[i].double().cpu().numpy()])
+            g = O.evaluate(tXq[i].double().cpu().numpy(), zz, tgq[i].double().cpu().numpy(), toq[i].double().cpu().numpy(), Pq, level=0)["g"]
+            assert g.min() >= -2e-3 * max(1.0, float(np.abs(g).max()) * 1e-3), (i, g.min())
+    sel = torch.arange(5000, 5064, device=DEV)
+    ru_s = uni.solve(tXu[sel].contiguous(), upu[sel].contiguous(), tgu[sel].contiguous(), tou[sel].contiguous())
+    rq_s = quad.solve(tXq[sel].contiguous(), upq[sel].contiguous(), tgq[sel].contiguous(), toq[sel].contiguous())
+    assert torch.equal(ru_s[0].nan_to_num(), uu[sel].nan_to_num()) and torch.equal(ru_s[2], stu[sel])
+    assert torch.equal(rq_s[0].nan_to_num(), uq[sel].nan_to_num()) and torch.equal(rq_s[2], stq[sel])
