@@ -116,20 +116,40 @@ __device__ __forceinline__ double lane_value(double v, int src);
 // that are not part of the trailing matrix (already final) are switched off by zeroing their MFMA operand, so a tile
 // element needs no predicate (the strict upper triangle holds don't-care values); only the last tile row of an order that
 // is not a multiple of 16 takes the guarded variant (rows and columns >= n do not exist in the n x ld scratch).
-template <int U, bool GUARD>
-__device__ __forceinline__ void chol_tiles(double* A, int ld, int j0, int t0, int n, int pw, int ti, int tj0, double a, int q, int l15) {
+// Storage of the factor.  LdRect: n x ld rectangle (ld odd).  LdTile: only the 16 x 16 tiles on and below the diagonal, tile
+// (ti, tj <= ti) at ((ti (ti + 1) / 2 + tj) * 272, rows of a tile 17 doubles apart (odd: conflict-free column walks): 4080
+// instead of 6480 doubles at n = 80, which is what lets two order-80 problems share a CU's LDS.  Elements above the diagonal
+// TILE ROW do not exist: `at` is only called with (r >> 4) >= (c >> 4); the call sites below that used to read don't-care
+// values from there clamp their row / column first (`row_for`, `col_for`).
+struct LdRect {
+    int ld;
+    __device__ __forceinline__ int at(int r, int c) const { return r * ld + c; }
+    __device__ __forceinline__ int row_for(int r, int c) const { return r; }
+    __device__ __forceinline__ int col_for(int r, int c) const { return c; }
+};
+struct LdTile {
+    __device__ __forceinline__ int at(int r, int c) const {
+        const int ti = r >> 4, tj = c >> 4;
+        return (((ti * (ti + 1)) >> 1) + tj) * 272 + (r & 15) * 17 + (c & 15);
+    }
+    __device__ __forceinline__ int row_for(int r, int c) const { return (r >> 4) >= (c >> 4) ? r : c; }   // an existing row for column c
+    __device__ __forceinline__ int col_for(int r, int c) const { return (r >> 4) >= (c >> 4) ? c : r; }   // an existing column for row r
+    static __host__ __device__ inline size_t doubles(int n) { const size_t nt = ((size_t)n + 15) >> 4; return nt * (nt + 1) / 2 * 272; }
+};
+
+template <int U, bool GUARD, typename IX>
+__device__ __forceinline__ void chol_tiles(double* A, const IX ix, int j0, int t0, int n, int pw, int ti, int tj0, double a, int q, int l15) {
     double b[U];
     ipm_c4 acc[U];
-    double* crow = A + (16 * ti + q) * ld + l15;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int rb = 16 * (tj0 + u) + l15;
-        const double bv = A[(GUARD && rb >= n ? 0 : rb) * ld + j0 + q];
+        const double bv = A[ix.at(GUARD && rb >= n ? j0 : rb, j0 + q)];
         b[u] = (rb >= t0 && rb < n && q < pw) ? bv : 0.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool in = !GUARD || (16 * ti + q + 4 * r < n && rb < n);
-            acc[u][r] = in ? crow[4 * r * ld + 16 * (tj0 + u)] : 0.0;
+            acc[u][r] = in ? A[ix.at(16 * ti + q + 4 * r, 16 * (tj0 + u) + l15)] : 0.0;
         }
     }
 #pragma unroll
@@ -139,19 +159,21 @@ __device__ __forceinline__ void chol_tiles(double* A, int ld, int j0, int t0, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool in = !GUARD || (16 * ti + q + 4 * r < n && 16 * (tj0 + u) + l15 < n);
-            if (in) crow[4 * r * ld + 16 * (tj0 + u)] = acc[u][r];
+            if (in) A[ix.at(16 * ti + q + 4 * r, 16 * (tj0 + u) + l15)] = acc[u][r];
         }
     }
 }
 // One panel (columns j0 .. j0 + pw - 1) in the registers of ONE wave; false (wave-uniform) on a pivot <= 0.
-__device__ __forceinline__ bool chol_panel(double* A, int n, int ld, int j0, int pw, int lane) {
+template <typename IX>
+__device__ __forceinline__ bool chol_panel(double* A, int n, const IX ix, int j0, int pw, int lane) {
     const int r0 = lane, r1 = 64 + lane;
     const int c1 = r1 < n ? r1 : r0;                                       // in-range stand-in row for the loads of lanes without a second row
+    const int l0 = ix.row_for(r0 < n ? r0 : j0, j0), l1 = ix.row_for(c1 < n ? c1 : j0, j0);   // rows whose (., j0) entries exist
     double p0[4], p1[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        p0[c] = A[r0 * ld + j0 + (c < pw ? c : 0)];
-        p1[c] = A[c1 * ld + j0 + (c < pw ? c : 0)];
+        p0[c] = A[ix.at(l0, j0 + (c < pw ? c : 0))];
+        p1[c] = A[ix.at(l1, j0 + (c < pw ? c : 0))];
     }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
@@ -175,24 +197,24 @@ __device__ __forceinline__ bool chol_panel(double* A, int n, int ld, int j0, int
     }
     if (r0 >= j0 && r0 < n) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (c < pw) A[r0 * ld + j0 + c] = p0[c];
+        for (int c = 0; c < 4; ++c) if (c < pw) A[ix.at(r0, j0 + c)] = p0[c];
     }
     if (r1 >= j0 && r1 < n) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (c < pw) A[r1 * ld + j0 + c] = p1[c];
+        for (int c = 0; c < 4; ++c) if (c < pw) A[ix.at(r1, j0 + c)] = p1[c];
     }
     return true;
 }
 // NW waves share the factorisation (tid = thread index among them): wave 0 factors the panel and posts its verdict in
 // `flag` (an LDS word), the tiles of the trailing update are dealt round-robin.  NW = 1: flag unused.
-template <int NW = 1>
-__device__ __forceinline__ bool cholesky_lds(double* A, int n, int ld, int tid, double* flag = nullptr) {
+template <int NW = 1, typename IX = LdRect>
+__device__ __forceinline__ bool cholesky_ix(double* A, int n, const IX ix, int tid, double* flag = nullptr) {
     const int lane = tid & 63, wv = tid >> 6;
     const int q = lane >> 4, l15 = lane & 15;
     for (int j0 = 0; j0 < n; j0 += 4) {
         const int pw = n - j0 < 4 ? n - j0 : 4;
         bool ok = true;
-        if (NW == 1 || wv == 0) ok = chol_panel(A, n, ld, j0, pw, lane);
+        if (NW == 1 || wv == 0) ok = chol_panel(A, n, ix, j0, pw, lane);
         if constexpr (NW > 1) {
             if (tid == 0) *flag = ok ? 1.0 : 0.0;
             SC_SYNC();
@@ -207,26 +229,30 @@ __device__ __forceinline__ bool cholesky_lds(double* A, int n, int ld, int tid, 
         int item = 0;
         for (int ti = tb; ti < te; ++ti) {
             const int ra = 16 * ti + l15;
-            const double av = A[(ra < n ? ra : 0) * ld + j0 + q];
+            const double av = A[ix.at(ra < n ? ra : j0, j0 + q)];
             const double a = (ra >= t0 && ra < n && q < pw) ? -av : 0.0;
             int tj = tb;
             if (16 * ti + 16 <= n) {
                 if constexpr (NW == 1) {
-                    for (; tj + 3 <= ti; tj += 4) chol_tiles<4, false>(A, ld, j0, t0, n, pw, ti, tj, a, q, l15);
-                    if (tj + 1 <= ti) { chol_tiles<2, false>(A, ld, j0, t0, n, pw, ti, tj, a, q, l15); tj += 2; }
-                    if (tj <= ti) chol_tiles<1, false>(A, ld, j0, t0, n, pw, ti, tj, a, q, l15);
+                    for (; tj + 3 <= ti; tj += 4) chol_tiles<4, false>(A, ix, j0, t0, n, pw, ti, tj, a, q, l15);
+                    if (tj + 1 <= ti) { chol_tiles<2, false>(A, ix, j0, t0, n, pw, ti, tj, a, q, l15); tj += 2; }
+                    if (tj <= ti) chol_tiles<1, false>(A, ix, j0, t0, n, pw, ti, tj, a, q, l15);
                 } else {
                     for (; tj <= ti; ++tj)
-                        if ((item++ & (NW - 1)) == wv) chol_tiles<1, false>(A, ld, j0, t0, n, pw, ti, tj, a, q, l15);
+                        if ((item++ & (NW - 1)) == wv) chol_tiles<1, false>(A, ix, j0, t0, n, pw, ti, tj, a, q, l15);
                 }
             } else {
                 for (; tj <= ti; ++tj)
-                    if (NW == 1 || (item++ & (NW - 1)) == wv) chol_tiles<1, true>(A, ld, j0, t0, n, pw, ti, tj, a, q, l15);
+                    if (NW == 1 || (item++ & (NW - 1)) == wv) chol_tiles<1, true>(A, ix, j0, t0, n, pw, ti, tj, a, q, l15);
             }
         }
         SC_SYNC();
     }
     return true;
+}
+template <int NW = 1>
+__device__ __forceinline__ bool cholesky_lds(double* A, int n, int ld, int tid, double* flag = nullptr) {
+    return cholesky_ix<NW, LdRect>(A, n, LdRect{ld}, tid, flag);
 }
 __device__ __forceinline__ double lane_value(double v, int src) {           // src: wave-uniform lane
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -238,20 +264,20 @@ __device__ __forceinline__ double lane_value(double v, int src) {           // s
 // elimination steps run without a barrier and with no LDS access on their dependency chain: the multipliers of 16 steps
 // (a block column of L going down, a block row going up) are loaded in one burst ahead of them.
 // TWO: n > 64.  LO: the 16 pivots of the block are first-row entries (c0 < 64).
-template <bool TWO, bool LO, bool FWD>
-__device__ __forceinline__ void chol_solve_block(const double* L, int n, int ld, int c0, int lane, int k0, int k1, double d0, double d1,
+template <bool TWO, bool LO, bool FWD, typename IX>
+__device__ __forceinline__ void chol_solve_block(const double* L, int n, const IX ix, int c0, int lane, int k0, int k1, double d0, double d1,
                                                  double& b0, double& b1) {
     const int i0 = lane, i1 = 64 + lane;
     double m0[16], m1[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         const int j = c0 + c < n ? c0 + c : n - 1;
-        if (FWD) {                                                         // column j of L, rows of this lane
-            if (LO) m0[c] = L[k0 * ld + j];
-            if (TWO) m1[c] = L[k1 * ld + j];
-        } else {                                                           // row j of L, columns of this lane
-            m0[c] = L[j * ld + k0];
-            if (TWO && !LO) m1[c] = L[j * ld + k1];
+        if (FWD) {                                                         // column j of L, rows of this lane (rows above it: unused, clamped)
+            if (LO) m0[c] = L[ix.at(ix.row_for(k0, j), j)];
+            if (TWO) m1[c] = L[ix.at(ix.row_for(k1, j), j)];
+        } else {                                                           // row j of L, columns of this lane (columns right of it: unused, clamped)
+            m0[c] = L[ix.at(j, ix.col_for(j, k0))];
+            if (TWO && !LO) m1[c] = L[ix.at(j, ix.col_for(j, k1))];
         }
     }
 #pragma unroll
@@ -270,31 +296,35 @@ __device__ __forceinline__ void chol_solve_block(const double* L, int n, int ld,
         }
     }
 }
-template <bool TWO>
-__device__ __forceinline__ void chol_solve_wave(const double* L, double* b, int n, int ld, int lane) {
+template <bool TWO, typename IX>
+__device__ __forceinline__ void chol_solve_wave(const double* L, double* b, int n, const IX ix, int lane) {
     const int i0 = lane, i1 = 64 + lane;
     const int k0 = i0 < n ? i0 : 0, k1 = i1 < n ? i1 : k0;                 // in-range rows for the unpredicated loads
     double b0 = i0 < n ? b[i0] : 0.0, b1 = (TWO && i1 < n) ? b[i1] : 0.0;
-    const double d0 = L[k0 * ld + k0], d1 = TWO ? L[k1 * ld + k1] : 0.0;
+    const double d0 = L[ix.at(k0, k0)], d1 = TWO ? L[ix.at(k1, k1)] : 0.0;
     const int nb = (n + 15) >> 4;
     for (int kb = 0; kb < nb; ++kb) {
-        if (!TWO || kb < 4) chol_solve_block<TWO, true, true>(L, n, ld, 16 * kb, lane, k0, k1, d0, d1, b0, b1);
-        else chol_solve_block<TWO, false, true>(L, n, ld, 16 * kb, lane, k0, k1, d0, d1, b0, b1);
+        if (!TWO || kb < 4) chol_solve_block<TWO, true, true>(L, n, ix, 16 * kb, lane, k0, k1, d0, d1, b0, b1);
+        else chol_solve_block<TWO, false, true>(L, n, ix, 16 * kb, lane, k0, k1, d0, d1, b0, b1);
     }
     for (int kb = nb - 1; kb >= 0; --kb) {
-        if (!TWO || kb < 4) chol_solve_block<TWO, true, false>(L, n, ld, 16 * kb, lane, k0, k1, d0, d1, b0, b1);
-        else chol_solve_block<TWO, false, false>(L, n, ld, 16 * kb, lane, k0, k1, d0, d1, b0, b1);
+        if (!TWO || kb < 4) chol_solve_block<TWO, true, false>(L, n, ix, 16 * kb, lane, k0, k1, d0, d1, b0, b1);
+        else chol_solve_block<TWO, false, false>(L, n, ix, 16 * kb, lane, k0, k1, d0, d1, b0, b1);
     }
     if (i0 < n) b[i0] = b0;
     if (TWO && i1 < n) b[i1] = b1;
 }
-template <int NW = 1>
-__device__ __forceinline__ void chol_solve_lds(const double* L, double* b, int n, int ld, int tid) {
+template <int NW = 1, typename IX = LdRect>
+__device__ __forceinline__ void chol_solve_ix(const double* L, double* b, int n, const IX ix, int tid) {
     if (NW == 1 || tid < 64) {                                             // the other waves of the problem wait for wave 0
-        if (n > 64) chol_solve_wave<true>(L, b, n, ld, tid);
-        else chol_solve_wave<false>(L, b, n, ld, tid);
+        if (n > 64) chol_solve_wave<true>(L, b, n, ix, tid);
+        else chol_solve_wave<false>(L, b, n, ix, tid);
     }
     SC_SYNC();
+}
+template <int NW = 1>
+__device__ __forceinline__ void chol_solve_lds(const double* L, double* b, int n, int ld, int tid) {
+    chol_solve_ix<NW, LdRect>(L, b, n, LdRect{ld}, tid);
 }
 
 // register Cholesky for a compile-time order (mpc_chol.hpp); out of line like mpc_cbf.hip's (code size)

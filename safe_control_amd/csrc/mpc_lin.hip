@@ -79,16 +79,19 @@ struct LinDims { int N, K, nx, nu, n, m, mc; };
 // memory as well (49 KB, three problems per CU instead of two) was measured: 8 % faster at 65536 problems, 15 % slower
 // at 4096 (the L1/L2 latency sits on every iteration's critical path) -- G stays in LDS.
 // big (mode 2) = run-time sizes whose standard layout exceeds 80 KB, i.e. leaves one problem per CU or does not fit at all
-// (Quad3D at N = 20: n = 80, 250 KB): G is read from global memory, the LDS Cholesky factor takes the dead T region (widened to
-// n (n + 1) where 4N n falls short), and the block is FOUR waves per problem (see mpclin_kernel).
+// (Quad3D at N = 20: n = 80, 250 KB): the block is FOUR waves per problem (see mpclin_kernel), G is read from global memory
+// (a model constant: L1 / L2 resident), T = Phi G is never stored (the M assembly forms its T operand on the fly from the 4 x 4
+// stage blocks and four rows of G), M is assembled STRAIGHT INTO the Cholesky storage (and re-assembled in the rare
+// inertia-correction retry), and that storage holds only the 16 x 16 tiles on and below the diagonal (ipm::LdTile).  Quad3D at
+// N = 20, K = 8: 146 KB -> 77 KB, i.e. TWO problems per CU instead of one for a kernel that is latency bound.
 enum { LIN_STD = 0, LIN_LEAN = 1, LIN_BIG = 2 };
 __host__ __device__ inline size_t mpclin_lds_doubles(int N, int K, int nx, int nu, int mode = LIN_STD, bool od = false) {
     const bool lean = mode == LIN_LEAN;
     const size_t n = (size_t)N * nu, m = (size_t)N * K + 2 * n;
     return (od ? 12 * (size_t)N : 0) + (size_t)nx * nx + (size_t)nx * nu + 2 * nx + 2 * nu + nx + nu + 2 * nx + 24 + 10 + 7 * n + (size_t)(N + 1) * nx + 12 * N +
-           7 * (size_t)K + 12 * (size_t)N * K + 6 * m + 16 * N + 4 * (size_t)N * n + n * n +
-           (mode == LIN_BIG ? (n * (n + 1) > 4 * (size_t)N * n ? n * (n + 1) - 4 * (size_t)N * n : 0)
-                            : 4 * (size_t)N * n + (lean ? n * n + n : n * (n + 1)));
+           7 * (size_t)K + 12 * (size_t)N * K + 6 * m + 16 * N +
+           (mode == LIN_BIG ? ipm::LdTile::doubles((int)n)
+                            : 4 * (size_t)N * n + n * n + 4 * (size_t)N * n + (lean ? n * n + n : n * (n + 1)));
 }
 
 __device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode, bool od = false) {
@@ -102,8 +105,9 @@ __device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode, bool o
     W.xs = take((N + 1) * nx); W.pts = take(4 * N); W.y = take(4 * N); W.pdz = take(4 * N);
     W.obs = take(7 * K); W.hk = take(2 * N * K); W.dh = take(4 * N * K); W.hh = take(6 * N * K);
     W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m); W.vb = take(m);
-    const size_t tsz = (size_t)4 * N * n, lsz = (size_t)n * (n + 1);       // big: L (row stride n | 1) takes the dead T, widened to hold it
-    W.Phi = take(16 * N); W.T = take(mode == LIN_BIG && lsz > tsz ? lsz : tsz); W.M = take((size_t)n * n);
+    W.Phi = take(16 * N);
+    W.T = W.M = nullptr;
+    if (mode != LIN_BIG) { W.T = take((size_t)4 * N * n); W.M = take((size_t)n * n); }
     W.Hc = W.clin = nullptr;
     W.rho = W.rhot = W.drho = W.rhob = W.w0k = W.Cv = W.dinv = W.rr = W.rdr = nullptr;
     auto take_od = [&]() {
@@ -111,7 +115,7 @@ __device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode, bool o
         W.rho = take(N); W.rhot = take(N); W.drho = take(N); W.rhob = take(N); W.w0k = take(N);
         W.Cv = take(4 * N); W.dinv = take(N); W.rr = take(N); W.rdr = take(N);
     };
-    if (mode == LIN_BIG) { W.G = nullptr; W.L = W.T; take_od(); return W; }
+    if (mode == LIN_BIG) { W.G = nullptr; W.L = take(ipm::LdTile::doubles(n)); take_od(); return W; }
     W.G = take((size_t)4 * N * n);
     if (lean) { W.L = W.T; W.Hc = take((size_t)n * n); W.clin = take(n); }                   // the transpose scratch lives in the dead T | M region (4N n + n n >= n (n + 1))
     else W.L = take((size_t)n * (n + 1));
@@ -268,9 +272,12 @@ typedef double lin_d4 __attribute__((ext_vector_type(4)));
 // NT, NU > 0: compile-time horizon and input count (all operands of a tile are loaded first, then its MFMAs issue back to
 // back); NT == 0: run-time sizes, operands in chunks of 4 stages.
 // NW > 1: the tiles are dealt round-robin to the NW waves of the problem (tid = thread index among them).
-template <int NT, int NU, int NW = 1>
+// TILED (big layout): there is no T and no M in LDS -- the B operand T[4k + q][j] = sum_c Phi_k[q][c] G[row(k, c)][j] is formed
+// from the stage block and four (cached) rows of G, and the lower tiles of M + delta I go straight into the tile-packed
+// Cholesky storage W.L.
+template <int NT, int NU, int NW = 1, bool TILED = false>
 __device__ __forceinline__ void lin_condense_mfma(const LinMem& W, const int N_rt, const int nu_rt, double sf, const double* Hc,
-                                                  const double* G, const double* box, int tid) {
+                                                  const double* G, const double* box, int tid, double delta = 0.0) {
     const int lane = tid & 63, wv = tid >> 6;
     int tile = 0;
     const int N = NT > 0 ? NT : N_rt, nu = NT > 0 ? NU : nu_rt, n = N * nu, nt = (n + 15) / 16;
@@ -293,7 +300,15 @@ __device__ __forceinline__ void lin_condense_mfma(const LinMem& W, const int N_r
                 for (int t = 0; t < S; ++t) {
                     const int k = k0 + t < N ? k0 + t : N - 1;
                     const int gr = q < 2 ? 2 * k + q : 2 * N + 2 * k + q - 2;
-                    const double av = G[(size_t)gr * n + iac], bv = W.T[(size_t)(4 * k + q) * n + jbc];
+                    const double av = G[(size_t)gr * n + iac];
+                    double bv;
+                    if constexpr (TILED) {
+                        const double* ph = W.Phi + 16 * k + 4 * q;
+                        bv = ph[0] * G[(size_t)(2 * k) * n + jbc] + ph[1] * G[(size_t)(2 * k + 1) * n + jbc] +
+                             ph[2] * G[(size_t)(2 * N + 2 * k) * n + jbc] + ph[3] * G[(size_t)(2 * N + 2 * k + 1) * n + jbc];
+                    } else {
+                        bv = W.T[(size_t)(4 * k + q) * n + jbc];
+                    }
                     a[t] = okA ? av : 0.0;
                     b[t] = okB ? bv : 0.0;
                 }
@@ -306,8 +321,12 @@ __device__ __forceinline__ void lin_condense_mfma(const LinMem& W, const int N_r
                 const int row = 16 * ti + q + 4 * r, col = 16 * tj + l15;
                 if (row < n && col < n) {
                     const double v = acc[r] + sf * Hc[(size_t)row * n + col] + (row == col ? box[row] : 0.0);
-                    W.M[(size_t)row * n + col] = v;
-                    if (ti != tj) W.M[(size_t)col * n + row] = v;
+                    if constexpr (TILED) {
+                        W.L[ipm::LdTile{}.at(row, col)] = v + (row == col ? delta : 0.0);   // (the strict upper part of a diagonal tile: don't-care)
+                    } else {
+                        W.M[(size_t)row * n + col] = v;
+                        if (ti != tj) W.M[(size_t)col * n + row] = v;
+                    }
                 }
             }
         }
@@ -330,7 +349,8 @@ __device__ __forceinline__ void lin_condense_mfma(const LinMem& W, const int N_r
 // the right-hand side loses G_k' C_k rr_k / D_k, and d rho_k = (rr_k - C_k' (G dz)_k) / D_k after the solve -- the condensed
 // n x n system, its MFMA assembly and the Cholesky are untouched.
 template <int NX, int NU, int NT, int KT, bool BIG = false, bool OD = false>
-__global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, const long long B,
+__global__ __launch_bounds__(BIG ? 256 : 64) __attribute__((amdgpu_waves_per_eu(BIG ? 2 : 1, BIG ? 2 : 8)))
+void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, const long long B,
                                                     const int K_rt, const void* __restrict__ X, const void* __restrict__ u_prev,
                                                     const void* __restrict__ goal, const void* __restrict__ obs,
                                                     void* __restrict__ u_out, int* __restrict__ status_out,
@@ -528,6 +548,7 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
         SC_SYNC();
         LP(5);
         // T = Phi G (rows 4k..4k+3), then M = sf Hc + G' T + diag(sig_hi + sig_lo)
+        if constexpr (!BIG)
         for (int e = lane; e < 4 * N * n; e += TH) {
             const int row = e / n, col = e - row * n, k = row >> 2, r = row & 3;
             double acc = 0.0;
@@ -542,8 +563,10 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
         for (int i = lane; i < n; i += TH)                                   // r_d is consumed: its space holds the box terms
             W.rd[i] = W.ds[d.mc + i] + W.ds[d.mc + n + i];                    // sigma of the two box rows (stored above)
         SC_SYNC();
-        lin_condense_mfma<NT, NU, NW>(W, N, nu, sf, Hc, G, W.rd, lane);
-        SC_SYNC();
+        if constexpr (!BIG) {
+            lin_condense_mfma<NT, NU, NW>(W, N, nu, sf, Hc, G, W.rd, lane);
+            SC_SYNC();
+        }
         LP(6);
         // inertia correction: M + delta I until the Cholesky succeeds
         double delta = 0.0;
@@ -551,6 +574,10 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
         for (int t = 0; t < 40 && !ok; ++t) {
             if constexpr (NN > 0) {
                 ok = ipm::chol_reg_solve<NN>(W.M, W.rhs, W.L, W.dz, delta, lane);
+            } else if constexpr (BIG) {
+                lin_condense_mfma<NT, NU, NW, true>(W, N, nu, sf, Hc, G, W.rd, lane, delta);   // M + delta I, lower tiles, into the factor's storage
+                SC_SYNC();
+                ok = ipm::cholesky_ix<NW, ipm::LdTile>(W.L, n, ipm::LdTile{}, lane, W.red + 8);
             } else {
                 for (int r = lane >> 6; r < n; r += NW)                      // lower triangle, row stride n | 1 (odd: no LDS bank conflicts)
                     for (int cc = lane & 63; cc <= r; cc += 64) W.L[r * (n | 1) + cc] = W.M[r * n + cc] + (cc == r ? delta : 0.0);
@@ -564,7 +591,8 @@ __global__ __launch_bounds__(BIG ? 256 : 64) void mpclin_kernel(const sc_mpclin_
         if constexpr (NN == 0) {
             for (int i = lane; i < n; i += TH) W.dz[i] = W.rhs[i];
             SC_SYNC();
-            chol_solve_lds<NW>(W.L, W.dz, n, n | 1, lane);
+            if constexpr (BIG) ipm::chol_solve_ix<NW, ipm::LdTile>(W.L, W.dz, n, ipm::LdTile{}, lane);
+            else chol_solve_lds<NW>(W.L, W.dz, n, n | 1, lane);
         }
         LP(7);
         // point displacements  G dz, then ds = J dz + r_p, dlam, step lengths
