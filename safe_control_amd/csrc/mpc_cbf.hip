@@ -207,16 +207,19 @@ __device__ inline void barrier_at(double px_, double py_, const double* o, const
     const double a = fmax(fabs(o[2]), 1e-3) + c.Rrob, b = fmax(fabs(o[3]), 1e-3) + c.Rrob;
     const double e = fmax(fabs(o[4]), 2.0);
     double st, ct;
-    sincos(o[5], &st, &ct);
+    sincos_(o[5], &st, &ct);
     const double dx = px_ - o[0], dy = py_ - o[1];
     const double px = ct * dx + st * dy, py = -st * dx + ct * dy;
     const double ax = fabs(px) / a, ay = fabs(py) / b;
     const double sc = o[6];
-    h = sc * (pow(ax, e) + pow(ay, e) - 1.0);
+    double xe, xe1, xe2, ye, ye1, ye2;
+    ipm::pow3(ax, e, derivs, xe, xe1, xe2);                                // integer exponents: one multiply chain instead of three pow()
+    ipm::pow3(ay, e, derivs, ye, ye1, ye2);
+    h = sc * (xe + ye - 1.0);
     if (!derivs) { d0 = d1 = hxx = hxy = hyy = 0.0; return; }
     const double sx = px > 0 ? 1.0 : (px < 0 ? -1.0 : 0.0), sy = py > 0 ? 1.0 : (py < 0 ? -1.0 : 0.0);
-    const double gpx = e * pow(ax, e - 1) / a * sx, gpy = e * pow(ay, e - 1) / b * sy;
-    const double cxx = e * (e - 1) * pow(ax, e - 2) / (a * a), cyy = e * (e - 1) * pow(ay, e - 2) / (b * b);
+    const double gpx = e * xe1 / a * sx, gpy = e * ye1 / b * sy;
+    const double cxx = e * (e - 1) * xe2 / (a * a), cyy = e * (e - 1) * ye2 / (b * b);
     d0 = sc * (ct * gpx - st * gpy);
     d1 = sc * (st * gpx + ct * gpy);
     hxx = sc * (ct * ct * cxx + st * st * cyy);

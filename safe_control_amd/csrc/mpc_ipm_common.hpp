@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mpc_chol.hpp"
+#include "sc_math.hpp"
 
 namespace sc {
 namespace ipm {
@@ -41,6 +42,28 @@ __device__ __forceinline__ double wmax(double v) { return wred(v, [](double a, d
 // a, b >= 1e-3, e >= 2); oracle/mpc_cbf.py: barrier
 // LDS obstacle rows of the kernels that have the superellipsoid branch are normalised on load (normalise_obstacle_flags):
 // slot 6 is 0 for a circle and the ROW SCALE (> 0, 1 until scale_steep_barriers has run) for a superellipsoid.
+// x^e, x^(e-1), x^(e-2) for x >= 0, e >= 2.  The exponents the reference's scenes use are small even integers (4, 6, 10:
+// examples, dynamic_unicycle2D.py:159-183); for an integer e <= 64 ONE multiply chain gives x^(e-2) and two more products
+// the other powers, instead of three library pow() calls of ~150 instructions each -- six per barrier evaluation, which is
+// what an interior-point iteration on superellipsoid scenes (BASELINE config 5) mostly consisted of.
+__device__ __forceinline__ void pow3(double x, double e, bool derivs, double& pe, double& pe1, double& pe2) {
+    const double er = rint(e);
+    if (er == e && e <= 64.0) {
+        int n = (int)er - 2;                                               // >= 0
+        double r = 1.0, b = x;
+        while (n) { if (n & 1) r *= b; b *= b; n >>= 1; }
+        pe2 = r; pe1 = r * x; pe = pe1 * x;
+    } else {
+        pe = pow(x, e);
+        pe1 = derivs ? pow(x, e - 1) : 0.0;
+        pe2 = derivs ? pow(x, e - 2) : 0.0;
+    }
+}
+
+// CHAIN: integer exponents by multiply chain (pow3).  Off for mpc_gn.hip: with it the Quad2D / DoubleIntegrator2D kernels -- which
+// never execute this branch -- come out of the compiler broken (every solve fails in its first iteration; the same source with
+// library pow() is fine).  The cause was not isolated; tests/test_mpcgn_gpu.py guards the instantiation that is shipped.
+template <bool CHAIN = false>
 __device__ inline void ipm_barrier(double px_, double py_, const double* o, double Rrob, double beta, bool circles_only, bool derivs,
                                    double& h, double& d0, double& d1, double& hxx, double& hxy, double& hyy) {
     if (circles_only || o[6] == 0.0) {
@@ -58,11 +81,20 @@ __device__ inline void ipm_barrier(double px_, double py_, const double* o, doub
     const double px = ct * dx + st * dy, py = -st * dx + ct * dy;
     const double ax = fabs(px) / a, ay = fabs(py) / b;
     const double sc = o[6];
-    h = sc * (pow(ax, e) + pow(ay, e) - 1.0);
+    double xe, xe1, xe2, ye, ye1, ye2;
+    if constexpr (CHAIN) {
+        pow3(ax, e, derivs, xe, xe1, xe2);
+        pow3(ay, e, derivs, ye, ye1, ye2);
+    } else {
+        xe = pow(ax, e); ye = pow(ay, e);
+        xe1 = derivs ? pow(ax, e - 1) : 0.0; ye1 = derivs ? pow(ay, e - 1) : 0.0;
+        xe2 = derivs ? pow(ax, e - 2) : 0.0; ye2 = derivs ? pow(ay, e - 2) : 0.0;
+    }
+    h = sc * (xe + ye - 1.0);
     if (!derivs) { d0 = d1 = hxx = hxy = hyy = 0.0; return; }
     const double sx = px > 0 ? 1.0 : (px < 0 ? -1.0 : 0.0), sy = py > 0 ? 1.0 : (py < 0 ? -1.0 : 0.0);
-    const double gpx = e * pow(ax, e - 1) / a * sx, gpy = e * pow(ay, e - 1) / b * sy;
-    const double cxx = e * (e - 1) * pow(ax, e - 2) / (a * a), cyy = e * (e - 1) * pow(ay, e - 2) / (b * b);
+    const double gpx = e * xe1 / a * sx, gpy = e * ye1 / b * sy;
+    const double cxx = e * (e - 1) * xe2 / (a * a), cyy = e * (e - 1) * ye2 / (b * b);
     d0 = sc * (ct * gpx - st * gpy);
     d1 = sc * (st * gpx + ct * gpy);
     hxx = sc * (ct * ct * cxx + st * st * cyy);

@@ -177,7 +177,7 @@ __device__ __forceinline__ double lin_eval(const double* zv, const double* rhov,
     for (int e = lane; e < 2 * N * K; e += TH) {
         const int pt = e / K, j = e - pt * K;
         double h, d0, d1, hxx, hxy, hyy;
-        ipm::ipm_barrier(W.pts[2 * pt], W.pts[2 * pt + 1], W.obs + 7 * j, c.Rrob, c.beta, c.circles_only != 0, derivs, h, d0, d1, hxx, hxy, hyy);
+        ipm::ipm_barrier<true>(W.pts[2 * pt], W.pts[2 * pt + 1], W.obs + 7 * j, c.Rrob, c.beta, c.circles_only != 0, derivs, h, d0, d1, hxx, hxy, hyy);
         W.hk[e] = h;
         if (derivs) {
             W.dh[2 * e] = d0; W.dh[2 * e + 1] = d1;
