@@ -30,6 +30,12 @@
 #include "mpc_chol.hpp"
 #include "mpc_ipm_common.hpp"
 
+// the superellipsoid powers: library pow() here (false); the multiply chain of mpc_lin.hip / mpc_cbf.hip (true) is a developer
+// switch only -- tests/test_mpcgn_gpu.py failed with it (kernel 8)
+#ifndef SC_GN_CHAIN
+#define SC_GN_CHAIN false
+#endif
+
 namespace sc {
 
 namespace {
@@ -269,7 +275,7 @@ __device__ __forceinline__ double gn_eval(const double* zv, const GnMem& W, cons
     for (int e = lane; e < 3 * N * K; e += 64) {
         const int pt = e / K, j = e - pt * K;
         double h, d0, d1, hxx, hxy, hyy;
-        ipm::ipm_barrier(W.pts[2 * pt], W.pts[2 * pt + 1], W.obs + 7 * j, c.Rrob, c.beta, c.circles_only != 0, derivs, h, d0, d1, hxx, hxy, hyy);
+        ipm::ipm_barrier<SC_GN_CHAIN>(W.pts[2 * pt], W.pts[2 * pt + 1], W.obs + 7 * j, c.Rrob, c.beta, c.circles_only != 0, derivs, h, d0, d1, hxx, hxy, hyy);
         W.hk[e] = h;
         if (derivs) {
             W.dh[2 * e] = d0; W.dh[2 * e + 1] = d1;

@@ -60,9 +60,13 @@ __device__ __forceinline__ void pow3(double x, double e, bool derivs, double& pe
     }
 }
 
-// CHAIN: integer exponents by multiply chain (pow3).  Off for mpc_gn.hip: with it the Quad2D / DoubleIntegrator2D kernels -- which
-// never execute this branch -- come out of the compiler broken (every solve fails in its first iteration; the same source with
-// library pow() is fine).  The cause was not isolated; tests/test_mpcgn_gpu.py guards the instantiation that is shipped.
+// CHAIN: integer exponents by multiply chain (pow3).  Off for mpc_gn.hip (developer switch SC_GN_CHAIN there): with pow3 inlined
+// as written -- multiply loop AND pow() fallback -- the Quad2D kernel, which never executes this branch (circles only), stops
+// every solve in its first iteration (garbage barrier values), at -O3 and -O2, with -ffp-contract=on / off, and with SGPR spills
+// sent to memory (there: a perturbed path instead); with either half of pow3 alone, or with pow3 noinline, it is bit-identical
+// to the pow() build (tools/diag_gn.py, round 2).  Rounding is ruled out; what is left is the code generated for the
+// lane-divergent loop-plus-call region.  tests/test_mpcgn_gpu.py guards the instantiation that is shipped,
+// tests/test_mpclin_gpu.py / test_mpccbf*_gpu.py / test_od_rd1_gpu.py the two kernels that use the chain.
 template <bool CHAIN = false>
 __device__ inline void ipm_barrier(double px_, double py_, const double* o, double Rrob, double beta, bool circles_only, bool derivs,
                                    double& h, double& d0, double& d1, double& hxx, double& hxy, double& hyy) {
