@@ -192,8 +192,9 @@ static int check_mpclin(const sc_mpclin_params* p, const double* model, int64_t 
 static int check_mpcgn(const sc_mpcgn_params* p, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,
                        const void* obs, const void* u_out, const void* status_out) {
     if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
-    if (p->model_id != SC_MODEL_DOUBLE_INTEGRATOR2D && p->model_id != SC_MODEL_QUAD2D)
-        return fail(SC_ERR_UNSUPPORTED, "this entry point serves DoubleIntegrator2D and Quad2D");
+    if (p->model_id != SC_MODEL_DOUBLE_INTEGRATOR2D && p->model_id != SC_MODEL_QUAD2D && p->model_id != SC_MODEL_KINEMATIC_BICYCLE2D)
+        return fail(SC_ERR_UNSUPPORTED, "this entry point serves DoubleIntegrator2D, Quad2D and KinematicBicycle2D (the C3BF / DPCBF "
+                                        "discrete-time barriers of the bicycle are functions of the full state: not served)");
     if (B < 0) return fail(SC_ERR_INVALID_ARGUMENT, "B < 0");
     if (K < 1) return fail(SC_ERR_INVALID_ARGUMENT, "K < 1 (pad with [1000,1000,0,...] rows like update_tvp)");
     if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
@@ -206,6 +207,8 @@ static int check_mpcgn(const sc_mpcgn_params* p, int64_t B, int32_t K, const voi
     if (!(p->u_hi[0] > p->u_lo[0]) || !(p->u_hi[1] > p->u_lo[1])) return fail(SC_ERR_INVALID_ARGUMENT, "u_hi must be > u_lo");
     if (p->model_id == SC_MODEL_DOUBLE_INTEGRATOR2D && !(p->v_max > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "DoubleIntegrator2D needs v_max > 0");
     if (p->model_id == SC_MODEL_QUAD2D && (!(p->mass > 0) || !(p->inertia > 0))) return fail(SC_ERR_INVALID_ARGUMENT, "Quad2D needs mass, inertia > 0");
+    if (p->model_id == SC_MODEL_KINEMATIC_BICYCLE2D && (!(p->rear_ax_dist > 0) || !(p->v_max > p->v_min)))
+        return fail(SC_ERR_INVALID_ARGUMENT, "KinematicBicycle2D needs rear_ax_dist > 0 and v_max > v_min");
     if (B > 0 && (!X || !u_prev || !goal || !obs || !u_out || !status_out)) return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
     return SC_OK;

@@ -57,7 +57,7 @@ template <> struct GnModel<SC_MODEL_DOUBLE_INTEGRATOR2D> {
     // and including that curvature changes neither the convergence statistics nor the iteration counts on the test draws
     // while the backward pass costs 70 % more time per solve (measured) -- so it is left out (the oracle does the same).
     static constexpr bool EXACT = false;
-    static constexpr int TIDX = 0;
+    static constexpr int TIDX = 0, NH = 2;
     template <bool JAC, bool STEP>
     static __device__ __forceinline__ void map(const double* x, const double* u, const GnPar& q, double* xn, double (*A)[4], double (*B)[2]) {
         const double dt = q.dt;
@@ -121,7 +121,7 @@ template <> struct GnModel<SC_MODEL_QUAD2D> {
     // (x, u); c_k = pos(F(F(x, u), u)) reaches the nonlinear rows through x + dt v), the term D' H(y1; P' nu_2) D vanishes
     // (P' nu_2 has no velocity component).  Costates: p_N = mu_N, p_k = mu_k + (d points_k / d x_k)' nu + A_k' p_{k+1}, with
     // A_k = I + dt (e_0 e_3' + e_1 e_4' + e_2 e_5') + A32 e_3 e_2' + A42 e_4 e_2'.  Wave-uniform: every lane, in registers.
-    static constexpr int TIDX = 2;
+    static constexpr int TIDX = 2, NH = 2;                                   // NH: second-order scalars per stage (a_k, b_k)
     static __device__ __forceinline__ void second_order(const double* xs, const double* z, const double* y, const double* cq,
                                                         const double* xg, double* ab, int N, double sf, const GnPar& q, int lane) {
         const double dt = q.dt, im = 1.0 / q.mass;
@@ -154,6 +154,123 @@ template <> struct GnModel<SC_MODEL_QUAD2D> {
     }
 };
 
+// KinematicBicycle2D (robots/kinematic_bicycle2D.py:75-123: x = (px, py, theta, v), u = (a, beta); f = [v cos, v sin, 0, 0],
+// g = [[0, -v sin], [0, v cos], [0, v / Lr], [1, 0]]; step() = Euler + speed clipped to [v_min, v_max]); oracle/mpc_gn.py: kb_F,
+// kb_S, kb_H.  The speed is a bounded state (mpc_cbf.py:205-207): NB = 1 pair of rows per stage on component BIDX = 3.
+template <> struct GnModel<SC_MODEL_KINEMATIC_BICYCLE2D> {
+    static constexpr int NX = 4, NB = 1, BIDX = 3;
+    static constexpr bool EXACT = true;                     // heading dynamics: Gauss-Newton alone converges on a third of the draws
+    static constexpr int TIDX = 2, NH = 10;                 // NH: the 4 x 4 symmetric stage Hessian over (theta, v, a, beta)
+    template <bool JAC, bool STEP>
+    static __device__ __forceinline__ void map(const double* x, const double* u, const GnPar& q, double* xn, double (*A)[4], double (*B)[2]) {
+        double s, c;
+        sincos_(x[2], &s, &c);
+        const double dt = q.dt, v = x[3], b = u[1], iL = 1.0 / q.Lr;
+        xn[0] = x[0] + (v * c - v * s * b) * dt;
+        xn[1] = x[1] + (v * s + v * c * b) * dt;
+        xn[2] = x[2] + (v * iL * b) * dt;
+        double vn = v + u[0] * dt;
+        if constexpr (JAC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) A[i][j] = i == j ? 1.0 : 0.0;
+                B[i][0] = 0.0; B[i][1] = 0.0;
+            }
+            A[0][2] = dt * (-v * s - v * c * b); A[0][3] = dt * (c - s * b);
+            A[1][2] = dt * (v * c - v * s * b);  A[1][3] = dt * (s + c * b);
+            A[2][3] = dt * b * iL;
+            B[0][1] = -dt * v * s; B[1][1] = dt * v * c; B[2][1] = dt * v * iL; B[3][0] = dt;
+        }
+        if constexpr (STEP) {
+            if (!(q.v_min <= vn && vn <= q.v_max)) {
+                vn = fmin(fmax(vn, q.v_min), q.v_max);
+                if constexpr (JAC) { A[3][3] = 0.0; B[3][0] = 0.0; }
+            }
+        }
+        xn[3] = vn;
+    }
+    // Second-order terms (oracle/mpc_gn.py: evaluate, exact_hessian; kb_H).  sum_i c_i grad^2 F_i has four entries, on (theta, theta),
+    // (theta, v), (theta, beta), (v, beta), the same for F and for step() (the clipped row is linear).  Per stage
+    //   H_k = H(x_k, u_k; p_{k+1} + P'nu_1 + S2x'P'nu_2) + D' H(y1, u_k; P'nu_2) D,   y1 = step(x_k, u_k),  D = d(y1, u_k) / d(x_k, u_k),
+    // a symmetric 4 x 4 over (theta, v, a, beta): ten scalars in Hk[10 k ..].  Costates: p_N = mu_N,
+    // p_k = mu_k + P'nu_0 + S1x'(P'nu_1 + S2x'P'nu_2) + A_k' p_{k+1}; mu_k = sf 2 Q (x_k - xg) + (lam_hi - lam_lo) e_v.
+    // Wave-uniform: every lane, in registers; lane 0 stores.
+    static __device__ __forceinline__ void second_order(const double* xs, const double* z, const double* y, const double* cq,
+                                                        const double* xg, const double* lam_v, double* Hk, int N, double sf,
+                                                        const GnPar& q, int lane) {
+        const double dt = q.dt, iL = 1.0 / q.Lr;
+        double p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = sf * 2.0 * cq[i] * (xs[N * 4 + i] - xg[i]);
+        p[3] += lam_v[2 * (N - 1)] - lam_v[2 * (N - 1) + 1];
+        for (int k = N - 1; k >= 0; --k) {
+            const double th = xs[k * 4 + 2], v = xs[k * 4 + 3], a = z[2 * k], b = z[2 * k + 1];
+            double s, c, s1, c1;
+            sincos_(th, &s, &c);
+            const double th1 = th + (v * iL * b) * dt, v1u = v + a * dt;
+            const bool cl = !(q.v_min <= v1u && v1u <= q.v_max);
+            const double v1 = fmin(fmax(v1u, q.v_min), q.v_max);
+            sincos_(th1, &s1, &c1);
+            const double n0x = -y[6 * k], n0y = -y[6 * k + 1], n1x = -y[6 * k + 2], n1y = -y[6 * k + 3], n2x = -y[6 * k + 4], n2y = -y[6 * k + 5];
+            // S2x rows 0, 1 (at y1): columns theta, v
+            const double B02 = dt * (-v1 * s1 - v1 * c1 * b), B03 = dt * (c1 - s1 * b), B12 = dt * (v1 * c1 - v1 * s1 * b), B13 = dt * (s1 + c1 * b);
+            const double w0 = n1x + n2x, w1 = n1y + n2y, w2 = B02 * n2x + B12 * n2y, w3 = B03 * n2x + B13 * n2y;   // P'nu_1 + S2x'P'nu_2
+            const double ct0 = p[0] + w0, ct1 = p[1] + w1, ct2 = p[2] + w2;
+            const double h22 = ct0 * (dt * (-v * c + v * s * b)) + ct1 * (dt * (-v * s - v * c * b));
+            const double h23 = ct0 * (dt * (-s - c * b)) + ct1 * (dt * (c - s * b));
+            const double h25 = ct0 * (-dt * v * c) + ct1 * (-dt * v * s);
+            const double h35 = ct0 * (-dt * s) + ct1 * (dt * c) + ct2 * (dt * iL);
+            const double g22 = n2x * (dt * (-v1 * c1 + v1 * s1 * b)) + n2y * (dt * (-v1 * s1 - v1 * c1 * b));
+            const double g23 = n2x * (dt * (-s1 - c1 * b)) + n2y * (dt * (c1 - s1 * b));
+            const double g25 = n2x * (-dt * v1 * c1) + n2y * (-dt * v1 * s1);
+            const double g35 = n2x * (-dt * s1) + n2y * (dt * c1);
+            if (lane == 0) {
+                // rows of D for theta+, v+, beta over (theta, v, a, beta)
+                const double d2[4] = {1.0, dt * b * iL, 0.0, dt * v * iL};
+                const double d3[4] = {0.0, cl ? 0.0 : 1.0, cl ? 0.0 : dt, 0.0};
+                const double d5[4] = {0.0, 0.0, 0.0, 1.0};
+                double H[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        H[i][j] = g22 * d2[i] * d2[j] + g23 * (d2[i] * d3[j] + d3[i] * d2[j]) + g25 * (d2[i] * d5[j] + d5[i] * d2[j]) +
+                                  g35 * (d3[i] * d5[j] + d5[i] * d3[j]);
+                H[0][0] += h22; H[0][1] += h23; H[0][3] += h25; H[1][3] += h35;
+                int o = 10 * k;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = i; j < 4; ++j) Hk[o++] = H[i][j];
+            }
+            if (k >= 1) {
+                const double A02 = dt * (-v * s - v * c * b), A03 = dt * (c - s * b), A12 = dt * (v * c - v * s * b), A13 = dt * (s + c * b),
+                             A23 = dt * b * iL;
+                double np_[4];
+                np_[0] = n0x + w0 + p[0];
+                np_[1] = n0y + w1 + p[1];
+                np_[2] = (w2 + A02 * w0 + A12 * w1) + (p[2] + A02 * p[0] + A12 * p[1]);
+                np_[3] = ((cl ? 0.0 : w3) + A03 * w0 + A13 * w1 + A23 * w2) + (p[3] + A03 * p[0] + A13 * p[1] + A23 * p[2]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) p[i] = np_[i] + sf * 2.0 * cq[i] * (xs[k * 4 + i] - xg[i]);
+                p[3] += lam_v[2 * (k - 1)] - lam_v[2 * (k - 1) + 1];
+            }
+        }
+    }
+    // q_i' H_k q_j with q = (dtheta_k/dz_i, dv_k/dz_i, [i = a_k], [i = beta_k])
+    static __device__ __forceinline__ double hess_term(const double* Ph, const double* Hk, int k, int i, int j, int n) {
+        const double qi[4] = {Ph[(size_t)(k * 4 + 2) * n + i], Ph[(size_t)(k * 4 + 3) * n + i], i == 2 * k ? 1.0 : 0.0, i == 2 * k + 1 ? 1.0 : 0.0};
+        const double qj[4] = {Ph[(size_t)(k * 4 + 2) * n + j], Ph[(size_t)(k * 4 + 3) * n + j], j == 2 * k ? 1.0 : 0.0, j == 2 * k + 1 ? 1.0 : 0.0};
+        const double* H = Hk + 10 * k;
+        const double r0 = H[0] * qj[0] + H[1] * qj[1] + H[2] * qj[2] + H[3] * qj[3];
+        const double r1 = H[1] * qj[0] + H[4] * qj[1] + H[5] * qj[2] + H[6] * qj[3];
+        const double r2 = H[2] * qj[0] + H[5] * qj[1] + H[7] * qj[2] + H[8] * qj[3];
+        const double r3 = H[3] * qj[0] + H[6] * qj[1] + H[8] * qj[2] + H[9] * qj[3];
+        return qi[0] * r0 + qi[1] * r1 + qi[2] * r2 + qi[3] * r3;
+    }
+};
+
 struct GnMem {
     double *cq, *xg, *up;                                 // Q (6) | R (2) | u_lo (2) | u_hi (2) ; goal state ; previous input
     double *z, *zt, *zb, *dz, *gs, *rd, *rhs;             // n each
@@ -161,21 +278,21 @@ struct GnMem {
     double *obs, *hk, *dh, *hh;                           // 7K | 3N K | 6N K | 9N K
     double *g, *s, *lam, *ds, *dlam, *vb;                 // m each
     double *Psi, *M, *L;                                  // 36 N | n n | (L: scratch in T)
-    double *Hk;                                           // 2 N: second-order terms of the dynamics (a_k, b_k)
+    double *Hk;                                           // NH N: second-order terms of the dynamics per stage
 };
 
 struct GnDims { int N, K, n, m, mc, ms; bool circles; };
 
 // circles: the barrier Hessian of a circle is 2 I, so its per-point table (9 N K) is not stored
-__host__ __device__ inline size_t mpcgn_lds_doubles(int N, int K, int nx, int nb, bool circles) {
+__host__ __device__ inline size_t mpcgn_lds_doubles(int N, int K, int nx, int nb, bool circles, int nh = 2) {
     const size_t n = 2 * (size_t)N, m = (size_t)N * K + 2 * (size_t)nb * N + 2 * n;
     size_t tot = 12 + nx + 2 + 7 * n + (size_t)(N + 1) * nx + (size_t)(N + 1) * nx * n + 18 * (size_t)N + 12 * (size_t)N * n +
-                 7 * (size_t)K + (circles ? 9 : 18) * (size_t)N * K + 5 * m + 36 * (size_t)N + n * n + 2 * (size_t)N;
+                 7 * (size_t)K + (circles ? 9 : 18) * (size_t)N * K + 5 * m + 36 * (size_t)N + n * n + (size_t)nh * N;
     const size_t need_l = n * (n + 1) + m, have = 6 * (size_t)N * n;         // Cholesky scratch L and the row vector vb live in T
     return tot + (need_l > have ? need_l - have : 0);
 }
 
-template <int NX>
+template <int NX, int NH>
 __device__ inline GnMem carve_gn(double* b, const GnDims& d) {
     GnMem W;
     auto take = [&](size_t c) { double* r = b; b += c; return r; };
@@ -188,7 +305,7 @@ __device__ inline GnMem carve_gn(double* b, const GnDims& d) {
     W.obs = take(7 * K); W.hk = take(3 * N * K); W.dh = take(6 * N * K); W.hh = take(d.circles ? 0 : 9 * N * K);
     W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m);
     W.Psi = take(36 * N); W.M = take((size_t)n * n);
-    W.Hk = take(2 * (size_t)N);
+    W.Hk = take((size_t)NH * N);
     W.T = take((size_t)6 * N * n); W.L = W.T;                     // T is dead once M is assembled
     W.vb = W.T + (size_t)n * (n + 1);                              // written before T is built and again after the solve
     return W;
@@ -357,7 +474,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
     d.N = NT > 0 ? NT : p.horizon; d.K = K; d.n = 2 * d.N; d.mc = d.N * K; d.ms = 2 * NB * d.N; d.m = d.mc + d.ms + 2 * d.n;
     d.circles = p.circles_only != 0;
     const int N = d.N, n = d.n, m = d.m;
-    const GnMem W = carve_gn<NX>(sm, d);
+    const GnMem W = carve_gn<NX, Mdl::NH>(sm, d);
     GnConst c;
     {
         const double g1 = p.alpha1 + p.alpha2, g2 = p.alpha1 * p.alpha2;
@@ -432,7 +549,8 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         GP(1);
         // ---- second derivatives of the dynamics and of step o step, weighted by the costates of the Lagrangian (oracle:
         // evaluate, exact_hessian).  W.y still holds A' lam per point (= -nu).  Leaves two scalars per stage in W.Hk.
-        if constexpr (Mdl::EXACT) Mdl::second_order(W.xs, W.z, W.y, W.cq, W.xg, W.Hk, N, sf, q, lane);
+        if constexpr (MODEL == SC_MODEL_KINEMATIC_BICYCLE2D) Mdl::second_order(W.xs, W.z, W.y, W.cq, W.xg, W.lam + d.mc, W.Hk, N, sf, q, lane);
+        else if constexpr (Mdl::EXACT) Mdl::second_order(W.xs, W.z, W.y, W.cq, W.xg, W.Hk, N, sf, q, lane);
         SC_SYNC();
         GP(2);
         double e_d = 0.0, e_p = 0.0, e_c0 = 0.0, lmx = 0.0;
@@ -516,7 +634,9 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
                     acc += (W.ds[r0] + W.ds[r0 + 1]) * W.Ph[(size_t)(k * NX + Mdl::BIDX) * n + i] * W.Ph[(size_t)(k * NX + Mdl::BIDX) * n + j];
                 }
             }
-            if constexpr (Mdl::EXACT) {
+            if constexpr (MODEL == SC_MODEL_KINEMATIC_BICYCLE2D) {
+                for (int k = 0; k < N; ++k) acc += Mdl::hess_term(W.Ph, W.Hk, k, i, j, n);
+            } else if constexpr (Mdl::EXACT) {
                 // V_k' H_k V_k with H_k = a_k e_t e_t' + b_k (e_t s' + s e_t'): t = the model's angle state, s = the two inputs of stage k
                 for (int k = 0; k < N; ++k) {
                     const double ti = W.Ph[(size_t)(k * NX + Mdl::TIDX) * n + i], tj = W.Ph[(size_t)(k * NX + Mdl::TIDX) * n + j];
@@ -660,7 +780,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
 template <int MODEL>
 static hipError_t mpcgn_launch_m(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
                                  const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream) {
-    const size_t lds = mpcgn_lds_doubles(p.horizon, K, GnModel<MODEL>::NX, GnModel<MODEL>::NB, p.circles_only != 0) * sizeof(double);
+    const size_t lds = mpcgn_lds_doubles(p.horizon, K, GnModel<MODEL>::NX, GnModel<MODEL>::NB, p.circles_only != 0, GnModel<MODEL>::NH) * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 64 * 1024) {
@@ -678,7 +798,8 @@ static hipError_t mpcgn_launch_m(const sc_mpcgn_params& p, long long B, int K, c
 
 size_t mpcgn_lds_bytes(int model_id, int N, int K, int circles_only) {
     const int nx = model_id == SC_MODEL_QUAD2D ? 6 : 4;
-    return mpcgn_lds_doubles(N, K, nx, 0, circles_only != 0) * sizeof(double);
+    const bool kb = model_id == SC_MODEL_KINEMATIC_BICYCLE2D;
+    return mpcgn_lds_doubles(N, K, nx, kb ? 1 : 0, circles_only != 0, kb ? 10 : 2) * sizeof(double);
 }
 
 hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
@@ -688,6 +809,8 @@ hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void
             return mpcgn_launch_m<SC_MODEL_DOUBLE_INTEGRATOR2D>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
         case SC_MODEL_QUAD2D:
             return mpcgn_launch_m<SC_MODEL_QUAD2D>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        case SC_MODEL_KINEMATIC_BICYCLE2D:
+            return mpcgn_launch_m<SC_MODEL_KINEMATIC_BICYCLE2D>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
         default:
             return hipErrorInvalidValue;
     }

@@ -1,4 +1,4 @@
-"""MPC-CBF for DoubleIntegrator2D and Quad2D on the gfx950 kernel csrc/mpc_gn.hip.
+"""MPC-CBF for DoubleIntegrator2D, Quad2D and KinematicBicycle2D on the gfx950 kernel csrc/mpc_gn.hip.
 
 ``safe_control_amd.MPCCBF(robot, robot_spec, ...)`` returns a ``GnMPCCBF`` for these models (the reference serves every
 model from the one MPCCBF class, position_control/mpc_cbf.py:7-100); ``BatchedGnMPCCBF`` solves B agents per launch on
@@ -12,7 +12,7 @@ from .. import _lib
 from ..robots.spec import complete_robot_spec
 from .mpc_cbf import apply_mpc_overrides, pad_obstacles
 
-GN_MODELS = ("DoubleIntegrator2D", "Quad2D")
+GN_MODELS = ("DoubleIntegrator2D", "Quad2D", "KinematicBicycle2D")
 
 
 def model_constants(robot_spec):
@@ -26,6 +26,10 @@ def model_constants(robot_spec):
     if m == "Quad2D":
         return dict(nx=6, Q=[25.0, 25.0, 50.0, 10.0, 10.0, 50.0], R=[0.5, 0.5], cbf_param={"alpha1": 0.15, "alpha2": 0.15},
                     beta=1.01, u_lo=[robot_spec["f_min"]] * 2, u_hi=[robot_spec["f_max"]] * 2, circles_only=True)
+    if m == "KinematicBicycle2D":               # mpc_cbf.py:31-33,64-67,205-211; barrier inflation kinematic_bicycle2D.py:175 (1.1)
+        return dict(nx=4, Q=[50.0, 50.0, 1.0, 1.0], R=[0.5, 5000.0], cbf_param={"alpha1": 0.1, "alpha2": 0.1}, beta=1.1,
+                    u_lo=[-robot_spec["a_max"], -robot_spec["beta_max"]], u_hi=[robot_spec["a_max"], robot_spec["beta_max"]],
+                    circles_only=True)
     raise NotImplementedError(m)
 
 
@@ -56,7 +60,7 @@ def make_params(robot_spec, mc, cbf_param, horizon, dt, radius, io_dtype, obs_sh
 
 
 class GnMPCCBF:
-    """Drop-in for position_control.mpc_cbf.MPCCBF with a DoubleIntegrator2D or Quad2D robot."""
+    """Drop-in for position_control.mpc_cbf.MPCCBF with a DoubleIntegrator2D, Quad2D or KinematicBicycle2D robot."""
 
     def __init__(self, robot, robot_spec, show_mpc_traj=False, num_obs=5, device=0):
         self.robot = robot
@@ -112,7 +116,7 @@ class GnMPCCBF:
 
 class BatchedGnMPCCBF:
     """``solve(X[B,nx], u_prev[B,2], goal[B,2], obs[B,K,7] | obs[K,7])`` -> ``u[B,2]``, ``status[B]``, ``iters[B]`` (and
-    ``z[B,2N]`` if asked); nx = 4 (DoubleIntegrator2D) or 6 (Quad2D)."""
+    ``z[B,2N]`` if asked); nx = 4 (DoubleIntegrator2D, KinematicBicycle2D) or 6 (Quad2D)."""
 
     def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=100):
         self.robot_spec = complete_robot_spec(robot_spec)
