@@ -365,8 +365,8 @@ def linear_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
 
 
 def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
-    """MPC-CBF for DoubleIntegrator2D / Quad2D (csrc/mpc_gn.hip): the barrier steps the state with the robot's
-    own step(), one NLP per wavefront."""
+    """MPC-CBF for DoubleIntegrator2D / Quad2D / KinematicBicycle2D (csrc/mpc_gn.hip): the barrier steps the state
+    with the robot's own step(), one NLP per wavefront."""
     import numpy as np
     import torch
     import safe_control_amd as sca
@@ -377,6 +377,10 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
     if model == "Quad2D":
         Xn = np.zeros((B, 6)); Xn[:, 0:2] = Xd[:, 0:2]; Xn[:, 2] = rng.uniform(-0.2, 0.2, B); Xn[:, 3:5] = rng.uniform(-0.5, 0.5, (B, 2))
         up0 = np.full((B, 2), 0.5 * (ctl.robot_spec["f_min"] + ctl.robot_spec["f_max"]))
+    elif model == "KinematicBicycle2D":               # driving roughly towards the goal at 0.5 .. 3 m/s
+        Xn = np.zeros((B, 4)); Xn[:, 0:2] = Xd[:, 0:2]
+        Xn[:, 2] = np.arctan2(gn[:, 1] - Xd[:, 1], gn[:, 0] - Xd[:, 0]) + rng.uniform(-0.6, 0.6, B); Xn[:, 3] = rng.uniform(0.5, 3.0, B)
+        up0 = np.zeros((B, 2))
     else:
         Xn = np.zeros((B, 4)); Xn[:, 0:2] = Xd[:, 0:2]; Xn[:, 2:4] = rng.uniform(-0.7, 0.7, (B, 2))
         up0 = np.zeros((B, 2))
@@ -632,6 +636,7 @@ def main():
             res["quad3d_mpc_cbf_n20"] = linear_mpc_leg(dev, "Quad3D", N=20, steps=2)   # BASELINE config 5's horizon: big layout, four waves per problem
             res["double_integrator_mpc_cbf"] = gn_mpc_leg(dev, "DoubleIntegrator2D")
             res["quad2d_mpc_cbf"] = gn_mpc_leg(dev, "Quad2D")
+            res["kinematic_bicycle_mpc_cbf"] = gn_mpc_leg(dev, "KinematicBicycle2D")
             res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
             res["backup_cbf_qp"] = backup_cbf_leg(dev)
         if ws == 1 and not a.no_cpu_baseline:

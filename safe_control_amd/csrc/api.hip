@@ -192,9 +192,10 @@ static int check_mpclin(const sc_mpclin_params* p, const double* model, int64_t 
 static int check_mpcgn(const sc_mpcgn_params* p, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,
                        const void* obs, const void* u_out, const void* status_out) {
     if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
-    if (p->model_id != SC_MODEL_DOUBLE_INTEGRATOR2D && p->model_id != SC_MODEL_QUAD2D && p->model_id != SC_MODEL_KINEMATIC_BICYCLE2D)
-        return fail(SC_ERR_UNSUPPORTED, "this entry point serves DoubleIntegrator2D, Quad2D and KinematicBicycle2D (the C3BF / DPCBF "
-                                        "discrete-time barriers of the bicycle are functions of the full state: not served)");
+    const bool kb_family = p->model_id == SC_MODEL_KINEMATIC_BICYCLE2D || p->model_id == SC_MODEL_KINEMATIC_BICYCLE2D_C3BF ||
+                           p->model_id == SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF;
+    if (p->model_id != SC_MODEL_DOUBLE_INTEGRATOR2D && p->model_id != SC_MODEL_QUAD2D && !kb_family)
+        return fail(SC_ERR_UNSUPPORTED, "this entry point serves DoubleIntegrator2D, Quad2D and the KinematicBicycle2D family");
     if (B < 0) return fail(SC_ERR_INVALID_ARGUMENT, "B < 0");
     if (K < 1) return fail(SC_ERR_INVALID_ARGUMENT, "K < 1 (pad with [1000,1000,0,...] rows like update_tvp)");
     if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
@@ -207,7 +208,7 @@ static int check_mpcgn(const sc_mpcgn_params* p, int64_t B, int32_t K, const voi
     if (!(p->u_hi[0] > p->u_lo[0]) || !(p->u_hi[1] > p->u_lo[1])) return fail(SC_ERR_INVALID_ARGUMENT, "u_hi must be > u_lo");
     if (p->model_id == SC_MODEL_DOUBLE_INTEGRATOR2D && !(p->v_max > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "DoubleIntegrator2D needs v_max > 0");
     if (p->model_id == SC_MODEL_QUAD2D && (!(p->mass > 0) || !(p->inertia > 0))) return fail(SC_ERR_INVALID_ARGUMENT, "Quad2D needs mass, inertia > 0");
-    if (p->model_id == SC_MODEL_KINEMATIC_BICYCLE2D && (!(p->rear_ax_dist > 0) || !(p->v_max > p->v_min)))
+    if (kb_family && (!(p->rear_ax_dist > 0) || !(p->v_max > p->v_min)))
         return fail(SC_ERR_INVALID_ARGUMENT, "KinematicBicycle2D needs rear_ax_dist > 0 and v_max > v_min");
     if (B > 0 && (!X || !u_prev || !goal || !obs || !u_out || !status_out)) return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
@@ -765,9 +766,11 @@ static int check_tracking_split(const sc_tracking_params* params, int64_t B, int
     const sc_cbfqp_params* q = &params->qp;
     if (B < 0 || M < 0) return sc::fail(SC_ERR_INVALID_ARGUMENT, "B < 0 or M < 0");
     const bool integrator = q->model_id == SC_MODEL_SINGLE_INTEGRATOR2D || q->model_id == SC_MODEL_DOUBLE_INTEGRATOR2D;
-    if (q->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && q->model_id != SC_MODEL_KINEMATIC_BICYCLE2D && q->model_id != SC_MODEL_UNICYCLE2D &&
-        !integrator)
-        return sc::fail(SC_ERR_UNSUPPORTED, "select / apply are built for DynamicUnicycle2D, Unicycle2D, KinematicBicycle2D and the integrators");
+    // the C3BF / DPCBF bicycles differ from KinematicBicycle2D in their barrier only: select / apply run the bicycle's kernels for them
+    const bool bicycle = q->model_id == SC_MODEL_KINEMATIC_BICYCLE2D || q->model_id == SC_MODEL_KINEMATIC_BICYCLE2D_C3BF ||
+                         q->model_id == SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF;
+    if (q->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && !bicycle && q->model_id != SC_MODEL_UNICYCLE2D && !integrator)
+        return sc::fail(SC_ERR_UNSUPPORTED, "select / apply are built for DynamicUnicycle2D, Unicycle2D, the KinematicBicycle2D family and the integrators");
     if (integrator && params->enable_rotation)
         return sc::fail(SC_ERR_UNSUPPORTED, "the integrators' rotate state needs an attitude controller: enable_rotation must be 0");
     if (q->io_dtype != SC_DTYPE_F32 && q->io_dtype != SC_DTYPE_F64)

@@ -29,6 +29,7 @@
 #include "sc_math.hpp"
 #include "mpc_chol.hpp"
 #include "mpc_ipm_common.hpp"
+#include "mpc_hd4.hpp"
 
 // the superellipsoid powers: library pow() here (false); the multiply chain of mpc_lin.hip / mpc_cbf.hip (true) is a developer
 // switch only -- tests/test_mpcgn_gpu.py failed with it (kernel 8)
@@ -57,7 +58,7 @@ template <> struct GnModel<SC_MODEL_DOUBLE_INTEGRATOR2D> {
     // and including that curvature changes neither the convergence statistics nor the iteration counts on the test draws
     // while the backward pass costs 70 % more time per solve (measured) -- so it is left out (the oracle does the same).
     static constexpr bool EXACT = false;
-    static constexpr int TIDX = 0, NH = 2;
+    static constexpr int TIDX = 0, NH = 2, PD = 2, NP = 3;   // PD: dimension of a barrier point, NP: points per stage
     template <bool JAC, bool STEP>
     static __device__ __forceinline__ void map(const double* x, const double* u, const GnPar& q, double* xn, double (*A)[4], double (*B)[2]) {
         const double dt = q.dt;
@@ -121,7 +122,7 @@ template <> struct GnModel<SC_MODEL_QUAD2D> {
     // (x, u); c_k = pos(F(F(x, u), u)) reaches the nonlinear rows through x + dt v), the term D' H(y1; P' nu_2) D vanishes
     // (P' nu_2 has no velocity component).  Costates: p_N = mu_N, p_k = mu_k + (d points_k / d x_k)' nu + A_k' p_{k+1}, with
     // A_k = I + dt (e_0 e_3' + e_1 e_4' + e_2 e_5') + A32 e_3 e_2' + A42 e_4 e_2'.  Wave-uniform: every lane, in registers.
-    static constexpr int TIDX = 2, NH = 2;                                   // NH: second-order scalars per stage (a_k, b_k)
+    static constexpr int TIDX = 2, NH = 2, PD = 2, NP = 3;                   // NH: second-order scalars per stage (a_k, b_k)
     static __device__ __forceinline__ void second_order(const double* xs, const double* z, const double* y, const double* cq,
                                                         const double* xg, double* ab, int N, double sf, const GnPar& q, int lane) {
         const double dt = q.dt, im = 1.0 / q.mass;
@@ -160,7 +161,7 @@ template <> struct GnModel<SC_MODEL_QUAD2D> {
 template <> struct GnModel<SC_MODEL_KINEMATIC_BICYCLE2D> {
     static constexpr int NX = 4, NB = 1, BIDX = 3;
     static constexpr bool EXACT = true;                     // heading dynamics: Gauss-Newton alone converges on a third of the draws
-    static constexpr int TIDX = 2, NH = 10;                 // NH: the 4 x 4 symmetric stage Hessian over (theta, v, a, beta)
+    static constexpr int TIDX = 2, NH = 10, PD = 2, NP = 3;  // NH: the 4 x 4 symmetric stage Hessian over (theta, v, a, beta)
     template <bool JAC, bool STEP>
     static __device__ __forceinline__ void map(const double* x, const double* u, const GnPar& q, double* xn, double (*A)[4], double (*B)[2]) {
         double s, c;
@@ -271,6 +272,85 @@ template <> struct GnModel<SC_MODEL_KINEMATIC_BICYCLE2D> {
     }
 };
 
+// KinematicBicycle2D_C3BF / _DPCBF under the MPC (mpc_cbf.py:31-33,68-73,205-211,312-315): the bicycle's dynamics, cost and bounds with
+// a rel-degree-1 discrete-time barrier of the FULL state, row = h(step(x_k, u_k)) - (1 - alpha) h(x_k); oracle/mpc_kb_state.py.
+struct GnKbState : GnModel<SC_MODEL_KINEMATIC_BICYCLE2D> {
+    static constexpr int PD = 4, NP = 2;
+    // H_k = H(x_k, u_k; p_{k+1} + nu_1) (kb_H: entries (theta,theta), (theta,v), (theta,beta), (v,beta); the clipped row of step() is
+    // linear); costates p_k = mu_k + nu_0 + S1x' nu_1 + A_k' p_{k+1}, nu_p = -w_p sum_j lam_kj dh_j(point p) = -y[8 k + 4 p ..].
+    static __device__ __forceinline__ void second_order(const double* xs, const double* z, const double* y, const double* cq,
+                                                        const double* xg, const double* lam_v, double* Hk, int N, double sf,
+                                                        const GnPar& q, int lane) {
+        const double dt = q.dt, iL = 1.0 / q.Lr;
+        double p[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = sf * 2.0 * cq[i] * (xs[N * 4 + i] - xg[i]);
+        p[3] += lam_v[2 * (N - 1)] - lam_v[2 * (N - 1) + 1];
+        for (int k = N - 1; k >= 0; --k) {
+            const double th = xs[k * 4 + 2], v = xs[k * 4 + 3], a = z[2 * k], b = z[2 * k + 1];
+            double s, c;
+            sincos_(th, &s, &c);
+            const double v1u = v + a * dt;
+            const bool cl = !(q.v_min <= v1u && v1u <= q.v_max);
+            double n0[4], n1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { n0[i] = -y[8 * k + i]; n1[i] = -y[8 * k + 4 + i]; }
+            const double ct0 = p[0] + n1[0], ct1 = p[1] + n1[1], ct2 = p[2] + n1[2];
+            if (lane == 0) {
+                double* H = Hk + 10 * k;
+#pragma unroll
+                for (int t = 0; t < 10; ++t) H[t] = 0.0;
+                H[0] = ct0 * (dt * (-v * c + v * s * b)) + ct1 * (dt * (-v * s - v * c * b));
+                H[1] = ct0 * (dt * (-s - c * b)) + ct1 * (dt * (c - s * b));
+                H[3] = ct0 * (-dt * v * c) + ct1 * (-dt * v * s);
+                H[6] = ct0 * (-dt * s) + ct1 * (dt * c) + ct2 * (dt * iL);
+            }
+            if (k >= 1) {
+                const double A02 = dt * (-v * s - v * c * b), A03 = dt * (c - s * b), A12 = dt * (v * c - v * s * b), A13 = dt * (s + c * b),
+                             A23 = dt * b * iL;
+                double np_[4];
+                np_[0] = n0[0] + n1[0] + p[0];
+                np_[1] = n0[1] + n1[1] + p[1];
+                np_[2] = n0[2] + (n1[2] + A02 * n1[0] + A12 * n1[1]) + (p[2] + A02 * p[0] + A12 * p[1]);
+                np_[3] = n0[3] + ((cl ? 0.0 : n1[3]) + A03 * n1[0] + A13 * n1[1] + A23 * n1[2]) + (p[3] + A03 * p[0] + A13 * p[1] + A23 * p[2]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) p[i] = np_[i] + sf * 2.0 * cq[i] * (xs[k * 4 + i] - xg[i]);
+                p[3] += lam_v[2 * (k - 1)] - lam_v[2 * (k - 1) + 1];
+            }
+        }
+    }
+    template <class F>
+    static __device__ __forceinline__ void derivs_of(F fn, const double* xv, const double* o, double radius, double& h, double* g4, double* h10) {
+        hd::Hd4 x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = hd::variable(xv[i], i);
+        const hd::Hd4 r = fn(x, o, radius);
+        h = r.v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g4[i] = r.g[i];
+#pragma unroll
+        for (int t = 0; t < 10; ++t) h10[t] = r.h[t];
+    }
+};
+template <> struct GnModel<SC_MODEL_KINEMATIC_BICYCLE2D_C3BF> : GnKbState {
+    static __device__ __noinline__ void barrier_d(const double* xv, const double* o, double radius, double& h, double* g4, double* h10) {
+        derivs_of([](const hd::Hd4* x, const double* ob, double r) { return hd::h_c3bf<hd::Hd4>(x, ob, r); }, xv, o, radius, h, g4, h10);
+    }
+    static __device__ __forceinline__ double barrier_v(const double* xv, const double* o, double radius) {
+        const double x[4] = {xv[0], xv[1], xv[2], xv[3]};
+        return hd::h_c3bf<double>(x, o, radius);
+    }
+};
+template <> struct GnModel<SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF> : GnKbState {
+    static __device__ __noinline__ void barrier_d(const double* xv, const double* o, double radius, double& h, double* g4, double* h10) {
+        derivs_of([](const hd::Hd4* x, const double* ob, double r) { return hd::h_dpcbf<hd::Hd4>(x, ob, r); }, xv, o, radius, h, g4, h10);
+    }
+    static __device__ __forceinline__ double barrier_v(const double* xv, const double* o, double radius) {
+        const double x[4] = {xv[0], xv[1], xv[2], xv[3]};
+        return hd::h_dpcbf<double>(x, o, radius);
+    }
+};
+
 struct GnMem {
     double *cq, *xg, *up;                                 // Q (6) | R (2) | u_lo (2) | u_hi (2) ; goal state ; previous input
     double *z, *zt, *zb, *dz, *gs, *rd, *rhs;             // n each
@@ -284,15 +364,16 @@ struct GnMem {
 struct GnDims { int N, K, n, m, mc, ms; bool circles; };
 
 // circles: the barrier Hessian of a circle is 2 I, so its per-point table (9 N K) is not stored
-__host__ __device__ inline size_t mpcgn_lds_doubles(int N, int K, int nx, int nb, bool circles, int nh = 2) {
+__host__ __device__ inline size_t mpcgn_lds_doubles(int N, int K, int nx, int nb, bool circles, int nh = 2, int pd = 2, int np = 3) {
     const size_t n = 2 * (size_t)N, m = (size_t)N * K + 2 * (size_t)nb * N + 2 * n;
-    size_t tot = 12 + nx + 2 + 7 * n + (size_t)(N + 1) * nx + (size_t)(N + 1) * nx * n + 18 * (size_t)N + 12 * (size_t)N * n +
-                 7 * (size_t)K + (circles ? 9 : 18) * (size_t)N * K + 5 * m + 36 * (size_t)N + n * n + (size_t)nh * N;
-    const size_t need_l = n * (n + 1) + m, have = 6 * (size_t)N * n;         // Cholesky scratch L and the row vector vb live in T
+    const size_t rs = (size_t)pd * np, hs = (size_t)pd * (pd + 1) / 2;       // rows of a stage block (6 | 8), entries of a point Hessian (3 | 10)
+    size_t tot = 12 + nx + 2 + 7 * n + (size_t)(N + 1) * nx + (size_t)(N + 1) * nx * n + 3 * rs * N + 2 * rs * N * n +
+                 7 * (size_t)K + (size_t)np * (1 + pd + (circles ? 0 : hs)) * N * K + 5 * m + rs * rs * N + n * n + (size_t)nh * N;
+    const size_t need_l = n * (n + 1) + m, have = rs * N * n;                // Cholesky scratch L and the row vector vb live in T
     return tot + (need_l > have ? need_l - have : 0);
 }
 
-template <int NX, int NH>
+template <int NX, int NH, int PD, int NP>
 __device__ inline GnMem carve_gn(double* b, const GnDims& d) {
     GnMem W;
     auto take = [&](size_t c) { double* r = b; b += c; return r; };
@@ -300,13 +381,14 @@ __device__ inline GnMem carve_gn(double* b, const GnDims& d) {
     W.cq = take(12); W.xg = take(NX); W.up = take(2);
     W.z = take(n); W.zt = take(n); W.zb = take(n); W.dz = take(n); W.gs = take(n); W.rd = take(n); W.rhs = take(n);
     W.xs = take((N + 1) * NX); W.Ph = take((size_t)(N + 1) * NX * n);
-    W.pts = take(6 * N); W.y = take(6 * N); W.pdz = take(6 * N);
-    W.G = take((size_t)6 * N * n);
-    W.obs = take(7 * K); W.hk = take(3 * N * K); W.dh = take(6 * N * K); W.hh = take(d.circles ? 0 : 9 * N * K);
+    constexpr int RS = PD * NP, HS = PD * (PD + 1) / 2;
+    W.pts = take(RS * N); W.y = take(RS * N); W.pdz = take(RS * N);
+    W.G = take((size_t)RS * N * n);
+    W.obs = take(7 * K); W.hk = take(NP * N * K); W.dh = take(PD * NP * N * K); W.hh = take(d.circles ? 0 : HS * NP * N * K);
     W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m);
-    W.Psi = take(36 * N); W.M = take((size_t)n * n);
+    W.Psi = take(RS * RS * N); W.M = take((size_t)n * n);
     W.Hk = take((size_t)NH * N);
-    W.T = take((size_t)6 * N * n); W.L = W.T;                     // T is dead once M is assembled
+    W.T = take((size_t)RS * N * n); W.L = W.T;                     // T is dead once M is assembled
     W.vb = W.T + (size_t)n * (n + 1);                              // written before T is built and again after the solve
     return W;
 }
@@ -447,6 +529,142 @@ __device__ __forceinline__ void gn_jt(const double* v, double* out, const GnMem&
     SC_SYNC();
 }
 
+// ---- full-state barrier points (KinematicBicycle2D_C3BF / _DPCBF; oracle/mpc_kb_state.py) -------------------------------------
+// Stage k has two points of dimension four, x_k and y1 = step(x_k, u_k); row (k, j) is w0 h(x_k) + w1 h(y1) with w = (alpha - 1, 1).
+// Point index 2 k + p; tables: hk[e], dh[4 e + d], hh[10 e + t] (upper triangle by rows) for e = point * K + j;
+// G rows (2 k + p) * 4 + d; stage blocks Psi are 8 x 8.
+template <int MODEL>
+__device__ __forceinline__ double gn_eval_state(const double* zv, const GnMem& W, const GnDims& d, const GnConst& c, const GnPar& q,
+                                                int lane, bool derivs) {
+    using Mdl = GnModel<MODEL>;
+    constexpr int NX = 4;
+    const int N = d.N, K = d.K, n = d.n;
+    double x[NX], col[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { x[i] = W.xs[i]; col[i] = 0.0; }
+    const int myk = lane >> 1, myc = lane & 1;
+    for (int k = 0; k < N; ++k) {
+        const double u[2] = {zv[2 * k], zv[2 * k + 1]};
+        double xn[NX], y1[NX];
+        if (derivs) {
+            double A[NX][NX], B[NX][2], S1x[NX][NX], S1u[NX][2];
+            Mdl::template map<true, false>(x, u, q, xn, A, B);
+            Mdl::template map<true, true>(x, u, q, y1, S1x, S1u);
+            const bool mine = (lane < n) && (myk == k);
+            double nc[NX], Y1[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                double a = 0.0, b1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) { a += A[i][j] * col[j]; b1 += S1x[i][j] * col[j]; }
+                nc[i] = a + (mine ? B[i][myc] : 0.0);
+                Y1[i] = b1 + (mine ? S1u[i][myc] : 0.0);
+            }
+            if (lane < n) {
+#pragma unroll
+                for (int dd = 0; dd < NX; ++dd) {
+                    W.G[(size_t)((2 * k + 0) * 4 + dd) * n + lane] = col[dd];
+                    W.G[(size_t)((2 * k + 1) * 4 + dd) * n + lane] = Y1[dd];
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { col[i] = nc[i]; W.Ph[(size_t)((k + 1) * NX + i) * n + lane] = nc[i]; }
+            }
+        } else {
+            double (*nul4)[NX] = nullptr;
+            double (*nul2)[2] = nullptr;
+            Mdl::template map<false, false>(x, u, q, xn, nul4, nul2);
+            Mdl::template map<false, true>(x, u, q, y1, nul4, nul2);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { W.pts[8 * k + i] = x[i]; W.pts[8 * k + 4 + i] = y1[i]; W.xs[(k + 1) * NX + i] = xn[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    }
+    SC_SYNC();
+    double part = 0.0;
+    for (int e = lane; e < N * NX; e += 64) {
+        const int k = e / NX + 1, i = e - (k - 1) * NX;
+        const double dv = W.xs[k * NX + i] - W.xg[i];
+        part += W.cq[i] * dv * dv;
+    }
+    for (int i = lane; i < n; i += 64) {
+        const double prev = i >= 2 ? zv[i - 2] : W.up[i];
+        const double du = zv[i] - prev;
+        part += W.cq[6 + (i & 1)] * du * du;
+    }
+    for (int e = lane; e < 2 * N * K; e += 64) {
+        const int pt = e / K, j = e - pt * K;
+        if (derivs) {
+            double h, g4[4], h10[10];
+            Mdl::barrier_d(W.pts + 4 * pt, W.obs + 7 * j, c.Rrob, h, g4, h10);
+            W.hk[e] = h;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) W.dh[4 * e + t] = g4[t];
+#pragma unroll
+            for (int t = 0; t < 10; ++t) W.hh[10 * e + t] = h10[t];
+        } else {
+            W.hk[e] = Mdl::barrier_v(W.pts + 4 * pt, W.obs + 7 * j, c.Rrob);
+        }
+    }
+    SC_SYNC();
+    for (int i = lane; i < d.m; i += 64) {
+        double gi;
+        if (i < d.mc) {
+            const int k = i / K, j = i - k * K;
+            gi = c.w0 * W.hk[(2 * k) * K + j] + c.w1 * W.hk[(2 * k + 1) * K + j];
+        } else if (i < d.mc + d.ms) {
+            const int r = i - d.mc, k = (r >> 1) + 1;
+            const double xv = W.xs[k * NX + Mdl::BIDX];
+            gi = (r & 1) ? xv - c.blo : c.bhi - xv;
+        } else if (i < d.mc + d.ms + n) {
+            const int col_ = i - d.mc - d.ms;
+            gi = W.cq[10 + (col_ & 1)] - zv[col_];
+        } else {
+            const int col_ = i - d.mc - d.ms - n;
+            gi = zv[col_] - W.cq[8 + (col_ & 1)];
+        }
+        W.g[i] = gi;
+    }
+    SC_SYNC();
+    return gsum(part);
+}
+
+template <int MODEL>
+__device__ __forceinline__ void gn_jt_state(const double* v, double* out, const GnMem& W, const GnDims& d, const GnConst& c, int lane) {
+    using Mdl = GnModel<MODEL>;
+    constexpr int NX = 4;
+    const int N = d.N, K = d.K, n = d.n;
+    for (int e = lane; e < 8 * N; e += 64) {
+        const int pt = e >> 2, dd = e & 3, k = pt >> 1, p = pt & 1;
+        double acc = 0.0;
+        for (int j = 0; j < K; ++j) acc += v[k * K + j] * W.dh[4 * (pt * K + j) + dd];
+        W.y[e] = (p == 0 ? c.w0 : c.w1) * acc;
+    }
+    SC_SYNC();
+    for (int i = lane; i < n; i += 64) {
+        double acc = 0.0;
+        for (int r = 0; r < 8 * N; ++r) acc += W.G[(size_t)r * n + i] * W.y[r];
+        for (int k = 1; k <= N; ++k)
+            acc += (v[d.mc + 2 * (k - 1) + 1] - v[d.mc + 2 * (k - 1)]) * W.Ph[(size_t)(k * NX + Mdl::BIDX) * n + i];
+        out[i] = acc - v[d.mc + d.ms + i] + v[d.mc + d.ms + n + i];
+    }
+    SC_SYNC();
+}
+
+template <int MODEL>
+__device__ __forceinline__ double gn_eval_any(const double* zv, const GnMem& W, const GnDims& d, const GnConst& c, const GnPar& q,
+                                              int lane, bool derivs) {
+    if constexpr (GnModel<MODEL>::PD == 4) return gn_eval_state<MODEL>(zv, W, d, c, q, lane, derivs);
+    else return gn_eval<MODEL>(zv, W, d, c, q, lane, derivs);
+}
+template <int MODEL>
+__device__ __forceinline__ void gn_jt_any(const double* v, double* out, const GnMem& W, const GnDims& d, const GnConst& c, int lane) {
+    if constexpr (GnModel<MODEL>::PD == 4) gn_jt_state<MODEL>(v, out, W, d, c, lane);
+    else gn_jt<MODEL>(v, out, W, d, c, lane);
+}
+
 #ifdef SC_GN_PROF
 #define GP(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += (double)(t_ - tlast); tlast = t_; } while (0)
 #else
@@ -472,13 +690,14 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
 
     GnDims d;
     d.N = NT > 0 ? NT : p.horizon; d.K = K; d.n = 2 * d.N; d.mc = d.N * K; d.ms = 2 * NB * d.N; d.m = d.mc + d.ms + 2 * d.n;
-    d.circles = p.circles_only != 0;
+    d.circles = Mdl::PD == 2 && p.circles_only != 0;         // full-state barriers keep their 4 x 4 Hessians per point
     const int N = d.N, n = d.n, m = d.m;
-    const GnMem W = carve_gn<NX, Mdl::NH>(sm, d);
+    const GnMem W = carve_gn<NX, Mdl::NH, Mdl::PD, Mdl::NP>(sm, d);
     GnConst c;
     {
         const double g1 = p.alpha1 + p.alpha2, g2 = p.alpha1 * p.alpha2;
         c.w0 = 1.0 - g1 + g2; c.w1 = g1 - 2.0; c.w2 = 1.0;
+        if constexpr (Mdl::PD == 4) { c.w0 = p.alpha1 - 1.0; c.w1 = 1.0; c.w2 = 0.0; }   // d_h + alpha h_k (mpc_cbf.py:312-315)
     }
     c.Rrob = p.robot_radius; c.beta = p.beta; c.circles_only = p.circles_only; c.blo = -p.v_max; c.bhi = p.v_max;
     GnPar q;
@@ -516,11 +735,11 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         SC_SYNC();
     };
 
-    double f = gn_eval<MODEL>(W.z, W, d, c, q, lane, true);
+    double f = gn_eval_any<MODEL>(W.z, W, d, c, q, lane, true);
     // steep (superellipsoid) barriers: IPOPT-style gradient-based row scaling from the initial guess, then a fresh evaluation
     if (!c.circles_only &&
         ipm::scale_steep_barriers(W.obs, K, W.dh, 3 * N, lane, 64, [](double v) { return gmax_(v); }, [] { SC_SYNC(); }))
-        f = gn_eval<MODEL>(W.z, W, d, c, q, lane, true);
+        f = gn_eval_any<MODEL>(W.z, W, d, c, q, lane, true);
     grad_f(1.0);
     double gmx = 0.0;
     for (int i = lane; i < n; i += 64) gmx = fmax(gmx, fabs(W.gs[i]));
@@ -542,14 +761,14 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
 #endif
     for (it = 1; it <= p.max_iter; ++it) {
         GP(11);
-        if (it > 1) f = gn_eval<MODEL>(W.z, W, d, c, q, lane, true);
+        if (it > 1) f = gn_eval_any<MODEL>(W.z, W, d, c, q, lane, true);
         GP(0);
         grad_f(sf);
-        gn_jt<MODEL>(W.lam, W.rd, W, d, c, lane);
+        gn_jt_any<MODEL>(W.lam, W.rd, W, d, c, lane);
         GP(1);
         // ---- second derivatives of the dynamics and of step o step, weighted by the costates of the Lagrangian (oracle:
         // evaluate, exact_hessian).  W.y still holds A' lam per point (= -nu).  Leaves two scalars per stage in W.Hk.
-        if constexpr (MODEL == SC_MODEL_KINEMATIC_BICYCLE2D) Mdl::second_order(W.xs, W.z, W.y, W.cq, W.xg, W.lam + d.mc, W.Hk, N, sf, q, lane);
+        if constexpr (MODEL == SC_MODEL_KINEMATIC_BICYCLE2D || Mdl::PD == 4) Mdl::second_order(W.xs, W.z, W.y, W.cq, W.xg, W.lam + d.mc, W.Hk, N, sf, q, lane);
         else if constexpr (Mdl::EXACT) Mdl::second_order(W.xs, W.z, W.y, W.cq, W.xg, W.Hk, N, sf, q, lane);
         SC_SYNC();
         GP(2);
@@ -584,10 +803,26 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             W.ds[i] = sig;                                                // sigma, read below; ds proper is written after the solve
         }
         SC_SYNC();
-        gn_jt<MODEL>(W.vb, W.rhs, W, d, c, lane);
+        gn_jt_any<MODEL>(W.vb, W.rhs, W, d, c, lane);
         for (int i = lane; i < n; i += 64) W.rhs[i] = -W.gs[i] + W.rhs[i];
         GP(3);
         // stage blocks Psi_k (6 x 6 over a_k, b_k, c_k): sum_j sig v v' (v = [w0 dh_a; w1 dh_b; w2 dh_c]) - sum_j lam w_p Hh_p
+        if constexpr (Mdl::PD == 4) {
+            // 8 x 8 stage blocks over (x_k, y1): sum_j sig v v' (v = [w0 dh(x_k); w1 dh(y1)]) - sum_j lam w_p Hh_p on the diagonal blocks
+            for (int e = lane; e < 64 * N; e += 64) {
+                const int k = e >> 6, r = (e >> 3) & 7, cc = e & 7, pr = r >> 2, pc = cc >> 2, a = r & 3, b = cc & 3;
+                const double wr = pr == 0 ? c.w0 : c.w1, wc = pc == 0 ? c.w0 : c.w1;
+                const int lo = a < b ? a : b, hi = a < b ? b : a, t = lo * 4 - (lo * (lo - 1)) / 2 + (hi - lo);
+                double acc = 0.0;
+                for (int j = 0; j < K; ++j) {
+                    const int row = k * K + j, er = (2 * k + pr) * K + j, ec = (2 * k + pc) * K + j;
+                    const double l = W.lam[row], sig = W.ds[row];
+                    acc += sig * (wr * W.dh[4 * er + a]) * (wc * W.dh[4 * ec + b]);
+                    if (pr == pc) acc -= l * wr * W.hh[10 * er + t];
+                }
+                W.Psi[e] = acc;
+            }
+        } else
         for (int e = lane; e < 36 * N; e += 64) {
             const int k = e / 36, r = (e - 36 * k) / 6, cc = e - 36 * k - 6 * r, pr = r >> 1, pc = cc >> 1;
             const double wr = pr == 0 ? c.w0 : (pr == 1 ? c.w1 : c.w2), wc = pc == 0 ? c.w0 : (pc == 1 ? c.w1 : c.w2);
@@ -603,6 +838,15 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         GP(4);
         SC_SYNC();
         GP(5);
+        if constexpr (Mdl::PD == 4) {
+            for (int e = lane; e < 8 * N * n; e += 64) {
+                const int row = e / n, col_ = e - row * n, k = row >> 3, r = row & 7;
+                double acc = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) acc += W.Psi[64 * k + 8 * r + cc] * W.G[(size_t)(8 * k + cc) * n + col_];
+                W.T[e] = acc;
+            }
+        } else
         for (int e = lane; e < 6 * N * n; e += 64) {                          // T = Psi G
             const int row = e / n, col_ = e - row * n, k = row / 6, r = row - 6 * k;
             double acc = 0.0;
@@ -627,14 +871,14 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             if (i == j) acc += 2.0 * ri + (i + 2 < n ? 2.0 * ri : 0.0);
             if (i == j + 2) acc -= 2.0 * ri;
             acc *= sf;
-            for (int r = 0; r < 6 * N; ++r) acc += W.G[(size_t)r * n + i] * W.T[(size_t)r * n + j];
+            for (int r = 0; r < Mdl::PD * Mdl::NP * N; ++r) acc += W.G[(size_t)r * n + i] * W.T[(size_t)r * n + j];
             if constexpr (NB > 0) {
                 for (int k = 1; k <= N; ++k) {
                     const int r0 = d.mc + 2 * (k - 1);
                     acc += (W.ds[r0] + W.ds[r0 + 1]) * W.Ph[(size_t)(k * NX + Mdl::BIDX) * n + i] * W.Ph[(size_t)(k * NX + Mdl::BIDX) * n + j];
                 }
             }
-            if constexpr (MODEL == SC_MODEL_KINEMATIC_BICYCLE2D) {
+            if constexpr (MODEL == SC_MODEL_KINEMATIC_BICYCLE2D || Mdl::PD == 4) {
                 for (int k = 0; k < N; ++k) acc += Mdl::hess_term(W.Ph, W.Hk, k, i, j, n);
             } else if constexpr (Mdl::EXACT) {
                 // V_k' H_k V_k with H_k = a_k e_t e_t' + b_k (e_t s' + s e_t'): t = the model's angle state, s = the two inputs of stage k
@@ -670,7 +914,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             ipm::chol_solve_lds(W.L, W.dz, n, n | 1, lane);
         }
         GP(7);
-        for (int r = lane; r < 6 * N; r += 64) {
+        for (int r = lane; r < Mdl::PD * Mdl::NP * N; r += 64) {
             double acc = 0.0;
             for (int i = 0; i < n; ++i) acc += W.G[(size_t)r * n + i] * W.dz[i];
             W.pdz[r] = acc;
@@ -686,6 +930,16 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             if (i < d.mc) {
                 const int k = i / K, j = i - k * K;
                 jd = 0.0;
+                if constexpr (Mdl::PD == 4) {
+#pragma unroll
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const int ep = (2 * k + pp) * K + j;
+                        double a4 = 0.0;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) a4 += W.dh[4 * ep + t] * W.pdz[8 * k + 4 * pp + t];
+                        jd += (pp == 0 ? c.w0 : c.w1) * a4;
+                    }
+                } else
 #pragma unroll
                 for (int pp = 0; pp < 3; ++pp) {
                     const int ep = (3 * k + pp) * K + j;
@@ -727,7 +981,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         for (int ls = 0; ls < 12; ++ls) {
             for (int i = lane; i < n; i += 64) W.zt[i] = W.z[i] + alpha * W.dz[i];
             SC_SYNC();
-            const double ft = gn_eval<MODEL>(W.zt, W, d, c, q, lane, false);
+            const double ft = gn_eval_any<MODEL>(W.zt, W, d, c, q, lane, false);
             double srp = 0.0, slog = 0.0;
             for (int i = lane; i < m; i += 64) {
                 const double s_t = W.s[i] + alpha * W.ds[i];
@@ -757,7 +1011,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         status = SC_STATUS_OPTIMAL;
     }
     SC_SYNC();
-    gn_eval<MODEL>(W.z, W, d, c, q, lane, false);
+    gn_eval_any<MODEL>(W.z, W, d, c, q, lane, false);
     if (status != SC_STATUS_OPTIMAL) {
         double g_min = 1e300;
         for (int i = lane; i < m; i += 64) g_min = fmin(g_min, W.g[i]);
@@ -780,7 +1034,8 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
 template <int MODEL>
 static hipError_t mpcgn_launch_m(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
                                  const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream) {
-    const size_t lds = mpcgn_lds_doubles(p.horizon, K, GnModel<MODEL>::NX, GnModel<MODEL>::NB, p.circles_only != 0, GnModel<MODEL>::NH) * sizeof(double);
+    const size_t lds = mpcgn_lds_doubles(p.horizon, K, GnModel<MODEL>::NX, GnModel<MODEL>::NB, GnModel<MODEL>::PD == 2 && p.circles_only != 0, GnModel<MODEL>::NH,
+                                         GnModel<MODEL>::PD, GnModel<MODEL>::NP) * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 64 * 1024) {
@@ -798,8 +1053,9 @@ static hipError_t mpcgn_launch_m(const sc_mpcgn_params& p, long long B, int K, c
 
 size_t mpcgn_lds_bytes(int model_id, int N, int K, int circles_only) {
     const int nx = model_id == SC_MODEL_QUAD2D ? 6 : 4;
-    const bool kb = model_id == SC_MODEL_KINEMATIC_BICYCLE2D;
-    return mpcgn_lds_doubles(N, K, nx, kb ? 1 : 0, circles_only != 0, kb ? 10 : 2) * sizeof(double);
+    const bool st = model_id == SC_MODEL_KINEMATIC_BICYCLE2D_C3BF || model_id == SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF;
+    const bool kb = model_id == SC_MODEL_KINEMATIC_BICYCLE2D || st;
+    return mpcgn_lds_doubles(N, K, nx, kb ? 1 : 0, !st && circles_only != 0, kb ? 10 : 2, st ? 4 : 2, st ? 2 : 3) * sizeof(double);
 }
 
 hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
@@ -811,6 +1067,10 @@ hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void
             return mpcgn_launch_m<SC_MODEL_QUAD2D>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
         case SC_MODEL_KINEMATIC_BICYCLE2D:
             return mpcgn_launch_m<SC_MODEL_KINEMATIC_BICYCLE2D>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        case SC_MODEL_KINEMATIC_BICYCLE2D_C3BF:
+            return mpcgn_launch_m<SC_MODEL_KINEMATIC_BICYCLE2D_C3BF>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        case SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF:
+            return mpcgn_launch_m<SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
         default:
             return hipErrorInvalidValue;
     }

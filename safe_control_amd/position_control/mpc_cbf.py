@@ -102,7 +102,8 @@ class MPCCBF:
         if cls is MPCCBF and robot_spec.get("model") in ("SingleIntegrator2D", "Quad3D"):
             from .mpc_cbf_linear import LinearMPCCBF
             return LinearMPCCBF(robot, robot_spec, *args, **kwargs)
-        if cls is MPCCBF and robot_spec.get("model") in ("DoubleIntegrator2D", "Quad2D", "KinematicBicycle2D"):
+        if cls is MPCCBF and robot_spec.get("model") in ("DoubleIntegrator2D", "Quad2D", "KinematicBicycle2D", "KinematicBicycle2D_C3BF",
+                                                         "KinematicBicycle2D_DPCBF"):
             from .mpc_cbf_gn import GnMPCCBF
             return GnMPCCBF(robot, robot_spec, *args, **kwargs)
         return super().__new__(cls)

@@ -1,4 +1,4 @@
-"""MPC-CBF for DoubleIntegrator2D, Quad2D and KinematicBicycle2D on the gfx950 kernel csrc/mpc_gn.hip.
+"""MPC-CBF for DoubleIntegrator2D, Quad2D and the KinematicBicycle2D family (HOCBF, C3BF, DPCBF) on the gfx950 kernel csrc/mpc_gn.hip.
 
 ``safe_control_amd.MPCCBF(robot, robot_spec, ...)`` returns a ``GnMPCCBF`` for these models (the reference serves every
 model from the one MPCCBF class, position_control/mpc_cbf.py:7-100); ``BatchedGnMPCCBF`` solves B agents per launch on
@@ -12,7 +12,7 @@ from .. import _lib
 from ..robots.spec import complete_robot_spec
 from .mpc_cbf import apply_mpc_overrides, pad_obstacles
 
-GN_MODELS = ("DoubleIntegrator2D", "Quad2D", "KinematicBicycle2D")
+GN_MODELS = ("DoubleIntegrator2D", "Quad2D", "KinematicBicycle2D", "KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF")
 
 
 def model_constants(robot_spec):
@@ -28,6 +28,12 @@ def model_constants(robot_spec):
                     beta=1.01, u_lo=[robot_spec["f_min"]] * 2, u_hi=[robot_spec["f_max"]] * 2, circles_only=True)
     if m == "KinematicBicycle2D":               # mpc_cbf.py:31-33,64-67,205-211; barrier inflation kinematic_bicycle2D.py:175 (1.1)
         return dict(nx=4, Q=[50.0, 50.0, 1.0, 1.0], R=[0.5, 5000.0], cbf_param={"alpha1": 0.1, "alpha2": 0.1}, beta=1.1,
+                    u_lo=[-robot_spec["a_max"], -robot_spec["beta_max"]], u_hi=[robot_spec["a_max"], robot_spec["beta_max"]],
+                    circles_only=True)
+    if m in ("KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"):
+        # mpc_cbf.py:31-33,68-73,205-211: one gain, row d_h + alpha h_k (:312-315); the barrier's own inflation (1.01 / 1.05) is fixed in
+        # kinematic_bicycle2D_c3bf.py:77 / _dpcbf.py:86 and in the kernel
+        return dict(nx=4, Q=[50.0, 50.0, 1.0, 1.0], R=[0.5, 5000.0], cbf_param={"alpha": 0.15}, beta=1.01 if m.endswith("C3BF") else 1.05,
                     u_lo=[-robot_spec["a_max"], -robot_spec["beta_max"]], u_hi=[robot_spec["a_max"], robot_spec["beta_max"]],
                     circles_only=True)
     raise NotImplementedError(m)
@@ -47,7 +53,10 @@ def make_params(robot_spec, mc, cbf_param, horizon, dt, radius, io_dtype, obs_sh
         p.Q[i] = float(v)
     for i in range(2):
         p.R[i], p.u_lo[i], p.u_hi[i] = float(mc["R"][i]), float(mc["u_lo"][i]), float(mc["u_hi"][i])
-    p.alpha1, p.alpha2 = float(cbf_param["alpha1"]), float(cbf_param["alpha2"])
+    if "alpha" in cbf_param:                              # rel-degree-1 barriers: the one gain travels in alpha1
+        p.alpha1, p.alpha2 = float(cbf_param["alpha"]), 0.0
+    else:
+        p.alpha1, p.alpha2 = float(cbf_param["alpha1"]), float(cbf_param["alpha2"])
     p.v_min = float(robot_spec.get("v_min", 0.0))
     p.v_max = float(robot_spec.get("v_max", 0.0))
     p.rear_ax_dist = float(robot_spec.get("rear_ax_dist", 0.0))

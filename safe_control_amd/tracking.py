@@ -104,13 +104,12 @@ class BatchedTrackingController:
             if self.model == "SingleIntegrator2D":             # linear model: csrc/mpc_lin.hip
                 from .position_control.mpc_cbf_linear import BatchedLinearMPCCBF
                 cls = BatchedLinearMPCCBF
-            elif self.model in ("DoubleIntegrator2D", "KinematicBicycle2D"):   # barrier through the robot's own step(): csrc/mpc_gn.hip
+            elif self.model in ("DoubleIntegrator2D", "KinematicBicycle2D", "KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"):
+                # barrier through the robot's own step(): csrc/mpc_gn.hip
                 if self.pos_controller_type != "mpc_cbf":
                     raise ValueError(f"{self.model}: 'cbf_qp' or 'mpc_cbf'")
                 from .position_control.mpc_cbf_gn import BatchedGnMPCCBF
                 cls = BatchedGnMPCCBF
-            elif self.model in ("KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"):
-                raise ValueError(f"{self.model}: 'cbf_qp' only (the discrete-time C3BF / DPCBF barriers of mpc_cbf.py:312-315 are not served)")
             else:
                 cls = BatchedMPCCBF if self.pos_controller_type == "mpc_cbf" else BatchedOptimalDecayMPCCBF
             self.mpc = cls(self.robot_spec, dt=self.dt, io_dtype=io_dtype)

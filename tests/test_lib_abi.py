@@ -100,10 +100,11 @@ def test_argument_validation_of_the_newer_entry_points_without_gpu():
     g = GN.make_params(gspec, mc, mc["cbf_param"], 10, 0.05, 0.25, _lib.DTYPE_F64)
     assert lib.sc_mpcgn_solve_batch(C.byref(g), 0, 8, None, None, None, None, None, None, None, None, None) == 0
     assert lib.sc_mpcgn_solve_batch(C.byref(g), 1, 8, ptr, ptr, None, ptr, ptr, ptr, None, None, None) == 1
-    g.model_id = _lib.MODEL_IDS["KinematicBicycle2D_C3BF"]
-    assert lib.sc_mpcgn_solve_batch(C.byref(g), 1, 8, ptr, ptr, ptr, ptr, ptr, ptr, None, None, None) == 2           # not served
-    g.model_id = _lib.MODEL_IDS["KinematicBicycle2D"]                                                               # needs its own spec
-    assert lib.sc_mpcgn_solve_batch(C.byref(g), 1, 8, ptr, ptr, ptr, ptr, ptr, ptr, None, None, None) == 1           # rear_ax_dist = 0
+    g.model_id = _lib.MODEL_IDS["Unicycle2D"]
+    assert lib.sc_mpcgn_solve_batch(C.byref(g), 1, 8, ptr, ptr, ptr, ptr, ptr, ptr, None, None, None) == 2           # sc_mpccbf serves it
+    for name in ("KinematicBicycle2D", "KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"):                      # need their own spec
+        g.model_id = _lib.MODEL_IDS[name]
+        assert lib.sc_mpcgn_solve_batch(C.byref(g), 1, 8, ptr, ptr, ptr, ptr, ptr, ptr, None, None, None) == 1       # rear_ax_dist = 0
     g.model_id, g.horizon = _lib.MODEL_IDS["Quad2D"], 33
     assert lib.sc_mpcgn_solve_batch(C.byref(g), 1, 8, ptr, ptr, ptr, ptr, ptr, ptr, None, None, None) == 2
     g.horizon, g.mass = 10, 0.0

@@ -128,7 +128,7 @@ def test_drop_in_class_and_bad_arguments():
         ref["state_machine"] = "stop"
         assert ctl.solve_control_problem(robot.X, ref, None) is ref["u_ref"]
     with pytest.raises(NotImplementedError):
-        sca.BatchedGnMPCCBF({"model": "KinematicBicycle2D_C3BF"})      # full-state DT barrier: not served (tests/test_mpcgn_kb_gpu.py)
+        sca.BatchedGnMPCCBF({"model": "Unicycle2D"})                   # rel-degree-1 distance barrier: csrc/mpc_cbf.hip serves it
     ctl = sca.BatchedGnMPCCBF({"model": "Quad2D"})
     with pytest.raises(ValueError):
         ctl.solve(t(np.zeros((2, 4))), t(np.zeros((2, 2))), t(np.zeros((2, 2))), t(np.zeros((2, 1, 7))))

@@ -136,9 +136,8 @@ def test_f32_arrays_shared_table_and_guards():
             assert np.abs(u[i] - uo).max() <= (2e-6 if info["err"] <= 1e-6 else 1e-4) * max(1.0, np.abs(uo).max())
             n += 1
     assert n >= 4
-    for bad in ("KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"):      # full-state DT barriers: not served
-        with pytest.raises(NotImplementedError):
-            sca.BatchedGnMPCCBF({"model": bad})
+    with pytest.raises(NotImplementedError):
+        sca.BatchedGnMPCCBF({"model": "Unicycle2D"})
     with pytest.raises(RuntimeError):
         sca.BatchedGnMPCCBF({"model": NAME, "rear_ax_dist": 0.0}).solve(t(X), t(np.zeros((B, 2))), t(Gl), t(shared))
 
@@ -167,4 +166,98 @@ def test_full_batch_properties():
     P = G.params(mdl, N)
     for i in np.flatnonzero(ok)[::97]:
         g = G.evaluate(X[i], z[i], up[i], Gl[i], O[i], P, level=0)["g"]
+        assert g.min() >= -1e-6
+
+
+# ---- KinematicBicycle2D_C3BF / _DPCBF: full-state discrete-time barriers (oracle/mpc_kb_state.py) ---------------------------------
+from oracle import mpc_kb_state as S  # noqa: E402
+
+STATE_MODELS = {"KinematicBicycle2D_C3BF": S.c3bf_model, "KinematicBicycle2D_DPCBF": S.dpcbf_model}
+
+
+@pytest.mark.parametrize("name,N,K", [("KinematicBicycle2D_C3BF", 10, 5), ("KinematicBicycle2D_DPCBF", 10, 5), ("KinematicBicycle2D_C3BF", 6, 3)])
+def test_state_barrier_batch_matches_oracle(name, N, K):
+    B = 12
+    mdl = STATE_MODELS[name]()
+    rng = np.random.default_rng(7 * N + K + len(name))
+    X = np.zeros((B, 4)); Gl = np.zeros((B, 2)); O = np.zeros((B, K, 7))
+    for i in range(B):
+        X[i], Gl[i], O[i] = draw(mdl, rng, K, clear=1.5)
+        O[i, :, 3:5] = rng.uniform(-1, 1, (K, 2))                       # velocity columns: the MPC's barrier never reads them
+    up = np.zeros((B, 2))
+    ctl = sca.BatchedGnMPCCBF({"model": name}, io_dtype="f64", horizon=N)
+    u, st, it, z = ctl.solve(t(X), t(up), t(Gl), t(O), want_z=True)
+    torch.cuda.synchronize()
+    u, st, it, z = u.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), z.cpu().numpy()
+    n_opt = n_loose = n_path = 0
+    for i in range(B):
+        uo, so, ito, info = S.solve(mdl, X[i], up[i], Gl[i], O[i], N=N, return_info=True)
+        if st[i] != so:
+            assert {int(st[i]), int(so)} <= {0, 2} and np.abs(z[i] - info["z"]).max() <= 1e-3, f"status differs at problem {i}: {st[i]} vs {so}"
+            n_loose += 1
+            continue
+        if so == 0 and info["err"] > 1e-6:
+            assert np.abs(u[i] - uo).max() <= 1e-4 * max(1.0, np.abs(uo).max())
+            n_loose += 1
+            continue
+        n_path += int(abs(int(it[i]) - ito) > max(2, ito // 10))
+        if so == 0:
+            assert np.abs(u[i] - uo).max() <= 1e-6 * max(1.0, np.abs(uo).max()), i
+            assert np.abs(z[i] - info["z"]).max() <= 2e-5 * max(1.0, np.abs(info["z"]).max()), i
+            n_opt += 1
+    # cold starts in a field of cones: many of these draws have no feasible plan, and both solvers say so (status compared above)
+    assert n_opt >= B // 4 and n_loose <= B // 4 and n_path <= B // 4
+
+
+@pytest.mark.parametrize("name", list(STATE_MODELS))
+def test_state_barrier_reference_scene_closed_loop_drop_in(name):
+    """The reference's bicycle scene, 40 control steps, MPCCBF drop-in against the oracle on the oracle's own closed loop."""
+    spec = {"model": name, "a_max": 0.5, "radius": 0.5}
+    mdl = STATE_MODELS[name]({"a_max": 0.5, "radius": 0.5})
+    K, N = 5, 10
+    x = np.array([2.0, 2.0, math.pi / 2, 1.0]); up = np.zeros(2)
+    robot = sca.RobotHandle(x, dict(spec))
+    ctl = sca.MPCCBF(robot, robot.robot_spec, num_obs=K)
+    assert type(ctl).__name__ == "GnMPCCBF" and ctl.cbf_param == {"alpha": 0.15} and ctl.R.tolist() == [0.5, 5000.0]
+    goal = SCENE_WPS[1]
+    n_opt = 0
+    names = {0: "optimal", 1: "infeasible", 2: "optimal_inaccurate"}
+    for step in range(40):
+        near = np.argsort(np.linalg.norm(SCENE_OBS[:, :2] - x[:2], axis=1) - SCENE_OBS[:, 2])[:K]
+        uo, so, ito, info = S.solve(mdl, x, up, goal, M.pad_obstacles(SCENE_OBS[near], K), N=N, return_info=True)
+        ctl.u_prev = up.copy()
+        ref = {"state_machine": "track", "u_ref": np.zeros((2, 1)), "goal": goal}
+        u = ctl.solve_control_problem(x.reshape(-1, 1), ref, SCENE_OBS[near]).reshape(-1)
+        assert ctl.solver_status == names[so] or {ctl.solver_status, names[so]} == {"optimal", "optimal_inaccurate"}, step
+        if so == 0:
+            assert np.abs(u - uo).max() <= (1e-6 if info["err"] <= 1e-6 else 1e-4) * max(1.0, np.abs(uo).max()), step
+            n_opt += 1
+        x = G.kb_S(x, uo, mdl["spec"], mdl["dt"]); up = uo
+    assert n_opt >= 20
+
+
+@pytest.mark.parametrize("name", list(STATE_MODELS))
+def test_state_barrier_full_batch_properties(name):
+    B, K, N = 2048, 8, 10
+    mdl = STATE_MODELS[name]()
+    rng = np.random.default_rng(33)
+    X = np.zeros((B, 4)); Gl = np.zeros((B, 2)); O = np.zeros((B, K, 7))
+    for i in range(B):
+        X[i], Gl[i], O[i] = draw(mdl, rng, K, clear=1.5)
+    up = np.zeros((B, 2))
+    ctl = sca.BatchedGnMPCCBF({"model": name}, io_dtype="f64", horizon=N)
+    args = (t(X), t(up), t(Gl), t(O))
+    u1, s1, i1, z1 = ctl.solve(*args, want_z=True)
+    u2, s2, i2, z2 = ctl.solve(*args, want_z=True)
+    torch.cuda.synchronize()
+    assert torch.equal(u1, u2) and torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(z1, z2)
+    st, it, z = s1.cpu().numpy(), i1.cpu().numpy(), z1.cpu().numpy()
+    # seven cones within five metres of a cold start: about half of these draws have a feasible plan (47 % / 60 % measured)
+    assert it.max() <= 100 and set(np.unique(st)) <= {0, 1, 2} and (st == 0).mean() > 0.35
+    lo, hi = np.tile(mdl["u_lo"], N), np.tile(mdl["u_hi"], N)
+    ok = st == 0
+    assert np.all(z[ok] >= lo - 1e-9) and np.all(z[ok] <= hi + 1e-9)
+    P = S.params(mdl, N)
+    for i in np.flatnonzero(ok)[::211]:
+        g = S.evaluate(X[i], z[i], up[i], Gl[i], O[i], P, level=0)["g"]
         assert g.min() >= -1e-6

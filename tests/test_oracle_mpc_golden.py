@@ -14,6 +14,7 @@ import pytest
 from oracle import mpc_cbf as M
 from oracle import mpc_cbf_uni as MU
 from oracle import mpc_gn as G
+from oracle import mpc_kb_state as KS
 from oracle import mpc_lin as L
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "mpc_functions.npz"))
@@ -47,6 +48,10 @@ def one_stage(name):
         mdl = L.si_model(dict(v_max=sp["v_max"], radius=R)) if name == "SingleIntegrator2D" else L.quad3d_model(dict(sp, radius=R))
         P = L.params(mdl, N=1)
         return lambda x, u, goal, obs: L.evaluate(x, u, np.zeros(mdl["nu"]), goal, obs, P, level=0), P
+    if name in ("KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"):     # full-state DT barriers, one gain
+        mdl = (KS.c3bf_model if name.endswith("C3BF") else KS.dpcbf_model)(dict(sp, radius=R))
+        P = KS.params(mdl, N=1)
+        return lambda x, u, goal, obs: KS.evaluate(x, u, np.zeros(2), goal, obs, P, level=0), P
     mk = {"DoubleIntegrator2D": G.di_model, "Quad2D": G.quad2d_model, "KinematicBicycle2D": G.kb_model}[name]
     mdl = mk(dict(sp, radius=R))
     P = G.params(mdl, N=1)
@@ -54,7 +59,7 @@ def one_stage(name):
 
 
 ORACLE_MODELS = ["DynamicUnicycle2D", "Unicycle2D", "SingleIntegrator2D", "Quad3D", "DoubleIntegrator2D", "Quad2D",
-                 "KinematicBicycle2D"]
+                 "KinematicBicycle2D", "KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"]
 
 
 @pytest.mark.parametrize("name", ORACLE_MODELS)
@@ -116,6 +121,14 @@ def test_host_tables_equal_the_reference_tables():
         # the barrier's own step (Euler for SI, RK4 for Quad3D) against As, Bs
         st = fx(name, "step")
         assert close(x @ mdl["As"].T + u @ mdl["Bs"].T, st, rtol=1e-11)
+    for name in ("KinematicBicycle2D", "KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"):
+        sp = complete_robot_spec(dict(spec_of(name), model=name))
+        mc = HG.model_constants(sp)
+        assert np.array_equal(np.diag(mc["Q"]), fx(name, "Q")) and np.array_equal(mc["R"], fx(name, "R"))
+        assert mc["cbf_param"] == {k.split("/")[-1]: float(GOLD[k]) for k in GOLD.files if k.startswith(f"{name}/cbf_param/")}
+        assert close(mc["u_lo"], fx(name, "u_lo")) and close(mc["u_hi"], fx(name, "u_hi")) and mc["nx"] == int(fx(name, "n_states"))
+        xlo, xhi = fx(name, "x_lo"), fx(name, "x_hi")                    # the speed is the one bounded state (mpc_cbf.py:205-207)
+        assert np.isinf(xlo[:3]).all() and np.isinf(xhi[:3]).all() and (xlo[3], xhi[3]) == (-sp["v_max"], sp["v_max"])
     for name in ("DoubleIntegrator2D", "Quad2D"):
         sp = complete_robot_spec(dict(spec_of(name), model=name))
         mc = HG.model_constants(sp)
@@ -123,7 +136,7 @@ def test_host_tables_equal_the_reference_tables():
         assert mc["cbf_param"] == {"alpha1": float(fx(name, "cbf_param/alpha1")), "alpha2": float(fx(name, "cbf_param/alpha2"))}
         assert np.array_equal(mc["u_lo"], fx(name, "u_lo")) and np.array_equal(mc["u_hi"], fx(name, "u_hi"))
         assert mc["nx"] == int(fx(name, "n_states"))
-    for name in ORACLE_MODELS + ["KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF", "VTOL2D"]:
+    for name in ORACLE_MODELS + ["VTOL2D"]:
         assert int(fx(name, "horizon")) == int(fx(name, "n_horizon_param")) == (30 if name == "VTOL2D" else 10)
         assert np.array_equal(fx(name, "rterm_u"), fx(name, "R"))          # set_rterm(u=R), mpc_cbf.py:180
         assert float(fx(name, "t_step")) == 0.05
@@ -194,3 +207,34 @@ def test_update_tvp_padding(name):
     for pad in (host_pad, M.pad_obstacles):
         with pytest.raises(ValueError):
             pad([np.array([1.0, 2.0, 0.3, 0.0, 0.0])], K)
+
+
+@pytest.mark.parametrize("name", ["KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"])
+def test_full_state_barriers_equal_agent_barrier_dt_and_their_derivatives_are_exact(name):
+    """h(x_k) and h(step(x_k, u_k)) - h(x_k) of oracle/mpc_kb_state.py against (h_k, d_h) of the reference's agent_barrier_dt as the MPC
+    calls it (obstacle row 1 x 7: the velocity columns are never read); gradient and Hessian of the second-order forward mode against
+    central differences."""
+    mdl = (KS.c3bf_model if name.endswith("C3BF") else KS.dpcbf_model)(dict(spec_of(name), radius=float(fx(name, "robot_radius"))))
+    P = KS.params(mdl, N=1)
+    x, u, obs, hk, dh = fx(name, "x"), fx(name, "u"), fx(name, "obs"), fx(name, "hk"), fx(name, "dh")
+    assert np.abs(obs[:, :, 3:5]).max() > 0.1                            # the draws DO carry obstacle velocities
+    for i in range(x.shape[0]):
+        y1 = G.kb_S(x[i], u[i], mdl["spec"], 0.05)
+        for j in range(obs.shape[1]):
+            h0 = KS.barrier(x[i], obs[i, j], P, False)[0]
+            h1 = KS.barrier(y1, obs[i, j], P, False)[0]
+            big = max(1.0, abs(h0))
+            assert abs(h0 - hk[i, j]) <= 1e-12 * big and abs((h1 - h0) - dh[i, j]) <= 1e-12 * big, (i, j)
+    rng = np.random.default_rng(0)
+    for t in range(40):
+        xv = np.array([rng.uniform(0, 5), rng.uniform(0, 5), rng.uniform(-3, 3), rng.uniform(0.3, 3)])
+        ang = rng.uniform(-np.pi, np.pi); rho = rng.uniform(1.8, 4.0)
+        ob = np.array([xv[0] + rho * np.cos(ang), xv[1] + rho * np.sin(ang), rng.uniform(0.2, 0.8), 0.3, -0.2, 0, 0])
+        h, g, H = KS.barrier(xv, ob, P)
+        eps = 1e-6
+        for a in range(4):
+            e = np.zeros(4); e[a] = eps
+            hp, gp, _ = KS.barrier(xv + e, ob, P); hm, gm, _ = KS.barrier(xv - e, ob, P)
+            assert abs((hp - hm) / (2 * eps) - g[a]) <= 1e-7 * max(1.0, np.abs(g).max())
+            assert np.abs((gp - gm) / (2 * eps) - H[a]).max() <= 1e-6 * max(1.0, np.abs(H).max())
+        assert np.abs(H - H.T).max() <= 1e-14 * max(1.0, np.abs(H).max())

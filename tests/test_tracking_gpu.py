@@ -523,4 +523,46 @@ def test_kinematic_bicycle_closed_loop_with_mpc():
         n_track += state.get("n", 0)
     assert n_track >= T
     with pytest.raises(ValueError):
-        sca.BatchedTrackingController(X0, {"model": "KinematicBicycle2D_C3BF"}, controller_type={"pos": "mpc_cbf"}, obs=obs7)
+        sca.BatchedTrackingController(X0, {"model": "KinematicBicycle2D_C3BF"}, controller_type={"pos": "optimal_decay_mpc_cbf"}, obs=obs7)
+
+
+@pytest.mark.parametrize("model_name,model_id", [("KinematicBicycle2D_C3BF", R.MODEL_KB_C3BF), ("KinematicBicycle2D_DPCBF", R.MODEL_KB_DPCBF)])
+def test_collision_cone_bicycles_closed_loop_with_mpc(model_name, model_id):
+    """--model kb with the C3BF / DPCBF robots under the default --algo mpc_cbf: select -> MPC launch with the full-state discrete-time
+    barrier (csrc/mpc_gn.hip, model ids 2 / 3) -> apply, against the oracle loop with oracle/mpc_kb_state.py behind solve_fn."""
+    from oracle import mpc_cbf as M, mpc_kb_state as S
+    obs = np.array([[2.2, 5.0, 0.2], [3.0, 5.0, 0.2], [4.0, 9.0, 0.3], [1.5, 10.0, 0.5], [9.0, 11.0, 1.0], [7.0, 7.0, 3.0], [4.0, 3.5, 1.5],
+                    [10.0, 7.3, 0.4], [6.0, 13.0, 0.7], [5.0, 10.0, 0.6], [11.0, 5.0, 0.8], [13.5, 11.0, 0.6], [2.0, 7.0, 0.7], [2.0, 8.0, 0.5]])
+    obs7 = np.hstack([obs, np.zeros((len(obs), 4))])
+    K, T = 5, 25
+    spec = {"model": model_name, "a_max": 0.5, "radius": 0.5, "num_constraints": K}
+    X0 = np.array([[2.0, 2.0, np.pi / 2, 1.0], [12.0, 12.5, -1.4, 1.5]])
+    wl = [np.array([[2.0, 12.0]]), np.array([[12.0, 2.0]])]
+    ctl = sca.BatchedTrackingController(X0, dict(spec), controller_type={"pos": "mpc_cbf"}, obs=obs7, io_dtype="f64")
+    ctl.set_waypoints(wl)
+    ret, tX, tU = ctl.control_step(T, record=True)
+    tX = tX.cpu().numpy(); ret = ret.cpu().numpy()
+    mdl = (S.c3bf_model if model_id == R.MODEL_KB_C3BF else S.dpcbf_model)({"a_max": 0.5, "radius": 0.5})
+    n_track = 0
+    for i in range(len(X0)):
+        state = {"up": np.zeros(2)}
+
+        def solve_fn(X, cref, nobs, state=state):
+            if cref["state_machine"] != "track":
+                return np.asarray(cref["u_ref"], dtype=np.float64).reshape(-1), 0
+            o = M.pad_obstacles(None if nobs is None else list(nobs), K)
+            u, st, it = S.solve(mdl, X[:4], state["up"], cref["goal"], o)
+            state["up"] = u
+            state["n"] = state.get("n", 0) + 1
+            return u, 0
+
+        t = tracking.TrackingOracle(model_id, X0[i], {"a_max": 0.5, "radius": 0.5}, dt=0.05, obs=obs7, num_constraints=K, solve_fn=solve_fn)
+        t.set_waypoints(wl[i])
+        for k in range(T):
+            r = t.control_step()
+            np.testing.assert_allclose(tX[k, i], t.X, rtol=0, atol=5e-5, err_msg=f"agent {i} step {k}")
+            if r != 0:
+                assert ret[i] == r
+                break
+        n_track += state.get("n", 0)
+    assert n_track >= T
