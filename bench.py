@@ -377,7 +377,7 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
     if model == "Quad2D":
         Xn = np.zeros((B, 6)); Xn[:, 0:2] = Xd[:, 0:2]; Xn[:, 2] = rng.uniform(-0.2, 0.2, B); Xn[:, 3:5] = rng.uniform(-0.5, 0.5, (B, 2))
         up0 = np.full((B, 2), 0.5 * (ctl.robot_spec["f_min"] + ctl.robot_spec["f_max"]))
-    elif model == "KinematicBicycle2D":               # driving roughly towards the goal at 0.5 .. 3 m/s
+    elif model.startswith("KinematicBicycle2D"):       # driving roughly towards the goal at 0.5 .. 3 m/s
         Xn = np.zeros((B, 4)); Xn[:, 0:2] = Xd[:, 0:2]
         Xn[:, 2] = np.arctan2(gn[:, 1] - Xd[:, 1], gn[:, 0] - Xd[:, 0]) + rng.uniform(-0.6, 0.6, B); Xn[:, 3] = rng.uniform(0.5, 3.0, B)
         up0 = np.zeros((B, 2))
@@ -637,6 +637,7 @@ def main():
             res["double_integrator_mpc_cbf"] = gn_mpc_leg(dev, "DoubleIntegrator2D")
             res["quad2d_mpc_cbf"] = gn_mpc_leg(dev, "Quad2D")
             res["kinematic_bicycle_mpc_cbf"] = gn_mpc_leg(dev, "KinematicBicycle2D")
+            res["kinematic_bicycle_c3bf_mpc_cbf"] = gn_mpc_leg(dev, "KinematicBicycle2D_C3BF")
             res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
             res["backup_cbf_qp"] = backup_cbf_leg(dev)
         if ws == 1 and not a.no_cpu_baseline:

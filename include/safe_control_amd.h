@@ -226,28 +226,33 @@ int sc_odmpclin_solve_batch(const sc_mpclin_params* params, const double* model,
                             const void* X, const void* u_prev, const void* goal, const void* obs,
                             void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
 
-/* ---- MPC-CBF for DoubleIntegrator2D and Quad2D -----------------------------------------------
+/* ---- MPC-CBF for DoubleIntegrator2D, Quad2D and the KinematicBicycle2D family ----------------
  * MPCCBF (position_control/mpc_cbf.py:7-402) for the planar models whose rel-deg-2 DT-CBF steps the state with the robot's
  * own step(): x1 = step(x_k, u_k), x2 = step(x1, u_k) (double_integrator2D.py:222-272 with the speed rescaled to v_max
  * :79-107; quad2D.py:179-206), so the barrier points are functions of (x_k, u_k) and not predicted positions.  Weights /
  * gains / bounds of mpc_cbf.py: DI Q = diag(50,50,20,20), R = (.5,.5), alpha .2, |a| <= (ax_max, ay_max); Quad2D Q =
  * diag(25,25,50,10,10,50), R = (.5,.5), alpha .15, f_min <= u <= f_max.  Interior point as sc_mpccbf_solve_batch (exact
- * Hessian for Quad2D, Gauss-Newton for the linear DoubleIntegrator2D; oracle/mpc_gn.py).  KinematicBicycle2D has the same
- * structure but the solver does not converge reliably on it yet (not served: SC_ERR_UNSUPPORTED).
+ * Hessian for Quad2D, Gauss-Newton for the linear DoubleIntegrator2D; oracle/mpc_gn.py).
+ * KinematicBicycle2D (mpc_cbf.py:31-33,64-67,205-211; kinematic_bicycle2D.py:113-123,175-199): Q = diag(50,50,1,1), R = (.5, 5000),
+ * alpha .1, beta 1.1, |a| <= a_max, |beta| <= beta_max, |v_k| <= v_max as state rows; step() clips the speed to [v_min, v_max].
+ * KinematicBicycle2D_C3BF / _DPCBF (mpc_cbf.py:68-73,312-315; kinematic_bicycle2D_c3bf.py:77-118, ..._dpcbf.py:86-142): the same
+ * dynamics, cost and bounds with the row d_h + alpha h_k of a barrier of the FULL state; the one gain (0.15) travels in alpha1,
+ * alpha2 = 0, beta unused (1.01 / 1.05 are fixed in the barriers).  As in the reference's MPC the obstacle's velocity columns are
+ * not read (the barrier gets a 1 x 7 row there: `obs.shape[0] > 3` is False); oracle/mpc_kb_state.py.
  * X [B,nx] (nx = 4, or 6 for Quad2D), u_prev [B,2], goal [B,2], obs [B,K,7] (or [K,7]) padded like update_tvp;
  * u_out [B,2], status_out [B], iters_out [B] or NULL, z_out [B, 2*horizon] or NULL.  One NLP per wavefront, f64 arithmetic.
  */
 typedef struct sc_mpcgn_params {
-    int32_t model_id;        /* SC_MODEL_DOUBLE_INTEGRATOR2D or SC_MODEL_QUAD2D                                    */
+    int32_t model_id;        /* SC_MODEL_DOUBLE_INTEGRATOR2D, SC_MODEL_QUAD2D, SC_MODEL_KINEMATIC_BICYCLE2D[_C3BF|_DPCBF] */
     int32_t io_dtype, horizon, max_iter, obs_shared, acceptable_iter;      /* as sc_mpccbf_params                  */
     int32_t circles_only;    /* 1: no superellipsoid branch in the model's DT barrier (KB, Quad2D)                 */
     int32_t reserved;
     double  dt;
     double  Q[6], R[2];      /* mpc_cbf.py:28-36                                                                   */
-    double  alpha1, alpha2;  /* mpc_cbf.py:60-76                                                                   */
+    double  alpha1, alpha2;  /* mpc_cbf.py:60-76 (C3BF / DPCBF: alpha, 0)                                          */
     double  u_lo[2], u_hi[2];
-    double  v_min, v_max;    /* DI: speed rescaling of step() (v_max); v_min reserved                              */
-    double  rear_ax_dist;    /* reserved (KinematicBicycle2D)                                                      */
+    double  v_min, v_max;    /* DI: speed rescaling of step() (v_max); bicycles: clip of step(), state bound |v| <= v_max */
+    double  rear_ax_dist;    /* bicycles: L_r                                                                      */
     double  mass, inertia;   /* Quad2D                                                                             */
     double  robot_radius;    /* barrier radius (and the rotor arm of Quad2D, quad2D.py:72)                         */
     double  beta;            /* barrier inflation: 1.01                                                            */
