@@ -56,3 +56,27 @@ def test_tables_and_cbf_rows():
         assert np.abs(ev["g"][:K] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
         # rows: CBF | x_dot <= v_max, x_dot >= -v_max, z_dot >= -descent, |theta| <= pitch_max | input box
         assert ev["g"].shape[0] == K + 5 + 8 and ev["J"].shape == (K + 5 + 8, 4)
+
+
+def test_the_reference_scene_starts_infeasible():
+    """examples/test_vtol.py: x0 = (2, 10, 0, v_max = 20, 0, 0), one disc of radius 1.5 at (60, 12), robot radius 0.6.  The stage-0 CBF
+    row against that disc depends on u_0 alone (x_0 is given) and is negative over the WHOLE input box: at 20 m/s and 58 m the
+    0.1 d_h term (-11.6) outweighs 0.0025 h (+8.4) and two Euler steps of any admissible input move dd_h by a few tenths.  So the first
+    NLP of the reference's own example has no feasible point; what the reference applies there is the output of IPOPT's restoration
+    phase (MPCCBF.status is hard-wired to 'optimal', mpc_cbf.py:10,400) -- not reproducible without IPOPT."""
+    import itertools
+    from oracle import mpc_cbf as M
+    mdl = V.vtol_model(dict(radius=0.6, v_max=20.0))
+    x0 = np.array([2.0, 10.0, 0.0, 20.0, 0.0, 0.0])
+    obs = np.array([[60.0, 12.0, 1.5, 0, 0, 0, 0]])
+    P = G.params(mdl, 1)
+    lo, hi = mdl["u_lo"], mdl["u_hi"]
+    best = -np.inf
+    for c in itertools.product(np.linspace(0, 1, 5), repeat=4):
+        best = max(best, G.evaluate(x0, lo + (hi - lo) * np.array(c), np.zeros(4), np.array([70.0, 10.0]), obs, P, level=0)["g"][0])
+    assert -1.0 < best < -0.7
+    # the row is monotone enough in u_0 that the grid maximum sits on a vertex; a gradient check around it finds nothing better
+    from scipy.optimize import minimize
+    r = minimize(lambda u: -G.evaluate(x0, u, np.zeros(4), np.array([70.0, 10.0]), obs, P, level=0)["g"][0], hi, method="L-BFGS-B",
+                 bounds=list(zip(lo, hi)))
+    assert -r.fun <= best + 1e-9
