@@ -195,6 +195,10 @@ struct MpcConst {
 
 // ---- barrier h, dh/dp, d2h/dp2 at a position (oracle/mpc_cbf.py: barrier) ---------------------
 // circle robots/dynamic_unicycle2D.py:194-202; superellipsoid :204-220 (fabs, clamps a,b>=1e-3, e>=2)
+// CHAIN: integer superellipsoid exponents by the multiply chain of ipm::pow3 -- the N = 20 and run-time-horizon kernels (config 5's
+// superellipsoid scenes).  The compile-time N = 10 kernels are capped at 256 VGPRs for two waves per SIMD and the inlined chain costs them
+// 31 - 134 spilled registers (config 3: 1.48 -> 1.65 ms, optimal decay 4.0 -> 4.5 ms per 4096 problems): they keep the library pow().
+template <bool CHAIN>
 __device__ inline void barrier_at(double px_, double py_, const double* o, const MpcConst& c, bool derivs,
                                   double& h, double& d0, double& d1, double& hxx, double& hxy, double& hyy) {
     if (o[6] == 0.0) {                      // LDS rows: 0 = circle, otherwise the row scale of a superellipsoid (mpc_ipm_common.hpp)
@@ -207,14 +211,21 @@ __device__ inline void barrier_at(double px_, double py_, const double* o, const
     const double a = fmax(fabs(o[2]), 1e-3) + c.Rrob, b = fmax(fabs(o[3]), 1e-3) + c.Rrob;
     const double e = fmax(fabs(o[4]), 2.0);
     double st, ct;
-    sincos_(o[5], &st, &ct);
+    if constexpr (CHAIN) sincos_(o[5], &st, &ct);
+    else sincos(o[5], &st, &ct);                                           // as pow(): the register budget of the N = 10 kernels
     const double dx = px_ - o[0], dy = py_ - o[1];
     const double px = ct * dx + st * dy, py = -st * dx + ct * dy;
     const double ax = fabs(px) / a, ay = fabs(py) / b;
     const double sc = o[6];
     double xe, xe1, xe2, ye, ye1, ye2;
-    ipm::pow3(ax, e, derivs, xe, xe1, xe2);                                // integer exponents: one multiply chain instead of three pow()
-    ipm::pow3(ay, e, derivs, ye, ye1, ye2);
+    if constexpr (CHAIN) {
+        ipm::pow3(ax, e, derivs, xe, xe1, xe2);                            // integer exponents: one multiply chain instead of three pow()
+        ipm::pow3(ay, e, derivs, ye, ye1, ye2);
+    } else {
+        xe = pow(ax, e); ye = pow(ay, e);
+        xe1 = derivs ? pow(ax, e - 1) : 0.0; ye1 = derivs ? pow(ay, e - 1) : 0.0;
+        xe2 = derivs ? pow(ax, e - 2) : 0.0; ye2 = derivs ? pow(ay, e - 2) : 0.0;
+    }
     h = sc * (xe + ye - 1.0);
     if (!derivs) { d0 = d1 = hxx = hxy = hyy = 0.0; return; }
     const double sx = px > 0 ? 1.0 : (px < 0 ? -1.0 : 0.0), sy = py > 0 ? 1.0 : (py < 0 ? -1.0 : 0.0);
@@ -340,7 +351,7 @@ __device__ inline double eval_values(const double* z, const double* rho, const M
     for (int e = lane; e < NP * K; e += 64) {
         const int k = e / K, j = e - k * K;
         double h, d0, d1, hxx, hxy, hyy;
-        barrier_at(W.pos[2 * k], W.pos[2 * k + 1], W.obs + 7 * j, c, derivs, h, d0, d1, hxx, hxy, hyy);
+        barrier_at<!ROW16>(W.pos[2 * k], W.pos[2 * k + 1], W.obs + 7 * j, c, derivs, h, d0, d1, hxx, hxy, hyy);
         W.hk[e] = h;
         if (derivs) {
             W.dh[2 * e] = d0; W.dh[2 * e + 1] = d1;
@@ -456,7 +467,7 @@ __device__ __forceinline__ double stage_pass(const MpcMem& W, const MpcConst& c,
             double hxx = 2.0, hxy = 0.0, hyy = 2.0;                  // d2h/dp2 of a circle; superellipsoids recompute theirs
             if (W.obs[7 * jo + 6] != 0.0) {
                 double h_, g0_, g1_;
-                barrier_at(pk0, pk1, W.obs + 7 * jo, c, true, h_, g0_, g1_, hxx, hxy, hyy);
+                barrier_at<!ROW16>(pk0, pk1, W.obs + 7 * jo, c, true, h_, g0_, g1_, hxx, hxy, hyy);
             }
             const double ml = w0 * l0 + w1 * l1 + w2 * l2, ma = w0 * i0 + w1 * i1 + w2 * i2, mb = w0 * b0 + w1 * b1 + w2 * b2;
             const double c0 = w0 * w0 * s0 + w1 * w1 * s1 + w2 * w2 * s2;
