@@ -245,7 +245,11 @@ __global__ __launch_bounds__(64) void cbfqp_coop_kernel(const sc_cbfqp_params p,
 #pragma unroll
     for (int f = 0; f < 7; ++f) o[f] = TC(orow[f]);
     TC h, a0, a1, cc;
+#ifndef SC_EXP_NOROW
     const bool ok = cbf_row<TC, MODEL, false>(ag, o, k, a0, a1, cc, h);
+#else
+    const bool ok = true; a0 = o[0] - ag.x; a1 = o[1] - ag.y; cc = o[2]; h = o[3];
+#endif
     const bool used = sub < nk;
     const bool bad_mine = used && !ok;
     a0 = used ? a0 : TC(0); a1 = used ? a1 : TC(0); cc = used ? cc : TC(0);
@@ -255,7 +259,13 @@ __global__ __launch_bounds__(64) void cbfqp_coop_kernel(const sc_cbfqp_params p,
     // ---- cooperative walk ----------------------------------------------------------------------
     QpState<TC> S;
     qp_begin(S, ur0, ur1, k);
+#ifndef SC_EXP_NOWALK                                     // developer builds only (tools/README.md): what the solve costs in the launch
+#ifndef SC_COOP_OLD_WALK
+    if constexpr (G == 8) coop_solve_all8<TC>(S, K, sub, lane, a0, a1, cc, k);          // fixed critical path (sc_group.hpp)
+    else
+#endif
     coop_walk_violated<TC, G>(S, K, sub, lane, a0, a1, cc, k);
+#endif
     qp_finish_box(S, k);
     TC worst = qp_row_margin(num<TC>::inf(), a0, a1, cc, S.u0, S.u1, poison);
     worst = group_min<TC, G>(worst);

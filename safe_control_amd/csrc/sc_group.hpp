@@ -87,7 +87,10 @@ __device__ __forceinline__ void coop_walk_violated(QpState<TC>& S, int K, int su
     const unsigned long long grp = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gbase;
     const bool testable = (sub < K) && !((a0 == TC(0)) && (a1 == TC(0)));     // all-zero rows are never projected on
     int last = -1;
-    for (int it = 0; it < G; ++it) {                          // at most K commits per agent
+#ifndef SC_EXP_MAXIT
+#define SC_EXP_MAXIT G                                     // developer builds cap it to time one pass of the loop
+#endif
+    for (int it = 0; it < SC_EXP_MAXIT; ++it) {               // at most K commits per agent
         const TC s = a0 * S.u0 + (a1 * S.u1 + cc);
         const bool v = testable && (sub > last) && (s < TC(0));
         const unsigned long long m = __builtin_amdgcn_ballot_w64(v);
@@ -105,6 +108,61 @@ __device__ __forceinline__ void coop_walk_violated(QpState<TC>& S, int K, int su
         qp_row_commit(S, L, viol);
         last = has ? istar : K;
     }
+}
+
+// ---- all candidates at once (G = 8) ---------------------------------------------------------------------------------
+// The walk above commits one violated row per pass: its latency is (number of commits of the slowest agent of the WAVE + 1)
+// passes of ~1000 cycles each for a lone wave (measured on the headline launch: 0.5 us for the first pass, 1.9 us for the five
+// passes its slowest wave needs -- the launch ends with that wave).  This form has a fixed, shorter critical path: the
+// minimiser of ||u - u_ref||^2 over {box, rows} is u_box = clamp(u_ref) when no row is violated there; otherwise it lies on the
+// line of a row that IS violated at u_box (moving from the optimum towards u_box lowers the objective, so it must leave the
+// feasible set through an active row, which u_box then violates), and on that line it is the point of the feasible interval
+// closest to the foot of u_ref.  So every lane whose row is violated at u_box clips ITS line against the box and against the
+// seven other rows of the group (seven xor-partners: DPP quad permutes and the half-row mirror, no LDS round trip), takes the
+// closest point of the interval, and the group keeps the candidate with the smallest distance.  Same clip_box / clip_row /
+// midpoint rule as the walk, so the chosen point is computed by the same arithmetic as the walk's last commit on that row;
+// feasibility is again decided once, in slack space, by the caller.
+template <typename T, int X>
+__device__ __forceinline__ T group_xor8(T v, T mirrored) {          // value of lane (sub ^ X), X = 1..7; mirrored = lane (sub ^ 7)
+    if constexpr (X == 1) return dpp_mov<0xB1>(v);
+    else if constexpr (X == 2) return dpp_mov<0x4E>(v);
+    else if constexpr (X == 3) return dpp_mov<0x1B>(v);
+    else if constexpr (X == 4) return dpp_mov<0x1B>(mirrored);
+    else if constexpr (X == 5) return dpp_mov<0x4E>(mirrored);
+    else if constexpr (X == 6) return dpp_mov<0xB1>(mirrored);
+    else return mirrored;
+}
+template <typename TC, int... Xs>
+__device__ __forceinline__ void clip_partners8(LineQP<TC>& L, TC a0, TC a1, TC cc, std::integer_sequence<int, Xs...>) {
+    const TC m0 = dpp_mov<0x141>(a0), m1 = dpp_mov<0x141>(a1), mc = dpp_mov<0x141>(cc);
+    (clip_row(L, group_xor8<TC, Xs + 1>(a0, m0), group_xor8<TC, Xs + 1>(a1, m1), group_xor8<TC, Xs + 1>(cc, mc)), ...);
+}
+template <typename TC>
+__device__ __forceinline__ void coop_solve_all8(QpState<TC>& S, int K, int sub, int lane, TC a0, TC a1, TC cc,
+                                                const CbfConsts<TC>& k) {
+    const TC inf = num<TC>::inf();
+    const bool testable = (sub < K) && !((a0 == TC(0)) && (a1 == TC(0)));     // all-zero rows are never projected on
+    LineQP<TC> L;
+    const bool viol = qp_row_violated(S, a0, a1, cc, L, k) && testable;       // S holds u_box; L: the line of this lane's row
+    if (__builtin_amdgcn_ballot_w64(viol) == 0ull) return;                   // wave-uniform: nothing violated anywhere
+    clip_box(L, k);
+    clip_partners8(L, a0, a1, cc, std::make_integer_sequence<int, 7>{});
+    TC t = fmin_(fmax_(TC(0), L.lo), L.hi);
+    const bool inverted = L.lo > L.hi;
+    t = inverted ? TC(0.5) * (L.lo + L.hi) : t;                               // by a hair (rounding): split the difference, as the walk
+    const bool empty = L.lo > L.hi + num<TC>::tol_feas() * fmax_(TC(1), fmax_(fabs_(L.lo), fabs_(L.hi)));
+    const TC v0 = L.p0 + t * L.d0, v1 = L.p1 + t * L.d1;
+    const TC e0 = v0 - S.ur0, e1 = v1 - S.ur1;
+    TC cost = e0 * e0 + e1 * e1;
+    cost = (viol && !empty && (cost == cost)) ? cost : inf;
+    const TC best = group_min<TC, 8>(cost);
+    const int gbase = lane & ~7;
+    const unsigned long long mg = __builtin_amdgcn_ballot_w64((cost == best) && (best < inf)) & (0xffull << gbase);
+    const bool has = mg != 0ull;
+    const int win = has ? (__builtin_ctzll(mg) - gbase) : -1;
+    const TC s0 = group_max<TC, 8>(sub == win ? v0 : -inf), s1 = group_max<TC, 8>(sub == win ? v1 : -inf);
+    S.u0 = has ? s0 : S.u0;                                                   // no candidate: u_box stays and fails the slack check
+    S.u1 = has ? s1 : S.u1;
 }
 
 }  // namespace sc
