@@ -262,6 +262,7 @@ __global__ __launch_bounds__(64) void cbfqp_coop_kernel(const sc_cbfqp_params p,
 #ifndef SC_EXP_NOWALK                                     // developer builds only (tools/README.md): what the solve costs in the launch
 #ifndef SC_COOP_OLD_WALK
     if constexpr (G == 8) coop_solve_all8<TC>(S, K, sub, lane, a0, a1, cc, k);          // fixed critical path (sc_group.hpp)
+    else if constexpr (G == 16) coop_solve_all16<TC>(S, K, sub, lane, a0, a1, cc, k);
     else
 #endif
     coop_walk_violated<TC, G>(S, K, sub, lane, a0, a1, cc, k);

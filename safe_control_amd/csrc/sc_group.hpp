@@ -165,4 +165,47 @@ __device__ __forceinline__ void coop_solve_all8(QpState<TC>& S, int K, int sub, 
     S.u1 = has ? s1 : S.u1;
 }
 
+// The same for 16 lanes per agent (K <= 16; one DPP row per agent): fifteen partners by row_ror, reductions by quad permutes and
+// the two mirrors.
+template <typename T>
+__device__ __forceinline__ T row_min16(T v) {
+    v = fmin_(v, dpp_mov<0xB1>(v)); v = fmin_(v, dpp_mov<0x4E>(v)); v = fmin_(v, dpp_mov<0x141>(v)); v = fmin_(v, dpp_mov<0x140>(v));
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ T row_max16(T v) {
+    v = fmax_(v, dpp_mov<0xB1>(v)); v = fmax_(v, dpp_mov<0x4E>(v)); v = fmax_(v, dpp_mov<0x141>(v)); v = fmax_(v, dpp_mov<0x140>(v));
+    return v;
+}
+template <typename TC, int... Rs>
+__device__ __forceinline__ void clip_partners16(LineQP<TC>& L, TC a0, TC a1, TC cc, std::integer_sequence<int, Rs...>) {
+    (clip_row(L, dpp_mov<0x121 + Rs>(a0), dpp_mov<0x121 + Rs>(a1), dpp_mov<0x121 + Rs>(cc)), ...);     // row_ror:1 .. row_ror:15
+}
+template <typename TC>
+__device__ __forceinline__ void coop_solve_all16(QpState<TC>& S, int K, int sub, int lane, TC a0, TC a1, TC cc,
+                                                 const CbfConsts<TC>& k) {
+    const TC inf = num<TC>::inf();
+    const bool testable = (sub < K) && !((a0 == TC(0)) && (a1 == TC(0)));
+    LineQP<TC> L;
+    const bool viol = qp_row_violated(S, a0, a1, cc, L, k) && testable;
+    if (__builtin_amdgcn_ballot_w64(viol) == 0ull) return;
+    clip_box(L, k);
+    clip_partners16(L, a0, a1, cc, std::make_integer_sequence<int, 15>{});
+    TC t = fmin_(fmax_(TC(0), L.lo), L.hi);
+    t = (L.lo > L.hi) ? TC(0.5) * (L.lo + L.hi) : t;
+    const bool empty = L.lo > L.hi + num<TC>::tol_feas() * fmax_(TC(1), fmax_(fabs_(L.lo), fabs_(L.hi)));
+    const TC v0 = L.p0 + t * L.d0, v1 = L.p1 + t * L.d1;
+    const TC e0 = v0 - S.ur0, e1 = v1 - S.ur1;
+    TC cost = e0 * e0 + e1 * e1;
+    cost = (viol && !empty && (cost == cost)) ? cost : inf;
+    const TC best = row_min16(cost);
+    const int gbase = lane & ~15;
+    const unsigned long long mg = __builtin_amdgcn_ballot_w64((cost == best) && (best < inf)) & (0xffffull << gbase);
+    const bool has = mg != 0ull;
+    const int win = has ? (__builtin_ctzll(mg) - gbase) : -1;
+    const TC s0 = row_max16(sub == win ? v0 : -inf), s1 = row_max16(sub == win ? v1 : -inf);
+    S.u0 = has ? s0 : S.u0;
+    S.u1 = has ? s1 : S.u1;
+}
+
 }  // namespace sc
