@@ -608,7 +608,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": ("cbfqp_coop_kernel" if B <= 32768 else "cbfqp_reg_kernel") if K <= 8 else "cbfqp_coop_kernel",
                          "kernel_us": 1e3 * kernel_ms,
-                         "algorithmic_bytes_per_solve": BYTES_IN_CBFQP(K, es) + BYTES_OUT_CBFQP(K, es)},
+                         "algorithmic_bytes_per_solve": BYTES_IN_CBFQP(K, es) + BYTES_OUT_CBFQP(K, es),
+                         # HIP events on the launch stream; ms_per_step is the host clock around the same region.  Under
+                         # rocprofv3 --kernel-trace the dependent graph nodes are dispatched one completion signal at a time:
+                         # its per-dispatch figure is that period when the launch is shorter (profiles/README.md, round 2)
+                         "timing": "hip_events_over_timed_region"},
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
