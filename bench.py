@@ -454,14 +454,18 @@ def closed_loop_leg(dev, B=4096, T=200, seed=0):
     ctl.set_waypoints(wps)
     ctl.control_step(1)                                                   # warm-up launch
     torch.cuda.synchronize()
-    ctl = sca.BatchedTrackingController(X0, dict(spec), obs=obs, io_dtype="f32", device=str(dev))
-    ctl.set_waypoints(wps)
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    ret = ctl.control_step(T)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1)
+    # one launch per run: the event bracket also holds the host's launch latency, so the run is repeated and the fastest kept
+    ms = float("inf")
+    for _ in range(3):
+        ctl = sca.BatchedTrackingController(X0, dict(spec), obs=obs, io_dtype="f32", device=str(dev))
+        ctl.set_waypoints(wps)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ret = ctl.control_step(T)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = min(ms, e0.elapsed_time(e1))
     ret = ret.cpu().numpy(); rs = ctl.ret_step.cpu().numpy()
     steps_run = np.where(ret == 0, T, rs + 1).sum()
     return {"workload": f"{B} DynamicUnicycle2D agents x {T} closed-loop control steps, 14 shared obstacles, num_constraints 10, one launch",
