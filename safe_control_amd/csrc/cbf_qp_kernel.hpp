@@ -212,15 +212,18 @@ __global__ __launch_bounds__(256) void cbfqp_reg_kernel(const sc_cbfqp_params p,
 // same code as the lane-per-QP kernel (min/max reductions are exact), so both give the same answer.
 // G lanes per agent (G = 8, 16 or 32 >= K), 64 / G agents per wave.
 template <typename TIO, typename TC, int G, int MODEL>
-__global__ __launch_bounds__(64) void cbfqp_coop_kernel(const sc_cbfqp_params p, const long long B, const int K,
+#ifndef SC_COOP_WAVES
+#define SC_COOP_WAVES 1                                   // waves per workgroup of the cooperative kernel (developer builds time 2 and 4)
+#endif
+__global__ __launch_bounds__(64 * SC_COOP_WAVES) void cbfqp_coop_kernel(const sc_cbfqp_params p, const long long B, const int K,
                                                         const TIO* __restrict__ X, const TIO* __restrict__ u_ref,
                                                         const TIO* __restrict__ obs, const int* __restrict__ n_obs,
                                                         TIO* __restrict__ u_out, int* __restrict__ status_out,
                                                         TIO* __restrict__ h_out) {
     constexpr int APW = 64 / G;                            // agents per wave
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int sub = lane & (G - 1);                        // obstacle row handled by this lane
-    const long long agent = (long long)blockIdx.x * APW + lane / G;
+    const long long agent = ((long long)blockIdx.x * SC_COOP_WAVES + (threadIdx.x >> 6)) * APW + lane / G;
     const bool active = agent < B;
     const long long ag_i = active ? agent : 0;
     using V2 = typename vec2<TIO>::type;
@@ -295,8 +298,8 @@ static hipError_t launch_coop(const sc_cbfqp_params& p, long long B, int K, cons
                               const void* obs, const int* n_obs, void* u_out, int* status, void* h_out,
                               hipStream_t stream) {
     constexpr int APW = 64 / G;
-    const unsigned nblk = (unsigned)((B + APW - 1) / APW);
-    hipLaunchKernelGGL((cbfqp_coop_kernel<TIO, TC, G, MODEL>), dim3(nblk), dim3(64), 0, stream, p, B, K,
+    const unsigned nblk = (unsigned)((B + APW * SC_COOP_WAVES - 1) / (APW * SC_COOP_WAVES));
+    hipLaunchKernelGGL((cbfqp_coop_kernel<TIO, TC, G, MODEL>), dim3(nblk), dim3(64 * SC_COOP_WAVES), 0, stream, p, B, K,
                        (const TIO*)X, (const TIO*)u_ref, (const TIO*)obs, n_obs, (TIO*)u_out, status, (TIO*)h_out);
     return hipGetLastError();
 }
