@@ -250,6 +250,26 @@ def test_degenerate_geometry():
                 compare(R.MODEL_DU, du_spec(), X, u_ref, obs, io, comp)
 
 
+@pytest.mark.parametrize("K", [8, 13, 16])
+def test_crowded_scenes_cooperative_kernels(K):
+    """Many rows violated at once (obstacles 0.35 - 1.5 m ahead of a moving agent, large reference inputs): optima at vertices of two
+    rows, rows that only bind after another row moved the point, and infeasible crowds.  The 8- and 16-lanes-per-agent kernels take
+    every candidate line at once (sc_group.hpp: coop_solve_all8 / 16); every agent of the batch is compared with the enumerating C
+    oracle."""
+    rng = np.random.default_rng(1000 + K)
+    B = 4096
+    X, goal, u_ref, obs = W.du_cbfqp_batch(B, K, seed=K)
+    X[:, 3] = rng.uniform(0.3, 1.0, B)
+    for j in range(K):
+        rho = rng.uniform(0.35, 1.5, B) + 0.25; ang = X[:, 2] + rng.uniform(-1.2, 1.2, B)
+        obs[:, j, 0] = X[:, 0] + rho * np.cos(ang); obs[:, j, 1] = X[:, 1] + rho * np.sin(ang)
+        obs[:, j, 2] = rng.uniform(0.05, 0.3, B); obs[:, j, 3:] = 0.0
+    u_ref = rng.uniform(-1.0, 1.0, (B, 2)) * np.array([1.0, 0.5]) * rng.choice([0.3, 1.0, 4.0], (B, 1))
+    for io, comp in (("f64", "f64"), ("f32", "f64")):
+        r = compare(R.MODEL_DU, du_spec(), X, u_ref, obs, io, comp)
+        assert 0.02 * B < r["infeasible"] < 0.9 * B                       # both kinds of outcome are in the batch
+
+
 # ------------------------------------------------------------------ golden fixtures
 def test_golden_cases_through_dropin_class(golden_dir):
     """tests/golden/cbfqp_cases.npz through the reference-shaped CBFQP class (host-pointer C-ABI)."""
