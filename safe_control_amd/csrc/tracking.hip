@@ -706,9 +706,11 @@ __global__ __launch_bounds__(64) void tracking_coop_kernel(
         else {
             QpState<TC> S;
             qp_begin(S, ur0, ur1, k);
+#ifndef SC_EXP_NOWALK                                     // developer builds: what the solve costs inside the rollout
             if constexpr (G == 8) coop_solve_all8<TC>(S, t.K, sub, lane, a0, a1, cc, k);       // all candidates at once (sc_group.hpp)
             else if constexpr (G == 16) coop_solve_all16<TC>(S, t.K, sub, lane, a0, a1, cc, k);
             else coop_walk_violated<TC, G>(S, t.K, sub, lane, a0, a1, cc, k);
+#endif
             qp_finish_box(S, k);
             TC worst = qp_row_margin(num<TC>::inf(), a0, a1, cc, S.u0, S.u1, poison);
             worst = group_min<TC, G>(worst);
