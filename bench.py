@@ -755,7 +755,7 @@ def hetero_roofline(od, n_total, ws, steps, elapsed, nbytes):
                 return {"bound": "valu_issue", "achieved": ach, "peak": VALU_PEAK_GIPS * ws, "unit": "G wave-instr/s", "frac": ach / (VALU_PEAK_GIPS * ws),
                         "traffic": None, "kernel": "odmpccbf_uni_kernel<20> + mpclin_kernel<12,4,0,0,big,od>", "valu_instructions_per_step": sum(insts),
                         "source": f"profiles/{rnd}_counters.json:hetero_sq",
-                        "note": "latency-bound interior-point solves (one Quad3D problem per CU: 147 KB of LDS, four waves)"}
+                        "note": "latency-bound interior-point solves (two Quad3D problems per CU: 77 KB of LDS and four waves each; two Unicycle2D problems per CU: 65 KB, one wave each)"}
     return {"bound": "hbm", "achieved": nbytes * steps / elapsed / 1e9, "peak": HBM_PEAK_GBS * ws, "unit": "GB/s",
             "frac": nbytes * steps / elapsed / 1e9 / (HBM_PEAK_GBS * ws), "traffic": None,
             "kernel": ("odmpccbf_uni_kernel<20> + mpclin_kernel<12,4,0,0,big,od>" if od else "mpccbf_uni_kernel<20> + mpclin_kernel<12,4,0,0,big>"),
