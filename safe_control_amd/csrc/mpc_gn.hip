@@ -407,6 +407,37 @@ __device__ __forceinline__ double gn_eval(const double* zv, const GnMem& W, cons
 #pragma unroll
     for (int i = 0; i < NX; ++i) { x[i] = W.xs[i]; col[i] = 0.0; }
     const int myk = lane >> 1, myc = lane & 1;                               // z index lane = input myc of stage myk
+    if (!derivs) {
+        // values only (line search): the prediction chain x_{k+1} = F(x_k, u_k) is sequential and wave-uniform; the barrier points
+        // b_k = pos(S(x_k, u_k)), c_k = pos(S(S(x_k, u_k), u_k)) hang off x_k only, so lane k computes the two of stage k
+        for (int k = 0; k < N; ++k) {
+            const double u[2] = {zv[2 * k], zv[2 * k + 1]};
+            double xn[NX];
+            double (*nul4)[NX] = nullptr;
+            double (*nul2)[2] = nullptr;
+            Mdl::template map<false, false>(x, u, q, xn, nul4, nul2);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) W.xs[(k + 1) * NX + i] = xn[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = xn[i];
+        }
+        SC_SYNC();
+        for (int k = lane; k < N; k += 64) {
+            const double u[2] = {zv[2 * k], zv[2 * k + 1]};
+            double xk[NX], y1[NX], y2[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xk[i] = W.xs[k * NX + i];
+            double (*nul4)[NX] = nullptr;
+            double (*nul2)[2] = nullptr;
+            Mdl::template map<false, true>(xk, u, q, y1, nul4, nul2);
+            Mdl::template map<false, true>(y1, u, q, y2, nul4, nul2);
+            W.pts[6 * k + 0] = xk[0]; W.pts[6 * k + 1] = xk[1];
+            W.pts[6 * k + 2] = y1[0]; W.pts[6 * k + 3] = y1[1];
+            W.pts[6 * k + 4] = y2[0]; W.pts[6 * k + 5] = y2[1];
+        }
+    } else
     for (int k = 0; k < N; ++k) {
         const double u[2] = {zv[2 * k], zv[2 * k + 1]};
         double xn[NX], y1[NX], y2[NX];
@@ -543,6 +574,33 @@ __device__ __forceinline__ double gn_eval_state(const double* zv, const GnMem& W
 #pragma unroll
     for (int i = 0; i < NX; ++i) { x[i] = W.xs[i]; col[i] = 0.0; }
     const int myk = lane >> 1, myc = lane & 1;
+    if (!derivs) {                                                          // values only: sequential chain, then lane k takes stage k
+        for (int k = 0; k < N; ++k) {
+            const double u[2] = {zv[2 * k], zv[2 * k + 1]};
+            double xn[NX];
+            double (*nul4)[NX] = nullptr;
+            double (*nul2)[2] = nullptr;
+            Mdl::template map<false, false>(x, u, q, xn, nul4, nul2);
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) W.xs[(k + 1) * NX + i] = xn[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = xn[i];
+        }
+        SC_SYNC();
+        for (int k = lane; k < N; k += 64) {
+            const double u[2] = {zv[2 * k], zv[2 * k + 1]};
+            double xk[NX], y1[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xk[i] = W.xs[k * NX + i];
+            double (*nul4)[NX] = nullptr;
+            double (*nul2)[2] = nullptr;
+            Mdl::template map<false, true>(xk, u, q, y1, nul4, nul2);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { W.pts[8 * k + i] = xk[i]; W.pts[8 * k + 4 + i] = y1[i]; }
+        }
+    } else
     for (int k = 0; k < N; ++k) {
         const double u[2] = {zv[2 * k], zv[2 * k + 1]};
         double xn[NX], y1[NX];
