@@ -127,6 +127,15 @@ def valu_roofline(run, kernel_substr, kernel_ms, note=None):
     return None
 
 
+def with_roofline(res, kernel_substr):
+    """Attach the VALU-issue roofline of an interior-point leg when the committed counter profile holds the kernel
+    (profiles/r02_counters.json: run bench_full_sq = the default bench command under rocprofv3 --pmc, same batches)."""
+    r = valu_roofline("bench_full_sq", kernel_substr, res["kernel_ms"])
+    if r is not None:
+        res["roofline"] = r
+    return res
+
+
 def mpc_cpu_baseline(Xn, goal, on, N, seconds):
     """oracle/mpc_cbf.py (numpy float64, the same interior-point method) on one host core: bounded sample of the
     same batch, starting from its first problem."""
@@ -271,11 +280,11 @@ def od_mpc_leg(dev, B=4096, K=8, N=10, steps=2, seed=0):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    return {"workload": f"{B}-agent batch DynamicUnicycle2D optimal-decay MPC-CBF, horizon N={N}, {K} obstacles",
+    return with_roofline({"workload": f"{B}-agent batch DynamicUnicycle2D optimal-decay MPC-CBF, horizon N={N}, {K} obstacles",
             "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
             "optimal_fraction": float((st == 0).double().mean().item()),
             "mean_ipm_iterations": float(it.double().mean().item()),
-            "max_decay_deviation": float((rho - 1.0).abs().max().item())}
+            "max_decay_deviation": float((rho - 1.0).abs().max().item())}, f"odmpccbf_kernel<{N}>")
 
 
 def manip_leg(dev, B=4096, K=3, steps=20, seed=0):
@@ -357,11 +366,13 @@ def linear_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    return {"workload": f"{B}-agent batch {model} MPC-CBF, horizon N={N}, {K} obstacles ({N * up.shape[1]} variables)",
+    nxu = "12, 4" if model == "Quad3D" else "2, 2"
+    kname = f"mpclin_kernel<{nxu}, {N}, {K}, false, false>" if N == 10 else f"mpclin_kernel<{nxu}, 0, 0, true, false>"
+    return with_roofline({"workload": f"{B}-agent batch {model} MPC-CBF, horizon N={N}, {K} obstacles ({N * up.shape[1]} variables)",
             "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
             "optimal_fraction": float((st == 0).double().mean().item()),
             "infeasible_fraction": float((st == 1).double().mean().item()),
-            "mean_ipm_iterations": float(it.double().mean().item())}
+            "mean_ipm_iterations": float(it.double().mean().item())}, kname)
 
 
 def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
@@ -395,11 +406,12 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    return {"workload": f"{B}-agent batch {model} MPC-CBF, horizon N={N}, {K} obstacles",
+    mid = {"DoubleIntegrator2D": 5, "Quad2D": 6, "KinematicBicycle2D": 1, "KinematicBicycle2D_C3BF": 2, "KinematicBicycle2D_DPCBF": 3}[model]
+    return with_roofline({"workload": f"{B}-agent batch {model} MPC-CBF, horizon N={N}, {K} obstacles",
             "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
             "optimal_fraction": float((st == 0).double().mean().item()),
             "infeasible_fraction": float((st == 1).double().mean().item()),
-            "mean_ipm_iterations": float(it.double().mean().item())}
+            "mean_ipm_iterations": float(it.double().mean().item())}, f"mpcgn_kernel<{mid}, {N if N == 10 else 0}>")
 
 
 def manip_closed_loop_leg(dev, B=4096, T=100, seed=0):

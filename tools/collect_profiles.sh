@@ -30,6 +30,8 @@ for CFG in "1048576 8 f32 f32" "1048576 8 f32 f64"; do
 done
 # 4b. the full default bench line (sweep, closed-loop rollout and MPC legs) under the kernel trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench_full -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_full_under_rocprof.json 2>/dev/null
+# 4c. instruction counts of every interior-point leg of the default line (VALU rooflines of bench.py: with_roofline)
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT -o bench_full_sq -- python3 $R/bench.py --no-cpu-baseline --no-sweep > /dev/null 2>&1
 # 5. MPC-CBF kernel
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o mpc -- python3 $R/bench.py --workload mpc_cbf --steps 5 --warmup 1 > $OUT/mpc_under_rocprof.json 2>/dev/null
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o mpc_sq -- python3 $R/bench.py --workload mpc_cbf --steps 2 --warmup 1 > /dev/null 2>&1
