@@ -91,7 +91,8 @@ __host__ __device__ inline size_t mpclin_lds_doubles(int N, int K, int nx, int n
     return (od ? 12 * (size_t)N : 0) + (size_t)nx * nx + (size_t)nx * nu + 2 * nx + 2 * nu + nx + nu + 2 * nx + 24 + 10 + 7 * n + (size_t)(N + 1) * nx + 12 * N +
            7 * (size_t)K + 12 * (size_t)N * K + 6 * m + 16 * N +
            (mode == LIN_BIG ? ipm::LdTile::doubles((int)n)
-                            : 4 * (size_t)N * n + n * n + 4 * (size_t)N * n + (lean ? n * n + n : n * (n + 1)));
+                            : (lean ? 4 * (size_t)N * n + n * (n + 1) + n                             // G | M (n (n + 1): the factor's transposition scratch too) | clin
+                                    : 4 * (size_t)N * n + n * n + 4 * (size_t)N * n + n * (n + 1)));   // T | M | G | L
 }
 
 __device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode, bool od = false) {
@@ -107,7 +108,8 @@ __device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode, bool o
     W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m); W.vb = take(m);
     W.Phi = take(16 * N);
     W.T = W.M = nullptr;
-    if (mode != LIN_BIG) { W.T = take((size_t)4 * N * n); W.M = take((size_t)n * n); }
+    if (mode == LIN_STD) W.T = take((size_t)4 * N * n);
+    if (mode != LIN_BIG) W.M = take(lean ? (size_t)n * (n + 1) : (size_t)n * n);       // lean: the scratch of chol_solve_reg (row stride n + 1) lies over M
     W.Hc = W.clin = nullptr;
     W.rho = W.rhot = W.drho = W.rhob = W.w0k = W.Cv = W.dinv = W.rr = W.rdr = nullptr;
     auto take_od = [&]() {
@@ -117,7 +119,11 @@ __device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode, bool o
     };
     if (mode == LIN_BIG) { W.G = nullptr; W.L = take(ipm::LdTile::doubles(n)); take_od(); return W; }
     W.G = take((size_t)4 * N * n);
-    if (lean) { W.L = W.T; W.Hc = take((size_t)n * n); W.clin = take(n); }                   // the transpose scratch lives in the dead T | M region (4N n + n n >= n (n + 1))
+    // lean (round 2): no T (the condensation forms that operand on the fly), no copy of Hc (read through L1 / L2: every problem of the
+    // batch shares it), and the register factorisation writes its transposed factor over M, which it has read into registers by then
+    // and which nothing reads again before the next condensation (chol_reg_solve leaves M alone when the factorisation fails):
+    // Quad3D N = 10 75 -> 50 KB, three problems per CU
+    if (lean) { W.L = W.M; W.clin = take(n); }
     else W.L = take((size_t)n * (n + 1));
     take_od();
     return W;
@@ -275,13 +281,14 @@ typedef double lin_d4 __attribute__((ext_vector_type(4)));
 // TILED (big layout): there is no T and no M in LDS -- the B operand T[4k + q][j] = sum_c Phi_k[q][c] G[row(k, c)][j] is formed
 // from the stage block and four (cached) rows of G, and the lower tiles of M + delta I go straight into the tile-packed
 // Cholesky storage W.L.
-template <int NT, int NU, int NW = 1, bool TILED = false>
+// FLY: the B operand formed on the fly with the output still in W.M (the lean layout: no T in LDS either).
+template <int NT, int NU, int NW = 1, bool TILED = false, bool FLY = TILED>
 __device__ __forceinline__ void lin_condense_mfma(const LinMem& W, const int N_rt, const int nu_rt, double sf, const double* Hc,
                                                   const double* G, const double* box, int tid, double delta = 0.0) {
     const int lane = tid & 63, wv = tid >> 6;
     int tile = 0;
     const int N = NT > 0 ? NT : N_rt, nu = NT > 0 ? NU : nu_rt, n = N * nu, nt = (n + 15) / 16;
-    constexpr int S = NT > 0 ? NT : 4;
+    constexpr int S = NT > 0 ? ((FLY && !TILED && NT % 2 == 0) ? NT / 2 : NT) : 4;   // lean + on-the-fly operand: two chunks (all NT at once spills 100+ VGPRs)
     const int q = lane >> 4, l15 = lane & 15;
     for (int ti = 0; ti < nt; ++ti) {
         const int ia = 16 * ti + l15;
@@ -302,7 +309,7 @@ __device__ __forceinline__ void lin_condense_mfma(const LinMem& W, const int N_r
                     const int gr = q < 2 ? 2 * k + q : 2 * N + 2 * k + q - 2;
                     const double av = G[(size_t)gr * n + iac];
                     double bv;
-                    if constexpr (TILED) {
+                    if constexpr (FLY) {
                         const double* ph = W.Phi + 16 * k + 4 * q;
                         bv = ph[0] * G[(size_t)(2 * k) * n + jbc] + ph[1] * G[(size_t)(2 * k + 1) * n + jbc] +
                              ph[2] * G[(size_t)(2 * N + 2 * k) * n + jbc] + ph[3] * G[(size_t)(2 * N + 2 * k + 1) * n + jbc];
@@ -385,10 +392,7 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
     for (int e = lane; e < nmat; e += TH) W.Ae[e] = model[e];            // the four small matrices are contiguous in LDS too
     const double* __restrict__ Hcg = model + nmat;
     const double* __restrict__ Gg = Hcg + (size_t)n * n;
-    if constexpr (LEAN) {
-        for (int e = lane; e < n * n; e += TH) W.Hc[e] = Hcg[e];
-    }
-    const double* Hc = LEAN ? W.Hc : Hcg;
+    const double* Hc = Hcg;
     if constexpr (!BIG) {
         for (int e = lane; e < 4 * N * n; e += TH) W.G[e] = Gg[e];
     }
@@ -548,7 +552,7 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         SC_SYNC();
         LP(5);
         // T = Phi G (rows 4k..4k+3), then M = sf Hc + G' T + diag(sig_hi + sig_lo)
-        if constexpr (!BIG)
+        if constexpr (!BIG && !LEAN)
         for (int e = lane; e < 4 * N * n; e += TH) {
             const int row = e / n, col = e - row * n, k = row >> 2, r = row & 3;
             double acc = 0.0;
@@ -564,7 +568,7 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
             W.rd[i] = W.ds[d.mc + i] + W.ds[d.mc + n + i];                    // sigma of the two box rows (stored above)
         SC_SYNC();
         if constexpr (!BIG) {
-            lin_condense_mfma<NT, NU, NW>(W, N, nu, sf, Hc, G, W.rd, lane);
+            lin_condense_mfma<NT, NU, NW, false, LEAN>(W, N, nu, sf, Hc, G, W.rd, lane);
             SC_SYNC();
         }
         LP(6);
