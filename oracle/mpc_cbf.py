@@ -38,7 +38,8 @@ STATUS_INACCURATE = 2
 
 DEFAULTS = dict(N=10, dt=0.05, Q=(50.0, 50.0, 0.01, 30.0), R=(0.5, 0.5), alpha1=0.15, alpha2=0.15,
                 v_max=1.0, a_max=1.0, w_max=0.5, radius=0.25, beta=1.01,
-                tol=1e-6, acceptable_tol=1e-5, acceptable_iter=15, max_iter=100, mu_init=0.1, mu_min=1e-9)
+                tol=1e-6, acceptable_tol=1e-5, acceptable_iter=15, max_iter=100, mu_init=0.1, mu_min=1e-9,
+                resto_rho=1000.0, resto_kappa=0.1, resto_theta_tol=1e-6, resto_max=3)
 
 DUMMY_OBS = np.array([1000.0, 1000.0, 0.0, 0.0, 0.0, 0.0, 0.0])
 
@@ -268,14 +269,44 @@ def problem_functions(x0, z, u_prev, goal, obs, P, want_jac=True):
     return r["f"], r["grad"], r["W"], r["g"], r["J"], r["X"]
 
 
+def _resto_central_path(g, mu, rho):
+    """Slack of an elastic row on the central path of the restoration problem:  mu/s + mu/t = rho  with  t = s - g  > 0."""
+    return ((2.0 * mu + rho * g) + np.sqrt(rho * rho * g * g + 4.0 * mu * mu)) / (2.0 * rho)
+
+
+def violation(g, m_el):
+    """theta(z): l1 norm of the violated part of the ELASTIC rows (everything but the input box, which stays hard)."""
+    return float(np.sum(np.maximum(0.0, -g[:m_el])))
+
+
 def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=None):
     """One MPC-CBF solve.  Returns u_0 (2,), status, iterations [, info dict].
 
-    Primal-dual interior point on  min f(z) s.t. g(z) - s = 0, s >= 0  with the exact Hessian of the
+    Regular phase: primal-dual interior point on  min f(z) s.t. g(z) - s = 0, s >= 0  with the exact Hessian of the
     Lagrangian, inertia correction (W + delta I until the condensed matrix is positive definite),
     fraction-to-the-boundary 0.995, l1 merit backtracking, monotone barrier decrease
     mu <- max(mu_min, min(0.2 mu, mu^1.5)) once the barrier problem is solved to 10 mu.
     The objective is scaled by min(1, 100 / |grad f(z0)|_inf) like IPOPT's gradient-based scaling.
+
+    Feasibility restoration (Waechter & Biegler 2006, section 3.3, on the condensed problem): when the regular phase
+    cannot continue at an infeasible iterate z_R -- its line search fails after 12 halvings, or the multipliers pass
+    1e10 -- the solver switches to
+        min_z  rho_R * sum_i t_i + zeta/2 |z - z_R|^2    s.t.  g_i(z) + t_i >= 0, t_i >= 0  (elastic rows i: CBF and
+               state-bound rows),   u_lo <= z <= u_hi  (the input box stays hard),      rho_R = 1000, zeta = sqrt(mu),
+    solved by the SAME primal-dual iteration.  An elastic row  g_i + t_i - s_i = 0  keeps its slack s_i and multiplier
+    lam_i and gains ONE number, t_i; the multiplier of t_i >= 0 is rho_R - lam_i (stationarity in t_i, kept exactly by
+    a common dual step) and dt_i is eliminated from the Newton system, so the restoration differs from the regular phase
+    only per row: Sigma_i = Sigma_s Sigma_t / (Sigma_s + Sigma_t) with Sigma_t = (rho_R - lam) / t, another right-hand-
+    side entry, two more fraction-to-the-boundary ratios (t, rho_R - lam) and the merit terms rho_R t - mu log t.  It
+    starts on the central path of the elastic rows (s, t from g and mu_R = max(mu, |violation|_inf)) with the box rows
+    re-centred as at the start of the solve, and returns to the regular phase -- a fresh start at the current z with the
+    barrier parameter it left with -- as soon as the violation theta(z) = sum max(0, -g_i) has dropped to resto_kappa *
+    theta(z_R).  If instead it CONVERGES (its own KKT error <= tol, or the acceptable rule) with theta > resto_theta_tol,
+    z is a stationary point of the violation: status INFEASIBLE is that certificate and u_0 of that minimiser is what
+    is returned (what IPOPT reports as "converged to a point of local infeasibility").  At most resto_max entries.
+    Both phases raise the merit penalty when a step is not a descent direction of the merit function (the penalty was
+    below the multipliers lam + dlam of the step).
+    Every other unsuccessful exit is STATUS_INACCURATE.
     """
     P = dict(DEFAULTS)
     if params:
@@ -297,9 +328,10 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
         obs = barrier_scales(ev["pts"], obs, P)                            # steep (superellipsoid) barriers: IPOPT-style scaling
         if np.any(obs[:, 7] < 1.0):
             ev = evaluate(x0, z, u_prev, goal, obs, P, None, level=1)
-    sf = min(1.0, 100.0 / max(1e-12, float(np.max(np.abs(ev["grad"])))))   # objective scaling
+    sf0 = min(1.0, 100.0 / max(1e-12, float(np.max(np.abs(ev["grad"])))))  # objective scaling
     g = ev["g"]
     m = g.shape[0]
+    m_el = m - 2 * nz                                                       # elastic rows in the restoration; the box rows are last
     mu = P["mu_init"]
     s = np.maximum(g, 1e-2)
     lam = mu / s
@@ -309,97 +341,184 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     err = np.inf
     e_best, z_best = np.inf, z.copy()
     n_eval = 1
+    # restoration state
+    resto = False
+    rho_R, kappa_R, theta_tol = P["resto_rho"], P["resto_kappa"], P["resto_theta_tol"]
+    n_resto, it_resto, theta_R, mu_reg, z_R = 0, 0, 0.0, mu, z.copy()
+    SF_OFF = 1e-40                                                          # "no objective": evaluate() divides lam by it
+    el = np.arange(m) < m_el
+    Hq = P.get("quadratic_cost")                                            # linear models: f is exactly quadratic in z
+    t_ = np.zeros(m)                                                        # elastic variables of the restoration (0 on hard rows)
     for it in range(1, P["max_iter"] + 1):
+        sf = SF_OFF if resto else sf0
         ev = evaluate(x0, z, u_prev, goal, obs, P, lam / sf, level=2)      # multipliers of the unscaled problem
         f, grad, W, g, J = sf * ev["f"], sf * ev["grad"], sf * ev["W"], ev["g"], ev["J"]
+        if resto and violation(g, m_el) <= kappa_R * theta_R:
+            # enough of the violation is gone: back to the regular phase from here (slacks kept, multipliers on the
+            # central path of the regular barrier problem, merit penalty and best iterate reset)
+            resto, mu, sf = False, mu_reg, sf0
+            s = np.maximum(g, 1e-2)                                         # a fresh start of the regular phase at this z
+            lam = mu / s
+            nu, n_acc, e_best, z_best = 10.0, 0, np.inf, z.copy()
+            ev = evaluate(x0, z, u_prev, goal, obs, P, lam / sf, level=2)
+            f, grad, W, g, J = sf * ev["f"], sf * ev["grad"], sf * ev["W"], ev["g"], ev["J"]
+        if resto:
+            zeta = math.sqrt(mu)
+            f, grad, W = 0.5 * zeta * float((z - z_R) @ (z - z_R)), zeta * (z - z_R), W + zeta * np.eye(nz)
+            nu_t = rho_R - lam
+            r_p = g + t_ - s
+            ct, ct_mu = np.where(el, np.abs(t_ * nu_t), 0.0), np.where(el, np.abs(t_ * nu_t - mu), 0.0)
+        else:
+            r_p = g - s
+            ct, ct_mu = 0.0, 0.0
         r_d = grad - J.T @ lam
-        r_p = g - s
-        e_opt = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam)))
-        e_mu = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam - mu)))
+        e_opt = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam)), np.max(ct))
+        e_mu = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam - mu)), np.max(ct_mu))
         err = e_opt
-        if e_opt < e_best:                                                  # remember the best iterate
+        if not resto and e_opt < e_best:                                    # remember the best iterate
             e_best, z_best = e_opt, z.copy()
         if e_opt <= P["tol"]:
-            status = STATUS_OPTIMAL
+            if resto:
+                # the restoration problem is solved and the violation is still there: a stationary point of the violation
+                status = STATUS_INFEASIBLE if violation(g, m_el) > theta_tol else STATUS_INACCURATE
+            else:
+                status = STATUS_OPTIMAL
             break
         n_acc = n_acc + 1 if e_opt <= P["acceptable_tol"] else 0          # IPOPT's acceptable_iter rule
         if n_acc >= P["acceptable_iter"]:
+            if resto and violation(g, m_el) > theta_tol:
+                status = STATUS_INFEASIBLE
             break
-        if np.max(lam) > 1e10:                                              # multipliers diverge: locally infeasible
-            status = STATUS_INFEASIBLE
-            break
-        while e_mu <= 10.0 * mu and mu > P["mu_min"]:
-            mu = max(P["mu_min"], min(0.2 * mu, mu ** 1.5))
-            e_mu = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam - mu)))
-        sig = lam / s
-        Mb = W + J.T @ (sig[:, None] * J)
-        rhs = -grad - J.T @ (sig * r_p) + J.T @ (mu / s)
-        delta = 0.0
-        L = None
-        for _try in range(40):                                              # inertia correction
-            try:
-                L = np.linalg.cholesky(Mb + delta * np.eye(nz))
+        want_resto = not resto and np.max(lam) > 1e10                       # multipliers diverge: locally infeasible
+        if not want_resto:
+            while e_mu <= 10.0 * mu and mu > P["mu_min"]:
+                mu = max(P["mu_min"], min(0.2 * mu, mu ** 1.5))
+                if resto:
+                    ct_mu = np.where(el, np.abs(t_ * nu_t - mu), 0.0)
+                e_mu = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam - mu)), np.max(ct_mu))
+            # ---- row quantities: Sigma_i and the multiplier step at dz = 0 -------------------------------------------------
+            sig = lam / s
+            dl0 = -sig * r_p - lam + mu / s
+            if resto:
+                # elastic row:  g + t - s = 0 (lam),  t >= 0 (rho_R - lam);  t is eliminated from the Newton system
+                tt_ = np.where(el, t_, 1.0)
+                sg_t = nu_t / tt_
+                se = sig * sg_t / (sig + sg_t)
+                dl0 = np.where(el, -se * (r_p + mu / nu_t - t_) - (se / sig) * (lam - mu / s), dl0)
+                sig = np.where(el, se, sig)
+            Mb = W + J.T @ (sig[:, None] * J)
+            rhs = -grad + J.T @ (lam + dl0)
+            delta = 0.0
+            L = None
+            for _try in range(40):                                          # inertia correction
+                try:
+                    L = np.linalg.cholesky(Mb + delta * np.eye(nz))
+                    break
+                except np.linalg.LinAlgError:
+                    delta = max(1e-4, delta_last / 3.0) if delta == 0.0 else delta * 8.0
+            if L is None:
                 break
-            except np.linalg.LinAlgError:
-                delta = max(1e-4, delta_last / 3.0) if delta == 0.0 else delta * 8.0
-        if L is None:
-            break
-        if delta > 0:
-            delta_last = delta
-        dz = np.linalg.solve(L.T, np.linalg.solve(L, rhs))
-        ds = J @ dz + r_p
-        dlam = -sig * ds - (lam - mu / s)
-        neg = ds < 0
-        ap = min(1.0, float(np.min(-tau * s[neg] / ds[neg]))) if np.any(neg) else 1.0
-        neg = dlam < 0
-        ad = min(1.0, float(np.min(-tau * lam[neg] / dlam[neg]))) if np.any(neg) else 1.0
-        nu = max(nu, 1.1 * float(np.max(np.abs(lam))))
-        phi0 = f - mu * np.sum(np.log(s)) + nu * np.sum(np.abs(r_p))
-        dphi = grad @ dz - mu * np.sum(ds / s) - nu * np.sum(np.abs(r_p))
-        alpha, accepted = ap, False
-        Hq = P.get("quadratic_cost")                                        # linear models: f is exactly quadratic in z
-        curv = sf * float(dz @ Hq @ dz) if Hq is not None else 0.0
-        # round-off of the constraint part of the merit: a far-away dummy obstacle row has h ~ 2e6, so |g - s| carries an
-        # absolute error of ~ulp(2e6) per such row, times nu (only the linear models ask for this allowance)
-        noise_rows = P.get("row_noise", 0.0) * nu * float(np.sum(np.abs(g)))
-        for _ in range(12):                                                 # at most 12 halvings, then give up (best iterate)
-            zt, st = z + alpha * dz, s + alpha * ds
-            e0 = evaluate(x0, zt, u_prev, goal, obs, P, level=0)
-            n_eval += 1
-            if Hq is not None:
-                # f(z + a dz) - f(z) = a grad.dz + a^2/2 dz'H dz without the cancellation of two sums of size |f|
-                # (a quadrotor far from its goal has f ~ 1e3 and a decrease of 1e-9 to resolve)
-                phit = phi0 + alpha * float(grad @ dz) + 0.5 * alpha * alpha * curv \
-                    - mu * float(np.sum(np.log(st) - np.log(s))) \
-                    + nu * float(np.sum(np.abs(e0["g"] - st)) - np.sum(np.abs(r_p)))
+            if delta > 0:
+                delta_last = delta
+            dz = np.linalg.solve(L.T, np.linalg.solve(L, rhs))
+            jd = J @ dz
+            dlam = -sig * jd + dl0
+            if resto:
+                dt_ = np.where(el, (mu / nu_t - t_) + dlam / sg_t, 0.0)
+                ds = jd + dt_ + r_p
             else:
-                phit = sf * e0["f"] - mu * np.sum(np.log(st)) + nu * np.sum(np.abs(e0["g"] - st))
-            # Armijo, with an allowance for round-off in the merit function near convergence
-            # (f is a sum of a few hundred terms of size |phi|: its noise is ~1e-13 |phi|)
-            if phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * abs(phi0) + noise_rows:
-                accepted = True
+                ds = jd + r_p
+            neg = ds < 0
+            ap = min(1.0, float(np.min(-tau * s[neg] / ds[neg]))) if np.any(neg) else 1.0
+            neg = dlam < 0
+            ad = min(1.0, float(np.min(-tau * lam[neg] / dlam[neg]))) if np.any(neg) else 1.0
+            if resto:
+                neg = el & (dt_ < 0)
+                if np.any(neg):
+                    ap = min(ap, float(np.min(-tau * t_[neg] / dt_[neg])))
+                neg = el & (dlam > 0)
+                if np.any(neg):
+                    ad = min(ad, float(np.min(tau * nu_t[neg] / dlam[neg])))
+            nu = max(nu, 1.1 * float(np.max(np.abs(lam))))
+            srp = float(np.sum(np.abs(r_p)))
+            if resto:
+                bar0 = f + rho_R * float(np.sum(t_[el])) - mu * (np.sum(np.log(s)) + np.sum(np.log(t_[el])))
+                dbar = grad @ dz + rho_R * float(np.sum(dt_[el])) - mu * (np.sum(ds / s) + np.sum(dt_[el] / t_[el]))
+            else:
+                bar0 = f - mu * np.sum(np.log(s))
+                dbar = grad @ dz - mu * np.sum(ds / s)
+            if dbar - nu * srp >= 0.0 and srp > 0.0:
+                # the step is no descent direction of the merit function: the penalty is below the multipliers of the step
+                # (lam + dlam); raise it so that the directional derivative is -0.1 nu |r_p|_1  (Nocedal & Wright (18.36))
+                nu = dbar / (0.9 * srp)
+            phi0 = bar0 + nu * srp
+            dphi = dbar - nu * srp
+            alpha, accepted = ap, False
+            curv = sf * float(dz @ Hq @ dz) if Hq is not None else 0.0
+            # round-off of the constraint part of the merit: a far-away dummy obstacle row has h ~ 2e6, so |g - s| carries an
+            # absolute error of ~ulp(2e6) per such row, times nu (only the linear models ask for this allowance)
+            noise_rows = P.get("row_noise", 0.0) * nu * float(np.sum(np.abs(g)))
+            for _ in range(12):                                             # at most 12 halvings, then give up (best iterate)
+                zt, st = z + alpha * dz, s + alpha * ds
+                e0 = evaluate(x0, zt, u_prev, goal, obs, P, level=0)
+                n_eval += 1
+                if resto:
+                    tt = t_ + alpha * dt_
+                    phit = 0.5 * zeta * float((zt - z_R) @ (zt - z_R)) + rho_R * float(np.sum(tt[el])) \
+                        - mu * (np.sum(np.log(st)) + np.sum(np.log(tt[el]))) + nu * np.sum(np.abs(e0["g"] + tt - st))
+                elif Hq is not None:
+                    # f(z + a dz) - f(z) = a grad.dz + a^2/2 dz'H dz without the cancellation of two sums of size |f|
+                    # (a quadrotor far from its goal has f ~ 1e3 and a decrease of 1e-9 to resolve)
+                    phit = phi0 + alpha * float(grad @ dz) + 0.5 * alpha * alpha * curv \
+                        - mu * float(np.sum(np.log(st) - np.log(s))) \
+                        + nu * float(np.sum(np.abs(e0["g"] - st)) - np.sum(np.abs(r_p)))
+                else:
+                    phit = sf * e0["f"] - mu * np.sum(np.log(st)) + nu * np.sum(np.abs(e0["g"] - st))
+                # Armijo, with an allowance for round-off in the merit function near convergence
+                # (f is a sum of a few hundred terms of size |phi|: its noise is ~1e-13 |phi|)
+                if phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * abs(phi0) + noise_rows:
+                    accepted = True
+                    break
+                alpha *= 0.5
+            if P.get("trace") is not None:
+                P["trace"].append(dict(it=it, resto=resto, e_opt=e_opt, r_d=float(np.max(np.abs(r_d))), r_p=float(np.max(np.abs(r_p))), mu=mu,
+                                       delta=delta, alpha=alpha if accepted else 0.0, ap=ap, ad=ad, dz=float(np.max(np.abs(dz))),
+                                       theta=violation(g, m_el), z=z.copy()))
+            if not accepted:
+                if resto:
+                    break
+                want_resto = True
+        if want_resto:
+            # the regular phase cannot continue from z.  Nothing to restore at a feasible point (kinks of step(), round-off
+            # at the precision limit) or once the restoration has been entered resto_max times.
+            theta_R = violation(g, m_el)
+            if e_best <= P["acceptable_tol"] or theta_R <= theta_tol or n_resto >= P["resto_max"]:
                 break
-            alpha *= 0.5
-        if P.get("trace") is not None:
-            P["trace"].append(dict(it=it, e_opt=e_opt, r_d=float(np.max(np.abs(r_d))), r_p=float(np.max(np.abs(r_p))), mu=mu, delta=delta,
-                                   alpha=alpha if accepted else 0.0, ap=ap, ad=ad, dz=float(np.max(np.abs(dz))), z=z.copy()))
-        if not accepted:
-            break
+            resto, n_resto, it_resto = True, n_resto + 1, it
+            z_R, mu_reg = z.copy(), mu
+            mu = max(mu, float(np.max(np.maximum(0.0, -g[:m_el]))))        # IPOPT: mu_R = max(mu, |c|_inf)
+            s = np.where(el, _resto_central_path(g, mu, rho_R), np.maximum(g, 1e-2))   # elastic rows start on their central path,
+            t_ = np.where(el, s - g, 0.0)                                   # the box rows like at the start of the solve
+            lam = mu / s
+            nu, n_acc = 10.0, 0
+            continue
         z, s = z + alpha * dz, s + alpha * ds
         lam = lam + ad * dlam
         lam = np.minimum(np.maximum(lam, mu / (1e10 * s)), 1e10 * mu / s)   # IPOPT eq. (16) safeguard
-    if status != STATUS_OPTIMAL and e_best <= P["acceptable_tol"]:
+        if resto:
+            t_ = np.where(el, t_ + alpha * dt_, 0.0)
+            # the same safeguard for the multiplier rho_R - lam of t
+            tn = np.where(el, t_, 1.0)
+            lam = np.where(el, np.minimum(np.maximum(lam, rho_R - 1e10 * mu / tn), rho_R - mu / (1e10 * tn)), lam)
+            lam = np.where(el, np.minimum(np.maximum(lam, 1e-300), rho_R * (1.0 - 1e-15)), lam)
+    if status != STATUS_OPTIMAL and status != STATUS_INFEASIBLE and e_best <= P["acceptable_tol"] and not resto:
         # stalled at the precision limit (ill-conditioned condensed system at mu ~ 1e-9): the best iterate is
         # within the acceptable tolerance, like IPOPT's acceptable_tol exit
         z, status, err = z_best, STATUS_OPTIMAL, e_best
     ev = evaluate(x0, z, u_prev, goal, obs, P, level=0)
-    if status != STATUS_OPTIMAL:
-        if np.min(ev["g"]) < -1e-6:
-            status = STATUS_INFEASIBLE
-        elif status != STATUS_INFEASIBLE:
-            status = STATUS_INACCURATE
     u0 = z[0:P.get("nu", 2)].copy()
     if return_info:
-        return u0, status, it, dict(z=z, X=ev["X"], f=ev["f"], g=ev["g"], lam=lam / sf, s=s, err=err, mu=mu,
-                                    n_eval=n_eval, scale=sf, obs=obs)
+        return u0, status, it, dict(z=z, X=ev["X"], f=ev["f"], g=ev["g"], lam=lam / sf0, s=s, err=err, mu=mu,
+                                    n_eval=n_eval, scale=sf0, obs=obs, n_resto=n_resto, it_resto=it_resto, in_resto=resto,
+                                    theta=violation(ev["g"], m_el))
     return u0, status, it
