@@ -383,18 +383,8 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
     import safe_control_amd as sca
     from safe_control_amd import workloads as W
     ctl = sca.BatchedGnMPCCBF({"model": model}, io_dtype="f32", horizon=N)
-    Xd, gn, _, on = W.du_cbfqp_batch(B, K, seed=seed)
-    rng = np.random.default_rng(seed + 1)
-    if model == "Quad2D":
-        Xn = np.zeros((B, 6)); Xn[:, 0:2] = Xd[:, 0:2]; Xn[:, 2] = rng.uniform(-0.2, 0.2, B); Xn[:, 3:5] = rng.uniform(-0.5, 0.5, (B, 2))
-        up0 = np.full((B, 2), 0.5 * (ctl.robot_spec["f_min"] + ctl.robot_spec["f_max"]))
-    elif model.startswith("KinematicBicycle2D"):       # driving roughly towards the goal at 0.5 .. 3 m/s
-        Xn = np.zeros((B, 4)); Xn[:, 0:2] = Xd[:, 0:2]
-        Xn[:, 2] = np.arctan2(gn[:, 1] - Xd[:, 1], gn[:, 0] - Xd[:, 0]) + rng.uniform(-0.6, 0.6, B); Xn[:, 3] = rng.uniform(0.5, 3.0, B)
-        up0 = np.zeros((B, 2))
-    else:
-        Xn = np.zeros((B, 4)); Xn[:, 0:2] = Xd[:, 0:2]; Xn[:, 2:4] = rng.uniform(-0.7, 0.7, (B, 2))
-        up0 = np.zeros((B, 2))
+    fam = {v: k for k, v in W.MPC_FAMILIES.items()}[model]
+    Xn, up0, gn, on = W.mpc_family_batch(fam, B, K, seed=seed)
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
     X, g, ob, up = t(Xn), t(gn), t(on), t(up0)
     u, st, it = ctl.solve(X, up, g, ob)

@@ -53,8 +53,8 @@ typedef enum sc_error {
  * Mapped by the Python shim to the strings tracking.py:628 compares with
  * 'optimal' ('optimal' / 'infeasible' / 'optimal_inaccurate').             */
 #define SC_STATUS_OPTIMAL      0
-#define SC_STATUS_INFEASIBLE   1
-#define SC_STATUS_INACCURATE   2   /* MPC-CBF only: iteration limit reached            */
+#define SC_STATUS_INFEASIBLE   1   /* MPC-CBF: certified by a converged feasibility restoration (sc_resto_params) */
+#define SC_STATUS_INACCURATE   2   /* MPC-CBF only: stopped without convergence (iteration limit, line search)    */
 #define SC_STATUS_BAD_OBSTACLE 3   /* obstacle flag not 0/1 for a model that needs it
                                       (the reference raises inside agent_barrier,
                                       robots/dynamic_unicycle2D.py:133-136)            */
@@ -133,6 +133,24 @@ int sc_cbfqp_solve_batch_host(const sc_cbfqp_params* params, int64_t B, int32_t 
  * from robot_spec (position_control/mpc_cbf.py:7-100).                     */
 #define SC_MPCCBF_MAX_HORIZON 32
 
+/* Feasibility restoration of the interior point behind every sc_mpc*_solve_batch (Waechter & Biegler 2006, section 3.3, on
+ * the condensed problem; the reference's solver is IPOPT via do-mpc, position_control/mpc_cbf.py:163,384, whose restoration
+ * phase this stands in for).  When the regular iteration cannot continue at an infeasible iterate z_R (line search failed,
+ * multipliers above 1e10) the kernels minimise  rho * sum_i t_i + sqrt(mu)/2 |z - z_R|^2  s.t.  g_i(z) + t_i >= 0, t_i >= 0
+ * over the CBF rows i (state bounds and the input box stay hard) with the same primal-dual iteration, return to the regular
+ * phase once the l1 violation has dropped to kappa * violation(z_R), and report SC_STATUS_INFEASIBLE only when the restoration
+ * CONVERGES with a violation above theta_tol: the returned input is then that minimiser of the violation.  Any other
+ * unsuccessful exit is SC_STATUS_INACCURATE.  oracle/mpc_cbf.py: solve is the float64 statement of the same steps.       */
+typedef struct sc_resto_params {
+    double  rho;             /* l1 penalty of the elastic variables (IPOPT: 1000)                                    */
+    double  kappa;           /* return to the regular phase at violation <= kappa * violation(z_R) (0.1)           */
+    double  theta_tol;       /* a converged restoration with l1 violation above this is SC_STATUS_INFEASIBLE (1e-6) */
+    double  tol;             /* KKT tolerance of the restoration problem itself (1e-4): theta has long settled by then */
+    double  small_alpha;     /* the regular phase also hands over after small_iter consecutive accepted steps shorter  */
+    int32_t small_iter;      /*   than small_alpha at an infeasible iterate (0.02, 4): IPOPT's alpha_min rule          */
+    int32_t max_entries;     /* restoration may be entered this many times per solve (3); 0 disables it             */
+} sc_resto_params;
+
 typedef struct sc_mpccbf_params {
     int32_t model_id;        /* SC_MODEL_DYNAMIC_UNICYCLE2D or SC_MODEL_UNICYCLE2D (others: SC_ERR_UNSUPPORTED).
                               * Unicycle2D (robots/unicycle2D.py): inputs [v, omega], u_max = (v_max, w_max),
@@ -156,6 +174,7 @@ typedef struct sc_mpccbf_params {
     double  acceptable_tol;  /* accepted when the iteration stalls at the precision limit (1e-5)   */
     double  mu_init;         /* initial barrier parameter (0.1, IPOPT's default)                   */
     double  mu_min;          /* smallest barrier parameter (1e-9)                                  */
+    sc_resto_params resto;   /* feasibility restoration (not used by the optimal-decay entry points) */
 } sc_mpccbf_params;
 
 /* Replaces, for a whole batch of agents in one launch:
@@ -210,6 +229,7 @@ typedef struct sc_mpclin_params {
     double  R[4];            /* input-rate weights (mpc_cbf.py:21, :39)                                    */
     double  u_lo[4], u_hi[4];
     double  od_omega_ref, od_p_sb;   /* optimal_decay = 1: reference 1.0 and penalty 10.0 (optimal_decay_mpc_cbf.py:88-89) */
+    sc_resto_params resto;   /* feasibility restoration (optimal_decay = 0 only)                           */
 } sc_mpclin_params;
 
 size_t sc_mpclin_model_doubles(int32_t nx, int32_t nu, int32_t horizon);
@@ -257,6 +277,7 @@ typedef struct sc_mpcgn_params {
     double  robot_radius;    /* barrier radius (and the rotor arm of Quad2D, quad2D.py:72)                         */
     double  beta;            /* barrier inflation: 1.01                                                            */
     double  tol, acceptable_tol, mu_init, mu_min;
+    sc_resto_params resto;   /* feasibility restoration, as sc_mpccbf_params                                       */
 } sc_mpcgn_params;
 
 int sc_mpcgn_solve_batch(const sc_mpcgn_params* params, int64_t B, int32_t K,

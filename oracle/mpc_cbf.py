@@ -39,7 +39,8 @@ STATUS_INACCURATE = 2
 DEFAULTS = dict(N=10, dt=0.05, Q=(50.0, 50.0, 0.01, 30.0), R=(0.5, 0.5), alpha1=0.15, alpha2=0.15,
                 v_max=1.0, a_max=1.0, w_max=0.5, radius=0.25, beta=1.01,
                 tol=1e-6, acceptable_tol=1e-5, acceptable_iter=15, max_iter=100, mu_init=0.1, mu_min=1e-9,
-                resto_rho=1000.0, resto_kappa=0.1, resto_theta_tol=1e-6, resto_max=3)
+                resto_rho=1000.0, resto_kappa=0.1, resto_theta_tol=1e-6, resto_max=3, resto_tol=1e-4,
+                resto_small_alpha=0.02, resto_small_iter=4)
 
 DUMMY_OBS = np.array([1000.0, 1000.0, 0.0, 0.0, 0.0, 0.0, 0.0])
 
@@ -291,8 +292,8 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     Feasibility restoration (Waechter & Biegler 2006, section 3.3, on the condensed problem): when the regular phase
     cannot continue at an infeasible iterate z_R -- its line search fails after 12 halvings, or the multipliers pass
     1e10 -- the solver switches to
-        min_z  rho_R * sum_i t_i + zeta/2 |z - z_R|^2    s.t.  g_i(z) + t_i >= 0, t_i >= 0  (elastic rows i: CBF and
-               state-bound rows),   u_lo <= z <= u_hi  (the input box stays hard),      rho_R = 1000, zeta = sqrt(mu),
+        min_z  rho_R * sum_i t_i + zeta/2 |z - z_R|^2    s.t.  g_i(z) + t_i >= 0, t_i >= 0  (elastic rows i: the N K
+               CBF rows),   state bounds and the input box stay hard (both linear in z),   rho_R = 1000, zeta = sqrt(mu),
     solved by the SAME primal-dual iteration.  An elastic row  g_i + t_i - s_i = 0  keeps its slack s_i and multiplier
     lam_i and gains ONE number, t_i; the multiplier of t_i >= 0 is rho_R - lam_i (stationarity in t_i, kept exactly by
     a common dual step) and dt_i is eliminated from the Newton system, so the restoration differs from the regular phase
@@ -331,7 +332,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     sf0 = min(1.0, 100.0 / max(1e-12, float(np.max(np.abs(ev["grad"])))))  # objective scaling
     g = ev["g"]
     m = g.shape[0]
-    m_el = m - 2 * nz                                                       # elastic rows in the restoration; the box rows are last
+    m_el = N * obs.shape[0]                                                 # elastic rows in the restoration: the CBF rows come first
     mu = P["mu_init"]
     s = np.maximum(g, 1e-2)
     lam = mu / s
@@ -345,6 +346,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     resto = False
     rho_R, kappa_R, theta_tol = P["resto_rho"], P["resto_kappa"], P["resto_theta_tol"]
     n_resto, it_resto, theta_R, mu_reg, z_R = 0, 0, 0.0, mu, z.copy()
+    n_small = 0                                                             # consecutive regular iterations with a tiny step at an infeasible z
     SF_OFF = 1e-40                                                          # "no objective": evaluate() divides lam by it
     el = np.arange(m) < m_el
     Hq = P.get("quadratic_cost")                                            # linear models: f is exactly quadratic in z
@@ -362,9 +364,10 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
             nu, n_acc, e_best, z_best = 10.0, 0, np.inf, z.copy()
             ev = evaluate(x0, z, u_prev, goal, obs, P, lam / sf, level=2)
             f, grad, W, g, J = sf * ev["f"], sf * ev["grad"], sf * ev["W"], ev["g"], ev["J"]
+        Wc = W
         if resto:
             zeta = math.sqrt(mu)
-            f, grad, W = 0.5 * zeta * float((z - z_R) @ (z - z_R)), zeta * (z - z_R), W + zeta * np.eye(nz)
+            f, grad, W = 0.5 * zeta * float((z - z_R) @ (z - z_R)), zeta * (z - z_R), Wc + zeta * np.eye(nz)
             nu_t = rho_R - lam
             r_p = g + t_ - s
             ct, ct_mu = np.where(el, np.abs(t_ * nu_t), 0.0), np.where(el, np.abs(t_ * nu_t - mu), 0.0)
@@ -377,7 +380,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
         err = e_opt
         if not resto and e_opt < e_best:                                    # remember the best iterate
             e_best, z_best = e_opt, z.copy()
-        if e_opt <= P["tol"]:
+        if e_opt <= (P["resto_tol"] if resto else P["tol"]):
             if resto:
                 # the restoration problem is solved and the violation is still there: a stationary point of the violation
                 status = STATUS_INFEASIBLE if violation(g, m_el) > theta_tol else STATUS_INACCURATE
@@ -391,11 +394,15 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
             break
         want_resto = not resto and np.max(lam) > 1e10                       # multipliers diverge: locally infeasible
         if not want_resto:
+            mu_old = mu
             while e_mu <= 10.0 * mu and mu > P["mu_min"]:
                 mu = max(P["mu_min"], min(0.2 * mu, mu ** 1.5))
                 if resto:
                     ct_mu = np.where(el, np.abs(t_ * nu_t - mu), 0.0)
                 e_mu = max(np.max(np.abs(r_d)), np.max(np.abs(r_p)), np.max(np.abs(s * lam - mu)), np.max(ct_mu))
+            if resto and mu != mu_old:                                      # zeta = sqrt(mu): the proximity term follows the new mu
+                zeta = math.sqrt(mu)
+                f, grad, W = 0.5 * zeta * float((z - z_R) @ (z - z_R)), zeta * (z - z_R), Wc + zeta * np.eye(nz)
             # ---- row quantities: Sigma_i and the multiplier step at dz = 0 -------------------------------------------------
             sig = lam / s
             dl0 = -sig * r_p - lam + mu / s
@@ -488,13 +495,19 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
                 if resto:
                     break
                 want_resto = True
+            elif not resto:
+                # IPOPT enters the restoration when the step length falls below its alpha_min; here: resto_small_iter consecutive
+                # accepted steps shorter than resto_small_alpha at an infeasible iterate
+                n_small = n_small + 1 if (alpha < P["resto_small_alpha"] and violation(g, m_el) > theta_tol) else 0
+                if n_small >= P["resto_small_iter"] and n_resto < P["resto_max"] and e_best > P["acceptable_tol"]:
+                    want_resto = True                                       # (the accepted step is not taken)
         if want_resto:
             # the regular phase cannot continue from z.  Nothing to restore at a feasible point (kinks of step(), round-off
             # at the precision limit) or once the restoration has been entered resto_max times.
             theta_R = violation(g, m_el)
             if e_best <= P["acceptable_tol"] or theta_R <= theta_tol or n_resto >= P["resto_max"]:
                 break
-            resto, n_resto, it_resto = True, n_resto + 1, it
+            resto, n_resto, it_resto, n_small = True, n_resto + 1, it, 0
             z_R, mu_reg = z.copy(), mu
             mu = max(mu, float(np.max(np.maximum(0.0, -g[:m_el]))))        # IPOPT: mu_R = max(mu, |c|_inf)
             s = np.where(el, _resto_central_path(g, mu, rho_R), np.maximum(g, 1e-2))   # elastic rows start on their central path,

@@ -139,6 +139,105 @@ def h_dpcbf(x, obs, radius, s=1.05):
     return vn0 + (kl * rd / vm) * vn1 * vn1 + km * rd
 
 
+class HDV:
+    """HD over a batch: value (P,), gradient (P, 4), Hessian (P, 4, 4).  Same arithmetic, operation for operation, as HD (held to it
+    in tests/test_oracle_mpc_kb.py); it exists because evaluate() needs the barrier at 2 N K (point, obstacle) pairs per call and
+    the scalar class costs a Python object per operation."""
+    __slots__ = ("v", "g", "H")
+    __array_ufunc__ = None
+
+    def __init__(self, v, g=None, H=None):
+        self.v = np.asarray(v, dtype=np.float64)
+        n = self.v.shape[0]
+        self.g = np.zeros((n, NS)) if g is None else g
+        self.H = np.zeros((n, NS, NS)) if H is None else H
+
+    @staticmethod
+    def var(v, i):
+        v = np.asarray(v, dtype=np.float64)
+        g = np.zeros((v.shape[0], NS)); g[:, i] = 1.0
+        return HDV(v, g)
+
+    def lift(self, a):
+        return a if isinstance(a, HDV) else HDV(np.full(self.v.shape, float(a)) if np.ndim(a) == 0 else a)
+
+    def chain(self, f, f1, f2):
+        return HDV(f, f1[:, None] * self.g, f1[:, None, None] * self.H + f2[:, None, None] * (self.g[:, :, None] * self.g[:, None, :]))
+
+    def __add__(self, o):
+        o = self.lift(o)
+        return HDV(self.v + o.v, self.g + o.g, self.H + o.H)
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        o = self.lift(o)
+        return HDV(self.v - o.v, self.g - o.g, self.H - o.H)
+
+    def __rsub__(self, o):
+        return self.lift(o) - self
+
+    def __neg__(self):
+        return HDV(-self.v, -self.g, -self.H)
+
+    def __mul__(self, o):
+        o = self.lift(o)
+        return HDV(self.v * o.v, self.v[:, None] * o.g + o.v[:, None] * self.g,
+                   self.v[:, None, None] * o.H + o.v[:, None, None] * self.H + self.g[:, :, None] * o.g[:, None, :]
+                   + o.g[:, :, None] * self.g[:, None, :])
+    __rmul__ = __mul__
+
+    def recip(self):
+        r = 1.0 / self.v
+        return self.chain(r, -r * r, 2.0 * r * r * r)
+
+    def __truediv__(self, o):
+        return self * self.lift(o).recip()
+
+    def __rtruediv__(self, o):
+        return self.lift(o) * self.recip()
+
+    def where(self, mask, other):
+        """self where mask, else the constant `other` (zero derivatives)."""
+        return HDV(np.where(mask, self.v, other), np.where(mask[:, None], self.g, 0.0), np.where(mask[:, None, None], self.H, 0.0))
+
+
+def _v_sqrt(a):
+    r = np.sqrt(a.v)
+    return a.chain(r, 0.5 / r, -0.25 / (r * a.v))
+
+
+def barrier_batch(pts, obs, P, derivs=True):
+    """barrier() at the rows of pts (P, 4) against the rows of obs (P, 7): h (P,), grad (P, 4), Hessian (P, 4, 4)."""
+    pts = np.asarray(pts, dtype=np.float64); obs = np.asarray(obs, dtype=np.float64)
+    n = pts.shape[0]
+    x = [HDV.var(pts[:, i], i) if derivs else HDV(pts[:, i]) for i in range(NS)]
+    px, py = obs[:, 0] - x[0], obs[:, 1] - x[1]
+    sn, cs = np.sin(x[2].v), np.cos(x[2].v)
+    c, s = x[2].chain(cs, -sn, -cs), x[2].chain(sn, cs, -sn)
+    vx, vy = 0.0 - x[3] * c, 0.0 - x[3] * s
+    pm2 = px * px + py * py
+    vm = _v_sqrt(vx * vx + vy * vy)
+    pm = _v_sqrt(pm2)
+    if P["model"]["kind"] == "c3bf":
+        ego = (obs[:, 2] + P["radius"]) * 1.01
+        a = pm2 - ego * ego
+        pos = a.v > 0.0
+        root = _v_sqrt(HDV(np.where(pos, a.v, 1.0), a.g, a.H)).where(pos, 0.0)
+        r = px * vx + py * vy + pm * vm * root / pm
+    else:
+        sc = 1.05
+        ego = (obs[:, 2] + P["radius"]) * sc
+        cr, sr = px / pm, py / pm
+        vn0, vn1 = cr * vx + sr * vy, cr * vy - sr * vx
+        a = pm2 - ego * ego
+        big = a.v > 1e-6
+        d = a.where(big, 1e-6)
+        kl, km = 0.1 * math.sqrt(sc * sc - 1.0) / ego, 0.5 * math.sqrt(sc * sc - 1.0) / ego
+        rd = _v_sqrt(d)
+        r = vn0 + (kl * rd / vm) * vn1 * vn1 + km * rd
+    return r.v, (r.g if derivs else None), (r.H if derivs else None)
+
+
 def barrier(xv, obs, P, derivs=True):
     """h, grad (4), Hessian (4 x 4) of the model's barrier at the state xv."""
     fn = h_c3bf if P["model"]["kind"] == "c3bf" else h_dpcbf
@@ -208,14 +307,11 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     du = up[nu:] - up[:-nu]
     Rd = np.tile(Rw, N)
     f += float(np.sum(Rd * du * du))
-    hv = np.zeros((N, 2, K)); dh = np.zeros((N, 2, K, nx)); Hh = np.zeros((N, 2, K, nx, nx))
-    for k in range(N):
-        for p in range(2):
-            for j in range(K):
-                h, g_, H_ = barrier(pts[k, p], obs[j], P, der)
-                hv[k, p, j] = h
-                if der:
-                    dh[k, p, j], Hh[k, p, j] = g_, H_
+    # the barrier at every (stage, point, obstacle) at once (barrier_batch: the scalar barrier(), vectorised)
+    hb, gb, Hb = barrier_batch(np.repeat(pts.reshape(N * 2, nx), K, axis=0), np.tile(obs[:, :7], (N * 2, 1)), P, der)
+    hv = hb.reshape(N, 2, K)
+    dh = gb.reshape(N, 2, K, nx) if der else np.zeros((N, 2, K, nx))
+    Hh = Hb.reshape(N, 2, K, nx, nx) if der else np.zeros((N, 2, K, nx, nx))
     m = N * K + 2 * N + 2 * n
     g = np.zeros(m)
     g[: N * K] = (wp[0] * hv[:, 0] + wp[1] * hv[:, 1]).reshape(-1)

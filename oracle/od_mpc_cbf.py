@@ -278,8 +278,11 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
         neg = dlam < 0
         ad = min(1.0, float(np.min(-tau * lam[neg] / dlam[neg]))) if np.any(neg) else 1.0
         nu = max(nu, 1.1 * float(np.max(np.abs(lam))))
-        phi0 = f - mu * np.sum(np.log(s)) + nu * np.sum(np.abs(r_p))
-        dphi = grad @ dzz - mu * np.sum(ds / s) - nu * np.sum(np.abs(r_p))
+        srp, dbar = float(np.sum(np.abs(r_p))), float(grad @ dzz - mu * np.sum(ds / s))
+        if dbar - nu * srp >= 0.0 and srp > 0.0:
+            nu = dbar / (0.9 * srp)                       # no descent direction of the merit: raise the penalty (oracle/mpc_cbf.py: solve)
+        phi0 = f - mu * np.sum(np.log(s)) + nu * srp
+        dphi = dbar - nu * srp
         alpha, accepted = ap, False
         for _ in range(12):
             zt, st = zz + alpha * dzz, s + alpha * ds

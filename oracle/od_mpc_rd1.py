@@ -172,8 +172,11 @@ def solve(x0, u_prev, goal, obs, P, return_info=False, linear_algebra="schur"):
         neg = dlam < 0
         ad = min(1.0, float(np.min(-tau * lam[neg] / dlam[neg]))) if np.any(neg) else 1.0
         nu_m = max(nu_m, 1.1 * float(np.max(np.abs(lam))))
-        phi0 = f - mu * np.sum(np.log(s)) + nu_m * np.sum(np.abs(r_p))
-        dphi = grad @ dzz - mu * np.sum(ds / s) - nu_m * np.sum(np.abs(r_p))
+        srp, dbar = float(np.sum(np.abs(r_p))), float(grad @ dzz - mu * np.sum(ds / s))
+        if dbar - nu_m * srp >= 0.0 and srp > 0.0:
+            nu_m = dbar / (0.9 * srp)                     # no descent direction of the merit: raise the penalty (oracle/mpc_cbf.py: solve)
+        phi0 = f - mu * np.sum(np.log(s)) + nu_m * srp
+        dphi = dbar - nu_m * srp
         # linear models: the cost is exactly quadratic in (z, rho) -- merit differences without cancellation (oracle/mpc_cbf.py: solve)
         curv = sf * (float(dzz[:n] @ Hq @ dzz[:n]) + 2.0 * P["p_sb1"] * float(dzz[n:] @ dzz[n:])) if Hq is not None else 0.0
         noise_rows = P.get("row_noise", 0.0) * nu_m * float(np.sum(np.abs(g)))

@@ -73,6 +73,21 @@ class BackupCbfParams(C.Structure):
 MPCCBF_MAX_HORIZON = 32
 
 
+class RestoParams(C.Structure):
+    """Mirror of ``sc_resto_params``: the feasibility-restoration phase of the MPC interior point."""
+    _fields_ = [("rho", C.c_double), ("kappa", C.c_double), ("theta_tol", C.c_double), ("tol", C.c_double),
+                ("small_alpha", C.c_double), ("small_iter", C.c_int32), ("max_entries", C.c_int32)]
+
+
+def default_resto(**over):
+    """IPOPT's penalty (1000), return at a tenth of the violation, certificate threshold 1e-6, restoration tolerance 1e-4,
+    hand-over after 4 steps shorter than 0.02, at most three entries (oracle/mpc_cbf.py: DEFAULTS)."""
+    r = RestoParams(rho=1000.0, kappa=0.1, theta_tol=1e-6, tol=1e-4, small_alpha=0.02, small_iter=4, max_entries=3)
+    for k, v in over.items():
+        setattr(r, k, v)
+    return r
+
+
 class MpcCbfParams(C.Structure):
     """Mirror of ``sc_mpccbf_params``."""
     _fields_ = [
@@ -81,7 +96,7 @@ class MpcCbfParams(C.Structure):
         ("dt", C.c_double), ("Q", C.c_double * 4), ("R", C.c_double * 2),
         ("alpha1", C.c_double), ("alpha2", C.c_double), ("v_max", C.c_double), ("u_max", C.c_double * 2),
         ("robot_radius", C.c_double), ("beta", C.c_double), ("tol", C.c_double), ("acceptable_tol", C.c_double),
-        ("mu_init", C.c_double), ("mu_min", C.c_double),
+        ("mu_init", C.c_double), ("mu_min", C.c_double), ("resto", RestoParams),
     ]
 
 
@@ -104,7 +119,7 @@ class MpcLinParams(C.Structure):
         ("alpha", C.c_double), ("robot_radius", C.c_double), ("beta", C.c_double), ("tol", C.c_double),
         ("acceptable_tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double),
         ("Q", C.c_double * 12), ("R", C.c_double * 4), ("u_lo", C.c_double * 4), ("u_hi", C.c_double * 4),
-        ("od_omega_ref", C.c_double), ("od_p_sb", C.c_double),
+        ("od_omega_ref", C.c_double), ("od_p_sb", C.c_double), ("resto", RestoParams),
     ]
 
 
@@ -117,6 +132,7 @@ class MpcGnParams(C.Structure):
         ("u_lo", C.c_double * 2), ("u_hi", C.c_double * 2), ("v_min", C.c_double), ("v_max", C.c_double),
         ("rear_ax_dist", C.c_double), ("mass", C.c_double), ("inertia", C.c_double), ("robot_radius", C.c_double),
         ("beta", C.c_double), ("tol", C.c_double), ("acceptable_tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double),
+        ("resto", RestoParams),
     ]
 
 

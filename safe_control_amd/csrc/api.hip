@@ -15,7 +15,7 @@ hipError_t cbfqp_launch(const sc_cbfqp_params& p, long long B, int K, const void
 hipError_t mpccbf_launch(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                          hipStream_t stream);
-size_t mpccbf_lds_bytes(int N, int K);
+size_t mpccbf_lds_bytes(int N, int K, bool uni);
 size_t odmpccbf_lds_bytes(int N, int K);
 hipError_t odmpccbf_launch(const sc_odmpccbf_params& q, long long B, int K, const void* X, const void* u_prev,
                            const void* goal, const void* obs, void* u_out, void* rho_out, int* status, int* iters,
@@ -147,7 +147,7 @@ static int check_mpccbf(const sc_mpccbf_params* p, int64_t B, int32_t K, const v
         return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
     if (p->horizon < 1 || p->horizon > SC_MPCCBF_MAX_HORIZON)
         return fail(SC_ERR_UNSUPPORTED, "horizon outside [1, SC_MPCCBF_MAX_HORIZON]");
-    if (mpccbf_lds_bytes(p->horizon, K) > 160 * 1024)
+    if (mpccbf_lds_bytes(p->horizon, K, p->model_id == SC_MODEL_UNICYCLE2D) > 160 * 1024)
         return fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
     if (!(p->dt > 0) || !(p->tol > 0) || !(p->acceptable_tol >= p->tol) || p->max_iter < 1 || !(p->mu_init > 0) || !(p->mu_min > 0))
         return fail(SC_ERR_INVALID_ARGUMENT, "dt, tol, mu_init, mu_min must be > 0 and max_iter >= 1");

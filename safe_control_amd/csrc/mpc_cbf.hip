@@ -127,6 +127,7 @@ struct MpcMem {                 // LDS carve-up (doubles); NP = N + 2 predicted 
     double *obs;                                  // K*7
     double *dh;                                   // NP*K*2
     double *g, *sl, *lam;                         // m
+    double *tel;                                  // N K elastic variables of the feasibility restoration (see carve)
     double *ds, *dlam;                            // m   (aliases: is = ds, vb = dlam, dead before ds / dlam are written)
     double *dP;                                   // 2 NP * n : G = d p / d z
     // region A, max(n n, NP (26 + K)):  [Phi 2 NP * 10 | Y 3 * 2 NP | hk NP K]  then  M n*n
@@ -148,16 +149,22 @@ __host__ __device__ inline size_t mpc_region_b(int N, bool od) {
     const size_t n = 2 * (size_t)N, NP = (size_t)N + 2;
     return (od && 39 * (size_t)N > 2 * NP * n) ? 39 * (size_t)N : 2 * NP * n;
 }
-__host__ __device__ inline size_t mpc_lds_doubles(int N, int K, bool od = false) {
+// The restoration's elastic variables t (one per CBF row, mpc_ipm_common.hpp).  Rows 0..3 of G = d p / d z belong to p_0 and p_1,
+// which do not depend on z: 4 n = 8 N doubles that no product reads (every loop over the rows of G starts at row 4) -- for
+// K <= 8 the N K elastic variables live there, and the compile-time kernel of BASELINE config 3 keeps its 20 KiB (eight
+// problems per CU).  Unicycle2D (first live row 2) and larger K get their own N K doubles; optimal decay has no restoration.
+__host__ __device__ inline bool mpc_tel_in_g(int K, bool od, bool uni) { return !od && !uni && K <= 8; }
+__host__ __device__ inline size_t mpc_lds_doubles(int N, int K, bool od = false, bool uni = false) {
     const size_t n = 2 * (size_t)N, NP = (size_t)N + 2, m = (size_t)N * K + 2 * N + 2 * n;   // (rows: sized for the larger, DU, layout)
     const size_t regA = n * n > NP * (26 + K) ? n * n : NP * (26 + K);
     const size_t cvt = 2 * n > 3 * (size_t)N + 5 ? 2 * n : 3 * (size_t)N + 5;
-    const size_t odx = od ? 4 * n + 2 * (size_t)N + 2 * (size_t)N * K + 22 * (size_t)N : 0;
+    const size_t odx = (od ? 4 * n + 2 * (size_t)N + 2 * (size_t)N * K + 22 * (size_t)N : 0) +
+                       ((od || mpc_tel_in_g(K, od, uni)) ? 0 : (size_t)N * K);
     return 4 * n + n + cvt + 4 * (N + 1) + 2 * NP + 3 * NP + (size_t)K * 7 + NP * K * 2 + 5 * m + 2 * NP * n + regA +
            mpc_region_b(N, od) + odx;
 }
 
-__device__ inline MpcMem carve(double* b, int N, int K, bool od = false) {
+__device__ inline MpcMem carve(double* b, int N, int K, bool od = false, bool uni = false) {
     const int n = 2 * N, NP = N + 2, m = N * K + 2 * N + 2 * n;
     MpcMem M;
     auto take = [&](size_t c) { double* r = b; b += c; return r; };
@@ -177,6 +184,7 @@ __device__ inline MpcMem carve(double* b, int N, int K, bool od = false) {
     M.T = take(mpc_region_b(N, od)); M.L = M.T; M.PC = M.T; M.PD = M.T + 2 * NP; M.XS = M.T;
     M.rhs = M.dz; M.is = M.ds;
     M.rho = M.rhot = M.drho = M.rhob = M.w0s = M.w1s = M.A1 = M.A2 = M.ods = nullptr;
+    M.tel = od ? nullptr : (mpc_tel_in_g(K, od, uni) ? M.dP : take((size_t)N * K));
     if (od) {
         M.rho = take(n); M.rhot = take(n); M.drho = take(n); M.rhob = take(n);
         M.w0s = take(N); M.w1s = take(N);
@@ -404,15 +412,26 @@ __device__ inline double eval_values(const double* z, const double* rho, const M
 // which replaces the N K x 2 N Jacobian build and every loop over its rows by work on 2 NP = 24 position rows.
 
 // rows: sigma = lam / s, 1/s, sigma r_p + lam; returns the lane-partial residual norms
-__device__ __forceinline__ void row_pass(const MpcMem& W, const MpcConst& c, int lane, double& e_p, double& e_c0, double& lmax) {
+// resto: the CBF rows (i < mc) are the elastic rows of the feasibility restoration (ipm::resto_row)
+__device__ __forceinline__ void row_pass(const MpcMem& W, const MpcConst& c, int lane, double& e_p, double& e_c0, double& lmax,
+                                         bool resto = false, double mu = 0.0, double rho = 0.0) {
     lane = opaque(lane);
     double* is = W.is;
     double* vb = W.dlam;
     e_p = 0.0; e_c0 = 0.0; lmax = 0.0;
     for (int i = lane; i < c.m; i += 64) {
-        const double s = W.sl[i], l = W.lam[i], rp = W.g[i] - s;
-        const double inv = rcp_(s), sig = l * inv;
-        is[i] = inv; vb[i] = sig * rp + l;
+        const double s = W.sl[i], l = W.lam[i];
+        double rp, inv, vbi;
+        if (resto && i < c.mc) {
+            const double t = W.tel[i];
+            ipm::resto_row(W.g[i], s, l, t, mu, rho, rp, inv, vbi);
+            e_c0 = fmax(e_c0, fabs(t * (rho - l)));
+        } else {
+            rp = W.g[i] - s;
+            inv = rcp_(s);
+            vbi = (l * inv) * rp + l;
+        }
+        is[i] = inv; vb[i] = vbi;
         e_p = fmax(e_p, fabs(rp));
         e_c0 = fmax(e_c0, fabs(s * l));
         lmax = fmax(lmax, l);
@@ -635,7 +654,8 @@ __device__ __forceinline__ double stage_pass(const MpcMem& W, const MpcConst& c,
 // Every inner loop has a trip count that does not depend on the lane (structural zeros of G, masks on the stage
 // sums), so with compile-time N the loads of a lane are issued back to back instead of one round trip per term.
 template <bool OD, bool UNI = false>
-__device__ __forceinline__ double col_pass(const MpcMem& W, const MpcConst& c, int lane, double sf) {
+// zeta > 0 (restoration): the objective is zeta/2 |z - z_R|^2 with z_R kept in W.zb (sf = 0 switches the cost off)
+__device__ __forceinline__ double col_pass(const MpcMem& W, const MpcConst& c, int lane, double sf, double zeta = 0.0) {
     lane = opaque(lane);
     const int N = c.N, n = c.n, NP = N + 2;
     double e_d = 0.0;
@@ -664,6 +684,7 @@ __device__ __forceinline__ double col_pass(const MpcMem& W, const MpcConst& c, i
             double gr = 2.0 * Qs * c.dt * sx + 2.0 * Rc * (OD ? W.z[col] : W.z[col] - prev);
             if (!OD && col + 2 < n) gr -= 2.0 * Rc * (W.z[col + 2] - W.z[col]);
             acc += sf * gr - sb;
+            if (zeta != 0.0) acc += zeta * (W.z[col] - W.zb[col]);
             e_d = fmax(e_d, fabs(acc));
         } else {
             acc += sb;
@@ -853,7 +874,7 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     c.gx = ld(goal, prob * 2 + 0); c.gy = ld(goal, prob * 2 + 1);
     c.al1 = p.alpha1; c.al2 = p.alpha2; c.ps1 = od.p_sb[0]; c.ps2 = od.p_sb[1]; c.rf1 = od.omega_ref[0]; c.rf2 = od.omega_ref[1];
     const int N = c.N, n = c.n, m = c.m;
-    const MpcMem W = carve(sm, N, K, OD);
+    const MpcMem W = carve(sm, N, K, OD, UNI);
     constexpr bool ROW16 = NT > 0 && NT + 2 <= 16;
     constexpr int MS = NT > 0 ? (2 * NT + 3) / 4 : 4;                  // MFMA k-steps batched per LDS round trip
     for (int e = lane; e < 2 * (N + 2) * n; e += 64) W.dP[e] = 0.0;      // structural zeros of G stay
@@ -898,55 +919,105 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     double nu = 10.0, delta_last = 0.0, e_best = 1e300;
     int n_acc = 0;
     const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
+    // feasibility restoration (mpc_ipm_common.hpp; oracle/mpc_cbf.py: solve): all wave-uniform
+    constexpr bool RESTO = !OD;
+    bool resto = false;
+    int n_resto = 0, n_small = 0;                                       // n_small: consecutive tiny accepted steps at an infeasible z
+    double theta_R = 0.0, mu_reg = mu;
+    const double rho_R = p.resto.rho;
     for (int i = lane; i < n; i += 64) { W.zb[i] = W.z[i]; if constexpr (OD) W.rhob[i] = W.rho[i]; }
     for (it = 1; it <= p.max_iter; ++it) {
         if (it > 1) f = eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, true, pf, 12);
         SC_PH(0);
-        row_pass(W, c, lane, e_p, e_c0, lmax);
-        SC_SYNC();
-        SC_PH(1);
-        const double e_rho = stage_pass<KT, ROW16, OD, UNI>(W, c, lane, sf);
-        SC_SYNC();
-        SC_PH(2);
-        const double e_d = fmax(e_rho, col_pass<OD, UNI>(W, c, lane, sf));
-        SC_PH(3);
-        const double e_opt = fmax(e_d, fmax(e_p, e_c0));
-        if (e_opt < e_best) {                                            // remember the best iterate
-            e_best = e_opt;
-            for (int i = lane; i < n; i += 64) { W.zb[i] = W.z[i]; if constexpr (OD) W.rhob[i] = W.rho[i]; }
+        double theta = 0.0;                                              // l1 violation of the elastic (CBF) rows at z
+        if constexpr (RESTO) {
+            for (int i = lane; i < c.mc; i += 64) theta += fmax(0.0, -W.g[i]);
+            theta = wsum(theta);
+            if (resto && theta <= p.resto.kappa * theta_R) {
+                // enough of the violation is gone: a fresh start of the regular phase at this z with the barrier parameter it left with
+                resto = false; mu = mu_reg;
+                for (int i = lane; i < m; i += 64) { const double s0 = fmax(W.g[i], 1e-2); W.sl[i] = s0; W.lam[i] = mu * rcp_(s0); }
+                for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
+                nu = 10.0; n_acc = 0; e_best = 1e300;
+                SC_SYNC();
+            }
         }
-        if (e_opt <= p.tol) { status = SC_STATUS_OPTIMAL; break; }
-        // IPOPT's acceptable-point rule: acceptable_iter consecutive iterates within acceptable_tol end the solve (the
-        // best iterate is returned below)
-        n_acc = e_opt <= p.acceptable_tol ? n_acc + 1 : 0;
-        if (n_acc >= acc_iter) break;
-        if (lmax > 1e10) { status = SC_STATUS_INFEASIBLE; break; }
-        // barrier update
-        for (;;) {
-            double e_c = 0.0;
-            for (int i = lane; i < m; i += 64) e_c = fmax(e_c, fabs(W.sl[i] * W.lam[i] - mu));
-            e_c = wmax(e_c);
-            const double e_mu = fmax(e_d, fmax(e_p, e_c));
-            if (e_mu <= 10.0 * mu && mu > p.mu_min) mu = fmax(p.mu_min, fmin(0.2 * mu, mu * sqrt(mu)));
-            else break;
+        double e_p, e_c0, lmax, e_d;
+        bool stop = false, want_resto = false;
+        for (int pass = 0;; ++pass) {
+            // restoration: no objective but zeta/2 |z - z_R|^2, zeta = sqrt(mu); the elastic rows' entries depend on mu, so the
+            // passes run again when the barrier update below has changed it
+            const double sfe = resto ? 0.0 : sf, zeta = resto ? sqrt(mu) : 0.0;
+            row_pass(W, c, lane, e_p, e_c0, lmax, resto, mu, rho_R);
+            SC_SYNC();
+            SC_PH(1);
+            const double e_rho = stage_pass<KT, ROW16, OD, UNI>(W, c, lane, sfe);
+            SC_SYNC();
+            SC_PH(2);
+            e_d = fmax(e_rho, col_pass<OD, UNI>(W, c, lane, sfe, zeta));
+            SC_PH(3);
+            if (pass == 1) break;
+            const double e_opt = fmax(e_d, fmax(e_p, e_c0));
+            if (!resto && e_opt < e_best) {                              // remember the best iterate
+                e_best = e_opt;
+                for (int i = lane; i < n; i += 64) { W.zb[i] = W.z[i]; if constexpr (OD) W.rhob[i] = W.rho[i]; }
+            }
+            if (e_opt <= (resto ? p.resto.tol : p.tol)) {
+                // restoration solved with the violation still there: a stationary point of the violation, the certificate
+                status = resto ? (theta > p.resto.theta_tol ? SC_STATUS_INFEASIBLE : SC_STATUS_INACCURATE) : SC_STATUS_OPTIMAL;
+                stop = true; break;
+            }
+            // IPOPT's acceptable-point rule: acceptable_iter consecutive iterates within acceptable_tol end the solve (the
+            // best iterate is returned below)
+            n_acc = e_opt <= p.acceptable_tol ? n_acc + 1 : 0;
+            if (n_acc >= acc_iter) {
+                if (resto && theta > p.resto.theta_tol) status = SC_STATUS_INFEASIBLE;
+                stop = true; break;
+            }
+            if (!resto && lmax > 1e10) {                                 // multipliers diverge: locally infeasible
+                if constexpr (RESTO) want_resto = true;
+                else { status = SC_STATUS_INFEASIBLE; stop = true; }
+                break;
+            }
+            // barrier update
+            const double mu_old = mu;
+            for (;;) {
+                double e_c = 0.0;
+                for (int i = lane; i < m; i += 64) {
+                    const double l = W.lam[i];
+                    e_c = fmax(e_c, fabs(W.sl[i] * l - mu));
+                    if (RESTO && resto && i < c.mc) e_c = fmax(e_c, fabs(W.tel[i] * (rho_R - l) - mu));
+                }
+                e_c = wmax(e_c);
+                const double e_mu = fmax(e_d, fmax(e_p, e_c));
+                if (e_mu <= 10.0 * mu && mu > p.mu_min) mu = fmax(p.mu_min, fmin(0.2 * mu, mu * sqrt(mu)));
+                else break;
+            }
+            SC_PH(4);
+            if (!(RESTO && resto && mu != mu_old)) break;
+            SC_SYNC();
         }
-        SC_PH(4);
+        if (stop) break;
+        bool accepted = false;
+        double alpha = 0.0, ad = 0.0;
+        if (!want_resto) {
+        const double sfe = resto ? 0.0 : sf, zeta = resto ? sqrt(mu) : 0.0;
         phi_times_G<MS, UNI ? 2 : 4>(W, c, lane);
         SC_SYNC();
         SC_PH(5);
         // condensed system  (sf W + J' Sigma J) dz = -r_d + J' (mu/s - Sigma r_p - lam)
         for (int col = lane; col < n; col += 64) W.rhs[col] = -W.cv[col] + (mu * W.cv[n + col] - W.cv[2 * n + col]);
-        condense_mfma<MS, OD, UNI>(W, c, lane, sf);
+        condense_mfma<MS, OD, UNI>(W, c, lane, sfe);
         SC_SYNC();
         SC_PH(6);
-        // inertia correction: M + delta I until the Cholesky succeeds
+        // inertia correction: M + delta I until the Cholesky succeeds (restoration: + zeta I, the proximity term)
         double delta = 0.0;
         bool ok = false;
         if constexpr (NT > 0) {
             constexpr int nn = NT > 0 ? 2 * NT : 2;
             // out of line (see chol_factor_solve): keeps the interior-point loop short enough for plain branches
             for (int t = 0; t < 40 && !ok; ++t) {
-                ok = chol_factor_solve<nn>((int)(W.M - sm), (int)(W.rhs - sm), (int)(W.L - sm), (int)(W.dz - sm), delta, lane);
+                ok = chol_factor_solve<nn>((int)(W.M - sm), (int)(W.rhs - sm), (int)(W.L - sm), (int)(W.dz - sm), delta + zeta, lane);
                 if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
             }
             if (!ok) break;
@@ -955,7 +1026,7 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         } else {
             for (int t = 0; t < 40 && !ok; ++t) {
                 for (int r = 0; r < n; ++r)                  // lower triangle, odd row stride (mpc_ipm_common.hpp: no LDS bank conflicts)
-                    for (int cc = lane; cc <= r; cc += 64) W.L[r * (n | 1) + cc] = W.M[r * n + cc] + (cc == r ? delta : 0.0);
+                    for (int cc = lane; cc <= r; cc += 64) W.L[r * (n | 1) + cc] = W.M[r * n + cc] + (cc == r ? delta + zeta : 0.0);
                 SC_SYNC();
                 ok = ipm::cholesky_lds(W.L, n, n | 1, lane);
                 if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
@@ -969,8 +1040,10 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         // position and speed displacements  dp = G dz,  dV_k = dt sum_{j < k} dz_{2j}
         for (int row = lane; row < 2 * (N + 2); row += 64) {
             double acc = 0.0;                                             // p_k depends on stages j <= k - 2 (zeros stored)
+            if (row >= (UNI ? 2 : 4)) {                                   // rows of p_0 (and p_1): zero, their storage may hold W.tel
 #pragma unroll
-            for (int col = 0; col < n; ++col) acc += W.dP[(size_t)row * n + col] * W.dz[col];
+                for (int col = 0; col < n; ++col) acc += W.dP[(size_t)row * n + col] * W.dz[col];
+            }
             W.dp[row] = acc;
         }
         for (int k = lane; k <= N; k += 64) {
@@ -979,8 +1052,11 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
             for (int j = 0; j < N; ++j) { const double dzj = W.dz[2 * j]; acc += j < k ? dzj : 0.0; }
             W.dV[k] = c.dt * acc;
         }
-        double gdz = 0.0;
-        for (int i = lane; i < n; i += 64) gdz += W.cv[i] * W.dz[i];      // r_d . dz
+        double gdz = 0.0, prox = 0.0;
+        for (int i = lane; i < n; i += 64) {
+            gdz += W.cv[i] * W.dz[i];                                     // r_d . dz
+            if (RESTO && resto) { const double dzr = W.z[i] - W.zb[i]; prox += dzr * dzr; }
+        }
         SC_SYNC();
         if constexpr (OD) {
             // back-substitution of the decay variables:  d rho_k = D_k^-1 (rhs_k - C_k' dp_{k..k+2}),  rhs = -t0 + mu t1 - t2
@@ -1001,11 +1077,12 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
             SC_SYNC();
         }
         SC_PH(9);
-        // ds = J dz + r_p, dlam, step lengths
-        double rs_min = 0.0, rl_min = 0.0, sum_ds_s = 0.0, sum_rp = 0.0;
+        // ds = J dz + r_p, dlam, step lengths.  Elastic rows of the restoration: dlam = -Sigma_eff J dz + dl0 with both taken from
+        // the row pass's arrays (lam * is, mu * is - vb), dt from dlam, ds = J dz + dt + r_p; t and rho - lam join the ratios
+        double rs_min = 0.0, rl_min = 0.0, sum_ds_s = 0.0, sum_rp = 0.0, sum_t = 0.0, sum_dt = 0.0;
         LogSum ls0;
         for (int i = lane; i < m; i += 64) {
-            const double s = W.sl[i], lam = W.lam[i], rp = W.g[i] - s, isv = W.is[i];
+            const double s = W.sl[i], lam = W.lam[i], isv = W.is[i];
             double jd;
             if (i < c.mc) {
                 const int k = i / K, jo = i - k * K;
@@ -1022,25 +1099,49 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
                 const int r = i - c.mc - c.ns;
                 jd = r < n ? -W.dz[r] : W.dz[r - n];
             }
-            const double ds = jd + rp;
-            const double dl = -(lam * isv) * ds - (lam - mu * isv);
+            double ds, dl, rp, rs;
+            if (RESTO && resto && i < c.mc) {
+                const double t = W.tel[i], nut = rho_R - lam;
+                rp = W.g[i] + t - s;
+                dl = -(lam * isv) * jd + (mu * isv - W.dlam[i]);            // W.dlam still holds vb of this row
+                const double dt = ipm::resto_dt(lam, t, dl, mu, rho_R);
+                ds = jd + dt + rp;
+                rs = ds * rcp_(s);
+                const double rt = dt * rcp_(t);
+                rs_min = fmin(rs_min, rt); rl_min = fmin(rl_min, -dl * rcp_(nut));
+                sum_ds_s += rt; sum_t += t; sum_dt += dt; ls0.add(t);
+            } else {
+                rp = W.g[i] - s;
+                ds = jd + rp;
+                dl = -(lam * isv) * ds - (lam - mu * isv);
+                rs = ds * isv;
+            }
             gdz += lam * jd;                                              // sf grad f . dz = r_d . dz + lam . (J dz)
-            const double rs = ds * isv, rl = dl * rcp_(lam);              // fraction to the boundary: most negative ratios
+            const double rl = dl * rcp_(lam);                             // fraction to the boundary: most negative ratios
             rs_min = fmin(rs_min, rs); rl_min = fmin(rl_min, rl);
             sum_ds_s += rs; sum_rp += fabs(rp); ls0.add(s);
             W.ds[i] = ds; W.dlam[i] = dl;
         }
         rs_min = wmin(rs_min); rl_min = wmin(rl_min); sum_ds_s = wsum(sum_ds_s); sum_rp = wsum(sum_rp);
         const double sum_log = ls0.total();
-        const double ap = rs_min < 0.0 ? fmin(1.0, -tau / rs_min) : 1.0, ad = rl_min < 0.0 ? fmin(1.0, -tau / rl_min) : 1.0;
+        const double ap = rs_min < 0.0 ? fmin(1.0, -tau / rs_min) : 1.0;
+        ad = rl_min < 0.0 ? fmin(1.0, -tau / rl_min) : 1.0;
         gdz = wsum(gdz);
         nu = fmax(nu, 1.1 * lmax);
-        const double phi0 = sf * f - mu * sum_log + nu * sum_rp;
-        const double dphi = gdz - mu * sum_ds_s - nu * sum_rp;
+        double bar0 = sfe * f - mu * sum_log, dbar = gdz - mu * sum_ds_s;
+        if (RESTO && resto) {
+            prox = wsum(prox); sum_t = wsum(sum_t); sum_dt = wsum(sum_dt);
+            bar0 = 0.5 * zeta * prox + rho_R * sum_t - mu * sum_log;
+            dbar += rho_R * sum_dt;
+        }
+        // not a descent direction of the merit function (the penalty is below the multipliers of the step): raise the penalty so that
+        // the directional derivative is -0.1 nu |r_p|_1  (Nocedal & Wright (18.36))
+        if (dbar - nu * sum_rp >= 0.0 && sum_rp > 0.0) nu = dbar / (0.9 * sum_rp);
+        const double phi0 = bar0 + nu * sum_rp;
+        const double dphi = dbar - nu * sum_rp;
         SC_PH(10);
         // l1-merit backtracking
-        double alpha = ap;
-        bool accepted = false;
+        alpha = ap;
         for (int ls = 0; ls < 12; ++ls) {                              // at most 12 halvings, then give up (best iterate)
             for (int i = lane; i < n; i += 64) {
                 W.zt[i] = W.z[i] + alpha * W.dz[i];
@@ -1048,40 +1149,87 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
             }
             SC_SYNC();
             const double ft = eval_values<ROW16, OD, UNI>(W.zt, W.rhot, W, c, lane, false, pf, 16);
-            double srp = 0.0;
+            double srp = 0.0, st_ = 0.0, proxt = 0.0;
             LogSum lst;
             for (int i = lane; i < m; i += 64) {
                 const double st = W.sl[i] + alpha * W.ds[i];
-                lst.add(st); srp += fabs(W.g[i] - st);
+                lst.add(st);
+                if (RESTO && resto && i < c.mc) {
+                    const double t = W.tel[i];
+                    const double tt = t + alpha * ipm::resto_dt(W.lam[i], t, W.dlam[i], mu, rho_R);
+                    lst.add(tt); st_ += tt;
+                    srp += fabs(W.g[i] + tt - st);
+                } else {
+                    srp += fabs(W.g[i] - st);
+                }
+            }
+            if (RESTO && resto) {
+                for (int i = lane; i < n; i += 64) { const double dzr = W.zt[i] - W.zb[i]; proxt += dzr * dzr; }
             }
             const double slog = lst.total();
             srp = wsum(srp);
-            const double phit = sf * ft - mu * slog + nu * srp;
+            double phit = sfe * ft - mu * slog + nu * srp;
+            if (RESTO && resto) phit = 0.5 * zeta * wsum(proxt) + rho_R * wsum(st_) - mu * slog + nu * srp;
             // Armijo, with an allowance for round-off in the merit function near convergence
             // (f is a sum of a few hundred terms of size |phi|: its noise is ~1e-13 |phi|)
             if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0)) { accepted = true; break; }
             alpha *= 0.5;
         }
-        if (!accepted) break;
+        if (!accepted) {
+            if (!RESTO || resto) break;
+            want_resto = true;
+        } else if (RESTO && !resto) {
+            // IPOPT hands over to the restoration when the step length falls below its alpha_min; here: small_iter consecutive
+            // accepted steps shorter than small_alpha at an infeasible iterate (the accepted step is then not taken)
+            n_small = (alpha < p.resto.small_alpha && theta > p.resto.theta_tol) ? n_small + 1 : 0;
+            if (n_small >= p.resto.small_iter && n_resto < p.resto.max_entries && e_best > p.acceptable_tol) want_resto = true;
+        }
+        }
+        if (want_resto) {
+            // the regular phase cannot continue from z.  Nothing to restore at a feasible point (kinks of step(), round-off at the
+            // precision limit) or once the restoration has been entered max_entries times
+            if (e_best <= p.acceptable_tol || theta <= p.resto.theta_tol || n_resto >= p.resto.max_entries) break;
+            SC_SYNC();
+            eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, false, pf, 16);   // W.g holds the last trial point's rows
+            resto = true; ++n_resto; n_small = 0; theta_R = theta; mu_reg = mu;
+            double vmax = 0.0;
+            for (int i = lane; i < c.mc; i += 64) vmax = fmax(vmax, -W.g[i]);
+            mu = fmax(mu, wmax(vmax));                                   // IPOPT: mu_R = max(mu, |c|_inf)
+            for (int i = lane; i < m; i += 64) {
+                // elastic rows start on their central path, the others like at the start of the solve
+                const double gi = W.g[i];
+                const double s0 = i < c.mc ? ipm::resto_central_slack(gi, mu, rho_R) : fmax(gi, 1e-2);
+                if (i < c.mc) W.tel[i] = s0 - gi;
+                W.sl[i] = s0; W.lam[i] = mu * rcp_(s0);
+            }
+            for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];          // z_R
+            nu = 10.0; n_acc = 0;
+            SC_SYNC();
+            continue;
+        }
         for (int i = lane; i < n; i += 64) {
             W.z[i] = W.z[i] + alpha * W.dz[i];
             if constexpr (OD) W.rho[i] = W.rho[i] + alpha * W.drho[i];
         }
         for (int i = lane; i < m; i += 64) {
             const double s = W.sl[i] + alpha * W.ds[i];
-            double lam = W.lam[i] + ad * W.dlam[i];
+            const double l0 = W.lam[i], dl = W.dlam[i];
+            double lam = l0 + ad * dl;
             const double mus = mu * rcp_(s);
             lam = fmin(fmax(lam, 1e-10 * mus), 1e10 * mus);               // IPOPT eq. (16) safeguard
+            if (RESTO && resto && i < c.mc) {
+                const double t = W.tel[i];
+                const double tn = t + alpha * ipm::resto_dt(l0, t, dl, mu, rho_R);
+                W.tel[i] = tn;
+                lam = ipm::resto_clamp_lam(lam, tn, mu, rho_R);
+            }
             W.sl[i] = s; W.lam[i] = lam;
         }
         SC_SYNC();
         SC_PH(11);
-#if defined(SC_EXP_TRACE) && !defined(SC_EXP_BOTH)
-        if (z_out && lane == 0 && it <= 20) { st(z_out, prob * n + (it - 1) * 2, e_opt); st(z_out, prob * n + (it - 1) * 2 + 1, delta > 0 ? delta : alpha); }
-#endif
     }
     if (it > p.max_iter) it = p.max_iter;
-    if (status != SC_STATUS_OPTIMAL && e_best <= p.acceptable_tol) {
+    if (status == SC_STATUS_INACCURATE && !resto && e_best <= p.acceptable_tol) {
         // stalled at the precision limit (ill-conditioned condensed system at mu ~ 1e-9): the best iterate is
         // within the acceptable tolerance, like IPOPT's acceptable_tol exit
         SC_SYNC();
@@ -1089,13 +1237,15 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         status = SC_STATUS_OPTIMAL;
     }
     SC_SYNC();
-    eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, false, pf, 16);
-    if (status != SC_STATUS_OPTIMAL) {
-        double gmin = 1e300;
-        for (int i = lane; i < m; i += 64) gmin = fmin(gmin, W.g[i]);
-        gmin = wmin(gmin);
-        if (gmin < -1e-6) status = SC_STATUS_INFEASIBLE;
-        else if (status != SC_STATUS_INFEASIBLE) status = SC_STATUS_INACCURATE;
+    if constexpr (OD) {
+        // optimal decay has no restoration phase: "infeasible" there still means "stopped at an infeasible iterate"
+        eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, false, pf, 16);
+        if (status != SC_STATUS_OPTIMAL) {
+            double gmin = 1e300;
+            for (int i = lane; i < m; i += 64) gmin = fmin(gmin, W.g[i]);
+            gmin = wmin(gmin);
+            if (gmin < -1e-6) status = SC_STATUS_INFEASIBLE;
+        }
     }
     if (lane == 0) {
         st(u_out, prob * 2 + 0, W.z[0]);
@@ -1192,7 +1342,7 @@ void odmpccbf_uni_kernel_rt(const sc_mpccbf_params p, const OdExtra od, const lo
     mpccbf_body<0, 0, true, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
 }
 
-size_t mpccbf_lds_bytes(int N, int K) { return mpc_lds_doubles(N, K) * sizeof(double); }
+size_t mpccbf_lds_bytes(int N, int K, bool uni) { return mpc_lds_doubles(N, K, false, uni) * sizeof(double); }
 size_t odmpccbf_lds_bytes(int N, int K) { return mpc_lds_doubles(N, K, true) * sizeof(double); }
 
 static hipError_t odmpc_launch_t(const sc_odmpccbf_params& q, long long B, int K, const void* X, const void* u_prev,
@@ -1232,7 +1382,7 @@ template <int NT, int KT, bool UNI = false>
 static hipError_t mpc_launch_one(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
                                  const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                                  hipStream_t stream) {
-    const size_t lds = mpc_lds_doubles(p.horizon, K) * sizeof(double);
+    const size_t lds = mpc_lds_doubles(p.horizon, K, false, UNI) * sizeof(double);
     auto launch = [&](auto kern) {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1268,7 +1418,7 @@ static hipError_t mpc_launch_t(const sc_mpccbf_params& p, long long B, int K, co
 hipError_t mpccbf_launch(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
                          hipStream_t stream) {
-    if (mpc_lds_doubles(p.horizon, K) * sizeof(double) > 160 * 1024) return hipErrorInvalidValue;
+    if (mpc_lds_doubles(p.horizon, K, false, p.model_id == SC_MODEL_UNICYCLE2D) * sizeof(double) > 160 * 1024) return hipErrorInvalidValue;
     return mpc_launch_t(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
 }
 

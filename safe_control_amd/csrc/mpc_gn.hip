@@ -357,6 +357,7 @@ struct GnMem {
     double *xs, *Ph, *pts, *y, *pdz, *G, *T;              // (N+1) nx | (N+1) nx n | 6N | 6N | 6N | 6N n | 6N n
     double *obs, *hk, *dh, *hh;                           // 7K | 3N K | 6N K | 9N K
     double *g, *s, *lam, *ds, *dlam, *vb;                 // m each
+    double *tel;                                          // N K: elastic variables of the feasibility restoration (mpc_ipm_common.hpp)
     double *Psi, *M, *L;                                  // 36 N | n n | (L: scratch in T)
     double *Hk;                                           // NH N: second-order terms of the dynamics per stage
 };
@@ -368,7 +369,7 @@ __host__ __device__ inline size_t mpcgn_lds_doubles(int N, int K, int nx, int nb
     const size_t n = 2 * (size_t)N, m = (size_t)N * K + 2 * (size_t)nb * N + 2 * n;
     const size_t rs = (size_t)pd * np, hs = (size_t)pd * (pd + 1) / 2;       // rows of a stage block (6 | 8), entries of a point Hessian (3 | 10)
     size_t tot = 12 + nx + 2 + 7 * n + (size_t)(N + 1) * nx + (size_t)(N + 1) * nx * n + 3 * rs * N + 2 * rs * N * n +
-                 7 * (size_t)K + (size_t)np * (1 + pd + (circles ? 0 : hs)) * N * K + 5 * m + rs * rs * N + n * n + (size_t)nh * N;
+                 7 * (size_t)K + (size_t)np * (1 + pd + (circles ? 0 : hs)) * N * K + 5 * m + (size_t)N * K + rs * rs * N + n * n + (size_t)nh * N;
     const size_t need_l = n * (n + 1) + m, have = rs * N * n;                // Cholesky scratch L and the row vector vb live in T
     return tot + (need_l > have ? need_l - have : 0);
 }
@@ -386,6 +387,7 @@ __device__ inline GnMem carve_gn(double* b, const GnDims& d) {
     W.G = take((size_t)RS * N * n);
     W.obs = take(7 * K); W.hk = take(NP * N * K); W.dh = take(PD * NP * N * K); W.hh = take(d.circles ? 0 : HS * NP * N * K);
     W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m);
+    W.tel = take((size_t)N * K);
     W.Psi = take(RS * RS * N); W.M = take((size_t)n * n);
     W.Hk = take((size_t)NH * N);
     W.T = take((size_t)RS * N * n); W.L = W.T;                     // T is dead once M is assembled
@@ -813,6 +815,11 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
     double nu_m = 10.0, delta_last = 0.0, e_best = 1e300;
     int n_acc = 0;
     const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
+    // feasibility restoration (mpc_ipm_common.hpp; oracle/mpc_cbf.py: solve): wave-uniform state
+    bool resto = false;
+    int n_resto = 0, n_small = 0;                                       // n_small: consecutive tiny accepted steps at an infeasible z
+    double theta_R = 0.0, mu_reg = mu;
+    const double rho_R = p.resto.rho;
 #ifdef SC_GN_PROF
     double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_readcyclecounter();
@@ -821,44 +828,92 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         GP(11);
         if (it > 1) f = gn_eval_any<MODEL>(W.z, W, d, c, q, lane, true);
         GP(0);
-        grad_f(sf);
+        double theta = 0.0;                                               // l1 violation of the elastic (CBF) rows at z
+        for (int i = lane; i < d.mc; i += 64) theta += fmax(0.0, -W.g[i]);
+        theta = gsum(theta);
+        if (resto && theta <= p.resto.kappa * theta_R) {
+            // enough of the violation is gone: a fresh start of the regular phase at this z with the barrier parameter it left with
+            resto = false; mu = mu_reg;
+            for (int i = lane; i < m; i += 64) { const double s0 = fmax(W.g[i], 1e-2); W.s[i] = s0; W.lam[i] = mu / s0; }
+            for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
+            nu_m = 10.0; n_acc = 0; e_best = 1e300;
+            SC_SYNC();
+        }
+        // restoration: no objective but zeta/2 |z - z_R|^2 (z_R in W.zb), zeta = sqrt(mu)
+        double zeta = resto ? sqrt(mu) : 0.0;
+        const double sfe = resto ? 0.0 : sf;
+        if (resto) {
+            for (int i = lane; i < n; i += 64) W.gs[i] = zeta * (W.z[i] - W.zb[i]);
+            SC_SYNC();
+        } else {
+            grad_f(sf);
+        }
         gn_jt_any<MODEL>(W.lam, W.rd, W, d, c, lane);
         GP(1);
         // ---- second derivatives of the dynamics and of step o step, weighted by the costates of the Lagrangian (oracle:
         // evaluate, exact_hessian).  W.y still holds A' lam per point (= -nu).  Leaves two scalars per stage in W.Hk.
-        if constexpr (MODEL == SC_MODEL_KINEMATIC_BICYCLE2D || Mdl::PD == 4) Mdl::second_order(W.xs, W.z, W.y, W.cq, W.xg, W.lam + d.mc, W.Hk, N, sf, q, lane);
-        else if constexpr (Mdl::EXACT) Mdl::second_order(W.xs, W.z, W.y, W.cq, W.xg, W.Hk, N, sf, q, lane);
+        if constexpr (MODEL == SC_MODEL_KINEMATIC_BICYCLE2D || Mdl::PD == 4) Mdl::second_order(W.xs, W.z, W.y, W.cq, W.xg, W.lam + d.mc, W.Hk, N, sfe, q, lane);
+        else if constexpr (Mdl::EXACT) Mdl::second_order(W.xs, W.z, W.y, W.cq, W.xg, W.Hk, N, sfe, q, lane);
         SC_SYNC();
         GP(2);
         double e_d = 0.0, e_p = 0.0, e_c0 = 0.0, lmx = 0.0;
         for (int i = lane; i < n; i += 64) { const double r = W.gs[i] - W.rd[i]; W.rd[i] = r; e_d = fmax(e_d, fabs(r)); }
         for (int i = lane; i < m; i += 64) {
             const double s = W.s[i], l = W.lam[i];
-            e_p = fmax(e_p, fabs(W.g[i] - s)); e_c0 = fmax(e_c0, fabs(s * l)); lmx = fmax(lmx, l);
+            double rp = W.g[i] - s;
+            if (resto && i < d.mc) { const double t = W.tel[i]; rp += t; e_c0 = fmax(e_c0, fabs(t * (rho_R - l))); }
+            e_p = fmax(e_p, fabs(rp)); e_c0 = fmax(e_c0, fabs(s * l)); lmx = fmax(lmx, l);
         }
         e_d = gmax_(e_d); e_p = gmax_(e_p); e_c0 = gmax_(e_c0); lmx = gmax_(lmx);
         const double e_opt = fmax(e_d, fmax(e_p, e_c0));
-        if (e_opt < e_best) {
+        if (!resto && e_opt < e_best) {
             e_best = e_opt;
             for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
         }
-        if (e_opt <= p.tol) { status = SC_STATUS_OPTIMAL; break; }
+        if (e_opt <= (resto ? p.resto.tol : p.tol)) {
+            // restoration solved with the violation still there: a stationary point of the violation, the certificate
+            status = resto ? (theta > p.resto.theta_tol ? SC_STATUS_INFEASIBLE : SC_STATUS_INACCURATE) : SC_STATUS_OPTIMAL;
+            break;
+        }
         n_acc = e_opt <= p.acceptable_tol ? n_acc + 1 : 0;
-        if (n_acc >= acc_iter) break;
-        if (lmx > 1e10) { status = SC_STATUS_INFEASIBLE; break; }
+        if (n_acc >= acc_iter) {
+            if (resto && theta > p.resto.theta_tol) status = SC_STATUS_INFEASIBLE;
+            break;
+        }
         if (!(e_opt < 1e300)) break;
+        bool want_resto = !resto && lmx > 1e10;                           // multipliers diverge: locally infeasible
+        bool accepted = false;
+        double alpha = 0.0, ad = 0.0;
+        if (!want_resto) {
+        const double mu_old = mu;
         for (;;) {
             double e_c = 0.0;
-            for (int i = lane; i < m; i += 64) e_c = fmax(e_c, fabs(W.s[i] * W.lam[i] - mu));
+            for (int i = lane; i < m; i += 64) {
+                const double l = W.lam[i];
+                e_c = fmax(e_c, fabs(W.s[i] * l - mu));
+                if (resto && i < d.mc) e_c = fmax(e_c, fabs(W.tel[i] * (rho_R - l) - mu));
+            }
             e_c = gmax_(e_c);
             const double e_mu = fmax(e_d, fmax(e_p, e_c));
             if (e_mu <= 10.0 * mu && mu > p.mu_min) mu = fmax(p.mu_min, fmin(0.2 * mu, mu * sqrt(mu)));
             else break;
         }
+        if (resto && mu != mu_old) {                                      // zeta = sqrt(mu): the proximity term follows the new mu
+            zeta = sqrt(mu);
+            for (int i = lane; i < n; i += 64) W.gs[i] = zeta * (W.z[i] - W.zb[i]);
+        }
         for (int i = lane; i < m; i += 64) {
-            const double s = W.s[i], l = W.lam[i], is = rcp_(s), sig = l * is;   // v_rcp seed + two Newton steps (sc_qp2.hpp)
-            W.vb[i] = mu * is - sig * (W.g[i] - s);
-            W.ds[i] = sig;                                                // sigma, read below; ds proper is written after the solve
+            const double s = W.s[i], l = W.lam[i];
+            if (resto && i < d.mc) {                                      // elastic row: lam + dl0 and Sigma_eff (ipm::resto_row)
+                double rp, ise, vbe;
+                ipm::resto_row(W.g[i], s, l, W.tel[i], mu, rho_R, rp, ise, vbe);
+                W.vb[i] = l + (mu * ise - vbe);
+                W.ds[i] = l * ise;
+            } else {
+                const double is = rcp_(s), sig = l * is;                  // v_rcp seed + two Newton steps (sc_qp2.hpp)
+                W.vb[i] = mu * is - sig * (W.g[i] - s);
+                W.ds[i] = sig;                                            // sigma, read below; ds proper is written after the solve
+            }
         }
         SC_SYNC();
         gn_jt_any<MODEL>(W.vb, W.rhs, W, d, c, lane);
@@ -928,7 +983,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             const double ri = W.cq[6 + (i & 1)];
             if (i == j) acc += 2.0 * ri + (i + 2 < n ? 2.0 * ri : 0.0);
             if (i == j + 2) acc -= 2.0 * ri;
-            acc *= sf;
+            acc *= sfe;
             for (int r = 0; r < Mdl::PD * Mdl::NP * N; ++r) acc += W.G[(size_t)r * n + i] * W.T[(size_t)r * n + j];
             if constexpr (NB > 0) {
                 for (int k = 1; k <= N; ++k) {
@@ -955,10 +1010,10 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         bool ok = false;
         for (int t = 0; t < 40 && !ok; ++t) {
             if constexpr (NT > 0) {
-                ok = ipm::chol_reg_solve<2 * NT>(W.M, W.rhs, W.L, W.dz, delta, lane);
+                ok = ipm::chol_reg_solve<2 * NT>(W.M, W.rhs, W.L, W.dz, delta + zeta, lane);   // restoration: + zeta I, the proximity term
             } else {
                 for (int r = 0; r < n; ++r)                                 // lower triangle, row stride n | 1 (odd: no LDS bank conflicts)
-                    for (int cc = lane; cc <= r; cc += 64) W.L[r * (n | 1) + cc] = W.M[r * n + cc] + (cc == r ? delta : 0.0);
+                    for (int cc = lane; cc <= r; cc += 64) W.L[r * (n | 1) + cc] = W.M[r * n + cc] + (cc == r ? delta + zeta : 0.0);
                 SC_SYNC();
                 ok = ipm::cholesky_lds(W.L, n, n | 1, lane);
             }
@@ -980,9 +1035,9 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         double gdz = 0.0;
         for (int i = lane; i < n; i += 64) gdz += W.gs[i] * W.dz[i];
         SC_SYNC();
-        double rs_min = 0.0, rl_min = 0.0, sum_ds_s = 0.0, sum_rp = 0.0, sum_log = 0.0, sum_g = 0.0;
+        double rs_min = 0.0, rl_min = 0.0, sum_ds_s = 0.0, sum_rp = 0.0, sum_log = 0.0, sum_g = 0.0, sum_t = 0.0, sum_dt = 0.0;
         for (int i = lane; i < m; i += 64) {
-            const double s = W.s[i], l = W.lam[i], rp = W.g[i] - s, sig = W.ds[i];
+            const double s = W.s[i], l = W.lam[i], sig = W.ds[i];
             sum_g += fabs(W.g[i]);
             double jd;
             if (i < d.mc) {
@@ -1014,9 +1069,24 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             } else {
                 jd = W.dz[i - d.mc - d.ms - n];
             }
-            const double dsi = jd + rp;
             const double is = rcp_(s);
-            const double dl = -sig * dsi - (l - mu * is);
+            double dsi, dl, rp;
+            if (resto && i < d.mc) {
+                // elastic row: dlam = -Sigma_eff J dz + dl0 (the row's entries again: W.vb lies in the T region), dt from dlam
+                const double t = W.tel[i];
+                double ise, vbe;
+                ipm::resto_row(W.g[i], s, l, t, mu, rho_R, rp, ise, vbe);
+                dl = -sig * jd + (mu * ise - vbe);
+                const double dt = ipm::resto_dt(l, t, dl, mu, rho_R);
+                dsi = jd + dt + rp;
+                const double rt = dt * rcp_(t);
+                rs_min = fmin(rs_min, rt); rl_min = fmin(rl_min, -dl * rcp_(rho_R - l));
+                sum_ds_s += rt; sum_t += t; sum_dt += dt; sum_log += log(t);
+            } else {
+                rp = W.g[i] - s;
+                dsi = jd + rp;
+                dl = -sig * dsi - (l - mu * is);
+            }
             const double rs = dsi * is, rl = dl * rcp_(l);
             rs_min = fmin(rs_min, rs); rl_min = fmin(rl_min, rl);
             sum_ds_s += rs; sum_rp += fabs(rp); sum_log += log(s);
@@ -1028,55 +1098,107 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         rs_min = gmin(rs_min); rl_min = gmin(rl_min); sum_ds_s = gsum(sum_ds_s); sum_rp = gsum(sum_rp); sum_log = gsum(sum_log);
         gdz = gsum(gdz); sum_g = gsum(sum_g);
         SC_SYNC();
-        const double ap = rs_min < 0.0 ? fmin(1.0, -tau / rs_min) : 1.0, ad = rl_min < 0.0 ? fmin(1.0, -tau / rl_min) : 1.0;
+        const double ap = rs_min < 0.0 ? fmin(1.0, -tau / rs_min) : 1.0;
+        ad = rl_min < 0.0 ? fmin(1.0, -tau / rl_min) : 1.0;
         nu_m = fmax(nu_m, 1.1 * lmx);
-        const double phi0 = sf * f - mu * sum_log + nu_m * sum_rp;
-        const double dphi = gdz - mu * sum_ds_s - nu_m * sum_rp;
+        double bar0 = sfe * f - mu * sum_log, dbar = gdz - mu * sum_ds_s;
+        if (resto) {
+            double prox = 0.0;
+            for (int i = lane; i < n; i += 64) { const double dzr = W.z[i] - W.zb[i]; prox += dzr * dzr; }
+            prox = gsum(prox); sum_t = gsum(sum_t); sum_dt = gsum(sum_dt);
+            bar0 = 0.5 * zeta * prox + rho_R * sum_t - mu * sum_log;
+            dbar += rho_R * sum_dt;
+        }
+        // not a descent direction of the merit function (the penalty is below the multipliers of the step): raise the penalty so that
+        // the directional derivative is -0.1 nu |r_p|_1  (Nocedal & Wright (18.36))
+        if (dbar - nu_m * sum_rp >= 0.0 && sum_rp > 0.0) nu_m = dbar / (0.9 * sum_rp);
+        const double phi0 = bar0 + nu_m * sum_rp;
+        const double dphi = dbar - nu_m * sum_rp;
         const double noise_rows = 1e-15 * nu_m * sum_g;                  // round-off of far dummy-obstacle rows (oracle: row_noise)
         GP(8);
-        double alpha = ap;
-        bool accepted = false;
+        alpha = ap;
         for (int ls = 0; ls < 12; ++ls) {
             for (int i = lane; i < n; i += 64) W.zt[i] = W.z[i] + alpha * W.dz[i];
             SC_SYNC();
             const double ft = gn_eval_any<MODEL>(W.zt, W, d, c, q, lane, false);
-            double srp = 0.0, slog = 0.0;
+            double srp = 0.0, slog = 0.0, st_ = 0.0, proxt = 0.0;
             for (int i = lane; i < m; i += 64) {
                 const double s_t = W.s[i] + alpha * W.ds[i];
-                slog += log(s_t); srp += fabs(W.g[i] - s_t);
+                slog += log(s_t);
+                if (resto && i < d.mc) {
+                    const double t = W.tel[i];
+                    const double t_t = t + alpha * ipm::resto_dt(W.lam[i], t, W.dlam[i], mu, rho_R);
+                    slog += log(t_t); st_ += t_t; srp += fabs(W.g[i] + t_t - s_t);
+                } else {
+                    srp += fabs(W.g[i] - s_t);
+                }
             }
             slog = gsum(slog); srp = gsum(srp);
-            const double phit = sf * ft - mu * slog + nu_m * srp;
+            double phit = sfe * ft - mu * slog + nu_m * srp;
+            if (resto) {
+                for (int i = lane; i < n; i += 64) { const double dzr = W.zt[i] - W.zb[i]; proxt += dzr * dzr; }
+                phit = 0.5 * zeta * gsum(proxt) + rho_R * gsum(st_) - mu * slog + nu_m * srp;
+            }
             if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0) + noise_rows) { accepted = true; break; }
             alpha *= 0.5;
         }
         GP(9);
-        if (!accepted) break;
+        if (!accepted) {
+            if (resto) break;
+            want_resto = true;
+        } else if (!resto) {
+            // IPOPT hands over to the restoration when the step length falls below its alpha_min; here: small_iter consecutive
+            // accepted steps shorter than small_alpha at an infeasible iterate (the accepted step is then not taken)
+            n_small = (alpha < p.resto.small_alpha && theta > p.resto.theta_tol) ? n_small + 1 : 0;
+            if (n_small >= p.resto.small_iter && n_resto < p.resto.max_entries && e_best > p.acceptable_tol) want_resto = true;
+        }
+        }
+        if (want_resto) {
+            // the regular phase cannot continue from z.  Nothing to restore at a feasible point (kinks of step(), round-off at the
+            // precision limit) or once the restoration has been entered max_entries times
+            if (e_best <= p.acceptable_tol || theta <= p.resto.theta_tol || n_resto >= p.resto.max_entries) break;
+            SC_SYNC();
+            gn_eval_any<MODEL>(W.z, W, d, c, q, lane, false);               // W.g holds the last trial point's rows
+            resto = true; ++n_resto; n_small = 0; theta_R = theta; mu_reg = mu;
+            double vmax = 0.0;
+            for (int i = lane; i < d.mc; i += 64) vmax = fmax(vmax, -W.g[i]);
+            mu = fmax(mu, gmax_(vmax));                                     // IPOPT: mu_R = max(mu, |c|_inf)
+            for (int i = lane; i < m; i += 64) {
+                // elastic rows start on their central path, the others like at the start of the solve
+                const double gi = W.g[i];
+                const double s0 = i < d.mc ? ipm::resto_central_slack(gi, mu, rho_R) : fmax(gi, 1e-2);
+                if (i < d.mc) W.tel[i] = s0 - gi;
+                W.s[i] = s0; W.lam[i] = mu / s0;
+            }
+            for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];            // z_R
+            nu_m = 10.0; n_acc = 0;
+            SC_SYNC();
+            continue;
+        }
         for (int i = lane; i < n; i += 64) W.z[i] = W.z[i] + alpha * W.dz[i];
         for (int i = lane; i < m; i += 64) {
             const double s = W.s[i] + alpha * W.ds[i];
-            double l = W.lam[i] + ad * W.dlam[i];
+            const double l0 = W.lam[i], dl = W.dlam[i];
+            double l = l0 + ad * dl;
             const double mus = mu * rcp_(s);
             l = fmin(fmax(l, 1e-10 * mus), 1e10 * mus);
+            if (resto && i < d.mc) {
+                const double t = W.tel[i];
+                const double tn = t + alpha * ipm::resto_dt(l0, t, dl, mu, rho_R);
+                W.tel[i] = tn;
+                l = ipm::resto_clamp_lam(l, tn, mu, rho_R);
+            }
             W.s[i] = s; W.lam[i] = l;
         }
         SC_SYNC();
     }
     if (it > p.max_iter) it = p.max_iter;
-    if (status != SC_STATUS_OPTIMAL && e_best <= p.acceptable_tol) {
+    if (status == SC_STATUS_INACCURATE && !resto && e_best <= p.acceptable_tol) {
         SC_SYNC();
         for (int i = lane; i < n; i += 64) W.z[i] = W.zb[i];
         status = SC_STATUS_OPTIMAL;
     }
     SC_SYNC();
-    gn_eval_any<MODEL>(W.z, W, d, c, q, lane, false);
-    if (status != SC_STATUS_OPTIMAL) {
-        double g_min = 1e300;
-        for (int i = lane; i < m; i += 64) g_min = fmin(g_min, W.g[i]);
-        g_min = gmin(g_min);
-        if (g_min < -1e-6) status = SC_STATUS_INFEASIBLE;
-        else if (status != SC_STATUS_INFEASIBLE) status = SC_STATUS_INACCURATE;
-    }
     if (lane < 2) st(u_out, prob * 2 + lane, W.z[lane]);
     if (lane == 0) {
         status_out[prob] = status;

@@ -49,9 +49,10 @@ __device__ __forceinline__ double wmax(double v) { return wred(v, [](double a, d
 __device__ __forceinline__ void pow3(double x, double e, bool derivs, double& pe, double& pe1, double& pe2) {
     const double er = rint(e);
     if (er == e && e <= 64.0) {
-        int n = (int)er - 2;                                               // >= 0
-        double r = 1.0, b = x;
-        while (n) { if (n & 1) r *= b; b *= b; n >>= 1; }
+        const int n = (int)er - 2;                                         // 0 .. 62: six square-and-multiply steps, straight-line
+        double r = 1.0, b = x;                                             // (no lane-divergent loop next to the pow() call below: see CHAIN)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { r = ((n >> k) & 1) ? r * b : r; b *= b; }
         pe2 = r; pe1 = r * x; pe = pe1 * x;
     } else {
         pe = pow(x, e);
@@ -104,6 +105,41 @@ __device__ inline void ipm_barrier(double px_, double py_, const double* o, doub
     hxx = sc * (ct * ct * cxx + st * st * cyy);
     hxy = sc * (ct * st * cxx - st * ct * cyy);
     hyy = sc * (st * st * cxx + ct * ct * cyy);
+}
+
+// ---- feasibility restoration (include/safe_control_amd.h: sc_resto_params; oracle/mpc_cbf.py: solve) -----------------------
+// When the regular phase cannot continue at an infeasible iterate z_R the kernels minimise
+//     rho sum_i t_i + zeta/2 |z - z_R|^2   s.t.  g_i(z) + t_i - s_i = 0,  s_i, t_i >= 0   over the CBF rows i (the elastic rows),
+// zeta = sqrt(mu), with every other row as in the regular phase, by the SAME primal-dual iteration.  An elastic row keeps its
+// slack s and multiplier lam and gains ONE stored number, t; the multiplier of t >= 0 is rho - lam (stationarity in t, kept
+// exactly by a common dual step) and dt is eliminated from the Newton system, so the row enters the condensed system as
+//     Sigma_eff = Sigma_s Sigma_t / (Sigma_s + Sigma_t),  Sigma_s = lam / s,  Sigma_t = (rho - lam) / t,
+// with its own multiplier step at dz = 0 (dl0).  The row pass hands both over in the two arrays the regular phase uses
+// (is: lam * is = Sigma;  vb: mu * is - vb = dl0), so the assembly and the column passes do not know about the restoration.
+// slack of an elastic row on the central path  mu / s + mu / t = rho,  t = s - g
+__device__ __forceinline__ double resto_central_slack(double g, double mu, double rho) {
+    return ((2.0 * mu + rho * g) + sqrt(rho * rho * g * g + 4.0 * mu * mu)) / (2.0 * rho);
+}
+__device__ __forceinline__ void resto_row(double g, double s, double lam, double t, double mu, double rho, double& rp, double& is_eff,
+                                          double& vb_eff) {
+    rp = g + t - s;
+    const double nu = rho - lam, inv_s = rcp_(s);
+    const double sig = lam * inv_s, sgt = nu * rcp_(t);
+    const double se = sig * sgt * rcp_(sig + sgt);
+    const double dl0 = -se * (rp + mu * rcp_(nu) - t) - (se * rcp_(sig)) * (lam - mu * inv_s);
+    is_eff = se * rcp_(lam);
+    vb_eff = mu * is_eff - dl0;
+}
+// dt of an elastic row from its multiplier step dl:  (rho - lam) dt - t dl = mu - t (rho - lam)
+__device__ __forceinline__ double resto_dt(double lam, double t, double dl, double mu, double rho) {
+    const double inu = rcp_(rho - lam);
+    return (mu * inu - t) + dl * t * inu;
+}
+// multiplier safeguard of an elastic row after the step (IPOPT eq. (16) for both lam and rho - lam)
+__device__ __forceinline__ double resto_clamp_lam(double lam, double t, double mu, double rho) {
+    const double mut = mu * rcp_(t);
+    lam = fmin(fmax(lam, rho - 1e10 * mut), rho - 1e-10 * mut);
+    return fmin(fmax(lam, 1e-300), rho * (1.0 - 1e-15));
 }
 
 __device__ inline void normalise_obstacle_flags(double* obs, int K, int tid, int nthreads) {

@@ -62,6 +62,7 @@ struct LinMem {
     double *z, *zt, *zb, *dz, *gs, *rd, *rhs;            // n each
     double *xs, *pts, *y, *pdz, *obs, *hk, *dh, *hh;     // (N+1) nx | 4N | 4N | 4N | 7K | 2N K | 4N K | 6N K
     double *g, *s, *lam, *ds, *dlam, *vb;                // m each
+    double *tel;                                         // N K: elastic variables of the feasibility restoration (mpc_ipm_common.hpp)
     double *cq;                                          // Q (12) | R (4) | u_lo (4) | u_hi (4)
     double *Phi, *T, *M, *L, *G;                         // 16 N | 4N n | n n | n (n + 1) | 4N n
     double *red;                                         // 8 reduction slots + the Cholesky status word (multi-wave layout)
@@ -88,7 +89,7 @@ enum { LIN_STD = 0, LIN_LEAN = 1, LIN_BIG = 2 };
 __host__ __device__ inline size_t mpclin_lds_doubles(int N, int K, int nx, int nu, int mode = LIN_STD, bool od = false) {
     const bool lean = mode == LIN_LEAN;
     const size_t n = (size_t)N * nu, m = (size_t)N * K + 2 * n;
-    return (od ? 12 * (size_t)N : 0) + (size_t)nx * nx + (size_t)nx * nu + 2 * nx + 2 * nu + nx + nu + 2 * nx + 24 + 10 + 7 * n + (size_t)(N + 1) * nx + 12 * N +
+    return (od ? 12 * (size_t)N : (size_t)N * K) + (size_t)nx * nx + (size_t)nx * nu + 2 * nx + 2 * nu + nx + nu + 2 * nx + 24 + 10 + 7 * n + (size_t)(N + 1) * nx + 12 * N +
            7 * (size_t)K + 12 * (size_t)N * K + 6 * m + 16 * N +
            (mode == LIN_BIG ? ipm::LdTile::doubles((int)n)
                             : (lean ? 4 * (size_t)N * n + n * (n + 1) + n                             // G | M (n (n + 1): the factor's transposition scratch too) | clin
@@ -106,6 +107,7 @@ __device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode, bool o
     W.xs = take((N + 1) * nx); W.pts = take(4 * N); W.y = take(4 * N); W.pdz = take(4 * N);
     W.obs = take(7 * K); W.hk = take(2 * N * K); W.dh = take(4 * N * K); W.hh = take(6 * N * K);
     W.g = take(m); W.s = take(m); W.lam = take(m); W.ds = take(m); W.dlam = take(m); W.vb = take(m);
+    W.tel = od ? nullptr : take((size_t)N * K);
     W.Phi = take(16 * N);
     W.T = W.M = nullptr;
     if (mode == LIN_STD) W.T = take((size_t)4 * N * n);
@@ -443,6 +445,12 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
     int n_acc = 0;
     bool fresh = false;
     const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
+    // feasibility restoration (mpc_ipm_common.hpp; oracle/mpc_cbf.py: solve): block-uniform state
+    constexpr bool RESTO = !OD;
+    bool resto = false, regrad = false;
+    int n_resto = 0, n_small = 0;                                       // n_small: consecutive tiny accepted steps at an infeasible z
+    double theta_R = 0.0, mu_reg = mu;
+    const double rho_R = p.resto.rho;
 #ifdef SC_LIN_PROF
     double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_readcyclecounter();
@@ -451,7 +459,25 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         LP(11);
         if (it > 1 && !fresh) f = lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, true, R);   // fresh: the accepted trial point was evaluated with derivatives
         LP(0);
-        if constexpr (LEAN) {                                             // gs = sf grad f = sf (Hc z + c)
+        double theta = 0.0;                                               // l1 violation of the elastic (CBF) rows at z
+        if constexpr (RESTO) {
+            for (int i = lane; i < d.mc; i += TH) theta += fmax(0.0, -W.g[i]);
+            theta = lsum<TH>(theta, R);
+            if (resto && theta <= p.resto.kappa * theta_R) {
+                // enough of the violation is gone: a fresh start of the regular phase at this z with the barrier parameter it left with
+                resto = false; mu = mu_reg; regrad = true;
+                for (int i = lane; i < m; i += TH) { const double s0 = fmax(W.g[i], 1e-2); W.s[i] = s0; W.lam[i] = mu / s0; }
+                for (int i = lane; i < n; i += TH) W.zb[i] = W.z[i];
+                nu_m = 10.0; n_acc = 0; e_best = 1e300;
+                SC_SYNC();
+            }
+        }
+        double zeta = (RESTO && resto) ? sqrt(mu) : 0.0;
+        const double sfe = (RESTO && resto) ? 0.0 : sf;
+        if (RESTO && resto) {                                             // objective of the restoration: zeta/2 |z - z_R|^2, z_R in W.zb
+            for (int i = lane; i < n; i += TH) W.gs[i] = zeta * (W.z[i] - W.zb[i]);
+            SC_SYNC();
+        } else if constexpr (LEAN) {                                      // gs = sf grad f = sf (Hc z + c)
             for (int i = lane; i < n; i += TH) {
                 double q = W.clin[i];
 #pragma unroll
@@ -459,8 +485,9 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
                 W.gs[i] = sf * q;
             }
             SC_SYNC();
-        } else if (it == 1) {
+        } else if (it == 1 || regrad) {
             lin_grad<TH, OD>(W, d, c, lane, sf);                            // later iterations: gs += alpha sf Hc dz at the update (the cost is quadratic)
+            regrad = false;
         }
         LP(1);
         lin_jt<TH, OD>(W.lam, W.rd, W, d, c, G, lane);
@@ -478,35 +505,64 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         }
         for (int i = lane; i < m; i += TH) {
             const double s = W.s[i], l = W.lam[i];
-            e_p = fmax(e_p, fabs(W.g[i] - s)); e_c0 = fmax(e_c0, fabs(s * l)); lmx = fmax(lmx, l);
+            double rp = W.g[i] - s;
+            if (RESTO && resto && i < d.mc) { const double t = W.tel[i]; rp += t; e_c0 = fmax(e_c0, fabs(t * (rho_R - l))); }
+            e_p = fmax(e_p, fabs(rp)); e_c0 = fmax(e_c0, fabs(s * l)); lmx = fmax(lmx, l);
         }
         e_d = lmax_<TH>(e_d, R); e_p = lmax_<TH>(e_p, R); e_c0 = lmax_<TH>(e_c0, R); lmx = lmax_<TH>(lmx, R);
         const double e_opt = fmax(e_d, fmax(e_p, e_c0));
-        if (e_opt < e_best) {
+        if (!resto && e_opt < e_best) {
             e_best = e_opt;
             for (int i = lane; i < n; i += TH) W.zb[i] = W.z[i];
             if constexpr (OD) for (int k = lane; k < N; k += TH) W.rhob[k] = W.rho[k];
         }
-        if (e_opt <= p.tol) { status = SC_STATUS_OPTIMAL; break; }
+        if (e_opt <= (resto ? p.resto.tol : p.tol)) {
+            // restoration solved with the violation still there: a stationary point of the violation, the certificate
+            status = resto ? (theta > p.resto.theta_tol ? SC_STATUS_INFEASIBLE : SC_STATUS_INACCURATE) : SC_STATUS_OPTIMAL;
+            break;
+        }
         n_acc = e_opt <= p.acceptable_tol ? n_acc + 1 : 0;
-        if (n_acc >= acc_iter) break;
-        if (lmx > 1e10) { status = SC_STATUS_INFEASIBLE; break; }
+        if (n_acc >= acc_iter) {
+            if (resto && theta > p.resto.theta_tol) status = SC_STATUS_INFEASIBLE;
+            break;
+        }
         if (!(e_opt < 1e300)) break;                                      // non-finite data: give up
+        bool want_resto = RESTO && !resto && lmx > 1e10;                  // multipliers diverge: locally infeasible
+        if (!RESTO && lmx > 1e10) { status = SC_STATUS_INFEASIBLE; break; }
+        bool accepted = false;
+        double alpha = 0.0, ad = 0.0;
+        if (!want_resto) {
+        const double mu_old = mu;
         for (;;) {                                                        // barrier update
             double e_c = 0.0;
-            for (int i = lane; i < m; i += TH) e_c = fmax(e_c, fabs(W.s[i] * W.lam[i] - mu));
+            for (int i = lane; i < m; i += TH) {
+                const double l = W.lam[i];
+                e_c = fmax(e_c, fabs(W.s[i] * l - mu));
+                if (RESTO && resto && i < d.mc) e_c = fmax(e_c, fabs(W.tel[i] * (rho_R - l) - mu));
+            }
             e_c = lmax_<TH>(e_c, R);
             const double e_mu = fmax(e_d, fmax(e_p, e_c));
             if (e_mu <= 10.0 * mu && mu > p.mu_min) mu = fmax(p.mu_min, fmin(0.2 * mu, mu * sqrt(mu)));
             else break;
         }
+        if (RESTO && resto && mu != mu_old) {                             // zeta = sqrt(mu): the proximity term follows the new mu
+            zeta = sqrt(mu);
+            for (int i = lane; i < n; i += TH) W.gs[i] = zeta * (W.z[i] - W.zb[i]);
+        }
         LP(3);
-        // rhs = -sf grad f + J' (mu / s - sig r_p)
+        // rhs = -sf grad f + J' (mu / s - sig r_p);  elastic rows of the restoration: lam + dl0 and Sigma_eff (ipm::resto_row)
         for (int i = lane; i < m; i += TH) {
             const double s = W.s[i], l = W.lam[i];
-            const double is = rcp_(s), sig = l * is;                      // v_rcp seed + two Newton steps (sc_qp2.hpp), as kernel 3
-            W.vb[i] = mu * is - sig * (W.g[i] - s);
-            W.ds[i] = sig;                                                // read by the Phi blocks below; ds proper is written after the solve
+            if (RESTO && resto && i < d.mc) {
+                double rp, ise, vbe;
+                ipm::resto_row(W.g[i], s, l, W.tel[i], mu, rho_R, rp, ise, vbe);
+                W.vb[i] = l + (mu * ise - vbe);
+                W.ds[i] = l * ise;
+            } else {
+                const double is = rcp_(s), sig = l * is;                  // v_rcp seed + two Newton steps (sc_qp2.hpp), as kernel 3
+                W.vb[i] = mu * is - sig * (W.g[i] - s);
+                W.ds[i] = sig;                                            // read by the Phi blocks below; ds proper is written after the solve
+            }
         }
         SC_SYNC();
         if constexpr (OD) {
@@ -568,23 +624,23 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
             W.rd[i] = W.ds[d.mc + i] + W.ds[d.mc + n + i];                    // sigma of the two box rows (stored above)
         SC_SYNC();
         if constexpr (!BIG) {
-            lin_condense_mfma<NT, NU, NW, false, LEAN>(W, N, nu, sf, Hc, G, W.rd, lane);
+            lin_condense_mfma<NT, NU, NW, false, LEAN>(W, N, nu, sfe, Hc, G, W.rd, lane);
             SC_SYNC();
         }
         LP(6);
-        // inertia correction: M + delta I until the Cholesky succeeds
+        // inertia correction: M + delta I until the Cholesky succeeds (restoration: + zeta I, the proximity term)
         double delta = 0.0;
         bool ok = false;
         for (int t = 0; t < 40 && !ok; ++t) {
             if constexpr (NN > 0) {
-                ok = ipm::chol_reg_solve<NN>(W.M, W.rhs, W.L, W.dz, delta, lane);
+                ok = ipm::chol_reg_solve<NN>(W.M, W.rhs, W.L, W.dz, delta + zeta, lane);
             } else if constexpr (BIG) {
-                lin_condense_mfma<NT, NU, NW, true>(W, N, nu, sf, Hc, G, W.rd, lane, delta);   // M + delta I, lower tiles, into the factor's storage
+                lin_condense_mfma<NT, NU, NW, true>(W, N, nu, sfe, Hc, G, W.rd, lane, delta + zeta);   // M + delta I, lower tiles, into the factor's storage
                 SC_SYNC();
                 ok = ipm::cholesky_ix<NW, ipm::LdTile>(W.L, n, ipm::LdTile{}, lane, W.red + 8);
             } else {
                 for (int r = lane >> 6; r < n; r += NW)                      // lower triangle, row stride n | 1 (odd: no LDS bank conflicts)
-                    for (int cc = lane & 63; cc <= r; cc += 64) W.L[r * (n | 1) + cc] = W.M[r * n + cc] + (cc == r ? delta : 0.0);
+                    for (int cc = lane & 63; cc <= r; cc += 64) W.L[r * (n | 1) + cc] = W.M[r * n + cc] + (cc == r ? delta + zeta : 0.0);
                 SC_SYNC();
                 ok = cholesky_lds<NW>(W.L, n, n | 1, lane, W.red + 8);
             }
@@ -608,9 +664,11 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         }
         // sf grad f . dz and the curvature sf dz' Hc dz: the cost is exactly quadratic in z, so the line search takes
         // f(z + a dz) - f(z) = a grad.dz + a^2/2 dz' Hc dz instead of the difference of two sums of size |f|
+        // (restoration: the proximity term is quadratic too, curvature zeta |dz|^2)
         double gdz = 0.0, curv = 0.0;
         for (int i = lane; i < n; i += TH) {
             gdz += W.gs[i] * W.dz[i];
+            if (RESTO && resto) { curv += W.dz[i] * W.dz[i]; continue; }
             double q = 0.0;
 #pragma unroll 8
             for (int j = 0; j < n; ++j) q += Hc[(size_t)j * n + i] * W.dz[j];
@@ -627,11 +685,11 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
                 curv += 2.0 * c.ps * dr * dr;
             }
         }
-        curv = sf * lsum<TH>(curv, R);
+        curv = ((RESTO && resto) ? zeta : sf) * lsum<TH>(curv, R);
         SC_SYNC();
-        double rs_min = 0.0, rl_min = 0.0, sum_ds_s = 0.0, sum_rp = 0.0, sum_log = 0.0, sum_g = 0.0;
+        double rs_min = 0.0, rl_min = 0.0, sum_ds_s = 0.0, sum_rp = 0.0, sum_log = 0.0, sum_g = 0.0, sum_t = 0.0, sum_dt = 0.0;
         for (int i = lane; i < m; i += TH) {
-            const double s = W.s[i], l = W.lam[i], rp = W.g[i] - s;
+            const double s = W.s[i], l = W.lam[i];
             double jd;
             if (i < d.mc) {
                 const int k = i / K, j = i - k * K, ea = k * K + j, eb = (N + k) * K + j;
@@ -643,9 +701,23 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
             } else {
                 jd = W.dz[i - d.mc - n];
             }
-            const double dsi = jd + rp;
             const double is = rcp_(s);
-            const double dl = -(l * is) * dsi - (l - mu * is);
+            double dsi, dl, rp;
+            if (RESTO && resto && i < d.mc) {
+                // elastic row: dlam = -Sigma_eff J dz + dl0 (W.ds still holds Sigma_eff, W.vb = lam + dl0), dt from dlam
+                const double t = W.tel[i];
+                rp = W.g[i] + t - s;
+                dl = -W.ds[i] * jd + (W.vb[i] - l);
+                const double dt = ipm::resto_dt(l, t, dl, mu, rho_R);
+                dsi = jd + dt + rp;
+                const double rt = dt * rcp_(t);
+                rs_min = fmin(rs_min, rt); rl_min = fmin(rl_min, -dl * rcp_(rho_R - l));
+                sum_ds_s += rt; sum_t += t; sum_dt += dt; sum_log += log(t);
+            } else {
+                rp = W.g[i] - s;
+                dsi = jd + rp;
+                dl = -(l * is) * dsi - (l - mu * is);
+            }
             const double rs = dsi * is, rl = dl * rcp_(l);
             rs_min = fmin(rs_min, rs); rl_min = fmin(rl_min, rl);
             sum_ds_s += rs; sum_rp += fabs(rp); sum_log += log(s); sum_g += fabs(W.g[i]);
@@ -653,15 +725,27 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         }
         rs_min = lmin<TH>(rs_min, R); rl_min = lmin<TH>(rl_min, R); sum_ds_s = lsum<TH>(sum_ds_s, R); sum_rp = lsum<TH>(sum_rp, R); sum_log = lsum<TH>(sum_log, R);
         gdz = lsum<TH>(gdz, R); sum_g = lsum<TH>(sum_g, R);
-        const double ap = rs_min < 0.0 ? fmin(1.0, -tau / rs_min) : 1.0, ad = rl_min < 0.0 ? fmin(1.0, -tau / rl_min) : 1.0;
+        const double ap = rs_min < 0.0 ? fmin(1.0, -tau / rs_min) : 1.0;
+        ad = rl_min < 0.0 ? fmin(1.0, -tau / rl_min) : 1.0;
         nu_m = fmax(nu_m, 1.1 * lmx);
-        const double phi0 = sf * f - mu * sum_log + nu_m * sum_rp;
-        const double dphi = gdz - mu * sum_ds_s - nu_m * sum_rp;
+        double bar0 = sfe * f - mu * sum_log, dbar = gdz - mu * sum_ds_s, lin_t = 0.0;
+        if (RESTO && resto) {
+            double prox = 0.0;
+            for (int i = lane; i < n; i += TH) { const double dzr = W.z[i] - W.zb[i]; prox += dzr * dzr; }
+            prox = lsum<TH>(prox, R); sum_t = lsum<TH>(sum_t, R); sum_dt = lsum<TH>(sum_dt, R);
+            bar0 = 0.5 * zeta * prox + rho_R * sum_t - mu * sum_log;
+            lin_t = rho_R * sum_dt;                                       // rho sum t is linear along the step
+            dbar += lin_t;
+        }
+        // not a descent direction of the merit function (the penalty is below the multipliers of the step): raise the penalty so that
+        // the directional derivative is -0.1 nu |r_p|_1  (Nocedal & Wright (18.36))
+        if (dbar - nu_m * sum_rp >= 0.0 && sum_rp > 0.0) nu_m = dbar / (0.9 * sum_rp);
+        const double phi0 = bar0 + nu_m * sum_rp;
+        const double dphi = dbar - nu_m * sum_rp;
         // round-off of the constraint part of the merit: a far-away dummy obstacle row has h ~ 2e6 (oracle: row_noise)
         const double noise_rows = 1e-15 * nu_m * sum_g;
         LP(8);
-        double alpha = ap;
-        bool accepted = false;
+        alpha = ap;
         fresh = false;
         for (int ls = 0; ls < 12; ++ls) {
             for (int i = lane; i < n; i += TH) W.zt[i] = W.z[i] + alpha * W.dz[i];
@@ -672,10 +756,17 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
             double srp = 0.0, slog = 0.0;
             for (int i = lane; i < m; i += TH) {
                 const double s_t = W.s[i] + alpha * W.ds[i];
-                slog += log(s_t); srp += fabs(W.g[i] - s_t);
+                slog += log(s_t);
+                if (RESTO && resto && i < d.mc) {
+                    const double t = W.tel[i];
+                    const double t_t = t + alpha * ipm::resto_dt(W.lam[i], t, W.dlam[i], mu, rho_R);
+                    slog += log(t_t); srp += fabs(W.g[i] + t_t - s_t);
+                } else {
+                    srp += fabs(W.g[i] - s_t);
+                }
             }
             slog = lsum<TH>(slog, R); srp = lsum<TH>(srp, R);
-            const double phit = phi0 + alpha * gdz + 0.5 * alpha * alpha * curv - mu * (slog - sum_log) + nu_m * (srp - sum_rp);
+            const double phit = phi0 + alpha * (gdz + lin_t) + 0.5 * alpha * alpha * curv - mu * (slog - sum_log) + nu_m * (srp - sum_rp);
             if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0) + noise_rows) {
                 accepted = true; fresh = full;
                 if (fresh) f = f_t;
@@ -684,36 +775,77 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
             alpha *= 0.5;
         }
         LP(9);
-        if (!accepted) break;
+        if (!accepted) {
+            if (!RESTO || resto) break;
+            want_resto = true;
+        } else if (RESTO && !resto) {
+            // IPOPT hands over to the restoration when the step length falls below its alpha_min; here: small_iter consecutive
+            // accepted steps shorter than small_alpha at an infeasible iterate (the accepted step is then not taken)
+            n_small = (alpha < p.resto.small_alpha && theta > p.resto.theta_tol) ? n_small + 1 : 0;
+            if (n_small >= p.resto.small_iter && n_resto < p.resto.max_entries && e_best > p.acceptable_tol) want_resto = true;
+        }
+        }
+        if (want_resto) {
+            // the regular phase cannot continue from z.  Nothing to restore at a feasible point or once the restoration has been
+            // entered max_entries times
+            if (e_best <= p.acceptable_tol || theta <= p.resto.theta_tol || n_resto >= p.resto.max_entries) break;
+            SC_SYNC();
+            f = lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, true, R);       // the rows and derivatives in LDS are the last trial point's
+            fresh = true;
+            resto = true; ++n_resto; n_small = 0; theta_R = theta; mu_reg = mu;
+            double vmax = 0.0;
+            for (int i = lane; i < d.mc; i += TH) vmax = fmax(vmax, -W.g[i]);
+            mu = fmax(mu, lmax_<TH>(vmax, R));                              // IPOPT: mu_R = max(mu, |c|_inf)
+            for (int i = lane; i < m; i += TH) {
+                // elastic rows start on their central path, the box rows like at the start of the solve
+                const double gi = W.g[i];
+                const double s0 = i < d.mc ? ipm::resto_central_slack(gi, mu, rho_R) : fmax(gi, 1e-2);
+                if (i < d.mc) W.tel[i] = s0 - gi;
+                W.s[i] = s0; W.lam[i] = mu / s0;
+            }
+            for (int i = lane; i < n; i += TH) W.zb[i] = W.z[i];            // z_R
+            nu_m = 10.0; n_acc = 0;
+            SC_SYNC();
+            continue;
+        }
         for (int i = lane; i < n; i += TH) {
             W.z[i] = W.z[i] + alpha * W.dz[i];
-            if constexpr (!LEAN) W.gs[i] += alpha * sf * W.rd[i];
+            if constexpr (!LEAN) { if (!(RESTO && resto)) W.gs[i] += alpha * sf * W.rd[i]; }
         }
         if constexpr (OD) for (int k = lane; k < N; k += TH) W.rho[k] = W.rho[k] + alpha * W.drho[k];
         for (int i = lane; i < m; i += TH) {
             const double s = W.s[i] + alpha * W.ds[i];
-            double l = W.lam[i] + ad * W.dlam[i];
+            const double l0 = W.lam[i], dl = W.dlam[i];
+            double l = l0 + ad * dl;
             const double mus = mu * rcp_(s);
             l = fmin(fmax(l, 1e-10 * mus), 1e10 * mus);                   // IPOPT eq. (16) safeguard
+            if (RESTO && resto && i < d.mc) {
+                const double t = W.tel[i];
+                const double tn = t + alpha * ipm::resto_dt(l0, t, dl, mu, rho_R);
+                W.tel[i] = tn;
+                l = ipm::resto_clamp_lam(l, tn, mu, rho_R);
+            }
             W.s[i] = s; W.lam[i] = l;
         }
         SC_SYNC();
     }
     if (it > p.max_iter) it = p.max_iter;
-    if (status != SC_STATUS_OPTIMAL && e_best <= p.acceptable_tol) {
+    if (status == SC_STATUS_INACCURATE && !resto && e_best <= p.acceptable_tol) {
         SC_SYNC();
         for (int i = lane; i < n; i += TH) W.z[i] = W.zb[i];
         if constexpr (OD) for (int k = lane; k < N; k += TH) W.rho[k] = W.rhob[k];
         status = SC_STATUS_OPTIMAL;
     }
     SC_SYNC();
-    lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, false, R);
-    if (status != SC_STATUS_OPTIMAL) {
-        double gmin = 1e300;
-        for (int i = lane; i < m; i += TH) gmin = fmin(gmin, W.g[i]);
-        gmin = lmin<TH>(gmin, R);
-        if (gmin < -1e-6) status = SC_STATUS_INFEASIBLE;
-        else if (status != SC_STATUS_INFEASIBLE) status = SC_STATUS_INACCURATE;
+    if constexpr (OD) {
+        // optimal decay has no restoration phase: "infeasible" there still means "stopped at an infeasible iterate"
+        lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, false, R);
+        if (status != SC_STATUS_OPTIMAL) {
+            double gmin = 1e300;
+            for (int i = lane; i < m; i += TH) gmin = fmin(gmin, W.g[i]);
+            gmin = lmin<TH>(gmin, R);
+            if (gmin < -1e-6) status = SC_STATUS_INFEASIBLE;
+        }
     }
     if (lane < nu) st(u_out, prob * nu + lane, W.z[lane]);
     if (lane == 0) {

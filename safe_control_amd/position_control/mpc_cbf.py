@@ -68,7 +68,7 @@ def pad_obstacles(obs, num_obs):
 
 
 def make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_shared=False,
-                tol=1e-6, max_iter=100, mu_init=0.1, mu_min=1e-9, acceptable_tol=1e-5):
+                tol=1e-6, max_iter=100, mu_init=0.1, mu_min=1e-9, acceptable_tol=1e-5, resto=None):
     p = _lib.MpcCbfParams()
     p.model_id = _lib.MODEL_IDS[robot_spec["model"]]
     p.io_dtype = io_dtype
@@ -91,6 +91,7 @@ def make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_
     p.beta = 1.01                                           # agent_barrier_dt default, dynamic_unicycle2D.py:188
     p.tol, p.mu_init, p.mu_min = float(tol), float(mu_init), float(mu_min)
     p.acceptable_tol = float(acceptable_tol)
+    p.resto = resto if resto is not None else _lib.default_resto()     # feasibility restoration (sc_resto_params)
     return p
 
 

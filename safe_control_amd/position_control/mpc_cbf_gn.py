@@ -40,7 +40,7 @@ def model_constants(robot_spec):
 
 
 def make_params(robot_spec, mc, cbf_param, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=100,
-                mu_init=0.1, mu_min=1e-9, acceptable_tol=1e-5):
+                mu_init=0.1, mu_min=1e-9, acceptable_tol=1e-5, resto=None):
     p = _lib.MpcGnParams()
     p.model_id = _lib.MODEL_IDS[robot_spec["model"]]
     p.io_dtype = io_dtype
@@ -65,6 +65,7 @@ def make_params(robot_spec, mc, cbf_param, horizon, dt, radius, io_dtype, obs_sh
     p.robot_radius = float(radius)
     p.beta = float(mc["beta"])
     p.tol, p.acceptable_tol, p.mu_init, p.mu_min = float(tol), float(acceptable_tol), float(mu_init), float(mu_min)
+    p.resto = resto if resto is not None else _lib.default_resto()     # feasibility restoration (sc_resto_params)
     return p
 
 

@@ -15,7 +15,7 @@ from .mpc_cbf import apply_mpc_overrides, pad_obstacles
 
 
 def make_params(mdl, cbf_param, horizon, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=100, mu_init=0.1,
-                mu_min=1e-9, acceptable_tol=1e-5):
+                mu_min=1e-9, acceptable_tol=1e-5, resto=None):
     p = _lib.MpcLinParams()
     p.io_dtype = io_dtype
     p.nx, p.nu, p.ng = mdl["nx"], mdl["nu"], mdl["ng"]
@@ -32,6 +32,7 @@ def make_params(mdl, cbf_param, horizon, radius, io_dtype, obs_shared=False, tol
         p.Q[i] = float(qd[i])
     for i in range(mdl["nu"]):
         p.R[i], p.u_lo[i], p.u_hi[i] = float(mdl["R"][i]), float(mdl["u_lo"][i]), float(mdl["u_hi"][i])
+    p.resto = resto if resto is not None else _lib.default_resto()     # feasibility restoration (sc_resto_params)
     return p
 
 

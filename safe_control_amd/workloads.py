@@ -116,6 +116,38 @@ def linear_mpc_batch(model="Quad3D", B=4096, K=8, seed=0, radius=0.25):
     return X, goal, obs
 
 
+MPC_FAMILIES = {"du": "DynamicUnicycle2D", "kb": "KinematicBicycle2D", "c3bf": "KinematicBicycle2D_C3BF", "dpcbf": "KinematicBicycle2D_DPCBF",
+                "di": "DoubleIntegrator2D", "quad2d": "Quad2D", "si": "SingleIntegrator2D", "quad3d": "Quad3D"}
+
+
+def mpc_family_batch(family, B=4096, K=8, seed=0):
+    """The MPC-CBF batches bench.py times and the full-batch parity tests solve, one per model family (keys of MPC_FAMILIES):
+    positions, goals and K circles per agent from du_cbfqp_batch(seed) (BASELINE config 3's draws) -- linear_mpc_batch(seed) for
+    the two linear models -- with the model's remaining states from default_rng(seed + 1): bicycles drive roughly towards their
+    goal at 0.5 .. 3 m/s, DoubleIntegrator2D velocities in +-0.7 m/s, Quad2D near hover.  Returns float64 X, u_prev, goal, obs."""
+    from .robots.spec import complete_robot_spec
+    if family in ("si", "quad3d"):
+        X, goal, obs = linear_mpc_batch(MPC_FAMILIES[family], B, K, seed=seed)
+        return X, np.zeros((B, 4 if family == "quad3d" else 2)), goal, obs
+    Xd, goal, _, obs = du_cbfqp_batch(B, K, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    up = np.zeros((B, 2))
+    if family == "du":
+        X = Xd
+    elif family == "quad2d":
+        spec = complete_robot_spec({"model": "Quad2D"})
+        X = np.zeros((B, 6)); X[:, 0:2] = Xd[:, 0:2]; X[:, 2] = rng.uniform(-0.2, 0.2, B); X[:, 3:5] = rng.uniform(-0.5, 0.5, (B, 2))
+        up = np.full((B, 2), 0.5 * (spec["f_min"] + spec["f_max"]))
+    elif family in ("kb", "c3bf", "dpcbf"):
+        X = np.zeros((B, 4)); X[:, 0:2] = Xd[:, 0:2]
+        X[:, 2] = np.arctan2(goal[:, 1] - Xd[:, 1], goal[:, 0] - Xd[:, 0]) + rng.uniform(-0.6, 0.6, B); X[:, 3] = rng.uniform(0.5, 3.0, B)
+    elif family == "di":
+        X = np.zeros((B, 4)); X[:, 0:2] = Xd[:, 0:2]; X[:, 2:4] = rng.uniform(-0.7, 0.7, (B, 2))
+    else:
+        raise KeyError(family)
+    return X, up, goal, obs
+
+
 def superellipsoid_obstacles(pos, K=8, seed=0, radius=0.25, exponents=(4.0, 6.0), rho_max=4.0):
     """BASELINE config 5's obstacles: K superellipsoid rows ``[ox, oy, a, b, e, theta, 1]`` per agent (the 7-wide layout of
     robots/dynamic_unicycle2D.py:148-183 / :204-220), semi-axes U(0.2, 0.8), exponent drawn from ``exponents``, random

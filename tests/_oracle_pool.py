@@ -33,12 +33,54 @@ def _worker_od_rd1(d, outp):
     np.savez(outp, u=u, st=st, it=it, z=z, rho=rho, f=f)
 
 
+def family_problem(family, N=10, over=None):
+    """(params, evaluate function) of one model family of workloads.MPC_FAMILIES for oracle.mpc_cbf.solve."""
+    from oracle import mpc_cbf as M, mpc_gn as G, mpc_kb_state as S, mpc_lin as L
+    over = dict(over or {})
+    if family == "du":
+        P = dict(M.DEFAULTS, N=N); P.update(over); return P, M.evaluate
+    if family in ("kb", "di", "quad2d"):
+        mdl = {"kb": G.kb_model, "di": G.di_model, "quad2d": G.quad2d_model}[family]()
+        return G.params(mdl, N, **over), G.evaluate
+    if family in ("c3bf", "dpcbf"):
+        mdl = S.c3bf_model() if family == "c3bf" else S.dpcbf_model()
+        P = S.params(mdl, N, **over); P["model"] = dict(mdl, circles_only=True); return P, S.evaluate
+    mdl = L.quad3d_model() if family == "quad3d" else L.si_model()
+    return L.params(mdl, N, **over), L.evaluate
+
+
+def _worker_family(d, outp):
+    """kind = "fam:<family>": the shared solver with that family's problem functions; also records the l1 violation of the CBF
+    rows at the returned point and how often the restoration was entered."""
+    from oracle import mpc_cbf as M
+    fam = str(d["kind"])[4:]
+    X, up, goal, obs = d["X"], d["up"], d["goal"], d["obs"]
+    over = d["params"].item() if "params" in d.files else {}
+    N = over.pop("N", 10) if isinstance(over, dict) else 10
+    B = X.shape[0]
+    nu = up.shape[1]
+    u = np.zeros((B, nu)); st = np.zeros(B, dtype=np.int64); it = np.zeros(B, dtype=np.int64); z = np.zeros((B, nu * N))
+    theta = np.zeros(B); nr = np.zeros(B, dtype=np.int64); err = np.zeros(B)
+    for i in range(B):
+        P, ev = family_problem(fam, N, over)
+        u[i], st[i], it[i], info = M.solve(X[i], up[i], goal[i], obs[i], params=P, return_info=True, evaluate_fn=ev)
+        z[i], theta[i], nr[i], err[i] = info["z"], info["theta"], info["n_resto"], info["err"]
+    np.savez(outp, u=u, st=st, it=it, z=z, theta=theta, n_resto=nr, err=err)
+
+
+def family_solve_many(family, X, up, goal, obs, params=None, workers=None, timeout=1800):
+    """oracle.mpc_cbf.solve with the problem functions of `family` on every row; dict(u, st, it, z, theta, n_resto, err)."""
+    return _run(dict(kind=np.array("fam:" + family)), X, up, goal, obs, params, workers, timeout)
+
+
 def _worker(inp, outp):
     sys.path.insert(0, ROOT)
     from oracle import mpc_cbf as M
     d = np.load(inp, allow_pickle=True)
     if "kind" in d.files and str(d["kind"]).startswith("od_"):
         return _worker_od_rd1(d, outp)
+    if "kind" in d.files and str(d["kind"]).startswith("fam:"):
+        return _worker_family(d, outp)
     X, up, goal, obs = d["X"], d["up"], d["goal"], d["obs"]
     params = d["params"].item() if "params" in d.files else None
     B = X.shape[0]

@@ -19,7 +19,7 @@ Q2 = {"model": "Quad2D", "f_min": 3.0, "f_max": 10.0, "radius": 0.25}
 Q3 = {"model": "Quad3D", "radius": 0.25}
 
 
-@pytest.mark.parametrize("tag,spec,steps", [("q2_example", Q2, 100), ("q2_behind", Q2, 100), ("q3_example", Q3, 73), ("q3_behind", Q3, 150)])
+@pytest.mark.parametrize("tag,spec,steps", [("q2_example", Q2, 100), ("q2_behind", Q2, 100), ("q3_example", Q3, 150), ("q3_behind", Q3, 150)])
 def test_reference_closed_loops(tag, spec, steps):
     ctl = sca.BatchedTrackingController(G[f"{tag}/x0"][None, :], dict(spec), controller_type={"pos": "mpc_cbf"}, obs=G[f"{tag}/obs"],
                                         io_dtype="f64", device=DEV)
@@ -42,21 +42,25 @@ def test_reference_closed_loops(tag, spec, steps):
         assert {1, 2, 3} <= seen                      # stop -> rotate -> track
 
 
-def test_collision_ends_the_quad3d_example():
-    """The reference run of --model quad3d ends with -2 at step 73 (the vehicle grazes the first obstacle)."""
+def test_quad3d_example_passes_its_first_obstacle():
+    """The reference scene of --model quad3d.  With round 2's interior point (no restoration phase) the golden run ended with -2
+    at step 73: the solver gave up at an infeasible iterate beside the first obstacle and the loop flew that iterate into it.
+    With the feasibility restoration every one of the 260 recorded solves converges and the vehicle passes; the batched loop
+    reproduces the whole recorded run, return codes included, and never touches an obstacle."""
     tag = "q3_example"
     n = len(G[f"{tag}/ret"])
-    assert int(G[f"{tag}/ret"][-1]) == -2
+    assert n == 260 and np.all(G[f"{tag}/ret"] == 0)
     ctl = sca.BatchedTrackingController(G[f"{tag}/x0"][None, :], dict(Q3), obs=G[f"{tag}/obs"], device=DEV)
     ctl.set_waypoints(G[f"{tag}/waypoints"])
-    ret = ctl.control_step(n + 5)
-    assert int(ret[0].item()) == -2 and int(ctl.ret_step[0].item()) == n - 1
-    # post-step collision (tracking.py:641-648): the robot HAS stepped into the obstacle; the fixture's last row is the state before it
-    d = np.abs(ctl.X[0].cpu().numpy() - G[f"{tag}/X"][-1])
-    assert 1e-3 < d[:2].max() < 0.1
     o = G[f"{tag}/obs"]
-    x = ctl.X[0].cpu().numpy()
-    assert (np.hypot(o[:, 0] - x[0], o[:, 1] - x[1]) - o[:, 2] - 0.25).min() < 0.0
+    clear = np.inf
+    for k in range(n):
+        ret = ctl.control_step(1)
+        assert int(ret[0].item()) == 0, k
+        x = ctl.X[0].cpu().numpy()
+        clear = min(clear, (np.hypot(o[:, 0] - x[0], o[:, 1] - x[1]) - o[:, 2] - 0.25).min())
+    assert clear > 0.0
+    assert np.abs(ctl.X[0].cpu().numpy() - G[f"{tag}/X"][-1])[:2].max() < 1e-4
 
 
 @pytest.mark.parametrize("spec", [Q2, Q3])
@@ -82,4 +86,7 @@ def test_batch_agrees_with_single_agents_and_f32_runs(spec):
     c32.control_step(12)
     same = (c32.ret == ctl.ret)
     assert same.double().mean() > 0.95
-    assert (c32.X.double() - ctl.X)[same][:, :2].abs().max() < 5e-3
+    # f32 arrays round the states fed to every solve; an agent whose solve sits at a branch of the solver (restoration entered or
+    # not, a line search decided at the round-off level) can take another input there, so the bound is on all but a few agents
+    dev = (c32.X.double() - ctl.X)[same][:, :2].abs().max(dim=1).values
+    assert torch.quantile(dev, 0.95) < 5e-3

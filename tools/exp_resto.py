@@ -11,31 +11,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import mpc_cbf as M, mpc_gn as G, mpc_kb_state as S, mpc_lin as L   # noqa: E402
 from safe_control_amd import workloads as W   # noqa: E402
-from safe_control_amd.robots.spec import complete_robot_spec   # noqa: E402
 
 
 def batch(fam, B=4096, K=8, seed=0):
-    """The inputs of bench.py's legs (mpc_leg, gn_mpc_leg, linear_mpc_leg), rounded to f32 like the device arrays."""
-    Xd, gn, _, on = W.du_cbfqp_batch(B, K, seed=seed)
-    rng = np.random.default_rng(seed + 1)
-    if fam == "du":
-        Xn, up = Xd, np.zeros((B, 2))
-    elif fam == "quad2d":
-        spec = complete_robot_spec({"model": "Quad2D"})
-        Xn = np.zeros((B, 6)); Xn[:, 0:2] = Xd[:, 0:2]; Xn[:, 2] = rng.uniform(-0.2, 0.2, B); Xn[:, 3:5] = rng.uniform(-0.5, 0.5, (B, 2))
-        up = np.full((B, 2), 0.5 * (spec["f_min"] + spec["f_max"]))
-    elif fam in ("kb", "c3bf", "dpcbf"):
-        Xn = np.zeros((B, 4)); Xn[:, 0:2] = Xd[:, 0:2]
-        Xn[:, 2] = np.arctan2(gn[:, 1] - Xd[:, 1], gn[:, 0] - Xd[:, 0]) + rng.uniform(-0.6, 0.6, B); Xn[:, 3] = rng.uniform(0.5, 3.0, B)
-        up = np.zeros((B, 2))
-    elif fam == "di":
-        Xn = np.zeros((B, 4)); Xn[:, 0:2] = Xd[:, 0:2]; Xn[:, 2:4] = rng.uniform(-0.7, 0.7, (B, 2))
-        up = np.zeros((B, 2))
-    elif fam in ("si", "quad3d"):
-        Xn, gn, on = W.linear_mpc_batch("Quad3D" if fam == "quad3d" else "SingleIntegrator2D", B, K, seed=seed)
-        up = np.zeros((B, 4 if fam == "quad3d" else 2))
+    """The inputs of bench.py's legs (workloads.mpc_family_batch), rounded to f32 like the device arrays."""
     f32 = lambda a: a.astype(np.float32).astype(np.float64)
-    return f32(Xn), f32(up), f32(gn), f32(on)
+    return tuple(f32(a) for a in W.mpc_family_batch(fam, B, K, seed))
 
 
 def problem(fam, over):

@@ -31,6 +31,7 @@ def main():
             g = lambda k: (re.search(rf"\.{k}:\s+(\S+)", blk) or [None, "?"])[1]
             name = g("name")
             dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
+            dem = dem.replace("(anonymous namespace)::", "")              # mpc_lin / mpc_gn keep their kernels in one
             dem = re.sub(r"\(.*", "", dem).replace("void sc::", "")
             if pats and not any(p in dem for p in pats):
                 continue
