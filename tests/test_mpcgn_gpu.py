@@ -54,28 +54,21 @@ def test_batch_matches_oracle(name, N, K):
     u, st, it, z = ctl.solve(t(X), t(up), t(Gl), t(O), want_z=True)
     torch.cuda.synchronize()
     u, st, it, z = u.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), z.cpu().numpy()
-    n_opt = n_act = n_loose = n_path = 0
+    n_opt = n_act = 0
     for i in range(B):
         uo, so, ito, info = G.solve(mdl, X[i], up[i], Gl[i], O[i], N=N, return_info=True)
-        if st[i] != so:
-            # line-search failures at a kink of step() (speed rescaling) or at the round-off limit end one solver an iteration
-            # before the other: both must then be at (nearly) the same non-converged point
-            assert {int(st[i]), int(so)} <= {0, 2} and np.abs(z[i] - info["z"]).max() <= 1e-3, f"status differs at problem {i}"
-            n_loose += 1
-            continue
-        if so == 0 and info["err"] > 1e-6:                          # acceptable-point exit: the stopping iteration depends on rounding
-            assert np.abs(u[i] - uo).max() <= 1e-4 * max(1.0, np.abs(uo).max())
-            n_loose += 1
-            continue
-        # the quasi-Newton path is sensitive to rounding in the accept / reject decisions of the line search: most problems
-        # follow the oracle iteration for iteration, a few reach the same optimum along a slightly different path
-        n_path += int(abs(int(it[i]) - ito) > max(2, ito // 10))
+        assert st[i] == so, f"status differs at problem {i}: {st[i]} vs {so}"          # the bar of tests/test_mpccbf_gpu.py
         if so == 0:
-            assert np.abs(u[i] - uo).max() <= 1e-6 * max(1.0, np.abs(uo).max())
-            assert np.abs(z[i] - info["z"]).max() <= 2e-5 * max(1.0, np.abs(info["z"]).max())
+            # (an optimum that stopped on the acceptable rule: both solvers are then within acceptable_tol of the same point)
+            tol_u, tol_z = (1e-6, 2e-5) if info["err"] <= 1e-6 else (1e-4, 1e-3)
+            assert np.abs(u[i] - uo).max() <= tol_u * max(1.0, np.abs(uo).max()), i
+            assert np.abs(z[i] - info["z"]).max() <= tol_z * max(1.0, np.abs(info["z"]).max()), i
+            assert abs(int(it[i]) - ito) <= 2, i
             n_opt += 1
             n_act += int(np.min(info["g"][: N * K]) < 1e-4)
-    assert n_opt >= B // 2 and n_loose <= B // 4 and n_path <= B // 5 and (n_act >= 1 or N < 10)
+        elif so == 1:
+            assert info["theta"] > 1e-6 and np.abs(u[i] - uo).max() <= 1e-5 * max(1.0, np.abs(uo).max()), i
+    assert n_opt >= B // 2 and (n_act >= 1 or N < 10)
 
 
 def test_double_integrator_superellipsoid_f32_and_shared_table():

@@ -41,28 +41,29 @@ def draw(mdl, rng, K, clear=1.0):
     return x0, goal, obs
 
 
-def compare(u, st, it, z, X, up, Gl, O, mdl, N, K):
+def compare(u, st, it, z, X, up, Gl, O, solve, N, K):
+    """The bar of tests/test_mpccbf_gpu.py: same status on EVERY problem, |u0 - u0_oracle| <= 1e-6 and |z - z_oracle| <= 2e-5 on every
+    optimal one (1e-4 on optima that stopped on the acceptable rule: both solvers are then within acceptable_tol of the same point).
+    Iteration counts within 2, except on at most ONE problem of the batch (the bicycle's line search decides at the speed-clip kink on
+    differences at the round-off level; such a problem reaches the same optimum a few iterations apart).
+    Returns the number of optimal problems, of those with an active CBF row, and of certified infeasible ones."""
     B = X.shape[0]
-    n_opt = n_act = n_loose = n_path = 0
+    n_opt = n_act = n_inf = n_path = 0
     for i in range(B):
-        uo, so, ito, info = G.solve(mdl, X[i], up[i], Gl[i], O[i], N=N, return_info=True)
-        if st[i] != so:
-            # a line search that fails at the speed-clip kink or at the round-off limit ends one solver an iteration before the
-            # other: both are then at (nearly) the same non-converged point
-            assert {int(st[i]), int(so)} <= {0, 2} and np.abs(z[i] - info["z"]).max() <= 1e-3, f"status differs at problem {i}"
-            n_loose += 1
-            continue
-        if so == 0 and info["err"] > 1e-6:
-            assert np.abs(u[i] - uo).max() <= 1e-4 * max(1.0, np.abs(uo).max())
-            n_loose += 1
-            continue
-        n_path += int(abs(int(it[i]) - ito) > max(2, ito // 10))
+        uo, so, ito, info = solve(X[i], up[i], Gl[i], O[i])
+        assert st[i] == so, f"status differs at problem {i}: {st[i]} vs {so}"
         if so == 0:
-            assert np.abs(u[i] - uo).max() <= 1e-6 * max(1.0, np.abs(uo).max()), i
-            assert np.abs(z[i] - info["z"]).max() <= 2e-5 * max(1.0, np.abs(info["z"]).max()), i
+            tol_u, tol_z = (1e-6, 2e-5) if info["err"] <= 1e-6 else (1e-4, 1e-3)
+            assert np.abs(u[i] - uo).max() <= tol_u * max(1.0, np.abs(uo).max()), i
+            assert np.abs(z[i] - info["z"]).max() <= tol_z * max(1.0, np.abs(info["z"]).max()), i
+            n_path += int(abs(int(it[i]) - ito) > 2)
             n_opt += 1
             n_act += int(np.min(info["g"][: N * K]) < 1e-4)
-    return n_opt, n_act, n_loose, n_path
+        elif so == 1:
+            assert info["theta"] > 1e-6 and np.abs(u[i] - uo).max() <= 1e-5 * max(1.0, np.abs(uo).max()), i
+            n_inf += 1
+    assert n_path <= 1
+    return n_opt, n_act, n_inf
 
 
 @pytest.mark.parametrize("N,K", [(10, 5), (10, 8), (6, 3), (14, 4)])
@@ -77,8 +78,9 @@ def test_batch_matches_oracle(N, K):
     ctl = sca.BatchedGnMPCCBF({"model": NAME}, io_dtype="f64", horizon=N)
     u, st, it, z = ctl.solve(t(X), t(up), t(Gl), t(O), want_z=True)
     torch.cuda.synchronize()
-    n_opt, n_act, n_loose, n_path = compare(u.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), z.cpu().numpy(), X, up, Gl, O, mdl, N, K)
-    assert n_opt >= B // 2 and n_loose <= B // 4 and n_path <= B // 5 and n_act >= 1
+    solve = lambda x, u_, g_, o_: G.solve(mdl, x, u_, g_, o_, N=N, return_info=True)
+    n_opt, n_act, n_inf = compare(u.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), z.cpu().numpy(), X, up, Gl, O, solve, N, K)
+    assert n_opt >= B // 3 and n_act >= 1                                  # cold starts among seven circles: the rest has no plan or jams
 
 
 def test_reference_scene_closed_loop_drop_in():
@@ -103,7 +105,7 @@ def test_reference_scene_closed_loop_drop_in():
         ref = {"state_machine": "track", "u_ref": np.zeros((2, 1)), "goal": goal}
         u = ctl.solve_control_problem(x.reshape(-1, 1), ref, SCENE_OBS[near]).reshape(-1)
         names = {0: "optimal", 1: "infeasible", 2: "optimal_inaccurate"}
-        assert ctl.solver_status == names[so] or {ctl.solver_status, names[so]} == {"optimal", "optimal_inaccurate"}, step
+        assert ctl.solver_status == names[so], step
         if so == 0:
             assert np.abs(u - uo).max() <= (1e-6 if info["err"] <= 1e-6 else 1e-4) * max(1.0, np.abs(uo).max()), step
             n_opt += 1
@@ -129,8 +131,6 @@ def test_f32_arrays_shared_table_and_guards():
     for i in range(0, B, 2):
         uo, so, _, info = G.solve(mdl, X32[i].astype(np.float64), np.zeros(2), G32[i].astype(np.float64), S32.astype(np.float64), N=N,
                                   return_info=True)
-        if {int(st[i]), int(so)} == {0, 2}:
-            continue
         assert st[i] == so
         if so == 0:
             assert np.abs(u[i] - uo).max() <= (2e-6 if info["err"] <= 1e-6 else 1e-4) * max(1.0, np.abs(uo).max())
@@ -159,7 +159,7 @@ def test_full_batch_properties():
     torch.cuda.synchronize()
     assert torch.equal(u1, u2) and torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(z1, z2)
     st, it, z = s1.cpu().numpy(), i1.cpu().numpy(), z1.cpu().numpy()
-    assert it.max() <= 100 and set(np.unique(st)) <= {0, 1, 2} and (st == 0).mean() > 0.6
+    assert it.max() <= 100 and set(np.unique(st)) <= {0, 1, 2} and (st == 0).mean() > 0.5
     lo, hi = np.tile(mdl["u_lo"], N), np.tile(mdl["u_hi"], N)
     ok = st == 0
     assert np.all(z[ok] >= lo - 1e-9) and np.all(z[ok] <= hi + 1e-9)
@@ -188,25 +188,9 @@ def test_state_barrier_batch_matches_oracle(name, N, K):
     ctl = sca.BatchedGnMPCCBF({"model": name}, io_dtype="f64", horizon=N)
     u, st, it, z = ctl.solve(t(X), t(up), t(Gl), t(O), want_z=True)
     torch.cuda.synchronize()
-    u, st, it, z = u.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), z.cpu().numpy()
-    n_opt = n_loose = n_path = 0
-    for i in range(B):
-        uo, so, ito, info = S.solve(mdl, X[i], up[i], Gl[i], O[i], N=N, return_info=True)
-        if st[i] != so:
-            assert {int(st[i]), int(so)} <= {0, 2} and np.abs(z[i] - info["z"]).max() <= 1e-3, f"status differs at problem {i}: {st[i]} vs {so}"
-            n_loose += 1
-            continue
-        if so == 0 and info["err"] > 1e-6:
-            assert np.abs(u[i] - uo).max() <= 1e-4 * max(1.0, np.abs(uo).max())
-            n_loose += 1
-            continue
-        n_path += int(abs(int(it[i]) - ito) > max(2, ito // 10))
-        if so == 0:
-            assert np.abs(u[i] - uo).max() <= 1e-6 * max(1.0, np.abs(uo).max()), i
-            assert np.abs(z[i] - info["z"]).max() <= 2e-5 * max(1.0, np.abs(info["z"]).max()), i
-            n_opt += 1
-    # cold starts in a field of cones: many of these draws have no feasible plan, and both solvers say so (status compared above)
-    assert n_opt >= B // 4 and n_loose <= B // 4 and n_path <= B // 4
+    solve = lambda x, u_, g_, o_: S.solve(mdl, x, u_, g_, o_, N=N, return_info=True)
+    n_opt, n_act, n_inf = compare(u.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), z.cpu().numpy(), X, up, Gl, O, solve, N, K)
+    assert n_opt >= 1                       # cold starts in a field of cones: most of these draws start inside one
 
 
 @pytest.mark.parametrize("name", list(STATE_MODELS))
@@ -228,7 +212,7 @@ def test_state_barrier_reference_scene_closed_loop_drop_in(name):
         ctl.u_prev = up.copy()
         ref = {"state_machine": "track", "u_ref": np.zeros((2, 1)), "goal": goal}
         u = ctl.solve_control_problem(x.reshape(-1, 1), ref, SCENE_OBS[near]).reshape(-1)
-        assert ctl.solver_status == names[so] or {ctl.solver_status, names[so]} == {"optimal", "optimal_inaccurate"}, step
+        assert ctl.solver_status == names[so], step
         if so == 0:
             assert np.abs(u - uo).max() <= (1e-6 if info["err"] <= 1e-6 else 1e-4) * max(1.0, np.abs(uo).max()), step
             n_opt += 1
