@@ -476,8 +476,44 @@ def closed_loop_leg(dev, B=4096, T=200, seed=0):
             "dtype": "f64", "storage": "f32"}
 
 
+def self_launch(a):
+    """``python bench.py --gpus N`` with N > 1 and no launcher environment: this process starts the N ranks itself, as a CHILD
+    (``python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>``), before anything here has
+    imported torch or touched the GPU; it relays the child's output (rank 0's JSON line) and exit code, and fails if no line came
+    back.  Under torchrun (WORLD_SIZE set) it does nothing.  Returns the exit code, or None when there is nothing to launch."""
+    if a.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    import socket
+    import subprocess
+    with socket.socket() as sk:                                    # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    got_line = False
+    for line in proc.stdout:
+        got_line = got_line or line.startswith("{")
+        print(line, end="", flush=True)
+    rc = proc.wait()
+    if rc == 0 and not got_line:
+        print(f"bench.py: the {a.gpus} ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def emit(d, ws):
+    """rank 0's ONE JSON line; ``ranks_seen`` is the world size the process group reported, not the --gpus argument."""
+    d["ranks_seen"] = ws
+    print(json.dumps(d), flush=True)
+
+
 def main():
     a = parse()
+    rc = self_launch(a)
+    if rc is not None:
+        sys.exit(rc)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -501,8 +537,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    if a.gpus != ws and rank == 0 and ws > 1:
-        print(f"note: --gpus {a.gpus} but WORLD_SIZE {ws}; using WORLD_SIZE", file=sys.stderr)
+    if ws > 1:
+        ws = dist.get_world_size()                                 # what the process group saw, reported as n_gpus / ranks_seen
+    if a.gpus != ws and rank == 0:
+        print(f"note: --gpus {a.gpus} but the process group has {ws} rank(s); reporting {ws}", file=sys.stderr)
 
     B, K = a.agents, a.obstacles
     if a.workload == "mpc_cbf":
@@ -512,7 +550,7 @@ def main():
                     cpu_seconds=(6.0 if (ws == 1 and not a.no_cpu_baseline) else 0.0))
         elapsed = sharding.max_over_ranks(B * a.steps / r["value"], device=dev if backend == "nccl" else None)
         if rank == 0:
-            print(json.dumps({"metric": "QP solves/sec (batched agents)", "value": B * ws * a.steps / elapsed,
+            emit({"metric": "QP solves/sec (batched agents)", "value": B * ws * a.steps / elapsed,
                               "unit": "solves/s", "n_gpus": ws, "steps": a.steps, "warmup": a.warmup,
                               "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
                               "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -523,7 +561,7 @@ def main():
                                            "kernel": "mpccbf_kernel", "kernel_us": 1e3 * r["kernel_ms"],
                                            "note": "ALU/LDS-bound interior-point iterations; no VALU counter profile committed for this "
                                                    "configuration, HBM fraction reported for completeness"},
-                              "cpu_baseline": r.get("cpu_baseline"), "mpc": r}), flush=True)
+                              "cpu_baseline": r.get("cpu_baseline"), "mpc": r}, ws)
         if ws > 1:
             dist.destroy_process_group()
         return
@@ -653,7 +691,7 @@ def main():
         if ws == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(X.double().cpu().numpy(), ur.double().cpu().numpy(),
                                                ob.double().cpu().numpy(), a.cpu_seconds)
-        print(json.dumps(res), flush=True)
+        emit(res, ws)
     if ws > 1:
         dist.destroy_process_group()
 
@@ -721,7 +759,7 @@ def hetero_fleet_workload(a, dev, ws, rank, backend):
         su, sq = (res["u"][2], res["q"][2]) if od else (res["u"][1], res["q"][1])
         iu, iq = (res["u"][3], res["q"][3]) if od else (res["u"][2], res["q"][2])
         nbytes = ((16 + 8 + 8 + 7 * K * 4 + 8 + 4 + 4) + (48 + 16 + 12 + 7 * K * 4 + 16 + 4 + 4)) * (n_total // 2)
-        print(json.dumps({"metric": "QP solves/sec (batched agents)", "value": n_total * steps / elapsed, "unit": "solves/s",
+        emit({"metric": "QP solves/sec (batched agents)", "value": n_total * steps / elapsed, "unit": "solves/s",
                           "n_gpus": ws, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * elapsed / steps,
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                           "config": {"workload": (f"{n_total}-agent heterogeneous fleet (Unicycle2D + Quad3D), optimal-decay MPC-CBF "
@@ -737,7 +775,7 @@ def hetero_fleet_workload(a, dev, ws, rank, backend):
                                      "unicycle_mean_iterations": float(iu.double().mean().item()),
                                      "quad3d_mean_iterations": float(iq.double().mean().item())},
                           "roofline": hetero_roofline(od, n_total, ws, steps, elapsed, nbytes),
-                          "cpu_baseline": None}), flush=True)
+                          "cpu_baseline": None}, ws)
 
 
 def hetero_roofline(od, n_total, ws, steps, elapsed, nbytes):
@@ -815,7 +853,7 @@ def kb_c3bf_workload(a, dev, ws, rank, backend, collect=False, steps_override=No
                 "equal_shards": bool(ex.equal), "achieved_GBs": nb * steps / elapsed / 1e9}
     if rank == 0:
         nbytes = (16 + 8 + 7 * K * 4 + 8 + 4 + K * 4) * n_agents
-        print(json.dumps({"metric": "QP solves/sec (batched agents)", "value": n_agents * a.steps / elapsed, "unit": "solves/s",
+        emit({"metric": "QP solves/sec (batched agents)", "value": n_agents * a.steps / elapsed, "unit": "solves/s",
                           "n_gpus": ws, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                           "config": {"workload": "16384-agent KinematicBicycle2D C3BF, 16 nearest other agents as moving "
@@ -826,7 +864,7 @@ def kb_c3bf_workload(a, dev, ws, rank, backend, collect=False, steps_override=No
                                        "unit": "GB/s", "frac": nbytes * a.steps / elapsed / 1e9 / (HBM_PEAK_GBS * ws),
                                        "traffic": None, "kernel": "neighbor_kernel + cbfqp_coop_kernel",
                                        "algorithmic_bytes_per_solve": nbytes // n_agents},
-                          "cpu_baseline": None}), flush=True)
+                          "cpu_baseline": None}, ws)
 
 
 def sweep(ctl, dev, td, es, K):

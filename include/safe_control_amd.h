@@ -143,12 +143,13 @@ int sc_cbfqp_solve_batch_host(const sc_cbfqp_params* params, int64_t B, int32_t 
  * unsuccessful exit is SC_STATUS_INACCURATE.  oracle/mpc_cbf.py: solve is the float64 statement of the same steps.       */
 typedef struct sc_resto_params {
     double  rho;             /* l1 penalty of the elastic variables (IPOPT: 1000)                                    */
-    double  kappa;           /* return to the regular phase at violation <= kappa * violation(z_R) (0.1)           */
+    double  kappa;           /* first entry: back to the regular phase at violation <= kappa * violation(z_R) (0.1)           */
     double  theta_tol;       /* a converged restoration with l1 violation above this is SC_STATUS_INFEASIBLE (1e-6) */
-    double  tol;             /* KKT tolerance of the restoration problem itself (1e-4): theta has long settled by then */
+    double  tol;             /* KKT tolerance of the restoration problem (1e-2, in units of its objective rho * violation:
+                              * |grad violation| <= 1e-5); the certificate also needs violation > 10 * error / rho      */
     double  small_alpha;     /* the regular phase also hands over after small_iter consecutive accepted steps shorter  */
     int32_t small_iter;      /*   than small_alpha at an infeasible iterate (0.02, 4): IPOPT's alpha_min rule          */
-    int32_t max_entries;     /* restoration may be entered this many times per solve (3); 0 disables it             */
+    int32_t max_entries;     /* restoration may be entered this many times per solve (2); 0 disables it             */
 } sc_resto_params;
 
 typedef struct sc_mpccbf_params {

@@ -39,7 +39,7 @@ STATUS_INACCURATE = 2
 DEFAULTS = dict(N=10, dt=0.05, Q=(50.0, 50.0, 0.01, 30.0), R=(0.5, 0.5), alpha1=0.15, alpha2=0.15,
                 v_max=1.0, a_max=1.0, w_max=0.5, radius=0.25, beta=1.01,
                 tol=1e-6, acceptable_tol=1e-5, acceptable_iter=15, max_iter=100, mu_init=0.1, mu_min=1e-9,
-                resto_rho=1000.0, resto_kappa=0.1, resto_theta_tol=1e-6, resto_max=3, resto_tol=1e-4,
+                resto_rho=1000.0, resto_kappa=0.1, resto_theta_tol=1e-6, resto_max=2, resto_tol=1e-2,
                 resto_small_alpha=0.02, resto_small_iter=4)
 
 DUMMY_OBS = np.array([1000.0, 1000.0, 0.0, 0.0, 0.0, 0.0, 0.0])
@@ -302,7 +302,8 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     starts on the central path of the elastic rows (s, t from g and mu_R = max(mu, |violation|_inf)) with the box rows
     re-centred as at the start of the solve, and returns to the regular phase -- a fresh start at the current z with the
     barrier parameter it left with -- as soon as the violation theta(z) = sum max(0, -g_i) has dropped to resto_kappa *
-    theta(z_R).  If instead it CONVERGES (its own KKT error <= tol, or the acceptable rule) with theta > resto_theta_tol,
+    theta(z_R) (first entry; a later entry means the regular phase came back to the same stall, and runs until no violation
+    is left).  If instead it CONVERGES (its own KKT error <= tol, or the acceptable rule) with theta > resto_theta_tol,
     z is a stationary point of the violation: status INFEASIBLE is that certificate and u_0 of that minimiser is what
     is returned (what IPOPT reports as "converged to a point of local infeasibility").  At most resto_max entries.
     Both phases raise the merit penalty when a step is not a descent direction of the merit function (the penalty was
@@ -355,7 +356,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
         sf = SF_OFF if resto else sf0
         ev = evaluate(x0, z, u_prev, goal, obs, P, lam / sf, level=2)      # multipliers of the unscaled problem
         f, grad, W, g, J = sf * ev["f"], sf * ev["grad"], sf * ev["W"], ev["g"], ev["J"]
-        if resto and violation(g, m_el) <= kappa_R * theta_R:
+        if resto and violation(g, m_el) <= max(kappa_R * theta_R if n_resto == 1 else 0.0, theta_tol):
             # enough of the violation is gone: back to the regular phase from here (slacks kept, multipliers on the
             # central path of the regular barrier problem, merit penalty and best iterate reset)
             resto, mu, sf = False, mu_reg, sf0
@@ -380,12 +381,18 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
         err = e_opt
         if not resto and e_opt < e_best:                                    # remember the best iterate
             e_best, z_best = e_opt, z.copy()
-        if e_opt <= (P["resto_tol"] if resto else P["tol"]):
-            if resto:
-                # the restoration problem is solved and the violation is still there: a stationary point of the violation
-                status = STATUS_INFEASIBLE if violation(g, m_el) > theta_tol else STATUS_INACCURATE
-            else:
-                status = STATUS_OPTIMAL
+        if resto:
+            # A stationary point of the violation.  The restoration's KKT error is in units of its objective rho_R * theta, so
+            # |grad theta| <= e_opt / rho_R; over the input box (a few units across) theta cannot fall by more than ~10 e_opt /
+            # rho_R from here: the certificate asks for more violation than that.
+            theta = violation(g, m_el)
+            if e_opt <= P["resto_tol"] and theta > max(theta_tol, 10.0 * e_opt / rho_R):
+                status = STATUS_INFEASIBLE
+                break
+            if e_opt <= P["tol"]:                                           # solved, and (nearly) no violation left: nothing to certify
+                break
+        elif e_opt <= P["tol"]:
+            status = STATUS_OPTIMAL
             break
         n_acc = n_acc + 1 if e_opt <= P["acceptable_tol"] else 0          # IPOPT's acceptable_iter rule
         if n_acc >= P["acceptable_iter"]:

@@ -80,9 +80,9 @@ class RestoParams(C.Structure):
 
 
 def default_resto(**over):
-    """IPOPT's penalty (1000), return at a tenth of the violation, certificate threshold 1e-6, restoration tolerance 1e-4,
-    hand-over after 4 steps shorter than 0.02, at most three entries (oracle/mpc_cbf.py: DEFAULTS)."""
-    r = RestoParams(rho=1000.0, kappa=0.1, theta_tol=1e-6, tol=1e-4, small_alpha=0.02, small_iter=4, max_entries=3)
+    """IPOPT's penalty (1000), return at a tenth of the violation, certificate threshold 1e-6, restoration tolerance 1e-2 (in units of rho * violation),
+    hand-over after 4 steps shorter than 0.02, at most two entries (oracle/mpc_cbf.py: DEFAULTS)."""
+    r = RestoParams(rho=1000.0, kappa=0.1, theta_tol=1e-6, tol=1e-2, small_alpha=0.02, small_iter=4, max_entries=2)
     for k, v in over.items():
         setattr(r, k, v)
     return r

@@ -933,8 +933,9 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         if constexpr (RESTO) {
             for (int i = lane; i < c.mc; i += 64) theta += fmax(0.0, -W.g[i]);
             theta = wsum(theta);
-            if (resto && theta <= p.resto.kappa * theta_R) {
-                // enough of the violation is gone: a fresh start of the regular phase at this z with the barrier parameter it left with
+            if (resto && theta <= fmax(n_resto == 1 ? p.resto.kappa * theta_R : 0.0, p.resto.theta_tol)) {
+                // enough of the violation is gone (first entry: a tenth of it; later entries run until nothing is left -- the regular
+                // phase came back to the same stall): a fresh start of the regular phase at this z with the barrier parameter it left with
                 resto = false; mu = mu_reg;
                 for (int i = lane; i < m; i += 64) { const double s0 = fmax(W.g[i], 1e-2); W.sl[i] = s0; W.lam[i] = mu * rcp_(s0); }
                 for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
@@ -962,9 +963,14 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
                 e_best = e_opt;
                 for (int i = lane; i < n; i += 64) { W.zb[i] = W.z[i]; if constexpr (OD) W.rhob[i] = W.rho[i]; }
             }
-            if (e_opt <= (resto ? p.resto.tol : p.tol)) {
-                // restoration solved with the violation still there: a stationary point of the violation, the certificate
-                status = resto ? (theta > p.resto.theta_tol ? SC_STATUS_INFEASIBLE : SC_STATUS_INACCURATE) : SC_STATUS_OPTIMAL;
+            if (resto) {
+                // A stationary point of the violation.  The restoration's KKT error is in units of its objective rho theta, so |grad theta|
+                // <= e_opt / rho; over the input box (a few units across) theta cannot fall by more than ~10 e_opt / rho from here: the
+                // certificate asks for more violation than that.
+                if (e_opt <= p.resto.tol && theta > fmax(p.resto.theta_tol, 10.0 * e_opt / rho_R)) { status = SC_STATUS_INFEASIBLE; stop = true; break; }
+                if (e_opt <= p.tol) { stop = true; break; }                             // solved, and (nearly) no violation left: nothing to certify
+            } else if (e_opt <= p.tol) {
+                status = SC_STATUS_OPTIMAL;
                 stop = true; break;
             }
             // IPOPT's acceptable-point rule: acceptable_iter consecutive iterates within acceptable_tol end the solve (the

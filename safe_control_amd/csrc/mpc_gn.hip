@@ -831,8 +831,9 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         double theta = 0.0;                                               // l1 violation of the elastic (CBF) rows at z
         for (int i = lane; i < d.mc; i += 64) theta += fmax(0.0, -W.g[i]);
         theta = gsum(theta);
-        if (resto && theta <= p.resto.kappa * theta_R) {
-            // enough of the violation is gone: a fresh start of the regular phase at this z with the barrier parameter it left with
+        if (resto && theta <= fmax(n_resto == 1 ? p.resto.kappa * theta_R : 0.0, p.resto.theta_tol)) {
+            // enough of the violation is gone (first entry: a tenth of it; later entries run until nothing is left -- the regular
+            // phase came back to the same stall): a fresh start of the regular phase at this z with the barrier parameter it left with
             resto = false; mu = mu_reg;
             for (int i = lane; i < m; i += 64) { const double s0 = fmax(W.g[i], 1e-2); W.s[i] = s0; W.lam[i] = mu / s0; }
             for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
@@ -870,9 +871,14 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             e_best = e_opt;
             for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
         }
-        if (e_opt <= (resto ? p.resto.tol : p.tol)) {
-            // restoration solved with the violation still there: a stationary point of the violation, the certificate
-            status = resto ? (theta > p.resto.theta_tol ? SC_STATUS_INFEASIBLE : SC_STATUS_INACCURATE) : SC_STATUS_OPTIMAL;
+        if (resto) {
+            // A stationary point of the violation.  The restoration's KKT error is in units of its objective rho theta, so |grad theta|
+            // <= e_opt / rho; over the input box (a few units across) theta cannot fall by more than ~10 e_opt / rho from here: the
+            // certificate asks for more violation than that.
+            if (e_opt <= p.resto.tol && theta > fmax(p.resto.theta_tol, 10.0 * e_opt / rho_R)) { status = SC_STATUS_INFEASIBLE; break; }
+            if (e_opt <= p.tol) { break; }                             // solved, and (nearly) no violation left: nothing to certify
+        } else if (e_opt <= p.tol) {
+            status = SC_STATUS_OPTIMAL;
             break;
         }
         n_acc = e_opt <= p.acceptable_tol ? n_acc + 1 : 0;

@@ -211,7 +211,7 @@ class BatchedMPCCBF:
             u, status, iters, z = out
         p = make_params(self.robot_spec, self.cbf_param, self.Q, self.R, self.horizon, self.dt,
                         self.robot_spec["radius"], self.io_dtype, obs_shared=shared, tol=self.tol,
-                        max_iter=self.max_iter)
+                        max_iter=self.max_iter, resto=getattr(self, "resto", None))   # .resto: a _lib.RestoParams override
         stream = torch.cuda.current_stream(X.device).cuda_stream
         rc = self._lib.sc_mpccbf_solve_batch(
             C.byref(p), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(),

@@ -164,7 +164,7 @@ class BatchedGnMPCCBF:
         iters = torch.empty((B,), dtype=torch.int32, device=X.device)
         z = torch.empty((B, 2 * self.horizon), dtype=dt_, device=X.device) if want_z else None
         p = make_params(self.robot_spec, self._mc, self.cbf_param, self.horizon, self.dt, self.robot_spec["radius"],
-                        self.io_dtype, obs_shared=shared, tol=self.tol, max_iter=self.max_iter)
+                        self.io_dtype, obs_shared=shared, tol=self.tol, max_iter=self.max_iter, resto=getattr(self, "resto", None))
         stream = torch.cuda.current_stream(X.device).cuda_stream
         rc = self._lib.sc_mpcgn_solve_batch(
             C.byref(p), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(),

@@ -155,7 +155,7 @@ class BatchedLinearMPCCBF:
         iters = torch.empty((B,), dtype=torch.int32, device=X.device)
         z = torch.empty((B, nu * self.horizon), dtype=dt_, device=X.device) if want_z else None
         p = make_params(self._mdl, self.cbf_param, self.horizon, self.robot_spec["radius"], self.io_dtype,
-                        obs_shared=shared, tol=self.tol, max_iter=self.max_iter)
+                        obs_shared=shared, tol=self.tol, max_iter=self.max_iter, resto=getattr(self, "resto", None))
         stream = torch.cuda.current_stream(X.device).cuda_stream
         rc = self._lib.sc_mpclin_solve_batch(
             C.byref(p), self._blob(X.device).data_ptr(), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(),

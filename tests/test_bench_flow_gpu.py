@@ -60,3 +60,25 @@ def test_two_rank_heterogeneous_fleet_flow():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["agents_total"] == 1024
     assert d["config"]["unicycle_optimal_fraction"] > 0.8 and d["config"]["quad3d_optimal_fraction"] > 0.5
     assert d["value"] > 5e3
+
+
+def test_gpus_flag_starts_its_own_ranks():
+    """``python bench.py --gpus 2`` with no launcher around it (how a driver would call it): the parent starts the two ranks as a
+    child ``torch.distributed.run`` before touching the GPU, relays rank 0's line and exit code; the line says what the process
+    group saw.  (One GPU here, so the ranks share it and rendezvous over gloo.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SC_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak"
+    assert "collective_leg" in d and d["collective_leg"]["all_gather_bytes_per_step"] == 16384 * 16
+
+
+def test_a_failing_rank_fails_the_launch():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SC_BENCH_BACKEND"] = "no-such-backend"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0

@@ -1,0 +1,122 @@
+"""CPU: the feasibility-restoration phase of the MPC interior point (oracle/mpc_cbf.py: solve; the HIP kernels follow it step for
+step, tests/test_mpc_full_batch_gpu.py) and what STATUS_INFEASIBLE means since round 3.
+
+The reference hands the NLP to IPOPT (position_control/mpc_cbf.py:163,384), whose answer to an iterate it cannot improve is the
+restoration phase (Waechter & Biegler 2006, section 3.3); `status` is hard-wired to 'optimal' there (mpc_cbf.py:10), so what the
+loop flies on IS whatever that phase returns.  Here: INFEASIBLE is reported only when the restoration problem itself converged
+with a violation left -- a certificate of LOCAL infeasibility.  The test every batch below must pass: an independent phase-1
+(scipy L-BFGS-B on sum min(g_i, 0)^2 over the input box, from the solver's point, the initial guess and random starts, using
+nothing but the oracle's `evaluate`) finds NO feasible plan for any problem labelled infeasible.  Round 2's label failed exactly
+this test (C3BF bench draws 1, 6, 9; DynamicUnicycle2D draw 336)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+sys.path.insert(0, os.path.dirname(__file__))
+from _oracle_pool import family_problem  # noqa: E402
+
+from oracle import mpc_cbf as M  # noqa: E402
+from safe_control_amd import workloads as W  # noqa: E402
+
+
+def bench_batch(family, n):
+    """First n problems of the batch bench.py times for this family, rounded to f32 like its device arrays."""
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    X, up, goal, obs = (f32(a) for a in W.mpc_family_batch(family, 4096, 8, seed=0))
+    return X[:n], up[:n], goal[:n], obs[:n]
+
+
+def phase_one(x, up, goal, P, ev, info, starts=5, seed=1):
+    """Best min_i g_i over the CBF rows that an independent feasibility search reaches (>= -1e-9: a feasible plan exists)."""
+    obs, nz, N = info["obs"], info["z"].shape[0], P["N"]
+    if "u_hi" in P:
+        lo, hi = np.tile(np.asarray(P["u_lo"], float), N), np.tile(np.asarray(P["u_hi"], float), N)
+    else:
+        hi = np.tile([P["a_max"], P["w_max"]], N); lo = -hi
+    mc = N * obs.shape[0]
+
+    def fun(z):
+        e = ev(x, z, up, goal, obs, P, None, level=1)
+        v = np.minimum(e["g"][:mc], 0.0)
+        return float(v @ v), 2.0 * e["J"][:mc].T @ v
+    rng = np.random.default_rng(seed)
+    best = -np.inf
+    for z0 in [info["z"], np.clip(np.tile(up, N), lo, hi)] + [rng.uniform(lo, hi) for _ in range(starts - 2)]:
+        r = minimize(fun, np.clip(z0, lo, hi), jac=True, method="L-BFGS-B", bounds=list(zip(lo, hi)),
+                     options=dict(maxiter=300, ftol=1e-16, gtol=1e-12))
+        best = max(best, float(np.min(ev(x, r.x, up, goal, obs, P, None, level=0)["g"][:mc])))
+        if best >= -1e-9:
+            break
+    return best
+
+
+# family, first problem, number of problems (chunks keep a test under a minute and spread over xdist workers)
+CHUNKS = [("du", 0, 128), ("du", 128, 128), ("du", 256, 128), ("kb", 0, 96), ("c3bf", 0, 16), ("c3bf", 16, 16), ("dpcbf", 0, 16),
+          ("dpcbf", 16, 16), ("di", 0, 64), ("quad3d", 0, 64)]
+
+
+@pytest.mark.parametrize("family,first,count", CHUNKS)
+def test_no_feasible_plan_exists_for_a_problem_labelled_infeasible(family, first, count):
+    X, up, goal, obs = bench_batch(family, first + count)
+    n_inf = 0
+    for i in range(first, first + count):
+        P, ev = family_problem(family)
+        u, st, it, info = M.solve(X[i], up[i], goal[i], obs[i], params=P, return_info=True, evaluate_fn=ev)
+        assert st in (M.STATUS_OPTIMAL, M.STATUS_INFEASIBLE, M.STATUS_INACCURATE) and it <= P["max_iter"]
+        if st == M.STATUS_OPTIMAL:
+            assert info["theta"] <= 1e-6 and info["g"].min() >= -1e-6
+        if st == M.STATUS_INFEASIBLE:
+            n_inf += 1
+            assert info["n_resto"] >= 1 and info["in_resto"] and info["theta"] > P["resto_theta_tol"]
+            best = phase_one(X[i], up[i], goal[i], P, ev, info)
+            assert best < -1e-7, f"{family} draw {i}: labelled infeasible, but a plan with min g = {best:.2e} exists"
+    if family == "du" and first == 0:
+        assert n_inf >= 8                                   # config 3: about one draw in nine starts beside an obstacle it cannot avoid
+
+
+def test_the_draws_the_round_2_review_found_mislabelled():
+    """C3BF bench draws 1, 6 (strictly feasible plans exist) and 9, DynamicUnicycle2D draw 336 (feasible on the boundary): none of
+    them may be called infeasible any more."""
+    X, up, goal, obs = bench_batch("c3bf", 10)
+    for i in (1, 6, 9):
+        P, ev = family_problem("c3bf")
+        st = M.solve(X[i], up[i], goal[i], obs[i], params=P, evaluate_fn=ev)[1]
+        assert st != M.STATUS_INFEASIBLE, i
+    X, up, goal, obs = bench_batch("du", 337)
+    P, ev = family_problem("du")
+    u, st, it, info = M.solve(X[336], up[336], goal[336], obs[336], params=P, return_info=True, evaluate_fn=ev)
+    assert st != M.STATUS_INFEASIBLE and info["theta"] < 1e-4
+
+
+def test_restoration_returns_and_the_regular_phase_converges():
+    """A start the regular phase cannot leave on its own (review: 'solver quit after 2 iterations'): the restoration brings the
+    violation down, hands back, and the solve ends optimal."""
+    X, up, goal, obs = bench_batch("du", 400)
+    done = 0
+    for i in range(400):
+        P, ev = family_problem("du")
+        u, st, it, info = M.solve(X[i], up[i], goal[i], obs[i], params=P, return_info=True, evaluate_fn=ev)
+        if info["n_resto"] >= 1 and st == M.STATUS_OPTIMAL:
+            assert not info["in_resto"] and info["theta"] <= 1e-6 and info["err"] <= P["acceptable_tol"]
+            done += 1
+    assert done >= 1
+
+
+def test_restoration_minimises_the_violation_of_a_blocked_agent():
+    """An agent boxed in by a wall of circles it cannot brake for: the certificate comes with the minimiser of the l1 violation.
+    Its violation is no larger than that of the initial guess or of full braking, and the input box holds exactly."""
+    P, ev = family_problem("du")
+    x0 = np.array([0.0, 0.0, 0.0, 1.0])                        # 1 m/s towards a wall 0.6 m ahead
+    obs = np.array([[0.9, y, 0.3, 0, 0, 0, 0] for y in (-0.9, -0.45, 0.0, 0.45, 0.9)] + [M.DUMMY_OBS.tolist()] * 3)
+    u, st, it, info = M.solve(x0, np.zeros(2), np.array([5.0, 0.0]), obs, params=P, return_info=True, evaluate_fn=ev)
+    assert st == M.STATUS_INFEASIBLE and info["theta"] > 1e-3
+    ub = np.tile([P["a_max"], P["w_max"]], P["N"])
+    assert np.all(np.abs(info["z"]) <= ub + 1e-12)
+    mc = P["N"] * 8
+    viol = lambda z: float(np.sum(np.maximum(0.0, -ev(x0, z, np.zeros(2), np.array([5.0, 0.0]), info["obs"], P, None, level=0)["g"][:mc])))
+    brake = np.tile([-P["a_max"], 0.0], P["N"])
+    assert info["theta"] <= viol(np.zeros(2 * P["N"])) and info["theta"] <= viol(brake) + 1e-4   # (restoration tolerance: |grad theta| <= 1e-5)
+    assert u[0] < -0.5                                           # it brakes
