@@ -318,7 +318,8 @@ int sc_odmpccbf_solve_batch_host(const sc_odmpccbf_params* params, int64_t B, in
 /* ---- optimal-decay CBF-QP --------------------------------------
  * OptimalDecayCBFQP (position_control/optimal_decay_cbf_qp.py:13-158): decision variables u (2) and the
  * decay multipliers omega1, omega2 with penalties p_sb (omega - omega_ref)^2 (:72-76); ONE obstacle row
- *   rel-deg 2 (DU, KB):  A u + b + (alpha1+alpha2) omega1 h_dot + alpha1 alpha2 h omega2 >= 0   (:83-90)
+ *   rel-deg 2 (DU, KB, Quad2D):  A u + b + (alpha1+alpha2) omega1 h_dot + alpha1 alpha2 h omega2 >= 0   (:83-90,105-115;
+ *              Quad2D: X is [B,6], qp.state_dim = 6, box f_min <= u <= f_max in qp.u_min/u_max, qp.mass)
  *   rel-deg 1 (C3BF/DPCBF): A u + b + alpha h omega1 >= 0, no omega2 term                        (:99-104)
  * plus the input box.  `qp.alpha1/alpha2` carry the optimal-decay gains (0.5, :19-20).  The reference
  * copy is stale (it is handed a (k,7) array): here the obstacle is one 7-wide row per
@@ -330,7 +331,7 @@ typedef struct sc_odcbfqp_params {
     double p_sb[2];          /* cbf_param['p_sb1'], ['p_sb2'] = 1e4                                   */
 } sc_odcbfqp_params;
 
-/* X [B,4], u_ref [B,2], obs [B,7], has_obs [B] int32 or NULL (all present);
+/* X [B,4] ([B,6] for Quad2D), u_ref [B,2], obs [B,7], has_obs [B] int32 or NULL (all present);
  * u_out [B,2] (NaN if not optimal), omega_out [B,2] (omega2 = omega_ref[1] for rel-deg-1 models),
  * status_out [B], h_out [B] or NULL. */
 int sc_odcbfqp_solve_batch(const sc_odcbfqp_params* params, int64_t B,

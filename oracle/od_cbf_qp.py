@@ -8,10 +8,10 @@ obstacles while its barrier call expects one obstacle, so it cannot run as check
 
   variables   u (2), omega1, omega2                                            :57-60
   objective   ||u - u_ref||^2 + p_sb1 (omega1 - 1)^2 + p_sb2 (omega2 - 1)^2      :72-76  (p_sb = 1e4, :21-24)
-  rel-deg 2   A u + b + (a1 + a2) omega1 h_dot + a1 a2 h omega2 >= 0             :83-90  (DU, KB; a1 = a2 = .5)
+  rel-deg 2   A u + b + (a1 + a2) omega1 h_dot + a1 a2 h omega2 >= 0             :83-90,105-115  (DU, KB, Quad2D; a1 = a2 = .5)
               A = dh_dot_dx g, b = dh_dot_dx f                                   :141-146
   rel-deg 1   A u + b + alpha h omega1 >= 0, objective without the omega2 term   :65-70,99-104 (C3BF; alpha = .5)
-  bounds      |u0| <= a_max, |u1| <= w_max | beta_max                            :88-89,96-97
+  bounds      |u0| <= a_max, |u1| <= w_max | beta_max; Quad2D f_min <= u <= f_max   :88-89,96-97,110-113
   no obstacle A = b = h = h_dot = 0                                              :133-137
 
 Parity: pinned by uniqueness of the minimiser of a strictly convex QP (exact active-set enumeration

@@ -132,8 +132,10 @@ static int check_cbfqp(const sc_cbfqp_params* p, int64_t B, int32_t K, const voi
     if (B > 0 && (!X || !u_ref || !obs || !u_out || !status_out))
         return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
     const size_t es = p->io_dtype == SC_DTYPE_F64 ? 8 : 4;
-    if (misaligned(X, 16) || misaligned(u_ref, 2 * es) || misaligned(u_out, 2 * es))
-        return fail(SC_ERR_INVALID_ARGUMENT, "X must be 16-byte aligned, u_ref / u_out aligned to two elements (vector loads)");
+    // 4-state rows are read with vector loads (a row is 16 / 32 bytes, so every row slice of an aligned array qualifies); Quad2D's
+    // six-value rows are read element by element and only need element alignment (a [lo:] slice of an f32 array is 8-byte aligned)
+    if (misaligned(X, want_dim == 4 ? 16 : es) || misaligned(u_ref, 2 * es) || misaligned(u_out, 2 * es))
+        return fail(SC_ERR_INVALID_ARGUMENT, "X must be 16-byte aligned (Quad2D: element aligned), u_ref / u_out aligned to two elements (vector loads)");
     return SC_OK;
 }
 static int check_mpccbf(const sc_mpccbf_params* p, int64_t B, int32_t K, const void* X, const void* u_prev,
@@ -338,6 +340,7 @@ int sc_mpclin_solve_batch_host(const sc_mpclin_params* params, const double* mod
                                int32_t* iters_out, void* z_out, int device) {
     int rc = sc::check_mpclin(params, model, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
+    if (params->optimal_decay) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay = 1: call sc_odmpclin_solve_batch (device pointers)");
     if (B == 0) return SC_OK;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return sc::fail_hip(e, "hipSetDevice");
@@ -824,8 +827,8 @@ static int check_od(const sc_odcbfqp_params* p, int64_t B, const void* X, const 
     if (!p) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
     int rc = sc::check_cbfqp(&p->qp, B, 1, X, u_ref, obs, u_out, st);
     if (rc != SC_OK) return rc;
-    if (p->qp.model_id > SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF)
-        return sc::fail(SC_ERR_UNSUPPORTED, "optimal-decay CBF-QP is built for the unicycle / bicycle models");
+    if (p->qp.model_id > SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF && p->qp.model_id != SC_MODEL_QUAD2D)
+        return sc::fail(SC_ERR_UNSUPPORTED, "optimal-decay CBF-QP is built for the unicycle / bicycle models and Quad2D");
     if (!(p->p_sb[0] > 0) || !(p->p_sb[1] > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "p_sb must be > 0");
     if (B > 0 && !w_out) return sc::fail(SC_ERR_INVALID_ARGUMENT, "omega_out is NULL");
     return SC_OK;
@@ -853,7 +856,8 @@ int sc_odcbfqp_solve_batch_host(const sc_odcbfqp_params* params, int64_t B, cons
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return sc::fail_hip(e, "hipSetDevice");
     const size_t es = params->qp.io_dtype == SC_DTYPE_F64 ? 8 : 4;
-    const size_t nX = (size_t)B * 4 * es, nU = (size_t)B * 2 * es, nO = (size_t)B * 7 * es, nS = (size_t)B * 4, nH = (size_t)B * es;
+    const size_t nX = (size_t)B * (params->qp.model_id == SC_MODEL_QUAD2D ? 6 : 4) * es, nU = (size_t)B * 2 * es, nO = (size_t)B * 7 * es,
+                 nS = (size_t)B * 4, nH = (size_t)B * es;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t oX = 0, oU = oX + up(nX), oO = oU + up(nU), oN = oO + up(nO), oUo = oN + up(nS), oW = oUo + up(nU),
                  oS = oW + up(nU), oH = oS + up(nS), total = oH + up(nH);

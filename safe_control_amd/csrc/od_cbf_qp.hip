@@ -26,15 +26,21 @@ __global__ __launch_bounds__(256) void odcbfqp_kernel(const sc_odcbfqp_params p,
     const long long agent = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (agent >= B) return;
     using V2 = typename odv2<TIO>::type;
-    const V2* Xv = reinterpret_cast<const V2*>(X) + agent * 2;
-    const V2 xa = Xv[0], xb = Xv[1];
     const V2 ur = reinterpret_cast<const V2*>(u_ref)[agent];
     const CbfConsts<TC> k = make_consts<TC>(p.qp);
-    const Agent<TC> ag = make_agent<TC>(TC(xa.x), TC(xa.y), TC(xb.x), TC(xb.y));
+    Agent<TC> ag;
+    if constexpr (MODEL == SC_MODEL_QUAD2D) {                   // six states per row: [x, z, theta, vx, vz, theta_dot] (robots/quad2D.py:41-44)
+        const TIO* r = X + agent * 6;
+        ag = make_agent_m<TC, MODEL>(TC(r[0]), TC(r[1]), TC(r[2]), TC(r[3]), TC(r[4]));
+    } else {
+        const V2* Xv = reinterpret_cast<const V2*>(X) + agent * 2;
+        const V2 xa = Xv[0], xb = Xv[1];
+        ag = make_agent<TC>(TC(xa.x), TC(xa.y), TC(xb.x), TC(xb.y));
+    }
     const TC r0 = TC(ur.x), r1 = TC(ur.y);
     const TC wr1 = TC(p.omega_ref[0]), wr2 = TC(p.omega_ref[1]);
     const TC p1 = TC(p.p_sb[0]), p2 = TC(p.p_sb[1]);
-    constexpr bool REL2 = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D || MODEL == SC_MODEL_KINEMATIC_BICYCLE2D);
+    constexpr bool REL2 = (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D || MODEL == SC_MODEL_KINEMATIC_BICYCLE2D || MODEL == SC_MODEL_QUAD2D);
 
     // ---- the row: A = dh g, b = dh f (optimal_decay_cbf_qp.py:138-146), e1, e2 -------------------
     TC a0 = 0, a1 = 0, b = 0, e1 = 0, e2 = 0, h = 0;
@@ -44,7 +50,19 @@ __global__ __launch_bounds__(256) void odcbfqp_kernel(const sc_odcbfqp_params p,
         TC o[7];
 #pragma unroll
         for (int f = 0; f < 7; ++f) o[f] = TC(obs[agent * 7 + f]);
-        if constexpr (REL2) {
+        if constexpr (MODEL == SC_MODEL_QUAD2D) {
+            // optimal_decay_cbf_qp.py:38-45,105-115,141-146 over robots/quad2D.py:166-177 (circle, no flag test) and g of :68-81: both
+            // thrusts enter alike, A = dh_dot_dx g = [a, a], a = 2 (-ex sin th + ez cos th) / m; b = dh_dot_dx f = 2 |v|^2 - 2 g ez
+            const TC ex = ag.x - o[0], ez = ag.y - o[1];
+            const TC dmin = o[2] + k.R;
+            h = (ex * ex + ez * ez) - TC(1.01) * dmin * dmin;
+            const TC hdot = TC(2) * (ex * ag.f0 + ez * ag.f1);
+            a0 = (TC(2) * ex * (-ag.s) + TC(2) * ez * ag.c) * k.inv_mass;
+            a1 = a0;
+            b = TC(2) * ag.f0 * ag.f0 + TC(2) * ag.f1 * ag.f1 + TC(2) * ez * TC(-9.81);
+            e1 = k.g1 * hdot;
+            e2 = k.g2 * h;
+        } else if constexpr (REL2) {
             TC hdot, d[4];
             if constexpr (MODEL == SC_MODEL_DYNAMIC_UNICYCLE2D) {
                 if (o[6] == TC(0)) hocbf_circle(ag, o, k.R, TC(1.01), h, hdot, d);
@@ -142,6 +160,7 @@ static hipError_t od_launch_model(const sc_odcbfqp_params& p, long long B, const
         case SC_MODEL_DYNAMIC_UNICYCLE2D: SC_OD(SC_MODEL_DYNAMIC_UNICYCLE2D); break;
         case SC_MODEL_KINEMATIC_BICYCLE2D: SC_OD(SC_MODEL_KINEMATIC_BICYCLE2D); break;
         case SC_MODEL_KINEMATIC_BICYCLE2D_C3BF: SC_OD(SC_MODEL_KINEMATIC_BICYCLE2D_C3BF); break;
+        case SC_MODEL_QUAD2D: SC_OD(SC_MODEL_QUAD2D); break;
         default: SC_OD(SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF); break;
     }
 #undef SC_OD

@@ -26,7 +26,7 @@ class NotCompatibleError(Exception):
 
 def default_od_param(model):
     """optimal_decay_cbf_qp.py:17-50."""
-    if model in ("DynamicUnicycle2D", "KinematicBicycle2D"):
+    if model in ("DynamicUnicycle2D", "KinematicBicycle2D", "Quad2D"):        # :17-32, :38-45
         return dict(alpha1=0.5, alpha2=0.5, omega1=1.0, p_sb1=10 ** 4, omega2=1.0, p_sb2=10 ** 4)
     if model in ("KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"):
         return dict(alpha=0.5, omega1=1.0, p_sb1=10 ** 4)
@@ -58,7 +58,8 @@ class OptimalDecayCBFQP:
 
     def solve_control_problem(self, robot_state, control_ref, nearest_obs):
         u_ref = np.ascontiguousarray(np.asarray(control_ref["u_ref"], dtype=np.float64).reshape(-1))
-        X = np.ascontiguousarray(np.asarray(robot_state, dtype=np.float64).reshape(-1)[:4])
+        nx = 6 if self.robot_spec["model"] == "Quad2D" else 4
+        X = np.ascontiguousarray(np.asarray(robot_state, dtype=np.float64).reshape(-1)[:nx])
         has = np.array([0 if nearest_obs is None else 1], dtype=np.int32)
         obs = np.zeros(7)
         if nearest_obs is not None:
@@ -106,8 +107,9 @@ class BatchedOptimalDecayCBFQP:
             if not (t.is_cuda and t.is_contiguous() and t.dtype == dt_):
                 raise ValueError(f"{name} must be a contiguous CUDA tensor of dtype {dt_}")
         B = X.shape[0]
-        if X.shape != (B, 4) or u_ref.shape != (B, 2) or obs.shape != (B, 7):
-            raise ValueError("expected X[B,4], u_ref[B,2], obs[B,7]")
+        nx = 6 if self.robot_spec["model"] == "Quad2D" else 4
+        if X.shape != (B, nx) or u_ref.shape != (B, 2) or obs.shape != (B, 7):
+            raise ValueError(f"expected X[B,{nx}], u_ref[B,2], obs[B,7]")
         u = torch.empty((B, 2), dtype=dt_, device=X.device)
         w = torch.empty((B, 2), dtype=dt_, device=X.device)
         st = torch.empty((B,), dtype=torch.int32, device=X.device)
