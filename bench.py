@@ -100,27 +100,58 @@ VALU_PEAK_GIPS = 519.0   # measured sustained f64 VALU issue rate of the chip, G
                          # profiles/r02_valu_peak.txt: 0.507 G/s per SIMD at four waves per SIMD; 1024 SIMDs x 2.4 GHz / 4 = 614 on paper)
 
 
+def csrc_sha16():
+    """Hash of the kernel sources of this tree (tools/parse_profiles.py stores the same one with the counter profile)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "safe_control_amd", "csrc", "*.h*"))):
+        h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
+F64_VECTOR_PEAK_TFLOPS = 78.6                                   # MI355X data sheet, vector f64 (MI355X_MICROARCH.md)
+
+
 def valu_roofline(run, kernel_substr, kernel_ms, note=None):
     """VALU-issue roofline of an interior-point kernel: VALU wave-instructions per launch -- the SQ_INSTS_VALU counter of
     the same launch configuration, collected with rocprofv3 --pmc and committed under profiles/ (the count is a property
-    of the batch: same seed, same iterates) -- over this run's measured launch time, against the measured issue peak."""
-    for rnd in ("r02", "r01"):
+    of the batch: same seed, same iterates) -- over this run's measured launch time, against the measured issue peak.
+    Issue slots are not useful work (they count spill moves, DPP moves and idle lanes), so two more figures ride along when the
+    profile has them: lane utilisation = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU), and the f64 flops of the launch
+    (lanes x (2 FMA + ADD + MUL) + 512 per MFMA op) against the 78.6 TFLOP/s vector peak.  The profile is used only when it
+    was taken from the kernel sources of this tree (csrc hash); otherwise the entry says "stale"."""
+    for rnd in ("r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_counters.json")
         if not os.path.exists(path):
             continue
         try:
-            d = json.load(open(path)).get(run, {})
+            allc = json.load(open(path))
         except Exception:
             continue
+        d = allc.get(run, {})
+        meta = allc.get("_meta", {})
         for k, c in d.items():
-            if kernel_substr in k and "SQ_INSTS_VALU" in c:
+            name = k.replace("void sc::", "")
+            if (name == kernel_substr or kernel_substr in k) and "SQ_INSTS_VALU" in c:
                 insts = c["SQ_INSTS_VALU"]
                 ach = insts / (kernel_ms * 1e-3) / 1e9
                 out = {"bound": "valu_issue", "achieved": ach, "peak": VALU_PEAK_GIPS, "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GIPS,
-                       "traffic": None, "kernel": k.replace("void sc::", ""), "kernel_us": 1e3 * kernel_ms,
-                       "valu_instructions_per_launch": insts, "source": f"profiles/{rnd}_counters.json:{run}"}
+                       "traffic": None, "kernel": name, "kernel_us": 1e3 * kernel_ms,
+                       "valu_instructions_per_launch": insts, "source": f"profiles/{rnd}_counters.json:{run}",
+                       "stale": meta.get("csrc_sha16") != csrc_sha16()}
                 if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_ACTIVE_INST_LDS"):
                     out["lds_bank_conflict_fraction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_ACTIVE_INST_LDS"]
+                lane = allc.get(run.replace("_sq", "_lane"), {}).get(k)
+                flop = allc.get(run.replace("_sq", "_flop"), {}).get(k)
+                if lane and lane.get("SQ_ACTIVE_INST_VALU"):
+                    out["lane_utilisation"] = lane["SQ_THREAD_CYCLES_VALU"] / (64.0 * lane["SQ_ACTIVE_INST_VALU"])
+                if flop and "lane_utilisation" in out:
+                    vec = 2.0 * flop.get("SQ_INSTS_VALU_FMA_F64", 0.0) + flop.get("SQ_INSTS_VALU_ADD_F64", 0.0) + flop.get("SQ_INSTS_VALU_MUL_F64", 0.0)
+                    fl = 64.0 * out["lane_utilisation"] * vec + 512.0 * flop.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
+                    out["f64_flops_per_launch"] = fl
+                    out["f64_tflops"] = fl / (kernel_ms * 1e-3) / 1e12
+                    out["f64_vector_peak_frac"] = out["f64_tflops"] / F64_VECTOR_PEAK_TFLOPS
                 if note:
                     out["note"] = note
                 return out
@@ -180,7 +211,7 @@ def mpc_leg(dev, B, K, N, steps, warmup, seed=0, cpu_seconds=0.0):
     extra = {"cpu_baseline": mpc_cpu_baseline(Xn, goal, on, N, cpu_seconds)} if cpu_seconds > 0 else {}
     if (B, K, N, seed) == (4096, 8, 10, 0):
         rl = valu_roofline("mpc_sq", "mpccbf_kernel<10, 8>", ms, note="4096 problems = two rounds of 2048 resident waves; the launch ends with its "
-                           "slowest problem (max 67 interior-point iterations against a mean of 18)")
+                           "slowest problem (max 82 interior-point iterations, restoration included, against a mean of 19)")
         if rl:
             extra["roofline"] = rl
     return {**extra, "workload": f"{B}-agent batch DynamicUnicycle2D MPC-CBF, horizon N={N}, {K} obstacles (BASELINE configs[2])",
@@ -318,7 +349,7 @@ def manip_leg(dev, B=4096, K=3, steps=20, seed=0):
             "constrained_fraction": float(((u - tu).abs().amax(dim=1) > 1e-6).double().mean().item())}
 
 
-def backup_cbf_leg(dev, B=4096, steps=5, seed=0):
+def backup_cbf_leg(dev, B=4096, steps=5, seed=0, split=True):
     """Backup-CBF QP on the reference's evade scenario, on states OF ITS CLOSED LOOP: a fleet starts like the
     example (examples/evade/test_evade.py: robot at the hallway entrance, bullet behind it) with staggered start positions and
     bullet offsets, runs the example's loop for 30 .. 90 control steps on the device, and the timed launches solve the QP at the
@@ -365,10 +396,13 @@ def backup_cbf_leg(dev, B=4096, steps=5, seed=0):
            "using_backup_fraction": float((using != 0).double().mean().item())}
     for name, sel in (("solved", st == 0), ("fallback", st == 1)):
         n = int(sel.sum().item())
-        if n >= 64:
+        if split and n >= 64:
             ms_s, _, _ = timed(tX[sel].contiguous(), bx[sel].contiguous())
             out[f"{name}_only"] = {"agents": n, "kernel_ms": ms_s, "value": n / (ms_s * 1e-3), "unit": "solves/s"}
-    return with_roofline(out, "backupcbf_kernel")
+    rl = valu_roofline("backup_sq", "backupcbf_kernel", ms)         # tools/prof_backup.py: the same fleet, full-batch launches only
+    if rl is not None:
+        out["roofline"] = rl
+    return out
 
 
 def linear_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):

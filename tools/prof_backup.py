@@ -5,4 +5,4 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 B = int(sys.argv[1]); n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-print(bench.backup_cbf_leg(torch.device("cuda:0"), B=B, steps=n))
+print(bench.backup_cbf_leg(torch.device("cuda:0"), B=B, steps=n, split=False))
