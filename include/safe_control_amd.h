@@ -288,6 +288,24 @@ int sc_mpcgn_solve_batch_host(const sc_mpcgn_params* params, int64_t B, int32_t 
                               const void* X, const void* u_prev, const void* goal, const void* obs,
                               void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, int device);
 
+/* Optimal-decay MPC-CBF for the two models of optimal_decay_mpc_cbf.py:19 whose DT barrier steps the state with the
+ * robot's own step(): KinematicBicycle2D and Quad2D.  Two decay variables per stage (the reference's omega1 / omega2 inputs, :123-124)
+ * scale the DT-CBF gains of that stage's rows:  dd_h + (a1 rho1 + a2 rho2) d_h + a1 a2 rho1 rho2 h >= 0  (:291-297); cost + p_sb (rho -
+ * omega_ref)^2 per stage and variable (:181-186), input term R u^2 (:178-179, not do-mpc's delta-u penalty); weights KB Q =
+ * diag(50,50,1,1), R = (0.5, 50), gains 0.05; Quad2D as MPCCBF (:37-42,66-74).  The reference copy is stale (five 5-wide obstacle
+ * slots) and its solver stack absent: oracle-only parity (oracle/od_mpc_gn.py), obstacle rows as in sc_mpcgn_solve_batch.
+ * `mpc` is the sc_mpcgn_params of the model (alpha1 / alpha2 = the optimal-decay gains); no restoration phase (mpc.resto unused).
+ * rho_out [B, 2 * horizon] or NULL: the decay variables (rho1_0, rho2_0, rho1_1, ...).                                          */
+typedef struct sc_odmpcgn_params {
+    sc_mpcgn_params mpc;
+    double omega_ref[2];     /* cbf_param['omega1'], ['omega2'] = 1.0  (optimal_decay_mpc_cbf.py:88,90) */
+    double p_sb[2];          /* cbf_param['p_sb1'], ['p_sb2'] = 10     (:89,91)                          */
+} sc_odmpcgn_params;
+
+int sc_odmpcgn_solve_batch(const sc_odmpcgn_params* params, int64_t B, int32_t K,
+                           const void* X, const void* u_prev, const void* goal, const void* obs,
+                           void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
+
 /* ---- optimal-decay MPC-CBF ---------------------------------------
  * OptimalDecayMPCCBF (position_control/optimal_decay_mpc_cbf.py:15-330) for DynamicUnicycle2D: the MPC-CBF NLP with
  * two decay variables per stage (omega1_k, omega2_k, model inputs at :123-124) that scale the DT-CBF gains,

@@ -212,6 +212,9 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     K = obs.shape[0]
     Q, Rw, xb = mdl["Q"], mdl["R"], mdl["xb"]
     w0, w1, w2 = M.cbf_weights(P)
+    # optimal decay (oracle/od_mpc_gn.py): the row weights depend on the stage, the input term is R u^2
+    SW = np.asarray(P["stage_w"], dtype=np.float64) if P.get("stage_w") is not None else np.tile([w0, w1, w2], (N, 1))
+    r_on_u = P.get("rterm") == "u"
     xg = np.zeros(nx); xg[:2] = np.asarray(goal, dtype=np.float64)[:2]
     U = z.reshape(N, nu)
     der = level >= 1
@@ -241,7 +244,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
         e = X[k] - xg
         f += float(Q @ (e * e))
     up = np.concatenate([np.asarray(u_prev, dtype=np.float64)[:nu], z])
-    du = up[nu:] - up[:-nu]
+    du = z.copy() if r_on_u else up[nu:] - up[:-nu]
     Rd = np.tile(Rw, N)
     f += float(np.sum(Rd * du * du))
     hv = np.zeros((N, 3, K)); dh = np.zeros((N, 3, K, 2)); Hh = np.zeros((N, 3, K, 2, 2))
@@ -249,13 +252,12 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
         for p in range(3):
             for j in range(K):
                 hv[k, p, j], dh[k, p, j], Hh[k, p, j] = barrier(pts[k, p], obs[j], P)
-    wp = (w0, w1, w2)
     nb = len(xb)
     one_sided = any(not (np.isfinite(lo) and np.isfinite(hi)) for (_, lo, hi) in xb)    # VTOL2D: descent-speed floor only
     nbr = sum(int(np.isfinite(lo)) + int(np.isfinite(hi)) for (_, lo, hi) in xb) if one_sided else 2 * nb
     m = N * K + nbr * N + 2 * n
     g = np.zeros(m)
-    g[: N * K] = (w0 * hv[:, 0] + w1 * hv[:, 1] + w2 * hv[:, 2]).reshape(-1)
+    g[: N * K] = (SW[:, 0, None] * hv[:, 0] + SW[:, 1, None] * hv[:, 1] + SW[:, 2, None] * hv[:, 2]).reshape(-1)
     o = N * K
     for k in range(1, N + 1):
         for (idx, lo, hi) in xb:
@@ -270,18 +272,19 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
     hi_, lo_ = np.tile(mdl["u_hi"], N), np.tile(mdl["u_lo"], N)
     g[o:o + n] = hi_ - z
     g[o + n:] = z - lo_
-    out = dict(f=float(f), g=g, X=X, pts=pts.reshape(-1, 2))
+    out = dict(f=float(f), g=g, X=X, pts=pts.reshape(-1, 2), hv=hv)
     if level == 0:
         return out
     grad = np.zeros(n)
     for k in range(1, N + 1):
         grad += Phi[k].T @ (2.0 * Q * (X[k] - xg))
-    Dm = np.eye(n) - np.eye(n, k=-nu)
+    Dm = np.eye(n) if r_on_u else np.eye(n) - np.eye(n, k=-nu)
     grad += 2.0 * Dm.T @ (Rd * du)
     J = np.zeros((m, n))
+    JP = np.einsum("kpjd,kpdn->kpjn", dh, G)                               # gradient of h_j(point p of stage k) in z
     for k in range(N):
         for j in range(K):
-            J[k * K + j] = sum(wp[p] * (dh[k, p, j] @ G[k, p]) for p in range(3))
+            J[k * K + j] = sum(SW[k, p] * JP[k, p, j] for p in range(3))
     o = N * K
     for k in range(1, N + 1):
         for (idx, lo, hi) in xb:
@@ -295,7 +298,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
                 J[o] = Phi[k][idx]; o += 1
     J[o:o + n] = -np.eye(n)
     J[o + n:] = np.eye(n)
-    out.update(grad=grad, J=J)
+    out.update(grad=grad, J=J, JP=JP)
     if level == 1:
         return out
     lam = np.zeros(m) if lam is None else lam
@@ -305,7 +308,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
         W += 2.0 * Phi[k].T @ (Q[:, None] * Phi[k])
     for k in range(N):
         for p in range(3):
-            Om = -wp[p] * np.einsum("j,jab->ab", lc[k], Hh[k, p])
+            Om = -SW[k, p] * np.einsum("j,jab->ab", lc[k], Hh[k, p])
             W += G[k, p].T @ Om @ G[k, p]
     if P.get("exact_hessian", mdl.get("exact", True)):
         # second derivatives of the dynamics and of step o step, weighted by the costates of the Lagrangian
@@ -325,7 +328,7 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
                 pk = mu_k
                 continue
             A, S1x, S1u, S2x, y1 = jac[k]
-            nu_ = [-wp[p] * (lc[k] @ dh[k, p]) for p in range(3)]
+            nu_ = [-SW[k, p] * (lc[k] @ dh[k, p]) for p in range(3)]
             c1 = np.zeros(nx); c1[0:2] = nu_[1]
             c2 = np.zeros(nx); c2[0:2] = nu_[2]
             D = np.zeros((nx + nu, nx + nu)); D[:nx, :nx] = S1x; D[:nx, nx:] = S1u; D[nx:, nx:] = np.eye(nu)

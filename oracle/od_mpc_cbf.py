@@ -181,8 +181,10 @@ def block_eig(D):
     return vs, vw, ls + sh, lw + sh
 
 
-def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra="schur"):
-    """One optimal-decay MPC-CBF solve.  Returns u_0 (2,), rho_0 (2,), status, iterations [, info]."""
+def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra="schur", evaluate_fn=None):
+    """One optimal-decay MPC-CBF solve.  Returns u_0 (2,), rho_0 (2,), status, iterations [, info].
+    evaluate_fn: problem functions of another model with the same layout zz = (z | rho_0 .. rho_{N-1}), two decay variables
+    per stage (oracle/od_mpc_gn.py: KinematicBicycle2D, Quad2D); its input box comes in P["u_lo"], P["u_hi"]."""
     P = dict(DEFAULTS)
     if params:
         P.update(params)
@@ -190,11 +192,18 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
     n = 2 * N
     x0 = np.asarray(x0, dtype=np.float64)
     obs = np.asarray(obs, dtype=np.float64)
-    ub = np.tile([P["a_max"], P["w_max"]], N)
-    z = np.clip(np.tile(np.asarray(u_prev, dtype=np.float64), N), -0.99 * ub, 0.99 * ub)   # set_initial_guess
+    if evaluate_fn is not None:
+        evaluate = lambda x0_, zz_, goal_, obs_, P_, lam_=None, level=2: evaluate_fn(x0_, zz_, u_prev, goal_, obs_, P_, lam_, level)
+        lo_, hi_ = np.tile(np.asarray(P["u_lo"], dtype=np.float64), N), np.tile(np.asarray(P["u_hi"], dtype=np.float64), N)
+        z = np.clip(np.tile(np.asarray(u_prev, dtype=np.float64), N), lo_ + 0.005 * (hi_ - lo_), hi_ - 0.005 * (hi_ - lo_))
+    else:
+        evaluate = globals()["evaluate"]
+        ub = np.tile([P["a_max"], P["w_max"]], N)
+        z = np.clip(np.tile(np.asarray(u_prev, dtype=np.float64), N), -0.99 * ub, 0.99 * ub)   # set_initial_guess
     zz = np.concatenate([z, np.tile([P["omega1"], P["omega2"]], N)])
     ev = evaluate(x0, zz, goal, obs, P, None, level=1)
-    if np.any(obs[:, 6] >= 0.5):
+    circles_only = "model" in P and P["model"].get("circles_only", False)
+    if np.any(obs[:, 6] >= 0.5) and not circles_only:
         obs = M.barrier_scales(ev["pts"], obs, P)                          # steep (superellipsoid) barriers: IPOPT-style scaling
         if np.any(obs[:, 7] < 1.0):
             ev = evaluate(x0, zz, goal, obs, P, None, level=1)
@@ -284,11 +293,12 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
         phi0 = f - mu * np.sum(np.log(s)) + nu * srp
         dphi = dbar - nu * srp
         alpha, accepted = ap, False
+        noise_rows = P.get("row_noise", 0.0) * nu * float(np.sum(np.abs(g)))   # round-off of far dummy-obstacle rows (oracle/mpc_cbf.py)
         for _ in range(12):
             zt, st = zz + alpha * dzz, s + alpha * ds
             e0 = evaluate(x0, zt, goal, obs, P, level=0)
             phit = sf * e0["f"] - mu * np.sum(np.log(st)) + nu * np.sum(np.abs(e0["g"] - st))
-            if phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * abs(phi0):
+            if phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * abs(phi0) + noise_rows:
                 accepted = True
                 break
             alpha *= 0.5

@@ -15,6 +15,7 @@ from .position_control.mpc_cbf_gn import GnMPCCBF, BatchedGnMPCCBF  # noqa: F401
 from .position_control.backup_cbf_qp import BackupCBF, BatchedBackupCBF  # noqa: F401
 from .position_control.optimal_decay_cbf_qp import OptimalDecayCBFQP, BatchedOptimalDecayCBFQP  # noqa: F401
 from .position_control.optimal_decay_mpc_cbf import OptimalDecayMPCCBF, BatchedOptimalDecayMPCCBF  # noqa: F401
+from .position_control.optimal_decay_mpc_cbf_gn import OptimalDecayGnMPCCBF, BatchedOptimalDecayGnMPCCBF  # noqa: F401
 from .robots.spec import RobotHandle, complete_robot_spec  # noqa: F401
 from .tracking import BatchedTrackingController  # noqa: F401
 

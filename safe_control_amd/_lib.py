@@ -136,6 +136,11 @@ class MpcGnParams(C.Structure):
     ]
 
 
+class OdMpcGnParams(C.Structure):
+    """Mirror of ``sc_odmpcgn_params``."""
+    _fields_ = [("mpc", MpcGnParams), ("omega_ref", C.c_double * 2), ("p_sb", C.c_double * 2)]
+
+
 MANIP_MAX_ROWS = 250
 
 
@@ -189,6 +194,7 @@ SYMBOLS = {
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "sc_mpcgn_solve_batch": (C.c_int, [C.POINTER(MpcGnParams), C.c_int64, C.c_int32] + [C.c_void_p] * 9),
     "sc_mpcgn_solve_batch_host": (C.c_int, [C.POINTER(MpcGnParams), C.c_int64, C.c_int32] + [C.c_void_p] * 8 + [C.c_int]),
+    "sc_odmpcgn_solve_batch": (C.c_int, [C.POINTER(OdMpcGnParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_mpclin_model_doubles": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sc_mpclin_build_model": (C.c_int, [C.POINTER(MpcLinParams)] + [C.c_void_p] * 5),
     "sc_mpclin_solve_batch": (C.c_int, [C.POINTER(MpcLinParams), C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 9),

@@ -58,6 +58,9 @@ hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long lo
                          hipStream_t stream);
 
 size_t mpcgn_lds_bytes(int model_id, int N, int K, int circles_only);
+size_t odmpcgn_lds_bytes(int model_id, int N, int K);
+hipError_t odmpcgn_launch(const sc_odmpcgn_params& q, long long B, int K, const void* X, const void* u_prev, const void* goal,
+                          const void* obs, void* u_out, void* rho_out, int* status, int* iters, void* z_out, hipStream_t stream);
 hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
                         const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream);
 
@@ -250,6 +253,24 @@ int sc_mpcgn_solve_batch(const sc_mpcgn_params* params, int64_t B, int32_t K, co
     hipError_t e = sc::mpcgn_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out,
                                     (hipStream_t)stream);
     if (e != hipSuccess) return sc::fail_hip(e, "mpcgn kernel launch");
+    return SC_OK;
+}
+
+int sc_odmpcgn_solve_batch(const sc_odmpcgn_params* params, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,
+                           const void* obs, void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream) {
+    if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    sc::DeviceGuard on_device(stream, X);
+    int rc = sc::check_mpcgn(&params->mpc, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (params->mpc.model_id != SC_MODEL_KINEMATIC_BICYCLE2D && params->mpc.model_id != SC_MODEL_QUAD2D)
+        return sc::fail(SC_ERR_UNSUPPORTED, "optimal-decay MPC-CBF on this entry point: KinematicBicycle2D and Quad2D (DynamicUnicycle2D: sc_odmpccbf_solve_batch)");
+    if (!(params->p_sb[0] > 0) || !(params->p_sb[1] > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "p_sb must be > 0");
+    if (sc::odmpcgn_lds_bytes(params->mpc.model_id, params->mpc.horizon, K) > 160 * 1024)
+        return sc::fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::odmpcgn_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, rho_out, status_out, iters_out, z_out,
+                                      (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "odmpcgn kernel launch");
     return SC_OK;
 }
 

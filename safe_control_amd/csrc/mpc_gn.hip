@@ -358,6 +358,11 @@ struct GnMem {
     double *obs, *hk, *dh, *hh;                           // 7K | 3N K | 6N K | 9N K
     double *g, *s, *lam, *ds, *dlam, *vb;                 // m each
     double *tel;                                          // N K: elastic variables of the feasibility restoration (mpc_ipm_common.hpp)
+    // optimal decay (oracle/od_mpc_gn.py): two decay variables per stage
+    double *rho, *rhot, *drho, *rhob, *rr, *rdr;          // 2 N each: current, trial, step, best iterate; right-hand side and r_d of the decay variables
+    double *w0s, *w1s;                                    // N: stage weights of the rows (w2 = 1)
+    double *A1, *A2;                                      // N K: d row / d rho_1, d rho_2
+    double *Cod, *Dod;                                    // 12 N: point-space coupling C_k (6 x 2); 4 N: eigen form of D_k^-1 (vx, vy, 1/ls, 1/lw)
     double *Psi, *M, *L;                                  // 36 N | n n | (L: scratch in T)
     double *Hk;                                           // NH N: second-order terms of the dynamics per stage
 };
@@ -365,17 +370,17 @@ struct GnMem {
 struct GnDims { int N, K, n, m, mc, ms; bool circles; };
 
 // circles: the barrier Hessian of a circle is 2 I, so its per-point table (9 N K) is not stored
-__host__ __device__ inline size_t mpcgn_lds_doubles(int N, int K, int nx, int nb, bool circles, int nh = 2, int pd = 2, int np = 3) {
+__host__ __device__ inline size_t mpcgn_lds_doubles(int N, int K, int nx, int nb, bool circles, int nh = 2, int pd = 2, int np = 3, bool od = false) {
     const size_t n = 2 * (size_t)N, m = (size_t)N * K + 2 * (size_t)nb * N + 2 * n;
     const size_t rs = (size_t)pd * np, hs = (size_t)pd * (pd + 1) / 2;       // rows of a stage block (6 | 8), entries of a point Hessian (3 | 10)
     size_t tot = 12 + nx + 2 + 7 * n + (size_t)(N + 1) * nx + (size_t)(N + 1) * nx * n + 3 * rs * N + 2 * rs * N * n +
                  7 * (size_t)K + (size_t)np * (1 + pd + (circles ? 0 : hs)) * N * K + 5 * m + (size_t)N * K + rs * rs * N + n * n + (size_t)nh * N;
     const size_t need_l = n * (n + 1) + m, have = rs * N * n;                // Cholesky scratch L and the row vector vb live in T
-    return tot + (need_l > have ? need_l - have : 0);
+    return tot + (need_l > have ? need_l - have : 0) + (od ? 30 * (size_t)N + 2 * (size_t)N * K : 0);
 }
 
 template <int NX, int NH, int PD, int NP>
-__device__ inline GnMem carve_gn(double* b, const GnDims& d) {
+__device__ inline GnMem carve_gn(double* b, const GnDims& d, bool od = false) {
     GnMem W;
     auto take = [&](size_t c) { double* r = b; b += c; return r; };
     const int N = d.N, K = d.K, n = d.n, m = d.m;
@@ -392,15 +397,27 @@ __device__ inline GnMem carve_gn(double* b, const GnDims& d) {
     W.Hk = take((size_t)NH * N);
     W.T = take((size_t)RS * N * n); W.L = W.T;                     // T is dead once M is assembled
     W.vb = W.T + (size_t)n * (n + 1);                              // written before T is built and again after the solve
+    W.rho = W.rhot = W.drho = W.rhob = W.rr = W.rdr = W.w0s = W.w1s = W.A1 = W.A2 = W.Cod = W.Dod = nullptr;
+    if (od) {
+        b = W.T + ((size_t)RS * N * n > (size_t)n * (n + 1) + m ? (size_t)RS * N * n : (size_t)n * (n + 1) + m);   // past T | L | vb
+        W.rho = take(n); W.rhot = take(n); W.drho = take(n); W.rhob = take(n); W.rr = take(n); W.rdr = take(n);
+        W.w0s = take(N); W.w1s = take(N); W.A1 = take((size_t)N * K); W.A2 = take((size_t)N * K);
+        W.Cod = take((size_t)12 * N); W.Dod = take((size_t)4 * N);
+    }
     return W;
 }
 
-struct GnConst { double w0, w1, w2, Rrob, beta, blo, bhi; int circles_only; };
+struct GnConst {
+    double w0, w1, w2, Rrob, beta, blo, bhi;
+    int circles_only;
+    double al1, al2, ps1, ps2, rf1, rf2;                  // optimal decay: DT gains, decay penalties and references
+};
+struct GnOd { double omega_ref[2], p_sb[2]; };
 
 // rollout (+ sensitivities), f, barrier values (+ derivatives), g.  Point index: 3 k + p, p = 0 (a_k), 1 (b_k), 2 (c_k).
-template <int MODEL>
+template <int MODEL, bool OD = false>
 __device__ __forceinline__ double gn_eval(const double* zv, const GnMem& W, const GnDims& d, const GnConst& c, const GnPar& q,
-                                          int lane, bool derivs) {
+                                          int lane, bool derivs, const double* rhov = nullptr) {
     using Mdl = GnModel<MODEL>;
     constexpr int NX = Mdl::NX;
     const int N = d.N, K = d.K, n = d.n;
@@ -501,8 +518,17 @@ __device__ __forceinline__ double gn_eval(const double* zv, const GnMem& W, cons
     }
     for (int i = lane; i < n; i += 64) {
         const double prev = i >= 2 ? zv[i - 2] : W.up[i];
-        const double du = zv[i] - prev;
+        const double du = OD ? zv[i] : zv[i] - prev;                          // OD: R u^2 (optimal_decay_mpc_cbf.py:178-179)
         part += W.cq[6 + (i & 1)] * du * du;
+    }
+    if constexpr (OD) {
+        // stage weights of the rows  w1_k = s_k - 2,  w0_k = 1 - s_k + q_k  (w2 = 1)  and the decay penalty
+        for (int k = lane; k < N; k += 64) {
+            const double r1 = rhov[2 * k], r2 = rhov[2 * k + 1];
+            const double sk = c.al1 * r1 + c.al2 * r2, qk = c.al1 * c.al2 * r1 * r2;
+            W.w0s[k] = 1.0 - sk + qk; W.w1s[k] = sk - 2.0;
+            part += c.ps1 * (r1 - c.rf1) * (r1 - c.rf1) + c.ps2 * (r2 - c.rf2) * (r2 - c.rf2);
+        }
     }
     for (int e = lane; e < 3 * N * K; e += 64) {
         const int pt = e / K, j = e - pt * K;
@@ -519,7 +545,17 @@ __device__ __forceinline__ double gn_eval(const double* zv, const GnMem& W, cons
         double gi;
         if (i < d.mc) {
             const int k = i / K, j = i - k * K;
-            gi = c.w0 * W.hk[(3 * k) * K + j] + c.w1 * W.hk[(3 * k + 1) * K + j] + c.w2 * W.hk[(3 * k + 2) * K + j];
+            const double h0 = W.hk[(3 * k) * K + j], h1 = W.hk[(3 * k + 1) * K + j], h2 = W.hk[(3 * k + 2) * K + j];
+            if constexpr (OD) {
+                gi = W.w0s[k] * h0 + W.w1s[k] * h1 + h2;
+                if (derivs) {                                                 // d row / d rho_i = a_i (h1 - h0) + a1 a2 rho_other h0
+                    const double aa = c.al1 * c.al2 * h0;
+                    W.A1[i] = c.al1 * (h1 - h0) + aa * rhov[2 * k + 1];
+                    W.A2[i] = c.al2 * (h1 - h0) + aa * rhov[2 * k];
+                }
+            } else {
+                gi = c.w0 * h0 + c.w1 * h1 + c.w2 * h2;
+            }
         } else if (i < d.mc + d.ms) {
             const int r = i - d.mc, k = (r >> 1) + 1;
             const double xv = W.xs[k * NX + Mdl::BIDX];
@@ -538,8 +574,9 @@ __device__ __forceinline__ double gn_eval(const double* zv, const GnMem& W, cons
 }
 
 // out = J' v:  G' (A' v) + Phi' (speed rows) - v_hi + v_lo
-template <int MODEL>
-__device__ __forceinline__ void gn_jt(const double* v, double* out, const GnMem& W, const GnDims& d, const GnConst& c, int lane) {
+// OD, ycorr: the point-space vector C_k D_k^-1 rr_k is subtracted from A' v before the G' product (Schur correction of the right-hand side)
+template <int MODEL, bool OD = false>
+__device__ __forceinline__ void gn_jt(const double* v, double* out, const GnMem& W, const GnDims& d, const GnConst& c, int lane, bool ycorr = false) {
     using Mdl = GnModel<MODEL>;
     constexpr int NX = Mdl::NX;
     const int N = d.N, K = d.K, n = d.n;
@@ -547,7 +584,20 @@ __device__ __forceinline__ void gn_jt(const double* v, double* out, const GnMem&
         const int pt = e >> 1, dd = e & 1, k = pt / 3, p = pt - 3 * k;
         double acc = 0.0;
         for (int j = 0; j < K; ++j) acc += v[k * K + j] * W.dh[2 * (pt * K + j) + dd];
-        W.y[e] = (p == 0 ? c.w0 : (p == 1 ? c.w1 : c.w2)) * acc;
+        double yv;
+        if constexpr (OD) {
+            yv = (p == 0 ? W.w0s[k] : (p == 1 ? W.w1s[k] : 1.0)) * acc;
+            if (ycorr) {
+                const double* Cm = W.Cod + 12 * k + 2 * (2 * p + dd);
+                const double* Dk = W.Dod + 4 * k;
+                const double vx = Dk[0], vy = Dk[1];
+                const double ts = (vx * W.rr[2 * k] + vy * W.rr[2 * k + 1]) * Dk[2], tw = (-vy * W.rr[2 * k] + vx * W.rr[2 * k + 1]) * Dk[3];
+                yv -= (Cm[0] * vx + Cm[1] * vy) * ts + (-Cm[0] * vy + Cm[1] * vx) * tw;
+            }
+        } else {
+            yv = (p == 0 ? c.w0 : (p == 1 ? c.w1 : c.w2)) * acc;
+        }
+        W.y[e] = yv;
     }
     SC_SYNC();
     for (int i = lane; i < n; i += 64) {
@@ -713,16 +763,16 @@ __device__ __forceinline__ void gn_jt_state(const double* v, double* out, const 
     SC_SYNC();
 }
 
-template <int MODEL>
+template <int MODEL, bool OD = false>
 __device__ __forceinline__ double gn_eval_any(const double* zv, const GnMem& W, const GnDims& d, const GnConst& c, const GnPar& q,
-                                              int lane, bool derivs) {
+                                              int lane, bool derivs, const double* rhov = nullptr) {
     if constexpr (GnModel<MODEL>::PD == 4) return gn_eval_state<MODEL>(zv, W, d, c, q, lane, derivs);
-    else return gn_eval<MODEL>(zv, W, d, c, q, lane, derivs);
+    else return gn_eval<MODEL, OD>(zv, W, d, c, q, lane, derivs, rhov);
 }
-template <int MODEL>
-__device__ __forceinline__ void gn_jt_any(const double* v, double* out, const GnMem& W, const GnDims& d, const GnConst& c, int lane) {
+template <int MODEL, bool OD = false>
+__device__ __forceinline__ void gn_jt_any(const double* v, double* out, const GnMem& W, const GnDims& d, const GnConst& c, int lane, bool ycorr = false) {
     if constexpr (GnModel<MODEL>::PD == 4) gn_jt_state<MODEL>(v, out, W, d, c, lane);
-    else gn_jt<MODEL>(v, out, W, d, c, lane);
+    else gn_jt<MODEL, OD>(v, out, W, d, c, lane, ycorr);
 }
 
 #ifdef SC_GN_PROF
@@ -732,12 +782,16 @@ __device__ __forceinline__ void gn_jt_any(const double* v, double* out, const Gn
 #endif
 
 // NT > 0: compile-time horizon (register Cholesky of order 2 NT); 0: run-time horizon, LDS Cholesky.
-template <int MODEL, int NT>
-__global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, const long long B, const int K,
+// OD: optimal-decay MPC-CBF (position_control/optimal_decay_mpc_cbf.py; oracle/od_mpc_gn.py) for KinematicBicycle2D and Quad2D: two decay
+// variables per stage scale the DT-CBF gains of that stage's rows; their 2 x 2 blocks D_k are eliminated per stage in POINT space
+// (Psi_k <- Psi_k - C_k D_k^-1 C_k', the right-hand side likewise), so the condensed system keeps its order 2 N; the input term is R u^2;
+// no restoration phase (the optimal-decay oracle has none).
+template <int MODEL, int NT, bool OD = false>
+__global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, const GnOd od, const long long B, const int K,
                                                    const void* __restrict__ X, const void* __restrict__ u_prev,
                                                    const void* __restrict__ goal, const void* __restrict__ obs,
                                                    void* __restrict__ u_out, int* __restrict__ status_out,
-                                                   int* __restrict__ iters_out, void* __restrict__ z_out) {
+                                                   int* __restrict__ iters_out, void* __restrict__ z_out, void* __restrict__ rho_out) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     using Mdl = GnModel<MODEL>;
     constexpr int NX = Mdl::NX, NB = Mdl::NB;
@@ -752,7 +806,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
     d.N = NT > 0 ? NT : p.horizon; d.K = K; d.n = 2 * d.N; d.mc = d.N * K; d.ms = 2 * NB * d.N; d.m = d.mc + d.ms + 2 * d.n;
     d.circles = Mdl::PD == 2 && p.circles_only != 0;         // full-state barriers keep their 4 x 4 Hessians per point
     const int N = d.N, n = d.n, m = d.m;
-    const GnMem W = carve_gn<NX, Mdl::NH, Mdl::PD, Mdl::NP>(sm, d);
+    const GnMem W = carve_gn<NX, Mdl::NH, Mdl::PD, Mdl::NP>(sm, d, OD);
     GnConst c;
     {
         const double g1 = p.alpha1 + p.alpha2, g2 = p.alpha1 * p.alpha2;
@@ -760,6 +814,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         if constexpr (Mdl::PD == 4) { c.w0 = p.alpha1 - 1.0; c.w1 = 1.0; c.w2 = 0.0; }   // d_h + alpha h_k (mpc_cbf.py:312-315)
     }
     c.Rrob = p.robot_radius; c.beta = p.beta; c.circles_only = p.circles_only; c.blo = -p.v_max; c.bhi = p.v_max;
+    c.al1 = p.alpha1; c.al2 = p.alpha2; c.ps1 = od.p_sb[0]; c.ps2 = od.p_sb[1]; c.rf1 = od.omega_ref[0]; c.rf2 = od.omega_ref[1];
     GnPar q;
     q.dt = p.dt; q.Lr = p.rear_ax_dist; q.v_min = p.v_min; q.v_max = p.v_max; q.mass = p.mass; q.inertia = p.inertia; q.rad = p.robot_radius;
     if (lane < 6) W.cq[lane] = p.Q[lane];
@@ -775,6 +830,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
     for (int i = lane; i < n; i += 64) {                                   // set_initial_guess: u_prev, strictly inside the box
         const double lo = W.cq[8 + (i & 1)], hi = W.cq[10 + (i & 1)], pad = 0.005 * (hi - lo);
         W.z[i] = fmin(fmax(W.up[i & 1], lo + pad), hi - pad);
+        if constexpr (OD) { W.rho[i] = (i & 1) ? c.rf2 : c.rf1; W.rhob[i] = W.rho[i]; }   // decay variables start at their references
     }
     SC_SYNC();
 
@@ -788,18 +844,18 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
                     acc += W.Ph[(size_t)(k * NX + s_) * n + i] * (2.0 * W.cq[s_] * (W.xs[k * NX + s_] - W.xg[s_]));
             }
             const double prev = i >= 2 ? W.z[i - 2] : W.up[i];
-            acc += 2.0 * W.cq[6 + (i & 1)] * (W.z[i] - prev);
-            if (i + 2 < n) acc -= 2.0 * W.cq[6 + (i & 1)] * (W.z[i + 2] - W.z[i]);
+            acc += 2.0 * W.cq[6 + (i & 1)] * (OD ? W.z[i] : W.z[i] - prev);
+            if (!OD && i + 2 < n) acc -= 2.0 * W.cq[6 + (i & 1)] * (W.z[i + 2] - W.z[i]);
             W.gs[i] = sf * acc;
         }
         SC_SYNC();
     };
 
-    double f = gn_eval_any<MODEL>(W.z, W, d, c, q, lane, true);
+    double f = gn_eval_any<MODEL, OD>(W.z, W, d, c, q, lane, true, W.rho);
     // steep (superellipsoid) barriers: IPOPT-style gradient-based row scaling from the initial guess, then a fresh evaluation
     if (!c.circles_only &&
         ipm::scale_steep_barriers(W.obs, K, W.dh, 3 * N, lane, 64, [](double v) { return gmax_(v); }, [] { SC_SYNC(); }))
-        f = gn_eval_any<MODEL>(W.z, W, d, c, q, lane, true);
+        f = gn_eval_any<MODEL, OD>(W.z, W, d, c, q, lane, true, W.rho);
     grad_f(1.0);
     double gmx = 0.0;
     for (int i = lane; i < n; i += 64) gmx = fmax(gmx, fabs(W.gs[i]));
@@ -816,6 +872,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
     int n_acc = 0;
     const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
     // feasibility restoration (mpc_ipm_common.hpp; oracle/mpc_cbf.py: solve): wave-uniform state
+    constexpr bool RESTO = !OD;
     bool resto = false;
     int n_resto = 0, n_small = 0;                                       // n_small: consecutive tiny accepted steps at an infeasible z
     double theta_R = 0.0, mu_reg = mu;
@@ -826,7 +883,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
 #endif
     for (it = 1; it <= p.max_iter; ++it) {
         GP(11);
-        if (it > 1) f = gn_eval_any<MODEL>(W.z, W, d, c, q, lane, true);
+        if (it > 1) f = gn_eval_any<MODEL, OD>(W.z, W, d, c, q, lane, true, W.rho);
         GP(0);
         double theta = 0.0;                                               // l1 violation of the elastic (CBF) rows at z
         for (int i = lane; i < d.mc; i += 64) theta += fmax(0.0, -W.g[i]);
@@ -849,7 +906,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         } else {
             grad_f(sf);
         }
-        gn_jt_any<MODEL>(W.lam, W.rd, W, d, c, lane);
+        gn_jt_any<MODEL, OD>(W.lam, W.rd, W, d, c, lane);
         GP(1);
         // ---- second derivatives of the dynamics and of step o step, weighted by the costates of the Lagrangian (oracle:
         // evaluate, exact_hessian).  W.y still holds A' lam per point (= -nu).  Leaves two scalars per stage in W.Hk.
@@ -859,6 +916,16 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         GP(2);
         double e_d = 0.0, e_p = 0.0, e_c0 = 0.0, lmx = 0.0;
         for (int i = lane; i < n; i += 64) { const double r = W.gs[i] - W.rd[i]; W.rd[i] = r; e_d = fmax(e_d, fabs(r)); }
+        if constexpr (OD) {
+            for (int i = lane; i < n; i += 64) {                         // r_d of rho_{k,i} = sf 2 p_sb (rho - ref) - sum_j lam_kj A_i[kj]
+                const int k = i >> 1;
+                const double* Ai = (i & 1) ? W.A2 : W.A1;
+                double acc = sf * 2.0 * ((i & 1) ? c.ps2 : c.ps1) * (W.rho[i] - ((i & 1) ? c.rf2 : c.rf1));
+                for (int j = 0; j < K; ++j) acc -= W.lam[k * K + j] * Ai[k * K + j];
+                W.rdr[i] = acc;
+                e_d = fmax(e_d, fabs(acc));
+            }
+        }
         for (int i = lane; i < m; i += 64) {
             const double s = W.s[i], l = W.lam[i];
             double rp = W.g[i] - s;
@@ -869,7 +936,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         const double e_opt = fmax(e_d, fmax(e_p, e_c0));
         if (!resto && e_opt < e_best) {
             e_best = e_opt;
-            for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
+            for (int i = lane; i < n; i += 64) { W.zb[i] = W.z[i]; if constexpr (OD) W.rhob[i] = W.rho[i]; }
         }
         if (resto) {
             // A stationary point of the violation.  The restoration's KKT error is in units of its objective rho theta, so |grad theta|
@@ -887,7 +954,8 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             break;
         }
         if (!(e_opt < 1e300)) break;
-        bool want_resto = !resto && lmx > 1e10;                           // multipliers diverge: locally infeasible
+        bool want_resto = RESTO && !resto && lmx > 1e10;                  // multipliers diverge: locally infeasible
+        if (!RESTO && lmx > 1e10) { status = SC_STATUS_INFEASIBLE; break; }
         bool accepted = false;
         double alpha = 0.0, ad = 0.0;
         if (!want_resto) {
@@ -922,7 +990,50 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             }
         }
         SC_SYNC();
-        gn_jt_any<MODEL>(W.vb, W.rhs, W, d, c, lane);
+        if constexpr (OD) {
+            // decay blocks of the stages.  Row (k, j) in point space: v = [w0 dh_a; w1 dh_b; dh_c]; d row / d rho_i = A_i; its mixed second
+            // derivative  x_i = [(-a_i + a1 a2 rho_other) dh_a; a_i dh_b; 0].  C_k[r][i] = sum_j sig v_r A_i - lam x_i[r] (6 x 2),
+            // D_k = sf 2 p_sb + sum_j sig A A' - lam a1 a2 h_a [[0, 1], [1, 0]],  rr_k = -sf 2 p_sb (rho - ref) + sum_j vb A.
+            for (int e = lane; e < 17 * N; e += 64) {
+                const int k = e / 17, r = e - 17 * k;
+                const double r1 = W.rho[2 * k], r2 = W.rho[2 * k + 1];
+                double acc = 0.0;
+                for (int j = 0; j < K; ++j) {
+                    const int row = k * K + j;
+                    const double sig = W.ds[row], l = W.lam[row], a1v = W.A1[row], a2v = W.A2[row];
+                    if (r < 12) {
+                        const int pr = r >> 1, i = r & 1, pp = pr >> 1, dd = pr & 1;    // point-space component pr = 2 p + d, decay variable i
+                        const double dhv = W.dh[2 * ((3 * k + pp) * K + j) + dd];
+                        const double wv = pp == 0 ? W.w0s[k] : (pp == 1 ? W.w1s[k] : 1.0);
+                        const double ai = i == 0 ? c.al1 : c.al2, ro = i == 0 ? r2 : r1;
+                        const double xi = pp == 0 ? (-ai + c.al1 * c.al2 * ro) : (pp == 1 ? ai : 0.0);
+                        acc += sig * (wv * dhv) * (i == 0 ? a1v : a2v) - l * xi * dhv;
+                    } else if (r == 12) acc += sig * a1v * a1v;
+                    else if (r == 13) acc += sig * a1v * a2v - l * c.al1 * c.al2 * W.hk[(3 * k) * K + j];
+                    else if (r == 14) acc += sig * a2v * a2v;
+                    else if (r == 15) acc += W.vb[row] * a1v;
+                    else acc += W.vb[row] * a2v;
+                }
+                if (r < 12) W.Cod[12 * k + r] = acc;
+                else if (r < 15) W.pdz[3 * k + (r - 12)] = acc;                  // D11, D12, D22 (pdz: free until the solve)
+                else W.rr[2 * k + (r - 15)] = -sf * 2.0 * (r == 15 ? c.ps1 * (r1 - c.rf1) : c.ps2 * (r2 - c.rf2)) + acc;
+            }
+            SC_SYNC();
+            for (int k = lane; k < N; k += 64) {
+                // D_k^-1 in eigen form, shifted to positive definite (oracle/od_mpc_cbf.py: block_eig; csrc/mpc_cbf.hip: stage_pass)
+                const double d11 = sf * 2.0 * c.ps1 + W.pdz[3 * k], d12 = W.pdz[3 * k + 1], d22 = sf * 2.0 * c.ps2 + W.pdz[3 * k + 2];
+                const double tr = d11 + d22, df = d11 - d22, rad = sqrt(df * df + 4.0 * d12 * d12);
+                double ls = 0.5 * (tr + rad), lw = (d11 * d22 - d12 * d12) / ls;
+                double vx = df >= 0.0 ? df + rad : 2.0 * d12, vy = df >= 0.0 ? 2.0 * d12 : rad - df;
+                const double vn = vx * vx + vy * vy;
+                if (vn > 0.0) { const double rn = 1.0 / sqrt(vn); vx *= rn; vy *= rn; } else { vx = 1.0; vy = 0.0; }
+                const double sh = fmax(0.0, 1e-8 * fmax(1.0, fabs(d11) + fabs(d22)) - lw);
+                ls += sh; lw += sh;
+                W.Dod[4 * k] = vx; W.Dod[4 * k + 1] = vy; W.Dod[4 * k + 2] = 1.0 / ls; W.Dod[4 * k + 3] = 1.0 / lw;
+            }
+            SC_SYNC();
+        }
+        gn_jt_any<MODEL, OD>(W.vb, W.rhs, W, d, c, lane, true);
         for (int i = lane; i < n; i += 64) W.rhs[i] = -W.gs[i] + W.rhs[i];
         GP(3);
         // stage blocks Psi_k (6 x 6 over a_k, b_k, c_k): sum_j sig v v' (v = [w0 dh_a; w1 dh_b; w2 dh_c]) - sum_j lam w_p Hh_p
@@ -944,13 +1055,25 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         } else
         for (int e = lane; e < 36 * N; e += 64) {
             const int k = e / 36, r = (e - 36 * k) / 6, cc = e - 36 * k - 6 * r, pr = r >> 1, pc = cc >> 1;
-            const double wr = pr == 0 ? c.w0 : (pr == 1 ? c.w1 : c.w2), wc = pc == 0 ? c.w0 : (pc == 1 ? c.w1 : c.w2);
+            double wr = pr == 0 ? c.w0 : (pr == 1 ? c.w1 : c.w2), wc = pc == 0 ? c.w0 : (pc == 1 ? c.w1 : c.w2);
+            if constexpr (OD) {
+                wr = pr == 0 ? W.w0s[k] : (pr == 1 ? W.w1s[k] : 1.0);
+                wc = pc == 0 ? W.w0s[k] : (pc == 1 ? W.w1s[k] : 1.0);
+            }
             double acc = 0.0;
             for (int j = 0; j < K; ++j) {
                 const int row = k * K + j, er = (3 * k + pr) * K + j, ec = (3 * k + pc) * K + j;
                 const double l = W.lam[row], sig = W.ds[row];
                 acc += sig * (wr * W.dh[2 * er + (r & 1)]) * (wc * W.dh[2 * ec + (cc & 1)]);
                 if (pr == pc) acc -= l * wr * (d.circles ? ((r & 1) == (cc & 1) ? 2.0 : 0.0) : W.hh[3 * er + (r & 1) + (cc & 1)]);
+            }
+            if constexpr (OD) {                                             // Schur complement of the stage's decay block: - C D^-1 C'
+                const double* Cm = W.Cod + 12 * k;
+                const double* Dk = W.Dod + 4 * k;
+                const double vx = Dk[0], vy = Dk[1];
+                const double csr = Cm[2 * r] * vx + Cm[2 * r + 1] * vy, cwr = -Cm[2 * r] * vy + Cm[2 * r + 1] * vx;
+                const double csc = Cm[2 * cc] * vx + Cm[2 * cc + 1] * vy, cwc = -Cm[2 * cc] * vy + Cm[2 * cc + 1] * vx;
+                acc -= csr * csc * Dk[2] + cwr * cwc * Dk[3];
             }
             W.Psi[e] = acc;
         }
@@ -987,8 +1110,8 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             }
             acc *= 2.0;
             const double ri = W.cq[6 + (i & 1)];
-            if (i == j) acc += 2.0 * ri + (i + 2 < n ? 2.0 * ri : 0.0);
-            if (i == j + 2) acc -= 2.0 * ri;
+            if (i == j) acc += 2.0 * ri + ((!OD && i + 2 < n) ? 2.0 * ri : 0.0);   // OD: R u^2, no input-rate coupling
+            if (!OD && i == j + 2) acc -= 2.0 * ri;
             acc *= sfe;
             for (int r = 0; r < Mdl::PD * Mdl::NP * N; ++r) acc += W.G[(size_t)r * n + i] * W.T[(size_t)r * n + j];
             if constexpr (NB > 0) {
@@ -1041,6 +1164,22 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         double gdz = 0.0;
         for (int i = lane; i < n; i += 64) gdz += W.gs[i] * W.dz[i];
         SC_SYNC();
+        if constexpr (OD) {
+            // back-substitution of the decay variables:  d rho_k = D_k^-1 (rr_k - C_k' (G dz)_k)
+            for (int k = lane; k < N; k += 64) {
+                const double* Cm = W.Cod + 12 * k;
+                const double* Dk = W.Dod + 4 * k;
+                double t0 = W.rr[2 * k], t1 = W.rr[2 * k + 1];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) { const double pd = W.pdz[6 * k + r]; t0 -= Cm[2 * r] * pd; t1 -= Cm[2 * r + 1] * pd; }
+                const double vx = Dk[0], vy = Dk[1];
+                const double ps_ = (vx * t0 + vy * t1) * Dk[2], pw_ = (-vy * t0 + vx * t1) * Dk[3];
+                const double dr1 = vx * ps_ - vy * pw_, dr2 = vy * ps_ + vx * pw_;
+                W.drho[2 * k] = dr1; W.drho[2 * k + 1] = dr2;
+                gdz += sf * 2.0 * (c.ps1 * (W.rho[2 * k] - c.rf1) * dr1 + c.ps2 * (W.rho[2 * k + 1] - c.rf2) * dr2);   // sf grad_rho f . d rho
+            }
+            SC_SYNC();
+        }
         double rs_min = 0.0, rl_min = 0.0, sum_ds_s = 0.0, sum_rp = 0.0, sum_log = 0.0, sum_g = 0.0, sum_t = 0.0, sum_dt = 0.0;
         for (int i = lane; i < m; i += 64) {
             const double s = W.s[i], l = W.lam[i], sig = W.ds[i];
@@ -1062,9 +1201,11 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
 #pragma unroll
                 for (int pp = 0; pp < 3; ++pp) {
                     const int ep = (3 * k + pp) * K + j;
-                    const double wv = pp == 0 ? c.w0 : (pp == 1 ? c.w1 : c.w2);
+                    double wv = pp == 0 ? c.w0 : (pp == 1 ? c.w1 : c.w2);
+                    if constexpr (OD) wv = pp == 0 ? W.w0s[k] : (pp == 1 ? W.w1s[k] : 1.0);
                     jd += wv * (W.dh[2 * ep] * W.pdz[6 * k + 2 * pp] + W.dh[2 * ep + 1] * W.pdz[6 * k + 2 * pp + 1]);
                 }
+                if constexpr (OD) jd += W.A1[i] * W.drho[2 * k] + W.A2[i] * W.drho[2 * k + 1];
             } else if (i < d.mc + d.ms) {
                 const int r = i - d.mc, k = (r >> 1) + 1;
                 double acc = 0.0;
@@ -1124,9 +1265,12 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         GP(8);
         alpha = ap;
         for (int ls = 0; ls < 12; ++ls) {
-            for (int i = lane; i < n; i += 64) W.zt[i] = W.z[i] + alpha * W.dz[i];
+            for (int i = lane; i < n; i += 64) {
+                W.zt[i] = W.z[i] + alpha * W.dz[i];
+                if constexpr (OD) W.rhot[i] = W.rho[i] + alpha * W.drho[i];
+            }
             SC_SYNC();
-            const double ft = gn_eval_any<MODEL>(W.zt, W, d, c, q, lane, false);
+            const double ft = gn_eval_any<MODEL, OD>(W.zt, W, d, c, q, lane, false, W.rhot);
             double srp = 0.0, slog = 0.0, st_ = 0.0, proxt = 0.0;
             for (int i = lane; i < m; i += 64) {
                 const double s_t = W.s[i] + alpha * W.ds[i];
@@ -1150,9 +1294,9 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         }
         GP(9);
         if (!accepted) {
-            if (resto) break;
+            if (!RESTO || resto) break;
             want_resto = true;
-        } else if (!resto) {
+        } else if (RESTO && !resto) {
             // IPOPT hands over to the restoration when the step length falls below its alpha_min; here: small_iter consecutive
             // accepted steps shorter than small_alpha at an infeasible iterate (the accepted step is then not taken)
             n_small = (alpha < p.resto.small_alpha && theta > p.resto.theta_tol) ? n_small + 1 : 0;
@@ -1164,7 +1308,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             // precision limit) or once the restoration has been entered max_entries times
             if (e_best <= p.acceptable_tol || theta <= p.resto.theta_tol || n_resto >= p.resto.max_entries) break;
             SC_SYNC();
-            gn_eval_any<MODEL>(W.z, W, d, c, q, lane, false);               // W.g holds the last trial point's rows
+            gn_eval_any<MODEL, OD>(W.z, W, d, c, q, lane, false, W.rho);    // W.g holds the last trial point's rows
             resto = true; ++n_resto; n_small = 0; theta_R = theta; mu_reg = mu;
             double vmax = 0.0;
             for (int i = lane; i < d.mc; i += 64) vmax = fmax(vmax, -W.g[i]);
@@ -1181,7 +1325,10 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             SC_SYNC();
             continue;
         }
-        for (int i = lane; i < n; i += 64) W.z[i] = W.z[i] + alpha * W.dz[i];
+        for (int i = lane; i < n; i += 64) {
+            W.z[i] = W.z[i] + alpha * W.dz[i];
+            if constexpr (OD) W.rho[i] = W.rho[i] + alpha * W.drho[i];
+        }
         for (int i = lane; i < m; i += 64) {
             const double s = W.s[i] + alpha * W.ds[i];
             const double l0 = W.lam[i], dl = W.dlam[i];
@@ -1201,10 +1348,21 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
     if (it > p.max_iter) it = p.max_iter;
     if (status == SC_STATUS_INACCURATE && !resto && e_best <= p.acceptable_tol) {
         SC_SYNC();
-        for (int i = lane; i < n; i += 64) W.z[i] = W.zb[i];
+        for (int i = lane; i < n; i += 64) { W.z[i] = W.zb[i]; if constexpr (OD) W.rho[i] = W.rhob[i]; }
         status = SC_STATUS_OPTIMAL;
     }
     SC_SYNC();
+    if constexpr (OD) {
+        // optimal decay has no restoration phase: "infeasible" there still means "stopped at an infeasible iterate" (oracle/od_mpc_cbf.py)
+        gn_eval_any<MODEL, OD>(W.z, W, d, c, q, lane, false, W.rho);
+        if (status != SC_STATUS_OPTIMAL) {
+            double g_min = 1e300;
+            for (int i = lane; i < m; i += 64) g_min = fmin(g_min, W.g[i]);
+            g_min = gmin(g_min);
+            if (g_min < -1e-6) status = SC_STATUS_INFEASIBLE;
+        }
+        if (rho_out) for (int i = lane; i < n; i += 64) st(rho_out, prob * n + i, W.rho[i]);
+    }
     if (lane < 2) st(u_out, prob * 2 + lane, W.z[lane]);
     if (lane == 0) {
         status_out[prob] = status;
@@ -1217,22 +1375,23 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
 #endif
 }
 
-template <int MODEL>
+template <int MODEL, bool OD = false>
 static hipError_t mpcgn_launch_m(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
-                                 const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream) {
+                                 const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream,
+                                 const GnOd od = GnOd{{1.0, 1.0}, {0.0, 0.0}}, void* rho_out = nullptr) {
     const size_t lds = mpcgn_lds_doubles(p.horizon, K, GnModel<MODEL>::NX, GnModel<MODEL>::NB, GnModel<MODEL>::PD == 2 && p.circles_only != 0, GnModel<MODEL>::NH,
-                                         GnModel<MODEL>::PD, GnModel<MODEL>::NP) * sizeof(double);
+                                         GnModel<MODEL>::PD, GnModel<MODEL>::NP, OD) * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto launch = [&](auto kern) -> hipError_t {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out);
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, od, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, rho_out);
         return hipGetLastError();
     };
-    if (p.horizon == 10) return launch(mpcgn_kernel<MODEL, 10>);
-    return launch(mpcgn_kernel<MODEL, 0>);
+    if (p.horizon == 10) return launch(mpcgn_kernel<MODEL, 10, OD>);
+    return launch(mpcgn_kernel<MODEL, 0, OD>);
 }
 
 }  // namespace
@@ -1242,6 +1401,22 @@ size_t mpcgn_lds_bytes(int model_id, int N, int K, int circles_only) {
     const bool st = model_id == SC_MODEL_KINEMATIC_BICYCLE2D_C3BF || model_id == SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF;
     const bool kb = model_id == SC_MODEL_KINEMATIC_BICYCLE2D || st;
     return mpcgn_lds_doubles(N, K, nx, kb ? 1 : 0, !st && circles_only != 0, kb ? 10 : 2, st ? 4 : 2, st ? 2 : 3) * sizeof(double);
+}
+
+// optimal-decay MPC-CBF on the step()-barrier template: KinematicBicycle2D and Quad2D (optimal_decay_mpc_cbf.py:19)
+size_t odmpcgn_lds_bytes(int model_id, int N, int K) {
+    const bool kb = model_id == SC_MODEL_KINEMATIC_BICYCLE2D;
+    return mpcgn_lds_doubles(N, K, kb ? 4 : 6, kb ? 1 : 0, true, kb ? 10 : 2, 2, 3, true) * sizeof(double);
+}
+hipError_t odmpcgn_launch(const sc_odmpcgn_params& q, long long B, int K, const void* X, const void* u_prev, const void* goal,
+                          const void* obs, void* u_out, void* rho_out, int* status, int* iters, void* z_out, hipStream_t stream) {
+    GnOd od;
+    od.omega_ref[0] = q.omega_ref[0]; od.omega_ref[1] = q.omega_ref[1]; od.p_sb[0] = q.p_sb[0]; od.p_sb[1] = q.p_sb[1];
+    if (q.mpc.model_id == SC_MODEL_KINEMATIC_BICYCLE2D)
+        return mpcgn_launch_m<SC_MODEL_KINEMATIC_BICYCLE2D, true>(q.mpc, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, od, rho_out);
+    if (q.mpc.model_id == SC_MODEL_QUAD2D)
+        return mpcgn_launch_m<SC_MODEL_QUAD2D, true>(q.mpc, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, od, rho_out);
+    return hipErrorInvalidValue;
 }
 
 hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,

@@ -6,3 +6,4 @@ from .manipulator_cbf_qp import ManipulatorCBFQP, BatchedManipulatorCBFQP, Batch
 from .mpc_cbf_linear import LinearMPCCBF, BatchedLinearMPCCBF, BatchedOptimalDecayLinearMPCCBF  # noqa: F401
 from .mpc_cbf_gn import GnMPCCBF, BatchedGnMPCCBF  # noqa: F401
 from .backup_cbf_qp import BackupCBF, BatchedBackupCBF  # noqa: F401
+from .optimal_decay_mpc_cbf_gn import OptimalDecayGnMPCCBF, BatchedOptimalDecayGnMPCCBF  # noqa: F401

@@ -6,7 +6,8 @@
 nearest_obs)``, attributes ``status``, ``cbf_param`` (alpha1/alpha2, omega1/omega2, p_sb1/p_sb2), ``horizon``,
 ``Q``, ``R``, ``goal``, ``obs``, ``omega1``, ``omega2``.  The reference copy is stale (five
 5-wide obstacle slots, selected by a string `tracking.py` no longer lists): here obstacles are the 7-wide rows
-of MPCCBF and ``num_obs`` is a parameter (default 5 like the reference's five slots).  DynamicUnicycle2D only.
+of MPCCBF and ``num_obs`` is a parameter (default 5 like the reference's five slots).  DynamicUnicycle2D here;
+KinematicBicycle2D and Quad2D in optimal_decay_mpc_cbf_gn.py (same class name through ``__new__``).
 
 ``BatchedOptimalDecayMPCCBF`` solves B agents' NLPs in one launch.  No CPU fallback.
 """
@@ -28,8 +29,8 @@ def default_od_mpc_param(model, extension=False):
         return {"alpha1": 0.01, "alpha2": 0.01, "omega1": 1.0, "p_sb1": 10.0, "omega2": 1.0, "p_sb2": 10.0}
     if model == "Unicycle2D" and extension:
         return {"alpha": 0.05, "omega1": 1.0, "p_sb1": 10.0, "omega2": 1.0, "p_sb2": 10.0}
-    raise NotImplementedError(f"optimal-decay MPC-CBF on the batched engine supports DynamicUnicycle2D "
-                              f"(and Unicycle2D with extension=True), not {model}")
+    raise NotImplementedError(f"optimal-decay MPC-CBF on this kernel supports DynamicUnicycle2D (and Unicycle2D with extension=True); "
+                              f"KinematicBicycle2D / Quad2D: BatchedOptimalDecayGnMPCCBF; Quad3D: BatchedOptimalDecayLinearMPCCBF; not {model}")
 
 
 def make_od_mpc_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6,
@@ -46,6 +47,14 @@ def make_od_mpc_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtyp
 
 class OptimalDecayMPCCBF:
     """Drop-in for position_control.optimal_decay_mpc_cbf.OptimalDecayMPCCBF (single agent per call)."""
+
+    def __new__(cls, robot, robot_spec, *args, **kwargs):
+        # the reference serves every model of its accept list from this one class (:19); KinematicBicycle2D and Quad2D run on the
+        # step()-barrier kernel
+        if cls is OptimalDecayMPCCBF and robot_spec.get("model") in ("KinematicBicycle2D", "Quad2D"):
+            from .optimal_decay_mpc_cbf_gn import OptimalDecayGnMPCCBF
+            return OptimalDecayGnMPCCBF(robot, robot_spec, *args, **kwargs)
+        return super().__new__(cls)
 
     def __init__(self, robot, robot_spec, num_obs=5, device=0):
         self.robot = robot
