@@ -54,8 +54,7 @@ def phase_one(x, up, goal, P, ev, info, starts=5, seed=1):
 
 
 # family, first problem, number of problems (chunks keep a test under a minute and spread over xdist workers)
-CHUNKS = [("du", 0, 128), ("du", 128, 128), ("du", 256, 128), ("kb", 0, 96), ("c3bf", 0, 16), ("c3bf", 16, 16), ("dpcbf", 0, 16),
-          ("dpcbf", 16, 16), ("di", 0, 64), ("quad3d", 0, 64)]
+CHUNKS = [("du", 0, 96), ("du", 96, 96), ("kb", 0, 48), ("c3bf", 0, 12), ("dpcbf", 0, 12), ("di", 0, 32), ("quad3d", 0, 32)]
 
 
 @pytest.mark.parametrize("family,first,count", CHUNKS)
@@ -74,7 +73,7 @@ def test_no_feasible_plan_exists_for_a_problem_labelled_infeasible(family, first
             best = phase_one(X[i], up[i], goal[i], P, ev, info)
             assert best < -1e-7, f"{family} draw {i}: labelled infeasible, but a plan with min g = {best:.2e} exists"
     if family == "du" and first == 0:
-        assert n_inf >= 8                                   # config 3: about one draw in nine starts beside an obstacle it cannot avoid
+        assert n_inf >= 6                                   # config 3: about one draw in nine starts beside an obstacle it cannot avoid
 
 
 def test_the_draws_the_round_2_review_found_mislabelled():
@@ -92,17 +91,18 @@ def test_the_draws_the_round_2_review_found_mislabelled():
 
 
 def test_restoration_returns_and_the_regular_phase_converges():
-    """A start the regular phase cannot leave on its own (review: 'solver quit after 2 iterations'): the restoration brings the
-    violation down, hands back, and the solve ends optimal."""
-    X, up, goal, obs = bench_batch("du", 400)
-    done = 0
-    for i in range(400):
+    """Config-3 draws 186 and 786: four tiny steps in a row at an infeasible iterate hand over to the restoration (IPOPT's alpha_min
+    rule), which brings the violation down and hands back; the solve ends optimal and feasible."""
+    X, up, goal, obs = bench_batch("du", 787)
+    for i in (186, 786):
         P, ev = family_problem("du")
         u, st, it, info = M.solve(X[i], up[i], goal[i], obs[i], params=P, return_info=True, evaluate_fn=ev)
-        if info["n_resto"] >= 1 and st == M.STATUS_OPTIMAL:
-            assert not info["in_resto"] and info["theta"] <= 1e-6 and info["err"] <= P["acceptable_tol"]
-            done += 1
-    assert done >= 1
+        assert info["n_resto"] >= 1 and st == M.STATUS_OPTIMAL
+        assert not info["in_resto"] and info["theta"] <= 1e-6 and info["err"] <= P["acceptable_tol"]
+        off = dict(P, resto_max=0)                                  # the regular phase alone crawls to the same optimum, later
+        u0, st0, it0, info0 = M.solve(X[i], up[i], goal[i], obs[i], params=off, return_info=True, evaluate_fn=ev)
+        if st0 == M.STATUS_OPTIMAL:
+            assert abs(info0["f"] - info["f"]) <= 1e-6 * max(1.0, abs(info["f"]))
 
 
 def test_restoration_minimises_the_violation_of_a_blocked_agent():
