@@ -31,8 +31,10 @@
 #include "mpc_ipm_common.hpp"
 #include "mpc_hd4.hpp"
 
-// the superellipsoid powers: library pow() here (false); the multiply chain of mpc_lin.hip / mpc_cbf.hip (true) is a developer
-// switch only -- tests/test_mpcgn_gpu.py failed with it (kernel 8)
+// the superellipsoid powers: library pow() here (false).  The multiply chain of mpc_lin.hip / mpc_cbf.hip (true) stays a developer
+// switch: with ipm::pow3 inlined -- in its round-2 loop form AND in round 3's straight-line form -- the circles-only instantiations of
+// this kernel (Quad2D, KinematicBicycle2D at N = 10), which never execute that branch, return garbage (tests/test_mpcgn_gpu.py,
+// tests/test_odmpcgn_gpu.py fail within seconds); see mpc_ipm_common.hpp: CHAIN.
 #ifndef SC_GN_CHAIN
 #define SC_GN_CHAIN false
 #endif

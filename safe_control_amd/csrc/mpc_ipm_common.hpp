@@ -61,13 +61,20 @@ __device__ __forceinline__ void pow3(double x, double e, bool derivs, double& pe
     }
 }
 
-// CHAIN: integer exponents by multiply chain (pow3).  Off for mpc_gn.hip (developer switch SC_GN_CHAIN there): with pow3 inlined
-// as written -- multiply loop AND pow() fallback -- the Quad2D kernel, which never executes this branch (circles only), stops
-// every solve in its first iteration (garbage barrier values), at -O3 and -O2, with -ffp-contract=on / off, and with SGPR spills
-// sent to memory (there: a perturbed path instead); with either half of pow3 alone, or with pow3 noinline, it is bit-identical
-// to the pow() build (tools/diag_gn.py, round 2).  Rounding is ruled out; what is left is the code generated for the
-// lane-divergent loop-plus-call region.  tests/test_mpcgn_gpu.py guards the instantiation that is shipped,
-// tests/test_mpclin_gpu.py / test_mpccbf*_gpu.py / test_od_rd1_gpu.py the two kernels that use the chain.
+// CHAIN: integer exponents by the multiply chain of pow3, non-integer ones by pow().  History of a miscompile that is NOT root-caused:
+// rounds 1 - 2 wrote the chain as a `while (n)` square-and-multiply loop next to the pow() fallback.  With that form inlined the
+// Quad2D step()-barrier kernel -- which never executes this branch (circles only) -- stopped every solve in its first iteration
+// with garbage barrier values, at -O3 and -O2, with or without FMA contraction (mpc_gn.hip stays on pow() for it), and in round 3
+// an unrelated change of the LDS layout made mpclin_kernel<2, 2, 10, 0> (run-time obstacle count, circles only!) return wrong
+// solves for K = 6 while K = 8 and every other instantiation stayed right.  Writing the chain as SIX STRAIGHT-LINE select steps
+// (below) made mpc_lin.hip right again with the SAME layout -- so it is neither rounding nor an out-of-bounds access of ours --
+// but mpc_gn.hip's circles-only instantiations still break with the straight-line chain inlined (measured, round 3).  What is
+// established: the trigger is inlined code of the NEVER-EXECUTED superellipsoid branch (loop or not) next to the divergent pow()
+// call, in kernels at the edge of their register budget; pow3 noinline and the pow()-only build are right everywhere.  Guards:
+// tests/test_pow_chain_gpu.py solves superellipsoid scenes with integer exponents (chain, where a kernel uses it) and with
+// exponents a hair off an integer (pow()) through all three kernels and holds them together; every instantiation that ships is
+// under a parity test against the oracle, and tests/test_tracking_gpu.py::test_single_integrator_closed_loop_with_mpc is the
+// K = 6 case that caught the mpc_lin manifestation.
 template <bool CHAIN = false>
 __device__ inline void ipm_barrier(double px_, double py_, const double* o, double Rrob, double beta, bool circles_only, bool derivs,
                                    double& h, double& d0, double& d1, double& hxx, double& hxy, double& hyy) {
