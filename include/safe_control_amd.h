@@ -55,6 +55,9 @@ typedef enum sc_error {
 #define SC_STATUS_OPTIMAL      0
 #define SC_STATUS_INFEASIBLE   1   /* MPC-CBF: certified by a converged feasibility restoration (sc_resto_params) */
 #define SC_STATUS_INACCURATE   2   /* MPC-CBF only: stopped without convergence (iteration limit, line search)    */
+/* (-1 is used INSIDE sc_cbfqp_solve_batch between the two launches of its large-batch DynamicUnicycle2D path -- "pending: left to the
+ * generic pass" -- and is overwritten by the second launch; if that launch fails the call returns an error code and status_out,
+ * u_out and h_out are undefined, like after any failed call.)                                                                     */
 #define SC_STATUS_BAD_OBSTACLE 3   /* obstacle flag not 0/1 for a model that needs it
                                       (the reference raises inside agent_barrier,
                                       robots/dynamic_unicycle2D.py:133-136)            */

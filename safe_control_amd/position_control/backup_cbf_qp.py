@@ -45,7 +45,7 @@ def env_from_object(env):
                 bullet_length=float(env.bullet_length), bullet_width=float(env.bullet_width), bullet_start_x=float(env.bullet_start_x))
 
 
-def make_params(env, robot_spec, dt, backup_horizon, io_dtype, bullet_shared=True, alpha=1.0, alpha_terminal=2.0):
+def make_params(env, robot_spec, dt, backup_horizon, io_dtype, bullet_shared=True, alpha=1.0, alpha_terminal=2.0, kp=2.0, kd=2.0):
     p = _lib.BackupCbfParams()
     p.io_dtype = io_dtype
     p.n_steps = int(backup_horizon / dt)                          # backup_cbf_qp.py:55
@@ -56,7 +56,7 @@ def make_params(env, robot_spec, dt, backup_horizon, io_dtype, bullet_shared=Tru
     p.v_max = float(robot_spec.get("v_max", 1.5))                 # :533
     p.safety_margin = float(robot_spec.get("safety_margin", 0.0))  # :98-101
     p.alpha, p.alpha_terminal = float(alpha), float(alpha_terminal)
-    p.backup_kp, p.backup_kd = 2.0, 2.0                           # backup_controller.py:449-450
+    p.backup_kp, p.backup_kd = float(kp), float(kd)               # backup_controller.py:449-450 (2.0, 2.0)
     for k in ENV_KEYS:
         setattr(p, k, float(env[k]))
     return p
@@ -79,6 +79,7 @@ class BatchedBackupCBF:
         self.io_dtype = _lib.DTYPE_F32 if io_dtype in ("f32", "float32") else _lib.DTYPE_F64
         self.N = int(self.backup_horizon / self.dt)
         self.alpha, self.alpha_terminal = 1.0, 2.0                # backup_cbf_qp.py:93-94
+        self.kp, self.kd = 2.0, 2.0                               # EvadeBackupController's PD gains (backup_controller.py:449-450)
         self._lib = _lib.load()
 
     @property
@@ -107,7 +108,7 @@ class BatchedBackupCBF:
         n_rows = torch.zeros((B,), dtype=torch.int32, device=dev) if want_rows else None
         rows = torch.zeros((B, self.N, 3), dtype=torch.float64, device=dev) if want_rows else None
         p = make_params(self.env, self.robot_spec, self.dt, self.backup_horizon, self.io_dtype, bullet_shared=shared,
-                        alpha=self.alpha, alpha_terminal=self.alpha_terminal)
+                        alpha=self.alpha, alpha_terminal=self.alpha_terminal, kp=self.kp, kd=self.kd)
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = self._lib.sc_backupcbf_solve_batch(
             C.byref(p), B, X.data_ptr(), u_nom.data_ptr() if u_nom is not None else None, bullet_x.data_ptr(), u.data_ptr(),
@@ -129,7 +130,7 @@ class BatchedBackupCBF:
         using = torch.empty((B,), dtype=torch.int32, device=dev)
         h_min = torch.empty((B,), dtype=self.torch_dtype, device=dev)
         p = make_params(self.env, self.robot_spec, self.dt, self.backup_horizon, self.io_dtype, bullet_shared=False,
-                        alpha=self.alpha, alpha_terminal=self.alpha_terminal)
+                        alpha=self.alpha, alpha_terminal=self.alpha_terminal, kp=self.kp, kd=self.kd)
         stream = torch.cuda.current_stream(dev).cuda_stream
         rc = self._lib.sc_backupcbf_rollout_batch(C.byref(p), B, int(n_ctrl), int(step_offset), X.data_ptr(), bullet_x.data_ptr(),
                                                   u.data_ptr(), status.data_ptr(), using.data_ptr(), h_min.data_ptr(),
@@ -165,7 +166,16 @@ class BackupCBF:
         for attr in ("safe_center", "safe_bounds", "Kp", "Kd"):
             if not hasattr(backup_controller, attr):
                 raise NotImplementedError("the native Backup-CBF path serves EvadeBackupController (backup_controller.py:420)")
+        # What the kernel implements of that controller: PD gains Kp / Kd (passed through), the pocket and the goal zone OF THE
+        # ENVIRONMENT, one clamp a_max for the QP scaling and the backup input.  A controller set up differently would get silently
+        # different inputs, so it is refused instead.
+        a_spec = float(self.robot_spec.get("a_max", 2.0))
+        if abs(float(getattr(backup_controller, "a_max", a_spec)) - a_spec) > 1e-12:
+            raise NotImplementedError("backup controller a_max differs from robot_spec['a_max']: the kernel clamps both with one value")
+        if getattr(backup_controller, "goal_bounds", True) is None:
+            raise NotImplementedError("goal_bounds=None: the kernel always treats the goal zone of the environment as safe")
         self.backup_controller, self.backup_target = backup_controller, target
+        self._batched = None
 
     def set_environment(self, env):
         self.env = env
@@ -197,6 +207,12 @@ class BackupCBF:
         if self._batched is None:
             self._batched = BatchedBackupCBF(dict(self.robot_spec), env_from_object(self.env), self.dt, self.backup_horizon)
             self._batched.alpha, self._batched.alpha_terminal = self.alpha, self.alpha_terminal
+            self._batched.kp, self._batched.kd = float(self.backup_controller.Kp), float(self.backup_controller.Kd)
+            pc = np.asarray(self.backup_controller.safe_center, dtype=np.float64).flatten()
+            e = self._batched.env
+            want = np.array([0.5 * (e["pocket_x_min"] + e["pocket_x_max"]), 0.5 * (e["pocket_y_min"] + e["pocket_y_max"])])
+            if np.abs(pc[:2] - want).max() > 1e-9:
+                raise NotImplementedError("safe_center is not the centre of the environment's pocket: the kernel steers to the pocket of EvadeEnv")
         x = np.asarray(robot_state, dtype=np.float64).flatten()
         # the bullet as the obstacle predictor reports it at t = 0 (get_bullet_state: centre = bullet_x + length / 6)
         ob = self.moving_obstacles(0.0) if callable(self.moving_obstacles) else self.moving_obstacles

@@ -520,6 +520,52 @@ def test_full_size_properties(comp):
     assert np.mean(e <= (2e-6 if comp == "f64" else 1e-4)) >= (1.0 if comp == "f64" else 0.995)
 
 
+@pytest.mark.parametrize("ragged", [False, True])
+def test_two_launch_path_with_superellipsoids_mixed_into_waves(ragged, tmp_path):
+    """DynamicUnicycle2D, f64 arithmetic, B >= 2^18: a circles-only fast launch, then the generic body for the waves that saw an obstacle
+    flag != 0 (csrc/cbf_qp_kernel.hpp: cbfqp_reg_kernel<.., PASS>; between the two launches those agents carry the internal status
+    SC_STATUS_PENDING = -1, which must never reach the caller).  Superellipsoids sit in a third of the waves -- some alone in their
+    wave, some beside circles -- with and without ragged obstacle counts.  Held to (i) the single-launch kernel (SC_CBFQP_TWO_PASS=0,
+    run in a child process: the switch is read once per process) bit for bit and (ii) the C oracle on a sample."""
+    import os
+    import subprocess
+    import sys
+    B, K = (1 << 18) + 77, 8
+    rng = np.random.default_rng(5)
+    X, goal, u_ref, obs = W.du_cbfqp_batch(B, K, seed=5)
+    wave = np.arange(B) // 64
+    pick = (rng.random(B) < 0.35) & (wave % 3 == 0)                      # a third of the waves hold superellipsoids
+    for i in np.flatnonzero(pick):
+        k = int(rng.integers(K))
+        a, b = rng.uniform(0.3, 1.2, 2)
+        rho = rng.uniform(max(a, b) + 0.55, 4.5); phi = rng.uniform(-np.pi, np.pi)
+        obs[i, k] = [X[i, 0] + rho * np.cos(phi), X[i, 1] + rho * np.sin(phi), a, b, float(rng.choice([4, 6, 10])), rng.uniform(-np.pi, np.pi), 1.0]
+    n_obs = rng.integers(0, K + 1, B).astype(np.int32) if ragged else None
+    ug, sg, hg, (Xs, us, os_) = run_gpu(du_spec(), X, u_ref, obs, "f32", "f64", n_obs)
+    assert set(np.unique(sg)) <= {0, 1}                                  # no pending agent left behind
+    inp = tmp_path / "in.npz"; outp = tmp_path / "out.npz"
+    np.savez(inp, X=Xs.astype(np.float32), u=us.astype(np.float32), o=os_.astype(np.float32), n=(n_obs if ragged else np.zeros(0, np.int32)))
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); import safe_control_amd as sca\n"
+            "d = np.load(%r); ctl = sca.BatchedCBFQP(%r, dt=0.05, io_dtype='f32', compute_dtype='f64')\n"
+            "t = lambda a: torch.tensor(a, device='cuda:0')\n"
+            "n = t(d['n']) if d['n'].size else None\n"
+            "u, st, h = ctl.solve(t(d['X']), t(d['u']), t(d['o']), n)\n"
+            "np.savez(%r, u=u.cpu().numpy(), st=st.cpu().numpy(), h=h.cpu().numpy())\n") % (os.path.dirname(os.path.dirname(__file__)), str(inp), du_spec(), str(outp))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SC_CBFQP_TWO_PASS="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    one = np.load(outp)
+    assert np.array_equal(one["st"], sg)
+    assert np.array_equal(np.nan_to_num(one["u"].astype(np.float64), nan=7.0), np.nan_to_num(ug, nan=7.0))
+    assert np.array_equal(one["h"].astype(np.float64), hg)
+    idx = np.concatenate([np.flatnonzero(pick)[::97], np.arange(0, B, 1019)])
+    uo, so, ho = c_oracle.cbfqp_batch(R.MODEL_DU, Xs[idx], us[idx], os_[idx], oracle_spec(R.MODEL_DU, du_spec()), ocbf.default_cbf_param(R.MODEL_DU),
+                                      0.05, "cbf", None if n_obs is None else n_obs[idx])
+    agree = sg[idx] == so
+    assert agree.mean() > 0.995
+    ok = agree & (so == 0)
+    assert np.abs(ug[idx][ok] - uo[ok]).max() <= 2e-6
+
+
 def test_argument_errors():
     ctl = sca.BatchedCBFQP(du_spec())
     tX = torch.zeros((4, 4), device=DEV); tu = torch.zeros((4, 2), device=DEV)
