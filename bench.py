@@ -352,8 +352,8 @@ def manip_leg(dev, B=4096, K=3, steps=20, seed=0):
 def backup_cbf_leg(dev, B=4096, steps=5, seed=0, split=True):
     """Backup-CBF QP on the reference's evade scenario, on states OF ITS CLOSED LOOP: a fleet starts like the
     example (examples/evade/test_evade.py: robot at the hallway entrance, bullet behind it) with staggered start positions and
-    bullet offsets, runs the example's loop for 30 .. 90 control steps on the device, and the timed launches solve the QP at the
-    states it is in then (round 2 drew states uniformly over the hallway: three quarters of those QPs were infeasible and the
+    bullet offsets, runs the example's loop for 0 .. 560 control steps on the device (the example runs 600: the whole bullet cycle), and the
+    timed launches solve the QP at the states it is in then (round 2 drew states uniformly over the hallway: three quarters of those QPs were infeasible and the
     figure was mostly the fallback branch).  Per agent: a 120-state backup rollout with forward-difference sensitivities, <= 120
     rows, exact QP (csrc/backup_cbf.hip).  The solved and the fallback sub-batches are also timed on their own."""
     import numpy as np
@@ -361,17 +361,20 @@ def backup_cbf_leg(dev, B=4096, steps=5, seed=0, split=True):
     import safe_control_amd as sca
     rng = np.random.default_rng(seed)
     ctl = sca.BatchedBackupCBF(io_dtype="f32")
-    X = np.column_stack([rng.uniform(1.0, 12.0, B), rng.uniform(-0.8, 0.8, B), rng.uniform(0.0, 1.0, B), np.zeros(B)])
+    # the example's start (robot at x = 20, bullet 30 m behind it, examples/evade/test_evade.py) with a little spread; agent i then
+    # runs the example's loop for 40 * (i mod 15) control steps, so the fleet samples the whole bullet cycle of the 600-step run
+    X = np.column_stack([20.0 + rng.uniform(-2.0, 2.0, B), rng.uniform(-0.5, 0.5, B), np.zeros(B), np.zeros(B)])
     tX = torch.tensor(X, dtype=torch.float32, device=dev)
-    bx = torch.tensor(X[:, 0] - rng.uniform(8.0, 30.0, B), dtype=torch.float32, device=dev)
+    bx = torch.tensor(-10.0 + rng.uniform(-3.0, 3.0, B), dtype=torch.float32, device=dev)
     ret = torch.zeros(B, dtype=torch.int32, device=dev); rs = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    groups = 15
     done = 0
-    for n_ctrl, frac in ((30, 1.0), (30, 0.66), (30, 0.33)):           # a third of the fleet each stops after 30 / 60 / 90 steps
-        m = int(B * frac)
+    for g_ in range(1, groups):                                        # agents sorted by how long they run: the first m continue
+        m = (B * (groups - g_)) // groups
         sub = (tX[:m].contiguous(), bx[:m].contiguous(), ret[:m].contiguous(), rs[:m].contiguous())
-        ctl.rollout(*sub, n_ctrl, step_offset=done)
+        ctl.rollout(*sub, 40, step_offset=done)
         tX[:m], bx[:m], ret[:m], rs[:m] = sub
-        done += n_ctrl
+        done += 40
     alive = ret == 0
     tX, bx = tX[alive].contiguous(), bx[alive].contiguous()
     Bn = int(tX.shape[0])
@@ -387,7 +390,7 @@ def backup_cbf_leg(dev, B=4096, steps=5, seed=0, split=True):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / steps, st, using
     ms, st, using = timed(tX, bx)
-    out = {"workload": f"{Bn} DoubleIntegrator2D agents on states of the evade example's closed loop (30 - 90 control steps in), Backup-CBF "
+    out = {"workload": f"{Bn} DoubleIntegrator2D agents on states of the evade example's closed loop (0 - 560 control steps in), Backup-CBF "
                        "QP: 120 backup states, forward-difference sensitivities, <= 120 rows, 2 inputs",
            "value": Bn / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32", "agents": Bn,
            "qp_solved_fraction": float((st == 0).double().mean().item()),
