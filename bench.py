@@ -349,7 +349,7 @@ def manip_leg(dev, B=4096, K=3, steps=20, seed=0):
             "constrained_fraction": float(((u - tu).abs().amax(dim=1) > 1e-6).double().mean().item())}
 
 
-def backup_cbf_leg(dev, B=4096, steps=5, seed=0, split=True):
+def backup_cbf_leg(dev, B=4096, steps=5, seed=0, split=True, fleet=None):
     """Backup-CBF QP on the reference's evade scenario, on states OF ITS CLOSED LOOP: a fleet starts like the
     example (examples/evade/test_evade.py: robot at the hallway entrance, bullet behind it) with staggered start positions and
     bullet offsets, runs the example's loop for 0 .. 560 control steps on the device (the example runs 600: the whole bullet cycle), and the
@@ -361,23 +361,28 @@ def backup_cbf_leg(dev, B=4096, steps=5, seed=0, split=True):
     import safe_control_amd as sca
     rng = np.random.default_rng(seed)
     ctl = sca.BatchedBackupCBF(io_dtype="f32")
-    # the example's start (robot at x = 20, bullet 30 m behind it, examples/evade/test_evade.py) with a little spread; agent i then
-    # runs the example's loop for 40 * (i mod 15) control steps, so the fleet samples the whole bullet cycle of the 600-step run
-    X = np.column_stack([20.0 + rng.uniform(-2.0, 2.0, B), rng.uniform(-0.5, 0.5, B), np.zeros(B), np.zeros(B)])
-    tX = torch.tensor(X, dtype=torch.float32, device=dev)
-    bx = torch.tensor(-10.0 + rng.uniform(-3.0, 3.0, B), dtype=torch.float32, device=dev)
-    ret = torch.zeros(B, dtype=torch.int32, device=dev); rs = torch.full((B,), -1, dtype=torch.int32, device=dev)
-    groups = 15
-    done = 0
-    for g_ in range(1, groups):                                        # agents sorted by how long they run: the first m continue
-        m = (B * (groups - g_)) // groups
-        sub = (tX[:m].contiguous(), bx[:m].contiguous(), ret[:m].contiguous(), rs[:m].contiguous())
-        ctl.rollout(*sub, 40, step_offset=done)
-        tX[:m], bx[:m], ret[:m], rs[:m] = sub
-        done += 40
-    alive = ret == 0
-    tX, bx = tX[alive].contiguous(), bx[alive].contiguous()
+    if fleet is not None:                                              # tools/prof_backup.py: a fleet prepared outside the profiled process
+        tX, bx = fleet
+    else:
+        # the example's start (robot at x = 20, bullet 30 m behind it, examples/evade/test_evade.py) with a little spread; agent i then
+        # runs the example's loop for 40 * (i mod 15) control steps, so the fleet samples the whole bullet cycle of the 600-step run
+        X = np.column_stack([20.0 + rng.uniform(-2.0, 2.0, B), rng.uniform(-0.5, 0.5, B), np.zeros(B), np.zeros(B)])
+        tX = torch.tensor(X, dtype=torch.float32, device=dev)
+        bx = torch.tensor(-10.0 + rng.uniform(-3.0, 3.0, B), dtype=torch.float32, device=dev)
+        ret = torch.zeros(B, dtype=torch.int32, device=dev); rs = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        groups = 15
+        done = 0
+        for g_ in range(1, groups):                                        # agents sorted by how long they run: the first m continue
+            m = (B * (groups - g_)) // groups
+            sub = (tX[:m].contiguous(), bx[:m].contiguous(), ret[:m].contiguous(), rs[:m].contiguous())
+            ctl.rollout(*sub, 40, step_offset=done)
+            tX[:m], bx[:m], ret[:m], rs[:m] = sub
+            done += 40
+        alive = ret == 0
+        tX, bx = tX[alive].contiguous(), bx[alive].contiguous()
     Bn = int(tX.shape[0])
+    if steps == 0:
+        return tX, bx
 
     def timed(Xs, bs):
         u, st, using, hmin = ctl.solve(Xs, None, bs)
