@@ -352,6 +352,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     el = np.arange(m) < m_el
     Hq = P.get("quadratic_cost")                                            # linear models: f is exactly quadratic in z
     t_ = np.zeros(m)                                                        # elastic variables of the restoration (0 on hard rows)
+    sreset = int(P.get("slack_reset", 0))
     for it in range(1, P["max_iter"] + 1):
         sf = SF_OFF if resto else sf0
         ev = evaluate(x0, z, u_prev, goal, obs, P, lam / sf, level=2)      # multipliers of the unscaled problem
@@ -476,6 +477,12 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
                 zt, st = z + alpha * dz, s + alpha * ds
                 e0 = evaluate(x0, zt, u_prev, goal, obs, P, level=0)
                 n_eval += 1
+                if sreset and not resto:
+                    # slack reset (Byrd, Hribar & Nocedal 1999, section 3): for fixed z the merit function is separable in s and
+                    # -mu log s_i + nu |g_i - s_i| is smallest at s_i = max(g_i, mu / nu).  Mode 1 only raises slacks
+                    # (s = max(s, g): a row whose curvature beat its linearisation is not charged for it), mode 2 takes the minimiser
+                    gt = e0["g"]
+                    st = np.maximum(st, gt) if sreset == 1 else np.where(gt >= mu / nu, gt, st)
                 if resto:
                     tt = t_ + alpha * dt_
                     phit = 0.5 * zeta * float((zt - z_R) @ (zt - z_R)) + rho_R * float(np.sum(tt[el])) \
@@ -522,7 +529,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
             lam = mu / s
             nu, n_acc = 10.0, 0
             continue
-        z, s = z + alpha * dz, s + alpha * ds
+        z, s = z + alpha * dz, (st if sreset and not resto else s + alpha * ds)
         lam = lam + ad * dlam
         lam = np.minimum(np.maximum(lam, mu / (1e10 * s)), 1e10 * mu / s)   # IPOPT eq. (16) safeguard
         if resto:

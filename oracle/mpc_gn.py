@@ -315,15 +315,18 @@ def evaluate(x0, z, u_prev, goal, obs, P, lam=None, level=2):
         #   p_N = mu_N,  p_k = mu_k + (d points_k / d x_k)' nu + A_k' p_{k+1};   mu_k = 2 Q (x_k - xg) + bound multipliers,
         #   nu_p = -w_p sum_j lam_kj dh_j(point_p);   W += V_k' H_k V_k,  V_k = [Phi_k; E_k],
         #   H_k = H_F(x_k,u_k; p_{k+1}) + H_S(x_k,u_k; P'nu_1) + D' H_S(y1,u_k; P'nu_2) D + H_S(x_k,u_k; S2x' P'nu_2)
-        assert not one_sided, "exact Hessian: two-sided state bounds only"
-        ls = lam[N * K:N * K + 2 * nb * N].reshape(N, nb, 2) if nb else None
+        ls = lam[N * K:N * K + nbr * N].reshape(N, nbr) if nb else None     # per stage, rows in the order g lists them
         pk = np.zeros(nx)
         for k in range(N, -1, -1):
             mu_k = np.zeros(nx)
             if k >= 1:
                 mu_k = 2.0 * Q * (X[k] - xg)
-                for bi, (idx, lo, hi) in enumerate(xb):
-                    mu_k[idx] += ls[k - 1, bi, 0] - ls[k - 1, bi, 1]
+                o = 0
+                for (idx, lo, hi) in xb:
+                    if not one_sided or np.isfinite(hi):
+                        mu_k[idx] += ls[k - 1, o]; o += 1                  # row hi - x >= 0: -lam * d(row)/dx = +lam
+                    if not one_sided or np.isfinite(lo):
+                        mu_k[idx] -= ls[k - 1, o]; o += 1
             if k == N:
                 pk = mu_k
                 continue

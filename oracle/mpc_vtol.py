@@ -63,13 +63,69 @@ class Dual:
     def __pow__(self, p): return Dual(self.v ** p, p * self.v ** (p - 1) * self.d)
 
 
-def _sin(a): return Dual(math.sin(a.v), math.cos(a.v) * a.d) if isinstance(a, Dual) else math.sin(a)
-def _cos(a): return Dual(math.cos(a.v), -math.sin(a.v) * a.d) if isinstance(a, Dual) else math.cos(a)
-def _exp(a): return Dual(math.exp(a.v), math.exp(a.v) * a.d) if isinstance(a, Dual) else math.exp(a)
-def _sqrt(a): return Dual(math.sqrt(a.v), a.d / (2.0 * math.sqrt(a.v))) if isinstance(a, Dual) else math.sqrt(a)
+class Dual2:
+    """value + gradient + Hessian (forward mode, second order) over n directions: the exact-Hessian terms of the dynamics."""
+    __slots__ = ("v", "d", "H")
+    __array_ufunc__ = None
+
+    def __init__(self, v, d, H):
+        self.v, self.d, self.H = float(v), d, H
+
+    def _o(self, o):
+        return o if isinstance(o, Dual2) else Dual2(o, np.zeros_like(self.d), np.zeros_like(self.H))
+
+    def chain(self, f, f1, f2):
+        return Dual2(f, f1 * self.d, f1 * self.H + f2 * np.outer(self.d, self.d))
+
+    def __add__(self, o): o = self._o(o); return Dual2(self.v + o.v, self.d + o.d, self.H + o.H)
+    __radd__ = __add__
+    def __sub__(self, o): o = self._o(o); return Dual2(self.v - o.v, self.d - o.d, self.H - o.H)
+    def __rsub__(self, o): return self._o(o) - self
+    def __neg__(self): return Dual2(-self.v, -self.d, -self.H)
+
+    def __mul__(self, o):
+        o = self._o(o)
+        return Dual2(self.v * o.v, self.v * o.d + o.v * self.d, self.v * o.H + o.v * self.H + np.outer(self.d, o.d) + np.outer(o.d, self.d))
+    __rmul__ = __mul__
+
+    def recip(self):
+        r = 1.0 / self.v
+        return self.chain(r, -r * r, 2.0 * r * r * r)
+
+    def __truediv__(self, o): return self * self._o(o).recip()
+    def __rtruediv__(self, o): return self._o(o) * self.recip()
+    def __pow__(self, p): return self.chain(self.v ** p, p * self.v ** (p - 1), p * (p - 1) * self.v ** (p - 2))
+
+
+def _sin(a):
+    if isinstance(a, Dual2): return a.chain(math.sin(a.v), math.cos(a.v), -math.sin(a.v))
+    return Dual(math.sin(a.v), math.cos(a.v) * a.d) if isinstance(a, Dual) else math.sin(a)
+
+
+def _cos(a):
+    if isinstance(a, Dual2): return a.chain(math.cos(a.v), -math.sin(a.v), -math.cos(a.v))
+    return Dual(math.cos(a.v), -math.sin(a.v) * a.d) if isinstance(a, Dual) else math.cos(a)
+
+
+def _exp(a):
+    if isinstance(a, Dual2): e = math.exp(a.v); return a.chain(e, e, e)
+    return Dual(math.exp(a.v), math.exp(a.v) * a.d) if isinstance(a, Dual) else math.exp(a)
+
+
+def _sqrt(a):
+    if isinstance(a, Dual2): r = math.sqrt(a.v); return a.chain(r, 0.5 / r, -0.25 / (r * a.v))
+    return Dual(math.sqrt(a.v), a.d / (2.0 * math.sqrt(a.v))) if isinstance(a, Dual) else math.sqrt(a)
 
 
 def _atan2(y, x):
+    if isinstance(y, Dual2) or isinstance(x, Dual2):
+        ref = y if isinstance(y, Dual2) else x
+        y, x = ref._o(y), ref._o(x)
+        r2 = x.v * x.v + y.v * y.v
+        ty, tx = x.v / r2, -y.v / r2                            # d atan2 / dy, / dx
+        tyy, txx, txy = -2.0 * x.v * y.v / (r2 * r2), 2.0 * x.v * y.v / (r2 * r2), (y.v * y.v - x.v * x.v) / (r2 * r2)
+        H = ty * y.H + tx * x.H + tyy * np.outer(y.d, y.d) + txx * np.outer(x.d, x.d) + txy * (np.outer(y.d, x.d) + np.outer(x.d, y.d))
+        return Dual2(math.atan2(y.v, x.v), ty * y.d + tx * x.d, H)
     if isinstance(y, Dual) or isinstance(x, Dual):
         n = (y.d if isinstance(y, Dual) else x.d).shape[0]
         y, x = Dual.lift(y, n), Dual.lift(x, n)
@@ -155,17 +211,44 @@ def vt_S(x, u, spec, dt, jac=False):
     return (xn, r[1], r[2]) if jac else xn
 
 
+def vt_H(x, u, spec, dt, c, step=False):
+    """sum_i c_i * Hessian of F_i (or of step()'s i-th component: the pitch wrap has no derivative) in (x, u): 10 x 10."""
+    n = 10
+    Z = np.zeros((n, n))
+    xs = [Dual2(x[i], np.eye(n)[i], Z) for i in range(6)]
+    us = [Dual2(u[j], np.eye(n)[6 + j], Z) for j in range(4)]
+    f, gc = fg(xs, spec)
+    H = np.zeros((n, n))
+    for i in range(3, 6):                                       # rows 0..2 of F are linear in (x, u)
+        if c[i] == 0.0:
+            continue
+        acc = xs[0]._o(f[i])
+        for j in range(4):
+            acc = acc + gc[j][i - 3] * us[j]
+        H += c[i] * dt * acc.H
+    return H
+
+
 def vtol_model(spec=None, dt=0.05):
     s = default_spec(**(spec or {}))
     pm = s["pitch_max"] * 3.14159 / 180                        # mpc_cbf.py:232-233
-    return dict(name="VTOL2D", nx=6, nu=4, F=vt_F, S=vt_S, H=None, spec=s, dt=dt, Q=np.array([10.0, 10.0, 250.0, 10.0, 10.0, 50.0]),
+    return dict(name="VTOL2D", nx=6, nu=4, F=vt_F, S=vt_S, H=vt_H, spec=s, dt=dt, Q=np.array([10.0, 10.0, 250.0, 10.0, 10.0, 50.0]),
                 R=np.array([0.5, 0.5, 0.5, 50000.0]), alpha1=0.05, alpha2=0.05, beta=1.01, radius=s["radius"],
                 u_lo=np.array([s["throttle_min"]] * 3 + [s["elevator_min"]]), u_hi=np.array([s["throttle_max"]] * 3 + [s["elevator_max"]]),
-                xb=[(3, -s["v_max"], s["v_max"]), (4, -s["descent_speed_max"], np.inf), (2, -pm, pm)], circles_only=True, exact=False)
+                xb=[(3, -s["v_max"], s["v_max"]), (4, -s["descent_speed_max"], np.inf), (2, -pm, pm)], circles_only=True, exact=True)
+
+
+def params(N=30, spec=None, dt=0.05, **over):
+    """Solver parameters for VTOL2D: the exact Hessian (vt_H) and the slack reset of the line search are what make the shared interior
+    point converge on this model (tools/exp_vtol.py: 18-26 iterations on feasible cruise / hover / climb probes; with either one
+    missing, 100 iterations end at KKT errors of 1e-2 .. 1e+2)."""
+    from . import mpc_gn as G
+    P = G.params(vtol_model(spec, dt), N, exact_hessian=True, slack_reset=2)
+    P.update(over)
+    return P
 
 
 def solve(x0, u_prev, goal, obs, N=30, spec=None, dt=0.05, params_over=None, return_info=False):
     from . import mpc_gn as G
-    mdl = vtol_model(spec, dt)
-    P = G.params(mdl, N, **(params_over or {}))
+    P = params(N, spec, dt, **(params_over or {}))
     return M.solve(x0, u_prev, goal, obs, params=P, return_info=return_info, evaluate_fn=G.evaluate)

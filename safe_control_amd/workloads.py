@@ -117,7 +117,7 @@ def linear_mpc_batch(model="Quad3D", B=4096, K=8, seed=0, radius=0.25):
 
 
 MPC_FAMILIES = {"du": "DynamicUnicycle2D", "kb": "KinematicBicycle2D", "c3bf": "KinematicBicycle2D_C3BF", "dpcbf": "KinematicBicycle2D_DPCBF",
-                "di": "DoubleIntegrator2D", "quad2d": "Quad2D", "si": "SingleIntegrator2D", "quad3d": "Quad3D"}
+                "di": "DoubleIntegrator2D", "quad2d": "Quad2D", "si": "SingleIntegrator2D", "quad3d": "Quad3D", "vtol": "VTOL2D"}
 
 
 def mpc_family_batch(family, B=4096, K=8, seed=0):
@@ -126,6 +126,8 @@ def mpc_family_batch(family, B=4096, K=8, seed=0):
     the two linear models -- with the model's remaining states from default_rng(seed + 1): bicycles drive roughly towards their
     goal at 0.5 .. 3 m/s, DoubleIntegrator2D velocities in +-0.7 m/s, Quad2D near hover.  Returns float64 X, u_prev, goal, obs."""
     from .robots.spec import complete_robot_spec
+    if family == "vtol":
+        return vtol_mpc_batch(B, K, seed=seed)
     if family in ("si", "quad3d"):
         X, goal, obs = linear_mpc_batch(MPC_FAMILIES[family], B, K, seed=seed)
         return X, np.zeros((B, 4 if family == "quad3d" else 2)), goal, obs
@@ -145,6 +147,26 @@ def mpc_family_batch(family, B=4096, K=8, seed=0):
         X = np.zeros((B, 4)); X[:, 0:2] = Xd[:, 0:2]; X[:, 2:4] = rng.uniform(-0.7, 0.7, (B, 2))
     else:
         raise KeyError(family)
+    return X, up, goal, obs
+
+
+def vtol_mpc_batch(B=4096, K=8, seed=0):
+    """VTOL2D MPC-CBF batch (x-z plane; examples/test_vtol.py's flight regime scaled to where the first NLP is feasible): cruise at
+    8 .. 14 m/s, altitude 8 .. 12 m, pitch and pitch rate near zero, a goal 60 .. 120 m ahead within +-3 m of altitude, K discs of
+    radius 0.5 .. 2 m placed 60 .. 150 m away inside a +-30 degree cone ahead (the stage-0 DT-CBF row with alpha = 0.05 needs roughly
+    distance >= 4 x closing speed), previous input near trim.  Returns float64 X[B,6], u_prev[B,4], goal[B,2], obs[B,K,7]."""
+    rng = np.random.default_rng(seed)
+    X = np.zeros((B, 6))
+    X[:, 0] = rng.uniform(-5.0, 5.0, B); X[:, 1] = rng.uniform(8.0, 12.0, B)
+    X[:, 2] = rng.uniform(-0.05, 0.05, B); X[:, 3] = rng.uniform(8.0, 14.0, B)
+    X[:, 4] = rng.uniform(-1.0, 1.0, B); X[:, 5] = rng.uniform(-0.05, 0.05, B)
+    goal = np.stack([X[:, 0] + rng.uniform(60.0, 120.0, B), X[:, 1] + rng.uniform(-3.0, 3.0, B)], axis=1)
+    up = np.stack([rng.uniform(0.4, 0.6, B), rng.uniform(0.4, 0.6, B), rng.uniform(0.2, 0.5, B), rng.uniform(-0.02, 0.02, B)], axis=1)
+    d = rng.uniform(60.0, 150.0, (B, K)); phi = rng.uniform(-np.pi / 6, np.pi / 6, (B, K))
+    obs = np.zeros((B, K, 7))
+    obs[..., 0] = X[:, None, 0] + d * np.cos(phi)
+    obs[..., 1] = X[:, None, 1] + d * np.sin(phi)
+    obs[..., 2] = rng.uniform(0.5, 2.0, (B, K))
     return X, up, goal, obs
 
 

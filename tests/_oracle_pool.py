@@ -42,6 +42,9 @@ def family_problem(family, N=10, over=None):
     if family in ("kb", "di", "quad2d"):
         mdl = {"kb": G.kb_model, "di": G.di_model, "quad2d": G.quad2d_model}[family]()
         return G.params(mdl, N, **over), G.evaluate
+    if family == "vtol":
+        from oracle import mpc_vtol as V
+        return V.params(N=30 if N == 10 else N, **over), G.evaluate      # the reference's VTOL2D horizon is 30
     if family in ("c3bf", "dpcbf"):
         mdl = S.c3bf_model() if family == "c3bf" else S.dpcbf_model()
         P = S.params(mdl, N, **over); P["model"] = dict(mdl, circles_only=True); return P, S.evaluate
@@ -56,7 +59,7 @@ def _worker_family(d, outp):
     fam = str(d["kind"])[4:]
     X, up, goal, obs = d["X"], d["up"], d["goal"], d["obs"]
     over = d["params"].item() if "params" in d.files else {}
-    N = over.pop("N", 10) if isinstance(over, dict) else 10
+    N = over.pop("N", 30 if fam == "vtol" else 10) if isinstance(over, dict) else 10
     B = X.shape[0]
     nu = up.shape[1]
     u = np.zeros((B, nu)); st = np.zeros(B, dtype=np.int64); it = np.zeros(B, dtype=np.int64); z = np.zeros((B, nu * N))
