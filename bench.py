@@ -141,7 +141,9 @@ def valu_roofline(run, kernel_substr, kernel_ms, note=None):
                        "valu_instructions_per_launch": insts, "source": f"profiles/{rnd}_counters.json:{run}",
                        "stale": meta.get("csrc_sha16") != csrc_sha16()}
                 if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_ACTIVE_INST_LDS"):
-                    out["lds_bank_conflict_fraction"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_ACTIVE_INST_LDS"]
+                    r_ = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_ACTIVE_INST_LDS"]
+                    if r_ <= 1.0:                                           # (a kernel with a handful of LDS instructions gives a meaningless ratio)
+                        out["lds_bank_conflict_fraction"] = r_
                 lane = allc.get(run.replace("_sq", "_lane"), {}).get(k)
                 flop = allc.get(run.replace("_sq", "_flop"), {}).get(k)
                 if lane and lane.get("SQ_ACTIVE_INST_VALU"):
@@ -471,6 +473,33 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
             "mean_ipm_iterations": float(it.double().mean().item())}, f"mpcgn_kernel<{mid}, {N if N == 10 else 0}>")
 
 
+def vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
+    """MPC-CBF for VTOL2D (csrc/mpc_vtol.hip): N = 30, 4 inputs, one NLP per lane, stage-wise Riccati Newton steps; the
+    work arrays of the batch (0.1 MB per problem) stay in HBM between launches."""
+    import torch
+    import safe_control_amd as sca
+    from safe_control_amd import workloads as W
+    ctl = sca.BatchedVtolMPCCBF(io_dtype="f32")
+    Xn, up0, gn, on = W.mpc_family_batch("vtol", B, K, seed=seed)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    X, g, ob, up = t(Xn), t(gn), t(on), t(up0)
+    u, st, it = ctl.solve(X, up, g, ob)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        u, st, it = ctl.solve(X, up, g, ob)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return with_roofline({"workload": f"{B}-aircraft batch VTOL2D MPC-CBF, horizon N=30, {K} obstacles (120 variables, 630 rows per NLP)",
+            "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
+            "optimal_fraction": float((st == 0).double().mean().item()),
+            "infeasible_fraction": float((st == 1).double().mean().item()),
+            "mean_ipm_iterations": float(it.double().mean().item()), "max_ipm_iterations": int(it.max().item()),
+            "workspace_MB": ctl._ws.numel() / 1e6}, "mpcvtol_kernel<float>")
+
+
 def manip_closed_loop_leg(dev, B=4096, T=100, seed=0):
     """Fused closed loop for B arms (csrc/manip_cbf_qp.hip: manip_rollout_kernel): T control steps in one launch, four shared
     obstacles around the workspace, two waypoints per arm."""
@@ -753,6 +782,7 @@ def main():
             res["quad2d_mpc_cbf"] = gn_mpc_leg(dev, "Quad2D")
             res["kinematic_bicycle_mpc_cbf"] = gn_mpc_leg(dev, "KinematicBicycle2D")
             res["kinematic_bicycle_c3bf_mpc_cbf"] = gn_mpc_leg(dev, "KinematicBicycle2D_C3BF")
+            res["vtol_mpc_cbf"] = vtol_mpc_leg(dev)
             res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
             res["backup_cbf_qp"] = backup_cbf_leg(dev)
         if ws == 1 and not a.no_cpu_baseline:

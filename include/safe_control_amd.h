@@ -309,6 +309,42 @@ int sc_odmpcgn_solve_batch(const sc_odmpcgn_params* params, int64_t B, int32_t K
                            const void* X, const void* u_prev, const void* goal, const void* obs,
                            void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
 
+/* ---- MPC-CBF for VTOL2D ----------------------------------------------
+ * MPCCBF (position_control/mpc_cbf.py:40-43,83-87,135-141,222-233,316-321) for the tilt-rotor of robots/vtol2D.py:118-311: 6 states
+ * (x, z, theta, x_dot, z_dot, theta_dot), 4 inputs (front / rear / pusher throttle, elevator), prediction x + (f + g u) dt, horizon 30,
+ * Q = diag(10, 10, 250, 10, 10, 50), delta-u weights R = (0.5, 0.5, 0.5, 50000), rel-degree-2 DT-CBF rows through step o step against K
+ * discs (vtol2D.py:475-497, beta = 1.01, alpha1 = alpha2 = 0.05), bounds |x_dot| <= v_max, z_dot >= -descent_speed_max,
+ * |theta| <= pitch_max, throttles in [0, 1], |elevator| <= 0.5.  Same interior point and statuses as sc_mpccbf_solve_batch
+ * (restoration included), with the exact Hessian of the aero model and the slack reset of the line search that this model needs
+ * (oracle/mpc_vtol.py: params).  One NLP per LANE: the Newton system is solved stage by stage (Riccati recursion over 14 x 14
+ * blocks), the work arrays of a problem live in `workspace` (sc_mpcvtol_workspace_bytes(), device memory, no initialisation needed).
+ * X [B,6], u_prev [B,4], goal [B,2], obs [B,K,7] (or [K,7] with obs_shared; columns 0..2 used: x, z, radius), u_out [B,4],
+ * status_out [B], iters_out [B] or NULL, z_out [B, 4*horizon] or NULL.  f64 arithmetic; io_dtype f32 or f64.                       */
+typedef struct sc_mpcvtol_params {
+    int32_t io_dtype, horizon, max_iter, obs_shared, acceptable_iter;
+    int32_t slack_reset;     /* 0: off, 1: s = max(s, g) after a trial step, 2: s = g where g >= mu / nu (oracle default for VTOL2D) */
+    int32_t reserved[2];
+    double  dt;
+    double  Q[6], R[4];
+    double  alpha1, alpha2;
+    double  u_lo[4], u_hi[4];
+    double  v_max, descent_speed_max, pitch_max;      /* pitch_max in rad (mpc_cbf.py:232: degrees * 3.14159 / 180) */
+    double  robot_radius, beta;
+    double  tol, acceptable_tol, mu_init, mu_min;
+    double  airframe[21];    /* vtol2D.py:56-111: mass, inertia, S_wing, rho, C_L0, C_Lalpha, M, alpha_0, C_Ldelta_e, C_D0, C_Dalpha,
+                                C_Ddelta_e, C_m0, C_malpha, C_mdelta_e, chord, k_front, k_rear, k_pusher, ell_f, ell_r            */
+    sc_resto_params resto;
+} sc_mpcvtol_params;
+
+size_t sc_mpcvtol_workspace_bytes(const sc_mpcvtol_params* params, int64_t B, int32_t K);
+int sc_mpcvtol_solve_batch(const sc_mpcvtol_params* params, int64_t B, int32_t K,
+                           const void* X, const void* u_prev, const void* goal, const void* obs,
+                           void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int sc_mpcvtol_solve_batch_host(const sc_mpcvtol_params* params, int64_t B, int32_t K,
+                                const void* X, const void* u_prev, const void* goal, const void* obs,
+                                void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, int device);
+
 /* ---- optimal-decay MPC-CBF ---------------------------------------
  * OptimalDecayMPCCBF (position_control/optimal_decay_mpc_cbf.py:15-330) for DynamicUnicycle2D: the MPC-CBF NLP with
  * two decay variables per stage (omega1_k, omega2_k, model inputs at :123-124) that scale the DT-CBF gains,

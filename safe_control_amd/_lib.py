@@ -136,6 +136,23 @@ class MpcGnParams(C.Structure):
     ]
 
 
+class MpcVtolParams(C.Structure):
+    """Mirror of ``sc_mpcvtol_params``."""
+    _fields_ = [
+        ("io_dtype", C.c_int32), ("horizon", C.c_int32), ("max_iter", C.c_int32), ("obs_shared", C.c_int32),
+        ("acceptable_iter", C.c_int32), ("slack_reset", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("dt", C.c_double), ("Q", C.c_double * 6), ("R", C.c_double * 4), ("alpha1", C.c_double), ("alpha2", C.c_double),
+        ("u_lo", C.c_double * 4), ("u_hi", C.c_double * 4), ("v_max", C.c_double), ("descent_speed_max", C.c_double),
+        ("pitch_max", C.c_double), ("robot_radius", C.c_double), ("beta", C.c_double), ("tol", C.c_double),
+        ("acceptable_tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double), ("airframe", C.c_double * 21),
+        ("resto", RestoParams),
+    ]
+
+
+VTOL_AIRFRAME_KEYS = ("mass", "inertia", "S_wing", "rho", "C_L0", "C_Lalpha", "M", "alpha_0", "C_Ldelta_e", "C_D0", "C_Dalpha",
+                      "C_Ddelta_e", "C_m0", "C_malpha", "C_mdelta_e", "chord", "k_front", "k_rear", "k_pusher", "ell_f", "ell_r")
+
+
 class OdMpcGnParams(C.Structure):
     """Mirror of ``sc_odmpcgn_params``."""
     _fields_ = [("mpc", MpcGnParams), ("omega_ref", C.c_double * 2), ("p_sb", C.c_double * 2)]
@@ -194,6 +211,9 @@ SYMBOLS = {
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "sc_mpcgn_solve_batch": (C.c_int, [C.POINTER(MpcGnParams), C.c_int64, C.c_int32] + [C.c_void_p] * 9),
     "sc_mpcgn_solve_batch_host": (C.c_int, [C.POINTER(MpcGnParams), C.c_int64, C.c_int32] + [C.c_void_p] * 8 + [C.c_int]),
+    "sc_mpcvtol_workspace_bytes": (C.c_size_t, [C.POINTER(MpcVtolParams), C.c_int64, C.c_int32]),
+    "sc_mpcvtol_solve_batch": (C.c_int, [C.POINTER(MpcVtolParams), C.c_int64, C.c_int32] + [C.c_void_p] * 9 + [C.c_size_t, C.c_void_p]),
+    "sc_mpcvtol_solve_batch_host": (C.c_int, [C.POINTER(MpcVtolParams), C.c_int64, C.c_int32] + [C.c_void_p] * 8 + [C.c_int]),
     "sc_odmpcgn_solve_batch": (C.c_int, [C.POINTER(OdMpcGnParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_mpclin_model_doubles": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sc_mpclin_build_model": (C.c_int, [C.POINTER(MpcLinParams)] + [C.c_void_p] * 5),

@@ -59,6 +59,9 @@ hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long lo
 
 size_t mpcgn_lds_bytes(int model_id, int N, int K, int circles_only);
 size_t odmpcgn_lds_bytes(int model_id, int N, int K);
+size_t mpcvtol_workspace_bytes(int horizon, long long B, int K);
+hipError_t mpcvtol_launch(const sc_mpcvtol_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
+                          const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, void* workspace, hipStream_t stream);
 hipError_t odmpcgn_launch(const sc_odmpcgn_params& q, long long B, int K, const void* X, const void* u_prev, const void* goal,
                           const void* obs, void* u_out, void* rho_out, int* status, int* iters, void* z_out, hipStream_t stream);
 hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
@@ -219,6 +222,26 @@ static int check_mpcgn(const sc_mpcgn_params* p, int64_t B, int32_t K, const voi
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
     return SC_OK;
 }
+static int check_mpcvtol(const sc_mpcvtol_params* p, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,
+                         const void* obs, const void* u_out, const void* status_out) {
+    if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (B < 0) return fail(SC_ERR_INVALID_ARGUMENT, "B < 0");
+    if (K < 1) return fail(SC_ERR_INVALID_ARGUMENT, "K < 1 (pad with [1000,1000,0,...] rows like update_tvp)");
+    if (K > 16) return fail(SC_ERR_UNSUPPORTED, "K > 16 obstacles per aircraft");
+    if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
+        return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
+    if (p->horizon < 1 || p->horizon > 64) return fail(SC_ERR_UNSUPPORTED, "horizon outside [1, 64]");
+    if (!(p->dt > 0) || !(p->tol > 0) || !(p->acceptable_tol >= p->tol) || p->max_iter < 1 || !(p->mu_init > 0) || !(p->mu_min > 0))
+        return fail(SC_ERR_INVALID_ARGUMENT, "dt, tol, mu_init, mu_min must be > 0 and max_iter >= 1");
+    for (int i = 0; i < 4; ++i)
+        if (!(p->u_hi[i] > p->u_lo[i])) return fail(SC_ERR_INVALID_ARGUMENT, "u_hi must be > u_lo");
+    if (!(p->airframe[0] > 0) || !(p->airframe[1] > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "airframe: mass and inertia must be > 0");
+    if (!(p->v_max > 0) || !(p->pitch_max > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "v_max and pitch_max must be > 0");
+    if (p->slack_reset < 0 || p->slack_reset > 2) return fail(SC_ERR_INVALID_ARGUMENT, "slack_reset must be 0, 1 or 2");
+    if (B > 0 && (!X || !u_prev || !goal || !obs || !u_out || !status_out)) return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
+    if (B > 0x7fffffffLL / 16384) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch (workspace index range)");
+    return SC_OK;
+}
 static int check_manip(const sc_manip_cbfqp_params* p, int64_t B, int32_t K, const void* X, const void* u_ref,
                        const void* obs, const void* u_out, const void* status_out) {
     if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
@@ -254,6 +277,67 @@ int sc_mpcgn_solve_batch(const sc_mpcgn_params* params, int64_t B, int32_t K, co
                                     (hipStream_t)stream);
     if (e != hipSuccess) return sc::fail_hip(e, "mpcgn kernel launch");
     return SC_OK;
+}
+
+size_t sc_mpcvtol_workspace_bytes(const sc_mpcvtol_params* params, int64_t B, int32_t K) {
+    if (!params || B < 0 || K < 1 || params->horizon < 1) return 0;
+    return sc::mpcvtol_workspace_bytes(params->horizon, (long long)B, (int)K);
+}
+
+int sc_mpcvtol_solve_batch(const sc_mpcvtol_params* params, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,
+                           const void* obs, void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    int rc = sc::check_mpcvtol(params, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    if (!workspace) return sc::fail(SC_ERR_INVALID_ARGUMENT, "workspace is NULL");
+    if (workspace_bytes < sc::mpcvtol_workspace_bytes(params->horizon, (long long)B, (int)K))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "workspace smaller than sc_mpcvtol_workspace_bytes()");
+    hipError_t e = sc::mpcvtol_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, workspace,
+                                      (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "mpcvtol kernel launch");
+    return SC_OK;
+}
+
+int sc_mpcvtol_solve_batch_host(const sc_mpcvtol_params* params, int64_t B, int32_t K, const void* X, const void* u_prev,
+                                const void* goal, const void* obs, void* u_out, int32_t* status_out, int32_t* iters_out,
+                                void* z_out, int device) {
+    int rc = sc::check_mpcvtol(params, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipSetDevice");
+    const size_t es = params->io_dtype == SC_DTYPE_F64 ? 8 : 4;
+    const size_t n = 4 * (size_t)params->horizon;
+    const size_t nX = (size_t)B * 6 * es, nU = (size_t)B * 4 * es, nG = (size_t)B * 2 * es;
+    const size_t nO = (params->obs_shared ? (size_t)K * 7 : (size_t)B * K * 7) * es;
+    const size_t nS = (size_t)B * 4, nZ = (size_t)B * n * es, nW = sc::mpcvtol_workspace_bytes(params->horizon, (long long)B, (int)K);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t oX = 0, oU = oX + up(nX), oG = oU + up(nU), oO = oG + up(nG), oUo = oO + up(nO), oS = oUo + up(nU),
+                 oI = oS + up(nS), oZ = oI + up(nS), oW = oZ + up(nZ), total = oW + up(nW);
+    unsigned char* d = nullptr;
+    e = hipMalloc((void**)&d, total);
+    if (e != hipSuccess) return sc::fail_hip(e, "hipMalloc");
+    hipStream_t s = nullptr;
+    rc = SC_OK;
+    do {
+        if ((e = hipMemcpyAsync(d + oX, X, nX, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oU, u_prev, nU, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oG, goal, nG, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        e = sc::mpcvtol_launch(*params, (long long)B, (int)K, d + oX, d + oU, d + oG, d + oO, d + oUo, (int*)(d + oS),
+                               iters_out ? (int*)(d + oI) : nullptr, z_out ? d + oZ : nullptr, d + oW, s);
+        if (e != hipSuccess) break;
+        if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (iters_out && (e = hipMemcpyAsync(iters_out, d + oI, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (z_out && (e = hipMemcpyAsync(z_out, d + oZ, nZ, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        e = hipStreamSynchronize(s);
+    } while (0);
+    if (e != hipSuccess) rc = sc::fail_hip(e, "sc_mpcvtol_solve_batch_host");
+    (void)hipFree(d);
+    return rc;
 }
 
 int sc_odmpcgn_solve_batch(const sc_odmpcgn_params* params, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,

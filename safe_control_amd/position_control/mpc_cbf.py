@@ -107,6 +107,9 @@ class MPCCBF:
                                                          "KinematicBicycle2D_DPCBF"):
             from .mpc_cbf_gn import GnMPCCBF
             return GnMPCCBF(robot, robot_spec, *args, **kwargs)
+        if cls is MPCCBF and robot_spec.get("model") == "VTOL2D":
+            from .mpc_cbf_vtol import VtolMPCCBF
+            return VtolMPCCBF(robot, robot_spec, *args, **kwargs)
         return super().__new__(cls)
 
     def __init__(self, robot, robot_spec, show_mpc_traj=False, num_obs=5, device=0):

@@ -15,6 +15,12 @@ import numpy as np
 from .._lib import MODEL_IDS
 
 
+VTOL2D_DEFAULTS = dict(mass=11.0, inertia=1.135, S_wing=0.55, rho=1.2682, C_L0=0.23, C_Lalpha=5.61, M=50.0, alpha_0=math.radians(15.0),
+                       C_Ldelta_e=0.13, C_D0=0.043, C_Dalpha=0.03, C_Ddelta_e=0.0, C_m0=0.0135, C_malpha=-2.74, C_mdelta_e=-0.99,
+                       chord=0.18994, k_front=70.0, k_rear=70.0, k_pusher=60.0, ell_f=0.5, ell_r=0.5, throttle_min=0.0, throttle_max=1.0,
+                       elevator_min=-0.5, elevator_max=0.5, v_max=15.0, pitch_max=15.0, descent_speed_max=5.0, radius=0.6)
+
+
 def complete_robot_spec(robot_spec):
     """Apply the defaults the reference's robot classes ``setdefault`` into robot_spec.
 
@@ -32,6 +38,10 @@ def complete_robot_spec(robot_spec):
     if model == "Quad3D":                           # robots/quad3D.py:50-59 (MPC-CBF only)
         for k, v in (("mass", 3.0), ("Ix", 0.5), ("Iy", 0.5), ("Iz", 0.5), ("L", 0.3), ("nu", 0.1), ("u_max", 10.0),
                      ("u_min", -10.0), ("radius", 0.25)):
+            robot_spec.setdefault(k, v)
+        return robot_spec
+    if model == "VTOL2D":                           # robots/vtol2D.py:56-111 (MPC-CBF only)
+        for k, v in VTOL2D_DEFAULTS.items():
             robot_spec.setdefault(k, v)
         return robot_spec
     if model not in MODEL_IDS:

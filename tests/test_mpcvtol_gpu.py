@@ -1,0 +1,93 @@
+"""GPU: the VTOL2D MPC-CBF kernel (csrc/mpc_vtol.hip, one NLP per lane, stage-wise Riccati Newton steps) against the numpy oracle
+(oracle/mpc_vtol.py: condensed single shooting, dense Cholesky -- a different linear algebra for the same Newton step).
+
+Bar: SAME STATUS on every problem (restoration phase included), |u0 - u0_oracle| <= 1e-6 and |z - z_oracle| <= 2e-5 on every problem
+both call optimal, the first 512 problems of the vtol workload batch (the oracle needs ~10 s per problem, on the host cores in child
+processes).  `parted` counts problems where two solvers that follow each other to rounding end apart (bounded, as for the other
+families in test_mpc_full_batch_gpu.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import safe_control_amd as sca  # noqa: E402
+from safe_control_amd import workloads as W  # noqa: E402
+from oracle import mpc_vtol as V  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(__file__))
+from _oracle_pool import family_solve_many  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def t(a, dtype=torch.float64):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV)
+
+
+def test_batch_against_oracle():
+    n = 512
+    X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("vtol", 4096, 8, seed=0))
+    ctl = sca.BatchedVtolMPCCBF(io_dtype="f64")
+    u, st, it, z = ctl.solve(t(X), t(up), t(goal), t(obs), want_z=True)
+    torch.cuda.synchronize()
+    u, st, it, z = u.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), z.cpu().numpy()
+    o = family_solve_many("vtol", X, up, goal, obs, timeout=3000)
+    same = st == o["st"]
+    ok = same & (o["st"] == 0)
+    du = np.abs(u - o["u"]).max(axis=1); dz = np.abs(z - o["z"]).max(axis=1)
+    parted = ~same | (ok & ((du > 1e-6) | (dz > 2e-5)))
+    print(f"vtol: optimal {np.mean(o['st'] == 0):.4f} infeasible {np.mean(o['st'] == 1):.4f} inaccurate {np.mean(o['st'] == 2):.4f}; "
+          f"parted {int(parted.sum())} (status {int((~same).sum())}); restoration entered on {np.mean(o['n_resto'] > 0):.4f}; "
+          f"iterations equal on {np.mean(it == o['it']):.4f}, mean {o['it'].mean():.1f}")
+    assert parted.sum() <= 4, np.flatnonzero(parted)[:20]
+    assert (o["st"] == 0).mean() >= 0.9
+    assert np.all(o["theta"][o["st"] == 0] <= 1e-6)
+
+
+def test_f32_storage_shared_obstacles_and_no_z():
+    n = 64
+    X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("vtol", 4096, 8, seed=3))
+    obs_sh = np.ascontiguousarray(obs[0])                                   # one obstacle set for everybody, far enough ahead for all
+    obs_sh[:, 0] += 40.0
+    c64, c32 = sca.BatchedVtolMPCCBF(io_dtype="f64"), sca.BatchedVtolMPCCBF(io_dtype="f32")
+    X32, up32, goal32, obs32 = (a.astype(np.float32) for a in (X, up, goal, obs_sh))
+    u64, s64, i64 = c64.solve(t(X32.astype(np.float64)), t(up32.astype(np.float64)), t(goal32.astype(np.float64)), t(obs32.astype(np.float64)))
+    u32, s32, i32 = c32.solve(t(X32, torch.float32), t(up32, torch.float32), t(goal32, torch.float32), t(obs32, torch.float32))
+    torch.cuda.synchronize()
+    assert torch.equal(s64, s32) and torch.equal(i64, i32)
+    assert (u64.float() - u32).abs().max().item() <= 1e-6                   # same arithmetic, outputs rounded to f32 once
+
+
+def test_drop_in_class_matches_the_oracle_on_a_cruise_probe():
+    from safe_control_amd.robots.spec import RobotHandle
+    spec = {"model": "VTOL2D"}
+    x0 = np.array([0.0, 10.0, 0.0, 12.0, 0.0, 0.0])
+    robot = RobotHandle(x0.reshape(-1, 1), spec, dt=0.05)
+    ctl = sca.MPCCBF(robot, spec, num_obs=2)
+    assert type(ctl).__name__ == "VtolMPCCBF" and ctl.horizon == 30 and ctl.n_controls == 4
+    obs = np.array([[80.0, 10.5, 1.5]])
+    ref = {"state_machine": "track", "goal": np.array([100.0, 10.0]), "u_ref": np.zeros((4, 1))}
+    ctl.u_prev = np.array([0.5, 0.5, 0.3, 0.0])
+    u = ctl.solve_control_problem(robot.X, ref, obs)
+    from oracle import mpc_cbf as M
+    uo, so, io = V.solve(x0, np.array([0.5, 0.5, 0.3, 0.0]), ref["goal"], M.pad_obstacles(obs, 2),
+                         spec=dict(radius=robot.robot_radius))
+    assert so == 0 and ctl.solver_status == "optimal" and ctl.iterations == io
+    assert np.abs(u.reshape(-1) - uo).max() <= 1e-6
+    assert np.array_equal(ctl.solve_control_problem(robot.X, dict(ref, state_machine="stop"), obs), ref["u_ref"])
+
+
+def test_argument_checks():
+    ctl = sca.BatchedVtolMPCCBF(io_dtype="f64")
+    X, up, goal, obs = (a[:4] for a in W.mpc_family_batch("vtol", 8, 3, seed=0))
+    with pytest.raises(ValueError):
+        ctl.solve(t(X[:, :4]), t(up), t(goal), t(obs))
+    with pytest.raises(ValueError):
+        ctl.solve(t(X, torch.float32), t(up), t(goal), t(obs))
+    big = np.zeros((4, 17, 7))
+    with pytest.raises(Exception, match="K > 16"):
+        ctl.solve(t(X), t(up), t(goal), t(big))
