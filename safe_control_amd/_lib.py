@@ -140,7 +140,7 @@ class MpcVtolParams(C.Structure):
     """Mirror of ``sc_mpcvtol_params``."""
     _fields_ = [
         ("io_dtype", C.c_int32), ("horizon", C.c_int32), ("max_iter", C.c_int32), ("obs_shared", C.c_int32),
-        ("acceptable_iter", C.c_int32), ("slack_reset", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("acceptable_iter", C.c_int32), ("slack_reset", C.c_int32), ("kernel", C.c_int32), ("reserved", C.c_int32),
         ("dt", C.c_double), ("Q", C.c_double * 6), ("R", C.c_double * 4), ("alpha1", C.c_double), ("alpha2", C.c_double),
         ("u_lo", C.c_double * 4), ("u_hi", C.c_double * 4), ("v_max", C.c_double), ("descent_speed_max", C.c_double),
         ("pitch_max", C.c_double), ("robot_radius", C.c_double), ("beta", C.c_double), ("tol", C.c_double),

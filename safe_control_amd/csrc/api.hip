@@ -59,7 +59,8 @@ hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long lo
 
 size_t mpcgn_lds_bytes(int model_id, int N, int K, int circles_only);
 size_t odmpcgn_lds_bytes(int model_id, int N, int K);
-size_t mpcvtol_workspace_bytes(int horizon, long long B, int K);
+size_t mpcvtol_workspace_bytes(const sc_mpcvtol_params& p, long long B, int K);
+bool mpcvtol_uses_wave(const sc_mpcvtol_params& p, int K);
 hipError_t mpcvtol_launch(const sc_mpcvtol_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
                           const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, void* workspace, hipStream_t stream);
 hipError_t odmpcgn_launch(const sc_odmpcgn_params& q, long long B, int K, const void* X, const void* u_prev, const void* goal,
@@ -238,6 +239,8 @@ static int check_mpcvtol(const sc_mpcvtol_params* p, int64_t B, int32_t K, const
     if (!(p->airframe[0] > 0) || !(p->airframe[1] > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "airframe: mass and inertia must be > 0");
     if (!(p->v_max > 0) || !(p->pitch_max > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "v_max and pitch_max must be > 0");
     if (p->slack_reset < 0 || p->slack_reset > 2) return fail(SC_ERR_INVALID_ARGUMENT, "slack_reset must be 0, 1 or 2");
+    if (p->kernel < 0 || p->kernel > 2) return fail(SC_ERR_INVALID_ARGUMENT, "kernel must be 0 (auto), 1 (lane per problem) or 2 (wave per problem)");
+    if (p->kernel == 2 && !mpcvtol_uses_wave(*p, K)) return fail(SC_ERR_UNSUPPORTED, "the wave-per-problem kernel serves K <= 8, horizon <= 64");
     if (B > 0 && (!X || !u_prev || !goal || !obs || !u_out || !status_out)) return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
     if (B > 0x7fffffffLL / 16384) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch (workspace index range)");
     return SC_OK;
@@ -281,7 +284,7 @@ int sc_mpcgn_solve_batch(const sc_mpcgn_params* params, int64_t B, int32_t K, co
 
 size_t sc_mpcvtol_workspace_bytes(const sc_mpcvtol_params* params, int64_t B, int32_t K) {
     if (!params || B < 0 || K < 1 || params->horizon < 1) return 0;
-    return sc::mpcvtol_workspace_bytes(params->horizon, (long long)B, (int)K);
+    return sc::mpcvtol_workspace_bytes(*params, (long long)B, (int)K);
 }
 
 int sc_mpcvtol_solve_batch(const sc_mpcvtol_params* params, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,
@@ -291,9 +294,9 @@ int sc_mpcvtol_solve_batch(const sc_mpcvtol_params* params, int64_t B, int32_t K
     int rc = sc::check_mpcvtol(params, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
-    if (!workspace) return sc::fail(SC_ERR_INVALID_ARGUMENT, "workspace is NULL");
-    if (workspace_bytes < sc::mpcvtol_workspace_bytes(params->horizon, (long long)B, (int)K))
-        return sc::fail(SC_ERR_INVALID_ARGUMENT, "workspace smaller than sc_mpcvtol_workspace_bytes()");
+    const size_t need = sc::mpcvtol_workspace_bytes(*params, (long long)B, (int)K);
+    if (need > 0 && !workspace) return sc::fail(SC_ERR_INVALID_ARGUMENT, "workspace is NULL");
+    if (workspace_bytes < need) return sc::fail(SC_ERR_INVALID_ARGUMENT, "workspace smaller than sc_mpcvtol_workspace_bytes()");
     hipError_t e = sc::mpcvtol_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, workspace,
                                       (hipStream_t)stream);
     if (e != hipSuccess) return sc::fail_hip(e, "mpcvtol kernel launch");
@@ -312,7 +315,7 @@ int sc_mpcvtol_solve_batch_host(const sc_mpcvtol_params* params, int64_t B, int3
     const size_t n = 4 * (size_t)params->horizon;
     const size_t nX = (size_t)B * 6 * es, nU = (size_t)B * 4 * es, nG = (size_t)B * 2 * es;
     const size_t nO = (params->obs_shared ? (size_t)K * 7 : (size_t)B * K * 7) * es;
-    const size_t nS = (size_t)B * 4, nZ = (size_t)B * n * es, nW = sc::mpcvtol_workspace_bytes(params->horizon, (long long)B, (int)K);
+    const size_t nS = (size_t)B * 4, nZ = (size_t)B * n * es, nW = sc::mpcvtol_workspace_bytes(*params, (long long)B, (int)K);
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t oX = 0, oU = oX + up(nX), oG = oU + up(nU), oO = oG + up(nG), oUo = oO + up(nO), oS = oUo + up(nU),
                  oI = oS + up(nS), oZ = oI + up(nS), oW = oZ + up(nZ), total = oW + up(nW);

@@ -51,13 +51,25 @@ __global__ void __launch_bounds__(64) mpcvtol_kernel(const vtol::Params P, long 
     if (z_out) for (int i = 0; i < S.L.n; ++i) z_out[b * S.L.n + i] = (TIO)S.W(S.L.z + i);
 }
 
-size_t mpcvtol_workspace_bytes(int horizon, long long B, int K) {
-    vtol::Layout L(horizon, K);
+hipError_t mpcvtol_wave_launch(const sc_mpcvtol_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
+                               const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream);
+
+// which kernel serves (p, K): the wave-per-problem kernel (mpc_vtol_wave.hip) holds K <= 8 rows per stage in registers and one stage per
+// lane; everything else, or p.kernel = 1, runs one problem per lane out of the workspace
+bool mpcvtol_uses_wave(const sc_mpcvtol_params& p, int K) {
+    if (p.kernel == 1) return false;
+    return K <= 8 && p.horizon <= 64;
+}
+
+size_t mpcvtol_workspace_bytes(const sc_mpcvtol_params& p, long long B, int K) {
+    if (mpcvtol_uses_wave(p, K)) return 0;
+    vtol::Layout L(p.horizon, K);
     return (size_t)L.total * (size_t)B * sizeof(double);
 }
 
 hipError_t mpcvtol_launch(const sc_mpcvtol_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
                           const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, void* workspace, hipStream_t stream) {
+    if (mpcvtol_uses_wave(p, K)) return mpcvtol_wave_launch(p, B, K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream);
     const vtol::Params P = vtol::from_c(p, K);
     int lanes = B <= 16384 ? 16 : 64;
     if (const char* e = std::getenv("SC_VTOL_LANES")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) lanes = v; }

@@ -25,6 +25,13 @@
 #ifndef SC_HD
 #define SC_HD __host__ __device__
 #endif
+// hooks for the device build's short reciprocal / sincos (sc_qp2.hpp, sc_math.hpp: an ulp or two from the IEEE results)
+#ifndef SC_VTOL_RCP
+#define SC_VTOL_RCP(a) (1.0 / (a))
+#endif
+#ifndef SC_VTOL_SINCOS
+#define SC_VTOL_SINCOS(a, s, c) { s = sin(a); c = cos(a); }
+#endif
 
 namespace sc {
 namespace vtol {
@@ -41,6 +48,8 @@ struct Params {                      // filled from sc_mpcvtol_params by the lau
     // airframe (vtol2D.py:56-111)
     double mass, inertia, S_wing, rho_air, C_L0, C_Lalpha, M, alpha_0, C_Ldelta_e, C_D0, C_Dalpha, C_Ddelta_e, C_m0, C_malpha, C_mdelta_e,
         chord, k_front, k_rear, k_pusher, ell_f, ell_r;
+    double eMa0sq;                   // exp(2 M alpha_0)
+    double inv_m, inv_I, kf_m, kr_m, kp_m, lfkf_I, lrkr_I;
 };
 
 #ifdef SC_VTOL_WITH_C_PARAMS
@@ -59,6 +68,10 @@ inline Params from_c(const sc_mpcvtol_params& c, int K) {
     P.mass = a[0]; P.inertia = a[1]; P.S_wing = a[2]; P.rho_air = a[3]; P.C_L0 = a[4]; P.C_Lalpha = a[5]; P.M = a[6]; P.alpha_0 = a[7];
     P.C_Ldelta_e = a[8]; P.C_D0 = a[9]; P.C_Dalpha = a[10]; P.C_Ddelta_e = a[11]; P.C_m0 = a[12]; P.C_malpha = a[13]; P.C_mdelta_e = a[14];
     P.chord = a[15]; P.k_front = a[16]; P.k_rear = a[17]; P.k_pusher = a[18]; P.ell_f = a[19]; P.ell_r = a[20];
+    P.eMa0sq = exp(2.0 * P.M * P.alpha_0);
+    P.inv_m = 1.0 / P.mass; P.inv_I = 1.0 / P.inertia;
+    P.kf_m = P.k_front / P.mass; P.kr_m = P.k_rear / P.mass; P.kp_m = P.k_pusher / P.mass;
+    P.lfkf_I = P.ell_f * P.k_front / P.inertia; P.lrkr_I = P.ell_r * P.k_rear / P.inertia;
     return P;
 }
 #endif
@@ -92,7 +105,7 @@ SC_HD inline D2 operator-(const D2& a, double c) { D2 r = a; r.v -= c; return r;
 SC_HD inline D2 operator-(double c, const D2& a) { D2 r = -a; r.v += c; return r; }
 SC_HD inline D2 operator*(const D2& a, double c) { D2 r; r.v = a.v * c; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] * c; for (int i = 0; i < 6; ++i) r.h[i] = a.h[i] * c; return r; }
 SC_HD inline D2 operator*(double c, const D2& a) { return a * c; }
-SC_HD inline D2 recip(const D2& a) { const double r = 1.0 / a.v; return chain(a, r, -r * r, 2.0 * r * r * r); }
+SC_HD inline D2 recip(const D2& a) { const double r = SC_VTOL_RCP(a.v); return chain(a, r, -r * r, 2.0 * r * r * r); }
 SC_HD inline D2 operator/(const D2& a, const D2& b) { return a * recip(b); }
 SC_HD inline D2 operator/(const D2& a, double c) { return a * (1.0 / c); }
 SC_HD inline D2 sin_(const D2& a) { const double s = sin(a.v), c = cos(a.v); return chain(a, s, c, -s); }
@@ -117,44 +130,51 @@ SC_HD inline double exp_(double a) { return exp(a); }
 SC_HD inline double sqrt_(double a) { return sqrt(a); }
 SC_HD inline double sq_(double a) { return a * a; }
 SC_HD inline double atan2_(double y, double x) { return atan2(y, x); }
+SC_HD inline double recip_or(double a) { return SC_VTOL_RCP(a); }
+SC_HD inline D2 recip_or(const D2& a) { return recip(a); }
 SC_HD inline double val(double a) { return a; }
 SC_HD inline double val(const D2& a) { return a.v; }
 
 // ---- the airframe: vtol2D.py:333-452 as oracle/mpc_vtol.py: fg -------------------------------------------------------------------
-template <typename T>
-SC_HD inline void lift_drag_moment(const Params& P, const T& V, const T& alpha, double delta_e, T& L, T& D, T& Mo) {
-    const T sig_a = exp_(-P.M * (alpha - P.alpha_0));
-    const T sig_b = exp_(P.M * (alpha + P.alpha_0));
-    const T sigma = (1.0 + sig_a + sig_b) / ((1.0 + sig_a) * (1.0 + sig_b));
-    const T CL_lin = P.C_L0 + P.C_Lalpha * alpha;
-    const T CL_non = 2.0 * sin_(alpha) * cos_(alpha);
-    const T CL = (1.0 - sigma) * CL_lin + sigma * CL_non + P.C_Ldelta_e * delta_e;
-    const T CD = P.C_D0 + P.C_Dalpha * sq_(alpha) + P.C_Ddelta_e * delta_e;
-    const T CM = P.C_m0 + P.C_malpha * alpha + P.C_mdelta_e * delta_e;
-    const T qbar = 0.5 * P.rho_air * sq_(V);
-    L = qbar * P.S_wing * CL; D = qbar * P.S_wing * CD; Mo = qbar * P.S_wing * CM * P.chord;
-}
+// Same functions, fewer library calls than the literal form (ten transcendental calls per evaluation there, four here -- the rollout of
+// an evaluation is thirty of these in a row): with alpha = atan2(-w_b, u_b) the sine and cosine of alpha are -w_b / V and u_b / V, those
+// of theta + alpha follow from the addition theorems, exp(M (alpha + alpha_0)) is exp(M alpha_0)^2 / exp(-M (alpha - alpha_0)), and the
+// elevator column (the model at delta_e = 1) shares everything but three constants with the drift term (delta_e = 0).
+SC_HD inline void sincos_(double a, double& s, double& c) { SC_VTOL_SINCOS(a, s, c) }
+SC_HD inline void sincos_(const D2& a, D2& s, D2& c) { double sv, cv; SC_VTOL_SINCOS(a.v, sv, cv) s = chain(a, sv, cv, -sv); c = chain(a, cv, -sv, -cv); }
+SC_HD inline double inv_(double a) { return a > 0.0 ? SC_VTOL_RCP(a) : 0.0; }            // V = 0: every aerodynamic force carries the factor V^2
+SC_HD inline D2 inv_(const D2& a) { return recip(a); }
 
 // accelerations (x_ddot, z_ddot, theta_ddot) at (theta, x_dot, z_dot) with input u: acc[i] = f_i + sum_j g_ij u_j; gcol[j][i] = g_ij
 template <typename T>
 SC_HD inline void accel(const Params& P, const T& th, const T& xd, const T& zd, const double* u, T acc[3], T gcol[4][3]) {
-    const T c = cos_(th), sn = sin_(th);
+    T c, sn;
+    sincos_(th, sn, c);
     const T u_b = c * xd + sn * zd, w_b = c * zd - sn * xd;
-    const T V = sqrt_(u_b * u_b + w_b * w_b);
+    const T V2 = u_b * u_b + w_b * w_b;
+    const T V = sqrt_(V2), iV = inv_(V);
+    const T ca = u_b * iV, sa = -(w_b * iV);
     const T alpha = atan2_(-w_b, u_b);
-    T L0, D0, M0, Le, De, Me;
-    lift_drag_moment(P, V, alpha, 0.0, L0, D0, M0);
-    lift_drag_moment(P, V, alpha, 1.0, Le, De, Me);
-    const T hh = th + alpha;
-    const T ch = cos_(hh), sh = sin_(hh);
+    // lift blending (vtol2D.py:348-372)
+    const T sig_a = exp_(-P.M * (alpha - P.alpha_0));
+    const T sig_b = P.eMa0sq * recip_or(sig_a);
+    const T sigma = (1.0 + sig_a + sig_b) * recip_or((1.0 + sig_a) * (1.0 + sig_b));
+    const T CL_lin = P.C_L0 + P.C_Lalpha * alpha;
+    const T CL_non = 2.0 * sa * ca;
+    const T CL = (1.0 - sigma) * CL_lin + sigma * CL_non;
+    const T CD = P.C_D0 + P.C_Dalpha * sq_(alpha);
+    const T CM = P.C_m0 + P.C_malpha * alpha;
+    const T qS = (0.5 * P.rho_air * P.S_wing) * V2;
+    const T L0 = qS * CL, D0 = qS * CD, M0 = qS * CM * P.chord;
+    const T Le = qS * (CL + P.C_Ldelta_e), De = qS * (CD + P.C_Ddelta_e), Me = qS * (CM + P.C_mdelta_e) * P.chord;
+    const T ch = c * ca - sn * sa, sh = sn * ca + c * sa;              // cos, sin of theta + alpha
     const T fx = -(ch * D0) - sh * L0, fz = ch * L0 - sh * D0;         // wind -> inertial of (-D, L)
     const T ex = -(ch * De) - sh * Le, ez = ch * Le - sh * De;
-    const double m = P.mass, I = P.inertia;
-    acc[0] = fx / m; acc[1] = (fz - m * 9.81) / m; acc[2] = M0 / I;
-    gcol[0][0] = -(sn * (P.k_front / m)); gcol[0][1] = c * (P.k_front / m); gcol[0][2] = 0.0 * c + (P.ell_f * P.k_front / I);
-    gcol[1][0] = -(sn * (P.k_rear / m)); gcol[1][1] = c * (P.k_rear / m); gcol[1][2] = 0.0 * c + (-P.ell_r * P.k_rear / I);
-    gcol[2][0] = c * (P.k_pusher / m); gcol[2][1] = sn * (P.k_pusher / m); gcol[2][2] = 0.0 * c;
-    gcol[3][0] = ex / m; gcol[3][1] = ez / m; gcol[3][2] = Me / I;
+    acc[0] = fx * P.inv_m; acc[1] = fz * P.inv_m - 9.81; acc[2] = M0 * P.inv_I;
+    gcol[0][0] = -(sn * P.kf_m); gcol[0][1] = c * P.kf_m; gcol[0][2] = 0.0 * c + P.lfkf_I;
+    gcol[1][0] = -(sn * P.kr_m); gcol[1][1] = c * P.kr_m; gcol[1][2] = 0.0 * c - P.lrkr_I;
+    gcol[2][0] = c * P.kp_m; gcol[2][1] = sn * P.kp_m; gcol[2][2] = 0.0 * c;
+    gcol[3][0] = ex * P.inv_m; gcol[3][1] = ez * P.inv_m; gcol[3][2] = Me * P.inv_I;
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 4; ++j) acc[i] = acc[i] + gcol[j][i] * u[j];
 }

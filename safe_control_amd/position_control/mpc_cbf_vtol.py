@@ -19,10 +19,11 @@ HORIZON_VTOL = 30
 
 
 def make_params(robot_spec, cbf_param, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=100, mu_init=0.1,
-                mu_min=1e-9, acceptable_tol=1e-5, resto=None, slack_reset=2):
+                mu_min=1e-9, acceptable_tol=1e-5, resto=None, slack_reset=2, kernel=0):
     p = _lib.MpcVtolParams()
     p.io_dtype, p.horizon, p.max_iter, p.obs_shared, p.acceptable_iter = io_dtype, int(horizon), int(max_iter), 1 if obs_shared else 0, 15
     p.slack_reset = int(slack_reset)
+    p.kernel = int(kernel)                                 # 0 auto, 1 one NLP per lane, 2 one NLP per wavefront (K <= 8)
     p.dt = float(dt)
     for i in range(6):
         p.Q[i] = Q_VTOL[i]
@@ -107,6 +108,7 @@ class BatchedVtolMPCCBF:
         self.cbf_param = cbf_param or apply_mpc_overrides(dict(CBF_VTOL), self.robot_spec)
         self.tol, self.max_iter = tol, max_iter
         self.slack_reset = 2
+        self.kernel = 0
         self._lib = _lib.load()
         self._ws = None
 
@@ -132,10 +134,10 @@ class BatchedVtolMPCCBF:
         z = torch.empty((B, 4 * self.horizon), dtype=dt_, device=X.device) if want_z else None
         p = make_params(self.robot_spec, self.cbf_param, self.horizon, self.dt, self.robot_spec["radius"], self.io_dtype,
                         obs_shared=shared, tol=self.tol, max_iter=self.max_iter, resto=getattr(self, "resto", None),
-                        slack_reset=self.slack_reset)
+                        slack_reset=self.slack_reset, kernel=self.kernel)
         need = int(self._lib.sc_mpcvtol_workspace_bytes(C.byref(p), B, K))
         if self._ws is None or self._ws.numel() < need or self._ws.device != X.device:
-            self._ws = torch.empty((need,), dtype=torch.uint8, device=X.device)
+            self._ws = torch.empty((max(need, 8),), dtype=torch.uint8, device=X.device)
         stream = torch.cuda.current_stream(X.device).cuda_stream
         rc = self._lib.sc_mpcvtol_solve_batch(
             C.byref(p), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(),
