@@ -316,16 +316,16 @@ int sc_odmpcgn_solve_batch(const sc_odmpcgn_params* params, int64_t B, int32_t K
  * discs (vtol2D.py:475-497, beta = 1.01, alpha1 = alpha2 = 0.05), bounds |x_dot| <= v_max, z_dot >= -descent_speed_max,
  * |theta| <= pitch_max, throttles in [0, 1], |elevator| <= 0.5.  Same interior point and statuses as sc_mpccbf_solve_batch
  * (restoration included), with the exact Hessian of the aero model and the slack reset of the line search that this model needs
- * (oracle/mpc_vtol.py: params).  The Newton system is solved stage by stage (Riccati recursion over 14 x 14 blocks).  K <= 8: one NLP
- * per wavefront, one stage per lane, everything in registers and LDS (no workspace: sc_mpcvtol_workspace_bytes() returns 0 and
- * `workspace` may be NULL).  K > 8 (or kernel = 1): one NLP per lane with its work arrays in `workspace` (device memory, no
- * initialisation needed).
+ * (oracle/mpc_vtol.py: params).  The Newton system is solved stage by stage (Riccati recursion over 14 x 14 blocks): one NLP per
+ * wavefront, one stage per lane, everything in registers and LDS (no workspace: sc_mpcvtol_workspace_bytes() returns 0 and
+ * `workspace` may be NULL).  kernel = 1 selects the one-NLP-per-lane kernel the wave kernel was checked against; its work arrays
+ * live in `workspace` (device memory, no initialisation needed).  K <= 16, horizon <= 64.
  * X [B,6], u_prev [B,4], goal [B,2], obs [B,K,7] (or [K,7] with obs_shared; columns 0..2 used: x, z, radius), u_out [B,4],
  * status_out [B], iters_out [B] or NULL, z_out [B, 4*horizon] or NULL.  f64 arithmetic; io_dtype f32 or f64.                       */
 typedef struct sc_mpcvtol_params {
     int32_t io_dtype, horizon, max_iter, obs_shared, acceptable_iter;
     int32_t slack_reset;     /* 0: off, 1: s = max(s, g) after a trial step, 2: s = g where g >= mu / nu (oracle default for VTOL2D) */
-    int32_t kernel;          /* 0: auto (one NLP per wavefront, one stage per lane for K <= 8; one NLP per lane otherwise), 1 / 2: force */
+    int32_t kernel;          /* 0 / 2: one NLP per wavefront (one stage per lane); 1: one NLP per lane (needs the workspace)         */
     int32_t reserved;
     double  dt;
     double  Q[6], R[4];

@@ -54,11 +54,11 @@ __global__ void __launch_bounds__(64) mpcvtol_kernel(const vtol::Params P, long 
 hipError_t mpcvtol_wave_launch(const sc_mpcvtol_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
                                const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream);
 
-// which kernel serves (p, K): the wave-per-problem kernel (mpc_vtol_wave.hip) holds K <= 8 rows per stage in registers and one stage per
-// lane; everything else, or p.kernel = 1, runs one problem per lane out of the workspace
+// which kernel serves (p, K): the wave-per-problem kernel (mpc_vtol_wave.hip: one stage per lane, the stage's rows in registers, instantiated
+// for 8 and 16 row slots) unless p.kernel = 1 asks for one problem per lane out of the workspace
 bool mpcvtol_uses_wave(const sc_mpcvtol_params& p, int K) {
     if (p.kernel == 1) return false;
-    return K <= 8 && p.horizon <= 64;
+    return K <= 16 && p.horizon <= 64;
 }
 
 size_t mpcvtol_workspace_bytes(const sc_mpcvtol_params& p, long long B, int K) {

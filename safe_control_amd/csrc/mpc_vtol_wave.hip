@@ -33,8 +33,7 @@ using namespace vtol;
 #define VPROF_ADD(i)
 #endif
 
-constexpr int WKT = 8;                 // CBF rows per stage held in registers
-constexpr int WNR = WKT + 13;          // + 5 state bounds of x_{k+1} + 4 + 4 input box
+constexpr int WKT_MAX = 16;            // CBF rows per stage held in registers: instantiated for 8 and 16
 
 struct WaveLds {
     int U, UT, DU, AB, H, Q, XD, XQ, PS, KK, kk, OB, Pm, Pn, pv, pn, PAB, Quu, QX, qu, RD, Dl, DX, total;
@@ -42,7 +41,7 @@ struct WaveLds {
         int o = 0;
         auto take = [&](int c) { int r = o; o += c; return r; };
         U = take(N * 4); UT = take(N * 4); DU = take(N * 4); AB = take(N * 60); H = take(N * 55); Q = take(N * 10);
-        XD = take(N * 6); XQ = take(N * 6); PS = take((N + 1) * 6); KK = take(N * 40); kk = take(N * 4); OB = take(3 * WKT);
+        XD = take(N * 6); XQ = take(N * 6); PS = take((N + 1) * 6); KK = take(N * 40); kk = take(N * 4); OB = take(3 * WKT_MAX);
         Pm = take(100); Pn = take(100); pv = take(10); pn = take(10); PAB = take(100); Quu = take(16); QX = take(40); qu = take(4);
         RD = take(N * 4); Dl = take(4); DX = take((N + 1) * 6);
         total = o;
@@ -221,7 +220,9 @@ __device__ __attribute__((noinline)) void vtol_costates(ldsd* lds, const WaveLds
     }
 }
 
+template <int WKT>
 struct Wave {
+    static constexpr int WNR = WKT + 13;          // + 5 state bounds of x_{k+1} + 4 + 4 input box
     const Params& P;
     ldsd* lds;
     const WaveLds L;
@@ -851,16 +852,16 @@ struct Wave {
     }
 };
 
-template <typename TIO>
+template <typename TIO, int WKT>
 __global__ void __launch_bounds__(64) mpcvtol_wave_kernel(const Params P, long long B, int obs_shared, const TIO* __restrict__ X,
                                                           const TIO* __restrict__ u_prev, const TIO* __restrict__ goal,
                                                           const TIO* __restrict__ obs, TIO* __restrict__ u_out, int* __restrict__ status_out,
                                                           int* __restrict__ iters_out, TIO* __restrict__ z_out) {
     extern __shared__ double vtol_lds[];
     const long long b = blockIdx.x;
-    Wave S(P, (ldsd*)vtol_lds);
+    Wave<WKT> S(P, (ldsd*)vtol_lds);
     const TIO* ob = obs + (obs_shared ? 0 : b * P.K * 7);
-    if ((int)threadIdx.x < 3 * WKT) {
+    if ((int)threadIdx.x < 3 * WKT_MAX) {
         const int j = threadIdx.x / 3, c = threadIdx.x % 3;
         vtol_lds[S.L.OB + threadIdx.x] = j < P.K ? (double)ob[7 * j + c] : 0.0;
     }
@@ -884,23 +885,25 @@ __global__ void __launch_bounds__(64) mpcvtol_wave_kernel(const Params P, long l
         for (int j = 0; j < NU; ++j) z_out[b * (long long)(P.N * NU) + S.k * NU + j] = (TIO)vtol_lds[S.L.U + S.k * NU + j];
 }
 
+template <typename TIO, int WKT>
+static hipError_t wave_launch_t(const Params& P, const sc_mpcvtol_params& p, long long B, size_t lds, const void* X, const void* u_prev,
+                                const void* goal, const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)mpcvtol_wave_kernel<TIO, WKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((mpcvtol_wave_kernel<TIO, WKT>), dim3((unsigned)B), dim3(64), lds, stream, P, B, p.obs_shared, (const TIO*)X,
+                       (const TIO*)u_prev, (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status_out, iters_out, (TIO*)z_out);
+    return hipGetLastError();
+}
+
 hipError_t mpcvtol_wave_launch(const sc_mpcvtol_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
                                const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream) {
     const Params P = from_c(p, K);
     const size_t lds = mpcvtol_wave_lds_bytes(p.horizon);
-    hipError_t e;
-    if (p.io_dtype == SC_DTYPE_F64) {
-        e = hipFuncSetAttribute((const void*)mpcvtol_wave_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(mpcvtol_wave_kernel<double>, dim3((unsigned)B), dim3(64), lds, stream, P, B, p.obs_shared, (const double*)X,
-                           (const double*)u_prev, (const double*)goal, (const double*)obs, (double*)u_out, status_out, iters_out, (double*)z_out);
-    } else {
-        e = hipFuncSetAttribute((const void*)mpcvtol_wave_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(mpcvtol_wave_kernel<float>, dim3((unsigned)B), dim3(64), lds, stream, P, B, p.obs_shared, (const float*)X,
-                           (const float*)u_prev, (const float*)goal, (const float*)obs, (float*)u_out, status_out, iters_out, (float*)z_out);
-    }
-    return hipGetLastError();
+    if (p.io_dtype == SC_DTYPE_F64)
+        return K <= 8 ? wave_launch_t<double, 8>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream)
+                      : wave_launch_t<double, 16>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream);
+    return K <= 8 ? wave_launch_t<float, 8>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream)
+                  : wave_launch_t<float, 16>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream);
 }
 
 }  // namespace sc

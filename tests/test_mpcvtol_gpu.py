@@ -1,5 +1,6 @@
-"""GPU: the VTOL2D MPC-CBF kernel (csrc/mpc_vtol.hip, one NLP per lane, stage-wise Riccati Newton steps) against the numpy oracle
-(oracle/mpc_vtol.py: condensed single shooting, dense Cholesky -- a different linear algebra for the same Newton step).
+"""GPU: the VTOL2D MPC-CBF kernels -- csrc/mpc_vtol_wave.hip (one NLP per wavefront, one stage per lane, K <= 8; the default) and
+csrc/mpc_vtol.hip (one NLP per lane, any K <= 16) -- against the numpy oracle (oracle/mpc_vtol.py: condensed single shooting, dense
+Cholesky: a different linear algebra for the same Newton step) and against each other.
 
 Bar: SAME STATUS on every problem (restoration phase included), |u0 - u0_oracle| <= 1e-6 and |z - z_oracle| <= 2e-5 on every problem
 both call optimal, the first 512 problems of the vtol workload batch (the oracle needs ~10 s per problem, on the host cores in child
@@ -91,3 +92,35 @@ def test_argument_checks():
     big = np.zeros((4, 17, 7))
     with pytest.raises(Exception, match="K > 16"):
         ctl.solve(t(X), t(up), t(goal), t(big))
+
+
+def test_wave_and_lane_kernels_agree():
+    """Same interior point, different division of labour (and different summation orders): statuses equal, plans equal to rounding."""
+    n = 256
+    X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("vtol", 4096, 8, seed=5))
+    out = {}
+    for kern in (1, 2):
+        ctl = sca.BatchedVtolMPCCBF(io_dtype="f64"); ctl.kernel = kern
+        u, st, it, z = ctl.solve(t(X), t(up), t(goal), t(obs), want_z=True)
+        torch.cuda.synchronize()
+        out[kern] = (u.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), z.cpu().numpy())
+    (u1, s1, i1, z1), (u2, s2, i2, z2) = out[1], out[2]
+    both = (s1 == 0) & (s2 == 0)
+    parted = (s1 != s2) | (both & (np.abs(z1 - z2).max(axis=1) > 2e-5))
+    assert parted.sum() <= 2 and both.mean() >= 0.9
+    assert np.mean(i1 == i2) >= 0.97
+
+
+@pytest.mark.parametrize("K", [3, 10])
+def test_other_obstacle_counts_against_oracle(K):
+    """K = 3: the wave kernel with five of its eight row slots per stage switched off; K = 10: served by the lane-per-problem kernel."""
+    n = 12
+    X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("vtol", 64, K, seed=7))
+    ctl = sca.BatchedVtolMPCCBF(io_dtype="f64")
+    u, st, it, z = ctl.solve(t(X), t(up), t(goal), t(obs), want_z=True)
+    torch.cuda.synchronize()
+    o = family_solve_many("vtol", X, up, goal, obs, timeout=3000)
+    st = st.cpu().numpy()
+    assert np.array_equal(st, o["st"])
+    ok = o["st"] == 0
+    assert ok.mean() >= 0.75 and np.abs(u.cpu().numpy() - o["u"])[ok].max() <= 1e-6 and np.abs(z.cpu().numpy() - o["z"])[ok].max() <= 2e-5

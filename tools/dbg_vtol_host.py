@@ -25,8 +25,8 @@ def build():
     return lib
 
 
-def host_solve(lib, x0, up, goal, obs, **over):
-    spec = complete_robot_spec({"model": "VTOL2D"})
+def host_solve(lib, x0, up, goal, obs, v_max=None, **over):
+    spec = complete_robot_spec({"model": "VTOL2D"} if v_max is None else {"model": "VTOL2D", "v_max": v_max})
     p = PV.make_params(spec, PV.CBF_VTOL, 30, 0.05, spec["radius"], _lib.DTYPE_F64, **over)
     K = obs.shape[0]
     u = np.zeros(4); z = np.zeros(120); st = C.c_int(0); it = C.c_int(0)
