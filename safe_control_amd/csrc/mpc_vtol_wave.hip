@@ -10,7 +10,7 @@
 //     with the 10 x 10 value function in LDS and the lanes spread over the ENTRIES of each product (P A, P B, Quu, Qux, the new P);
 //     the 4 x 4 Cholesky and its eleven right-hand sides are done redundantly, one column per lane;
 //   * sums and maxima over rows are DPP wave reductions; every decision of the interior point is wave-uniform.
-// LDS per problem: stage Jacobians and blocks, gains, costates, the Riccati workspace -- 50.8 KB for N = 30, three problems per CU.
+// LDS per problem: stage Jacobians and blocks, gains, costates, the Riccati workspace -- 39.3 KB for N = 30, four problems per CU.
 // Kernel 11 in DESIGN.md.
 #include <hip/hip_runtime.h>
 
@@ -36,17 +36,25 @@ using namespace vtol;
 constexpr int WKT_MAX = 16;            // CBF rows per stage held in registers: instantiated for 8 and 16
 
 struct WaveLds {
-    int U, UT, DU, AB, H, Q, XD, XQ, PS, KK, kk, OB, Pm, Pn, pv, pn, PAB, Quu, QX, qu, RD, Dl, DX, total;
+    int U, UT, DU, AB, H, Q, XD, XQ, PS, OB, Pm, Pn, pv, pn, PAB, Quu, QX, qu, UP, Dl, DX, total;
+    // Lifetimes that do not overlap share a slot (39.3 KB per problem for N = 30: four problems per CU, one per SIMD):
+    //   gains KK_k | kk_k (44 numbers) of the Riccati recursion go into the slot of H_{k+1}, which stage k + 1 has finished with
+    //     (H has N + 1 slots; a retry with a larger delta rebuilds the stage blocks first);
+    //   dx of the forward LQ rollout overwrites the costates (read for the last time when the stage blocks are built);
+    //   the trial inputs UT and the step DU overwrite the own terms XD, XQ (read for the last time by the Riccati recursion).
     __host__ __device__ explicit WaveLds(int N) {
         int o = 0;
         auto take = [&](int c) { int r = o; o += c; return r; };
-        U = take(N * 4); UT = take(N * 4); DU = take(N * 4); AB = take(N * 60); H = take(N * 55); Q = take(N * 10);
-        XD = take(N * 6); XQ = take(N * 6); PS = take((N + 1) * 6); KK = take(N * 40); kk = take(N * 4); OB = take(3 * WKT_MAX);
+        U = take(N * 4); AB = take(N * 60); H = take((N + 1) * 55); Q = take(N * 10);
+        XD = take(N * 6); XQ = take(N * 6); PS = take((N + 1) * 6); OB = take(3 * WKT_MAX);
         Pm = take(100); Pn = take(100); pv = take(10); pn = take(10); PAB = take(100); Quu = take(16); QX = take(40); qu = take(4);
-        RD = take(N * 4); Dl = take(4); DX = take((N + 1) * 6);
+        UP = take(4); Dl = take(4);
+        UT = XD; DX = PS; DU = XQ;
         total = o;
     }
 };
+#define VT_KK(kk) (lds + L.H + ((kk) + 1) * 55)
+#define VT_kk(kk) (lds + L.H + ((kk) + 1) * 55 + 40)
 
 size_t mpcvtol_wave_lds_bytes(int horizon) { return (size_t)WaveLds(horizon).total * sizeof(double); }
 
@@ -81,7 +89,8 @@ __device__ __attribute__((noinline)) bool vtol_riccati(ldsd* lds, const WaveLds 
     __syncthreads();
     for (int kk = N - 1; kk >= 0; --kk) {
         const ldsd* AB = VT_AB(kk); const ldsd* H = lds + L.H + kk * 55;
-        const ldsd* q = lds + L.Q + kk * 10; const ldsd* rD = lds + L.RD + kk * NU;
+        const ldsd* q = lds + L.Q + kk * 10;
+        const ldsd* Uk = lds + L.U + kk * NU; const ldsd* Um = kk ? lds + L.U + (kk - 1) * NU : lds + L.UP;   // rD_i = Dl_i (u_k - u_{k-1})_i
         // A
         {
             double a0[NX], b0[NX], a1[NX], b1[NX];
@@ -106,7 +115,7 @@ __device__ __attribute__((noinline)) bool vtol_riccati(ldsd* lds, const WaveLds 
             if (lane < 40) { if (bc < NX) QX[bi * 10 + bc] = v; else Quu[bi * 4 + bc - NX] = v; }
             if (lane >= 40 && lane < 44) {
                 const int i = lane - 40;
-                double w = q[6 + i] - rD[i] + pc[6 + i];
+                double w = q[6 + i] - Dl[i] * (Uk[i] - Um[i]) + pc[6 + i];
 #pragma unroll
                 for (int r = 0; r < NX; ++r) w += AB[r * 10 + 6 + i] * pc[r];
                 qu[i] = w;
@@ -129,14 +138,14 @@ __device__ __attribute__((noinline)) bool vtol_riccati(ldsd* lds, const WaveLds 
             const double y0 = b0 * r0, y1 = (b1 - l10 * y0) * r1, y2 = (b2 - l20 * y0 - l21 * y1) * r2, y3 = (b3 - l30 * y0 - l31 * y1 - l32 * y2) * r3;
             const double x3 = y3 * r3, x2 = (y2 - l32 * x3) * r2, x1 = (y1 - l21 * x2 - l31 * x3) * r1, x0_ = (y0 - l10 * x1 - l20 * x2 - l30 * x3) * r0;
             if (lane < 11) {
-                ldsd* dst = c < NV ? lds + L.KK + kk * 40 + c : lds + L.kk + kk * NU;
+                ldsd* dst = c < NV ? VT_KK(kk) + c : VT_kk(kk);
                 dst[0] = x0_; dst[bst] = x1; dst[2 * bst] = x2; dst[3 * bst] = x3;
             }
         }
         __syncthreads();
         // D
         {
-            const ldsd* KKm = lds + L.KK + kk * 40; const ldsd* kkv = lds + L.kk + kk * NU;
+            const ldsd* KKm = VT_KK(kk); const ldsd* kkv = VT_kk(kk);
             double a0[NX], b0[NX], c0[NU], d0[NU];
 #pragma unroll
             for (int i = 0; i < NX; ++i) { a0[i] = AB[i * 10 + trr]; b0[i] = PAB[i * 10 + tcc]; }
@@ -156,7 +165,7 @@ __device__ __attribute__((noinline)) bool vtol_riccati(ldsd* lds, const WaveLds 
 #pragma unroll
                 for (int i = 0; i < NX; ++i) w += AB[i * 10 + rx] * pc[i];
                 if (kk >= 1) w += lds[L.XQ + (kk - 1) * 6 + rx];
-                w = r < NX ? w : rD[r >= NX ? r - NX : 0];
+                { const int ri = r >= NX ? r - NX : 0; w = r < NX ? w : Dl[ri] * (Uk[ri] - Um[ri]); }
 #pragma unroll
                 for (int i = 0; i < NU; ++i) w -= QX[i * 10 + r] * kkv[i];
                 pn[r] = w;
@@ -178,10 +187,10 @@ __device__ __attribute__((noinline)) void vtol_lq_forward(ldsd* lds, const WaveL
         {
             double a0[NV], b0[NV];
 #pragma unroll
-            for (int c = 0; c < NX; ++c) { a0[c] = lds[L.KK + kk * 40 + li * NV + c]; b0[c] = lds[L.DX + kk * 6 + c]; }
+            for (int c = 0; c < NX; ++c) { a0[c] = VT_KK(kk)[li * NV + c]; b0[c] = lds[L.DX + kk * 6 + c]; }
 #pragma unroll
-            for (int c = 0; c < NU; ++c) { a0[6 + c] = lds[L.KK + kk * 40 + li * NV + 6 + c]; b0[6 + c] = kk > 0 ? lds[L.DU + (kk - 1) * NU + c] : 0.0; }
-            double v = lds[L.kk + kk * NU + li];
+            for (int c = 0; c < NU; ++c) { a0[6 + c] = VT_KK(kk)[li * NV + 6 + c]; b0[6 + c] = kk > 0 ? lds[L.DU + (kk - 1) * NU + c] : 0.0; }
+            double v = VT_kk(kk)[li];
 #pragma unroll
             for (int c = 0; c < NV; ++c) v -= a0[c] * b0[c];
             if (lane < NU) lds[L.DU + kk * NU + lane] = v;
@@ -518,11 +527,8 @@ struct Wave {
         }
         if (act) {
 #pragma unroll
-            for (int j = 0; j < NU; ++j) {
-                const double um = k ? lds[L.U + (k - 1) * NU + j] : uprev[j];
-                lds[L.RD + k * NU + j] = 2.0 * cw * P.R[j] * (lds[L.U + k * NU + j] - um);
-                if (k == 0) lds[L.Dl + j] = 2.0 * cw * P.R[j];
-            }
+            for (int j = 0; j < NU; ++j)
+                if (k == 0) { lds[L.Dl + j] = 2.0 * cw * P.R[j]; lds[L.UP + j] = uprev[j]; }
 #pragma unroll
             for (int i = 0; i < 55; ++i) lds[L.H + k * 55 + i] = H[i];
 #pragma unroll
@@ -640,11 +646,11 @@ struct Wave {
                 }
                 if (resto) zeta = sqrt(mu);
                 VPROF_ADD(6)
-                stage_blocks(cw, resto, zeta, mu, rho);
-                VPROF_ADD(3)
                 double delta = 0.0;
                 bool ok = false;
                 for (int tr = 0; tr < 40; ++tr) {
+                    stage_blocks(cw, resto, zeta, mu, rho);                 // rebuilt for a retry: the gains of the failed pass sit in the slots of H
+                    VPROF_ADD(3)
                     if (riccati(delta + zeta)) { ok = true; break; }
                     sync();
                     delta = delta == 0.0 ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
