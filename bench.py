@@ -497,7 +497,7 @@ def vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
             "optimal_fraction": float((st == 0).double().mean().item()),
             "infeasible_fraction": float((st == 1).double().mean().item()),
             "mean_ipm_iterations": float(it.double().mean().item()), "max_ipm_iterations": int(it.max().item()),
-            "workspace_MB": ctl._ws.numel() / 1e6}, "mpcvtol_kernel<float>")
+            "lds_KB_per_problem": 39.3, "problems_per_CU": 4}, "mpcvtol_wave_kernel<float, 8>")
 
 
 def manip_closed_loop_leg(dev, B=4096, T=100, seed=0):

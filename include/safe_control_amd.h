@@ -620,6 +620,8 @@ int sc_backupcbf_rollout_batch(const sc_backupcbf_params* params, int64_t B, int
  */
 #define SC_QUADTRACK_QUAD2D 0
 #define SC_QUADTRACK_QUAD3D 1
+#define SC_QUADTRACK_VTOL2D 2   /* X [B,6], u [B,4], goal_out [B,2]; 'rotate' skipped, reference input zero (vtol2D.py:459-465), obstacles
+                                  inside the 1.2 pi cone about the pitch angle first (tracking.py:354-355), ground and pitch tests (:490-495) */
 
 typedef struct sc_quadtrack_params {
     int32_t model;               /* SC_QUADTRACK_QUAD2D: X [B,6], u [B,2], goal_out [B,2];  _QUAD3D: X [B,12], u [B,4], goal_out [B,3] */
@@ -633,6 +635,8 @@ typedef struct sc_quadtrack_params {
     double  mass;                /* Quad2D 1.0 (quad2D.py:41), Quad3D 3.0 (quad3D.py:50)                                    */
     double  inertia, f_min, f_max;                                   /* Quad2D (quad2D.py:42-44)                            */
     double  Ix, Iy, Iz, L, nu, u_min, u_max;                         /* Quad3D (quad3D.py:51-59)                            */
+    double  airframe[21];        /* VTOL2D: as sc_mpcvtol_params.airframe (mass and inertia are read from here for this model)   */
+    double  pitch_limit;         /* VTOL2D: what tracking.py:493 compares |theta| with -- robot_spec['pitch_max'] AS GIVEN (degrees: 15) */
 } sc_quadtrack_params;
 
 /* X [B,nx]; waypoints, n_wp, wp_index, state_machine, ret as in sc_tracking_select_batch; goal [B,4] in/out = (gx, gy, gz,

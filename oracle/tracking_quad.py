@@ -9,6 +9,11 @@ robot functions and control_step, tests/golden/make_golden_quads.py).  Follows:
            models take every obstacle: angle_unpassed = 2 pi), control_step :559-668, is_in_fov robots/robot.py:854-872 with
            yaw = X[2] (Quad2D) / X[5] (Quad3D) robots/robot.py:449-452
   MPCCBF.solve_control_problem protocol                     position_control/mpc_cbf.py:366-402
+  VTOL2D   X0 padding tracking.py:94-99 (cruise at 5 m/s), 'rotate' skipped (:512-513), is_in_fov always True (robot.py:858-860), zero
+           nominal_input / stop (vtol2D.py:459-465), has_stopped on the planar speed (:467-469), obstacles inside the 1.2 pi cone about
+           the pitch angle first and the nearest of all when the cone is empty (tracking.py:354-355,389-394), ground and pitch tests
+           (:490-495: |theta| against robot_spec['pitch_max'] as given -- degrees), step = oracle/mpc_vtol.vt_S.  The reference's
+           closed loop for this model cannot be run here (do-mpc / IPOPT absent): this part is a restatement, not pinned on a run.
 """
 import math
 
@@ -118,6 +123,9 @@ def q3_rotate_to(X, ang, spec, k=2.0):
 
 
 def default_spec(model):
+    if model == "VTOL2D":
+        from . import mpc_vtol as OV
+        return OV.default_spec()
     if model == "Quad2D":
         return dict(R.default_spec(R.MODEL_QUAD2D))
     s = dict(mass=3.0, Ix=0.5, Iy=0.5, Iz=0.5, L=0.3, nu=0.1, u_max=10.0, u_min=-10.0, radius=0.25)   # quad3D.py:50-61
@@ -128,13 +136,17 @@ class QuadTrackingOracle:
     """Single-agent closed loop (mpc_cbf position controller = this repo's oracle NLP solver)."""
 
     def __init__(self, model, X0, spec=None, dt=0.05, obs=None, num_constraints=10, enable_rotation=True, horizon=10, solve_fn=None):
-        assert model in ("Quad2D", "Quad3D")
-        self.model, self.q3 = model, model == "Quad3D"
+        assert model in ("Quad2D", "Quad3D", "VTOL2D")
+        self.model, self.q3, self.vt = model, model == "Quad3D", model == "VTOL2D"
+        if self.vt and horizon == 10:
+            horizon = 30                                       # mpc_cbf.py:41
         self.spec = default_spec(model)
         self.spec.update(spec or {})
         self.spec.setdefault("exploration", False)
         X0 = np.asarray(X0, dtype=float).reshape(-1)
-        if not self.q3:                                       # tracking.py:80-84
+        if self.vt:                                           # tracking.py:94-99
+            self.X = np.array([X0[0], X0[1], 0.0, 5.0, 0.0, 0.0]) if X0.shape[0] in (2, 3) else X0.copy()
+        elif not self.q3:                                     # tracking.py:80-84
             self.X = np.array([X0[0], X0[1], 0, 0, 0, 0.0]) if X0.shape[0] in (2, 3) else X0.copy()
         else:                                                 # tracking.py:85-93
             X = np.zeros(12)
@@ -155,10 +167,10 @@ class QuadTrackingOracle:
         self.reached_threshold, self.rotation_threshold = self.spec.get("reached_threshold", 0.3), 0.1
         self.fov_angle = math.radians(float(self.spec.get("fov_angle", 70.0)))
         self.n_pos = 3 if self.q3 else 2
-        self.u_prev = np.zeros(4 if self.q3 else 2)
+        self.u_prev = np.zeros(4 if (self.q3 or self.vt) else 2)
         self.solve_fn = solve_fn
         self.u_pos = None
-        self.mdl = OL.quad3d_model(dict(self.spec), dt=dt) if self.q3 else OG.quad2d_model(dict(self.spec), dt=dt)
+        self.mdl = None if self.vt else (OL.quad3d_model(dict(self.spec), dt=dt) if self.q3 else OG.quad2d_model(dict(self.spec), dt=dt))
 
     @property
     def yaw(self):
@@ -188,7 +200,7 @@ class QuadTrackingOracle:
         if self.state_machine == "rotate":
             rg = self.waypoints[self.current_goal_index]
             goal_angle = math.atan2(rg[1] - self.X[1], rg[0] - self.X[0])
-            if not self.q3:                                   # Quad2D skips 'rotate' (tracking.py:512-513)
+            if not self.q3:                                   # Quad2D and VTOL2D skip 'rotate' (tracking.py:512-513)
                 self.state_machine = "track"
             if not self.enable_rotation:
                 self.state_machine = "track"
@@ -209,12 +221,23 @@ class QuadTrackingOracle:
         """get_nearest_unpassed_obs with angle_unpassed = 2 pi: the K nearest centres, ties by index."""
         if len(self.obs) == 0:
             return None
-        d = np.hypot(self.obs[:, 0] - self.X[0], self.obs[:, 1] - self.X[1])
+        pool = self.obs
+        if self.vt:                                           # angle_unpassed = 1.2 pi about the pitch angle; empty cone: everything
+            ang = np.arctan2(pool[:, 1] - self.X[1], pool[:, 0] - self.X[0])
+            front = np.abs(R.angle_normalize(ang - self.yaw)) <= 0.6 * np.pi
+            if front.any():
+                pool = pool[front]
+        d = np.hypot(pool[:, 0] - self.X[0], pool[:, 1] - self.X[1])
         order = np.argsort(d, kind="stable")[: self.K]
-        return self.obs[order]
+        return pool[order]
+
+    def _collide(self):
+        if is_collide(self.X, self.obs, self.spec["radius"]):
+            return True
+        return self.vt and (self.X[1] < 0 or abs(self.X[2]) > self.spec["pitch_max"])     # tracking.py:490-495
 
     def control_step(self):
-        has_stopped = q3_has_stopped(self.X) if self.q3 else q2_has_stopped(self.X)
+        has_stopped = q3_has_stopped(self.X) if self.q3 else q2_has_stopped(self.X)      # VTOL2D: the same planar-speed test (vtol2D.py:467-469)
         if self.state_machine == "stop":
             if has_stopped:
                 self.state_machine = "rotate" if self.enable_rotation else "track"
@@ -222,7 +245,9 @@ class QuadTrackingOracle:
         else:
             self.goal = self.update_goal()
         near = self.nearest()
-        if self.state_machine == "rotate":
+        if self.vt:
+            u_ref = np.zeros(4)
+        elif self.state_machine == "rotate":
             ga = math.atan2(self.goal[1] - self.X[1], self.goal[0] - self.X[0])
             u_ref = q3_rotate_to(self.X, ga, self.spec) if self.q3 else np.array([0.0, 2.0 * R.angle_normalize(ga - self.X[2])])
         elif self.goal is None:
@@ -237,17 +262,24 @@ class QuadTrackingOracle:
                 obs[: len(near)] = near[:, :7]
             if self.solve_fn is not None:
                 u = self.solve_fn(self.X, self.u_prev, self.goal, obs)
+            elif self.vt:
+                from . import mpc_vtol as OV
+                u = OV.solve(self.X, self.u_prev, self.goal[:2], obs, N=self.N, spec=dict(self.spec), dt=self.dt)[0]
             elif self.q3:
                 u = OL.solve(self.mdl, self.X, self.u_prev, self.goal[:3], obs, N=self.N)[0]
             else:
                 u = OG.solve(self.mdl, self.X, self.u_prev, self.goal[:2], obs, N=self.N)[0]
             u = np.asarray(u, dtype=float)
             self.u_prev = u.copy()
-        if is_collide(self.X, self.obs, self.spec["radius"]):
+        if self._collide():
             return -2
-        self.X = q3_step(self.X, u, self.dt, self.spec) if self.q3 else q2_step(self.X, u, self.dt, self.spec)
+        if self.vt:
+            from . import mpc_vtol as OV
+            self.X = OV.vt_S(self.X, u, self.spec, self.dt)
+        else:
+            self.X = q3_step(self.X, u, self.dt, self.spec) if self.q3 else q2_step(self.X, u, self.dt, self.spec)
         self.u_pos = np.asarray(u, dtype=float).reshape(-1)
-        if is_collide(self.X, self.obs, self.spec["radius"]):
+        if self._collide():
             return -2
         if self.goal is None and self.state_machine != "stop":
             return -1

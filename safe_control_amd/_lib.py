@@ -52,7 +52,7 @@ class QuadTrackParams(C.Structure):
         ("dt", C.c_double), ("reached_threshold", C.c_double), ("rotation_threshold", C.c_double), ("robot_radius", C.c_double),
         ("mass", C.c_double), ("inertia", C.c_double), ("f_min", C.c_double), ("f_max", C.c_double),
         ("Ix", C.c_double), ("Iy", C.c_double), ("Iz", C.c_double), ("L", C.c_double), ("nu", C.c_double),
-        ("u_min", C.c_double), ("u_max", C.c_double),
+        ("u_min", C.c_double), ("u_max", C.c_double), ("airframe", C.c_double * 21), ("pitch_limit", C.c_double),
     ]
 
 

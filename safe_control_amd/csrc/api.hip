@@ -510,12 +510,16 @@ int sc_manip_tracking_rollout_batch(const sc_manip_tracking_params* params, int6
 static int check_quadtrack(const sc_quadtrack_params* p, int64_t B, int32_t M) {
     if (!p) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
     if (B < 0 || M < 0) return sc::fail(SC_ERR_INVALID_ARGUMENT, "B < 0 or M < 0");
-    if (p->model != SC_QUADTRACK_QUAD2D && p->model != SC_QUADTRACK_QUAD3D) return sc::fail(SC_ERR_INVALID_ARGUMENT, "model must be SC_QUADTRACK_QUAD2D or _QUAD3D");
+    if (p->model != SC_QUADTRACK_QUAD2D && p->model != SC_QUADTRACK_QUAD3D && p->model != SC_QUADTRACK_VTOL2D)
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "model must be SC_QUADTRACK_QUAD2D, _QUAD3D or _VTOL2D");
     if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64) return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
     if (p->num_constraints < 1 || p->num_constraints > SC_TRACKING_MAX_CONSTRAINTS) return sc::fail(SC_ERR_UNSUPPORTED, "num_constraints outside 1..SC_TRACKING_MAX_CONSTRAINTS");
     if (p->max_waypoints < 1) return sc::fail(SC_ERR_INVALID_ARGUMENT, "max_waypoints < 1");
     if ((size_t)M * 7 * 8 > 64 * 1024) return sc::fail(SC_ERR_UNSUPPORTED, "obstacle table does not fit 64 KiB of LDS");
-    if (!(p->dt > 0) || !(p->mass > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "dt and mass must be > 0");
+    if (!(p->dt > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "dt must be > 0");
+    if (p->model != SC_QUADTRACK_VTOL2D && !(p->mass > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "mass must be > 0");
+    if (p->model == SC_QUADTRACK_VTOL2D && (!(p->airframe[0] > 0) || !(p->airframe[1] > 0) || !(p->pitch_limit > 0)))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "VTOL2D: airframe mass and inertia and pitch_limit must be > 0");
     if (p->model == SC_QUADTRACK_QUAD2D && (!(p->inertia > 0) || !(p->robot_radius > 0))) return sc::fail(SC_ERR_INVALID_ARGUMENT, "Quad2D: inertia and radius must be > 0");
     if (p->model == SC_QUADTRACK_QUAD3D && (!(p->Ix > 0) || !(p->Iy > 0) || !(p->Iz > 0) || !(p->L > 0) || !(p->nu > 0)))
         return sc::fail(SC_ERR_INVALID_ARGUMENT, "Quad3D: Ix, Iy, Iz, L, nu must be > 0");

@@ -52,6 +52,17 @@ struct Params {                      // filled from sc_mpcvtol_params by the lau
     double inv_m, inv_I, kf_m, kr_m, kp_m, lfkf_I, lrkr_I;
 };
 
+// the 21 airframe constants (sc_mpcvtol_params.airframe order) and what the aero model precomputes from them
+SC_HD inline void set_airframe(Params& P, const double* a) {
+    P.mass = a[0]; P.inertia = a[1]; P.S_wing = a[2]; P.rho_air = a[3]; P.C_L0 = a[4]; P.C_Lalpha = a[5]; P.M = a[6]; P.alpha_0 = a[7];
+    P.C_Ldelta_e = a[8]; P.C_D0 = a[9]; P.C_Dalpha = a[10]; P.C_Ddelta_e = a[11]; P.C_m0 = a[12]; P.C_malpha = a[13]; P.C_mdelta_e = a[14];
+    P.chord = a[15]; P.k_front = a[16]; P.k_rear = a[17]; P.k_pusher = a[18]; P.ell_f = a[19]; P.ell_r = a[20];
+    P.eMa0sq = exp(2.0 * P.M * P.alpha_0);
+    P.inv_m = 1.0 / P.mass; P.inv_I = 1.0 / P.inertia;
+    P.kf_m = P.k_front / P.mass; P.kr_m = P.k_rear / P.mass; P.kp_m = P.k_pusher / P.mass;
+    P.lfkf_I = P.ell_f * P.k_front / P.inertia; P.lrkr_I = P.ell_r * P.k_rear / P.inertia;
+}
+
 #ifdef SC_VTOL_WITH_C_PARAMS
 inline Params from_c(const sc_mpcvtol_params& c, int K) {
     Params P;
@@ -64,14 +75,7 @@ inline Params from_c(const sc_mpcvtol_params& c, int K) {
     P.tol = c.tol; P.acceptable_tol = c.acceptable_tol; P.mu_init = c.mu_init; P.mu_min = c.mu_min; P.row_noise = 1e-15;
     P.rho = c.resto.rho; P.kappa = c.resto.kappa; P.theta_tol = c.resto.theta_tol; P.resto_tol = c.resto.tol; P.small_alpha = c.resto.small_alpha;
     P.small_iter = c.resto.small_iter; P.max_entries = c.resto.max_entries;
-    const double* a = c.airframe;
-    P.mass = a[0]; P.inertia = a[1]; P.S_wing = a[2]; P.rho_air = a[3]; P.C_L0 = a[4]; P.C_Lalpha = a[5]; P.M = a[6]; P.alpha_0 = a[7];
-    P.C_Ldelta_e = a[8]; P.C_D0 = a[9]; P.C_Dalpha = a[10]; P.C_Ddelta_e = a[11]; P.C_m0 = a[12]; P.C_malpha = a[13]; P.C_mdelta_e = a[14];
-    P.chord = a[15]; P.k_front = a[16]; P.k_rear = a[17]; P.k_pusher = a[18]; P.ell_f = a[19]; P.ell_r = a[20];
-    P.eMa0sq = exp(2.0 * P.M * P.alpha_0);
-    P.inv_m = 1.0 / P.mass; P.inv_I = 1.0 / P.inertia;
-    P.kf_m = P.k_front / P.mass; P.kr_m = P.k_rear / P.mass; P.kp_m = P.k_pusher / P.mass;
-    P.lfkf_I = P.ell_f * P.k_front / P.inertia; P.lrkr_I = P.ell_r * P.k_rear / P.inertia;
+    set_airframe(P, c.airframe);
     return P;
 }
 #endif

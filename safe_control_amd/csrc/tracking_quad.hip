@@ -11,18 +11,20 @@
 
 #include "sc_math.hpp"
 #include "../../include/safe_control_amd.h"
+#include "mpc_vtol_solver.hpp"
 
 namespace sc {
 namespace {
 
 struct QtP {
-    int q3, nx, nu, ng, K, enable_rotation;
-    double dt, reached, rot_thr, R, mass, inertia, f_min, f_max, Ix, Iy, Iz, L, nu_c, u_min, u_max;
+    int q3, vt, nx, nu, ng, K, enable_rotation;
+    double dt, reached, rot_thr, R, mass, inertia, f_min, f_max, Ix, Iy, Iz, L, nu_c, u_min, u_max, pitch_limit;
 };
 
 __device__ __forceinline__ QtP make_qtp(const sc_quadtrack_params& p) {
     QtP P;
-    P.q3 = p.model == SC_QUADTRACK_QUAD3D; P.nx = P.q3 ? 12 : 6; P.nu = P.q3 ? 4 : 2; P.ng = P.q3 ? 3 : 2;
+    P.q3 = p.model == SC_QUADTRACK_QUAD3D; P.vt = p.model == SC_QUADTRACK_VTOL2D;
+    P.nx = P.q3 ? 12 : 6; P.nu = (P.q3 || P.vt) ? 4 : 2; P.ng = P.q3 ? 3 : 2; P.pitch_limit = p.pitch_limit;
     P.K = p.num_constraints; P.enable_rotation = p.enable_rotation;
     P.dt = p.dt; P.reached = p.reached_threshold; P.rot_thr = p.rotation_threshold; P.R = p.robot_radius;
     P.mass = p.mass; P.inertia = p.inertia; P.f_min = p.f_min; P.f_max = p.f_max;
@@ -163,8 +165,15 @@ __global__ __launch_bounds__(64) void quadtrack_select_kernel(
     int si[KMAX];
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) { sd[j] = __builtin_huge_val(); si[j] = -1; }
+    // VTOL2D (like the unicycles, tracking.py:354-355): obstacles inside the 1.2 pi cone about the heading -- the pitch angle -- count as
+    // unpassed and are preferred; with none in the cone the nearest of all are taken (:389-394)
+    bool any_front = false;
+    if (P.vt)
+        for (int m = 0; m < M; ++m)
+            any_front |= fabs(angle_normalize(atan2(qt_table[7 * m + 1] - y, qt_table[7 * m] - x) - yaw)) <= 0.6 * 3.141592653589793;
     for (int m = 0; m < M; ++m) {
         const double dx = qt_table[7 * m] - x, dy = qt_table[7 * m + 1] - y;
+        if (P.vt && any_front && !(fabs(angle_normalize(atan2(dy, dx) - yaw)) <= 0.6 * 3.141592653589793)) continue;
         double cd = sqrt(dx * dx + dy * dy);
         int ci = m;
         bool moved = false;
@@ -178,7 +187,9 @@ __global__ __launch_bounds__(64) void quadtrack_select_kernel(
         }
     }
     double ur[4] = {0, 0, 0, 0};
-    if (sm == SC_SM_ROTATE) {
+    if (P.vt) {
+        // nominal_input, stop, rotate_to of vtol2D.py:459-465 are not implemented there: zeros
+    } else if (sm == SC_SM_ROTATE) {
         const double ga = atan2(gy - y, gx - x);
         if (P.q3) q3_rotate_to(Xs, ga, P, ur);
         else { ur[0] = 0.0; ur[1] = 2.0 * angle_normalize(ga - Xs[2]); }             // quad2D.py:160-164 (never reached: Quad2D skips 'rotate')
@@ -227,7 +238,9 @@ __global__ __launch_bounds__(64) void quadtrack_apply_kernel(
     const int sm = state_machine[ag];
     const bool gvalid = ld(goal, ag * 4 + 3) != 0.0;
     const bool run = active && ret_out[ag] == 0;
-    const bool pre_fail = qt_collides(Xs[0], Xs[1], qt_table, M, P.R);
+    // VTOL2D: below the ground or past the pitch limit counts as a collision (tracking.py:490-495)
+    auto vt_fail = [&](const double* Xc) { return P.vt && (Xc[1] < 0.0 || fabs(Xc[2]) > P.pitch_limit); };
+    const bool pre_fail = qt_collides(Xs[0], Xs[1], qt_table, M, P.R) || vt_fail(Xs);
     if (P.q3) {                                                                        // quad3D.py:113-151
         const double w[4] = {U[0] + U[1] + U[2] + U[3], P.L * (U[1] - U[3]), P.L * (U[0] - U[2]), P.nu_c * (U[0] - U[1] + U[2] - U[3])};
         double k1[12], k2[12], k3[12], k4[12], t[12];
@@ -244,6 +257,15 @@ __global__ __launch_bounds__(64) void quadtrack_apply_kernel(
 #pragma unroll
         for (int i = 0; i < 12; ++i) Xn[i] = Xs[i] + P.dt / 6 * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
         Xn[3] = angle_normalize(Xn[3]); Xn[4] = angle_normalize(Xn[4]); Xn[5] = angle_normalize(Xn[5]);
+    } else if (P.vt) {                                                                 // vtol2D.py:299-321: Euler + pitch wrap
+        vtol::Params VP;
+        vtol::set_airframe(VP, p.airframe);
+        double acc[3], gc[4][3];
+        vtol::accel<double>(VP, Xs[2], Xs[3], Xs[4], U, acc, gc);
+        Xn[0] = Xs[0] + Xs[3] * P.dt; Xn[1] = Xs[1] + Xs[4] * P.dt; Xn[2] = angle_normalize(Xs[2] + Xs[5] * P.dt);
+        Xn[3] = Xs[3] + acc[0] * P.dt; Xn[4] = Xs[4] + acc[1] * P.dt; Xn[5] = Xs[5] + acc[2] * P.dt;
+#pragma unroll
+        for (int i = 6; i < 12; ++i) Xn[i] = 0.0;
     } else {                                                                           // quad2D.py:46-86
         double s, c;
         sincos(Xs[2], &s, &c);
@@ -257,7 +279,7 @@ __global__ __launch_bounds__(64) void quadtrack_apply_kernel(
     }
     int code;
     if (pre_fail) code = -2;
-    else if (qt_collides(Xn[0], Xn[1], qt_table, M, P.R)) code = -2;
+    else if (qt_collides(Xn[0], Xn[1], qt_table, M, P.R) || vt_fail(Xn)) code = -2;
     else code = (!gvalid && sm != SC_SM_STOP) ? -1 : 0;
     if (run) {
         if (!pre_fail) {

@@ -34,7 +34,7 @@ class BatchedTrackingController:
     """
 
     def __new__(cls, X0, robot_spec, *args, **kwargs):
-        if cls is BatchedTrackingController and robot_spec.get("model") in ("Quad2D", "Quad3D"):
+        if cls is BatchedTrackingController and robot_spec.get("model") in ("Quad2D", "Quad3D", "VTOL2D"):
             return super().__new__(BatchedQuadTrackingController)      # 6 / 12 states, 2 / 4 inputs: its own select / apply kernels
         return super().__new__(cls)
 
@@ -291,9 +291,10 @@ class BatchedTrackingController:
 
 
 class BatchedQuadTrackingController(BatchedTrackingController):
-    """The batched closed loop for Quad2D (examples/test_tracking.py --model quad) and Quad3D (--model quad3d) with the
-    reference's default position controller ``mpc_cbf``: per step  sc_quadtrack_select_batch -> one MPC-CBF launch for the
-    batch (csrc/mpc_gn.hip / csrc/mpc_lin.hip) -> sc_quadtrack_apply_batch.  ``X0`` rows follow tracking.py:80-93 (Quad2D:
+    """The batched closed loop for Quad2D (examples/test_tracking.py --model quad), Quad3D (--model quad3d) and VTOL2D
+    (examples/test_vtol.py) with the reference's default position controller ``mpc_cbf``: per step  sc_quadtrack_select_batch -> one
+    MPC-CBF launch for the batch (csrc/mpc_gn.hip / csrc/mpc_lin.hip / csrc/mpc_vtol_wave.hip) -> sc_quadtrack_apply_batch.
+    VTOL2D: ``X0`` rows [x, z(, .)] (cruise at 5 m/s, tracking.py:94-99) or six states.  ``X0`` rows follow tracking.py:80-93 (Quad2D:
     [x, z(, .)] or six states; Quad3D: [x, y], [x, y, yaw], [x, y, z, yaw] or twelve states); waypoints are [x, y, z] rows for
     Quad3D (the example's third column -- a heading for the planar models -- is the altitude goal there, tracking.py:501-502)."""
 
@@ -304,11 +305,12 @@ class BatchedQuadTrackingController(BatchedTrackingController):
         controller_type = controller_type or {"pos": "mpc_cbf"}
         self.pos_controller_type = controller_type.get("pos", "mpc_cbf")
         if self.pos_controller_type != "mpc_cbf":
-            raise ValueError("Quad2D / Quad3D closed loop: position controller 'mpc_cbf' (the reference's default)")
+            raise ValueError("Quad2D / Quad3D / VTOL2D closed loop: position controller 'mpc_cbf' (the reference's default)")
         if dyn_obs:
             raise ValueError("moving obstacle tables are stepped by the fused 'cbf_qp' rollout only")
         self.model = robot_spec["model"]
         self.q3 = self.model == "Quad3D"
+        self.vt = self.model == "VTOL2D"
         self.robot_spec = complete_robot_spec(robot_spec)
         self.robot_spec.setdefault("exploration", False)
         self.integrator = False
@@ -321,13 +323,21 @@ class BatchedQuadTrackingController(BatchedTrackingController):
         self.rotation_threshold = 0.1
         self.fov_angle = math.radians(float(self.robot_spec.get("fov_angle", 70.0)))
         self._lib = _lib.load()
-        self.nx, self.nu, self.ng = (12, 4, 3) if self.q3 else (6, 2, 2)
+        self.nx, self.nu, self.ng = (12, 4, 3) if self.q3 else ((6, 4, 2) if self.vt else (6, 2, 2))
         X0 = np.asarray(X0, dtype=np.float64)
         if X0.ndim == 1:
             X0 = X0[None, :]
         B = X0.shape[0]
         X = np.zeros((B, self.nx))
-        if not self.q3:                                        # tracking.py:80-84
+        if self.vt:                                            # tracking.py:94-99
+            if X0.shape[1] in (2, 3):
+                X[:, :2] = X0[:, :2]
+                X[:, 3] = 5.0
+            elif X0.shape[1] == 6:
+                X = X0.copy()
+            else:
+                raise ValueError("Invalid initial state dimension for VTOL2D")
+        elif not self.q3:                                      # tracking.py:80-84
             if X0.shape[1] in (2, 3):
                 X[:, :2] = X0[:, :2]
             elif X0.shape[1] == 6:
@@ -359,6 +369,8 @@ class BatchedQuadTrackingController(BatchedTrackingController):
         self.steps_done = 0
         if self.q3:
             from .position_control.mpc_cbf_linear import BatchedLinearMPCCBF as cls
+        elif self.vt:
+            from .position_control.mpc_cbf_vtol import BatchedVtolMPCCBF as cls
         else:
             from .position_control.mpc_cbf_gn import BatchedGnMPCCBF as cls
         self.mpc = cls(self.robot_spec, dt=self.dt, io_dtype=io_dtype)
@@ -422,7 +434,7 @@ class BatchedQuadTrackingController(BatchedTrackingController):
     def _params(self, n_steps=1):
         rs = self.robot_spec
         p = _lib.QuadTrackParams()
-        p.model = 1 if self.q3 else 0
+        p.model = 1 if self.q3 else (2 if self.vt else 0)
         p.io_dtype = self.io_dtype
         p.max_waypoints = int(self.waypoints.shape[1])
         p.waypoints_shared = 0
@@ -431,7 +443,11 @@ class BatchedQuadTrackingController(BatchedTrackingController):
         p.dt, p.reached_threshold, p.rotation_threshold = self.dt, self.reached_threshold, self.rotation_threshold
         p.robot_radius = float(rs["radius"])
         p.mass = float(rs["mass"])
-        if self.q3:
+        if self.vt:
+            for i, key in enumerate(_lib.VTOL_AIRFRAME_KEYS):
+                p.airframe[i] = float(rs[key])
+            p.pitch_limit = float(rs["pitch_max"])                 # tracking.py:493 compares |theta| [rad] with this number as given
+        elif self.q3:
             p.Ix, p.Iy, p.Iz, p.L, p.nu = (float(rs[k]) for k in ("Ix", "Iy", "Iz", "L", "nu"))
             p.u_min, p.u_max = float(rs["u_min"]), float(rs["u_max"])
         else:

@@ -124,3 +124,25 @@ def test_other_obstacle_counts_against_oracle(K):
     assert np.array_equal(st, o["st"])
     ok = o["st"] == 0
     assert ok.mean() >= 0.75 and np.abs(u.cpu().numpy() - o["u"])[ok].max() <= 1e-6 and np.abs(z.cpu().numpy() - o["z"])[ok].max() <= 2e-5
+
+
+def test_first_nlp_of_the_reference_example_scene():
+    """examples/test_vtol.py: 20 m/s at (2, 10), the ten nearest of its 24 discs (tracking.py:345-404), goal (70, 10).  That NLP has no
+    feasible point (tests/test_oracle_mpc_vtol.py); both solvers leave the regular phase, spend the rest of their 100 iterations in the
+    restoration and stop there: same status, same iteration count, same (unfinished) iterate -- what the kernel returns on the reference's
+    own scene is what the oracle defines, whatever IPOPT's restoration would have returned."""
+    p1, p2 = 67.0, 73.0
+    obs_all = np.array([[p1, z, 0.5] for z in (6.0, 7.0, 8.0, 9.0)] + [[p2, float(z), 0.5] for z in range(1, 16)] + [[60.0, 12.0, 1.5]])
+    x0 = np.array([2.0, 10.0, 0.0, 20.0, 0.0, 0.0])
+    near = obs_all[np.argsort(np.linalg.norm(obs_all[:, :2] - x0[:2], axis=1))[:10]]
+    obs = np.hstack([near, np.zeros((10, 4))])
+    goal = np.array([70.0, 10.0])
+    spec = {"model": "VTOL2D", "radius": 0.6, "v_max": 20.0}
+    ctl = sca.BatchedVtolMPCCBF(dict(spec), io_dtype="f64")
+    u, st, it, z = ctl.solve(t(x0[None]), t(np.zeros((1, 4))), t(goal[None]), t(obs[None]), want_z=True)
+    torch.cuda.synchronize()
+    uo, so, io, info = V.solve(x0, np.zeros(4), goal, obs, spec=dict(radius=0.6, v_max=20.0), return_info=True)
+    assert so == 2 and info["n_resto"] >= 1 and info["theta"] > 1.0          # stopped inside the restoration, violation left
+    assert int(st[0]) == so and int(it[0]) == io == 100
+    # an unfinished iterate is not a minimiser: 100 iterations of two arithmetic orders apart (host build of the lane solver: 9e-7)
+    assert np.abs(u.cpu().numpy()[0] - uo).max() <= 1e-4 and np.abs(z.cpu().numpy()[0] - info["z"]).max() <= 1e-4

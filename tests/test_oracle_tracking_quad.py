@@ -85,3 +85,29 @@ def test_oracle_solver_reproduces_a_few_recorded_solves():
             else:
                 u = OL.solve(OL.quad3d_model(dict(Q3), dt=0.05), x, up, goal[:3], obs, N=10)[0]
             assert np.abs(u - G[f"{tag}/mpc_u"][k]).max() <= 1e-9
+
+
+def test_vtol_loop_restatement():
+    """VTOL2D around a stub controller: X0 padding (5 m/s cruise), 'rotate' skipped, the 1.2 pi cone about the pitch angle with its
+    nearest-of-all fallback, zero reference input outside 'track', the ground test."""
+    from oracle.tracking_quad import QuadTrackingOracle
+    obs = np.array([[30.0, 10.0, 1.0, 0, 0, 0, 0], [-3.0, 10.0, 0.5, 0, 0, 0, 0], [10.0, 40.0, 1.0, 0, 0, 0, 0], [50.0, 9.0, 1.0, 0, 0, 0, 0]])
+    seen = []
+
+    def stub(X, up, goal, ob):
+        seen.append(ob.copy())
+        return np.array([0.6, 0.6, 0.3, 0.0])
+    o = QuadTrackingOracle("VTOL2D", [0.0, 10.0], obs=obs, num_constraints=3, solve_fn=stub)
+    assert np.array_equal(o.X, [0.0, 10.0, 0.0, 5.0, 0.0, 0.0]) and o.N == 30
+    o.set_waypoints(np.array([[0.0, 10.0], [100.0, 10.0]]))
+    assert o.state_machine == "track"
+    assert o.control_step() == 0
+    # in the cone: (30, 10), (50, 9) and (10, 40) (72 degrees up); (-3, 10) is behind -> never handed over while something is ahead
+    assert np.array_equal(seen[0][:, 0], [30.0, 10.0, 50.0])
+    o2 = QuadTrackingOracle("VTOL2D", [0.0, 10.0], obs=obs[1:2], num_constraints=3, solve_fn=stub)
+    o2.set_waypoints(np.array([[0.0, 10.0], [100.0, 10.0]]))
+    o2.control_step()
+    assert seen[-1][0, 0] == -3.0 and seen[-1][1, 0] == 1000.0            # empty cone: nearest of all, padded with the far dummy
+    low = QuadTrackingOracle("VTOL2D", [0.0, 0.2, 0.0, 10.0, -5.0, 0.0], obs=obs, num_constraints=3, solve_fn=lambda *a: np.zeros(4))
+    low.set_waypoints(np.array([[0.0, 0.2], [100.0, 0.2]]))
+    assert [low.control_step() for _ in range(2)][-1] == -2 and low.X[1] < 0
