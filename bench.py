@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_ACHIEVABLE_GBS = 6300.0   # what a streaming kernel reaches on this part (MI355X_MICROARCH.md: "8 TB/s peak (spec); ~6.3 TB/s achievable")
 BYTES_IN_CBFQP = lambda K, es: (4 + 2 + 7 * K) * es            # X + u_ref + obs rows   # noqa: E731
 BYTES_OUT_CBFQP = lambda K, es: (2 + K) * es + 4               # u + h + status(int32)   # noqa: E731
 
@@ -1014,7 +1015,8 @@ def sweep(ctl, dev, td, es, K):
             ms = e0.elapsed_time(e1) / n
             gbs = nbytes / (ms * 1e-3) / 1e9
             row.update({"kernel_us" + label: 1e3 * ms, "solves_per_s" + label: B / (ms * 1e-3),
-                        "achieved_GBs" + label: gbs, "frac_hbm_peak" + label: gbs / HBM_PEAK_GBS})
+                        "achieved_GBs" + label: gbs, "frac_hbm_peak" + label: gbs / HBM_PEAK_GBS,
+                        "frac_hbm_achievable" + label: gbs / HBM_ACHIEVABLE_GBS})
         res.append(row)
         del X, ur, obs, out
     return res
