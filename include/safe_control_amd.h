@@ -270,7 +270,8 @@ typedef struct sc_mpcgn_params {
     int32_t model_id;        /* SC_MODEL_DOUBLE_INTEGRATOR2D, SC_MODEL_QUAD2D, SC_MODEL_KINEMATIC_BICYCLE2D[_C3BF|_DPCBF] */
     int32_t io_dtype, horizon, max_iter, obs_shared, acceptable_iter;      /* as sc_mpccbf_params                  */
     int32_t circles_only;    /* 1: no superellipsoid branch in the model's DT barrier (KB, Quad2D)                 */
-    int32_t reserved;
+    int32_t slack_reset;     /* line search: 0 off; 2: s = g where g >= mu / nu after a trial step (the oracle's setting for the
+                                KinematicBicycle2D family since round 3; as sc_mpcvtol_params, mode 1 is not offered here) */
     double  dt;
     double  Q[6], R[2];      /* mpc_cbf.py:28-36                                                                   */
     double  alpha1, alpha2;  /* mpc_cbf.py:60-76 (C3BF / DPCBF: alpha, 0)                                          */

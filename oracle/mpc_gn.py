@@ -168,7 +168,8 @@ def kb_model(spec=None, dt=0.05):
     return dict(name="KinematicBicycle2D", nx=4, nu=2, F=kb_F, S=kb_S, H=kb_H, spec=s, dt=dt, Q=np.array([50.0, 50.0, 1.0, 1.0]),
                 R=np.array([0.5, 5000.0]), alpha1=0.1, alpha2=0.1, beta=1.1, radius=s["radius"],
                 u_lo=np.array([-s["a_max"], -s["beta_max"]]), u_hi=np.array([s["a_max"], s["beta_max"]]),
-                xb=[(3, -s["v_max"], s["v_max"])], circles_only=True)
+                xb=[(3, -s["v_max"], s["v_max"])], circles_only=True,
+                slack_reset=2)    # the bicycles' line search resets the slacks (oracle/mpc_cbf.py: solve): fewer crawlers, more optima
 
 
 def di_model(spec=None, dt=0.05):
@@ -192,6 +193,8 @@ def quad2d_model(spec=None, dt=0.05):
 def params(model, N=10, **over):
     P = dict(M.DEFAULTS, N=N, dt=model["dt"], nu=model.get("nu", 2), u_lo=model["u_lo"], u_hi=model["u_hi"], radius=model["radius"],
              alpha1=model["alpha1"], alpha2=model["alpha2"], beta=model["beta"], model=model)
+    if "slack_reset" in model:
+        P["slack_reset"] = model["slack_reset"]
     P.update(over)
     P.setdefault("row_noise", 1e-15)                       # Armijo allowance for the round-off of far dummy-obstacle rows (as mpc_lin)
     return P

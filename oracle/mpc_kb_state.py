@@ -266,6 +266,8 @@ def dpcbf_model(spec=None, dt=0.05):
 def params(model, N=10, **over):
     P = dict(M.DEFAULTS, N=N, dt=model["dt"], nu=2, u_lo=model["u_lo"], u_hi=model["u_hi"], radius=model["radius"],
              alpha=model["alpha"], model=model)
+    if "slack_reset" in model:
+        P["slack_reset"] = model["slack_reset"]
     P.update(over)
     P.setdefault("row_noise", 1e-15)
     return P

@@ -127,7 +127,7 @@ class MpcGnParams(C.Structure):
     """Mirror of ``sc_mpcgn_params``."""
     _fields_ = [
         ("model_id", C.c_int32), ("io_dtype", C.c_int32), ("horizon", C.c_int32), ("max_iter", C.c_int32),
-        ("obs_shared", C.c_int32), ("acceptable_iter", C.c_int32), ("circles_only", C.c_int32), ("reserved", C.c_int32),
+        ("obs_shared", C.c_int32), ("acceptable_iter", C.c_int32), ("circles_only", C.c_int32), ("slack_reset", C.c_int32),
         ("dt", C.c_double), ("Q", C.c_double * 6), ("R", C.c_double * 2), ("alpha1", C.c_double), ("alpha2", C.c_double),
         ("u_lo", C.c_double * 2), ("u_hi", C.c_double * 2), ("v_min", C.c_double), ("v_max", C.c_double),
         ("rear_ax_dist", C.c_double), ("mass", C.c_double), ("inertia", C.c_double), ("robot_radius", C.c_double),

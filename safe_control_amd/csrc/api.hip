@@ -210,6 +210,7 @@ static int check_mpcgn(const sc_mpcgn_params* p, int64_t B, int32_t K, const voi
     if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
         return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
     if (p->horizon < 1 || p->horizon > 32) return fail(SC_ERR_UNSUPPORTED, "horizon outside [1, 32]");
+    if (p->slack_reset != 0 && p->slack_reset != 2) return fail(SC_ERR_INVALID_ARGUMENT, "slack_reset must be 0 or 2 on this entry point");
     if (mpcgn_lds_bytes(p->model_id, p->horizon, K, p->circles_only) > 160 * 1024)
         return fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
     if (!(p->dt > 0) || !(p->tol > 0) || !(p->acceptable_tol >= p->tol) || p->max_iter < 1 || !(p->mu_init > 0) || !(p->mu_min > 0))

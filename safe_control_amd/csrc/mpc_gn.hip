@@ -958,7 +958,8 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         if (!(e_opt < 1e300)) break;
         bool want_resto = RESTO && !resto && lmx > 1e10;                  // multipliers diverge: locally infeasible
         if (!RESTO && lmx > 1e10) { status = SC_STATUS_INFEASIBLE; break; }
-        bool accepted = false;
+        bool accepted = false, sreset = false;
+        double thr_reset = 0.0;
         double alpha = 0.0, ad = 0.0;
         if (!want_resto) {
         const double mu_old = mu;
@@ -1266,6 +1267,8 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         const double noise_rows = 1e-15 * nu_m * sum_g;                  // round-off of far dummy-obstacle rows (oracle: row_noise)
         GP(8);
         alpha = ap;
+        sreset = !OD && p.slack_reset == 2 && !resto;
+        thr_reset = mu * rcp_(nu_m);
         for (int ls = 0; ls < 12; ++ls) {
             for (int i = lane; i < n; i += 64) {
                 W.zt[i] = W.z[i] + alpha * W.dz[i];
@@ -1275,7 +1278,9 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             const double ft = gn_eval_any<MODEL, OD>(W.zt, W, d, c, q, lane, false, W.rhot);
             double srp = 0.0, slog = 0.0, st_ = 0.0, proxt = 0.0;
             for (int i = lane; i < m; i += 64) {
-                const double s_t = W.s[i] + alpha * W.ds[i];
+                const double s_lin = W.s[i] + alpha * W.ds[i], g_t = W.g[i];
+                // slack reset (oracle/mpc_cbf.py: solve, P["slack_reset"] = 2): for fixed z the merit function is smallest at s = max(g, mu / nu)
+                const double s_t = (sreset && g_t >= thr_reset) ? g_t : s_lin;
                 slog += log(s_t);
                 if (resto && i < d.mc) {
                     const double t = W.tel[i];
@@ -1332,7 +1337,8 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             if constexpr (OD) W.rho[i] = W.rho[i] + alpha * W.drho[i];
         }
         for (int i = lane; i < m; i += 64) {
-            const double s = W.s[i] + alpha * W.ds[i];
+            const double s_lin = W.s[i] + alpha * W.ds[i], g_t = W.g[i];       // W.g holds the accepted trial point's rows
+            const double s = (sreset && g_t >= thr_reset) ? g_t : s_lin;
             const double l0 = W.lam[i], dl = W.dlam[i];
             double l = l0 + ad * dl;
             const double mus = mu * rcp_(s);

@@ -29,13 +29,13 @@ def model_constants(robot_spec):
     if m == "KinematicBicycle2D":               # mpc_cbf.py:31-33,64-67,205-211; barrier inflation kinematic_bicycle2D.py:175 (1.1)
         return dict(nx=4, Q=[50.0, 50.0, 1.0, 1.0], R=[0.5, 5000.0], cbf_param={"alpha1": 0.1, "alpha2": 0.1}, beta=1.1,
                     u_lo=[-robot_spec["a_max"], -robot_spec["beta_max"]], u_hi=[robot_spec["a_max"], robot_spec["beta_max"]],
-                    circles_only=True)
+                    circles_only=True, slack_reset=2)
     if m in ("KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"):
         # mpc_cbf.py:31-33,68-73,205-211: one gain, row d_h + alpha h_k (:312-315); the barrier's own inflation (1.01 / 1.05) is fixed in
         # kinematic_bicycle2D_c3bf.py:77 / _dpcbf.py:86 and in the kernel
         return dict(nx=4, Q=[50.0, 50.0, 1.0, 1.0], R=[0.5, 5000.0], cbf_param={"alpha": 0.15}, beta=1.01 if m.endswith("C3BF") else 1.05,
                     u_lo=[-robot_spec["a_max"], -robot_spec["beta_max"]], u_hi=[robot_spec["a_max"], robot_spec["beta_max"]],
-                    circles_only=True)
+                    circles_only=True, slack_reset=2)
     raise NotImplementedError(m)
 
 
@@ -48,6 +48,7 @@ def make_params(robot_spec, mc, cbf_param, horizon, dt, radius, io_dtype, obs_sh
     p.max_iter = int(max_iter)
     p.obs_shared = 1 if obs_shared else 0
     p.circles_only = 1 if mc["circles_only"] else 0
+    p.slack_reset = int(mc.get("slack_reset", 0))         # the bicycles: 2 (oracle/mpc_gn.py: kb_model)
     p.dt = float(dt)
     for i, v in enumerate(mc["Q"]):
         p.Q[i] = float(v)
