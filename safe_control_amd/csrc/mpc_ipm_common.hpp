@@ -71,6 +71,9 @@ __device__ __forceinline__ void pow3(double x, double e, bool derivs, double& pe
 // but mpc_gn.hip's circles-only instantiations still break with the straight-line chain inlined (measured, round 3).  What is
 // established: the trigger is inlined code of the NEVER-EXECUTED superellipsoid branch (loop or not) next to the divergent pow()
 // call, in kernels at the edge of their register budget; pow3 noinline and the pow()-only build are right everywhere.  Guards:
+// A third manifestation (late round 3): adding the slack reset of the line search to mpc_gn.hip as a nested conditional on
+// p.slack_reset inside the two row loops made mpcgn_kernel<1, 10, false> -- the HOCBF bicycle, and only it -- stop every solve after
+// ~5 iterations, with the reset switched off as well; with the switch and the threshold hoisted out of the loops it is right.
 // tests/test_pow_chain_gpu.py solves superellipsoid scenes with integer exponents (chain, where a kernel uses it) and with
 // exponents a hair off an integer (pow()) through all three kernels and holds them together; every instantiation that ships is
 // under a parity test against the oracle, and tests/test_tracking_gpu.py::test_single_integrator_closed_loop_with_mpc is the
