@@ -153,6 +153,10 @@ typedef struct sc_resto_params {
     double  small_alpha;     /* the regular phase also hands over after small_iter consecutive accepted steps shorter  */
     int32_t small_iter;      /*   than small_alpha at an infeasible iterate (0.02, 4): IPOPT's alpha_min rule          */
     int32_t max_entries;     /* restoration may be entered this many times per solve (2); 0 disables it             */
+    int32_t slack_reset;     /* 1: the restoration's line search sets the slack of a row to g + t where that is >= mu / nu, the
+                              * minimiser of its merit function in s for fixed z, t (default; turns most restorations that crawled
+                              * to the iteration limit into certificates); 0: off                                     */
+    int32_t reserved;
 } sc_resto_params;
 
 typedef struct sc_mpccbf_params {

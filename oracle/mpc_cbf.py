@@ -40,7 +40,7 @@ DEFAULTS = dict(N=10, dt=0.05, Q=(50.0, 50.0, 0.01, 30.0), R=(0.5, 0.5), alpha1=
                 v_max=1.0, a_max=1.0, w_max=0.5, radius=0.25, beta=1.01,
                 tol=1e-6, acceptable_tol=1e-5, acceptable_iter=15, max_iter=100, mu_init=0.1, mu_min=1e-9,
                 resto_rho=1000.0, resto_kappa=0.1, resto_theta_tol=1e-6, resto_max=2, resto_tol=1e-2,
-                resto_small_alpha=0.02, resto_small_iter=4)
+                resto_small_alpha=0.02, resto_small_iter=4, resto_slack_reset=True)
 
 DUMMY_OBS = np.array([1000.0, 1000.0, 0.0, 0.0, 0.0, 0.0, 0.0])
 
@@ -353,6 +353,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     Hq = P.get("quadratic_cost")                                            # linear models: f is exactly quadratic in z
     t_ = np.zeros(m)                                                        # elastic variables of the restoration (0 on hard rows)
     sreset = int(P.get("slack_reset", 0))
+    sreset_r = bool(P.get("slack_reset_resto", P["resto_slack_reset"]))   # the restoration's line search resets the slack of a row to g + t
     for it in range(1, P["max_iter"] + 1):
         sf = SF_OFF if resto else sf0
         ev = evaluate(x0, z, u_prev, goal, obs, P, lam / sf, level=2)      # multipliers of the unscaled problem
@@ -485,6 +486,9 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
                     st = np.maximum(st, gt) if sreset == 1 else np.where(gt >= mu / nu, gt, st)
                 if resto:
                     tt = t_ + alpha * dt_
+                    if sreset_r:                                            # the same reset on g + t of the restoration's rows
+                        tot = e0["g"] + tt
+                        st = np.where(tot >= mu / nu, tot, st)
                     phit = 0.5 * zeta * float((zt - z_R) @ (zt - z_R)) + rho_R * float(np.sum(tt[el])) \
                         - mu * (np.sum(np.log(st)) + np.sum(np.log(tt[el]))) + nu * np.sum(np.abs(e0["g"] + tt - st))
                 elif Hq is not None:
@@ -529,7 +533,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
             lam = mu / s
             nu, n_acc = 10.0, 0
             continue
-        z, s = z + alpha * dz, (st if sreset and not resto else s + alpha * ds)
+        z, s = z + alpha * dz, (st if (sreset and not resto) or (sreset_r and resto) else s + alpha * ds)
         lam = lam + ad * dlam
         lam = np.minimum(np.maximum(lam, mu / (1e10 * s)), 1e10 * mu / s)   # IPOPT eq. (16) safeguard
         if resto:

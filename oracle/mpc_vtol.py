@@ -243,7 +243,9 @@ def params(N=30, spec=None, dt=0.05, **over):
     point converge on this model (tools/exp_vtol.py: 18-26 iterations on feasible cruise / hover / climb probes; with either one
     missing, 100 iterations end at KKT errors of 1e-2 .. 1e+2)."""
     from . import mpc_gn as G
-    P = G.params(vtol_model(spec, dt), N, exact_hessian=True, slack_reset=2)
+    # no slack reset inside the restoration for this model: with it the restoration converges -- to least-violation inputs such as
+    # (1, 0, 0, -0.5) that pitch the aircraft past its limit when applied (tools/exp_vtol_closed_loop.py, DESIGN.md (f) item 1)
+    P = G.params(vtol_model(spec, dt), N, exact_hessian=True, slack_reset=2, resto_slack_reset=False)
     P.update(over)
     return P
 

@@ -1148,6 +1148,8 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         SC_PH(10);
         // l1-merit backtracking
         alpha = ap;
+        const bool rreset = RESTO && resto && p.resto.slack_reset != 0;
+        const double thr_reset = mu * rcp_(nu);
         for (int ls = 0; ls < 12; ++ls) {                              // at most 12 halvings, then give up (best iterate)
             for (int i = lane; i < n; i += 64) {
                 W.zt[i] = W.z[i] + alpha * W.dz[i];
@@ -1158,16 +1160,18 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
             double srp = 0.0, st_ = 0.0, proxt = 0.0;
             LogSum lst;
             for (int i = lane; i < m; i += 64) {
-                const double st = W.sl[i] + alpha * W.ds[i];
-                lst.add(st);
+                const double s_lin = W.sl[i] + alpha * W.ds[i];
+                double tot = W.g[i];
                 if (RESTO && resto && i < c.mc) {
                     const double t = W.tel[i];
                     const double tt = t + alpha * ipm::resto_dt(W.lam[i], t, W.dlam[i], mu, rho_R);
                     lst.add(tt); st_ += tt;
-                    srp += fabs(W.g[i] + tt - st);
-                } else {
-                    srp += fabs(W.g[i] - st);
+                    tot += tt;
                 }
+                // slack reset of the restoration's line search (sc_resto_params.slack_reset): s = g + t where that is >= mu / nu
+                const double st = (rreset && tot >= thr_reset) ? tot : s_lin;
+                lst.add(st);
+                srp += fabs(tot - st);
             }
             if (RESTO && resto) {
                 for (int i = lane; i < n; i += 64) { const double dzr = W.zt[i] - W.zb[i]; proxt += dzr * dzr; }
@@ -1217,19 +1221,23 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
             W.z[i] = W.z[i] + alpha * W.dz[i];
             if constexpr (OD) W.rho[i] = W.rho[i] + alpha * W.drho[i];
         }
+        {
+        const bool rreset = RESTO && resto && p.resto.slack_reset != 0;   // W.g holds the accepted trial point's rows
+        const double thr_reset = mu * rcp_(nu);
         for (int i = lane; i < m; i += 64) {
-            const double s = W.sl[i] + alpha * W.ds[i];
+            const double s_lin = W.sl[i] + alpha * W.ds[i];
             const double l0 = W.lam[i], dl = W.dlam[i];
+            double tn = 0.0;
+            const bool el = RESTO && resto && i < c.mc;
+            if (el) { const double t = W.tel[i]; tn = t + alpha * ipm::resto_dt(l0, t, dl, mu, rho_R); W.tel[i] = tn; }
+            const double tot = W.g[i] + tn;
+            const double s = (rreset && tot >= thr_reset) ? tot : s_lin;
             double lam = l0 + ad * dl;
             const double mus = mu * rcp_(s);
             lam = fmin(fmax(lam, 1e-10 * mus), 1e10 * mus);               // IPOPT eq. (16) safeguard
-            if (RESTO && resto && i < c.mc) {
-                const double t = W.tel[i];
-                const double tn = t + alpha * ipm::resto_dt(l0, t, dl, mu, rho_R);
-                W.tel[i] = tn;
-                lam = ipm::resto_clamp_lam(lam, tn, mu, rho_R);
-            }
+            if (el) lam = ipm::resto_clamp_lam(lam, tn, mu, rho_R);
             W.sl[i] = s; W.lam[i] = lam;
+        }
         }
         SC_SYNC();
         SC_PH(11);

@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         const double noise_rows = 1e-15 * nu_m * sum_g;                  // round-off of far dummy-obstacle rows (oracle: row_noise)
         GP(8);
         alpha = ap;
-        sreset = !OD && p.slack_reset == 2 && !resto;
+        sreset = !OD && (resto ? p.resto.slack_reset != 0 : p.slack_reset == 2);
         thr_reset = mu * rcp_(nu_m);
         for (int ls = 0; ls < 12; ++ls) {
             for (int i = lane; i < n; i += 64) {
@@ -1278,17 +1278,18 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             const double ft = gn_eval_any<MODEL, OD>(W.zt, W, d, c, q, lane, false, W.rhot);
             double srp = 0.0, slog = 0.0, st_ = 0.0, proxt = 0.0;
             for (int i = lane; i < m; i += 64) {
-                const double s_lin = W.s[i] + alpha * W.ds[i], g_t = W.g[i];
-                // slack reset (oracle/mpc_cbf.py: solve, P["slack_reset"] = 2): for fixed z the merit function is smallest at s = max(g, mu / nu)
-                const double s_t = (sreset && g_t >= thr_reset) ? g_t : s_lin;
-                slog += log(s_t);
+                const double s_lin = W.s[i] + alpha * W.ds[i];
+                double tot = W.g[i];
                 if (resto && i < d.mc) {
                     const double t = W.tel[i];
                     const double t_t = t + alpha * ipm::resto_dt(W.lam[i], t, W.dlam[i], mu, rho_R);
-                    slog += log(t_t); st_ += t_t; srp += fabs(W.g[i] + t_t - s_t);
-                } else {
-                    srp += fabs(W.g[i] - s_t);
+                    slog += log(t_t); st_ += t_t; tot += t_t;
                 }
+                // slack reset (oracle/mpc_cbf.py: solve): for fixed z (and t) the merit function is smallest at s = max(g + t, mu / nu);
+                // regular phase: P["slack_reset"] = 2 of the bicycles, restoration: sc_resto_params.slack_reset
+                const double s_t = (sreset && tot >= thr_reset) ? tot : s_lin;
+                slog += log(s_t);
+                srp += fabs(tot - s_t);
             }
             slog = gsum(slog); srp = gsum(srp);
             double phit = sfe * ft - mu * slog + nu_m * srp;
@@ -1337,18 +1338,17 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             if constexpr (OD) W.rho[i] = W.rho[i] + alpha * W.drho[i];
         }
         for (int i = lane; i < m; i += 64) {
-            const double s_lin = W.s[i] + alpha * W.ds[i], g_t = W.g[i];       // W.g holds the accepted trial point's rows
-            const double s = (sreset && g_t >= thr_reset) ? g_t : s_lin;
+            const double s_lin = W.s[i] + alpha * W.ds[i];                     // W.g holds the accepted trial point's rows
             const double l0 = W.lam[i], dl = W.dlam[i];
+            double tn = 0.0;
+            const bool el = resto && i < d.mc;
+            if (el) { const double t = W.tel[i]; tn = t + alpha * ipm::resto_dt(l0, t, dl, mu, rho_R); W.tel[i] = tn; }
+            const double tot = W.g[i] + tn;
+            const double s = (sreset && tot >= thr_reset) ? tot : s_lin;
             double l = l0 + ad * dl;
             const double mus = mu * rcp_(s);
             l = fmin(fmax(l, 1e-10 * mus), 1e10 * mus);
-            if (resto && i < d.mc) {
-                const double t = W.tel[i];
-                const double tn = t + alpha * ipm::resto_dt(l0, t, dl, mu, rho_R);
-                W.tel[i] = tn;
-                l = ipm::resto_clamp_lam(l, tn, mu, rho_R);
-            }
+            if (el) l = ipm::resto_clamp_lam(l, tn, mu, rho_R);
             W.s[i] = s; W.lam[i] = l;
         }
         SC_SYNC();

@@ -753,6 +753,8 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         LP(8);
         alpha = ap;
         fresh = false;
+        const bool rreset = RESTO && resto && p.resto.slack_reset != 0;
+        const double thr_reset = mu * rcp_(nu_m);
         for (int ls = 0; ls < 12; ++ls) {
             for (int i = lane; i < n; i += TH) W.zt[i] = W.z[i] + alpha * W.dz[i];
             if constexpr (OD) for (int k = lane; k < N; k += TH) W.rhot[k] = W.rho[k] + alpha * W.drho[k];
@@ -761,15 +763,17 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
             const double f_t = lin_eval<TH, OD>(W.zt, W.rhot, W, d, c, lane, full, R);     // derivatives (circles: they cost nothing next to the rollout)
             double srp = 0.0, slog = 0.0;
             for (int i = lane; i < m; i += TH) {
-                const double s_t = W.s[i] + alpha * W.ds[i];
-                slog += log(s_t);
+                const double s_lin = W.s[i] + alpha * W.ds[i];
+                double tot = W.g[i];
                 if (RESTO && resto && i < d.mc) {
                     const double t = W.tel[i];
                     const double t_t = t + alpha * ipm::resto_dt(W.lam[i], t, W.dlam[i], mu, rho_R);
-                    slog += log(t_t); srp += fabs(W.g[i] + t_t - s_t);
-                } else {
-                    srp += fabs(W.g[i] - s_t);
+                    slog += log(t_t); tot += t_t;
                 }
+                // slack reset of the restoration's line search (sc_resto_params.slack_reset): s = g + t where that is >= mu / nu
+                const double s_t = (rreset && tot >= thr_reset) ? tot : s_lin;
+                slog += log(s_t);
+                srp += fabs(tot - s_t);
             }
             slog = lsum<TH>(slog, R); srp = lsum<TH>(srp, R);
             const double phit = phi0 + alpha * (gdz + lin_t) + 0.5 * alpha * alpha * curv - mu * (slog - sum_log) + nu_m * (srp - sum_rp);
@@ -819,19 +823,23 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
             if constexpr (!LEAN) { if (!(RESTO && resto)) W.gs[i] += alpha * sf * W.rd[i]; }
         }
         if constexpr (OD) for (int k = lane; k < N; k += TH) W.rho[k] = W.rho[k] + alpha * W.drho[k];
+        {
+        const bool rreset = RESTO && resto && p.resto.slack_reset != 0;   // W.g holds the accepted trial point's rows
+        const double thr_reset = mu * rcp_(nu_m);
         for (int i = lane; i < m; i += TH) {
-            const double s = W.s[i] + alpha * W.ds[i];
+            const double s_lin = W.s[i] + alpha * W.ds[i];
             const double l0 = W.lam[i], dl = W.dlam[i];
+            double tn = 0.0;
+            const bool el = RESTO && resto && i < d.mc;
+            if (el) { const double t = W.tel[i]; tn = t + alpha * ipm::resto_dt(l0, t, dl, mu, rho_R); W.tel[i] = tn; }
+            const double tot = W.g[i] + tn;
+            const double s = (rreset && tot >= thr_reset) ? tot : s_lin;
             double l = l0 + ad * dl;
             const double mus = mu * rcp_(s);
             l = fmin(fmax(l, 1e-10 * mus), 1e10 * mus);                   // IPOPT eq. (16) safeguard
-            if (RESTO && resto && i < d.mc) {
-                const double t = W.tel[i];
-                const double tn = t + alpha * ipm::resto_dt(l0, t, dl, mu, rho_R);
-                W.tel[i] = tn;
-                l = ipm::resto_clamp_lam(l, tn, mu, rho_R);
-            }
+            if (el) l = ipm::resto_clamp_lam(l, tn, mu, rho_R);
             W.s[i] = s; W.lam[i] = l;
+        }
         }
         SC_SYNC();
     }

@@ -40,7 +40,7 @@ constexpr int NX = 6, NU = 4, NV = 10, NXB = 5;
 constexpr int ST_OPTIMAL = 0, ST_INFEASIBLE = 1, ST_INACCURATE = 2;
 
 struct Params {                      // filled from sc_mpcvtol_params by the launcher
-    int N, K, max_iter, acceptable_iter, slack_reset;
+    int N, K, max_iter, acceptable_iter, slack_reset, resto_reset;
     double dt, Q[6], R[4], alpha1, alpha2, beta, radius, u_lo[4], u_hi[4], v_max, descent_max, pitch_max;
     double tol, acceptable_tol, mu_init, mu_min, row_noise;
     double rho, kappa, theta_tol, resto_tol, small_alpha;
@@ -74,7 +74,7 @@ inline Params from_c(const sc_mpcvtol_params& c, int K) {
     P.v_max = c.v_max; P.descent_max = c.descent_speed_max; P.pitch_max = c.pitch_max;
     P.tol = c.tol; P.acceptable_tol = c.acceptable_tol; P.mu_init = c.mu_init; P.mu_min = c.mu_min; P.row_noise = 1e-15;
     P.rho = c.resto.rho; P.kappa = c.resto.kappa; P.theta_tol = c.resto.theta_tol; P.resto_tol = c.resto.tol; P.small_alpha = c.resto.small_alpha;
-    P.small_iter = c.resto.small_iter; P.max_entries = c.resto.max_entries;
+    P.small_iter = c.resto.small_iter; P.max_entries = c.resto.max_entries; P.resto_reset = c.resto.slack_reset;
     set_airframe(P, c.airframe);
     return P;
 }
@@ -754,6 +754,7 @@ struct Solver {
                         if (resto) {
                             double tt = 0.0;
                             if (i < m_el) { tt = W(L.t + i) + alpha * W(L.dtt + i); st_t += tt; slogt += log(tt); }
+                            if (P.resto_reset && gt + tt >= mu / nu) st = gt + tt;       // sc_resto_params.slack_reset
                             sabs += fabs(gt + tt - st);
                         } else {
                             if (sreset) st = (P.slack_reset == 1) ? fmax(st, gt) : (gt >= mu / nu ? gt : st);
@@ -800,7 +801,7 @@ struct Solver {
             // take the step
             for (int i = 0; i < n; ++i) W(L.z + i) += alpha * W(L.dz + i);
             for (int i = 0; i < m; ++i) {
-                const double s = (sreset && !resto) ? W(L.st + i) : W(L.s + i) + alpha * W(L.ds + i);
+                const double s = ((sreset && !resto) || (P.resto_reset && resto)) ? W(L.st + i) : W(L.s + i) + alpha * W(L.ds + i);
                 double l = W(L.lam + i) + ad * W(L.dlam + i);
                 l = fmin(fmax(l, mu / (1e10 * s)), 1e10 * mu / s);
                 if (resto && i < m_el) {

@@ -763,6 +763,7 @@ struct Wave {
                             if (resto) {
                                 double tt = 0.0;
                                 if (r < WKT) { tt = t[r < WKT ? r : 0] + alpha * dtt[r < WKT ? r : 0]; st_t += tt; pr_t *= tt; }
+                                if (P.resto_reset && gt[r] + tt >= thr) st = gt[r] + tt;   // sc_resto_params.slack_reset
                                 sabs += fabs(gt[r] + tt - st);
                             } else {
                                 if (sreset) st = (P.slack_reset == 1) ? fmax(st, gt[r]) : (gt[r] >= thr ? gt[r] : st);
@@ -804,6 +805,10 @@ struct Wave {
                     for (int r = 0; r < WNR; ++r) {
                         double sn = s[r] + alpha * ds[r];
                         if (sreset && !resto) sn = (P.slack_reset == 1) ? fmax(sn, gt[r]) : (gt[r] >= mu * rcp_(nu) ? gt[r] : sn);
+                        if (resto && P.resto_reset) {
+                            const double tot = gt[r] + (r < WKT ? t[r < WKT ? r : 0] + alpha * dtt[r < WKT ? r : 0] : 0.0);
+                            if (tot >= mu * rcp_(nu)) sn = tot;
+                        }
                         double l = lam[r] + ad * dlam[r];
                         const double mus = mu * rcp_(sn);
                         l = fmin(fmax(l, 1e-10 * mus), 1e10 * mus);
