@@ -243,7 +243,7 @@ static int check_mpcvtol(const sc_mpcvtol_params* p, int64_t B, int32_t K, const
     if (p->kernel < 0 || p->kernel > 2) return fail(SC_ERR_INVALID_ARGUMENT, "kernel must be 0 (auto), 1 (lane per problem) or 2 (wave per problem)");
     if (p->kernel == 2 && !mpcvtol_uses_wave(*p, K)) return fail(SC_ERR_UNSUPPORTED, "the wave-per-problem kernel serves K <= 16, horizon <= 64");
     if (B > 0 && (!X || !u_prev || !goal || !obs || !u_out || !status_out)) return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
-    if (B > 0x7fffffffLL / 16384) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch (workspace index range)");
+    if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
     return SC_OK;
 }
 static int check_manip(const sc_manip_cbfqp_params* p, int64_t B, int32_t K, const void* X, const void* u_ref,
