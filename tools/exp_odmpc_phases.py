@@ -22,7 +22,7 @@ for name, ctl in (("plain", sca.BatchedMPCCBF(dict(spec), io_dtype="f32", horizo
                   ("optimal decay", sca.BatchedOptimalDecayMPCCBF(dict(spec), io_dtype="f32", horizon=10))):
     out = ctl.solve(X, up, g, ob, want_z=True)
     torch.cuda.synchronize()
-    it, z = out[2], out[-1]
+    it, z = out[-2], out[-1]
     ph = z.cpu().numpy()[:, :20].astype(np.float64)
     itn = it.cpu().numpy().astype(np.float64)
     res[name] = (ph.sum(0) / itn.sum(), itn.mean())
