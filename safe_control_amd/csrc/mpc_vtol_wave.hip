@@ -1,16 +1,20 @@
-// MPC-CBF for VTOL2D, the throughput kernel: ONE NLP PER WAVEFRONT, ONE STAGE PER LANE (K <= 8 obstacles).
+// MPC-CBF for VTOL2D, the kernel that serves it: ONE NLP PER WAVEFRONT, ONE STAGE PER LANE (K <= 16 obstacles, N <= 64).
 //
-// Same problem and same interior point as mpc_vtol_solver.hpp (the lane-per-problem code, which stays as the K > 8 path and as the
-// statement this kernel was checked against); what changes is who does what:
+// Same problem and same interior point as mpc_vtol_solver.hpp (the lane-per-problem code, which stays as the statement this kernel
+// was developed and is still checked against: sc_mpcvtol_params.kernel = 1); what changes is who does what:
 //   * lane k owns stage k: its input u_k, its K + 13 rows (CBF rows of (x_k, u_k), the five state bounds of x_{k+1}, the input box) with
-//     their slacks, multipliers and steps IN REGISTERS, the aero model's derivatives at (x_k, u_k), its stage block of the Newton system;
+//     their slacks, multipliers and steps IN REGISTERS (instantiated for 8 and 16 CBF row slots, slots >= K switched off), the aero
+//     model's derivatives at (x_k, u_k), its stage block of the Newton system;
 //   * the nonlinear rollout is a serial recursion: every lane runs it (wave-uniform, same cost as one lane) and keeps x_k, x_{k+1} and
 //     the acceleration when the loop passes its stage, so a function evaluation is one rollout + one parallel row pass;
-//   * the costate sweep is a 6-vector recursion over stage vectors the lanes left in LDS; the Riccati recursion walks the stages backwards
-//     with the 10 x 10 value function in LDS and the lanes spread over the ENTRIES of each product (P A, P B, Quu, Qux, the new P);
-//     the 4 x 4 Cholesky and its eleven right-hand sides are done redundantly, one column per lane;
+//   * the costate sweep is a 6-vector recursion over stage vectors the lanes left in LDS (six lanes, one barrier per stage); the Riccati
+//     recursion walks the stages backwards with the 10 x 10 value function in LDS and the lanes spread over the ENTRIES of each product
+//     (P [A | B], Qux | Quu, the new P) in four branch-free phases per stage; the 4 x 4 Cholesky and its eleven right-hand sides are
+//     done redundantly, one column per lane; the forward LQ rollout takes four + six lanes and two barriers per stage;
 //   * sums and maxima over rows are DPP wave reductions; every decision of the interior point is wave-uniform.
-// LDS per problem: stage Jacobians and blocks, gains, costates, the Riccati workspace -- 39.3 KB for N = 30, four problems per CU.
+// LDS per problem: stage Jacobians and blocks, gains, costates, the Riccati workspace -- 39.3 KB for N = 30 (slots with disjoint lifetimes
+// shared, WaveLds), four problems per CU, one per SIMD (512 VGPRs).  The serial routines are noinline functions on LDS-address-space
+// pointers: compiled without the row state's register pressure.
 // Kernel 11 in DESIGN.md.
 #include <hip/hip_runtime.h>
 

@@ -23,7 +23,7 @@ def make_params(robot_spec, cbf_param, horizon, dt, radius, io_dtype, obs_shared
     p = _lib.MpcVtolParams()
     p.io_dtype, p.horizon, p.max_iter, p.obs_shared, p.acceptable_iter = io_dtype, int(horizon), int(max_iter), 1 if obs_shared else 0, 15
     p.slack_reset = int(slack_reset)
-    p.kernel = int(kernel)                                 # 0 auto, 1 one NLP per lane, 2 one NLP per wavefront (K <= 8)
+    p.kernel = int(kernel)                                 # 0 / 2: one NLP per wavefront (the kernel that serves the model), 1: one NLP per lane (cross-check; needs the workspace)
     p.dt = float(dt)
     for i in range(6):
         p.Q[i] = Q_VTOL[i]

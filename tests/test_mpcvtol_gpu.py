@@ -1,5 +1,5 @@
-"""GPU: the VTOL2D MPC-CBF kernels -- csrc/mpc_vtol_wave.hip (one NLP per wavefront, one stage per lane, K <= 8; the default) and
-csrc/mpc_vtol.hip (one NLP per lane, any K <= 16) -- against the numpy oracle (oracle/mpc_vtol.py: condensed single shooting, dense
+"""GPU: the VTOL2D MPC-CBF kernels -- csrc/mpc_vtol_wave.hip (one NLP per wavefront, one stage per lane; the default) and
+csrc/mpc_vtol.hip (one NLP per lane, params.kernel = 1) -- against the numpy oracle (oracle/mpc_vtol.py: condensed single shooting, dense
 Cholesky: a different linear algebra for the same Newton step) and against each other.
 
 Bar: SAME STATUS on every problem (restoration phase included), |u0 - u0_oracle| <= 1e-6 and |z - z_oracle| <= 2e-5 on every problem
@@ -113,7 +113,7 @@ def test_wave_and_lane_kernels_agree():
 
 @pytest.mark.parametrize("K", [3, 10])
 def test_other_obstacle_counts_against_oracle(K):
-    """K = 3: the wave kernel with five of its eight row slots per stage switched off; K = 10: served by the lane-per-problem kernel."""
+    """K = 3: the wave kernel with five of its eight row slots per stage switched off; K = 10: its 16-slot instantiation."""
     n = 12
     X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("vtol", 64, K, seed=7))
     ctl = sca.BatchedVtolMPCCBF(io_dtype="f64")
