@@ -308,6 +308,13 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     is returned (what IPOPT reports as "converged to a point of local infeasibility").  At most resto_max entries.
     Both phases raise the merit penalty when a step is not a descent direction of the merit function (the penalty was
     below the multipliers lam + dlam of the step).
+    Slack reset (Byrd, Hribar & Nocedal 1999, section 3): for fixed z the merit function is separable in s, and
+    -mu log s_i + nu |g_i - s_i| is smallest at s_i = max(g_i, mu / nu); after a trial step the line search may therefore
+    replace the linearly updated slack of a row by the row's value.  P["slack_reset"] (regular phase; 0 off, 1 only raises
+    slacks, 2 takes the minimiser where g_i >= mu / nu: the bicycles and VTOL2D) and P["resto_slack_reset"] (the same on
+    g_i + t_i inside the restoration; on by default, off for VTOL2D) switch it on.  A row whose curvature beat its
+    linearisation -- a far obstacle's row, never active -- is then not charged for it, which is what kept those models'
+    searches at step lengths of 1e-3 and their restorations crawling to the iteration limit.
     Every other unsuccessful exit is STATUS_INACCURATE.
     """
     P = dict(DEFAULTS)
@@ -353,7 +360,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     Hq = P.get("quadratic_cost")                                            # linear models: f is exactly quadratic in z
     t_ = np.zeros(m)                                                        # elastic variables of the restoration (0 on hard rows)
     sreset = int(P.get("slack_reset", 0))
-    sreset_r = bool(P.get("slack_reset_resto", P["resto_slack_reset"]))   # the restoration's line search resets the slack of a row to g + t
+    sreset_r = bool(P["resto_slack_reset"])                               # the restoration's line search resets the slack of a row to g + t
     for it in range(1, P["max_iter"] + 1):
         sf = SF_OFF if resto else sf0
         ev = evaluate(x0, z, u_prev, goal, obs, P, lam / sf, level=2)      # multipliers of the unscaled problem

@@ -15,7 +15,7 @@ if __name__ == "__main__":
         ref = None
         for mode in modes:
             t = time.time()
-            r = family_solve_many(fam, X, up, goal, obs, params=dict(slack_reset=mode % 10, slack_reset_resto=mode >= 10), workers=8, timeout=3000)
+            r = family_solve_many(fam, X, up, goal, obs, params=dict(slack_reset=mode % 10, resto_slack_reset=mode >= 10), workers=8, timeout=3000)
             st, it = r["st"], r["it"]
             line = f"{fam:7s} reset {mode}: opt {np.mean(st == 0):.3f} inf {np.mean(st == 1):.3f} inacc {np.mean(st == 2):.3f} | it mean {it.mean():.1f} p95 {np.percentile(it, 95):.0f} max {it.max()} n_resto {np.mean(r['n_resto'] > 0):.3f}"
             if ref is not None:
