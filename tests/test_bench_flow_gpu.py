@@ -32,6 +32,12 @@ def test_single_gpu_line_has_contract_fields():
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert d["mpc_cbf"]["value"] > 5e3               # BASELINE target: >= 5k MPC-CBF (N = 10) solves/s
+    # every interior-point leg of the line, VTOL2D included, with its VALU-issue roofline and the flag that says whether the committed
+    # counters were collected from this tree's kernel sources (tools/collect_profiles.sh after the last csrc change makes it False)
+    for leg in ("od_mpc_cbf", "quad3d_mpc_cbf", "quad2d_mpc_cbf", "kinematic_bicycle_mpc_cbf", "vtol_mpc_cbf", "backup_cbf_qp"):
+        assert leg in d and d[leg]["kernel_ms"] > 0, leg
+        assert d[leg]["roofline"]["bound"] == "valu_issue" and d[leg]["roofline"]["stale"] in (False, True), leg
+    assert d["vtol_mpc_cbf"]["optimal_fraction"] > 0.9 and d["vtol_mpc_cbf"]["value"] > 2e4
 
 
 def test_two_rank_flow_on_one_gpu():
