@@ -159,6 +159,29 @@ typedef struct sc_resto_params {
     int32_t reserved;
 } sc_resto_params;
 
+/* Continuation launches of the interior point (sc_mpc*_solve_batch_sliced; csrc/mpc_cont.hpp).  The reference hands its NLPs to
+ * IPOPT with default options (position_control/mpc_cbf.py:163-173: max_iter = 3000); one launch ends with its slowest problem, so
+ * a budget of that size is only affordable when the launch that serves the whole batch stops at a much smaller cap and hands the
+ * few unfinished solves -- WITH their solver state (iterate, slacks, multipliers, elastic variables, barrier parameter, merit
+ * penalty, restoration flags, counters: one record per problem in `workspace`) -- to the next launch, which continues them with
+ * the instructions an uninterrupted solve would have executed (resumed == uninterrupted bit for bit).
+ *   launches:  [classify]  ->  solve to it_stop[0]  ->  ... ->  solve to it_stop[n_caps - 1]  ->  solve to params->max_iter
+ * `order`: pending solves whose CBF rows are violated at the hand-over (the ones that crawl or restore feasibility) start first in
+ * the next launch.  `classify_first`: a launch that only evaluates the initial guess sorts the batch the same way before the first
+ * solve launch (a launch ends with its slowest problem: the long solves have to start in its first scheduling round).
+ * Every status the caller sees is final: SC_STATUS_PENDING is only written between the launches of one call.                     */
+#define SC_STATUS_PENDING    (-1)
+#define SC_MPC_MAX_SLICES    8
+typedef struct sc_mpc_slices {
+    int32_t n_caps;                       /* launches before the last one: 0 .. SC_MPC_MAX_SLICES                              */
+    int32_t it_stop[SC_MPC_MAX_SLICES];   /* their iteration caps (cumulative, strictly increasing, >= 1; caps >= max_iter are dropped) */
+    int32_t order;                        /* 0 / 1                                                                               */
+    int32_t classify_first;               /* 0 / 1                                                                               */
+    int32_t reserved;
+    void*   workspace;                    /* device memory of sc_mpc*_slices_workspace_bytes(...) bytes, no initialisation needed */
+    size_t  workspace_bytes;
+} sc_mpc_slices;
+
 typedef struct sc_mpccbf_params {
     int32_t model_id;        /* SC_MODEL_DYNAMIC_UNICYCLE2D or SC_MODEL_UNICYCLE2D (others: SC_ERR_UNSUPPORTED).
                               * Unicycle2D (robots/unicycle2D.py): inputs [v, omega], u_max = (v_max, w_max),
@@ -198,6 +221,13 @@ int sc_mpccbf_solve_batch(const sc_mpccbf_params* params, int64_t B, int32_t K,
                           const void* X, const void* u_prev, const void* goal, const void* obs,
                           void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out,
                           void* stream);
+
+/* The same solve as a sequence of continuation launches (sc_mpc_slices above); slices == NULL or an empty schedule: one launch. */
+size_t sc_mpccbf_slices_workspace_bytes(const sc_mpccbf_params* params, int64_t B, int32_t K);
+int sc_mpccbf_solve_batch_sliced(const sc_mpccbf_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K,
+                                 const void* X, const void* u_prev, const void* goal, const void* obs,
+                                 void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out,
+                                 void* stream);
 
 int sc_mpccbf_solve_batch_host(const sc_mpccbf_params* params, int64_t B, int32_t K,
                                const void* X, const void* u_prev, const void* goal, const void* obs,

@@ -89,6 +89,50 @@ def default_resto(**over):
     return r
 
 
+MPC_MAX_SLICES = 8
+STATUS_PENDING = -1
+
+
+class MpcSlices(C.Structure):
+    """Mirror of ``sc_mpc_slices``: the continuation launches of one sc_mpc*_solve_batch_sliced call."""
+    _fields_ = [("n_caps", C.c_int32), ("it_stop", C.c_int32 * MPC_MAX_SLICES), ("order", C.c_int32), ("classify_first", C.c_int32),
+                ("reserved", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+def make_slices(caps=(), order=True, classify_first=False):
+    """An MpcSlices without its workspace (SlicedSolver attaches one)."""
+    caps = [int(c) for c in caps]
+    if len(caps) > MPC_MAX_SLICES:
+        raise ValueError(f"at most {MPC_MAX_SLICES} iteration caps")
+    sl = MpcSlices(n_caps=len(caps), order=1 if order else 0, classify_first=1 if classify_first else 0)
+    for i, c in enumerate(caps):
+        sl.it_stop[i] = c
+    return sl
+
+
+class SlicedSolver:
+    """What the batched MPC classes share for their continuation launches: the schedule (``iter_slices``: iteration caps of the
+    launches before the last one; ``classify_first``; ``order``) and a workspace tensor that is kept between calls and grows with
+    the batch.  ``slices_for(B, need_bytes, device)`` returns the ctypes struct to pass, or None for a single launch."""
+
+    def init_slices(self, iter_slices=None, classify_first=False, order=True):
+        self.iter_slices = tuple(int(c) for c in (iter_slices or ()))
+        self.classify_first, self.order_slices = bool(classify_first), bool(order)
+        self._slice_ws = None
+
+    def slices_for(self, need_bytes_fn, device):
+        import torch
+        caps = [c for c in self.iter_slices if c < self.max_iter]
+        if not caps and not self.classify_first:
+            return None
+        sl = make_slices(caps, self.order_slices, self.classify_first)
+        need = int(need_bytes_fn())
+        if self._slice_ws is None or self._slice_ws.numel() < need or self._slice_ws.device != device:
+            self._slice_ws = torch.empty((need,), dtype=torch.uint8, device=device)
+        sl.workspace, sl.workspace_bytes = self._slice_ws.data_ptr(), self._slice_ws.numel()
+        return sl
+
+
 class MpcCbfParams(C.Structure):
     """Mirror of ``sc_mpccbf_params``."""
     _fields_ = [
@@ -227,6 +271,8 @@ SYMBOLS = {
     "sc_mpccbf_solve_batch": (C.c_int, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "sc_mpccbf_slices_workspace_bytes": (C.c_size_t, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32]),
+    "sc_mpccbf_solve_batch_sliced": (C.c_int, [C.POINTER(MpcCbfParams), C.POINTER(MpcSlices), C.c_int64, C.c_int32] + [C.c_void_p] * 9),
     "sc_odmpccbf_solve_batch": (C.c_int, [C.POINTER(OdMpcCbfParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_odmpccbf_solve_batch_host": (C.c_int, [C.POINTER(OdMpcCbfParams), C.c_int64, C.c_int32] + [C.c_void_p] * 9 + [C.c_int]),
     "sc_odcbfqp_solve_batch": (C.c_int, [C.POINTER(OdCbfQpParams), C.c_int64] + [C.c_void_p] * 9),

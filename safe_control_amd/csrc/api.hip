@@ -6,6 +6,7 @@
 #include <cstring>
 
 #include "../../include/safe_control_amd.h"
+#include "mpc_slices_host.hpp"
 
 namespace sc {
 hipError_t cbfqp_launch(const sc_cbfqp_params& p, long long B, int K, const void* X, const void* u_ref,
@@ -14,7 +15,8 @@ hipError_t cbfqp_launch(const sc_cbfqp_params& p, long long B, int K, const void
 
 hipError_t mpccbf_launch(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
-                         hipStream_t stream);
+                         hipStream_t stream, const ipm::Cont& ct);
+size_t mpccbf_state_doubles(int N, int K, bool od);
 size_t mpccbf_lds_bytes(int N, int K, bool uni);
 size_t odmpccbf_lds_bytes(int N, int K);
 hipError_t odmpccbf_launch(const sc_odmpccbf_params& q, long long B, int K, const void* X, const void* u_prev,
@@ -145,6 +147,28 @@ static int check_cbfqp(const sc_cbfqp_params* p, int64_t B, int32_t K, const voi
         return fail(SC_ERR_INVALID_ARGUMENT, "X must be 16-byte aligned (Quad2D: element aligned), u_ref / u_out aligned to two elements (vector loads)");
     return SC_OK;
 }
+// sc_resto_params of every MPC entry point: a zero-initialised block (max_entries = 0) switches the restoration off and is valid --
+// the statuses then have their pre-restoration meaning (a multiplier above 1e10 or a failed line search at an infeasible iterate
+// ends the solve as SC_STATUS_INFEASIBLE / SC_STATUS_INACCURATE without a certificate); a partially filled one would divide by rho.
+static int check_resto(const sc_resto_params& r) {
+    if (r.max_entries < 0) return fail(SC_ERR_INVALID_ARGUMENT, "resto.max_entries must be >= 0");
+    if (r.slack_reset != 0 && r.slack_reset != 1) return fail(SC_ERR_INVALID_ARGUMENT, "resto.slack_reset must be 0 or 1");
+    if (r.max_entries == 0) return SC_OK;
+    if (!(r.rho > 0) || !(r.kappa > 0 && r.kappa < 1) || !(r.theta_tol > 0) || !(r.tol > 0) || !(r.small_alpha >= 0) || r.small_iter < 1)
+        return fail(SC_ERR_INVALID_ARGUMENT, "resto: rho > 0, 0 < kappa < 1, theta_tol > 0, tol > 0, small_alpha >= 0, small_iter >= 1 "
+                                             "are required when max_entries > 0");
+    return SC_OK;
+}
+static int check_slices(const sc_mpc_slices* sl, int max_iter, size_t need_bytes) {
+    if (!slices_valid(sl)) return fail(SC_ERR_INVALID_ARGUMENT, "slices: 0 <= n_caps <= SC_MPC_MAX_SLICES, caps >= 1 and strictly increasing, order / classify_first in {0, 1}");
+    if (slices_active(sl, max_iter)) {
+        if (!sl->workspace) return fail(SC_ERR_INVALID_ARGUMENT, "slices.workspace is NULL");
+        if (sl->workspace_bytes < need_bytes) return fail(SC_ERR_INVALID_ARGUMENT, "slices.workspace_bytes below sc_mpc*_slices_workspace_bytes()");
+        if (misaligned(sl->workspace, 16)) return fail(SC_ERR_INVALID_ARGUMENT, "slices.workspace must be 16-byte aligned");
+    }
+    return SC_OK;
+}
+
 static int check_mpccbf(const sc_mpccbf_params* p, int64_t B, int32_t K, const void* X, const void* u_prev,
                         const void* goal, const void* obs, const void* u_out, const void* status_out) {
     if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
@@ -165,7 +189,7 @@ static int check_mpccbf(const sc_mpccbf_params* p, int64_t B, int32_t K, const v
     if (B > 0 && (!X || !u_prev || !goal || !obs || !u_out || !status_out))
         return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
-    return SC_OK;
+    return check_resto(p->resto);
 }
 static int check_mpclin_dims(const sc_mpclin_params* p) {
     if (!p) return fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
@@ -728,9 +752,34 @@ int sc_mpccbf_solve_batch(const sc_mpccbf_params* params, int64_t B, int32_t K, 
     int rc = sc::check_mpccbf(params, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
+    sc::ipm::Cont ct{};
+    ct.it_stop = params->max_iter;
     hipError_t e = sc::mpccbf_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out,
-                                     z_out, (hipStream_t)stream);
+                                     z_out, (hipStream_t)stream, ct);
     if (e != hipSuccess) return sc::fail_hip(e, "mpccbf kernel launch");
+    return SC_OK;
+}
+
+size_t sc_mpccbf_slices_workspace_bytes(const sc_mpccbf_params* params, int64_t B, int32_t K) {
+    if (!params || B < 0 || K < 1 || params->horizon < 1 || params->horizon > SC_MPCCBF_MAX_HORIZON) return 0;
+    return sc::slices_workspace_bytes((long long)B, sc::mpccbf_state_doubles(params->horizon, K, false));
+}
+
+int sc_mpccbf_solve_batch_sliced(const sc_mpccbf_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K, const void* X,
+                                 const void* u_prev, const void* goal, const void* obs, void* u_out, int32_t* status_out,
+                                 int32_t* iters_out, void* z_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    int rc = sc::check_mpccbf(params, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    rc = sc::check_slices(slices, params->max_iter, sc_mpccbf_slices_workspace_bytes(params, B, K));
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::run_slices(slices, params->max_iter, (long long)B, sc::mpccbf_state_doubles(params->horizon, K, false),
+                                  (hipStream_t)stream, [&](const sc::ipm::Cont& ct) {
+        return sc::mpccbf_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out,
+                                 (hipStream_t)stream, ct);
+    });
+    if (e != hipSuccess) return sc::fail_hip(e, "mpccbf kernel launch (sliced)");
     return SC_OK;
 }
 
@@ -759,8 +808,10 @@ int sc_mpccbf_solve_batch_host(const sc_mpccbf_params* params, int64_t B, int32_
         if ((e = hipMemcpyAsync(d + oU, u_prev, nU, hipMemcpyHostToDevice, s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d + oG, goal, nG, hipMemcpyHostToDevice, s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        sc::ipm::Cont ct{};
+        ct.it_stop = params->max_iter;
         e = sc::mpccbf_launch(*params, (long long)B, (int)K, d + oX, d + oU, d + oG, d + oO, d + oUo, (int*)(d + oS),
-                              (int*)(d + oI), z_out ? d + oZ : nullptr, s);
+                              (int*)(d + oI), z_out ? d + oZ : nullptr, s, ct);
         if (e != hipSuccess) break;
         if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;

@@ -25,6 +25,7 @@
 #include "sc_qp2.hpp"
 #include "mpc_chol.hpp"
 #include "mpc_ipm_common.hpp"
+#include "mpc_cont.hpp"
 #include "../../include/safe_control_amd.h"
 
 namespace sc {
@@ -853,14 +854,14 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
                                             const void* __restrict__ X, const void* __restrict__ u_prev,
                                             const void* __restrict__ goal, const void* __restrict__ obs,
                                             void* __restrict__ u_out, int* __restrict__ status_out,
-                                            int* __restrict__ iters_out, void* __restrict__ z_out,
+                                            int* __restrict__ iters_out, void* __restrict__ z_out, const ipm::Cont& ct,
                                             const OdExtra od = OdExtra{{1.0, 1.0}, {0.0, 0.0}}, void* __restrict__ rho_out = nullptr) {
     const bool io32 = p.io_dtype == SC_DTYPE_F32;
     auto ld = [io32](const void* a, size_t i) { return io32 ? (double)((const float*)a)[i] : ((const double*)a)[i]; };
     auto st = [io32](void* a, size_t i, double v) { if (io32) ((float*)a)[i] = (float)v; else ((double*)a)[i] = v; };
     const int lane = threadIdx.x;
-    const long long prob = blockIdx.x;
-    if (prob >= B) return;
+    long long prob;
+    if (!ipm::cont_problem(ct, B, prob)) return;                        // mpc_cont.hpp: block index, or an entry of the previous launch's queue
     MpcConst c;
     const int K = KT > 0 ? KT : K_rt;
     c.N = NT > 0 ? NT : p.horizon; c.K = K; c.n = 2 * c.N; c.mc = c.N * K; c.ns = UNI ? 0 : 2 * c.N; c.m = c.mc + c.ns + 2 * c.n;
@@ -879,6 +880,34 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     constexpr int MS = NT > 0 ? (2 * NT + 3) / 4 : 4;                  // MFMA k-steps batched per LDS round trip
     for (int e = lane; e < 2 * (N + 2) * n; e += 64) W.dP[e] = 0.0;      // structural zeros of G stay
 
+    // the scalars of the interior-point loop (all wave-uniform); a continuation launch loads them with the arrays below
+    constexpr bool RESTO = !OD;
+    const int nel = OD ? 0 : c.mc;                                       // elastic variables of the restoration
+    double* const cst = ct.state ? ct.state + prob * ct.stride : nullptr;
+    Prof pf;
+    pf.start();
+    double f = 0.0, sf = 1.0, mu = p.mu_init;
+    double nu = 10.0, delta_last = 0.0, e_best = 1e300;
+    int n_acc = 0, it0 = 1;
+    // feasibility restoration (mpc_ipm_common.hpp; oracle/mpc_cbf.py: solve)
+    bool resto = false;
+    int n_resto = 0, n_small = 0;                                       // n_small: consecutive tiny accepted steps at an infeasible z
+    double theta_R = 0.0, mu_reg = mu;
+    if (ct.resume) {
+        // the state a previous launch left (mpc_cont.hpp): [scalars | z | zb | sl | lam | obs | tel | rho | rhob]
+        const double* a = cst + ipm::CONT_SCALARS;
+        SC_SYNC();                                                       // (the zeros of G above: tel may live in its first rows)
+        ipm::cont_copy(W.z, a, n, lane, 64); a += n;
+        ipm::cont_copy(W.zb, a, n, lane, 64); a += n;
+        ipm::cont_copy(W.sl, a, m, lane, 64); a += m;
+        ipm::cont_copy(W.lam, a, m, lane, 64); a += m;
+        ipm::cont_copy(W.obs, a, K * 7, lane, 64); a += K * 7;
+        if (nel) { ipm::cont_copy(W.tel, a, nel, lane, 64); a += nel; }
+        if constexpr (OD) { ipm::cont_copy(W.rho, a, n, lane, 64); a += n; ipm::cont_copy(W.rhob, a, n, lane, 64); }
+        it0 = (int)cst[0] + 1; mu = cst[1]; nu = cst[2]; delta_last = cst[3]; e_best = cst[4]; n_acc = (int)cst[5];
+        resto = cst[6] != 0.0; n_resto = (int)cst[7]; n_small = (int)cst[8]; theta_R = cst[9]; mu_reg = cst[10]; sf = cst[11];
+        SC_SYNC();
+    } else {
     const size_t obase = p.obs_shared ? 0 : (size_t)prob * K * 7;
     for (int e = lane; e < K * 7; e += 64) W.obs[e] = ld(obs, obase + e);
     SC_SYNC();
@@ -892,9 +921,16 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     }
     SC_SYNC();
 
-    Prof pf;
-    pf.start();
-    double f = eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, true, pf, 12);
+    f = eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, true, pf, 12);
+    if (ct.it_stop < 0) {
+        // classify only (mpc_cont.hpp): is a CBF row violated at the initial guess?  Those are the solves that crawl or restore
+        // feasibility; the next launch starts them first
+        double th0 = 0.0;
+        for (int i = lane; i < c.mc; i += 64) th0 += fmax(0.0, -W.g[i]);
+        th0 = wsum(th0);
+        if (lane == 0) ipm::cont_push(ct, prob, th0 > 0.0);
+        return;
+    }
     // steep (superellipsoid) barriers: IPOPT-style gradient-based row scaling from the initial guess, then a fresh evaluation
     if (ipm::scale_steep_barriers(W.obs, K, W.dh, N + 2, lane, 64, [](double v) { return wmax(v); }, [] { SC_SYNC(); }))
         f = eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, true, pf, 12);
@@ -907,27 +943,22 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     stage_pass<KT, ROW16, OD, UNI>(W, c, lane, 1.0);
     SC_SYNC();
     const double gmax = col_pass<OD, UNI>(W, c, lane, 1.0);
-    const double sf = fmin(1.0, 100.0 / fmax(1e-12, gmax));             // objective scaling
-    double mu = p.mu_init;
+    sf = fmin(1.0, 100.0 / fmax(1e-12, gmax));                          // objective scaling
     SC_SYNC();
     for (int i = lane; i < m; i += 64) W.lam[i] = mu * W.is[i];
     SC_SYNC();
+    for (int i = lane; i < n; i += 64) { W.zb[i] = W.z[i]; if constexpr (OD) W.rhob[i] = W.rho[i]; }
+    }
 
     int status = SC_STATUS_INACCURATE, it = 0;
     pf.start();
     const double tau = 0.995;
-    double nu = 10.0, delta_last = 0.0, e_best = 1e300;
-    int n_acc = 0;
     const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
-    // feasibility restoration (mpc_ipm_common.hpp; oracle/mpc_cbf.py: solve): all wave-uniform
-    constexpr bool RESTO = !OD;
-    bool resto = false;
-    int n_resto = 0, n_small = 0;                                       // n_small: consecutive tiny accepted steps at an infeasible z
-    double theta_R = 0.0, mu_reg = mu;
     const double rho_R = p.resto.rho;
-    for (int i = lane; i < n; i += 64) { W.zb[i] = W.z[i]; if constexpr (OD) W.rhob[i] = W.rho[i]; }
-    for (it = 1; it <= p.max_iter; ++it) {
-        if (it > 1) f = eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, true, pf, 12);
+    bool pending = false;
+    for (it = it0; it <= p.max_iter; ++it) {
+        if (cst && it > ct.it_stop) { pending = true; break; }            // the cap of this launch: the solve goes on in the next one
+        if (it > 1 || ct.resume) f = eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, true, pf, 12);
         SC_PH(0);
         double theta = 0.0;                                              // l1 violation of the elastic (CBF) rows at z
         if constexpr (RESTO) {
@@ -1242,6 +1273,30 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         SC_SYNC();
         SC_PH(11);
     }
+    if (pending) {
+        // hand-over (mpc_cont.hpp).  W.g holds the rows of the current z on every path to the top of the loop (the accepted trial
+        // point, the evaluation before a restoration entry, the initial evaluation)
+        SC_SYNC();
+        double th = 0.0;
+        for (int i = lane; i < c.mc; i += 64) th += fmax(0.0, -W.g[i]);
+        th = wsum(th);
+        double* a = cst + ipm::CONT_SCALARS;
+        ipm::cont_copy(a, W.z, n, lane, 64); a += n;
+        ipm::cont_copy(a, W.zb, n, lane, 64); a += n;
+        ipm::cont_copy(a, W.sl, m, lane, 64); a += m;
+        ipm::cont_copy(a, W.lam, m, lane, 64); a += m;
+        ipm::cont_copy(a, W.obs, K * 7, lane, 64); a += K * 7;
+        if (nel) { ipm::cont_copy(a, W.tel, nel, lane, 64); a += nel; }
+        if constexpr (OD) { ipm::cont_copy(a, W.rho, n, lane, 64); a += n; ipm::cont_copy(a, W.rhob, n, lane, 64); }
+        if (lane == 0) {
+            cst[0] = (double)(it - 1); cst[1] = mu; cst[2] = nu; cst[3] = delta_last; cst[4] = e_best; cst[5] = (double)n_acc;
+            cst[6] = resto ? 1.0 : 0.0; cst[7] = (double)n_resto; cst[8] = (double)n_small; cst[9] = theta_R; cst[10] = mu_reg; cst[11] = sf;
+            status_out[prob] = SC_STATUS_PENDING_MPC;
+            if (iters_out) iters_out[prob] = it - 1;
+            ipm::cont_push(ct, prob, th > p.resto.theta_tol);
+        }
+        return;
+    }
     if (it > p.max_iter) it = p.max_iter;
     if (status == SC_STATUS_INACCURATE && !resto && e_best <= p.acceptable_tol) {
         // stalled at the precision limit (ill-conditioned condensed system at mu ~ 1e-9): the best iterate is
@@ -1287,16 +1342,18 @@ template <int NT, int KT>
 __global__ __launch_bounds__(64) SC_MPC_WAVES(NT)
 void mpccbf_kernel(const sc_mpccbf_params p, const long long B, const int K_rt, const void* __restrict__ X,
                    const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
-                   void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out) {
+                   void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out,
+                   const ipm::Cont ct) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<NT, KT>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
+    mpccbf_body<NT, KT>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, ct);
 }
 __global__ __launch_bounds__(64)
 void mpccbf_kernel_rt(const sc_mpccbf_params p, const long long B, const int K_rt, const void* __restrict__ X,
                       const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
-                      void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out) {
+                      void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out,
+                   const ipm::Cont ct) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<0, 0>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
+    mpccbf_body<0, 0>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, ct);
 }
 
 // kinematic Unicycle2D (robots/unicycle2D.py through position_control/mpc_cbf.py), K run-time
@@ -1304,16 +1361,18 @@ template <int NT>
 __global__ __launch_bounds__(64) SC_MPC_WAVES(NT)
 void mpccbf_uni_kernel(const sc_mpccbf_params p, const long long B, const int K_rt, const void* __restrict__ X,
                        const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
-                       void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out) {
+                       void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out,
+                   const ipm::Cont ct) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<NT, 0, false, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
+    mpccbf_body<NT, 0, false, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, ct);
 }
 __global__ __launch_bounds__(64)
 void mpccbf_uni_kernel_rt(const sc_mpccbf_params p, const long long B, const int K_rt, const void* __restrict__ X,
                           const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
-                          void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out) {
+                          void* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out, void* __restrict__ z_out,
+                   const ipm::Cont ct) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<0, 0, false, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out);
+    mpccbf_body<0, 0, false, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, ct);
 }
 
 // optimal-decay variant (position_control/optimal_decay_mpc_cbf.py), K run-time.  Compile-time horizon: capped at 256
@@ -1324,17 +1383,17 @@ __global__ __launch_bounds__(64) SC_MPC_WAVES(NT)
 void odmpccbf_kernel(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const void* __restrict__ X,
                      const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
                      void* __restrict__ u_out, void* __restrict__ rho_out, int* __restrict__ status_out,
-                     int* __restrict__ iters_out, void* __restrict__ z_out) {
+                     int* __restrict__ iters_out, void* __restrict__ z_out, const ipm::Cont ct) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<NT, 0, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
+    mpccbf_body<NT, 0, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, ct, od, rho_out);
 }
 __global__ __launch_bounds__(64)
 void odmpccbf_kernel_rt(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const void* __restrict__ X,
                         const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
                         void* __restrict__ u_out, void* __restrict__ rho_out, int* __restrict__ status_out,
-                        int* __restrict__ iters_out, void* __restrict__ z_out) {
+                        int* __restrict__ iters_out, void* __restrict__ z_out, const ipm::Cont ct) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<0, 0, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
+    mpccbf_body<0, 0, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, ct, od, rho_out);
 }
 
 // optimal decay on the kinematic Unicycle2D: BASELINE config 5's extension (oracle/od_mpc_rd1.py)
@@ -1343,17 +1402,17 @@ __global__ __launch_bounds__(64) SC_MPC_WAVES(NT)
 void odmpccbf_uni_kernel(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const void* __restrict__ X,
                          const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
                          void* __restrict__ u_out, void* __restrict__ rho_out, int* __restrict__ status_out,
-                         int* __restrict__ iters_out, void* __restrict__ z_out) {
+                         int* __restrict__ iters_out, void* __restrict__ z_out, const ipm::Cont ct) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<NT, 0, true, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
+    mpccbf_body<NT, 0, true, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, ct, od, rho_out);
 }
 __global__ __launch_bounds__(64)
 void odmpccbf_uni_kernel_rt(const sc_mpccbf_params p, const OdExtra od, const long long B, const int K_rt, const void* __restrict__ X,
                             const void* __restrict__ u_prev, const void* __restrict__ goal, const void* __restrict__ obs,
                             void* __restrict__ u_out, void* __restrict__ rho_out, int* __restrict__ status_out,
-                            int* __restrict__ iters_out, void* __restrict__ z_out) {
+                            int* __restrict__ iters_out, void* __restrict__ z_out, const ipm::Cont ct) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    mpccbf_body<0, 0, true, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, od, rho_out);
+    mpccbf_body<0, 0, true, true>(sm, p, B, K_rt, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, ct, od, rho_out);
 }
 
 size_t mpccbf_lds_bytes(int N, int K, bool uni) { return mpc_lds_doubles(N, K, false, uni) * sizeof(double); }
@@ -1371,8 +1430,10 @@ static hipError_t odmpc_launch_t(const sc_odmpccbf_params& q, long long B, int K
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
+        ipm::Cont ct{};
+        ct.it_stop = p.max_iter;
         hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, od, B, K, X, u_prev,
-                           goal, obs, u_out, rho_out, status, iters, z_out);
+                           goal, obs, u_out, rho_out, status, iters, z_out, ct);
         return hipGetLastError();
     };
     if (p.model_id == SC_MODEL_UNICYCLE2D) {
@@ -1395,7 +1456,7 @@ hipError_t odmpccbf_launch(const sc_odmpccbf_params& q, long long B, int K, cons
 template <int NT, int KT, bool UNI = false>
 static hipError_t mpc_launch_one(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
                                  const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, const ipm::Cont& ct) {
     const size_t lds = mpc_lds_doubles(p.horizon, K, false, UNI) * sizeof(double);
     auto launch = [&](auto kern) {
         if (lds > 64 * 1024) {
@@ -1403,7 +1464,7 @@ static hipError_t mpc_launch_one(const sc_mpccbf_params& p, long long B, int K, 
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, B, K, X, u_prev,
-                           goal, obs, u_out, status, iters, z_out);
+                           goal, obs, u_out, status, iters, z_out, ct);
         return hipGetLastError();
     };
     if constexpr (UNI && NT > 0) return launch(mpccbf_uni_kernel<NT>);
@@ -1414,26 +1475,32 @@ static hipError_t mpc_launch_one(const sc_mpccbf_params& p, long long B, int K, 
 
 static hipError_t mpc_launch_t(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
                                const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
-                               hipStream_t stream) {
+                               hipStream_t stream, const ipm::Cont& ct) {
     if (p.model_id == SC_MODEL_UNICYCLE2D) {
-        if (p.horizon == 10) return mpc_launch_one<10, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
-        if (p.horizon == 20) return mpc_launch_one<20, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
-        return mpc_launch_one<0, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        if (p.horizon == 10) return mpc_launch_one<10, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct);
+        if (p.horizon == 20) return mpc_launch_one<20, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct);
+        return mpc_launch_one<0, 0, true>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct);
     }
     if (p.horizon == 10 && K == 8)            // BASELINE config 3
-        return mpc_launch_one<10, 8>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        return mpc_launch_one<10, 8>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct);
     if (p.horizon == 10)                      // the reference's default horizon (mpc_cbf.py:15) with any obstacle count
-        return mpc_launch_one<10, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        return mpc_launch_one<10, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct);
     if (p.horizon == 20)                      // BASELINE config 5's horizon
-        return mpc_launch_one<20, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
-    return mpc_launch_one<0, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+        return mpc_launch_one<20, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct);
+    return mpc_launch_one<0, 0>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct);
+}
+
+// doubles of one problem's solver state in a continuation workspace (mpc_cont.hpp; the layout of mpccbf_body's hand-over)
+size_t mpccbf_state_doubles(int N, int K, bool od) {
+    const size_t n = 2 * (size_t)N, m = (size_t)N * K + 2 * N + 2 * n;
+    return ipm::CONT_SCALARS + 2 * n + 2 * m + 7 * (size_t)K + (od ? 2 * n : (size_t)N * K);
 }
 
 hipError_t mpccbf_launch(const sc_mpccbf_params& p, long long B, int K, const void* X, const void* u_prev,
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out,
-                         hipStream_t stream) {
+                         hipStream_t stream, const ipm::Cont& ct) {
     if (mpc_lds_doubles(p.horizon, K, false, p.model_id == SC_MODEL_UNICYCLE2D) * sizeof(double) > 160 * 1024) return hipErrorInvalidValue;
-    return mpc_launch_t(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+    return mpc_launch_t(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct);
 }
 
 }  // namespace sc

@@ -168,16 +168,18 @@ class MPCCBF:
         return u.reshape(-1, 1).copy()
 
 
-class BatchedMPCCBF:
+class BatchedMPCCBF(_lib.SlicedSolver):
     """MPC-CBF for B agents per launch on device tensors.
 
     ``solve(X[B,4], u_prev[B,2], goal[B,2], obs[B,K,7] | obs[K,7])`` ->
     ``u[B,2]``, ``status[B] int32``, ``iters[B] int32`` (and ``z[B,2N]`` if asked).
     Unicycle2D states are [x, y, theta] padded to 4 columns (the last is not read).
+    ``iter_slices`` / ``classify_first`` / ``order``: continuation launches (include/safe_control_amd.h: sc_mpc_slices).
     """
 
     def __init__(self, robot_spec, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None,
-                 tol=1e-6, max_iter=100):
+                 tol=1e-6, max_iter=100, iter_slices=None, classify_first=False, order=True):
+        self.init_slices(iter_slices, classify_first, order)
         self.robot_spec = complete_robot_spec(robot_spec)
         model = self.robot_spec["model"]
         self.dt = float(dt)
@@ -216,8 +218,12 @@ class BatchedMPCCBF:
                         self.robot_spec["radius"], self.io_dtype, obs_shared=shared, tol=self.tol,
                         max_iter=self.max_iter, resto=getattr(self, "resto", None))   # .resto: a _lib.RestoParams override
         stream = torch.cuda.current_stream(X.device).cuda_stream
-        rc = self._lib.sc_mpccbf_solve_batch(
-            C.byref(p), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(),
-            u.data_ptr(), status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        sl = self.slices_for(lambda: self._lib.sc_mpccbf_slices_workspace_bytes(C.byref(p), B, K), X.device)
+        args = (B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(),
+                u.data_ptr(), status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        if sl is None:
+            rc = self._lib.sc_mpccbf_solve_batch(C.byref(p), *args)
+        else:
+            rc = self._lib.sc_mpccbf_solve_batch_sliced(C.byref(p), C.byref(sl), *args)
         _lib.check(rc, "sc_mpccbf_solve_batch")
         return (u, status, iters, z) if want_z else (u, status, iters)

@@ -1,0 +1,116 @@
+"""Continuation launches of the MPC interior point (include/safe_control_amd.h: sc_mpc_slices; csrc/mpc_cont.hpp): a solve that is
+stopped at an iteration cap, written to the workspace and continued by the next launch must agree BIT FOR BIT with the
+uninterrupted solve -- input, status, iteration count and the whole plan -- for every family; neither the order in which a launch
+starts its problems nor the classify-only pre-pass may change any result; no problem is left pending."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import safe_control_amd as sca                                       # noqa: E402
+from safe_control_amd import workloads as W                          # noqa: E402
+
+DEV = "cuda:0"
+
+
+def make(fam, **kw):
+    if fam == "du":
+        return sca.BatchedMPCCBF({"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}, io_dtype="f64", horizon=10, **kw)
+    if fam == "uni":
+        return sca.BatchedMPCCBF({"model": "Unicycle2D", "v_max": 1.0, "w_max": 0.5, "radius": 0.25}, io_dtype="f64", horizon=10, **kw)
+    if fam in ("quad3d", "si"):
+        return sca.BatchedLinearMPCCBF({"model": W.MPC_FAMILIES[fam]}, io_dtype="f64", horizon=10, **kw)
+    if fam == "vtol":
+        return sca.BatchedVtolMPCCBF(io_dtype="f64", **kw)
+    return sca.BatchedGnMPCCBF({"model": W.MPC_FAMILIES[fam]}, io_dtype="f64", horizon=10, **kw)
+
+
+def batch(fam, B, seed=0):
+    if fam == "uni":
+        X, up, goal, obs = W.mpc_family_batch("du", B, 8, seed=seed)
+        X = X.copy(); X[:, 3] = 0.0
+    else:
+        X, up, goal, obs = W.mpc_family_batch(fam, B, 8, seed=seed)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=DEV)     # noqa: E731
+    return t(X), t(up), t(goal), t(obs)
+
+
+def solve(ctl, arrs):
+    out = ctl.solve(*arrs, want_z=True)
+    torch.cuda.synchronize()
+    return [o.cpu().numpy() for o in out]
+
+
+def same(a, b, what):
+    for x, y, name in zip(a, b, ("u", "status", "iters", "z")):
+        assert x.shape == y.shape
+        bad = np.nonzero(~((x == y) | (np.isnan(x) & np.isnan(y))).reshape(x.shape[0], -1).all(axis=1))[0]
+        assert len(bad) == 0, f"{what}: {name} differs on {len(bad)} problems, first {bad[:5]}"
+
+
+FAMILIES = ["du", "uni"]
+
+
+@pytest.mark.parametrize("fam", FAMILIES)
+def test_resumed_solve_is_bitwise_the_uninterrupted_solve(fam):
+    B = 256
+    arrs = batch(fam, B)
+    ref = solve(make(fam, max_iter=100), arrs)
+    assert (ref[1] >= 0).all()
+    it = ref[2]
+    assert it.max() > 30, "the batch should hold solves that cross several caps"
+    # caps that cut solves in every phase: regular, restoration, the first iteration, one before the end
+    for caps in ((1, 2, 3, 5, 8, 13, 21, 34), (7, 40), (int(it.max()) - 1,), (16,)):
+        got = solve(make(fam, max_iter=100, iter_slices=caps, order=False), arrs)
+        same(ref, got, f"{fam} caps {caps}")
+        got = solve(make(fam, max_iter=100, iter_slices=caps, order=True), arrs)
+        same(ref, got, f"{fam} caps {caps} ordered")
+
+
+@pytest.mark.parametrize("fam", FAMILIES)
+def test_classify_first_changes_the_launch_order_only(fam):
+    arrs = batch(fam, 512, seed=1)
+    ref = solve(make(fam, max_iter=100), arrs)
+    got = solve(make(fam, max_iter=100, classify_first=True), arrs)
+    same(ref, got, f"{fam} classify_first")
+    got = solve(make(fam, max_iter=100, classify_first=True, iter_slices=(10, 25)), arrs)
+    same(ref, got, f"{fam} classify_first + caps")
+
+
+@pytest.mark.parametrize("fam", FAMILIES)
+def test_budget_of_the_reference_solver(fam):
+    """max_iter = 3000 (IPOPT's default, which the reference does not change: mpc_cbf.py:163-173) behind a first cap of 100: whatever ended
+    below the cap is untouched, nothing is pending, and a solve that reaches 'optimal' later is a converged one."""
+    arrs = batch(fam, 512, seed=2)
+    ref = solve(make(fam, max_iter=100), arrs)
+    got = solve(make(fam, max_iter=3000, iter_slices=(100,)), arrs)
+    assert (got[1] >= 0).all() and (got[1] <= 2).all()
+    done = ref[2] < 100
+    same([r[done] for r in ref], [g[done] for g in got], f"{fam} below the cap")
+    one = solve(make(fam, max_iter=3000), arrs)
+    same(one, got, f"{fam} 3000 in one launch vs sliced")
+
+
+def test_sliced_entry_rejects_bad_schedules():
+    import ctypes as C
+    from safe_control_amd import _lib
+    ctl = make("du", max_iter=100, iter_slices=(20, 10))
+    with pytest.raises(_lib.HipLibraryError):
+        ctl.solve(*batch("du", 8))
+    ctl = make("du", max_iter=100, iter_slices=(0,))
+    with pytest.raises(_lib.HipLibraryError):
+        ctl.solve(*batch("du", 8))
+    ctl = make("du", max_iter=100, iter_slices=(10,))
+    arrs = batch("du", 8)
+    ctl.solve(*arrs)
+    ctl._slice_ws = ctl._slice_ws[:64]                                 # a workspace that is too small
+    ctl.slices_for = lambda fn, dev: _with_ws(ctl, _lib)
+    with pytest.raises(_lib.HipLibraryError):
+        ctl.solve(*arrs)
+
+
+def _with_ws(ctl, _lib):
+    sl = _lib.make_slices([10])
+    sl.workspace, sl.workspace_bytes = ctl._slice_ws.data_ptr(), ctl._slice_ws.numel()
+    return sl
