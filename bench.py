@@ -475,8 +475,8 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
 
 
 def vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
-    """MPC-CBF for VTOL2D (csrc/mpc_vtol.hip): N = 30, 4 inputs, one NLP per lane, stage-wise Riccati Newton steps; the
-    work arrays of the batch (0.1 MB per problem) stay in HBM between launches."""
+    """MPC-CBF for VTOL2D (csrc/mpc_vtol_wave.hip): N = 30, 4 inputs, one NLP per wavefront, one stage per lane, stage-wise
+    Riccati Newton steps, rows in registers, everything else in LDS (no workspace)."""
     import torch
     import safe_control_amd as sca
     from safe_control_amd import workloads as W

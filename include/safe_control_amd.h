@@ -276,6 +276,11 @@ int sc_mpclin_build_model(const sc_mpclin_params* params, const double* Ae, cons
 int sc_mpclin_solve_batch(const sc_mpclin_params* params, const double* model, int64_t B, int32_t K,
                           const void* X, const void* u_prev, const void* goal, const void* obs,
                           void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
+/* continuation launches (sc_mpc_slices, above sc_mpccbf_params); optimal_decay = 0 only */
+size_t sc_mpclin_slices_workspace_bytes(const sc_mpclin_params* params, int64_t B, int32_t K);
+int sc_mpclin_solve_batch_sliced(const sc_mpclin_params* params, const sc_mpc_slices* slices, const double* model, int64_t B, int32_t K,
+                                 const void* X, const void* u_prev, const void* goal, const void* obs,
+                                 void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
 int sc_mpclin_solve_batch_host(const sc_mpclin_params* params, const double* model, int64_t B, int32_t K,
                                const void* X, const void* u_prev, const void* goal, const void* obs,
                                void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, int device);
@@ -322,6 +327,10 @@ typedef struct sc_mpcgn_params {
 int sc_mpcgn_solve_batch(const sc_mpcgn_params* params, int64_t B, int32_t K,
                          const void* X, const void* u_prev, const void* goal, const void* obs,
                          void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
+size_t sc_mpcgn_slices_workspace_bytes(const sc_mpcgn_params* params, int64_t B, int32_t K);
+int sc_mpcgn_solve_batch_sliced(const sc_mpcgn_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K,
+                                const void* X, const void* u_prev, const void* goal, const void* obs,
+                                void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
 int sc_mpcgn_solve_batch_host(const sc_mpcgn_params* params, int64_t B, int32_t K,
                               const void* X, const void* u_prev, const void* goal, const void* obs,
                               void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, int device);
@@ -379,6 +388,11 @@ int sc_mpcvtol_solve_batch(const sc_mpcvtol_params* params, int64_t B, int32_t K
                            const void* X, const void* u_prev, const void* goal, const void* obs,
                            void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* continuation launches (sc_mpc_slices): the wave-per-problem kernel only (kernel = 0 / 2) */
+size_t sc_mpcvtol_slices_workspace_bytes(const sc_mpcvtol_params* params, int64_t B, int32_t K);
+int sc_mpcvtol_solve_batch_sliced(const sc_mpcvtol_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K,
+                                  const void* X, const void* u_prev, const void* goal, const void* obs,
+                                  void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
 int sc_mpcvtol_solve_batch_host(const sc_mpcvtol_params* params, int64_t B, int32_t K,
                                 const void* X, const void* u_prev, const void* goal, const void* obs,
                                 void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, int device);

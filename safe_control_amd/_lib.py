@@ -271,6 +271,12 @@ SYMBOLS = {
     "sc_mpccbf_solve_batch": (C.c_int, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
+    "sc_mpcgn_slices_workspace_bytes": (C.c_size_t, [C.POINTER(MpcGnParams), C.c_int64, C.c_int32]),
+    "sc_mpcgn_solve_batch_sliced": (C.c_int, [C.POINTER(MpcGnParams), C.POINTER(MpcSlices), C.c_int64, C.c_int32] + [C.c_void_p] * 9),
+    "sc_mpclin_slices_workspace_bytes": (C.c_size_t, [C.POINTER(MpcLinParams), C.c_int64, C.c_int32]),
+    "sc_mpclin_solve_batch_sliced": (C.c_int, [C.POINTER(MpcLinParams), C.POINTER(MpcSlices), C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 9),
+    "sc_mpcvtol_slices_workspace_bytes": (C.c_size_t, [C.POINTER(MpcVtolParams), C.c_int64, C.c_int32]),
+    "sc_mpcvtol_solve_batch_sliced": (C.c_int, [C.POINTER(MpcVtolParams), C.POINTER(MpcSlices), C.c_int64, C.c_int32] + [C.c_void_p] * 9),
     "sc_mpccbf_slices_workspace_bytes": (C.c_size_t, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32]),
     "sc_mpccbf_solve_batch_sliced": (C.c_int, [C.POINTER(MpcCbfParams), C.POINTER(MpcSlices), C.c_int64, C.c_int32] + [C.c_void_p] * 9),
     "sc_odmpccbf_solve_batch": (C.c_int, [C.POINTER(OdMpcCbfParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),

@@ -57,18 +57,22 @@ bool mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const doubl
                         double* out);
 hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long long B, int K, const void* X, const void* u_prev,
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out, void* rho_out,
-                         hipStream_t stream);
+                         hipStream_t stream, const ipm::Cont& ct);
+size_t mpclin_state_doubles(int N, int K, int nu);
+size_t mpcgn_state_doubles(int N, int K);
+size_t mpcvtol_state_doubles(int N, int K);
 
 size_t mpcgn_lds_bytes(int model_id, int N, int K, int circles_only);
 size_t odmpcgn_lds_bytes(int model_id, int N, int K);
 size_t mpcvtol_workspace_bytes(const sc_mpcvtol_params& p, long long B, int K);
 bool mpcvtol_uses_wave(const sc_mpcvtol_params& p, int K);
 hipError_t mpcvtol_launch(const sc_mpcvtol_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
-                          const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, void* workspace, hipStream_t stream);
+                          const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, void* workspace, hipStream_t stream,
+                          const ipm::Cont& ct);
 hipError_t odmpcgn_launch(const sc_odmpcgn_params& q, long long B, int K, const void* X, const void* u_prev, const void* goal,
                           const void* obs, void* u_out, void* rho_out, int* status, int* iters, void* z_out, hipStream_t stream);
 hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
-                        const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream);
+                        const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream, const ipm::Cont& ct);
 
 hipError_t manip_rollout_launch(const sc_manip_tracking_params& t, long long B, int M, void* X, const void* wps, const int* n_wp,
                                 int* wp_index, int* sm, void* goal, const void* table, void* u_last, int* ret, int* ret_step,
@@ -159,6 +163,7 @@ static int check_resto(const sc_resto_params& r) {
                                              "are required when max_entries > 0");
     return SC_OK;
 }
+static ipm::Cont one_launch(int max_iter) { ipm::Cont ct{}; ct.it_stop = max_iter; return ct; }
 static int check_slices(const sc_mpc_slices* sl, int max_iter, size_t need_bytes) {
     if (!slices_valid(sl)) return fail(SC_ERR_INVALID_ARGUMENT, "slices: 0 <= n_caps <= SC_MPC_MAX_SLICES, caps >= 1 and strictly increasing, order / classify_first in {0, 1}");
     if (slices_active(sl, max_iter)) {
@@ -220,7 +225,7 @@ static int check_mpclin(const sc_mpclin_params* p, const double* model, int64_t 
     if (B > 0 && (!model || !X || !u_prev || !goal || !obs || !u_out || !status_out))
         return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
-    return SC_OK;
+    return p->optimal_decay ? SC_OK : check_resto(p->resto);
 }
 static int check_mpcgn(const sc_mpcgn_params* p, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,
                        const void* obs, const void* u_out, const void* status_out) {
@@ -246,7 +251,7 @@ static int check_mpcgn(const sc_mpcgn_params* p, int64_t B, int32_t K, const voi
         return fail(SC_ERR_INVALID_ARGUMENT, "KinematicBicycle2D needs rear_ax_dist > 0 and v_max > v_min");
     if (B > 0 && (!X || !u_prev || !goal || !obs || !u_out || !status_out)) return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
-    return SC_OK;
+    return check_resto(p->resto);
 }
 static int check_mpcvtol(const sc_mpcvtol_params* p, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,
                          const void* obs, const void* u_out, const void* status_out) {
@@ -268,7 +273,7 @@ static int check_mpcvtol(const sc_mpcvtol_params* p, int64_t B, int32_t K, const
     if (p->kernel == 2 && !mpcvtol_uses_wave(*p, K)) return fail(SC_ERR_UNSUPPORTED, "the wave-per-problem kernel serves K <= 16, horizon <= 64");
     if (B > 0 && (!X || !u_prev || !goal || !obs || !u_out || !status_out)) return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
-    return SC_OK;
+    return check_resto(p->resto);
 }
 static int check_manip(const sc_manip_cbfqp_params* p, int64_t B, int32_t K, const void* X, const void* u_ref,
                        const void* obs, const void* u_out, const void* status_out) {
@@ -302,7 +307,7 @@ int sc_mpcgn_solve_batch(const sc_mpcgn_params* params, int64_t B, int32_t K, co
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
     hipError_t e = sc::mpcgn_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out,
-                                    (hipStream_t)stream);
+                                    (hipStream_t)stream, sc::one_launch(params->max_iter));
     if (e != hipSuccess) return sc::fail_hip(e, "mpcgn kernel launch");
     return SC_OK;
 }
@@ -323,7 +328,7 @@ int sc_mpcvtol_solve_batch(const sc_mpcvtol_params* params, int64_t B, int32_t K
     if (need > 0 && !workspace) return sc::fail(SC_ERR_INVALID_ARGUMENT, "workspace is NULL");
     if (workspace_bytes < need) return sc::fail(SC_ERR_INVALID_ARGUMENT, "workspace smaller than sc_mpcvtol_workspace_bytes()");
     hipError_t e = sc::mpcvtol_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, workspace,
-                                      (hipStream_t)stream);
+                                      (hipStream_t)stream, sc::one_launch(params->max_iter));
     if (e != hipSuccess) return sc::fail_hip(e, "mpcvtol kernel launch");
     return SC_OK;
 }
@@ -355,7 +360,7 @@ int sc_mpcvtol_solve_batch_host(const sc_mpcvtol_params* params, int64_t B, int3
         if ((e = hipMemcpyAsync(d + oG, goal, nG, hipMemcpyHostToDevice, s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
         e = sc::mpcvtol_launch(*params, (long long)B, (int)K, d + oX, d + oU, d + oG, d + oO, d + oUo, (int*)(d + oS),
-                               iters_out ? (int*)(d + oI) : nullptr, z_out ? d + oZ : nullptr, d + oW, s);
+                               iters_out ? (int*)(d + oI) : nullptr, z_out ? d + oZ : nullptr, d + oW, s, sc::one_launch(params->max_iter));
         if (e != hipSuccess) break;
         if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
@@ -413,7 +418,7 @@ int sc_mpcgn_solve_batch_host(const sc_mpcgn_params* params, int64_t B, int32_t 
         if ((e = hipMemcpyAsync(d + oG, goal, nG, hipMemcpyHostToDevice, s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
         e = sc::mpcgn_launch(*params, (long long)B, (int)K, d + oX, d + oU, d + oG, d + oO, d + oUo, (int*)(d + oS),
-                             iters_out ? (int*)(d + oI) : nullptr, z_out ? d + oZ : nullptr, s);
+                             iters_out ? (int*)(d + oI) : nullptr, z_out ? d + oZ : nullptr, s, sc::one_launch(params->max_iter));
         if (e != hipSuccess) break;
         if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
@@ -449,7 +454,7 @@ int sc_mpclin_solve_batch(const sc_mpclin_params* params, const double* model, i
     if (B == 0) return SC_OK;
     if (params->optimal_decay) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay = 1: call sc_odmpclin_solve_batch");
     hipError_t e = sc::mpclin_launch(*params, model, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out,
-                                     z_out, nullptr, (hipStream_t)stream);
+                                     z_out, nullptr, (hipStream_t)stream, sc::one_launch(params->max_iter));
     if (e != hipSuccess) return sc::fail_hip(e, "mpclin kernel launch");
     return SC_OK;
 }
@@ -463,7 +468,7 @@ int sc_odmpclin_solve_batch(const sc_mpclin_params* params, const double* model,
     if (!params->optimal_decay) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay = 0: call sc_mpclin_solve_batch");
     if (B == 0) return SC_OK;
     hipError_t e = sc::mpclin_launch(*params, model, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out,
-                                     z_out, rho_out, (hipStream_t)stream);
+                                     z_out, rho_out, (hipStream_t)stream, sc::one_launch(params->max_iter));
     if (e != hipSuccess) return sc::fail_hip(e, "mpclin (optimal decay) kernel launch");
     return SC_OK;
 }
@@ -498,7 +503,7 @@ int sc_mpclin_solve_batch_host(const sc_mpclin_params* params, const double* mod
         if ((e = hipMemcpyAsync(d + oG, goal, nG, hipMemcpyHostToDevice, s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
         e = sc::mpclin_launch(*params, (const double*)(d + oM), (long long)B, (int)K, d + oX, d + oU, d + oG, d + oO, d + oUo,
-                              (int*)(d + oS), iters_out ? (int*)(d + oI) : nullptr, z_out ? d + oZ : nullptr, nullptr, s);
+                              (int*)(d + oS), iters_out ? (int*)(d + oI) : nullptr, z_out ? d + oZ : nullptr, nullptr, s, sc::one_launch(params->max_iter));
         if (e != hipSuccess) break;
         if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
@@ -757,6 +762,74 @@ int sc_mpccbf_solve_batch(const sc_mpccbf_params* params, int64_t B, int32_t K, 
     hipError_t e = sc::mpccbf_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out,
                                      z_out, (hipStream_t)stream, ct);
     if (e != hipSuccess) return sc::fail_hip(e, "mpccbf kernel launch");
+    return SC_OK;
+}
+
+/* ---- continuation launches of the other MPC families (sc_mpc_slices) ------------------------------------------------------- */
+size_t sc_mpcgn_slices_workspace_bytes(const sc_mpcgn_params* params, int64_t B, int32_t K) {
+    if (!params || B < 0 || K < 1 || params->horizon < 1 || params->horizon > 32) return 0;
+    return sc::slices_workspace_bytes((long long)B, sc::mpcgn_state_doubles(params->horizon, K));
+}
+int sc_mpcgn_solve_batch_sliced(const sc_mpcgn_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K, const void* X,
+                                const void* u_prev, const void* goal, const void* obs, void* u_out, int32_t* status_out,
+                                int32_t* iters_out, void* z_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    int rc = sc::check_mpcgn(params, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    rc = sc::check_slices(slices, params->max_iter, sc_mpcgn_slices_workspace_bytes(params, B, K));
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::run_slices(slices, params->max_iter, (long long)B, sc::mpcgn_state_doubles(params->horizon, K), (hipStream_t)stream,
+                                  [&](const sc::ipm::Cont& ct) {
+        return sc::mpcgn_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, (hipStream_t)stream, ct);
+    });
+    if (e != hipSuccess) return sc::fail_hip(e, "mpcgn kernel launch (sliced)");
+    return SC_OK;
+}
+
+size_t sc_mpclin_slices_workspace_bytes(const sc_mpclin_params* params, int64_t B, int32_t K) {
+    if (!params || B < 0 || K < 1 || sc::check_mpclin_dims(params) != SC_OK) return 0;
+    return sc::slices_workspace_bytes((long long)B, sc::mpclin_state_doubles(params->horizon, K, params->nu));
+}
+int sc_mpclin_solve_batch_sliced(const sc_mpclin_params* params, const sc_mpc_slices* slices, const double* model, int64_t B, int32_t K,
+                                 const void* X, const void* u_prev, const void* goal, const void* obs, void* u_out, int32_t* status_out,
+                                 int32_t* iters_out, void* z_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    int rc = sc::check_mpclin(params, model, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (params->optimal_decay) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay = 1: call sc_odmpclin_solve_batch");
+    rc = sc::check_slices(slices, params->max_iter, sc_mpclin_slices_workspace_bytes(params, B, K));
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::run_slices(slices, params->max_iter, (long long)B, sc::mpclin_state_doubles(params->horizon, K, params->nu),
+                                  (hipStream_t)stream, [&](const sc::ipm::Cont& ct) {
+        return sc::mpclin_launch(*params, model, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, nullptr,
+                                 (hipStream_t)stream, ct);
+    });
+    if (e != hipSuccess) return sc::fail_hip(e, "mpclin kernel launch (sliced)");
+    return SC_OK;
+}
+
+size_t sc_mpcvtol_slices_workspace_bytes(const sc_mpcvtol_params* params, int64_t B, int32_t K) {
+    if (!params || B < 0 || K < 1 || K > 16 || params->horizon < 1 || params->horizon > 64) return 0;
+    return sc::slices_workspace_bytes((long long)B, sc::mpcvtol_state_doubles(params->horizon, K));
+}
+int sc_mpcvtol_solve_batch_sliced(const sc_mpcvtol_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K, const void* X,
+                                  const void* u_prev, const void* goal, const void* obs, void* u_out, int32_t* status_out,
+                                  int32_t* iters_out, void* z_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    int rc = sc::check_mpcvtol(params, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (!sc::mpcvtol_uses_wave(*params, K)) return sc::fail(SC_ERR_UNSUPPORTED, "continuation launches are served by the wave-per-problem kernel (kernel = 0 / 2)");
+    rc = sc::check_slices(slices, params->max_iter, sc_mpcvtol_slices_workspace_bytes(params, B, K));
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::run_slices(slices, params->max_iter, (long long)B, sc::mpcvtol_state_doubles(params->horizon, K), (hipStream_t)stream,
+                                  [&](const sc::ipm::Cont& ct) {
+        return sc::mpcvtol_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, nullptr,
+                                  (hipStream_t)stream, ct);
+    });
+    if (e != hipSuccess) return sc::fail_hip(e, "mpcvtol kernel launch (sliced)");
     return SC_OK;
 }
 

@@ -29,14 +29,26 @@
 #include "sc_math.hpp"
 #include "mpc_chol.hpp"
 #include "mpc_ipm_common.hpp"
+#include "mpc_cont.hpp"
+// -DSC_GN_TRACE: developer build that writes 32 scalars per interior-point iteration (first 100 iterations) into z_out, which the
+// tool then sizes as [B, 4096] doubles (tools/exp_gn_trace.py); never defined in the shipped library
+#ifdef SC_GN_TRACE
+#define GT(slot, val) do { if (lane == 0 && z_out && it <= 100) ((double*)z_out)[prob * 4096 + (it - 1) * 32 + (slot)] = (double)(val); } while (0)
+#else
+#define GT(slot, val)
+#endif
+#ifndef SC_CONT_LEVEL
+#define SC_CONT_LEVEL 3      // developer switch (tools/build_variants.sh): 0 .. 2 compile parts of the continuation code out
+#endif
 #include "mpc_hd4.hpp"
 
-// the superellipsoid powers: library pow() here (false).  The multiply chain of mpc_lin.hip / mpc_cbf.hip (true) stays a developer
-// switch: with ipm::pow3 inlined -- in its round-2 loop form AND in round 3's straight-line form -- the circles-only instantiations of
-// this kernel (Quad2D, KinematicBicycle2D at N = 10), which never execute that branch, return garbage (tests/test_mpcgn_gpu.py,
-// tests/test_odmpcgn_gpu.py fail within seconds); see mpc_ipm_common.hpp: CHAIN.
+// the superellipsoid powers: the multiply chain of ipm::pow3 for integer exponents, as mpc_lin.hip / mpc_cbf.hip.  Rounds 2 - 3 kept the
+// library pow() here because the circles-only instantiations (Quad2D, KinematicBicycle2D at N = 10), which never execute that branch,
+// returned garbage with the chain inlined: one of the faces of the compiler defect that round 4 root-caused (mpc_ipm_common.hpp: CHAIN;
+// csrc/Makefile: SAFE_RA).  With the register-allocation flags of the Makefile the chain is right everywhere; -DSC_GN_CHAIN=false
+// brings pow() back.
 #ifndef SC_GN_CHAIN
-#define SC_GN_CHAIN false
+#define SC_GN_CHAIN true
 #endif
 
 namespace sc {
@@ -793,13 +805,19 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
                                                    const void* __restrict__ X, const void* __restrict__ u_prev,
                                                    const void* __restrict__ goal, const void* __restrict__ obs,
                                                    void* __restrict__ u_out, int* __restrict__ status_out,
-                                                   int* __restrict__ iters_out, void* __restrict__ z_out, void* __restrict__ rho_out) {
+                                                   int* __restrict__ iters_out, void* __restrict__ z_out, void* __restrict__ rho_out,
+                                                   const ipm::Cont ct) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     using Mdl = GnModel<MODEL>;
     constexpr int NX = Mdl::NX, NB = Mdl::NB;
     const int lane = threadIdx.x;
-    const long long prob = blockIdx.x;
+    long long prob;
+#if SC_CONT_LEVEL >= 1
+    if (!ipm::cont_problem(ct, B, prob)) return;                        // mpc_cont.hpp: block index, or an entry of the previous launch's queue
+#else
+    prob = blockIdx.x;
     if (prob >= B) return;
+#endif
     const bool io32 = p.io_dtype == SC_DTYPE_F32;
     auto ld = [io32](const void* a, size_t i) { return io32 ? (double)((const float*)a)[i] : ((const double*)a)[i]; };
     auto st = [io32](void* a, size_t i, double v) { if (io32) ((float*)a)[i] = (float)v; else ((double*)a)[i] = v; };
@@ -827,6 +845,30 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
     for (int e = lane; e < K * 7; e += 64) W.obs[e] = ld(obs, obase + e);
     for (int e = lane; e < NX * n; e += 64) W.Ph[e] = 0.0;                  // Phi_0 = 0
     SC_SYNC();
+    // the scalars of the interior-point loop (wave-uniform); a continuation launch loads them with the arrays (mpc_cont.hpp)
+    constexpr bool RESTO = !OD;
+    const int nel = OD ? 0 : d.mc;                                      // elastic variables of the restoration
+    double* const cst = ct.state ? ct.state + prob * ct.stride : nullptr;
+    double f = 0.0, sf = 1.0, mu = p.mu_init;
+    double nu_m = 10.0, delta_last = 0.0, e_best = 1e300;
+    int n_acc = 0, it0 = 1;
+    bool resto = false;
+    int n_resto = 0, n_small = 0;                                       // n_small: consecutive tiny accepted steps at an infeasible z
+    double theta_R = 0.0, mu_reg = mu;
+    if (SC_CONT_LEVEL >= 2 && ct.resume) {
+        // the state a previous launch left: [scalars | z | zb | s | lam | obs | tel | rho | rhob]
+        const double* a = cst + ipm::CONT_SCALARS;
+        ipm::cont_copy(W.z, a, n, lane, 64); a += n;
+        ipm::cont_copy(W.zb, a, n, lane, 64); a += n;
+        ipm::cont_copy(W.s, a, m, lane, 64); a += m;
+        ipm::cont_copy(W.lam, a, m, lane, 64); a += m;
+        ipm::cont_copy(W.obs, a, K * 7, lane, 64); a += K * 7;
+        if (nel) { ipm::cont_copy(W.tel, a, nel, lane, 64); a += nel; }
+        if constexpr (OD) { ipm::cont_copy(W.rho, a, n, lane, 64); a += n; ipm::cont_copy(W.rhob, a, n, lane, 64); }
+        it0 = (int)cst[0] + 1; mu = cst[1]; nu_m = cst[2]; delta_last = cst[3]; e_best = cst[4]; n_acc = (int)cst[5];
+        resto = cst[6] != 0.0; n_resto = (int)cst[7]; n_small = (int)cst[8]; theta_R = cst[9]; mu_reg = cst[10]; sf = cst[11];
+        SC_SYNC();
+    } else {
     if (!c.circles_only) ipm::normalise_obstacle_flags(W.obs, K, lane, 64);
     SC_SYNC();
     for (int i = lane; i < n; i += 64) {                                   // set_initial_guess: u_prev, strictly inside the box
@@ -835,6 +877,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         if constexpr (OD) { W.rho[i] = (i & 1) ? c.rf2 : c.rf1; W.rhob[i] = W.rho[i]; }   // decay variables start at their references
     }
     SC_SYNC();
+    }
 
     // grad f = sum_k Phi_k' 2 Q (x_k - xg) + r-term; gs = sf grad f
     auto grad_f = [&](double sf) {
@@ -853,7 +896,16 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         SC_SYNC();
     };
 
-    double f = gn_eval_any<MODEL, OD>(W.z, W, d, c, q, lane, true, W.rho);
+    if (!(SC_CONT_LEVEL >= 2 && ct.resume)) {
+    f = gn_eval_any<MODEL, OD>(W.z, W, d, c, q, lane, true, W.rho);
+    if (SC_CONT_LEVEL >= 2 && ct.it_stop < 0) {
+        // classify only (mpc_cont.hpp): is a CBF row violated at the initial guess?
+        double th0 = 0.0;
+        for (int i = lane; i < d.mc; i += 64) th0 += fmax(0.0, -W.g[i]);
+        th0 = gsum(th0);
+        if (lane == 0) ipm::cont_push(ct, prob, th0 > 0.0);
+        return;
+    }
     // steep (superellipsoid) barriers: IPOPT-style gradient-based row scaling from the initial guess, then a fresh evaluation
     if (!c.circles_only &&
         ipm::scale_steep_barriers(W.obs, K, W.dh, 3 * N, lane, 64, [](double v) { return gmax_(v); }, [] { SC_SYNC(); }))
@@ -862,30 +914,26 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
     double gmx = 0.0;
     for (int i = lane; i < n; i += 64) gmx = fmax(gmx, fabs(W.gs[i]));
     gmx = gmax_(gmx);
-    const double sf = fmin(1.0, 100.0 / fmax(1e-12, gmx));
-    double mu = p.mu_init;
+    sf = fmin(1.0, 100.0 / fmax(1e-12, gmx));
     for (int i = lane; i < m; i += 64) { const double s = fmax(W.g[i], 1e-2); W.s[i] = s; W.lam[i] = mu / s; }
     for (int i = lane; i < n; i += 64) W.zb[i] = W.z[i];
     SC_SYNC();
+    }
 
     int status = SC_STATUS_INACCURATE, it = 0;
     const double tau = 0.995;
-    double nu_m = 10.0, delta_last = 0.0, e_best = 1e300;
-    int n_acc = 0;
     const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
     // feasibility restoration (mpc_ipm_common.hpp; oracle/mpc_cbf.py: solve): wave-uniform state
-    constexpr bool RESTO = !OD;
-    bool resto = false;
-    int n_resto = 0, n_small = 0;                                       // n_small: consecutive tiny accepted steps at an infeasible z
-    double theta_R = 0.0, mu_reg = mu;
     const double rho_R = p.resto.rho;
+    bool pending = false;
 #ifdef SC_GN_PROF
     double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_readcyclecounter();
 #endif
-    for (it = 1; it <= p.max_iter; ++it) {
+    for (it = it0; it <= p.max_iter; ++it) {
         GP(11);
-        if (it > 1) f = gn_eval_any<MODEL, OD>(W.z, W, d, c, q, lane, true, W.rho);
+        if (SC_CONT_LEVEL >= 3 && cst && it > ct.it_stop) { pending = true; break; }   // the cap of this launch: the solve goes on in the next one
+        if (it > 1 || (SC_CONT_LEVEL >= 2 && ct.resume)) f = gn_eval_any<MODEL, OD>(W.z, W, d, c, q, lane, true, W.rho);
         GP(0);
         double theta = 0.0;                                               // l1 violation of the elastic (CBF) rows at z
         for (int i = lane; i < d.mc; i += 64) theta += fmax(0.0, -W.g[i]);
@@ -936,6 +984,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         }
         e_d = gmax_(e_d); e_p = gmax_(e_p); e_c0 = gmax_(e_c0); lmx = gmax_(lmx);
         const double e_opt = fmax(e_d, fmax(e_p, e_c0));
+        GT(0, it); GT(1, e_d); GT(2, e_p); GT(3, e_c0); GT(4, lmx); GT(5, mu); GT(6, theta); GT(7, f); GT(25, resto ? 1.0 : 0.0);
         if (!resto && e_opt < e_best) {
             e_best = e_opt;
             for (int i = lane; i < n; i += 64) { W.zb[i] = W.z[i]; if constexpr (OD) W.rhob[i] = W.rho[i]; }
@@ -1151,6 +1200,12 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             }
             if (!ok) delta = (delta == 0.0) ? fmax(1e-4, delta_last / 3.0) : delta * 8.0;
         }
+        GT(8, delta); GT(9, ok ? 1.0 : 0.0);
+#ifdef SC_GN_TRACE
+        { double sm_ = 0.0, sr_ = 0.0, sd_ = 0.0;
+          for (int i = 0; i < n; ++i) { sm_ += W.M[(size_t)i * n + i]; sr_ += W.rhs[i]; sd_ += W.dz[i]; }
+          GT(22, sd_); GT(23, sr_); GT(24, sm_); }
+#endif
         if (!ok) break;
         if (delta > 0.0) delta_last = delta;
         if constexpr (NT == 0) {
@@ -1265,6 +1320,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         const double phi0 = bar0 + nu_m * sum_rp;
         const double dphi = dbar - nu_m * sum_rp;
         const double noise_rows = 1e-15 * nu_m * sum_g;                  // round-off of far dummy-obstacle rows (oracle: row_noise)
+        GT(10, rs_min); GT(11, rl_min); GT(12, sum_ds_s); GT(13, sum_rp); GT(14, sum_log); GT(15, gdz); GT(16, nu_m); GT(17, phi0); GT(18, dphi);
         GP(8);
         alpha = ap;
         sreset = !OD && (resto ? p.resto.slack_reset != 0 : p.slack_reset == 2);
@@ -1297,9 +1353,11 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
                 for (int i = lane; i < n; i += 64) { const double dzr = W.zt[i] - W.zb[i]; proxt += dzr * dzr; }
                 phit = 0.5 * zeta * gsum(proxt) + rho_R * gsum(st_) - mu * slog + nu_m * srp;
             }
+            GT(19, alpha); GT(20, phit); GT(26, ft); GT(27, slog); GT(28, srp);
             if (phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * fabs(phi0) + noise_rows) { accepted = true; break; }
             alpha *= 0.5;
         }
+        GT(21, accepted ? 1.0 : 0.0);
         GP(9);
         if (!accepted) {
             if (!RESTO || resto) break;
@@ -1353,6 +1411,29 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         }
         SC_SYNC();
     }
+    if (SC_CONT_LEVEL >= 3 && pending) {
+        // hand-over (mpc_cont.hpp); W.g holds the rows of the current z on every path to the top of the loop
+        SC_SYNC();
+        double th = 0.0;
+        for (int i = lane; i < d.mc; i += 64) th += fmax(0.0, -W.g[i]);
+        th = gsum(th);
+        double* a = cst + ipm::CONT_SCALARS;
+        ipm::cont_copy(a, W.z, n, lane, 64); a += n;
+        ipm::cont_copy(a, W.zb, n, lane, 64); a += n;
+        ipm::cont_copy(a, W.s, m, lane, 64); a += m;
+        ipm::cont_copy(a, W.lam, m, lane, 64); a += m;
+        ipm::cont_copy(a, W.obs, K * 7, lane, 64); a += K * 7;
+        if (nel) { ipm::cont_copy(a, W.tel, nel, lane, 64); a += nel; }
+        if constexpr (OD) { ipm::cont_copy(a, W.rho, n, lane, 64); a += n; ipm::cont_copy(a, W.rhob, n, lane, 64); }
+        if (lane == 0) {
+            cst[0] = (double)(it - 1); cst[1] = mu; cst[2] = nu_m; cst[3] = delta_last; cst[4] = e_best; cst[5] = (double)n_acc;
+            cst[6] = resto ? 1.0 : 0.0; cst[7] = (double)n_resto; cst[8] = (double)n_small; cst[9] = theta_R; cst[10] = mu_reg; cst[11] = sf;
+            status_out[prob] = SC_STATUS_PENDING_MPC;
+            if (iters_out) iters_out[prob] = it - 1;
+            ipm::cont_push(ct, prob, th > p.resto.theta_tol);
+        }
+        return;
+    }
     if (it > p.max_iter) it = p.max_iter;
     if (status == SC_STATUS_INACCURATE && !resto && e_best <= p.acceptable_tol) {
         SC_SYNC();
@@ -1378,6 +1459,10 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
     }
 #ifdef SC_GN_PROF
     if (z_out && lane == 0) for (int i = 0; i < 12; ++i) st(z_out, prob * n + i, prof[i]);
+#elif defined(SC_GN_TRACE)
+#elif defined(SC_GN_DUMP)
+    // developer build (tools/exp_gn_dump.py): the whole LDS image of the problem at the end of the solve, z_out sized [B, SC_GN_DUMP]
+    if (z_out) { SC_SYNC(); for (int i = lane; i < SC_GN_DUMP; i += 64) ((double*)z_out)[prob * (long long)SC_GN_DUMP + i] = sm[i]; }
 #else
     if (z_out) for (int i = lane; i < n; i += 64) st(z_out, prob * n + i, W.z[i]);
 #endif
@@ -1385,7 +1470,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
 
 template <int MODEL, bool OD = false>
 static hipError_t mpcgn_launch_m(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
-                                 const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream,
+                                 const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream, const ipm::Cont& ct,
                                  const GnOd od = GnOd{{1.0, 1.0}, {0.0, 0.0}}, void* rho_out = nullptr) {
     const size_t lds = mpcgn_lds_doubles(p.horizon, K, GnModel<MODEL>::NX, GnModel<MODEL>::NB, GnModel<MODEL>::PD == 2 && p.circles_only != 0, GnModel<MODEL>::NH,
                                          GnModel<MODEL>::PD, GnModel<MODEL>::NP, OD) * sizeof(double);
@@ -1395,7 +1480,7 @@ static hipError_t mpcgn_launch_m(const sc_mpcgn_params& p, long long B, int K, c
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, od, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, rho_out);
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, od, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, rho_out, ct);
         return hipGetLastError();
     };
     if (p.horizon == 10) return launch(mpcgn_kernel<MODEL, 10, OD>);
@@ -1418,28 +1503,36 @@ size_t odmpcgn_lds_bytes(int model_id, int N, int K) {
 }
 hipError_t odmpcgn_launch(const sc_odmpcgn_params& q, long long B, int K, const void* X, const void* u_prev, const void* goal,
                           const void* obs, void* u_out, void* rho_out, int* status, int* iters, void* z_out, hipStream_t stream) {
+    ipm::Cont ct0{};
+    ct0.it_stop = q.mpc.max_iter;
     GnOd od;
     od.omega_ref[0] = q.omega_ref[0]; od.omega_ref[1] = q.omega_ref[1]; od.p_sb[0] = q.p_sb[0]; od.p_sb[1] = q.p_sb[1];
     if (q.mpc.model_id == SC_MODEL_KINEMATIC_BICYCLE2D)
-        return mpcgn_launch_m<SC_MODEL_KINEMATIC_BICYCLE2D, true>(q.mpc, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, od, rho_out);
+        return mpcgn_launch_m<SC_MODEL_KINEMATIC_BICYCLE2D, true>(q.mpc, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct0, od, rho_out);
     if (q.mpc.model_id == SC_MODEL_QUAD2D)
-        return mpcgn_launch_m<SC_MODEL_QUAD2D, true>(q.mpc, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, od, rho_out);
+        return mpcgn_launch_m<SC_MODEL_QUAD2D, true>(q.mpc, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct0, od, rho_out);
     return hipErrorInvalidValue;
 }
 
+// doubles of one problem's solver state in a continuation workspace (mpc_cont.hpp; the layout of mpcgn_kernel's hand-over)
+size_t mpcgn_state_doubles(int N, int K) {
+    const size_t n = 2 * (size_t)N, mc = (size_t)N * K, m = mc + 2 * (size_t)N + 2 * n;     // (at most one bounded state)
+    return ipm::CONT_SCALARS + 2 * n + 2 * m + 7 * (size_t)K + mc + 2 * n;
+}
+
 hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
-                        const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream) {
+                        const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream, const ipm::Cont& ct) {
     switch (p.model_id) {
         case SC_MODEL_DOUBLE_INTEGRATOR2D:
-            return mpcgn_launch_m<SC_MODEL_DOUBLE_INTEGRATOR2D>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+            return mpcgn_launch_m<SC_MODEL_DOUBLE_INTEGRATOR2D>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct);
         case SC_MODEL_QUAD2D:
-            return mpcgn_launch_m<SC_MODEL_QUAD2D>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+            return mpcgn_launch_m<SC_MODEL_QUAD2D>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct);
         case SC_MODEL_KINEMATIC_BICYCLE2D:
-            return mpcgn_launch_m<SC_MODEL_KINEMATIC_BICYCLE2D>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+            return mpcgn_launch_m<SC_MODEL_KINEMATIC_BICYCLE2D>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct);
         case SC_MODEL_KINEMATIC_BICYCLE2D_C3BF:
-            return mpcgn_launch_m<SC_MODEL_KINEMATIC_BICYCLE2D_C3BF>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+            return mpcgn_launch_m<SC_MODEL_KINEMATIC_BICYCLE2D_C3BF>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct);
         case SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF:
-            return mpcgn_launch_m<SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream);
+            return mpcgn_launch_m<SC_MODEL_KINEMATIC_BICYCLE2D_DPCBF>(p, B, K, X, u_prev, goal, obs, u_out, status, iters, z_out, stream, ct);
         default:
             return hipErrorInvalidValue;
     }

@@ -24,6 +24,7 @@
 #include "sc_math.hpp"
 #include "mpc_chol.hpp"
 #include "mpc_ipm_common.hpp"
+#include "mpc_cont.hpp"
 
 namespace sc {
 
@@ -364,12 +365,12 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
                                                     const void* __restrict__ goal, const void* __restrict__ obs,
                                                     void* __restrict__ u_out, int* __restrict__ status_out,
                                                     int* __restrict__ iters_out, void* __restrict__ z_out,
-                                                    void* __restrict__ rho_out) {
+                                                    void* __restrict__ rho_out, const ipm::Cont ct) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     constexpr int NW = BIG ? 4 : 1, TH = 64 * NW;                 // threads per problem: the big layout leaves one problem per CU, so it takes all four SIMDs
     const int lane = threadIdx.x;                                 // index among the TH threads of the problem
-    const long long prob = blockIdx.x;
-    if (prob >= B) return;
+    long long prob;
+    if (!ipm::cont_problem(ct, B, prob)) return;                  // mpc_cont.hpp: block index, or an entry of the previous launch's queue
     const bool io32 = p.io_dtype == SC_DTYPE_F32;
     auto ld = [io32](const void* a, size_t i) { return io32 ? (double)((const float*)a)[i] : ((const double*)a)[i]; };
     auto st = [io32](void* a, size_t i, double v) { if (io32) ((float*)a)[i] = (float)v; else ((double*)a)[i] = v; };
@@ -404,6 +405,31 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
     const size_t obase = p.obs_shared ? 0 : (size_t)prob * K * 7;
     for (int e = lane; e < K * 7; e += TH) W.obs[e] = ld(obs, obase + e);
     SC_SYNC();
+    // the scalars of the interior-point loop (block-uniform); a continuation launch loads them with the arrays (mpc_cont.hpp)
+    constexpr bool RESTO = !OD;
+    const int nel = OD ? 0 : d.mc;                                      // elastic variables of the restoration
+    double* const cst = ct.state ? ct.state + prob * ct.stride : nullptr;
+    double f = 0.0, sf = 1.0, mu = p.mu_init;
+    double nu_m = 10.0, delta_last = 0.0, e_best = 1e300;
+    int n_acc = 0, it0 = 1;
+    bool resto = false;
+    int n_resto = 0, n_small = 0;                                       // n_small: consecutive tiny accepted steps at an infeasible z
+    double theta_R = 0.0, mu_reg = mu;
+    if (ct.resume) {
+        // the state a previous launch left: [scalars | z | zb | s | lam | obs | gs or clin | tel | rho | rhob]
+        const double* a = cst + ipm::CONT_SCALARS;
+        ipm::cont_copy(W.z, a, n, lane, TH); a += n;
+        ipm::cont_copy(W.zb, a, n, lane, TH); a += n;
+        ipm::cont_copy(W.s, a, m, lane, TH); a += m;
+        ipm::cont_copy(W.lam, a, m, lane, TH); a += m;
+        ipm::cont_copy(W.obs, a, K * 7, lane, TH); a += K * 7;
+        ipm::cont_copy(LEAN ? W.clin : W.gs, a, n, lane, TH); a += n;
+        if (nel) { ipm::cont_copy(W.tel, a, nel, lane, TH); a += nel; }
+        if constexpr (OD) { ipm::cont_copy(W.rho, a, N, lane, TH); a += N; ipm::cont_copy(W.rhob, a, N, lane, TH); }
+        it0 = (int)cst[0] + 1; mu = cst[1]; nu_m = cst[2]; delta_last = cst[3]; e_best = cst[4]; n_acc = (int)cst[5];
+        resto = cst[6] != 0.0; n_resto = (int)cst[7]; n_small = (int)cst[8]; theta_R = cst[9]; mu_reg = cst[10]; sf = cst[11];
+        SC_SYNC();
+    } else {
     if (!c.circles_only) ipm::normalise_obstacle_flags(W.obs, K, lane, TH);
     SC_SYNC();
     // set_initial_guess (mpc_cbf.py:369): u_prev at every stage, pulled strictly inside the box
@@ -414,7 +440,15 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
     if constexpr (OD) for (int k = lane; k < N; k += TH) { W.rho[k] = c.rf; W.rhob[k] = c.rf; }   // decay variables start at their reference
     SC_SYNC();
 
-    double f = lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, true, R);
+    f = lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, true, R);
+    if (ct.it_stop < 0) {
+        // classify only (mpc_cont.hpp): is a CBF row violated at the initial guess?
+        double th0 = 0.0;
+        for (int i = lane; i < d.mc; i += TH) th0 += fmax(0.0, -W.g[i]);
+        th0 = lsum<TH>(th0, R);
+        if (lane == 0) ipm::cont_push(ct, prob, th0 > 0.0);
+        return;
+    }
     // steep (superellipsoid) barriers: IPOPT-style gradient-based row scaling from the initial guess, then a fresh evaluation
     if (!c.circles_only &&
         ipm::scale_steep_barriers(W.obs, K, W.dh, 2 * N, lane, TH, [&](double v) { return lmax_<TH>(v, R); }, [] { SC_SYNC(); }))
@@ -433,31 +467,28 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
     double gmax = 0.0;
     for (int i = lane; i < n; i += TH) gmax = fmax(gmax, fabs(W.gs[i]));
     gmax = lmax_<TH>(gmax, R);
-    const double sf = fmin(1.0, 100.0 / fmax(1e-12, gmax));             // objective scaling
-    double mu = p.mu_init;
+    sf = fmin(1.0, 100.0 / fmax(1e-12, gmax));                          // objective scaling
     for (int i = lane; i < m; i += TH) { const double s = fmax(W.g[i], 1e-2); W.s[i] = s; W.lam[i] = mu / s; }
     for (int i = lane; i < n; i += TH) W.zb[i] = W.z[i];
     SC_SYNC();
+    }
 
     int status = SC_STATUS_INACCURATE, it = 0;
     const double tau = 0.995;
-    double nu_m = 10.0, delta_last = 0.0, e_best = 1e300;
-    int n_acc = 0;
     bool fresh = false;
     const int acc_iter = p.acceptable_iter > 0 ? p.acceptable_iter : 15;
     // feasibility restoration (mpc_ipm_common.hpp; oracle/mpc_cbf.py: solve): block-uniform state
-    constexpr bool RESTO = !OD;
-    bool resto = false, regrad = false;
-    int n_resto = 0, n_small = 0;                                       // n_small: consecutive tiny accepted steps at an infeasible z
-    double theta_R = 0.0, mu_reg = mu;
+    bool regrad = false, pending = false;
     const double rho_R = p.resto.rho;
 #ifdef SC_LIN_PROF
     double prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_readcyclecounter();
 #endif
-    for (it = 1; it <= p.max_iter; ++it) {
+    for (it = it0; it <= p.max_iter; ++it) {
         LP(11);
-        if (it > 1 && !fresh) f = lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, true, R);   // fresh: the accepted trial point was evaluated with derivatives
+        if (cst && it > ct.it_stop) { pending = true; break; }            // the cap of this launch: the solve goes on in the next one
+        // fresh: the accepted trial point was evaluated with derivatives (a continuation launch evaluates: same point, same values)
+        if ((it > 1 && !fresh) || (ct.resume && it == it0)) f = lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, true, R);
         LP(0);
         double theta = 0.0;                                               // l1 violation of the elastic (CBF) rows at z
         if constexpr (RESTO) {
@@ -843,6 +874,30 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         }
         SC_SYNC();
     }
+    if (pending) {
+        // hand-over (mpc_cont.hpp); W.g holds the rows of the current z on every path to the top of the loop
+        SC_SYNC();
+        double th = 0.0;
+        for (int i = lane; i < d.mc; i += TH) th += fmax(0.0, -W.g[i]);
+        th = lsum<TH>(th, R);
+        double* a = cst + ipm::CONT_SCALARS;
+        ipm::cont_copy(a, W.z, n, lane, TH); a += n;
+        ipm::cont_copy(a, W.zb, n, lane, TH); a += n;
+        ipm::cont_copy(a, W.s, m, lane, TH); a += m;
+        ipm::cont_copy(a, W.lam, m, lane, TH); a += m;
+        ipm::cont_copy(a, W.obs, K * 7, lane, TH); a += K * 7;
+        ipm::cont_copy(a, LEAN ? W.clin : W.gs, n, lane, TH); a += n;
+        if (nel) { ipm::cont_copy(a, W.tel, nel, lane, TH); a += nel; }
+        if constexpr (OD) { ipm::cont_copy(a, W.rho, N, lane, TH); a += N; ipm::cont_copy(a, W.rhob, N, lane, TH); }
+        if (lane == 0) {
+            cst[0] = (double)(it - 1); cst[1] = mu; cst[2] = nu_m; cst[3] = delta_last; cst[4] = e_best; cst[5] = (double)n_acc;
+            cst[6] = resto ? 1.0 : 0.0; cst[7] = (double)n_resto; cst[8] = (double)n_small; cst[9] = theta_R; cst[10] = mu_reg; cst[11] = sf;
+            status_out[prob] = SC_STATUS_PENDING_MPC;
+            if (iters_out) iters_out[prob] = it - 1;
+            ipm::cont_push(ct, prob, th > p.resto.theta_tol);
+        }
+        return;
+    }
     if (it > p.max_iter) it = p.max_iter;
     if (status == SC_STATUS_INACCURATE && !resto && e_best <= p.acceptable_tol) {
         SC_SYNC();
@@ -963,9 +1018,15 @@ bool mpclin_build_model(const sc_mpclin_params& p, const double* Ae, const doubl
     return true;
 }
 
+// doubles of one problem's solver state in a continuation workspace (mpc_cont.hpp; the layout of mpclin_kernel's hand-over)
+size_t mpclin_state_doubles(int N, int K, int nu) {
+    const size_t n = (size_t)N * nu, mc = (size_t)N * K, m = mc + 2 * n;
+    return ipm::CONT_SCALARS + 3 * n + 2 * m + 7 * (size_t)K + mc + 2 * (size_t)N;
+}
+
 hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long long B, int K, const void* X, const void* u_prev,
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out, void* rho_out,
-                         hipStream_t stream) {
+                         hipStream_t stream, const ipm::Cont& ct) {
     const bool od = p.optimal_decay != 0;
     const size_t lds = mpclin_lds_bytes(p.horizon, K, p.nx, p.nu, od);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -977,7 +1038,7 @@ hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long lo
             if (e != hipSuccess) return e;
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(threads), lds, stream, p, model, B, K, X, u_prev, goal, obs, u_out, status,
-                           iters, z_out, rho_out);
+                           iters, z_out, rho_out, ct);
         return hipGetLastError();
     };
     if (od) {                                                           // the config-5 extension: Quad3D only

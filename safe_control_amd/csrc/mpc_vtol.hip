@@ -13,6 +13,7 @@
 #include "../../include/safe_control_amd.h"
 #define SC_VTOL_WITH_C_PARAMS
 #include "mpc_vtol_solver.hpp"
+#include "mpc_cont.hpp"
 
 namespace sc {
 
@@ -52,7 +53,8 @@ __global__ void __launch_bounds__(64) mpcvtol_kernel(const vtol::Params P, long 
 }
 
 hipError_t mpcvtol_wave_launch(const sc_mpcvtol_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
-                               const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream);
+                               const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream,
+                               const ipm::Cont& ct);
 
 // which kernel serves (p, K): the wave-per-problem kernel (mpc_vtol_wave.hip: one stage per lane, the stage's rows in registers, instantiated
 // for 8 and 16 row slots) unless p.kernel = 1 asks for one problem per lane out of the workspace
@@ -68,11 +70,12 @@ size_t mpcvtol_workspace_bytes(const sc_mpcvtol_params& p, long long B, int K) {
 }
 
 hipError_t mpcvtol_launch(const sc_mpcvtol_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
-                          const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, void* workspace, hipStream_t stream) {
-    if (mpcvtol_uses_wave(p, K)) return mpcvtol_wave_launch(p, B, K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream);
+                          const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, void* workspace, hipStream_t stream,
+                          const ipm::Cont& ct) {
+    if (mpcvtol_uses_wave(p, K)) return mpcvtol_wave_launch(p, B, K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct);
+    if (ct.state || ct.queue_in || ct.it_stop < p.max_iter) return hipErrorInvalidValue;   // continuation launches: the wave kernel only
     const vtol::Params P = vtol::from_c(p, K);
-    int lanes = B <= 16384 ? 16 : 64;
-    if (const char* e = std::getenv("SC_VTOL_LANES")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) lanes = v; }
+    const int lanes = B <= 16384 ? 16 : 64;                               // problems per block of the one-NLP-per-lane kernel (kernel = 1)
     const unsigned blocks = (unsigned)((B + lanes - 1) / lanes);
     if (p.io_dtype == SC_DTYPE_F64)
         hipLaunchKernelGGL(mpcvtol_kernel<double>, dim3(blocks), dim3(64), 0, stream, P, B, lanes, p.obs_shared, (const double*)X,

@@ -20,6 +20,7 @@
 
 #include "../../include/safe_control_amd.h"
 #include "mpc_ipm_common.hpp"
+#include "mpc_cont.hpp"
 #define SC_VTOL_WITH_C_PARAMS
 #define SC_VTOL_RCP(a) sc::rcp_(a)
 #define SC_VTOL_SINCOS(a, s, c) sc::sincos_((a), &(s), &(c));
@@ -37,6 +38,7 @@ using namespace vtol;
 #define VPROF_ADD(i)
 #endif
 
+constexpr int ST_PENDING = -1;      // Wave::solve: stopped at the cap of this launch (or classified only)
 constexpr int WKT_MAX = 16;            // CBF rows per stage held in registers: instantiated for 8 and 16
 
 struct WaveLds {
@@ -559,7 +561,36 @@ struct Wave {
     }
 
     // ---- oracle/mpc_cbf.py: solve(), wave-uniform control flow -----------------------------------------------------------------
-    __device__ __forceinline__ void solve(int& status_out, int& iters_out) {
+    // doubles of one stage (lane) in a problem's hand-over record (mpc_cont.hpp): s | lam | t | zb | zR
+    static constexpr int CONT_LANE = 2 * WNR + WKT + 2 * NU;
+    // ST_PENDING in status_out: the solve stopped at the cap of this launch and its state is in cst
+    __device__ __forceinline__ void solve(int& status_out, int& iters_out, const ipm::Cont& ct, double* cst, bool& violated) {
+        double fraw = 0.0, sf0 = 1.0, mu = P.mu_init;
+        double nu = 10.0, delta_last = 0.0, e_best = INFINITY;
+        int n_acc = 0, n_resto = 0, n_small = 0, it0 = 1;
+        bool resto = false, have = true;
+        double theta_R = 0.0, mu_reg = mu;
+#pragma unroll
+        for (int r = 0; r < WNR; ++r) { ds[r] = 0.0; dlam[r] = 0.0; }
+#pragma unroll
+        for (int j = 0; j < WKT; ++j) { t[j] = 0.0; dtt[j] = 0.0; }
+        if (ct.resume) {
+            // the state a previous launch left: [scalars | U (N NU) | per stage: s, lam, t, zb, zR]; the rows, the stage's states and the
+            // cost come from an evaluation of U (the same function on the same inputs as the accepted trial's: the same values)
+            const double* a = cst + ipm::CONT_SCALARS;
+            for (int i = lane; i < N * NU; i += 64) lds[L.U + i] = a[i];
+            a += N * NU + (size_t)k * CONT_LANE;
+#pragma unroll
+            for (int r = 0; r < WNR; ++r) { s[r] = a[r]; lam[r] = a[WNR + r]; }
+#pragma unroll
+            for (int j = 0; j < WKT; ++j) t[j] = a[2 * WNR + j];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { zb[j] = a[2 * WNR + WKT + j]; zR[j] = a[2 * WNR + WKT + NU + j]; }
+            it0 = (int)cst[0] + 1; mu = cst[1]; nu = cst[2]; delta_last = cst[3]; e_best = cst[4]; n_acc = (int)cst[5];
+            resto = cst[6] != 0.0; n_resto = (int)cst[7]; n_small = (int)cst[8]; theta_R = cst[9]; mu_reg = cst[10]; sf0 = cst[11];
+            have = false;
+            sync();
+        } else {
         double uk[NU];
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -569,24 +600,21 @@ struct Wave {
             zb[j] = uk[j]; zR[j] = uk[j];
         }
         sync();
-        double fraw = eval(L.U, g);
+        fraw = eval(L.U, g);
+        if (ct.it_stop < 0) { violated = violation() > 0.0; status_out = ST_PENDING; iters_out = 0; return; }   // classify only
         linearise();
         sync();
         const double g0 = adjoint(false, 1.0, false, 0.0);
-        const double sf0 = fmin(1.0, 100.0 / fmax(1e-12, g0));
-        double mu = P.mu_init;
+        sf0 = fmin(1.0, 100.0 / fmax(1e-12, g0));
 #pragma unroll
-        for (int r = 0; r < WNR; ++r) { s[r] = fmax(g[r], 1e-2); lam[r] = mu / s[r]; ds[r] = 0.0; dlam[r] = 0.0; }
-#pragma unroll
-        for (int j = 0; j < WKT; ++j) { t[j] = 0.0; dtt[j] = 0.0; }
+        for (int r = 0; r < WNR; ++r) { s[r] = fmax(g[r], 1e-2); lam[r] = mu / s[r]; }
+        }
         int status = ST_INACCURATE, it = 0;
         const double tau = 0.995, rho = P.rho, theta_tol = P.theta_tol;
-        double nu = 10.0, delta_last = 0.0, e_best = INFINITY;
-        int n_acc = 0, n_resto = 0, n_small = 0;
-        bool resto = false, have = true;
-        double theta_R = 0.0, mu_reg = mu;
         const bool sreset = P.slack_reset != 0;
-        for (it = 1; it <= P.max_iter; ++it) {
+        bool pending = false;
+        for (it = it0; it <= P.max_iter; ++it) {
+            if (cst && it > ct.it_stop) { pending = true; break; }        // the cap of this launch: the solve goes on in the next one
             double cw = resto ? 0.0 : sf0;
             VPROF_T0
             if (!have) fraw = eval(L.U, g);
@@ -853,6 +881,29 @@ struct Wave {
             }
             nu = 10.0; n_acc = 0; have = true;
         }
+        if (pending) {
+            // hand-over (mpc_cont.hpp): g holds the rows of U on every path to the top of the loop (accepted trial, the evaluation
+            // before a restoration entry, the initial one) -- except right after a resume, which never stops again at once
+            sync();
+            violated = violation() > theta_tol;
+            double* a = cst + ipm::CONT_SCALARS;
+            for (int i = lane; i < N * NU; i += 64) a[i] = lds[L.U + i];
+            a += N * NU + (size_t)k * CONT_LANE;
+            if (act) {
+#pragma unroll
+                for (int r = 0; r < WNR; ++r) { a[r] = s[r]; a[WNR + r] = lam[r]; }
+#pragma unroll
+                for (int j = 0; j < WKT; ++j) a[2 * WNR + j] = t[j];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) { a[2 * WNR + WKT + j] = zb[j]; a[2 * WNR + WKT + NU + j] = zR[j]; }
+            }
+            if (lane == 0) {
+                cst[0] = (double)(it - 1); cst[1] = mu; cst[2] = nu; cst[3] = delta_last; cst[4] = e_best; cst[5] = (double)n_acc;
+                cst[6] = resto ? 1.0 : 0.0; cst[7] = (double)n_resto; cst[8] = (double)n_small; cst[9] = theta_R; cst[10] = mu_reg; cst[11] = sf0;
+            }
+            status_out = ST_PENDING; iters_out = it - 1;
+            return;
+        }
         if (it > P.max_iter) it = P.max_iter;
         if (status != ST_OPTIMAL && status != ST_INFEASIBLE && e_best <= P.acceptable_tol && !resto) {
             sync();
@@ -871,9 +922,10 @@ template <typename TIO, int WKT>
 __global__ void __launch_bounds__(64) mpcvtol_wave_kernel(const Params P, long long B, int obs_shared, const TIO* __restrict__ X,
                                                           const TIO* __restrict__ u_prev, const TIO* __restrict__ goal,
                                                           const TIO* __restrict__ obs, TIO* __restrict__ u_out, int* __restrict__ status_out,
-                                                          int* __restrict__ iters_out, TIO* __restrict__ z_out) {
+                                                          int* __restrict__ iters_out, TIO* __restrict__ z_out, const ipm::Cont ct) {
     extern __shared__ double vtol_lds[];
-    const long long b = blockIdx.x;
+    long long b;
+    if (!ipm::cont_problem(ct, B, b)) return;                           // mpc_cont.hpp: block index, or an entry of the previous launch's queue
     Wave<WKT> S(P, (ldsd*)vtol_lds);
     const TIO* ob = obs + (obs_shared ? 0 : b * P.K * 7);
     if ((int)threadIdx.x < 3 * WKT_MAX) {
@@ -885,7 +937,15 @@ __global__ void __launch_bounds__(64) mpcvtol_wave_kernel(const Params P, long l
     S.xg[0] = (double)goal[b * 2]; S.xg[1] = (double)goal[b * 2 + 1];
     __syncthreads();
     int st, it;
-    S.solve(st, it);
+    bool violated = false;
+    S.solve(st, it, ct, ct.state ? ct.state + b * ct.stride : nullptr, violated);
+    if (st == ST_PENDING) {
+        if (threadIdx.x == 0) {
+            if (ct.it_stop >= 0) { status_out[b] = SC_STATUS_PENDING_MPC; if (iters_out) iters_out[b] = it; }
+            ipm::cont_push(ct, b, violated);
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
         for (int j = 0; j < NU; ++j) u_out[b * NU + j] = (TIO)vtol_lds[S.L.U + j];
         status_out[b] = st;
@@ -902,23 +962,30 @@ __global__ void __launch_bounds__(64) mpcvtol_wave_kernel(const Params P, long l
 
 template <typename TIO, int WKT>
 static hipError_t wave_launch_t(const Params& P, const sc_mpcvtol_params& p, long long B, size_t lds, const void* X, const void* u_prev,
-                                const void* goal, const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream) {
+                                const void* goal, const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream,
+                                const ipm::Cont& ct) {
     hipError_t e = hipFuncSetAttribute((const void*)mpcvtol_wave_kernel<TIO, WKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((mpcvtol_wave_kernel<TIO, WKT>), dim3((unsigned)B), dim3(64), lds, stream, P, B, p.obs_shared, (const TIO*)X,
-                       (const TIO*)u_prev, (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status_out, iters_out, (TIO*)z_out);
+                       (const TIO*)u_prev, (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status_out, iters_out, (TIO*)z_out, ct);
     return hipGetLastError();
 }
 
+// doubles of one problem's solver state in a continuation workspace (mpc_cont.hpp; the layout of Wave::solve's hand-over)
+size_t mpcvtol_state_doubles(int N, int K) {
+    return ipm::CONT_SCALARS + (size_t)N * NU + (size_t)N * (K <= 8 ? Wave<8>::CONT_LANE : Wave<16>::CONT_LANE);
+}
+
 hipError_t mpcvtol_wave_launch(const sc_mpcvtol_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
-                               const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream) {
+                               const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream,
+                               const ipm::Cont& ct) {
     const Params P = from_c(p, K);
     const size_t lds = mpcvtol_wave_lds_bytes(p.horizon);
     if (p.io_dtype == SC_DTYPE_F64)
-        return K <= 8 ? wave_launch_t<double, 8>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream)
-                      : wave_launch_t<double, 16>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream);
-    return K <= 8 ? wave_launch_t<float, 8>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream)
-                  : wave_launch_t<float, 16>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream);
+        return K <= 8 ? wave_launch_t<double, 8>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct)
+                      : wave_launch_t<double, 16>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct);
+    return K <= 8 ? wave_launch_t<float, 8>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct)
+                  : wave_launch_t<float, 16>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct);
 }
 
 }  // namespace sc

@@ -125,11 +125,13 @@ class GnMPCCBF:
         return u.reshape(-1, 1).copy()
 
 
-class BatchedGnMPCCBF:
+class BatchedGnMPCCBF(_lib.SlicedSolver):
     """``solve(X[B,nx], u_prev[B,2], goal[B,2], obs[B,K,7] | obs[K,7])`` -> ``u[B,2]``, ``status[B]``, ``iters[B]`` (and
     ``z[B,2N]`` if asked); nx = 4 (DoubleIntegrator2D, KinematicBicycle2D) or 6 (Quad2D)."""
 
-    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=100):
+    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=100,
+                 iter_slices=None, classify_first=False, order=True):
+        self.init_slices(iter_slices, classify_first, order)      # continuation launches (include/safe_control_amd.h: sc_mpc_slices)
         self.robot_spec = complete_robot_spec(robot_spec)
         if self.robot_spec["model"] not in GN_MODELS:
             raise NotImplementedError(f"this controller serves {GN_MODELS}")
@@ -167,8 +169,12 @@ class BatchedGnMPCCBF:
         p = make_params(self.robot_spec, self._mc, self.cbf_param, self.horizon, self.dt, self.robot_spec["radius"],
                         self.io_dtype, obs_shared=shared, tol=self.tol, max_iter=self.max_iter, resto=getattr(self, "resto", None))
         stream = torch.cuda.current_stream(X.device).cuda_stream
-        rc = self._lib.sc_mpcgn_solve_batch(
-            C.byref(p), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(),
-            status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        sl = self.slices_for(lambda: self._lib.sc_mpcgn_slices_workspace_bytes(C.byref(p), B, K), X.device)
+        args = (B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(),
+                status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        if sl is None:
+            rc = self._lib.sc_mpcgn_solve_batch(C.byref(p), *args)
+        else:
+            rc = self._lib.sc_mpcgn_solve_batch_sliced(C.byref(p), C.byref(sl), *args)
         _lib.check(rc, "sc_mpcgn_solve_batch")
         return (u, status, iters, z) if want_z else (u, status, iters)

@@ -105,11 +105,14 @@ class LinearMPCCBF:
         return u.reshape(-1, 1).copy()
 
 
-class BatchedLinearMPCCBF:
+class BatchedLinearMPCCBF(_lib.SlicedSolver):
     """``solve(X[B,nx], u_prev[B,nu], goal[B,ng], obs[B,K,7] | obs[K,7])`` -> ``u[B,nu]``, ``status[B]``, ``iters[B]``
-    (and ``z[B, nu*N]`` if asked) for SingleIntegrator2D (nx 2, nu 2, ng 2) or Quad3D (nx 12, nu 4, ng 3)."""
+    (and ``z[B, nu*N]`` if asked) for SingleIntegrator2D (nx 2, nu 2, ng 2) or Quad3D (nx 12, nu 4, ng 3).
+    ``iter_slices`` / ``classify_first`` / ``order``: continuation launches (include/safe_control_amd.h: sc_mpc_slices)."""
 
-    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=100):
+    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=100,
+                 iter_slices=None, classify_first=False, order=True):
+        self.init_slices(iter_slices, classify_first, order)
         self.robot_spec = complete_robot_spec(robot_spec)
         if self.robot_spec["model"] not in LINEAR_MODELS:
             raise NotImplementedError(f"linear-model MPC-CBF supports {LINEAR_MODELS}")
@@ -157,9 +160,13 @@ class BatchedLinearMPCCBF:
         p = make_params(self._mdl, self.cbf_param, self.horizon, self.robot_spec["radius"], self.io_dtype,
                         obs_shared=shared, tol=self.tol, max_iter=self.max_iter, resto=getattr(self, "resto", None))
         stream = torch.cuda.current_stream(X.device).cuda_stream
-        rc = self._lib.sc_mpclin_solve_batch(
-            C.byref(p), self._blob(X.device).data_ptr(), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(),
-            obs.data_ptr(), u.data_ptr(), status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        sl = self.slices_for(lambda: self._lib.sc_mpclin_slices_workspace_bytes(C.byref(p), B, K), X.device)
+        args = (self._blob(X.device).data_ptr(), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(),
+                obs.data_ptr(), u.data_ptr(), status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        if sl is None:
+            rc = self._lib.sc_mpclin_solve_batch(C.byref(p), *args)
+        else:
+            rc = self._lib.sc_mpclin_solve_batch_sliced(C.byref(p), C.byref(sl), *args)
         _lib.check(rc, "sc_mpclin_solve_batch")
         return (u, status, iters, z) if want_z else (u, status, iters)
 

@@ -1,4 +1,5 @@
-"""MPC-CBF for VTOL2D on the gfx950 kernel csrc/mpc_vtol.hip (one NLP per lane, stage-wise Riccati Newton steps).
+"""MPC-CBF for VTOL2D on the gfx950 kernel csrc/mpc_vtol_wave.hip (one NLP per wavefront, one stage per lane, stage-wise Riccati Newton steps;
+csrc/mpc_vtol.hip holds the one-NLP-per-lane kernel it was checked against, ``kernel = 1``).
 
 ``safe_control_amd.MPCCBF(robot, robot_spec, ...)`` returns a ``VtolMPCCBF`` for ``model == 'VTOL2D'`` (the reference serves
 every model from the one MPCCBF class, position_control/mpc_cbf.py:7-100; VTOL2D: :40-43 weights, :83-87 gains, horizon 30,
@@ -93,11 +94,16 @@ class VtolMPCCBF:
         return u.reshape(-1, 1).copy()
 
 
-class BatchedVtolMPCCBF:
+class BatchedVtolMPCCBF(_lib.SlicedSolver):
     """``solve(X[B,6], u_prev[B,4], goal[B,2], obs[B,K,7] | obs[K,7])`` -> ``u[B,4]``, ``status[B]``, ``iters[B]`` (and ``z[B,4N]`` if
-    asked).  The work arrays of the B problems (sc_mpcvtol_workspace_bytes: about 0.1 MB per problem) are kept between calls."""
+    asked).  The default kernel (one NLP per wavefront, one stage per lane: csrc/mpc_vtol_wave.hip) keeps everything in registers
+    and LDS and needs no workspace; ``kernel = 1`` selects the one-NLP-per-lane kernel it was checked against, whose work arrays
+    (sc_mpcvtol_workspace_bytes: about 0.1 MB per problem) are kept between calls.  ``iter_slices`` / ``classify_first`` / ``order``:
+    continuation launches of the wave kernel (include/safe_control_amd.h: sc_mpc_slices)."""
 
-    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f64", cbf_param=None, tol=1e-6, max_iter=100):
+    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f64", cbf_param=None, tol=1e-6, max_iter=100,
+                 iter_slices=None, classify_first=False, order=True):
+        self.init_slices(iter_slices, classify_first, order)
         self.robot_spec = complete_robot_spec(dict(robot_spec or {"model": "VTOL2D"}))
         if self.robot_spec["model"] != "VTOL2D":
             raise NotImplementedError("this controller serves VTOL2D")
@@ -139,8 +145,12 @@ class BatchedVtolMPCCBF:
         if self._ws is None or self._ws.numel() < need or self._ws.device != X.device:
             self._ws = torch.empty((max(need, 8),), dtype=torch.uint8, device=X.device)
         stream = torch.cuda.current_stream(X.device).cuda_stream
-        rc = self._lib.sc_mpcvtol_solve_batch(
-            C.byref(p), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(),
-            status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, self._ws.data_ptr(), need, stream)
+        sl = self.slices_for(lambda: self._lib.sc_mpcvtol_slices_workspace_bytes(C.byref(p), B, K), X.device)
+        args = (B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(),
+                status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None)
+        if sl is None:
+            rc = self._lib.sc_mpcvtol_solve_batch(C.byref(p), *args, self._ws.data_ptr(), need, stream)
+        else:
+            rc = self._lib.sc_mpcvtol_solve_batch_sliced(C.byref(p), C.byref(sl), *args, stream)
         _lib.check(rc, "sc_mpcvtol_solve_batch")
         return (u, status, iters, z) if want_z else (u, status, iters)

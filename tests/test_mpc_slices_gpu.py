@@ -49,7 +49,7 @@ def same(a, b, what):
         assert len(bad) == 0, f"{what}: {name} differs on {len(bad)} problems, first {bad[:5]}"
 
 
-FAMILIES = ["du", "uni"]
+FAMILIES = ["du", "uni", "si", "quad3d", "di", "quad2d", "kb", "c3bf", "dpcbf", "vtol"]
 
 
 @pytest.mark.parametrize("fam", FAMILIES)
@@ -59,7 +59,7 @@ def test_resumed_solve_is_bitwise_the_uninterrupted_solve(fam):
     ref = solve(make(fam, max_iter=100), arrs)
     assert (ref[1] >= 0).all()
     it = ref[2]
-    assert it.max() > 30, "the batch should hold solves that cross several caps"
+    assert it.max() > 12, "the batch should hold solves that cross several caps"
     # caps that cut solves in every phase: regular, restoration, the first iteration, one before the end
     for caps in ((1, 2, 3, 5, 8, 13, 21, 34), (7, 40), (int(it.max()) - 1,), (16,)):
         got = solve(make(fam, max_iter=100, iter_slices=caps, order=False), arrs)
