@@ -122,7 +122,7 @@ def valu_roofline(run, kernel_substr, kernel_ms, note=None):
     profile has them: lane utilisation = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU), and the f64 flops of the launch
     (lanes x (2 FMA + ADD + MUL) + 512 per MFMA op) against the 78.6 TFLOP/s vector peak.  The profile is used only when it
     was taken from the kernel sources of this tree (csrc hash); otherwise the entry says "stale"."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_counters.json")
         if not os.path.exists(path):
             continue
@@ -170,6 +170,28 @@ def with_roofline(res, kernel_substr):
     return res
 
 
+def budget_note(make_ctl, args, steps, ms_full, st_full, it_full):
+    """The interior-point legs run the reference solver's budget (IPOPT's max_iter = 3000, mpc_cbf.py:163-173) as continuation launches
+    (first cap 100, classify-only pre-pass).  Beside that figure: the same batch with the round-3 limit of 100 iterations in one launch,
+    and how many problems needed more."""
+    import torch
+    ctl = make_ctl(max_iter=100, iter_slices=(), classify_first=False)
+    out = ctl.solve(*args)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        out = ctl.solve(*args)
+    e1.record()
+    torch.cuda.synchronize()
+    st = out[1]
+    return {"budget": 3000, "launches": "classify + cap 100 + rest", "max_ipm_iterations": int(it_full.max().item()),
+            "inaccurate_fraction": float((st_full == 2).double().mean().item()),
+            "one_launch_limit_100": {"kernel_ms": e0.elapsed_time(e1) / steps, "optimal_fraction": float((st == 0).double().mean().item()),
+                                     "inaccurate_fraction": float((st == 2).double().mean().item())},
+            "beyond_100_iterations": int((it_full > 100).sum().item())}
+
+
 def mpc_cpu_baseline(Xn, goal, on, N, seconds):
     """oracle/mpc_cbf.py (numpy float64, the same interior-point method) on one host core: bounded sample of the
     same batch, starting from its first problem."""
@@ -190,7 +212,8 @@ def mpc_leg(dev, B, K, N, steps, warmup, seed=0, cpu_seconds=0.0):
     import safe_control_amd as sca
     from safe_control_amd import workloads as W
     spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}
-    ctl = sca.BatchedMPCCBF(dict(spec), io_dtype="f32", horizon=N)
+    mk = lambda **kw: sca.BatchedMPCCBF(dict(spec), io_dtype="f32", horizon=N, **kw)   # noqa: E731
+    ctl = mk()
     Xn, goal, un, on = W.du_cbfqp_batch(B, K, seed=seed)
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
     X, g, ob = t(Xn), t(goal), t(on)
@@ -212,9 +235,11 @@ def mpc_leg(dev, B, K, N, steps, warmup, seed=0, cpu_seconds=0.0):
     st, it = out[1], out[2]
     nbytes = ((4 + 2 + 2 + 7 * K) * 4 + 2 * 4 + 4 + 4) * B
     extra = {"cpu_baseline": mpc_cpu_baseline(Xn, goal, on, N, cpu_seconds)} if cpu_seconds > 0 else {}
+    extra.update(budget_note(mk, (X, up, g, ob), steps, ms, st, it))
     if (B, K, N, seed) == (4096, 8, 10, 0):
         rl = valu_roofline("mpc_sq", "mpccbf_kernel<10, 8>", ms, note="4096 problems = two rounds of 2048 resident waves; the launch ends with its "
-                           "slowest problem (max 82 interior-point iterations, restoration included, against a mean of 19)")
+                           "slowest problem (74 interior-point iterations against a mean of 19: the 40 longest solves ALONE take 1.77 ms, "
+                           "tools/exp_tail.py)")
         if rl:
             extra["roofline"] = rl
     return {**extra, "workload": f"{B}-agent batch DynamicUnicycle2D MPC-CBF, horizon N={N}, {K} obstacles (BASELINE configs[2])",
@@ -422,7 +447,8 @@ def linear_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
     import torch
     import safe_control_amd as sca
     from safe_control_amd import workloads as W
-    ctl = sca.BatchedLinearMPCCBF({"model": model}, io_dtype="f32", horizon=N)
+    mk = lambda **kw: sca.BatchedLinearMPCCBF({"model": model}, io_dtype="f32", horizon=N, **kw)   # noqa: E731
+    ctl = mk()
     Xn, gn, on = W.linear_mpc_batch(model, B, K, seed=seed)
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
     X, g, ob = t(Xn), t(gn), t(on)
@@ -438,7 +464,8 @@ def linear_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
     ms = e0.elapsed_time(e1) / steps
     nxu = "12, 4" if model == "Quad3D" else "2, 2"
     kname = f"mpclin_kernel<{nxu}, {N}, {K}, false, false>" if N == 10 else f"mpclin_kernel<{nxu}, 0, 0, true, false>"
-    return with_roofline({"workload": f"{B}-agent batch {model} MPC-CBF, horizon N={N}, {K} obstacles ({N * up.shape[1]} variables)",
+    return with_roofline({**budget_note(mk, (X, up, g, ob), steps, ms, st, it),
+            "workload": f"{B}-agent batch {model} MPC-CBF, horizon N={N}, {K} obstacles ({N * up.shape[1]} variables)",
             "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
             "optimal_fraction": float((st == 0).double().mean().item()),
             "infeasible_fraction": float((st == 1).double().mean().item()),
@@ -452,7 +479,8 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
     import torch
     import safe_control_amd as sca
     from safe_control_amd import workloads as W
-    ctl = sca.BatchedGnMPCCBF({"model": model}, io_dtype="f32", horizon=N)
+    mk = lambda **kw: sca.BatchedGnMPCCBF({"model": model}, io_dtype="f32", horizon=N, **kw)   # noqa: E731
+    ctl = mk()
     fam = {v: k for k, v in W.MPC_FAMILIES.items()}[model]
     Xn, up0, gn, on = W.mpc_family_batch(fam, B, K, seed=seed)
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
@@ -467,7 +495,8 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     mid = {"DoubleIntegrator2D": 5, "Quad2D": 6, "KinematicBicycle2D": 1, "KinematicBicycle2D_C3BF": 2, "KinematicBicycle2D_DPCBF": 3}[model]
-    return with_roofline({"workload": f"{B}-agent batch {model} MPC-CBF, horizon N={N}, {K} obstacles",
+    return with_roofline({**budget_note(mk, (X, up, g, ob), steps, ms, st, it),
+            "workload": f"{B}-agent batch {model} MPC-CBF, horizon N={N}, {K} obstacles",
             "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
             "optimal_fraction": float((st == 0).double().mean().item()),
             "infeasible_fraction": float((st == 1).double().mean().item()),
@@ -480,7 +509,8 @@ def vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
     import torch
     import safe_control_amd as sca
     from safe_control_amd import workloads as W
-    ctl = sca.BatchedVtolMPCCBF(io_dtype="f32")
+    mk = lambda **kw: sca.BatchedVtolMPCCBF(io_dtype="f32", **kw)   # noqa: E731
+    ctl = mk()
     Xn, up0, gn, on = W.mpc_family_batch("vtol", B, K, seed=seed)
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
     X, g, ob, up = t(Xn), t(gn), t(on), t(up0)
@@ -493,11 +523,12 @@ def vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    return with_roofline({"workload": f"{B}-aircraft batch VTOL2D MPC-CBF, horizon N=30, {K} obstacles (120 variables, 630 rows per NLP)",
+    return with_roofline({**budget_note(mk, (X, up, g, ob), steps, ms, st, it),
+            "workload": f"{B}-aircraft batch VTOL2D MPC-CBF, horizon N=30, {K} obstacles (120 variables, 630 rows per NLP)",
             "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
             "optimal_fraction": float((st == 0).double().mean().item()),
             "infeasible_fraction": float((st == 1).double().mean().item()),
-            "mean_ipm_iterations": float(it.double().mean().item()), "max_ipm_iterations": int(it.max().item()),
+            "mean_ipm_iterations": float(it.double().mean().item()),
             "lds_KB_per_problem": 39.3, "problems_per_CU": 4}, "mpcvtol_wave_kernel<float, 8>")
 
 
@@ -615,9 +646,11 @@ def compact_leg(v):
     keep = {}
     for k in ("value", "unit", "kernel_ms", "ms_per_control_step", "us_per_step", "agent_steps_per_s", "solves_per_s", "optimal_fraction",
               "infeasible_fraction", "mean_ipm_iterations", "max_ipm_iterations", "agents", "GBs", "frac_of_peak", "error", "launches",
-              "optimal_only_value", "budget"):
+              "optimal_only_value", "budget", "inaccurate_fraction", "beyond_100_iterations"):
         if k in v:
             keep[k] = round(v[k], 6) if isinstance(v[k], float) else v[k]
+    if isinstance(v.get("one_launch_limit_100"), dict):
+        keep["limit_100_ms"] = round(v["one_launch_limit_100"]["kernel_ms"], 4)
     rl = v.get("roofline")
     if isinstance(rl, dict):
         keep["roofline"] = {k: (round(rl[k], 5) if isinstance(rl[k], float) else rl[k]) for k in ("bound", "frac", "stale") if k in rl}

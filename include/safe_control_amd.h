@@ -260,7 +260,12 @@ typedef struct sc_mpclin_params {
                                 decay variable rho_k per stage, rows h(step) - (1 - alpha rho_k) h(x_k) >= 0 -- the
                                 rel-degree-1 form of optimal_decay_cbf_qp.py:96-101,113-125 -- cost + od_p_sb (rho_k -
                                 od_omega_ref)^2, r-term R u^2 (optimal_decay_mpc_cbf.py:178-184); oracle/od_mpc_rd1.py.
-                                The model blob must be built with the same flag (its cost Hessian differs).   */
+                                The model blob must be built with the same flag (its cost Hessian differs).
+                                2: the semantics the reference's OptimalDecayMPCCBF gives the models of its rel-degree-1 branch
+                                (Quad3D: optimal_decay_mpc_cbf.py:284-287): the PLAIN row d_h + alpha h_k -- the decay inputs omega1,
+                                omega2 exist in the model but touch no row, their penalty keeps them at their reference -- with that
+                                class's input term R u^2 (:173-179) instead of MPCCBF's delta-u penalty; solved through
+                                sc_mpclin_solve_batch (restoration and continuation launches included).                        */
     double  alpha;           /* DT-CBF gain: SI 0.05 (mpc_cbf.py:48-50), Quad3D 0.15 (:77-78)              */
     double  robot_radius, beta, tol, acceptable_tol, mu_init, mu_min;   /* as sc_mpccbf_params            */
     double  Q[12];           /* diagonal state weights (mpc_cbf.py:19-20, :37-38)                          */

@@ -38,7 +38,7 @@ STATUS_INACCURATE = 2
 
 DEFAULTS = dict(N=10, dt=0.05, Q=(50.0, 50.0, 0.01, 30.0), R=(0.5, 0.5), alpha1=0.15, alpha2=0.15,
                 v_max=1.0, a_max=1.0, w_max=0.5, radius=0.25, beta=1.01,
-                tol=1e-6, acceptable_tol=1e-5, acceptable_iter=15, max_iter=100, mu_init=0.1, mu_min=1e-9,
+                tol=1e-6, acceptable_tol=1e-5, acceptable_iter=15, max_iter=3000, mu_init=0.1, mu_min=1e-9,
                 resto_rho=1000.0, resto_kappa=0.1, resto_theta_tol=1e-6, resto_max=2, resto_tol=1e-2,
                 resto_small_alpha=0.02, resto_small_iter=4, resto_slack_reset=True)
 

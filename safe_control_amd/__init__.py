@@ -10,7 +10,7 @@ from ._lib import HipLibraryError, load as load_library  # noqa: F401
 from .position_control.cbf_qp import CBFQP, BatchedCBFQP  # noqa: F401
 from .position_control.manipulator_cbf_qp import ManipulatorCBFQP, BatchedManipulatorCBFQP, BatchedManipulatorTracking  # noqa: F401
 from .position_control.mpc_cbf import MPCCBF, BatchedMPCCBF  # noqa: F401
-from .position_control.mpc_cbf_linear import LinearMPCCBF, BatchedLinearMPCCBF, BatchedOptimalDecayLinearMPCCBF  # noqa: F401
+from .position_control.mpc_cbf_linear import LinearMPCCBF, BatchedLinearMPCCBF, BatchedOptimalDecayLinearMPCCBF, OptimalDecayLinearMPCCBF  # noqa: F401
 from .position_control.mpc_cbf_gn import GnMPCCBF, BatchedGnMPCCBF  # noqa: F401
 from .position_control.mpc_cbf_vtol import VtolMPCCBF, BatchedVtolMPCCBF  # noqa: F401
 from .position_control.backup_cbf_qp import BackupCBF, BatchedBackupCBF  # noqa: F401

@@ -91,6 +91,11 @@ def default_resto(**over):
 
 MPC_MAX_SLICES = 8
 STATUS_PENDING = -1
+# The reference hands its NLPs to IPOPT with default options (position_control/mpc_cbf.py:163-173): max_iter = 3000.  The batched
+# classes serve that budget with continuation launches: the launch over the whole batch stops at FIRST_CAP iterations, the few
+# unfinished solves continue in a second launch (sc_mpc_slices); a classify-only pre-pass starts the long solves first.
+IPOPT_MAX_ITER = 3000
+FIRST_CAP = 100
 
 
 class MpcSlices(C.Structure):
@@ -115,8 +120,9 @@ class SlicedSolver:
     launches before the last one; ``classify_first``; ``order``) and a workspace tensor that is kept between calls and grows with
     the batch.  ``slices_for(B, need_bytes, device)`` returns the ctypes struct to pass, or None for a single launch."""
 
-    def init_slices(self, iter_slices=None, classify_first=False, order=True):
-        self.iter_slices = tuple(int(c) for c in (iter_slices or ()))
+    def init_slices(self, iter_slices=None, classify_first=True, order=True):
+        """iter_slices: None = the default schedule (FIRST_CAP), () = one launch"""
+        self.iter_slices = (FIRST_CAP,) if iter_slices is None else tuple(int(c) for c in iter_slices)
         self.classify_first, self.order_slices = bool(classify_first), bool(order)
         self._slice_ws = None
 

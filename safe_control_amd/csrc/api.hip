@@ -212,11 +212,11 @@ static int check_mpclin(const sc_mpclin_params* p, const double* model, int64_t 
     if (K < 1) return fail(SC_ERR_INVALID_ARGUMENT, "K < 1 (pad with [1000,1000,0,...] rows like update_tvp)");
     if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
         return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
-    if (p->optimal_decay != 0 && p->optimal_decay != 1) return fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay must be 0 or 1");
-    if (p->optimal_decay && !(p->nx == 12 && p->nu == 4))
+    if (p->optimal_decay < 0 || p->optimal_decay > 2) return fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay must be 0, 1 or 2");
+    if (p->optimal_decay == 1 && !(p->nx == 12 && p->nu == 4))
         return fail(SC_ERR_UNSUPPORTED, "the optimal-decay extension of this kernel is built for Quad3D (nx = 12, nu = 4)");
-    if (p->optimal_decay && !(p->od_p_sb > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "od_p_sb must be > 0");
-    if (mpclin_lds_bytes(p->horizon, K, p->nx, p->nu, p->optimal_decay != 0) > 160 * 1024)
+    if (p->optimal_decay == 1 && !(p->od_p_sb > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "od_p_sb must be > 0");
+    if (mpclin_lds_bytes(p->horizon, K, p->nx, p->nu, p->optimal_decay == 1) > 160 * 1024)
         return fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
     if (!(p->tol > 0) || !(p->acceptable_tol >= p->tol) || p->max_iter < 1 || !(p->mu_init > 0) || !(p->mu_min > 0))
         return fail(SC_ERR_INVALID_ARGUMENT, "tol, mu_init, mu_min must be > 0 and max_iter >= 1");
@@ -225,7 +225,7 @@ static int check_mpclin(const sc_mpclin_params* p, const double* model, int64_t 
     if (B > 0 && (!model || !X || !u_prev || !goal || !obs || !u_out || !status_out))
         return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
-    return p->optimal_decay ? SC_OK : check_resto(p->resto);
+    return p->optimal_decay == 1 ? SC_OK : check_resto(p->resto);
 }
 static int check_mpcgn(const sc_mpcgn_params* p, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,
                        const void* obs, const void* u_out, const void* status_out) {
@@ -452,7 +452,7 @@ int sc_mpclin_solve_batch(const sc_mpclin_params* params, const double* model, i
     int rc = sc::check_mpclin(params, model, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
-    if (params->optimal_decay) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay = 1: call sc_odmpclin_solve_batch");
+    if (params->optimal_decay == 1) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay = 1: call sc_odmpclin_solve_batch");
     hipError_t e = sc::mpclin_launch(*params, model, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out,
                                      z_out, nullptr, (hipStream_t)stream, sc::one_launch(params->max_iter));
     if (e != hipSuccess) return sc::fail_hip(e, "mpclin kernel launch");
@@ -465,7 +465,7 @@ int sc_odmpclin_solve_batch(const sc_mpclin_params* params, const double* model,
     sc::DeviceGuard on_device(stream, X);
     int rc = sc::check_mpclin(params, model, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
-    if (!params->optimal_decay) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay = 0: call sc_mpclin_solve_batch");
+    if (params->optimal_decay != 1) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay != 1: call sc_mpclin_solve_batch");
     if (B == 0) return SC_OK;
     hipError_t e = sc::mpclin_launch(*params, model, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out,
                                      z_out, rho_out, (hipStream_t)stream, sc::one_launch(params->max_iter));
@@ -478,7 +478,7 @@ int sc_mpclin_solve_batch_host(const sc_mpclin_params* params, const double* mod
                                int32_t* iters_out, void* z_out, int device) {
     int rc = sc::check_mpclin(params, model, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
-    if (params->optimal_decay) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay = 1: call sc_odmpclin_solve_batch (device pointers)");
+    if (params->optimal_decay == 1) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay = 1: call sc_odmpclin_solve_batch (device pointers)");
     if (B == 0) return SC_OK;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return sc::fail_hip(e, "hipSetDevice");
@@ -797,7 +797,7 @@ int sc_mpclin_solve_batch_sliced(const sc_mpclin_params* params, const sc_mpc_sl
     sc::DeviceGuard on_device(stream, X);
     int rc = sc::check_mpclin(params, model, B, K, X, u_prev, goal, obs, u_out, status_out);
     if (rc != SC_OK) return rc;
-    if (params->optimal_decay) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay = 1: call sc_odmpclin_solve_batch");
+    if (params->optimal_decay == 1) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay = 1: call sc_odmpclin_solve_batch");
     rc = sc::check_slices(slices, params->max_iter, sc_mpclin_slices_workspace_bytes(params, B, K));
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;

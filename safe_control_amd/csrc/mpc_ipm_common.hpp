@@ -61,23 +61,18 @@ __device__ __forceinline__ void pow3(double x, double e, bool derivs, double& pe
     }
 }
 
-// CHAIN: integer exponents by the multiply chain of pow3, non-integer ones by pow().  History of a miscompile that is NOT root-caused:
-// rounds 1 - 2 wrote the chain as a `while (n)` square-and-multiply loop next to the pow() fallback.  With that form inlined the
-// Quad2D step()-barrier kernel -- which never executes this branch (circles only) -- stopped every solve in its first iteration
-// with garbage barrier values, at -O3 and -O2, with or without FMA contraction (mpc_gn.hip stays on pow() for it), and in round 3
-// an unrelated change of the LDS layout made mpclin_kernel<2, 2, 10, 0> (run-time obstacle count, circles only!) return wrong
-// solves for K = 6 while K = 8 and every other instantiation stayed right.  Writing the chain as SIX STRAIGHT-LINE select steps
-// (below) made mpc_lin.hip right again with the SAME layout -- so it is neither rounding nor an out-of-bounds access of ours --
-// but mpc_gn.hip's circles-only instantiations still break with the straight-line chain inlined (measured, round 3).  What is
-// established: the trigger is inlined code of the NEVER-EXECUTED superellipsoid branch (loop or not) next to the divergent pow()
-// call, in kernels at the edge of their register budget; pow3 noinline and the pow()-only build are right everywhere.  Guards:
-// A third manifestation (late round 3): adding the slack reset of the line search to mpc_gn.hip as a nested conditional on
-// p.slack_reset inside the two row loops made mpcgn_kernel<1, 10, false> -- the HOCBF bicycle, and only it -- stop every solve after
-// ~5 iterations, with the reset switched off as well; with the switch and the threshold hoisted out of the loops it is right.
-// tests/test_pow_chain_gpu.py solves superellipsoid scenes with integer exponents (chain, where a kernel uses it) and with
-// exponents a hair off an integer (pow()) through all three kernels and holds them together; every instantiation that ships is
-// under a parity test against the oracle, and tests/test_tracking_gpu.py::test_single_integrator_closed_loop_with_mpc is the
-// K = 6 case that caught the mpc_lin manifestation.
+// CHAIN: integer exponents by the multiply chain of pow3, non-integer ones by pow().
+// History, now closed.  Rounds 1 - 3 met a "code-generation fragility" four times: the chain inlined made the Quad2D kernel -- which never
+// executes it -- return garbage; an unrelated LDS-layout change broke mpclin_kernel<2, 2, 10, 0> for K = 6 only; a nested conditional
+// made mpcgn_kernel<1, 10, false> stop every solve after five iterations with the feature switched off; the continuation code of round 4
+// broke the same kernel again (and a sibling build broke Quad2D instead).  Round 4 root-caused it ("The code-generation
+// fragility: root cause"; tools/check_exec_prologue.py): after a divergent loop the compiler re-enables the parked lanes with
+// s_or_b64 exec at the top of the join block, and the ROCm 7.2 register allocator places the copies of a VGPR live-range split IN FRONT of
+// that instruction when the block starts with reloads of spilled SGPRs -- the copies run under the narrow mask (or EXEC = 0), so the
+// lanes that sat out the last loop pass lose loop-invariant per-lane values (LDS addresses, a counter) when they are copied back after
+// the Cholesky call.  Which value is hit depends on where the allocator splits: any edit, inlining decision or scheduling change moves
+// it.  The MPC translation units are now compiled with the basic VGPR allocator, which never splits a live range (csrc/Makefile:
+// SAFE_RA), and the objects are scanned for the signature after every build (tests/test_codegen_guard.py).
 template <bool CHAIN = false>
 __device__ inline void ipm_barrier(double px_, double py_, const double* o, double Rrob, double beta, bool circles_only, bool derivs,
                                    double& h, double& d0, double& d1, double& hxx, double& hxy, double& hyy) {

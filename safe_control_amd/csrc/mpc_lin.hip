@@ -135,6 +135,7 @@ __device__ inline LinMem carve_lin(double* b, const LinDims& d, int mode, bool o
 struct LinConst {
     double w0, Rrob, beta;
     int circles_only;
+    int abs_r;                                           // input term R u^2 instead of do-mpc's delta-u penalty (optimal_decay = 2, OD)
     double alpha, ps, rf;                                // optimal decay: gain, penalty p_sb1, reference omega1
 };
 
@@ -172,7 +173,7 @@ __device__ __forceinline__ double lin_eval(const double* zv, const double* rhov,
     }
     for (int i = lane; i < n; i += TH) {
         const double prev = i >= nu ? zv[i - nu] : W.up[i];
-        const double du = OD ? zv[i] : zv[i] - prev;                      // optimal decay: R u^2 (optimal_decay_mpc_cbf.py:178-179)
+        const double du = (OD || c.abs_r) ? zv[i] : zv[i] - prev;         // optimal decay: R u^2 (optimal_decay_mpc_cbf.py:178-179)
         part += W.cq[12 + i % nu] * du * du;
     }
     if constexpr (OD) {
@@ -237,8 +238,9 @@ __device__ __forceinline__ void lin_grad(const LinMem& W, const LinDims& d, cons
     }
     for (int i = lane; i < n; i += TH) {
         const double prev = i >= nu ? W.z[i - nu] : W.up[i];
-        double gr = W.gs[i] + 2.0 * W.cq[12 + i % nu] * (OD ? W.z[i] : W.z[i] - prev);
-        if (!OD && i + nu < n) gr -= 2.0 * W.cq[12 + i % nu] * (W.z[i + nu] - W.z[i]);
+        const bool absr = OD || c.abs_r;
+        double gr = W.gs[i] + 2.0 * W.cq[12 + i % nu] * (absr ? W.z[i] : W.z[i] - prev);
+        if (!absr && i + nu < n) gr -= 2.0 * W.cq[12 + i % nu] * (W.z[i + nu] - W.z[i]);
         W.gs[i] = sf * gr;
     }
     SC_SYNC();
@@ -386,7 +388,7 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
     Red R;
     R.buf = W.red; R.par = 0;
     LinConst c;
-    c.w0 = -(1.0 - p.alpha); c.Rrob = p.robot_radius; c.beta = p.beta; c.circles_only = p.circles_only;
+    c.w0 = -(1.0 - p.alpha); c.Rrob = p.robot_radius; c.beta = p.beta; c.circles_only = p.circles_only; c.abs_r = p.optimal_decay == 2;
     c.alpha = p.alpha; c.ps = p.od_p_sb; c.rf = p.od_omega_ref;
     if (lane < 12) W.cq[lane] = p.Q[lane];
     if (lane < 4) { W.cq[12 + lane] = p.R[lane]; W.cq[16 + lane] = p.u_lo[lane]; W.cq[20 + lane] = p.u_hi[lane]; }
@@ -1027,7 +1029,7 @@ size_t mpclin_state_doubles(int N, int K, int nu) {
 hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long long B, int K, const void* X, const void* u_prev,
                          const void* goal, const void* obs, void* u_out, int* status, int* iters, void* z_out, void* rho_out,
                          hipStream_t stream, const ipm::Cont& ct) {
-    const bool od = p.optimal_decay != 0;
+    const bool od = p.optimal_decay == 1;
     const size_t lds = mpclin_lds_bytes(p.horizon, K, p.nx, p.nu, od);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int mode = mpclin_mode(p.horizon, K, p.nx, p.nu, od);

@@ -68,7 +68,7 @@ def pad_obstacles(obs, num_obs):
 
 
 def make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_shared=False,
-                tol=1e-6, max_iter=100, mu_init=0.1, mu_min=1e-9, acceptable_tol=1e-5, resto=None):
+                tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER, mu_init=0.1, mu_min=1e-9, acceptable_tol=1e-5, resto=None):
     p = _lib.MpcCbfParams()
     p.model_id = _lib.MODEL_IDS[robot_spec["model"]]
     p.io_dtype = io_dtype
@@ -178,7 +178,7 @@ class BatchedMPCCBF(_lib.SlicedSolver):
     """
 
     def __init__(self, robot_spec, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None,
-                 tol=1e-6, max_iter=100, iter_slices=None, classify_first=False, order=True):
+                 tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER, iter_slices=None, classify_first=True, order=True):
         self.init_slices(iter_slices, classify_first, order)
         self.robot_spec = complete_robot_spec(robot_spec)
         model = self.robot_spec["model"]

@@ -39,7 +39,7 @@ def model_constants(robot_spec):
     raise NotImplementedError(m)
 
 
-def make_params(robot_spec, mc, cbf_param, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=100,
+def make_params(robot_spec, mc, cbf_param, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER,
                 mu_init=0.1, mu_min=1e-9, acceptable_tol=1e-5, resto=None):
     p = _lib.MpcGnParams()
     p.model_id = _lib.MODEL_IDS[robot_spec["model"]]
@@ -129,8 +129,8 @@ class BatchedGnMPCCBF(_lib.SlicedSolver):
     """``solve(X[B,nx], u_prev[B,2], goal[B,2], obs[B,K,7] | obs[K,7])`` -> ``u[B,2]``, ``status[B]``, ``iters[B]`` (and
     ``z[B,2N]`` if asked); nx = 4 (DoubleIntegrator2D, KinematicBicycle2D) or 6 (Quad2D)."""
 
-    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=100,
-                 iter_slices=None, classify_first=False, order=True):
+    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER,
+                 iter_slices=None, classify_first=True, order=True):
         self.init_slices(iter_slices, classify_first, order)      # continuation launches (include/safe_control_amd.h: sc_mpc_slices)
         self.robot_spec = complete_robot_spec(robot_spec)
         if self.robot_spec["model"] not in GN_MODELS:

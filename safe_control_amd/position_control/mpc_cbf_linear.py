@@ -14,9 +14,12 @@ from ..robots.spec import complete_robot_spec
 from .mpc_cbf import apply_mpc_overrides, pad_obstacles
 
 
-def make_params(mdl, cbf_param, horizon, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=100, mu_init=0.1,
-                mu_min=1e-9, acceptable_tol=1e-5, resto=None):
+def make_params(mdl, cbf_param, horizon, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER, mu_init=0.1,
+                mu_min=1e-9, acceptable_tol=1e-5, resto=None, input_rterm="du"):
+    """``input_rterm``: "du" = MPCCBF's do-mpc delta-u penalty (mpc_cbf.py:180); "u2" = the R u^2 expression of the reference's
+    OptimalDecayMPCCBF (optimal_decay_mpc_cbf.py:173-179) with the plain row that class gives Quad3D (:284-287): sc_mpclin_params.optimal_decay = 2."""
     p = _lib.MpcLinParams()
+    p.optimal_decay = {"du": 0, "u2": 2}[input_rterm]
     p.io_dtype = io_dtype
     p.nx, p.nu, p.ng = mdl["nx"], mdl["nu"], mdl["ng"]
     p.horizon = int(horizon)
@@ -50,6 +53,7 @@ def build_model_blob(lib, p, mdl):
 
 class LinearMPCCBF:
     """Drop-in for position_control.mpc_cbf.MPCCBF with a SingleIntegrator2D or Quad3D robot (single agent per call)."""
+    input_rterm = "du"
 
     def __init__(self, robot, robot_spec, show_mpc_traj=False, num_obs=5, device=0):
         self.robot = robot
@@ -70,7 +74,7 @@ class LinearMPCCBF:
 
     def setup_control_problem(self):
         self._lib = _lib.load()
-        p = make_params(self._mdl, self.cbf_param, self.horizon, self.robot.robot_radius, _lib.DTYPE_F64)
+        p = make_params(self._mdl, self.cbf_param, self.horizon, self.robot.robot_radius, _lib.DTYPE_F64, input_rterm=self.input_rterm)
         self._blob = build_model_blob(self._lib, p, self._mdl)
         self.u_prev = np.zeros(self.n_controls)
         self.z = np.zeros(self.n_controls * self.horizon)
@@ -93,7 +97,7 @@ class LinearMPCCBF:
         gs = np.asarray(self.goal, dtype=np.float64).reshape(-1)[:ng]
         g[: gs.shape[0]] = gs
         obs = np.ascontiguousarray(self.obs, dtype=np.float64)
-        p = make_params(self._mdl, self.cbf_param, self.horizon, self.robot.robot_radius, _lib.DTYPE_F64)
+        p = make_params(self._mdl, self.cbf_param, self.horizon, self.robot.robot_radius, _lib.DTYPE_F64, input_rterm=self.input_rterm)
         u = np.zeros(nu); st = np.zeros(1, dtype=np.int32); it = np.zeros(1, dtype=np.int32)
         rc = self._lib.sc_mpclin_solve_batch_host(
             C.byref(p), self._blob.ctypes.data, 1, self.num_obs, X.ctypes.data, self.u_prev.ctypes.data, g.ctypes.data,
@@ -105,14 +109,37 @@ class LinearMPCCBF:
         return u.reshape(-1, 1).copy()
 
 
+class OptimalDecayLinearMPCCBF(LinearMPCCBF):
+    """``OptimalDecayMPCCBF(robot, {'model': 'Quad3D'})`` of the reference (optimal_decay_mpc_cbf.py:19 accepts the model): its
+    compute_cbf_constraint gives Quad3D the PLAIN row d_h + alpha h_k (:284-287) -- the decay inputs omega1, omega2 are part of the
+    model (:123-124) but touch no row, and their penalty p_sb (omega - 1)^2 keeps them at 1 -- with that class's weights (:41-43: the
+    same Q, R as MPCCBF), gain 0.15 (:78-82), bounds u_min .. u_max (:211-215) and its input term R u^2 (:173-179).  Extension label as
+    for every optimal-decay class: the reference copy is stale (five 5-wide obstacle slots), parity is against oracle/mpc_lin.py
+    (rterm = "u2").  ``omega1`` / ``omega2`` report the inert decay inputs."""
+    input_rterm = "u2"
+
+    def __init__(self, robot, robot_spec, num_obs=5, device=0):
+        super().__init__(robot, robot_spec, show_mpc_traj=False, num_obs=num_obs, device=device)
+        self.cbf_param.update({"omega1": 1.0, "p_sb1": 10.0, "omega2": 1.0, "p_sb2": 10.0})     # :88-91
+        self.omega1 = None
+        self.omega2 = None
+
+    def solve_control_problem(self, robot_state, control_ref, nearest_obs):
+        u = super().solve_control_problem(robot_state, control_ref, nearest_obs)
+        if control_ref["state_machine"] == "track":
+            self.omega1, self.omega2 = float(self.cbf_param["omega1"]), float(self.cbf_param["omega2"])
+        return u
+
+
 class BatchedLinearMPCCBF(_lib.SlicedSolver):
     """``solve(X[B,nx], u_prev[B,nu], goal[B,ng], obs[B,K,7] | obs[K,7])`` -> ``u[B,nu]``, ``status[B]``, ``iters[B]``
     (and ``z[B, nu*N]`` if asked) for SingleIntegrator2D (nx 2, nu 2, ng 2) or Quad3D (nx 12, nu 4, ng 3).
     ``iter_slices`` / ``classify_first`` / ``order``: continuation launches (include/safe_control_amd.h: sc_mpc_slices)."""
 
-    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=100,
-                 iter_slices=None, classify_first=False, order=True):
+    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER,
+                 iter_slices=None, classify_first=True, order=True, input_rterm="du"):
         self.init_slices(iter_slices, classify_first, order)
+        self.input_rterm = input_rterm                        # "u2": OptimalDecayMPCCBF's semantics for Quad3D (make_params)
         self.robot_spec = complete_robot_spec(robot_spec)
         if self.robot_spec["model"] not in LINEAR_MODELS:
             raise NotImplementedError(f"linear-model MPC-CBF supports {LINEAR_MODELS}")
@@ -124,7 +151,7 @@ class BatchedLinearMPCCBF(_lib.SlicedSolver):
         self.cbf_param = cbf_param or apply_mpc_overrides(dict(self._mdl["cbf_param"]), self.robot_spec)
         self.tol, self.max_iter = tol, max_iter
         self._lib = _lib.load()
-        p = make_params(self._mdl, self.cbf_param, self.horizon, self.robot_spec["radius"], self.io_dtype)
+        p = make_params(self._mdl, self.cbf_param, self.horizon, self.robot_spec["radius"], self.io_dtype, input_rterm=self.input_rterm)
         self._blob_host = build_model_blob(self._lib, p, self._mdl)
         self._blob_dev = {}
 
@@ -158,7 +185,8 @@ class BatchedLinearMPCCBF(_lib.SlicedSolver):
         iters = torch.empty((B,), dtype=torch.int32, device=X.device)
         z = torch.empty((B, nu * self.horizon), dtype=dt_, device=X.device) if want_z else None
         p = make_params(self._mdl, self.cbf_param, self.horizon, self.robot_spec["radius"], self.io_dtype,
-                        obs_shared=shared, tol=self.tol, max_iter=self.max_iter, resto=getattr(self, "resto", None))
+                        obs_shared=shared, tol=self.tol, max_iter=self.max_iter, resto=getattr(self, "resto", None),
+                        input_rterm=self.input_rterm)
         stream = torch.cuda.current_stream(X.device).cuda_stream
         sl = self.slices_for(lambda: self._lib.sc_mpclin_slices_workspace_bytes(C.byref(p), B, K), X.device)
         args = (self._blob(X.device).data_ptr(), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(),
@@ -179,7 +207,7 @@ class BatchedOptimalDecayLinearMPCCBF(BatchedLinearMPCCBF):
     MPCCBF's for the model.  oracle/od_mpc_rd1.py states the problem and the method.
     ``solve(...)`` -> ``u[B,4]``, ``rho[B,N]``, ``status[B]``, ``iters[B]`` (and ``z[B,4N]`` if asked)."""
 
-    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=100,
+    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER,
                  superellipsoids=True):
         spec = complete_robot_spec(robot_spec)
         if spec["model"] != "Quad3D":

@@ -19,7 +19,7 @@ CBF_VTOL = {"alpha1": 0.05, "alpha2": 0.05}                    # mpc_cbf.py:83-8
 HORIZON_VTOL = 30
 
 
-def make_params(robot_spec, cbf_param, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=100, mu_init=0.1,
+def make_params(robot_spec, cbf_param, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER, mu_init=0.1,
                 mu_min=1e-9, acceptable_tol=1e-5, resto=None, slack_reset=2, kernel=0):
     p = _lib.MpcVtolParams()
     p.io_dtype, p.horizon, p.max_iter, p.obs_shared, p.acceptable_iter = io_dtype, int(horizon), int(max_iter), 1 if obs_shared else 0, 15
@@ -101,8 +101,8 @@ class BatchedVtolMPCCBF(_lib.SlicedSolver):
     (sc_mpcvtol_workspace_bytes: about 0.1 MB per problem) are kept between calls.  ``iter_slices`` / ``classify_first`` / ``order``:
     continuation launches of the wave kernel (include/safe_control_amd.h: sc_mpc_slices)."""
 
-    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f64", cbf_param=None, tol=1e-6, max_iter=100,
-                 iter_slices=None, classify_first=False, order=True):
+    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f64", cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER,
+                 iter_slices=None, classify_first=True, order=True):
         self.init_slices(iter_slices, classify_first, order)
         self.robot_spec = complete_robot_spec(dict(robot_spec or {"model": "VTOL2D"}))
         if self.robot_spec["model"] != "VTOL2D":
@@ -145,7 +145,8 @@ class BatchedVtolMPCCBF(_lib.SlicedSolver):
         if self._ws is None or self._ws.numel() < need or self._ws.device != X.device:
             self._ws = torch.empty((max(need, 8),), dtype=torch.uint8, device=X.device)
         stream = torch.cuda.current_stream(X.device).cuda_stream
-        sl = self.slices_for(lambda: self._lib.sc_mpcvtol_slices_workspace_bytes(C.byref(p), B, K), X.device)
+        # (continuation launches are the wave kernel's; the one-NLP-per-lane cross-check kernel runs one launch)
+        sl = None if self.kernel == 1 else self.slices_for(lambda: self._lib.sc_mpcvtol_slices_workspace_bytes(C.byref(p), B, K), X.device)
         args = (B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(),
                 status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None)
         if sl is None:

@@ -34,7 +34,7 @@ def default_od_mpc_param(model, extension=False):
 
 
 def make_od_mpc_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6,
-                       max_iter=100):
+                       max_iter=_lib.IPOPT_MAX_ITER):
     p = _lib.OdMpcCbfParams()
     p.mpc = make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_shared=obs_shared, tol=tol,
                         max_iter=max_iter)
@@ -54,6 +54,9 @@ class OptimalDecayMPCCBF:
         if cls is OptimalDecayMPCCBF and robot_spec.get("model") in ("KinematicBicycle2D", "Quad2D"):
             from .optimal_decay_mpc_cbf_gn import OptimalDecayGnMPCCBF
             return OptimalDecayGnMPCCBF(robot, robot_spec, *args, **kwargs)
+        if cls is OptimalDecayMPCCBF and robot_spec.get("model") == "Quad3D":        # the plain row with R u^2 (:284-287)
+            from .mpc_cbf_linear import OptimalDecayLinearMPCCBF
+            return OptimalDecayLinearMPCCBF(robot, robot_spec, *args, **kwargs)
         return super().__new__(cls)
 
     def __init__(self, robot, robot_spec, num_obs=5, device=0):
@@ -118,7 +121,7 @@ class BatchedOptimalDecayMPCCBF:
     reference) -- BASELINE config 5, no reference counterpart.
     """
 
-    def __init__(self, robot_spec, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None, tol=1e-6, max_iter=100,
+    def __init__(self, robot_spec, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER,
                  extension=False):
         self.robot_spec = complete_robot_spec(robot_spec)
         model = self.robot_spec["model"]

@@ -30,7 +30,7 @@ def od_model_constants(robot_spec):
     return mc
 
 
-def make_od_params(robot_spec, mc, cbf_param, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=100):
+def make_od_params(robot_spec, mc, cbf_param, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER):
     p = _lib.OdMpcGnParams()
     p.mpc = make_params(robot_spec, mc, cbf_param, horizon, dt, radius, io_dtype, obs_shared=obs_shared, tol=tol, max_iter=max_iter)
     p.omega_ref[0], p.omega_ref[1] = float(cbf_param.get("omega1", 1.0)), float(cbf_param.get("omega2", 1.0))
@@ -42,7 +42,7 @@ class BatchedOptimalDecayGnMPCCBF:
     """``solve(X[B,nx], u_prev[B,2], goal[B,2], obs[B,K,7] | obs[K,7])`` -> ``u[B,2]``, ``rho[B,2N]`` (omega1_k, omega2_k per
     stage), ``status[B]``, ``iters[B]`` (and ``z[B,2N]`` if asked); nx = 4 (KinematicBicycle2D) or 6 (Quad2D)."""
 
-    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=100):
+    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER):
         self.robot_spec = complete_robot_spec(robot_spec)
         if self.robot_spec["model"] not in OD_GN_MODELS:
             raise NotImplementedError(f"this controller serves {OD_GN_MODELS}")

@@ -114,3 +114,29 @@ def _with_ws(ctl, _lib):
     sl = _lib.make_slices([10])
     sl.workspace, sl.workspace_bytes = ctl._slice_ws.data_ptr(), ctl._slice_ws.numel()
     return sl
+
+
+def test_solves_the_old_iteration_cap_cut_off():
+    """Round 3 stopped every solve at 100 iterations and handed control_step the iterate it had: VTOL2D bench draw 549 is feasible and
+    converges at iteration 126 (the 100-iteration input was off by 0.55), KinematicBicycle2D draw 1746 needs 145 and draw 847 is
+    certified infeasible at 140.  With the reference solver's budget behind the first cap they end with a final status, the one the
+    oracle gives, at the oracle's iteration count."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from _oracle_pool import family_problem
+    from oracle import mpc_cbf as M
+    for fam, draw in (("vtol", 549), ("kb", 1746), ("kb", 847)):
+        X, up, goal, obs = W.mpc_family_batch(fam, 4096, 8, seed=0)
+        sel = slice(draw, draw + 1)
+        arrs = [torch.tensor(np.ascontiguousarray(a[sel]), dtype=torch.float64, device=DEV) for a in (X, up, goal, obs)]
+        u100, st100, it100, _ = solve(make(fam, max_iter=100, iter_slices=()), arrs)
+        u, st, it, z = solve(make(fam), arrs)                            # defaults: 3000 behind a cap of 100
+        assert it100[0] == 100 and st100[0] == 2 and it[0] > 100
+        P, ev = family_problem(fam, 10, {})
+        uo, so, ito, info = M.solve(X[draw], up[draw], goal[draw], obs[draw], params=P, return_info=True, evaluate_fn=ev)
+        # (the long crawls part from the oracle by a few iterations: 145 / 142 and 140 / 143 on the two bicycles)
+        assert so in (0, 1) and st[0] == so and abs(int(it[0]) - ito) <= 5 and ito > 100
+        if so == 0:
+            assert np.abs(u[0] - uo).max() <= 1e-5
+            assert np.abs(u[0] - u100[0]).max() > 1e-3                    # what the cap used to return was not the solution

