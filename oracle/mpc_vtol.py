@@ -2,9 +2,9 @@
 
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  The model functions are pinned on the reference's own code
 (tests/golden/mpc_functions.npz: f, g, x_next, step, agent_barrier_dt, MPCCBF tables for VTOL2D); the solver is this repo's
-interior point (parity unpinned: IPOPT absent).  **No HIP kernel serves this model** (DESIGN.md (f) item 1): the first NLP of the
-reference's own example (examples/test_vtol.py) has no feasible point (tests/test_oracle_mpc_vtol.py), so what the reference applies
-there is IPOPT's restoration output; this module is the pinned problem statement.
+interior point (parity unpinned: IPOPT absent).  The kernel that serves the model is csrc/mpc_vtol_wave.hip (DESIGN.md kernel 11), held to
+this module problem by problem.  The first NLP of the reference's own example (examples/test_vtol.py) has no feasible point
+(tests/test_oracle_mpc_vtol.py), so what the reference applies there is IPOPT's restoration output.
 
   dynamics    f, g of robots/vtol2D.py:118-311 (body velocity :333-343, lift blending :348-372, lift / drag / moment :374-401,
               wind -> inertial :410-419, rotors :424-452); prediction x+ = x + (f + g u) dt (mpc_cbf.py:135-141); step() adds the

@@ -53,7 +53,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 python3 $R/tools/prof_backup.py 4096 3 --prepare > /dev/null 2>&1     # the fleet (closed-loop rollouts) outside the profiled process
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o backup_sq -- python3 $R/tools/prof_backup.py 4096 3 > /dev/null 2>&1
 # 11. VTOL2D MPC-CBF kernel (one NLP per wavefront): kernel trace, instruction mix, LDS conflicts
-export LANES=16
+
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o vtol -- python3 $R/tools/time_mpcvtol.py 4096 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o vtol_sq -- python3 $R/tools/time_mpcvtol.py 4096 > /dev/null 2>&1
 # 10. sustained VALU issue peak of the part (the denominator of the valu_issue rooflines)
