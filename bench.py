@@ -56,6 +56,9 @@ def parse():
                     help="hetero_fleet: plain MPCCBF of both models on circular obstacles (round 1's variant)")
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--no-mpc", action="store_true", help="skip the short MPC-CBF leg of the default run")
+    ap.add_argument("--no-limit100", action="store_true",
+                    help="interior-point legs: skip the extra timing of the round-3 configuration (one launch, 100 iterations); the counter "
+                         "passes of tools/collect_profiles.sh use it so that every dispatch of a leg belongs to a budget solve")
     return ap.parse_args()
 
 
@@ -97,6 +100,8 @@ def cpu_baseline(X, u_ref, obs, seconds):
             "all_cores_threads": out["all_cores"][1]}
 
 
+NO_LIMIT100 = False            # --no-limit100
+LAUNCHES_PER_BUDGET_SOLVE = 3  # classify + cap 100 + rest: the counter profile holds per-dispatch averages of a kernel
 VALU_PEAK_GIPS = 519.0   # measured sustained f64 VALU issue rate of the chip, G wave-instructions/s (tools/micro/valu_peak.hip,
                          # profiles/r02_valu_peak.txt: 0.507 G/s per SIMD at four waves per SIMD; 1024 SIMDs x 2.4 GHz / 4 = 614 on paper)
 
@@ -114,7 +119,7 @@ def csrc_sha16():
 F64_VECTOR_PEAK_TFLOPS = 78.6                                   # MI355X data sheet, vector f64 (MI355X_MICROARCH.md)
 
 
-def valu_roofline(run, kernel_substr, kernel_ms, note=None):
+def valu_roofline(run, kernel_substr, kernel_ms, note=None, launches=1):
     """VALU-issue roofline of an interior-point kernel: VALU wave-instructions per launch -- the SQ_INSTS_VALU counter of
     the same launch configuration, collected with rocprofv3 --pmc and committed under profiles/ (the count is a property
     of the batch: same seed, same iterates) -- over this run's measured launch time, against the measured issue peak.
@@ -135,7 +140,7 @@ def valu_roofline(run, kernel_substr, kernel_ms, note=None):
         for k, c in d.items():
             name = k.replace("void sc::", "")
             if (name == kernel_substr or kernel_substr in k) and "SQ_INSTS_VALU" in c:
-                insts = c["SQ_INSTS_VALU"]
+                insts = c["SQ_INSTS_VALU"] * launches                   # per-dispatch average x dispatches of one solve
                 ach = insts / (kernel_ms * 1e-3) / 1e9
                 out = {"bound": "valu_issue", "achieved": ach, "peak": VALU_PEAK_GIPS, "unit": "G wave-instr/s", "frac": ach / VALU_PEAK_GIPS,
                        "traffic": None, "kernel": name, "kernel_us": 1e3 * kernel_ms,
@@ -151,7 +156,7 @@ def valu_roofline(run, kernel_substr, kernel_ms, note=None):
                     out["lane_utilisation"] = lane["SQ_THREAD_CYCLES_VALU"] / (64.0 * lane["SQ_ACTIVE_INST_VALU"])
                 if flop and "lane_utilisation" in out:
                     vec = 2.0 * flop.get("SQ_INSTS_VALU_FMA_F64", 0.0) + flop.get("SQ_INSTS_VALU_ADD_F64", 0.0) + flop.get("SQ_INSTS_VALU_MUL_F64", 0.0)
-                    fl = 64.0 * out["lane_utilisation"] * vec + 512.0 * flop.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
+                    fl = launches * (64.0 * out["lane_utilisation"] * vec + 512.0 * flop.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0))
                     out["f64_flops_per_launch"] = fl
                     out["f64_tflops"] = fl / (kernel_ms * 1e-3) / 1e12
                     out["f64_vector_peak_frac"] = out["f64_tflops"] / F64_VECTOR_PEAK_TFLOPS
@@ -161,10 +166,11 @@ def valu_roofline(run, kernel_substr, kernel_ms, note=None):
     return None
 
 
-def with_roofline(res, kernel_substr):
+def with_roofline(res, kernel_substr, launches=LAUNCHES_PER_BUDGET_SOLVE):
     """Attach the VALU-issue roofline of an interior-point leg when the committed counter profile holds the kernel
-    (profiles/r02_counters.json: run bench_full_sq = the default bench command under rocprofv3 --pmc, same batches)."""
-    r = valu_roofline("bench_full_sq", kernel_substr, res["kernel_ms"])
+    (profiles/r04_counters.json: run bench_full_sq = the default bench command with --no-limit100 under rocprofv3 --pmc, same
+    batches; a budget solve is `launches` dispatches of the kernel)."""
+    r = valu_roofline("bench_full_sq", kernel_substr, res["kernel_ms"], launches=launches)
     if r is not None:
         res["roofline"] = r
     return res
@@ -175,6 +181,10 @@ def budget_note(make_ctl, args, steps, ms_full, st_full, it_full):
     (first cap 100, classify-only pre-pass).  Beside that figure: the same batch with the round-3 limit of 100 iterations in one launch,
     and how many problems needed more."""
     import torch
+    base = {"budget": 3000, "launches": "classify + cap 100 + rest", "max_ipm_iterations": int(it_full.max().item()),
+            "inaccurate_fraction": float((st_full == 2).double().mean().item()), "beyond_100_iterations": int((it_full > 100).sum().item())}
+    if NO_LIMIT100:
+        return base
     ctl = make_ctl(max_iter=100, iter_slices=(), classify_first=False)
     out = ctl.solve(*args)
     torch.cuda.synchronize()
@@ -185,11 +195,8 @@ def budget_note(make_ctl, args, steps, ms_full, st_full, it_full):
     e1.record()
     torch.cuda.synchronize()
     st = out[1]
-    return {"budget": 3000, "launches": "classify + cap 100 + rest", "max_ipm_iterations": int(it_full.max().item()),
-            "inaccurate_fraction": float((st_full == 2).double().mean().item()),
-            "one_launch_limit_100": {"kernel_ms": e0.elapsed_time(e1) / steps, "optimal_fraction": float((st == 0).double().mean().item()),
-                                     "inaccurate_fraction": float((st == 2).double().mean().item())},
-            "beyond_100_iterations": int((it_full > 100).sum().item())}
+    return {**base, "one_launch_limit_100": {"kernel_ms": e0.elapsed_time(e1) / steps, "optimal_fraction": float((st == 0).double().mean().item()),
+                                             "inaccurate_fraction": float((st == 2).double().mean().item())}}
 
 
 def mpc_cpu_baseline(Xn, goal, on, N, seconds):
@@ -237,7 +244,7 @@ def mpc_leg(dev, B, K, N, steps, warmup, seed=0, cpu_seconds=0.0):
     extra = {"cpu_baseline": mpc_cpu_baseline(Xn, goal, on, N, cpu_seconds)} if cpu_seconds > 0 else {}
     extra.update(budget_note(mk, (X, up, g, ob), steps, ms, st, it))
     if (B, K, N, seed) == (4096, 8, 10, 0):
-        rl = valu_roofline("mpc_sq", "mpccbf_kernel<10, 8>", ms, note="4096 problems = two rounds of 2048 resident waves; the launch ends with its "
+        rl = valu_roofline("mpc_sq", "mpccbf_kernel<10, 8>", ms, launches=LAUNCHES_PER_BUDGET_SOLVE, note="4096 problems = two rounds of 2048 resident waves; the launch ends with its "
                            "slowest problem (74 interior-point iterations against a mean of 19: the 40 longest solves ALONE take 1.77 ms, "
                            "tools/exp_tail.py)")
         if rl:
@@ -343,7 +350,7 @@ def od_mpc_leg(dev, B=4096, K=8, N=10, steps=2, seed=0):
             "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
             "optimal_fraction": float((st == 0).double().mean().item()),
             "mean_ipm_iterations": float(it.double().mean().item()),
-            "max_decay_deviation": float((rho - 1.0).abs().max().item())}, f"odmpccbf_kernel<{N}>")
+            "max_decay_deviation": float((rho - 1.0).abs().max().item())}, f"odmpccbf_kernel<{N}>", launches=1)
 
 
 def manip_leg(dev, B=4096, K=3, steps=20, seed=0):
@@ -503,6 +510,66 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
             "mean_ipm_iterations": float(it.double().mean().item())}, f"mpcgn_kernel<{mid}, {N if N == 10 else 0}, false>")
 
 
+def bicycle_loop_leg(dev, model, B=4096, T=160, every=10, steps=3, seed=0):
+    """MPC-CBF of the collision-cone bicycles on states OF THEIR CLOSED LOOP (round 3 timed batches drawn uniformly, half of them inside
+    collision cones: half the "solves" were restorations).  The fleet flies dynamic_env/main.py's scene (:241-268: start (1, 7.5),
+    heading 0, 1 m/s; goal (20, 7.5); eight discs of radius 0.5 moving at (-0.5, +-0.5) m/s, stepped like step_dyn_obs, :54-58) with
+    start positions, headings and speeds spread a little; agent i is sampled after `every` * (i mod 16) control steps, so the timed batch
+    covers the whole approach.  Reported: the batch rate and the rate of the problems that end optimal."""
+    import numpy as np
+    import torch
+    import safe_control_amd as sca
+    rng = np.random.default_rng(seed)
+    dt = 0.05
+    table = np.array([[8.0, 9.0], [10.0, 4.0], [12.0, 5.0], [14.0, 9.0], [16.0, 6.0], [18.0, 14.0], [20.0, 4.0], [22.0, 12.0]])
+    obs = np.zeros((8, 7)); obs[:, :2] = table; obs[:, 2] = 0.5
+    obs[:, 3] = -0.5; obs[:, 4] = np.where(np.arange(8) % 2 == 0, 0.5, -0.5)
+    X0 = np.column_stack([1.0 + rng.uniform(-0.5, 0.5, B), 7.5 + rng.uniform(-1.5, 1.5, B), rng.uniform(-0.3, 0.3, B), 1.0 + rng.uniform(0.0, 1.0, B)])
+    spec = {"model": model, "a_max": 5.0, "radius": 0.3, "num_constraints": 8}
+    ctl = sca.BatchedTrackingController(X0, spec, controller_type={"pos": "mpc_cbf"}, obs=obs, io_dtype="f32", device=str(dev))
+    ctl.mpc.max_iter, ctl.mpc.iter_slices, ctl.mpc.classify_first = 100, (), False      # preparing the fleet: the round-3 limit is enough
+    ctl.set_waypoints(np.array([[1.0, 7.5], [20.0, 7.5]]))
+    G = 16
+    grp = torch.arange(B, device=dev) % G
+    Xs = torch.zeros((B, 4), dtype=torch.float32, device=dev); Us = torch.zeros((B, 2), dtype=torch.float32, device=dev)
+    Os = torch.zeros((B, 8, 7), dtype=torch.float32, device=dev); live = torch.zeros(B, dtype=torch.bool, device=dev)
+    for step in range(min(T, every * (G - 1)) + 1):
+        if step % every == 0:
+            m = grp == step // every
+            Xs[m] = ctl.X[m]; Us[m] = ctl.u_prev[m]; live[m] = ctl.ret[m] == 0
+            Os[m] = torch.tensor(obs, dtype=torch.float32, device=dev)
+        ctl.set_obstacles(obs)
+        ctl.control_step(1)
+        obs[:, 0] += obs[:, 3] * dt; obs[:, 1] += obs[:, 4] * dt
+    X, up, ob = Xs[live].contiguous(), Us[live].contiguous(), Os[live].contiguous()
+    Bn = int(X.shape[0])
+    g = torch.tensor([[20.0, 7.5]], dtype=torch.float32, device=dev).repeat(Bn, 1).contiguous()
+    mk = lambda **kw: sca.BatchedGnMPCCBF({"model": model, "a_max": 5.0, "radius": 0.3}, io_dtype="f32", horizon=10, **kw)   # noqa: E731
+
+    def timed(c, args):
+        out = c.solve(*args)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            out = c.solve(*args)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps, out[1], out[2]
+    ms, st, it = timed(mk(), (X, up, g, ob))
+    res = {**budget_note(mk, (X, up, g, ob), steps, ms, st, it),
+           "workload": f"{Bn} {model} agents on states of the dynamic_env closed loop (0 - {every * (G - 1)} control steps in, eight moving discs), MPC-CBF N=10",
+           "value": Bn / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32", "agents": Bn,
+           "optimal_fraction": float((st == 0).double().mean().item()), "infeasible_fraction": float((st == 1).double().mean().item()),
+           "mean_ipm_iterations": float(it.double().mean().item())}
+    opt = st == 0
+    if int(opt.sum()) >= 64:
+        ms_o, _, _ = timed(mk(), (X[opt].contiguous(), up[opt].contiguous(), g[opt].contiguous(), ob[opt].contiguous()))
+        res["optimal_only_value"] = int(opt.sum()) / (ms_o * 1e-3)
+        res["optimal_only_kernel_ms"] = ms_o
+    return res
+
+
 def vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
     """MPC-CBF for VTOL2D (csrc/mpc_vtol_wave.hip): N = 30, 4 inputs, one NLP per wavefront, one stage per lane, stage-wise
     Riccati Newton steps, rows in registers, everything else in LDS (no workspace)."""
@@ -643,17 +710,17 @@ def compact_leg(v):
         return [compact_leg(x) for x in v]
     if not isinstance(v, dict):
         return v
+    sig = lambda x: float(f"{x:.5g}") if isinstance(x, float) else x     # noqa: E731
     keep = {}
-    for k in ("value", "unit", "kernel_ms", "ms_per_control_step", "us_per_step", "agent_steps_per_s", "solves_per_s", "optimal_fraction",
-              "infeasible_fraction", "mean_ipm_iterations", "max_ipm_iterations", "agents", "GBs", "frac_of_peak", "error", "launches",
-              "optimal_only_value", "budget", "inaccurate_fraction", "beyond_100_iterations"):
+    for k in ("value", "kernel_ms", "ms_per_control_step", "us_per_step", "agent_steps_per_s", "solves_per_s", "optimal_fraction",
+              "max_ipm_iterations", "agents", "GBs", "frac_of_peak", "error", "optimal_only_value", "beyond_100_iterations"):
         if k in v:
-            keep[k] = round(v[k], 6) if isinstance(v[k], float) else v[k]
+            keep[k] = sig(v[k])
     if isinstance(v.get("one_launch_limit_100"), dict):
-        keep["limit_100_ms"] = round(v["one_launch_limit_100"]["kernel_ms"], 4)
+        keep["limit_100_ms"] = sig(v["one_launch_limit_100"]["kernel_ms"])
     rl = v.get("roofline")
     if isinstance(rl, dict):
-        keep["roofline"] = {k: (round(rl[k], 5) if isinstance(rl[k], float) else rl[k]) for k in ("bound", "frac", "stale") if k in rl}
+        keep["roofline"] = {k: sig(rl[k]) for k in ("bound", "frac", "stale") if k in rl}
     return keep
 
 
@@ -710,6 +777,8 @@ def emit(d, ws):
 
 def main():
     a = parse()
+    global NO_LIMIT100
+    NO_LIMIT100 = bool(a.no_limit100)
     rc = self_launch(a)
     if rc is not None:
         sys.exit(rc)
@@ -885,6 +954,12 @@ def main():
             res["quad2d_mpc_cbf"] = gn_mpc_leg(dev, "Quad2D")
             res["kinematic_bicycle_mpc_cbf"] = gn_mpc_leg(dev, "KinematicBicycle2D")
             res["kinematic_bicycle_c3bf_mpc_cbf"] = gn_mpc_leg(dev, "KinematicBicycle2D_C3BF")
+            try:
+                if not NO_LIMIT100:                              # (a counter pass keeps one batch per kernel name)
+                    res["c3bf_closed_loop_states_mpc"] = bicycle_loop_leg(dev, "KinematicBicycle2D_C3BF")
+                    res["dpcbf_closed_loop_states_mpc"] = bicycle_loop_leg(dev, "KinematicBicycle2D_DPCBF")
+            except Exception as e:                               # an extra leg never takes the line down
+                res["c3bf_closed_loop_states_mpc"] = {"error": repr(e)[:200]}
             res["vtol_mpc_cbf"] = vtol_mpc_leg(dev)
             res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
             res["backup_cbf_qp"] = backup_cbf_leg(dev)

@@ -411,6 +411,10 @@ int sc_mpcvtol_solve_batch_host(const sc_mpcvtol_params* params, int64_t B, int3
  * (0.01 for DU, :59-60); `mpc.R` the weights of u^2.  The reference copy is stale (5-wide obstacle rows, 5 fixed
  * slots): here obstacles are the K 7-wide rows of sc_mpccbf_solve_batch.  No runnable reference exists; parity is
  * against oracle/od_mpc_cbf.py.
+ * A reading the build cannot settle: the reference calls mpc.set_rterm(R u^2) and then mpc.set_rterm(p_sb terms) (:177-178).  If do-mpc's
+ * set_rterm(expression) ASSIGNS the r-term (do-mpc is not installed here; its documentation suggests it does), the second call replaces the
+ * first and the reference's objective has no R u^2 at all.  The kernels implement the sum of both, which is what the code says it means;
+ * `mpc.R = {0, 0}` gives the other reading with no other change (the Python classes pass their public attribute R: set ctl.R to zeros).
  * Outputs as sc_mpccbf_solve_batch plus rho_out [B, 2*horizon] or NULL: (omega1_k, omega2_k) for every stage.
  */
 typedef struct sc_odmpccbf_params {

@@ -263,10 +263,12 @@ class BatchedTrackingController:
             obs_in = obs_sel[:, :5].contiguous() if (self.pos_controller_type == "optimal_decay_mpc_cbf" and K > 5) else obs_sel
             out = self.mpc.solve(Xm, self.u_prev, goal2, obs_in)
             u_mpc, st = (out[0], out[2]) if self.pos_controller_type == "optimal_decay_mpc_cbf" else (out[0], out[1])
+            its = out[3] if self.pos_controller_type == "optimal_decay_mpc_cbf" else out[2]
             tr = (track != 0).unsqueeze(1)
             u = torch.where(tr, u_mpc, u_ref).contiguous()
             self.u_prev = torch.where(tr, u_mpc, self.u_prev).contiguous()
-            self.mpc_status = torch.where(track != 0, st, self.mpc_status)
+            self.mpc_status = torch.where(track != 0, st, self.mpc_status)      # (see BatchedQuadTrackingController: status / iterations of the last solve)
+            self.mpc_iters = torch.where(track != 0, its, getattr(self, "mpc_iters", torch.zeros_like(its)))
             rc = self._lib.sc_tracking_apply_batch(
                 C.byref(p), B, M, self.steps_done + k, self.X.data_ptr(), self.state_machine.data_ptr(), self.goal.data_ptr(), obs_ptr,
                 u.data_ptr(), None, self.u_pos.data_ptr(), self.ret.data_ptr(), self.ret_step.data_ptr(), stream)
@@ -479,7 +481,10 @@ class BatchedQuadTrackingController(BatchedTrackingController):
             tr = (track != 0).unsqueeze(1)
             u = torch.where(tr, u_mpc, u_ref).contiguous()                       # mpc_cbf.py:379-381: u_ref passes through outside 'track'
             self.u_prev = torch.where(tr, u_mpc, self.u_prev).contiguous()
+            # per-agent status / iteration count of the last MPC solve: the reference's `status` stays 'optimal' whatever IPOPT returned
+            # (mpc_cbf.py:10); a caller that wants to know about unconverged steps reads these (SC_STATUS_*)
             self.mpc_status = torch.where(track != 0, st, self.mpc_status)
+            self.mpc_iters = torch.where(track != 0, out[2], getattr(self, "mpc_iters", torch.zeros_like(out[2])))
             rc = self._lib.sc_quadtrack_apply_batch(
                 C.byref(p), B, M, self.steps_done + k, self.X.data_ptr(), self.state_machine.data_ptr(), self.goal.data_ptr(), obs_ptr,
                 u.data_ptr(), self.u_pos.data_ptr(), self.ret.data_ptr(), self.ret_step.data_ptr(), stream)

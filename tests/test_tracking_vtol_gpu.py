@@ -104,3 +104,55 @@ def test_cone_fallback_ground_and_batch():
         one.set_waypoints(WPS)
         one.control_step(6)
         assert torch.equal(one.X[0], big.X[i]) and int(one.ret[0]) == int(big.ret[i])
+
+
+def test_twenty_steps_with_the_numpy_oracle_as_position_controller():
+    """A stretch of the flight on which every solve converges (the climb after the first obstacle: control steps 40 .. 59, 25 - 60
+    iterations each): the device loop and the oracle loop -- oracle/mpc_vtol.py solving, nothing handed over after the common
+    start -- fly twenty control steps apart from each other and end in the same state.  (The steps before it are not comparable:
+    a third of the solves of this flight end `optimal_inaccurate`, and two solvers that stop unconverged stop at different
+    points.)"""
+    ctl = sca.BatchedTrackingController(X0[None, :], dict(SPEC), obs=OBS, device=DEV)
+    ctl.set_waypoints(WPS)
+    ctl.control_step(40)
+    assert int(ctl.ret[0].item()) == 0
+    o = QuadTrackingOracle("VTOL2D", X0, spec=dict(reached_threshold=3.0), obs=OBS, num_constraints=4)
+    o.set_waypoints(WPS)
+    o.X = ctl.X[0].cpu().numpy().copy()
+    o.u_prev = ctl.u_prev[0].cpu().numpy().copy()
+    o.current_goal_index = int(ctl.current_goal_index[0].item())
+    worst = 0.0
+    for k in range(20):
+        assert int(ctl.control_step(1)[0].item()) == o.control_step() == 0, k
+        assert int(ctl.mpc_status[0].item()) == 0, k                       # every solve of this stretch converges
+        worst = max(worst, float(np.abs(ctl.X[0].cpu().numpy() - o.X).max()))
+        assert np.abs(ctl.u_pos[0].cpu().numpy() - o.u_pos).max() <= 1e-5, k
+    assert worst <= 1e-5, worst
+
+
+def test_reference_example_scene_flown_with_the_reference_solver_budget():
+    """examples/test_vtol.py:21-64 (20 m/s at (2, 10), 24 discs, goal (70, 10) then (70, 0.5)) with IPOPT's iteration budget behind
+    every solve.  What happens, stated as a test so that it cannot drift unnoticed: the first NLPs have no feasible point, almost
+    every solve of the flight ends `optimal_inaccurate` inside the restoration, the applied iterates pitch the aircraft far past
+    its 15 degree limit and the flight ends on the ground (-2) before the first wall.  The reference's own demo presumably flies
+    (IPOPT's restoration returns something else): this is the open gap of the VTOL2D closed loop."""
+    p1, p2 = 67.0, 73.0
+    obs = np.array([[p1, z, 0.5] for z in (6.0, 7.0, 8.0, 9.0)] + [[p2, float(z), 0.5] for z in range(1, 16)] + [[60.0, 12.0, 1.5]])
+    obs7 = np.hstack([obs, np.zeros((len(obs), 4))])
+    spec = {"model": "VTOL2D", "radius": 0.6, "v_max": 20.0, "reached_threshold": 1.0, "num_constraints": 10}
+    ctl = sca.BatchedTrackingController(np.array([[2.0, 10.0, 0.0, 20.0, 0.0, 0.0]]), spec, obs=obs7, device=DEV)
+    assert ctl.mpc.max_iter == 3000
+    ctl.set_waypoints(np.array([[2.0, 10.0], [70.0, 10.0], [70.0, 0.5]]))
+    n_inacc = n_steps = 0
+    pitch_max = 0.0
+    ret = 0
+    for k in range(150):
+        ret = int(ctl.control_step(1)[0].item())
+        n_steps += 1
+        n_inacc += int(ctl.mpc_status[0].item() == 2)
+        pitch_max = max(pitch_max, abs(float(ctl.X[0, 2].item())))
+        if ret != 0:
+            break
+    assert ret == -2 and 40 <= n_steps <= 110, (ret, n_steps)
+    assert n_inacc >= 0.8 * n_steps and pitch_max > np.radians(45.0)
+    assert float(ctl.X[0, 0].item()) < 60.0                                # it never reaches the obstacles

@@ -31,13 +31,13 @@ done
 # 4b. the full default bench line (sweep, closed-loop rollout and MPC legs) under the kernel trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench_full -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_full_under_rocprof.json 2>/dev/null
 # 4c. instruction counts of every interior-point leg of the default line (VALU rooflines of bench.py: with_roofline)
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT -o bench_full_sq -- python3 $R/bench.py --no-cpu-baseline --no-sweep > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $OUT -o bench_full_sq -- python3 $R/bench.py --no-cpu-baseline --no-sweep --no-limit100 > /dev/null 2>&1
 # 4d. lane utilisation and the f64 instruction mix of the same legs (separate passes: the SQ counters of one pass are limited)
-rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT -o bench_full_lane -- python3 $R/bench.py --no-cpu-baseline --no-sweep > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d $OUT -o bench_full_flop -- python3 $R/bench.py --no-cpu-baseline --no-sweep > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $OUT -o bench_full_lane -- python3 $R/bench.py --no-cpu-baseline --no-sweep --no-limit100 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 --output-format csv -d $OUT -o bench_full_flop -- python3 $R/bench.py --no-cpu-baseline --no-sweep --no-limit100 > /dev/null 2>&1
 # 5. MPC-CBF kernel
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o mpc -- python3 $R/bench.py --workload mpc_cbf --steps 5 --warmup 1 > $OUT/mpc_under_rocprof.json 2>/dev/null
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o mpc_sq -- python3 $R/bench.py --workload mpc_cbf --steps 2 --warmup 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o mpc_sq -- python3 $R/bench.py --workload mpc_cbf --steps 2 --warmup 1 --no-limit100 --no-cpu-baseline > /dev/null 2>&1
 # 6. linear-model MPC-CBF kernel (Quad3D, n = 40): instruction mix and LDS conflicts
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o mpclin -- python3 $R/tools/prof_mpclin.py Quad3D 4096 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o mpclin_sq -- python3 $R/tools/prof_mpclin.py Quad3D 4096 2 > /dev/null 2>&1
