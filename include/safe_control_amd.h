@@ -402,6 +402,23 @@ int sc_mpcvtol_solve_batch_host(const sc_mpcvtol_params* params, int64_t B, int3
                                 const void* X, const void* u_prev, const void* goal, const void* obs,
                                 void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, int device);
 
+/* Optimal-decay MPC-CBF for VTOL2D -- the last model of the reference's accept list (optimal_decay_mpc_cbf.py:19): the NLP of
+ * sc_mpcvtol_solve_batch with two decay variables per stage scaling the DT-CBF gains of that stage's rows,
+ *   dd_h + (a1 rho1 + a2 rho2) d_h + a1 a2 rho1 rho2 h >= 0   (:288-296; gains 0.35: :83-86),
+ * cost + p_sb (rho - omega_ref)^2 per stage and variable (:175-176), input term R u^2 (:173-174; not the delta-u penalty).  Same kernel
+ * (one NLP per wavefront, one stage per lane, Riccati recursion); the 2 x 2 decay block of a stage is eliminated from the stage block
+ * before the recursion.  No restoration phase (mpc.resto unused), one launch (no continuation entry).  The reference copy is stale and its
+ * solver absent: oracle-only parity (oracle/od_mpc_vtol.py).  rho_out [B, 2 * horizon] or NULL.                                        */
+typedef struct sc_odmpcvtol_params {
+    sc_mpcvtol_params mpc;   /* alpha1 / alpha2 = the optimal-decay gains (0.35); kernel must be 0 or 2 */
+    double omega_ref[2];     /* cbf_param['omega1'], ['omega2'] = 1.0 */
+    double p_sb[2];          /* cbf_param['p_sb1'], ['p_sb2'] = 10    */
+} sc_odmpcvtol_params;
+
+int sc_odmpcvtol_solve_batch(const sc_odmpcvtol_params* params, int64_t B, int32_t K,
+                             const void* X, const void* u_prev, const void* goal, const void* obs,
+                             void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
+
 /* ---- optimal-decay MPC-CBF ---------------------------------------
  * OptimalDecayMPCCBF (position_control/optimal_decay_mpc_cbf.py:15-330) for DynamicUnicycle2D: the MPC-CBF NLP with
  * two decay variables per stage (omega1_k, omega2_k, model inputs at :123-124) that scale the DT-CBF gains,

@@ -189,7 +189,9 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
     if params:
         P.update(params)
     N = P["N"]
-    n = 2 * N
+    n = int(P.get("nu", 2)) * N                                           # inputs of all stages (VTOL2D: four per stage)
+    nu_in = n // N
+    sreset = int(P.get("slack_reset", 0))                                 # line search: 2 = s_i <- g_i where g_i >= mu / nu (oracle/mpc_cbf.py: solve)
     x0 = np.asarray(x0, dtype=np.float64)
     obs = np.asarray(obs, dtype=np.float64)
     if evaluate_fn is not None:
@@ -297,6 +299,8 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
         for _ in range(12):
             zt, st = zz + alpha * dzz, s + alpha * ds
             e0 = evaluate(x0, zt, goal, obs, P, level=0)
+            if sreset == 2:
+                st = np.where(e0["g"] >= mu / nu, e0["g"], st)
             phit = sf * e0["f"] - mu * np.sum(np.log(st)) + nu * np.sum(np.abs(e0["g"] - st))
             if phit <= phi0 + 1e-4 * alpha * dphi + 1e-13 * abs(phi0) + noise_rows:
                 accepted = True
@@ -304,7 +308,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
             alpha *= 0.5
         if not accepted:
             break
-        zz, s = zz + alpha * dzz, s + alpha * ds
+        zz, s = zz + alpha * dzz, (st if sreset == 2 else s + alpha * ds)
         lam = lam + ad * dlam
         lam = np.minimum(np.maximum(lam, mu / (1e10 * s)), 1e10 * mu / s)
     if status != STATUS_OPTIMAL and e_best <= P["acceptable_tol"]:
@@ -315,7 +319,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, linear_algebra=
             status = STATUS_INFEASIBLE
         elif status != STATUS_INFEASIBLE:
             status = STATUS_INACCURATE
-    u0, rho0 = zz[0:2].copy(), zz[n:n + 2].copy()
+    u0, rho0 = zz[0:nu_in].copy(), zz[n:n + 2].copy()
     if return_info:
         return u0, rho0, status, it, dict(zz=zz, X=ev["X"], f=ev["f"], g=ev["g"], lam=lam / sf, s=s, err=err, mu=mu, scale=sf, obs=obs, trace=trace)
     return u0, rho0, status, it

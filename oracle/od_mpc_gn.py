@@ -55,7 +55,7 @@ def stage_weights(rho, P):
 def evaluate(x0, zz, u_prev, goal, obs, P, lam=None, level=2):
     """Problem functions at zz = (z | rho); levels and row order of oracle.mpc_gn.evaluate."""
     N = P["N"]
-    n = 2 * N
+    n = int(P.get("nu", 2)) * N
     a1, a2 = P["alpha1"], P["alpha2"]
     pen = np.array([P["p_sb1"], P["p_sb2"]]); ref = np.array([P["omega1"], P["omega2"]])
     z, rho = zz[:n], zz[n:].reshape(N, 2)
@@ -68,7 +68,7 @@ def evaluate(x0, zz, u_prev, goal, obs, P, lam=None, level=2):
         return out
     hv = b["hv"]                                                            # (N, 3, K): h at a_k, b_k, c_k
     m = b["g"].shape[0]
-    J = np.zeros((m, 2 * n))
+    J = np.zeros((m, n + 2 * N))
     J[:, :n] = b["J"]
     A = np.zeros((N, K, 2))                                                 # d row / d rho_i = a_i (h_b - h_a) + a1 a2 rho_other h_a
     for k in range(N):
@@ -82,7 +82,7 @@ def evaluate(x0, zz, u_prev, goal, obs, P, lam=None, level=2):
         return out
     lamv = np.zeros(m) if lam is None else lam
     lc = lamv[: N * K].reshape(N, K)
-    W = np.zeros((2 * n, 2 * n))
+    W = np.zeros((n + 2 * N, n + 2 * N))
     W[:n, :n] = b["W"]
     JP = b["JP"]                                                            # (N, 3, K, n): gradient of h at each point in z
     for k in range(N):

@@ -204,6 +204,11 @@ VTOL_AIRFRAME_KEYS = ("mass", "inertia", "S_wing", "rho", "C_L0", "C_Lalpha", "M
                       "C_Ddelta_e", "C_m0", "C_malpha", "C_mdelta_e", "chord", "k_front", "k_rear", "k_pusher", "ell_f", "ell_r")
 
 
+class OdMpcVtolParams(C.Structure):
+    """Mirror of ``sc_odmpcvtol_params``."""
+    _fields_ = [("mpc", MpcVtolParams), ("omega_ref", C.c_double * 2), ("p_sb", C.c_double * 2)]
+
+
 class OdMpcGnParams(C.Structure):
     """Mirror of ``sc_odmpcgn_params``."""
     _fields_ = [("mpc", MpcGnParams), ("omega_ref", C.c_double * 2), ("p_sb", C.c_double * 2)]
@@ -265,6 +270,7 @@ SYMBOLS = {
     "sc_mpcvtol_workspace_bytes": (C.c_size_t, [C.POINTER(MpcVtolParams), C.c_int64, C.c_int32]),
     "sc_mpcvtol_solve_batch": (C.c_int, [C.POINTER(MpcVtolParams), C.c_int64, C.c_int32] + [C.c_void_p] * 9 + [C.c_size_t, C.c_void_p]),
     "sc_mpcvtol_solve_batch_host": (C.c_int, [C.POINTER(MpcVtolParams), C.c_int64, C.c_int32] + [C.c_void_p] * 8 + [C.c_int]),
+    "sc_odmpcvtol_solve_batch": (C.c_int, [C.POINTER(OdMpcVtolParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_odmpcgn_solve_batch": (C.c_int, [C.POINTER(OdMpcGnParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_mpclin_model_doubles": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sc_mpclin_build_model": (C.c_int, [C.POINTER(MpcLinParams)] + [C.c_void_p] * 5),

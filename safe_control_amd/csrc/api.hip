@@ -61,6 +61,8 @@ hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long lo
 size_t mpclin_state_doubles(int N, int K, int nu);
 size_t mpcgn_state_doubles(int N, int K);
 size_t mpcvtol_state_doubles(int N, int K);
+hipError_t odmpcvtol_wave_launch(const sc_odmpcvtol_params& q, long long B, int K, const void* X, const void* u_prev, const void* goal,
+                                 const void* obs, void* u_out, void* rho_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream);
 
 size_t mpcgn_lds_bytes(int model_id, int N, int K, int circles_only);
 size_t odmpcgn_lds_bytes(int model_id, int N, int K);
@@ -807,6 +809,21 @@ int sc_mpclin_solve_batch_sliced(const sc_mpclin_params* params, const sc_mpc_sl
                                  (hipStream_t)stream, ct);
     });
     if (e != hipSuccess) return sc::fail_hip(e, "mpclin kernel launch (sliced)");
+    return SC_OK;
+}
+
+int sc_odmpcvtol_solve_batch(const sc_odmpcvtol_params* params, int64_t B, int32_t K, const void* X, const void* u_prev, const void* goal,
+                             const void* obs, void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    int rc = sc::check_mpcvtol(&params->mpc, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (!sc::mpcvtol_uses_wave(params->mpc, K)) return sc::fail(SC_ERR_UNSUPPORTED, "optimal-decay MPC-CBF for VTOL2D runs on the wave-per-problem kernel (kernel = 0 / 2)");
+    if (!(params->p_sb[0] > 0) || !(params->p_sb[1] > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "p_sb must be > 0");
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::odmpcvtol_wave_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, rho_out, status_out, iters_out, z_out,
+                                             (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "odmpcvtol kernel launch");
     return SC_OK;
 }
 

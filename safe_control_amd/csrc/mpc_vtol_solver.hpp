@@ -48,6 +48,7 @@ struct Params {                      // filled from sc_mpcvtol_params by the lau
     // airframe (vtol2D.py:56-111)
     double mass, inertia, S_wing, rho_air, C_L0, C_Lalpha, M, alpha_0, C_Ldelta_e, C_D0, C_Dalpha, C_Ddelta_e, C_m0, C_malpha, C_mdelta_e,
         chord, k_front, k_rear, k_pusher, ell_f, ell_r;
+    double ps1 = 0.0, ps2 = 0.0, rf1 = 1.0, rf2 = 1.0;   // optimal decay (mpc_vtol_wave.hip, OD): penalties and references of the decay variables
     double eMa0sq;                   // exp(2 M alpha_0)
     double inv_m, inv_I, kf_m, kr_m, kp_m, lfkf_I, lrkr_I;
 };

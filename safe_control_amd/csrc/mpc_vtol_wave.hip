@@ -235,7 +235,12 @@ __device__ __attribute__((noinline)) void vtol_costates(ldsd* lds, const WaveLds
     }
 }
 
-template <int WKT>
+// OD: the optimal-decay NLP (optimal_decay_mpc_cbf.py:288-296; oracle/od_mpc_vtol.py): two decay variables per stage, which enter only
+// that stage's CBF rows (through the stage weights w0 = 1 - s + q, w1 = s - 2, s = a1 rho1 + a2 rho2, q = a1 a2 rho1 rho2) and the cost
+// p_sb (rho - ref)^2; their 2 x 2 block D_k is eliminated from the stage block before the Riccati recursion (H_k -= C_k D_k^-1 C_k',
+// q_k -= C_k D_k^-1 rr_k, d rho_k = D_k^-1 (rr_k - C_k' (dx_k, du_k)) afterwards), the input term is R u^2 (no coupling between the stages'
+// inputs: Dl = 0 in the recursion), no restoration phase (the optimal-decay oracle has none).
+template <int WKT, bool OD = false>
 struct Wave {
     static constexpr int WNR = WKT + 13;          // + 5 state bounds of x_{k+1} + 4 + 4 input box
     const Params& P;
@@ -251,6 +256,8 @@ struct Wave {
     // my stage's state, next state, acceleration (from the last evaluation), rows 3, 4 of [A B]
     double xk[NX], xk1[NX], ak[2], a34[2][NV];
     double zR[NU], zb[NU];
+    // optimal decay: my stage's decay variables, their best iterate, and what the elimination of stage_blocks leaves for the step
+    double dk[2], dkb[2], Cm[NV][2], rrv[2], dvx, dvy, dils, dilw;
 #ifdef SC_VTOL_PROF
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // eval, linearise, adjoint, blocks, riccati, lq forward, rows + rest, trials
 #endif
@@ -261,10 +268,26 @@ struct Wave {
         w0 = 1.0 - g1 + g2; w1 = g1 - 2.0; w2 = 1.0;
     }
     __device__ __forceinline__ bool valid(int r) const { return act && (r >= WKT || r < K); }
+    // stage weights of the rows for decay variables (r1, r2)
+    __device__ __forceinline__ void od_weights(double r1, double r2, double& a, double& b) const {
+        const double sk = P.alpha1 * r1 + P.alpha2 * r2, qk = P.alpha1 * P.alpha2 * r1 * r2;
+        a = 1.0 - sk + qk; b = sk - 2.0;
+    }
+    // h at the first two barrier points of obstacle j
+    __device__ __forceinline__ void od_h01(const double pt[3][2], int j, double& h0, double& h1) const {
+        const double cx = lds[L.OB + 3 * j], cz = lds[L.OB + 3 * j + 1], d = P.radius + lds[L.OB + 3 * j + 2], off = P.beta * d * d;
+        const double e0x = pt[0][0] - cx, e0z = pt[0][1] - cz, e1x = pt[1][0] - cx, e1z = pt[1][1] - cz;
+        h0 = e0x * e0x + e0z * e0z - off; h1 = e1x * e1x + e1z * e1z - off;
+    }
+    // d row / d rho_1, d rho_2
+    __device__ __forceinline__ void od_row_drho(double h0, double h1, double& A1, double& A2) const {
+        const double aa = P.alpha1 * P.alpha2 * h0;
+        A1 = P.alpha1 * (h1 - h0) + aa * dk[1]; A2 = P.alpha2 * (h1 - h0) + aa * dk[0];
+    }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
 
     // ---- function evaluation: rollout (every lane) + my rows -----------------------------------------------------------------
-    __device__ __forceinline__ void rows_from_state(const double* u, double* go) const {
+    __device__ __forceinline__ void rows_from_state(const double* u, double* go, double w0, double w1) const {
         double pt[3][2];
         const double dt = P.dt;
         pt[0][0] = xk[0]; pt[0][1] = xk[1];
@@ -288,7 +311,7 @@ struct Wave {
         for (int j = 0; j < NU; ++j) { go[WKT + 5 + j] = P.u_hi[j] - u[j]; go[WKT + 9 + j] = u[j] - P.u_lo[j]; }
     }
     // rollout over the inputs at LDS offset zo; returns the unscaled cost, rows to go
-    __device__ __forceinline__ double eval(int zo, double* go) {
+    __device__ __forceinline__ double eval(int zo, double* go, double r1 = 1.0, double r2 = 1.0) {
         double x[NX], xn[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = x0[i];
@@ -311,15 +334,20 @@ struct Wave {
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             u[j] = lds[zo + k * NU + j];
-            const double um = k ? lds[zo + (k - 1) * NU + j] : uprev[j], du = u[j] - um;
+            const double um = k ? lds[zo + (k - 1) * NU + j] : uprev[j], du = OD ? u[j] : u[j] - um;     // OD: R u^2 (optimal_decay_mpc_cbf.py:173-179)
             f += P.R[j] * du * du;
+        }
+        double wa = w0, wb = w1;
+        if constexpr (OD) {
+            od_weights(r1, r2, wa, wb);
+            f += P.ps1 * (r1 - P.rf1) * (r1 - P.rf1) + P.ps2 * (r2 - P.rf2) * (r2 - P.rf2);
         }
         {
             const double e0 = xk1[0] - xg[0], e1 = xk1[1] - xg[1];
             f += P.Q[0] * e0 * e0 + P.Q[1] * e1 * e1 + P.Q[2] * xk1[2] * xk1[2] + P.Q[3] * xk1[3] * xk1[3] + P.Q[4] * xk1[4] * xk1[4] +
                  P.Q[5] * xk1[5] * xk1[5];
         }
-        rows_from_state(u, go);
+        rows_from_state(u, go, wa, wb);
         return ipm::wsum(act ? f : 0.0);
     }
 
@@ -392,10 +420,12 @@ struct Wave {
     // ---- costate sweep: |grad f - J' lam|_inf, costates to LDS ----------------------------------------------------------------
     __device__ __forceinline__ double adjoint(bool with_rows, double cw, bool resto, double zeta) {
         double cx[NX], cu[NU], own[NX];
+        double rdr1 = 0.0, rdr2 = 0.0;                                     // OD: r_d of my decay variables
 #pragma unroll
         for (int i = 0; i < NX; ++i) cx[i] = 0.0;
 #pragma unroll
         for (int j = 0; j < NU; ++j) cu[j] = 0.0;
+        if constexpr (OD) { rdr1 = 2.0 * cw * P.ps1 * (dk[0] - P.rf1); rdr2 = 2.0 * cw * P.ps2 * (dk[1] - P.rf2); }
         if (with_rows) {
             double pt[3][2], G2[2][NV];
             points(pt); point_jac(G2);
@@ -407,6 +437,11 @@ struct Wave {
                     for (int i = 0; i < NX; ++i) cx[i] -= lam[j] * r[i];
 #pragma unroll
                     for (int i = 0; i < NU; ++i) cu[i] -= lam[j] * r[6 + i];
+                    if constexpr (OD) {
+                        double h0, h1, A1, A2;
+                        od_h01(pt, j, h0, h1); od_row_drho(h0, h1, A1, A2);
+                        rdr1 -= lam[j] * A1; rdr2 -= lam[j] * A2;
+                    }
                 }
 #pragma unroll
             for (int j = 0; j < NU; ++j) cu[j] += lam[WKT + 5 + j] - lam[WKT + 9 + j];
@@ -418,8 +453,8 @@ struct Wave {
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             const double uk = lds[L.U + k * NU + j], um = k ? lds[L.U + (k - 1) * NU + j] : uprev[j];
-            double gj = 2.0 * cw * P.R[j] * (uk - um);
-            if (k + 1 < N) gj -= 2.0 * cw * P.R[j] * (lds[L.U + (k + 1) * NU + j] - uk);
+            double gj = 2.0 * cw * P.R[j] * (OD ? uk : uk - um);
+            if (!OD && k + 1 < N) gj -= 2.0 * cw * P.R[j] * (lds[L.U + (k + 1) * NU + j] - uk);
             if (resto) gj += zeta * (uk - zR[j]);
             cu[j] += gj;
         }
@@ -439,6 +474,7 @@ struct Wave {
             for (int i = 0; i < NX; ++i) r += lds[L.AB + k * 60 + i * 10 + 6 + j] * lds[L.PS + (k + 1) * 6 + i];
             rd = fmax(rd, fabs(r));
         }
+        if constexpr (OD) rd = fmax(rd, fmax(fabs(rdr1), fabs(rdr2)));
         return ipm::wmax(act ? rd : 0.0);
     }
 
@@ -456,7 +492,7 @@ struct Wave {
     }
 
     // ---- my stage block of the Newton system to LDS -----------------------------------------------------------------------------
-    __device__ __forceinline__ void stage_blocks(double cw, bool resto, double zeta, double mu, double rho) {
+    __device__ __forceinline__ void stage_blocks(double cw, bool resto, double zeta, double mu, double rho_R) {
         double H[55], q[NV];
 #pragma unroll
         for (int i = 0; i < 55; ++i) H[i] = 0.0;
@@ -467,18 +503,44 @@ struct Wave {
         double pt[3][2], G2[2][NV];
         points(pt); point_jac(G2);
         double slam = 0.0, nu2[2] = {0.0, 0.0};
+        double od11 = 0.0, od12 = 0.0, od22 = 0.0;
+        if constexpr (OD) {
+#pragma unroll
+            for (int a = 0; a < NV; ++a) { Cm[a][0] = 0.0; Cm[a][1] = 0.0; }
+            rrv[0] = -2.0 * cw * P.ps1 * (dk[0] - P.rf1); rrv[1] = -2.0 * cw * P.ps2 * (dk[1] - P.rf2);
+        }
 #pragma unroll
         for (int j = 0; j < WKT; ++j)
             if (j < K) {
                 double r[NV]; cbf_row_grad(pt, G2, j, r);
                 double sg, d0;
-                if (resto) row_sig_el(j, mu, rho, sg, d0); else row_sig(j, false, mu, sg, d0);
+                if (resto) row_sig_el(j, mu, rho_R, sg, d0); else row_sig(j, false, mu, sg, d0);
                 const double lq = lam[j] + d0, l = lam[j];
 #pragma unroll
                 for (int a = 0; a < NV; ++a) {
                     q[a] += lq * r[a];
 #pragma unroll
                     for (int b = a; b < NV; ++b) H[sym(a, b)] += sg * r[a] * r[b];
+                }
+                if constexpr (OD) {
+                    // decay block of my stage: C[a][i] = sum_j sig r_a A_i - lam x_i[a] (x_i: d2 row / d rho_i d(x, u) = a_i (grad h1 - grad h0) +
+                    // a1 a2 rho_other grad h0), D = sum_j sig A A' - lam a1 a2 h0 [[0, 1], [1, 0]], rr = sum_j (lam + dl0) A
+                    double h0, h1, A1, A2;
+                    od_h01(pt, j, h0, h1); od_row_drho(h0, h1, A1, A2);
+                    const double cx_ = lds[L.OB + 3 * j], cz_ = lds[L.OB + 3 * j + 1];
+                    const double e0x = pt[0][0] - cx_, e0z = pt[0][1] - cz_, e1x = pt[1][0] - cx_, e1z = pt[1][1] - cz_;
+                    const double m1 = -P.alpha1 + P.alpha1 * P.alpha2 * dk[1], m2 = -P.alpha2 + P.alpha1 * P.alpha2 * dk[0];   // weight of grad h0 in x_i
+                    double x1[NV], x2[NV];
+#pragma unroll
+                    for (int a = 0; a < NV; ++a) { x1[a] = 0.0; x2[a] = 0.0; }
+                    x1[0] = 2.0 * (m1 * e0x + P.alpha1 * e1x); x1[1] = 2.0 * (m1 * e0z + P.alpha1 * e1z);
+                    x1[3] = 2.0 * P.alpha1 * e1x * P.dt; x1[4] = 2.0 * P.alpha1 * e1z * P.dt;
+                    x2[0] = 2.0 * (m2 * e0x + P.alpha2 * e1x); x2[1] = 2.0 * (m2 * e0z + P.alpha2 * e1z);
+                    x2[3] = 2.0 * P.alpha2 * e1x * P.dt; x2[4] = 2.0 * P.alpha2 * e1z * P.dt;
+#pragma unroll
+                    for (int a = 0; a < NV; ++a) { Cm[a][0] += sg * r[a] * A1 - l * x1[a]; Cm[a][1] += sg * r[a] * A2 - l * x2[a]; }
+                    od11 += sg * A1 * A1; od12 += sg * A1 * A2 - l * P.alpha1 * P.alpha2 * h0; od22 += sg * A2 * A2;
+                    rrv[0] += lq * A1; rrv[1] += lq * A2;
                 }
                 slam += l;
                 nu2[0] -= w2 * l * 2.0 * (pt[2][0] - lds[L.OB + 3 * j]); nu2[1] -= w2 * l * 2.0 * (pt[2][1] - lds[L.OB + 3 * j + 1]);
@@ -514,6 +576,31 @@ struct Wave {
             q[6 + j] += -(lam[WKT + 5 + j] + dh) + (lam[WKT + 9 + j] + dl);
             if (resto) q[6 + j] -= zeta * (lds[L.U + k * NU + j] - zR[j]);
         }
+        if constexpr (OD) {
+            // input term R u^2: its Hessian and negative gradient sit in my stage block (the recursion's coupling term Dl is zero)
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { H[sym(6 + j, 6 + j)] += 2.0 * cw * P.R[j]; q[6 + j] -= 2.0 * cw * P.R[j] * lds[L.U + k * NU + j]; }
+            // D^-1 in eigen form, shifted to positive definite (oracle/od_mpc_cbf.py: block_eig; csrc/mpc_gn.hip), then the Schur complement
+            const double d11 = 2.0 * cw * P.ps1 + od11, d12 = od12, d22 = 2.0 * cw * P.ps2 + od22;
+            const double tr = d11 + d22, df = d11 - d22, rad = sqrt(df * df + 4.0 * d12 * d12);
+            double ls = 0.5 * (tr + rad), lw = (d11 * d22 - d12 * d12) / ls;
+            double vx = df >= 0.0 ? df + rad : 2.0 * d12, vy = df >= 0.0 ? 2.0 * d12 : rad - df;
+            const double vn = vx * vx + vy * vy;
+            if (vn > 0.0) { const double rn = 1.0 / sqrt(vn); vx *= rn; vy *= rn; } else { vx = 1.0; vy = 0.0; }
+            const double sh = fmax(0.0, 1e-8 * fmax(1.0, fabs(d11) + fabs(d22)) - lw);
+            ls += sh; lw += sh;
+            dvx = vx; dvy = vy; dils = 1.0 / ls; dilw = 1.0 / lw;
+            const double ts = (vx * rrv[0] + vy * rrv[1]) * dils, tw = (-vy * rrv[0] + vx * rrv[1]) * dilw;
+            double cs[NV], cwv[NV];
+#pragma unroll
+            for (int a = 0; a < NV; ++a) { cs[a] = Cm[a][0] * vx + Cm[a][1] * vy; cwv[a] = -Cm[a][0] * vy + Cm[a][1] * vx; }
+#pragma unroll
+            for (int a = 0; a < NV; ++a) {
+                q[a] -= cs[a] * ts + cwv[a] * tw;
+#pragma unroll
+                for (int b = a; b < NV; ++b) H[sym(a, b)] -= cs[a] * cs[b] * dils + cwv[a] * cwv[b] * dilw;
+            }
+        }
         // own terms of x_{k+1}: diagonal and negative gradient
         double xd[NX], xq[NX];
 #pragma unroll
@@ -534,7 +621,7 @@ struct Wave {
         if (act) {
 #pragma unroll
             for (int j = 0; j < NU; ++j)
-                if (k == 0) { lds[L.Dl + j] = 2.0 * cw * P.R[j]; lds[L.UP + j] = uprev[j]; }
+                if (k == 0) { lds[L.Dl + j] = OD ? 0.0 : 2.0 * cw * P.R[j]; lds[L.UP + j] = uprev[j]; }
 #pragma unroll
             for (int i = 0; i < 55; ++i) lds[L.H + k * 55 + i] = H[i];
 #pragma unroll
@@ -600,7 +687,8 @@ struct Wave {
             zb[j] = uk[j]; zR[j] = uk[j];
         }
         sync();
-        fraw = eval(L.U, g);
+        if constexpr (OD) { dk[0] = dkb[0] = P.rf1; dk[1] = dkb[1] = P.rf2; od_weights(dk[0], dk[1], w0, w1); }   // decay variables start at their references
+        fraw = eval(L.U, g, dk[0], dk[1]);
         if (ct.it_stop < 0) { violated = violation() > 0.0; status_out = ST_PENDING; iters_out = 0; return; }   // classify only
         linearise();
         sync();
@@ -617,7 +705,7 @@ struct Wave {
             if (cst && it > ct.it_stop) { pending = true; break; }        // the cap of this launch: the solve goes on in the next one
             double cw = resto ? 0.0 : sf0;
             VPROF_T0
-            if (!have) fraw = eval(L.U, g);
+            if (!have) fraw = eval(L.U, g, dk[0], dk[1]);
             have = false;
             VPROF_ADD(0)
             linearise();
@@ -649,6 +737,7 @@ struct Wave {
                 e_best = e_opt;
 #pragma unroll
                 for (int j = 0; j < NU; ++j) zb[j] = lds[L.U + k * NU + j];
+                if constexpr (OD) { dkb[0] = dk[0]; dkb[1] = dk[1]; }
             }
             if (resto) {
                 const double theta = violation();
@@ -661,7 +750,9 @@ struct Wave {
                 break;
             }
             bool want_resto = !resto && lmax > 1e10;
+            if (OD && want_resto) { status = ST_INFEASIBLE; break; }       // (optimal decay: no restoration phase; oracle/od_mpc_cbf.py)
             double alpha = 0.0, ad = 0.0, ft_acc = fraw;
+            double drho[2] = {0.0, 0.0}, rhot[2] = {1.0, 1.0};
             if (!want_resto) {
                 for (;;) {
                     double cm = 0.0;
@@ -702,6 +793,14 @@ struct Wave {
                     for (int i = 0; i < NX; ++i) v[i] = dxk[i];
 #pragma unroll
                     for (int j = 0; j < NU; ++j) v[6 + j] = duk[j];
+                    if constexpr (OD) {
+                        // back-substitution of my decay variables: d rho = D^-1 (rr - C' (dx_k, du_k))
+                        double t0 = rrv[0], t1 = rrv[1];
+#pragma unroll
+                        for (int a = 0; a < NV; ++a) { t0 -= Cm[a][0] * v[a]; t1 -= Cm[a][1] * v[a]; }
+                        const double ps_ = (dvx * t0 + dvy * t1) * dils, pw_ = (-dvy * t0 + dvx * t1) * dilw;
+                        drho[0] = dvx * ps_ - dvy * pw_; drho[1] = dvy * ps_ + dvx * pw_;
+                    }
 #pragma unroll
                     for (int j = 0; j < WKT; ++j) {
                         double sacc = 0.0;
@@ -709,6 +808,11 @@ struct Wave {
                             double r[NV]; cbf_row_grad(pt, G2, j, r);
 #pragma unroll
                             for (int i = 0; i < NV; ++i) sacc += r[i] * v[i];
+                            if constexpr (OD) {
+                                double h0, h1, A1, A2;
+                                od_h01(pt, j, h0, h1); od_row_drho(h0, h1, A1, A2);
+                                sacc += A1 * drho[0] + A2 * drho[1];
+                            }
                         }
                         jd[j] = sacc;
                     }
@@ -765,8 +869,9 @@ struct Wave {
                     for (int j = 0; j < NU; ++j) {
                         const double u_ = lds[L.U + k * NU + j], um = k ? lds[L.U + (k - 1) * NU + j] : uprev[j];
                         const double dm = k ? lds[L.DU + (k - 1) * NU + j] : 0.0;
-                        v += 2.0 * cw * P.R[j] * (u_ - um) * (duk[j] - dm);
+                        v += OD ? 2.0 * cw * P.R[j] * u_ * duk[j] : 2.0 * cw * P.R[j] * (u_ - um) * (duk[j] - dm);
                     }
+                    if constexpr (OD) v += 2.0 * cw * (P.ps1 * (dk[0] - P.rf1) * drho[0] + P.ps2 * (dk[1] - P.rf2) * drho[1]);
                     gdz = ipm::wsum(act ? v : 0.0);
                 }
                 double bar0, dbar;
@@ -785,7 +890,8 @@ struct Wave {
                         for (int j = 0; j < NU; ++j) lds[L.UT + k * NU + j] = lds[L.U + k * NU + j] + alpha * duk[j];
                     }
                     sync();
-                    const double ft = eval(L.UT, gt);
+                    if constexpr (OD) { rhot[0] = dk[0] + alpha * drho[0]; rhot[1] = dk[1] + alpha * drho[1]; }
+                    const double ft = eval(L.UT, gt, rhot[0], rhot[1]);
                     double slog = 0.0, sabs = 0.0, st_t = 0.0, slogt = 0.0, pr_s = 1.0, pr_t = 1.0;
                     const double thr = mu * rcp_(nu);
 #pragma unroll
@@ -823,7 +929,7 @@ struct Wave {
                 if (!accepted) {
                     if (resto) break;
                     want_resto = true;
-                } else if (!resto) {
+                } else if (!resto && !OD) {
                     n_small = (alpha < P.small_alpha && violation() > theta_tol) ? n_small + 1 : 0;
                     if (n_small >= P.small_iter && n_resto < P.max_entries && e_best > P.acceptable_tol) want_resto = true;
                 }
@@ -854,11 +960,13 @@ struct Wave {
                         }
                         s[r] = sn; lam[r] = l; g[r] = gt[r];
                     }
+                    if constexpr (OD) { dk[0] = rhot[0]; dk[1] = rhot[1]; od_weights(dk[0], dk[1], w0, w1); }
                     fraw = ft_acc; have = true;
                     sync();
                     continue;
                 }
                 // the step is not taken: my registers hold the trial's state, bring the iterate's back
+                if (OD) break;                                             // (optimal decay: no restoration to hand over to)
                 fraw = eval(L.U, g);
             }
             // want_resto
@@ -911,22 +1019,35 @@ struct Wave {
 #pragma unroll
                 for (int j = 0; j < NU; ++j) lds[L.U + k * NU + j] = zb[j];
             }
+            if constexpr (OD) { dk[0] = dkb[0]; dk[1] = dkb[1]; }
             status = ST_OPTIMAL;
         }
         sync();
+        if constexpr (OD) {
+            // optimal decay has no restoration phase: "infeasible" there means "stopped at an infeasible iterate" (oracle/od_mpc_cbf.py)
+            if (status != ST_OPTIMAL) {
+                eval(L.U, g, dk[0], dk[1]);
+                double gm = 1e300;
+#pragma unroll
+                for (int r = 0; r < WNR; ++r) if (valid(r)) gm = fmin(gm, g[r]);
+                gm = ipm::wmin(act ? gm : 1e300);
+                status = (gm < -1e-6 || status == ST_INFEASIBLE) ? ST_INFEASIBLE : ST_INACCURATE;
+            }
+        }
         status_out = status; iters_out = it;
     }
 };
 
-template <typename TIO, int WKT>
+template <typename TIO, int WKT, bool OD = false>
 __global__ void __launch_bounds__(64) mpcvtol_wave_kernel(const Params P, long long B, int obs_shared, const TIO* __restrict__ X,
                                                           const TIO* __restrict__ u_prev, const TIO* __restrict__ goal,
                                                           const TIO* __restrict__ obs, TIO* __restrict__ u_out, int* __restrict__ status_out,
-                                                          int* __restrict__ iters_out, TIO* __restrict__ z_out, const ipm::Cont ct) {
+                                                          int* __restrict__ iters_out, TIO* __restrict__ z_out, const ipm::Cont ct,
+                                                          TIO* __restrict__ rho_out) {
     extern __shared__ double vtol_lds[];
     long long b;
     if (!ipm::cont_problem(ct, B, b)) return;                           // mpc_cont.hpp: block index, or an entry of the previous launch's queue
-    Wave<WKT> S(P, (ldsd*)vtol_lds);
+    Wave<WKT, OD> S(P, (ldsd*)vtol_lds);
     const TIO* ob = obs + (obs_shared ? 0 : b * P.K * 7);
     if ((int)threadIdx.x < 3 * WKT_MAX) {
         const int j = threadIdx.x / 3, c = threadIdx.x % 3;
@@ -958,16 +1079,19 @@ __global__ void __launch_bounds__(64) mpcvtol_wave_kernel(const Params P, long l
     if (z_out && S.act)
 #endif
         for (int j = 0; j < NU; ++j) z_out[b * (long long)(P.N * NU) + S.k * NU + j] = (TIO)vtol_lds[S.L.U + S.k * NU + j];
+    if constexpr (OD) {
+        if (rho_out && S.act) { rho_out[b * (long long)(2 * P.N) + 2 * S.k] = (TIO)S.dk[0]; rho_out[b * (long long)(2 * P.N) + 2 * S.k + 1] = (TIO)S.dk[1]; }
+    }
 }
 
-template <typename TIO, int WKT>
+template <typename TIO, int WKT, bool OD = false>
 static hipError_t wave_launch_t(const Params& P, const sc_mpcvtol_params& p, long long B, size_t lds, const void* X, const void* u_prev,
                                 const void* goal, const void* obs, void* u_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream,
-                                const ipm::Cont& ct) {
-    hipError_t e = hipFuncSetAttribute((const void*)mpcvtol_wave_kernel<TIO, WKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                const ipm::Cont& ct, void* rho_out = nullptr) {
+    hipError_t e = hipFuncSetAttribute((const void*)mpcvtol_wave_kernel<TIO, WKT, OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mpcvtol_wave_kernel<TIO, WKT>), dim3((unsigned)B), dim3(64), lds, stream, P, B, p.obs_shared, (const TIO*)X,
-                       (const TIO*)u_prev, (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status_out, iters_out, (TIO*)z_out, ct);
+    hipLaunchKernelGGL((mpcvtol_wave_kernel<TIO, WKT, OD>), dim3((unsigned)B), dim3(64), lds, stream, P, B, p.obs_shared, (const TIO*)X,
+                       (const TIO*)u_prev, (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status_out, iters_out, (TIO*)z_out, ct, (TIO*)rho_out);
     return hipGetLastError();
 }
 
@@ -986,6 +1110,22 @@ hipError_t mpcvtol_wave_launch(const sc_mpcvtol_params& p, long long B, int K, c
                       : wave_launch_t<double, 16>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct);
     return K <= 8 ? wave_launch_t<float, 8>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct)
                   : wave_launch_t<float, 16>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct);
+}
+
+// optimal-decay MPC-CBF for VTOL2D (include/safe_control_amd.h: sc_odmpcvtol_params): one launch, no continuation
+hipError_t odmpcvtol_wave_launch(const sc_odmpcvtol_params& q, long long B, int K, const void* X, const void* u_prev, const void* goal,
+                                 const void* obs, void* u_out, void* rho_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream) {
+    const sc_mpcvtol_params& p = q.mpc;
+    Params P = from_c(p, K);
+    P.ps1 = q.p_sb[0]; P.ps2 = q.p_sb[1]; P.rf1 = q.omega_ref[0]; P.rf2 = q.omega_ref[1];
+    const size_t lds = mpcvtol_wave_lds_bytes(p.horizon);
+    ipm::Cont ct{};
+    ct.it_stop = p.max_iter;
+    if (p.io_dtype == SC_DTYPE_F64)
+        return K <= 8 ? wave_launch_t<double, 8, true>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct, rho_out)
+                      : wave_launch_t<double, 16, true>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct, rho_out);
+    return K <= 8 ? wave_launch_t<float, 8, true>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct, rho_out)
+                  : wave_launch_t<float, 16, true>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct, rho_out);
 }
 
 }  // namespace sc

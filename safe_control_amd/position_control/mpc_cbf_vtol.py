@@ -155,3 +155,121 @@ class BatchedVtolMPCCBF(_lib.SlicedSolver):
             rc = self._lib.sc_mpcvtol_solve_batch_sliced(C.byref(p), C.byref(sl), *args, stream)
         _lib.check(rc, "sc_mpcvtol_solve_batch")
         return (u, status, iters, z) if want_z else (u, status, iters)
+
+
+# ---- optimal decay (position_control/optimal_decay_mpc_cbf.py with a VTOL2D robot) ---------------------------------------------
+OD_CBF_VTOL = {"alpha1": 0.35, "alpha2": 0.35, "omega1": 1.0, "p_sb1": 10.0, "omega2": 1.0, "p_sb2": 10.0}     # optimal_decay_mpc_cbf.py:83-91
+
+
+def make_od_params(robot_spec, cbf_param, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER):
+    p = _lib.OdMpcVtolParams()
+    p.mpc = make_params(robot_spec, cbf_param, horizon, dt, radius, io_dtype, obs_shared=obs_shared, tol=tol, max_iter=max_iter)
+    p.omega_ref[0], p.omega_ref[1] = float(cbf_param.get("omega1", 1.0)), float(cbf_param.get("omega2", 1.0))
+    p.p_sb[0], p.p_sb[1] = float(cbf_param.get("p_sb1", 10.0)), float(cbf_param.get("p_sb2", 10.0))
+    return p
+
+
+class BatchedOptimalDecayVtolMPCCBF:
+    """Optimal-decay MPC-CBF for B aircraft per launch (csrc/mpc_vtol_wave.hip, OD instantiation: the two decay variables of a stage
+    are eliminated from the stage block before the Riccati recursion).
+
+    ``solve(X[B,6], u_prev[B,4], goal[B,2], obs[B,K,7] | obs[K,7])`` -> ``u[B,4]``, ``rho[B,2N]`` (omega1_k, omega2_k per stage),
+    ``status[B]``, ``iters[B]`` (and ``z[B,4N]`` if asked).  ``u_prev`` is taken for the signature's sake: the input term of this
+    class is R u^2 (optimal_decay_mpc_cbf.py:173-174).  No CPU fallback."""
+
+    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f64", cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER):
+        self.robot_spec = complete_robot_spec(dict(robot_spec or {"model": "VTOL2D"}))
+        if self.robot_spec["model"] != "VTOL2D":
+            raise NotImplementedError("this controller serves VTOL2D")
+        self.dt = float(dt)
+        self.io_dtype = {"f32": _lib.DTYPE_F32, "f64": _lib.DTYPE_F64}[io_dtype]
+        self.horizon = HORIZON_VTOL
+        self.Q, self.R = np.diag(Q_VTOL), np.array(R_VTOL)
+        self.cbf_param = cbf_param or dict(OD_CBF_VTOL)
+        self.tol, self.max_iter = tol, max_iter
+        self._lib = _lib.load()
+
+    @property
+    def torch_dtype(self):
+        import torch
+        return torch.float32 if self.io_dtype == _lib.DTYPE_F32 else torch.float64
+
+    def solve(self, X, u_prev, goal, obs, want_z=False):
+        import torch
+        dt_ = self.torch_dtype
+        for name, t in (("X", X), ("u_prev", u_prev), ("goal", goal), ("obs", obs)):
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == dt_):
+                raise ValueError(f"{name} must be a contiguous CUDA tensor of dtype {dt_}")
+        B = X.shape[0]
+        shared = obs.dim() == 2
+        K = obs.shape[-2]
+        if X.shape != (B, 6) or u_prev.shape != (B, 4) or goal.shape != (B, 2) or obs.shape[-1] != 7 or (not shared and obs.shape[0] != B):
+            raise ValueError("expected X[B,6], u_prev[B,4], goal[B,2], obs[B,K,7] or obs[K,7]")
+        u = torch.empty((B, 4), dtype=dt_, device=X.device)
+        rho = torch.empty((B, 2 * self.horizon), dtype=dt_, device=X.device)
+        status = torch.empty((B,), dtype=torch.int32, device=X.device)
+        iters = torch.empty((B,), dtype=torch.int32, device=X.device)
+        z = torch.empty((B, 4 * self.horizon), dtype=dt_, device=X.device) if want_z else None
+        p = make_od_params(self.robot_spec, self.cbf_param, self.horizon, self.dt, self.robot_spec["radius"], self.io_dtype,
+                           obs_shared=shared, tol=self.tol, max_iter=self.max_iter)
+        stream = torch.cuda.current_stream(X.device).cuda_stream
+        rc = self._lib.sc_odmpcvtol_solve_batch(
+            C.byref(p), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(), rho.data_ptr(),
+            status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        _lib.check(rc, "sc_odmpcvtol_solve_batch")
+        return (u, rho, status, iters, z) if want_z else (u, rho, status, iters)
+
+
+class OptimalDecayVtolMPCCBF:
+    """Drop-in for position_control.optimal_decay_mpc_cbf.OptimalDecayMPCCBF with a VTOL2D robot (single agent per call; the one
+    NLP goes through the batched entry point on device ``device``).  Horizon 30, Q / R of :44-47, gains 0.35 (:83-86)."""
+
+    def __init__(self, robot, robot_spec, num_obs=5, device=0):
+        self.robot = robot
+        self.robot_spec = complete_robot_spec(robot_spec)
+        self.status = "optimal"                               # optimal_decay_mpc_cbf.py:21
+        self.num_obs = int(num_obs)
+        self.device = device
+        self.horizon = HORIZON_VTOL                           # :44
+        self.dt = robot.dt
+        self.Q, self.R = np.diag(Q_VTOL), np.array(R_VTOL)
+        self.n_states, self.n_controls = 6, 4
+        self.cbf_param = dict(OD_CBF_VTOL)
+        self.omega1 = None                                    # :92-93
+        self.omega2 = None
+        self.goal = np.array([0, 0])
+        self.obs = None
+        self.setup_control_problem()
+
+    def setup_control_problem(self):
+        self._ctl = BatchedOptimalDecayVtolMPCCBF(self.robot_spec, dt=self.dt, io_dtype="f64", cbf_param=self.cbf_param)
+        self.u_prev = np.zeros(4)
+        self.z = np.zeros(4 * self.horizon)
+        self.rho = np.ones(2 * self.horizon)
+        self.iterations = 0
+        self.solver_status = "optimal"
+
+    def update_tvp(self, goal, obs):
+        self.goal = np.array(goal)
+        self.obs = pad_obstacles(obs, self.num_obs)
+
+    def solve_control_problem(self, robot_state, control_ref, nearest_obs):
+        import torch
+        self.update_tvp(control_ref["goal"], nearest_obs)
+        if control_ref["state_machine"] != "track":           # optimal_decay_mpc_cbf.py:339-341
+            return control_ref["u_ref"]
+        X = np.zeros(6)
+        xs = np.asarray(robot_state, dtype=np.float64).reshape(-1)[:6]
+        X[: xs.shape[0]] = xs
+        dev = torch.device("cuda", int(self.device))
+        t = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float64), dtype=torch.float64, device=dev)     # noqa: E731
+        self._ctl.cbf_param = self.cbf_param                  # (users mutate cbf_param in place: README "online adaptive CBF")
+        self._ctl.robot_spec["radius"] = self.robot.robot_radius
+        u, rho, st, it, z = self._ctl.solve(t(X[None]), t(self.u_prev[None]), t(np.asarray(self.goal, dtype=np.float64).reshape(-1)[None, :2]),
+                                            t(self.obs[None]), want_z=True)
+        self.iterations = int(it[0].item())
+        self.solver_status = _lib.STATUS_STRINGS[int(st[0].item())]
+        self.rho, self.z = rho[0].cpu().numpy(), z[0].cpu().numpy()
+        self.omega1, self.omega2 = float(self.rho[0]), float(self.rho[1])
+        self.u_prev = u[0].cpu().numpy().copy()
+        return self.u_prev.reshape(-1, 1).copy()

@@ -57,6 +57,9 @@ class OptimalDecayMPCCBF:
         if cls is OptimalDecayMPCCBF and robot_spec.get("model") == "Quad3D":        # the plain row with R u^2 (:284-287)
             from .mpc_cbf_linear import OptimalDecayLinearMPCCBF
             return OptimalDecayLinearMPCCBF(robot, robot_spec, *args, **kwargs)
+        if cls is OptimalDecayMPCCBF and robot_spec.get("model") == "VTOL2D":        # one NLP per wavefront, one stage per lane
+            from .mpc_cbf_vtol import OptimalDecayVtolMPCCBF
+            return OptimalDecayVtolMPCCBF(robot, robot_spec, *args, **kwargs)
         return super().__new__(cls)
 
     def __init__(self, robot, robot_spec, num_obs=5, device=0):

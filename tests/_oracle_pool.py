@@ -33,6 +33,27 @@ def _worker_od_rd1(d, outp):
     np.savez(outp, u=u, st=st, it=it, z=z, rho=rho, f=f)
 
 
+def _worker_od_vtol(d, outp):
+    """kind = "odvtol": oracle.od_mpc_vtol.solve (optimal-decay MPC-CBF of VTOL2D); zz = [u (4 N) | rho (2 N)]."""
+    from oracle import od_mpc_vtol as OV
+    X, up, goal, obs = d["X"], d["up"], d["goal"], d["obs"]
+    over = d["params"].item() if "params" in d.files else {}
+    over = dict(over or {})
+    N = over.pop("N", 30)
+    B = X.shape[0]
+    u = np.zeros((B, 4)); st = np.zeros(B, dtype=np.int64); it = np.zeros(B, dtype=np.int64)
+    z = np.zeros((B, 4 * N)); rho = np.zeros((B, 2 * N)); f = np.zeros(B); gmin = np.zeros(B); err = np.zeros(B); lam = np.zeros(B)
+    for i in range(B):
+        u[i], _, st[i], it[i], info = OV.solve(X[i], up[i], goal[i], obs[i], N=N, params_over=over, return_info=True)
+        z[i], rho[i], f[i], gmin[i], err[i], lam[i] = info["zz"][: 4 * N], info["zz"][4 * N:], info["f"], info["g"].min(), info["err"], info["lam"].max()
+    np.savez(outp, u=u, st=st, it=it, z=z, rho=rho, f=f, gmin=gmin, err=err, lam=lam)
+
+
+def od_vtol_solve_many(X, up, goal, obs, params=None, workers=None, timeout=1800):
+    """oracle.od_mpc_vtol.solve on every row; dict(u, st, it, z, rho, f, gmin, err, lam)."""
+    return _run(dict(kind=np.array("odvtol")), X, up, goal, obs, params, workers, timeout)
+
+
 def family_problem(family, N=10, over=None):
     """(params, evaluate function) of one model family of workloads.MPC_FAMILIES for oracle.mpc_cbf.solve."""
     from oracle import mpc_cbf as M, mpc_gn as G, mpc_kb_state as S, mpc_lin as L
@@ -80,6 +101,8 @@ def _worker(inp, outp):
     sys.path.insert(0, ROOT)
     from oracle import mpc_cbf as M
     d = np.load(inp, allow_pickle=True)
+    if "kind" in d.files and str(d["kind"]) == "odvtol":
+        return _worker_od_vtol(d, outp)
     if "kind" in d.files and str(d["kind"]).startswith("od_"):
         return _worker_od_rd1(d, outp)
     if "kind" in d.files and str(d["kind"]).startswith("fam:"):

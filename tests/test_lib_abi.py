@@ -181,19 +181,21 @@ def test_header_is_plain_c(tmp_path):
                    '  printf("%zu %zu %zu\\n", sizeof(sc_manip_tracking_params), sizeof(sc_odcbfqp_params), sizeof(sc_backupcbf_params));\n'
                    '  printf("%zu\\n", sizeof(sc_quadtrack_params));\n'
                    '  printf("%zu %zu %zu %zu\\n", sizeof(sc_resto_params), sizeof(sc_mpcvtol_params), sizeof(sc_odmpcgn_params), sizeof(sc_mpc_slices));\n'
+                   '  printf("%zu\\n", sizeof(sc_odmpcvtol_params));\n'
                    '  printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(sc_mpccbf_params, resto), offsetof(sc_mpclin_params, resto), offsetof(sc_mpcgn_params, resto),\n'
                    '         offsetof(sc_mpcvtol_params, resto), offsetof(sc_mpcvtol_params, airframe), offsetof(sc_quadtrack_params, airframe));\n'
                    '  printf("%zu %zu %zu\\n", offsetof(sc_mpc_slices, order), offsetof(sc_mpc_slices, workspace), offsetof(sc_odmpcgn_params, omega_ref));\n'
+                   '  printf("%zu %zu\\n", offsetof(sc_odmpcvtol_params, omega_ref), offsetof(sc_odmpcvtol_params, p_sb));\n'
                    '  return 0;\n}\n')
     exe = tmp_path / "abi"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
     sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     mirrors = [_lib.CbfQpParams, _lib.MpcCbfParams, _lib.TrackingParams, _lib.ManipCbfQpParams, _lib.MpcLinParams, _lib.MpcGnParams,
                _lib.OdMpcCbfParams, _lib.ManipTrackingParams, _lib.OdCbfQpParams, _lib.BackupCbfParams, _lib.QuadTrackParams,
-               _lib.RestoParams, _lib.MpcVtolParams, _lib.OdMpcGnParams, _lib.MpcSlices]
+               _lib.RestoParams, _lib.MpcVtolParams, _lib.OdMpcGnParams, _lib.MpcSlices, _lib.OdMpcVtolParams]
     assert sizes[:len(mirrors)] == [C.sizeof(m) for m in mirrors]
     # field offsets of the blocks a padding or order mismatch would move
     offs = [_lib.MpcCbfParams.resto.offset, _lib.MpcLinParams.resto.offset, _lib.MpcGnParams.resto.offset, _lib.MpcVtolParams.resto.offset,
             _lib.MpcVtolParams.airframe.offset, _lib.QuadTrackParams.airframe.offset, _lib.MpcSlices.order.offset, _lib.MpcSlices.workspace.offset,
-            _lib.OdMpcGnParams.omega_ref.offset]
+            _lib.OdMpcGnParams.omega_ref.offset, _lib.OdMpcVtolParams.omega_ref.offset, _lib.OdMpcVtolParams.p_sb.offset]
     assert sizes[len(mirrors):] == offs

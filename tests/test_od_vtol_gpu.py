@@ -1,0 +1,120 @@
+"""GPU: optimal-decay MPC-CBF for VTOL2D -- the last model of the reference's accept list (position_control/optimal_decay_mpc_cbf.py:19)
+-- on the OD instantiation of csrc/mpc_vtol_wave.hip (decay block of a stage eliminated before the Riccati recursion), against
+oracle/od_mpc_vtol.py (condensed single shooting, dense Schur complement: a different linear algebra for the same Newton step).
+Extension label: the reference copy is stale and do-mpc / IPOPT are absent, so parity is oracle-only.
+
+Bar: same status on every problem; on every problem both call optimal |u0 - u0_oracle| <= 1e-6, |z - z_oracle| <= 2e-5 and
+|rho - rho_oracle| <= 2e-5."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import safe_control_amd as sca  # noqa: E402
+from safe_control_amd import workloads as W  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(__file__))
+from _oracle_pool import od_vtol_solve_many  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def t(a, dtype=torch.float64):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV)
+
+
+def hard_batch(n, K=8, seed=0):
+    """The vtol workload draws; every other one gets a disc on its flight path 10 - 30 m ahead, so that CBF rows are active and the
+    decay variables leave their reference (the closest ones have no feasible point)."""
+    X, up, goal, obs = (a[:n].copy() for a in W.mpc_family_batch("vtol", 4096, K, seed=seed))
+    rng = np.random.default_rng(seed + 100)
+    for i in range(0, n, 2):
+        r = rng.uniform(0.8, 1.6)
+        obs[i, 0, :3] = [X[i, 0] + 10.0 + 20.0 * rng.uniform() + r, X[i, 1] + rng.uniform(-1.0, 1.0), r]
+    return X, up, goal, obs
+
+
+def test_batch_against_oracle():
+    n = 48
+    X, up, goal, obs = hard_batch(n)
+    ctl = sca.BatchedOptimalDecayVtolMPCCBF(io_dtype="f64")
+    u, rho, st, it, z = ctl.solve(t(X), t(up), t(goal), t(obs), want_z=True)
+    torch.cuda.synchronize()
+    u, rho, st, it, z = (a.cpu().numpy() for a in (u, rho, st, it, z))
+    o = od_vtol_solve_many(X, up, goal, obs, timeout=3000)
+    same = st == o["st"]
+    ok = same & (o["st"] == 0)
+    du = np.abs(u - o["u"]).max(axis=1); dz = np.abs(z - o["z"]).max(axis=1); dr = np.abs(rho - o["rho"]).max(axis=1)
+    moved = np.abs(o["rho"] - 1.0).max(axis=1)
+    print(f"od vtol: optimal {np.mean(o['st'] == 0):.3f} infeasible {np.mean(o['st'] == 1):.3f} inaccurate {np.mean(o['st'] == 2):.3f}; "
+          f"status differs on {int((~same).sum())}; iterations equal on {np.mean(it == o['it']):.3f}, mean {o['it'].mean():.1f}; "
+          f"max du {du[ok].max():.2e} dz {dz[ok].max():.2e} drho {dr[ok].max():.2e}; decay moved > 1e-3 on {int((moved > 1e-3).sum())}, "
+          f"multiplier > 1e-3 on {int((o['lam'] > 1e-3).sum())}")
+    assert same.all(), np.flatnonzero(~same)
+    assert ok.mean() >= 0.75
+    assert du[ok].max() <= 1e-6 and dz[ok].max() <= 2e-5 and dr[ok].max() <= 2e-5
+    assert (moved[ok] > 1e-3).sum() >= 4, "the batch must hold problems whose decay variables leave the reference"
+
+
+def test_decay_variables_stay_at_reference_when_no_row_is_active_and_cost_is_absolute():
+    n = 8
+    X, up, goal, obs = (a[:n].copy() for a in W.mpc_family_batch("vtol", 64, 4, seed=3))
+    obs[:, :, 0] += 500.0                                                   # nothing near
+    ctl = sca.BatchedOptimalDecayVtolMPCCBF(io_dtype="f64")
+    u, rho, st, it = ctl.solve(t(X), t(up), t(goal), t(obs))
+    u2 = ctl.solve(t(X), t(up + 0.3), t(goal), t(obs))[0]
+    torch.cuda.synchronize()
+    assert (st == 0).all() and (rho - 1.0).abs().max().item() <= 1e-5    # (barrier-level pull of the far rows)
+    # R u^2: the previous input is not part of this class's cost (optimal_decay_mpc_cbf.py:173-174); it is only the start iterate
+    assert (u - u2).abs().max().item() <= 1e-6
+
+
+def test_f32_storage_and_k16_instantiation():
+    n = 16
+    X, up, goal, obs = hard_batch(n, K=10, seed=5)
+    c64, c32 = sca.BatchedOptimalDecayVtolMPCCBF(io_dtype="f64"), sca.BatchedOptimalDecayVtolMPCCBF(io_dtype="f32")
+    a32 = [a.astype(np.float32) for a in (X, up, goal, obs)]
+    u64, r64, s64, i64 = c64.solve(*[t(a.astype(np.float64)) for a in a32])
+    u32, r32, s32, i32 = c32.solve(*[t(a, torch.float32) for a in a32])
+    torch.cuda.synchronize()
+    assert torch.equal(s64, s32) and torch.equal(i64, i32)
+    assert (u64.float() - u32).abs().max().item() <= 1e-6 and (r64.float() - r32).abs().max().item() <= 1e-6
+    o = od_vtol_solve_many(X.astype(np.float32).astype(np.float64), *[a.astype(np.float64) for a in a32[1:]], timeout=3000)
+    assert np.array_equal(s64.cpu().numpy(), o["st"])
+    ok = o["st"] == 0
+    assert ok.mean() >= 0.5 and np.abs(u64.cpu().numpy() - o["u"])[ok].max() <= 1e-6
+
+
+def test_drop_in_class_routes_vtol2d():
+    from safe_control_amd.robots.spec import RobotHandle
+    spec = {"model": "VTOL2D"}
+    x0 = np.array([0.0, 10.0, 0.0, 12.0, 0.0, 0.0])
+    robot = RobotHandle(x0.reshape(-1, 1), spec, dt=0.05)
+    ctl = sca.OptimalDecayMPCCBF(robot, spec, num_obs=2)
+    assert type(ctl).__name__ == "OptimalDecayVtolMPCCBF" and ctl.horizon == 30 and ctl.n_controls == 4 and ctl.status == "optimal"
+    assert ctl.cbf_param["alpha1"] == 0.35 and ctl.cbf_param["p_sb1"] == 10.0
+    obsl = np.array([[30.0, 10.5, 1.5]])
+    ref = {"state_machine": "track", "goal": np.array([100.0, 10.0]), "u_ref": np.zeros((4, 1))}
+    u = ctl.solve_control_problem(robot.X, ref, obsl)
+    from oracle import mpc_cbf as M, od_mpc_vtol as OV
+    uo, ro, so, io, info = OV.solve(x0, np.zeros(4), ref["goal"], M.pad_obstacles(obsl, 2), spec=dict(radius=robot.robot_radius), return_info=True)
+    assert so == 0 and ctl.solver_status == "optimal" and abs(ctl.iterations - io) <= 1
+    assert np.abs(u.reshape(-1) - uo).max() <= 1e-6
+    assert abs(ctl.omega1 - ro[0]) <= 2e-5 and abs(ctl.omega2 - ro[1]) <= 2e-5
+    assert np.abs(ctl.rho - info["zz"][120:]).max() <= 2e-5
+    assert np.array_equal(ctl.solve_control_problem(robot.X, dict(ref, state_machine="stop"), obsl), ref["u_ref"])
+
+
+def test_argument_checks():
+    from safe_control_amd import _lib
+    ctl = sca.BatchedOptimalDecayVtolMPCCBF(io_dtype="f64")
+    X, up, goal, obs = (a[:4] for a in W.mpc_family_batch("vtol", 8, 3, seed=0))
+    with pytest.raises(ValueError):
+        ctl.solve(t(X[:, :4]), t(up), t(goal), t(obs))
+    ctl.cbf_param = dict(ctl.cbf_param, p_sb1=0.0)
+    with pytest.raises(_lib.HipLibraryError):
+        ctl.solve(t(X), t(up), t(goal), t(obs))
