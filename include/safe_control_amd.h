@@ -142,7 +142,8 @@ int sc_cbfqp_solve_batch_host(const sc_cbfqp_params* params, int64_t B, int32_t 
  * multipliers above 1e10) the kernels minimise  rho * sum_i t_i + sqrt(mu)/2 |z - z_R|^2  s.t.  g_i(z) + t_i >= 0, t_i >= 0
  * over the CBF rows i (state bounds and the input box stay hard) with the same primal-dual iteration, return to the regular
  * phase once the l1 violation has dropped to kappa * violation(z_R), and report SC_STATUS_INFEASIBLE only when the restoration
- * CONVERGES with a violation above theta_tol: the returned input is then that minimiser of the violation.  Any other
+ * CONVERGES with a violation above theta_tol: the returned input is then that minimiser of the violation -- or when it STALLS
+ * with violation left (retry_max, stall_iter, stall_theta below; round 4).  Any other
  * unsuccessful exit is SC_STATUS_INACCURATE.  oracle/mpc_cbf.py: solve is the float64 statement of the same steps.       */
 typedef struct sc_resto_params {
     double  rho;             /* l1 penalty of the elastic variables (IPOPT: 1000)                                    */
@@ -156,6 +157,13 @@ typedef struct sc_resto_params {
     int32_t slack_reset;     /* 1: the restoration's line search sets the slack of a row to g + t where that is >= mu / nu, the
                               * minimiser of its merit function in s for fixed z, t (default; turns most restorations that crawled
                               * to the iteration limit into certificates); 0: off                                     */
+    int32_t retry_max;       /* a restoration step whose line search fails is retried from the same iterate with a Levenberg-damped
+                              * Newton system, delta >= 1, 1e2, 1e4, ... (each retry is one iteration), this many times before the
+                              * solve gives up (3); 0: give up at once (round 3)                                       */
+    double  stall_theta;     /* a restoration that has not lowered the l1 violation by 1 % within stall_iter iterations while the  */
+    int32_t stall_iter;      /*   violation is above stall_theta stops with SC_STATUS_INFEASIBLE: a local minimiser of the violation
+                              *   at a kink of the rows, where no KKT error goes to zero (1e-3, 40); stall_iter = 0: off.
+                              *   The one-NLP-per-lane VTOL2D cross-check kernel supports neither (retry_max = stall_iter = 0).  */
     int32_t reserved;
 } sc_resto_params;
 

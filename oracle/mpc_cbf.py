@@ -40,7 +40,8 @@ DEFAULTS = dict(N=10, dt=0.05, Q=(50.0, 50.0, 0.01, 30.0), R=(0.5, 0.5), alpha1=
                 v_max=1.0, a_max=1.0, w_max=0.5, radius=0.25, beta=1.01,
                 tol=1e-6, acceptable_tol=1e-5, acceptable_iter=15, max_iter=3000, mu_init=0.1, mu_min=1e-9,
                 resto_rho=1000.0, resto_kappa=0.1, resto_theta_tol=1e-6, resto_max=2, resto_tol=1e-2,
-                resto_small_alpha=0.02, resto_small_iter=4, resto_slack_reset=True)
+                resto_small_alpha=0.02, resto_small_iter=4, resto_slack_reset=True,
+                resto_retry=3, resto_stall_iter=40, resto_stall_theta=1e-3)
 
 DUMMY_OBS = np.array([1000.0, 1000.0, 0.0, 0.0, 0.0, 0.0, 0.0])
 
@@ -315,6 +316,14 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     g_i + t_i inside the restoration; on by default, off for VTOL2D) switch it on.  A row whose curvature beat its
     linearisation -- a far obstacle's row, never active -- is then not charged for it, which is what kept those models'
     searches at step lengths of 1e-3 and their restorations crawling to the iteration limit.
+    Stalled restorations (round 4).  A restoration whose line search fails is retried from the same z with a Levenberg-damped
+    step, delta >= 1, 1e2, 1e4 (P["resto_retry"] = 3 retries, each one iteration; the damping decays through the inertia
+    correction's memory delta_last / 3 like a shrinking trust region): the plateaus where the Newton direction of the minimal
+    inertia correction makes no progress are left this way, towards a proper stationary point of the violation or back to the
+    regular phase.  A restoration that has not lowered theta by 1 % within P["resto_stall_iter"] = 40 iterations while theta >
+    P["resto_stall_theta"] = 1e-3 is stopped with STATUS_INFEASIBLE: it sits at a local minimiser of the violation at a kink of the
+    rows (C3BF's sqrt(max(|p|^2 - r^2, 0))), where no KKT error goes to zero and the steps crawl at lengths of 1e-3 for the rest of
+    the budget (tests/test_oracle_mpc_resto.py: an independent phase-1 finds no feasible plan for such problems).
     Every other unsuccessful exit is STATUS_INACCURATE.
     """
     P = dict(DEFAULTS)
@@ -354,6 +363,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     resto = False
     rho_R, kappa_R, theta_tol = P["resto_rho"], P["resto_kappa"], P["resto_theta_tol"]
     n_resto, it_resto, theta_R, mu_reg, z_R = 0, 0, 0.0, mu, z.copy()
+    delta_force, n_retry, theta_ref, n_stall, n_stalled = 0.0, 0, 0.0, 0, 0     # stalled restorations: damped retries, stall counter
     n_small = 0                                                             # consecutive regular iterations with a tiny step at an infeasible z
     SF_OFF = 1e-40                                                          # "no objective": evaluate() divides lam by it
     el = np.arange(m) < m_el
@@ -400,6 +410,14 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
                 break
             if e_opt <= P["tol"]:                                           # solved, and (nearly) no violation left: nothing to certify
                 break
+            if P["resto_stall_iter"] > 0:
+                if theta <= 0.99 * theta_ref:
+                    theta_ref, n_stall = theta, 0
+                else:
+                    n_stall += 1
+                    if n_stall >= P["resto_stall_iter"] and theta > P["resto_stall_theta"]:
+                        status, n_stalled = STATUS_INFEASIBLE, 1           # stalled at a kink of the rows with violation left
+                        break
         elif e_opt <= P["tol"]:
             status = STATUS_OPTIMAL
             break
@@ -431,7 +449,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
                 sig = np.where(el, se, sig)
             Mb = W + J.T @ (sig[:, None] * J)
             rhs = -grad + J.T @ (lam + dl0)
-            delta = 0.0
+            delta = delta_force                                             # 0 unless a failed restoration step is being retried
             L = None
             for _try in range(40):                                          # inertia correction
                 try:
@@ -518,7 +536,11 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
                                        theta=violation(g, m_el), z=z.copy()))
             if not accepted:
                 if resto:
-                    break
+                    if n_retry >= P["resto_retry"]:
+                        break
+                    # the same z again, Levenberg-damped (the retry is an iteration of its own: everything is re-evaluated)
+                    n_retry, delta_force = n_retry + 1, max(1.0, 100.0 * max(delta_force, delta))
+                    continue
                 want_resto = True
             elif not resto:
                 # IPOPT enters the restoration when the step length falls below its alpha_min; here: resto_small_iter consecutive
@@ -533,6 +555,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
             if e_best <= P["acceptable_tol"] or theta_R <= theta_tol or n_resto >= P["resto_max"]:
                 break
             resto, n_resto, it_resto, n_small = True, n_resto + 1, it, 0
+            delta_force, n_retry, theta_ref, n_stall = 0.0, 0, theta_R, 0
             z_R, mu_reg = z.copy(), mu
             mu = max(mu, float(np.max(np.maximum(0.0, -g[:m_el]))))        # IPOPT: mu_R = max(mu, |c|_inf)
             s = np.where(el, _resto_central_path(g, mu, rho_R), np.maximum(g, 1e-2))   # elastic rows start on their central path,
@@ -541,6 +564,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
             nu, n_acc = 10.0, 0
             continue
         z, s = z + alpha * dz, (st if (sreset and not resto) or (sreset_r and resto) else s + alpha * ds)
+        delta_force, n_retry = 0.0, 0
         lam = lam + ad * dlam
         lam = np.minimum(np.maximum(lam, mu / (1e10 * s)), 1e10 * mu / s)   # IPOPT eq. (16) safeguard
         if resto:
@@ -557,6 +581,6 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     u0 = z[0:P.get("nu", 2)].copy()
     if return_info:
         return u0, status, it, dict(z=z, X=ev["X"], f=ev["f"], g=ev["g"], lam=lam / sf0, s=s, err=err, mu=mu,
-                                    n_eval=n_eval, scale=sf0, obs=obs, n_resto=n_resto, it_resto=it_resto, in_resto=resto,
+                                    n_eval=n_eval, scale=sf0, obs=obs, n_resto=n_resto, it_resto=it_resto, in_resto=resto, stalled=n_stalled,
                                     theta=violation(ev["g"], m_el))
     return u0, status, it

@@ -77,13 +77,15 @@ class RestoParams(C.Structure):
     """Mirror of ``sc_resto_params``: the feasibility-restoration phase of the MPC interior point."""
     _fields_ = [("rho", C.c_double), ("kappa", C.c_double), ("theta_tol", C.c_double), ("tol", C.c_double),
                 ("small_alpha", C.c_double), ("small_iter", C.c_int32), ("max_entries", C.c_int32), ("slack_reset", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("retry_max", C.c_int32), ("stall_theta", C.c_double), ("stall_iter", C.c_int32), ("reserved", C.c_int32)]
 
 
 def default_resto(**over):
     """IPOPT's penalty (1000), return at a tenth of the violation, certificate threshold 1e-6, restoration tolerance 1e-2 (in units of rho * violation),
-    hand-over after 4 steps shorter than 0.02, at most two entries, slack reset in the restoration's line search (oracle/mpc_cbf.py: DEFAULTS)."""
-    r = RestoParams(rho=1000.0, kappa=0.1, theta_tol=1e-6, tol=1e-2, small_alpha=0.02, small_iter=4, max_entries=2, slack_reset=1)
+    hand-over after 4 steps shorter than 0.02, at most two entries, slack reset in the restoration's line search, three damped retries of a
+    failed restoration step, stall certificate after 40 iterations without 1 % less violation above 1e-3 (oracle/mpc_cbf.py: DEFAULTS)."""
+    r = RestoParams(rho=1000.0, kappa=0.1, theta_tol=1e-6, tol=1e-2, small_alpha=0.02, small_iter=4, max_entries=2, slack_reset=1,
+                    retry_max=3, stall_theta=1e-3, stall_iter=40)                # (round 4: damped retries, stall certificate)
     for k, v in over.items():
         setattr(r, k, v)
     return r

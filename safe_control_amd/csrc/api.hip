@@ -159,6 +159,8 @@ static int check_cbfqp(const sc_cbfqp_params* p, int64_t B, int32_t K, const voi
 static int check_resto(const sc_resto_params& r) {
     if (r.max_entries < 0) return fail(SC_ERR_INVALID_ARGUMENT, "resto.max_entries must be >= 0");
     if (r.slack_reset != 0 && r.slack_reset != 1) return fail(SC_ERR_INVALID_ARGUMENT, "resto.slack_reset must be 0 or 1");
+    if (r.retry_max < 0 || r.retry_max > 8) return fail(SC_ERR_INVALID_ARGUMENT, "resto.retry_max must be in [0, 8]");
+    if (r.stall_iter < 0 || (r.stall_iter > 0 && !(r.stall_theta > 0))) return fail(SC_ERR_INVALID_ARGUMENT, "resto: stall_iter >= 0, stall_theta > 0 with stall_iter > 0");
     if (r.max_entries == 0) return SC_OK;
     if (!(r.rho > 0) || !(r.kappa > 0 && r.kappa < 1) || !(r.theta_tol > 0) || !(r.tol > 0) || !(r.small_alpha >= 0) || r.small_iter < 1)
         return fail(SC_ERR_INVALID_ARGUMENT, "resto: rho > 0, 0 < kappa < 1, theta_tol > 0, tol > 0, small_alpha >= 0, small_iter >= 1 "
@@ -275,6 +277,8 @@ static int check_mpcvtol(const sc_mpcvtol_params* p, int64_t B, int32_t K, const
     if (p->kernel == 2 && !mpcvtol_uses_wave(*p, K)) return fail(SC_ERR_UNSUPPORTED, "the wave-per-problem kernel serves K <= 16, horizon <= 64");
     if (B > 0 && (!X || !u_prev || !goal || !obs || !u_out || !status_out)) return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
+    if (p->resto.retry_max != 0 || p->resto.stall_iter != 0)
+        return fail(SC_ERR_UNSUPPORTED, "the VTOL2D kernels run the restoration without damped retries and without the stall certificate (resto.retry_max = resto.stall_iter = 0)");
     return check_resto(p->resto);
 }
 static int check_manip(const sc_manip_cbfqp_params* p, int64_t B, int32_t K, const void* X, const void* u_ref,

@@ -893,6 +893,10 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
     bool resto = false;
     int n_resto = 0, n_small = 0;                                       // n_small: consecutive tiny accepted steps at an infeasible z
     double theta_R = 0.0, mu_reg = mu;
+    // stalled restorations (sc_resto_params.retry_max / stall_iter; oracle/mpc_cbf.py: solve): the damping a retried step starts its
+    // inertia correction with, retries so far at this iterate, the violation the stall counter measures against, iterations since
+    double delta_force = 0.0, theta_ref = 0.0;
+    int n_retry = 0, n_stall = 0;
     if (ct.resume) {
         // the state a previous launch left (mpc_cont.hpp): [scalars | z | zb | sl | lam | obs | tel | rho | rhob]
         const double* a = cst + ipm::CONT_SCALARS;
@@ -906,6 +910,7 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         if constexpr (OD) { ipm::cont_copy(W.rho, a, n, lane, 64); a += n; ipm::cont_copy(W.rhob, a, n, lane, 64); }
         it0 = (int)cst[0] + 1; mu = cst[1]; nu = cst[2]; delta_last = cst[3]; e_best = cst[4]; n_acc = (int)cst[5];
         resto = cst[6] != 0.0; n_resto = (int)cst[7]; n_small = (int)cst[8]; theta_R = cst[9]; mu_reg = cst[10]; sf = cst[11];
+        delta_force = cst[12]; n_retry = (int)cst[13]; theta_ref = cst[14]; n_stall = (int)cst[15];
         SC_SYNC();
     } else {
     const size_t obase = p.obs_shared ? 0 : (size_t)prob * K * 7;
@@ -1000,6 +1005,13 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
                 // certificate asks for more violation than that.
                 if (e_opt <= p.resto.tol && theta > fmax(p.resto.theta_tol, 10.0 * e_opt / rho_R)) { status = SC_STATUS_INFEASIBLE; stop = true; break; }
                 if (e_opt <= p.tol) { stop = true; break; }                             // solved, and (nearly) no violation left: nothing to certify
+                if (p.resto.stall_iter > 0) {
+                    // no 1 % less violation within stall_iter iterations and violation left: a local minimiser of the violation at a kink
+                    const bool less = theta <= 0.99 * theta_ref;                  // (selects, not branches: the values are wave-uniform)
+                    theta_ref = less ? theta : theta_ref;
+                    n_stall = less ? 0 : n_stall + 1;
+                    if (n_stall >= p.resto.stall_iter && theta > p.resto.stall_theta) { status = SC_STATUS_INFEASIBLE; stop = true; break; }
+                }
             } else if (e_opt <= p.tol) {
                 status = SC_STATUS_OPTIMAL;
                 stop = true; break;
@@ -1048,7 +1060,7 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         SC_SYNC();
         SC_PH(6);
         // inertia correction: M + delta I until the Cholesky succeeds (restoration: + zeta I, the proximity term)
-        double delta = 0.0;
+        double delta = delta_force;                                      // 0 unless a failed restoration step is being retried
         bool ok = false;
         if constexpr (NT > 0) {
             constexpr int nn = NT > 0 ? 2 * NT : 2;
@@ -1217,7 +1229,16 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
             alpha *= 0.5;
         }
         if (!accepted) {
-            if (!RESTO || resto) break;
+            if (!RESTO) break;
+            if (resto) {
+                if (n_retry >= p.resto.retry_max) break;
+                // the same z again, Levenberg-damped; the retry is an iteration of its own (W.g holds the last trial point's rows)
+                ++n_retry; delta_force = fmax(1.0, 100.0 * fmax(delta_force, delta));
+                SC_SYNC();
+                eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, false, pf, 16);
+                SC_SYNC();
+                continue;
+            }
             want_resto = true;
         } else if (RESTO && !resto) {
             // IPOPT hands over to the restoration when the step length falls below its alpha_min; here: small_iter consecutive
@@ -1233,6 +1254,7 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
             SC_SYNC();
             eval_values<ROW16, OD, UNI>(W.z, W.rho, W, c, lane, false, pf, 16);   // W.g holds the last trial point's rows
             resto = true; ++n_resto; n_small = 0; theta_R = theta; mu_reg = mu;
+            delta_force = 0.0; n_retry = 0; theta_ref = theta; n_stall = 0;
             double vmax = 0.0;
             for (int i = lane; i < c.mc; i += 64) vmax = fmax(vmax, -W.g[i]);
             mu = fmax(mu, wmax(vmax));                                   // IPOPT: mu_R = max(mu, |c|_inf)
@@ -1252,6 +1274,7 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
             W.z[i] = W.z[i] + alpha * W.dz[i];
             if constexpr (OD) W.rho[i] = W.rho[i] + alpha * W.drho[i];
         }
+        delta_force = 0.0; n_retry = 0;
         {
         const bool rreset = RESTO && resto && p.resto.slack_reset != 0;   // W.g holds the accepted trial point's rows
         const double thr_reset = mu * rcp_(nu);
@@ -1291,6 +1314,7 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         if (lane == 0) {
             cst[0] = (double)(it - 1); cst[1] = mu; cst[2] = nu; cst[3] = delta_last; cst[4] = e_best; cst[5] = (double)n_acc;
             cst[6] = resto ? 1.0 : 0.0; cst[7] = (double)n_resto; cst[8] = (double)n_small; cst[9] = theta_R; cst[10] = mu_reg; cst[11] = sf;
+            cst[12] = delta_force; cst[13] = (double)n_retry; cst[14] = theta_ref; cst[15] = (double)n_stall;
             status_out[prob] = SC_STATUS_PENDING_MPC;
             if (iters_out) iters_out[prob] = it - 1;
             ipm::cont_push(ct, prob, th > p.resto.theta_tol);

@@ -855,6 +855,9 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
     bool resto = false;
     int n_resto = 0, n_small = 0;                                       // n_small: consecutive tiny accepted steps at an infeasible z
     double theta_R = 0.0, mu_reg = mu;
+    // stalled restorations (sc_resto_params.retry_max / stall_iter; oracle/mpc_cbf.py: solve)
+    double delta_force = 0.0, theta_ref = 0.0;
+    int n_retry = 0, n_stall = 0;
     if (SC_CONT_LEVEL >= 2 && ct.resume) {
         // the state a previous launch left: [scalars | z | zb | s | lam | obs | tel | rho | rhob]
         const double* a = cst + ipm::CONT_SCALARS;
@@ -867,6 +870,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         if constexpr (OD) { ipm::cont_copy(W.rho, a, n, lane, 64); a += n; ipm::cont_copy(W.rhob, a, n, lane, 64); }
         it0 = (int)cst[0] + 1; mu = cst[1]; nu_m = cst[2]; delta_last = cst[3]; e_best = cst[4]; n_acc = (int)cst[5];
         resto = cst[6] != 0.0; n_resto = (int)cst[7]; n_small = (int)cst[8]; theta_R = cst[9]; mu_reg = cst[10]; sf = cst[11];
+        delta_force = cst[12]; n_retry = (int)cst[13]; theta_ref = cst[14]; n_stall = (int)cst[15];
         SC_SYNC();
     } else {
     if (!c.circles_only) ipm::normalise_obstacle_flags(W.obs, K, lane, 64);
@@ -995,6 +999,13 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             // certificate asks for more violation than that.
             if (e_opt <= p.resto.tol && theta > fmax(p.resto.theta_tol, 10.0 * e_opt / rho_R)) { status = SC_STATUS_INFEASIBLE; break; }
             if (e_opt <= p.tol) { break; }                             // solved, and (nearly) no violation left: nothing to certify
+            if (p.resto.stall_iter > 0) {
+                // no 1 % less violation within stall_iter iterations and violation left: a local minimiser of the violation at a kink
+                const bool less = theta <= 0.99 * theta_ref;                  // (selects, not branches: the values are wave-uniform)
+                theta_ref = less ? theta : theta_ref;
+                n_stall = less ? 0 : n_stall + 1;
+                if (n_stall >= p.resto.stall_iter && theta > p.resto.stall_theta) { status = SC_STATUS_INFEASIBLE; break; }
+            }
         } else if (e_opt <= p.tol) {
             status = SC_STATUS_OPTIMAL;
             break;
@@ -1187,7 +1198,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         }
         SC_SYNC();
         GP(6);
-        double delta = 0.0;
+        double delta = delta_force;                                      // 0 unless a failed restoration step is being retried
         bool ok = false;
         for (int t = 0; t < 40 && !ok; ++t) {
             if constexpr (NT > 0) {
@@ -1360,7 +1371,16 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         GT(21, accepted ? 1.0 : 0.0);
         GP(9);
         if (!accepted) {
-            if (!RESTO || resto) break;
+            if (!RESTO) break;
+            if (resto) {
+                if (n_retry >= p.resto.retry_max) break;
+                // the same z again, Levenberg-damped; the retry is an iteration of its own (W.g holds the last trial point's rows)
+                ++n_retry; delta_force = fmax(1.0, 100.0 * fmax(delta_force, delta));
+                SC_SYNC();
+                gn_eval_any<MODEL, OD>(W.z, W, d, c, q, lane, false, W.rho);
+                SC_SYNC();
+                continue;
+            }
             want_resto = true;
         } else if (RESTO && !resto) {
             // IPOPT hands over to the restoration when the step length falls below its alpha_min; here: small_iter consecutive
@@ -1376,6 +1396,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             SC_SYNC();
             gn_eval_any<MODEL, OD>(W.z, W, d, c, q, lane, false, W.rho);    // W.g holds the last trial point's rows
             resto = true; ++n_resto; n_small = 0; theta_R = theta; mu_reg = mu;
+            delta_force = 0.0; n_retry = 0; theta_ref = theta; n_stall = 0;
             double vmax = 0.0;
             for (int i = lane; i < d.mc; i += 64) vmax = fmax(vmax, -W.g[i]);
             mu = fmax(mu, gmax_(vmax));                                     // IPOPT: mu_R = max(mu, |c|_inf)
@@ -1395,6 +1416,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
             W.z[i] = W.z[i] + alpha * W.dz[i];
             if constexpr (OD) W.rho[i] = W.rho[i] + alpha * W.drho[i];
         }
+        delta_force = 0.0; n_retry = 0;
         for (int i = lane; i < m; i += 64) {
             const double s_lin = W.s[i] + alpha * W.ds[i];                     // W.g holds the accepted trial point's rows
             const double l0 = W.lam[i], dl = W.dlam[i];
@@ -1428,6 +1450,7 @@ __global__ __launch_bounds__(64) void mpcgn_kernel(const sc_mpcgn_params p, cons
         if (lane == 0) {
             cst[0] = (double)(it - 1); cst[1] = mu; cst[2] = nu_m; cst[3] = delta_last; cst[4] = e_best; cst[5] = (double)n_acc;
             cst[6] = resto ? 1.0 : 0.0; cst[7] = (double)n_resto; cst[8] = (double)n_small; cst[9] = theta_R; cst[10] = mu_reg; cst[11] = sf;
+            cst[12] = delta_force; cst[13] = (double)n_retry; cst[14] = theta_ref; cst[15] = (double)n_stall;
             status_out[prob] = SC_STATUS_PENDING_MPC;
             if (iters_out) iters_out[prob] = it - 1;
             ipm::cont_push(ct, prob, th > p.resto.theta_tol);

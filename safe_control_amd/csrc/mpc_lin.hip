@@ -417,6 +417,9 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
     bool resto = false;
     int n_resto = 0, n_small = 0;                                       // n_small: consecutive tiny accepted steps at an infeasible z
     double theta_R = 0.0, mu_reg = mu;
+    // stalled restorations (sc_resto_params.retry_max / stall_iter; oracle/mpc_cbf.py: solve)
+    double delta_force = 0.0, theta_ref = 0.0;
+    int n_retry = 0, n_stall = 0;
     if (ct.resume) {
         // the state a previous launch left: [scalars | z | zb | s | lam | obs | gs or clin | tel | rho | rhob]
         const double* a = cst + ipm::CONT_SCALARS;
@@ -430,6 +433,7 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         if constexpr (OD) { ipm::cont_copy(W.rho, a, N, lane, TH); a += N; ipm::cont_copy(W.rhob, a, N, lane, TH); }
         it0 = (int)cst[0] + 1; mu = cst[1]; nu_m = cst[2]; delta_last = cst[3]; e_best = cst[4]; n_acc = (int)cst[5];
         resto = cst[6] != 0.0; n_resto = (int)cst[7]; n_small = (int)cst[8]; theta_R = cst[9]; mu_reg = cst[10]; sf = cst[11];
+        delta_force = cst[12]; n_retry = (int)cst[13]; theta_ref = cst[14]; n_stall = (int)cst[15];
         SC_SYNC();
     } else {
     if (!c.circles_only) ipm::normalise_obstacle_flags(W.obs, K, lane, TH);
@@ -556,6 +560,13 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
             // certificate asks for more violation than that.
             if (e_opt <= p.resto.tol && theta > fmax(p.resto.theta_tol, 10.0 * e_opt / rho_R)) { status = SC_STATUS_INFEASIBLE; break; }
             if (e_opt <= p.tol) { break; }                             // solved, and (nearly) no violation left: nothing to certify
+            if (p.resto.stall_iter > 0) {
+                // no 1 % less violation within stall_iter iterations and violation left: a local minimiser of the violation at a kink
+                const bool less = theta <= 0.99 * theta_ref;                  // (selects, not branches: the values are wave-uniform)
+                theta_ref = less ? theta : theta_ref;
+                n_stall = less ? 0 : n_stall + 1;
+                if (n_stall >= p.resto.stall_iter && theta > p.resto.stall_theta) { status = SC_STATUS_INFEASIBLE; break; }
+            }
         } else if (e_opt <= p.tol) {
             status = SC_STATUS_OPTIMAL;
             break;
@@ -668,7 +679,7 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         }
         LP(6);
         // inertia correction: M + delta I until the Cholesky succeeds (restoration: + zeta I, the proximity term)
-        double delta = 0.0;
+        double delta = delta_force;                                      // 0 unless a failed restoration step is being retried
         bool ok = false;
         for (int t = 0; t < 40 && !ok; ++t) {
             if constexpr (NN > 0) {
@@ -819,7 +830,17 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         }
         LP(9);
         if (!accepted) {
-            if (!RESTO || resto) break;
+            if (!RESTO) break;
+            if (resto) {
+                if (n_retry >= p.resto.retry_max) break;
+                // the same z again, Levenberg-damped; the retry is an iteration of its own (LDS holds the last trial point's rows)
+                ++n_retry; delta_force = fmax(1.0, 100.0 * fmax(delta_force, delta));
+                SC_SYNC();
+                f = lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, true, R);
+                fresh = true;
+                SC_SYNC();
+                continue;
+            }
             want_resto = true;
         } else if (RESTO && !resto) {
             // IPOPT hands over to the restoration when the step length falls below its alpha_min; here: small_iter consecutive
@@ -836,6 +857,7 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
             f = lin_eval<TH, OD>(W.z, W.rho, W, d, c, lane, true, R);       // the rows and derivatives in LDS are the last trial point's
             fresh = true;
             resto = true; ++n_resto; n_small = 0; theta_R = theta; mu_reg = mu;
+            delta_force = 0.0; n_retry = 0; theta_ref = theta; n_stall = 0;
             double vmax = 0.0;
             for (int i = lane; i < d.mc; i += TH) vmax = fmax(vmax, -W.g[i]);
             mu = fmax(mu, lmax_<TH>(vmax, R));                              // IPOPT: mu_R = max(mu, |c|_inf)
@@ -856,6 +878,7 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
             if constexpr (!LEAN) { if (!(RESTO && resto)) W.gs[i] += alpha * sf * W.rd[i]; }
         }
         if constexpr (OD) for (int k = lane; k < N; k += TH) W.rho[k] = W.rho[k] + alpha * W.drho[k];
+        delta_force = 0.0; n_retry = 0;
         {
         const bool rreset = RESTO && resto && p.resto.slack_reset != 0;   // W.g holds the accepted trial point's rows
         const double thr_reset = mu * rcp_(nu_m);
@@ -894,6 +917,7 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         if (lane == 0) {
             cst[0] = (double)(it - 1); cst[1] = mu; cst[2] = nu_m; cst[3] = delta_last; cst[4] = e_best; cst[5] = (double)n_acc;
             cst[6] = resto ? 1.0 : 0.0; cst[7] = (double)n_resto; cst[8] = (double)n_small; cst[9] = theta_R; cst[10] = mu_reg; cst[11] = sf;
+            cst[12] = delta_force; cst[13] = (double)n_retry; cst[14] = theta_ref; cst[15] = (double)n_stall;
             status_out[prob] = SC_STATUS_PENDING_MPC;
             if (iters_out) iters_out[prob] = it - 1;
             ipm::cont_push(ct, prob, th > p.resto.theta_tol);

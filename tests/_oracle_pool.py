@@ -84,16 +84,38 @@ def _worker_family(d, outp):
     B = X.shape[0]
     nu = up.shape[1]
     u = np.zeros((B, nu)); st = np.zeros(B, dtype=np.int64); it = np.zeros(B, dtype=np.int64); z = np.zeros((B, nu * N))
-    theta = np.zeros(B); nr = np.zeros(B, dtype=np.int64); err = np.zeros(B)
+    theta = np.zeros(B); nr = np.zeros(B, dtype=np.int64); err = np.zeros(B); stalled = np.zeros(B, dtype=np.int64)
     for i in range(B):
         P, ev = family_problem(fam, N, over)
         u[i], st[i], it[i], info = M.solve(X[i], up[i], goal[i], obs[i], params=P, return_info=True, evaluate_fn=ev)
-        z[i], theta[i], nr[i], err[i] = info["z"], info["theta"], info["n_resto"], info["err"]
-    np.savez(outp, u=u, st=st, it=it, z=z, theta=theta, n_resto=nr, err=err)
+        z[i], theta[i], nr[i], err[i], stalled[i] = info["z"], info["theta"], info["n_resto"], info["err"], info.get("stalled", 0)
+    np.savez(outp, u=u, st=st, it=it, z=z, theta=theta, n_resto=nr, err=err, stalled=stalled)
+
+
+def _worker_phase1(d, outp):
+    """kind = "p1:<family>": an independent feasibility search (tests/test_oracle_mpc_resto.py: phase_one) from the plan `z` a solver
+    returned: best min_i g_i over the CBF rows it reaches."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_mpc_resto import phase_one
+    fam = str(d["kind"])[3:]
+    X, up, goal, obs, Z = d["X"], d["up"], d["goal"], d["obs"], d["z"]
+    over = d["params"].item() if "params" in d.files else {}
+    starts = int((over or {}).get("starts", 8))
+    best = np.zeros(X.shape[0])
+    for i in range(X.shape[0]):
+        P, ev = family_problem(fam, 10, {})
+        info = dict(z=Z[i], obs=obs[i])
+        best[i] = phase_one(X[i], up[i], goal[i], P, ev, info, starts=starts)
+    np.savez(outp, best=best)
+
+
+def phase_one_many(family, X, up, goal, obs, z, starts=8, workers=None, timeout=3000):
+    """phase_one on every row, from the plans `z`; returns best min g per row."""
+    return _run(dict(kind=np.array("p1:" + family), z=z), X, up, goal, obs, dict(starts=starts), workers, timeout)["best"]
 
 
 def family_solve_many(family, X, up, goal, obs, params=None, workers=None, timeout=1800):
-    """oracle.mpc_cbf.solve with the problem functions of `family` on every row; dict(u, st, it, z, theta, n_resto, err)."""
+    """oracle.mpc_cbf.solve with the problem functions of `family` on every row; dict(u, st, it, z, theta, n_resto, err, stalled)."""
     return _run(dict(kind=np.array("fam:" + family)), X, up, goal, obs, params, workers, timeout)
 
 
@@ -105,6 +127,8 @@ def _worker(inp, outp):
         return _worker_od_vtol(d, outp)
     if "kind" in d.files and str(d["kind"]).startswith("od_"):
         return _worker_od_rd1(d, outp)
+    if "kind" in d.files and str(d["kind"]).startswith("p1:"):
+        return _worker_phase1(d, outp)
     if "kind" in d.files and str(d["kind"]).startswith("fam:"):
         return _worker_family(d, outp)
     X, up, goal, obs = d["X"], d["up"], d["goal"], d["obs"]
@@ -138,7 +162,8 @@ def _run(extra, X, up, goal, obs, params, workers, timeout):
         for w in range(workers):
             a, b = edges[w], edges[w + 1]
             inp, outp = os.path.join(tmp, f"in{w}.npz"), os.path.join(tmp, f"out{w}.npz")
-            kw = dict(extra, X=X[a:b], up=up[a:b], goal=goal[a:b], obs=obs[a:b])
+            per_row = {k: (v[a:b] if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == B else v) for k, v in extra.items()}
+            kw = dict(per_row, X=X[a:b], up=up[a:b], goal=goal[a:b], obs=obs[a:b])
             if params is not None:
                 kw["params"] = np.array(params, dtype=object)
             np.savez(inp, **kw)

@@ -186,6 +186,7 @@ def test_header_is_plain_c(tmp_path):
                    '         offsetof(sc_mpcvtol_params, resto), offsetof(sc_mpcvtol_params, airframe), offsetof(sc_quadtrack_params, airframe));\n'
                    '  printf("%zu %zu %zu\\n", offsetof(sc_mpc_slices, order), offsetof(sc_mpc_slices, workspace), offsetof(sc_odmpcgn_params, omega_ref));\n'
                    '  printf("%zu %zu\\n", offsetof(sc_odmpcvtol_params, omega_ref), offsetof(sc_odmpcvtol_params, p_sb));\n'
+                   '  printf("%zu %zu %zu\\n", offsetof(sc_resto_params, retry_max), offsetof(sc_resto_params, stall_theta), offsetof(sc_resto_params, stall_iter));\n'
                    '  return 0;\n}\n')
     exe = tmp_path / "abi"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
@@ -197,5 +198,6 @@ def test_header_is_plain_c(tmp_path):
     # field offsets of the blocks a padding or order mismatch would move
     offs = [_lib.MpcCbfParams.resto.offset, _lib.MpcLinParams.resto.offset, _lib.MpcGnParams.resto.offset, _lib.MpcVtolParams.resto.offset,
             _lib.MpcVtolParams.airframe.offset, _lib.QuadTrackParams.airframe.offset, _lib.MpcSlices.order.offset, _lib.MpcSlices.workspace.offset,
-            _lib.OdMpcGnParams.omega_ref.offset, _lib.OdMpcVtolParams.omega_ref.offset, _lib.OdMpcVtolParams.p_sb.offset]
+            _lib.OdMpcGnParams.omega_ref.offset, _lib.OdMpcVtolParams.omega_ref.offset, _lib.OdMpcVtolParams.p_sb.offset,
+            _lib.RestoParams.retry_max.offset, _lib.RestoParams.stall_theta.offset, _lib.RestoParams.stall_iter.offset]
     assert sizes[len(mirrors):] == offs

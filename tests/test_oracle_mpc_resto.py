@@ -120,3 +120,28 @@ def test_restoration_minimises_the_violation_of_a_blocked_agent():
     brake = np.tile([-P["a_max"], 0.0], P["N"])
     assert info["theta"] <= viol(np.zeros(2 * P["N"])) and info["theta"] <= viol(brake) + 1e-4   # (restoration tolerance: |grad theta| <= 1e-5)
     assert u[0] < -0.5                                           # it brakes
+
+
+def test_stalled_restorations_are_finished_or_certified():
+    """Round 4 (oracle/mpc_cbf.py: solve, "Stalled restorations").  C3BF bench draws whose restoration used to quit with
+    `optimal_inaccurate` after a failed line search: draw 67 is a FEASIBLE problem -- the Levenberg-damped retries leave the plateau at
+    theta = 0.54 and the solve ends optimal; draw 24 reaches a proper stationary point of the violation (theta 0.86 -> 0.32); draw 46
+    crawls at a kink of the cone row (theta constant to four digits for as long as it is given) and ends with the stall certificate, for
+    which the independent phase-1 finds no feasible plan.  With both rules switched off the three end as in round 3."""
+    X, up, goal, obs = W.mpc_family_batch("c3bf", 4096, 8, seed=0)
+    out = {}
+    for i in (67, 24, 46):
+        P, ev = family_problem("c3bf")
+        u, st, it, info = M.solve(X[i], up[i], goal[i], obs[i], params=P, return_info=True, evaluate_fn=ev)
+        out[i] = (st, it, info)
+        off = dict(P, resto_retry=0, resto_stall_iter=0)
+        st0 = M.solve(X[i], up[i], goal[i], obs[i], params=off, evaluate_fn=ev)[1]
+        assert st0 == M.STATUS_INACCURATE, i
+    st, it, info = out[67]
+    assert st == M.STATUS_OPTIMAL and info["theta"] <= 1e-6 and info["g"].min() >= -1e-6 and 100 < it < 200
+    st, it, info = out[24]
+    assert st == M.STATUS_INFEASIBLE and not info["stalled"] and 0.25 < info["theta"] < 0.4      # a converged restoration
+    st, it, info = out[46]
+    assert st == M.STATUS_INFEASIBLE and info["stalled"] and it < 150 and 0.05 < info["theta"] < 0.07
+    P, ev = family_problem("c3bf")
+    assert phase_one(X[46], up[46], goal[46], P, ev, info, starts=4) < -1e-4
