@@ -596,7 +596,7 @@ def vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
             "optimal_fraction": float((st == 0).double().mean().item()),
             "infeasible_fraction": float((st == 1).double().mean().item()),
             "mean_ipm_iterations": float(it.double().mean().item()),
-            "lds_KB_per_problem": 39.3, "problems_per_CU": 4}, "mpcvtol_wave_kernel<float, 8, false>")
+            "lds_KB_per_problem": 39.3, "problems_per_CU": 4}, "mpcvtol_wave_kernel<float, 8")   # (<float, 8> in the profiles of rounds 3; <float, 8, false> since the OD flag)
 
 
 def od_vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
@@ -746,7 +746,8 @@ def compact_leg(v):
     sig = lambda x: float(f"{x:.5g}") if isinstance(x, float) else x     # noqa: E731
     keep = {}
     for k in ("value", "kernel_ms", "ms_per_control_step", "us_per_step", "agent_steps_per_s", "solves_per_s", "optimal_fraction",
-              "max_ipm_iterations", "agents", "GBs", "frac_of_peak", "error", "optimal_only_value", "beyond_100_iterations"):
+              "max_ipm_iterations", "agents", "GBs", "frac_of_peak", "error", "optimal_only_value", "beyond_100_iterations",
+              "all_gather_bytes_per_step", "inaccurate_fraction"):
         if k in v:
             keep[k] = sig(v[k])
     if isinstance(v.get("one_launch_limit_100"), dict):

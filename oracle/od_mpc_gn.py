@@ -41,6 +41,7 @@ def quad2d_model(spec=None, dt=0.05):
 def params(model, N=10, **over):
     P = G.params(model, N)
     P.update(omega1=1.0, omega2=1.0, p_sb1=10.0, p_sb2=10.0, rterm="u")
+    P["slack_reset"] = 0            # the optimal-decay solver of KinematicBicycle2D / Quad2D has no slack reset (VTOL2D switches it on: od_mpc_vtol.py)
     P.update(over)
     return P
 

@@ -37,7 +37,10 @@ def test_single_gpu_line_has_contract_fields():
     for leg in ("od_mpc_cbf", "quad3d_mpc_cbf", "quad2d_mpc_cbf", "kinematic_bicycle_mpc_cbf", "vtol_mpc_cbf", "backup_cbf_qp"):
         assert leg in d and d[leg]["kernel_ms"] > 0, leg
         assert d[leg]["roofline"]["bound"] == "valu_issue" and d[leg]["roofline"]["stale"] in (False, True), leg
-    assert d["vtol_mpc_cbf"]["optimal_fraction"] > 0.9 and d["vtol_mpc_cbf"]["value"] > 2e4
+    # (the legs run the reference solver's budget of 3000 iterations as continuation launches; the one-launch time at the round-3
+    # limit of 100 rides along)
+    assert d["vtol_mpc_cbf"]["optimal_fraction"] > 0.9 and d["vtol_mpc_cbf"]["value"] > 3e3 and d["vtol_mpc_cbf"]["limit_100_ms"] < 150
+    assert d["od_vtol_mpc_cbf"]["kernel_ms"] > 0 and d["kinematic_bicycle_c3bf_mpc_cbf"]["inaccurate_fraction"] <= 0.03
 
 
 def test_two_rank_flow_on_one_gpu():

@@ -70,7 +70,7 @@ def test_decay_variables_stay_at_reference_when_no_row_is_active_and_cost_is_abs
     torch.cuda.synchronize()
     assert (st == 0).all() and (rho - 1.0).abs().max().item() <= 1e-5    # (barrier-level pull of the far rows)
     # R u^2: the previous input is not part of this class's cost (optimal_decay_mpc_cbf.py:173-174); it is only the start iterate
-    assert (u - u2).abs().max().item() <= 1e-6
+    assert (u - u2).abs().max().item() <= 1e-5
 
 
 def test_f32_storage_and_k16_instantiation():

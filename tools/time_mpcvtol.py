@@ -1,5 +1,6 @@
 """Launch time of the VTOL2D MPC-CBF wave kernel on the vtol bench batch: one launch with the round-3 limit of 100 iterations, and the
-reference solver's budget (3000) as continuation launches.  MI355X only.   python tools/time_mpcvtol.py [B] [f32|f64]"""
+reference solver's budget (3000) as continuation launches.  MI355X only.   python tools/time_mpcvtol.py [B] [f32|f64] [limit100]
+(`limit100`: the one-launch configuration only -- counter passes want one kind of dispatch)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +14,10 @@ X, up, goal, obs = W.mpc_family_batch("vtol", B, 8, seed=0)
 td = torch.float32 if io == "f32" else torch.float64
 tt = lambda a: torch.tensor(a, dtype=td, device=dev)
 X, up, goal, obs = tt(X), tt(up), tt(goal), tt(obs)
-for label, kw in (("limit 100, one launch", dict(max_iter=100, iter_slices=(), classify_first=False)), ("budget 3000, sliced", dict())):
+CONFIGS = (("limit 100, one launch", dict(max_iter=100, iter_slices=(), classify_first=False)), ("budget 3000, sliced", dict()))
+if len(sys.argv) > 3 and sys.argv[3] == "limit100":
+    CONFIGS = CONFIGS[:1]
+for label, kw in CONFIGS:
     ctl = sca.BatchedVtolMPCCBF(io_dtype=io, **kw)
     u, st, it = ctl.solve(X, up, goal, obs); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
