@@ -510,12 +510,12 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
             "mean_ipm_iterations": float(it.double().mean().item())}, f"mpcgn_kernel<{mid}, {N if N == 10 else 0}, false>")
 
 
-def bicycle_loop_leg(dev, model, B=4096, T=160, every=10, steps=3, seed=0):
+def bicycle_loop_states(dev, model, B=4096, T=160, every=10, seed=0):
     """MPC-CBF of the collision-cone bicycles on states OF THEIR CLOSED LOOP (round 3 timed batches drawn uniformly, half of them inside
     collision cones: half the "solves" were restorations).  The fleet flies dynamic_env/main.py's scene (:241-268: start (1, 7.5),
     heading 0, 1 m/s; goal (20, 7.5); eight discs of radius 0.5 moving at (-0.5, +-0.5) m/s, stepped like step_dyn_obs, :54-58) with
     start positions, headings and speeds spread a little; agent i is sampled after `every` * (i mod 16) control steps, so the timed batch
-    covers the whole approach.  Reported: the batch rate and the rate of the problems that end optimal."""
+    covers the whole approach.  Returns X[Bn,4], u_prev[Bn,2], goal[Bn,2], obs[Bn,8,7] (f32, on the device), G, every."""
     import numpy as np
     import torch
     import safe_control_amd as sca
@@ -544,6 +544,17 @@ def bicycle_loop_leg(dev, model, B=4096, T=160, every=10, steps=3, seed=0):
     X, up, ob = Xs[live].contiguous(), Us[live].contiguous(), Os[live].contiguous()
     Bn = int(X.shape[0])
     g = torch.tensor([[20.0, 7.5]], dtype=torch.float32, device=dev).repeat(Bn, 1).contiguous()
+    return X, up, g, ob, G, every
+
+
+def bicycle_loop_leg(dev, model, B=4096, T=160, every=10, steps=3, seed=0):
+    """MPC-CBF of the collision-cone bicycles on states OF THEIR CLOSED LOOP (bicycle_loop_states; round 3 timed batches drawn
+    uniformly, half of them inside collision cones: half the "solves" were restorations).  Reported: the batch rate and the rate of
+    the problems that end optimal."""
+    import torch
+    import safe_control_amd as sca
+    X, up, g, ob, G, every = bicycle_loop_states(dev, model, B, T, every, seed)
+    Bn = int(X.shape[0])
     mk = lambda **kw: sca.BatchedGnMPCCBF({"model": model, "a_max": 5.0, "radius": 0.3}, io_dtype="f32", horizon=10, **kw)   # noqa: E731
 
     def timed(c, args):

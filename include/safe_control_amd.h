@@ -161,7 +161,7 @@ typedef struct sc_resto_params {
                               * Newton system, delta >= 1, 1e2, 1e4, ... (each retry is one iteration), this many times before the
                               * solve gives up (3); 0: give up at once (round 3)                                       */
     double  stall_theta;     /* a restoration that has not lowered the l1 violation by 1 % within stall_iter iterations while the  */
-    int32_t stall_iter;      /*   violation is above stall_theta stops with SC_STATUS_INFEASIBLE: a local minimiser of the violation
+    int32_t stall_iter;      /*   violation is above stall_theta stops with SC_STATUS_INFEASIBLE (below it: stops too, SC_STATUS_INACCURATE): a local minimiser of the violation
                               *   at a kink of the rows, where no KKT error goes to zero (1e-3, 40); stall_iter = 0: off.
                               *   The one-NLP-per-lane VTOL2D cross-check kernel supports neither (retry_max = stall_iter = 0).  */
     int32_t reserved;

@@ -321,7 +321,8 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     correction's memory delta_last / 3 like a shrinking trust region): the plateaus where the Newton direction of the minimal
     inertia correction makes no progress are left this way, towards a proper stationary point of the violation or back to the
     regular phase.  A restoration that has not lowered theta by 1 % within P["resto_stall_iter"] = 40 iterations while theta >
-    P["resto_stall_theta"] = 1e-3 is stopped with STATUS_INFEASIBLE: it sits at a local minimiser of the violation at a kink of the
+    P["resto_stall_theta"] = 1e-3 is stopped with STATUS_INFEASIBLE (with less violation than that: stopped as well, STATUS_INACCURATE --
+    the crawl gets nowhere either way, and a violation of 1e-5 is not evidence of infeasibility): it sits at a local minimiser of the violation at a kink of the
     rows (C3BF's sqrt(max(|p|^2 - r^2, 0))), where no KKT error goes to zero and the steps crawl at lengths of 1e-3 for the rest of
     the budget (tests/test_oracle_mpc_resto.py: an independent phase-1 finds no feasible plan for such problems).
     Every other unsuccessful exit is STATUS_INACCURATE.
@@ -415,9 +416,10 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
                     theta_ref, n_stall = theta, 0
                 else:
                     n_stall += 1
-                    if n_stall >= P["resto_stall_iter"] and theta > P["resto_stall_theta"]:
-                        status, n_stalled = STATUS_INFEASIBLE, 1           # stalled at a kink of the rows with violation left
-                        break
+                    if n_stall >= P["resto_stall_iter"]:
+                        if theta > P["resto_stall_theta"]:
+                            status, n_stalled = STATUS_INFEASIBLE, 1       # stalled at a kink of the rows with violation left
+                        break                                               # (a stall with next to no violation left stays INACCURATE)
         elif e_opt <= P["tol"]:
             status = STATUS_OPTIMAL
             break

@@ -1010,7 +1010,7 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
                     const bool less = theta <= 0.99 * theta_ref;                  // (selects, not branches: the values are wave-uniform)
                     theta_ref = less ? theta : theta_ref;
                     n_stall = less ? 0 : n_stall + 1;
-                    if (n_stall >= p.resto.stall_iter && theta > p.resto.stall_theta) { status = SC_STATUS_INFEASIBLE; stop = true; break; }
+                    if (n_stall >= p.resto.stall_iter) { if (theta > p.resto.stall_theta) status = SC_STATUS_INFEASIBLE; stop = true; break; }   // (less violation: SC_STATUS_INACCURATE)
                 }
             } else if (e_opt <= p.tol) {
                 status = SC_STATUS_OPTIMAL;
