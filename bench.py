@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--plain-fleet", action="store_true",
                     help="hetero_fleet: plain MPCCBF of both models on circular obstacles (round 1's variant)")
     ap.add_argument("--horizon", type=int, default=10)
+    ap.add_argument("--max-iter", type=int, default=0,
+                    help="hetero_fleet: iteration limit of the interior point (0: the classes' default, IPOPT's 3000; 100: rounds 1 - 3)")
     ap.add_argument("--no-mpc", action="store_true", help="skip the short MPC-CBF leg of the default run")
     ap.add_argument("--no-limit100", action="store_true",
                     help="interior-point legs: skip the extra timing of the round-3 configuration (one launch, 100 iterations); the counter "
@@ -634,7 +636,19 @@ def od_vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    return with_roofline({"workload": f"{B}-aircraft batch VTOL2D optimal-decay MPC-CBF, horizon N=30, {K} obstacles, a disc ahead of every other aircraft",
+    lim = {}
+    if not NO_LIMIT100:                                              # the same batch stopped at 100 iterations (one solve crawls to the budget)
+        c100 = sca.BatchedOptimalDecayVtolMPCCBF(io_dtype="f32", max_iter=100)
+        o100 = c100.solve(X, up, g, ob)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            o100 = c100.solve(X, up, g, ob)
+        e1.record()
+        torch.cuda.synchronize()
+        lim = {"one_launch_limit_100": {"kernel_ms": e0.elapsed_time(e1) / steps, "optimal_fraction": float((o100[2] == 0).double().mean().item())},
+               "beyond_100_iterations": int((it > 100).sum().item()), "inaccurate_fraction": float((st == 2).double().mean().item())}
+    return with_roofline({**lim, "workload": f"{B}-aircraft batch VTOL2D optimal-decay MPC-CBF, horizon N=30, {K} obstacles, a disc ahead of every other aircraft",
             "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
             "optimal_fraction": float((st == 0).double().mean().item()),
             "infeasible_fraction": float((st == 1).double().mean().item()),
@@ -1036,17 +1050,18 @@ def hetero_fleet_workload(a, dev, ws, rank, backend):
     Bl = hi - lo
     uspec = {"model": "Unicycle2D", "v_max": 1.0, "w_max": 0.5, "radius": 0.25}
     od = not a.plain_fleet
+    mi = {"max_iter": a.max_iter} if a.max_iter > 0 else {}
     Xu, gu, _, ou = W.du_cbfqp_batch(n_total // 2, K, seed=0)
     Xq, gq, oq = W.linear_mpc_batch("Quad3D", n_total // 2, K, seed=1)
     if od:
-        uni = sca.BatchedOptimalDecayMPCCBF(uspec, io_dtype="f32", horizon=N, extension=True)
-        quad = sca.BatchedOptimalDecayLinearMPCCBF({"model": "Quad3D"}, io_dtype="f32", horizon=N)
+        uni = sca.BatchedOptimalDecayMPCCBF(uspec, io_dtype="f32", horizon=N, extension=True, **mi)
+        quad = sca.BatchedOptimalDecayLinearMPCCBF({"model": "Quad3D"}, io_dtype="f32", horizon=N, **mi)
         Xu[:, 3] = 0.0
         ou = W.superellipsoid_obstacles(Xu[:, :2], K, seed=1000)
         oq = W.superellipsoid_obstacles(Xq[:, :2], K, seed=1001)
     else:
-        uni = sca.BatchedMPCCBF(uspec, io_dtype="f32", horizon=N)
-        quad = sca.BatchedLinearMPCCBF({"model": "Quad3D"}, io_dtype="f32", horizon=N)
+        uni = sca.BatchedMPCCBF(uspec, io_dtype="f32", horizon=N, **mi)
+        quad = sca.BatchedLinearMPCCBF({"model": "Quad3D"}, io_dtype="f32", horizon=N, **mi)
     t = lambda arr: torch.tensor(arr[lo:hi], dtype=torch.float32, device=dev)
     tXu, tgu, tou = t(Xu), t(gu), t(ou)
     tXq, tgq, toq = t(Xq), t(gq), t(oq)
