@@ -201,3 +201,44 @@ def test_header_is_plain_c(tmp_path):
             _lib.OdMpcGnParams.omega_ref.offset, _lib.OdMpcVtolParams.omega_ref.offset, _lib.OdMpcVtolParams.p_sb.offset,
             _lib.RestoParams.retry_max.offset, _lib.RestoParams.stall_theta.offset, _lib.RestoParams.stall_iter.offset]
     assert sizes[len(mirrors):] == offs
+
+
+def test_argument_validation_of_the_round4_entry_points_without_gpu():
+    """Continuation launches (sc_mpc_slices), the restoration's retry / stall fields and optimal-decay MPC-CBF for VTOL2D: bad arguments are
+    rejected before anything is launched."""
+    from safe_control_amd.position_control import mpc_cbf as MC, mpc_cbf_vtol as MV
+    from safe_control_amd.robots.spec import complete_robot_spec
+    lib = _lib.load()
+    buf = np.zeros(4096)
+    ptr = buf.ctypes.data
+    iptr = np.zeros(64, dtype=np.int32).ctypes.data
+    spec = complete_robot_spec({"model": "DynamicUnicycle2D"})
+    Q, R = MC.default_mpc_weights("DynamicUnicycle2D")
+    p = MC.make_params(spec, {"alpha1": 0.15, "alpha2": 0.15}, Q, R, 10, 0.05, 0.25, _lib.DTYPE_F64)
+    assert (p.resto.retry_max, p.resto.stall_iter, p.resto.stall_theta) == (3, 40, 1e-3)
+    args = (ptr, ptr, ptr, ptr, ptr, iptr, iptr, None)
+    sl = _lib.make_slices([100])
+    assert lib.sc_mpccbf_solve_batch_sliced(C.byref(p), C.byref(_lib.make_slices([])), 0, 8, *args, None) == 0    # B == 0, one plain launch
+    assert lib.sc_mpccbf_solve_batch_sliced(C.byref(p), C.byref(sl), 4, 8, *args, None) == 1                       # caps without a workspace
+    bad = _lib.make_slices([20, 10])
+    assert lib.sc_mpccbf_solve_batch_sliced(C.byref(p), C.byref(bad), 4, 8, *args, None) == 1                      # caps must increase
+    need = lib.sc_mpccbf_slices_workspace_bytes(C.byref(p), 4, 8)
+    assert need > 4 * 8 * (16 + 2 * 20)                                                                           # a state record per problem
+    p.resto.retry_max = 9
+    assert lib.sc_mpccbf_solve_batch(C.byref(p), 4, 8, *args, None) == 1
+    p.resto.retry_max, p.resto.stall_iter, p.resto.stall_theta = 3, 10, 0.0
+    assert lib.sc_mpccbf_solve_batch(C.byref(p), 4, 8, *args, None) == 1
+    # optimal-decay MPC-CBF for VTOL2D
+    vspec = complete_robot_spec({"model": "VTOL2D"})
+    q = MV.make_od_params(vspec, dict(MV.OD_CBF_VTOL), 30, 0.05, vspec["radius"], _lib.DTYPE_F64)
+    assert q.mpc.alpha1 == 0.35 and q.p_sb[0] == 10.0 and q.omega_ref[1] == 1.0 and q.mpc.resto.stall_iter == 0
+    vargs = (ptr, ptr, ptr, ptr, ptr, ptr, iptr, iptr, None)
+    assert lib.sc_odmpcvtol_solve_batch(C.byref(q), 0, 8, *vargs, None) == 0                                       # B == 0
+    assert lib.sc_odmpcvtol_solve_batch(None, 1, 8, *vargs, None) == 1
+    assert lib.sc_odmpcvtol_solve_batch(C.byref(q), 1, 17, *vargs, None) != 0                                      # K > 16
+    q.p_sb[1] = 0.0
+    assert lib.sc_odmpcvtol_solve_batch(C.byref(q), 1, 8, *vargs, None) == 1
+    q.p_sb[1], q.mpc.kernel = 10.0, 1
+    assert lib.sc_odmpcvtol_solve_batch(C.byref(q), 1, 8, *vargs, None) == 2                                       # the lane kernel has no OD form
+    q.mpc.kernel, q.mpc.resto.stall_iter = 0, 40
+    assert lib.sc_odmpcvtol_solve_batch(C.byref(q), 1, 8, *vargs, None) == 2                                       # the VTOL2D kernels keep round 3's restoration
