@@ -168,6 +168,18 @@ def valu_roofline(run, kernel_substr, kernel_ms, note=None, launches=1):
     return None
 
 
+def work_level(r, ub, mean_it, B):
+    """Issue rate at the WORK level (no tail): VALU instructions per iteration and problem from the profiled batch (instructions /
+    sum of iterations), times the iterations of the uniform batch (budget_note: copies of the median-iteration problem, one launch),
+    over that batch's launch time."""
+    if not (isinstance(r, dict) and isinstance(ub, dict) and ub.get("iterations") and mean_it and B):
+        return
+    per_it = r["valu_instructions_per_launch"] / (mean_it * B)
+    ach = per_it * ub["iterations"] * B / (ub["kernel_ms"] * 1e-3) / 1e9
+    r["work_level"] = {"achieved": ach, "frac": ach / VALU_PEAK_GIPS, "us_per_iteration_of_the_batch": 1e3 * ub["kernel_ms"] / ub["iterations"],
+                       "note": "uniform batch: copies of the median-iteration problem, one launch"}
+
+
 def with_roofline(res, kernel_substr, launches=LAUNCHES_PER_BUDGET_SOLVE):
     """Attach the VALU-issue roofline of an interior-point leg when the committed counter profile holds the kernel
     (profiles/r04_counters.json: run bench_full_sq = the default bench command with --no-limit100 under rocprofv3 --pmc, same
@@ -175,6 +187,11 @@ def with_roofline(res, kernel_substr, launches=LAUNCHES_PER_BUDGET_SOLVE):
     r = valu_roofline("bench_full_sq", kernel_substr, res["kernel_ms"], launches=launches)
     if r is not None:
         res["roofline"] = r
+        try:
+            B = int(res["workload"].split("-")[0].split()[0]) if res.get("workload", " ")[0].isdigit() else None
+        except Exception:
+            B = None
+        work_level(r, res.get("uniform_batch"), res.get("mean_ipm_iterations"), B or res.get("agents"))
     return res
 
 
@@ -197,8 +214,29 @@ def budget_note(make_ctl, args, steps, ms_full, st_full, it_full):
     e1.record()
     torch.cuda.synchronize()
     st = out[1]
-    return {**base, "one_launch_limit_100": {"kernel_ms": e0.elapsed_time(e1) / steps, "optimal_fraction": float((st == 0).double().mean().item()),
-                                             "inaccurate_fraction": float((st == 2).double().mean().item())}}
+    res = {**base, "one_launch_limit_100": {"kernel_ms": e0.elapsed_time(e1) / steps, "optimal_fraction": float((st == 0).double().mean().item()),
+                                            "inaccurate_fraction": float((st == 2).double().mean().item())}}
+    # The work without the tail: the batch filled with copies of ONE problem -- the optimal solve with the median iteration count -- so
+    # that every wave runs the same number of iterations and the launch time is work / machine, not longest solve x lone-wave latency.
+    try:
+        opt = torch.nonzero(st_full == 0).flatten()
+        if opt.numel() >= 8:
+            its = it_full[opt]
+            j = int(opt[torch.argsort(its)[its.numel() // 2]].item())
+            B = int(st_full.shape[0])
+            rep = tuple((a[j:j + 1].expand(B, *a.shape[1:]).contiguous() if a.shape[0] == B else a) for a in args)
+            o2 = ctl.solve(*rep)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(steps):
+                o2 = ctl.solve(*rep)
+            e1.record()
+            torch.cuda.synchronize()
+            res["uniform_batch"] = {"copies_of_draw": j, "iterations": int(o2[2][0].item()), "kernel_ms": e0.elapsed_time(e1) / steps,
+                                    "all_equal": bool((o2[2] == o2[2][0]).all().item())}
+    except Exception as e:                                           # an extra figure never takes the leg down
+        res["uniform_batch"] = {"error": repr(e)[:120]}
+    return res
 
 
 def mpc_cpu_baseline(Xn, goal, on, N, seconds):
@@ -250,6 +288,7 @@ def mpc_leg(dev, B, K, N, steps, warmup, seed=0, cpu_seconds=0.0):
                            "slowest problem (74 interior-point iterations against a mean of 19: the 40 longest solves ALONE take 1.77 ms, "
                            "tools/exp_tail.py)")
         if rl:
+            work_level(rl, extra.get("uniform_batch"), float(it.double().mean().item()), B)
             extra["roofline"] = rl
     return {**extra, "workload": f"{B}-agent batch DynamicUnicycle2D MPC-CBF, horizon N={N}, {K} obstacles (BASELINE configs[2])",
             "value": B * steps / wall, "unit": "solves/s", "steps": steps, "kernel_ms": ms,
@@ -780,6 +819,8 @@ def compact_leg(v):
     rl = v.get("roofline")
     if isinstance(rl, dict):
         keep["roofline"] = {k: sig(rl[k]) for k in ("bound", "frac", "stale") if k in rl}
+        if isinstance(rl.get("work_level"), dict):
+            keep["roofline"]["work_frac"] = sig(rl["work_level"]["frac"])
     return keep
 
 
@@ -810,6 +851,8 @@ def emit(d, ws):
         if isinstance(mpc.get("roofline"), dict):
             m["roofline"] = {k: mpc["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_us", "stale")
                              if k in mpc["roofline"]}
+            if isinstance(mpc["roofline"].get("work_level"), dict):
+                m["roofline"]["work_frac"] = mpc["roofline"]["work_level"]["frac"]
         if isinstance(mpc.get("cpu_baseline"), dict):
             m["cpu_baseline"] = {k: mpc["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample")}
         if isinstance(line.get("config"), dict) and "mpc" not in d:
