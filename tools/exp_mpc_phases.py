@@ -3,6 +3,9 @@ Needs a developer build:  make -C safe_control_amd/csrc EXTRA=-DSC_MPC_PROF   (t
 import sys
 import numpy as np, torch
 sys.path.insert(0, ".")
+import os
+from safe_control_amd import _lib as _L
+if os.environ.get("SC_EXP_LIB"): _L.LIB_PATH = os.path.abspath(os.environ["SC_EXP_LIB"])
 import safe_control_amd as sca
 from safe_control_amd import workloads as W
 
