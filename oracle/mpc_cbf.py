@@ -364,7 +364,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     resto = False
     rho_R, kappa_R, theta_tol = P["resto_rho"], P["resto_kappa"], P["resto_theta_tol"]
     n_resto, it_resto, theta_R, mu_reg, z_R = 0, 0, 0.0, mu, z.copy()
-    delta_force, n_retry, theta_ref, n_stall, n_stalled = 0.0, 0, 0.0, 0, 0     # stalled restorations: damped retries, stall counter
+    delta_force, n_retry, theta_ref, n_stall, n_stalled, n_retried = 0.0, 0, 0.0, 0, 0, 0   # stalled restorations: damped retries, stall counter
     n_small = 0                                                             # consecutive regular iterations with a tiny step at an infeasible z
     SF_OFF = 1e-40                                                          # "no objective": evaluate() divides lam by it
     el = np.arange(m) < m_el
@@ -542,6 +542,7 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
                         break
                     # the same z again, Levenberg-damped (the retry is an iteration of its own: everything is re-evaluated)
                     n_retry, delta_force = n_retry + 1, max(1.0, 100.0 * max(delta_force, delta))
+                    n_retried += 1
                     continue
                 want_resto = True
             elif not resto:
@@ -583,6 +584,6 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     u0 = z[0:P.get("nu", 2)].copy()
     if return_info:
         return u0, status, it, dict(z=z, X=ev["X"], f=ev["f"], g=ev["g"], lam=lam / sf0, s=s, err=err, mu=mu,
-                                    n_eval=n_eval, scale=sf0, obs=obs, n_resto=n_resto, it_resto=it_resto, in_resto=resto, stalled=n_stalled,
+                                    n_eval=n_eval, scale=sf0, obs=obs, n_resto=n_resto, it_resto=it_resto, in_resto=resto, stalled=n_stalled, retried=n_retried,
                                     theta=violation(ev["g"], m_el))
     return u0, status, it
