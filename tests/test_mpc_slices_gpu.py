@@ -140,3 +140,17 @@ def test_solves_the_old_iteration_cap_cut_off():
         if so == 0:
             assert np.abs(u[0] - uo).max() <= 1e-5
             assert np.abs(u[0] - u100[0]).max() > 1e-3                    # what the cap used to return was not the solution
+
+
+@pytest.mark.parametrize("fam", FAMILIES)
+def test_random_schedules_are_bitwise_the_uninterrupted_solve(fam):
+    """Seeded random schedules (1 - 8 caps anywhere below the longest solve, order and the classify pre-pass on or off) with the
+    restoration's damped retries and stall counters in flight across the caps (budget 300: the collision-cone bicycles run 200+
+    iterations here).  tools/exp_fuzz_slices.py is the same with more schedules."""
+    rng = np.random.default_rng(sum(map(ord, fam)))
+    arrs = batch(fam, 160, seed=7)
+    ref = solve(make(fam, max_iter=300), arrs)
+    for _ in range(4):
+        caps = tuple(sorted(set(int(c) for c in rng.integers(1, max(4, int(ref[2].max())), size=int(rng.integers(1, 9))))))
+        kw = dict(iter_slices=caps, order=bool(rng.integers(0, 2)), classify_first=bool(rng.integers(0, 2)))
+        same(ref, solve(make(fam, max_iter=300, **kw), arrs), f"{fam} {kw}")
