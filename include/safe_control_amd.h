@@ -164,7 +164,10 @@ typedef struct sc_resto_params {
     int32_t stall_iter;      /*   violation is above stall_theta stops with SC_STATUS_INFEASIBLE (below it: stops too, SC_STATUS_INACCURATE): a local minimiser of the violation
                               *   at a kink of the rows, where no KKT error goes to zero (1e-3, 40); stall_iter = 0: off.
                               *   The one-NLP-per-lane VTOL2D cross-check kernel supports neither (retry_max = stall_iter = 0).  */
-    int32_t reserved;
+    int32_t gauss_newton;    /* 1: the restoration's Newton system is J' Sigma J + zeta I -- the second-order terms of the rows (multipliers
+                              * near rho) and of the dynamics are dropped.  VTOL2D (sc_mpcvtol_*) only, where the exact Hessian of the
+                              * restoration's Lagrangian is so indefinite that its steps shrink to 1e-3 (default there: 1); the other
+                              * entry points require 0                                                                   */
 } sc_resto_params;
 
 /* Continuation launches of the interior point (sc_mpc*_solve_batch_sliced; csrc/mpc_cont.hpp).  The reference hands its NLPs to

@@ -325,6 +325,12 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
     the crawl gets nowhere either way, and a violation of 1e-5 is not evidence of infeasibility): it sits at a local minimiser of the violation at a kink of the
     rows (C3BF's sqrt(max(|p|^2 - r^2, 0))), where no KKT error goes to zero and the steps crawl at lengths of 1e-3 for the rest of
     the budget (tests/test_oracle_mpc_resto.py: an independent phase-1 finds no feasible plan for such problems).
+    Gauss-Newton restoration (P["resto_gn"], VTOL2D; round 4).  The Hessian of the restoration's Lagrangian is zeta I - sum_i lam_i
+    grad^2 g_i with multipliers of the violated rows near rho_R = 1000: for the tilt-rotor (exact Hessian through the aero model, R =
+    50000 on the elevator) it is so indefinite that the inertia correction adds delta ~ 1e6 and the steps shrink to 1e-3 -- restorations
+    that lower a violation of 4 - 90 by 10 % per 40 iterations and then fail a line search.  With the flag the restoration's Newton
+    system is J' Sigma J + zeta I (the second-order terms of the rows dropped: a convex model of a problem whose objective is the l1
+    violation): the eight bench draws traced (one of them 517 iterations to a failed line search before) end OPTIMAL in 61 - 114.
     Every other unsuccessful exit is STATUS_INACCURATE.
     """
     P = dict(DEFAULTS)
@@ -386,6 +392,8 @@ def solve(x0, u_prev, goal, obs, params=None, return_info=False, evaluate_fn=Non
             ev = evaluate(x0, z, u_prev, goal, obs, P, lam / sf, level=2)
             f, grad, W, g, J = sf * ev["f"], sf * ev["grad"], sf * ev["W"], ev["g"], ev["J"]
         Wc = W
+        if resto and P.get("resto_gn"):
+            Wc = 0.0 * W                                                    # Gauss-Newton restoration (VTOL2D): see the docstring
         if resto:
             zeta = math.sqrt(mu)
             f, grad, W = 0.5 * zeta * float((z - z_R) @ (z - z_R)), zeta * (z - z_R), Wc + zeta * np.eye(nz)

@@ -245,7 +245,7 @@ def params(N=30, spec=None, dt=0.05, **over):
     from . import mpc_gn as G
     # no slack reset inside the restoration for this model: with it the restoration converges -- to least-violation inputs such as
     # (1, 0, 0, -0.5) that pitch the aircraft past its limit when applied (tools/exp_vtol_closed_loop.py)
-    P = G.params(vtol_model(spec, dt), N, exact_hessian=True, slack_reset=2, resto_slack_reset=False, resto_retry=0, resto_stall_iter=0)
+    P = G.params(vtol_model(spec, dt), N, exact_hessian=True, slack_reset=2, resto_slack_reset=False, resto_retry=0, resto_stall_iter=0, resto_gn=True)
     P.update(over)
     return P
 

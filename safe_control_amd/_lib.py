@@ -77,7 +77,7 @@ class RestoParams(C.Structure):
     """Mirror of ``sc_resto_params``: the feasibility-restoration phase of the MPC interior point."""
     _fields_ = [("rho", C.c_double), ("kappa", C.c_double), ("theta_tol", C.c_double), ("tol", C.c_double),
                 ("small_alpha", C.c_double), ("small_iter", C.c_int32), ("max_entries", C.c_int32), ("slack_reset", C.c_int32),
-                ("retry_max", C.c_int32), ("stall_theta", C.c_double), ("stall_iter", C.c_int32), ("reserved", C.c_int32)]
+                ("retry_max", C.c_int32), ("stall_theta", C.c_double), ("stall_iter", C.c_int32), ("gauss_newton", C.c_int32)]
 
 
 def default_resto(**over):

@@ -156,7 +156,9 @@ static int check_cbfqp(const sc_cbfqp_params* p, int64_t B, int32_t K, const voi
 // sc_resto_params of every MPC entry point: a zero-initialised block (max_entries = 0) switches the restoration off and is valid --
 // the statuses then have their pre-restoration meaning (a multiplier above 1e10 or a failed line search at an infeasible iterate
 // ends the solve as SC_STATUS_INFEASIBLE / SC_STATUS_INACCURATE without a certificate); a partially filled one would divide by rho.
-static int check_resto(const sc_resto_params& r) {
+static int check_resto(const sc_resto_params& r, bool gauss_newton_ok = false) {
+    if (r.gauss_newton != 0 && !(gauss_newton_ok && r.gauss_newton == 1))
+        return fail(SC_ERR_UNSUPPORTED, "resto.gauss_newton: 0, or 1 on the VTOL2D entry points");
     if (r.max_entries < 0) return fail(SC_ERR_INVALID_ARGUMENT, "resto.max_entries must be >= 0");
     if (r.slack_reset != 0 && r.slack_reset != 1) return fail(SC_ERR_INVALID_ARGUMENT, "resto.slack_reset must be 0 or 1");
     if (r.retry_max < 0 || r.retry_max > 8) return fail(SC_ERR_INVALID_ARGUMENT, "resto.retry_max must be in [0, 8]");
@@ -279,7 +281,7 @@ static int check_mpcvtol(const sc_mpcvtol_params* p, int64_t B, int32_t K, const
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
     if (p->resto.retry_max != 0 || p->resto.stall_iter != 0)
         return fail(SC_ERR_UNSUPPORTED, "the VTOL2D kernels run the restoration without damped retries and without the stall certificate (resto.retry_max = resto.stall_iter = 0)");
-    return check_resto(p->resto);
+    return check_resto(p->resto, true);
 }
 static int check_manip(const sc_manip_cbfqp_params* p, int64_t B, int32_t K, const void* X, const void* u_ref,
                        const void* obs, const void* u_out, const void* status_out) {

@@ -40,7 +40,7 @@ constexpr int NX = 6, NU = 4, NV = 10, NXB = 5;
 constexpr int ST_OPTIMAL = 0, ST_INFEASIBLE = 1, ST_INACCURATE = 2;
 
 struct Params {                      // filled from sc_mpcvtol_params by the launcher
-    int N, K, max_iter, acceptable_iter, slack_reset, resto_reset;
+    int N, K, max_iter, acceptable_iter, slack_reset, resto_reset, resto_gn;
     double dt, Q[6], R[4], alpha1, alpha2, beta, radius, u_lo[4], u_hi[4], v_max, descent_max, pitch_max;
     double tol, acceptable_tol, mu_init, mu_min, row_noise;
     double rho, kappa, theta_tol, resto_tol, small_alpha;
@@ -75,7 +75,7 @@ inline Params from_c(const sc_mpcvtol_params& c, int K) {
     P.v_max = c.v_max; P.descent_max = c.descent_speed_max; P.pitch_max = c.pitch_max;
     P.tol = c.tol; P.acceptable_tol = c.acceptable_tol; P.mu_init = c.mu_init; P.mu_min = c.mu_min; P.row_noise = 1e-15;
     P.rho = c.resto.rho; P.kappa = c.resto.kappa; P.theta_tol = c.resto.theta_tol; P.resto_tol = c.resto.tol; P.small_alpha = c.resto.small_alpha;
-    P.small_iter = c.resto.small_iter; P.max_entries = c.resto.max_entries; P.resto_reset = c.resto.slack_reset;
+    P.small_iter = c.resto.small_iter; P.max_entries = c.resto.max_entries; P.resto_reset = c.resto.slack_reset; P.resto_gn = c.resto.gauss_newton;
     set_airframe(P, c.airframe);
     return P;
 }
@@ -381,6 +381,7 @@ struct Solver {
     // x-terms of stage k >= 1 (cost, state bounds) are attached to stage k; the terminal stage's go to HT, qT.
     SC_HD void stage_blocks(double cw, bool resto, double zeta, double HT[21], double qT[NX]) {
         const int N = L.N;
+        const double so = (resto && P.resto_gn) ? 0.0 : 1.0;
         for (int k = 0; k < N; ++k) {
             double H[55], q[NV], u[NU];
             for (int i = 0; i < 55; ++i) H[i] = 0.0;
@@ -408,7 +409,8 @@ struct Solver {
             }
             // curvature of h in the points: sum_p om_p G_p' G_p, om_p = -2 w_p sum_j lam_kj
             {
-                const double o0 = -2.0 * cw_.w0 * slam, o1 = -2.0 * cw_.w1 * slam, o2 = -2.0 * cw_.w2 * slam;
+                // (so: 0 in a Gauss-Newton restoration, sc_resto_params.gauss_newton -- the second-order terms of rows and dynamics are dropped)
+                const double o0 = -2.0 * cw_.w0 * slam * so, o1 = -2.0 * cw_.w1 * slam * so, o2 = -2.0 * cw_.w2 * slam * so;
                 H[sym(0, 0)] += o0 + o1; H[sym(1, 1)] += o0 + o1;
                 H[sym(0, 3)] += o1 * P.dt; H[sym(1, 4)] += o1 * P.dt; H[sym(3, 3)] += o1 * P.dt * P.dt; H[sym(4, 4)] += o1 * P.dt * P.dt;
                 for (int a = 0; a < NV; ++a)
@@ -418,7 +420,7 @@ struct Solver {
             {
                 const double c3 = W(L.p + (k + 1) * NX + 3) + P.dt * nu2[0], c4 = W(L.p + (k + 1) * NX + 4) + P.dt * nu2[1],
                              c5 = W(L.p + (k + 1) * NX + 5);
-                const double cc[3] = {c3 * P.dt, c4 * P.dt, c5 * P.dt};
+                const double cc[3] = {c3 * P.dt * so, c4 * P.dt * so, c5 * P.dt * so};
                 int e = 0;
                 for (int a = 0; a < 3; ++a)
                     for (int b = a; b < 3; ++b, ++e)

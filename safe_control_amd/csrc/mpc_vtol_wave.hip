@@ -494,6 +494,7 @@ struct Wave {
     // ---- my stage block of the Newton system to LDS -----------------------------------------------------------------------------
     __device__ __forceinline__ void stage_blocks(double cw, bool resto, double zeta, double mu, double rho_R) {
         double H[55], q[NV];
+        const double so = (resto && P.resto_gn) ? 0.0 : 1.0;
 #pragma unroll
         for (int i = 0; i < 55; ++i) H[i] = 0.0;
 #pragma unroll
@@ -546,7 +547,8 @@ struct Wave {
                 nu2[0] -= w2 * l * 2.0 * (pt[2][0] - lds[L.OB + 3 * j]); nu2[1] -= w2 * l * 2.0 * (pt[2][1] - lds[L.OB + 3 * j + 1]);
             }
         {
-            const double o0 = -2.0 * w0 * slam, o1 = -2.0 * w1 * slam, o2 = -2.0 * w2 * slam;
+            // (so: 0 in a Gauss-Newton restoration, sc_resto_params.gauss_newton -- the second-order terms of rows and dynamics are dropped)
+            const double o0 = -2.0 * w0 * slam * so, o1 = -2.0 * w1 * slam * so, o2 = -2.0 * w2 * slam * so;
             H[sym(0, 0)] += o0 + o1; H[sym(1, 1)] += o0 + o1;
             H[sym(0, 3)] += o1 * P.dt; H[sym(1, 4)] += o1 * P.dt; H[sym(3, 3)] += o1 * P.dt * P.dt; H[sym(4, 4)] += o1 * P.dt * P.dt;
 #pragma unroll
@@ -557,7 +559,7 @@ struct Wave {
         {
             const double c3 = lds[L.PS + (k + 1) * 6 + 3] + P.dt * nu2[0], c4 = lds[L.PS + (k + 1) * 6 + 4] + P.dt * nu2[1],
                          c5 = lds[L.PS + (k + 1) * 6 + 5];
-            const double cc[3] = {c3 * P.dt, c4 * P.dt, c5 * P.dt};
+            const double cc[3] = {c3 * P.dt * so, c4 * P.dt * so, c5 * P.dt * so};
             int e = 0;
 #pragma unroll
             for (int a = 0; a < 3; ++a)

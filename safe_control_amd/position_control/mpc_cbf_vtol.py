@@ -39,7 +39,7 @@ def make_params(robot_spec, cbf_param, horizon, dt, radius, io_dtype, obs_shared
     p.tol, p.acceptable_tol, p.mu_init, p.mu_min = float(tol), float(acceptable_tol), float(mu_init), float(mu_min)
     for i, k in enumerate(_lib.VTOL_AIRFRAME_KEYS):
         p.airframe[i] = float(robot_spec[k])
-    p.resto = resto if resto is not None else _lib.default_resto(slack_reset=0, retry_max=0, stall_iter=0)      # oracle/mpc_vtol.py: params
+    p.resto = resto if resto is not None else _lib.default_resto(slack_reset=0, retry_max=0, stall_iter=0, gauss_newton=1)      # oracle/mpc_vtol.py: params
     return p
 
 

@@ -117,10 +117,11 @@ def _with_ws(ctl, _lib):
 
 
 def test_solves_the_old_iteration_cap_cut_off():
-    """Round 3 stopped every solve at 100 iterations and handed control_step the iterate it had: VTOL2D bench draw 549 is feasible and
-    converges at iteration 126 (the 100-iteration input was off by 0.55), KinematicBicycle2D draw 1746 needs 145 and draw 847 is
-    certified infeasible at 140.  With the reference solver's budget behind the first cap they end with a final status, the one the
-    oracle gives, at the oracle's iteration count."""
+    """Round 3 stopped every solve at 100 iterations and handed control_step the iterate it had: KinematicBicycle2D draw 1746 needs 145
+    and draw 847 is certified infeasible at 140.  With the reference solver's budget behind the first cap they end with a final status,
+    the one the oracle gives, at the oracle's iteration count.  VTOL2D bench draw 549 (feasible; 126 iterations with round 3's
+    exact-Hessian restoration, whose 100-iteration input was off by 0.55) converges in 55 iterations since the restoration is
+    Gauss-Newton (sc_resto_params.gauss_newton): inside the old cap."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(__file__))
@@ -132,9 +133,12 @@ def test_solves_the_old_iteration_cap_cut_off():
         arrs = [torch.tensor(np.ascontiguousarray(a[sel]), dtype=torch.float64, device=DEV) for a in (X, up, goal, obs)]
         u100, st100, it100, _ = solve(make(fam, max_iter=100, iter_slices=()), arrs)
         u, st, it, z = solve(make(fam), arrs)                            # defaults: 3000 behind a cap of 100
-        assert it100[0] == 100 and st100[0] == 2 and it[0] > 100
         P, ev = family_problem(fam, 10, {})
         uo, so, ito, info = M.solve(X[draw], up[draw], goal[draw], obs[draw], params=P, return_info=True, evaluate_fn=ev)
+        if fam == "vtol":
+            assert st100[0] == 0 and it100[0] < 100 and so == 0 and abs(int(it[0]) - ito) <= 2 and np.abs(u[0] - uo).max() <= 1e-6
+            continue
+        assert it100[0] == 100 and st100[0] == 2 and it[0] > 100
         # (the long crawls part from the oracle by a few iterations: 145 / 142 and 140 / 143 on the two bicycles)
         assert so in (0, 1) and st[0] == so and abs(int(it[0]) - ito) <= 5 and ito > 100
         if so == 0:

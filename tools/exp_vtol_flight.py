@@ -41,3 +41,5 @@ for k in range(steps):
         break
 sts = np.array([l[1] for l in log])
 print("steps flown", len(log), "ret", ret, "statuses opt/infeas/inacc", [(sts == s).sum() for s in (0, 1, 2)], "goal index", int(ctl.current_goal_index[0].item()))
+print("status per step:", "".join(str(l[1]) for l in log))
+print("iterations per step:", [l[2] for l in log])
