@@ -277,6 +277,10 @@ typedef struct sc_mpclin_params {
                                 omega2 exist in the model but touch no row, their penalty keeps them at their reference -- with that
                                 class's input term R u^2 (:173-179) instead of MPCCBF's delta-u penalty; solved through
                                 sc_mpclin_solve_batch (restoration and continuation launches included).                        */
+    int32_t slack_reset;     /* line search of the regular phase: 0 off; 2: s = g where g >= mu / nu after a trial step (as in
+                                sc_mpcgn_params; the oracle's setting for the linear models since round 4: Quad3D at N = 20 crawled
+                                for hundreds of iterations without it).  optimal_decay = 1 ignores it.                        */
+    int32_t reserved;
     double  alpha;           /* DT-CBF gain: SI 0.05 (mpc_cbf.py:48-50), Quad3D 0.15 (:77-78)              */
     double  robot_radius, beta, tol, acceptable_tol, mu_init, mu_min;   /* as sc_mpccbf_params            */
     double  Q[12];           /* diagonal state weights (mpc_cbf.py:19-20, :37-38)                          */

@@ -95,7 +95,9 @@ def condensed(model, N, rterm="du"):
 
 def params(model, N=10, **over):
     P = dict(M.DEFAULTS, N=N, dt=model["dt"], nu=model["nu"], u_lo=model["u_lo"], u_hi=model["u_hi"], radius=model["radius"],
-             alpha=model["alpha"], model=model)
+             alpha=model["alpha"], model=model,
+             slack_reset=2)     # round 4: the line search resets slacks (oracle/mpc_cbf.py: solve) -- Quad3D at N = 20 crawled for up to 351
+                                # iterations at step lengths of 1e-2 without it (71 with it), SingleIntegrator2D 34 -> 20; N = 10 Quad3D unchanged
     P.update(over)
     P["quadratic_cost"] = condensed(model, P["N"], P.get("rterm", "du"))[0]   # exact merit differences in the line search
     P.setdefault("row_noise", 1e-15)

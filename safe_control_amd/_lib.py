@@ -168,7 +168,7 @@ class MpcLinParams(C.Structure):
     _fields_ = [
         ("io_dtype", C.c_int32), ("nx", C.c_int32), ("nu", C.c_int32), ("ng", C.c_int32), ("horizon", C.c_int32),
         ("max_iter", C.c_int32), ("obs_shared", C.c_int32), ("acceptable_iter", C.c_int32), ("circles_only", C.c_int32),
-        ("optimal_decay", C.c_int32),
+        ("optimal_decay", C.c_int32), ("slack_reset", C.c_int32), ("reserved", C.c_int32),
         ("alpha", C.c_double), ("robot_radius", C.c_double), ("beta", C.c_double), ("tol", C.c_double),
         ("acceptable_tol", C.c_double), ("mu_init", C.c_double), ("mu_min", C.c_double),
         ("Q", C.c_double * 12), ("R", C.c_double * 4), ("u_lo", C.c_double * 4), ("u_hi", C.c_double * 4),

@@ -219,6 +219,7 @@ static int check_mpclin(const sc_mpclin_params* p, const double* model, int64_t 
     if (p->io_dtype != SC_DTYPE_F32 && p->io_dtype != SC_DTYPE_F64)
         return fail(SC_ERR_INVALID_ARGUMENT, "io_dtype must be SC_DTYPE_F32 or SC_DTYPE_F64");
     if (p->optimal_decay < 0 || p->optimal_decay > 2) return fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay must be 0, 1 or 2");
+    if (p->slack_reset != 0 && p->slack_reset != 2) return fail(SC_ERR_INVALID_ARGUMENT, "slack_reset must be 0 or 2");
     if (p->optimal_decay == 1 && !(p->nx == 12 && p->nu == 4))
         return fail(SC_ERR_UNSUPPORTED, "the optimal-decay extension of this kernel is built for Quad3D (nx = 12, nu = 4)");
     if (p->optimal_decay == 1 && !(p->od_p_sb > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "od_p_sb must be > 0");

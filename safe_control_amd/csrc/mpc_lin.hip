@@ -797,7 +797,8 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         LP(8);
         alpha = ap;
         fresh = false;
-        const bool rreset = RESTO && resto && p.resto.slack_reset != 0;
+        // slack reset of the line search: restoration sc_resto_params.slack_reset, regular phase sc_mpclin_params.slack_reset = 2
+        const bool rreset = RESTO && (resto ? p.resto.slack_reset != 0 : p.slack_reset == 2);
         const double thr_reset = mu * rcp_(nu_m);
         for (int ls = 0; ls < 12; ++ls) {
             for (int i = lane; i < n; i += TH) W.zt[i] = W.z[i] + alpha * W.dz[i];
@@ -814,7 +815,7 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
                     const double t_t = t + alpha * ipm::resto_dt(W.lam[i], t, W.dlam[i], mu, rho_R);
                     slog += log(t_t); tot += t_t;
                 }
-                // slack reset of the restoration's line search (sc_resto_params.slack_reset): s = g + t where that is >= mu / nu
+                // slack reset (both phases; t = 0 in the regular one): s = g + t where that is >= mu / nu
                 const double s_t = (rreset && tot >= thr_reset) ? tot : s_lin;
                 slog += log(s_t);
                 srp += fabs(tot - s_t);
@@ -880,7 +881,7 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         if constexpr (OD) for (int k = lane; k < N; k += TH) W.rho[k] = W.rho[k] + alpha * W.drho[k];
         delta_force = 0.0; n_retry = 0;
         {
-        const bool rreset = RESTO && resto && p.resto.slack_reset != 0;   // W.g holds the accepted trial point's rows
+        const bool rreset = RESTO && (resto ? p.resto.slack_reset != 0 : p.slack_reset == 2);   // W.g holds the accepted trial point's rows
         const double thr_reset = mu * rcp_(nu_m);
         for (int i = lane; i < m; i += TH) {
             const double s_lin = W.s[i] + alpha * W.ds[i];

@@ -15,11 +15,12 @@ from .mpc_cbf import apply_mpc_overrides, pad_obstacles
 
 
 def make_params(mdl, cbf_param, horizon, radius, io_dtype, obs_shared=False, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER, mu_init=0.1,
-                mu_min=1e-9, acceptable_tol=1e-5, resto=None, input_rterm="du"):
+                mu_min=1e-9, acceptable_tol=1e-5, resto=None, input_rterm="du", slack_reset=2):
     """``input_rterm``: "du" = MPCCBF's do-mpc delta-u penalty (mpc_cbf.py:180); "u2" = the R u^2 expression of the reference's
     OptimalDecayMPCCBF (optimal_decay_mpc_cbf.py:173-179) with the plain row that class gives Quad3D (:284-287): sc_mpclin_params.optimal_decay = 2."""
     p = _lib.MpcLinParams()
     p.optimal_decay = {"du": 0, "u2": 2}[input_rterm]
+    p.slack_reset = int(slack_reset)                          # line search of the regular phase (oracle/mpc_lin.py: params)
     p.io_dtype = io_dtype
     p.nx, p.nu, p.ng = mdl["nx"], mdl["nu"], mdl["ng"]
     p.horizon = int(horizon)
