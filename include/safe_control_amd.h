@@ -204,6 +204,11 @@ typedef struct sc_mpccbf_params {
     int32_t obs_shared;      /* 0: obs is [B,K,7]; 1: one [K,7] table for all agents               */
     int32_t acceptable_iter; /* stop after this many consecutive iterations within acceptable_tol (IPOPT's
                               * acceptable_iter, 15); 0 = 15                                       */
+    int32_t slack_reset;     /* line search of the regular phase: 0 off (MPCCBF of both unicycles and the DynamicUnicycle2D
+                              * optimal-decay class: measured to change nothing there); 2: s = g where g >= mu / nu after a
+                              * trial step -- the setting of the config-5 extension (Unicycle2D optimal decay, N = 20,
+                              * superellipsoids), oracle/od_mpc_rd1.py                              */
+    int32_t reserved;
     double  dt;              /* robot.dt                                                           */
     double  Q[4];            /* diagonal state weights, DU: 50,50,.01,30 (mpc_cbf.py:25-27)        */
     double  R[2];            /* input-rate weights of mpc.set_rterm, DU: .5,.5 (mpc_cbf.py:180)    */
@@ -279,7 +284,7 @@ typedef struct sc_mpclin_params {
                                 sc_mpclin_solve_batch (restoration and continuation launches included).                        */
     int32_t slack_reset;     /* line search of the regular phase: 0 off; 2: s = g where g >= mu / nu after a trial step (as in
                                 sc_mpcgn_params; the oracle's setting for the linear models since round 4: Quad3D at N = 20 crawled
-                                for hundreds of iterations without it).  optimal_decay = 1 ignores it.                        */
+                                for hundreds of iterations without it; optimal_decay = 1, the config-5 extension, uses it too).     */
     int32_t reserved;
     double  alpha;           /* DT-CBF gain: SI 0.05 (mpc_cbf.py:48-50), Quad3D 0.15 (:77-78)              */
     double  robot_radius, beta, tol, acceptable_tol, mu_init, mu_min;   /* as sc_mpccbf_params            */

@@ -34,7 +34,10 @@ from . import mpc_lin as L
 
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_INACCURATE = M.STATUS_OPTIMAL, M.STATUS_INFEASIBLE, M.STATUS_INACCURATE
 
-OD_DEFAULTS = dict(omega1=1.0, p_sb1=10.0, rterm="u2")
+OD_DEFAULTS = dict(omega1=1.0, p_sb1=10.0, rterm="u2",
+                   slack_reset=2)   # round 4: the line search resets slacks (oracle/mpc_cbf.py: solve).  On the config-5 batches (N = 20,
+                                    # superellipsoids) Quad3D went from 245 of 256 optimal, 33.5 iterations mean, 477 max to 256 of 256, 14.9, 34;
+                                    # Unicycle2D from 255, 31.3, 222 to 256, 20.7, 40.
 
 
 def uni_params(N=10, **over):
@@ -184,6 +187,8 @@ def solve(x0, u_prev, goal, obs, P, return_info=False, linear_algebra="schur"):
         for _ in range(12):
             zt, st = zz + alpha * dzz, s + alpha * ds
             e0 = evaluate(x0, zt, goal, obs, P, level=0)
+            if P.get("slack_reset", 0) == 2:                               # s_i = g_i where g_i >= mu / nu: the minimiser of the merit function in s
+                st = np.where(e0["g"] >= mu / nu_m, e0["g"], st)
             if Hq is not None:
                 phit = phi0 + alpha * float(grad @ dzz) + 0.5 * alpha * alpha * curv \
                     - mu * float(np.sum(np.log(st) - np.log(s))) \
@@ -196,7 +201,7 @@ def solve(x0, u_prev, goal, obs, P, return_info=False, linear_algebra="schur"):
             alpha *= 0.5
         if not accepted:
             break
-        zz, s = zz + alpha * dzz, s + alpha * ds
+        zz, s = zz + alpha * dzz, (st if P.get("slack_reset", 0) == 2 else s + alpha * ds)
         lam = lam + ad * dlam
         lam = np.minimum(np.maximum(lam, mu / (1e10 * s)), 1e10 * mu / s)
     if status != STATUS_OPTIMAL and e_best <= P["acceptable_tol"]:

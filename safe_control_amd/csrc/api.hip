@@ -200,6 +200,7 @@ static int check_mpccbf(const sc_mpccbf_params* p, int64_t B, int32_t K, const v
     if (B > 0 && (!X || !u_prev || !goal || !obs || !u_out || !status_out))
         return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
+    if (p->slack_reset != 0 && p->slack_reset != 2) return fail(SC_ERR_INVALID_ARGUMENT, "slack_reset must be 0 or 2");
     return check_resto(p->resto);
 }
 static int check_mpclin_dims(const sc_mpclin_params* p) {

@@ -1191,7 +1191,8 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         SC_PH(10);
         // l1-merit backtracking
         alpha = ap;
-        const bool rreset = RESTO && resto && p.resto.slack_reset != 0;
+        // slack reset of the line search: restoration sc_resto_params.slack_reset, otherwise sc_mpccbf_params.slack_reset = 2
+        const bool rreset = (RESTO && resto) ? p.resto.slack_reset != 0 : p.slack_reset == 2;
         const double thr_reset = mu * rcp_(nu);
         for (int ls = 0; ls < 12; ++ls) {                              // at most 12 halvings, then give up (best iterate)
             for (int i = lane; i < n; i += 64) {
@@ -1211,7 +1212,7 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
                     lst.add(tt); st_ += tt;
                     tot += tt;
                 }
-                // slack reset of the restoration's line search (sc_resto_params.slack_reset): s = g + t where that is >= mu / nu
+                // slack reset (t = 0 outside the restoration): s = g + t where that is >= mu / nu
                 const double st = (rreset && tot >= thr_reset) ? tot : s_lin;
                 lst.add(st);
                 srp += fabs(tot - st);
@@ -1276,7 +1277,7 @@ __device__ __forceinline__ void mpccbf_body(double* sm, const sc_mpccbf_params& 
         }
         delta_force = 0.0; n_retry = 0;
         {
-        const bool rreset = RESTO && resto && p.resto.slack_reset != 0;   // W.g holds the accepted trial point's rows
+        const bool rreset = (RESTO && resto) ? p.resto.slack_reset != 0 : p.slack_reset == 2;   // W.g holds the accepted trial point's rows
         const double thr_reset = mu * rcp_(nu);
         for (int i = lane; i < m; i += 64) {
             const double s_lin = W.sl[i] + alpha * W.ds[i];

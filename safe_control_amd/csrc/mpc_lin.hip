@@ -798,7 +798,7 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         alpha = ap;
         fresh = false;
         // slack reset of the line search: restoration sc_resto_params.slack_reset, regular phase sc_mpclin_params.slack_reset = 2
-        const bool rreset = RESTO && (resto ? p.resto.slack_reset != 0 : p.slack_reset == 2);
+        const bool rreset = (RESTO && resto) ? p.resto.slack_reset != 0 : p.slack_reset == 2;
         const double thr_reset = mu * rcp_(nu_m);
         for (int ls = 0; ls < 12; ++ls) {
             for (int i = lane; i < n; i += TH) W.zt[i] = W.z[i] + alpha * W.dz[i];
@@ -881,7 +881,7 @@ void mpclin_kernel(const sc_mpclin_params p, const double* __restrict__ model, c
         if constexpr (OD) for (int k = lane; k < N; k += TH) W.rho[k] = W.rho[k] + alpha * W.drho[k];
         delta_force = 0.0; n_retry = 0;
         {
-        const bool rreset = RESTO && (resto ? p.resto.slack_reset != 0 : p.slack_reset == 2);   // W.g holds the accepted trial point's rows
+        const bool rreset = (RESTO && resto) ? p.resto.slack_reset != 0 : p.slack_reset == 2;   // W.g holds the accepted trial point's rows
         const double thr_reset = mu * rcp_(nu_m);
         for (int i = lane; i < m; i += TH) {
             const double s_lin = W.s[i] + alpha * W.ds[i];

@@ -68,8 +68,9 @@ def pad_obstacles(obs, num_obs):
 
 
 def make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_shared=False,
-                tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER, mu_init=0.1, mu_min=1e-9, acceptable_tol=1e-5, resto=None):
+                tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER, mu_init=0.1, mu_min=1e-9, acceptable_tol=1e-5, resto=None, slack_reset=0):
     p = _lib.MpcCbfParams()
+    p.slack_reset = int(slack_reset)                         # 2: the config-5 extension (oracle/od_mpc_rd1.py)
     p.model_id = _lib.MODEL_IDS[robot_spec["model"]]
     p.io_dtype = io_dtype
     p.horizon = int(horizon)

@@ -34,10 +34,10 @@ def default_od_mpc_param(model, extension=False):
 
 
 def make_od_mpc_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_shared=False, tol=1e-6,
-                       max_iter=_lib.IPOPT_MAX_ITER):
+                       max_iter=_lib.IPOPT_MAX_ITER, slack_reset=0):
     p = _lib.OdMpcCbfParams()
     p.mpc = make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_shared=obs_shared, tol=tol,
-                        max_iter=max_iter)
+                        max_iter=max_iter, slack_reset=slack_reset)
     p.omega_ref[0] = float(cbf_param.get("omega1", 1.0))
     p.omega_ref[1] = float(cbf_param.get("omega2", 1.0))
     p.p_sb[0] = float(cbf_param.get("p_sb1", 10.0))
@@ -162,7 +162,8 @@ class BatchedOptimalDecayMPCCBF:
         z = torch.empty((B, 2 * self.horizon), dtype=dt_, device=X.device) if want_z else None
         p = make_od_mpc_params(self.robot_spec, self.cbf_param, self.Q, self.R, self.horizon, self.dt,
                                self.robot_spec["radius"], self.io_dtype, obs_shared=shared, tol=self.tol,
-                               max_iter=self.max_iter)
+                               max_iter=self.max_iter,
+                               slack_reset=2 if (self.extension and self.robot_spec["model"] == "Unicycle2D") else 0)   # oracle/od_mpc_rd1.py
         stream = torch.cuda.current_stream(X.device).cuda_stream
         rc = self._lib.sc_odmpccbf_solve_batch(
             C.byref(p), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(),
