@@ -236,6 +236,27 @@ class BatchedTrackingController:
         self.steps_done += n
         return (self.ret, tX, tU) if record else self.ret
 
+    def _dummy_rows(self, like):
+        """[1000, 1000, 0, 0, 0, 0, 0] rows (update_tvp's padding, mpc_cbf.py:360) in the shape of one obstacle selection."""
+        d = getattr(self, "_dummy_obs", None)
+        if d is None or d.shape != like.shape[1:] or d.dtype != like.dtype:
+            d = self.torch.zeros(like.shape[1:], dtype=like.dtype, device=like.device)
+            d[:, 0] = 1000.0; d[:, 1] = 1000.0
+            self._dummy_obs = d
+        return d.unsqueeze(0)
+
+    def _easy_problem(self, X, goal):
+        """State and goal rows of a problem every MPC kernel solves in a few iterations (the slots of agents outside 'track')."""
+        e = getattr(self, "_easy", None)
+        if e is None or e[0].shape[1] != X.shape[1] or e[0].dtype != X.dtype:
+            xe = self.torch.zeros((1, X.shape[1]), dtype=X.dtype, device=X.device)
+            ge = self.torch.zeros((1, goal.shape[1]), dtype=goal.dtype, device=goal.device)
+            ge[0, 0] = 1.0
+            if X.shape[1] == 4:
+                xe[0, 3] = 0.5                                     # unicycles / bicycle: 0.5 m/s along x; DoubleIntegrator2D: 0.5 m/s along y
+            self._easy = e = (xe, ge)
+        return e
+
     def _control_step_split(self, n, record):
         """control_step with an MPC position controller: per step  select (tracking.py:569-609) -> one MPC launch for
         the whole batch -> apply (tracking.py:627-668).  Agents whose state machine is not 'track' get u_ref
@@ -261,10 +282,20 @@ class BatchedTrackingController:
             # OptimalDecayMPCCBF has five fixed obstacle slots (optimal_decay_mpc_cbf.py:249-252,333-339: padded_obs[:5]):
             # it sees the five nearest of the selected rows, MPCCBF all num_constraints of them
             obs_in = obs_sel[:, :5].contiguous() if (self.pos_controller_type == "optimal_decay_mpc_cbf" and K > 5) else obs_sel
-            out = self.mpc.solve(Xm, self.u_prev, goal2, obs_in)
+            # Agents outside 'track' get u_ref and the reference does not solve for them (mpc_cbf.py:379-381).  Their slots of the batched
+            # launch are handed ONE easy problem (_easy_problem: a short run to a goal 1 m ahead, dummy obstacle rows) instead of a solve
+            # whose result is discarded and which may run the whole iteration budget: an agent turning on the spot (v = 0) makes a
+            # degenerate NLP that crawled for up to 1700 iterations.  No host round trip: four selects on the device.
+            tr = (track != 0).unsqueeze(1)
+            xe, ge = self._easy_problem(Xm, goal2)
+            X_in = torch.where(tr, Xm, xe).contiguous()
+            goal_in = torch.where(tr, goal2, ge).contiguous()
+            up_in = torch.where(tr, self.u_prev, torch.zeros_like(self.u_prev)).contiguous()
+            obs_in = torch.where(tr.unsqueeze(2), obs_in, self._dummy_rows(obs_in)).contiguous()
+            out = self.mpc.solve(X_in, up_in, goal_in, obs_in)
             u_mpc, st = (out[0], out[2]) if self.pos_controller_type == "optimal_decay_mpc_cbf" else (out[0], out[1])
             its = out[3] if self.pos_controller_type == "optimal_decay_mpc_cbf" else out[2]
-            tr = (track != 0).unsqueeze(1)
+            self._raw_iters, self._raw_track = its, track                      # (what the launch ran, slots outside 'track' included)
             u = torch.where(tr, u_mpc, u_ref).contiguous()
             self.u_prev = torch.where(tr, u_mpc, self.u_prev).contiguous()
             self.mpc_status = torch.where(track != 0, st, self.mpc_status)      # (see BatchedQuadTrackingController: status / iterations of the last solve)
@@ -326,6 +357,7 @@ class BatchedQuadTrackingController(BatchedTrackingController):
         self.fov_angle = math.radians(float(self.robot_spec.get("fov_angle", 70.0)))
         self._lib = _lib.load()
         self.nx, self.nu, self.ng = (12, 4, 3) if self.q3 else ((6, 4, 2) if self.vt else (6, 2, 2))
+        self._pos_cols = [0, 1, 2] if self.q3 else [0, 1]                  # position entries of a state row (Quad3D: x, y, z; planar: x, z)
         X0 = np.asarray(X0, dtype=np.float64)
         if X0.ndim == 1:
             X0 = X0[None, :]
@@ -456,6 +488,20 @@ class BatchedQuadTrackingController(BatchedTrackingController):
             p.inertia, p.f_min, p.f_max = float(rs["inertia"]), float(rs["f_min"]), float(rs["f_max"])
         return p
 
+    def _easy_problem(self, X, goal):
+        """The discarded slots' problem for the quadrotors (at rest, goal 1 m along x) and for VTOL2D (the cruise probe of
+        tests/test_mpcvtol_gpu.py: 12 m/s at 10 m, goal 100 m ahead -- zero airspeed is a singular point of the aero model)."""
+        e = getattr(self, "_easy", None)
+        if e is None:
+            xe = self.torch.zeros((1, self.nx), dtype=X.dtype, device=X.device)
+            ge = self.torch.zeros((1, self.ng), dtype=goal.dtype, device=goal.device)
+            ge[0, 0] = 1.0
+            if self.vt:
+                xe[0, 1], xe[0, 3] = 10.0, 12.0
+                ge[0, 0], ge[0, 1] = 100.0, 10.0
+            self._easy = e = (xe, ge)
+        return e
+
     def control_step(self, n=1, record=False):
         torch = self.torch
         if self.waypoints is None:
@@ -476,9 +522,16 @@ class BatchedQuadTrackingController(BatchedTrackingController):
                 self.state_machine.data_ptr(), self.goal.data_ptr(), obs_ptr, self.ret.data_ptr(), obs_sel.data_ptr(), goal_c.data_ptr(),
                 u_ref.data_ptr(), track.data_ptr(), stream)
             _lib.check(rc, "sc_quadtrack_select_batch")
-            out = self.mpc.solve(self.X, self.u_prev, goal_c, obs_sel)
-            u_mpc, st = out[0], out[1]
+            # (outside 'track' the slot gets a problem that is solved at once -- goal on the vehicle, dummy obstacle rows -- see
+            # BatchedTrackingController._control_step_split)
             tr = (track != 0).unsqueeze(1)
+            xe, ge = self._easy_problem(self.X, goal_c)
+            X_in = torch.where(tr, self.X, xe).contiguous()
+            goal_in = torch.where(tr, goal_c, ge).contiguous()
+            up_in = torch.where(tr, self.u_prev, torch.zeros_like(self.u_prev)).contiguous()
+            obs_in = torch.where(tr.unsqueeze(2), obs_sel, self._dummy_rows(obs_sel)).contiguous()
+            out = self.mpc.solve(X_in, up_in, goal_in, obs_in)
+            u_mpc, st = out[0], out[1]
             u = torch.where(tr, u_mpc, u_ref).contiguous()                       # mpc_cbf.py:379-381: u_ref passes through outside 'track'
             self.u_prev = torch.where(tr, u_mpc, self.u_prev).contiguous()
             # per-agent status / iteration count of the last MPC solve: the reference's `status` stays 'optimal' whatever IPOPT returned
