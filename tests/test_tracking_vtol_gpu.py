@@ -137,8 +137,9 @@ def test_reference_example_scene_flown_with_the_reference_solver_budget():
       solves end infeasible / inaccurate, the aircraft pitches up to its limit meanwhile;
     * from then on the solves converge (more than 85 % of the flight `optimal`): the aircraft climbs over the discs (above 18 m),
       slows down and descends towards the first waypoint, to within 1.5 m of it at less than 2.5 m/s;
-    * in that near-hover the NLPs stop converging (the aero model is singular at zero airspeed), the aircraft pitches over and the
-      flight ends with -2 about 200 control steps in, before the waypoint counts as reached.
+    * the first waypoint counts as reached at control step 188 and the goal becomes the landing point (70, 0.5): the solve of step 189
+      converges and trades pitch for descent at 0.8 m/s (full front thrust, 0.27 rear), the aircraft picks up pitch rate, the NLPs
+      after it stop converging and the flight ends with -2 about 200 control steps in.
     Rounds 3 - 4 (exact-Hessian restoration): 80 % of the solves `optimal_inaccurate`, on the ground before the first wall."""
     p1, p2 = 67.0, 73.0
     obs = np.array([[p1, z, 0.5] for z in (6.0, 7.0, 8.0, 9.0)] + [[p2, float(z), 0.5] for z in range(1, 16)] + [[60.0, 12.0, 1.5]])

@@ -29,12 +29,14 @@ ctl.set_waypoints(wps)
 print("mpc budget", ctl.mpc.max_iter, "slices", ctl.mpc.iter_slices)
 names = {0: "opt", 1: "infeas", 2: "inacc"}
 log = []
+dump = []
 for k in range(steps):
     ret = int(ctl.control_step(1)[0].item())
     X = ctl.X[0].cpu().numpy()
     st = int(ctl.mpc_status[0].item())
     it = int(getattr(ctl, "mpc_iters", torch.zeros(1))[0].item()) if hasattr(ctl, "mpc_iters") else -1
     log.append((k, st, it, X[0], X[1], X[2], X[3]))
+    dump.append(dict(k=k, X_after=X.copy(), u_prev=ctl.u_prev[0].cpu().numpy().copy(), goal=ctl.goal[0].cpu().numpy().copy(), st=st, it=it))
     if k < 8 or k % 10 == 0 or ret != 0:
         print(f"step {k:3d} ret {ret:2d} mpc {names.get(st, st):6s} it {it:5d}  x {X[0]:7.2f} z {X[1]:6.2f} pitch {np.degrees(X[2]):6.1f} deg vx {X[3]:6.2f}  u {ctl.u_pos[0].cpu().numpy().round(3)}")
     if ret != 0:
@@ -43,3 +45,7 @@ sts = np.array([l[1] for l in log])
 print("steps flown", len(log), "ret", ret, "statuses opt/infeas/inacc", [(sts == s).sum() for s in (0, 1, 2)], "goal index", int(ctl.current_goal_index[0].item()))
 print("status per step:", "".join(str(l[1]) for l in log))
 print("iterations per step:", [l[2] for l in log])
+
+if len(sys.argv) > 3:
+    np.savez(sys.argv[3], X=np.array([d["X_after"] for d in dump]), u_prev=np.array([d["u_prev"] for d in dump]), goal=np.array([d["goal"] for d in dump]),
+             st=np.array([d["st"] for d in dump]), it=np.array([d["it"] for d in dump]), obs=obs7, spec_radius=spec.get("radius", 0.0), v_max=spec.get("v_max", 0.0))
