@@ -1,0 +1,955 @@
+"""The MPC-CBF NLP as do-mpc poses it -- MULTIPLE SHOOTING -- solved by a restatement of IPOPT's published algorithm.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).   **Parity unpinned**: do-mpc, casadi and IPOPT are absent from the image
+(SURVEY 8c), so nothing here can be held to an execution of the reference's solver.  What this module is for: the other oracles
+(oracle/mpc_cbf.py, mpc_gn.py, mpc_vtol.py) and every kernel solve the CONDENSED single-shooting problem in z = (u_0 .. u_{N-1})
+from the rollout of u_prev with an l1-merit interior point.  The reference does not.  do-mpc (`state_discretization =
+'discrete'`, `n_robust = 0`; position_control/mpc_cbf.py:162-174) hands IPOPT
+
+    variables    x_0 .. x_N, u_0 .. u_{N-1}                       ((N + 1) nx + N nu)
+    objective    sum_{k<N} l(x_k) + m(x_N) + sum_k (u_k - u_{k-1})' R (u_k - u_{k-1}),  l = m = (x - goal)' Q (x - goal)
+                                                                  mpc_cbf.py:144,176-180;  u_{-1} = the input applied last
+    equalities   x_0 = x0;   x_{k+1} = x_k + (f(x_k) + g(x_k) u_k) dt                    mpc_cbf.py:135-141
+    inequalities -cbf_i(x_k, u_k) <= 0,  k = 0 .. N-1, i < num_obs                       mpc_cbf.py:295-325
+    bounds       on every x_k (k = 0 .. N) and u_k                                       mpc_cbf.py:182-233
+    start        x_k = x0 for EVERY k, u_k = u_prev                                      mpc_cbf.py:366-369 (set_initial_guess)
+
+and IPOPT runs with its defaults (do-mpc only silences it).  Same stationary points as the condensed problem, different iterates,
+different basins on a non-convex problem, different behaviour on infeasible starts.  This module restates that side:
+
+  * `StageNLP`: the multiple-shooting problem for DynamicUnicycle2D (robots/dynamic_unicycle2D.py:42-78,188-238) and VTOL2D
+    (robots/vtol2D.py:118-311,475-497), derivatives by second-order forward mode vectorised over the stages (class VD2);
+    held to tests/golden/mpc_functions.npz like the other oracles (tests/test_oracle_ms.py).
+  * `solve_nlp`: Waechter & Biegler, "On the implementation of an interior-point filter line-search algorithm for large-scale
+    nonlinear programming", Math. Program. 106 (2006) -- the paper IPOPT's documentation cites as its algorithm -- with the
+    option defaults of IPOPT 3.14's documentation: gradient-based scaling (max gradient 100), bound_push = bound_frac = 1e-2,
+    bound_relax_factor 1e-8, bound multipliers 1, least-square equality multipliers (dropped above 1e3), mu_init 0.1 with the
+    monotone update (kappa_mu .2, theta_mu 1.5, kappa_eps 10), tau_min .99, the filter line search (gamma_theta 1e-5, gamma_phi
+    1e-8, delta 1, s_theta 1.1, s_phi 2.3, eta_phi 1e-8, theta_max / theta_min = 1e4 / 1e-4 max(1, theta_0), alpha_min_frac .05),
+    second-order corrections (4, kappa_soc .99), inertia correction (Algorithm IC: 1e-4, x100 / x8 / 1/3, delta_c = 1e-8 mu^.25),
+    kappa_sigma 1e10, kappa_d 1e-5, tol 1e-8 (+ dual_inf 1, constr_viol 1e-4, compl 1e-4 unscaled), acceptable 1e-6 x 15,
+    max_iter 3000, and the feasibility restoration phase of section 3.3 (rho 1000, zeta = sqrt(mu), D_R = 1 / max(1, |x_R|),
+    closed-form n / p start, leaves when the iterate is acceptable to the original filter with 10 % less infeasibility;
+    multipliers 0 and bound multipliers kept (<= 1e3) on return; "converged to a point of local infeasibility" when it
+    converges instead).
+    NOT restated: the watchdog, the soft restoration phase, the tiny-step and iterative-refinement heuristics and MUMPS'
+    pivoting (LAPACK's Bunch-Kaufman factorisation supplies the inertia here) -- the iterates of a real IPOPT run differ
+    in the digits those choices touch.
+  * Linear algebra: the slacks and the restoration's n / p are eliminated from the primal-dual system (each sits in one row
+    with coefficient +-1 and a diagonal Hessian block), every constraint row is kept: a dense symmetric indefinite system of
+    order n + m (792 for VTOL2D, 188 for config 3).
+"""
+import math
+
+import numpy as np
+from scipy.linalg import lapack
+
+INF = np.inf
+
+
+# ---- second-order forward mode, vectorised over a batch (the stages of the horizon) -----------------------------------
+class VD2:
+    """value (B,), gradient (B, n), Hessian (B, n, n)."""
+    __slots__ = ("v", "d", "H")
+    __array_ufunc__ = None
+
+    def __init__(self, v, d, H):
+        self.v, self.d, self.H = v, d, H
+
+    @staticmethod
+    def seed(vals):
+        """vals (B, n) -> n independent variables."""
+        B, n = vals.shape
+        Z = np.zeros((B, n, n))
+        eye = np.eye(n)
+        return [VD2(vals[:, i].copy(), np.tile(eye[i], (B, 1)), Z) for i in range(n)]
+
+    def _c(self, o):
+        return VD2(np.full_like(self.v, o), np.zeros_like(self.d), np.zeros_like(self.H))
+
+    def chain(self, f, f1, f2):
+        return VD2(f, f1[:, None] * self.d, f1[:, None, None] * self.H + f2[:, None, None] * (self.d[:, :, None] * self.d[:, None, :]))
+
+    def __add__(self, o):
+        if isinstance(o, VD2):
+            return VD2(self.v + o.v, self.d + o.d, self.H + o.H)
+        return VD2(self.v + o, self.d, self.H)
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        if isinstance(o, VD2):
+            return VD2(self.v - o.v, self.d - o.d, self.H - o.H)
+        return VD2(self.v - o, self.d, self.H)
+
+    def __rsub__(self, o):
+        return VD2(o - self.v, -self.d, -self.H)
+
+    def __neg__(self):
+        return VD2(-self.v, -self.d, -self.H)
+
+    def __mul__(self, o):
+        if isinstance(o, VD2):
+            x = self.d[:, :, None] * o.d[:, None, :]
+            return VD2(self.v * o.v, self.v[:, None] * o.d + o.v[:, None] * self.d,
+                       self.v[:, None, None] * o.H + o.v[:, None, None] * self.H + x + x.transpose(0, 2, 1))
+        return VD2(self.v * o, self.d * o, self.H * o)
+    __rmul__ = __mul__
+
+    def recip(self):
+        r = 1.0 / self.v
+        return self.chain(r, -r * r, 2.0 * r * r * r)
+
+    def __truediv__(self, o):
+        if isinstance(o, VD2):
+            return self * o.recip()
+        return self * (1.0 / o)
+
+    def __rtruediv__(self, o):
+        return self.recip() * o
+
+    def __pow__(self, p):
+        return self.chain(self.v ** p, p * self.v ** (p - 1), p * (p - 1) * self.v ** (p - 2))
+
+
+def _sin(a):
+    return a.chain(np.sin(a.v), np.cos(a.v), -np.sin(a.v)) if isinstance(a, VD2) else np.sin(a)
+
+
+def _cos(a):
+    return a.chain(np.cos(a.v), -np.sin(a.v), -np.cos(a.v)) if isinstance(a, VD2) else np.cos(a)
+
+
+def _exp(a):
+    if isinstance(a, VD2):
+        e = np.exp(a.v)
+        return a.chain(e, e, e)
+    return np.exp(a)
+
+
+def _sqrt(a):
+    if isinstance(a, VD2):
+        r = np.sqrt(a.v)
+        return a.chain(r, 0.5 / r, -0.25 / (r * a.v))
+    return np.sqrt(a)
+
+
+def _abs(a):
+    if isinstance(a, VD2):
+        sg = np.sign(a.v)
+        return VD2(np.abs(a.v), sg[:, None] * a.d, sg[:, None, None] * a.H)
+    return np.abs(a)
+
+
+def _atan2(y, x):
+    if isinstance(y, VD2) or isinstance(x, VD2):
+        ref = y if isinstance(y, VD2) else x
+        y = y if isinstance(y, VD2) else ref._c(y)
+        x = x if isinstance(x, VD2) else ref._c(x)
+        r2 = x.v * x.v + y.v * y.v
+        ty, tx = x.v / r2, -y.v / r2
+        tyy, txx, txy = -2.0 * x.v * y.v / (r2 * r2), 2.0 * x.v * y.v / (r2 * r2), (y.v * y.v - x.v * x.v) / (r2 * r2)
+        oyy = y.d[:, :, None] * y.d[:, None, :]
+        oxx = x.d[:, :, None] * x.d[:, None, :]
+        oyx = y.d[:, :, None] * x.d[:, None, :]
+        H = ty[:, None, None] * y.H + tx[:, None, None] * x.H + tyy[:, None, None] * oyy + txx[:, None, None] * oxx \
+            + txy[:, None, None] * (oyx + oyx.transpose(0, 2, 1))
+        return VD2(np.arctan2(y.v, x.v), ty[:, None] * y.d + tx[:, None] * x.d, H)
+    return np.arctan2(y, x)
+
+
+# ---- models: x+ = x + (f(x) + g(x) u) dt, written once for floats-arrays and for VD2 ---------------------------------------
+def du_next(x, u, spec, dt):
+    """DynamicUnicycle2D: f = [v cos th, v sin th, 0, 0], g u = [0, 0, w, a]   (dynamic_unicycle2D.py:42-73; U = [a, w])."""
+    c, s = _cos(x[2]), _sin(x[2])
+    return [x[0] + x[3] * c * dt, x[1] + x[3] * s * dt, x[2] + u[1] * dt, x[3] + u[0] * dt]
+
+
+GRAVITY = 9.81                                                   # vtol2D.py:113
+
+
+def _vt_ldm(V2, alpha, delta_e, s):
+    """vtol2D.py:348-401 (lift blending, lift / drag / moment); V2 = V^2."""
+    sig_a = _exp(-s["M"] * (alpha - s["alpha_0"]))
+    sig_b = _exp(s["M"] * (alpha + s["alpha_0"]))
+    sigma = (1.0 + sig_a + sig_b) / ((1.0 + sig_a) * (1.0 + sig_b))
+    CL_lin = s["C_L0"] + s["C_Lalpha"] * alpha
+    CL_non = 2.0 * _sin(alpha) * _cos(alpha)
+    CL = (1.0 - sigma) * CL_lin + sigma * CL_non + s["C_Ldelta_e"] * delta_e
+    CD = s["C_D0"] + s["C_Dalpha"] * (alpha * alpha) + s["C_Ddelta_e"] * delta_e
+    CM = s["C_m0"] + s["C_malpha"] * alpha + s["C_mdelta_e"] * delta_e
+    qS = (0.5 * s["rho"] * s["S_wing"]) * V2
+    return qS * CL, qS * CD, qS * CM * s["chord"]
+
+
+def vt_next(x, u, s, dt):
+    """VTOL2D (vtol2D.py:118-311): body velocity :333-343, wind -> inertial :410-419, rotors :424-452."""
+    th, xd, zd, thd = x[2], x[3], x[4], x[5]
+    c, sn = _cos(th), _sin(th)
+    u_b, w_b = c * xd + sn * zd, c * zd - sn * xd
+    V2 = u_b * u_b + w_b * w_b                                  # (sqrt(.))^2 of the reference: equal to the last bit or two
+    alpha = _atan2(-w_b, u_b)
+    m, I = s["mass"], s["inertia"]
+    L0, D0, M0 = _vt_ldm(V2, alpha, 0.0, s)
+    Le, De, Me = _vt_ldm(V2, alpha, 1.0, s)
+    hd = th + alpha
+    ch, sh = _cos(hd), _sin(hd)
+    fx, fz = -(ch * D0) - sh * L0, ch * L0 - sh * D0            # _wind_to_inertial(theta, alpha, -D, L)
+    ex, ez = -(ch * De) - sh * Le, ch * Le - sh * De
+    kf, kr, kp = s["k_front"], s["k_rear"], s["k_pusher"]
+    ax = fx / m + (-(sn * kf) / m) * u[0] + (-(sn * kr) / m) * u[1] + ((c * kp) / m) * u[2] + (ex / m) * u[3]
+    az = (fz - m * GRAVITY) / m + ((c * kf) / m) * u[0] + ((c * kr) / m) * u[1] + ((sn * kp) / m) * u[2] + (ez / m) * u[3]
+    at = M0 / I + (s["ell_f"] * kf / I) * u[0] + (-s["ell_r"] * kr / I) * u[1] + (Me / I) * u[3]
+    return [x[0] + xd * dt, x[1] + zd * dt, x[2] + thd * dt, x[3] + ax * dt, x[4] + az * dt, x[5] + at * dt]
+
+
+def du_model(spec=None, dt=0.05):
+    s = dict(v_max=1.0, a_max=1.0, w_max=0.5, radius=0.25)
+    s.update(spec or {})
+    return dict(name="DynamicUnicycle2D", nx=4, nu=2, next=du_next, spec=s, dt=dt, N=10, Q=np.array([50.0, 50.0, 0.01, 30.0]),
+                R=np.array([0.5, 0.5]), alpha1=0.15, alpha2=0.15, beta=1.01, radius=s["radius"],
+                u_lo=np.array([-s["a_max"], -s["w_max"]]), u_hi=np.array([s["a_max"], s["w_max"]]),
+                x_lo=np.array([-INF, -INF, -INF, -s["v_max"]]), x_hi=np.array([INF, INF, INF, s["v_max"]]))
+
+
+def vtol_model(spec=None, dt=0.05):
+    from . import mpc_vtol as OV
+    s = OV.default_spec(**(spec or {}))
+    pm = s["pitch_max"] * 3.14159 / 180                        # mpc_cbf.py:232-233
+    return dict(name="VTOL2D", nx=6, nu=4, next=vt_next, spec=s, dt=dt, N=30, Q=np.array([10.0, 10.0, 250.0, 10.0, 10.0, 50.0]),
+                R=np.array([0.5, 0.5, 0.5, 50000.0]), alpha1=0.05, alpha2=0.05, beta=1.01, radius=s["radius"],
+                u_lo=np.array([s["throttle_min"]] * 3 + [s["elevator_min"]]), u_hi=np.array([s["throttle_max"]] * 3 + [s["elevator_max"]]),
+                x_lo=np.array([-INF, -INF, -pm, -s["v_max"], -s["descent_speed_max"], -INF]),
+                x_hi=np.array([INF, INF, pm, s["v_max"], INF, INF]))
+
+
+class StageNLP:
+    """min f(w)  s.t.  c(w) = 0,  d(w) <= 0,  w_lo <= w <= w_hi   with w = [x_0, u_0, x_1, u_1, .., x_{N-1}, u_{N-1}, x_N]."""
+
+    def __init__(self, model, x0, u_prev, goal, obs, N=None):
+        self.mdl = model
+        self.N = N = int(N or model["N"])
+        self.nx, self.nu = nx, nu = model["nx"], model["nu"]
+        self.nv = nx + nu
+        self.x0 = np.asarray(x0, dtype=float).reshape(-1)[:nx].copy()
+        self.u_prev = np.asarray(u_prev, dtype=float).reshape(-1)[:nu].copy()
+        self.xg = np.zeros(nx)
+        self.xg[:2] = np.asarray(goal, dtype=float).reshape(-1)[:2]     # goal padded with zeros (mpc_cbf.py:267)
+        self.obs = np.asarray(obs, dtype=float)
+        self.circles_only = model["name"] == "VTOL2D"                  # vtol2D.py:482-490 has no superellipsoid branch
+        self.K = K = self.obs.shape[0]
+        self.n = (N + 1) * nx + N * nu
+        self.m_c = (N + 1) * nx
+        self.m_d = N * K
+        self.ix = np.array([k * self.nv + np.arange(nx) for k in range(N + 1)])          # (N+1, nx) indices of x_k
+        self.iu = np.array([k * self.nv + nx + np.arange(nu) for k in range(N)])          # (N, nu)
+        self.w_lo = np.full(self.n, -INF)
+        self.w_hi = np.full(self.n, INF)
+        self.w_lo[self.ix] = model["x_lo"]
+        self.w_hi[self.ix] = model["x_hi"]
+        self.w_lo[self.iu] = model["u_lo"]
+        self.w_hi[self.iu] = model["u_hi"]
+        self.d_lo = np.full(self.m_d, -INF)
+        self.d_hi = np.zeros(self.m_d)
+        g1, g2 = model["alpha1"] + model["alpha2"], model["alpha1"] * model["alpha2"]
+        self.cw = (1.0 - g1 + g2, g1 - 2.0, 1.0)                        # weights of h(x), h(x1), h(x2): dd_h + g1 d_h + g2 h
+        self.n_eval = 0
+
+    def initial_guess(self):
+        """set_initial_guess (mpc_cbf.py:366-369): every stage's state at x0, every input at the input applied last."""
+        w = np.zeros(self.n)
+        w[self.ix] = self.x0
+        w[self.iu] = self.u_prev
+        return w
+
+    def split(self, w):
+        return w[self.ix], w[self.iu]
+
+    def _h(self, px, pz):
+        """h_j = |p - p_obs_j|^2 - beta (R + r_j)^2 for every obstacle (agent_barrier_dt: dynamic_unicycle2D.py:194-202, vtol2D.py:482-490)."""
+        out = []
+        R = self.mdl["radius"]
+        for j in range(self.K):
+            o = self.obs[j]
+            if o[6] < 0.5 or self.circles_only:
+                dmin = R + o[2]
+                ex, ez = px - o[0], pz - o[1]
+                out.append(ex * ex + ez * ez - self.mdl["beta"] * dmin * dmin)
+                continue
+            # superellipsoid (dynamic_unicycle2D.py:204-220): fabs, clamps a, b >= 1e-3, e >= 2
+            a, b, e = max(abs(o[2]), 1e-3) + R, max(abs(o[3]), 1e-3) + R, max(abs(o[4]), 2.0)
+            ct, st = math.cos(o[5]), math.sin(o[5])
+            qx, qy = ct * (px - o[0]) + st * (pz - o[1]), ct * (pz - o[1]) - st * (px - o[0])
+            out.append(_abs(qx) ** e / a ** e + _abs(qy) ** e / b ** e - 1.0)
+        return out
+
+    def _rows(self, x, u):
+        """d_kj = -(dd_h + (a1 + a2) d_h + a1 a2 h) with x1 = step(x, u), x2 = step(x1, u) (mpc_cbf.py:304,316-321); the heading /
+        pitch wrap inside step() touches no position."""
+        spec, dt, nxt = self.mdl["spec"], self.mdl["dt"], self.mdl["next"]
+        x1 = nxt(x, u, spec, dt)
+        x2 = nxt(x1, u, spec, dt)
+        h0, h1, h2 = self._h(x[0], x[1]), self._h(x1[0], x1[1]), self._h(x2[0], x2[1])
+        w0, w1, w2 = self.cw
+        return x1, [-(w2 * h2[j] + w1 * h1[j] + w0 * h0[j]) for j in range(self.K)]
+
+    def evaluate(self, w, level=2):
+        """level 0: f, c, d.   level 2: + grad f, J_c, J_d and `hess(sigma_f, y_c, y_d)`."""
+        self.n_eval += 1
+        N, nx, nu, nv, K = self.N, self.nx, self.nu, self.nv, self.K
+        X, U = self.split(w)
+        Q, R = self.mdl["Q"], self.mdl["R"]
+        e = X - self.xg
+        up = np.vstack([self.u_prev[None, :], U])
+        du = up[1:] - up[:-1]
+        f = float(np.sum(Q * e * e) + np.sum(R * du * du))
+        out = dict(f=f)
+        if level == 0:
+            xs = [X[:N, i] for i in range(nx)]
+            us = [U[:, i] for i in range(nu)]
+            x1, rows = self._rows(xs, us)
+            c = np.concatenate([X[0] - self.x0, (np.stack(x1, axis=1) - X[1:]).reshape(-1)])
+            out.update(c=c, d=np.stack(rows, axis=1).reshape(-1))
+            return out
+        V = VD2.seed(np.hstack([X[:N], U]))
+        x1, rows = self._rows(V[:nx], V[nx:])
+        c = np.concatenate([X[0] - self.x0, (np.stack([a.v for a in x1], axis=1) - X[1:]).reshape(-1)])
+        d = np.stack([r.v for r in rows], axis=1).reshape(-1)
+        grad = np.zeros(self.n)
+        grad[self.ix] = 2.0 * Q * e
+        gu = 2.0 * R * du
+        grad[self.iu] += gu
+        grad[self.iu[:-1]] -= gu[1:]
+        Jc = np.zeros((self.m_c, self.n))
+        Jc[np.arange(nx), np.arange(nx)] = 1.0
+        Jd = np.zeros((self.m_d, self.n))
+        F1 = np.stack([a.d for a in x1], axis=1)                          # (N, nx, nv)
+        D1 = np.stack([r.d for r in rows], axis=1)                        # (N, K, nv)
+        for k in range(N):
+            r0 = nx + k * nx
+            Jc[r0:r0 + nx, k * nv:(k + 1) * nv] = F1[k]
+            Jc[np.arange(r0, r0 + nx), (k + 1) * nv + np.arange(nx)] = -1.0
+            Jd[k * K:(k + 1) * K, k * nv:(k + 1) * nv] = D1[k]
+        FH = np.stack([a.H for a in x1], axis=1)                          # (N, nx, nv, nv)
+        DH = np.stack([r.H for r in rows], axis=1)                        # (N, K, nv, nv)
+        Hf = np.zeros((self.n, self.n))
+        Hf[self.ix, self.ix] = 2.0 * Q
+        for k in range(N):
+            iu = self.iu[k]
+            Hf[iu, iu] += 2.0 * R
+            if k + 1 < N:
+                Hf[iu, iu] += 2.0 * R
+                Hf[iu, self.iu[k + 1]] -= 2.0 * R
+                Hf[self.iu[k + 1], iu] -= 2.0 * R
+
+        def hess(sigma_f, y_c, y_d):
+            W = sigma_f * Hf
+            yc = y_c[nx:].reshape(N, nx)
+            yd = y_d.reshape(N, K)
+            blk = np.einsum("ki,kiab->kab", yc, FH) + np.einsum("kj,kjab->kab", yd, DH)
+            for k in range(N):
+                W[k * nv:(k + 1) * nv, k * nv:(k + 1) * nv] += blk[k]
+            return W
+
+        out.update(c=c, d=d, grad=grad, Jc=Jc, Jd=Jd, hess=hess)
+        return out
+
+    def x_bounds(self):
+        return self.w_lo, self.w_hi
+
+    def u0(self, w):
+        return w[self.iu[0]].copy()
+
+
+# ---- the interior point -----------------------------------------------------------------------------------------------
+OPTS = dict(tol=1e-8, max_iter=3000, dual_inf_tol=1.0, constr_viol_tol=1e-4, compl_inf_tol=1e-4,
+            acceptable_tol=1e-6, acceptable_iter=15, acceptable_dual_inf_tol=1e10, acceptable_constr_viol_tol=1e-2, acceptable_compl_inf_tol=1e-2,
+            nlp_scaling_max_gradient=100.0, nlp_scaling_min_value=1e-8, bound_relax_factor=1e-8,
+            bound_push=1e-2, bound_frac=1e-2, bound_mult_init_val=1.0, constr_mult_init_max=1e3,
+            mu_init=0.1, mu_linear_decrease_factor=0.2, mu_superlinear_decrease_power=1.5, barrier_tol_factor=10.0, tau_min=0.99,
+            kappa_sigma=1e10, kappa_d=1e-5, s_max=100.0,
+            theta_max_fact=1e4, theta_min_fact=1e-4, eta_phi=1e-8, delta=1.0, s_phi=2.3, s_theta=1.1, gamma_phi=1e-8, gamma_theta=1e-5,
+            alpha_min_frac=0.05, alpha_red_factor=0.5, max_soc=4, kappa_soc=0.99, obj_max_inc=5.0,
+            first_hessian_perturbation=1e-4, min_hessian_perturbation=1e-20, max_hessian_perturbation=1e20,
+            perturb_inc_fact_first=100.0, perturb_inc_fact=8.0, perturb_dec_fact=1.0 / 3.0, jacobian_regularization_value=1e-8,
+            jacobian_regularization_exponent=0.25,
+            resto_penalty_parameter=1000.0, resto_proximity_weight=1.0, required_infeasibility_reduction=0.9,
+            bound_mult_reset_threshold=1e3, constr_mult_reset_threshold=0.0, resto_failure_feasibility_threshold=1e-6,
+            resto_theta_max_fact=1e8)
+
+EPS = np.finfo(float).eps
+
+
+def compare_le(lhs, rhs, basval):
+    """IPOPT's Compare_le: lhs <= rhs up to 10 eps |basval|."""
+    return lhs - rhs <= 10.0 * EPS * abs(basval)
+
+
+class _Problem:
+    """min f(x) + rho_t' t   s.t.  g(x) + A_t t = 0,  x_L <= x <= x_U,  t_L <= t <= t_U;  every column of A_t is +-e_row.
+    Regular phase: g = [c; d] scaled, t = the slacks of the d rows.  Restoration: + n, p >= 0 on every row."""
+
+
+class _Regular(_Problem):
+    def __init__(self, nlp, w_start, o):
+        self.nlp = nlp
+        self.n, self.m_c, self.m_d = nlp.n, nlp.m_c, nlp.m_d
+        self.m = self.m_c + self.m_d
+        ev = nlp.evaluate(w_start, 2)
+        gmax, gmin = o["nlp_scaling_max_gradient"], o["nlp_scaling_min_value"]
+        a = float(np.max(np.abs(ev["grad"]))) if self.n else 0.0
+        self.df = max(gmin, gmax / a) if a > gmax else 1.0
+        J = np.vstack([ev["Jc"], ev["Jd"]])
+        ra = np.max(np.abs(J), axis=1) if self.m else np.zeros(0)
+        self.dg = np.where(ra > gmax, np.maximum(gmin, gmax / np.maximum(ra, 1e-300)), 1.0)
+        rl = o["bound_relax_factor"]
+        lo, hi = nlp.x_bounds()
+        self.x_L = np.where(np.isfinite(lo), lo - rl * np.maximum(1.0, np.abs(lo)), -INF)
+        self.x_U = np.where(np.isfinite(hi), hi + rl * np.maximum(1.0, np.abs(hi)), INF)
+        dl, dh = nlp.d_lo * self.dg[self.m_c:], nlp.d_hi * self.dg[self.m_c:]
+        self.nt = self.m_d
+        self.t_L = np.where(np.isfinite(dl), dl - rl * np.maximum(1.0, np.abs(dl)), -INF)
+        self.t_U = np.where(np.isfinite(dh), dh + rl * np.maximum(1.0, np.abs(dh)), INF)
+        self.t_row = self.m_c + np.arange(self.m_d)
+        self.t_sig = -np.ones(self.m_d)
+        self.t_rho = np.zeros(self.m_d)
+
+    def evaluate(self, x, level, mu=None):
+        ev = self.nlp.evaluate(x, level)
+        out = dict(f=self.df * ev["f"], g=self.dg * np.concatenate([ev["c"], ev["d"]]))
+        if level >= 2:
+            out["grad"] = self.df * ev["grad"]
+            out["J"] = self.dg[:, None] * np.vstack([ev["Jc"], ev["Jd"]])
+            h, df, dg, mc = ev["hess"], self.df, self.dg, self.m_c
+            out["hess"] = lambda y: h(df, dg[:mc] * y[:mc], dg[mc:] * y[mc:])
+        return out
+
+
+class _Resto(_Problem):
+    """Section 3.3:  min rho sum(n + p) + zeta/2 |D_R (x - x_R)|^2   s.t.  g(x) + A_s s + n - p = 0,  n, p >= 0,  zeta = sqrt(mu)."""
+
+    def __init__(self, reg, x_R, o):
+        self.reg = reg
+        self.n, self.m = reg.n, reg.m
+        self.x_L, self.x_U = reg.x_L, reg.x_U
+        m, ms = reg.m, reg.nt
+        self.ns = ms
+        self.nt = ms + 2 * m
+        self.t_L = np.concatenate([reg.t_L, np.zeros(2 * m)])
+        self.t_U = np.concatenate([reg.t_U, np.full(2 * m, INF)])
+        self.t_row = np.concatenate([reg.t_row, np.arange(m), np.arange(m)])
+        self.t_sig = np.concatenate([reg.t_sig, np.ones(m), -np.ones(m)])
+        self.rho = o["resto_penalty_parameter"]
+        self.t_rho = np.concatenate([np.zeros(ms), np.full(2 * m, self.rho)])
+        self.x_R = x_R.copy()
+        self.DR2 = (1.0 / np.maximum(1.0, np.abs(x_R))) ** 2
+        self.eta = o["resto_proximity_weight"]
+
+    def evaluate(self, x, level, mu=None):
+        ev = self.reg.evaluate(x, level)
+        zeta = self.eta * math.sqrt(mu)
+        dx = x - self.x_R
+        out = dict(f=0.5 * zeta * float(np.sum(self.DR2 * dx * dx)), g=ev["g"], f_orig=ev["f"])
+        if level >= 2:
+            out["grad"] = zeta * self.DR2 * dx
+            out["J"] = ev["J"]
+            DR2, hreg = self.DR2, ev["hess"]
+            W0 = hreg(np.zeros(self.m))                                   # = scaled Hessian of the original objective, which does not enter:
+
+            def hess(y):                                                    # zeta D_R^2 + sum_i y_i grad^2 g_i
+                return hreg(y) - W0 + np.diag(zeta * DR2)
+            out["hess"] = hess
+        return out
+
+
+def _dist(v, lo, hi):
+    return v - lo, hi - v                                                  # +inf where there is no bound
+
+
+def _ftb(tau, slack, dslack):
+    """largest alpha in (0, 1] with slack + alpha dslack >= (1 - tau) slack."""
+    neg = dslack < 0
+    if not np.any(neg):
+        return 1.0
+    return min(1.0, float(np.min(-tau * slack[neg] / dslack[neg])))
+
+
+class _Filter:
+    def __init__(self):
+        self.e = []
+
+    def acceptable(self, phi, theta):
+        for (p, t) in self.e:
+            if not (compare_le(phi, p, p) or compare_le(theta, t, t)):
+                return False
+        return True
+
+    def add(self, phi, theta):
+        self.e = [(p, t) for (p, t) in self.e if not (p >= phi and t >= theta)]
+        self.e.append((phi, theta))
+
+    def clear(self):
+        self.e = []
+
+
+class _Algo:
+    """One run of the algorithm on a _Problem; the restoration phase is another _Algo on the _Resto problem."""
+
+    def __init__(self, prob, o, resto_of=None, trace=None):
+        self.P, self.o, self.outer, self.trace = prob, o, resto_of, trace
+        self.in_resto = resto_of is not None
+        self.filter = _Filter()
+        self.delta_w_last = 0.0
+        self.iters = 0
+
+    # -- quantities of an iterate --------------------------------------------------------------------------------------
+    def slacks(self, x, t):
+        P = self.P
+        return _dist(x, P.x_L, P.x_U) + _dist(t, P.t_L, P.t_U)
+
+    def barrier(self, f, x, t, mu):
+        P, kd = self.P, self.o["kappa_d"]
+        sxL, sxU, stL, stU = self.slacks(x, t)
+        if min(np.min(sxL, initial=1.0), np.min(sxU, initial=1.0), np.min(stL, initial=1.0), np.min(stU, initial=1.0)) <= 0.0:
+            return INF
+        phi = f + float(P.t_rho @ t)
+        for s_, o_ in ((sxL, sxU), (sxU, sxL), (stL, stU), (stU, stL)):
+            fin = np.isfinite(s_)
+            phi -= mu * float(np.sum(np.log(s_[fin])))
+            one = fin & ~np.isfinite(o_)
+            phi += kd * mu * float(np.sum(s_[one]))
+        return phi
+
+    def barrier_grad(self, grad, x, t, mu):
+        P, kd = self.P, self.o["kappa_d"]
+        sxL, sxU, stL, stU = self.slacks(x, t)
+        gx = grad - mu / sxL + mu / sxU + kd * mu * ((np.isfinite(sxL) & ~np.isfinite(sxU)).astype(float) - (np.isfinite(sxU) & ~np.isfinite(sxL)).astype(float))
+        gt = P.t_rho - mu / stL + mu / stU + kd * mu * ((np.isfinite(stL) & ~np.isfinite(stU)).astype(float) - (np.isfinite(stU) & ~np.isfinite(stL)).astype(float))
+        return gx, gt
+
+    def residual(self, g, t):
+        P = self.P
+        r = g.copy()
+        np.add.at(r, P.t_row, P.t_sig * t)
+        return r
+
+    def errors(self, ev, x, t, y, z, mu):
+        """E_mu (scaled, eq. (5)) and its parts."""
+        P, smax = self.P, self.o["s_max"]
+        zxL, zxU, ztL, ztU = z
+        sxL, sxU, stL, stU = self.slacks(x, t)
+        dual_x = ev["grad"] + ev["J"].T @ y - zxL + zxU
+        dual_t = P.t_rho + P.t_sig * y[P.t_row] - ztL + ztU
+        r = self.residual(ev["g"], t)
+        comp = 0.0
+        for s_, z_ in ((sxL, zxL), (sxU, zxU), (stL, ztL), (stU, ztU)):
+            fin = np.isfinite(s_)
+            if np.any(fin):
+                comp = max(comp, float(np.max(np.abs(s_[fin] * z_[fin] - mu))))
+        nb = sum(int(np.sum(np.isfinite(s_))) for s_ in (sxL, sxU, stL, stU))
+        zsum = float(sum(np.sum(np.abs(z_)) for z_ in z))
+        sd = max(smax, (float(np.sum(np.abs(y))) + zsum) / max(1, P.m + nb)) / smax
+        sc = max(smax, zsum / max(1, nb)) / smax
+        dinf = max(float(np.max(np.abs(dual_x))), float(np.max(np.abs(dual_t), initial=0.0)))
+        pinf = float(np.max(np.abs(r), initial=0.0))
+        return max(dinf / sd, pinf, comp / sc), dinf, pinf, comp, r
+
+    # -- the primal-dual system ----------------------------------------------------------------------------------------
+    def factor(self, W, J, sig_x, sig_t, mu):
+        """Algorithm IC around the reduced system; returns a solver closure or None (-> restoration)."""
+        P, o = self.P, self.o
+        n, m = P.n, P.m
+        dw, dc = 0.0, 0.0
+        K = np.zeros((n + m, n + m))
+        stage = 0                                                          # 0: unperturbed, 1: delta_c only (singular), 2: delta_w > 0
+        while True:
+            q = 1.0 / (sig_t + dw)
+            e = np.full(m, dc)
+            np.add.at(e, P.t_row, q)
+            K[:n, :n] = W
+            K[np.arange(n), np.arange(n)] += sig_x + dw
+            K[:n, n:] = J.T
+            K[n:, :n] = J
+            K[n:, n:] = 0.0
+            K[n + np.arange(m), n + np.arange(m)] = -e
+            ldu, piv, info = lapack.dsytrf(K, lower=1)
+            singular = info > 0
+            if not singular and self._n_negative(ldu, piv) == m:
+                if dw > 0.0:
+                    self.delta_w_last = dw
+                self.last_delta = (dw, dc)
+                break
+            if stage == 0 and singular:
+                stage, dc = 1, o["jacobian_regularization_value"] * mu ** o["jacobian_regularization_exponent"]
+                continue
+            if stage < 2:
+                stage = 2
+                dw = o["first_hessian_perturbation"] if self.delta_w_last == 0.0 else max(o["min_hessian_perturbation"], o["perturb_dec_fact"] * self.delta_w_last)
+            else:
+                if singular and dc == 0.0:
+                    dc = o["jacobian_regularization_value"] * mu ** o["jacobian_regularization_exponent"]
+                dw = dw * (o["perturb_inc_fact_first"] if self.delta_w_last == 0.0 else o["perturb_inc_fact"])
+            if dw > o["max_hessian_perturbation"]:
+                return None
+
+        def solve(rhs_x, rhs_t, rhs_g):
+            """H dx + J'dy = rhs_x;  (sig_t + dw) dt + sigma dy_row = rhs_t;  J dx + A_t dt - dc dy = rhs_g."""
+            b = np.concatenate([rhs_x, rhs_g])
+            np.subtract.at(b, n + P.t_row, P.t_sig * q * rhs_t)
+            sol, info2 = lapack.dsytrs(ldu, piv, b, lower=1)
+            res = b - self._kmul(W, J, sig_x + dw, e, sol)                  # one step of iterative refinement
+            cor, _ = lapack.dsytrs(ldu, piv, res, lower=1)
+            sol = sol + cor
+            dx, dy = sol[:n], sol[n:]
+            dt = q * (rhs_t - P.t_sig * dy[P.t_row])
+            return dx, dt, dy
+        return solve
+
+    @staticmethod
+    def _kmul(W, J, dxx, e, v):
+        n = W.shape[0]
+        return np.concatenate([W @ v[:n] + dxx * v[:n] + J.T @ v[n:], J @ v[:n] - e * v[n:]])
+
+    @staticmethod
+    def _n_negative(ldu, piv):
+        """negative eigenvalues of the block diagonal of LAPACK's Bunch-Kaufman factorisation (a 2 x 2 pivot has one of each sign)."""
+        nn, k, neg = ldu.shape[0], 0, 0
+        d = np.diagonal(ldu)
+        while k < nn:
+            if piv[k] > 0:
+                if d[k] < 0:
+                    neg += 1
+                k += 1
+            else:
+                neg += 1
+                k += 2
+        return neg
+
+    # -- initialisation ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def push(v, lo, hi, k1, k2):
+        v = v.copy()
+        fl, fu = np.isfinite(lo), np.isfinite(hi)
+        both = fl & fu
+        lo_, hi_ = np.where(fl, lo, 0.0), np.where(fu, hi, 0.0)
+        rng = np.where(both, hi_ - lo_, INF)
+        pl = np.minimum(k1 * np.maximum(1.0, np.abs(lo_)), k2 * rng)
+        pu = np.minimum(k1 * np.maximum(1.0, np.abs(hi_)), k2 * rng)
+        v = np.where(fl, np.maximum(v, lo_ + pl), v)
+        v = np.where(fu, np.minimum(v, hi_ - pu), v)
+        return v
+
+    def ls_multipliers(self, ev, z):
+        """least-square estimate of y for given bound multipliers (section 3.6)."""
+        P = self.P
+        zxL, zxU, ztL, ztU = z
+        sol = self.factor_ls(ev["J"])
+        if sol is None:
+            return np.zeros(P.m)
+        _, _, y = sol(-(ev["grad"] - zxL + zxU), -(P.t_rho - ztL + ztU), np.zeros(P.m))
+        return y
+
+    def factor_ls(self, J):
+        save = self.delta_w_last
+        s = self.factor(np.zeros((self.P.n, self.P.n)), J, np.ones(self.P.n), np.ones(self.P.nt), 1.0)
+        self.delta_w_last = save
+        return s
+
+    # -- main loop -----------------------------------------------------------------------------------------------------
+    def run(self, x, t, y, z, mu, budget):
+        """Returns (status, x, t, y, z, mu, iterations).  status: 'optimal', 'acceptable', 'max_iter', 'resto_failed',
+        'local_infeasibility', 'resto_converged_feasible', 'orig_progress' (restoration only), 'error'."""
+        P, o = self.P, self.o
+        tau = max(o["tau_min"], 1.0 - mu)
+        ev = P.evaluate(x, 2, mu)
+        theta0 = float(np.sum(np.abs(self.residual(ev["g"], t))))
+        fact = o["resto_theta_max_fact"] if self.in_resto else o["theta_max_fact"]
+        self.theta_max = fact * max(1.0, theta0)
+        self.theta_min = o["theta_min_fact"] * max(1.0, theta0)
+        n_acc = 0
+        first_iter = True
+        status = "max_iter"
+        while True:
+            E0, dinf, pinf, comp, r = self.errors(ev, x, t, y, z, 0.0)
+            if self.trace is not None:
+                self.trace.append(dict(it=self.total_iters(), resto=self.in_resto, E0=E0, dinf=dinf, pinf=pinf, comp=comp, mu=mu, f=ev["f"],
+                                       theta=float(np.sum(np.abs(r))), delta=getattr(self, "last_delta", (0, 0))[0], alpha=getattr(self, "last_alpha", 0.0)))
+            # ---- convergence ---------------------------------------------------------------------------------------------
+            if self.in_resto:
+                st = self.outer_progress(x, t, first_iter)
+                if st:
+                    status = "orig_progress"
+                    break
+            df = getattr(P, "df", 1.0)
+            dgs = getattr(P, "dg", None)
+            un_pinf = float(np.max(np.abs(r / dgs), initial=0.0)) if dgs is not None else pinf
+            if E0 <= o["tol"] and dinf / df <= o["dual_inf_tol"] and un_pinf <= o["constr_viol_tol"] and comp / df <= o["compl_inf_tol"]:
+                status = "optimal"
+                break
+            if E0 <= o["acceptable_tol"] and dinf / df <= o["acceptable_dual_inf_tol"] and un_pinf <= o["acceptable_constr_viol_tol"] \
+                    and comp / df <= o["acceptable_compl_inf_tol"]:
+                n_acc += 1
+                if n_acc >= o["acceptable_iter"]:
+                    status = "acceptable"
+                    break
+            else:
+                n_acc = 0
+            if self.total_iters() >= budget:
+                status = "max_iter"
+                break
+            # ---- barrier parameter -----------------------------------------------------------------------------------------
+            mu_min = min(o["tol"], o["compl_inf_tol"]) / (o["barrier_tol_factor"] + 1.0)
+            while True:
+                Emu = self.errors(ev, x, t, y, z, mu)[0]
+                if Emu > o["barrier_tol_factor"] * mu or mu <= mu_min:
+                    break
+                mu_new = max(mu_min, min(o["mu_linear_decrease_factor"] * mu, mu ** o["mu_superlinear_decrease_power"]))
+                if mu_new == mu:
+                    break
+                mu = mu_new
+                tau = max(o["tau_min"], 1.0 - mu)
+                self.filter.clear()
+                if getattr(P, "eta", None) is not None:                     # the restoration's objective depends on mu
+                    ev = P.evaluate(x, 2, mu)
+            first_iter = False
+            # ---- search direction ------------------------------------------------------------------------------------------
+            zxL, zxU, ztL, ztU = z
+            sxL, sxU, stL, stU = self.slacks(x, t)
+            sig_x = zxL / sxL + zxU / sxU
+            sig_t = ztL / stL + ztU / stU
+            W = ev["hess"](y)
+            J = ev["J"]
+            solver = self.factor(W, J, sig_x, sig_t, mu)
+            gx, gt = self.barrier_grad(ev["grad"], x, t, mu)
+            r = self.residual(ev["g"], t)
+            need_resto = solver is None
+            if not need_resto:
+                rhs_x = -(gx + J.T @ y)
+                rhs_t = -(gt + P.t_sig * y[P.t_row])
+                dx, dt, dy = solver(rhs_x, rhs_t, -r)
+                dz = (mu / sxL - zxL - zxL * dx / sxL, mu / sxU - zxU + zxU * dx / sxU,
+                      mu / stL - ztL - ztL * dt / stL, mu / stU - ztU + ztU * dt / stU)
+                dz = tuple(np.where(np.isfinite(s_), d_, 0.0) for s_, d_ in zip((sxL, sxU, stL, stU), dz))
+                # ---- filter line search ----------------------------------------------------------------------------------
+                a_max = min(_ftb(tau, sxL, dx), _ftb(tau, sxU, -dx), _ftb(tau, stL, dt), _ftb(tau, stU, -dt))
+                a_z = min(_ftb(tau, zxL, dz[0]), _ftb(tau, zxU, dz[1]), _ftb(tau, ztL, dz[2]), _ftb(tau, ztU, dz[3]))
+                theta = float(np.sum(np.abs(r)))
+                phi = self.barrier(ev["f"], x, t, mu)
+                gBD = float(gx @ dx + gt @ dt)
+                acc = self.line_search(x, t, dx, dt, a_max, theta, phi, gBD, mu, tau, solver, r, rhs_x, rhs_t)
+                need_resto = acc is None
+            if need_resto:
+                if self.in_resto:
+                    status = "resto_failed"
+                    break
+                rs = self.restoration(x, t, y, z, mu, ev, budget)
+                if rs[0] != "ok":
+                    status, x, t = rs[0], rs[1], rs[2]
+                    ev = P.evaluate(x, 2, mu)
+                    break
+                _, x, t, z = rs
+                y = np.zeros(P.m)
+                ev = P.evaluate(x, 2, mu)
+                if o["constr_mult_reset_threshold"] > 0.0:
+                    yl = self.ls_multipliers(ev, z)
+                    if np.max(np.abs(yl), initial=0.0) <= o["constr_mult_reset_threshold"]:
+                        y = yl
+                continue
+            alpha, x, t, ev_new = acc
+            self.last_alpha = alpha
+            y = y + alpha * dy
+            z = tuple(z_ + a_z * d_ for z_, d_ in zip(z, dz))
+            sl = self.slacks(x, t)
+            ks = o["kappa_sigma"]
+            z = tuple(np.where(np.isfinite(s_), np.maximum(np.minimum(z_, ks * mu / s_), mu / (ks * s_)), 0.0) for z_, s_ in zip(z, sl))
+            ev = P.evaluate(x, 2, mu)
+            self.iters += 1
+        return status, x, t, y, z, mu
+
+    def total_iters(self):
+        return self.iters + (self.outer.total_iters() if self.outer is not None else 0)
+
+    # -- line search ---------------------------------------------------------------------------------------------------
+    def trial(self, x, t, mu):
+        P = self.P
+        ev = P.evaluate(x, 0, mu)
+        if not (np.all(np.isfinite(ev["g"])) and np.isfinite(ev["f"])):
+            return None
+        phi = self.barrier(ev["f"], x, t, mu)
+        if not np.isfinite(phi):
+            return None
+        return phi, float(np.sum(np.abs(self.residual(ev["g"], t)))), ev
+
+    def acceptable_to_iterate(self, phi_t, th_t, phi, theta):
+        o = self.o
+        if phi_t > phi:
+            bas = max(1.0, math.log10(abs(phi))) if abs(phi) > 10.0 else 1.0
+            if math.log10(phi_t - phi) > o["obj_max_inc"] + bas:
+                return False
+        return compare_le(th_t, (1.0 - o["gamma_theta"]) * theta, theta) or compare_le(phi_t - phi, -o["gamma_phi"] * theta, phi)
+
+    def line_search(self, x, t, dx, dt, a_max, theta, phi, gBD, mu, tau, solver, r, rhs_x, rhs_t):
+        o, P = self.o, self.P
+        if gBD < 0.0:
+            a_min = o["gamma_theta"]
+            a_min = min(a_min, o["gamma_phi"] * theta / (-gBD))
+            if theta <= self.theta_min:
+                a_min = min(a_min, o["delta"] * theta ** o["s_theta"] / (-gBD) ** o["s_phi"])
+        else:
+            a_min = o["gamma_theta"]
+        a_min *= o["alpha_min_frac"]
+
+        def ftype(a):
+            return gBD < 0.0 and a * (-gBD) ** o["s_phi"] > o["delta"] * theta ** o["s_theta"]
+
+        def armijo(a, phi_t):
+            return compare_le(phi_t - phi, o["eta_phi"] * a * gBD, phi)
+
+        def check(a, phi_t, th_t):
+            if th_t > self.theta_max:
+                return False
+            if a > 0.0 and ftype(a) and theta <= self.theta_min:
+                ok = armijo(a, phi_t)
+            else:
+                ok = self.acceptable_to_iterate(phi_t, th_t, phi, theta)
+            return ok and self.filter.acceptable(phi_t, th_t)
+
+        alpha = a_max
+        first = True
+        accepted = None
+        while alpha > a_min or first:
+            xt, tt = x + alpha * dx, t + alpha * dt
+            tr = self.trial(xt, tt, mu)
+            if tr is not None:
+                phi_t, th_t, ev_t = tr
+                if check(alpha, phi_t, th_t):
+                    accepted = (alpha, xt, tt, ev_t, alpha, phi_t)
+                    break
+                if first and th_t >= theta and o["max_soc"] > 0:
+                    # second-order correction (section 3.4 / A-5.5 .. A-5.9)
+                    c_soc = alpha * r + self.residual(ev_t["g"], tt)
+                    th_old = theta
+                    th_soc_old = th_t
+                    for _ in range(o["max_soc"]):
+                        dxs, dts, _dy = solver(rhs_x, rhs_t, -c_soc)
+                        sxL, sxU, stL, stU = self.slacks(x, t)
+                        a_soc = min(_ftb(tau, sxL, dxs), _ftb(tau, sxU, -dxs), _ftb(tau, stL, dts), _ftb(tau, stU, -dts))
+                        xs, ts = x + a_soc * dxs, t + a_soc * dts
+                        trs = self.trial(xs, ts, mu)
+                        if trs is None:
+                            break
+                        phi_s, th_s, ev_s = trs
+                        if check(alpha, phi_s, th_s):
+                            accepted = (a_soc, xs, ts, ev_s, alpha, phi_s)
+                            break
+                        if th_s > o["kappa_soc"] * th_soc_old:
+                            break
+                        th_soc_old = th_s
+                        c_soc = a_soc * c_soc + self.residual(ev_s["g"], ts)
+                    if accepted is not None:
+                        break
+            first = False
+            alpha *= o["alpha_red_factor"]
+        if accepted is None:
+            return None
+        a_step, xt, tt, ev_t, a_test, phi_t = accepted
+        if not ftype(a_test) or not armijo(a_test, phi_t):
+            self.filter.add(phi - o["gamma_phi"] * theta, (1.0 - o["gamma_theta"]) * theta)
+        return a_step, xt, tt, ev_t
+
+    # -- restoration ---------------------------------------------------------------------------------------------------
+    def restoration(self, x, t, y, z, mu, ev, budget):
+        P, o = self.P, self.o
+        r = self.residual(ev["g"], t)
+        if float(np.max(np.abs(r), initial=0.0)) <= o["resto_failure_feasibility_threshold"]:
+            return ("resto_failed", x, t)                                   # "restoration phase is called at a point that is almost feasible"
+        theta = float(np.sum(np.abs(r)))
+        phi = self.barrier(ev["f"], x, t, mu)
+        self.filter.add(phi - o["gamma_phi"] * theta, (1.0 - o["gamma_theta"]) * theta)
+        RP = _Resto(P, x, o)
+        ra = _Algo(RP, o, resto_of=self, trace=self.trace)
+        ra.orig = dict(mu=mu, theta=theta, phi=phi, pinf=float(np.max(np.abs(r))))
+        mu_r = max(mu, float(np.max(np.abs(r))))
+        rho = RP.rho
+        a = (mu_r - rho * r) / (2.0 * rho)
+        nn = a + np.sqrt(a * a + mu_r * r / (2.0 * rho))                    # eq. (33): row + n - p = 0 with residual r = p - n ... sign below
+        # the rows are  g + A_s s + n - p = 0:  p - n = r
+        pp = r + nn
+        tt = np.concatenate([t, nn, pp])
+        zxL, zxU, ztL, ztU = z
+        zr = (np.minimum(rho, zxL), np.minimum(rho, zxU),
+              np.concatenate([np.minimum(rho, ztL), mu_r / nn, mu_r / pp]), np.concatenate([np.minimum(rho, ztU), np.zeros(2 * P.m)]))
+        zr = tuple(np.where(np.isfinite(s_), z_, 0.0) for z_, s_ in zip(zr, ra.slacks(x, tt)))
+        st, xr, tr, yr, zrr, mur = ra.run(x.copy(), tt, np.zeros(P.m), zr, mu_r, budget)
+        self.iters += ra.iters
+        ra.outer = None
+        ns = P.nt
+        if st == "orig_progress":
+            znew = (zrr[0], zrr[1], zrr[2][:ns], zrr[3][:ns])
+            if max(float(np.max(zz, initial=0.0)) for zz in znew) > o["bound_mult_reset_threshold"]:
+                sl = self.slacks(xr, tr[:ns])
+                znew = tuple(np.where(np.isfinite(s_), 1.0, 0.0) for s_ in sl)
+            return ("ok", xr, tr[:ns], znew)
+        if st in ("optimal", "acceptable"):
+            rr = self.residual(P.evaluate(xr, 0, mu)["g"], tr[:ns])
+            feas = float(np.max(np.abs(rr), initial=0.0)) <= 1e2 * o["tol"]
+            return ("resto_converged_feasible" if feas else "local_infeasibility", xr, tr[:ns])
+        return (st if st == "max_iter" else "resto_failed", xr, tr[:ns])
+
+    def outer_progress(self, x, tt, first_iter):
+        """RestoFilterConvergenceCheck: leave the restoration when the (x, s) part is acceptable to the original filter and to the
+        iterate the restoration started from, with the infeasibility reduced to kappa_resto of what it was."""
+        if first_iter:
+            return False
+        out, o = self.outer, self.o
+        ns = out.P.nt
+        s = tt[:ns]
+        ev = out.P.evaluate(x, 0, None)
+        r = out.residual(ev["g"], s)
+        pinf = float(np.max(np.abs(r), initial=0.0))
+        if pinf > o["required_infeasibility_reduction"] * self.orig["pinf"]:
+            return False
+        phi_t = out.barrier(ev["f"], x, s, self.orig["mu"])
+        th_t = float(np.sum(np.abs(r)))
+        if not np.isfinite(phi_t):
+            return False
+        if not out.filter.acceptable(phi_t, th_t):
+            return False
+        return out.acceptable_to_iterate(phi_t, th_t, self.orig["phi"], self.orig["theta"])
+
+
+STATUS_OF = dict(optimal=0, acceptable=0, local_infeasibility=1, max_iter=2, resto_failed=2, resto_converged_feasible=2, error=2)
+
+
+def solve_nlp(nlp, w0, opts=None, trace=None):
+    """IPOPT's algorithm (see the module docstring) on an NLP object with evaluate / x_bounds / d_lo / d_hi.  Returns a dict."""
+    o = dict(OPTS)
+    if opts:
+        o.update(opts)
+    w0 = np.asarray(w0, dtype=float)
+    P = _Regular(nlp, w0, o)
+    A = _Algo(P, o, trace=trace)
+    x = A.push(w0, P.x_L, P.x_U, o["bound_push"], o["bound_frac"])
+    ev = P.evaluate(x, 2)
+    s = A.push(ev["g"][P.m_c:], P.t_L, P.t_U, o["bound_push"], o["bound_frac"])
+    sl = A.slacks(x, s)
+    z = tuple(np.where(np.isfinite(s_), o["bound_mult_init_val"], 0.0) for s_ in sl)
+    y = A.ls_multipliers(ev, z)
+    if np.max(np.abs(y), initial=0.0) > o["constr_mult_init_max"]:
+        y = np.zeros(P.m)
+    status, x, s, y, z, mu = A.run(x, s, y, z, o["mu_init"], o["max_iter"])
+    ev = nlp.evaluate(x, 0)
+    return dict(x=x, status=status, code=STATUS_OF.get(status, 2), iters=A.iters, f=ev["f"], c=ev["c"], d=ev["d"], y=y / P.dg * P.df if False else y,
+                mu=mu, obj_scale=P.df, con_scale=P.dg)
+
+
+def solve(model, x0, u_prev, goal, obs, N=None, opts=None, return_info=False, trace=None):
+    """One control step's NLP from do-mpc's starting point.  Returns u_0, status code (0 optimal / acceptable, 1 converged to a point
+    of local infeasibility, 2 everything else), iterations [, info]."""
+    nlp = StageNLP(model, x0, u_prev, goal, obs, N)
+    r = solve_nlp(nlp, nlp.initial_guess(), opts, trace)
+    u0 = nlp.u0(r["x"])
+    if return_info:
+        X, U = nlp.split(r["x"])
+        r.update(X=X, U=U, n_eval=nlp.n_eval)
+        return u0, r["code"], r["iters"], r
+    return u0, r["code"], r["iters"]
