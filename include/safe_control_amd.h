@@ -37,8 +37,11 @@
 extern "C" {
 #endif
 
+/* ABI version: the minor number goes up with EVERY change of a struct layout or an entry point's signature (round 4 grew
+ * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2).  A binding compares sc_version() with the
+ * version its struct mirrors were written for before the first call (safe_control_amd/_lib.py: ABI_VERSION). */
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 1
+#define SC_VERSION_MINOR 2
 
 /* ---- return codes ------------------------------------------------------ */
 typedef enum sc_error {

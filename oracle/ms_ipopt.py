@@ -430,7 +430,7 @@ class _Resto(_Problem):
     def __init__(self, reg, x_R, o):
         self.reg = reg
         self.n, self.m = reg.n, reg.m
-        self.x_L, self.x_U = reg.x_L, reg.x_U
+        self.x_L, self.x_U = reg.x_L.copy(), reg.x_U.copy()
         m, ms = reg.m, reg.nt
         self.ns = ms
         self.nt = ms + 2 * m
@@ -505,6 +505,19 @@ class _Algo:
     def slacks(self, x, t):
         P = self.P
         return _dist(x, P.x_L, P.x_U) + _dist(t, P.t_L, P.t_U)
+
+    def safe_slacks(self, x, t, mu):
+        """IPOPT's CalculateSafeSlack: a slack below eps min(1, mu) is raised to slack_move max(1, |bound|), slack_move = eps^(3/4), by
+        moving the bound (for good) -- "slack too small, adjusting variable bound"."""
+        P = self.P
+        s_min, move = EPS * min(1.0, mu), EPS ** 0.75
+        for v, lo, hi in ((x, P.x_L, P.x_U), (t, P.t_L, P.t_U)):
+            bad = np.isfinite(lo) & (v - lo < s_min)
+            if np.any(bad):
+                lo[bad] = v[bad] - np.maximum(v[bad] - lo[bad], move * np.maximum(1.0, np.abs(lo[bad])))
+            bad = np.isfinite(hi) & (hi - v < s_min)
+            if np.any(bad):
+                hi[bad] = v[bad] + np.maximum(hi[bad] - v[bad], move * np.maximum(1.0, np.abs(hi[bad])))
 
     def barrier(self, f, x, t, mu):
         P, kd = self.P, self.o["kappa_d"]
@@ -756,6 +769,7 @@ class _Algo:
                 continue
             alpha, x, t, ev_new = acc
             self.last_alpha = alpha
+            self.safe_slacks(x, t, mu)
             y = y + alpha * dy
             z = tuple(z_ + a_z * d_ for z_, d_ in zip(z, dz))
             sl = self.slacks(x, t)
@@ -771,6 +785,7 @@ class _Algo:
     # -- line search ---------------------------------------------------------------------------------------------------
     def trial(self, x, t, mu):
         P = self.P
+        self.safe_slacks(x, t, mu)                                          # IPOPT computes trial slacks through CalculateSafeSlack as well
         ev = P.evaluate(x, 0, mu)
         if not (np.all(np.isfinite(ev["g"])) and np.isfinite(ev["f"])):
             return None
@@ -922,6 +937,15 @@ STATUS_OF = dict(optimal=0, acceptable=0, local_infeasibility=1, max_iter=2, res
 
 def solve_nlp(nlp, w0, opts=None, trace=None):
     """IPOPT's algorithm (see the module docstring) on an NLP object with evaluate / x_bounds / d_lo / d_hi.  Returns a dict."""
+    try:                                                                 # matrices of order < 1000: threaded BLAS only costs
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            return _solve_nlp(nlp, w0, opts, trace)
+    except ImportError:
+        return _solve_nlp(nlp, w0, opts, trace)
+
+
+def _solve_nlp(nlp, w0, opts, trace):
     o = dict(OPTS)
     if opts:
         o.update(opts)
@@ -938,7 +962,7 @@ def solve_nlp(nlp, w0, opts=None, trace=None):
         y = np.zeros(P.m)
     status, x, s, y, z, mu = A.run(x, s, y, z, o["mu_init"], o["max_iter"])
     ev = nlp.evaluate(x, 0)
-    return dict(x=x, status=status, code=STATUS_OF.get(status, 2), iters=A.iters, f=ev["f"], c=ev["c"], d=ev["d"], y=y / P.dg * P.df if False else y,
+    return dict(x=x, status=status, code=STATUS_OF.get(status, 2), iters=A.iters, f=ev["f"], c=ev["c"], d=ev["d"], y=y,
                 mu=mu, obj_scale=P.df, con_scale=P.dg)
 
 

@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsafe_control_hip.so")
+# SAFE_CONTROL_AMD_LIB points the binding at another build of the same library (an integrator's own build; the allocator-guard build
+# tests/test_codegen_guard_gpu.py compares with).  Still no fallback: the named file must exist and export every symbol.
+LIB_PATH = os.environ.get("SAFE_CONTROL_AMD_LIB") or os.path.join(_HERE, "lib", "libsafe_control_hip.so")
 
 SC_OK = 0
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_INACCURATE, STATUS_BAD_OBSTACLE = 0, 1, 2, 3
@@ -316,6 +318,9 @@ SYMBOLS = {
 
 _lib = None
 
+# SC_VERSION_MAJOR * 1000 + SC_VERSION_MINOR of the header the ctypes mirrors above were written for
+ABI_VERSION = 2
+
 
 class HipLibraryError(RuntimeError):
     pass
@@ -337,6 +342,11 @@ def load():
         except AttributeError as e:
             raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype, fn.argtypes = res, args
+    got = lib.sc_version()
+    if got != ABI_VERSION:
+        raise HipLibraryError(
+            f"{LIB_PATH} reports ABI version {got}, this binding was written for {ABI_VERSION}: a stale library would misread the "
+            "parameter structs -- rebuild it with `make -C safe_control_amd/csrc`")
     _lib = lib
     return lib
 

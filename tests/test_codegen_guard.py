@@ -4,7 +4,10 @@ the parked lanes of a join block, so lanes that sat out the region lose the valu
   * the translation units with the big interior-point kernels are compiled with the basic VGPR allocator, which never splits a live
     range (csrc/Makefile: SAFE_RA) -- the defect cannot occur there by construction;
   * tools/check_exec_prologue.py scans the built gfx950 objects for the signature (two or more long-lived copies / reloads in front of
-    an EXEC restore): none may be left, and the scanner must still recognise the defect in a recorded excerpt of a miscompiled build."""
+    an EXEC restore; ONE in the translation units that keep the splitting allocator, minus the reviewed sites of
+    tools/exec_prologue_allow.json): none may be left, and the scanner must still recognise the defect in a recorded excerpt of a
+    miscompiled build.  The Makefile runs the scanner on every link (a hit fails the build) and records the compiler version the
+    two -mllvm flags were validated on; the GPU half of the guard is tests/test_codegen_guard_gpu.py."""
 import os
 import re
 import subprocess
@@ -54,9 +57,64 @@ def test_scanner_recognises_the_recorded_defect():
     assert C.scan(good) == []
 
 
+SINGLE = BAD.replace("	v_mov_b32_e32 v78, v150                                    // 000000001020: 7E9C0396\n", "").replace(
+    "	v_mov_b32_e32 v150, v78                                    // 000000001038: 7F2C034E\n", "")
+
+
+def test_a_new_singleton_fails_in_a_unit_built_with_the_splitting_allocator(tmp_path, monkeypatch):
+    """Threshold ONE where the allocator can split (csrc/Makefile: everything without SAFE_RA), with an allow-list keyed by kernel and
+    blanked instruction text: the reviewed site passes, any other single copy in front of an EXEC restore is a hit."""
+    import check_exec_prologue as C
+    hits = C.scan(SINGLE)
+    assert len(hits) == 1 and len(hits[0][2]) == 1
+    assert C.norm("scratch_store_dword off, v5, off offset:728") == "scratch_store_dword off, v#, off offset:#"
+    assert C.norm("v_mov_b32_e32 v79, v151") == "v_mov_b32_e32 v#, v#"
+    greedy = C.unsafe_units()
+    assert greedy("build/csrc/mpc_vtol_wave.o") and greedy("build/csrc/cbf_qp_f32.o") and greedy("x/od_cbf_qp.o")
+    assert not greedy("build/csrc/mpc_gn.o") and not greedy("build/csrc/mpc_cbf.o")
+    allow = C.load_allow()
+    assert allow and all(a["review"] and a["kernel"] and a["instruction"] for a in allow)
+    # end to end on fake objects: the scanner's main() over a "disassembly" that carries the singleton
+    monkeypatch.setattr(C, "device_objects", lambda path: [SINGLE])
+    monkeypatch.setattr(sys, "argv", ["check", "build/csrc/mpc_vtol_wave.o"])
+    assert C.main() == 1                                                  # greedy unit, site not on the list: fails
+    monkeypatch.setattr(sys, "argv", ["check", "build/csrc/mpc_gn.o"])
+    assert C.main() == 0                                                  # basic allocator: singletons are ordinary region code
+    monkeypatch.setattr(C, "load_allow", lambda: [dict(kernel="kernel", instruction="v_mov_b32_e32 v#, v#", review="test")])
+    monkeypatch.setattr(sys, "argv", ["check", "build/csrc/mpc_vtol_wave.o"])
+    assert C.main() == 0                                                  # the same site once reviewed and listed
+
+
+# the compiler build the two -mllvm flags of SAFE_RA (undocumented switches of LLVM's AMDGPU back end) were validated on
+VALIDATED_HIPCC = ("HIP version: 7.2.26015-fc0010cf6a", "roc-7.2.0 26014 7b800a19466229b8479a78de19143dc33c3ab9b5")
+
+
+def test_compiler_is_the_one_the_allocator_flags_were_validated_on():
+    mk = open(os.path.join(ROOT, "safe_control_amd", "csrc", "Makefile")).read()
+    assert "hipcc_version.txt" in mk and "$(SCANNER) $(OBJS)" in mk       # every link records the compiler and runs the scanner
+    rec = os.path.join(ROOT, "build", "csrc", "hipcc_version.txt")
+    if os.path.exists(rec):
+        txt = open(rec).read()
+    else:
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True)
+        if r.returncode != 0:
+            pytest.skip("no hipcc here and no recorded version")
+        txt = r.stdout
+    assert all(v in txt for v in VALIDATED_HIPCC), (
+        "the library was built with a compiler other than the one `-mllvm -vgpr-regalloc=basic -mllvm -disable-machine-licm` and the "
+        "scanner were validated on (ROCm 7.2.0, clang roc-7.2.0 26014): re-run tools/build_variants.sh + tests/test_codegen_guard_gpu.py "
+        "+ the bitwise-resume tests on the new compiler, then update VALIDATED_HIPCC.  Found:\n" + txt)
+
+
 def test_built_objects_are_free_of_the_defect_signature():
-    objs = [f for f in os.listdir(os.path.join(ROOT, "build", "csrc"))] if os.path.isdir(os.path.join(ROOT, "build", "csrc")) else []
+    """(The Makefile runs the same scan on every link.)  Objects when there are any, else the shipped library itself."""
+    bdir = os.path.join(ROOT, "build", "csrc")
+    objs = [f for f in os.listdir(bdir)] if os.path.isdir(bdir) else []
+    args = []
     if not any(f.endswith(".o") for f in objs):
-        pytest.skip("no built objects (run __graft_entry__.build() first)")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_exec_prologue.py")], capture_output=True, text=True, timeout=600)
+        lib = os.path.join(ROOT, "safe_control_amd", "lib", "libsafe_control_hip.so")
+        if not os.path.exists(lib):
+            pytest.skip("nothing built yet (run __graft_entry__.build() first)")
+        args = [lib]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_exec_prologue.py")] + args, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:]

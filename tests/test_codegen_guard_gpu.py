@@ -1,0 +1,67 @@
+"""GPU half of the code-generation guard ("The code-generation fragility: root cause").
+
+csrc/mpc_vtol_wave.hip is the one big interior-point translation unit that keeps LLVM's splitting (greedy) VGPR allocator -- the basic
+allocator triples its spills.  The defect the other units are protected from by construction (copies of a live-range split placed in
+front of the s_or_b64 exec of a join block) would show there as lanes losing loop-invariant values: different iterates on some
+problems.  csrc/Makefile therefore builds the SAME source a second time with the allocator that cannot split and links it into
+lib/libsafe_control_hip_guard.so; this test solves the VTOL2D workload batch with both libraries (the guard one in a child process:
+SAFE_CONTROL_AMD_LIB) and requires every output -- inputs, statuses, iteration counts, full plans -- to be equal BIT FOR BIT, for the
+plain and the optimal-decay instantiations, f64 and f32 storage, with the budget and its continuation launches."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GUARD = os.path.join(ROOT, "safe_control_amd", "lib", "libsafe_control_hip_guard.so")
+
+CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import safe_control_amd as sca
+from safe_control_amd import workloads as W
+from safe_control_amd import _lib
+assert _lib.LIB_PATH == sys.argv[2], _lib.LIB_PATH
+n = int(sys.argv[4])
+X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("vtol", 4096, 8, seed=0))
+out = {}
+for io in ("f64", "f32"):
+    dt = torch.float64 if io == "f64" else torch.float32
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=dt, device="cuda:0")
+    for name, cls in (("plain", sca.BatchedVtolMPCCBF), ("od", sca.BatchedOptimalDecayVtolMPCCBF)):
+        ctl = cls(io_dtype=io)
+        r = ctl.solve(t(X), t(up), t(goal), t(obs), want_z=True)
+        torch.cuda.synchronize()
+        for k, a in enumerate(r):
+            if a is not None:
+                out[f"{io}/{name}/{k}"] = a.cpu().numpy()
+np.savez(sys.argv[3], **out)
+"""
+
+
+def run(lib, out, n):
+    env = dict(os.environ, SAFE_CONTROL_AMD_LIB=lib)
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, lib, out, str(n)], env=env, capture_output=True, text=True, timeout=3000)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return np.load(out)
+
+
+def test_wave_kernel_equals_its_build_with_the_allocator_that_cannot_split(tmp_path):
+    if not os.path.exists(GUARD):
+        pytest.fail(f"{GUARD} is missing: `make -C safe_control_amd/csrc` builds it next to the library")
+    shipped = os.path.join(ROOT, "safe_control_amd", "lib", "libsafe_control_hip.so")
+    n = 512
+    a = run(shipped, str(tmp_path / "a.npz"), n)
+    b = run(GUARD, str(tmp_path / "b.npz"), n)
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 12
+    for k in a.files:
+        x, y = a[k], b[k]
+        assert x.dtype == y.dtype and x.shape == y.shape
+        assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), (k, int((x != y).sum()))
+    st = a["f64/plain/1"]
+    assert (st == 0).mean() > 0.9 and a["f64/plain/2"].max() > 100        # the batch does reach the continuation launches

@@ -1,0 +1,49 @@
+"""CPU: how often does the multiple-shooting solve from do-mpc's start (oracle/ms_ipopt.py: filter interior point, x_k = x0) end somewhere
+else than the condensed single-shooting solve (oracle/mpc_cbf.py / mpc_vtol.py: l1-merit interior point from the rollout of u_prev)?
+256 config-3 draws (DynamicUnicycle2D) and 256 VTOL2D bench draws.
+    python3 tools/exp_ms_vs_condensed.py [du|vtol] [n] [first] [workers]"""
+import os, sys, time
+os.environ.setdefault("OMP_NUM_THREADS", "1"); os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from multiprocessing import Pool
+from oracle import ms_ipopt as MS, mpc_cbf as M, mpc_vtol as OV
+from safe_control_amd import workloads as W
+
+fam = sys.argv[1] if len(sys.argv) > 1 else "du"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+workers = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+X, up, goal, obs = W.mpc_family_batch(fam, first + n, 8, seed=0)
+mdl = MS.du_model() if fam == "du" else MS.vtol_model()
+
+
+def one(i):
+    t0 = time.time()
+    u, st, it, info = MS.solve(mdl, X[i], up[i], goal[i], obs[i], return_info=True)
+    t1 = time.time()
+    if fam == "du":
+        uo, so, ito, io = M.solve(X[i], up[i], goal[i], obs[i], return_info=True)
+    else:
+        uo, so, ito, io = OV.solve(X[i], up[i], goal[i], obs[i], return_info=True)
+    viol = float(max(np.abs(info["c"]).max(), info["d"].max()))
+    # objective of both answers on the same footing: the multiple-shooting f counts l(x_0) as well
+    return dict(i=i, st=st, status=info["status"], it=it, u=u, so=so, ito=ito, uo=uo, viol=viol, t_ms=t1 - t0, t_c=time.time() - t1,
+                f_ms=info["f"], f_c=io["f"], l0=float(np.sum(mdl["Q"] * (X[i][: mdl["nx"]] - np.r_[goal[i][:2], np.zeros(mdl["nx"] - 2)]) ** 2)))
+
+
+if __name__ == "__main__":
+    with Pool(workers) as p:
+        res = p.map(one, range(first, first + n), chunksize=2)
+    st = np.array([r["st"] for r in res]); so = np.array([r["so"] for r in res])
+    du = np.array([np.abs(r["u"] - r["uo"]).max() for r in res])
+    both = (st == 0) & (so == 0)
+    print(f"{fam}: {n} draws [{first}, {first + n});  multiple shooting: optimal {np.sum(st == 0)}, locally infeasible {np.sum(st == 1)}, other {np.sum(st == 2)};"
+          f"  condensed: optimal {np.sum(so == 0)}, infeasible {np.sum(so == 1)}, inaccurate {np.sum(so == 2)}")
+    print(f"status equal on {np.sum(st == so)};  both optimal: {both.sum()}, of which |u0 - u0'|_inf > 1e-3: {np.sum(du[both] > 1e-3)}, > 1e-5: {np.sum(du[both] > 1e-5)},"
+          f" max {du[both].max() if both.any() else 0:.2e}")
+    print(f"iterations  ms median {np.median([r['it'] for r in res]):.0f} max {max(r['it'] for r in res)};  condensed median {np.median([r['ito'] for r in res]):.0f} max {max(r['ito'] for r in res)};"
+          f"  time per solve ms {np.mean([r['t_ms'] for r in res]):.2f}s condensed {np.mean([r['t_c'] for r in res]):.2f}s")
+    for r in res:
+        if r["st"] != r["so"] or (r["st"] == 0 and np.abs(r["u"] - r["uo"]).max() > 1e-5):
+            print(f"  draw {r['i']}: ms {r['status']} it {r['it']} u0 {np.round(r['u'], 5)} f {r['f_ms'] - r['l0']:.6f} viol {r['viol']:.1e} | condensed st {r['so']} it {r['ito']} u0 {np.round(r['uo'], 5)} f {r['f_c']:.6f}")
