@@ -38,10 +38,10 @@ extern "C" {
 #endif
 
 /* ABI version: the minor number goes up with EVERY change of a struct layout or an entry point's signature (round 4 grew
- * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2).  A binding compares sc_version() with the
+ * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2; round 5 added sc_ipopt_params and sc_mpcvtol_ms_solve_batch: 0.3).  A binding compares sc_version() with the
  * version its struct mirrors were written for before the first call (safe_control_amd/_lib.py: ABI_VERSION). */
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 2
+#define SC_VERSION_MINOR 3
 
 /* ---- return codes ------------------------------------------------------ */
 typedef enum sc_error {
@@ -424,6 +424,37 @@ int sc_mpcvtol_solve_batch_sliced(const sc_mpcvtol_params* params, const sc_mpc_
 int sc_mpcvtol_solve_batch_host(const sc_mpcvtol_params* params, int64_t B, int32_t K,
                                 const void* X, const void* u_prev, const void* goal, const void* obs,
                                 void* u_out, int32_t* status_out, int32_t* iters_out, void* z_out, int device);
+
+/* MPC-CBF for VTOL2D AS DO-MPC POSES IT -- multiple shooting, IPOPT's algorithm (csrc/mpc_vtol_ms.hip, DESIGN.md kernel 12; round 5).
+ * position_control/mpc_cbf.py:162-174 hands IPOPT the states x_0 .. x_N as variables with the dynamics as equality rows and
+ * set_initial_guess (:366-369) starts every stage at x0; sc_mpcvtol_solve_batch solves the condensed single-shooting problem instead and
+ * loses the reference's own example flight to one diverging rollout.  This entry point solves the multiple-shooting NLP with the filter
+ * line-search interior point of Waechter & Biegler (2006) at IPOPT's documented option defaults (sc_ipopt_params; oracle/ms_ipopt.py is the
+ * float64 statement, iterate for iterate), one NLP per wavefront, one stage per lane, Riccati recursion with defects.
+ *   params      the model / problem fields of sc_mpcvtol_params (horizon, dt, Q, R, alpha1/2, bounds, radius, beta, airframe, io_dtype,
+ *               obs_shared); its solver fields (tol .. resto, slack_reset, kernel, max_iter) are NOT read -- sc_ipopt_params has them
+ *   status_out  SC_STATUS_OPTIMAL (tol or IPOPT's acceptable rule), SC_STATUS_INACCURATE (iteration limit), SC_STATUS_NEEDS_RESTO: the
+ *               line search ended below alpha_min (or the inertia correction ran out) -- IPOPT would enter its restoration phase here;
+ *               the caller re-solves these problems with sc_mpcvtol_solve_batch and its restoration (BatchedVtolMPCCBF does)
+ *   plan_out    [B, (horizon + 1) * 6 + horizon * 4] or NULL: x_0 .. x_N, then u_0 .. u_{N-1}
+ *   trace_out   [B, max_iter + 1, 8] float64 or NULL: per iteration E_0, dual / primal infeasibility, complementarity, mu, theta,
+ *               delta_w, alpha (a debugging aid: the columns of oracle/ms_ipopt.py's trace)                                                 */
+#define SC_STATUS_NEEDS_RESTO 4
+typedef struct sc_ipopt_params {
+    int32_t max_iter, acceptable_iter;
+    double  tol, dual_inf_tol, constr_viol_tol, compl_inf_tol;
+    double  acceptable_tol, acceptable_dual_inf_tol, acceptable_constr_viol_tol, acceptable_compl_inf_tol;
+    double  nlp_scaling_max_gradient, nlp_scaling_min_value, bound_relax_factor, bound_push, bound_frac, constr_mult_init_max;
+    double  mu_init, mu_linear_decrease_factor, mu_superlinear_decrease_power, barrier_tol_factor, tau_min;
+    double  kappa_sigma, kappa_d, s_max;
+    double  theta_max_fact, theta_min_fact, eta_phi, delta, s_phi, s_theta, gamma_phi, gamma_theta, alpha_min_frac, alpha_red_factor, obj_max_inc;
+    double  first_hessian_perturbation, min_hessian_perturbation, max_hessian_perturbation, perturb_inc_fact_first, perturb_inc_fact,
+            perturb_dec_fact;
+} sc_ipopt_params;
+
+int sc_mpcvtol_ms_solve_batch(const sc_mpcvtol_params* params, const sc_ipopt_params* ipopt, int64_t B, int32_t K,
+                              const void* X, const void* u_prev, const void* goal, const void* obs,
+                              void* u_out, int32_t* status_out, int32_t* iters_out, void* plan_out, double* trace_out, void* stream);
 
 /* Optimal-decay MPC-CBF for VTOL2D -- the last model of the reference's accept list (optimal_decay_mpc_cbf.py:19): the NLP of
  * sc_mpcvtol_solve_batch with two decay variables per stage scaling the DT-CBF gains of that stage's rows,

@@ -392,6 +392,7 @@ class _Problem:
 class _Regular(_Problem):
     def __init__(self, nlp, w_start, o):
         self.nlp = nlp
+        self.stage = nlp if isinstance(nlp, StageNLP) else None
         self.n, self.m_c, self.m_d = nlp.n, nlp.m_c, nlp.m_d
         self.m = self.m_c + self.m_d
         ev = nlp.evaluate(w_start, 2)
@@ -429,17 +430,22 @@ class _Resto(_Problem):
 
     def __init__(self, reg, x_R, o):
         self.reg = reg
+        self.stage = reg.stage
         self.n, self.m = reg.n, reg.m
         self.x_L, self.x_U = reg.x_L.copy(), reg.x_U.copy()
         m, ms = reg.m, reg.nt
+        # rows that get n - p: all of them (IPOPT), or the inequality rows only (o["resto_elastic"] = "ineq": the dynamics rows stay
+        # hard equalities inside the restoration -- the variant csrc/mpc_vtol_ms.hip runs, DESIGN.md kernel 12)
+        self.el = np.arange(m) if o.get("resto_elastic", "all") == "all" else np.arange(reg.m_c, m)
+        ne = len(self.el)
         self.ns = ms
-        self.nt = ms + 2 * m
-        self.t_L = np.concatenate([reg.t_L, np.zeros(2 * m)])
-        self.t_U = np.concatenate([reg.t_U, np.full(2 * m, INF)])
-        self.t_row = np.concatenate([reg.t_row, np.arange(m), np.arange(m)])
-        self.t_sig = np.concatenate([reg.t_sig, np.ones(m), -np.ones(m)])
+        self.nt = ms + 2 * ne
+        self.t_L = np.concatenate([reg.t_L, np.zeros(2 * ne)])
+        self.t_U = np.concatenate([reg.t_U, np.full(2 * ne, INF)])
+        self.t_row = np.concatenate([reg.t_row, self.el, self.el])
+        self.t_sig = np.concatenate([reg.t_sig, np.ones(ne), -np.ones(ne)])
         self.rho = o["resto_penalty_parameter"]
-        self.t_rho = np.concatenate([np.zeros(ms), np.full(2 * m, self.rho)])
+        self.t_rho = np.concatenate([np.zeros(ms), np.full(2 * ne, self.rho)])
         self.x_R = x_R.copy()
         self.DR2 = (1.0 / np.maximum(1.0, np.abs(x_R))) ** 2
         self.eta = o["resto_proximity_weight"]
@@ -570,6 +576,8 @@ class _Algo:
     def factor(self, W, J, sig_x, sig_t, mu):
         """Algorithm IC around the reduced system; returns a solver closure or None (-> restoration)."""
         P, o = self.P, self.o
+        if o.get("linear_solver") == "riccati" and P.stage is not None:
+            return self.factor_riccati(W, J, sig_x, sig_t, mu)
         n, m = P.n, P.m
         dw, dc = 0.0, 0.0
         K = np.zeros((n + m, n + m))
@@ -616,6 +624,172 @@ class _Algo:
             dt = q * (rhs_t - P.t_sig * dy[P.t_row])
             return dx, dt, dy
         return solve
+
+
+    # -- the same system by a Riccati recursion over the stages: the linear algebra of the HIP kernel ------------------------
+    def factor_riccati(self, W, J, sig_x, sig_t, mu):
+        """The primal-dual system of a StageNLP solved stage by stage (csrc/mpc_vtol_ms.hip does exactly this):
+          * the inequality rows of stage k are condensed into its Hessian block, H_k += Jd_k' diag(1 / e) Jd_k (e > 0 on every row that
+            carries a slack);
+          * the input-rate term couples u_k with u_{k+1}: the recursion runs on the augmented state xi_k = (x_k, v_k), v_k = u_{k-1},
+            with xi_{k+1} = (A_k x_k + B_k u_k + c_k, u_k); value function 1/2 xi' P_k xi + p_k' xi;
+          * regular phase: hard dynamics.  Restoration: every dynamics row carries n - p, which makes the row SOFT -- dx+ = a + c - E
+            dy+ with E = diag(1 / (Sigma_n + dw) + 1 / (Sigma_p + dw)): the recursion then uses the parallel sum P~ = P - P E^1/2 (I +
+            E^1/2 P E^1/2)^-1 E^1/2 P in place of P (section "restoration" of DESIGN.md kernel 12);
+          * inertia: the full system has (n, m, 0) iff every 4 x 4 input block Quu_k and every I + E^1/2 P_k E^1/2 is positive
+            definite (block elimination in stage order + Sylvester's law); on failure delta_w grows as in Algorithm IC (delta_c is
+            never needed: the dynamics rows have full rank by construction)."""
+        P, o = self.P, self.o
+        S = P.stage
+        N, nx, nu, nv, K = S.N, S.nx, S.nu, S.nv, S.K
+        n, m, mc = P.n, P.m, (S.N + 1) * S.nx
+        na = nx + nu
+        Wd = [W[k * nv:(k + 1) * nv, k * nv:(k + 1) * nv] for k in range(N)]
+        WN = W[N * nv:, N * nv:]
+        cpl = [np.array([-W[S.iu[k][i], S.iu[k + 1][i]] for i in range(nu)]) for k in range(N - 1)]
+        # the dynamics rows carry their scaling factor: row = dg (F - x+); the recursion runs on the unscaled rows (costate = dg dy)
+        sc = np.ones(mc)
+        for k in range(N):
+            sc[nx + k * nx: nx + (k + 1) * nx] = -np.diagonal(J[nx + k * nx: nx + (k + 1) * nx, (k + 1) * nv:(k + 1) * nv + nx])
+        Jc = [J[nx + k * nx: nx + (k + 1) * nx, k * nv:(k + 1) * nv] / sc[nx + k * nx: nx + (k + 1) * nx, None] for k in range(N)]       # [A_k B_k]
+        Jd = [J[mc + k * K: mc + (k + 1) * K, k * nv:(k + 1) * nv] for k in range(N)]
+        dw = 0.0
+        first = True
+        while True:
+            q = 1.0 / (sig_t + dw)
+            e = np.zeros(m)
+            np.add.at(e, P.t_row, q)
+            e_c, e_d = (e[:mc] / (sc * sc)).reshape(N + 1, nx), e[mc:].reshape(N, K)
+            soft = bool(np.any(e_c > 0.0))
+            fac = self._riccati_backward(S, Wd, WN, cpl, Jc, Jd, sig_x, dw, e_c, e_d, soft)
+            if fac is not None:
+                if dw > 0.0:
+                    self.delta_w_last = dw
+                self.last_delta = (dw, 0.0)
+                break
+            if first:
+                first = False
+                dw = o["first_hessian_perturbation"] if self.delta_w_last == 0.0 else max(o["min_hessian_perturbation"], o["perturb_dec_fact"] * self.delta_w_last)
+            else:
+                dw = dw * (o["perturb_inc_fact_first"] if self.delta_w_last == 0.0 else o["perturb_inc_fact"])
+            if dw > o["max_hessian_perturbation"]:
+                return None
+
+        def solve(rhs_x, rhs_t, rhs_g):
+            b = rhs_g.copy()
+            np.subtract.at(b, P.t_row, P.t_sig * q * rhs_t)
+            b[:mc] /= sc
+            dx, dy = self._riccati_solve(S, fac, Jc, Jd, e_c, e_d, soft, rhs_x, b)
+            dy[:mc] /= sc
+            dt = q * (rhs_t - P.t_sig * dy[P.t_row])
+            return dx, dt, dy
+        return solve
+
+    @staticmethod
+    def _riccati_backward(S, Wd, WN, cpl, Jc, Jd, sig_x, dw, e_c, e_d, soft):
+        N, nx, nu, nv, K = S.N, S.nx, S.nu, S.nv, S.K
+        na = nx + nu
+        Pm = np.zeros((N + 1, na, na))                                     # value functions (unmodified)
+        Pt = np.zeros((N + 1, na, na))                                     # parallel sums (soft rows) = what the stage before sees
+        Lq, Kg, Lm, Hs = [None] * N, [None] * N, [None] * (N + 1), [None] * N
+        Pm[N][:nx, :nx] = WN + np.diag(sig_x[N * nv:] + dw)
+        for k in range(N, -1, -1):
+            if k < N:
+                H = Wd[k] + np.diag(sig_x[k * nv:(k + 1) * nv] + dw) + Jd[k].T @ (Jd[k] / e_d[k][:, None])
+                Hs[k] = H
+                G = np.zeros((na, na + nu))                                # xi+ = G (xi; u):  [[A, 0, B], [0, 0, I]]
+                G[:nx, :nx] = Jc[k][:, :nx]
+                G[:nx, na:] = Jc[k][:, nx:]
+                G[nx:, na:] = np.eye(nu)
+                Sk = np.zeros((na + nu, na + nu))
+                Sk[:nx, :nx] = H[:nx, :nx]; Sk[:nx, na:] = H[:nx, nx:]; Sk[na:, :nx] = H[nx:, :nx]; Sk[na:, na:] = H[nx:, nx:]
+                if k >= 1:                                                  # -2 R (u_k, v_k) cross term (the diagonal 2 R sits on u_{k-1})
+                    c = cpl[k - 1]
+                    Sk[nx + np.arange(nu), na + np.arange(nu)] -= c
+                    Sk[na + np.arange(nu), nx + np.arange(nu)] -= c
+                Q = Sk + G.T @ Pt[k + 1] @ G
+                Quu = Q[na:, na:]
+                try:
+                    L = np.linalg.cholesky(Quu)
+                except np.linalg.LinAlgError:
+                    return None
+                if not np.all(np.isfinite(L)):
+                    return None
+                Kk = -np.linalg.solve(L.T, np.linalg.solve(L, Q[na:, :na]))
+                Pk = Q[:na, :na] + Q[:na, na:] @ Kk
+                Pm[k] = 0.5 * (Pk + Pk.T)
+                Lq[k], Kg[k] = L, Kk
+            # what stage k - 1 (or the initial condition) sees of stage k: soft rows -> parallel sum
+            if soft:
+                Eh = np.zeros(na)
+                Eh[:nx] = np.sqrt(e_c[k])
+                M = np.eye(na) + Eh[:, None] * Pm[k] * Eh[None, :]
+                try:
+                    Lk = np.linalg.cholesky(M)
+                except np.linalg.LinAlgError:
+                    return None
+                Y = np.linalg.solve(Lk, Eh[:, None] * Pm[k])               # L^-1 E^1/2 P
+                Pt[k] = Pm[k] - Y.T @ Y
+                Pt[k] = 0.5 * (Pt[k] + Pt[k].T)
+                Lm[k] = Lk
+            else:
+                Pt[k] = Pm[k]
+        return dict(Pm=Pm, Pt=Pt, Lq=Lq, Kg=Kg, Hs=Hs)
+
+    @staticmethod
+    def _riccati_solve(S, fac, Jc, Jd, e_c, e_d, soft, rhs_x, b):
+        """H dx + J' dy = rhs_x,  J dx - e dy = b  for one right-hand side with the factors of _riccati_backward."""
+        N, nx, nu, nv, K = S.N, S.nx, S.nu, S.nv, S.K
+        na, mc = nx + nu, (S.N + 1) * S.nx
+        Pm, Pt, Lq, Kg = fac["Pm"], fac["Pt"], fac["Lq"], fac["Kg"]
+        b_c, b_d = b[:mc].reshape(N + 1, nx), b[mc:].reshape(N, K)
+        pm = np.zeros((N + 1, na))                                         # linear terms of the value functions, and as the stage before sees them
+        pt = np.zeros((N + 1, na))
+        kff = [None] * N
+        pm[N][:nx] = -rhs_x[N * nv:]
+        E = np.zeros((N + 1, na))
+        E[:, :nx] = e_c
+        for k in range(N, -1, -1):
+            if k < N:
+                g = -rhs_x[k * nv:(k + 1) * nv] - Jd[k].T @ (b_d[k] / e_d[k])
+                cb = np.zeros(na)
+                cb[:nx] = -b_c[k + 1]                                       # defect of the dynamics row block k + 1
+                G = np.zeros((na, na + nu))
+                G[:nx, :nx] = Jc[k][:, :nx]; G[:nx, na:] = Jc[k][:, nx:]; G[nx:, na:] = np.eye(nu)
+                sk = np.zeros(na + nu)
+                sk[:nx] = g[:nx]; sk[na:] = g[nx:]
+                qv = sk + G.T @ (Pt[k + 1] @ cb + pt[k + 1])
+                kff[k] = -np.linalg.solve(Lq[k].T, np.linalg.solve(Lq[k], qv[na:]))
+                Q_xu_K = None
+                # p_k = q_x + Q_xu kff   (Q_xu = -K' Quu  =>  Q_xu kff = K' (-Quu kff) = K' q_u)
+                pm[k] = qv[:na] + Kg[k].T @ qv[na:]
+            pt[k] = pm[k] - Pt[k] @ (E[k] * pm[k]) if soft else pm[k]
+        dx, dy = np.zeros(S.n), np.zeros(mc + N * K)
+        xi = np.zeros(na)
+        if soft:                                                            # row 0: dx_0 - e dy_0 = b_0, dy_0 = -(P_0 dx_0 + p_0)
+            rhs0 = np.zeros(na)
+            rhs0[:nx] = b_c[0]
+            xi = rhs0 - E[0] * pm[0]
+            xi = xi - E[0] * (Pt[0] @ xi)                                   # (I + E P)^-1 = I - E P~
+            xi[nx:] = 0.0
+        else:
+            xi[:nx] = b_c[0]
+        dy[:nx] = -(Pm[0] @ xi + pm[0])[:nx]
+        for k in range(N):
+            u = Kg[k] @ xi + kff[k]
+            dx[k * nv:k * nv + nx] = xi[:nx]
+            dx[k * nv + nx:(k + 1) * nv] = u
+            dy[mc + k * K: mc + (k + 1) * K] = (Jd[k] @ np.concatenate([xi[:nx], u]) - b_d[k]) / e_d[k]
+            a = np.zeros(na)
+            a[:nx] = Jc[k] @ np.concatenate([xi[:nx], u]) - b_c[k + 1]
+            a[nx:] = u
+            if soft:
+                a = a - E[k + 1] * pm[k + 1]
+                a = a - E[k + 1] * (Pt[k + 1] @ a)
+            xi = a
+            dy[nx + k * nx: nx + (k + 1) * nx] = (Pm[k + 1] @ xi + pm[k + 1])[:nx]
+        dx[N * nv:] = xi[:nx]
+        return dx, dy
 
     @staticmethod
     def _kmul(W, J, dxx, e, v):
@@ -754,6 +928,9 @@ class _Algo:
                 if self.in_resto:
                     status = "resto_failed"
                     break
+                if o.get("restoration", "ipopt") == "none":               # the caller has another solver for these (csrc/mpc_vtol_ms.hip: the
+                    status = "needs_resto"                                  # condensed wave kernel and its restoration)
+                    break
                 rs = self.restoration(x, t, y, z, mu, ev, budget)
                 if rs[0] != "ok":
                     status, x, t = rs[0], rs[1], rs[2]
@@ -885,6 +1062,8 @@ class _Algo:
         ra.orig = dict(mu=mu, theta=theta, phi=phi, pinf=float(np.max(np.abs(r))))
         mu_r = max(mu, float(np.max(np.abs(r))))
         rho = RP.rho
+        r_all = r
+        r = r[RP.el]
         a = (mu_r - rho * r) / (2.0 * rho)
         nn = a + np.sqrt(a * a + mu_r * r / (2.0 * rho))                    # eq. (33): row + n - p = 0 with residual r = p - n ... sign below
         # the rows are  g + A_s s + n - p = 0:  p - n = r
@@ -892,7 +1071,7 @@ class _Algo:
         tt = np.concatenate([t, nn, pp])
         zxL, zxU, ztL, ztU = z
         zr = (np.minimum(rho, zxL), np.minimum(rho, zxU),
-              np.concatenate([np.minimum(rho, ztL), mu_r / nn, mu_r / pp]), np.concatenate([np.minimum(rho, ztU), np.zeros(2 * P.m)]))
+              np.concatenate([np.minimum(rho, ztL), mu_r / nn, mu_r / pp]), np.concatenate([np.minimum(rho, ztU), np.zeros(2 * len(RP.el))]))
         zr = tuple(np.where(np.isfinite(s_), z_, 0.0) for z_, s_ in zip(zr, ra.slacks(x, tt)))
         st, xr, tr, yr, zrr, mur = ra.run(x.copy(), tt, np.zeros(P.m), zr, mu_r, budget)
         self.iters += ra.iters
@@ -932,7 +1111,7 @@ class _Algo:
         return out.acceptable_to_iterate(phi_t, th_t, self.orig["phi"], self.orig["theta"])
 
 
-STATUS_OF = dict(optimal=0, acceptable=0, local_infeasibility=1, max_iter=2, resto_failed=2, resto_converged_feasible=2, error=2)
+STATUS_OF = dict(optimal=0, acceptable=0, local_infeasibility=1, max_iter=2, resto_failed=2, resto_converged_feasible=2, error=2, needs_resto=4)
 
 
 def solve_nlp(nlp, w0, opts=None, trace=None):

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SAFE_CONTROL_AMD_LIB") or os.path.join(_HERE, "lib", 
 
 SC_OK = 0
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_INACCURATE, STATUS_BAD_OBSTACLE = 0, 1, 2, 3
-STATUS_STRINGS = {0: "optimal", 1: "infeasible", 2: "optimal_inaccurate", 3: "bad_obstacle"}
+STATUS_STRINGS = {0: "optimal", 1: "infeasible", 2: "optimal_inaccurate", 3: "bad_obstacle", 4: "needs_restoration"}
 DTYPE_F32, DTYPE_F64 = 0, 1
 CBF_MODE = {"cbf": 0, "hard": 1}
 CBFQP_MAX_OBS = 32
@@ -241,6 +241,41 @@ class ManipTrackingParams(C.Structure):
     ]
 
 
+STATUS_NEEDS_RESTO = 4          # sc_mpcvtol_ms_solve_batch: IPOPT would enter its restoration phase here (the host class re-solves with the condensed kernel)
+
+
+class IpoptParams(C.Structure):
+    """Mirror of ``sc_ipopt_params``: IPOPT's option names with IPOPT's documented defaults (oracle/ms_ipopt.py: OPTS)."""
+    _fields_ = [("max_iter", C.c_int32), ("acceptable_iter", C.c_int32)] + [(k, C.c_double) for k in (
+        "tol", "dual_inf_tol", "constr_viol_tol", "compl_inf_tol",
+        "acceptable_tol", "acceptable_dual_inf_tol", "acceptable_constr_viol_tol", "acceptable_compl_inf_tol",
+        "nlp_scaling_max_gradient", "nlp_scaling_min_value", "bound_relax_factor", "bound_push", "bound_frac", "constr_mult_init_max",
+        "mu_init", "mu_linear_decrease_factor", "mu_superlinear_decrease_power", "barrier_tol_factor", "tau_min",
+        "kappa_sigma", "kappa_d", "s_max",
+        "theta_max_fact", "theta_min_fact", "eta_phi", "delta", "s_phi", "s_theta", "gamma_phi", "gamma_theta", "alpha_min_frac", "alpha_red_factor",
+        "obj_max_inc",
+        "first_hessian_perturbation", "min_hessian_perturbation", "max_hessian_perturbation", "perturb_inc_fact_first", "perturb_inc_fact",
+        "perturb_dec_fact")]
+
+
+IPOPT_DEFAULTS = dict(
+    max_iter=3000, acceptable_iter=15, tol=1e-8, dual_inf_tol=1.0, constr_viol_tol=1e-4, compl_inf_tol=1e-4,
+    acceptable_tol=1e-6, acceptable_dual_inf_tol=1e10, acceptable_constr_viol_tol=1e-2, acceptable_compl_inf_tol=1e-2,
+    nlp_scaling_max_gradient=100.0, nlp_scaling_min_value=1e-8, bound_relax_factor=1e-8, bound_push=1e-2, bound_frac=1e-2,
+    constr_mult_init_max=1e3, mu_init=0.1, mu_linear_decrease_factor=0.2, mu_superlinear_decrease_power=1.5, barrier_tol_factor=10.0,
+    tau_min=0.99, kappa_sigma=1e10, kappa_d=1e-5, s_max=100.0, theta_max_fact=1e4, theta_min_fact=1e-4, eta_phi=1e-8, delta=1.0,
+    s_phi=2.3, s_theta=1.1, gamma_phi=1e-8, gamma_theta=1e-5, alpha_min_frac=0.05, alpha_red_factor=0.5, obj_max_inc=5.0,
+    first_hessian_perturbation=1e-4, min_hessian_perturbation=1e-20, max_hessian_perturbation=1e20, perturb_inc_fact_first=100.0,
+    perturb_inc_fact=8.0, perturb_dec_fact=1.0 / 3.0)
+
+
+def default_ipopt(**over):
+    p = IpoptParams()
+    for k, v in dict(IPOPT_DEFAULTS, **over).items():
+        setattr(p, k, v)
+    return p
+
+
 SM_IDLE, SM_TRACK, SM_STOP, SM_ROTATE = 0, 1, 2, 3
 SM_NAMES = {0: "idle", 1: "track", 2: "stop", 3: "rotate"}
 TRACKING_MAX_CONSTRAINTS = 16
@@ -274,6 +309,7 @@ SYMBOLS = {
     "sc_mpcvtol_workspace_bytes": (C.c_size_t, [C.POINTER(MpcVtolParams), C.c_int64, C.c_int32]),
     "sc_mpcvtol_solve_batch": (C.c_int, [C.POINTER(MpcVtolParams), C.c_int64, C.c_int32] + [C.c_void_p] * 9 + [C.c_size_t, C.c_void_p]),
     "sc_mpcvtol_solve_batch_host": (C.c_int, [C.POINTER(MpcVtolParams), C.c_int64, C.c_int32] + [C.c_void_p] * 8 + [C.c_int]),
+    "sc_mpcvtol_ms_solve_batch": (C.c_int, [C.POINTER(MpcVtolParams), C.POINTER(IpoptParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_odmpcvtol_solve_batch": (C.c_int, [C.POINTER(OdMpcVtolParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_odmpcgn_solve_batch": (C.c_int, [C.POINTER(OdMpcGnParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_mpclin_model_doubles": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
@@ -319,7 +355,7 @@ SYMBOLS = {
 _lib = None
 
 # SC_VERSION_MAJOR * 1000 + SC_VERSION_MINOR of the header the ctypes mirrors above were written for
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class HipLibraryError(RuntimeError):

@@ -1,0 +1,1140 @@
+// MPC-CBF for VTOL2D as do-mpc poses it -- MULTIPLE SHOOTING -- solved by IPOPT's filter line-search interior point: ONE NLP PER
+// WAVEFRONT, ONE STAGE PER LANE.  Kernel 12 in DESIGN.md; the algorithm is oracle/ms_ipopt.py with the "kernel profile"
+// (linear_solver = riccati, max_soc = 0, restoration = none), iterate for iterate.
+//
+// Why a second VTOL2D kernel.  mpc_vtol_wave.hip solves the CONDENSED problem in z = (u_0 .. u_{N-1}) from the rollout of u_prev.  The
+// reference does not (position_control/mpc_cbf.py:162-174,366-369): do-mpc hands IPOPT the states x_0 .. x_N as variables with the
+// dynamics as equality rows, and starts every stage's state at x0.  On the reference's own example scene (examples/test_vtol.py) one
+// condensed solve fails on a FEASIBLE problem -- the rollout of an aggressive u_prev over 30 unstable stages diverges, the Newton steps
+// of the single-shooting problem find no descent -- and the flight is lost; the multiple-shooting solve of the same NLP converges in
+// 32 iterations and the flight lands (tools/exp_ms_vtol_flight.py, profiles/r05_ms_vtol_flight*.log).
+//
+//   variables   lane k <= N owns x_k (6) and, for k < N, u_k (4), the 6 dynamics rows  F(x_k, u_k) - x_{k+1} = 0  with their multipliers
+//               and the K rows  d_kj = -cbf_j(x_k, u_k) <= 0  with slack, multiplier and slack-bound multiplier -- all in registers;
+//               bounds on theta, x_dot, z_dot (>= only) and the inputs as IPOPT treats variable bounds (log barrier, z_L / z_U)
+//   evaluation  NO rollout: every lane evaluates the aero model at its own (x_k, u_k) (second-order forward mode over (theta, x_dot,
+//               z_dot): mpc_vtol_solver.hpp: accel<D2>), one evaluation per stage and function call instead of a chain of thirty
+//   Newton step the inequality rows of a stage are condensed into its 10 x 10 block, the primal-dual system is an LQ problem with
+//               defects and is solved by a Riccati recursion over the augmented state (dx_k, du_{k-1}) (the input-rate penalty couples
+//               neighbouring inputs), lanes over matrix entries, four phases per stage; inertia correction = "every 4 x 4 input block
+//               positive definite" (Algorithm IC's delta_w ladder); multipliers of the dynamics rows from the costate sweep
+//   globalisation  IPOPT's filter (theta = l1 norm of the row residuals, phi = barrier function), switching condition + Armijo,
+//               alpha_min -> "needs a restoration": status SC_STATUS_NEEDS_RESTO, which the host class hands to the condensed kernel
+//               and ITS restoration phase (csrc/mpc_vtol_wave.hip); fraction to the boundary tau = max(0.99, 1 - mu), monotone mu,
+//               gradient-based scaling, bound push / relaxation, least-square initial multipliers, kappa_sigma, safe slacks
+//
+// LDS per problem (N = 30): stage Jacobians [A | B], stage blocks, gains, gradient / defect / step vectors, the Riccati workspace: 53 KB
+// (three problems per CU).  Compiled with the non-splitting register allocator (csrc/Makefile: SAFE_RA).
+#include <hip/hip_runtime.h>
+
+#include "../../include/safe_control_amd.h"
+#include "mpc_ipm_common.hpp"
+#include "sc_qp2.hpp"
+#define SC_VTOL_WITH_C_PARAMS
+#define SC_VTOL_RCP(a) sc::rcp_(a)
+#define SC_VTOL_SINCOS(a, s, c) sc::sincos_((a), &(s), &(c));
+#include "mpc_vtol_solver.hpp"
+
+namespace sc {
+
+using namespace vtol;
+
+namespace msk {
+
+typedef __attribute__((address_space(3))) double ldsd;
+
+constexpr int KS_MAX = 16;
+constexpr int NFILT = 48;                       // filter entries kept (the filter is cleared with every decrease of mu)
+constexpr int TRACE_W = 8;
+
+struct Lds {
+    int OB, AB, H, KG, G, C, DX, DU, LAM, XS, US, YS, Pc, Pn, T, QU, Quu, pc, pn, FP, FT, total;
+    __host__ __device__ explicit Lds(int N) {
+        int o = 0;
+        auto take = [&](int c) { int r = o; o += c; return r; };
+        OB = take(3 * KS_MAX); AB = take(N * 60); H = take((N + 1) * 55); KG = take(N * 44); G = take((N + 1) * 10); C = take((N + 1) * 6);
+        DX = take((N + 1) * 6); DU = take(N * 4); LAM = take((N + 2) * 6); XS = take((N + 2) * 6); US = take((N + 2) * 4); YS = take((N + 2) * 6);
+        Pc = take(100); Pn = take(100); T = take(110); QU = take(44); Quu = take(16); pc = take(10); pn = take(10);
+        FP = take(NFILT); FT = take(NFILT);
+        total = o;
+    }
+};
+
+size_t lds_bytes(int horizon) { return (size_t)Lds(horizon).total * sizeof(double); }
+
+// ---- Riccati recursion with defects (oracle/ms_ipopt.py: _riccati_backward / _riccati_solve, hard dynamics) ----------------------------
+// LDS in: AB[k] (6 x 10 [A | B]), H[k] (upper-packed 10 x 10 over (x_k, u_k); H[N]: its x block), G[k] (gradient, 10), C[k + 1] (defect of the
+// dynamics of stage k), C[0] = dx_0;  cpl[j] = 2 df R_j: the (u_{k-1}, u_k) cross term, -cpl on the (v, u) entries of stage k >= 1.
+// Out: KG[k] = gains (K: 4 x 10 over (dx_k, du_{k-1}), then kff: 4); false (wave-uniform) when an input block is not positive definite.
+__device__ __attribute__((noinline)) bool riccati_backward(ldsd* lds, const Lds L, const int N, const int lane, const double c0, const double c1,
+                                                           const double c2, const double c3) {
+    ldsd* T = lds + L.T; ldsd* QU = lds + L.QU; ldsd* Quu = lds + L.Quu;
+    ldsd* Pc = lds + L.Pc; ldsd* Pn = lds + L.Pn; ldsd* pc = lds + L.pc; ldsd* pn = lds + L.pn;
+    const double cpl[4] = {c0, c1, c2, c3};
+    int tr = 0, tc = 0;                                                   // phase D: upper-triangle entry `lane` of 55
+    { int e = lane < 55 ? lane : 0; int r = 0; while (e >= NV - r) { e -= NV - r; ++r; } tr = r; tc = r + e; }
+    {
+        const ldsd* HN = lds + L.H + N * 55; const ldsd* GN = lds + L.G + N * 10;
+        for (int e = lane; e < 100; e += 64) { const int r = e / 10, c = e % 10; Pc[e] = (r < NX && c < NX) ? HN[sym(r, c)] : 0.0; }
+        if (lane < NV) pc[lane] = lane < NX ? GN[lane] : 0.0;
+    }
+    __syncthreads();
+    for (int kk = N - 1; kk >= 0; --kk) {
+        const ldsd* AB = lds + L.AB + kk * 60; const ldsd* H = lds + L.H + kk * 55; const ldsd* g = lds + L.G + kk * 10;
+        const ldsd* cd = lds + L.C + (kk + 1) * 6;
+        // A: T = P [A | B] (+ P's v columns under B), column 10: P c + p
+        for (int e = lane; e < 110; e += 64) {
+            const int r = e / 11, c = e % 11;
+            double v;
+            if (c < 10) {
+                v = c >= NX ? Pc[r * 10 + c] : 0.0;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) v += Pc[r * 10 + i] * AB[i * 10 + c];
+            } else {
+                v = pc[r];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) v += Pc[r * 10 + i] * cd[i];
+            }
+            T[e] = v;
+        }
+        __syncthreads();
+        // B: u rows of H + G' T: [Qux | Quu], and qu
+        if (lane < 44) {
+            const int i = lane / 11, c = lane % 11;
+            double v;
+            if (c < 10) {
+                v = T[(6 + i) * 11 + c] + H[sym(c, 6 + i)];
+#pragma unroll
+                for (int r = 0; r < NX; ++r) v += AB[r * 10 + 6 + i] * T[r * 11 + c];
+                if (c < NX) QU[i * 11 + c] = v; else Quu[i * 4 + c - NX] = v;
+            } else {
+                v = g[6 + i] + T[(6 + i) * 11 + 10];
+#pragma unroll
+                for (int r = 0; r < NX; ++r) v += AB[r * 10 + 6 + i] * T[r * 11 + 10];
+                QU[i * 11 + 10] = v;
+            }
+        }
+        __syncthreads();
+        // C: the 4 x 4 factorisation in every lane, one right-hand side per lane (10 columns of [Qux | Quv], then qu)
+        {
+            const double q00 = Quu[0], q10 = Quu[4], q11 = Quu[5], q20 = Quu[8], q21 = Quu[9], q22 = Quu[10], q30 = Quu[12], q31 = Quu[13],
+                         q32 = Quu[14], q33 = Quu[15];
+            const int c = lane < 11 ? lane : 0;
+            double b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (c < NX) b[i] = QU[i * 11 + c];
+                else if (c < NV) b[i] = (kk >= 1 && c - NX == i) ? -cpl[i] : 0.0;
+                else b[i] = QU[i * 11 + 10];
+            }
+            const double r0 = rsqrt_(q00), l10 = q10 * r0, l20 = q20 * r0, l30 = q30 * r0;
+            const double d1 = q11 - l10 * l10, r1 = rsqrt_(d1), l21 = (q21 - l20 * l10) * r1, l31 = (q31 - l30 * l10) * r1;
+            const double d2 = q22 - l20 * l20 - l21 * l21, r2 = rsqrt_(d2), l32 = (q32 - l30 * l20 - l31 * l21) * r2;
+            const double d3 = q33 - l30 * l30 - l31 * l31 - l32 * l32, r3 = rsqrt_(d3);
+            if (!(q00 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0)) return false;     // wave-uniform: every lane factors the same block
+            const double y0 = b[0] * r0, y1 = (b[1] - l10 * y0) * r1, y2 = (b[2] - l20 * y0 - l21 * y1) * r2, y3 = (b[3] - l30 * y0 - l31 * y1 - l32 * y2) * r3;
+            const double x3 = y3 * r3, x2 = (y2 - l32 * x3) * r2, x1 = (y1 - l21 * x2 - l31 * x3) * r1, x0_ = (y0 - l10 * x1 - l20 * x2 - l30 * x3) * r0;
+            if (lane < 11) {
+                ldsd* dst = lds + L.KG + kk * 44 + (c < NV ? c : 40);
+                const int st = c < NV ? 10 : 1;
+                dst[0] = -x0_; dst[st] = -x1; dst[2 * st] = -x2; dst[3 * st] = -x3;
+            }
+        }
+        __syncthreads();
+        // D: the new P = Q_xixi + Q_xiu K (upper triangle, mirrored on the write) and p = q_xi + Q_xiu kff
+        {
+            const ldsd* KK = lds + L.KG + kk * 44; const ldsd* kf = KK + 40;
+            double v = 0.0;
+            if (tr < NX && tc < NX) {
+                v = H[sym(tr, tc)];
+#pragma unroll
+                for (int r = 0; r < NX; ++r) v += AB[r * 10 + tr] * T[r * 11 + tc];
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const double qa = tr < NX ? QU[i * 11 + tr] : ((kk >= 1 && tr - NX == i) ? -cpl[i] : 0.0);
+                v += qa * KK[i * 10 + tc];
+            }
+            if (lane < 55) { Pn[tr * 10 + tc] = v; Pn[tc * 10 + tr] = v; }
+            if (lane < NV) {
+                const int a = lane;
+                double w = 0.0;
+                if (a < NX) {
+                    w = g[a];
+#pragma unroll
+                    for (int r = 0; r < NX; ++r) w += AB[r * 10 + a] * T[r * 11 + 10];
+                }
+#pragma unroll
+                for (int i = 0; i < NU; ++i) {
+                    const double qa = a < NX ? QU[i * 11 + a] : ((kk >= 1 && a - NX == i) ? -cpl[i] : 0.0);
+                    w += qa * kf[i];
+                }
+                pn[a] = w;
+            }
+        }
+        __syncthreads();
+        { ldsd* tP = Pc; Pc = Pn; Pn = tP; ldsd* tp = pc; pc = pn; pn = tp; }
+    }
+    return true;
+}
+
+// forward LQ rollout: du_k = K (dx_k, du_{k-1}) + kff, dx_{k+1} = [A | B] (dx_k, du_k) + c_{k+1}; four + six lanes, two barriers per stage
+__device__ __attribute__((noinline)) void riccati_forward(ldsd* lds, const Lds L, const int N, const int lane) {
+    if (lane < NX) lds[L.DX + lane] = lds[L.C + lane];
+    __syncthreads();
+    const int li = lane < NU ? lane : 0, lx = lane < NX ? lane : 0;
+    for (int kk = 0; kk < N; ++kk) {
+        const ldsd* AB = lds + L.AB + kk * 60; const ldsd* KK = lds + L.KG + kk * 44;
+        {
+            double v = KK[40 + li];
+#pragma unroll
+            for (int c = 0; c < NX; ++c) v += KK[li * 10 + c] * lds[L.DX + kk * 6 + c];
+            if (kk > 0) {
+#pragma unroll
+                for (int c = 0; c < NU; ++c) v += KK[li * 10 + 6 + c] * lds[L.DU + (kk - 1) * NU + c];
+            }
+            if (lane < NU) lds[L.DU + kk * NU + lane] = v;
+        }
+        __syncthreads();
+        {
+            double v = lds[L.C + (kk + 1) * 6 + lx];
+#pragma unroll
+            for (int c = 0; c < NX; ++c) v += AB[lx * 10 + c] * lds[L.DX + kk * 6 + c];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) v += AB[lx * 10 + 6 + j] * lds[L.DU + kk * NU + j];
+            if (lane < NX) lds[L.DX + (kk + 1) * 6 + lane] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// costates lam_k = h_k + A_k' lam_{k+1}, k = N - 1 .. 0, with h_k (and lam_N = h_N) already in LAM: six lanes, one barrier per stage
+__device__ __attribute__((noinline)) void costates(ldsd* lds, const Lds L, const int N, const int lane) {
+    const int c = lane < NX ? lane : 0;
+    for (int j = N - 1; j >= 0; --j) {
+        const ldsd* AB = lds + L.AB + j * 60;
+        double v = lds[L.LAM + j * 6 + c];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) v += AB[i * 10 + c] * lds[L.LAM + (j + 1) * 6 + i];
+        __syncthreads();
+        if (lane < NX) lds[L.LAM + j * 6 + lane] = v;
+        __syncthreads();
+    }
+}
+
+constexpr double EPSD = 2.220446049250313e-16;
+constexpr double INF_ = 1e300;
+
+__device__ __forceinline__ bool cmp_le(double lhs, double rhs, double bas) { return lhs - rhs <= 10.0 * EPSD * fabs(bas); }
+
+template <int KS>
+struct Wave {
+    const Params& P;
+    const sc_ipopt_params& O;
+    ldsd* lds;
+    const Lds L;
+    const int lane, N, K;
+    const bool act, stg;               // lane owns a state (k <= N) / a stage with inputs and rows (k < N)
+    const int k;
+    double x0[NX], uprev[NU], xg[2];
+    double w0, w1, w2;
+    // iterate
+    double x[NX], u[NU], yc[NX], y0[NX];
+    double xbL[3], xbU[2], ubL[NU], ubU[NU];              // (relaxed, adjustable) bounds: x idx 2, 3, 4 lower / 2, 3 upper; inputs
+    double zxL[3], zxU[2], zuL[NU], zuU[NU];
+    double s[KS], yd[KS], vU[KS], sU[KS];
+    // scales
+    double df, dgc[NX], dgd[KS];
+    // last evaluation
+    double rc[NX], r0[NX], dv[KS];                       // scaled residuals of my dynamics rows / of the initial-state rows (lane 0) / scaled row values
+    double fk;                                           // my stage's share of the unscaled objective
+    // steps
+    double dx[NX], du[NU], dyc[NX], dy0[NX], ds[KS], dyd[KS], dvU[KS], dzxL[3], dzxU[2], dzuL[NU], dzuU[NU];
+    int nfilt;
+    double dw_last, last_dw;
+
+    __device__ __forceinline__ Wave(const Params& P_, const sc_ipopt_params& O_, ldsd* lds_)
+        : P(P_), O(O_), lds(lds_), L(P_.N), lane(threadIdx.x), N(P_.N), K(P_.K), act((int)threadIdx.x <= P_.N), stg((int)threadIdx.x < P_.N),
+          k((int)threadIdx.x <= P_.N ? (int)threadIdx.x : 0) {
+        const double g1 = P.alpha1 + P.alpha2, g2 = P.alpha1 * P.alpha2;
+        w0 = 1.0 - g1 + g2; w1 = g1 - 2.0; w2 = 1.0;
+        nfilt = 0; dw_last = 0.0; last_dw = 0.0;
+    }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ bool row_on(int j) const { return stg && j < K; }
+
+    // ---- level 0: my stage's F(x, u), row values (unscaled cbf), cost share ----------------------------------------------------------
+    __device__ __forceinline__ void points(const double* xs, const double a0, const double a1, double pt[3][2]) const {
+        const double dt = P.dt;
+        pt[0][0] = xs[0]; pt[0][1] = xs[1];
+        pt[1][0] = xs[0] + dt * xs[3]; pt[1][1] = xs[1] + dt * xs[4];
+        pt[2][0] = pt[1][0] + dt * (xs[3] + dt * a0); pt[2][1] = pt[1][1] + dt * (xs[4] + dt * a1);
+    }
+    __device__ __forceinline__ double cbf_value(const double pt[3][2], int j) const {
+        const double cx = lds[L.OB + 3 * j], cz = lds[L.OB + 3 * j + 1], d = P.radius + lds[L.OB + 3 * j + 2], off = P.beta * d * d;
+        double hv[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { const double ex = pt[p][0] - cx, ez = pt[p][1] - cz; hv[p] = ex * ex + ez * ez - off; }
+        return w0 * hv[0] + w1 * hv[1] + w2 * hv[2];
+    }
+    // objective share of lane k: l(x_k) (+ m(x_N)) + R (u_k - u_{k-1})^2; um = u_{k-1}
+    __device__ __forceinline__ double cost_share(const double* xs, const double* us, const double* um) const {
+        double f = 0.0;
+        if (act) {
+            const double e0 = xs[0] - xg[0], e1 = xs[1] - xg[1];
+            f = P.Q[0] * e0 * e0 + P.Q[1] * e1 * e1 + P.Q[2] * xs[2] * xs[2] + P.Q[3] * xs[3] * xs[3] + P.Q[4] * xs[4] * xs[4] + P.Q[5] * xs[5] * xs[5];
+        }
+        if (stg) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { const double d = us[j] - um[j]; f += P.R[j] * d * d; }
+        }
+        return f;
+    }
+    // trial evaluation at (xs, us, ss): theta (l1 residual of the scaled rows) and the unscaled objective; xs of every lane goes through XS
+    __device__ __forceinline__ void eval0(const double* xs, const double* us, const double* ss, double& theta, double& fsum, double* rc_o, double* r0_o,
+                                          double* dv_o) {
+        sync();
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) lds[L.XS + k * 6 + i] = xs[i];
+        }
+        if (stg) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) lds[L.US + (k + 1) * 4 + j] = us[j];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) lds[L.US + j] = uprev[j];
+        }
+        sync();
+        double th = 0.0;
+        double um[NU];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) um[j] = lds[L.US + k * 4 + j];
+        if (stg) {
+            double acc[3], gc[4][3], xn[NX];
+            accel<double>(P, xs[2], xs[3], xs[4], us, acc, gc);
+            xn[0] = xs[0] + P.dt * xs[3]; xn[1] = xs[1] + P.dt * xs[4]; xn[2] = xs[2] + P.dt * xs[5];
+            xn[3] = xs[3] + P.dt * acc[0]; xn[4] = xs[4] + P.dt * acc[1]; xn[5] = xs[5] + P.dt * acc[2];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { rc_o[i] = dgc[i] * (xn[i] - lds[L.XS + (k + 1) * 6 + i]); th += fabs(rc_o[i]); }
+            double pt[3][2];
+            points(xs, acc[0], acc[1], pt);
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                if (j < K) { dv_o[j] = -dgd[j] * cbf_value(pt, j); th += fabs(dv_o[j] - ss[j]); } else dv_o[j] = 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) rc_o[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) dv_o[j] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { r0_o[i] = lane == 0 ? xs[i] - x0[i] : 0.0; th += fabs(r0_o[i]); }
+        theta = ipm::wsum(th);
+        fsum = ipm::wsum(cost_share(xs, us, um));
+    }
+
+    // ---- barrier function (scaled objective + log barrier of every bound + damping of the one-sided ones) ------------------------------
+    __device__ __forceinline__ double barrier_terms(const double* xs, const double* us, const double* ss, double mu, bool& ok) const {
+        double v = 0.0;
+        ok = true;
+        if (act) {
+            const double sl[5] = {xs[2] - xbL[0], xs[3] - xbL[1], xs[4] - xbL[2], xbU[0] - xs[2], xbU[1] - xs[3]};
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { if (!(sl[i] > 0.0)) ok = false; v -= mu * log(sl[i]); }
+            v += O.kappa_d * mu * sl[2];
+        }
+        if (stg) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const double a = us[j] - ubL[j], b = ubU[j] - us[j];
+                if (!(a > 0.0) || !(b > 0.0)) ok = false;
+                v -= mu * (log(a) + log(b));
+            }
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                if (j < K) { const double a = sU[j] - ss[j]; if (!(a > 0.0)) ok = false; v -= mu * log(a); v += O.kappa_d * mu * a; }
+            }
+        }
+        return v;
+    }
+    __device__ __forceinline__ double barrier(double fsum, const double* xs, const double* us, const double* ss, double mu) const {
+        bool ok;
+        const double b = barrier_terms(xs, us, ss, mu, ok);
+        const double bad = ipm::wmax(ok ? 0.0 : 1.0);
+        if (bad > 0.0) return INF_;
+        return df * fsum + ipm::wsum(b);
+    }
+    // IPOPT's CalculateSafeSlack: a slack below eps min(1, mu) is raised to eps^(3/4) max(1, |bound|) by moving the bound
+    __device__ __forceinline__ void safe1(double v, double& lo, bool lower, double s_min, double move) const {
+        if (lower) { if (v - lo < s_min) lo = v - fmax(v - lo, move * fmax(1.0, fabs(lo))); }
+        else { if (lo - v < s_min) lo = v + fmax(lo - v, move * fmax(1.0, fabs(lo))); }
+    }
+    __device__ __forceinline__ void safe_slacks(const double* xs, const double* us, const double* ss, double mu) {
+        const double s_min = EPSD * fmin(1.0, mu), move = 1.8189894035458565e-12;     // eps^(3/4)
+        if (act) {
+            safe1(xs[2], xbL[0], true, s_min, move); safe1(xs[3], xbL[1], true, s_min, move); safe1(xs[4], xbL[2], true, s_min, move);
+            safe1(xs[2], xbU[0], false, s_min, move); safe1(xs[3], xbU[1], false, s_min, move);
+        }
+        if (stg) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { safe1(us[j], ubL[j], true, s_min, move); safe1(us[j], ubU[j], false, s_min, move); }
+#pragma unroll
+            for (int j = 0; j < KS; ++j) if (j < K) safe1(ss[j], sU[j], false, s_min, move);
+        }
+    }
+
+    // ---- level 2 at the iterate: residuals, [A | B], stage block H (condensed rows, bounds, dw), gradient g, and what the step needs ----
+    // mode 0: the Newton system of the iterate (mu, dw);  mode 1: least-square multipliers (W = 0, Sigma = 1)
+    // outputs: LDS AB, H, G, C; registers: rc, r0, dv, fk; Jty (J' y of my variables), aj rows kept implicitly (recomputed in finish_step)
+    struct Eval2 {
+        double Jty[NV];          // J' y at my (x_k, u_k)
+        double gfx[NX], gfu[NU]; // scaled objective gradient
+    };
+    __device__ __forceinline__ void row_grad(const double pt[3][2], const double G2[2][NV], int j, double r[NV]) const {
+        const double cx = lds[L.OB + 3 * j], cz = lds[L.OB + 3 * j + 1];
+        const double e0x = pt[0][0] - cx, e0z = pt[0][1] - cz, e1x = pt[1][0] - cx, e1z = pt[1][1] - cz, e2x = pt[2][0] - cx, e2z = pt[2][1] - cz;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) r[i] = 2.0 * w2 * (e2x * G2[0][i] + e2z * G2[1][i]);
+        r[0] += 2.0 * (w0 * e0x + w1 * e1x); r[1] += 2.0 * (w0 * e0z + w1 * e1z);
+        r[3] += 2.0 * w1 * e1x * P.dt; r[4] += 2.0 * w1 * e1z * P.dt;
+    }
+
+    // exchange through LDS: x_{k+1} (XS), u_{k-1} / u_{k+1} (US, slot k + 1 = u_k, slot 0 = u_prev), multipliers of the rows that DEFINE x_k (YS, slot k)
+    __device__ __forceinline__ void publish() {
+        sync();
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) lds[L.XS + k * 6 + i] = x[i];
+        }
+        if (stg) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) lds[L.US + (k + 1) * 4 + j] = u[j];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) lds[L.YS + (k + 1) * 6 + i] = dgc[i] * yc[i];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) lds[L.US + j] = uprev[j];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) lds[L.YS + i] = -y0[i];
+        }
+        if (lane == N) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) lds[L.US + (N + 1) * 4 + j] = 0.0;
+        }
+        sync();
+    }
+
+    // The big one.  `build`: also write AB / H / G / C for the Riccati recursion with (mu, dw); ls: least-square system instead.
+    __device__ __forceinline__ void eval2(Eval2& E, bool build, bool ls, double mu, double dw, double& theta, double& fsum) {
+        publish();
+        double um[NU], un[NU];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { um[j] = lds[L.US + k * 4 + j]; un[j] = lds[L.US + (k + 2 <= N + 1 ? k + 2 : N + 1) * 4 + j]; }
+        const bool last = k == N - 1;
+        double th = 0.0;
+        double H[55], g[NV];
+#pragma unroll
+        for (int i = 0; i < 55; ++i) H[i] = 0.0;
+        // scaled objective gradient
+#pragma unroll
+        for (int i = 0; i < NX; ++i) E.gfx[i] = 0.0;
+        if (act) {
+            E.gfx[0] = 2.0 * df * P.Q[0] * (x[0] - xg[0]); E.gfx[1] = 2.0 * df * P.Q[1] * (x[1] - xg[1]);
+#pragma unroll
+            for (int i = 2; i < NX; ++i) E.gfx[i] = 2.0 * df * P.Q[i] * x[i];
+        }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            double gj = 0.0;
+            if (stg) { gj = 2.0 * df * P.R[j] * (u[j] - um[j]); if (!last) gj -= 2.0 * df * P.R[j] * (un[j] - u[j]); }
+            E.gfu[j] = gj;
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) E.Jty[i] = 0.0;
+        // rows that define x_k: -I (scaled) on x_k from the dynamics of stage k - 1; +I from the initial-state rows on x_0
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) E.Jty[i] = -lds[L.YS + k * 6 + i];
+        }
+        if (stg) {
+            D2 acc[3], gc[4][3];
+            accel<D2>(P, d2var(x[2], 0), d2var(x[3], 1), d2var(x[4], 2), u, acc, gc);
+            const double dt = P.dt;
+            double xn[NX];
+            xn[0] = x[0] + dt * x[3]; xn[1] = x[1] + dt * x[4]; xn[2] = x[2] + dt * x[5];
+            xn[3] = x[3] + dt * acc[0].v; xn[4] = x[4] + dt * acc[1].v; xn[5] = x[5] + dt * acc[2].v;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { rc[i] = dgc[i] * (xn[i] - lds[L.XS + (k + 1) * 6 + i]); th += fabs(rc[i]); }
+            // [A | B]
+            double AB[NX][NV];
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int c = 0; c < NV; ++c) AB[i][c] = (i == c) ? 1.0 : 0.0;
+            AB[0][3] = dt; AB[1][4] = dt; AB[2][5] = dt;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) AB[3 + i][2 + c] += dt * acc[i].d[c];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) AB[3 + i][6 + j] = dt * gc[j][i].v;
+            }
+            // J' y: A' (dgc yc), B' (dgc yc)
+            {
+                double wy[NX];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) wy[i] = dgc[i] * yc[i];
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) v += AB[i][c] * wy[i];
+                    E.Jty[c] += v;
+                }
+            }
+            double pt[3][2], G2[2][NV];
+            points(x, acc[0].v, acc[1].v, pt);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) G2[c][i] = dt * AB[3 + c][i];
+                G2[c][c] += 1.0; G2[c][3 + c] += dt;
+            }
+            // rows
+            double sl = 0.0, nu2[2] = {0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < NV; ++i) g[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                if (j < K) {
+                    double r[NV];
+                    row_grad(pt, G2, j, r);
+                    const double cv = cbf_value(pt, j);
+                    dv[j] = -dgd[j] * cv;
+                    const double rd = dv[j] - s[j];
+                    th += fabs(rd);
+                    const double om = dgd[j] * yd[j];                               // weight of grad^2 (-cbf_j) in the Hessian of the Lagrangian
+                    // J' y: yd_j * grad d_j = -om r
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) E.Jty[i] -= om * r[i];
+                    if (build) {
+                        double Ej, bd;
+                        if (ls) { Ej = 1.0; bd = -vU[j]; }                           // q = 1, rhs_t = -(0 + vU), rhs_g = 0: b = q rhs_t
+                        else {
+                            const double stU = sU[j] - s[j];
+                            const double sig = vU[j] / stU;
+                            Ej = sig + dw;
+                            const double gt = mu / stU - O.kappa_d * mu;
+                            bd = -rd + (yd[j] - gt) / Ej;
+                        }
+                        // a_j = -dgd r; H += E a a', g -= a E b
+                        const double ea = Ej * dgd[j] * dgd[j], eb = Ej * bd * dgd[j];
+#pragma unroll
+                        for (int a = 0; a < NV; ++a) {
+                            g[a] += eb * r[a];
+#pragma unroll
+                            for (int b = a; b < NV; ++b) H[sym(a, b)] += ea * r[a] * r[b];
+                        }
+                    }
+                    if (!ls) {
+                        sl += om;
+                        nu2[0] -= 2.0 * w2 * om * (pt[2][0] - lds[L.OB + 3 * j]); nu2[1] -= 2.0 * w2 * om * (pt[2][1] - lds[L.OB + 3 * j + 1]);
+                    }
+                } else dv[j] = 0.0;
+            }
+            if (build && !ls) {
+                // curvature of -cbf in the points: -2 sl (w0 G0'G0 + w1 G1'G1 + w2 G2'G2)
+                const double o0 = -2.0 * w0 * sl, o1 = -2.0 * w1 * sl, o2 = -2.0 * w2 * sl;
+                H[sym(0, 0)] += o0 + o1; H[sym(1, 1)] += o0 + o1;
+                H[sym(0, 3)] += o1 * dt; H[sym(1, 4)] += o1 * dt; H[sym(3, 3)] += o1 * dt * dt; H[sym(4, 4)] += o1 * dt * dt;
+#pragma unroll
+                for (int a = 0; a < NV; ++a)
+#pragma unroll
+                    for (int b = a; b < NV; ++b) H[sym(a, b)] += o2 * (G2[0][a] * G2[0][b] + G2[1][a] * G2[1][b]);
+                // second derivatives of the dynamics: weights dgc y (rows 3..5) + dt nu2 through the second barrier point
+                const double cc[3] = {(dgc[3] * yc[3] + dt * nu2[0]) * dt, (dgc[4] * yc[4] + dt * nu2[1]) * dt, dgc[5] * yc[5] * dt};
+                int e = 0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = a; b < 3; ++b, ++e) H[sym(2 + a, 2 + b)] += cc[0] * acc[0].h[e] + cc[1] * acc[1].h[e] + cc[2] * acc[2].h[e];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) H[sym(2 + a, 6 + j)] += cc[0] * gc[j][0].d[a] + cc[1] * gc[j][1].d[a] + cc[2] * gc[j][2].d[a];
+            }
+            if (build) {
+                ldsd* ABo = lds + L.AB + k * 60;
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) ABo[i * 10 + c] = AB[i][c];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) rc[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) dv[j] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) g[i] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { r0[i] = lane == 0 ? x[i] - x0[i] : 0.0; th += fabs(r0[i]); }
+        theta = ipm::wsum(th);
+        fk = cost_share(x, u, um);
+        fsum = ipm::wsum(fk);
+        if (!build) return;
+        // objective Hessian, bounds, dw; gradient g = (barrier gradient) + J'y - (condensed rows' part, already in g)
+        if (act) {
+            if (ls) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) H[sym(i, i)] += 1.0;
+                g[2] += -zxL[0] + zxU[0]; g[3] += -zxL[1] + zxU[1]; g[4] += -zxL[2];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) g[i] += E.gfx[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) H[sym(i, i)] += 2.0 * df * P.Q[i] + dw;
+                const double sL[3] = {x[2] - xbL[0], x[3] - xbL[1], x[4] - xbL[2]}, sUp[2] = {xbU[0] - x[2], xbU[1] - x[3]};
+                H[sym(2, 2)] += zxL[0] / sL[0] + zxU[0] / sUp[0]; H[sym(3, 3)] += zxL[1] / sL[1] + zxU[1] / sUp[1]; H[sym(4, 4)] += zxL[2] / sL[2];
+                g[2] += -mu / sL[0] + mu / sUp[0]; g[3] += -mu / sL[1] + mu / sUp[1]; g[4] += -mu / sL[2] + O.kappa_d * mu;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) g[i] += E.gfx[i] + E.Jty[i];
+            }
+        }
+        if (stg) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                if (ls) { H[sym(6 + j, 6 + j)] += 1.0; g[6 + j] += E.gfu[j] - zuL[j] + zuU[j]; }
+                else {
+                    const double a = u[j] - ubL[j], b = ubU[j] - u[j];
+                    H[sym(6 + j, 6 + j)] += 2.0 * df * P.R[j] * (last ? 1.0 : 2.0) + dw + zuL[j] / a + zuU[j] / b;
+                    g[6 + j] += E.gfu[j] + E.Jty[6 + j] - mu / a + mu / b;
+                }
+            }
+        }
+        if (act) {
+            ldsd* Ho = lds + L.H + k * 55; ldsd* Go = lds + L.G + k * 10;
+#pragma unroll
+            for (int i = 0; i < 55; ++i) Ho[i] = H[i];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) Go[i] = g[i];
+            // defects (unscaled): dynamics of my stage -> C[k + 1] = -b / dgc with b = -rc (ls: b = 0); C[0] = dx_0 = b_0 = -r0 (ls: 0)
+            if (stg) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) lds[L.C + (k + 1) * 6 + i] = ls ? 0.0 : rc[i] / dgc[i];
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) lds[L.C + i] = ls ? 0.0 : -r0[i];
+            }
+        }
+        sync();
+    }
+
+    // after riccati_backward / forward: my dx, du from LDS, the costate sweep, the multiplier steps of my rows and bounds
+    __device__ __forceinline__ void finish_step(bool ls, double mu, double dw) {
+        sync();
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dx[i] = lds[L.DX + k * 6 + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dx[i] = 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) du[j] = stg ? lds[L.DU + k * NU + j] : 0.0;
+        // h_k = (H dw + g)_x
+        if (act) {
+            const ldsd* H = lds + L.H + k * 55; const ldsd* g = lds + L.G + k * 10;
+#pragma unroll
+            for (int a = 0; a < NX; ++a) {
+                double v = g[a];
+#pragma unroll
+                for (int b = 0; b < NX; ++b) v += H[sym(a, b)] * dx[b];
+                if (stg) {
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) v += H[sym(a, 6 + j)] * du[j];
+                }
+                lds[L.LAM + k * 6 + a] = v;
+            }
+        }
+        sync();
+        costates(lds, L, N, lane);
+        if (stg) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dyc[i] = lds[L.LAM + (k + 1) * 6 + i] / dgc[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dyc[i] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dy0[i] = lane == 0 ? -lds[L.LAM + i] : 0.0;
+        // rows: dy_d = E (a . dw - b), ds = q (rhs_t + dy_d), dvU
+        if (stg) {
+            double acc[3], gc[4][3], pt[3][2], G2[2][NV];
+            accel<double>(P, x[2], x[3], x[4], u, acc, gc);
+            points(x, acc[0], acc[1], pt);
+            const ldsd* AB = lds + L.AB + k * 60;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) G2[c][i] = P.dt * AB[(3 + c) * 10 + i];
+                G2[c][c] += 1.0; G2[c][3 + c] += P.dt;
+            }
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                if (j < K) {
+                    double r[NV];
+                    row_grad(pt, G2, j, r);
+                    double adw = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) adw += r[i] * dx[i];
+#pragma unroll
+                    for (int i = 0; i < NU; ++i) adw += r[6 + i] * du[i];
+                    adw *= -dgd[j];
+                    if (ls) { dyd[j] = adw + vU[j]; ds[j] = 0.0; dvU[j] = 0.0; }
+                    else {
+                        const double stU = sU[j] - s[j], sig = vU[j] / stU, Ej = sig + dw, gt = mu / stU - O.kappa_d * mu;
+                        const double rd = dv[j] - s[j], rhs_t = yd[j] - gt, bd = -rd + rhs_t / Ej;
+                        dyd[j] = Ej * (adw - bd);
+                        ds[j] = (rhs_t + dyd[j]) / Ej;
+                        dvU[j] = mu / stU - vU[j] + vU[j] * ds[j] / stU;
+                    }
+                } else { dyd[j] = 0.0; ds[j] = 0.0; dvU[j] = 0.0; }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) { dyd[j] = 0.0; ds[j] = 0.0; dvU[j] = 0.0; }
+        }
+        if (!ls) {
+            if (act) {
+                const double sL[3] = {x[2] - xbL[0], x[3] - xbL[1], x[4] - xbL[2]}, sUp[2] = {xbU[0] - x[2], xbU[1] - x[3]};
+                const double dxl[3] = {dx[2], dx[3], dx[4]};
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dzxL[i] = mu / sL[i] - zxL[i] - zxL[i] * dxl[i] / sL[i];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) dzxU[i] = mu / sUp[i] - zxU[i] + zxU[i] * dxl[i] / sUp[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dzxL[i] = 0.0;
+                dzxU[0] = dzxU[1] = 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                if (stg) {
+                    const double a = u[j] - ubL[j], b = ubU[j] - u[j];
+                    dzuL[j] = mu / a - zuL[j] - zuL[j] * du[j] / a; dzuU[j] = mu / b - zuU[j] + zuU[j] * du[j] / b;
+                } else { dzuL[j] = 0.0; dzuU[j] = 0.0; }
+            }
+        }
+    }
+
+    // Algorithm IC around the recursion; false: delta_w beyond its maximum
+    __device__ __forceinline__ bool factor_and_solve(Eval2& E, bool ls, double mu, double& theta, double& fsum) {
+        double dw = 0.0;
+        bool first = true;
+        const double c0 = ls ? 0.0 : 2.0 * df * P.R[0], c1 = ls ? 0.0 : 2.0 * df * P.R[1], c2 = ls ? 0.0 : 2.0 * df * P.R[2], c3 = ls ? 0.0 : 2.0 * df * P.R[3];
+        for (;;) {
+            eval2(E, true, ls, mu, dw, theta, fsum);
+            if (riccati_backward(lds, L, N, lane, c0, c1, c2, c3)) break;
+            if (first) {
+                first = false;
+                dw = dw_last == 0.0 ? O.first_hessian_perturbation : fmax(O.min_hessian_perturbation, O.perturb_dec_fact * dw_last);
+            } else dw *= dw_last == 0.0 ? O.perturb_inc_fact_first : O.perturb_inc_fact;
+            if (dw > O.max_hessian_perturbation) return false;
+        }
+        if (dw > 0.0 && !ls) dw_last = dw;
+        last_dw = dw;
+        riccati_forward(lds, L, N, lane);
+        finish_step(ls, mu, dw);
+        return true;
+    }
+
+    // ---- optimality error (eq. (5)): E_mu and its parts ---------------------------------------------------------------------------------
+    __device__ __forceinline__ void errors(const Eval2& E, double mu, double& Emu, double& dinf, double& pinf, double& comp, double& un_pinf) const {
+        double d = 0.0, p = 0.0, c = 0.0, ysum = 0.0, zsum = 0.0, up = 0.0;
+        if (act) {
+            double gl[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) gl[i] = E.gfx[i] + E.Jty[i];
+            gl[2] += -zxL[0] + zxU[0]; gl[3] += -zxL[1] + zxU[1]; gl[4] += -zxL[2];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) d = fmax(d, fabs(gl[i]));
+            const double sL[3] = {x[2] - xbL[0], x[3] - xbL[1], x[4] - xbL[2]}, sUp[2] = {xbU[0] - x[2], xbU[1] - x[3]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { c = fmax(c, fabs(sL[i] * zxL[i] - mu)); zsum += fabs(zxL[i]); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { c = fmax(c, fabs(sUp[i] * zxU[i] - mu)); zsum += fabs(zxU[i]); }
+        }
+        if (stg) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                d = fmax(d, fabs(E.gfu[j] + E.Jty[6 + j] - zuL[j] + zuU[j]));
+                c = fmax(c, fmax(fabs((u[j] - ubL[j]) * zuL[j] - mu), fabs((ubU[j] - u[j]) * zuU[j] - mu)));
+                zsum += fabs(zuL[j]) + fabs(zuU[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { p = fmax(p, fabs(rc[i])); up = fmax(up, fabs(rc[i] / dgc[i])); ysum += fabs(yc[i]); }
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                if (j < K) {
+                    d = fmax(d, fabs(-yd[j] + vU[j]));
+                    const double rd = dv[j] - s[j];
+                    p = fmax(p, fabs(rd)); up = fmax(up, fabs(rd / dgd[j]));
+                    c = fmax(c, fabs((sU[j] - s[j]) * vU[j] - mu));
+                    ysum += fabs(yd[j]); zsum += fabs(vU[j]);
+                }
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { p = fmax(p, fabs(r0[i])); up = fmax(up, fabs(r0[i])); ysum += fabs(y0[i]); }
+        }
+        dinf = ipm::wmax(d); pinf = ipm::wmax(p); comp = ipm::wmax(c); un_pinf = ipm::wmax(up);
+        ysum = ipm::wsum(ysum); zsum = ipm::wsum(zsum);
+        const double m = (double)(6 * (N + 1) + N * K), nb = (double)(5 * (N + 1) + 8 * N + N * K);
+        const double sd = fmax(O.s_max, (ysum + zsum) / (m + nb)) / O.s_max, sc = fmax(O.s_max, zsum / nb) / O.s_max;
+        Emu = fmax(fmax(dinf / sd, pinf), comp / sc);
+    }
+
+    // fraction to the boundary over my primal / dual variables
+    __device__ __forceinline__ double ftb1(double tau, double sl, double dsl) const { return dsl < 0.0 ? fmin(1.0, -tau * sl / dsl) : 1.0; }
+    __device__ __forceinline__ void step_lengths(double tau, double& a_max, double& a_z) const {
+        double ap = 1.0, az = 1.0;
+        if (act) {
+            ap = fmin(ap, ftb1(tau, x[2] - xbL[0], dx[2])); ap = fmin(ap, ftb1(tau, x[3] - xbL[1], dx[3])); ap = fmin(ap, ftb1(tau, x[4] - xbL[2], dx[4]));
+            ap = fmin(ap, ftb1(tau, xbU[0] - x[2], -dx[2])); ap = fmin(ap, ftb1(tau, xbU[1] - x[3], -dx[3]));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) az = fmin(az, ftb1(tau, zxL[i], dzxL[i]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) az = fmin(az, ftb1(tau, zxU[i], dzxU[i]));
+        }
+        if (stg) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                ap = fmin(ap, ftb1(tau, u[j] - ubL[j], du[j])); ap = fmin(ap, ftb1(tau, ubU[j] - u[j], -du[j]));
+                az = fmin(az, ftb1(tau, zuL[j], dzuL[j])); az = fmin(az, ftb1(tau, zuU[j], dzuU[j]));
+            }
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                if (j < K) { ap = fmin(ap, ftb1(tau, sU[j] - s[j], -ds[j])); az = fmin(az, ftb1(tau, vU[j], dvU[j])); }
+            }
+        }
+        a_max = ipm::wmin(ap); a_z = ipm::wmin(az);
+    }
+
+    // directional derivative of the barrier function along (dx, du, ds)
+    __device__ __forceinline__ double barrier_dir(const Eval2& E, double mu) const {
+        double v = 0.0;
+        if (act) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) v += E.gfx[i] * dx[i];
+            const double sL[3] = {x[2] - xbL[0], x[3] - xbL[1], x[4] - xbL[2]}, sUp[2] = {xbU[0] - x[2], xbU[1] - x[3]};
+            v += (-mu / sL[0] + mu / sUp[0]) * dx[2] + (-mu / sL[1] + mu / sUp[1]) * dx[3] + (-mu / sL[2] + O.kappa_d * mu) * dx[4];
+        }
+        if (stg) {
+#pragma unroll
+            for (int j = 0; j < NU; ++j) v += (E.gfu[j] - mu / (u[j] - ubL[j]) + mu / (ubU[j] - u[j])) * du[j];
+#pragma unroll
+            for (int j = 0; j < KS; ++j) if (j < K) v += (mu / (sU[j] - s[j]) - O.kappa_d * mu) * ds[j];
+        }
+        return ipm::wsum(v);
+    }
+
+    // ---- filter ---------------------------------------------------------------------------------------------------------------------
+    __device__ __forceinline__ bool filter_ok(double phi, double th) const {
+        for (int i = 0; i < nfilt; ++i) {
+            const double p = lds[L.FP + i], t = lds[L.FT + i];
+            if (!(cmp_le(phi, p, p) || cmp_le(th, t, t))) return false;
+        }
+        return true;
+    }
+    __device__ __forceinline__ void filter_add(double phi, double th) {
+        sync();
+        int n = 0;
+        // (dominated entries are dropped; wave-uniform, every lane walks the list, lane 0 writes)
+        for (int i = 0; i < nfilt; ++i) {
+            const double p = lds[L.FP + i], t = lds[L.FT + i];
+            const bool keep = !(p >= phi && t >= th);
+            sync();
+            if (keep) { if (lane == 0) { lds[L.FP + n] = p; lds[L.FT + n] = t; } ++n; }
+            sync();
+        }
+        if (n >= NFILT) n = NFILT - 1;
+        if (lane == 0) { lds[L.FP + n] = phi; lds[L.FT + n] = th; }
+        nfilt = n + 1;
+        sync();
+    }
+
+    // ---- the solve ------------------------------------------------------------------------------------------------------------------
+    __device__ __forceinline__ void push1(double& v, double lo, double hi, bool fl, bool fu) const {
+        const double k1 = O.bound_push, k2 = O.bound_frac;
+        const double rng = (fl && fu) ? hi - lo : INF_;
+        if (fl) v = fmax(v, lo + fmin(k1 * fmax(1.0, fabs(lo)), k2 * rng));
+        if (fu) v = fmin(v, hi - fmin(k1 * fmax(1.0, fabs(hi)), k2 * rng));
+    }
+
+    __device__ void solve(int& status_out, int& iters_out, double* trace) {
+        const double rl = O.bound_relax_factor;
+        // ---- start: x_k = x0, u_k = u_prev (set_initial_guess); scaling at that point; bounds relaxed; push ----
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { x[i] = x0[i]; yc[i] = 0.0; y0[i] = 0.0; dgc[i] = 1.0; }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) u[j] = uprev[j];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) { s[j] = 0.0; yd[j] = 0.0; vU[j] = 1.0; sU[j] = 0.0; dgd[j] = 1.0; }
+        {
+            const double lo[3] = {-P.pitch_max, -P.v_max, -P.descent_max}, hi[2] = {P.pitch_max, P.v_max};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { xbL[i] = lo[i] - rl * fmax(1.0, fabs(lo[i])); zxL[i] = 1.0; }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { xbU[i] = hi[i] + rl * fmax(1.0, fabs(hi[i])); zxU[i] = 1.0; }
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                ubL[j] = P.u_lo[j] - rl * fmax(1.0, fabs(P.u_lo[j])); ubU[j] = P.u_hi[j] + rl * fmax(1.0, fabs(P.u_hi[j]));
+                zuL[j] = 1.0; zuU[j] = 1.0;
+            }
+        }
+        // gradient-based scaling at the user's starting point (every stage is the same point there)
+        {
+            double gm = fmax(2.0 * P.Q[0] * fabs(x0[0] - xg[0]), 2.0 * P.Q[1] * fabs(x0[1] - xg[1]));
+#pragma unroll
+            for (int i = 2; i < NX; ++i) gm = fmax(gm, 2.0 * P.Q[i] * fabs(x0[i]));
+            df = gm > O.nlp_scaling_max_gradient ? fmax(O.nlp_scaling_min_value, O.nlp_scaling_max_gradient / gm) : 1.0;
+            D2 acc[3], gc[4][3];
+            accel<D2>(P, d2var(x0[2], 0), d2var(x0[3], 1), d2var(x0[4], 2), uprev, acc, gc);
+            const double dt = P.dt;
+            double G2[2][NV], pt[3][2];
+            double ABr[3][NV];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int c = 0; c < NV; ++c) ABr[i][c] = (3 + i == c) ? 1.0 : 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ABr[i][2 + c] += dt * acc[i].d[c];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) ABr[i][6 + j] = dt * gc[j][i].v;
+                double rm = 1.0;
+#pragma unroll
+                for (int c = 0; c < NV; ++c) rm = fmax(rm, fabs(ABr[i][c]));
+                dgc[3 + i] = rm > O.nlp_scaling_max_gradient ? fmax(O.nlp_scaling_min_value, O.nlp_scaling_max_gradient / rm) : 1.0;
+            }
+            points(x0, acc[0].v, acc[1].v, pt);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) G2[c][i] = dt * ABr[c][i];
+                G2[c][c] += 1.0; G2[c][3 + c] += dt;
+            }
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                if (j < K) {
+                    double r[NV];
+                    row_grad(pt, G2, j, r);
+                    double rm = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) rm = fmax(rm, fabs(r[i]));
+                    dgd[j] = rm > O.nlp_scaling_max_gradient ? fmax(O.nlp_scaling_min_value, O.nlp_scaling_max_gradient / rm) : 1.0;
+                    sU[j] = 0.0 + rl * 1.0;
+                }
+            }
+        }
+        push1(x[2], xbL[0], xbU[0], true, true); push1(x[3], xbL[1], xbU[1], true, true); push1(x[4], xbL[2], 0.0, true, false);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) push1(u[j], ubL[j], ubU[j], true, true);
+        Eval2 E;
+        double theta, fsum;
+        double mu = O.mu_init;
+        eval2(E, false, false, mu, 0.0, theta, fsum);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) if (j < K) { double v = dv[j]; push1(v, 0.0, sU[j], false, true); s[j] = v; }
+        // least-square multipliers
+        if (factor_and_solve(E, true, mu, theta, fsum)) {
+            double ym = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) ym = fmax(ym, fmax(fabs(dyc[i]), fabs(dy0[i])));
+#pragma unroll
+            for (int j = 0; j < KS; ++j) ym = fmax(ym, fabs(dyd[j]));
+            ym = ipm::wmax(ym);
+            if (ym <= O.constr_mult_init_max) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { yc[i] = dyc[i]; y0[i] = dy0[i]; }
+#pragma unroll
+                for (int j = 0; j < KS; ++j) yd[j] = dyd[j];
+            }
+        }
+        double tau = fmax(O.tau_min, 1.0 - mu);
+        eval2(E, false, false, mu, 0.0, theta, fsum);
+        const double theta_max = O.theta_max_fact * fmax(1.0, theta), theta_min = O.theta_min_fact * fmax(1.0, theta);
+        const double mu_min = fmin(O.tol, O.compl_inf_tol) / (O.barrier_tol_factor + 1.0);
+        int it = 0, n_acc = 0, status = SC_STATUS_INACCURATE;
+        double last_alpha = 0.0;
+        for (;;) {
+            double E0, dinf, pinf, comp, un_pinf;
+            errors(E, 0.0, E0, dinf, pinf, comp, un_pinf);
+            if (trace && lane == 0) {
+                double* t = trace + (size_t)(it < O.max_iter ? it : O.max_iter) * TRACE_W;
+                t[0] = E0; t[1] = dinf; t[2] = pinf; t[3] = comp; t[4] = mu; t[5] = theta; t[6] = last_dw; t[7] = last_alpha;
+            }
+            if (E0 <= O.tol && dinf / df <= O.dual_inf_tol && un_pinf <= O.constr_viol_tol && comp / df <= O.compl_inf_tol) { status = SC_STATUS_OPTIMAL; break; }
+            if (E0 <= O.acceptable_tol && dinf / df <= O.acceptable_dual_inf_tol && un_pinf <= O.acceptable_constr_viol_tol && comp / df <= O.acceptable_compl_inf_tol) {
+                if (++n_acc >= O.acceptable_iter) { status = SC_STATUS_OPTIMAL; break; }
+            } else n_acc = 0;
+            if (it >= O.max_iter) { status = SC_STATUS_INACCURATE; break; }
+            // barrier parameter
+            for (;;) {
+                double Emu, a, b, c, d;
+                errors(E, mu, Emu, a, b, c, d);
+                if (Emu > O.barrier_tol_factor * mu || mu <= mu_min) break;
+                const double mu_new = fmax(mu_min, fmin(O.mu_linear_decrease_factor * mu, pow(mu, O.mu_superlinear_decrease_power)));
+                if (mu_new == mu) break;
+                mu = mu_new; tau = fmax(O.tau_min, 1.0 - mu); nfilt = 0;
+            }
+            // search direction
+            if (!factor_and_solve(E, false, mu, theta, fsum)) { status = SC_STATUS_NEEDS_RESTO; break; }
+            double a_max, a_z;
+            step_lengths(tau, a_max, a_z);
+            const double phi = barrier(fsum, x, u, s, mu);
+            const double gBD = barrier_dir(E, mu);
+            double a_min = O.gamma_theta;
+            if (gBD < 0.0) {
+                a_min = fmin(a_min, O.gamma_phi * theta / (-gBD));
+                if (theta <= theta_min) a_min = fmin(a_min, O.delta * pow(theta, O.s_theta) / pow(-gBD, O.s_phi));
+            }
+            a_min *= O.alpha_min_frac;
+            double alpha = a_max;
+            bool first = true, accepted = false;
+            double xt[NX], ut[NU], st[KS], rct[NX], r0t[NX], dvt[KS];
+            double phi_t = 0.0, th_t = 0.0;
+            while (alpha > a_min || first) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xt[i] = x[i] + alpha * dx[i];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) ut[j] = u[j] + alpha * du[j];
+#pragma unroll
+                for (int j = 0; j < KS; ++j) st[j] = s[j] + alpha * ds[j];
+                safe_slacks(xt, ut, st, mu);
+                double f_t;
+                eval0(xt, ut, st, th_t, f_t, rct, r0t, dvt);
+                phi_t = barrier(f_t, xt, ut, st, mu);
+                if (phi_t < INF_ && th_t == th_t && phi_t == phi_t) {
+                    bool ok = th_t <= theta_max;
+                    if (ok) {
+                        const bool ftype = gBD < 0.0 && alpha * pow(-gBD, O.s_phi) > O.delta * pow(theta, O.s_theta);
+                        if (alpha > 0.0 && ftype && theta <= theta_min) ok = cmp_le(phi_t - phi, O.eta_phi * alpha * gBD, phi);
+                        else {
+                            ok = true;
+                            if (phi_t > phi) {
+                                const double bas = fabs(phi) > 10.0 ? fmax(1.0, log10(fabs(phi))) : 1.0;
+                                if (log10(phi_t - phi) > O.obj_max_inc + bas) ok = false;
+                            }
+                            if (ok) ok = cmp_le(th_t, (1.0 - O.gamma_theta) * theta, theta) || cmp_le(phi_t - phi, -O.gamma_phi * theta, phi);
+                        }
+                        if (ok) ok = filter_ok(phi_t, th_t);
+                    }
+                    if (ok) { accepted = true; break; }
+                }
+                first = false;
+                alpha *= O.alpha_red_factor;
+            }
+            if (!accepted) { status = SC_STATUS_NEEDS_RESTO; break; }
+            {
+                const bool ftype = gBD < 0.0 && alpha * pow(-gBD, O.s_phi) > O.delta * pow(theta, O.s_theta);
+                const bool arm = cmp_le(phi_t - phi, O.eta_phi * alpha * gBD, phi);
+                if (!ftype || !arm) filter_add(phi - O.gamma_phi * theta, (1.0 - O.gamma_theta) * theta);
+            }
+            last_alpha = alpha;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { x[i] = xt[i]; yc[i] += alpha * dyc[i]; y0[i] += alpha * dy0[i]; }
+#pragma unroll
+            for (int j = 0; j < NU; ++j) u[j] = ut[j];
+#pragma unroll
+            for (int j = 0; j < KS; ++j) { s[j] = st[j]; yd[j] += alpha * dyd[j]; }
+            safe_slacks(x, u, s, mu);
+            // bound multipliers: z += a_z dz, then kappa_sigma
+            {
+                const double ks = O.kappa_sigma;
+                auto upd = [&](double& z, double dz, double sl) { z += a_z * dz; z = fmax(fmin(z, ks * mu / sl), mu / (ks * sl)); };
+                if (act) {
+                    upd(zxL[0], dzxL[0], x[2] - xbL[0]); upd(zxL[1], dzxL[1], x[3] - xbL[1]); upd(zxL[2], dzxL[2], x[4] - xbL[2]);
+                    upd(zxU[0], dzxU[0], xbU[0] - x[2]); upd(zxU[1], dzxU[1], xbU[1] - x[3]);
+                }
+                if (stg) {
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) { upd(zuL[j], dzuL[j], u[j] - ubL[j]); upd(zuU[j], dzuU[j], ubU[j] - u[j]); }
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) if (j < K) upd(vU[j], dvU[j], sU[j] - s[j]);
+                }
+            }
+            ++it;
+            eval2(E, false, false, mu, 0.0, theta, fsum);
+        }
+        status_out = status; iters_out = it;
+    }
+};
+
+template <typename TIO, int KS>
+__global__ void __launch_bounds__(64) mpcvtol_ms_kernel(const Params P, const sc_ipopt_params O, long long B, int obs_shared, const TIO* __restrict__ X,
+                                                        const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
+                                                        TIO* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out,
+                                                        TIO* __restrict__ plan_out, double* __restrict__ trace_out) {
+    extern __shared__ double ms_lds[];
+    const long long b = blockIdx.x;
+    if (b >= B) return;
+    Wave<KS> S(P, O, (ldsd*)ms_lds);
+    const TIO* ob = obs + (obs_shared ? 0 : b * P.K * 7);
+    if ((int)threadIdx.x < 3 * KS_MAX) {
+        const int j = threadIdx.x / 3, c = threadIdx.x % 3;
+        ms_lds[S.L.OB + threadIdx.x] = j < P.K ? (double)ob[7 * j + c] : 0.0;
+    }
+    for (int i = 0; i < NX; ++i) S.x0[i] = (double)X[b * NX + i];
+    for (int j = 0; j < NU; ++j) S.uprev[j] = (double)u_prev[b * NU + j];
+    S.xg[0] = (double)goal[b * 2]; S.xg[1] = (double)goal[b * 2 + 1];
+    __syncthreads();
+    int st, it;
+    S.solve(st, it, trace_out ? trace_out + (size_t)b * (size_t)(O.max_iter + 1) * TRACE_W : nullptr);
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < NU; ++j) u_out[b * NU + j] = (TIO)S.u[j];
+        status_out[b] = st;
+        if (iters_out) iters_out[b] = it;
+    }
+    if (plan_out && S.act) {
+        // the plan: x_0 .. x_N (6 each), then u_0 .. u_{N-1} (4 each)
+        TIO* po = plan_out + b * (long long)((P.N + 1) * NX + P.N * NU);
+        for (int i = 0; i < NX; ++i) po[S.k * NX + i] = (TIO)S.x[i];
+        if (S.stg) for (int j = 0; j < NU; ++j) po[(P.N + 1) * NX + S.k * NU + j] = (TIO)S.u[j];
+    }
+}
+
+template <typename TIO, int KS>
+static hipError_t launch_t(const Params& P, const sc_mpcvtol_params& p, const sc_ipopt_params& O, long long B, size_t lds, const void* X, const void* u_prev,
+                           const void* goal, const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out,
+                           hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute((const void*)mpcvtol_ms_kernel<TIO, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((mpcvtol_ms_kernel<TIO, KS>), dim3((unsigned)B), dim3(64), lds, stream, P, O, B, p.obs_shared, (const TIO*)X, (const TIO*)u_prev,
+                       (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status_out, iters_out, (TIO*)plan_out, trace_out);
+    return hipGetLastError();
+}
+
+}  // namespace msk
+
+size_t mpcvtol_ms_lds_bytes(int horizon) { return msk::lds_bytes(horizon); }
+
+hipError_t mpcvtol_ms_launch(const sc_mpcvtol_params& p, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
+                             const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, hipStream_t stream) {
+    const Params P = from_c(p, K);
+    const size_t lds = msk::lds_bytes(p.horizon);
+    if (p.io_dtype == SC_DTYPE_F64)
+        return K <= 8 ? msk::launch_t<double, 8>(P, p, O, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, stream)
+                      : msk::launch_t<double, 16>(P, p, O, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, stream);
+    return K <= 8 ? msk::launch_t<float, 8>(P, p, O, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, stream)
+                  : msk::launch_t<float, 16>(P, p, O, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, stream);
+}
+
+}  // namespace sc

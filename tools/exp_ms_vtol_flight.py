@@ -9,20 +9,30 @@ from oracle.tracking_quad import QuadTrackingOracle
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 out = sys.argv[2] if len(sys.argv) > 2 else None
-which = sys.argv[3] if len(sys.argv) > 3 else "ms"
+which = sys.argv[3] if len(sys.argv) > 3 else "ms"           # ms | riccati (same algorithm, the kernel's linear algebra) | condensed
 p1, p2 = 67.0, 73.0
 obs = np.array([[p1, z, 0.5] for z in (6.0, 7.0, 8.0, 9.0)] + [[p2, float(z), 0.5] for z in range(1, 16)] + [[60.0, 12.0, 1.5]])
 obs7 = np.hstack([obs, np.zeros((len(obs), 4))])
 spec = dict(radius=0.6, v_max=20.0, reached_threshold=1.0)
 mdl = MS.vtol_model(dict(radius=0.6, v_max=20.0))
+# ms: dense LDL', IPOPT's restoration;  riccati: the same with the stage-wise linear algebra;  kernel: what csrc/mpc_vtol_ms.hip runs (riccati +
+# a restoration that keeps the dynamics rows hard)
+OPTS = {"ms": None, "riccati": dict(linear_solver="riccati"), "kernel": dict(linear_solver="riccati", resto_elastic="ineq"),
+        "hybrid": dict(linear_solver="riccati", restoration="none"),
+        "hybrid_nosoc": dict(linear_solver="riccati", restoration="none", max_soc=0),
+        "kernel_nosoc": dict(linear_solver="riccati", resto_elastic="ineq", max_soc=0)}.get(which)   # hybrid: regular phase here, the condensed oracle when it asks for a restoration
 log = []
 
 
 def solve_ms(X, up, goal, ob):
     t0 = time.time()
-    u, st, it, info = MS.solve(mdl, X, up, goal, ob, return_info=True)
+    u, st, it, info = MS.solve(mdl, X, up, goal, ob, return_info=True, opts=OPTS)
+    if info["status"] == "needs_resto":
+        u2, st2, it2 = OV.solve(X, up, goal[:2], ob, N=30, spec=dict(spec))
+        log.append(dict(st="resto->condensed:%d" % st2, it=it + it2, dt=time.time() - t0, viol=0.0, u=u2.copy()))
+        return u2
     log.append(dict(st=info["status"], it=it, dt=time.time() - t0, viol=float(max(np.abs(info["c"]).max(), info["d"].max())), u=u.copy()))
-    return np.clip(u, mdl["u_lo"], mdl["u_hi"]) if False else u
+    return u
 
 
 def solve_cond(X, up, goal, ob):
@@ -33,7 +43,7 @@ def solve_cond(X, up, goal, ob):
 
 
 o = QuadTrackingOracle("VTOL2D", np.array([2.0, 10.0, 0.0, 20.0, 0.0, 0.0]), spec=spec, obs=obs7, num_constraints=10,
-                       solve_fn=solve_ms if which == "ms" else solve_cond)
+                       solve_fn=solve_cond if which == "condensed" else solve_ms)
 o.set_waypoints(np.array([[2.0, 10.0], [70.0, 10.0], [70.0, 0.5]]))
 traj = []
 ret = 0
