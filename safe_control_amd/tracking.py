@@ -404,7 +404,12 @@ class BatchedQuadTrackingController(BatchedTrackingController):
         if self.q3:
             from .position_control.mpc_cbf_linear import BatchedLinearMPCCBF as cls
         elif self.vt:
-            from .position_control.mpc_cbf_vtol import BatchedVtolMPCCBF as cls
+            # robot_spec['mpc_formulation']: 'multiple_shooting' (default: the NLP as do-mpc poses it, IPOPT's algorithm, csrc/mpc_vtol_ms.hip,
+            # with the condensed kernel behind it for the solves that need a restoration) or 'condensed' (csrc/mpc_vtol_wave.hip alone)
+            if self.robot_spec.get("mpc_formulation", "multiple_shooting") == "condensed":
+                from .position_control.mpc_cbf_vtol import BatchedVtolMPCCBF as cls
+            else:
+                from .position_control.mpc_cbf_vtol_ms import BatchedVtolMSMPCCBF as cls
         else:
             from .position_control.mpc_cbf_gn import BatchedGnMPCCBF as cls
         self.mpc = cls(self.robot_spec, dt=self.dt, io_dtype=io_dtype)

@@ -1,0 +1,130 @@
+"""GPU: csrc/mpc_vtol_ms.hip -- the VTOL2D MPC-CBF NLP as do-mpc poses it (multiple shooting), IPOPT's filter interior point, one NLP per
+wavefront -- against oracle/ms_ipopt.py in the kernel's profile (Riccati linear algebra, no second-order corrections, "needs a
+restoration" handed back): SAME STATUS and SAME ITERATION COUNT problem by problem (a handful may differ by one iteration at the
+tolerance), |u0 - u0_oracle| <= 1e-8, plans to 1e-6; the traces of the two solvers (E_0, infeasibilities, mu, theta, delta_w, alpha per
+iteration) agree to 1e-6 relative over the first 15 iterations.  Then the host class: restoration fallback to the condensed kernel,
+f32 storage, shared obstacles, 16 row slots."""
+import os
+import sys
+from multiprocessing import Pool
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import safe_control_amd as sca  # noqa: E402
+from safe_control_amd import _lib, workloads as W  # noqa: E402
+from oracle import ms_ipopt as MS  # noqa: E402
+
+DEV = "cuda:0"
+PROFILE = dict(linear_solver="riccati", max_soc=0, restoration="none")
+
+
+def t(a, dtype=torch.float64):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV)
+
+
+def _one(args):
+    x, up, g, ob, spec = args
+    os.environ["OMP_NUM_THREADS"] = "1"
+    tr = []
+    u, st, it, info = MS.solve(MS.vtol_model(spec), x, up, g, ob, return_info=True, opts=PROFILE, trace=tr)
+    T = np.array([[q["E0"], q["dinf"], q["pinf"], q["comp"], q["mu"], q["theta"], q["delta"], q["alpha"]] for q in tr])
+    return u, st, it, T, np.concatenate([info["X"].reshape(-1), info["U"].reshape(-1)])
+
+
+def oracle_many(X, up, goal, obs, spec=None):
+    with Pool(min(32, os.cpu_count() or 4)) as p:
+        return p.map(_one, [(X[i], up[i], goal[i], obs[i] if obs.ndim == 3 else obs, spec) for i in range(len(X))], chunksize=2)
+
+
+def compare(u, st, it, plan, res, n_off=3):
+    so, ito = np.array([r[1] for r in res]), np.array([r[2] for r in res])
+    assert np.array_equal(st, so), np.flatnonzero(st != so)[:10]
+    off = it != ito
+    assert off.sum() <= n_off and np.abs(it - ito).max() <= 1, (int(off.sum()), int(np.abs(it - ito).max()))
+    ok = so == 0
+    du = np.array([np.abs(u[i] - r[0]).max() for i, r in enumerate(res)])
+    assert du[ok].max() <= 1e-8, du[ok].max()
+    if plan is not None:
+        dp = np.array([np.abs(plan[i] - r[4]).max() for i, r in enumerate(res)])
+        assert dp[ok].max() <= 1e-6, dp[ok].max()
+    return so, ito
+
+
+def test_batch_against_the_oracle_iterate_for_iterate():
+    n = 256
+    X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("vtol", 4096, 8, seed=0))
+    ctl = sca.BatchedVtolMSMPCCBF(io_dtype="f64", fallback=False)
+    u, st, it, plan, trace = ctl.solve(t(X), t(up), t(goal), t(obs), want_plan=True, want_trace=True)
+    torch.cuda.synchronize()
+    u, st, it, plan, trace = (a.cpu().numpy() for a in (u, st, it, plan, trace))
+    res = oracle_many(X, up, goal, obs)
+    so, ito = compare(u, st, it, plan, res)
+    assert (so == 0).mean() >= 0.98
+    worst = 0.0
+    for i, r in enumerate(res):
+        m = min(len(r[3]), it[i] + 1, 15)
+        worst = max(worst, float((np.abs(trace[i, :m] - r[3][:m]) / np.maximum(1e-9, np.abs(r[3][:m]))).max()))
+    assert worst <= 1e-6, worst
+    print(f"ms kernel: optimal {np.mean(so == 0):.4f}, iterations mean {ito.mean():.1f} max {ito.max()}, equal on {np.mean(it == ito):.4f}")
+
+
+def test_sixteen_slots_f32_storage_shared_obstacles():
+    n = 48
+    X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("vtol", 64, 10, seed=5))
+    ctl = sca.BatchedVtolMSMPCCBF(io_dtype="f64", fallback=False)
+    u, st, it = (a.cpu().numpy() for a in ctl.solve(t(X), t(up), t(goal), t(obs)))
+    compare(u, st, it, None, oracle_many(X, up, goal, obs), n_off=2)
+    # f32 storage of f32-representable inputs = the f64 solve of the same numbers, rounded on the way out
+    X32, up32, goal32 = (a.astype(np.float32) for a in (X, up, goal))
+    ob32 = np.ascontiguousarray(obs[0]).astype(np.float32)
+    ob32[:, 0] += 40.0                                                      # one obstacle set for everybody, far enough ahead for all
+    c32 = sca.BatchedVtolMSMPCCBF(io_dtype="f32", fallback=False)
+    u32, s32, i32 = c32.solve(t(X32, torch.float32), t(up32, torch.float32), t(goal32, torch.float32), t(ob32, torch.float32))
+    u64, s64, i64 = ctl.solve(t(X32.astype(np.float64)), t(up32.astype(np.float64)), t(goal32.astype(np.float64)), t(ob32.astype(np.float64)))
+    assert torch.equal(s32, s64) and torch.equal(i32, i64)
+    assert torch.equal(u32, u64.float())
+
+
+def test_restoration_fallback_to_the_condensed_kernel():
+    """The first NLP of the reference's example scene has no feasible point (20 m/s towards a wall 65 m ahead, 15 degrees of pitch): IPOPT
+    would enter its restoration phase; the kernel hands the problem back (SC_STATUS_NEEDS_RESTO) and the host class solves it with the
+    condensed kernel, whose status and input it then carries."""
+    obs = np.hstack([np.array([[67.0, z, 0.5] for z in (6.0, 7.0, 8.0, 9.0)] + [[73.0, float(z), 0.5] for z in range(1, 7)]), np.zeros((10, 4))])
+    spec = {"model": "VTOL2D", "radius": 0.6, "v_max": 20.0}
+    X = np.array([[2.0, 10.0, 0.0, 20.0, 0.0, 0.0], [2.0, 10.0, 0.0, 8.0, 0.0, 0.0]])
+    goal = np.array([[70.0, 10.0], [40.0, 10.0]])
+    ob = np.stack([obs, np.tile(np.array([1000.0, 1000.0, 0, 0, 0, 0, 0]), (10, 1))])
+    up = np.zeros((2, 4))
+    raw = sca.BatchedVtolMSMPCCBF(spec, io_dtype="f64", fallback=False)
+    u, st, it = raw.solve(t(X), t(up), t(goal), t(ob))
+    assert st.cpu().tolist() == [_lib.STATUS_NEEDS_RESTO, 0]
+    res = oracle_many(X, up, goal, ob, spec=dict(radius=0.6, v_max=20.0))
+    assert [r[1] for r in res] == [4, 0] and [r[2] for r in res] == it.cpu().tolist()
+    full = sca.BatchedVtolMSMPCCBF(spec, io_dtype="f64")
+    u2, st2, it2 = full.solve(t(X), t(up), t(goal), t(ob))
+    assert full.n_fallback == 1 and int(st2[0]) in (1, 2) and int(st2[1]) == 0
+    cond = sca.BatchedVtolMPCCBF(spec, io_dtype="f64")
+    uc, sc_, ic = cond.solve(t(X[:1]), t(up[:1]), t(goal[:1]), t(ob[:1]))
+    assert torch.equal(u2[0], uc[0]) and int(st2[0]) == int(sc_[0]) and int(it2[0]) == int(it[0]) + int(ic[0])
+    assert torch.equal(u2[1], u[1])
+
+
+def test_argument_validation():
+    lib = _lib.load()
+    import ctypes as C
+    from safe_control_amd.position_control.mpc_cbf_vtol import make_params, CBF_VTOL
+    from safe_control_amd.robots.spec import complete_robot_spec
+    sp = complete_robot_spec({"model": "VTOL2D"})
+    p = make_params(sp, CBF_VTOL, 30, 0.05, sp["radius"], _lib.DTYPE_F64)
+    ip = _lib.default_ipopt()
+    assert lib.sc_mpcvtol_ms_solve_batch(C.byref(p), C.byref(ip), 0, 8, *([None] * 10)) == _lib.SC_OK
+    assert lib.sc_mpcvtol_ms_solve_batch(C.byref(p), C.byref(ip), 1, 17, *([None] * 10)) != _lib.SC_OK
+    assert lib.sc_mpcvtol_ms_solve_batch(C.byref(p), None, 1, 8, *([None] * 10)) != _lib.SC_OK
+    bad = _lib.default_ipopt(tau_min=1.5)
+    assert lib.sc_mpcvtol_ms_solve_batch(C.byref(p), C.byref(bad), 1, 8, *([None] * 10)) != _lib.SC_OK
+    p.horizon = 63
+    assert lib.sc_mpcvtol_ms_solve_batch(C.byref(p), C.byref(ip), 1, 8, *([None] * 10)) != _lib.SC_OK

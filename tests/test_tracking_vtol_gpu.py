@@ -1,4 +1,5 @@
-"""GPU: closed loop of VTOL2D (csrc/tracking_quad.hip around csrc/mpc_vtol_wave.hip) against the oracle loop
+"""GPU: closed loop of VTOL2D (csrc/tracking_quad.hip around csrc/mpc_vtol_ms.hip -- the default since round 5 -- or csrc/mpc_vtol_wave.hip with
+robot_spec['mpc_formulation'] = 'condensed') against the oracle loop
 (oracle/tracking_quad.py: QuadTrackingOracle("VTOL2D")).  The reference's own closed loop for this model cannot be executed here
 (do-mpc / IPOPT absent), so the loop is held to its restatement: goal updates, the 1.2 pi obstacle cone about the pitch angle with
 its nearest-of-all fallback, zero reference input, Euler step + pitch wrap, ground / pitch / disc tests, return codes."""
@@ -12,7 +13,7 @@ import safe_control_amd as sca  # noqa: E402
 from oracle.tracking_quad import QuadTrackingOracle  # noqa: E402
 
 DEV = "cuda:0"
-SPEC = {"model": "VTOL2D", "num_constraints": 4, "reached_threshold": 3.0}
+SPEC = {"model": "VTOL2D", "num_constraints": 4, "reached_threshold": 3.0, "mpc_formulation": "condensed"}     # these loops are held to the condensed oracle
 OBS = np.array([[80.0, 10.5, 1.5, 0, 0, 0, 0], [95.0, 7.0, 1.0, 0, 0, 0, 0], [-20.0, 10.0, 1.0, 0, 0, 0, 0], [40.0, 30.0, 1.0, 0, 0, 0, 0],
                 [-5.0, 12.0, 0.5, 0, 0, 0, 0], [130.0, 12.0, 1.0, 0, 0, 0, 0]])
 X0 = np.array([0.0, 10.0, 0.0, 12.0, 0.0, 0.0])
@@ -130,27 +131,18 @@ def test_twenty_steps_with_the_numpy_oracle_as_position_controller():
     assert worst <= 1e-5, worst
 
 
-def test_reference_example_scene_flown_with_the_reference_solver_budget():
-    """examples/test_vtol.py:21-64 (20 m/s at (2, 10), 24 discs, goal (70, 10) then (70, 0.5)) with IPOPT's iteration budget behind
-    every solve.  What happens, stated as a test so that it cannot drift unnoticed (round 4, Gauss-Newton restoration):
-    * the first NLPs have no feasible point (20 m/s towards a wall 65 m ahead with a 15 degree pitch limit): six of the first seven
-      solves end infeasible / inaccurate, the aircraft pitches up to its limit meanwhile;
-    * from then on the solves converge (more than 85 % of the flight `optimal`): the aircraft climbs over the discs (above 18 m),
-      slows down and descends towards the first waypoint, to within 1.5 m of it at less than 2.5 m/s;
-    * the first waypoint counts as reached at control step 188 and the goal becomes the landing point (70, 0.5): the solve of step 189
-      converges and trades pitch for descent at 0.8 m/s (full front thrust, 0.27 rear), the aircraft picks up pitch rate, the NLPs
-      after it stop converging and the flight ends with -2 about 200 control steps in.
-    Rounds 3 - 4 (exact-Hessian restoration): 80 % of the solves `optimal_inaccurate`, on the ground before the first wall."""
-    p1, p2 = 67.0, 73.0
-    obs = np.array([[p1, z, 0.5] for z in (6.0, 7.0, 8.0, 9.0)] + [[p2, float(z), 0.5] for z in range(1, 16)] + [[60.0, 12.0, 1.5]])
-    obs7 = np.hstack([obs, np.zeros((len(obs), 4))])
-    spec = {"model": "VTOL2D", "radius": 0.6, "v_max": 20.0, "reached_threshold": 1.0, "num_constraints": 10}
-    ctl = sca.BatchedTrackingController(np.array([[2.0, 10.0, 0.0, 20.0, 0.0, 0.0]]), spec, obs=obs7, device=DEV)
-    assert ctl.mpc.max_iter == 3000
-    ctl.set_waypoints(np.array([[2.0, 10.0], [70.0, 10.0], [70.0, 0.5]]))
-    st, zmax, dmin, vmin = [], 0.0, np.inf, np.inf
-    ret = 0
-    for k in range(320):
+REF_OBS = np.array([[67.0, z, 0.5] for z in (6.0, 7.0, 8.0, 9.0)] + [[73.0, float(z), 0.5] for z in range(1, 16)] + [[60.0, 12.0, 1.5]])
+REF_OBS7 = np.hstack([REF_OBS, np.zeros((len(REF_OBS), 4))])
+REF_SPEC = {"model": "VTOL2D", "radius": 0.6, "v_max": 20.0, "reached_threshold": 1.0, "num_constraints": 10}
+REF_X0 = np.array([[2.0, 10.0, 0.0, 20.0, 0.0, 0.0]])
+REF_WPS = np.array([[2.0, 10.0], [70.0, 10.0], [70.0, 0.5]])
+
+
+def fly_reference_scene(spec, steps=400):
+    ctl = sca.BatchedTrackingController(REF_X0, spec, obs=REF_OBS7, device=DEV)
+    ctl.set_waypoints(REF_WPS)
+    st, zmax, dmin, vmin, ret = [], 0.0, np.inf, np.inf, 0
+    for k in range(steps):
         ret = int(ctl.control_step(1)[0].item())
         st.append(int(ctl.mpc_status[0].item()))
         X = ctl.X[0].cpu().numpy()
@@ -160,8 +152,35 @@ def test_reference_example_scene_flown_with_the_reference_solver_budget():
             dmin, vmin = d, float(np.hypot(X[3], X[4]))
         if ret != 0:
             break
-    st = np.array(st)
+    return ctl, ret, np.array(st), zmax, dmin, vmin
+
+
+def test_reference_example_scene_lands():
+    """examples/test_vtol.py:12-92 (20 m/s at (2, 10), 24 discs, waypoints (70, 10) then (70, 0.5); README.md:43-45 lists it as a runnable
+    demo; its success test is `unexpected_beh in (-1, 0)`, :88-91) through the drop-in loop with the default position controller for this
+    model: the NLP as do-mpc poses it (multiple shooting, x_k = x0 start) under IPOPT's algorithm on csrc/mpc_vtol_ms.hip, the condensed
+    kernel behind it for the solves that need a restoration.  The flight LANDS: every waypoint reached, return code -1 (tracking.py:664-666)
+    -- measured round 5: 276 control steps, 273 solves optimal, over the discs at 20 m.  (The condensed kernel alone loses this flight at
+    the start of the landing leg: one diverging rollout, see the next test and DESIGN.md kernel 12.)"""
+    ctl, ret, st, zmax, dmin, vmin = fly_reference_scene(dict(REF_SPEC))
+    assert type(ctl.mpc).__name__ == "BatchedVtolMSMPCCBF" and ctl.mpc.max_iter == 3000
+    assert ret == -1, (ret, len(st))
+    assert int(ctl.current_goal_index[0].item()) == 2 and 200 <= len(st) <= 400
+    X = ctl.X[0].cpu().numpy()
+    assert np.hypot(X[0] - 70.0, X[1] - 0.5) < 1.0 and X[1] > 0.0                  # within the reached_threshold of the landing waypoint, above ground
+    assert zmax > 18.0 and dmin < 1.0                                               # over the wall, through the first waypoint
+    assert np.mean(st == 0) >= 0.95
+
+
+def test_reference_example_scene_with_the_condensed_kernel_alone():
+    """The same scene with robot_spec['mpc_formulation'] = 'condensed' (csrc/mpc_vtol_wave.hip, IPOPT's iteration budget): what holds is
+    asserted -- the infeasible start, the climb over the discs, the first waypoint -- and where the flight ends is only recorded (round 4:
+    -2 about 200 control steps in, lost at the start of the landing leg when the rollout of an aggressive u_prev over 30 unstable stages
+    diverges and one solve of a FEASIBLE NLP stops unconverged; tools/exp_ms_vtol_flight.py; this is why the multiple-shooting kernel is
+    the default)."""
+    ctl, ret, st, zmax, dmin, vmin = fly_reference_scene(dict(REF_SPEC, mpc_formulation="condensed"), steps=320)
+    assert type(ctl.mpc).__name__ == "BatchedVtolMPCCBF" and ctl.mpc.max_iter == 3000
     assert (st[:7] != 0).sum() >= 4                                         # the infeasible start
     assert np.mean(st == 0) >= 0.85 and np.all(st[12:150] == 0)             # the climb and the approach: every solve converges
-    assert zmax > 18.0 and dmin < 1.5 and vmin < 2.5                        # over the wall, down to the waypoint, slow (measured: 22.2 m, 0.70 m, 1.7 m/s)
-    assert ret == -2 and 170 <= len(st) <= 260, (ret, len(st))              # lost in the hover
+    assert zmax > 18.0 and dmin < 1.5 and vmin < 2.5                        # over the wall, down to the waypoint, slow
+    print(f"condensed kernel alone: ret {ret} after {len(st)} control steps")
