@@ -129,7 +129,7 @@ def valu_roofline(run, kernel_substr, kernel_ms, note=None, launches=1):
     profile has them: lane utilisation = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU), and the f64 flops of the launch
     (lanes x (2 FMA + ADD + MUL) + 512 per MFMA op) against the 78.6 TFLOP/s vector peak.  The profile is used only when it
     was taken from the kernel sources of this tree (csrc hash); otherwise the entry says "stale"."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_counters.json")
         if not os.path.exists(path):
             continue
@@ -651,6 +651,74 @@ def vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
             "lds_KB_per_problem": 39.3, "problems_per_CU": 4}, "mpcvtol_wave_kernel<float, 8")   # (<float, 8> in the profiles of rounds 3; <float, 8, false> since the OD flag)
 
 
+def vtol_ms_mpc_leg(dev, B=4096, K=8, steps=3, seed=0):
+    """MPC-CBF for VTOL2D AS DO-MPC POSES IT (round 5, csrc/mpc_vtol_ms.hip, DESIGN.md kernel 12): multiple shooting (states of every stage are
+    variables, dynamics as equality rows, x_k = x0 start: position_control/mpc_cbf.py:162-174,366-369) under IPOPT's filter line-search
+    interior point with IPOPT's option defaults (tol 1e-8, max_iter 3000), one NLP per wavefront, one stage per lane, Riccati recursion with
+    defects; problems that would enter IPOPT's restoration phase go to the condensed kernel (none of this batch does).  One launch: the
+    longest solve of the batch is ~100 iterations, no continuation needed.  Same batch as vtol_mpc_cbf."""
+    import torch
+    import safe_control_amd as sca
+    from safe_control_amd import workloads as W
+    ctl = sca.BatchedVtolMSMPCCBF(io_dtype="f32")
+    Xn, up0, gn, on = W.mpc_family_batch("vtol", B, K, seed=seed)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    X, g, ob, up = t(Xn), t(gn), t(on), t(up0)
+    u, st, it = ctl.solve(X, up, g, ob)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        u, st, it = ctl.solve(X, up, g, ob)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    res = {"workload": f"{B}-aircraft batch VTOL2D MPC-CBF, multiple shooting (306 variables, 186 equality rows, {30 * K} inequality rows per NLP), horizon N=30, {K} obstacles",
+           "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32", "budget": 3000, "launches": 1,
+           "optimal_fraction": float((st == 0).double().mean().item()), "inaccurate_fraction": float((st == 2).double().mean().item()),
+           "restoration_fallback": int(ctl.n_fallback), "mean_ipm_iterations": float(it.double().mean().item()), "max_ipm_iterations": int(it.max().item()),
+           "lds_KB_per_problem": 53.3, "problems_per_CU": 3}
+    # the work without the tail: the batch filled with copies of the median problem
+    try:
+        opt = torch.nonzero(st == 0).flatten()
+        med = opt[torch.argsort(it[opt])[opt.numel() // 2]]
+        rep = lambda a: a[med:med + 1].repeat(B, *([1] * (a.dim() - 1))).contiguous()
+        args = (rep(X), rep(up), rep(g), rep(ob))
+        ctl.solve(*args); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            o2 = ctl.solve(*args)
+        e1.record(); torch.cuda.synchronize()
+        res["uniform_batch"] = {"kernel_ms": e0.elapsed_time(e1) / steps, "iterations": int(o2[2][0].item())}
+    except Exception as e:
+        res["uniform_batch"] = {"error": repr(e)[:100]}
+    return with_roofline(res, "mpcvtol_ms_kernel<float, 8>", launches=1)
+
+
+def vtol_ms_closed_loop_leg(dev):
+    """The reference's own VTOL2D demo (examples/test_vtol.py:12-92) through the drop-in loop with the default position controller of the model
+    (multiple-shooting kernel + condensed fallback): one aircraft, control steps until the loop returns."""
+    import time
+    import numpy as np
+    import torch
+    import safe_control_amd as sca
+    obs = np.array([[67.0, z, 0.5] for z in (6.0, 7.0, 8.0, 9.0)] + [[73.0, float(z), 0.5] for z in range(1, 16)] + [[60.0, 12.0, 1.5]])
+    obs7 = np.hstack([obs, np.zeros((len(obs), 4))])
+    spec = {"model": "VTOL2D", "radius": 0.6, "v_max": 20.0, "reached_threshold": 1.0, "num_constraints": 10}
+    ctl = sca.BatchedTrackingController(np.array([[2.0, 10.0, 0.0, 20.0, 0.0, 0.0]]), spec, obs=obs7, device=str(dev))
+    ctl.set_waypoints(np.array([[2.0, 10.0], [70.0, 10.0], [70.0, 0.5]]))
+    torch.cuda.synchronize()
+    t0 = time.time()
+    ret, n, nopt = 0, 0, 0
+    for n in range(1, 401):
+        ret = int(ctl.control_step(1)[0].item())
+        nopt += int(ctl.mpc_status[0].item() == 0)
+        if ret != 0:
+            break
+    return {"workload": "examples/test_vtol.py scene, one VTOL2D aircraft, MPC-CBF N=30, 10 obstacle slots, closed loop to the landing waypoint",
+            "return_code": ret, "landed": ret == -1, "control_steps": n, "optimal_solves": nopt, "ms_per_control_step": 1e3 * (time.time() - t0) / n}
+
+
 def od_vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
     """Optimal-decay MPC-CBF for VTOL2D (the last model of the reference class's accept list): the vtol batch with a disc
     on every other aircraft's flight path 10 - 30 m ahead, so that decay variables leave their reference.  One launch per solve."""
@@ -811,7 +879,7 @@ def compact_leg(v):
     keep = {}
     for k in ("value", "kernel_ms", "ms_per_control_step", "us_per_step", "agent_steps_per_s", "solves_per_s", "optimal_fraction",
               "max_ipm_iterations", "agents", "GBs", "frac_of_peak", "error", "optimal_only_value", "beyond_100_iterations",
-              "all_gather_bytes_per_step", "inaccurate_fraction"):
+              "all_gather_bytes_per_step", "inaccurate_fraction", "landed", "return_code", "control_steps", "restoration_fallback"):
         if k in v:
             keep[k] = sig(v[k])
     if isinstance(v.get("one_launch_limit_100"), dict):
@@ -1063,6 +1131,12 @@ def main():
             except Exception as e:                               # an extra leg never takes the line down
                 res["c3bf_closed_loop_states_mpc"] = {"error": repr(e)[:200]}
             res["vtol_mpc_cbf"] = vtol_mpc_leg(dev)
+            res["vtol_ms_mpc_cbf"] = vtol_ms_mpc_leg(dev)
+            try:
+                if not NO_LIMIT100:
+                    res["vtol_reference_scene_closed_loop"] = vtol_ms_closed_loop_leg(dev)
+            except Exception as e:
+                res["vtol_reference_scene_closed_loop"] = {"error": repr(e)[:200]}
             res["od_vtol_mpc_cbf"] = od_vtol_mpc_leg(dev)
             res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
             res["backup_cbf_qp"] = backup_cbf_leg(dev)

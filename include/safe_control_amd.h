@@ -38,10 +38,10 @@ extern "C" {
 #endif
 
 /* ABI version: the minor number goes up with EVERY change of a struct layout or an entry point's signature (round 4 grew
- * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2; round 5 added sc_ipopt_params and sc_mpcvtol_ms_solve_batch: 0.3).  A binding compares sc_version() with the
+ * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2; round 5 added sc_ipopt_params and sc_mpcvtol_ms_solve_batch: 0.3; the continuation entry points of the optimal-decay families: 0.4).  A binding compares sc_version() with the
  * version its struct mirrors were written for before the first call (safe_control_amd/_lib.py: ABI_VERSION). */
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 3
+#define SC_VERSION_MINOR 4
 
 /* ---- return codes ------------------------------------------------------ */
 typedef enum sc_error {
@@ -473,6 +473,11 @@ int sc_odmpcvtol_solve_batch(const sc_odmpcvtol_params* params, int64_t B, int32
                              const void* X, const void* u_prev, const void* goal, const void* obs,
                              void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
 
+size_t sc_odmpcvtol_slices_workspace_bytes(const sc_odmpcvtol_params* params, int64_t B, int32_t K);
+int sc_odmpcvtol_solve_batch_sliced(const sc_odmpcvtol_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K,
+                                    const void* X, const void* u_prev, const void* goal, const void* obs,
+                                    void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
+
 /* ---- optimal-decay MPC-CBF ---------------------------------------
  * OptimalDecayMPCCBF (position_control/optimal_decay_mpc_cbf.py:15-330) for DynamicUnicycle2D: the MPC-CBF NLP with
  * two decay variables per stage (omega1_k, omega2_k, model inputs at :123-124) that scale the DT-CBF gains,
@@ -499,6 +504,19 @@ int sc_odmpccbf_solve_batch(const sc_odmpccbf_params* params, int64_t B, int32_t
                             void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out,
                             void* stream);
 
+/* continuation launches (sc_mpc_slices) of the optimal-decay families -- round 5; the decay variables travel with the solver state:
+ * resumed == uninterrupted bit for bit (tests/test_mpc_slices_gpu.py).  sc_odmpclin: sc_mpclin_slices_workspace_bytes sizes the workspace. */
+size_t sc_odmpccbf_slices_workspace_bytes(const sc_odmpccbf_params* params, int64_t B, int32_t K);
+int sc_odmpccbf_solve_batch_sliced(const sc_odmpccbf_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K,
+                                   const void* X, const void* u_prev, const void* goal, const void* obs,
+                                   void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
+size_t sc_odmpcgn_slices_workspace_bytes(const sc_odmpcgn_params* params, int64_t B, int32_t K);
+int sc_odmpcgn_solve_batch_sliced(const sc_odmpcgn_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K,
+                                  const void* X, const void* u_prev, const void* goal, const void* obs,
+                                  void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
+int sc_odmpclin_solve_batch_sliced(const sc_mpclin_params* params, const sc_mpc_slices* slices, const double* model, int64_t B, int32_t K,
+                                   const void* X, const void* u_prev, const void* goal, const void* obs,
+                                   void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
 int sc_odmpccbf_solve_batch_host(const sc_odmpccbf_params* params, int64_t B, int32_t K,
                                  const void* X, const void* u_prev, const void* goal, const void* obs,
                                  void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out,

@@ -331,6 +331,13 @@ SYMBOLS = {
     "sc_mpcvtol_solve_batch_sliced": (C.c_int, [C.POINTER(MpcVtolParams), C.POINTER(MpcSlices), C.c_int64, C.c_int32] + [C.c_void_p] * 9),
     "sc_mpccbf_slices_workspace_bytes": (C.c_size_t, [C.POINTER(MpcCbfParams), C.c_int64, C.c_int32]),
     "sc_mpccbf_solve_batch_sliced": (C.c_int, [C.POINTER(MpcCbfParams), C.POINTER(MpcSlices), C.c_int64, C.c_int32] + [C.c_void_p] * 9),
+    "sc_odmpccbf_slices_workspace_bytes": (C.c_size_t, [C.POINTER(OdMpcCbfParams), C.c_int64, C.c_int32]),
+    "sc_odmpccbf_solve_batch_sliced": (C.c_int, [C.POINTER(OdMpcCbfParams), C.POINTER(MpcSlices), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
+    "sc_odmpcgn_slices_workspace_bytes": (C.c_size_t, [C.POINTER(OdMpcGnParams), C.c_int64, C.c_int32]),
+    "sc_odmpcgn_solve_batch_sliced": (C.c_int, [C.POINTER(OdMpcGnParams), C.POINTER(MpcSlices), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
+    "sc_odmpclin_solve_batch_sliced": (C.c_int, [C.POINTER(MpcLinParams), C.POINTER(MpcSlices), C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 10),
+    "sc_odmpcvtol_slices_workspace_bytes": (C.c_size_t, [C.POINTER(OdMpcVtolParams), C.c_int64, C.c_int32]),
+    "sc_odmpcvtol_solve_batch_sliced": (C.c_int, [C.POINTER(OdMpcVtolParams), C.POINTER(MpcSlices), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_odmpccbf_solve_batch": (C.c_int, [C.POINTER(OdMpcCbfParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_odmpccbf_solve_batch_host": (C.c_int, [C.POINTER(OdMpcCbfParams), C.c_int64, C.c_int32] + [C.c_void_p] * 9 + [C.c_int]),
     "sc_odcbfqp_solve_batch": (C.c_int, [C.POINTER(OdCbfQpParams), C.c_int64] + [C.c_void_p] * 9),
@@ -355,7 +362,7 @@ SYMBOLS = {
 _lib = None
 
 # SC_VERSION_MAJOR * 1000 + SC_VERSION_MINOR of the header the ctypes mirrors above were written for
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class HipLibraryError(RuntimeError):

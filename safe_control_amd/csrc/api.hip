@@ -21,7 +21,7 @@ size_t mpccbf_lds_bytes(int N, int K, bool uni);
 size_t odmpccbf_lds_bytes(int N, int K);
 hipError_t odmpccbf_launch(const sc_odmpccbf_params& q, long long B, int K, const void* X, const void* u_prev,
                            const void* goal, const void* obs, void* u_out, void* rho_out, int* status, int* iters,
-                           void* z_out, hipStream_t stream);
+                           void* z_out, hipStream_t stream, const ipm::Cont& ct);
 hipError_t neighbors_launch(int io_dtype, long long B_all, long long first, long long B_local, int K, double r, const void* X,
                             void* out, hipStream_t stream);
 hipError_t odcbfqp_launch(const sc_odcbfqp_params& p, long long B, const void* X, const void* u_ref, const void* obs,
@@ -60,9 +60,10 @@ hipError_t mpclin_launch(const sc_mpclin_params& p, const double* model, long lo
                          hipStream_t stream, const ipm::Cont& ct);
 size_t mpclin_state_doubles(int N, int K, int nu);
 size_t mpcgn_state_doubles(int N, int K);
-size_t mpcvtol_state_doubles(int N, int K);
+size_t mpcvtol_state_doubles(int N, int K, bool od = false);
 hipError_t odmpcvtol_wave_launch(const sc_odmpcvtol_params& q, long long B, int K, const void* X, const void* u_prev, const void* goal,
-                                 const void* obs, void* u_out, void* rho_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream);
+                                 const void* obs, void* u_out, void* rho_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream,
+                                 const ipm::Cont& ct);
 
 size_t mpcgn_lds_bytes(int model_id, int N, int K, int circles_only);
 size_t odmpcgn_lds_bytes(int model_id, int N, int K);
@@ -74,7 +75,8 @@ hipError_t mpcvtol_launch(const sc_mpcvtol_params& p, long long B, int K, const 
 hipError_t mpcvtol_ms_launch(const sc_mpcvtol_params& p, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
                              const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, hipStream_t stream);
 hipError_t odmpcgn_launch(const sc_odmpcgn_params& q, long long B, int K, const void* X, const void* u_prev, const void* goal,
-                          const void* obs, void* u_out, void* rho_out, int* status, int* iters, void* z_out, hipStream_t stream);
+                          const void* obs, void* u_out, void* rho_out, int* status, int* iters, void* z_out, hipStream_t stream,
+                          const ipm::Cont& ct);
 hipError_t mpcgn_launch(const sc_mpcgn_params& p, long long B, int K, const void* X, const void* u_prev, const void* goal,
                         const void* obs, void* u_out, int* status, int* iters, void* z_out, hipStream_t stream, const ipm::Cont& ct);
 
@@ -398,7 +400,7 @@ int sc_odmpcgn_solve_batch(const sc_odmpcgn_params* params, int64_t B, int32_t K
         return sc::fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
     if (B == 0) return SC_OK;
     hipError_t e = sc::odmpcgn_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, rho_out, status_out, iters_out, z_out,
-                                      (hipStream_t)stream);
+                                      (hipStream_t)stream, sc::one_launch(params->mpc.max_iter));
     if (e != hipSuccess) return sc::fail_hip(e, "odmpcgn kernel launch");
     return SC_OK;
 }
@@ -832,8 +834,32 @@ int sc_odmpcvtol_solve_batch(const sc_odmpcvtol_params* params, int64_t B, int32
     if (!(params->p_sb[0] > 0) || !(params->p_sb[1] > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "p_sb must be > 0");
     if (B == 0) return SC_OK;
     hipError_t e = sc::odmpcvtol_wave_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, rho_out, status_out, iters_out, z_out,
-                                             (hipStream_t)stream);
+                                             (hipStream_t)stream, sc::one_launch(params->mpc.max_iter));
     if (e != hipSuccess) return sc::fail_hip(e, "odmpcvtol kernel launch");
+    return SC_OK;
+}
+size_t sc_odmpcvtol_slices_workspace_bytes(const sc_odmpcvtol_params* params, int64_t B, int32_t K) {
+    if (!params || B < 0 || K < 1 || K > 16 || params->mpc.horizon < 1 || params->mpc.horizon > 64) return 0;
+    return sc::slices_workspace_bytes((long long)B, sc::mpcvtol_state_doubles(params->mpc.horizon, K, true));
+}
+int sc_odmpcvtol_solve_batch_sliced(const sc_odmpcvtol_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K, const void* X,
+                                    const void* u_prev, const void* goal, const void* obs, void* u_out, void* rho_out, int32_t* status_out,
+                                    int32_t* iters_out, void* z_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    int rc = sc::check_mpcvtol(&params->mpc, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (!sc::mpcvtol_uses_wave(params->mpc, K)) return sc::fail(SC_ERR_UNSUPPORTED, "optimal-decay MPC-CBF for VTOL2D runs on the wave-per-problem kernel (kernel = 0 / 2)");
+    if (!(params->p_sb[0] > 0) || !(params->p_sb[1] > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "p_sb must be > 0");
+    rc = sc::check_slices(slices, params->mpc.max_iter, sc_odmpcvtol_slices_workspace_bytes(params, B, K));
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::run_slices(slices, params->mpc.max_iter, (long long)B, sc::mpcvtol_state_doubles(params->mpc.horizon, K, true),
+                                  (hipStream_t)stream, [&](const sc::ipm::Cont& ct) {
+        return sc::odmpcvtol_wave_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, rho_out, status_out, iters_out, z_out,
+                                         (hipStream_t)stream, ct);
+    });
+    if (e != hipSuccess) return sc::fail_hip(e, "odmpcvtol kernel launch (sliced)");
     return SC_OK;
 }
 
@@ -969,8 +995,76 @@ int sc_odmpccbf_solve_batch(const sc_odmpccbf_params* params, int64_t B, int32_t
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
     hipError_t e = sc::odmpccbf_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, rho_out, status_out,
-                                       iters_out, z_out, (hipStream_t)stream);
+                                       iters_out, z_out, (hipStream_t)stream, sc::one_launch(params->mpc.max_iter));
     if (e != hipSuccess) return sc::fail_hip(e, "odmpccbf kernel launch");
+    return SC_OK;
+}
+
+/* ---- continuation launches of the optimal-decay families (round 5): the same kernels hand their state over (decay variables included) ---- */
+size_t sc_odmpccbf_slices_workspace_bytes(const sc_odmpccbf_params* params, int64_t B, int32_t K) {
+    if (!params || B < 0 || K < 1 || params->mpc.horizon < 1) return 0;
+    return sc::slices_workspace_bytes((long long)B, sc::mpccbf_state_doubles(params->mpc.horizon, K, true));
+}
+int sc_odmpccbf_solve_batch_sliced(const sc_odmpccbf_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K, const void* X,
+                                   const void* u_prev, const void* goal, const void* obs, void* u_out, void* rho_out, int32_t* status_out,
+                                   int32_t* iters_out, void* z_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    int rc = check_odmpccbf(params, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    rc = sc::check_slices(slices, params->mpc.max_iter, sc_odmpccbf_slices_workspace_bytes(params, B, K));
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::run_slices(slices, params->mpc.max_iter, (long long)B, sc::mpccbf_state_doubles(params->mpc.horizon, K, true),
+                                  (hipStream_t)stream, [&](const sc::ipm::Cont& ct) {
+        return sc::odmpccbf_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, rho_out, status_out, iters_out, z_out,
+                                   (hipStream_t)stream, ct);
+    });
+    if (e != hipSuccess) return sc::fail_hip(e, "odmpccbf kernel launch (sliced)");
+    return SC_OK;
+}
+size_t sc_odmpcgn_slices_workspace_bytes(const sc_odmpcgn_params* params, int64_t B, int32_t K) {
+    if (!params) return 0;
+    return sc_mpcgn_slices_workspace_bytes(&params->mpc, B, K);
+}
+int sc_odmpcgn_solve_batch_sliced(const sc_odmpcgn_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K, const void* X,
+                                  const void* u_prev, const void* goal, const void* obs, void* u_out, void* rho_out, int32_t* status_out,
+                                  int32_t* iters_out, void* z_out, void* stream) {
+    if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    sc::DeviceGuard on_device(stream, X);
+    int rc = sc::check_mpcgn(&params->mpc, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (params->mpc.model_id != SC_MODEL_KINEMATIC_BICYCLE2D && params->mpc.model_id != SC_MODEL_QUAD2D)
+        return sc::fail(SC_ERR_UNSUPPORTED, "optimal-decay MPC-CBF on this entry point: KinematicBicycle2D and Quad2D");
+    if (!(params->p_sb[0] > 0) || !(params->p_sb[1] > 0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "p_sb must be > 0");
+    if (sc::odmpcgn_lds_bytes(params->mpc.model_id, params->mpc.horizon, K) > 160 * 1024)
+        return sc::fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
+    rc = sc::check_slices(slices, params->mpc.max_iter, sc_odmpcgn_slices_workspace_bytes(params, B, K));
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::run_slices(slices, params->mpc.max_iter, (long long)B, sc::mpcgn_state_doubles(params->mpc.horizon, K), (hipStream_t)stream,
+                                  [&](const sc::ipm::Cont& ct) {
+        return sc::odmpcgn_launch(*params, (long long)B, (int)K, X, u_prev, goal, obs, u_out, rho_out, status_out, iters_out, z_out,
+                                  (hipStream_t)stream, ct);
+    });
+    if (e != hipSuccess) return sc::fail_hip(e, "odmpcgn kernel launch (sliced)");
+    return SC_OK;
+}
+int sc_odmpclin_solve_batch_sliced(const sc_mpclin_params* params, const sc_mpc_slices* slices, const double* model, int64_t B, int32_t K,
+                                   const void* X, const void* u_prev, const void* goal, const void* obs, void* u_out, void* rho_out,
+                                   int32_t* status_out, int32_t* iters_out, void* z_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    int rc = sc::check_mpclin(params, model, B, K, X, u_prev, goal, obs, u_out, status_out);
+    if (rc != SC_OK) return rc;
+    if (params->optimal_decay != 1) return sc::fail(SC_ERR_INVALID_ARGUMENT, "optimal_decay != 1: call sc_mpclin_solve_batch_sliced");
+    rc = sc::check_slices(slices, params->max_iter, sc_mpclin_slices_workspace_bytes(params, B, K));
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    hipError_t e = sc::run_slices(slices, params->max_iter, (long long)B, sc::mpclin_state_doubles(params->horizon, K, params->nu),
+                                  (hipStream_t)stream, [&](const sc::ipm::Cont& ct) {
+        return sc::mpclin_launch(*params, model, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, rho_out,
+                                 (hipStream_t)stream, ct);
+    });
+    if (e != hipSuccess) return sc::fail_hip(e, "mpclin (optimal decay) kernel launch (sliced)");
     return SC_OK;
 }
 
@@ -1001,7 +1095,8 @@ int sc_odmpccbf_solve_batch_host(const sc_odmpccbf_params* params, int64_t B, in
         if ((e = hipMemcpyAsync(d + oG, goal, nG, hipMemcpyHostToDevice, s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d + oO, obs, nO, hipMemcpyHostToDevice, s)) != hipSuccess) break;
         e = sc::odmpccbf_launch(*params, (long long)B, (int)K, d + oX, d + oU, d + oG, d + oO, d + oUo,
-                                rho_out ? d + oR : nullptr, (int*)(d + oS), (int*)(d + oI), z_out ? d + oZ : nullptr, s);
+                                rho_out ? d + oR : nullptr, (int*)(d + oS), (int*)(d + oI), z_out ? d + oZ : nullptr, s,
+                                sc::one_launch(params->mpc.max_iter));
         if (e != hipSuccess) break;
         if ((e = hipMemcpyAsync(u_out, d + oUo, nU, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(status_out, d + oS, nS, hipMemcpyDeviceToHost, s)) != hipSuccess) break;

@@ -1445,7 +1445,7 @@ size_t odmpccbf_lds_bytes(int N, int K) { return mpc_lds_doubles(N, K, true) * s
 
 static hipError_t odmpc_launch_t(const sc_odmpccbf_params& q, long long B, int K, const void* X, const void* u_prev,
                                  const void* goal, const void* obs, void* u_out, void* rho_out, int* status, int* iters,
-                                 void* z_out, hipStream_t stream) {
+                                 void* z_out, hipStream_t stream, const ipm::Cont& ct) {
     const sc_mpccbf_params& p = q.mpc;
     const size_t lds = mpc_lds_doubles(p.horizon, K, true) * sizeof(double);
     OdExtra od;
@@ -1455,8 +1455,6 @@ static hipError_t odmpc_launch_t(const sc_odmpccbf_params& q, long long B, int K
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
         }
-        ipm::Cont ct{};
-        ct.it_stop = p.max_iter;
         hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(64), lds, stream, p, od, B, K, X, u_prev,
                            goal, obs, u_out, rho_out, status, iters, z_out, ct);
         return hipGetLastError();
@@ -1473,9 +1471,9 @@ static hipError_t odmpc_launch_t(const sc_odmpccbf_params& q, long long B, int K
 
 hipError_t odmpccbf_launch(const sc_odmpccbf_params& q, long long B, int K, const void* X, const void* u_prev,
                            const void* goal, const void* obs, void* u_out, void* rho_out, int* status, int* iters,
-                           void* z_out, hipStream_t stream) {
+                           void* z_out, hipStream_t stream, const ipm::Cont& ct) {
     if (mpc_lds_doubles(q.mpc.horizon, K, true) * sizeof(double) > 160 * 1024) return hipErrorInvalidValue;
-    return odmpc_launch_t(q, B, K, X, u_prev, goal, obs, u_out, rho_out, status, iters, z_out, stream);
+    return odmpc_launch_t(q, B, K, X, u_prev, goal, obs, u_out, rho_out, status, iters, z_out, stream, ct);
 }
 
 template <int NT, int KT, bool UNI = false>

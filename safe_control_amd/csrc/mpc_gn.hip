@@ -1525,9 +1525,8 @@ size_t odmpcgn_lds_bytes(int model_id, int N, int K) {
     return mpcgn_lds_doubles(N, K, kb ? 4 : 6, kb ? 1 : 0, true, kb ? 10 : 2, 2, 3, true) * sizeof(double);
 }
 hipError_t odmpcgn_launch(const sc_odmpcgn_params& q, long long B, int K, const void* X, const void* u_prev, const void* goal,
-                          const void* obs, void* u_out, void* rho_out, int* status, int* iters, void* z_out, hipStream_t stream) {
-    ipm::Cont ct0{};
-    ct0.it_stop = q.mpc.max_iter;
+                          const void* obs, void* u_out, void* rho_out, int* status, int* iters, void* z_out, hipStream_t stream,
+                          const ipm::Cont& ct0) {
     GnOd od;
     od.omega_ref[0] = q.omega_ref[0]; od.omega_ref[1] = q.omega_ref[1]; od.p_sb[0] = q.p_sb[0]; od.p_sb[1] = q.p_sb[1];
     if (q.mpc.model_id == SC_MODEL_KINEMATIC_BICYCLE2D)

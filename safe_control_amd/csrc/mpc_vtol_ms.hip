@@ -23,9 +23,11 @@
 //               and ITS restoration phase (csrc/mpc_vtol_wave.hip); fraction to the boundary tau = max(0.99, 1 - mu), monotone mu,
 //               gradient-based scaling, bound push / relaxation, least-square initial multipliers, kappa_sigma, safe slacks
 //
-// LDS per problem (N = 30): stage Jacobians [A | B], stage blocks, gains, gradient / defect / step vectors, the Riccati workspace: 53 KB
-// (three problems per CU).  Compiled with the non-splitting register allocator (csrc/Makefile: SAFE_RA).
+// LDS per problem (N = 30): stage Jacobians [A | B] (compact), stage blocks, gains, gradient / defect / step vectors, the Riccati workspace
+// (over the exchange vectors): 39.9 KB, four problems per CU.  Compiled with the non-splitting register allocator (csrc/Makefile: SAFE_RA).
 #include <hip/hip_runtime.h>
+
+#include <utility>
 
 #include "../../include/safe_control_amd.h"
 #include "mpc_ipm_common.hpp"
@@ -43,36 +45,73 @@ namespace msk {
 
 typedef __attribute__((address_space(3))) double ldsd;
 
+#ifndef SC_MS_SOLVE_INLINE
+#define SC_MS_SOLVE_INLINE __forceinline__
+#endif
+#ifdef SC_MS_PROF
+#define MPROF_T0_AGAIN _t0 = __builtin_readcyclecounter();
+#define MPROF_T0 long long _t0 = __builtin_readcyclecounter();
+#define MPROF_ADD(i) { const long long _t1 = __builtin_readcyclecounter(); prof[i] += (double)(_t1 - _t0); _t0 = _t1; }
+#else
+#define MPROF_T0
+#define MPROF_T0_AGAIN
+#define MPROF_ADD(i)
+#endif
+
 constexpr int KS_MAX = 16;
-constexpr int NFILT = 48;                       // filter entries kept (the filter is cleared with every decrease of mu)
+constexpr int NFILT = 24;                       // filter entries kept (the filter is cleared with every decrease of mu)
+constexpr int ABS = 21;                         // [A | B] of a stage, compact: rows 3..5 x columns (2, 3, 4 | 6..9); rows 0..2 are e_i + dt e_{i+3}, A[5][5] = 1
 constexpr int TRACE_W = 8;
 
 struct Lds {
-    int OB, AB, H, KG, G, C, DX, DU, LAM, XS, US, YS, Pc, Pn, T, QU, Quu, pc, pn, FP, FT, total;
+    int OB, AB, H, KG, G, C, DX, DU, LAM, XS, US, YS, Pc, Pn, T, QU, Quu, pc, pn, FP, FT, SC, Y0, total;
     __host__ __device__ explicit Lds(int N) {
         int o = 0;
         auto take = [&](int c) { int r = o; o += c; return r; };
-        OB = take(3 * KS_MAX); AB = take(N * 60); H = take((N + 1) * 55); KG = take(N * 44); G = take((N + 1) * 10); C = take((N + 1) * 6);
-        DX = take((N + 1) * 6); DU = take(N * 4); LAM = take((N + 2) * 6); XS = take((N + 2) * 6); US = take((N + 2) * 4); YS = take((N + 2) * 6);
-        Pc = take(100); Pn = take(100); T = take(110); QU = take(44); Quu = take(16); pc = take(10); pn = take(10);
-        FP = take(NFILT); FT = take(NFILT);
+        OB = take(3 * KS_MAX); AB = take(N * ABS); H = take((N + 1) * 55); KG = take(N * 44); G = take((N + 1) * 10);
+        // Slots whose lifetimes do not overlap share storage (39.9 KB per problem for N = 30: four problems per CU):
+        //   the defects C are consumed by the forward sweep as it writes the step dx in their place;
+        //   YS (multipliers as the neighbours see them: written and read at the start of an evaluation) / LAM (costates = multiplier steps:
+        //   written after the recursion, read at the update);
+        //   the recursion's workspace Pc | Pn | T lies over the exchange vectors XS | US, which an evaluation rewrites before it reads them.
+        DX = take((N + 1) * 6); C = DX; DU = take(N * 4); LAM = take((N + 2) * 6); YS = LAM;
+        const int ex = (N + 2) * 10 < 310 ? 310 : (N + 2) * 10;
+        XS = take(ex); US = XS + (N + 2) * 6; Pc = XS; Pn = XS + 100; T = XS + 200;
+        QU = take(44); Quu = take(16); pc = take(10); pn = take(10);
+        FP = take(NFILT); FT = take(NFILT); SC = take(6 + KS_MAX); Y0 = take(6);
         total = o;
     }
 };
 
 size_t lds_bytes(int horizon) { return (size_t)Lds(horizon).total * sizeof(double); }
 
+// entry (i, c) of the 6 x 10 block [A | B] from its compact form (ABS); ci = compact column of c (ab_col), or -1
+__device__ __forceinline__ int ab_col(int c) { return (c >= 2 && c <= 4) ? c - 2 : (c >= 6 ? c - 3 : -1); }
+template <int I>
+__device__ __forceinline__ double ab_at(const ldsd* A3, int c, int ci, double dt) {
+    if constexpr (I < 3) return c == I ? 1.0 : (c == I + 3 ? dt : 0.0);
+    else return ci >= 0 ? A3[(I - 3) * 7 + ci] : ((I == 5 && c == 5) ? 1.0 : 0.0);
+}
+template <typename F, int... Is>
+__device__ __forceinline__ void for6(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+#define SC_FOR6(body) for6([&](auto I_) { constexpr int I = decltype(I_)::value; body }, std::make_integer_sequence<int, 6>{})
+
 // ---- Riccati recursion with defects (oracle/ms_ipopt.py: _riccati_backward / _riccati_solve, hard dynamics) ----------------------------
 // LDS in: AB[k] (6 x 10 [A | B]), H[k] (upper-packed 10 x 10 over (x_k, u_k); H[N]: its x block), G[k] (gradient, 10), C[k + 1] (defect of the
 // dynamics of stage k), C[0] = dx_0;  cpl[j] = 2 df R_j: the (u_{k-1}, u_k) cross term, -cpl on the (v, u) entries of stage k >= 1.
 // Out: KG[k] = gains (K: 4 x 10 over (dx_k, du_{k-1}), then kff: 4); false (wave-uniform) when an input block is not positive definite.
-__device__ __attribute__((noinline)) bool riccati_backward(ldsd* lds, const Lds L, const int N, const int lane, const double c0, const double c1,
-                                                           const double c2, const double c3) {
+__device__ __attribute__((noinline)) bool riccati_backward(ldsd* lds, const Lds L, const int N, const int lane, const double dt, const double c0,
+                                                           const double c1, const double c2, const double c3) {
     ldsd* T = lds + L.T; ldsd* QU = lds + L.QU; ldsd* Quu = lds + L.Quu;
     ldsd* Pc = lds + L.Pc; ldsd* Pn = lds + L.Pn; ldsd* pc = lds + L.pc; ldsd* pn = lds + L.pn;
     const double cpl[4] = {c0, c1, c2, c3};
     int tr = 0, tc = 0;                                                   // phase D: upper-triangle entry `lane` of 55
     { int e = lane < 55 ? lane : 0; int r = 0; while (e >= NV - r) { e -= NV - r; ++r; } tr = r; tc = r + e; }
+    const int tri = ab_col(tr);
+    const int ar0 = lane / 11, ac0 = lane % 11;                           // phase A, round 0: entry `lane` of 110
+    const int e1 = lane < 46 ? lane + 64 : 109;
+    const int ar1 = e1 / 11, ac1 = e1 % 11;                               // round 1 (lanes < 46)
+    const int aci0 = ab_col(ac0), aci1 = ab_col(ac1);
     {
         const ldsd* HN = lds + L.H + N * 55; const ldsd* GN = lds + L.G + N * 10;
         for (int e = lane; e < 100; e += 64) { const int r = e / 10, c = e % 10; Pc[e] = (r < NX && c < NX) ? HN[sym(r, c)] : 0.0; }
@@ -80,22 +119,19 @@ __device__ __attribute__((noinline)) bool riccati_backward(ldsd* lds, const Lds 
     }
     __syncthreads();
     for (int kk = N - 1; kk >= 0; --kk) {
-        const ldsd* AB = lds + L.AB + kk * 60; const ldsd* H = lds + L.H + kk * 55; const ldsd* g = lds + L.G + kk * 10;
+        const ldsd* A3 = lds + L.AB + kk * ABS; const ldsd* H = lds + L.H + kk * 55; const ldsd* g = lds + L.G + kk * 10;
         const ldsd* cd = lds + L.C + (kk + 1) * 6;
-        // A: T = P [A | B] (+ P's v columns under B), column 10: P c + p
-        for (int e = lane; e < 110; e += 64) {
-            const int r = e / 11, c = e % 11;
-            double v;
-            if (c < 10) {
-                v = c >= NX ? Pc[r * 10 + c] : 0.0;
-#pragma unroll
-                for (int i = 0; i < NX; ++i) v += Pc[r * 10 + i] * AB[i * 10 + c];
-            } else {
-                v = pc[r];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) v += Pc[r * 10 + i] * cd[i];
-            }
-            T[e] = v;
+        // A: T = P [A | B] (+ P's v columns under B), column 10: P c + p   (two rounds of 64 entries; index maps are lane constants)
+        {
+            double v0 = ac0 < 10 ? (ac0 >= NX ? Pc[ar0 * 10 + ac0] : 0.0) : pc[ar0];
+            double v1 = ac1 < 10 ? (ac1 >= NX ? Pc[ar1 * 10 + ac1] : 0.0) : pc[ar1];
+            SC_FOR6(
+                const double b0 = ac0 < 10 ? ab_at<I>(A3, ac0, aci0, dt) : cd[I];
+                const double b1 = ac1 < 10 ? ab_at<I>(A3, ac1, aci1, dt) : cd[I];
+                v0 += Pc[ar0 * 10 + I] * b0; v1 += Pc[ar1 * 10 + I] * b1;
+            );
+            T[lane] = v0;
+            if (lane < 46) T[lane + 64] = v1;
         }
         __syncthreads();
         // B: u rows of H + G' T: [Qux | Quu], and qu
@@ -105,12 +141,12 @@ __device__ __attribute__((noinline)) bool riccati_backward(ldsd* lds, const Lds 
             if (c < 10) {
                 v = T[(6 + i) * 11 + c] + H[sym(c, 6 + i)];
 #pragma unroll
-                for (int r = 0; r < NX; ++r) v += AB[r * 10 + 6 + i] * T[r * 11 + c];
+                for (int r = 3; r < NX; ++r) v += A3[(r - 3) * 7 + 3 + i] * T[r * 11 + c];      // B' T: rows 0..2 of B are zero
                 if (c < NX) QU[i * 11 + c] = v; else Quu[i * 4 + c - NX] = v;
             } else {
                 v = g[6 + i] + T[(6 + i) * 11 + 10];
 #pragma unroll
-                for (int r = 0; r < NX; ++r) v += AB[r * 10 + 6 + i] * T[r * 11 + 10];
+                for (int r = 3; r < NX; ++r) v += A3[(r - 3) * 7 + 3 + i] * T[r * 11 + 10];
                 QU[i * 11 + 10] = v;
             }
         }
@@ -147,8 +183,7 @@ __device__ __attribute__((noinline)) bool riccati_backward(ldsd* lds, const Lds 
             double v = 0.0;
             if (tr < NX && tc < NX) {
                 v = H[sym(tr, tc)];
-#pragma unroll
-                for (int r = 0; r < NX; ++r) v += AB[r * 10 + tr] * T[r * 11 + tc];
+                SC_FOR6( v += ab_at<I>(A3, tr, tri, dt) * T[I * 11 + tc]; );
             }
 #pragma unroll
             for (int i = 0; i < NU; ++i) {
@@ -161,8 +196,7 @@ __device__ __attribute__((noinline)) bool riccati_backward(ldsd* lds, const Lds 
                 double w = 0.0;
                 if (a < NX) {
                     w = g[a];
-#pragma unroll
-                    for (int r = 0; r < NX; ++r) w += AB[r * 10 + a] * T[r * 11 + 10];
+                    SC_FOR6( w += ab_at<I>(A3, a, ab_col(a), dt) * T[I * 11 + 10]; );
                 }
 #pragma unroll
                 for (int i = 0; i < NU; ++i) {
@@ -179,12 +213,12 @@ __device__ __attribute__((noinline)) bool riccati_backward(ldsd* lds, const Lds 
 }
 
 // forward LQ rollout: du_k = K (dx_k, du_{k-1}) + kff, dx_{k+1} = [A | B] (dx_k, du_k) + c_{k+1}; four + six lanes, two barriers per stage
-__device__ __attribute__((noinline)) void riccati_forward(ldsd* lds, const Lds L, const int N, const int lane) {
+__device__ __attribute__((noinline)) void riccati_forward(ldsd* lds, const Lds L, const int N, const int lane, const double dt) {
     if (lane < NX) lds[L.DX + lane] = lds[L.C + lane];
     __syncthreads();
     const int li = lane < NU ? lane : 0, lx = lane < NX ? lane : 0;
     for (int kk = 0; kk < N; ++kk) {
-        const ldsd* AB = lds + L.AB + kk * 60; const ldsd* KK = lds + L.KG + kk * 44;
+        const ldsd* A3 = lds + L.AB + kk * ABS; const ldsd* KK = lds + L.KG + kk * 44;
         {
             double v = KK[40 + li];
 #pragma unroll
@@ -197,11 +231,15 @@ __device__ __attribute__((noinline)) void riccati_forward(ldsd* lds, const Lds L
         }
         __syncthreads();
         {
+            // row lx of [A | B] (dx_k, du_k) + c: rows 0..2: dx_i + dt dx_{i+3}; rows 3..5: the stored entries (+ dx_5 for row 5)
+            const ldsd* dxk = lds + L.DX + kk * 6; const ldsd* duk = lds + L.DU + kk * NU;
             double v = lds[L.C + (kk + 1) * 6 + lx];
-#pragma unroll
-            for (int c = 0; c < NX; ++c) v += AB[lx * 10 + c] * lds[L.DX + kk * 6 + c];
-#pragma unroll
-            for (int j = 0; j < NU; ++j) v += AB[lx * 10 + 6 + j] * lds[L.DU + kk * NU + j];
+            if (lx < 3) v += dxk[lx] + dt * dxk[lx + 3];
+            else {
+                const ldsd* row = A3 + (lx - 3) * 7;
+                v += row[0] * dxk[2] + row[1] * dxk[3] + row[2] * dxk[4] + row[3] * duk[0] + row[4] * duk[1] + row[5] * duk[2] + row[6] * duk[3];
+                if (lx == 5) v += dxk[5];
+            }
             if (lane < NX) lds[L.DX + (kk + 1) * 6 + lane] = v;
         }
         __syncthreads();
@@ -209,13 +247,12 @@ __device__ __attribute__((noinline)) void riccati_forward(ldsd* lds, const Lds L
 }
 
 // costates lam_k = h_k + A_k' lam_{k+1}, k = N - 1 .. 0, with h_k (and lam_N = h_N) already in LAM: six lanes, one barrier per stage
-__device__ __attribute__((noinline)) void costates(ldsd* lds, const Lds L, const int N, const int lane) {
-    const int c = lane < NX ? lane : 0;
+__device__ __attribute__((noinline)) void costates(ldsd* lds, const Lds L, const int N, const int lane, const double dt) {
+    const int c = lane < NX ? lane : 0, ci = ab_col(c);
     for (int j = N - 1; j >= 0; --j) {
-        const ldsd* AB = lds + L.AB + j * 60;
+        const ldsd* A3 = lds + L.AB + j * ABS;
         double v = lds[L.LAM + j * 6 + c];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) v += AB[i * 10 + c] * lds[L.LAM + (j + 1) * 6 + i];
+        SC_FOR6( v += ab_at<I>(A3, c, ci, dt) * lds[L.LAM + (j + 1) * 6 + I]; );
         __syncthreads();
         if (lane < NX) lds[L.LAM + j * 6 + lane] = v;
         __syncthreads();
@@ -238,20 +275,20 @@ struct Wave {
     const int k;
     double x0[NX], uprev[NU], xg[2];
     double w0, w1, w2;
-    // iterate
-    double x[NX], u[NU], yc[NX], y0[NX];
+    // iterate: registers hold what a lane alone touches; the vectors the neighbours / the recursion read live in LDS (XS, US, YS, DX, DU, LAM),
+    // wave-uniform data (row scales, multipliers of the initial-state rows) in LDS as well
+    double x[NX], u[NU], yc[NX];
     double xbL[3], xbU[2], ubL[NU], ubU[NU];              // (relaxed, adjustable) bounds: x idx 2, 3, 4 lower / 2, 3 upper; inputs
     double zxL[3], zxU[2], zuL[NU], zuU[NU];
     double s[KS], yd[KS], vU[KS], sU[KS];
-    // scales
-    double df, dgc[NX], dgd[KS];
-    // last evaluation
-    double rc[NX], r0[NX], dv[KS];                       // scaled residuals of my dynamics rows / of the initial-state rows (lane 0) / scaled row values
-    double fk;                                           // my stage's share of the unscaled objective
-    // steps
-    double dx[NX], du[NU], dyc[NX], dy0[NX], ds[KS], dyd[KS], dvU[KS], dzxL[3], dzxU[2], dzuL[NU], dzuU[NU];
+    double df;
+    double rc[NX], dv[KS];                               // scaled residuals of my dynamics rows, scaled row values (last evaluation)
+    double ds[KS], dyd[KS], dvU[KS], dzxL[3], dzxU[2], dzuL[NU], dzuU[NU];
     int nfilt;
     double dw_last, last_dw;
+#ifdef SC_MS_PROF
+    double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};            // eval2 (errors), errors + mu, eval2 (build), riccati backward, forward, finish_step, line search, update
+#endif
 
     __device__ __forceinline__ Wave(const Params& P_, const sc_ipopt_params& O_, ldsd* lds_)
         : P(P_), O(O_), lds(lds_), L(P_.N), lane(threadIdx.x), N(P_.N), K(P_.K), act((int)threadIdx.x <= P_.N), stg((int)threadIdx.x < P_.N),
@@ -261,7 +298,8 @@ struct Wave {
         nfilt = 0; dw_last = 0.0; last_dw = 0.0;
     }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
-    __device__ __forceinline__ bool row_on(int j) const { return stg && j < K; }
+    __device__ __forceinline__ double dgc(int i) const { return lds[L.SC + i]; }
+    __device__ __forceinline__ double dgd(int j) const { return lds[L.SC + 6 + j]; }
 
     // ---- level 0: my stage's F(x, u), row values (unscaled cbf), cost share ----------------------------------------------------------
     __device__ __forceinline__ void points(const double* xs, const double a0, const double a1, double pt[3][2]) const {
@@ -291,8 +329,7 @@ struct Wave {
         return f;
     }
     // trial evaluation at (xs, us, ss): theta (l1 residual of the scaled rows) and the unscaled objective; xs of every lane goes through XS
-    __device__ __forceinline__ void eval0(const double* xs, const double* us, const double* ss, double& theta, double& fsum, double* rc_o, double* r0_o,
-                                          double* dv_o) {
+    __device__ __forceinline__ void eval0(const double* xs, const double* us, const double* ss, double& theta, double& fsum) {
         sync();
         if (act) {
 #pragma unroll
@@ -317,55 +354,59 @@ struct Wave {
             xn[0] = xs[0] + P.dt * xs[3]; xn[1] = xs[1] + P.dt * xs[4]; xn[2] = xs[2] + P.dt * xs[5];
             xn[3] = xs[3] + P.dt * acc[0]; xn[4] = xs[4] + P.dt * acc[1]; xn[5] = xs[5] + P.dt * acc[2];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { rc_o[i] = dgc[i] * (xn[i] - lds[L.XS + (k + 1) * 6 + i]); th += fabs(rc_o[i]); }
+            for (int i = 0; i < NX; ++i) th += fabs(dgc(i) * (xn[i] - lds[L.XS + (k + 1) * 6 + i]));
             double pt[3][2];
             points(xs, acc[0], acc[1], pt);
 #pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                if (j < K) { dv_o[j] = -dgd[j] * cbf_value(pt, j); th += fabs(dv_o[j] - ss[j]); } else dv_o[j] = 0.0;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) rc_o[i] = 0.0;
-#pragma unroll
-            for (int j = 0; j < KS; ++j) dv_o[j] = 0.0;
+            for (int j = 0; j < KS; ++j) if (j < K) th += fabs(-dgd(j) * cbf_value(pt, j) - ss[j]);
         }
+        if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { r0_o[i] = lane == 0 ? xs[i] - x0[i] : 0.0; th += fabs(r0_o[i]); }
+            for (int i = 0; i < NX; ++i) th += fabs(xs[i] - x0[i]);
+        }
         theta = ipm::wsum(th);
         fsum = ipm::wsum(cost_share(xs, us, um));
     }
 
     // ---- barrier function (scaled objective + log barrier of every bound + damping of the one-sided ones) ------------------------------
-    __device__ __forceinline__ double barrier_terms(const double* xs, const double* us, const double* ss, double mu, bool& ok) const {
+    __device__ __forceinline__ double barrier(double fsum, const double* xs, const double* us, const double* ss, double mu) const {
         double v = 0.0;
-        ok = true;
+        bool ok = true;
         if (act) {
             const double sl[5] = {xs[2] - xbL[0], xs[3] - xbL[1], xs[4] - xbL[2], xbU[0] - xs[2], xbU[1] - xs[3]};
+            double pr = 1.0;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) { if (!(sl[i] > 0.0)) ok = false; v -= mu * log(sl[i]); }
+            for (int i = 0; i < 5; ++i) { if (!(sl[i] > 0.0)) ok = false; pr *= sl[i]; }
+            v -= mu * log(pr);
             v += O.kappa_d * mu * sl[2];
         }
         if (stg) {
+            double pr = 1.0;
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
                 const double a = us[j] - ubL[j], b = ubU[j] - us[j];
                 if (!(a > 0.0) || !(b > 0.0)) ok = false;
-                v -= mu * (log(a) + log(b));
+                pr *= a * b;
             }
+            v -= mu * log(pr);
+            double ps = 1.0, sa = 0.0;
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
-                if (j < K) { const double a = sU[j] - ss[j]; if (!(a > 0.0)) ok = false; v -= mu * log(a); v += O.kappa_d * mu * a; }
+                if (j < K) {
+                    const double a = sU[j] - ss[j];
+                    if (!(a > 0.0)) ok = false;
+                    sa += a;
+                    // (slacks of far rows are ~1e3 .. 1e6: the product of eight stays far inside the double range; two logs for sixteen)
+                    if (j == 8) { v -= mu * log(ps); ps = 1.0; }
+                    ps *= a;
+                }
             }
+            v -= mu * log(ps);
+            v += O.kappa_d * mu * sa;
         }
-        return v;
-    }
-    __device__ __forceinline__ double barrier(double fsum, const double* xs, const double* us, const double* ss, double mu) const {
-        bool ok;
-        const double b = barrier_terms(xs, us, ss, mu, ok);
         const double bad = ipm::wmax(ok ? 0.0 : 1.0);
         if (bad > 0.0) return INF_;
-        return df * fsum + ipm::wsum(b);
+        return df * fsum + ipm::wsum(v);
     }
     // IPOPT's CalculateSafeSlack: a slack below eps min(1, mu) is raised to eps^(3/4) max(1, |bound|) by moving the bound
     __device__ __forceinline__ void safe1(double v, double& lo, bool lower, double s_min, double move) const {
@@ -386,20 +427,19 @@ struct Wave {
         }
     }
 
-    // ---- level 2 at the iterate: residuals, [A | B], stage block H (condensed rows, bounds, dw), gradient g, and what the step needs ----
-    // mode 0: the Newton system of the iterate (mu, dw);  mode 1: least-square multipliers (W = 0, Sigma = 1)
-    // outputs: LDS AB, H, G, C; registers: rc, r0, dv, fk; Jty (J' y of my variables), aj rows kept implicitly (recomputed in finish_step)
     struct Eval2 {
         double Jty[NV];          // J' y at my (x_k, u_k)
         double gfx[NX], gfu[NU]; // scaled objective gradient
     };
-    __device__ __forceinline__ void row_grad(const double pt[3][2], const double G2[2][NV], int j, double r[NV]) const {
-        const double cx = lds[L.OB + 3 * j], cz = lds[L.OB + 3 * j + 1];
+    // Every row gradient of a stage lies in the span of V = [G2[0], G2[1], e_0, e_1, e_3, e_4] (the gradient of the second barrier point and
+    // four unit vectors):  grad cbf_j = V c_j.  The rows of a stage are therefore accumulated as 6-vectors / 6 x 6 matrices and expanded once.
+    __device__ __forceinline__ double row_coeffs(const double pt[3][2], int j, double c[6]) const {
+        const double cx = lds[L.OB + 3 * j], cz = lds[L.OB + 3 * j + 1], d = P.radius + lds[L.OB + 3 * j + 2], off = P.beta * d * d;
         const double e0x = pt[0][0] - cx, e0z = pt[0][1] - cz, e1x = pt[1][0] - cx, e1z = pt[1][1] - cz, e2x = pt[2][0] - cx, e2z = pt[2][1] - cz;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) r[i] = 2.0 * w2 * (e2x * G2[0][i] + e2z * G2[1][i]);
-        r[0] += 2.0 * (w0 * e0x + w1 * e1x); r[1] += 2.0 * (w0 * e0z + w1 * e1z);
-        r[3] += 2.0 * w1 * e1x * P.dt; r[4] += 2.0 * w1 * e1z * P.dt;
+        c[0] = 2.0 * w2 * e2x; c[1] = 2.0 * w2 * e2z;
+        c[2] = 2.0 * (w0 * e0x + w1 * e1x); c[3] = 2.0 * (w0 * e0z + w1 * e1z);
+        c[4] = 2.0 * w1 * e1x * P.dt; c[5] = 2.0 * w1 * e1z * P.dt;
+        return w0 * (e0x * e0x + e0z * e0z - off) + w1 * (e1x * e1x + e1z * e1z - off) + w2 * (e2x * e2x + e2z * e2z - off);
     }
 
     // exchange through LDS: x_{k+1} (XS), u_{k-1} / u_{k+1} (US, slot k + 1 = u_k, slot 0 = u_prev), multipliers of the rows that DEFINE x_k (YS, slot k)
@@ -413,13 +453,13 @@ struct Wave {
 #pragma unroll
             for (int j = 0; j < NU; ++j) lds[L.US + (k + 1) * 4 + j] = u[j];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) lds[L.YS + (k + 1) * 6 + i] = dgc[i] * yc[i];
+            for (int i = 0; i < NX; ++i) lds[L.YS + (k + 1) * 6 + i] = dgc(i) * yc[i];
         }
         if (lane == 0) {
 #pragma unroll
             for (int j = 0; j < NU; ++j) lds[L.US + j] = uprev[j];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) lds[L.YS + i] = -y0[i];
+            for (int i = 0; i < NX; ++i) lds[L.YS + i] = -lds[L.Y0 + i];
         }
         if (lane == N) {
 #pragma unroll
@@ -428,17 +468,17 @@ struct Wave {
         sync();
     }
 
-    // The big one.  `build`: also write AB / H / G / C for the Riccati recursion with (mu, dw); ls: least-square system instead.
-    __device__ __forceinline__ void eval2(Eval2& E, bool build, bool ls, double mu, double dw, double& theta, double& fsum) {
+    // Level 2 at the iterate: residuals, J'y, and -- `build` -- the stage block for the recursion: [A | B], H (condensed rows, bounds, dw; every
+    // entry computed once and stored), gradient, defects.  ls: the least-square multiplier system (W = 0, Sigma = 1) instead of the Newton system.
+    template <bool build, bool ls>
+    __device__ __forceinline__ void eval2(Eval2& E, double mu, double dw, double& theta, double& fsum) {
         publish();
         double um[NU], un[NU];
 #pragma unroll
         for (int j = 0; j < NU; ++j) { um[j] = lds[L.US + k * 4 + j]; un[j] = lds[L.US + (k + 2 <= N + 1 ? k + 2 : N + 1) * 4 + j]; }
         const bool last = k == N - 1;
+        const double dt = P.dt;
         double th = 0.0;
-        double H[55], g[NV];
-#pragma unroll
-        for (int i = 0; i < 55; ++i) H[i] = 0.0;
         // scaled objective gradient
 #pragma unroll
         for (int i = 0; i < NX; ++i) E.gfx[i] = 0.0;
@@ -460,192 +500,208 @@ struct Wave {
 #pragma unroll
             for (int i = 0; i < NX; ++i) E.Jty[i] = -lds[L.YS + k * 6 + i];
         }
+        // diagonal of the block (objective, bound terms, dw) and the bound terms of the gradient
+        double dg_[NV], gb[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { dg_[i] = 0.0; gb[i] = 0.0; }
+        if (build) {
+            if (ls) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) dg_[i] = 1.0;
+                gb[2] = -zxL[0] + zxU[0]; gb[3] = -zxL[1] + zxU[1]; gb[4] = -zxL[2];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) gb[6 + j] = -zuL[j] + zuU[j];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) dg_[i] = 2.0 * df * P.Q[i] + dw;
+                const double sL[3] = {x[2] - xbL[0], x[3] - xbL[1], x[4] - xbL[2]}, sUp[2] = {xbU[0] - x[2], xbU[1] - x[3]};
+                dg_[2] += zxL[0] / sL[0] + zxU[0] / sUp[0]; dg_[3] += zxL[1] / sL[1] + zxU[1] / sUp[1]; dg_[4] += zxL[2] / sL[2];
+                gb[2] = -mu / sL[0] + mu / sUp[0]; gb[3] = -mu / sL[1] + mu / sUp[1]; gb[4] = -mu / sL[2] + O.kappa_d * mu;
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {
+                    const double a = u[j] - ubL[j], b = ubU[j] - u[j];
+                    dg_[6 + j] = 2.0 * df * P.R[j] * (last ? 1.0 : 2.0) + dw + zuL[j] / a + zuU[j] / b;
+                    gb[6 + j] = -mu / a + mu / b;
+                }
+            }
+        }
         if (stg) {
             D2 acc[3], gc[4][3];
             accel<D2>(P, d2var(x[2], 0), d2var(x[3], 1), d2var(x[4], 2), u, acc, gc);
-            const double dt = P.dt;
-            double xn[NX];
-            xn[0] = x[0] + dt * x[3]; xn[1] = x[1] + dt * x[4]; xn[2] = x[2] + dt * x[5];
-            xn[3] = x[3] + dt * acc[0].v; xn[4] = x[4] + dt * acc[1].v; xn[5] = x[5] + dt * acc[2].v;
+            {
+                double xn[NX];
+                xn[0] = x[0] + dt * x[3]; xn[1] = x[1] + dt * x[4]; xn[2] = x[2] + dt * x[5];
+                xn[3] = x[3] + dt * acc[0].v; xn[4] = x[4] + dt * acc[1].v; xn[5] = x[5] + dt * acc[2].v;
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { rc[i] = dgc[i] * (xn[i] - lds[L.XS + (k + 1) * 6 + i]); th += fabs(rc[i]); }
-            // [A | B]
-            double AB[NX][NV];
-#pragma unroll
-            for (int i = 0; i < NX; ++i)
-#pragma unroll
-                for (int c = 0; c < NV; ++c) AB[i][c] = (i == c) ? 1.0 : 0.0;
-            AB[0][3] = dt; AB[1][4] = dt; AB[2][5] = dt;
+                for (int i = 0; i < NX; ++i) { rc[i] = dgc(i) * (xn[i] - lds[L.XS + (k + 1) * 6 + i]); th += fabs(rc[i]); }
+            }
+            // rows 3..5 of [A | B] (rows 0..2 are e_i + dt e_{i+3}): columns 2, 3, 4 (theta, x_dot, z_dot) and 6..9 (inputs)
+            double a3[3][7];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) AB[3 + i][2 + c] += dt * acc[i].d[c];
+                for (int c = 0; c < 3; ++c) a3[i][c] = dt * acc[i].d[c] + ((i + 1 == c) ? 1.0 : 0.0);      // A[3+i][2+c]: the identity sits at column 3 + i
 #pragma unroll
-                for (int j = 0; j < NU; ++j) AB[3 + i][6 + j] = dt * gc[j][i].v;
+                for (int j = 0; j < NU; ++j) a3[i][3 + j] = dt * gc[j][i].v;
             }
-            // J' y: A' (dgc yc), B' (dgc yc)
+            // (A[5][5] = 1: theta_dot's own column carries no derivative of the accelerations)
+            if (build) {
+                ldsd* ABo = lds + L.AB + k * ABS;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) ABo[i * 7 + c] = a3[i][c];
+            }
+            // J' y of my dynamics rows: [A | B]' (dgc yc)
             {
                 double wy[NX];
 #pragma unroll
-                for (int i = 0; i < NX; ++i) wy[i] = dgc[i] * yc[i];
+                for (int i = 0; i < NX; ++i) wy[i] = dgc(i) * yc[i];
+                E.Jty[0] += wy[0]; E.Jty[1] += wy[1]; E.Jty[2] += wy[2];
+                E.Jty[3] += dt * wy[0]; E.Jty[4] += dt * wy[1]; E.Jty[5] += dt * wy[2] + wy[5];
 #pragma unroll
-                for (int c = 0; c < NV; ++c) {
-                    double v = 0.0;
+                for (int c = 0; c < 3; ++c) E.Jty[2 + c] += a3[0][c] * wy[3] + a3[1][c] * wy[4] + a3[2][c] * wy[5];
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) v += AB[i][c] * wy[i];
-                    E.Jty[c] += v;
-                }
+                for (int j = 0; j < NU; ++j) E.Jty[6 + j] += a3[0][3 + j] * wy[3] + a3[1][3 + j] * wy[4] + a3[2][3 + j] * wy[5];
             }
             double pt[3][2], G2[2][NV];
             points(x, acc[0].v, acc[1].v, pt);
+            // gradient of the second barrier point: e_c + 2 dt e_{3+c} + dt (row 3 + c of [A | B] minus its identity)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
 #pragma unroll
-                for (int i = 0; i < NV; ++i) G2[c][i] = dt * AB[3 + c][i];
+                for (int i = 0; i < NV; ++i) G2[c][i] = 0.0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) G2[c][2 + q] = dt * a3[c][q];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) G2[c][6 + j] = dt * a3[c][3 + j];
                 G2[c][c] += 1.0; G2[c][3 + c] += dt;
             }
-            // rows
-            double sl = 0.0, nu2[2] = {0.0, 0.0};
+            // rows: accumulated in the 6-dimensional span of V (row_coeffs)
+            double M[21], gv[6], jv[6], sl = 0.0;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) g[i] = 0.0;
+            for (int i = 0; i < 21; ++i) M[i] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { gv[i] = 0.0; jv[i] = 0.0; }
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
                 if (j < K) {
-                    double r[NV];
-                    row_grad(pt, G2, j, r);
-                    const double cv = cbf_value(pt, j);
-                    dv[j] = -dgd[j] * cv;
+                    double c[6];
+                    const double cv = row_coeffs(pt, j, c);
+                    const double sc = dgd(j);
+                    dv[j] = -sc * cv;
                     const double rd = dv[j] - s[j];
                     th += fabs(rd);
-                    const double om = dgd[j] * yd[j];                               // weight of grad^2 (-cbf_j) in the Hessian of the Lagrangian
-                    // J' y: yd_j * grad d_j = -om r
+                    const double om = sc * yd[j];                                   // weight of grad^2 (-cbf_j) in the Hessian of the Lagrangian
 #pragma unroll
-                    for (int i = 0; i < NV; ++i) E.Jty[i] -= om * r[i];
+                    for (int i = 0; i < 6; ++i) jv[i] += om * c[i];                 // J' y: yd_j * grad d_j = -om V c
+                    sl += om;
                     if (build) {
                         double Ej, bd;
                         if (ls) { Ej = 1.0; bd = -vU[j]; }                           // q = 1, rhs_t = -(0 + vU), rhs_g = 0: b = q rhs_t
                         else {
                             const double stU = sU[j] - s[j];
-                            const double sig = vU[j] / stU;
-                            Ej = sig + dw;
+                            Ej = vU[j] / stU + dw;
                             const double gt = mu / stU - O.kappa_d * mu;
                             bd = -rd + (yd[j] - gt) / Ej;
                         }
-                        // a_j = -dgd r; H += E a a', g -= a E b
-                        const double ea = Ej * dgd[j] * dgd[j], eb = Ej * bd * dgd[j];
+                        // a_j = -dgd V c; H += E a a' = V (ea c c') V', g -= a E b = V (eb c)
+                        const double ea = Ej * sc * sc, eb = Ej * bd * sc;
+                        int e = 0;
 #pragma unroll
-                        for (int a = 0; a < NV; ++a) {
-                            g[a] += eb * r[a];
+                        for (int a = 0; a < 6; ++a) {
+                            gv[a] += eb * c[a];
 #pragma unroll
-                            for (int b = a; b < NV; ++b) H[sym(a, b)] += ea * r[a] * r[b];
+                            for (int b = a; b < 6; ++b, ++e) M[e] += ea * c[a] * c[b];
                         }
-                    }
-                    if (!ls) {
-                        sl += om;
-                        nu2[0] -= 2.0 * w2 * om * (pt[2][0] - lds[L.OB + 3 * j]); nu2[1] -= 2.0 * w2 * om * (pt[2][1] - lds[L.OB + 3 * j + 1]);
                     }
                 } else dv[j] = 0.0;
             }
-            if (build && !ls) {
-                // curvature of -cbf in the points: -2 sl (w0 G0'G0 + w1 G1'G1 + w2 G2'G2)
-                const double o0 = -2.0 * w0 * sl, o1 = -2.0 * w1 * sl, o2 = -2.0 * w2 * sl;
-                H[sym(0, 0)] += o0 + o1; H[sym(1, 1)] += o0 + o1;
-                H[sym(0, 3)] += o1 * dt; H[sym(1, 4)] += o1 * dt; H[sym(3, 3)] += o1 * dt * dt; H[sym(4, 4)] += o1 * dt * dt;
+            // Jty -= V jv
 #pragma unroll
-                for (int a = 0; a < NV; ++a)
-#pragma unroll
-                    for (int b = a; b < NV; ++b) H[sym(a, b)] += o2 * (G2[0][a] * G2[0][b] + G2[1][a] * G2[1][b]);
-                // second derivatives of the dynamics: weights dgc y (rows 3..5) + dt nu2 through the second barrier point
-                const double cc[3] = {(dgc[3] * yc[3] + dt * nu2[0]) * dt, (dgc[4] * yc[4] + dt * nu2[1]) * dt, dgc[5] * yc[5] * dt};
-                int e = 0;
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int b = a; b < 3; ++b, ++e) H[sym(2 + a, 2 + b)] += cc[0] * acc[0].h[e] + cc[1] * acc[1].h[e] + cc[2] * acc[2].h[e];
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int j = 0; j < NU; ++j) H[sym(2 + a, 6 + j)] += cc[0] * gc[j][0].d[a] + cc[1] * gc[j][1].d[a] + cc[2] * gc[j][2].d[a];
-            }
+            for (int a = 0; a < NV; ++a) E.Jty[a] -= G2[0][a] * jv[0] + G2[1][a] * jv[1];
+            E.Jty[0] -= jv[2]; E.Jty[1] -= jv[3]; E.Jty[3] -= jv[4]; E.Jty[4] -= jv[5];
             if (build) {
-                ldsd* ABo = lds + L.AB + k * 60;
+                // M index of (a, b), a <= b, in the 6 x 6 upper packing: 0:(0,0) 1:(0,1) .. 5:(0,5) 6:(1,1) .. 10:(1,5) 11:(2,2) .. 14:(2,5) 15:(3,3) 16:(3,4) 17:(3,5) 18:(4,4) 19:(4,5) 20:(5,5)
+                double cc[3] = {0.0, 0.0, 0.0};
+                if (!ls) {
+                    // curvature of -cbf in the points: -2 sl (w0 G0'G0 + w1 G1'G1 + w2 G2'G2), in the same span
+                    const double o0 = -2.0 * w0 * sl, o1 = -2.0 * w1 * sl, o2 = -2.0 * w2 * sl;
+                    M[0] += o2; M[6] += o2;
+                    M[11] += o0 + o1; M[15] += o0 + o1; M[13] += o1 * dt; M[17] += o1 * dt; M[18] += o1 * dt * dt; M[20] += o1 * dt * dt;
+                    // second derivatives of the dynamics: weights dgc y (rows 3..5) + dt nu2 through the second barrier point, nu2 = -(jv[0], jv[1])
+                    cc[0] = (dgc(3) * yc[3] - dt * jv[0]) * dt; cc[1] = (dgc(4) * yc[4] - dt * jv[1]) * dt; cc[2] = dgc(5) * yc[5] * dt;
+                }
+                // H[a][b] = sum_q t_a[q] V[b][q] with t_a[q] = sum_p V[a][p] M[p][q]  (+ dynamics curvature, + diagonal): computed once, stored
+                const int U4[4] = {0, 1, 3, 4};
+                auto Mi = [](int a, int b) { return a <= b ? a * 6 - a * (a - 1) / 2 + (b - a) : b * 6 - b * (b - 1) / 2 + (a - b); };
+                ldsd* Ho = lds + L.H + k * 55; ldsd* Go = lds + L.G + k * 10;
 #pragma unroll
-                for (int i = 0; i < NX; ++i)
+                for (int a = 0; a < NV; ++a) {
+                    double ta[6];
 #pragma unroll
-                    for (int c = 0; c < NV; ++c) ABo[i * 10 + c] = AB[i][c];
+                    for (int q = 0; q < 6; ++q) {
+                        double v = G2[0][a] * M[Mi(0, q)] + G2[1][a] * M[Mi(1, q)];
+#pragma unroll
+                        for (int pp = 0; pp < 4; ++pp) if (U4[pp] == a) v += M[Mi(2 + pp, q)];
+                        ta[q] = v;
+                    }
+#pragma unroll
+                    for (int b = a; b < NV; ++b) {
+                        double v = ta[0] * G2[0][b] + ta[1] * G2[1][b];
+#pragma unroll
+                        for (int pp = 0; pp < 4; ++pp) if (U4[pp] == b) v += ta[2 + pp];
+                        if (a == b) v += dg_[a];
+                        if (a >= 2 && a <= 4 && b <= 4) {
+                            const int e = (a - 2) * 3 - (a - 2) * (a - 3) / 2 + (b - a);         // (a-2, b-2) in the 3 x 3 upper packing 00 01 02 11 12 22
+                            v += cc[0] * acc[0].h[e] + cc[1] * acc[1].h[e] + cc[2] * acc[2].h[e];
+                        }
+                        if (a >= 2 && a <= 4 && b >= 6) v += cc[0] * gc[b - 6][0].d[a - 2] + cc[1] * gc[b - 6][1].d[a - 2] + cc[2] * gc[b - 6][2].d[a - 2];
+                        Ho[sym(a, b)] = v;
+                    }
+                    double gval = gb[a] + G2[0][a] * gv[0] + G2[1][a] * gv[1] + (a < NX ? E.gfx[a] : E.gfu[a - NX]) + (ls ? 0.0 : E.Jty[a]);
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) if (U4[pp] == a) gval += gv[2 + pp];
+                    Go[a] = gval;
+                }
+                // defects (unscaled) of my dynamics rows -> C[k + 1] = rc / dgc (ls: 0)
+#pragma unroll
+                for (int i = 0; i < NX; ++i) lds[L.C + (k + 1) * 6 + i] = ls ? 0.0 : rc[i] / dgc(i);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NX; ++i) rc[i] = 0.0;
 #pragma unroll
             for (int j = 0; j < KS; ++j) dv[j] = 0.0;
+            if (build && lane == N) {                                       // terminal state: diagonal block, gradient
+                ldsd* Ho = lds + L.H + N * 55; ldsd* Go = lds + L.G + N * 10;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) g[i] = 0.0;
-        }
+                for (int a = 0; a < NX; ++a) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { r0[i] = lane == 0 ? x[i] - x0[i] : 0.0; th += fabs(r0[i]); }
-        theta = ipm::wsum(th);
-        fk = cost_share(x, u, um);
-        fsum = ipm::wsum(fk);
-        if (!build) return;
-        // objective Hessian, bounds, dw; gradient g = (barrier gradient) + J'y - (condensed rows' part, already in g)
-        if (act) {
-            if (ls) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i) H[sym(i, i)] += 1.0;
-                g[2] += -zxL[0] + zxU[0]; g[3] += -zxL[1] + zxU[1]; g[4] += -zxL[2];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) g[i] += E.gfx[i];
-            } else {
-#pragma unroll
-                for (int i = 0; i < NX; ++i) H[sym(i, i)] += 2.0 * df * P.Q[i] + dw;
-                const double sL[3] = {x[2] - xbL[0], x[3] - xbL[1], x[4] - xbL[2]}, sUp[2] = {xbU[0] - x[2], xbU[1] - x[3]};
-                H[sym(2, 2)] += zxL[0] / sL[0] + zxU[0] / sUp[0]; H[sym(3, 3)] += zxL[1] / sL[1] + zxU[1] / sUp[1]; H[sym(4, 4)] += zxL[2] / sL[2];
-                g[2] += -mu / sL[0] + mu / sUp[0]; g[3] += -mu / sL[1] + mu / sUp[1]; g[4] += -mu / sL[2] + O.kappa_d * mu;
-#pragma unroll
-                for (int i = 0; i < NX; ++i) g[i] += E.gfx[i] + E.Jty[i];
-            }
-        }
-        if (stg) {
-#pragma unroll
-            for (int j = 0; j < NU; ++j) {
-                if (ls) { H[sym(6 + j, 6 + j)] += 1.0; g[6 + j] += E.gfu[j] - zuL[j] + zuU[j]; }
-                else {
-                    const double a = u[j] - ubL[j], b = ubU[j] - u[j];
-                    H[sym(6 + j, 6 + j)] += 2.0 * df * P.R[j] * (last ? 1.0 : 2.0) + dw + zuL[j] / a + zuU[j] / b;
-                    g[6 + j] += E.gfu[j] + E.Jty[6 + j] - mu / a + mu / b;
+                    for (int b = a; b < NX; ++b) Ho[sym(a, b)] = a == b ? dg_[a] : 0.0;
+                    Go[a] = gb[a] + E.gfx[a] + (ls ? 0.0 : E.Jty[a]);
                 }
             }
         }
-        if (act) {
-            ldsd* Ho = lds + L.H + k * 55; ldsd* Go = lds + L.G + k * 10;
+        if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 55; ++i) Ho[i] = H[i];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) Go[i] = g[i];
-            // defects (unscaled): dynamics of my stage -> C[k + 1] = -b / dgc with b = -rc (ls: b = 0); C[0] = dx_0 = b_0 = -r0 (ls: 0)
-            if (stg) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i) lds[L.C + (k + 1) * 6 + i] = ls ? 0.0 : rc[i] / dgc[i];
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i) lds[L.C + i] = ls ? 0.0 : -r0[i];
+            for (int i = 0; i < NX; ++i) {
+                const double r0 = x[i] - x0[i];
+                th += fabs(r0);
+                if (build) lds[L.C + i] = ls ? 0.0 : -r0;                  // C[0] = dx_0 = b_0 = -r0
             }
         }
-        sync();
+        theta = ipm::wsum(th);
+        fsum = ipm::wsum(cost_share(x, u, um));
+        if (build) sync();
     }
 
-    // after riccati_backward / forward: my dx, du from LDS, the costate sweep, the multiplier steps of my rows and bounds
+    // after riccati_backward / forward: the costate sweep, the multiplier steps of my rows and bounds (dx, du stay in LDS: DX, DU; dy in LAM)
     __device__ __forceinline__ void finish_step(bool ls, double mu, double dw) {
         sync();
-        if (act) {
+        double dx[NX], du[NU];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) dx[i] = lds[L.DX + k * 6 + i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) dx[i] = 0.0;
-        }
+        for (int i = 0; i < NX; ++i) dx[i] = act ? lds[L.DX + k * 6 + i] : 0.0;
 #pragma unroll
         for (int j = 0; j < NU; ++j) du[j] = stg ? lds[L.DU + k * NU + j] : 0.0;
         // h_k = (H dw + g)_x
@@ -664,39 +720,30 @@ struct Wave {
             }
         }
         sync();
-        costates(lds, L, N, lane);
-        if (stg) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) dyc[i] = lds[L.LAM + (k + 1) * 6 + i] / dgc[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) dyc[i] = 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) dy0[i] = lane == 0 ? -lds[L.LAM + i] : 0.0;
+        costates(lds, L, N, lane, P.dt);
         // rows: dy_d = E (a . dw - b), ds = q (rhs_t + dy_d), dvU
         if (stg) {
-            double acc[3], gc[4][3], pt[3][2], G2[2][NV];
+            double acc[3], gc[4][3], pt[3][2];
             accel<double>(P, x[2], x[3], x[4], u, acc, gc);
             points(x, acc[0], acc[1], pt);
-            const ldsd* AB = lds + L.AB + k * 60;
+            const ldsd* A3 = lds + L.AB + k * ABS;
+            // vd = V' (dx, du): grad p2_c = e_c + 2 dt e_{3+c} + dt (row 3 + c of [A | B] - e_{3+c})
+            double vd[6] = {dx[0] + P.dt * dx[3], dx[1] + P.dt * dx[4], dx[0], dx[1], dx[3], dx[4]};
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-#pragma unroll
-                for (int i = 0; i < NV; ++i) G2[c][i] = P.dt * AB[(3 + c) * 10 + i];
-                G2[c][c] += 1.0; G2[c][3 + c] += P.dt;
+                const ldsd* row = A3 + c * 7;
+                const double v = row[0] * dx[2] + row[1] * dx[3] + row[2] * dx[4] + row[3] * du[0] + row[4] * du[1] + row[5] * du[2] + row[6] * du[3];
+                vd[c] += P.dt * v;
             }
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
                 if (j < K) {
-                    double r[NV];
-                    row_grad(pt, G2, j, r);
+                    double c[6];
+                    row_coeffs(pt, j, c);
                     double adw = 0.0;
 #pragma unroll
-                    for (int i = 0; i < NX; ++i) adw += r[i] * dx[i];
-#pragma unroll
-                    for (int i = 0; i < NU; ++i) adw += r[6 + i] * du[i];
-                    adw *= -dgd[j];
+                    for (int i = 0; i < 6; ++i) adw += c[i] * vd[i];
+                    adw *= -dgd(j);
                     if (ls) { dyd[j] = adw + vU[j]; ds[j] = 0.0; dvU[j] = 0.0; }
                     else {
                         const double stU = sU[j] - s[j], sig = vU[j] / stU, Ej = sig + dw, gt = mu / stU - O.kappa_d * mu;
@@ -734,27 +781,6 @@ struct Wave {
         }
     }
 
-    // Algorithm IC around the recursion; false: delta_w beyond its maximum
-    __device__ __forceinline__ bool factor_and_solve(Eval2& E, bool ls, double mu, double& theta, double& fsum) {
-        double dw = 0.0;
-        bool first = true;
-        const double c0 = ls ? 0.0 : 2.0 * df * P.R[0], c1 = ls ? 0.0 : 2.0 * df * P.R[1], c2 = ls ? 0.0 : 2.0 * df * P.R[2], c3 = ls ? 0.0 : 2.0 * df * P.R[3];
-        for (;;) {
-            eval2(E, true, ls, mu, dw, theta, fsum);
-            if (riccati_backward(lds, L, N, lane, c0, c1, c2, c3)) break;
-            if (first) {
-                first = false;
-                dw = dw_last == 0.0 ? O.first_hessian_perturbation : fmax(O.min_hessian_perturbation, O.perturb_dec_fact * dw_last);
-            } else dw *= dw_last == 0.0 ? O.perturb_inc_fact_first : O.perturb_inc_fact;
-            if (dw > O.max_hessian_perturbation) return false;
-        }
-        if (dw > 0.0 && !ls) dw_last = dw;
-        last_dw = dw;
-        riccati_forward(lds, L, N, lane);
-        finish_step(ls, mu, dw);
-        return true;
-    }
-
     // ---- optimality error (eq. (5)): E_mu and its parts ---------------------------------------------------------------------------------
     __device__ __forceinline__ void errors(const Eval2& E, double mu, double& Emu, double& dinf, double& pinf, double& comp, double& un_pinf) const {
         double d = 0.0, p = 0.0, c = 0.0, ysum = 0.0, zsum = 0.0, up = 0.0;
@@ -779,13 +805,13 @@ struct Wave {
                 zsum += fabs(zuL[j]) + fabs(zuU[j]);
             }
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { p = fmax(p, fabs(rc[i])); up = fmax(up, fabs(rc[i] / dgc[i])); ysum += fabs(yc[i]); }
+            for (int i = 0; i < NX; ++i) { p = fmax(p, fabs(rc[i])); up = fmax(up, fabs(rc[i] / dgc(i))); ysum += fabs(yc[i]); }
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
                 if (j < K) {
                     d = fmax(d, fabs(-yd[j] + vU[j]));
                     const double rd = dv[j] - s[j];
-                    p = fmax(p, fabs(rd)); up = fmax(up, fabs(rd / dgd[j]));
+                    p = fmax(p, fabs(rd)); up = fmax(up, fabs(rd / dgd(j)));
                     c = fmax(c, fabs((sU[j] - s[j]) * vU[j] - mu));
                     ysum += fabs(yd[j]); zsum += fabs(vU[j]);
                 }
@@ -793,7 +819,7 @@ struct Wave {
         }
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) { p = fmax(p, fabs(r0[i])); up = fmax(up, fabs(r0[i])); ysum += fabs(y0[i]); }
+            for (int i = 0; i < NX; ++i) { const double r0 = fabs(x[i] - x0[i]); p = fmax(p, r0); up = fmax(up, r0); ysum += fabs(lds[L.Y0 + i]); }
         }
         dinf = ipm::wmax(d); pinf = ipm::wmax(p); comp = ipm::wmax(c); un_pinf = ipm::wmax(up);
         ysum = ipm::wsum(ysum); zsum = ipm::wsum(zsum);
@@ -802,48 +828,42 @@ struct Wave {
         Emu = fmax(fmax(dinf / sd, pinf), comp / sc);
     }
 
-    // fraction to the boundary over my primal / dual variables
+    // fraction to the boundary over my primal / dual variables; directional derivative of the barrier function along the step
     __device__ __forceinline__ double ftb1(double tau, double sl, double dsl) const { return dsl < 0.0 ? fmin(1.0, -tau * sl / dsl) : 1.0; }
-    __device__ __forceinline__ void step_lengths(double tau, double& a_max, double& a_z) const {
-        double ap = 1.0, az = 1.0;
+    __device__ __forceinline__ void step_lengths(const Eval2& E, double tau, double mu, double& a_max, double& a_z, double& gBD) const {
+        double ap = 1.0, az = 1.0, v = 0.0;
         if (act) {
-            ap = fmin(ap, ftb1(tau, x[2] - xbL[0], dx[2])); ap = fmin(ap, ftb1(tau, x[3] - xbL[1], dx[3])); ap = fmin(ap, ftb1(tau, x[4] - xbL[2], dx[4]));
-            ap = fmin(ap, ftb1(tau, xbU[0] - x[2], -dx[2])); ap = fmin(ap, ftb1(tau, xbU[1] - x[3], -dx[3]));
+            double dx[NX];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) dx[i] = lds[L.DX + k * 6 + i];
+            const double sL[3] = {x[2] - xbL[0], x[3] - xbL[1], x[4] - xbL[2]}, sUp[2] = {xbU[0] - x[2], xbU[1] - x[3]};
+            ap = fmin(ap, ftb1(tau, sL[0], dx[2])); ap = fmin(ap, ftb1(tau, sL[1], dx[3])); ap = fmin(ap, ftb1(tau, sL[2], dx[4]));
+            ap = fmin(ap, ftb1(tau, sUp[0], -dx[2])); ap = fmin(ap, ftb1(tau, sUp[1], -dx[3]));
 #pragma unroll
             for (int i = 0; i < 3; ++i) az = fmin(az, ftb1(tau, zxL[i], dzxL[i]));
 #pragma unroll
             for (int i = 0; i < 2; ++i) az = fmin(az, ftb1(tau, zxU[i], dzxU[i]));
-        }
-        if (stg) {
-#pragma unroll
-            for (int j = 0; j < NU; ++j) {
-                ap = fmin(ap, ftb1(tau, u[j] - ubL[j], du[j])); ap = fmin(ap, ftb1(tau, ubU[j] - u[j], -du[j]));
-                az = fmin(az, ftb1(tau, zuL[j], dzuL[j])); az = fmin(az, ftb1(tau, zuU[j], dzuU[j]));
-            }
-#pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                if (j < K) { ap = fmin(ap, ftb1(tau, sU[j] - s[j], -ds[j])); az = fmin(az, ftb1(tau, vU[j], dvU[j])); }
-            }
-        }
-        a_max = ipm::wmin(ap); a_z = ipm::wmin(az);
-    }
-
-    // directional derivative of the barrier function along (dx, du, ds)
-    __device__ __forceinline__ double barrier_dir(const Eval2& E, double mu) const {
-        double v = 0.0;
-        if (act) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) v += E.gfx[i] * dx[i];
-            const double sL[3] = {x[2] - xbL[0], x[3] - xbL[1], x[4] - xbL[2]}, sUp[2] = {xbU[0] - x[2], xbU[1] - x[3]};
             v += (-mu / sL[0] + mu / sUp[0]) * dx[2] + (-mu / sL[1] + mu / sUp[1]) * dx[3] + (-mu / sL[2] + O.kappa_d * mu) * dx[4];
         }
         if (stg) {
 #pragma unroll
-            for (int j = 0; j < NU; ++j) v += (E.gfu[j] - mu / (u[j] - ubL[j]) + mu / (ubU[j] - u[j])) * du[j];
+            for (int j = 0; j < NU; ++j) {
+                const double duj = lds[L.DU + k * NU + j];
+                ap = fmin(ap, ftb1(tau, u[j] - ubL[j], duj)); ap = fmin(ap, ftb1(tau, ubU[j] - u[j], -duj));
+                az = fmin(az, ftb1(tau, zuL[j], dzuL[j])); az = fmin(az, ftb1(tau, zuU[j], dzuU[j]));
+                v += (E.gfu[j] - mu / (u[j] - ubL[j]) + mu / (ubU[j] - u[j])) * duj;
+            }
 #pragma unroll
-            for (int j = 0; j < KS; ++j) if (j < K) v += (mu / (sU[j] - s[j]) - O.kappa_d * mu) * ds[j];
+            for (int j = 0; j < KS; ++j) {
+                if (j < K) {
+                    ap = fmin(ap, ftb1(tau, sU[j] - s[j], -ds[j])); az = fmin(az, ftb1(tau, vU[j], dvU[j]));
+                    v += (mu / (sU[j] - s[j]) - O.kappa_d * mu) * ds[j];
+                }
+            }
         }
-        return ipm::wsum(v);
+        a_max = ipm::wmin(ap); a_z = ipm::wmin(az); gBD = ipm::wsum(v);
     }
 
     // ---- filter ---------------------------------------------------------------------------------------------------------------------
@@ -879,15 +899,15 @@ struct Wave {
         if (fu) v = fmin(v, hi - fmin(k1 * fmax(1.0, fabs(hi)), k2 * rng));
     }
 
-    __device__ void solve(int& status_out, int& iters_out, double* trace) {
+    __device__ SC_MS_SOLVE_INLINE void solve(int& status_out, int& iters_out, double* trace) {
         const double rl = O.bound_relax_factor;
         // ---- start: x_k = x0, u_k = u_prev (set_initial_guess); scaling at that point; bounds relaxed; push ----
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { x[i] = x0[i]; yc[i] = 0.0; y0[i] = 0.0; dgc[i] = 1.0; }
+        for (int i = 0; i < NX; ++i) { x[i] = x0[i]; yc[i] = 0.0; }
 #pragma unroll
         for (int j = 0; j < NU; ++j) u[j] = uprev[j];
 #pragma unroll
-        for (int j = 0; j < KS; ++j) { s[j] = 0.0; yd[j] = 0.0; vU[j] = 1.0; sU[j] = 0.0; dgd[j] = 1.0; }
+        for (int j = 0; j < KS; ++j) { s[j] = 0.0; yd[j] = 0.0; vU[j] = 1.0; sU[j] = rl; }
         {
             const double lo[3] = {-P.pitch_max, -P.v_max, -P.descent_max}, hi[2] = {P.pitch_max, P.v_max};
 #pragma unroll
@@ -900,7 +920,7 @@ struct Wave {
                 zuL[j] = 1.0; zuU[j] = 1.0;
             }
         }
-        // gradient-based scaling at the user's starting point (every stage is the same point there)
+        // gradient-based scaling at the user's starting point (every stage is the same point there): df, and the row scales into LDS
         {
             double gm = fmax(2.0 * P.Q[0] * fabs(x0[0] - xg[0]), 2.0 * P.Q[1] * fabs(x0[1] - xg[1]));
 #pragma unroll
@@ -910,7 +930,7 @@ struct Wave {
             accel<D2>(P, d2var(x0[2], 0), d2var(x0[3], 1), d2var(x0[4], 2), uprev, acc, gc);
             const double dt = P.dt;
             double G2[2][NV], pt[3][2];
-            double ABr[3][NV];
+            double ABr[3][NV], scl[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -922,7 +942,7 @@ struct Wave {
                 double rm = 1.0;
 #pragma unroll
                 for (int c = 0; c < NV; ++c) rm = fmax(rm, fabs(ABr[i][c]));
-                dgc[3 + i] = rm > O.nlp_scaling_max_gradient ? fmax(O.nlp_scaling_min_value, O.nlp_scaling_max_gradient / rm) : 1.0;
+                scl[i] = rm > O.nlp_scaling_max_gradient ? fmax(O.nlp_scaling_min_value, O.nlp_scaling_max_gradient / rm) : 1.0;
             }
             points(x0, acc[0].v, acc[1].v, pt);
 #pragma unroll
@@ -931,50 +951,203 @@ struct Wave {
                 for (int i = 0; i < NV; ++i) G2[c][i] = dt * ABr[c][i];
                 G2[c][c] += 1.0; G2[c][3 + c] += dt;
             }
+            sync();
+            if (lane == 0) {
+                lds[L.SC + 0] = 1.0; lds[L.SC + 1] = 1.0; lds[L.SC + 2] = 1.0; lds[L.SC + 3] = scl[0]; lds[L.SC + 4] = scl[1]; lds[L.SC + 5] = scl[2];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) lds[L.Y0 + i] = 0.0;
+            }
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
+                double sc = 1.0;
                 if (j < K) {
-                    double r[NV];
-                    row_grad(pt, G2, j, r);
+                    double c[6], r[NV];
+                    row_coeffs(pt, j, c);
+#pragma unroll
+                    for (int a = 0; a < NV; ++a) r[a] = G2[0][a] * c[0] + G2[1][a] * c[1];
+                    r[0] += c[2]; r[1] += c[3]; r[3] += c[4]; r[4] += c[5];
                     double rm = 0.0;
 #pragma unroll
                     for (int i = 0; i < NV; ++i) rm = fmax(rm, fabs(r[i]));
-                    dgd[j] = rm > O.nlp_scaling_max_gradient ? fmax(O.nlp_scaling_min_value, O.nlp_scaling_max_gradient / rm) : 1.0;
-                    sU[j] = 0.0 + rl * 1.0;
+                    sc = rm > O.nlp_scaling_max_gradient ? fmax(O.nlp_scaling_min_value, O.nlp_scaling_max_gradient / rm) : 1.0;
                 }
+                if (lane == 0) lds[L.SC + 6 + j] = sc;
             }
+            sync();
         }
         push1(x[2], xbL[0], xbU[0], true, true); push1(x[3], xbL[1], xbU[1], true, true); push1(x[4], xbL[2], 0.0, true, false);
 #pragma unroll
         for (int j = 0; j < NU; ++j) push1(u[j], ubL[j], ubU[j], true, true);
+        // One pass of the loop = one evaluation at the iterate + what the phase does with it (a single call site of every big routine keeps
+        // the code, and the register allocator's problem, small):
+        //   PH_INIT   first evaluation: slacks from the row values                          -> PH_LS
+        //   PH_LS     least-square multiplier system: recursion, multipliers                  -> PH_START
+        //   PH_START  evaluation with the multipliers: theta_0 for the filter's limits       -> (as PH_EVAL)
+        //   PH_EVAL   errors, convergence tests, barrier parameter                            -> PH_BUILD
+        //   PH_BUILD  Newton system with (mu, dw): recursion (Algorithm IC: PH_BUILD again with a larger dw), step, line search, update -> PH_EVAL
+        enum { PH_INIT, PH_LS, PH_START, PH_EVAL, PH_BUILD };
         Eval2 E;
-        double theta, fsum;
-        double mu = O.mu_init;
-        eval2(E, false, false, mu, 0.0, theta, fsum);
-#pragma unroll
-        for (int j = 0; j < KS; ++j) if (j < K) { double v = dv[j]; push1(v, 0.0, sU[j], false, true); s[j] = v; }
-        // least-square multipliers
-        if (factor_and_solve(E, true, mu, theta, fsum)) {
-            double ym = 0.0;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) ym = fmax(ym, fmax(fabs(dyc[i]), fabs(dy0[i])));
-#pragma unroll
-            for (int j = 0; j < KS; ++j) ym = fmax(ym, fabs(dyd[j]));
-            ym = ipm::wmax(ym);
-            if (ym <= O.constr_mult_init_max) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i) { yc[i] = dyc[i]; y0[i] = dy0[i]; }
-#pragma unroll
-                for (int j = 0; j < KS; ++j) yd[j] = dyd[j];
-            }
-        }
-        double tau = fmax(O.tau_min, 1.0 - mu);
-        eval2(E, false, false, mu, 0.0, theta, fsum);
-        const double theta_max = O.theta_max_fact * fmax(1.0, theta), theta_min = O.theta_min_fact * fmax(1.0, theta);
+        double theta = 0.0, fsum = 0.0;
+        double mu = O.mu_init, tau = fmax(O.tau_min, 1.0 - mu);
+        double theta_max = INF_, theta_min = 0.0;
         const double mu_min = fmin(O.tol, O.compl_inf_tol) / (O.barrier_tol_factor + 1.0);
-        int it = 0, n_acc = 0, status = SC_STATUS_INACCURATE;
-        double last_alpha = 0.0;
+        int it = 0, n_acc = 0, status = SC_STATUS_INACCURATE, phase = PH_INIT;
+        double last_alpha = 0.0, dw = 0.0;
+        bool ic_first = true;
         for (;;) {
+            MPROF_T0
+            const bool ls = phase == PH_LS, build = phase == PH_LS || phase == PH_BUILD;
+            if (phase == PH_BUILD) eval2<true, false>(E, mu, dw, theta, fsum);
+            else if (phase == PH_LS) eval2<true, true>(E, mu, dw, theta, fsum);
+            else eval2<false, false>(E, mu, dw, theta, fsum);
+            if (phase == PH_INIT) {
+#pragma unroll
+                for (int j = 0; j < KS; ++j) if (j < K) { double v = dv[j]; push1(v, 0.0, sU[j], false, true); s[j] = v; }
+                phase = PH_LS; dw = 0.0; ic_first = true;
+                continue;
+            }
+            if (build) {
+                MPROF_ADD(2)
+                const double cs = ls ? 0.0 : 2.0 * df;
+                const bool okf = riccati_backward(lds, L, N, lane, P.dt, cs * P.R[0], cs * P.R[1], cs * P.R[2], cs * P.R[3]);
+                MPROF_ADD(3)
+                if (!okf) {                                                 // Algorithm IC: the same system with a larger delta_w
+                    if (ic_first) {
+                        ic_first = false;
+                        dw = dw_last == 0.0 ? O.first_hessian_perturbation : fmax(O.min_hessian_perturbation, O.perturb_dec_fact * dw_last);
+                    } else dw *= dw_last == 0.0 ? O.perturb_inc_fact_first : O.perturb_inc_fact;
+                    if (dw > O.max_hessian_perturbation) {
+                        if (ls) { phase = PH_START; continue; }             // (no least-square estimate: multipliers stay zero)
+                        status = SC_STATUS_NEEDS_RESTO; break;
+                    }
+                    continue;
+                }
+                if (dw > 0.0 && !ls) dw_last = dw;
+                last_dw = dw;
+                riccati_forward(lds, L, N, lane, P.dt);
+                MPROF_ADD(4)
+                finish_step(ls, mu, dw);
+                MPROF_ADD(5)
+                if (ls) {
+                    double ym = 0.0;
+                    if (stg) {
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) ym = fmax(ym, fabs(lds[L.LAM + (k + 1) * 6 + i] / dgc(i)));
+                    }
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) ym = fmax(ym, fabs(lds[L.LAM + i]));
+                    }
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) ym = fmax(ym, fabs(dyd[j]));
+                    ym = ipm::wmax(ym);
+                    if (ym <= O.constr_mult_init_max) {
+                        if (stg) {
+#pragma unroll
+                            for (int i = 0; i < NX; ++i) yc[i] = lds[L.LAM + (k + 1) * 6 + i] / dgc(i);
+                        }
+                        if (lane == 0) {
+#pragma unroll
+                            for (int i = 0; i < NX; ++i) lds[L.Y0 + i] = -lds[L.LAM + i];
+                        }
+#pragma unroll
+                        for (int j = 0; j < KS; ++j) yd[j] = dyd[j];
+                    }
+                    phase = PH_START;
+                    continue;
+                }
+                // ---- filter line search ----
+                double a_max, a_z, gBD;
+                step_lengths(E, tau, mu, a_max, a_z, gBD);
+                const double phi = barrier(fsum, x, u, s, mu);
+                double a_min = O.gamma_theta;
+                if (gBD < 0.0) {
+                    a_min = fmin(a_min, O.gamma_phi * theta / (-gBD));
+                    if (theta <= theta_min) a_min = fmin(a_min, O.delta * pow(theta, O.s_theta) / pow(-gBD, O.s_phi));
+                }
+                a_min *= O.alpha_min_frac;
+                const double sw_l = gBD < 0.0 ? pow(-gBD, O.s_phi) : 0.0, sw_r = O.delta * pow(theta, O.s_theta);
+                double alpha = a_max;
+                bool first = true, accepted = false;
+                double xt[NX], ut[NU], st[KS];
+                double phi_t = 0.0, th_t = 0.0;
+                while (alpha > a_min || first) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) xt[i] = x[i] + alpha * (act ? lds[L.DX + k * 6 + i] : 0.0);
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) ut[j] = u[j] + alpha * (stg ? lds[L.DU + k * NU + j] : 0.0);
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) st[j] = s[j] + alpha * ds[j];
+                    safe_slacks(xt, ut, st, mu);
+                    double f_t;
+                    eval0(xt, ut, st, th_t, f_t);
+                    phi_t = barrier(f_t, xt, ut, st, mu);
+                    if (phi_t < INF_ && th_t == th_t && phi_t == phi_t) {
+                        bool ok = th_t <= theta_max;
+                        if (ok) {
+                            const bool ftype = gBD < 0.0 && alpha * sw_l > sw_r;
+                            if (alpha > 0.0 && ftype && theta <= theta_min) ok = cmp_le(phi_t - phi, O.eta_phi * alpha * gBD, phi);
+                            else {
+                                ok = true;
+                                if (phi_t > phi) {
+                                    const double bas = fabs(phi) > 10.0 ? fmax(1.0, log10(fabs(phi))) : 1.0;
+                                    if (log10(phi_t - phi) > O.obj_max_inc + bas) ok = false;
+                                }
+                                if (ok) ok = cmp_le(th_t, (1.0 - O.gamma_theta) * theta, theta) || cmp_le(phi_t - phi, -O.gamma_phi * theta, phi);
+                            }
+                            if (ok) ok = filter_ok(phi_t, th_t);
+                        }
+                        if (ok) { accepted = true; break; }
+                    }
+                    first = false;
+                    alpha *= O.alpha_red_factor;
+                }
+                if (!accepted) { status = SC_STATUS_NEEDS_RESTO; break; }
+                MPROF_ADD(6)
+                {
+                    const bool ftype = gBD < 0.0 && alpha * sw_l > sw_r;
+                    const bool arm = cmp_le(phi_t - phi, O.eta_phi * alpha * gBD, phi);
+                    if (!ftype || !arm) filter_add(phi - O.gamma_phi * theta, (1.0 - O.gamma_theta) * theta);
+                }
+                last_alpha = alpha;
+#pragma unroll
+                for (int i = 0; i < NX; ++i) x[i] = xt[i];
+                if (stg) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) yc[i] += alpha * (lds[L.LAM + (k + 1) * 6 + i] / dgc(i));
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) lds[L.Y0 + i] += alpha * (-lds[L.LAM + i]);
+                }
+#pragma unroll
+                for (int j = 0; j < NU; ++j) u[j] = ut[j];
+#pragma unroll
+                for (int j = 0; j < KS; ++j) { s[j] = st[j]; yd[j] += alpha * dyd[j]; }
+                safe_slacks(x, u, s, mu);
+                // bound multipliers: z += a_z dz, then kappa_sigma
+                {
+                    const double ks = O.kappa_sigma;
+                    auto upd = [&](double& z, double dz, double sl) { z += a_z * dz; z = fmax(fmin(z, ks * mu / sl), mu / (ks * sl)); };
+                    if (act) {
+                        upd(zxL[0], dzxL[0], x[2] - xbL[0]); upd(zxL[1], dzxL[1], x[3] - xbL[1]); upd(zxL[2], dzxL[2], x[4] - xbL[2]);
+                        upd(zxU[0], dzxU[0], xbU[0] - x[2]); upd(zxU[1], dzxU[1], xbU[1] - x[3]);
+                    }
+                    if (stg) {
+#pragma unroll
+                        for (int j = 0; j < NU; ++j) { upd(zuL[j], dzuL[j], u[j] - ubL[j]); upd(zuU[j], dzuU[j], ubU[j] - u[j]); }
+#pragma unroll
+                        for (int j = 0; j < KS; ++j) if (j < K) upd(vU[j], dvU[j], sU[j] - s[j]);
+                    }
+                }
+                ++it;
+                MPROF_ADD(7)
+                phase = PH_EVAL;
+                continue;
+            }
+            // ---- PH_START / PH_EVAL: errors, convergence, barrier parameter ----
+            MPROF_ADD(0)
+            if (phase == PH_START) { theta_max = O.theta_max_fact * fmax(1.0, theta); theta_min = O.theta_min_fact * fmax(1.0, theta); }
             double E0, dinf, pinf, comp, un_pinf;
             errors(E, 0.0, E0, dinf, pinf, comp, un_pinf);
             if (trace && lane == 0) {
@@ -986,7 +1159,6 @@ struct Wave {
                 if (++n_acc >= O.acceptable_iter) { status = SC_STATUS_OPTIMAL; break; }
             } else n_acc = 0;
             if (it >= O.max_iter) { status = SC_STATUS_INACCURATE; break; }
-            // barrier parameter
             for (;;) {
                 double Emu, a, b, c, d;
                 errors(E, mu, Emu, a, b, c, d);
@@ -995,85 +1167,12 @@ struct Wave {
                 if (mu_new == mu) break;
                 mu = mu_new; tau = fmax(O.tau_min, 1.0 - mu); nfilt = 0;
             }
-            // search direction
-            if (!factor_and_solve(E, false, mu, theta, fsum)) { status = SC_STATUS_NEEDS_RESTO; break; }
-            double a_max, a_z;
-            step_lengths(tau, a_max, a_z);
-            const double phi = barrier(fsum, x, u, s, mu);
-            const double gBD = barrier_dir(E, mu);
-            double a_min = O.gamma_theta;
-            if (gBD < 0.0) {
-                a_min = fmin(a_min, O.gamma_phi * theta / (-gBD));
-                if (theta <= theta_min) a_min = fmin(a_min, O.delta * pow(theta, O.s_theta) / pow(-gBD, O.s_phi));
-            }
-            a_min *= O.alpha_min_frac;
-            double alpha = a_max;
-            bool first = true, accepted = false;
-            double xt[NX], ut[NU], st[KS], rct[NX], r0t[NX], dvt[KS];
-            double phi_t = 0.0, th_t = 0.0;
-            while (alpha > a_min || first) {
-#pragma unroll
-                for (int i = 0; i < NX; ++i) xt[i] = x[i] + alpha * dx[i];
-#pragma unroll
-                for (int j = 0; j < NU; ++j) ut[j] = u[j] + alpha * du[j];
-#pragma unroll
-                for (int j = 0; j < KS; ++j) st[j] = s[j] + alpha * ds[j];
-                safe_slacks(xt, ut, st, mu);
-                double f_t;
-                eval0(xt, ut, st, th_t, f_t, rct, r0t, dvt);
-                phi_t = barrier(f_t, xt, ut, st, mu);
-                if (phi_t < INF_ && th_t == th_t && phi_t == phi_t) {
-                    bool ok = th_t <= theta_max;
-                    if (ok) {
-                        const bool ftype = gBD < 0.0 && alpha * pow(-gBD, O.s_phi) > O.delta * pow(theta, O.s_theta);
-                        if (alpha > 0.0 && ftype && theta <= theta_min) ok = cmp_le(phi_t - phi, O.eta_phi * alpha * gBD, phi);
-                        else {
-                            ok = true;
-                            if (phi_t > phi) {
-                                const double bas = fabs(phi) > 10.0 ? fmax(1.0, log10(fabs(phi))) : 1.0;
-                                if (log10(phi_t - phi) > O.obj_max_inc + bas) ok = false;
-                            }
-                            if (ok) ok = cmp_le(th_t, (1.0 - O.gamma_theta) * theta, theta) || cmp_le(phi_t - phi, -O.gamma_phi * theta, phi);
-                        }
-                        if (ok) ok = filter_ok(phi_t, th_t);
-                    }
-                    if (ok) { accepted = true; break; }
-                }
-                first = false;
-                alpha *= O.alpha_red_factor;
-            }
-            if (!accepted) { status = SC_STATUS_NEEDS_RESTO; break; }
-            {
-                const bool ftype = gBD < 0.0 && alpha * pow(-gBD, O.s_phi) > O.delta * pow(theta, O.s_theta);
-                const bool arm = cmp_le(phi_t - phi, O.eta_phi * alpha * gBD, phi);
-                if (!ftype || !arm) filter_add(phi - O.gamma_phi * theta, (1.0 - O.gamma_theta) * theta);
-            }
-            last_alpha = alpha;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) { x[i] = xt[i]; yc[i] += alpha * dyc[i]; y0[i] += alpha * dy0[i]; }
-#pragma unroll
-            for (int j = 0; j < NU; ++j) u[j] = ut[j];
-#pragma unroll
-            for (int j = 0; j < KS; ++j) { s[j] = st[j]; yd[j] += alpha * dyd[j]; }
-            safe_slacks(x, u, s, mu);
-            // bound multipliers: z += a_z dz, then kappa_sigma
-            {
-                const double ks = O.kappa_sigma;
-                auto upd = [&](double& z, double dz, double sl) { z += a_z * dz; z = fmax(fmin(z, ks * mu / sl), mu / (ks * sl)); };
-                if (act) {
-                    upd(zxL[0], dzxL[0], x[2] - xbL[0]); upd(zxL[1], dzxL[1], x[3] - xbL[1]); upd(zxL[2], dzxL[2], x[4] - xbL[2]);
-                    upd(zxU[0], dzxU[0], xbU[0] - x[2]); upd(zxU[1], dzxU[1], xbU[1] - x[3]);
-                }
-                if (stg) {
-#pragma unroll
-                    for (int j = 0; j < NU; ++j) { upd(zuL[j], dzuL[j], u[j] - ubL[j]); upd(zuU[j], dzuU[j], ubU[j] - u[j]); }
-#pragma unroll
-                    for (int j = 0; j < KS; ++j) if (j < K) upd(vU[j], dvU[j], sU[j] - s[j]);
-                }
-            }
-            ++it;
-            eval2(E, false, false, mu, 0.0, theta, fsum);
+            MPROF_ADD(1)
+            phase = PH_BUILD; dw = 0.0; ic_first = true;
         }
+#ifdef SC_MS_PROF
+        if (trace && lane == 0) { double* t = trace + (size_t)O.max_iter * TRACE_W; for (int i = 0; i < 8; ++i) t[i] = prof[i]; }
+#endif
         status_out = status; iters_out = it;
     }
 };

@@ -651,7 +651,7 @@ struct Wave {
 
     // ---- oracle/mpc_cbf.py: solve(), wave-uniform control flow -----------------------------------------------------------------
     // doubles of one stage (lane) in a problem's hand-over record (mpc_cont.hpp): s | lam | t | zb | zR
-    static constexpr int CONT_LANE = 2 * WNR + WKT + 2 * NU;
+    static constexpr int CONT_LANE = 2 * WNR + WKT + 2 * NU + (OD ? 4 : 0);     // (optimal decay: + the stage's decay variables and their best iterate)
     // ST_PENDING in status_out: the solve stopped at the cap of this launch and its state is in cst
     __device__ __forceinline__ void solve(int& status_out, int& iters_out, const ipm::Cont& ct, double* cst, bool& violated) {
         double fraw = 0.0, sf0 = 1.0, mu = P.mu_init;
@@ -675,6 +675,10 @@ struct Wave {
             for (int j = 0; j < WKT; ++j) t[j] = a[2 * WNR + j];
 #pragma unroll
             for (int j = 0; j < NU; ++j) { zb[j] = a[2 * WNR + WKT + j]; zR[j] = a[2 * WNR + WKT + NU + j]; }
+            if constexpr (OD) {
+                dk[0] = a[2 * WNR + WKT + 2 * NU]; dk[1] = a[2 * WNR + WKT + 2 * NU + 1]; dkb[0] = a[2 * WNR + WKT + 2 * NU + 2]; dkb[1] = a[2 * WNR + WKT + 2 * NU + 3];
+                od_weights(dk[0], dk[1], w0, w1);
+            }
             it0 = (int)cst[0] + 1; mu = cst[1]; nu = cst[2]; delta_last = cst[3]; e_best = cst[4]; n_acc = (int)cst[5];
             resto = cst[6] != 0.0; n_resto = (int)cst[7]; n_small = (int)cst[8]; theta_R = cst[9]; mu_reg = cst[10]; sf0 = cst[11];
             have = false;
@@ -1006,6 +1010,7 @@ struct Wave {
                 for (int j = 0; j < WKT; ++j) a[2 * WNR + j] = t[j];
 #pragma unroll
                 for (int j = 0; j < NU; ++j) { a[2 * WNR + WKT + j] = zb[j]; a[2 * WNR + WKT + NU + j] = zR[j]; }
+                if constexpr (OD) { a[2 * WNR + WKT + 2 * NU] = dk[0]; a[2 * WNR + WKT + 2 * NU + 1] = dk[1]; a[2 * WNR + WKT + 2 * NU + 2] = dkb[0]; a[2 * WNR + WKT + 2 * NU + 3] = dkb[1]; }
             }
             if (lane == 0) {
                 cst[0] = (double)(it - 1); cst[1] = mu; cst[2] = nu; cst[3] = delta_last; cst[4] = e_best; cst[5] = (double)n_acc;
@@ -1098,7 +1103,8 @@ static hipError_t wave_launch_t(const Params& P, const sc_mpcvtol_params& p, lon
 }
 
 // doubles of one problem's solver state in a continuation workspace (mpc_cont.hpp; the layout of Wave::solve's hand-over)
-size_t mpcvtol_state_doubles(int N, int K) {
+size_t mpcvtol_state_doubles(int N, int K, bool od) {
+    if (od) return ipm::CONT_SCALARS + (size_t)N * NU + (size_t)N * (K <= 8 ? Wave<8, true>::CONT_LANE : Wave<16, true>::CONT_LANE);
     return ipm::CONT_SCALARS + (size_t)N * NU + (size_t)N * (K <= 8 ? Wave<8>::CONT_LANE : Wave<16>::CONT_LANE);
 }
 
@@ -1114,15 +1120,14 @@ hipError_t mpcvtol_wave_launch(const sc_mpcvtol_params& p, long long B, int K, c
                   : wave_launch_t<float, 16>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct);
 }
 
-// optimal-decay MPC-CBF for VTOL2D (include/safe_control_amd.h: sc_odmpcvtol_params): one launch, no continuation
+// optimal-decay MPC-CBF for VTOL2D (include/safe_control_amd.h: sc_odmpcvtol_params)
 hipError_t odmpcvtol_wave_launch(const sc_odmpcvtol_params& q, long long B, int K, const void* X, const void* u_prev, const void* goal,
-                                 const void* obs, void* u_out, void* rho_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream) {
+                                 const void* obs, void* u_out, void* rho_out, int* status_out, int* iters_out, void* z_out, hipStream_t stream,
+                                 const ipm::Cont& ct) {
     const sc_mpcvtol_params& p = q.mpc;
     Params P = from_c(p, K);
     P.ps1 = q.p_sb[0]; P.ps2 = q.p_sb[1]; P.rf1 = q.omega_ref[0]; P.rf2 = q.omega_ref[1];
     const size_t lds = mpcvtol_wave_lds_bytes(p.horizon);
-    ipm::Cont ct{};
-    ct.it_stop = p.max_iter;
     if (p.io_dtype == SC_DTYPE_F64)
         return K <= 8 ? wave_launch_t<double, 8, true>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct, rho_out)
                       : wave_launch_t<double, 16, true>(P, p, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, z_out, stream, ct, rho_out);

@@ -251,9 +251,10 @@ class BatchedOptimalDecayLinearMPCCBF(BatchedLinearMPCCBF):
         z = torch.empty((B, nu * self.horizon), dtype=dt_, device=X.device) if want_z else None
         p = self._params(obs_shared=shared, tol=self.tol, max_iter=self.max_iter)
         stream = torch.cuda.current_stream(X.device).cuda_stream
-        rc = self._lib.sc_odmpclin_solve_batch(
-            C.byref(p), self._blob(X.device).data_ptr(), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(),
-            obs.data_ptr(), u.data_ptr(), rho.data_ptr(), status.data_ptr(), iters.data_ptr(),
-            z.data_ptr() if z is not None else None, stream)
+        sl = self.slices_for(lambda: self._lib.sc_mpclin_slices_workspace_bytes(C.byref(p), B, K), X.device)
+        args = (self._blob(X.device).data_ptr(), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(),
+                obs.data_ptr(), u.data_ptr(), rho.data_ptr(), status.data_ptr(), iters.data_ptr(),
+                z.data_ptr() if z is not None else None, stream)
+        rc = self._lib.sc_odmpclin_solve_batch(C.byref(p), *args) if sl is None else self._lib.sc_odmpclin_solve_batch_sliced(C.byref(p), C.byref(sl), *args)
         _lib.check(rc, "sc_odmpclin_solve_batch")
         return (u, rho, status, iters, z) if want_z else (u, rho, status, iters)

@@ -169,7 +169,7 @@ def make_od_params(robot_spec, cbf_param, horizon, dt, radius, io_dtype, obs_sha
     return p
 
 
-class BatchedOptimalDecayVtolMPCCBF:
+class BatchedOptimalDecayVtolMPCCBF(_lib.SlicedSolver):
     """Optimal-decay MPC-CBF for B aircraft per launch (csrc/mpc_vtol_wave.hip, OD instantiation: the two decay variables of a stage
     are eliminated from the stage block before the Riccati recursion).
 
@@ -177,7 +177,9 @@ class BatchedOptimalDecayVtolMPCCBF:
     ``status[B]``, ``iters[B]`` (and ``z[B,4N]`` if asked).  ``u_prev`` is taken for the signature's sake: the input term of this
     class is R u^2 (optimal_decay_mpc_cbf.py:173-174).  No CPU fallback."""
 
-    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f64", cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER):
+    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f64", cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER,
+                 iter_slices=None, classify_first=True, order=True):
+        self.init_slices(iter_slices, classify_first, order)
         self.robot_spec = complete_robot_spec(dict(robot_spec or {"model": "VTOL2D"}))
         if self.robot_spec["model"] != "VTOL2D":
             raise NotImplementedError("this controller serves VTOL2D")
@@ -213,9 +215,10 @@ class BatchedOptimalDecayVtolMPCCBF:
         p = make_od_params(self.robot_spec, self.cbf_param, self.horizon, self.dt, self.robot_spec["radius"], self.io_dtype,
                            obs_shared=shared, tol=self.tol, max_iter=self.max_iter)
         stream = torch.cuda.current_stream(X.device).cuda_stream
-        rc = self._lib.sc_odmpcvtol_solve_batch(
-            C.byref(p), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(), rho.data_ptr(),
-            status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        sl = self.slices_for(lambda: self._lib.sc_odmpcvtol_slices_workspace_bytes(C.byref(p), B, K), X.device)
+        args = (B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(), rho.data_ptr(),
+                status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        rc = self._lib.sc_odmpcvtol_solve_batch(C.byref(p), *args) if sl is None else self._lib.sc_odmpcvtol_solve_batch_sliced(C.byref(p), C.byref(sl), *args)
         _lib.check(rc, "sc_odmpcvtol_solve_batch")
         return (u, rho, status, iters, z) if want_z else (u, rho, status, iters)
 

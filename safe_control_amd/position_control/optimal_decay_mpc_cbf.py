@@ -115,7 +115,7 @@ class OptimalDecayMPCCBF:
         return u.reshape(-1, 1).copy()
 
 
-class BatchedOptimalDecayMPCCBF:
+class BatchedOptimalDecayMPCCBF(_lib.SlicedSolver):
     """Optimal-decay MPC-CBF for B agents per launch on device tensors.
 
     ``solve(X[B,4], u_prev[B,2], goal[B,2], obs[B,K,7] | obs[K,7])`` -> ``u[B,2]``, ``rho[B,2N]`` (omega1_k, omega2_k
@@ -125,7 +125,8 @@ class BatchedOptimalDecayMPCCBF:
     """
 
     def __init__(self, robot_spec, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER,
-                 extension=False):
+                 extension=False, iter_slices=None, classify_first=True, order=True):
+        self.init_slices(iter_slices, classify_first, order)     # continuation launches (round 5): first cap 100, the rest of the budget behind it
         self.robot_spec = complete_robot_spec(robot_spec)
         model = self.robot_spec["model"]
         self.dt = float(dt)
@@ -165,8 +166,9 @@ class BatchedOptimalDecayMPCCBF:
                                max_iter=self.max_iter,
                                slack_reset=2 if (self.extension and self.robot_spec["model"] == "Unicycle2D") else 0)   # oracle/od_mpc_rd1.py
         stream = torch.cuda.current_stream(X.device).cuda_stream
-        rc = self._lib.sc_odmpccbf_solve_batch(
-            C.byref(p), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(),
-            rho.data_ptr(), status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        sl = self.slices_for(lambda: self._lib.sc_odmpccbf_slices_workspace_bytes(C.byref(p), B, K), X.device)
+        args = (B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(),
+                rho.data_ptr(), status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        rc = self._lib.sc_odmpccbf_solve_batch(C.byref(p), *args) if sl is None else self._lib.sc_odmpccbf_solve_batch_sliced(C.byref(p), C.byref(sl), *args)
         _lib.check(rc, "sc_odmpccbf_solve_batch")
         return (u, rho, status, iters, z) if want_z else (u, rho, status, iters)

@@ -38,11 +38,13 @@ def make_od_params(robot_spec, mc, cbf_param, horizon, dt, radius, io_dtype, obs
     return p
 
 
-class BatchedOptimalDecayGnMPCCBF:
+class BatchedOptimalDecayGnMPCCBF(_lib.SlicedSolver):
     """``solve(X[B,nx], u_prev[B,2], goal[B,2], obs[B,K,7] | obs[K,7])`` -> ``u[B,2]``, ``rho[B,2N]`` (omega1_k, omega2_k per
     stage), ``status[B]``, ``iters[B]`` (and ``z[B,2N]`` if asked); nx = 4 (KinematicBicycle2D) or 6 (Quad2D)."""
 
-    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER):
+    def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER,
+                 iter_slices=None, classify_first=True, order=True):
+        self.init_slices(iter_slices, classify_first, order)
         self.robot_spec = complete_robot_spec(robot_spec)
         if self.robot_spec["model"] not in OD_GN_MODELS:
             raise NotImplementedError(f"this controller serves {OD_GN_MODELS}")
@@ -81,9 +83,10 @@ class BatchedOptimalDecayGnMPCCBF:
         p = make_od_params(self.robot_spec, self._mc, self.cbf_param, self.horizon, self.dt, self.robot_spec["radius"], self.io_dtype,
                            obs_shared=shared, tol=self.tol, max_iter=self.max_iter)
         stream = torch.cuda.current_stream(X.device).cuda_stream
-        rc = self._lib.sc_odmpcgn_solve_batch(
-            C.byref(p), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(), rho.data_ptr(),
-            status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        sl = self.slices_for(lambda: self._lib.sc_odmpcgn_slices_workspace_bytes(C.byref(p), B, K), X.device)
+        args = (B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(), u.data_ptr(), rho.data_ptr(),
+                status.data_ptr(), iters.data_ptr(), z.data_ptr() if z is not None else None, stream)
+        rc = self._lib.sc_odmpcgn_solve_batch(C.byref(p), *args) if sl is None else self._lib.sc_odmpcgn_solve_batch_sliced(C.byref(p), C.byref(sl), *args)
         _lib.check(rc, "sc_odmpcgn_solve_batch")
         return (u, rho, status, iters, z) if want_z else (u, rho, status, iters)
 

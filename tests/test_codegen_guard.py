@@ -70,7 +70,7 @@ def test_a_new_singleton_fails_in_a_unit_built_with_the_splitting_allocator(tmp_
     assert C.norm("scratch_store_dword off, v5, off offset:728") == "scratch_store_dword off, v#, off offset:#"
     assert C.norm("v_mov_b32_e32 v79, v151") == "v_mov_b32_e32 v#, v#"
     greedy = C.unsafe_units()
-    assert greedy("build/csrc/mpc_vtol_wave.o") and greedy("build/csrc/cbf_qp_f32.o") and greedy("x/od_cbf_qp.o")
+    assert greedy("build/csrc/mpc_vtol_wave.o") and greedy("build/csrc/mpc_vtol_ms.o") and greedy("build/csrc/cbf_qp_f32.o") and greedy("x/od_cbf_qp.o")
     assert not greedy("build/csrc/mpc_gn.o") and not greedy("build/csrc/mpc_cbf.o")
     allow = C.load_allow()
     assert allow and all(a["review"] and a["kernel"] and a["instruction"] for a in allow)

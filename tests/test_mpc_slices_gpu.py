@@ -158,3 +158,56 @@ def test_random_schedules_are_bitwise_the_uninterrupted_solve(fam):
         caps = tuple(sorted(set(int(c) for c in rng.integers(1, max(4, int(ref[2].max())), size=int(rng.integers(1, 9))))))
         kw = dict(iter_slices=caps, order=bool(rng.integers(0, 2)), classify_first=bool(rng.integers(0, 2)))
         same(ref, solve(make(fam, max_iter=300, **kw), arrs), f"{fam} {kw}")
+
+
+# ---- the optimal-decay families (round 5: sc_od*_solve_batch_sliced; the decay variables travel with the solver state) -------------
+OD_FAMILIES = ["od_du", "od_uni", "od_kb", "od_quad2d", "od_quad3d", "od_vtol"]
+
+
+def make_od(fam, **kw):
+    if fam == "od_du":
+        return sca.BatchedOptimalDecayMPCCBF({"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}, io_dtype="f64", horizon=10, **kw)
+    if fam == "od_uni":
+        return sca.BatchedOptimalDecayMPCCBF({"model": "Unicycle2D", "v_max": 1.0, "w_max": 0.5, "radius": 0.25}, io_dtype="f64", horizon=10, extension=True, **kw)
+    if fam == "od_kb":
+        return sca.BatchedOptimalDecayGnMPCCBF({"model": "KinematicBicycle2D"}, io_dtype="f64", **kw)
+    if fam == "od_quad2d":
+        return sca.BatchedOptimalDecayGnMPCCBF({"model": "Quad2D"}, io_dtype="f64", **kw)
+    if fam == "od_quad3d":
+        return sca.BatchedOptimalDecayLinearMPCCBF({"model": "Quad3D"}, io_dtype="f64", horizon=10, **kw)
+    return sca.BatchedOptimalDecayVtolMPCCBF(io_dtype="f64", **kw)
+
+
+def batch_od(fam, B, seed=0):
+    base = {"od_du": "du", "od_uni": "uni", "od_kb": "kb", "od_quad2d": "quad2d", "od_quad3d": "quad3d", "od_vtol": "vtol"}[fam]
+    arrs = list(batch(base, B, seed))
+    if fam == "od_vtol":                                              # a disc on every other aircraft's path: decay variables leave their reference
+        ob = arrs[3].clone(); X = arrs[0]
+        ob[::2, 0, 0] = X[::2, 0] + 20.0; ob[::2, 0, 1] = X[::2, 1] + 0.5; ob[::2, 0, 2] = 1.2
+        arrs[3] = ob.contiguous()
+    return tuple(arrs)
+
+
+def same_od(a, b, what):
+    for x, y, name in zip(a, b, ("u", "rho", "status", "iters", "z")):
+        assert x.shape == y.shape
+        bad = np.nonzero(~((x == y) | (np.isnan(x) & np.isnan(y))).reshape(x.shape[0], -1).all(axis=1))[0]
+        assert len(bad) == 0, f"{what}: {name} differs on {len(bad)} problems, first {bad[:5]}"
+
+
+@pytest.mark.parametrize("fam", OD_FAMILIES)
+def test_optimal_decay_resumed_solve_is_bitwise_the_uninterrupted_solve(fam):
+    B = 192
+    arrs = batch_od(fam, B)
+    ref = solve(make_od(fam, max_iter=100, iter_slices=(), classify_first=False), arrs)
+    assert (ref[2] >= 0).all() and ref[3].max() > 12
+    for caps in ((1, 2, 3, 5, 8, 13, 21, 34), (7, 40), (int(ref[3].max()) - 1,)):
+        for order in (False, True):
+            same_od(ref, solve(make_od(fam, max_iter=100, iter_slices=caps, order=order, classify_first=False), arrs), f"{fam} caps {caps} order {order}")
+    same_od(ref, solve(make_od(fam, max_iter=100, iter_slices=(10, 25), classify_first=True), arrs), f"{fam} classify_first + caps")
+    # the budget behind a first cap: nothing pending, problems that ended below the cap untouched, one launch == sliced
+    got = solve(make_od(fam, max_iter=3000, iter_slices=(100,)), arrs)
+    assert (got[2] >= 0).all() and (got[2] <= 2).all()
+    done = ref[3] < 100
+    same_od([r[done] for r in ref], [g[done] for g in got], f"{fam} below the cap")
+    same_od(solve(make_od(fam, max_iter=3000, iter_slices=(), classify_first=False), arrs), got, f"{fam} 3000 in one launch vs sliced")

@@ -161,3 +161,53 @@ def test_multiple_shooting_and_condensed_solves_agree_on_config3_draws():
         if st == 0 and so == 0:
             n_same += int(np.abs(u - uo).max() <= 1e-5)
     assert n_same >= 20, n_same
+
+
+def _vtol_problem(i=0):
+    from safe_control_amd import workloads as W
+    X, up, goal, obs = W.mpc_family_batch("vtol", 8, 8, seed=0)
+    return MS.vtol_model(), X[i], up[i], goal[i], obs[i]
+
+
+@pytest.mark.parametrize("phase", ["regular", "restoration", "restoration_ineq"])
+def test_riccati_recursion_solves_the_same_system_as_the_dense_factorisation(phase):
+    """The linear algebra of csrc/mpc_vtol_ms.hip (rows condensed into the stage blocks, Riccati recursion over (dx_k, du_{k-1}) with
+    defects; in IPOPT's restoration the dynamics rows are soft: parallel sums) against LAPACK's symmetric indefinite factorisation of the
+    whole primal-dual system, at a random interior iterate with random right-hand sides."""
+    mdl, x0, up, goal, obs = _vtol_problem(1)
+    nlp = MS.StageNLP(mdl, x0, up, goal, obs)
+    o = dict(MS.OPTS, resto_elastic="ineq" if phase == "restoration_ineq" else "all")
+    Pr = MS._Regular(nlp, nlp.initial_guess(), o)
+    P = Pr if phase == "regular" else MS._Resto(Pr, nlp.initial_guess(), o)
+    rng = np.random.default_rng(1)
+    A = MS._Algo(P, o)
+    x = A.push(nlp.initial_guess() + 0.01 * rng.standard_normal(nlp.n), P.x_L, P.x_U, 0.01, 0.01)
+    ev = P.evaluate(x, 2, 0.1)
+    y = 0.1 * rng.standard_normal(P.m)
+    sig_x = np.where(np.isfinite(P.x_L) | np.isfinite(P.x_U), rng.uniform(0.1, 10, P.n), 0.0)
+    sig_t = rng.uniform(0.01, 100, P.nt)
+    W = ev["hess"](y) + (5.0 * np.eye(P.n) if phase == "regular" else 0.0)
+    rx, rt, rg = rng.standard_normal(P.n), rng.standard_normal(P.nt), rng.standard_normal(P.m)
+    sols = []
+    for ls in (None, "riccati"):
+        o["linear_solver"] = ls
+        A.delta_w_last = 0.0
+        sols.append(A.factor(W, ev["J"], sig_x, sig_t, 0.1)(rx, rt, rg))
+        assert A.last_delta[0] == 0.0
+    for a, b in zip(*sols):
+        assert np.abs(a - b).max() <= 1e-8 * max(1.0, np.abs(a).max())
+
+
+def test_kernel_profile_follows_the_default_solve_and_hands_back_restorations():
+    """linear_solver = riccati, max_soc = 0, restoration = none (what the HIP kernel runs): same iterates as the dense solve with second-order
+    corrections on a feasible problem; on the first NLP of the reference's example scene (no feasible point) it stops with 'needs_resto' where
+    the full algorithm enters its restoration phase and reports local infeasibility."""
+    mdl, x0, up, goal, obs = _vtol_problem(0)
+    prof = dict(linear_solver="riccati", max_soc=0, restoration="none")
+    u1, s1, i1 = MS.solve(mdl, x0, up, goal, obs)
+    u2, s2, i2 = MS.solve(mdl, x0, up, goal, obs, opts=prof)
+    assert (s1, i1) == (s2, i2) == (0, i1) and np.abs(u1 - u2).max() <= 1e-10
+    ob = np.hstack([np.array([[67.0, z, 0.5] for z in (6.0, 7.0, 8.0, 9.0)] + [[73.0, float(z), 0.5] for z in range(1, 7)]), np.zeros((10, 4))])
+    mdl2 = MS.vtol_model(dict(radius=0.6, v_max=20.0))
+    u, st, it, info = MS.solve(mdl2, np.array([2.0, 10.0, 0.0, 20.0, 0.0, 0.0]), np.zeros(4), [70.0, 10.0], ob, return_info=True, opts=prof)
+    assert info["status"] == "needs_resto" and st == 4 and it < 100

@@ -62,6 +62,13 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_FLAT S
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o vtol_fetch -- python3 $R/tools/time_mpcvtol.py 4096 f32 limit100 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o vtol_write -- python3 $R/tools/time_mpcvtol.py 4096 f32 limit100 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum --output-format csv -d $OUT -o vtol_tcp -- python3 $R/tools/time_mpcvtol.py 4096 f32 limit100 > /dev/null 2>&1
+# 12. the multiple-shooting VTOL2D kernel of round 5 (csrc/mpc_vtol_ms.hip): kernel trace, instruction mix, scratch traffic
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o vtolms -- python3 $R/tools/time_mpcvtol.py 4096 f32 ms > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o vtolms_sq -- python3 $R/tools/time_mpcvtol.py 4096 f32 ms > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM --output-format csv -d $OUT -o vtolms_mem -- python3 $R/tools/time_mpcvtol.py 4096 f32 ms > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT -o vtolms_mem2 -- python3 $R/tools/time_mpcvtol.py 4096 f32 ms > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o vtolms_fetch -- python3 $R/tools/time_mpcvtol.py 4096 f32 ms > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o vtolms_write -- python3 $R/tools/time_mpcvtol.py 4096 f32 ms > /dev/null 2>&1
 # 10. sustained VALU issue peak of the part (the denominator of the valu_issue rooflines)
 [ -x $R/exp_libs/valu_peak ] || { mkdir -p $R/exp_libs; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/micro/valu_peak.hip -o $R/exp_libs/valu_peak > /dev/null 2>&1; }
 [ -x $R/exp_libs/valu_peak ] && $R/exp_libs/valu_peak > $OUT/valu_peak.txt 2>&1

@@ -1,6 +1,7 @@
 """Launch time of the VTOL2D MPC-CBF wave kernel on the vtol bench batch: one launch with the round-3 limit of 100 iterations, and the
 reference solver's budget (3000) as continuation launches.  MI355X only.   python tools/time_mpcvtol.py [B] [f32|f64] [limit100]
-(`limit100`: the one-launch configuration only -- counter passes want one kind of dispatch)."""
+(`limit100`: the one-launch configuration only -- counter passes want one kind of dispatch; `ms`: the multiple-shooting kernel of
+round 5, csrc/mpc_vtol_ms.hip, one launch with IPOPT's budget)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,8 +18,11 @@ X, up, goal, obs = tt(X), tt(up), tt(goal), tt(obs)
 CONFIGS = (("limit 100, one launch", dict(max_iter=100, iter_slices=(), classify_first=False)), ("budget 3000, sliced", dict()))
 if len(sys.argv) > 3 and sys.argv[3] == "limit100":
     CONFIGS = CONFIGS[:1]
+MS = len(sys.argv) > 3 and sys.argv[3] == "ms"
+if MS:
+    CONFIGS = (("multiple shooting, budget", dict()),)
 for label, kw in CONFIGS:
-    ctl = sca.BatchedVtolMPCCBF(io_dtype=io, **kw)
+    ctl = sca.BatchedVtolMSMPCCBF(io_dtype=io, fallback=False) if MS else sca.BatchedVtolMPCCBF(io_dtype=io, **kw)
     u, st, it = ctl.solve(X, up, goal, obs); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
