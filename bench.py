@@ -692,7 +692,7 @@ def vtol_ms_mpc_leg(dev, B=4096, K=8, steps=3, seed=0):
         res["uniform_batch"] = {"kernel_ms": e0.elapsed_time(e1) / steps, "iterations": int(o2[2][0].item())}
     except Exception as e:
         res["uniform_batch"] = {"error": repr(e)[:100]}
-    return with_roofline(res, "mpcvtol_ms_kernel<float, 8>", launches=1)
+    return with_roofline(res, "mpcvtol_ms_kernel<float, 8, false>", launches=1)
 
 
 def vtol_ms_closed_loop_leg(dev):
@@ -762,6 +762,40 @@ def od_vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
             "mean_ipm_iterations": float(it.double().mean().item()), "max_ipm_iterations": int(it.max().item()),
             "decay_moved_fraction": float(((rho - 1.0).abs().max(dim=1).values > 1e-3).double().mean().item())},
             "mpcvtol_wave_kernel<float, 8, true>", launches=1)
+
+
+def od_vtol_ms_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
+    """Optimal-decay MPC-CBF for VTOL2D in the multiple-shooting form (round 5: the OD instantiation of csrc/mpc_vtol_ms.hip; the decay rates are
+    two more inputs of a stage, as in the reference, optimal_decay_mpc_cbf.py:123-124).  Same batch as od_vtol_mpc_cbf; problems that would
+    enter IPOPT's restoration phase go to the condensed optimal-decay kernel."""
+    import numpy as np
+    import torch
+    import safe_control_amd as sca
+    from safe_control_amd import workloads as W
+    ctl = sca.BatchedOptimalDecayVtolMSMPCCBF(io_dtype="f32")
+    Xn, up0, gn, on = W.mpc_family_batch("vtol", B, K, seed=seed)
+    on = on.copy()
+    rng = np.random.default_rng(seed + 100)
+    r = rng.uniform(0.8, 1.6, B); d = 10.0 + 20.0 * rng.uniform(size=B); off = rng.uniform(-1.0, 1.0, B)
+    on[::2, 0, 0], on[::2, 0, 1], on[::2, 0, 2] = (Xn[:, 0] + d + r)[::2], (Xn[:, 1] + off)[::2], r[::2]
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    X, g, ob, up = t(Xn), t(gn), t(on), t(up0)
+    u, rho, st, it = ctl.solve(X, up, g, ob)
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        u, rho, st, it = ctl.solve(X, up, g, ob)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    return with_roofline({"workload": f"{B}-aircraft batch VTOL2D optimal-decay MPC-CBF, multiple shooting, horizon N=30, {K} obstacles, a disc ahead of every other aircraft",
+            "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32", "budget": 3000,
+            "optimal_fraction": float((st == 0).double().mean().item()), "infeasible_fraction": float((st == 1).double().mean().item()),
+            "inaccurate_fraction": float((st == 2).double().mean().item()), "restoration_fallback": int(ctl.n_fallback),
+            "mean_ipm_iterations": float(it.double().mean().item()), "max_ipm_iterations": int(it.max().item()),
+            "decay_moved_fraction": float(((rho - 1.0).abs().max(dim=1).values > 1e-3).double().mean().item())},
+            "mpcvtol_ms_kernel<float, 8, true>", launches=1)
 
 
 def manip_closed_loop_leg(dev, B=4096, T=100, seed=0):
@@ -1138,6 +1172,7 @@ def main():
             except Exception as e:
                 res["vtol_reference_scene_closed_loop"] = {"error": repr(e)[:200]}
             res["od_vtol_mpc_cbf"] = od_vtol_mpc_leg(dev)
+            res["od_vtol_ms_mpc_cbf"] = od_vtol_ms_mpc_leg(dev)
             res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
             res["backup_cbf_qp"] = backup_cbf_leg(dev)
         if ws == 1 and not a.no_cpu_baseline:

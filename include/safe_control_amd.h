@@ -38,10 +38,10 @@ extern "C" {
 #endif
 
 /* ABI version: the minor number goes up with EVERY change of a struct layout or an entry point's signature (round 4 grew
- * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2; round 5 added sc_ipopt_params and sc_mpcvtol_ms_solve_batch: 0.3; the continuation entry points of the optimal-decay families: 0.4).  A binding compares sc_version() with the
+ * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2; round 5 added sc_ipopt_params and sc_mpcvtol_ms_solve_batch: 0.3; the continuation entry points of the optimal-decay families: 0.4; sc_odmpcvtol_ms_solve_batch: 0.5).  A binding compares sc_version() with the
  * version its struct mirrors were written for before the first call (safe_control_amd/_lib.py: ABI_VERSION). */
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 4
+#define SC_VERSION_MINOR 5
 
 /* ---- return codes ------------------------------------------------------ */
 typedef enum sc_error {
@@ -473,6 +473,11 @@ int sc_odmpcvtol_solve_batch(const sc_odmpcvtol_params* params, int64_t B, int32
                              const void* X, const void* u_prev, const void* goal, const void* obs,
                              void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
 
+/* the same NLP in the multiple-shooting form under IPOPT's algorithm (kernel 12 with the decay rates as two more inputs of a stage, which is
+ * what they are in the reference: optimal_decay_mpc_cbf.py:123-124); params->mpc as for sc_mpcvtol_ms_solve_batch, status / plan / trace too */
+int sc_odmpcvtol_ms_solve_batch(const sc_odmpcvtol_params* params, const sc_ipopt_params* ipopt, int64_t B, int32_t K,
+                                const void* X, const void* u_prev, const void* goal, const void* obs,
+                                void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* plan_out, double* trace_out, void* stream);
 size_t sc_odmpcvtol_slices_workspace_bytes(const sc_odmpcvtol_params* params, int64_t B, int32_t K);
 int sc_odmpcvtol_solve_batch_sliced(const sc_odmpcvtol_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K,
                                     const void* X, const void* u_prev, const void* goal, const void* obs,

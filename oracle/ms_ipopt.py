@@ -222,6 +222,17 @@ def vtol_model(spec=None, dt=0.05):
                 x_hi=np.array([INF, INF, pm, s["v_max"], INF, INF]))
 
 
+def vtol_od_model(spec=None, dt=0.05):
+    """OptimalDecayMPCCBF with a VTOL2D robot (optimal_decay_mpc_cbf.py:19,44-47,83-91,123-124,173-186,288-296) in the multiple-shooting form:
+    the two decay rates omega1_k, omega2_k are INPUTS 4 and 5 of a stage (free), the CBF row of the stage reads
+    dd_h + (a1 omega1 + a2 omega2) d_h + a1 a2 omega1 omega2 h >= 0 with a1 = a2 = 0.35, cost + p_sb (omega - 1)^2, input term R u^2."""
+    m = vtol_model(spec, dt)
+    big = np.array([INF, INF])
+    m.update(name="VTOL2D_OD", nu=6, nu_dyn=4, alpha1=0.35, alpha2=0.35, rterm="u", od=dict(omega_ref=np.array([1.0, 1.0]), p_sb=np.array([10.0, 10.0])),
+             u_lo=np.concatenate([m["u_lo"], -big]), u_hi=np.concatenate([m["u_hi"], big]), R=np.concatenate([m["R"], [0.0, 0.0]]))
+    return m
+
+
 class StageNLP:
     """min f(w)  s.t.  c(w) = 0,  d(w) <= 0,  w_lo <= w <= w_hi   with w = [x_0, u_0, x_1, u_1, .., x_{N-1}, u_{N-1}, x_N]."""
 
@@ -231,7 +242,9 @@ class StageNLP:
         self.nx, self.nu = nx, nu = model["nx"], model["nu"]
         self.nv = nx + nu
         self.x0 = np.asarray(x0, dtype=float).reshape(-1)[:nx].copy()
-        self.u_prev = np.asarray(u_prev, dtype=float).reshape(-1)[:nu].copy()
+        self.u_prev = np.zeros(nu)
+        up_ = np.asarray(u_prev, dtype=float).reshape(-1)[:nu]
+        self.u_prev[: up_.shape[0]] = up_
         self.xg = np.zeros(nx)
         self.xg[:2] = np.asarray(goal, dtype=float).reshape(-1)[:2]     # goal padded with zeros (mpc_cbf.py:267)
         self.obs = np.asarray(obs, dtype=float)
@@ -258,7 +271,10 @@ class StageNLP:
         """set_initial_guess (mpc_cbf.py:366-369): every stage's state at x0, every input at the input applied last."""
         w = np.zeros(self.n)
         w[self.ix] = self.x0
-        w[self.iu] = self.u_prev
+        up = self.u_prev
+        if self.mdl.get("od"):                                              # (the decay rates start at their references, as in oracle/od_mpc_cbf.py)
+            up = np.concatenate([up[: self.mdl["nu_dyn"]], self.mdl["od"]["omega_ref"]])
+        w[self.iu] = up
         return w
 
     def split(self, w):
@@ -286,10 +302,15 @@ class StageNLP:
         """d_kj = -(dd_h + (a1 + a2) d_h + a1 a2 h) with x1 = step(x, u), x2 = step(x1, u) (mpc_cbf.py:304,316-321); the heading /
         pitch wrap inside step() touches no position."""
         spec, dt, nxt = self.mdl["spec"], self.mdl["dt"], self.mdl["next"]
-        x1 = nxt(x, u, spec, dt)
-        x2 = nxt(x1, u, spec, dt)
+        nd = self.mdl.get("nu_dyn", self.nu)
+        x1 = nxt(x, u[:nd], spec, dt)
+        x2 = nxt(x1, u[:nd], spec, dt)
         h0, h1, h2 = self._h(x[0], x[1]), self._h(x1[0], x1[1]), self._h(x2[0], x2[1])
         w0, w1, w2 = self.cw
+        if self.mdl.get("od"):                                              # optimal decay: the gains of the stage's rows scale with its decay rates
+            a1, a2 = self.mdl["alpha1"], self.mdl["alpha2"]
+            sk, qk = a1 * u[nd] + a2 * u[nd + 1], (a1 * a2) * (u[nd] * u[nd + 1])
+            w0, w1 = 1.0 - sk + qk, sk - 2.0
         return x1, [-(w2 * h2[j] + w1 * h1[j] + w0 * h0[j]) for j in range(self.K)]
 
     def evaluate(self, w, level=2):
@@ -300,8 +321,13 @@ class StageNLP:
         Q, R = self.mdl["Q"], self.mdl["R"]
         e = X - self.xg
         up = np.vstack([self.u_prev[None, :], U])
-        du = up[1:] - up[:-1]
+        r_on_u = self.mdl.get("rterm") == "u"                              # optimal decay: R u^2 (an expression r-term), not the delta-u penalty
+        du = U.copy() if r_on_u else up[1:] - up[:-1]
         f = float(np.sum(Q * e * e) + np.sum(R * du * du))
+        od = self.mdl.get("od")
+        if od:
+            dom = U[:, self.mdl["nu_dyn"]:] - od["omega_ref"]
+            f += float(np.sum(od["p_sb"] * dom * dom))
         out = dict(f=f)
         if level == 0:
             xs = [X[:N, i] for i in range(nx)]
@@ -318,7 +344,10 @@ class StageNLP:
         grad[self.ix] = 2.0 * Q * e
         gu = 2.0 * R * du
         grad[self.iu] += gu
-        grad[self.iu[:-1]] -= gu[1:]
+        if not r_on_u:
+            grad[self.iu[:-1]] -= gu[1:]
+        if od:
+            grad[self.iu[:, self.mdl["nu_dyn"]:]] += 2.0 * od["p_sb"] * dom
         Jc = np.zeros((self.m_c, self.n))
         Jc[np.arange(nx), np.arange(nx)] = 1.0
         Jd = np.zeros((self.m_d, self.n))
@@ -336,7 +365,10 @@ class StageNLP:
         for k in range(N):
             iu = self.iu[k]
             Hf[iu, iu] += 2.0 * R
-            if k + 1 < N:
+            if od:
+                io = iu[self.mdl["nu_dyn"]:]
+                Hf[io, io] += 2.0 * od["p_sb"]
+            if k + 1 < N and not r_on_u:
                 Hf[iu, iu] += 2.0 * R
                 Hf[iu, self.iu[k + 1]] -= 2.0 * R
                 Hf[self.iu[k + 1], iu] -= 2.0 * R

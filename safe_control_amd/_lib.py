@@ -336,6 +336,7 @@ SYMBOLS = {
     "sc_odmpcgn_slices_workspace_bytes": (C.c_size_t, [C.POINTER(OdMpcGnParams), C.c_int64, C.c_int32]),
     "sc_odmpcgn_solve_batch_sliced": (C.c_int, [C.POINTER(OdMpcGnParams), C.POINTER(MpcSlices), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_odmpclin_solve_batch_sliced": (C.c_int, [C.POINTER(MpcLinParams), C.POINTER(MpcSlices), C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 10),
+    "sc_odmpcvtol_ms_solve_batch": (C.c_int, [C.POINTER(OdMpcVtolParams), C.POINTER(IpoptParams), C.c_int64, C.c_int32] + [C.c_void_p] * 11),
     "sc_odmpcvtol_slices_workspace_bytes": (C.c_size_t, [C.POINTER(OdMpcVtolParams), C.c_int64, C.c_int32]),
     "sc_odmpcvtol_solve_batch_sliced": (C.c_int, [C.POINTER(OdMpcVtolParams), C.POINTER(MpcSlices), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_odmpccbf_solve_batch": (C.c_int, [C.POINTER(OdMpcCbfParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
@@ -362,7 +363,7 @@ SYMBOLS = {
 _lib = None
 
 # SC_VERSION_MAJOR * 1000 + SC_VERSION_MINOR of the header the ctypes mirrors above were written for
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class HipLibraryError(RuntimeError):

@@ -264,7 +264,10 @@ constexpr double INF_ = 1e300;
 
 __device__ __forceinline__ bool cmp_le(double lhs, double rhs, double bas) { return lhs - rhs <= 10.0 * EPSD * fabs(bas); }
 
-template <int KS>
+// OD: OptimalDecayMPCCBF (optimal_decay_mpc_cbf.py:123-124,173-186,288-296; oracle/ms_ipopt.py: vtol_od_model) -- the two decay rates of a
+// stage are two more (free) inputs of that stage: they scale the gains of its rows, cost p_sb (omega - ref)^2, input term R u^2 (no coupling of
+// neighbouring inputs).  Their 2 x 2 block is eliminated from the stage block inside the 8-dimensional span (V | rho) before it is expanded.
+template <int KS, bool OD = false>
 struct Wave {
     const Params& P;
     const sc_ipopt_params& O;
@@ -281,10 +284,12 @@ struct Wave {
     double xbL[3], xbU[2], ubL[NU], ubU[NU];              // (relaxed, adjustable) bounds: x idx 2, 3, 4 lower / 2, 3 upper; inputs
     double zxL[3], zxU[2], zuL[NU], zuU[NU];
     double s[KS], yd[KS], vU[KS], sU[KS];
+    double rho[2], drho[2], odD[3], odM[2][6], odg[2];   // OD: decay rates, their step; D^-1 (11, 12, 22), M_rho,v and g_rho of the last Newton system
     double df;
     double rc[NX], dv[KS];                               // scaled residuals of my dynamics rows, scaled row values (last evaluation)
     double ds[KS], dyd[KS], dvU[KS], dzxL[3], dzxU[2], dzuL[NU], dzuU[NU];
     int nfilt;
+    bool od_bad = false;
     double dw_last, last_dw;
 #ifdef SC_MS_PROF
     double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};            // eval2 (errors), errors + mu, eval2 (build), riccati backward, forward, finish_step, line search, update
@@ -298,6 +303,10 @@ struct Wave {
         nfilt = 0; dw_last = 0.0; last_dw = 0.0;
     }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ void od_weights(double r1, double r2) {       // stage weights of the rows for decay rates (r1, r2)
+        const double sk = P.alpha1 * r1 + P.alpha2 * r2, qk = P.alpha1 * P.alpha2 * r1 * r2;
+        w0 = 1.0 - sk + qk; w1 = sk - 2.0;
+    }
     __device__ __forceinline__ double dgc(int i) const { return lds[L.SC + i]; }
     __device__ __forceinline__ double dgd(int j) const { return lds[L.SC + 6 + j]; }
 
@@ -316,7 +325,7 @@ struct Wave {
         return w0 * hv[0] + w1 * hv[1] + w2 * hv[2];
     }
     // objective share of lane k: l(x_k) (+ m(x_N)) + R (u_k - u_{k-1})^2; um = u_{k-1}
-    __device__ __forceinline__ double cost_share(const double* xs, const double* us, const double* um) const {
+    __device__ __forceinline__ double cost_share(const double* xs, const double* us, const double* um, const double* rs) const {
         double f = 0.0;
         if (act) {
             const double e0 = xs[0] - xg[0], e1 = xs[1] - xg[1];
@@ -324,12 +333,14 @@ struct Wave {
         }
         if (stg) {
 #pragma unroll
-            for (int j = 0; j < NU; ++j) { const double d = us[j] - um[j]; f += P.R[j] * d * d; }
+            for (int j = 0; j < NU; ++j) { const double d = OD ? us[j] : us[j] - um[j]; f += P.R[j] * d * d; }
+            if constexpr (OD) f += P.ps1 * (rs[0] - P.rf1) * (rs[0] - P.rf1) + P.ps2 * (rs[1] - P.rf2) * (rs[1] - P.rf2);
         }
         return f;
     }
     // trial evaluation at (xs, us, ss): theta (l1 residual of the scaled rows) and the unscaled objective; xs of every lane goes through XS
-    __device__ __forceinline__ void eval0(const double* xs, const double* us, const double* ss, double& theta, double& fsum) {
+    __device__ __forceinline__ void eval0(const double* xs, const double* us, const double* ss, const double* rs, double& theta, double& fsum) {
+        if constexpr (OD) od_weights(rs[0], rs[1]);
         sync();
         if (act) {
 #pragma unroll
@@ -365,7 +376,7 @@ struct Wave {
             for (int i = 0; i < NX; ++i) th += fabs(xs[i] - x0[i]);
         }
         theta = ipm::wsum(th);
-        fsum = ipm::wsum(cost_share(xs, us, um));
+        fsum = ipm::wsum(cost_share(xs, us, um, rs));
     }
 
     // ---- barrier function (scaled objective + log barrier of every bound + damping of the one-sided ones) ------------------------------
@@ -430,15 +441,17 @@ struct Wave {
     struct Eval2 {
         double Jty[NV];          // J' y at my (x_k, u_k)
         double gfx[NX], gfu[NU]; // scaled objective gradient
+        double Jr[2], gfr[2];    // OD: J' y and the objective gradient at my decay rates
     };
     // Every row gradient of a stage lies in the span of V = [G2[0], G2[1], e_0, e_1, e_3, e_4] (the gradient of the second barrier point and
     // four unit vectors):  grad cbf_j = V c_j.  The rows of a stage are therefore accumulated as 6-vectors / 6 x 6 matrices and expanded once.
-    __device__ __forceinline__ double row_coeffs(const double pt[3][2], int j, double c[6]) const {
+    __device__ __forceinline__ double row_coeffs(const double pt[3][2], int j, double c[6], double* hh = nullptr, double* e01 = nullptr) const {
         const double cx = lds[L.OB + 3 * j], cz = lds[L.OB + 3 * j + 1], d = P.radius + lds[L.OB + 3 * j + 2], off = P.beta * d * d;
         const double e0x = pt[0][0] - cx, e0z = pt[0][1] - cz, e1x = pt[1][0] - cx, e1z = pt[1][1] - cz, e2x = pt[2][0] - cx, e2z = pt[2][1] - cz;
         c[0] = 2.0 * w2 * e2x; c[1] = 2.0 * w2 * e2z;
         c[2] = 2.0 * (w0 * e0x + w1 * e1x); c[3] = 2.0 * (w0 * e0z + w1 * e1z);
         c[4] = 2.0 * w1 * e1x * P.dt; c[5] = 2.0 * w1 * e1z * P.dt;
+        if (hh) { hh[0] = e0x * e0x + e0z * e0z - off; hh[1] = e1x * e1x + e1z * e1z - off; e01[0] = e0x; e01[1] = e0z; e01[2] = e1x; e01[3] = e1z; }
         return w0 * (e0x * e0x + e0z * e0z - off) + w1 * (e1x * e1x + e1z * e1z - off) + w2 * (e2x * e2x + e2z * e2z - off);
     }
 
@@ -473,10 +486,11 @@ struct Wave {
     template <bool build, bool ls>
     __device__ __forceinline__ void eval2(Eval2& E, double mu, double dw, double& theta, double& fsum) {
         publish();
+        if constexpr (OD) od_weights(rho[0], rho[1]);
         double um[NU], un[NU];
 #pragma unroll
         for (int j = 0; j < NU; ++j) { um[j] = lds[L.US + k * 4 + j]; un[j] = lds[L.US + (k + 2 <= N + 1 ? k + 2 : N + 1) * 4 + j]; }
-        const bool last = k == N - 1;
+        const bool last = OD || k == N - 1;                                 // (optimal decay: R u^2, nothing couples neighbouring inputs)
         const double dt = P.dt;
         double th = 0.0;
         // scaled objective gradient
@@ -490,9 +504,11 @@ struct Wave {
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             double gj = 0.0;
-            if (stg) { gj = 2.0 * df * P.R[j] * (u[j] - um[j]); if (!last) gj -= 2.0 * df * P.R[j] * (un[j] - u[j]); }
+            if (stg) { gj = 2.0 * df * P.R[j] * (OD ? u[j] : u[j] - um[j]); if (!last) gj -= 2.0 * df * P.R[j] * (un[j] - u[j]); }
             E.gfu[j] = gj;
         }
+        E.Jr[0] = E.Jr[1] = 0.0;
+        E.gfr[0] = (OD && stg) ? 2.0 * df * P.ps1 * (rho[0] - P.rf1) : 0.0; E.gfr[1] = (OD && stg) ? 2.0 * df * P.ps2 * (rho[1] - P.rf2) : 0.0;
 #pragma unroll
         for (int i = 0; i < NV; ++i) E.Jty[i] = 0.0;
         // rows that define x_k: -I (scaled) on x_k from the dynamics of stage k - 1; +I from the initial-state rows on x_0
@@ -579,15 +595,17 @@ struct Wave {
             }
             // rows: accumulated in the 6-dimensional span of V (row_coeffs)
             double M[21], gv[6], jv[6], sl = 0.0;
+            // OD: the rho part of the 8 x 8 accumulation: Mr[r][0..5] = coupling with the span, Dr = (11, 12, 22) block, gr = gradient part
+            double Mr[2][6], Dr[3] = {0.0, 0.0, 0.0}, gr[2] = {0.0, 0.0};
 #pragma unroll
             for (int i = 0; i < 21; ++i) M[i] = 0.0;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { gv[i] = 0.0; jv[i] = 0.0; }
+            for (int i = 0; i < 6; ++i) { gv[i] = 0.0; jv[i] = 0.0; Mr[0][i] = 0.0; Mr[1][i] = 0.0; }
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
                 if (j < K) {
-                    double c[6];
-                    const double cv = row_coeffs(pt, j, c);
+                    double c[6], hh[2], e01[4], br[2] = {0.0, 0.0};
+                    const double cv = row_coeffs(pt, j, c, hh, e01);
                     const double sc = dgd(j);
                     dv[j] = -sc * cv;
                     const double rd = dv[j] - s[j];
@@ -596,6 +614,23 @@ struct Wave {
 #pragma unroll
                     for (int i = 0; i < 6; ++i) jv[i] += om * c[i];                 // J' y: yd_j * grad d_j = -om V c
                     sl += om;
+                    if constexpr (OD) {
+                        // d cbf / d rho_i = a_i (h1 - h0) + a1 a2 rho_other h0;  d2 / d rho1 d rho2 = a1 a2 h0;
+                        // d2 cbf / d (x, u) d rho_i = a_i (grad h1 - grad h0) + a1 a2 rho_other grad h0, in span coordinates (e_0, e_1 | e_3, e_4)
+                        const double a12 = P.alpha1 * P.alpha2;
+                        br[0] = P.alpha1 * (hh[1] - hh[0]) + a12 * rho[1] * hh[0]; br[1] = P.alpha2 * (hh[1] - hh[0]) + a12 * rho[0] * hh[0];
+                        E.Jr[0] -= om * br[0]; E.Jr[1] -= om * br[1];
+                        if (build && !ls) {
+                            Dr[1] -= om * a12 * hh[0];
+#pragma unroll
+                            for (int r = 0; r < 2; ++r) {
+                                const double ai = r == 0 ? P.alpha1 : P.alpha2, ro = r == 0 ? rho[1] : rho[0];
+                                const double k0 = a12 * ro - ai;                     // factor of grad h0; grad h1 carries a_i
+                                Mr[r][2] -= om * 2.0 * (ai * e01[2] + k0 * e01[0]); Mr[r][3] -= om * 2.0 * (ai * e01[3] + k0 * e01[1]);
+                                Mr[r][4] -= om * 2.0 * ai * e01[2] * P.dt; Mr[r][5] -= om * 2.0 * ai * e01[3] * P.dt;
+                            }
+                        }
+                    }
                     if (build) {
                         double Ej, bd;
                         if (ls) { Ej = 1.0; bd = -vU[j]; }                           // q = 1, rhs_t = -(0 + vU), rhs_g = 0: b = q rhs_t
@@ -613,6 +648,12 @@ struct Wave {
                             gv[a] += eb * c[a];
 #pragma unroll
                             for (int b = a; b < 6; ++b, ++e) M[e] += ea * c[a] * c[b];
+                        }
+                        if constexpr (OD) {                                         // the row's gradient in rho is -dgd br: same condensation
+                            gr[0] += eb * br[0]; gr[1] += eb * br[1];
+                            Dr[0] += ea * br[0] * br[0]; Dr[1] += ea * br[0] * br[1]; Dr[2] += ea * br[1] * br[1];
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) { Mr[0][a] += ea * br[0] * c[a]; Mr[1][a] += ea * br[1] * c[a]; }
                         }
                     }
                 } else dv[j] = 0.0;
@@ -632,9 +673,27 @@ struct Wave {
                     // second derivatives of the dynamics: weights dgc y (rows 3..5) + dt nu2 through the second barrier point, nu2 = -(jv[0], jv[1])
                     cc[0] = (dgc(3) * yc[3] - dt * jv[0]) * dt; cc[1] = (dgc(4) * yc[4] - dt * jv[1]) * dt; cc[2] = dgc(5) * yc[5] * dt;
                 }
+                auto Mi = [](int a, int b) { return a <= b ? a * 6 - a * (a - 1) / 2 + (b - a) : b * 6 - b * (b - 1) / 2 + (a - b); };
+                if constexpr (OD) {
+                    // the decay block D = (objective + dw) I + Dr, gradient g_rho; eliminated inside the span: M -= Mr' D^-1 Mr, gv -= Mr' D^-1 g_rho
+                    const double d11 = (ls ? 1.0 : 2.0 * df * P.ps1 + dw) + Dr[0], d12 = Dr[1], d22 = (ls ? 1.0 : 2.0 * df * P.ps2 + dw) + Dr[2];
+                    const double det = d11 * d22 - d12 * d12;
+                    od_bad = !(d11 > 0.0) || !(det > 0.0);                          // not positive definite: the inertia correction takes it
+                    const double idet = 1.0 / det;
+                    odD[0] = d22 * idet; odD[1] = -d12 * idet; odD[2] = d11 * idet;
+                    odg[0] = E.gfr[0] + (ls ? 0.0 : E.Jr[0]) + gr[0]; odg[1] = E.gfr[1] + (ls ? 0.0 : E.Jr[1]) + gr[1];
+                    const double t0 = odD[0] * odg[0] + odD[1] * odg[1], t1 = odD[1] * odg[0] + odD[2] * odg[1];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        odM[0][a] = Mr[0][a]; odM[1][a] = Mr[1][a];
+                        gv[a] -= Mr[0][a] * t0 + Mr[1][a] * t1;
+                        const double s0 = odD[0] * Mr[0][a] + odD[1] * Mr[1][a], s1 = odD[1] * Mr[0][a] + odD[2] * Mr[1][a];
+#pragma unroll
+                        for (int b = a; b < 6; ++b) M[Mi(a, b)] -= s0 * Mr[0][b] + s1 * Mr[1][b];
+                    }
+                }
                 // H[a][b] = sum_q t_a[q] V[b][q] with t_a[q] = sum_p V[a][p] M[p][q]  (+ dynamics curvature, + diagonal): computed once, stored
                 const int U4[4] = {0, 1, 3, 4};
-                auto Mi = [](int a, int b) { return a <= b ? a * 6 - a * (a - 1) / 2 + (b - a) : b * 6 - b * (b - 1) / 2 + (a - b); };
                 ldsd* Ho = lds + L.H + k * 55; ldsd* Go = lds + L.G + k * 10;
 #pragma unroll
                 for (int a = 0; a < NV; ++a) {
@@ -692,7 +751,7 @@ struct Wave {
             }
         }
         theta = ipm::wsum(th);
-        fsum = ipm::wsum(cost_share(x, u, um));
+        fsum = ipm::wsum(cost_share(x, u, um, rho));
         if (build) sync();
     }
 
@@ -735,14 +794,24 @@ struct Wave {
                 const double v = row[0] * dx[2] + row[1] * dx[3] + row[2] * dx[4] + row[3] * du[0] + row[4] * du[1] + row[5] * du[2] + row[6] * du[3];
                 vd[c] += P.dt * v;
             }
+            if constexpr (OD) {                                              // d rho = -D^-1 (g_rho + M_rho,v vd)
+                double t0 = odg[0], t1 = odg[1];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { t0 += odM[0][i] * vd[i]; t1 += odM[1][i] * vd[i]; }
+                drho[0] = -(odD[0] * t0 + odD[1] * t1); drho[1] = -(odD[1] * t0 + odD[2] * t1);
+            }
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
                 if (j < K) {
-                    double c[6];
-                    row_coeffs(pt, j, c);
+                    double c[6], hh[2], e01[4];
+                    row_coeffs(pt, j, c, hh, e01);
                     double adw = 0.0;
 #pragma unroll
                     for (int i = 0; i < 6; ++i) adw += c[i] * vd[i];
+                    if constexpr (OD) {
+                        const double a12 = P.alpha1 * P.alpha2;
+                        adw += (P.alpha1 * (hh[1] - hh[0]) + a12 * rho[1] * hh[0]) * drho[0] + (P.alpha2 * (hh[1] - hh[0]) + a12 * rho[0] * hh[0]) * drho[1];
+                    }
                     adw *= -dgd(j);
                     if (ls) { dyd[j] = adw + vU[j]; ds[j] = 0.0; dvU[j] = 0.0; }
                     else {
@@ -757,6 +826,7 @@ struct Wave {
         } else {
 #pragma unroll
             for (int j = 0; j < KS; ++j) { dyd[j] = 0.0; ds[j] = 0.0; dvU[j] = 0.0; }
+            drho[0] = drho[1] = 0.0;
         }
         if (!ls) {
             if (act) {
@@ -804,6 +874,7 @@ struct Wave {
                 c = fmax(c, fmax(fabs((u[j] - ubL[j]) * zuL[j] - mu), fabs((ubU[j] - u[j]) * zuU[j] - mu)));
                 zsum += fabs(zuL[j]) + fabs(zuU[j]);
             }
+            if constexpr (OD) d = fmax(d, fmax(fabs(E.gfr[0] + E.Jr[0]), fabs(E.gfr[1] + E.Jr[1])));
 #pragma unroll
             for (int i = 0; i < NX; ++i) { p = fmax(p, fabs(rc[i])); up = fmax(up, fabs(rc[i] / dgc(i))); ysum += fabs(yc[i]); }
 #pragma unroll
@@ -862,6 +933,7 @@ struct Wave {
                     v += (mu / (sU[j] - s[j]) - O.kappa_d * mu) * ds[j];
                 }
             }
+            if constexpr (OD) v += E.gfr[0] * drho[0] + E.gfr[1] * drho[1];
         }
         a_max = ipm::wmin(ap); a_z = ipm::wmin(az); gBD = ipm::wsum(v);
     }
@@ -908,6 +980,8 @@ struct Wave {
         for (int j = 0; j < NU; ++j) u[j] = uprev[j];
 #pragma unroll
         for (int j = 0; j < KS; ++j) { s[j] = 0.0; yd[j] = 0.0; vU[j] = 1.0; sU[j] = rl; }
+        rho[0] = P.rf1; rho[1] = P.rf2; drho[0] = drho[1] = 0.0;
+        if constexpr (OD) od_weights(rho[0], rho[1]);
         {
             const double lo[3] = {-P.pitch_max, -P.v_max, -P.descent_max}, hi[2] = {P.pitch_max, P.v_max};
 #pragma unroll
@@ -961,14 +1035,18 @@ struct Wave {
             for (int j = 0; j < KS; ++j) {
                 double sc = 1.0;
                 if (j < K) {
-                    double c[6], r[NV];
-                    row_coeffs(pt, j, c);
+                    double c[6], r[NV], hh[2], e01[4];
+                    row_coeffs(pt, j, c, hh, e01);
 #pragma unroll
                     for (int a = 0; a < NV; ++a) r[a] = G2[0][a] * c[0] + G2[1][a] * c[1];
                     r[0] += c[2]; r[1] += c[3]; r[3] += c[4]; r[4] += c[5];
                     double rm = 0.0;
 #pragma unroll
                     for (int i = 0; i < NV; ++i) rm = fmax(rm, fabs(r[i]));
+                    if constexpr (OD) {
+                        const double a12 = P.alpha1 * P.alpha2;
+                        rm = fmax(rm, fmax(fabs(P.alpha1 * (hh[1] - hh[0]) + a12 * rho[1] * hh[0]), fabs(P.alpha2 * (hh[1] - hh[0]) + a12 * rho[0] * hh[0])));
+                    }
                     sc = rm > O.nlp_scaling_max_gradient ? fmax(O.nlp_scaling_min_value, O.nlp_scaling_max_gradient / rm) : 1.0;
                 }
                 if (lane == 0) lds[L.SC + 6 + j] = sc;
@@ -1008,8 +1086,10 @@ struct Wave {
             }
             if (build) {
                 MPROF_ADD(2)
-                const double cs = ls ? 0.0 : 2.0 * df;
-                const bool okf = riccati_backward(lds, L, N, lane, P.dt, cs * P.R[0], cs * P.R[1], cs * P.R[2], cs * P.R[3]);
+                const double cs = (ls || OD) ? 0.0 : 2.0 * df;
+                bool okf = true;
+                if constexpr (OD) okf = ipm::wmax((stg && od_bad) ? 1.0 : 0.0) == 0.0;      // a decay block that is not positive definite
+                if (okf) okf = riccati_backward(lds, L, N, lane, P.dt, cs * P.R[0], cs * P.R[1], cs * P.R[2], cs * P.R[3]);
                 MPROF_ADD(3)
                 if (!okf) {                                                 // Algorithm IC: the same system with a larger delta_w
                     if (ic_first) {
@@ -1069,7 +1149,7 @@ struct Wave {
                 const double sw_l = gBD < 0.0 ? pow(-gBD, O.s_phi) : 0.0, sw_r = O.delta * pow(theta, O.s_theta);
                 double alpha = a_max;
                 bool first = true, accepted = false;
-                double xt[NX], ut[NU], st[KS];
+                double xt[NX], ut[NU], st[KS], rt[2] = {rho[0], rho[1]};
                 double phi_t = 0.0, th_t = 0.0;
                 while (alpha > a_min || first) {
 #pragma unroll
@@ -1078,9 +1158,10 @@ struct Wave {
                     for (int j = 0; j < NU; ++j) ut[j] = u[j] + alpha * (stg ? lds[L.DU + k * NU + j] : 0.0);
 #pragma unroll
                     for (int j = 0; j < KS; ++j) st[j] = s[j] + alpha * ds[j];
+                    if constexpr (OD) { rt[0] = rho[0] + alpha * drho[0]; rt[1] = rho[1] + alpha * drho[1]; }
                     safe_slacks(xt, ut, st, mu);
                     double f_t;
-                    eval0(xt, ut, st, th_t, f_t);
+                    eval0(xt, ut, st, rt, th_t, f_t);
                     phi_t = barrier(f_t, xt, ut, st, mu);
                     if (phi_t < INF_ && th_t == th_t && phi_t == phi_t) {
                         bool ok = th_t <= theta_max;
@@ -1124,6 +1205,7 @@ struct Wave {
                 for (int j = 0; j < NU; ++j) u[j] = ut[j];
 #pragma unroll
                 for (int j = 0; j < KS; ++j) { s[j] = st[j]; yd[j] += alpha * dyd[j]; }
+                if constexpr (OD) { rho[0] = rt[0]; rho[1] = rt[1]; }
                 safe_slacks(x, u, s, mu);
                 // bound multipliers: z += a_z dz, then kappa_sigma
                 {
@@ -1177,15 +1259,15 @@ struct Wave {
     }
 };
 
-template <typename TIO, int KS>
+template <typename TIO, int KS, bool OD = false>
 __global__ void __launch_bounds__(64) mpcvtol_ms_kernel(const Params P, const sc_ipopt_params O, long long B, int obs_shared, const TIO* __restrict__ X,
                                                         const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
                                                         TIO* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out,
-                                                        TIO* __restrict__ plan_out, double* __restrict__ trace_out) {
+                                                        TIO* __restrict__ plan_out, double* __restrict__ trace_out, TIO* __restrict__ rho_out) {
     extern __shared__ double ms_lds[];
     const long long b = blockIdx.x;
     if (b >= B) return;
-    Wave<KS> S(P, O, (ldsd*)ms_lds);
+    Wave<KS, OD> S(P, O, (ldsd*)ms_lds);
     const TIO* ob = obs + (obs_shared ? 0 : b * P.K * 7);
     if ((int)threadIdx.x < 3 * KS_MAX) {
         const int j = threadIdx.x / 3, c = threadIdx.x % 3;
@@ -1208,16 +1290,19 @@ __global__ void __launch_bounds__(64) mpcvtol_ms_kernel(const Params P, const sc
         for (int i = 0; i < NX; ++i) po[S.k * NX + i] = (TIO)S.x[i];
         if (S.stg) for (int j = 0; j < NU; ++j) po[(P.N + 1) * NX + S.k * NU + j] = (TIO)S.u[j];
     }
+    if constexpr (OD) {
+        if (rho_out && S.stg) { rho_out[b * (long long)(2 * P.N) + 2 * S.k] = (TIO)S.rho[0]; rho_out[b * (long long)(2 * P.N) + 2 * S.k + 1] = (TIO)S.rho[1]; }
+    }
 }
 
-template <typename TIO, int KS>
+template <typename TIO, int KS, bool OD = false>
 static hipError_t launch_t(const Params& P, const sc_mpcvtol_params& p, const sc_ipopt_params& O, long long B, size_t lds, const void* X, const void* u_prev,
                            const void* goal, const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out,
-                           hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute((const void*)mpcvtol_ms_kernel<TIO, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                           hipStream_t stream, void* rho_out = nullptr) {
+    hipError_t e = hipFuncSetAttribute((const void*)mpcvtol_ms_kernel<TIO, KS, OD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mpcvtol_ms_kernel<TIO, KS>), dim3((unsigned)B), dim3(64), lds, stream, P, O, B, p.obs_shared, (const TIO*)X, (const TIO*)u_prev,
-                       (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status_out, iters_out, (TIO*)plan_out, trace_out);
+    hipLaunchKernelGGL((mpcvtol_ms_kernel<TIO, KS, OD>), dim3((unsigned)B), dim3(64), lds, stream, P, O, B, p.obs_shared, (const TIO*)X, (const TIO*)u_prev,
+                       (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status_out, iters_out, (TIO*)plan_out, trace_out, (TIO*)rho_out);
     return hipGetLastError();
 }
 
@@ -1234,6 +1319,21 @@ hipError_t mpcvtol_ms_launch(const sc_mpcvtol_params& p, const sc_ipopt_params& 
                       : msk::launch_t<double, 16>(P, p, O, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, stream);
     return K <= 8 ? msk::launch_t<float, 8>(P, p, O, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, stream)
                   : msk::launch_t<float, 16>(P, p, O, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, stream);
+}
+
+// optimal-decay MPC-CBF for VTOL2D in the multiple-shooting form (sc_odmpcvtol_params: the condensed entry's struct)
+hipError_t odmpcvtol_ms_launch(const sc_odmpcvtol_params& q, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
+                               const void* obs, void* u_out, void* rho_out, int* status_out, int* iters_out, void* plan_out, double* trace_out,
+                               hipStream_t stream) {
+    const sc_mpcvtol_params& p = q.mpc;
+    Params P = from_c(p, K);
+    P.ps1 = q.p_sb[0]; P.ps2 = q.p_sb[1]; P.rf1 = q.omega_ref[0]; P.rf2 = q.omega_ref[1];
+    const size_t lds = msk::lds_bytes(p.horizon);
+    if (p.io_dtype == SC_DTYPE_F64)
+        return K <= 8 ? msk::launch_t<double, 8, true>(P, p, O, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, stream, rho_out)
+                      : msk::launch_t<double, 16, true>(P, p, O, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, stream, rho_out);
+    return K <= 8 ? msk::launch_t<float, 8, true>(P, p, O, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, stream, rho_out)
+                  : msk::launch_t<float, 16, true>(P, p, O, B, lds, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, stream, rho_out);
 }
 
 }  // namespace sc

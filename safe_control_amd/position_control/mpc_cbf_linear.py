@@ -209,7 +209,7 @@ class BatchedOptimalDecayLinearMPCCBF(BatchedLinearMPCCBF):
     ``solve(...)`` -> ``u[B,4]``, ``rho[B,N]``, ``status[B]``, ``iters[B]`` (and ``z[B,4N]`` if asked)."""
 
     def __init__(self, robot_spec, dt=0.05, io_dtype="f64", horizon=None, cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER,
-                 superellipsoids=True):
+                 superellipsoids=True, iter_slices=None, classify_first=True, order=True):
         spec = complete_robot_spec(robot_spec)
         if spec["model"] != "Quad3D":
             raise NotImplementedError("the optimal-decay extension of the linear-model kernel serves Quad3D")
@@ -217,7 +217,8 @@ class BatchedOptimalDecayLinearMPCCBF(BatchedLinearMPCCBF):
         if cbf_param:
             self.od.update({k: cbf_param[k] for k in ("omega1", "p_sb1") if k in cbf_param})
         self._superellipsoids = bool(superellipsoids)
-        super().__init__(robot_spec, dt=dt, io_dtype=io_dtype, horizon=horizon, cbf_param=cbf_param, tol=tol, max_iter=max_iter)
+        super().__init__(robot_spec, dt=dt, io_dtype=io_dtype, horizon=horizon, cbf_param=cbf_param, tol=tol, max_iter=max_iter,
+                         iter_slices=iter_slices, classify_first=classify_first, order=order)
 
     def _params(self, **kw):
         p = make_params(self._mdl, self.cbf_param, self.horizon, self.robot_spec["radius"], self.io_dtype, **kw)

@@ -15,7 +15,8 @@ import numpy as np
 from .. import _lib
 from ..robots.spec import complete_robot_spec
 from .mpc_cbf import apply_mpc_overrides
-from .mpc_cbf_vtol import CBF_VTOL, HORIZON_VTOL, Q_VTOL, R_VTOL, BatchedVtolMPCCBF, make_params
+from .mpc_cbf_vtol import (CBF_VTOL, HORIZON_VTOL, OD_CBF_VTOL, Q_VTOL, R_VTOL, BatchedOptimalDecayVtolMPCCBF, BatchedVtolMPCCBF, make_od_params,
+                           make_params)
 
 
 class BatchedVtolMSMPCCBF:
@@ -89,6 +90,61 @@ class BatchedVtolMSMPCCBF:
                     plan[idx] = float("nan")
                     plan[idx, (self.horizon + 1) * 6:] = r[3]
         out = [u, status, iters]
+        if want_plan:
+            out.append(plan)
+        if want_trace:
+            out.append(trace)
+        return tuple(out)
+
+
+class BatchedOptimalDecayVtolMSMPCCBF(BatchedVtolMSMPCCBF):
+    """Optimal-decay MPC-CBF for VTOL2D (optimal_decay_mpc_cbf.py with a VTOL2D robot) in the multiple-shooting form: the decay rates are two
+    more inputs of a stage.  ``solve(...)`` -> ``u[B,4]``, ``rho[B,2N]``, ``status[B]``, ``iters[B]`` [, ``plan``].  Problems that come back
+    SC_STATUS_NEEDS_RESTO go to the condensed optimal-decay kernel (``BatchedOptimalDecayVtolMPCCBF``)."""
+
+    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f64", cbf_param=None, ipopt=None, fallback=True, max_iter=None):
+        super().__init__(robot_spec, dt=dt, io_dtype=io_dtype, cbf_param=cbf_param or dict(OD_CBF_VTOL), ipopt=ipopt, fallback=False, max_iter=max_iter)
+        self.fallback = bool(fallback)
+        self.condensed = BatchedOptimalDecayVtolMPCCBF(dict(self.robot_spec), dt=dt, io_dtype=io_dtype, cbf_param=dict(self.cbf_param)) if fallback else None
+
+    def solve(self, X, u_prev, goal, obs, want_plan=False, want_trace=False, want_z=False):
+        import torch
+        dt_ = self.torch_dtype
+        for name, t in (("X", X), ("u_prev", u_prev), ("goal", goal), ("obs", obs)):
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == dt_):
+                raise ValueError(f"{name} must be a contiguous CUDA tensor of dtype {dt_}")
+        B = X.shape[0]
+        shared = obs.dim() == 2
+        K = obs.shape[-2]
+        if X.shape != (B, 6) or u_prev.shape != (B, 4) or goal.shape != (B, 2) or obs.shape[-1] != 7 or (not shared and obs.shape[0] != B):
+            raise ValueError("expected X[B,6], u_prev[B,4], goal[B,2], obs[B,K,7] or obs[K,7]")
+        u = torch.empty((B, 4), dtype=dt_, device=X.device)
+        rho = torch.empty((B, 2 * self.horizon), dtype=dt_, device=X.device)
+        status = torch.empty((B,), dtype=torch.int32, device=X.device)
+        iters = torch.empty((B,), dtype=torch.int32, device=X.device)
+        want_plan = want_plan or want_z
+        plan = torch.empty((B, self.plan_width), dtype=dt_, device=X.device) if want_plan else None
+        ip = _lib.default_ipopt(**self.ipopt)
+        trace = torch.zeros((B, ip.max_iter + 1, 8), dtype=torch.float64, device=X.device) if want_trace else None
+        p = make_od_params(self.robot_spec, self.cbf_param, self.horizon, self.dt, self.robot_spec["radius"], self.io_dtype, obs_shared=shared)
+        stream = torch.cuda.current_stream(X.device).cuda_stream
+        rc = self._lib.sc_odmpcvtol_ms_solve_batch(C.byref(p), C.byref(ip), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(),
+                                                   u.data_ptr(), rho.data_ptr(), status.data_ptr(), iters.data_ptr(),
+                                                   plan.data_ptr() if plan is not None else None, trace.data_ptr() if trace is not None else None, stream)
+        _lib.check(rc, "sc_odmpcvtol_ms_solve_batch")
+        self.n_fallback = 0
+        if self.fallback:
+            idx = torch.nonzero(status == _lib.STATUS_NEEDS_RESTO).flatten()
+            self.n_fallback = int(idx.numel())
+            if self.n_fallback:
+                ob = obs if shared else obs[idx].contiguous()
+                r = self.condensed.solve(X[idx].contiguous(), u_prev[idx].contiguous(), goal[idx].contiguous(), ob, want_z=plan is not None)
+                u[idx], rho[idx], status[idx] = r[0], r[1], r[2]
+                iters[idx] = iters[idx] + r[3]
+                if plan is not None:
+                    plan[idx] = float("nan")
+                    plan[idx, (self.horizon + 1) * 6:] = r[4]
+        out = [u, rho, status, iters]
         if want_plan:
             out.append(plan)
         if want_trace:
