@@ -60,6 +60,30 @@ def test_batch_against_oracle():
     assert (moved[ok] > 1e-3).sum() >= 4, "the batch must hold problems whose decay variables leave the reference"
 
 
+def test_wide_batch_against_oracle():
+    """256 problems (128 with a disc on the flight path) at a 600-iteration budget on both sides: the run that lived in
+    tools/exp_od_vtol_wide.py.  Bars: same status on >= 99 %; of the problems both call optimal, >= 99 % agree to the bars of the
+    small test (the rest sit on a flat valley of the decay penalty and are printed)."""
+    n = 256
+    X, up, goal, obs = hard_batch(n)
+    ctl = sca.BatchedOptimalDecayVtolMPCCBF(io_dtype="f64", max_iter=600)
+    u, rho, st, it, z = (a.cpu().numpy() for a in ctl.solve(t(X), t(up), t(goal), t(obs), want_z=True))
+    o = od_vtol_solve_many(X, up, goal, obs, params={"max_iter": 600}, timeout=6000)
+    same = st == o["st"]
+    ok = same & (o["st"] == 0)
+    du = np.abs(u - o["u"]).max(axis=1); dz = np.abs(z - o["z"]).max(axis=1); dr = np.abs(rho - o["rho"]).max(axis=1)
+    good = (du <= 1e-6) & (dz <= 2e-5) & (dr <= 2e-5)
+    moved = np.abs(o["rho"] - 1.0).max(axis=1) > 1e-3
+    print(f"od vtol, {n} problems: optimal {np.mean(o['st'] == 0):.4f} infeasible {np.mean(o['st'] == 1):.4f} inaccurate {np.mean(o['st'] == 2):.4f}; "
+          f"status differs on {int((~same).sum())} {np.flatnonzero(~same)[:10]}; iterations equal on {np.mean(it == o['it']):.4f}, mean {o['it'].mean():.1f} "
+          f"max {o['it'].max()}; on the optimal ones max du {du[ok].max():.2e} dz {dz[ok].max():.2e} drho {dr[ok].max():.2e}; beyond the bars: "
+          f"{np.flatnonzero(ok & ~good)[:10]}; decay moved on {int((moved & ok).sum())}")
+    assert same.mean() >= 0.99, np.flatnonzero(~same)
+    assert ok.mean() >= 0.75
+    assert good[ok].mean() >= 0.99
+    assert (moved & ok).sum() >= 16
+
+
 def test_decay_variables_stay_at_reference_when_no_row_is_active_and_cost_is_absolute():
     n = 8
     X, up, goal, obs = (a[:n].copy() for a in W.mpc_family_batch("vtol", 64, 4, seed=3))
