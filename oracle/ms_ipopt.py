@@ -685,6 +685,14 @@ class _Algo:
             sc[nx + k * nx: nx + (k + 1) * nx] = -np.diagonal(J[nx + k * nx: nx + (k + 1) * nx, (k + 1) * nv:(k + 1) * nv + nx])
         Jc = [J[nx + k * nx: nx + (k + 1) * nx, k * nv:(k + 1) * nv] / sc[nx + k * nx: nx + (k + 1) * nx, None] for k in range(N)]       # [A_k B_k]
         Jd = [J[mc + k * K: mc + (k + 1) * K, k * nv:(k + 1) * nv] for k in range(N)]
+        # optimal-decay stages: the decay rates (the last nr inputs, absent from the dynamics) leave the stage before the recursion
+        nr = (nu - S.mdl["nu_dyn"]) if (S.mdl.get("od") is not None and o.get("od_elimination", "sequential") == "sequential") else 0
+        if nr:
+            from types import SimpleNamespace
+            Sr = SimpleNamespace(N=N, nx=nx, nu=nu - nr, nv=nv - nr, K=K, n=n - N * nr)
+            Jcr = [a[:, :nv - nr] for a in Jc]
+            Jdr = [a[:, :nv - nr] for a in Jd]
+            cplr = [c[:nu - nr] for c in cpl]
         dw = 0.0
         first = True
         while True:
@@ -693,7 +701,11 @@ class _Algo:
             np.add.at(e, P.t_row, q)
             e_c, e_d = (e[:mc] / (sc * sc)).reshape(N + 1, nx), e[mc:].reshape(N, K)
             soft = bool(np.any(e_c > 0.0))
-            fac = self._riccati_backward(S, Wd, WN, cpl, Jc, Jd, sig_x, dw, e_c, e_d, soft)
+            if nr:
+                red = self._od_eliminate(S, Wd, Jd, sig_x, dw, e_d, nr)
+                fac = None if red is None else self._riccati_backward(Sr, None, WN, cplr, Jcr, None, sig_x[N * nv:], dw, e_c, e_d, soft, Hs=red["R"])
+            else:
+                fac = self._riccati_backward(S, Wd, WN, cpl, Jc, Jd, sig_x, dw, e_c, e_d, soft)
             if fac is not None:
                 if dw > 0.0:
                     self.delta_w_last = dw
@@ -711,15 +723,94 @@ class _Algo:
             b = rhs_g.copy()
             np.subtract.at(b, P.t_row, P.t_sig * q * rhs_t)
             b[:mc] /= sc
-            dx, dy = self._riccati_solve(S, fac, Jc, Jd, e_c, e_d, soft, rhs_x, b)
+            if nr:
+                nvr = nv - nr
+                b_d = b[mc:].reshape(N, K)
+                gs, ts = self._od_reduce_rhs(red, rhs_x, b_d, N, nv, nr)
+                dxr, dy = self._riccati_solve(Sr, fac, Jcr, Jdr, e_c, e_d, soft, np.concatenate([np.zeros(N * nvr), rhs_x[N * nv:]]), b, gs=gs)
+                dx = np.zeros(n)
+                dx[N * nv:] = dxr[N * nvr:]
+                for k in range(N):
+                    v = dxr[k * nvr:(k + 1) * nvr]
+                    dr = -(ts[k] + red["T"][k].T @ v)                      # d rho = -D^-1 (g_rho + M_rho,v d(x, u))
+                    dx[k * nv:k * nv + nvr] = v
+                    dx[k * nv + nvr:(k + 1) * nv] = dr
+                    dy[mc + k * K: mc + (k + 1) * K] += (Jd[k][:, nvr:] @ dr) / e_d[k]
+            else:
+                dx, dy = self._riccati_solve(S, fac, Jc, Jd, e_c, e_d, soft, rhs_x, b)
             dy[:mc] /= sc
             dt = q * (rhs_t - P.t_sig * dy[P.t_row])
             return dx, dt, dy
         return solve
 
     @staticmethod
-    def _riccati_backward(S, Wd, WN, cpl, Jc, Jd, sig_x, dw, e_c, e_d, soft):
+    def _od_eliminate(S, Wd, Jd, sig_x, dw, e_d, nr):
+        """Schur complement of the nr trailing stage variables (decay rates) in H_k = W_k + Sigma + dw + Jd_k' E Jd_k, the way
+        csrc/mpc_vtol_ms.hip takes it (eval2, OD): the block without the rows is eliminated first, every row then enters as a rank-one
+        update of the complement,
+            w = D^-1 b, r = c - T b, q = 1 / E + b . w:   H/rho += r r' / q,  T += r w' / q,  D^-1 -= w w' / q        (T = M_v,rho D^-1)
+        with (c, b) the row's gradient in (x, u | rho).  An active row at mu ~ 1e-9 has E b^2 ~ 1e13 against 2 df p_sb ~ 1e-2: the
+        assembled block keeps nothing of the small part (tools/micro/seq_schur.py).  Inertia: every q < 0 turns one negative eigenvalue of
+        D positive (det (D + E b b') = det D (1 + E b' D^-1 b); a positive semidefinite update lowers no eigenvalue); D not positive
+        definite at the end -> None (Algorithm IC raises delta_w)."""
+        N, nv, K = S.N, S.nv, S.K
+        nvr = nv - nr
+        assert nr == 2
+        Rs, Ts, D0, T0, steps = [], [], [], [], []
+        for k in range(N):
+            H0 = Wd[k] + np.diag(sig_x[k * nv:(k + 1) * nv] + dw)
+            s11, s12, s22 = H0[nvr, nvr], H0[nvr, nvr + 1], H0[nvr + 1, nvr + 1]
+            det = s11 * s22 - s12 * s12
+            if not abs(det) > 0.0:
+                return None
+            nneg = (0 if s11 > 0.0 else 2) if det > 0.0 else 1
+            Di = np.array([[s22, -s12], [-s12, s11]]) / det
+            Mr = H0[nvr:, :nvr]
+            T = Mr.T @ Di
+            R = H0[:nvr, :nvr] - T @ Mr
+            D0.append(Di.copy()); T0.append(T.copy())
+            st = []
+            for j in range(K):
+                c, b = Jd[k][j, :nvr], Jd[k][j, nvr:]
+                w = Di @ b
+                q = e_d[k][j] + b @ w                                      # e_d = 1 / E
+                if q < 0.0:
+                    nneg -= 1
+                if not abs(q) > 0.0:
+                    return None
+                r = c - T @ b
+                st.append((w, q, r, b))
+                R = R + np.outer(r, r) / q
+                T = T + np.outer(r, w) / q
+                Di = Di - np.outer(w, w) / q
+            if nneg != 0:
+                return None
+            Rs.append(0.5 * (R + R.T)); Ts.append(T); steps.append(st)
+        return dict(R=Rs, T=Ts, D0=D0, T0=T0, steps=steps)
+
+    @staticmethod
+    def _od_reduce_rhs(red, rhs_x, b_d, N, nv, nr):
+        """gradient side of _od_eliminate: g_(x,u) and t = D^-1 g_rho after the rows  (sigma = (gamma / E - b . t) / q:  g += sigma r,  t += sigma w;
+        the row's share of the gradient is gamma (c, b) with gamma / E = -b_d)."""
+        nvr = nv - nr
+        gs, ts = [], []
+        for k in range(N):
+            g0 = -rhs_x[k * nv:(k + 1) * nv]
+            t = red["D0"][k] @ g0[nvr:]
+            g = g0[:nvr] - red["T0"][k] @ g0[nvr:]
+            for j, (w, q, r, b) in enumerate(red["steps"][k]):
+                sig = (-b_d[k][j] - b @ t) / q
+                g = g + sig * r
+                t = t + sig * w
+            gs.append(g); ts.append(t)
+        return gs, ts
+
+    @staticmethod
+    def _riccati_backward(S, Wd, WN, cpl, Jc, Jd, sig_x, dw, e_c, e_d, soft, Hs=None):
         N, nx, nu, nv, K = S.N, S.nx, S.nu, S.nv, S.K
+        if Hs is not None:                                                 # stage Hessians given (rows and regularisation inside): sig_x = the terminal block's
+            sig_x = np.concatenate([np.zeros(N * nv), sig_x])
+        Hs_in = Hs
         na = nx + nu
         Pm = np.zeros((N + 1, na, na))                                     # value functions (unmodified)
         Pt = np.zeros((N + 1, na, na))                                     # parallel sums (soft rows) = what the stage before sees
@@ -727,7 +818,7 @@ class _Algo:
         Pm[N][:nx, :nx] = WN + np.diag(sig_x[N * nv:] + dw)
         for k in range(N, -1, -1):
             if k < N:
-                H = Wd[k] + np.diag(sig_x[k * nv:(k + 1) * nv] + dw) + Jd[k].T @ (Jd[k] / e_d[k][:, None])
+                H = Hs_in[k] if Hs_in is not None else Wd[k] + np.diag(sig_x[k * nv:(k + 1) * nv] + dw) + Jd[k].T @ (Jd[k] / e_d[k][:, None])
                 Hs[k] = H
                 G = np.zeros((na, na + nu))                                # xi+ = G (xi; u):  [[A, 0, B], [0, 0, I]]
                 G[:nx, :nx] = Jc[k][:, :nx]
@@ -769,7 +860,7 @@ class _Algo:
         return dict(Pm=Pm, Pt=Pt, Lq=Lq, Kg=Kg, Hs=Hs)
 
     @staticmethod
-    def _riccati_solve(S, fac, Jc, Jd, e_c, e_d, soft, rhs_x, b):
+    def _riccati_solve(S, fac, Jc, Jd, e_c, e_d, soft, rhs_x, b, gs=None):
         """H dx + J' dy = rhs_x,  J dx - e dy = b  for one right-hand side with the factors of _riccati_backward."""
         N, nx, nu, nv, K = S.N, S.nx, S.nu, S.nv, S.K
         na, mc = nx + nu, (S.N + 1) * S.nx
@@ -783,7 +874,7 @@ class _Algo:
         E[:, :nx] = e_c
         for k in range(N, -1, -1):
             if k < N:
-                g = -rhs_x[k * nv:(k + 1) * nv] - Jd[k].T @ (b_d[k] / e_d[k])
+                g = gs[k] if gs is not None else -rhs_x[k * nv:(k + 1) * nv] - Jd[k].T @ (b_d[k] / e_d[k])
                 cb = np.zeros(na)
                 cb[:nx] = -b_c[k + 1]                                       # defect of the dynamics row block k + 1
                 G = np.zeros((na, na + nu))

@@ -284,7 +284,7 @@ struct Wave {
     double xbL[3], xbU[2], ubL[NU], ubU[NU];              // (relaxed, adjustable) bounds: x idx 2, 3, 4 lower / 2, 3 upper; inputs
     double zxL[3], zxU[2], zuL[NU], zuU[NU];
     double s[KS], yd[KS], vU[KS], sU[KS];
-    double rho[2], drho[2], odD[3], odM[2][6], odg[2];   // OD: decay rates, their step; D^-1 (11, 12, 22), M_rho,v and g_rho of the last Newton system
+    double rho[2], drho[2], odT[6][2], odt[2];           // OD: decay rates, their step; (D^-1 M_rho,v)' and D^-1 g_rho of the last Newton system
     double df;
     double rc[NX], dv[KS];                               // scaled residuals of my dynamics rows, scaled row values (last evaluation)
     double ds[KS], dyd[KS], dvU[KS], dzxL[3], dzxU[2], dzuL[NU], dzuU[NU];
@@ -596,7 +596,7 @@ struct Wave {
             // rows: accumulated in the 6-dimensional span of V (row_coeffs)
             double M[21], gv[6], jv[6], sl = 0.0;
             // OD: the rho part of the 8 x 8 accumulation: Mr[r][0..5] = coupling with the span, Dr = (11, 12, 22) block, gr = gradient part
-            double Mr[2][6], Dr[3] = {0.0, 0.0, 0.0}, gr[2] = {0.0, 0.0};
+            double Mr[2][6], Dl12 = 0.0;
 #pragma unroll
             for (int i = 0; i < 21; ++i) M[i] = 0.0;
 #pragma unroll
@@ -621,7 +621,7 @@ struct Wave {
                         br[0] = P.alpha1 * (hh[1] - hh[0]) + a12 * rho[1] * hh[0]; br[1] = P.alpha2 * (hh[1] - hh[0]) + a12 * rho[0] * hh[0];
                         E.Jr[0] -= om * br[0]; E.Jr[1] -= om * br[1];
                         if (build && !ls) {
-                            Dr[1] -= om * a12 * hh[0];
+                            Dl12 -= om * a12 * hh[0];
 #pragma unroll
                             for (int r = 0; r < 2; ++r) {
                                 const double ai = r == 0 ? P.alpha1 : P.alpha2, ro = r == 0 ? rho[1] : rho[0];
@@ -631,7 +631,7 @@ struct Wave {
                             }
                         }
                     }
-                    if (build) {
+                    if (build && !OD) {
                         double Ej, bd;
                         if (ls) { Ej = 1.0; bd = -vU[j]; }                           // q = 1, rhs_t = -(0 + vU), rhs_g = 0: b = q rhs_t
                         else {
@@ -649,14 +649,81 @@ struct Wave {
 #pragma unroll
                             for (int b = a; b < 6; ++b, ++e) M[e] += ea * c[a] * c[b];
                         }
-                        if constexpr (OD) {                                         // the row's gradient in rho is -dgd br: same condensation
-                            gr[0] += eb * br[0]; gr[1] += eb * br[1];
-                            Dr[0] += ea * br[0] * br[0]; Dr[1] += ea * br[0] * br[1]; Dr[2] += ea * br[1] * br[1];
-#pragma unroll
-                            for (int a = 0; a < 6; ++a) { Mr[0][a] += ea * br[0] * c[a]; Mr[1][a] += ea * br[1] * c[a]; }
-                        }
                     }
                 } else dv[j] = 0.0;
+            }
+            if constexpr (OD) {
+                if (build) {
+                    // The decay rates leave the stage before the recursion: with a = -dgd (V c; br) the row's gradient in (span, rho), the 8 x 8 block is
+                    // K = K0 + sum_j ea_j a_j a_j', K0 = [0, Mr'; Mr, S] from the Lagrangian alone (S = (objective + dw) I + cross term), and what the
+                    // recursion needs is its Schur complement on the span.  Assembled first and eliminated afterwards, an active row at mu ~ 1e-9
+                    // (ea br^2 ~ 1e13 against S ~ 1e-2) leaves nothing of S in D and nothing of K0 in ea c c' - (ea br c')' D^-1 (ea br c') -- measured:
+                    // the dual infeasibility stalls at 1e-4 and the solve crawls for thousands of iterations where the oracle takes one step.  So S is
+                    // eliminated first and the rows enter one at a time as rank-one updates of the Schur complement:
+                    //   w = D^-1 br, r = c - T br, q = 1 / ea + br . w:   K/rho += r r' / q,  T += r w' / q,  D^-1 -= w w' / q       (T = Mr' D^-1)
+                    //   sigma = (eb / ea - br . t) / q:                   g_span += sigma r,  t += sigma w                        (t = D^-1 g_rho)
+                    // -- no difference of large numbers anywhere (tools/micro/seq_schur.py: 1e-13 where the assembled form is off by 1e+4).  Inertia:
+                    // det (D + e b b') = det D (1 + e b' D^-1 b) and a positive semidefinite update lowers no eigenvalue, so every q < 0 turns one
+                    // negative eigenvalue of D positive; S alone may be indefinite (its cross term against 2 df ps)
+                    const double s11 = ls ? 1.0 : 2.0 * df * P.ps1 + dw, s22 = ls ? 1.0 : 2.0 * df * P.ps2 + dw, s12 = Dl12;
+                    const double det = s11 * s22 - s12 * s12;
+                    int nneg = det > 0.0 ? (s11 > 0.0 ? 0 : 2) : 1;
+                    bool sing = !(fabs(det) > 0.0);
+                    const double idet = 1.0 / det;
+                    double Di[3] = {s22 * idet, -s12 * idet, s11 * idet};
+                    const double g0 = E.gfr[0] + (ls ? 0.0 : E.Jr[0]), g1 = E.gfr[1] + (ls ? 0.0 : E.Jr[1]);
+                    odt[0] = Di[0] * g0 + Di[1] * g1; odt[1] = Di[1] * g0 + Di[2] * g1;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        odT[a][0] = Mr[0][a] * Di[0] + Mr[1][a] * Di[1]; odT[a][1] = Mr[0][a] * Di[1] + Mr[1][a] * Di[2];
+                        gv[a] -= odT[a][0] * g0 + odT[a][1] * g1;
+                    }
+                    {
+                        int e = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a)
+#pragma unroll
+                            for (int b = a; b < 6; ++b, ++e) M[e] -= odT[a][0] * Mr[0][b] + odT[a][1] * Mr[1][b];
+                    }
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) {
+                        if (j < K) {
+                            double c[6], hh[2], e01[4];
+                            row_coeffs(pt, j, c, hh, e01);
+                            const double a12 = P.alpha1 * P.alpha2;
+                            const double b0 = P.alpha1 * (hh[1] - hh[0]) + a12 * rho[1] * hh[0], b1 = P.alpha2 * (hh[1] - hh[0]) + a12 * rho[0] * hh[0];
+                            const double sc = dgd(j);
+                            double Ej, bd;
+                            if (ls) { Ej = 1.0; bd = -vU[j]; }
+                            else {
+                                const double stU = sU[j] - s[j];
+                                Ej = vU[j] / stU + dw;
+                                const double gt = mu / stU - O.kappa_d * mu;
+                                bd = -(dv[j] - s[j]) + (yd[j] - gt) / Ej;
+                            }
+                            const double w0_ = Di[0] * b0 + Di[1] * b1, w1_ = Di[1] * b0 + Di[2] * b1;
+                            const double q = 1.0 / (Ej * sc * sc) + b0 * w0_ + b1 * w1_;
+                            if (q < 0.0) --nneg;
+                            sing |= !(fabs(q) > 0.0);
+                            const double iq = 1.0 / q, sig = (bd / sc - (b0 * odt[0] + b1 * odt[1])) * iq;
+                            double r[6];
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) r[a] = c[a] - (odT[a][0] * b0 + odT[a][1] * b1);
+                            int e = 0;
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) {
+                                const double ra = r[a] * iq;
+                                gv[a] += sig * r[a];
+                                odT[a][0] += ra * w0_; odT[a][1] += ra * w1_;
+#pragma unroll
+                                for (int b = a; b < 6; ++b, ++e) M[e] += ra * r[b];
+                            }
+                            odt[0] += sig * w0_; odt[1] += sig * w1_;
+                            Di[0] -= w0_ * w0_ * iq; Di[1] -= w0_ * w1_ * iq; Di[2] -= w1_ * w1_ * iq;
+                        }
+                    }
+                    od_bad = sing || nneg != 0;                                     // not positive definite: the inertia correction takes it
+                }
             }
             // Jty -= V jv
 #pragma unroll
@@ -674,24 +741,6 @@ struct Wave {
                     cc[0] = (dgc(3) * yc[3] - dt * jv[0]) * dt; cc[1] = (dgc(4) * yc[4] - dt * jv[1]) * dt; cc[2] = dgc(5) * yc[5] * dt;
                 }
                 auto Mi = [](int a, int b) { return a <= b ? a * 6 - a * (a - 1) / 2 + (b - a) : b * 6 - b * (b - 1) / 2 + (a - b); };
-                if constexpr (OD) {
-                    // the decay block D = (objective + dw) I + Dr, gradient g_rho; eliminated inside the span: M -= Mr' D^-1 Mr, gv -= Mr' D^-1 g_rho
-                    const double d11 = (ls ? 1.0 : 2.0 * df * P.ps1 + dw) + Dr[0], d12 = Dr[1], d22 = (ls ? 1.0 : 2.0 * df * P.ps2 + dw) + Dr[2];
-                    const double det = d11 * d22 - d12 * d12;
-                    od_bad = !(d11 > 0.0) || !(det > 0.0);                          // not positive definite: the inertia correction takes it
-                    const double idet = 1.0 / det;
-                    odD[0] = d22 * idet; odD[1] = -d12 * idet; odD[2] = d11 * idet;
-                    odg[0] = E.gfr[0] + (ls ? 0.0 : E.Jr[0]) + gr[0]; odg[1] = E.gfr[1] + (ls ? 0.0 : E.Jr[1]) + gr[1];
-                    const double t0 = odD[0] * odg[0] + odD[1] * odg[1], t1 = odD[1] * odg[0] + odD[2] * odg[1];
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) {
-                        odM[0][a] = Mr[0][a]; odM[1][a] = Mr[1][a];
-                        gv[a] -= Mr[0][a] * t0 + Mr[1][a] * t1;
-                        const double s0 = odD[0] * Mr[0][a] + odD[1] * Mr[1][a], s1 = odD[1] * Mr[0][a] + odD[2] * Mr[1][a];
-#pragma unroll
-                        for (int b = a; b < 6; ++b) M[Mi(a, b)] -= s0 * Mr[0][b] + s1 * Mr[1][b];
-                    }
-                }
                 // H[a][b] = sum_q t_a[q] V[b][q] with t_a[q] = sum_p V[a][p] M[p][q]  (+ dynamics curvature, + diagonal): computed once, stored
                 const int U4[4] = {0, 1, 3, 4};
                 ldsd* Ho = lds + L.H + k * 55; ldsd* Go = lds + L.G + k * 10;
@@ -794,11 +843,11 @@ struct Wave {
                 const double v = row[0] * dx[2] + row[1] * dx[3] + row[2] * dx[4] + row[3] * du[0] + row[4] * du[1] + row[5] * du[2] + row[6] * du[3];
                 vd[c] += P.dt * v;
             }
-            if constexpr (OD) {                                              // d rho = -D^-1 (g_rho + M_rho,v vd)
-                double t0 = odg[0], t1 = odg[1];
+            if constexpr (OD) {                                              // d rho = -D^-1 (g_rho + M_rho,v vd) = -(t + T' vd)
+                double t0 = odt[0], t1 = odt[1];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) { t0 += odM[0][i] * vd[i]; t1 += odM[1][i] * vd[i]; }
-                drho[0] = -(odD[0] * t0 + odD[1] * t1); drho[1] = -(odD[1] * t0 + odD[2] * t1);
+                for (int i = 0; i < 6; ++i) { t0 += odT[i][0] * vd[i]; t1 += odT[i][1] * vd[i]; }
+                drho[0] = -t0; drho[1] = -t1;
             }
 #pragma unroll
             for (int j = 0; j < KS; ++j) {
@@ -999,6 +1048,10 @@ struct Wave {
             double gm = fmax(2.0 * P.Q[0] * fabs(x0[0] - xg[0]), 2.0 * P.Q[1] * fabs(x0[1] - xg[1]));
 #pragma unroll
             for (int i = 2; i < NX; ++i) gm = fmax(gm, 2.0 * P.Q[i] * fabs(x0[i]));
+            if constexpr (OD) {                                               // the input term is R u^2 there (not the rate): 2 R u at u_prev
+#pragma unroll
+                for (int j = 0; j < NU; ++j) gm = fmax(gm, 2.0 * P.R[j] * fabs(uprev[j]));
+            }
             df = gm > O.nlp_scaling_max_gradient ? fmax(O.nlp_scaling_min_value, O.nlp_scaling_max_gradient / gm) : 1.0;
             D2 acc[3], gc[4][3];
             accel<D2>(P, d2var(x0[2], 0), d2var(x0[3], 1), d2var(x0[4], 2), uprev, acc, gc);
@@ -1121,6 +1174,9 @@ struct Wave {
 #pragma unroll
                     for (int j = 0; j < KS; ++j) ym = fmax(ym, fabs(dyd[j]));
                     ym = ipm::wmax(ym);
+#ifdef SC_MS_DBG
+                    last_alpha = ym; last_dw = dw;
+#endif
                     if (ym <= O.constr_mult_init_max) {
                         if (stg) {
 #pragma unroll

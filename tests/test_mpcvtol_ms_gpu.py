@@ -138,13 +138,13 @@ def _one_od(args):
 
 
 def test_optimal_decay_instantiation_against_the_oracle():
-    """OptimalDecayMPCCBF with a VTOL2D robot in the multiple-shooting form (the decay rates are two more inputs of a stage; kernel: eliminated
-    inside the span before the recursion, oracle: a six-input stage): a disc 10 - 30 m ahead of every other aircraft, so that decay rates
-    leave their reference.  The first twelve iterations agree to rounding (tools/dbg_od_trace.py); these NLPs are non-convex where a decay
-    rate is active (the inertia correction works to the end), so the PATH to the optimum depends on rounding and iteration counts differ --
-    what is held: same status on 95 %, and the same optimum on nine in ten of those both call optimal (u_0 to 1e-6, decay rates to 1e-4); without a disc (odd
-    problems) the solve IS the plain one: iterate for iterate."""
-    n = 48
+    """OptimalDecayMPCCBF with a VTOL2D robot in the multiple-shooting form (the decay rates are two more inputs of a stage, eliminated
+    before the recursion -- kernel and oracle take the rows into that Schur complement one at a time, oracle/ms_ipopt.py:_od_eliminate): a
+    disc 10 - 30 m ahead of every other aircraft, so that decay rates leave their reference.  Held: same status on every problem; the same
+    optimum on every problem both call optimal (u_0 to 1e-6, decay rates to 1e-5); iteration counts equal on >= 85 % and within 20 % + 5
+    on all (these NLPs are non-convex where a decay rate is active and take 150 - 400 iterations there: the last digits of a long path
+    differ); without a disc (odd problems) the solve IS the plain one: iterate for iterate."""
+    n = 128
     Xn, up0, gn, on = W.mpc_family_batch("vtol", 4096, 8, seed=0)
     on = on.copy()
     rng = np.random.default_rng(100)
@@ -156,12 +156,13 @@ def test_optimal_decay_instantiation_against_the_oracle():
     with Pool(min(32, os.cpu_count() or 4)) as p:
         res = p.map(_one_od, [(X[i], up[i], goal[i], obs[i]) for i in range(n)], chunksize=2)
     so = np.array([q[1] for q in res]); ito = np.array([q[2] for q in res])
-    assert np.mean(st == so) >= 0.95, np.flatnonzero(st != so)
+    assert (st == so).all(), np.flatnonzero(st != so)
     both = (st == 0) & (so == 0)
     assert both.mean() >= 0.9
     du = np.array([np.abs(u[i] - q[0]).max() for i, q in enumerate(res)]); dr = np.array([np.abs(rho[i] - q[3]).max() for i, q in enumerate(res)])
-    same = (du <= 1e-6) & (dr <= 1e-4)
-    assert same[both].mean() >= 0.9, (np.flatnonzero(both & ~same), du[both].max(), dr[both].max())      # (a parted one = another local optimum of a non-convex NLP)
+    print(f"od ms: optimal {both.mean():.3f}, iterations equal {np.mean(it == ito):.3f} (mean {ito.mean():.1f} max {ito.max()}), max du {du[both].max():.2e} drho {dr[both].max():.2e}")
+    assert du[both].max() <= 1e-6 and dr[both].max() <= 1e-5
+    assert np.mean(it[both] == ito[both]) >= 0.85 and (np.abs(it[both] - ito[both]) <= 0.2 * ito[both] + 5).all()
     odd = np.arange(n) % 2 == 1                                           # no disc ahead: decay rates stay at 1, the plain solve
     assert np.abs(rho[odd] - 1.0).max() <= 1e-6 and np.mean(it[odd] == ito[odd]) >= 0.75 and np.abs(it[odd] - ito[odd]).max() <= 3
     moved = np.abs(rho - 1.0).max(axis=1) > 1e-3

@@ -198,6 +198,48 @@ def test_riccati_recursion_solves_the_same_system_as_the_dense_factorisation(pha
         assert np.abs(a - b).max() <= 1e-8 * max(1.0, np.abs(a).max())
 
 
+def test_optimal_decay_stage_elimination_against_the_dense_factorisation():
+    """vtol_od_model in the recursion: the decay rates leave each stage first, the rows entering the Schur complement one at a time
+    (_od_eliminate, what csrc/mpc_vtol_ms.hip does).  (a) Same step as LAPACK's factorisation of the whole system at a random interior
+    iterate.  (b) With one row per stage at E = 1e12 (an active row at mu ~ 1e-9) the sequential form still gives the step to 1e-6 where
+    the assembled block (od_elimination = 'none': rows condensed first, six-input stage) is off in the first digit -- the reason it exists."""
+    mdl, x0, up, goal, obs = _vtol_problem(1)
+    mdl = MS.vtol_od_model()
+    nlp = MS.StageNLP(mdl, x0, up, goal, obs)
+    o = dict(MS.OPTS)
+    P = MS._Regular(nlp, nlp.initial_guess(), o)
+    rng = np.random.default_rng(2)
+    A = MS._Algo(P, o)
+    x = A.push(nlp.initial_guess() + 0.01 * rng.standard_normal(nlp.n), P.x_L, P.x_U, 0.01, 0.01)
+    ev = P.evaluate(x, 2, 0.1)
+    y = 1e-3 * rng.standard_normal(P.m)                                # (the decay block carries a1 a2 h0 y: keep it below the 5 I)
+    sig_x = np.where(np.isfinite(P.x_L) | np.isfinite(P.x_U), rng.uniform(0.1, 10, P.n), 0.0)
+    W = ev["hess"](y) + 5.0 * np.eye(P.n)
+    rx, rt, rg = rng.standard_normal(P.n), rng.standard_normal(P.nt), rng.standard_normal(P.m)
+    for stiff in (False, True):
+        sig_t = rng.uniform(0.01, 100, P.nt)
+        if stiff:
+            sig_t[::8] = 1e12
+        sols = {}
+        for name, extra in (("dense", dict(linear_solver=None)), ("seq", dict(linear_solver="riccati")), ("assembled", dict(linear_solver="riccati", od_elimination="none"))):
+            A.o = dict(o, **extra)
+            A.delta_w_last = 0.0
+            sols[name] = A.factor(W, ev["J"], sig_x, sig_t, 0.1)(rx, rt, rg)
+            assert A.last_delta[0] == 0.0
+        # (the multipliers of the stiff rows come back as E (a . dx - b): the rounding of dx times 1e12 -- they are left out of the stiff comparison;
+        # the next iterate's residual is evaluated exactly, so the algorithm corrects them, which is what the GPU parity test sees)
+        soft = np.ones(P.m, dtype=bool)
+        if stiff:
+            soft[P.t_row[::8]] = False
+        pick = lambda sol: (sol[0], sol[1], sol[2][soft])
+        err = {k: max(np.abs(a - b).max() / max(1.0, np.abs(a).max()) for a, b in zip(pick(sols[k]), pick(sols["dense"]))) for k in ("seq", "assembled")}
+        assert err["seq"] <= (1e-6 if stiff else 1e-8), err
+        if stiff:
+            assert err["assembled"] >= 1e-3, err
+        else:
+            assert err["assembled"] <= 1e-8, err
+
+
 def test_kernel_profile_follows_the_default_solve_and_hands_back_restorations():
     """linear_solver = riccati, max_soc = 0, restoration = none (what the HIP kernel runs): same iterates as the dense solve with second-order
     corrections on a feasible problem; on the first NLP of the reference's example scene (no feasible point) it stops with 'needs_resto' where
