@@ -97,118 +97,129 @@ __device__ __forceinline__ void for6(F&& f, std::integer_sequence<int, Is...>) {
 #define SC_FOR6(body) for6([&](auto I_) { constexpr int I = decltype(I_)::value; body }, std::make_integer_sequence<int, 6>{})
 
 // ---- Riccati recursion with defects (oracle/ms_ipopt.py: _riccati_backward / _riccati_solve, hard dynamics) ----------------------------
-// LDS in: AB[k] (6 x 10 [A | B]), H[k] (upper-packed 10 x 10 over (x_k, u_k); H[N]: its x block), G[k] (gradient, 10), C[k + 1] (defect of the
+// LDS in: AB[k] (compact [A | B]), H[k] (upper-packed 10 x 10 over (x_k, u_k); H[N]: its x block), G[k] (gradient, 10), C[k + 1] (defect of the
 // dynamics of stage k), C[0] = dx_0;  cpl[j] = 2 df R_j: the (u_{k-1}, u_k) cross term, -cpl on the (v, u) entries of stage k >= 1.
 // Out: KG[k] = gains (K: 4 x 10 over (dx_k, du_{k-1}), then kff: 4); false (wave-uniform) when an input block is not positive definite.
+//
+// One stage is three small matrix products, on v_mfma_f64_16x16x4_f64 with the value function living in the accumulator registers from one
+// stage to the next.  Tile index t of the 16 x 16 tiles:  0..5 = x,  6..9 = v (= u_{k-1}),  10..13 = u,  14 = the affine column (defect /
+// gradient / p),  15 unused.   Gt = [[A, 0, B, c], [0, 0, I, 0]] (10 x 15: xi+ = Gt (xi, u, 1)),  S = stage block (H over (x, u), -cpl on
+// (v_i, u_i), gradient in column 14):
+//     T = P Gt (+ p on column 14),   Q = S + Gt' T,   Quu = L L',  Y = L^-1 Q[u, :],   P' = Q - Y' Y   (column 14 of P' = the new p)
+// Operand layout (MI355X guide, "f64 MFMA"): lane l feeds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; result register r of lane l is
+// D[row = (l >> 4) + 4 r][col = l & 15] -- so register s of a result IS the B operand of k-step s of the next product (B[4 s + g][c]), and,
+// for a symmetric result, the A operand as well: nothing moves between the three products.  Only the four u rows of Q cross lanes (through
+// LDS: every lane factors Quu and solves for its own column), and the gains go to LDS for the forward sweep.
+// (Before: entry-per-lane loops over LDS copies of P, T, Q: ~1000 instructions per stage for a lone wave, 40 % of an iteration.)
+typedef double d4_t __attribute__((ext_vector_type(4)));
 __device__ __attribute__((noinline)) bool riccati_backward(ldsd* lds, const Lds L, const int N, const int lane, const double dt, const double c0,
                                                            const double c1, const double c2, const double c3) {
-    ldsd* T = lds + L.T; ldsd* QU = lds + L.QU; ldsd* Quu = lds + L.Quu;
-    ldsd* Pc = lds + L.Pc; ldsd* Pn = lds + L.Pn; ldsd* pc = lds + L.pc; ldsd* pn = lds + L.pn;
+    ldsd* QX = lds + L.QU;                                                 // 4 x 16 exchange: the u rows of Q  (QU | Quu | pc | pn: 80 doubles)
+    const int c = lane & 15, g = lane >> 4;
+    // tile index -> index in the (x, u) ordering of H / G (-1: the v block, the affine column, unused)
+    auto hx = [](int t) { return t < 6 ? t : ((t >= 10 && t < 14) ? t - 4 : -1); };
+    const int hc = hx(c);
+    // S[g + 4 r][c], r = 0..3: an entry of H, of the gradient (column 14), or the cross-term coefficient
+    // (every load is unconditional -- a lane without an entry reads the first one and drops it: one LDS round trip for the seven operands
+    // instead of one per divergent branch): address of stage k = so + k * ss, sl = the lane does take the loaded value
+    int so[4], ss[4];
+    bool sl[4];
+    double cp[4];
     const double cpl[4] = {c0, c1, c2, c3};
-    int tr = 0, tc = 0;                                                   // phase D: upper-triangle entry `lane` of 55
-    { int e = lane < 55 ? lane : 0; int r = 0; while (e >= NV - r) { e -= NV - r; ++r; } tr = r; tc = r + e; }
-    const int tri = ab_col(tr);
-    const int ar0 = lane / 11, ac0 = lane % 11;                           // phase A, round 0: entry `lane` of 110
-    const int e1 = lane < 46 ? lane + 64 : 109;
-    const int ar1 = e1 / 11, ac1 = e1 % 11;                               // round 1 (lanes < 46)
-    const int aci0 = ab_col(ac0), aci1 = ab_col(ac1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = g + 4 * r, hr = hx(row);
+        sl[r] = true;
+        if (hr >= 0 && hc >= 0) { so[r] = L.H + sym(hr, hc); ss[r] = 55; }
+        else if (hr >= 0 && c == 14) { so[r] = L.G + hr; ss[r] = 10; }
+        else { so[r] = L.H; ss[r] = 55; sl[r] = false; }
+        cp[r] = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if ((row == 6 + q && c == 10 + q) || (row == 10 + q && c == 6 + q)) cp[r] = -cpl[q];
+    }
+    // Gt[4 s + g][c], s = 0..2: a constant, or an entry of the stage's compact [A | B] (offset into AB[k]), or of its defect (offset into C[k + 1])
+    double gk[3];
+    int go[3], gs[3];
+    bool gl[3];
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+        const int kk = 4 * s_ + g;
+        gk[s_] = 0.0; go[s_] = L.AB; gs[s_] = ABS; gl[s_] = false;
+        if (kk < 3) gk[s_] = c == kk ? 1.0 : (c == kk + 3 ? dt : 0.0);
+        else if (kk < 6) {
+            const int ci = (c >= 2 && c <= 4) ? c - 2 : ((c >= 10 && c < 14) ? c - 7 : -1);      // compact column of tile column c
+            if (ci >= 0) { go[s_] = L.AB + (kk - 3) * 7 + ci; gl[s_] = true; }
+            else if (kk == 5 && c == 5) gk[s_] = 1.0;
+        } else if (kk < 10) gk[s_] = c == kk + 4 ? 1.0 : 0.0;                                    // v+ = u
+        if (kk < 6 && c == 14) { gk[s_] = 0.0; go[s_] = L.C + 6 + kk; gs[s_] = 6; gl[s_] = true; }     // defect of stage k: C[k + 1]
+    }
+    // value function of the last stage: the x block of H[N], gradient in column 14
+    d4_t Pv;
     {
         const ldsd* HN = lds + L.H + N * 55; const ldsd* GN = lds + L.G + N * 10;
-        for (int e = lane; e < 100; e += 64) { const int r = e / 10, c = e % 10; Pc[e] = (r < NX && c < NX) ? HN[sym(r, c)] : 0.0; }
-        if (lane < NV) pc[lane] = lane < NX ? GN[lane] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = g + 4 * r;
+            double v = 0.0;
+            if (row < NX && c < NX) v = HN[sym(row, c)];
+            else if (row < NX && c == 14) v = GN[row];
+            Pv[r] = v;
+        }
     }
-    __syncthreads();
     for (int kk = N - 1; kk >= 0; --kk) {
-        const ldsd* A3 = lds + L.AB + kk * ABS; const ldsd* H = lds + L.H + kk * 55; const ldsd* g = lds + L.G + kk * 10;
-        const ldsd* cd = lds + L.C + (kk + 1) * 6;
-        // A: T = P [A | B] (+ P's v columns under B), column 10: P c + p   (two rounds of 64 entries; index maps are lane constants)
-        {
-            double v0 = ac0 < 10 ? (ac0 >= NX ? Pc[ar0 * 10 + ac0] : 0.0) : pc[ar0];
-            double v1 = ac1 < 10 ? (ac1 >= NX ? Pc[ar1 * 10 + ac1] : 0.0) : pc[ar1];
-            SC_FOR6(
-                const double b0 = ac0 < 10 ? ab_at<I>(A3, ac0, aci0, dt) : cd[I];
-                const double b1 = ac1 < 10 ? ab_at<I>(A3, ac1, aci1, dt) : cd[I];
-                v0 += Pc[ar0 * 10 + I] * b0; v1 += Pc[ar1 * 10 + I] * b1;
-            );
-            T[lane] = v0;
-            if (lane < 46) T[lane + 64] = v1;
-        }
-        __syncthreads();
-        // B: u rows of H + G' T: [Qux | Quu], and qu
-        if (lane < 44) {
-            const int i = lane / 11, c = lane % 11;
-            double v;
-            if (c < 10) {
-                v = T[(6 + i) * 11 + c] + H[sym(c, 6 + i)];
+        double G_[3], ld[7];
 #pragma unroll
-                for (int r = 3; r < NX; ++r) v += A3[(r - 3) * 7 + 3 + i] * T[r * 11 + c];      // B' T: rows 0..2 of B are zero
-                if (c < NX) QU[i * 11 + c] = v; else Quu[i * 4 + c - NX] = v;
-            } else {
-                v = g[6 + i] + T[(6 + i) * 11 + 10];
+        for (int s_ = 0; s_ < 3; ++s_) ld[s_] = lds[go[s_] + kk * gs[s_]];
 #pragma unroll
-                for (int r = 3; r < NX; ++r) v += A3[(r - 3) * 7 + 3 + i] * T[r * 11 + 10];
-                QU[i * 11 + 10] = v;
-            }
+        for (int r = 0; r < 4; ++r) ld[3 + r] = lds[so[r] + kk * ss[r]];
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_) G_[s_] = gl[s_] ? ld[s_] : gk[s_];
+        d4_t Sv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Sv[r] = sl[r] ? ld[3 + r] : (kk >= 1 ? cp[r] : 0.0);
+        // T = P Gt: A = P (symmetric: registers 0..2 of the previous result; its rows 10, 11 -- the u rows -- do not belong to P)
+        d4_t Tv = {0.0, 0.0, 0.0, 0.0};
+        Tv = __builtin_amdgcn_mfma_f64_16x16x4f64(Pv[0], G_[0], Tv, 0, 0, 0);
+        Tv = __builtin_amdgcn_mfma_f64_16x16x4f64(Pv[1], G_[1], Tv, 0, 0, 0);
+        Tv = __builtin_amdgcn_mfma_f64_16x16x4f64(g < 2 ? Pv[2] : 0.0, G_[2], Tv, 0, 0, 0);
+        if (c == 14) {                                                      // + p (rows 0..9 of column 14)
+            Tv[0] += Pv[0]; Tv[1] += Pv[1];
+            if (g < 2) Tv[2] += Pv[2];
         }
+        // Q = S + Gt' T
+        d4_t Qv = Sv;
+        Qv = __builtin_amdgcn_mfma_f64_16x16x4f64(G_[0], Tv[0], Qv, 0, 0, 0);
+        Qv = __builtin_amdgcn_mfma_f64_16x16x4f64(G_[1], Tv[1], Qv, 0, 0, 0);
+        Qv = __builtin_amdgcn_mfma_f64_16x16x4f64(G_[2], g < 2 ? Tv[2] : 0.0, Qv, 0, 0, 0);
+        // rows 10..13 of Q to every lane: row 10 = (g 2, r 2), 11 = (g 3, r 2), 12 = (g 0, r 3), 13 = (g 1, r 3)
         __syncthreads();
-        // C: the 4 x 4 factorisation in every lane, one right-hand side per lane (10 columns of [Qux | Quv], then qu)
+        QX[((g + 2) & 3) * 16 + c] = g >= 2 ? Qv[2] : Qv[3];
+        __syncthreads();
         {
-            const double q00 = Quu[0], q10 = Quu[4], q11 = Quu[5], q20 = Quu[8], q21 = Quu[9], q22 = Quu[10], q30 = Quu[12], q31 = Quu[13],
-                         q32 = Quu[14], q33 = Quu[15];
-            const int c = lane < 11 ? lane : 0;
+            const double q00 = QX[10], q10 = QX[16 + 10], q11 = QX[16 + 11], q20 = QX[32 + 10], q21 = QX[32 + 11], q22 = QX[32 + 12], q30 = QX[48 + 10],
+                         q31 = QX[48 + 11], q32 = QX[48 + 12], q33 = QX[48 + 13];
+            const bool rhs = c < 10 || c == 14;                             // columns over (x, v) and the affine one; the others carry zeros
             double b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (c < NX) b[i] = QU[i * 11 + c];
-                else if (c < NV) b[i] = (kk >= 1 && c - NX == i) ? -cpl[i] : 0.0;
-                else b[i] = QU[i * 11 + 10];
-            }
+            for (int i = 0; i < 4; ++i) b[i] = rhs ? QX[i * 16 + c] : 0.0;
             const double r0 = rsqrt_(q00), l10 = q10 * r0, l20 = q20 * r0, l30 = q30 * r0;
             const double d1 = q11 - l10 * l10, r1 = rsqrt_(d1), l21 = (q21 - l20 * l10) * r1, l31 = (q31 - l30 * l10) * r1;
             const double d2 = q22 - l20 * l20 - l21 * l21, r2 = rsqrt_(d2), l32 = (q32 - l30 * l20 - l31 * l21) * r2;
             const double d3 = q33 - l30 * l30 - l31 * l31 - l32 * l32, r3 = rsqrt_(d3);
             if (!(q00 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0)) return false;     // wave-uniform: every lane factors the same block
             const double y0 = b[0] * r0, y1 = (b[1] - l10 * y0) * r1, y2 = (b[2] - l20 * y0 - l21 * y1) * r2, y3 = (b[3] - l30 * y0 - l31 * y1 - l32 * y2) * r3;
-            const double x3 = y3 * r3, x2 = (y2 - l32 * x3) * r2, x1 = (y1 - l21 * x2 - l31 * x3) * r1, x0_ = (y0 - l10 * x1 - l20 * x2 - l30 * x3) * r0;
-            if (lane < 11) {
+            if (rhs && g == 0) {                                            // gains K = -L^-T Y (columns over (x, v)), kff (column 14)
+                const double x3 = y3 * r3, x2 = (y2 - l32 * x3) * r2, x1 = (y1 - l21 * x2 - l31 * x3) * r1, x0_ = (y0 - l10 * x1 - l20 * x2 - l30 * x3) * r0;
                 ldsd* dst = lds + L.KG + kk * 44 + (c < NV ? c : 40);
                 const int st = c < NV ? 10 : 1;
                 dst[0] = -x0_; dst[st] = -x1; dst[2 * st] = -x2; dst[3 * st] = -x3;
             }
+            // P' = Q - Y' Y  (A[i = c][k = g] = -Y[g][c], B[k = g][j = c] = Y[g][c])
+            const double yg = g == 0 ? y0 : (g == 1 ? y1 : (g == 2 ? y2 : y3));
+            Pv = __builtin_amdgcn_mfma_f64_16x16x4f64(-yg, yg, Qv, 0, 0, 0);
         }
-        __syncthreads();
-        // D: the new P = Q_xixi + Q_xiu K (upper triangle, mirrored on the write) and p = q_xi + Q_xiu kff
-        {
-            const ldsd* KK = lds + L.KG + kk * 44; const ldsd* kf = KK + 40;
-            double v = 0.0;
-            if (tr < NX && tc < NX) {
-                v = H[sym(tr, tc)];
-                SC_FOR6( v += ab_at<I>(A3, tr, tri, dt) * T[I * 11 + tc]; );
-            }
-#pragma unroll
-            for (int i = 0; i < NU; ++i) {
-                const double qa = tr < NX ? QU[i * 11 + tr] : ((kk >= 1 && tr - NX == i) ? -cpl[i] : 0.0);
-                v += qa * KK[i * 10 + tc];
-            }
-            if (lane < 55) { Pn[tr * 10 + tc] = v; Pn[tc * 10 + tr] = v; }
-            if (lane < NV) {
-                const int a = lane;
-                double w = 0.0;
-                if (a < NX) {
-                    w = g[a];
-                    SC_FOR6( w += ab_at<I>(A3, a, ab_col(a), dt) * T[I * 11 + 10]; );
-                }
-#pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    const double qa = a < NX ? QU[i * 11 + a] : ((kk >= 1 && a - NX == i) ? -cpl[i] : 0.0);
-                    w += qa * kf[i];
-                }
-                pn[a] = w;
-            }
-        }
-        __syncthreads();
-        { ldsd* tP = Pc; Pc = Pn; Pn = tP; ldsd* tp = pc; pc = pn; pn = tp; }
     }
+    __syncthreads();
     return true;
 }
 
