@@ -9,6 +9,7 @@ from safe_control_amd import workloads as W
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 X, up, goal, obs = W.mpc_family_batch("vtol", max(B, 64), 8, seed=0)
+if len(sys.argv) > 2: obs = obs[:, :int(sys.argv[2])]
 t = lambda a: torch.tensor(np.ascontiguousarray(a[:B]), dtype=torch.float64, device="cuda:0")
 ctl = sca.BatchedVtolMSMPCCBF(io_dtype="f64", fallback=False)
 u, st, it, trace = ctl.solve(t(X), t(up), t(goal), t(obs), want_trace=True)
