@@ -41,7 +41,7 @@ extern "C" {
  * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2; round 5 added sc_ipopt_params and sc_mpcvtol_ms_solve_batch: 0.3; the continuation entry points of the optimal-decay families: 0.4; sc_odmpcvtol_ms_solve_batch: 0.5).  A binding compares sc_version() with the
  * version its struct mirrors were written for before the first call (safe_control_amd/_lib.py: ABI_VERSION). */
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 5
+#define SC_VERSION_MINOR 6
 
 /* ---- return codes ------------------------------------------------------ */
 typedef enum sc_error {
@@ -450,7 +450,23 @@ typedef struct sc_ipopt_params {
     double  theta_max_fact, theta_min_fact, eta_phi, delta, s_phi, s_theta, gamma_phi, gamma_theta, alpha_min_frac, alpha_red_factor, obj_max_inc;
     double  first_hessian_perturbation, min_hessian_perturbation, max_hessian_perturbation, perturb_inc_fact_first, perturb_inc_fact,
             perturb_dec_fact;
+    /* restoration phase (section 3.3 of the paper; IPOPT's option names and defaults: 1000, 1, 0.9, 1e3, 1e-6, 1e8).  It runs inside the kernel when
+     * resto_workspace points at sc_mpcvtol_ms_workspace_bytes(B, K) bytes of device memory (row state of the elastic problem, one slab per NLP);
+     * with resto_workspace = NULL a solve that needs it ends with SC_STATUS_NEEDS_RESTO.  The elastic variables sit on the inequality rows only
+     * (the dynamics rows stay hard): oracle/ms_ipopt.py, resto_elastic = "ineq".                                                          */
+    double  resto_penalty_parameter, resto_proximity_weight, required_infeasibility_reduction, bound_mult_reset_threshold,
+            resto_failure_feasibility_threshold, resto_theta_max_fact;
+    void*   resto_workspace;
+    int64_t resto_workspace_bytes;
+    /* NOT an IPOPT option (IPOPT's watchdog and tiny-step heuristics are not restated): a regular-phase solve whose accepted step length stays
+     * below stall_alpha for stall_iter consecutive iterations ends SC_STATUS_INACCURATE there instead of crawling to max_iter (the fraction-to-
+     * the-boundary rule pins every step against a bound: measured on 2 of 4096 optimal-decay bench problems, after their restoration).
+     * stall_iter = 0 disables the rule.  Oracle: oracle/ms_ipopt.py, options stall_iter / stall_alpha.                                    */
+    double  stall_alpha;
+    int32_t stall_iter, reserved;
 } sc_ipopt_params;
+
+size_t sc_mpcvtol_ms_workspace_bytes(int64_t B, int32_t K);
 
 int sc_mpcvtol_ms_solve_batch(const sc_mpcvtol_params* params, const sc_ipopt_params* ipopt, int64_t B, int32_t K,
                               const void* X, const void* u_prev, const void* goal, const void* obs,

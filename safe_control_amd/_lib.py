@@ -255,7 +255,10 @@ class IpoptParams(C.Structure):
         "theta_max_fact", "theta_min_fact", "eta_phi", "delta", "s_phi", "s_theta", "gamma_phi", "gamma_theta", "alpha_min_frac", "alpha_red_factor",
         "obj_max_inc",
         "first_hessian_perturbation", "min_hessian_perturbation", "max_hessian_perturbation", "perturb_inc_fact_first", "perturb_inc_fact",
-        "perturb_dec_fact")]
+        "perturb_dec_fact",
+        "resto_penalty_parameter", "resto_proximity_weight", "required_infeasibility_reduction", "bound_mult_reset_threshold",
+        "resto_failure_feasibility_threshold", "resto_theta_max_fact")] + [("resto_workspace", C.c_void_p), ("resto_workspace_bytes", C.c_int64),
+                                                                      ("stall_alpha", C.c_double), ("stall_iter", C.c_int32), ("reserved", C.c_int32)]
 
 
 IPOPT_DEFAULTS = dict(
@@ -266,7 +269,9 @@ IPOPT_DEFAULTS = dict(
     tau_min=0.99, kappa_sigma=1e10, kappa_d=1e-5, s_max=100.0, theta_max_fact=1e4, theta_min_fact=1e-4, eta_phi=1e-8, delta=1.0,
     s_phi=2.3, s_theta=1.1, gamma_phi=1e-8, gamma_theta=1e-5, alpha_min_frac=0.05, alpha_red_factor=0.5, obj_max_inc=5.0,
     first_hessian_perturbation=1e-4, min_hessian_perturbation=1e-20, max_hessian_perturbation=1e20, perturb_inc_fact_first=100.0,
-    perturb_inc_fact=8.0, perturb_dec_fact=1.0 / 3.0)
+    perturb_inc_fact=8.0, perturb_dec_fact=1.0 / 3.0,
+    resto_penalty_parameter=1000.0, resto_proximity_weight=1.0, required_infeasibility_reduction=0.9, bound_mult_reset_threshold=1e3,
+    resto_failure_feasibility_threshold=1e-6, resto_theta_max_fact=1e8, stall_alpha=1e-5, stall_iter=60)
 
 
 def default_ipopt(**over):
@@ -310,6 +315,7 @@ SYMBOLS = {
     "sc_mpcvtol_solve_batch": (C.c_int, [C.POINTER(MpcVtolParams), C.c_int64, C.c_int32] + [C.c_void_p] * 9 + [C.c_size_t, C.c_void_p]),
     "sc_mpcvtol_solve_batch_host": (C.c_int, [C.POINTER(MpcVtolParams), C.c_int64, C.c_int32] + [C.c_void_p] * 8 + [C.c_int]),
     "sc_mpcvtol_ms_solve_batch": (C.c_int, [C.POINTER(MpcVtolParams), C.POINTER(IpoptParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
+    "sc_mpcvtol_ms_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "sc_odmpcvtol_solve_batch": (C.c_int, [C.POINTER(OdMpcVtolParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_odmpcgn_solve_batch": (C.c_int, [C.POINTER(OdMpcGnParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_mpclin_model_doubles": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
@@ -363,7 +369,7 @@ SYMBOLS = {
 _lib = None
 
 # SC_VERSION_MAJOR * 1000 + SC_VERSION_MINOR of the header the ctypes mirrors above were written for
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class HipLibraryError(RuntimeError):

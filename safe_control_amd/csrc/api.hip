@@ -886,6 +886,11 @@ int sc_mpcvtol_ms_solve_batch(const sc_mpcvtol_params* params, const sc_ipopt_pa
     return SC_OK;
 }
 
+size_t sc_mpcvtol_ms_workspace_bytes(int64_t B, int32_t K) {
+    if (B < 0 || K < 0 || K > 16) return 0;
+    return (size_t)B * (size_t)((8 * (K <= 8 ? 8 : 16) + 12) * 64) * sizeof(double);       // Wave<KS>::R_SLOTS x 64 lanes (csrc/mpc_vtol_ms.hip)
+}
+
 static int check_ms_common(const sc_mpcvtol_params* params, const sc_ipopt_params* ipopt, int64_t B, int32_t K) {
     if (!params || !ipopt) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params / ipopt is NULL");
     if (B < 0 || K < 0 || K > 16) return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting kernel serves 0 <= K <= 16");
@@ -896,6 +901,11 @@ static int check_ms_common(const sc_mpcvtol_params* params, const sc_ipopt_param
         !(ipopt->alpha_red_factor > 0.0 && ipopt->alpha_red_factor < 1.0) || !(ipopt->perturb_inc_fact > 1.0) || !(ipopt->perturb_inc_fact_first > 1.0) ||
         !(ipopt->first_hessian_perturbation > 0.0) || !(ipopt->s_max > 0.0) || !(ipopt->kappa_sigma > 1.0))
         return sc::fail(SC_ERR_INVALID_ARGUMENT, "sc_ipopt_params out of range");
+    if (ipopt->resto_workspace) {
+        if ((size_t)ipopt->resto_workspace_bytes < sc_mpcvtol_ms_workspace_bytes(B, K)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "resto_workspace smaller than sc_mpcvtol_ms_workspace_bytes(B, K)");
+        if (!(ipopt->resto_penalty_parameter > 0.0) || !(ipopt->resto_proximity_weight >= 0.0) || !(ipopt->required_infeasibility_reduction > 0.0 && ipopt->required_infeasibility_reduction < 1.0))
+            return sc::fail(SC_ERR_INVALID_ARGUMENT, "sc_ipopt_params: restoration options out of range");
+    }
     return SC_OK;
 }
 

@@ -64,7 +64,7 @@ constexpr int ABS = 21;                         // [A | B] of a stage, compact: 
 constexpr int TRACE_W = 8;
 
 struct Lds {
-    int OB, AB, H, KG, G, C, DX, DU, LAM, XS, US, YS, Pc, Pn, T, QU, Quu, pc, pn, FP, FT, SC, Y0, total;
+    int OB, AB, H, KG, G, C, DX, DU, LAM, XS, US, YS, Pc, Pn, T, QU, Quu, pc, pn, FP, FT, FP2, FT2, SC, Y0, total;
     __host__ __device__ explicit Lds(int N) {
         int o = 0;
         auto take = [&](int c) { int r = o; o += c; return r; };
@@ -78,7 +78,7 @@ struct Lds {
         const int ex = (N + 2) * 10 < 310 ? 310 : (N + 2) * 10;
         XS = take(ex); US = XS + (N + 2) * 6; Pc = XS; Pn = XS + 100; T = XS + 200;
         QU = take(44); Quu = take(16); pc = take(10); pn = take(10);
-        FP = take(NFILT); FT = take(NFILT); SC = take(6 + KS_MAX); Y0 = take(6);
+        FP = take(NFILT); FT = take(NFILT); FP2 = take(NFILT); FT2 = take(NFILT); SC = take(6 + KS_MAX); Y0 = take(6);      // (FP2 / FT2: the restoration's own filter)
         total = o;
     }
 };
@@ -302,6 +302,17 @@ struct Wave {
     int nfilt;
     bool od_bad = false;
     double dw_last, last_dw;
+    // Restoration phase (section 3.3 of the paper; oracle/ms_ipopt.py: _Resto with resto_elastic = "ineq"): the same algorithm on
+    //     min  rho_R sum (n + p) + zeta / 2 |D_R (w - w_R)|^2    s.t.  dynamics rows (hard),  -dgd cbf_j - s_j + n_j - p_j = 0,  n, p >= 0
+    // Its row state (n, p, their multipliers, the four steps) and the reference point live in a global workspace, rw (64 lanes x slot), so that
+    // the regular iteration keeps its registers: rw == nullptr -> no restoration phase (SC_STATUS_NEEDS_RESTO).
+    double* rw = nullptr;
+    bool rs = false;                   // inside the restoration phase (wave-uniform)
+    double zeta = 0.0;
+    int fpo, fto;                      // LDS offsets of the filter in use
+    static constexpr int R_N = 0, R_P = KS, R_ZN = 2 * KS, R_ZP = 3 * KS, R_DN = 4 * KS, R_DP = 5 * KS, R_DZN = 6 * KS, R_DZP = 7 * KS, R_XR = 8 * KS, R_SLOTS = 8 * KS + 12;
+    __device__ __forceinline__ double& RW(int slot) const { return rw[slot * 64 + lane]; }
+    __device__ __forceinline__ double dr2(int i) const { const double a = fabs(RW(R_XR + i)); return a > 1.0 ? 1.0 / (a * a) : 1.0; }      // D_R^2 = 1 / max(1, |w_R|)^2
 #ifdef SC_MS_PROF
     double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};            // eval2 (errors), errors + mu, eval2 (build), riccati backward, forward, finish_step, line search, update
 #endif
@@ -311,7 +322,7 @@ struct Wave {
           k((int)threadIdx.x <= P_.N ? (int)threadIdx.x : 0) {
         const double g1 = P.alpha1 + P.alpha2, g2 = P.alpha1 * P.alpha2;
         w0 = 1.0 - g1 + g2; w1 = g1 - 2.0; w2 = 1.0;
-        nfilt = 0; dw_last = 0.0; last_dw = 0.0;
+        nfilt = 0; dw_last = 0.0; last_dw = 0.0; fpo = L.FP; fto = L.FT;
     }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ void od_weights(double r1, double r2) {       // stage weights of the rows for decay rates (r1, r2)
@@ -336,8 +347,20 @@ struct Wave {
         return w0 * hv[0] + w1 * hv[1] + w2 * hv[2];
     }
     // objective share of lane k: l(x_k) (+ m(x_N)) + R (u_k - u_{k-1})^2; um = u_{k-1}
-    __device__ __forceinline__ double cost_share(const double* xs, const double* us, const double* um, const double* rs) const {
+    __device__ __forceinline__ double cost_share(const double* xs, const double* us, const double* um, const double* rs_) const {
         double f = 0.0;
+        if (rs) {                                                          // restoration: sum D_R^2 (w - w_R)^2 over my variables (x zeta / 2 in barrier())
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) { const double d = xs[i] - RW(R_XR + i); f += dr2(i) * d * d; }
+            }
+            if (stg) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j) { const double d = us[j] - RW(R_XR + NX + j); f += dr2(NX + j) * d * d; }
+                if constexpr (OD) { const double d0 = rs_[0] - RW(R_XR + 10), d1 = rs_[1] - RW(R_XR + 11); f += dr2(10) * d0 * d0 + dr2(11) * d1 * d1; }
+            }
+            return f;
+        }
         if (act) {
             const double e0 = xs[0] - xg[0], e1 = xs[1] - xg[1];
             f = P.Q[0] * e0 * e0 + P.Q[1] * e1 * e1 + P.Q[2] * xs[2] * xs[2] + P.Q[3] * xs[3] * xs[3] + P.Q[4] * xs[4] * xs[4] + P.Q[5] * xs[5] * xs[5];
@@ -345,13 +368,15 @@ struct Wave {
         if (stg) {
 #pragma unroll
             for (int j = 0; j < NU; ++j) { const double d = OD ? us[j] : us[j] - um[j]; f += P.R[j] * d * d; }
-            if constexpr (OD) f += P.ps1 * (rs[0] - P.rf1) * (rs[0] - P.rf1) + P.ps2 * (rs[1] - P.rf2) * (rs[1] - P.rf2);
+            if constexpr (OD) f += P.ps1 * (rs_[0] - P.rf1) * (rs_[0] - P.rf1) + P.ps2 * (rs_[1] - P.rf2) * (rs_[1] - P.rf2);
         }
         return f;
     }
     // trial evaluation at (xs, us, ss): theta (l1 residual of the scaled rows) and the unscaled objective; xs of every lane goes through XS
-    __device__ __forceinline__ void eval0(const double* xs, const double* us, const double* ss, const double* rs, double& theta, double& fsum) {
-        if constexpr (OD) od_weights(rs[0], rs[1]);
+    // a_np: step length applied to (n, p) inside the restoration; pmax (optional): largest residual
+    __device__ __forceinline__ void eval0(const double* xs, const double* us, const double* ss, const double* rs_, double& theta, double& fsum, double a_np = 0.0,
+                                          double* pmax = nullptr) {
+        if constexpr (OD) od_weights(rs_[0], rs_[1]);
         sync();
         if (act) {
 #pragma unroll
@@ -366,7 +391,7 @@ struct Wave {
             for (int j = 0; j < NU; ++j) lds[L.US + j] = uprev[j];
         }
         sync();
-        double th = 0.0;
+        double th = 0.0, pm = 0.0;
         double um[NU];
 #pragma unroll
         for (int j = 0; j < NU; ++j) um[j] = lds[L.US + k * 4 + j];
@@ -376,22 +401,29 @@ struct Wave {
             xn[0] = xs[0] + P.dt * xs[3]; xn[1] = xs[1] + P.dt * xs[4]; xn[2] = xs[2] + P.dt * xs[5];
             xn[3] = xs[3] + P.dt * acc[0]; xn[4] = xs[4] + P.dt * acc[1]; xn[5] = xs[5] + P.dt * acc[2];
 #pragma unroll
-            for (int i = 0; i < NX; ++i) th += fabs(dgc(i) * (xn[i] - lds[L.XS + (k + 1) * 6 + i]));
+            for (int i = 0; i < NX; ++i) { const double r = fabs(dgc(i) * (xn[i] - lds[L.XS + (k + 1) * 6 + i])); th += r; pm = fmax(pm, r); }
             double pt[3][2];
             points(xs, acc[0], acc[1], pt);
 #pragma unroll
-            for (int j = 0; j < KS; ++j) if (j < K) th += fabs(-dgd(j) * cbf_value(pt, j) - ss[j]);
+            for (int j = 0; j < KS; ++j) {
+                if (j < K) {
+                    double r = -dgd(j) * cbf_value(pt, j) - ss[j];
+                    if (rs) r += (RW(R_N + j) + a_np * RW(R_DN + j)) - (RW(R_P + j) + a_np * RW(R_DP + j));
+                    th += fabs(r); pm = fmax(pm, fabs(r));
+                }
+            }
         }
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) th += fabs(xs[i] - x0[i]);
+            for (int i = 0; i < NX; ++i) { const double r = fabs(xs[i] - x0[i]); th += r; pm = fmax(pm, r); }
         }
         theta = ipm::wsum(th);
-        fsum = ipm::wsum(cost_share(xs, us, um, rs));
+        if (pmax) *pmax = ipm::wmax(pm);
+        fsum = ipm::wsum(cost_share(xs, us, um, rs_));
     }
 
     // ---- barrier function (scaled objective + log barrier of every bound + damping of the one-sided ones) ------------------------------
-    __device__ __forceinline__ double barrier(double fsum, const double* xs, const double* us, const double* ss, double mu) const {
+    __device__ __forceinline__ double barrier(double fsum, const double* xs, const double* us, const double* ss, double mu, double a_np = 0.0) const {
         double v = 0.0;
         bool ok = true;
         if (act) {
@@ -425,10 +457,23 @@ struct Wave {
             }
             v -= mu * log(ps);
             v += O.kappa_d * mu * sa;
+            if (rs) {                                                       // n, p >= 0: linear term rho_R, log barrier, damping (one-sided)
+                double sn = 0.0;
+#pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    if (j < K) {
+                        const double nt = RW(R_N + j) + a_np * RW(R_DN + j), pt_ = RW(R_P + j) + a_np * RW(R_DP + j);
+                        if (!(nt > 0.0) || !(pt_ > 0.0)) ok = false;
+                        sn += nt + pt_;
+                        v -= mu * log(nt * pt_);
+                    }
+                }
+                v += (O.resto_penalty_parameter + O.kappa_d * mu) * sn;
+            }
         }
         const double bad = ipm::wmax(ok ? 0.0 : 1.0);
         if (bad > 0.0) return INF_;
-        return df * fsum + ipm::wsum(v);
+        return (rs ? 0.5 * zeta : df) * fsum + ipm::wsum(v);
     }
     // IPOPT's CalculateSafeSlack: a slack below eps min(1, mu) is raised to eps^(3/4) max(1, |bound|) by moving the bound
     __device__ __forceinline__ void safe1(double v, double& lo, bool lower, double s_min, double move) const {
@@ -464,6 +509,27 @@ struct Wave {
         c[4] = 2.0 * w1 * e1x * P.dt; c[5] = 2.0 * w1 * e1z * P.dt;
         if (hh) { hh[0] = e0x * e0x + e0z * e0z - off; hh[1] = e1x * e1x + e1z * e1z - off; e01[0] = e0x; e01[1] = e0z; e01[2] = e1x; e01[3] = e1z; }
         return w0 * (e0x * e0x + e0z * e0z - off) + w1 * (e1x * e1x + e1z * e1z - off) + w2 * (e2x * e2x + e2z * e2z - off);
+    }
+
+    // condensed weight E_j and right-hand side b_j of row j (J dx - dy / E = b): the slack -- and in the restoration n and p -- are eliminated,
+    //   1 / E = sum_v q_v,  q_v = 1 / (Sigma_v + dw);   b = -r + q_s rhs_s - q_n rhs_n + q_p rhs_p   (rhs_v = -(barrier gradient + sign_v y))
+    struct RowW { double E, b, qs, qn, qp, rs_, rn, rp; };
+    __device__ __forceinline__ RowW row_weights(int j, double mu, double dw) const {
+        RowW w;
+        const double stU = sU[j] - s[j];
+        w.qs = 1.0 / (vU[j] / stU + dw);
+        w.rs_ = yd[j] - (mu / stU - O.kappa_d * mu);
+        double rd = dv[j] - s[j], e = w.qs, b = w.qs * w.rs_;
+        w.qn = w.qp = w.rn = w.rp = 0.0;
+        if (rs) {
+            const double n = RW(R_N + j), p = RW(R_P + j), rho_R = O.resto_penalty_parameter;
+            rd += n - p;
+            w.qn = 1.0 / (RW(R_ZN + j) / n + dw); w.qp = 1.0 / (RW(R_ZP + j) / p + dw);
+            w.rn = -(rho_R - mu / n + O.kappa_d * mu + yd[j]); w.rp = -(rho_R - mu / p + O.kappa_d * mu - yd[j]);
+            e += w.qn + w.qp; b += -w.qn * w.rn + w.qp * w.rp;
+        }
+        w.E = 1.0 / e; w.b = -rd + b;
+        return w;
     }
 
     // exchange through LDS: x_{k+1} (XS), u_{k-1} / u_{k+1} (US, slot k + 1 = u_k, slot 0 = u_prev), multipliers of the rows that DEFINE x_k (YS, slot k)
@@ -508,18 +574,29 @@ struct Wave {
 #pragma unroll
         for (int i = 0; i < NX; ++i) E.gfx[i] = 0.0;
         if (act) {
-            E.gfx[0] = 2.0 * df * P.Q[0] * (x[0] - xg[0]); E.gfx[1] = 2.0 * df * P.Q[1] * (x[1] - xg[1]);
+            if (rs) {
 #pragma unroll
-            for (int i = 2; i < NX; ++i) E.gfx[i] = 2.0 * df * P.Q[i] * x[i];
+                for (int i = 0; i < NX; ++i) E.gfx[i] = zeta * dr2(i) * (x[i] - RW(R_XR + i));
+            } else {
+                E.gfx[0] = 2.0 * df * P.Q[0] * (x[0] - xg[0]); E.gfx[1] = 2.0 * df * P.Q[1] * (x[1] - xg[1]);
+#pragma unroll
+                for (int i = 2; i < NX; ++i) E.gfx[i] = 2.0 * df * P.Q[i] * x[i];
+            }
         }
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             double gj = 0.0;
-            if (stg) { gj = 2.0 * df * P.R[j] * (OD ? u[j] : u[j] - um[j]); if (!last) gj -= 2.0 * df * P.R[j] * (un[j] - u[j]); }
+            if (stg) {
+                if (rs) gj = zeta * dr2(NX + j) * (u[j] - RW(R_XR + NX + j));
+                else { gj = 2.0 * df * P.R[j] * (OD ? u[j] : u[j] - um[j]); if (!last) gj -= 2.0 * df * P.R[j] * (un[j] - u[j]); }
+            }
             E.gfu[j] = gj;
         }
         E.Jr[0] = E.Jr[1] = 0.0;
         E.gfr[0] = (OD && stg) ? 2.0 * df * P.ps1 * (rho[0] - P.rf1) : 0.0; E.gfr[1] = (OD && stg) ? 2.0 * df * P.ps2 * (rho[1] - P.rf2) : 0.0;
+        if constexpr (OD) {
+            if (rs && stg) { E.gfr[0] = zeta * dr2(10) * (rho[0] - RW(R_XR + 10)); E.gfr[1] = zeta * dr2(11) * (rho[1] - RW(R_XR + 11)); }
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) E.Jty[i] = 0.0;
         // rows that define x_k: -I (scaled) on x_k from the dynamics of stage k - 1; +I from the initial-state rows on x_0
@@ -540,14 +617,14 @@ struct Wave {
                 for (int j = 0; j < NU; ++j) gb[6 + j] = -zuL[j] + zuU[j];
             } else {
 #pragma unroll
-                for (int i = 0; i < NX; ++i) dg_[i] = 2.0 * df * P.Q[i] + dw;
+                for (int i = 0; i < NX; ++i) dg_[i] = ((rs && act) ? zeta * dr2(i) : 2.0 * df * P.Q[i]) + dw;
                 const double sL[3] = {x[2] - xbL[0], x[3] - xbL[1], x[4] - xbL[2]}, sUp[2] = {xbU[0] - x[2], xbU[1] - x[3]};
                 dg_[2] += zxL[0] / sL[0] + zxU[0] / sUp[0]; dg_[3] += zxL[1] / sL[1] + zxU[1] / sUp[1]; dg_[4] += zxL[2] / sL[2];
                 gb[2] = -mu / sL[0] + mu / sUp[0]; gb[3] = -mu / sL[1] + mu / sUp[1]; gb[4] = -mu / sL[2] + O.kappa_d * mu;
 #pragma unroll
                 for (int j = 0; j < NU; ++j) {
                     const double a = u[j] - ubL[j], b = ubU[j] - u[j];
-                    dg_[6 + j] = 2.0 * df * P.R[j] * (last ? 1.0 : 2.0) + dw + zuL[j] / a + zuU[j] / b;
+                    dg_[6 + j] = ((rs && stg) ? zeta * dr2(NX + j) : 2.0 * df * P.R[j] * (last ? 1.0 : 2.0)) + dw + zuL[j] / a + zuU[j] / b;
                     gb[6 + j] = -mu / a + mu / b;
                 }
             }
@@ -619,7 +696,7 @@ struct Wave {
                     const double cv = row_coeffs(pt, j, c, hh, e01);
                     const double sc = dgd(j);
                     dv[j] = -sc * cv;
-                    const double rd = dv[j] - s[j];
+                    const double rd = dv[j] - s[j] + (rs ? RW(R_N + j) - RW(R_P + j) : 0.0);
                     th += fabs(rd);
                     const double om = sc * yd[j];                                   // weight of grad^2 (-cbf_j) in the Hessian of the Lagrangian
 #pragma unroll
@@ -645,6 +722,7 @@ struct Wave {
                     if (build && !OD) {
                         double Ej, bd;
                         if (ls) { Ej = 1.0; bd = -vU[j]; }                           // q = 1, rhs_t = -(0 + vU), rhs_g = 0: b = q rhs_t
+                        else if (rs) { const RowW w = row_weights(j, mu, dw); Ej = w.E; bd = w.b; }
                         else {
                             const double stU = sU[j] - s[j];
                             Ej = vU[j] / stU + dw;
@@ -676,7 +754,7 @@ struct Wave {
                     // -- no difference of large numbers anywhere (tools/micro/seq_schur.py: 1e-13 where the assembled form is off by 1e+4).  Inertia:
                     // det (D + e b b') = det D (1 + e b' D^-1 b) and a positive semidefinite update lowers no eigenvalue, so every q < 0 turns one
                     // negative eigenvalue of D positive; S alone may be indefinite (its cross term against 2 df ps)
-                    const double s11 = ls ? 1.0 : 2.0 * df * P.ps1 + dw, s22 = ls ? 1.0 : 2.0 * df * P.ps2 + dw, s12 = Dl12;
+                    const double s11 = ls ? 1.0 : (rs ? zeta * dr2(10) : 2.0 * df * P.ps1) + dw, s22 = ls ? 1.0 : (rs ? zeta * dr2(11) : 2.0 * df * P.ps2) + dw, s12 = Dl12;
                     const double det = s11 * s22 - s12 * s12;
                     int nneg = det > 0.0 ? (s11 > 0.0 ? 0 : 2) : 1;
                     bool sing = !(fabs(det) > 0.0);
@@ -706,6 +784,7 @@ struct Wave {
                             const double sc = dgd(j);
                             double Ej, bd;
                             if (ls) { Ej = 1.0; bd = -vU[j]; }
+                            else if (rs) { const RowW w = row_weights(j, mu, dw); Ej = w.E; bd = w.b; }
                             else {
                                 const double stU = sU[j] - s[j];
                                 Ej = vU[j] / stU + dw;
@@ -874,7 +953,16 @@ struct Wave {
                     }
                     adw *= -dgd(j);
                     if (ls) { dyd[j] = adw + vU[j]; ds[j] = 0.0; dvU[j] = 0.0; }
-                    else {
+                    else if (rs) {                                                   // dy = E (a . dw - b);  dv = q_v (rhs_v - sign_v dy);  multipliers of n, p >= 0
+                        const RowW w = row_weights(j, mu, dw);
+                        const double stU = sU[j] - s[j], n = RW(R_N + j), p = RW(R_P + j), zn = RW(R_ZN + j), zp = RW(R_ZP + j);
+                        dyd[j] = w.E * (adw - w.b);
+                        ds[j] = w.qs * (w.rs_ + dyd[j]);
+                        dvU[j] = mu / stU - vU[j] + vU[j] * ds[j] / stU;
+                        const double dn = w.qn * (w.rn - dyd[j]), dp = w.qp * (w.rp + dyd[j]);
+                        RW(R_DN + j) = dn; RW(R_DP + j) = dp;
+                        RW(R_DZN + j) = mu / n - zn - zn * dn / n; RW(R_DZP + j) = mu / p - zp - zp * dp / p;
+                    } else {
                         const double stU = sU[j] - s[j], sig = vU[j] / stU, Ej = sig + dw, gt = mu / stU - O.kappa_d * mu;
                         const double rd = dv[j] - s[j], rhs_t = yd[j] - gt, bd = -rd + rhs_t / Ej;
                         dyd[j] = Ej * (adw - bd);
@@ -941,7 +1029,14 @@ struct Wave {
             for (int j = 0; j < KS; ++j) {
                 if (j < K) {
                     d = fmax(d, fabs(-yd[j] + vU[j]));
-                    const double rd = dv[j] - s[j];
+                    double rd = dv[j] - s[j];
+                    if (rs) {
+                        const double n = RW(R_N + j), pp = RW(R_P + j), zn = RW(R_ZN + j), zp = RW(R_ZP + j), rho_R = O.resto_penalty_parameter;
+                        rd += n - pp;
+                        d = fmax(d, fmax(fabs(rho_R + yd[j] - zn), fabs(rho_R - yd[j] - zp)));
+                        c = fmax(c, fmax(fabs(n * zn - mu), fabs(pp * zp - mu)));
+                        zsum += fabs(zn) + fabs(zp);
+                    }
                     p = fmax(p, fabs(rd)); up = fmax(up, fabs(rd / dgd(j)));
                     c = fmax(c, fabs((sU[j] - s[j]) * vU[j] - mu));
                     ysum += fabs(yd[j]); zsum += fabs(vU[j]);
@@ -954,7 +1049,7 @@ struct Wave {
         }
         dinf = ipm::wmax(d); pinf = ipm::wmax(p); comp = ipm::wmax(c); un_pinf = ipm::wmax(up);
         ysum = ipm::wsum(ysum); zsum = ipm::wsum(zsum);
-        const double m = (double)(6 * (N + 1) + N * K), nb = (double)(5 * (N + 1) + 8 * N + N * K);
+        const double m = (double)(6 * (N + 1) + N * K), nb = (double)(5 * (N + 1) + 8 * N + N * K * (rs ? 3 : 1));
         const double sd = fmax(O.s_max, (ysum + zsum) / (m + nb)) / O.s_max, sc = fmax(O.s_max, zsum / nb) / O.s_max;
         Emu = fmax(fmax(dinf / sd, pinf), comp / sc);
     }
@@ -991,6 +1086,12 @@ struct Wave {
                 if (j < K) {
                     ap = fmin(ap, ftb1(tau, sU[j] - s[j], -ds[j])); az = fmin(az, ftb1(tau, vU[j], dvU[j]));
                     v += (mu / (sU[j] - s[j]) - O.kappa_d * mu) * ds[j];
+                    if (rs) {
+                        const double n = RW(R_N + j), p = RW(R_P + j), dn = RW(R_DN + j), dp = RW(R_DP + j), rho_R = O.resto_penalty_parameter;
+                        ap = fmin(ap, fmin(ftb1(tau, n, dn), ftb1(tau, p, dp)));
+                        az = fmin(az, fmin(ftb1(tau, RW(R_ZN + j), RW(R_DZN + j)), ftb1(tau, RW(R_ZP + j), RW(R_DZP + j))));
+                        v += (rho_R - mu / n + O.kappa_d * mu) * dn + (rho_R - mu / p + O.kappa_d * mu) * dp;
+                    }
                 }
             }
             if constexpr (OD) v += E.gfr[0] * drho[0] + E.gfr[1] * drho[1];
@@ -1001,7 +1102,7 @@ struct Wave {
     // ---- filter ---------------------------------------------------------------------------------------------------------------------
     __device__ __forceinline__ bool filter_ok(double phi, double th) const {
         for (int i = 0; i < nfilt; ++i) {
-            const double p = lds[L.FP + i], t = lds[L.FT + i];
+            const double p = lds[fpo + i], t = lds[fto + i];
             if (!(cmp_le(phi, p, p) || cmp_le(th, t, t))) return false;
         }
         return true;
@@ -1011,14 +1112,14 @@ struct Wave {
         int n = 0;
         // (dominated entries are dropped; wave-uniform, every lane walks the list, lane 0 writes)
         for (int i = 0; i < nfilt; ++i) {
-            const double p = lds[L.FP + i], t = lds[L.FT + i];
+            const double p = lds[fpo + i], t = lds[fto + i];
             const bool keep = !(p >= phi && t >= th);
             sync();
-            if (keep) { if (lane == 0) { lds[L.FP + n] = p; lds[L.FT + n] = t; } ++n; }
+            if (keep) { if (lane == 0) { lds[fpo + n] = p; lds[fto + n] = t; } ++n; }
             sync();
         }
         if (n >= NFILT) n = NFILT - 1;
-        if (lane == 0) { lds[L.FP + n] = phi; lds[L.FT + n] = th; }
+        if (lane == 0) { lds[fpo + n] = phi; lds[fto + n] = th; }
         nfilt = n + 1;
         sync();
     }
@@ -1136,8 +1237,68 @@ struct Wave {
         int it = 0, n_acc = 0, status = SC_STATUS_INACCURATE, phase = PH_INIT;
         double last_alpha = 0.0, dw = 0.0;
         bool ic_first = true;
+        // the regular algorithm's state while the restoration runs (its filter stays in FP / FT), and the iterate the restoration started from
+        int o_nfilt = 0, o_nacc = 0;
+        double o_mu = 0.0, o_theta = 0.0, o_phi = 0.0, o_pinf = 0.0, o_dw_last = 0.0, o_theta_max = 0.0, o_theta_min = 0.0;
+        bool r_first = false, want_resto = false;
+        int n_tiny = 0;                                                    // consecutive accepted steps below stall_alpha (regular phase)
         for (;;) {
             MPROF_T0
+            if (want_resto) {
+                // ---- enter the restoration phase (oracle/ms_ipopt.py: _Algo.restoration) at the current iterate; E, theta, fsum are of this iterate ----
+                want_resto = false;
+                if (rw == nullptr || rs) { status = rs ? SC_STATUS_INACCURATE : SC_STATUS_NEEDS_RESTO; break; }      // (a failure INSIDE the restoration: resto_failed)
+                double pm = 0.0;
+                if (stg) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) pm = fmax(pm, fabs(rc[i]));
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) if (j < K) pm = fmax(pm, fabs(dv[j] - s[j]));
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) pm = fmax(pm, fabs(x[i] - x0[i]));
+                }
+                pm = ipm::wmax(pm);
+                if (pm <= O.resto_failure_feasibility_threshold) { status = SC_STATUS_INACCURATE; break; }      // "called at a point that is almost feasible"
+                const double phi = barrier(fsum, x, u, s, mu);
+                filter_add(phi - O.gamma_phi * theta, (1.0 - O.gamma_theta) * theta);
+                o_nfilt = nfilt; o_nacc = n_acc; o_mu = mu; o_theta = theta; o_phi = phi; o_pinf = pm; o_dw_last = dw_last; o_theta_max = theta_max; o_theta_min = theta_min;
+                fpo = L.FP2; fto = L.FT2; nfilt = 0; n_acc = 0; dw_last = 0.0;
+                mu = fmax(mu, pm); tau = fmax(O.tau_min, 1.0 - mu);
+                zeta = O.resto_proximity_weight * sqrt(mu);
+                const double rho_R = O.resto_penalty_parameter;
+                if (act) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) RW(R_XR + i) = x[i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) zxL[i] = fmin(rho_R, zxL[i]);
+                    zxU[0] = fmin(rho_R, zxU[0]); zxU[1] = fmin(rho_R, zxU[1]);
+                }
+                if (stg) {
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) { RW(R_XR + NX + j) = u[j]; zuL[j] = fmin(rho_R, zuL[j]); zuU[j] = fmin(rho_R, zuU[j]); }
+                    RW(R_XR + 10) = rho[0]; RW(R_XR + 11) = rho[1];
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) {
+                        if (j < K) {                                        // eq. (33): the n, p >= 0 that minimise rho (n + p) - mu (log n + log p) on  r + n - p = 0
+                            const double r = dv[j] - s[j], a = (mu - rho_R * r) / (2.0 * rho_R);
+                            const double n = a + sqrt(a * a + mu * r / (2.0 * rho_R)), pp = r + n;
+                            RW(R_N + j) = n; RW(R_P + j) = pp; RW(R_ZN + j) = mu / n; RW(R_ZP + j) = mu / pp;
+                            vU[j] = fmin(rho_R, vU[j]); yd[j] = 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) yc[i] = 0.0;
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) lds[L.Y0 + i] = 0.0;
+                }
+                rs = true; r_first = true;
+                phase = PH_START;
+                continue;
+            }
             const bool ls = phase == PH_LS, build = phase == PH_LS || phase == PH_BUILD;
             if (phase == PH_BUILD) eval2<true, false>(E, mu, dw, theta, fsum);
             else if (phase == PH_LS) eval2<true, true>(E, mu, dw, theta, fsum);
@@ -1150,7 +1311,7 @@ struct Wave {
             }
             if (build) {
                 MPROF_ADD(2)
-                const double cs = (ls || OD) ? 0.0 : 2.0 * df;
+                const double cs = (ls || OD || rs) ? 0.0 : 2.0 * df;         // (the restoration's objective has no input-rate term)
                 bool okf = true;
                 if constexpr (OD) okf = ipm::wmax((stg && od_bad) ? 1.0 : 0.0) == 0.0;      // a decay block that is not positive definite
                 if (okf) okf = riccati_backward(lds, L, N, lane, P.dt, cs * P.R[0], cs * P.R[1], cs * P.R[2], cs * P.R[3]);
@@ -1162,7 +1323,7 @@ struct Wave {
                     } else dw *= dw_last == 0.0 ? O.perturb_inc_fact_first : O.perturb_inc_fact;
                     if (dw > O.max_hessian_perturbation) {
                         if (ls) { phase = PH_START; continue; }             // (no least-square estimate: multipliers stay zero)
-                        status = SC_STATUS_NEEDS_RESTO; break;
+                        want_resto = true; continue;
                     }
                     continue;
                 }
@@ -1228,8 +1389,8 @@ struct Wave {
                     if constexpr (OD) { rt[0] = rho[0] + alpha * drho[0]; rt[1] = rho[1] + alpha * drho[1]; }
                     safe_slacks(xt, ut, st, mu);
                     double f_t;
-                    eval0(xt, ut, st, rt, th_t, f_t);
-                    phi_t = barrier(f_t, xt, ut, st, mu);
+                    eval0(xt, ut, st, rt, th_t, f_t, alpha);
+                    phi_t = barrier(f_t, xt, ut, st, mu, alpha);
                     if (phi_t < INF_ && th_t == th_t && phi_t == phi_t) {
                         bool ok = th_t <= theta_max;
                         if (ok) {
@@ -1250,7 +1411,7 @@ struct Wave {
                     first = false;
                     alpha *= O.alpha_red_factor;
                 }
-                if (!accepted) { status = SC_STATUS_NEEDS_RESTO; break; }
+                if (!accepted) { want_resto = true; continue; }
                 MPROF_ADD(6)
                 {
                     const bool ftype = gBD < 0.0 && alpha * sw_l > sw_r;
@@ -1258,6 +1419,7 @@ struct Wave {
                     if (!ftype || !arm) filter_add(phi - O.gamma_phi * theta, (1.0 - O.gamma_theta) * theta);
                 }
                 last_alpha = alpha;
+                n_tiny = (!rs && alpha < O.stall_alpha) ? n_tiny + 1 : 0;
 #pragma unroll
                 for (int i = 0; i < NX; ++i) x[i] = xt[i];
                 if (stg) {
@@ -1287,6 +1449,17 @@ struct Wave {
                         for (int j = 0; j < NU; ++j) { upd(zuL[j], dzuL[j], u[j] - ubL[j]); upd(zuU[j], dzuU[j], ubU[j] - u[j]); }
 #pragma unroll
                         for (int j = 0; j < KS; ++j) if (j < K) upd(vU[j], dvU[j], sU[j] - s[j]);
+                        if (rs) {
+#pragma unroll
+                            for (int j = 0; j < KS; ++j) {
+                                if (j < K) {
+                                    const double n = RW(R_N + j) + alpha * RW(R_DN + j), pp = RW(R_P + j) + alpha * RW(R_DP + j);
+                                    double zn = RW(R_ZN + j), zp = RW(R_ZP + j);
+                                    upd(zn, RW(R_DZN + j), n); upd(zp, RW(R_DZP + j), pp);
+                                    RW(R_N + j) = n; RW(R_P + j) = pp; RW(R_ZN + j) = zn; RW(R_ZP + j) = zp;
+                                }
+                            }
+                        }
                     }
                 }
                 ++it;
@@ -1296,26 +1469,101 @@ struct Wave {
             }
             // ---- PH_START / PH_EVAL: errors, convergence, barrier parameter ----
             MPROF_ADD(0)
-            if (phase == PH_START) { theta_max = O.theta_max_fact * fmax(1.0, theta); theta_min = O.theta_min_fact * fmax(1.0, theta); }
+            if (phase == PH_START) { theta_max = (rs ? O.resto_theta_max_fact : O.theta_max_fact) * fmax(1.0, theta); theta_min = O.theta_min_fact * fmax(1.0, theta); }
             double E0, dinf, pinf, comp, un_pinf;
             errors(E, 0.0, E0, dinf, pinf, comp, un_pinf);
             if (trace && lane == 0) {
                 double* t = trace + (size_t)(it < O.max_iter ? it : O.max_iter) * TRACE_W;
-                t[0] = E0; t[1] = dinf; t[2] = pinf; t[3] = comp; t[4] = mu; t[5] = theta; t[6] = last_dw; t[7] = last_alpha;
+                t[0] = E0; t[1] = dinf; t[2] = pinf; t[3] = comp; t[4] = mu; t[5] = theta; t[6] = last_dw; t[7] = rs ? -last_alpha : last_alpha;      // (a negative step length marks an iterate of the restoration)
             }
-            if (E0 <= O.tol && dinf / df <= O.dual_inf_tol && un_pinf <= O.constr_viol_tol && comp / df <= O.compl_inf_tol) { status = SC_STATUS_OPTIMAL; break; }
-            if (E0 <= O.acceptable_tol && dinf / df <= O.acceptable_dual_inf_tol && un_pinf <= O.acceptable_constr_viol_tol && comp / df <= O.acceptable_compl_inf_tol) {
-                if (++n_acc >= O.acceptable_iter) { status = SC_STATUS_OPTIMAL; break; }
-            } else n_acc = 0;
+            bool conv = false;
+            if (rs) {
+                // RestoFilterConvergenceCheck: back to the regular algorithm when (x, s) is acceptable to ITS filter and to the iterate the restoration
+                // started from, with the infeasibility down to kappa_resto of what it was; and the restoration's own convergence tests (unscaled problem)
+                double th_o = 0.0, f_o = 0.0, pm_o = 0.0;
+                rs = false;
+                eval0(x, u, s, rho, th_o, f_o, 0.0, &pm_o);
+                const double phi_o = barrier(f_o, x, u, s, o_mu);
+                rs = true;
+                bool leave = !r_first && pm_o <= O.required_infeasibility_reduction * o_pinf && phi_o < INF_ && phi_o == phi_o;
+                if (leave) {
+                    for (int i = 0; i < o_nfilt; ++i) {
+                        const double p = lds[L.FP + i], t = lds[L.FT + i];
+                        if (!(cmp_le(phi_o, p, p) || cmp_le(th_o, t, t))) { leave = false; break; }
+                    }
+                }
+                if (leave && phi_o > o_phi) {
+                    const double bas = fabs(o_phi) > 10.0 ? fmax(1.0, log10(fabs(o_phi))) : 1.0;
+                    if (log10(phi_o - o_phi) > O.obj_max_inc + bas) leave = false;
+                }
+                if (leave) leave = cmp_le(th_o, (1.0 - O.gamma_theta) * o_theta, o_theta) || cmp_le(phi_o - o_phi, -O.gamma_phi * o_theta, o_phi);
+                if (leave) {
+                    // bound multipliers of (x, s) come back (reset to 1 when one of them is beyond bound_mult_reset_threshold), the others start at zero
+                    double zm = 0.0;
+                    if (act) { zm = fmax(fmax(zxL[0], zxL[1]), fmax(zxL[2], fmax(zxU[0], zxU[1]))); }
+                    if (stg) {
+#pragma unroll
+                        for (int j = 0; j < NU; ++j) zm = fmax(zm, fmax(zuL[j], zuU[j]));
+#pragma unroll
+                        for (int j = 0; j < KS; ++j) if (j < K) zm = fmax(zm, vU[j]);
+                    }
+                    zm = ipm::wmax(zm);
+                    if (zm > O.bound_mult_reset_threshold) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) zxL[i] = 1.0;
+                        zxU[0] = zxU[1] = 1.0;
+#pragma unroll
+                        for (int j = 0; j < NU; ++j) { zuL[j] = 1.0; zuU[j] = 1.0; }
+#pragma unroll
+                        for (int j = 0; j < KS; ++j) vU[j] = 1.0;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) yc[i] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < KS; ++j) yd[j] = 0.0;
+                    if (lane == 0) {
+#pragma unroll
+                        for (int i = 0; i < NX; ++i) lds[L.Y0 + i] = 0.0;
+                    }
+                    rs = false; fpo = L.FP; fto = L.FT; nfilt = o_nfilt; n_acc = o_nacc; mu = o_mu; tau = fmax(O.tau_min, 1.0 - mu); dw_last = o_dw_last;
+                    theta_max = o_theta_max; theta_min = o_theta_min;
+                    phase = PH_EVAL;
+                    continue;
+                }
+                if (E0 <= O.tol && dinf <= O.dual_inf_tol && pinf <= O.constr_viol_tol && comp <= O.compl_inf_tol) conv = true;
+                else if (E0 <= O.acceptable_tol && dinf <= O.acceptable_dual_inf_tol && pinf <= O.acceptable_constr_viol_tol && comp <= O.acceptable_compl_inf_tol) {
+                    if (++n_acc >= O.acceptable_iter) conv = true;
+                } else n_acc = 0;
+                if (conv) {                                                 // a stationary point of the violation: infeasible (certificate) unless it is feasible after all
+                    status = pm_o <= 1e2 * O.tol ? SC_STATUS_INACCURATE : SC_STATUS_INFEASIBLE;
+                    break;
+                }
+            } else {
+                if (E0 <= O.tol && dinf / df <= O.dual_inf_tol && un_pinf <= O.constr_viol_tol && comp / df <= O.compl_inf_tol) { status = SC_STATUS_OPTIMAL; break; }
+                if (E0 <= O.acceptable_tol && dinf / df <= O.acceptable_dual_inf_tol && un_pinf <= O.acceptable_constr_viol_tol && comp / df <= O.acceptable_compl_inf_tol) {
+                    if (++n_acc >= O.acceptable_iter) { status = SC_STATUS_OPTIMAL; break; }
+                } else n_acc = 0;
+            }
             if (it >= O.max_iter) { status = SC_STATUS_INACCURATE; break; }
+            if (O.stall_iter > 0 && n_tiny >= O.stall_iter) { status = SC_STATUS_INACCURATE; break; }       // (stall rule: see sc_ipopt_params)
             for (;;) {
                 double Emu, a, b, c, d;
                 errors(E, mu, Emu, a, b, c, d);
                 if (Emu > O.barrier_tol_factor * mu || mu <= mu_min) break;
                 const double mu_new = fmax(mu_min, fmin(O.mu_linear_decrease_factor * mu, pow(mu, O.mu_superlinear_decrease_power)));
                 if (mu_new == mu) break;
+                if (rs) {                                                   // the restoration's objective carries zeta = eta sqrt(mu): its gradient scales with it
+                    const double sc_ = sqrt(mu_new / mu);
+                    zeta *= sc_;
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) E.gfx[i] *= sc_;
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) E.gfu[j] *= sc_;
+                    E.gfr[0] *= sc_; E.gfr[1] *= sc_;
+                }
                 mu = mu_new; tau = fmax(O.tau_min, 1.0 - mu); nfilt = 0;
             }
+            r_first = false;
             MPROF_ADD(1)
             phase = PH_BUILD; dw = 0.0; ic_first = true;
         }
@@ -1335,6 +1583,7 @@ __global__ void __launch_bounds__(64) mpcvtol_ms_kernel(const Params P, const sc
     const long long b = blockIdx.x;
     if (b >= B) return;
     Wave<KS, OD> S(P, O, (ldsd*)ms_lds);
+    if (O.resto_workspace) S.rw = (double*)O.resto_workspace + (size_t)b * (size_t)(Wave<KS, OD>::R_SLOTS * 64);
     const TIO* ob = obs + (obs_shared ? 0 : b * P.K * 7);
     if ((int)threadIdx.x < 3 * KS_MAX) {
         const int j = threadIdx.x / 3, c = threadIdx.x % 3;

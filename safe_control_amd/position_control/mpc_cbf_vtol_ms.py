@@ -21,10 +21,12 @@ from .mpc_cbf_vtol import (CBF_VTOL, HORIZON_VTOL, OD_CBF_VTOL, Q_VTOL, R_VTOL, 
 
 class BatchedVtolMSMPCCBF:
     """``solve(X[B,6], u_prev[B,4], goal[B,2], obs[B,K,7] | obs[K,7])`` -> ``u[B,4]``, ``status[B]``, ``iters[B]`` [, ``plan[B, 31*6 + 30*4]``].
-    ``ipopt``: overrides of IPOPT's option defaults (``_lib.IPOPT_DEFAULTS``).  ``fallback``: re-solve SC_STATUS_NEEDS_RESTO problems with
-    the condensed kernel (default), or hand the status to the caller."""
+    ``ipopt``: overrides of IPOPT's option defaults (``_lib.IPOPT_DEFAULTS``).  ``restoration``: run IPOPT's restoration phase inside the
+    kernel (elastic variables on the CBF rows; a workspace of ``sc_mpcvtol_ms_workspace_bytes`` is kept between calls) -- a stationary
+    point of the violation comes back as SC_STATUS_INFEASIBLE.  ``fallback``: re-solve what still comes back SC_STATUS_NEEDS_RESTO (only
+    with ``restoration=False``) with the condensed kernel, or hand the status to the caller."""
 
-    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f64", cbf_param=None, ipopt=None, fallback=True, max_iter=None):
+    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f64", cbf_param=None, ipopt=None, fallback=True, max_iter=None, restoration=True):
         self.robot_spec = complete_robot_spec(dict(robot_spec or {"model": "VTOL2D"}))
         if self.robot_spec["model"] != "VTOL2D":
             raise NotImplementedError("this controller serves VTOL2D")
@@ -39,6 +41,8 @@ class BatchedVtolMSMPCCBF:
             self.ipopt["max_iter"] = int(max_iter)
         self.max_iter = int(self.ipopt.get("max_iter", _lib.IPOPT_DEFAULTS["max_iter"]))
         self.fallback = bool(fallback)
+        self.restoration = bool(restoration)
+        self._resto_ws = None
         self.condensed = BatchedVtolMPCCBF(dict(self.robot_spec), dt=dt, io_dtype=io_dtype, cbf_param=dict(self.cbf_param)) if fallback else None
         self.n_fallback = 0                                  # problems of the last call that went to the condensed kernel
         self.iter_slices = ()
@@ -52,6 +56,17 @@ class BatchedVtolMSMPCCBF:
     @property
     def plan_width(self):
         return (self.horizon + 1) * 6 + self.horizon * 4
+
+    def _ipopt_params(self, B, K, device):
+        """sc_ipopt_params of this call; with ``restoration`` the workspace of the in-kernel restoration phase (grown on demand, kept)."""
+        import torch
+        ip = _lib.default_ipopt(**self.ipopt)
+        if self.restoration:
+            need = int(self._lib.sc_mpcvtol_ms_workspace_bytes(B, K))
+            if self._resto_ws is None or self._resto_ws.numel() < need or self._resto_ws.device != device:
+                self._resto_ws = torch.empty((max(need, 8),), dtype=torch.uint8, device=device)
+            ip.resto_workspace, ip.resto_workspace_bytes = self._resto_ws.data_ptr(), self._resto_ws.numel()
+        return ip
 
     def solve(self, X, u_prev, goal, obs, want_plan=False, want_trace=False, want_z=False):
         import torch
@@ -69,7 +84,7 @@ class BatchedVtolMSMPCCBF:
         iters = torch.empty((B,), dtype=torch.int32, device=X.device)
         want_plan = want_plan or want_z
         plan = torch.empty((B, self.plan_width), dtype=dt_, device=X.device) if want_plan else None
-        ip = _lib.default_ipopt(**self.ipopt)
+        ip = self._ipopt_params(B, K, X.device)
         trace = torch.zeros((B, ip.max_iter + 1, 8), dtype=torch.float64, device=X.device) if want_trace else None
         p = make_params(self.robot_spec, self.cbf_param, self.horizon, self.dt, self.robot_spec["radius"], self.io_dtype, obs_shared=shared)
         stream = torch.cuda.current_stream(X.device).cuda_stream
@@ -102,8 +117,9 @@ class BatchedOptimalDecayVtolMSMPCCBF(BatchedVtolMSMPCCBF):
     more inputs of a stage.  ``solve(...)`` -> ``u[B,4]``, ``rho[B,2N]``, ``status[B]``, ``iters[B]`` [, ``plan``].  Problems that come back
     SC_STATUS_NEEDS_RESTO go to the condensed optimal-decay kernel (``BatchedOptimalDecayVtolMPCCBF``)."""
 
-    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f64", cbf_param=None, ipopt=None, fallback=True, max_iter=None):
-        super().__init__(robot_spec, dt=dt, io_dtype=io_dtype, cbf_param=cbf_param or dict(OD_CBF_VTOL), ipopt=ipopt, fallback=False, max_iter=max_iter)
+    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f64", cbf_param=None, ipopt=None, fallback=True, max_iter=None, restoration=True):
+        super().__init__(robot_spec, dt=dt, io_dtype=io_dtype, cbf_param=cbf_param or dict(OD_CBF_VTOL), ipopt=ipopt, fallback=False, max_iter=max_iter,
+                         restoration=restoration)
         self.fallback = bool(fallback)
         self.condensed = BatchedOptimalDecayVtolMPCCBF(dict(self.robot_spec), dt=dt, io_dtype=io_dtype, cbf_param=dict(self.cbf_param)) if fallback else None
 
@@ -124,7 +140,7 @@ class BatchedOptimalDecayVtolMSMPCCBF(BatchedVtolMSMPCCBF):
         iters = torch.empty((B,), dtype=torch.int32, device=X.device)
         want_plan = want_plan or want_z
         plan = torch.empty((B, self.plan_width), dtype=dt_, device=X.device) if want_plan else None
-        ip = _lib.default_ipopt(**self.ipopt)
+        ip = self._ipopt_params(B, K, X.device)
         trace = torch.zeros((B, ip.max_iter + 1, 8), dtype=torch.float64, device=X.device) if want_trace else None
         p = make_od_params(self.robot_spec, self.cbf_param, self.horizon, self.dt, self.robot_spec["radius"], self.io_dtype, obs_shared=shared)
         stream = torch.cuda.current_stream(X.device).cuda_stream
