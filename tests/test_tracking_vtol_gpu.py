@@ -158,17 +158,22 @@ def fly_reference_scene(spec, steps=400):
 def test_reference_example_scene_lands():
     """examples/test_vtol.py:12-92 (20 m/s at (2, 10), 24 discs, waypoints (70, 10) then (70, 0.5); README.md:43-45 lists it as a runnable
     demo; its success test is `unexpected_beh in (-1, 0)`, :88-91) through the drop-in loop with the default position controller for this
-    model: the NLP as do-mpc poses it (multiple shooting, x_k = x0 start) under IPOPT's algorithm on csrc/mpc_vtol_ms.hip, the condensed
-    kernel behind it for the solves that need a restoration.  The flight LANDS: every waypoint reached, return code -1 (tracking.py:664-666)
-    -- measured round 5: 276 control steps, 273 solves optimal, over the discs at 20 m.  (The condensed kernel alone loses this flight at
-    the start of the landing leg: one diverging rollout, see the next test and DESIGN.md kernel 12.)"""
+    model: the NLP as do-mpc poses it (multiple shooting, x_k = x0 start) under IPOPT's algorithm on csrc/mpc_vtol_ms.hip, restoration phase
+    included (no other solver behind it).  The flight LANDS: every waypoint reached, return code -1 (tracking.py:664-666) -- measured round 5:
+    306 control steps in 1.6 s, 301 solves optimal, the first five locally infeasible (20 m/s towards the wall: their restoration phase
+    converges to a stationary point of the violation and the loop applies that input, as do-mpc does with IPOPT's).  With the hand-over
+    to the condensed kernel instead of the in-kernel restoration the flight went over the discs at 20 m (276 steps); the CPU oracle's
+    flights take either route (profiles/r05_ms_vtol_flight*.log) -- which one depends on the inputs of those first infeasible NLPs.
+    (The condensed kernel alone loses this flight at the start of the landing leg: one diverging rollout, see the next test and
+    DESIGN.md kernel 12.)"""
     ctl, ret, st, zmax, dmin, vmin = fly_reference_scene(dict(REF_SPEC))
     assert type(ctl.mpc).__name__ == "BatchedVtolMSMPCCBF" and ctl.mpc.max_iter == 3000
     assert ret == -1, (ret, len(st))
     assert int(ctl.current_goal_index[0].item()) == 2 and 200 <= len(st) <= 400
     X = ctl.X[0].cpu().numpy()
     assert np.hypot(X[0] - 70.0, X[1] - 0.5) < 1.0 and X[1] > 0.0                  # within the reached_threshold of the landing waypoint, above ground
-    assert zmax > 18.0 and dmin < 1.0                                               # over the wall, through the first waypoint
+    assert zmax > 10.5 and dmin < 1.0                                               # past the wall, through the first waypoint
+    assert ctl.mpc.n_fallback == 0 and not (st == 4).any() and (st == 0).mean() >= 0.95
     assert np.mean(st == 0) >= 0.95
 
 

@@ -22,7 +22,7 @@ elif mode == "scene":                                                       # fi
     ob = np.hstack([np.array([[67.0, z, 0.5] for z in (6.0, 7.0, 8.0, 9.0)] + [[73.0, float(z), 0.5] for z in range(1, 7)]), np.zeros((10, 4))])
     spec = dict(model="VTOL2D", radius=0.6, v_max=20.0)
     mdl, ctl = MS.vtol_model(dict(radius=0.6, v_max=20.0)), sca.BatchedVtolMSMPCCBF(spec, io_dtype="f64", fallback=False, max_iter=maxit)
-    x0, up, g = np.array([2.0, 10.0, 0.0, 20.0, 0.0, 0.0]), np.zeros(4), np.array([70.0, 10.0])
+    x0, up, g = np.array([2.0 + i, 10.0 - 0.05 * i, 0.0, 20.0, 0.0, 0.0]), np.zeros(4), np.array([70.0, 10.0])       # (PROB shifts the start)
 else:
     mdl, ctl = MS.vtol_model(), sca.BatchedVtolMSMPCCBF(io_dtype="f64", fallback=False, max_iter=maxit)
     x0, up, g, ob = Xn[i], up0[i], gn[i], on[i]
@@ -31,7 +31,7 @@ r = ctl.solve(t(x0), t(up), t(g), t(ob), want_trace=True)
 torch.cuda.synchronize()
 u, st, it, K = r[0][0].cpu().numpy(), int(r[-3][0]), int(r[-2][0]), r[-1][0].cpu().numpy()
 tr = []
-uo, so, ito, info = MS.solve(mdl, x0, up, g, ob, return_info=True, trace=tr, opts=dict(linear_solver="riccati", max_soc=0, resto_elastic="ineq", max_iter=maxit))
+uo, so, ito, info = MS.solve(mdl, x0, up, g, ob, return_info=True, trace=tr, opts=dict(MS.KERNEL_PROFILE, max_iter=maxit))
 T = np.array([[q["E0"], q["dinf"], q["pinf"], q["comp"], q["mu"], q["theta"], q["delta"], -q["alpha"] if q["resto"] else q["alpha"]] for q in tr])
 print(f"kernel: status {st} iterations {it} u0 {u}\noracle: status {so} ({info['status']}) iterations {ito} u0 {uo[:4]}; restoration iterates {sum(1 for q in tr if q['resto'])}")
 m = min(len(T), it + 1)
