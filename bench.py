@@ -655,7 +655,7 @@ def vtol_ms_mpc_leg(dev, B=4096, K=8, steps=3, seed=0):
     """MPC-CBF for VTOL2D AS DO-MPC POSES IT (round 5, csrc/mpc_vtol_ms.hip, DESIGN.md kernel 12): multiple shooting (states of every stage are
     variables, dynamics as equality rows, x_k = x0 start: position_control/mpc_cbf.py:162-174,366-369) under IPOPT's filter line-search
     interior point with IPOPT's option defaults (tol 1e-8, max_iter 3000), one NLP per wavefront, one stage per lane, Riccati recursion with
-    defects; problems that would enter IPOPT's restoration phase go to the condensed kernel (none of this batch does).  One launch: the
+    defects on the f64 matrix cores, IPOPT's restoration phase inside the kernel (no solve of this batch enters it).  One launch: the
     longest solve of the batch is ~100 iterations, no continuation needed.  Same batch as vtol_mpc_cbf."""
     import torch
     import safe_control_amd as sca
@@ -677,7 +677,7 @@ def vtol_ms_mpc_leg(dev, B=4096, K=8, steps=3, seed=0):
            "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32", "budget": 3000, "launches": 1,
            "optimal_fraction": float((st == 0).double().mean().item()), "inaccurate_fraction": float((st == 2).double().mean().item()),
            "restoration_fallback": int(ctl.n_fallback), "mean_ipm_iterations": float(it.double().mean().item()), "max_ipm_iterations": int(it.max().item()),
-           "lds_KB_per_problem": 53.3, "problems_per_CU": 3}
+           "lds_KB_per_problem": 40.0, "problems_per_CU": 4}
     # the work without the tail: the batch filled with copies of the median problem
     try:
         opt = torch.nonzero(st == 0).flatten()
@@ -697,7 +697,7 @@ def vtol_ms_mpc_leg(dev, B=4096, K=8, steps=3, seed=0):
 
 def vtol_ms_closed_loop_leg(dev):
     """The reference's own VTOL2D demo (examples/test_vtol.py:12-92) through the drop-in loop with the default position controller of the model
-    (multiple-shooting kernel + condensed fallback): one aircraft, control steps until the loop returns."""
+    (the multiple-shooting kernel, restoration phase included): one aircraft, control steps until the loop returns."""
     import time
     import numpy as np
     import torch
@@ -767,7 +767,7 @@ def od_vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
 def od_vtol_ms_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
     """Optimal-decay MPC-CBF for VTOL2D in the multiple-shooting form (round 5: the OD instantiation of csrc/mpc_vtol_ms.hip; the decay rates are
     two more inputs of a stage, as in the reference, optimal_decay_mpc_cbf.py:123-124).  Same batch as od_vtol_mpc_cbf; problems that would
-    enter IPOPT's restoration phase go to the condensed optimal-decay kernel."""
+    enter IPOPT's restoration phase run it inside the kernel (elastic variables on the CBF rows)."""
     import numpy as np
     import torch
     import safe_control_amd as sca

@@ -253,3 +253,19 @@ def test_kernel_profile_follows_the_default_solve_and_hands_back_restorations():
     mdl2 = MS.vtol_model(dict(radius=0.6, v_max=20.0))
     u, st, it, info = MS.solve(mdl2, np.array([2.0, 10.0, 0.0, 20.0, 0.0, 0.0]), np.zeros(4), [70.0, 10.0], ob, return_info=True, opts=prof)
     assert info["status"] == "needs_resto" and st == 4 and it < 100
+
+
+def test_kernel_profile_restoration_reaches_the_same_verdict_as_the_full_algorithm():
+    """KERNEL_PROFILE (what csrc/mpc_vtol_ms.hip runs since its restoration phase went into the kernel: elastic variables on the CBF rows only,
+    dynamics rows hard inside the restoration, stall rule) on the first NLP of the reference's example scene: converged to a point of local
+    infeasibility like the full algorithm (elastic variables on every row: a different restoration problem, hence another stationary point
+    of the violation -- front thrust 1.0 against 0.73); the iteration count is the one the GPU test holds the kernel to."""
+    ob = np.hstack([np.array([[67.0, z, 0.5] for z in (6.0, 7.0, 8.0, 9.0)] + [[73.0, float(z), 0.5] for z in range(1, 7)]), np.zeros((10, 4))])
+    mdl = MS.vtol_model(dict(radius=0.6, v_max=20.0))
+    x0 = np.array([2.0, 10.0, 0.0, 20.0, 0.0, 0.0])
+    tr = []
+    u1, s1, i1, info1 = MS.solve(mdl, x0, np.zeros(4), [70.0, 10.0], ob, return_info=True, opts=dict(MS.KERNEL_PROFILE), trace=tr)
+    u2, s2, i2, info2 = MS.solve(mdl, x0, np.zeros(4), [70.0, 10.0], ob, return_info=True)
+    assert info1["status"] == info2["status"] == "local_infeasibility" and s1 == s2 == 1
+    assert i1 == 134 and sum(1 for q in tr if q["resto"]) >= 50
+    assert u1[0] >= 0.7 and u2[0] >= 0.7 and u1[3] > 0.3 and u2[3] > 0.3   # (both: front thrust up, elevator up)
