@@ -223,51 +223,63 @@ __device__ __attribute__((noinline)) bool riccati_backward(ldsd* lds, const Lds 
     return true;
 }
 
-// forward LQ rollout: du_k = K (dx_k, du_{k-1}) + kff, dx_{k+1} = [A | B] (dx_k, du_k) + c_{k+1}; four + six lanes, two barriers per stage
+// forward LQ rollout: du_k = K (dx_k, du_{k-1}) + kff, dx_{k+1} = [A | B] (dx_k, du_k) + c_{k+1}.  Lanes 0..5 carry dx_k and lanes 0..3 du_{k-1} in
+// REGISTERS; the ten numbers a stage needs from its predecessor are v_readlane broadcasts, so the recurrence has no LDS round trip and no barrier
+// inside the loop (before: two barriers and ~25 dependent LDS loads per stage, 1.2 k cycles; the loads left -- gains, [A | B] rows, defects -- do
+// not depend on the recurrence).  The steps go to LDS (DX over the defects C, which a lane reads before it writes the same slot; DU) on the way.
 __device__ __attribute__((noinline)) void riccati_forward(ldsd* lds, const Lds L, const int N, const int lane, const double dt) {
-    if (lane < NX) lds[L.DX + lane] = lds[L.C + lane];
-    __syncthreads();
-    const int li = lane < NU ? lane : 0, lx = lane < NX ? lane : 0;
+    const int li = lane < NU ? lane : 0, lx = lane < NX ? lane : 0, lr = lx < 3 ? 0 : lx - 3;
+    double xr = lds[L.C + lx], vr = 0.0;                                   // dx_0 = C[0]; du_{-1} = 0
     for (int kk = 0; kk < N; ++kk) {
-        const ldsd* A3 = lds + L.AB + kk * ABS; const ldsd* KK = lds + L.KG + kk * 44;
-        {
-            double v = KK[40 + li];
+        const ldsd* A3 = lds + L.AB + kk * ABS + lr * 7; const ldsd* KK = lds + L.KG + kk * 44 + li * 10;
+        double kr[10], ar[7];
 #pragma unroll
-            for (int c = 0; c < NX; ++c) v += KK[li * 10 + c] * lds[L.DX + kk * 6 + c];
-            if (kk > 0) {
+        for (int c = 0; c < 10; ++c) kr[c] = KK[c];
+        const double kf = lds[L.KG + kk * 44 + 40 + li], cn = lds[L.C + (kk + 1) * 6 + lx];
 #pragma unroll
-                for (int c = 0; c < NU; ++c) v += KK[li * 10 + 6 + c] * lds[L.DU + (kk - 1) * NU + c];
-            }
-            if (lane < NU) lds[L.DU + kk * NU + lane] = v;
-        }
-        __syncthreads();
-        {
-            // row lx of [A | B] (dx_k, du_k) + c: rows 0..2: dx_i + dt dx_{i+3}; rows 3..5: the stored entries (+ dx_5 for row 5)
-            const ldsd* dxk = lds + L.DX + kk * 6; const ldsd* duk = lds + L.DU + kk * NU;
-            double v = lds[L.C + (kk + 1) * 6 + lx];
-            if (lx < 3) v += dxk[lx] + dt * dxk[lx + 3];
-            else {
-                const ldsd* row = A3 + (lx - 3) * 7;
-                v += row[0] * dxk[2] + row[1] * dxk[3] + row[2] * dxk[4] + row[3] * duk[0] + row[4] * duk[1] + row[5] * duk[2] + row[6] * duk[3];
-                if (lx == 5) v += dxk[5];
-            }
-            if (lane < NX) lds[L.DX + (kk + 1) * 6 + lane] = v;
-        }
-        __syncthreads();
+        for (int t = 0; t < 7; ++t) ar[t] = A3[t];
+        double d_[NX], v_[NU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) d_[i] = ipm::row_value(xr, i);
+#pragma unroll
+        for (int jj = 0; jj < NU; ++jj) v_[jj] = ipm::row_value(vr, jj);
+        const double du = (kf + kr[0] * d_[0] + kr[1] * d_[1]) + (kr[2] * d_[2] + kr[3] * d_[3] + kr[4] * d_[4]) + (kr[5] * d_[5] + kr[6] * v_[0] + kr[7] * v_[1]) +
+                          (kr[8] * v_[2] + kr[9] * v_[3]);
+        if (lane < NU) lds[L.DU + kk * NU + lane] = du;
+        double u_[NU];
+#pragma unroll
+        for (int jj = 0; jj < NU; ++jj) u_[jj] = ipm::row_value(du, jj);
+        // row lx of [A | B] (dx_k, du_k) + c: rows 0..2: dx_i + dt dx_{i+3}; rows 3..5: the stored entries (+ dx_5 for row 5)
+        const double up3 = lx == 0 ? d_[3] : (lx == 1 ? d_[4] : d_[5]);
+        const double lo = cn + xr + dt * up3;
+        const double hi = (cn + ar[0] * d_[2] + ar[1] * d_[3]) + (ar[2] * d_[4] + ar[3] * u_[0] + ar[4] * u_[1]) + (ar[5] * u_[2] + ar[6] * u_[3]) + (lx == 5 ? d_[5] : 0.0);
+        const double xn = lx < 3 ? lo : hi;
+        if (lane < NX) lds[L.DX + (kk + 1) * 6 + lane] = xn;
+        if (kk == 0 && lane < NX) lds[L.DX + lane] = xr;
+        xr = xn; vr = du;
     }
+    __syncthreads();
 }
 
-// costates lam_k = h_k + A_k' lam_{k+1}, k = N - 1 .. 0, with h_k (and lam_N = h_N) already in LAM: six lanes, one barrier per stage
+// costates lam_k = h_k + A_k' lam_{k+1}, k = N - 1 .. 0, with h_k (and lam_N = h_N) already in LAM: six lanes carry lam_{k+1} in registers, the six
+// numbers a stage needs are v_readlane broadcasts (no barrier inside the loop; a lane reads h_k from the slot it then overwrites)
 __device__ __attribute__((noinline)) void costates(ldsd* lds, const Lds L, const int N, const int lane, const double dt) {
     const int c = lane < NX ? lane : 0, ci = ab_col(c);
+    const double a0 = c == 0 ? 1.0 : (c == 3 ? dt : 0.0), a1 = c == 1 ? 1.0 : (c == 4 ? dt : 0.0), a2 = c == 2 ? 1.0 : (c == 5 ? dt : 0.0);   // A[I][c], I < 3
+    const int ao = ci >= 0 ? ci : 0;
+    const double am = ci >= 0 ? 1.0 : 0.0, a55 = c == 5 ? 1.0 : 0.0;
+    double lr = lds[L.LAM + N * 6 + c];
     for (int j = N - 1; j >= 0; --j) {
-        const ldsd* A3 = lds + L.AB + j * ABS;
-        double v = lds[L.LAM + j * 6 + c];
-        SC_FOR6( v += ab_at<I>(A3, c, ci, dt) * lds[L.LAM + (j + 1) * 6 + I]; );
-        __syncthreads();
+        const ldsd* A3 = lds + L.AB + j * ABS + ao;
+        const double h = lds[L.LAM + j * 6 + c], a3 = A3[0] * am, a4 = A3[7] * am, a5 = A3[14] * am + a55;
+        double l_[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) l_[i] = ipm::row_value(lr, i);
+        const double v = (h + a0 * l_[0] + a1 * l_[1]) + (a2 * l_[2] + a3 * l_[3]) + (a4 * l_[4] + a5 * l_[5]);
         if (lane < NX) lds[L.LAM + j * 6 + lane] = v;
-        __syncthreads();
+        lr = v;
     }
+    __syncthreads();
 }
 
 constexpr double EPSD = 2.220446049250313e-16;
