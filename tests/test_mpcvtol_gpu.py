@@ -49,6 +49,27 @@ def test_batch_against_oracle():
     assert np.all(o["theta"][o["st"] == 0] <= 1e-6)
 
 
+def test_default_budget_path_against_oracle_beyond_iteration_100():
+    """The shipped default (3000-iteration budget, classify pass + cap-100 continuation launches, Gauss-Newton restoration) on the solves the
+    capped parity test above never sees: the eight problems of the first 512 bench draws that take the most iterations (60 - 400),
+    kernel with its default schedule against oracle/mpc_vtol.py at max_iter = 3000.  Same status on all; where both call it optimal,
+    |u0 - u0_oracle| <= 1e-6 and the iteration counts within 2 % + 2 (a straggler: minutes of numpy on one core, hence eight of them)."""
+    n = 512
+    X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("vtol", 4096, 8, seed=0))
+    ctl = sca.BatchedVtolMPCCBF(io_dtype="f64")                          # max_iter 3000, default iter_slices
+    assert ctl.max_iter == 3000 and tuple(ctl.iter_slices) != ()
+    u, st, it = (a.cpu().numpy() for a in ctl.solve(t(X), t(up), t(goal), t(obs))[:3])
+    pick = np.argsort(-it)[:8]
+    o = family_solve_many("vtol", X[pick], up[pick], goal[pick], obs[pick], params={"max_iter": 3000}, timeout=6000)
+    print("default budget: kernel", st[pick].tolist(), it[pick].tolist(), "oracle", o["st"].tolist(), o["it"].tolist())
+    assert it[pick].min() >= 60
+    assert np.array_equal(st[pick], o["st"])
+    ok = o["st"] == 0
+    du = np.abs(u[pick] - o["u"]).max(axis=1)
+    assert ok.sum() >= 6 and du[ok].max() <= 1e-6, du
+    assert (np.abs(it[pick] - o["it"])[ok] <= 0.02 * o["it"][ok] + 2).all()
+
+
 def test_f32_storage_shared_obstacles_and_no_z():
     n = 64
     X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("vtol", 4096, 8, seed=3))
