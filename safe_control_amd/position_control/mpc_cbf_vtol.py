@@ -44,7 +44,9 @@ def make_params(robot_spec, cbf_param, horizon, dt, radius, io_dtype, obs_shared
 
 
 class VtolMPCCBF:
-    """Drop-in for position_control.mpc_cbf.MPCCBF with a VTOL2D robot (horizon fixed at 30: mpc_cbf.py:41)."""
+    """Drop-in for position_control.mpc_cbf.MPCCBF with a VTOL2D robot (horizon fixed at 30: mpc_cbf.py:41).  ``robot_spec['mpc_formulation']``:
+    'multiple_shooting' (default since round 5: the NLP as do-mpc poses it under IPOPT's algorithm with its restoration phase,
+    csrc/mpc_vtol_ms.hip -- the formulation that lands examples/test_vtol.py) or 'condensed' (single shooting, csrc/mpc_vtol_wave.hip)."""
 
     def __init__(self, robot, robot_spec, show_mpc_traj=False, num_obs=5, device=0):
         self.robot = robot
@@ -68,6 +70,10 @@ class VtolMPCCBF:
         self.z = np.zeros(4 * self.horizon)
         self.iterations = 0
         self.solver_status = "optimal"
+        self._ms = None
+        if self.robot_spec.get("mpc_formulation", "multiple_shooting") != "condensed":
+            from .mpc_cbf_vtol_ms import BatchedVtolMSMPCCBF
+            self._ms = BatchedVtolMSMPCCBF(self.robot_spec, dt=self.dt, io_dtype="f64", cbf_param=self.cbf_param, fallback=False)
 
     def update_tvp(self, goal, obs):
         self.goal = np.array(goal)
@@ -82,6 +88,18 @@ class VtolMPCCBF:
         X[: xs.shape[0]] = xs
         g = np.ascontiguousarray(np.asarray(self.goal, dtype=np.float64).reshape(-1)[:2])
         obs = np.ascontiguousarray(self.obs, dtype=np.float64)
+        if self._ms is not None:
+            import torch
+            dev = torch.device("cuda", int(self.device))
+            t = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float64), dtype=torch.float64, device=dev)     # noqa: E731
+            self._ms.cbf_param = self.cbf_param               # (users mutate cbf_param in place: README "online adaptive CBF")
+            self._ms.robot_spec["radius"] = self.robot.robot_radius
+            u, st, it, plan = self._ms.solve(t(X[None]), t(self.u_prev[None]), t(g[None]), t(obs[None]), want_plan=True)
+            self.iterations = int(it[0].item())
+            self.solver_status = _lib.STATUS_STRINGS[int(st[0].item())]
+            self.z = plan[0, (self.horizon + 1) * 6:].cpu().numpy().copy()      # the planned inputs u_0 .. u_{N-1}
+            self.u_prev = u[0].cpu().numpy().copy()
+            return self.u_prev.reshape(-1, 1).copy()
         p = make_params(self.robot_spec, self.cbf_param, self.horizon, self.dt, self.robot.robot_radius, _lib.DTYPE_F64)
         u = np.zeros(4); st = np.zeros(1, dtype=np.int32); it = np.zeros(1, dtype=np.int32)
         rc = self._lib.sc_mpcvtol_solve_batch_host(
@@ -225,7 +243,8 @@ class BatchedOptimalDecayVtolMPCCBF(_lib.SlicedSolver):
 
 class OptimalDecayVtolMPCCBF:
     """Drop-in for position_control.optimal_decay_mpc_cbf.OptimalDecayMPCCBF with a VTOL2D robot (single agent per call; the one
-    NLP goes through the batched entry point on device ``device``).  Horizon 30, Q / R of :44-47, gains 0.35 (:83-86)."""
+    NLP goes through the batched entry point on device ``device``).  Horizon 30, Q / R of :44-47, gains 0.35 (:83-86).
+    ``robot_spec['mpc_formulation']`` as for ``VtolMPCCBF`` (default: multiple shooting, the decay rates two more inputs of a stage)."""
 
     def __init__(self, robot, robot_spec, num_obs=5, device=0):
         self.robot = robot
@@ -245,7 +264,12 @@ class OptimalDecayVtolMPCCBF:
         self.setup_control_problem()
 
     def setup_control_problem(self):
-        self._ctl = BatchedOptimalDecayVtolMPCCBF(self.robot_spec, dt=self.dt, io_dtype="f64", cbf_param=self.cbf_param)
+        self.multiple_shooting = self.robot_spec.get("mpc_formulation", "multiple_shooting") != "condensed"
+        if self.multiple_shooting:
+            from .mpc_cbf_vtol_ms import BatchedOptimalDecayVtolMSMPCCBF
+            self._ctl = BatchedOptimalDecayVtolMSMPCCBF(self.robot_spec, dt=self.dt, io_dtype="f64", cbf_param=self.cbf_param, fallback=False)
+        else:
+            self._ctl = BatchedOptimalDecayVtolMPCCBF(self.robot_spec, dt=self.dt, io_dtype="f64", cbf_param=self.cbf_param)
         self.u_prev = np.zeros(4)
         self.z = np.zeros(4 * self.horizon)
         self.rho = np.ones(2 * self.horizon)
@@ -270,6 +294,8 @@ class OptimalDecayVtolMPCCBF:
         self._ctl.robot_spec["radius"] = self.robot.robot_radius
         u, rho, st, it, z = self._ctl.solve(t(X[None]), t(self.u_prev[None]), t(np.asarray(self.goal, dtype=np.float64).reshape(-1)[None, :2]),
                                             t(self.obs[None]), want_z=True)
+        if self.multiple_shooting:
+            z = z[:, (self.horizon + 1) * 6:]                 # (the plan holds the states first: keep the planned inputs)
         self.iterations = int(it[0].item())
         self.solver_status = _lib.STATUS_STRINGS[int(st[0].item())]
         self.rho, self.z = rho[0].cpu().numpy(), z[0].cpu().numpy()
