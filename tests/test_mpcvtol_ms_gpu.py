@@ -241,3 +241,23 @@ def test_optimal_decay_solves_that_pass_through_the_restoration_phase():
           f"restoration iterates {nr.min()} - {nr.max()}")
     assert not (st == 4).any() and (nr >= 1).all()
     assert np.mean(st == so) >= 0.9 and np.mean(du < 1e-6) >= 0.85 and np.mean(st == 0) >= 0.9
+
+
+def test_edge_sizes():
+    """B = 0 and B = 1; no obstacle at all (K = 0: the solve of a far-away obstacle, to rounding); the largest obstacle count (K = 16), plain and
+    optimal decay."""
+    X, up, g, ob = W.mpc_family_batch("vtol", 32, 16, seed=1)
+    ctl = sca.BatchedVtolMSMPCCBF(io_dtype="f64", fallback=False)
+    r0 = ctl.solve(t(X[:0]), t(up[:0]), t(g[:0]), t(ob[:0, :8]))
+    assert [tuple(a.shape) for a in r0] == [(0, 4), (0,), (0,)]
+    u1, s1, i1 = ctl.solve(t(X[:1]), t(up[:1]), t(g[:1]), t(ob[:1, :8]))
+    u8, s8, i8 = ctl.solve(t(X[:8]), t(up[:8]), t(g[:8]), t(ob[:8, :8]))
+    assert torch.equal(u1[0], u8[0]) and int(s1[0]) == 0 and int(i1[0]) == int(i8[0])
+    none = torch.zeros((32, 0, 7), dtype=torch.float64, device=DEV)
+    far = torch.zeros((32, 1, 7), dtype=torch.float64, device=DEV); far[:, 0, 0] = 1e4; far[:, 0, 1] = 1e4; far[:, 0, 2] = 1.0
+    ua, sa, ia = ctl.solve(t(X), t(up), t(g), none)
+    ub, sb, ib = ctl.solve(t(X), t(up), t(g), far)
+    assert bool((sa == 0).all()) and bool((sb == 0).all()) and float((ua - ub).abs().max()) <= 1e-6
+    for cls in (sca.BatchedVtolMSMPCCBF, sca.BatchedOptimalDecayVtolMSMPCCBF):
+        r = cls(io_dtype="f64", fallback=False).solve(t(X), t(up), t(g), t(ob))
+        assert bool((r[-2] == 0).all()) and int(r[-1].max()) < 100
