@@ -404,8 +404,8 @@ class BatchedQuadTrackingController(BatchedTrackingController):
         if self.q3:
             from .position_control.mpc_cbf_linear import BatchedLinearMPCCBF as cls
         elif self.vt:
-            # robot_spec['mpc_formulation']: 'multiple_shooting' (default: the NLP as do-mpc poses it, IPOPT's algorithm, csrc/mpc_vtol_ms.hip,
-            # with the condensed kernel behind it for the solves that need a restoration) or 'condensed' (csrc/mpc_vtol_wave.hip alone)
+            # robot_spec['mpc_formulation']: 'multiple_shooting' (default: the NLP as do-mpc poses it, IPOPT's algorithm with its restoration phase,
+            # csrc/mpc_vtol_ms.hip) or 'condensed' (single shooting, csrc/mpc_vtol_wave.hip)
             if self.robot_spec.get("mpc_formulation", "multiple_shooting") == "condensed":
                 from .position_control.mpc_cbf_vtol import BatchedVtolMPCCBF as cls
             else:
