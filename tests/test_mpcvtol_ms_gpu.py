@@ -262,3 +262,35 @@ def test_edge_sizes():
     for cls in (sca.BatchedVtolMSMPCCBF, sca.BatchedOptimalDecayVtolMSMPCCBF):
         r = cls(io_dtype="f64", fallback=False).solve(t(X), t(up), t(g), t(ob))
         assert bool((r[-2] == 0).all()) and int(r[-1].max()) < 100
+
+
+def test_full_bench_batch_is_deterministic_and_position_independent():
+    """BASELINE-size batch (4096 aircraft): two launches give the same bits; a problem's result does not depend on its place in the batch (reversed
+    order) nor on its neighbours (a slice solved alone); every solve ends optimal and satisfies the NLP it was given -- dynamics residual of the
+    returned plan <= 1e-6, CBF rows >= -1e-6 (recomputed on the host from the plan, not read from the solver)."""
+    B = 4096
+    X, up, g, ob = W.mpc_family_batch("vtol", B, 8, seed=0)
+    ctl = sca.BatchedVtolMSMPCCBF(io_dtype="f64", fallback=False)
+    u1, s1, i1, p1 = ctl.solve(t(X), t(up), t(g), t(ob), want_plan=True)
+    u2, s2, i2, p2 = ctl.solve(t(X), t(up), t(g), t(ob), want_plan=True)
+    assert torch.equal(u1, u2) and torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(p1, p2)
+    ur, sr, ir = ctl.solve(t(X[::-1]), t(up[::-1]), t(g[::-1]), t(ob[::-1]))
+    assert torch.equal(ur.flip(0), u1) and torch.equal(ir.flip(0), i1)
+    ua, sa, ia = ctl.solve(t(X[1000:1064]), t(up[1000:1064]), t(g[1000:1064]), t(ob[1000:1064]))
+    assert torch.equal(ua, u1[1000:1064]) and torch.equal(ia, i1[1000:1064])
+    assert bool((s1 == 0).all())
+    # the returned plans against the model, on the host (oracle/ms_ipopt.py: the stage functions)
+    mdl = MS.vtol_model()
+    P = p1.cpu().numpy()
+    worst_c, worst_d = 0.0, 0.0
+    for i in range(0, B, 97):
+        nlp = MS.StageNLP(mdl, X[i], up[i], g[i], ob[i])
+        w = np.zeros(nlp.n)
+        xs, us = P[i, :31 * 6].reshape(31, 6), P[i, 31 * 6:].reshape(30, 4)
+        for k in range(30):
+            w[k * 10:k * 10 + 6] = xs[k]; w[k * 10 + 6:(k + 1) * 10] = us[k]
+        w[300:] = xs[30]
+        ev = nlp.evaluate(w, 0)
+        worst_c = max(worst_c, float(np.abs(ev["c"]).max())); worst_d = max(worst_d, float(ev["d"].max()))
+    print(f"4096 plans: dynamics residual <= {worst_c:.1e}, CBF rows violated by <= {max(worst_d, 0.0):.1e}")
+    assert worst_c <= 1e-6 and worst_d <= 1e-6
