@@ -719,6 +719,51 @@ def vtol_ms_closed_loop_leg(dev):
             "return_code": ret, "landed": ret == -1, "control_steps": n, "optimal_solves": nopt, "ms_per_control_step": 1e3 * (time.time() - t0) / n}
 
 
+def vtol_fleet_closed_loop_leg(dev, B=256, seed=0):
+    """The same scene flown by B aircraft at once (starts spread over 10 m of approach and 1 m of altitude, 18 - 20 m/s; waypoints (70, 10) then
+    (70, 0.5)): one control_step of the batched loop = select the nearest obstacles, ONE launch of the multiple-shooting kernel for every aircraft
+    that is tracking, apply.  Runs until every aircraft has returned (landed = -1, collision = -2) or 450 steps; once with the reference solver's
+    budget (3000 iterations: a step lasts as long as its hardest NLP -- the first ~50 steps hold infeasible approaches) and once with
+    robot_spec['mpc_max_iter'] = 200."""
+    import time
+    import numpy as np
+    import torch
+    import safe_control_amd as sca
+    obs = np.array([[67.0, z, 0.5] for z in (6.0, 7.0, 8.0, 9.0)] + [[73.0, float(z), 0.5] for z in range(1, 16)] + [[60.0, 12.0, 1.5]])
+    obs7 = np.hstack([obs, np.zeros((len(obs), 4))])
+    rng = np.random.default_rng(seed)
+    X0 = np.zeros((B, 6))
+    X0[:, 0] = 2.0 + 10.0 * rng.uniform(size=B); X0[:, 1] = 10.0 + rng.uniform(-0.5, 0.5, B); X0[:, 3] = rng.uniform(18.0, 20.0, B)
+    X0[0] = [2.0, 10.0, 0.0, 20.0, 0.0, 0.0]
+
+    def fly(extra):
+        spec = dict({"model": "VTOL2D", "radius": 0.6, "v_max": 20.0, "reached_threshold": 1.0, "num_constraints": 10}, **extra)
+        ctl = sca.BatchedTrackingController(X0, spec, obs=obs7, device=str(dev))
+        ctl.set_waypoints(np.array([[70.0, 10.0], [70.0, 0.5]]))            # (the demo's first waypoint is its start: not a target for the others)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        done = torch.zeros(B, dtype=torch.int32, device=dev)
+        n, t_late, n_late = 0, 0.0, 0
+        for n in range(1, 451):
+            ts = time.time()
+            ret = ctl.control_step(1)
+            done = torch.where((done == 0) & (ret != 0), ret.to(torch.int32), done)
+            fin = bool((done != 0).all())
+            if n > 100:
+                t_late += time.time() - ts; n_late += 1
+            if fin:
+                break
+        dt = time.time() - t0
+        return {"control_steps": n, "landed_fraction": float((done == -1).double().mean().item()), "lost_fraction": float((done == -2).double().mean().item()),
+                "ms_per_control_step": 1e3 * dt / n, "ms_per_control_step_after_step_100": 1e3 * t_late / max(1, n_late), "agent_steps_per_s": B * n / dt}
+
+    res = {"workload": f"examples/test_vtol.py scene, {B} VTOL2D aircraft at once from perturbed starts, MPC-CBF N=30, 10 obstacle slots, closed loop until every aircraft has returned",
+           "aircraft": B}
+    res.update(fly({}))
+    res["with_mpc_max_iter_200"] = fly({"mpc_max_iter": 200})
+    return res
+
+
 def od_vtol_mpc_leg(dev, B=4096, K=8, steps=2, seed=0):
     """Optimal-decay MPC-CBF for VTOL2D (the last model of the reference class's accept list): the vtol batch with a disc
     on every other aircraft's flight path 10 - 30 m ahead, so that decay variables leave their reference.  One launch per solve."""
@@ -913,7 +958,7 @@ def compact_leg(v):
     keep = {}
     for k in ("value", "kernel_ms", "ms_per_control_step", "us_per_step", "agent_steps_per_s", "solves_per_s", "optimal_fraction",
               "max_ipm_iterations", "agents", "GBs", "frac_of_peak", "error", "optimal_only_value", "beyond_100_iterations",
-              "all_gather_bytes_per_step", "inaccurate_fraction", "landed", "return_code", "control_steps", "restoration_fallback"):
+              "all_gather_bytes_per_step", "inaccurate_fraction", "landed", "return_code", "control_steps", "restoration_fallback", "landed_fraction", "lost_fraction", "aircraft"):
         if k in v:
             keep[k] = sig(v[k])
     if isinstance(v.get("one_launch_limit_100"), dict):
@@ -1169,6 +1214,7 @@ def main():
             try:
                 if not NO_LIMIT100:
                     res["vtol_reference_scene_closed_loop"] = vtol_ms_closed_loop_leg(dev)
+                    res["vtol_reference_scene_fleet_closed_loop"] = vtol_fleet_closed_loop_leg(dev)
             except Exception as e:
                 res["vtol_reference_scene_closed_loop"] = {"error": repr(e)[:200]}
             res["od_vtol_mpc_cbf"] = od_vtol_mpc_leg(dev)

@@ -412,7 +412,11 @@ class BatchedQuadTrackingController(BatchedTrackingController):
                 from .position_control.mpc_cbf_vtol_ms import BatchedVtolMSMPCCBF as cls
         else:
             from .position_control.mpc_cbf_gn import BatchedGnMPCCBF as cls
-        self.mpc = cls(self.robot_spec, dt=self.dt, io_dtype=io_dtype)
+        # robot_spec['mpc_max_iter'] (not a reference key): iteration budget of a solve inside the loop.  The default is the reference solver's (IPOPT:
+        # 3000), and ONE hard NLP of the batch then holds a control step for as long as its solve takes (measured on 256 VTOL2D aircraft
+        # flying the example scene at once: 0.3 s per step while a few of them face an infeasible approach, 7 ms afterwards)
+        kw = {"max_iter": int(self.robot_spec["mpc_max_iter"])} if "mpc_max_iter" in self.robot_spec else {}
+        self.mpc = cls(self.robot_spec, dt=self.dt, io_dtype=io_dtype, **kw)
         self.u_prev = torch.zeros((B, self.nu), dtype=self.tdtype, device=self.device)
         self.mpc_status = torch.zeros(B, dtype=torch.int32, device=self.device)
 
