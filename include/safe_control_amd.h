@@ -458,8 +458,8 @@ typedef struct sc_ipopt_params {
             resto_failure_feasibility_threshold, resto_theta_max_fact;
     void*   resto_workspace;
     int64_t resto_workspace_bytes;
-    /* NOT an IPOPT option (IPOPT's watchdog and tiny-step heuristics are not restated): a regular-phase solve whose accepted step length stays
-     * below stall_alpha for stall_iter consecutive iterations ends SC_STATUS_INACCURATE there instead of crawling to max_iter (the fraction-to-
+    /* NOT an IPOPT option (IPOPT's watchdog and tiny-step heuristics are not restated): a solve whose accepted step length stays below
+     * stall_alpha for stall_iter consecutive iterations of one phase (regular or restoration) ends SC_STATUS_INACCURATE there instead of crawling to max_iter (the fraction-to-
      * the-boundary rule pins every step against a bound: measured on 2 of 4096 optimal-decay bench problems, after their restoration).
      * stall_iter = 0 disables the rule.  Oracle: oracle/ms_ipopt.py, options stall_iter / stall_alpha.                                    */
     double  stall_alpha;

@@ -407,9 +407,9 @@ OPTS = dict(tol=1e-8, max_iter=3000, dual_inf_tol=1.0, constr_viol_tol=1e-4, com
             resto_penalty_parameter=1000.0, resto_proximity_weight=1.0, required_infeasibility_reduction=0.9,
             bound_mult_reset_threshold=1e3, constr_mult_reset_threshold=0.0, resto_failure_feasibility_threshold=1e-6,
             resto_theta_max_fact=1e8,
-            # NOT IPOPT options (IPOPT's watchdog / tiny-step heuristics are not restated): stop a regular-phase solve whose accepted step length
-            # stays below stall_alpha for stall_iter consecutive iterations (0: never) -- csrc/mpc_vtol_ms.hip runs with (60, 1e-5)
-            stall_iter=0, stall_alpha=1e-5)
+            # NOT IPOPT options (IPOPT's watchdog / tiny-step heuristics are not restated): stop a solve -- or its restoration phase -- whose accepted
+            # step length stays below stall_alpha for stall_iter consecutive iterations (0: never) -- csrc/mpc_vtol_ms.hip runs with (60, 1e-4)
+            stall_iter=0, stall_alpha=1e-4)
 
 EPS = np.finfo(float).eps
 
@@ -504,8 +504,8 @@ class _Resto(_Problem):
 
 # what csrc/mpc_vtol_ms.hip runs (DESIGN.md kernel 12): stage-wise Riccati linear algebra, no second-order corrections, restoration phase with
 # elastic variables on the inequality rows only, the stall rule.  KERNEL_PROFILE_NO_RESTO: the same without a restoration phase (status 4).
-KERNEL_PROFILE = dict(linear_solver="riccati", max_soc=0, resto_elastic="ineq", stall_iter=60, stall_alpha=1e-5)
-KERNEL_PROFILE_NO_RESTO = dict(linear_solver="riccati", max_soc=0, restoration="none", stall_iter=60, stall_alpha=1e-5)
+KERNEL_PROFILE = dict(linear_solver="riccati", max_soc=0, resto_elastic="ineq", stall_iter=60, stall_alpha=1e-4)
+KERNEL_PROFILE_NO_RESTO = dict(linear_solver="riccati", max_soc=0, restoration="none", stall_iter=60, stall_alpha=1e-4)
 
 
 def _dist(v, lo, hi):
@@ -1015,8 +1015,8 @@ class _Algo:
             if self.total_iters() >= budget:
                 status = "max_iter"
                 break
-            if not self.in_resto and o["stall_iter"] > 0 and getattr(self, "n_tiny", 0) >= o["stall_iter"]:
-                status = "max_iter"                                          # (the stall rule: same class as running out of iterations)
+            if o["stall_iter"] > 0 and getattr(self, "n_tiny", 0) >= o["stall_iter"]:
+                status = "resto_failed" if self.in_resto else "max_iter"     # (the stall rule, in either phase: same class as running out of iterations)
                 break
             # ---- barrier parameter -----------------------------------------------------------------------------------------
             mu_min = min(o["tol"], o["compl_inf_tol"]) / (o["barrier_tol_factor"] + 1.0)
@@ -1082,7 +1082,7 @@ class _Algo:
                 continue
             alpha, x, t, ev_new = acc
             self.last_alpha = alpha
-            self.n_tiny = getattr(self, "n_tiny", 0) + 1 if (not self.in_resto and alpha < o["stall_alpha"]) else 0
+            self.n_tiny = getattr(self, "n_tiny", 0) + 1 if alpha < o["stall_alpha"] else 0
             self.safe_slacks(x, t, mu)
             y = y + alpha * dy
             z = tuple(z_ + a_z * d_ for z_, d_ in zip(z, dz))

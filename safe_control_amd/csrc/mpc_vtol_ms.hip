@@ -218,6 +218,21 @@ __device__ __attribute__((noinline)) bool riccati_backward(ldsd* lds, const Lds 
             const double yg = g == 0 ? y0 : (g == 1 ? y1 : (g == 2 ? y2 : y3));
             Pv = __builtin_amdgcn_mfma_f64_16x16x4f64(-yg, yg, Qv, 0, 0, 0);
         }
+        // the x rows of this stage's value function go where its H block was (consumed above): finish_step reads the multipliers of the dynamics
+        // rows off them, lam_k = (P_k xi_k + p_k)_x, instead of running the costate recursion lam_k = h_k + A_k' lam_{k+1} (which multiplies the
+        // rounding of every h_j, j > k, by the transition matrices of an unstable airframe; same iterates on the parity tests, one barrier-free sweep
+        // less).  Layout (51 of the 55 doubles): x-x upper triangle (21), x-v block (24), linear term (6).
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = g + 4 * r;
+            int idx = -1;
+            if (row < NX) {
+                if (c < NX) { if (c >= row) idx = row * NX - row * (row - 1) / 2 + (c - row); }
+                else if (c < NV) idx = 21 + row * 4 + (c - NX);
+                else if (c == 14) idx = 45 + row;
+            }
+            if (idx >= 0) lds[L.H + kk * 55 + idx] = Pv[r];
+        }
     }
     __syncthreads();
     return true;
@@ -257,27 +272,6 @@ __device__ __attribute__((noinline)) void riccati_forward(ldsd* lds, const Lds L
         if (lane < NX) lds[L.DX + (kk + 1) * 6 + lane] = xn;
         if (kk == 0 && lane < NX) lds[L.DX + lane] = xr;
         xr = xn; vr = du;
-    }
-    __syncthreads();
-}
-
-// costates lam_k = h_k + A_k' lam_{k+1}, k = N - 1 .. 0, with h_k (and lam_N = h_N) already in LAM: six lanes carry lam_{k+1} in registers, the six
-// numbers a stage needs are v_readlane broadcasts (no barrier inside the loop; a lane reads h_k from the slot it then overwrites)
-__device__ __attribute__((noinline)) void costates(ldsd* lds, const Lds L, const int N, const int lane, const double dt) {
-    const int c = lane < NX ? lane : 0, ci = ab_col(c);
-    const double a0 = c == 0 ? 1.0 : (c == 3 ? dt : 0.0), a1 = c == 1 ? 1.0 : (c == 4 ? dt : 0.0), a2 = c == 2 ? 1.0 : (c == 5 ? dt : 0.0);   // A[I][c], I < 3
-    const int ao = ci >= 0 ? ci : 0;
-    const double am = ci >= 0 ? 1.0 : 0.0, a55 = c == 5 ? 1.0 : 0.0;
-    double lr = lds[L.LAM + N * 6 + c];
-    for (int j = N - 1; j >= 0; --j) {
-        const ldsd* A3 = lds + L.AB + j * ABS + ao;
-        const double h = lds[L.LAM + j * 6 + c], a3 = A3[0] * am, a4 = A3[7] * am, a5 = A3[14] * am + a55;
-        double l_[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) l_[i] = ipm::row_value(lr, i);
-        const double v = (h + a0 * l_[0] + a1 * l_[1]) + (a2 * l_[2] + a3 * l_[3]) + (a4 * l_[4] + a5 * l_[5]);
-        if (lane < NX) lds[L.LAM + j * 6 + lane] = v;
-        lr = v;
     }
     __syncthreads();
 }
@@ -906,7 +900,7 @@ struct Wave {
         if (build) sync();
     }
 
-    // after riccati_backward / forward: the costate sweep, the multiplier steps of my rows and bounds (dx, du stay in LDS: DX, DU; dy in LAM)
+    // after riccati_backward / forward: the multiplier steps of the dynamics rows (from the value function), of my rows and bounds (dx, du stay in LDS: DX, DU; dy in LAM)
     __device__ __forceinline__ void finish_step(bool ls, double mu, double dw) {
         sync();
         double dx[NX], du[NU];
@@ -914,23 +908,35 @@ struct Wave {
         for (int i = 0; i < NX; ++i) dx[i] = act ? lds[L.DX + k * 6 + i] : 0.0;
 #pragma unroll
         for (int j = 0; j < NU; ++j) du[j] = stg ? lds[L.DU + k * NU + j] : 0.0;
-        // h_k = (H dw + g)_x
+        // multipliers of the dynamics rows (and of the initial-state rows: k = 0): lam_k = (P_k xi_k + p_k)_x, xi_k = (dx_k, du_{k-1}), with the x rows
+        // of P_k where riccati_backward left them (the H slot of stage k); the terminal stage has no recursion behind it: lam_N = H_N dx_N + g_N
         if (act) {
-            const ldsd* H = lds + L.H + k * 55; const ldsd* g = lds + L.G + k * 10;
+            const ldsd* Pk = lds + L.H + k * 55;
+            if (k < N) {
+                double dv_[NU];
 #pragma unroll
-            for (int a = 0; a < NX; ++a) {
-                double v = g[a];
+                for (int j = 0; j < NU; ++j) dv_[j] = k > 0 ? lds[L.DU + (k - 1) * NU + j] : 0.0;
 #pragma unroll
-                for (int b = 0; b < NX; ++b) v += H[sym(a, b)] * dx[b];
-                if (stg) {
+                for (int a = 0; a < NX; ++a) {
+                    double v = Pk[45 + a];
 #pragma unroll
-                    for (int j = 0; j < NU; ++j) v += H[sym(a, 6 + j)] * du[j];
+                    for (int b = 0; b < NX; ++b) { const int lo_ = a < b ? a : b, hi_ = a < b ? b : a; v += Pk[lo_ * NX - lo_ * (lo_ - 1) / 2 + (hi_ - lo_)] * dx[b]; }
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) v += Pk[21 + a * 4 + j] * dv_[j];
+                    lds[L.LAM + k * 6 + a] = v;
                 }
-                lds[L.LAM + k * 6 + a] = v;
+            } else {
+                const ldsd* g = lds + L.G + k * 10;
+#pragma unroll
+                for (int a = 0; a < NX; ++a) {
+                    double v = g[a];
+#pragma unroll
+                    for (int b = 0; b < NX; ++b) v += Pk[sym(a, b)] * dx[b];
+                    lds[L.LAM + k * 6 + a] = v;
+                }
             }
         }
         sync();
-        costates(lds, L, N, lane, P.dt);
         // rows: dy_d = E (a . dw - b), ds = q (rhs_t + dy_d), dvU
         if (stg) {
             double acc[3], gc[4][3], pt[3][2];
@@ -1253,7 +1259,7 @@ struct Wave {
         int o_nfilt = 0, o_nacc = 0;
         double o_mu = 0.0, o_theta = 0.0, o_phi = 0.0, o_pinf = 0.0, o_dw_last = 0.0, o_theta_max = 0.0, o_theta_min = 0.0;
         bool r_first = false, want_resto = false;
-        int n_tiny = 0;                                                    // consecutive accepted steps below stall_alpha (regular phase)
+        int n_tiny = 0;                                                    // consecutive accepted steps below stall_alpha (of the phase the solve is in)
         for (;;) {
             MPROF_T0
             if (want_resto) {
@@ -1307,7 +1313,7 @@ struct Wave {
 #pragma unroll
                     for (int i = 0; i < NX; ++i) lds[L.Y0 + i] = 0.0;
                 }
-                rs = true; r_first = true;
+                rs = true; r_first = true; n_tiny = 0;
                 phase = PH_START;
                 continue;
             }
@@ -1431,7 +1437,7 @@ struct Wave {
                     if (!ftype || !arm) filter_add(phi - O.gamma_phi * theta, (1.0 - O.gamma_theta) * theta);
                 }
                 last_alpha = alpha;
-                n_tiny = (!rs && alpha < O.stall_alpha) ? n_tiny + 1 : 0;
+                n_tiny = alpha < O.stall_alpha ? n_tiny + 1 : 0;
 #pragma unroll
                 for (int i = 0; i < NX; ++i) x[i] = xt[i];
                 if (stg) {
@@ -1537,7 +1543,7 @@ struct Wave {
 #pragma unroll
                         for (int i = 0; i < NX; ++i) lds[L.Y0 + i] = 0.0;
                     }
-                    rs = false; fpo = L.FP; fto = L.FT; nfilt = o_nfilt; n_acc = o_nacc; mu = o_mu; tau = fmax(O.tau_min, 1.0 - mu); dw_last = o_dw_last;
+                    rs = false; n_tiny = 0; fpo = L.FP; fto = L.FT; nfilt = o_nfilt; n_acc = o_nacc; mu = o_mu; tau = fmax(O.tau_min, 1.0 - mu); dw_last = o_dw_last;
                     theta_max = o_theta_max; theta_min = o_theta_min;
                     phase = PH_EVAL;
                     continue;

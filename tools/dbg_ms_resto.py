@@ -23,6 +23,11 @@ elif mode == "scene":                                                       # fi
     spec = dict(model="VTOL2D", radius=0.6, v_max=20.0)
     mdl, ctl = MS.vtol_model(dict(radius=0.6, v_max=20.0)), sca.BatchedVtolMSMPCCBF(spec, io_dtype="f64", fallback=False, max_iter=maxit)
     x0, up, g = np.array([2.0 + i, 10.0 - 0.05 * i, 0.0, 20.0, 0.0, 0.0]), np.zeros(4), np.array([70.0, 10.0])       # (PROB shifts the start)
+elif mode == "file":                                                      # a solve saved by tools/exp_vtol_fleet.py
+    d = np.load(os.environ.get("FILE", "tools/data/vtol_crawlers.npz"))
+    spec = dict(model="VTOL2D", radius=0.6, v_max=20.0)
+    mdl, ctl = MS.vtol_model(dict(radius=0.6, v_max=20.0)), sca.BatchedVtolMSMPCCBF(spec, io_dtype="f64", fallback=False, max_iter=maxit)
+    x0, up, g, ob = d[f"X_{i}"], d[f"up_{i}"], d[f"g_{i}"][:2], d[f"ob_{i}"]
 else:
     mdl, ctl = MS.vtol_model(), sca.BatchedVtolMSMPCCBF(io_dtype="f64", fallback=False, max_iter=maxit)
     x0, up, g, ob = Xn[i], up0[i], gn[i], on[i]
@@ -41,5 +46,8 @@ r0 = int(w[0][0]) if len(w) else m - 3
 first_resto = next((j for j, q in enumerate(tr) if q["resto"]), None)
 print("first parting at iteration", r0, "; oracle enters the restoration at", first_resto)
 show = sorted(set(list(range(max(0, r0 - 2), min(m, r0 + 4))) + ([] if first_resto is None else list(range(max(0, first_resto - 1), min(m, first_resto + 4))))))
+if os.environ.get("TAIL"):
+    show = sorted(set(show + list(range(max(0, len(T) - int(os.environ["TAIL"])), len(T))) + list(range(max(0, m - 3), m))))
 for j in show:
+    if j >= len(K) or j >= len(T): continue
     print(j, 'k', np.array2string(K[j], precision=5, max_line_width=220)); print(j, 'o', np.array2string(T[j], precision=5, max_line_width=220))
