@@ -42,9 +42,10 @@ def solve_cond(X, up, goal, ob):
     return u
 
 
-o = QuadTrackingOracle("VTOL2D", np.array([2.0, 10.0, 0.0, 20.0, 0.0, 0.0]), spec=spec, obs=obs7, num_constraints=10,
+_start = [float(v) for v in os.environ["START"].split(",")] if os.environ.get("START") else [2.0, 10.0, 20.0]        # START="x,z,speed": another start (tools/exp_vtol_fleet.py)
+o = QuadTrackingOracle("VTOL2D", np.array([_start[0], _start[1], 0.0, _start[2], 0.0, 0.0]), spec=spec, obs=obs7, num_constraints=10,
                        solve_fn=solve_cond if which == "condensed" else solve_ms)
-o.set_waypoints(np.array([[2.0, 10.0], [70.0, 10.0], [70.0, 0.5]]))
+o.set_waypoints(np.array([[70.0, 10.0], [70.0, 0.5]]) if os.environ.get("START") else np.array([[2.0, 10.0], [70.0, 10.0], [70.0, 0.5]]))
 traj = []
 ret = 0
 for k in range(steps):
