@@ -1,6 +1,6 @@
 // MPC-CBF for VTOL2D as do-mpc poses it -- MULTIPLE SHOOTING -- solved by IPOPT's filter line-search interior point: ONE NLP PER
-// WAVEFRONT, ONE STAGE PER LANE.  Kernel 12 in DESIGN.md; the algorithm is oracle/ms_ipopt.py with the "kernel profile"
-// (linear_solver = riccati, max_soc = 0, restoration = none), iterate for iterate.
+// WAVEFRONT, ONE STAGE PER LANE.  Kernel 12 in DESIGN.md; the algorithm is oracle/ms_ipopt.py with KERNEL_PROFILE (linear_solver = riccati,
+// max_soc = 0, resto_elastic = "ineq", the stall rule), iterate for iterate.
 //
 // Why a second VTOL2D kernel.  mpc_vtol_wave.hip solves the CONDENSED problem in z = (u_0 .. u_{N-1}) from the rollout of u_prev.  The
 // reference does not (position_control/mpc_cbf.py:162-174,366-369): do-mpc hands IPOPT the states x_0 .. x_N as variables with the
@@ -16,15 +16,20 @@
 //               z_dot): mpc_vtol_solver.hpp: accel<D2>), one evaluation per stage and function call instead of a chain of thirty
 //   Newton step the inequality rows of a stage are condensed into its 10 x 10 block, the primal-dual system is an LQ problem with
 //               defects and is solved by a Riccati recursion over the augmented state (dx_k, du_{k-1}) (the input-rate penalty couples
-//               neighbouring inputs), lanes over matrix entries, four phases per stage; inertia correction = "every 4 x 4 input block
-//               positive definite" (Algorithm IC's delta_w ladder); multipliers of the dynamics rows from the costate sweep
+//               neighbouring inputs): the backward sweep on v_mfma_f64_16x16x4_f64 with the value function resident in the accumulator
+//               registers (riccati_backward), the forward sweep with its recurrence in registers (v_readlane broadcasts); inertia
+//               correction = "every 4 x 4 input block positive definite" (Algorithm IC's delta_w ladder); multipliers of the dynamics
+//               rows from the value function, lam_k = (P_k xi_k + p_k)_x
 //   globalisation  IPOPT's filter (theta = l1 norm of the row residuals, phi = barrier function), switching condition + Armijo,
-//               alpha_min -> "needs a restoration": status SC_STATUS_NEEDS_RESTO, which the host class hands to the condensed kernel
-//               and ITS restoration phase (csrc/mpc_vtol_wave.hip); fraction to the boundary tau = max(0.99, 1 - mu), monotone mu,
-//               gradient-based scaling, bound push / relaxation, least-square initial multipliers, kappa_sigma, safe slacks
+//               alpha_min -> IPOPT's restoration phase, a mode of the same loop (elastic variables on the CBF rows, own filter, return test
+//               against the regular filter, infeasibility certificate; its row state in a global workspace: sc_ipopt_params.resto_workspace
+//               -- without one the solve ends SC_STATUS_NEEDS_RESTO and the host class hands it to the condensed kernel); fraction to the
+//               boundary tau = max(0.99, 1 - mu), monotone mu, gradient-based scaling, bound push / relaxation, least-square initial
+//               multipliers, kappa_sigma, safe slacks; OD = true: the optimal-decay NLP (decay rates = two more inputs of a stage)
 //
-// LDS per problem (N = 30): stage Jacobians [A | B] (compact), stage blocks, gains, gradient / defect / step vectors, the Riccati workspace
-// (over the exchange vectors): 39.9 KB, four problems per CU.  Compiled with the non-splitting register allocator (csrc/Makefile: SAFE_RA).
+// LDS per problem (N = 30): stage Jacobians [A | B] (compact), stage blocks, gains, gradient / defect / step vectors, exchange vectors, two
+// filters: 40.3 KB, four problems per CU.  Compiled with LLVM's splitting register allocator and therefore guarded (csrc/Makefile: GUARDED;
+// tools/check_exec_prologue.py on every link; tests/test_codegen_guard_gpu.py holds it bitwise equal to a build with the non-splitting one).
 #include <hip/hip_runtime.h>
 
 #include <utility>
