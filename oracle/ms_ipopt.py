@@ -409,7 +409,11 @@ OPTS = dict(tol=1e-8, max_iter=3000, dual_inf_tol=1.0, constr_viol_tol=1e-4, com
             resto_theta_max_fact=1e8,
             # NOT IPOPT options (IPOPT's watchdog / tiny-step heuristics are not restated): stop a solve -- or its restoration phase -- whose accepted
             # step length stays below stall_alpha for stall_iter consecutive iterations (0: never) -- csrc/mpc_vtol_ms.hip runs with (60, 1e-4)
-            stall_iter=0, stall_alpha=1e-4)
+            stall_iter=0, stall_alpha=1e-4,
+            # IPOPT's recalc_y as a rescue (an experiment of round 5, DESIGN.md (f) 2b'; the kernel does not run it): once a regular-phase solve has sat recalc_y_iter iterations at a barrier
+            # parameter within 10 x its floor with everything but the dual infeasibility inside the 'acceptable' tolerances, the row multipliers are
+            # re-estimated by least squares at every iterate from then on (0: never)
+            recalc_y_iter=0)
 
 EPS = np.finfo(float).eps
 
@@ -1015,6 +1019,18 @@ class _Algo:
             if self.total_iters() >= budget:
                 status = "max_iter"
                 break
+            if not self.in_resto and o["recalc_y_iter"] > 0 and not getattr(self, "recalc_y", False):
+                sxL_, sxU_, stL_, stU_ = self.slacks(x, t)
+                nb_ = sum(int(np.sum(np.isfinite(s_))) for s_ in (sxL_, sxU_, stL_, stU_))
+                sc_ = max(o["s_max"], float(sum(np.sum(np.abs(z_)) for z_ in z)) / max(1, nb_)) / o["s_max"]
+                mu_min_ = min(o["tol"], o["compl_inf_tol"]) / (o["barrier_tol_factor"] + 1.0)
+                floor_ = (mu <= 10.0 * mu_min_ and n_acc == 0 and max(pinf, comp / sc_) <= o["acceptable_tol"] and un_pinf <= o["acceptable_constr_viol_tol"]
+                          and comp <= o["acceptable_compl_inf_tol"] * df)
+                self.n_floor = getattr(self, "n_floor", 0) + 1 if floor_ else 0
+                if self.n_floor >= o["recalc_y_iter"]:
+                    self.recalc_y = True
+                    y = self.ls_multipliers(ev, z)
+                    continue
             if o["stall_iter"] > 0 and getattr(self, "n_tiny", 0) >= o["stall_iter"]:
                 status = "resto_failed" if self.in_resto else "max_iter"     # (the stall rule, in either phase: same class as running out of iterations)
                 break
@@ -1091,6 +1107,8 @@ class _Algo:
             z = tuple(np.where(np.isfinite(s_), np.maximum(np.minimum(z_, ks * mu / s_), mu / (ks * s_)), 0.0) for z_, s_ in zip(z, sl))
             ev = P.evaluate(x, 2, mu)
             self.iters += 1
+            if getattr(self, "recalc_y", False) and not self.in_resto:
+                y = self.ls_multipliers(ev, z)
         return status, x, t, y, z, mu
 
     def total_iters(self):
