@@ -109,13 +109,14 @@ VALU_PEAK_GIPS = 519.0   # measured sustained f64 VALU issue rate of the chip, G
 
 
 def csrc_sha16():
-    """Hash of the kernel sources of this tree (tools/parse_profiles.py stores the same one with the counter profile)."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    for fn in sorted(glob.glob(os.path.join(ROOT, "safe_control_amd", "csrc", "*.h*"))):
-        h.update(open(fn, "rb").read())
-    return h.hexdigest()[:16]
+    """Hash of the kernel sources of this tree as code (comments and blank lines stripped: tools/csrc_hash.py;
+    tools/parse_profiles.py stores the same one with the counter profile)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import csrc_hash
+    finally:
+        sys.path.pop(0)
+    return csrc_hash.csrc_sha16(ROOT)
 
 
 F64_VECTOR_PEAK_TFLOPS = 78.6                                   # MI355X data sheet, vector f64 (MI355X_MICROARCH.md)

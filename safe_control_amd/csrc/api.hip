@@ -866,26 +866,6 @@ int sc_odmpcvtol_solve_batch_sliced(const sc_odmpcvtol_params* params, const sc_
     return SC_OK;
 }
 
-int sc_mpcvtol_ms_solve_batch(const sc_mpcvtol_params* params, const sc_ipopt_params* ipopt, int64_t B, int32_t K, const void* X, const void* u_prev,
-                              const void* goal, const void* obs, void* u_out, int32_t* status_out, int32_t* iters_out, void* plan_out, double* trace_out,
-                              void* stream) {
-    if (!params || !ipopt) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params / ipopt is NULL");
-    if (B < 0 || K < 0 || K > 16) return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting kernel serves 0 <= K <= 16");
-    if (params->horizon < 1 || params->horizon > 62) return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting kernel serves 1 <= horizon <= 62 (one stage per lane + the terminal state)");
-    if (params->io_dtype != SC_DTYPE_F32 && params->io_dtype != SC_DTYPE_F64) return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype");
-    if (!(params->dt > 0.0) || !(params->beta > 0.0)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "dt and beta must be positive");
-    if (ipopt->max_iter < 0 || ipopt->acceptable_iter < 1 || !(ipopt->tol > 0.0) || !(ipopt->mu_init > 0.0) || !(ipopt->tau_min > 0.0 && ipopt->tau_min < 1.0) ||
-        !(ipopt->alpha_red_factor > 0.0 && ipopt->alpha_red_factor < 1.0) || !(ipopt->perturb_inc_fact > 1.0) || !(ipopt->perturb_inc_fact_first > 1.0) ||
-        !(ipopt->first_hessian_perturbation > 0.0) || !(ipopt->s_max > 0.0) || !(ipopt->kappa_sigma > 1.0))
-        return sc::fail(SC_ERR_INVALID_ARGUMENT, "sc_ipopt_params out of range");
-    if (B == 0) return SC_OK;
-    if (!X || !u_prev || !goal || !u_out || !status_out || (K > 0 && !obs)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL buffer");
-    hipError_t e = sc::mpcvtol_ms_launch(*params, *ipopt, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out,
-                                         (hipStream_t)stream);
-    if (e != hipSuccess) return sc::fail_hip(e, "mpcvtol multiple-shooting kernel launch");
-    return SC_OK;
-}
-
 size_t sc_mpcvtol_ms_workspace_bytes(int64_t B, int32_t K) {
     if (B < 0 || K < 0 || K > 16) return 0;
     return (size_t)B * (size_t)((8 * (K <= 8 ? 8 : 16) + 12) * 64) * sizeof(double);       // Wave<KS>::R_SLOTS x 64 lanes (csrc/mpc_vtol_ms.hip)
@@ -909,9 +889,24 @@ static int check_ms_common(const sc_mpcvtol_params* params, const sc_ipopt_param
     return SC_OK;
 }
 
+int sc_mpcvtol_ms_solve_batch(const sc_mpcvtol_params* params, const sc_ipopt_params* ipopt, int64_t B, int32_t K, const void* X, const void* u_prev,
+                              const void* goal, const void* obs, void* u_out, int32_t* status_out, int32_t* iters_out, void* plan_out, double* trace_out,
+                              void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    int rc = check_ms_common(params, ipopt, B, K);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    if (!X || !u_prev || !goal || !u_out || !status_out || (K > 0 && !obs)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL buffer");
+    hipError_t e = sc::mpcvtol_ms_launch(*params, *ipopt, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out,
+                                         (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "mpcvtol multiple-shooting kernel launch");
+    return SC_OK;
+}
+
 int sc_odmpcvtol_ms_solve_batch(const sc_odmpcvtol_params* params, const sc_ipopt_params* ipopt, int64_t B, int32_t K, const void* X, const void* u_prev,
                                 const void* goal, const void* obs, void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* plan_out,
                                 double* trace_out, void* stream) {
+    sc::DeviceGuard on_device(stream, X);
     if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
     int rc = check_ms_common(&params->mpc, ipopt, B, K);
     if (rc != SC_OK) return rc;

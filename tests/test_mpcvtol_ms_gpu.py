@@ -154,6 +154,21 @@ def test_argument_validation():
     assert lib.sc_mpcvtol_ms_solve_batch(C.byref(p), None, 1, 8, *([None] * 10)) != _lib.SC_OK
     bad = _lib.default_ipopt(tau_min=1.5)
     assert lib.sc_mpcvtol_ms_solve_batch(C.byref(p), C.byref(bad), 1, 8, *([None] * 10)) != _lib.SC_OK
+    # a restoration workspace one byte short of sc_mpcvtol_ms_workspace_bytes(B, K) is refused by BOTH entry points before anything is
+    # launched (the kernel indexes the workspace per problem without a bound check), and so are restoration options out of range
+    from safe_control_amd.position_control.mpc_cbf_vtol import make_od_params, OD_CBF_VTOL
+    pod = make_od_params(sp, OD_CBF_VTOL, 30, 0.05, sp["radius"], _lib.DTYPE_F64)
+    need = int(lib.sc_mpcvtol_ms_workspace_bytes(4, 8))
+    assert need == 4 * (8 * 8 + 12) * 64 * 8 and int(lib.sc_mpcvtol_ms_workspace_bytes(4, 9)) == 4 * (8 * 16 + 12) * 64 * 8
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    for short, kw in ((1, {}), (0, {"resto_penalty_parameter": 0.0}), (0, {"required_infeasibility_reduction": 1.0})):
+        q = _lib.default_ipopt(**kw)
+        q.resto_workspace, q.resto_workspace_bytes = ws.data_ptr(), need - short
+        assert lib.sc_mpcvtol_ms_solve_batch(C.byref(p), C.byref(q), 4, 8, *([None] * 10)) == _lib.SC_ERR_INVALID_ARGUMENT
+        assert lib.sc_odmpcvtol_ms_solve_batch(C.byref(pod), C.byref(q), 4, 8, *([None] * 11)) == _lib.SC_ERR_INVALID_ARGUMENT
+    q = _lib.default_ipopt()
+    q.resto_workspace, q.resto_workspace_bytes = ws.data_ptr(), need
+    assert lib.sc_mpcvtol_ms_solve_batch(C.byref(p), C.byref(q), 0, 8, *([None] * 10)) == _lib.SC_OK
     p.horizon = 63
     assert lib.sc_mpcvtol_ms_solve_batch(C.byref(p), C.byref(ip), 1, 8, *([None] * 10)) != _lib.SC_OK
 

@@ -69,11 +69,9 @@ for path in sorted(glob.glob(os.path.join(src, "*_counter_collection.csv"))):
     allc[os.path.basename(path).replace("_counter_collection.csv", "")] = counters(path)
 # what the counts belong to: a hash of the kernel sources the profiled library was built from (bench.py attaches a roofline
 # only when the running tree has the same one, otherwise it says "stale")
-import hashlib  # noqa: E402
-hsh = hashlib.sha256()
-for fn in sorted(glob.glob(os.path.join(ROOT, "safe_control_amd", "csrc", "*.h*"))):
-    hsh.update(open(fn, "rb").read())
-allc["_meta"] = {"csrc_sha16": hsh.hexdigest()[:16], "round": rnd,
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import csrc_hash  # noqa: E402
+allc["_meta"] = {"csrc_sha16": csrc_hash.csrc_sha16(ROOT), "round": rnd,
                  "note": "per-launch averages of every counter per run; bench_full_* = the default bench.py line (same seeds, same batches)"}
 json.dump(allc, open(os.path.join(dst, f"{rnd}_counters.json"), "w"), indent=1, sort_keys=True)
 
