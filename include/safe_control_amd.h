@@ -38,10 +38,10 @@ extern "C" {
 #endif
 
 /* ABI version: the minor number goes up with EVERY change of a struct layout or an entry point's signature (round 4 grew
- * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2; round 5 added sc_ipopt_params and sc_mpcvtol_ms_solve_batch: 0.3; the continuation entry points of the optimal-decay families: 0.4; sc_odmpcvtol_ms_solve_batch: 0.5).  A binding compares sc_version() with the
+ * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2; round 5 added sc_ipopt_params and sc_mpcvtol_ms_solve_batch: 0.3; the continuation entry points of the optimal-decay families: 0.4; sc_odmpcvtol_ms_solve_batch: 0.5; round 6 added sc_mpccbf_ms_solve_batch: 0.7).  A binding compares sc_version() with the
  * version its struct mirrors were written for before the first call (safe_control_amd/_lib.py: ABI_VERSION). */
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 6
+#define SC_VERSION_MINOR 7
 
 /* ---- return codes ------------------------------------------------------ */
 typedef enum sc_error {
@@ -498,6 +498,29 @@ size_t sc_odmpcvtol_slices_workspace_bytes(const sc_odmpcvtol_params* params, in
 int sc_odmpcvtol_solve_batch_sliced(const sc_odmpcvtol_params* params, const sc_mpc_slices* slices, int64_t B, int32_t K,
                                     const void* X, const void* u_prev, const void* goal, const void* obs,
                                     void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
+
+/* MPC-CBF for DynamicUnicycle2D AS DO-MPC POSES IT (csrc/mpc_du_ms.hip, DESIGN.md kernel 13; round 6): BASELINE configs[2] in the reference's
+ * own formulation.  Replaces MPCCBF.solve_control_problem (position_control/mpc_cbf.py:366-402: mpc.x0 = x; set_initial_guess(); update_tvp;
+ * make_step -> do-mpc multiple shooting -> IPOPT, :162-174) for a batch: states x_0 .. x_N as variables, dynamics as equality rows, every
+ * stage started at x0, IPOPT's filter line-search interior point at its documented defaults (sc_ipopt_params; oracle/ms_ipopt.py with
+ * du_model() is the float64 statement, iterate for iterate), restoration phase inside the kernel (its state lives in LDS:
+ * sc_ipopt_params.resto_workspace is not read).  sc_mpccbf_solve_batch solves the condensed single-shooting form of the same NLP with an
+ * l1-merit interior point: same optimum where there is one (4086 of 4096 config-3 draws), a different last iterate where the NLP has no
+ * feasible point -- and the reference APPLIES that iterate (mpc_cbf.py:384, status hard-wired 'optimal', :10).
+ *   params      the problem fields of sc_mpccbf_params (model_id = SC_MODEL_DYNAMIC_UNICYCLE2D only, horizon 1 .. 62, dt, Q, R, alpha1/2,
+ *               v_max, u_max, robot_radius, beta, io_dtype, obs_shared); its solver fields (tol .. resto, slack_reset, max_iter) are NOT
+ *               read; obstacles must be circles (flag column < 0.5: a superellipsoid row returns SC_ERR_UNSUPPORTED from the host-side
+ *               classes, the kernel treats every row as a circle), 1 <= K <= 16
+ *   status_out  SC_STATUS_OPTIMAL (tol or IPOPT's acceptable rule), SC_STATUS_INFEASIBLE (the restoration phase converged to a stationary
+ *               point of the violation: IPOPT's "converged to a point of local infeasibility"), SC_STATUS_INACCURATE (iteration limit,
+ *               restoration failed, stall rule); u_out is the last iterate's u_0 in every case, as in the reference
+ *   plan_out    [B, (horizon + 1) * 4 + horizon * 2] or NULL: x_0 .. x_N, then u_0 .. u_{N-1}
+ *   trace_out   [B, max_iter + 1, 8] float64 or NULL: per iteration E_0, dual / primal infeasibility, complementarity, mu, theta,
+ *               delta_w, alpha (negative inside the restoration phase)                                                                   */
+int sc_mpccbf_ms_solve_batch(const sc_mpccbf_params* params, const sc_ipopt_params* ipopt, int64_t B, int32_t K,
+                             const void* X, const void* u_prev, const void* goal, const void* obs,
+                             void* u_out, int32_t* status_out, int32_t* iters_out, void* plan_out, double* trace_out, void* stream);
+size_t sc_mpccbf_ms_lds_bytes(int32_t horizon, int32_t K);      /* LDS per NLP (one wavefront): 160 KiB / this = NLPs resident per CU */
 
 /* ---- optimal-decay MPC-CBF ---------------------------------------
  * OptimalDecayMPCCBF (position_control/optimal_decay_mpc_cbf.py:15-330) for DynamicUnicycle2D: the MPC-CBF NLP with

@@ -13,6 +13,7 @@ from .position_control.mpc_cbf import MPCCBF, BatchedMPCCBF  # noqa: F401
 from .position_control.mpc_cbf_linear import LinearMPCCBF, BatchedLinearMPCCBF, BatchedOptimalDecayLinearMPCCBF, OptimalDecayLinearMPCCBF  # noqa: F401
 from .position_control.mpc_cbf_gn import GnMPCCBF, BatchedGnMPCCBF  # noqa: F401
 from .position_control.mpc_cbf_vtol import VtolMPCCBF, BatchedVtolMPCCBF, OptimalDecayVtolMPCCBF, BatchedOptimalDecayVtolMPCCBF  # noqa: F401
+from .position_control.mpc_cbf_ms import BatchedMSMPCCBF  # noqa: F401
 from .position_control.mpc_cbf_vtol_ms import BatchedVtolMSMPCCBF, BatchedOptimalDecayVtolMSMPCCBF  # noqa: F401
 from .position_control.backup_cbf_qp import BackupCBF, BatchedBackupCBF  # noqa: F401
 from .position_control.optimal_decay_cbf_qp import OptimalDecayCBFQP, BatchedOptimalDecayCBFQP  # noqa: F401

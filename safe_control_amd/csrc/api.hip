@@ -74,6 +74,9 @@ hipError_t mpcvtol_launch(const sc_mpcvtol_params& p, long long B, int K, const 
                           const ipm::Cont& ct);
 hipError_t mpcvtol_ms_launch(const sc_mpcvtol_params& p, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
                              const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, hipStream_t stream);
+hipError_t mpcdu_ms_launch(const sc_mpccbf_params& p, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
+                           const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, hipStream_t stream);
+size_t mpcdu_ms_lds_bytes(int horizon, int K);
 hipError_t odmpcvtol_ms_launch(const sc_odmpcvtol_params& q, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
                                const void* obs, void* u_out, void* rho_out, int* status_out, int* iters_out, void* plan_out, double* trace_out,
                                hipStream_t stream);
@@ -916,6 +919,45 @@ int sc_odmpcvtol_ms_solve_batch(const sc_odmpcvtol_params* params, const sc_ipop
     hipError_t e = sc::odmpcvtol_ms_launch(*params, *ipopt, (long long)B, (int)K, X, u_prev, goal, obs, u_out, rho_out, status_out, iters_out, plan_out,
                                            trace_out, (hipStream_t)stream);
     if (e != hipSuccess) return sc::fail_hip(e, "odmpcvtol multiple-shooting kernel launch");
+    return SC_OK;
+}
+
+static int check_ipopt_options(const sc_ipopt_params* ipopt) {
+    if (!ipopt) return sc::fail(SC_ERR_INVALID_ARGUMENT, "ipopt is NULL");
+    if (ipopt->max_iter < 0 || ipopt->acceptable_iter < 1 || !(ipopt->tol > 0.0) || !(ipopt->mu_init > 0.0) || !(ipopt->tau_min > 0.0 && ipopt->tau_min < 1.0) ||
+        !(ipopt->alpha_red_factor > 0.0 && ipopt->alpha_red_factor < 1.0) || !(ipopt->perturb_inc_fact > 1.0) || !(ipopt->perturb_inc_fact_first > 1.0) ||
+        !(ipopt->first_hessian_perturbation > 0.0) || !(ipopt->s_max > 0.0) || !(ipopt->kappa_sigma > 1.0))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "sc_ipopt_params out of range");
+    if (!(ipopt->resto_penalty_parameter > 0.0) || !(ipopt->resto_proximity_weight >= 0.0) || !(ipopt->required_infeasibility_reduction > 0.0 && ipopt->required_infeasibility_reduction < 1.0))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "sc_ipopt_params: restoration options out of range");
+    return SC_OK;
+}
+
+size_t sc_mpccbf_ms_lds_bytes(int32_t horizon, int32_t K) {
+    if (horizon < 1 || horizon > 62 || K < 1 || K > 16) return 0;
+    return sc::mpcdu_ms_lds_bytes(horizon, K);
+}
+
+int sc_mpccbf_ms_solve_batch(const sc_mpccbf_params* params, const sc_ipopt_params* ipopt, int64_t B, int32_t K, const void* X, const void* u_prev,
+                             const void* goal, const void* obs, void* u_out, int32_t* status_out, int32_t* iters_out, void* plan_out, double* trace_out,
+                             void* stream) {
+    sc::DeviceGuard on_device(stream, X);
+    if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (params->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D) return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting MPC-CBF kernel is built for DynamicUnicycle2D");
+    if (B < 0 || K < 1 || K > 16) return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting kernel serves 1 <= K <= 16 (pad with [1000,1000,0,...] rows like update_tvp)");
+    if (B > 0x7fffffffLL) return sc::fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
+    if (params->horizon < 1 || params->horizon > 62) return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting kernel serves 1 <= horizon <= 62 (one stage per lane + the terminal state)");
+    if (sc::mpcdu_ms_lds_bytes(params->horizon, K) > 160 * 1024) return sc::fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
+    if (params->io_dtype != SC_DTYPE_F32 && params->io_dtype != SC_DTYPE_F64) return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype");
+    if (!(params->dt > 0.0) || !(params->beta > 0.0) || !(params->u_max[0] > 0.0) || !(params->u_max[1] > 0.0) || !(params->v_max > 0.0))
+        return sc::fail(SC_ERR_INVALID_ARGUMENT, "dt, beta, u_max and v_max must be positive");
+    int rc = check_ipopt_options(ipopt);
+    if (rc != SC_OK) return rc;
+    if (B == 0) return SC_OK;
+    if (!X || !u_prev || !goal || !obs || !u_out || !status_out) return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL buffer");
+    hipError_t e = sc::mpcdu_ms_launch(*params, *ipopt, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out,
+                                       (hipStream_t)stream);
+    if (e != hipSuccess) return sc::fail_hip(e, "mpccbf multiple-shooting kernel launch");
     return SC_OK;
 }
 

@@ -1,0 +1,97 @@
+// Kernel 13: MPC-CBF for DynamicUnicycle2D as do-mpc poses it -- multiple shooting under IPOPT's filter interior point, one NLP
+// per wavefront, one stage per lane.  The algorithm and what each lane holds: mpc_du_ms_solver.hpp (plain C++ over a context; the same code
+// runs on the host, one thread per lane, in tools/du_ms_host.cpp).  This unit supplies the device context -- LDS through an address-space
+// pointer, __syncthreads, the DPP wave reductions of mpc_ipm_common.hpp -- the kernel and its launcher.
+//
+// LDS per problem at N = 10, K = 8: stage blocks, gains, value-function rows, exchange vectors, two filters, and the per-row state (slacks,
+// multipliers, their steps, the restoration's n / p: 16 slots x K rows x N stages): 19.9 KB, eight problems per CU (two waves per SIMD).  HBM per solve: X 4 + u_prev 2 + goal 2 + K x 7 obstacle values in, u 2 + status +
+// iterations out (272 B at K = 8, f32 storage).
+#include <hip/hip_runtime.h>
+
+#include "../../include/safe_control_amd.h"
+#include "mpc_ipm_common.hpp"
+#define SC_HD __host__ __device__
+#define SC_DUMS_INLINE __forceinline__
+#include "mpc_du_ms_solver.hpp"
+
+namespace sc {
+namespace dums {
+
+typedef __attribute__((address_space(3))) double ldsd;
+
+struct DevCtx {
+    typedef ldsd* ptr;
+    ptr lds;
+    int lane;
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ long long clock() const { return __builtin_readcyclecounter(); }
+    __device__ __forceinline__ double wsum(double v) const { return ipm::wsum(v); }
+    __device__ __forceinline__ double wmax(double v) const { return ipm::wmax(v); }
+    __device__ __forceinline__ double wmin(double v) const { return ipm::wmin(v); }
+};
+
+#ifndef SC_DUMS_WAVES
+#define SC_DUMS_WAVES 1
+#endif
+template <typename TIO>
+__global__ void __launch_bounds__(64, SC_DUMS_WAVES) mpcdu_ms_kernel(const Params P, const sc_ipopt_params O, long long B, int obs_shared, const TIO* __restrict__ X,
+                                                      const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
+                                                      TIO* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out,
+                                                      TIO* __restrict__ plan_out, double* __restrict__ trace_out) {
+    extern __shared__ double dums_lds[];
+    const long long b = blockIdx.x;
+    if (b >= B) return;
+    DevCtx cx{(ldsd*)dums_lds, (int)threadIdx.x};
+    Wave<DevCtx> S(cx, P, O);
+    const TIO* ob = obs + (obs_shared ? 0 : b * P.K * 7);
+    if ((int)threadIdx.x < 3 * P.K) {
+        const int j = threadIdx.x / 3, c = threadIdx.x % 3;
+        dums_lds[S.L.OB + threadIdx.x] = j < P.K ? (double)ob[7 * j + c] : 0.0;
+    }
+    for (int i = 0; i < NX; ++i) S.x0[i] = (double)X[b * NX + i];
+    for (int j = 0; j < NU; ++j) S.uprev[j] = (double)u_prev[b * NU + j];
+    S.xg[0] = (double)goal[b * 2]; S.xg[1] = (double)goal[b * 2 + 1];
+    __syncthreads();
+    int st, it;
+    S.solve(st, it, trace_out ? trace_out + (size_t)b * (size_t)(O.max_iter + 1) * TRACE_W : nullptr);
+    if (threadIdx.x == 0) {
+        for (int j = 0; j < NU; ++j) u_out[b * NU + j] = (TIO)S.u[j];
+        status_out[b] = st;
+        if (iters_out) iters_out[b] = it;
+    }
+    if (plan_out && S.act) {
+        // the plan: x_0 .. x_N (4 each), then u_0 .. u_{N-1} (2 each)
+        TIO* po = plan_out + b * (long long)((P.N + 1) * NX + P.N * NU);
+        for (int i = 0; i < NX; ++i) po[S.k * NX + i] = (TIO)S.x[i];
+        if (S.stg) for (int j = 0; j < NU; ++j) po[(P.N + 1) * NX + S.k * NU + j] = (TIO)S.u[j];
+    }
+}
+
+template <typename TIO>
+static hipError_t launch_t(const Params& P, const sc_ipopt_params& O, long long B, int obs_shared, const void* X, const void* u_prev, const void* goal,
+                           const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, hipStream_t stream) {
+    const size_t lds = (size_t)Lds(P.N, P.K).total * sizeof(double);
+    hipError_t e = hipFuncSetAttribute((const void*)mpcdu_ms_kernel<TIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((mpcdu_ms_kernel<TIO>), dim3((unsigned)B), dim3(64), lds, stream, P, O, B, obs_shared, (const TIO*)X, (const TIO*)u_prev,
+                       (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status_out, iters_out, (TIO*)plan_out, trace_out);
+    return hipGetLastError();
+}
+
+}  // namespace dums
+
+size_t mpcdu_ms_lds_bytes(int horizon, int K) { return (size_t)dums::Lds(horizon, K).total * sizeof(double); }
+
+hipError_t mpcdu_ms_launch(const sc_mpccbf_params& p, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
+                           const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, hipStream_t stream) {
+    dums::Params P;
+    P.N = p.horizon; P.K = K; P.dt = p.dt;
+    for (int i = 0; i < 4; ++i) P.Q[i] = p.Q[i];
+    for (int j = 0; j < 2; ++j) { P.R[j] = p.R[j]; P.u_lo[j] = -p.u_max[j]; P.u_hi[j] = p.u_max[j]; }
+    P.alpha1 = p.alpha1; P.alpha2 = p.alpha2; P.beta = p.beta; P.radius = p.robot_radius; P.v_max = p.v_max;
+    if (p.io_dtype == SC_DTYPE_F64)
+        return dums::launch_t<double>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, stream);
+    return dums::launch_t<float>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, stream);
+}
+
+}  // namespace sc

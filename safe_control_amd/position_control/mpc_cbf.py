@@ -97,7 +97,10 @@ def make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_
 
 
 class MPCCBF:
-    """Drop-in for position_control.mpc_cbf.MPCCBF (single agent per call)."""
+    """Drop-in for position_control.mpc_cbf.MPCCBF (single agent per call).  ``robot_spec['mpc_formulation']`` (DynamicUnicycle2D):
+    'multiple_shooting' (default since round 6: the NLP as do-mpc poses it under IPOPT's algorithm with its restoration phase,
+    csrc/mpc_du_ms.hip, kernel 13 -- what the reference's solver returns also where the NLP has no feasible point) or 'condensed'
+    (single shooting, csrc/mpc_cbf.hip); scenes with superellipsoid rows and Unicycle2D run on the condensed kernel."""
 
     def __new__(cls, robot, robot_spec, *args, **kwargs):
         # the reference serves every model from this one class; the linear models run on their own kernel
@@ -139,6 +142,11 @@ class MPCCBF:
         self.z = np.zeros(2 * self.horizon, dtype=np.float64)
         self.iterations = 0
         self.solver_status = "optimal"
+        self._ms = None
+        if self.robot_spec["model"] == "DynamicUnicycle2D" and self.robot_spec.get("mpc_formulation", "multiple_shooting") != "condensed" \
+                and self.horizon <= 62 and self.num_obs <= 16:
+            from .mpc_cbf_ms import BatchedMSMPCCBF
+            self._ms = BatchedMSMPCCBF(self.robot_spec, dt=self.dt, io_dtype="f64", horizon=self.horizon, cbf_param=self.cbf_param, check_circles=False)
 
     def update_tvp(self, goal, obs):
         self.goal = np.array(goal)
@@ -154,6 +162,18 @@ class MPCCBF:
         X[: xs.shape[0]] = xs
         g = np.ascontiguousarray(np.asarray(self.goal, dtype=np.float64).reshape(-1)[:2])
         obs = np.ascontiguousarray(self.obs, dtype=np.float64)
+        if self._ms is not None and not (obs[:, 6] >= 0.5).any():
+            import torch
+            dev = torch.device("cuda", int(self.device))
+            t = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float64), dtype=torch.float64, device=dev)     # noqa: E731
+            self._ms.cbf_param = self.cbf_param               # (users mutate cbf_param in place: README "online adaptive CBF")
+            self._ms.robot_spec["radius"] = self.robot.robot_radius
+            u, st, it, plan = self._ms.solve(t(X[None]), t(self.u_prev[None]), t(g[None]), t(obs[None]), want_plan=True)
+            self.iterations = int(it[0].item())
+            self.solver_status = _lib.STATUS_STRINGS[int(st[0].item())]
+            self.z = plan[0, (self.horizon + 1) * 4:].cpu().numpy().copy()      # the planned inputs u_0 .. u_{N-1}
+            self.u_prev = u[0].cpu().numpy().copy()
+            return self.u_prev.reshape(-1, 1).copy()
         p = make_params(self.robot_spec, self.cbf_param, self.Q, self.R, self.horizon, self.dt,
                         self.robot.robot_radius, _lib.DTYPE_F64)
         u = np.zeros(2); st = np.zeros(1, dtype=np.int32); it = np.zeros(1, dtype=np.int32)

@@ -154,9 +154,10 @@ def test_full_batch_4096_is_deterministic_and_position_independent():
 
 
 def test_dropin_class_closed_loop_matches_oracle():
-    """MPCCBF through the reference's plugin surface, 15 closed-loop steps with u_prev feedback."""
+    """MPCCBF through the reference's plugin surface on the CONDENSED kernel (robot_spec['mpc_formulation'] = 'condensed'; the default
+    formulation of this robot is the multiple-shooting kernel since round 6: tests/test_mpccbf_ms_gpu.py), 15 closed-loop steps with u_prev feedback."""
     from oracle import robots as R
-    spec = dict(SPEC)
+    spec = dict(SPEC, mpc_formulation="condensed")
     robot = sca.RobotHandle(np.array([2.0, 2.0, np.pi / 2, 1.0]), spec, dt=0.05)
     ctl = sca.MPCCBF(robot, spec, num_obs=8)
     obs = [[2.2, 5.0, 0.2], [3.0, 5.0, 0.2], [4.0, 9.0, 0.3]]
