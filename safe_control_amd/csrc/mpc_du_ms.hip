@@ -25,6 +25,14 @@ struct DevCtx {
     int lane;
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ long long clock() const { return __builtin_readcyclecounter(); }
+    __device__ __forceinline__ void sincos(double a, double& s, double& c) const { sc::sincos_(a, &s, &c); }
+    // two powers of wave-uniform arguments at the price of one: even lanes take the first, odd lanes the second
+    __device__ __forceinline__ void pow2(double x1, double e1, double x2, double e2, double& r1, double& r2) const {
+        const bool odd = lane & 1;
+        const double v = pow(odd ? x2 : x1, odd ? e2 : e1);
+        r1 = ipm::row_value(v, 0); r2 = ipm::row_value(v, 1);
+    }
+    __device__ __forceinline__ double rsqrt(double v) const { return ::rsqrt(v); }
     __device__ __forceinline__ double wsum(double v) const { return ipm::wsum(v); }
     __device__ __forceinline__ double wmax(double v) const { return ipm::wmax(v); }
     __device__ __forceinline__ double wmin(double v) const { return ipm::wmin(v); }

@@ -100,23 +100,36 @@ struct Lds {
 //     T = P G (6 x 8) and t = P c + p        G = [[A, 0, B], [0, 0, I]]: xi+ = G (xi, u) + (c, 0)
 //     Q = S + G' T,  q = s + G' t            S = stage block (H over (x, u), -cpl on (v_i, u_i))
 //     Quu = L L',  Y = L^-1 Q[u, :],  P' = Q - Y' Y,  p' = q - Y' L^-1 q_u,  K = -L^-T Y,  kff = -L^-T L^-1 q_u
-template <class Cx>
-SC_HD SC_DUMS_INLINE void g_column(const typename Cx::ptr ab, int t, double dt, double g[NA]) {
-    // column t of G = [[A, 0, B], [0, 0, I]] (selects, no indexed stores: the array stays in registers)
-    g[0] = t == 0 ? 1.0 : (t == 2 ? ab[0] : (t == 3 ? ab[1] : 0.0));
-    g[1] = t == 1 ? 1.0 : (t == 2 ? ab[2] : (t == 3 ? ab[3] : 0.0));
-    g[2] = t == 2 ? 1.0 : (t == 7 ? dt : 0.0);
-    g[3] = t == 3 ? 1.0 : (t == 6 ? dt : 0.0);
-    g[4] = t == 6 ? 1.0 : 0.0;
-    g[5] = t == 7 ? 1.0 : 0.0;
-}
+// a lane's column of G~ = [G | (c, 0, 0)] (6 x 9, G = [[A, 0, B], [0, 0, I]]): what does not change from stage to stage is worked out once
+//     column 0, 1: e_0, e_1;  2: (a02, a12, 1, 0, 0, 0);  3: (a03, a13, 0, 1, 0, 0);  4, 5: 0;  6: (0, 0, 0, dt, 1, 0);  7: (0, 0, dt, 0, 0, 1);  8: (c, 0, 0)
+struct GCol {
+    double b[NA], s2, s3, s8;
+    SC_HD void set(int t, double dt) {
+        b[0] = t == 0 ? 1.0 : 0.0; b[1] = t == 1 ? 1.0 : 0.0; b[2] = t == 2 ? 1.0 : (t == 7 ? dt : 0.0); b[3] = t == 3 ? 1.0 : (t == 6 ? dt : 0.0);
+        b[4] = t == 6 ? 1.0 : 0.0; b[5] = t == 7 ? 1.0 : 0.0;
+        s2 = t == 2 ? 1.0 : 0.0; s3 = t == 3 ? 1.0 : 0.0; s8 = t == 8 ? 1.0 : 0.0;
+    }
+    // (a02, a03, a12, a13) of the stage
+    SC_HD void at(double a02, double a03, double a12, double a13, double g[NA]) const {
+        g[0] = b[0] + s2 * a02 + s3 * a03; g[1] = b[1] + s2 * a12 + s3 * a13; g[2] = b[2]; g[3] = b[3]; g[4] = b[4]; g[5] = b[5];
+    }
+};
 
 template <class Cx>
 SC_HD SC_DUMS_INLINE bool riccati_backward(Cx& cx, const Lds& L, const int N, const double dt, const double cpl0, const double cpl1) {
     typename Cx::ptr lds = cx.lds;
     const int lane = cx.lane, r = lane >> 3, c = lane & 7;
     const int rr = r < c ? r : c, cc = r < c ? c : r;
-    auto hx = [](int t) { return t < 4 ? t : (t >= 6 ? t - 2 : -1); };
+    // T phase: lane l < 54 owns T~[l / 9][l % 9] (column 8 = the affine column P c + p)
+    const int tr = lane < 54 ? lane / 9 : 0, tc = lane < 54 ? lane % 9 : 0;
+    GCol gT, gR, gC;
+    gT.set(tc, dt); gR.set(rr, dt); gC.set(c, dt);
+    // S[rr][cc]: an entry of H (index map 0..3 -> x, 6..7 -> u), or -cpl on (v_i, u_i) for k >= 1; s[c]: an entry of the gradient
+    const int hr = rr < 4 ? rr : (rr >= 6 ? rr - 2 : -1), hc = cc < 4 ? cc : (cc >= 6 ? cc - 2 : -1), hq = c < 4 ? c : (c >= 6 ? c - 2 : -1);
+    const bool inH = hr >= 0 && hc >= 0;
+    const int oH = inH ? sym6(hr, hc) : 0, oG = hq >= 0 ? hq : 0;
+    const double mH = inH ? 1.0 : 0.0, mG = hq >= 0 ? 1.0 : 0.0;
+    const double cplv = (rr == 4 && cc == 6) ? -cpl0 : ((rr == 5 && cc == 7) ? -cpl1 : 0.0);
     int cur = L.Pa, nxt = L.Pb;
     // P_N = x block of H_N, p_N = g_N
     cx.sync();
@@ -125,46 +138,36 @@ SC_HD SC_DUMS_INLINE bool riccati_backward(Cx& cx, const Lds& L, const int N, co
     cx.sync();
     for (int k = N - 1; k >= 0; --k) {
         const typename Cx::ptr ab = lds + L.AB + k * 4;
-        double gc[NA], gr[NA];
-        g_column<Cx>(ab, c, dt, gc);
-        g_column<Cx>(ab, rr, dt, gr);
-        // T and t
-        if (r < 6) {
-            double v = 0.0;
-            SC_UNROLL for (int m = 0; m < NA; ++m) v += lds[cur + r * 6 + m] * gc[m];
-            lds[L.T + r * 8 + c] = v;
-        } else if (r == 6 && c < 6) {
-            double v = lds[cur + 36 + c];
-            SC_UNROLL for (int m = 0; m < NX; ++m) v += lds[cur + c * 6 + m] * lds[L.C + (k + 1) * 4 + m];
-            lds[L.T + 48 + c] = v;
+        const typename Cx::ptr cd = lds + L.C + (k + 1) * 4;
+        const double a02 = ab[0], a03 = ab[1], a12 = ab[2], a13 = ab[3];
+        double g[NA];
+        // T~ = P G~ (+ p on the affine column)
+        gT.at(a02, a03, a12, a13, g);
+        g[0] += gT.s8 * cd[0]; g[1] += gT.s8 * cd[1]; g[2] += gT.s8 * cd[2]; g[3] += gT.s8 * cd[3];
+        {
+            double v = gT.s8 * lds[cur + 36 + tr];
+            SC_UNROLL for (int m = 0; m < NA; ++m) v += lds[cur + tr * 6 + m] * g[m];
+            if (lane < 54) lds[L.T + (tc < 8 ? tr * 8 + tc : 48 + tr)] = v;
         }
         cx.sync();
-        // Q (entry (rr, cc)) and q (lanes of row 0: q[c])
-        double qv = 0.0, ql = 0.0;
-        {
-            const int hr = hx(rr), hc = hx(cc);
-            if (hr >= 0 && hc >= 0) qv = lds[L.H + k * 21 + sym6(hr, hc)];
-            else if (k >= 1 && rr >= 4 && rr < 6 && cc == rr + 2) qv = rr == 4 ? -cpl0 : -cpl1;
-            SC_UNROLL for (int m = 0; m < NA; ++m) qv += gr[m] * lds[L.T + m * 8 + cc];
-            if (r == 0) {
-                const int hq = hx(c);
-                ql = hq >= 0 ? lds[L.G + k * 6 + hq] : 0.0;
-                double gq[NA];
-                g_column<Cx>(ab, c, dt, gq);
-                SC_UNROLL for (int m = 0; m < NA; ++m) ql += gq[m] * lds[L.T + 48 + m];
-            }
-        }
+        // Q[rr][cc] = S + G[:, rr]' T[:, cc];  q[c] = s[c] + G[:, c]' t  (every lane of column c)
+        gR.at(a02, a03, a12, a13, g);
+        double qv = mH * lds[L.H + k * 21 + oH] + (k >= 1 ? cplv : 0.0);
+        SC_UNROLL for (int m = 0; m < NA; ++m) qv += g[m] * lds[L.T + m * 8 + cc];
+        gC.at(a02, a03, a12, a13, g);
+        double ql = mG * lds[L.G + k * 6 + oG];
+        SC_UNROLL for (int m = 0; m < NA; ++m) ql += g[m] * lds[L.T + 48 + m];
         if (r >= 6) lds[L.QU + (r - 6) * 8 + c] = qv;
         if (r == 0 && c >= 6) lds[L.QU + 16 + (c - 6)] = ql;
         cx.sync();
         const double q66 = lds[L.QU + 6], q67 = lds[L.QU + 7], q77 = lds[L.QU + 8 + 7];
         if (!(q66 > 0.0) || !(q66 < 1e300)) return false;
-        const double l00 = sqrt(q66), l10 = q67 / l00, d11 = q77 - l10 * l10;
+        const double li0 = cx.rsqrt(q66), l10 = q67 * li0, d11 = q77 - l10 * l10;
         if (!(d11 > 0.0) || !(d11 < 1e300)) return false;
-        const double l11 = sqrt(d11);
-        const double ya0 = lds[L.QU + rr] / l00, ya1 = (lds[L.QU + 8 + rr] - l10 * ya0) / l11;
-        const double yb0 = lds[L.QU + cc] / l00, yb1 = (lds[L.QU + 8 + cc] - l10 * yb0) / l11;
-        const double yq0 = lds[L.QU + 16] / l00, yq1 = (lds[L.QU + 17] - l10 * yq0) / l11;
+        const double li1 = cx.rsqrt(d11);
+        const double ya0 = lds[L.QU + rr] * li0, ya1 = (lds[L.QU + 8 + rr] - l10 * ya0) * li1;
+        const double yb0 = lds[L.QU + cc] * li0, yb1 = (lds[L.QU + 8 + cc] - l10 * yb0) * li1;
+        const double yq0 = lds[L.QU + 16] * li0, yq1 = (lds[L.QU + 17] - l10 * yq0) * li1;
         if (r < 6 && c < 6) {
             const double pv = qv - (ya0 * yb0 + ya1 * yb1);
             lds[nxt + r * 6 + c] = pv;
@@ -175,13 +178,11 @@ SC_HD SC_DUMS_INLINE bool riccati_backward(Cx& cx, const Lds& L, const int N, co
             lds[nxt + 36 + c] = pl;
             if (c < 4) lds[L.PX + k * 28 + 24 + c] = pl;
         }
-        if (r == 6 && c < 6) {                                             // gains of column c (= rr): K = -L^-T y
-            const double k1 = ya1 / l11, k0 = (ya0 - l10 * k1) / l00;
-            lds[L.KG + k * 14 + c] = -k0; lds[L.KG + k * 14 + 6 + c] = -k1;
-        }
-        if (r == 6 && c == 6) {
-            const double k1 = yq1 / l11, k0 = (yq0 - l10 * k1) / l00;
-            lds[L.KG + k * 14 + 12] = -k0; lds[L.KG + k * 14 + 13] = -k1;
+        if (r == 6) {                                                      // gains of column c (= rr for c < 6), kff on (6, 6): K = -L^-T y
+            const double y0 = c < 6 ? ya0 : yq0, y1 = c < 6 ? ya1 : yq1;
+            const double k1 = y1 * li1, k0 = (y0 - l10 * k1) * li0;
+            if (c < 6) { lds[L.KG + k * 14 + c] = -k0; lds[L.KG + k * 14 + 6 + c] = -k1; }
+            else if (c == 6) { lds[L.KG + k * 14 + 12] = -k0; lds[L.KG + k * 14 + 13] = -k1; }
         }
         cx.sync();
         const int t_ = cur; cur = nxt; nxt = t_;
@@ -266,12 +267,14 @@ struct Wave {
         double a02, a03, a12, a13;       // d p1 / d (theta, v)  = the non-trivial entries of A
         double g02, g03, g12, g13;       // d (p2 - p1) / d (theta, v);  d / d a = dt (g03, g13),  d / d omega = dt (g02, g12)
     };
-    SC_HD void geometry(const double* xs, const double* us, Geo& g) const {
+    double tc_ = 1.0, ts_ = 0.0, tc1_ = 1.0, ts1_ = 0.0;        // cos / sin of theta_k and of theta_k + dt omega_k at the ITERATE (eval2 sets them, finish_step reuses them)
+    SC_HD void geometry(const double* xs, const double* us, Geo& g, bool cached = false) const {
         const double dt = P.dt;
-        g.c = cos(xs[2]); g.s = sin(xs[2]);
-        g.F[0] = xs[0] + dt * xs[3] * g.c; g.F[1] = xs[1] + dt * xs[3] * g.s; g.F[2] = xs[2] + dt * us[1]; g.F[3] = xs[3] + dt * us[0];
+        g.F[2] = xs[2] + dt * us[1];
+        if (cached) { g.c = tc_; g.s = ts_; g.c1 = tc1_; g.s1 = ts1_; }
+        else { cx.sincos(xs[2], g.s, g.c); cx.sincos(g.F[2], g.s1, g.c1); }
+        g.F[0] = xs[0] + dt * xs[3] * g.c; g.F[1] = xs[1] + dt * xs[3] * g.s; g.F[3] = xs[3] + dt * us[0];
         g.v1 = g.F[3];
-        g.c1 = cos(g.F[2]); g.s1 = sin(g.F[2]);
         g.p1[0] = g.F[0]; g.p1[1] = g.F[1];
         g.p2[0] = g.F[0] + dt * g.v1 * g.c1; g.p2[1] = g.F[1] + dt * g.v1 * g.s1;
         g.a02 = -dt * xs[3] * g.s; g.a03 = dt * g.c; g.a12 = dt * xs[3] * g.c; g.a13 = dt * g.s;
@@ -306,9 +309,56 @@ struct Wave {
         if (stg) SC_UNROLL for (int j = 0; j < NU; ++j) { const double d = us[j] - um[j]; f += P.R[j] * d * d; }
         return f;
     }
-    // trial evaluation at (xs, us, ss): theta (l1 residual of the scaled rows) and the unscaled objective; a_np: step length applied to
-    // the slacks and, inside the restoration, to (n, p); pmax (optional): largest residual
-    SC_HD void eval0(const double* xs, const double* us, double& theta, double& fsum, double a_np = 0.0, double* pmax = nullptr) {
+    // Log-barrier terms of a point, gathered while its rows are walked (the objective / mu-independent part): the log of the product of every
+    // slack to a bound (one log per lane: the x / u bounds give six factors of order one, eight row slacks lie in [1e-11, 1e6]; the product is
+    // flushed every eight rows, every two inside the restoration where n and p ride along), the sum of the one-sided slacks (damping), n + p
+    struct BarAcc {
+        double prod, lg, sa, sn;
+        bool ok;
+    };
+    SC_HD void bar_begin(BarAcc& B, const double* xs, const double* us) const {
+        B.prod = 1.0; B.lg = 0.0; B.sa = 0.0; B.sn = 0.0; B.ok = true;
+        if (act) {
+            const double a = xs[3] - xbL, b = xbU - xs[3];
+            if (!(a > 0.0) || !(b > 0.0)) B.ok = false;
+            B.prod = a * b;
+        }
+        if (stg) {
+            SC_UNROLL for (int j = 0; j < NU; ++j) {
+                const double a = us[j] - ubL[j], b = ubU[j] - us[j];
+                if (!(a > 0.0) || !(b > 0.0)) B.ok = false;
+                B.prod *= a * b;
+            }
+        }
+    }
+    // row j: slack to its bound sl = sU - s (and n, p of the restoration at step length a_np)
+    SC_HD void bar_row(BarAcc& B, int j, double sl, double a_np) const {
+        if (!(sl > 0.0)) B.ok = false;
+        B.sa += sl;
+        B.prod *= sl;
+        if (rs) {
+            const double nt = lds[ri(R_N, j)] + a_np * lds[ri(R_DN, j)], pt_ = lds[ri(R_P, j)] + a_np * lds[ri(R_DP, j)];
+            if (!(nt > 0.0) || !(pt_ > 0.0)) B.ok = false;
+            B.sn += nt + pt_;
+            B.prod *= nt * pt_;
+            if (j & 1) { B.lg += log(B.prod); B.prod = 1.0; }
+        } else if ((j & 7) == 7 && j + 1 < K) { B.lg += log(B.prod); B.prod = 1.0; }
+    }
+    // barrier function (scaled objective + log barrier of every bound + damping of the one-sided ones) from the gathered terms
+    SC_HD double barrier(double fsum, BarAcc& B, double mu) const {
+        if (act) { B.lg += log(B.prod); B.prod = 1.0; }
+        double v = -mu * B.lg;
+        if (stg) {
+            v += O.kappa_d * mu * B.sa;
+            if (rs) v += (O.resto_penalty_parameter + O.kappa_d * mu) * B.sn;    // n, p >= 0: linear term rho_R, damping (one-sided)
+        }
+        const double bad = cx.wmax(B.ok ? 0.0 : 1.0);
+        if (bad > 0.0) return INFINITY;
+        return (rs ? 0.5 * zeta : df) * fsum + cx.wsum(v);
+    }
+    // trial evaluation at (xs, us) and slacks s + a_np ds (inside the restoration n, p at a_np as well): theta (l1 residual of the scaled rows),
+    // the unscaled objective, the barrier terms; `safe`: IPOPT's safe-slack rule on the rows' slack bounds on the way; pmax (optional): largest residual
+    SC_HD void eval0(const double* xs, const double* us, double& theta, double& fsum, BarAcc& B, double mu, double a_np, bool safe, double* pmax = nullptr) {
         sync();
         if (act) SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.XS + k * 4 + i] = xs[i];
         if (stg) SC_UNROLL for (int j = 0; j < NU; ++j) lds[L.US + (k + 1) * 2 + j] = us[j];
@@ -317,16 +367,20 @@ struct Wave {
         double th = 0.0, pm = 0.0;
         double um[NU];
         SC_UNROLL for (int j = 0; j < NU; ++j) um[j] = lds[L.US + k * 2 + j];
+        bar_begin(B, xs, us);
         if (stg) {
+            const double s_min = EPS_ * fmin(1.0, mu), move = 1.8189894035458565e-12;     // eps^(3/4)
             Geo g;
             geometry(xs, us, g);
             SC_UNROLL for (int i = 0; i < NX; ++i) { const double r = fabs(dgc(i) * (g.F[i] - lds[L.XS + (k + 1) * 4 + i])); th += r; pm = fmax(pm, r); }
             for (int j = 0; j < K; ++j) {
-                if (j < K) {
-                    double r = -dgd(j) * row(xs, g, j) - (lds[ri(R_S, j)] + a_np * lds[ri(R_DS, j)]);
-                    if (rs) r += (lds[ri(R_N, j)] + a_np * lds[ri(R_DN, j)]) - (lds[ri(R_P, j)] + a_np * lds[ri(R_DP, j)]);
-                    th += fabs(r); pm = fmax(pm, fabs(r));
-                }
+                const double sj = lds[ri(R_S, j)] + a_np * lds[ri(R_DS, j)];
+                double bj = lds[ri(R_SU, j)];
+                if (safe) { safe1(sj, bj, false, s_min, move); lds[ri(R_SU, j)] = bj; }
+                double r = -dgd(j) * row(xs, g, j) - sj;
+                if (rs) r += (lds[ri(R_N, j)] + a_np * lds[ri(R_DN, j)]) - (lds[ri(R_P, j)] + a_np * lds[ri(R_DP, j)]);
+                th += fabs(r); pm = fmax(pm, fabs(r));
+                bar_row(B, j, bj - sj, a_np);
             }
         }
         if (lane == 0) SC_UNROLL for (int i = 0; i < NX; ++i) { const double r = fabs(xs[i] - x0[i]); th += r; pm = fmax(pm, r); }
@@ -335,64 +389,17 @@ struct Wave {
         fsum = cx.wsum(cost_share(xs, us, um));
     }
 
-    // ---- barrier function (scaled objective + log barrier of every bound + damping of the one-sided ones) ------------------------------
-    SC_HD double barrier(double fsum, const double* xs, const double* us, double mu, double a_np = 0.0) const {
-        double v = 0.0;
-        bool ok = true;
-        if (act) {
-            const double a = xs[3] - xbL, b = xbU - xs[3];
-            if (!(a > 0.0) || !(b > 0.0)) ok = false;
-            v -= mu * log(a * b);
-        }
-        if (stg) {
-            double pr = 1.0;
-            SC_UNROLL for (int j = 0; j < NU; ++j) {
-                const double a = us[j] - ubL[j], b = ubU[j] - us[j];
-                if (!(a > 0.0) || !(b > 0.0)) ok = false;
-                pr *= a * b;
-            }
-            v -= mu * log(pr);
-            double ps = 1.0, sa = 0.0;
-            for (int j = 0; j < K; ++j) {
-                if (j < K) {
-                    const double a = lds[ri(R_SU, j)] - (lds[ri(R_S, j)] + a_np * lds[ri(R_DS, j)]);
-                    if (!(a > 0.0)) ok = false;
-                    sa += a;
-                    if (j == 8) { v -= mu * log(ps); ps = 1.0; }          // (slacks of far rows are ~1e2 .. 1e6: a product of eight stays inside the double range)
-                    ps *= a;
-                }
-            }
-            v -= mu * log(ps);
-            v += O.kappa_d * mu * sa;
-            if (rs) {                                                       // n, p >= 0: linear term rho_R, log barrier, damping (one-sided)
-                double sn = 0.0;
-                for (int j = 0; j < K; ++j) {
-                    if (j < K) {
-                        const double nt = lds[ri(R_N, j)] + a_np * lds[ri(R_DN, j)], pt_ = lds[ri(R_P, j)] + a_np * lds[ri(R_DP, j)];
-                        if (!(nt > 0.0) || !(pt_ > 0.0)) ok = false;
-                        sn += nt + pt_;
-                        v -= mu * log(nt * pt_);
-                    }
-                }
-                v += (O.resto_penalty_parameter + O.kappa_d * mu) * sn;
-            }
-        }
-        const double bad = cx.wmax(ok ? 0.0 : 1.0);
-        if (bad > 0.0) return INFINITY;
-        return (rs ? 0.5 * zeta : df) * fsum + cx.wsum(v);
-    }
+    // fraction to the boundary: the largest step in (0, 1] that keeps sl + a dsl >= (1 - tau) sl
+    SC_HD double ftb1(double tau, double sl, double dsl) const { return dsl < 0.0 ? fmin(1.0, -tau * sl / dsl) : 1.0; }
     // IPOPT's CalculateSafeSlack: a slack below eps min(1, mu) is raised to eps^(3/4) max(1, |bound|) by moving the bound
     SC_HD void safe1(double v, double& lo, bool lower, double s_min, double move) const {
         if (lower) { if (v - lo < s_min) lo = v - fmax(v - lo, move * fmax(1.0, fabs(lo))); }
         else { if (lo - v < s_min) lo = v + fmax(lo - v, move * fmax(1.0, fabs(lo))); }
     }
-    SC_HD void safe_slacks(const double* xs, const double* us, double mu, double a_np) {
+    SC_HD void safe_slacks_xu(const double* xs, const double* us, double mu) {      // (the rows' slack bounds: inside eval0's / the update's row loop)
         const double s_min = EPS_ * fmin(1.0, mu), move = 1.8189894035458565e-12;     // eps^(3/4)
         if (act) { safe1(xs[3], xbL, true, s_min, move); safe1(xs[3], xbU, false, s_min, move); }
-        if (stg) {
-            SC_UNROLL for (int j = 0; j < NU; ++j) { safe1(us[j], ubL[j], true, s_min, move); safe1(us[j], ubU[j], false, s_min, move); }
-            for (int j = 0; j < K; ++j) { double b = lds[ri(R_SU, j)]; safe1(lds[ri(R_S, j)] + a_np * lds[ri(R_DS, j)], b, false, s_min, move); lds[ri(R_SU, j)] = b; }
-        }
+        if (stg) SC_UNROLL for (int j = 0; j < NU; ++j) { safe1(us[j], ubL[j], true, s_min, move); safe1(us[j], ubU[j], false, s_min, move); }
     }
 
     struct Eval2 {
@@ -439,8 +446,13 @@ struct Wave {
 
     // Level 2 at the iterate: residuals, J'y, and -- `build` -- the stage block for the recursion: A, H (condensed rows, bounds, dw), gradient,
     // defects.  ls: the least-square multiplier system (W = 0, Sigma = 1) instead of the Newton system.
+    BarAcc Bcur;                 // barrier terms of the iterate (eval2 gathers them)
+    struct ErrAcc { double d, p, up, cmin, cmax, ysum, zsum; };
+    ErrAcc Ecur;                 // the rows' share of the optimality error at the iterate (eval2 gathers it; errors())
     SC_HD void eval2(const bool build, const bool ls, Eval2& E, double mu, double dw, double& theta, double& fsum) {
         publish();
+        bar_begin(Bcur, x, u);
+        Ecur.d = 0.0; Ecur.p = 0.0; Ecur.up = 0.0; Ecur.cmin = INFINITY; Ecur.cmax = -INFINITY; Ecur.ysum = 0.0; Ecur.zsum = 0.0;
         double um[NU], un[NU];
         SC_UNROLL for (int j = 0; j < NU; ++j) { um[j] = lds[L.US + k * 2 + j]; un[j] = lds[L.US + (k + 2 <= N + 1 ? k + 2 : N + 1) * 2 + j]; }
         const bool last = k == N - 1;
@@ -488,6 +500,7 @@ struct Wave {
         if (stg) {
             Geo g;
             geometry(x, u, g);
+            tc_ = g.c; ts_ = g.s; tc1_ = g.c1; ts1_ = g.s1;
             SC_UNROLL for (int i = 0; i < NX; ++i) { rc[i] = dgc(i) * (g.F[i] - lds[L.XS + (k + 1) * 4 + i]); th += fabs(rc[i]); }
             if (build) { lds[L.AB + k * 4 + 0] = g.a02; lds[L.AB + k * 4 + 1] = g.a03; lds[L.AB + k * 4 + 2] = g.a12; lds[L.AB + k * 4 + 3] = g.a13; }
             // J' y of my dynamics rows: [A | B]' (dgc yc)
@@ -509,6 +522,20 @@ struct Wave {
                     lds[ri(R_DV, j)] = -sc * cv;
                     const double rd = lds[ri(R_DV, j)] - lds[ri(R_S, j)] + (rs ? lds[ri(R_N, j)] - lds[ri(R_P, j)] : 0.0);
                     th += fabs(rd);
+                    bar_row(Bcur, j, lds[ri(R_SU, j)] - lds[ri(R_S, j)], 0.0);
+                    {
+                        const double ydj = lds[ri(R_YD, j)], vUj = lds[ri(R_VU, j)], cp = (lds[ri(R_SU, j)] - lds[ri(R_S, j)]) * vUj;
+                        Ecur.d = fmax(Ecur.d, fabs(-ydj + vUj));
+                        Ecur.p = fmax(Ecur.p, fabs(rd)); Ecur.up = fmax(Ecur.up, fabs(rd / sc));
+                        Ecur.cmin = fmin(Ecur.cmin, cp); Ecur.cmax = fmax(Ecur.cmax, cp);
+                        Ecur.ysum += fabs(ydj); Ecur.zsum += fabs(vUj);
+                        if (rs) {
+                            const double n = lds[ri(R_N, j)], pp = lds[ri(R_P, j)], zn = lds[ri(R_ZN, j)], zp = lds[ri(R_ZP, j)], rho_R = O.resto_penalty_parameter;
+                            Ecur.d = fmax(Ecur.d, fmax(fabs(rho_R + ydj - zn), fabs(rho_R - ydj - zp)));
+                            Ecur.cmin = fmin(Ecur.cmin, fmin(n * zn, pp * zp)); Ecur.cmax = fmax(Ecur.cmax, fmax(n * zn, pp * zp));
+                            Ecur.zsum += fabs(zn) + fabs(zp);
+                        }
+                    }
                     const double om = sc * lds[ri(R_YD, j)];                                   // weight of grad^2 (-cbf_j) in the Hessian of the Lagrangian
                     SC_UNROLL for (int i = 0; i < NV; ++i) E.Jty[i] -= om * a[i];             // yd_j * grad d_j = -om grad cbf_j
                     sl += om; socx += om * lds[L.OB + 3 * j]; socy += om * lds[L.OB + 3 * j + 1];
@@ -587,7 +614,8 @@ struct Wave {
     }
 
     // after the recursion: the multiplier steps of the dynamics rows (from the value function), of my rows and bounds
-    SC_HD void finish_step(bool ls, double mu, double dw) {
+    double sl_ap = 1.0, sl_az = 1.0, sl_v = 0.0;       // the rows' share of step_lengths (finish_step gathers it)
+    SC_HD void finish_step(bool ls, double mu, double dw, double tau) {
         {
             double xi[NA];
             riccati_forward<Cx>(cx, L, N, P.dt, act ? k : -1, xi, du);
@@ -614,36 +642,44 @@ struct Wave {
             }
         }
         sync();
-        // rows: dy_d = E (a . dw - b), ds = q (rhs_t + dy_d), dvU
+        // rows: dy_d = E (a . dw - b), ds = q (rhs_t + dy_d), dvU -- and, on the way, the rows' share of the fraction-to-the-boundary step lengths
+        // and of the barrier function's directional derivative (step_lengths)
+        sl_ap = 1.0; sl_az = 1.0; sl_v = 0.0;
         if (stg) {
             Geo g;
-            geometry(x, u, g);
+            geometry(x, u, g, true);
             const double dz[NV] = {dx[0], dx[1], dx[2], dx[3], du[0], du[1]};
             for (int j = 0; j < K; ++j) {
-                if (j < K) {
-                    double a[NV];
-                    row(x, g, j, a);
-                    double adw = 0.0;
-                    SC_UNROLL for (int i = 0; i < NV; ++i) adw += a[i] * dz[i];
-                    adw *= -dgd(j);
-                    if (ls) { lds[ri(R_DYD, j)] = adw + lds[ri(R_VU, j)]; lds[ri(R_DS, j)] = 0.0; lds[ri(R_DVU, j)] = 0.0; }
-                    else if (rs) {                                                   // dy = E (a . dw - b);  dv = q_v (rhs_v - sign_v dy);  multipliers of n, p >= 0
-                        const RowW w = row_weights(j, mu, dw);
-                        const double stU = lds[ri(R_SU, j)] - lds[ri(R_S, j)], n = lds[ri(R_N, j)], p = lds[ri(R_P, j)], zn = lds[ri(R_ZN, j)], zp = lds[ri(R_ZP, j)];
-                        lds[ri(R_DYD, j)] = w.E * (adw - w.b);
-                        lds[ri(R_DS, j)] = w.qs * (w.rs_ + lds[ri(R_DYD, j)]);
-                        lds[ri(R_DVU, j)] = mu / stU - lds[ri(R_VU, j)] + lds[ri(R_VU, j)] * lds[ri(R_DS, j)] / stU;
-                        const double dn = w.qn * (w.rn - lds[ri(R_DYD, j)]), dp = w.qp * (w.rp + lds[ri(R_DYD, j)]);
-                        lds[ri(R_DN, j)] = dn; lds[ri(R_DP, j)] = dp;
-                        lds[ri(R_DZN, j)] = mu / n - zn - zn * dn / n; lds[ri(R_DZP, j)] = mu / p - zp - zp * dp / p;
-                    } else {
-                        const double stU = lds[ri(R_SU, j)] - lds[ri(R_S, j)], sig = lds[ri(R_VU, j)] / stU, Ej = sig + dw, gt = mu / stU - O.kappa_d * mu;
-                        const double rd = lds[ri(R_DV, j)] - lds[ri(R_S, j)], rhs_t = lds[ri(R_YD, j)] - gt, bd = -rd + rhs_t / Ej;
-                        lds[ri(R_DYD, j)] = Ej * (adw - bd);
-                        lds[ri(R_DS, j)] = (rhs_t + lds[ri(R_DYD, j)]) / Ej;
-                        lds[ri(R_DVU, j)] = mu / stU - lds[ri(R_VU, j)] + lds[ri(R_VU, j)] * lds[ri(R_DS, j)] / stU;
-                    }
+                double a[NV];
+                row(x, g, j, a);
+                double adw = 0.0;
+                SC_UNROLL for (int i = 0; i < NV; ++i) adw += a[i] * dz[i];
+                adw *= -dgd(j);
+                const double vUj = lds[ri(R_VU, j)];
+                if (ls) { lds[ri(R_DYD, j)] = adw + vUj; lds[ri(R_DS, j)] = 0.0; lds[ri(R_DVU, j)] = 0.0; continue; }
+                const double stU = lds[ri(R_SU, j)] - lds[ri(R_S, j)], istU = 1.0 / stU;
+                double dyd_, ds_;
+                if (rs) {                                                        // dy = E (a . dw - b);  dv = q_v (rhs_v - sign_v dy);  multipliers of n, p >= 0
+                    const RowW w = row_weights(j, mu, dw);
+                    const double n = lds[ri(R_N, j)], p = lds[ri(R_P, j)], zn = lds[ri(R_ZN, j)], zp = lds[ri(R_ZP, j)], rho_R = O.resto_penalty_parameter;
+                    dyd_ = w.E * (adw - w.b);
+                    ds_ = w.qs * (w.rs_ + dyd_);
+                    const double dn = w.qn * (w.rn - dyd_), dp = w.qp * (w.rp + dyd_);
+                    const double dzn = mu / n - zn - zn * dn / n, dzp = mu / p - zp - zp * dp / p;
+                    lds[ri(R_DN, j)] = dn; lds[ri(R_DP, j)] = dp; lds[ri(R_DZN, j)] = dzn; lds[ri(R_DZP, j)] = dzp;
+                    sl_ap = fmin(sl_ap, fmin(ftb1(tau, n, dn), ftb1(tau, p, dp)));
+                    sl_az = fmin(sl_az, fmin(ftb1(tau, zn, dzn), ftb1(tau, zp, dzp)));
+                    sl_v += (rho_R - mu / n + O.kappa_d * mu) * dn + (rho_R - mu / p + O.kappa_d * mu) * dp;
+                } else {
+                    const double Ej = vUj * istU + dw, gt = mu * istU - O.kappa_d * mu;
+                    const double rd = lds[ri(R_DV, j)] - lds[ri(R_S, j)], rhs_t = lds[ri(R_YD, j)] - gt, iE = 1.0 / Ej, bd = -rd + rhs_t * iE;
+                    dyd_ = Ej * (adw - bd);
+                    ds_ = (rhs_t + dyd_) * iE;
                 }
+                const double dvU_ = mu * istU - vUj + vUj * ds_ * istU;
+                lds[ri(R_DYD, j)] = dyd_; lds[ri(R_DS, j)] = ds_; lds[ri(R_DVU, j)] = dvU_;
+                sl_ap = fmin(sl_ap, ftb1(tau, stU, -ds_)); sl_az = fmin(sl_az, ftb1(tau, vUj, dvU_));
+                sl_v += (mu * istU - O.kappa_d * mu) * ds_;
             }
         }
         if (!ls) {
@@ -661,50 +697,41 @@ struct Wave {
     }
 
     // ---- optimality error (eq. (5)): E_mu and its parts ---------------------------------------------------------------------------------
-    SC_HD void errors(const Eval2& E, double mu, double& Emu, double& dinf, double& pinf, double& comp, double& un_pinf) const {
-        double d = 0.0, p = 0.0, c = 0.0, ysum = 0.0, zsum = 0.0, up = 0.0;
+    // The rows' share of the optimality error is gathered by eval2's row loop (ErrAcc): dual infeasibility of the slacks, residuals, multiplier
+    // sums, and the smallest / largest complementarity product -- max |s z - mu| over a set is max(|max - mu|, |min - mu|), so the error for ANY
+    // barrier parameter comes without another pass over the rows.  errors() adds the x / u share and the wave reductions.
+    SC_HD void errors(const Eval2& E, double mu, double& E0, double& Emu, double& dinf, double& pinf, double& comp0, double& un_pinf) const {
+        double d = Ecur.d, p = Ecur.p, up = Ecur.up, cmin = Ecur.cmin, cmax = Ecur.cmax, ysum = Ecur.ysum, zsum = Ecur.zsum;
         if (act) {
             double gl[NX];
             SC_UNROLL for (int i = 0; i < NX; ++i) gl[i] = E.gfx[i] + E.Jty[i];
             gl[3] += -zxL + zxU;
             SC_UNROLL for (int i = 0; i < NX; ++i) d = fmax(d, fabs(gl[i]));
-            c = fmax(c, fmax(fabs((x[3] - xbL) * zxL - mu), fabs((xbU - x[3]) * zxU - mu)));
+            const double c1 = (x[3] - xbL) * zxL, c2 = (xbU - x[3]) * zxU;
+            cmin = fmin(cmin, fmin(c1, c2)); cmax = fmax(cmax, fmax(c1, c2));
             zsum += fabs(zxL) + fabs(zxU);
         }
         if (stg) {
             SC_UNROLL for (int j = 0; j < NU; ++j) {
                 d = fmax(d, fabs(E.gfu[j] + E.Jty[4 + j] - zuL[j] + zuU[j]));
-                c = fmax(c, fmax(fabs((u[j] - ubL[j]) * zuL[j] - mu), fabs((ubU[j] - u[j]) * zuU[j] - mu)));
+                const double c1 = (u[j] - ubL[j]) * zuL[j], c2 = (ubU[j] - u[j]) * zuU[j];
+                cmin = fmin(cmin, fmin(c1, c2)); cmax = fmax(cmax, fmax(c1, c2));
                 zsum += fabs(zuL[j]) + fabs(zuU[j]);
             }
             SC_UNROLL for (int i = 0; i < NX; ++i) { p = fmax(p, fabs(rc[i])); up = fmax(up, fabs(rc[i] / dgc(i))); ysum += fabs(yc[i]); }
-            for (int j = 0; j < K; ++j) {
-                if (j < K) {
-                    d = fmax(d, fabs(-lds[ri(R_YD, j)] + lds[ri(R_VU, j)]));
-                    double rd = lds[ri(R_DV, j)] - lds[ri(R_S, j)];
-                    if (rs) {
-                        const double n = lds[ri(R_N, j)], pp = lds[ri(R_P, j)], zn = lds[ri(R_ZN, j)], zp = lds[ri(R_ZP, j)], rho_R = O.resto_penalty_parameter;
-                        rd += n - pp;
-                        d = fmax(d, fmax(fabs(rho_R + lds[ri(R_YD, j)] - zn), fabs(rho_R - lds[ri(R_YD, j)] - zp)));
-                        c = fmax(c, fmax(fabs(n * zn - mu), fabs(pp * zp - mu)));
-                        zsum += fabs(zn) + fabs(zp);
-                    }
-                    p = fmax(p, fabs(rd)); up = fmax(up, fabs(rd / dgd(j)));
-                    c = fmax(c, fabs((lds[ri(R_SU, j)] - lds[ri(R_S, j)]) * lds[ri(R_VU, j)] - mu));
-                    ysum += fabs(lds[ri(R_YD, j)]); zsum += fabs(lds[ri(R_VU, j)]);
-                }
-            }
         }
         if (lane == 0) SC_UNROLL for (int i = 0; i < NX; ++i) { const double r0 = fabs(x[i] - x0[i]); p = fmax(p, r0); up = fmax(up, r0); ysum += fabs(lds[L.Y0 + i]); }
-        dinf = cx.wmax(d); pinf = cx.wmax(p); comp = cx.wmax(c); un_pinf = cx.wmax(up);
+        const double c0 = act ? fmax(fabs(cmax), fabs(cmin)) : 0.0, cm = act ? fmax(fabs(cmax - mu), fabs(cmin - mu)) : 0.0;
+        dinf = cx.wmax(d); pinf = cx.wmax(p); comp0 = cx.wmax(c0); un_pinf = cx.wmax(up);
+        const double compm = cx.wmax(cm);
         ysum = cx.wsum(ysum); zsum = cx.wsum(zsum);
         const double m = (double)(NX * (N + 1) + N * K), nb = (double)(2 * (N + 1) + 4 * N + N * K * (rs ? 3 : 1));
         const double sd = fmax(O.s_max, (ysum + zsum) / (m + nb)) / O.s_max, sc = fmax(O.s_max, zsum / nb) / O.s_max;
-        Emu = fmax(fmax(dinf / sd, pinf), comp / sc);
+        E0 = fmax(fmax(dinf / sd, pinf), comp0 / sc);
+        Emu = fmax(fmax(dinf / sd, pinf), compm / sc);
     }
 
     // fraction to the boundary over my primal / dual variables; directional derivative of the barrier function along the step
-    SC_HD double ftb1(double tau, double sl, double dsl) const { return dsl < 0.0 ? fmin(1.0, -tau * sl / dsl) : 1.0; }
     SC_HD void step_lengths(const Eval2& E, double tau, double mu, double& a_max, double& a_z, double& gBD) const {
         double ap = 1.0, az = 1.0, v = 0.0;
         if (act) {
@@ -720,18 +747,7 @@ struct Wave {
                 az = fmin(az, ftb1(tau, zuL[j], dzuL[j])); az = fmin(az, ftb1(tau, zuU[j], dzuU[j]));
                 v += (E.gfu[j] - mu / (u[j] - ubL[j]) + mu / (ubU[j] - u[j])) * du[j];
             }
-            for (int j = 0; j < K; ++j) {
-                if (j < K) {
-                    ap = fmin(ap, ftb1(tau, lds[ri(R_SU, j)] - lds[ri(R_S, j)], -lds[ri(R_DS, j)])); az = fmin(az, ftb1(tau, lds[ri(R_VU, j)], lds[ri(R_DVU, j)]));
-                    v += (mu / (lds[ri(R_SU, j)] - lds[ri(R_S, j)]) - O.kappa_d * mu) * lds[ri(R_DS, j)];
-                    if (rs) {
-                        const double n = lds[ri(R_N, j)], p = lds[ri(R_P, j)], dn = lds[ri(R_DN, j)], dp = lds[ri(R_DP, j)], rho_R = O.resto_penalty_parameter;
-                        ap = fmin(ap, fmin(ftb1(tau, n, dn), ftb1(tau, p, dp)));
-                        az = fmin(az, fmin(ftb1(tau, lds[ri(R_ZN, j)], lds[ri(R_DZN, j)]), ftb1(tau, lds[ri(R_ZP, j)], lds[ri(R_DZP, j)])));
-                        v += (rho_R - mu / n + O.kappa_d * mu) * dn + (rho_R - mu / p + O.kappa_d * mu) * dp;
-                    }
-                }
-            }
+            ap = fmin(ap, sl_ap); az = fmin(az, sl_az); v += sl_v;                // (the rows: gathered by finish_step)
         }
         a_max = cx.wmin(ap); a_z = cx.wmin(az); gBD = cx.wsum(v);
     }
@@ -844,7 +860,7 @@ struct Wave {
                 if (lane == 0) SC_UNROLL for (int i = 0; i < NX; ++i) pm = fmax(pm, fabs(x[i] - x0[i]));
                 pm = cx.wmax(pm);
                 if (pm <= O.resto_failure_feasibility_threshold) { status = SC_STATUS_INACCURATE; break; }      // "called at a point that is almost feasible"
-                const double phi = barrier(fsum, x, u, mu);
+                const double phi = barrier(fsum, Bcur, mu);
                 filter_add(phi - O.gamma_phi * theta, (1.0 - O.gamma_theta) * theta);
                 o_nfilt = nfilt; o_nacc = n_acc; o_mu = mu; o_theta = theta; o_phi = phi; o_pinf = pm; o_dw_last = dw_last; o_theta_max = theta_max; o_theta_min = theta_min;
                 fpo = L.FP2; fto = L.FT2; nfilt = 0; n_acc = 0; dw_last = 0.0;
@@ -898,7 +914,7 @@ struct Wave {
                 }
                 if (dw > 0.0 && !ls) dw_last = dw;
                 last_dw = dw;
-                finish_step(ls, mu, dw);
+                finish_step(ls, mu, dw, tau);
                 DPROF_ADD(4)
                 if (ls) {
                     double ym = 0.0;
@@ -917,14 +933,16 @@ struct Wave {
                 // ---- filter line search ----
                 double a_max, a_z, gBD;
                 step_lengths(E, tau, mu, a_max, a_z, gBD);
-                const double phi = barrier(fsum, x, u, mu);
+                const double phi = barrier(fsum, Bcur, mu);
+                double pw_t, pw_g;                                          // theta^s_theta, (-gBD)^s_phi: the switching condition (19) and alpha_min (23)
+                cx.pow2(theta, O.s_theta, gBD < 0.0 ? -gBD : 1.0, O.s_phi, pw_t, pw_g);
                 double a_min = O.gamma_theta;
                 if (gBD < 0.0) {
                     a_min = fmin(a_min, O.gamma_phi * theta / (-gBD));
-                    if (theta <= theta_min) a_min = fmin(a_min, O.delta * pow(theta, O.s_theta) / pow(-gBD, O.s_phi));
+                    if (theta <= theta_min) a_min = fmin(a_min, O.delta * pw_t / pw_g);
                 }
                 a_min *= O.alpha_min_frac;
-                const double sw_l = gBD < 0.0 ? pow(-gBD, O.s_phi) : 0.0, sw_r = O.delta * pow(theta, O.s_theta);
+                const double sw_l = gBD < 0.0 ? pw_g : 0.0, sw_r = O.delta * pw_t;
                 double alpha = a_max;
                 bool first = true, accepted = false;
                 DPROF_ADD(5)
@@ -933,10 +951,11 @@ struct Wave {
                 while (alpha > a_min || first) {
                     SC_UNROLL for (int i = 0; i < NX; ++i) xt[i] = x[i] + alpha * dx[i];
                     SC_UNROLL for (int j = 0; j < NU; ++j) ut[j] = u[j] + alpha * du[j];
-                    safe_slacks(xt, ut, mu, alpha);
+                    safe_slacks_xu(xt, ut, mu);
                     double f_t;
-                    eval0(xt, ut, th_t, f_t, alpha);
-                    phi_t = barrier(f_t, xt, ut, mu, alpha);
+                    BarAcc Bt;
+                    eval0(xt, ut, th_t, f_t, Bt, mu, alpha, true);
+                    phi_t = barrier(f_t, Bt, mu);
                     if (phi_t < INFINITY && th_t == th_t && phi_t == phi_t) {
                         bool ok = th_t <= theta_max;
                         if (ok) {
@@ -970,24 +989,30 @@ struct Wave {
                 if (stg) SC_UNROLL for (int i = 0; i < NX; ++i) yc[i] += alpha * (lds[L.LAM + (k + 1) * 4 + i] / dgc(i));
                 if (lane == 0) SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.Y0 + i] += alpha * (-lds[L.LAM + i]);
                 SC_UNROLL for (int j = 0; j < NU; ++j) u[j] = ut[j];
-                if (stg) for (int j = 0; j < K; ++j) { lds[ri(R_S, j)] += alpha * lds[ri(R_DS, j)]; lds[ri(R_YD, j)] += alpha * lds[ri(R_DYD, j)]; }
-                safe_slacks(x, u, mu, 0.0);
-                // bound multipliers: z += a_z dz, then kappa_sigma
+                safe_slacks_xu(x, u, mu);
+                // bound multipliers: z += a_z dz, then kappa_sigma; the rows in ONE pass: slack, multiplier, safe slack, slack-bound multiplier (n, p)
                 {
-                    const double ks = O.kappa_sigma;
-                    auto upd = [&](double& z, double dz, double sl) { z += a_z * dz; z = fmax(fmin(z, ks * mu / sl), mu / (ks * sl)); };
+                    const double ks = O.kappa_sigma, ksm = ks * mu, mks = mu / ks;
+                    auto upd = [&](double& z, double dz, double sl) { const double is = 1.0 / sl; z += a_z * dz; z = fmax(fmin(z, ksm * is), mks * is); };
                     if (act) { upd(zxL, dzxL, x[3] - xbL); upd(zxU, dzxU, xbU - x[3]); }
                     if (stg) {
                         SC_UNROLL for (int j = 0; j < NU; ++j) { upd(zuL[j], dzuL[j], u[j] - ubL[j]); upd(zuU[j], dzuU[j], ubU[j] - u[j]); }
-                        for (int j = 0; j < K; ++j) { double z = lds[ri(R_VU, j)]; upd(z, lds[ri(R_DVU, j)], lds[ri(R_SU, j)] - lds[ri(R_S, j)]); lds[ri(R_VU, j)] = z; }
-                        if (rs) {
-                            for (int j = 0; j < K; ++j) {
-                                if (j < K) {
-                                    const double n = lds[ri(R_N, j)] + alpha * lds[ri(R_DN, j)], pp = lds[ri(R_P, j)] + alpha * lds[ri(R_DP, j)];
-                                    double zn = lds[ri(R_ZN, j)], zp = lds[ri(R_ZP, j)];
-                                    upd(zn, lds[ri(R_DZN, j)], n); upd(zp, lds[ri(R_DZP, j)], pp);
-                                    lds[ri(R_N, j)] = n; lds[ri(R_P, j)] = pp; lds[ri(R_ZN, j)] = zn; lds[ri(R_ZP, j)] = zp;
-                                }
+                        const double s_min = EPS_ * fmin(1.0, mu), move = 1.8189894035458565e-12;     // eps^(3/4)
+                        for (int j = 0; j < K; ++j) {
+                            const double sj = lds[ri(R_S, j)] + alpha * lds[ri(R_DS, j)];
+                            lds[ri(R_S, j)] = sj;
+                            lds[ri(R_YD, j)] += alpha * lds[ri(R_DYD, j)];
+                            double bj = lds[ri(R_SU, j)];
+                            safe1(sj, bj, false, s_min, move);
+                            lds[ri(R_SU, j)] = bj;
+                            double z = lds[ri(R_VU, j)];
+                            upd(z, lds[ri(R_DVU, j)], bj - sj);
+                            lds[ri(R_VU, j)] = z;
+                            if (rs) {
+                                const double n = lds[ri(R_N, j)] + alpha * lds[ri(R_DN, j)], pp = lds[ri(R_P, j)] + alpha * lds[ri(R_DP, j)];
+                                double zn = lds[ri(R_ZN, j)], zp = lds[ri(R_ZP, j)];
+                                upd(zn, lds[ri(R_DZN, j)], n); upd(zp, lds[ri(R_DZP, j)], pp);
+                                lds[ri(R_N, j)] = n; lds[ri(R_P, j)] = pp; lds[ri(R_ZN, j)] = zn; lds[ri(R_ZP, j)] = zp;
                             }
                         }
                     }
@@ -1000,8 +1025,8 @@ struct Wave {
             // ---- PH_START / PH_EVAL: errors, convergence, barrier parameter ----
             DPROF_ADD(0)
             if (phase == PH_START) { theta_max = (rs ? O.resto_theta_max_fact : O.theta_max_fact) * fmax(1.0, theta); theta_min = O.theta_min_fact * fmax(1.0, theta); }
-            double E0, dinf, pinf, comp, un_pinf;
-            errors(E, 0.0, E0, dinf, pinf, comp, un_pinf);
+            double E0, Emu, dinf, pinf, comp, un_pinf;
+            errors(E, mu, E0, Emu, dinf, pinf, comp, un_pinf);
             if (trace && lane == 0) {
                 double* t = trace + (size_t)(it < O.max_iter ? it : O.max_iter) * TRACE_W;
                 t[0] = E0; t[1] = dinf; t[2] = pinf; t[3] = comp; t[4] = mu; t[5] = theta; t[6] = last_dw; t[7] = rs ? -last_alpha : last_alpha;      // (a negative step length marks an iterate of the restoration)
@@ -1012,8 +1037,9 @@ struct Wave {
                 // started from, with the infeasibility down to kappa_resto of what it was; and the restoration's own convergence tests (unscaled problem)
                 double th_o = 0.0, f_o = 0.0, pm_o = 0.0;
                 rs = false;
-                eval0(x, u, th_o, f_o, 0.0, &pm_o);
-                const double phi_o = barrier(f_o, x, u, o_mu);
+                BarAcc Bo;
+                eval0(x, u, th_o, f_o, Bo, o_mu, 0.0, false, &pm_o);
+                const double phi_o = barrier(f_o, Bo, o_mu);
                 rs = true;
                 bool leave = !r_first && pm_o <= O.required_infeasibility_reduction * o_pinf && phi_o < INFINITY && phi_o == phi_o;
                 if (leave) {
@@ -1065,9 +1091,8 @@ struct Wave {
             }
             if (it >= O.max_iter) { status = SC_STATUS_INACCURATE; break; }
             if (O.stall_iter > 0 && n_tiny >= O.stall_iter) { status = SC_STATUS_INACCURATE; break; }       // (stall rule: see sc_ipopt_params)
-            for (;;) {
-                double Emu, a, b, c, d;
-                errors(E, mu, Emu, a, b, c, d);
+            for (bool again = false;; again = true) {
+                if (again) { double e0_, a, b, c, d; errors(E, mu, e0_, Emu, a, b, c, d); }     // (the barrier parameter went down: E_mu for the new one)
                 if (Emu > O.barrier_tol_factor * mu || mu <= mu_min) break;
                 const double mu_new = fmax(mu_min, fmin(O.mu_linear_decrease_factor * mu, pow(mu, O.mu_superlinear_decrease_power)));
                 if (mu_new == mu) break;

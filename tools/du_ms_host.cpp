@@ -24,6 +24,9 @@ struct HostCtx {
     Shared* sh;
     void sync() { pthread_barrier_wait(&sh->bar); }
     long long clock() const { return 0; }
+    void sincos(double a, double& s, double& c) const { s = std::sin(a); c = std::cos(a); }
+    void pow2(double x1, double e1, double x2, double e2, double& r1, double& r2) const { r1 = std::pow(x1, e1); r2 = std::pow(x2, e2); }
+    double rsqrt(double v) const { return 1.0 / std::sqrt(v); }
     template <typename F>
     double reduce(double v, F f) {
         pthread_barrier_wait(&sh->bar);
