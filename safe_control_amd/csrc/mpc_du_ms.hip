@@ -33,6 +33,18 @@ struct DevCtx {
         r1 = ipm::row_value(v, 0); r2 = ipm::row_value(v, 1);
     }
     __device__ __forceinline__ double rsqrt(double v) const { return ::rsqrt(v); }
+    // sum over the G (4 / 2 / 1) lanes of a group: DPP within the quad
+    template <int n>
+    __device__ __forceinline__ void gsum(double* v, int G) const {
+        if (G >= 2) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) v[i] += ipm::dpp_mv<0xB1>(v[i]);                   // quad_perm [1,0,3,2]
+        }
+        if (G == 4) {
+#pragma unroll
+            for (int i = 0; i < n; ++i) v[i] += ipm::dpp_mv<0x4E>(v[i]);                   // quad_perm [2,3,0,1]
+        }
+    }
     __device__ __forceinline__ double wsum(double v) const { return ipm::wsum(v); }
     __device__ __forceinline__ double wmax(double v) const { return ipm::wmax(v); }
     __device__ __forceinline__ double wmin(double v) const { return ipm::wmin(v); }
@@ -67,7 +79,7 @@ __global__ void __launch_bounds__(64, SC_DUMS_WAVES) mpcdu_ms_kernel(const Param
         status_out[b] = st;
         if (iters_out) iters_out[b] = it;
     }
-    if (plan_out && S.act) {
+    if (plan_out && S.acl) {
         // the plan: x_0 .. x_N (4 each), then u_0 .. u_{N-1} (2 each)
         TIO* po = plan_out + b * (long long)((P.N + 1) * NX + P.N * NU);
         for (int i = 0; i < NX; ++i) po[S.k * NX + i] = (TIO)S.x[i];

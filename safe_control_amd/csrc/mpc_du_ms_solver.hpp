@@ -211,6 +211,7 @@ SC_HD SC_DUMS_INLINE void riccati_forward(Cx& cx, const Lds& L, const int N, con
     }
 }
 
+SC_HD inline int group_lanes(int N) { return (N + 1) * 4 <= 64 ? 4 : ((N + 1) * 2 <= 64 ? 2 : 1); }
 SC_HD inline bool cmp_le(double lhs, double rhs, double bas) { return lhs - rhs <= 10.0 * EPS_ * fabs(bas); }
 
 template <class Cx>
@@ -221,7 +222,13 @@ struct Wave {
     typename Cx::ptr lds;
     const Lds L;
     const int lane, N, K;
-    const bool act, stg;               // lane owns a state (k <= N) / a stage with inputs and rows (k < N)
+    // G lanes per stage (4 while (N + 1) * 4 <= 64, else 2, else 1): they hold the stage's state in copies (same arithmetic, no exchange) and
+    // SPLIT ITS ROWS -- lane q of the group walks rows q, q + G, .. --; row sums that the stage needs as a whole (the condensed block, J'y) are
+    // added over the group (cx.gsum: DPP within a quad), everything else ends in a wave reduction anyway.  The group's first lane (`lead`)
+    // owns the stage's share of the wave sums and its LDS slots.
+    const int G, q;
+    const bool act, stg;               // lane belongs to a state (k <= N) / a stage with inputs and rows (k < N)
+    const bool acl, stl;               // ... and is the first lane of its group
     const int k;
     double x0[NX], uprev[NU], xg[2];
     double w0, w1, w2;
@@ -250,8 +257,10 @@ struct Wave {
     SC_HD double dr2(int i) const { const double a = fabs(lds[XRi(i)]); return a > 1.0 ? 1.0 / (a * a) : 1.0; }      // D_R^2 = 1 / max(1, |w_R|)^2
 
     SC_HD Wave(Cx& cx_, const Params& P_, const sc_ipopt_params& O_)
-        : cx(cx_), P(P_), O(O_), lds(cx_.lds), L(P_.N, P_.K), lane(cx_.lane), N(P_.N), K(P_.K), act(cx_.lane <= P_.N), stg(cx_.lane < P_.N),
-          k(cx_.lane <= P_.N ? cx_.lane : 0) {
+        : cx(cx_), P(P_), O(O_), lds(cx_.lds), L(P_.N, P_.K), lane(cx_.lane), N(P_.N), K(P_.K),
+          G(group_lanes(P_.N)), q(cx_.lane % group_lanes(P_.N)), act(cx_.lane / group_lanes(P_.N) <= P_.N), stg(cx_.lane / group_lanes(P_.N) < P_.N),
+          acl(cx_.lane / group_lanes(P_.N) <= P_.N && cx_.lane % group_lanes(P_.N) == 0), stl(cx_.lane / group_lanes(P_.N) < P_.N && cx_.lane % group_lanes(P_.N) == 0),
+          k(cx_.lane / group_lanes(P_.N) <= P_.N ? cx_.lane / group_lanes(P_.N) : 0) {
         const double g1 = P.alpha1 + P.alpha2, g2 = P.alpha1 * P.alpha2;
         w0 = 1.0 - g1 + g2; w1 = g1 - 2.0; w2 = 1.0;
         nfilt = 0; dw_last = 0.0; last_dw = 0.0; fpo = L.FP; fto = L.FT;
@@ -298,15 +307,15 @@ struct Wave {
     SC_HD double cost_share(const double* xs, const double* us, const double* um) const {
         double f = 0.0;
         if (rs) {                                                          // restoration: sum D_R^2 (w - w_R)^2 over my variables (x zeta / 2 in barrier())
-            if (act) SC_UNROLL for (int i = 0; i < NX; ++i) { const double d = xs[i] - lds[XRi(i)]; f += dr2(i) * d * d; }
-            if (stg) SC_UNROLL for (int j = 0; j < NU; ++j) { const double d = us[j] - lds[XRi(NX + j)]; f += dr2(NX + j) * d * d; }
+            if (acl) SC_UNROLL for (int i = 0; i < NX; ++i) { const double d = xs[i] - lds[XRi(i)]; f += dr2(i) * d * d; }
+            if (stl) SC_UNROLL for (int j = 0; j < NU; ++j) { const double d = us[j] - lds[XRi(NX + j)]; f += dr2(NX + j) * d * d; }
             return f;
         }
-        if (act) {
+        if (acl) {
             const double e0 = xs[0] - xg[0], e1 = xs[1] - xg[1];
             f = P.Q[0] * e0 * e0 + P.Q[1] * e1 * e1 + P.Q[2] * xs[2] * xs[2] + P.Q[3] * xs[3] * xs[3];
         }
-        if (stg) SC_UNROLL for (int j = 0; j < NU; ++j) { const double d = us[j] - um[j]; f += P.R[j] * d * d; }
+        if (stl) SC_UNROLL for (int j = 0; j < NU; ++j) { const double d = us[j] - um[j]; f += P.R[j] * d * d; }
         return f;
     }
     // Log-barrier terms of a point, gathered while its rows are walked (the objective / mu-independent part): the log of the product of every
@@ -314,16 +323,17 @@ struct Wave {
     // flushed every eight rows, every two inside the restoration where n and p ride along), the sum of the one-sided slacks (damping), n + p
     struct BarAcc {
         double prod, lg, sa, sn;
+        int nf;
         bool ok;
     };
     SC_HD void bar_begin(BarAcc& B, const double* xs, const double* us) const {
-        B.prod = 1.0; B.lg = 0.0; B.sa = 0.0; B.sn = 0.0; B.ok = true;
-        if (act) {
+        B.prod = 1.0; B.lg = 0.0; B.sa = 0.0; B.sn = 0.0; B.ok = true; B.nf = 0;
+        if (acl) {
             const double a = xs[3] - xbL, b = xbU - xs[3];
             if (!(a > 0.0) || !(b > 0.0)) B.ok = false;
             B.prod = a * b;
         }
-        if (stg) {
+        if (stl) {
             SC_UNROLL for (int j = 0; j < NU; ++j) {
                 const double a = us[j] - ubL[j], b = ubU[j] - us[j];
                 if (!(a > 0.0) || !(b > 0.0)) B.ok = false;
@@ -341,8 +351,8 @@ struct Wave {
             if (!(nt > 0.0) || !(pt_ > 0.0)) B.ok = false;
             B.sn += nt + pt_;
             B.prod *= nt * pt_;
-            if (j & 1) { B.lg += log(B.prod); B.prod = 1.0; }
-        } else if ((j & 7) == 7 && j + 1 < K) { B.lg += log(B.prod); B.prod = 1.0; }
+            if (++B.nf == 2) { B.lg += log(B.prod); B.prod = 1.0; B.nf = 0; }
+        } else if (++B.nf == 8) { B.lg += log(B.prod); B.prod = 1.0; B.nf = 0; }
     }
     // barrier function (scaled objective + log barrier of every bound + damping of the one-sided ones) from the gathered terms
     SC_HD double barrier(double fsum, BarAcc& B, double mu) const {
@@ -360,8 +370,8 @@ struct Wave {
     // the unscaled objective, the barrier terms; `safe`: IPOPT's safe-slack rule on the rows' slack bounds on the way; pmax (optional): largest residual
     SC_HD void eval0(const double* xs, const double* us, double& theta, double& fsum, BarAcc& B, double mu, double a_np, bool safe, double* pmax = nullptr) {
         sync();
-        if (act) SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.XS + k * 4 + i] = xs[i];
-        if (stg) SC_UNROLL for (int j = 0; j < NU; ++j) lds[L.US + (k + 1) * 2 + j] = us[j];
+        if (acl) SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.XS + k * 4 + i] = xs[i];
+        if (stl) SC_UNROLL for (int j = 0; j < NU; ++j) lds[L.US + (k + 1) * 2 + j] = us[j];
         if (lane == 0) SC_UNROLL for (int j = 0; j < NU; ++j) lds[L.US + j] = uprev[j];
         sync();
         double th = 0.0, pm = 0.0;
@@ -372,8 +382,8 @@ struct Wave {
             const double s_min = EPS_ * fmin(1.0, mu), move = 1.8189894035458565e-12;     // eps^(3/4)
             Geo g;
             geometry(xs, us, g);
-            SC_UNROLL for (int i = 0; i < NX; ++i) { const double r = fabs(dgc(i) * (g.F[i] - lds[L.XS + (k + 1) * 4 + i])); th += r; pm = fmax(pm, r); }
-            for (int j = 0; j < K; ++j) {
+            if (stl) SC_UNROLL for (int i = 0; i < NX; ++i) { const double r = fabs(dgc(i) * (g.F[i] - lds[L.XS + (k + 1) * 4 + i])); th += r; pm = fmax(pm, r); }
+            for (int j = q; j < K; j += G) {
                 const double sj = lds[ri(R_S, j)] + a_np * lds[ri(R_DS, j)];
                 double bj = lds[ri(R_SU, j)];
                 if (safe) { safe1(sj, bj, false, s_min, move); lds[ri(R_SU, j)] = bj; }
@@ -431,8 +441,8 @@ struct Wave {
     // exchange through LDS: x_{k+1} (XS), u_{k-1} / u_{k+1} (US, slot k + 1 = u_k, slot 0 = u_prev), multipliers of the rows that DEFINE x_k (YS, slot k)
     SC_HD void publish() {
         sync();
-        if (act) SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.XS + k * 4 + i] = x[i];
-        if (stg) {
+        if (acl) SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.XS + k * 4 + i] = x[i];
+        if (stl) {
             SC_UNROLL for (int j = 0; j < NU; ++j) lds[L.US + (k + 1) * 2 + j] = u[j];
             SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.YS + (k + 1) * 4 + i] = dgc(i) * yc[i];
         }
@@ -440,7 +450,7 @@ struct Wave {
             SC_UNROLL for (int j = 0; j < NU; ++j) lds[L.US + j] = uprev[j];
             SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.YS + i] = -lds[L.Y0 + i];
         }
-        if (lane == N) SC_UNROLL for (int j = 0; j < NU; ++j) lds[L.US + (N + 1) * 2 + j] = 0.0;
+        if (acl && k == N) SC_UNROLL for (int j = 0; j < NU; ++j) lds[L.US + (N + 1) * 2 + j] = 0.0;
         sync();
     }
 
@@ -497,108 +507,110 @@ struct Wave {
                 }
             }
         }
+        // my share of the stage's rows (lane q of the group walks rows q, q + G, ..); the sums the stage needs as a whole -- J'y, and for the
+        // recursion the condensed block and gradient, the multiplier sums of the curvature terms -- are added over the group afterwards
+        double acc[36];                                                     // jr (6) | M (21) | gv (6) | sl, socx, socy
+        SC_UNROLL for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+        double* const jr = acc; double* const M = acc + 6; double* const gv = acc + 27;
+        Geo g;
+        double wy[NX] = {0.0, 0.0, 0.0, 0.0};
         if (stg) {
-            Geo g;
             geometry(x, u, g);
             tc_ = g.c; ts_ = g.s; tc1_ = g.c1; ts1_ = g.s1;
-            SC_UNROLL for (int i = 0; i < NX; ++i) { rc[i] = dgc(i) * (g.F[i] - lds[L.XS + (k + 1) * 4 + i]); th += fabs(rc[i]); }
-            if (build) { lds[L.AB + k * 4 + 0] = g.a02; lds[L.AB + k * 4 + 1] = g.a03; lds[L.AB + k * 4 + 2] = g.a12; lds[L.AB + k * 4 + 3] = g.a13; }
+            SC_UNROLL for (int i = 0; i < NX; ++i) { rc[i] = dgc(i) * (g.F[i] - lds[L.XS + (k + 1) * 4 + i]); if (stl) th += fabs(rc[i]); }
+            if (build && stl) { lds[L.AB + k * 4 + 0] = g.a02; lds[L.AB + k * 4 + 1] = g.a03; lds[L.AB + k * 4 + 2] = g.a12; lds[L.AB + k * 4 + 3] = g.a13; }
             // J' y of my dynamics rows: [A | B]' (dgc yc)
-            double wy[NX];
             SC_UNROLL for (int i = 0; i < NX; ++i) wy[i] = dgc(i) * yc[i];
             E.Jty[0] += wy[0]; E.Jty[1] += wy[1];
             E.Jty[2] += g.a02 * wy[0] + g.a12 * wy[1] + wy[2];
             E.Jty[3] += g.a03 * wy[0] + g.a13 * wy[1] + wy[3];
             E.Jty[4] += dt * wy[3]; E.Jty[5] += dt * wy[2];
-            // rows
-            double M[21], gv[NV], sl = 0.0, socx = 0.0, socy = 0.0;
-            SC_UNROLL for (int i = 0; i < 21; ++i) M[i] = 0.0;
-            SC_UNROLL for (int i = 0; i < NV; ++i) gv[i] = 0.0;
-            for (int j = 0; j < K; ++j) {
-                if (j < K) {
-                    double a[NV];
-                    const double cv = row(x, g, j, a);
-                    const double sc = dgd(j);
-                    lds[ri(R_DV, j)] = -sc * cv;
-                    const double rd = lds[ri(R_DV, j)] - lds[ri(R_S, j)] + (rs ? lds[ri(R_N, j)] - lds[ri(R_P, j)] : 0.0);
-                    th += fabs(rd);
-                    bar_row(Bcur, j, lds[ri(R_SU, j)] - lds[ri(R_S, j)], 0.0);
-                    {
-                        const double ydj = lds[ri(R_YD, j)], vUj = lds[ri(R_VU, j)], cp = (lds[ri(R_SU, j)] - lds[ri(R_S, j)]) * vUj;
-                        Ecur.d = fmax(Ecur.d, fabs(-ydj + vUj));
-                        Ecur.p = fmax(Ecur.p, fabs(rd)); Ecur.up = fmax(Ecur.up, fabs(rd / sc));
-                        Ecur.cmin = fmin(Ecur.cmin, cp); Ecur.cmax = fmax(Ecur.cmax, cp);
-                        Ecur.ysum += fabs(ydj); Ecur.zsum += fabs(vUj);
-                        if (rs) {
-                            const double n = lds[ri(R_N, j)], pp = lds[ri(R_P, j)], zn = lds[ri(R_ZN, j)], zp = lds[ri(R_ZP, j)], rho_R = O.resto_penalty_parameter;
-                            Ecur.d = fmax(Ecur.d, fmax(fabs(rho_R + ydj - zn), fabs(rho_R - ydj - zp)));
-                            Ecur.cmin = fmin(Ecur.cmin, fmin(n * zn, pp * zp)); Ecur.cmax = fmax(Ecur.cmax, fmax(n * zn, pp * zp));
-                            Ecur.zsum += fabs(zn) + fabs(zp);
-                        }
-                    }
-                    const double om = sc * lds[ri(R_YD, j)];                                   // weight of grad^2 (-cbf_j) in the Hessian of the Lagrangian
-                    SC_UNROLL for (int i = 0; i < NV; ++i) E.Jty[i] -= om * a[i];             // yd_j * grad d_j = -om grad cbf_j
-                    sl += om; socx += om * lds[L.OB + 3 * j]; socy += om * lds[L.OB + 3 * j + 1];
-                    if (build) {
-                        double Ej, bd;
-                        if (ls) { Ej = 1.0; bd = -lds[ri(R_VU, j)]; }                           // q = 1, rhs_t = -(0 + vU), rhs_g = 0: b = q rhs_t
-                        else if (rs) { const RowW w = row_weights(j, mu, dw); Ej = w.E; bd = w.b; }
-                        else {
-                            const double stU = lds[ri(R_SU, j)] - lds[ri(R_S, j)];
-                            Ej = lds[ri(R_VU, j)] / stU + dw;
-                            const double gt = mu / stU - O.kappa_d * mu;
-                            bd = -rd + (lds[ri(R_YD, j)] - gt) / Ej;
-                        }
-                        // row gradient = -sc a:  H += E (sc a)(sc a)',  g += E b sc a
-                        const double ea = Ej * sc * sc, eb = Ej * bd * sc;
-                        int e = 0;
-                        SC_UNROLL for (int p = 0; p < NV; ++p) {
-                            gv[p] += eb * a[p];
-                            SC_UNROLL for (int q = p; q < NV; ++q, ++e) M[e] += ea * a[p] * a[q];
-                        }
+            for (int j = q; j < K; j += G) {
+                double a[NV];
+                const double cv = row(x, g, j, a);
+                const double sc = dgd(j);
+                const double dvj = -sc * cv, sj = lds[ri(R_S, j)], stU = lds[ri(R_SU, j)] - sj, ydj = lds[ri(R_YD, j)], vUj = lds[ri(R_VU, j)];
+                lds[ri(R_DV, j)] = dvj;
+                const double rd = dvj - sj + (rs ? lds[ri(R_N, j)] - lds[ri(R_P, j)] : 0.0);
+                th += fabs(rd);
+                bar_row(Bcur, j, stU, 0.0);
+                {
+                    const double cp = stU * vUj;
+                    Ecur.d = fmax(Ecur.d, fabs(-ydj + vUj));
+                    Ecur.p = fmax(Ecur.p, fabs(rd)); Ecur.up = fmax(Ecur.up, fabs(rd / sc));
+                    Ecur.cmin = fmin(Ecur.cmin, cp); Ecur.cmax = fmax(Ecur.cmax, cp);
+                    Ecur.ysum += fabs(ydj); Ecur.zsum += fabs(vUj);
+                    if (rs) {
+                        const double n = lds[ri(R_N, j)], pp = lds[ri(R_P, j)], zn = lds[ri(R_ZN, j)], zp = lds[ri(R_ZP, j)], rho_R = O.resto_penalty_parameter;
+                        Ecur.d = fmax(Ecur.d, fmax(fabs(rho_R + ydj - zn), fabs(rho_R - ydj - zp)));
+                        Ecur.cmin = fmin(Ecur.cmin, fmin(n * zn, pp * zp)); Ecur.cmax = fmax(Ecur.cmax, fmax(n * zn, pp * zp));
+                        Ecur.zsum += fabs(zn) + fabs(zp);
                     }
                 }
-            }
-            if (build) {
-                if (!ls) {
-                    // curvature of the Lagrangian: dynamics rows (weights dgc y on F_0, F_1, which are p1) and the rows' -cbf_j (weights om_j):
-                    //   -2 sl sum_p w_p Jp' Jp  -  2 sum_p w_p (S_p,x grad^2 p_p,x + S_p,y grad^2 p_p,y),   S_p = sum_j om_j (p_p - c_j) = sl p_p - soc
-                    const double s1x = sl * g.p1[0] - socx, s1y = sl * g.p1[1] - socy, s2x = sl * g.p2[0] - socx, s2y = sl * g.p2[1] - socy;
-                    const double nx_ = wy[0] - 2.0 * w1 * s1x - 2.0 * w2 * s2x, ny_ = wy[1] - 2.0 * w1 * s1y - 2.0 * w2 * s2y;    // on grad^2 p1
-                    const double kx = -2.0 * w2 * s2x, ky = -2.0 * w2 * s2y;                                                        // on grad^2 (p2 - p1)
-                    const double v = x[3], v1 = g.v1, c = g.c, s_ = g.s, c1 = g.c1, s1 = g.s1, dt2 = dt * dt, dt3 = dt2 * dt;
-                    M[sym6(2, 2)] += nx_ * (-dt * v * c) + ny_ * (-dt * v * s_) + kx * (-dt * v1 * c1) + ky * (-dt * v1 * s1);
-                    M[sym6(2, 3)] += nx_ * (-dt * s_) + ny_ * (dt * c) + kx * (-dt * s1) + ky * (dt * c1);
-                    M[sym6(2, 4)] += kx * (-dt2 * s1) + ky * (dt2 * c1);
-                    M[sym6(2, 5)] += kx * (-dt2 * v1 * c1) + ky * (-dt2 * v1 * s1);
-                    M[sym6(3, 5)] += kx * (-dt2 * s1) + ky * (dt2 * c1);
-                    M[sym6(4, 5)] += kx * (-dt3 * s1) + ky * (dt3 * c1);
-                    M[sym6(5, 5)] += kx * (-dt3 * v1 * c1) + ky * (-dt3 * v1 * s1);
-                    // -2 sl (w0 J0'J0 + w1 J1'J1 + w2 J2'J2): J0 = [e_0; e_1], J1 = J0 + [a0.; a1.] on (theta, v), J2 = J1 + [g..] on (theta, v, a, omega)
-                    const double o0 = -2.0 * sl * w0, o1 = -2.0 * sl * w1, o2 = -2.0 * sl * w2;
-                    const double j1x[NV] = {1.0, 0.0, g.a02, g.a03, 0.0, 0.0}, j1y[NV] = {0.0, 1.0, g.a12, g.a13, 0.0, 0.0};
-                    const double j2x[NV] = {1.0, 0.0, g.a02 + g.g02, g.a03 + g.g03, dt * g.g03, dt * g.g02};
-                    const double j2y[NV] = {0.0, 1.0, g.a12 + g.g12, g.a13 + g.g13, dt * g.g13, dt * g.g12};
-                    M[sym6(0, 0)] += o0; M[sym6(1, 1)] += o0;
+                const double om = sc * ydj;                                         // weight of grad^2 (-cbf_j) in the Hessian of the Lagrangian
+                SC_UNROLL for (int i = 0; i < NV; ++i) jr[i] += om * a[i];             // yd_j * grad d_j = -om grad cbf_j
+                acc[33] += om; acc[34] += om * lds[L.OB + 3 * j]; acc[35] += om * lds[L.OB + 3 * j + 1];
+                if (build) {
+                    double Ej, bd;
+                    if (ls) { Ej = 1.0; bd = -vUj; }                                 // q = 1, rhs_t = -(0 + vU), rhs_g = 0: b = q rhs_t
+                    else if (rs) { const RowW w = row_weights(j, mu, dw); Ej = w.E; bd = w.b; }
+                    else {
+                        Ej = vUj / stU + dw;
+                        const double gt = mu / stU - O.kappa_d * mu;
+                        bd = -rd + (ydj - gt) / Ej;
+                    }
+                    // row gradient = -sc a:  H += E (sc a)(sc a)',  g += E b sc a
+                    const double ea = Ej * sc * sc, eb = Ej * bd * sc;
                     int e = 0;
-                    SC_UNROLL for (int p = 0; p < NV; ++p)
-                        SC_UNROLL for (int q = p; q < NV; ++q, ++e) M[e] += o1 * (j1x[p] * j1x[q] + j1y[p] * j1y[q]) + o2 * (j2x[p] * j2x[q] + j2y[p] * j2y[q]);
+                    SC_UNROLL for (int p = 0; p < NV; ++p) {
+                        gv[p] += eb * a[p];
+                        SC_UNROLL for (int r_ = p; r_ < NV; ++r_, ++e) M[e] += ea * a[p] * a[r_];
+                    }
                 }
-                int e = 0;
-                SC_UNROLL for (int p = 0; p < NV; ++p) {
-                    SC_UNROLL for (int q = p; q < NV; ++q, ++e) lds[L.H + k * 21 + e] = M[e] + (p == q ? dg_[p] : 0.0);
-                    lds[L.G + k * 6 + p] = gb[p] + gv[p] + (p < NX ? E.gfx[p] : E.gfu[p - NX]) + (ls ? 0.0 : E.Jty[p]);
-                }
-                // defects (unscaled) of my dynamics rows -> C[k + 1] = rc / dgc (ls: 0)
-                SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.C + (k + 1) * 4 + i] = ls ? 0.0 : rc[i] / dgc(i);
             }
         } else {
             SC_UNROLL for (int i = 0; i < NX; ++i) rc[i] = 0.0;
-            if (build && lane == N) {                                       // terminal state: diagonal block, gradient
-                SC_UNROLL for (int a = 0; a < NX; ++a) {
-                    SC_UNROLL for (int b = a; b < NX; ++b) lds[L.H + N * 21 + sym6(a, b)] = a == b ? dg_[a] : 0.0;
-                    lds[L.G + N * 6 + a] = gb[a] + E.gfx[a] + (ls ? 0.0 : E.Jty[a]);
-                }
+        }
+        if (build) cx.template gsum<36>(acc, G); else cx.template gsum<6>(acc, G);
+        SC_UNROLL for (int i = 0; i < NV; ++i) E.Jty[i] -= jr[i];
+        if (build && stl) {
+            const double sl = acc[33], socx = acc[34], socy = acc[35];
+            if (!ls) {
+                // curvature of the Lagrangian: dynamics rows (weights dgc y on F_0, F_1, which are p1) and the rows' -cbf_j (weights om_j):
+                //   -2 sl sum_p w_p Jp' Jp  -  2 sum_p w_p (S_p,x grad^2 p_p,x + S_p,y grad^2 p_p,y),   S_p = sum_j om_j (p_p - c_j) = sl p_p - soc
+                const double s1x = sl * g.p1[0] - socx, s1y = sl * g.p1[1] - socy, s2x = sl * g.p2[0] - socx, s2y = sl * g.p2[1] - socy;
+                const double nx_ = wy[0] - 2.0 * w1 * s1x - 2.0 * w2 * s2x, ny_ = wy[1] - 2.0 * w1 * s1y - 2.0 * w2 * s2y;    // on grad^2 p1
+                const double kx = -2.0 * w2 * s2x, ky = -2.0 * w2 * s2y;                                                        // on grad^2 (p2 - p1)
+                const double v = x[3], v1 = g.v1, c = g.c, s_ = g.s, c1 = g.c1, s1 = g.s1, dt2 = dt * dt, dt3 = dt2 * dt;
+                M[sym6(2, 2)] += nx_ * (-dt * v * c) + ny_ * (-dt * v * s_) + kx * (-dt * v1 * c1) + ky * (-dt * v1 * s1);
+                M[sym6(2, 3)] += nx_ * (-dt * s_) + ny_ * (dt * c) + kx * (-dt * s1) + ky * (dt * c1);
+                M[sym6(2, 4)] += kx * (-dt2 * s1) + ky * (dt2 * c1);
+                M[sym6(2, 5)] += kx * (-dt2 * v1 * c1) + ky * (-dt2 * v1 * s1);
+                M[sym6(3, 5)] += kx * (-dt2 * s1) + ky * (dt2 * c1);
+                M[sym6(4, 5)] += kx * (-dt3 * s1) + ky * (dt3 * c1);
+                M[sym6(5, 5)] += kx * (-dt3 * v1 * c1) + ky * (-dt3 * v1 * s1);
+                // -2 sl (w0 J0'J0 + w1 J1'J1 + w2 J2'J2): J0 = [e_0; e_1], J1 = J0 + [a0.; a1.] on (theta, v), J2 = J1 + [g..] on (theta, v, a, omega)
+                const double o0 = -2.0 * sl * w0, o1 = -2.0 * sl * w1, o2 = -2.0 * sl * w2;
+                const double j1x[NV] = {1.0, 0.0, g.a02, g.a03, 0.0, 0.0}, j1y[NV] = {0.0, 1.0, g.a12, g.a13, 0.0, 0.0};
+                const double j2x[NV] = {1.0, 0.0, g.a02 + g.g02, g.a03 + g.g03, dt * g.g03, dt * g.g02};
+                const double j2y[NV] = {0.0, 1.0, g.a12 + g.g12, g.a13 + g.g13, dt * g.g13, dt * g.g12};
+                M[sym6(0, 0)] += o0; M[sym6(1, 1)] += o0;
+                int e = 0;
+                SC_UNROLL for (int p = 0; p < NV; ++p)
+                    SC_UNROLL for (int r_ = p; r_ < NV; ++r_, ++e) M[e] += o1 * (j1x[p] * j1x[r_] + j1y[p] * j1y[r_]) + o2 * (j2x[p] * j2x[r_] + j2y[p] * j2y[r_]);
+            }
+            int e = 0;
+            SC_UNROLL for (int p = 0; p < NV; ++p) {
+                SC_UNROLL for (int r_ = p; r_ < NV; ++r_, ++e) lds[L.H + k * 21 + e] = M[e] + (p == r_ ? dg_[p] : 0.0);
+                lds[L.G + k * 6 + p] = gb[p] + gv[p] + (p < NX ? E.gfx[p] : E.gfu[p - NX]) + (ls ? 0.0 : E.Jty[p]);
+            }
+            // defects (unscaled) of my dynamics rows -> C[k + 1] = rc / dgc (ls: 0)
+            SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.C + (k + 1) * 4 + i] = ls ? 0.0 : rc[i] / dgc(i);
+        }
+        if (build && acl && k == N) {                                       // terminal state: diagonal block, gradient
+            SC_UNROLL for (int a = 0; a < NX; ++a) {
+                SC_UNROLL for (int b = a; b < NX; ++b) lds[L.H + N * 21 + sym6(a, b)] = a == b ? dg_[a] : 0.0;
+                lds[L.G + N * 6 + a] = gb[a] + E.gfx[a] + (ls ? 0.0 : E.Jty[a]);
             }
         }
         if (lane == 0) {
@@ -624,7 +636,7 @@ struct Wave {
         }
         // lam_k = (P_k xi_k + p_k)_x with the x rows of P_k where riccati_backward left them; the terminal stage: lam_N = H_N dx_N + g_N
         sync();
-        if (act) {
+        if (acl) {
             if (k < N) {
                 const typename Cx::ptr px = lds + L.PX + k * 28;
                 SC_UNROLL for (int a = 0; a < NX; ++a) {
@@ -649,7 +661,7 @@ struct Wave {
             Geo g;
             geometry(x, u, g, true);
             const double dz[NV] = {dx[0], dx[1], dx[2], dx[3], du[0], du[1]};
-            for (int j = 0; j < K; ++j) {
+            for (int j = q; j < K; j += G) {
                 double a[NV];
                 row(x, g, j, a);
                 double adw = 0.0;
@@ -702,7 +714,7 @@ struct Wave {
     // barrier parameter comes without another pass over the rows.  errors() adds the x / u share and the wave reductions.
     SC_HD void errors(const Eval2& E, double mu, double& E0, double& Emu, double& dinf, double& pinf, double& comp0, double& un_pinf) const {
         double d = Ecur.d, p = Ecur.p, up = Ecur.up, cmin = Ecur.cmin, cmax = Ecur.cmax, ysum = Ecur.ysum, zsum = Ecur.zsum;
-        if (act) {
+        if (acl) {
             double gl[NX];
             SC_UNROLL for (int i = 0; i < NX; ++i) gl[i] = E.gfx[i] + E.Jty[i];
             gl[3] += -zxL + zxU;
@@ -711,7 +723,7 @@ struct Wave {
             cmin = fmin(cmin, fmin(c1, c2)); cmax = fmax(cmax, fmax(c1, c2));
             zsum += fabs(zxL) + fabs(zxU);
         }
-        if (stg) {
+        if (stl) {
             SC_UNROLL for (int j = 0; j < NU; ++j) {
                 d = fmax(d, fabs(E.gfu[j] + E.Jty[4 + j] - zuL[j] + zuU[j]));
                 const double c1 = (u[j] - ubL[j]) * zuL[j], c2 = (ubU[j] - u[j]) * zuU[j];
@@ -721,7 +733,8 @@ struct Wave {
             SC_UNROLL for (int i = 0; i < NX; ++i) { p = fmax(p, fabs(rc[i])); up = fmax(up, fabs(rc[i] / dgc(i))); ysum += fabs(yc[i]); }
         }
         if (lane == 0) SC_UNROLL for (int i = 0; i < NX; ++i) { const double r0 = fabs(x[i] - x0[i]); p = fmax(p, r0); up = fmax(up, r0); ysum += fabs(lds[L.Y0 + i]); }
-        const double c0 = act ? fmax(fabs(cmax), fabs(cmin)) : 0.0, cm = act ? fmax(fabs(cmax - mu), fabs(cmin - mu)) : 0.0;
+        const bool any = act && cmax >= cmin;                               // (a lane without a product of its own: nothing to report)
+        const double c0 = any ? fmax(fabs(cmax), fabs(cmin)) : 0.0, cm = any ? fmax(fabs(cmax - mu), fabs(cmin - mu)) : 0.0;
         dinf = cx.wmax(d); pinf = cx.wmax(p); comp0 = cx.wmax(c0); un_pinf = cx.wmax(up);
         const double compm = cx.wmax(cm);
         ysum = cx.wsum(ysum); zsum = cx.wsum(zsum);
@@ -734,20 +747,20 @@ struct Wave {
     // fraction to the boundary over my primal / dual variables; directional derivative of the barrier function along the step
     SC_HD void step_lengths(const Eval2& E, double tau, double mu, double& a_max, double& a_z, double& gBD) const {
         double ap = 1.0, az = 1.0, v = 0.0;
-        if (act) {
+        if (acl) {
             const double a = x[3] - xbL, b = xbU - x[3];
             ap = fmin(ap, fmin(ftb1(tau, a, dx[3]), ftb1(tau, b, -dx[3])));
             az = fmin(az, fmin(ftb1(tau, zxL, dzxL), ftb1(tau, zxU, dzxU)));
             SC_UNROLL for (int i = 0; i < NX; ++i) v += E.gfx[i] * dx[i];
             v += (-mu / a + mu / b) * dx[3];
         }
-        if (stg) {
+        if (stg) { ap = fmin(ap, sl_ap); az = fmin(az, sl_az); v += sl_v; }      // (my rows: gathered by finish_step)
+        if (stl) {
             SC_UNROLL for (int j = 0; j < NU; ++j) {
                 ap = fmin(ap, ftb1(tau, u[j] - ubL[j], du[j])); ap = fmin(ap, ftb1(tau, ubU[j] - u[j], -du[j]));
                 az = fmin(az, ftb1(tau, zuL[j], dzuL[j])); az = fmin(az, ftb1(tau, zuU[j], dzuU[j]));
                 v += (E.gfu[j] - mu / (u[j] - ubL[j]) + mu / (ubU[j] - u[j])) * du[j];
             }
-            ap = fmin(ap, sl_ap); az = fmin(az, sl_az); v += sl_v;                // (the rows: gathered by finish_step)
         }
         a_max = cx.wmin(ap); a_z = cx.wmin(az); gBD = cx.wsum(v);
     }
@@ -790,7 +803,7 @@ struct Wave {
         // ---- start: x_k = x0, u_k = u_prev (set_initial_guess); scaling at that point; bounds relaxed; push ----
         SC_UNROLL for (int i = 0; i < NX; ++i) { x[i] = x0[i]; yc[i] = 0.0; dx[i] = 0.0; }
         SC_UNROLL for (int j = 0; j < NU; ++j) { u[j] = uprev[j]; du[j] = 0.0; dvv[j] = 0.0; }
-        if (stg) for (int j = 0; j < K; ++j) { lds[ri(R_S, j)] = 0.0; lds[ri(R_YD, j)] = 0.0; lds[ri(R_VU, j)] = 1.0; lds[ri(R_SU, j)] = rl; lds[ri(R_DS, j)] = 0.0; lds[ri(R_DYD, j)] = 0.0; lds[ri(R_DVU, j)] = 0.0; lds[ri(R_DV, j)] = 0.0; }
+        if (stg) for (int j = q; j < K; j += G) { lds[ri(R_S, j)] = 0.0; lds[ri(R_YD, j)] = 0.0; lds[ri(R_VU, j)] = 1.0; lds[ri(R_SU, j)] = rl; lds[ri(R_DS, j)] = 0.0; lds[ri(R_DYD, j)] = 0.0; lds[ri(R_DVU, j)] = 0.0; lds[ri(R_DV, j)] = 0.0; }
         xbL = -P.v_max - rl * fmax(1.0, fabs(P.v_max)); xbU = P.v_max + rl * fmax(1.0, fabs(P.v_max)); zxL = 1.0; zxU = 1.0; dzxL = dzxU = 0.0;
         SC_UNROLL for (int j = 0; j < NU; ++j) {
             ubL[j] = P.u_lo[j] - rl * fmax(1.0, fabs(P.u_lo[j])); ubU[j] = P.u_hi[j] + rl * fmax(1.0, fabs(P.u_hi[j]));
@@ -855,7 +868,7 @@ struct Wave {
                 double pm = 0.0;
                 if (stg) {
                     SC_UNROLL for (int i = 0; i < NX; ++i) pm = fmax(pm, fabs(rc[i]));
-                    for (int j = 0; j < K; ++j) if (j < K) pm = fmax(pm, fabs(lds[ri(R_DV, j)] - lds[ri(R_S, j)]));
+                    for (int j = q; j < K; j += G) if (j < K) pm = fmax(pm, fabs(lds[ri(R_DV, j)] - lds[ri(R_S, j)]));
                 }
                 if (lane == 0) SC_UNROLL for (int i = 0; i < NX; ++i) pm = fmax(pm, fabs(x[i] - x0[i]));
                 pm = cx.wmax(pm);
@@ -868,12 +881,12 @@ struct Wave {
                 zeta = O.resto_proximity_weight * sqrt(mu);
                 const double rho_R = O.resto_penalty_parameter;
                 if (act) {
-                    SC_UNROLL for (int i = 0; i < NX; ++i) lds[XRi(i)] = x[i];
+                    if (acl) SC_UNROLL for (int i = 0; i < NX; ++i) lds[XRi(i)] = x[i];
                     zxL = fmin(rho_R, zxL); zxU = fmin(rho_R, zxU);
                 }
                 if (stg) {
-                    SC_UNROLL for (int j = 0; j < NU; ++j) { lds[XRi(NX + j)] = u[j]; zuL[j] = fmin(rho_R, zuL[j]); zuU[j] = fmin(rho_R, zuU[j]); }
-                    for (int j = 0; j < K; ++j) {
+                    SC_UNROLL for (int j = 0; j < NU; ++j) { if (stl) lds[XRi(NX + j)] = u[j]; zuL[j] = fmin(rho_R, zuL[j]); zuU[j] = fmin(rho_R, zuU[j]); }
+                    for (int j = q; j < K; j += G) {
                         if (j < K) {                                        // eq. (33): the n, p >= 0 that minimise rho (n + p) - mu (log n + log p) on  r + n - p = 0
                             const double r = lds[ri(R_DV, j)] - lds[ri(R_S, j)], a = (mu - rho_R * r) / (2.0 * rho_R);
                             const double n = a + sqrt(a * a + mu * r / (2.0 * rho_R)), pp = r + n;
@@ -892,7 +905,7 @@ struct Wave {
             DPROF_T0
             eval2(build, ls, E, mu, dw, theta, fsum);
             if (phase == PH_INIT) {
-                if (stg) for (int j = 0; j < K; ++j) { double v = lds[ri(R_DV, j)]; push1(v, 0.0, lds[ri(R_SU, j)], false, true); lds[ri(R_S, j)] = v; }
+                if (stg) for (int j = q; j < K; j += G) { double v = lds[ri(R_DV, j)]; push1(v, 0.0, lds[ri(R_SU, j)], false, true); lds[ri(R_S, j)] = v; }
                 phase = PH_LS; dw = 0.0; ic_first = true;
                 continue;
             }
@@ -920,12 +933,12 @@ struct Wave {
                     double ym = 0.0;
                     if (stg) SC_UNROLL for (int i = 0; i < NX; ++i) ym = fmax(ym, fabs(lds[L.LAM + (k + 1) * 4 + i] / dgc(i)));
                     if (lane == 0) SC_UNROLL for (int i = 0; i < NX; ++i) ym = fmax(ym, fabs(lds[L.LAM + i]));
-                    if (stg) for (int j = 0; j < K; ++j) ym = fmax(ym, fabs(lds[ri(R_DYD, j)]));
+                    if (stg) for (int j = q; j < K; j += G) ym = fmax(ym, fabs(lds[ri(R_DYD, j)]));
                     ym = cx.wmax(ym);
                     if (ym <= O.constr_mult_init_max) {
                         if (stg) SC_UNROLL for (int i = 0; i < NX; ++i) yc[i] = lds[L.LAM + (k + 1) * 4 + i] / dgc(i);
                         if (lane == 0) SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.Y0 + i] = -lds[L.LAM + i];
-                        if (stg) for (int j = 0; j < K; ++j) lds[ri(R_YD, j)] = lds[ri(R_DYD, j)];
+                        if (stg) for (int j = q; j < K; j += G) lds[ri(R_YD, j)] = lds[ri(R_DYD, j)];
                     }
                     phase = PH_START;
                     continue;
@@ -998,7 +1011,7 @@ struct Wave {
                     if (stg) {
                         SC_UNROLL for (int j = 0; j < NU; ++j) { upd(zuL[j], dzuL[j], u[j] - ubL[j]); upd(zuU[j], dzuU[j], ubU[j] - u[j]); }
                         const double s_min = EPS_ * fmin(1.0, mu), move = 1.8189894035458565e-12;     // eps^(3/4)
-                        for (int j = 0; j < K; ++j) {
+                        for (int j = q; j < K; j += G) {
                             const double sj = lds[ri(R_S, j)] + alpha * lds[ri(R_DS, j)];
                             lds[ri(R_S, j)] = sj;
                             lds[ri(R_YD, j)] += alpha * lds[ri(R_DYD, j)];
@@ -1059,16 +1072,16 @@ struct Wave {
                     if (act) zm = fmax(zxL, zxU);
                     if (stg) {
                         SC_UNROLL for (int j = 0; j < NU; ++j) zm = fmax(zm, fmax(zuL[j], zuU[j]));
-                        for (int j = 0; j < K; ++j) if (j < K) zm = fmax(zm, lds[ri(R_VU, j)]);
+                        for (int j = q; j < K; j += G) if (j < K) zm = fmax(zm, lds[ri(R_VU, j)]);
                     }
                     zm = cx.wmax(zm);
                     if (zm > O.bound_mult_reset_threshold) {
                         zxL = zxU = 1.0;
                         SC_UNROLL for (int j = 0; j < NU; ++j) { zuL[j] = 1.0; zuU[j] = 1.0; }
-                        if (stg) for (int j = 0; j < K; ++j) lds[ri(R_VU, j)] = 1.0;
+                        if (stg) for (int j = q; j < K; j += G) lds[ri(R_VU, j)] = 1.0;
                     }
                     SC_UNROLL for (int i = 0; i < NX; ++i) yc[i] = 0.0;
-                    if (stg) for (int j = 0; j < K; ++j) lds[ri(R_YD, j)] = 0.0;
+                    if (stg) for (int j = q; j < K; j += G) lds[ri(R_YD, j)] = 0.0;
                     if (lane == 0) SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.Y0 + i] = 0.0;
                     rs = false; n_tiny = 0; fpo = L.FP; fto = L.FT; nfilt = o_nfilt; n_acc = o_nacc; mu = o_mu; tau = fmax(O.tau_min, 1.0 - mu); dw_last = o_dw_last;
                     theta_max = o_theta_max; theta_min = o_theta_min;

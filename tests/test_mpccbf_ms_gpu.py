@@ -67,7 +67,7 @@ def test_config3_draws_against_the_oracle_iterate_for_iterate(seed):
     worst = 0.0
     for i, r in enumerate(res):
         m = min(len(r[3]), it[i] + 1, 12)
-        in_resto = np.flatnonzero(r[3][:, 7] < 0)                                 # (the oracle's restoration writes a row of its own when it starts: rows before it)
+        in_resto = np.flatnonzero(np.signbit(r[3][:, 7]))                               # (the oracle's restoration writes a row of its own when it starts: rows before it)
         m = min(m, in_resto[0]) if len(in_resto) else m
         worst = max(worst, float((np.abs(trace[i, :m, :6] - r[3][:m, :6]) / np.maximum(1e-7, np.abs(r[3][:m, :6]))).max()))
     assert worst <= 1e-5, worst

@@ -16,6 +16,7 @@ struct Shared {
     pthread_barrier_t bar;
     std::vector<double> lds;
     double red[64];
+    double gred[64][36];
 };
 struct HostCtx {
     typedef double* ptr;
@@ -37,6 +38,17 @@ struct HostCtx {
         pthread_barrier_wait(&sh->bar);
         return a;
     }
+    // sum over the G lanes of a group (lanes l / G equal), every lane of the wave calls it
+    template <int n>
+    void gsum(double* v, int G) {
+        if (G == 1) return;
+        pthread_barrier_wait(&sh->bar);
+        for (int i = 0; i < n; ++i) sh->gred[lane][i] = v[i];
+        pthread_barrier_wait(&sh->bar);
+        const int base = lane / G * G;
+        for (int i = 0; i < n; ++i) { double a = 0.0; for (int l = 0; l < G; ++l) a += sh->gred[base + l][i]; v[i] = a; }
+        pthread_barrier_wait(&sh->bar);
+    }
     double wsum(double v) { return reduce(v, [](double a, double b) { return a + b; }); }
     double wmax(double v) { return reduce(v, [](double a, double b) { return std::fmax(a, b); }); }
     double wmin(double v) { return reduce(v, [](double a, double b) { return std::fmin(a, b); }); }
@@ -55,7 +67,7 @@ void lane_main(int lane, Shared* sh, const sc::dums::Params* P, const sc_ipopt_p
     int st, it;
     S.solve(st, it, trace);
     if (lane == 0) { u_out[0] = S.u[0]; u_out[1] = S.u[1]; *status = st; *iters = it; }
-    if (plan && S.act) {
+    if (plan && S.acl) {
         for (int i = 0; i < NX; ++i) plan[S.k * NX + i] = S.x[i];
         if (S.stg) for (int j = 0; j < NU; ++j) plan[(P->N + 1) * NX + S.k * NU + j] = S.u[j];
     }
