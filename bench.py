@@ -130,7 +130,7 @@ def valu_roofline(run, kernel_substr, kernel_ms, note=None, launches=1):
     profile has them: lane utilisation = SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU), and the f64 flops of the launch
     (lanes x (2 FMA + ADD + MUL) + 512 per MFMA op) against the 78.6 TFLOP/s vector peak.  The profile is used only when it
     was taken from the kernel sources of this tree (csrc hash); otherwise the entry says "stale"."""
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_counters.json")
         if not os.path.exists(path):
             continue
@@ -241,63 +241,105 @@ def budget_note(make_ctl, args, steps, ms_full, st_full, it_full):
 
 
 def mpc_cpu_baseline(Xn, goal, on, N, seconds):
-    """oracle/mpc_cbf.py (numpy float64, the same interior-point method) on one host core: bounded sample of the
-    same batch, starting from its first problem."""
+    """BASELINE configs[2] on the host cores: the multiple-shooting solve compiled for the CPU (oracle/c/mpc_du_ms_cpu.cpp: the same
+    algorithm as kernel 13 -- oracle/ms_ipopt.py's, which tests/test_oracle_c.py holds it to --, the wavefront's lanes as fibers of one
+    thread, OpenMP over problems) on a bounded sample of the same batch, one core and all cores; beside it the numpy oracle on one core."""
     import numpy as np
-    from oracle import mpc_cbf as O
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds and n < Xn.shape[0]:
-        O.solve(Xn[n], np.zeros(2), goal[n], on[n], params={"N": N})
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "solves/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} problems of the same batch, oracle/mpc_cbf.py (numpy float64 interior point), 1 thread"}
+    from oracle import c_oracle, ms_ipopt as MS
+    up = np.zeros((Xn.shape[0], 2))
+    nt_all = c_oracle.load_ms().du_ms_cpu_num_threads()
+    out = {}
+    for label, nt, share in (("one_core", 1, 0.3), ("all_cores", 0, 0.45)):
+        n, t0, chunk = 0, time.perf_counter(), (32 if nt == 1 else 64 * max(1, nt_all))
+        c_oracle.du_ms_cpu_batch(Xn[:8], up[:8], goal[:8], on[:8], horizon=N, n_threads=nt)      # (thread pool and page faults out of the way)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < share * seconds and n < Xn.shape[0]:
+            m = min(chunk, Xn.shape[0] - n)
+            c_oracle.du_ms_cpu_batch(Xn[n:n + m], up[n:n + m], goal[n:n + m], on[n:n + m], horizon=N, n_threads=nt)
+            n += m
+        out[label] = (n / (time.perf_counter() - t0), nt_all if nt == 0 else 1, n)
+    n_py, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 0.2 * seconds and n_py < Xn.shape[0]:
+        MS.solve(MS.du_model(), Xn[n_py], up[n_py], goal[n_py], on[n_py], N=N, opts=MS.KERNEL_PROFILE)
+        n_py += 1
+    py_rate = n_py / (time.perf_counter() - t0)
+    best = "all_cores" if out["all_cores"][0] >= out["one_core"][0] else "one_core"
+    v, nt, n = out[best]
+    return {"value": v, "unit": "solves/s", "cores": nt, "kind": "port",
+            "sample": f"first {n} problems of the same batch, oracle/c/mpc_du_ms_cpu.cpp (float64, multiple shooting under IPOPT's algorithm: "
+                      f"oracle/ms_ipopt.py compiled; OpenMP {nt} threads)",
+            "one_core_value": out["one_core"][0], "all_cores_value": out["all_cores"][0],
+            "python_oracle_value": py_rate, "python_oracle_sample": f"first {n_py} problems, oracle/ms_ipopt.py (numpy float64), 1 thread"}
 
 
 def mpc_leg(dev, B, K, N, steps, warmup, seed=0, cpu_seconds=0.0):
-    """BASELINE configs[2]: B DynamicUnicycle2D agents, MPC-CBF horizon N, K obstacles, u_prev = 0."""
+    """BASELINE configs[2]: B DynamicUnicycle2D agents, MPC-CBF horizon N, K obstacles, u_prev = 0 -- in the reference's own formulation
+    (do-mpc's multiple shooting under IPOPT's algorithm, restoration phase included: kernel 13, csrc/mpc_du_ms.hip; the default since
+    round 6).  `condensed`: the same batch on kernel 3 (single shooting, l1-merit interior point), the formulation of rounds 1 - 5,
+    selectable with robot_spec['mpc_formulation'] = 'condensed'."""
     import torch
     import safe_control_amd as sca
     from safe_control_amd import workloads as W
     spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25}
     mk = lambda **kw: sca.BatchedMPCCBF(dict(spec), io_dtype="f32", horizon=N, **kw)   # noqa: E731
-    ctl = mk()
+    ms = sca.BatchedMSMPCCBF(dict(spec), io_dtype="f32", horizon=N, check_circles=False)
+    cond = mk()
     Xn, goal, un, on = W.du_cbfqp_batch(B, K, seed=seed)
     t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
     X, g, ob = t(Xn), t(goal), t(on)
     up = torch.zeros((B, 2), dtype=torch.float32, device=dev)
-    out = (torch.empty((B, 2), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
-           torch.empty((B,), dtype=torch.int32, device=dev), None)
-    for _ in range(max(1, warmup)):
-        ctl.solve(X, up, g, ob, out=out)
-    torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(steps):
-        ctl.solve(X, up, g, ob, out=out)
-    e1.record()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    ms = e0.elapsed_time(e1) / steps
+
+    def timed(ctl, n_out):
+        out = (torch.empty((B, 2), dtype=torch.float32, device=dev), torch.empty((B,), dtype=torch.int32, device=dev),
+               torch.empty((B,), dtype=torch.int32, device=dev)) + ((None,) if n_out == 4 else ())
+        for _ in range(max(1, warmup)):
+            ctl.solve(X, up, g, ob, out=out)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            ctl.solve(X, up, g, ob, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        return out, time.perf_counter() - t0, e0.elapsed_time(e1) / steps
+
+    out, wall, ms_ms = timed(ms, 3)
     st, it = out[1], out[2]
+    outc, wallc, ms_c = timed(cond, 4)
+    stc, itc = outc[1], outc[2]
     nbytes = ((4 + 2 + 2 + 7 * K) * 4 + 2 * 4 + 4 + 4) * B
     extra = {"cpu_baseline": mpc_cpu_baseline(Xn, goal, on, N, cpu_seconds)} if cpu_seconds > 0 else {}
-    extra.update(budget_note(mk, (X, up, g, ob), steps, ms, st, it))
+    both = (st == 0) & (stc == 0)
+    condensed = {"kernel": "mpccbf_kernel<10, 8> (kernel 3: single shooting, l1-merit interior point)", "value": B * steps / wallc, "kernel_ms": ms_c,
+                 "optimal_fraction": float((stc == 0).double().mean().item()), "infeasible_fraction": float((stc == 1).double().mean().item()),
+                 "mean_ipm_iterations": float(itc.double().mean().item()),
+                 "same_status_fraction": float((st == stc).double().mean().item()),
+                 "same_u0_where_both_optimal_fraction": float(((out[0] - outc[0]).abs().amax(dim=1) <= 1e-4)[both].double().mean().item()) if bool(both.any()) else None,
+                 "u0_differs_by_more_than_1e-3_where_neither_is_optimal_fraction":
+                     float(((out[0] - outc[0]).abs().amax(dim=1) > 1e-3)[(st != 0) & (stc != 0)].double().mean().item()) if bool(((st != 0) & (stc != 0)).any()) else None}
+    condensed.update(budget_note(mk, (X, up, g, ob), steps, ms_c, stc, itc))
     if (B, K, N, seed) == (4096, 8, 10, 0):
-        rl = valu_roofline("mpc_sq", "mpccbf_kernel<10, 8>", ms, launches=LAUNCHES_PER_BUDGET_SOLVE, note="4096 problems = two rounds of 2048 resident waves; the launch ends with its "
-                           "slowest problem (74 interior-point iterations against a mean of 19: the 40 longest solves ALONE take 1.77 ms, "
-                           "tools/exp_tail.py)")
+        rlc = valu_roofline("mpc_sq", "mpccbf_kernel<10, 8>", ms_c, launches=LAUNCHES_PER_BUDGET_SOLVE)
+        if rlc:
+            work_level(rlc, condensed.get("uniform_batch"), float(itc.double().mean().item()), B)
+            condensed["roofline"] = rlc
+        rl = valu_roofline("mpc_sq", "mpcdu_ms_kernel<float>", ms_ms, launches=1, note="one wave per problem, four lanes per stage; 512 registers: one wave "
+                           "per SIMD = 1024 resident problems; the launch ends with its slowest problem (94 iterations, most of them inside the restoration phase, "
+                           "against a mean of 17.6 at ~40 us per iteration)")
         if rl:
-            work_level(rl, extra.get("uniform_batch"), float(it.double().mean().item()), B)
             extra["roofline"] = rl
     return {**extra, "workload": f"{B}-agent batch DynamicUnicycle2D MPC-CBF, horizon N={N}, {K} obstacles (BASELINE configs[2])",
-            "value": B * steps / wall, "unit": "solves/s", "steps": steps, "kernel_ms": ms,
-            "dtype": "f64", "storage": "f32",
+            "formulation": "multiple shooting under IPOPT's filter interior point, restoration phase in the kernel (do-mpc's NLP: mpc_cbf.py:162-174,366-402)",
+            "kernel": "mpcdu_ms_kernel<float> (kernel 13)",
+            "value": B * steps / wall, "unit": "solves/s", "steps": steps, "kernel_ms": ms_ms,
+            "dtype": "f64", "storage": "f32", "budget": 3000, "launches": "one",
             "optimal_fraction": float((st == 0).double().mean().item()),
             "infeasible_fraction": float((st == 1).double().mean().item()),
-            "mean_ipm_iterations": float(it.double().mean().item()),
-            "achieved_GBs": nbytes / (ms * 1e-3) / 1e9, "algorithmic_bytes_per_solve": nbytes // B}
+            "inaccurate_fraction": float((st == 2).double().mean().item()),
+            "mean_ipm_iterations": float(it.double().mean().item()), "max_ipm_iterations": int(it.max().item()),
+            "achieved_GBs": nbytes / (ms_ms * 1e-3) / 1e9, "algorithmic_bytes_per_solve": nbytes // B,
+            "condensed": condensed}
 
 
 def pipelined_leg(ctl, dev, X, ur, ob, K, steps):
@@ -1001,8 +1043,13 @@ def emit(d, ws):
                              if k in mpc["roofline"]}
             if isinstance(mpc["roofline"].get("work_level"), dict):
                 m["roofline"]["work_frac"] = mpc["roofline"]["work_level"]["frac"]
+        if isinstance(mpc.get("condensed"), dict):                     # the formulation of rounds 1 - 5 on the same batch (kernel 3), and how the two answers compare
+            c = mpc["condensed"]
+            m["kernel"] = mpc.get("kernel"); m["infeasible_fraction"] = mpc.get("infeasible_fraction")
+            m["condensed"] = {**compact_leg(c), **{k: c.get(k) for k in ("same_status_fraction", "same_u0_where_both_optimal_fraction",
+                                                                        "u0_differs_by_more_than_1e-3_where_neither_is_optimal_fraction")}}
         if isinstance(mpc.get("cpu_baseline"), dict):
-            m["cpu_baseline"] = {k: mpc["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample")}
+            m["cpu_baseline"] = {k: mpc["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample", "one_core_value", "python_oracle_value")}
         if isinstance(line.get("config"), dict) and "mpc" not in d:
             line["config"]["mpc_cbf_configs2"] = {"solves_per_s": m.get("value"), "kernel_ms": m.get("kernel_ms"),
                                                   "roofline_frac": (m.get("roofline") or {}).get("frac"),

@@ -113,6 +113,13 @@ class BatchedTrackingController:
             else:
                 cls = BatchedMPCCBF if self.pos_controller_type == "mpc_cbf" else BatchedOptimalDecayMPCCBF
             self.mpc = cls(self.robot_spec, dt=self.dt, io_dtype=io_dtype)
+            # DynamicUnicycle2D under 'mpc_cbf': the NLP as do-mpc poses it (multiple shooting, IPOPT's algorithm: csrc/mpc_du_ms.hip, kernel 13)
+            # unless robot_spec['mpc_formulation'] = 'condensed'; a scene with superellipsoid rows runs on the condensed kernel
+            self.mpc_ms = None
+            if cls is BatchedMPCCBF and self.model == "DynamicUnicycle2D" and self.robot_spec.get("mpc_formulation", "multiple_shooting") != "condensed" \
+                    and self.num_constraints <= 16:
+                from .position_control.mpc_cbf_ms import BatchedMSMPCCBF
+                self.mpc_ms = BatchedMSMPCCBF(self.robot_spec, dt=self.dt, io_dtype=io_dtype, check_circles=False)
             self.u_prev = torch.zeros((self.B, 2), dtype=self.tdtype, device=self.device)   # do-mpc's u0 per agent
             self.mpc_status = torch.zeros(self.B, dtype=torch.int32, device=self.device)
 
@@ -121,11 +128,13 @@ class BatchedTrackingController:
         torch = self.torch
         if obs is None or len(obs) == 0:
             self.obs = torch.zeros((0, 7), dtype=self.tdtype, device=self.device)
+            self.obs_has_superellipsoid = False
             return
         obs = np.asarray(obs, dtype=np.float64)
         if obs.shape[1] < 7:                                   # examples/test_tracking.py:147-148
             obs = np.hstack([obs, np.zeros((obs.shape[0], 7 - obs.shape[1]))])
         self.obs = torch.tensor(obs[:, :7], dtype=self.tdtype, device=self.device).contiguous()
+        self.obs_has_superellipsoid = bool((obs[:, 6] >= 0.5).any())
 
     # -- waypoints: set_waypoints / filter_waypoints / first update_goal (tracking.py:197-249, 497-535) --
     def set_waypoints(self, waypoints):
@@ -292,7 +301,8 @@ class BatchedTrackingController:
             goal_in = torch.where(tr, goal2, ge).contiguous()
             up_in = torch.where(tr, self.u_prev, torch.zeros_like(self.u_prev)).contiguous()
             obs_in = torch.where(tr.unsqueeze(2), obs_in, self._dummy_rows(obs_in)).contiguous()
-            out = self.mpc.solve(X_in, up_in, goal_in, obs_in)
+            mpc = self.mpc_ms if (getattr(self, "mpc_ms", None) is not None and not self.obs_has_superellipsoid) else self.mpc
+            out = mpc.solve(X_in, up_in, goal_in, obs_in)
             u_mpc, st = (out[0], out[2]) if self.pos_controller_type == "optimal_decay_mpc_cbf" else (out[0], out[1])
             its = out[3] if self.pos_controller_type == "optimal_decay_mpc_cbf" else out[2]
             self._raw_iters, self._raw_track = its, track                      # (what the launch ran, slots outside 'track' included)

@@ -84,3 +84,29 @@ def test_c_oracle_unicycle2d_on_reference_cases(golden_dir):
     assert np.array_equal(st, G["status_oracle"])
     ok = st == 0
     np.testing.assert_allclose(u[ok], G["u_star_oracle"][ok], rtol=1e-8, atol=1e-8)
+
+
+def _ms_one(a):
+    from oracle import ms_ipopt as MS
+    os.environ["OMP_NUM_THREADS"] = "1"
+    u, st, it = MS.solve(MS.du_model(), a[0], a[1], a[2], a[3], opts=MS.KERNEL_PROFILE)
+    return u, st, it
+
+
+def test_compiled_cpu_baseline_of_config3_equals_the_numpy_oracle():
+    """oracle/c/mpc_du_ms_cpu.cpp -- the multiple-shooting MPC-CBF solve compiled for the host cores (bench.py's cpu_baseline of BASELINE
+    configs[2]; the 64 lanes of the kernel's solver header as fibers of one thread, OpenMP over problems) -- against oracle/ms_ipopt.py on the
+    first 256 configs[2] problems: same status and iteration count on every one (the infeasible tenth with its restoration phase included),
+    u0 to 1e-9; one thread and all threads give the same bits."""
+    from multiprocessing import Pool
+    n = 256
+    X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("du", 4096, 8, seed=0))
+    u, st, it = c_oracle.du_ms_cpu_batch(X, up, goal, obs, n_threads=0)
+    u1, st1, it1 = c_oracle.du_ms_cpu_batch(X[:32], up[:32], goal[:32], obs[:32], n_threads=1)
+    assert np.array_equal(u[:32], u1) and np.array_equal(st[:32], st1) and np.array_equal(it[:32], it1)
+    with Pool(min(8, os.cpu_count() or 2)) as p:
+        res = p.map(_ms_one, [(X[i], up[i], goal[i], obs[i]) for i in range(n)], chunksize=4)
+    so = np.array([r[1] for r in res]); ito = np.array([r[2] for r in res]); uo = np.array([r[0] for r in res])
+    assert np.array_equal(st, so) and (so == 1).sum() >= 10
+    assert (it != ito).sum() <= 2 and np.abs(it - ito).max() <= 1
+    assert np.abs(u - uo)[it == ito].max() <= 1e-9

@@ -202,23 +202,29 @@ def test_cooperative_and_lane_per_agent_kernels_agree(golden_dir, num_constraint
     assert (out["0"][0] != 0).any() and (out["0"][0] == 0).any()
 
 
-@pytest.mark.parametrize("pos", ["mpc_cbf", "optimal_decay_mpc_cbf"])
+@pytest.mark.parametrize("pos", ["mpc_cbf", "mpc_cbf/condensed", "optimal_decay_mpc_cbf"])
 def test_closed_loop_with_mpc_position_controller(golden_dir, pos):
     """examples/test_tracking.py's default --algo mpc_cbf, batched: select -> one MPC launch -> apply per step, against
-    the oracle loop with the oracle MPC behind solve_fn (u_prev feedback, u_ref pass-through when not tracking)."""
-    from oracle import mpc_cbf as M, od_mpc_cbf as O
+    the oracle loop with the oracle MPC behind solve_fn (u_prev feedback, u_ref pass-through when not tracking).  'mpc_cbf': the
+    default formulation since round 6 -- multiple shooting under IPOPT's algorithm (kernel 13) against oracle/ms_ipopt.py;
+    'mpc_cbf/condensed': robot_spec['mpc_formulation'] = 'condensed' (kernel 3) against oracle/mpc_cbf.py."""
+    from oracle import mpc_cbf as M, od_mpc_cbf as O, ms_ipopt as MS
+    pos, _, form = pos.partition("/")
     g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
     obs = g["du14/obs"]
     K = 8
     spec = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "radius": 0.25, "num_constraints": K}
+    if form:
+        spec["mpc_formulation"] = form
     X0 = np.array([[2.0, 2.0, np.pi / 2, 1.0], [6.0, 1.0, 2.6, 0.3], [1.0, 6.0, -1.2, 0.0]])   # the last one starts in 'stop'
     wl = [np.array([[2.0, 12.0], [12.0, 12.0]]), np.array([[1.0, 4.0]]), np.array([[1.0, 12.0]])]
     T = 30
     ctl = sca.BatchedTrackingController(X0, dict(spec), controller_type={"pos": pos}, obs=obs, io_dtype="f64")
     ctl.set_waypoints(wl)
+    assert (ctl.mpc_ms is not None) == (pos == "mpc_cbf" and not form)
     ret, tX, tU = ctl.control_step(T, record=True)
     tX = tX.cpu().numpy(); tU = tU.cpu().numpy(); ret = ret.cpu().numpy()
-    ospec = {k: v for k, v in spec.items() if k not in ("model", "num_constraints")}
+    ospec = {k: v for k, v in spec.items() if k not in ("model", "num_constraints", "mpc_formulation")}
     n_track = 0
     for i in range(len(X0)):
         state = {"up": np.zeros(2)}
@@ -227,7 +233,9 @@ def test_closed_loop_with_mpc_position_controller(golden_dir, pos):
             if cref["state_machine"] != "track":
                 return np.asarray(cref["u_ref"], dtype=np.float64).reshape(-1), 0
             o = M.pad_obstacles(None if nobs is None else list(nobs), K if pos == "mpc_cbf" else 5)   # OD: five slots
-            if pos == "mpc_cbf":
+            if pos == "mpc_cbf" and not form:
+                u, st, it = MS.solve(MS.du_model(), X, state["up"], cref["goal"], o, opts=MS.KERNEL_PROFILE)
+            elif pos == "mpc_cbf":
                 u, st, it = M.solve(X, state["up"], cref["goal"], o)
             else:
                 u, rho, st, it = O.solve(X, state["up"], cref["goal"], o)

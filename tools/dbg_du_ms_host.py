@@ -27,11 +27,11 @@ def build():
     return lib
 
 
-LDS_NAMES = "OB AB H G C KG PX LAM XS US YS Pa Pb T QU FP FT FP2 FT2 SC Y0 RW XR total".split()
+LDS_NAMES = "OB AB H G G1 C KG PX LAM XS US YS Pa Pb T QU FP FT FP2 FT2 SC Y0 RW XR total".split()
 
 
 def lds_layout(lib, N, KS):
-    out = (C.c_int * 24)()
+    out = (C.c_int * 25)()
     lib.du_ms_host_lds_layout(N, KS, out)
     return dict(zip(LDS_NAMES, list(out)))
 
@@ -66,7 +66,7 @@ if __name__ == "__main__":
     first = int(args[1]) if len(args) > 1 else 0
     verbose = "-v" in sys.argv
     lib = build()
-    X, up, goal, obs = W.mpc_family_batch("du", first + n, 8, seed=0)
+    X, up, goal, obs = W.mpc_family_batch("du", 4096, 8, seed=0)
     bad = 0
     for i in range(first, first + n):
         t = time.time()

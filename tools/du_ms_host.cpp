@@ -5,6 +5,8 @@
 #include <pthread.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -16,7 +18,7 @@ struct Shared {
     pthread_barrier_t bar;
     std::vector<double> lds;
     double red[64];
-    double gred[64][36];
+    double gred[64][42];
 };
 struct HostCtx {
     typedef double* ptr;
@@ -66,7 +68,7 @@ void lane_main(int lane, Shared* sh, const sc::dums::Params* P, const sc_ipopt_p
     cx.sync();
     int st, it;
     S.solve(st, it, trace);
-    if (lane == 0) { u_out[0] = S.u[0]; u_out[1] = S.u[1]; *status = st; *iters = it; }
+    if (lane == 0) { u_out[0] = S.u[0]; u_out[1] = S.u[1]; *status = st; *iters = it; if (getenv("DUMS_DEBUG")) fprintf(stderr, "filt_over %d nfilt %d rs %d\n", (int)S.filt_over, S.nfilt, (int)S.rs); }
     if (plan && S.acl) {
         for (int i = 0; i < NX; ++i) plan[S.k * NX + i] = S.x[i];
         if (S.stg) for (int j = 0; j < NU; ++j) plan[(P->N + 1) * NX + S.k * NU + j] = S.u[j];
@@ -76,9 +78,9 @@ void lane_main(int lane, Shared* sh, const sc::dums::Params* P, const sc_ipopt_p
 
 extern "C" int du_ms_host_lds_layout(int N, int K, int* out) {
     const sc::dums::Lds L(N, K);
-    const int v[] = {L.OB, L.AB, L.H, L.G, L.C, L.KG, L.PX, L.LAM, L.XS, L.US, L.YS, L.Pa, L.Pb, L.T, L.QU, L.FP, L.FT, L.FP2, L.FT2, L.SC, L.Y0, L.RW, L.XR, L.total};
-    for (int i = 0; i < 24; ++i) out[i] = v[i];
-    return 24;
+    const int v[] = {L.OB, L.AB, L.H, L.G, L.G1, L.C, L.KG, L.PX, L.LAM, L.XS, L.US, L.YS, L.Pa, L.Pb, L.T, L.QU, L.FP, L.FT, L.FP2, L.FT2, L.SC, L.Y0, L.RW, L.XR, L.total};
+    for (int i = 0; i < 25; ++i) out[i] = v[i];
+    return 25;
 }
 
 extern "C" int du_ms_host_solve(const sc_mpccbf_params* prm, const sc_ipopt_params* O, int K, const double* x0, const double* u_prev, const double* goal,
