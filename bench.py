@@ -999,7 +999,7 @@ def compact_leg(v):
         return v
     sig = lambda x: float(f"{x:.5g}") if isinstance(x, float) else x     # noqa: E731
     keep = {}
-    for k in ("value", "kernel_ms", "ms_per_control_step", "us_per_step", "agent_steps_per_s", "solves_per_s", "optimal_fraction",
+    for k in ("value", "kernel_ms", "ms_per_step", "ms_per_control_step", "us_per_step", "agent_steps_per_s", "solves_per_s", "optimal_fraction",
               "max_ipm_iterations", "agents", "GBs", "frac_of_peak", "error", "optimal_only_value", "beyond_100_iterations",
               "all_gather_bytes_per_step", "inaccurate_fraction", "landed", "return_code", "control_steps", "restoration_fallback", "landed_fraction", "lost_fraction", "aircraft"):
         if k in v:
@@ -1269,6 +1269,17 @@ def main():
             res["od_vtol_ms_mpc_cbf"] = od_vtol_ms_mpc_leg(dev)
             res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
             res["backup_cbf_qp"] = backup_cbf_leg(dev)
+            # the two remaining BASELINE configs on the one-GPU line: configs[3] (16384 C3BF agents, one rank: the all-gather is a copy) and
+            # configs[4] (the 65536-agent heterogeneous fleet as one warm + one timed step)
+            try:
+                res["kb_c3bf"] = kb_c3bf_workload(a, dev, ws, rank, backend, collect=True, steps_override=50)
+            except Exception as e:
+                res["kb_c3bf"] = {"error": repr(e)[:200]}
+            try:
+                if not NO_LIMIT100:
+                    res["hetero_fleet"] = hetero_fleet_workload(a, dev, ws, rank, backend, collect=True)
+            except Exception as e:
+                res["hetero_fleet"] = {"error": repr(e)[:200]}
         if ws == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(X.double().cpu().numpy(), ur.double().cpu().numpy(),
                                                ob.double().cpu().numpy(), a.cpu_seconds)
@@ -1277,7 +1288,7 @@ def main():
         dist.destroy_process_group()
 
 
-def hetero_fleet_workload(a, dev, ws, rank, backend):
+def hetero_fleet_workload(a, dev, ws, rank, backend, collect=False):
     """BASELINE configs[4], built as SURVEY 8d defines it -- a labelled EXTENSION (no runnable reference): a heterogeneous
     fleet of 65536 agents (or --agents per GPU x ranks when given), half kinematic Unicycle2D and half Quad3D, every
     agent solving an OPTIMAL-DECAY MPC-CBF with horizon 20 against 8 SUPERELLIPSOID obstacles (7-wide rows).  The
@@ -1324,6 +1335,8 @@ def hetero_fleet_workload(a, dev, ws, rank, backend):
 
     torch.cuda.synchronize()
     steps, warm = min(a.steps, 5), min(max(a.warmup, 1), 2)           # a step is 2 x Bl NLPs: seconds, not microseconds
+    if collect:                                                        # a leg of the default line: one warm and one timed fleet step
+        steps, warm = 1, 1
     for _ in range(warm):
         step()
     torch.cuda.synchronize()
@@ -1341,6 +1354,14 @@ def hetero_fleet_workload(a, dev, ws, rank, backend):
         su, sq = (res["u"][2], res["q"][2]) if od else (res["u"][1], res["q"][1])
         iu, iq = (res["u"][3], res["q"][3]) if od else (res["u"][2], res["q"][2])
         nbytes = ((16 + 8 + 8 + 7 * K * 4 + 8 + 4 + 4) + (48 + 16 + 12 + 7 * K * 4 + 16 + 4 + 4)) * (n_total // 2)
+        if collect:
+            return {"workload": f"{n_total}-agent heterogeneous fleet (Unicycle2D + Quad3D), optimal-decay MPC-CBF N=20, 8 superellipsoid obstacles "
+                                "(BASELINE configs[4]; extension, oracle/od_mpc_rd1.py)", "extension": True, "agents": n_total,
+                    "value": n_total * steps / elapsed, "unit": "solves/s", "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
+                    "optimal_fraction": float(((su == 0).double().mean().item() + (sq == 0).double().mean().item()) / 2),
+                    "unicycle_optimal_fraction": float((su == 0).double().mean().item()), "quad3d_optimal_fraction": float((sq == 0).double().mean().item()),
+                    "max_ipm_iterations": int(max(iu.max().item(), iq.max().item())),
+                    "roofline": hetero_roofline(od, n_total, ws, steps, elapsed, nbytes)}
         emit({"metric": "QP solves/sec (batched agents)", "value": n_total * steps / elapsed, "unit": "solves/s",
                           "n_gpus": ws, "steps": steps, "warmup": warm, "ms_per_step": 1e3 * elapsed / steps,
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -1365,18 +1386,21 @@ def hetero_roofline(od, n_total, ws, steps, elapsed, nbytes):
     model kernels run side by side on two streams: their instruction counts add); falls back to the (meaningless) HBM
     figure when the profile does not hold this configuration."""
     if od and n_total == 65536:
-        for rnd in ("r02",):
+        for rnd in ("r06", "r05", "r04", "r03", "r02"):                # the newest round that profiled this launch pair
             path = os.path.join(ROOT, "profiles", f"{rnd}_counters.json")
             try:
-                d = json.load(open(path)).get("hetero_sq", {})
+                allc = json.load(open(path))
+                d = allc.get("hetero_sq", {})
             except Exception:
-                d = {}
-            insts = [c["SQ_INSTS_VALU"] for k, c in d.items() if ("mpclin_kernel" in k or "odmpccbf_uni_kernel" in k) and "SQ_INSTS_VALU" in c]
+                allc, d = {}, {}
+            # per-dispatch averages x dispatches of one fleet step (a budget solve of either kernel = classify + cap 100 + rest)
+            insts = [c["SQ_INSTS_VALU"] * LAUNCHES_PER_BUDGET_SOLVE for k, c in d.items()
+                     if ("mpclin_kernel" in k or "odmpccbf_uni_kernel" in k) and "SQ_INSTS_VALU" in c]
             if len(insts) == 2:
                 ach = sum(insts) * steps / elapsed / 1e9
                 return {"bound": "valu_issue", "achieved": ach, "peak": VALU_PEAK_GIPS * ws, "unit": "G wave-instr/s", "frac": ach / (VALU_PEAK_GIPS * ws),
                         "traffic": None, "kernel": "odmpccbf_uni_kernel<20> + mpclin_kernel<12,4,0,0,big,od>", "valu_instructions_per_step": sum(insts),
-                        "source": f"profiles/{rnd}_counters.json:hetero_sq",
+                        "source": f"profiles/{rnd}_counters.json:hetero_sq", "stale": allc.get("_meta", {}).get("csrc_sha16") != csrc_sha16(),
                         "note": "latency-bound interior-point solves (two Quad3D problems per CU: 77 KB of LDS and four waves each; two Unicycle2D problems per CU: 65 KB, one wave each)"}
     return {"bound": "hbm", "achieved": nbytes * steps / elapsed / 1e9, "peak": HBM_PEAK_GBS * ws, "unit": "GB/s",
             "frac": nbytes * steps / elapsed / 1e9 / (HBM_PEAK_GBS * ws), "traffic": None,
@@ -1431,8 +1455,13 @@ def kb_c3bf_workload(a, dev, ws, rank, backend, collect=False, steps_override=No
         return {"workload": "16384-agent KinematicBicycle2D C3BF, 16 nearest other agents as moving obstacles (BASELINE configs[3]): "
                             "all-gather of the states (RCCL) -> neighbour kernel -> CBF-QP per step",
                 "value": n_agents * steps / elapsed, "unit": "solves/s", "steps": steps, "ms_per_step": 1e3 * elapsed / steps,
-                "scaling": "strong", "agents_total": n_agents, "all_gather_bytes_per_step": n_agents * 16,
-                "equal_shards": bool(ex.equal), "achieved_GBs": nb * steps / elapsed / 1e9}
+                "scaling": "strong", "agents": n_agents, "agents_total": n_agents, "all_gather_bytes_per_step": n_agents * 16,
+                "equal_shards": bool(ex.equal), "achieved_GBs": nb * steps / elapsed / 1e9,
+                "optimal_fraction": float((out[1] == 0).double().mean().item()),
+                "roofline": {"bound": "hbm", "achieved": nb * steps / elapsed / 1e9, "peak": HBM_PEAK_GBS * ws, "unit": "GB/s",
+                             "frac": nb * steps / elapsed / 1e9 / (HBM_PEAK_GBS * ws), "traffic": None,
+                             "kernel": "nb_bbox / nb_count / nb_scan / nb_scatter / nb_select (uniform-grid cell list) + cbfqp kernel: six launches per step",
+                             "algorithmic_bytes_per_solve": nb // n_agents}}
     if rank == 0:
         nbytes = (16 + 8 + 7 * K * 4 + 8 + 4 + K * 4) * n_agents
         emit({"metric": "QP solves/sec (batched agents)", "value": n_agents * a.steps / elapsed, "unit": "solves/s",

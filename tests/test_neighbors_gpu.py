@@ -89,8 +89,8 @@ def test_agents_as_obstacles_pipeline_one_rank():
                                                    (3000, 100, 777, 8, torch.float64), (900, 0, 900, 32, torch.float64),
                                                    (300, 0, 300, 16, torch.float32)])
 def test_candidate_split_search_equals_the_single_scan(B, lo, n_local, K, dtype):
-    """sc_neighbor_obstacles_batch_ws (slices + merge) against sc_neighbor_obstacles_batch (one scan): bit for bit, with
-    exact ties (agents on a grid) and duplicate positions."""
+    """sc_neighbor_obstacles_batch_ws (the uniform-grid cell list since round 6; rounds 3 - 5: candidate slices + merge) against
+    sc_neighbor_obstacles_batch (one scan over every agent): bit for bit, with exact ties (agents on a grid) and duplicate positions."""
     from safe_control_amd import _lib
     rng = np.random.default_rng(B + K)
     X = np.column_stack([rng.integers(0, 60, B).astype(np.float64), rng.integers(0, 60, B).astype(np.float64),
@@ -112,3 +112,48 @@ def test_candidate_split_search_equals_the_single_scan(B, lo, n_local, K, dtype)
         want = brute_force(tX.double().cpu().numpy(), lo, lo + n_local, K, 0.3)
         np.testing.assert_allclose(b.double().cpu().numpy(), want, rtol=1e-6, atol=1e-6)
     assert lib.sc_neighbor_obstacles_batch_ws(io, B, lo, n_local, K, 0.3, tX.data_ptr(), b.data_ptr(), ws.data_ptr(), nbytes - 1, stream) != 0
+
+
+@pytest.mark.parametrize("case", ["clusters", "line", "far_outlier", "coincident", "fewer_than_K", "nan_and_inf", "config4"])
+def test_cell_list_on_awkward_fleets_equals_the_single_scan(case):
+    """The cell list's stop test (K-th best inside the covered block) and its binning on fleets a uniform grid does not like: dense clusters
+    far apart, every agent on one line, one agent 10 km away (the grid hits its 256 x 256 limit and the cells are large), everybody on the
+    same spot, fewer agents than K, non-finite positions (never anybody's neighbour, as in the scan), and BASELINE configs[3]'s 16384 agents."""
+    from safe_control_amd import _lib
+    rng = np.random.default_rng(7)
+    K, dtype = 16, torch.float32
+    if case == "clusters":
+        B = 6000
+        c = rng.uniform(0, 500, (12, 2))
+        P = c[rng.integers(0, 12, B)] + rng.normal(0, 0.3, (B, 2))
+    elif case == "line":
+        B = 4000
+        P = np.column_stack([rng.uniform(0, 100, B), np.full(B, 3.0)])
+    elif case == "far_outlier":
+        B = 5000
+        P = rng.uniform(0, 14, (B, 2)); P[17] = [1.0e4, -1.0e4]
+    elif case == "coincident":
+        B = 1500
+        P = np.tile([[2.5, -1.0]], (B, 1)); P[::7] += rng.uniform(-1, 1, (len(P[::7]), 2))
+    elif case == "fewer_than_K":
+        B = 9
+        P = rng.uniform(0, 5, (B, 2))
+    elif case == "nan_and_inf":
+        B = 2000
+        P = rng.uniform(0, 30, (B, 2)); P[5, 0] = np.nan; P[99] = [np.inf, 3.0]; P[1000, 1] = -np.inf
+    else:
+        B = 16384
+        P = W.kb_c3bf_batch(B, K, seed=0)[0][:, :2]
+    X = np.column_stack([P, rng.uniform(-np.pi, np.pi, B), rng.uniform(0.2, 3.5, B)])
+    tX = torch.tensor(X, dtype=dtype, device=DEV)
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    a = torch.empty((B, K, 7), dtype=dtype, device=DEV)
+    b = torch.empty((B, K, 7), dtype=dtype, device=DEV)
+    assert lib.sc_neighbor_obstacles_batch(0, B, 0, B, K, 0.3, tX.data_ptr(), a.data_ptr(), stream) == 0
+    nbytes = int(lib.sc_neighbor_workspace_bytes(0, B, B, K))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=DEV)
+    for _ in range(2):                                              # (the workspace is reused call after call: no state may survive in it)
+        assert lib.sc_neighbor_obstacles_batch_ws(0, B, 0, B, K, 0.3, tX.data_ptr(), b.data_ptr(), ws.data_ptr(), nbytes, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a.nan_to_num(nan=-7.0, posinf=-8.0, neginf=-9.0), b.nan_to_num(nan=-7.0, posinf=-8.0, neginf=-9.0))
