@@ -266,8 +266,7 @@ def mpc_cpu_baseline(Xn, goal, on, N, seconds):
     best = "all_cores" if out["all_cores"][0] >= out["one_core"][0] else "one_core"
     v, nt, n = out[best]
     return {"value": v, "unit": "solves/s", "cores": nt, "kind": "port",
-            "sample": f"first {n} problems of the same batch, oracle/c/mpc_du_ms_cpu.cpp (float64, multiple shooting under IPOPT's algorithm: "
-                      f"oracle/ms_ipopt.py compiled; OpenMP {nt} threads)",
+            "sample": f"first {n} problems of the batch, oracle/c/mpc_du_ms_cpu.cpp (f64, oracle/ms_ipopt.py's algorithm compiled), OpenMP {nt} threads",
             "one_core_value": out["one_core"][0], "all_cores_value": out["all_cores"][0],
             "python_oracle_value": py_rate, "python_oracle_sample": f"first {n_py} problems, oracle/ms_ipopt.py (numpy float64), 1 thread"}
 
@@ -997,14 +996,14 @@ def compact_leg(v):
         return [compact_leg(x) for x in v]
     if not isinstance(v, dict):
         return v
-    sig = lambda x: float(f"{x:.5g}") if isinstance(x, float) else x     # noqa: E731
+    sig = lambda x: float(f"{x:.4g}") if isinstance(x, float) else x     # noqa: E731
     keep = {}
     for k in ("value", "kernel_ms", "ms_per_step", "ms_per_control_step", "us_per_step", "agent_steps_per_s", "solves_per_s", "optimal_fraction",
-              "max_ipm_iterations", "agents", "GBs", "frac_of_peak", "error", "optimal_only_value", "beyond_100_iterations",
+              "max_ipm_iterations", "agents", "GBs", "frac_of_peak", "error", "optimal_only_value",
               "all_gather_bytes_per_step", "inaccurate_fraction", "landed", "return_code", "control_steps", "restoration_fallback", "landed_fraction", "lost_fraction", "aircraft"):
         if k in v:
             keep[k] = sig(v[k])
-    if isinstance(v.get("one_launch_limit_100"), dict):
+    if isinstance(v.get("one_launch_limit_100"), dict) and v.get("beyond_100_iterations"):      # (only where the budget beyond 100 iterations is used)
         keep["limit_100_ms"] = sig(v["one_launch_limit_100"]["kernel_ms"])
     rl = v.get("roofline")
     if isinstance(rl, dict):
@@ -1029,6 +1028,9 @@ def emit(d, ws):
     except OSError:
         pass
     line = {k: d[k] for k in CONTRACT_KEYS if k in d}
+    if isinstance(line.get("cpu_baseline"), dict):                       # (the full dict is in bench_legs.json)
+        line["cpu_baseline"] = {k: (float(f"{v_:.6g}") if isinstance(v_, float) else v_) for k, v_ in line["cpu_baseline"].items()
+                                if k in ("value", "unit", "cores", "kind", "sample", "one_core_value", "python_per_agent_loop_value")}
     line["ranks_seen"] = ws
     mpc = d.get("mpc_cbf") or d.get("mpc")
     for k, v in d.items():
@@ -1046,10 +1048,13 @@ def emit(d, ws):
         if isinstance(mpc.get("condensed"), dict):                     # the formulation of rounds 1 - 5 on the same batch (kernel 3), and how the two answers compare
             c = mpc["condensed"]
             m["kernel"] = mpc.get("kernel"); m["infeasible_fraction"] = mpc.get("infeasible_fraction")
-            m["condensed"] = {**compact_leg(c), **{k: c.get(k) for k in ("same_status_fraction", "same_u0_where_both_optimal_fraction",
-                                                                        "u0_differs_by_more_than_1e-3_where_neither_is_optimal_fraction")}}
+            r4 = lambda x: float(f"{x:.4g}") if isinstance(x, float) else x     # noqa: E731
+            m["condensed"] = {**compact_leg(c), "same_status": r4(c.get("same_status_fraction")), "same_u0_both_optimal": r4(c.get("same_u0_where_both_optimal_fraction")),
+                              "u0_diff_gt_1e-3_neither_optimal": r4(c.get("u0_differs_by_more_than_1e-3_where_neither_is_optimal_fraction"))}
+            m["infeasible_fraction"] = r4(m["infeasible_fraction"])
         if isinstance(mpc.get("cpu_baseline"), dict):
-            m["cpu_baseline"] = {k: mpc["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample", "one_core_value", "python_oracle_value")}
+            m["cpu_baseline"] = {k: (float(f"{v_:.5g}") if isinstance(v_, float) else v_) for k, v_ in
+                                 ((k, mpc["cpu_baseline"].get(k)) for k in ("value", "unit", "cores", "kind", "sample", "one_core_value", "python_oracle_value"))}
         if isinstance(line.get("config"), dict) and "mpc" not in d:
             line["config"]["mpc_cbf_configs2"] = {"solves_per_s": m.get("value"), "kernel_ms": m.get("kernel_ms"),
                                                   "roofline_frac": (m.get("roofline") or {}).get("frac"),

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # tests/test_codegen_guard_gpu.py compares with).  Still no fallback: the named file must exist and export every symbol.
 LIB_PATH = os.environ.get("SAFE_CONTROL_AMD_LIB") or os.path.join(_HERE, "lib", "libsafe_control_hip.so")
 
-SC_OK = 0
+SC_OK, SC_ERR_INVALID_ARGUMENT, SC_ERR_UNSUPPORTED, SC_ERR_HIP, SC_ERR_NO_DEVICE = 0, 1, 2, 3, 4            # sc_error (include/safe_control_amd.h)
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_INACCURATE, STATUS_BAD_OBSTACLE = 0, 1, 2, 3
 STATUS_STRINGS = {0: "optimal", 1: "infeasible", 2: "optimal_inaccurate", 3: "bad_obstacle", 4: "needs_restoration"}
 DTYPE_F32, DTYPE_F64 = 0, 1

@@ -33,7 +33,7 @@ def test_single_gpu_line_has_contract_fields():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
     assert d["mpc_cbf"]["value"] > 5e3               # BASELINE target: >= 5k MPC-CBF (N = 10) solves/s
     # configs[2] runs in the reference's formulation (kernel 13: multiple shooting, IPOPT's algorithm), the condensed kernel beside it
-    assert "kernel 13" in d["mpc_cbf"]["kernel"] and d["mpc_cbf"]["condensed"]["kernel_ms"] > 0 and d["mpc_cbf"]["condensed"]["same_status_fraction"] > 0.99
+    assert "kernel 13" in d["mpc_cbf"]["kernel"] and d["mpc_cbf"]["condensed"]["kernel_ms"] > 0 and d["mpc_cbf"]["condensed"]["same_status"] > 0.99
     assert d["mpc_cbf"]["cpu_baseline"]["cores"] >= 1 and d["mpc_cbf"]["cpu_baseline"]["value"] > 20      # (the compiled multi-core baseline)
     # configs[3] and configs[4] are on the one-GPU line
     assert d["kb_c3bf"]["agents"] == 16384 and d["kb_c3bf"]["ms_per_step"] < 0.5 and d["hetero_fleet"]["agents"] == 65536 and d["hetero_fleet"]["optimal_fraction"] > 0.99

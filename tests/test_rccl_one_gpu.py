@@ -77,5 +77,5 @@ def test_world_size_one_nccl_group_runs_the_exchange_and_the_config4_step(tmp_pa
     X = torch.tensor(Xn, dtype=torch.float32, device="cuda:0"); ur = torch.tensor(un, dtype=torch.float32, device="cuda:0")
     obs = sharding.neighbor_obstacles(X, n, K, 0.3)
     u, st, h = sca.BatchedCBFQP(dict(spec), dt=0.05, io_dtype="f32", compute_dtype="f64").solve(X, ur, obs)
-    assert np.array_equal(got["obs"], obs.cpu().numpy()) and np.array_equal(got["u"], u.cpu().numpy()) and np.array_equal(got["st"], st.cpu().numpy())
-    assert got["t"][0] == 1.25 and np.array_equal(got["tab"], on[0].astype(np.float32)) and np.array_equal(got["g"], u.cpu().numpy())
+    assert np.array_equal(got["obs"], obs.cpu().numpy()) and np.array_equal(got["u"], u.cpu().numpy(), equal_nan=True) and np.array_equal(got["st"], st.cpu().numpy())
+    assert got["t"][0] == 1.25 and np.array_equal(got["tab"], on[0].astype(np.float32)) and np.array_equal(got["g"], u.cpu().numpy(), equal_nan=True)
