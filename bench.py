@@ -1270,7 +1270,8 @@ def main():
                     res["vtol_reference_scene_fleet_closed_loop"] = vtol_fleet_closed_loop_leg(dev)
             except Exception as e:
                 res["vtol_reference_scene_closed_loop"] = {"error": repr(e)[:200]}
-            res["od_vtol_mpc_cbf"] = od_vtol_mpc_leg(dev)
+            # (od_vtol_mpc_cbf, the condensed optimal-decay VTOL2D kernel -- 1.1 s per 4096, 87 % optimal, superseded by the multiple-shooting
+            #  instantiation below -- left the default line in round 6; tests/test_od_vtol_gpu.py still holds it to its oracle)
             res["od_vtol_ms_mpc_cbf"] = od_vtol_ms_mpc_leg(dev)
             res["closed_loop_mpc"] = closed_loop_mpc_leg(dev)
             res["backup_cbf_qp"] = backup_cbf_leg(dev)

@@ -287,7 +287,8 @@ static int check_mpcvtol(const sc_mpcvtol_params* p, int64_t B, int32_t K, const
     if (!(p->airframe[0] > 0) || !(p->airframe[1] > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "airframe: mass and inertia must be > 0");
     if (!(p->v_max > 0) || !(p->pitch_max > 0)) return fail(SC_ERR_INVALID_ARGUMENT, "v_max and pitch_max must be > 0");
     if (p->slack_reset < 0 || p->slack_reset > 2) return fail(SC_ERR_INVALID_ARGUMENT, "slack_reset must be 0, 1 or 2");
-    if (p->kernel < 0 || p->kernel > 2) return fail(SC_ERR_INVALID_ARGUMENT, "kernel must be 0 (auto), 1 (lane per problem) or 2 (wave per problem)");
+    if (p->kernel < 0 || p->kernel > 2) return fail(SC_ERR_INVALID_ARGUMENT, "kernel must be 0 (auto) or 2 (wave per problem)");
+    if (p->kernel == 1) return fail(SC_ERR_UNSUPPORTED, "kernel = 1 (one NLP per lane) was retired in round 6: the wave-per-problem kernel serves every case");
     if (p->kernel == 2 && !mpcvtol_uses_wave(*p, K)) return fail(SC_ERR_UNSUPPORTED, "the wave-per-problem kernel serves K <= 16, horizon <= 64");
     if (B > 0 && (!X || !u_prev || !goal || !obs || !u_out || !status_out)) return fail(SC_ERR_INVALID_ARGUMENT, "NULL data pointer");
     if (B > 0x7fffffffLL) return fail(SC_ERR_UNSUPPORTED, "B too large for one launch");

@@ -1,5 +1,5 @@
 """MPC-CBF for VTOL2D on the gfx950 kernel csrc/mpc_vtol_wave.hip (one NLP per wavefront, one stage per lane, stage-wise Riccati Newton steps;
-csrc/mpc_vtol.hip holds the one-NLP-per-lane kernel it was checked against, ``kernel = 1``).
+the one-NLP-per-lane kernel it was developed against, ``kernel = 1``, was retired in round 6 and is refused by the C-ABI).
 
 ``safe_control_amd.MPCCBF(robot, robot_spec, ...)`` returns a ``VtolMPCCBF`` for ``model == 'VTOL2D'`` (the reference serves
 every model from the one MPCCBF class, position_control/mpc_cbf.py:7-100; VTOL2D: :40-43 weights, :83-87 gains, horizon 30,
@@ -24,7 +24,7 @@ def make_params(robot_spec, cbf_param, horizon, dt, radius, io_dtype, obs_shared
     p = _lib.MpcVtolParams()
     p.io_dtype, p.horizon, p.max_iter, p.obs_shared, p.acceptable_iter = io_dtype, int(horizon), int(max_iter), 1 if obs_shared else 0, 15
     p.slack_reset = int(slack_reset)
-    p.kernel = int(kernel)                                 # 0 / 2: one NLP per wavefront (the kernel that serves the model), 1: one NLP per lane (cross-check; needs the workspace)
+    p.kernel = int(kernel)                                 # 0 / 2: one NLP per wavefront (the kernel that serves the model); 1 (one NLP per lane) is retired and refused
     p.dt = float(dt)
     for i in range(6):
         p.Q[i] = Q_VTOL[i]
@@ -115,8 +115,8 @@ class VtolMPCCBF:
 class BatchedVtolMPCCBF(_lib.SlicedSolver):
     """``solve(X[B,6], u_prev[B,4], goal[B,2], obs[B,K,7] | obs[K,7])`` -> ``u[B,4]``, ``status[B]``, ``iters[B]`` (and ``z[B,4N]`` if
     asked).  The default kernel (one NLP per wavefront, one stage per lane: csrc/mpc_vtol_wave.hip) keeps everything in registers
-    and LDS and needs no workspace; ``kernel = 1`` selects the one-NLP-per-lane kernel it was checked against, whose work arrays
-    (sc_mpcvtol_workspace_bytes: about 0.1 MB per problem) are kept between calls.  ``iter_slices`` / ``classify_first`` / ``order``:
+    and LDS and needs no workspace (``kernel = 1``, the one-NLP-per-lane kernel it was checked against, is retired: the C-ABI refuses it).
+    ``iter_slices`` / ``classify_first`` / ``order``:
     continuation launches of the wave kernel (include/safe_control_amd.h: sc_mpc_slices)."""
 
     def __init__(self, robot_spec=None, dt=0.05, io_dtype="f64", cbf_param=None, tol=1e-6, max_iter=_lib.IPOPT_MAX_ITER,
@@ -244,7 +244,10 @@ class BatchedOptimalDecayVtolMPCCBF(_lib.SlicedSolver):
 class OptimalDecayVtolMPCCBF:
     """Drop-in for position_control.optimal_decay_mpc_cbf.OptimalDecayMPCCBF with a VTOL2D robot (single agent per call; the one
     NLP goes through the batched entry point on device ``device``).  Horizon 30, Q / R of :44-47, gains 0.35 (:83-86).
-    ``robot_spec['mpc_formulation']`` as for ``VtolMPCCBF`` (default: multiple shooting, the decay rates two more inputs of a stage)."""
+    The NLP is solved in the multiple-shooting form (the decay rates two more inputs of a stage: csrc/mpc_vtol_ms.hip, 99.95 % optimal in
+    0.14 s per 4096 on the bench batch).  The condensed optimal-decay kernel (87 % optimal, one solve at the 3000-iteration budget, 1.1 s) is
+    no longer selectable here: ``robot_spec['mpc_formulation'] = 'condensed'`` raises; ``BatchedOptimalDecayVtolMPCCBF`` remains as the
+    restoration-less kernel behind ``BatchedOptimalDecayVtolMSMPCCBF(restoration=False, fallback=True)`` with a budget of 300 iterations."""
 
     def __init__(self, robot, robot_spec, num_obs=5, device=0):
         self.robot = robot
@@ -264,12 +267,12 @@ class OptimalDecayVtolMPCCBF:
         self.setup_control_problem()
 
     def setup_control_problem(self):
-        self.multiple_shooting = self.robot_spec.get("mpc_formulation", "multiple_shooting") != "condensed"
-        if self.multiple_shooting:
-            from .mpc_cbf_vtol_ms import BatchedOptimalDecayVtolMSMPCCBF
-            self._ctl = BatchedOptimalDecayVtolMSMPCCBF(self.robot_spec, dt=self.dt, io_dtype="f64", cbf_param=self.cbf_param, fallback=False)
-        else:
-            self._ctl = BatchedOptimalDecayVtolMPCCBF(self.robot_spec, dt=self.dt, io_dtype="f64", cbf_param=self.cbf_param)
+        if self.robot_spec.get("mpc_formulation", "multiple_shooting") == "condensed":
+            raise ValueError("OptimalDecayMPCCBF for VTOL2D: the condensed kernel was withdrawn as a position controller in round 6 (87 % optimal, 1.1 s per 4096 "
+                             "with one solve at the iteration budget); the multiple-shooting kernel serves the model")
+        self.multiple_shooting = True
+        from .mpc_cbf_vtol_ms import BatchedOptimalDecayVtolMSMPCCBF
+        self._ctl = BatchedOptimalDecayVtolMSMPCCBF(self.robot_spec, dt=self.dt, io_dtype="f64", cbf_param=self.cbf_param, fallback=False)
         self.u_prev = np.zeros(4)
         self.z = np.zeros(4 * self.horizon)
         self.rho = np.ones(2 * self.horizon)

@@ -239,6 +239,6 @@ def test_argument_validation_of_the_round4_entry_points_without_gpu():
     q.p_sb[1] = 0.0
     assert lib.sc_odmpcvtol_solve_batch(C.byref(q), 1, 8, *vargs, None) == 1
     q.p_sb[1], q.mpc.kernel = 10.0, 1
-    assert lib.sc_odmpcvtol_solve_batch(C.byref(q), 1, 8, *vargs, None) == 2                                       # the lane kernel has no OD form
+    assert lib.sc_odmpcvtol_solve_batch(C.byref(q), 1, 8, *vargs, None) == 2                                       # the lane kernel is retired
     q.mpc.kernel, q.mpc.resto.stall_iter = 0, 40
     assert lib.sc_odmpcvtol_solve_batch(C.byref(q), 1, 8, *vargs, None) == 2                                       # the VTOL2D kernels keep round 3's restoration

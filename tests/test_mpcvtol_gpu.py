@@ -1,5 +1,5 @@
 """GPU: the VTOL2D MPC-CBF kernels -- csrc/mpc_vtol_wave.hip (one NLP per wavefront, one stage per lane; the default) and
-csrc/mpc_vtol.hip (one NLP per lane, params.kernel = 1) -- against the numpy oracle (oracle/mpc_vtol.py: condensed single shooting, dense
+the retired one-NLP-per-lane form (params.kernel = 1, now refused) -- against the numpy oracle (oracle/mpc_vtol.py: condensed single shooting, dense
 Cholesky: a different linear algebra for the same Newton step) and against each other.
 
 Bar: SAME STATUS on every problem (restoration phase included), |u0 - u0_oracle| <= 1e-6 and |z - z_oracle| <= 2e-5 on every problem
@@ -126,21 +126,14 @@ def test_argument_checks():
         ctl.solve(t(X), t(up), t(goal), t(big))
 
 
-def test_wave_and_lane_kernels_agree():
-    """Same interior point, different division of labour (and different summation orders): statuses equal, plans equal to rounding."""
-    n = 256
-    X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("vtol", 4096, 8, seed=5))
-    out = {}
-    for kern in (1, 2):
-        ctl = sca.BatchedVtolMPCCBF(io_dtype="f64", max_iter=100, iter_slices=()); ctl.kernel = kern
-        u, st, it, z = ctl.solve(t(X), t(up), t(goal), t(obs), want_z=True)
-        torch.cuda.synchronize()
-        out[kern] = (u.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy(), z.cpu().numpy())
-    (u1, s1, i1, z1), (u2, s2, i2, z2) = out[1], out[2]
-    both = (s1 == 0) & (s2 == 0)
-    parted = (s1 != s2) | (both & (np.abs(z1 - z2).max(axis=1) > 2e-5))
-    assert parted.sum() <= 2 and both.mean() >= 0.9
-    assert np.mean(i1 == i2) >= 0.97
+def test_the_retired_lane_kernel_is_refused():
+    """sc_mpcvtol_params.kernel = 1 (one NLP per lane out of a caller workspace: the kernel the wave kernel was developed against) was retired in
+    round 6; the C-ABI says so instead of running something else."""
+    n = 4
+    X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("vtol", 64, 8, seed=5))
+    ctl = sca.BatchedVtolMPCCBF(io_dtype="f64", max_iter=100, iter_slices=()); ctl.kernel = 1
+    with pytest.raises(Exception, match="retired"):
+        ctl.solve(t(X), t(up), t(goal), t(obs))
 
 
 @pytest.mark.parametrize("K", [3, 10])

@@ -115,26 +115,25 @@ def test_f32_storage_and_k16_instantiation():
 
 def test_drop_in_class_routes_vtol2d():
     """safe_control_amd.OptimalDecayMPCCBF with a VTOL2D robot: the multiple-shooting kernel by default (decay rates as two more inputs of a
-    stage; held to oracle/ms_ipopt.py: vtol_od_model), the condensed one with robot_spec['mpc_formulation'] = 'condensed' (oracle/od_mpc_vtol.py)."""
+    stage; held to oracle/ms_ipopt.py: vtol_od_model); robot_spec['mpc_formulation'] = 'condensed' is refused since round 6 (the condensed
+    optimal-decay kernel stays reachable as BatchedOptimalDecayVtolMPCCBF and is held to oracle/od_mpc_vtol.py by the tests above)."""
     from safe_control_amd.robots.spec import RobotHandle
     from oracle import mpc_cbf as M, od_mpc_vtol as OV, ms_ipopt as MS
     x0 = np.array([0.0, 10.0, 0.0, 12.0, 0.0, 0.0])
     obsl = np.array([[30.0, 10.5, 1.5]])
     ref = {"state_machine": "track", "goal": np.array([100.0, 10.0]), "u_ref": np.zeros((4, 1))}
-    for form in ("multiple_shooting", "condensed"):
-        spec = {"model": "VTOL2D"} if form == "multiple_shooting" else {"model": "VTOL2D", "mpc_formulation": form}
+    with pytest.raises(ValueError, match="withdrawn"):                      # (round 6: 87 % optimal / 1.1 s per 4096 / one solve at the budget -- not a position controller)
+        sca.OptimalDecayMPCCBF(RobotHandle(x0.reshape(-1, 1), {"model": "VTOL2D"}, dt=0.05), {"model": "VTOL2D", "mpc_formulation": "condensed"}, num_obs=2)
+    for form in ("multiple_shooting",):
+        spec = {"model": "VTOL2D"}
         robot = RobotHandle(x0.reshape(-1, 1), spec, dt=0.05)
         ctl = sca.OptimalDecayMPCCBF(robot, spec, num_obs=2)
         assert type(ctl).__name__ == "OptimalDecayVtolMPCCBF" and ctl.horizon == 30 and ctl.n_controls == 4 and ctl.status == "optimal"
-        assert ctl.cbf_param["alpha1"] == 0.35 and ctl.cbf_param["p_sb1"] == 10.0 and ctl.multiple_shooting == (form == "multiple_shooting")
+        assert ctl.cbf_param["alpha1"] == 0.35 and ctl.cbf_param["p_sb1"] == 10.0 and ctl.multiple_shooting
         u = ctl.solve_control_problem(robot.X, ref, obsl)
-        if form == "condensed":
-            uo, ro, so, io, info = OV.solve(x0, np.zeros(4), ref["goal"], M.pad_obstacles(obsl, 2), spec=dict(radius=robot.robot_radius), return_info=True)
-            rho_o = info["zz"][120:]
-        else:
-            mdl = MS.vtol_od_model(dict(radius=robot.robot_radius))
-            uo, so, io, info = MS.solve(mdl, x0, np.zeros(4), ref["goal"], M.pad_obstacles(obsl, 2), return_info=True, opts=dict(MS.KERNEL_PROFILE))
-            rho_o = info["U"][:, 4:].reshape(-1); ro = rho_o[:2]; uo = uo[:4]
+        mdl = MS.vtol_od_model(dict(radius=robot.robot_radius))
+        uo, so, io, info = MS.solve(mdl, x0, np.zeros(4), ref["goal"], M.pad_obstacles(obsl, 2), return_info=True, opts=dict(MS.KERNEL_PROFILE))
+        rho_o = info["U"][:, 4:].reshape(-1); ro = rho_o[:2]; uo = uo[:4]
         assert so == 0 and ctl.solver_status == "optimal" and abs(ctl.iterations - io) <= 1, (form, ctl.iterations, io)
         assert np.abs(u.reshape(-1) - uo).max() <= 1e-6
         assert abs(ctl.omega1 - ro[0]) <= 2e-5 and abs(ctl.omega2 - ro[1]) <= 2e-5
