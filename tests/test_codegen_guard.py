@@ -85,6 +85,31 @@ def test_a_new_singleton_fails_in_a_unit_built_with_the_splitting_allocator(tmp_
     assert C.main() == 0                                                  # the same site once reviewed and listed
 
 
+def test_a_split_copy_followed_by_a_spill_of_the_copy_is_still_a_hit():
+    """The exemption for scratch stores in front of an EXEC restore (a store whose data the block itself sets is region code) holds only
+    when that data comes from an immediate or a scalar register: `v_mov vT, vLong; scratch_store vT` -- a live-range split copy that is
+    spilled right away -- in front of the s_or_b64 is the defect's signature and must be reported; `v_mov vT, 0; scratch_store vT` must not."""
+    import check_exec_prologue as C
+    head = """
+0000000000001000 <kernel>:
+	s_cbranch_execz 3                                          // 000000001000: BF880003
+	v_add_f64 v[0:1], v[0:1], v[2:3]                           // 000000001004: D2800000
+	s_branch 65534                                             // 00000000100C: BF82FFFE
+	s_nop 0                                                    // 000000001010: BF800000
+	v_readlane_b32 s0, v253, 35                                // 000000001014: D2890000
+"""
+    tail = """	scratch_store_dword off, v5, off offset:728                // 000000001020: DC700000
+	s_or_b64 exec, exec, s[4:5]                                // 00000000102C: 87FE047E
+	s_endpgm                                                   // 00000000103C: BF810000
+"""
+    split_then_spill = head + "	v_mov_b32_e32 v5, v151                                     // 00000000101C: 7E9E0397\n" + tail
+    from_constant = head + "	v_mov_b32_e32 v5, 0                                        // 00000000101C: 7E9E0280\n" + tail
+    from_scalar = head + "	v_mov_b32_e32 v5, s7                                       // 00000000101C: 7E9E0207\n" + tail
+    from_agpr = head + "	v_accvgpr_read_b32 v5, a12                                 // 00000000101C: D3D84005\n" + tail
+    assert len(C.scan(split_then_spill)) == 1 and len(C.scan(from_agpr)) == 1
+    assert C.scan(from_constant) == [] and C.scan(from_scalar) == []
+
+
 # the compiler build the two -mllvm flags of SAFE_RA (undocumented switches of LLVM's AMDGPU back end) were validated on
 VALIDATED_HIPCC = ("HIP version: 7.2.26015-fc0010cf6a", "roc-7.2.0 26014 7b800a19466229b8479a78de19143dc33c3ab9b5")
 

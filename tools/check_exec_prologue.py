@@ -116,8 +116,8 @@ def scan(asm):
                     continue
                 if COPY.match(txt) or SCR.match(txt):
                     if SCR.match(txt):
-                        # a store whose data register was written in THIS block in front of it (a constant / a value the block
-                        # computes for the lanes that run it: a phi of the region) is code of the region, not a split copy
+                        # a store whose data register was written in THIS block in front of it FROM A CONSTANT OR A SCALAR (a value the block
+                        # sets for the lanes that run it: a phi of the region) is code of the region, not a split copy
                         ms = re.match(r"^scratch_store_\w+\s+off,\s*([va]\[?\d+(?::\d+\])?)", txt)
                         local = False
                         if ms:
@@ -127,7 +127,10 @@ def scan(asm):
                                 if len(parts) == 2 and parts[0].startswith("v_") and not parts[0].startswith(("v_readlane", "v_cmp")):
                                     k2, r2 = reg_numbers(parts[1].split(",")[0].strip())
                                     if k2 == kind and r2 & want:
-                                        local = True
+                                        # ... and only when that write takes an immediate or an SGPR: a VGPR / AGPR -> VGPR copy followed by a
+                                        # spill of the copy in front of the EXEC restore IS the defect's signature (split copy, then store)
+                                        ops = [o.strip() for o in parts[1].split(",")]
+                                        local = not (len(ops) >= 2 and re.match(r"^[va]\[?\d", ops[1]))
                         if not local:
                             copies.append(txt)
                     continue
@@ -157,6 +160,16 @@ def unsafe_units():
     return lambda path: os.path.basename(path).split(".")[0] not in safe
 
 
+# kernels of the translation units csrc/Makefile lists as GUARDED (big kernels on the splitting allocator)
+KERNEL_OF_UNIT = {"mpc_vtol_wave": "mpcvtol_wave_kernel", "mpc_vtol_ms": "mpcvtol_ms_kernel", "mpc_du_ms": "mpcdu_ms_kernel"}
+
+
+def guarded_kernels():
+    mk = open(os.path.join(ROOT, "safe_control_amd", "csrc", "Makefile")).read()
+    m = re.search(r"^GUARDED\s*:=\s*(.*)$", mk, re.M)
+    return [KERNEL_OF_UNIT[u] for u in (m.group(1).split() if m else []) if u in KERNEL_OF_UNIT]
+
+
 def main():
     """Threshold: two or more long-lived copies / reloads in front of an EXEC restore everywhere; ONE in the translation units built
     with the splitting (greedy) allocator, unless the site is in tools/exec_prologue_allow.json (kernel, blanked instruction text,
@@ -166,8 +179,11 @@ def main():
     total, allowed = 0, 0
     for p in paths:
         strict = greedy(p)
-        for asm in device_objects(p):
+        is_lib = p.endswith(".so")                                            # a linked library: which unit a kernel came from is no longer visible --
+        for asm in device_objects(p):                                         # threshold one for the kernels of the GUARDED units only (by name)
             for name, addr, copies in scan(asm):
+                if is_lib:
+                    strict = any(k in name for k in guarded_kernels())
                 if len(copies) < (1 if strict else 2):                    # single moves in front of an s_or_b64 are ordinary code of the region with the basic
                     continue                                              # allocator, which never splits (measured); with the greedy one they are reviewed one by one
                 dem = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
