@@ -463,7 +463,14 @@ typedef struct sc_ipopt_params {
      * the-boundary rule pins every step against a bound: measured on 2 of 4096 optimal-decay bench problems, after their restoration).
      * stall_iter = 0 disables the rule.  Oracle: oracle/ms_ipopt.py, options stall_iter / stall_alpha.                                    */
     double  stall_alpha;
-    int32_t stall_iter, reserved;
+    int32_t stall_iter;
+    /* NOT an IPOPT option either (round 6; the slot was `reserved`: no layout change): a regular-phase solve that has sat floor_iter consecutive
+     * iterations at the smallest barrier parameter with everything but the dual infeasibility inside the 'acceptable' tolerances ends
+     * SC_STATUS_INACCURATE there.  Found with the 256-aircraft flight: six of ~80 k VTOL2D solves reach their optimum (the float64 oracle calls
+     * them optimal after ~95 iterations with the same input to 3e-8) and then sit on a precision floor of the kernel's multiplier recovery
+     * (multipliers of 1e8, a dual infeasibility that stays ~1) until max_iter: 0.7 s each in a closed loop.  30 in the Python classes; 0 disables
+     * the rule.  Oracle: oracle/ms_ipopt.py, option floor_iter.                                                                             */
+    int32_t floor_iter;
 } sc_ipopt_params;
 
 size_t sc_mpcvtol_ms_workspace_bytes(int64_t B, int32_t K);

@@ -413,7 +413,12 @@ OPTS = dict(tol=1e-8, max_iter=3000, dual_inf_tol=1.0, constr_viol_tol=1e-4, com
             # IPOPT's recalc_y as a rescue (an experiment of round 5, DESIGN.md (f) 2b'; the kernel does not run it): once a regular-phase solve has sat recalc_y_iter iterations at a barrier
             # parameter within 10 x its floor with everything but the dual infeasibility inside the 'acceptable' tolerances, the row multipliers are
             # re-estimated by least squares at every iterate from then on (0: never)
-            recalc_y_iter=0)
+            recalc_y_iter=0,
+            # NOT an IPOPT option either (round 6; csrc/mpc_vtol_ms.hip runs with 30): a regular-phase solve that has sat floor_iter consecutive iterations
+            # at the smallest barrier parameter with everything but the dual infeasibility inside the 'acceptable' tolerances stops there (same class as
+            # running out of iterations: status 2) -- the iterate is the optimum, what does not come down is the precision floor of the multiplier
+            # recovery (DESIGN.md kernel 12), and IPOPT itself would spend the rest of its 3000 iterations there for the same input (0: never)
+            floor_iter=0)
 
 EPS = np.finfo(float).eps
 
@@ -507,9 +512,9 @@ class _Resto(_Problem):
 
 
 # what csrc/mpc_vtol_ms.hip runs (DESIGN.md kernel 12): stage-wise Riccati linear algebra, no second-order corrections, restoration phase with
-# elastic variables on the inequality rows only, the stall rule.  KERNEL_PROFILE_NO_RESTO: the same without a restoration phase (status 4).
-KERNEL_PROFILE = dict(linear_solver="riccati", max_soc=0, resto_elastic="ineq", stall_iter=60, stall_alpha=1e-4)
-KERNEL_PROFILE_NO_RESTO = dict(linear_solver="riccati", max_soc=0, restoration="none", stall_iter=60, stall_alpha=1e-4)
+# elastic variables on the inequality rows only, the stall rule, the precision-floor stop.  KERNEL_PROFILE_NO_RESTO: the same without a restoration phase (status 4).
+KERNEL_PROFILE = dict(linear_solver="riccati", max_soc=0, resto_elastic="ineq", stall_iter=60, stall_alpha=1e-4, floor_iter=30)
+KERNEL_PROFILE_NO_RESTO = dict(linear_solver="riccati", max_soc=0, restoration="none", stall_iter=60, stall_alpha=1e-4, floor_iter=30)
 
 
 def _dist(v, lo, hi):
@@ -1031,6 +1036,17 @@ class _Algo:
                     self.recalc_y = True
                     y = self.ls_multipliers(ev, z)
                     continue
+            if not self.in_resto and o["floor_iter"] > 0:
+                sxL_, sxU_, stL_, stU_ = self.slacks(x, t)
+                nb_ = sum(int(np.sum(np.isfinite(s_))) for s_ in (sxL_, sxU_, stL_, stU_))
+                sc_ = max(o["s_max"], float(sum(np.sum(np.abs(z_)) for z_ in z)) / max(1, nb_)) / o["s_max"]
+                mu_min_ = min(o["tol"], o["compl_inf_tol"]) / (o["barrier_tol_factor"] + 1.0)
+                at_floor = (mu <= 10.0 * mu_min_ and n_acc == 0 and max(pinf, comp / sc_) <= o["acceptable_tol"] and un_pinf <= o["acceptable_constr_viol_tol"]
+                            and comp <= o["acceptable_compl_inf_tol"] * df)
+                self.n_at_floor = getattr(self, "n_at_floor", 0) + 1 if at_floor else 0
+                if self.n_at_floor >= o["floor_iter"]:
+                    status = "max_iter"
+                    break
             if o["stall_iter"] > 0 and getattr(self, "n_tiny", 0) >= o["stall_iter"]:
                 status = "resto_failed" if self.in_resto else "max_iter"     # (the stall rule, in either phase: same class as running out of iterations)
                 break

@@ -258,7 +258,7 @@ class IpoptParams(C.Structure):
         "perturb_dec_fact",
         "resto_penalty_parameter", "resto_proximity_weight", "required_infeasibility_reduction", "bound_mult_reset_threshold",
         "resto_failure_feasibility_threshold", "resto_theta_max_fact")] + [("resto_workspace", C.c_void_p), ("resto_workspace_bytes", C.c_int64),
-                                                                      ("stall_alpha", C.c_double), ("stall_iter", C.c_int32), ("reserved", C.c_int32)]
+                                                                      ("stall_alpha", C.c_double), ("stall_iter", C.c_int32), ("floor_iter", C.c_int32)]
 
 
 IPOPT_DEFAULTS = dict(
@@ -271,7 +271,8 @@ IPOPT_DEFAULTS = dict(
     first_hessian_perturbation=1e-4, min_hessian_perturbation=1e-20, max_hessian_perturbation=1e20, perturb_inc_fact_first=100.0,
     perturb_inc_fact=8.0, perturb_dec_fact=1.0 / 3.0,
     resto_penalty_parameter=1000.0, resto_proximity_weight=1.0, required_infeasibility_reduction=0.9, bound_mult_reset_threshold=1e3,
-    resto_failure_feasibility_threshold=1e-6, resto_theta_max_fact=1e8, stall_alpha=1e-4, stall_iter=60)
+    resto_failure_feasibility_threshold=1e-6, resto_theta_max_fact=1e8, stall_alpha=1e-4, stall_iter=60,
+    floor_iter=30)          # (stall_alpha / stall_iter / floor_iter: NOT IPOPT options, see sc_ipopt_params)
 
 
 def default_ipopt(**over):

@@ -885,6 +885,7 @@ static int check_ms_common(const sc_mpcvtol_params* params, const sc_ipopt_param
         !(ipopt->alpha_red_factor > 0.0 && ipopt->alpha_red_factor < 1.0) || !(ipopt->perturb_inc_fact > 1.0) || !(ipopt->perturb_inc_fact_first > 1.0) ||
         !(ipopt->first_hessian_perturbation > 0.0) || !(ipopt->s_max > 0.0) || !(ipopt->kappa_sigma > 1.0))
         return sc::fail(SC_ERR_INVALID_ARGUMENT, "sc_ipopt_params out of range");
+    if (ipopt->stall_iter < 0 || ipopt->floor_iter < 0) return sc::fail(SC_ERR_INVALID_ARGUMENT, "sc_ipopt_params: stall_iter and floor_iter must be >= 0");
     if (ipopt->resto_workspace) {
         if ((size_t)ipopt->resto_workspace_bytes < sc_mpcvtol_ms_workspace_bytes(B, K)) return sc::fail(SC_ERR_INVALID_ARGUMENT, "resto_workspace smaller than sc_mpcvtol_ms_workspace_bytes(B, K)");
         if (!(ipopt->resto_penalty_parameter > 0.0) || !(ipopt->resto_proximity_weight >= 0.0) || !(ipopt->required_infeasibility_reduction > 0.0 && ipopt->required_infeasibility_reduction < 1.0))
@@ -929,6 +930,7 @@ static int check_ipopt_options(const sc_ipopt_params* ipopt) {
         !(ipopt->alpha_red_factor > 0.0 && ipopt->alpha_red_factor < 1.0) || !(ipopt->perturb_inc_fact > 1.0) || !(ipopt->perturb_inc_fact_first > 1.0) ||
         !(ipopt->first_hessian_perturbation > 0.0) || !(ipopt->s_max > 0.0) || !(ipopt->kappa_sigma > 1.0))
         return sc::fail(SC_ERR_INVALID_ARGUMENT, "sc_ipopt_params out of range");
+    if (ipopt->stall_iter < 0 || ipopt->floor_iter < 0) return sc::fail(SC_ERR_INVALID_ARGUMENT, "sc_ipopt_params: stall_iter and floor_iter must be >= 0");
     if (!(ipopt->resto_penalty_parameter > 0.0) || !(ipopt->resto_proximity_weight >= 0.0) || !(ipopt->required_infeasibility_reduction > 0.0 && ipopt->required_infeasibility_reduction < 1.0))
         return sc::fail(SC_ERR_INVALID_ARGUMENT, "sc_ipopt_params: restoration options out of range");
     return SC_OK;

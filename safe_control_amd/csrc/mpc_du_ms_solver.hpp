@@ -722,7 +722,7 @@ struct Wave {
     // The rows' share of the optimality error is gathered by eval2's row loop (ErrAcc): dual infeasibility of the slacks, residuals, multiplier
     // sums, and the smallest / largest complementarity product -- max |s z - mu| over a set is max(|max - mu|, |min - mu|), so the error for ANY
     // barrier parameter comes without another pass over the rows.  errors() adds the x / u share and the wave reductions.
-    SC_HD void errors(const Eval2& E, double mu, double& E0, double& Emu, double& dinf, double& pinf, double& comp0, double& un_pinf) const {
+    SC_HD void errors(const Eval2& E, double mu, double& E0, double& Emu, double& dinf, double& pinf, double& comp0, double& un_pinf, double* sc_out = nullptr) const {
         double d = Ecur.d, p = Ecur.p, up = Ecur.up, cmin = Ecur.cmin, cmax = Ecur.cmax, ysum = Ecur.ysum, zsum = Ecur.zsum;
         if (acl) {
             double gl[NX];
@@ -752,6 +752,7 @@ struct Wave {
         const double sd = fmax(O.s_max, (ysum + zsum) / (m + nb)) / O.s_max, sc = fmax(O.s_max, zsum / nb) / O.s_max;
         E0 = fmax(fmax(dinf / sd, pinf), comp0 / sc);
         Emu = fmax(fmax(dinf / sd, pinf), compm / sc);
+        if (sc_out) *sc_out = sc;
     }
 
     // fraction to the boundary over my primal / dual variables; directional derivative of the barrier function along the step
@@ -869,6 +870,7 @@ struct Wave {
         double o_mu = 0.0, o_theta = 0.0, o_phi = 0.0, o_pinf = 0.0, o_dw_last = 0.0, o_theta_max = 0.0, o_theta_min = 0.0;
         bool r_first = false, want_resto = false, presolved = false;
         int n_tiny = 0;                                                    // consecutive accepted steps below stall_alpha (of the phase the solve is in)
+        int n_floor = 0;                                                   // consecutive regular iterates at the precision floor (sc_ipopt_params.floor_iter)
         for (;;) {
             if (filt_over) { status = SC_STATUS_INACCURATE; break; }
             if (want_resto) {
@@ -1056,7 +1058,8 @@ struct Wave {
             DPROF_ADD(0)
             if (phase == PH_START) { theta_max = (rs ? O.resto_theta_max_fact : O.theta_max_fact) * fmax(1.0, theta); theta_min = O.theta_min_fact * fmax(1.0, theta); }
             double E0, Emu, dinf, pinf, comp, un_pinf;
-            errors(E, mu, E0, Emu, dinf, pinf, comp, un_pinf);
+            double sc_c = 1.0;
+            errors(E, mu, E0, Emu, dinf, pinf, comp, un_pinf, &sc_c);
             if (trace && lane == 0) {
                 double* t = trace + (size_t)(it < O.max_iter ? it : O.max_iter) * TRACE_W;
                 t[0] = E0; t[1] = dinf; t[2] = pinf; t[3] = comp; t[4] = mu; t[5] = theta; t[6] = last_dw; t[7] = rs ? -last_alpha : last_alpha;      // (a negative step length marks an iterate of the restoration)
@@ -1120,6 +1123,12 @@ struct Wave {
                 } else n_acc = 0;
             }
             if (it >= O.max_iter) { status = SC_STATUS_INACCURATE; break; }
+            if (!rs && O.floor_iter > 0) {                                  // (sc_ipopt_params.floor_iter)
+                const bool at_floor = mu <= 10.0 * mu_min && n_acc == 0 && fmax(pinf, comp / sc_c) <= O.acceptable_tol && un_pinf <= O.acceptable_constr_viol_tol &&
+                                      comp <= O.acceptable_compl_inf_tol * df;
+                n_floor = at_floor ? n_floor + 1 : 0;
+                if (n_floor >= O.floor_iter) { status = SC_STATUS_INACCURATE; break; }
+            }
             if (O.stall_iter > 0 && n_tiny >= O.stall_iter) { status = SC_STATUS_INACCURATE; break; }       // (stall rule: see sc_ipopt_params)
             for (bool again = false;; again = true) {
                 if (again) { double e0_, a, b, c, d; errors(E, mu, e0_, Emu, a, b, c, d); }     // (the barrier parameter went down: E_mu for the new one)

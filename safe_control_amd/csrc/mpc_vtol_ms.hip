@@ -1023,7 +1023,7 @@ struct Wave {
     }
 
     // ---- optimality error (eq. (5)): E_mu and its parts ---------------------------------------------------------------------------------
-    __device__ __forceinline__ void errors(const Eval2& E, double mu, double& Emu, double& dinf, double& pinf, double& comp, double& un_pinf) const {
+    __device__ __forceinline__ void errors(const Eval2& E, double mu, double& Emu, double& dinf, double& pinf, double& comp, double& un_pinf, double* sc_out = nullptr) const {
         double d = 0.0, p = 0.0, c = 0.0, ysum = 0.0, zsum = 0.0, up = 0.0;
         if (act) {
             double gl[NX];
@@ -1075,6 +1075,7 @@ struct Wave {
         const double m = (double)(6 * (N + 1) + N * K), nb = (double)(5 * (N + 1) + 8 * N + N * K * (rs ? 3 : 1));
         const double sd = fmax(O.s_max, (ysum + zsum) / (m + nb)) / O.s_max, sc = fmax(O.s_max, zsum / nb) / O.s_max;
         Emu = fmax(fmax(dinf / sd, pinf), comp / sc);
+        if (sc_out) *sc_out = sc;
     }
 
     // fraction to the boundary over my primal / dual variables; directional derivative of the barrier function along the step
@@ -1265,6 +1266,7 @@ struct Wave {
         double o_mu = 0.0, o_theta = 0.0, o_phi = 0.0, o_pinf = 0.0, o_dw_last = 0.0, o_theta_max = 0.0, o_theta_min = 0.0;
         bool r_first = false, want_resto = false;
         int n_tiny = 0;                                                    // consecutive accepted steps below stall_alpha (of the phase the solve is in)
+        int n_floor = 0;                                                   // consecutive regular iterates at the precision floor (sc_ipopt_params.floor_iter)
         for (;;) {
             MPROF_T0
             if (want_resto) {
@@ -1494,7 +1496,8 @@ struct Wave {
             MPROF_ADD(0)
             if (phase == PH_START) { theta_max = (rs ? O.resto_theta_max_fact : O.theta_max_fact) * fmax(1.0, theta); theta_min = O.theta_min_fact * fmax(1.0, theta); }
             double E0, dinf, pinf, comp, un_pinf;
-            errors(E, 0.0, E0, dinf, pinf, comp, un_pinf);
+            double sc_c = 1.0;
+            errors(E, 0.0, E0, dinf, pinf, comp, un_pinf, &sc_c);
             if (trace && lane == 0) {
                 double* t = trace + (size_t)(it < O.max_iter ? it : O.max_iter) * TRACE_W;
                 t[0] = E0; t[1] = dinf; t[2] = pinf; t[3] = comp; t[4] = mu; t[5] = theta; t[6] = last_dw; t[7] = rs ? -last_alpha : last_alpha;      // (a negative step length marks an iterate of the restoration)
@@ -1568,6 +1571,12 @@ struct Wave {
                 } else n_acc = 0;
             }
             if (it >= O.max_iter) { status = SC_STATUS_INACCURATE; break; }
+            if (!rs && O.floor_iter > 0) {                                  // (see sc_ipopt_params.floor_iter: the iterate is the optimum, the dual infeasibility sits on a precision floor)
+                const bool at_floor = mu <= 10.0 * mu_min && n_acc == 0 && fmax(pinf, comp / sc_c) <= O.acceptable_tol && un_pinf <= O.acceptable_constr_viol_tol &&
+                                      comp <= O.acceptable_compl_inf_tol * df;
+                n_floor = at_floor ? n_floor + 1 : 0;
+                if (n_floor >= O.floor_iter) { status = SC_STATUS_INACCURATE; break; }
+            }
             if (O.stall_iter > 0 && n_tiny >= O.stall_iter) { status = SC_STATUS_INACCURATE; break; }       // (stall rule: see sc_ipopt_params)
             for (;;) {
                 double Emu, a, b, c, d;
