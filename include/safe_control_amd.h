@@ -38,10 +38,10 @@ extern "C" {
 #endif
 
 /* ABI version: the minor number goes up with EVERY change of a struct layout or an entry point's signature (round 4 grew
- * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2; round 5 added sc_ipopt_params and sc_mpcvtol_ms_solve_batch: 0.3; the continuation entry points of the optimal-decay families: 0.4; sc_odmpcvtol_ms_solve_batch: 0.5; round 6 added sc_mpccbf_ms_solve_batch: 0.7).  A binding compares sc_version() with the
+ * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2; round 5 added sc_ipopt_params and sc_mpcvtol_ms_solve_batch: 0.3; the continuation entry points of the optimal-decay families: 0.4; sc_odmpcvtol_ms_solve_batch: 0.5; round 6 added sc_mpccbf_ms_solve_batch: 0.7; sc_mpccbf_ms_workspace_bytes and sc_ipopt_params.floor_iter in the slot that was `reserved`: 0.8).  A binding compares sc_version() with the
  * version its struct mirrors were written for before the first call (safe_control_amd/_lib.py: ABI_VERSION). */
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 7
+#define SC_VERSION_MINOR 8
 
 /* ---- return codes ------------------------------------------------------ */
 typedef enum sc_error {
@@ -510,8 +510,8 @@ int sc_odmpcvtol_solve_batch_sliced(const sc_odmpcvtol_params* params, const sc_
  * own formulation.  Replaces MPCCBF.solve_control_problem (position_control/mpc_cbf.py:366-402: mpc.x0 = x; set_initial_guess(); update_tvp;
  * make_step -> do-mpc multiple shooting -> IPOPT, :162-174) for a batch: states x_0 .. x_N as variables, dynamics as equality rows, every
  * stage started at x0, IPOPT's filter line-search interior point at its documented defaults (sc_ipopt_params; oracle/ms_ipopt.py with
- * du_model() is the float64 statement, iterate for iterate), restoration phase inside the kernel (its state lives in LDS:
- * sc_ipopt_params.resto_workspace is not read).  sc_mpccbf_solve_batch solves the condensed single-shooting form of the same NLP with an
+ * du_model() is the float64 statement, iterate for iterate), restoration phase inside the kernel (its state lives in LDS;
+ * sc_ipopt_params.resto_workspace is the optional launch-order workspace here: sc_mpccbf_ms_workspace_bytes).  sc_mpccbf_solve_batch solves the condensed single-shooting form of the same NLP with an
  * l1-merit interior point: same optimum where there is one (4086 of 4096 config-3 draws), a different last iterate where the NLP has no
  * feasible point -- and the reference APPLIES that iterate (mpc_cbf.py:384, status hard-wired 'optimal', :10).
  *   params      the problem fields of sc_mpccbf_params (model_id = SC_MODEL_DYNAMIC_UNICYCLE2D only, horizon 1 .. 62, dt, Q, R, alpha1/2,
@@ -528,6 +528,11 @@ int sc_mpccbf_ms_solve_batch(const sc_mpccbf_params* params, const sc_ipopt_para
                              const void* X, const void* u_prev, const void* goal, const void* obs,
                              void* u_out, int32_t* status_out, int32_t* iters_out, void* plan_out, double* trace_out, void* stream);
 size_t sc_mpccbf_ms_lds_bytes(int32_t horizon, int32_t K);      /* LDS per NLP (one wavefront): 160 KiB / this = NLPs resident per CU */
+/* Optional launch-order workspace (device memory, no initialisation needed): passed as ipopt->resto_workspace / resto_workspace_bytes -- the
+ * fields the VTOL2D entry uses for its restoration state, which this kernel keeps in LDS.  With it, a pre-pass sends the problems whose start
+ * point violates a CBF row (every NLP without a feasible point is one: the long solves) to the front of the grid, and a launch of more than 1024
+ * problems ends with its longest solve instead of ~15 % later (configs[2]: 5.0 -> 4.3 ms).  Results do not depend on it.                       */
+size_t sc_mpccbf_ms_workspace_bytes(int64_t B);
 
 /* ---- optimal-decay MPC-CBF ---------------------------------------
  * OptimalDecayMPCCBF (position_control/optimal_decay_mpc_cbf.py:15-330) for DynamicUnicycle2D: the MPC-CBF NLP with

@@ -319,6 +319,7 @@ SYMBOLS = {
     "sc_mpcvtol_ms_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "sc_mpccbf_ms_solve_batch": (C.c_int, [C.POINTER(MpcCbfParams), C.POINTER(IpoptParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_mpccbf_ms_lds_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "sc_mpccbf_ms_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "sc_odmpcvtol_solve_batch": (C.c_int, [C.POINTER(OdMpcVtolParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_odmpcgn_solve_batch": (C.c_int, [C.POINTER(OdMpcGnParams), C.c_int64, C.c_int32] + [C.c_void_p] * 10),
     "sc_mpclin_model_doubles": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
@@ -372,7 +373,7 @@ SYMBOLS = {
 _lib = None
 
 # SC_VERSION_MAJOR * 1000 + SC_VERSION_MINOR of the header the ctypes mirrors above were written for
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class HipLibraryError(RuntimeError):

@@ -75,8 +75,9 @@ hipError_t mpcvtol_launch(const sc_mpcvtol_params& p, long long B, int K, const 
 hipError_t mpcvtol_ms_launch(const sc_mpcvtol_params& p, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
                              const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, hipStream_t stream);
 hipError_t mpcdu_ms_launch(const sc_mpccbf_params& p, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
-                           const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, hipStream_t stream);
+                           const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, void* order_ws, hipStream_t stream);
 size_t mpcdu_ms_lds_bytes(int horizon, int K);
+size_t mpcdu_ms_order_bytes(long long B);
 hipError_t odmpcvtol_ms_launch(const sc_odmpcvtol_params& q, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
                                const void* obs, void* u_out, void* rho_out, int* status_out, int* iters_out, void* plan_out, double* trace_out,
                                hipStream_t stream);
@@ -936,6 +937,8 @@ static int check_ipopt_options(const sc_ipopt_params* ipopt) {
     return SC_OK;
 }
 
+size_t sc_mpccbf_ms_workspace_bytes(int64_t B) { return B < 0 ? 0 : sc::mpcdu_ms_order_bytes((long long)B); }
+
 size_t sc_mpccbf_ms_lds_bytes(int32_t horizon, int32_t K) {
     if (horizon < 1 || horizon > 62 || K < 1 || K > 16) return 0;
     return sc::mpcdu_ms_lds_bytes(horizon, K);
@@ -958,8 +961,15 @@ int sc_mpccbf_ms_solve_batch(const sc_mpccbf_params* params, const sc_ipopt_para
     if (rc != SC_OK) return rc;
     if (B == 0) return SC_OK;
     if (!X || !u_prev || !goal || !obs || !u_out || !status_out) return sc::fail(SC_ERR_INVALID_ARGUMENT, "NULL buffer");
+    // the optional launch-order workspace rides in the fields the VTOL2D entry uses for its restoration state (this kernel keeps that in LDS)
+    void* order_ws = nullptr;
+    if (ipopt->resto_workspace) {
+        if ((size_t)ipopt->resto_workspace_bytes < sc::mpcdu_ms_order_bytes((long long)B))
+            return sc::fail(SC_ERR_INVALID_ARGUMENT, "resto_workspace (launch-order workspace here) smaller than sc_mpccbf_ms_workspace_bytes(B)");
+        order_ws = ipopt->resto_workspace;
+    }
     hipError_t e = sc::mpcdu_ms_launch(*params, *ipopt, (long long)B, (int)K, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out,
-                                       (hipStream_t)stream);
+                                       order_ws, (hipStream_t)stream);
     if (e != hipSuccess) return sc::fail_hip(e, "mpccbf multiple-shooting kernel launch");
     return SC_OK;
 }

@@ -85,6 +85,9 @@ def test_full_batch_properties_and_the_condensed_kernel_on_the_feasible_draws():
     u1, s1, i1 = ctl.solve(f(X), f(up), f(goal), f(obs))
     u2, s2, i2 = ctl.solve(f(X), f(up), f(goal), f(obs))
     assert torch.equal(u1, u2) and torch.equal(s1, s2) and torch.equal(i1, i2)
+    # the launch order (problems whose start violates a CBF row first: a pre-pass + a permutation of the grid) changes the launch time only
+    u3, s3, i3 = sca.BatchedMSMPCCBF(SPEC, io_dtype="f32", order=False).solve(f(X), f(up), f(goal), f(obs))
+    assert torch.equal(u1, u3) and torch.equal(s1, s3) and torch.equal(i1, i3)
     assert (u1[:, 0].abs() <= 1.0 + 1e-6).all() and (u1[:, 1].abs() <= 0.5 + 1e-6).all()
     opt = (s1 == 0).double().mean().item()
     assert 0.85 <= opt <= 0.93 and (s1 == 2).double().mean().item() <= 0.005, opt
