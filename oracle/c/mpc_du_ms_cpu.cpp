@@ -65,7 +65,7 @@ struct Problem {
 struct Wavefront {
     std::vector<double> lds;
     double red[WAVE];
-    double gred[WAVE][42];
+    double gred[WAVE][36];
     void* sp[WAVE];
     void* main_sp = nullptr;
     bool done[WAVE];

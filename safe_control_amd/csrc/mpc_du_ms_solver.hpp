@@ -68,12 +68,12 @@ struct Params {
 SC_HD inline int sym6(int a, int b) { return a <= b ? a * 6 - a * (a - 1) / 2 + (b - a) : b * 6 - b * (b - 1) / 2 + (a - b); }
 
 struct Lds {
-    int OB, AB, H, G, G1, C, KG, PX, LAM, XS, US, YS, Pa, Pb, T, QU, FP, FT, FP2, FT2, SC, Y0, RW, XR, total;
+    int OB, AB, H, G, C, KG, PX, LAM, XS, US, YS, Pa, Pb, T, QU, FP, FT, FP2, FT2, SC, Y0, RW, XR, total;
     int N, K;
     SC_HD Lds(int N_, int K_) : N(N_), K(K_ < 1 ? 1 : K_) {
         int o = 0;
         auto take = [&](int c) { int r = o; o += c; return r; };
-        OB = take(3 * K); AB = take(N * 4); H = take((N + 1) * 21); G = take((N + 1) * 6); G1 = take((N + 1) * 6); C = take((N + 1) * 4);
+        OB = take(3 * K); AB = take(N * 4); H = take((N + 1) * 21); G = take((N + 1) * 6); C = take((N + 1) * 4);
         KG = take(N * 14); PX = take(N * 28);
         // Slots whose lifetimes do not overlap share storage (19.7 KB per problem at N = 10, K = 8: eight problems per CU):
         //   YS (multipliers as the neighbours see them: written and read at the start of an evaluation) / LAM (costates = multiplier steps:
@@ -459,14 +459,7 @@ struct Wave {
     BarAcc Bcur;                 // barrier terms of the iterate (eval2 gathers them)
     struct ErrAcc { double d, p, up, cmin, cmax, ysum, zsum; };
     ErrAcc Ecur;                 // the rows' share of the optimality error at the iterate (eval2 gathers it; errors())
-    // param (regular phase, dw = 0): the system is built BEFORE the barrier parameter of the step is known -- only the gradient depends on it,
-    // linearly: G = G0 + mu G1 (bound terms -mu / s and the rows' mu / s - kappa_d mu); G0 goes to L.G, G1 to L.G1, fix_gradient(mu) adds them
-    // once errors() and the mu update are through: one evaluation pass per iteration instead of two.
-    SC_HD void fix_gradient(double mu) {
-        if (acl) SC_UNROLL for (int p = 0; p < NV; ++p) if (p < NX || k < N) lds[L.G + k * 6 + p] += mu * lds[L.G1 + k * 6 + p];
-        sync();
-    }
-    SC_HD void eval2(const bool build, const bool ls, const bool param, Eval2& E, double mu, double dw, double& theta, double& fsum) {
+    SC_HD void eval2(const bool build, const bool ls, Eval2& E, double mu, double dw, double& theta, double& fsum) {
         publish();
         bar_begin(Bcur, x, u);
         Ecur.d = 0.0; Ecur.p = 0.0; Ecur.up = 0.0; Ecur.cmin = INFINITY; Ecur.cmax = -INFINITY; Ecur.ysum = 0.0; Ecur.zsum = 0.0;
@@ -504,20 +497,20 @@ struct Wave {
                 SC_UNROLL for (int j = 0; j < NU; ++j) gb[4 + j] = -zuL[j] + zuU[j];
             } else {
                 SC_UNROLL for (int i = 0; i < NX; ++i) dg_[i] = ((rs && act) ? zeta * dr2(i) : 2.0 * df * P.Q[i]) + dw;
-                const double a = x[3] - xbL, b = xbU - x[3], mg = param ? 1.0 : mu;        // (param: gb holds the coefficient of mu)
+                const double a = x[3] - xbL, b = xbU - x[3];
                 dg_[3] += zxL / a + zxU / b;
-                gb[3] = -mg / a + mg / b;
+                gb[3] = -mu / a + mu / b;
                 SC_UNROLL for (int j = 0; j < NU; ++j) {
                     const double a_ = u[j] - ubL[j], b_ = ubU[j] - u[j];
                     dg_[4 + j] = ((rs && stg) ? zeta * dr2(NX + j) : 2.0 * df * P.R[j] * (last ? 1.0 : 2.0)) + dw + zuL[j] / a_ + zuU[j] / b_;
-                    gb[4 + j] = -mg / a_ + mg / b_;
+                    gb[4 + j] = -mu / a_ + mu / b_;
                 }
             }
         }
         // my share of the stage's rows (lane q of the group walks rows q, q + G, ..); the sums the stage needs as a whole -- J'y, and for the
         // recursion the condensed block and gradient, the multiplier sums of the curvature terms -- are added over the group afterwards
-        double acc[42];                                                     // jr (6) | M (21) | gv (6) | sl, socx, socy | gv1 (6: param)
-        SC_UNROLL for (int i = 0; i < 42; ++i) acc[i] = 0.0;
+        double acc[36];                                                     // jr (6) | M (21) | gv (6) | sl, socx, socy
+        SC_UNROLL for (int i = 0; i < 36; ++i) acc[i] = 0.0;
         double* const jr = acc; double* const M = acc + 6; double* const gv = acc + 27;
         Geo g;
         double wy[NX] = {0.0, 0.0, 0.0, 0.0};
@@ -563,12 +556,11 @@ struct Wave {
                     else if (rs) { const RowW w = row_weights(j, mu, dw); Ej = w.E; bd = w.b; }
                     else {
                         Ej = vUj / stU + dw;
-                        const double gt = param ? 0.0 : mu / stU - O.kappa_d * mu;
+                        const double gt = mu / stU - O.kappa_d * mu;
                         bd = -rd + (ydj - gt) / Ej;
                     }
-                    // row gradient = -sc a:  H += E (sc a)(sc a)',  g += E b sc a   (param: E b = E b|mu=0 - mu (1 / s - kappa_d))
+                    // row gradient = -sc a:  H += E (sc a)(sc a)',  g += E b sc a
                     const double ea = Ej * sc * sc, eb = Ej * bd * sc;
-                    if (param) { const double eb1 = -sc * (1.0 / stU - O.kappa_d); SC_UNROLL for (int p = 0; p < NV; ++p) acc[36 + p] += eb1 * a[p]; }
                     int e = 0;
                     SC_UNROLL for (int p = 0; p < NV; ++p) {
                         gv[p] += eb * a[p];
@@ -579,7 +571,7 @@ struct Wave {
         } else {
             SC_UNROLL for (int i = 0; i < NX; ++i) rc[i] = 0.0;
         }
-        if (param) cx.template gsum<42>(acc, G); else if (build) cx.template gsum<36>(acc, G); else cx.template gsum<6>(acc, G);
+        if (build) cx.template gsum<36>(acc, G); else cx.template gsum<6>(acc, G);
         SC_UNROLL for (int i = 0; i < NV; ++i) E.Jty[i] -= jr[i];
         if (build && stl) {
             const double sl = acc[33], socx = acc[34], socy = acc[35];
@@ -610,8 +602,7 @@ struct Wave {
             int e = 0;
             SC_UNROLL for (int p = 0; p < NV; ++p) {
                 SC_UNROLL for (int r_ = p; r_ < NV; ++r_, ++e) lds[L.H + k * 21 + e] = M[e] + (p == r_ ? dg_[p] : 0.0);
-                lds[L.G + k * 6 + p] = (param ? 0.0 : gb[p]) + gv[p] + (p < NX ? E.gfx[p] : E.gfu[p - NX]) + (ls ? 0.0 : E.Jty[p]);
-                if (param) lds[L.G1 + k * 6 + p] = gb[p] + acc[36 + p];
+                lds[L.G + k * 6 + p] = gb[p] + gv[p] + (p < NX ? E.gfx[p] : E.gfu[p - NX]) + (ls ? 0.0 : E.Jty[p]);
             }
             // defects (unscaled) of my dynamics rows -> C[k + 1] = rc / dgc (ls: 0)
             SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.C + (k + 1) * 4 + i] = ls ? 0.0 : rc[i] / dgc(i);
@@ -619,8 +610,7 @@ struct Wave {
         if (build && acl && k == N) {                                       // terminal state: diagonal block, gradient
             SC_UNROLL for (int a = 0; a < NX; ++a) {
                 SC_UNROLL for (int b = a; b < NX; ++b) lds[L.H + N * 21 + sym6(a, b)] = a == b ? dg_[a] : 0.0;
-                lds[L.G + N * 6 + a] = (param ? 0.0 : gb[a]) + E.gfx[a] + (ls ? 0.0 : E.Jty[a]);
-                if (param) lds[L.G1 + N * 6 + a] = gb[a];
+                lds[L.G + N * 6 + a] = gb[a] + E.gfx[a] + (ls ? 0.0 : E.Jty[a]);
             }
         }
         if (lane == 0) {
@@ -914,14 +904,18 @@ struct Wave {
                 continue;
             }
             const bool ls = phase == PH_LS, build = phase == PH_LS || phase == PH_BUILD;
-#ifdef SC_DUMS_ONE_PASS                                                     // (measured: 5.34 ms per 4096 against 4.95 with two passes -- the launch ends with its
-            const bool param = !rs && (phase == PH_START || phase == PH_EVAL);      //  longest solve, which sits in the restoration phase, and the bigger pass costs registers)
+            // -DSC_DUMS_EARLY_BUILD: PH_START / PH_EVAL build the Newton system on the way (dw = 0) with the barrier parameter they arrive with, and
+            // PH_BUILD skips its evaluation when the mu update left it alone (most iterations inside a restoration).  Measured on configs[2]: the
+            // cycle counters of the longest solve say 116 k -> 109 k per iteration, the launch says 4.45 -> 4.53 ms (twice, alternating builds): not on.
+            // (Neither is the variant that always skips the second pass by keeping the gradient as G0 + mu G1: 5.34 ms against 4.95.)
+#ifdef SC_DUMS_EARLY_BUILD
+            const bool early = phase == PH_START || phase == PH_EVAL;
 #else
-            const bool param = false;
+            const bool early = false;
 #endif
+            const double mu_eval = mu;
             DPROF_T0
-            if (phase == PH_BUILD && presolved) fix_gradient(mu);
-            else eval2(build || param, ls, param, E, mu, param ? 0.0 : dw, theta, fsum);
+            if (!(phase == PH_BUILD && presolved)) eval2(build || early, ls, E, mu, early ? 0.0 : dw, theta, fsum);
             presolved = false;
             if (phase == PH_INIT) {
                 if (stg) for (int j = q; j < K; j += G) { double v = lds[ri(R_DV, j)]; push1(v, 0.0, lds[ri(R_SU, j)], false, true); lds[ri(R_S, j)] = v; }
@@ -1145,7 +1139,7 @@ struct Wave {
             }
             r_first = false;
             DPROF_ADD(1)
-            phase = PH_BUILD; dw = 0.0; ic_first = true; presolved = param;
+            phase = PH_BUILD; dw = 0.0; ic_first = true; presolved = early && mu == mu_eval;
         }
 #ifdef SC_DUMS_PROF
         if (trace && lane == 0) { double* t = trace + (size_t)O.max_iter * TRACE_W; for (int i = 0; i < 8; ++i) t[i] = prof[i]; }

@@ -27,11 +27,11 @@ def build():
     return lib
 
 
-LDS_NAMES = "OB AB H G G1 C KG PX LAM XS US YS Pa Pb T QU FP FT FP2 FT2 SC Y0 RW XR total".split()
+LDS_NAMES = "OB AB H G C KG PX LAM XS US YS Pa Pb T QU FP FT FP2 FT2 SC Y0 RW XR total".split()
 
 
 def lds_layout(lib, N, KS):
-    out = (C.c_int * 25)()
+    out = (C.c_int * 24)()
     lib.du_ms_host_lds_layout(N, KS, out)
     return dict(zip(LDS_NAMES, list(out)))
 

@@ -18,7 +18,7 @@ struct Shared {
     pthread_barrier_t bar;
     std::vector<double> lds;
     double red[64];
-    double gred[64][42];
+    double gred[64][36];
 };
 struct HostCtx {
     typedef double* ptr;
@@ -78,9 +78,9 @@ void lane_main(int lane, Shared* sh, const sc::dums::Params* P, const sc_ipopt_p
 
 extern "C" int du_ms_host_lds_layout(int N, int K, int* out) {
     const sc::dums::Lds L(N, K);
-    const int v[] = {L.OB, L.AB, L.H, L.G, L.G1, L.C, L.KG, L.PX, L.LAM, L.XS, L.US, L.YS, L.Pa, L.Pb, L.T, L.QU, L.FP, L.FT, L.FP2, L.FT2, L.SC, L.Y0, L.RW, L.XR, L.total};
-    for (int i = 0; i < 25; ++i) out[i] = v[i];
-    return 25;
+    const int v[] = {L.OB, L.AB, L.H, L.G, L.C, L.KG, L.PX, L.LAM, L.XS, L.US, L.YS, L.Pa, L.Pb, L.T, L.QU, L.FP, L.FT, L.FP2, L.FT2, L.SC, L.Y0, L.RW, L.XR, L.total};
+    for (int i = 0; i < 24; ++i) out[i] = v[i];
+    return 24;
 }
 
 extern "C" int du_ms_host_solve(const sc_mpccbf_params* prm, const sc_ipopt_params* O, int K, const double* x0, const double* u_prev, const double* goal,

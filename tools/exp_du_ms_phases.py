@@ -20,3 +20,7 @@ for B in (256, 4096):
     print(f"B = {B}: {its.sum():.0f} iterations; cycles per iteration {per.sum():.0f}")
     for n, v in zip(NAMES, per):
         print(f"   {n:24s} {v:9.0f}  {100 * v / per.sum():5.1f} %")
+    j = int(its.argmax())
+    pj = prof[j] / its[j]
+    print(f"   the longest solve (problem {j}, {its[j]:.0f} iterations, status {int(st[j])}): {pj.sum():.0f} cycles per iteration = {pj.sum() * its[j] / 2.4e6:.2f} ms at 2.4 GHz: " +
+          ", ".join(f"{n} {v:.0f}" for n, v in zip(NAMES, pj)))
