@@ -69,6 +69,20 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INS
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT -o vtolms_mem2 -- python3 $R/tools/time_mpcvtol.py 4096 f32 ms > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o vtolms_fetch -- python3 $R/tools/time_mpcvtol.py 4096 f32 ms > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o vtolms_write -- python3 $R/tools/time_mpcvtol.py 4096 f32 ms > /dev/null 2>&1
+# 13. BASELINE configs[3] on one rank: the neighbour search (uniform-grid cell list: nb_bbox / nb_count / nb_scan / nb_scatter / nb_select) + C3BF CBF-QP per step;
+#     and the search next to the plain scan it is held to (neighbor_kernel)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o kbc3bf -- python3 $R/bench.py --workload kb_c3bf --steps 50 --warmup 5 > $OUT/kbc3bf_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o kbc3bf_sq -- python3 $R/bench.py --workload kb_c3bf --steps 10 --warmup 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o kbc3bf_fetch -- python3 $R/bench.py --workload kb_c3bf --steps 10 --warmup 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o kbc3bf_write -- python3 $R/bench.py --workload kb_c3bf --steps 10 --warmup 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o neighbors -- python3 $R/tools/time_neighbors.py > /dev/null 2>&1
+# 14. kernel 13 (csrc/mpc_du_ms.hip: configs[2] as do-mpc poses it) next to the condensed kernel on the same batch: kernel trace, instruction mix, memory side
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o dums -- python3 $R/tools/time_mpcdu_ms.py 4096 f32 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o dums_sq -- python3 $R/tools/time_mpcdu_ms.py 4096 f32 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VMEM --output-format csv -d $OUT -o dums_mem -- python3 $R/tools/time_mpcdu_ms.py 4096 f32 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT -o dums_mem2 -- python3 $R/tools/time_mpcdu_ms.py 4096 f32 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o dums_fetch -- python3 $R/tools/time_mpcdu_ms.py 4096 f32 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o dums_write -- python3 $R/tools/time_mpcdu_ms.py 4096 f32 2 > /dev/null 2>&1
 # 10. sustained VALU issue peak of the part (the denominator of the valu_issue rooflines)
 [ -x $R/exp_libs/valu_peak ] || { mkdir -p $R/exp_libs; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/micro/valu_peak.hip -o $R/exp_libs/valu_peak > /dev/null 2>&1; }
 [ -x $R/exp_libs/valu_peak ] && $R/exp_libs/valu_peak > $OUT/valu_peak.txt 2>&1

@@ -26,7 +26,8 @@ src = os.path.join(ROOT, "gpurun_out", f"profiles_{rnd}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-OURS = ("cbfqp", "mpccbf", "tracking_rollout", "tracking_coop", "tracking_select", "tracking_apply", "neighbor_kernel", "odcbfqp", "mpclin", "mpcgn", "backupcbf", "mpcvtol", "quadtrack")   # manip_cbfqp matches "cbfqp"
+OURS = ("cbfqp", "mpccbf", "tracking_rollout", "tracking_coop", "tracking_select", "tracking_apply", "neighbor_kernel", "nb_bbox", "nb_count", "nb_scan", "nb_scatter",
+        "nb_select", "odcbfqp", "mpclin", "mpcgn", "backupcbf", "mpcvtol", "quadtrack", "mpcdu_ms")   # manip_cbfqp matches "cbfqp"
 
 
 def counters(path):
