@@ -266,7 +266,7 @@ def mpc_cpu_baseline(Xn, goal, on, N, seconds):
     best = "all_cores" if out["all_cores"][0] >= out["one_core"][0] else "one_core"
     v, nt, n = out[best]
     return {"value": v, "unit": "solves/s", "cores": nt, "kind": "port",
-            "sample": f"first {n} problems of the batch, oracle/c/mpc_du_ms_cpu.cpp (f64, oracle/ms_ipopt.py's algorithm compiled), OpenMP {nt} threads",
+            "sample": f"first {n} problems, oracle/c/mpc_du_ms_cpu.cpp (oracle/ms_ipopt.py's algorithm compiled), OpenMP {nt} threads",
             "one_core_value": out["one_core"][0], "all_cores_value": out["all_cores"][0],
             "python_oracle_value": py_rate, "python_oracle_sample": f"first {n_py} problems, oracle/ms_ipopt.py (numpy float64), 1 thread"}
 
@@ -1000,8 +1000,8 @@ def compact_leg(v):
     keep = {}
     for k in ("value", "kernel_ms", "ms_per_step", "ms_per_control_step", "us_per_step", "agent_steps_per_s", "solves_per_s", "optimal_fraction",
               "max_ipm_iterations", "agents", "GBs", "frac_of_peak", "error", "optimal_only_value",
-              "all_gather_bytes_per_step", "inaccurate_fraction", "landed", "return_code", "control_steps", "restoration_fallback", "landed_fraction", "lost_fraction", "aircraft"):
-        if k in v:
+              "inaccurate_fraction", "landed", "return_code", "control_steps", "restoration_fallback", "landed_fraction", "lost_fraction", "aircraft"):
+        if k in v and not (k == "inaccurate_fraction" and v[k] == 0.0) and v[k] is not None:      # (no inaccurate solves: not worth 28 bytes of the line)
             keep[k] = sig(v[k])
     if isinstance(v.get("one_launch_limit_100"), dict) and v.get("beyond_100_iterations"):      # (only where the budget beyond 100 iterations is used)
         keep["limit_100_ms"] = sig(v["one_launch_limit_100"]["kernel_ms"])
@@ -1041,8 +1041,8 @@ def emit(d, ws):
         m = compact_leg(mpc)
         m["workload"] = "BASELINE configs[2]: 4096 x DynamicUnicycle2D MPC-CBF N=10 K=8" if "configs[2]" in str(mpc.get("workload")) else mpc.get("workload")
         if isinstance(mpc.get("roofline"), dict):
-            m["roofline"] = {k: mpc["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_us", "stale")
-                             if k in mpc["roofline"]}
+            m["roofline"] = {k: (float(f"{v_:.5g}") if isinstance(v_, float) else v_) for k, v_ in
+                             ((k, mpc["roofline"].get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "stale") if k in mpc["roofline"])}
             if isinstance(mpc["roofline"].get("work_level"), dict):
                 m["roofline"]["work_frac"] = mpc["roofline"]["work_level"]["frac"]
         if isinstance(mpc.get("condensed"), dict):                     # the formulation of rounds 1 - 5 on the same batch (kernel 3), and how the two answers compare
