@@ -418,7 +418,8 @@ OPTS = dict(tol=1e-8, max_iter=3000, dual_inf_tol=1.0, constr_viol_tol=1e-4, com
             # at the smallest barrier parameter with everything but the dual infeasibility inside the 'acceptable' tolerances stops there (same class as
             # running out of iterations: status 2) -- the iterate is the optimum, what does not come down is the precision floor of the multiplier
             # recovery (DESIGN.md kernel 12), and IPOPT itself would spend the rest of its 3000 iterations there for the same input (0: never)
-            floor_iter=0)
+            floor_iter=0,
+            filter_cap=0)                   # (experiments: emulate a kernel's fixed-size filters; 0 = unbounded, as IPOPT's)
 
 EPS = np.finfo(float).eps
 
@@ -530,8 +531,10 @@ def _ftb(tau, slack, dslack):
 
 
 class _Filter:
-    def __init__(self):
+    def __init__(self, cap=0):
         self.e = []
+        self.cap = cap          # > 0: a kernel's fixed-size filter -- a full filter overwrites its last entry (option filter_cap; experiments only)
+        self.peak = 0
 
     def acceptable(self, phi, theta):
         for (p, t) in self.e:
@@ -541,7 +544,10 @@ class _Filter:
 
     def add(self, phi, theta):
         self.e = [(p, t) for (p, t) in self.e if not (p >= phi and t >= theta)]
+        if self.cap > 0 and len(self.e) >= self.cap:
+            self.e = self.e[:self.cap - 1]
         self.e.append((phi, theta))
+        self.peak = max(self.peak, len(self.e))
 
     def clear(self):
         self.e = []
@@ -553,7 +559,7 @@ class _Algo:
     def __init__(self, prob, o, resto_of=None, trace=None):
         self.P, self.o, self.outer, self.trace = prob, o, resto_of, trace
         self.in_resto = resto_of is not None
-        self.filter = _Filter()
+        self.filter = _Filter(int(o.get("filter_cap", 0) or 0))
         self.delta_w_last = 0.0
         self.iters = 0
 

@@ -20,13 +20,20 @@ mdl = MS.vtol_model(dict(radius=0.6, v_max=20.0))
 OPTS = {"ms": None, "riccati": dict(linear_solver="riccati"), "kernel": dict(linear_solver="riccati", resto_elastic="ineq"),
         "hybrid": dict(linear_solver="riccati", restoration="none"),
         "hybrid_nosoc": dict(linear_solver="riccati", restoration="none", max_soc=0),
-        "kernel_nosoc": dict(linear_solver="riccati", resto_elastic="ineq", max_soc=0)}.get(which)   # hybrid: regular phase here, the condensed oracle when it asks for a restoration
+        "kernel_nosoc": dict(linear_solver="riccati", resto_elastic="ineq", max_soc=0),
+        "profile": dict(MS.KERNEL_PROFILE)}.get(which)                       # profile: exactly what csrc/mpc_vtol_ms.hip is held to (stall / floor rules included)   # hybrid: regular phase here, the condensed oracle when it asks for a restoration
 log = []
+
+
+rec = []                                                                    # REC=<file.npz>: the inputs and results of every solve (replayed on the GPU: tools/exp_vtol_lost_replay.py)
 
 
 def solve_ms(X, up, goal, ob):
     t0 = time.time()
     u, st, it, info = MS.solve(mdl, X, up, goal, ob, return_info=True, opts=OPTS)
+    if os.environ.get("REC"):
+        rec.append(dict(X=np.array(X, float), up=np.array(up, float), goal=np.array(goal, float), ob=np.array(ob, float), u=np.array(u, float), st=st, it=it, status=info["status"]))
+        np.savez(os.environ["REC"], **{k: np.array([r[k] for r in rec]) for k in rec[0]})
     if info["status"] == "needs_resto":
         u2, st2, it2 = OV.solve(X, up, goal[:2], ob, N=30, spec=dict(spec))
         log.append(dict(st="resto->condensed:%d" % st2, it=it + it2, dt=time.time() - t0, viol=0.0, u=u2.copy()))

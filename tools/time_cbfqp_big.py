@@ -22,5 +22,8 @@ for comp in ("f64", "f32"):
     for _ in range(10): ctl.solve(a, b, c, out=out)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
+    import hashlib
+    hh = hashlib.sha256(); [hh.update(o.cpu().numpy().tobytes()) for o in out]
+    print("  outputs sha", hh.hexdigest()[:16], "stream_min", os.environ.get("SC_CBFQP_STREAM_MIN", "default"))
     print(f"2^{lg} agents, f32 storage, {comp} arithmetic: {ms:.3f} ms = {B / ms / 1e6:.2f} G solves/s = {292 * B / ms / 1e9:.2f} TB/s = {292 * B / ms / 1e9 / 8:.3f} of the HBM peak")
     del a, b, c, out
