@@ -323,14 +323,14 @@ def mpc_leg(dev, B, K, N, steps, warmup, seed=0, cpu_seconds=0.0):
         if rlc:
             work_level(rlc, condensed.get("uniform_batch"), float(itc.double().mean().item()), B)
             condensed["roofline"] = rlc
-        rl = valu_roofline("mpc_sq", "mpcdu_ms_kernel<float>", ms_ms, launches=1, note="one wave per problem, four lanes per stage; 512 registers: one wave "
+        rl = valu_roofline("mpc_sq", "mpcdu_ms_kernel<float, 0>", ms_ms, launches=1, note="one wave per problem, four lanes per stage; 512 registers: one wave "
                            "per SIMD = 1024 resident problems; the launch ends with its slowest problem (94 iterations, most of them inside the restoration phase, "
                            "against a mean of 17.6 at ~40 us per iteration)")
         if rl:
             extra["roofline"] = rl
     return {**extra, "workload": f"{B}-agent batch DynamicUnicycle2D MPC-CBF, horizon N={N}, {K} obstacles (BASELINE configs[2])",
             "formulation": "multiple shooting under IPOPT's filter interior point, restoration phase in the kernel (do-mpc's NLP: mpc_cbf.py:162-174,366-402)",
-            "kernel": "mpcdu_ms_kernel<float> (kernel 13)",
+            "kernel": "mpcdu_ms_kernel<float, 0> (kernel 13)",
             "value": B * steps / wall, "unit": "solves/s", "steps": steps, "kernel_ms": ms_ms,
             "dtype": "f64", "storage": "f32", "budget": 3000, "launches": "one",
             "optimal_fraction": float((st == 0).double().mean().item()),
@@ -585,7 +585,30 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     mid = {"DoubleIntegrator2D": 5, "Quad2D": 6, "KinematicBicycle2D": 1, "KinematicBicycle2D_C3BF": 2, "KinematicBicycle2D_DPCBF": 3}[model]
-    return with_roofline({**budget_note(mk, (X, up, g, ob), steps, ms, st, it),
+    extra = {}
+    if model == "DoubleIntegrator2D" and N <= 62 and K <= 16:
+        # the same batch in the reference's own formulation: kernel 13 instantiated for this robot (multiple shooting under IPOPT's algorithm)
+        msc = sca.BatchedMSMPCCBF({"model": model}, io_dtype="f32", horizon=N, check_circles=False)
+        um, sm, im = msc.solve(X, up, g, ob)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            um, sm, im = msc.solve(X, up, g, ob)
+        e1.record()
+        torch.cuda.synchronize()
+        mms = e0.elapsed_time(e1) / steps
+        both = (sm == 0) & (st == 0)
+        ms_d = {"kernel": "mpcdu_ms_kernel<float, 1> (kernel 13: multiple shooting, IPOPT's filter interior point; the drop-in's default for this robot)",
+                "value": B / (mms * 1e-3), "kernel_ms": mms, "optimal_fraction": float((sm == 0).double().mean().item()),
+                "infeasible_fraction": float((sm == 1).double().mean().item()), "inaccurate_fraction": float((sm == 2).double().mean().item()),
+                "mean_ipm_iterations": float(im.double().mean().item()), "max_ipm_iterations": int(im.max().item()),
+                "same_status_fraction": float((sm == st).double().mean().item()),
+                "same_u0_where_both_optimal_fraction": float(((um - u).abs().amax(dim=1) <= 1e-4)[both].double().mean().item()) if bool(both.any()) else None}
+        rl = valu_roofline("dumsdi_sq", "mpcdu_ms_kernel<float, 1>", mms) if (B, K, N, seed) == (4096, 8, 10, 0) else None
+        if rl:
+            ms_d["roofline"] = rl
+        extra["multiple_shooting"] = ms_d
+    return with_roofline({**extra, **budget_note(mk, (X, up, g, ob), steps, ms, st, it),
             "workload": f"{B}-agent batch {model} MPC-CBF, horizon N={N}, {K} obstacles",
             "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
             "optimal_fraction": float((st == 0).double().mean().item()),
@@ -1005,6 +1028,8 @@ def compact_leg(v):
             keep[k] = sig(v[k])
     if isinstance(v.get("one_launch_limit_100"), dict) and v.get("beyond_100_iterations"):      # (only where the budget beyond 100 iterations is used)
         keep["limit_100_ms"] = sig(v["one_launch_limit_100"]["kernel_ms"])
+    if isinstance(v.get("multiple_shooting"), dict):                     # the same batch on kernel 13 (the reference's own formulation)
+        keep["ms"] = compact_leg(v["multiple_shooting"])
     rl = v.get("roofline")
     if isinstance(rl, dict):
         keep["roofline"] = {k: sig(rl[k]) for k in ("bound", "frac", "stale") if k in rl}

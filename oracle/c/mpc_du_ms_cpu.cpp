@@ -60,6 +60,7 @@ struct Problem {
     const double *x0, *up, *goal, *obs;
     double* u_out;
     int *status, *iters;
+    int model;
 };
 
 struct Wavefront {
@@ -127,19 +128,24 @@ struct FiberCtx {
     double wmin(double v) { return reduce(v, [](double a, double b) { return std::fmin(a, b); }); }
 };
 
-void lane_body(Wavefront* w, int lane) {
+template <int MODEL>
+void lane_body_m(Wavefront* w, int lane) {
     using namespace sc::dums;
     const Problem& q = w->prob;
     FiberCtx cx{w->lds.data(), lane, w};
-    Wave<FiberCtx> S(cx, *q.P, *q.O);
+    Wave<FiberCtx, MODEL> S(cx, *q.P, *q.O);
+    constexpr int U0 = MODEL == M_DI ? 1 : 0;            // (M_DI holds its inputs swapped: mpc_du_ms_solver.hpp)
     if (lane < 3 * q.P->K) { const int j = lane / 3, c = lane % 3; w->lds[S.L.OB + lane] = q.obs[7 * j + c]; }
     for (int i = 0; i < NX; ++i) S.x0[i] = q.x0[i];
-    for (int j = 0; j < NU; ++j) S.uprev[j] = q.up[j];
+    for (int j = 0; j < NU; ++j) S.uprev[j] = q.up[j ^ U0];
     S.xg[0] = q.goal[0]; S.xg[1] = q.goal[1];
     cx.sync();
     int st, it;
     S.solve(st, it, nullptr);
-    if (lane == 0) { q.u_out[0] = S.u[0]; q.u_out[1] = S.u[1]; *q.status = st; *q.iters = it; }
+    if (lane == 0) { q.u_out[0 ^ U0] = S.u[0]; q.u_out[1 ^ U0] = S.u[1]; *q.status = st; *q.iters = it; }
+}
+void lane_body(Wavefront* w, int lane) {
+    if (w->prob.model == sc::dums::M_DI) lane_body_m<sc::dums::M_DI>(w, lane); else lane_body_m<sc::dums::M_DU>(w, lane);
 }
 
 extern "C" void sc_fiber_entry() {
@@ -177,6 +183,8 @@ extern "C" int du_ms_cpu_solve_batch(const sc_mpccbf_params* prm, const sc_ipopt
     for (int i = 0; i < 4; ++i) P.Q[i] = prm->Q[i];
     for (int j = 0; j < 2; ++j) { P.R[j] = prm->R[j]; P.u_lo[j] = -prm->u_max[j]; P.u_hi[j] = prm->u_max[j]; }
     P.alpha1 = prm->alpha1; P.alpha2 = prm->alpha2; P.beta = prm->beta; P.radius = prm->robot_radius; P.v_max = prm->v_max;
+    const int model = prm->model_id == SC_MODEL_DOUBLE_INTEGRATOR2D ? M_DI : M_DU;
+    if (model == M_DI) for (int j = 0; j < 2; ++j) { P.R[j] = prm->R[1 - j]; P.u_lo[j] = -prm->u_max[1 - j]; P.u_hi[j] = prm->u_max[1 - j]; }
     const size_t nl = (size_t)Lds(P.N, P.K).total;
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
@@ -190,7 +198,7 @@ extern "C" int du_ms_cpu_solve_batch(const sc_mpccbf_params* prm, const sc_ipopt
 #pragma omp for schedule(dynamic, 4)
         for (long b = 0; b < B; ++b) {
             std::fill(w->lds.begin(), w->lds.end(), 0.0);
-            w->prob = Problem{&P, O, X + 4 * b, u_prev + 2 * b, goal + 2 * b, obs + (prm->obs_shared ? 0 : (size_t)b * K * 7), u_out + 2 * b, status + b, iters + b};
+            w->prob = Problem{&P, O, X + 4 * b, u_prev + 2 * b, goal + 2 * b, obs + (prm->obs_shared ? 0 : (size_t)b * K * 7), u_out + 2 * b, status + b, iters + b, model};
             run_wave(w);
         }
         delete w;

@@ -71,7 +71,7 @@ def load_ms():
     return _lib_ms
 
 
-def du_ms_cpu_batch(X, u_prev, goal, obs, spec=None, horizon=10, dt=0.05, n_threads=0, ipopt=None):
+def du_ms_cpu_batch(X, u_prev, goal, obs, spec=None, horizon=10, dt=0.05, n_threads=0, ipopt=None, model="DynamicUnicycle2D"):
     """The multiple-shooting DynamicUnicycle2D MPC-CBF solve (oracle/ms_ipopt.py's algorithm in KERNEL_PROFILE) compiled for the host cores:
     X [B,4], u_prev [B,2], goal [B,2], obs [B,K,7] | [K,7] float64 -> u [B,2], status [B], iterations [B].  n_threads = 0: every core.
     The parameter structs are the C-ABI's own (safe_control_amd._lib mirrors of sc_mpccbf_params / sc_ipopt_params)."""
@@ -79,10 +79,11 @@ def du_ms_cpu_batch(X, u_prev, goal, obs, spec=None, horizon=10, dt=0.05, n_thre
     from safe_control_amd.position_control import mpc_cbf as PM
     from safe_control_amd.robots.spec import complete_robot_spec
     lib = load_ms()
-    sp = complete_robot_spec(dict({"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "v_max": 1.0, "radius": 0.25}, **(spec or {})))
-    Q, R = PM.default_mpc_weights("DynamicUnicycle2D")
+    base = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "v_max": 1.0, "radius": 0.25} if model == "DynamicUnicycle2D" else {"model": model}
+    sp = complete_robot_spec(dict(base, **(spec or {})))
+    Q, R = PM.default_mpc_weights(model)
     X, u_prev, goal, obs = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, u_prev, goal, obs))
-    p = PM.make_params(sp, PM.default_mpc_cbf_param("DynamicUnicycle2D"), Q, R, horizon, dt, sp["radius"], L.DTYPE_F64, obs_shared=obs.ndim == 2)
+    p = PM.make_params(sp, PM.default_mpc_cbf_param(model), Q, R, horizon, dt, sp["radius"], L.DTYPE_F64, obs_shared=obs.ndim == 2)
     ip = L.default_ipopt(**(ipopt or {}))
     B, K = X.shape[0], obs.shape[-2]
     u = np.empty((B, 2)); st = np.empty(B, dtype=np.int32); it = np.empty(B, dtype=np.int32)

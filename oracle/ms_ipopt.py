@@ -164,6 +164,51 @@ def du_next(x, u, spec, dt):
     return [x[0] + x[3] * c * dt, x[1] + x[3] * s * dt, x[2] + u[1] * dt, x[3] + u[0] * dt]
 
 
+def _clip(a, lo, hi):
+    """fmax(fmin(a, hi), lo) as casadi differentiates it: slope one inside, zero outside."""
+    if isinstance(a, VD2):
+        ins = ((a.v >= lo) & (a.v <= hi)).astype(float)
+        return VD2(np.clip(a.v, lo, hi), ins[:, None] * a.d, ins[:, None, None] * a.H)
+    return np.clip(a, lo, hi)
+
+
+def kb_next(x, u, spec, dt):
+    """KinematicBicycle2D: f = [v cos th, v sin th, 0, 0], g u = [-v sin th b, v cos th b, v b / L_r, a]   (kinematic_bicycle2D.py:67-110; U = [a, beta])."""
+    c, s = _cos(x[2]), _sin(x[2])
+    return [x[0] + (x[3] * c - x[3] * s * u[1]) * dt, x[1] + (x[3] * s + x[3] * c * u[1]) * dt, x[2] + (x[3] * u[1] / spec["rear_ax_dist"]) * dt, x[3] + u[0] * dt]
+
+
+def kb_step(x, u, spec, dt):
+    """robot.step as the DT barrier calls it (kinematic_bicycle2D.py:112-123,178-179): Euler, the heading wrap (touches no position), and the
+    speed clipped to [v_min, v_max] -- the model's x_next (mpc_cbf.py:138) has neither."""
+    xn = kb_next(x, u, spec, dt)
+    xn[3] = _clip(xn[3], spec["v_min"], spec["v_max"])
+    return xn
+
+
+def di_next(x, u, spec, dt):
+    """DoubleIntegrator2D: f = [vx, vy, 0, 0], g u = [0, 0, ax, ay]   (double_integrator2D.py:46-77)."""
+    return [x[0] + x[2] * dt, x[1] + x[3] * dt, x[2] + u[0] * dt, x[3] + u[1] * dt]
+
+
+def di_step(x, u, spec, dt):
+    """robot.step as the DT barrier calls it (double_integrator2D.py:79-107,225-226): Euler, then the velocity rescaled to norm v_max where it
+    is above it (casadi: if_else(v_mag > v_max, v_max / v_mag, 1)) -- the model's x_next (mpc_cbf.py:138) is the plain Euler step."""
+    xn = di_next(x, u, spec, dt)
+    vmag = _sqrt(xn[2] * xn[2] + xn[3] * xn[3])
+    over = (vmag.v if isinstance(vmag, VD2) else vmag) > spec["v_max"]
+    if isinstance(vmag, VD2):
+        if over.any():
+            sc = spec["v_max"] / vmag
+            o = over.astype(float)
+            mix = lambda a, b: VD2(o * a.v + (1 - o) * b.v, o[:, None] * a.d + (1 - o)[:, None] * b.d, o[:, None, None] * a.H + (1 - o)[:, None, None] * b.H)
+            xn[2], xn[3] = mix(xn[2] * sc, xn[2]), mix(xn[3] * sc, xn[3])
+    else:                                                                   # floats or arrays over the stages
+        sc = np.where(over, spec["v_max"] / np.where(over, vmag, 1.0), 1.0)
+        xn[2], xn[3] = xn[2] * sc, xn[3] * sc
+    return xn
+
+
 GRAVITY = 9.81                                                   # vtol2D.py:113
 
 
@@ -211,6 +256,28 @@ def du_model(spec=None, dt=0.05):
                 x_lo=np.array([-INF, -INF, -INF, -s["v_max"]]), x_hi=np.array([INF, INF, INF, s["v_max"]]))
 
 
+def kb_model(spec=None, dt=0.05):
+    """mpc_cbf.py:31-33 (Q, R), :64-66 (alpha1 = alpha2 = 0.1), :202-208 (|v| <= v_max, input box), kinematic_bicycle2D.py:175 (beta = 1.1)."""
+    s = dict(wheel_base=0.4, radius=0.3, rear_ax_dist=0.2, v_max=3.5, a_max=5.0, v_min=0.2)
+    s["beta_max"] = math.atan((0.2 / 0.4) * math.tan(math.radians(32)))
+    s.update(spec or {})
+    return dict(name="KinematicBicycle2D", nx=4, nu=2, next=kb_next, row_next=kb_step, spec=s, dt=dt, N=10, Q=np.array([50.0, 50.0, 1.0, 1.0]),
+                R=np.array([0.5, 5000.0]), alpha1=0.1, alpha2=0.1, beta=1.1, radius=s["radius"], circles_only=True,
+                u_lo=np.array([-s["a_max"], -s["beta_max"]]), u_hi=np.array([s["a_max"], s["beta_max"]]),
+                x_lo=np.array([-INF, -INF, -INF, -s["v_max"]]), x_hi=np.array([INF, INF, INF, s["v_max"]]))
+
+
+def di_model(spec=None, dt=0.05):
+    """mpc_cbf.py:28-30 (Q, R), :56-59 (alpha1 = alpha2 = 0.2), :196-200 (input box, no state bounds), double_integrator2D.py:222 (beta = 1.01)."""
+    s = dict(a_max=1.0, v_max=1.0, radius=0.25)
+    s.update(spec or {})
+    s.setdefault("ax_max", s["a_max"]); s.setdefault("ay_max", s["a_max"])
+    return dict(name="DoubleIntegrator2D", nx=4, nu=2, next=di_next, row_next=di_step, spec=s, dt=dt, N=10, Q=np.array([50.0, 50.0, 20.0, 20.0]),
+                R=np.array([0.5, 0.5]), alpha1=0.2, alpha2=0.2, beta=1.01, radius=s["radius"],
+                u_lo=np.array([-s["ax_max"], -s["ay_max"]]), u_hi=np.array([s["ax_max"], s["ay_max"]]),
+                x_lo=np.full(4, -INF), x_hi=np.full(4, INF))
+
+
 def vtol_model(spec=None, dt=0.05):
     from . import mpc_vtol as OV
     s = OV.default_spec(**(spec or {}))
@@ -248,7 +315,7 @@ class StageNLP:
         self.xg = np.zeros(nx)
         self.xg[:2] = np.asarray(goal, dtype=float).reshape(-1)[:2]     # goal padded with zeros (mpc_cbf.py:267)
         self.obs = np.asarray(obs, dtype=float)
-        self.circles_only = model["name"] == "VTOL2D"                  # vtol2D.py:482-490 has no superellipsoid branch
+        self.circles_only = model["name"] == "VTOL2D" or bool(model.get("circles_only"))     # vtol2D.py:482-490, kinematic_bicycle2D.py:181-189: no superellipsoid branch
         self.K = K = self.obs.shape[0]
         self.n = (N + 1) * nx + N * nu
         self.m_c = (N + 1) * nx
@@ -304,6 +371,13 @@ class StageNLP:
         spec, dt, nxt = self.mdl["spec"], self.mdl["dt"], self.mdl["next"]
         nd = self.mdl.get("nu_dyn", self.nu)
         x1 = nxt(x, u[:nd], spec, dt)
+        if self.mdl.get("row_next"):                                        # robot.step differs from the model's x_next (the bicycle's speed clip)
+            step = self.mdl["row_next"]
+            x1r = step(x, u[:nd], spec, dt)
+            x2 = step(x1r, u[:nd], spec, dt)
+            h0, h1, h2 = self._h(x[0], x[1]), self._h(x1r[0], x1r[1]), self._h(x2[0], x2[1])
+            w0, w1, w2 = self.cw
+            return x1, [-(w2 * h2[j] + w1 * h1[j] + w0 * h0[j]) for j in range(self.K)]
         x2 = nxt(x1, u[:nd], spec, dt)
         h0, h1, h2 = self._h(x[0], x[1]), self._h(x1[0], x1[1]), self._h(x2[0], x2[1])
         w0, w1, w2 = self.cw

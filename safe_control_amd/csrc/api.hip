@@ -949,7 +949,8 @@ int sc_mpccbf_ms_solve_batch(const sc_mpccbf_params* params, const sc_ipopt_para
                              void* stream) {
     sc::DeviceGuard on_device(stream, X);
     if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
-    if (params->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D) return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting MPC-CBF kernel is built for DynamicUnicycle2D");
+    if (params->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && params->model_id != SC_MODEL_DOUBLE_INTEGRATOR2D)
+        return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting MPC-CBF kernel is built for DynamicUnicycle2D and DoubleIntegrator2D");
     if (B < 0 || K < 1 || K > 16) return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting kernel serves 1 <= K <= 16 (pad with [1000,1000,0,...] rows like update_tvp)");
     if (B > 0x7fffffffLL) return sc::fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
     if (params->horizon < 1 || params->horizon > 62) return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting kernel serves 1 <= horizon <= 62 (one stage per lane + the terminal state)");

@@ -55,15 +55,25 @@ struct DevCtx {
 // caller workspace (sc_mpccbf_ms_workspace_bytes) a pre-pass evaluates the K rows of stage 0 at the start point and sends the problems with a
 // violated row to the front of the grid (two atomic counters; the order inside the two groups does not matter: a problem's result does not
 // depend on where it ran): list scheduling on the 1024 resident slots then ends at the longest solve instead of 15 % later.
-template <typename TIO>
+template <typename TIO, int MODEL>
 __global__ void __launch_bounds__(256) mpcdu_ms_order_kernel(const Params P, long long B, int obs_shared, const TIO* __restrict__ X, const TIO* __restrict__ u_prev,
                                                              const TIO* __restrict__ obs, int* __restrict__ counters, int* __restrict__ perm) {
     const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     const double x = (double)X[b * NX], y = (double)X[b * NX + 1], th = (double)X[b * NX + 2], v = (double)X[b * NX + 3];
     const double a = (double)u_prev[b * NU], w = (double)u_prev[b * NU + 1], dt = P.dt;
-    const double p1x = x + dt * v * cos(th), p1y = y + dt * v * sin(th), th1 = th + dt * w, v1 = v + dt * a;
-    const double p2x = p1x + dt * v1 * cos(th1), p2y = p1y + dt * v1 * sin(th1);
+    double p1x, p1y, p2x, p2y;
+    if constexpr (MODEL == M_DI) {                                            // (x, y, vx, vy), (ax, ay): th = vx, v = vy, a = ax, w = ay
+        p1x = x + dt * th; p1y = y + dt * v;
+        double wx = th + dt * a, wy = v + dt * w;
+        const double vm = sqrt(wx * wx + wy * wy);
+        if (vm > P.v_max) { wx *= P.v_max / vm; wy *= P.v_max / vm; }
+        p2x = p1x + dt * wx; p2y = p1y + dt * wy;
+    } else {
+        const double th1 = th + dt * w, v1 = v + dt * a;
+        p1x = x + dt * v * cos(th); p1y = y + dt * v * sin(th);
+        p2x = p1x + dt * v1 * cos(th1); p2y = p1y + dt * v1 * sin(th1);
+    }
     const double g1 = P.alpha1 + P.alpha2, g2 = P.alpha1 * P.alpha2, w0 = 1.0 - g1 + g2, w1 = g1 - 2.0;
     const TIO* ob = obs + (obs_shared ? 0 : b * P.K * 7);
     bool viol = false;
@@ -80,7 +90,7 @@ __global__ void __launch_bounds__(256) mpcdu_ms_order_kernel(const Params P, lon
 #ifndef SC_DUMS_WAVES
 #define SC_DUMS_WAVES 1
 #endif
-template <typename TIO>
+template <typename TIO, int MODEL>
 __global__ void __launch_bounds__(64, SC_DUMS_WAVES) mpcdu_ms_kernel(const Params P, const sc_ipopt_params O, long long B, int obs_shared, const TIO* __restrict__ X,
                                                       const TIO* __restrict__ u_prev, const TIO* __restrict__ goal, const TIO* __restrict__ obs,
                                                       TIO* __restrict__ u_out, int* __restrict__ status_out, int* __restrict__ iters_out,
@@ -89,20 +99,21 @@ __global__ void __launch_bounds__(64, SC_DUMS_WAVES) mpcdu_ms_kernel(const Param
     if ((long long)blockIdx.x >= B) return;
     const long long b = perm ? (long long)perm[blockIdx.x] : (long long)blockIdx.x;
     DevCtx cx{(ldsd*)dums_lds, (int)threadIdx.x};
-    Wave<DevCtx> S(cx, P, O);
+    Wave<DevCtx, MODEL> S(cx, P, O);
+    constexpr int U0 = MODEL == M_DI ? 1 : 0;                                 // M_DI keeps its inputs as (ay, ax): swapped on the way in and out
     const TIO* ob = obs + (obs_shared ? 0 : b * P.K * 7);
     if ((int)threadIdx.x < 3 * P.K) {
         const int j = threadIdx.x / 3, c = threadIdx.x % 3;
         dums_lds[S.L.OB + threadIdx.x] = j < P.K ? (double)ob[7 * j + c] : 0.0;
     }
     for (int i = 0; i < NX; ++i) S.x0[i] = (double)X[b * NX + i];
-    for (int j = 0; j < NU; ++j) S.uprev[j] = (double)u_prev[b * NU + j];
+    for (int j = 0; j < NU; ++j) S.uprev[j] = (double)u_prev[b * NU + (j ^ U0)];
     S.xg[0] = (double)goal[b * 2]; S.xg[1] = (double)goal[b * 2 + 1];
     __syncthreads();
     int st, it;
     S.solve(st, it, trace_out ? trace_out + (size_t)b * (size_t)(O.max_iter + 1) * TRACE_W : nullptr);
     if (threadIdx.x == 0) {
-        for (int j = 0; j < NU; ++j) u_out[b * NU + j] = (TIO)S.u[j];
+        for (int j = 0; j < NU; ++j) u_out[b * NU + (j ^ U0)] = (TIO)S.u[j];
         status_out[b] = st;
         if (iters_out) iters_out[b] = it;
     }
@@ -110,11 +121,11 @@ __global__ void __launch_bounds__(64, SC_DUMS_WAVES) mpcdu_ms_kernel(const Param
         // the plan: x_0 .. x_N (4 each), then u_0 .. u_{N-1} (2 each)
         TIO* po = plan_out + b * (long long)((P.N + 1) * NX + P.N * NU);
         for (int i = 0; i < NX; ++i) po[S.k * NX + i] = (TIO)S.x[i];
-        if (S.stg) for (int j = 0; j < NU; ++j) po[(P.N + 1) * NX + S.k * NU + j] = (TIO)S.u[j];
+        if (S.stg) for (int j = 0; j < NU; ++j) po[(P.N + 1) * NX + S.k * NU + (j ^ U0)] = (TIO)S.u[j];
     }
 }
 
-template <typename TIO>
+template <typename TIO, int MODEL>
 static hipError_t launch_t(const Params& P, const sc_ipopt_params& O, long long B, int obs_shared, const void* X, const void* u_prev, const void* goal,
                            const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, void* order_ws, hipStream_t stream) {
     const size_t lds = (size_t)Lds(P.N, P.K).total * sizeof(double);
@@ -124,12 +135,12 @@ static hipError_t launch_t(const Params& P, const sc_ipopt_params& O, long long 
         perm = counters + 4;
         hipError_t e0 = hipMemsetAsync(counters, 0, 4 * sizeof(int), stream);
         if (e0 != hipSuccess) return e0;
-        hipLaunchKernelGGL((mpcdu_ms_order_kernel<TIO>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, P, B, obs_shared, (const TIO*)X, (const TIO*)u_prev,
+        hipLaunchKernelGGL((mpcdu_ms_order_kernel<TIO, MODEL>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, P, B, obs_shared, (const TIO*)X, (const TIO*)u_prev,
                            (const TIO*)obs, counters, perm);
     }
-    hipError_t e = hipFuncSetAttribute((const void*)mpcdu_ms_kernel<TIO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)mpcdu_ms_kernel<TIO, MODEL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((mpcdu_ms_kernel<TIO>), dim3((unsigned)B), dim3(64), lds, stream, P, O, B, obs_shared, (const TIO*)X, (const TIO*)u_prev,
+    hipLaunchKernelGGL((mpcdu_ms_kernel<TIO, MODEL>), dim3((unsigned)B), dim3(64), lds, stream, P, O, B, obs_shared, (const TIO*)X, (const TIO*)u_prev,
                        (const TIO*)goal, (const TIO*)obs, (TIO*)u_out, status_out, iters_out, (TIO*)plan_out, trace_out, (const int*)perm);
     return hipGetLastError();
 }
@@ -146,9 +157,14 @@ hipError_t mpcdu_ms_launch(const sc_mpccbf_params& p, const sc_ipopt_params& O, 
     for (int i = 0; i < 4; ++i) P.Q[i] = p.Q[i];
     for (int j = 0; j < 2; ++j) { P.R[j] = p.R[j]; P.u_lo[j] = -p.u_max[j]; P.u_hi[j] = p.u_max[j]; }
     P.alpha1 = p.alpha1; P.alpha2 = p.alpha2; P.beta = p.beta; P.radius = p.robot_radius; P.v_max = p.v_max;
-    if (p.io_dtype == SC_DTYPE_F64)
-        return dums::launch_t<double>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
-    return dums::launch_t<float>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
+    const bool f64 = p.io_dtype == SC_DTYPE_F64;
+    if (p.model_id == SC_MODEL_DOUBLE_INTEGRATOR2D) {                          // inputs held as (ay, ax): mpc_du_ms_solver.hpp, M_DI
+        for (int j = 0; j < 2; ++j) { P.R[j] = p.R[1 - j]; P.u_lo[j] = -p.u_max[1 - j]; P.u_hi[j] = p.u_max[1 - j]; }
+        if (f64) return dums::launch_t<double, dums::M_DI>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
+        return dums::launch_t<float, dums::M_DI>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
+    }
+    if (f64) return dums::launch_t<double, dums::M_DU>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
+    return dums::launch_t<float, dums::M_DU>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
 }
 
 }  // namespace sc

@@ -60,6 +60,13 @@ constexpr int KS_MAX = 16, NFILT = 128, TRACE_W = 8;      // NFILT: entries per 
 constexpr double EPS_ = 2.220446049250313e-16;
 constexpr int ST_FILTER_FULL = 7;                 // (internal) the filter ran over: reported as SC_STATUS_INACCURATE
 
+// Models (template parameter of Wave): both have x+ = x + (f(x) + g(x) u) dt with the inputs entering states 2 and 3 only, two-step barrier rows
+// on the positions, and differ in the geometry, in its curvature and in the state bound:
+//   M_DU  DynamicUnicycle2D  x = (px, py, theta, v), u = (a, omega); |v_k| <= v_max                        (the header comment above)
+//   M_DI  DoubleIntegrator2D x = (px, py, vx, vy), u = (ax, ay), held here as (ay, ax) so that B = dt [[0, 0], [0, 0], [0, 1], [1, 0]] like
+//         the unicycle's (the launcher swaps R, the bounds and the I/O); no state bound; the barrier's robot.step rescales the velocity to
+//         norm v_max where it is above it (double_integrator2D.py:79-107,225-226): v_max is that norm            mpc_cbf.py:28-30,56-59,196-200
+enum { M_DU = 0, M_DI = 1 };
 struct Params {
     int N, K;
     double dt, Q[4], R[2], alpha1, alpha2, beta, radius, u_lo[2], u_hi[2], v_max;
@@ -214,8 +221,9 @@ SC_HD SC_DUMS_INLINE void riccati_forward(Cx& cx, const Lds& L, const int N, con
 SC_HD inline int group_lanes(int N) { return (N + 1) * 4 <= 64 ? 4 : ((N + 1) * 2 <= 64 ? 2 : 1); }
 SC_HD inline bool cmp_le(double lhs, double rhs, double bas) { return lhs - rhs <= 10.0 * EPS_ * fabs(bas); }
 
-template <class Cx>
+template <class Cx, int MODEL = M_DU>
 struct Wave {
+    static constexpr bool XB = MODEL == M_DU;          // the model has the state bound |x_3| <= v_max
     Cx& cx;
     const Params& P;
     const sc_ipopt_params& O;
@@ -279,6 +287,24 @@ struct Wave {
     double tc_ = 1.0, ts_ = 0.0, tc1_ = 1.0, ts1_ = 0.0;        // cos / sin of theta_k and of theta_k + dt omega_k at the ITERATE (eval2 sets them, finish_step reuses them)
     SC_HD void geometry(const double* xs, const double* us, Geo& g, bool cached = false) const {
         const double dt = P.dt;
+        if constexpr (MODEL == M_DI) {
+            // p1 = p + dt v;  w = v + dt a,  p2 = p1 + dt w min(1, v_max / |w|)   (the rescaling of robot.step; the model's x_next has none)
+            g.c = g.s = g.c1 = g.s1 = 0.0;
+            g.F[0] = xs[0] + dt * xs[2]; g.F[1] = xs[1] + dt * xs[3]; g.F[2] = xs[2] + dt * us[1]; g.F[3] = xs[3] + dt * us[0];
+            g.p1[0] = g.F[0]; g.p1[1] = g.F[1];
+            g.a02 = dt; g.a03 = 0.0; g.a12 = 0.0; g.a13 = dt;
+            const double w0_ = g.F[2], w1_ = g.F[3], vm = sqrt(w0_ * w0_ + w1_ * w1_);
+            g.v1 = vm;
+            if (vm > P.v_max) {
+                const double sc = P.v_max / vm, i3 = P.v_max / (vm * vm * vm);
+                g.p2[0] = g.F[0] + dt * (w0_ * sc); g.p2[1] = g.F[1] + dt * (w1_ * sc);
+                g.g02 = dt * (sc - w0_ * w0_ * i3); g.g03 = dt * (-w0_ * w1_ * i3); g.g12 = g.g03; g.g13 = dt * (sc - w1_ * w1_ * i3);
+            } else {
+                g.p2[0] = g.F[0] + dt * w0_; g.p2[1] = g.F[1] + dt * w1_;
+                g.g02 = dt; g.g03 = 0.0; g.g12 = 0.0; g.g13 = dt;
+            }
+            return;
+        }
         g.F[2] = xs[2] + dt * us[1];
         if (cached) { g.c = tc_; g.s = ts_; g.c1 = tc1_; g.s1 = ts1_; }
         else { cx.sincos(xs[2], g.s, g.c); cx.sincos(g.F[2], g.s1, g.c1); }
@@ -328,7 +354,7 @@ struct Wave {
     };
     SC_HD void bar_begin(BarAcc& B, const double* xs, const double* us) const {
         B.prod = 1.0; B.lg = 0.0; B.sa = 0.0; B.sn = 0.0; B.ok = true; B.nf = 0;
-        if (acl) {
+        if (XB && acl) {
             const double a = xs[3] - xbL, b = xbU - xs[3];
             if (!(a > 0.0) || !(b > 0.0)) B.ok = false;
             B.prod = a * b;
@@ -408,7 +434,7 @@ struct Wave {
     }
     SC_HD void safe_slacks_xu(const double* xs, const double* us, double mu) {      // (the rows' slack bounds: inside eval0's / the update's row loop)
         const double s_min = EPS_ * fmin(1.0, mu), move = 1.8189894035458565e-12;     // eps^(3/4)
-        if (act) { safe1(xs[3], xbL, true, s_min, move); safe1(xs[3], xbU, false, s_min, move); }
+        if (XB && act) { safe1(xs[3], xbL, true, s_min, move); safe1(xs[3], xbU, false, s_min, move); }
         if (stg) SC_UNROLL for (int j = 0; j < NU; ++j) { safe1(us[j], ubL[j], true, s_min, move); safe1(us[j], ubU[j], false, s_min, move); }
     }
 
@@ -497,9 +523,11 @@ struct Wave {
                 SC_UNROLL for (int j = 0; j < NU; ++j) gb[4 + j] = -zuL[j] + zuU[j];
             } else {
                 SC_UNROLL for (int i = 0; i < NX; ++i) dg_[i] = ((rs && act) ? zeta * dr2(i) : 2.0 * df * P.Q[i]) + dw;
-                const double a = x[3] - xbL, b = xbU - x[3];
-                dg_[3] += zxL / a + zxU / b;
-                gb[3] = -mu / a + mu / b;
+                if constexpr (XB) {
+                    const double a = x[3] - xbL, b = xbU - x[3];
+                    dg_[3] += zxL / a + zxU / b;
+                    gb[3] = -mu / a + mu / b;
+                }
                 SC_UNROLL for (int j = 0; j < NU; ++j) {
                     const double a_ = u[j] - ubL[j], b_ = ubU[j] - u[j];
                     dg_[4 + j] = ((rs && stg) ? zeta * dr2(NX + j) : 2.0 * df * P.R[j] * (last ? 1.0 : 2.0)) + dw + zuL[j] / a_ + zuU[j] / b_;
@@ -581,6 +609,21 @@ struct Wave {
                 const double s1x = sl * g.p1[0] - socx, s1y = sl * g.p1[1] - socy, s2x = sl * g.p2[0] - socx, s2y = sl * g.p2[1] - socy;
                 const double nx_ = wy[0] - 2.0 * w1 * s1x - 2.0 * w2 * s2x, ny_ = wy[1] - 2.0 * w1 * s1y - 2.0 * w2 * s2y;    // on grad^2 p1
                 const double kx = -2.0 * w2 * s2x, ky = -2.0 * w2 * s2y;                                                        // on grad^2 (p2 - p1)
+                if constexpr (MODEL == M_DI) {
+                    // p1 is affine; p2 - p1 = dt wt(w), wt = w v_max / |w| where |w| > v_max:  grad^2 wt_d = v_max (-(d_da w_b + d_db w_a + d_ab w_d) / |w|^3
+                    // + 3 w_d w_a w_b / |w|^5) over w = (F_2, F_3), F_2 = x_2 + dt u_1, F_3 = x_3 + dt u_0
+                    (void)nx_; (void)ny_;
+                    const double wa = g.F[2], wb = g.F[3], vm = g.v1;
+                    if (vm > P.v_max) {
+                        const double i3 = P.v_max / (vm * vm * vm), i5 = 3.0 * i3 / (vm * vm);
+                        const double hx00 = -3.0 * wa * i3 + wa * wa * wa * i5, hx01 = -wb * i3 + wa * wa * wb * i5, hx11 = -wa * i3 + wa * wb * wb * i5;
+                        const double hy00 = -wb * i3 + wb * wa * wa * i5, hy01 = -wa * i3 + wb * wa * wb * i5, hy11 = -3.0 * wb * i3 + wb * wb * wb * i5;
+                        const double s00 = dt * (kx * hx00 + ky * hy00), s01 = dt * (kx * hx01 + ky * hy01), s11 = dt * (kx * hx11 + ky * hy11), dt2 = dt * dt;
+                        M[sym6(2, 2)] += s00; M[sym6(2, 5)] += dt * s00; M[sym6(5, 5)] += dt2 * s00;
+                        M[sym6(3, 3)] += s11; M[sym6(3, 4)] += dt * s11; M[sym6(4, 4)] += dt2 * s11;
+                        M[sym6(2, 3)] += s01; M[sym6(2, 4)] += dt * s01; M[sym6(3, 5)] += dt * s01; M[sym6(4, 5)] += dt2 * s01;
+                    }
+                } else {
                 const double v = x[3], v1 = g.v1, c = g.c, s_ = g.s, c1 = g.c1, s1 = g.s1, dt2 = dt * dt, dt3 = dt2 * dt;
                 M[sym6(2, 2)] += nx_ * (-dt * v * c) + ny_ * (-dt * v * s_) + kx * (-dt * v1 * c1) + ky * (-dt * v1 * s1);
                 M[sym6(2, 3)] += nx_ * (-dt * s_) + ny_ * (dt * c) + kx * (-dt * s1) + ky * (dt * c1);
@@ -589,6 +632,7 @@ struct Wave {
                 M[sym6(3, 5)] += kx * (-dt2 * s1) + ky * (dt2 * c1);
                 M[sym6(4, 5)] += kx * (-dt3 * s1) + ky * (dt3 * c1);
                 M[sym6(5, 5)] += kx * (-dt3 * v1 * c1) + ky * (-dt3 * v1 * s1);
+                }
                 // -2 sl (w0 J0'J0 + w1 J1'J1 + w2 J2'J2): J0 = [e_0; e_1], J1 = J0 + [a0.; a1.] on (theta, v), J2 = J1 + [g..] on (theta, v, a, omega)
                 const double o0 = -2.0 * sl * w0, o1 = -2.0 * sl * w1, o2 = -2.0 * sl * w2;
                 const double j1x[NV] = {1.0, 0.0, g.a02, g.a03, 0.0, 0.0}, j1y[NV] = {0.0, 1.0, g.a12, g.a13, 0.0, 0.0};
@@ -695,7 +739,7 @@ struct Wave {
             }
         }
         if (!ls) {
-            if (act) {
+            if (XB && act) {
                 const double a = x[3] - xbL, b = xbU - x[3];
                 dzxL = mu / a - zxL - zxL * dx[3] / a; dzxU = mu / b - zxU + zxU * dx[3] / b;
             } else { dzxL = 0.0; dzxU = 0.0; }
@@ -717,11 +761,13 @@ struct Wave {
         if (acl) {
             double gl[NX];
             SC_UNROLL for (int i = 0; i < NX; ++i) gl[i] = E.gfx[i] + E.Jty[i];
-            gl[3] += -zxL + zxU;
+            if constexpr (XB) gl[3] += -zxL + zxU;
             SC_UNROLL for (int i = 0; i < NX; ++i) d = fmax(d, fabs(gl[i]));
-            const double c1 = (x[3] - xbL) * zxL, c2 = (xbU - x[3]) * zxU;
-            cmin = fmin(cmin, fmin(c1, c2)); cmax = fmax(cmax, fmax(c1, c2));
-            zsum += fabs(zxL) + fabs(zxU);
+            if constexpr (XB) {
+                const double c1 = (x[3] - xbL) * zxL, c2 = (xbU - x[3]) * zxU;
+                cmin = fmin(cmin, fmin(c1, c2)); cmax = fmax(cmax, fmax(c1, c2));
+                zsum += fabs(zxL) + fabs(zxU);
+            }
         }
         if (stl) {
             SC_UNROLL for (int j = 0; j < NU; ++j) {
@@ -738,7 +784,7 @@ struct Wave {
         dinf = cx.wmax(d); pinf = cx.wmax(p); comp0 = cx.wmax(c0); un_pinf = cx.wmax(up);
         const double compm = cx.wmax(cm);
         ysum = cx.wsum(ysum); zsum = cx.wsum(zsum);
-        const double m = (double)(NX * (N + 1) + N * K), nb = (double)(2 * (N + 1) + 4 * N + N * K * (rs ? 3 : 1));
+        const double m = (double)(NX * (N + 1) + N * K), nb = (double)((XB ? 2 * (N + 1) : 0) + 4 * N + N * K * (rs ? 3 : 1));
         const double sd = fmax(O.s_max, (ysum + zsum) / (m + nb)) / O.s_max, sc = fmax(O.s_max, zsum / nb) / O.s_max;
         E0 = fmax(fmax(dinf / sd, pinf), comp0 / sc);
         Emu = fmax(fmax(dinf / sd, pinf), compm / sc);
@@ -749,11 +795,13 @@ struct Wave {
     SC_HD void step_lengths(const Eval2& E, double tau, double mu, double& a_max, double& a_z, double& gBD) const {
         double ap = 1.0, az = 1.0, v = 0.0;
         if (acl) {
-            const double a = x[3] - xbL, b = xbU - x[3];
-            ap = fmin(ap, fmin(ftb1(tau, a, dx[3]), ftb1(tau, b, -dx[3])));
-            az = fmin(az, fmin(ftb1(tau, zxL, dzxL), ftb1(tau, zxU, dzxU)));
             SC_UNROLL for (int i = 0; i < NX; ++i) v += E.gfx[i] * dx[i];
-            v += (-mu / a + mu / b) * dx[3];
+            if constexpr (XB) {
+                const double a = x[3] - xbL, b = xbU - x[3];
+                ap = fmin(ap, fmin(ftb1(tau, a, dx[3]), ftb1(tau, b, -dx[3])));
+                az = fmin(az, fmin(ftb1(tau, zxL, dzxL), ftb1(tau, zxU, dzxU)));
+                v += (-mu / a + mu / b) * dx[3];
+            }
         }
         if (stg) { ap = fmin(ap, sl_ap); az = fmin(az, sl_az); v += sl_v; }      // (my rows: gathered by finish_step)
         if (stl) {
@@ -805,7 +853,7 @@ struct Wave {
         SC_UNROLL for (int i = 0; i < NX; ++i) { x[i] = x0[i]; yc[i] = 0.0; dx[i] = 0.0; }
         SC_UNROLL for (int j = 0; j < NU; ++j) { u[j] = uprev[j]; du[j] = 0.0; dvv[j] = 0.0; }
         if (stg) for (int j = q; j < K; j += G) { lds[ri(R_S, j)] = 0.0; lds[ri(R_YD, j)] = 0.0; lds[ri(R_VU, j)] = 1.0; lds[ri(R_SU, j)] = rl; lds[ri(R_DS, j)] = 0.0; lds[ri(R_DYD, j)] = 0.0; lds[ri(R_DVU, j)] = 0.0; lds[ri(R_DV, j)] = 0.0; }
-        xbL = -P.v_max - rl * fmax(1.0, fabs(P.v_max)); xbU = P.v_max + rl * fmax(1.0, fabs(P.v_max)); zxL = 1.0; zxU = 1.0; dzxL = dzxU = 0.0;
+        xbL = -P.v_max - rl * fmax(1.0, fabs(P.v_max)); xbU = P.v_max + rl * fmax(1.0, fabs(P.v_max)); zxL = XB ? 1.0 : 0.0; zxU = zxL; dzxL = dzxU = 0.0;
         SC_UNROLL for (int j = 0; j < NU; ++j) {
             ubL[j] = P.u_lo[j] - rl * fmax(1.0, fabs(P.u_lo[j])); ubU[j] = P.u_hi[j] + rl * fmax(1.0, fabs(P.u_hi[j]));
             zuL[j] = 1.0; zuU[j] = 1.0; dzuL[j] = dzuU[j] = 0.0;
@@ -838,7 +886,7 @@ struct Wave {
             }
             sync();
         }
-        push1(x[3], xbL, xbU, true, true);
+        if constexpr (XB) push1(x[3], xbL, xbU, true, true);
         SC_UNROLL for (int j = 0; j < NU; ++j) push1(u[j], ubL[j], ubU[j], true, true);
         // One pass of the loop = one evaluation at the iterate + what the phase does with it:
         //   PH_INIT   first evaluation: slacks from the row values                          -> PH_LS
@@ -1020,7 +1068,7 @@ struct Wave {
                 {
                     const double ks = O.kappa_sigma, ksm = ks * mu, mks = mu / ks;
                     auto upd = [&](double& z, double dz, double sl) { const double is = 1.0 / sl; z += a_z * dz; z = fmax(fmin(z, ksm * is), mks * is); };
-                    if (act) { upd(zxL, dzxL, x[3] - xbL); upd(zxU, dzxU, xbU - x[3]); }
+                    if (XB && act) { upd(zxL, dzxL, x[3] - xbL); upd(zxU, dzxU, xbU - x[3]); }
                     if (stg) {
                         SC_UNROLL for (int j = 0; j < NU; ++j) { upd(zuL[j], dzuL[j], u[j] - ubL[j]); upd(zuU[j], dzuU[j], ubU[j] - u[j]); }
                         const double s_min = EPS_ * fmin(1.0, mu), move = 1.8189894035458565e-12;     // eps^(3/4)
@@ -1090,7 +1138,7 @@ struct Wave {
                     }
                     zm = cx.wmax(zm);
                     if (zm > O.bound_mult_reset_threshold) {
-                        zxL = zxU = 1.0;
+                        if constexpr (XB) zxL = zxU = 1.0;
                         SC_UNROLL for (int j = 0; j < NU; ++j) { zuL[j] = 1.0; zuU[j] = 1.0; }
                         if (stg) for (int j = q; j < K; j += G) lds[ri(R_VU, j)] = 1.0;
                     }

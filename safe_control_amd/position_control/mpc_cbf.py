@@ -28,6 +28,8 @@ def default_mpc_weights(model):
         return np.diag([50.0, 50.0, 0.01, 30.0]), np.array([0.5, 0.5])
     if model == "Unicycle2D":
         return np.diag([50.0, 50.0, 0.01]), np.array([0.5, 0.5])
+    if model == "DoubleIntegrator2D":                       # mpc_cbf.py:28-30 (the multiple-shooting kernel; the condensed solve of this model is mpc_cbf_gn.py)
+        return np.diag([50.0, 50.0, 20.0, 20.0]), np.array([0.5, 0.5])
     raise NotImplementedError(f"MPC-CBF on the batched engine supports DynamicUnicycle2D and Unicycle2D, not {model}")
 
 
@@ -37,6 +39,8 @@ def default_mpc_cbf_param(model):
         return {"alpha1": 0.15, "alpha2": 0.15}
     if model == "Unicycle2D":
         return {"alpha": 0.05}                              # mpc_cbf.py:52-53
+    if model == "DoubleIntegrator2D":
+        return {"alpha1": 0.2, "alpha2": 0.2}               # mpc_cbf.py:56-59
     raise NotImplementedError(model)
 
 
@@ -85,6 +89,9 @@ def make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_
     if robot_spec["model"] == "Unicycle2D":                 # inputs [v, omega] (mpc_cbf.py:188-192), one gain alpha
         p.alpha1, p.alpha2 = float(cbf_param["alpha"]), 0.0
         p.u_max[0], p.u_max[1] = float(robot_spec["v_max"]), float(robot_spec["w_max"])
+    elif robot_spec["model"] == "DoubleIntegrator2D":       # inputs [ax, ay] (mpc_cbf.py:196-200); v_max is the norm robot.step rescales the velocity to
+        p.alpha1, p.alpha2 = float(cbf_param["alpha1"]), float(cbf_param["alpha2"])
+        p.u_max[0], p.u_max[1] = float(robot_spec.get("ax_max", robot_spec["a_max"])), float(robot_spec.get("ay_max", robot_spec["a_max"]))
     else:
         p.alpha1, p.alpha2 = float(cbf_param["alpha1"]), float(cbf_param["alpha2"])
         p.u_max[0], p.u_max[1] = float(robot_spec["a_max"]), float(robot_spec["w_max"])

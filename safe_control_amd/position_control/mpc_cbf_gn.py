@@ -98,6 +98,12 @@ class GnMPCCBF:
         self.z = np.zeros(2 * self.horizon)
         self.iterations = 0
         self.solver_status = "optimal"
+        # DoubleIntegrator2D: the NLP as do-mpc poses it (multiple shooting under IPOPT's algorithm, csrc/mpc_du_ms.hip, kernel 13) unless
+        # robot_spec['mpc_formulation'] = 'condensed'; superellipsoid rows run on the condensed kernel
+        self._ms = None
+        if self.robot_spec["model"] == "DoubleIntegrator2D" and self.robot_spec.get("mpc_formulation", "multiple_shooting") != "condensed" and self.num_obs <= 16:
+            from .mpc_cbf_ms import BatchedMSMPCCBF
+            self._ms = BatchedMSMPCCBF(self.robot_spec, dt=self.dt, io_dtype="f64", horizon=self.horizon, cbf_param=self.cbf_param, check_circles=False)
 
     def update_tvp(self, goal, obs):
         self.goal = np.array(goal)
@@ -113,6 +119,18 @@ class GnMPCCBF:
         X[: xs.shape[0]] = xs
         g = np.ascontiguousarray(np.asarray(self.goal, dtype=np.float64).reshape(-1)[:2])
         obs = np.ascontiguousarray(self.obs, dtype=np.float64)
+        if self._ms is not None and not (obs[:, 6] >= 0.5).any():
+            import torch
+            dev = torch.device("cuda", int(self.device))
+            t = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float64), dtype=torch.float64, device=dev)     # noqa: E731
+            self._ms.cbf_param = self.cbf_param
+            self._ms.robot_spec["radius"] = self.robot.robot_radius
+            u, st, it, plan = self._ms.solve(t(X[None]), t(self.u_prev[None]), t(g[None]), t(obs[None]), want_plan=True)
+            self.iterations = int(it[0].item())
+            self.solver_status = _lib.STATUS_STRINGS[int(st[0].item())]
+            self.z = plan[0, (self.horizon + 1) * 4:].cpu().numpy().copy()
+            self.u_prev = u[0].cpu().numpy().copy()
+            return self.u_prev.reshape(-1, 1).copy()
         p = make_params(self.robot_spec, self._mc, self.cbf_param, self.horizon, self.dt, self.robot.robot_radius, _lib.DTYPE_F64)
         u = np.zeros(2); st = np.zeros(1, dtype=np.int32); it = np.zeros(1, dtype=np.int32)
         rc = self._lib.sc_mpcgn_solve_batch_host(

@@ -1,5 +1,5 @@
-"""MPC-CBF for DynamicUnicycle2D as do-mpc poses it -- multiple shooting, IPOPT's filter interior point with its restoration phase -- on
-csrc/mpc_du_ms.hip (DESIGN.md kernel 13): BASELINE configs[2] in the reference's own formulation.
+"""MPC-CBF for DynamicUnicycle2D and DoubleIntegrator2D as do-mpc poses it -- multiple shooting, IPOPT's filter interior point with its
+restoration phase -- on csrc/mpc_du_ms.hip (DESIGN.md kernel 13): BASELINE configs[2] in the reference's own formulation.
 
 position_control/mpc_cbf.py:162-174 / :366-369: the states and inputs of every stage are variables, the dynamics are equality rows, every
 stage starts at x0 and every input at the input applied last, IPOPT runs with its defaults and whatever it holds at the end is applied
@@ -26,16 +26,17 @@ class BatchedMSMPCCBF:
 
     def __init__(self, robot_spec=None, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None, ipopt=None, max_iter=None, check_circles=True, order=True):
         self.robot_spec = complete_robot_spec(dict(robot_spec or {"model": "DynamicUnicycle2D"}))
-        if self.robot_spec["model"] != "DynamicUnicycle2D":
-            raise NotImplementedError("the multiple-shooting MPC-CBF kernel serves DynamicUnicycle2D (VTOL2D: BatchedVtolMSMPCCBF)")
+        self.model = self.robot_spec["model"]
+        if self.model not in ("DynamicUnicycle2D", "DoubleIntegrator2D"):
+            raise NotImplementedError("the multiple-shooting MPC-CBF kernel serves DynamicUnicycle2D and DoubleIntegrator2D (VTOL2D: BatchedVtolMSMPCCBF)")
         self.dt = float(dt)
         self.io_name = io_dtype
         self.io_dtype = {"f32": _lib.DTYPE_F32, "f64": _lib.DTYPE_F64}[io_dtype]
         self.horizon = int(horizon if horizon is not None else self.robot_spec.get("mpc_horizon", 10))
         if not 1 <= self.horizon <= 62:
             raise ValueError("mpc_horizon must be in [1, 62]")
-        self.Q, self.R = default_mpc_weights("DynamicUnicycle2D")
-        self.cbf_param = cbf_param or apply_mpc_overrides(default_mpc_cbf_param("DynamicUnicycle2D"), self.robot_spec)
+        self.Q, self.R = default_mpc_weights(self.model)
+        self.cbf_param = cbf_param or apply_mpc_overrides(default_mpc_cbf_param(self.model), self.robot_spec)
         self.ipopt = dict(ipopt or {})
         if max_iter is not None:
             self.ipopt["max_iter"] = int(max_iter)

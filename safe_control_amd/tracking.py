@@ -113,11 +113,11 @@ class BatchedTrackingController:
             else:
                 cls = BatchedMPCCBF if self.pos_controller_type == "mpc_cbf" else BatchedOptimalDecayMPCCBF
             self.mpc = cls(self.robot_spec, dt=self.dt, io_dtype=io_dtype)
-            # DynamicUnicycle2D under 'mpc_cbf': the NLP as do-mpc poses it (multiple shooting, IPOPT's algorithm: csrc/mpc_du_ms.hip, kernel 13)
+            # DynamicUnicycle2D and DoubleIntegrator2D under 'mpc_cbf': the NLP as do-mpc poses it (multiple shooting, IPOPT's algorithm: csrc/mpc_du_ms.hip, kernel 13)
             # unless robot_spec['mpc_formulation'] = 'condensed'; a scene with superellipsoid rows runs on the condensed kernel
             self.mpc_ms = None
-            if cls is BatchedMPCCBF and self.model == "DynamicUnicycle2D" and self.robot_spec.get("mpc_formulation", "multiple_shooting") != "condensed" \
-                    and self.num_constraints <= 16:
+            ms_model = (cls is BatchedMPCCBF and self.model == "DynamicUnicycle2D") or (self.model == "DoubleIntegrator2D" and self.pos_controller_type == "mpc_cbf")
+            if ms_model and self.robot_spec.get("mpc_formulation", "multiple_shooting") != "condensed" and self.num_constraints <= 16:
                 from .position_control.mpc_cbf_ms import BatchedMSMPCCBF
                 self.mpc_ms = BatchedMSMPCCBF(self.robot_spec, dt=self.dt, io_dtype=io_dtype, check_circles=False)
             self.u_prev = torch.zeros((self.B, 2), dtype=self.tdtype, device=self.device)   # do-mpc's u0 per agent

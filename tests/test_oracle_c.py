@@ -110,3 +110,30 @@ def test_compiled_cpu_baseline_of_config3_equals_the_numpy_oracle():
     assert np.array_equal(st, so) and (so == 1).sum() >= 10
     assert (it != ito).sum() <= 2 and np.abs(it - ito).max() <= 1
     assert np.abs(u - uo)[it == ito].max() <= 1e-9
+
+
+def _ms_one_di(a):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    from oracle import ms_ipopt as MS
+    from safe_control_amd.robots.spec import complete_robot_spec
+    sp = complete_robot_spec({"model": "DoubleIntegrator2D"})
+    mdl = MS.di_model({k: v for k, v in sp.items() if k in MS.di_model()["spec"]})
+    return MS.solve(mdl, a[0], a[1], a[2], a[3], opts=dict(MS.KERNEL_PROFILE))
+
+
+def test_solver_header_for_double_integrator_equals_the_numpy_oracle():
+    """The DoubleIntegrator2D instantiation of csrc/mpc_du_ms_solver.hpp (inputs held swapped, no state bound, robot.step's velocity rescaling
+    and its curvature inside the barrier rows) compiled for the host, against oracle/ms_ipopt.py: di_model() on 192 bench draws and on 128
+    draws that start above v_max with a random last input -- same status, same iteration count, u0 to 1e-9."""
+    from multiprocessing import Pool
+    n = 192
+    X, up, goal, obs = (a[:n + 128].copy() for a in W.mpc_family_batch("di", 4096, 8, seed=0))
+    rng = np.random.default_rng(5)
+    X[n:, 2:4] = rng.uniform(-1.3, 1.3, (128, 2)); up[n:] = rng.uniform(-1.0, 1.0, (128, 2))
+    u, st, it = c_oracle.du_ms_cpu_batch(X, up, goal, obs, n_threads=0, model="DoubleIntegrator2D")
+    with Pool(min(8, os.cpu_count() or 2)) as p:
+        res = p.map(_ms_one_di, [(X[i], up[i], goal[i], obs[i]) for i in range(n + 128)], chunksize=4)
+    so = np.array([r[1] for r in res]); ito = np.array([r[2] for r in res]); uo = np.array([r[0] for r in res])
+    assert np.array_equal(st, so) and (so[:n] == 1).sum() >= 8 and (so[n:] == 1).sum() >= 8
+    assert (it != ito).sum() <= 2 and np.abs(it - ito).max() <= 1
+    assert np.abs(u - uo)[it == ito].max() <= 1e-9
