@@ -586,7 +586,7 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
     ms = e0.elapsed_time(e1) / steps
     mid = {"DoubleIntegrator2D": 5, "Quad2D": 6, "KinematicBicycle2D": 1, "KinematicBicycle2D_C3BF": 2, "KinematicBicycle2D_DPCBF": 3}[model]
     extra = {}
-    if model == "DoubleIntegrator2D" and N <= 62 and K <= 16:
+    if model in ("DoubleIntegrator2D", "KinematicBicycle2D") and N <= 62 and K <= 16:
         # the same batch in the reference's own formulation: kernel 13 instantiated for this robot (multiple shooting under IPOPT's algorithm)
         msc = sca.BatchedMSMPCCBF({"model": model}, io_dtype="f32", horizon=N, check_circles=False)
         um, sm, im = msc.solve(X, up, g, ob)
@@ -598,15 +598,28 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
         torch.cuda.synchronize()
         mms = e0.elapsed_time(e1) / steps
         both = (sm == 0) & (st == 0)
-        ms_d = {"kernel": "mpcdu_ms_kernel<float, 1> (kernel 13: multiple shooting, IPOPT's filter interior point; the drop-in's default for this robot)",
+        mi = 1 if model == "DoubleIntegrator2D" else 2
+        ms_d = {"kernel": f"mpcdu_ms_kernel<float, {mi}> (kernel 13: multiple shooting, IPOPT's filter interior point; " +
+                          ("the drop-in's default for this robot)" if mi == 1 else "on request: mpc_formulation = 'multiple_shooting')"),
                 "value": B / (mms * 1e-3), "kernel_ms": mms, "optimal_fraction": float((sm == 0).double().mean().item()),
                 "infeasible_fraction": float((sm == 1).double().mean().item()), "inaccurate_fraction": float((sm == 2).double().mean().item()),
                 "mean_ipm_iterations": float(im.double().mean().item()), "max_ipm_iterations": int(im.max().item()),
                 "same_status_fraction": float((sm == st).double().mean().item()),
                 "same_u0_where_both_optimal_fraction": float(((um - u).abs().amax(dim=1) <= 1e-4)[both].double().mean().item()) if bool(both.any()) else None}
-        rl = valu_roofline("dumsdi_sq", "mpcdu_ms_kernel<float, 1>", mms) if (B, K, N, seed) == (4096, 8, 10, 0) else None
+        rl = valu_roofline("dumsdi_sq" if mi == 1 else "dumskb_sq", f"mpcdu_ms_kernel<float, {mi}>", mms) if (B, K, N, seed) == (4096, 8, 10, 0) else None
         if rl:
             ms_d["roofline"] = rl
+        if int(im.max().item()) > 100 and not NO_LIMIT100:                  # (the bicycle: solves that cycle around the kink of robot.step's speed clip run to the budget)
+            m100 = sca.BatchedMSMPCCBF({"model": model}, io_dtype="f32", horizon=N, check_circles=False, max_iter=100)
+            o100 = m100.solve(X, up, g, ob)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(steps):
+                o100 = m100.solve(X, up, g, ob)
+            e1.record()
+            torch.cuda.synchronize()
+            ms_d["beyond_100_iterations"] = int((im > 100).sum().item())
+            ms_d["one_launch_limit_100"] = {"kernel_ms": e0.elapsed_time(e1) / steps, "optimal_fraction": float((o100[1] == 0).double().mean().item())}
         extra["multiple_shooting"] = ms_d
     return with_roofline({**extra, **budget_note(mk, (X, up, g, ob), steps, ms, st, it),
             "workload": f"{B}-agent batch {model} MPC-CBF, horizon N={N}, {K} obstacles",

@@ -41,7 +41,7 @@ extern "C" {
  * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2; round 5 added sc_ipopt_params and sc_mpcvtol_ms_solve_batch: 0.3; the continuation entry points of the optimal-decay families: 0.4; sc_odmpcvtol_ms_solve_batch: 0.5; round 6 added sc_mpccbf_ms_solve_batch: 0.7; sc_mpccbf_ms_workspace_bytes and sc_ipopt_params.floor_iter in the slot that was `reserved`: 0.8).  A binding compares sc_version() with the
  * version its struct mirrors were written for before the first call (safe_control_amd/_lib.py: ABI_VERSION). */
 #define SC_VERSION_MAJOR 0
-#define SC_VERSION_MINOR 8
+#define SC_VERSION_MINOR 9
 
 /* ---- return codes ------------------------------------------------------ */
 typedef enum sc_error {
@@ -225,6 +225,9 @@ typedef struct sc_mpccbf_params {
     double  mu_init;         /* initial barrier parameter (0.1, IPOPT's default)                   */
     double  mu_min;          /* smallest barrier parameter (1e-9)                                  */
     sc_resto_params resto;   /* feasibility restoration (not used by the optimal-decay entry points) */
+    double  v_min;           /* sc_mpccbf_ms_solve_batch with SC_MODEL_KINEMATIC_BICYCLE2D: lower end of robot.step's speed clip
+                              * (kinematic_bicycle2D.py:116-121; v_max is the upper end and the state bound); unused elsewhere */
+    double  rear_ax_dist;    /* ... and L_r of x+ = x + dt (.., v beta / L_r, a) (kinematic_bicycle2D.py:67-110)            */
 } sc_mpccbf_params;
 
 /* Replaces, for a whole batch of agents in one launch:

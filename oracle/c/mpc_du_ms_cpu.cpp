@@ -61,6 +61,7 @@ struct Problem {
     double* u_out;
     int *status, *iters;
     int model;
+    double* trace;                                       // [max_iter + 1][8] or NULL (du_ms_cpu_solve_batch with trace_out: B = 1)
 };
 
 struct Wavefront {
@@ -141,11 +142,13 @@ void lane_body_m(Wavefront* w, int lane) {
     S.xg[0] = q.goal[0]; S.xg[1] = q.goal[1];
     cx.sync();
     int st, it;
-    S.solve(st, it, nullptr);
+    S.solve(st, it, q.trace);
     if (lane == 0) { q.u_out[0 ^ U0] = S.u[0]; q.u_out[1 ^ U0] = S.u[1]; *q.status = st; *q.iters = it; }
 }
 void lane_body(Wavefront* w, int lane) {
-    if (w->prob.model == sc::dums::M_DI) lane_body_m<sc::dums::M_DI>(w, lane); else lane_body_m<sc::dums::M_DU>(w, lane);
+    if (w->prob.model == sc::dums::M_DI) lane_body_m<sc::dums::M_DI>(w, lane);
+    else if (w->prob.model == sc::dums::M_KB) lane_body_m<sc::dums::M_KB>(w, lane);
+    else lane_body_m<sc::dums::M_DU>(w, lane);
 }
 
 extern "C" void sc_fiber_entry() {
@@ -173,6 +176,11 @@ void run_wave(Wavefront* w) {
 
 }  // namespace
 
+static double* g_trace = nullptr;
+// the iteration trace of the next B = 1 solve (rows of 8: E_0, dual / primal infeasibility, complementarity, mu, theta, delta_w, step length; a negative
+// step length marks an iterate of the restoration phase); NULL switches it off
+extern "C" void du_ms_cpu_set_trace(double* trace) { g_trace = trace; }
+
 // X [B,4], u_prev [B,2], goal [B,2], obs [B,K,7] (or [K,7] when obs_shared), float64; returns 0.  n_threads <= 0: every core.
 extern "C" int du_ms_cpu_solve_batch(const sc_mpccbf_params* prm, const sc_ipopt_params* O, long B, int K, const double* X, const double* u_prev,
                                      const double* goal, const double* obs, double* u_out, int* status, int* iters, int n_threads) {
@@ -183,9 +191,10 @@ extern "C" int du_ms_cpu_solve_batch(const sc_mpccbf_params* prm, const sc_ipopt
     for (int i = 0; i < 4; ++i) P.Q[i] = prm->Q[i];
     for (int j = 0; j < 2; ++j) { P.R[j] = prm->R[j]; P.u_lo[j] = -prm->u_max[j]; P.u_hi[j] = prm->u_max[j]; }
     P.alpha1 = prm->alpha1; P.alpha2 = prm->alpha2; P.beta = prm->beta; P.radius = prm->robot_radius; P.v_max = prm->v_max;
-    const int model = prm->model_id == SC_MODEL_DOUBLE_INTEGRATOR2D ? M_DI : M_DU;
+    const int model = prm->model_id == SC_MODEL_DOUBLE_INTEGRATOR2D ? M_DI : (prm->model_id == SC_MODEL_KINEMATIC_BICYCLE2D ? M_KB : M_DU);
+    if (model == M_KB) { P.v_min = prm->v_min; P.inv_Lr = 1.0 / prm->rear_ax_dist; }
     if (model == M_DI) for (int j = 0; j < 2; ++j) { P.R[j] = prm->R[1 - j]; P.u_lo[j] = -prm->u_max[1 - j]; P.u_hi[j] = prm->u_max[1 - j]; }
-    const size_t nl = (size_t)Lds(P.N, P.K).total;
+    const size_t nl = (size_t)Lds(P.N, P.K, general_layout(model)).total;
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
 #else
@@ -198,7 +207,7 @@ extern "C" int du_ms_cpu_solve_batch(const sc_mpccbf_params* prm, const sc_ipopt
 #pragma omp for schedule(dynamic, 4)
         for (long b = 0; b < B; ++b) {
             std::fill(w->lds.begin(), w->lds.end(), 0.0);
-            w->prob = Problem{&P, O, X + 4 * b, u_prev + 2 * b, goal + 2 * b, obs + (prm->obs_shared ? 0 : (size_t)b * K * 7), u_out + 2 * b, status + b, iters + b, model};
+            w->prob = Problem{&P, O, X + 4 * b, u_prev + 2 * b, goal + 2 * b, obs + (prm->obs_shared ? 0 : (size_t)b * K * 7), u_out + 2 * b, status + b, iters + b, model, B == 1 ? g_trace : nullptr};
             run_wave(w);
         }
         delete w;

@@ -152,6 +152,7 @@ class MpcCbfParams(C.Structure):
         ("alpha1", C.c_double), ("alpha2", C.c_double), ("v_max", C.c_double), ("u_max", C.c_double * 2),
         ("robot_radius", C.c_double), ("beta", C.c_double), ("tol", C.c_double), ("acceptable_tol", C.c_double),
         ("mu_init", C.c_double), ("mu_min", C.c_double), ("resto", RestoParams),
+        ("v_min", C.c_double), ("rear_ax_dist", C.c_double),
     ]
 
 
@@ -373,7 +374,7 @@ SYMBOLS = {
 _lib = None
 
 # SC_VERSION_MAJOR * 1000 + SC_VERSION_MINOR of the header the ctypes mirrors above were written for
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class HipLibraryError(RuntimeError):

@@ -63,7 +63,11 @@ __global__ void __launch_bounds__(256) mpcdu_ms_order_kernel(const Params P, lon
     const double x = (double)X[b * NX], y = (double)X[b * NX + 1], th = (double)X[b * NX + 2], v = (double)X[b * NX + 3];
     const double a = (double)u_prev[b * NU], w = (double)u_prev[b * NU + 1], dt = P.dt;
     double p1x, p1y, p2x, p2y;
-    if constexpr (MODEL == M_DI) {                                            // (x, y, vx, vy), (ax, ay): th = vx, v = vy, a = ax, w = ay
+    if constexpr (MODEL == M_KB) {                                            // (x, y, theta, v), (a, beta): w = beta
+        const double c = cos(th), s = sin(th), th1 = th + dt * v * w * P.inv_Lr, v1 = fmax(fmin(v + dt * a, P.v_max), P.v_min);
+        p1x = x + dt * v * (c - w * s); p1y = y + dt * v * (s + w * c);
+        p2x = p1x + dt * v1 * (cos(th1) - w * sin(th1)); p2y = p1y + dt * v1 * (sin(th1) + w * cos(th1));
+    } else if constexpr (MODEL == M_DI) {                                     // (x, y, vx, vy), (ax, ay): th = vx, v = vy, a = ax, w = ay
         p1x = x + dt * th; p1y = y + dt * v;
         double wx = th + dt * a, wy = v + dt * w;
         const double vm = sqrt(wx * wx + wy * wy);
@@ -128,7 +132,7 @@ __global__ void __launch_bounds__(64, SC_DUMS_WAVES) mpcdu_ms_kernel(const Param
 template <typename TIO, int MODEL>
 static hipError_t launch_t(const Params& P, const sc_ipopt_params& O, long long B, int obs_shared, const void* X, const void* u_prev, const void* goal,
                            const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, void* order_ws, hipStream_t stream) {
-    const size_t lds = (size_t)Lds(P.N, P.K).total * sizeof(double);
+    const size_t lds = (size_t)Lds(P.N, P.K, general_layout(MODEL)).total * sizeof(double);
     int* perm = nullptr;
     if (order_ws && B > 1024) {                                               // (up to 1024 problems are all resident at once: nothing to order)
         int* counters = (int*)order_ws;
@@ -148,7 +152,9 @@ static hipError_t launch_t(const Params& P, const sc_ipopt_params& O, long long 
 }  // namespace dums
 
 size_t mpcdu_ms_order_bytes(long long B) { return (size_t)(B + 4) * sizeof(int); }
-size_t mpcdu_ms_lds_bytes(int horizon, int K) { return (size_t)dums::Lds(horizon, K).total * sizeof(double); }
+size_t mpcdu_ms_lds_bytes(int horizon, int K, int model_id) {
+    return (size_t)dums::Lds(horizon, K, model_id == SC_MODEL_KINEMATIC_BICYCLE2D).total * sizeof(double);
+}
 
 hipError_t mpcdu_ms_launch(const sc_mpccbf_params& p, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
                            const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, void* order_ws, hipStream_t stream) {
@@ -162,6 +168,11 @@ hipError_t mpcdu_ms_launch(const sc_mpccbf_params& p, const sc_ipopt_params& O, 
         for (int j = 0; j < 2; ++j) { P.R[j] = p.R[1 - j]; P.u_lo[j] = -p.u_max[1 - j]; P.u_hi[j] = p.u_max[1 - j]; }
         if (f64) return dums::launch_t<double, dums::M_DI>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
         return dums::launch_t<float, dums::M_DI>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
+    }
+    if (p.model_id == SC_MODEL_KINEMATIC_BICYCLE2D) {
+        P.v_min = p.v_min; P.inv_Lr = 1.0 / p.rear_ax_dist;
+        if (f64) return dums::launch_t<double, dums::M_KB>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
+        return dums::launch_t<float, dums::M_KB>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
     }
     if (f64) return dums::launch_t<double, dums::M_DU>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
     return dums::launch_t<float, dums::M_DU>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);

@@ -30,6 +30,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/safe_control_amd.h"
 
 #ifndef SC_HD
@@ -66,21 +68,27 @@ constexpr int ST_FILTER_FULL = 7;                 // (internal) the filter ran o
 //   M_DI  DoubleIntegrator2D x = (px, py, vx, vy), u = (ax, ay), held here as (ay, ax) so that B = dt [[0, 0], [0, 0], [0, 1], [1, 0]] like
 //         the unicycle's (the launcher swaps R, the bounds and the I/O); no state bound; the barrier's robot.step rescales the velocity to
 //         norm v_max where it is above it (double_integrator2D.py:79-107,225-226): v_max is that norm            mpc_cbf.py:28-30,56-59,196-200
-enum { M_DU = 0, M_DI = 1 };
+//   M_KB  KinematicBicycle2D x = (px, py, theta, v), u = (a, beta): x+ = x + dt (v (cos th - beta sin th), v (sin th + beta cos th), v beta / L_r, a);
+//         |v_k| <= v_max; the barrier's robot.step clips the speed to [v_min, v_max] (kinematic_bicycle2D.py:112-123,175-199)     mpc_cbf.py:31-33,64-66,202-208
+// M_KB runs the GENERAL stage layout: the inputs enter the positions directly, so a stage keeps the two non-trivial columns of A and all of B
+// (16 values) where the other two keep four entries of A and know B; the recursion, the sweep, J'y and the rows read those.
+enum { M_DU = 0, M_DI = 1, M_KB = 2 };
+constexpr bool general_layout(int model) { return model == M_KB; }
 struct Params {
     int N, K;
     double dt, Q[4], R[2], alpha1, alpha2, beta, radius, u_lo[2], u_hi[2], v_max;
+    double v_min = 0.0, inv_Lr = 0.0;                   // M_KB: lower end of robot.step's speed clip; 1 / rear_ax_dist
 };
 
 SC_HD inline int sym6(int a, int b) { return a <= b ? a * 6 - a * (a - 1) / 2 + (b - a) : b * 6 - b * (b - 1) / 2 + (a - b); }
 
 struct Lds {
     int OB, AB, H, G, C, KG, PX, LAM, XS, US, YS, Pa, Pb, T, QU, FP, FT, FP2, FT2, SC, Y0, RW, XR, total;
-    int N, K;
-    SC_HD Lds(int N_, int K_) : N(N_), K(K_ < 1 ? 1 : K_) {
+    int N, K, ABW;
+    SC_HD Lds(int N_, int K_, bool gen = false) : N(N_), K(K_ < 1 ? 1 : K_), ABW(gen ? 16 : 4) {
         int o = 0;
         auto take = [&](int c) { int r = o; o += c; return r; };
-        OB = take(3 * K); AB = take(N * 4); H = take((N + 1) * 21); G = take((N + 1) * 6); C = take((N + 1) * 4);
+        OB = take(3 * K); AB = take(N * ABW); H = take((N + 1) * 21); G = take((N + 1) * 6); C = take((N + 1) * 4);
         KG = take(N * 14); PX = take(N * 28);
         // Slots whose lifetimes do not overlap share storage (19.7 KB per problem at N = 10, K = 8: eight problems per CU):
         //   YS (multipliers as the neighbours see them: written and read at the start of an evaluation) / LAM (costates = multiplier steps:
@@ -122,14 +130,35 @@ struct GCol {
     }
 };
 
-template <class Cx>
+// general layout: AB[k] = the columns of [A_2 | A_3 | B_0 | B_1] (4 rows each, 16 values); column t of G~: 0, 1: e_t; 2, 3: A's column; 4, 5: 0;
+// 6, 7: (B's column, e_{t-6});  8: (c, 0, 0)
+struct GColG {
+    double b[NA], sel, s8;
+    int ci;
+    SC_HD void set(int t, double) {
+        SC_UNROLL for (int m = 0; m < NA; ++m) b[m] = 0.0;
+        if (t < 2) b[t] = 1.0;
+        if (t == 6) b[4] = 1.0;
+        if (t == 7) b[5] = 1.0;
+        sel = (t == 2 || t == 3 || t == 6 || t == 7) ? 1.0 : 0.0;
+        ci = t == 3 ? 4 : (t == 6 ? 8 : (t == 7 ? 12 : 0));
+        s8 = t == 8 ? 1.0 : 0.0;
+    }
+    template <class P>
+    SC_HD void at(P ab, double g[NA]) const {
+        SC_UNROLL for (int m = 0; m < 4; ++m) g[m] = b[m] + sel * ab[ci + m];
+        g[4] = b[4]; g[5] = b[5];
+    }
+};
+
+template <class Cx, bool GEN = false>
 SC_HD SC_DUMS_INLINE bool riccati_backward(Cx& cx, const Lds& L, const int N, const double dt, const double cpl0, const double cpl1) {
     typename Cx::ptr lds = cx.lds;
     const int lane = cx.lane, r = lane >> 3, c = lane & 7;
     const int rr = r < c ? r : c, cc = r < c ? c : r;
     // T phase: lane l < 54 owns T~[l / 9][l % 9] (column 8 = the affine column P c + p)
     const int tr = lane < 54 ? lane / 9 : 0, tc = lane < 54 ? lane % 9 : 0;
-    GCol gT, gR, gC;
+    typename std::conditional<GEN, GColG, GCol>::type gT, gR, gC;
     gT.set(tc, dt); gR.set(rr, dt); gC.set(c, dt);
     // S[rr][cc]: an entry of H (index map 0..3 -> x, 6..7 -> u), or -cpl on (v_i, u_i) for k >= 1; s[c]: an entry of the gradient
     const int hr = rr < 4 ? rr : (rr >= 6 ? rr - 2 : -1), hc = cc < 4 ? cc : (cc >= 6 ? cc - 2 : -1), hq = c < 4 ? c : (c >= 6 ? c - 2 : -1);
@@ -144,12 +173,13 @@ SC_HD SC_DUMS_INLINE bool riccati_backward(Cx& cx, const Lds& L, const int N, co
     if (r == 6 && c < 6) lds[cur + 36 + c] = c < 4 ? lds[L.G + N * 6 + c] : 0.0;
     cx.sync();
     for (int k = N - 1; k >= 0; --k) {
-        const typename Cx::ptr ab = lds + L.AB + k * 4;
+        const typename Cx::ptr ab = lds + L.AB + k * L.ABW;
         const typename Cx::ptr cd = lds + L.C + (k + 1) * 4;
-        const double a02 = ab[0], a03 = ab[1], a12 = ab[2], a13 = ab[3];
+        double a02 = 0.0, a03 = 0.0, a12 = 0.0, a13 = 0.0;
+        if constexpr (!GEN) { a02 = ab[0]; a03 = ab[1]; a12 = ab[2]; a13 = ab[3]; }
         double g[NA];
         // T~ = P G~ (+ p on the affine column)
-        gT.at(a02, a03, a12, a13, g);
+        if constexpr (GEN) gT.at(ab, g); else gT.at(a02, a03, a12, a13, g);
         g[0] += gT.s8 * cd[0]; g[1] += gT.s8 * cd[1]; g[2] += gT.s8 * cd[2]; g[3] += gT.s8 * cd[3];
         {
             double v = gT.s8 * lds[cur + 36 + tr];
@@ -158,10 +188,10 @@ SC_HD SC_DUMS_INLINE bool riccati_backward(Cx& cx, const Lds& L, const int N, co
         }
         cx.sync();
         // Q[rr][cc] = S + G[:, rr]' T[:, cc];  q[c] = s[c] + G[:, c]' t  (every lane of column c)
-        gR.at(a02, a03, a12, a13, g);
+        if constexpr (GEN) gR.at(ab, g); else gR.at(a02, a03, a12, a13, g);
         double qv = mH * lds[L.H + k * 21 + oH] + (k >= 1 ? cplv : 0.0);
         SC_UNROLL for (int m = 0; m < NA; ++m) qv += g[m] * lds[L.T + m * 8 + cc];
-        gC.at(a02, a03, a12, a13, g);
+        if constexpr (GEN) gC.at(ab, g); else gC.at(a02, a03, a12, a13, g);
         double ql = mG * lds[L.G + k * 6 + oG];
         SC_UNROLL for (int m = 0; m < NA; ++m) ql += g[m] * lds[L.T + 48 + m];
         if (r >= 6) lds[L.QU + (r - 6) * 8 + c] = qv;
@@ -198,7 +228,7 @@ SC_HD SC_DUMS_INLINE bool riccati_backward(Cx& cx, const Lds& L, const int N, co
 }
 
 // forward sweep, redundantly in every lane: lane k keeps xi_k = (dx_k, du_{k-1}) and du_k
-template <class Cx>
+template <class Cx, bool GEN = false>
 SC_HD SC_DUMS_INLINE void riccati_forward(Cx& cx, const Lds& L, const int N, const double dt, const int k_me, double xi_me[NA], double du_me[NU]) {
     typename Cx::ptr lds = cx.lds;
     double xi[NA] = {lds[L.C + 0], lds[L.C + 1], lds[L.C + 2], lds[L.C + 3], 0.0, 0.0};
@@ -209,10 +239,17 @@ SC_HD SC_DUMS_INLINE void riccati_forward(Cx& cx, const Lds& L, const int N, con
         double du0 = kg[12], du1 = kg[13];
         SC_UNROLL for (int m = 0; m < NA; ++m) { du0 += kg[m] * xi[m]; du1 += kg[6 + m] * xi[m]; }
         if (k == k_me) { du_me[0] = du0; du_me[1] = du1; }
-        const typename Cx::ptr ab = lds + L.AB + k * 4;
+        const typename Cx::ptr ab = lds + L.AB + k * L.ABW;
         const typename Cx::ptr cd = lds + L.C + (k + 1) * 4;
-        const double n0 = xi[0] + ab[0] * xi[2] + ab[1] * xi[3] + cd[0], n1 = xi[1] + ab[2] * xi[2] + ab[3] * xi[3] + cd[1];
-        const double n2 = xi[2] + dt * du1 + cd[2], n3 = xi[3] + dt * du0 + cd[3];
+        double n0, n1, n2, n3;
+        if constexpr (GEN) {
+            double nn[4];
+            SC_UNROLL for (int r = 0; r < 4; ++r) nn[r] = (r < 2 ? xi[r] : 0.0) + ab[r] * xi[2] + ab[4 + r] * xi[3] + ab[8 + r] * du0 + ab[12 + r] * du1 + cd[r];
+            n0 = nn[0]; n1 = nn[1]; n2 = nn[2]; n3 = nn[3];
+        } else {
+            n0 = xi[0] + ab[0] * xi[2] + ab[1] * xi[3] + cd[0]; n1 = xi[1] + ab[2] * xi[2] + ab[3] * xi[3] + cd[1];
+            n2 = xi[2] + dt * du1 + cd[2]; n3 = xi[3] + dt * du0 + cd[3];
+        }
         xi[0] = n0; xi[1] = n1; xi[2] = n2; xi[3] = n3; xi[4] = du0; xi[5] = du1;
         if (k + 1 == k_me) SC_UNROLL for (int m = 0; m < NA; ++m) xi_me[m] = xi[m];
     }
@@ -223,7 +260,8 @@ SC_HD inline bool cmp_le(double lhs, double rhs, double bas) { return lhs - rhs 
 
 template <class Cx, int MODEL = M_DU>
 struct Wave {
-    static constexpr bool XB = MODEL == M_DU;          // the model has the state bound |x_3| <= v_max
+    static constexpr bool XB = MODEL == M_DU || MODEL == M_KB;          // the model has the state bound |x_3| <= v_max
+    static constexpr bool GEN = general_layout(MODEL);
     Cx& cx;
     const Params& P;
     const sc_ipopt_params& O;
@@ -265,7 +303,7 @@ struct Wave {
     SC_HD double dr2(int i) const { const double a = fabs(lds[XRi(i)]); return a > 1.0 ? 1.0 / (a * a) : 1.0; }      // D_R^2 = 1 / max(1, |w_R|)^2
 
     SC_HD Wave(Cx& cx_, const Params& P_, const sc_ipopt_params& O_)
-        : cx(cx_), P(P_), O(O_), lds(cx_.lds), L(P_.N, P_.K), lane(cx_.lane), N(P_.N), K(P_.K),
+        : cx(cx_), P(P_), O(O_), lds(cx_.lds), L(P_.N, P_.K, general_layout(MODEL)), lane(cx_.lane), N(P_.N), K(P_.K),
           G(group_lanes(P_.N)), q(cx_.lane % group_lanes(P_.N)), act(cx_.lane / group_lanes(P_.N) <= P_.N), stg(cx_.lane / group_lanes(P_.N) < P_.N),
           acl(cx_.lane / group_lanes(P_.N) <= P_.N && cx_.lane % group_lanes(P_.N) == 0), stl(cx_.lane / group_lanes(P_.N) < P_.N && cx_.lane % group_lanes(P_.N) == 0),
           k(cx_.lane / group_lanes(P_.N) <= P_.N ? cx_.lane / group_lanes(P_.N) : 0) {
@@ -283,10 +321,42 @@ struct Wave {
         double F[NX], p1[2], p2[2];
         double a02, a03, a12, a13;       // d p1 / d (theta, v)  = the non-trivial entries of A
         double g02, g03, g12, g13;       // d (p2 - p1) / d (theta, v);  d / d a = dt (g03, g13),  d / d omega = dt (g02, g12)
+        // general layout: ab = [A_2 | A_3 | B_0 | B_1] (d F / d (x_2, x_3, u_0, u_1), 4 rows each), j2 = d p2 / d (x_2, x_3, u_0, u_1) (2 x 4),
+        // and what the curvature needs again (model-specific)
+        double ab[16], j2[2][4], cw[8];
     };
     double tc_ = 1.0, ts_ = 0.0, tc1_ = 1.0, ts1_ = 0.0;        // cos / sin of theta_k and of theta_k + dt omega_k at the ITERATE (eval2 sets them, finish_step reuses them)
     SC_HD void geometry(const double* xs, const double* us, Geo& g, bool cached = false) const {
         const double dt = P.dt;
+        if constexpr (MODEL == M_KB) {
+            const double v = xs[3], be = us[1], iL = P.inv_Lr;
+            if (cached) { g.c = tc_; g.s = ts_; } else cx.sincos(xs[2], g.s, g.c);
+            const double fv = g.c - be * g.s, pv = g.s + be * g.c, ph = v * fv, ps = v * pv;          // phi, psi and their d / dv
+            g.F[0] = xs[0] + dt * ph; g.F[1] = xs[1] + dt * ps; g.F[2] = xs[2] + dt * (v * be * iL); g.F[3] = xs[3] + dt * us[0];
+            if (cached) { g.c1 = tc1_; g.s1 = ts1_; } else cx.sincos(g.F[2], g.s1, g.c1);
+            const bool in = g.F[3] >= P.v_min && g.F[3] <= P.v_max;
+            const double v1 = in ? g.F[3] : (g.F[3] < P.v_min ? P.v_min : P.v_max), chi = in ? 1.0 : 0.0;      // robot.step's clip (casadi: slope 1 inside, 0 outside)
+            const double fv1 = g.c1 - be * g.s1, pv1 = g.s1 + be * g.c1, ph1 = v1 * fv1, ps1 = v1 * pv1;
+            g.v1 = v1;
+            g.p1[0] = g.F[0]; g.p1[1] = g.F[1];
+            g.p2[0] = g.F[0] + dt * ph1; g.p2[1] = g.F[1] + dt * ps1;
+            // [A_2 | A_3 | B_0 | B_1]
+            g.ab[0] = -dt * ps; g.ab[1] = dt * ph; g.ab[2] = 1.0; g.ab[3] = 0.0;
+            g.ab[4] = dt * fv; g.ab[5] = dt * pv; g.ab[6] = dt * be * iL; g.ab[7] = 1.0;
+            g.ab[8] = 0.0; g.ab[9] = 0.0; g.ab[10] = 0.0; g.ab[11] = dt;
+            g.ab[12] = -dt * v * g.s; g.ab[13] = dt * v * g.c; g.ab[14] = dt * v * iL; g.ab[15] = 0.0;
+            // q = (theta_1, v_1, beta) over (theta, v, a, beta)
+            const double qt[4] = {1.0, dt * be * iL, 0.0, dt * v * iL}, qv[4] = {0.0, chi, chi * dt, 0.0};
+            SC_UNROLL for (int i = 0; i < 4; ++i) {
+                const double qb = i == 3 ? 1.0 : 0.0;
+                g.j2[0][i] = g.ab[4 * i + 0] + dt * (-ps1 * qt[i] + fv1 * qv[i] - v1 * g.s1 * qb);
+                g.j2[1][i] = g.ab[4 * i + 1] + dt * (ph1 * qt[i] + pv1 * qv[i] + v1 * g.c1 * qb);
+            }
+            g.cw[0] = chi; g.cw[1] = ph; g.cw[2] = ps; g.cw[3] = ph1; g.cw[4] = ps1;
+            g.a02 = g.ab[0]; g.a12 = g.ab[1]; g.a03 = g.ab[4]; g.a13 = g.ab[5];
+            g.g02 = g.g03 = g.g12 = g.g13 = 0.0;
+            return;
+        }
         if constexpr (MODEL == M_DI) {
             // p1 = p + dt v;  w = v + dt a,  p2 = p1 + dt w min(1, v_max / |w|)   (the rescaling of robot.step; the model's x_next has none)
             g.c = g.s = g.c1 = g.s1 = 0.0;
@@ -322,6 +392,11 @@ struct Wave {
         if (a) {
             const double dt = P.dt;
             a[0] = 2.0 * (w0 * e0x + w1 * e1x + w2 * e2x); a[1] = 2.0 * (w0 * e0y + w1 * e1y + w2 * e2y);
+            if constexpr (GEN) {
+                SC_UNROLL for (int i = 0; i < 4; ++i)
+                    a[2 + i] = 2.0 * (w1 * (e1x * g.ab[4 * i] + e1y * g.ab[4 * i + 1]) + w2 * (e2x * g.j2[0][i] + e2y * g.j2[1][i]));
+                return w0 * (e0x * e0x + e0y * e0y - off) + w1 * (e1x * e1x + e1y * e1y - off) + w2 * (e2x * e2x + e2y * e2y - off);
+            }
             a[2] = 2.0 * (w1 * (e1x * g.a02 + e1y * g.a12) + w2 * (e2x * (g.a02 + g.g02) + e2y * (g.a12 + g.g12)));
             a[3] = 2.0 * (w1 * (e1x * g.a03 + e1y * g.a13) + w2 * (e2x * (g.a03 + g.g03) + e2y * (g.a13 + g.g13)));
             a[4] = 2.0 * w2 * dt * (e2x * g.g03 + e2y * g.g13);
@@ -546,13 +621,18 @@ struct Wave {
             geometry(x, u, g);
             tc_ = g.c; ts_ = g.s; tc1_ = g.c1; ts1_ = g.s1;
             SC_UNROLL for (int i = 0; i < NX; ++i) { rc[i] = dgc(i) * (g.F[i] - lds[L.XS + (k + 1) * 4 + i]); if (stl) th += fabs(rc[i]); }
-            if (build && stl) { lds[L.AB + k * 4 + 0] = g.a02; lds[L.AB + k * 4 + 1] = g.a03; lds[L.AB + k * 4 + 2] = g.a12; lds[L.AB + k * 4 + 3] = g.a13; }
             // J' y of my dynamics rows: [A | B]' (dgc yc)
             SC_UNROLL for (int i = 0; i < NX; ++i) wy[i] = dgc(i) * yc[i];
             E.Jty[0] += wy[0]; E.Jty[1] += wy[1];
-            E.Jty[2] += g.a02 * wy[0] + g.a12 * wy[1] + wy[2];
-            E.Jty[3] += g.a03 * wy[0] + g.a13 * wy[1] + wy[3];
-            E.Jty[4] += dt * wy[3]; E.Jty[5] += dt * wy[2];
+            if constexpr (GEN) {
+                if (build && stl) SC_UNROLL for (int i = 0; i < 16; ++i) lds[L.AB + k * 16 + i] = g.ab[i];
+                SC_UNROLL for (int i = 0; i < 4; ++i) E.Jty[2 + i] += g.ab[4 * i] * wy[0] + g.ab[4 * i + 1] * wy[1] + g.ab[4 * i + 2] * wy[2] + g.ab[4 * i + 3] * wy[3];
+            } else {
+                if (build && stl) { lds[L.AB + k * 4 + 0] = g.a02; lds[L.AB + k * 4 + 1] = g.a03; lds[L.AB + k * 4 + 2] = g.a12; lds[L.AB + k * 4 + 3] = g.a13; }
+                E.Jty[2] += g.a02 * wy[0] + g.a12 * wy[1] + wy[2];
+                E.Jty[3] += g.a03 * wy[0] + g.a13 * wy[1] + wy[3];
+                E.Jty[4] += dt * wy[3]; E.Jty[5] += dt * wy[2];
+            }
             for (int j = q; j < K; j += G) {
                 double a[NV];
                 const double cv = row(x, g, j, a);
@@ -609,7 +689,29 @@ struct Wave {
                 const double s1x = sl * g.p1[0] - socx, s1y = sl * g.p1[1] - socy, s2x = sl * g.p2[0] - socx, s2y = sl * g.p2[1] - socy;
                 const double nx_ = wy[0] - 2.0 * w1 * s1x - 2.0 * w2 * s2x, ny_ = wy[1] - 2.0 * w1 * s1y - 2.0 * w2 * s2y;    // on grad^2 p1
                 const double kx = -2.0 * w2 * s2x, ky = -2.0 * w2 * s2y;                                                        // on grad^2 (p2 - p1)
-                if constexpr (MODEL == M_DI) {
+                if constexpr (MODEL == M_KB) {
+                    // over (theta, v, a, beta) = entries 2 .. 5.  phi = v (c - b s), psi = v (s + b c):  phi_tt = -phi, phi_tv = -(s + b c), phi_tb = -v c,
+                    // phi_vb = -s;  psi_tt = -psi, psi_tv = c - b s, psi_tb = -v s, psi_vb = c;  F_2 = theta + dt v b / L_r: (v, b) entry dt / L_r
+                    const double v = x[3], be = u[1], iL = P.inv_Lr, c = g.c, s_ = g.s, c1 = g.c1, s1 = g.s1, v1 = g.v1, chi = g.cw[0];
+                    const double ph = g.cw[1], ps = g.cw[2], ph1 = g.cw[3], ps1 = g.cw[4];
+                    M[sym6(2, 2)] += dt * (nx_ * (-ph) + ny_ * (-ps));
+                    M[sym6(2, 3)] += dt * (nx_ * (-(s_ + be * c)) + ny_ * (c - be * s_));
+                    M[sym6(2, 5)] += dt * (nx_ * (-v * c) + ny_ * (-v * s_));
+                    M[sym6(3, 5)] += dt * (nx_ * (-s_) + ny_ * c) + wy[2] * dt * iL;
+                    // (p2 - p1) = dt (phi, psi)(q), q = (theta_1, v_1, beta):  J_q' S J_q + (kx phi_t + ky psi_t)(q) grad^2 theta_1
+                    const double S00 = kx * (-ph1) + ky * (-ps1), S01 = kx * (-(s1 + be * c1)) + ky * (c1 - be * s1), S02 = kx * (-v1 * c1) + ky * (-v1 * s1), S12 = kx * (-s1) + ky * c1;
+                    const double qt[4] = {1.0, dt * be * iL, 0.0, dt * v * iL}, qv[4] = {0.0, chi, chi * dt, 0.0}, qb[4] = {0.0, 0.0, 0.0, 1.0};
+                    const double gt = kx * (-ps1) + ky * ph1;
+                    SC_UNROLL for (int i = 0; i < 4; ++i) {
+                        // (S J_q)[:, i]
+                        const double t0 = S00 * qt[i] + S01 * qv[i] + S02 * qb[i], t1 = S01 * qt[i] + S12 * qb[i], t2 = S02 * qt[i] + S12 * qv[i];
+                        SC_UNROLL for (int j = i; j < 4; ++j) {
+                            double hv = qt[j] * t0 + qv[j] * t1 + qb[j] * t2;
+                            if (i == 1 && j == 3) hv += gt * dt * iL;
+                            M[sym6(2 + i, 2 + j)] += dt * hv;
+                        }
+                    }
+                } else if constexpr (MODEL == M_DI) {
                     // p1 is affine; p2 - p1 = dt wt(w), wt = w v_max / |w| where |w| > v_max:  grad^2 wt_d = v_max (-(d_da w_b + d_db w_a + d_ab w_d) / |w|^3
                     // + 3 w_d w_a w_b / |w|^5) over w = (F_2, F_3), F_2 = x_2 + dt u_1, F_3 = x_3 + dt u_0
                     (void)nx_; (void)ny_;
@@ -635,9 +737,10 @@ struct Wave {
                 }
                 // -2 sl (w0 J0'J0 + w1 J1'J1 + w2 J2'J2): J0 = [e_0; e_1], J1 = J0 + [a0.; a1.] on (theta, v), J2 = J1 + [g..] on (theta, v, a, omega)
                 const double o0 = -2.0 * sl * w0, o1 = -2.0 * sl * w1, o2 = -2.0 * sl * w2;
-                const double j1x[NV] = {1.0, 0.0, g.a02, g.a03, 0.0, 0.0}, j1y[NV] = {0.0, 1.0, g.a12, g.a13, 0.0, 0.0};
-                const double j2x[NV] = {1.0, 0.0, g.a02 + g.g02, g.a03 + g.g03, dt * g.g03, dt * g.g02};
-                const double j2y[NV] = {0.0, 1.0, g.a12 + g.g12, g.a13 + g.g13, dt * g.g13, dt * g.g12};
+                double j1x[NV] = {1.0, 0.0, g.a02, g.a03, 0.0, 0.0}, j1y[NV] = {0.0, 1.0, g.a12, g.a13, 0.0, 0.0};
+                double j2x[NV] = {1.0, 0.0, g.a02 + g.g02, g.a03 + g.g03, dt * g.g03, dt * g.g02};
+                double j2y[NV] = {0.0, 1.0, g.a12 + g.g12, g.a13 + g.g13, dt * g.g13, dt * g.g12};
+                if constexpr (GEN) SC_UNROLL for (int i = 0; i < 4; ++i) { j1x[2 + i] = g.ab[4 * i]; j1y[2 + i] = g.ab[4 * i + 1]; j2x[2 + i] = g.j2[0][i]; j2y[2 + i] = g.j2[1][i]; }
                 M[sym6(0, 0)] += o0; M[sym6(1, 1)] += o0;
                 int e = 0;
                 SC_UNROLL for (int p = 0; p < NV; ++p)
@@ -674,7 +777,7 @@ struct Wave {
     SC_HD void finish_step(bool ls, double mu, double dw, double tau) {
         {
             double xi[NA];
-            riccati_forward<Cx>(cx, L, N, P.dt, act ? k : -1, xi, du);
+            riccati_forward<Cx, GEN>(cx, L, N, P.dt, act ? k : -1, xi, du);
             SC_UNROLL for (int i = 0; i < NX; ++i) dx[i] = act ? xi[i] : 0.0;
             SC_UNROLL for (int j = 0; j < NU; ++j) { dvv[j] = act ? xi[4 + j] : 0.0; if (!stg) du[j] = 0.0; }
         }
@@ -866,11 +969,16 @@ struct Wave {
             df = gm > gmax ? fmax(gmin, gmax / gm) : 1.0;
             Geo g;
             geometry(x0, uprev, g);
-            const double rm0 = fmax(1.0, fmax(fabs(g.a02), fabs(g.a03))), rm1 = fmax(1.0, fmax(fabs(g.a12), fabs(g.a13))), rm2 = fmax(1.0, P.dt);
+            double rm0 = fmax(1.0, fmax(fabs(g.a02), fabs(g.a03))), rm1 = fmax(1.0, fmax(fabs(g.a12), fabs(g.a13))), rm2 = fmax(1.0, P.dt), rm3 = rm2;
+            if constexpr (GEN) {
+                double rm[4];
+                SC_UNROLL for (int r = 0; r < 4; ++r) rm[r] = fmax(fmax(1.0, fabs(g.ab[r])), fmax(fabs(g.ab[4 + r]), fmax(fabs(g.ab[8 + r]), fabs(g.ab[12 + r]))));
+                rm0 = rm[0]; rm1 = rm[1]; rm2 = rm[2]; rm3 = rm[3];
+            }
             sync();
             if (lane == 0) {
                 lds[L.SC + 0] = rm0 > gmax ? fmax(gmin, gmax / rm0) : 1.0; lds[L.SC + 1] = rm1 > gmax ? fmax(gmin, gmax / rm1) : 1.0;
-                lds[L.SC + 2] = rm2 > gmax ? fmax(gmin, gmax / rm2) : 1.0; lds[L.SC + 3] = lds[L.SC + 2];
+                lds[L.SC + 2] = rm2 > gmax ? fmax(gmin, gmax / rm2) : 1.0; lds[L.SC + 3] = rm3 > gmax ? fmax(gmin, gmax / rm3) : 1.0;
                 SC_UNROLL for (int i = 0; i < NX; ++i) lds[L.Y0 + i] = 0.0;
             }
             for (int j = 0; j < K; ++j) {
@@ -973,7 +1081,7 @@ struct Wave {
             if (build) {
                 const double cs = (ls || rs) ? 0.0 : 2.0 * df;               // (the restoration's objective has no input-rate term)
                 DPROF_ADD(2)
-                const bool okf = riccati_backward<Cx>(cx, L, N, P.dt, cs * P.R[0], cs * P.R[1]);
+                const bool okf = riccati_backward<Cx, GEN>(cx, L, N, P.dt, cs * P.R[0], cs * P.R[1]);
                 DPROF_ADD(3)
                 if (!okf) {                                                 // Algorithm IC: the same system with a larger delta_w
                     if (ic_first) {

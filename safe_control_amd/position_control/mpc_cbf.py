@@ -30,6 +30,8 @@ def default_mpc_weights(model):
         return np.diag([50.0, 50.0, 0.01]), np.array([0.5, 0.5])
     if model == "DoubleIntegrator2D":                       # mpc_cbf.py:28-30 (the multiple-shooting kernel; the condensed solve of this model is mpc_cbf_gn.py)
         return np.diag([50.0, 50.0, 20.0, 20.0]), np.array([0.5, 0.5])
+    if model == "KinematicBicycle2D":                       # mpc_cbf.py:31-33 (likewise)
+        return np.diag([50.0, 50.0, 1.0, 1.0]), np.array([0.5, 5000.0])
     raise NotImplementedError(f"MPC-CBF on the batched engine supports DynamicUnicycle2D and Unicycle2D, not {model}")
 
 
@@ -41,6 +43,8 @@ def default_mpc_cbf_param(model):
         return {"alpha": 0.05}                              # mpc_cbf.py:52-53
     if model == "DoubleIntegrator2D":
         return {"alpha1": 0.2, "alpha2": 0.2}               # mpc_cbf.py:56-59
+    if model == "KinematicBicycle2D":
+        return {"alpha1": 0.1, "alpha2": 0.1}               # mpc_cbf.py:64-66
     raise NotImplementedError(model)
 
 
@@ -89,6 +93,10 @@ def make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_
     if robot_spec["model"] == "Unicycle2D":                 # inputs [v, omega] (mpc_cbf.py:188-192), one gain alpha
         p.alpha1, p.alpha2 = float(cbf_param["alpha"]), 0.0
         p.u_max[0], p.u_max[1] = float(robot_spec["v_max"]), float(robot_spec["w_max"])
+    elif robot_spec["model"] == "KinematicBicycle2D":       # inputs [a, beta] (mpc_cbf.py:202-208); robot.step clips the speed to [v_min, v_max]
+        p.alpha1, p.alpha2 = float(cbf_param["alpha1"]), float(cbf_param["alpha2"])
+        p.u_max[0], p.u_max[1] = float(robot_spec["a_max"]), float(robot_spec["beta_max"])
+        p.v_min, p.rear_ax_dist = float(robot_spec["v_min"]), float(robot_spec["rear_ax_dist"])
     elif robot_spec["model"] == "DoubleIntegrator2D":       # inputs [ax, ay] (mpc_cbf.py:196-200); v_max is the norm robot.step rescales the velocity to
         p.alpha1, p.alpha2 = float(cbf_param["alpha1"]), float(cbf_param["alpha2"])
         p.u_max[0], p.u_max[1] = float(robot_spec.get("ax_max", robot_spec["a_max"])), float(robot_spec.get("ay_max", robot_spec["a_max"]))
@@ -96,7 +104,7 @@ def make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_
         p.alpha1, p.alpha2 = float(cbf_param["alpha1"]), float(cbf_param["alpha2"])
         p.u_max[0], p.u_max[1] = float(robot_spec["a_max"]), float(robot_spec["w_max"])
     p.robot_radius = float(radius)
-    p.beta = 1.01                                           # agent_barrier_dt default, dynamic_unicycle2D.py:188
+    p.beta = 1.1 if robot_spec["model"] == "KinematicBicycle2D" else 1.01      # agent_barrier_dt defaults: kinematic_bicycle2D.py:175, dynamic_unicycle2D.py:188
     p.tol, p.mu_init, p.mu_min = float(tol), float(mu_init), float(mu_min)
     p.acceptable_tol = float(acceptable_tol)
     p.resto = resto if resto is not None else _lib.default_resto()     # feasibility restoration (sc_resto_params)

@@ -99,9 +99,13 @@ class GnMPCCBF:
         self.iterations = 0
         self.solver_status = "optimal"
         # DoubleIntegrator2D: the NLP as do-mpc poses it (multiple shooting under IPOPT's algorithm, csrc/mpc_du_ms.hip, kernel 13) unless
-        # robot_spec['mpc_formulation'] = 'condensed'; superellipsoid rows run on the condensed kernel
+        # robot_spec['mpc_formulation'] = 'condensed'; superellipsoid rows run on the condensed kernel.  KinematicBicycle2D: the same kernel ON
+        # REQUEST (robot_spec['mpc_formulation'] = 'multiple_shooting'): where a plan slows down to v_min the kink of robot.step's speed clip sits
+        # on the solution and the Newton iteration cycles to the iteration limit (3 % of the bench draws; DESIGN.md kernel 13), which the
+        # condensed solve's l1 merit function does not
         self._ms = None
-        if self.robot_spec["model"] == "DoubleIntegrator2D" and self.robot_spec.get("mpc_formulation", "multiple_shooting") != "condensed" and self.num_obs <= 16:
+        want = self.robot_spec.get("mpc_formulation", "multiple_shooting" if self.robot_spec["model"] == "DoubleIntegrator2D" else "condensed")
+        if self.robot_spec["model"] in ("DoubleIntegrator2D", "KinematicBicycle2D") and want == "multiple_shooting" and self.num_obs <= 16:
             from .mpc_cbf_ms import BatchedMSMPCCBF
             self._ms = BatchedMSMPCCBF(self.robot_spec, dt=self.dt, io_dtype="f64", horizon=self.horizon, cbf_param=self.cbf_param, check_circles=False)
 

@@ -117,7 +117,10 @@ class BatchedTrackingController:
             # unless robot_spec['mpc_formulation'] = 'condensed'; a scene with superellipsoid rows runs on the condensed kernel
             self.mpc_ms = None
             ms_model = (cls is BatchedMPCCBF and self.model == "DynamicUnicycle2D") or (self.model == "DoubleIntegrator2D" and self.pos_controller_type == "mpc_cbf")
-            if ms_model and self.robot_spec.get("mpc_formulation", "multiple_shooting") != "condensed" and self.num_constraints <= 16:
+            want = self.robot_spec.get("mpc_formulation", "multiple_shooting" if ms_model else "condensed")
+            if self.model == "KinematicBicycle2D" and self.pos_controller_type == "mpc_cbf":      # on request only (position_control/mpc_cbf_gn.py: GnMPCCBF)
+                ms_model = True
+            if ms_model and want == "multiple_shooting" and self.num_constraints <= 16:
                 from .position_control.mpc_cbf_ms import BatchedMSMPCCBF
                 self.mpc_ms = BatchedMSMPCCBF(self.robot_spec, dt=self.dt, io_dtype=io_dtype, check_circles=False)
             self.u_prev = torch.zeros((self.B, 2), dtype=self.tdtype, device=self.device)   # do-mpc's u0 per agent

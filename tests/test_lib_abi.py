@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in header_functions():
         assert hasattr(lib, name), name
-    assert lib.sc_version() == _lib.ABI_VERSION == 8
+    assert lib.sc_version() == _lib.ABI_VERSION == 9
 
 
 def test_params_struct_layout_matches_header():

@@ -137,3 +137,30 @@ def test_solver_header_for_double_integrator_equals_the_numpy_oracle():
     assert np.array_equal(st, so) and (so[:n] == 1).sum() >= 8 and (so[n:] == 1).sum() >= 8
     assert (it != ito).sum() <= 2 and np.abs(it - ito).max() <= 1
     assert np.abs(u - uo)[it == ito].max() <= 1e-9
+
+
+def _ms_one_kb(a):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    from oracle import ms_ipopt as MS
+    from safe_control_amd.robots.spec import complete_robot_spec
+    sp = complete_robot_spec({"model": "KinematicBicycle2D"})
+    mdl = MS.kb_model({k: v for k, v in sp.items() if k in MS.kb_model()["spec"]})
+    return MS.solve(mdl, a[0], a[1], a[2], a[3], opts=dict(MS.KERNEL_PROFILE, max_iter=150))
+
+
+def test_solver_header_for_kinematic_bicycle_equals_the_numpy_oracle():
+    """The KinematicBicycle2D instantiation of csrc/mpc_du_ms_solver.hpp (general stage layout: the inputs enter the positions; robot.step's speed
+    clip inside the barrier rows; curvature of the bilinear dynamics) compiled for the host, against oracle/ms_ipopt.py: kb_model() on 160 bench
+    draws at an iteration limit of 150: same status everywhere; same iteration count and u0 to 1e-8 on the solves that end within 60 iterations
+    (the others cycle around the clip's kink, on both sides, along paths that rounding separates)."""
+    from multiprocessing import Pool
+    n = 160
+    X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("kb", 4096, 8, seed=0))
+    u, st, it = c_oracle.du_ms_cpu_batch(X, up, goal, obs, n_threads=0, model="KinematicBicycle2D", ipopt=dict(max_iter=150))
+    with Pool(min(8, os.cpu_count() or 2)) as p:
+        res = p.map(_ms_one_kb, [(X[i], up[i], goal[i], obs[i]) for i in range(n)], chunksize=4)
+    so = np.array([r[1] for r in res]); ito = np.array([r[2] for r in res]); uo = np.array([r[0] for r in res])
+    assert np.array_equal(st, so)
+    short = ito < 60
+    assert short.mean() >= 0.9 and (it != ito)[short].sum() <= 2 and np.abs(it - ito)[short].max() <= 1
+    assert np.abs(u - uo)[short & (it == ito)].max() <= 1e-8

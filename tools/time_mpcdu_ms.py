@@ -1,5 +1,5 @@
 """GPU: launch time of the multiple-shooting DynamicUnicycle2D kernel (csrc/mpc_du_ms.hip, kernel 13) on the 4096 configs[2] problems, next to the
-condensed kernel on the same batch.   python tools/time_mpcdu_ms.py [B] [f32|f64] [reps] [du|di]"""
+condensed kernel on the same batch.   python tools/time_mpcdu_ms.py [B] [f32|f64] [reps] [du|di|kb] [max_iter]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,12 +11,13 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 io = sys.argv[2] if len(sys.argv) > 2 else "f32"
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 fam = sys.argv[4] if len(sys.argv) > 4 else "du"
-SPEC = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "v_max": 1.0, "radius": 0.25} if fam == "du" else {"model": "DoubleIntegrator2D"}
+SPEC = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "v_max": 1.0, "radius": 0.25} if fam == "du" else {"model": W.MPC_FAMILIES[fam]}
+MAXIT = int(sys.argv[5]) if len(sys.argv) > 5 else None
 dt = torch.float32 if io == "f32" else torch.float64
 X, up, goal, obs = W.mpc_family_batch(fam, B, 8, seed=0)
 t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=dt, device="cuda:0")
 args = (t(X), t(up), t(goal), t(obs))
-for name, ctl in (("multiple shooting (kernel 13)", sca.BatchedMSMPCCBF(SPEC, io_dtype=io, check_circles=False)), ("condensed (kernel 3)" if fam == "du" else "condensed (mpcgn)", sca.BatchedMPCCBF(SPEC, io_dtype=io) if fam == "du" else sca.BatchedGnMPCCBF(SPEC, io_dtype=io))):
+for name, ctl in (("multiple shooting (kernel 13)", sca.BatchedMSMPCCBF(SPEC, io_dtype=io, check_circles=False, max_iter=MAXIT)), ("condensed (kernel 3)" if fam == "du" else "condensed (mpcgn)", sca.BatchedMPCCBF(SPEC, io_dtype=io) if fam == "du" else sca.BatchedGnMPCCBF(SPEC, io_dtype=io))):
     u, st, it = ctl.solve(*args)[:3]
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
