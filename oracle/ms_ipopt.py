@@ -172,6 +172,11 @@ def _clip(a, lo, hi):
     return np.clip(a, lo, hi)
 
 
+def uni_next(x, u, spec, dt):
+    """Unicycle2D: x = (px, py, theta), f = 0, g u = [v cos th, v sin th, w]   (unicycle2D.py:42-68; U = [v, w])."""
+    return [x[0] + u[0] * _cos(x[2]) * dt, x[1] + u[0] * _sin(x[2]) * dt, x[2] + u[1] * dt]
+
+
 def kb_next(x, u, spec, dt):
     """KinematicBicycle2D: f = [v cos th, v sin th, 0, 0], g u = [-v sin th b, v cos th b, v b / L_r, a]   (kinematic_bicycle2D.py:67-110; U = [a, beta])."""
     c, s = _cos(x[2]), _sin(x[2])
@@ -256,6 +261,15 @@ def du_model(spec=None, dt=0.05):
                 x_lo=np.array([-INF, -INF, -INF, -s["v_max"]]), x_hi=np.array([INF, INF, INF, s["v_max"]]))
 
 
+def uni_model(spec=None, dt=0.05):
+    """mpc_cbf.py:22-24 (Q, R), :52-53 (alpha = 0.05), :188-192 (input box), :312-315 (d_h + alpha h_k >= 0: one step), unicycle2D.py:127 (beta = 1.01)."""
+    s = dict(v_max=1.0, w_max=0.5, radius=0.25)
+    s.update(spec or {})
+    return dict(name="Unicycle2D", nx=3, nu=2, next=uni_next, spec=s, dt=dt, N=10, Q=np.array([50.0, 50.0, 0.01]), R=np.array([0.5, 0.5]),
+                alpha=0.05, alpha1=0.0, alpha2=0.0, beta=1.01, radius=s["radius"], circles_only=True,
+                u_lo=np.array([-s["v_max"], -s["w_max"]]), u_hi=np.array([s["v_max"], s["w_max"]]), x_lo=np.full(3, -INF), x_hi=np.full(3, INF))
+
+
 def kb_model(spec=None, dt=0.05):
     """mpc_cbf.py:31-33 (Q, R), :64-66 (alpha1 = alpha2 = 0.1), :202-208 (|v| <= v_max, input box), kinematic_bicycle2D.py:175 (beta = 1.1)."""
     s = dict(wheel_base=0.4, radius=0.3, rear_ax_dist=0.2, v_max=3.5, a_max=5.0, v_min=0.2)
@@ -332,6 +346,8 @@ class StageNLP:
         self.d_hi = np.zeros(self.m_d)
         g1, g2 = model["alpha1"] + model["alpha2"], model["alpha1"] * model["alpha2"]
         self.cw = (1.0 - g1 + g2, g1 - 2.0, 1.0)                        # weights of h(x), h(x1), h(x2): dd_h + g1 d_h + g2 h
+        if model.get("alpha") is not None:                              # one-step rows d_h + alpha h (mpc_cbf.py:312-315): h(x1) - (1 - alpha) h(x)
+            self.cw = (float(model["alpha"]) - 1.0, 1.0, 0.0)
         self.n_eval = 0
 
     def initial_guess(self):
@@ -371,6 +387,9 @@ class StageNLP:
         spec, dt, nxt = self.mdl["spec"], self.mdl["dt"], self.mdl["next"]
         nd = self.mdl.get("nu_dyn", self.nu)
         x1 = nxt(x, u[:nd], spec, dt)
+        if self.cw[2] == 0.0:                                               # one-step rows (robot.step = x_next but for the heading wrap, which touches no position)
+            h0, h1 = self._h(x[0], x[1]), self._h(x1[0], x1[1])
+            return x1, [-(self.cw[1] * h1[j] + self.cw[0] * h0[j]) for j in range(self.K)]
         if self.mdl.get("row_next"):                                        # robot.step differs from the model's x_next (the bicycle's speed clip)
             step = self.mdl["row_next"]
             x1r = step(x, u[:nd], spec, dt)

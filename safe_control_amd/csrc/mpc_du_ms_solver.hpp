@@ -72,8 +72,10 @@ constexpr int ST_FILTER_FULL = 7;                 // (internal) the filter ran o
 //         |v_k| <= v_max; the barrier's robot.step clips the speed to [v_min, v_max] (kinematic_bicycle2D.py:112-123,175-199)     mpc_cbf.py:31-33,64-66,202-208
 // M_KB runs the GENERAL stage layout: the inputs enter the positions directly, so a stage keeps the two non-trivial columns of A and all of B
 // (16 values) where the other two keep four entries of A and know B; the recursion, the sweep, J'y and the rows read those.
-enum { M_DU = 0, M_DI = 1, M_KB = 2 };
-constexpr bool general_layout(int model) { return model == M_KB; }
+//   M_UNI Unicycle2D x = (px, py, theta) -- held as four states, the last one idle (x_3+ = x_3 = 0, no cost) --, u = (v, omega): x+ = x + dt (v cos th,
+//         v sin th, omega); no state bound; ONE-step rows h(p1) - (1 - alpha1) h(p0) >= 0 (alpha1 carries the reference's `alpha`)  mpc_cbf.py:22-24,52-53,188-192,312-315
+enum { M_DU = 0, M_DI = 1, M_KB = 2, M_UNI = 3 };
+constexpr bool general_layout(int model) { return model == M_KB || model == M_UNI; }
 struct Params {
     int N, K;
     double dt, Q[4], R[2], alpha1, alpha2, beta, radius, u_lo[2], u_hi[2], v_max;
@@ -262,6 +264,7 @@ template <class Cx, int MODEL = M_DU>
 struct Wave {
     static constexpr bool XB = MODEL == M_DU || MODEL == M_KB;          // the model has the state bound |x_3| <= v_max
     static constexpr bool GEN = general_layout(MODEL);
+    static constexpr int NXT = MODEL == M_UNI ? 3 : NX;                  // states of the reference's model (the count in the error scaling)
     Cx& cx;
     const Params& P;
     const sc_ipopt_params& O;
@@ -309,6 +312,7 @@ struct Wave {
           k(cx_.lane / group_lanes(P_.N) <= P_.N ? cx_.lane / group_lanes(P_.N) : 0) {
         const double g1 = P.alpha1 + P.alpha2, g2 = P.alpha1 * P.alpha2;
         w0 = 1.0 - g1 + g2; w1 = g1 - 2.0; w2 = 1.0;
+        if constexpr (MODEL == M_UNI) { w0 = P.alpha1 - 1.0; w1 = 1.0; w2 = 0.0; }              // d_h + alpha h_k
         nfilt = 0; dw_last = 0.0; last_dw = 0.0; fpo = L.FP; fto = L.FT;
     }
     SC_HD void sync() const { cx.sync(); }
@@ -328,6 +332,22 @@ struct Wave {
     double tc_ = 1.0, ts_ = 0.0, tc1_ = 1.0, ts1_ = 0.0;        // cos / sin of theta_k and of theta_k + dt omega_k at the ITERATE (eval2 sets them, finish_step reuses them)
     SC_HD void geometry(const double* xs, const double* us, Geo& g, bool cached = false) const {
         const double dt = P.dt;
+        if constexpr (MODEL == M_UNI) {
+            const double v = us[0];
+            if (cached) { g.c = tc_; g.s = ts_; } else cx.sincos(xs[2], g.s, g.c);
+            g.c1 = g.s1 = 0.0; g.v1 = v;
+            g.F[0] = xs[0] + dt * v * g.c; g.F[1] = xs[1] + dt * v * g.s; g.F[2] = xs[2] + dt * us[1]; g.F[3] = xs[3];
+            g.p1[0] = g.F[0]; g.p1[1] = g.F[1]; g.p2[0] = g.F[0]; g.p2[1] = g.F[1];              // (w2 = 0: the second point is not read)
+            SC_UNROLL for (int i = 0; i < 16; ++i) g.ab[i] = 0.0;
+            g.ab[0] = -dt * v * g.s; g.ab[1] = dt * v * g.c; g.ab[2] = 1.0;                     // A_2 (theta)
+            g.ab[7] = 1.0;                                                                      // A_3 (the idle state)
+            g.ab[8] = dt * g.c; g.ab[9] = dt * g.s;                                             // B_0 (v)
+            g.ab[14] = dt;                                                                      // B_1 (omega)
+            SC_UNROLL for (int i = 0; i < 4; ++i) { g.j2[0][i] = g.ab[4 * i]; g.j2[1][i] = g.ab[4 * i + 1]; }
+            g.a02 = g.ab[0]; g.a12 = g.ab[1]; g.a03 = 0.0; g.a13 = 0.0;
+            g.g02 = g.g03 = g.g12 = g.g13 = 0.0;
+            return;
+        }
         if constexpr (MODEL == M_KB) {
             const double v = xs[3], be = us[1], iL = P.inv_Lr;
             if (cached) { g.c = tc_; g.s = ts_; } else cx.sincos(xs[2], g.s, g.c);
@@ -689,7 +709,13 @@ struct Wave {
                 const double s1x = sl * g.p1[0] - socx, s1y = sl * g.p1[1] - socy, s2x = sl * g.p2[0] - socx, s2y = sl * g.p2[1] - socy;
                 const double nx_ = wy[0] - 2.0 * w1 * s1x - 2.0 * w2 * s2x, ny_ = wy[1] - 2.0 * w1 * s1y - 2.0 * w2 * s2y;    // on grad^2 p1
                 const double kx = -2.0 * w2 * s2x, ky = -2.0 * w2 * s2y;                                                        // on grad^2 (p2 - p1)
-                if constexpr (MODEL == M_KB) {
+                if constexpr (MODEL == M_UNI) {
+                    // p1 = p + dt v (c, s) over (theta = entry 2, v = entry 4); no second point
+                    (void)kx; (void)ky;
+                    const double v = u[0];
+                    M[sym6(2, 2)] += nx_ * (-dt * v * g.c) + ny_ * (-dt * v * g.s);
+                    M[sym6(2, 4)] += nx_ * (-dt * g.s) + ny_ * (dt * g.c);
+                } else if constexpr (MODEL == M_KB) {
                     // over (theta, v, a, beta) = entries 2 .. 5.  phi = v (c - b s), psi = v (s + b c):  phi_tt = -phi, phi_tv = -(s + b c), phi_tb = -v c,
                     // phi_vb = -s;  psi_tt = -psi, psi_tv = c - b s, psi_tb = -v s, psi_vb = c;  F_2 = theta + dt v b / L_r: (v, b) entry dt / L_r
                     const double v = x[3], be = u[1], iL = P.inv_Lr, c = g.c, s_ = g.s, c1 = g.c1, s1 = g.s1, v1 = g.v1, chi = g.cw[0];
@@ -887,7 +913,7 @@ struct Wave {
         dinf = cx.wmax(d); pinf = cx.wmax(p); comp0 = cx.wmax(c0); un_pinf = cx.wmax(up);
         const double compm = cx.wmax(cm);
         ysum = cx.wsum(ysum); zsum = cx.wsum(zsum);
-        const double m = (double)(NX * (N + 1) + N * K), nb = (double)((XB ? 2 * (N + 1) : 0) + 4 * N + N * K * (rs ? 3 : 1));
+        const double m = (double)(NXT * (N + 1) + N * K), nb = (double)((XB ? 2 * (N + 1) : 0) + 4 * N + N * K * (rs ? 3 : 1));
         const double sd = fmax(O.s_max, (ysum + zsum) / (m + nb)) / O.s_max, sc = fmax(O.s_max, zsum / nb) / O.s_max;
         E0 = fmax(fmax(dinf / sd, pinf), comp0 / sc);
         Emu = fmax(fmax(dinf / sd, pinf), compm / sc);

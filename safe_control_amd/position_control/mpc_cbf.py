@@ -112,10 +112,10 @@ def make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_
 
 
 class MPCCBF:
-    """Drop-in for position_control.mpc_cbf.MPCCBF (single agent per call).  ``robot_spec['mpc_formulation']`` (DynamicUnicycle2D):
+    """Drop-in for position_control.mpc_cbf.MPCCBF (single agent per call).  ``robot_spec['mpc_formulation']`` (DynamicUnicycle2D, Unicycle2D):
     'multiple_shooting' (default since round 6: the NLP as do-mpc poses it under IPOPT's algorithm with its restoration phase,
     csrc/mpc_du_ms.hip, kernel 13 -- what the reference's solver returns also where the NLP has no feasible point) or 'condensed'
-    (single shooting, csrc/mpc_cbf.hip); scenes with superellipsoid rows and Unicycle2D run on the condensed kernel."""
+    (single shooting, csrc/mpc_cbf.hip); scenes with superellipsoid rows run on the condensed kernel."""
 
     def __new__(cls, robot, robot_spec, *args, **kwargs):
         # the reference serves every model from this one class; the linear models run on their own kernel
@@ -158,8 +158,8 @@ class MPCCBF:
         self.iterations = 0
         self.solver_status = "optimal"
         self._ms = None
-        if self.robot_spec["model"] == "DynamicUnicycle2D" and self.robot_spec.get("mpc_formulation", "multiple_shooting") != "condensed" \
-                and self.horizon <= 62 and self.num_obs <= 16:
+        want = self.robot_spec.get("mpc_formulation", "multiple_shooting")
+        if self.robot_spec["model"] in ("DynamicUnicycle2D", "Unicycle2D") and want == "multiple_shooting" and self.horizon <= 62 and self.num_obs <= 16:
             from .mpc_cbf_ms import BatchedMSMPCCBF
             self._ms = BatchedMSMPCCBF(self.robot_spec, dt=self.dt, io_dtype="f64", horizon=self.horizon, cbf_param=self.cbf_param, check_circles=False)
 

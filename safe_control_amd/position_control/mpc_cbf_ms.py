@@ -27,8 +27,8 @@ class BatchedMSMPCCBF:
     def __init__(self, robot_spec=None, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None, ipopt=None, max_iter=None, check_circles=True, order=True):
         self.robot_spec = complete_robot_spec(dict(robot_spec or {"model": "DynamicUnicycle2D"}))
         self.model = self.robot_spec["model"]
-        if self.model not in ("DynamicUnicycle2D", "DoubleIntegrator2D", "KinematicBicycle2D"):
-            raise NotImplementedError("the multiple-shooting MPC-CBF kernel serves DynamicUnicycle2D, DoubleIntegrator2D and KinematicBicycle2D (VTOL2D: BatchedVtolMSMPCCBF)")
+        if self.model not in ("DynamicUnicycle2D", "Unicycle2D", "DoubleIntegrator2D", "KinematicBicycle2D"):
+            raise NotImplementedError("the multiple-shooting MPC-CBF kernel serves DynamicUnicycle2D, Unicycle2D, DoubleIntegrator2D and KinematicBicycle2D (VTOL2D: BatchedVtolMSMPCCBF)")
         self.dt = float(dt)
         self.io_name = io_dtype
         self.io_dtype = {"f32": _lib.DTYPE_F32, "f64": _lib.DTYPE_F64}[io_dtype]

@@ -113,10 +113,10 @@ class BatchedTrackingController:
             else:
                 cls = BatchedMPCCBF if self.pos_controller_type == "mpc_cbf" else BatchedOptimalDecayMPCCBF
             self.mpc = cls(self.robot_spec, dt=self.dt, io_dtype=io_dtype)
-            # DynamicUnicycle2D and DoubleIntegrator2D under 'mpc_cbf': the NLP as do-mpc poses it (multiple shooting, IPOPT's algorithm: csrc/mpc_du_ms.hip, kernel 13)
+            # DynamicUnicycle2D, Unicycle2D and DoubleIntegrator2D under 'mpc_cbf': the NLP as do-mpc poses it (multiple shooting, IPOPT's algorithm: csrc/mpc_du_ms.hip, kernel 13)
             # unless robot_spec['mpc_formulation'] = 'condensed'; a scene with superellipsoid rows runs on the condensed kernel
             self.mpc_ms = None
-            ms_model = (cls is BatchedMPCCBF and self.model == "DynamicUnicycle2D") or (self.model == "DoubleIntegrator2D" and self.pos_controller_type == "mpc_cbf")
+            ms_model = (cls is BatchedMPCCBF and self.model in ("DynamicUnicycle2D", "Unicycle2D")) or (self.model == "DoubleIntegrator2D" and self.pos_controller_type == "mpc_cbf")
             want = self.robot_spec.get("mpc_formulation", "multiple_shooting" if ms_model else "condensed")
             if self.model == "KinematicBicycle2D" and self.pos_controller_type == "mpc_cbf":      # on request only (position_control/mpc_cbf_gn.py: GnMPCCBF)
                 ms_model = True

@@ -117,7 +117,7 @@ def linear_mpc_batch(model="Quad3D", B=4096, K=8, seed=0, radius=0.25):
 
 
 MPC_FAMILIES = {"du": "DynamicUnicycle2D", "kb": "KinematicBicycle2D", "c3bf": "KinematicBicycle2D_C3BF", "dpcbf": "KinematicBicycle2D_DPCBF",
-                "di": "DoubleIntegrator2D", "quad2d": "Quad2D", "si": "SingleIntegrator2D", "quad3d": "Quad3D", "vtol": "VTOL2D"}
+                "di": "DoubleIntegrator2D", "quad2d": "Quad2D", "si": "SingleIntegrator2D", "quad3d": "Quad3D", "vtol": "VTOL2D", "uni": "Unicycle2D"}
 
 
 def mpc_family_batch(family, B=4096, K=8, seed=0):
@@ -145,6 +145,9 @@ def mpc_family_batch(family, B=4096, K=8, seed=0):
         X[:, 2] = np.arctan2(goal[:, 1] - Xd[:, 1], goal[:, 0] - Xd[:, 0]) + rng.uniform(-0.6, 0.6, B); X[:, 3] = rng.uniform(0.5, 3.0, B)
     elif family == "di":
         X = np.zeros((B, 4)); X[:, 0:2] = Xd[:, 0:2]; X[:, 2:4] = rng.uniform(-0.7, 0.7, (B, 2))
+    elif family == "uni":                                   # Unicycle2D: (x, y, theta) padded to four columns; last input (v, w) as the DynamicUnicycle2D draw's (speed, 0)
+        X = np.zeros((B, 4)); X[:, 0:3] = Xd[:, 0:3]
+        up[:, 0] = Xd[:, 3]
     else:
         raise KeyError(family)
     return X, up, goal, obs

@@ -137,7 +137,9 @@ def test_argument_validation_and_superellipsoid_rows():
     p.horizon = 63
     assert lib.sc_mpccbf_ms_solve_batch(C.byref(p), C.byref(ip), 0, 8, *none10) != _lib.SC_OK
     p.horizon = 10
-    p.model_id = _lib.MODEL_IDS["Unicycle2D"]
+    p.model_id = _lib.MODEL_IDS["Quad2D"]                                       # (served: DynamicUnicycle2D, Unicycle2D, DoubleIntegrator2D, KinematicBicycle2D)
+    assert lib.sc_mpccbf_ms_solve_batch(C.byref(p), C.byref(ip), 0, 8, *none10) != _lib.SC_OK
+    p.model_id = _lib.MODEL_IDS["KinematicBicycle2D"]; p.rear_ax_dist = 0.0     # (the bicycle needs its L_r)
     assert lib.sc_mpccbf_ms_solve_batch(C.byref(p), C.byref(ip), 0, 8, *none10) != _lib.SC_OK
     assert int(lib.sc_mpccbf_ms_lds_bytes(10, 8)) > 0 and int(lib.sc_mpccbf_ms_lds_bytes(10, 17)) == 0
     X, up, goal, obs = (a[:4] for a in W.mpc_family_batch("du", 4, 8, seed=0))
@@ -145,7 +147,7 @@ def test_argument_validation_and_superellipsoid_rows():
     with pytest.raises(NotImplementedError):
         sca.BatchedMSMPCCBF(SPEC, io_dtype="f64").solve(t(X), t(up), t(goal), t(obs))
     with pytest.raises(NotImplementedError):
-        sca.BatchedMSMPCCBF({"model": "Unicycle2D"})
+        sca.BatchedMSMPCCBF({"model": "Quad2D"})
 
 
 def test_dropin_class_closed_loop_follows_the_multiple_shooting_oracle():

@@ -164,3 +164,23 @@ def test_solver_header_for_kinematic_bicycle_equals_the_numpy_oracle():
     short = ito < 60
     assert short.mean() >= 0.9 and (it != ito)[short].sum() <= 2 and np.abs(it - ito)[short].max() <= 1
     assert np.abs(u - uo)[short & (it == ito)].max() <= 1e-8
+
+
+def _ms_one_uni(a):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    from oracle import ms_ipopt as MS
+    return MS.solve(MS.uni_model(), a[0], a[1], a[2], a[3], opts=dict(MS.KERNEL_PROFILE))
+
+
+def test_solver_header_for_unicycle2d_equals_the_numpy_oracle():
+    """The Unicycle2D instantiation of csrc/mpc_du_ms_solver.hpp (three states held as four with an idle one, inputs (v, omega) entering the
+    positions, one-step barrier rows) compiled for the host, against oracle/ms_ipopt.py: uni_model() on 192 bench draws."""
+    from multiprocessing import Pool
+    n = 192
+    X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("uni", 4096, 8, seed=0))
+    u, st, it = c_oracle.du_ms_cpu_batch(X, up, goal, obs, n_threads=0, model="Unicycle2D")
+    with Pool(min(8, os.cpu_count() or 2)) as p:
+        res = p.map(_ms_one_uni, [(X[i], up[i], goal[i], obs[i]) for i in range(n)], chunksize=4)
+    so = np.array([r[1] for r in res]); ito = np.array([r[2] for r in res]); uo = np.array([r[0] for r in res])
+    assert np.array_equal(st, so) and (it != ito).sum() <= 2 and np.abs(it - ito).max() <= 1
+    assert np.abs(u - uo)[it == ito].max() <= 1e-9

@@ -297,14 +297,16 @@ def test_unicycle2d_closed_loop_against_oracle(golden_dir):
         assert n_done > 0
 
 
-def test_unicycle2d_closed_loop_with_mpc(golden_dir):
+@pytest.mark.parametrize("formulation", ["multiple_shooting", "condensed"])
+def test_unicycle2d_closed_loop_with_mpc(golden_dir, formulation):
     """test_tracking.py --model un (default --algo mpc_cbf), batched, against the oracle loop with the Unicycle2D MPC
-    oracle behind solve_fn."""
-    from oracle import mpc_cbf as M, mpc_cbf_uni as U
+    oracle behind solve_fn: the multiple-shooting NLP under IPOPT's algorithm (the loop's default: kernel 13, oracle/ms_ipopt.py: uni_model) and
+    the condensed solve (robot_spec['mpc_formulation'] = 'condensed', oracle/mpc_cbf_uni.py)."""
+    from oracle import mpc_cbf as M, mpc_cbf_uni as U, ms_ipopt as MS
     g = np.load(os.path.join(golden_dir, "closed_loop.npz"))
     obs = g["du14/obs"]
     K = 8
-    spec = {"model": "Unicycle2D", "v_max": 1.0, "w_max": 0.5, "radius": 0.25, "num_constraints": K}
+    spec = {"model": "Unicycle2D", "v_max": 1.0, "w_max": 0.5, "radius": 0.25, "num_constraints": K, "mpc_formulation": formulation}
     X0 = np.array([[2.0, 2.0, np.pi / 2], [6.0, 1.0, 2.6], [1.0, 6.0, -1.2]])       # the last one starts in 'stop'
     wl = [np.array([[2.0, 12.0], [12.0, 12.0]]), np.array([[1.0, 4.0]]), np.array([[1.0, 12.0]])]
     T = 30
@@ -312,7 +314,9 @@ def test_unicycle2d_closed_loop_with_mpc(golden_dir):
     ctl.set_waypoints(wl)
     ret, tX, tU = ctl.control_step(T, record=True)
     tX = tX.cpu().numpy(); ret = ret.cpu().numpy()
-    ospec = {k: v for k, v in spec.items() if k not in ("model", "num_constraints")}
+    ospec = {k: v for k, v in spec.items() if k not in ("model", "num_constraints", "mpc_formulation")}
+    assert (ctl.mpc_ms is not None) == (formulation == "multiple_shooting")
+    ms_model = MS.uni_model(dict(v_max=1.0, w_max=0.5, radius=0.25))
     n_track = 0
     for i in range(len(X0)):
         state = {"up": np.zeros(2)}
@@ -321,7 +325,10 @@ def test_unicycle2d_closed_loop_with_mpc(golden_dir):
             if cref["state_machine"] != "track":
                 return np.asarray(cref["u_ref"], dtype=np.float64).reshape(-1), 0
             o = M.pad_obstacles(None if nobs is None else list(nobs), K)
-            u, st, it = U.solve(X, state["up"], cref["goal"], o)
+            if formulation == "multiple_shooting":
+                u, st, it = MS.solve(ms_model, X, state["up"], cref["goal"], o, opts=dict(MS.KERNEL_PROFILE))
+            else:
+                u, st, it = U.solve(X, state["up"], cref["goal"], o)
             state["up"] = u
             state["n"] = state.get("n", 0) + 1
             return u, 0
@@ -445,14 +452,16 @@ def test_single_integrator_closed_loop_with_mpc(golden_dir):
     assert n_track >= T
 
 
-def test_double_integrator_closed_loop_with_mpc(golden_dir):
-    """--model di with the default --algo mpc_cbf, batched: select -> Gauss-Newton MPC launch (csrc/mpc_gn.hip) -> apply,
-    against the oracle loop with oracle/mpc_gn.py behind solve_fn."""
-    from oracle import mpc_cbf as M, mpc_gn as G
+@pytest.mark.parametrize("formulation", ["multiple_shooting", "condensed"])
+def test_double_integrator_closed_loop_with_mpc(golden_dir, formulation):
+    """--model di with the default --algo mpc_cbf, batched: select -> MPC launch -> apply, against the oracle loop with the matching oracle
+    behind solve_fn: the multiple-shooting NLP under IPOPT's algorithm (the loop's default: kernel 13, oracle/ms_ipopt.py: di_model) and the
+    condensed Gauss-Newton solve (robot_spec['mpc_formulation'] = 'condensed': csrc/mpc_gn.hip, oracle/mpc_gn.py)."""
+    from oracle import mpc_cbf as M, mpc_gn as G, ms_ipopt as MS
     g = np.load(os.path.join(golden_dir, "closed_loop_integrators.npz"))
     obs = g["di/obs"]
     K = 6
-    spec = {"model": "DoubleIntegrator2D", "v_max": 1.0, "a_max": 1.0, "radius": 0.25, "num_constraints": K}
+    spec = {"model": "DoubleIntegrator2D", "v_max": 1.0, "a_max": 1.0, "radius": 0.25, "num_constraints": K, "mpc_formulation": formulation}
     X0 = np.array([[2.0, 2.0, 0.0, 0.3, np.pi / 2], [6.0, 1.0, -0.2, 0.1, 2.6], [1.0, 6.0, 0.3, -0.3, -1.2]])   # the last starts in 'stop'
     wl = [np.array([[2.0, 12.0], [12.0, 12.0]]), np.array([[1.0, 4.0]]), np.array([[1.0, 12.0]])]
     T = 40
@@ -462,6 +471,8 @@ def test_double_integrator_closed_loop_with_mpc(golden_dir):
     ret, tX, tU = ctl.control_step(T, record=True)
     tX = tX.cpu().numpy(); ret = ret.cpu().numpy()
     mdl = G.di_model({"v_max": 1.0, "a_max": 1.0, "radius": 0.25})
+    ms_model = MS.di_model({"v_max": 1.0, "a_max": 1.0, "radius": 0.25})
+    assert (ctl.mpc_ms is not None) == (formulation == "multiple_shooting")
     n_track = 0
     for i in range(len(X0)):
         state = {"up": np.zeros(2)}
@@ -470,7 +481,10 @@ def test_double_integrator_closed_loop_with_mpc(golden_dir):
             if cref["state_machine"] != "track":
                 return np.asarray(cref["u_ref"], dtype=np.float64).reshape(-1), 0
             o = M.pad_obstacles(None if nobs is None else list(nobs), K)
-            u, st, it = G.solve(mdl, X[:4], state["up"], cref["goal"], o)
+            if formulation == "multiple_shooting":
+                u, st, it = MS.solve(ms_model, X[:4], state["up"], cref["goal"], o, opts=dict(MS.KERNEL_PROFILE))
+            else:
+                u, st, it = G.solve(mdl, X[:4], state["up"], cref["goal"], o)
             state["up"] = u
             state["n"] = state.get("n", 0) + 1
             return u, 0
