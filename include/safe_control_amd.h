@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 /* ABI version: the minor number goes up with EVERY change of a struct layout or an entry point's signature (round 4 grew
- * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2; round 5 added sc_ipopt_params and sc_mpcvtol_ms_solve_batch: 0.3; the continuation entry points of the optimal-decay families: 0.4; sc_odmpcvtol_ms_solve_batch: 0.5; round 6 added sc_mpccbf_ms_solve_batch: 0.7; sc_mpccbf_ms_workspace_bytes and sc_ipopt_params.floor_iter in the slot that was `reserved`: 0.8).  A binding compares sc_version() with the
+ * sc_resto_params and put slack_reset into sc_mpccbf_params / sc_mpclin_params: 0.2; round 5 added sc_ipopt_params and sc_mpcvtol_ms_solve_batch: 0.3; the continuation entry points of the optimal-decay families: 0.4; sc_odmpcvtol_ms_solve_batch: 0.5; round 6 added sc_mpccbf_ms_solve_batch: 0.7; sc_mpccbf_ms_workspace_bytes and sc_ipopt_params.floor_iter in the slot that was `reserved`: 0.8; sc_mpccbf_params.v_min / rear_ax_dist for the KinematicBicycle2D instantiation of sc_mpccbf_ms_solve_batch: 0.9).  A binding compares sc_version() with the
  * version its struct mirrors were written for before the first call (safe_control_amd/_lib.py: ABI_VERSION). */
 #define SC_VERSION_MAJOR 0
 #define SC_VERSION_MINOR 9
@@ -509,17 +509,26 @@ int sc_odmpcvtol_solve_batch_sliced(const sc_odmpcvtol_params* params, const sc_
                                     const void* X, const void* u_prev, const void* goal, const void* obs,
                                     void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
 
-/* MPC-CBF for DynamicUnicycle2D AS DO-MPC POSES IT (csrc/mpc_du_ms.hip, DESIGN.md kernel 13; round 6): BASELINE configs[2] in the reference's
- * own formulation.  Replaces MPCCBF.solve_control_problem (position_control/mpc_cbf.py:366-402: mpc.x0 = x; set_initial_guess(); update_tvp;
+/* MPC-CBF for DynamicUnicycle2D, Unicycle2D, DoubleIntegrator2D and KinematicBicycle2D AS DO-MPC POSES IT (csrc/mpc_du_ms.hip, DESIGN.md
+ * kernel 13; round 6): BASELINE configs[2] in the reference's own formulation.  Replaces MPCCBF.solve_control_problem (position_control/mpc_cbf.py:366-402: mpc.x0 = x; set_initial_guess(); update_tvp;
  * make_step -> do-mpc multiple shooting -> IPOPT, :162-174) for a batch: states x_0 .. x_N as variables, dynamics as equality rows, every
  * stage started at x0, IPOPT's filter line-search interior point at its documented defaults (sc_ipopt_params; oracle/ms_ipopt.py with
  * du_model() is the float64 statement, iterate for iterate), restoration phase inside the kernel (its state lives in LDS;
  * sc_ipopt_params.resto_workspace is the optional launch-order workspace here: sc_mpccbf_ms_workspace_bytes).  sc_mpccbf_solve_batch solves the condensed single-shooting form of the same NLP with an
  * l1-merit interior point: same optimum where there is one (4086 of 4096 config-3 draws), a different last iterate where the NLP has no
  * feasible point -- and the reference APPLIES that iterate (mpc_cbf.py:384, status hard-wired 'optimal', :10).
- *   params      the problem fields of sc_mpccbf_params (model_id = SC_MODEL_DYNAMIC_UNICYCLE2D only, horizon 1 .. 62, dt, Q, R, alpha1/2,
- *               v_max, u_max, robot_radius, beta, io_dtype, obs_shared); its solver fields (tol .. resto, slack_reset, max_iter) are NOT
- *               read; obstacles must be circles (flag column < 0.5: a superellipsoid row returns SC_ERR_UNSUPPORTED from the host-side
+ *   params      the problem fields of sc_mpccbf_params (horizon 1 .. 62, dt, Q, R, alpha1/2, v_max, u_max, robot_radius, beta, io_dtype,
+ *               obs_shared); its solver fields (tol .. resto, slack_reset, max_iter) are NOT read.  model_id:
+ *                 SC_MODEL_DYNAMIC_UNICYCLE2D   x = (px, py, theta, v), u = (a, omega), |v_k| <= v_max, two-step rows (alpha1, alpha2)
+ *                 SC_MODEL_UNICYCLE2D           X rows [px, py, theta, unused], u = (v, omega), u_max = (v_max, w_max), ONE-step rows
+ *                                               h(p_k+1) - (1 - alpha1) h(p_k) >= 0 (mpc_cbf.py:312-315), Q[3] / alpha2 / v_max unused
+ *                 SC_MODEL_DOUBLE_INTEGRATOR2D  x = (px, py, vx, vy), u = (ax, ay), no state bound; v_max = the norm robot.step rescales the
+ *                                               velocity to inside the barrier (double_integrator2D.py:79-107,225-226)
+ *                 SC_MODEL_KINEMATIC_BICYCLE2D  x = (px, py, theta, v), u = (a, beta), |v_k| <= v_max; robot.step clips the speed to
+ *                                               [v_min, v_max] inside the barrier (kinematic_bicycle2D.py:112-123,175-199); rear_ax_dist.
+ *                                               Where a plan slows down to v_min the clip's kink sits on the solution and the iteration
+ *                                               cycles to max_iter (kernel 13): bound it
+ *               ; obstacles must be circles (flag column < 0.5: a superellipsoid row returns SC_ERR_UNSUPPORTED from the host-side
  *               classes, the kernel treats every row as a circle), 1 <= K <= 16
  *   status_out  SC_STATUS_OPTIMAL (tol or IPOPT's acceptable rule), SC_STATUS_INFEASIBLE (the restoration phase converged to a stationary
  *               point of the violation: IPOPT's "converged to a point of local infeasibility"), SC_STATUS_INACCURATE (iteration limit,

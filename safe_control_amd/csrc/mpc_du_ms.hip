@@ -1,5 +1,5 @@
-// Kernel 13: MPC-CBF for DynamicUnicycle2D as do-mpc poses it -- multiple shooting under IPOPT's filter interior point, one NLP
-// per wavefront, one stage per lane.  The algorithm and what each lane holds: mpc_du_ms_solver.hpp (plain C++ over a context; the same code
+// Kernel 13: MPC-CBF as do-mpc poses it -- multiple shooting under IPOPT's filter interior point, one NLP per wavefront, four
+// lanes per stage -- for DynamicUnicycle2D, Unicycle2D, DoubleIntegrator2D and KinematicBicycle2D (template parameter MODEL: dums::M_*).  The algorithm and what each lane holds: mpc_du_ms_solver.hpp (plain C++ over a context; the same code
 // runs on the host, one thread per lane, in tools/du_ms_host.cpp).  This unit supplies the device context -- LDS through an address-space
 // pointer, __syncthreads, the DPP wave reductions of mpc_ipm_common.hpp -- the kernel and its launcher.
 //

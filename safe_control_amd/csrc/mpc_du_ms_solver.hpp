@@ -1,5 +1,6 @@
-// MPC-CBF for DynamicUnicycle2D AS DO-MPC POSES IT -- multiple shooting under IPOPT's filter line-search interior point: ONE NLP PER
-// WAVEFRONT, ONE STAGE PER LANE.  Kernel 13 in DESIGN.md; the algorithm is oracle/ms_ipopt.py (StageNLP with du_model()) in KERNEL_PROFILE
+// MPC-CBF AS DO-MPC POSES IT -- multiple shooting under IPOPT's filter line-search interior point: ONE NLP PER WAVEFRONT, FOUR LANES PER
+// STAGE.  Written out below for DynamicUnicycle2D; the other robots it is instantiated for (Unicycle2D, DoubleIntegrator2D,
+// KinematicBicycle2D) are described at `enum { M_DU, .. }`.  Kernel 13 in DESIGN.md; the algorithm is oracle/ms_ipopt.py (StageNLP with du_model()) in KERNEL_PROFILE
 // (linear_solver = riccati, max_soc = 0, resto_elastic = "ineq", the stall rule), iterate for iterate.  The reference
 // (position_control/mpc_cbf.py:162-174,366-369) hands IPOPT
 //     variables    x_0 .. x_N (4 each), u_0 .. u_{N-1} (2 each)
