@@ -629,6 +629,45 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
             "mean_ipm_iterations": float(it.double().mean().item())}, f"mpcgn_kernel<{mid}, {N if N == 10 else 0}, false>")
 
 
+def unicycle_mpc_leg(dev, B=4096, K=8, N=10, steps=3, seed=0):
+    """MPC-CBF for Unicycle2D (three states, inputs (v, omega), one-step rows): kernel 13's instantiation for this robot (the drop-in's default
+    since the end of round 6) with the condensed kernel 3 on the same batch beside it."""
+    import numpy as np
+    import torch
+    import safe_control_amd as sca
+    from safe_control_amd import workloads as W
+    Xn, up0, gn, on = W.mpc_family_batch("uni", B, K, seed=seed)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)     # noqa: E731
+    X, g, ob, up = t(Xn), t(gn), t(on), t(up0)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+
+    def timed(ctl):
+        out = ctl.solve(X, up, g, ob)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            out = ctl.solve(X, up, g, ob)
+        e1.record()
+        torch.cuda.synchronize()
+        return out, e0.elapsed_time(e1) / steps
+
+    (u, st, it), ms = timed(sca.BatchedMSMPCCBF({"model": "Unicycle2D"}, io_dtype="f32", horizon=N, check_circles=False))
+    (uc, sc_, ic), msc = timed(sca.BatchedMPCCBF({"model": "Unicycle2D"}, io_dtype="f32", horizon=N))
+    both = (st == 0) & (sc_ == 0)
+    res = {"workload": f"{B}-agent batch Unicycle2D MPC-CBF, horizon N={N}, {K} obstacles", "kernel": "mpcdu_ms_kernel<float, 3> (kernel 13)",
+           "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
+           "optimal_fraction": float((st == 0).double().mean().item()), "infeasible_fraction": float((st == 1).double().mean().item()),
+           "inaccurate_fraction": float((st == 2).double().mean().item()),
+           "mean_ipm_iterations": float(it.double().mean().item()), "max_ipm_iterations": int(it.max().item()),
+           "condensed": {"kernel": "mpccbf_uni_kernel (kernel 3)", "value": B / (msc * 1e-3), "kernel_ms": msc, "optimal_fraction": float((sc_ == 0).double().mean().item()),
+                         "inaccurate_fraction": float((sc_ == 2).double().mean().item()), "max_ipm_iterations": int(ic.max().item()),
+                         "same_u0_where_both_optimal_fraction": float(((u - uc).abs().amax(dim=1) <= 1e-4)[both].double().mean().item()) if bool(both.any()) else None}}
+    rl = valu_roofline("dumsuni_sq", "mpcdu_ms_kernel<float, 3>", ms) if (B, K, N, seed) == (4096, 8, 10, 0) else None
+    if rl:
+        res["roofline"] = rl
+    return res
+
+
 def bicycle_loop_states(dev, model, B=4096, T=160, every=10, seed=0):
     """MPC-CBF of the collision-cone bicycles on states OF THEIR CLOSED LOOP (round 3 timed batches drawn uniformly, half of them inside
     collision cones: half the "solves" were restorations).  The fleet flies dynamic_env/main.py's scene (:241-268: start (1, 7.5),
@@ -1043,6 +1082,8 @@ def compact_leg(v):
         keep["limit_100_ms"] = sig(v["one_launch_limit_100"]["kernel_ms"])
     if isinstance(v.get("multiple_shooting"), dict):                     # the same batch on kernel 13 (the reference's own formulation)
         keep["ms"] = compact_leg(v["multiple_shooting"])
+    if isinstance(v.get("condensed"), dict) and "kernel_ms" in v["condensed"]:      # ... or, where kernel 13 is the leg, the condensed kernel beside it
+        keep["condensed_ms"] = sig(v["condensed"]["kernel_ms"])
     rl = v.get("roofline")
     if isinstance(rl, dict):
         keep["roofline"] = {k: sig(rl[k]) for k in ("bound", "frac", "stale") if k in rl}
@@ -1290,6 +1331,7 @@ def main():
             res["quad3d_mpc_cbf"] = linear_mpc_leg(dev, "Quad3D")
             res["single_integrator_mpc_cbf"] = linear_mpc_leg(dev, "SingleIntegrator2D")
             res["quad3d_mpc_cbf_n20"] = linear_mpc_leg(dev, "Quad3D", N=20, steps=2)   # BASELINE config 5's horizon: big layout, four waves per problem
+            res["unicycle2d_mpc_cbf"] = unicycle_mpc_leg(dev)
             res["double_integrator_mpc_cbf"] = gn_mpc_leg(dev, "DoubleIntegrator2D")
             res["quad2d_mpc_cbf"] = gn_mpc_leg(dev, "Quad2D")
             res["kinematic_bicycle_mpc_cbf"] = gn_mpc_leg(dev, "KinematicBicycle2D")
