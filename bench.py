@@ -1075,7 +1075,8 @@ def compact_leg(v):
     keep = {}
     for k in ("value", "kernel_ms", "ms_per_step", "ms_per_control_step", "us_per_step", "agent_steps_per_s", "solves_per_s", "optimal_fraction",
               "max_ipm_iterations", "agents", "GBs", "frac_of_peak", "error", "optimal_only_value",
-              "inaccurate_fraction", "landed", "return_code", "control_steps", "restoration_fallback", "landed_fraction", "lost_fraction", "aircraft"):
+              "inaccurate_fraction", "landed", "return_code", "control_steps", "restoration_fallback", "landed_fraction", "lost_fraction", "aircraft",
+              "all_gather_bytes_per_step", "scaling"):
         if k in v and not (k == "inaccurate_fraction" and v[k] == 0.0) and v[k] is not None:      # (no inaccurate solves: not worth 28 bytes of the line)
             keep[k] = sig(v[k])
     if isinstance(v.get("one_launch_limit_100"), dict) and v.get("beyond_100_iterations"):      # (only where the budget beyond 100 iterations is used)
