@@ -95,8 +95,7 @@ def cpu_baseline(X, u_ref, obs, seconds):
     best = "all_cores" if out["all_cores"][0] >= out["one_core"][0] else "one_core"
     v, nt, n = out[best]
     return {"value": v, "unit": "solves/s", "cores": nt, "kind": "port",
-            "sample": f"{n} passes over the same {X.shape[0]}-agent x {obs.shape[1]}-obstacle batch, "
-                      f"oracle/c/cbfqp_oracle.c (float64, exact active-set enumeration), OpenMP {nt} threads",
+            "sample": f"{n} passes over the same {X.shape[0]} x {obs.shape[1]} batch, oracle/c/cbfqp_oracle.c (f64, exact active-set enumeration), OpenMP {nt} threads",
             "one_core_value": out["one_core"][0], "all_cores_value": out["all_cores"][0],
             "python_per_agent_loop_value": py_rate, "python_per_agent_loop_sample": f"first {n_py} agents, oracle/cbf_qp.py (numpy float64), 1 thread",
             "all_cores_threads": out["all_cores"][1]}
@@ -266,7 +265,7 @@ def mpc_cpu_baseline(Xn, goal, on, N, seconds):
     best = "all_cores" if out["all_cores"][0] >= out["one_core"][0] else "one_core"
     v, nt, n = out[best]
     return {"value": v, "unit": "solves/s", "cores": nt, "kind": "port",
-            "sample": f"first {n} problems, oracle/c/mpc_du_ms_cpu.cpp (oracle/ms_ipopt.py's algorithm compiled), OpenMP {nt} threads",
+            "sample": f"first {n} problems, oracle/c/mpc_du_ms_cpu.cpp (oracle/ms_ipopt.py compiled), OpenMP {nt} threads",
             "one_core_value": out["one_core"][0], "all_cores_value": out["all_cores"][0],
             "python_oracle_value": py_rate, "python_oracle_sample": f"first {n_py} problems, oracle/ms_ipopt.py (numpy float64), 1 thread"}
 
@@ -1071,14 +1070,18 @@ def compact_leg(v):
         return [compact_leg(x) for x in v]
     if not isinstance(v, dict):
         return v
-    sig = lambda x: float(f"{x:.4g}") if isinstance(x, float) else x     # noqa: E731
+    def sig(x):                                                          # four significant digits; rates as integers (two bytes each on a 7 KB line)
+        if not isinstance(x, float):
+            return x
+        y = float(f"{x:.4g}")
+        return int(y) if abs(y) >= 1e4 and y == int(y) else y
     keep = {}
     for k in ("value", "kernel_ms", "ms_per_step", "ms_per_control_step", "us_per_step", "agent_steps_per_s", "solves_per_s", "optimal_fraction",
               "max_ipm_iterations", "agents", "GBs", "frac_of_peak", "error", "optimal_only_value",
               "inaccurate_fraction", "landed", "return_code", "control_steps", "restoration_fallback", "landed_fraction", "lost_fraction", "aircraft",
               "all_gather_bytes_per_step", "scaling"):
-        if k in v and not (k == "inaccurate_fraction" and v[k] == 0.0) and v[k] is not None:      # (no inaccurate solves: not worth 28 bytes of the line)
-            keep[k] = sig(v[k])
+        if k in v and not (k in ("inaccurate_fraction", "restoration_fallback") and v[k] == 0.0) and v[k] is not None:      # (no inaccurate solves: not worth 28 bytes of the line)
+            keep[{"max_ipm_iterations": "max_iter", "inaccurate_fraction": "inaccurate"}.get(k, k)] = sig(v[k])      # (the line is 7 KB for ~35 legs: two key names shortened)
     if isinstance(v.get("one_launch_limit_100"), dict) and v.get("beyond_100_iterations"):      # (only where the budget beyond 100 iterations is used)
         keep["limit_100_ms"] = sig(v["one_launch_limit_100"]["kernel_ms"])
     if isinstance(v.get("multiple_shooting"), dict):                     # the same batch on kernel 13 (the reference's own formulation)
@@ -1087,7 +1090,7 @@ def compact_leg(v):
         keep["condensed_ms"] = sig(v["condensed"]["kernel_ms"])
     rl = v.get("roofline")
     if isinstance(rl, dict):
-        keep["roofline"] = {k: sig(rl[k]) for k in ("bound", "frac", "stale") if k in rl}
+        keep["roofline"] = {k: ("valu" if rl[k] == "valu_issue" else sig(rl[k])) for k in ("bound", "frac", "stale") if k in rl}
         if isinstance(rl.get("work_level"), dict):
             keep["roofline"]["work_frac"] = sig(rl["work_level"]["frac"])
     return keep
@@ -1119,6 +1122,7 @@ def emit(d, ws):
         line[k] = compact_leg(v)
     if isinstance(mpc, dict):
         m = compact_leg(mpc)
+        m.pop("condensed_ms", None)                                      # (the condensed kernel's numbers follow in full)
         m["workload"] = "BASELINE configs[2]: 4096 x DynamicUnicycle2D MPC-CBF N=10 K=8" if "configs[2]" in str(mpc.get("workload")) else mpc.get("workload")
         if isinstance(mpc.get("roofline"), dict):
             m["roofline"] = {k: (float(f"{v_:.5g}") if isinstance(v_, float) else v_) for k, v_ in
@@ -1127,7 +1131,7 @@ def emit(d, ws):
                 m["roofline"]["work_frac"] = mpc["roofline"]["work_level"]["frac"]
         if isinstance(mpc.get("condensed"), dict):                     # the formulation of rounds 1 - 5 on the same batch (kernel 3), and how the two answers compare
             c = mpc["condensed"]
-            m["kernel"] = mpc.get("kernel"); m["infeasible_fraction"] = mpc.get("infeasible_fraction")
+            m["infeasible_fraction"] = mpc.get("infeasible_fraction")
             r4 = lambda x: float(f"{x:.4g}") if isinstance(x, float) else x     # noqa: E731
             m["condensed"] = {**compact_leg(c), "same_status": r4(c.get("same_status_fraction")), "same_u0_both_optimal": r4(c.get("same_u0_where_both_optimal_fraction")),
                               "u0_diff_gt_1e-3_neither_optimal": r4(c.get("u0_differs_by_more_than_1e-3_where_neither_is_optimal_fraction"))}

@@ -45,7 +45,7 @@ def test_single_gpu_line_has_contract_fields():
     # (the legs run the reference solver's budget of 3000 iterations as continuation launches; the one-launch time at the round-3
     # limit of 100 rides along)
     assert d["vtol_mpc_cbf"]["optimal_fraction"] > 0.9 and d["vtol_mpc_cbf"]["value"] > 3e3 and d["vtol_mpc_cbf"]["limit_100_ms"] < 150
-    assert d["od_vtol_ms_mpc_cbf"]["kernel_ms"] > 0 and d["kinematic_bicycle_c3bf_mpc_cbf"].get("inaccurate_fraction", 0.0) <= 0.03
+    assert d["od_vtol_ms_mpc_cbf"]["kernel_ms"] > 0 and d["kinematic_bicycle_c3bf_mpc_cbf"].get("inaccurate", 0.0) <= 0.03
 
 
 def test_two_rank_flow_on_one_gpu():
