@@ -553,7 +553,25 @@ def linear_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
     ms = e0.elapsed_time(e1) / steps
     nxu = "12, 4" if model == "Quad3D" else "2, 2"
     kname = f"mpclin_kernel<{nxu}, {N}, {K}, false, false>" if N == 10 else f"mpclin_kernel<{nxu}, 0, 0, true, false>"
-    return with_roofline({**budget_note(mk, (X, up, g, ob), steps, ms, st, it),
+    extra = {}
+    if model == "SingleIntegrator2D" and N <= 62 and K <= 16:          # the same batch on kernel 13 (the reference's formulation; on request for this robot)
+        msc = sca.BatchedMSMPCCBF({"model": model}, io_dtype="f32", horizon=N, check_circles=False)
+        um, sm, im = msc.solve(X, up, g, ob)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            um, sm, im = msc.solve(X, up, g, ob)
+        e1.record()
+        torch.cuda.synchronize()
+        mms = e0.elapsed_time(e1) / steps
+        both = (sm == 0) & (st == 0)
+        extra["multiple_shooting"] = {"kernel": "mpcdu_ms_kernel<float, 4> (kernel 13; on request: mpc_formulation = 'multiple_shooting')", "value": B / (mms * 1e-3), "kernel_ms": mms,
+                                      "optimal_fraction": float((sm == 0).double().mean().item()), "max_ipm_iterations": int(im.max().item()),
+                                      "same_u0_where_both_optimal_fraction": float(((um - u).abs().amax(dim=1) <= 1e-4)[both].double().mean().item()) if bool(both.any()) else None}
+        rl = valu_roofline("dumssi_sq", "mpcdu_ms_kernel<float, 4>", mms) if (B, K, N, seed) == (4096, 8, 10, 0) else None
+        if rl:
+            extra["multiple_shooting"]["roofline"] = rl
+    return with_roofline({**extra, **budget_note(mk, (X, up, g, ob), steps, ms, st, it),
             "workload": f"{B}-agent batch {model} MPC-CBF, horizon N={N}, {K} obstacles ({N * up.shape[1]} variables)",
             "value": B / (ms * 1e-3), "unit": "solves/s", "kernel_ms": ms, "dtype": "f64", "storage": "f32",
             "optimal_fraction": float((st == 0).double().mean().item()),

@@ -509,7 +509,7 @@ int sc_odmpcvtol_solve_batch_sliced(const sc_odmpcvtol_params* params, const sc_
                                     const void* X, const void* u_prev, const void* goal, const void* obs,
                                     void* u_out, void* rho_out, int32_t* status_out, int32_t* iters_out, void* z_out, void* stream);
 
-/* MPC-CBF for DynamicUnicycle2D, Unicycle2D, DoubleIntegrator2D and KinematicBicycle2D AS DO-MPC POSES IT (csrc/mpc_du_ms.hip, DESIGN.md
+/* MPC-CBF for DynamicUnicycle2D, Unicycle2D, SingleIntegrator2D, DoubleIntegrator2D and KinematicBicycle2D AS DO-MPC POSES IT (csrc/mpc_du_ms.hip, DESIGN.md
  * kernel 13; round 6): BASELINE configs[2] in the reference's own formulation.  Replaces MPCCBF.solve_control_problem (position_control/mpc_cbf.py:366-402: mpc.x0 = x; set_initial_guess(); update_tvp;
  * make_step -> do-mpc multiple shooting -> IPOPT, :162-174) for a batch: states x_0 .. x_N as variables, dynamics as equality rows, every
  * stage started at x0, IPOPT's filter line-search interior point at its documented defaults (sc_ipopt_params; oracle/ms_ipopt.py with
@@ -522,6 +522,7 @@ int sc_odmpcvtol_solve_batch_sliced(const sc_odmpcvtol_params* params, const sc_
  *                 SC_MODEL_DYNAMIC_UNICYCLE2D   x = (px, py, theta, v), u = (a, omega), |v_k| <= v_max, two-step rows (alpha1, alpha2)
  *                 SC_MODEL_UNICYCLE2D           X rows [px, py, theta, unused], u = (v, omega), u_max = (v_max, w_max), ONE-step rows
  *                                               h(p_k+1) - (1 - alpha1) h(p_k) >= 0 (mpc_cbf.py:312-315), Q[3] / alpha2 / v_max unused
+ *                 SC_MODEL_SINGLE_INTEGRATOR2D  X rows [px, py, unused, unused] (four columns), u = (vx, vy), u_max = (v_max, v_max), one-step rows
  *                 SC_MODEL_DOUBLE_INTEGRATOR2D  x = (px, py, vx, vy), u = (ax, ay), no state bound; v_max = the norm robot.step rescales the
  *                                               velocity to inside the barrier (double_integrator2D.py:79-107,225-226)
  *                 SC_MODEL_KINEMATIC_BICYCLE2D  x = (px, py, theta, v), u = (a, beta), |v_k| <= v_max; robot.step clips the speed to

@@ -137,7 +137,7 @@ void lane_body_m(Wavefront* w, int lane) {
     Wave<FiberCtx, MODEL> S(cx, *q.P, *q.O);
     constexpr int U0 = MODEL == M_DI ? 1 : 0;            // (M_DI holds its inputs swapped: mpc_du_ms_solver.hpp)
     if (lane < 3 * q.P->K) { const int j = lane / 3, c = lane % 3; w->lds[S.L.OB + lane] = q.obs[7 * j + c]; }
-    for (int i = 0; i < NX; ++i) S.x0[i] = (MODEL == M_UNI && i == 3) ? 0.0 : q.x0[i];
+    for (int i = 0; i < NX; ++i) S.x0[i] = ((MODEL == M_UNI && i == 3) || (MODEL == M_SI && i >= 2)) ? 0.0 : q.x0[i];
     for (int j = 0; j < NU; ++j) S.uprev[j] = q.up[j ^ U0];
     S.xg[0] = q.goal[0]; S.xg[1] = q.goal[1];
     cx.sync();
@@ -149,6 +149,7 @@ void lane_body(Wavefront* w, int lane) {
     if (w->prob.model == sc::dums::M_DI) lane_body_m<sc::dums::M_DI>(w, lane);
     else if (w->prob.model == sc::dums::M_KB) lane_body_m<sc::dums::M_KB>(w, lane);
     else if (w->prob.model == sc::dums::M_UNI) lane_body_m<sc::dums::M_UNI>(w, lane);
+    else if (w->prob.model == sc::dums::M_SI) lane_body_m<sc::dums::M_SI>(w, lane);
     else lane_body_m<sc::dums::M_DU>(w, lane);
 }
 
@@ -192,8 +193,9 @@ extern "C" int du_ms_cpu_solve_batch(const sc_mpccbf_params* prm, const sc_ipopt
     for (int i = 0; i < 4; ++i) P.Q[i] = prm->Q[i];
     for (int j = 0; j < 2; ++j) { P.R[j] = prm->R[j]; P.u_lo[j] = -prm->u_max[j]; P.u_hi[j] = prm->u_max[j]; }
     P.alpha1 = prm->alpha1; P.alpha2 = prm->alpha2; P.beta = prm->beta; P.radius = prm->robot_radius; P.v_max = prm->v_max;
-    const int model = prm->model_id == SC_MODEL_DOUBLE_INTEGRATOR2D ? M_DI : (prm->model_id == SC_MODEL_KINEMATIC_BICYCLE2D ? M_KB : (prm->model_id == SC_MODEL_UNICYCLE2D ? M_UNI : M_DU));
+    const int model = prm->model_id == SC_MODEL_DOUBLE_INTEGRATOR2D ? M_DI : (prm->model_id == SC_MODEL_KINEMATIC_BICYCLE2D ? M_KB : (prm->model_id == SC_MODEL_UNICYCLE2D ? M_UNI : (prm->model_id == SC_MODEL_SINGLE_INTEGRATOR2D ? M_SI : M_DU)));
     if (model == M_UNI) P.Q[3] = 0.0;
+    if (prm->model_id == SC_MODEL_SINGLE_INTEGRATOR2D) { P.Q[2] = 0.0; P.Q[3] = 0.0; }
     if (model == M_KB) { P.v_min = prm->v_min; P.inv_Lr = 1.0 / prm->rear_ax_dist; }
     if (model == M_DI) for (int j = 0; j < 2; ++j) { P.R[j] = prm->R[1 - j]; P.u_lo[j] = -prm->u_max[1 - j]; P.u_hi[j] = prm->u_max[1 - j]; }
     const size_t nl = (size_t)Lds(P.N, P.K, general_layout(model)).total;

@@ -82,6 +82,9 @@ def du_ms_cpu_batch(X, u_prev, goal, obs, spec=None, horizon=10, dt=0.05, n_thre
     base = {"model": "DynamicUnicycle2D", "a_max": 1.0, "w_max": 0.5, "v_max": 1.0, "radius": 0.25} if model == "DynamicUnicycle2D" else {"model": model}
     sp = complete_robot_spec(dict(base, **(spec or {})))
     Q, R = PM.default_mpc_weights(model)
+    X = np.asarray(X, dtype=np.float64)
+    if X.shape[1] < 4:                                       # (SingleIntegrator2D / Unicycle2D rows: the solver reads four columns)
+        X = np.hstack([X, np.zeros((X.shape[0], 4 - X.shape[1]))])
     X, u_prev, goal, obs = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, u_prev, goal, obs))
     p = PM.make_params(sp, PM.default_mpc_cbf_param(model), Q, R, horizon, dt, sp["radius"], L.DTYPE_F64, obs_shared=obs.ndim == 2)
     ip = L.default_ipopt(**(ipopt or {}))

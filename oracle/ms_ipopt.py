@@ -172,6 +172,11 @@ def _clip(a, lo, hi):
     return np.clip(a, lo, hi)
 
 
+def si_next(x, u, spec, dt):
+    """SingleIntegrator2D: x = (px, py), f = 0, g = I   (single_integrator2D.py:45-66; U = [vx, vy])."""
+    return [x[0] + u[0] * dt, x[1] + u[1] * dt]
+
+
 def uni_next(x, u, spec, dt):
     """Unicycle2D: x = (px, py, theta), f = 0, g u = [v cos th, v sin th, w]   (unicycle2D.py:42-68; U = [v, w])."""
     return [x[0] + u[0] * _cos(x[2]) * dt, x[1] + u[0] * _sin(x[2]) * dt, x[2] + u[1] * dt]
@@ -259,6 +264,16 @@ def du_model(spec=None, dt=0.05):
                 R=np.array([0.5, 0.5]), alpha1=0.15, alpha2=0.15, beta=1.01, radius=s["radius"],
                 u_lo=np.array([-s["a_max"], -s["w_max"]]), u_hi=np.array([s["a_max"], s["w_max"]]),
                 x_lo=np.array([-INF, -INF, -INF, -s["v_max"]]), x_hi=np.array([INF, INF, INF, s["v_max"]]))
+
+
+def si_model(spec=None, dt=0.05):
+    """mpc_cbf.py:19-21 (Q, R), :49-51 (alpha = 0.05), :183-187 (input box), :312-315 (one-step rows), single_integrator2D.py:148 (beta = 1.01; the
+    barrier has a superellipsoid branch: StageNLP._h serves it, the kernel does not)."""
+    s = dict(v_max=1.0, radius=0.25)
+    s.update(spec or {})
+    return dict(name="SingleIntegrator2D", nx=2, nu=2, next=si_next, spec=s, dt=dt, N=10, Q=np.array([50.0, 50.0]), R=np.array([5.0, 5.0]),
+                alpha=0.05, alpha1=0.0, alpha2=0.0, beta=1.01, radius=s["radius"],
+                u_lo=np.array([-s["v_max"], -s["v_max"]]), u_hi=np.array([s["v_max"], s["v_max"]]), x_lo=np.full(2, -INF), x_hi=np.full(2, INF))
 
 
 def uni_model(spec=None, dt=0.05):

@@ -950,8 +950,8 @@ int sc_mpccbf_ms_solve_batch(const sc_mpccbf_params* params, const sc_ipopt_para
     sc::DeviceGuard on_device(stream, X);
     if (!params) return sc::fail(SC_ERR_INVALID_ARGUMENT, "params is NULL");
     if (params->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && params->model_id != SC_MODEL_DOUBLE_INTEGRATOR2D && params->model_id != SC_MODEL_KINEMATIC_BICYCLE2D &&
-        params->model_id != SC_MODEL_UNICYCLE2D)
-        return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting MPC-CBF kernel is built for DynamicUnicycle2D, Unicycle2D, DoubleIntegrator2D and KinematicBicycle2D");
+        params->model_id != SC_MODEL_UNICYCLE2D && params->model_id != SC_MODEL_SINGLE_INTEGRATOR2D)
+        return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting MPC-CBF kernel is built for DynamicUnicycle2D, Unicycle2D, SingleIntegrator2D, DoubleIntegrator2D and KinematicBicycle2D");
     if (params->model_id == SC_MODEL_KINEMATIC_BICYCLE2D && (!(params->rear_ax_dist > 0.0) || !(params->v_min <= params->v_max)))
         return sc::fail(SC_ERR_INVALID_ARGUMENT, "KinematicBicycle2D: rear_ax_dist must be positive and v_min <= v_max");
     if (B < 0 || K < 1 || K > 16) return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting kernel serves 1 <= K <= 16 (pad with [1000,1000,0,...] rows like update_tvp)");

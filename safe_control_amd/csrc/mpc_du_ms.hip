@@ -1,5 +1,5 @@
 // Kernel 13: MPC-CBF as do-mpc poses it -- multiple shooting under IPOPT's filter interior point, one NLP per wavefront, four
-// lanes per stage -- for DynamicUnicycle2D, Unicycle2D, DoubleIntegrator2D and KinematicBicycle2D (template parameter MODEL: dums::M_*).  The algorithm and what each lane holds: mpc_du_ms_solver.hpp (plain C++ over a context; the same code
+// lanes per stage -- for DynamicUnicycle2D, Unicycle2D, SingleIntegrator2D, DoubleIntegrator2D and KinematicBicycle2D (template parameter MODEL: dums::M_*).  The algorithm and what each lane holds: mpc_du_ms_solver.hpp (plain C++ over a context; the same code
 // runs on the host, one thread per lane, in tools/du_ms_host.cpp).  This unit supplies the device context -- LDS through an address-space
 // pointer, __syncthreads, the DPP wave reductions of mpc_ipm_common.hpp -- the kernel and its launcher.
 //
@@ -63,7 +63,9 @@ __global__ void __launch_bounds__(256) mpcdu_ms_order_kernel(const Params P, lon
     const double x = (double)X[b * NX], y = (double)X[b * NX + 1], th = (double)X[b * NX + 2], v = (double)X[b * NX + 3];
     const double a = (double)u_prev[b * NU], w = (double)u_prev[b * NU + 1], dt = P.dt;
     double p1x, p1y, p2x, p2y;
-    if constexpr (MODEL == M_UNI) {                                           // (x, y, theta), (v, omega): a = v; one-step rows
+    if constexpr (MODEL == M_SI) {                                            // (x, y), (vx, vy): a = vx, w = vy; one-step rows
+        p1x = x + dt * a; p1y = y + dt * w; p2x = p1x; p2y = p1y;
+    } else if constexpr (MODEL == M_UNI) {                                    // (x, y, theta), (v, omega): a = v; one-step rows
         p1x = x + dt * a * cos(th); p1y = y + dt * a * sin(th); p2x = p1x; p2y = p1y;
     } else if constexpr (MODEL == M_KB) {                                     // (x, y, theta, v), (a, beta): w = beta
         const double c = cos(th), s = sin(th), th1 = th + dt * v * w * P.inv_Lr, v1 = fmax(fmin(v + dt * a, P.v_max), P.v_min);
@@ -81,7 +83,8 @@ __global__ void __launch_bounds__(256) mpcdu_ms_order_kernel(const Params P, lon
         p2x = p1x + dt * v1 * cos(th1); p2y = p1y + dt * v1 * sin(th1);
     }
     const double g1 = P.alpha1 + P.alpha2, g2 = P.alpha1 * P.alpha2;
-    const double w0 = MODEL == M_UNI ? P.alpha1 - 1.0 : 1.0 - g1 + g2, w1 = MODEL == M_UNI ? 1.0 : g1 - 2.0, w2 = MODEL == M_UNI ? 0.0 : 1.0;
+    constexpr bool one_step = MODEL == M_UNI || MODEL == M_SI;
+    const double w0 = one_step ? P.alpha1 - 1.0 : 1.0 - g1 + g2, w1 = one_step ? 1.0 : g1 - 2.0, w2 = one_step ? 0.0 : 1.0;
     const TIO* ob = obs + (obs_shared ? 0 : b * P.K * 7);
     bool viol = false;
     for (int j = 0; j < P.K; ++j) {
@@ -113,7 +116,7 @@ __global__ void __launch_bounds__(64, SC_DUMS_WAVES) mpcdu_ms_kernel(const Param
         const int j = threadIdx.x / 3, c = threadIdx.x % 3;
         dums_lds[S.L.OB + threadIdx.x] = j < P.K ? (double)ob[7 * j + c] : 0.0;
     }
-    for (int i = 0; i < NX; ++i) S.x0[i] = (MODEL == M_UNI && i == 3) ? 0.0 : (double)X[b * NX + i];      // (Unicycle2D rows are [x, y, theta, unused])
+    for (int i = 0; i < NX; ++i) S.x0[i] = ((MODEL == M_UNI && i == 3) || (MODEL == M_SI && i >= 2)) ? 0.0 : (double)X[b * NX + i];      // (Unicycle2D rows are [x, y, theta, unused], SingleIntegrator2D's [x, y, unused, unused])
     for (int j = 0; j < NU; ++j) S.uprev[j] = (double)u_prev[b * NU + (j ^ U0)];
     S.xg[0] = (double)goal[b * 2]; S.xg[1] = (double)goal[b * 2 + 1];
     __syncthreads();
@@ -156,7 +159,7 @@ static hipError_t launch_t(const Params& P, const sc_ipopt_params& O, long long 
 
 size_t mpcdu_ms_order_bytes(long long B) { return (size_t)(B + 4) * sizeof(int); }
 size_t mpcdu_ms_lds_bytes(int horizon, int K, int model_id) {
-    return (size_t)dums::Lds(horizon, K, model_id == SC_MODEL_KINEMATIC_BICYCLE2D || model_id == SC_MODEL_UNICYCLE2D).total * sizeof(double);
+    return (size_t)dums::Lds(horizon, K, model_id == SC_MODEL_KINEMATIC_BICYCLE2D || model_id == SC_MODEL_UNICYCLE2D || model_id == SC_MODEL_SINGLE_INTEGRATOR2D).total * sizeof(double);
 }
 
 hipError_t mpcdu_ms_launch(const sc_mpccbf_params& p, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
@@ -171,6 +174,11 @@ hipError_t mpcdu_ms_launch(const sc_mpccbf_params& p, const sc_ipopt_params& O, 
         for (int j = 0; j < 2; ++j) { P.R[j] = p.R[1 - j]; P.u_lo[j] = -p.u_max[1 - j]; P.u_hi[j] = p.u_max[1 - j]; }
         if (f64) return dums::launch_t<double, dums::M_DI>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
         return dums::launch_t<float, dums::M_DI>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
+    }
+    if (p.model_id == SC_MODEL_SINGLE_INTEGRATOR2D) {
+        P.Q[2] = 0.0; P.Q[3] = 0.0;
+        if (f64) return dums::launch_t<double, dums::M_SI>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
+        return dums::launch_t<float, dums::M_SI>(P, O, B, p.obs_shared, X, u_prev, goal, obs, u_out, status_out, iters_out, plan_out, trace_out, order_ws, stream);
     }
     if (p.model_id == SC_MODEL_UNICYCLE2D) {
         P.Q[3] = 0.0;

@@ -75,8 +75,9 @@ constexpr int ST_FILTER_FULL = 7;                 // (internal) the filter ran o
 // (16 values) where the other two keep four entries of A and know B; the recursion, the sweep, J'y and the rows read those.
 //   M_UNI Unicycle2D x = (px, py, theta) -- held as four states, the last one idle (x_3+ = x_3 = 0, no cost) --, u = (v, omega): x+ = x + dt (v cos th,
 //         v sin th, omega); no state bound; ONE-step rows h(p1) - (1 - alpha1) h(p0) >= 0 (alpha1 carries the reference's `alpha`)  mpc_cbf.py:22-24,52-53,188-192,312-315
-enum { M_DU = 0, M_DI = 1, M_KB = 2, M_UNI = 3 };
-constexpr bool general_layout(int model) { return model == M_KB || model == M_UNI; }
+//   M_SI  SingleIntegrator2D x = (px, py) -- two idle states --, u = (vx, vy): x+ = x + dt u; no state bound; one-step rows like M_UNI       mpc_cbf.py:19-21,49-51,183-187
+enum { M_DU = 0, M_DI = 1, M_KB = 2, M_UNI = 3, M_SI = 4 };
+constexpr bool general_layout(int model) { return model == M_KB || model == M_UNI || model == M_SI; }
 struct Params {
     int N, K;
     double dt, Q[4], R[2], alpha1, alpha2, beta, radius, u_lo[2], u_hi[2], v_max;
@@ -265,7 +266,7 @@ template <class Cx, int MODEL = M_DU>
 struct Wave {
     static constexpr bool XB = MODEL == M_DU || MODEL == M_KB;          // the model has the state bound |x_3| <= v_max
     static constexpr bool GEN = general_layout(MODEL);
-    static constexpr int NXT = MODEL == M_UNI ? 3 : NX;                  // states of the reference's model (the count in the error scaling)
+    static constexpr int NXT = MODEL == M_UNI ? 3 : (MODEL == M_SI ? 2 : NX);     // states of the reference's model (the count in the error scaling)
     Cx& cx;
     const Params& P;
     const sc_ipopt_params& O;
@@ -313,7 +314,7 @@ struct Wave {
           k(cx_.lane / group_lanes(P_.N) <= P_.N ? cx_.lane / group_lanes(P_.N) : 0) {
         const double g1 = P.alpha1 + P.alpha2, g2 = P.alpha1 * P.alpha2;
         w0 = 1.0 - g1 + g2; w1 = g1 - 2.0; w2 = 1.0;
-        if constexpr (MODEL == M_UNI) { w0 = P.alpha1 - 1.0; w1 = 1.0; w2 = 0.0; }              // d_h + alpha h_k
+        if constexpr (MODEL == M_UNI || MODEL == M_SI) { w0 = P.alpha1 - 1.0; w1 = 1.0; w2 = 0.0; }              // d_h + alpha h_k
         nfilt = 0; dw_last = 0.0; last_dw = 0.0; fpo = L.FP; fto = L.FT;
     }
     SC_HD void sync() const { cx.sync(); }
@@ -333,6 +334,17 @@ struct Wave {
     double tc_ = 1.0, ts_ = 0.0, tc1_ = 1.0, ts1_ = 0.0;        // cos / sin of theta_k and of theta_k + dt omega_k at the ITERATE (eval2 sets them, finish_step reuses them)
     SC_HD void geometry(const double* xs, const double* us, Geo& g, bool cached = false) const {
         const double dt = P.dt;
+        if constexpr (MODEL == M_SI) {
+            g.c = g.s = g.c1 = g.s1 = 0.0; g.v1 = 0.0;
+            g.F[0] = xs[0] + dt * us[0]; g.F[1] = xs[1] + dt * us[1]; g.F[2] = xs[2]; g.F[3] = xs[3];
+            g.p1[0] = g.F[0]; g.p1[1] = g.F[1]; g.p2[0] = g.F[0]; g.p2[1] = g.F[1];
+            SC_UNROLL for (int i = 0; i < 16; ++i) g.ab[i] = 0.0;
+            g.ab[2] = 1.0; g.ab[7] = 1.0; g.ab[8] = dt; g.ab[13] = dt;                          // A_2, A_3: the idle states; B_0 = dt e_0, B_1 = dt e_1
+            SC_UNROLL for (int i = 0; i < 4; ++i) { g.j2[0][i] = g.ab[4 * i]; g.j2[1][i] = g.ab[4 * i + 1]; }
+            g.a02 = g.a12 = g.a03 = g.a13 = 0.0;
+            g.g02 = g.g03 = g.g12 = g.g13 = 0.0;
+            return;
+        }
         if constexpr (MODEL == M_UNI) {
             const double v = us[0];
             if (cached) { g.c = tc_; g.s = ts_; } else cx.sincos(xs[2], g.s, g.c);
@@ -710,7 +722,9 @@ struct Wave {
                 const double s1x = sl * g.p1[0] - socx, s1y = sl * g.p1[1] - socy, s2x = sl * g.p2[0] - socx, s2y = sl * g.p2[1] - socy;
                 const double nx_ = wy[0] - 2.0 * w1 * s1x - 2.0 * w2 * s2x, ny_ = wy[1] - 2.0 * w1 * s1y - 2.0 * w2 * s2y;    // on grad^2 p1
                 const double kx = -2.0 * w2 * s2x, ky = -2.0 * w2 * s2y;                                                        // on grad^2 (p2 - p1)
-                if constexpr (MODEL == M_UNI) {
+                if constexpr (MODEL == M_SI) {
+                    (void)nx_; (void)ny_; (void)kx; (void)ky;                                   // affine points: no curvature
+                } else if constexpr (MODEL == M_UNI) {
                     // p1 = p + dt v (c, s) over (theta = entry 2, v = entry 4); no second point
                     (void)kx; (void)ky;
                     const double v = u[0];

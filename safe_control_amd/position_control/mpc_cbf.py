@@ -28,6 +28,8 @@ def default_mpc_weights(model):
         return np.diag([50.0, 50.0, 0.01, 30.0]), np.array([0.5, 0.5])
     if model == "Unicycle2D":
         return np.diag([50.0, 50.0, 0.01]), np.array([0.5, 0.5])
+    if model == "SingleIntegrator2D":                       # mpc_cbf.py:19-21 (the multiple-shooting kernel; the condensed solve of this model is mpc_cbf_linear.py)
+        return np.diag([50.0, 50.0]), np.array([5.0, 5.0])
     if model == "DoubleIntegrator2D":                       # mpc_cbf.py:28-30 (the multiple-shooting kernel; the condensed solve of this model is mpc_cbf_gn.py)
         return np.diag([50.0, 50.0, 20.0, 20.0]), np.array([0.5, 0.5])
     if model == "KinematicBicycle2D":                       # mpc_cbf.py:31-33 (likewise)
@@ -41,6 +43,8 @@ def default_mpc_cbf_param(model):
         return {"alpha1": 0.15, "alpha2": 0.15}
     if model == "Unicycle2D":
         return {"alpha": 0.05}                              # mpc_cbf.py:52-53
+    if model == "SingleIntegrator2D":
+        return {"alpha": 0.05}                              # mpc_cbf.py:49-51
     if model == "DoubleIntegrator2D":
         return {"alpha1": 0.2, "alpha2": 0.2}               # mpc_cbf.py:56-59
     if model == "KinematicBicycle2D":
@@ -90,7 +94,10 @@ def make_params(robot_spec, cbf_param, Q, R, horizon, dt, radius, io_dtype, obs_
         p.Q[i] = float(qd[i]) if i < len(qd) else 0.0
     p.R[0], p.R[1] = float(R[0]), float(R[1])
     p.v_max = float(robot_spec["v_max"])
-    if robot_spec["model"] == "Unicycle2D":                 # inputs [v, omega] (mpc_cbf.py:188-192), one gain alpha
+    if robot_spec["model"] == "SingleIntegrator2D":         # inputs [vx, vy] (mpc_cbf.py:183-187), one gain alpha
+        p.alpha1, p.alpha2 = float(cbf_param["alpha"]), 0.0
+        p.u_max[0], p.u_max[1] = float(robot_spec["v_max"]), float(robot_spec["v_max"])
+    elif robot_spec["model"] == "Unicycle2D":               # inputs [v, omega] (mpc_cbf.py:188-192), one gain alpha
         p.alpha1, p.alpha2 = float(cbf_param["alpha"]), 0.0
         p.u_max[0], p.u_max[1] = float(robot_spec["v_max"]), float(robot_spec["w_max"])
     elif robot_spec["model"] == "KinematicBicycle2D":       # inputs [a, beta] (mpc_cbf.py:202-208); robot.step clips the speed to [v_min, v_max]

@@ -81,6 +81,13 @@ class LinearMPCCBF:
         self.z = np.zeros(self.n_controls * self.horizon)
         self.iterations = 0
         self.solver_status = "optimal"
+        # SingleIntegrator2D under MPCCBF: the NLP as do-mpc poses it (multiple shooting under IPOPT's algorithm, csrc/mpc_du_ms.hip, kernel 13) on
+        # request -- robot_spec['mpc_formulation'] = 'multiple_shooting'; circles only (a scene with superellipsoid rows runs on this class's kernel)
+        self._ms = None
+        if self._mdl["nx"] == 2 and self.input_rterm == "du" and self.robot_spec.get("mpc_formulation", "condensed") == "multiple_shooting" \
+                and self.horizon <= 62 and self.num_obs <= 16:
+            from .mpc_cbf_ms import BatchedMSMPCCBF
+            self._ms = BatchedMSMPCCBF(self.robot_spec, dt=self.dt, io_dtype="f64", horizon=self.horizon, cbf_param=self.cbf_param, check_circles=False)
 
     def update_tvp(self, goal, obs):
         self.goal = np.array(goal)
@@ -98,6 +105,18 @@ class LinearMPCCBF:
         gs = np.asarray(self.goal, dtype=np.float64).reshape(-1)[:ng]
         g[: gs.shape[0]] = gs
         obs = np.ascontiguousarray(self.obs, dtype=np.float64)
+        if self._ms is not None and not (obs[:, 6] >= 0.5).any():
+            import torch
+            dev = torch.device("cuda", int(self.device))
+            t = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float64), dtype=torch.float64, device=dev)     # noqa: E731
+            self._ms.cbf_param = self.cbf_param
+            self._ms.robot_spec["radius"] = self.robot.robot_radius
+            um, sm, im, plan = self._ms.solve(t(X[None]), t(self.u_prev[None]), t(g[None]), t(obs[None]), want_plan=True)
+            self.iterations = int(im[0].item())
+            self.solver_status = _lib.STATUS_STRINGS[int(sm[0].item())]
+            self.z = plan[0, (self.horizon + 1) * 4:].cpu().numpy().copy()
+            self.u_prev = um[0].cpu().numpy().copy()
+            return self.u_prev.reshape(-1, 1).copy()
         p = make_params(self._mdl, self.cbf_param, self.horizon, self.robot.robot_radius, _lib.DTYPE_F64, input_rterm=self.input_rterm)
         u = np.zeros(nu); st = np.zeros(1, dtype=np.int32); it = np.zeros(1, dtype=np.int32)
         rc = self._lib.sc_mpclin_solve_batch_host(

@@ -27,8 +27,9 @@ class BatchedMSMPCCBF:
     def __init__(self, robot_spec=None, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None, ipopt=None, max_iter=None, check_circles=True, order=True):
         self.robot_spec = complete_robot_spec(dict(robot_spec or {"model": "DynamicUnicycle2D"}))
         self.model = self.robot_spec["model"]
-        if self.model not in ("DynamicUnicycle2D", "Unicycle2D", "DoubleIntegrator2D", "KinematicBicycle2D"):
-            raise NotImplementedError("the multiple-shooting MPC-CBF kernel serves DynamicUnicycle2D, Unicycle2D, DoubleIntegrator2D and KinematicBicycle2D (VTOL2D: BatchedVtolMSMPCCBF)")
+        if self.model not in ("DynamicUnicycle2D", "Unicycle2D", "SingleIntegrator2D", "DoubleIntegrator2D", "KinematicBicycle2D"):
+            raise NotImplementedError("the multiple-shooting MPC-CBF kernel serves DynamicUnicycle2D, Unicycle2D, SingleIntegrator2D, DoubleIntegrator2D and "
+                                      "KinematicBicycle2D (VTOL2D: BatchedVtolMSMPCCBF)")
         self.dt = float(dt)
         self.io_name = io_dtype
         self.io_dtype = {"f32": _lib.DTYPE_F32, "f64": _lib.DTYPE_F64}[io_dtype]
@@ -65,6 +66,8 @@ class BatchedMSMPCCBF:
         B = X.shape[0]
         shared = obs.dim() == 2
         K = obs.shape[-2]
+        if self.model == "SingleIntegrator2D" and X.shape == (B, 2):      # the reference's two-state rows: the kernel reads four columns, the last two unused
+            X = torch.cat([X, torch.zeros_like(X)], dim=1)
         if X.shape != (B, 4) or u_prev.shape != (B, 2) or goal.shape != (B, 2) or obs.shape[-1] != 7 or (not shared and obs.shape[0] != B):
             raise ValueError("expected X[B,4], u_prev[B,2], goal[B,2], obs[B,K,7] or obs[K,7]")
         if self.check_circles and B > 0 and bool((obs[..., 6] >= 0.5).any().item()):

@@ -184,3 +184,23 @@ def test_solver_header_for_unicycle2d_equals_the_numpy_oracle():
     so = np.array([r[1] for r in res]); ito = np.array([r[2] for r in res]); uo = np.array([r[0] for r in res])
     assert np.array_equal(st, so) and (it != ito).sum() <= 2 and np.abs(it - ito).max() <= 1
     assert np.abs(u - uo)[it == ito].max() <= 1e-9
+
+
+def _ms_one_si(a):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    from oracle import ms_ipopt as MS
+    return MS.solve(MS.si_model(), a[0], a[1], a[2], a[3], opts=dict(MS.KERNEL_PROFILE))
+
+
+def test_solver_header_for_single_integrator_equals_the_numpy_oracle():
+    """The SingleIntegrator2D instantiation of csrc/mpc_du_ms_solver.hpp (two states held as four with two idle ones, one-step rows, no curvature)
+    compiled for the host, against oracle/ms_ipopt.py: si_model() on 160 bench draws."""
+    from multiprocessing import Pool
+    n = 160
+    X, up, goal, obs = (a[:n] for a in W.mpc_family_batch("si", 4096, 8, seed=0))
+    u, st, it = c_oracle.du_ms_cpu_batch(X, up, goal, obs, n_threads=0, model="SingleIntegrator2D")
+    with Pool(min(8, os.cpu_count() or 2)) as p:
+        res = p.map(_ms_one_si, [(X[i], up[i], goal[i], obs[i]) for i in range(n)], chunksize=4)
+    so = np.array([r[1] for r in res]); ito = np.array([r[2] for r in res]); uo = np.array([r[0] for r in res])
+    assert np.array_equal(st, so) and (it != ito).sum() <= 2 and np.abs(it - ito).max() <= 1
+    assert np.abs(u - uo)[it == ito].max() <= 1e-9

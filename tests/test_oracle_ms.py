@@ -38,6 +38,8 @@ def model_of(name):
     if name == "VTOL2D":
         keys = MS.vtol_model()["spec"].keys()
         return MS.vtol_model(dict({k: v for k, v in sp.items() if k in keys}, radius=R))
+    if name == "SingleIntegrator2D":
+        return MS.si_model(dict(v_max=sp["v_max"], radius=R))
     if name == "Unicycle2D":
         return MS.uni_model(dict(v_max=sp["v_max"], w_max=sp["w_max"], radius=R))
     if name == "DoubleIntegrator2D":
@@ -49,7 +51,7 @@ def model_of(name):
     return MS.du_model(dict(v_max=sp["v_max"], a_max=sp["a_max"], w_max=sp["w_max"], radius=R))
 
 
-@pytest.mark.parametrize("name", ["DynamicUnicycle2D", "VTOL2D", "KinematicBicycle2D", "DoubleIntegrator2D", "Unicycle2D"])
+@pytest.mark.parametrize("name", ["DynamicUnicycle2D", "VTOL2D", "KinematicBicycle2D", "DoubleIntegrator2D", "Unicycle2D", "SingleIntegrator2D"])
 def test_rows_and_cost_of_a_one_stage_problem_equal_the_reference(name):
     """N = 1, w = [x, u, x_next]: the dynamics rows vanish at the reference's x_next (mpc_cbf.py:138-141), the inequality rows are the
     registered -cbf (:304), the objective is l(x) + m(x_next) (:144,176-178) + the rterm on u - u_prev (:180)."""
@@ -72,7 +74,7 @@ def test_rows_and_cost_of_a_one_stage_problem_equal_the_reference(name):
             assert abs(ev["f"] - want) <= 1e-11 * max(1.0, abs(want)), (name, i, level)
 
 
-@pytest.mark.parametrize("name", ["DynamicUnicycle2D", "VTOL2D", "KinematicBicycle2D", "DoubleIntegrator2D", "Unicycle2D"])
+@pytest.mark.parametrize("name", ["DynamicUnicycle2D", "VTOL2D", "KinematicBicycle2D", "DoubleIntegrator2D", "Unicycle2D", "SingleIntegrator2D"])
 def test_derivatives_against_central_differences(name):
     mdl = model_of(name)
     rng = np.random.default_rng(3)

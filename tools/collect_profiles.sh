@@ -89,6 +89,8 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 # ... Unicycle2D (general stage layout, one-step rows)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o dumsuni -- python3 $R/tools/time_mpcdu_ms.py 4096 f32 3 uni > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o dumsuni_sq -- python3 $R/tools/time_mpcdu_ms.py 4096 f32 2 uni > /dev/null 2>&1
+# ... SingleIntegrator2D
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o dumssi_sq -- python3 $R/tools/time_mpcdu_ms.py 4096 f32 2 si > /dev/null 2>&1
 # ... and KinematicBicycle2D (general stage layout; with the reference solver's budget: a few solves cycle to it)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o dumskb -- python3 $R/tools/time_mpcdu_ms.py 4096 f32 2 kb > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT -o dumskb_sq -- python3 $R/tools/time_mpcdu_ms.py 4096 f32 1 kb > /dev/null 2>&1

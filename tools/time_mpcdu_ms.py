@@ -1,5 +1,5 @@
 """GPU: launch time of the multiple-shooting DynamicUnicycle2D kernel (csrc/mpc_du_ms.hip, kernel 13) on the 4096 configs[2] problems, next to the
-condensed kernel on the same batch.   python tools/time_mpcdu_ms.py [B] [f32|f64] [reps] [du|di|kb|uni] [max_iter]"""
+condensed kernel on the same batch.   python tools/time_mpcdu_ms.py [B] [f32|f64] [reps] [du|di|kb|uni|si] [max_iter]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,7 +17,8 @@ dt = torch.float32 if io == "f32" else torch.float64
 X, up, goal, obs = W.mpc_family_batch(fam, B, 8, seed=0)
 t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=dt, device="cuda:0")
 args = (t(X), t(up), t(goal), t(obs))
-for name, ctl in (("multiple shooting (kernel 13)", sca.BatchedMSMPCCBF(SPEC, io_dtype=io, check_circles=False, max_iter=MAXIT)), ("condensed (kernel 3)" if fam in ("du", "uni") else "condensed (mpcgn)", sca.BatchedMPCCBF(SPEC, io_dtype=io) if fam in ("du", "uni") else sca.BatchedGnMPCCBF(SPEC, io_dtype=io))):
+for name, ctl in (("multiple shooting (kernel 13)", sca.BatchedMSMPCCBF(SPEC, io_dtype=io, check_circles=False, max_iter=MAXIT)), ("condensed (kernel 3)" if fam in ("du", "uni") else ("condensed (mpclin)" if fam == "si" else "condensed (mpcgn)"),
+                   sca.BatchedMPCCBF(SPEC, io_dtype=io) if fam in ("du", "uni") else (sca.BatchedLinearMPCCBF(SPEC, io_dtype=io) if fam == "si" else sca.BatchedGnMPCCBF(SPEC, io_dtype=io)))):
     u, st, it = ctl.solve(*args)[:3]
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
