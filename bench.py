@@ -1108,7 +1108,8 @@ def compact_leg(v):
         keep["condensed_ms"] = sig(v["condensed"]["kernel_ms"])
     rl = v.get("roofline")
     if isinstance(rl, dict):
-        keep["roofline"] = {k: ("valu" if rl[k] == "valu_issue" else sig(rl[k])) for k in ("bound", "frac", "stale") if k in rl}
+        # ("stale" rides along only when it is true: emit() lists the legs whose counter profile is not from this tree's kernels under `stale_rooflines`)
+        keep["roofline"] = {k: ("valu" if rl[k] == "valu_issue" else sig(rl[k])) for k in ("bound", "frac", "stale") if k in rl and not (k == "stale" and not rl[k])}
         if isinstance(rl.get("work_level"), dict):
             keep["roofline"]["work_frac"] = sig(rl["work_level"]["frac"])
     return keep
@@ -1163,6 +1164,10 @@ def emit(d, ws):
                                                   "optimal_fraction": m.get("optimal_fraction")}
         line["mpc_cbf" if "mpc_cbf" in d else "mpc"] = m
     line["full_legs"] = "gpurun_out/bench_legs.json"
+
+    def stale_in(v):
+        return isinstance(v, dict) and (bool(v.get("stale")) or any(stale_in(x) for x in v.values()))
+    line["stale_rooflines"] = sorted(k for k, v in d.items() if stale_in(v))       # legs whose VALU-issue roofline uses a counter profile of OTHER kernel sources ([] = none)
     s = json.dumps(line)
     if len(s) > LINE_LIMIT:                                             # never the contract fields nor configs[2]: drop the largest extras
         extras = sorted((k for k in line if k not in CONTRACT_KEYS and k not in ("mpc_cbf", "mpc", "ranks_seen", "full_legs")),
