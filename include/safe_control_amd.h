@@ -211,7 +211,9 @@ typedef struct sc_mpccbf_params {
                               * optimal-decay class: measured to change nothing there); 2: s = g where g >= mu / nu after a
                               * trial step -- the setting of the config-5 extension (Unicycle2D optimal decay, N = 20,
                               * superellipsoids), oracle/od_mpc_rd1.py                              */
-    int32_t reserved;
+    int32_t superellipsoid_rows; /* sc_mpccbf_ms_solve_batch only: 0 = every obstacle row is a circle (flag column < 0.5; the kernel does not look);
+                              * 1 = rows may be superellipsoids [ox, oy, a, b, e, theta, 1] -- DynamicUnicycle2D and DoubleIntegrator2D, whose
+                              * DT barriers have that branch (dynamic_unicycle2D.py:204-220): a slower instantiation                       */
     double  dt;              /* robot.dt                                                           */
     double  Q[4];            /* diagonal state weights, DU: 50,50,.01,30 (mpc_cbf.py:25-27)        */
     double  R[2];            /* input-rate weights of mpc.set_rterm, DU: .5,.5 (mpc_cbf.py:180)    */
@@ -529,8 +531,8 @@ int sc_odmpcvtol_solve_batch_sliced(const sc_odmpcvtol_params* params, const sc_
  *                                               [v_min, v_max] inside the barrier (kinematic_bicycle2D.py:112-123,175-199); rear_ax_dist.
  *                                               Where a plan slows down to v_min the clip's kink sits on the solution and the iteration
  *                                               cycles to max_iter (kernel 13): bound it
- *               ; obstacles must be circles (flag column < 0.5: a superellipsoid row returns SC_ERR_UNSUPPORTED from the host-side
- *               classes, the kernel treats every row as a circle), 1 <= K <= 16
+ *               ; obstacle rows: circles (flag column < 0.5) unless params->superellipsoid_rows = 1 (DynamicUnicycle2D and
+ *               DoubleIntegrator2D; the host-side classes set it from the rows' flags), 1 <= K <= 16
  *   status_out  SC_STATUS_OPTIMAL (tol or IPOPT's acceptable rule), SC_STATUS_INFEASIBLE (the restoration phase converged to a stationary
  *               point of the violation: IPOPT's "converged to a point of local infeasibility"), SC_STATUS_INACCURATE (iteration limit,
  *               restoration failed, stall rule); u_out is the last iterate's u_0 in every case, as in the reference

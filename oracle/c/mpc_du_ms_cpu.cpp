@@ -60,14 +60,14 @@ struct Problem {
     const double *x0, *up, *goal, *obs;
     double* u_out;
     int *status, *iters;
-    int model;
+    int model, se;
     double* trace;                                       // [max_iter + 1][8] or NULL (du_ms_cpu_solve_batch with trace_out: B = 1)
 };
 
 struct Wavefront {
     std::vector<double> lds;
     double red[WAVE];
-    double gred[WAVE][36];
+    double gred[WAVE][48];
     void* sp[WAVE];
     void* main_sp = nullptr;
     bool done[WAVE];
@@ -127,16 +127,19 @@ struct FiberCtx {
     double wsum(double v) { return reduce(v, [](double a, double b) { return a + b; }); }
     double wmax(double v) { return reduce(v, [](double a, double b) { return std::fmax(a, b); }); }
     double wmin(double v) { return reduce(v, [](double a, double b) { return std::fmin(a, b); }); }
+    double pow(double x, double y) const { return std::pow(x, y); }
 };
 
-template <int MODEL>
+template <int MODEL, bool SE = false>
 void lane_body_m(Wavefront* w, int lane) {
     using namespace sc::dums;
     const Problem& q = w->prob;
     FiberCtx cx{w->lds.data(), lane, w};
-    Wave<FiberCtx, MODEL> S(cx, *q.P, *q.O);
+    Wave<FiberCtx, MODEL, SE> S(cx, *q.P, *q.O);
     constexpr int U0 = MODEL == M_DI ? 1 : 0;            // (M_DI holds its inputs swapped: mpc_du_ms_solver.hpp)
-    if (lane < 3 * q.P->K) { const int j = lane / 3, c = lane % 3; w->lds[S.L.OB + lane] = q.obs[7 * j + c]; }
+    if constexpr (SE) {
+        if (lane < q.P->K) pack_obstacle(q.obs + 7 * lane, q.P->radius, q.P->beta, [](double a, double b) { return std::pow(a, b); }, &w->lds[S.L.OB + 8 * lane]);
+    } else if (lane < 3 * q.P->K) { const int j = lane / 3, c = lane % 3; w->lds[S.L.OB + lane] = q.obs[7 * j + c]; }
     for (int i = 0; i < NX; ++i) S.x0[i] = ((MODEL == M_UNI && i == 3) || (MODEL == M_SI && i >= 2)) ? 0.0 : q.x0[i];
     for (int j = 0; j < NU; ++j) S.uprev[j] = q.up[j ^ U0];
     S.xg[0] = q.goal[0]; S.xg[1] = q.goal[1];
@@ -146,6 +149,12 @@ void lane_body_m(Wavefront* w, int lane) {
     if (lane == 0) { q.u_out[0 ^ U0] = S.u[0]; q.u_out[1 ^ U0] = S.u[1]; *q.status = st; *q.iters = it; }
 }
 void lane_body(Wavefront* w, int lane) {
+    if (w->prob.se) {                                    // rows that may be superellipsoids (the three robots whose barrier has the branch)
+        if (w->prob.model == sc::dums::M_DI) lane_body_m<sc::dums::M_DI, true>(w, lane);
+        else if (w->prob.model == sc::dums::M_SI) lane_body_m<sc::dums::M_SI, true>(w, lane);
+        else lane_body_m<sc::dums::M_DU, true>(w, lane);
+        return;
+    }
     if (w->prob.model == sc::dums::M_DI) lane_body_m<sc::dums::M_DI>(w, lane);
     else if (w->prob.model == sc::dums::M_KB) lane_body_m<sc::dums::M_KB>(w, lane);
     else if (w->prob.model == sc::dums::M_UNI) lane_body_m<sc::dums::M_UNI>(w, lane);
@@ -198,7 +207,7 @@ extern "C" int du_ms_cpu_solve_batch(const sc_mpccbf_params* prm, const sc_ipopt
     if (prm->model_id == SC_MODEL_SINGLE_INTEGRATOR2D) { P.Q[2] = 0.0; P.Q[3] = 0.0; }
     if (model == M_KB) { P.v_min = prm->v_min; P.inv_Lr = 1.0 / prm->rear_ax_dist; }
     if (model == M_DI) for (int j = 0; j < 2; ++j) { P.R[j] = prm->R[1 - j]; P.u_lo[j] = -prm->u_max[1 - j]; P.u_hi[j] = prm->u_max[1 - j]; }
-    const size_t nl = (size_t)Lds(P.N, P.K, general_layout(model)).total;
+    const size_t nl = (size_t)Lds(P.N, P.K, general_layout(model), prm->superellipsoid_rows != 0).total;
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
 #else
@@ -211,7 +220,7 @@ extern "C" int du_ms_cpu_solve_batch(const sc_mpccbf_params* prm, const sc_ipopt
 #pragma omp for schedule(dynamic, 4)
         for (long b = 0; b < B; ++b) {
             std::fill(w->lds.begin(), w->lds.end(), 0.0);
-            w->prob = Problem{&P, O, X + 4 * b, u_prev + 2 * b, goal + 2 * b, obs + (prm->obs_shared ? 0 : (size_t)b * K * 7), u_out + 2 * b, status + b, iters + b, model, B == 1 ? g_trace : nullptr};
+            w->prob = Problem{&P, O, X + 4 * b, u_prev + 2 * b, goal + 2 * b, obs + (prm->obs_shared ? 0 : (size_t)b * K * 7), u_out + 2 * b, status + b, iters + b, model, prm->superellipsoid_rows != 0, B == 1 ? g_trace : nullptr};
             run_wave(w);
         }
         delete w;

@@ -87,6 +87,7 @@ def du_ms_cpu_batch(X, u_prev, goal, obs, spec=None, horizon=10, dt=0.05, n_thre
         X = np.hstack([X, np.zeros((X.shape[0], 4 - X.shape[1]))])
     X, u_prev, goal, obs = (np.ascontiguousarray(a, dtype=np.float64) for a in (X, u_prev, goal, obs))
     p = PM.make_params(sp, PM.default_mpc_cbf_param(model), Q, R, horizon, dt, sp["radius"], L.DTYPE_F64, obs_shared=obs.ndim == 2)
+    p.superellipsoid_rows = 1 if bool((obs[..., 6] >= 0.5).any()) else 0
     ip = L.default_ipopt(**(ipopt or {}))
     B, K = X.shape[0], obs.shape[-2]
     u = np.empty((B, 2)); st = np.empty(B, dtype=np.int32); it = np.empty(B, dtype=np.int32)

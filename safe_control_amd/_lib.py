@@ -147,7 +147,7 @@ class MpcCbfParams(C.Structure):
     """Mirror of ``sc_mpccbf_params``."""
     _fields_ = [
         ("model_id", C.c_int32), ("io_dtype", C.c_int32), ("horizon", C.c_int32), ("max_iter", C.c_int32),
-        ("obs_shared", C.c_int32), ("acceptable_iter", C.c_int32), ("slack_reset", C.c_int32), ("reserved", C.c_int32),
+        ("obs_shared", C.c_int32), ("acceptable_iter", C.c_int32), ("slack_reset", C.c_int32), ("superellipsoid_rows", C.c_int32),
         ("dt", C.c_double), ("Q", C.c_double * 4), ("R", C.c_double * 2),
         ("alpha1", C.c_double), ("alpha2", C.c_double), ("v_max", C.c_double), ("u_max", C.c_double * 2),
         ("robot_radius", C.c_double), ("beta", C.c_double), ("tol", C.c_double), ("acceptable_tol", C.c_double),

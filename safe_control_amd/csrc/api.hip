@@ -76,7 +76,7 @@ hipError_t mpcvtol_ms_launch(const sc_mpcvtol_params& p, const sc_ipopt_params& 
                              const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, hipStream_t stream);
 hipError_t mpcdu_ms_launch(const sc_mpccbf_params& p, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
                            const void* obs, void* u_out, int* status_out, int* iters_out, void* plan_out, double* trace_out, void* order_ws, hipStream_t stream);
-size_t mpcdu_ms_lds_bytes(int horizon, int K, int model_id);
+size_t mpcdu_ms_lds_bytes(int horizon, int K, int model_id, int se);
 size_t mpcdu_ms_order_bytes(long long B);
 hipError_t odmpcvtol_ms_launch(const sc_odmpcvtol_params& q, const sc_ipopt_params& O, long long B, int K, const void* X, const void* u_prev, const void* goal,
                                const void* obs, void* u_out, void* rho_out, int* status_out, int* iters_out, void* plan_out, double* trace_out,
@@ -941,7 +941,7 @@ size_t sc_mpccbf_ms_workspace_bytes(int64_t B) { return B < 0 ? 0 : sc::mpcdu_ms
 
 size_t sc_mpccbf_ms_lds_bytes(int32_t horizon, int32_t K) {
     if (horizon < 1 || horizon > 62 || K < 1 || K > 16) return 0;
-    return sc::mpcdu_ms_lds_bytes(horizon, K, SC_MODEL_KINEMATIC_BICYCLE2D);      /* (the largest layout: 96 B per stage more than the unicycle's) */
+    return sc::mpcdu_ms_lds_bytes(horizon, K, SC_MODEL_KINEMATIC_BICYCLE2D, 1);      /* (the largest layout: 96 B per stage more than the unicycle's) */
 }
 
 int sc_mpccbf_ms_solve_batch(const sc_mpccbf_params* params, const sc_ipopt_params* ipopt, int64_t B, int32_t K, const void* X, const void* u_prev,
@@ -957,7 +957,9 @@ int sc_mpccbf_ms_solve_batch(const sc_mpccbf_params* params, const sc_ipopt_para
     if (B < 0 || K < 1 || K > 16) return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting kernel serves 1 <= K <= 16 (pad with [1000,1000,0,...] rows like update_tvp)");
     if (B > 0x7fffffffLL) return sc::fail(SC_ERR_UNSUPPORTED, "B too large for one launch");
     if (params->horizon < 1 || params->horizon > 62) return sc::fail(SC_ERR_UNSUPPORTED, "the multiple-shooting kernel serves 1 <= horizon <= 62 (one stage per lane + the terminal state)");
-    if (sc::mpcdu_ms_lds_bytes(params->horizon, K, params->model_id) > 160 * 1024) return sc::fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
+    if (params->superellipsoid_rows && params->model_id != SC_MODEL_DYNAMIC_UNICYCLE2D && params->model_id != SC_MODEL_DOUBLE_INTEGRATOR2D)
+        return sc::fail(SC_ERR_UNSUPPORTED, "superellipsoid rows: served for DynamicUnicycle2D and DoubleIntegrator2D (SingleIntegrator2D: sc_mpclin_solve_batch; the other robots' DT barriers have no such branch)");
+    if (sc::mpcdu_ms_lds_bytes(params->horizon, K, params->model_id, params->superellipsoid_rows) > 160 * 1024) return sc::fail(SC_ERR_UNSUPPORTED, "horizon x obstacles does not fit the 160 KiB LDS of one CU");
     if (params->io_dtype != SC_DTYPE_F32 && params->io_dtype != SC_DTYPE_F64) return sc::fail(SC_ERR_INVALID_ARGUMENT, "io_dtype");
     if (!(params->dt > 0.0) || !(params->beta > 0.0) || !(params->u_max[0] > 0.0) || !(params->u_max[1] > 0.0) || !(params->v_max > 0.0))
         return sc::fail(SC_ERR_INVALID_ARGUMENT, "dt, beta, u_max and v_max must be positive");

@@ -88,11 +88,11 @@ SC_HD inline int sym6(int a, int b) { return a <= b ? a * 6 - a * (a - 1) / 2 + 
 
 struct Lds {
     int OB, AB, H, G, C, KG, PX, LAM, XS, US, YS, Pa, Pb, T, QU, FP, FT, FP2, FT2, SC, Y0, RW, XR, total;
-    int N, K, ABW;
-    SC_HD Lds(int N_, int K_, bool gen = false) : N(N_), K(K_ < 1 ? 1 : K_), ABW(gen ? 16 : 4) {
+    int N, K, ABW, OBW;
+    SC_HD Lds(int N_, int K_, bool gen = false, bool se = false) : N(N_), K(K_ < 1 ? 1 : K_), ABW(gen ? 16 : 4), OBW(se ? 8 : 3) {
         int o = 0;
         auto take = [&](int c) { int r = o; o += c; return r; };
-        OB = take(3 * K); AB = take(N * ABW); H = take((N + 1) * 21); G = take((N + 1) * 6); C = take((N + 1) * 4);
+        OB = take(OBW * K); AB = take(N * ABW); H = take((N + 1) * 21); G = take((N + 1) * 6); C = take((N + 1) * 4);
         KG = take(N * 14); PX = take(N * 28);
         // Slots whose lifetimes do not overlap share storage (19.7 KB per problem at N = 10, K = 8: eight problems per CU):
         //   YS (multipliers as the neighbours see them: written and read at the start of an evaluation) / LAM (costates = multiplier steps:
@@ -107,6 +107,18 @@ struct Lds {
         total = o;
     }
 };
+
+// Obstacle rows of a launch that may hold superellipsoids (Wave<.., SE = true>; dynamic_unicycle2D.py:204-220, double_integrator2D.py:238-254,
+// single_integrator2D.py:162-178: h = |q_x|^e / (a + R)^e + |q_y|^e / (b + R)^e - 1 in the obstacle's frame, with the reference's clamps) are
+// packed once per problem: [ox, oy, off | 1 / (a + R)^e, 1 / (b + R)^e, e, cos th, sin th, flag]; a circle keeps off = beta (R + r)^2 in slot 2.
+template <class PowF>
+SC_HD inline void pack_obstacle(const double o[7], double radius, double beta, PowF powf, double out[8]) {
+    out[0] = o[0]; out[1] = o[1];
+    if (o[6] < 0.5) { const double d = radius + o[2]; out[2] = beta * d * d; out[3] = 0.0; out[4] = 2.0; out[5] = 1.0; out[6] = 0.0; out[7] = 0.0; return; }
+    const double a = fmax(fabs(o[2]), 1e-3) + radius, b = fmax(fabs(o[3]), 1e-3) + radius, e = fmax(fabs(o[4]), 2.0);
+    out[2] = 1.0 / powf(a, e); out[3] = 1.0 / powf(b, e); out[4] = e; out[5] = cos(o[5]); out[6] = sin(o[5]); out[7] = 1.0;
+}
+struct HP { double h, gx, gy, hxx, hxy, hyy; };      // a barrier at a point: value, gradient, Hessian over (p_x, p_y)
 
 // ---- Riccati recursion with defects (oracle/ms_ipopt.py: _riccati_backward / _riccati_solve, hard dynamics) ----------------------------
 // LDS in: AB[k] = (a02, a03, a12, a13) of A_k = I + [[0, 0, a02, a03], [0, 0, a12, a13], 0, 0] (B = dt [[0, 0], [0, 0], [0, 1], [1, 0]]),
@@ -262,7 +274,7 @@ SC_HD SC_DUMS_INLINE void riccati_forward(Cx& cx, const Lds& L, const int N, con
 SC_HD inline int group_lanes(int N) { return (N + 1) * 4 <= 64 ? 4 : ((N + 1) * 2 <= 64 ? 2 : 1); }
 SC_HD inline bool cmp_le(double lhs, double rhs, double bas) { return lhs - rhs <= 10.0 * EPS_ * fabs(bas); }
 
-template <class Cx, int MODEL = M_DU>
+template <class Cx, int MODEL = M_DU, bool SE = false>
 struct Wave {
     static constexpr bool XB = MODEL == M_DU || MODEL == M_KB;          // the model has the state bound |x_3| <= v_max
     static constexpr bool GEN = general_layout(MODEL);
@@ -308,7 +320,7 @@ struct Wave {
     SC_HD double dr2(int i) const { const double a = fabs(lds[XRi(i)]); return a > 1.0 ? 1.0 / (a * a) : 1.0; }      // D_R^2 = 1 / max(1, |w_R|)^2
 
     SC_HD Wave(Cx& cx_, const Params& P_, const sc_ipopt_params& O_)
-        : cx(cx_), P(P_), O(O_), lds(cx_.lds), L(P_.N, P_.K, general_layout(MODEL)), lane(cx_.lane), N(P_.N), K(P_.K),
+        : cx(cx_), P(P_), O(O_), lds(cx_.lds), L(P_.N, P_.K, general_layout(MODEL), SE), lane(cx_.lane), N(P_.N), K(P_.K),
           G(group_lanes(P_.N)), q(cx_.lane % group_lanes(P_.N)), act(cx_.lane / group_lanes(P_.N) <= P_.N), stg(cx_.lane / group_lanes(P_.N) < P_.N),
           acl(cx_.lane / group_lanes(P_.N) <= P_.N && cx_.lane % group_lanes(P_.N) == 0), stl(cx_.lane / group_lanes(P_.N) < P_.N && cx_.lane % group_lanes(P_.N) == 0),
           k(cx_.lane / group_lanes(P_.N) <= P_.N ? cx_.lane / group_lanes(P_.N) : 0) {
@@ -419,7 +431,40 @@ struct Wave {
         g.g02 = -dt * g.v1 * g.s1; g.g03 = dt * g.c1; g.g12 = dt * g.v1 * g.c1; g.g13 = dt * g.s1;
     }
     // cbf_j = w0 h(p0) + w1 h(p1) + w2 h(p2),  h(p) = |p - c_j|^2 - beta (R + r_j)^2;  a = grad cbf_j over (px, py, theta, v, a, omega) when asked
-    SC_HD double row(const double* xs, const Geo& g, int j, double* a = nullptr) const {
+    // SE: h_j at a point with its first and second derivatives (circle or superellipsoid by the row's flag)
+    SC_HD void hpoint(int j, double px, double py, HP& o) const {
+        const typename Cx::ptr ob = lds + L.OB + 8 * j;
+        const double ex = px - ob[0], ey = py - ob[1];
+        if (ob[7] < 0.5) { o.h = ex * ex + ey * ey - ob[2]; o.gx = 2.0 * ex; o.gy = 2.0 * ey; o.hxx = 2.0; o.hxy = 0.0; o.hyy = 2.0; return; }
+        const double e = ob[4], ct = ob[5], st = ob[6];
+        const double qx = ct * ex + st * ey, qy = ct * ey - st * ex;
+        const double px2 = cx.pow(fabs(qx), e - 2.0) * ob[2], py2 = cx.pow(fabs(qy), e - 2.0) * ob[3];      // |q|^(e - 2) / (a + R)^e
+        o.h = qx * qx * px2 + qy * qy * py2 - 1.0;
+        const double hx = e * qx * px2, hy = e * qy * py2, hxx = e * (e - 1.0) * px2, hyy = e * (e - 1.0) * py2;
+        o.gx = ct * hx - st * hy; o.gy = st * hx + ct * hy;
+        o.hxx = ct * ct * hxx + st * st * hyy; o.hxy = ct * st * (hxx - hyy); o.hyy = st * st * hxx + ct * ct * hyy;
+    }
+    SC_HD double row(const double* xs, const Geo& g, int j, double* a = nullptr, HP* hp = nullptr) const {
+        if constexpr (SE) {
+            HP h0, h1, h2;
+            hpoint(j, xs[0], xs[1], h0); hpoint(j, g.p1[0], g.p1[1], h1);
+            if (w2 != 0.0) hpoint(j, g.p2[0], g.p2[1], h2); else { h2.h = h2.gx = h2.gy = h2.hxx = h2.hxy = h2.hyy = 0.0; }
+            if (a) {
+                const double dt = P.dt;
+                a[0] = w0 * h0.gx + w1 * h1.gx + w2 * h2.gx; a[1] = w0 * h0.gy + w1 * h1.gy + w2 * h2.gy;
+                if constexpr (GEN) {
+                    SC_UNROLL for (int i = 0; i < 4; ++i)
+                        a[2 + i] = w1 * (h1.gx * g.ab[4 * i] + h1.gy * g.ab[4 * i + 1]) + w2 * (h2.gx * g.j2[0][i] + h2.gy * g.j2[1][i]);
+                } else {
+                    a[2] = w1 * (h1.gx * g.a02 + h1.gy * g.a12) + w2 * (h2.gx * (g.a02 + g.g02) + h2.gy * (g.a12 + g.g12));
+                    a[3] = w1 * (h1.gx * g.a03 + h1.gy * g.a13) + w2 * (h2.gx * (g.a03 + g.g03) + h2.gy * (g.a13 + g.g13));
+                    a[4] = w2 * dt * (h2.gx * g.g03 + h2.gy * g.g13);
+                    a[5] = w2 * dt * (h2.gx * g.g02 + h2.gy * g.g12);
+                }
+            }
+            if (hp) { hp[0] = h0; hp[1] = h1; hp[2] = h2; }
+            return w0 * h0.h + w1 * h1.h + w2 * h2.h;
+        }
         const double ox = lds[L.OB + 3 * j], oy = lds[L.OB + 3 * j + 1], d = P.radius + lds[L.OB + 3 * j + 2], off = P.beta * d * d;
         const double e0x = xs[0] - ox, e0y = xs[1] - oy, e1x = g.p1[0] - ox, e1y = g.p1[1] - oy, e2x = g.p2[0] - ox, e2y = g.p2[1] - oy;
         if (a) {
@@ -645,8 +690,10 @@ struct Wave {
         }
         // my share of the stage's rows (lane q of the group walks rows q, q + G, ..); the sums the stage needs as a whole -- J'y, and for the
         // recursion the condensed block and gradient, the multiplier sums of the curvature terms -- are added over the group afterwards
-        double acc[36];                                                     // jr (6) | M (21) | gv (6) | sl, socx, socy
-        SC_UNROLL for (int i = 0; i < 36; ++i) acc[i] = 0.0;
+        // jr (6) | M (21) | gv (6) | sl, socx, socy  -- SE: per barrier point the om-weighted gradient (2) and Hessian (3) of the rows instead
+        constexpr int NACC = SE ? 48 : 36;
+        double acc[NACC];
+        SC_UNROLL for (int i = 0; i < NACC; ++i) acc[i] = 0.0;
         double* const jr = acc; double* const M = acc + 6; double* const gv = acc + 27;
         Geo g;
         double wy[NX] = {0.0, 0.0, 0.0, 0.0};
@@ -668,7 +715,8 @@ struct Wave {
             }
             for (int j = q; j < K; j += G) {
                 double a[NV];
-                const double cv = row(x, g, j, a);
+                HP hp[3];
+                const double cv = row(x, g, j, a, SE ? hp : nullptr);
                 const double sc = dgd(j);
                 const double dvj = -sc * cv, sj = lds[ri(R_S, j)], stU = lds[ri(R_SU, j)] - sj, ydj = lds[ri(R_YD, j)], vUj = lds[ri(R_VU, j)];
                 lds[ri(R_DV, j)] = dvj;
@@ -690,7 +738,12 @@ struct Wave {
                 }
                 const double om = sc * ydj;                                         // weight of grad^2 (-cbf_j) in the Hessian of the Lagrangian
                 SC_UNROLL for (int i = 0; i < NV; ++i) jr[i] += om * a[i];             // yd_j * grad d_j = -om grad cbf_j
-                acc[33] += om; acc[34] += om * lds[L.OB + 3 * j]; acc[35] += om * lds[L.OB + 3 * j + 1];
+                if constexpr (SE) {
+                    SC_UNROLL for (int i = 0; i < 3; ++i) {
+                        acc[33 + 5 * i] += om * hp[i].gx; acc[34 + 5 * i] += om * hp[i].gy;
+                        acc[35 + 5 * i] += om * hp[i].hxx; acc[36 + 5 * i] += om * hp[i].hxy; acc[37 + 5 * i] += om * hp[i].hyy;
+                    }
+                } else { acc[33] += om; acc[34] += om * lds[L.OB + 3 * j]; acc[35] += om * lds[L.OB + 3 * j + 1]; }
                 if (build) {
                     double Ej, bd;
                     if (ls) { Ej = 1.0; bd = -vUj; }                                 // q = 1, rhs_t = -(0 + vU), rhs_g = 0: b = q rhs_t
@@ -712,14 +765,16 @@ struct Wave {
         } else {
             SC_UNROLL for (int i = 0; i < NX; ++i) rc[i] = 0.0;
         }
-        if (build) cx.template gsum<36>(acc, G); else cx.template gsum<6>(acc, G);
+        if (build) cx.template gsum<NACC>(acc, G); else cx.template gsum<6>(acc, G);
         SC_UNROLL for (int i = 0; i < NV; ++i) E.Jty[i] -= jr[i];
         if (build && stl) {
-            const double sl = acc[33], socx = acc[34], socy = acc[35];
+            const double sl = SE ? 0.0 : acc[33], socx = SE ? 0.0 : acc[34], socy = SE ? 0.0 : acc[35];
             if (!ls) {
                 // curvature of the Lagrangian: dynamics rows (weights dgc y on F_0, F_1, which are p1) and the rows' -cbf_j (weights om_j):
                 //   -2 sl sum_p w_p Jp' Jp  -  2 sum_p w_p (S_p,x grad^2 p_p,x + S_p,y grad^2 p_p,y),   S_p = sum_j om_j (p_p - c_j) = sl p_p - soc
-                const double s1x = sl * g.p1[0] - socx, s1y = sl * g.p1[1] - socy, s2x = sl * g.p2[0] - socx, s2y = sl * g.p2[1] - socy;
+                // (SE: S_p = half the om-weighted gradient sum of the rows at point p; the constant 2 I of a circle becomes the rows' Hessian sum)
+                const double s1x = SE ? 0.5 * acc[38] : sl * g.p1[0] - socx, s1y = SE ? 0.5 * acc[39] : sl * g.p1[1] - socy;
+                const double s2x = SE ? 0.5 * acc[43] : sl * g.p2[0] - socx, s2y = SE ? 0.5 * acc[44] : sl * g.p2[1] - socy;
                 const double nx_ = wy[0] - 2.0 * w1 * s1x - 2.0 * w2 * s2x, ny_ = wy[1] - 2.0 * w1 * s1y - 2.0 * w2 * s2y;    // on grad^2 p1
                 const double kx = -2.0 * w2 * s2x, ky = -2.0 * w2 * s2y;                                                        // on grad^2 (p2 - p1)
                 if constexpr (MODEL == M_SI) {
@@ -782,10 +837,20 @@ struct Wave {
                 double j2x[NV] = {1.0, 0.0, g.a02 + g.g02, g.a03 + g.g03, dt * g.g03, dt * g.g02};
                 double j2y[NV] = {0.0, 1.0, g.a12 + g.g12, g.a13 + g.g13, dt * g.g13, dt * g.g12};
                 if constexpr (GEN) SC_UNROLL for (int i = 0; i < 4; ++i) { j1x[2 + i] = g.ab[4 * i]; j1y[2 + i] = g.ab[4 * i + 1]; j2x[2 + i] = g.j2[0][i]; j2y[2 + i] = g.j2[1][i]; }
+                if constexpr (SE) {
+                    // - sum_p w_p J_p' (sum_j om_j grad^2 h_j(p)) J_p
+                    M[sym6(0, 0)] -= w0 * acc[35]; M[sym6(0, 1)] -= w0 * acc[36]; M[sym6(1, 1)] -= w0 * acc[37];
+                    int e = 0;
+                    SC_UNROLL for (int p = 0; p < NV; ++p)
+                        SC_UNROLL for (int r_ = p; r_ < NV; ++r_, ++e)
+                            M[e] -= w1 * (acc[40] * j1x[p] * j1x[r_] + acc[41] * (j1x[p] * j1y[r_] + j1y[p] * j1x[r_]) + acc[42] * j1y[p] * j1y[r_])
+                                  + w2 * (acc[45] * j2x[p] * j2x[r_] + acc[46] * (j2x[p] * j2y[r_] + j2y[p] * j2x[r_]) + acc[47] * j2y[p] * j2y[r_]);
+                } else {
                 M[sym6(0, 0)] += o0; M[sym6(1, 1)] += o0;
                 int e = 0;
                 SC_UNROLL for (int p = 0; p < NV; ++p)
                     SC_UNROLL for (int r_ = p; r_ < NV; ++r_, ++e) M[e] += o1 * (j1x[p] * j1x[r_] + j1y[p] * j1y[r_]) + o2 * (j2x[p] * j2x[r_] + j2y[p] * j2y[r_]);
+                }
             }
             int e = 0;
             SC_UNROLL for (int p = 0; p < NV; ++p) {

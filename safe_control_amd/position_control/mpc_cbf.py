@@ -122,7 +122,8 @@ class MPCCBF:
     """Drop-in for position_control.mpc_cbf.MPCCBF (single agent per call).  ``robot_spec['mpc_formulation']`` (DynamicUnicycle2D, Unicycle2D):
     'multiple_shooting' (default since round 6: the NLP as do-mpc poses it under IPOPT's algorithm with its restoration phase,
     csrc/mpc_du_ms.hip, kernel 13 -- what the reference's solver returns also where the NLP has no feasible point) or 'condensed'
-    (single shooting, csrc/mpc_cbf.hip); scenes with superellipsoid rows run on the condensed kernel."""
+    (single shooting, csrc/mpc_cbf.hip); a DynamicUnicycle2D scene with superellipsoid rows runs on kernel 13's instantiation for them
+    (csrc/mpc_du_ms_se.hip)."""
 
     def __new__(cls, robot, robot_spec, *args, **kwargs):
         # the reference serves every model from this one class; the linear models run on their own kernel
@@ -184,8 +185,10 @@ class MPCCBF:
         X[: xs.shape[0]] = xs
         g = np.ascontiguousarray(np.asarray(self.goal, dtype=np.float64).reshape(-1)[:2])
         obs = np.ascontiguousarray(self.obs, dtype=np.float64)
-        if self._ms is not None and not (obs[:, 6] >= 0.5).any():
+        se = bool((obs[:, 6] >= 0.5).any())
+        if self._ms is not None and (not se or self.robot_spec["model"] == "DynamicUnicycle2D"):      # (superellipsoid rows: csrc/mpc_du_ms_se.hip; Unicycle2D's barrier has no such branch)
             import torch
+            self._ms.superellipsoids = se
             dev = torch.device("cuda", int(self.device))
             t = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float64), dtype=torch.float64, device=dev)     # noqa: E731
             self._ms.cbf_param = self.cbf_param               # (users mutate cbf_param in place: README "online adaptive CBF")

@@ -123,8 +123,10 @@ class GnMPCCBF:
         X[: xs.shape[0]] = xs
         g = np.ascontiguousarray(np.asarray(self.goal, dtype=np.float64).reshape(-1)[:2])
         obs = np.ascontiguousarray(self.obs, dtype=np.float64)
-        if self._ms is not None and not (obs[:, 6] >= 0.5).any():
+        se = bool((obs[:, 6] >= 0.5).any())
+        if self._ms is not None and (not se or self.robot_spec["model"] == "DoubleIntegrator2D"):      # (superellipsoid rows: csrc/mpc_du_ms_se.hip)
             import torch
+            self._ms.superellipsoids = se
             dev = torch.device("cuda", int(self.device))
             t = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.float64), dtype=torch.float64, device=dev)     # noqa: E731
             self._ms.cbf_param = self.cbf_param

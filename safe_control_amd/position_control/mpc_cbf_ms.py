@@ -24,7 +24,8 @@ class BatchedMSMPCCBF:
     that (one reduction and a host read per call).  ``order``: launches of more than 1024 problems start the NLPs whose start point violates a
     CBF row first (a pre-pass kernel and a small workspace; results do not depend on it, the launch ends ~15 % sooner)."""
 
-    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None, ipopt=None, max_iter=None, check_circles=True, order=True):
+    def __init__(self, robot_spec=None, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None, ipopt=None, max_iter=None, check_circles=True, order=True,
+                 superellipsoids=None):
         self.robot_spec = complete_robot_spec(dict(robot_spec or {"model": "DynamicUnicycle2D"}))
         self.model = self.robot_spec["model"]
         if self.model not in ("DynamicUnicycle2D", "Unicycle2D", "SingleIntegrator2D", "DoubleIntegrator2D", "KinematicBicycle2D"):
@@ -43,6 +44,7 @@ class BatchedMSMPCCBF:
             self.ipopt["max_iter"] = int(max_iter)
         self.max_iter = int(self.ipopt.get("max_iter", _lib.IPOPT_DEFAULTS["max_iter"]))
         self.check_circles = bool(check_circles)
+        self.superellipsoids = superellipsoids                # None: look at the rows' flags (if check_circles) and pick the instantiation; True / False: say so
         self.order = bool(order)                              # launches of more than 1024 problems: problems whose start violates a CBF row go first
         self._order_ws = None
         self.iter_slices = ()
@@ -70,8 +72,11 @@ class BatchedMSMPCCBF:
             X = torch.cat([X, torch.zeros_like(X)], dim=1)
         if X.shape != (B, 4) or u_prev.shape != (B, 2) or goal.shape != (B, 2) or obs.shape[-1] != 7 or (not shared and obs.shape[0] != B):
             raise ValueError("expected X[B,4], u_prev[B,2], goal[B,2], obs[B,K,7] or obs[K,7]")
-        if self.check_circles and B > 0 and bool((obs[..., 6] >= 0.5).any().item()):
-            raise NotImplementedError("superellipsoid obstacle rows: use the condensed kernel (BatchedMPCCBF / mpc_formulation='condensed')")
+        se = 1 if self.superellipsoids is True else 0
+        if self.superellipsoids is None and self.check_circles and B > 0 and bool((obs[..., 6] >= 0.5).any().item()):
+            se = 1                                            # rows with the superellipsoid flag: the slower instantiation that evaluates them
+        if se and self.model not in ("DynamicUnicycle2D", "DoubleIntegrator2D"):
+            raise NotImplementedError(f"superellipsoid obstacle rows: kernel 13 serves them for DynamicUnicycle2D and DoubleIntegrator2D, not for {self.model}")
         if out is None:
             u = torch.empty((B, 2), dtype=dt_, device=X.device)
             status = torch.empty((B,), dtype=torch.int32, device=X.device)
@@ -88,6 +93,7 @@ class BatchedMSMPCCBF:
         trace = torch.zeros((B, ip.max_iter + 1, 8), dtype=torch.float64, device=X.device) if want_trace else None
         p = make_params(self.robot_spec, self.cbf_param, self.Q, self.R, self.horizon, self.dt, self.robot_spec["radius"], self.io_dtype,
                         obs_shared=shared)
+        p.superellipsoid_rows = se
         stream = torch.cuda.current_stream(X.device).cuda_stream
         rc = self._lib.sc_mpccbf_ms_solve_batch(C.byref(p), C.byref(ip), B, K, X.data_ptr(), u_prev.data_ptr(), goal.data_ptr(), obs.data_ptr(),
                                                 u.data_ptr(), status.data_ptr(), iters.data_ptr(), plan.data_ptr() if plan is not None else None,

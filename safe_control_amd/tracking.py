@@ -304,7 +304,13 @@ class BatchedTrackingController:
             goal_in = torch.where(tr, goal2, ge).contiguous()
             up_in = torch.where(tr, self.u_prev, torch.zeros_like(self.u_prev)).contiguous()
             obs_in = torch.where(tr.unsqueeze(2), obs_in, self._dummy_rows(obs_in)).contiguous()
-            mpc = self.mpc_ms if (getattr(self, "mpc_ms", None) is not None and not self.obs_has_superellipsoid) else self.mpc
+            # kernel 13 serves superellipsoid rows for the two robots whose DT barrier has that branch (csrc/mpc_du_ms_se.hip); other robots' scenes
+            # with such rows run on the condensed kernels as before
+            ms = getattr(self, "mpc_ms", None)
+            se_ok = self.model in ("DynamicUnicycle2D", "DoubleIntegrator2D")
+            if ms is not None:
+                ms.superellipsoids = bool(self.obs_has_superellipsoid and se_ok)
+            mpc = ms if (ms is not None and (not self.obs_has_superellipsoid or se_ok)) else self.mpc
             out = mpc.solve(X_in, up_in, goal_in, obs_in)
             u_mpc, st = (out[0], out[2]) if self.pos_controller_type == "optimal_decay_mpc_cbf" else (out[0], out[1])
             its = out[3] if self.pos_controller_type == "optimal_decay_mpc_cbf" else out[2]

@@ -142,17 +142,19 @@ def test_argument_validation_and_superellipsoid_rows():
     p.model_id = _lib.MODEL_IDS["KinematicBicycle2D"]; p.rear_ax_dist = 0.0     # (the bicycle needs its L_r)
     assert lib.sc_mpccbf_ms_solve_batch(C.byref(p), C.byref(ip), 0, 8, *none10) != _lib.SC_OK
     assert int(lib.sc_mpccbf_ms_lds_bytes(10, 8)) > 0 and int(lib.sc_mpccbf_ms_lds_bytes(10, 17)) == 0
-    X, up, goal, obs = (a[:4] for a in W.mpc_family_batch("du", 4, 8, seed=0))
+    X, up, goal, obs = (a[:4] for a in W.mpc_family_batch("uni", 4, 8, seed=0))
     obs = obs.copy(); obs[2, 3] = [4.0, 4.0, 0.6, 0.4, 4.0, 0.3, 1.0]
-    with pytest.raises(NotImplementedError):
-        sca.BatchedMSMPCCBF(SPEC, io_dtype="f64").solve(t(X), t(up), t(goal), t(obs))
+    with pytest.raises(NotImplementedError):                                    # (Unicycle2D's DT barrier has no superellipsoid branch; tests/test_mpccbf_ms_se_gpu.py: the robots that have)
+        sca.BatchedMSMPCCBF({"model": "Unicycle2D"}, io_dtype="f64").solve(t(X), t(up), t(goal), t(obs))
+    p.model_id = _lib.MODEL_IDS["KinematicBicycle2D"]; p.rear_ax_dist = 0.2; p.superellipsoid_rows = 1
+    assert lib.sc_mpccbf_ms_solve_batch(C.byref(p), C.byref(ip), 0, 8, *none10) != _lib.SC_OK
     with pytest.raises(NotImplementedError):
         sca.BatchedMSMPCCBF({"model": "Quad2D"})
 
 
 def test_dropin_class_closed_loop_follows_the_multiple_shooting_oracle():
     """MPCCBF through the reference's plugin surface (the default formulation of a DynamicUnicycle2D robot since round 6), 15 closed-loop steps
-    with u_prev feedback against oracle/ms_ipopt.py; 'condensed' stays selectable; a superellipsoid row in the scene goes to the condensed kernel."""
+    with u_prev feedback against oracle/ms_ipopt.py; 'condensed' stays selectable; a superellipsoid row in the scene selects the kernel's superellipsoid instantiation."""
     from oracle import robots as R, mpc_cbf as M
     robot = sca.RobotHandle(np.array([2.0, 2.0, np.pi / 2, 1.0]), dict(SPEC), dt=0.05)
     ctl = sca.MPCCBF(robot, dict(SPEC), num_obs=8)
@@ -179,5 +181,8 @@ def test_dropin_class_closed_loop_follows_the_multiple_shooting_oracle():
     x0 = np.array([2.0, 2.0, np.pi / 2, 1.0])
     ctl.u_prev = np.zeros(2)
     u_se = ctl.solve_control_problem(x0.reshape(-1, 1), {"state_machine": "track", "u_ref": np.zeros((2, 1)), "goal": goal}, [o + [0.0] * (7 - len(o)) for o in se])
-    uo, so, _ = M.solve(x0, np.zeros(2), goal, M.pad_obstacles([o + [0.0] * (7 - len(o)) for o in se], 8))
-    assert so == 0 and np.abs(u_se.reshape(-1) - uo).max() <= 2e-6
+    pad = M.pad_obstacles([o + [0.0] * (7 - len(o)) for o in se], 8)
+    um, sm, _ = MS.solve(MS.du_model(), x0, np.zeros(2), goal, pad, opts=PROFILE)                # (kernel 13's superellipsoid instantiation: csrc/mpc_du_ms_se.hip)
+    assert sm == 0 and ctl._ms.superellipsoids is True and np.abs(u_se.reshape(-1) - um).max() <= 1e-8
+    uo, so, _ = M.solve(x0, np.zeros(2), goal, pad)                                               # (the condensed oracle: the same optimum)
+    assert so == 0 and np.abs(u_se.reshape(-1) - uo).max() <= 1e-5

@@ -18,7 +18,7 @@ struct Shared {
     pthread_barrier_t bar;
     std::vector<double> lds;
     double red[64];
-    double gred[64][36];
+    double gred[64][48];
 };
 struct HostCtx {
     typedef double* ptr;
