@@ -1108,8 +1108,8 @@ def compact_leg(v):
         keep["condensed_ms"] = sig(v["condensed"]["kernel_ms"])
     rl = v.get("roofline")
     if isinstance(rl, dict):
-        # ("stale" rides along only when it is true: emit() lists the legs whose counter profile is not from this tree's kernels under `stale_rooflines`)
-        keep["roofline"] = {k: ("valu" if rl[k] == "valu_issue" else sig(rl[k])) for k in ("bound", "frac", "stale") if k in rl and not (k == "stale" and not rl[k])}
+        # (no "stale" per leg: emit() counts the legs whose counter profile is not from this tree's kernels under `stale_rooflines`; bench_legs.json has the flags)
+        keep["roofline"] = {k: ("valu" if rl[k] == "valu_issue" else sig(rl[k])) for k in ("bound", "frac") if k in rl}
         if isinstance(rl.get("work_level"), dict):
             keep["roofline"]["work_frac"] = sig(rl["work_level"]["frac"])
     return keep
@@ -1167,7 +1167,9 @@ def emit(d, ws):
 
     def stale_in(v):
         return isinstance(v, dict) and (bool(v.get("stale")) or any(stale_in(x) for x in v.values()))
-    line["stale_rooflines"] = sorted(k for k, v in d.items() if stale_in(v))       # legs whose VALU-issue roofline uses a counter profile of OTHER kernel sources ([] = none)
+    # legs whose VALU-issue roofline uses a counter profile of OTHER kernel sources: [] = none; more than four: their number (a full list would push legs off the line)
+    stale = sorted(k for k, v in d.items() if stale_in(v))
+    line["stale_rooflines"] = stale if len(stale) <= 4 else len(stale)
     s = json.dumps(line)
     if len(s) > LINE_LIMIT:                                             # never the contract fields nor configs[2]: drop the largest extras
         extras = sorted((k for k in line if k not in CONTRACT_KEYS and k not in ("mpc_cbf", "mpc", "ranks_seen", "full_legs")),

