@@ -322,7 +322,7 @@ def mpc_leg(dev, B, K, N, steps, warmup, seed=0, cpu_seconds=0.0):
         if rlc:
             work_level(rlc, condensed.get("uniform_batch"), float(itc.double().mean().item()), B)
             condensed["roofline"] = rlc
-        rl = valu_roofline("mpc_sq", "mpcdu_ms_kernel<float, 0>", ms_ms, launches=1, note="one wave per problem, four lanes per stage; 512 registers: one wave "
+        rl = valu_roofline("mpc_sq", "mpcdu_ms_kernel<float, 0,", ms_ms, launches=1, note="one wave per problem, four lanes per stage; 512 registers: one wave "
                            "per SIMD = 1024 resident problems; the launch ends with its slowest problem (94 iterations, most of them inside the restoration phase, "
                            "against a mean of 17.6 at ~40 us per iteration)")
         if rl:
@@ -568,7 +568,7 @@ def linear_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
         extra["multiple_shooting"] = {"kernel": "mpcdu_ms_kernel<float, 4> (kernel 13; on request: mpc_formulation = 'multiple_shooting')", "value": B / (mms * 1e-3), "kernel_ms": mms,
                                       "optimal_fraction": float((sm == 0).double().mean().item()), "max_ipm_iterations": int(im.max().item()),
                                       "same_u0_where_both_optimal_fraction": float(((um - u).abs().amax(dim=1) <= 1e-4)[both].double().mean().item()) if bool(both.any()) else None}
-        rl = valu_roofline("dumssi_sq", "mpcdu_ms_kernel<float, 4>", mms) if (B, K, N, seed) == (4096, 8, 10, 0) else None
+        rl = valu_roofline("dumssi_sq", "mpcdu_ms_kernel<float, 4,", mms) if (B, K, N, seed) == (4096, 8, 10, 0) else None
         if rl:
             extra["multiple_shooting"]["roofline"] = rl
     return with_roofline({**extra, **budget_note(mk, (X, up, g, ob), steps, ms, st, it),
@@ -623,7 +623,7 @@ def gn_mpc_leg(dev, model, B=4096, K=8, N=10, steps=3, seed=0):
                 "mean_ipm_iterations": float(im.double().mean().item()), "max_ipm_iterations": int(im.max().item()),
                 "same_status_fraction": float((sm == st).double().mean().item()),
                 "same_u0_where_both_optimal_fraction": float(((um - u).abs().amax(dim=1) <= 1e-4)[both].double().mean().item()) if bool(both.any()) else None}
-        rl = valu_roofline("dumsdi_sq" if mi == 1 else "dumskb_sq", f"mpcdu_ms_kernel<float, {mi}>", mms) if (B, K, N, seed) == (4096, 8, 10, 0) else None
+        rl = valu_roofline("dumsdi_sq" if mi == 1 else "dumskb_sq", f"mpcdu_ms_kernel<float, {mi},", mms) if (B, K, N, seed) == (4096, 8, 10, 0) else None
         if rl:
             ms_d["roofline"] = rl
         if int(im.max().item()) > 100 and not NO_LIMIT100:                  # (the bicycle: solves that cycle around the kink of robot.step's speed clip run to the budget)
@@ -679,7 +679,7 @@ def unicycle_mpc_leg(dev, B=4096, K=8, N=10, steps=3, seed=0):
            "condensed": {"kernel": "mpccbf_uni_kernel (kernel 3)", "value": B / (msc * 1e-3), "kernel_ms": msc, "optimal_fraction": float((sc_ == 0).double().mean().item()),
                          "inaccurate_fraction": float((sc_ == 2).double().mean().item()), "max_ipm_iterations": int(ic.max().item()),
                          "same_u0_where_both_optimal_fraction": float(((u - uc).abs().amax(dim=1) <= 1e-4)[both].double().mean().item()) if bool(both.any()) else None}}
-    rl = valu_roofline("dumsuni_sq", "mpcdu_ms_kernel<float, 3>", ms) if (B, K, N, seed) == (4096, 8, 10, 0) else None
+    rl = valu_roofline("dumsuni_sq", "mpcdu_ms_kernel<float, 3,", ms) if (B, K, N, seed) == (4096, 8, 10, 0) else None
     if rl:
         res["roofline"] = rl
     return res
