@@ -285,6 +285,65 @@ def uni_model(spec=None, dt=0.05):
                 u_lo=np.array([-s["v_max"], -s["w_max"]]), u_hi=np.array([s["v_max"], s["w_max"]]), x_lo=np.full(3, -INF), x_hi=np.full(3, INF))
 
 
+def _where(mask, a, b):
+    """a where mask else b, for arrays and VD2 alike (a piecewise expression as casadi's if_else / fmax differentiates it)."""
+    if isinstance(a, VD2) or isinstance(b, VD2):
+        ref = a if isinstance(a, VD2) else b
+        a = a if isinstance(a, VD2) else ref._c(a)
+        b = b if isinstance(b, VD2) else ref._c(b)
+        m = np.asarray(mask, dtype=float)
+        return VD2(m * a.v + (1 - m) * b.v, m[:, None] * a.d + (1 - m)[:, None] * b.d, m[:, None, None] * a.H + (1 - m)[:, None, None] * b.H)
+    return np.where(mask, a, b)
+
+
+def _val(a):
+    return a.v if isinstance(a, VD2) else a
+
+
+def _kb_rel(x, o):
+    """p_rel, v_rel of the state against an obstacle row.  The obstacle's velocity is ZERO, as in the reference's MPC: set_cbf_constraint hands the
+    barrier a 1 x 7 casadi slice whose `shape[0] > 3` test is False (oracle/mpc_kb_state.py: _rel; the goldens say the same)."""
+    px, py = o[0] - x[0], o[1] - x[1]
+    c, s = _cos(x[2]), _sin(x[2])
+    vx, vy = 0.0 - x[3] * c, 0.0 - x[3] * s
+    return px, py, vx, vy, px * px + py * py, _sqrt(vx * vx + vy * vy)
+
+
+def h_c3bf(x, o, radius):
+    """kinematic_bicycle2D_c3bf.py:83-109 (beta = 1.01): <p_rel, v_rel> + |p_rel| |v_rel| sqrt(max(|p_rel|^2 - ego^2, 0)) / |p_rel|; inside the
+    inflated radius the root is held at zero with zero derivatives (oracle/mpc_kb_state.py)."""
+    px, py, vx, vy, pm2, vm = _kb_rel(x, o)
+    ego = (o[2] + radius) * 1.01
+    pm = _sqrt(pm2)
+    a = pm2 - ego * ego
+    pos = _val(a) > 0.0
+    root = _where(pos, _sqrt(_where(pos, a, 1.0)), 0.0)
+    return px * vx + py * vy + pm * vm * root / pm
+
+
+def h_dpcbf(x, o, radius):
+    """kinematic_bicycle2D_dpcbf.py:91-136 (s = 1.05): line-of-sight frame, cos / sin of atan2(p_y, p_x) = p_x / |p|, p_y / |p|."""
+    px, py, vx, vy, pm2, vm = _kb_rel(x, o)
+    s = 1.05
+    ego = (o[2] + radius) * s
+    pm = _sqrt(pm2)
+    cr, sr = px / pm, py / pm
+    vn0, vn1 = cr * vx + sr * vy, cr * vy - sr * vx
+    a = pm2 - ego * ego
+    d = _where(_val(a) > 1e-6, a, 1e-6)
+    kl, km = 0.1 * math.sqrt(s * s - 1.0) / ego, 0.5 * math.sqrt(s * s - 1.0) / ego
+    rd = _sqrt(d)
+    return vn0 + (kl * rd / vm) * vn1 * vn1 + km * rd
+
+
+def kb_state_model(name, spec=None, dt=0.05):
+    """KinematicBicycle2D_C3BF / _DPCBF: the bicycle's dynamics, weights and boxes (mpc_cbf.py:31-33,202-208) with ONE-step rows on a barrier of the
+    full state, d_h + alpha h_k >= 0 with alpha = 0.15 (mpc_cbf.py:67-72,312-315); x_k+1 = robot.step (speed clip)."""
+    m = kb_model(spec, dt)
+    m.update(name=name, alpha=0.15, alpha1=0.0, alpha2=0.0, state_barrier=h_c3bf if name.endswith("C3BF") else h_dpcbf)
+    return m
+
+
 def kb_model(spec=None, dt=0.05):
     """mpc_cbf.py:31-33 (Q, R), :64-66 (alpha1 = alpha2 = 0.1), :202-208 (|v| <= v_max, input box), kinematic_bicycle2D.py:175 (beta = 1.1)."""
     s = dict(wheel_base=0.4, radius=0.3, rear_ax_dist=0.2, v_max=3.5, a_max=5.0, v_min=0.2)
@@ -402,6 +461,11 @@ class StageNLP:
         spec, dt, nxt = self.mdl["spec"], self.mdl["dt"], self.mdl["next"]
         nd = self.mdl.get("nu_dyn", self.nu)
         x1 = nxt(x, u[:nd], spec, dt)
+        if self.mdl.get("state_barrier"):                                   # one-step rows on a barrier of the whole state (the collision-cone bicycles)
+            hf, a_ = self.mdl["state_barrier"], float(self.mdl["alpha"])
+            S = self.mdl["row_next"](x, u[:nd], spec, dt)
+            R = self.mdl["radius"]
+            return x1, [-(hf(S, self.obs[j], R) - (1.0 - a_) * hf(x, self.obs[j], R)) for j in range(self.K)]
         if self.cw[2] == 0.0:                                               # one-step rows (robot.step = x_next but for the heading wrap, which touches no position)
             h0, h1 = self._h(x[0], x[1]), self._h(x1[0], x1[1])
             return x1, [-(self.cw[1] * h1[j] + self.cw[0] * h0[j]) for j in range(self.K)]

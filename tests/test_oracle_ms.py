@@ -48,10 +48,13 @@ def model_of(name):
     if name == "KinematicBicycle2D":
         keys = MS.kb_model()["spec"].keys()
         return MS.kb_model(dict({k: v for k, v in sp.items() if k in keys}, radius=R))
+    if name in ("KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"):
+        keys = MS.kb_model()["spec"].keys()
+        return MS.kb_state_model(name, dict({k: v for k, v in sp.items() if k in keys}, radius=R))
     return MS.du_model(dict(v_max=sp["v_max"], a_max=sp["a_max"], w_max=sp["w_max"], radius=R))
 
 
-@pytest.mark.parametrize("name", ["DynamicUnicycle2D", "VTOL2D", "KinematicBicycle2D", "DoubleIntegrator2D", "Unicycle2D", "SingleIntegrator2D"])
+@pytest.mark.parametrize("name", ["DynamicUnicycle2D", "VTOL2D", "KinematicBicycle2D", "DoubleIntegrator2D", "Unicycle2D", "SingleIntegrator2D", "KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"])
 def test_rows_and_cost_of_a_one_stage_problem_equal_the_reference(name):
     """N = 1, w = [x, u, x_next]: the dynamics rows vanish at the reference's x_next (mpc_cbf.py:138-141), the inequality rows are the
     registered -cbf (:304), the objective is l(x) + m(x_next) (:144,176-178) + the rterm on u - u_prev (:180)."""
@@ -74,7 +77,7 @@ def test_rows_and_cost_of_a_one_stage_problem_equal_the_reference(name):
             assert abs(ev["f"] - want) <= 1e-11 * max(1.0, abs(want)), (name, i, level)
 
 
-@pytest.mark.parametrize("name", ["DynamicUnicycle2D", "VTOL2D", "KinematicBicycle2D", "DoubleIntegrator2D", "Unicycle2D", "SingleIntegrator2D"])
+@pytest.mark.parametrize("name", ["DynamicUnicycle2D", "VTOL2D", "KinematicBicycle2D", "DoubleIntegrator2D", "Unicycle2D", "SingleIntegrator2D", "KinematicBicycle2D_C3BF", "KinematicBicycle2D_DPCBF"])
 def test_derivatives_against_central_differences(name):
     mdl = model_of(name)
     rng = np.random.default_rng(3)
