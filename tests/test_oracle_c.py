@@ -204,3 +204,31 @@ def test_solver_header_for_single_integrator_equals_the_numpy_oracle():
     so = np.array([r[1] for r in res]); ito = np.array([r[2] for r in res]); uo = np.array([r[0] for r in res])
     assert np.array_equal(st, so) and (it != ito).sum() <= 2 and np.abs(it - ito).max() <= 1
     assert np.abs(u - uo)[it == ito].max() <= 1e-9
+
+
+def _ms_one_sweep(a):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    from oracle import ms_ipopt as MS
+    from safe_control_amd.robots.spec import complete_robot_spec
+    fam, N, x, up, g, ob = a
+    mk = {"du": MS.du_model, "di": MS.di_model, "kb": MS.kb_model, "uni": MS.uni_model, "si": MS.si_model}[fam]
+    sp = complete_robot_spec(dict({"model": W.MPC_FAMILIES[fam]}, **({"a_max": 1.0, "w_max": 0.5, "v_max": 1.0, "radius": 0.25} if fam == "du" else {})))
+    return MS.solve(mk({k: v for k, v in sp.items() if k in mk()["spec"]}), x, up, g, ob, N=N, opts=dict(MS.KERNEL_PROFILE, max_iter=150))
+
+
+@pytest.mark.parametrize("N,K", [(5, 1), (20, 3), (40, 16)])
+def test_solver_header_over_horizons_and_obstacle_counts(N, K):
+    """Every instantiation of csrc/mpc_du_ms_solver.hpp at horizons 5 / 20 / 40 (four, two and one lane per stage) with 1 / 3 / 16 obstacle
+    slots, host build against the oracle: same status everywhere, same iteration count and u0 to 1e-8 on the solves that end within 60 iterations."""
+    from multiprocessing import Pool
+    n = 10
+    for fam in ("du", "di", "uni", "si", "kb"):
+        X, up, goal, obs = (a[:n].copy() for a in W.mpc_family_batch(fam, 64, K, seed=N))
+        u, st, it = c_oracle.du_ms_cpu_batch(X, up, goal, obs, model=W.MPC_FAMILIES[fam], horizon=N, ipopt=dict(max_iter=150),
+                                             spec=({"a_max": 1.0, "w_max": 0.5, "v_max": 1.0, "radius": 0.25} if fam == "du" else None))
+        with Pool(min(8, os.cpu_count() or 2)) as p:
+            res = p.map(_ms_one_sweep, [(fam, N, X[i], up[i], goal[i], obs[i]) for i in range(n)], chunksize=2)
+        so = np.array([r[1] for r in res]); ito = np.array([r[2] for r in res]); uo = np.array([r[0] for r in res])
+        assert np.array_equal(st, so), (fam, N, K)
+        short = ito < 60
+        assert (it != ito)[short].sum() <= 1 and np.abs(u - uo)[short & (it == ito)].max() <= 1e-8, (fam, N, K)
