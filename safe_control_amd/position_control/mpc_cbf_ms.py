@@ -6,7 +6,9 @@ stage starts at x0 and every input at the input applied last, IPOPT runs with it
 (:384; ``status`` is hard-wired 'optimal', :10).  ``BatchedMSMPCCBF.solve`` launches that solve for B agents, one NLP per wavefront.  The
 condensed kernel (``BatchedMPCCBF``, csrc/mpc_cbf.hip) solves the single-shooting form of the same NLP: the same optimum where the NLP has
 one, another last iterate where it has no feasible point (tools/exp_ms_vs_condensed.py) -- it stays available as
-``robot_spec['mpc_formulation'] = 'condensed'`` and serves superellipsoid obstacles, which this kernel does not.  No CPU fallback.
+``robot_spec['mpc_formulation'] = 'condensed'``.  Robots: DynamicUnicycle2D, Unicycle2D, SingleIntegrator2D, DoubleIntegrator2D, KinematicBicycle2D
+(the kernel is templated on the model: csrc/mpc_du_ms_solver.hpp); superellipsoid obstacle rows for the first and the fourth (csrc/mpc_du_ms_se.hip,
+picked from the rows' flags).  No CPU fallback.
 """
 import ctypes as C
 
@@ -20,8 +22,9 @@ from .mpc_cbf import apply_mpc_overrides, default_mpc_cbf_param, default_mpc_wei
 class BatchedMSMPCCBF:
     """``solve(X[B,4], u_prev[B,2], goal[B,2], obs[B,K,7] | obs[K,7])`` -> ``u[B,2]``, ``status[B] int32``, ``iters[B] int32``
     [, ``plan[B, (N+1)*4 + N*2]``] [, ``trace[B, max_iter+1, 8]``].  ``ipopt``: overrides of IPOPT's option defaults
-    (``_lib.IPOPT_DEFAULTS``).  Obstacle rows must be circles (column 6 < 0.5); ``check_circles=False`` skips the device-side check of
-    that (one reduction and a host read per call).  ``order``: launches of more than 1024 problems start the NLPs whose start point violates a
+    (``_lib.IPOPT_DEFAULTS``).  ``superellipsoids``: None = look at the rows' flags (column 6 >= 0.5; one reduction and a host read per call, skipped
+    with ``check_circles=False``: rows are then taken as circles) and launch the instantiation that evaluates superellipsoids when there are any;
+    True / False = say so.  ``order``: launches of more than 1024 problems start the NLPs whose start point violates a
     CBF row first (a pre-pass kernel and a small workspace; results do not depend on it, the launch ends ~15 % sooner)."""
 
     def __init__(self, robot_spec=None, dt=0.05, io_dtype="f32", horizon=None, cbf_param=None, ipopt=None, max_iter=None, check_circles=True, order=True,
