@@ -7,7 +7,8 @@ problems.  csrc/Makefile therefore builds the SAME sources a second time with th
 lib/libsafe_control_hip_guard.so; this test solves the VTOL2D workload batch with both libraries (the guard one in a child process:
 SAFE_CONTROL_AMD_LIB) and requires every output -- inputs, statuses, iteration counts, full plans -- to be equal BIT FOR BIT, for the
 plain and the optimal-decay instantiations of the condensed kernel and of the multiple-shooting kernel (full plans x_0 .. x_N, u_0 .. u_{N-1}), and
-for kernel 13 on configs[2] draws (restoration phase included) with 8 and 12 obstacle slots, f64 and f32 storage, with the budget and its continuation launches."""
+for kernel 13 on configs[2] draws (restoration phase included) with 8 and 12 obstacle slots and on the bench draws of its four other robots, f64 and f32
+storage, with the budget and its continuation launches."""
 import os
 import subprocess
 import sys
@@ -52,6 +53,13 @@ for io in ("f64", "f32"):
         torch.cuda.synchronize()
         for k, a in enumerate(r):
             out[f"{io}/{name}/{k}"] = a.cpu().numpy()
+    # ... and its other robots (the same translation unit, the same allocator): Unicycle2D, SingleIntegrator2D, DoubleIntegrator2D, KinematicBicycle2D
+    for fam in ("uni", "si", "di", "kb"):
+        Xf, upf, gf, of = (a[:n] for a in W.mpc_family_batch(fam, n, 8, seed=0))
+        r = sca.BatchedMSMPCCBF({"model": W.MPC_FAMILIES[fam]}, io_dtype=io, max_iter=150).solve(t(Xf), t(upf), t(gf), t(of), want_plan=True)
+        torch.cuda.synchronize()
+        for k, a in enumerate(r):
+            out[f"{io}/dums_{fam}/{k}"] = a.cpu().numpy()
 np.savez(sys.argv[3], **out)
 """
 
